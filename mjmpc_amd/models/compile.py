@@ -1,0 +1,246 @@
+"""Host-side model compiler: RawModel -> the flat constant block the HIP arm kernel consumes.
+
+What MuJoCo's XML compiler + ``mj_setConst`` do for ``sawyer.xml`` (inertiafromgeom, welded-body
+bookkeeping, ``dof_invweight0`` / ``body_invweight0``) is done here once, in float64 numpy, and
+laid out for the kernel's execution model: a serial chain of <= 7 hinge links, ONE LANE PER LINK
+inside an 8-lane group (lane 7 carries the contact row).  Bodies without a joint are merged into
+the link that carries them, and every link frame is chosen to be world-aligned at qpos0, so the
+kernel never multiplies by a fixed body rotation.
+
+The layout of the block (``ARM_LAYOUT``) is mirrored by ``struct ArmConst`` in
+``mjmpc_amd/csrc/arm_model.h`` and documented in ``include/mjmpc_amd.h``.
+"""
+from dataclasses import dataclass
+
+import numpy as np
+
+from .raw import GEOM_CAPSULE, GEOM_SPHERE, RawModel
+
+LANES = 8          # lanes per particle in the HIP kernel
+MAX_LINKS = 7
+
+# (name, length) in float64 slots; per-link fields are stored [component][lane]
+ARM_LAYOUT = [
+    ("off", 3 * LANES), ("axis", 3 * LANES), ("mass", LANES), ("com", 3 * LANES),
+    ("inertia", 6 * LANES),                    # xx, yy, zz, xy, xz, yz about the link COM
+    ("armature", LANES), ("damping", LANES), ("range_lo", LANES), ("range_hi", LANES),
+    ("limited", LANES), ("gear", LANES), ("ctrl_lo", LANES), ("ctrl_hi", LANES),
+    ("dof_invweight0", LANES),
+    ("nv", 1), ("timestep", 1), ("frame_skip", 1),
+    ("site_link", 1), ("site_pos", 3),
+    ("n_sphere", 1), ("sph_link", 1), ("sph_pos", 3), ("sph_r", 1), ("sph_margin", 1),
+    ("sph_invweight", 1), ("plane_n", 3), ("plane_d", 1),
+    ("sol_K", 1), ("sol_B", 1), ("sol_dmin", 1), ("sol_dmax", 1), ("sol_width", 1),
+    ("sol_mid", 1), ("sol_power", 1), ("gravity", 3),
+]
+ARM_BLOB_LEN = sum(n for _, n in ARM_LAYOUT)
+MJ_MINVAL = 1e-15
+
+
+def _offsets():
+    o, out = 0, {}
+    for name, n in ARM_LAYOUT:
+        out[name] = (o, n)
+        o += n
+    return out
+
+
+ARM_OFFSETS = _offsets()
+
+
+def _quat2mat(q):
+    w, x, y, z = np.asarray(q, float) / np.linalg.norm(q)
+    return np.array([[1 - 2 * (y * y + z * z), 2 * (x * y - w * z), 2 * (x * z + w * y)],
+                     [2 * (x * y + w * z), 1 - 2 * (x * x + z * z), 2 * (y * z - w * x)],
+                     [2 * (x * z - w * y), 2 * (y * z + w * x), 1 - 2 * (x * x + y * y)]])
+
+
+def _geom_inertial(g):
+    """(mass, centre, inertia about centre) of one geom, MuJoCo inertiafromgeom conventions."""
+    r = float(g.radius)
+    if g.type == GEOM_SPHERE:
+        m = g.density * 4.0 / 3.0 * np.pi * r ** 3
+        return m, np.asarray(g.a, float), np.eye(3) * (0.4 * m * r * r)
+    if g.type == GEOM_CAPSULE:
+        a, b = np.asarray(g.a, float), np.asarray(g.b, float)
+        h = np.linalg.norm(b - a)
+        u = (b - a) / h
+        m = g.density * (np.pi * r * r * h + 4.0 / 3.0 * np.pi * r ** 3)
+        ms = m * 4 * r / (4 * r + 3 * h)
+        mc = m - ms
+        i_perp = mc * (3 * r * r + h * h) / 12 + 0.4 * ms * r * r + ms * h * (3 * r + 2 * h) / 8
+        i_ax = mc * r * r / 2 + 0.4 * ms * r * r
+        return m, 0.5 * (a + b), i_perp * np.eye(3) + (i_ax - i_perp) * np.outer(u, u)
+    raise ValueError("unsupported geom type %r" % (g.type,))
+
+
+def _shift_inertia(I, m, d):
+    return I + m * (d @ d * np.eye(3) - np.outer(d, d))
+
+
+@dataclass
+class ArmModel:
+    """Compiled arm.  ``blob`` is what crosses the C ABI; the rest is for host code and tests."""
+    blob: np.ndarray
+    nv: int
+    nu: int
+    d_obs: int
+    timestep: float
+    frame_skip: int
+    target_default: np.ndarray
+    ctrl_lo: np.ndarray
+    ctrl_hi: np.ndarray
+    body_mass: np.ndarray          # per raw body (world excluded)
+    body_ipos: np.ndarray
+    body_inertia: np.ndarray
+    body_invweight0: np.ndarray
+    dof_invweight0: np.ndarray
+    link_of_body: list
+
+    def field(self, name):
+        o, n = ARM_OFFSETS[name]
+        return self.blob[o:o + n]
+
+
+def compile_arm(raw: RawModel) -> ArmModel:
+    nb = len(raw.bodies)
+    # ---- per-body inertial + pose at qpos0 ------------------------------------------------
+    R0 = [None] * nb
+    p0 = [None] * nb
+    mass = np.zeros(nb)
+    ipos = np.zeros((nb, 3))
+    inert = np.zeros((nb, 3, 3))
+    for i, b in enumerate(raw.bodies):
+        Rp, pp = (np.eye(3), np.zeros(3)) if b.parent < 0 else (R0[b.parent], p0[b.parent])
+        if b.parent >= i:
+            raise ValueError("bodies must be listed parents-first")
+        R0[i] = Rp @ _quat2mat(b.quat)
+        p0[i] = pp + Rp @ np.asarray(b.pos, float)
+        parts = [_geom_inertial(g) for g in b.geoms]
+        mass[i] = sum(m for m, _, _ in parts)
+        if mass[i] > 0:
+            ipos[i] = sum(m * c for m, c, _ in parts) / mass[i]
+            inert[i] = sum(_shift_inertia(I, m, c - ipos[i]) for m, c, I in parts)
+
+    # ---- links: one per hinge, welded bodies merged in ------------------------------------
+    jointed = [i for i, b in enumerate(raw.bodies) if b.joint is not None]
+    nv = len(jointed)
+    if not 1 <= nv <= MAX_LINKS:
+        raise ValueError("arm kernel supports 1..%d hinge links, got %d" % (MAX_LINKS, nv))
+    link_of_body = [-1] * nb
+    for i, b in enumerate(raw.bodies):
+        if b.joint is not None:
+            li = jointed.index(i)
+            pl = -1 if b.parent < 0 else link_of_body[b.parent]
+            if pl != li - 1:
+                raise ValueError("arm kernel needs a serial chain (body %s branches)" % b.name)
+            link_of_body[i] = li
+        else:
+            if b.parent < 0 or link_of_body[b.parent] < 0:
+                raise ValueError("static body %s before the first joint is not supported" % b.name)
+            link_of_body[i] = link_of_body[b.parent]
+
+    L = LANES
+    f = {name: np.zeros(n) for name, n in ARM_LAYOUT}
+    origin = [p0[j] for j in jointed]
+    for li, bj in enumerate(jointed):
+        jt = raw.bodies[bj].joint
+        prev = origin[li - 1] if li > 0 else np.zeros(3)
+        axis = R0[bj] @ (np.asarray(jt.axis, float) / np.linalg.norm(jt.axis))
+        members = [i for i in range(nb) if link_of_body[i] == li]
+        m = mass[members].sum()
+        com_w = sum(mass[i] * (p0[i] + R0[i] @ ipos[i]) for i in members) / m
+        I = sum(_shift_inertia(R0[i] @ inert[i] @ R0[i].T, mass[i], p0[i] + R0[i] @ ipos[i] - com_w)
+                for i in members)
+        for c in range(3):
+            f["off"][c * L + li] = (origin[li] - prev)[c]
+            f["axis"][c * L + li] = axis[c]
+            f["com"][c * L + li] = (com_w - origin[li])[c]
+        f["mass"][li] = m
+        for k, (r, c) in enumerate([(0, 0), (1, 1), (2, 2), (0, 1), (0, 2), (1, 2)]):
+            f["inertia"][k * L + li] = I[r, c]
+        f["armature"][li] = jt.armature
+        f["damping"][li] = jt.damping
+        f["range_lo"][li], f["range_hi"][li] = jt.range
+        f["limited"][li] = 1.0 if jt.limited else 0.0
+
+    if len(raw.actuators) != nv:
+        raise ValueError("arm kernel expects one motor per hinge")
+    ctrl_lo, ctrl_hi = np.zeros(nv), np.zeros(nv)
+    for a, act in enumerate(raw.actuators):
+        if raw.dof_of_joint(act.joint) != a:
+            raise ValueError("motors must be listed in joint order")
+        f["gear"][a] = act.gear
+        f["ctrl_lo"][a], f["ctrl_hi"][a] = act.ctrlrange
+        ctrl_lo[a], ctrl_hi[a] = act.ctrlrange
+
+    # ---- constants at qpos0 (MuJoCo mj_setConst): M0, dof / body invweight0 ----------------
+    def jac_point(pt, link):
+        J = np.zeros((3, nv))
+        for k in range(link + 1):
+            ax = np.array([f["axis"][c * L + k] for c in range(3)])
+            J[:, k] = np.cross(ax, pt - origin[k])
+        return J
+
+    M0 = np.diag([f["armature"][k] for k in range(nv)]).astype(float)
+    for i in range(nb):
+        if mass[i] <= 0:
+            continue
+        li = link_of_body[i]
+        Jp = jac_point(p0[i] + R0[i] @ ipos[i], li)
+        Jr = np.zeros((3, nv))
+        for k in range(li + 1):
+            Jr[:, k] = [f["axis"][c * L + k] for c in range(3)]
+        Iw = R0[i] @ inert[i] @ R0[i].T
+        M0 += mass[i] * Jp.T @ Jp + Jr.T @ Iw @ Jr
+    M0inv = np.linalg.inv(M0)
+    dof_iw = np.diag(M0inv).copy()
+    f["dof_invweight0"][:nv] = dof_iw
+    body_iw = np.zeros(nb)
+    for i in range(nb):
+        Jp = jac_point(p0[i] + R0[i] @ ipos[i], link_of_body[i])
+        body_iw[i] = np.trace(Jp @ M0inv @ Jp.T) / 3.0
+
+    # ---- scalars -------------------------------------------------------------------------
+    f["nv"][0] = nv
+    f["timestep"][0] = raw.timestep
+    f["frame_skip"][0] = raw.frame_skip
+    sb = raw.site_body
+    f["site_link"][0] = link_of_body[sb]
+    f["site_pos"][:] = p0[sb] + R0[sb] @ np.asarray(raw.site_pos, float) - origin[link_of_body[sb]]
+    spheres = [(i, g) for i, b in enumerate(raw.bodies) for g in b.geoms if g.collide]
+    if raw.plane is not None and spheres:
+        if len(spheres) > 1:
+            raise ValueError("arm kernel supports one collision sphere")
+        i, g = spheres[0]
+        if g.type != GEOM_SPHERE:
+            raise ValueError("only sphere-plane contacts are supported")
+        li = link_of_body[i]
+        n = np.asarray(raw.plane.normal, float)
+        n = n / np.linalg.norm(n)
+        f["n_sphere"][0] = 1
+        f["sph_link"][0] = li
+        f["sph_pos"][:] = p0[i] + R0[i] @ np.asarray(g.a, float) - origin[li]
+        f["sph_r"][0] = g.radius
+        f["sph_margin"][0] = max(raw.plane.margin, g.margin)     # MuJoCo: max of geom margins
+        f["sph_invweight"][0] = 0.0 + body_iw[i]                 # world body weighs 0
+        f["plane_n"][:] = n
+        f["plane_d"][0] = n @ np.asarray(raw.plane.pos, float)
+    tc, dr = raw.solref
+    tc = max(tc, 2 * raw.timestep)                               # refsafe
+    dmin, dmax, width, mid, power = raw.solimp
+    f["sol_K"][0] = 1.0 / (dmax * dmax * tc * tc * dr * dr)
+    f["sol_B"][0] = 2.0 / (dmax * tc)
+    f["sol_dmin"][0], f["sol_dmax"][0] = dmin, dmax
+    f["sol_width"][0], f["sol_mid"][0], f["sol_power"][0] = width, mid, power
+    f["gravity"][:] = raw.gravity
+
+    blob = np.concatenate([f[name] for name, _ in ARM_LAYOUT]).astype(np.float64)
+    assert blob.size == ARM_BLOB_LEN
+    return ArmModel(blob=blob, nv=nv, nu=len(raw.actuators), d_obs=2 * nv + 6,
+                    timestep=raw.timestep, frame_skip=raw.frame_skip,
+                    target_default=np.asarray(raw.target_pos, float),
+                    ctrl_lo=ctrl_lo, ctrl_hi=ctrl_hi,
+                    body_mass=mass, body_ipos=ipos, body_inertia=inert,
+                    body_invweight0=body_iw, dof_invweight0=dof_iw,
+                    link_of_body=link_of_body)

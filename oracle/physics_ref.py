@@ -1,0 +1,142 @@
+"""ctypes binding of oracle/libreacher_ref.so  --  TEST ORACLE, NOT PRODUCT CODE.
+
+PARITY UNPINNED for the physics (see the header of reacher_ref.c).  Only tests/,
+``__graft_entry__.smoke()`` and ``bench.py``'s cpu_baseline leg may import this module.
+"""
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+_dp = ctypes.POINTER(ctypes.c_double)
+
+
+def build(force=False):
+    so = os.path.join(_HERE, "libreacher_ref.so")
+    src = os.path.join(_HERE, "reacher_ref.c")
+    if force or not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(src):
+        subprocess.check_call(["make", "-C", _HERE, "-B", "libreacher_ref.so"], stdout=subprocess.DEVNULL)
+    return so
+
+
+def _lib():
+    global _LIB
+    if _LIB is None:
+        L = ctypes.CDLL(build())
+        L.or_model_compile.restype = ctypes.c_void_p
+        L.or_model_compile.argtypes = [_dp, ctypes.c_int]
+        L.or_model_free.argtypes = [ctypes.c_void_p]
+        for name in ("or_nv", "or_nbody", "or_dobs"):
+            getattr(L, name).restype = ctypes.c_int
+            getattr(L, name).argtypes = [ctypes.c_void_p]
+        L.or_kinetic.restype = ctypes.c_double
+        L.or_kinetic.argtypes = [ctypes.c_void_p, _dp, _dp]
+        L.or_env_step.restype = ctypes.c_double
+        L.or_env_step.argtypes = [ctypes.c_void_p, _dp, _dp, _dp, _dp, _dp]
+        L.or_step.argtypes = [ctypes.c_void_p, _dp, _dp, _dp, _dp, _dp]
+        L.or_rollout.argtypes = [ctypes.c_void_p, _dp, _dp, _dp, ctypes.c_long, ctypes.c_int,
+                                 _dp, _dp, _dp, _dp, _dp, _dp, _dp]
+        _LIB = L
+    return _LIB
+
+
+def _p(a):
+    return None if a is None else a.ctypes.data_as(_dp)
+
+
+def _c(a):
+    return np.ascontiguousarray(a, dtype=np.float64)
+
+
+class RefArm:
+    """FP64 reference arm: compiled from ``RawModel.to_flat()`` by the C oracle itself."""
+
+    def __init__(self, flat):
+        flat = _c(flat)
+        self._L = _lib()
+        self._h = self._L.or_model_compile(_p(flat), flat.size)
+        if not self._h:
+            raise ValueError("oracle: bad model blob")
+        self.nv = self._L.or_nv(self._h)
+        self.nbody = self._L.or_nbody(self._h)
+        self.d_obs = self._L.or_dobs(self._h)
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            self._L.or_model_free(self._h)
+            self._h = None
+
+    # -- compiled constants -------------------------------------------------
+    def inertial(self):
+        mass = np.zeros(self.nbody)
+        ipos = np.zeros((self.nbody, 3))
+        inertia = np.zeros((self.nbody, 3, 3))
+        self._L.or_get_inertial(ctypes.c_void_p(self._h), _p(mass), _p(ipos), _p(inertia))
+        return mass, ipos, inertia
+
+    def invweight0(self):
+        dof = np.zeros(self.nv)
+        body = np.zeros(self.nbody)
+        self._L.or_get_invweight0(ctypes.c_void_p(self._h), _p(dof), _p(body))
+        return dof, body
+
+    def newton_stats(self):
+        out = (ctypes.c_long * 3)()
+        self._L.or_get_newton_stats(ctypes.c_void_p(self._h), out)
+        return dict(calls=out[0], iters=out[1], fails=out[2])
+
+    # -- building blocks ----------------------------------------------------
+    def mass_matrix(self, q):
+        M = np.zeros((self.nv, self.nv))
+        self._L.or_mass_matrix(ctypes.c_void_p(self._h), _p(_c(q)), _p(M))
+        return M
+
+    def rne(self, q, v, a=None):
+        tau = np.zeros(self.nv)
+        self._L.or_rne(ctypes.c_void_p(self._h), _p(_c(q)), _p(_c(v)),
+                       _p(None if a is None else _c(a)), _p(tau))
+        return tau
+
+    def site(self, q):
+        x = np.zeros(3)
+        self._L.or_site(ctypes.c_void_p(self._h), _p(_c(q)), _p(x))
+        return x
+
+    def kinetic(self, q, v):
+        return self._L.or_kinetic(self._h, _p(_c(q)), _p(_c(v)))
+
+    def step(self, q, v, ctrl):
+        """One mj_step.  Returns (q', v', site position seen by that step, diag)."""
+        q, v = _c(q).copy(), _c(v).copy()
+        site = np.zeros(3)
+        diag = np.zeros(1 + self.nv)
+        self._L.or_step(self._h, _p(q), _p(v), _p(_c(ctrl)), _p(site), _p(diag))
+        return q, v, site, diag
+
+    def env_step(self, q, v, u, target):
+        q, v = _c(q).copy(), _c(v).copy()
+        obs = np.zeros(self.d_obs)
+        r = self._L.or_env_step(self._h, _p(q), _p(v), _p(_c(u)), _p(_c(target)), _p(obs))
+        return q, v, r, obs
+
+    def rollout(self, qp0, qv0, target, mean, noise, want_obs=True):
+        """GymEnvWrapper.rollout(mode='open_loop') -> (obs, rew, act, done, next_obs)."""
+        mean = _c(mean)
+        H, nu = mean.shape
+        if noise is not None:
+            noise = _c(noise)
+            P = noise.shape[0]
+            assert noise.shape == (P, H, nu)
+        else:
+            P = 1
+        rew = np.zeros((P, H))
+        act = np.zeros((P, H, nu))
+        done = np.zeros((P, H))
+        obs = np.zeros((P, H, self.d_obs)) if want_obs else None
+        nobs = np.zeros((P, H, self.d_obs)) if want_obs else None
+        self._L.or_rollout(self._h, _p(_c(qp0)), _p(_c(qv0)), _p(_c(target)), P, H,
+                           _p(mean), _p(noise), _p(obs), _p(rew), _p(act), _p(done), _p(nobs))
+        return obs, rew, act, done, nobs

@@ -1,0 +1,748 @@
+/*
+ * oracle/reacher_ref.c  --  TEST ORACLE, NOT PRODUCT CODE.
+ *
+ * Plain-C, FP64, deliberately simple restatement of the physics half of mjmpc's hot path
+ * for reacher_7dof-v0.  Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline
+ * leg may load this library; nothing under mjmpc_amd/ does.
+ *
+ * PARITY UNPINNED: the arithmetic restated here lives in closed-source MuJoCo 2.0
+ * (mujoco-py >=2.0,<2.1, reference setup/environment.yml:19, setup.py:26), which is not in
+ * /root/reference and cannot be installed here; the reference's tests hold no golden vector
+ * for it.  What follows restates MuJoCo's *published* algorithm (Computation chapter of the
+ * MuJoCo documentation; Todorov 2014 "Convex and analytically-invertible dynamics with
+ * contacts and constraints") and is anchored on the reference call sites:
+ *
+ *   model          mjmpc/envs/assets/xml/sawyer.xml:2-6,11-59,101-109
+ *   env.step       mjmpc/envs/basic/reacher_env.py:29-39   (do_simulation x frame_skip, reward)
+ *   get_obs        mjmpc/envs/basic/reacher_env.py:41-47
+ *   set_env_state  mjmpc/envs/basic/reacher_env.py:87-99
+ *   rollout loop   mjmpc/envs/gym_env_wrapper.py:89-156
+ *
+ * The formulation is chosen to be INDEPENDENT of the HIP kernel's: the mass matrix is built
+ * from body Jacobians (not CRBA), bias forces from an inertial-frame Newton-Euler pass, all
+ * linear solves are dense Cholesky, and the constraint problem is minimised by Newton with an
+ * exact piecewise-quadratic line search.
+ *
+ * One mj_step  (MuJoCo: mj_forward, then mj_Euler):
+ *   1. kinematics (body frames, site)            4. passive (-damping*v) + motor (gear*clip(ctrl))
+ *   2. M(q) + armature                           5. limit / sphere-plane rows, soft-constraint solve
+ *   3. bias c(q,v)                               6. semi-implicit Euler with implicit joint damping
+ */
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+
+#define MAXB 16            /* bodies incl. world */
+#define MAXV 12
+#define MAXG 32
+#define MAXS 4             /* collision spheres */
+#define MAXC (2 * MAXV + MAXS)
+#define MJ_MINVAL 1e-15    /* MuJoCo mjMINVAL */
+
+#define HEADER_LEN 40
+#define BODY_STRIDE 20
+#define GEOM_STRIDE 16
+#define ACT_STRIDE 4
+
+typedef struct {
+    int nbody, nv, nu;
+    double timestep, gravity[3];
+    int frame_skip;
+    double solref[2], solimp[5];
+    /* tree */
+    int parent[MAXB];
+    double bpos[MAXB][3], bR0[MAXB][9];      /* fixed offset / rotation in the parent frame */
+    int dofid[MAXB];                         /* -1: welded */
+    double jaxis[MAXB][3];
+    int dof_body[MAXV];
+    double range[MAXV][2];
+    int limited[MAXV];
+    double damping[MAXV], armature[MAXV];
+    /* inertial (inertiafromgeom) */
+    double mass[MAXB], ipos[MAXB][3], inertia[MAXB][9];  /* tensor about the COM, body frame */
+    /* motors */
+    int act_dof[MAXV];
+    double gear[MAXV], ctrl_lo[MAXV], ctrl_hi[MAXV];
+    /* site + target */
+    int site_body;
+    double site_pos[3], target_default[3];
+    /* contact: one plane (world) versus collision spheres */
+    int has_plane, nsphere;
+    double plane_pos[3], plane_n[3], plane_margin;
+    int sph_body[MAXS];
+    double sph_pos[MAXS][3], sph_r[MAXS], sph_margin[MAXS];
+    /* constants computed at qpos0 (MuJoCo mj_setConst) */
+    double dof_invweight0[MAXV], body_invweight0[MAXB];
+    /* statistics */
+    long newton_iters, newton_calls, newton_fail;
+} OrModel;
+
+/* ---------------------------------------------------------------- small linear algebra */
+static void cross3(const double *a, const double *b, double *c) {
+    c[0] = a[1] * b[2] - a[2] * b[1];
+    c[1] = a[2] * b[0] - a[0] * b[2];
+    c[2] = a[0] * b[1] - a[1] * b[0];
+}
+static double dot3(const double *a, const double *b) { return a[0] * b[0] + a[1] * b[1] + a[2] * b[2]; }
+static void matvec3(const double *R, const double *x, double *y) {
+    for (int i = 0; i < 3; i++) y[i] = R[3 * i] * x[0] + R[3 * i + 1] * x[1] + R[3 * i + 2] * x[2];
+}
+static void matmul3(const double *A, const double *B, double *C) {
+    for (int i = 0; i < 3; i++)
+        for (int j = 0; j < 3; j++) {
+            double s = 0;
+            for (int k = 0; k < 3; k++) s += A[3 * i + k] * B[3 * k + j];
+            C[3 * i + j] = s;
+        }
+}
+static void quat2mat(const double *q, double *R) {
+    double n = sqrt(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);
+    double w = q[0] / n, x = q[1] / n, y = q[2] / n, z = q[3] / n;
+    R[0] = 1 - 2 * (y * y + z * z); R[1] = 2 * (x * y - w * z);     R[2] = 2 * (x * z + w * y);
+    R[3] = 2 * (x * y + w * z);     R[4] = 1 - 2 * (x * x + z * z); R[5] = 2 * (y * z - w * x);
+    R[6] = 2 * (x * z - w * y);     R[7] = 2 * (y * z + w * x);     R[8] = 1 - 2 * (x * x + y * y);
+}
+/* rotation by angle about a unit axis (Rodrigues) */
+static void axisangle2mat(const double *u, double ang, double *R) {
+    double c = cos(ang), s = sin(ang), t = 1 - c;
+    R[0] = c + t * u[0] * u[0];        R[1] = t * u[0] * u[1] - s * u[2]; R[2] = t * u[0] * u[2] + s * u[1];
+    R[3] = t * u[0] * u[1] + s * u[2]; R[4] = c + t * u[1] * u[1];        R[5] = t * u[1] * u[2] - s * u[0];
+    R[6] = t * u[0] * u[2] - s * u[1]; R[7] = t * u[1] * u[2] + s * u[0]; R[8] = c + t * u[2] * u[2];
+}
+/* dense Cholesky A = L L^T (lower, in place); returns 0 on success */
+static int chol(double *A, int n) {
+    for (int j = 0; j < n; j++) {
+        double d = A[j * n + j];
+        for (int k = 0; k < j; k++) d -= A[j * n + k] * A[j * n + k];
+        if (d <= 0) return 1;
+        d = sqrt(d);
+        A[j * n + j] = d;
+        for (int i = j + 1; i < n; i++) {
+            double s = A[i * n + j];
+            for (int k = 0; k < j; k++) s -= A[i * n + k] * A[j * n + k];
+            A[i * n + j] = s / d;
+        }
+    }
+    return 0;
+}
+static void chol_solve(const double *L, int n, double *x) {
+    for (int i = 0; i < n; i++) {
+        double s = x[i];
+        for (int k = 0; k < i; k++) s -= L[i * n + k] * x[k];
+        x[i] = s / L[i * n + i];
+    }
+    for (int i = n - 1; i >= 0; i--) {
+        double s = x[i];
+        for (int k = i + 1; k < n; k++) s -= L[k * n + i] * x[k];
+        x[i] = s / L[i * n + i];
+    }
+}
+
+/* ---------------------------------------------------------------- kinematics */
+typedef struct {
+    double xpos[MAXB][3], xmat[MAXB][9];    /* body frame origin / orientation in the world */
+    double xipos[MAXB][3];                  /* body COM in the world */
+    double xaxis[MAXV][3], xanchor[MAXV][3];
+} Kin;
+
+/* MuJoCo mj_kinematics restricted to hinge joints anchored at the body origin (jnt pos = 0,
+ * qpos0 = 0): xquat = parent * body_quat * rot(axis, q). */
+static void kinematics(const OrModel *m, const double *q, Kin *k) {
+    memset(k->xpos[0], 0, sizeof(k->xpos[0]));
+    static const double I3[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
+    memcpy(k->xmat[0], I3, sizeof(I3));
+    memset(k->xipos[0], 0, sizeof(k->xipos[0]));
+    for (int b = 1; b < m->nbody; b++) {
+        int p = m->parent[b];
+        double t[3], R[9];
+        matvec3(k->xmat[p], m->bpos[b], t);
+        for (int i = 0; i < 3; i++) k->xpos[b][i] = k->xpos[p][i] + t[i];
+        matmul3(k->xmat[p], m->bR0[b], R);
+        int j = m->dofid[b];
+        if (j >= 0) {
+            double E[9];
+            axisangle2mat(m->jaxis[b], q[j], E);
+            matmul3(R, E, k->xmat[b]);
+            matvec3(k->xmat[b], m->jaxis[b], k->xaxis[j]);
+            memcpy(k->xanchor[j], k->xpos[b], sizeof(double) * 3);
+        } else {
+            memcpy(k->xmat[b], R, sizeof(R));
+        }
+        matvec3(k->xmat[b], m->ipos[b], t);
+        for (int i = 0; i < 3; i++) k->xipos[b][i] = k->xpos[b][i] + t[i];
+    }
+}
+
+/* is dof j an ancestor-or-self joint of body b? */
+static int dof_affects(const OrModel *m, int j, int b) {
+    int jb = m->dof_body[j];
+    while (b > 0) {
+        if (b == jb) return 1;
+        b = m->parent[b];
+    }
+    return 0;
+}
+
+/* translational Jacobian of a world point rigidly attached to body b (3 x nv, row-major) and
+ * rotational Jacobian of body b */
+static void jacobian(const OrModel *m, const Kin *k, int b, const double *point, double *Jp, double *Jr) {
+    int nv = m->nv;
+    for (int j = 0; j < nv; j++) {
+        double col[3] = {0, 0, 0}, ax[3] = {0, 0, 0};
+        if (dof_affects(m, j, b)) {
+            double r[3] = {point[0] - k->xanchor[j][0], point[1] - k->xanchor[j][1], point[2] - k->xanchor[j][2]};
+            cross3(k->xaxis[j], r, col);
+            memcpy(ax, k->xaxis[j], sizeof(ax));
+        }
+        for (int i = 0; i < 3; i++) {
+            Jp[i * nv + j] = col[i];
+            if (Jr) Jr[i * nv + j] = ax[i];
+        }
+    }
+}
+
+/* world-frame inertia tensor of body b about its COM */
+static void world_inertia(const OrModel *m, const Kin *k, int b, double *Iw) {
+    double T[9], Rt[9];
+    matmul3(k->xmat[b], m->inertia[b], T);
+    for (int i = 0; i < 3; i++)
+        for (int j = 0; j < 3; j++) Rt[3 * i + j] = k->xmat[b][3 * j + i];
+    matmul3(T, Rt, Iw);
+}
+
+/* M(q) = sum_b m_b Jp^T Jp + Jr^T Iw Jr  + diag(armature)   (nv x nv, row-major) */
+static void mass_matrix(const OrModel *m, const Kin *k, double *M) {
+    int nv = m->nv;
+    memset(M, 0, sizeof(double) * nv * nv);
+    for (int b = 1; b < m->nbody; b++) {
+        if (m->mass[b] <= 0) continue;
+        double Jp[3 * MAXV], Jr[3 * MAXV], Iw[9], IJ[3 * MAXV];
+        jacobian(m, k, b, k->xipos[b], Jp, Jr);
+        world_inertia(m, k, b, Iw);
+        for (int i = 0; i < 3; i++)
+            for (int j = 0; j < nv; j++) {
+                double s = 0;
+                for (int c = 0; c < 3; c++) s += Iw[3 * i + c] * Jr[c * nv + j];
+                IJ[i * nv + j] = s;
+            }
+        for (int i = 0; i < nv; i++)
+            for (int j = 0; j < nv; j++) {
+                double s = 0;
+                for (int c = 0; c < 3; c++) s += m->mass[b] * Jp[c * nv + i] * Jp[c * nv + j] + Jr[c * nv + i] * IJ[c * nv + j];
+                M[i * nv + j] += s;
+            }
+    }
+    for (int j = 0; j < nv; j++) M[j * nv + j] += m->armature[j];
+}
+
+/* Recursive Newton-Euler in the inertial frame: tau = M(q) qacc + c(q, qvel) (+ gravity).
+ * MuJoCo mj_rne; with qacc = NULL it returns the bias force qfrc_bias. */
+static void rne(const OrModel *m, const Kin *k, const double *v, const double *a, double *tau) {
+    double w[MAXB][3], al[MAXB][3], oacc[MAXB][3];    /* ang. vel, ang. acc, origin acceleration */
+    double F[MAXB][3], N[MAXB][3];                    /* net force at COM, net moment about body origin */
+    memset(w[0], 0, 24);
+    memset(al[0], 0, 24);
+    for (int i = 0; i < 3; i++) oacc[0][i] = -m->gravity[i];
+    for (int b = 1; b < m->nbody; b++) {
+        int p = m->parent[b], j = m->dofid[b];
+        double r[3], t1[3], t2[3];
+        for (int i = 0; i < 3; i++) r[i] = k->xpos[b][i] - k->xpos[p][i];
+        cross3(al[p], r, t1);
+        cross3(w[p], r, t2);
+        double t3[3];
+        cross3(w[p], t2, t3);
+        for (int i = 0; i < 3; i++) {
+            oacc[b][i] = oacc[p][i] + t1[i] + t3[i];
+            w[b][i] = w[p][i];
+            al[b][i] = al[p][i];
+        }
+        if (j >= 0) {
+            double wxa[3];
+            cross3(w[p], k->xaxis[j], wxa);
+            for (int i = 0; i < 3; i++) {
+                w[b][i] += k->xaxis[j][i] * v[j];
+                al[b][i] += wxa[i] * v[j] + (a ? k->xaxis[j][i] * a[j] : 0.0);
+            }
+        }
+        /* COM acceleration */
+        double d[3], cacc[3], Iw[9], Iwv[3], Ial[3], wIw[3];
+        for (int i = 0; i < 3; i++) d[i] = k->xipos[b][i] - k->xpos[b][i];
+        cross3(al[b], d, t1);
+        cross3(w[b], d, t2);
+        cross3(w[b], t2, t3);
+        for (int i = 0; i < 3; i++) cacc[i] = oacc[b][i] + t1[i] + t3[i];
+        world_inertia(m, k, b, Iw);
+        matvec3(Iw, w[b], Iwv);
+        matvec3(Iw, al[b], Ial);
+        cross3(w[b], Iwv, wIw);
+        double dxF[3];
+        for (int i = 0; i < 3; i++) F[b][i] = m->mass[b] * cacc[i];
+        cross3(d, F[b], dxF);
+        for (int i = 0; i < 3; i++) N[b][i] = Ial[i] + wIw[i] + dxF[i];
+    }
+    for (int b = m->nbody - 1; b >= 1; b--) {
+        int p = m->parent[b], j = m->dofid[b];
+        if (j >= 0) tau[j] = dot3(k->xaxis[j], N[b]);
+        if (p > 0) {
+            double r[3], rxF[3];
+            for (int i = 0; i < 3; i++) r[i] = k->xpos[b][i] - k->xpos[p][i];
+            cross3(r, F[b], rxF);
+            for (int i = 0; i < 3; i++) {
+                F[p][i] += F[b][i];
+                N[p][i] += N[b][i] + rxF[i];
+            }
+        }
+    }
+}
+
+/* ---------------------------------------------------------------- model compile */
+/* MuJoCo compiler, inertiafromgeom="true": geom mass = density * volume; sphere 2/5 m r^2;
+ * capsule = cylinder + two hemispheres (MuJoCo user_objects: mjCGeom::SetInertia). */
+static void geom_inertia(int type, double r, const double *a, const double *b_, double density,
+                         double *mass, double *pos, double *I) {
+    const double PI = 3.14159265358979323846;
+    memset(I, 0, sizeof(double) * 9);
+    if (type == 1) {
+        *mass = density * 4.0 / 3.0 * PI * r * r * r;
+        memcpy(pos, a, 24);
+        double i = 0.4 * (*mass) * r * r;
+        I[0] = I[4] = I[8] = i;
+    } else {
+        double u[3] = {b_[0] - a[0], b_[1] - a[1], b_[2] - a[2]};
+        double len = sqrt(dot3(u, u));
+        for (int i = 0; i < 3; i++) { u[i] /= len; pos[i] = 0.5 * (a[i] + b_[i]); }
+        double h = len;     /* cylinder height = 2 * half-length */
+        *mass = density * (PI * r * r * h + 4.0 / 3.0 * PI * r * r * r);
+        double ms = (*mass) * 4 * r / (4 * r + 3 * h), mc = (*mass) - ms;
+        double Iperp = mc * (3 * r * r + h * h) / 12 + 0.4 * ms * r * r + ms * h * (3 * r + 2 * h) / 8;
+        double Iax = mc * r * r / 2 + 0.4 * ms * r * r;
+        for (int i = 0; i < 3; i++)
+            for (int j = 0; j < 3; j++) I[3 * i + j] = (i == j ? Iperp : 0.0) + (Iax - Iperp) * u[i] * u[j];
+    }
+}
+
+static void set_const(OrModel *m);
+
+OrModel *or_model_compile(const double *f, int n) {
+    OrModel *m = (OrModel *)calloc(1, sizeof(OrModel));
+    int nb = (int)f[0], ng = (int)f[1], nu = (int)f[2];
+    if (n != HEADER_LEN + nb * BODY_STRIDE + ng * GEOM_STRIDE + nu * ACT_STRIDE || nb + 1 > MAXB || ng > MAXG) {
+        free(m);
+        return NULL;
+    }
+    m->nbody = nb + 1;
+    m->nu = nu;
+    m->timestep = f[3];
+    memcpy(m->gravity, f + 4, 24);
+    m->frame_skip = (int)f[7];
+    memcpy(m->solref, f + 8, 16);
+    memcpy(m->solimp, f + 10, 40);
+    m->site_body = (int)f[15] + 1;
+    memcpy(m->site_pos, f + 16, 24);
+    memcpy(m->target_default, f + 19, 24);
+    m->has_plane = (int)f[22];
+    memcpy(m->plane_pos, f + 23, 24);
+    memcpy(m->plane_n, f + 26, 24);
+    m->plane_margin = f[29];
+    m->dofid[0] = -1;
+    int nv = 0;
+    for (int b = 1; b <= nb; b++) {
+        const double *r = f + HEADER_LEN + (b - 1) * BODY_STRIDE;
+        m->parent[b] = (int)r[0] + 1;
+        memcpy(m->bpos[b], r + 1, 24);
+        quat2mat(r + 4, m->bR0[b]);
+        m->dofid[b] = -1;
+        if (r[8] != 0) {
+            int j = nv++;
+            m->dofid[b] = j;
+            m->dof_body[j] = b;
+            double nrm = sqrt(dot3(r + 9, r + 9));
+            for (int i = 0; i < 3; i++) m->jaxis[b][i] = r[9 + i] / nrm;
+            m->range[j][0] = r[12];
+            m->range[j][1] = r[13];
+            m->limited[j] = (int)r[14];
+            m->damping[j] = r[15];
+            m->armature[j] = r[16];
+        }
+    }
+    m->nv = nv;
+    /* inertiafromgeom */
+    double gm[MAXG], gp[MAXG][3], gI[MAXG][9];
+    int gb[MAXG];
+    const double *g0 = f + HEADER_LEN + nb * BODY_STRIDE;
+    for (int g = 0; g < ng; g++) {
+        const double *r = g0 + g * GEOM_STRIDE;
+        gb[g] = (int)r[0] + 1;
+        geom_inertia((int)r[1], r[2], r + 3, r + 6, r[9], &gm[g], gp[g], gI[g]);
+        if (r[10] != 0 && (int)r[1] == 1 && m->nsphere < MAXS) {
+            int s = m->nsphere++;
+            m->sph_body[s] = gb[g];
+            memcpy(m->sph_pos[s], r + 3, 24);
+            m->sph_r[s] = r[2];
+            m->sph_margin[s] = r[11];
+        }
+    }
+    for (int b = 1; b <= nb; b++) {
+        double mass = 0, com[3] = {0, 0, 0};
+        for (int g = 0; g < ng; g++)
+            if (gb[g] == b) {
+                mass += gm[g];
+                for (int i = 0; i < 3; i++) com[i] += gm[g] * gp[g][i];
+            }
+        m->mass[b] = mass;
+        if (mass > 0)
+            for (int i = 0; i < 3; i++) com[i] /= mass;
+        memcpy(m->ipos[b], com, 24);
+        for (int g = 0; g < ng; g++)
+            if (gb[g] == b) {
+                double d[3] = {gp[g][0] - com[0], gp[g][1] - com[1], gp[g][2] - com[2]};
+                double dd = dot3(d, d);
+                for (int i = 0; i < 3; i++)
+                    for (int j = 0; j < 3; j++)
+                        m->inertia[b][3 * i + j] += gI[g][3 * i + j] + gm[g] * ((i == j ? dd : 0.0) - d[i] * d[j]);
+            }
+    }
+    const double *a0 = g0 + ng * GEOM_STRIDE;
+    for (int a = 0; a < nu; a++) {
+        m->act_dof[a] = (int)a0[a * ACT_STRIDE];
+        m->gear[a] = a0[a * ACT_STRIDE + 1];
+        m->ctrl_lo[a] = a0[a * ACT_STRIDE + 2];
+        m->ctrl_hi[a] = a0[a * ACT_STRIDE + 3];
+    }
+    set_const(m);
+    return m;
+}
+
+void or_model_free(OrModel *m) { free(m); }
+
+/* MuJoCo mj_setConst (set0): at qpos0, dof_invweight0[j] = (M^-1)_jj for hinge dofs,
+ * body_invweight0[b] (translational) = trace(Jcom M^-1 Jcom^T) / 3, world = 0. */
+static void set_const(OrModel *m) {
+    int nv = m->nv;
+    double q0[MAXV] = {0}, M[MAXV * MAXV];
+    Kin k;
+    kinematics(m, q0, &k);
+    mass_matrix(m, &k, M);
+    chol(M, nv);
+    for (int j = 0; j < nv; j++) {
+        double e[MAXV] = {0};
+        e[j] = 1;
+        chol_solve(M, nv, e);
+        m->dof_invweight0[j] = e[j];
+    }
+    m->body_invweight0[0] = 0;
+    for (int b = 1; b < m->nbody; b++) {
+        double Jp[3 * MAXV], tr = 0;
+        jacobian(m, &k, b, k.xipos[b], Jp, NULL);
+        for (int i = 0; i < 3; i++) {
+            double x[MAXV];
+            memcpy(x, Jp + i * nv, sizeof(double) * nv);
+            chol_solve(M, nv, x);
+            for (int j = 0; j < nv; j++) tr += Jp[i * nv + j] * x[j];
+        }
+        m->body_invweight0[b] = tr / 3;
+    }
+}
+
+/* ---------------------------------------------------------------- soft constraints */
+/* MuJoCo mj_makeImpedance / getimpedance / mj_referenceConstraint for one scalar row.
+ * pos: signed distance, margin: activation margin; r = pos - margin. */
+static void row_params(const OrModel *m, double pos, double margin, double diagApprox, double jv,
+                       double *D, double *aref) {
+    double dmin = m->solimp[0], dmax = m->solimp[1], width = m->solimp[2], mid = m->solimp[3], power = m->solimp[4];
+    double r = pos - margin, imp;
+    if (dmin == dmax || width <= MJ_MINVAL) {
+        imp = 0.5 * (dmin + dmax);
+    } else {
+        double x = fabs(r) / width;
+        if (x >= 1) imp = dmax;
+        else if (x <= 0) imp = dmin;
+        else {
+            double y;
+            if (power == 1) y = x;
+            else if (x <= mid) y = pow(x, power) / pow(mid, power - 1);
+            else y = 1 - pow(1 - x, power) / pow(1 - mid, power - 1);
+            imp = dmin + y * (dmax - dmin);
+        }
+    }
+    double R = (1 - imp) / imp * diagApprox;
+    if (R < MJ_MINVAL) R = MJ_MINVAL;
+    *D = 1 / R;
+    /* standard solref = (timeconst, dampratio); refsafe: timeconst >= 2*timestep */
+    double tc = m->solref[0], dr = m->solref[1];
+    if (tc < 2 * m->timestep) tc = 2 * m->timestep;
+    double b = 2 / (dmax * tc), kk = 1 / (dmax * dmax * tc * tc * dr * dr);
+    *aref = -b * jv - kk * imp * r;
+}
+
+/* minimise  1/2 (a - a_s)^T M (a - a_s) + sum_i 1/2 D_i min(0, J_i a - aref_i)^2
+ * (MuJoCo primal problem for frictionless unilateral rows; the Newton solver of mj_fwdConstraint
+ * converges to this unique minimiser up to its 1e-8 tolerance). Here: Newton + exact line search,
+ * run to machine precision.  fs = M a_s.  Returns qacc in a and row forces in force. */
+static void solve_rows(OrModel *m, int nv, const double *M, const double *fs, int nc,
+                       double (*J)[MAXV], const double *aref, const double *D, double *a, double *force) {
+    double L[MAXV * MAXV];
+    memcpy(L, M, sizeof(double) * nv * nv);
+    chol(L, nv);
+    memcpy(a, fs, sizeof(double) * nv);
+    chol_solve(L, nv, a);
+    double scale = 1;
+    for (int i = 0; i < nv; i++) if (fabs(fs[i]) > scale) scale = fabs(fs[i]);
+    m->newton_calls++;
+    int it;
+    for (it = 0; it < 100 && nc > 0; it++) {
+        double jar[MAXC], g[MAXV], H[MAXV * MAXV], d[MAXV];
+        for (int i = 0; i < nv; i++) {
+            double s = -fs[i];
+            for (int j = 0; j < nv; j++) s += M[i * nv + j] * a[j];
+            g[i] = s;
+        }
+        memcpy(H, M, sizeof(double) * nv * nv);
+        for (int c = 0; c < nc; c++) {
+            double s = -aref[c];
+            for (int j = 0; j < nv; j++) s += J[c][j] * a[j];
+            jar[c] = s;
+            if (s < 0) {
+                for (int i = 0; i < nv; i++) {
+                    g[i] += D[c] * s * J[c][i];
+                    for (int j = 0; j < nv; j++) H[i * nv + j] += D[c] * J[c][i] * J[c][j];
+                }
+            }
+        }
+        double gn = 0;
+        for (int i = 0; i < nv; i++) if (fabs(g[i]) > gn) gn = fabs(g[i]);
+        if (gn <= 1e-11 * scale) break;
+        chol(H, nv);
+        for (int i = 0; i < nv; i++) d[i] = -g[i];
+        chol_solve(H, nv, d);
+        /* exact line search: phi'(alpha) = p0 + alpha p1 + sum_c D jd min(0, jar + alpha jd) */
+        double p0 = 0, p1 = 0, jd[MAXC], bp[MAXC];
+        int idx[MAXC], nbp = 0;
+        for (int i = 0; i < nv; i++) {
+            double Md = 0, Ma = -fs[i];
+            for (int j = 0; j < nv; j++) { Md += M[i * nv + j] * d[j]; Ma += M[i * nv + j] * a[j]; }
+            p0 += d[i] * Ma;
+            p1 += d[i] * Md;
+        }
+        double c0 = p0, c1 = p1;
+        for (int c = 0; c < nc; c++) {
+            double s = 0;
+            for (int j = 0; j < nv; j++) s += J[c][j] * d[j];
+            jd[c] = s;
+            if (jar[c] < 0 || (jar[c] == 0 && s < 0)) { c0 += D[c] * s * jar[c]; c1 += D[c] * s * s; }
+            if (s != 0) {
+                double al = -jar[c] / s;
+                if (al > 0) { bp[nbp] = al; idx[nbp++] = c; }
+            }
+        }
+        for (int i = 1; i < nbp; i++)       /* insertion sort of break points */
+            for (int j = i; j > 0 && bp[j] < bp[j - 1]; j--) {
+                double t = bp[j]; bp[j] = bp[j - 1]; bp[j - 1] = t;
+                int ti = idx[j]; idx[j] = idx[j - 1]; idx[j - 1] = ti;
+            }
+        double alpha = -c0 / c1;
+        for (int i = 0; i < nbp; i++) {
+            if (alpha <= bp[i]) break;
+            int c = idx[i];
+            /* row c toggles at bp[i]: it was active iff jar < 0 (or jar == 0 moving down) */
+            int was_active = jar[c] < 0;
+            double sgn = was_active ? -1.0 : 1.0;
+            c0 += sgn * D[c] * jd[c] * jar[c];
+            c1 += sgn * D[c] * jd[c] * jd[c];
+            alpha = -c0 / c1;
+            if (alpha < bp[i]) alpha = bp[i];
+        }
+        for (int i = 0; i < nv; i++) a[i] += alpha * d[i];
+    }
+    m->newton_iters += it;
+    if (it >= 100) m->newton_fail++;
+    for (int c = 0; c < nc; c++) {
+        double s = -aref[c];
+        for (int j = 0; j < nv; j++) s += J[c][j] * a[j];
+        force[c] = s < 0 ? -D[c] * s : 0.0;
+    }
+}
+
+/* ---------------------------------------------------------------- one mj_step */
+/* q, v updated in place; site_out (optional) = finger site position computed from the q the step
+ * STARTED with (MuJoCo runs kinematics before integrating and MjSim.step() does not call
+ * mj_forward afterwards, so data.site_xpos lags qpos by one substep). */
+void or_step(OrModel *m, double *q, double *v, const double *ctrl, double *site_out, double *diag) {
+    int nv = m->nv;
+    Kin k;
+    double M[MAXV * MAXV], bias[MAXV], fs[MAXV];
+    kinematics(m, q, &k);
+    if (site_out) {
+        double t[3];
+        matvec3(k.xmat[m->site_body], m->site_pos, t);
+        for (int i = 0; i < 3; i++) site_out[i] = k.xpos[m->site_body][i] + t[i];
+    }
+    mass_matrix(m, &k, M);
+    rne(m, &k, v, NULL, bias);
+    for (int j = 0; j < nv; j++) fs[j] = -bias[j] - m->damping[j] * v[j];     /* passive: no springs */
+    for (int a = 0; a < m->nu; a++) {                                          /* motors, ctrllimited */
+        double u = ctrl[a];
+        if (u < m->ctrl_lo[a]) u = m->ctrl_lo[a];
+        if (u > m->ctrl_hi[a]) u = m->ctrl_hi[a];
+        fs[m->act_dof[a]] += m->gear[a] * u;
+    }
+    /* constraint rows: MuJoCo mj_instantiateLimit (dist < margin, jnt margin = 0) */
+    double J[MAXC][MAXV], aref[MAXC], D[MAXC], force[MAXC], qacc[MAXV];
+    int nc = 0;
+    for (int j = 0; j < nv; j++) {
+        if (!m->limited[j]) continue;
+        for (int side = -1; side <= 1; side += 2) {
+            double dist = side * (m->range[j][(side + 1) / 2] - q[j]);
+            if (dist < 0) {
+                memset(J[nc], 0, sizeof(J[nc]));
+                J[nc][j] = -side;
+                row_params(m, dist, 0.0, m->dof_invweight0[j], -side * v[j], &D[nc], &aref[nc]);
+                nc++;
+            }
+        }
+    }
+    /* plane-sphere contact, condim 1 (mjc_PlaneSphere + mj_instantiateContact):
+     * margin = max of the two geom margins, gap = 0, included when dist < margin */
+    for (int s = 0; m->has_plane && s < m->nsphere; s++) {
+        int b = m->sph_body[s];
+        double c[3], t[3];
+        matvec3(k.xmat[b], m->sph_pos[s], t);
+        for (int i = 0; i < 3; i++) c[i] = k.xpos[b][i] + t[i] - m->plane_pos[i];
+        double dist = dot3(c, m->plane_n) - m->sph_r[s];
+        double margin = m->plane_margin > m->sph_margin[s] ? m->plane_margin : m->sph_margin[s];
+        if (dist < margin) {
+            double cp[3], Jp[3 * MAXV], jv = 0;
+            for (int i = 0; i < 3; i++)
+                cp[i] = k.xpos[b][i] + t[i] - m->plane_n[i] * (m->sph_r[s] + 0.5 * dist);
+            jacobian(m, &k, b, cp, Jp, NULL);
+            for (int j = 0; j < nv; j++) {
+                J[nc][j] = m->plane_n[0] * Jp[j] + m->plane_n[1] * Jp[nv + j] + m->plane_n[2] * Jp[2 * nv + j];
+                jv += J[nc][j] * v[j];
+            }
+            row_params(m, dist, margin, m->body_invweight0[0] + m->body_invweight0[b], jv, &D[nc], &aref[nc]);
+            nc++;
+        }
+    }
+    solve_rows(m, nv, M, fs, nc, J, aref, D, qacc, force);
+    /* mj_Euler with implicit joint damping: (M + h diag(damping)) qacc' = qfrc_smooth + qfrc_constraint */
+    double rhs[MAXV];
+    memcpy(rhs, fs, sizeof(double) * nv);
+    for (int c = 0; c < nc; c++)
+        for (int j = 0; j < nv; j++) rhs[j] += J[c][j] * force[c];
+    for (int j = 0; j < nv; j++) M[j * nv + j] += m->timestep * m->damping[j];
+    chol(M, nv);
+    chol_solve(M, nv, rhs);
+    for (int j = 0; j < nv; j++) {
+        v[j] += m->timestep * rhs[j];
+        q[j] += m->timestep * v[j];
+    }
+    if (diag) {
+        diag[0] = nc;
+        for (int j = 0; j < nv; j++) diag[1 + j] = qacc[j];
+    }
+}
+
+/* ---------------------------------------------------------------- accessors for tests */
+int or_nv(const OrModel *m) { return m->nv; }
+int or_nbody(const OrModel *m) { return m->nbody; }
+int or_dobs(const OrModel *m) { return 2 * m->nv + 6; }
+void or_get_inertial(const OrModel *m, double *mass, double *ipos, double *inertia) {
+    for (int b = 0; b < m->nbody; b++) {
+        mass[b] = m->mass[b];
+        memcpy(ipos + 3 * b, m->ipos[b], 24);
+        memcpy(inertia + 9 * b, m->inertia[b], 72);
+    }
+}
+void or_get_invweight0(const OrModel *m, double *dof, double *body) {
+    memcpy(dof, m->dof_invweight0, sizeof(double) * m->nv);
+    memcpy(body, m->body_invweight0, sizeof(double) * m->nbody);
+}
+void or_get_newton_stats(const OrModel *m, long *out) {
+    out[0] = m->newton_calls; out[1] = m->newton_iters; out[2] = m->newton_fail;
+}
+void or_mass_matrix(const OrModel *m, const double *q, double *M) {
+    Kin k;
+    kinematics(m, q, &k);
+    mass_matrix(m, &k, M);
+}
+void or_rne(const OrModel *m, const double *q, const double *v, const double *a, double *tau) {
+    Kin k;
+    kinematics(m, q, &k);
+    rne(m, &k, v, a, tau);
+}
+void or_site(const OrModel *m, const double *q, double *xyz) {
+    Kin k;
+    kinematics(m, q, &k);
+    double t[3];
+    matvec3(k.xmat[m->site_body], m->site_pos, t);
+    for (int i = 0; i < 3; i++) xyz[i] = k.xpos[m->site_body][i] + t[i];
+}
+/* total kinetic energy 1/2 v^T M v (armature included) */
+double or_kinetic(const OrModel *m, const double *q, const double *v) {
+    double M[MAXV * MAXV], e = 0;
+    or_mass_matrix(m, q, M);
+    for (int i = 0; i < m->nv; i++)
+        for (int j = 0; j < m->nv; j++) e += 0.5 * v[i] * M[i * m->nv + j] * v[j];
+    return e;
+}
+
+/* ---------------------------------------------------------------- env step + rollout */
+/* Reacher7DOFEnv.step (reacher_env.py:29-39): frame_skip x mj_step, then
+ * reward = -(|h-g|_1 + 5 |h-g|_2) with h = data.site_xpos[finger] (lagging one substep) and
+ * obs = [qpos, qvel, h, h - g] (reacher_env.py:41-47). */
+static double env_step(OrModel *m, double *q, double *v, const double *u, const double *target, double *obs) {
+    double h[3] = {0, 0, 0};
+    for (int s = 0; s < m->frame_skip; s++) or_step(m, q, v, u, h, NULL);
+    double d[3] = {h[0] - target[0], h[1] - target[1], h[2] - target[2]};
+    double l1 = fabs(d[0]) + fabs(d[1]) + fabs(d[2]), l2 = sqrt(dot3(d, d));
+    if (obs) {
+        int nv = m->nv;
+        memcpy(obs, q, sizeof(double) * nv);
+        memcpy(obs + nv, v, sizeof(double) * nv);
+        memcpy(obs + 2 * nv, h, 24);
+        memcpy(obs + 2 * nv + 3, d, 24);
+    }
+    return -l1 - 5.0 * l2;
+}
+
+double or_env_step(OrModel *m, double *q, double *v, const double *u, const double *target, double *obs) {
+    return env_step(m, q, v, u, target, obs);
+}
+
+/* GymEnvWrapper.rollout (gym_env_wrapper.py:89-156), mode "open_loop":
+ * every particle restarts from (qp0, qv0); obs[b,0] is the fresh observation after
+ * set_env_state (which ends with sim.forward(), reacher_env.py:99); act is the UNCLIPPED
+ * mean + noise (gym_env_wrapper.py:151); done is always False (reacher_env.py:39).
+ * Any of obs / next_obs / act / done may be NULL.  OpenMP over particles. */
+void or_rollout(OrModel *m, const double *qp0, const double *qv0, const double *target, long P, int H,
+                const double *mean, const double *noise, double *obs, double *rew, double *act,
+                double *done, double *next_obs) {
+    int nv = m->nv, nu = m->nu, dobs = 2 * nv + 6;
+    double h0[3];
+    or_site(m, qp0, h0);
+    long calls = 0, iters = 0, fails = 0;
+#pragma omp parallel for schedule(static) reduction(+ : calls, iters, fails)
+    for (long b = 0; b < P; b++) {
+        OrModel loc = *m;       /* private statistics */
+        loc.newton_calls = loc.newton_iters = loc.newton_fail = 0;
+        double q[MAXV], v[MAXV], cur[2 * MAXV + 6], nxt[2 * MAXV + 6], u[MAXV];
+        memcpy(q, qp0, sizeof(double) * nv);
+        memcpy(v, qv0, sizeof(double) * nv);
+        memcpy(cur, q, sizeof(double) * nv);
+        memcpy(cur + nv, v, sizeof(double) * nv);
+        for (int i = 0; i < 3; i++) { cur[2 * nv + i] = h0[i]; cur[2 * nv + 3 + i] = h0[i] - target[i]; }
+        for (int t = 0; t < H; t++) {
+            for (int a = 0; a < nu; a++) u[a] = mean[t * nu + a] + (noise ? noise[(b * H + t) * nu + a] : 0.0);
+            double r = env_step(&loc, q, v, u, target, nxt);
+            long o = (b * H + t);
+            if (obs) memcpy(obs + o * dobs, cur, sizeof(double) * dobs);
+            if (next_obs) memcpy(next_obs + o * dobs, nxt, sizeof(double) * dobs);
+            rew[o] = r;
+            if (act) memcpy(act + o * nu, u, sizeof(double) * nu);
+            if (done) done[o] = 0.0;
+            memcpy(cur, nxt, sizeof(double) * dobs);
+        }
+        calls += loc.newton_calls; iters += loc.newton_iters; fails += loc.newton_fail;
+    }
+    m->newton_calls += calls; m->newton_iters += iters; m->newton_fail += fails;
+}
