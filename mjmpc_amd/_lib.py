@@ -1,0 +1,69 @@
+"""ctypes binding of libmjmpc_amd.so (the C ABI in include/mjmpc_amd.h).
+
+There is NO CPU fallback: if the library is missing or no GPU is visible, the product path raises.
+"""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libmjmpc_amd.so")
+
+F32, F64 = 0, 1
+
+_vp = ctypes.c_void_p
+_i64 = ctypes.c_int64
+_int = ctypes.c_int
+_dbl = ctypes.c_double
+_dp = ctypes.POINTER(ctypes.c_double)
+
+# name -> (restype, argtypes); doubles as the list of symbols include/mjmpc_amd.h declares
+SIGNATURES = {
+    "mjmpc_abi_version": (_int, []),
+    "mjmpc_last_error": (ctypes.c_char_p, []),
+    "mjmpc_device_count": (_int, []),
+    "mjmpc_arm_create": (_int, [_dp, _int, _int, ctypes.POINTER(_vp)]),
+    "mjmpc_arm_destroy": (_int, [_vp]),
+    "mjmpc_arm_dims": (_int, [_vp, ctypes.POINTER(_int), ctypes.POINTER(_int), ctypes.POINTER(_int)]),
+    "mjmpc_arm_set_state": (_int, [_vp, _dp, _dp, _dp, _vp]),
+    "mjmpc_arm_state_ptr": (_vp, [_vp]),
+    "mjmpc_arm_rollout": (_int, [_vp, _int, _i64, _int, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "mjmpc_arm_solver_failures": (_int, [_vp, ctypes.POINTER(ctypes.c_uint32)]),
+}
+
+_LIB = None
+
+
+class MjmpcError(RuntimeError):
+    pass
+
+
+def load():
+    """Load the shared library (no GPU needed just to load and inspect symbols)."""
+    global _LIB
+    if _LIB is None:
+        if not os.path.exists(LIB_PATH):
+            raise MjmpcError("%s not built - run `python -m mjmpc_amd.build` (needs hipcc); "
+                             "mjmpc_amd has no CPU fallback" % LIB_PATH)
+        # torch bundles its own libamdhip64.so.7; it has to be the copy this process binds, so
+        # that device pointers and streams are shared - import torch BEFORE dlopen'ing our library
+        # (the other order leaves torch with "No HIP GPUs are available").
+        import torch  # noqa: F401
+        lib = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(lib, name)
+            fn.restype, fn.argtypes = res, args
+        _LIB = lib
+    return _LIB
+
+
+def check(rc):
+    if rc != 0:
+        raise MjmpcError("mjmpc_amd call failed (%d): %s" % (rc, load().mjmpc_last_error().decode()))
+
+
+def require_gpu():
+    lib = load()
+    if lib.mjmpc_device_count() < 1:
+        raise MjmpcError("no HIP device visible: the mjmpc_amd product path runs only on the GPU "
+                         "(the CPU oracle under oracle/ is test infrastructure, not a fallback)")
+    return lib

@@ -1,0 +1,509 @@
+// Fused rollout kernel for a serial hinge arm (reacher_7dof-v0): the whole
+//   for b in particles: for t in horizon: env.step(mean[t] + noise[b,t])
+// double loop of GymEnvWrapper.rollout (reference mjmpc/envs/gym_env_wrapper.py:125-153) with
+// Reacher7DOFEnv.step (mjmpc/envs/basic/reacher_env.py:29-39) and MuJoCo's mj_step inlined,
+// one launch per control iteration.
+//
+// Execution model (CDNA4, wave64): ONE PARTICLE = 8 LANES, lane l8 = link / dof index
+// (lane 7 is a zero-mass spare), 8 particles per wavefront, one wavefront per workgroup.
+// All per-particle state (q, v, frames, spatial inertias, the 7x7 mass matrix row of "my" dof)
+// lives in VGPRs; links talk through DPP row shifts (lanegroup.h).  Everything is expressed in
+// world coordinates about the world origin, so tree recursions become plain prefix / suffix
+// sums over the lane group:
+//   forward kinematics   = inclusive scan of affine transforms (3 DPP steps)
+//   velocities, vel.-product accelerations = prefix sums of spatial vectors
+//   RNE forces, composite inertias         = suffix sums
+//   M[i][i+s] = S_i . (Ic_{i+s} S_{i+s})   = 7 shifted dot products  -> LDS 8x8 transpose
+//   (M + E) x = r                          = in-register LDL^T, one row per lane, DPP broadcasts
+// The soft-constraint problem (joint limits + sphere/plane contact, all frictionless rows) is
+// solved by a primal active-set Newton iteration: with the active set fixed the objective is
+// quadratic, so each iteration is one 7x7 solve; it stops when the active set reproduces itself,
+// which is the exact minimiser MuJoCo's Newton solver converges to.
+#include <hip/hip_runtime.h>
+
+#include "arm_model.h"
+#include "arm_rollout.h"
+#include "lanegroup.h"
+
+namespace mjmpc {
+namespace {
+
+constexpr int NEWTON_MAXIT = 12;
+
+template <typename T>
+struct LaneConst {          // constants of "my" link
+    T off[3], ax[3], mass, com[3], I[6], armature, damping, lo, hi, gear, ulo, uhi, invw;
+    bool limited;
+};
+
+template <typename T>
+struct ArmGlobals {         // wave-uniform (SGPR) constants
+    int site_link, n_sphere, sph_link, frame_skip;
+    T h, site_pos[3], sph_pos[3], sph_r, sph_margin, sph_invw, pn[3], pd;
+    T K, B, dmin, dmax, width, mid, power, grav[3];
+};
+
+template <typename T>
+__device__ __forceinline__ void load_consts(const T* __restrict__ m, int l8, LaneConst<T>& C, ArmGlobals<T>& Gc) {
+    for (int c = 0; c < 3; ++c) {
+        C.off[c] = m[O_OFF + c * LANES + l8];
+        C.ax[c] = m[O_AXIS + c * LANES + l8];
+        C.com[c] = m[O_COM + c * LANES + l8];
+    }
+    for (int c = 0; c < 6; ++c) C.I[c] = m[O_INERTIA + c * LANES + l8];
+    C.mass = m[O_MASS + l8];
+    C.armature = m[O_ARMATURE + l8];
+    C.damping = m[O_DAMPING + l8];
+    C.lo = m[O_RANGE_LO + l8];
+    C.hi = m[O_RANGE_HI + l8];
+    C.limited = m[O_LIMITED + l8] != T(0);
+    C.gear = m[O_GEAR + l8];
+    C.ulo = m[O_CTRL_LO + l8];
+    C.uhi = m[O_CTRL_HI + l8];
+    C.invw = m[O_DOF_INVW + l8];
+    Gc.site_link = (int)m[O_SITE_LINK];
+    Gc.n_sphere = (int)m[O_N_SPHERE];
+    Gc.sph_link = (int)m[O_SPH_LINK];
+    Gc.frame_skip = (int)m[O_FRAME_SKIP];
+    Gc.h = m[O_TIMESTEP];
+    for (int c = 0; c < 3; ++c) {
+        Gc.site_pos[c] = m[O_SITE_POS + c];
+        Gc.sph_pos[c] = m[O_SPH_POS + c];
+        Gc.pn[c] = m[O_PLANE_N + c];
+        Gc.grav[c] = m[O_GRAVITY + c];
+    }
+    Gc.sph_r = m[O_SPH_R];
+    Gc.sph_margin = m[O_SPH_MARGIN];
+    Gc.sph_invw = m[O_SPH_INVW];
+    Gc.pd = m[O_PLANE_D];
+    Gc.K = m[O_SOL_K];
+    Gc.B = m[O_SOL_B];
+    Gc.dmin = m[O_SOL_DMIN];
+    Gc.dmax = m[O_SOL_DMAX];
+    Gc.width = m[O_SOL_WIDTH];
+    Gc.mid = m[O_SOL_MID];
+    Gc.power = m[O_SOL_POWER];
+}
+
+// ---- small vector helpers -------------------------------------------------------------------
+template <typename T>
+__device__ __forceinline__ void cross(const T* a, const T* b, T* c) {
+    c[0] = a[1] * b[2] - a[2] * b[1];
+    c[1] = a[2] * b[0] - a[0] * b[2];
+    c[2] = a[0] * b[1] - a[1] * b[0];
+}
+template <typename T>
+__device__ __forceinline__ T dot(const T* a, const T* b) { return a[0] * b[0] + a[1] * b[1] + a[2] * b[2]; }
+template <typename T>
+__device__ __forceinline__ void matvec(const T* R, const T* x, T* y) {
+    for (int i = 0; i < 3; ++i) y[i] = R[3 * i] * x[0] + R[3 * i + 1] * x[1] + R[3 * i + 2] * x[2];
+}
+// symmetric 3x3 stored xx yy zz xy xz yz times vector
+template <typename T>
+__device__ __forceinline__ void symvec(const T* S, const T* x, T* y) {
+    y[0] = S[0] * x[0] + S[3] * x[1] + S[4] * x[2];
+    y[1] = S[3] * x[0] + S[1] * x[1] + S[5] * x[2];
+    y[2] = S[4] * x[0] + S[5] * x[1] + S[2] * x[2];
+}
+
+// one Hillis-Steele step of the transform scan:  X_i <- X_{i-S} o X_i   (identity where i < S)
+template <int S, typename T>
+__device__ __forceinline__ void fk_scan_step(T* R, T* p, int l8) {
+    T Ra[9], pa[3], Rn[9], t[3];
+    for (int k = 0; k < 9; ++k) Ra[k] = shr<S>(R[k], (k % 4 == 0) ? T(1) : T(0), l8);
+    for (int k = 0; k < 3; ++k) pa[k] = shr<S>(p[k], T(0), l8);
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j)
+            Rn[3 * i + j] = Ra[3 * i] * R[j] + Ra[3 * i + 1] * R[3 + j] + Ra[3 * i + 2] * R[6 + j];
+    matvec(Ra, p, t);
+    for (int k = 0; k < 3; ++k) p[k] = pa[k] + t[k];
+    for (int k = 0; k < 9; ++k) R[k] = Rn[k];
+}
+
+// MuJoCo mj_makeImpedance + mj_referenceConstraint for one scalar row (r = pos - margin)
+template <typename T>
+__device__ __forceinline__ void row_params(const ArmGlobals<T>& Gc, T r, T diag_approx, T jv, T& D, T& aref) {
+    T x = fabs(r) / Gc.width, y;
+    x = x > T(1) ? T(1) : x;
+    if (Gc.power == T(2)) {
+        T om = T(1) - x;
+        y = x <= Gc.mid ? x * x / Gc.mid : T(1) - om * om / (T(1) - Gc.mid);
+    } else if (Gc.power == T(1)) {
+        y = x;
+    } else {
+        y = x <= Gc.mid ? pow_(x, Gc.power) / pow_(Gc.mid, Gc.power - T(1))
+                        : T(1) - pow_(T(1) - x, Gc.power) / pow_(T(1) - Gc.mid, Gc.power - T(1));
+    }
+    T imp = Gc.dmin + y * (Gc.dmax - Gc.dmin);
+    T Rr = (T(1) - imp) / imp * diag_approx;
+    Rr = Rr < T(1e-15) ? T(1e-15) : Rr;
+    D = T(1) / Rr;
+    aref = -Gc.B * jv - Gc.K * imp * r;
+}
+
+// Solve (sym. pos. def.) H x = b.  Lane i holds row i: off-diagonals hr[j] (slot j == i unused),
+// diagonal hd.  In-register LDL^T; pivots and pivot rows travel by DPP broadcast.
+template <int K, typename T>
+struct LdlStep {
+    static __device__ __forceinline__ void factor(T& hd, T* hr, T& inv_own, int l8) {
+        T piv = bcast<K>(hd);
+        T inv = rcp_(piv);
+        inv_own = (l8 == K) ? inv : inv_own;
+        T l = (l8 > K) ? hr[K] * inv : T(0);          // l_iK for rows below the pivot
+        hd -= l * hr[K];
+#pragma unroll
+        for (int j = K + 1; j < MAX_LINKS; ++j) hr[j] -= l * bcast<K>(hr[j]);
+        hr[K] = (l8 > K) ? l : hr[K];                 // keep l_iK; lane K keeps its pivot row A_Kj
+        if constexpr (K + 1 < MAX_LINKS) LdlStep<K + 1, T>::factor(hd, hr, inv_own, l8);
+    }
+    static __device__ __forceinline__ void forward(const T* hr, T& b, int l8) {
+        T yk = bcast<K>(b);
+        b -= (l8 > K) ? hr[K] * yk : T(0);
+        if constexpr (K + 1 < MAX_LINKS) LdlStep<K + 1, T>::forward(hr, b, l8);
+    }
+    static __device__ __forceinline__ void backward(const T* hr, T inv_own, T& x, int l8) {
+        // x_i -= l_Ki x_K for i < K, with l_Ki = A_iK / d_i held (unscaled) in lane i slot K
+        T xk = bcast<K>(x);
+        x -= (l8 < K) ? hr[K] * inv_own * xk : T(0);
+        if constexpr (K > 0) LdlStep<K - 1, T>::backward(hr, inv_own, x, l8);
+    }
+};
+
+template <typename T>
+__device__ __forceinline__ T solve_spd(T hd, T* hr, T b, int l8) {
+    T inv_own = T(1);
+    LdlStep<0, T>::factor(hd, hr, inv_own, l8);
+    LdlStep<0, T>::forward(hr, b, l8);
+    b *= inv_own;
+    LdlStep<MAX_LINKS - 1, T>::backward(hr, inv_own, b, l8);
+    return b;
+}
+
+template <int J, typename T>
+__device__ __forceinline__ void add_rank1(T* hr, T wj, T jc) {
+    hr[J] += wj * bcast<J>(jc);
+    if constexpr (J + 1 < MAX_LINKS) add_rank1<J + 1, T>(hr, wj, jc);
+}
+
+template <int S, typename T>
+__device__ __forceinline__ void mass_diagonals(const T* sw, const T* sv, const T* Fn, const T* Ff, T* d) {
+    if constexpr (S == 0) {
+        d[0] = dot(sw, Fn) + dot(sv, Ff);
+    } else {
+        T fn[3], ff[3];
+        for (int c = 0; c < 3; ++c) {
+            fn[c] = shl_raw<S>(Fn[c]);
+            ff[c] = shl_raw<S>(Ff[c]);
+        }
+        d[S] = dot(sw, fn) + dot(sv, ff);
+    }
+    if constexpr (S + 1 < MAX_LINKS) mass_diagonals<S + 1, T>(sw, sv, Fn, Ff, d);
+}
+
+// ---- one mj_step ------------------------------------------------------------------------------
+// q, v: state of my dof (updated).  aw: constraint-solver warm start (previous qacc).
+// tau_act: gear * clip(ctrl) of my dof.  site: world position of the tracked site computed from
+// the q this substep STARTED with (MuJoCo runs kinematics before integrating).
+template <typename T>
+__device__ __forceinline__ void arm_substep(const LaneConst<T>& C, const ArmGlobals<T>& Gc, T& q, T& v, T& aw,
+                                            T tau_act, T* ldsM, int lane, int l8, T* site, unsigned* diag) {
+    // 1. forward kinematics: local transform (Rodrigues, frames are world-aligned at qpos0) + scan
+    T s, c;
+    sincos_(q, s, c);
+    T tt = T(1) - c;
+    T R[9], p[3];
+    R[0] = c + tt * C.ax[0] * C.ax[0];
+    R[1] = tt * C.ax[0] * C.ax[1] - s * C.ax[2];
+    R[2] = tt * C.ax[0] * C.ax[2] + s * C.ax[1];
+    R[3] = tt * C.ax[0] * C.ax[1] + s * C.ax[2];
+    R[4] = c + tt * C.ax[1] * C.ax[1];
+    R[5] = tt * C.ax[1] * C.ax[2] - s * C.ax[0];
+    R[6] = tt * C.ax[0] * C.ax[2] - s * C.ax[1];
+    R[7] = tt * C.ax[1] * C.ax[2] + s * C.ax[0];
+    R[8] = c + tt * C.ax[2] * C.ax[2];
+    for (int k = 0; k < 3; ++k) p[k] = C.off[k];
+    fk_scan_step<1>(R, p, l8);
+    fk_scan_step<2>(R, p, l8);
+    fk_scan_step<4>(R, p, l8);
+
+    const int gbase = lane & ~7;
+    {
+        T t[3];
+        matvec(R, Gc.site_pos, t);
+        for (int k = 0; k < 3; ++k) site[k] = __shfl(p[k] + t[k], gbase + Gc.site_link);
+    }
+
+    // 2. world-frame quantities of my link, everything about the WORLD ORIGIN
+    T a[3], cw[3], t3[3];
+    matvec(R, C.ax, a);                     // joint axis
+    matvec(R, C.com, t3);
+    for (int k = 0; k < 3; ++k) cw[k] = p[k] + t3[k];
+    T Ib[6];                                // rotational inertia about the origin: R I R^T + m(|c|^2 - c c^T)
+    {
+        T RI[9];
+        for (int i = 0; i < 3; ++i) {
+            const T* r = R + 3 * i;
+            RI[3 * i + 0] = r[0] * C.I[0] + r[1] * C.I[3] + r[2] * C.I[4];
+            RI[3 * i + 1] = r[0] * C.I[3] + r[1] * C.I[1] + r[2] * C.I[5];
+            RI[3 * i + 2] = r[0] * C.I[4] + r[1] * C.I[5] + r[2] * C.I[2];
+        }
+        T cc = dot(cw, cw);
+        Ib[0] = dot(RI + 0, R + 0) + C.mass * (cc - cw[0] * cw[0]);
+        Ib[1] = dot(RI + 3, R + 3) + C.mass * (cc - cw[1] * cw[1]);
+        Ib[2] = dot(RI + 6, R + 6) + C.mass * (cc - cw[2] * cw[2]);
+        Ib[3] = dot(RI + 0, R + 3) - C.mass * cw[0] * cw[1];
+        Ib[4] = dot(RI + 0, R + 6) - C.mass * cw[0] * cw[2];
+        Ib[5] = dot(RI + 3, R + 6) - C.mass * cw[1] * cw[2];
+    }
+    T hm[3] = {C.mass * cw[0], C.mass * cw[1], C.mass * cw[2]};     // first moment m c
+    T sw[3] = {a[0], a[1], a[2]}, sv[3];                             // motion axis S = (a, p x a)
+    cross(p, a, sv);
+
+    // 3. spatial velocity V_i = sum_{k<=i} S_k qd_k and velocity-product acceleration
+    T Vw[3], Vv[3];
+    for (int k = 0; k < 3; ++k) {
+        Vw[k] = psum(sw[k] * v, l8);
+        Vv[k] = psum(sv[k] * v, l8);
+    }
+    T Aw[3], Av[3];
+    {
+        T xw[3] = {sw[0] * v, sw[1] * v, sw[2] * v}, xv[3] = {sv[0] * v, sv[1] * v, sv[2] * v};
+        T dw[3], d1[3], d2[3];
+        cross(Vw, xw, dw);
+        cross(Vw, xv, d1);
+        cross(Vv, xw, d2);
+        for (int k = 0; k < 3; ++k) {
+            Aw[k] = psum(dw[k], l8);
+            Av[k] = psum(d1[k] + d2[k], l8) - Gc.grav[k];       // base acceleration -g
+        }
+    }
+    // body force  f = I A + V x* (I V),  I(w, v) = (Ib w + h x v, m v - h x w)
+    T bias;
+    {
+        T nV[3], fV[3], nA[3], fA[3], t1[3], t2[3];
+        symvec(Ib, Vw, nV);
+        cross(hm, Vv, t1);
+        cross(hm, Vw, t2);
+        for (int k = 0; k < 3; ++k) { nV[k] += t1[k]; fV[k] = C.mass * Vv[k] - t2[k]; }
+        symvec(Ib, Aw, nA);
+        cross(hm, Av, t1);
+        cross(hm, Aw, t2);
+        for (int k = 0; k < 3; ++k) { nA[k] += t1[k]; fA[k] = C.mass * Av[k] - t2[k]; }
+        T c1[3], c2[3], c3[3];
+        cross(Vw, nV, c1);
+        cross(Vv, fV, c2);
+        cross(Vw, fV, c3);
+        T fn[3], ff[3];
+        for (int k = 0; k < 3; ++k) {
+            fn[k] = ssum(nA[k] + c1[k] + c2[k], l8);
+            ff[k] = ssum(fA[k] + c3[k], l8);
+        }
+        bias = dot(sw, fn) + dot(sv, ff);
+    }
+
+    // 4. composite inertia (suffix sums) and the mass matrix by diagonals
+    T d[MAX_LINKS];
+    {
+        T mc = ssum(C.mass, l8), hc[3], Ic[6];
+        for (int k = 0; k < 3; ++k) hc[k] = ssum(hm[k], l8);
+        for (int k = 0; k < 6; ++k) Ic[k] = ssum(Ib[k], l8);
+        T Fn[3], Ff[3], t1[3], t2[3];
+        symvec(Ic, sw, Fn);
+        cross(hc, sv, t1);
+        cross(hc, sw, t2);
+        for (int k = 0; k < 3; ++k) { Fn[k] += t1[k]; Ff[k] = mc * sv[k] - t2[k]; }
+        mass_diagonals<0, T>(sw, sv, Fn, Ff, d);
+    }
+    // diagonal-major -> row-major through this particle's 8x8 LDS tile
+    T aM[MAX_LINKS];
+#pragma unroll
+    for (int sft = 0; sft < MAX_LINKS; ++sft) {
+        if (l8 + sft < MAX_LINKS) {
+            ldsM[l8 * LANES + l8 + sft] = d[sft];
+            ldsM[(l8 + sft) * LANES + l8] = d[sft];
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < MAX_LINKS; ++j) aM[j] = ldsM[l8 * LANES + j];
+    __syncthreads();
+    const T dgM = d[0] + C.armature;
+
+    // 5. smooth force: -bias + passive damping + motor
+    const T tau = -bias - C.damping * v + tau_act;
+
+    // 6. constraint rows.  Limits: MuJoCo mj_instantiateLimit, strict dist < margin(=0)
+    T sig = T(0), dist = T(0);
+    bool inst = false;
+    if (C.limited) {
+        T dlo = q - C.lo, dhi = C.hi - q;
+        if (dlo < T(0)) { sig = T(1); dist = dlo; inst = true; }
+        else if (dhi < T(0)) { sig = T(-1); dist = dhi; inst = true; }
+    }
+    T D, aref;
+    row_params(Gc, dist, C.invw, sig * v, D, aref);
+    D = inst ? D : T(0);
+    aref = inst ? aref : T(0);
+    // plane-sphere contact (condim 1): mjc_PlaneSphere + mj_instantiateContact
+    bool cinst = false;
+    T jc = T(0), Dc = T(0), arefc = T(0);
+    if (Gc.n_sphere > 0) {
+        T ctr[3], t[3];
+        matvec(R, Gc.sph_pos, t);
+        for (int k = 0; k < 3; ++k) ctr[k] = __shfl(p[k] + t[k], gbase + Gc.sph_link);
+        T cdist = dot(ctr, Gc.pn) - Gc.pd - Gc.sph_r;
+        cinst = cdist < Gc.sph_margin;
+        if (__any(cinst)) {
+            T r[3], ar[3];
+            for (int k = 0; k < 3; ++k) r[k] = ctr[k] - Gc.pn[k] * (Gc.sph_r + T(0.5) * cdist) - p[k];
+            cross(a, r, ar);
+            jc = (cinst && l8 <= Gc.sph_link) ? dot(Gc.pn, ar) : T(0);
+            T jv = gsum(jc * v);
+            row_params(Gc, cdist - Gc.sph_margin, Gc.sph_invw, jv, Dc, arefc);
+            Dc = cinst ? Dc : T(0);
+            arefc = cinst ? arefc : T(0);
+        }
+    }
+
+    // 7. primal active-set Newton on  1/2 a'Ma - tau'a + sum_active 1/2 D (J a - aref)^2
+    T qfrc_c = T(0);
+    const bool any_rows = __any(inst || cinst);
+    if (any_rows) {
+        bool act = inst && (sig * aw - aref < T(0));
+        bool cact = cinst && (gsum(jc * aw) - arefc < T(0));
+        bool changed = true;
+        for (int it = 0; it < NEWTON_MAXIT; ++it) {
+            T hd = dgM + (act ? D : T(0));
+            T rhs = tau + (act ? D * sig * aref : T(0));
+            T hr[MAX_LINKS];
+#pragma unroll
+            for (int j = 0; j < MAX_LINKS; ++j) hr[j] = aM[j];
+            if (__any(cact)) {
+                T wj = cact ? Dc * jc : T(0);
+                hd += wj * jc;
+                rhs += wj * arefc;
+                add_rank1<0, T>(hr, wj, jc);
+            }
+            aw = solve_spd(hd, hr, rhs, l8);
+            bool act2 = inst && (sig * aw - aref < T(0));
+            bool cact2 = cinst && (gsum(jc * aw) - arefc < T(0));
+            changed = (act2 != act) || (cact2 != cact);
+            act = act2;
+            cact = cact2;
+            if (!__any(changed)) break;
+        }
+        if (changed && diag) atomicAdd(diag, 1u);
+        // qfrc_constraint = J^T f,  f = -D (J a - aref) on active rows
+        qfrc_c = act ? -D * (sig * aw - aref) * sig : T(0);
+        if (__any(cact)) {
+            T fcn = cact ? -Dc * (gsum(jc * aw) - arefc) : T(0);
+            qfrc_c += jc * fcn;
+        }
+    }
+
+    // 8. mj_Euler with implicit joint damping:  (M + h B) qacc = qfrc_smooth + qfrc_constraint
+    {
+        T hr[MAX_LINKS];
+#pragma unroll
+        for (int j = 0; j < MAX_LINKS; ++j) hr[j] = aM[j];
+        T x = solve_spd(dgM + Gc.h * C.damping, hr, tau + qfrc_c, l8);
+        if (!any_rows) aw = x;
+        v += Gc.h * x;
+        q += Gc.h * v;
+    }
+}
+
+// ---- the rollout kernel -------------------------------------------------------------------------
+// state: f64 [qpos(8) | qvel(8) | target(3)]; mean: f64 [H][A]; noise/cost/act/obs/next_obs: T, in the
+// reference's C-order layouts (P,H,A) / (P,H) / (P,H,2nv+6).  noise, act, obs, next_obs, q0 may be null.
+template <typename T>
+__global__ __launch_bounds__(64) void arm_rollout_kernel(const T* __restrict__ model, const double* __restrict__ state,
+                                                         long P, int H, int A, const double* __restrict__ mean,
+                                                         const T* __restrict__ noise, T* __restrict__ cost,
+                                                         T* __restrict__ act, T* __restrict__ obs,
+                                                         T* __restrict__ nobs, unsigned* diag) {
+    __shared__ T lds[LANES * LANES * LANES];
+    const int lane = threadIdx.x;
+    const int l8 = lane & 7, g = lane >> 3;
+    const long pid = (long)blockIdx.x * LANES + g;
+    const bool live = pid < P;
+    for (int k = lane; k < LANES * LANES * LANES; k += 64) lds[k] = T(0);
+    __syncthreads();
+    T* ldsM = lds + g * LANES * LANES;
+
+    LaneConst<T> C;
+    ArmGlobals<T> Gc;
+    load_consts(model, l8, C, Gc);
+    const int nv = (int)model[O_NV];
+    const int dobs = 2 * nv + 6;
+
+    T q = (T)state[l8], v = (T)state[LANES + l8], aw = T(0);
+    const T tgt[3] = {(T)state[2 * LANES], (T)state[2 * LANES + 1], (T)state[2 * LANES + 2]};
+    if (l8 >= nv) { q = T(0); v = T(0); }
+    T cq = q, cv = v, chand[3] = {T(0), T(0), T(0)};
+    const bool has_u = l8 < A;
+
+    for (int t = 0; t < H; ++t) {
+        T u = T(0);
+        if (has_u) {
+            u = (T)mean[t * A + l8];
+            if (noise && live) u += noise[(pid * H + t) * A + l8];
+            if (act && live) act[(pid * H + t) * A + l8] = u;        // unclipped (gym_env_wrapper.py:151)
+        }
+        const T tau_act = C.gear * fmin(fmax(u, C.ulo), C.uhi);       // MuJoCo clamps ctrl, not the record
+        T site[3];
+        for (int sub = 0; sub < Gc.frame_skip; ++sub) {
+            arm_substep(C, Gc, q, v, aw, tau_act, ldsM, lane, l8, site, diag);
+            if (t == 0 && sub == 0) for (int k = 0; k < 3; ++k) chand[k] = site[k];   // fresh obs after set_env_state
+        }
+        // reward = -(|h-g|_1 + 5 |h-g|_2), h = site_xpos lagging one substep (reacher_env.py:31-35)
+        T dx = site[0] - tgt[0], dy = site[1] - tgt[1], dz = site[2] - tgt[2];
+        T cst = fabs(dx) + fabs(dy) + fabs(dz) + T(5) * sqrt_(dx * dx + dy * dy + dz * dz);
+        if (live && l8 == 0) cost[pid * H + t] = cst;
+        if (live && (obs || nobs)) {
+            const long o = (pid * H + t) * dobs;
+            if (obs) {
+                if (l8 < nv) { obs[o + l8] = cq; obs[o + nv + l8] = cv; }
+                if (l8 < 3) {
+                    T hh = l8 == 0 ? chand[0] : (l8 == 1 ? chand[1] : chand[2]);
+                    T gg = l8 == 0 ? tgt[0] : (l8 == 1 ? tgt[1] : tgt[2]);
+                    obs[o + 2 * nv + l8] = hh;
+                    obs[o + 2 * nv + 3 + l8] = hh - gg;
+                }
+            }
+            if (nobs) {
+                if (l8 < nv) { nobs[o + l8] = q; nobs[o + nv + l8] = v; }
+                if (l8 < 3) {
+                    T hh = l8 == 0 ? site[0] : (l8 == 1 ? site[1] : site[2]);
+                    T gg = l8 == 0 ? tgt[0] : (l8 == 1 ? tgt[1] : tgt[2]);
+                    nobs[o + 2 * nv + l8] = hh;
+                    nobs[o + 2 * nv + 3 + l8] = hh - gg;
+                }
+            }
+        }
+        cq = q;
+        cv = v;
+        for (int k = 0; k < 3; ++k) chand[k] = site[k];
+    }
+}
+
+}  // namespace
+
+template <typename T>
+hipError_t launch_arm_rollout(const T* model, const double* state, long P, int H, int A, const double* mean,
+                              const T* noise, T* cost, T* act, T* obs, T* nobs, unsigned* diag,
+                              hipStream_t stream) {
+    if (P <= 0 || H <= 0) return hipSuccess;
+    const unsigned grid = (unsigned)((P + LANES - 1) / LANES);
+    hipLaunchKernelGGL(arm_rollout_kernel<T>, dim3(grid), dim3(64), 0, stream, model, state, P, H, A, mean, noise,
+                       cost, act, obs, nobs, diag);
+    return hipGetLastError();
+}
+
+template hipError_t launch_arm_rollout<float>(const float*, const double*, long, int, int, const double*,
+                                              const float*, float*, float*, float*, float*, unsigned*, hipStream_t);
+template hipError_t launch_arm_rollout<double>(const double*, const double*, long, int, int, const double*,
+                                               const double*, double*, double*, double*, double*, unsigned*,
+                                               hipStream_t);
+
+}  // namespace mjmpc

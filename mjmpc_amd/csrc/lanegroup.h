@@ -1,0 +1,99 @@
+// Cross-lane primitives for 8-lane particle groups on CDNA4 (wave64).
+//
+// One particle = 8 consecutive lanes (lane l8 = link index), 8 particles per wavefront.  A DPP
+// "row" is 16 lanes = two particles, so every shift has to stop at the 8-lane group boundary:
+// shifts by 4 do it with the DPP bank mask alone (banks are 4 lanes), shifts by 1/2/3 with one
+// extra v_cndmask.  Broadcasts are a quad_perm plus one bank-masked row shift; the 8-lane sum
+// is row_half_mirror + two quad_perm butterflies.  No LDS traffic, no ds_bpermute.
+#pragma once
+#include <hip/hip_runtime.h>
+
+namespace mjmpc {
+
+template <int CTRL, int BANK>
+__device__ __forceinline__ float dpp(float old, float x) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(old), __float_as_int(x), CTRL, 0xF, BANK, false));
+}
+template <int CTRL, int BANK>
+__device__ __forceinline__ double dpp(double old, double x) {
+    int lo = __builtin_amdgcn_update_dpp(__double2loint(old), __double2loint(x), CTRL, 0xF, BANK, false);
+    int hi = __builtin_amdgcn_update_dpp(__double2hiint(old), __double2hiint(x), CTRL, 0xF, BANK, false);
+    return __hiloint2double(hi, lo);
+}
+
+// lane i <- x[i - S] inside the group, `fill` where i < S          (row_shr)
+template <int S, typename T>
+__device__ __forceinline__ T shr(T x, T fill, int l8) {
+    if constexpr (S == 4) {
+        return dpp<0x114, 0xA>(fill, x);            // banks 1,3 = lanes 4-7 / 12-15 of the row
+    } else {
+        T t = dpp<0x110 + S, 0xF>(fill, x);
+        return l8 >= S ? t : fill;
+    }
+}
+// lane i <- x[i + S] inside the group, `fill` where i + S > 7      (row_shl)
+template <int S, typename T>
+__device__ __forceinline__ T shl(T x, T fill, int l8) {
+    if constexpr (S == 4) {
+        return dpp<0x104, 0x5>(fill, x);            // banks 0,2 = lanes 0-3 / 8-11
+    } else {
+        T t = dpp<0x100 + S, 0xF>(fill, x);
+        return l8 + S < 8 ? t : fill;
+    }
+}
+// unmasked row_shl: lanes with i + S > 7 receive another particle's data - caller discards them
+template <int S, typename T>
+__device__ __forceinline__ T shl_raw(T x) {
+    return dpp<0x100 + S, 0xF>(x, x);
+}
+// every lane of the group <- x[K]
+template <int K, typename T>
+__device__ __forceinline__ T bcast(T x) {
+    constexpr int q = K & 3;
+    constexpr int QP = q | (q << 2) | (q << 4) | (q << 6);
+    T t = dpp<QP, 0xF>(x, x);                       // broadcast inside each quad
+    if constexpr (K < 4) return dpp<0x114, 0xA>(t, t);   // lanes 4-7 <- lanes 0-3
+    else return dpp<0x104, 0x5>(t, t);                   // lanes 0-3 <- lanes 4-7
+}
+// sum over the 8 lanes of the group, result in every lane
+template <typename T>
+__device__ __forceinline__ T gsum(T x) {
+    x += dpp<0x141, 0xF>(x, x);                     // row_half_mirror: i <-> 7 - i
+    x += dpp<0xB1, 0xF>(x, x);                      // quad_perm [1,0,3,2]
+    x += dpp<0x4E, 0xF>(x, x);                      // quad_perm [2,3,0,1]
+    return x;
+}
+// inclusive prefix / suffix sums over the group
+template <typename T>
+__device__ __forceinline__ T psum(T x, int l8) {
+    x += shr<1>(x, T(0), l8);
+    x += shr<2>(x, T(0), l8);
+    x += shr<4>(x, T(0), l8);
+    return x;
+}
+template <typename T>
+__device__ __forceinline__ T ssum(T x, int l8) {
+    x += shl<1>(x, T(0), l8);
+    x += shl<2>(x, T(0), l8);
+    x += shl<4>(x, T(0), l8);
+    return x;
+}
+
+// reciprocal: hardware seed + Newton steps (1 for f32, 2 for f64) - avoids the IEEE divide expansion
+__device__ __forceinline__ float rcp_(float x) {
+    float r = __builtin_amdgcn_rcpf(x);
+    return fmaf(fmaf(-x, r, 1.0f), r, r);
+}
+__device__ __forceinline__ double rcp_(double x) {
+    double r = __builtin_amdgcn_rcp(x);
+    r = fma(fma(-x, r, 1.0), r, r);
+    return fma(fma(-x, r, 1.0), r, r);
+}
+__device__ __forceinline__ void sincos_(float x, float& s, float& c) { sincosf(x, &s, &c); }
+__device__ __forceinline__ void sincos_(double x, double& s, double& c) { sincos(x, &s, &c); }
+__device__ __forceinline__ float sqrt_(float x) { return sqrtf(x); }
+__device__ __forceinline__ double sqrt_(double x) { return sqrt(x); }
+__device__ __forceinline__ float pow_(float x, float y) { return powf(x, y); }
+__device__ __forceinline__ double pow_(double x, double y) { return pow(x, y); }
+
+}  // namespace mjmpc

@@ -1,0 +1,180 @@
+"""GPU rollout engine for arm models - the drop-in for the reference's ``SubprocVecEnv``.
+
+The reference fans particles out to forked CPU workers that each run ``GymEnvWrapper.rollout``
+(mjmpc/envs/vec_env/subproc_vec_env.py:128-186, mjmpc/envs/gym_env_wrapper.py:89-156).  Here the
+whole particle set is one HIP kernel launch (mjmpc_amd/csrc/arm_rollout.hip) reached through the C
+ABI; this class keeps the reference's method names, argument meaning and return layout so that
+the closures of examples/example_mpc.py:112-155 work unchanged:
+
+    sim_env = ArmRolloutEngine(reacher7dof_raw())
+    controller.set_sim_state_fn = sim_env.set_env_state
+    controller.rollout_fn = make_rollout_fn(sim_env)
+
+torch is used only as the owner of device memory and streams.
+"""
+import ctypes
+import time
+
+import numpy as np
+
+from .. import _lib
+from ..models.compile import ArmModel, compile_arm
+from ..models.raw import RawModel
+
+_DT = {"f32": (_lib.F32, np.float32), "f64": (_lib.F64, np.float64)}
+
+
+def _torch():
+    import torch
+    return torch
+
+
+def _ptr(t):
+    return None if t is None else ctypes.c_void_p(t.data_ptr())
+
+
+class ArmRolloutEngine:
+    """One GPU's worth of particles for a compiled arm model (``reacher_7dof-v0``)."""
+
+    def __init__(self, model, device=0, dtype="f64", num_shards=1):
+        if isinstance(model, RawModel):
+            model = compile_arm(model)
+        if not isinstance(model, ArmModel):
+            raise TypeError("model must be a RawModel or a compiled ArmModel")
+        if dtype not in _DT:
+            raise ValueError("dtype must be 'f32' or 'f64'")
+        self.model = model
+        self.dtype = dtype
+        self._code, self._np = _DT[dtype]
+        self.num_shards = int(num_shards)       # reported like the reference's num_cpu (infos['total_time'])
+        self._lib = _lib.require_gpu()
+        torch = _torch()
+        self.device = torch.device("cuda", device)
+        self._tdtype = torch.float32 if dtype == "f32" else torch.float64
+        h = ctypes.c_void_p()
+        blob = np.ascontiguousarray(model.blob, np.float64)
+        _lib.check(self._lib.mjmpc_arm_create(blob.ctypes.data_as(_lib._dp), blob.size, device, ctypes.byref(h)))
+        self._h = h
+        self.d_action = model.nu
+        self.d_obs = model.d_obs
+        self.d_state = 3 * model.nv + 3 + 1     # qp, qv, qa, target_pos, timestep (reacher_env.py:81-85)
+        self.action_lows = model.ctrl_lo.copy()
+        self.action_highs = model.ctrl_hi.copy()
+        self.closed = False
+        self._buf = {}
+        self.set_env_state(dict(qp=np.zeros(model.nv), qv=np.zeros(model.nv), qa=np.zeros(model.nv),
+                                target_pos=model.target_default.copy(), timestep=0))
+
+    # ------------------------------------------------------------------ reference-shaped API
+    def set_env_state(self, state_dicts):
+        """``SubprocVecEnv.set_env_state`` (subproc_vec_env.py:235-251): one dict, or a list holding
+        one dict (every shard gets the same state).  Keys as reacher_env.py:81-85; ``qa`` and
+        ``timestep`` do not influence a rollout and are ignored."""
+        if isinstance(state_dicts, (list, tuple)):
+            if len(state_dicts) not in (1, self.num_shards):
+                raise AssertionError("num states should equal 1 (same for all envs) or 1 per env")
+            if any(not _same_state(state_dicts[0], s) for s in state_dicts[1:]):
+                raise NotImplementedError("per-shard start states are not supported yet")
+            state = state_dicts[0]
+        else:
+            state = state_dicts
+        qp = np.ascontiguousarray(state["qp"], np.float64).reshape(-1)
+        qv = np.ascontiguousarray(state["qv"], np.float64).reshape(-1)
+        tg = np.ascontiguousarray(state["target_pos"], np.float64).reshape(-1)
+        if qp.size != self.model.nv or qv.size != self.model.nv or tg.size != 3:
+            raise ValueError("state has the wrong dimensions for this model")
+        self._state = dict(qp=qp.copy(), qv=qv.copy(), target_pos=tg.copy())
+        _lib.check(self._lib.mjmpc_arm_set_state(self._h, qp.ctypes.data_as(_lib._dp), qv.ctypes.data_as(_lib._dp),
+                                                 tg.ctypes.data_as(_lib._dp), self._stream()))
+
+    def get_env_state(self):
+        return [dict(qp=self._state["qp"].copy(), qv=self._state["qv"].copy(),
+                     qa=np.zeros(self.model.nv), target_pos=self._state["target_pos"].copy(), timestep=0)]
+
+    def rollout(self, num_particles, horizon, mean, noise, mode="open_loop"):
+        """``SubprocVecEnv.rollout``: numpy in, numpy out, reference layouts.
+        Returns (obs, rew, act, done, info, next_obs); ``info`` is a list with one dict per shard."""
+        t0 = time.time()
+        out = self.rollout_device(num_particles, horizon, mean, noise, mode, want_obs=True)
+        costs, act, obs, nobs = (x.to("cpu").numpy().astype(np.float64, copy=False) for x in out)
+        done = np.zeros((num_particles, horizon))
+        dt = time.time() - t0
+        info = [{"total_time": dt} for _ in range(self.num_shards)]
+        return obs, -costs, act, done, info, nobs
+
+    def reset(self):
+        self.set_env_state(dict(qp=np.zeros(self.model.nv), qv=np.zeros(self.model.nv),
+                                target_pos=self.model.target_default.copy()))
+
+    def close(self):
+        if not self.closed:
+            self._lib.mjmpc_arm_destroy(self._h)
+            self.closed = True
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ------------------------------------------------------------------ device-resident API
+    def rollout_device(self, num_particles, horizon, mean, noise, mode="open_loop", want_obs=False,
+                       want_actions=True):
+        """Launch the fused rollout.  ``mean`` / ``noise`` may be numpy arrays or CUDA tensors.
+        Returns device tensors (costs, actions, obs, next_obs); buffers are reused between calls."""
+        if mode != "open_loop":
+            raise ValueError("unsupported rollout mode %r (only 'open_loop')" % (mode,))
+        if num_particles % self.num_shards != 0:
+            raise AssertionError("Number of particles must be divisible by number of shards")
+        torch = _torch()
+        P, H, A = int(num_particles), int(horizon), self.d_action
+        mean_d = self._as_device(mean, torch.float64, (H, A))
+        noise_d = None if noise is None else self._as_device(noise, self._tdtype, (P, H, A))
+        costs = self._buffer("costs", (P, H))
+        act = self._buffer("act", (P, H, A)) if want_actions else None
+        obs = self._buffer("obs", (P, H, self.d_obs)) if want_obs else None
+        nobs = self._buffer("nobs", (P, H, self.d_obs)) if want_obs else None
+        _lib.check(self._lib.mjmpc_arm_rollout(self._h, self._code, P, H, _ptr(mean_d), _ptr(noise_d), _ptr(costs),
+                                               _ptr(act), _ptr(obs), _ptr(nobs), self._stream()))
+        return costs, act, obs, nobs
+
+    def solver_failures(self):
+        c = ctypes.c_uint32()
+        _lib.check(self._lib.mjmpc_arm_solver_failures(self._h, ctypes.byref(c)))
+        return int(c.value)
+
+    # ------------------------------------------------------------------ helpers
+    def _stream(self):
+        return ctypes.c_void_p(_torch().cuda.current_stream(self.device).cuda_stream)
+
+    def _buffer(self, name, shape):
+        torch = _torch()
+        t = self._buf.get(name)
+        if t is None or tuple(t.shape) != tuple(shape):
+            t = torch.empty(shape, dtype=self._tdtype, device=self.device)
+            self._buf[name] = t
+        return t
+
+    def _as_device(self, x, tdtype, shape):
+        torch = _torch()
+        if not isinstance(x, torch.Tensor):
+            x = torch.from_numpy(np.ascontiguousarray(x))
+        if tuple(x.shape) != tuple(shape):
+            raise ValueError("expected shape %s, got %s" % (shape, tuple(x.shape)))
+        return x.to(device=self.device, dtype=tdtype).contiguous()
+
+
+def _same_state(a, b):
+    return all(np.array_equal(np.asarray(a[k]), np.asarray(b[k])) for k in ("qp", "qv", "target_pos"))
+
+
+def make_rollout_fn(sim_env):
+    """The ``rollout_fn`` closure of examples/example_mpc.py:112-133 over any engine with a
+    reference-shaped ``rollout``: negates rewards into costs and builds the trajectory dict."""
+    def rollout_fn(num_particles, horizon, mean, noise, mode):
+        obs, rew, act, done, info, nobs = sim_env.rollout(num_particles, horizon, np.array(mean, copy=True),
+                                                          noise, mode)
+        infos = {k: np.array([d[k] for d in info]) for k in info[0]}
+        return dict(observations=obs, actions=act, costs=-1.0 * rew, dones=done,
+                    next_observations=nobs, infos=infos)
+    return rollout_fn

@@ -164,6 +164,8 @@ def compile_arm(raw: RawModel) -> ArmModel:
         f["range_lo"][li], f["range_hi"][li] = jt.range
         f["limited"][li] = 1.0 if jt.limited else 0.0
 
+    f["armature"][nv:] = 1.0        # spare lanes: unit diagonal keeps the in-register LDL^T regular
+
     if len(raw.actuators) != nv:
         raise ValueError("arm kernel expects one motor per hinge")
     ctrl_lo, ctrl_hi = np.zeros(nv), np.zeros(nv)

@@ -1,0 +1,110 @@
+"""GPU parity: the HIP arm rollout (through the C ABI) against the FP64 C oracle on the same
+seeded inputs.  Tolerances:
+  f64 kernel vs oracle: costs rel <= 1e-9, observations abs <= 1e-9
+  f32 kernel vs oracle: measured, stated below (abs <= 2e-3 on costs, a damped 7-dof arm over
+  64 substeps with discontinuous limit activation)."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _noise(P, H, A, seed, scale=1.0):
+    rs = np.random.RandomState(seed)
+    eps = scale * rs.standard_normal((P, H, A))
+    for t in range(2, H):
+        eps[:, t] = 0.25 * eps[:, t] + 0.8 * eps[:, t - 1]
+    return eps
+
+
+@pytest.fixture(scope="module")
+def engines(raw_arm):
+    from mjmpc_amd.envs.arm_engine import ArmRolloutEngine
+    return {dt: ArmRolloutEngine(raw_arm, dtype=dt) for dt in ("f64", "f32")}
+
+
+STATES = [
+    dict(qp=np.zeros(7), qv=np.zeros(7), target_pos=np.array([0.1, 0.1, 0.1])),
+    dict(qp=np.array([0.3, 0.5, -0.2, -1.0, 0.4, -0.6, 0.2]), qv=np.array([0.5, -1.0, 0.3, 2.0, -0.5, 1.0, 0.1]),
+         target_pos=np.array([-0.25, 0.15, 0.2])),
+    # folded down onto the table: the wrist ball touches the plane during the rollout
+    dict(qp=np.array([0.0, 0.7, 0.0, -0.2, 0.0, -0.1, 0.0]), qv=np.array([0.0, 1.5, 0.0, 0.0, 0.0, 0.0, 0.0]),
+         target_pos=np.array([0.2, -0.1, -0.25])),
+]
+
+
+@pytest.mark.parametrize("si", range(len(STATES)))
+def test_f64_matches_oracle(engines, ref_arm, si):
+    eng = engines["f64"]
+    st = STATES[si]
+    P, H = 200, 32                     # P not a multiple of 8: ragged last wavefront
+    rs = np.random.RandomState(10 + si)
+    mean = 0.3 * rs.standard_normal((H, 7))
+    noise = _noise(P, H, 7, 20 + si)
+    eng.set_env_state(dict(st, qa=np.zeros(7), timestep=0))
+    obs, rew, act, done, info, nobs = eng.rollout(P, H, mean, noise, "open_loop")
+    o_obs, o_rew, o_act, o_done, o_nobs = ref_arm.rollout(st["qp"], st["qv"], st["target_pos"], mean, noise)
+    assert np.array_equal(act, o_act)
+    assert not done.any()
+    np.testing.assert_allclose(rew, o_rew, rtol=1e-9, atol=1e-9)
+    np.testing.assert_allclose(nobs, o_nobs, rtol=0, atol=1e-9)
+    np.testing.assert_allclose(obs, o_obs, rtol=0, atol=1e-9)
+    assert eng.solver_failures() == 0
+    assert len(info) == 1 and "total_time" in info[0]
+
+
+def test_contact_case_really_touches(ref_arm):
+    st = STATES[2]
+    mean = np.zeros((32, 7))
+    obs, rew, act, done, nobs = ref_arm.rollout(st["qp"], st["qv"], st["target_pos"], mean, None)
+    assert nobs[0, :, 16].min() - 0.08 < -0.425 + 0.002      # hand z - ball radius below table + margin
+
+
+def test_f32_within_stated_tolerance(engines, ref_arm):
+    eng = engines["f32"]
+    st = STATES[1]
+    P, H = 512, 32
+    mean = np.zeros((H, 7))
+    noise = _noise(P, H, 7, 5).astype(np.float32).astype(np.float64)   # identical inputs to both sides
+    eng.set_env_state(dict(st, qa=np.zeros(7), timestep=0))
+    obs, rew, act, done, info, nobs = eng.rollout(P, H, mean, noise, "open_loop")
+    o_obs, o_rew, o_act, o_done, o_nobs = ref_arm.rollout(st["qp"], st["qv"], st["target_pos"], mean, noise)
+    err = np.abs(rew - o_rew)
+    print("f32 cost error: max %.3e  mean %.3e" % (err.max(), err.mean()))
+    assert err.max() < 2e-3
+    assert np.abs(nobs - o_nobs).max() < 2e-2
+    assert eng.solver_failures() == 0
+
+
+def test_mean_only_and_tiny_shapes(engines, ref_arm):
+    eng = engines["f64"]
+    st = STATES[0]
+    eng.set_env_state(dict(st, qa=np.zeros(7), timestep=0))
+    mean = 0.5 * np.ones((3, 7))
+    obs, rew, act, done, info, nobs = eng.rollout(1, 3, mean, None, "open_loop")
+    o = ref_arm.rollout(st["qp"], st["qv"], st["target_pos"], mean, None)
+    np.testing.assert_allclose(rew, o[1], rtol=1e-9, atol=1e-9)
+    assert np.array_equal(act[0], mean)
+    with pytest.raises(ValueError):
+        eng.rollout(1, 3, mean, None, "closed_loop_linear")
+
+
+def test_full_size_properties(engines):
+    """BASELINE size (4096 x 32): size-independent properties instead of the (slow) oracle."""
+    eng = engines["f64"]
+    st = STATES[0]
+    eng.set_env_state(dict(st, qa=np.zeros(7), timestep=0))
+    P, H = 4096, 32
+    noise = _noise(P, H, 7, 99)
+    noise[P // 2:] = noise[:P // 2]                    # duplicated particles
+    obs, rew, act, done, info, nobs = eng.rollout(P, H, np.zeros((H, 7)), noise, "open_loop")
+    assert np.array_equal(rew[:P // 2], rew[P // 2:])   # determinism / particle independence
+    assert np.array_equal(obs[:, 1:], nobs[:, :-1])     # obs[t] == next_obs[t-1]
+    assert np.isfinite(rew).all() and (rew < 0).all()
+    d = nobs[..., 17:20]
+    np.testing.assert_allclose(-rew, np.abs(d).sum(-1) + 5 * np.sqrt((d ** 2).sum(-1)), rtol=1e-12)
+    lo = np.array([-2.2854, -0.5236, -1.5, -2.3213, -1.5, -1.094, -1.5]) - 0.2
+    hi = np.array([1.714602, 1.3963, 1.7, 0.0, 1.5, 0.0, 1.5]) + 0.2
+    q = nobs[..., :7]
+    assert (q > lo).all() and (q < hi).all()            # soft limits hold the joints near their range
+    assert eng.solver_failures() == 0
