@@ -82,6 +82,78 @@ int mjmpc_arm_rollout(mjmpc_arm_t h, int dtype, int64_t P, int H, const double* 
  * iteration cap since engine creation (synchronises the device).  0 in every test.               */
 int mjmpc_arm_solver_failures(mjmpc_arm_t h, uint32_t* count);
 
+/* ---- sampling-distribution updates: the device side of Controller._update_distribution --------
+ * All functions below are stateless; `d_ws` is a caller-owned device workspace of at least
+ * mjmpc_update_workspace_bytes(P, H, A) bytes that carries intermediate results between the
+ * calls of one update (per-particle costs, elite flags).  P is the number of particles ON THIS
+ * GPU.  "Records" are small float64 vectors designed to be all-gathered across GPUs (one
+ * collective per control iteration) and combined identically on every rank:
+ *   softmax record  [ xmax[Hw] | S[Hw] | W[H*A] | C[A*A] ]   Hw = time_based_weights ? H : 1
+ *   CEM sum record  [ n_elite_local | sum over local elites of actions[H*A] ]
+ *   CEM cov record  [ sum over local elites and t of (d - dbar)(d - dbar)^T  [A*A] ]
+ *   RS record       [ min q0 | global particle index | actions[H*A] of that particle ]
+ * d_gseq is Controller.gamma_seq (controller.py:71) as float64[H]; gamma_zero = any(gseq == 0)
+ * (control_utils.cost_to_go returns its input unchanged in that case, control_utils.py:41-42).   */
+int64_t mjmpc_update_workspace_bytes(int64_t P, int H, int A);
+int mjmpc_softmax_record_len(int H, int A, int time_based_weights);
+
+/* cost_to_go (mjmpc/utils/control_utils.py:37-46) of the local particles, [:,0] column, left in
+ * the workspace for the CEM / random-shooting calls; mjmpc_workspace_q0 returns its device address. */
+int mjmpc_traj_cost(int dtype, int64_t P, int H, int A, const void* d_costs, const double* d_gseq, int gamma_zero,
+                    void* d_ws, void* stream);
+double* mjmpc_workspace_q0(void* d_ws, int64_t P, int H, int A);
+
+/* MPPI._exp_util + _control_costs (mjmpc/control/mppi.py:84-111), DMDMPC._exp_util
+ * (gaussian_dmd.py:94-104), PFMPC._exp_util (particle_filter_controller.py:104-113): exponentiated
+ * cost weights reduced to this GPU's softmax record.  d_covinv (float64 [A][A]) is read only when
+ * alpha == 0 (control cost on); want_cov adds the weighted scatter C used by DMD-MPC.             */
+int mjmpc_softmax_stats(int dtype, int64_t P, int H, int A, const void* d_costs, const void* d_actions,
+                        const double* d_mean, const double* d_covinv, const double* d_gseq, int gamma_zero,
+                        double lam, int alpha, int time_based_weights, int want_cov, double* d_record, void* d_ws,
+                        void* stream);
+/* MPPI._update_distribution (mppi.py:69-82) / DMDMPC._update_distribution (gaussian_dmd.py:65-91)
+ * / _calc_val (mppi.py:113-131, gaussian_dmd.py:126-139) from G gathered records.
+ * cov_mode: 0 leave cov, 1 diagonal update, 2 full update.  d_cov, d_value, d_wnorm may be NULL;
+ * d_wnorm receives {global max, global normaliser} for mjmpc_softmax_weights.                     */
+int mjmpc_softmax_combine(const double* d_records, int G, int H, int A, int time_based_weights, double lam,
+                          double step_size, int cov_mode, double P_total, double* d_mean, double* d_cov,
+                          double* d_value, double* d_wnorm, void* stream);
+/* normalised per-particle weights (PFMPC resampling input), float64 [P] */
+int mjmpc_softmax_weights(int64_t P, int H, int A, const double* d_wnorm, void* d_ws, double* d_weights,
+                          void* stream);
+
+/* CEM._update_distribution (mjmpc/control/cem.py:63-86) in three steps.  Elite = the k particles
+ * with the smallest (q0, global index); d_q_all is the all-gathered q0 of every GPU (NULL = this
+ * GPU holds all particles) and `offset` the global index of local particle 0.                     */
+int mjmpc_cem_elite_sums(int dtype, int64_t P, int H, int A, const void* d_actions, const double* d_q_all,
+                         int64_t P_all, int64_t offset, int64_t k, double* d_sum_record, void* d_ws, void* stream);
+int mjmpc_cem_elite_cov(int dtype, int64_t P, int H, int A, const void* d_actions, const double* d_mean,
+                        const double* d_sum_records, int G, double* d_cov_record, void* d_ws, void* stream);
+int mjmpc_cem_final(const double* d_cov_records, int G, int64_t P, int H, int A, double n_elite, int full_cov,
+                    double step_size, double* d_mean, double* d_cov, void* d_ws, void* stream);
+
+/* RandomShooting._update_distribution (mjmpc/control/random_shooting.py:52-62). */
+int mjmpc_rs_best(int dtype, int64_t P, int H, int A, const void* d_actions, int64_t offset, double* d_record,
+                  void* d_ws, void* stream);
+int mjmpc_rs_combine(const double* d_records, int G, int H, int A, double step_size, double* d_mean, void* stream);
+
+/* sum of q0 over local particles (CEM / RandomShooting _calc_val: cem.py:107-112) -> d_out[0] */
+int mjmpc_q0_sum(int64_t P, int H, int A, double* d_out, void* d_ws, void* stream);
+
+/* OLGaussianMPC._shift (mjmpc/control/olgaussian_mpc.py:116-129).  mode 0 'null', 1 'repeat',
+ * 2 the appended row is read from d_row ('random': drawn by the host from np.random).            */
+int mjmpc_shift_mean(double* d_mean, int H, int A, int mode, const double* d_row, void* stream);
+
+/* control_utils.generate_noise (mjmpc/utils/control_utils.py:24-34), performance mode: Philox
+ * normals coloured by the lower Cholesky factor d_chol (float64 [A][A]) and filtered in place with
+ * d_coeffs (float64 [3]).  Same distribution as the reference, different bit stream; `offset`
+ * plays the role of num_steps in base_seed = seed_val + num_steps (olgaussian_mpc.py:91);
+ * `particle_offset` is the global index of local particle 0, so that a sharded run draws exactly
+ * the samples a single GPU would draw for the same particles.                                    */
+int mjmpc_sample_noise(int dtype, void* d_noise, int64_t P, int H, int A, const double* d_chol,
+                       const double* d_coeffs, uint64_t seed, uint64_t offset, int64_t particle_offset,
+                       void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,240 @@
+"""Device-side state and kernel calls shared by the controllers (torch = memory + streams only).
+
+``DeviceUpdater`` owns the float64 device copies of the sampling distribution (mean ``(H,A)``,
+cov ``(A,A)``), the discount sequence and the update workspace, and wraps the C-ABI update entry
+points of include/mjmpc_amd.h.  Multi-GPU: every rank holds a contiguous block of particles (the
+reference's worker mapping, subproc_vec_env.py:163-167); the small per-GPU *records* are exchanged
+with ONE all-gather per reduction through ``comm`` and combined identically on every rank.
+"""
+import ctypes
+
+import numpy as np
+
+from .. import _lib
+
+
+def _vp(t):
+    return None if t is None else ctypes.c_void_p(t.data_ptr())
+
+
+class SingleProcessComm:
+    """World of one: the all-gather is the identity."""
+    rank, world_size = 0, 1
+
+    def all_gather(self, t):
+        return t.reshape(1, -1)
+
+    def all_gather_flat(self, t):
+        return t
+
+
+class TorchDistComm:
+    """One process per GPU over torch.distributed (backend "nccl" = RCCL over xGMI; "gloo" in CPU tests)."""
+
+    def __init__(self, group=None):
+        import torch.distributed as dist
+        self._dist, self._group = dist, group
+        self.rank = dist.get_rank(group)
+        self.world_size = dist.get_world_size(group)
+
+    def all_gather(self, t):
+        import torch
+        out = torch.empty((self.world_size, t.numel()), dtype=t.dtype, device=t.device)
+        self._dist.all_gather_into_tensor(out, t.reshape(-1).contiguous(), group=self._group)
+        return out
+
+    def all_gather_flat(self, t):
+        return self.all_gather(t).reshape(-1)
+
+
+class DeviceUpdater:
+    def __init__(self, horizon, d_action, gamma_seq, device=0, comm=None):
+        import torch
+        self.lib = _lib.require_gpu()
+        self.torch = torch
+        self.device = torch.device("cuda", device)
+        self.H, self.A = int(horizon), int(d_action)
+        self.comm = comm or SingleProcessComm()
+        g = np.asarray(gamma_seq, np.float64).reshape(-1)
+        self.gamma_zero = int(bool(np.any(g == 0)))
+        self.gseq = torch.from_numpy(g.copy()).to(self.device)
+        self.mean = torch.zeros((self.H, self.A), dtype=torch.float64, device=self.device)
+        self.cov = torch.zeros((self.A, self.A), dtype=torch.float64, device=self.device)
+        self.covinv = torch.zeros((self.A, self.A), dtype=torch.float64, device=self.device)
+        self.value = torch.zeros(1, dtype=torch.float64, device=self.device)
+        self.wnorm = torch.zeros(2, dtype=torch.float64, device=self.device)
+        self._ws, self._ws_P = None, -1
+        self._rec = {}
+
+    # ------------------------------------------------------------------ plumbing
+    def stream(self):
+        return ctypes.c_void_p(self.torch.cuda.current_stream(self.device).cuda_stream)
+
+    def workspace(self, P):
+        if self._ws is None or self._ws_P < P:
+            nbytes = self.lib.mjmpc_update_workspace_bytes(P, self.H, self.A)
+            self._ws = self.torch.empty((nbytes + 7) // 8, dtype=self.torch.float64, device=self.device)
+            self._ws_P = P
+        return self._ws
+
+    def record(self, name, n):
+        t = self._rec.get(name)
+        if t is None or t.numel() != n:
+            t = self.torch.empty(n, dtype=self.torch.float64, device=self.device)
+            self._rec[name] = t
+        return t
+
+    def to_device(self, x, name):
+        """numpy or tensor -> contiguous CUDA tensor (f32 stays f32, everything else f64)."""
+        torch = self.torch
+        if not isinstance(x, torch.Tensor):
+            x = torch.from_numpy(np.ascontiguousarray(x))
+        if x.dtype not in (torch.float32, torch.float64):
+            x = x.to(torch.float64)
+        return x.to(self.device).contiguous()
+
+    @staticmethod
+    def code(t):
+        import torch
+        return _lib.F32 if t.dtype == torch.float32 else _lib.F64
+
+    def set_mean(self, mean):
+        self.mean.copy_(self.torch.from_numpy(np.ascontiguousarray(mean, np.float64)))
+
+    def set_cov(self, cov):
+        self.cov.copy_(self.torch.from_numpy(np.ascontiguousarray(cov, np.float64)))
+
+    def get_mean(self):
+        return self.mean.cpu().numpy()
+
+    def get_cov(self):
+        return self.cov.cpu().numpy()
+
+    def _pair(self, costs, actions):
+        costs = self.to_device(costs, "costs")
+        actions = self.to_device(actions, "actions")
+        if costs.dtype != actions.dtype:
+            costs = costs.to(actions.dtype)
+        P = costs.shape[0]
+        if tuple(costs.shape) != (P, self.H) or tuple(actions.shape) != (P, self.H, self.A):
+            raise ValueError("costs must be (P,H) and actions (P,H,A)")
+        return costs, actions, P
+
+    # ------------------------------------------------------------------ softmax family (MPPI / DMD / PFMPC)
+    def softmax_update(self, costs, actions, lam, step_size, alpha=1, time_based_weights=False, cov_mode=0,
+                       covinv=None, want_value=False, update_mean=True):
+        costs, actions, P = self._pair(costs, actions)
+        tbw = int(bool(time_based_weights))
+        n = self.lib.mjmpc_softmax_record_len(self.H, self.A, tbw)
+        rec = self.record("softmax", n)
+        if alpha == 0:
+            self.covinv.copy_(self.torch.from_numpy(np.ascontiguousarray(covinv, np.float64)))
+        ws = self.workspace(P)
+        _lib.check(self.lib.mjmpc_softmax_stats(self.code(costs), P, self.H, self.A, _vp(costs), _vp(actions),
+                                                _vp(self.mean), _vp(self.covinv), _vp(self.gseq), self.gamma_zero,
+                                                float(lam), int(alpha), tbw, int(cov_mode != 0), _vp(rec), _vp(ws),
+                                                self.stream()))
+        recs = self.comm.all_gather(rec)
+        G = recs.shape[0]
+        mean_out = self.mean if update_mean else self.record("mean_scratch", self.H * self.A).copy_(self.mean.reshape(-1))
+        _lib.check(self.lib.mjmpc_softmax_combine(_vp(recs), G, self.H, self.A, tbw, float(lam), float(step_size),
+                                                  int(cov_mode), float(P * G), _vp(mean_out),
+                                                  _vp(self.cov) if cov_mode else None,
+                                                  _vp(self.value) if want_value else None, _vp(self.wnorm),
+                                                  self.stream()))
+        return P
+
+    def zero_actions(self, P, like):
+        """(P,H,A) zeros of ``like``'s dtype on the device (weights-only calls need no actions)."""
+        key = ("zero_actions", like.dtype)
+        t = self._rec.get(key)
+        if t is None or t.shape[0] != P:
+            t = self.torch.zeros((P, self.H, self.A), dtype=like.dtype, device=self.device)
+            self._rec[key] = t
+        return t
+
+    def softmax_weights(self, P):
+        w = self.record("weights", P)
+        _lib.check(self.lib.mjmpc_softmax_weights(P, self.H, self.A, _vp(self.wnorm), _vp(self.workspace(P)), _vp(w),
+                                                  self.stream()))
+        return w
+
+    # ------------------------------------------------------------------ CEM
+    def cem_update(self, costs, actions, num_elite, step_size, full_cov):
+        costs, actions, P = self._pair(costs, actions)
+        ws = self.workspace(P)
+        code = self.code(costs)
+        G, rank = self.comm.world_size, self.comm.rank
+        _lib.check(self.lib.mjmpc_traj_cost(code, P, self.H, self.A, _vp(costs), _vp(self.gseq), self.gamma_zero,
+                                            _vp(ws), self.stream()))
+        q_all_ptr, P_all = None, P
+        if G > 1:
+            q0 = self._q0_view(ws, P)
+            q_all = self.comm.all_gather_flat(q0)
+            q_all_ptr, P_all = _vp(q_all), P * G
+        srec = self.record("cem_sum", 1 + self.H * self.A)
+        _lib.check(self.lib.mjmpc_cem_elite_sums(code, P, self.H, self.A, _vp(actions), q_all_ptr, P_all, rank * P,
+                                                 int(num_elite), _vp(srec), _vp(ws), self.stream()))
+        srecs = self.comm.all_gather(srec)
+        crec = self.record("cem_cov", self.A * self.A)
+        _lib.check(self.lib.mjmpc_cem_elite_cov(code, P, self.H, self.A, _vp(actions), _vp(self.mean), _vp(srecs), G,
+                                                _vp(crec), _vp(ws), self.stream()))
+        crecs = self.comm.all_gather(crec)
+        _lib.check(self.lib.mjmpc_cem_final(_vp(crecs), G, P, self.H, self.A, float(num_elite), int(full_cov),
+                                            float(step_size), _vp(self.mean), _vp(self.cov), _vp(ws), self.stream()))
+
+    def _q0_view(self, ws, P):
+        addr = self.lib.mjmpc_workspace_q0(_vp(ws), P, self.H, self.A)
+        off = (addr - ws.data_ptr()) // 8
+        return ws[off:off + P]
+
+    # ------------------------------------------------------------------ random shooting
+    def rs_update(self, costs, actions, step_size):
+        costs, actions, P = self._pair(costs, actions)
+        ws = self.workspace(P)
+        code = self.code(costs)
+        _lib.check(self.lib.mjmpc_traj_cost(code, P, self.H, self.A, _vp(costs), _vp(self.gseq), self.gamma_zero,
+                                            _vp(ws), self.stream()))
+        rec = self.record("rs", 2 + self.H * self.A)
+        _lib.check(self.lib.mjmpc_rs_best(code, P, self.H, self.A, _vp(actions), self.comm.rank * P, _vp(rec), _vp(ws),
+                                          self.stream()))
+        recs = self.comm.all_gather(rec)
+        _lib.check(self.lib.mjmpc_rs_combine(_vp(recs), recs.shape[0], self.H, self.A, float(step_size),
+                                             _vp(self.mean), self.stream()))
+
+    def mean_q0(self, costs):
+        """CEM / RandomShooting _calc_val: average cost-to-go over ALL particles."""
+        costs = self.to_device(costs, "costs")
+        P = costs.shape[0]
+        ws = self.workspace(P)
+        _lib.check(self.lib.mjmpc_traj_cost(self.code(costs), P, self.H, self.A, _vp(costs), _vp(self.gseq),
+                                            self.gamma_zero, _vp(ws), self.stream()))
+        s = self.record("q0sum", 1)
+        _lib.check(self.lib.mjmpc_q0_sum(P, self.H, self.A, _vp(s), _vp(ws), self.stream()))
+        tot = self.comm.all_gather(s)
+        return float(tot.sum().item()) / (P * tot.shape[0])
+
+    # ------------------------------------------------------------------ shift / noise
+    def shift(self, mode, row=None):
+        row_d = None
+        if mode == 2:
+            row_d = self.record("shift_row", self.A)
+            row_d.copy_(self.torch.from_numpy(np.ascontiguousarray(row, np.float64)))
+        _lib.check(self.lib.mjmpc_shift_mean(_vp(self.mean), self.H, self.A, int(mode), _vp(row_d), self.stream()))
+
+    def sample_noise(self, P, cov, filter_coeffs, seed, offset, dtype="f64", particle_offset=0):
+        torch = self.torch
+        tdt = torch.float32 if dtype == "f32" else torch.float64
+        key = ("noise", dtype)
+        buf = self._rec.get(key)
+        if buf is None or tuple(buf.shape) != (P, self.H, self.A):
+            buf = torch.empty((P, self.H, self.A), dtype=tdt, device=self.device)
+            self._rec[key] = buf
+        chol = self.record("chol", self.A * self.A)
+        chol.copy_(torch.from_numpy(np.linalg.cholesky(np.asarray(cov, np.float64)).reshape(-1).copy()))
+        co = self.record("coeffs", 3)
+        co.copy_(torch.from_numpy(np.asarray(filter_coeffs, np.float64).copy()))
+        _lib.check(self.lib.mjmpc_sample_noise(_lib.F32 if dtype == "f32" else _lib.F64, _vp(buf), P, self.H, self.A,
+                                               _vp(chol), _vp(co), int(seed) & (2 ** 64 - 1), int(offset),
+                                               int(particle_offset), self.stream()))
+        return buf

@@ -1,0 +1,240 @@
+"""Controller base classes with the reference's public surface.
+
+``Controller`` keeps mjmpc/control/controller.py's contract: settable ``rollout_fn`` /
+``set_sim_state_fn`` plug points (:152-175) and ``optimize(state, calc_val, hotstart) -> (action,
+value)`` (:207-257).  ``OLGaussianMPC`` keeps mjmpc/control/olgaussian_mpc.py's: a mean ``(H,A)`` and
+a covariance ``(A,A)``, ``sample_noise`` (:88-93), ``generate_rollouts`` (:95-114), ``_shift``
+(:116-129), ``reset`` (:131-135).
+
+What is new: the distribution lives on the GPU (``DeviceUpdater``) and ``_update_distribution`` runs
+HIP reductions; ``mean_action`` / ``cov_action`` are host mirrors refreshed after every update, so
+code that reads them keeps working.  ``rollout_fn`` may return numpy arrays (any user callback, as
+in the reference) or CUDA tensors (``make_device_rollout_fn``: nothing leaves the GPU).
+
+Extra constructor keywords (all optional, defaults reproduce the reference bit for bit):
+  noise_mode  'host'   legacy numpy stream, identical seeds -> identical noise (parity mode)
+              'device' Philox sampler on the GPU (same distribution, not the same bits)
+  noise_dtype 'f64' | 'f32'  storage type of device-sampled noise
+  device      CUDA device ordinal;  comm  particle-sharding communicator (see _device.py)
+"""
+import copy
+from abc import ABC, abstractmethod
+
+import numpy as np
+
+from ._device import DeviceUpdater
+from .control_utils import generate_noise
+
+
+def _seed_value(seed):
+    """gym.utils.seeding.np_random(seed) semantics: the given seed is the seed value."""
+    if seed is None:
+        seed = int(np.random.SeedSequence().generate_state(1)[0])
+    if not isinstance(seed, (int, np.integer)) or seed < 0:
+        raise ValueError("Seed must be a non-negative integer or omitted, not {}".format(seed))
+    return int(seed)
+
+
+class Controller(ABC):
+    def __init__(self, d_state, d_obs, d_action, action_lows, action_highs, horizon, gamma, n_iters,
+                 set_sim_state_fn=None, rollout_fn=None, sample_mode='mean', batch_size=1, seed=0,
+                 device=0, comm=None):
+        self.d_state = d_state
+        self.d_obs = d_obs
+        self.d_action = d_action
+        self.action_lows = action_lows
+        self.action_highs = action_highs
+        self.horizon = horizon
+        self.gamma = gamma
+        self.gamma_seq = np.cumprod([1.0] + [self.gamma] * (horizon - 1)).reshape(1, horizon)
+        self.n_iters = n_iters
+        self._set_sim_state_fn = set_sim_state_fn
+        self._rollout_fn = rollout_fn
+        self.sample_mode = sample_mode
+        self.batch_size = batch_size
+        self.num_steps = 0
+        self.seed_val = self.seed(seed)
+        self.dev = DeviceUpdater(horizon, d_action, self.gamma_seq, device=device, comm=comm)
+
+    # -- plug points (controller.py:152-175) ------------------------------------------------
+    @property
+    def set_sim_state_fn(self):
+        return self._set_sim_state_fn
+
+    @set_sim_state_fn.setter
+    def set_sim_state_fn(self, fn):
+        self._set_sim_state_fn = fn
+
+    @property
+    def rollout_fn(self):
+        return self._rollout_fn
+
+    @rollout_fn.setter
+    def rollout_fn(self, fn):
+        self._rollout_fn = fn
+
+    # -- hooks ------------------------------------------------------------------------------
+    @abstractmethod
+    def _get_next_action(self, state, mode='mean'):
+        pass
+
+    @abstractmethod
+    def _update_distribution(self, trajectories):
+        pass
+
+    @abstractmethod
+    def _shift(self):
+        pass
+
+    @abstractmethod
+    def reset(self):
+        pass
+
+    @abstractmethod
+    def _calc_val(self, trajectories):
+        pass
+
+    @abstractmethod
+    def generate_rollouts(self, state):
+        pass
+
+    def sample_actions(self):
+        raise NotImplementedError('sample_actions funtion not implemented')
+
+    def check_convergence(self):
+        return False
+
+    # -- the MPC iteration (controller.py:207-257) ---------------------------------------------
+    def optimize(self, state, calc_val=False, hotstart=True):
+        for _ in range(self.n_iters):
+            trajectory = self.generate_rollouts(copy.deepcopy(state))
+            self._update_distribution(trajectory)
+            if self.check_convergence():
+                break
+        curr_action = self._get_next_action(state, mode=self.sample_mode)
+        value = 0.0
+        if calc_val:
+            trajectories = self.generate_rollouts(copy.deepcopy(state))
+            value = self._calc_val(trajectories)
+        self.num_steps += 1
+        if hotstart:
+            self._shift()
+        return curr_action, value
+
+    def get_optimal_value(self, state):
+        self.reset()
+        _, value = self.optimize(state, calc_val=True, hotstart=False)
+        return value
+
+    def seed(self, seed=None):
+        seed = _seed_value(seed)
+        self.np_random = np.random.RandomState(seed)
+        return seed
+
+
+_SHIFT_MODES = {'null': 0, 'repeat': 1, 'random': 2}
+
+
+class OLGaussianMPC(Controller):
+    """Open-loop Gaussian MPC: N(mean_action[t], cov_action) per horizon step."""
+
+    def __init__(self, d_state, d_obs, d_action, action_lows, action_highs, horizon, init_cov, init_mean,
+                 base_action, num_particles, gamma, n_iters, step_size, filter_coeffs, set_sim_state_fn=None,
+                 rollout_fn=None, cov_type='diagonal', sample_mode='mean', batch_size=1, seed=0,
+                 use_zero_control_seq=False, noise_mode='host', noise_dtype='f64', device=0, comm=None):
+        super().__init__(d_state, d_obs, d_action, action_lows, action_highs, horizon, gamma, n_iters,
+                         set_sim_state_fn, rollout_fn, sample_mode, batch_size, seed, device=device, comm=comm)
+        if noise_mode not in ('host', 'device'):
+            raise ValueError("noise_mode must be 'host' or 'device'")
+        self.init_cov = np.array([init_cov] * self.d_action)
+        self.init_mean = init_mean.copy()
+        self.mean_action = init_mean
+        self.base_action = base_action
+        self.num_particles = num_particles
+        self.cov_type = cov_type
+        self.cov_action = np.diag(self.init_cov)
+        self.step_size = step_size
+        self.filter_coeffs = filter_coeffs
+        self.use_zero_control_seq = use_zero_control_seq
+        self.noise_mode = noise_mode
+        self.noise_dtype = noise_dtype
+        self._push()
+
+    # -- host <-> device mirrors ---------------------------------------------------------------
+    def _push(self):
+        self.dev.set_mean(self.mean_action)
+        self.dev.set_cov(self.cov_action)
+        self._mean_seen = np.array(self.mean_action, copy=True)
+        self._cov_seen = np.array(self.cov_action, copy=True)
+
+    def _pull(self, cov=False):
+        self.mean_action = self.dev.get_mean()
+        self._mean_seen = self.mean_action.copy()
+        if cov:
+            self.cov_action = self.dev.get_cov()
+            self._cov_seen = self.cov_action.copy()
+
+    def _sync_in(self):
+        """The host arrays are the public truth (users assign ``mean_action`` directly, as the
+        reference allows): re-upload them if they were changed behind the device copy's back."""
+        if not (np.array_equal(self.mean_action, self._mean_seen) and np.array_equal(self.cov_action, self._cov_seen)):
+            self._push()
+
+    @property
+    def local_particles(self):
+        ws = self.dev.comm.world_size
+        assert self.num_particles % ws == 0, "Number of particles must be divisible by number of shards"
+        return self.num_particles // ws
+
+    # -- sampling (olgaussian_mpc.py:69-93) ------------------------------------------------------
+    def _get_next_action(self, state, mode='mean'):
+        if mode == 'mean':
+            return self.mean_action[0].copy()
+        if mode == 'sample':
+            delta = generate_noise(self.cov_action, self.filter_coeffs, shape=(1, 1),
+                                   base_seed=self.seed_val + 123 * self.num_steps)
+            return self.mean_action[0].copy() + delta.reshape(self.d_action).copy()
+        raise ValueError('Unidentified sampling mode in get_next_action')
+
+    def sample_noise(self):
+        """(P_local, H, A) perturbations.  'host': the reference's stream, sliced to this rank's
+        contiguous particle block; 'device': Philox, keyed by the GLOBAL particle index."""
+        n_loc, rank = self.local_particles, self.dev.comm.rank
+        if self.noise_mode == 'host':
+            delta = generate_noise(self.cov_action, self.filter_coeffs, shape=(self.num_particles, self.horizon),
+                                   base_seed=self.seed_val + self.num_steps)
+            return delta[rank * n_loc:(rank + 1) * n_loc] if self.dev.comm.world_size > 1 else delta
+        return self.dev.sample_noise(n_loc, self.cov_action, self.filter_coeffs, self.seed_val, self.num_steps,
+                                     dtype=self.noise_dtype, particle_offset=rank * n_loc)
+
+    def generate_rollouts(self, state):
+        self._sync_in()
+        self._set_sim_state_fn(copy.deepcopy(state))
+        delta = self.sample_noise()
+        if self.use_zero_control_seq and self.dev.comm.rank == self.dev.comm.world_size - 1:
+            if isinstance(delta, np.ndarray):
+                delta[-1, :] = -1.0 * self.mean_action.copy()
+            else:
+                delta[-1] = (-self.dev.mean).to(delta.dtype)
+        return self._rollout_fn(self.local_particles, self.horizon, self.mean_action, delta, mode="open_loop")
+
+    # -- shift / reset (olgaussian_mpc.py:116-135) -------------------------------------------------
+    def _shift(self):
+        if self.base_action not in _SHIFT_MODES:
+            raise NotImplementedError("invalid option for base action during shift")
+        self._sync_in()
+        row = None
+        if self.base_action == 'random':
+            row = np.random.normal(0, self.init_cov, self.d_action)
+        self.dev.shift(_SHIFT_MODES[self.base_action], row)
+        self._pull()
+
+    def reset(self):
+        self.num_steps = 0
+        self.mean_action = np.zeros(shape=(self.horizon, self.d_action))
+        self.cov_action = np.diag(self.init_cov)
+        self.gamma_seq = np.cumprod([1.0] + [self.gamma] * (self.horizon - 1)).reshape(1, self.horizon)
+        self._push()
+
+    def _calc_val(self, trajectories):
+        raise NotImplementedError("_calc_val not implemented")

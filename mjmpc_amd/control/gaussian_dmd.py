@@ -1,0 +1,49 @@
+"""DMD-MPC (Gaussian, exponential utility, optional covariance adaptation) on the GPU
+(reference mjmpc/control/gaussian_dmd.py)."""
+import numpy as np
+
+from .controller import OLGaussianMPC
+
+
+class DMDMPC(OLGaussianMPC):
+    def __init__(self, d_state, d_obs, d_action, horizon, init_cov, beta, base_action, lam, num_particles,
+                 step_size, gamma, n_iters, action_lows, action_highs, set_sim_state_fn=None, rollout_fn=None,
+                 update_cov=False, cov_type='diagonal', sample_mode='mean', batch_size=1,
+                 filter_coeffs=[1., 0., 0.], seed=0, **device_kw):
+        super().__init__(d_state, d_obs, d_action, action_lows, action_highs, horizon, init_cov,
+                         np.zeros(shape=(horizon, d_action)), base_action, num_particles, gamma, n_iters, step_size,
+                         filter_coeffs, set_sim_state_fn, rollout_fn, cov_type, sample_mode, batch_size, seed,
+                         **device_kw)
+        self.lam = lam
+        self.beta = beta
+        self.update_cov = update_cov
+
+    def _update_distribution(self, trajectories):
+        """gaussian_dmd.py:65-104: softmax weights; weighted mean; if update_cov the weighted scatter,
+        diagonal = mean_t sum_p w delta^2, full = (sum_{p,t} w delta delta^T) / H."""
+        self._sync_in()
+        cov_mode = 0
+        if self.update_cov:
+            if self.cov_type == 'diagonal':
+                cov_mode = 1
+            elif self.cov_type == 'full':
+                cov_mode = 2
+            else:
+                raise ValueError('Unidentified covariance type in update_distribution')
+        self.dev.softmax_update(trajectories["costs"], trajectories["actions"], self.lam, self.step_size,
+                                cov_mode=cov_mode)
+        self._pull(cov=bool(cov_mode))
+
+    def _shift(self):
+        """gaussian_dmd.py:106-113: shift the mean; grow the covariance by beta * I when it adapts."""
+        super()._shift()
+        if self.update_cov:
+            self.cov_action = self.cov_action + self.beta * np.eye(self.d_action)
+            self._push()
+
+    def _calc_val(self, trajectories):
+        """gaussian_dmd.py:126-139."""
+        self._sync_in()
+        self.dev.softmax_update(trajectories["costs"], trajectories["actions"], self.lam, 0.0, want_value=True,
+                                update_mean=False)
+        return float(self.dev.value.item())

@@ -9,6 +9,7 @@
 #include "../../include/mjmpc_amd.h"
 #include "arm_model.h"
 #include "arm_rollout.h"
+#include "update.h"
 
 namespace {
 
@@ -148,6 +149,140 @@ int mjmpc_arm_solver_failures(mjmpc_arm_t h, uint32_t* count) {
     HIP_TRY(hipMemcpy(&c, h->diag, sizeof(unsigned), hipMemcpyDeviceToHost));
     *count = c;
     return 0;
+}
+
+// ---- update / noise entry points -------------------------------------------------------------------
+#define DISPATCH(dtype, CALL_F32, CALL_F64)                                   \
+    do {                                                                      \
+        hipError_t e_;                                                        \
+        if ((dtype) == MJMPC_F32) e_ = (CALL_F32);                            \
+        else if ((dtype) == MJMPC_F64) e_ = (CALL_F64);                       \
+        else return fail(MJMPC_E_BADARG, "unknown dtype %d", (int)(dtype));   \
+        if (e_ != hipSuccess) return hip_fail(e_, __func__);                  \
+        return 0;                                                             \
+    } while (0)
+#define PLAIN(CALL)                                           \
+    do {                                                      \
+        hipError_t e_ = (CALL);                               \
+        if (e_ != hipSuccess) return hip_fail(e_, __func__);  \
+        return 0;                                             \
+    } while (0)
+
+int64_t mjmpc_update_workspace_bytes(int64_t P, int H, int A) {
+    return (int64_t)sizeof(double) * mjmpc::update_workspace_doubles((long)P, H, A);
+}
+
+int mjmpc_softmax_record_len(int H, int A, int tbw) { return 2 * (tbw ? H : 1) + H * A + A * A; }
+
+int mjmpc_traj_cost(int dtype, int64_t P, int H, int A, const void* d_costs, const double* d_gseq, int gamma_zero,
+                    void* d_ws, void* stream) {
+    if (!d_costs || !d_gseq || !d_ws) return fail(MJMPC_E_BADARG, "null argument");
+    hipStream_t s = (hipStream_t)stream;
+    DISPATCH(dtype,
+             mjmpc::traj_cost<float>((const float*)d_costs, nullptr, nullptr, nullptr, d_gseq, gamma_zero, 1.0, 1, 0,
+                                     (long)P, H, A, (double*)d_ws, s),
+             mjmpc::traj_cost<double>((const double*)d_costs, nullptr, nullptr, nullptr, d_gseq, gamma_zero, 1.0, 1, 0,
+                                      (long)P, H, A, (double*)d_ws, s));
+}
+
+double* mjmpc_workspace_q0(void* d_ws, int64_t P, int H, int A) {
+    return mjmpc::workspace_q0((double*)d_ws, (long)P, H, A);
+}
+
+int mjmpc_softmax_stats(int dtype, int64_t P, int H, int A, const void* d_costs, const void* d_actions,
+                        const double* d_mean, const double* d_covinv, const double* d_gseq, int gamma_zero,
+                        double lam, int alpha, int tbw, int want_cov, double* d_record, void* d_ws, void* stream) {
+    if (!d_costs || !d_actions || !d_mean || !d_gseq || !d_record || !d_ws) return fail(MJMPC_E_BADARG, "null argument");
+    if (alpha == 0 && !d_covinv) return fail(MJMPC_E_BADARG, "alpha == 0 needs d_covinv");
+    if (tbw && want_cov) return fail(MJMPC_E_BADARG, "time_based_weights and want_cov are exclusive");
+    if (!(lam > 0)) return fail(MJMPC_E_BADARG, "lam must be positive");
+    hipStream_t s = (hipStream_t)stream;
+    DISPATCH(dtype,
+             mjmpc::softmax_stats<float>((const float*)d_costs, (const float*)d_actions, d_mean, d_covinv, d_gseq,
+                                         gamma_zero, lam, alpha, tbw, want_cov, (long)P, H, A, d_record,
+                                         (double*)d_ws, s),
+             mjmpc::softmax_stats<double>((const double*)d_costs, (const double*)d_actions, d_mean, d_covinv, d_gseq,
+                                          gamma_zero, lam, alpha, tbw, want_cov, (long)P, H, A, d_record,
+                                          (double*)d_ws, s));
+}
+
+int mjmpc_softmax_combine(const double* d_records, int G, int H, int A, int tbw, double lam, double step_size,
+                          int cov_mode, double P_total, double* d_mean, double* d_cov, double* d_value,
+                          double* d_wnorm, void* stream) {
+    if (!d_records || !d_mean || G < 1) return fail(MJMPC_E_BADARG, "bad argument");
+    if (cov_mode && !d_cov) return fail(MJMPC_E_BADARG, "cov_mode needs d_cov");
+    PLAIN(mjmpc::softmax_combine(d_records, G, H, A, tbw, lam, step_size, cov_mode, P_total, d_mean, d_cov, d_value,
+                                 d_wnorm, (hipStream_t)stream));
+}
+
+int mjmpc_softmax_weights(int64_t P, int H, int A, const double* d_wnorm, void* d_ws, double* d_weights,
+                          void* stream) {
+    if (!d_wnorm || !d_ws || !d_weights) return fail(MJMPC_E_BADARG, "null argument");
+    PLAIN(mjmpc::softmax_weights((long)P, d_wnorm, (double*)d_ws, H, A, d_weights, (hipStream_t)stream));
+}
+
+int mjmpc_cem_elite_sums(int dtype, int64_t P, int H, int A, const void* d_actions, const double* d_q_all,
+                         int64_t P_all, int64_t offset, int64_t k, double* d_sum_record, void* d_ws, void* stream) {
+    if (!d_actions || !d_sum_record || !d_ws) return fail(MJMPC_E_BADARG, "null argument");
+    hipStream_t s = (hipStream_t)stream;
+    DISPATCH(dtype,
+             mjmpc::cem_elite_sums<float>((const float*)d_actions, d_q_all, (long)P_all, (long)offset, (long)k, (long)P,
+                                          H, A, d_sum_record, (double*)d_ws, s),
+             mjmpc::cem_elite_sums<double>((const double*)d_actions, d_q_all, (long)P_all, (long)offset, (long)k,
+                                           (long)P, H, A, d_sum_record, (double*)d_ws, s));
+}
+
+int mjmpc_cem_elite_cov(int dtype, int64_t P, int H, int A, const void* d_actions, const double* d_mean,
+                        const double* d_sum_records, int G, double* d_cov_record, void* d_ws, void* stream) {
+    if (!d_actions || !d_mean || !d_sum_records || !d_cov_record || !d_ws) return fail(MJMPC_E_BADARG, "null argument");
+    hipStream_t s = (hipStream_t)stream;
+    DISPATCH(dtype,
+             mjmpc::cem_elite_cov<float>((const float*)d_actions, d_mean, d_sum_records, G, (long)P, H, A, d_cov_record,
+                                         (double*)d_ws, s),
+             mjmpc::cem_elite_cov<double>((const double*)d_actions, d_mean, d_sum_records, G, (long)P, H, A,
+                                          d_cov_record, (double*)d_ws, s));
+}
+
+int mjmpc_cem_final(const double* d_cov_records, int G, int64_t P, int H, int A, double n_elite, int full_cov,
+                    double step_size, double* d_mean, double* d_cov, void* d_ws, void* stream) {
+    if (!d_cov_records || !d_mean || !d_cov || !d_ws) return fail(MJMPC_E_BADARG, "null argument");
+    PLAIN(mjmpc::cem_final(d_cov_records, G, (long)P, H, A, n_elite, full_cov, step_size, d_mean, d_cov,
+                           (double*)d_ws, (hipStream_t)stream));
+}
+
+int mjmpc_rs_best(int dtype, int64_t P, int H, int A, const void* d_actions, int64_t offset, double* d_record,
+                  void* d_ws, void* stream) {
+    if (!d_actions || !d_record || !d_ws) return fail(MJMPC_E_BADARG, "null argument");
+    hipStream_t s = (hipStream_t)stream;
+    DISPATCH(dtype,
+             mjmpc::rs_best<float>((const float*)d_actions, (long)offset, (long)P, H, A, d_record, (double*)d_ws, s),
+             mjmpc::rs_best<double>((const double*)d_actions, (long)offset, (long)P, H, A, d_record, (double*)d_ws, s));
+}
+
+int mjmpc_rs_combine(const double* d_records, int G, int H, int A, double step_size, double* d_mean, void* stream) {
+    if (!d_records || !d_mean || G < 1) return fail(MJMPC_E_BADARG, "bad argument");
+    PLAIN(mjmpc::rs_combine(d_records, G, H, A, step_size, d_mean, (hipStream_t)stream));
+}
+
+int mjmpc_q0_sum(int64_t P, int H, int A, double* d_out, void* d_ws, void* stream) {
+    if (!d_out || !d_ws) return fail(MJMPC_E_BADARG, "null argument");
+    PLAIN(mjmpc::q0_sum((long)P, H, A, d_out, (double*)d_ws, (hipStream_t)stream));
+}
+
+int mjmpc_shift_mean(double* d_mean, int H, int A, int mode, const double* d_row, void* stream) {
+    if (!d_mean || (mode == 2 && !d_row) || mode < 0 || mode > 2) return fail(MJMPC_E_BADARG, "bad argument");
+    PLAIN(mjmpc::shift_mean(d_mean, H, A, mode, d_row, (hipStream_t)stream));
+}
+
+int mjmpc_sample_noise(int dtype, void* d_noise, int64_t P, int H, int A, const double* d_chol,
+                       const double* d_coeffs, uint64_t seed, uint64_t offset, int64_t particle_offset, void* stream) {
+    if (!d_noise || !d_chol || !d_coeffs) return fail(MJMPC_E_BADARG, "null argument");
+    hipStream_t s = (hipStream_t)stream;
+    DISPATCH(dtype,
+             mjmpc::sample_noise<float>((float*)d_noise, (long)P, H, A, d_chol, d_coeffs, seed, offset,
+                                        (long)particle_offset, s),
+             mjmpc::sample_noise<double>((double*)d_noise, (long)P, H, A, d_chol, d_coeffs, seed, offset,
+                                         (long)particle_offset, s));
 }
 
 }  // extern "C"

@@ -1,0 +1,1 @@
+from .mpc_policy import MPCPolicy

@@ -1,0 +1,207 @@
+"""GPU parity of the controller updates (HIP reductions behind the reference-shaped classes)
+against the golden vectors captured from the reference (tests/golden/updates.npz, e2e.npz).
+Tolerance: controller maths in FP64, <= 1e-12 relative."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+TOL = dict(rtol=1e-12, atol=1e-12)
+H, A, P = 10, 4, 64
+
+
+def _kw(**extra):
+    kw = dict(d_state=5, d_obs=6, d_action=A, horizon=H, num_particles=P, n_iters=1,
+              action_lows=-np.ones(A), action_highs=np.ones(A), seed=123)
+    kw.update(extra)
+    return kw
+
+
+def _traj(g, t, as_tensor=False, dtype=np.float64):
+    d = dict(costs=g[t + "_costs"].astype(dtype), actions=g[t + "_actions"].astype(dtype))
+    if as_tensor:
+        import torch
+        d = {k: torch.from_numpy(v).cuda() for k, v in d.items()}
+    return d
+
+
+def _check_cycle(c, g, t, has_val=True):
+    c.mean_action = g[t + "_mean0"].copy()
+    c.cov_action = g[t + "_cov0"].copy()
+    if has_val and t + "_val" in g.files:
+        np.testing.assert_allclose(c._calc_val(_traj(g, t)), g[t + "_val"], **TOL)
+        np.testing.assert_array_equal(c.mean_action, g[t + "_mean0"])         # _calc_val must not move the mean
+    c._update_distribution(_traj(g, t))
+    np.testing.assert_allclose(c.mean_action, g[t + "_mean1"], **TOL)
+    np.testing.assert_allclose(c.cov_action, g[t + "_cov1"], **TOL)
+    c.num_steps += 1
+    c._shift()
+    np.testing.assert_allclose(c.mean_action, g[t + "_mean2"], **TOL)
+    np.testing.assert_allclose(c.cov_action, g[t + "_cov2"], **TOL)
+
+
+def test_mppi_updates(golden):
+    from mjmpc_amd.control import MPPI
+    g = golden("updates")
+    for i in range(int(g["mppi_n"])):
+        t = "mppi%d" % i
+        lam, alpha, tbw, gamma, step, c0 = g[t + "_cfg"]
+        c = MPPI(init_cov=c0, base_action=str(g[t + "_base"]), lam=lam, step_size=step, alpha=int(alpha), gamma=gamma,
+                 time_based_weights=bool(tbw), filter_coeffs=[0.25, 0.8, 0.0], **_kw())
+        _check_cycle(c, g, t)
+        if bool(tbw):
+            with pytest.raises(ValueError):
+                c._calc_val(_traj(g, t))
+
+
+def test_mppi_accepts_device_tensors_and_f32(golden):
+    from mjmpc_amd.control import MPPI
+    g = golden("updates")
+    t = "mppi0"
+    lam, alpha, tbw, gamma, step, c0 = g[t + "_cfg"]
+    c = MPPI(init_cov=c0, base_action="null", lam=lam, step_size=step, alpha=1, gamma=gamma, **_kw())
+    c.mean_action = g[t + "_mean0"].copy()
+    c._update_distribution(_traj(g, t, as_tensor=True))
+    np.testing.assert_allclose(c.mean_action, g[t + "_mean1"], **TOL)
+    # f32 storage of costs/actions: accumulation stays f64, error is input rounding only.
+    # lam = 0.01 amplifies cost rounding by 1/lam in the exponent -> compare on the lam = 0.2 case
+    t = "mppi8"
+    lam, alpha, tbw, gamma, step, c0 = g[t + "_cfg"]
+    assert lam == 0.2 and alpha == 1 and not tbw
+    c = MPPI(init_cov=c0, base_action="null", lam=lam, step_size=step, alpha=1, gamma=gamma, **_kw())
+    c.mean_action = g[t + "_mean0"].copy()
+    c._update_distribution(_traj(g, t, as_tensor=True, dtype=np.float32))
+    np.testing.assert_allclose(c.mean_action, g[t + "_mean1"], rtol=0, atol=2e-5)
+
+
+def test_cem_updates(golden):
+    from mjmpc_amd.control import CEM
+    g = golden("updates")
+    for i in range(int(g["cem_n"])):
+        t = "cem%d" % i
+        elite, beta, gamma, step, c0 = g[t + "_cfg"]
+        c = CEM(init_cov=c0, base_action="null", elite_frac=elite, step_size=step, gamma=gamma, beta=beta,
+                cov_type=str(g[t + "_covtype"]), **_kw())
+        _check_cycle(c, g, t)
+
+
+def test_dmd_updates(golden):
+    from mjmpc_amd.control import DMDMPC
+    g = golden("updates")
+    for i in range(int(g["dmd_n"])):
+        t = "dmd%d" % i
+        lam, beta, gamma, step, c0, ucov = g[t + "_cfg"]
+        c = DMDMPC(init_cov=c0, beta=beta, base_action="repeat", lam=lam, step_size=step, gamma=gamma,
+                   update_cov=bool(ucov), cov_type=str(g[t + "_covtype"]), **_kw())
+        _check_cycle(c, g, t)
+
+
+def test_rs_updates(golden):
+    from mjmpc_amd.control import RandomShooting
+    g = golden("updates")
+    for i in range(int(g["rs_n"])):
+        t = "rs%d" % i
+        gamma, step, c0 = g[t + "_cfg"]
+        c = RandomShooting(init_cov=c0, base_action="null", step_size=step, gamma=gamma, **_kw())
+        _check_cycle(c, g, t)
+
+
+def test_pfmpc(golden):
+    from mjmpc_amd.control import PFMPC
+    g = golden("updates")
+    for i in range(int(g["pf_n"])):
+        t = "pf%d" % i
+        lam, gamma, cshift, cres = g[t + "_cfg"]
+        c = PFMPC(cov_shift=cshift, cov_resample=cres, base_action=str(g[t + "_base"]), lam=lam, gamma=gamma,
+                  filter_coeffs=[0.25, 0.8, 0.0], **_kw())
+        assert np.array_equal(c.action_samples, g[t + "_samples0"])
+        c._update_distribution(dict(costs=g[t + "_costs"], actions=c.action_samples.copy()))
+        assert np.array_equal(c.action_samples, g[t + "_samples1"])
+        np.testing.assert_allclose(c.mean_action, g[t + "_mean1"], **TOL)
+        c.num_steps += 1
+        c._shift()
+        np.testing.assert_allclose(c.action_samples, g[t + "_samples2"], **TOL)
+
+
+# ---- optimize() end to end with a user-supplied python rollout_fn (the reference's callback
+# contract): the env arithmetic comes from the numpy env oracle, everything else is the product.
+def _e2e(golden, tag, make, env, steps_check=True):
+    from oracle import envs_ref as er
+    g = golden("e2e")
+    state = {"cur": None}
+
+    def set_state(s):
+        state["cur"] = np.asarray(s["state"], float).reshape(-1).copy()
+
+    def rollout_fn(num_particles, horizon, mean, noise, mode):
+        obs, rew, act, done, nobs = er.rollout(env, state["cur"], num_particles, horizon, mean, noise)
+        return dict(observations=obs, actions=act, costs=-rew, dones=done, next_observations=nobs)
+
+    c = make()
+    c.set_sim_state_fn = set_state
+    c.rollout_fn = rollout_fn
+    s = g[tag + "_states"][0].copy()
+    for k in range(g[tag + "_actions"].shape[0]):
+        np.testing.assert_allclose(s, g[tag + "_states"][k], rtol=1e-11, atol=1e-11)
+        a, _ = c.optimize({"state": s.copy()})
+        np.testing.assert_allclose(a, g[tag + "_actions"][k], rtol=1e-10, atol=1e-10)
+        s, _ = env.step(s, a)
+    np.testing.assert_allclose(c.mean_action, g[tag + "_final_mean"], rtol=1e-10, atol=1e-10)
+
+
+def test_e2e_pendulum_mppi(golden):
+    from mjmpc_amd.control import MPPI
+    from oracle.envs_ref import PendulumRef
+    kw = dict(d_state=2, d_obs=3, d_action=1, horizon=10, num_particles=48, n_iters=1,
+              action_lows=np.array([-2.0]), action_highs=np.array([2.0]), seed=123)
+    _e2e(golden, "pend_mppi", lambda: MPPI(init_cov=0.8, base_action="null", lam=0.1, step_size=0.9, alpha=1,
+                                            gamma=0.99, filter_coeffs=[0.25, 0.8, 0.0], **kw), PendulumRef())
+
+
+def test_e2e_pendulum_rs(golden):
+    from mjmpc_amd.control import RandomShooting
+    from oracle.envs_ref import PendulumRef
+    kw = dict(d_state=2, d_obs=3, d_action=1, horizon=10, num_particles=48, n_iters=1,
+              action_lows=np.array([-2.0]), action_highs=np.array([2.0]), seed=123)
+    _e2e(golden, "pend_rs", lambda: RandomShooting(init_cov=0.8, base_action="null", step_size=1.0, gamma=1.0,
+                                                    filter_coeffs=[1.0, 0.0, 0.0], **kw), PendulumRef())
+
+
+def test_e2e_lqr_cem_and_dmd(golden):
+    from mjmpc_amd.control import CEM, DMDMPC
+    from oracle.envs_ref import LQRRef
+    g = golden("e2e")
+    env = LQRRef(g["lqr_A"], g["lqr_B"], g["lqr_Q"], g["lqr_R"])
+    kw = dict(d_state=3, d_obs=3, d_action=2, horizon=8, num_particles=40, n_iters=2,
+              action_lows=-np.ones(2) * 5, action_highs=np.ones(2) * 5, seed=77)
+    _e2e(golden, "lqr_cem", lambda: CEM(init_cov=1.0, base_action="null", elite_frac=0.2, step_size=0.8, gamma=1.0,
+                                         beta=0.1, cov_type="full", filter_coeffs=[1.0, 0.0, 0.0], **kw), env)
+    _e2e(golden, "lqr_dmd", lambda: DMDMPC(init_cov=1.0, beta=0.1, base_action="null", lam=0.5, step_size=0.7,
+                                            gamma=1.0, update_cov=True, cov_type="diagonal",
+                                            filter_coeffs=[1.0, 0.0, 0.0], **kw), env)
+
+
+def test_device_noise_statistics():
+    """Performance-mode sampler: N(0, cov) + the recursive filter, checked by moments."""
+    from mjmpc_amd.control._device import DeviceUpdater
+    Pn, Hn, An = 20000, 6, 3
+    dev = DeviceUpdater(Hn, An, np.ones(Hn))
+    rs = np.random.RandomState(0)
+    B = rs.randn(An, An)
+    cov = B @ B.T + 0.3 * np.eye(An)
+    raw = dev.sample_noise(Pn, cov, [1.0, 0.0, 0.0], 7, 3).cpu().numpy()
+    flat = raw.reshape(-1, An)
+    np.testing.assert_allclose(flat.mean(0), 0, atol=0.02)
+    np.testing.assert_allclose(np.cov(flat, rowvar=False), cov, rtol=0.05, atol=0.03)
+    assert abs(np.corrcoef(raw[:, 0, 0], raw[:, 1, 0])[0, 1]) < 0.03          # white along the horizon
+    co = [0.25, 0.8, 0.1]
+    filt = dev.sample_noise(Pn, cov, co, 7, 3).cpu().numpy()
+    want = raw.copy()
+    for t in range(2, Hn):
+        want[:, t] = co[0] * want[:, t] + co[1] * want[:, t - 1] + co[2] * want[:, t - 2]
+    np.testing.assert_allclose(filt, want, rtol=1e-13, atol=1e-13)              # same stream, filter applied
+    other = dev.sample_noise(Pn, cov, [1.0, 0.0, 0.0], 7, 4).cpu().numpy()
+    assert np.abs(other - raw).max() > 1.0                                      # next step: fresh stream
+    # sharding invariance: particles [1000, 1500) drawn as a shard equal the same rows of the full draw
+    shard = dev.sample_noise(500, cov, [1.0, 0.0, 0.0], 7, 3, particle_offset=1000).cpu().numpy()
+    np.testing.assert_array_equal(shard, raw[1000:1500])
