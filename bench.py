@@ -1,0 +1,175 @@
+#!/usr/bin/env python
+"""Headline benchmark: reacher_7dof-v0 MPPI, 4096 particles x H=32 per GPU (BASELINE.json metric).
+
+    python bench.py --gpus 1 --steps 50 --warmup 5
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+One "step" is one control iteration, i.e. one ``Controller.optimize()``: sample noise ->
+roll out every particle for H env steps (2 MuJoCo substeps each) -> MPPI update -> shift -> D2H of
+the action, followed by stepping the "real" arm with that action.  Everything but the action stays
+in HBM.  N > 1: weak scaling, each rank owns a contiguous block of 4096 particles; the per-GPU softmax
+record is all-gathered (RCCL over xGMI) once per iteration.
+
+Prints ONE JSON line (rank 0) with `roofline` (dominant kernel = arm_rollout_kernel, timed live with
+events on the launch stream) and `cpu_baseline` (oracle/ on the host cores, N = 1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s
+FP64_VALU_PEAK_TF = 78.6       # vector FP64; FP32 157.3
+FP32_VALU_PEAK_TF = 157.3
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--particles", type=int, default=4096, help="particles PER GPU")
+    ap.add_argument("--horizon", type=int, default=32)
+    ap.add_argument("--dtype", choices=["f64", "f32"], default="f64")
+    ap.add_argument("--noise", choices=["device", "host"], default="device")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=10.0)
+    return ap.parse_args()
+
+
+def cpu_baseline(P, H, budget_s):
+    """The FP64 C oracle (kind "port") on this box's host cores: same model, same start state, same
+    noise recipe; a bounded sample of the workload (batches of 512 particles x H until the budget)."""
+    from mjmpc_amd.models.reacher7dof import reacher7dof_raw
+    from oracle.physics_ref import RefArm
+    arm = RefArm(reacher7dof_raw().to_flat())
+    cores = len(os.sched_getaffinity(0))
+    rs = np.random.RandomState(123)
+    batch = 512
+    noise = rs.standard_normal((batch, H, 7))
+    for t in range(2, H):
+        noise[:, t] = 0.25 * noise[:, t] + 0.8 * noise[:, t - 1]
+    mean = np.zeros((H, 7))
+    tgt = np.array([0.1, 0.1, 0.1])
+    arm.rollout(np.zeros(7), np.zeros(7), tgt, mean, noise[:64], want_obs=False)     # warm up
+    n, t0 = 0, time.time()
+    while time.time() - t0 < budget_s:
+        arm.rollout(np.zeros(7), np.zeros(7), tgt, mean, noise, want_obs=False)
+        n += batch
+    dt = time.time() - t0
+    return {"value": n * H / dt, "unit": "particle-steps/s", "cores": cores, "kind": "port",
+            "sample": "%d particles x H=%d rollouts of the same workload (OpenMP over particles, %d threads), %.1f s"
+                      % (n, H, cores, dt)}
+
+
+def main():
+    args = parse()
+    import torch
+    import torch.distributed as dist
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch --gpus %d through torch.distributed.run (one process per GPU)" % args.gpus)
+    torch.cuda.set_device(local)
+    comm = None
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        from mjmpc_amd.control._device import TorchDistComm
+        comm = TorchDistComm()
+
+    from mjmpc_amd.control import MPPI
+    from mjmpc_amd.envs.arm_engine import ArmRolloutEngine, make_device_rollout_fn
+    from mjmpc_amd.models.reacher7dof import reacher7dof_raw
+
+    P_loc, H, A = args.particles, args.horizon, 7
+    P_tot = P_loc * world
+    eng = ArmRolloutEngine(reacher7dof_raw(), device=local, dtype=args.dtype)
+    ctrl = MPPI(d_state=eng.d_state, d_obs=eng.d_obs, d_action=A, horizon=H, init_cov=1.0, base_action="null",
+                lam=0.01, num_particles=P_tot, step_size=1.0, alpha=1, gamma=1.0, n_iters=1,
+                action_lows=eng.action_lows, action_highs=eng.action_highs, filter_coeffs=[0.25, 0.8, 0.0],
+                seed=123, noise_mode=args.noise, noise_dtype=args.dtype, device=local, comm=comm)
+    base_fn = make_device_rollout_fn(eng)
+    ev = []
+
+    def rollout_fn(num_particles, horizon, mean, noise, mode):      # events bracket exactly the rollout launch
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        out = base_fn(num_particles, horizon, mean, noise, mode)
+        e1.record()
+        ev.append((e0, e1))
+        return out
+
+    ctrl.rollout_fn = rollout_fn
+    ctrl.set_sim_state_fn = lambda s: None          # the "real" arm lives on the device (step_state)
+    eng.set_env_state(dict(qp=np.zeros(7), qv=np.zeros(7), target_pos=np.array([0.1, 0.1, 0.1])))
+    state = {"resident": True}
+
+    def control_step():
+        action, _ = ctrl.optimize(state)
+        eng.step_state(action)
+
+    def sync():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        control_step()
+    ev.clear()
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        control_step()
+    sync()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    kern_ms = float(np.mean([a.elapsed_time(b) for a, b in ev])) if ev else float("nan")
+    _, nobs = eng.step_state(np.zeros(A))
+    dist_to_target = float(torch.linalg.norm(nobs[17:20]).item())
+    fails = eng.solver_failures()
+
+    psteps = P_tot * H * ctrl.n_iters * args.steps
+    s = 8 if args.dtype == "f64" else 4
+    b_alg = (3 * A + 2) * s                       # delta in, action + cost out, action + cost re-read
+    achieved = b_alg * P_loc * H / (kern_ms * 1e-3) / 1e9
+    out = {
+        "metric": "particle-steps/sec (reacher_7dof-v0 MPPI %dp x H%d per GPU, control loop incl. noise, rollout, update, shift)" % (P_loc, H),
+        "value": psteps / dt, "unit": "particle-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": args.dtype, "data": "synthetic",
+        "config": {"workload": "reacher_7dof-v0 MPPI lam=0.01 H=%d, %d particles per GPU (%d total), frame_skip 2, "
+                               "filter [0.25,0.8,0], closed loop from qpos0 to target [0.1,0.1,0.1]" % (H, P_loc, P_tot),
+                   "noise": args.noise, "particles_per_gpu": P_loc, "horizon": H},
+        "control_loop_hz": args.steps / dt,
+        "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                     "kernel": "arm_rollout_kernel<%s>" % ("double" if args.dtype == "f64" else "float"),
+                     "kernel_ms": kern_ms, "alg_bytes_per_particle_step": b_alg,
+                     "note": "latency/VALU-bound path (SURVEY 8d): ~100+ FLOP per byte, HBM fraction is small by construction"},
+        "solver_failures": fails, "final_distance_to_target": dist_to_target,
+    }
+    if rank == 0:
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(P_loc, H, args.cpu_seconds)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -78,6 +78,13 @@ double* mjmpc_arm_state_ptr(mjmpc_arm_t h);
 int mjmpc_arm_rollout(mjmpc_arm_t h, int dtype, int64_t P, int H, const double* d_mean, const void* d_noise,
                       void* d_costs, void* d_actions, void* d_obs, void* d_next_obs, void* stream);
 
+/* env.step of the "real" environment kept on the device (examples/example_mpc.py:168 ->
+ * Reacher7DOFEnv.step, reacher_env.py:29-39): advances the engine state IN PLACE by one env step
+ * under d_action (float64 [A]), writes the step cost (= -reward, dtype[1]) and, if not NULL, the
+ * resulting observation (dtype[2nv+6]).                                                          */
+int mjmpc_arm_step_state(mjmpc_arm_t h, int dtype, const double* d_action, void* d_cost, void* d_next_obs,
+                         void* stream);
+
 /* Number of (particle, substep) constraint solves whose active set had not settled after the
  * iteration cap since engine creation (synchronises the device).  0 in every test.               */
 int mjmpc_arm_solver_failures(mjmpc_arm_t h, uint32_t* count);

@@ -417,11 +417,11 @@ __device__ __forceinline__ void arm_substep(const LaneConst<T>& C, const ArmGlob
 // state: f64 [qpos(8) | qvel(8) | target(3)]; mean: f64 [H][A]; noise/cost/act/obs/next_obs: T, in the
 // reference's C-order layouts (P,H,A) / (P,H) / (P,H,2nv+6).  noise, act, obs, next_obs, q0 may be null.
 template <typename T>
-__global__ __launch_bounds__(64) void arm_rollout_kernel(const T* __restrict__ model, const double* __restrict__ state,
+__global__ __launch_bounds__(64) void arm_rollout_kernel(const T* __restrict__ model, const double* state,
                                                          long P, int H, int A, const double* __restrict__ mean,
                                                          const T* __restrict__ noise, T* __restrict__ cost,
                                                          T* __restrict__ act, T* __restrict__ obs,
-                                                         T* __restrict__ nobs, unsigned* diag) {
+                                                         T* __restrict__ nobs, double* state_out, unsigned* diag) {
     __shared__ T lds[LANES * LANES * LANES];
     const int lane = threadIdx.x;
     const int l8 = lane & 7, g = lane >> 3;
@@ -485,25 +485,31 @@ __global__ __launch_bounds__(64) void arm_rollout_kernel(const T* __restrict__ m
         cv = v;
         for (int k = 0; k < 3; ++k) chand[k] = site[k];
     }
+    // "real env" stepping on the device: particle 0 writes its final (qpos, qvel) back into a state vector
+    if (state_out && pid == 0 && l8 < nv) {
+        state_out[l8] = (double)q;
+        state_out[LANES + l8] = (double)v;
+    }
 }
 
 }  // namespace
 
 template <typename T>
 hipError_t launch_arm_rollout(const T* model, const double* state, long P, int H, int A, const double* mean,
-                              const T* noise, T* cost, T* act, T* obs, T* nobs, unsigned* diag,
-                              hipStream_t stream) {
+                              const T* noise, T* cost, T* act, T* obs, T* nobs, double* state_out,
+                              unsigned* diag, hipStream_t stream) {
     if (P <= 0 || H <= 0) return hipSuccess;
     const unsigned grid = (unsigned)((P + LANES - 1) / LANES);
     hipLaunchKernelGGL(arm_rollout_kernel<T>, dim3(grid), dim3(64), 0, stream, model, state, P, H, A, mean, noise,
-                       cost, act, obs, nobs, diag);
+                       cost, act, obs, nobs, state_out, diag);
     return hipGetLastError();
 }
 
 template hipError_t launch_arm_rollout<float>(const float*, const double*, long, int, int, const double*,
-                                              const float*, float*, float*, float*, float*, unsigned*, hipStream_t);
+                                              const float*, float*, float*, float*, float*, double*, unsigned*,
+                                              hipStream_t);
 template hipError_t launch_arm_rollout<double>(const double*, const double*, long, int, int, const double*,
-                                               const double*, double*, double*, double*, double*, unsigned*,
+                                               const double*, double*, double*, double*, double*, double*, unsigned*,
                                                hipStream_t);
 
 }  // namespace mjmpc

@@ -129,15 +129,33 @@ int mjmpc_arm_rollout(mjmpc_arm_t h, int dtype, int64_t P, int H, const double* 
     if (dtype == MJMPC_F32) {
         e = mjmpc::launch_arm_rollout<float>(h->model_f32, h->state, (long)P, H, h->nu, d_mean, (const float*)d_noise,
                                              (float*)d_costs, (float*)d_actions, (float*)d_obs, (float*)d_next_obs,
-                                             h->diag, s);
+                                             nullptr, h->diag, s);
     } else if (dtype == MJMPC_F64) {
         e = mjmpc::launch_arm_rollout<double>(h->model_f64, h->state, (long)P, H, h->nu, d_mean,
                                               (const double*)d_noise, (double*)d_costs, (double*)d_actions,
-                                              (double*)d_obs, (double*)d_next_obs, h->diag, s);
+                                              (double*)d_obs, (double*)d_next_obs, nullptr, h->diag, s);
     } else {
         return fail(MJMPC_E_BADARG, "unknown dtype %d", dtype);
     }
     if (e != hipSuccess) return hip_fail(e, "arm_rollout launch");
+    return 0;
+}
+
+int mjmpc_arm_step_state(mjmpc_arm_t h, int dtype, const double* d_action, void* d_cost, void* d_next_obs,
+                         void* stream) {
+    if (!h || !d_action || !d_cost) return fail(MJMPC_E_BADARG, "null argument");
+    HIP_TRY(hipSetDevice(h->device));
+    hipStream_t s = (hipStream_t)stream;
+    hipError_t e;
+    if (dtype == MJMPC_F32)
+        e = mjmpc::launch_arm_rollout<float>(h->model_f32, h->state, 1, 1, h->nu, d_action, nullptr, (float*)d_cost,
+                                             nullptr, nullptr, (float*)d_next_obs, h->state, h->diag, s);
+    else if (dtype == MJMPC_F64)
+        e = mjmpc::launch_arm_rollout<double>(h->model_f64, h->state, 1, 1, h->nu, d_action, nullptr, (double*)d_cost,
+                                              nullptr, nullptr, (double*)d_next_obs, h->state, h->diag, s);
+    else
+        return fail(MJMPC_E_BADARG, "unknown dtype %d", dtype);
+    if (e != hipSuccess) return hip_fail(e, "arm_step_state launch");
     return 0;
 }
 

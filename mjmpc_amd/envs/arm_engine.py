@@ -138,6 +138,17 @@ class ArmRolloutEngine:
                                                _ptr(act), _ptr(obs), _ptr(nobs), self._stream()))
         return costs, act, obs, nobs
 
+    def step_state(self, action):
+        """Advance the engine state in place by one env step (the "real env" kept on the device).
+        ``action``: numpy (A,) or CUDA float64 tensor.  Returns (cost, next_obs) device tensors."""
+        torch = _torch()
+        a = self._as_device(action, torch.float64, (self.d_action,))
+        cost = self._buffer("step_cost", (1,))
+        nobs = self._buffer("step_obs", (self.d_obs,))
+        _lib.check(self._lib.mjmpc_arm_step_state(self._h, self._code, _ptr(a), _ptr(cost), _ptr(nobs),
+                                                  self._stream()))
+        return cost, nobs
+
     def solver_failures(self):
         c = ctypes.c_uint32()
         _lib.check(self._lib.mjmpc_arm_solver_failures(self._h, ctypes.byref(c)))
@@ -162,6 +173,18 @@ class ArmRolloutEngine:
         if tuple(x.shape) != tuple(shape):
             raise ValueError("expected shape %s, got %s" % (shape, tuple(x.shape)))
         return x.to(device=self.device, dtype=tdtype).contiguous()
+
+
+def make_device_rollout_fn(sim_env):
+    """Device-resident ``rollout_fn``: costs and actions come back as CUDA tensors (no observations,
+    which the MPPI / CEM / DMD / random-shooting updates never read - SURVEY 8b), so one control
+    iteration moves nothing across PCIe but the final action."""
+    def rollout_fn(num_particles, horizon, mean, noise, mode):
+        t0 = time.time()
+        costs, act, _, _ = sim_env.rollout_device(num_particles, horizon, mean, noise, mode, want_obs=False)
+        return dict(costs=costs, actions=act, observations=None, next_observations=None, dones=None,
+                    infos={"total_time": np.array([time.time() - t0] * sim_env.num_shards)})
+    return rollout_fn
 
 
 def _same_state(a, b):
