@@ -230,10 +230,16 @@ class DeviceUpdater:
         if buf is None or tuple(buf.shape) != (P, self.H, self.A):
             buf = torch.empty((P, self.H, self.A), dtype=tdt, device=self.device)
             self._rec[key] = buf
-        chol = self.record("chol", self.A * self.A)
-        chol.copy_(torch.from_numpy(np.linalg.cholesky(np.asarray(cov, np.float64)).reshape(-1).copy()))
-        co = self.record("coeffs", 3)
-        co.copy_(torch.from_numpy(np.asarray(filter_coeffs, np.float64).copy()))
+        cov = np.asarray(cov, np.float64)
+        fc = np.asarray(filter_coeffs, np.float64)
+        cached = self._rec.get("noise_params")
+        if cached is None or not (np.array_equal(cached[0], cov) and np.array_equal(cached[1], fc)):
+            chol = self.record("chol", self.A * self.A)
+            chol.copy_(torch.from_numpy(np.linalg.cholesky(cov).reshape(-1).copy()))
+            co = self.record("coeffs", 3)
+            co.copy_(torch.from_numpy(fc.copy()))
+            self._rec["noise_params"] = (cov.copy(), fc.copy())
+        chol, co = self._rec["chol"], self._rec["coeffs"]
         _lib.check(self.lib.mjmpc_sample_noise(_lib.F32 if dtype == "f32" else _lib.F64, _vp(buf), P, self.H, self.A,
                                                _vp(chol), _vp(co), int(seed) & (2 ** 64 - 1), int(offset),
                                                int(particle_offset), self.stream()))

@@ -31,7 +31,7 @@ class CEM(OLGaussianMPC):
         """cem.py:89-95."""
         super()._shift()
         self.cov_action = self.cov_action + self.beta * np.diag(self.init_cov)
-        self._push()
+        self._sync_in()
 
     def _calc_val(self, trajectories):
         """cem.py:107-112."""

@@ -146,6 +146,8 @@ class OLGaussianMPC(Controller):
                          set_sim_state_fn, rollout_fn, sample_mode, batch_size, seed, device=device, comm=comm)
         if noise_mode not in ('host', 'device'):
             raise ValueError("noise_mode must be 'host' or 'device'")
+        self._mean_stale = self._cov_stale = False
+        self._mean_seen = self._cov_seen = None
         self.init_cov = np.array([init_cov] * self.d_action)
         self.init_mean = init_mean.copy()
         self.mean_action = init_mean
@@ -161,24 +163,58 @@ class OLGaussianMPC(Controller):
         self._push()
 
     # -- host <-> device mirrors ---------------------------------------------------------------
+    # ``mean_action`` / ``cov_action`` are lazy host mirrors of the device tensors: a device-side
+    # update only marks them stale, the D2H copy happens when somebody reads them.
+    @property
+    def mean_action(self):
+        if self._mean_stale:
+            self._mean_host = self.dev.get_mean()
+            self._mean_seen = self._mean_host.copy()
+            self._mean_stale = False
+        return self._mean_host
+
+    @mean_action.setter
+    def mean_action(self, value):
+        self._mean_host = value
+        self._mean_seen = None            # unknown to the device: _sync_in will upload it
+        self._mean_stale = False
+
+    @property
+    def cov_action(self):
+        if self._cov_stale:
+            self._cov_host = self.dev.get_cov()
+            self._cov_seen = self._cov_host.copy()
+            self._cov_stale = False
+        return self._cov_host
+
+    @cov_action.setter
+    def cov_action(self, value):
+        self._cov_host = value
+        self._cov_seen = None
+        self._cov_stale = False
+
     def _push(self):
         self.dev.set_mean(self.mean_action)
         self.dev.set_cov(self.cov_action)
-        self._mean_seen = np.array(self.mean_action, copy=True)
-        self._cov_seen = np.array(self.cov_action, copy=True)
+        self._mean_seen = np.array(self._mean_host, copy=True)
+        self._cov_seen = np.array(self._cov_host, copy=True)
 
     def _pull(self, cov=False):
-        self.mean_action = self.dev.get_mean()
-        self._mean_seen = self.mean_action.copy()
+        """Called after a device-side update: the host mirrors are now out of date."""
+        self._mean_stale = True
         if cov:
-            self.cov_action = self.dev.get_cov()
-            self._cov_seen = self.cov_action.copy()
+            self._cov_stale = True
 
     def _sync_in(self):
-        """The host arrays are the public truth (users assign ``mean_action`` directly, as the
-        reference allows): re-upload them if they were changed behind the device copy's back."""
-        if not (np.array_equal(self.mean_action, self._mean_seen) and np.array_equal(self.cov_action, self._cov_seen)):
-            self._push()
+        """The host arrays are the public truth whenever they are fresh (users assign or edit
+        ``mean_action`` directly, as the reference allows): upload them if they differ from what the
+        device last saw."""
+        if not self._mean_stale and (self._mean_seen is None or not np.array_equal(self._mean_host, self._mean_seen)):
+            self.dev.set_mean(self._mean_host)
+            self._mean_seen = np.array(self._mean_host, copy=True)
+        if not self._cov_stale and (self._cov_seen is None or not np.array_equal(self._cov_host, self._cov_seen)):
+            self.dev.set_cov(self._cov_host)
+            self._cov_seen = np.array(self._cov_host, copy=True)
 
     @property
     def local_particles(self):
@@ -213,10 +249,11 @@ class OLGaussianMPC(Controller):
         delta = self.sample_noise()
         if self.use_zero_control_seq and self.dev.comm.rank == self.dev.comm.world_size - 1:
             if isinstance(delta, np.ndarray):
-                delta[-1, :] = -1.0 * self.mean_action.copy()
+                delta[-1, :] = -1.0 * np.array(self.mean_action, copy=True)
             else:
                 delta[-1] = (-self.dev.mean).to(delta.dtype)
-        return self._rollout_fn(self.local_particles, self.horizon, self.mean_action, delta, mode="open_loop")
+        mean = self.dev.mean if getattr(self._rollout_fn, "accepts_device", False) else self.mean_action
+        return self._rollout_fn(self.local_particles, self.horizon, mean, delta, mode="open_loop")
 
     # -- shift / reset (olgaussian_mpc.py:116-135) -------------------------------------------------
     def _shift(self):

@@ -39,7 +39,7 @@ class DMDMPC(OLGaussianMPC):
         super()._shift()
         if self.update_cov:
             self.cov_action = self.cov_action + self.beta * np.eye(self.d_action)
-            self._push()
+            self._sync_in()
 
     def _calc_val(self, trajectories):
         """gaussian_dmd.py:126-139."""

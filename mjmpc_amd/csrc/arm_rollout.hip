@@ -416,7 +416,9 @@ __device__ __forceinline__ void arm_substep(const LaneConst<T>& C, const ArmGlob
 // ---- the rollout kernel -------------------------------------------------------------------------
 // state: f64 [qpos(8) | qvel(8) | target(3)]; mean: f64 [H][A]; noise/cost/act/obs/next_obs: T, in the
 // reference's C-order layouts (P,H,A) / (P,H) / (P,H,2nv+6).  noise, act, obs, next_obs, q0 may be null.
-template <typename T>
+// STEP = true is the same code instantiated under its own name for the single-particle "real env" step
+// (mjmpc_arm_step_state), so that profiler statistics of the P-particle rollout are not diluted by it.
+template <typename T, bool STEP>
 __global__ __launch_bounds__(64) void arm_rollout_kernel(const T* __restrict__ model, const double* state,
                                                          long P, int H, int A, const double* __restrict__ mean,
                                                          const T* __restrict__ noise, T* __restrict__ cost,
@@ -500,8 +502,12 @@ hipError_t launch_arm_rollout(const T* model, const double* state, long P, int H
                               unsigned* diag, hipStream_t stream) {
     if (P <= 0 || H <= 0) return hipSuccess;
     const unsigned grid = (unsigned)((P + LANES - 1) / LANES);
-    hipLaunchKernelGGL(arm_rollout_kernel<T>, dim3(grid), dim3(64), 0, stream, model, state, P, H, A, mean, noise,
-                       cost, act, obs, nobs, state_out, diag);
+    if (state_out)
+        hipLaunchKernelGGL((arm_rollout_kernel<T, true>), dim3(grid), dim3(64), 0, stream, model, state, P, H, A, mean,
+                           noise, cost, act, obs, nobs, state_out, diag);
+    else
+        hipLaunchKernelGGL((arm_rollout_kernel<T, false>), dim3(grid), dim3(64), 0, stream, model, state, P, H, A, mean,
+                           noise, cost, act, obs, nobs, state_out, diag);
     return hipGetLastError();
 }
 

@@ -4,7 +4,7 @@
 // MT19937 stream, which is serial).  Bit-identical noise is the host path
 // (mjmpc_amd.control.control_utils.generate_noise + upload).
 //
-// One thread per (particle, action channel): every normal is a pure function of
+// Every normal is a pure function of
 // (seed, step offset, particle, channel, t/2), so a channel of a correlated sample,
 // eps[a] = sum_{b<=a} L[a][b] z[b], is recomputed locally instead of exchanged between threads.
 #include <hip/hip_runtime.h>
@@ -42,37 +42,47 @@ __device__ __forceinline__ void normal_pair(unsigned long long seed, unsigned lo
     z1 = r * s;
 }
 
+// pass 1: coloured normals, one thread per (particle, channel, t-pair)
 template <typename T>
 __global__ void noise_kernel(T* __restrict__ noise, long P, int H, int A, const double* __restrict__ chol,
-                             const double* __restrict__ coeffs, unsigned long long seed, unsigned long long offset,
-                             long particle_offset) {
+                             unsigned long long seed, unsigned long long offset, long particle_offset) {
+    const int H2 = (H + 1) / 2;
+    const long gid = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (gid >= P * H2 * A) return;
+    const int a = (int)(gid % A);
+    const int t2 = (int)((gid / A) % H2);
+    const long p = gid / ((long)A * H2);
+    double x0 = 0.0, x1 = 0.0;
+    for (int b = 0; b <= a; ++b) {
+        const double l = chol[a * A + b];
+        if (l == 0.0) continue;
+        double z0, z1;
+        normal_pair(seed, offset, (unsigned long long)((p + particle_offset) * A + b), (unsigned)t2, z0, z1);
+        x0 += l * z0;
+        x1 += l * z1;
+    }
+    const int t = 2 * t2;
+    noise[(p * H + t) * A + a] = (T)x0;
+    if (t + 1 < H) noise[(p * H + t + 1) * A + a] = (T)x1;
+}
+
+// pass 2: eps[t] = b0 eps[t] + b1 eps[t-1] + b2 eps[t-2] for t >= 2, in place, in float64
+// (control_utils.py:32-33: t-1 and t-2 are already filtered).  One thread per (particle, channel).
+template <typename T>
+__global__ void filter_kernel(T* __restrict__ noise, long P, int H, int A, const double* __restrict__ coeffs) {
     const long gid = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (gid >= P * A) return;
     const long p = gid / A;
     const int a = (int)(gid % A);
     const double b0 = coeffs[0], b1 = coeffs[1], b2 = coeffs[2];
-    double e1 = 0.0, e2 = 0.0;          // filtered eps[t-1], eps[t-2]
-    for (int t2 = 0; t2 * 2 < H; ++t2) {
-        double x0 = 0.0, x1 = 0.0;
-        for (int b = 0; b <= a; ++b) {
-            const double l = chol[a * A + b];
-            if (l == 0.0) continue;
-            double z0, z1;
-            normal_pair(seed, offset, (unsigned long long)((p + particle_offset) * A + b), (unsigned)t2, z0, z1);
-            x0 += l * z0;
-            x1 += l * z1;
-        }
-        const int t = 2 * t2;
-        double v0 = t >= 2 ? b0 * x0 + b1 * e1 + b2 * e2 : x0;
-        noise[(p * H + t) * A + a] = (T)v0;
+    if (b0 == 1.0 && b1 == 0.0 && b2 == 0.0) return;
+    T* row = noise + p * H * A + a;
+    double e2 = H > 0 ? (double)row[0] : 0.0, e1 = H > 1 ? (double)row[A] : 0.0;
+    for (int t = 2; t < H; ++t) {
+        const double v = b0 * (double)row[(long)t * A] + b1 * e1 + b2 * e2;
+        row[(long)t * A] = (T)v;
         e2 = e1;
-        e1 = v0;
-        if (t + 1 < H) {
-            double v1 = t + 1 >= 2 ? b0 * x1 + b1 * e1 + b2 * e2 : x1;
-            noise[(p * H + t + 1) * A + a] = (T)v1;
-            e2 = e1;
-            e1 = v1;
-        }
+        e1 = v;
     }
 }
 
@@ -82,9 +92,10 @@ template <typename T>
 hipError_t sample_noise(T* noise, long P, int H, int A, const double* chol, const double* coeffs,
                         unsigned long long seed, unsigned long long offset, long particle_offset, hipStream_t s) {
     if (P <= 0 || H <= 0) return hipSuccess;
-    const long n = P * A;
-    hipLaunchKernelGGL(noise_kernel<T>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, noise, P, H, A, chol, coeffs,
-                       seed, offset, particle_offset);
+    const long n = P * A * ((H + 1) / 2), m = P * A;
+    hipLaunchKernelGGL(noise_kernel<T>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, noise, P, H, A, chol, seed,
+                       offset, particle_offset);
+    hipLaunchKernelGGL(filter_kernel<T>, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, s, noise, P, H, A, coeffs);
     return hipGetLastError();
 }
 

@@ -130,15 +130,26 @@ __global__ void softmax_partial_kernel(const double* __restrict__ x, const doubl
     }
 }
 
-// record = [ xmax[Hw] | ordered sum over workgroups of partial ]
+// sum over workgroups of entry j of the partials: one wavefront per entry, lane l adds partials
+// l, l+64, ... in order, then a fixed butterfly - the same tree every run, on every GPU
+__device__ __forceinline__ double wave_entry_sum(const double* __restrict__ partial, int nb, int rec, int j) {
+    const int l = threadIdx.x & 63;
+    double s = 0.0;
+    for (int b = l; b < nb; b += 64) s += partial[(long)b * rec + j];
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+    return s;
+}
+
+// record = [ xmax[Hw] | sum over workgroups of partial ]
 __global__ void softmax_record_kernel(const double* __restrict__ partial, const double* __restrict__ xmax, int nb,
                                       int Hw, int rec, double* __restrict__ record) {
-    const int j = blockIdx.x * blockDim.x + threadIdx.x;
-    if (j < Hw) record[j] = xmax[j];
+    const int j = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     if (j >= rec) return;
-    double s = 0.0;
-    for (int b = 0; b < nb; ++b) s += partial[(long)b * rec + j];
-    record[Hw + j] = s;
+    const double s = wave_entry_sum(partial, nb, rec, j);
+    if ((threadIdx.x & 63) == 0) {
+        record[Hw + j] = s;
+        if (j < Hw) record[j] = xmax[j];
+    }
 }
 
 // mean <- (1-eta) mean + eta * sum_g sc_g W_g / sum_g sc_g S_g,   sc_g = exp(xmax_g - max_g xmax_g);
@@ -252,11 +263,10 @@ __global__ void elite_partial_kernel(const int* __restrict__ elite, const T* __r
 }
 
 __global__ void ordered_sum_kernel(const double* __restrict__ partial, int nb, int rec, double* __restrict__ out) {
-    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    const int j = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     if (j >= rec) return;
-    double s = 0.0;
-    for (int b = 0; b < nb; ++b) s += partial[(long)b * rec + j];
-    out[j] = s;
+    const double s = wave_entry_sum(partial, nb, rec, j);
+    if ((threadIdx.x & 63) == 0) out[j] = s;
 }
 
 // records[g] = {count, sum a[H*A]} -> elite_mean[H*A], dmean[A] = mean over (H * k) elite deltas
@@ -420,8 +430,8 @@ hipError_t softmax_stats(const T* costs, const T* actions, const double* mean, c
     hipLaunchKernelGGL(colmax_kernel, dim3(Hw), dim3(BLK), 0, s, w.x, P, Hw, w.xmax);
     hipLaunchKernelGGL(softmax_partial_kernel<T>, dim3(nb), dim3(BLK), sizeof(double) * CHUNK * Hw, s, w.x, w.xmax,
                        actions, mean, P, H, A, Hw, CHUNK, want_cov, w.partial);
-    hipLaunchKernelGGL(softmax_record_kernel, dim3(nblocks(rec, BLK)), dim3(BLK), 0, s, w.partial, w.xmax, nb, Hw, rec,
-                       record);
+    hipLaunchKernelGGL(softmax_record_kernel, dim3(nblocks(rec, BLK / 64)), dim3(BLK), 0, s, w.partial, w.xmax, nb, Hw,
+                       rec, record);
     return hipGetLastError();
 }
 
@@ -451,7 +461,7 @@ hipError_t cem_elite_sums(const T* actions, const double* q_all, long P_all, lon
                        q_all ? P_all : P, offset, k, w.elite);
     hipLaunchKernelGGL(elite_partial_kernel<T>, dim3(nb), dim3(BLK), 0, s, w.elite, actions, (const double*)nullptr,
                        (const double*)nullptr, P, H, A, CHUNK, 0, w.partial);
-    hipLaunchKernelGGL(ordered_sum_kernel, dim3(nblocks(1 + HA, BLK)), dim3(BLK), 0, s, w.partial, nb, 1 + HA, record);
+    hipLaunchKernelGGL(ordered_sum_kernel, dim3(nblocks(1 + HA, BLK / 64)), dim3(BLK), 0, s, w.partial, nb, 1 + HA, record);
     return hipGetLastError();
 }
 
@@ -463,7 +473,7 @@ hipError_t cem_elite_cov(const T* actions, const double* mean, const double* sum
     hipLaunchKernelGGL(cem_mean_kernel, dim3(1), dim3(BLK), 0, s, sum_records, G, H, A, mean, w.elite_mean, w.dmean);
     hipLaunchKernelGGL(elite_partial_kernel<T>, dim3(nb), dim3(BLK), 0, s, w.elite, actions, mean, w.dmean, P, H, A,
                        CHUNK, 1, w.partial);
-    hipLaunchKernelGGL(ordered_sum_kernel, dim3(nblocks(A * A, BLK)), dim3(BLK), 0, s, w.partial, nb, A * A, crecord);
+    hipLaunchKernelGGL(ordered_sum_kernel, dim3(nblocks(A * A, BLK / 64)), dim3(BLK), 0, s, w.partial, nb, A * A, crecord);
     return hipGetLastError();
 }
 

@@ -184,6 +184,7 @@ def make_device_rollout_fn(sim_env):
         costs, act, _, _ = sim_env.rollout_device(num_particles, horizon, mean, noise, mode, want_obs=False)
         return dict(costs=costs, actions=act, observations=None, next_observations=None, dones=None,
                     infos={"total_time": np.array([time.time() - t0] * sim_env.num_shards)})
+    rollout_fn.accepts_device = True          # controllers may hand over their device-resident mean
     return rollout_fn
 
 
