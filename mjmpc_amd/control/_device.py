@@ -39,9 +39,9 @@ class TorchDistComm:
 
     def all_gather(self, t):
         import torch
-        out = torch.empty((self.world_size, t.numel()), dtype=t.dtype, device=t.device)
+        out = torch.empty(self.world_size * t.numel(), dtype=t.dtype, device=t.device)    # flat: gloo insists
         self._dist.all_gather_into_tensor(out, t.reshape(-1).contiguous(), group=self._group)
-        return out
+        return out.reshape(self.world_size, t.numel())
 
     def all_gather_flat(self, t):
         return self.all_gather(t).reshape(-1)

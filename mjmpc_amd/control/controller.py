@@ -23,6 +23,7 @@ from abc import ABC, abstractmethod
 import numpy as np
 
 from ._device import DeviceUpdater
+from .sharding import local_block
 from .control_utils import generate_noise
 
 
@@ -218,9 +219,7 @@ class OLGaussianMPC(Controller):
 
     @property
     def local_particles(self):
-        ws = self.dev.comm.world_size
-        assert self.num_particles % ws == 0, "Number of particles must be divisible by number of shards"
-        return self.num_particles // ws
+        return local_block(self.num_particles, self.dev.comm.rank, self.dev.comm.world_size)[1]
 
     # -- sampling (olgaussian_mpc.py:69-93) ------------------------------------------------------
     def _get_next_action(self, state, mode='mean'):

@@ -213,3 +213,48 @@ def pf_shift(samples, cov_shift, filter_coeffs, seed, base_action, cov_resample=
     else:
         raise NotImplementedError("invalid option for base action during shift")
     return samples
+
+
+# ---------------------------------------------------------------------------- multi-GPU records
+# numpy statement of the per-GPU records the HIP update kernels exchange (include/mjmpc_amd.h):
+# used by the CPU gloo tests as the stand-in for the kernels, and by the GPU tests to check them.
+def softmax_record(costs, actions, mean, gseq, lam, want_cov=False):
+    """[xmax | S | W[H*A] | C[A*A]] of one shard (time_based_weights = False, alpha = 1)."""
+    P, H, A = actions.shape
+    x = (-1.0 / lam) * cost_to_go(costs.copy(), gseq)[:, 0]
+    xmax = np.max(x)
+    e = np.exp(x - xmax)
+    W = np.tensordot(e, actions, axes=(0, 0)).reshape(-1)
+    C = np.zeros((A, A))
+    if want_cov:
+        d = actions - mean[None]
+        C = np.einsum("p,pti,ptj->ij", e, d, d)
+    return np.concatenate([[xmax, e.sum()], W, C.reshape(-1)])
+
+
+def softmax_combine(records, mean, cov, H, A, lam, step_size, cov_mode, P_total):
+    """Combine G shard records exactly as softmax_combine_kernel does -> (mean, cov, value)."""
+    records = np.asarray(records).reshape(len(records), -1)
+    M = records[:, 0].max()
+    sc = np.exp(records[:, 0] - M)
+    S = np.sum(sc * records[:, 1])
+    W = (sc[:, None] * records[:, 2:2 + H * A]).sum(0).reshape(H, A)
+    new_mean = (1.0 - step_size) * mean + step_size * (W / S)
+    new_cov = cov
+    if cov_mode:
+        C = (sc[:, None] * records[:, 2 + H * A:]).sum(0).reshape(A, A) / S / H
+        if cov_mode == 1:
+            C = np.diag(np.diag(C))
+        new_cov = (1.0 - step_size) * cov + step_size * C
+    value = -lam * (np.log(S / P_total) + M)
+    return new_mean, new_cov, value
+
+
+def elite_flags(q_local, q_all, offset, k):
+    """rank_select_kernel: elite iff fewer than k particles precede in (q0, global index) order."""
+    idx_all = np.arange(q_all.shape[0])
+    out = np.zeros(q_local.shape[0], dtype=bool)
+    for i, qi in enumerate(q_local):
+        gi = offset + i
+        out[i] = np.sum((q_all < qi) | ((q_all == qi) & (idx_all < gi))) < k
+    return out

@@ -108,3 +108,51 @@ def test_full_size_properties(engines):
     q = nobs[..., :7]
     assert (q > lo).all() and (q < hi).all()            # soft limits hold the joints near their range
     assert eng.solver_failures() == 0
+
+
+def test_two_link_arm_with_gravity(tmp_path):
+    """Generality of the kernel beyond sawyer.xml: nv = 2, gravity on, rotated body frame, no contact."""
+    import textwrap
+    from mjmpc_amd.envs.arm_engine import ArmRolloutEngine
+    from mjmpc_amd.models.mjcf import load_mjcf
+    from oracle.physics_ref import RefArm
+    xml = textwrap.dedent("""
+    <mujoco>
+      <compiler inertiafromgeom="true" angle="radian" coordinate="local"/>
+      <option timestep="0.005" gravity="0 0 -9.81" integrator="Euler"/>
+      <default><joint armature="0.01" damping="0.5" limited="true"/><geom margin="0.001" contype="0" conaffinity="0"/></default>
+      <worldbody>
+        <site name="target" pos="0.3 0 0.2"/>
+        <body name="a" pos="0 0 0.1" quat="0.9238795325112867 0 0.3826834323650898 0">
+          <geom type="capsule" fromto="0 0 0 0.2 0 0" size="0.03"/>
+          <joint name="j0" axis="0 0 1" range="-1 1"/>
+          <body name="b" pos="0.2 0 0">
+            <geom type="sphere" pos="0.1 0 0" size="0.04"/>
+            <geom type="capsule" fromto="0 0 0 0.1 0.05 0" size="0.02"/>
+            <joint name="j1" axis="0 1 0" range="-0.4 2" damping="0.1"/>
+            <site name="finger" pos="0.1 0 0"/>
+          </body>
+        </body>
+      </worldbody>
+      <actuator>
+        <motor joint="j0" gear="5" ctrlrange="-1 1" ctrllimited="true"/>
+        <motor joint="j1" gear="2" ctrlrange="-1 1" ctrllimited="true"/>
+      </actuator>
+    </mujoco>""")
+    p = tmp_path / "two_link.xml"
+    p.write_text(xml)
+    raw = load_mjcf(str(p), frame_skip=3)
+    eng = ArmRolloutEngine(raw, dtype="f64")
+    ref = RefArm(raw.to_flat())
+    P, H = 40, 20
+    rs = np.random.RandomState(3)
+    mean, noise = 0.2 * rs.randn(H, 2), rs.randn(P, H, 2)
+    st = dict(qp=np.array([0.2, -0.1]), qv=np.array([0.5, 0.0]), target_pos=np.array([0.3, 0.0, 0.2]))
+    eng.set_env_state(st)
+    obs, rew, act, done, info, nobs = eng.rollout(P, H, mean, noise, "open_loop")
+    o_obs, o_rew, o_act, _, o_nobs = ref.rollout(st["qp"], st["qv"], st["target_pos"], mean, noise)
+    assert obs.shape == (P, H, 10)
+    np.testing.assert_allclose(rew, o_rew, rtol=1e-9, atol=1e-9)
+    np.testing.assert_allclose(nobs, o_nobs, rtol=0, atol=1e-9)
+    assert nobs[..., 1].min() < -0.4                      # the lower limit of j1 was hit under gravity
+    assert eng.solver_failures() == 0

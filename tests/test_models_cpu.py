@@ -1,0 +1,72 @@
+"""CPU: model description, MJCF-subset loader and the host compiler."""
+import os
+import textwrap
+
+import numpy as np
+import pytest
+
+from mjmpc_amd.models.compile import ARM_BLOB_LEN, compile_arm
+from mjmpc_amd.models.mjcf import load_mjcf
+from mjmpc_amd.models.reacher7dof import reacher7dof_raw
+
+SAWYER = "/root/reference/mjmpc/envs/assets/xml/sawyer.xml"
+
+
+def test_blob_layout_and_kinematic_constants():
+    m = compile_arm(reacher7dof_raw())
+    assert m.blob.shape == (ARM_BLOB_LEN,) and ARM_BLOB_LEN == 229
+    assert (m.nv, m.nu, m.d_obs, m.frame_skip) == (7, 7, 20, 2)
+    off = m.field("off").reshape(3, 8).T
+    np.testing.assert_allclose(off[:7].sum(0), [0.821, -0.6, 0.0], atol=1e-15)     # hand at qpos0
+    assert m.field("armature")[7] == 1.0 and m.field("mass")[7] == 0.0             # spare lane
+    np.testing.assert_allclose(m.field("mass")[:7].sum(), 47.10975, rtol=1e-6)
+    assert m.field("sph_margin")[0] == 0.002 and m.field("n_sphere")[0] == 1
+
+
+@pytest.mark.skipif(not os.path.exists(SAWYER), reason="reference tree not mounted")
+def test_loader_reproduces_builtin_table_from_the_reference_xml():
+    a = load_mjcf(SAWYER).to_flat()
+    b = reacher7dof_raw().to_flat()
+    np.testing.assert_array_equal(a, b)
+
+
+def test_loader_on_a_small_model_and_rejections(tmp_path):
+    xml = textwrap.dedent("""
+    <mujoco>
+      <compiler inertiafromgeom="true" angle="radian" coordinate="local"/>
+      <option timestep="0.005" gravity="0 0 -9.81" integrator="Euler"/>
+      <default><joint armature="0.01" damping="0.5" limited="true"/><geom margin="0.001" contype="0" conaffinity="0"/></default>
+      <worldbody>
+        <site name="target" pos="0.3 0 0.2"/>
+        <body name="a" pos="0 0 0.1">
+          <geom type="capsule" fromto="0 0 0 0.2 0 0" size="0.03"/>
+          <joint name="j0" axis="0 0 1" range="-1 1"/>
+          <body name="b" pos="0.2 0 0">
+            <geom type="sphere" pos="0.1 0 0" size="0.04"/>
+            <joint name="j1" axis="0 1 0" range="-2 2" damping="0.1"/>
+            <site name="finger" pos="0.1 0 0"/>
+          </body>
+        </body>
+      </worldbody>
+      <actuator>
+        <motor joint="j0" gear="5" ctrlrange="-1 1" ctrllimited="true"/>
+        <motor joint="j1" gear="2" ctrlrange="-1 1" ctrllimited="true"/>
+      </actuator>
+    </mujoco>""")
+    p = tmp_path / "two_link.xml"
+    p.write_text(xml)
+    raw = load_mjcf(str(p))
+    m = compile_arm(raw)
+    assert (m.nv, m.nu, m.timestep) == (2, 2, 0.005)
+    np.testing.assert_array_equal(m.field("gravity"), [0, 0, -9.81])
+    np.testing.assert_array_equal(m.field("damping")[:2], [0.5, 0.1])
+    np.testing.assert_allclose(m.field("site_pos"), [0.1, 0, 0])
+    assert m.field("n_sphere")[0] == 0
+    bad = xml.replace('type="sphere"', 'type="box"')
+    (tmp_path / "bad.xml").write_text(bad)
+    with pytest.raises(ValueError):
+        load_mjcf(str(tmp_path / "bad.xml"))
+    bad = xml.replace('<joint name="j1"', '<joint name="j1" type="slide"')
+    (tmp_path / "bad2.xml").write_text(bad)
+    with pytest.raises(ValueError):
+        load_mjcf(str(tmp_path / "bad2.xml"))
