@@ -6,7 +6,7 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libmjmpc_amd.so")
+LIB_PATH = os.environ.get("MJMPC_AMD_LIB", os.path.join(_HERE, "libmjmpc_amd.so"))
 
 F32, F64 = 0, 1
 

@@ -1,0 +1,306 @@
+// extern "C" entry points declared in include/mjmpc_amd.h.
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <vector>
+
+#include "../../include/mjmpc_amd.h"
+#include "arm_model.h"
+#include "arm_rollout.h"
+#include "update.h"
+
+namespace {
+
+thread_local char g_err[512] = "";
+
+int fail(int code, const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+int hip_fail(hipError_t e, const char* what) {
+    return fail((int)e, "%s: %s", what, hipGetErrorString(e));
+}
+
+#define HIP_TRY(expr)                                \
+    do {                                             \
+        hipError_t e_ = (expr);                      \
+        if (e_ != hipSuccess) return hip_fail(e_, #expr); \
+    } while (0)
+
+}  // namespace
+
+struct mjmpc_arm_s {
+    int device = 0;
+    int nv = 0, nu = 0, d_obs = 0;
+    float* model_f32 = nullptr;
+    double* model_f64 = nullptr;
+    double* state = nullptr;        // MJMPC_ARM_STATE_LEN
+    unsigned* diag = nullptr;
+    double* pinned = nullptr;       // host staging for set_state
+};
+
+extern "C" {
+
+int mjmpc_abi_version(void) { return MJMPC_ABI_VERSION; }
+
+const char* mjmpc_last_error(void) { return g_err; }
+
+int mjmpc_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+int mjmpc_arm_create(const double* blob, int n_blob, int device, mjmpc_arm_t* out) {
+    if (!blob || !out) return fail(MJMPC_E_BADARG, "null argument");
+    if (n_blob != mjmpc::ARM_BLOB_LEN) return fail(MJMPC_E_BADMODEL, "model blob has %d scalars, expected %d", n_blob, (int)mjmpc::ARM_BLOB_LEN);
+    const int nv = (int)blob[mjmpc::O_NV];
+    if (nv < 1 || nv > mjmpc::MAX_LINKS) return fail(MJMPC_E_BADMODEL, "nv = %d outside 1..%d", nv, mjmpc::MAX_LINKS);
+    if (mjmpc_device_count() <= device) return fail(MJMPC_E_NOGPU, "HIP device %d not present", device);
+    HIP_TRY(hipSetDevice(device));
+    mjmpc_arm_s* h = new mjmpc_arm_s();
+    h->device = device;
+    h->nv = nv;
+    h->nu = nv;
+    h->d_obs = 2 * nv + 6;
+    std::vector<float> f32(blob, blob + n_blob);
+    HIP_TRY(hipMalloc(&h->model_f32, sizeof(float) * n_blob));
+    HIP_TRY(hipMalloc(&h->model_f64, sizeof(double) * n_blob));
+    HIP_TRY(hipMalloc(&h->state, sizeof(double) * MJMPC_ARM_STATE_LEN));
+    HIP_TRY(hipMalloc(&h->diag, sizeof(unsigned)));
+    HIP_TRY(hipHostMalloc(&h->pinned, sizeof(double) * MJMPC_ARM_STATE_LEN));
+    HIP_TRY(hipMemcpy(h->model_f32, f32.data(), sizeof(float) * n_blob, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(h->model_f64, blob, sizeof(double) * n_blob, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemset(h->state, 0, sizeof(double) * MJMPC_ARM_STATE_LEN));
+    HIP_TRY(hipMemset(h->diag, 0, sizeof(unsigned)));
+    *out = h;
+    return 0;
+}
+
+int mjmpc_arm_destroy(mjmpc_arm_t h) {
+    if (!h) return 0;
+    hipSetDevice(h->device);
+    hipFree(h->model_f32);
+    hipFree(h->model_f64);
+    hipFree(h->state);
+    hipFree(h->diag);
+    hipHostFree(h->pinned);
+    delete h;
+    return 0;
+}
+
+int mjmpc_arm_dims(mjmpc_arm_t h, int* nv, int* nu, int* d_obs) {
+    if (!h) return fail(MJMPC_E_BADARG, "null engine");
+    if (nv) *nv = h->nv;
+    if (nu) *nu = h->nu;
+    if (d_obs) *d_obs = h->d_obs;
+    return 0;
+}
+
+int mjmpc_arm_set_state(mjmpc_arm_t h, const double* qpos, const double* qvel, const double* target_pos,
+                        void* stream) {
+    if (!h || !qpos || !qvel || !target_pos) return fail(MJMPC_E_BADARG, "null argument");
+    hipStream_t s = (hipStream_t)stream;
+    HIP_TRY(hipSetDevice(h->device));
+    HIP_TRY(hipStreamSynchronize(s));            // the staging buffer may still be in flight
+    std::memset(h->pinned, 0, sizeof(double) * MJMPC_ARM_STATE_LEN);
+    std::memcpy(h->pinned, qpos, sizeof(double) * h->nv);
+    std::memcpy(h->pinned + mjmpc::LANES, qvel, sizeof(double) * h->nv);
+    std::memcpy(h->pinned + 2 * mjmpc::LANES, target_pos, sizeof(double) * 3);
+    HIP_TRY(hipMemcpyAsync(h->state, h->pinned, sizeof(double) * MJMPC_ARM_STATE_LEN, hipMemcpyHostToDevice, s));
+    return 0;
+}
+
+double* mjmpc_arm_state_ptr(mjmpc_arm_t h) { return h ? h->state : nullptr; }
+
+int mjmpc_arm_rollout(mjmpc_arm_t h, int dtype, int64_t P, int H, const double* d_mean, const void* d_noise,
+                      void* d_costs, void* d_actions, void* d_obs, void* d_next_obs, void* stream) {
+    if (!h || !d_mean || !d_costs) return fail(MJMPC_E_BADARG, "null argument");
+    if (P < 0 || H < 0) return fail(MJMPC_E_BADARG, "negative size");
+    HIP_TRY(hipSetDevice(h->device));
+    hipStream_t s = (hipStream_t)stream;
+    hipError_t e;
+    if (dtype == MJMPC_F32) {
+        e = mjmpc::launch_arm_rollout<float>(h->model_f32, h->state, (long)P, H, h->nu, d_mean, (const float*)d_noise,
+                                             (float*)d_costs, (float*)d_actions, (float*)d_obs, (float*)d_next_obs,
+                                             nullptr, h->diag, s);
+    } else if (dtype == MJMPC_F64) {
+        e = mjmpc::launch_arm_rollout<double>(h->model_f64, h->state, (long)P, H, h->nu, d_mean,
+                                              (const double*)d_noise, (double*)d_costs, (double*)d_actions,
+                                              (double*)d_obs, (double*)d_next_obs, nullptr, h->diag, s);
+    } else {
+        return fail(MJMPC_E_BADARG, "unknown dtype %d", dtype);
+    }
+    if (e != hipSuccess) return hip_fail(e, "arm_rollout launch");
+    return 0;
+}
+
+int mjmpc_arm_step_state(mjmpc_arm_t h, int dtype, const double* d_action, void* d_cost, void* d_next_obs,
+                         void* stream) {
+    if (!h || !d_action || !d_cost) return fail(MJMPC_E_BADARG, "null argument");
+    HIP_TRY(hipSetDevice(h->device));
+    hipStream_t s = (hipStream_t)stream;
+    hipError_t e;
+    if (dtype == MJMPC_F32)
+        e = mjmpc::launch_arm_rollout<float>(h->model_f32, h->state, 1, 1, h->nu, d_action, nullptr, (float*)d_cost,
+                                             nullptr, nullptr, (float*)d_next_obs, h->state, h->diag, s);
+    else if (dtype == MJMPC_F64)
+        e = mjmpc::launch_arm_rollout<double>(h->model_f64, h->state, 1, 1, h->nu, d_action, nullptr, (double*)d_cost,
+                                              nullptr, nullptr, (double*)d_next_obs, h->state, h->diag, s);
+    else
+        return fail(MJMPC_E_BADARG, "unknown dtype %d", dtype);
+    if (e != hipSuccess) return hip_fail(e, "arm_step_state launch");
+    return 0;
+}
+
+int mjmpc_arm_solver_failures(mjmpc_arm_t h, uint32_t* count) {
+    if (!h || !count) return fail(MJMPC_E_BADARG, "null argument");
+    HIP_TRY(hipSetDevice(h->device));
+    HIP_TRY(hipDeviceSynchronize());
+    unsigned c = 0;
+    HIP_TRY(hipMemcpy(&c, h->diag, sizeof(unsigned), hipMemcpyDeviceToHost));
+    *count = c;
+    return 0;
+}
+
+// ---- update / noise entry points -------------------------------------------------------------------
+#define DISPATCH(dtype, CALL_F32, CALL_F64)                                   \
+    do {                                                                      \
+        hipError_t e_;                                                        \
+        if ((dtype) == MJMPC_F32) e_ = (CALL_F32);                            \
+        else if ((dtype) == MJMPC_F64) e_ = (CALL_F64);                       \
+        else return fail(MJMPC_E_BADARG, "unknown dtype %d", (int)(dtype));   \
+        if (e_ != hipSuccess) return hip_fail(e_, __func__);                  \
+        return 0;                                                             \
+    } while (0)
+#define PLAIN(CALL)                                           \
+    do {                                                      \
+        hipError_t e_ = (CALL);                               \
+        if (e_ != hipSuccess) return hip_fail(e_, __func__);  \
+        return 0;                                             \
+    } while (0)
+
+int64_t mjmpc_update_workspace_bytes(int64_t P, int H, int A) {
+    return (int64_t)sizeof(double) * mjmpc::update_workspace_doubles((long)P, H, A);
+}
+
+int mjmpc_softmax_record_len(int H, int A, int tbw) { return 2 * (tbw ? H : 1) + H * A + A * A; }
+
+int mjmpc_traj_cost(int dtype, int64_t P, int H, int A, const void* d_costs, const double* d_gseq, int gamma_zero,
+                    void* d_ws, void* stream) {
+    if (!d_costs || !d_gseq || !d_ws) return fail(MJMPC_E_BADARG, "null argument");
+    hipStream_t s = (hipStream_t)stream;
+    DISPATCH(dtype,
+             mjmpc::traj_cost<float>((const float*)d_costs, nullptr, nullptr, nullptr, d_gseq, gamma_zero, 1.0, 1, 0,
+                                     (long)P, H, A, (double*)d_ws, s),
+             mjmpc::traj_cost<double>((const double*)d_costs, nullptr, nullptr, nullptr, d_gseq, gamma_zero, 1.0, 1, 0,
+                                      (long)P, H, A, (double*)d_ws, s));
+}
+
+double* mjmpc_workspace_q0(void* d_ws, int64_t P, int H, int A) {
+    return mjmpc::workspace_q0((double*)d_ws, (long)P, H, A);
+}
+
+int mjmpc_softmax_stats(int dtype, int64_t P, int H, int A, const void* d_costs, const void* d_actions,
+                        const double* d_mean, const double* d_covinv, const double* d_gseq, int gamma_zero,
+                        double lam, int alpha, int tbw, int want_cov, double* d_record, void* d_ws, void* stream) {
+    if (!d_costs || !d_actions || !d_mean || !d_gseq || !d_record || !d_ws) return fail(MJMPC_E_BADARG, "null argument");
+    if (alpha == 0 && !d_covinv) return fail(MJMPC_E_BADARG, "alpha == 0 needs d_covinv");
+    if (tbw && want_cov) return fail(MJMPC_E_BADARG, "time_based_weights and want_cov are exclusive");
+    if (!(lam > 0)) return fail(MJMPC_E_BADARG, "lam must be positive");
+    hipStream_t s = (hipStream_t)stream;
+    DISPATCH(dtype,
+             mjmpc::softmax_stats<float>((const float*)d_costs, (const float*)d_actions, d_mean, d_covinv, d_gseq,
+                                         gamma_zero, lam, alpha, tbw, want_cov, (long)P, H, A, d_record,
+                                         (double*)d_ws, s),
+             mjmpc::softmax_stats<double>((const double*)d_costs, (const double*)d_actions, d_mean, d_covinv, d_gseq,
+                                          gamma_zero, lam, alpha, tbw, want_cov, (long)P, H, A, d_record,
+                                          (double*)d_ws, s));
+}
+
+int mjmpc_softmax_combine(const double* d_records, int G, int H, int A, int tbw, double lam, double step_size,
+                          int cov_mode, double P_total, double* d_mean, double* d_cov, double* d_value,
+                          double* d_wnorm, void* stream) {
+    if (!d_records || !d_mean || G < 1) return fail(MJMPC_E_BADARG, "bad argument");
+    if (cov_mode && !d_cov) return fail(MJMPC_E_BADARG, "cov_mode needs d_cov");
+    PLAIN(mjmpc::softmax_combine(d_records, G, H, A, tbw, lam, step_size, cov_mode, P_total, d_mean, d_cov, d_value,
+                                 d_wnorm, (hipStream_t)stream));
+}
+
+int mjmpc_softmax_weights(int64_t P, int H, int A, const double* d_wnorm, void* d_ws, double* d_weights,
+                          void* stream) {
+    if (!d_wnorm || !d_ws || !d_weights) return fail(MJMPC_E_BADARG, "null argument");
+    PLAIN(mjmpc::softmax_weights((long)P, d_wnorm, (double*)d_ws, H, A, d_weights, (hipStream_t)stream));
+}
+
+int mjmpc_cem_elite_sums(int dtype, int64_t P, int H, int A, const void* d_actions, const double* d_q_all,
+                         int64_t P_all, int64_t offset, int64_t k, double* d_sum_record, void* d_ws, void* stream) {
+    if (!d_actions || !d_sum_record || !d_ws) return fail(MJMPC_E_BADARG, "null argument");
+    hipStream_t s = (hipStream_t)stream;
+    DISPATCH(dtype,
+             mjmpc::cem_elite_sums<float>((const float*)d_actions, d_q_all, (long)P_all, (long)offset, (long)k, (long)P,
+                                          H, A, d_sum_record, (double*)d_ws, s),
+             mjmpc::cem_elite_sums<double>((const double*)d_actions, d_q_all, (long)P_all, (long)offset, (long)k,
+                                           (long)P, H, A, d_sum_record, (double*)d_ws, s));
+}
+
+int mjmpc_cem_elite_cov(int dtype, int64_t P, int H, int A, const void* d_actions, const double* d_mean,
+                        const double* d_sum_records, int G, double* d_cov_record, void* d_ws, void* stream) {
+    if (!d_actions || !d_mean || !d_sum_records || !d_cov_record || !d_ws) return fail(MJMPC_E_BADARG, "null argument");
+    hipStream_t s = (hipStream_t)stream;
+    DISPATCH(dtype,
+             mjmpc::cem_elite_cov<float>((const float*)d_actions, d_mean, d_sum_records, G, (long)P, H, A, d_cov_record,
+                                         (double*)d_ws, s),
+             mjmpc::cem_elite_cov<double>((const double*)d_actions, d_mean, d_sum_records, G, (long)P, H, A,
+                                          d_cov_record, (double*)d_ws, s));
+}
+
+int mjmpc_cem_final(const double* d_cov_records, int G, int64_t P, int H, int A, double n_elite, int full_cov,
+                    double step_size, double* d_mean, double* d_cov, void* d_ws, void* stream) {
+    if (!d_cov_records || !d_mean || !d_cov || !d_ws) return fail(MJMPC_E_BADARG, "null argument");
+    PLAIN(mjmpc::cem_final(d_cov_records, G, (long)P, H, A, n_elite, full_cov, step_size, d_mean, d_cov,
+                           (double*)d_ws, (hipStream_t)stream));
+}
+
+int mjmpc_rs_best(int dtype, int64_t P, int H, int A, const void* d_actions, int64_t offset, double* d_record,
+                  void* d_ws, void* stream) {
+    if (!d_actions || !d_record || !d_ws) return fail(MJMPC_E_BADARG, "null argument");
+    hipStream_t s = (hipStream_t)stream;
+    DISPATCH(dtype,
+             mjmpc::rs_best<float>((const float*)d_actions, (long)offset, (long)P, H, A, d_record, (double*)d_ws, s),
+             mjmpc::rs_best<double>((const double*)d_actions, (long)offset, (long)P, H, A, d_record, (double*)d_ws, s));
+}
+
+int mjmpc_rs_combine(const double* d_records, int G, int H, int A, double step_size, double* d_mean, void* stream) {
+    if (!d_records || !d_mean || G < 1) return fail(MJMPC_E_BADARG, "bad argument");
+    PLAIN(mjmpc::rs_combine(d_records, G, H, A, step_size, d_mean, (hipStream_t)stream));
+}
+
+int mjmpc_q0_sum(int64_t P, int H, int A, double* d_out, void* d_ws, void* stream) {
+    if (!d_out || !d_ws) return fail(MJMPC_E_BADARG, "null argument");
+    PLAIN(mjmpc::q0_sum((long)P, H, A, d_out, (double*)d_ws, (hipStream_t)stream));
+}
+
+int mjmpc_shift_mean(double* d_mean, int H, int A, int mode, const double* d_row, void* stream) {
+    if (!d_mean || (mode == 2 && !d_row) || mode < 0 || mode > 2) return fail(MJMPC_E_BADARG, "bad argument");
+    PLAIN(mjmpc::shift_mean(d_mean, H, A, mode, d_row, (hipStream_t)stream));
+}
+
+int mjmpc_sample_noise(int dtype, void* d_noise, int64_t P, int H, int A, const double* d_chol,
+                       const double* d_coeffs, uint64_t seed, uint64_t offset, int64_t particle_offset, void* stream) {
+    if (!d_noise || !d_chol || !d_coeffs) return fail(MJMPC_E_BADARG, "null argument");
+    hipStream_t s = (hipStream_t)stream;
+    DISPATCH(dtype,
+             mjmpc::sample_noise<float>((float*)d_noise, (long)P, H, A, d_chol, d_coeffs, seed, offset,
+                                        (long)particle_offset, s),
+             mjmpc::sample_noise<double>((double*)d_noise, (long)P, H, A, d_chol, d_coeffs, seed, offset,
+                                         (long)particle_offset, s));
+}
+
+}  // extern "C"

@@ -1,0 +1,48 @@
+#pragma once
+#include <hip/hip_runtime.h>
+
+namespace mjmpc {
+
+// Workspace (in doubles) the update launchers need for P particles, horizon H, action dim A.
+long update_workspace_doubles(long P, int H, int A);
+double* workspace_q0(double* ws, long P, int H, int A);
+
+// x = (-1/lam) (cost_to_go + lam * control cost-to-go) and q0 = cost_to_go[:,0] into the workspace.
+template <typename T>
+hipError_t traj_cost(const T* costs, const T* actions, const double* mean, const double* covinv, const double* gseq,
+                     int gamma_zero, double lam, int alpha, int tbw, long P, int H, int A, double* ws, hipStream_t s);
+
+// Softmax record of this GPU's particles: [xmax[Hw] | S[Hw] | W[H*A] | C[A*A]], Hw = tbw ? H : 1.
+template <typename T>
+hipError_t softmax_stats(const T* costs, const T* actions, const double* mean, const double* covinv,
+                         const double* gseq, int gamma_zero, double lam, int alpha, int tbw, int want_cov, long P,
+                         int H, int A, double* record, double* ws, hipStream_t s);
+hipError_t softmax_combine(const double* records, int G, int H, int A, int tbw, double lam, double step, int cov_mode,
+                           double P_total, double* mean, double* cov, double* value, double* wnorm, hipStream_t s);
+hipError_t softmax_weights(long P, const double* wnorm, double* ws, int H, int A, double* weights, hipStream_t s);
+
+// CEM: elite flags by global rank (needs q0 in the workspace), then {count, sum a} / centred scatter records.
+template <typename T>
+hipError_t cem_elite_sums(const T* actions, const double* q_all, long P_all, long offset, long k, long P, int H, int A,
+                          double* record, double* ws, hipStream_t s);
+template <typename T>
+hipError_t cem_elite_cov(const T* actions, const double* mean, const double* sum_records, int G, long P, int H, int A,
+                         double* crecord, double* ws, hipStream_t s);
+hipError_t cem_final(const double* crecords, int G, long P, int H, int A, double n_elite, int full, double step,
+                     double* mean, double* cov, double* ws, hipStream_t s);
+
+// Random shooting: {min q0, global index, action[H*A]} record and the combine.
+template <typename T>
+hipError_t rs_best(const T* actions, long offset, long P, int H, int A, double* record, double* ws, hipStream_t s);
+hipError_t rs_combine(const double* records, int G, int H, int A, double step, double* mean, hipStream_t s);
+
+hipError_t q0_sum(long P, int H, int A, double* out, double* ws, hipStream_t s);
+hipError_t shift_mean(double* mean, int H, int A, int mode, const double* row, hipStream_t s);
+
+// Noise: standard normals from Philox4x32-10, coloured by L (A x A lower Cholesky factor of cov), then the
+// in-place AR filter of control_utils.py:32-33, written in the reference's (P,H,A) layout.
+template <typename T>
+hipError_t sample_noise(T* noise, long P, int H, int A, const double* chol, const double* coeffs,
+                        unsigned long long seed, unsigned long long offset, long particle_offset, hipStream_t s);
+
+}  // namespace mjmpc

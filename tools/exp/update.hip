@@ -1,0 +1,528 @@
+// Sampling-distribution update kernels: the device side of the controllers' _update_distribution
+// (reference mjmpc/control/{mppi,gaussian_dmd,cem,random_shooting,particle_filter_controller}.py).
+//
+// All of them reduce P particles x (H*A) actions to a handful of (H*A)- or (A*A)-sized moments, so
+// the pattern is the same everywhere:
+//   1. per-particle scalar(s)    (discounted cost-to-go, +lam * control cost)   one thread / particle
+//   2. block-partial moments     fixed chunk of particles per workgroup, lanes run along the
+//                                contiguous (H*A) axis of `actions` -> coalesced, deterministic order
+//   3. ordered sum of partials   -> a small float64 RECORD per GPU
+//   4. combine G records         (G = number of GPUs; records travel by one all-gather over xGMI)
+// Accumulation is float64 regardless of the storage type T of costs/actions.  Nothing here uses
+// atomics on floating point, so results are bit-reproducible run to run and identical on all ranks.
+#include <hip/hip_runtime.h>
+
+#include "update.h"
+
+namespace mjmpc {
+namespace {
+
+constexpr int BLK = 256;
+
+__device__ __forceinline__ double wave_max(double v) {
+    for (int o = 32; o > 0; o >>= 1) v = fmax(v, __shfl_xor(v, o));
+    return v;
+}
+
+// x[p][tw] = (-1/lam) * (cost_to_go(costs)[p][tw] + lam * cost_to_go(ctrl_cost)[p][tw]),  tw < Hw
+// q0[p]    = cost_to_go(costs)[p][0]                                    (optional output)
+// cost_to_go follows mjmpc/utils/control_utils.py:37-46 in the same summation order.
+template <typename T>
+__global__ void traj_cost_kernel(const T* __restrict__ costs, const T* __restrict__ actions,
+                                 const double* __restrict__ mean, const double* __restrict__ un,
+                                 const double* __restrict__ gseq, int gamma_zero, double lam, long P, int H, int A,
+                                 int Hw, double* __restrict__ x, double* __restrict__ q0) {
+    const long p = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= P) return;
+    const double neg_inv_lam = -1.0 / lam;
+    double acc = 0.0, accc = 0.0;
+    for (int t = H - 1; t >= 0; --t) {
+        const double c = (double)costs[p * H + t];
+        double qt, cq = 0.0;
+        if (gamma_zero) {
+            qt = c;
+        } else {
+            acc += gseq[t] * c;
+            qt = acc / gseq[t];
+        }
+        if (un) {
+            double cc = 0.0;
+            for (int a = 0; a < A; ++a) {
+                const double m = mean[t * A + a];
+                const double d = (double)actions[(p * H + t) * A + a] - m;
+                cc += 0.5 * un[t * A + a] * (m + 2.0 * d);
+            }
+            if (gamma_zero) {
+                cq = cc;
+            } else {
+                accc += gseq[t] * cc;
+                cq = accc / gseq[t];
+            }
+        }
+        if (Hw > 1) x[p * Hw + t] = neg_inv_lam * (qt + lam * cq);
+        else if (t == 0) x[p] = neg_inv_lam * (qt + lam * cq);
+        if (t == 0 && q0) q0[p] = qt;
+    }
+}
+
+// u_n = mean . cov^-1      (mppi.py:106)
+__global__ void un_kernel(const double* __restrict__ mean, const double* __restrict__ covinv, int H, int A,
+                          double* __restrict__ un) {
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= H * A) return;
+    const int t = j / A, a = j % A;
+    double s = 0.0;
+    for (int b = 0; b < A; ++b) s += mean[t * A + b] * covinv[b * A + a];
+    un[j] = s;
+}
+
+// xmax[tw] = max_p x[p][tw]; one workgroup per column
+__global__ void colmax_kernel(const double* __restrict__ x, long P, int Hw, double* __restrict__ xmax) {
+    __shared__ double sm[BLK / 64];
+    const int tw = blockIdx.x;
+    double m = -INFINITY;
+    for (long p = threadIdx.x; p < P; p += blockDim.x) m = fmax(m, x[p * Hw + tw]);
+    m = wave_max(m);
+    if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < BLK / 64; ++w) m = fmax(m, sm[w]);
+        xmax[tw] = m;
+    }
+}
+
+// partial[b] = { S[Hw], W[H*A], C[A*A] } over the particle chunk of workgroup b
+template <typename T>
+__global__ void softmax_partial_kernel(const double* __restrict__ x, const double* __restrict__ xmax,
+                                       const T* __restrict__ actions, const double* __restrict__ mean, long P, int H,
+                                       int A, int Hw, int chunk, int want_cov, double* __restrict__ partial) {
+    extern __shared__ double e_s[];                 // chunk * Hw
+    const int HA = H * A, rec = Hw + HA + A * A;
+    const long p0 = (long)blockIdx.x * chunk;
+    const int n = (int)((P - p0) < chunk ? (P - p0) : chunk);
+    double* out = partial + (long)blockIdx.x * rec;
+    for (int i = threadIdx.x; i < n * Hw; i += blockDim.x) e_s[i] = exp(x[p0 * Hw + i] - xmax[i % Hw]);
+    __syncthreads();
+    for (int tw = threadIdx.x; tw < Hw; tw += blockDim.x) {
+        double s = 0.0;
+        for (int p = 0; p < n; ++p) s += e_s[p * Hw + tw];
+        out[tw] = s;
+    }
+    for (int j = threadIdx.x; j < HA; j += blockDim.x) {
+        const int tw = Hw > 1 ? j / A : 0;
+        double s = 0.0;
+        for (int p = 0; p < n; ++p) s += e_s[p * Hw + tw] * (double)actions[(p0 + p) * HA + j];
+        out[Hw + j] = s;
+    }
+    for (int idx = threadIdx.x; idx < A * A; idx += blockDim.x) {
+        double s = 0.0;
+        if (want_cov) {
+            const int i = idx / A, k = idx % A;
+            for (int p = 0; p < n; ++p) {
+                double sp = 0.0;
+                const T* ap = actions + (p0 + p) * HA;
+                for (int t = 0; t < H; ++t)
+                    sp += ((double)ap[t * A + i] - mean[t * A + i]) * ((double)ap[t * A + k] - mean[t * A + k]);
+                s += e_s[p * Hw] * sp;
+            }
+        }
+        out[Hw + HA + idx] = s;
+    }
+}
+
+// sum over workgroups of entry j of the partials: one wavefront per entry, lane l adds partials
+// l, l+64, ... in order, then a fixed butterfly - the same tree every run, on every GPU
+__device__ __forceinline__ double wave_entry_sum(const double* __restrict__ partial, int nb, int rec, int j) {
+    const int l = threadIdx.x & 63;
+    double s = 0.0;
+    for (int b = l; b < nb; b += 64) s += partial[(long)b * rec + j];
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+    return s;
+}
+
+// record = [ xmax[Hw] | sum over workgroups of partial ]
+__global__ void softmax_record_kernel(const double* __restrict__ partial, const double* __restrict__ xmax, int nb,
+                                      int Hw, int rec, double* __restrict__ record) {
+    const int j = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (j >= rec) return;
+    const double s = wave_entry_sum(partial, nb, rec, j);
+    if ((threadIdx.x & 63) == 0) {
+        record[Hw + j] = s;
+        if (j < Hw) record[j] = xmax[j];
+    }
+}
+
+// mean <- (1-eta) mean + eta * sum_g sc_g W_g / sum_g sc_g S_g,   sc_g = exp(xmax_g - max_g xmax_g);
+// cov likewise (mode 1: diagonal only, 2: full); value = -lam * logsumexp(x, b = 1/P_total).
+__global__ void softmax_combine_kernel(const double* __restrict__ records, int G, int H, int A, int Hw, double lam,
+                                       double step, int cov_mode, double P_total, double* __restrict__ mean,
+                                       double* __restrict__ cov, double* __restrict__ value,
+                                       double* __restrict__ wnorm) {
+    const int HA = H * A, rlen = 2 * Hw + HA + A * A;
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    auto scale = [&](int g, int tw, double M) { return exp(records[(long)g * rlen + tw] - M); };
+    auto colmax = [&](int tw) {
+        double M = -INFINITY;
+        for (int g = 0; g < G; ++g) M = fmax(M, records[(long)g * rlen + tw]);
+        return M;
+    };
+    auto total = [&](int tw, double M) {
+        double S = 0.0;
+        for (int g = 0; g < G; ++g) S += scale(g, tw, M) * records[(long)g * rlen + Hw + tw];
+        return S;
+    };
+    if (j < HA) {
+        const int tw = Hw > 1 ? j / A : 0;
+        const double M = colmax(tw), S = total(tw, M);
+        double W = 0.0;
+        for (int g = 0; g < G; ++g) W += scale(g, tw, M) * records[(long)g * rlen + 2 * Hw + j];
+        mean[j] = (1.0 - step) * mean[j] + step * (W / S);
+    }
+    if (cov_mode && j < A * A) {
+        const int i = j / A, k = j % A;
+        const double M = colmax(0), S = total(0, M);
+        double C = 0.0;
+        for (int g = 0; g < G; ++g) C += scale(g, 0, M) * records[(long)g * rlen + 2 * Hw + HA + j];
+        double upd = C / S / (double)H;
+        if (cov_mode == 1 && i != k) upd = 0.0;
+        cov[j] = (1.0 - step) * cov[j] + step * upd;
+    }
+    if (j == 0) {
+        const double M = colmax(0), S = total(0, M);
+        if (value) *value = -lam * (log(S / P_total) + M);
+        if (wnorm) { wnorm[0] = M; wnorm[1] = S; }
+    }
+}
+
+// w[p] = exp(x[p] - M) / S          (PFMPC weights, particle_filter_controller.py:104-113)
+__global__ void softmax_weights_kernel(const double* __restrict__ x, const double* __restrict__ wnorm, long P,
+                                       double* __restrict__ w) {
+    const long p = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p < P) w[p] = exp(x[p] - wnorm[0]) / wnorm[1];
+}
+
+// ---- CEM ------------------------------------------------------------------------------------------
+// elite[i] = 1 iff fewer than k particles sort before local particle i in (q0, global index) order
+__global__ void rank_select_kernel(const double* __restrict__ q_local, long P_local, const double* __restrict__ q_all,
+                                   long P_all, long offset, long k, int* __restrict__ elite) {
+    __shared__ double tile[BLK];
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const double qi = i < P_local ? q_local[i] : 0.0;
+    const long gi = offset + i;
+    long rank = 0;
+    for (long base = 0; base < P_all; base += BLK) {
+        const long j = base + threadIdx.x;
+        tile[threadIdx.x] = j < P_all ? q_all[j] : INFINITY;
+        __syncthreads();
+        const int n = (int)((P_all - base) < BLK ? (P_all - base) : BLK);
+        for (int jj = 0; jj < n; ++jj) {
+            const double qj = tile[jj];
+            rank += (qj < qi) || (qj == qi && base + jj < gi);
+        }
+        __syncthreads();
+    }
+    if (i < P_local) elite[i] = rank < k ? 1 : 0;
+}
+
+// pass 0: partial[b] = { count, sum_elite a[H*A] }        pass 1: partial[b] = { sum_elite,t (d-dm)(d-dm)' [A*A] }
+template <typename T>
+__global__ void elite_partial_kernel(const int* __restrict__ elite, const T* __restrict__ actions,
+                                     const double* __restrict__ mean, const double* __restrict__ dmean, long P, int H,
+                                     int A, int chunk, int pass, double* __restrict__ partial) {
+    const int HA = H * A;
+    const long p0 = (long)blockIdx.x * chunk;
+    const int n = (int)((P - p0) < chunk ? (P - p0) : chunk);
+    if (pass == 0) {
+        double* out = partial + (long)blockIdx.x * (1 + HA);
+        if (threadIdx.x == 0) {
+            double c = 0.0;
+            for (int p = 0; p < n; ++p) c += elite[p0 + p];
+            out[0] = c;
+        }
+        for (int j = threadIdx.x; j < HA; j += blockDim.x) {
+            double s = 0.0;
+            for (int p = 0; p < n; ++p)
+                if (elite[p0 + p]) s += (double)actions[(p0 + p) * HA + j];
+            out[1 + j] = s;
+        }
+    } else {
+        double* out = partial + (long)blockIdx.x * (A * A);
+        for (int idx = threadIdx.x; idx < A * A; idx += blockDim.x) {
+            const int i = idx / A, k = idx % A;
+            double s = 0.0;
+            for (int p = 0; p < n; ++p) {
+                if (!elite[p0 + p]) continue;
+                const T* ap = actions + (p0 + p) * HA;
+                for (int t = 0; t < H; ++t)
+                    s += ((double)ap[t * A + i] - mean[t * A + i] - dmean[i]) *
+                         ((double)ap[t * A + k] - mean[t * A + k] - dmean[k]);
+            }
+            out[idx] = s;
+        }
+    }
+}
+
+__global__ void ordered_sum_kernel(const double* __restrict__ partial, int nb, int rec, double* __restrict__ out) {
+    const int j = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (j >= rec) return;
+    const double s = wave_entry_sum(partial, nb, rec, j);
+    if ((threadIdx.x & 63) == 0) out[j] = s;
+}
+
+// records[g] = {count, sum a[H*A]} -> elite_mean[H*A], dmean[A] = mean over (H * k) elite deltas
+__global__ void cem_mean_kernel(const double* __restrict__ records, int G, int H, int A,
+                                const double* __restrict__ mean, double* __restrict__ elite_mean,
+                                double* __restrict__ dmean) {
+    const int HA = H * A;
+    double cnt = 0.0;
+    for (int g = 0; g < G; ++g) cnt += records[(long)g * (1 + HA)];
+    for (int j = threadIdx.x; j < HA; j += blockDim.x) {
+        double s = 0.0;
+        for (int g = 0; g < G; ++g) s += records[(long)g * (1 + HA) + 1 + j];
+        elite_mean[j] = s / cnt;
+    }
+    __syncthreads();
+    for (int a = threadIdx.x; a < A; a += blockDim.x) {
+        double s = 0.0;
+        for (int t = 0; t < H; ++t) s += elite_mean[t * A + a] - mean[t * A + a];
+        dmean[a] = s / (double)H;
+    }
+}
+
+// cem.py:76-86: diag -> np.var (ddof 0), full -> np.cov (ddof 1) over the H*k elite deltas
+__global__ void cem_final_kernel(const double* __restrict__ crec, int G, int H, int A, double n_elite, int full,
+                                 double step, const double* __restrict__ elite_mean, double* __restrict__ mean,
+                                 double* __restrict__ cov) {
+    const int HA = H * A;
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j < A * A) {
+        const int i = j / A, k = j % A;
+        double C = 0.0;
+        for (int g = 0; g < G; ++g) C += crec[(long)g * A * A + j];
+        const double N = (double)H * n_elite;
+        double upd = full ? C / (N - 1.0) : (i == k ? C / N : 0.0);
+        cov[j] = (1.0 - step) * cov[j] + step * upd;
+    }
+    if (j < HA) mean[j] = (1.0 - step) * mean[j] + step * elite_mean[j];
+}
+
+// ---- random shooting --------------------------------------------------------------------------------
+// first index of the minimum (np.argmin), single workgroup
+__global__ void argmin_kernel(const double* __restrict__ q, long P, double* __restrict__ out_val, long* __restrict__ out_idx) {
+    __shared__ double sv[BLK];
+    __shared__ long si[BLK];
+    double bv = INFINITY;
+    long bi = P;
+    for (long p = threadIdx.x; p < P; p += blockDim.x) {
+        const double v = q[p];
+        if (v < bv) { bv = v; bi = p; }
+    }
+    sv[threadIdx.x] = bv;
+    si[threadIdx.x] = bi;
+    __syncthreads();
+    for (int s = BLK / 2; s > 0; s >>= 1) {
+        if (threadIdx.x < s) {
+            const double v = sv[threadIdx.x + s];
+            const long i = si[threadIdx.x + s];
+            if (v < sv[threadIdx.x] || (v == sv[threadIdx.x] && i < si[threadIdx.x])) { sv[threadIdx.x] = v; si[threadIdx.x] = i; }
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) { *out_val = sv[0]; *out_idx = si[0]; }
+}
+
+// best[g] = {value, global index, action[H*A]} records -> mean update (random_shooting.py:52-62)
+__global__ void rs_combine_kernel(const double* __restrict__ records, int G, int HA, double step, double* __restrict__ mean) {
+    int best = 0;
+    for (int g = 1; g < G; ++g) {
+        const double v = records[(long)g * (2 + HA)], b = records[(long)best * (2 + HA)];
+        if (v < b || (v == b && records[(long)g * (2 + HA) + 1] < records[(long)best * (2 + HA) + 1])) best = g;
+    }
+    for (int j = threadIdx.x; j < HA; j += blockDim.x)
+        mean[j] = (1.0 - step) * mean[j] + step * records[(long)best * (2 + HA) + 2 + j];
+}
+
+template <typename T>
+__global__ void rs_record_kernel(const double* __restrict__ val, const long* __restrict__ idx, long offset,
+                                 const T* __restrict__ actions, int HA, double* __restrict__ record) {
+    if (threadIdx.x == 0) { record[0] = *val; record[1] = (double)(offset + *idx); }
+    for (int j = threadIdx.x; j < HA; j += blockDim.x) record[2 + j] = (double)actions[(*idx) * HA + j];
+}
+
+__global__ void mean_value_kernel(const double* __restrict__ q, long P, double* __restrict__ sum_out) {
+    __shared__ double sm[BLK];
+    double s = 0.0;
+    for (long p = threadIdx.x; p < P; p += blockDim.x) s += q[p];
+    sm[threadIdx.x] = s;
+    __syncthreads();
+    for (int st = BLK / 2; st > 0; st >>= 1) {
+        if (threadIdx.x < st) sm[threadIdx.x] += sm[threadIdx.x + st];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) *sum_out = sm[0];
+}
+
+// OLGaussianMPC._shift (olgaussian_mpc.py:116-129): mode 0 null, 1 repeat, 2 row supplied by the host
+__global__ void shift_kernel(double* __restrict__ mean, int H, int A, int mode, const double* __restrict__ row) {
+    __shared__ double last[64];
+    const int a = threadIdx.x;
+    if (a >= A) return;
+    for (int t = 0; t + 1 < H; ++t) mean[t * A + a] = mean[(t + 1) * A + a];   // column-wise: no cross-thread hazard
+    last[a] = mode == 0 ? 0.0 : (mode == 1 ? (H >= 2 ? mean[(H - 2) * A + a] : mean[a]) : row[a]);
+    mean[(H - 1) * A + a] = last[a];
+}
+
+inline int nblocks(long n, int b) { return (int)((n + b - 1) / b); }
+
+}  // namespace
+
+// ---- host-side launchers ------------------------------------------------------------------------------
+constexpr int CHUNK = 16;      // particles per workgroup in the partial-moment kernels
+
+long update_workspace_doubles(long P, int H, int A) {
+    const long Hw = H, HA = (long)H * A, rec = Hw + HA + (long)A * A;
+    const long nb = (P + CHUNK - 1) / CHUNK;
+    return HA /*un*/ + P * Hw /*x*/ + P /*q0*/ + Hw /*xmax*/ + nb * rec /*partials*/ + 64 + (P + 1) / 2 /*elite ints*/ + 2 * HA + 2 * A;
+}
+
+struct Ws {
+    double *un, *x, *q0, *xmax, *partial, *scratch, *elite_mean, *dmean;
+    int* elite;
+    Ws(double* base, long P, int H, int A) {
+        const long Hw = H, HA = (long)H * A, rec = Hw + HA + (long)A * A, nb = (P + CHUNK - 1) / CHUNK;
+        un = base;
+        x = un + HA;
+        q0 = x + P * Hw;
+        xmax = q0 + P;
+        partial = xmax + Hw;
+        scratch = partial + nb * rec;
+        elite = (int*)(scratch + 64);
+        elite_mean = scratch + 64 + (P + 1) / 2;
+        dmean = elite_mean + HA;
+    }
+};
+
+template <typename T>
+hipError_t traj_cost(const T* costs, const T* actions, const double* mean, const double* covinv, const double* gseq,
+                     int gamma_zero, double lam, int alpha, int tbw, long P, int H, int A, double* ws,
+                     hipStream_t s) {
+    Ws w(ws, P, H, A);
+    const double* un = nullptr;
+    if (alpha == 0) {
+        hipLaunchKernelGGL(un_kernel, dim3(nblocks(H * A, BLK)), dim3(BLK), 0, s, mean, covinv, H, A, w.un);
+        un = w.un;
+    }
+    const int Hw = tbw ? H : 1;
+    hipLaunchKernelGGL(traj_cost_kernel<T>, dim3(nblocks(P, BLK)), dim3(BLK), 0, s, costs, actions, mean, un, gseq,
+                       gamma_zero, lam, P, H, A, Hw, w.x, w.q0);
+    return hipGetLastError();
+}
+
+template <typename T>
+hipError_t softmax_stats(const T* costs, const T* actions, const double* mean, const double* covinv,
+                         const double* gseq, int gamma_zero, double lam, int alpha, int tbw, int want_cov, long P,
+                         int H, int A, double* record, double* ws, hipStream_t s) {
+    Ws w(ws, P, H, A);
+    hipError_t e = traj_cost<T>(costs, actions, mean, covinv, gseq, gamma_zero, lam, alpha, tbw, P, H, A, ws, s);
+    if (e != hipSuccess) return e;
+    const int Hw = tbw ? H : 1, HA = H * A, rec = Hw + HA + A * A;
+    const int nb = nblocks(P, CHUNK);
+    hipLaunchKernelGGL(colmax_kernel, dim3(Hw), dim3(BLK), 0, s, w.x, P, Hw, w.xmax);
+    hipLaunchKernelGGL(softmax_partial_kernel<T>, dim3(nb), dim3(BLK), sizeof(double) * CHUNK * Hw, s, w.x, w.xmax,
+                       actions, mean, P, H, A, Hw, CHUNK, want_cov, w.partial);
+    hipLaunchKernelGGL(softmax_record_kernel, dim3(nblocks(rec, BLK / 64)), dim3(BLK), 0, s, w.partial, w.xmax, nb, Hw,
+                       rec, record);
+    return hipGetLastError();
+}
+
+hipError_t softmax_combine(const double* records, int G, int H, int A, int tbw, double lam, double step, int cov_mode,
+                           double P_total, double* mean, double* cov, double* value, double* wnorm, hipStream_t s) {
+    const int Hw = tbw ? H : 1;
+    const int n = H * A > A * A ? H * A : A * A;
+    hipLaunchKernelGGL(softmax_combine_kernel, dim3(nblocks(n, BLK)), dim3(BLK), 0, s, records, G, H, A, Hw, lam, step,
+                       cov_mode, P_total, mean, cov, value, wnorm);
+    return hipGetLastError();
+}
+
+hipError_t softmax_weights(long P, const double* wnorm, double* ws, int H, int A, double* weights, hipStream_t s) {
+    Ws w(ws, P, H, A);
+    hipLaunchKernelGGL(softmax_weights_kernel, dim3(nblocks(P, BLK)), dim3(BLK), 0, s, w.x, wnorm, P, weights);
+    return hipGetLastError();
+}
+
+double* workspace_q0(double* ws, long P, int H, int A) { return Ws(ws, P, H, A).q0; }
+
+template <typename T>
+hipError_t cem_elite_sums(const T* actions, const double* q_all, long P_all, long offset, long k, long P, int H, int A,
+                          double* record, double* ws, hipStream_t s) {
+    Ws w(ws, P, H, A);
+    const int HA = H * A, nb = nblocks(P, CHUNK);
+    hipLaunchKernelGGL(rank_select_kernel, dim3(nblocks(P, BLK)), dim3(BLK), 0, s, w.q0, P, q_all ? q_all : w.q0,
+                       q_all ? P_all : P, offset, k, w.elite);
+    hipLaunchKernelGGL(elite_partial_kernel<T>, dim3(nb), dim3(BLK), 0, s, w.elite, actions, (const double*)nullptr,
+                       (const double*)nullptr, P, H, A, CHUNK, 0, w.partial);
+    hipLaunchKernelGGL(ordered_sum_kernel, dim3(nblocks(1 + HA, BLK / 64)), dim3(BLK), 0, s, w.partial, nb, 1 + HA, record);
+    return hipGetLastError();
+}
+
+template <typename T>
+hipError_t cem_elite_cov(const T* actions, const double* mean, const double* sum_records, int G, long P, int H, int A,
+                         double* crecord, double* ws, hipStream_t s) {
+    Ws w(ws, P, H, A);
+    const int nb = nblocks(P, CHUNK);
+    hipLaunchKernelGGL(cem_mean_kernel, dim3(1), dim3(BLK), 0, s, sum_records, G, H, A, mean, w.elite_mean, w.dmean);
+    hipLaunchKernelGGL(elite_partial_kernel<T>, dim3(nb), dim3(BLK), 0, s, w.elite, actions, mean, w.dmean, P, H, A,
+                       CHUNK, 1, w.partial);
+    hipLaunchKernelGGL(ordered_sum_kernel, dim3(nblocks(A * A, BLK / 64)), dim3(BLK), 0, s, w.partial, nb, A * A, crecord);
+    return hipGetLastError();
+}
+
+hipError_t cem_final(const double* crecords, int G, long P, int H, int A, double n_elite, int full, double step,
+                     double* mean, double* cov, double* ws, hipStream_t s) {
+    Ws w(ws, P, H, A);
+    const int n = H * A > A * A ? H * A : A * A;
+    hipLaunchKernelGGL(cem_final_kernel, dim3(nblocks(n, BLK)), dim3(BLK), 0, s, crecords, G, H, A, n_elite, full, step,
+                       w.elite_mean, mean, cov);
+    return hipGetLastError();
+}
+
+template <typename T>
+hipError_t rs_best(const T* actions, long offset, long P, int H, int A, double* record, double* ws, hipStream_t s) {
+    Ws w(ws, P, H, A);
+    long* idx = (long*)(w.scratch + 1);
+    hipLaunchKernelGGL(argmin_kernel, dim3(1), dim3(BLK), 0, s, w.q0, P, w.scratch, idx);
+    hipLaunchKernelGGL(rs_record_kernel<T>, dim3(1), dim3(BLK), 0, s, w.scratch, idx, offset, actions, H * A, record);
+    return hipGetLastError();
+}
+
+hipError_t rs_combine(const double* records, int G, int H, int A, double step, double* mean, hipStream_t s) {
+    hipLaunchKernelGGL(rs_combine_kernel, dim3(1), dim3(BLK), 0, s, records, G, H * A, step, mean);
+    return hipGetLastError();
+}
+
+hipError_t q0_sum(long P, int H, int A, double* out, double* ws, hipStream_t s) {
+    Ws w(ws, P, H, A);
+    hipLaunchKernelGGL(mean_value_kernel, dim3(1), dim3(BLK), 0, s, w.q0, P, out);
+    return hipGetLastError();
+}
+
+hipError_t shift_mean(double* mean, int H, int A, int mode, const double* row, hipStream_t s) {
+    if (A > 64) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(shift_kernel, dim3(1), dim3(64), 0, s, mean, H, A, mode, row);
+    return hipGetLastError();
+}
+
+#define INST(T)                                                                                                      \
+    template hipError_t traj_cost<T>(const T*, const T*, const double*, const double*, const double*, int, double,   \
+                                     int, int, long, int, int, double*, hipStream_t);                                \
+    template hipError_t softmax_stats<T>(const T*, const T*, const double*, const double*, const double*, int,       \
+                                         double, int, int, int, long, int, int, double*, double*, hipStream_t);     \
+    template hipError_t cem_elite_sums<T>(const T*, const double*, long, long, long, long, int, int, double*,        \
+                                          double*, hipStream_t);                                                     \
+    template hipError_t cem_elite_cov<T>(const T*, const double*, const double*, int, long, int, int, double*,       \
+                                         double*, hipStream_t);                                                      \
+    template hipError_t rs_best<T>(const T*, long, long, int, int, double*, double*, hipStream_t);
+INST(float)
+INST(double)
+
+}  // namespace mjmpc

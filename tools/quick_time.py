@@ -2,7 +2,7 @@
 import sys, time
 import numpy as np
 import torch
-sys.path.insert(0, ".")
+import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from mjmpc_amd.envs.arm_engine import ArmRolloutEngine
 from mjmpc_amd.models.reacher7dof import reacher7dof_raw
 
