@@ -78,6 +78,16 @@ double* mjmpc_arm_state_ptr(mjmpc_arm_t h);
 int mjmpc_arm_rollout(mjmpc_arm_t h, int dtype, int64_t P, int H, const double* d_mean, const void* d_noise,
                       void* d_costs, void* d_actions, void* d_obs, void* d_next_obs, void* stream);
 
+/* The same rollout with two optional fusions for a device-resident control iteration:
+ *   d_filter_coeffs float64[3] or NULL: d_noise holds RAW samples and the recursive filter of
+ *                   control_utils.generate_noise (control_utils.py:32-33) is applied inside the kernel;
+ *   d_gseq float64[H] + d_q0 float64[P] (both or neither): d_q0[p] = sum_t gseq[t] * cost[p][t], i.e.
+ *                   control_utils.cost_to_go(costs, gamma_seq)[:,0] (control_utils.py:37-46), so the
+ *                   update does not have to re-read the costs.  No observations are produced.     */
+int mjmpc_arm_rollout_fused(mjmpc_arm_t h, int dtype, int64_t P, int H, const double* d_mean, const void* d_noise,
+                            const double* d_filter_coeffs, const double* d_gseq, void* d_costs, void* d_actions,
+                            double* d_q0, void* stream);
+
 /* env.step of the "real" environment kept on the device (examples/example_mpc.py:168 ->
  * Reacher7DOFEnv.step, reacher_env.py:29-39): advances the engine state IN PLACE by one env step
  * under d_action (float64 [A]), writes the step cost (= -reward, dtype[1]) and, if not NULL, the
@@ -144,6 +154,15 @@ int mjmpc_rs_best(int dtype, int64_t P, int H, int A, const void* d_actions, int
                   void* d_ws, void* stream);
 int mjmpc_rs_combine(const double* d_records, int G, int H, int A, double step_size, double* d_mean, void* stream);
 
+/* MPPI._update_distribution (mppi.py:69-82, time_based_weights off, alpha == 1) + the action read-out
+ * (olgaussian_mpc.py:71) + OLGaussianMPC._shift (olgaussian_mpc.py:116-129) in two launches.
+ * d_q0: float64[P] cost-to-go (NULL = the one mjmpc_traj_cost left in d_ws).  shift_mode: -1 none,
+ * 0 'null', 1 'repeat'.  d_action_out (float64[A]), d_record ([xmax | S | W[H*A]], the softmax record
+ * without its covariance block) and d_value (_calc_val, mppi.py:113-131) may be NULL.              */
+int mjmpc_mppi_fused_update(int dtype, int64_t P, int H, int A, const double* d_q0, const void* d_actions, double lam,
+                            double step_size, int shift_mode, double* d_mean, double* d_action_out, double* d_record,
+                            double* d_value, void* d_ws, void* stream);
+
 /* sum of q0 over local particles (CEM / RandomShooting _calc_val: cem.py:107-112) -> d_out[0] */
 int mjmpc_q0_sum(int64_t P, int H, int A, double* d_out, void* d_ws, void* stream);
 
@@ -153,13 +172,14 @@ int mjmpc_shift_mean(double* d_mean, int H, int A, int mode, const double* d_row
 
 /* control_utils.generate_noise (mjmpc/utils/control_utils.py:24-34), performance mode: Philox
  * normals coloured by the lower Cholesky factor d_chol (float64 [A][A]) and filtered in place with
- * d_coeffs (float64 [3]).  Same distribution as the reference, different bit stream; `offset`
+ * d_coeffs (float64 [3]; NULL leaves the samples raw for mjmpc_arm_rollout_fused to filter).  Same distribution as the reference, different bit stream; `offset`
  * plays the role of num_steps in base_seed = seed_val + num_steps (olgaussian_mpc.py:91);
  * `particle_offset` is the global index of local particle 0, so that a sharded run draws exactly
- * the samples a single GPU would draw for the same particles.                                    */
+ * the samples a single GPU would draw for the same particles.  d_step (device int64, may be NULL)
+ * is added to `offset` on the device, so that a captured hipGraph can advance the stream itself.  */
 int mjmpc_sample_noise(int dtype, void* d_noise, int64_t P, int H, int A, const double* d_chol,
                        const double* d_coeffs, uint64_t seed, uint64_t offset, int64_t particle_offset,
-                       void* stream);
+                       const int64_t* d_step, void* stream);
 
 #ifdef __cplusplus
 }

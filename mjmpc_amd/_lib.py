@@ -27,6 +27,7 @@ SIGNATURES = {
     "mjmpc_arm_set_state": (_int, [_vp, _dp, _dp, _dp, _vp]),
     "mjmpc_arm_state_ptr": (_vp, [_vp]),
     "mjmpc_arm_rollout": (_int, [_vp, _int, _i64, _int, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "mjmpc_arm_rollout_fused": (_int, [_vp, _int, _i64, _int, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "mjmpc_arm_step_state": (_int, [_vp, _int, _vp, _vp, _vp, _vp]),
     "mjmpc_arm_solver_failures": (_int, [_vp, ctypes.POINTER(ctypes.c_uint32)]),
     "mjmpc_update_workspace_bytes": (_i64, [_i64, _int, _int]),
@@ -42,9 +43,10 @@ SIGNATURES = {
     "mjmpc_cem_final": (_int, [_vp, _int, _i64, _int, _int, _dbl, _int, _dbl, _vp, _vp, _vp, _vp]),
     "mjmpc_rs_best": (_int, [_int, _i64, _int, _int, _vp, _i64, _vp, _vp, _vp]),
     "mjmpc_rs_combine": (_int, [_vp, _int, _int, _int, _dbl, _vp, _vp]),
+    "mjmpc_mppi_fused_update": (_int, [_int, _i64, _int, _int, _vp, _vp, _dbl, _dbl, _int, _vp, _vp, _vp, _vp, _vp, _vp]),
     "mjmpc_q0_sum": (_int, [_i64, _int, _int, _vp, _vp, _vp]),
     "mjmpc_shift_mean": (_int, [_vp, _int, _int, _int, _vp, _vp]),
-    "mjmpc_sample_noise": (_int, [_int, _vp, _i64, _int, _int, _vp, _vp, ctypes.c_uint64, ctypes.c_uint64, _i64, _vp]),
+    "mjmpc_sample_noise": (_int, [_int, _vp, _i64, _int, _int, _vp, _vp, ctypes.c_uint64, ctypes.c_uint64, _i64, _vp, _vp]),
 }
 
 _LIB = None

@@ -159,6 +159,14 @@ class DeviceUpdater:
                                                   self.stream()))
         return w
 
+    def mppi_fused_update(self, q0, actions, lam, step_size, shift_mode, action_out):
+        """q0 (float64 [P], device) + actions -> mean update, action read-out and shift in two launches."""
+        P = q0.shape[0]
+        _lib.check(self.lib.mjmpc_mppi_fused_update(self.code(actions), P, self.H, self.A, _vp(q0), _vp(actions),
+                                                    float(lam), float(step_size), int(shift_mode), _vp(self.mean),
+                                                    _vp(action_out), None, None, _vp(self.workspace(P)),
+                                                    self.stream()))
+
     # ------------------------------------------------------------------ CEM
     def cem_update(self, costs, actions, num_elite, step_size, full_cov):
         costs, actions, P = self._pair(costs, actions)
@@ -222,7 +230,8 @@ class DeviceUpdater:
             row_d.copy_(self.torch.from_numpy(np.ascontiguousarray(row, np.float64)))
         _lib.check(self.lib.mjmpc_shift_mean(_vp(self.mean), self.H, self.A, int(mode), _vp(row_d), self.stream()))
 
-    def sample_noise(self, P, cov, filter_coeffs, seed, offset, dtype="f64", particle_offset=0):
+    def sample_noise(self, P, cov, filter_coeffs, seed, offset, dtype="f64", particle_offset=0, d_step=None,
+                     filtered=True):
         torch = self.torch
         tdt = torch.float32 if dtype == "f32" else torch.float64
         key = ("noise", dtype)
@@ -241,6 +250,7 @@ class DeviceUpdater:
             self._rec["noise_params"] = (cov.copy(), fc.copy())
         chol, co = self._rec["chol"], self._rec["coeffs"]
         _lib.check(self.lib.mjmpc_sample_noise(_lib.F32 if dtype == "f32" else _lib.F64, _vp(buf), P, self.H, self.A,
-                                               _vp(chol), _vp(co), int(seed) & (2 ** 64 - 1), int(offset),
-                                               int(particle_offset), self.stream()))
+                                               _vp(chol), _vp(co) if filtered else None, int(seed) & (2 ** 64 - 1),
+                                               int(offset),
+                                               int(particle_offset), _vp(d_step), self.stream()))
         return buf

@@ -161,6 +161,9 @@ class OLGaussianMPC(Controller):
         self.use_zero_control_seq = use_zero_control_seq
         self.noise_mode = noise_mode
         self.noise_dtype = noise_dtype
+        self._graph = None
+        self._graph_post = None
+        self._graph_on = False
         self._push()
 
     # -- host <-> device mirrors ---------------------------------------------------------------
@@ -254,6 +257,109 @@ class OLGaussianMPC(Controller):
         mean = self.dev.mean if getattr(self._rollout_fn, "accepts_device", False) else self.mean_action
         return self._rollout_fn(self.local_particles, self.horizon, mean, delta, mode="open_loop")
 
+    # -- hipGraph fast path ---------------------------------------------------------------------
+    def enable_graph(self, post_step=None):
+        """Capture one whole control iteration (noise -> rollout -> update -> action -> shift) as a
+        hipGraph and replay it from ``optimize()``: one launch and one stream sync per step instead of
+        ~12 launches.  Needs a device-resident pipeline: ``noise_mode='device'``, a rollout_fn made by
+        ``make_device_rollout_fn``, a static covariance, and a shift that needs no host RNG.
+        ``post_step(action_tensor)`` is captured too (e.g. stepping the real env on the device)."""
+        if not self._graph_capable():
+            raise ValueError("this controller configuration cannot run as a captured graph "
+                             "(needs noise_mode='device', a device rollout_fn, static covariance, "
+                             "base_action != 'random', a single GPU)")
+        self._graph_on = True
+        self._graph_post = post_step
+        self._graph = None
+
+    def _graph_capable(self):
+        return (self.noise_mode == 'device' and getattr(self._rollout_fn, "accepts_device", False)
+                and self.base_action in ('null', 'repeat') and self.dev.comm.world_size == 1
+                and self._static_cov() and self.sample_mode == 'mean')
+
+    def _static_cov(self):
+        return False            # subclasses whose update leaves cov_action alone say True
+
+    def _device_update(self, trajectories):
+        raise NotImplementedError
+
+    def _fused_capable(self):
+        return False            # MPPI overrides: filter + cost-to-go + update/shift fusions
+
+    def _device_iteration(self):
+        """The control iteration without any host synchronisation (capturable)."""
+        n_loc = self.local_particles
+        if self._fused_capable():
+            # noise (raw) -> rollout (filters the noise, emits the cost-to-go) -> update + action + shift
+            coeffs = self.dev.record("coeffs", 3)
+            for it in range(self.n_iters):
+                raw = self.dev.sample_noise(n_loc, self._cov_host, self.filter_coeffs, self.seed_val, 0,
+                                            dtype=self.noise_dtype, d_step=self._step_dev, filtered=False)
+                costs, actions, q0 = self._rollout_fn.fused(n_loc, self.horizon, self.dev.mean, raw, coeffs,
+                                                            self.dev.gseq)
+                last = it == self.n_iters - 1
+                self.dev.mppi_fused_update(q0, actions, self.lam, self.step_size,
+                                           _SHIFT_MODES[self.base_action] if last else -1,
+                                           self._action_dev if last else None)
+            self._action_pin.copy_(self._action_dev, non_blocking=True)
+            self._step_dev.add_(1)
+            if self._graph_post is not None:
+                self._graph_post(self._action_dev)
+            return
+        for _ in range(self.n_iters):
+            delta = self.dev.sample_noise(n_loc, self._cov_host, self.filter_coeffs, self.seed_val, 0,
+                                          dtype=self.noise_dtype, d_step=self._step_dev)
+            if self.use_zero_control_seq:
+                delta[-1] = (-self.dev.mean).to(delta.dtype)
+            traj = self._rollout_fn(n_loc, self.horizon, self.dev.mean, delta, mode="open_loop")
+            self._device_update(traj)
+        self._action_dev.copy_(self.dev.mean[0])
+        self._action_pin.copy_(self._action_dev, non_blocking=True)
+        self.dev.shift(_SHIFT_MODES[self.base_action], None)
+        self._step_dev.add_(1)
+        if self._graph_post is not None:
+            self._graph_post(self._action_dev)
+
+    def _optimize_graphed(self, state):
+        torch = self.dev.torch
+        self._sync_in()
+        self._set_sim_state_fn(copy.deepcopy(state))
+        if self._graph is None:
+            self._step_dev = torch.full((1,), self.num_steps, dtype=torch.int64, device=self.dev.device)
+            self._step_host = self.num_steps
+            self._action_dev = torch.zeros(self.d_action, dtype=torch.float64, device=self.dev.device)
+            self._action_pin = torch.zeros(self.d_action, dtype=torch.float64).pin_memory()
+            # eager dry run on a side stream (allocates every buffer), with the state it must not consume
+            keep = (self.dev.mean.clone(), self._step_dev.clone())
+            side = torch.cuda.Stream(self.dev.device)
+            side.wait_stream(torch.cuda.current_stream(self.dev.device))
+            post, self._graph_post = self._graph_post, None
+            with torch.cuda.stream(side):
+                self._device_iteration()
+            torch.cuda.current_stream(self.dev.device).wait_stream(side)
+            torch.cuda.synchronize(self.dev.device)
+            self._graph_post = post
+            self.dev.mean.copy_(keep[0])
+            self._step_dev.copy_(keep[1])
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                self._device_iteration()
+            self._graph = g
+        if self._step_host != self.num_steps:
+            self._step_dev.fill_(self.num_steps)
+        self._graph.replay()
+        torch.cuda.current_stream(self.dev.device).synchronize()
+        action = self._action_pin.numpy().copy()
+        self.num_steps += 1
+        self._step_host = self.num_steps
+        self._mean_stale = True
+        return action, 0.0
+
+    def optimize(self, state, calc_val=False, hotstart=True):
+        if self._graph_on and not calc_val and hotstart:
+            return self._optimize_graphed(state)
+        return super().optimize(state, calc_val, hotstart)
+
     # -- shift / reset (olgaussian_mpc.py:116-135) -------------------------------------------------
     def _shift(self):
         if self.base_action not in _SHIFT_MODES:
@@ -271,6 +377,7 @@ class OLGaussianMPC(Controller):
         self.cov_action = np.diag(self.init_cov)
         self.gamma_seq = np.cumprod([1.0] + [self.gamma] * (self.horizon - 1)).reshape(1, self.horizon)
         self._push()
+        self._graph = None
 
     def _calc_val(self, trajectories):
         raise NotImplementedError("_calc_val not implemented")

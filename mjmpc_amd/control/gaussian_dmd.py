@@ -18,6 +18,12 @@ class DMDMPC(OLGaussianMPC):
         self.beta = beta
         self.update_cov = update_cov
 
+    def _static_cov(self):
+        return not self.update_cov
+
+    def _device_update(self, trajectories):
+        self.dev.softmax_update(trajectories["costs"], trajectories["actions"], self.lam, self.step_size)
+
     def _update_distribution(self, trajectories):
         """gaussian_dmd.py:65-104: softmax weights; weighted mean; if update_cov the weighted scatter,
         diagonal = mean_t sum_p w delta^2, full = (sum_{p,t} w delta delta^T) / H."""

@@ -22,6 +22,17 @@ class MPPI(OLGaussianMPC):
     def _covinv(self):
         return np.linalg.inv(self.cov_action) if self.alpha != 1 else None
 
+    def _static_cov(self):
+        return self.alpha == 1          # alpha == 0 uploads cov^-1 every update (host work)
+
+    def _fused_capable(self):
+        return (self.alpha == 1 and not self.time_based_weights and not self.use_zero_control_seq
+                and not self.dev.gamma_zero and hasattr(self._rollout_fn, "fused"))
+
+    def _device_update(self, trajectories):
+        self.dev.softmax_update(trajectories["costs"], trajectories["actions"], self.lam, self.step_size,
+                                time_based_weights=self.time_based_weights)
+
     def _update_distribution(self, trajectories):
         """mppi.py:69-111: w = softmax(-(cost-to-go + lam * control cost)/lam) over particles (per
         horizon step when time_based_weights); mean <- (1-step) mean + step * sum_p w_p actions_p."""

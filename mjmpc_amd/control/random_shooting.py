@@ -13,6 +13,12 @@ class RandomShooting(OLGaussianMPC):
                          filter_coeffs, set_sim_state_fn, rollout_fn, 'diagonal', sample_mode, batch_size, seed,
                          **device_kw)
 
+    def _static_cov(self):
+        return True
+
+    def _device_update(self, trajectories):
+        self.dev.rs_update(trajectories["costs"], trajectories["actions"], self.step_size)
+
     def _update_distribution(self, trajectories):
         """random_shooting.py:52-62: move the mean towards the single best action sequence."""
         self._sync_in()

@@ -3,10 +3,20 @@
 
 namespace mjmpc {
 
+// Optional fusions into the rollout launch (all pointers may be null):
+//   filt    float64[3]  apply the recursive noise filter of control_utils.py:32-33 to `noise` on the fly
+//                       (then `noise` holds the raw, unfiltered samples)
+//   gseq    float64[H]  with q0_out: q0_out[p] = sum_t gseq[t] * cost[p][t]  (= cost_to_go(...)[:,0])
+struct RolloutFusion {
+    const double* filt = nullptr;
+    const double* gseq = nullptr;
+    double* q0_out = nullptr;
+};
+
 // Fused (particles x horizon x frame_skip) rollout of a compiled arm; see arm_rollout.hip.
 template <typename T>
 hipError_t launch_arm_rollout(const T* model, const double* state, long P, int H, int A, const double* mean,
                               const T* noise, T* cost, T* act, T* obs, T* nobs, double* state_out,
-                              unsigned* diag, hipStream_t stream);
+                              unsigned* diag, hipStream_t stream, RolloutFusion fuse = RolloutFusion());
 
 }  // namespace mjmpc

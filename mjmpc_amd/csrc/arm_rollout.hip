@@ -448,7 +448,8 @@ __global__ __launch_bounds__(64) void arm_rollout_kernel(const T* __restrict__ m
                                                          long P, int H, int A, const double* __restrict__ mean,
                                                          const T* __restrict__ noise, T* __restrict__ cost,
                                                          T* __restrict__ act, T* __restrict__ obs,
-                                                         T* __restrict__ nobs, double* state_out, unsigned* diag) {
+                                                         T* __restrict__ nobs, double* state_out, unsigned* diag,
+                                                         RolloutFusion fuse) {
     __shared__ T lds[LANES * LANES * LANES + ARM_BLOB_LEN + 3];
     const int lane = threadIdx.x;
     const int l8 = lane & 7, g = lane >> 3;
@@ -477,12 +478,23 @@ __global__ __launch_bounds__(64) void arm_rollout_kernel(const T* __restrict__ m
     int rows = 0;
     T cq = q, cv = v, chand[3] = {T(0), T(0), T(0)};
     const bool has_u = l8 < A;
+    double fb0 = 1.0, fb1 = 0.0, fb2 = 0.0, e1 = 0.0, e2 = 0.0, q0acc = 0.0;
+    if (fuse.filt) { fb0 = fuse.filt[0]; fb1 = fuse.filt[1]; fb2 = fuse.filt[2]; }
 
     for (int t = 0; t < H; ++t) {
         T u = T(0);
         if (has_u) {
             u = (T)mean[t * A + l8];
-            if (noise && live) u += noise[(pid * H + t) * A + l8];
+            if (noise && live) {
+                T eps = noise[(pid * H + t) * A + l8];
+                if (fuse.filt) {            // eps[t] = b0 eps[t] + b1 eps[t-1] + b2 eps[t-2], t >= 2
+                    const double f = t >= 2 ? fb0 * (double)eps + fb1 * e1 + fb2 * e2 : (double)eps;
+                    e2 = e1;
+                    e1 = f;
+                    eps = (T)f;
+                }
+                u += eps;
+            }
             if (act && live) act[(pid * H + t) * A + l8] = u;        // unclipped (gym_env_wrapper.py:151)
         }
         // MuJoCo clamps ctrl, not the record
@@ -496,6 +508,7 @@ __global__ __launch_bounds__(64) void arm_rollout_kernel(const T* __restrict__ m
         T dx = site[0] - tgt[0], dy = site[1] - tgt[1], dz = site[2] - tgt[2];
         T cst = fabs(dx) + fabs(dy) + fabs(dz) + T(5) * sqrt_(dx * dx + dy * dy + dz * dz);
         if (live && l8 == 0) cost[pid * H + t] = cst;
+        if (fuse.q0_out) q0acc += fuse.gseq[t] * (double)cst;
         if (live && (obs || nobs)) {
             const long o = (pid * H + t) * dobs;
             if (obs) {
@@ -521,6 +534,7 @@ __global__ __launch_bounds__(64) void arm_rollout_kernel(const T* __restrict__ m
         cv = v;
         for (int k = 0; k < 3; ++k) chand[k] = site[k];
     }
+    if (fuse.q0_out && live && l8 == 0) fuse.q0_out[pid] = q0acc;
     // "real env" stepping on the device: particle 0 writes its final (qpos, qvel) back into a state vector
     if (state_out && pid == 0 && l8 < nv) {
         state_out[l8] = (double)q;
@@ -533,23 +547,23 @@ __global__ __launch_bounds__(64) void arm_rollout_kernel(const T* __restrict__ m
 template <typename T>
 hipError_t launch_arm_rollout(const T* model, const double* state, long P, int H, int A, const double* mean,
                               const T* noise, T* cost, T* act, T* obs, T* nobs, double* state_out,
-                              unsigned* diag, hipStream_t stream) {
+                              unsigned* diag, hipStream_t stream, RolloutFusion fuse) {
     if (P <= 0 || H <= 0) return hipSuccess;
     const unsigned grid = (unsigned)((P + LANES - 1) / LANES);
     if (state_out)
         hipLaunchKernelGGL((arm_rollout_kernel<T, true>), dim3(grid), dim3(64), 0, stream, model, state, P, H, A, mean,
-                           noise, cost, act, obs, nobs, state_out, diag);
+                           noise, cost, act, obs, nobs, state_out, diag, fuse);
     else
         hipLaunchKernelGGL((arm_rollout_kernel<T, false>), dim3(grid), dim3(64), 0, stream, model, state, P, H, A, mean,
-                           noise, cost, act, obs, nobs, state_out, diag);
+                           noise, cost, act, obs, nobs, state_out, diag, fuse);
     return hipGetLastError();
 }
 
 template hipError_t launch_arm_rollout<float>(const float*, const double*, long, int, int, const double*,
                                               const float*, float*, float*, float*, float*, double*, unsigned*,
-                                              hipStream_t);
+                                              hipStream_t, RolloutFusion);
 template hipError_t launch_arm_rollout<double>(const double*, const double*, long, int, int, const double*,
                                                const double*, double*, double*, double*, double*, double*, unsigned*,
-                                               hipStream_t);
+                                               hipStream_t, RolloutFusion);
 
 }  // namespace mjmpc

@@ -141,6 +141,33 @@ int mjmpc_arm_rollout(mjmpc_arm_t h, int dtype, int64_t P, int H, const double* 
     return 0;
 }
 
+int mjmpc_arm_rollout_fused(mjmpc_arm_t h, int dtype, int64_t P, int H, const double* d_mean, const void* d_noise,
+                            const double* d_filter_coeffs, const double* d_gseq, void* d_costs, void* d_actions,
+                            double* d_q0, void* stream) {
+    if (!h || !d_mean || !d_costs) return fail(MJMPC_E_BADARG, "null argument");
+    if ((d_q0 != nullptr) != (d_gseq != nullptr)) return fail(MJMPC_E_BADARG, "d_q0 and d_gseq go together");
+    if (P < 0 || H < 0) return fail(MJMPC_E_BADARG, "negative size");
+    HIP_TRY(hipSetDevice(h->device));
+    hipStream_t s = (hipStream_t)stream;
+    mjmpc::RolloutFusion fuse;
+    fuse.filt = d_filter_coeffs;
+    fuse.gseq = d_gseq;
+    fuse.q0_out = d_q0;
+    hipError_t e;
+    if (dtype == MJMPC_F32)
+        e = mjmpc::launch_arm_rollout<float>(h->model_f32, h->state, (long)P, H, h->nu, d_mean, (const float*)d_noise,
+                                             (float*)d_costs, (float*)d_actions, nullptr, nullptr, nullptr, h->diag, s,
+                                             fuse);
+    else if (dtype == MJMPC_F64)
+        e = mjmpc::launch_arm_rollout<double>(h->model_f64, h->state, (long)P, H, h->nu, d_mean,
+                                              (const double*)d_noise, (double*)d_costs, (double*)d_actions, nullptr,
+                                              nullptr, nullptr, h->diag, s, fuse);
+    else
+        return fail(MJMPC_E_BADARG, "unknown dtype %d", dtype);
+    if (e != hipSuccess) return hip_fail(e, "arm_rollout_fused launch");
+    return 0;
+}
+
 int mjmpc_arm_step_state(mjmpc_arm_t h, int dtype, const double* d_action, void* d_cost, void* d_next_obs,
                          void* stream) {
     if (!h || !d_action || !d_cost) return fail(MJMPC_E_BADARG, "null argument");
@@ -282,6 +309,19 @@ int mjmpc_rs_combine(const double* d_records, int G, int H, int A, double step_s
     PLAIN(mjmpc::rs_combine(d_records, G, H, A, step_size, d_mean, (hipStream_t)stream));
 }
 
+int mjmpc_mppi_fused_update(int dtype, int64_t P, int H, int A, const double* d_q0, const void* d_actions, double lam,
+                            double step_size, int shift_mode, double* d_mean, double* d_action_out, double* d_record,
+                            double* d_value, void* d_ws, void* stream) {
+    if (!d_actions || !d_mean || !d_ws) return fail(MJMPC_E_BADARG, "null argument");
+    if (!(lam > 0) || shift_mode > 1) return fail(MJMPC_E_BADARG, "bad lam / shift_mode");
+    hipStream_t s = (hipStream_t)stream;
+    DISPATCH(dtype,
+             mjmpc::mppi_fused_update<float>(d_q0, (const float*)d_actions, lam, step_size, shift_mode, (long)P, H, A,
+                                             d_mean, d_action_out, d_record, d_value, (double*)d_ws, s),
+             mjmpc::mppi_fused_update<double>(d_q0, (const double*)d_actions, lam, step_size, shift_mode, (long)P, H, A,
+                                              d_mean, d_action_out, d_record, d_value, (double*)d_ws, s));
+}
+
 int mjmpc_q0_sum(int64_t P, int H, int A, double* d_out, void* d_ws, void* stream) {
     if (!d_out || !d_ws) return fail(MJMPC_E_BADARG, "null argument");
     PLAIN(mjmpc::q0_sum((long)P, H, A, d_out, (double*)d_ws, (hipStream_t)stream));
@@ -293,14 +333,15 @@ int mjmpc_shift_mean(double* d_mean, int H, int A, int mode, const double* d_row
 }
 
 int mjmpc_sample_noise(int dtype, void* d_noise, int64_t P, int H, int A, const double* d_chol,
-                       const double* d_coeffs, uint64_t seed, uint64_t offset, int64_t particle_offset, void* stream) {
-    if (!d_noise || !d_chol || !d_coeffs) return fail(MJMPC_E_BADARG, "null argument");
+                       const double* d_coeffs, uint64_t seed, uint64_t offset, int64_t particle_offset,
+                       const int64_t* d_step, void* stream) {
+    if (!d_noise || !d_chol) return fail(MJMPC_E_BADARG, "null argument");
     hipStream_t s = (hipStream_t)stream;
     DISPATCH(dtype,
              mjmpc::sample_noise<float>((float*)d_noise, (long)P, H, A, d_chol, d_coeffs, seed, offset,
-                                        (long)particle_offset, s),
+                                        (long)particle_offset, (const long long*)d_step, s),
              mjmpc::sample_noise<double>((double*)d_noise, (long)P, H, A, d_chol, d_coeffs, seed, offset,
-                                         (long)particle_offset, s));
+                                         (long)particle_offset, (const long long*)d_step, s));
 }
 
 }  // extern "C"

@@ -36,6 +36,13 @@ template <typename T>
 hipError_t rs_best(const T* actions, long offset, long P, int H, int A, double* record, double* ws, hipStream_t s);
 hipError_t rs_combine(const double* records, int G, int H, int A, double step, double* mean, hipStream_t s);
 
+// Fused MPPI update (weights per particle, control cost off): q0 -> mean, action, shift in two launches.
+// q0 == nullptr: use the cost-to-go traj_cost left in the workspace.
+template <typename T>
+hipError_t mppi_fused_update(const double* q0, const T* actions, double lam, double step, int shift_mode, long P, int H,
+                             int A, double* mean, double* action_out, double* record, double* value, double* ws,
+                             hipStream_t s);
+
 hipError_t q0_sum(long P, int H, int A, double* out, double* ws, hipStream_t s);
 hipError_t shift_mean(double* mean, int H, int A, int mode, const double* row, hipStream_t s);
 
@@ -43,6 +50,7 @@ hipError_t shift_mean(double* mean, int H, int A, int mode, const double* row, h
 // in-place AR filter of control_utils.py:32-33, written in the reference's (P,H,A) layout.
 template <typename T>
 hipError_t sample_noise(T* noise, long P, int H, int A, const double* chol, const double* coeffs,
-                        unsigned long long seed, unsigned long long offset, long particle_offset, hipStream_t s);
+                        unsigned long long seed, unsigned long long offset, long particle_offset, const long long* d_step,
+                        hipStream_t s);
 
 }  // namespace mjmpc

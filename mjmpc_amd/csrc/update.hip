@@ -372,6 +372,86 @@ __global__ void shift_kernel(double* __restrict__ mean, int H, int A, int mode, 
     mean[(H - 1) * A + a] = last[a];
 }
 
+// ---- fused MPPI fast path (time_based_weights off, control cost off, no covariance update) -------------
+// Two launches instead of six: per-workgroup softmax partials straight from the cost-to-go the rollout
+// kernel already produced, then ONE workgroup that merges them (max-rescaled, fixed order), updates the
+// mean, extracts the action and shifts the horizon.
+constexpr int FCH = 64;     // particles per workgroup
+
+__device__ __forceinline__ double wave_sum(double v) {
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+
+// partial[b] = { m_b, S_b, W_b[H*A] } with weights exp(x_p - m_b), x_p = -q0_p / lam
+template <typename T>
+__global__ void fused_partial_kernel(const double* __restrict__ q0, const T* __restrict__ actions, double lam, long P,
+                                     int HA, double* __restrict__ partial) {
+    __shared__ double e_s[FCH];
+    const long p0 = (long)blockIdx.x * FCH;
+    const int n = (int)((P - p0) < FCH ? (P - p0) : FCH);
+    double* out = partial + (long)blockIdx.x * (2 + HA);
+    if (threadIdx.x < 64) {
+        const double x = threadIdx.x < n ? (-1.0 / lam) * q0[p0 + threadIdx.x] : -INFINITY;
+        const double m = wave_max(x);
+        const double e = threadIdx.x < n ? exp(x - m) : 0.0;
+        e_s[threadIdx.x] = e;
+        const double s = wave_sum(e);
+        if (threadIdx.x == 0) { out[0] = m; out[1] = s; }
+    }
+    __syncthreads();
+    for (int j = threadIdx.x; j < HA; j += blockDim.x) {
+        double acc = 0.0;
+        for (int p = 0; p < n; ++p) acc += e_s[p] * (double)actions[(p0 + p) * HA + j];
+        out[2 + j] = acc;
+    }
+}
+
+// merge partials -> mean update (mppi.py:69-82) -> action = mean[0] (olgaussian_mpc.py:71) -> shift
+// (olgaussian_mpc.py:116-129; shift_mode < 0: no shift).  Optionally leaves the GPU record
+// [xmax | S | W] for the multi-GPU combine and the value -lam logsumexp (mppi.py:113-131).
+__global__ void fused_final_kernel(const double* __restrict__ partial, int nb, int H, int A, double lam, double step,
+                                   int shift_mode, double P_total, double* __restrict__ mean,
+                                   double* __restrict__ action_out, double* __restrict__ record,
+                                   double* __restrict__ value) {
+    extern __shared__ double sh[];          // sc[nb] | nm[H*A] | red[4]
+    const int HA = H * A, rec = 2 + HA;
+    double* sc = sh;
+    double* nm = sh + nb;
+    double* red = nm + HA;
+    double m = -INFINITY;
+    for (int b = threadIdx.x; b < nb; b += blockDim.x) m = fmax(m, partial[(long)b * rec]);
+    m = wave_max(m);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
+    __syncthreads();
+    const double M = fmax(fmax(red[0], red[1]), fmax(red[2], red[3]));
+    for (int b = threadIdx.x; b < nb; b += blockDim.x) sc[b] = exp(partial[(long)b * rec] - M);
+    __syncthreads();
+    double S = 0.0;
+    for (int b = 0; b < nb; ++b) S += sc[b] * partial[(long)b * rec + 1];      // every thread, same order
+    for (int j = threadIdx.x; j < HA; j += blockDim.x) {
+        double W = 0.0;
+        for (int b = 0; b < nb; ++b) W += sc[b] * partial[(long)b * rec + 2 + j];
+        if (record) record[2 + j] = W;
+        nm[j] = (1.0 - step) * mean[j] + step * (W / S);
+    }
+    if (threadIdx.x == 0) {
+        if (record) { record[0] = M; record[1] = S; }
+        if (value) *value = -lam * (log(S / P_total) + M);
+    }
+    __syncthreads();
+    if (action_out && threadIdx.x < A) action_out[threadIdx.x] = nm[threadIdx.x];
+    for (int j = threadIdx.x; j < HA; j += blockDim.x) {
+        double v = nm[j];
+        if (shift_mode >= 0) {
+            const int t = j / A, a = j % A;
+            if (t + 1 < H) v = nm[j + A];
+            else v = shift_mode == 0 ? 0.0 : nm[(H - 1) * A + a];      // 'null' / 'repeat' (the row that was last)
+        }
+        mean[j] = v;
+    }
+}
+
 inline int nblocks(long n, int b) { return (int)((n + b - 1) / b); }
 
 }  // namespace
@@ -500,6 +580,19 @@ hipError_t rs_combine(const double* records, int G, int H, int A, double step, d
     return hipGetLastError();
 }
 
+template <typename T>
+hipError_t mppi_fused_update(const double* q0, const T* actions, double lam, double step, int shift_mode, long P, int H,
+                             int A, double* mean, double* action_out, double* record, double* value, double* ws,
+                             hipStream_t s) {
+    Ws w(ws, P, H, A);
+    const int nb = nblocks(P, FCH), HA = H * A;
+    if (!q0) q0 = w.q0;
+    hipLaunchKernelGGL(fused_partial_kernel<T>, dim3(nb), dim3(BLK), 0, s, q0, actions, lam, P, HA, w.partial);
+    hipLaunchKernelGGL(fused_final_kernel, dim3(1), dim3(BLK), sizeof(double) * (nb + HA + 4), s, w.partial, nb, H, A, lam,
+                       step, shift_mode, (double)P, mean, action_out, record, value);
+    return hipGetLastError();
+}
+
 hipError_t q0_sum(long P, int H, int A, double* out, double* ws, hipStream_t s) {
     Ws w(ws, P, H, A);
     hipLaunchKernelGGL(mean_value_kernel, dim3(1), dim3(BLK), 0, s, w.q0, P, out);
@@ -521,7 +614,9 @@ hipError_t shift_mean(double* mean, int H, int A, int mode, const double* row, h
                                           double*, hipStream_t);                                                     \
     template hipError_t cem_elite_cov<T>(const T*, const double*, const double*, int, long, int, int, double*,       \
                                          double*, hipStream_t);                                                      \
-    template hipError_t rs_best<T>(const T*, long, long, int, int, double*, double*, hipStream_t);
+    template hipError_t rs_best<T>(const T*, long, long, int, int, double*, double*, hipStream_t);                   \
+    template hipError_t mppi_fused_update<T>(const double*, const T*, double, double, int, long, int, int, double*,  \
+                                             double*, double*, double*, double*, hipStream_t);
 INST(float)
 INST(double)
 

@@ -138,6 +138,24 @@ class ArmRolloutEngine:
                                                _ptr(act), _ptr(obs), _ptr(nobs), self._stream()))
         return costs, act, obs, nobs
 
+    def rollout_fused(self, num_particles, horizon, mean, raw_noise, filter_coeffs, gamma_seq):
+        """Device-resident rollout with the noise filter and the discounted cost-to-go fused into the
+        launch (``mjmpc_arm_rollout_fused``).  All arguments are CUDA tensors (``filter_coeffs`` may be
+        None).  Returns (costs, actions, q0)."""
+        torch = _torch()
+        P, H, A = int(num_particles), int(horizon), self.d_action
+        mean_d = self._as_device(mean, torch.float64, (H, A))
+        noise_d = self._as_device(raw_noise, self._tdtype, (P, H, A))
+        costs = self._buffer("costs", (P, H))
+        act = self._buffer("act", (P, H, A))
+        q0 = self._buf.get("q0")
+        if q0 is None or q0.shape[0] != P:
+            q0 = self._buf["q0"] = torch.empty(P, dtype=torch.float64, device=self.device)
+        _lib.check(self._lib.mjmpc_arm_rollout_fused(self._h, self._code, P, H, _ptr(mean_d), _ptr(noise_d),
+                                                     _ptr(filter_coeffs), _ptr(gamma_seq), _ptr(costs), _ptr(act),
+                                                     _ptr(q0), self._stream()))
+        return costs, act, q0
+
     def step_state(self, action):
         """Advance the engine state in place by one env step (the "real env" kept on the device).
         ``action``: numpy (A,) or CUDA float64 tensor.  Returns (cost, next_obs) device tensors."""
@@ -185,6 +203,7 @@ def make_device_rollout_fn(sim_env):
         return dict(costs=costs, actions=act, observations=None, next_observations=None, dones=None,
                     infos={"total_time": np.array([time.time() - t0] * sim_env.num_shards)})
     rollout_fn.accepts_device = True          # controllers may hand over their device-resident mean
+    rollout_fn.fused = sim_env.rollout_fused  # filter + cost-to-go fused into the launch (graph fast path)
     return rollout_fn
 
 

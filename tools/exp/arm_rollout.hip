@@ -30,64 +30,19 @@ namespace {
 
 constexpr int NEWTON_MAXIT = 12;
 
-template <typename T>
-struct LaneConst {          // constants of "my" link
-    T off[3], ax[3], mass, com[3], I[6], armature, damping, lo, hi, gear, ulo, uhi, invw;
-    bool limited;
-};
+// The compiled-model block (arm_model.h) is staged once per workgroup in LDS; every phase of a
+// substep reads the constants it needs from there (lane l8 reads slot l8 of a per-link field, all
+// lanes read the same word of a global field) instead of pinning ~25 VGPR pairs and ~35 SGPR pairs
+// for the whole rollout.  PHASE() is a compiler-only fence that keeps those reads inside their phase.
+#define PHASE() asm volatile("" ::: "memory")
 
 template <typename T>
-struct ArmGlobals {         // wave-uniform (SGPR) constants
-    int site_link, n_sphere, sph_link, frame_skip;
-    T h, site_pos[3], sph_pos[3], sph_r, sph_margin, sph_invw, pn[3], pd;
-    T K, B, dmin, dmax, width, mid, power, grav[3];
-    T inv_width, inv_mid, inv_1mid;      // reciprocals: no IEEE divide in the per-substep impedance model
+struct Model {                 // view of the LDS copy of the model block
+    const T* m;
+    int l8;
+    __device__ __forceinline__ T link(int off, int c = 0) const { return m[off + c * LANES + l8]; }
+    __device__ __forceinline__ T glob(int off, int c = 0) const { return m[off + c]; }
 };
-
-template <typename T>
-__device__ __forceinline__ void load_consts(const T* __restrict__ m, int l8, LaneConst<T>& C, ArmGlobals<T>& Gc) {
-    for (int c = 0; c < 3; ++c) {
-        C.off[c] = m[O_OFF + c * LANES + l8];
-        C.ax[c] = m[O_AXIS + c * LANES + l8];
-        C.com[c] = m[O_COM + c * LANES + l8];
-    }
-    for (int c = 0; c < 6; ++c) C.I[c] = m[O_INERTIA + c * LANES + l8];
-    C.mass = m[O_MASS + l8];
-    C.armature = m[O_ARMATURE + l8];
-    C.damping = m[O_DAMPING + l8];
-    C.lo = m[O_RANGE_LO + l8];
-    C.hi = m[O_RANGE_HI + l8];
-    C.limited = m[O_LIMITED + l8] != T(0);
-    C.gear = m[O_GEAR + l8];
-    C.ulo = m[O_CTRL_LO + l8];
-    C.uhi = m[O_CTRL_HI + l8];
-    C.invw = m[O_DOF_INVW + l8];
-    Gc.site_link = (int)m[O_SITE_LINK];
-    Gc.n_sphere = (int)m[O_N_SPHERE];
-    Gc.sph_link = (int)m[O_SPH_LINK];
-    Gc.frame_skip = (int)m[O_FRAME_SKIP];
-    Gc.h = m[O_TIMESTEP];
-    for (int c = 0; c < 3; ++c) {
-        Gc.site_pos[c] = m[O_SITE_POS + c];
-        Gc.sph_pos[c] = m[O_SPH_POS + c];
-        Gc.pn[c] = m[O_PLANE_N + c];
-        Gc.grav[c] = m[O_GRAVITY + c];
-    }
-    Gc.sph_r = m[O_SPH_R];
-    Gc.sph_margin = m[O_SPH_MARGIN];
-    Gc.sph_invw = m[O_SPH_INVW];
-    Gc.pd = m[O_PLANE_D];
-    Gc.K = m[O_SOL_K];
-    Gc.B = m[O_SOL_B];
-    Gc.dmin = m[O_SOL_DMIN];
-    Gc.dmax = m[O_SOL_DMAX];
-    Gc.width = m[O_SOL_WIDTH];
-    Gc.mid = m[O_SOL_MID];
-    Gc.power = m[O_SOL_POWER];
-    Gc.inv_width = T(1) / Gc.width;
-    Gc.inv_mid = T(1) / Gc.mid;
-    Gc.inv_1mid = T(1) / (T(1) - Gc.mid);
-}
 
 // ---- small vector helpers -------------------------------------------------------------------
 template <typename T>
@@ -126,60 +81,70 @@ __device__ __forceinline__ void fk_scan_step(T* R, T* p, int l8) {
 
 // MuJoCo mj_makeImpedance + mj_referenceConstraint for one scalar row (r = pos - margin)
 template <typename T>
-__device__ __forceinline__ void row_params(const ArmGlobals<T>& Gc, T r, T diag_approx, T jv, T& D, T& aref) {
-    T x = fabs(r) * Gc.inv_width, y;
+__device__ __forceinline__ void row_params(const Model<T>& M, T r, T diag_approx, T jv, T& D, T& aref) {
+    const T dmin = M.glob(O_SOL_DMIN), dmax = M.glob(O_SOL_DMAX), width = M.glob(O_SOL_WIDTH);
+    const T mid = M.glob(O_SOL_MID), power = M.glob(O_SOL_POWER);
+    T x = fabs(r) * rcp_(width), y;
     x = x > T(1) ? T(1) : x;
-    if (Gc.power == T(2)) {
+    if (power == T(2)) {
         T om = T(1) - x;
-        y = x <= Gc.mid ? x * x * Gc.inv_mid : T(1) - om * om * Gc.inv_1mid;
-    } else if (Gc.power == T(1)) {
+        y = x <= mid ? x * x * rcp_(mid) : T(1) - om * om * rcp_(T(1) - mid);
+    } else if (power == T(1)) {
         y = x;
     } else {
-        y = x <= Gc.mid ? pow_(x, Gc.power) / pow_(Gc.mid, Gc.power - T(1))
-                        : T(1) - pow_(T(1) - x, Gc.power) / pow_(T(1) - Gc.mid, Gc.power - T(1));
+        y = x <= mid ? pow_(x, power) / pow_(mid, power - T(1))
+                     : T(1) - pow_(T(1) - x, power) / pow_(T(1) - mid, power - T(1));
     }
-    T imp = Gc.dmin + y * (Gc.dmax - Gc.dmin);
+    T imp = dmin + y * (dmax - dmin);
     T Rr = (T(1) - imp) * rcp_(imp) * diag_approx;
     Rr = Rr < T(1e-15) ? T(1e-15) : Rr;
     D = rcp_(Rr);
-    aref = -Gc.B * jv - Gc.K * imp * r;
+    aref = -M.glob(O_SOL_B) * jv - M.glob(O_SOL_K) * imp * r;
 }
 
-// Solve (sym. pos. def.) H x = b.  Lane i holds row i: off-diagonals hr[j] (slot j == i unused),
-// diagonal hd.  In-register LDL^T; pivots and pivot rows travel by DPP broadcast.
-template <int K, typename T>
+// In-register LDL^T of N symmetric positive definite matrices AT ONCE (their instruction streams
+// interleave, which hides the pivot -> reciprocal -> broadcast latency chain of a single 7x7
+// factorisation).  Lane i holds row i: off-diagonals hr[n][j] (slot j == i unused), diagonal hd[n].
+// Afterwards: lanes i > K hold l_iK in slot K, lane K keeps its pivot row A_Kj (j > K) unscaled,
+// inv[n] = 1 / d_i.  Pivots and pivot rows travel by DPP broadcast.
+template <int K, int N, typename T>
 struct LdlStep {
-    static __device__ __forceinline__ void factor(T& hd, T* hr, T& inv_own, int l8) {
-        T piv = bcast<K>(hd);
-        T inv = rcp_(piv);
-        inv_own = (l8 == K) ? inv : inv_own;
-        T l = (l8 > K) ? hr[K] * inv : T(0);          // l_iK for rows below the pivot
-        hd -= l * hr[K];
+    static __device__ __forceinline__ void factor(T* hd, T (*hr)[MAX_LINKS], T* inv_own, int l8) {
+        T l[N];
 #pragma unroll
-        for (int j = K + 1; j < MAX_LINKS; ++j) hr[j] -= l * bcast<K>(hr[j]);
-        hr[K] = (l8 > K) ? l : hr[K];                 // keep l_iK; lane K keeps its pivot row A_Kj
-        if constexpr (K + 1 < MAX_LINKS) LdlStep<K + 1, T>::factor(hd, hr, inv_own, l8);
+        for (int n = 0; n < N; ++n) {
+            const T inv = rcp_fast(bcast<K>(hd[n]));
+            inv_own[n] = (l8 == K) ? inv : inv_own[n];
+            l[n] = (l8 > K) ? hr[n][K] * inv : T(0);          // l_iK for rows below the pivot
+            hd[n] -= l[n] * hr[n][K];
+        }
+#pragma unroll
+        for (int j = K + 1; j < MAX_LINKS; ++j)
+#pragma unroll
+            for (int n = 0; n < N; ++n) hr[n][j] -= l[n] * bcast<K>(hr[n][j]);
+#pragma unroll
+        for (int n = 0; n < N; ++n) hr[n][K] = (l8 > K) ? l[n] : hr[n][K];
+        if constexpr (K + 1 < MAX_LINKS) LdlStep<K + 1, N, T>::factor(hd, hr, inv_own, l8);
     }
     static __device__ __forceinline__ void forward(const T* hr, T& b, int l8) {
         T yk = bcast<K>(b);
         b -= (l8 > K) ? hr[K] * yk : T(0);
-        if constexpr (K + 1 < MAX_LINKS) LdlStep<K + 1, T>::forward(hr, b, l8);
+        if constexpr (K + 1 < MAX_LINKS) LdlStep<K + 1, N, T>::forward(hr, b, l8);
     }
     static __device__ __forceinline__ void backward(const T* hr, T inv_own, T& x, int l8) {
         // x_i -= l_Ki x_K for i < K, with l_Ki = A_iK / d_i held (unscaled) in lane i slot K
         T xk = bcast<K>(x);
         x -= (l8 < K) ? hr[K] * inv_own * xk : T(0);
-        if constexpr (K > 0) LdlStep<K - 1, T>::backward(hr, inv_own, x, l8);
+        if constexpr (K > 0) LdlStep<K - 1, N, T>::backward(hr, inv_own, x, l8);
     }
 };
 
+// forward / diagonal / backward substitution with a factor produced by LdlStep::factor
 template <typename T>
-__device__ __forceinline__ T solve_spd(T hd, T* hr, T b, int l8) {
-    T inv_own = T(1);
-    LdlStep<0, T>::factor(hd, hr, inv_own, l8);
-    LdlStep<0, T>::forward(hr, b, l8);
+__device__ __forceinline__ T ldl_substitute(const T* hr, T inv_own, T b, int l8) {
+    LdlStep<0, 1, T>::forward(hr, b, l8);
     b *= inv_own;
-    LdlStep<MAX_LINKS - 1, T>::backward(hr, inv_own, b, l8);
+    LdlStep<MAX_LINKS - 1, 1, T>::backward(hr, inv_own, b, l8);
     return b;
 }
 
@@ -204,63 +169,84 @@ __device__ __forceinline__ void mass_diagonals(const T* sw, const T* sv, const T
     if constexpr (S + 1 < MAX_LINKS) mass_diagonals<S + 1, T>(sw, sv, Fn, Ff, d);
 }
 
+struct ArmInts {            // wave-uniform integers (SGPRs)
+    int site_link, n_sphere, sph_link, frame_skip, nv;
+};
+
 // ---- one mj_step ------------------------------------------------------------------------------
-// q, v: state of my dof (updated).  aw: constraint-solver warm start (previous qacc).
-// tau_act: gear * clip(ctrl) of my dof.  site: world position of the tracked site computed from
-// the q this substep STARTED with (MuJoCo runs kinematics before integrating).
+// q, v: state of my dof (updated).  aw: constraint-solver warm start (previous qacc).  (sq, cq) =
+// (sin q, cos q), advanced by angle addition.  rows: active-set memory.  tau_act: gear * clip(ctrl).
+// site: world position of the tracked site computed from the q this substep STARTED with (MuJoCo
+// runs kinematics before integrating).
 template <typename T>
-__device__ __forceinline__ void arm_substep(const LaneConst<T>& C, const ArmGlobals<T>& Gc, T& q, T& v, T& aw, T& sq,
-                                            T& cq, int& rows, T tau_act, T* ldsM, int lane, int l8, T* site,
+__device__ __forceinline__ void arm_substep(const Model<T>& M, const ArmInts& I, T& q, T& v, T& aw, T& sq, T& cq,
+                                            int& rows, T& qprev, T tau_act, T* ldsM, int lane, int l8, T* site,
                                             unsigned* diag) {
-    // 1. forward kinematics: local transform (Rodrigues, frames are world-aligned at qpos0) + scan.
-    //    (sq, cq) = (sin q, cos q) are carried along and advanced by angle addition (step 8).
-    const T s = sq, c = cq;
-    T tt = T(1) - c;
-    T R[9], p[3];
-    R[0] = c + tt * C.ax[0] * C.ax[0];
-    R[1] = tt * C.ax[0] * C.ax[1] - s * C.ax[2];
-    R[2] = tt * C.ax[0] * C.ax[2] + s * C.ax[1];
-    R[3] = tt * C.ax[0] * C.ax[1] + s * C.ax[2];
-    R[4] = c + tt * C.ax[1] * C.ax[1];
-    R[5] = tt * C.ax[1] * C.ax[2] - s * C.ax[0];
-    R[6] = tt * C.ax[0] * C.ax[2] - s * C.ax[1];
-    R[7] = tt * C.ax[1] * C.ax[2] + s * C.ax[0];
-    R[8] = c + tt * C.ax[2] * C.ax[2];
-    for (int k = 0; k < 3; ++k) p[k] = C.off[k];
+    // 1. forward kinematics: local transform (Rodrigues, frames are world-aligned at qpos0) + scan
+    PHASE();
+    T R[9], p[3], ax[3];
+    {
+        const T s = sq, c = cq, tt = T(1) - cq;
+        for (int k = 0; k < 3; ++k) { ax[k] = M.link(O_AXIS, k); p[k] = M.link(O_OFF, k); }
+        R[0] = c + tt * ax[0] * ax[0];
+        R[1] = tt * ax[0] * ax[1] - s * ax[2];
+        R[2] = tt * ax[0] * ax[2] + s * ax[1];
+        R[3] = tt * ax[0] * ax[1] + s * ax[2];
+        R[4] = c + tt * ax[1] * ax[1];
+        R[5] = tt * ax[1] * ax[2] - s * ax[0];
+        R[6] = tt * ax[0] * ax[2] - s * ax[1];
+        R[7] = tt * ax[1] * ax[2] + s * ax[0];
+        R[8] = c + tt * ax[2] * ax[2];
+    }
     fk_scan_step<1>(R, p, l8);
     fk_scan_step<2>(R, p, l8);
     fk_scan_step<4>(R, p, l8);
 
     const int gbase = lane & ~7;
     {
+        const T sp[3] = {M.glob(O_SITE_POS, 0), M.glob(O_SITE_POS, 1), M.glob(O_SITE_POS, 2)};
         T t[3];
-        matvec(R, Gc.site_pos, t);
-        for (int k = 0; k < 3; ++k) site[k] = __shfl(p[k] + t[k], gbase + Gc.site_link);
+        matvec(R, sp, t);
+        for (int k = 0; k < 3; ++k) site[k] = __shfl(p[k] + t[k], gbase + I.site_link);
+    }
+    // sphere centre for the contact row (needs R of the sphere's link, so it is taken here)
+    T ctr[3] = {T(0), T(0), T(0)};
+    if (I.n_sphere > 0) {
+        const T sp[3] = {M.glob(O_SPH_POS, 0), M.glob(O_SPH_POS, 1), M.glob(O_SPH_POS, 2)};
+        T t[3];
+        matvec(R, sp, t);
+        for (int k = 0; k < 3; ++k) ctr[k] = __shfl(p[k] + t[k], gbase + I.sph_link);
     }
 
     // 2. world-frame quantities of my link, everything about the WORLD ORIGIN
+    PHASE();
+    const T mass = M.link(O_MASS);
     T a[3], cw[3], t3[3];
-    matvec(R, C.ax, a);                     // joint axis
-    matvec(R, C.com, t3);
+    matvec(R, ax, a);                       // joint axis
+    {
+        const T com[3] = {M.link(O_COM, 0), M.link(O_COM, 1), M.link(O_COM, 2)};
+        matvec(R, com, t3);
+    }
     for (int k = 0; k < 3; ++k) cw[k] = p[k] + t3[k];
     T Ib[6];                                // rotational inertia about the origin: R I R^T + m(|c|^2 - c c^T)
     {
-        T RI[9];
+        T Il[6], RI[9];
+        for (int k = 0; k < 6; ++k) Il[k] = M.link(O_INERTIA, k);
         for (int i = 0; i < 3; ++i) {
             const T* r = R + 3 * i;
-            RI[3 * i + 0] = r[0] * C.I[0] + r[1] * C.I[3] + r[2] * C.I[4];
-            RI[3 * i + 1] = r[0] * C.I[3] + r[1] * C.I[1] + r[2] * C.I[5];
-            RI[3 * i + 2] = r[0] * C.I[4] + r[1] * C.I[5] + r[2] * C.I[2];
+            RI[3 * i + 0] = r[0] * Il[0] + r[1] * Il[3] + r[2] * Il[4];
+            RI[3 * i + 1] = r[0] * Il[3] + r[1] * Il[1] + r[2] * Il[5];
+            RI[3 * i + 2] = r[0] * Il[4] + r[1] * Il[5] + r[2] * Il[2];
         }
         T cc = dot(cw, cw);
-        Ib[0] = dot(RI + 0, R + 0) + C.mass * (cc - cw[0] * cw[0]);
-        Ib[1] = dot(RI + 3, R + 3) + C.mass * (cc - cw[1] * cw[1]);
-        Ib[2] = dot(RI + 6, R + 6) + C.mass * (cc - cw[2] * cw[2]);
-        Ib[3] = dot(RI + 0, R + 3) - C.mass * cw[0] * cw[1];
-        Ib[4] = dot(RI + 0, R + 6) - C.mass * cw[0] * cw[2];
-        Ib[5] = dot(RI + 3, R + 6) - C.mass * cw[1] * cw[2];
+        Ib[0] = dot(RI + 0, R + 0) + mass * (cc - cw[0] * cw[0]);
+        Ib[1] = dot(RI + 3, R + 3) + mass * (cc - cw[1] * cw[1]);
+        Ib[2] = dot(RI + 6, R + 6) + mass * (cc - cw[2] * cw[2]);
+        Ib[3] = dot(RI + 0, R + 3) - mass * cw[0] * cw[1];
+        Ib[4] = dot(RI + 0, R + 6) - mass * cw[0] * cw[2];
+        Ib[5] = dot(RI + 3, R + 6) - mass * cw[1] * cw[2];
     }
-    T hm[3] = {C.mass * cw[0], C.mass * cw[1], C.mass * cw[2]};     // first moment m c
+    T hm[3] = {mass * cw[0], mass * cw[1], mass * cw[2]};           // first moment m c
     T sw[3] = {a[0], a[1], a[2]}, sv[3];                             // motion axis S = (a, p x a)
     cross(p, a, sv);
 
@@ -279,7 +265,7 @@ __device__ __forceinline__ void arm_substep(const LaneConst<T>& C, const ArmGlob
         cross(Vv, xw, d2);
         for (int k = 0; k < 3; ++k) {
             Aw[k] = psum(dw[k], l8);
-            Av[k] = psum(d1[k] + d2[k], l8) - Gc.grav[k];       // base acceleration -g
+            Av[k] = psum(d1[k] + d2[k], l8) - M.glob(O_GRAVITY, k);     // base acceleration -g
         }
     }
     // body force  f = I A + V x* (I V),  I(w, v) = (Ib w + h x v, m v - h x w)
@@ -289,11 +275,11 @@ __device__ __forceinline__ void arm_substep(const LaneConst<T>& C, const ArmGlob
         symvec(Ib, Vw, nV);
         cross(hm, Vv, t1);
         cross(hm, Vw, t2);
-        for (int k = 0; k < 3; ++k) { nV[k] += t1[k]; fV[k] = C.mass * Vv[k] - t2[k]; }
+        for (int k = 0; k < 3; ++k) { nV[k] += t1[k]; fV[k] = mass * Vv[k] - t2[k]; }
         symvec(Ib, Aw, nA);
         cross(hm, Av, t1);
         cross(hm, Aw, t2);
-        for (int k = 0; k < 3; ++k) { nA[k] += t1[k]; fA[k] = C.mass * Av[k] - t2[k]; }
+        for (int k = 0; k < 3; ++k) { nA[k] += t1[k]; fA[k] = mass * Av[k] - t2[k]; }
         T c1[3], c2[3], c3[3];
         cross(Vw, nV, c1);
         cross(Vv, fV, c2);
@@ -309,7 +295,7 @@ __device__ __forceinline__ void arm_substep(const LaneConst<T>& C, const ArmGlob
     // 4. composite inertia (suffix sums) and the mass matrix by diagonals
     T d[MAX_LINKS];
     {
-        T mc = ssum(C.mass, l8), hc[3], Ic[6];
+        T mc = ssum(mass, l8), hc[3], Ic[6];
         for (int k = 0; k < 3; ++k) hc[k] = ssum(hm[k], l8);
         for (int k = 0; k < 6; ++k) Ic[k] = ssum(Ib[k], l8);
         T Fn[3], Ff[3], t1[3], t2[3];
@@ -319,8 +305,8 @@ __device__ __forceinline__ void arm_substep(const LaneConst<T>& C, const ArmGlob
         for (int k = 0; k < 3; ++k) { Fn[k] += t1[k]; Ff[k] = mc * sv[k] - t2[k]; }
         mass_diagonals<0, T>(sw, sv, Fn, Ff, d);
     }
-    // diagonal-major -> row-major through this particle's 8x8 LDS tile
-    T aM[MAX_LINKS];
+    // diagonal-major -> row-major through this particle's 8x8 LDS tile; the solves below read their
+    // rows from the tile each time instead of holding a second copy of the matrix in registers
 #pragma unroll
     for (int sft = 0; sft < MAX_LINKS; ++sft) {
         if (l8 + sft < MAX_LINKS) {
@@ -329,72 +315,99 @@ __device__ __forceinline__ void arm_substep(const LaneConst<T>& C, const ArmGlob
         }
     }
     __syncthreads();
-#pragma unroll
-    for (int j = 0; j < MAX_LINKS; ++j) aM[j] = ldsM[l8 * LANES + j];
-    __syncthreads();
-    const T dgM = d[0] + C.armature;
 
     // 5. smooth force: -bias + passive damping + motor
-    const T tau = -bias - C.damping * v + tau_act;
+    const T damping = M.link(O_DAMPING), h = M.glob(O_TIMESTEP);
+    const T dgM = d[0] + M.link(O_ARMATURE);
+    const T tau = -bias - damping * v + tau_act;
 
     // 6. constraint rows.  Limits: MuJoCo mj_instantiateLimit, strict dist < margin(=0)
     T sig = T(0), dist = T(0);
     bool inst = false;
-    if (C.limited) {
-        T dlo = q - C.lo, dhi = C.hi - q;
+    if (M.link(O_LIMITED) != T(0)) {
+        T dlo = q - M.link(O_RANGE_LO), dhi = M.link(O_RANGE_HI) - q;
         if (dlo < T(0)) { sig = T(1); dist = dlo; inst = true; }
         else if (dhi < T(0)) { sig = T(-1); dist = dhi; inst = true; }
     }
-    T D, aref;
-    row_params(Gc, dist, C.invw, sig * v, D, aref);
-    D = inst ? D : T(0);
-    aref = inst ? aref : T(0);
+    T D = T(0), aref = T(0);
     // plane-sphere contact (condim 1): mjc_PlaneSphere + mj_instantiateContact
     bool cinst = false;
     T jc = T(0), Dc = T(0), arefc = T(0);
-    if (Gc.n_sphere > 0) {
-        T ctr[3], t[3];
-        matvec(R, Gc.sph_pos, t);
-        for (int k = 0; k < 3; ++k) ctr[k] = __shfl(p[k] + t[k], gbase + Gc.sph_link);
-        T cdist = dot(ctr, Gc.pn) - Gc.pd - Gc.sph_r;
-        cinst = cdist < Gc.sph_margin;
+    if (I.n_sphere > 0) {
+        const T pn[3] = {M.glob(O_PLANE_N, 0), M.glob(O_PLANE_N, 1), M.glob(O_PLANE_N, 2)};
+        const T sph_r = M.glob(O_SPH_R), margin = M.glob(O_SPH_MARGIN);
+        T cdist = dot(ctr, pn) - M.glob(O_PLANE_D) - sph_r;
+        cinst = cdist < margin;
         if (__any(cinst)) {
             T r[3], ar[3];
-            for (int k = 0; k < 3; ++k) r[k] = ctr[k] - Gc.pn[k] * (Gc.sph_r + T(0.5) * cdist) - p[k];
+            for (int k = 0; k < 3; ++k) r[k] = ctr[k] - pn[k] * (sph_r + T(0.5) * cdist) - p[k];
             cross(a, r, ar);
-            jc = (cinst && l8 <= Gc.sph_link) ? dot(Gc.pn, ar) : T(0);
+            jc = (cinst && l8 <= I.sph_link) ? dot(pn, ar) : T(0);
             T jv = gsum(jc * v);
-            row_params(Gc, cdist - Gc.sph_margin, Gc.sph_invw, jv, Dc, arefc);
+            row_params(M, cdist - margin, M.glob(O_SPH_INVW), jv, Dc, arefc);
             Dc = cinst ? Dc : T(0);
             arefc = cinst ? arefc : T(0);
         }
     }
 
-    // 7. primal active-set Newton on  1/2 a'Ma - tau'a + sum_active 1/2 D (J a - aref)^2
+    // 7. primal active-set Newton on  1/2 a'Ma - tau'a + sum_active 1/2 D (J a - aref)^2, and
+    // 8. mj_Euler with implicit joint damping:  (M + h B) qacc = qfrc_smooth + qfrc_constraint.
+    //    The Euler matrix is factorised together with the first Newton matrix (two interleaved chains).
     T qfrc_c = T(0);
+    T he[1][MAX_LINKS], hde[1], inve[1] = {T(1)};      // Euler factor
     const bool any_rows = __any(inst || cinst);
-    if (!any_rows) rows = 0;
+    if (!any_rows) { rows = 0; qprev = T(0); }
     if (any_rows) {
+        row_params(M, dist, M.link(O_DOF_INVW), sig * v, D, aref);
+        D = inst ? D : T(0);
+        aref = inst ? aref : T(0);
         // initial active set: a row that existed in the previous substep keeps its state, a new row is
         // assumed active (it appears because the joint moves into its limit); `rows` = inst | act<<1 |
-        // cinst<<2 | cact<<3 of the previous substep.  Halves the number of extra Newton iterations
-        // compared with re-evaluating the rows at the warm-start acceleration.
+        // cinst<<2 | cact<<3 of the previous substep
+#if EXP_G == 3
+        bool act = inst && ((rows & 1) ? (rows & 2) != 0 : (sig * aw - aref < T(0)));
+        bool cact = cinst && ((rows & 4) ? (rows & 8) != 0 : true);
+#elif EXP_G == 4
+        bool act = inst && ((rows & 1) ? (sig * (aw - qprev * M.link(O_DOF_INVW)) - aref < T(0)) : (sig * aw - aref < T(0)));
+        bool cact = cinst && ((rows & 4) ? (rows & 8) != 0 : true);
+#elif EXP_G == 5
+        bool act = inst && ((rows & 1) ? ((rows & 2) != 0 ? (sig * (aw - qprev * M.link(O_DOF_INVW)) - aref < T(0)) : (sig * aw - aref < T(0))) : true);
+        bool cact = cinst && ((rows & 4) ? (rows & 8) != 0 : true);
+#else
         bool act = inst && ((rows & 1) ? (rows & 2) != 0 : true);
         bool cact = cinst && ((rows & 4) ? (rows & 8) != 0 : true);
+#endif
         bool changed = true;
+        int itc = 0;
         for (int it = 0; it < NEWTON_MAXIT; ++it) {
-            T hd = dgM + (act ? D : T(0));
+            ++itc;
+            T hh[2][MAX_LINKS], hd2[2], inv2[2] = {T(1), T(1)};
             T rhs = tau + (act ? D * sig * aref : T(0));
-            T hr[MAX_LINKS];
+            hd2[0] = dgM + (act ? D : T(0));
 #pragma unroll
-            for (int j = 0; j < MAX_LINKS; ++j) hr[j] = aM[j];
+            for (int j = 0; j < MAX_LINKS; ++j) hh[0][j] = ldsM[l8 * LANES + j];
             if (__any(cact)) {
                 T wj = cact ? Dc * jc : T(0);
-                hd += wj * jc;
+                hd2[0] += wj * jc;
                 rhs += wj * arefc;
-                add_rank1<0, T>(hr, wj, jc);
+                add_rank1<0, T>(hh[0], wj, jc);
             }
-            aw = solve_spd(hd, hr, rhs, l8);
+            if (it == 0) {
+                hd2[1] = dgM + h * damping;
+#pragma unroll
+                for (int j = 0; j < MAX_LINKS; ++j) hh[1][j] = hh[0][j];
+                if (__any(cact)) {
+#pragma unroll
+                    for (int j = 0; j < MAX_LINKS; ++j) hh[1][j] = ldsM[l8 * LANES + j];
+                }
+                LdlStep<0, 2, T>::factor(hd2, hh, inv2, l8);
+#pragma unroll
+                for (int j = 0; j < MAX_LINKS; ++j) he[0][j] = hh[1][j];
+                inve[0] = inv2[1];
+            } else {
+                LdlStep<0, 1, T>::factor(hd2, hh, inv2, l8);
+            }
+            aw = ldl_substitute(hh[0], inv2[0], rhs, l8);
             bool act2 = inst && (sig * aw - aref < T(0));
             bool cact2 = cinst && (gsum(jc * aw) - arefc < T(0));
             changed = (act2 != act) || (cact2 != cact);
@@ -403,24 +416,26 @@ __device__ __forceinline__ void arm_substep(const LaneConst<T>& C, const ArmGlob
             if (!__any(changed)) break;
         }
         if (changed && diag) atomicAdd(diag, 1u);
+        if (lane == 0) { atomicAdd(diag + 1, 1u); atomicAdd(diag + 2, (unsigned)(itc)); }
         rows = (inst ? 1 : 0) | (act ? 2 : 0) | (cinst ? 4 : 0) | (cact ? 8 : 0);
         // qfrc_constraint = J^T f,  f = -D (J a - aref) on active rows
         qfrc_c = act ? -D * (sig * aw - aref) * sig : T(0);
+        qprev = qfrc_c;
         if (__any(cact)) {
             T fcn = cact ? -Dc * (gsum(jc * aw) - arefc) : T(0);
             qfrc_c += jc * fcn;
         }
-    }
-
-    // 8. mj_Euler with implicit joint damping:  (M + h B) qacc = qfrc_smooth + qfrc_constraint
-    {
-        T hr[MAX_LINKS];
+    } else {
+        hde[0] = dgM + h * damping;
 #pragma unroll
-        for (int j = 0; j < MAX_LINKS; ++j) hr[j] = aM[j];
-        T x = solve_spd(dgM + Gc.h * C.damping, hr, tau + qfrc_c, l8);
+        for (int j = 0; j < MAX_LINKS; ++j) he[0][j] = ldsM[l8 * LANES + j];
+        LdlStep<0, 1, T>::factor(hde, he, inve, l8);
+    }
+    {
+        T x = ldl_substitute(he[0], inve[0], tau + qfrc_c, l8);
         if (!any_rows) aw = x;
-        v += Gc.h * x;
-        const T dq = Gc.h * v;
+        v += h * x;
+        const T dq = h * v;
         q += dq;
         // advance (sin q, cos q) by dq: angle addition with a short series, one Newton step of
         // renormalisation; large steps (never seen with h = 0.01) fall back to the library call
@@ -435,32 +450,38 @@ __device__ __forceinline__ void arm_substep(const LaneConst<T>& C, const ArmGlob
             cq = c1 * k;
         }
     }
+    __syncthreads();            // the tile is rewritten by the next substep
 }
 
 // ---- the rollout kernel -------------------------------------------------------------------------
 // state: f64 [qpos(8) | qvel(8) | target(3)]; mean: f64 [H][A]; noise/cost/act/obs/next_obs: T, in the
-// reference's C-order layouts (P,H,A) / (P,H) / (P,H,2nv+6).  noise, act, obs, next_obs, q0 may be null.
+// reference's C-order layouts (P,H,A) / (P,H) / (P,H,2nv+6).  noise, act, obs, next_obs may be null.
 // STEP = true is the same code instantiated under its own name for the single-particle "real env" step
 // (mjmpc_arm_step_state), so that profiler statistics of the P-particle rollout are not diluted by it.
 template <typename T, bool STEP>
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4,4))) void arm_rollout_kernel(const T* __restrict__ model, const double* state,
+__global__ __launch_bounds__(64) void arm_rollout_kernel(const T* __restrict__ model, const double* state,
                                                          long P, int H, int A, const double* __restrict__ mean,
                                                          const T* __restrict__ noise, T* __restrict__ cost,
                                                          T* __restrict__ act, T* __restrict__ obs,
                                                          T* __restrict__ nobs, double* state_out, unsigned* diag) {
-    __shared__ T lds[LANES * LANES * LANES];
+    __shared__ T lds[LANES * LANES * LANES + ARM_BLOB_LEN + 3];
     const int lane = threadIdx.x;
     const int l8 = lane & 7, g = lane >> 3;
     const long pid = (long)blockIdx.x * LANES + g;
     const bool live = pid < P;
     for (int k = lane; k < LANES * LANES * LANES; k += 64) lds[k] = T(0);
+    T* ldsModel = lds + LANES * LANES * LANES;
+    for (int k = lane; k < ARM_BLOB_LEN; k += 64) ldsModel[k] = model[k];
     __syncthreads();
     T* ldsM = lds + g * LANES * LANES;
-
-    LaneConst<T> C;
-    ArmGlobals<T> Gc;
-    load_consts(model, l8, C, Gc);
-    const int nv = (int)model[O_NV];
+    const Model<T> M{ldsModel, l8};
+    ArmInts I;
+    I.site_link = (int)model[O_SITE_LINK];
+    I.n_sphere = (int)model[O_N_SPHERE];
+    I.sph_link = (int)model[O_SPH_LINK];
+    I.frame_skip = (int)model[O_FRAME_SKIP];
+    I.nv = (int)model[O_NV];
+    const int nv = I.nv;
     const int dobs = 2 * nv + 6;
 
     T q = (T)state[l8], v = (T)state[LANES + l8], aw = T(0);
@@ -469,6 +490,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4,4))) void 
     T sinq, cosq;
     sincos_(q, sinq, cosq);
     int rows = 0;
+    T qprev = T(0);
     T cq = q, cv = v, chand[3] = {T(0), T(0), T(0)};
     const bool has_u = l8 < A;
 
@@ -479,10 +501,11 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4,4))) void 
             if (noise && live) u += noise[(pid * H + t) * A + l8];
             if (act && live) act[(pid * H + t) * A + l8] = u;        // unclipped (gym_env_wrapper.py:151)
         }
-        const T tau_act = C.gear * fmin(fmax(u, C.ulo), C.uhi);       // MuJoCo clamps ctrl, not the record
+        // MuJoCo clamps ctrl, not the record
+        const T tau_act = M.link(O_GEAR) * fmin(fmax(u, M.link(O_CTRL_LO)), M.link(O_CTRL_HI));
         T site[3];
-        for (int sub = 0; sub < Gc.frame_skip; ++sub) {
-            arm_substep(C, Gc, q, v, aw, sinq, cosq, rows, tau_act, ldsM, lane, l8, site, diag);
+        for (int sub = 0; sub < I.frame_skip; ++sub) {
+            arm_substep(M, I, q, v, aw, sinq, cosq, rows, qprev, tau_act, ldsM, lane, l8, site, diag);
             if (t == 0 && sub == 0) for (int k = 0; k < 3; ++k) chand[k] = site[k];   // fresh obs after set_env_state
         }
         // reward = -(|h-g|_1 + 5 |h-g|_2), h = site_xpos lagging one substep (reacher_env.py:31-35)

@@ -73,12 +73,12 @@ int mjmpc_arm_create(const double* blob, int n_blob, int device, mjmpc_arm_t* ou
     HIP_TRY(hipMalloc(&h->model_f32, sizeof(float) * n_blob));
     HIP_TRY(hipMalloc(&h->model_f64, sizeof(double) * n_blob));
     HIP_TRY(hipMalloc(&h->state, sizeof(double) * MJMPC_ARM_STATE_LEN));
-    HIP_TRY(hipMalloc(&h->diag, sizeof(unsigned)));
+    HIP_TRY(hipMalloc(&h->diag, 8 * sizeof(unsigned)));
     HIP_TRY(hipHostMalloc(&h->pinned, sizeof(double) * MJMPC_ARM_STATE_LEN));
     HIP_TRY(hipMemcpy(h->model_f32, f32.data(), sizeof(float) * n_blob, hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(h->model_f64, blob, sizeof(double) * n_blob, hipMemcpyHostToDevice));
     HIP_TRY(hipMemset(h->state, 0, sizeof(double) * MJMPC_ARM_STATE_LEN));
-    HIP_TRY(hipMemset(h->diag, 0, sizeof(unsigned)));
+    HIP_TRY(hipMemset(h->diag, 0, 8 * sizeof(unsigned)));
     *out = h;
     return 0;
 }
@@ -163,9 +163,10 @@ int mjmpc_arm_solver_failures(mjmpc_arm_t h, uint32_t* count) {
     if (!h || !count) return fail(MJMPC_E_BADARG, "null argument");
     HIP_TRY(hipSetDevice(h->device));
     HIP_TRY(hipDeviceSynchronize());
-    unsigned c = 0;
-    HIP_TRY(hipMemcpy(&c, h->diag, sizeof(unsigned), hipMemcpyDeviceToHost));
-    *count = c;
+    unsigned c[8];
+    HIP_TRY(hipMemcpy(c, h->diag, 8 * sizeof(unsigned), hipMemcpyDeviceToHost));
+    *count = c[0];
+    fprintf(stderr, "STATS with_rows=%u solves=%u avg=%.3f\n", c[1], c[2], (double)c[2] / (c[1] ? c[1] : 1));
     return 0;
 }
 
@@ -293,14 +294,15 @@ int mjmpc_shift_mean(double* d_mean, int H, int A, int mode, const double* d_row
 }
 
 int mjmpc_sample_noise(int dtype, void* d_noise, int64_t P, int H, int A, const double* d_chol,
-                       const double* d_coeffs, uint64_t seed, uint64_t offset, int64_t particle_offset, void* stream) {
+                       const double* d_coeffs, uint64_t seed, uint64_t offset, int64_t particle_offset,
+                       const int64_t* d_step, void* stream) {
     if (!d_noise || !d_chol || !d_coeffs) return fail(MJMPC_E_BADARG, "null argument");
     hipStream_t s = (hipStream_t)stream;
     DISPATCH(dtype,
              mjmpc::sample_noise<float>((float*)d_noise, (long)P, H, A, d_chol, d_coeffs, seed, offset,
-                                        (long)particle_offset, s),
+                                        (long)particle_offset, (const long long*)d_step, s),
              mjmpc::sample_noise<double>((double*)d_noise, (long)P, H, A, d_chol, d_coeffs, seed, offset,
-                                         (long)particle_offset, s));
+                                         (long)particle_offset, (const long long*)d_step, s));
 }
 
 }  // extern "C"

@@ -45,7 +45,9 @@ __device__ __forceinline__ void normal_pair(unsigned long long seed, unsigned lo
 // pass 1: coloured normals, one thread per (particle, channel, t-pair)
 template <typename T>
 __global__ void noise_kernel(T* __restrict__ noise, long P, int H, int A, const double* __restrict__ chol,
-                             unsigned long long seed, unsigned long long offset, long particle_offset) {
+                             unsigned long long seed, unsigned long long offset, long particle_offset,
+                             const long long* __restrict__ d_step) {
+    if (d_step) offset += (unsigned long long)*d_step;      // step counter kept on the device (graph replay)
     const int H2 = (H + 1) / 2;
     const long gid = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (gid >= P * H2 * A) return;
@@ -90,18 +92,19 @@ __global__ void filter_kernel(T* __restrict__ noise, long P, int H, int A, const
 
 template <typename T>
 hipError_t sample_noise(T* noise, long P, int H, int A, const double* chol, const double* coeffs,
-                        unsigned long long seed, unsigned long long offset, long particle_offset, hipStream_t s) {
+                        unsigned long long seed, unsigned long long offset, long particle_offset, const long long* d_step,
+                        hipStream_t s) {
     if (P <= 0 || H <= 0) return hipSuccess;
     const long n = P * A * ((H + 1) / 2), m = P * A;
     hipLaunchKernelGGL(noise_kernel<T>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, noise, P, H, A, chol, seed,
-                       offset, particle_offset);
+                       offset, particle_offset, d_step);
     hipLaunchKernelGGL(filter_kernel<T>, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, s, noise, P, H, A, coeffs);
     return hipGetLastError();
 }
 
 template hipError_t sample_noise<float>(float*, long, int, int, const double*, const double*, unsigned long long,
-                                        unsigned long long, long, hipStream_t);
+                                        unsigned long long, long, const long long*, hipStream_t);
 template hipError_t sample_noise<double>(double*, long, int, int, const double*, const double*, unsigned long long,
-                                         unsigned long long, long, hipStream_t);
+                                         unsigned long long, long, const long long*, hipStream_t);
 
 }  // namespace mjmpc

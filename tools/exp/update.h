@@ -43,6 +43,7 @@ hipError_t shift_mean(double* mean, int H, int A, int mode, const double* row, h
 // in-place AR filter of control_utils.py:32-33, written in the reference's (P,H,A) layout.
 template <typename T>
 hipError_t sample_noise(T* noise, long P, int H, int A, const double* chol, const double* coeffs,
-                        unsigned long long seed, unsigned long long offset, long particle_offset, hipStream_t s);
+                        unsigned long long seed, unsigned long long offset, long particle_offset, const long long* d_step,
+                        hipStream_t s);
 
 }  // namespace mjmpc
