@@ -95,6 +95,17 @@ int mjmpc_arm_rollout_fused(mjmpc_arm_t h, int dtype, int64_t P, int H, const do
 int mjmpc_arm_step_state(mjmpc_arm_t h, int dtype, const double* d_action, void* d_cost, void* d_next_obs,
                          void* stream);
 
+/* rollout_fn over the reference's two analytic numpy envs (stateless; every pointer is a device
+ * pointer): kind 0 = PendulumEnv (mjmpc/envs/basic/pendulum.py:33-50; d_params = [max_speed,
+ * max_torque, dt, g, m, l], d_state = [th, thdot], observations have 3 entries), kind 1 = LQREnv
+ * (mjmpc/envs/basic/lqr.py:31-35; d_params = [A | B | Q | R] row-major, d_state = x[n_state],
+ * n_state, n_action <= 8).  Arrays as in mjmpc_arm_rollout (costs = -reward).                     */
+#define MJMPC_ENV_PENDULUM 0
+#define MJMPC_ENV_LQR 1
+int mjmpc_analytic_rollout(int kind, const double* d_params, int n_state, int n_action, const double* d_state, int dtype,
+                           int64_t P, int H, const double* d_mean, const void* d_noise, void* d_costs, void* d_actions,
+                           void* d_obs, void* d_next_obs, void* stream);
+
 /* Number of (particle, substep) constraint solves whose active set had not settled after the
  * iteration cap since engine creation (synchronises the device).  0 in every test.               */
 int mjmpc_arm_solver_failures(mjmpc_arm_t h, uint32_t* count);

@@ -8,6 +8,7 @@
 
 #include "../../include/mjmpc_amd.h"
 #include "arm_model.h"
+#include "analytic_rollout.h"
 #include "arm_rollout.h"
 #include "update.h"
 
@@ -193,6 +194,26 @@ int mjmpc_arm_solver_failures(mjmpc_arm_t h, uint32_t* count) {
     unsigned c = 0;
     HIP_TRY(hipMemcpy(&c, h->diag, sizeof(unsigned), hipMemcpyDeviceToHost));
     *count = c;
+    return 0;
+}
+
+int mjmpc_analytic_rollout(int kind, const double* d_params, int n_state, int n_action, const double* d_state, int dtype,
+                           int64_t P, int H, const double* d_mean, const void* d_noise, void* d_costs, void* d_actions,
+                           void* d_obs, void* d_next_obs, void* stream) {
+    if (!d_params || !d_state || !d_mean || !d_costs) return fail(MJMPC_E_BADARG, "null argument");
+    hipStream_t s = (hipStream_t)stream;
+    hipError_t e;
+    if (dtype == MJMPC_F32)
+        e = mjmpc::launch_analytic_rollout<float>(kind, d_params, n_state, n_action, d_state, (long)P, H, d_mean,
+                                                  (const float*)d_noise, (float*)d_costs, (float*)d_actions,
+                                                  (float*)d_obs, (float*)d_next_obs, s);
+    else if (dtype == MJMPC_F64)
+        e = mjmpc::launch_analytic_rollout<double>(kind, d_params, n_state, n_action, d_state, (long)P, H, d_mean,
+                                                   (const double*)d_noise, (double*)d_costs, (double*)d_actions,
+                                                   (double*)d_obs, (double*)d_next_obs, s);
+    else
+        return fail(MJMPC_E_BADARG, "unknown dtype %d", dtype);
+    if (e != hipSuccess) return hip_fail(e, "analytic rollout launch");
     return 0;
 }
 
