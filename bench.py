@@ -164,6 +164,14 @@ def main():
     dist_to_target = float(torch.linalg.norm(nobs[17:20]).item())
     fails = eng.solver_failures()
 
+    # HBM bytes of one launch of the dominant kernel from the PMC counters (separate rocprofv3 passes,
+    # FETCH_SIZE x2 on gfx950, calibrated on a known copy): measured offline, kept under profiles/
+    traffic = None
+    tpath = os.path.join(ROOT, "profiles", "r01_traffic_%s_%dx%d.json" % (args.dtype, P_loc, H))
+    if os.path.exists(tpath):
+        with open(tpath) as f:
+            traffic = json.load(f)["traffic_bytes_per_launch"]
+
     psteps = P_tot * H * ctrl.n_iters * args.steps
     s = 8 if args.dtype == "f64" else 4
     b_alg = (3 * A + 2) * s                       # delta in, action + cost out, action + cost re-read
@@ -179,7 +187,8 @@ def main():
                    "launch": "hipGraph replay" if graphed else "eager"},
         "control_loop_hz": args.steps / dt,
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                     "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                     "alg_bytes_per_launch": b_alg * P_loc * H,
                      "kernel": "arm_rollout_kernel<%s>" % ("double" if args.dtype == "f64" else "float"),
                      "kernel_ms": kern_ms, "alg_bytes_per_particle_step": b_alg,
                      "note": "latency/VALU-bound path (SURVEY 8d): ~100+ FLOP per byte, HBM fraction is small by construction"},
