@@ -69,8 +69,8 @@ __device__ __forceinline__ void symvec(const T* S, const T* x, T* y) {
 template <int S, typename T>
 __device__ __forceinline__ void fk_scan_step(T* R, T* p, int l8) {
     T Ra[9], pa[3], Rn[9], t[3];
-    for (int k = 0; k < 9; ++k) Ra[k] = shr<S>(R[k], (k % 4 == 0) ? T(1) : T(0), l8);
-    for (int k = 0; k < 3; ++k) pa[k] = shr<S>(p[k], T(0), l8);
+    for (int k = 0; k < 9; ++k) Ra[k] = (k % 4 == 0) ? shr<S>(R[k], T(1), l8) : shr0<S>(R[k], l8);
+    for (int k = 0; k < 3; ++k) pa[k] = shr0<S>(p[k], l8);
     for (int i = 0; i < 3; ++i)
         for (int j = 0; j < 3; ++j)
             Rn[3 * i + j] = Ra[3 * i] * R[j] + Ra[3 * i + 1] * R[3 + j] + Ra[3 * i + 2] * R[6 + j];
@@ -202,12 +202,11 @@ __device__ __forceinline__ void arm_substep(const Model<T>& M, const ArmInts& I,
     fk_scan_step<2>(R, p, l8);
     fk_scan_step<4>(R, p, l8);
 
-    const int gbase = lane & ~7;
     {
         const T sp[3] = {M.glob(O_SITE_POS, 0), M.glob(O_SITE_POS, 1), M.glob(O_SITE_POS, 2)};
         T t[3];
         matvec(R, sp, t);
-        for (int k = 0; k < 3; ++k) site[k] = __shfl(p[k] + t[k], gbase + I.site_link);
+        for (int k = 0; k < 3; ++k) site[k] = __shfl(p[k] + t[k], lane_of_link(lane, I.site_link));
     }
     // sphere centre for the contact row (needs R of the sphere's link, so it is taken here)
     T ctr[3] = {T(0), T(0), T(0)};
@@ -215,7 +214,7 @@ __device__ __forceinline__ void arm_substep(const Model<T>& M, const ArmInts& I,
         const T sp[3] = {M.glob(O_SPH_POS, 0), M.glob(O_SPH_POS, 1), M.glob(O_SPH_POS, 2)};
         T t[3];
         matvec(R, sp, t);
-        for (int k = 0; k < 3; ++k) ctr[k] = __shfl(p[k] + t[k], gbase + I.sph_link);
+        for (int k = 0; k < 3; ++k) ctr[k] = __shfl(p[k] + t[k], lane_of_link(lane, I.sph_link));
     }
 
     // 2. world-frame quantities of my link, everything about the WORLD ORIGIN
@@ -452,7 +451,7 @@ __global__ __launch_bounds__(64) void arm_rollout_kernel(const T* __restrict__ m
                                                          RolloutFusion fuse) {
     __shared__ T lds[LANES * LANES * LANES + ARM_BLOB_LEN + 3];
     const int lane = threadIdx.x;
-    const int l8 = lane & 7, g = lane >> 3;
+    const int l8 = lane_link(lane), g = lane_slot(lane);
     const long pid = (long)blockIdx.x * LANES + g;
     const bool live = pid < P;
     for (int k = lane; k < LANES * LANES * LANES; k += 64) lds[k] = T(0);

@@ -1,10 +1,8 @@
 // Cross-lane primitives for 8-lane particle groups on CDNA4 (wave64).
 //
-// One particle = 8 consecutive lanes (lane l8 = link index), 8 particles per wavefront.  A DPP
-// "row" is 16 lanes = two particles, so every shift has to stop at the 8-lane group boundary:
-// shifts by 4 do it with the DPP bank mask alone (banks are 4 lanes), shifts by 1/2/3 with one
-// extra v_cndmask.  Broadcasts are a quad_perm plus one bank-masked row shift; the 8-lane sum
-// is row_half_mirror + two quad_perm butterflies.  No LDS traffic, no ds_bpermute.
+// One particle = 8 lanes (one per link, link 7 a spare), 8 particles per wavefront, everything by DPP:
+// row shifts for the scans along the kinematic chain, quad_perm + bank-masked shifts for broadcasts,
+// rotations for the 8-lane sum.  No LDS traffic, no ds_bpermute.
 #pragma once
 #include <hip/hip_runtime.h>
 
@@ -33,6 +31,82 @@ __device__ __forceinline__ double dpp_all(double x) {
     return __hiloint2double(hi, lo);
 }
 
+// ---------------------------------------------------------------------------------------------------
+// Lane layout.  A DPP row is 16 lanes = two particles.  Two ways to place them:
+//   BLOCKED      lane = 8 * particle + link      (links of a particle are adjacent lanes)
+//   INTERLEAVED  lane = 2 * link + particle      (the two particles of a row alternate)
+// With the interleaved layout a shift by S links is a row shift by 2S lanes, which never crosses from
+// one particle into the other and falls off the END OF THE ROW exactly at the chain boundary: DPP's own
+// bound_ctrl (zero) / `old` (fill) semantics do the masking, so scans need no v_cndmask and - in f32 -
+// fold into a single v_add_f32_dpp.  The price is one more DPP per broadcast (three instead of two).
+#ifndef MJMPC_INTERLEAVED
+#define MJMPC_INTERLEAVED 1
+#endif
+
+// zero-filling DPP (bound_ctrl): lanes whose source falls outside the row read 0
+template <int CTRL>
+__device__ __forceinline__ float dpp_zero(float x) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), CTRL, 0xF, 0xF, true));
+}
+template <int CTRL>
+__device__ __forceinline__ double dpp_zero(double x) {
+    int lo = __builtin_amdgcn_update_dpp(0, __double2loint(x), CTRL, 0xF, 0xF, true);
+    int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(x), CTRL, 0xF, 0xF, true);
+    return __hiloint2double(hi, lo);
+}
+
+#if MJMPC_INTERLEAVED
+
+__device__ __forceinline__ int lane_link(int lane) { return (lane >> 1) & 7; }
+__device__ __forceinline__ int lane_slot(int lane) { return ((lane >> 4) << 1) | (lane & 1); }
+// wave lane holding `link` of the same particle as `lane`
+__device__ __forceinline__ int lane_of_link(int lane, int link) { return (lane & 0x31) | (link << 1); }
+
+// lane(link i) <- x[link i - S], `fill` where i < S
+template <int S, typename T>
+__device__ __forceinline__ T shr(T x, T fill, int) {
+    return dpp<0x110 + 2 * S, 0xF>(fill, x);
+}
+template <int S, typename T>
+__device__ __forceinline__ T shl(T x, T fill, int) {
+    return dpp<0x100 + 2 * S, 0xF>(fill, x);
+}
+template <int S, typename T>
+__device__ __forceinline__ T shr0(T x, int) { return dpp_zero<0x110 + 2 * S>(x); }
+template <int S, typename T>
+__device__ __forceinline__ T shl0(T x, int) { return dpp_zero<0x100 + 2 * S>(x); }
+// row_shl by S links; lanes past the end of the chain read 0
+template <int S, typename T>
+__device__ __forceinline__ T shl_raw(T x) { return dpp_zero<0x100 + 2 * S>(x); }
+
+// every lane of the particle <- x[link K]: pair-broadcast inside the quad holding links {2q, 2q+1}, then
+// copy that quad over the row with two bank-masked shifts
+template <int K, typename T>
+__device__ __forceinline__ T bcast(T x) {
+    constexpr int s = 2 * (K & 1);
+    constexpr int QP = s | ((s + 1) << 2) | (s << 4) | ((s + 1) << 6);
+    constexpr int Q = K >> 1;
+    T t = dpp_all<QP>(x);
+    if constexpr (Q == 0) { t = dpp<0x114, 0x2>(t, t); return dpp<0x118, 0xC>(t, t); }
+    else if constexpr (Q == 1) { t = dpp<0x104, 0x1>(t, t); return dpp<0x118, 0xC>(t, t); }
+    else if constexpr (Q == 2) { t = dpp<0x114, 0x8>(t, t); return dpp<0x108, 0x3>(t, t); }
+    else { t = dpp<0x104, 0x4>(t, t); return dpp<0x108, 0x3>(t, t); }
+}
+// sum over the 8 links of the particle, result in every lane
+template <typename T>
+__device__ __forceinline__ T gsum(T x) {
+    x += dpp_all<0x4E>(x);                          // quad_perm [2,3,0,1]: the other link of the quad
+    x += dpp_all<0x124>(x);                         // row_ror:4
+    x += dpp_all<0x128>(x);                         // row_ror:8
+    return x;
+}
+
+#else  // ---------------------------------------------------------------------------- BLOCKED layout
+
+__device__ __forceinline__ int lane_link(int lane) { return lane & 7; }
+__device__ __forceinline__ int lane_slot(int lane) { return lane >> 3; }
+__device__ __forceinline__ int lane_of_link(int lane, int link) { return (lane & ~7) | link; }
+
 // lane i <- x[i - S] inside the group, `fill` where i < S          (row_shr)
 template <int S, typename T>
 __device__ __forceinline__ T shr(T x, T fill, int l8) {
@@ -53,6 +127,10 @@ __device__ __forceinline__ T shl(T x, T fill, int l8) {
         return l8 + S < 8 ? t : fill;
     }
 }
+template <int S, typename T>
+__device__ __forceinline__ T shr0(T x, int l8) { return shr<S>(x, T(0), l8); }
+template <int S, typename T>
+__device__ __forceinline__ T shl0(T x, int l8) { return shl<S>(x, T(0), l8); }
 // unmasked row_shl: lanes with i + S > 7 receive another particle's data - caller discards them
 template <int S, typename T>
 __device__ __forceinline__ T shl_raw(T x) {
@@ -75,19 +153,22 @@ __device__ __forceinline__ T gsum(T x) {
     x += dpp_all<0x4E>(x);                          // quad_perm [2,3,0,1]
     return x;
 }
-// inclusive prefix / suffix sums over the group
+
+#endif
+
+// inclusive prefix / suffix sums over the links of a particle
 template <typename T>
 __device__ __forceinline__ T psum(T x, int l8) {
-    x += shr<1>(x, T(0), l8);
-    x += shr<2>(x, T(0), l8);
-    x += shr<4>(x, T(0), l8);
+    x += shr0<1>(x, l8);
+    x += shr0<2>(x, l8);
+    x += shr0<4>(x, l8);
     return x;
 }
 template <typename T>
 __device__ __forceinline__ T ssum(T x, int l8) {
-    x += shl<1>(x, T(0), l8);
-    x += shl<2>(x, T(0), l8);
-    x += shl<4>(x, T(0), l8);
+    x += shl0<1>(x, l8);
+    x += shl0<2>(x, l8);
+    x += shl0<4>(x, l8);
     return x;
 }
 
