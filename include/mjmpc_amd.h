@@ -78,6 +78,12 @@ double* mjmpc_arm_state_ptr(mjmpc_arm_t h);
 int mjmpc_arm_rollout(mjmpc_arm_t h, int dtype, int64_t P, int H, const double* d_mean, const void* d_noise,
                       void* d_costs, void* d_actions, void* d_obs, void* d_next_obs, void* stream);
 
+/* rollout_fn with mode="closed_loop_linear" (gym_env_wrapper.py:135-136): the nominal action of every
+ * step is d_weights^T [obs; 1], obs being the observation before the step; d_weights is float64
+ * [(2nv+7)][A] (the reference's `mean` argument in that mode).  Other arrays as in mjmpc_arm_rollout. */
+int mjmpc_arm_rollout_cl(mjmpc_arm_t h, int dtype, int64_t P, int H, const double* d_weights, const void* d_noise,
+                         void* d_costs, void* d_actions, void* d_obs, void* d_next_obs, void* stream);
+
 /* The same rollout with two optional fusions for a device-resident control iteration:
  *   d_filter_coeffs float64[3] or NULL: d_noise holds RAW samples and the recursive filter of
  *                   control_utils.generate_noise (control_utils.py:32-33) is applied inside the kernel;

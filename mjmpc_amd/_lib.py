@@ -27,6 +27,7 @@ SIGNATURES = {
     "mjmpc_arm_set_state": (_int, [_vp, _dp, _dp, _dp, _vp]),
     "mjmpc_arm_state_ptr": (_vp, [_vp]),
     "mjmpc_arm_rollout": (_int, [_vp, _int, _i64, _int, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "mjmpc_arm_rollout_cl": (_int, [_vp, _int, _i64, _int, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "mjmpc_arm_rollout_fused": (_int, [_vp, _int, _i64, _int, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "mjmpc_arm_step_state": (_int, [_vp, _int, _vp, _vp, _vp, _vp]),
     "mjmpc_analytic_rollout": (_int, [_int, _vp, _int, _int, _vp, _int, _i64, _int, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),

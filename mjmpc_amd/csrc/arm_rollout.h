@@ -7,7 +7,10 @@ namespace mjmpc {
 //   filt    float64[3]  apply the recursive noise filter of control_utils.py:32-33 to `noise` on the fly
 //                       (then `noise` holds the raw, unfiltered samples)
 //   gseq    float64[H]  with q0_out: q0_out[p] = sum_t gseq[t] * cost[p][t]  (= cost_to_go(...)[:,0])
+//   clw     float64[(2nv+7)][A]  mode "closed_loop_linear" (gym_env_wrapper.py:135-136): the nominal action of
+//                       a step is clw^T [obs; 1] with obs the observation BEFORE the step; `mean` is ignored
 struct RolloutFusion {
+    const double* clw = nullptr;
     const double* filt = nullptr;
     const double* gseq = nullptr;
     double* q0_out = nullptr;

@@ -154,6 +154,14 @@ __device__ __forceinline__ void add_rank1(T* hr, T wj, T jc) {
     if constexpr (J + 1 < MAX_LINKS) add_rank1<J + 1, T>(hr, wj, jc);
 }
 
+// u_i += sum_k W[k][i] q_k + W[nv+k][i] v_k   (the joint part of clw^T obs), link values by DPP broadcast
+template <int K, typename T>
+__device__ __forceinline__ void cl_accumulate(const double* __restrict__ W, int A, int nv, int l8, T cq, T cv, double& u) {
+    const double qk = (double)bcast<K>(cq), vk = (double)bcast<K>(cv);
+    if (K < nv) u += W[K * A + l8] * qk + W[(nv + K) * A + l8] * vk;
+    if constexpr (K + 1 < MAX_LINKS) cl_accumulate<K + 1, T>(W, A, nv, l8, cq, cv, u);
+}
+
 template <int S, typename T>
 __device__ __forceinline__ void mass_diagonals(const T* sw, const T* sv, const T* Fn, const T* Ff, T* d) {
     if constexpr (S == 0) {
@@ -480,10 +488,29 @@ __global__ __launch_bounds__(64) void arm_rollout_kernel(const T* __restrict__ m
     double fb0 = 1.0, fb1 = 0.0, fb2 = 0.0, e1 = 0.0, e2 = 0.0, q0acc = 0.0;
     if (fuse.filt) { fb0 = fuse.filt[0]; fb1 = fuse.filt[1]; fb2 = fuse.filt[2]; }
 
+    // fresh observation after set_env_state (sim.forward()): the site position at the start state is
+    // needed BEFORE the first step when the policy is closed-loop; one extra kinematics pass provides it
+    if (fuse.clw) {
+        T qq = q, vv = v, aa = aw, ss = sinq, cc = cosq;
+        int rr = 0;
+        T s0[3];
+        arm_substep(M, I, qq, vv, aa, ss, cc, rr, T(0), ldsM, lane, l8, s0, (unsigned*)nullptr);
+        for (int k = 0; k < 3; ++k) chand[k] = s0[k];
+    }
+
     for (int t = 0; t < H; ++t) {
         T u = T(0);
+        if (fuse.clw) {             // u = clw^T [q, v, hand, hand - target, 1]
+            const int wl = has_u ? l8 : 0;
+            double uu = fuse.clw[(2 * nv + 6) * A + wl];
+            cl_accumulate<0, T>(fuse.clw, A, nv, wl, cq, cv, uu);
+            for (int k = 0; k < 3; ++k)
+                uu += fuse.clw[(2 * nv + k) * A + wl] * (double)chand[k] +
+                      fuse.clw[(2 * nv + 3 + k) * A + wl] * (double)(chand[k] - tgt[k]);
+            u = has_u ? (T)uu : T(0);
+        }
         if (has_u) {
-            u = (T)mean[t * A + l8];
+            if (!fuse.clw) u = (T)mean[t * A + l8];
             if (noise && live) {
                 T eps = noise[(pid * H + t) * A + l8];
                 if (fuse.filt) {            // eps[t] = b0 eps[t] + b1 eps[t-1] + b2 eps[t-2], t >= 2

@@ -142,6 +142,29 @@ int mjmpc_arm_rollout(mjmpc_arm_t h, int dtype, int64_t P, int H, const double* 
     return 0;
 }
 
+int mjmpc_arm_rollout_cl(mjmpc_arm_t h, int dtype, int64_t P, int H, const double* d_weights, const void* d_noise,
+                         void* d_costs, void* d_actions, void* d_obs, void* d_next_obs, void* stream) {
+    if (!h || !d_weights || !d_costs) return fail(MJMPC_E_BADARG, "null argument");
+    if (P < 0 || H < 0) return fail(MJMPC_E_BADARG, "negative size");
+    HIP_TRY(hipSetDevice(h->device));
+    hipStream_t s = (hipStream_t)stream;
+    mjmpc::RolloutFusion fuse;
+    fuse.clw = d_weights;
+    hipError_t e;
+    if (dtype == MJMPC_F32)
+        e = mjmpc::launch_arm_rollout<float>(h->model_f32, h->state, (long)P, H, h->nu, d_weights, (const float*)d_noise,
+                                             (float*)d_costs, (float*)d_actions, (float*)d_obs, (float*)d_next_obs,
+                                             nullptr, h->diag, s, fuse);
+    else if (dtype == MJMPC_F64)
+        e = mjmpc::launch_arm_rollout<double>(h->model_f64, h->state, (long)P, H, h->nu, d_weights,
+                                              (const double*)d_noise, (double*)d_costs, (double*)d_actions,
+                                              (double*)d_obs, (double*)d_next_obs, nullptr, h->diag, s, fuse);
+    else
+        return fail(MJMPC_E_BADARG, "unknown dtype %d", dtype);
+    if (e != hipSuccess) return hip_fail(e, "arm_rollout_cl launch");
+    return 0;
+}
+
 int mjmpc_arm_rollout_fused(mjmpc_arm_t h, int dtype, int64_t P, int H, const double* d_mean, const void* d_noise,
                             const double* d_filter_coeffs, const double* d_gseq, void* d_costs, void* d_actions,
                             double* d_q0, void* stream) {

@@ -39,6 +39,7 @@ def _lib():
         L.or_step.argtypes = [ctypes.c_void_p, _dp, _dp, _dp, _dp, _dp]
         L.or_rollout.argtypes = [ctypes.c_void_p, _dp, _dp, _dp, ctypes.c_long, ctypes.c_int,
                                  _dp, _dp, _dp, _dp, _dp, _dp, _dp]
+        L.or_rollout_cl.argtypes = L.or_rollout.argtypes
         _LIB = L
     return _LIB
 
@@ -122,10 +123,14 @@ class RefArm:
         r = self._L.or_env_step(self._h, _p(q), _p(v), _p(_c(u)), _p(_c(target)), _p(obs))
         return q, v, r, obs
 
-    def rollout(self, qp0, qv0, target, mean, noise, want_obs=True):
-        """GymEnvWrapper.rollout(mode='open_loop') -> (obs, rew, act, done, next_obs)."""
+    def rollout(self, qp0, qv0, target, mean, noise, want_obs=True, mode="open_loop", horizon=None):
+        """GymEnvWrapper.rollout -> (obs, rew, act, done, next_obs).  mode 'closed_loop_linear': ``mean``
+        is the (d_obs+1, nu) weight matrix and ``horizon`` must be given when ``noise`` is None."""
         mean = _c(mean)
-        H, nu = mean.shape
+        closed = mode == "closed_loop_linear"
+        H, nu = (horizon, mean.shape[1]) if closed else mean.shape
+        if closed and noise is not None:
+            H = noise.shape[1]
         if noise is not None:
             noise = _c(noise)
             P = noise.shape[0]
@@ -137,6 +142,7 @@ class RefArm:
         done = np.zeros((P, H))
         obs = np.zeros((P, H, self.d_obs)) if want_obs else None
         nobs = np.zeros((P, H, self.d_obs)) if want_obs else None
-        self._L.or_rollout(self._h, _p(_c(qp0)), _p(_c(qv0)), _p(_c(target)), P, H,
-                           _p(mean), _p(noise), _p(obs), _p(rew), _p(act), _p(done), _p(nobs))
+        fn = self._L.or_rollout_cl if closed else self._L.or_rollout
+        fn(self._h, _p(_c(qp0)), _p(_c(qv0)), _p(_c(target)), P, H,
+           _p(mean), _p(noise), _p(obs), _p(rew), _p(act), _p(done), _p(nobs))
         return obs, rew, act, done, nobs

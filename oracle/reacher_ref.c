@@ -714,9 +714,27 @@ double or_env_step(OrModel *m, double *q, double *v, const double *u, const doub
  * set_env_state (which ends with sim.forward(), reacher_env.py:99); act is the UNCLIPPED
  * mean + noise (gym_env_wrapper.py:151); done is always False (reacher_env.py:39).
  * Any of obs / next_obs / act / done may be NULL.  OpenMP over particles. */
+static void rollout_impl(OrModel *m, const double *qp0, const double *qv0, const double *target, long P, int H,
+                         const double *mean, const double *noise, double *obs, double *rew, double *act,
+                         double *done, double *next_obs, int closed_loop);
+
 void or_rollout(OrModel *m, const double *qp0, const double *qv0, const double *target, long P, int H,
                 const double *mean, const double *noise, double *obs, double *rew, double *act,
                 double *done, double *next_obs) {
+    rollout_impl(m, qp0, qv0, target, P, H, mean, noise, obs, rew, act, done, next_obs, 0);
+}
+
+/* mode "closed_loop_linear" (gym_env_wrapper.py:135-136): mean is a (d_obs+1) x nu weight matrix and
+ * the nominal action of a step is mean.T @ append(curr_obs, 1.0) */
+void or_rollout_cl(OrModel *m, const double *qp0, const double *qv0, const double *target, long P, int H,
+                   const double *weights, const double *noise, double *obs, double *rew, double *act,
+                   double *done, double *next_obs) {
+    rollout_impl(m, qp0, qv0, target, P, H, weights, noise, obs, rew, act, done, next_obs, 1);
+}
+
+static void rollout_impl(OrModel *m, const double *qp0, const double *qv0, const double *target, long P, int H,
+                         const double *mean, const double *noise, double *obs, double *rew, double *act,
+                         double *done, double *next_obs, int closed_loop) {
     int nv = m->nv, nu = m->nu, dobs = 2 * nv + 6;
     double h0[3];
     or_site(m, qp0, h0);
@@ -732,7 +750,16 @@ void or_rollout(OrModel *m, const double *qp0, const double *qv0, const double *
         memcpy(cur + nv, v, sizeof(double) * nv);
         for (int i = 0; i < 3; i++) { cur[2 * nv + i] = h0[i]; cur[2 * nv + 3 + i] = h0[i] - target[i]; }
         for (int t = 0; t < H; t++) {
-            for (int a = 0; a < nu; a++) u[a] = mean[t * nu + a] + (noise ? noise[(b * H + t) * nu + a] : 0.0);
+            for (int a = 0; a < nu; a++) {
+                double ma;
+                if (closed_loop) {
+                    ma = mean[dobs * nu + a];
+                    for (int k = 0; k < dobs; k++) ma += mean[k * nu + a] * cur[k];
+                } else {
+                    ma = mean[t * nu + a];
+                }
+                u[a] = ma + (noise ? noise[(b * H + t) * nu + a] : 0.0);
+            }
             double r = env_step(&loc, q, v, u, target, nxt);
             long o = (b * H + t);
             if (obs) memcpy(obs + o * dobs, cur, sizeof(double) * dobs);

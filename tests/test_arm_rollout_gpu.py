@@ -86,7 +86,7 @@ def test_mean_only_and_tiny_shapes(engines, ref_arm):
     np.testing.assert_allclose(rew, o[1], rtol=1e-9, atol=1e-9)
     assert np.array_equal(act[0], mean)
     with pytest.raises(ValueError):
-        eng.rollout(1, 3, mean, None, "closed_loop_linear")
+        eng.rollout(1, 3, mean, None, "closed_loop")
 
 
 def test_full_size_properties(engines):
@@ -155,4 +155,31 @@ def test_two_link_arm_with_gravity(tmp_path):
     np.testing.assert_allclose(rew, o_rew, rtol=1e-9, atol=1e-9)
     np.testing.assert_allclose(nobs, o_nobs, rtol=0, atol=1e-9)
     assert nobs[..., 1].min() < -0.4                      # the lower limit of j1 was hit under gravity
+    assert eng.solver_failures() == 0
+
+
+def test_closed_loop_linear_mode(engines, ref_arm):
+    """mode='closed_loop_linear' (gym_env_wrapper.py:135-136): action = W^T [obs; 1] + noise."""
+    eng = engines["f64"]
+    st = STATES[1]
+    P, H = 64, 24
+    rs = np.random.RandomState(8)
+    W = 0.3 * rs.standard_normal((21, 7))
+    W[14:20] *= 2.0                                   # make the (lagged) hand position matter
+    noise = 0.3 * _noise(P, H, 7, 31)
+    eng.set_env_state(dict(st, qa=np.zeros(7), timestep=0))
+    obs, rew, act, done, info, nobs = eng.rollout(P, H, W, noise, "closed_loop_linear")
+    o_obs, o_rew, o_act, _, o_nobs = ref_arm.rollout(st["qp"], st["qv"], st["target_pos"], W, noise,
+                                                     mode="closed_loop_linear")
+    np.testing.assert_allclose(act, o_act, rtol=1e-9, atol=1e-9)
+    np.testing.assert_allclose(rew, o_rew, rtol=1e-9, atol=1e-9)
+    np.testing.assert_allclose(nobs, o_nobs, rtol=0, atol=1e-9)
+    np.testing.assert_allclose(obs, o_obs, rtol=0, atol=1e-9)
+    # the first action is a function of the fresh observation only
+    np.testing.assert_allclose(act[:, 0] - noise[:, 0], (W.T @ np.append(o_obs[0, 0], 1.0))[None].repeat(P, 0),
+                               rtol=1e-12, atol=1e-12)
+    # noise=None: every particle follows the deterministic closed loop
+    obs1, rew1, act1, _, _, _ = eng.rollout(1, H, W, None, "closed_loop_linear")
+    o1 = ref_arm.rollout(st["qp"], st["qv"], st["target_pos"], W, None, mode="closed_loop_linear", horizon=H)
+    np.testing.assert_allclose(rew1, o1[1], rtol=1e-9, atol=1e-9)
     assert eng.solver_failures() == 0
