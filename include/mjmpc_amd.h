@@ -57,6 +57,13 @@ int mjmpc_arm_create(const double* model_blob, int n_blob, int device, mjmpc_arm
 int mjmpc_arm_destroy(mjmpc_arm_t h);
 int mjmpc_arm_dims(mjmpc_arm_t h, int* nv, int* nu, int* d_obs);
 
+/* Dynamics randomization: SubprocVecEnv.randomize_dynamics (subproc_vec_env.py:304-312) gives every
+ * worker its own perturbed model (gym_env_wrapper.py:367-416).  Here: n_shards model blocks
+ * (float64 [n_shards][MJMPC_ARM_BLOB_LEN], HOST pointer); afterwards particles
+ * [k*P/n_shards, (k+1)*P/n_shards) of every rollout use block k (P/n_shards must be a multiple of 8).
+ * The single-particle mjmpc_arm_step_state keeps using block 0.  Synchronises the device.        */
+int mjmpc_arm_set_shard_models(mjmpc_arm_t h, const double* model_blobs, int n_shards);
+
 /* set_sim_state_fn: SubprocVecEnv.set_env_state (subproc_vec_env.py:235-251) ->
  * Reacher7DOFEnv.set_env_state (mjmpc/envs/basic/reacher_env.py:87-99).  HOST pointers
  * (qpos[nv], qvel[nv], target_pos[3]); copied to the engine's device state on `stream`.         */

@@ -9,7 +9,10 @@ namespace mjmpc {
 //   gseq    float64[H]  with q0_out: q0_out[p] = sum_t gseq[t] * cost[p][t]  (= cost_to_go(...)[:,0])
 //   clw     float64[(2nv+7)][A]  mode "closed_loop_linear" (gym_env_wrapper.py:135-136): the nominal action of
 //                       a step is clw^T [obs; 1] with obs the observation BEFORE the step; `mean` is ignored
+//   shard_size          > 0: particles [k*shard_size, (k+1)*shard_size) use model block k (dynamics randomization:
+//                       every shard of the reference's worker pool simulates its own perturbed model)
 struct RolloutFusion {
+    long shard_size = 0;
     const double* clw = nullptr;
     const double* filt = nullptr;
     const double* gseq = nullptr;

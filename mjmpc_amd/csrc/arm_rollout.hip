@@ -464,6 +464,7 @@ __global__ __launch_bounds__(64) void arm_rollout_kernel(const T* __restrict__ m
     const bool live = pid < P;
     for (int k = lane; k < LANES * LANES * LANES; k += 64) lds[k] = T(0);
     T* ldsModel = lds + LANES * LANES * LANES;
+    if (fuse.shard_size > 0) model += ((long)blockIdx.x * LANES / fuse.shard_size) * ARM_BLOB_LEN;
     for (int k = lane; k < ARM_BLOB_LEN; k += 64) ldsModel[k] = model[k];
     __syncthreads();
     T* ldsM = lds + g * LANES * LANES;

@@ -44,6 +44,7 @@ struct mjmpc_arm_s {
     double* state = nullptr;        // MJMPC_ARM_STATE_LEN
     unsigned* diag = nullptr;
     double* pinned = nullptr;       // host staging for set_state
+    int n_shards = 1;               // > 1: model_f32 / model_f64 hold one block per shard
 };
 
 extern "C" {
@@ -81,6 +82,38 @@ int mjmpc_arm_create(const double* blob, int n_blob, int device, mjmpc_arm_t* ou
     HIP_TRY(hipMemset(h->state, 0, sizeof(double) * MJMPC_ARM_STATE_LEN));
     HIP_TRY(hipMemset(h->diag, 0, sizeof(unsigned)));
     *out = h;
+    return 0;
+}
+
+int mjmpc_arm_set_shard_models(mjmpc_arm_t h, const double* blobs, int n_shards) {
+    if (!h || !blobs || n_shards < 1) return fail(MJMPC_E_BADARG, "bad argument");
+    HIP_TRY(hipSetDevice(h->device));
+    const size_t n = (size_t)n_shards * mjmpc::ARM_BLOB_LEN;
+    for (int s = 0; s < n_shards; ++s)
+        if ((int)blobs[(size_t)s * mjmpc::ARM_BLOB_LEN + mjmpc::O_NV] != h->nv)
+            return fail(MJMPC_E_BADMODEL, "shard %d has a different nv", s);
+    std::vector<float> f32(blobs, blobs + n);
+    HIP_TRY(hipDeviceSynchronize());
+    float* m32 = nullptr;
+    double* m64 = nullptr;
+    HIP_TRY(hipMalloc(&m32, sizeof(float) * n));
+    HIP_TRY(hipMalloc(&m64, sizeof(double) * n));
+    HIP_TRY(hipMemcpy(m32, f32.data(), sizeof(float) * n, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(m64, blobs, sizeof(double) * n, hipMemcpyHostToDevice));
+    hipFree(h->model_f32);
+    hipFree(h->model_f64);
+    h->model_f32 = m32;
+    h->model_f64 = m64;
+    h->n_shards = n_shards;
+    return 0;
+}
+
+static int shard_fusion(mjmpc_arm_t h, int64_t P, mjmpc::RolloutFusion& fuse) {
+    if (h->n_shards <= 1) return 0;
+    if (P % h->n_shards != 0) return fail(MJMPC_E_BADARG, "P = %lld is not divisible by %d shards", (long long)P, h->n_shards);
+    const long ss = (long)(P / h->n_shards);
+    if (ss % mjmpc::LANES != 0) return fail(MJMPC_E_BADARG, "with per-shard models a shard must hold a multiple of 8 particles (got %ld)", ss);
+    fuse.shard_size = ss;
     return 0;
 }
 
@@ -127,14 +160,16 @@ int mjmpc_arm_rollout(mjmpc_arm_t h, int dtype, int64_t P, int H, const double* 
     HIP_TRY(hipSetDevice(h->device));
     hipStream_t s = (hipStream_t)stream;
     hipError_t e;
+    mjmpc::RolloutFusion fuse;
+    if (int rc = shard_fusion(h, P, fuse)) return rc;
     if (dtype == MJMPC_F32) {
         e = mjmpc::launch_arm_rollout<float>(h->model_f32, h->state, (long)P, H, h->nu, d_mean, (const float*)d_noise,
                                              (float*)d_costs, (float*)d_actions, (float*)d_obs, (float*)d_next_obs,
-                                             nullptr, h->diag, s);
+                                             nullptr, h->diag, s, fuse);
     } else if (dtype == MJMPC_F64) {
         e = mjmpc::launch_arm_rollout<double>(h->model_f64, h->state, (long)P, H, h->nu, d_mean,
                                               (const double*)d_noise, (double*)d_costs, (double*)d_actions,
-                                              (double*)d_obs, (double*)d_next_obs, nullptr, h->diag, s);
+                                              (double*)d_obs, (double*)d_next_obs, nullptr, h->diag, s, fuse);
     } else {
         return fail(MJMPC_E_BADARG, "unknown dtype %d", dtype);
     }
@@ -149,6 +184,7 @@ int mjmpc_arm_rollout_cl(mjmpc_arm_t h, int dtype, int64_t P, int H, const doubl
     HIP_TRY(hipSetDevice(h->device));
     hipStream_t s = (hipStream_t)stream;
     mjmpc::RolloutFusion fuse;
+    if (int rc = shard_fusion(h, P, fuse)) return rc;
     fuse.clw = d_weights;
     hipError_t e;
     if (dtype == MJMPC_F32)
@@ -174,6 +210,7 @@ int mjmpc_arm_rollout_fused(mjmpc_arm_t h, int dtype, int64_t P, int H, const do
     HIP_TRY(hipSetDevice(h->device));
     hipStream_t s = (hipStream_t)stream;
     mjmpc::RolloutFusion fuse;
+    if (int rc = shard_fusion(h, P, fuse)) return rc;
     fuse.filt = d_filter_coeffs;
     fuse.gseq = d_gseq;
     fuse.q0_out = d_q0;

@@ -18,7 +18,8 @@ import time
 import numpy as np
 
 from .. import _lib
-from ..models.compile import ArmModel, compile_arm
+from ..models.compile import ArmModel, compile_arm, principal_inertia
+from .seeding import np_random
 from ..models.raw import RawModel
 
 _DT = {"f32": (_lib.F32, np.float32), "f64": (_lib.F64, np.float64)}
@@ -37,6 +38,7 @@ class ArmRolloutEngine:
     """One GPU's worth of particles for a compiled arm model (``reacher_7dof-v0``)."""
 
     def __init__(self, model, device=0, dtype="f64", num_shards=1):
+        self.raw = model if isinstance(model, RawModel) else None
         if isinstance(model, RawModel):
             model = compile_arm(model)
         if not isinstance(model, ArmModel):
@@ -62,6 +64,8 @@ class ArmRolloutEngine:
         self.action_highs = model.ctrl_hi.copy()
         self.closed = False
         self._buf = {}
+        self.default_dyn_params = [dict() for _ in range(self.num_shards)]
+        self.randomized_dyn_params = [dict() for _ in range(self.num_shards)]
         self.set_env_state(dict(qp=np.zeros(model.nv), qv=np.zeros(model.nv), qa=np.zeros(model.nv),
                                 target_pos=model.target_default.copy(), timestep=0))
 
@@ -101,6 +105,54 @@ class ArmRolloutEngine:
         dt = time.time() - t0
         info = [{"total_time": dt} for _ in range(self.num_shards)]
         return obs, -costs, act, done, info, nobs
+
+    def randomize_dynamics(self, param_dict, base_seed):
+        """``SubprocVecEnv.randomize_dynamics`` (subproc_vec_env.py:304-312): shard i draws from
+        ``np_random(base_seed + i*12345)`` a uniform value in ``m (1 +- noise)``, ``m = (1 + bias) * default``
+        for every ``{param_id: {name: [noise_scale, bias_scale]}}`` entry (gym_env_wrapper.py:367-416) and
+        from then on simulates its own model.  Supported: body_mass, body_inertia, dof_damping, geom_size
+        (collision geoms), geom_friction (accepted, no effect: every contact here is frictionless condim 1).
+        Returns (default_params, randomized_params), one dict per shard."""
+        if self.raw is None:
+            raise ValueError("randomize_dynamics needs the engine to be built from a RawModel")
+        base = self.model
+        blobs = []
+        for i in range(self.num_shards):
+            rng, _ = np_random(int(base_seed) + i * 12345)
+            defaults, rand = self.default_dyn_params[i], self.randomized_dyn_params[i]
+            for param_id, entries in param_dict.items():
+                for name, (noise_scale, bias_scale) in entries.items():
+                    cur = defaults.setdefault(param_id, {}).get(name)
+                    if cur is None:
+                        cur = defaults[param_id][name] = self._default_param(param_id, name)
+                    mean = (1.0 + bias_scale) * np.asarray(cur, float)
+                    val = rng.uniform(mean - mean * noise_scale, mean + mean * noise_scale)
+                    rand.setdefault(param_id, {})[name] = val
+            ov = {k: v for k, v in rand.items() if k != "geom_friction"}
+            blobs.append(compile_arm(self.raw, overrides=ov, base=base).blob)
+        blobs = np.ascontiguousarray(np.stack(blobs), np.float64)
+        _lib.check(self._lib.mjmpc_arm_set_shard_models(self._h, blobs.ctypes.data_as(_lib._dp), self.num_shards))
+        self.shard_blobs = blobs
+        return self.default_dyn_params, self.randomized_dyn_params
+
+    def _default_param(self, param_id, name):
+        raw, m = self.raw, self.model
+        names = [b.name for b in raw.bodies]
+        if param_id == "body_mass":
+            return float(m.body_mass[names.index(name)])
+        if param_id == "body_inertia":
+            return principal_inertia(m.body_inertia[names.index(name)])[0]
+        if param_id == "dof_damping":
+            return float(next(b.joint.damping for b in raw.bodies if b.joint is not None and b.joint.name == name))
+        if param_id in ("geom_size", "geom_friction"):
+            g = next(g for b in raw.bodies for g in b.geoms if g.name == name)
+            if param_id == "geom_friction":
+                return np.array([0.5, 0.1, 0.1])                      # sawyer.xml:6 default
+            half = 0.5 * np.linalg.norm(np.asarray(g.b, float) - np.asarray(g.a, float)) if g.type == 2 else 0.0
+            return np.array([g.radius, half, 0.0])
+        if param_id == "dof_frictionloss":
+            raise NotImplementedError("dof_frictionloss adds friction-loss constraint rows, which the arm kernel does not model")
+        raise ValueError("Unknown dynamics field")
 
     def reset(self):
         self.set_env_state(dict(qp=np.zeros(self.model.nv), qv=np.zeros(self.model.nv),

@@ -102,7 +102,19 @@ class ArmModel:
         return self.blob[o:o + n]
 
 
-def compile_arm(raw: RawModel) -> ArmModel:
+def principal_inertia(I):
+    """Principal moments of a body inertia tensor, descending (MuJoCo's ``body_inertia`` order [EXT])
+    and the rotation whose columns are the matching axes."""
+    w, V = np.linalg.eigh(np.asarray(I, float))
+    return w[::-1].copy(), V[:, ::-1].copy()
+
+
+def compile_arm(raw: RawModel, overrides=None, base: "ArmModel" = None) -> ArmModel:
+    """``overrides`` mimics run-time edits of the compiled MuJoCo model (dynamics randomization,
+    mjmpc/envs/gym_env_wrapper.py:367-416): ``{"body_mass": {body: m}, "body_inertia": {body: [I1,I2,I3]},
+    "dof_damping": {joint: d}, "geom_size": {geom: [..]}}``.  Like MuJoCo, such edits do NOT recompute the
+    qpos0 constants: pass the unperturbed model as ``base`` and its dof/body invweight0 are kept."""
+    overrides = overrides or {}
     nb = len(raw.bodies)
     # ---- per-body inertial + pose at qpos0 ------------------------------------------------
     R0 = [None] * nb
@@ -121,6 +133,11 @@ def compile_arm(raw: RawModel) -> ArmModel:
         if mass[i] > 0:
             ipos[i] = sum(m * c for m, c, _ in parts) / mass[i]
             inert[i] = sum(_shift_inertia(I, m, c - ipos[i]) for m, c, I in parts)
+        if b.name in overrides.get("body_mass", {}):
+            mass[i] = float(overrides["body_mass"][b.name])          # inertia / COM untouched, as in MuJoCo
+        if b.name in overrides.get("body_inertia", {}):
+            _, V = principal_inertia(inert[i])
+            inert[i] = V @ np.diag(np.asarray(overrides["body_inertia"][b.name], float)) @ V.T
 
     # ---- links: one per hinge, welded bodies merged in ------------------------------------
     jointed = [i for i, b in enumerate(raw.bodies) if b.joint is not None]
@@ -160,7 +177,7 @@ def compile_arm(raw: RawModel) -> ArmModel:
         for k, (r, c) in enumerate([(0, 0), (1, 1), (2, 2), (0, 1), (0, 2), (1, 2)]):
             f["inertia"][k * L + li] = I[r, c]
         f["armature"][li] = jt.armature
-        f["damping"][li] = jt.damping
+        f["damping"][li] = float(overrides.get("dof_damping", {}).get(jt.name, jt.damping))
         f["range_lo"][li], f["range_hi"][li] = jt.range
         f["limited"][li] = 1.0 if jt.limited else 0.0
 
@@ -223,7 +240,7 @@ def compile_arm(raw: RawModel) -> ArmModel:
         f["n_sphere"][0] = 1
         f["sph_link"][0] = li
         f["sph_pos"][:] = p0[i] + R0[i] @ np.asarray(g.a, float) - origin[li]
-        f["sph_r"][0] = g.radius
+        f["sph_r"][0] = float(np.ravel(overrides.get("geom_size", {}).get(g.name, [g.radius]))[0])
         f["sph_margin"][0] = max(raw.plane.margin, g.margin)     # MuJoCo: max of geom margins
         f["sph_invweight"][0] = 0.0 + body_iw[i]                 # world body weighs 0
         f["plane_n"][:] = n
@@ -237,6 +254,10 @@ def compile_arm(raw: RawModel) -> ArmModel:
     f["sol_width"][0], f["sol_mid"][0], f["sol_power"][0] = width, mid, power
     f["gravity"][:] = raw.gravity
 
+    if base is not None:            # run-time edit: MuJoCo keeps the constants mj_setConst computed at load time
+        f["dof_invweight0"][:] = base.field("dof_invweight0")
+        f["sph_invweight"][:] = base.field("sph_invweight")
+        dof_iw, body_iw = base.dof_invweight0.copy(), base.body_invweight0.copy()
     blob = np.concatenate([f[name] for name, _ in ARM_LAYOUT]).astype(np.float64)
     assert blob.size == ARM_BLOB_LEN
     return ArmModel(blob=blob, nv=nv, nu=len(raw.actuators), d_obs=2 * nv + 6,

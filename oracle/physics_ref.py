@@ -70,6 +70,19 @@ class RefArm:
             self._L.or_model_free(self._h)
             self._h = None
 
+    # -- run-time edits (dynamics randomization) ----------------------------
+    def set_body_mass(self, body, mass):
+        self._L.or_set_body_mass(ctypes.c_void_p(self._h), int(body), ctypes.c_double(mass))
+
+    def set_body_inertia(self, body, tensor):
+        self._L.or_set_body_inertia(ctypes.c_void_p(self._h), int(body), _p(_c(tensor).reshape(-1)))
+
+    def set_dof_damping(self, dof, d):
+        self._L.or_set_dof_damping(ctypes.c_void_p(self._h), int(dof), ctypes.c_double(d))
+
+    def set_sphere_radius(self, idx, r):
+        self._L.or_set_sphere_radius(ctypes.c_void_p(self._h), int(idx), ctypes.c_double(r))
+
     # -- compiled constants -------------------------------------------------
     def inertial(self):
         mass = np.zeros(self.nbody)

@@ -642,6 +642,14 @@ void or_step(OrModel *m, double *q, double *v, const double *ctrl, double *site_
     }
 }
 
+/* ---------------------------------------------------------------- run-time model edits (dynamics randomization)
+ * gym_env_wrapper.py:367-416 writes model.body_mass / body_inertia / dof_damping / geom_size in place;
+ * MuJoCo does not re-run mj_setConst afterwards, so dof/body_invweight0 keep their load-time values. */
+void or_set_body_mass(OrModel *m, int body, double mass) { m->mass[body] = mass; }
+void or_set_body_inertia(OrModel *m, int body, const double *I9) { memcpy(m->inertia[body], I9, 72); }
+void or_set_dof_damping(OrModel *m, int dof, double d) { m->damping[dof] = d; }
+void or_set_sphere_radius(OrModel *m, int s, double r) { m->sph_r[s] = r; }
+
 /* ---------------------------------------------------------------- accessors for tests */
 int or_nv(const OrModel *m) { return m->nv; }
 int or_nbody(const OrModel *m) { return m->nbody; }
