@@ -42,6 +42,8 @@ def parse():
     ap.add_argument("--no-graph", action="store_true", help="launch every kernel eagerly instead of replaying a hipGraph")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=10.0)
+    ap.add_argument("--backend", default="nccl", help=argparse.SUPPRESS)          # test knobs: gloo on one GPU
+    ap.add_argument("--device", type=int, default=None, help=argparse.SUPPRESS)
     return ap.parse_args()
 
 
@@ -80,11 +82,16 @@ def main():
     if args.gpus != world:
         if world == 1 and args.gpus > 1:
             raise SystemExit("launch --gpus %d through torch.distributed.run (one process per GPU)" % args.gpus)
+    if args.device is not None:
+        local = args.device
     torch.cuda.set_device(local)
     comm = None
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        else:
+            dist.init_process_group(args.backend)
         from mjmpc_amd.control._device import TorchDistComm
         comm = TorchDistComm()
 
@@ -111,7 +118,7 @@ def main():
         return out
 
     rollout_fn.accepts_device = True
-    graphed = (world == 1 and not args.no_graph and args.noise == "device")
+    graphed = (not args.no_graph and args.noise == "device" and (world == 1 or args.backend == "nccl"))
     ctrl.rollout_fn = base_fn if graphed else rollout_fn
     ctrl.set_sim_state_fn = lambda s: None          # the "real" arm lives on the device (step_state)
     eng.set_env_state(dict(qp=np.zeros(7), qv=np.zeros(7), target_pos=np.array([0.1, 0.1, 0.1])))
@@ -123,7 +130,7 @@ def main():
     def control_step():
         action, _ = ctrl.optimize(state)
         if not graphed:
-            eng.step_state(action)
+            eng.step_state(action)          # (in graph mode the env step is part of the captured iteration)
 
     def sync():
         torch.cuda.synchronize()
@@ -184,7 +191,7 @@ def main():
         "config": {"workload": "reacher_7dof-v0 MPPI lam=0.01 H=%d, %d particles per GPU (%d total), frame_skip 2, "
                                "filter [0.25,0.8,0], closed loop from qpos0 to target [0.1,0.1,0.1]" % (H, P_loc, P_tot),
                    "noise": args.noise, "particles_per_gpu": P_loc, "horizon": H,
-                   "launch": "hipGraph replay" if graphed else "eager"},
+                   "launch": "hipGraph replay" if (graphed and not getattr(ctrl, "graph_fallback", False)) else "eager"},
         "control_loop_hz": args.steps / dt,
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,

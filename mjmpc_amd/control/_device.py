@@ -36,11 +36,16 @@ class TorchDistComm:
         self._dist, self._group = dist, group
         self.rank = dist.get_rank(group)
         self.world_size = dist.get_world_size(group)
+        self.backend = dist.get_backend(group)
+        self._out = {}
 
     def all_gather(self, t):
         import torch
-        out = torch.empty(self.world_size * t.numel(), dtype=t.dtype, device=t.device)    # flat: gloo insists
-        self._dist.all_gather_into_tensor(out, t.reshape(-1).contiguous(), group=self._group)
+        key = (t.numel(), t.dtype, t.device)
+        out = self._out.get(key)            # persistent receive buffer: a captured graph replays into it
+        if out is None:
+            out = self._out[key] = torch.empty(self.world_size * t.numel(), dtype=t.dtype, device=t.device)
+        self._dist.all_gather_into_tensor(out, t.reshape(-1).contiguous(), group=self._group)   # flat: gloo insists
         return out.reshape(self.world_size, t.numel())
 
     def all_gather_flat(self, t):
@@ -160,12 +165,28 @@ class DeviceUpdater:
         return w
 
     def mppi_fused_update(self, q0, actions, lam, step_size, shift_mode, action_out):
-        """q0 (float64 [P], device) + actions -> mean update, action read-out and shift in two launches."""
+        """q0 (float64 [P], device) + actions -> mean update, action read-out and shift in two launches.
+        Sharded: the fused kernels only produce this GPU's record; one all-gather; then the combine."""
         P = q0.shape[0]
+        if self.comm.world_size == 1:
+            _lib.check(self.lib.mjmpc_mppi_fused_update(self.code(actions), P, self.H, self.A, _vp(q0), _vp(actions),
+                                                        float(lam), float(step_size), int(shift_mode),
+                                                        _vp(self.mean), _vp(action_out), None, None,
+                                                        _vp(self.workspace(P)), self.stream()))
+            return
+        rec = self.record("softmax", self.lib.mjmpc_softmax_record_len(self.H, self.A, 0))
         _lib.check(self.lib.mjmpc_mppi_fused_update(self.code(actions), P, self.H, self.A, _vp(q0), _vp(actions),
-                                                    float(lam), float(step_size), int(shift_mode), _vp(self.mean),
-                                                    _vp(action_out), None, None, _vp(self.workspace(P)),
-                                                    self.stream()))
+                                                    float(lam), 0.0, -1, _vp(self.mean), None, _vp(rec), None,
+                                                    _vp(self.workspace(P)), self.stream()))
+        recs = self.comm.all_gather(rec)
+        G = recs.shape[0]
+        _lib.check(self.lib.mjmpc_softmax_combine(_vp(recs), G, self.H, self.A, 0, float(lam), float(step_size), 0,
+                                                  float(P * G), _vp(self.mean), None, None, _vp(self.wnorm),
+                                                  self.stream()))
+        if action_out is not None:
+            action_out.copy_(self.mean[0])
+        if shift_mode >= 0:
+            self.shift(shift_mode)
 
     # ------------------------------------------------------------------ CEM
     def cem_update(self, costs, actions, num_elite, step_size, full_cov):

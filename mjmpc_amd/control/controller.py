@@ -267,15 +267,16 @@ class OLGaussianMPC(Controller):
         if not self._graph_capable():
             raise ValueError("this controller configuration cannot run as a captured graph "
                              "(needs noise_mode='device', a device rollout_fn, static covariance, "
-                             "base_action != 'random', a single GPU)")
+                             "base_action != 'random'; sharded runs additionally the fused MPPI path over RCCL)")
         self._graph_on = True
         self._graph_post = post_step
         self._graph = None
 
     def _graph_capable(self):
         return (self.noise_mode == 'device' and getattr(self._rollout_fn, "accepts_device", False)
-                and self.base_action in ('null', 'repeat') and self.dev.comm.world_size == 1
-                and self._static_cov() and self.sample_mode == 'mean')
+                and self.base_action in ('null', 'repeat') and self._static_cov() and self.sample_mode == 'mean'
+                and (self.dev.comm.world_size == 1 or (self._fused_capable()
+                                                       and getattr(self.dev.comm, "backend", "") == "nccl")))
 
     def _static_cov(self):
         return False            # subclasses whose update leaves cov_action alone say True
@@ -294,7 +295,8 @@ class OLGaussianMPC(Controller):
             coeffs = self.dev.record("coeffs", 3)
             for it in range(self.n_iters):
                 raw = self.dev.sample_noise(n_loc, self._cov_host, self.filter_coeffs, self.seed_val, 0,
-                                            dtype=self.noise_dtype, d_step=self._step_dev, filtered=False)
+                                            dtype=self.noise_dtype, d_step=self._step_dev, filtered=False,
+                                            particle_offset=self.dev.comm.rank * n_loc)
                 costs, actions, q0 = self._rollout_fn.fused(n_loc, self.horizon, self.dev.mean, raw, coeffs,
                                                             self.dev.gseq)
                 last = it == self.n_iters - 1
@@ -308,7 +310,8 @@ class OLGaussianMPC(Controller):
             return
         for _ in range(self.n_iters):
             delta = self.dev.sample_noise(n_loc, self._cov_host, self.filter_coeffs, self.seed_val, 0,
-                                          dtype=self.noise_dtype, d_step=self._step_dev)
+                                          dtype=self.noise_dtype, d_step=self._step_dev,
+                                          particle_offset=self.dev.comm.rank * n_loc)
             if self.use_zero_control_seq:
                 delta[-1] = (-self.dev.mean).to(delta.dtype)
             traj = self._rollout_fn(n_loc, self.horizon, self.dev.mean, delta, mode="open_loop")
@@ -341,10 +344,20 @@ class OLGaussianMPC(Controller):
             self._graph_post = post
             self.dev.mean.copy_(keep[0])
             self._step_dev.copy_(keep[1])
-            g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g):
-                self._device_iteration()
-            self._graph = g
+            try:
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g):
+                    self._device_iteration()
+                self._graph = g
+            except Exception as e:          # e.g. a collective that cannot be captured: run eagerly instead
+                import warnings
+                warnings.warn("hipGraph capture of the control iteration failed (%s); running eagerly" % (e,))
+                torch.cuda.synchronize(self.dev.device)
+                self.dev.mean.copy_(keep[0])
+                self._graph_on = False
+                self._graph = None
+                self.graph_fallback = True
+                return self._optimize_eager_after_fallback(state)
         if self._step_host != self.num_steps:
             self._step_dev.fill_(self.num_steps)
         self._graph.replay()
@@ -355,7 +368,15 @@ class OLGaussianMPC(Controller):
         self._mean_stale = True
         return action, 0.0
 
+    def _optimize_eager_after_fallback(self, state):
+        action, value = Controller.optimize(self, state, False, True)
+        if self._graph_post is not None:
+            self._graph_post(self.dev.torch.from_numpy(np.ascontiguousarray(action)).to(self.dev.device))
+        return action, value
+
     def optimize(self, state, calc_val=False, hotstart=True):
+        if getattr(self, "graph_fallback", False) and not calc_val and hotstart:
+            return self._optimize_eager_after_fallback(state)
         if self._graph_on and not calc_val and hotstart:
             return self._optimize_graphed(state)
         return super().optimize(state, calc_val, hotstart)
