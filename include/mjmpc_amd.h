@@ -69,6 +69,11 @@ int mjmpc_arm_set_shard_models(mjmpc_arm_t h, const double* model_blobs, int n_s
  * (qpos[nv], qvel[nv], target_pos[3]); copied to the engine's device state on `stream`.         */
 int mjmpc_arm_set_state(mjmpc_arm_t h, const double* qpos, const double* qvel, const double* target_pos,
                         void* stream);
+/* Per-shard start states: SubprocVecEnv.set_env_state with a list of one state dict per worker
+ * (subproc_vec_env.py:242-251).  states = float64 [n_shards][MJMPC_ARM_STATE_LEN] (HOST pointer, layout
+ * qpos[8] | qvel[8] | target[3]); afterwards particles of shard k start from states[k] (P / n_shards must
+ * be a multiple of 8).  n_shards = 0 returns to the single engine state.                           */
+int mjmpc_arm_set_shard_states(mjmpc_arm_t h, const double* states, int n_shards, void* stream);
 /* Device pointer to the state vector, for callers that keep the control loop on the GPU.        */
 double* mjmpc_arm_state_ptr(mjmpc_arm_t h);
 

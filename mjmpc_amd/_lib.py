@@ -23,6 +23,7 @@ SIGNATURES = {
     "mjmpc_device_count": (_int, []),
     "mjmpc_arm_create": (_int, [_dp, _int, _int, ctypes.POINTER(_vp)]),
     "mjmpc_arm_set_shard_models": (_int, [_vp, _dp, _int]),
+    "mjmpc_arm_set_shard_states": (_int, [_vp, _dp, _int, _vp]),
     "mjmpc_arm_destroy": (_int, [_vp]),
     "mjmpc_arm_dims": (_int, [_vp, ctypes.POINTER(_int), ctypes.POINTER(_int), ctypes.POINTER(_int)]),
     "mjmpc_arm_set_state": (_int, [_vp, _dp, _dp, _dp, _vp]),

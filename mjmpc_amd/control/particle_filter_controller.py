@@ -1,16 +1,36 @@
-"""Particle-filter MPC (reference mjmpc/control/particle_filter_controller.py).
+"""Particle-filter MPC with the rollout and the weights on the GPU.
 
-The rollout and the exponentiated-cost weights run on the GPU; the systematic resampling walk
-(:159-174) is a serial prefix scan whose float summation order decides which particle survives,
-so it stays on the host in the reference's order ("replicas + host gather").
+Counterpart of the reference's ``PFMPC`` (mjmpc/control/particle_filter_controller.py): the control
+distribution is a set of P action sequences; every iteration rolls them out, turns the discounted
+costs into softmax weights, resamples systematically and (on shift) diffuses the survivors.
+
+Split of work: rollouts and the exponentiated-cost weights are HIP kernels; the resampling itself is
+a cumulative-sum search whose float summation order decides which particle survives, so it is done
+on the host on the gathered weights, in the reference's order (per-GPU
+replicas, no particle sharding for this controller).
 """
 import copy
 import random
 
 import numpy as np
 
-from .controller import Controller
 from .control_utils import generate_noise
+from .controller import Controller
+
+
+def systematic_resample_indices(weights, first_pointer):
+    """Low-variance resampling: pointers ``first_pointer + m/M`` walk the running sum of ``weights``.
+
+    Equivalent to the serial walk of particle_filter_controller.py:159-171 (``while c < u: c += w[i]``):
+    ``np.cumsum`` accumulates in the same order, a pointer selects the first particle whose running sum
+    reaches it, pointers beyond the total select the last particle, and a pointer at 0 selects index -1
+    exactly as the reference's ``act_seq[i - 1]`` with ``i == 0`` does."""
+    M = weights.shape[0]
+    pointers = first_pointer + np.arange(M) * 1.0 / M * 1.0
+    running = np.cumsum(weights)
+    idx = np.minimum(np.searchsorted(running, pointers, side="left"), M - 1)
+    idx[pointers <= 0.0] = -1
+    return idx
 
 
 class PFMPC(Controller):
@@ -23,75 +43,75 @@ class PFMPC(Controller):
             raise NotImplementedError("PFMPC runs as per-GPU replicas; particle sharding is not supported")
         self.lam = lam
         self.num_particles = num_particles
-        self.cov_shift = np.diag(np.array([cov_shift] * self.d_action))
-        self.cov_resample = np.diag(np.array([cov_resample] * self.d_action))
         self.base_action = base_action
         self.filter_coeffs = filter_coeffs
-        random.seed(self.seed_val)
-        self.mean_action = np.zeros(shape=(horizon, d_action))
-        self.action_samples = generate_noise(self.cov_resample, self.filter_coeffs,
-                                             shape=(self.num_particles, self.horizon), base_seed=self.seed_val)
+        self.cov_shift = np.diag(np.full(self.d_action, float(cov_shift)))
+        self.cov_resample = np.diag(np.full(self.d_action, float(cov_resample)))
+        random.seed(self.seed_val)                       # the reference seeds the global `random` here (:66)
+        self.mean_action = np.zeros((horizon, d_action))
+        self.action_samples = self._fresh_samples()
 
-    def generate_rollouts(self, state):
-        self._set_sim_state_fn(copy.deepcopy(state))
-        delta = self.action_samples - self.mean_action
-        return self._rollout_fn(self.num_particles, self.horizon, self.mean_action, delta, mode="open_loop")
-
-    def _exp_util(self, costs):
-        """particle_filter_controller.py:104-113, evaluated by the softmax kernels."""
-        costs = self.dev.to_device(costs, "costs")
-        P = self.dev.softmax_update(costs, self.dev.zero_actions(costs.shape[0], costs), self.lam, 0.0,
-                                    update_mean=False)
-        return self.dev.softmax_weights(P).cpu().numpy()
-
-    def _update_distribution(self, trajectories):
-        w = self._exp_util(trajectories["costs"])
-        random.seed(self.seed_val + self.num_steps)
-        np.random.seed(self.seed_val + self.num_steps)
-        self.action_samples = self._resampling(self.action_samples, w, low_variance=True)
-        self.mean_action = np.mean(self.action_samples, axis=0)
+    # -- sampling ---------------------------------------------------------------------------------
+    def _fresh_samples(self):
+        """Initial particle set: filtered N(0, cov_resample) draws from the controller seed (:68-70)."""
+        return generate_noise(self.cov_resample, self.filter_coeffs, shape=(self.num_particles, self.horizon),
+                              base_seed=self.seed_val)
 
     def sample_actions(self):
         return self.action_samples
 
-    def _get_next_action(self, state, mode='mean'):
-        return np.mean(self.action_samples, axis=0)[0].copy()
+    def generate_rollouts(self, state):
+        """:74-90 - the particles are passed as deviations from their mean, the only form rollout_fn takes."""
+        self._set_sim_state_fn(copy.deepcopy(state))
+        return self._rollout_fn(self.num_particles, self.horizon, self.mean_action,
+                                self.action_samples - self.mean_action, mode="open_loop")
 
+    # -- update -------------------------------------------------------------------------------------
+    def _exp_util(self, costs):
+        """softmax(-cost_to_go[:, 0] / lam) (:104-113), by the HIP softmax kernels."""
+        costs = self.dev.to_device(costs, "costs")
+        n = self.dev.softmax_update(costs, self.dev.zero_actions(costs.shape[0], costs), self.lam, 0.0,
+                                    update_mean=False)
+        return self.dev.softmax_weights(n).cpu().numpy()
+
+    def _resampling(self, act_seq, weights, low_variance=True):
+        if low_variance:
+            M = act_seq.shape[0]
+            return act_seq[systematic_resample_indices(weights, random.uniform(0.0, 1.0 / M * 1.0))]
+        return np.array(random.choices(self.action_samples, weights=weights, k=self.num_particles))
+
+    def _update_distribution(self, trajectories):
+        """:92-102 - weights, reseed both global generators with seed + step, resample, recentre."""
+        w = self._exp_util(trajectories["costs"])
+        step_seed = self.seed_val + self.num_steps
+        random.seed(step_seed)
+        np.random.seed(step_seed)
+        self.action_samples = self._resampling(self.action_samples, w, low_variance=True)
+        self.mean_action = self.action_samples.mean(axis=0)
+
+    def _get_next_action(self, state, mode='mean'):
+        return self.action_samples.mean(axis=0)[0].copy()
+
+    # -- time shift ---------------------------------------------------------------------------------
     def _shift(self):
-        """particle_filter_controller.py:127-150: roll the samples, add fresh filtered noise, append."""
-        self.action_samples[:, :-1] = self.action_samples[:, 1:]
-        delta = generate_noise(self.cov_shift, self.filter_coeffs, shape=(self.num_particles, self.horizon),
-                               base_seed=self.seed_val + self.num_steps)
-        self.action_samples = self.action_samples + delta
-        if self.base_action == 'random':
-            self.action_samples[:, -1] = np.random.normal(0, self.cov_resample, self.d_action)
-        elif self.base_action == 'null':
-            self.action_samples[:, -1] = np.zeros((self.num_particles, self.d_action))
-        elif self.base_action == 'repeat':
-            self.action_samples[:, -1] = self.action_samples[:, -2]
-        else:
+        """:127-150 - advance every sequence one step, diffuse with fresh filtered noise, append the base action."""
+        moved = self.action_samples
+        moved[:, :-1] = moved[:, 1:]
+        jitter = generate_noise(self.cov_shift, self.filter_coeffs, shape=(self.num_particles, self.horizon),
+                                base_seed=self.seed_val + self.num_steps)
+        moved = moved + jitter
+        tails = {'null': lambda: np.zeros((self.num_particles, self.d_action)),
+                 'repeat': lambda: moved[:, -2],
+                 'random': lambda: np.random.normal(0, self.cov_resample, self.d_action)}
+        if self.base_action not in tails:
             raise NotImplementedError("invalid option for base action during shift")
+        moved[:, -1] = tails[self.base_action]()
+        self.action_samples = moved
 
     def reset(self):
         self.num_steps = 0
-        self.mean_action = np.zeros(shape=(self.horizon, self.d_action))
-        self.action_samples = generate_noise(self.cov_resample, self.filter_coeffs,
-                                             shape=(self.num_particles, self.horizon), base_seed=self.seed_val)
-
-    def _resampling(self, act_seq, weights, low_variance=True):
-        if not low_variance:
-            return np.array(random.choices(self.action_samples, weights=weights, k=self.num_particles))
-        M = act_seq.shape[0]
-        out = np.zeros_like(act_seq)
-        r = random.uniform(0.0, 1.0 / M * 1.0)
-        c, i = 0.0, 0
-        for m in range(M):
-            u = r + m * 1.0 / M * 1.0
-            while c < u and i < M:
-                c += weights[i]
-                i += 1
-            out[m] = act_seq[i - 1]
-        return out
+        self.mean_action = np.zeros((self.horizon, self.d_action))
+        self.action_samples = self._fresh_samples()
 
     def _calc_val(self, trajectories):
         raise NotImplementedError("_calc val not implemented yet")

@@ -11,8 +11,10 @@ namespace mjmpc {
 //                       a step is clw^T [obs; 1] with obs the observation BEFORE the step; `mean` is ignored
 //   shard_size          > 0: particles [k*shard_size, (k+1)*shard_size) use model block k (dynamics randomization:
 //                       every shard of the reference's worker pool simulates its own perturbed model)
+//   state_shard_size    > 0: likewise for the start state: shard k starts from state vector k
 struct RolloutFusion {
     long shard_size = 0;
+    long state_shard_size = 0;
     const double* clw = nullptr;
     const double* filt = nullptr;
     const double* gseq = nullptr;

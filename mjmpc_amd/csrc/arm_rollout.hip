@@ -465,6 +465,7 @@ __global__ __launch_bounds__(64) void arm_rollout_kernel(const T* __restrict__ m
     for (int k = lane; k < LANES * LANES * LANES; k += 64) lds[k] = T(0);
     T* ldsModel = lds + LANES * LANES * LANES;
     if (fuse.shard_size > 0) model += ((long)blockIdx.x * LANES / fuse.shard_size) * ARM_BLOB_LEN;
+    if (fuse.state_shard_size > 0) state += ((long)blockIdx.x * LANES / fuse.state_shard_size) * (2 * LANES + 3);
     for (int k = lane; k < ARM_BLOB_LEN; k += 64) ldsModel[k] = model[k];
     __syncthreads();
     T* ldsM = lds + g * LANES * LANES;

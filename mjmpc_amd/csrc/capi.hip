@@ -45,6 +45,8 @@ struct mjmpc_arm_s {
     unsigned* diag = nullptr;
     double* pinned = nullptr;       // host staging for set_state
     int n_shards = 1;               // > 1: model_f32 / model_f64 hold one block per shard
+    double* shard_states = nullptr; // n_state_shards state vectors (per-shard start states)
+    int n_state_shards = 0;
 };
 
 extern "C" {
@@ -108,7 +110,30 @@ int mjmpc_arm_set_shard_models(mjmpc_arm_t h, const double* blobs, int n_shards)
     return 0;
 }
 
+int mjmpc_arm_set_shard_states(mjmpc_arm_t h, const double* states, int n_shards, void* stream) {
+    if (!h || (n_shards > 0 && !states) || n_shards < 0) return fail(MJMPC_E_BADARG, "bad argument");
+    HIP_TRY(hipSetDevice(h->device));
+    if (n_shards != h->n_state_shards) {
+        HIP_TRY(hipDeviceSynchronize());
+        hipFree(h->shard_states);
+        h->shard_states = nullptr;
+        if (n_shards > 0) HIP_TRY(hipMalloc(&h->shard_states, sizeof(double) * MJMPC_ARM_STATE_LEN * n_shards));
+        h->n_state_shards = n_shards;
+    }
+    if (n_shards > 0) {
+        HIP_TRY(hipMemcpyAsync(h->shard_states, states, sizeof(double) * MJMPC_ARM_STATE_LEN * n_shards,
+                               hipMemcpyHostToDevice, (hipStream_t)stream));
+        HIP_TRY(hipStreamSynchronize((hipStream_t)stream));      // `states` is pageable host memory
+    }
+    return 0;
+}
+
 static int shard_fusion(mjmpc_arm_t h, int64_t P, mjmpc::RolloutFusion& fuse) {
+    if (h->n_state_shards > 1) {
+        if (P % h->n_state_shards != 0 || (P / h->n_state_shards) % mjmpc::LANES != 0)
+            return fail(MJMPC_E_BADARG, "with per-shard start states P / n_shards must be a multiple of 8");
+        fuse.state_shard_size = (long)(P / h->n_state_shards);
+    }
     if (h->n_shards <= 1) return 0;
     if (P % h->n_shards != 0) return fail(MJMPC_E_BADARG, "P = %lld is not divisible by %d shards", (long long)P, h->n_shards);
     const long ss = (long)(P / h->n_shards);
@@ -124,6 +149,7 @@ int mjmpc_arm_destroy(mjmpc_arm_t h) {
     hipFree(h->model_f64);
     hipFree(h->state);
     hipFree(h->diag);
+    hipFree(h->shard_states);
     hipHostFree(h->pinned);
     delete h;
     return 0;
@@ -162,12 +188,13 @@ int mjmpc_arm_rollout(mjmpc_arm_t h, int dtype, int64_t P, int H, const double* 
     hipError_t e;
     mjmpc::RolloutFusion fuse;
     if (int rc = shard_fusion(h, P, fuse)) return rc;
+    const double* st = fuse.state_shard_size > 0 ? h->shard_states : h->state;
     if (dtype == MJMPC_F32) {
-        e = mjmpc::launch_arm_rollout<float>(h->model_f32, h->state, (long)P, H, h->nu, d_mean, (const float*)d_noise,
+        e = mjmpc::launch_arm_rollout<float>(h->model_f32, st, (long)P, H, h->nu, d_mean, (const float*)d_noise,
                                              (float*)d_costs, (float*)d_actions, (float*)d_obs, (float*)d_next_obs,
                                              nullptr, h->diag, s, fuse);
     } else if (dtype == MJMPC_F64) {
-        e = mjmpc::launch_arm_rollout<double>(h->model_f64, h->state, (long)P, H, h->nu, d_mean,
+        e = mjmpc::launch_arm_rollout<double>(h->model_f64, st, (long)P, H, h->nu, d_mean,
                                               (const double*)d_noise, (double*)d_costs, (double*)d_actions,
                                               (double*)d_obs, (double*)d_next_obs, nullptr, h->diag, s, fuse);
     } else {
@@ -185,14 +212,15 @@ int mjmpc_arm_rollout_cl(mjmpc_arm_t h, int dtype, int64_t P, int H, const doubl
     hipStream_t s = (hipStream_t)stream;
     mjmpc::RolloutFusion fuse;
     if (int rc = shard_fusion(h, P, fuse)) return rc;
+    const double* st = fuse.state_shard_size > 0 ? h->shard_states : h->state;
     fuse.clw = d_weights;
     hipError_t e;
     if (dtype == MJMPC_F32)
-        e = mjmpc::launch_arm_rollout<float>(h->model_f32, h->state, (long)P, H, h->nu, d_weights, (const float*)d_noise,
+        e = mjmpc::launch_arm_rollout<float>(h->model_f32, st, (long)P, H, h->nu, d_weights, (const float*)d_noise,
                                              (float*)d_costs, (float*)d_actions, (float*)d_obs, (float*)d_next_obs,
                                              nullptr, h->diag, s, fuse);
     else if (dtype == MJMPC_F64)
-        e = mjmpc::launch_arm_rollout<double>(h->model_f64, h->state, (long)P, H, h->nu, d_weights,
+        e = mjmpc::launch_arm_rollout<double>(h->model_f64, st, (long)P, H, h->nu, d_weights,
                                               (const double*)d_noise, (double*)d_costs, (double*)d_actions,
                                               (double*)d_obs, (double*)d_next_obs, nullptr, h->diag, s, fuse);
     else
@@ -211,16 +239,17 @@ int mjmpc_arm_rollout_fused(mjmpc_arm_t h, int dtype, int64_t P, int H, const do
     hipStream_t s = (hipStream_t)stream;
     mjmpc::RolloutFusion fuse;
     if (int rc = shard_fusion(h, P, fuse)) return rc;
+    const double* st = fuse.state_shard_size > 0 ? h->shard_states : h->state;
     fuse.filt = d_filter_coeffs;
     fuse.gseq = d_gseq;
     fuse.q0_out = d_q0;
     hipError_t e;
     if (dtype == MJMPC_F32)
-        e = mjmpc::launch_arm_rollout<float>(h->model_f32, h->state, (long)P, H, h->nu, d_mean, (const float*)d_noise,
+        e = mjmpc::launch_arm_rollout<float>(h->model_f32, st, (long)P, H, h->nu, d_mean, (const float*)d_noise,
                                              (float*)d_costs, (float*)d_actions, nullptr, nullptr, nullptr, h->diag, s,
                                              fuse);
     else if (dtype == MJMPC_F64)
-        e = mjmpc::launch_arm_rollout<double>(h->model_f64, h->state, (long)P, H, h->nu, d_mean,
+        e = mjmpc::launch_arm_rollout<double>(h->model_f64, st, (long)P, H, h->nu, d_mean,
                                               (const double*)d_noise, (double*)d_costs, (double*)d_actions, nullptr,
                                               nullptr, nullptr, h->diag, s, fuse);
     else

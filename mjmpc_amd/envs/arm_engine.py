@@ -78,10 +78,13 @@ class ArmRolloutEngine:
             if len(state_dicts) not in (1, self.num_shards):
                 raise AssertionError("num states should equal 1 (same for all envs) or 1 per env")
             if any(not _same_state(state_dicts[0], s) for s in state_dicts[1:]):
-                raise NotImplementedError("per-shard start states are not supported yet")
+                return self._set_shard_states(state_dicts)
             state = state_dicts[0]
         else:
             state = state_dicts
+        if getattr(self, "_per_shard_states", False):
+            _lib.check(self._lib.mjmpc_arm_set_shard_states(self._h, None, 0, self._stream()))
+            self._per_shard_states = False
         qp = np.ascontiguousarray(state["qp"], np.float64).reshape(-1)
         qv = np.ascontiguousarray(state["qv"], np.float64).reshape(-1)
         tg = np.ascontiguousarray(state["target_pos"], np.float64).reshape(-1)
@@ -90,6 +93,19 @@ class ArmRolloutEngine:
         self._state = dict(qp=qp.copy(), qv=qv.copy(), target_pos=tg.copy())
         _lib.check(self._lib.mjmpc_arm_set_state(self._h, qp.ctypes.data_as(_lib._dp), qv.ctypes.data_as(_lib._dp),
                                                  tg.ctypes.data_as(_lib._dp), self._stream()))
+
+    def _set_shard_states(self, state_dicts):
+        nv = self.model.nv
+        arr = np.zeros((self.num_shards, 19))
+        for k, s in enumerate(state_dicts):
+            arr[k, :nv] = np.asarray(s["qp"], float).reshape(-1)
+            arr[k, 8:8 + nv] = np.asarray(s["qv"], float).reshape(-1)
+            arr[k, 16:19] = np.asarray(s["target_pos"], float).reshape(-1)
+        _lib.check(self._lib.mjmpc_arm_set_shard_states(self._h, arr.ctypes.data_as(_lib._dp), self.num_shards,
+                                                        self._stream()))
+        self._per_shard_states = True
+        self._shard_state_list = [dict(qp=arr[k, :nv].copy(), qv=arr[k, 8:8 + nv].copy(), target_pos=arr[k, 16:19].copy())
+                                  for k in range(self.num_shards)]
 
     def get_env_state(self):
         return [dict(qp=self._state["qp"].copy(), qv=self._state["qv"].copy(),

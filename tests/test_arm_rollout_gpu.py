@@ -242,3 +242,27 @@ def test_dynamics_randomization_per_shard(raw_arm):
     with pytest.raises(Exception):
         eng.rollout(4 * S, H, mean, noise[:4 * S], "open_loop")      # shard not a multiple of 8 particles
     assert eng.solver_failures() == 0
+
+
+def test_per_shard_start_states(raw_arm, ref_arm):
+    """set_env_state with one state dict per shard (subproc_vec_env.py:242-251)."""
+    from mjmpc_amd.envs.arm_engine import ArmRolloutEngine
+    S = 3
+    eng = ArmRolloutEngine(raw_arm, dtype="f64", num_shards=S)
+    P, H = 8 * 2 * S, 12
+    mean, noise = np.zeros((H, 7)), _noise(P, H, 7, 9)
+    eng.set_env_state([dict(STATES[k], qa=np.zeros(7), timestep=0) for k in range(S)])
+    obs, rew, act, done, info, nobs = eng.rollout(P, H, mean, noise, "open_loop")
+    n = P // S
+    for k in range(S):
+        st = STATES[k]
+        o = ref_arm.rollout(st["qp"], st["qv"], st["target_pos"], mean, noise[k * n:(k + 1) * n])
+        np.testing.assert_allclose(rew[k * n:(k + 1) * n], o[1], rtol=1e-9, atol=1e-9)
+        np.testing.assert_allclose(obs[k * n:(k + 1) * n], o[0], rtol=0, atol=1e-9)
+    # back to one state for everybody
+    eng.set_env_state(dict(STATES[1], qa=np.zeros(7), timestep=0))
+    _, rew1, _, _, _, _ = eng.rollout(P, H, mean, noise, "open_loop")
+    o = ref_arm.rollout(STATES[1]["qp"], STATES[1]["qv"], STATES[1]["target_pos"], mean, noise)
+    np.testing.assert_allclose(rew1, o[1], rtol=1e-9, atol=1e-9)
+    with pytest.raises(AssertionError):
+        eng.set_env_state([dict(STATES[0]), dict(STATES[1])])

@@ -70,3 +70,25 @@ def test_loader_on_a_small_model_and_rejections(tmp_path):
     (tmp_path / "bad2.xml").write_text(bad)
     with pytest.raises(ValueError):
         load_mjcf(str(tmp_path / "bad2.xml"))
+
+
+def test_systematic_resampling_matches_the_serial_walk(golden):
+    """Host logic of PFMPC: the vectorised cumulative-sum search selects exactly the particles the
+    reference's serial pointer walk selects (oracle restatement pinned on the golden vectors)."""
+    import random
+    from mjmpc_amd.control.particle_filter_controller import systematic_resample_indices
+    from oracle import controllers_ref as cr
+    g = golden("updates")
+    for i in range(int(g["pf_n"])):
+        t = "pf%d" % i
+        lam, gamma, _, _ = g[t + "_cfg"]
+        s0 = g[t + "_samples0"]
+        w = cr.pf_weights(g[t + "_costs"], cr.gamma_seq(gamma, s0.shape[1]), lam)
+        random.seed(123)
+        r = random.uniform(0.0, 1.0 / s0.shape[0] * 1.0)
+        idx = systematic_resample_indices(w, r)
+        assert np.array_equal(s0[idx], g[t + "_samples1"])
+    # degenerate pointers: at 0 the reference indexes [-1]; past the total it sticks to the last particle
+    w = np.array([0.5, 0.25, 0.25])
+    assert list(systematic_resample_indices(w, 0.0)) == [-1, 0, 1]
+    assert list(systematic_resample_indices(w * 0.5, 0.3)) == [1, 2, 2]
