@@ -35,6 +35,18 @@ constexpr int NEWTON_MAXIT = 12;
 // lanes read the same word of a global field) instead of pinning ~25 VGPR pairs and ~35 SGPR pairs
 // for the whole rollout.  PHASE() is a compiler-only fence that keeps those reads inside their phase.
 #define PHASE() asm volatile("" ::: "memory")
+// A workgroup is ONE wavefront and the DS unit executes a wave's LDS instructions in order, so lanes
+// exchanging data through LDS need no s_barrier (and none of the vmcnt(0) drain __syncthreads implies,
+// which would stall every substep on the global stores of the previous env step): a wavefront-scope
+// fence keeps the compiler from reordering the accesses and costs no instruction.
+// The sched_barrier keeps the instruction scheduler from hoisting the next phase's work across the
+// hand-over (what s_barrier did implicitly): without it the kernel needs ~50 more VGPRs.
+#define LDS_WAVE_SYNC()                                        \
+    do {                                                       \
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); \
+        asm volatile("" ::: "memory");                         \
+        __builtin_amdgcn_sched_barrier(0);                     \
+    } while (0)
 
 template <typename T>
 struct Model {                 // view of the LDS copy of the model block
@@ -321,7 +333,7 @@ __device__ __forceinline__ void arm_substep(const Model<T>& M, const ArmInts& I,
             ldsM[(l8 + sft) * LANES + l8] = d[sft];
         }
     }
-    __syncthreads();
+    LDS_WAVE_SYNC();
 
     // 5. smooth force: -bias + passive damping + motor
     const T damping = M.link(O_DAMPING), h = M.glob(O_TIMESTEP);
@@ -442,7 +454,7 @@ __device__ __forceinline__ void arm_substep(const Model<T>& M, const ArmInts& I,
             cq = c1 * k;
         }
     }
-    __syncthreads();            // the tile is rewritten by the next substep
+    LDS_WAVE_SYNC();            // the tile is rewritten by the next substep
 }
 
 // ---- the rollout kernel -------------------------------------------------------------------------
@@ -450,8 +462,12 @@ __device__ __forceinline__ void arm_substep(const Model<T>& M, const ArmInts& I,
 // reference's C-order layouts (P,H,A) / (P,H) / (P,H,2nv+6).  noise, act, obs, next_obs may be null.
 // STEP = true is the same code instantiated under its own name for the single-particle "real env" step
 // (mjmpc_arm_step_state), so that profiler statistics of the P-particle rollout are not diluted by it.
-template <typename T, bool STEP>
-__global__ __launch_bounds__(64) void arm_rollout_kernel(const T* __restrict__ model, const double* state,
+// second launch bound = waves per SIMD the register allocation has to leave room for: 2 for f64 (<= 256
+// VGPRs), 4 for f32 (<= 128) - occupancy is what carries the kernel once P exceeds ~8k particles
+// CL = true: the closed-loop-linear policy variant, its own instantiation so that the open-loop kernel does
+// not carry its registers (136 -> 178 VGPRs in f32 when both lived in one kernel)
+template <typename T, bool STEP, bool CL>
+__global__ __launch_bounds__(64, (sizeof(T) == 8 ? 2 : 4)) void arm_rollout_kernel(const T* __restrict__ model, const double* state,
                                                          long P, int H, int A, const double* __restrict__ mean,
                                                          const T* __restrict__ noise, T* __restrict__ cost,
                                                          T* __restrict__ act, T* __restrict__ obs,
@@ -492,7 +508,7 @@ __global__ __launch_bounds__(64) void arm_rollout_kernel(const T* __restrict__ m
 
     // fresh observation after set_env_state (sim.forward()): the site position at the start state is
     // needed BEFORE the first step when the policy is closed-loop; one extra kinematics pass provides it
-    if (fuse.clw) {
+    if constexpr (CL) {
         T qq = q, vv = v, aa = aw, ss = sinq, cc = cosq;
         int rr = 0;
         T s0[3];
@@ -500,9 +516,24 @@ __global__ __launch_bounds__(64) void arm_rollout_kernel(const T* __restrict__ m
         for (int k = 0; k < 3; ++k) chand[k] = s0[k];
     }
 
+    // inputs of step t+1 are fetched while step t computes (a lone wave would otherwise sit out the full
+    // HBM latency of its noise load at the top of every env step)
+    T eps_next = T(0);
+    double mean_next = 0.0;
+    if (has_u && H > 0) {
+        if constexpr (!CL) mean_next = mean[l8];
+        if (noise && live) eps_next = noise[(pid * H) * A + l8];
+    }
+
     for (int t = 0; t < H; ++t) {
         T u = T(0);
-        if (fuse.clw) {             // u = clw^T [q, v, hand, hand - target, 1]
+        const T eps_cur = eps_next;
+        const double mean_cur = mean_next;
+        if (has_u && t + 1 < H) {
+            if constexpr (!CL) mean_next = mean[(t + 1) * A + l8];
+            if (noise && live) eps_next = noise[(pid * H + t + 1) * A + l8];
+        }
+        if constexpr (CL) {         // u = clw^T [q, v, hand, hand - target, 1]
             const int wl = has_u ? l8 : 0;
             double uu = fuse.clw[(2 * nv + 6) * A + wl];
             cl_accumulate<0, T>(fuse.clw, A, nv, wl, cq, cv, uu);
@@ -512,9 +543,9 @@ __global__ __launch_bounds__(64) void arm_rollout_kernel(const T* __restrict__ m
             u = has_u ? (T)uu : T(0);
         }
         if (has_u) {
-            if (!fuse.clw) u = (T)mean[t * A + l8];
+            if constexpr (!CL) u = (T)mean_cur;
             if (noise && live) {
-                T eps = noise[(pid * H + t) * A + l8];
+                T eps = eps_cur;
                 if (fuse.filt) {            // eps[t] = b0 eps[t] + b1 eps[t-1] + b2 eps[t-2], t >= 2
                     const double f = t >= 2 ? fb0 * (double)eps + fb1 * e1 + fb2 * e2 : (double)eps;
                     e2 = e1;
@@ -578,12 +609,15 @@ hipError_t launch_arm_rollout(const T* model, const double* state, long P, int H
                               unsigned* diag, hipStream_t stream, RolloutFusion fuse) {
     if (P <= 0 || H <= 0) return hipSuccess;
     const unsigned grid = (unsigned)((P + LANES - 1) / LANES);
-    if (state_out)
-        hipLaunchKernelGGL((arm_rollout_kernel<T, true>), dim3(grid), dim3(64), 0, stream, model, state, P, H, A, mean,
-                           noise, cost, act, obs, nobs, state_out, diag, fuse);
+    if (fuse.clw)
+        hipLaunchKernelGGL((arm_rollout_kernel<T, false, true>), dim3(grid), dim3(64), 0, stream, model, state, P, H, A,
+                           mean, noise, cost, act, obs, nobs, state_out, diag, fuse);
+    else if (state_out)
+        hipLaunchKernelGGL((arm_rollout_kernel<T, true, false>), dim3(grid), dim3(64), 0, stream, model, state, P, H, A,
+                           mean, noise, cost, act, obs, nobs, state_out, diag, fuse);
     else
-        hipLaunchKernelGGL((arm_rollout_kernel<T, false>), dim3(grid), dim3(64), 0, stream, model, state, P, H, A, mean,
-                           noise, cost, act, obs, nobs, state_out, diag, fuse);
+        hipLaunchKernelGGL((arm_rollout_kernel<T, false, false>), dim3(grid), dim3(64), 0, stream, model, state, P, H, A,
+                           mean, noise, cost, act, obs, nobs, state_out, diag, fuse);
     return hipGetLastError();
 }
 
