@@ -49,13 +49,21 @@ def parse():
 
 def cpu_baseline(P, H, budget_s):
     """The FP64 C oracle (kind "port") on this box's host cores: same model, same start state, same
-    noise recipe; a bounded sample of the workload (batches of 512 particles x H until the budget)."""
+    noise recipe; a bounded sample of the workload (batches of >= 32 particles per thread x H until the budget)."""
     from mjmpc_amd.models.reacher7dof import reacher7dof_raw
-    from oracle.physics_ref import RefArm
+    from oracle.physics_ref import RefArm, threads
     arm = RefArm(reacher7dof_raw().to_flat())
-    cores = len(os.sched_getaffinity(0))
+    avail = len(os.sched_getaffinity(0))
+    try:                                    # a cgroup CPU quota below the visible core count: more threads only thrash
+        with open("/sys/fs/cgroup/cpu.max") as f:
+            q, per = f.read().split()
+        if q != "max":
+            avail = max(1, min(avail, int(np.ceil(int(q) / int(per)))))
+    except (OSError, ValueError):
+        pass
+    cores = threads(avail)
     rs = np.random.RandomState(123)
-    batch = 512
+    batch = max(512, 32 * cores)            # >= 32 particles per thread, or OpenMP fork/join dominates
     noise = rs.standard_normal((batch, H, 7))
     for t in range(2, H):
         noise[:, t] = 0.25 * noise[:, t] + 0.8 * noise[:, t - 1]
@@ -63,13 +71,28 @@ def cpu_baseline(P, H, budget_s):
     tgt = np.array([0.1, 0.1, 0.1])
     arm.rollout(np.zeros(7), np.zeros(7), tgt, mean, noise[:64], want_obs=False)     # warm up
     n, t0 = 0, time.time()
-    while time.time() - t0 < budget_s:
+    while time.time() - t0 < 0.8 * budget_s:
         arm.rollout(np.zeros(7), np.zeros(7), tgt, mean, noise, want_obs=False)
         n += batch
     dt = time.time() - t0
+    # the same code on ONE thread (2 s), to tell host-core scaling limits (cgroup quotas, SMT) from code speed
+    threads(1)
+    n1, t1 = 0, time.time()
+    while time.time() - t1 < 0.2 * budget_s:
+        arm.rollout(np.zeros(7), np.zeros(7), tgt, mean, noise[:64], want_obs=False)
+        n1 += 64
+    dt1 = time.time() - t1
+    threads(cores)
+    quota = ""
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as f:
+            quota = "; cgroup cpu.max = %s" % f.read().strip()
+    except OSError:
+        pass
     return {"value": n * H / dt, "unit": "particle-steps/s", "cores": cores, "kind": "port",
-            "sample": "%d particles x H=%d rollouts of the same workload (OpenMP over particles, %d threads), %.1f s"
-                      % (n, H, cores, dt)}
+            "single_thread_value": n1 * H / dt1,
+            "sample": "%d particles x H=%d rollouts of the same workload (OpenMP over particles, %d threads), %.1f s; "
+                      "one thread: %d particles in %.1f s%s" % (n, H, cores, dt, n1, dt1, quota)}
 
 
 def main():

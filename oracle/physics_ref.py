@@ -40,8 +40,15 @@ def _lib():
         L.or_rollout.argtypes = [ctypes.c_void_p, _dp, _dp, _dp, ctypes.c_long, ctypes.c_int,
                                  _dp, _dp, _dp, _dp, _dp, _dp, _dp]
         L.or_rollout_cl.argtypes = L.or_rollout.argtypes
+        L.or_threads.restype = ctypes.c_int
+        L.or_threads.argtypes = [ctypes.c_int]
         _LIB = L
     return _LIB
+
+
+def threads(n=0):
+    """OpenMP threads used by RefArm.rollout (n > 0 sets the count first)."""
+    return _lib().or_threads(int(n))
 
 
 def _p(a):

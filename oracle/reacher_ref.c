@@ -31,6 +31,9 @@
 #include <math.h>
 #include <stdlib.h>
 #include <string.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
 
 #define MAXB 16            /* bodies incl. world */
 #define MAXV 12
@@ -649,6 +652,17 @@ void or_set_body_mass(OrModel *m, int body, double mass) { m->mass[body] = mass;
 void or_set_body_inertia(OrModel *m, int body, const double *I9) { memcpy(m->inertia[body], I9, 72); }
 void or_set_dof_damping(OrModel *m, int dof, double d) { m->damping[dof] = d; }
 void or_set_sphere_radius(OrModel *m, int s, double r) { m->sph_r[s] = r; }
+
+/* number of OpenMP threads or_rollout uses (n > 0 sets it first); 1 without OpenMP */
+int or_threads(int n) {
+#ifdef _OPENMP
+    if (n > 0) omp_set_num_threads(n);
+    return omp_get_max_threads();
+#else
+    (void)n;
+    return 1;
+#endif
+}
 
 /* ---------------------------------------------------------------- accessors for tests */
 int or_nv(const OrModel *m) { return m->nv; }
