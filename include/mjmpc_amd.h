@@ -187,10 +187,13 @@ int mjmpc_rs_combine(const double* d_records, int G, int H, int A, double step_s
  * (olgaussian_mpc.py:71) + OLGaussianMPC._shift (olgaussian_mpc.py:116-129) in two launches.
  * d_q0: float64[P] cost-to-go (NULL = the one mjmpc_traj_cost left in d_ws).  shift_mode: -1 none,
  * 0 'null', 1 'repeat'.  d_action_out (float64[A]), d_record ([xmax | S | W[H*A]], the softmax record
- * without its covariance block) and d_value (_calc_val, mppi.py:113-131) may be NULL.              */
+ * without its covariance block) and d_value (_calc_val, mppi.py:113-131) may be NULL.  For a captured
+ * control iteration: h_action_mapped (device-visible pinned host memory, float64[A]) also receives the
+ * action, and *d_step_counter (device int64) is incremented (the noise stream index of the next step). */
 int mjmpc_mppi_fused_update(int dtype, int64_t P, int H, int A, const double* d_q0, const void* d_actions, double lam,
                             double step_size, int shift_mode, double* d_mean, double* d_action_out, double* d_record,
-                            double* d_value, void* d_ws, void* stream);
+                            double* d_value, double* h_action_mapped, int64_t* d_step_counter, void* d_ws,
+                            void* stream);
 
 /* sum of q0 over local particles (CEM / RandomShooting _calc_val: cem.py:107-112) -> d_out[0] */
 int mjmpc_q0_sum(int64_t P, int H, int A, double* d_out, void* d_ws, void* stream);
@@ -205,10 +208,11 @@ int mjmpc_shift_mean(double* d_mean, int H, int A, int mode, const double* d_row
  * plays the role of num_steps in base_seed = seed_val + num_steps (olgaussian_mpc.py:91);
  * `particle_offset` is the global index of local particle 0, so that a sharded run draws exactly
  * the samples a single GPU would draw for the same particles.  d_step (device int64, may be NULL)
- * is added to `offset` on the device, so that a captured hipGraph can advance the stream itself.  */
+ * is added to `offset` on the device, so that a captured hipGraph can advance the stream itself.
+ * chol_is_diagonal != 0 promises that d_chol has no off-diagonal entries (skips the colouring loop). */
 int mjmpc_sample_noise(int dtype, void* d_noise, int64_t P, int H, int A, const double* d_chol,
                        const double* d_coeffs, uint64_t seed, uint64_t offset, int64_t particle_offset,
-                       const int64_t* d_step, void* stream);
+                       const int64_t* d_step, int chol_is_diagonal, void* stream);
 
 #ifdef __cplusplus
 }

@@ -47,10 +47,11 @@ SIGNATURES = {
     "mjmpc_cem_final": (_int, [_vp, _int, _i64, _int, _int, _dbl, _int, _dbl, _vp, _vp, _vp, _vp]),
     "mjmpc_rs_best": (_int, [_int, _i64, _int, _int, _vp, _i64, _vp, _vp, _vp]),
     "mjmpc_rs_combine": (_int, [_vp, _int, _int, _int, _dbl, _vp, _vp]),
-    "mjmpc_mppi_fused_update": (_int, [_int, _i64, _int, _int, _vp, _vp, _dbl, _dbl, _int, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "mjmpc_mppi_fused_update": (_int, [_int, _i64, _int, _int, _vp, _vp, _dbl, _dbl, _int, _vp, _vp, _vp, _vp, _vp, _vp,
+                                        _vp, _vp]),
     "mjmpc_q0_sum": (_int, [_i64, _int, _int, _vp, _vp, _vp]),
     "mjmpc_shift_mean": (_int, [_vp, _int, _int, _int, _vp, _vp]),
-    "mjmpc_sample_noise": (_int, [_int, _vp, _i64, _int, _int, _vp, _vp, ctypes.c_uint64, ctypes.c_uint64, _i64, _vp, _vp]),
+    "mjmpc_sample_noise": (_int, [_int, _vp, _i64, _int, _int, _vp, _vp, ctypes.c_uint64, ctypes.c_uint64, _i64, _vp, _int, _vp]),
 }
 
 _LIB = None

@@ -164,7 +164,8 @@ class DeviceUpdater:
                                                   self.stream()))
         return w
 
-    def mppi_fused_update(self, q0, actions, lam, step_size, shift_mode, action_out):
+    def mppi_fused_update(self, q0, actions, lam, step_size, shift_mode, action_out, action_pinned=None,
+                          step_counter=None):
         """q0 (float64 [P], device) + actions -> mean update, action read-out and shift in two launches.
         Sharded: the fused kernels only produce this GPU's record; one all-gather; then the combine."""
         P = q0.shape[0]
@@ -172,12 +173,13 @@ class DeviceUpdater:
             _lib.check(self.lib.mjmpc_mppi_fused_update(self.code(actions), P, self.H, self.A, _vp(q0), _vp(actions),
                                                         float(lam), float(step_size), int(shift_mode),
                                                         _vp(self.mean), _vp(action_out), None, None,
+                                                        _vp(action_pinned), _vp(step_counter),
                                                         _vp(self.workspace(P)), self.stream()))
             return
         rec = self.record("softmax", self.lib.mjmpc_softmax_record_len(self.H, self.A, 0))
         _lib.check(self.lib.mjmpc_mppi_fused_update(self.code(actions), P, self.H, self.A, _vp(q0), _vp(actions),
-                                                    float(lam), 0.0, -1, _vp(self.mean), None, _vp(rec), None,
-                                                    _vp(self.workspace(P)), self.stream()))
+                                                    float(lam), 0.0, -1, _vp(self.mean), None, _vp(rec), None, None,
+                                                    None, _vp(self.workspace(P)), self.stream()))
         recs = self.comm.all_gather(rec)
         G = recs.shape[0]
         _lib.check(self.lib.mjmpc_softmax_combine(_vp(recs), G, self.H, self.A, 0, float(lam), float(step_size), 0,
@@ -185,6 +187,10 @@ class DeviceUpdater:
                                                   self.stream()))
         if action_out is not None:
             action_out.copy_(self.mean[0])
+        if action_pinned is not None:
+            action_pinned.copy_(self.mean[0], non_blocking=True)
+        if step_counter is not None:
+            step_counter.add_(1)
         if shift_mode >= 0:
             self.shift(shift_mode)
 
@@ -269,9 +275,11 @@ class DeviceUpdater:
             co = self.record("coeffs", 3)
             co.copy_(torch.from_numpy(fc.copy()))
             self._rec["noise_params"] = (cov.copy(), fc.copy())
+            self._rec["chol_diag"] = int(np.count_nonzero(cov - np.diag(np.diag(cov))) == 0)
         chol, co = self._rec["chol"], self._rec["coeffs"]
         _lib.check(self.lib.mjmpc_sample_noise(_lib.F32 if dtype == "f32" else _lib.F64, _vp(buf), P, self.H, self.A,
                                                _vp(chol), _vp(co) if filtered else None, int(seed) & (2 ** 64 - 1),
                                                int(offset),
-                                               int(particle_offset), _vp(d_step), self.stream()))
+                                               int(particle_offset), _vp(d_step), self._rec["chol_diag"],
+                                               self.stream()))
         return buf

@@ -302,9 +302,8 @@ class OLGaussianMPC(Controller):
                 last = it == self.n_iters - 1
                 self.dev.mppi_fused_update(q0, actions, self.lam, self.step_size,
                                            _SHIFT_MODES[self.base_action] if last else -1,
-                                           self._action_dev if last else None)
-            self._action_pin.copy_(self._action_dev, non_blocking=True)
-            self._step_dev.add_(1)
+                                           self._action_dev if last else None,
+                                           self._action_pin if last else None, self._step_dev if last else None)
             if self._graph_post is not None:
                 self._graph_post(self._action_dev)
             return

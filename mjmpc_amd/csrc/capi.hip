@@ -421,15 +421,18 @@ int mjmpc_rs_combine(const double* d_records, int G, int H, int A, double step_s
 
 int mjmpc_mppi_fused_update(int dtype, int64_t P, int H, int A, const double* d_q0, const void* d_actions, double lam,
                             double step_size, int shift_mode, double* d_mean, double* d_action_out, double* d_record,
-                            double* d_value, void* d_ws, void* stream) {
+                            double* d_value, double* h_action_mapped, int64_t* d_step_counter, void* d_ws,
+                            void* stream) {
     if (!d_actions || !d_mean || !d_ws) return fail(MJMPC_E_BADARG, "null argument");
     if (!(lam > 0) || shift_mode > 1) return fail(MJMPC_E_BADARG, "bad lam / shift_mode");
     hipStream_t s = (hipStream_t)stream;
     DISPATCH(dtype,
              mjmpc::mppi_fused_update<float>(d_q0, (const float*)d_actions, lam, step_size, shift_mode, (long)P, H, A,
-                                             d_mean, d_action_out, d_record, d_value, (double*)d_ws, s),
+                                             d_mean, d_action_out, d_record, d_value, (double*)d_ws, s, h_action_mapped,
+                                             (long long*)d_step_counter),
              mjmpc::mppi_fused_update<double>(d_q0, (const double*)d_actions, lam, step_size, shift_mode, (long)P, H, A,
-                                              d_mean, d_action_out, d_record, d_value, (double*)d_ws, s));
+                                              d_mean, d_action_out, d_record, d_value, (double*)d_ws, s,
+                                              h_action_mapped, (long long*)d_step_counter));
 }
 
 int mjmpc_q0_sum(int64_t P, int H, int A, double* d_out, void* d_ws, void* stream) {
@@ -444,14 +447,14 @@ int mjmpc_shift_mean(double* d_mean, int H, int A, int mode, const double* d_row
 
 int mjmpc_sample_noise(int dtype, void* d_noise, int64_t P, int H, int A, const double* d_chol,
                        const double* d_coeffs, uint64_t seed, uint64_t offset, int64_t particle_offset,
-                       const int64_t* d_step, void* stream) {
+                       const int64_t* d_step, int chol_is_diagonal, void* stream) {
     if (!d_noise || !d_chol) return fail(MJMPC_E_BADARG, "null argument");
     hipStream_t s = (hipStream_t)stream;
     DISPATCH(dtype,
              mjmpc::sample_noise<float>((float*)d_noise, (long)P, H, A, d_chol, d_coeffs, seed, offset,
-                                        (long)particle_offset, (const long long*)d_step, s),
+                                        (long)particle_offset, (const long long*)d_step, s, chol_is_diagonal),
              mjmpc::sample_noise<double>((double*)d_noise, (long)P, H, A, d_chol, d_coeffs, seed, offset,
-                                         (long)particle_offset, (const long long*)d_step, s));
+                                         (long)particle_offset, (const long long*)d_step, s, chol_is_diagonal));
 }
 
 }  // extern "C"

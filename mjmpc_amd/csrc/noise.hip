@@ -48,7 +48,7 @@ __device__ __forceinline__ void normal_pair(unsigned long long seed, unsigned lo
 template <typename T>
 __global__ void noise_kernel(T* __restrict__ noise, long P, int H, int A, const double* __restrict__ chol,
                              unsigned long long seed, unsigned long long offset, long particle_offset,
-                             const long long* __restrict__ d_step) {
+                             const long long* __restrict__ d_step, int diag_only) {
     if (d_step) offset += (unsigned long long)*d_step;      // step counter kept on the device (graph replay)
     const int H2 = (H + 1) / 2;
     const long gid = (long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -57,7 +57,7 @@ __global__ void noise_kernel(T* __restrict__ noise, long P, int H, int A, const 
     const int t2 = (int)((gid / A) % H2);
     const long p = gid / ((long)A * H2);
     double x0 = 0.0, x1 = 0.0;
-    for (int b = 0; b <= a; ++b) {
+    for (int b = diag_only ? a : 0; b <= a; ++b) {
         const double l = chol[a * A + b];
         if (l == 0.0) continue;
         double z0, z1;
@@ -95,19 +95,19 @@ __global__ void filter_kernel(T* __restrict__ noise, long P, int H, int A, const
 template <typename T>
 hipError_t sample_noise(T* noise, long P, int H, int A, const double* chol, const double* coeffs,
                         unsigned long long seed, unsigned long long offset, long particle_offset, const long long* d_step,
-                        hipStream_t s) {
+                        hipStream_t s, int diag_only) {
     if (P <= 0 || H <= 0) return hipSuccess;
     const long n = P * A * ((H + 1) / 2), m = P * A;
     hipLaunchKernelGGL(noise_kernel<T>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, noise, P, H, A, chol, seed,
-                       offset, particle_offset, d_step);
+                       offset, particle_offset, d_step, diag_only);
     if (coeffs)     // null: leave the samples raw (the rollout kernel can apply the filter on the fly)
         hipLaunchKernelGGL(filter_kernel<T>, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, s, noise, P, H, A, coeffs);
     return hipGetLastError();
 }
 
 template hipError_t sample_noise<float>(float*, long, int, int, const double*, const double*, unsigned long long,
-                                        unsigned long long, long, const long long*, hipStream_t);
+                                        unsigned long long, long, const long long*, hipStream_t, int);
 template hipError_t sample_noise<double>(double*, long, int, int, const double*, const double*, unsigned long long,
-                                         unsigned long long, long, const long long*, hipStream_t);
+                                         unsigned long long, long, const long long*, hipStream_t, int);
 
 }  // namespace mjmpc

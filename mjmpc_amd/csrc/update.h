@@ -41,7 +41,7 @@ hipError_t rs_combine(const double* records, int G, int H, int A, double step, d
 template <typename T>
 hipError_t mppi_fused_update(const double* q0, const T* actions, double lam, double step, int shift_mode, long P, int H,
                              int A, double* mean, double* action_out, double* record, double* value, double* ws,
-                             hipStream_t s);
+                             hipStream_t s, double* action_host = nullptr, long long* step_counter = nullptr);
 
 hipError_t q0_sum(long P, int H, int A, double* out, double* ws, hipStream_t s);
 hipError_t shift_mean(double* mean, int H, int A, int mode, const double* row, hipStream_t s);
@@ -51,6 +51,6 @@ hipError_t shift_mean(double* mean, int H, int A, int mode, const double* row, h
 template <typename T>
 hipError_t sample_noise(T* noise, long P, int H, int A, const double* chol, const double* coeffs,
                         unsigned long long seed, unsigned long long offset, long particle_offset, const long long* d_step,
-                        hipStream_t s);
+                        hipStream_t s, int diag_only = 0);
 
 }  // namespace mjmpc

@@ -413,7 +413,8 @@ __global__ void fused_partial_kernel(const double* __restrict__ q0, const T* __r
 __global__ void fused_final_kernel(const double* __restrict__ partial, int nb, int H, int A, double lam, double step,
                                    int shift_mode, double P_total, double* __restrict__ mean,
                                    double* __restrict__ action_out, double* __restrict__ record,
-                                   double* __restrict__ value) {
+                                   double* __restrict__ value, double* __restrict__ action_host,
+                                   long long* __restrict__ step_counter) {
     extern __shared__ double sh[];          // sc[nb] | nm[H*A] | red[4]
     const int HA = H * A, rec = 2 + HA;
     double* sc = sh;
@@ -441,6 +442,8 @@ __global__ void fused_final_kernel(const double* __restrict__ partial, int nb, i
     }
     __syncthreads();
     if (action_out && threadIdx.x < A) action_out[threadIdx.x] = nm[threadIdx.x];
+    if (action_host && threadIdx.x < A) action_host[threadIdx.x] = nm[threadIdx.x];   // mapped pinned host memory
+    if (step_counter && threadIdx.x == 0) *step_counter += 1;                         // noise stream of the next step
     for (int j = threadIdx.x; j < HA; j += blockDim.x) {
         double v = nm[j];
         if (shift_mode >= 0) {
@@ -583,13 +586,13 @@ hipError_t rs_combine(const double* records, int G, int H, int A, double step, d
 template <typename T>
 hipError_t mppi_fused_update(const double* q0, const T* actions, double lam, double step, int shift_mode, long P, int H,
                              int A, double* mean, double* action_out, double* record, double* value, double* ws,
-                             hipStream_t s) {
+                             hipStream_t s, double* action_host, long long* step_counter) {
     Ws w(ws, P, H, A);
     const int nb = nblocks(P, FCH), HA = H * A;
     if (!q0) q0 = w.q0;
     hipLaunchKernelGGL(fused_partial_kernel<T>, dim3(nb), dim3(BLK), 0, s, q0, actions, lam, P, HA, w.partial);
     hipLaunchKernelGGL(fused_final_kernel, dim3(1), dim3(BLK), sizeof(double) * (nb + HA + 4), s, w.partial, nb, H, A, lam,
-                       step, shift_mode, (double)P, mean, action_out, record, value);
+                       step, shift_mode, (double)P, mean, action_out, record, value, action_host, step_counter);
     return hipGetLastError();
 }
 
@@ -616,7 +619,7 @@ hipError_t shift_mean(double* mean, int H, int A, int mode, const double* row, h
                                          double*, hipStream_t);                                                      \
     template hipError_t rs_best<T>(const T*, long, long, int, int, double*, double*, hipStream_t);                   \
     template hipError_t mppi_fused_update<T>(const double*, const T*, double, double, int, long, int, int, double*,  \
-                                             double*, double*, double*, double*, hipStream_t);
+                                             double*, double*, double*, double*, hipStream_t, double*, long long*);
 INST(float)
 INST(double)
 
