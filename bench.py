@@ -38,7 +38,9 @@ def parse():
     ap.add_argument("--particles", type=int, default=4096, help="particles PER GPU")
     ap.add_argument("--horizon", type=int, default=32)
     ap.add_argument("--dtype", choices=["f64", "f32"], default="f64")
-    ap.add_argument("--noise", choices=["device", "host"], default="device")
+    ap.add_argument("--noise", choices=["device", "mt19937", "host"], default="device",
+                    help="device: Philox on the GPU; mt19937: the reference's own numpy stream regenerated on the GPU "
+                         "(seed-identical particles); host: numpy on the host, uploaded")
     ap.add_argument("--no-graph", action="store_true", help="launch every kernel eagerly instead of replaying a hipGraph")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=10.0)
@@ -128,7 +130,8 @@ def main():
     ctrl = MPPI(d_state=eng.d_state, d_obs=eng.d_obs, d_action=A, horizon=H, init_cov=1.0, base_action="null",
                 lam=0.01, num_particles=P_tot, step_size=1.0, alpha=1, gamma=1.0, n_iters=1,
                 action_lows=eng.action_lows, action_highs=eng.action_highs, filter_coeffs=[0.25, 0.8, 0.0],
-                seed=123, noise_mode=args.noise, noise_dtype=args.dtype, device=local, comm=comm)
+                seed=123, noise_mode={"mt19937": "device_mt19937"}.get(args.noise, args.noise), noise_dtype=args.dtype,
+                device=local, comm=comm)
     base_fn = make_device_rollout_fn(eng)
     ev = []
 
@@ -141,7 +144,7 @@ def main():
         return out
 
     rollout_fn.accepts_device = True
-    graphed = (not args.no_graph and args.noise == "device" and (world == 1 or args.backend == "nccl"))
+    graphed = (not args.no_graph and args.noise in ("device", "mt19937") and (world == 1 or args.backend == "nccl"))
     ctrl.rollout_fn = base_fn if graphed else rollout_fn
     ctrl.set_sim_state_fn = lambda s: None          # the "real" arm lives on the device (step_state)
     eng.set_env_state(dict(qp=np.zeros(7), qv=np.zeros(7), target_pos=np.array([0.1, 0.1, 0.1])))
@@ -178,7 +181,7 @@ def main():
     if graphed:
         # inside a replayed graph there is nothing to bracket from the host: time the dominant kernel
         # right here with events on its launch stream, 20 back-to-back launches on the run's own buffers
-        noise_t = ctrl.dev._rec[("noise", args.dtype)]
+        noise_t = ctrl.dev._rec[("noise_mt" if args.noise == "mt19937" else "noise", args.dtype)]
         n_t = 20
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         eng.rollout_device(P_loc, H, ctrl.dev.mean, noise_t)

@@ -202,6 +202,19 @@ int mjmpc_q0_sum(int64_t P, int H, int A, double* d_out, void* d_ws, void* strea
  * 2 the appended row is read from d_row ('random': drawn by the host from np.random).            */
 int mjmpc_shift_mean(double* d_mean, int H, int A, int mode, const double* d_row, void* stream);
 
+/* The recursive filter of generate_noise alone (control_utils.py:32-33), in place on d_noise [P][H][A]. */
+int mjmpc_filter_noise(int dtype, void* d_noise, int64_t P, int H, int A, const double* d_coeffs, void* stream);
+
+/* control_utils.generate_noise (mjmpc/utils/control_utils.py:24-34), SEED-IDENTICAL mode for an isotropic
+ * covariance c*I: d_noise[0..n_normals) = scale * the numpy legacy stream `np.random.seed(seed + *d_step);
+ * standard_normal(n_normals)` (MT19937 + polar method), regenerated on the device, unfiltered (C order over
+ * (P,H,A); scale = sqrt(c)).  Stream alignment is exact; values agree with numpy to <= 2 ulp (log()).
+ * d_ws: mjmpc_mt19937_workspace_bytes(n_normals) bytes, 16-byte aligned.  *d_status (device int, may be
+ * NULL) is set to 1 if the generated margin of polar attempts did not suffice.                    */
+int64_t mjmpc_mt19937_workspace_bytes(int64_t n_normals);
+int mjmpc_sample_noise_mt19937(int dtype, void* d_noise, int64_t n_normals, double scale, uint64_t seed,
+                               const int64_t* d_step, void* d_ws, int* d_status, void* stream);
+
 /* control_utils.generate_noise (mjmpc/utils/control_utils.py:24-34), performance mode: Philox
  * normals coloured by the lower Cholesky factor d_chol (float64 [A][A]) and filtered in place with
  * d_coeffs (float64 [3]; NULL leaves the samples raw for mjmpc_arm_rollout_fused to filter).  Same distribution as the reference, different bit stream; `offset`

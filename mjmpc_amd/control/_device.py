@@ -257,6 +257,38 @@ class DeviceUpdater:
             row_d.copy_(self.torch.from_numpy(np.ascontiguousarray(row, np.float64)))
         _lib.check(self.lib.mjmpc_shift_mean(_vp(self.mean), self.H, self.A, int(mode), _vp(row_d), self.stream()))
 
+    def sample_noise_mt19937(self, P, cov, filter_coeffs, seed, offset, dtype="f64", d_step=None, filtered=True):
+        """The reference's own noise (legacy numpy stream of ``np.random.seed(seed + offset)``) regenerated
+        on the device; isotropic covariance only.  Returns the (P,H,A) tensor, filtered unless told not to."""
+        torch = self.torch
+        cov = np.asarray(cov, np.float64)
+        c = float(cov[0, 0])
+        if np.count_nonzero(cov - c * np.eye(self.A)) != 0:
+            raise ValueError("seed-identical device noise needs an isotropic covariance c*I")
+        tdt = torch.float32 if dtype == "f32" else torch.float64
+        key = ("noise_mt", dtype)
+        buf = self._rec.get(key)
+        n = P * self.H * self.A
+        if buf is None or tuple(buf.shape) != (P, self.H, self.A):
+            buf = self._rec[key] = torch.empty((P, self.H, self.A), dtype=tdt, device=self.device)
+            nbytes = self.lib.mjmpc_mt19937_workspace_bytes(n)
+            self._rec["mt_ws"] = torch.empty((nbytes + 15) // 16 * 2, dtype=torch.float64, device=self.device)
+            self._rec["mt_status"] = torch.zeros(1, dtype=torch.int32, device=self.device)
+        fc = np.asarray(filter_coeffs, np.float64)
+        co = self.record("coeffs", 3)
+        cached = self._rec.get("mt_coeffs")
+        if cached is None or not np.array_equal(cached, fc):
+            co.copy_(torch.from_numpy(fc.copy()))
+            self._rec["mt_coeffs"] = fc.copy()
+        _lib.check(self.lib.mjmpc_sample_noise_mt19937(_lib.F32 if dtype == "f32" else _lib.F64, _vp(buf), n,
+                                                       float(np.sqrt(c)), (int(seed) + int(offset)) & (2 ** 64 - 1),
+                                                       _vp(d_step), _vp(self._rec["mt_ws"]),
+                                                       _vp(self._rec["mt_status"]), self.stream()))
+        if filtered and not (fc[0] == 1.0 and fc[1] == 0.0 and fc[2] == 0.0):
+            _lib.check(self.lib.mjmpc_filter_noise(_lib.F32 if dtype == "f32" else _lib.F64, _vp(buf), P, self.H, self.A,
+                                                   _vp(co), self.stream()))
+        return buf
+
     def sample_noise(self, P, cov, filter_coeffs, seed, offset, dtype="f64", particle_offset=0, d_step=None,
                      filtered=True):
         torch = self.torch

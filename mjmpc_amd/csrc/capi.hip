@@ -10,6 +10,7 @@
 #include "arm_model.h"
 #include "analytic_rollout.h"
 #include "arm_rollout.h"
+#include "noise_mt.h"
 #include "update.h"
 
 namespace {
@@ -443,6 +444,26 @@ int mjmpc_q0_sum(int64_t P, int H, int A, double* d_out, void* d_ws, void* strea
 int mjmpc_shift_mean(double* d_mean, int H, int A, int mode, const double* d_row, void* stream) {
     if (!d_mean || (mode == 2 && !d_row) || mode < 0 || mode > 2) return fail(MJMPC_E_BADARG, "bad argument");
     PLAIN(mjmpc::shift_mean(d_mean, H, A, mode, d_row, (hipStream_t)stream));
+}
+
+int mjmpc_filter_noise(int dtype, void* d_noise, int64_t P, int H, int A, const double* d_coeffs, void* stream) {
+    if (!d_noise || !d_coeffs) return fail(MJMPC_E_BADARG, "null argument");
+    hipStream_t s = (hipStream_t)stream;
+    DISPATCH(dtype, mjmpc::filter_noise<float>((float*)d_noise, (long)P, H, A, d_coeffs, s),
+             mjmpc::filter_noise<double>((double*)d_noise, (long)P, H, A, d_coeffs, s));
+}
+
+int64_t mjmpc_mt19937_workspace_bytes(int64_t n_normals) { return (int64_t)mjmpc::mt_workspace_bytes((long)n_normals); }
+
+int mjmpc_sample_noise_mt19937(int dtype, void* d_noise, int64_t n_normals, double scale, uint64_t seed,
+                               const int64_t* d_step, void* d_ws, int* d_status, void* stream) {
+    if (!d_noise || !d_ws) return fail(MJMPC_E_BADARG, "null argument");
+    hipStream_t s = (hipStream_t)stream;
+    DISPATCH(dtype,
+             mjmpc::sample_noise_mt19937<float>((float*)d_noise, (long)n_normals, scale, seed, (const long long*)d_step,
+                                                d_ws, d_status, s),
+             mjmpc::sample_noise_mt19937<double>((double*)d_noise, (long)n_normals, scale, seed,
+                                                 (const long long*)d_step, d_ws, d_status, s));
 }
 
 int mjmpc_sample_noise(int dtype, void* d_noise, int64_t P, int H, int A, const double* d_chol,

@@ -105,6 +105,16 @@ hipError_t sample_noise(T* noise, long P, int H, int A, const double* chol, cons
     return hipGetLastError();
 }
 
+template <typename T>
+hipError_t filter_noise(T* noise, long P, int H, int A, const double* coeffs, hipStream_t s) {
+    const long m = P * A;
+    if (m <= 0) return hipSuccess;
+    hipLaunchKernelGGL(filter_kernel<T>, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, s, noise, P, H, A, coeffs);
+    return hipGetLastError();
+}
+template hipError_t filter_noise<float>(float*, long, int, int, const double*, hipStream_t);
+template hipError_t filter_noise<double>(double*, long, int, int, const double*, hipStream_t);
+
 template hipError_t sample_noise<float>(float*, long, int, int, const double*, const double*, unsigned long long,
                                         unsigned long long, long, const long long*, hipStream_t, int);
 template hipError_t sample_noise<double>(double*, long, int, int, const double*, const double*, unsigned long long,

@@ -1,0 +1,16 @@
+#pragma once
+#include <hip/hip_runtime.h>
+
+namespace mjmpc {
+
+// polar attempts generated for n_normals samples (acceptance pi/4 plus a 1 % margin) and the workspace they need
+long mt_attempts_for(long n_normals);
+long mt_workspace_bytes(long n_normals);
+
+// noise[0..n) = scale * (numpy legacy standard_normal stream after np.random.seed(seed + *d_step)); see noise_mt.hip.
+// *status (device int, may be null) = 1 if the margin of attempts was not enough (never observed).
+template <typename T>
+hipError_t sample_noise_mt19937(T* noise, long n_normals, double scale, unsigned long long seed, const long long* d_step,
+                                void* ws, int* status, hipStream_t s);
+
+}  // namespace mjmpc

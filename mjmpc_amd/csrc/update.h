@@ -53,4 +53,8 @@ hipError_t sample_noise(T* noise, long P, int H, int A, const double* chol, cons
                         unsigned long long seed, unsigned long long offset, long particle_offset, const long long* d_step,
                         hipStream_t s, int diag_only = 0);
 
+// the in-place recursive 3-tap filter of control_utils.py:32-33 on its own
+template <typename T>
+hipError_t filter_noise(T* noise, long P, int H, int A, const double* coeffs, hipStream_t s);
+
 }  // namespace mjmpc
