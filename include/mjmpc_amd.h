@@ -215,6 +215,20 @@ int64_t mjmpc_mt19937_workspace_bytes(int64_t n_normals);
 int mjmpc_sample_noise_mt19937(int dtype, void* d_noise, int64_t n_normals, double scale, uint64_t seed,
                                const int64_t* d_step, void* d_ws, int* d_status, void* stream);
 
+/* The same stream produced in parallel.  MT19937's recurrence is serial, but its state transition is linear
+ * over GF(2): the state J words ahead is the XOR of the word windows x[i .. i+624) over the set bits i of
+ * t^J mod phi (phi = the generator's characteristic polynomial).  One workgroup generates the first
+ * head_words (a multiple of 4 in [19936, 19968]) words serially; workgroup g of n_segments (<= 64) then starts directly at word
+ * head_words + g*seg_words.  d_jump_idx / d_jump_starts[n_segments+1] (device int32) hold the set-bit lists
+ * of t^(head_words + g*seg_words) mod phi, g >= 1 (entry 0 empty), as computed by
+ * mjmpc_amd/control/mt_jump.py; the segments must cover mjmpc_mt19937_stream_words(n_normals) words.
+ * n_segments == 0 behaves as mjmpc_sample_noise_mt19937.  Output is bit-identical for any segmentation.  */
+int64_t mjmpc_mt19937_stream_words(int64_t n_normals);
+int mjmpc_sample_noise_mt19937_jump(int dtype, void* d_noise, int64_t n_normals, double scale, uint64_t seed,
+                                    const int64_t* d_step, const int32_t* d_jump_idx, const int32_t* d_jump_starts,
+                                    int64_t head_words, int64_t seg_words, int n_segments, void* d_ws, int* d_status,
+                                    void* stream);
+
 /* control_utils.generate_noise (mjmpc/utils/control_utils.py:24-34), performance mode: Philox
  * normals coloured by the lower Cholesky factor d_chol (float64 [A][A]) and filtered in place with
  * d_coeffs (float64 [3]; NULL leaves the samples raw for mjmpc_arm_rollout_fused to filter).  Same distribution as the reference, different bit stream; `offset`

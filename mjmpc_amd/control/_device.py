@@ -11,6 +11,7 @@ import ctypes
 import numpy as np
 
 from .. import _lib
+from . import mt_jump
 
 
 def _vp(t):
@@ -70,6 +71,7 @@ class DeviceUpdater:
         self.wnorm = torch.zeros(2, dtype=torch.float64, device=self.device)
         self._ws, self._ws_P = None, -1
         self._rec = {}
+        self.mt_segments = 32            # workgroups generating the MT19937 stream in parallel (0/1 = serial)
 
     # ------------------------------------------------------------------ plumbing
     def stream(self):
@@ -274,16 +276,25 @@ class DeviceUpdater:
             nbytes = self.lib.mjmpc_mt19937_workspace_bytes(n)
             self._rec["mt_ws"] = torch.empty((nbytes + 15) // 16 * 2, dtype=torch.float64, device=self.device)
             self._rec["mt_status"] = torch.zeros(1, dtype=torch.int32, device=self.device)
+            # jump-ahead plan: serial head + MT_SEGMENTS workgroups (tables are host-computed once per size)
+            head, seg, nseg = mt_jump.plan_segments(int(self.lib.mjmpc_mt19937_stream_words(n)), self.mt_segments)
+            if nseg:
+                idx, starts = mt_jump.jump_tables(seg, nseg, head)
+                self._rec["mt_jump"] = (torch.from_numpy(idx.copy()).to(self.device),
+                                        torch.from_numpy(starts.copy()).to(self.device), head, seg, nseg)
+            else:
+                self._rec["mt_jump"] = (None, None, 0, 0, 0)
         fc = np.asarray(filter_coeffs, np.float64)
         co = self.record("coeffs", 3)
         cached = self._rec.get("mt_coeffs")
         if cached is None or not np.array_equal(cached, fc):
             co.copy_(torch.from_numpy(fc.copy()))
             self._rec["mt_coeffs"] = fc.copy()
-        _lib.check(self.lib.mjmpc_sample_noise_mt19937(_lib.F32 if dtype == "f32" else _lib.F64, _vp(buf), n,
-                                                       float(np.sqrt(c)), (int(seed) + int(offset)) & (2 ** 64 - 1),
-                                                       _vp(d_step), _vp(self._rec["mt_ws"]),
-                                                       _vp(self._rec["mt_status"]), self.stream()))
+        jidx, jstarts, head, seg, nseg = self._rec["mt_jump"]
+        _lib.check(self.lib.mjmpc_sample_noise_mt19937_jump(
+            _lib.F32 if dtype == "f32" else _lib.F64, _vp(buf), n, float(np.sqrt(c)),
+            (int(seed) + int(offset)) & (2 ** 64 - 1), _vp(d_step), _vp(jidx), _vp(jstarts), head, seg, nseg,
+            _vp(self._rec["mt_ws"]), _vp(self._rec["mt_status"]), self.stream()))
         if filtered and not (fc[0] == 1.0 and fc[1] == 0.0 and fc[2] == 0.0):
             _lib.check(self.lib.mjmpc_filter_noise(_lib.F32 if dtype == "f32" else _lib.F64, _vp(buf), P, self.H, self.A,
                                                    _vp(co), self.stream()))

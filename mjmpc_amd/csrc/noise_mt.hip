@@ -45,50 +45,120 @@ __device__ __forceinline__ unsigned temper(unsigned y) {
     return y;
 }
 
-// out[j] = j-th UNTEMPERED twister word after np.random.seed(seed + *d_step) (tempering is a pure per-word
-// function and is left to the massively parallel consumers: the serial kernel keeps only what is serial).
+// Twister words, UNTEMPERED (tempering is a pure per-word function and is left to the massively parallel
+// consumers: the serial kernel keeps only what is serial).  all[0..624) = the seeded state x[0..624),
+// all[624 + j] = x[624 + j] = j-th generated word.
+//
+// One workgroup produces one SEGMENT of the stream:
+//   head launch (1 workgroup, jump_idx == nullptr): seed -> words [0, head_words)
+//   body launch (G workgroups): workgroup g owns words [head_words + g*seg_words, +seg_words) and starts from
+//     the 624-word state at that offset, obtained WITHOUT walking the stream (jump-ahead, see
+//     mjmpc_amd/control/mt_jump.py):  x[J + w] = XOR over the set bits i of (t^J mod phi) of x[i + w];
+//     segment 0 starts where the head stopped and simply reads its state.
 // The LDS buffer is LINEAR: addresses are one running base + compile-time offsets (no per-read index
 // arithmetic); every SPAN steps the last LOOKBACK words are moved back to the front.
+constexpr int JSLICES = 8;                     // workgroups sharing one segment's jump reduction
+constexpr int JHEAD_MAX = MT_N + 19968;        // words of the head staged in LDS by mt_jump_kernel (82 KB)
+
 constexpr int LOOKBACK = 1078;                 // deepest word the 3x-unrolled recurrence reads
 constexpr int SPAN = 22;                       // steps between compactions: LOOKBACK + SPAN * CHUNK words of LDS
 constexpr int LINEAR = LOOKBACK + SPAN * CHUNK;
 
-__global__ __launch_bounds__(640) void mt_stream_kernel(unsigned long long seed, const long long* __restrict__ d_step,
-                                                        long n_out, unsigned* __restrict__ out) {
+// Jump-ahead reduction: workgroup (g, slice) XORs the windows x[i .. i+624) of its share of segment g's
+// set-bit list.  The head of the stream (82 KB) is staged in LDS once per workgroup - the 10^4 x 624 reads per
+// segment are then LDS traffic spread over 8 CUs instead of L2 latency in one.
+__global__ __launch_bounds__(640) void mt_jump_kernel(const unsigned* __restrict__ all, int head_total,
+                                                      const int* __restrict__ jump_idx,
+                                                      const int* __restrict__ jump_starts,
+                                                      unsigned* __restrict__ jump_states) {
+    __shared__ unsigned x[JHEAD_MAX];
+    const int g = blockIdx.x / JSLICES, sl = blockIdx.x % JSLICES, tid = threadIdx.x;
+    if (g == 0) return;                         // segment 0 continues the head
+    {
+        const uint4* src = (const uint4*)all;   // head_total is a multiple of 4
+        uint4* dst = (uint4*)x;
+        for (int i = tid; i < head_total / 4; i += 640) dst[i] = src[i];
+    }
+    __syncthreads();
+    const int lo = jump_starts[g], cnt = jump_starts[g + 1] - lo;
+    const int per = (cnt + JSLICES - 1) / JSLICES;
+    const int k0 = lo + sl * per, k1 = min(lo + cnt, k0 + per);
+    if (tid < MT_N) {
+        unsigned acc = 0;
+        const unsigned* xt = x + tid;
+        int k = k0;
+        for (; k + 8 <= k1; k += 8) {
+            const unsigned t0 = xt[jump_idx[k]], t1 = xt[jump_idx[k + 1]], t2 = xt[jump_idx[k + 2]],
+                           t3 = xt[jump_idx[k + 3]], t4 = xt[jump_idx[k + 4]], t5 = xt[jump_idx[k + 5]],
+                           t6 = xt[jump_idx[k + 6]], t7 = xt[jump_idx[k + 7]];
+            acc ^= t0 ^ t1 ^ t2 ^ t3 ^ t4 ^ t5 ^ t6 ^ t7;
+        }
+        for (; k < k1; ++k) acc ^= xt[jump_idx[k]];
+        jump_states[(long)blockIdx.x * MT_N + tid] = acc;
+    }
+}
+
+__global__ __launch_bounds__(640) void mt_segment_kernel(unsigned long long seed, const long long* __restrict__ d_step,
+                                                         unsigned* __restrict__ all, long head_words, long seg_words,
+                                                         long total_words,
+                                                         const unsigned* __restrict__ jump_states) {
     __shared__ unsigned r[LINEAR];
     const int tid = threadIdx.x;
     const bool lane_on = tid < CHUNK;
-    // seeded state x[0..623] placed so that the first generated chunk lands right behind it
-    constexpr int BASE0 = LOOKBACK - MT_N;      // x[j] lives at r[BASE0 + j] during the start-up
-    if (tid == 0) {
-        unsigned s = (unsigned)((seed + (d_step ? (unsigned long long)*d_step : 0ull)) & 0xffffffffull);
-        for (int pos = 0; pos < MT_N; ++pos) {          // numpy mt19937_seed == init_genrand
-            r[BASE0 + pos] = s;
-            s = 1812433253u * (s ^ (s >> 30)) + (unsigned)pos + 1u;
+    constexpr int BASE0 = LOOKBACK - MT_N;      // the 624-word start state lives at r[BASE0 .. LOOKBACK)
+    long first, n_out;                          // generated-word range [first, first + n_out) of this workgroup
+    if (!jump_states) {
+        first = 0;
+        n_out = head_words < total_words ? head_words : total_words;
+        if (tid == 0) {
+            unsigned s = (unsigned)((seed + (d_step ? (unsigned long long)*d_step : 0ull)) & 0xffffffffull);
+            for (int pos = 0; pos < MT_N; ++pos) {          // numpy mt19937_seed == init_genrand
+                r[BASE0 + pos] = s;
+                all[pos] = s;
+                s = 1812433253u * (s ^ (s >> 30)) + (unsigned)pos + 1u;
+            }
+        }
+    } else {
+        first = head_words + (long)blockIdx.x * seg_words;
+        n_out = total_words - first;
+        if (n_out > seg_words) n_out = seg_words;
+        if (n_out <= 0) return;
+        if (tid < MT_N) {
+            unsigned acc;
+            if (blockIdx.x == 0) {
+                acc = all[first + tid];                     // state x[first .. first+624) in `all` indexing
+            } else {
+                acc = 0;                                    // XOR of the slices mt_jump_kernel reduced
+                const unsigned* part = jump_states + (long)blockIdx.x * JSLICES * MT_N + tid;
+#pragma unroll
+                for (int sl = 0; sl < JSLICES; ++sl) acc ^= part[sl * MT_N];
+            }
+            r[BASE0 + tid] = acc;
         }
     }
     __syncthreads();
-    // first chunk (n in [624, 1247)): x[n-227] may itself be new, so the plain recurrence runs in three
-    // dependent waves of <= 227 words (once per stream)
+    unsigned* out = all + MT_N + first;
+    // first chunk: x[n-227] may itself be new, so the plain recurrence runs in three dependent waves of <= 227
+    // words (once per segment); it needs nothing older than the 624-word state
     {
         const int n = MT_N + tid;
         unsigned v = 0;
         for (int ph = 0; ph < 3; ++ph) {
             const int t = tid - ph * 227;
-            if (t >= 0 && t < 227 && lane_on && n < MT_N + n_out) {
+            if (t >= 0 && t < 227 && lane_on && tid < n_out) {
                 v = r[BASE0 + n - 227] ^ twist(r[BASE0 + n - 624], r[BASE0 + n - 623]);
                 r[BASE0 + n] = v;
             }
             __syncthreads();
         }
-        if (lane_on && n < MT_N + n_out) out[n - MT_N] = v;
+        if (lane_on && tid < n_out) out[tid] = v;
     }
     // steady state.  `cur` = LDS slot of the word this lane produces next; the chunk just produced sits at
     // [LOOKBACK, LOOKBACK + CHUNK), i.e. exactly one compaction phase into the buffer.
     int cur = LOOKBACK + CHUNK + tid;
     unsigned* o = out + CHUNK + tid;
     long left = n_out - CHUNK - tid;
-    const long steps = (n_out - CHUNK + CHUNK - 1) / CHUNK;
+    const long steps = n_out > CHUNK ? (n_out - CHUNK + CHUNK - 1) / CHUNK : 0;
     int in_span = 1;
     for (long st = 0; st < steps; ++st) {
         if (in_span == SPAN) {          // move the last LOOKBACK words to the front (640 threads, 2 passes)
@@ -114,7 +184,7 @@ __global__ __launch_bounds__(640) void mt_stream_kernel(unsigned long long seed,
         left -= CHUNK;
         ++in_span;
         // LDS-only barrier: __syncthreads() would also drain the global store above (vmcnt(0)) on every
-        // one of the ~3800 steps; the words are only read by later kernels
+        // step; the words are only read by later kernels
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
     }
 }
@@ -204,18 +274,34 @@ long mt_attempts_for(long n_normals) {
 
 long mt_workspace_bytes(long n_normals) {
     const long na = mt_attempts_for(n_normals), nb = (na + FBLK - 1) / FBLK;
-    return 16 * na + 4 * nb + 8 * (nb + 1) + 64;
+    return 4 * MT_N + 16 * na + 4 * nb + 8 * (nb + 1) + 64 + 4L * MT_MAX_SEGMENTS * JSLICES * MT_N;
 }
 
 template <typename T>
 hipError_t sample_noise_mt19937(T* noise, long n_normals, double scale, unsigned long long seed, const long long* d_step,
-                                void* ws, int* status, hipStream_t s) {
+                                void* ws, int* status, hipStream_t s, const int* jump_idx, const int* jump_starts,
+                                long head_words, long seg_words, int n_segments) {
     if (n_normals <= 0) return hipSuccess;
     const long na = mt_attempts_for(n_normals), nb = (na + FBLK - 1) / FBLK;
-    unsigned* words = (unsigned*)ws;                               // 4 * na
+    unsigned* all = (unsigned*)ws;                                  // 624 + 4 * na words
+    unsigned* words = all + MT_N;
     int* counts = (int*)(words + 4 * na);
     long* offsets = (long*)(((uintptr_t)(counts + nb) + 7) & ~(uintptr_t)7);
-    hipLaunchKernelGGL(mt_stream_kernel, dim3(1), dim3(640), 0, s, seed, d_step, 4 * na, words);
+    unsigned* jstates = (unsigned*)(offsets + nb + 1);              // [n_segments][JSLICES][624]
+    const long total = 4 * na;
+    if (jump_idx && n_segments > 0) {
+        // head (serial, short) then n_segments workgroups in parallel, each from its jumped-ahead state
+        if (n_segments > MT_MAX_SEGMENTS || MT_N + head_words > JHEAD_MAX || (head_words & 3)) return hipErrorInvalidValue;
+        hipLaunchKernelGGL(mt_segment_kernel, dim3(1), dim3(640), 0, s, seed, d_step, all, head_words, 0L, total,
+                           (const unsigned*)nullptr);
+        hipLaunchKernelGGL(mt_jump_kernel, dim3(n_segments * JSLICES), dim3(640), 0, s, all, (int)(MT_N + head_words),
+                           jump_idx, jump_starts, jstates);
+        hipLaunchKernelGGL(mt_segment_kernel, dim3(n_segments), dim3(640), 0, s, seed, d_step, all, head_words,
+                           seg_words, total, (const unsigned*)jstates);
+    } else {
+        hipLaunchKernelGGL(mt_segment_kernel, dim3(1), dim3(640), 0, s, seed, d_step, all, total, 0L, total,
+                           (const unsigned*)nullptr);
+    }
     hipLaunchKernelGGL(polar_flags_kernel, dim3((unsigned)nb), dim3(FBLK), 0, s, words, na, counts);
     hipLaunchKernelGGL(block_offsets_kernel, dim3(1), dim3(1024), 0, s, counts, (int)nb, offsets);
     hipLaunchKernelGGL(polar_emit_kernel<T>, dim3((unsigned)nb), dim3(FBLK), 0, s, words, na, offsets, n_normals, scale,
@@ -224,8 +310,8 @@ hipError_t sample_noise_mt19937(T* noise, long n_normals, double scale, unsigned
 }
 
 template hipError_t sample_noise_mt19937<float>(float*, long, double, unsigned long long, const long long*, void*, int*,
-                                                hipStream_t);
+                                                hipStream_t, const int*, const int*, long, long, int);
 template hipError_t sample_noise_mt19937<double>(double*, long, double, unsigned long long, const long long*, void*, int*,
-                                                 hipStream_t);
+                                                 hipStream_t, const int*, const int*, long, long, int);
 
 }  // namespace mjmpc

@@ -51,6 +51,25 @@ def test_full_size_stream_alignment_and_step_counter():
         dev.sample_noise_mt19937(8, np.diag([1.0, 2, 1, 1, 1, 1, 1]), [1.0, 0.0, 0.0], 1, 0)
 
 
+def test_jump_ahead_segmentation_is_bit_identical_to_the_serial_stream():
+    """The stream cut into 2 / 7 / 32 jumped-ahead segments equals the single-workgroup stream bit for bit
+    (and therefore numpy's), including a short last segment."""
+    from mjmpc_amd.control._device import DeviceUpdater
+    P, H, A, seed = 1024, 32, 7, 77
+    outs = {}
+    for nseg in (0, 2, 7, 32):
+        dev = DeviceUpdater(H, A, np.ones(H))
+        dev.mt_segments = nseg
+        outs[nseg] = dev.sample_noise_mt19937(P, np.eye(A), [1.0, 0.0, 0.0], seed, 3).cpu().numpy()
+        assert dev._rec["mt_jump"][4] == nseg
+        assert int(dev._rec["mt_status"].item()) == 0
+    for nseg in (2, 7, 32):
+        np.testing.assert_array_equal(outs[nseg], outs[0])
+    np.random.seed(seed + 3)
+    want = np.random.standard_normal((P, H, A))
+    assert _ulp_diff(outs[0], want).max() <= 4
+
+
 def test_device_resident_loop_reproduces_the_reference_stream_loop(raw_arm):
     """End to end: the captured, fully device-resident MPPI loop fed by the on-device MT19937 sampler walks
     the same closed loop as the SAME controller fed by the reference's host noise (control_utils.generate_noise,
