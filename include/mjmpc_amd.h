@@ -117,12 +117,14 @@ int mjmpc_arm_step_state(mjmpc_arm_t h, int dtype, const double* d_action, void*
  * pointer): kind 0 = PendulumEnv (mjmpc/envs/basic/pendulum.py:33-50; d_params = [max_speed,
  * max_torque, dt, g, m, l], d_state = [th, thdot], observations have 3 entries), kind 1 = LQREnv
  * (mjmpc/envs/basic/lqr.py:31-35; d_params = [A | B | Q | R] row-major, d_state = x[n_state],
- * n_state, n_action <= 8).  Arrays as in mjmpc_arm_rollout (costs = -reward).                     */
+ * n_state, n_action <= 8).  Arrays as in mjmpc_arm_rollout (costs = -reward).  closed_loop_linear != 0:
+ * d_mean is the (d_obs+1, n_action) weight matrix of mode "closed_loop_linear"
+ * (mjmpc/envs/gym_env_wrapper.py:135-136), action = W^T [obs; 1] + noise.                          */
 #define MJMPC_ENV_PENDULUM 0
 #define MJMPC_ENV_LQR 1
 int mjmpc_analytic_rollout(int kind, const double* d_params, int n_state, int n_action, const double* d_state, int dtype,
                            int64_t P, int H, const double* d_mean, const void* d_noise, void* d_costs, void* d_actions,
-                           void* d_obs, void* d_next_obs, void* stream);
+                           void* d_obs, void* d_next_obs, int closed_loop_linear, void* stream);
 
 /* Number of (particle, substep) constraint solves whose active set had not settled after the
  * iteration cap since engine creation (synchronises the device).  0 in every test.               */
@@ -148,6 +150,17 @@ int mjmpc_softmax_record_len(int H, int A, int time_based_weights);
 int mjmpc_traj_cost(int dtype, int64_t P, int H, int A, const void* d_costs, const double* d_gseq, int gamma_zero,
                     void* d_ws, void* stream);
 double* mjmpc_workspace_q0(void* d_ws, int64_t P, int H, int A);
+
+/* MPPIQ.calculate_returns + _control_costs (mjmpc/control/mppiq.py:104-136): TD(lambda) returns
+ * d_returns (dtype [P][H]) from the per-step costs (+ beta * per-step control cost when alpha == 0; then
+ * d_actions, d_mean, d_covinv are read) and the optional Q estimates d_qvals (dtype [P][H]; NULL = the
+ * reference's default: zero except the last step's own cost).  d_wseq (float64 [H-1]) =
+ * cumprod(1, gamma*td_lam, ...) (mppiq.py:120); wseq_has_zero selects cost_to_go's pass-through branch
+ * (control_utils.py:39-40).  Feed d_returns to mjmpc_softmax_stats with gamma_zero = 1, alpha = 1.   */
+int mjmpc_td_lambda_returns(int dtype, int64_t P, int H, int A, const void* d_costs, const void* d_actions,
+                            const void* d_qvals, const double* d_mean, const double* d_covinv, const double* d_wseq,
+                            int wseq_has_zero, double beta, int alpha, double gamma, double td_lam, void* d_returns,
+                            void* d_ws, void* stream);
 
 /* MPPI._exp_util + _control_costs (mjmpc/control/mppi.py:84-111), DMDMPC._exp_util
  * (gaussian_dmd.py:94-104), PFMPC._exp_util (particle_filter_controller.py:104-113): exponentiated

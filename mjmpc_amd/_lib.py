@@ -32,12 +32,15 @@ SIGNATURES = {
     "mjmpc_arm_rollout_cl": (_int, [_vp, _int, _i64, _int, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "mjmpc_arm_rollout_fused": (_int, [_vp, _int, _i64, _int, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "mjmpc_arm_step_state": (_int, [_vp, _int, _vp, _vp, _vp, _vp]),
-    "mjmpc_analytic_rollout": (_int, [_int, _vp, _int, _int, _vp, _int, _i64, _int, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "mjmpc_analytic_rollout": (_int, [_int, _vp, _int, _int, _vp, _int, _i64, _int, _vp, _vp, _vp, _vp, _vp, _vp, _int,
+                                      _vp]),
     "mjmpc_arm_solver_failures": (_int, [_vp, ctypes.POINTER(ctypes.c_uint32)]),
     "mjmpc_update_workspace_bytes": (_i64, [_i64, _int, _int]),
     "mjmpc_softmax_record_len": (_int, [_int, _int, _int]),
     "mjmpc_traj_cost": (_int, [_int, _i64, _int, _int, _vp, _vp, _int, _vp, _vp]),
     "mjmpc_workspace_q0": (_vp, [_vp, _i64, _int, _int]),
+    "mjmpc_td_lambda_returns": (_int, [_int, _i64, _int, _int, _vp, _vp, _vp, _vp, _vp, _vp, _int, _dbl, _int, _dbl, _dbl,
+                                       _vp, _vp, _vp]),
     "mjmpc_softmax_stats": (_int, [_int, _i64, _int, _int, _vp, _vp, _vp, _vp, _vp, _int, _dbl, _int, _int, _int,
                                     _vp, _vp, _vp]),
     "mjmpc_softmax_combine": (_int, [_vp, _int, _int, _int, _int, _dbl, _dbl, _int, _dbl, _vp, _vp, _vp, _vp, _vp]),

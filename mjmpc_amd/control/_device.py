@@ -128,8 +128,32 @@ class DeviceUpdater:
         return costs, actions, P
 
     # ------------------------------------------------------------------ softmax family (MPPI / DMD / PFMPC)
+    def td_lambda_returns(self, costs, actions, qvals, beta, alpha, gamma, td_lam, covinv=None):
+        """MPPIQ.calculate_returns on the device (mppiq.py:104-136) -> (P,H) tensor of the costs' dtype."""
+        torch = self.torch
+        costs, actions, P = self._pair(costs, actions)
+        if qvals is not None:
+            qvals = self.to_device(qvals, "qvals").to(costs.dtype).contiguous()
+            if tuple(qvals.shape) != (P, self.H):
+                raise ValueError("qvals must have shape (P, H)")
+        wseq = np.cumprod([1.0] + [gamma * td_lam] * (self.H - 2)) if self.H > 1 else np.array([1.0])
+        wd = self.record("td_wseq", max(self.H - 1, 1))
+        wd.copy_(torch.from_numpy(np.ascontiguousarray(wseq, np.float64)))
+        if alpha == 0:
+            self.covinv.copy_(torch.from_numpy(np.ascontiguousarray(covinv, np.float64)))
+        key = ("td_returns", costs.dtype)
+        out = self._rec.get(key)
+        if out is None or tuple(out.shape) != (P, self.H):
+            out = self._rec[key] = torch.empty((P, self.H), dtype=costs.dtype, device=self.device)
+        _lib.check(self.lib.mjmpc_td_lambda_returns(self.code(costs), P, self.H, self.A, _vp(costs), _vp(actions),
+                                                    _vp(qvals), _vp(self.mean), _vp(self.covinv), _vp(wd),
+                                                    int(bool(np.any(wseq == 0))), float(beta), int(alpha), float(gamma),
+                                                    float(td_lam), _vp(out), _vp(self.workspace(P)), self.stream()))
+        return out
+
     def softmax_update(self, costs, actions, lam, step_size, alpha=1, time_based_weights=False, cov_mode=0,
-                       covinv=None, want_value=False, update_mean=True):
+                       covinv=None, want_value=False, update_mean=True, costs_are_returns=False):
+        """``costs_are_returns``: the (P,H) input already holds per-step returns - no cost_to_go (MPPIQ)."""
         costs, actions, P = self._pair(costs, actions)
         tbw = int(bool(time_based_weights))
         n = self.lib.mjmpc_softmax_record_len(self.H, self.A, tbw)
@@ -138,7 +162,8 @@ class DeviceUpdater:
             self.covinv.copy_(self.torch.from_numpy(np.ascontiguousarray(covinv, np.float64)))
         ws = self.workspace(P)
         _lib.check(self.lib.mjmpc_softmax_stats(self.code(costs), P, self.H, self.A, _vp(costs), _vp(actions),
-                                                _vp(self.mean), _vp(self.covinv), _vp(self.gseq), self.gamma_zero,
+                                                _vp(self.mean), _vp(self.covinv), _vp(self.gseq),
+                                                1 if costs_are_returns else self.gamma_zero,
                                                 float(lam), int(alpha), tbw, int(cov_mode != 0), _vp(rec), _vp(ws),
                                                 self.stream()))
         recs = self.comm.all_gather(rec)

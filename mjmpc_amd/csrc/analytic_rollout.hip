@@ -24,7 +24,7 @@ template <typename T>
 __global__ void pendulum_rollout_kernel(const double* __restrict__ prm, const double* __restrict__ state, long P, int H,
                                         const double* __restrict__ mean, const T* __restrict__ noise,
                                         T* __restrict__ cost, T* __restrict__ act, T* __restrict__ obs,
-                                        T* __restrict__ nobs) {
+                                        T* __restrict__ nobs, int closed) {
     const long p = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= P) return;
     const double max_speed = prm[0], max_torque = prm[1], dt = prm[2], g = prm[3], m = prm[4], l = prm[5];
@@ -32,7 +32,9 @@ __global__ void pendulum_rollout_kernel(const double* __restrict__ prm, const do
     double th = state[0], thdot = state[1];
     double o0 = cos(th), o1 = sin(th), o2 = thdot;
     for (int t = 0; t < H; ++t) {
-        double u = mean[t] + (noise ? (double)noise[p * H + t] : 0.0);
+        // closed_loop_linear (gym_env_wrapper.py:135-136): mean is the (d_obs+1, 1) weight matrix, action = W^T [obs; 1]
+        const double mu = closed ? mean[0] * o0 + mean[1] * o1 + mean[2] * o2 + mean[3] : mean[t];
+        double u = mu + (noise ? (double)noise[p * H + t] : 0.0);
         if (act) act[p * H + t] = (T)u;
         const double uc = fmin(fmax(u, -max_torque), max_torque);
         const double an = pymod(th + PI, 2 * PI) - PI;
@@ -53,7 +55,7 @@ template <typename T>
 __global__ void lqr_rollout_kernel(const double* __restrict__ prm, const double* __restrict__ state, int n, int m, long P,
                                    int H, const double* __restrict__ mean, const T* __restrict__ noise,
                                    T* __restrict__ cost, T* __restrict__ act, T* __restrict__ obs,
-                                   T* __restrict__ nobs) {
+                                   T* __restrict__ nobs, int closed) {
     const long p = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= P) return;
     const double *Am = prm, *Bm = prm + n * n, *Qm = Bm + n * m, *Rm = Qm + n * n;
@@ -61,7 +63,15 @@ __global__ void lqr_rollout_kernel(const double* __restrict__ prm, const double*
     for (int i = 0; i < n; ++i) x[i] = state[i];
     for (int t = 0; t < H; ++t) {
         for (int a = 0; a < m; ++a) {
-            u[a] = mean[t * m + a] + (noise ? (double)noise[(p * H + t) * m + a] : 0.0);
+            double mu;
+            if (closed) {                   // W^T [x; 1], W = mean (n+1, m)
+                mu = 0.0;
+                for (int i = 0; i < n; ++i) mu += mean[i * m + a] * x[i];
+                mu += mean[n * m + a];
+            } else {
+                mu = mean[t * m + a];
+            }
+            u[a] = mu + (noise ? (double)noise[(p * H + t) * m + a] : 0.0);
             if (act) act[(p * H + t) * m + a] = (T)u[a];
         }
         // cost = x'Qx + u'Ru in numpy's evaluation order: (x.T.dot(Q)).dot(x)
@@ -95,16 +105,16 @@ __global__ void lqr_rollout_kernel(const double* __restrict__ prm, const double*
 template <typename T>
 hipError_t launch_analytic_rollout(int kind, const double* prm, int n, int m, const double* state, long P, int H,
                                    const double* mean, const T* noise, T* cost, T* act, T* obs, T* nobs,
-                                   hipStream_t s) {
+                                   hipStream_t s, int closed) {
     if (P <= 0 || H <= 0) return hipSuccess;
     const unsigned grid = (unsigned)((P + 255) / 256);
     if (kind == ANALYTIC_PENDULUM) {
         hipLaunchKernelGGL(pendulum_rollout_kernel<T>, dim3(grid), dim3(256), 0, s, prm, state, P, H, mean, noise, cost, act,
-                           obs, nobs);
+                           obs, nobs, closed);
     } else if (kind == ANALYTIC_LQR) {
         if (n < 1 || n > MAXN || m < 1 || m > MAXN) return hipErrorInvalidValue;
         hipLaunchKernelGGL(lqr_rollout_kernel<T>, dim3(grid), dim3(256), 0, s, prm, state, n, m, P, H, mean, noise, cost,
-                           act, obs, nobs);
+                           act, obs, nobs, closed);
     } else {
         return hipErrorInvalidValue;
     }
@@ -112,9 +122,9 @@ hipError_t launch_analytic_rollout(int kind, const double* prm, int n, int m, co
 }
 
 template hipError_t launch_analytic_rollout<float>(int, const double*, int, int, const double*, long, int, const double*,
-                                                   const float*, float*, float*, float*, float*, hipStream_t);
+                                                   const float*, float*, float*, float*, float*, hipStream_t, int);
 template hipError_t launch_analytic_rollout<double>(int, const double*, int, int, const double*, long, int,
                                                     const double*, const double*, double*, double*, double*, double*,
-                                                    hipStream_t);
+                                                    hipStream_t, int);
 
 }  // namespace mjmpc

@@ -289,18 +289,18 @@ int mjmpc_arm_solver_failures(mjmpc_arm_t h, uint32_t* count) {
 
 int mjmpc_analytic_rollout(int kind, const double* d_params, int n_state, int n_action, const double* d_state, int dtype,
                            int64_t P, int H, const double* d_mean, const void* d_noise, void* d_costs, void* d_actions,
-                           void* d_obs, void* d_next_obs, void* stream) {
+                           void* d_obs, void* d_next_obs, int closed_loop_linear, void* stream) {
     if (!d_params || !d_state || !d_mean || !d_costs) return fail(MJMPC_E_BADARG, "null argument");
     hipStream_t s = (hipStream_t)stream;
     hipError_t e;
     if (dtype == MJMPC_F32)
         e = mjmpc::launch_analytic_rollout<float>(kind, d_params, n_state, n_action, d_state, (long)P, H, d_mean,
                                                   (const float*)d_noise, (float*)d_costs, (float*)d_actions,
-                                                  (float*)d_obs, (float*)d_next_obs, s);
+                                                  (float*)d_obs, (float*)d_next_obs, s, closed_loop_linear);
     else if (dtype == MJMPC_F64)
         e = mjmpc::launch_analytic_rollout<double>(kind, d_params, n_state, n_action, d_state, (long)P, H, d_mean,
                                                    (const double*)d_noise, (double*)d_costs, (double*)d_actions,
-                                                   (double*)d_obs, (double*)d_next_obs, s);
+                                                   (double*)d_obs, (double*)d_next_obs, s, closed_loop_linear);
     else
         return fail(MJMPC_E_BADARG, "unknown dtype %d", dtype);
     if (e != hipSuccess) return hip_fail(e, "analytic rollout launch");
@@ -343,6 +343,22 @@ int mjmpc_traj_cost(int dtype, int64_t P, int H, int A, const void* d_costs, con
 
 double* mjmpc_workspace_q0(void* d_ws, int64_t P, int H, int A) {
     return mjmpc::workspace_q0((double*)d_ws, (long)P, H, A);
+}
+
+int mjmpc_td_lambda_returns(int dtype, int64_t P, int H, int A, const void* d_costs, const void* d_actions,
+                            const void* d_qvals, const double* d_mean, const double* d_covinv, const double* d_wseq,
+                            int wseq_has_zero, double beta, int alpha, double gamma, double td_lam, void* d_returns,
+                            void* d_ws, void* stream) {
+    if (!d_costs || !d_returns || !d_ws || (H > 1 && !d_wseq)) return fail(MJMPC_E_BADARG, "null argument");
+    if (alpha == 0 && (!d_actions || !d_mean || !d_covinv)) return fail(MJMPC_E_BADARG, "control cost needs actions, mean, cov^-1");
+    hipStream_t s = (hipStream_t)stream;
+    DISPATCH(dtype,
+             mjmpc::td_lambda_returns<float>((const float*)d_costs, (const float*)d_actions, (const float*)d_qvals, d_mean,
+                                             d_covinv, d_wseq, wseq_has_zero, beta, alpha, gamma, td_lam, (long)P, H, A,
+                                             (float*)d_returns, (double*)d_ws, s),
+             mjmpc::td_lambda_returns<double>((const double*)d_costs, (const double*)d_actions, (const double*)d_qvals,
+                                              d_mean, d_covinv, d_wseq, wseq_has_zero, beta, alpha, gamma, td_lam,
+                                              (long)P, H, A, (double*)d_returns, (double*)d_ws, s));
 }
 
 int mjmpc_softmax_stats(int dtype, int64_t P, int H, int A, const void* d_costs, const void* d_actions,

@@ -12,6 +12,13 @@ template <typename T>
 hipError_t traj_cost(const T* costs, const T* actions, const double* mean, const double* covinv, const double* gseq,
                      int gamma_zero, double lam, int alpha, int tbw, long P, int H, int A, double* ws, hipStream_t s);
 
+// MPPIQ.calculate_returns (mppiq.py:104-126): TD(lambda) returns out[P][H] from per-step costs (+ beta * control
+// cost when alpha == 0) and optional Q estimates qvals[P][H]; wseq[H-1] = cumprod(1, gamma*td_lam, ...).
+template <typename T>
+hipError_t td_lambda_returns(const T* costs, const T* actions, const T* qvals, const double* mean, const double* covinv,
+                             const double* wseq, int wseq_zero, double beta, int alpha, double gamma, double td_lam,
+                             long P, int H, int A, T* out, double* ws, hipStream_t s);
+
 // Softmax record of this GPU's particles: [xmax[Hw] | S[Hw] | W[H*A] | C[A*A]], Hw = tbw ? H : 1.
 template <typename T>
 hipError_t softmax_stats(const T* costs, const T* actions, const double* mean, const double* covinv,

@@ -65,6 +65,49 @@ __global__ void traj_cost_kernel(const T* __restrict__ costs, const T* __restric
     }
 }
 
+// MPPIQ.calculate_returns (mjmpc/control/mppiq.py:104-126), one particle per thread:
+//   total[t] = cost[t] + beta * control_cost[t]        (per step, not accumulated; mppiq.py:128-136)
+//   td[t]    = total[t] + gamma q[t+1] - q[t],  t < H-1;   q = qvals, or 0 with q[H-1] = total[H-1]
+//   out[t]   = q[t] + td_lam * cost_to_go(td, wseq)[t],    out[H-1] = q[H-1]
+// cost_to_go in the order of control_utils.py:37-46 (reverse running sum, then / wseq; unchanged if wseq has a 0).
+template <typename T>
+__global__ void td_lambda_kernel(const T* __restrict__ costs, const T* __restrict__ actions, const T* __restrict__ qvals,
+                                 const double* __restrict__ mean, const double* __restrict__ un,
+                                 const double* __restrict__ wseq, int wseq_zero, double beta, double gamma,
+                                 double td_lam, long P, int H, int A, T* __restrict__ out) {
+    const long p = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= P) return;
+    auto total = [&](int t) {
+        double c = (double)costs[p * H + t];
+        if (un) {
+            double cc = 0.0;
+            for (int a = 0; a < A; ++a) {
+                const double m = mean[t * A + a];
+                const double d = (double)actions[(p * H + t) * A + a] - m;
+                cc += 0.5 * un[t * A + a] * (m + 2.0 * d);
+            }
+            c = c + beta * cc;
+        }
+        return c;
+    };
+    const double qlast = qvals ? (double)qvals[p * H + H - 1] : total(H - 1);
+    out[p * H + H - 1] = (T)qlast;
+    double acc = 0.0, qnext = qlast;
+    for (int t = H - 2; t >= 0; --t) {
+        const double q = qvals ? (double)qvals[p * H + t] : 0.0;
+        const double td = total(t) + gamma * qnext - q;
+        double g;
+        if (wseq_zero) {
+            g = td;
+        } else {
+            acc += wseq[t] * td;
+            g = acc / wseq[t];
+        }
+        out[p * H + t] = (T)(q + td_lam * g);
+        qnext = q;
+    }
+}
+
 // u_n = mean . cov^-1      (mppi.py:106)
 __global__ void un_kernel(const double* __restrict__ mean, const double* __restrict__ covinv, int H, int A,
                           double* __restrict__ un) {
@@ -502,6 +545,21 @@ hipError_t traj_cost(const T* costs, const T* actions, const double* mean, const
 }
 
 template <typename T>
+hipError_t td_lambda_returns(const T* costs, const T* actions, const T* qvals, const double* mean, const double* covinv,
+                             const double* wseq, int wseq_zero, double beta, int alpha, double gamma, double td_lam,
+                             long P, int H, int A, T* out, double* ws, hipStream_t s) {
+    Ws w(ws, P, H, A);
+    const double* un = nullptr;
+    if (alpha == 0) {
+        hipLaunchKernelGGL(un_kernel, dim3(nblocks(H * A, BLK)), dim3(BLK), 0, s, mean, covinv, H, A, w.un);
+        un = w.un;
+    }
+    hipLaunchKernelGGL(td_lambda_kernel<T>, dim3(nblocks(P, BLK)), dim3(BLK), 0, s, costs, actions, qvals, mean, un, wseq,
+                       wseq_zero, beta, gamma, td_lam, P, H, A, out);
+    return hipGetLastError();
+}
+
+template <typename T>
 hipError_t softmax_stats(const T* costs, const T* actions, const double* mean, const double* covinv,
                          const double* gseq, int gamma_zero, double lam, int alpha, int tbw, int want_cov, long P,
                          int H, int A, double* record, double* ws, hipStream_t s) {
@@ -609,6 +667,9 @@ hipError_t shift_mean(double* mean, int H, int A, int mode, const double* row, h
 }
 
 #define INST(T)                                                                                                      \
+    template hipError_t td_lambda_returns<T>(const T*, const T*, const T*, const double*, const double*,             \
+                                             const double*, int, double, int, double, double, long, int, int, T*,    \
+                                             double*, hipStream_t);                                                  \
     template hipError_t traj_cost<T>(const T*, const T*, const double*, const double*, const double*, int, double,   \
                                      int, int, long, int, int, double*, hipStream_t);                                \
     template hipError_t softmax_stats<T>(const T*, const T*, const double*, const double*, const double*, int,       \

@@ -55,8 +55,9 @@ class AnalyticRolloutEngine:
         self._state.copy_(self.torch.from_numpy(x.copy()))
 
     def rollout_device(self, num_particles, horizon, mean, noise, mode="open_loop", want_obs=False):
-        if mode != "open_loop":
-            raise ValueError("unsupported rollout mode %r (only 'open_loop')" % (mode,))
+        if mode not in ("open_loop", "closed_loop_linear"):
+            raise ValueError("unsupported rollout mode %r ('open_loop' or 'closed_loop_linear')" % (mode,))
+        closed = mode == "closed_loop_linear"
         if num_particles % self.num_shards != 0:
             raise AssertionError("Number of particles must be divisible by number of shards")
         torch = self.torch
@@ -69,7 +70,7 @@ class AnalyticRolloutEngine:
                 raise ValueError("expected shape %s, got %s" % (shape, tuple(x.shape)))
             return x.to(device=self.device, dtype=dt).contiguous()
 
-        mean_d = dev(mean, torch.float64, (H, A))
+        mean_d = dev(mean, torch.float64, (self.d_obs + 1, A) if closed else (H, A))
         noise_d = None if noise is None else dev(noise, self._tdtype, (P, H, A))
         costs = torch.empty((P, H), dtype=self._tdtype, device=self.device)
         act = torch.empty((P, H, A), dtype=self._tdtype, device=self.device)
@@ -78,7 +79,7 @@ class AnalyticRolloutEngine:
         stream = ctypes.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
         _lib.check(self._lib.mjmpc_analytic_rollout(self.kind, _ptr(self._params), self.d_state, A, _ptr(self._state),
                                                     self._code, P, H, _ptr(mean_d), _ptr(noise_d), _ptr(costs), _ptr(act),
-                                                    _ptr(obs), _ptr(nobs), stream))
+                                                    _ptr(obs), _ptr(nobs), int(closed), stream))
         return costs, act, obs, nobs
 
     def rollout(self, num_particles, horizon, mean, noise, mode="open_loop"):

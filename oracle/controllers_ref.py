@@ -105,6 +105,48 @@ def mppi_value(costs, actions, mean, cov, gseq, lam, alpha):
     return -lam * logsumexp_b((-1.0 / lam) * total, 1.0 / total.shape[0])
 
 
+# ---------------------------------------------------------------------------- MPPIQ
+def mppiq_control_costs(mean, cov, delta, alpha):
+    """MPPIQ._control_costs, mjmpc/control/mppiq.py:128-136: per-step, NOT accumulated."""
+    if alpha == 1:
+        return np.zeros(delta.shape[:2])
+    u_n = mean.dot(np.linalg.inv(cov))[None]
+    return np.sum(0.5 * u_n * (mean[None] + 2.0 * delta), axis=-1)
+
+
+def mppiq_returns(total_costs, qvals, gamma, td_lam):
+    """MPPIQ.calculate_returns, mjmpc/control/mppiq.py:104-126: TD(lambda) blend of the per-step costs and
+    the Q estimates; without estimates Q is zero except for the last step's own cost."""
+    P, H = total_costs.shape
+    if qvals is None:
+        qvals = np.zeros((P, H))
+        qvals[:, -1] = total_costs[:, -1]
+    td = total_costs[:, :-1] + gamma * qvals[:, 1:] - qvals[:, :-1]
+    if H == 1:
+        wseq = np.array([1.0])
+    else:
+        wseq = np.cumprod([1.0] + [gamma * td_lam] * (H - 2)).reshape(1, H - 1)
+    q_lam = qvals[:, :-1] + td_lam * cost_to_go(td, wseq)
+    return np.hstack([q_lam, qvals[:, [-1]]])
+
+
+def mppiq_update(costs, actions, qvals, mean, cov, beta, alpha, gamma, td_lam, step_size, time_based_weights):
+    """MPPIQ._update_distribution / _exp_util, mjmpc/control/mppiq.py:73-102."""
+    delta = actions - mean[None]
+    q_hat = mppiq_returns(costs + beta * mppiq_control_costs(mean, cov, delta, alpha), qvals, gamma, td_lam)
+    if not time_based_weights:
+        q_hat = q_hat[:, 0]
+    w = softmax0((-1.0 / beta) * q_hat)
+    return (1.0 - step_size) * mean + step_size * np.sum((w.T * actions.T).T, axis=0)
+
+
+def mppiq_value(costs, actions, qvals, mean, cov, beta, alpha, gamma, td_lam):
+    """MPPIQ._calc_val, mjmpc/control/mppiq.py:138-165."""
+    delta = actions - mean[None]
+    q0 = mppiq_returns(costs + beta * mppiq_control_costs(mean, cov, delta, alpha), qvals, gamma, td_lam)[:, 0]
+    return -beta * logsumexp_b((-1.0 / beta) * q0, 1.0 / q0.shape[0])
+
+
 # ---------------------------------------------------------------------------- a12 (CEM)
 def cem_update(costs, actions, mean, cov, gseq, elite_frac, step_size, cov_type):
     """CEM._update_distribution, mjmpc/control/cem.py:63-86."""

@@ -1,6 +1,6 @@
 """numpy restatement of the rollout loop over the two analytic envs  --  TEST ORACLE, NOT PRODUCT.
 
-Pinned against tests/golden/e2e.npz, which was produced by the reference's own
+Pinned against tests/golden/e2e.npz and closed_loop.npz, which were produced by the reference's own
 ``GymEnvWrapper.rollout`` (mjmpc/envs/gym_env_wrapper.py:89-156) driving ``PendulumEnv``
 (mjmpc/envs/basic/pendulum.py:33-50,62-64) and ``LQREnv`` (mjmpc/envs/basic/lqr.py:31-35).
 Only tests/, ``__graft_entry__.smoke()`` and ``bench.py``'s cpu_baseline leg may import this.
@@ -40,8 +40,9 @@ class LQRRef:
         return self.A.dot(s) + self.B.dot(u), -cost
 
 
-def rollout(env, state0, num_particles, horizon, mean, noise):
-    """GymEnvWrapper.rollout, mode='open_loop' -> (obs, rew, act, done, next_obs)."""
+def rollout(env, state0, num_particles, horizon, mean, noise, mode="open_loop"):
+    """GymEnvWrapper.rollout -> (obs, rew, act, done, next_obs); mode 'closed_loop_linear': ``mean`` is the
+    (d_obs+1, d_action) weight matrix and the action is W^T [obs; 1] (+ noise) (gym_env_wrapper.py:133-136)."""
     P, H = num_particles, horizon
     obs = np.zeros((P, H, env.d_obs))
     nobs = np.zeros((P, H, env.d_obs))
@@ -52,7 +53,8 @@ def rollout(env, state0, num_particles, horizon, mean, noise):
         s = np.asarray(state0, float).copy()
         cur = env.obs(s)
         for t in range(H):
-            u = mean[t] + (noise[b, t] if noise is not None else 0.0)
+            mean_act = mean[t] if mode == "open_loop" else mean.T @ np.append(cur, 1.0)
+            u = mean_act + (noise[b, t] if noise is not None else 0.0)
             s, r = env.step(s, u)
             nxt = env.obs(s)
             obs[b, t], nobs[b, t], rew[b, t], act[b, t] = cur, nxt, r, u

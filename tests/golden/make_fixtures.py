@@ -14,6 +14,8 @@ Pinned here:
   cost_to_go.npz   control_utils.cost_to_go                (mjmpc/utils/control_utils.py:37-46)
   update_*.npz     _update_distribution / _shift / _calc_val of MPPI, CEM, DMDMPC,
                    RandomShooting, PFMPC                   (mjmpc/control/*.py)
+  closed_loop.npz  GymEnvWrapper.rollout(mode='closed_loop_linear') over PendulumEnv / LQREnv
+  mppiq.npz        MPPIQ.calculate_returns / _update_distribution / _calc_val   (mjmpc/control/mppiq.py)
   e2e_*.npz        Controller.optimize() x k steps through the real GymEnvWrapper.rollout over
                    PendulumEnv / LQREnv                    (mjmpc/envs/gym_env_wrapper.py:89-156)
 """
@@ -333,6 +335,90 @@ def fx_e2e(ref):
     np.savez_compressed(os.path.join(OUT, "e2e.npz"), **out)
 
 
+def _lqr_env(ref, Amat, Bmat, Q, R):
+    class LQRWithGetObs(ref.LQREnv):       # same two reference quirks as in fx_e2e
+        def get_obs(self):
+            return self._get_obs()
+
+        def reset(self, seed=None):
+            super().reset(seed)
+            self.state = self.state.reshape(-1)
+            return self.state.copy()
+
+    env = LQRWithGetObs(Amat, Bmat, Q, R)
+    env._max_episode_steps = 200
+    return env
+
+
+def fx_closed_loop(ref):
+    """mode='closed_loop_linear' (gym_env_wrapper.py:135-136) through the reference's wrapper."""
+    out = {}
+    rs = np.random.RandomState(41)
+    env = ref.PendulumEnv()
+    env._max_episode_steps = 200
+    w = ref.GymEnvWrapper(env)
+    P, H = 12, 9
+    W = 0.6 * rs.randn(w.d_obs + 1, 1)
+    noise = 0.5 * rs.randn(P, H, 1)
+    s0 = {"state": np.array([1.3, 0.7])}
+    w.set_env_state(s0)
+    obs, rew, act, done, info, nobs = w.rollout(P, H, W.copy(), noise.copy(), "closed_loop_linear")
+    out.update(pend_state=s0["state"], pend_W=W, pend_noise=noise, pend_obs=obs, pend_rew=rew, pend_act=act,
+               pend_nobs=nobs)
+    w.set_env_state(s0)
+    obs, rew, act, done, info, nobs = w.rollout(1, H, W.copy(), None, "closed_loop_linear")
+    out.update(pend_mean_obs=obs, pend_mean_rew=rew, pend_mean_act=act)
+
+    Amat = np.eye(3) + 0.05 * rs.randn(3, 3)
+    Bmat = 0.3 * rs.randn(3, 2)
+    Q, R = np.diag([1.0, 0.5, 2.0]), 0.1 * np.eye(2)
+    w = ref.GymEnvWrapper(_lqr_env(ref, Amat, Bmat, Q, R))
+    W = 0.4 * rs.randn(w.d_obs + 1, 2)
+    P, H = 10, 7
+    noise = 0.3 * rs.randn(P, H, 2)
+    s0 = {"state": np.array([0.5, -1.0, 0.25])}
+    w.set_env_state(s0)
+    obs, rew, act, done, info, nobs = w.rollout(P, H, W.copy(), noise.copy(), "closed_loop_linear")
+    out.update(lqr_A=Amat, lqr_B=Bmat, lqr_Q=Q, lqr_R=R, lqr_state=s0["state"], lqr_W=W, lqr_noise=noise,
+               lqr_obs=obs, lqr_rew=rew, lqr_act=act, lqr_nobs=nobs)
+    np.savez_compressed(os.path.join(OUT, "closed_loop.npz"), **out)
+
+
+def fx_mppiq(ref):
+    """MPPIQ (mjmpc/control/mppiq.py): TD(lambda) returns over optional terminal Q estimates, softmax update."""
+    MPPIQ = _load("mjmpc.control.mppiq", "mjmpc/control/mppiq.py").MPPIQ
+    rs = np.random.RandomState(909)
+    H, A, P = 9, 3, 48
+    out = {}
+    i = 0
+    for beta, alpha, tbw, gamma, td_lam, step, with_q in (
+            (0.3, 1, True, 0.98, 0.9, 1.0, True), (0.3, 1, False, 0.98, 0.9, 0.7, True),
+            (0.05, 1, True, 1.0, 1.0, 1.0, False), (0.2, 0, True, 0.95, 0.8, 0.6, True),
+            (0.2, 0, False, 1.0, 0.5, 1.0, False), (0.5, 1, True, 0.9, 0.0, 1.0, True)):
+        c = MPPIQ(init_cov=1.2, base_action="null", beta=beta, step_size=step, alpha=alpha, gamma=gamma, n_iters=1,
+                  td_lam=td_lam, time_based_weights=tbw, filter_coeffs=[1.0, 0.0, 0.0], d_state=5, d_obs=6,
+                  d_action=A, horizon=H, num_particles=P, action_lows=-np.ones(A), action_highs=np.ones(A), seed=3)
+        c.mean_action = rs.randn(H, A) * 0.3
+        traj = _traj(rs, P, H, A, c.mean_action)
+        if with_q:
+            traj["qvals"] = rs.rand(P, H) * 4.0
+        tag = "q%d" % i
+        out[tag + "_cfg"] = np.array([beta, alpha, float(tbw), gamma, td_lam, step, 1.2, float(with_q)])
+        out[tag + "_costs"], out[tag + "_actions"] = traj["costs"], traj["actions"]
+        if with_q:
+            out[tag + "_qvals"] = traj["qvals"]
+        out[tag + "_mean0"] = c.mean_action.copy()
+        delta = traj["actions"] - c.mean_action[None]
+        out[tag + "_returns"] = c.calculate_returns(traj["costs"] + beta * c._control_costs(delta),
+                                                    traj.get("qvals"), gamma, td_lam)
+        out[tag + "_val"] = np.array(c._calc_val(traj))
+        c._update_distribution(traj)
+        out[tag + "_mean1"] = c.mean_action.copy()
+        i += 1
+    out["n"] = np.array(i)
+    np.savez_compressed(os.path.join(OUT, "mppiq.npz"), **out)
+
+
 def main():
     if not os.path.isdir(REF):
         print("reference tree not present; fixtures are already committed - nothing to do")
@@ -342,6 +428,8 @@ def main():
     fx_cost_to_go(ref)
     fx_updates(ref)
     fx_e2e(ref)
+    fx_closed_loop(ref)
+    fx_mppiq(ref)
     for f in sorted(os.listdir(OUT)):
         if f.endswith(".npz"):
             print("%-20s %8d bytes" % (f, os.path.getsize(os.path.join(OUT, f))))

@@ -89,3 +89,26 @@ def test_closed_loop_lqr_cem_and_dmd(golden):
     _closed_loop(golden, "lqr_dmd", lambda: DMDMPC(init_cov=1.0, beta=0.1, base_action="null", lam=0.5, step_size=0.7,
                                                     gamma=1.0, update_cov=True, cov_type="diagonal",
                                                     filter_coeffs=[1.0, 0.0, 0.0], **kw), _gpu_env_step)
+
+
+def test_closed_loop_linear_rollouts_match_the_reference_wrapper(golden):
+    """mode='closed_loop_linear' (gym_env_wrapper.py:133-136) on both analytic kernels against vectors produced
+    by the reference's GymEnvWrapper.rollout; f64 to 1e-12, f32 to its rounding."""
+    from mjmpc_amd.envs.analytic_engine import AnalyticRolloutEngine
+    g = golden("closed_loop")
+    for dtype, tol in (("f64", 1e-12), ("f32", 3e-5)):
+        eng = AnalyticRolloutEngine.pendulum(dtype=dtype)
+        eng.set_env_state({"state": g["pend_state"]})
+        P, H, _ = g["pend_noise"].shape
+        obs, rew, act, done, info, nobs = eng.rollout(P, H, g["pend_W"], g["pend_noise"], "closed_loop_linear")
+        for got, want in ((obs, "pend_obs"), (rew, "pend_rew"), (act, "pend_act"), (nobs, "pend_nobs")):
+            np.testing.assert_allclose(got, g[want], rtol=tol, atol=tol)
+        obs, rew, act, done, info, nobs = eng.rollout(1, H, g["pend_W"], None, "closed_loop_linear")
+        np.testing.assert_allclose(act, g["pend_mean_act"], rtol=tol, atol=tol)
+        np.testing.assert_allclose(rew, g["pend_mean_rew"], rtol=tol, atol=tol)
+        eng = AnalyticRolloutEngine.lqr(g["lqr_A"], g["lqr_B"], g["lqr_Q"], g["lqr_R"], dtype=dtype)
+        eng.set_env_state({"state": g["lqr_state"]})
+        P, H, _ = g["lqr_noise"].shape
+        obs, rew, act, done, info, nobs = eng.rollout(P, H, g["lqr_W"], g["lqr_noise"], "closed_loop_linear")
+        for got, want in ((obs, "lqr_obs"), (rew, "lqr_rew"), (act, "lqr_act"), (nobs, "lqr_nobs")):
+            np.testing.assert_allclose(got, g[want], rtol=tol, atol=tol)

@@ -205,3 +205,38 @@ def test_e2e_lqr_dmd(golden):
         return cr.dmd_update(costs, actions, mean, cov, gs, 0.5, 0.7, True, "diagonal")
     upd.shift = lambda mean, cov: (cr.shift_mean(mean, "null"), cr.dmd_shift_cov(cov, 0.1, True))
     _run_e2e(upd, env, g, "lqr_dmd", 40, H, 2, 77, 2, 1.0, [1.0, 0.0, 0.0])
+
+
+def test_mppiq(golden):
+    """MPPIQ (mppiq.py:73-165): TD(lambda) returns, update and value, against the reference's outputs."""
+    g = golden("mppiq")
+    for i in range(int(g["n"])):
+        t = "q%d" % i
+        beta, alpha, tbw, gamma, td_lam, step, c0, with_q = g[t + "_cfg"]
+        costs, actions, mean0 = g[t + "_costs"], g[t + "_actions"], g[t + "_mean0"]
+        qvals = g[t + "_qvals"] if with_q else None
+        cov = c0 * np.eye(actions.shape[-1])
+        total = costs + beta * cr.mppiq_control_costs(mean0, cov, actions - mean0[None], int(alpha))
+        np.testing.assert_allclose(cr.mppiq_returns(total, qvals, gamma, td_lam), g[t + "_returns"], **TOL)
+        m1 = cr.mppiq_update(costs, actions, qvals, mean0, cov, beta, int(alpha), gamma, td_lam, step, bool(tbw))
+        np.testing.assert_allclose(m1, g[t + "_mean1"], **TOL)
+        v = cr.mppiq_value(costs, actions, qvals, mean0, cov, beta, int(alpha), gamma, td_lam)
+        np.testing.assert_allclose(v, g[t + "_val"], **TOL)
+
+
+def test_closed_loop_linear_rollout_loop(golden):
+    """mode='closed_loop_linear' of GymEnvWrapper.rollout (gym_env_wrapper.py:133-136) over both analytic envs."""
+    g = golden("closed_loop")
+    env = er.PendulumRef()
+    P, H, _ = g["pend_noise"].shape
+    obs, rew, act, done, nobs = er.rollout(env, g["pend_state"], P, H, g["pend_W"], g["pend_noise"], "closed_loop_linear")
+    for got, want in ((obs, "pend_obs"), (rew, "pend_rew"), (act, "pend_act"), (nobs, "pend_nobs")):
+        np.testing.assert_allclose(got, g[want], rtol=1e-13, atol=1e-13)
+    obs, rew, act, done, nobs = er.rollout(env, g["pend_state"], 1, H, g["pend_W"], None, "closed_loop_linear")
+    np.testing.assert_allclose(act, g["pend_mean_act"], rtol=1e-13, atol=1e-13)
+    np.testing.assert_allclose(rew, g["pend_mean_rew"], rtol=1e-13, atol=1e-13)
+    env = er.LQRRef(g["lqr_A"], g["lqr_B"], g["lqr_Q"], g["lqr_R"])
+    P, H, _ = g["lqr_noise"].shape
+    obs, rew, act, done, nobs = er.rollout(env, g["lqr_state"], P, H, g["lqr_W"], g["lqr_noise"], "closed_loop_linear")
+    for got, want in ((obs, "lqr_obs"), (rew, "lqr_rew"), (act, "lqr_act"), (nobs, "lqr_nobs")):
+        np.testing.assert_allclose(got, g[want], rtol=1e-13, atol=1e-13)
