@@ -14,7 +14,7 @@
 //   velocities, vel.-product accelerations = prefix sums of spatial vectors
 //   RNE forces, composite inertias         = suffix sums
 //   M[i][i+s] = S_i . (Ic_{i+s} S_{i+s})   = 7 shifted dot products  -> LDS 8x8 transpose
-//   (M + E) x = r                          = in-register LDL^T, one row per lane, DPP broadcasts
+//   (M + E) x = r                          = dense LDL^T per solver lane, operands through the LDS tile
 // The soft-constraint problem (joint limits + sphere/plane contact, all frictionless rows) is
 // solved by a primal active-set Newton iteration: with the active set fixed the objective is
 // quadratic, so each iteration is one 7x7 solve; it stops when the active set reproduces itself,
@@ -114,57 +114,71 @@ __device__ __forceinline__ void row_params(const Model<T>& M, T r, T diag_approx
     aref = -M.glob(O_SOL_B) * jv - M.glob(O_SOL_K) * imp * r;
 }
 
-// In-register LDL^T of N symmetric positive definite matrices AT ONCE (their instruction streams
-// interleave, which hides the pivot -> reciprocal -> broadcast latency chain of a single 7x7
-// factorisation).  Lane i holds row i: off-diagonals hr[n][j] (slot j == i unused), diagonal hd[n].
-// Afterwards: lanes i > K hold l_iK in slot K, lane K keeps its pivot row A_Kj (j > K) unscaled,
-// inv[n] = 1 / d_i.  Pivots and pivot rows travel by DPP broadcast.
-template <int K, int N, typename T>
-struct LdlStep {
-    static __device__ __forceinline__ void factor(T* hd, T (*hr)[MAX_LINKS], T* inv_own, int l8) {
-        T l[N];
+// Dense LDL^T of one particle's 7x7 matrix held ENTIRELY by one lane (28 values), no cross-lane traffic.
+// The lanes of a particle do not share the factorisation - a DPP broadcast inside an 8-lane group costs 3 DPP
+// moves per 32 bits in the interleaved layout, which made the row-per-lane factorisation ~80 % data movement.
+// Instead the matrix goes through the particle's LDS tile anyway (diagonal-major -> row-major), every solver
+// lane reads all of it, and the lanes split by ROLE: links 0-3 factor the Newton matrix H = M + J'DJ, links 4-7
+// the Euler matrix M + h B - the same instruction stream on different data, so both factors cost one pass.
+template <typename T>
+struct Dense {
+    T a[21];            // strictly lower triangle, row-major: (1,0) (2,0) (2,1) (3,0) ...; l_ij after factor()
+    T d[MAX_LINKS];     // diagonal; 1 / pivot after factor()
+    static __device__ __forceinline__ constexpr int ix(int i, int j) { return i * (i - 1) / 2 + j; }
+
+    __device__ __forceinline__ void load(const T* tile, const T* diag) {
 #pragma unroll
-        for (int n = 0; n < N; ++n) {
-            const T inv = rcp_fast(bcast<K>(hd[n]));
-            inv_own[n] = (l8 == K) ? inv : inv_own[n];
-            l[n] = (l8 > K) ? hr[n][K] * inv : T(0);          // l_iK for rows below the pivot
-            hd[n] -= l[n] * hr[n][K];
+        for (int i = 1; i < MAX_LINKS; ++i)
+#pragma unroll
+            for (int j = 0; j < i; ++j) a[ix(i, j)] = tile[i * LANES + j];
+#pragma unroll
+        for (int i = 0; i < MAX_LINKS; ++i) d[i] = diag[i];
+    }
+    // += w * jc jc'
+    __device__ __forceinline__ void add_rank1(T w, const T* jc) {
+#pragma unroll
+        for (int i = 0; i < MAX_LINKS; ++i) {
+            const T wi = w * jc[i];
+            d[i] += wi * jc[i];
+#pragma unroll
+            for (int j = 0; j < i; ++j) a[ix(i, j)] += wi * jc[j];
         }
-#pragma unroll
-        for (int j = K + 1; j < MAX_LINKS; ++j)
-#pragma unroll
-            for (int n = 0; n < N; ++n) hr[n][j] -= l[n] * bcast<K>(hr[n][j]);
-#pragma unroll
-        for (int n = 0; n < N; ++n) hr[n][K] = (l8 > K) ? l[n] : hr[n][K];
-        if constexpr (K + 1 < MAX_LINKS) LdlStep<K + 1, N, T>::factor(hd, hr, inv_own, l8);
     }
-    static __device__ __forceinline__ void forward(const T* hr, T& b, int l8) {
-        T yk = bcast<K>(b);
-        b -= (l8 > K) ? hr[K] * yk : T(0);
-        if constexpr (K + 1 < MAX_LINKS) LdlStep<K + 1, N, T>::forward(hr, b, l8);
+    __device__ __forceinline__ void factor() {
+#pragma unroll
+        for (int k = 0; k < MAX_LINKS; ++k) {
+            const T inv = rcp_fast(d[k]);
+            d[k] = inv;
+#pragma unroll
+            for (int i = k + 1; i < MAX_LINKS; ++i) {
+                const T aik = a[ix(i, k)];              // unscaled a_ik = l_ik d_k
+                const T lik = aik * inv;
+#pragma unroll
+                for (int j = k + 1; j < i; ++j) a[ix(i, j)] -= aik * a[ix(j, k)];   // a_jk already holds l_jk
+                d[i] -= aik * lik;
+                a[ix(i, k)] = lik;
+            }
+        }
     }
-    static __device__ __forceinline__ void backward(const T* hr, T inv_own, T& x, int l8) {
-        // x_i -= l_Ki x_K for i < K, with l_Ki = A_iK / d_i held (unscaled) in lane i slot K
-        T xk = bcast<K>(x);
-        x -= (l8 < K) ? hr[K] * inv_own * xk : T(0);
-        if constexpr (K > 0) LdlStep<K - 1, N, T>::backward(hr, inv_own, x, l8);
+    // b <- (L D L')^-1 b
+    __device__ __forceinline__ void solve(T* b) const {
+#pragma unroll
+        for (int i = 1; i < MAX_LINKS; ++i)
+#pragma unroll
+            for (int j = 0; j < i; ++j) b[i] -= a[ix(i, j)] * b[j];
+#pragma unroll
+        for (int i = 0; i < MAX_LINKS; ++i) b[i] *= d[i];
+#pragma unroll
+        for (int i = MAX_LINKS - 2; i >= 0; --i)
+#pragma unroll
+            for (int j = i + 1; j < MAX_LINKS; ++j) b[i] -= a[ix(j, i)] * b[j];
     }
 };
 
-// forward / diagonal / backward substitution with a factor produced by LdlStep::factor
-template <typename T>
-__device__ __forceinline__ T ldl_substitute(const T* hr, T inv_own, T b, int l8) {
-    LdlStep<0, 1, T>::forward(hr, b, l8);
-    b *= inv_own;
-    LdlStep<MAX_LINKS - 1, 1, T>::backward(hr, inv_own, b, l8);
-    return b;
-}
-
-template <int J, typename T>
-__device__ __forceinline__ void add_rank1(T* hr, T wj, T jc) {
-    hr[J] += wj * bcast<J>(jc);
-    if constexpr (J + 1 < MAX_LINKS) add_rank1<J + 1, T>(hr, wj, jc);
-}
+// Per-particle LDS block: the 8x8 mass-matrix tile followed by the vectors the lanes hand to the solver lanes
+// and back.  The stride keeps 16-byte alignment and shifts consecutive particles by 4 (f32) / 8 (f64) banks.
+constexpr int V_DH = LANES * LANES, V_RH = V_DH + LANES, V_DE = V_RH + LANES, V_RE = V_DE + LANES, V_XH = V_RE + LANES,
+              V_XE = V_XH + LANES, V_JC = V_XE + LANES, PSTRIDE = V_JC + LANES + 4;
 
 // u_i += sum_k W[k][i] q_k + W[nv+k][i] v_k   (the joint part of clw^T obs), link values by DPP broadcast
 template <int K, typename T>
@@ -371,11 +385,14 @@ __device__ __forceinline__ void arm_substep(const Model<T>& M, const ArmInts& I,
 
     // 7. primal active-set Newton on  1/2 a'Ma - tau'a + sum_active 1/2 D (J a - aref)^2, and
     // 8. mj_Euler with implicit joint damping:  (M + h B) qacc = qfrc_smooth + qfrc_constraint.
-    //    The Euler matrix is factorised together with the first Newton matrix (two interleaved chains).
+    //    Solver lanes (struct Dense): links 0-3 of a particle hold the Newton factor, links 4-7 the Euler
+    //    factor; right-hand sides and solutions travel through the particle's LDS vectors.
     T qfrc_c = T(0);
-    T he[1][MAX_LINKS], hde[1], inve[1] = {T(1)};      // Euler factor
+    const bool roleH = l8 < 4;
     const bool any_rows = __any(inst || cinst);
     if (!any_rows) rows = 0;
+    Dense<T> F;
+    ldsM[V_DE + l8] = dgM + h * damping;
     if (any_rows) {
         row_params(M, dist, M.link(O_DOF_INVW), sig * v, D, aref);
         D = inst ? D : T(0);
@@ -386,34 +403,34 @@ __device__ __forceinline__ void arm_substep(const Model<T>& M, const ArmInts& I,
         bool act = inst && ((rows & 1) ? (rows & 2) != 0 : true);
         bool cact = cinst && ((rows & 4) ? (rows & 8) != 0 : true);
         bool changed = true;
+        const bool any_c = __any(cinst);
+        if (any_c) ldsM[V_JC + l8] = jc;
         for (int it = 0; it < NEWTON_MAXIT; ++it) {
-            T hh[2][MAX_LINKS], hd2[2], inv2[2] = {T(1), T(1)};
             T rhs = tau + (act ? D * sig * aref : T(0));
-            hd2[0] = dgM + (act ? D : T(0));
+            if (any_c) rhs += cact ? Dc * jc * arefc : T(0);
+            ldsM[V_DH + l8] = dgM + (act ? D : T(0));
+            ldsM[V_RH + l8] = rhs;
+            LDS_WAVE_SYNC();
+            if (it == 0 || roleH) {
+                F.load(ldsM, ldsM + (roleH ? V_DH : V_DE));
+                if (any_c && __any(cact)) {
+                    T jv[MAX_LINKS];
 #pragma unroll
-            for (int j = 0; j < MAX_LINKS; ++j) hh[0][j] = ldsM[l8 * LANES + j];
-            if (__any(cact)) {
-                T wj = cact ? Dc * jc : T(0);
-                hd2[0] += wj * jc;
-                rhs += wj * arefc;
-                add_rank1<0, T>(hh[0], wj, jc);
-            }
-            if (it == 0) {
-                hd2[1] = dgM + h * damping;
-#pragma unroll
-                for (int j = 0; j < MAX_LINKS; ++j) hh[1][j] = hh[0][j];
-                if (__any(cact)) {
-#pragma unroll
-                    for (int j = 0; j < MAX_LINKS; ++j) hh[1][j] = ldsM[l8 * LANES + j];
+                    for (int i = 0; i < MAX_LINKS; ++i) jv[i] = ldsM[V_JC + i];
+                    F.add_rank1((roleH && cact) ? Dc : T(0), jv);
                 }
-                LdlStep<0, 2, T>::factor(hd2, hh, inv2, l8);
-#pragma unroll
-                for (int j = 0; j < MAX_LINKS; ++j) he[0][j] = hh[1][j];
-                inve[0] = inv2[1];
-            } else {
-                LdlStep<0, 1, T>::factor(hd2, hh, inv2, l8);
+                F.factor();
             }
-            aw = ldl_substitute(hh[0], inv2[0], rhs, l8);
+            if (roleH) {
+                T b[MAX_LINKS];
+#pragma unroll
+                for (int i = 0; i < MAX_LINKS; ++i) b[i] = ldsM[V_RH + i];
+                F.solve(b);
+#pragma unroll
+                for (int i = 0; i < MAX_LINKS; ++i) ldsM[V_XH + i] = b[i];
+            }
+            LDS_WAVE_SYNC();
+            aw = ldsM[V_XH + l8];
             bool act2 = inst && (sig * aw - aref < T(0));
             bool cact2 = cinst && (gsum(jc * aw) - arefc < T(0));
             changed = (act2 != act) || (cact2 != cact);
@@ -429,14 +446,25 @@ __device__ __forceinline__ void arm_substep(const Model<T>& M, const ArmInts& I,
             T fcn = cact ? -Dc * (gsum(jc * aw) - arefc) : T(0);
             qfrc_c += jc * fcn;
         }
+        ldsM[V_RE + l8] = tau + qfrc_c;
+        LDS_WAVE_SYNC();
     } else {
-        hde[0] = dgM + h * damping;
-#pragma unroll
-        for (int j = 0; j < MAX_LINKS; ++j) he[0][j] = ldsM[l8 * LANES + j];
-        LdlStep<0, 1, T>::factor(hde, he, inve, l8);
+        ldsM[V_RE + l8] = tau;
+        LDS_WAVE_SYNC();
+        F.load(ldsM, ldsM + V_DE);
+        F.factor();
     }
+    if (!roleH) {
+        T b[MAX_LINKS];
+#pragma unroll
+        for (int i = 0; i < MAX_LINKS; ++i) b[i] = ldsM[V_RE + i];
+        F.solve(b);
+#pragma unroll
+        for (int i = 0; i < MAX_LINKS; ++i) ldsM[V_XE + i] = b[i];
+    }
+    LDS_WAVE_SYNC();
     {
-        T x = ldl_substitute(he[0], inve[0], tau + qfrc_c, l8);
+        T x = ldsM[V_XE + l8];
         if (!any_rows) aw = x;
         v += h * x;
         const T dq = h * v;
@@ -473,18 +501,18 @@ __global__ __launch_bounds__(64, (sizeof(T) == 8 ? 2 : 4)) void arm_rollout_kern
                                                          T* __restrict__ act, T* __restrict__ obs,
                                                          T* __restrict__ nobs, double* state_out, unsigned* diag,
                                                          RolloutFusion fuse) {
-    __shared__ T lds[LANES * LANES * LANES + ARM_BLOB_LEN + 3];
+    __shared__ __attribute__((aligned(16))) T lds[LANES * PSTRIDE + ARM_BLOB_LEN + 3];
     const int lane = threadIdx.x;
     const int l8 = lane_link(lane), g = lane_slot(lane);
     const long pid = (long)blockIdx.x * LANES + g;
     const bool live = pid < P;
-    for (int k = lane; k < LANES * LANES * LANES; k += 64) lds[k] = T(0);
-    T* ldsModel = lds + LANES * LANES * LANES;
+    for (int k = lane; k < LANES * PSTRIDE; k += 64) lds[k] = T(0);
+    T* ldsModel = lds + LANES * PSTRIDE;
     if (fuse.shard_size > 0) model += ((long)blockIdx.x * LANES / fuse.shard_size) * ARM_BLOB_LEN;
     if (fuse.state_shard_size > 0) state += ((long)blockIdx.x * LANES / fuse.state_shard_size) * (2 * LANES + 3);
     for (int k = lane; k < ARM_BLOB_LEN; k += 64) ldsModel[k] = model[k];
     __syncthreads();
-    T* ldsM = lds + g * LANES * LANES;
+    T* ldsM = lds + g * PSTRIDE;
     const Model<T> M{ldsModel, l8};
     ArmInts I;
     I.site_link = (int)model[O_SITE_LINK];
