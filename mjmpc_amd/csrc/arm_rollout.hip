@@ -491,11 +491,12 @@ __device__ __forceinline__ void arm_substep(const Model<T>& M, const ArmInts& I,
 // STEP = true is the same code instantiated under its own name for the single-particle "real env" step
 // (mjmpc_arm_step_state), so that profiler statistics of the P-particle rollout are not diluted by it.
 // second launch bound = waves per SIMD the register allocation has to leave room for: 2 for f64 (<= 256
-// VGPRs), 4 for f32 (<= 128) - occupancy is what carries the kernel once P exceeds ~8k particles
+// VGPRs), 3 for f32 (<= 168; the kernel needs 140, a budget of 128 spills) - occupancy carries the kernel once
+// P exceeds ~8k particles
 // CL = true: the closed-loop-linear policy variant, its own instantiation so that the open-loop kernel does
 // not carry its registers (136 -> 178 VGPRs in f32 when both lived in one kernel)
 template <typename T, bool STEP, bool CL>
-__global__ __launch_bounds__(64, (sizeof(T) == 8 ? 2 : 4)) void arm_rollout_kernel(const T* __restrict__ model, const double* state,
+__global__ __launch_bounds__(64, (sizeof(T) == 8 ? 2 : 3)) void arm_rollout_kernel(const T* __restrict__ model, const double* state,
                                                          long P, int H, int A, const double* __restrict__ mean,
                                                          const T* __restrict__ noise, T* __restrict__ cost,
                                                          T* __restrict__ act, T* __restrict__ obs,
