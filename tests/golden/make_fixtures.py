@@ -24,6 +24,8 @@ import os
 import sys
 import types
 
+sys.dont_write_bytecode = True      # the reference tree is read-only: importing it must not drop __pycache__ there
+
 import numpy as np
 
 REF = "/root/reference"
