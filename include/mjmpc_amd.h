@@ -215,6 +215,14 @@ int mjmpc_q0_sum(int64_t P, int H, int A, double* d_out, void* d_ws, void* strea
  * 2 the appended row is read from d_row ('random': drawn by the host from np.random).            */
 int mjmpc_shift_mean(double* d_mean, int H, int A, int mode, const double* d_row, void* stream);
 
+/* Covariance kept on the device (CEM cem.py:75-95, DMDMPC with update_cov gaussian_dmd.py:77-113): the lower
+ * Cholesky factor d_chol (float64 [A][A]) that mjmpc_sample_noise colours its normals with, computed from the
+ * device-resident d_cov (np.linalg.cholesky's role inside control_utils.generate_noise:28-29); *d_status (device
+ * int, may be NULL) is set to 1 if d_cov is not positive definite.  mjmpc_cov_add_diag: cov += scale * diag(d_diag)
+ * (the shift's `+ beta * diag(init_cov)` / `+ beta * I`; d_diag NULL = identity).  A <= 64.                  */
+int mjmpc_cholesky_lower(const double* d_cov, int A, double* d_chol, int* d_status, void* stream);
+int mjmpc_cov_add_diag(double* d_cov, int A, const double* d_diag, double scale, void* stream);
+
 /* The recursive filter of generate_noise alone (control_utils.py:32-33), in place on d_noise [P][H][A]. */
 int mjmpc_filter_noise(int dtype, void* d_noise, int64_t P, int H, int A, const double* d_coeffs, void* stream);
 

@@ -71,6 +71,7 @@ class DeviceUpdater:
         self.wnorm = torch.zeros(2, dtype=torch.float64, device=self.device)
         self._ws, self._ws_P = None, -1
         self._rec = {}
+        self.chol_status = torch.zeros(1, dtype=torch.int32, device=self.device)
         self.mt_segments = 32            # workgroups generating the MT19937 stream in parallel (0/1 = serial)
 
     # ------------------------------------------------------------------ plumbing
@@ -284,6 +285,18 @@ class DeviceUpdater:
             row_d.copy_(self.torch.from_numpy(np.ascontiguousarray(row, np.float64)))
         _lib.check(self.lib.mjmpc_shift_mean(_vp(self.mean), self.H, self.A, int(mode), _vp(row_d), self.stream()))
 
+    def add_cov_diag(self, diag, scale):
+        """cov += scale * diag(diag) on the device (diag None: identity)."""
+        d = None
+        if diag is not None:
+            d = self.record("cov_diag", self.A)
+            cached = self._rec.get("cov_diag_host")
+            diag = np.ascontiguousarray(diag, np.float64)
+            if cached is None or not np.array_equal(cached, diag):
+                d.copy_(self.torch.from_numpy(diag.copy()))
+                self._rec["cov_diag_host"] = diag.copy()
+        _lib.check(self.lib.mjmpc_cov_add_diag(_vp(self.cov), self.A, _vp(d), float(scale), self.stream()))
+
     def sample_noise_mt19937(self, P, cov, filter_coeffs, seed, offset, dtype="f64", d_step=None, filtered=True):
         """The reference's own noise (legacy numpy stream of ``np.random.seed(seed + offset)``) regenerated
         on the device; isotropic covariance only.  Returns the (P,H,A) tensor, filtered unless told not to."""
@@ -326,7 +339,9 @@ class DeviceUpdater:
         return buf
 
     def sample_noise(self, P, cov, filter_coeffs, seed, offset, dtype="f64", particle_offset=0, d_step=None,
-                     filtered=True):
+                     filtered=True, device_cov_diagonal=False):
+        """Philox noise coloured by ``cov`` (host array), or - ``cov=None`` - by the device-resident ``self.cov``
+        (``device_cov_diagonal`` promises it has no off-diagonal entries)."""
         torch = self.torch
         tdt = torch.float32 if dtype == "f32" else torch.float64
         key = ("noise", dtype)
@@ -334,16 +349,28 @@ class DeviceUpdater:
         if buf is None or tuple(buf.shape) != (P, self.H, self.A):
             buf = torch.empty((P, self.H, self.A), dtype=tdt, device=self.device)
             self._rec[key] = buf
-        cov = np.asarray(cov, np.float64)
         fc = np.asarray(filter_coeffs, np.float64)
-        cached = self._rec.get("noise_params")
-        if cached is None or not (np.array_equal(cached[0], cov) and np.array_equal(cached[1], fc)):
+        if cov is None:
+            # the covariance lives on the device (self.cov): factor it there - nothing crosses PCIe
             chol = self.record("chol", self.A * self.A)
-            chol.copy_(torch.from_numpy(np.linalg.cholesky(cov).reshape(-1).copy()))
-            co = self.record("coeffs", 3)
-            co.copy_(torch.from_numpy(fc.copy()))
-            self._rec["noise_params"] = (cov.copy(), fc.copy())
-            self._rec["chol_diag"] = int(np.count_nonzero(cov - np.diag(np.diag(cov))) == 0)
+            _lib.check(self.lib.mjmpc_cholesky_lower(_vp(self.cov), self.A, _vp(chol), _vp(self.chol_status),
+                                                     self.stream()))
+            cached = self._rec.get("noise_params")
+            if cached is None or cached[0] is not None or not np.array_equal(cached[1], fc):
+                self.record("coeffs", 3).copy_(torch.from_numpy(fc.copy()))
+                self._rec["noise_params"] = (None, fc.copy())
+            self._rec["chol_diag"] = int(bool(device_cov_diagonal))
+        else:
+            cov = np.asarray(cov, np.float64)
+            cached = self._rec.get("noise_params")
+            if cached is None or cached[0] is None or not (np.array_equal(cached[0], cov)
+                                                           and np.array_equal(cached[1], fc)):
+                chol = self.record("chol", self.A * self.A)
+                chol.copy_(torch.from_numpy(np.linalg.cholesky(cov).reshape(-1).copy()))
+                co = self.record("coeffs", 3)
+                co.copy_(torch.from_numpy(fc.copy()))
+                self._rec["noise_params"] = (cov.copy(), fc.copy())
+                self._rec["chol_diag"] = int(np.count_nonzero(cov - np.diag(np.diag(cov))) == 0)
         chol, co = self._rec["chol"], self._rec["coeffs"]
         _lib.check(self.lib.mjmpc_sample_noise(_lib.F32 if dtype == "f32" else _lib.F64, _vp(buf), P, self.H, self.A,
                                                _vp(chol), _vp(co) if filtered else None, int(seed) & (2 ** 64 - 1),

@@ -17,6 +17,16 @@ class CEM(OLGaussianMPC):
         self.beta = beta
         self.num_elite = int(self.num_particles * self.elite_frac)
 
+    def _device_cov(self):
+        return self.cov_type in ('diagonal', 'full')
+
+    def _device_update(self, trajectories):
+        self.dev.cem_update(trajectories["costs"], trajectories["actions"], self.num_elite, self.step_size,
+                            self.cov_type == 'full')
+
+    def _device_shift_cov(self):
+        self.dev.add_cov_diag(self.init_cov, self.beta)
+
     def _update_distribution(self, trajectories):
         """cem.py:65-86: the num_elite particles of least cost-to-go (ties by particle index) refit
         mean and covariance - np.var (ddof 0) on the diagonal, np.cov (ddof 1) for 'full'."""
@@ -30,8 +40,9 @@ class CEM(OLGaussianMPC):
     def _shift(self):
         """cem.py:89-95."""
         super()._shift()
-        self.cov_action = self.cov_action + self.beta * np.diag(self.init_cov)
         self._sync_in()
+        self._device_shift_cov()        # cov += beta * diag(init_cov), where the covariance lives
+        self._pull(cov=True)
 
     def _calc_val(self, trajectories):
         """cem.py:107-112."""

@@ -251,6 +251,11 @@ class OLGaussianMPC(Controller):
                 raise NotImplementedError("device_mt19937 noise is a single serial stream: single GPU only")
             return self.dev.sample_noise_mt19937(n_loc, self.cov_action, self.filter_coeffs, self.seed_val,
                                                  self.num_steps, dtype=self.noise_dtype)
+        if self._device_cov():
+            self._sync_in()             # a covariance the user assigned on the host is uploaded first
+            return self.dev.sample_noise(n_loc, None, self.filter_coeffs, self.seed_val, self.num_steps,
+                                         dtype=self.noise_dtype, particle_offset=rank * n_loc,
+                                         device_cov_diagonal=self.cov_type == 'diagonal')
         return self.dev.sample_noise(n_loc, self.cov_action, self.filter_coeffs, self.seed_val, self.num_steps,
                                      dtype=self.noise_dtype, particle_offset=rank * n_loc)
 
@@ -284,12 +289,19 @@ class OLGaussianMPC(Controller):
     def _graph_capable(self):
         return (self.noise_mode in ('device', 'device_mt19937') and getattr(self._rollout_fn, "accepts_device", False)
                 and (self.noise_mode == 'device' or self.dev.comm.world_size == 1)
-                and self.base_action in ('null', 'repeat') and self._static_cov() and self.sample_mode == 'mean'
+                and self.base_action in ('null', 'repeat') and self.sample_mode == 'mean'
+                and (self._static_cov() or (self._device_cov() and self.noise_mode == 'device'))
                 and (self.dev.comm.world_size == 1 or (self._fused_capable()
                                                        and getattr(self.dev.comm, "backend", "") == "nccl")))
 
     def _static_cov(self):
         return False            # subclasses whose update leaves cov_action alone say True
+
+    def _device_cov(self):
+        return False            # subclasses that adapt the covariance entirely on the device say True
+
+    def _device_shift_cov(self):
+        pass                    # ... and grow it here after the shift (cem.py:94, gaussian_dmd.py:111)
 
     def _device_update(self, trajectories):
         raise NotImplementedError
@@ -302,9 +314,14 @@ class OLGaussianMPC(Controller):
         if self.noise_mode == 'device_mt19937':
             return self.dev.sample_noise_mt19937(n_loc, self._cov_host, self.filter_coeffs, self.seed_val, steps_ahead,
                                                  dtype=self.noise_dtype, d_step=self._step_dev, filtered=False)
-        return self.dev.sample_noise(n_loc, self._cov_host, self.filter_coeffs, self.seed_val, steps_ahead,
+        return self.dev.sample_noise(n_loc, self._noise_cov(), self.filter_coeffs, self.seed_val, steps_ahead,
                                      dtype=self.noise_dtype, d_step=self._step_dev, filtered=False,
-                                     particle_offset=self.dev.comm.rank * n_loc)
+                                     particle_offset=self.dev.comm.rank * n_loc,
+                                     device_cov_diagonal=self.cov_type == 'diagonal')
+
+    def _noise_cov(self):
+        """Host covariance for the sampler, or None when the covariance adapts on the device."""
+        return self._cov_host if self._static_cov() else None
 
     def _device_iteration(self):
         """The control iteration without any host synchronisation (capturable)."""
@@ -329,9 +346,10 @@ class OLGaussianMPC(Controller):
                 delta = self.dev.sample_noise_mt19937(n_loc, self._cov_host, self.filter_coeffs, self.seed_val, 0,
                                                       dtype=self.noise_dtype, d_step=self._step_dev)
             else:
-                delta = self.dev.sample_noise(n_loc, self._cov_host, self.filter_coeffs, self.seed_val, 0,
+                delta = self.dev.sample_noise(n_loc, self._noise_cov(), self.filter_coeffs, self.seed_val, 0,
                                               dtype=self.noise_dtype, d_step=self._step_dev,
-                                              particle_offset=self.dev.comm.rank * n_loc)
+                                              particle_offset=self.dev.comm.rank * n_loc,
+                                              device_cov_diagonal=self.cov_type == 'diagonal')
             if self.use_zero_control_seq:
                 delta[-1] = (-self.dev.mean).to(delta.dtype)
             traj = self._rollout_fn(n_loc, self.horizon, self.dev.mean, delta, mode="open_loop")
@@ -339,6 +357,7 @@ class OLGaussianMPC(Controller):
         self._action_dev.copy_(self.dev.mean[0])
         self._action_pin.copy_(self._action_dev, non_blocking=True)
         self.dev.shift(_SHIFT_MODES[self.base_action], None)
+        self._device_shift_cov()
         self._step_dev.add_(1)
         if self._graph_post is not None:
             self._graph_post(self._action_dev)
@@ -353,7 +372,7 @@ class OLGaussianMPC(Controller):
             self._action_dev = torch.zeros(self.d_action, dtype=torch.float64, device=self.dev.device)
             self._action_pin = torch.zeros(self.d_action, dtype=torch.float64).pin_memory()
             # eager dry run on a side stream (allocates every buffer), with the state it must not consume
-            keep = (self.dev.mean.clone(), self._step_dev.clone())
+            keep = (self.dev.mean.clone(), self._step_dev.clone(), self.dev.cov.clone())
             side = torch.cuda.Stream(self.dev.device)
             side.wait_stream(torch.cuda.current_stream(self.dev.device))
             post, self._graph_post = self._graph_post, None
@@ -364,6 +383,7 @@ class OLGaussianMPC(Controller):
             self._graph_post = post
             self.dev.mean.copy_(keep[0])
             self._step_dev.copy_(keep[1])
+            self.dev.cov.copy_(keep[2])
             try:
                 g = torch.cuda.CUDAGraph()
                 with torch.cuda.graph(g):
@@ -374,6 +394,7 @@ class OLGaussianMPC(Controller):
                 warnings.warn("hipGraph capture of the control iteration failed (%s); running eagerly" % (e,))
                 torch.cuda.synchronize(self.dev.device)
                 self.dev.mean.copy_(keep[0])
+                self.dev.cov.copy_(keep[2])
                 self._graph_on = False
                 self._graph = None
                 self.graph_fallback = True
@@ -386,6 +407,8 @@ class OLGaussianMPC(Controller):
         self.num_steps += 1
         self._step_host = self.num_steps
         self._mean_stale = True
+        if not self._static_cov():
+            self._cov_stale = True
         return action, 0.0
 
     def _optimize_eager_after_fallback(self, state):

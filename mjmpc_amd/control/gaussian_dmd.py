@@ -21,21 +21,31 @@ class DMDMPC(OLGaussianMPC):
     def _static_cov(self):
         return not self.update_cov
 
+    def _device_cov(self):
+        return self.update_cov and self.cov_type in ('diagonal', 'full')
+
+    def _cov_mode(self):
+        if not self.update_cov:
+            return 0
+        if self.cov_type == 'diagonal':
+            return 1
+        if self.cov_type == 'full':
+            return 2
+        raise ValueError('Unidentified covariance type in update_distribution')
+
     def _device_update(self, trajectories):
-        self.dev.softmax_update(trajectories["costs"], trajectories["actions"], self.lam, self.step_size)
+        self.dev.softmax_update(trajectories["costs"], trajectories["actions"], self.lam, self.step_size,
+                                cov_mode=self._cov_mode())
+
+    def _device_shift_cov(self):
+        if self.update_cov:
+            self.dev.add_cov_diag(None, self.beta)
 
     def _update_distribution(self, trajectories):
         """gaussian_dmd.py:65-104: softmax weights; weighted mean; if update_cov the weighted scatter,
         diagonal = mean_t sum_p w delta^2, full = (sum_{p,t} w delta delta^T) / H."""
         self._sync_in()
-        cov_mode = 0
-        if self.update_cov:
-            if self.cov_type == 'diagonal':
-                cov_mode = 1
-            elif self.cov_type == 'full':
-                cov_mode = 2
-            else:
-                raise ValueError('Unidentified covariance type in update_distribution')
+        cov_mode = self._cov_mode()
         self.dev.softmax_update(trajectories["costs"], trajectories["actions"], self.lam, self.step_size,
                                 cov_mode=cov_mode)
         self._pull(cov=bool(cov_mode))
@@ -44,8 +54,9 @@ class DMDMPC(OLGaussianMPC):
         """gaussian_dmd.py:106-113: shift the mean; grow the covariance by beta * I when it adapts."""
         super()._shift()
         if self.update_cov:
-            self.cov_action = self.cov_action + self.beta * np.eye(self.d_action)
             self._sync_in()
+            self._device_shift_cov()    # cov += beta * I on the device
+            self._pull(cov=True)
 
     def _calc_val(self, trajectories):
         """gaussian_dmd.py:126-139."""

@@ -462,6 +462,16 @@ int mjmpc_shift_mean(double* d_mean, int H, int A, int mode, const double* d_row
     PLAIN(mjmpc::shift_mean(d_mean, H, A, mode, d_row, (hipStream_t)stream));
 }
 
+int mjmpc_cholesky_lower(const double* d_cov, int A, double* d_chol, int* d_status, void* stream) {
+    if (!d_cov || !d_chol || A < 1 || A > 64) return fail(MJMPC_E_BADARG, "bad argument (A <= 64)");
+    PLAIN(mjmpc::cholesky_lower(d_cov, A, d_chol, d_status, (hipStream_t)stream));
+}
+
+int mjmpc_cov_add_diag(double* d_cov, int A, const double* d_diag, double scale, void* stream) {
+    if (!d_cov || A < 1 || A > 64) return fail(MJMPC_E_BADARG, "bad argument (A <= 64)");
+    PLAIN(mjmpc::cov_add_diag(d_cov, A, d_diag, scale, (hipStream_t)stream));
+}
+
 int mjmpc_filter_noise(int dtype, void* d_noise, int64_t P, int H, int A, const double* d_coeffs, void* stream) {
     if (!d_noise || !d_coeffs) return fail(MJMPC_E_BADARG, "null argument");
     hipStream_t s = (hipStream_t)stream;

@@ -52,6 +52,9 @@ hipError_t mppi_fused_update(const double* q0, const T* actions, double lam, dou
 
 hipError_t q0_sum(long P, int H, int A, double* out, double* ws, hipStream_t s);
 hipError_t shift_mean(double* mean, int H, int A, int mode, const double* row, hipStream_t s);
+// lower Cholesky factor of a device-resident covariance (A <= 64); cov += scale * diag(d) (d null: identity)
+hipError_t cholesky_lower(const double* cov, int A, double* chol, int* status, hipStream_t s);
+hipError_t cov_add_diag(double* cov, int A, const double* d, double scale, hipStream_t s);
 
 // Noise: standard normals from Philox4x32-10, coloured by L (A x A lower Cholesky factor of cov), then the
 // in-place AR filter of control_utils.py:32-33, written in the reference's (P,H,A) layout.

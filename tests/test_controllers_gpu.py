@@ -242,6 +242,85 @@ def test_graph_replay_matches_eager_steps(raw_arm):
     np.testing.assert_allclose(m_g, m_e, rtol=1e-9, atol=1e-10)
 
 
+@pytest.mark.parametrize("kind", ["cem_full", "cem_diag", "dmd_full"])
+def test_adapting_covariance_stays_on_the_device_and_graph_matches_eager(raw_arm, kind):
+    """CEM / DMD-MPC with update_cov: the covariance is refit, grown (shift) and Cholesky-factored for the sampler
+    on the GPU.  The captured iteration walks the same closed loop as the eager path, and the eager path agrees
+    with a run whose covariance round-trips through the host every step (the reference's data flow)."""
+    import torch
+    from mjmpc_amd.control import CEM, DMDMPC
+    from mjmpc_amd.envs.arm_engine import ArmRolloutEngine, make_device_rollout_fn
+
+    def make(eng):
+        kw = dict(d_state=eng.d_state, d_obs=eng.d_obs, d_action=7, horizon=12, num_particles=512, n_iters=1,
+                  action_lows=eng.action_lows, action_highs=eng.action_highs, filter_coeffs=[0.25, 0.8, 0.0], seed=9,
+                  noise_mode="device", gamma=0.99, base_action="null")
+        if kind.startswith("cem"):
+            return CEM(init_cov=0.6, elite_frac=0.1, step_size=0.7, beta=0.05,
+                       cov_type="full" if kind == "cem_full" else "diagonal", **kw)
+        return DMDMPC(init_cov=0.6, beta=0.05, lam=0.2, step_size=0.7, update_cov=True, cov_type="full", **kw)
+
+    def run(mode, steps=5):
+        eng = ArmRolloutEngine(raw_arm, dtype="f64")
+        c = make(eng)
+        c.rollout_fn = make_device_rollout_fn(eng)
+        c.set_sim_state_fn = lambda s: None
+        eng.set_env_state(dict(qp=np.array([0.1, 0.2, 0.0, -0.5, 0.0, -0.3, 0.0]), qv=np.zeros(7),
+                               target_pos=np.array([0.2, -0.1, 0.2])))
+        if mode == "graph":
+            c.enable_graph(post_step=eng.step_state)
+        acts, covs = [], []
+        for _ in range(steps):
+            if mode == "host_cov":
+                c.cov_action = c.cov_action.copy()        # force the host round trip + re-upload every step
+            a, _ = c.optimize({})
+            if mode != "graph":
+                eng.step_state(a)
+            acts.append(a)
+            covs.append(c.cov_action.copy())
+        torch.cuda.synchronize()
+        assert int(c.dev.chol_status.item()) == 0
+        return np.array(acts), np.array(covs), c.mean_action.copy()
+
+    a_e, c_e, m_e = run("eager")
+    a_h, c_h, m_h = run("host_cov")
+    a_g, c_g, m_g = run("graph")
+    assert np.abs(c_e[-1] - c_e[0]).max() > 1e-3                      # the covariance really adapts
+    if kind != "cem_diag":
+        assert np.abs(c_e[-1] - np.diag(np.diag(c_e[-1]))).max() > 1e-4
+    for a, c, m in ((a_h, c_h, m_h), (a_g, c_g, m_g)):
+        np.testing.assert_allclose(a, a_e, rtol=1e-9, atol=1e-10)
+        np.testing.assert_allclose(c, c_e, rtol=1e-9, atol=1e-11)
+        np.testing.assert_allclose(m, m_e, rtol=1e-9, atol=1e-10)
+
+
+@pytest.mark.parametrize("P_,k_frac", [(1000, 0.1), (16384, 0.1), (777, 0.5), (64, 1.0)])
+def test_cem_elite_selection_with_ties_negative_costs_and_large_populations(P_, k_frac):
+    """The radix select behind CEM's elite set: heavy ties across the threshold (broken by particle index),
+    negative and zero costs, populations up to the BASELINE CEM configuration (16 384)."""
+    from mjmpc_amd.control import CEM
+    rs = np.random.RandomState(P_)
+    Hh, Aa = 6, 3
+    costs = np.round(rs.randn(P_, Hh) * 2.0, 1)                # quantised: many exactly equal cost-to-go values
+    costs[rs.rand(P_) < 0.05] = 0.0
+    mean0 = 0.2 * rs.randn(Hh, Aa)
+    actions = mean0[None] + rs.randn(P_, Hh, Aa)
+    c = CEM(init_cov=1.0, base_action="null", elite_frac=k_frac, step_size=0.9, gamma=1.0, beta=0.0, cov_type="full",
+            d_state=5, d_obs=6, d_action=Aa, horizon=Hh, num_particles=P_, n_iters=1, action_lows=-np.ones(Aa),
+            action_highs=np.ones(Aa), seed=1)
+    c.mean_action = mean0.copy()
+    c._update_distribution(dict(costs=costs, actions=actions))
+    k = int(P_ * k_frac)
+    q0 = costs[:, ::-1].cumsum(axis=1)[:, -1]                  # gamma = 1: plain sum, in cost_to_go's order
+    ids = np.argsort(q0, kind="stable")[:k]                    # (q0, index) order
+    assert np.sum(q0 == np.sort(q0)[k - 1]) > 1 or P_ == 64    # the threshold value really is tied
+    d = (actions - mean0[None])[ids].reshape(Hh * k, Aa)
+    want_cov = 0.1 * np.eye(Aa) + 0.9 * np.cov(d, rowvar=False)
+    want_mean = 0.1 * mean0 + 0.9 * actions[ids].mean(axis=0)
+    np.testing.assert_allclose(c.mean_action, want_mean, rtol=1e-11, atol=1e-12)
+    np.testing.assert_allclose(c.cov_action, want_cov, rtol=1e-11, atol=1e-12)
+
+
 def test_mppiq_returns_update_and_value(golden):
     """MPPIQ (mppiq.py:73-165) against the reference's outputs: TD(lambda) returns kernel, update, value."""
     from mjmpc_amd.control import MPPIQ

@@ -1,0 +1,88 @@
+"""The other BASELINE.json configurations on ONE GPU (bench.py stays the headline: MPPI 4096 x 32).
+
+    python tools/bench_configs.py [--steps 30] [--dtype f64]
+
+  cfg1  reacher_7dof-v0 MPPI, 1024 particles x H32, lam 0.01
+  cfg3  reacher_7dof-v0 CEM full covariance, 16384 particles x H32, elite_frac 0.1   (BASELINE shards it over 4 GPUs;
+        here the whole population on one)
+  cfg4* DMD-MPC, 65536 particles x H64 on the 7-dof arm (BASELINE names pen-v0, whose assets are not in the
+        reference tree: throughput of the same controller path on the model we have, flagged)
+One step = Controller.optimize() + stepping the real arm on the device, all data resident in HBM.  One JSON line each.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+
+def run(name, make, P, H, steps, warmup, dtype, note):
+    import torch
+    from mjmpc_amd.envs.arm_engine import ArmRolloutEngine, make_device_rollout_fn
+    from mjmpc_amd.models.reacher7dof import reacher7dof_raw
+    eng = ArmRolloutEngine(reacher7dof_raw(), dtype=dtype)
+    ctrl = make(eng, P, H)
+    ctrl.rollout_fn = make_device_rollout_fn(eng)
+    ctrl.set_sim_state_fn = lambda s: None
+    eng.set_env_state(dict(qp=np.zeros(7), qv=np.zeros(7), target_pos=np.array([0.1, 0.1, 0.1])))
+    graphed = ctrl._graph_capable()
+    if graphed:
+        ctrl.enable_graph(post_step=eng.step_state)
+    state = {"resident": True}
+
+    def step():
+        a, _ = ctrl.optimize(state)
+        if not graphed:
+            eng.step_state(a)
+
+    for _ in range(warmup):
+        step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    _, nobs = eng.step_state(np.zeros(7))
+    print(json.dumps({"config": name, "particles": P, "horizon": H, "dtype": dtype, "steps": steps,
+                      "ms_per_step": dt / steps * 1e3, "control_loop_hz": steps / dt,
+                      "particle_steps_per_s": P * H * ctrl.n_iters * steps / dt,
+                      "launch": "hipGraph replay" if graphed else "eager launches",
+                      "final_distance_to_target": float(torch.linalg.norm(nobs[17:20]).item()),
+                      "solver_failures": eng.solver_failures(), "note": note}), flush=True)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--steps", type=int, default=30)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--dtype", choices=["f64", "f32"], default="f64")
+    args = ap.parse_args()
+    from mjmpc_amd.control import CEM, DMDMPC, MPPI
+
+    def kw(eng, P, H):
+        return dict(d_state=eng.d_state, d_obs=eng.d_obs, d_action=7, horizon=H, num_particles=P, n_iters=1,
+                    action_lows=eng.action_lows, action_highs=eng.action_highs, seed=123, noise_mode="device",
+                    noise_dtype=args.dtype)
+
+    run("cfg1 reacher_7dof-v0 MPPI 1024xH32",
+        lambda e, P, H: MPPI(init_cov=1.0, base_action="null", lam=0.01, step_size=1.0, alpha=1, gamma=1.0,
+                             filter_coeffs=[0.25, 0.8, 0.0], **kw(e, P, H)),
+        1024, 32, args.steps, args.warmup, args.dtype, "")
+    run("cfg3 reacher_7dof-v0 CEM full-cov 16384xH32 elite 0.1 (one GPU)",
+        lambda e, P, H: CEM(init_cov=1.0, base_action="null", elite_frac=0.1, step_size=1.0, gamma=1.0, beta=0.1,
+                            cov_type="full", filter_coeffs=[0.25, 0.8, 0.0], **kw(e, P, H)),
+        16384, 32, args.steps, args.warmup, args.dtype, "covariance changes every step: the Cholesky factor is a host "
+        "computation, so the iteration runs as eager launches")
+    run("cfg4* DMD-MPC 65536xH64 on the 7-dof arm (pen-v0 assets absent)",
+        lambda e, P, H: DMDMPC(init_cov=1.0, beta=0.1, base_action="null", lam=0.1, step_size=1.0, gamma=1.0,
+                               update_cov=False, cov_type="diagonal", filter_coeffs=[0.25, 0.8, 0.0], **kw(e, P, H)),
+        65536, 64, max(5, args.steps // 3), 2, args.dtype, "stand-in model; throughput only")
+
+
+if __name__ == "__main__":
+    main()
