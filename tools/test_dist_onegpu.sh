@@ -35,24 +35,24 @@ def run(use_comm, graph):
     return np.array(acts), getattr(c, "graph_fallback", False)
 ref, _ = run(False, False)
 import mjmpc_amd.control._device as D
-# route the single-GPU fused update through the collective branch
+# route the single-GPU fused update through the collective (sharded) branch: the communicator claims two ranks for
+# the duration of the call, the all-gather over the real world-size-1 RCCL group returns one record
 orig = D.DeviceUpdater.mppi_fused_update
-def patched(self, q0, actions, lam, step_size, shift_mode, action_out):
-    ws = self.comm.world_size; self.comm.world_size = 2 if hasattr(self.comm, "backend") else ws
-    try:
-        if hasattr(self.comm, "backend"):
-            self.comm.world_size = 1
-            P = q0.shape[0]
-            rec = self.record("softmax", self.lib.mjmpc_softmax_record_len(self.H, self.A, 0))
-            D._lib.check(self.lib.mjmpc_mppi_fused_update(self.code(actions), P, self.H, self.A, D._vp(q0), D._vp(actions), float(lam), 0.0, -1, D._vp(self.mean), None, D._vp(rec), None, D._vp(self.workspace(P)), self.stream()))
-            recs = self.comm.all_gather(rec)
-            D._lib.check(self.lib.mjmpc_softmax_combine(D._vp(recs), 1, self.H, self.A, 0, float(lam), float(step_size), 0, float(P), D._vp(self.mean), None, None, D._vp(self.wnorm), self.stream()))
-            if action_out is not None: action_out.copy_(self.mean[0])
-            if shift_mode >= 0: self.shift(shift_mode)
-        else:
-            orig(self, q0, actions, lam, step_size, shift_mode, action_out)
-    finally:
+def patched(self, *a, **k):
+    if not hasattr(self.comm, "backend"):
+        return orig(self, *a, **k)
+    ws, gather = self.comm.world_size, self.comm.all_gather
+    def true_size_gather(t):
         self.comm.world_size = ws
+        try:
+            return gather(t)
+        finally:
+            self.comm.world_size = 2
+    self.comm.world_size, self.comm.all_gather = 2, true_size_gather
+    try:
+        return orig(self, *a, **k)
+    finally:
+        self.comm.world_size, self.comm.all_gather = ws, gather
 D.DeviceUpdater.mppi_fused_update = patched
 got, fb = run(True, True)
 print("rccl-in-graph fallback:", fb, " max |d action| vs eager single:", np.abs(got - ref).max())
