@@ -153,8 +153,9 @@ class DeviceUpdater:
         return out
 
     def softmax_update(self, costs, actions, lam, step_size, alpha=1, time_based_weights=False, cov_mode=0,
-                       covinv=None, want_value=False, update_mean=True, costs_are_returns=False):
-        """``costs_are_returns``: the (P,H) input already holds per-step returns - no cost_to_go (MPPIQ)."""
+                       covinv=None, want_value=False, update_mean=True, costs_are_returns=False, replicated=False):
+        """``costs_are_returns``: the (P,H) input already holds per-step returns - no cost_to_go (MPPIQ).
+        ``replicated``: every rank passes ALL particles (PFMPC after its cost gather) - no record exchange."""
         costs, actions, P = self._pair(costs, actions)
         tbw = int(bool(time_based_weights))
         n = self.lib.mjmpc_softmax_record_len(self.H, self.A, tbw)
@@ -167,7 +168,7 @@ class DeviceUpdater:
                                                 1 if costs_are_returns else self.gamma_zero,
                                                 float(lam), int(alpha), tbw, int(cov_mode != 0), _vp(rec), _vp(ws),
                                                 self.stream()))
-        recs = self.comm.all_gather(rec)
+        recs = rec.reshape(1, -1) if replicated else self.comm.all_gather(rec)
         G = recs.shape[0]
         mean_out = self.mean if update_mean else self.record("mean_scratch", self.H * self.A).copy_(self.mean.reshape(-1))
         _lib.check(self.lib.mjmpc_softmax_combine(_vp(recs), G, self.H, self.A, tbw, float(lam), float(step_size),

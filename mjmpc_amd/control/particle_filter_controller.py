@@ -6,8 +6,11 @@ costs into softmax weights, resamples systematically and (on shift) diffuses the
 
 Split of work: rollouts and the exponentiated-cost weights are HIP kernels; the resampling itself is
 a cumulative-sum search whose float summation order decides which particle survives, so it is done
-on the host on the gathered weights, in the reference's order (per-GPU
-replicas, no particle sharding for this controller).
+on the host on the gathered weights, in the reference's order.
+
+Sharded runs (one process per GPU): every rank holds the whole particle set, rolls out only its contiguous
+block, all-gathers the (P,H) costs - the path's one exchange - and then computes the same weights and the
+same resampling as every other rank (identical seeds), so the replicas stay bit-identical without a broadcast.
 """
 import copy
 import random
@@ -16,6 +19,7 @@ import numpy as np
 
 from .control_utils import generate_noise
 from .controller import Controller
+from .sharding import local_block
 
 
 def systematic_resample_indices(weights, first_pointer):
@@ -39,8 +43,8 @@ class PFMPC(Controller):
                  sample_mode="mean", batch_size=1, filter_coeffs=[1., 0., 0.], seed=0, device=0, comm=None):
         super().__init__(d_state, d_obs, d_action, action_lows, action_highs, horizon, gamma, n_iters,
                          set_sim_state_fn, rollout_fn, sample_mode, batch_size, seed, device=device, comm=comm)
-        if self.dev.comm.world_size != 1:
-            raise NotImplementedError("PFMPC runs as per-GPU replicas; particle sharding is not supported")
+        if num_particles % self.dev.comm.world_size != 0:
+            raise AssertionError("Number of particles must be divisible by number of shards")
         self.lam = lam
         self.num_particles = num_particles
         self.base_action = base_action
@@ -63,15 +67,18 @@ class PFMPC(Controller):
     def generate_rollouts(self, state):
         """:74-90 - the particles are passed as deviations from their mean, the only form rollout_fn takes."""
         self._set_sim_state_fn(copy.deepcopy(state))
-        return self._rollout_fn(self.num_particles, self.horizon, self.mean_action,
-                                self.action_samples - self.mean_action, mode="open_loop")
+        off, n = local_block(self.num_particles, self.dev.comm.rank, self.dev.comm.world_size)
+        return self._rollout_fn(n, self.horizon, self.mean_action,
+                                (self.action_samples - self.mean_action)[off:off + n], mode="open_loop")
 
     # -- update -------------------------------------------------------------------------------------
     def _exp_util(self, costs):
         """softmax(-cost_to_go[:, 0] / lam) (:104-113), by the HIP softmax kernels."""
         costs = self.dev.to_device(costs, "costs")
+        if self.dev.comm.world_size > 1:                  # the exchange: every rank sees all P cost rows
+            costs = self.dev.comm.all_gather_flat(costs.reshape(-1)).reshape(self.num_particles, self.horizon)
         n = self.dev.softmax_update(costs, self.dev.zero_actions(costs.shape[0], costs), self.lam, 0.0,
-                                    update_mean=False)
+                                    update_mean=False, replicated=True)
         return self.dev.softmax_weights(n).cpu().numpy()
 
     def _resampling(self, act_seq, weights, low_variance=True):
