@@ -21,6 +21,7 @@ class Reacher7DOFEnv:
         self.action_lows, self.action_highs = self.engine.action_lows, self.engine.action_highs
         self.np_random = np.random.RandomState(0)
         self.env_timestep = 0
+        self.real_step = True
         self._qp, self._qv = np.zeros(self.nv), np.zeros(self.nv)
         self._qa = np.zeros(self.nv)
         self._target = self.engine.model.target_default.copy()
@@ -46,11 +47,7 @@ class Reacher7DOFEnv:
         if seed is not None:
             self.seed(seed)
         self._qp, self._qv = np.zeros(self.nv), np.zeros(self.nv)
-        t = np.array([0.1, 0.1, 0.1])
-        t[0] = self.np_random.uniform(low=-0.3, high=0.3)
-        t[1] = self.np_random.uniform(low=-0.2, high=0.2)
-        t[2] = self.np_random.uniform(low=-0.25, high=0.25)
-        self._target = t
+        self.target_reset()
         self.env_timestep = 0
         self._hand = self._fresh_hand()
         return self.get_obs()
@@ -61,8 +58,24 @@ class Reacher7DOFEnv:
         o = nobs[0, 0]
         self._qp, self._qv = o[:self.nv].copy(), o[self.nv:2 * self.nv].copy()
         self._hand = o[2 * self.nv:2 * self.nv + 3].copy()
-        self.env_timestep += 1
-        return self.get_obs(), float(rew[0, 0]), False, self.get_env_infos()
+        ob = self.get_obs()
+        self.env_timestep += 1                      # reacher_env.py:37-38: the count, then the timed events
+        self.trigger_timed_events()
+        return ob, float(rew[0, 0]), False, self.get_env_infos()
+
+    def target_reset(self):
+        """reacher_env.py:56-62: a new target from the env's own generator."""
+        t = np.array([0.1, 0.1, 0.1])
+        t[0] = self.np_random.uniform(low=-0.3, high=0.3)
+        t[1] = self.np_random.uniform(low=-0.2, high=0.2)
+        t[2] = self.np_random.uniform(low=-0.25, high=0.25)
+        self._target = t
+
+    def trigger_timed_events(self):
+        pass                                        # used by the continual version (reacher_env.py:73-75)
+
+    def real_env_step(self, flag):
+        self.real_step = bool(flag)
 
     def get_obs(self):
         return np.concatenate([self._qp, self._qv, self._hand, self._hand - self._target])
@@ -86,3 +99,13 @@ class Reacher7DOFEnv:
     def evaluate_success(self, paths):
         n = sum(1 for p in paths if np.sum(p['env_infos']['goal_achieved']) > 10)
         return n * 100.0 / len(paths)
+
+
+class ContinualReacher7DOFEnv(Reacher7DOFEnv):
+    """``continual_reacher-v0`` (mjmpc/envs/__init__.py:27-31, reacher_env.py:128-132): the real environment
+    draws a new target every 50 steps; rollouts (real_step False) never do."""
+    max_episode_steps = 250
+
+    def trigger_timed_events(self):
+        if self.env_timestep % 50 == 0 and self.env_timestep > 0 and self.real_step is True:
+            self.target_reset()
