@@ -1,0 +1,112 @@
+#!/usr/bin/env python
+"""Closed-loop MPC episodes on the MI355X engine - the counterpart of mjmpc's examples/example_mpc.py.
+
+    python examples/example_mpc.py --config examples/configs/reacher_7dof-v0.yml --controller mppi
+        [--dyn_randomize_config examples/configs/dyn_randomize_configs/reacher_7dof-v0.yml]
+        [--noise_mode host|device|device_mt19937] [--dtype f64|f32] [--graph]
+
+Same experiment file format, same loop: per episode a fresh MPCPolicy whose controller gets
+``set_sim_state_fn`` / ``rollout_fn`` assigned, ``policy.get_action(state)`` -> ``env.step(action)``.  What changes
+is who executes the rollouts: one ``ArmRolloutEngine`` (all particles in one kernel launch, `num_cpu` model shards)
+instead of `num_cpu` MuJoCo worker processes.  `--noise_mode host` keeps the reference's random stream.
+"""
+import argparse
+import os
+import sys
+import time
+from copy import deepcopy
+
+import numpy as np
+import yaml
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+from mjmpc_amd.envs.arm_engine import ArmRolloutEngine, make_device_rollout_fn, make_rollout_fn   # noqa: E402
+from mjmpc_amd.envs.reacher_env import ContinualReacher7DOFEnv, Reacher7DOFEnv                   # noqa: E402
+from mjmpc_amd.models.reacher7dof import reacher7dof_raw                                         # noqa: E402
+from mjmpc_amd.policies import MPCPolicy                                                         # noqa: E402
+
+ENVS = {"reacher_7dof-v0": Reacher7DOFEnv, "continual_reacher-v0": ContinualReacher7DOFEnv}
+
+
+def main():
+    ap = argparse.ArgumentParser(description="Run an MPC algorithm on a given environment")
+    ap.add_argument("--config", required=True, help="yaml file with experiment parameters")
+    ap.add_argument("--dyn_randomize_config", help="yaml file with dynamics randomization parameters")
+    ap.add_argument("--controller", default="mppi", help="controller block of the config to run")
+    ap.add_argument("--noise_mode", default="host", choices=["host", "device", "device_mt19937"])
+    ap.add_argument("--dtype", default="f64", choices=["f64", "f32"])
+    ap.add_argument("--graph", action="store_true", help="replay the control iteration as a hipGraph (device noise modes)")
+    ap.add_argument("--episodes", type=int, help="override n_episodes")
+    args = ap.parse_args()
+    with open(args.config) as f:
+        exp = yaml.safe_load(f)
+    if exp["env_name"] not in ENVS:
+        raise SystemExit("environment %r is not built (have: %s)" % (exp["env_name"], ", ".join(ENVS)))
+    if args.controller not in exp:
+        raise SystemExit("the config has no %r block" % args.controller)
+    params = dict(exp[args.controller])
+    num_cpu = params.pop("num_cpu", 1)
+    if "particles_per_cpu" in params:
+        params["num_particles"] = num_cpu * params.pop("particles_per_cpu")
+    controller_type = "mppi" if args.controller == "bench" else args.controller
+
+    env = ENVS[exp["env_name"]](dtype=args.dtype)                    # the "real" environment
+    env.real_env_step(True)
+    sim = ArmRolloutEngine(reacher7dof_raw(), dtype=args.dtype, num_shards=num_cpu)   # the rollout engine
+    if args.dyn_randomize_config:
+        with open(args.dyn_randomize_config) as f:
+            default_params, randomized = sim.randomize_dynamics(yaml.safe_load(f), base_seed=exp["seed"])
+        print("default params   :", default_params[0])
+        print("randomized params:", randomized)
+
+    params.update(d_obs=env.d_obs, d_state=env.d_state, d_action=env.d_action, action_lows=env.action_lows,
+                  action_highs=env.action_highs)
+    if controller_type != "pfmpc":
+        params.setdefault("base_action", exp.get("base_action", "null"))
+        params.update(noise_mode=args.noise_mode, noise_dtype=args.dtype)
+    else:
+        params.setdefault("base_action", exp.get("base_action", "null"))
+    n_episodes = args.episodes or exp["n_episodes"]
+    ep_rewards = np.zeros(n_episodes)
+    trajectories = []
+    t_ctrl, n_ctrl = 0.0, 0
+    for i in range(n_episodes):
+        episode_seed = exp["seed"] + i * 12345                       # consistent episodes, as in the reference
+        params["seed"] = episode_seed
+        env.reset(seed=episode_seed)
+        policy = MPCPolicy(controller_type=controller_type, param_dict=params, batch_size=1)
+        ctrl = policy.controller
+        ctrl.set_sim_state_fn = sim.set_env_state
+        device_path = args.noise_mode != "host" and controller_type != "pfmpc"
+        ctrl.rollout_fn = make_device_rollout_fn(sim) if device_path else make_rollout_fn(sim)
+        if args.graph and device_path:
+            ctrl.enable_graph()
+        rewards, infos, actions, observations = [], [], [], []
+        for _ in range(exp["max_ep_length"]):
+            state = deepcopy(env.get_env_state())
+            t0 = time.perf_counter()
+            action, _ = policy.get_action(state, calc_val=False)
+            t_ctrl += time.perf_counter() - t0
+            n_ctrl += 1
+            obs, reward, done, info = env.step(action)
+            observations.append(obs)
+            actions.append(action)
+            rewards.append(reward)
+            infos.append(info["goal_achieved"])
+            ep_rewards[i] += reward
+        trajectories.append(dict(observations=np.array(observations), actions=np.array(actions),
+                                 rewards=np.array(rewards), env_infos=dict(goal_achieved=np.array(infos))))
+        print("episode %d: reward %.3f, final distance to target %.4f" % (i, ep_rewards[i],
+                                                                          np.linalg.norm(observations[-1][17:20])))
+    failures = sim.solver_failures()
+    sim.close()
+    print("Avg. reward = %.4f, Std. Reward = %.4f, Success Metric = %.1f" % (
+        ep_rewards.mean(), ep_rewards.std(), env.evaluate_success(trajectories)))
+    print("%s: %d particles x H%d, %.3f ms per optimize() (%.0f Hz), solver failures %d" % (
+        args.controller, params["num_particles"], params["horizon"], 1e3 * t_ctrl / n_ctrl, n_ctrl / t_ctrl,
+        failures))
+
+
+if __name__ == "__main__":
+    main()

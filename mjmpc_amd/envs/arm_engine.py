@@ -177,6 +177,7 @@ class ArmRolloutEngine:
     def close(self):
         if not self.closed:
             self._lib.mjmpc_arm_destroy(self._h)
+            self._h = None              # later calls fail with "null engine" instead of touching freed memory
             self.closed = True
 
     def __del__(self):

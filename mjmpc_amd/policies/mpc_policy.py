@@ -1,7 +1,8 @@
 """String -> controller dispatcher (reference mjmpc/policies/mpc_policy.py:7-40)."""
 from .. import control
 
-_TYPES = {"cem": "CEM", "dmd": "DMDMPC", "mppi": "MPPI", "pfmpc": "PFMPC", "random_shooting": "RandomShooting"}
+_TYPES = {"cem": "CEM", "dmd": "DMDMPC", "mppi": "MPPI", "mppiq": "MPPIQ", "pfmpc": "PFMPC",
+          "random_shooting": "RandomShooting"}
 
 
 class MPCPolicy:
