@@ -1,8 +1,8 @@
 #!/usr/bin/env python
 """Closed-loop MPC episodes on the MI355X engine - the counterpart of mjmpc's examples/example_mpc.py.
 
-    python examples/example_mpc.py --config examples/configs/reacher_7dof-v0.yml --controller mppi
-        [--dyn_randomize_config examples/configs/dyn_randomize_configs/reacher_7dof-v0.yml]
+    python examples/example_mpc.py --config examples/configs/reacher_gpu.yml --controller mppi
+        [--dyn_randomize_config examples/configs/reacher_gpu_dyn_randomize.yml]
         [--noise_mode host|device|device_mt19937] [--dtype f64|f32] [--graph]
 
 Same experiment file format, same loop: per episode a fresh MPCPolicy whose controller gets
@@ -43,8 +43,8 @@ def main():
         exp = yaml.safe_load(f)
     if exp["env_name"] not in ENVS:
         raise SystemExit("environment %r is not built (have: %s)" % (exp["env_name"], ", ".join(ENVS)))
-    if args.controller not in exp:
-        raise SystemExit("the config has no %r block" % args.controller)
+    if not isinstance(exp.get(args.controller), dict) or args.controller == "shared":
+        raise SystemExit("the config has no %r controller block" % args.controller)
     params = dict(exp[args.controller])
     num_cpu = params.pop("num_cpu", 1)
     if "particles_per_cpu" in params:

@@ -11,14 +11,14 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _short_config(tmp_path, name="reacher_7dof-v0.yml"):
-    with open(os.path.join(ROOT, "examples", "configs", name)) as f:
+def _short_config(tmp_path, env_name="reacher_7dof-v0"):
+    with open(os.path.join(ROOT, "examples", "configs", "reacher_gpu.yml")) as f:
         exp = yaml.safe_load(f)
-    exp["n_episodes"], exp["max_ep_length"] = 1, 6
+    exp["n_episodes"], exp["max_ep_length"], exp["env_name"] = 1, 6, env_name
     for block in exp.values():
         if isinstance(block, dict) and "particles_per_cpu" in block:
             block["num_cpu"], block["particles_per_cpu"] = 4, 16
-    p = tmp_path / name
+    p = tmp_path / "exp.yml"
     p.write_text(yaml.safe_dump(exp))
     return str(p)
 
@@ -26,7 +26,7 @@ def _short_config(tmp_path, name="reacher_7dof-v0.yml"):
 @pytest.mark.parametrize("controller,extra", [
     ("mppi", []), ("cem", ["--noise_mode", "device", "--graph"]), ("dmd", ["--noise_mode", "device"]),
     ("random_shooting", []), ("pfmpc", []),
-    ("mppi", ["--dyn_randomize_config", os.path.join(ROOT, "examples", "configs", "dyn_randomize_configs", "reacher_7dof-v0.yml")]),
+    ("mppi", ["--dyn_randomize_config", os.path.join(ROOT, "examples", "configs", "reacher_gpu_dyn_randomize.yml")]),
 ])
 def test_example_driver(tmp_path, controller, extra):
     cfg = _short_config(tmp_path)
@@ -37,7 +37,7 @@ def test_example_driver(tmp_path, controller, extra):
 
 
 def test_continual_config_parses(tmp_path):
-    cfg = _short_config(tmp_path, "continual_reacher-v0.yml")
+    cfg = _short_config(tmp_path, "continual_reacher-v0")
     out = subprocess.run([sys.executable, os.path.join(ROOT, "examples", "example_mpc.py"), "--config", cfg,
                           "--controller", "mppi", "--noise_mode", "device"], capture_output=True, text=True, timeout=300)
     assert out.returncode == 0, out.stderr[-2000:]
