@@ -47,3 +47,33 @@ def test_product_never_imports_oracle():
                 src = open(os.path.join(dp, f)).read()
                 assert "import oracle" not in src and "from oracle" not in src, f
                 assert "reacher_ref" not in src or f in ("raw.py",), f
+
+
+def test_argument_errors_are_codes_and_messages_not_crashes():
+    """Bad arguments are rejected before anything touches the GPU: non-zero return code + mjmpc_last_error()."""
+    import ctypes
+    lib = _lib.load()
+    bad = [
+        lambda: lib.mjmpc_arm_rollout(None, _lib.F64, 8, 4, None, None, None, None, None, None, None),
+        lambda: lib.mjmpc_arm_set_state(None, None, None, None, None),
+        lambda: lib.mjmpc_arm_solver_failures(None, None),
+        lambda: lib.mjmpc_analytic_rollout(0, None, 2, 1, None, _lib.F64, 8, 4, None, None, None, None, None, None, 0, None),
+        lambda: lib.mjmpc_softmax_stats(_lib.F64, 8, 4, 2, None, None, None, None, None, 0, 0.1, 1, 0, 0, None, None, None),
+        lambda: lib.mjmpc_td_lambda_returns(_lib.F64, 8, 4, 2, None, None, None, None, None, None, 0, 0.1, 1, 1.0, 1.0,
+                                            None, None, None),
+        lambda: lib.mjmpc_shift_mean(None, 4, 2, 0, None, None),
+        lambda: lib.mjmpc_cholesky_lower(None, 3, None, None, None),
+        lambda: lib.mjmpc_cov_add_diag(None, 3, None, 1.0, None),
+        lambda: lib.mjmpc_sample_noise(_lib.F64, None, 8, 4, 2, None, None, 1, 0, 0, None, 1, None),
+        lambda: lib.mjmpc_sample_noise_mt19937(_lib.F64, None, 64, 1.0, 1, None, None, None, None),
+        lambda: lib.mjmpc_sample_noise_mt19937_jump(_lib.F64, None, 64, 1.0, 1, None, None, None, 19968, 2000, 4, None,
+                                                    None, None),
+    ]
+    for call in bad:
+        rc = call()
+        assert rc != 0
+        assert len(lib.mjmpc_last_error()) > 0
+    h = ctypes.c_void_p()
+    assert lib.mjmpc_arm_create(None, 0, 0, ctypes.byref(h)) != 0          # no model blob
+    assert lib.mjmpc_arm_destroy(None) == 0                                 # destroying nothing is a no-op
+    assert lib.mjmpc_mt19937_stream_words(1000) > 4 * 500 / 0.79
