@@ -201,12 +201,27 @@ int mjmpc_rs_combine(const double* d_records, int G, int H, int A, double step_s
  * d_q0: float64[P] cost-to-go (NULL = the one mjmpc_traj_cost left in d_ws).  shift_mode: -1 none,
  * 0 'null', 1 'repeat'.  d_action_out (float64[A]), d_record ([xmax | S | W[H*A]], the softmax record
  * without its covariance block) and d_value (_calc_val, mppi.py:113-131) may be NULL.  For a captured
- * control iteration: h_action_mapped (device-visible pinned host memory, float64[A]) also receives the
- * action, and *d_step_counter (device int64) is incremented (the noise stream index of the next step). */
+ * control iteration: *d_step_counter (device int64) is incremented (the noise stream index of the next step),
+ * and h_action_mapped (device-visible pinned host memory, float64[A+1]) also receives the action followed by
+ * the new step count, written last behind a system-scope fence: a host polling entry [A] can read the action
+ * as soon as this kernel has produced it, while later work of the same stream is still running.            */
 int mjmpc_mppi_fused_update(int dtype, int64_t P, int H, int A, const double* d_q0, const void* d_actions, double lam,
                             double step_size, int shift_mode, double* d_mean, double* d_action_out, double* d_record,
                             double* d_value, double* h_action_mapped, int64_t* d_step_counter, void* d_ws,
                             void* stream);
+
+/* The same, and in the same two launches the RAW samples of the next control step are drawn into d_next_noise
+ * (dtype [P][H][A], unfiltered: mjmpc_arm_rollout_fused filters on the fly) - extra workgroups of the first
+ * launch, as mjmpc_sample_noise(dtype, d_next_noise, P, H, A, d_chol, NULL, seed, offset, particle_offset,
+ * d_step, chol_is_diagonal) would draw them.  The rollout that read d_next_noise has finished by then, and
+ * *d_step still holds the current step when it is read (the counter moves in the second launch), so `offset`
+ * is normally 1.  Saves the sampler's own launch on the critical path of a captured control iteration.     */
+int mjmpc_mppi_fused_update_draw_next(int dtype, int64_t P, int H, int A, const double* d_q0, const void* d_actions,
+                                      double lam, double step_size, int shift_mode, double* d_mean,
+                                      double* d_action_out, double* d_record, double* d_value, double* h_action_mapped,
+                                      int64_t* d_step_counter, void* d_ws, void* d_next_noise, const double* d_chol,
+                                      uint64_t seed, uint64_t offset, int64_t particle_offset, const int64_t* d_step,
+                                      int chol_is_diagonal, void* stream);
 
 /* sum of q0 over local particles (CEM / RandomShooting _calc_val: cem.py:107-112) -> d_out[0] */
 int mjmpc_q0_sum(int64_t P, int H, int A, double* d_out, void* d_ws, void* stream);

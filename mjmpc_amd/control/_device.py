@@ -194,21 +194,30 @@ class DeviceUpdater:
         return w
 
     def mppi_fused_update(self, q0, actions, lam, step_size, shift_mode, action_out, action_pinned=None,
-                          step_counter=None):
+                          step_counter=None, draw_next=None):
         """q0 (float64 [P], device) + actions -> mean update, action read-out and shift in two launches.
-        Sharded: the fused kernels only produce this GPU's record; one all-gather; then the combine."""
+        Sharded: the fused kernels only produce this GPU's record; one all-gather; then the combine.
+        ``draw_next`` = dict(seed, offset, particle_offset, d_step): the same launches also draw the next control
+        step's raw samples into the sampler's buffer (parameters as for ``sample_noise``, set up by its last call)."""
         P = q0.shape[0]
+
+        def fused(step, shift, mean_io, act, rec, pinned, counter):
+            args = [self.code(actions), P, self.H, self.A, _vp(q0), _vp(actions), float(lam), float(step), int(shift),
+                    _vp(mean_io), _vp(act), _vp(rec), None, _vp(pinned), _vp(counter), _vp(self.workspace(P))]
+            if draw_next is None:
+                _lib.check(self.lib.mjmpc_mppi_fused_update(*args, self.stream()))
+            else:
+                buf = self._rec[("noise", "f32" if actions.dtype == self.torch.float32 else "f64")]
+                _lib.check(self.lib.mjmpc_mppi_fused_update_draw_next(
+                    *args, _vp(buf), _vp(self._rec["chol"]), int(draw_next["seed"]) & (2 ** 64 - 1),
+                    int(draw_next["offset"]), int(draw_next["particle_offset"]), _vp(draw_next["d_step"]),
+                    self._rec["chol_diag"], self.stream()))
+
         if self.comm.world_size == 1:
-            _lib.check(self.lib.mjmpc_mppi_fused_update(self.code(actions), P, self.H, self.A, _vp(q0), _vp(actions),
-                                                        float(lam), float(step_size), int(shift_mode),
-                                                        _vp(self.mean), _vp(action_out), None, None,
-                                                        _vp(action_pinned), _vp(step_counter),
-                                                        _vp(self.workspace(P)), self.stream()))
+            fused(step_size, shift_mode, self.mean, action_out, None, action_pinned, step_counter)
             return
         rec = self.record("softmax", self.lib.mjmpc_softmax_record_len(self.H, self.A, 0))
-        _lib.check(self.lib.mjmpc_mppi_fused_update(self.code(actions), P, self.H, self.A, _vp(q0), _vp(actions),
-                                                    float(lam), 0.0, -1, _vp(self.mean), None, _vp(rec), None, None,
-                                                    None, _vp(self.workspace(P)), self.stream()))
+        fused(0.0, -1, self.mean, None, rec, None, None)
         recs = self.comm.all_gather(rec)
         G = recs.shape[0]
         _lib.check(self.lib.mjmpc_softmax_combine(_vp(recs), G, self.H, self.A, 0, float(lam), float(step_size), 0,
@@ -217,7 +226,7 @@ class DeviceUpdater:
         if action_out is not None:
             action_out.copy_(self.mean[0])
         if action_pinned is not None:
-            action_pinned.copy_(self.mean[0], non_blocking=True)
+            action_pinned[:self.A].copy_(self.mean[0], non_blocking=True)
         if step_counter is not None:
             step_counter.add_(1)
         if shift_mode >= 0:

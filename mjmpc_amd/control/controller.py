@@ -285,6 +285,7 @@ class OLGaussianMPC(Controller):
         self._graph_on = True
         self._graph_post = post_step
         self._graph = None
+        self._noise_valid = False
 
     def _graph_capable(self):
         return (self.noise_mode in ('device', 'device_mt19937') and getattr(self._rollout_fn, "accepts_device", False)
@@ -323,21 +324,34 @@ class OLGaussianMPC(Controller):
         """Host covariance for the sampler, or None when the covariance adapts on the device."""
         return self._cov_host if self._static_cov() else None
 
+    def _noise_ahead(self):
+        """Captured fused iterations with the Philox sampler draw the next step's samples inside the update."""
+        return self._graph_on and self.noise_mode == 'device' and self._fused_capable()
+
     def _device_iteration(self):
         """The control iteration without any host synchronisation (capturable)."""
         n_loc = self.local_particles
         if self._fused_capable():
             # noise (raw) -> rollout (filters the noise, emits the cost-to-go) -> update + action + shift
             coeffs = self.dev.record("coeffs", 3)
+            # In a captured iteration the sampler rides in the update's first launch: the raw samples of step k+1 are
+            # drawn (into the same buffer) once the rollout of step k no longer needs them - see _optimize_graphed
+            # for the first step.  Every iteration of one optimize() uses the same base seed (olgaussian_mpc.py:91).
+            ahead = self._noise_ahead()
             for it in range(self.n_iters):
-                raw = self._draw_raw(n_loc, 0)
+                raw = self.dev._rec[("noise", self.noise_dtype)] if ahead else self._draw_raw(n_loc, 0)
                 costs, actions, q0 = self._rollout_fn.fused(n_loc, self.horizon, self.dev.mean, raw, coeffs,
                                                             self.dev.gseq)
                 last = it == self.n_iters - 1
+                nxt = None
+                if ahead and last:
+                    nxt = dict(seed=self.seed_val, offset=1, particle_offset=self.dev.comm.rank * n_loc,
+                               d_step=self._step_dev)
                 self.dev.mppi_fused_update(q0, actions, self.lam, self.step_size,
                                            _SHIFT_MODES[self.base_action] if last else -1,
                                            self._action_dev if last else None,
-                                           self._action_pin if last else None, self._step_dev if last else None)
+                                           self._action_pin if last else None, self._step_dev if last else None,
+                                           draw_next=nxt)
             if self._graph_post is not None:
                 self._graph_post(self._action_dev)
             return
@@ -355,7 +369,7 @@ class OLGaussianMPC(Controller):
             traj = self._rollout_fn(n_loc, self.horizon, self.dev.mean, delta, mode="open_loop")
             self._device_update(traj)
         self._action_dev.copy_(self.dev.mean[0])
-        self._action_pin.copy_(self._action_dev, non_blocking=True)
+        self._action_pin[:self.d_action].copy_(self._action_dev, non_blocking=True)
         self.dev.shift(_SHIFT_MODES[self.base_action], None)
         self._device_shift_cov()
         self._step_dev.add_(1)
@@ -370,13 +384,16 @@ class OLGaussianMPC(Controller):
             self._step_dev = torch.full((1,), self.num_steps, dtype=torch.int64, device=self.dev.device)
             self._step_host = self.num_steps
             self._action_dev = torch.zeros(self.d_action, dtype=torch.float64, device=self.dev.device)
-            self._action_pin = torch.zeros(self.d_action, dtype=torch.float64).pin_memory()
+            self._action_pin = torch.zeros(self.d_action + 1, dtype=torch.float64).pin_memory()    # action | step flag
+            self._action_np = self._action_pin.numpy()
             # eager dry run on a side stream (allocates every buffer), with the state it must not consume
             keep = (self.dev.mean.clone(), self._step_dev.clone(), self.dev.cov.clone())
             side = torch.cuda.Stream(self.dev.device)
             side.wait_stream(torch.cuda.current_stream(self.dev.device))
             post, self._graph_post = self._graph_post, None
             with torch.cuda.stream(side):
+                if self._noise_ahead():
+                    self._draw_raw(self.local_particles, 0)     # buffer + sampler parameters for the dry run
                 self._device_iteration()
             torch.cuda.current_stream(self.dev.device).wait_stream(side)
             torch.cuda.synchronize(self.dev.device)
@@ -384,6 +401,7 @@ class OLGaussianMPC(Controller):
             self.dev.mean.copy_(keep[0])
             self._step_dev.copy_(keep[1])
             self.dev.cov.copy_(keep[2])
+            self._noise_valid = False       # the dry run left the samples of step + 1 behind
             try:
                 g = torch.cuda.CUDAGraph()
                 with torch.cuda.graph(g):
@@ -401,15 +419,37 @@ class OLGaussianMPC(Controller):
                 return self._optimize_eager_after_fallback(state)
         if self._step_host != self.num_steps:
             self._step_dev.fill_(self.num_steps)
+            self._noise_valid = False
+        if self._noise_ahead() and not self._noise_valid:
+            self._draw_raw(self.local_particles, 0)             # the current step's samples (first step / after a jump)
+            self._noise_valid = True
+        self._action_np[self.d_action] = -1.0               # completion flag (see _wait_action)
         self._graph.replay()
-        torch.cuda.current_stream(self.dev.device).synchronize()
-        action = self._action_pin.numpy().copy()
+        action = self._wait_action()
         self.num_steps += 1
         self._step_host = self.num_steps
         self._mean_stale = True
         if not self._static_cov():
             self._cov_stale = True
         return action, 0.0
+
+    def _wait_action(self):
+        """The action of the replayed iteration.  The fused update writes it into mapped pinned memory followed by
+        the new step count; polling that flag returns the action as soon as it exists, while the rest of the
+        graph (e.g. the captured env step) is still running - the next replay is enqueued behind it, so the GPU
+        never waits for the host round trip.  Other update paths: one stream synchronisation."""
+        A = self.d_action
+        if not (self._fused_capable() and self.dev.comm.world_size == 1):
+            self.dev.torch.cuda.current_stream(self.dev.device).synchronize()
+            return self._action_np[:A].copy()
+        flag, want, spins = self._action_np, float(self.num_steps + 1), 0
+        while flag[A] != want:
+            spins += 1
+            if spins > 2000000:                         # ~1 s without an answer: let the runtime report what happened
+                self.dev.torch.cuda.current_stream(self.dev.device).synchronize()
+                if flag[A] != want:
+                    raise RuntimeError("captured control iteration finished without publishing its action")
+        return flag[:A].copy()
 
     def _optimize_eager_after_fallback(self, state):
         action, value = Controller.optimize(self, state, False, True)

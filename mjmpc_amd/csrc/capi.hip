@@ -436,20 +436,41 @@ int mjmpc_rs_combine(const double* d_records, int G, int H, int A, double step_s
     PLAIN(mjmpc::rs_combine(d_records, G, H, A, step_size, d_mean, (hipStream_t)stream));
 }
 
-int mjmpc_mppi_fused_update(int dtype, int64_t P, int H, int A, const double* d_q0, const void* d_actions, double lam,
-                            double step_size, int shift_mode, double* d_mean, double* d_action_out, double* d_record,
-                            double* d_value, double* h_action_mapped, int64_t* d_step_counter, void* d_ws,
-                            void* stream) {
+static int fused_update(int dtype, int64_t P, int H, int A, const double* d_q0, const void* d_actions, double lam,
+                        double step_size, int shift_mode, double* d_mean, double* d_action_out, double* d_record,
+                        double* d_value, double* h_action_mapped, int64_t* d_step_counter, void* d_ws, void* stream,
+                        const mjmpc::NextNoise* next) {
     if (!d_actions || !d_mean || !d_ws) return fail(MJMPC_E_BADARG, "null argument");
     if (!(lam > 0) || shift_mode > 1) return fail(MJMPC_E_BADARG, "bad lam / shift_mode");
     hipStream_t s = (hipStream_t)stream;
     DISPATCH(dtype,
              mjmpc::mppi_fused_update<float>(d_q0, (const float*)d_actions, lam, step_size, shift_mode, (long)P, H, A,
                                              d_mean, d_action_out, d_record, d_value, (double*)d_ws, s, h_action_mapped,
-                                             (long long*)d_step_counter),
+                                             (long long*)d_step_counter, next),
              mjmpc::mppi_fused_update<double>(d_q0, (const double*)d_actions, lam, step_size, shift_mode, (long)P, H, A,
                                               d_mean, d_action_out, d_record, d_value, (double*)d_ws, s,
-                                              h_action_mapped, (long long*)d_step_counter));
+                                              h_action_mapped, (long long*)d_step_counter, next));
+}
+
+int mjmpc_mppi_fused_update(int dtype, int64_t P, int H, int A, const double* d_q0, const void* d_actions, double lam,
+                            double step_size, int shift_mode, double* d_mean, double* d_action_out, double* d_record,
+                            double* d_value, double* h_action_mapped, int64_t* d_step_counter, void* d_ws,
+                            void* stream) {
+    return fused_update(dtype, P, H, A, d_q0, d_actions, lam, step_size, shift_mode, d_mean, d_action_out, d_record,
+                        d_value, h_action_mapped, d_step_counter, d_ws, stream, nullptr);
+}
+
+int mjmpc_mppi_fused_update_draw_next(int dtype, int64_t P, int H, int A, const double* d_q0, const void* d_actions,
+                                      double lam, double step_size, int shift_mode, double* d_mean,
+                                      double* d_action_out, double* d_record, double* d_value, double* h_action_mapped,
+                                      int64_t* d_step_counter, void* d_ws, void* d_next_noise, const double* d_chol,
+                                      uint64_t seed, uint64_t offset, int64_t particle_offset, const int64_t* d_step,
+                                      int chol_is_diagonal, void* stream) {
+    if (!d_next_noise || !d_chol) return fail(MJMPC_E_BADARG, "null noise buffer or Cholesky factor");
+    mjmpc::NextNoise nn{d_next_noise, d_chol, seed, offset, (long)particle_offset, (const long long*)d_step,
+                        chol_is_diagonal};
+    return fused_update(dtype, P, H, A, d_q0, d_actions, lam, step_size, shift_mode, d_mean, d_action_out, d_record,
+                        d_value, h_action_mapped, d_step_counter, d_ws, stream, &nn);
 }
 
 int mjmpc_q0_sum(int64_t P, int H, int A, double* d_out, void* d_ws, void* stream) {

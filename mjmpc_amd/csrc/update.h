@@ -1,6 +1,8 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include "noise_device.h"
+
 namespace mjmpc {
 
 // Workspace (in doubles) the update launchers need for P particles, horizon H, action dim A.
@@ -44,11 +46,13 @@ hipError_t rs_best(const T* actions, long offset, long P, int H, int A, double* 
 hipError_t rs_combine(const double* records, int G, int H, int A, double step, double* mean, hipStream_t s);
 
 // Fused MPPI update (weights per particle, control cost off): q0 -> mean, action, shift in two launches.
-// q0 == nullptr: use the cost-to-go traj_cost left in the workspace.
+// q0 == nullptr: use the cost-to-go traj_cost left in the workspace.  next: also draw the raw samples of the next
+// control step (extra workgroups of the first launch).
 template <typename T>
 hipError_t mppi_fused_update(const double* q0, const T* actions, double lam, double step, int shift_mode, long P, int H,
                              int A, double* mean, double* action_out, double* record, double* value, double* ws,
-                             hipStream_t s, double* action_host = nullptr, long long* step_counter = nullptr);
+                             hipStream_t s, double* action_host = nullptr, long long* step_counter = nullptr,
+                             const NextNoise* next = nullptr);
 
 hipError_t q0_sum(long P, int H, int A, double* out, double* ws, hipStream_t s);
 hipError_t shift_mean(double* mean, int H, int A, int mode, const double* row, hipStream_t s);

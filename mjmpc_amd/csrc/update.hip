@@ -12,6 +12,7 @@
 // atomics on floating point, so results are bit-reproducible run to run and identical on all ranks.
 #include <hip/hip_runtime.h>
 
+#include "noise_device.h"
 #include "update.h"
 
 namespace mjmpc {
@@ -572,11 +573,15 @@ __device__ __forceinline__ double wave_sum(double v) {
 // partial[b] = { m_b, S_b, W_b[H*A] } with weights exp(x_p - m_b), x_p = -q0_p / lam
 template <typename T>
 __global__ void fused_partial_kernel(const double* __restrict__ q0, const T* __restrict__ actions, double lam, long P,
-                                     int HA, double* __restrict__ partial) {
+                                     int HA, double* __restrict__ partial, const long long* __restrict__ d_step,
+                                     long long* __restrict__ step_snapshot) {
     __shared__ double e_s[FCH];
     const long p0 = (long)blockIdx.x * FCH;
     const int n = (int)((P - p0) < FCH ? (P - p0) : FCH);
     double* out = partial + (long)blockIdx.x * (2 + HA);
+    // the step this iteration belongs to, for the sampler workgroups of the NEXT launch (which runs while that
+    // launch's first workgroup advances the counter)
+    if (step_snapshot && blockIdx.x == 0 && threadIdx.x == 0) *step_snapshot = d_step ? *d_step : 0;
     if (threadIdx.x < 64) {
         const double x = threadIdx.x < n ? (-1.0 / lam) * q0[p0 + threadIdx.x] : -INFINITY;
         const double m = wave_max(x);
@@ -587,8 +592,17 @@ __global__ void fused_partial_kernel(const double* __restrict__ q0, const T* __r
     }
     __syncthreads();
     for (int j = threadIdx.x; j < HA; j += blockDim.x) {
+        // eight loads in flight per lane; the summation order over particles stays 0, 1, 2, ...
         double acc = 0.0;
-        for (int p = 0; p < n; ++p) acc += e_s[p] * (double)actions[(p0 + p) * HA + j];
+        int p = 0;
+        for (; p + 8 <= n; p += 8) {
+            double v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = (double)actions[(p0 + p + u) * HA + j];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) acc += e_s[p + u] * v[u];
+        }
+        for (; p < n; ++p) acc += e_s[p] * (double)actions[(p0 + p) * HA + j];
         out[2 + j] = acc;
     }
 }
@@ -596,15 +610,26 @@ __global__ void fused_partial_kernel(const double* __restrict__ q0, const T* __r
 // merge partials -> mean update (mppi.py:69-82) -> action = mean[0] (olgaussian_mpc.py:71) -> shift
 // (olgaussian_mpc.py:116-129; shift_mode < 0: no shift).  Optionally leaves the GPU record
 // [xmax | S | W] for the multi-GPU combine and the value -lam logsumexp (mppi.py:113-131).
+// Workgroups past the first belong to a different job riding in the same launch: they draw the raw samples of the
+// NEXT control step (the noise buffer is free once the rollout has finished).  Workgroup 0 publishes the action
+// first, so the sampler runs in the shadow of the host's round trip instead of on the critical path.
+template <typename T>
 __global__ void fused_final_kernel(const double* __restrict__ partial, int nb, int H, int A, double lam, double step,
                                    int shift_mode, double P_total, double* __restrict__ mean,
                                    double* __restrict__ action_out, double* __restrict__ record,
                                    double* __restrict__ value, double* __restrict__ action_host,
-                                   long long* __restrict__ step_counter) {
-    extern __shared__ double sh[];          // sc[nb] | nm[H*A] | red[4]
+                                   long long* __restrict__ step_counter, NextNoise nn, long P,
+                                   const long long* __restrict__ step_snapshot) {
+    if (blockIdx.x > 0) {
+        noise_element<T>((T*)nn.noise, ((long)blockIdx.x - 1) * blockDim.x + threadIdx.x, P, H, A, nn.chol, nn.seed,
+                         nn.offset + (unsigned long long)*step_snapshot, nn.particle_offset, nn.diag_only);
+        return;
+    }
+    extern __shared__ double sh[];          // sc[nb] | ss[nb] | nm[H*A] | red[4]
     const int HA = H * A, rec = 2 + HA;
     double* sc = sh;
-    double* nm = sh + nb;
+    double* ss = sh + nb;
+    double* nm = ss + nb;
     double* red = nm + HA;
     double m = -INFINITY;
     for (int b = threadIdx.x; b < nb; b += blockDim.x) m = fmax(m, partial[(long)b * rec]);
@@ -612,13 +637,24 @@ __global__ void fused_final_kernel(const double* __restrict__ partial, int nb, i
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
     __syncthreads();
     const double M = fmax(fmax(red[0], red[1]), fmax(red[2], red[3]));
-    for (int b = threadIdx.x; b < nb; b += blockDim.x) sc[b] = exp(partial[(long)b * rec] - M);
+    for (int b = threadIdx.x; b < nb; b += blockDim.x) {
+        sc[b] = exp(partial[(long)b * rec] - M);
+        ss[b] = partial[(long)b * rec + 1];
+    }
     __syncthreads();
     double S = 0.0;
-    for (int b = 0; b < nb; ++b) S += sc[b] * partial[(long)b * rec + 1];      // every thread, same order
+    for (int b = 0; b < nb; ++b) S += sc[b] * ss[b];                            // every thread, same order
     for (int j = threadIdx.x; j < HA; j += blockDim.x) {
         double W = 0.0;
-        for (int b = 0; b < nb; ++b) W += sc[b] * partial[(long)b * rec + 2 + j];
+        int b = 0;
+        for (; b + 8 <= nb; b += 8) {                   // eight loads in flight; same order of summation
+            double v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = partial[(long)(b + u) * rec + 2 + j];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) W += sc[b + u] * v[u];
+        }
+        for (; b < nb; ++b) W += sc[b] * partial[(long)b * rec + 2 + j];
         if (record) record[2 + j] = W;
         nm[j] = (1.0 - step) * mean[j] + step * (W / S);
     }
@@ -628,8 +664,21 @@ __global__ void fused_final_kernel(const double* __restrict__ partial, int nb, i
     }
     __syncthreads();
     if (action_out && threadIdx.x < A) action_out[threadIdx.x] = nm[threadIdx.x];
-    if (action_host && threadIdx.x < A) action_host[threadIdx.x] = nm[threadIdx.x];   // mapped pinned host memory
-    if (step_counter && threadIdx.x == 0) *step_counter += 1;                         // noise stream of the next step
+    // mapped pinned host memory: the action, then - once every lane's write is visible system-wide - the new step
+    // count as a completion flag, so that the host can pick the action up without waiting for the stream to drain
+    if (action_host && threadIdx.x < A) {
+        action_host[threadIdx.x] = nm[threadIdx.x];
+        __threadfence_system();
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        long long count = 0;
+        if (step_counter) count = (*step_counter += 1);                               // noise stream of the next step
+        if (action_host) {
+            action_host[A] = (double)count;
+            __threadfence_system();
+        }
+    }
     for (int j = threadIdx.x; j < HA; j += blockDim.x) {
         double v = nm[j];
         if (shift_mode >= 0) {
@@ -792,13 +841,23 @@ hipError_t rs_combine(const double* records, int G, int H, int A, double step, d
 template <typename T>
 hipError_t mppi_fused_update(const double* q0, const T* actions, double lam, double step, int shift_mode, long P, int H,
                              int A, double* mean, double* action_out, double* record, double* value, double* ws,
-                             hipStream_t s, double* action_host, long long* step_counter) {
+                             hipStream_t s, double* action_host, long long* step_counter, const NextNoise* next) {
     Ws w(ws, P, H, A);
     const int nb = nblocks(P, FCH), HA = H * A;
     if (!q0) q0 = w.q0;
-    hipLaunchKernelGGL(fused_partial_kernel<T>, dim3(nb), dim3(BLK), 0, s, q0, actions, lam, P, HA, w.partial);
-    hipLaunchKernelGGL(fused_final_kernel, dim3(1), dim3(BLK), sizeof(double) * (nb + HA + 4), s, w.partial, nb, H, A, lam,
-                       step, shift_mode, (double)P, mean, action_out, record, value, action_host, step_counter);
+    NextNoise nn{};
+    int extra = 0;
+    long long* snap = nullptr;
+    if (next && next->noise) {
+        nn = *next;
+        extra = nblocks(P * ((H + 1) / 2) * A, BLK);
+        snap = (long long*)(w.scratch + 8);
+    }
+    hipLaunchKernelGGL(fused_partial_kernel<T>, dim3(nb), dim3(BLK), 0, s, q0, actions, lam, P, HA, w.partial, nn.d_step,
+                       snap);
+    hipLaunchKernelGGL(fused_final_kernel<T>, dim3(1 + extra), dim3(BLK), sizeof(double) * (2 * nb + HA + 4), s, w.partial, nb,
+                       H, A, lam, step, shift_mode, (double)P, mean, action_out, record, value, action_host, step_counter,
+                       nn, P, (const long long*)snap);
     return hipGetLastError();
 }
 
@@ -840,7 +899,8 @@ hipError_t shift_mean(double* mean, int H, int A, int mode, const double* row, h
                                          double*, hipStream_t);                                                      \
     template hipError_t rs_best<T>(const T*, long, long, int, int, double*, double*, hipStream_t);                   \
     template hipError_t mppi_fused_update<T>(const double*, const T*, double, double, int, long, int, int, double*,  \
-                                             double*, double*, double*, double*, hipStream_t, double*, long long*);
+                                             double*, double*, double*, double*, hipStream_t, double*, long long*,   \
+                                             const NextNoise*);
 INST(float)
 INST(double)
 
