@@ -223,6 +223,14 @@ int mjmpc_mppi_fused_update_draw_next(int dtype, int64_t P, int H, int A, const 
                                       uint64_t seed, uint64_t offset, int64_t particle_offset, const int64_t* d_step,
                                       int chol_is_diagonal, void* stream);
 
+/* Sharded MPPI: the G all-gathered records d_records (float64 [G][2 + H*A], as left in d_record by
+ * mjmpc_mppi_fused_update with step_size 0, shift_mode -1) merged in rank order -> mean update, action read-out,
+ * shift, step counter and the mapped host copy with its completion flag, exactly as the single-GPU call does
+ * (P_total = particles over all ranks; every rank computes the bit-identical result).                      */
+int mjmpc_mppi_fused_combine(const double* d_records, int G, double P_total, int H, int A, double lam, double step_size,
+                             int shift_mode, double* d_mean, double* d_action_out, double* d_value,
+                             double* h_action_mapped, int64_t* d_step_counter, void* stream);
+
 /* sum of q0 over local particles (CEM / RandomShooting _calc_val: cem.py:107-112) -> d_out[0] */
 int mjmpc_q0_sum(int64_t P, int H, int A, double* d_out, void* d_ws, void* stream);
 

@@ -52,6 +52,7 @@ SIGNATURES = {
     "mjmpc_rs_combine": (_int, [_vp, _int, _int, _int, _dbl, _vp, _vp]),
     "mjmpc_mppi_fused_update": (_int, [_int, _i64, _int, _int, _vp, _vp, _dbl, _dbl, _int, _vp, _vp, _vp, _vp, _vp, _vp,
                                         _vp, _vp]),
+    "mjmpc_mppi_fused_combine": (_int, [_vp, _int, _dbl, _int, _int, _dbl, _dbl, _int, _vp, _vp, _vp, _vp, _vp, _vp]),
     "mjmpc_mppi_fused_update_draw_next": (_int, [_int, _i64, _int, _int, _vp, _vp, _dbl, _dbl, _int, _vp, _vp, _vp, _vp,
                                                    _vp, _vp, _vp, _vp, _vp, ctypes.c_uint64, ctypes.c_uint64, _i64, _vp,
                                                    _int, _vp]),

@@ -216,21 +216,14 @@ class DeviceUpdater:
         if self.comm.world_size == 1:
             fused(step_size, shift_mode, self.mean, action_out, None, action_pinned, step_counter)
             return
-        rec = self.record("softmax", self.lib.mjmpc_softmax_record_len(self.H, self.A, 0))
+        rec = self.record("fused_rec", 2 + self.H * self.A)        # [xmax | S | W[H*A]]: the layout of a partial
         fused(0.0, -1, self.mean, None, rec, None, None)
         recs = self.comm.all_gather(rec)
         G = recs.shape[0]
-        _lib.check(self.lib.mjmpc_softmax_combine(_vp(recs), G, self.H, self.A, 0, float(lam), float(step_size), 0,
-                                                  float(P * G), _vp(self.mean), None, None, _vp(self.wnorm),
-                                                  self.stream()))
-        if action_out is not None:
-            action_out.copy_(self.mean[0])
-        if action_pinned is not None:
-            action_pinned[:self.A].copy_(self.mean[0], non_blocking=True)
-        if step_counter is not None:
-            step_counter.add_(1)
-        if shift_mode >= 0:
-            self.shift(shift_mode)
+        _lib.check(self.lib.mjmpc_mppi_fused_combine(_vp(recs), G, float(P * G), self.H, self.A, float(lam),
+                                                     float(step_size), int(shift_mode), _vp(self.mean),
+                                                     _vp(action_out), None, _vp(action_pinned), _vp(step_counter),
+                                                     self.stream()))
 
     # ------------------------------------------------------------------ CEM
     def cem_update(self, costs, actions, num_elite, step_size, full_cov):

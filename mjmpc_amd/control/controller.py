@@ -437,9 +437,10 @@ class OLGaussianMPC(Controller):
         """The action of the replayed iteration.  The fused update writes it into mapped pinned memory followed by
         the new step count; polling that flag returns the action as soon as it exists, while the rest of the
         graph (e.g. the captured env step) is still running - the next replay is enqueued behind it, so the GPU
-        never waits for the host round trip.  Other update paths: one stream synchronisation."""
+        never waits for the host round trip.  (Sharded runs publish from the combine kernel after the all-gather.)
+        Other update paths: one stream synchronisation."""
         A = self.d_action
-        if not (self._fused_capable() and self.dev.comm.world_size == 1):
+        if not self._fused_capable():
             self.dev.torch.cuda.current_stream(self.dev.device).synchronize()
             return self._action_np[:A].copy()
         flag, want, spins = self._action_np, float(self.num_steps + 1), 0

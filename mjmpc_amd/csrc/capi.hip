@@ -473,6 +473,15 @@ int mjmpc_mppi_fused_update_draw_next(int dtype, int64_t P, int H, int A, const 
                         d_value, h_action_mapped, d_step_counter, d_ws, stream, &nn);
 }
 
+int mjmpc_mppi_fused_combine(const double* d_records, int G, double P_total, int H, int A, double lam, double step_size,
+                             int shift_mode, double* d_mean, double* d_action_out, double* d_value,
+                             double* h_action_mapped, int64_t* d_step_counter, void* stream) {
+    if (!d_records || !d_mean || G < 1) return fail(MJMPC_E_BADARG, "null argument");
+    if (!(lam > 0) || shift_mode > 1) return fail(MJMPC_E_BADARG, "bad lam / shift_mode");
+    PLAIN(mjmpc::mppi_fused_combine(d_records, G, P_total, lam, step_size, shift_mode, H, A, d_mean, d_action_out, d_value,
+                                    h_action_mapped, (long long*)d_step_counter, (hipStream_t)stream));
+}
+
 int mjmpc_q0_sum(int64_t P, int H, int A, double* d_out, void* d_ws, void* stream) {
     if (!d_out || !d_ws) return fail(MJMPC_E_BADARG, "null argument");
     PLAIN(mjmpc::q0_sum((long)P, H, A, d_out, (double*)d_ws, (hipStream_t)stream));

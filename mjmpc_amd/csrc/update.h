@@ -54,6 +54,11 @@ hipError_t mppi_fused_update(const double* q0, const T* actions, double lam, dou
                              hipStream_t s, double* action_host = nullptr, long long* step_counter = nullptr,
                              const NextNoise* next = nullptr);
 
+// the all-gathered records of G GPUs -> mean, action (device + mapped host copy with completion flag), step counter, shift
+hipError_t mppi_fused_combine(const double* records, int G, double P_total, double lam, double step, int shift_mode,
+                              int H, int A, double* mean, double* action_out, double* value, double* action_host,
+                              long long* step_counter, hipStream_t s);
+
 hipError_t q0_sum(long P, int H, int A, double* out, double* ws, hipStream_t s);
 hipError_t shift_mean(double* mean, int H, int A, int mode, const double* row, hipStream_t s);
 // lower Cholesky factor of a device-resident covariance (A <= 64); cov += scale * diag(d) (d null: identity)

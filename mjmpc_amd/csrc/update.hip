@@ -861,6 +861,19 @@ hipError_t mppi_fused_update(const double* q0, const T* actions, double lam, dou
     return hipGetLastError();
 }
 
+// Sharded runs: the G all-gathered records [xmax | S | W[H*A]] have the layout of the per-workgroup partials, so
+// the same kernel merges them (rank order = fixed order -> bit-identical on every rank), updates the mean, reads
+// out and publishes the action, advances the step counter and shifts - one launch after the all-gather.
+hipError_t mppi_fused_combine(const double* records, int G, double P_total, double lam, double step, int shift_mode,
+                              int H, int A, double* mean, double* action_out, double* value, double* action_host,
+                              long long* step_counter, hipStream_t s) {
+    const int HA = H * A;
+    hipLaunchKernelGGL(fused_final_kernel<double>, dim3(1), dim3(BLK), sizeof(double) * (2 * G + HA + 4), s, records, G, H,
+                       A, lam, step, shift_mode, P_total, mean, action_out, (double*)nullptr, value, action_host,
+                       step_counter, NextNoise{}, 0L, (const long long*)nullptr);
+    return hipGetLastError();
+}
+
 hipError_t q0_sum(long P, int H, int A, double* out, double* ws, hipStream_t s) {
     Ws w(ws, P, H, A);
     hipLaunchKernelGGL(mean_value_kernel, dim3(1), dim3(BLK), 0, s, w.q0, P, out);

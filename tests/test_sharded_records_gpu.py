@@ -108,3 +108,40 @@ def test_cem_and_rs_records_combine(problem, G):
                                      "full" if full else "diagonal")
         np.testing.assert_allclose(d.get_mean(), m_ref, rtol=1e-12, atol=1e-12)
         np.testing.assert_allclose(d.get_cov(), c_ref, rtol=1e-11, atol=1e-12)
+
+
+@pytest.mark.parametrize("G", [2, 3, 4])
+def test_fused_mppi_records_and_single_kernel_combine(problem, G):
+    """The fused MPPI path sharded: per-shard records [xmax | S | W] from mjmpc_mppi_fused_update (record mode),
+    stacked as the all-gather delivers them, merged by mjmpc_mppi_fused_combine (mean update, action, mapped host
+    copy + completion flag, step counter, shift in one launch) = the unsharded MPPI update + shift."""
+    import torch
+    from mjmpc_amd import _lib
+    from mjmpc_amd.control._device import DeviceUpdater
+    pr = problem
+    P, H, A = pr["P"], pr["H"], pr["A"]
+    lam, step = 0.08, 0.6
+    n = P // G
+    q0 = cr.cost_to_go(pr["costs"].copy(), pr["gs"])[:, 0]
+    devs = [DeviceUpdater(H, A, pr["gs"]) for _ in range(G)]
+    lib = devs[0].lib
+    recs = torch.empty((G, 2 + H * A), dtype=torch.float64, device="cuda")
+    for g, d in enumerate(devs):
+        d.set_mean(pr["mean"])
+        q = torch.from_numpy(q0[g * n:(g + 1) * n].copy()).cuda()
+        a = torch.from_numpy(pr["actions"][g * n:(g + 1) * n].copy()).cuda()
+        _lib.check(lib.mjmpc_mppi_fused_update(_lib.F64, n, H, A, _vp(q), _vp(a), lam, 0.0, -1, _vp(d.mean), None,
+                                               _vp(recs[g]), None, None, None, _vp(d.workspace(n)), d.stream()))
+        np.testing.assert_array_equal(d.get_mean(), pr["mean"])              # record mode leaves the mean alone
+    d0 = devs[0]
+    act = torch.zeros(A, dtype=torch.float64, device="cuda")
+    pinned = torch.zeros(A + 1, dtype=torch.float64).pin_memory()
+    counter = torch.full((1,), 41, dtype=torch.int64, device="cuda")
+    _lib.check(lib.mjmpc_mppi_fused_combine(_vp(recs), G, float(P), H, A, lam, step, 1, _vp(d0.mean), _vp(act), None,
+                                            _vp(pinned), _vp(counter), d0.stream()))
+    torch.cuda.synchronize()
+    m1 = cr.mppi_update(pr["costs"], pr["actions"], pr["mean"], pr["cov"], pr["gs"], lam, 1, step)
+    np.testing.assert_allclose(act.cpu().numpy(), m1[0], rtol=1e-12, atol=1e-12)
+    np.testing.assert_allclose(pinned.numpy()[:A], m1[0], rtol=1e-12, atol=1e-12)
+    assert pinned.numpy()[A] == 42.0 and int(counter.item()) == 42          # completion flag = the new step count
+    np.testing.assert_allclose(d0.get_mean(), cr.shift_mean(m1, "repeat"), rtol=1e-12, atol=1e-12)
