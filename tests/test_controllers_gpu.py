@@ -294,10 +294,11 @@ def test_adapting_covariance_stays_on_the_device_and_graph_matches_eager(raw_arm
         np.testing.assert_allclose(m, m_e, rtol=1e-9, atol=1e-10)
 
 
-@pytest.mark.parametrize("P_,k_frac", [(1000, 0.1), (16384, 0.1), (777, 0.5), (64, 1.0)])
+@pytest.mark.parametrize("P_,k_frac", [(1000, 0.1), (16384, 0.1), (777, 0.5), (64, 1.0), (20000, 0.1), (40000, 0.05)])
 def test_cem_elite_selection_with_ties_negative_costs_and_large_populations(P_, k_frac):
     """The radix select behind CEM's elite set: heavy ties across the threshold (broken by particle index),
-    negative and zero costs, populations up to the BASELINE CEM configuration (16 384)."""
+    negative and zero costs, populations up to and beyond the BASELINE CEM configuration (16 384): the three
+    instantiations of the select kernel (16 or 32 keys per thread in registers, or streamed from memory)."""
     from mjmpc_amd.control import CEM
     rs = np.random.RandomState(P_)
     Hh, Aa = 6, 3
