@@ -266,12 +266,16 @@ int mjmpc_sample_noise_mt19937(int dtype, void* d_noise, int64_t n_normals, doub
  * head_words + g*seg_words.  d_jump_idx / d_jump_starts[n_segments+1] (device int32) hold the set-bit lists
  * of t^(head_words + g*seg_words) mod phi, g >= 1 (entry 0 empty), as computed by
  * mjmpc_amd/control/mt_jump.py; the segments must cover mjmpc_mt19937_stream_words(n_normals) words.
- * n_segments == 0 behaves as mjmpc_sample_noise_mt19937.  Output is bit-identical for any segmentation.  */
+ * n_segments == 0 behaves as mjmpc_sample_noise_mt19937.  Output is bit-identical for any segmentation.
+ * first_normal > 0 (particle sharding): d_noise[0..n_normals) receives normals [first_normal, first_normal +
+ * n_normals) of the one global stream - the polar method's rejections make positions data dependent, so a rank
+ * regenerates the stream up to the end of its block; workspace, segments and stream_words are then those of
+ * first_normal + n_normals.                                                                                   */
 int64_t mjmpc_mt19937_stream_words(int64_t n_normals);
 int mjmpc_sample_noise_mt19937_jump(int dtype, void* d_noise, int64_t n_normals, double scale, uint64_t seed,
                                     const int64_t* d_step, const int32_t* d_jump_idx, const int32_t* d_jump_starts,
-                                    int64_t head_words, int64_t seg_words, int n_segments, void* d_ws, int* d_status,
-                                    void* stream);
+                                    int64_t head_words, int64_t seg_words, int n_segments, int64_t first_normal,
+                                    void* d_ws, int* d_status, void* stream);
 
 /* control_utils.generate_noise (mjmpc/utils/control_utils.py:24-34), performance mode: Philox
  * normals coloured by the lower Cholesky factor d_chol (float64 [A][A]) and filtered in place with

@@ -65,7 +65,7 @@ SIGNATURES = {
     "mjmpc_sample_noise_mt19937": (_int, [_int, _vp, _i64, _dbl, ctypes.c_uint64, _vp, _vp, _vp, _vp]),
     "mjmpc_mt19937_stream_words": (_i64, [_i64]),
     "mjmpc_sample_noise_mt19937_jump": (_int, [_int, _vp, _i64, _dbl, ctypes.c_uint64, _vp, _vp, _vp, _i64, _i64, _int,
-                                                 _vp, _vp, _vp]),
+                                                 _i64, _vp, _vp, _vp]),
     "mjmpc_sample_noise": (_int, [_int, _vp, _i64, _int, _int, _vp, _vp, ctypes.c_uint64, ctypes.c_uint64, _i64, _vp, _int, _vp]),
 }
 

@@ -300,9 +300,12 @@ class DeviceUpdater:
                 self._rec["cov_diag_host"] = diag.copy()
         _lib.check(self.lib.mjmpc_cov_add_diag(_vp(self.cov), self.A, _vp(d), float(scale), self.stream()))
 
-    def sample_noise_mt19937(self, P, cov, filter_coeffs, seed, offset, dtype="f64", d_step=None, filtered=True):
+    def sample_noise_mt19937(self, P, cov, filter_coeffs, seed, offset, dtype="f64", d_step=None, filtered=True,
+                             particle_offset=0):
         """The reference's own noise (legacy numpy stream of ``np.random.seed(seed + offset)``) regenerated
-        on the device; isotropic covariance only.  Returns the (P,H,A) tensor, filtered unless told not to."""
+        on the device; isotropic covariance only.  Returns the (P,H,A) tensor, filtered unless told not to.
+        ``particle_offset``: global index of local particle 0 - a rank of a sharded run keeps its own block of the
+        one stream (and regenerates the stream up to the end of that block: rejections make positions data dependent)."""
         torch = self.torch
         cov = np.asarray(cov, np.float64)
         c = float(cov[0, 0])
@@ -312,13 +315,15 @@ class DeviceUpdater:
         key = ("noise_mt", dtype)
         buf = self._rec.get(key)
         n = P * self.H * self.A
-        if buf is None or tuple(buf.shape) != (P, self.H, self.A):
+        first = int(particle_offset) * self.H * self.A
+        if buf is None or tuple(buf.shape) != (P, self.H, self.A) or self._rec.get("mt_first") != first:
             buf = self._rec[key] = torch.empty((P, self.H, self.A), dtype=tdt, device=self.device)
-            nbytes = self.lib.mjmpc_mt19937_workspace_bytes(n)
+            self._rec["mt_first"] = first
+            nbytes = self.lib.mjmpc_mt19937_workspace_bytes(first + n)
             self._rec["mt_ws"] = torch.empty((nbytes + 15) // 16 * 2, dtype=torch.float64, device=self.device)
             self._rec["mt_status"] = torch.zeros(1, dtype=torch.int32, device=self.device)
             # jump-ahead plan: serial head + MT_SEGMENTS workgroups (tables are host-computed once per size)
-            head, seg, nseg = mt_jump.plan_segments(int(self.lib.mjmpc_mt19937_stream_words(n)), self.mt_segments)
+            head, seg, nseg = mt_jump.plan_segments(int(self.lib.mjmpc_mt19937_stream_words(first + n)), self.mt_segments)
             if nseg:
                 idx, starts = mt_jump.jump_tables(seg, nseg, head)
                 self._rec["mt_jump"] = (torch.from_numpy(idx.copy()).to(self.device),
@@ -334,7 +339,7 @@ class DeviceUpdater:
         jidx, jstarts, head, seg, nseg = self._rec["mt_jump"]
         _lib.check(self.lib.mjmpc_sample_noise_mt19937_jump(
             _lib.F32 if dtype == "f32" else _lib.F64, _vp(buf), n, float(np.sqrt(c)),
-            (int(seed) + int(offset)) & (2 ** 64 - 1), _vp(d_step), _vp(jidx), _vp(jstarts), head, seg, nseg,
+            (int(seed) + int(offset)) & (2 ** 64 - 1), _vp(d_step), _vp(jidx), _vp(jstarts), head, seg, nseg, first,
             _vp(self._rec["mt_ws"]), _vp(self._rec["mt_status"]), self.stream()))
         if filtered and not (fc[0] == 1.0 and fc[1] == 0.0 and fc[2] == 0.0):
             _lib.check(self.lib.mjmpc_filter_noise(_lib.F32 if dtype == "f32" else _lib.F64, _vp(buf), P, self.H, self.A,

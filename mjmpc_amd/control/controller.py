@@ -15,8 +15,8 @@ Extra constructor keywords (all optional, defaults reproduce the reference bit f
   noise_mode  'host'   legacy numpy stream, identical seeds -> identical noise (parity mode)
               'device' Philox sampler on the GPU (same distribution, not the same bits)
               'device_mt19937'  the reference's own stream (MT19937 + polar method) regenerated on the GPU:
-                       identical seeds -> the same particles (to the last bit or two), isotropic covariance,
-                       single GPU; the serial twister recurrence is cut into 32 jumped-ahead segments
+                       identical seeds -> the same particles (to the last bit or two), isotropic covariance;
+                       sharded runs keep their block of the one stream; the serial twister recurrence is cut into 32 jumped-ahead segments
                        (mt_jump.py), ~0.1 ms per 4096x32x7 draw
   noise_dtype 'f64' | 'f32'  storage type of device-sampled noise
   device      CUDA device ordinal;  comm  particle-sharding communicator (see _device.py)
@@ -247,10 +247,8 @@ class OLGaussianMPC(Controller):
                                    base_seed=self.seed_val + self.num_steps)
             return delta[rank * n_loc:(rank + 1) * n_loc] if self.dev.comm.world_size > 1 else delta
         if self.noise_mode == 'device_mt19937':
-            if self.dev.comm.world_size != 1:
-                raise NotImplementedError("device_mt19937 noise is a single serial stream: single GPU only")
             return self.dev.sample_noise_mt19937(n_loc, self.cov_action, self.filter_coeffs, self.seed_val,
-                                                 self.num_steps, dtype=self.noise_dtype)
+                                                 self.num_steps, dtype=self.noise_dtype, particle_offset=rank * n_loc)
         if self._device_cov():
             self._sync_in()             # a covariance the user assigned on the host is uploaded first
             return self.dev.sample_noise(n_loc, None, self.filter_coeffs, self.seed_val, self.num_steps,
@@ -289,7 +287,6 @@ class OLGaussianMPC(Controller):
 
     def _graph_capable(self):
         return (self.noise_mode in ('device', 'device_mt19937') and getattr(self._rollout_fn, "accepts_device", False)
-                and (self.noise_mode == 'device' or self.dev.comm.world_size == 1)
                 and self.base_action in ('null', 'repeat') and self.sample_mode == 'mean'
                 and (self._static_cov() or (self._device_cov() and self.noise_mode == 'device'))
                 and (self.dev.comm.world_size == 1 or (self._fused_capable()
@@ -314,7 +311,8 @@ class OLGaussianMPC(Controller):
         """Unfiltered device noise of control step (device step counter + steps_ahead)."""
         if self.noise_mode == 'device_mt19937':
             return self.dev.sample_noise_mt19937(n_loc, self._cov_host, self.filter_coeffs, self.seed_val, steps_ahead,
-                                                 dtype=self.noise_dtype, d_step=self._step_dev, filtered=False)
+                                                 dtype=self.noise_dtype, d_step=self._step_dev, filtered=False,
+                                                 particle_offset=self.dev.comm.rank * n_loc)
         return self.dev.sample_noise(n_loc, self._noise_cov(), self.filter_coeffs, self.seed_val, steps_ahead,
                                      dtype=self.noise_dtype, d_step=self._step_dev, filtered=False,
                                      particle_offset=self.dev.comm.rank * n_loc,
@@ -358,7 +356,8 @@ class OLGaussianMPC(Controller):
         for _ in range(self.n_iters):
             if self.noise_mode == 'device_mt19937':
                 delta = self.dev.sample_noise_mt19937(n_loc, self._cov_host, self.filter_coeffs, self.seed_val, 0,
-                                                      dtype=self.noise_dtype, d_step=self._step_dev)
+                                                      dtype=self.noise_dtype, d_step=self._step_dev,
+                                                      particle_offset=self.dev.comm.rank * n_loc)
             else:
                 delta = self.dev.sample_noise(n_loc, self._noise_cov(), self.filter_coeffs, self.seed_val, 0,
                                               dtype=self.noise_dtype, d_step=self._step_dev,

@@ -526,25 +526,25 @@ int64_t mjmpc_mt19937_stream_words(int64_t n_normals) { return 4 * (int64_t)mjmp
 
 int mjmpc_sample_noise_mt19937_jump(int dtype, void* d_noise, int64_t n_normals, double scale, uint64_t seed,
                                     const int64_t* d_step, const int32_t* d_jump_idx, const int32_t* d_jump_starts,
-                                    int64_t head_words, int64_t seg_words, int n_segments, void* d_ws, int* d_status,
-                                    void* stream) {
-    if (!d_noise || !d_ws) return fail(MJMPC_E_BADARG, "null argument");
+                                    int64_t head_words, int64_t seg_words, int n_segments, int64_t first_normal,
+                                    void* d_ws, int* d_status, void* stream) {
+    if (!d_noise || !d_ws || first_normal < 0) return fail(MJMPC_E_BADARG, "null argument");
     if (n_segments > 0) {
         if (!d_jump_idx || !d_jump_starts) return fail(MJMPC_E_BADARG, "jump tables missing");
         if (head_words < 19936 || head_words > 19968 || (head_words & 3) || seg_words < 2 * 624)
             return fail(MJMPC_E_BADARG, "head_words must be a multiple of 4 in [19936, 19968], seg_words >= 1248");
         if (n_segments > mjmpc::MT_MAX_SEGMENTS) return fail(MJMPC_E_BADARG, "too many segments (max 64)");
-        if (head_words + seg_words * (int64_t)n_segments < mjmpc_mt19937_stream_words(n_normals))
+        if (head_words + seg_words * (int64_t)n_segments < mjmpc_mt19937_stream_words(first_normal + n_normals))
             return fail(MJMPC_E_BADARG, "segments do not cover the stream");
     }
     hipStream_t s = (hipStream_t)stream;
     DISPATCH(dtype,
              mjmpc::sample_noise_mt19937<float>((float*)d_noise, (long)n_normals, scale, seed, (const long long*)d_step,
                                                 d_ws, d_status, s, d_jump_idx, d_jump_starts, (long)head_words,
-                                                (long)seg_words, n_segments),
+                                                (long)seg_words, n_segments, (long)first_normal),
              mjmpc::sample_noise_mt19937<double>((double*)d_noise, (long)n_normals, scale, seed,
                                                  (const long long*)d_step, d_ws, d_status, s, d_jump_idx, d_jump_starts,
-                                                 (long)head_words, (long)seg_words, n_segments));
+                                                 (long)head_words, (long)seg_words, n_segments, (long)first_normal));
 }
 
 int mjmpc_sample_noise(int dtype, void* d_noise, int64_t P, int H, int A, const double* d_chol,

@@ -242,7 +242,8 @@ __global__ void block_offsets_kernel(const int* __restrict__ block_count, int nb
 
 template <typename T>
 __global__ void polar_emit_kernel(const unsigned* __restrict__ w, long n_attempts, const long* __restrict__ offsets,
-                                  long n_normals, double scale, T* __restrict__ noise, int* __restrict__ status) {
+                                  long first, long n_normals, double scale, T* __restrict__ noise,
+                                  int* __restrict__ status) {
     __shared__ int cnt[FBLK / 64];
     const long i = (long)blockIdx.x * FBLK + threadIdx.x;
     double x1 = 0, x2 = 0, r2 = 1;
@@ -254,13 +255,16 @@ __global__ void polar_emit_kernel(const unsigned* __restrict__ w, long n_attempt
     long k = offsets[blockIdx.x];
     for (int q = 0; q < wv; ++q) k += cnt[q];
     k += __popcll(m & ((1ull << lane) - 1ull));
-    if (acc && 2 * k < n_normals) {
+    // normals [first, first + n_normals) of the stream land in noise[0 .. n_normals): a sharded run keeps its own
+    // block of the one global stream
+    const long last = first + n_normals;
+    if (acc && 2 * k + 1 >= first && 2 * k < last) {
         const double f = sqrt(-2.0 * log(r2) / r2);                 // legacy_gauss
-        noise[2 * k] = (T)((f * x2) * scale);                       // returned first
-        if (2 * k + 1 < n_normals) noise[2 * k + 1] = (T)((f * x1) * scale);   // the cached one
+        if (2 * k >= first) noise[2 * k - first] = (T)((f * x2) * scale);              // returned first
+        if (2 * k + 1 < last) noise[2 * k + 1 - first] = (T)((f * x1) * scale);        // the cached one
     }
     if (blockIdx.x == 0 && threadIdx.x == 0) {
-        const long need = (n_normals + 1) / 2;
+        const long need = (last + 1) / 2;
         if (status) *status = offsets[gridDim.x] >= need ? 0 : 1;              // 1: not enough attempts generated
     }
 }
@@ -280,9 +284,9 @@ long mt_workspace_bytes(long n_normals) {
 template <typename T>
 hipError_t sample_noise_mt19937(T* noise, long n_normals, double scale, unsigned long long seed, const long long* d_step,
                                 void* ws, int* status, hipStream_t s, const int* jump_idx, const int* jump_starts,
-                                long head_words, long seg_words, int n_segments) {
+                                long head_words, long seg_words, int n_segments, long first_normal) {
     if (n_normals <= 0) return hipSuccess;
-    const long na = mt_attempts_for(n_normals), nb = (na + FBLK - 1) / FBLK;
+    const long na = mt_attempts_for(first_normal + n_normals), nb = (na + FBLK - 1) / FBLK;
     unsigned* all = (unsigned*)ws;                                  // 624 + 4 * na words
     unsigned* words = all + MT_N;
     int* counts = (int*)(words + 4 * na);
@@ -304,14 +308,14 @@ hipError_t sample_noise_mt19937(T* noise, long n_normals, double scale, unsigned
     }
     hipLaunchKernelGGL(polar_flags_kernel, dim3((unsigned)nb), dim3(FBLK), 0, s, words, na, counts);
     hipLaunchKernelGGL(block_offsets_kernel, dim3(1), dim3(1024), 0, s, counts, (int)nb, offsets);
-    hipLaunchKernelGGL(polar_emit_kernel<T>, dim3((unsigned)nb), dim3(FBLK), 0, s, words, na, offsets, n_normals, scale,
-                       noise, status);
+    hipLaunchKernelGGL(polar_emit_kernel<T>, dim3((unsigned)nb), dim3(FBLK), 0, s, words, na, offsets, first_normal,
+                       n_normals, scale, noise, status);
     return hipGetLastError();
 }
 
 template hipError_t sample_noise_mt19937<float>(float*, long, double, unsigned long long, const long long*, void*, int*,
-                                                hipStream_t, const int*, const int*, long, long, int);
+                                                hipStream_t, const int*, const int*, long, long, int, long);
 template hipError_t sample_noise_mt19937<double>(double*, long, double, unsigned long long, const long long*, void*, int*,
-                                                 hipStream_t, const int*, const int*, long, long, int);
+                                                 hipStream_t, const int*, const int*, long, long, int, long);
 
 }  // namespace mjmpc

@@ -66,7 +66,7 @@ def test_argument_errors_are_codes_and_messages_not_crashes():
         lambda: lib.mjmpc_cov_add_diag(None, 3, None, 1.0, None),
         lambda: lib.mjmpc_sample_noise(_lib.F64, None, 8, 4, 2, None, None, 1, 0, 0, None, 1, None),
         lambda: lib.mjmpc_sample_noise_mt19937(_lib.F64, None, 64, 1.0, 1, None, None, None, None),
-        lambda: lib.mjmpc_sample_noise_mt19937_jump(_lib.F64, None, 64, 1.0, 1, None, None, None, 19968, 2000, 4, None,
+        lambda: lib.mjmpc_sample_noise_mt19937_jump(_lib.F64, None, 64, 1.0, 1, None, None, None, 19968, 2000, 4, 0, None,
                                                     None, None),
     ]
     for call in bad:

@@ -105,3 +105,21 @@ def test_device_resident_loop_reproduces_the_reference_stream_loop(raw_arm):
     a_host = run("host", False)
     a_dev = run("device_mt19937", True)
     np.testing.assert_allclose(a_dev, a_host, rtol=1e-8, atol=1e-9)
+
+
+def test_sharded_block_of_the_stream():
+    """particle_offset: a rank's block [offset, offset + P_local) of the ONE global stream equals the same rows of
+    the full draw (and therefore numpy's), for unfiltered and filtered noise."""
+    from mjmpc_amd.control._device import DeviceUpdater
+    P, H, A, seed = 768, 16, 7, 4242
+    full = DeviceUpdater(H, A, np.ones(H)).sample_noise_mt19937(P, 0.9 * np.eye(A), [0.25, 0.8, 0.0], seed, 2).cpu().numpy()
+    for G in (2, 3):
+        n = P // G
+        for g in range(G):
+            dev = DeviceUpdater(H, A, np.ones(H))
+            mine = dev.sample_noise_mt19937(n, 0.9 * np.eye(A), [0.25, 0.8, 0.0], seed, 2, particle_offset=g * n)
+            np.testing.assert_array_equal(mine.cpu().numpy(), full[g * n:(g + 1) * n])
+            assert int(dev._rec["mt_status"].item()) == 0
+    from mjmpc_amd.control.control_utils import generate_noise
+    want = generate_noise(0.9 * np.eye(A), [0.25, 0.8, 0.0], (P, H), seed + 2)
+    np.testing.assert_allclose(full, want, rtol=4e-15, atol=4e-15)
