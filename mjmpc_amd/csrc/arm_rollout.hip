@@ -431,8 +431,20 @@ __device__ __forceinline__ void arm_substep(const Model<T>& M, const ArmInts& I,
             }
             LDS_WAVE_SYNC();
             aw = ldsM[V_XH + l8];
-            bool act2 = inst && (sig * aw - aref < T(0));
-            bool cact2 = cinst && (gsum(jc * aw) - arefc < T(0));
+            bool act2, cact2;
+            if constexpr (sizeof(T) == 4) {
+                // f32: a row whose residual is within rounding of zero keeps its state - such rows otherwise flip
+                // back and forth until the iteration cap (seen a few times per 5e8 solves).  f64 has never failed to
+                // settle and keeps the plain sign test.
+                const T res = sig * aw - aref, resc = gsum(jc * aw) - arefc;
+                const T band = T(4e-6) * (fabs(aref) + fabs(aw) + T(1));
+                const T bandc = T(4e-6) * (fabs(arefc) + fabs(resc + arefc) + T(1));
+                act2 = inst && (act ? !(res > band) : (res < -band));
+                cact2 = cinst && (cact ? !(resc > bandc) : (resc < -bandc));
+            } else {
+                act2 = inst && (sig * aw - aref < T(0));
+                cact2 = cinst && (gsum(jc * aw) - arefc < T(0));
+            }
             changed = (act2 != act) || (cact2 != cact);
             act = act2;
             cact = cact2;
@@ -490,13 +502,16 @@ __device__ __forceinline__ void arm_substep(const Model<T>& M, const ArmInts& I,
 // reference's C-order layouts (P,H,A) / (P,H) / (P,H,2nv+6).  noise, act, obs, next_obs may be null.
 // STEP = true is the same code instantiated under its own name for the single-particle "real env" step
 // (mjmpc_arm_step_state), so that profiler statistics of the P-particle rollout are not diluted by it.
-// second launch bound = waves per SIMD the register allocation has to leave room for: 2 for f64 (<= 256
-// VGPRs), 3 for f32 (<= 168; the kernel needs 140, a budget of 128 spills) - occupancy carries the kernel once
-// P exceeds ~8k particles
+// Register budget: f64 needs ~250 VGPRs (two waves per SIMD), f32 ~140 (three; a budget of 128 spills) -
+// occupancy carries the kernel once P exceeds ~8k particles
 // CL = true: the closed-loop-linear policy variant, its own instantiation so that the open-loop kernel does
 // not carry its registers (136 -> 178 VGPRs in f32 when both lived in one kernel)
-template <typename T, bool STEP, bool CL>
-__global__ __launch_bounds__(64, (sizeof(T) == 8 ? 2 : 3)) void arm_rollout_kernel(const T* __restrict__ model, const double* state,
+// WAVES = cap on resident waves per SIMD.  The f32 build fits three, but when a launch has no more than two waves
+// per SIMD to offer the dispatcher packs some SIMDs with three and leaves others with one, and the launch lasts as
+// long as the crowded ones (measured inside the control loop at 16 384 particles: 0.42 ms against 0.31 ms) - so
+// such launches use the instantiation capped at two.
+template <typename T, bool STEP, bool CL, int WAVES>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WAVES, WAVES))) void arm_rollout_kernel(const T* __restrict__ model, const double* state,
                                                          long P, int H, int A, const double* __restrict__ mean,
                                                          const T* __restrict__ noise, T* __restrict__ cost,
                                                          T* __restrict__ act, T* __restrict__ obs,
@@ -638,15 +653,26 @@ hipError_t launch_arm_rollout(const T* model, const double* state, long P, int H
                               unsigned* diag, hipStream_t stream, RolloutFusion fuse) {
     if (P <= 0 || H <= 0) return hipSuccess;
     const unsigned grid = (unsigned)((P + LANES - 1) / LANES);
-    if (fuse.clw)
-        hipLaunchKernelGGL((arm_rollout_kernel<T, false, true>), dim3(grid), dim3(64), 0, stream, model, state, P, H, A,
-                           mean, noise, cost, act, obs, nobs, state_out, diag, fuse);
-    else if (state_out)
-        hipLaunchKernelGGL((arm_rollout_kernel<T, true, false>), dim3(grid), dim3(64), 0, stream, model, state, P, H, A,
-                           mean, noise, cost, act, obs, nobs, state_out, diag, fuse);
-    else
-        hipLaunchKernelGGL((arm_rollout_kernel<T, false, false>), dim3(grid), dim3(64), 0, stream, model, state, P, H, A,
-                           mean, noise, cost, act, obs, nobs, state_out, diag, fuse);
+    // Cap the resident waves per SIMD at what this launch needs (2, or - f32 only, f64 does not fit - 3): the
+    // dispatcher then has to spread the workgroups evenly instead of crowding some SIMDs.  (A cap of 1 for launches
+    // of at most one wave per SIMD measured 3 % slower than 2.)
+    int dev = 0, cus = 256;
+    if (hipGetDevice(&dev) == hipSuccess) hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+    const long simds = 4L * cus;
+    const int cap = ((long)grid <= 2 * simds || sizeof(T) == 8) ? 2 : 3;
+#define MJMPC_LAUNCH_W(STEP_, CL_, W_)                                                                               \
+    hipLaunchKernelGGL((arm_rollout_kernel<T, STEP_, CL_, W_>), dim3(grid), dim3(64), 0, stream, model, state, P, H, A, \
+                       mean, noise, cost, act, obs, nobs, state_out, diag, fuse)
+#define MJMPC_LAUNCH(STEP_, CL_)                          \
+    do {                                                  \
+        if (cap == 2) MJMPC_LAUNCH_W(STEP_, CL_, 2);      \
+        else MJMPC_LAUNCH_W(STEP_, CL_, 3);               \
+    } while (0)
+    if (fuse.clw) MJMPC_LAUNCH(false, true);
+    else if (state_out) MJMPC_LAUNCH(true, false);
+    else MJMPC_LAUNCH(false, false);
+#undef MJMPC_LAUNCH
+#undef MJMPC_LAUNCH_W
     return hipGetLastError();
 }
 
