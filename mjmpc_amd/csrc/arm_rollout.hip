@@ -104,8 +104,18 @@ __device__ __forceinline__ void row_params(const Model<T>& M, T r, T diag_approx
     } else if (power == T(1)) {
         y = x;
     } else {
-        y = x <= mid ? pow_(x, power) / pow_(mid, power - T(1))
-                     : T(1) - pow_(T(1) - x, power) / pow_(T(1) - mid, power - T(1));
+        // integer power > 2 (the model compiler rejects anything else): x^p / mid^(p-1) by repeated multiplication -
+        // the library pow() would cost the whole kernel ~20 VGPRs and ~60 spilled SGPRs for a path no shipped model takes
+        const int n = (int)power;
+        const bool lo = x <= mid;
+        const T xa = lo ? x : T(1) - x, ma = lo ? mid : T(1) - mid;
+        T num = xa, den = T(1);
+        for (int k = 1; k < n; ++k) {
+            num *= xa;
+            den *= ma;
+        }
+        const T qq = num * rcp_(den);
+        y = lo ? qq : T(1) - qq;
     }
     T imp = dmin + y * (dmax - dmin);
     T Rr = (T(1) - imp) * rcp_(imp) * diag_approx;
@@ -481,18 +491,23 @@ __device__ __forceinline__ void arm_substep(const Model<T>& M, const ArmInts& I,
         v += h * x;
         const T dq = h * v;
         q += dq;
-        // advance (sin q, cos q) by dq: angle addition with a short series, one Newton step of
-        // renormalisation; large steps (never seen with h = 0.01) fall back to the library call
-        if (__any(fabs(dq) > T(0.25))) {
-            sincos_(q, sq, cq);
+        // advance (sin q, cos q) by dq: angle addition with a short series, one Newton step of renormalisation.
+        // Large steps (|dq| > 0.25 rad per substep, never seen with h = 0.01): series at dq / 256, doubled back up.
+        T sd, cd;
+        if (__builtin_expect(__any(fabs(dq) > T(0.25)), 0)) {
+            sincos_small(dq * T(1.0 / 256.0), sd, cd);
+            for (int k = 0; k < 8; ++k) {
+                const T s2 = T(2) * sd * cd;
+                cd = T(1) - T(2) * sd * sd;
+                sd = s2;
+            }
         } else {
-            T sd, cd;
             sincos_small(dq, sd, cd);
-            const T s1 = sq * cd + cq * sd, c1 = cq * cd - sq * sd;
-            const T k = T(1.5) - T(0.5) * (s1 * s1 + c1 * c1);
-            sq = s1 * k;
-            cq = c1 * k;
         }
+        const T s1 = sq * cd + cq * sd, c1 = cq * cd - sq * sd;
+        const T k = T(1.5) - T(0.5) * (s1 * s1 + c1 * c1);
+        sq = s1 * k;
+        cq = c1 * k;
     }
     LDS_WAVE_SYNC();            // the tile is rewritten by the next substep
 }

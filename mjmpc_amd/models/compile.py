@@ -248,6 +248,9 @@ def compile_arm(raw: RawModel, overrides=None, base: "ArmModel" = None) -> ArmMo
     tc, dr = raw.solref
     tc = max(tc, 2 * raw.timestep)                               # refsafe
     dmin, dmax, width, mid, power = raw.solimp
+    if power < 1 or power != int(power) or power > 64:
+        # the kernel evaluates the impedance power by repeated multiplication (no library pow in the hot loop)
+        raise NotImplementedError("solimp power must be an integer in [1, 64] (MuJoCo's default is 2), got %r" % (power,))
     f["sol_K"][0] = 1.0 / (dmax * dmax * tc * tc * dr * dr)
     f["sol_B"][0] = 2.0 / (dmax * tc)
     f["sol_dmin"][0], f["sol_dmax"][0] = dmin, dmax

@@ -266,3 +266,28 @@ def test_per_shard_start_states(raw_arm, ref_arm):
     np.testing.assert_allclose(rew1, o[1], rtol=1e-9, atol=1e-9)
     with pytest.raises(AssertionError):
         eng.set_env_state([dict(STATES[0]), dict(STATES[1])])
+
+
+def test_cubic_impedance_and_fast_joints(raw_arm):
+    """The two small code paths that stand in for library calls in the hot loop: an integer solimp power > 2
+    (repeated multiplication instead of pow) with joints driven into their limits, and joint steps beyond
+    0.25 rad per substep (doubling formula instead of sincos) from a 60 rad/s spin - f64 against the oracle."""
+    import dataclasses
+    from mjmpc_amd.envs.arm_engine import ArmRolloutEngine
+    from oracle.physics_ref import RefArm
+    raw = dataclasses.replace(raw_arm, solimp=(0.9, 0.95, 0.001, 0.5, 3.0))
+    eng, ref = ArmRolloutEngine(raw, dtype="f64"), RefArm(raw.to_flat())
+    P, H = 64, 16
+    rs = np.random.RandomState(5)
+    mean = 0.8 * rs.standard_normal((H, 7))
+    noise = _noise(P, H, 7, 31, scale=1.5)
+    for st in (STATES[1], dict(qp=np.array([0.0, 0.2, 0.1, -0.4, 0.0, -0.2, 0.0]),
+                               qv=np.array([0.0, 0.0, 60.0, 0.0, -45.0, 0.0, 30.0]),
+                               target_pos=np.array([0.1, 0.1, 0.1]))):
+        eng.set_env_state(dict(st, qa=np.zeros(7), timestep=0))
+        obs, rew, act, done, info, nobs = eng.rollout(P, H, mean, noise, "open_loop")
+        o_obs, o_rew, o_act, o_done, o_nobs = ref.rollout(st["qp"], st["qv"], st["target_pos"], mean, noise)
+        np.testing.assert_allclose(rew, o_rew, rtol=1e-9, atol=1e-9)
+        np.testing.assert_allclose(nobs, o_nobs, rtol=0, atol=1e-8)
+    assert eng.solver_failures() == 0
+    assert ref.newton_stats()["calls"] > 0                    # the limits really were active

@@ -92,3 +92,17 @@ def test_systematic_resampling_matches_the_serial_walk(golden):
     w = np.array([0.5, 0.25, 0.25])
     assert list(systematic_resample_indices(w, 0.0)) == [-1, 0, 1]
     assert list(systematic_resample_indices(w * 0.5, 0.3)) == [1, 2, 2]
+
+
+def test_impedance_power_must_be_a_small_integer():
+    """The kernel evaluates solimp's power by repeated multiplication: the model compiler rejects the rest."""
+    import dataclasses
+    import pytest
+    from mjmpc_amd.models.compile import compile_arm
+    from mjmpc_amd.models.reacher7dof import reacher7dof_raw
+    raw = reacher7dof_raw()
+    for ok in (1.0, 2.0, 3.0, 6.0):
+        compile_arm(dataclasses.replace(raw, solimp=(0.9, 0.95, 0.001, 0.5, ok)))
+    for bad in (2.5, 0.5, 100.0):
+        with pytest.raises(NotImplementedError):
+            compile_arm(dataclasses.replace(raw, solimp=(0.9, 0.95, 0.001, 0.5, bad)))
