@@ -578,7 +578,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WAVES, WAVES
     // inputs of step t+1 are fetched while step t computes (a lone wave would otherwise sit out the full
     // HBM latency of its noise load at the top of every env step)
     T eps_next = T(0);
-    double mean_next = 0.0;
+    double mean_next = 0.0, gs_next = (fuse.q0_out && H > 0) ? fuse.gseq[0] : 0.0;   // (a load consumed in the iteration
+    // that issues it would make its s_waitcnt also wait for the prefetches issued before it)
     if (has_u && H > 0) {
         if constexpr (!CL) mean_next = mean[l8];
         if (noise && live) eps_next = noise[(pid * H) * A + l8];
@@ -587,7 +588,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WAVES, WAVES
     for (int t = 0; t < H; ++t) {
         T u = T(0);
         const T eps_cur = eps_next;
-        const double mean_cur = mean_next;
+        const double mean_cur = mean_next, gs_cur = gs_next;
+        if (fuse.q0_out && t + 1 < H) gs_next = fuse.gseq[t + 1];
         if (has_u && t + 1 < H) {
             if constexpr (!CL) mean_next = mean[(t + 1) * A + l8];
             if (noise && live) eps_next = noise[(pid * H + t + 1) * A + l8];
@@ -622,11 +624,15 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WAVES, WAVES
             arm_substep(M, I, q, v, aw, sinq, cosq, rows, tau_act, ldsM, lane, l8, site, diag);
             if (t == 0 && sub == 0) for (int k = 0; k < 3; ++k) chand[k] = site[k];   // fresh obs after set_env_state
         }
+        // Take delivery of the prefetched inputs HERE, before this step's stores are issued: loads and stores share
+        // one in-order counter (vmcnt), and the register hand-over the compiler otherwise places on the loop's
+        // back-edge waits with vmcnt(0) - i.e. for the cost / observation stores just issued (~2000 cycles per step).
+        asm volatile("" : "+v"(eps_next), "+v"(mean_next), "+v"(gs_next));
         // reward = -(|h-g|_1 + 5 |h-g|_2), h = site_xpos lagging one substep (reacher_env.py:31-35)
         T dx = site[0] - tgt[0], dy = site[1] - tgt[1], dz = site[2] - tgt[2];
         T cst = fabs(dx) + fabs(dy) + fabs(dz) + T(5) * sqrt_(dx * dx + dy * dy + dz * dz);
         if (live && l8 == 0) cost[pid * H + t] = cst;
-        if (fuse.q0_out) q0acc += fuse.gseq[t] * (double)cst;
+        if (fuse.q0_out) q0acc += gs_cur * (double)cst;
         if (live && (obs || nobs)) {
             const long o = (pid * H + t) * dobs;
             if (obs) {
