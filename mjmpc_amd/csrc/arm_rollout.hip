@@ -221,7 +221,9 @@ struct ArmInts {            // wave-uniform integers (SGPRs)
 // q, v: state of my dof (updated).  aw: constraint-solver warm start (previous qacc).  (sq, cq) =
 // (sin q, cos q), advanced by angle addition.  rows: active-set memory.  tau_act: gear * clip(ctrl).
 // site: world position of the tracked site computed from the q this substep STARTED with (MuJoCo
-// runs kinematics before integrating).
+// runs kinematics before integrating), evaluated as if it were attached to the calling lane's link: only the
+// lane of the site's link holds the real one, and the caller broadcasts it when a value is consumed (once per
+// env step instead of once per substep).
 template <typename T>
 __device__ __forceinline__ void arm_substep(const Model<T>& M, const ArmInts& I, T& q, T& v, T& aw, T& sq, T& cq,
                                             int& rows, T tau_act, T* ldsM, int lane, int l8, T* site,
@@ -250,7 +252,7 @@ __device__ __forceinline__ void arm_substep(const Model<T>& M, const ArmInts& I,
         const T sp[3] = {M.glob(O_SITE_POS, 0), M.glob(O_SITE_POS, 1), M.glob(O_SITE_POS, 2)};
         T t[3];
         matvec(R, sp, t);
-        for (int k = 0; k < 3; ++k) site[k] = __shfl(p[k] + t[k], lane_of_link(lane, I.site_link));
+        for (int k = 0; k < 3; ++k) site[k] = p[k] + t[k];      // as if the site sat on MY link; the caller picks the lane
     }
     // sphere centre for the contact row (needs R of the sphere's link, so it is taken here)
     T ctr[3] = {T(0), T(0), T(0)};
@@ -559,6 +561,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WAVES, WAVES
     if (l8 >= nv) { q = T(0); v = T(0); }
     T sinq, cosq;
     sincos_(q, sinq, cosq);
+    const int site_lane = lane_of_link(lane, I.site_link);
     int rows = 0;
     T cq = q, cv = v, chand[3] = {T(0), T(0), T(0)};
     const bool has_u = l8 < A;
@@ -572,7 +575,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WAVES, WAVES
         int rr = 0;
         T s0[3];
         arm_substep(M, I, qq, vv, aa, ss, cc, rr, T(0), ldsM, lane, l8, s0, (unsigned*)nullptr);
-        for (int k = 0; k < 3; ++k) chand[k] = s0[k];
+        for (int k = 0; k < 3; ++k) chand[k] = __shfl(s0[k], site_lane);
     }
 
     // inputs of step t+1 are fetched while step t computes (a lone wave would otherwise sit out the full
@@ -622,8 +625,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WAVES, WAVES
         T site[3];
         for (int sub = 0; sub < I.frame_skip; ++sub) {
             arm_substep(M, I, q, v, aw, sinq, cosq, rows, tau_act, ldsM, lane, l8, site, diag);
-            if (t == 0 && sub == 0) for (int k = 0; k < 3; ++k) chand[k] = site[k];   // fresh obs after set_env_state
+            if (t == 0 && sub == 0 && obs)                  // fresh observation after set_env_state
+                for (int k = 0; k < 3; ++k) chand[k] = __shfl(site[k], site_lane);
         }
+        for (int k = 0; k < 3; ++k) site[k] = __shfl(site[k], site_lane);
         // Take delivery of the prefetched inputs HERE, before this step's stores are issued: loads and stores share
         // one in-order counter (vmcnt), and the register hand-over the compiler otherwise places on the loop's
         // back-edge waits with vmcnt(0) - i.e. for the cost / observation stores just issued (~2000 cycles per step).
