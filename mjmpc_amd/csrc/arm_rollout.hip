@@ -691,8 +691,12 @@ hipError_t launch_arm_rollout(const T* model, const double* state, long P, int H
                        mean, noise, cost, act, obs, nobs, state_out, diag, fuse)
 #define MJMPC_LAUNCH(STEP_, CL_)                          \
     do {                                                  \
-        if (cap == 2) MJMPC_LAUNCH_W(STEP_, CL_, 2);      \
-        else MJMPC_LAUNCH_W(STEP_, CL_, 3);               \
+        if constexpr (sizeof(T) == 8) {                   \
+            MJMPC_LAUNCH_W(STEP_, CL_, 2);                \
+        } else {                                          \
+            if (cap == 2) MJMPC_LAUNCH_W(STEP_, CL_, 2);  \
+            else MJMPC_LAUNCH_W(STEP_, CL_, 3);           \
+        }                                                 \
     } while (0)
     if (fuse.clw) MJMPC_LAUNCH(false, true);
     else if (state_out) MJMPC_LAUNCH(true, false);
