@@ -182,7 +182,7 @@ __device__ __forceinline__ double rcp_(double x) {
     r = fma(fma(-x, r, 1.0), r, r);
     return fma(fma(-x, r, 1.0), r, r);
 }
-// pivot reciprocal of the in-register LDL^T: v_rcp_f64 is good to 4.6e-8 (measured on gfx950), one
+// pivot reciprocal of the dense LDL^T (arm_rollout.hip, struct Dense): v_rcp_f64 is good to 4.6e-8 (measured on gfx950), one
 // Newton step brings it to 2.2e-15 - enough for a factorisation whose backward error is O(eps) anyway
 __device__ __forceinline__ float rcp_fast(float x) { return rcp_(x); }
 __device__ __forceinline__ double rcp_fast(double x) {
@@ -218,7 +218,5 @@ __device__ __forceinline__ void sincos_small(double x, double& s, double& c) {
 }
 __device__ __forceinline__ float sqrt_(float x) { return sqrtf(x); }
 __device__ __forceinline__ double sqrt_(double x) { return sqrt(x); }
-__device__ __forceinline__ float pow_(float x, float y) { return powf(x, y); }
-__device__ __forceinline__ double pow_(double x, double y) { return pow(x, y); }
 
 }  // namespace mjmpc
