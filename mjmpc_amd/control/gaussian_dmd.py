@@ -21,6 +21,11 @@ class DMDMPC(OLGaussianMPC):
     def _static_cov(self):
         return not self.update_cov
 
+    def _fused_capable(self):
+        # without covariance adaptation the update is MPPI's with alpha = 1 (gaussian_dmd.py:65-104): same fused
+        # rollout (filter + cost-to-go) and two-launch update
+        return (not self.update_cov and not self.dev.gamma_zero and hasattr(self._rollout_fn, "fused"))
+
     def _device_cov(self):
         return self.update_cov and self.cov_type in ('diagonal', 'full')
 

@@ -242,7 +242,7 @@ def test_graph_replay_matches_eager_steps(raw_arm):
     np.testing.assert_allclose(m_g, m_e, rtol=1e-9, atol=1e-10)
 
 
-@pytest.mark.parametrize("kind", ["cem_full", "cem_diag", "dmd_full"])
+@pytest.mark.parametrize("kind", ["cem_full", "cem_diag", "dmd_full", "dmd_static"])
 def test_adapting_covariance_stays_on_the_device_and_graph_matches_eager(raw_arm, kind):
     """CEM / DMD-MPC with update_cov: the covariance is refit, grown (shift) and Cholesky-factored for the sampler
     on the GPU.  The captured iteration walks the same closed loop as the eager path, and the eager path agrees
@@ -258,7 +258,7 @@ def test_adapting_covariance_stays_on_the_device_and_graph_matches_eager(raw_arm
         if kind.startswith("cem"):
             return CEM(init_cov=0.6, elite_frac=0.1, step_size=0.7, beta=0.05,
                        cov_type="full" if kind == "cem_full" else "diagonal", **kw)
-        return DMDMPC(init_cov=0.6, beta=0.05, lam=0.2, step_size=0.7, update_cov=True, cov_type="full", **kw)
+        return DMDMPC(init_cov=0.6, beta=0.05, lam=0.2, step_size=0.7, update_cov=kind == "dmd_full", cov_type="full", **kw)
 
     def run(mode, steps=5):
         eng = ArmRolloutEngine(raw_arm, dtype="f64")
@@ -285,8 +285,11 @@ def test_adapting_covariance_stays_on_the_device_and_graph_matches_eager(raw_arm
     a_e, c_e, m_e = run("eager")
     a_h, c_h, m_h = run("host_cov")
     a_g, c_g, m_g = run("graph")
-    assert np.abs(c_e[-1] - c_e[0]).max() > 1e-3                      # the covariance really adapts
-    if kind != "cem_diag":
+    if kind == "dmd_static":                                          # (fixed covariance: the fused MPPI-style path)
+        assert np.array_equal(c_e[-1], c_e[0])
+    else:
+        assert np.abs(c_e[-1] - c_e[0]).max() > 1e-3                  # the covariance really adapts
+    if kind in ("cem_full", "dmd_full"):
         assert np.abs(c_e[-1] - np.diag(np.diag(c_e[-1]))).max() > 1e-4
     for a, c, m in ((a_h, c_h, m_h), (a_g, c_g, m_g)):
         np.testing.assert_allclose(a, a_e, rtol=1e-9, atol=1e-10)
