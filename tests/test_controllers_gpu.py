@@ -205,6 +205,18 @@ def test_device_noise_statistics():
     # sharding invariance: particles [1000, 1500) drawn as a shard equal the same rows of the full draw
     shard = dev.sample_noise(500, cov, [1.0, 0.0, 0.0], 7, 3, particle_offset=1000).cpu().numpy()
     np.testing.assert_array_equal(shard, raw[1000:1500])
+    # the two kernels behind the sampler (one thread per element / one thread per sample vector) draw the same
+    # numbers: a diagonal covariance through either gives identical bits
+    import ctypes
+    import torch
+    from mjmpc_amd import _lib
+    dcov = np.diag([0.5, 1.5, 0.8])
+    a = dev.sample_noise(Pn, dcov, [1.0, 0.0, 0.0], 11, 0).clone()
+    b = torch.empty_like(a)
+    vp = lambda t: ctypes.c_void_p(t.data_ptr())
+    _lib.check(dev.lib.mjmpc_sample_noise(_lib.F64, vp(b), Pn, Hn, An, vp(dev._rec["chol"]), None, 11, 0, 0, None, 0,
+                                          dev.stream()))
+    assert torch.equal(a, b)
 
 
 def test_graph_replay_matches_eager_steps(raw_arm):
