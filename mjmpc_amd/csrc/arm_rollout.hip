@@ -21,6 +21,8 @@
 // which is the exact minimiser MuJoCo's Newton solver converges to.
 #include <hip/hip_runtime.h>
 
+#include <cstdlib>
+
 #include "arm_model.h"
 #include "arm_rollout.h"
 #include "lanegroup.h"
@@ -48,13 +50,32 @@ constexpr int NEWTON_MAXIT = 12;
         __builtin_amdgcn_sched_barrier(0);                     \
     } while (0)
 
-template <typename T>
+// REG = true (DUO kernels, which have the registers to spare): my link's 25 per-link constants are read once and
+// stay in VGPRs - a lone wavefront otherwise sits out the LDS latency at the head of every phase.  Every call site
+// names the field with compile-time constants, so `reg` never becomes an indexed array, and the fields a wave's
+// role does not touch are dropped by the compiler.
+constexpr int N_LINK_FIELDS = O_NV / LANES;
+template <typename T, bool REG>
 struct Model {                 // view of the LDS copy of the model block
     const T* m;
     int l8;
-    __device__ __forceinline__ T link(int off, int c = 0) const { return m[off + c * LANES + l8]; }
+    T reg[REG ? N_LINK_FIELDS : 1];
+    __device__ __forceinline__ void cache() {
+        if constexpr (REG)
+#pragma unroll
+            for (int k = 0; k < N_LINK_FIELDS; ++k) reg[k] = m[k * LANES + l8];
+    }
+    __device__ __forceinline__ T link(int off, int c = 0) const {
+        if constexpr (REG) return reg[off / LANES + c];
+        else return m[off + c * LANES + l8];
+    }
     __device__ __forceinline__ T glob(int off, int c = 0) const { return m[off + c]; }
 };
+
+__device__ __forceinline__ float mul_rn(float a, float b) { return __fmul_rn(a, b); }
+__device__ __forceinline__ double mul_rn(double a, double b) { return __dmul_rn(a, b); }
+__device__ __forceinline__ float add_rn(float a, float b) { return __fadd_rn(a, b); }
+__device__ __forceinline__ double add_rn(double a, double b) { return __dadd_rn(a, b); }
 
 // ---- small vector helpers -------------------------------------------------------------------
 template <typename T>
@@ -92,8 +113,8 @@ __device__ __forceinline__ void fk_scan_step(T* R, T* p, int l8) {
 }
 
 // MuJoCo mj_makeImpedance + mj_referenceConstraint for one scalar row (r = pos - margin)
-template <typename T>
-__device__ __forceinline__ void row_params(const Model<T>& M, T r, T diag_approx, T jv, T& D, T& aref) {
+template <typename T, typename MT>
+__device__ __forceinline__ void row_params(const MT& M, T r, T diag_approx, T jv, T& D, T& aref) {
     const T dmin = M.glob(O_SOL_DMIN), dmax = M.glob(O_SOL_DMAX), width = M.glob(O_SOL_WIDTH);
     const T mid = M.glob(O_SOL_MID), power = M.glob(O_SOL_POWER);
     T x = fabs(r) * rcp_(width), y;
@@ -188,7 +209,8 @@ struct Dense {
 // Per-particle LDS block: the 8x8 mass-matrix tile followed by the vectors the lanes hand to the solver lanes
 // and back.  The stride keeps 16-byte alignment and shifts consecutive particles by 4 (f32) / 8 (f64) banks.
 constexpr int V_DH = LANES * LANES, V_RH = V_DH + LANES, V_DE = V_RH + LANES, V_RE = V_DE + LANES, V_XH = V_RE + LANES,
-              V_XE = V_XH + LANES, V_JC = V_XE + LANES, PSTRIDE = V_JC + LANES + 4;
+              V_XE = V_XH + LANES, V_JC = V_XE + LANES, V_TAU = V_JC + LANES, V_EI = V_TAU + LANES,
+              PSTRIDE = V_EI + LANES * LANES + 4;      // V_EI: (M + h B)^-1, DUO only
 
 // u_i += sum_k W[k][i] q_k + W[nv+k][i] v_k   (the joint part of clw^T obs), link values by DPP broadcast
 template <int K, typename T>
@@ -218,62 +240,52 @@ struct ArmInts {            // wave-uniform integers (SGPRs)
 };
 
 // ---- one mj_step ------------------------------------------------------------------------------
-// q, v: state of my dof (updated).  aw: constraint-solver warm start (previous qacc).  (sq, cq) =
-// (sin q, cos q), advanced by angle addition.  rows: active-set memory.  tau_act: gear * clip(ctrl).
-// site: world position of the tracked site computed from the q this substep STARTED with (MuJoCo
-// runs kinematics before integrating), evaluated as if it were attached to the calling lane's link: only the
-// lane of the site's link holds the real one, and the caller broadcasts it when a value is consumed (once per
-// env step instead of once per substep).
+// Quantities of my link after forward kinematics, everything in world coordinates about the WORLD ORIGIN.
 template <typename T>
-__device__ __forceinline__ void arm_substep(const Model<T>& M, const ArmInts& I, T& q, T& v, T& aw, T& sq, T& cq,
-                                            int& rows, T tau_act, T* ldsM, int lane, int l8, T* site,
-                                            unsigned* diag) {
-    // 1. forward kinematics: local transform (Rodrigues, frames are world-aligned at qpos0) + scan
-    PHASE();
-    T R[9], p[3], ax[3];
-    {
-        const T s = sq, c = cq, tt = T(1) - cq;
-        for (int k = 0; k < 3; ++k) { ax[k] = M.link(O_AXIS, k); p[k] = M.link(O_OFF, k); }
-        R[0] = c + tt * ax[0] * ax[0];
-        R[1] = tt * ax[0] * ax[1] - s * ax[2];
-        R[2] = tt * ax[0] * ax[2] + s * ax[1];
-        R[3] = tt * ax[0] * ax[1] + s * ax[2];
-        R[4] = c + tt * ax[1] * ax[1];
-        R[5] = tt * ax[1] * ax[2] - s * ax[0];
-        R[6] = tt * ax[0] * ax[2] - s * ax[1];
-        R[7] = tt * ax[1] * ax[2] + s * ax[0];
-        R[8] = c + tt * ax[2] * ax[2];
-    }
+struct LinkFrame {
+    T R[9], p[3], ax[3];        // link frame (rotation, origin), joint axis in link coordinates
+    T mass, a[3], cw[3];        // joint axis, centre of mass
+    T Ib[6], hm[3];             // rotational inertia about the origin, first moment m c
+    T sw[3], sv[3];             // motion axis S = (a, p x a)
+};
+
+// 1. forward kinematics: local transform (Rodrigues, frames are world-aligned at qpos0) + scan
+template <typename T, typename MT>
+__device__ __forceinline__ void kinematics(const MT& M, T sq, T cq, int l8, LinkFrame<T>& L) {
+    T* R = L.R;
+    T* p = L.p;
+    T* ax = L.ax;
+    const T s = sq, c = cq, tt = T(1) - cq;
+    for (int k = 0; k < 3; ++k) { ax[k] = M.link(O_AXIS, k); p[k] = M.link(O_OFF, k); }
+    R[0] = c + tt * ax[0] * ax[0];
+    R[1] = tt * ax[0] * ax[1] - s * ax[2];
+    R[2] = tt * ax[0] * ax[2] + s * ax[1];
+    R[3] = tt * ax[0] * ax[1] + s * ax[2];
+    R[4] = c + tt * ax[1] * ax[1];
+    R[5] = tt * ax[1] * ax[2] - s * ax[0];
+    R[6] = tt * ax[0] * ax[2] - s * ax[1];
+    R[7] = tt * ax[1] * ax[2] + s * ax[0];
+    R[8] = c + tt * ax[2] * ax[2];
     fk_scan_step<1>(R, p, l8);
     fk_scan_step<2>(R, p, l8);
     fk_scan_step<4>(R, p, l8);
+}
 
-    {
-        const T sp[3] = {M.glob(O_SITE_POS, 0), M.glob(O_SITE_POS, 1), M.glob(O_SITE_POS, 2)};
-        T t[3];
-        matvec(R, sp, t);
-        for (int k = 0; k < 3; ++k) site[k] = p[k] + t[k];      // as if the site sat on MY link; the caller picks the lane
-    }
-    // sphere centre for the contact row (needs R of the sphere's link, so it is taken here)
-    T ctr[3] = {T(0), T(0), T(0)};
-    if (I.n_sphere > 0) {
-        const T sp[3] = {M.glob(O_SPH_POS, 0), M.glob(O_SPH_POS, 1), M.glob(O_SPH_POS, 2)};
-        T t[3];
-        matvec(R, sp, t);
-        for (int k = 0; k < 3; ++k) ctr[k] = __shfl(p[k] + t[k], lane_of_link(lane, I.sph_link));
-    }
-
-    // 2. world-frame quantities of my link, everything about the WORLD ORIGIN
-    PHASE();
-    const T mass = M.link(O_MASS);
-    T a[3], cw[3], t3[3];
-    matvec(R, ax, a);                       // joint axis
+// 2. world-frame quantities of my link
+template <typename T, typename MT>
+__device__ __forceinline__ void link_frames(const MT& M, LinkFrame<T>& L) {
+    const T* R = L.R;
+    const T* p = L.p;
+    const T mass = L.mass = M.link(O_MASS);
+    T t3[3];
+    matvec(R, L.ax, L.a);                   // joint axis
     {
         const T com[3] = {M.link(O_COM, 0), M.link(O_COM, 1), M.link(O_COM, 2)};
         matvec(R, com, t3);
     }
+    T* cw = L.cw;
     for (int k = 0; k < 3; ++k) cw[k] = p[k] + t3[k];
-    T Ib[6];                                // rotational inertia about the origin: R I R^T + m(|c|^2 - c c^T)
+    T* Ib = L.Ib;                           // rotational inertia about the origin: R I R^T + m(|c|^2 - c c^T)
     {
         T Il[6], RI[9];
         for (int k = 0; k < 6; ++k) Il[k] = M.link(O_INERTIA, k);
@@ -291,11 +303,16 @@ __device__ __forceinline__ void arm_substep(const Model<T>& M, const ArmInts& I,
         Ib[4] = dot(RI + 0, R + 6) - mass * cw[0] * cw[2];
         Ib[5] = dot(RI + 3, R + 6) - mass * cw[1] * cw[2];
     }
-    T hm[3] = {mass * cw[0], mass * cw[1], mass * cw[2]};           // first moment m c
-    T sw[3] = {a[0], a[1], a[2]}, sv[3];                             // motion axis S = (a, p x a)
-    cross(p, a, sv);
+    for (int k = 0; k < 3; ++k) { L.hm[k] = mass * cw[k]; L.sw[k] = L.a[k]; }
+    cross(p, L.a, L.sv);
+}
 
-    // 3. spatial velocity V_i = sum_{k<=i} S_k qd_k and velocity-product acceleration
+// 3. joint-space bias force c(q, v) (Newton-Euler with zero joint acceleration, base acceleration -g)
+template <typename T, typename MT>
+__device__ __forceinline__ T bias_force(const MT& M, const LinkFrame<T>& L, T v, int l8) {
+    const T *sw = L.sw, *sv = L.sv, *Ib = L.Ib, *hm = L.hm;
+    const T mass = L.mass;
+    // spatial velocity V_i = sum_{k<=i} S_k qd_k and velocity-product acceleration
     T Vw[3], Vv[3];
     for (int k = 0; k < 3; ++k) {
         Vw[k] = psum(sw[k] * v, l8);
@@ -314,35 +331,38 @@ __device__ __forceinline__ void arm_substep(const Model<T>& M, const ArmInts& I,
         }
     }
     // body force  f = I A + V x* (I V),  I(w, v) = (Ib w + h x v, m v - h x w)
-    T bias;
-    {
-        T nV[3], fV[3], nA[3], fA[3], t1[3], t2[3];
-        symvec(Ib, Vw, nV);
-        cross(hm, Vv, t1);
-        cross(hm, Vw, t2);
-        for (int k = 0; k < 3; ++k) { nV[k] += t1[k]; fV[k] = mass * Vv[k] - t2[k]; }
-        symvec(Ib, Aw, nA);
-        cross(hm, Av, t1);
-        cross(hm, Aw, t2);
-        for (int k = 0; k < 3; ++k) { nA[k] += t1[k]; fA[k] = mass * Av[k] - t2[k]; }
-        T c1[3], c2[3], c3[3];
-        cross(Vw, nV, c1);
-        cross(Vv, fV, c2);
-        cross(Vw, fV, c3);
-        T fn[3], ff[3];
-        for (int k = 0; k < 3; ++k) {
-            fn[k] = ssum(nA[k] + c1[k] + c2[k], l8);
-            ff[k] = ssum(fA[k] + c3[k], l8);
-        }
-        bias = dot(sw, fn) + dot(sv, ff);
+    T nV[3], fV[3], nA[3], fA[3], t1[3], t2[3];
+    symvec(Ib, Vw, nV);
+    cross(hm, Vv, t1);
+    cross(hm, Vw, t2);
+    for (int k = 0; k < 3; ++k) { nV[k] += t1[k]; fV[k] = mass * Vv[k] - t2[k]; }
+    symvec(Ib, Aw, nA);
+    cross(hm, Av, t1);
+    cross(hm, Aw, t2);
+    for (int k = 0; k < 3; ++k) { nA[k] += t1[k]; fA[k] = mass * Av[k] - t2[k]; }
+    T c1[3], c2[3], c3[3];
+    cross(Vw, nV, c1);
+    cross(Vv, fV, c2);
+    cross(Vw, fV, c3);
+    T fn[3], ff[3];
+    for (int k = 0; k < 3; ++k) {
+        fn[k] = ssum(nA[k] + c1[k] + c2[k], l8);
+        ff[k] = ssum(fA[k] + c3[k], l8);
     }
+    return dot(sw, fn) + dot(sv, ff);
+}
 
-    // 4. composite inertia (suffix sums) and the mass matrix by diagonals
+// 4. composite inertia (suffix sums), the mass matrix by diagonals, and diagonal-major -> row-major through this
+// particle's 8x8 LDS tile: the solves read their rows from the tile instead of holding a second copy of the
+// matrix in registers.  Returns M[i][i] of my dof.
+template <typename T>
+__device__ __forceinline__ T mass_matrix_tile(const LinkFrame<T>& L, int l8, T* ldsM) {
+    const T *sw = L.sw, *sv = L.sv;
     T d[MAX_LINKS];
     {
-        T mc = ssum(mass, l8), hc[3], Ic[6];
-        for (int k = 0; k < 3; ++k) hc[k] = ssum(hm[k], l8);
-        for (int k = 0; k < 6; ++k) Ic[k] = ssum(Ib[k], l8);
+        T mc = ssum(L.mass, l8), hc[3], Ic[6];
+        for (int k = 0; k < 3; ++k) hc[k] = ssum(L.hm[k], l8);
+        for (int k = 0; k < 6; ++k) Ic[k] = ssum(L.Ib[k], l8);
         T Fn[3], Ff[3], t1[3], t2[3];
         symvec(Ic, sw, Fn);
         cross(hc, sv, t1);
@@ -350,8 +370,6 @@ __device__ __forceinline__ void arm_substep(const Model<T>& M, const ArmInts& I,
         for (int k = 0; k < 3; ++k) { Fn[k] += t1[k]; Ff[k] = mc * sv[k] - t2[k]; }
         mass_diagonals<0, T>(sw, sv, Fn, Ff, d);
     }
-    // diagonal-major -> row-major through this particle's 8x8 LDS tile; the solves below read their
-    // rows from the tile each time instead of holding a second copy of the matrix in registers
 #pragma unroll
     for (int sft = 0; sft < MAX_LINKS; ++sft) {
         if (l8 + sft < MAX_LINKS) {
@@ -359,12 +377,159 @@ __device__ __forceinline__ void arm_substep(const Model<T>& M, const ArmInts& I,
             ldsM[(l8 + sft) * LANES + l8] = d[sft];
         }
     }
-    LDS_WAVE_SYNC();
+    return d[0];
+}
 
-    // 5. smooth force: -bias + passive damping + motor
+// plane-sphere contact geometry (mjc_PlaneSphere): signed distance, and - if some particle of the wave is within
+// the margin - my dof's entry of the contact Jacobian row and the row velocity J v
+template <typename T, typename MT>
+__device__ __forceinline__ void contact_geometry(const MT& M, const ArmInts& I, const LinkFrame<T>& L,
+                                                 const T* ctr, T v, int l8, T& cdist, bool& cinst, T& jc, T& jv) {
+    const T pn[3] = {M.glob(O_PLANE_N, 0), M.glob(O_PLANE_N, 1), M.glob(O_PLANE_N, 2)};
+    const T sph_r = M.glob(O_SPH_R);
+    cdist = dot(ctr, pn) - M.glob(O_PLANE_D) - sph_r;
+    cinst = cdist < M.glob(O_SPH_MARGIN);
+    jc = T(0);
+    jv = T(0);
+    if (__any(cinst)) {
+        T r[3], ar[3];
+        for (int k = 0; k < 3; ++k) r[k] = ctr[k] - pn[k] * (sph_r + T(0.5) * cdist) - L.p[k];
+        cross(L.a, r, ar);
+        jc = (cinst && l8 <= I.sph_link) ? dot(pn, ar) : T(0);
+        jv = gsum(jc * v);
+    }
+}
+
+// q, v: state of my dof (updated).  aw: constraint-solver warm start (previous qacc).  (sq, cq) =
+// (sin q, cos q), advanced by angle addition.  rows: active-set memory.  tau_act: gear * clip(ctrl).
+// site: world position of the tracked site computed from the q this substep STARTED with (MuJoCo
+// runs kinematics before integrating), evaluated as if it were attached to the calling lane's link: only the
+// lane of the site's link holds the real one, and the caller broadcasts it when a value is consumed (once per
+// env step instead of once per substep).
+//
+// ROLE: below ~one wave per SIMD the launch lasts as long as ONE wavefront's serial program.  Such
+// launches therefore run TWO wavefronts per particle group (a 128-thread workgroup, the waves land on different SIMDs
+// of one CU) that split the substep's task graph and meet at three s_barriers through the particle's LDS block:
+//   DYN   kinematics, link frames, bias forces -> tau   [E1]  factor M + h B, explicit inverse    [E2]
+//         env-step records (inputs, action / cost / observations)                                 [E3] integrate
+//   SOLVE kinematics, link frames, mass matrix -> tile, constraint rows   [E1]  factor H = M + J'DJ, one column of
+//         H^-1 per lane, Newton iteration on the active set   [E2]   qacc = (M + h B)^-1 (tau + J'f)   [E3] integrate
+// Both waves integrate the same qacc with the same instructions, so their copies of (q, v, sin q, cos q) stay
+// bit-identical.  SOLO = one wave does everything (launches that fill the chip anyway).
+enum Role : int { SOLO = 0, DYN = 1, SOLVE = 2 };
+
+// Phase timing of one wavefront (developer builds: -DMJMPC_STAMPS, read back with tools/stamps.py).  Shader-clock
+// deltas between consecutive marks are summed per phase; workgroup 0 adds its sums to diag[2 + 16 * wave + phase]
+// (64-bit slots) when the rollout ends.  In product builds every member is empty.
+struct Stamps {
+#ifdef MJMPC_STAMPS
+    long long last, acc[16];
+    __device__ __forceinline__ void begin() { for (int k = 0; k < 16; ++k) acc[k] = 0; last = clock64(); }
+    __device__ __forceinline__ void mark(int k) { const long long t = clock64(); acc[k] += t - last; last = t; }
+    __device__ __forceinline__ void flush(unsigned* diag, int wave, int lane) {
+        if (diag && blockIdx.x == 0 && lane == 0)
+            for (int k = 0; k < 16; ++k) ((unsigned long long*)diag)[2 + 16 * wave + k] = (unsigned long long)acc[k];
+    }
+#else
+    __device__ __forceinline__ void begin() {}
+    __device__ __forceinline__ void mark(int) {}
+    __device__ __forceinline__ void flush(unsigned*, int, int) {}
+#endif
+};
+
+// cross-wave rendezvous of a DUO workgroup: LDS traffic of this wave has landed (lgkmcnt), global stores are NOT
+// waited for (__syncthreads() would drain vmcnt too and stall on the record stores of the env step)
+__device__ __forceinline__ void duo_barrier() {
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+}
+
+// active-set test of the constraint rows at acceleration aw (f32: a row whose residual is within rounding of zero
+// keeps its state - such rows otherwise flip back and forth until the iteration cap, seen a few times per 5e8
+// solves; f64 has never failed to settle and keeps the plain sign test)
+template <typename T>
+__device__ __forceinline__ void active_set(T aw, T sig, T aref, T jc, T arefc, bool inst, bool cinst, bool act,
+                                           bool cact, bool& act2, bool& cact2) {
+    if constexpr (sizeof(T) == 4) {
+        const T res = sig * aw - aref, resc = gsum(jc * aw) - arefc;
+        const T band = T(4e-6) * (fabs(aref) + fabs(aw) + T(1));
+        const T bandc = T(4e-6) * (fabs(arefc) + fabs(resc + arefc) + T(1));
+        act2 = inst && (act ? !(res > band) : (res < -band));
+        cact2 = cinst && (cact ? !(resc > bandc) : (resc < -bandc));
+    } else {
+        act2 = inst && (sig * aw - aref < T(0));
+        cact2 = cinst && (gsum(jc * aw) - arefc < T(0));
+    }
+}
+
+template <int ROLE, typename T, typename MT>
+__device__ __forceinline__ void arm_front(const MT& M, const ArmInts& I, T& q, T& v, T& aw, T& sq, T& cq,
+                                          int& rows, T tau_act, T* ldsM, int lane, int l8, T* site,
+                                          unsigned* diag, bool& free_step, Stamps& ST) {
+    free_step = false;
+    PHASE();
+    LinkFrame<T> L;
+    kinematics(M, sq, cq, l8, L);
+    if constexpr (ROLE != SOLVE) {
+        const T sp[3] = {M.glob(O_SITE_POS, 0), M.glob(O_SITE_POS, 1), M.glob(O_SITE_POS, 2)};
+        T t[3];
+        matvec(L.R, sp, t);
+        for (int k = 0; k < 3; ++k) site[k] = L.p[k] + t[k];    // as if the site sat on MY link; the caller picks the lane
+    }
+    // sphere centre for the contact row (needs R of the sphere's link, so it is taken here)
+    T ctr[3] = {T(0), T(0), T(0)};
+    if (ROLE != DYN && I.n_sphere > 0) {
+        const T sp[3] = {M.glob(O_SPH_POS, 0), M.glob(O_SPH_POS, 1), M.glob(O_SPH_POS, 2)};
+        T t[3];
+        matvec(L.R, sp, t);
+        for (int k = 0; k < 3; ++k) ctr[k] = __shfl(L.p[k] + t[k], lane_of_link(lane, I.sph_link));
+    }
+    ST.mark(0);         // kinematics
+    PHASE();
+    link_frames(M, L);
+    ST.mark(1);         // world-frame link quantities
+
+    if constexpr (ROLE == DYN) {
+        // 5. smooth force: -bias + passive damping + motor, handed to the SOLVE wave
+        const T bias = bias_force(M, L, v, l8);
+        ldsM[V_TAU + l8] = -bias - M.link(O_DAMPING) * v + tau_act;
+        ST.mark(2);     // velocities, bias forces
+        duo_barrier();                                  // E1: tau out; mass-matrix tile and Euler diagonal in
+        ST.mark(3);
+        // 8'. explicit inverse of the Euler matrix M + h B while the SOLVE wave works on the constraints: every lane
+        // holds the whole factorisation (struct Dense) and substitutes ITS unit vector - the same instruction stream
+        // as one solve yields all columns; the SOLVE wave then finishes the substep with a matrix-vector product
+        Dense<T> F;
+        F.load(ldsM, ldsM + V_DE);
+        F.factor();
+        T col[MAX_LINKS];
+#pragma unroll
+        for (int i = 0; i < MAX_LINKS; ++i) col[i] = (i == l8) ? T(1) : T(0);
+        F.solve(col);
+#pragma unroll
+        for (int i = 0; i < MAX_LINKS; ++i) ldsM[V_EI + l8 * LANES + i] = col[i];
+        ST.mark(6);     // Euler matrix: factorisation, inverse
+        duo_barrier();                                  // E2: inverse out
+        ST.mark(7);
+        return;
+    }
+
+    T bias = T(0);
+    if constexpr (ROLE == SOLO) bias = bias_force(M, L, v, l8);
+    T dgM = mass_matrix_tile(L, l8, ldsM);
     const T damping = M.link(O_DAMPING), h = M.glob(O_TIMESTEP);
-    const T dgM = d[0] + M.link(O_ARMATURE);
-    const T tau = -bias - damping * v + tau_act;
+    dgM += M.link(O_ARMATURE);
+    ldsM[V_DE + l8] = dgM + h * damping;
+    if constexpr (ROLE == SOLO) LDS_WAVE_SYNC();
+    ST.mark(4);         // (bias forces,) composite inertia, mass matrix, tile
+
+    // 5. smooth force: -bias + passive damping + motor (SOLVE: arrives from the DYN wave at E1)
+    T tau = -bias - damping * v + tau_act;
+    if constexpr (ROLE == SOLVE) {
+        duo_barrier();                                  // E1: tau in; tile and Euler diagonal out
+        ST.mark(3);
+        tau = ldsM[V_TAU + l8];
+    }
 
     // 6. constraint rows.  Limits: MuJoCo mj_instantiateLimit, strict dist < margin(=0)
     T sig = T(0), dist = T(0);
@@ -379,43 +544,100 @@ __device__ __forceinline__ void arm_substep(const Model<T>& M, const ArmInts& I,
     bool cinst = false;
     T jc = T(0), Dc = T(0), arefc = T(0);
     if (I.n_sphere > 0) {
-        const T pn[3] = {M.glob(O_PLANE_N, 0), M.glob(O_PLANE_N, 1), M.glob(O_PLANE_N, 2)};
-        const T sph_r = M.glob(O_SPH_R), margin = M.glob(O_SPH_MARGIN);
-        T cdist = dot(ctr, pn) - M.glob(O_PLANE_D) - sph_r;
-        cinst = cdist < margin;
+        T cdist, jv;
+        contact_geometry(M, I, L, ctr, v, l8, cdist, cinst, jc, jv);
         if (__any(cinst)) {
-            T r[3], ar[3];
-            for (int k = 0; k < 3; ++k) r[k] = ctr[k] - pn[k] * (sph_r + T(0.5) * cdist) - p[k];
-            cross(a, r, ar);
-            jc = (cinst && l8 <= I.sph_link) ? dot(pn, ar) : T(0);
-            T jv = gsum(jc * v);
-            row_params(M, cdist - margin, M.glob(O_SPH_INVW), jv, Dc, arefc);
+            row_params(M, cdist - M.glob(O_SPH_MARGIN), M.glob(O_SPH_INVW), jv, Dc, arefc);
             Dc = cinst ? Dc : T(0);
             arefc = cinst ? arefc : T(0);
         }
     }
-
-    // 7. primal active-set Newton on  1/2 a'Ma - tau'a + sum_active 1/2 D (J a - aref)^2, and
-    // 8. mj_Euler with implicit joint damping:  (M + h B) qacc = qfrc_smooth + qfrc_constraint.
-    //    Solver lanes (struct Dense): links 0-3 of a particle hold the Newton factor, links 4-7 the Euler
-    //    factor; right-hand sides and solutions travel through the particle's LDS vectors.
-    T qfrc_c = T(0);
-    const bool roleH = l8 < 4;
     const bool any_rows = __any(inst || cinst);
     if (!any_rows) rows = 0;
-    Dense<T> F;
-    ldsM[V_DE + l8] = dgM + h * damping;
     if (any_rows) {
         row_params(M, dist, M.link(O_DOF_INVW), sig * v, D, aref);
         D = inst ? D : T(0);
         aref = inst ? aref : T(0);
-        // initial active set: a row that existed in the previous substep keeps its state, a new row is
-        // assumed active (it appears because the joint moves into its limit); `rows` = inst | act<<1 |
-        // cinst<<2 | cact<<3 of the previous substep
-        bool act = inst && ((rows & 1) ? (rows & 2) != 0 : true);
-        bool cact = cinst && ((rows & 4) ? (rows & 8) != 0 : true);
-        bool changed = true;
-        const bool any_c = __any(cinst);
+    }
+    ST.mark(5);         // constraint rows
+    // initial active set: a row that existed in the previous substep keeps its state, a new row is assumed
+    // active (it appears because the joint moves into its limit); `rows` = inst | act<<1 | cinst<<2 | cact<<3
+    // of the previous substep
+    bool act = inst && ((rows & 1) ? (rows & 2) != 0 : true);
+    bool cact = cinst && ((rows & 4) ? (rows & 8) != 0 : true);
+    bool changed = false;
+    const bool any_c = __any(cinst);
+    T qfrc_c = T(0);
+
+    // 7. primal active-set Newton on  1/2 a'Ma - tau'a + sum_active 1/2 D (J a - aref)^2, and
+    // 8. mj_Euler with implicit joint damping:  (M + h B) qacc = qfrc_smooth + qfrc_constraint.
+    if constexpr (ROLE == SOLVE) {
+        // DUO: every lane factors the Newton matrix H = M + J'DJ and substitutes its own unit vector, i.e. holds one
+        // column (= row) of H^-1; the acceleration is then a dot product with the right-hand side, and the Euler
+        // solve a dot product with the row of (M + h B)^-1 the DYN wave has prepared meanwhile.
+        if (any_rows) {
+            if (any_c) ldsM[V_JC + l8] = jc;
+            changed = true;
+            for (int it = 0; it < NEWTON_MAXIT; ++it) {
+                T rhs = tau + (act ? D * sig * aref : T(0));
+                if (any_c) rhs += cact ? Dc * jc * arefc : T(0);
+                ldsM[V_DH + l8] = dgM + (act ? D : T(0));
+                ldsM[V_RH + l8] = rhs;
+                LDS_WAVE_SYNC();
+                Dense<T> F;
+                F.load(ldsM, ldsM + V_DH);
+                if (any_c && __any(cact)) {
+                    T jv[MAX_LINKS];
+#pragma unroll
+                    for (int i = 0; i < MAX_LINKS; ++i) jv[i] = ldsM[V_JC + i];
+                    F.add_rank1(cact ? Dc : T(0), jv);
+                }
+                F.factor();
+                T col[MAX_LINKS];
+#pragma unroll
+                for (int i = 0; i < MAX_LINKS; ++i) col[i] = (i == l8) ? T(1) : T(0);
+                F.solve(col);
+                ST.mark(it == 0 ? 6 : 9);               // factorisation + inverse / further iterations
+                T acc = T(0);
+#pragma unroll
+                for (int i = 0; i < MAX_LINKS; ++i) acc += col[i] * ldsM[V_RH + i];
+                aw = acc;
+                bool act2, cact2;
+                active_set(aw, sig, aref, jc, arefc, inst, cinst, act, cact, act2, cact2);
+                changed = (act2 != act) || (cact2 != cact);
+                act = act2;
+                cact = cact2;
+                ST.mark(it == 0 ? 8 : 9);               // acceleration + active-set check / further iterations
+                if (!__any(changed)) break;
+                LDS_WAVE_SYNC();                        // V_RH is rewritten
+            }
+            if (changed && diag) atomicAdd(diag, 1u);
+            rows = (inst ? 1 : 0) | (act ? 2 : 0) | (cinst ? 4 : 0) | (cact ? 8 : 0);
+            // qfrc_constraint = J^T f,  f = -D (J a - aref) on active rows
+            qfrc_c = act ? -D * (sig * aw - aref) * sig : T(0);
+            if (__any(cact)) {
+                T fcn = cact ? -Dc * (gsum(jc * aw) - arefc) : T(0);
+                qfrc_c += jc * fcn;
+            }
+        }
+        ldsM[V_RE + l8] = tau + qfrc_c;
+        duo_barrier();                                  // E2: inverse of the Euler matrix in
+        ST.mark(7);
+        T x = T(0);
+#pragma unroll
+        for (int i = 0; i < MAX_LINKS; ++i) x += ldsM[V_EI + l8 * LANES + i] * ldsM[V_RE + i];
+        ldsM[V_XE + l8] = x;
+        free_step = !any_rows;
+        ST.mark(10);    // constraint force, Euler product
+        return;
+    }
+
+    //    SOLO solver lanes (struct Dense): links 0-3 of a particle hold the Newton factor, links 4-7 the Euler
+    //    factor; right-hand sides and solutions travel through the particle's LDS vectors.
+    const bool roleH = l8 < 4;
+    Dense<T> F;
+    if (any_rows) {
+        changed = true;
         if (any_c) ldsM[V_JC + l8] = jc;
         for (int it = 0; it < NEWTON_MAXIT; ++it) {
             T rhs = tau + (act ? D * sig * aref : T(0));
@@ -433,6 +655,7 @@ __device__ __forceinline__ void arm_substep(const Model<T>& M, const ArmInts& I,
                 }
                 F.factor();
             }
+            ST.mark(it == 0 ? 6 : 9);                   // first factorisation / further iterations
             if (roleH) {
                 T b[MAX_LINKS];
 #pragma unroll
@@ -444,22 +667,11 @@ __device__ __forceinline__ void arm_substep(const Model<T>& M, const ArmInts& I,
             LDS_WAVE_SYNC();
             aw = ldsM[V_XH + l8];
             bool act2, cact2;
-            if constexpr (sizeof(T) == 4) {
-                // f32: a row whose residual is within rounding of zero keeps its state - such rows otherwise flip
-                // back and forth until the iteration cap (seen a few times per 5e8 solves).  f64 has never failed to
-                // settle and keeps the plain sign test.
-                const T res = sig * aw - aref, resc = gsum(jc * aw) - arefc;
-                const T band = T(4e-6) * (fabs(aref) + fabs(aw) + T(1));
-                const T bandc = T(4e-6) * (fabs(arefc) + fabs(resc + arefc) + T(1));
-                act2 = inst && (act ? !(res > band) : (res < -band));
-                cact2 = cinst && (cact ? !(resc > bandc) : (resc < -bandc));
-            } else {
-                act2 = inst && (sig * aw - aref < T(0));
-                cact2 = cinst && (gsum(jc * aw) - arefc < T(0));
-            }
+            active_set(aw, sig, aref, jc, arefc, inst, cinst, act, cact, act2, cact2);
             changed = (act2 != act) || (cact2 != cact);
             act = act2;
             cact = cact2;
+            ST.mark(it == 0 ? 8 : 9);                   // first solve + active-set check / further iterations
             if (!__any(changed)) break;
         }
         if (changed && diag) atomicAdd(diag, 1u);
@@ -486,13 +698,27 @@ __device__ __forceinline__ void arm_substep(const Model<T>& M, const ArmInts& I,
 #pragma unroll
         for (int i = 0; i < MAX_LINKS; ++i) ldsM[V_XE + i] = b[i];
     }
-    LDS_WAVE_SYNC();
+    free_step = !any_rows;
+    ST.mark(10);        // constraint force, Euler solve
+}
+
+// second half of a substep: take delivery of qacc and integrate (every role runs the same instructions)
+template <int ROLE, typename T, typename MT>
+__device__ __forceinline__ void arm_back(const MT& M, T& q, T& v, T& aw, T& sq, T& cq, T* ldsM, int l8,
+                                         bool free_step, Stamps& ST) {
+    ST.mark(11);        // DYN: env-step records
+    if constexpr (ROLE == SOLO) LDS_WAVE_SYNC();
+    else duo_barrier();                                 // E3
+    ST.mark(12);        // wait at B
+    const T h = M.glob(O_TIMESTEP);
     {
         T x = ldsM[V_XE + l8];
-        if (!any_rows) aw = x;
-        v += h * x;
-        const T dq = h * v;
-        q += dq;
+        if (free_step) aw = x;
+        // explicitly rounded products and sums: the two waves of a DUO group must compute bit-identical (q, v), so the
+        // compiler may not contract these differently in the two instantiations
+        v = add_rn(v, mul_rn(h, x));
+        const T dq = mul_rn(h, v);
+        q = add_rn(q, dq);
         // advance (sin q, cos q) by dq: angle addition with a short series, one Newton step of renormalisation.
         // Large steps (|dq| > 0.25 rad per substep, never seen with h = 0.01): series at dq / 256, doubled back up.
         T sd, cd;
@@ -512,6 +738,7 @@ __device__ __forceinline__ void arm_substep(const Model<T>& M, const ArmInts& I,
         cq = c1 * k;
     }
     LDS_WAVE_SYNC();            // the tile is rewritten by the next substep
+    ST.mark(13);        // integration
 }
 
 // ---- the rollout kernel -------------------------------------------------------------------------
@@ -527,26 +754,31 @@ __device__ __forceinline__ void arm_substep(const Model<T>& M, const ArmInts& I,
 // per SIMD to offer the dispatcher packs some SIMDs with three and leaves others with one, and the launch lasts as
 // long as the crowded ones (measured inside the control loop at 16 384 particles: 0.42 ms against 0.31 ms) - so
 // such launches use the instantiation capped at two.
-template <typename T, bool STEP, bool CL, int WAVES>
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WAVES, WAVES))) void arm_rollout_kernel(const T* __restrict__ model, const double* state,
+// DUO = two wavefronts per particle group (roles DYN / SOLVE above), for launches of at most half a wave per SIMD.
+template <typename T, bool STEP, bool CL, int WAVES, bool DUO>
+__global__ __launch_bounds__(DUO ? 128 : 64) __attribute__((amdgpu_waves_per_eu(WAVES, WAVES))) void arm_rollout_kernel(const T* __restrict__ model, const double* state,
                                                          long P, int H, int A, const double* __restrict__ mean,
                                                          const T* __restrict__ noise, T* __restrict__ cost,
                                                          T* __restrict__ act, T* __restrict__ obs,
                                                          T* __restrict__ nobs, double* state_out, unsigned* diag,
                                                          RolloutFusion fuse) {
     __shared__ __attribute__((aligned(16))) T lds[LANES * PSTRIDE + ARM_BLOB_LEN + 3];
-    const int lane = threadIdx.x;
+    static_assert(!(DUO && CL), "the closed-loop-linear variant runs one wave per particle group");
+    constexpr int NT = DUO ? 128 : 64;
+    const int lane = threadIdx.x & 63;
+    const int wave = DUO ? __builtin_amdgcn_readfirstlane(threadIdx.x >> 6) : 0;
     const int l8 = lane_link(lane), g = lane_slot(lane);
     const long pid = (long)blockIdx.x * LANES + g;
     const bool live = pid < P;
-    for (int k = lane; k < LANES * PSTRIDE; k += 64) lds[k] = T(0);
+    for (int k = threadIdx.x; k < LANES * PSTRIDE; k += NT) lds[k] = T(0);
     T* ldsModel = lds + LANES * PSTRIDE;
     if (fuse.shard_size > 0) model += ((long)blockIdx.x * LANES / fuse.shard_size) * ARM_BLOB_LEN;
     if (fuse.state_shard_size > 0) state += ((long)blockIdx.x * LANES / fuse.state_shard_size) * (2 * LANES + 3);
-    for (int k = lane; k < ARM_BLOB_LEN; k += 64) ldsModel[k] = model[k];
+    for (int k = threadIdx.x; k < ARM_BLOB_LEN; k += NT) ldsModel[k] = model[k];
     __syncthreads();
     T* ldsM = lds + g * PSTRIDE;
-    const Model<T> M{ldsModel, l8};
+    Model<T, DUO> M{ldsModel, l8};
+    M.cache();
     ArmInts I;
     I.site_link = (int)model[O_SITE_LINK];
     I.n_sphere = (int)model[O_N_SPHERE];
@@ -565,6 +797,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WAVES, WAVES
     int rows = 0;
     T cq = q, cv = v, chand[3] = {T(0), T(0), T(0)};
     const bool has_u = l8 < A;
+    Stamps ST;
+    ST.begin();
     double fb0 = 1.0, fb1 = 0.0, fb2 = 0.0, e1 = 0.0, e2 = 0.0, q0acc = 0.0;
     if (fuse.filt) { fb0 = fuse.filt[0]; fb1 = fuse.filt[1]; fb2 = fuse.filt[2]; }
 
@@ -574,8 +808,25 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WAVES, WAVES
         T qq = q, vv = v, aa = aw, ss = sinq, cc = cosq;
         int rr = 0;
         T s0[3];
-        arm_substep(M, I, qq, vv, aa, ss, cc, rr, T(0), ldsM, lane, l8, s0, (unsigned*)nullptr);
+        bool fs0;
+        arm_front<SOLO>(M, I, qq, vv, aa, ss, cc, rr, T(0), ldsM, lane, l8, s0, (unsigned*)nullptr, fs0, ST);
+        arm_back<SOLO>(M, qq, vv, aa, ss, cc, ldsM, l8, fs0, ST);
         for (int k = 0; k < 3; ++k) chand[k] = __shfl(s0[k], site_lane);
+    }
+
+    constexpr int R = DUO ? DYN : SOLO;
+    if constexpr (DUO) {
+        if (wave == 1) {            // the SOLVE wave: no inputs, no records - mass matrix, constraints, solves
+            bool fs;
+            T nosite[3];
+            for (int t = 0; t < H; ++t)
+                for (int sub = 0; sub < I.frame_skip; ++sub) {
+                    arm_front<SOLVE>(M, I, q, v, aw, sinq, cosq, rows, T(0), ldsM, lane, l8, nosite, diag, fs, ST);
+                    arm_back<SOLVE>(M, q, v, aw, sinq, cosq, ldsM, l8, fs, ST);
+                }
+            ST.flush(diag, 1, lane);
+            return;
+        }
     }
 
     // inputs of step t+1 are fetched while step t computes (a lone wave would otherwise sit out the full
@@ -623,11 +874,16 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WAVES, WAVES
         // MuJoCo clamps ctrl, not the record
         const T tau_act = M.link(O_GEAR) * fmin(fmax(u, M.link(O_CTRL_LO)), M.link(O_CTRL_HI));
         T site[3];
+        bool fs = false;
         for (int sub = 0; sub < I.frame_skip; ++sub) {
-            arm_substep(M, I, q, v, aw, sinq, cosq, rows, tau_act, ldsM, lane, l8, site, diag);
+            if (R == DYN && sub > 0) arm_back<R>(M, q, v, aw, sinq, cosq, ldsM, l8, fs, ST);
+            arm_front<R>(M, I, q, v, aw, sinq, cosq, rows, tau_act, ldsM, lane, l8, site, diag, fs, ST);
+            if constexpr (R == SOLO) arm_back<R>(M, q, v, aw, sinq, cosq, ldsM, l8, fs, ST);
             if (t == 0 && sub == 0 && obs)                  // fresh observation after set_env_state
                 for (int k = 0; k < 3; ++k) chand[k] = __shfl(site[k], site_lane);
         }
+        // DYN: the last substep is integrated further down - the cost record needs only its kinematics and is
+        // written while the SOLVE wave is still solving
         for (int k = 0; k < 3; ++k) site[k] = __shfl(site[k], site_lane);
         // Take delivery of the prefetched inputs HERE, before this step's stores are issued: loads and stores share
         // one in-order counter (vmcnt), and the register hand-over the compiler otherwise places on the loop's
@@ -638,6 +894,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WAVES, WAVES
         T cst = fabs(dx) + fabs(dy) + fabs(dz) + T(5) * sqrt_(dx * dx + dy * dy + dz * dz);
         if (live && l8 == 0) cost[pid * H + t] = cst;
         if (fuse.q0_out) q0acc += gs_cur * (double)cst;
+        if constexpr (R == DYN) arm_back<R>(M, q, v, aw, sinq, cosq, ldsM, l8, fs, ST);
         if (live && (obs || nobs)) {
             const long o = (pid * H + t) * dobs;
             if (obs) {
@@ -662,7 +919,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WAVES, WAVES
         cq = q;
         cv = v;
         for (int k = 0; k < 3; ++k) chand[k] = site[k];
+        ST.mark(14);    // observation records, loop
     }
+    ST.flush(diag, 0, lane);
     if (fuse.q0_out && live && l8 == 0) fuse.q0_out[pid] = q0acc;
     // "real env" stepping on the device: particle 0 writes its final (qpos, qvel) back into a state vector
     if (state_out && pid == 0 && l8 < nv) {
@@ -686,19 +945,27 @@ hipError_t launch_arm_rollout(const T* model, const double* state, long P, int H
     if (hipGetDevice(&dev) == hipSuccess) hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
     const long simds = 4L * cus;
     const int cap = ((long)grid <= 2 * simds || sizeof(T) == 8) ? 2 : 3;
-#define MJMPC_LAUNCH_W(STEP_, CL_, W_)                                                                               \
-    hipLaunchKernelGGL((arm_rollout_kernel<T, STEP_, CL_, W_>), dim3(grid), dim3(64), 0, stream, model, state, P, H, A, \
-                       mean, noise, cost, act, obs, nobs, state_out, diag, fuse)
-#define MJMPC_LAUNCH(STEP_, CL_)                          \
-    do {                                                  \
-        if constexpr (sizeof(T) == 8) {                   \
-            MJMPC_LAUNCH_W(STEP_, CL_, 2);                \
-        } else {                                          \
-            if (cap == 2) MJMPC_LAUNCH_W(STEP_, CL_, 2);  \
-            else MJMPC_LAUNCH_W(STEP_, CL_, 3);           \
-        }                                                 \
+    // two wavefronts per particle group while that still leaves every wave a SIMD of its own (P <= 4096 on 256 CUs);
+    // those kernels are capped at ONE resident wave per SIMD, which makes the dispatcher spread the 2 x 2 waves of
+    // the two workgroups a CU receives over its four SIMDs (0.253 -> 0.227 ms at 4096 particles with the cap).
+    // MJMPC_ARM_DUO=0/1 overrides the choice (developer switch for A/B timing).
+    static const int duo_env = [] { const char* e = getenv("MJMPC_ARM_DUO"); return e ? atoi(e) : -1; }();
+    const bool duo = !fuse.clw && (duo_env >= 0 ? duo_env != 0 : 2L * grid <= simds);
+#define MJMPC_LAUNCH_W(STEP_, CL_, W_, DUO_)                                                                        \
+    hipLaunchKernelGGL((arm_rollout_kernel<T, STEP_, CL_, W_, DUO_>), dim3(grid), dim3(DUO_ ? 128 : 64), 0, stream,  \
+                       model, state, P, H, A, mean, noise, cost, act, obs, nobs, state_out, diag, fuse)
+#define MJMPC_LAUNCH(STEP_, CL_)                                 \
+    do {                                                         \
+        if constexpr (sizeof(T) == 8) {                          \
+            MJMPC_LAUNCH_W(STEP_, CL_, 2, false);                \
+        } else {                                                 \
+            if (cap == 2) MJMPC_LAUNCH_W(STEP_, CL_, 2, false);  \
+            else MJMPC_LAUNCH_W(STEP_, CL_, 3, false);           \
+        }                                                        \
     } while (0)
     if (fuse.clw) MJMPC_LAUNCH(false, true);
+    else if (duo && state_out) MJMPC_LAUNCH_W(true, false, 1, true);
+    else if (duo) MJMPC_LAUNCH_W(false, false, 1, true);
     else if (state_out) MJMPC_LAUNCH(true, false);
     else MJMPC_LAUNCH(false, false);
 #undef MJMPC_LAUNCH

@@ -13,6 +13,9 @@
 #include "noise_mt.h"
 #include "update.h"
 
+// failure counter (one unsigned) followed by the phase-clock slots of developer builds (arm_rollout.hip, Stamps)
+constexpr size_t MJMPC_DIAG_BYTES = 8 * (2 + 32);
+
 namespace {
 
 thread_local char g_err[512] = "";
@@ -78,12 +81,12 @@ int mjmpc_arm_create(const double* blob, int n_blob, int device, mjmpc_arm_t* ou
     HIP_TRY(hipMalloc(&h->model_f32, sizeof(float) * n_blob));
     HIP_TRY(hipMalloc(&h->model_f64, sizeof(double) * n_blob));
     HIP_TRY(hipMalloc(&h->state, sizeof(double) * MJMPC_ARM_STATE_LEN));
-    HIP_TRY(hipMalloc(&h->diag, sizeof(unsigned)));
+    HIP_TRY(hipMalloc(&h->diag, MJMPC_DIAG_BYTES));
     HIP_TRY(hipHostMalloc(&h->pinned, sizeof(double) * MJMPC_ARM_STATE_LEN));
     HIP_TRY(hipMemcpy(h->model_f32, f32.data(), sizeof(float) * n_blob, hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(h->model_f64, blob, sizeof(double) * n_blob, hipMemcpyHostToDevice));
     HIP_TRY(hipMemset(h->state, 0, sizeof(double) * MJMPC_ARM_STATE_LEN));
-    HIP_TRY(hipMemset(h->diag, 0, sizeof(unsigned)));
+    HIP_TRY(hipMemset(h->diag, 0, MJMPC_DIAG_BYTES));
     *out = h;
     return 0;
 }
@@ -286,6 +289,17 @@ int mjmpc_arm_solver_failures(mjmpc_arm_t h, uint32_t* count) {
     *count = c;
     return 0;
 }
+
+#ifdef MJMPC_STAMPS
+// developer builds only (not declared in include/mjmpc_amd.h): read and clear the phase clocks
+extern "C" int mjmpc_debug_stamps(mjmpc_arm_t h, unsigned long long* out32) {
+    if (!h || !out32) return fail(MJMPC_E_BADARG, "null argument");
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemcpy(out32, (char*)h->diag + 16, 8 * 32, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemset((char*)h->diag + 16, 0, 8 * 32));
+    return 0;
+}
+#endif
 
 int mjmpc_analytic_rollout(int kind, const double* d_params, int n_state, int n_action, const double* d_state, int dtype,
                            int64_t P, int H, const double* d_mean, const void* d_noise, void* d_costs, void* d_actions,
