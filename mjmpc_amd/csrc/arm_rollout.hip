@@ -54,16 +54,34 @@ constexpr int NEWTON_MAXIT = 12;
 // stay in VGPRs - a lone wavefront otherwise sits out the LDS latency at the head of every phase.  Every call site
 // names the field with compile-time constants, so `reg` never becomes an indexed array, and the fields a wave's
 // role does not touch are dropped by the compiler.
+// The impedance constants of the constraint rows go to SGPRs the same way (with their reciprocals).
 constexpr int N_LINK_FIELDS = O_NV / LANES;
+__device__ __forceinline__ float uniform_(float x) { return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(x))); }
+__device__ __forceinline__ double uniform_(double x) {
+    return __hiloint2double(__builtin_amdgcn_readfirstlane(__double2hiint(x)), __builtin_amdgcn_readfirstlane(__double2loint(x)));
+}
 template <typename T, bool REG>
 struct Model {                 // view of the LDS copy of the model block
+    static constexpr bool cached = REG;
     const T* m;
     int l8;
     T reg[REG ? N_LINK_FIELDS : 1];
+    T inv_width, mid, inv_mid, inv_omid, dmin, ddiff, solB, solK;
+    int ipower;
     __device__ __forceinline__ void cache() {
-        if constexpr (REG)
+        if constexpr (REG) {
 #pragma unroll
             for (int k = 0; k < N_LINK_FIELDS; ++k) reg[k] = m[k * LANES + l8];
+            mid = uniform_(m[O_SOL_MID]);
+            inv_width = uniform_(rcp_(m[O_SOL_WIDTH]));
+            inv_mid = uniform_(rcp_(mid));
+            inv_omid = uniform_(rcp_(T(1) - mid));
+            dmin = uniform_(m[O_SOL_DMIN]);
+            ddiff = uniform_(m[O_SOL_DMAX] - m[O_SOL_DMIN]);
+            solB = uniform_(m[O_SOL_B]);
+            solK = uniform_(m[O_SOL_K]);
+            ipower = __builtin_amdgcn_readfirstlane((int)m[O_SOL_POWER]);
+        }
     }
     __device__ __forceinline__ T link(int off, int c = 0) const {
         if constexpr (REG) return reg[off / LANES + c];
@@ -115,6 +133,28 @@ __device__ __forceinline__ void fk_scan_step(T* R, T* p, int l8) {
 // MuJoCo mj_makeImpedance + mj_referenceConstraint for one scalar row (r = pos - margin)
 template <typename T, typename MT>
 __device__ __forceinline__ void row_params(const MT& M, T r, T diag_approx, T jv, T& D, T& aref) {
+    if constexpr (MT::cached) {
+        T x = fabs(r) * M.inv_width, y;
+        x = x > T(1) ? T(1) : x;
+        if (M.ipower == 2) {
+            T om = T(1) - x;
+            y = x <= M.mid ? x * x * M.inv_mid : T(1) - om * om * M.inv_omid;
+        } else if (M.ipower == 1) {
+            y = x;
+        } else {
+            const bool lo = x <= M.mid;
+            const T xa = lo ? x : T(1) - x, ia = lo ? M.inv_mid : M.inv_omid;
+            T qq = xa;
+            for (int k = 1; k < M.ipower; ++k) qq *= xa * ia;
+            y = lo ? qq : T(1) - qq;
+        }
+        const T imp = M.dmin + y * M.ddiff;
+        T Rr = (T(1) - imp) * rcp_(imp) * diag_approx;
+        Rr = Rr < T(1e-15) ? T(1e-15) : Rr;
+        D = rcp_(Rr);
+        aref = -M.solB * jv - M.solK * imp * r;
+        return;
+    }
     const T dmin = M.glob(O_SOL_DMIN), dmax = M.glob(O_SOL_DMAX), width = M.glob(O_SOL_WIDTH);
     const T mid = M.glob(O_SOL_MID), power = M.glob(O_SOL_POWER);
     T x = fabs(r) * rcp_(width), y;
@@ -478,11 +518,25 @@ __device__ __forceinline__ void arm_front(const MT& M, const ArmInts& I, T& q, T
     }
     // sphere centre for the contact row (needs R of the sphere's link, so it is taken here)
     T ctr[3] = {T(0), T(0), T(0)};
+    bool near_plane = false;
     if (ROLE != DYN && I.n_sphere > 0) {
         const T sp[3] = {M.glob(O_SPH_POS, 0), M.glob(O_SPH_POS, 1), M.glob(O_SPH_POS, 2)};
         T t[3];
         matvec(L.R, sp, t);
-        for (int k = 0; k < 3; ++k) ctr[k] = __shfl(L.p[k] + t[k], lane_of_link(lane, I.sph_link));
+        for (int k = 0; k < 3; ++k) t[k] += L.p[k];      // the centre as if the sphere sat on MY link
+        if constexpr (ROLE == SOLVE) {
+            // only the sphere link's lane holds the real centre; its distance test travels to the other lanes of
+            // the particle as one bit of a wave ballot, and the centre itself (6 ds_bpermute, ~21 cycles each for a
+            // lone wave) only when some particle of the wave is within the margin
+            const T pn[3] = {M.glob(O_PLANE_N, 0), M.glob(O_PLANE_N, 1), M.glob(O_PLANE_N, 2)};
+            const bool mine = dot(t, pn) - M.glob(O_PLANE_D) - M.glob(O_SPH_R) < M.glob(O_SPH_MARGIN);
+            const unsigned long long bal = __ballot(mine);
+            near_plane = (bal >> lane_of_link(lane, I.sph_link)) & 1ull;
+            if (__any(near_plane))
+                for (int k = 0; k < 3; ++k) ctr[k] = __shfl(t[k], lane_of_link(lane, I.sph_link));
+        } else {
+            for (int k = 0; k < 3; ++k) ctr[k] = __shfl(t[k], lane_of_link(lane, I.sph_link));
+        }
     }
     ST.mark(0);         // kinematics
     PHASE();
@@ -543,9 +597,13 @@ __device__ __forceinline__ void arm_front(const MT& M, const ArmInts& I, T& q, T
     // plane-sphere contact (condim 1): mjc_PlaneSphere + mj_instantiateContact
     bool cinst = false;
     T jc = T(0), Dc = T(0), arefc = T(0);
-    if (I.n_sphere > 0) {
+    if (I.n_sphere > 0 && (ROLE != SOLVE || __any(near_plane))) {
         T cdist, jv;
         contact_geometry(M, I, L, ctr, v, l8, cdist, cinst, jc, jv);
+        if constexpr (ROLE == SOLVE) {      // ctr is only valid where the ballot said so (same test, same operands)
+            cinst = cinst && near_plane;
+            jc = near_plane ? jc : T(0);
+        }
         if (__any(cinst)) {
             row_params(M, cdist - M.glob(O_SPH_MARGIN), M.glob(O_SPH_INVW), jv, Dc, arefc);
             Dc = cinst ? Dc : T(0);
@@ -604,11 +662,47 @@ __device__ __forceinline__ void arm_front(const MT& M, const ArmInts& I, T& q, T
                 aw = acc;
                 bool act2, cact2;
                 active_set(aw, sig, aref, jc, arefc, inst, cinst, act, cact, act2, cact2);
-                changed = (act2 != act) || (cact2 != cact);
+                const bool flip = act2 != act, cflip = cact2 != cact;
+                changed = flip || cflip;
                 act = act2;
                 cact = cact2;
                 ST.mark(it == 0 ? 8 : 9);               // acceleration + active-set check / further iterations
                 if (!__any(changed)) break;
+                // One limit row j of a particle changed state (the usual case): H' = H + c e_j e_j', c = +-D_j, and the
+                // right-hand side moves by d e_j, d = c sig_j aref_j.  With z = H^-1 e_j (lane i holds z_i = its
+                // column's entry j) Sherman-Morrison gives  a' = y - c z y_j / (1 + c z_j),  y = a + d z  - a few
+                // dozen instructions instead of a second factorisation.  Several flips in one particle, or a flip of
+                // the contact row, take the general path (next iteration refactors).
+                const float nflip = gsum(flip ? 1.0f : 0.0f);
+                if (!__any(cflip || nflip > 1.5f)) {
+                    if (flip) {
+                        T zjj = col[0];
+#pragma unroll
+                        for (int i = 1; i < MAX_LINKS; ++i) zjj = (l8 == i) ? col[i] : zjj;
+                        const T c = act ? D : -D;
+                        ldsM[V_XH + 0] = (T)l8;
+                        ldsM[V_XH + 1] = c;
+                        ldsM[V_XH + 2] = c * sig * aref;
+                        ldsM[V_XH + 3] = zjj;
+                        ldsM[V_XH + 4] = aw;
+                    }
+                    LDS_WAVE_SYNC();
+                    if (nflip > 0.5f) {
+                        const int j = (int)ldsM[V_XH + 0];
+                        const T c = ldsM[V_XH + 1], dl = ldsM[V_XH + 2], zjj = ldsM[V_XH + 3], aj = ldsM[V_XH + 4];
+                        T z = col[0];
+#pragma unroll
+                        for (int i = 1; i < MAX_LINKS; ++i) z = (j == i) ? col[i] : z;
+                        const T yj = aj + dl * zjj;
+                        aw = (aw + dl * z) - c * z * yj * rcp_(T(1) + c * zjj);
+                    }
+                    active_set(aw, sig, aref, jc, arefc, inst, cinst, act, cact, act2, cact2);
+                    changed = (act2 != act) || (cact2 != cact);
+                    act = act2;
+                    cact = cact2;
+                    ST.mark(9);
+                    if (!__any(changed)) break;
+                }
                 LDS_WAVE_SYNC();                        // V_RH is rewritten
             }
             if (changed && diag) atomicAdd(diag, 1u);
