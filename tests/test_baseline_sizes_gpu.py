@@ -1,0 +1,121 @@
+"""GPU parity at the sizes BASELINE.json quotes: the HIP path against the FP64 C oracle +
+the numpy controller restatement on the same seeded inputs, at full size.
+
+  * rollout, 1024 x 32 and 4096 x 32 (the launches that run two wavefronts per particle group): every cost vs
+    ``RefArm.rollout``, rel <= 1e-9;
+  * the SURVEY 7 "minimum slice": ``MPPI.optimize()`` driven by the HIP ``rollout_fn`` vs ``mppi_update`` on oracle
+    rollouts, identical host noise, 1024 x 32, lam = 0.01 (BASELINE) and lam = 5.0 (a softmax that is NOT an argmin);
+  * BASELINE config 3, CEM full covariance 16384 x 32, elite_frac 0.1: one whole step (HIP rollout + HIP update)
+    vs oracle rollout + ``cem_update``;
+  * f32 at 32768 particles (the three-waves-per-SIMD instantiation) within the stated f32 tolerance.
+The oracle runs OpenMP over particles: 16384 x 32 steps take ~0.2 s on the GPU box's 16 host threads.
+"""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+FILT = [0.25, 0.8, 0.0]
+START = dict(qp=np.zeros(7), qv=np.zeros(7), qa=np.zeros(7), target_pos=np.array([0.1, 0.1, 0.1]), timestep=0)
+MOVING = dict(qp=np.array([0.3, 0.5, -0.2, -1.0, 0.4, -0.6, 0.2]), qv=np.array([0.5, -1.0, 0.3, 2.0, -0.5, 1.0, 0.1]),
+              qa=np.zeros(7), target_pos=np.array([-0.25, 0.15, 0.2]), timestep=0)
+
+
+@pytest.fixture(scope="module")
+def eng64(raw_arm):
+    from mjmpc_amd.envs.arm_engine import ArmRolloutEngine
+    return ArmRolloutEngine(raw_arm, dtype="f64")
+
+
+def _filtered(P, H, A, seed, scale=1.0):
+    rs = np.random.RandomState(seed)
+    eps = scale * rs.standard_normal((P, H, A))
+    for t in range(2, H):
+        eps[:, t] = FILT[0] * eps[:, t] + FILT[1] * eps[:, t - 1] + FILT[2] * eps[:, t - 2]
+    return eps
+
+
+@pytest.mark.parametrize("P", [1024, 4096])
+@pytest.mark.parametrize("state", [START, MOVING], ids=["qpos0", "moving"])
+def test_rollout_matches_oracle_at_baseline_size(eng64, ref_arm, P, state):
+    H = 32
+    noise = _filtered(P, H, 7, 1000 + P)
+    mean = 0.2 * np.random.RandomState(P).standard_normal((H, 7))
+    eng64.set_env_state(state)
+    costs, act, _, _ = eng64.rollout_device(P, H, mean, noise, want_obs=False)
+    costs, act = costs.cpu().numpy(), act.cpu().numpy()
+    _, o_rew, o_act, _, _ = ref_arm.rollout(state["qp"], state["qv"], state["target_pos"], mean, noise, want_obs=False)
+    assert np.array_equal(act, o_act)
+    np.testing.assert_allclose(costs, -o_rew, rtol=1e-9, atol=1e-9)
+    assert eng64.solver_failures() == 0
+
+
+@pytest.mark.parametrize("lam", [0.01, 5.0])
+def test_mppi_minimum_slice_1024x32(eng64, ref_arm, lam):
+    """optimize() on the HIP engine == numpy MPPI on oracle rollouts, two consecutive control steps."""
+    from mjmpc_amd.control import MPPI
+    from mjmpc_amd.envs.arm_engine import make_rollout_fn
+    from oracle import controllers_ref as cr
+    P, H, A = 1024, 32, 7
+    ctrl = MPPI(d_state=eng64.d_state, d_obs=eng64.d_obs, d_action=A, horizon=H, init_cov=1.0, base_action="null",
+                lam=lam, num_particles=P, step_size=1.0, alpha=1, gamma=1.0, n_iters=1,
+                action_lows=eng64.action_lows, action_highs=eng64.action_highs, filter_coeffs=FILT, seed=123)
+    ctrl.set_sim_state_fn = eng64.set_env_state
+    ctrl.rollout_fn = make_rollout_fn(eng64)
+    mean, cov, gseq = np.zeros((H, A)), np.eye(A), cr.gamma_seq(1.0, H)
+    state = dict(START)
+    for step in range(2):
+        action, _ = ctrl.optimize(state)
+        noise = cr.generate_noise(cov, FILT, (P, H), 123 + step)
+        _, rew, act, _, _ = ref_arm.rollout(state["qp"], state["qv"], state["target_pos"], mean, noise, want_obs=False)
+        w = cr.softmax0((-1.0 / lam) * cr.cost_to_go(-rew, gseq)[:, 0])
+        if lam == 5.0:
+            assert np.sort(w)[-1] < 0.5            # genuinely a weighted mean, not the best particle
+        mean = cr.mppi_update(-rew, act, mean, cov, gseq, lam, 1, 1.0)
+        np.testing.assert_allclose(action, mean[0], rtol=0, atol=1e-9)
+        mean = cr.shift_mean(mean, "null")
+        np.testing.assert_allclose(ctrl.mean_action, mean, rtol=0, atol=1e-9)
+        # the "real" arm moves on with the oracle, so both sides plan from the same next state
+        q, v, _, _ = ref_arm.env_step(state["qp"], state["qv"], action, state["target_pos"])
+        state = dict(state, qp=q, qv=v)
+
+
+def test_cem_full_cov_16384x32_step(eng64, ref_arm):
+    """BASELINE config 3 on one GPU: rollout + elite selection + mean / full-covariance refit at size."""
+    from mjmpc_amd.control import CEM
+    from mjmpc_amd.envs.arm_engine import make_device_rollout_fn
+    from oracle import controllers_ref as cr
+    P, H, A = 16384, 32, 7
+    ctrl = CEM(d_state=eng64.d_state, d_obs=eng64.d_obs, d_action=A, horizon=H, init_cov=0.5, base_action="null",
+               elite_frac=0.1, num_particles=P, step_size=0.8, gamma=1.0, n_iters=1, beta=0.02, cov_type="full",
+               action_lows=eng64.action_lows, action_highs=eng64.action_highs, filter_coeffs=FILT, seed=7)
+    ctrl.set_sim_state_fn = eng64.set_env_state
+    ctrl.rollout_fn = make_device_rollout_fn(eng64)
+    action, _ = ctrl.optimize(dict(MOVING))
+    mean0, cov0 = np.zeros((H, A)), 0.5 * np.eye(A)
+    noise = cr.generate_noise(cov0, FILT, (P, H), 7)
+    _, rew, act, _, _ = ref_arm.rollout(MOVING["qp"], MOVING["qv"], MOVING["target_pos"], mean0, noise, want_obs=False)
+    mean1, cov1 = cr.cem_update(-rew, act, mean0, cov0, cr.gamma_seq(1.0, H), 0.1, 0.8, "full")
+    np.testing.assert_allclose(action, mean1[0], rtol=0, atol=1e-9)
+    np.testing.assert_allclose(ctrl.mean_action, cr.shift_mean(mean1, "null"), rtol=0, atol=1e-9)
+    np.testing.assert_allclose(ctrl.cov_action, cr.cem_shift_cov(cov1, 0.02, 0.5 * np.ones(A)), rtol=1e-9, atol=1e-12)
+    assert eng64.solver_failures() == 0
+
+
+def test_f32_three_waves_per_simd_32768(raw_arm, ref_arm):
+    """P > 16384 launches the f32 instantiation that keeps three waves per SIMD; stated f32 tolerance: costs within
+    2e-3 of the FP64 oracle (measured max in the test output), final joint angles within 2e-2."""
+    from mjmpc_amd.envs.arm_engine import ArmRolloutEngine
+    eng = ArmRolloutEngine(raw_arm, dtype="f32")
+    P, H = 32768, 32
+    noise = _filtered(P, H, 7, 4242).astype(np.float32).astype(np.float64)
+    mean = np.zeros((H, 7))
+    eng.set_env_state(MOVING)
+    costs, act, _, nobs = eng.rollout_device(P, H, mean, noise, want_obs=True)
+    costs, nobs = costs.cpu().numpy().astype(np.float64), nobs.cpu().numpy().astype(np.float64)
+    _, o_rew, _, _, o_nobs = ref_arm.rollout(MOVING["qp"], MOVING["qv"], MOVING["target_pos"], mean, noise)
+    err = np.abs(costs + o_rew)
+    print("f32 @ 32768: cost error max %.3e mean %.3e" % (err.max(), err.mean()))
+    assert err.max() < 2e-3
+    assert np.abs(nobs[:, -1, :7] - o_nobs[:, -1, :7]).max() < 2e-2
+    assert eng.solver_failures() == 0
