@@ -12,7 +12,9 @@ in HBM.  N > 1: weak scaling, each rank owns a contiguous block of 4096 particle
 record is all-gathered (RCCL over xGMI) once per iteration.
 
 Prints ONE JSON line (rank 0) with `roofline` (dominant kernel = arm_rollout_kernel, timed live with
-events on the launch stream) and `cpu_baseline` (oracle/ on the host cores, N = 1 only).
+events on the launch stream; the HBM block SURVEY 8d defines plus `valu`, the roofline that actually binds:
+FLOPs per particle-step COUNTED by the instrumented oracle build, oracle/flop_count.cpp) and `cpu_baseline`
+(oracle/ on the host cores, N = 1 only).
 """
 import argparse
 import json
@@ -97,6 +99,32 @@ def cpu_baseline(P, H, budget_s):
                       "one thread: %d particles in %.1f s%s" % (n, H, cores, dt, n1, dt1, quota)}
 
 
+def counted_flops(H):
+    """algorithmic FLOPs per particle-step, counted (not estimated) by running the instrumented build of
+    the oracle (oracle/flop_count.cpp: reacher_ref.c compiled with a counting scalar) on a sample of this workload."""
+    from mjmpc_amd.models.reacher7dof import reacher7dof_raw
+    from oracle.physics_ref import count_flops
+    rs = np.random.RandomState(123)
+    noise = rs.standard_normal((64, H, 7))
+    for t in range(2, H):
+        noise[:, t] = 0.25 * noise[:, t] + 0.8 * noise[:, t - 1]
+    d = count_flops(reacher7dof_raw().to_flat(), np.zeros(7), np.zeros(7), np.array([0.1, 0.1, 0.1]),
+                    np.zeros((H, 7)), noise)
+    d.pop("rew")
+    return d
+
+
+def profile_figure(name, dtype, P, H):
+    """A per-launch figure that needs PMC counters (separate rocprofv3 passes, MI355X_MICROARCH.md): measured
+    offline for the headline shape and kept under profiles/; other shapes report null."""
+    for rnd in ("r02", "r01"):
+        path = os.path.join(ROOT, "profiles", "%s_%s_%s_%dx%d.json" % (rnd, name, dtype, P, H))
+        if os.path.exists(path):
+            with open(path) as f:
+                return json.load(f), os.path.relpath(path, ROOT)
+    return None, None
+
+
 def main():
     args = parse()
     import torch
@@ -179,15 +207,25 @@ def main():
         dt = float(t.item())
 
     if graphed:
-        # inside a replayed graph there is nothing to bracket from the host: time the dominant kernel
-        # right here with events on its launch stream, 20 back-to-back launches on the run's own buffers
+        # inside a replayed graph there is nothing to bracket from the host: time the dominant kernel right here
+        # with events on its launch stream - 20 back-to-back launches of the SAME entry point the captured
+        # iteration uses (mjmpc_arm_rollout_fused: noise filter + cost-to-go fused in) on the run's own buffers
         noise_t = ctrl.dev._rec[("noise_mt" if args.noise == "mt19937" else "noise", args.dtype)]
+        fused = args.noise == "device"          # (the MT19937 sampler hands over filtered samples: plain entry point)
+        coeffs = ctrl.dev.record("coeffs", 3)
+
+        def launch():
+            if fused:
+                eng.rollout_fused(P_loc, H, ctrl.dev.mean, noise_t, coeffs, ctrl.dev.gseq)
+            else:
+                eng.rollout_device(P_loc, H, ctrl.dev.mean, noise_t)
+
         n_t = 20
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        eng.rollout_device(P_loc, H, ctrl.dev.mean, noise_t)
+        launch()
         e0.record()
         for _ in range(n_t):
-            eng.rollout_device(P_loc, H, ctrl.dev.mean, noise_t)
+            launch()
         e1.record()
         torch.cuda.synchronize()
         kern_ms = e0.elapsed_time(e1) / n_t
@@ -199,16 +237,27 @@ def main():
 
     # HBM bytes of one launch of the dominant kernel from the PMC counters (separate rocprofv3 passes,
     # FETCH_SIZE x2 on gfx950, calibrated on a known copy): measured offline, kept under profiles/
-    traffic = None
-    tpath = os.path.join(ROOT, "profiles", "r01_traffic_%s_%dx%d.json" % (args.dtype, P_loc, H))
-    if os.path.exists(tpath):
-        with open(tpath) as f:
-            traffic = json.load(f)["traffic_bytes_per_launch"]
+    tj, traffic_src = profile_figure("traffic", args.dtype, P_loc, H)
+    traffic = tj["traffic_bytes_per_launch"] if tj else None
+    ij, issue_src = profile_figure("valu_issue", args.dtype, P_loc, H)
 
     psteps = P_tot * H * ctrl.n_iters * args.steps
     s = 8 if args.dtype == "f64" else 4
     b_alg = (3 * A + 2) * s                       # delta in, action + cost out, action + cost re-read
     achieved = b_alg * P_loc * H / (kern_ms * 1e-3) / 1e9
+    valu = None
+    if rank == 0:
+        fl = counted_flops(H)
+        peak_tf = FP64_VALU_PEAK_TF if args.dtype == "f64" else FP32_VALU_PEAK_TF
+        tf = fl["flops"] * P_loc * H / (kern_ms * 1e-3) / 1e12
+        valu = {"bound": "valu", "flops_per_particle_step": fl["flops"],
+                "counted": {k: fl[k] for k in ("add", "mul", "div", "sqrt", "trig", "cmp")},
+                "counted_by": "oracle/flop_count.cpp (oracle/reacher_ref.c compiled with a counting scalar), 64 x H sample "
+                              "of this workload; an FMA counts as 2, compares are listed but not counted",
+                "achieved": tf, "peak": peak_tf, "unit": "TFLOP/s", "frac": tf / peak_tf,
+                # share of the chip's VALU issue slots the kernel's own instruction stream fills (SQ_INSTS_VALU x
+                # cycles per wave64 instruction / (SIMDs x duration x clock)): from the SQ PMC pass kept under profiles/
+                "issue_frac": ij["valu_issue_frac"] if ij else None, "issue_frac_source": issue_src}
     out = {
         "metric": "particle-steps/sec (reacher_7dof-v0 MPPI %dp x H%d per GPU, control loop incl. noise, rollout, update, shift)" % (P_loc, H),
         "value": psteps / dt, "unit": "particle-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -217,14 +266,20 @@ def main():
         "config": {"workload": "reacher_7dof-v0 MPPI lam=0.01 H=%d, %d particles per GPU (%d total), frame_skip 2, "
                                "filter [0.25,0.8,0], closed loop from qpos0 to target [0.1,0.1,0.1]" % (H, P_loc, P_tot),
                    "noise": args.noise, "particles_per_gpu": P_loc, "horizon": H,
+                   "ranks_seen": dist.get_world_size() if world > 1 else 1,
+                   "backend": (dist.get_backend() if world > 1 else None),
                    "launch": "hipGraph replay" if (graphed and not getattr(ctrl, "graph_fallback", False)) else "eager"},
         "control_loop_hz": args.steps / dt,
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                     "traffic_source": ("offline PMC passes, %s" % traffic_src) if traffic_src else None,
+                     "valu": valu,
                      "alg_bytes_per_launch": b_alg * P_loc * H,
                      "kernel": "arm_rollout_kernel<%s>" % ("double" if args.dtype == "f64" else "float"),
-                     "kernel_ms": kern_ms, "alg_bytes_per_particle_step": b_alg,
-                     "note": "latency/VALU-bound path (SURVEY 8d): ~100+ FLOP per byte, HBM fraction is small by construction"},
+                     "kernel_ms": kern_ms, "kernel_entry": ("mjmpc_arm_rollout_fused" if (graphed and args.noise == "device") else "mjmpc_arm_rollout"),
+                     "alg_bytes_per_particle_step": b_alg,
+                     "note": "latency/VALU-bound path (SURVEY 8d): ~160 counted FLOP per algorithmic byte, HBM fraction is small by "
+                             "construction; `valu` is the roofline that binds"},
         "solver_failures": fails, "final_distance_to_target": dist_to_target,
     }
     if rank == 0:

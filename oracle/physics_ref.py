@@ -22,6 +22,40 @@ def build(force=False):
     return so
 
 
+def build_flops(force=False):
+    """The FLOP-counting build of the same source (oracle/flop_count.cpp)."""
+    so = os.path.join(_HERE, "libreacher_flops.so")
+    srcs = [os.path.join(_HERE, f) for f in ("reacher_ref.c", "flop_count.cpp")]
+    if force or not os.path.exists(so) or os.path.getmtime(so) < max(os.path.getmtime(f) for f in srcs):
+        subprocess.check_call(["make", "-C", _HERE, "-B", "libreacher_flops.so"], stdout=subprocess.DEVNULL)
+    return so
+
+
+def count_flops(flat, qp0, qv0, target, mean, noise):
+    """Floating-point operations the oracle executes per particle-step of ``rollout``: a dict with the
+    tallies per kind and ``flops`` = add + mul + div + sqrt + trig (one each; compares are listed, not counted)."""
+    L = ctypes.CDLL(build_flops())
+    L.or_model_compile.restype = ctypes.c_void_p
+    L.or_model_compile.argtypes = [_dp, ctypes.c_int]
+    L.or_model_free.argtypes = [ctypes.c_void_p]
+    L.or_rollout.argtypes = [ctypes.c_void_p, _dp, _dp, _dp, ctypes.c_long, ctypes.c_int, _dp, _dp, _dp, _dp, _dp, _dp, _dp]
+    L.or_flops_get.argtypes = [ctypes.POINTER(ctypes.c_long)]
+    flat, mean, noise = _c(flat), _c(mean), _c(noise)
+    h = L.or_model_compile(_p(flat), flat.size)
+    P, H, nu = noise.shape
+    rew, act, done = np.zeros((P, H)), np.zeros((P, H, nu)), np.zeros((P, H))
+    L.or_flops_reset()
+    L.or_rollout(h, _p(_c(qp0)), _p(_c(qv0)), _p(_c(target)), P, H, _p(mean), _p(noise), None, _p(rew), _p(act), _p(done), None)
+    out = (ctypes.c_long * 6)()
+    L.or_flops_get(out)
+    L.or_model_free(h)
+    n = float(P * H)
+    d = dict(zip(("add", "mul", "div", "sqrt", "trig", "cmp"), (v / n for v in out)))
+    d["flops"] = d["add"] + d["mul"] + d["div"] + d["sqrt"] + d["trig"]
+    d["rew"] = rew
+    return d
+
+
 def _lib():
     global _LIB
     if _LIB is None:
