@@ -71,7 +71,12 @@ class DeviceUpdater:
         self.wnorm = torch.zeros(2, dtype=torch.float64, device=self.device)
         self._ws, self._ws_P = None, -1
         self._rec = {}
-        self.chol_status = torch.zeros(1, dtype=torch.int32, device=self.device)
+        # kernel-side error flags live in mapped pinned host memory (like the published action): the kernels store
+        # to them directly, the host reads them without a copy or a synchronisation (check_status)
+        self._status = torch.zeros(2, dtype=torch.int32).pin_memory()
+        self._status_np = self._status.numpy()
+        self.chol_status = self._status[0:1]
+        self.mt_status = self._status[1:2]
         self.mt_segments = 32            # workgroups generating the MT19937 stream in parallel (0/1 = serial)
 
     # ------------------------------------------------------------------ plumbing
@@ -249,6 +254,20 @@ class DeviceUpdater:
         _lib.check(self.lib.mjmpc_cem_final(_vp(crecs), G, P, self.H, self.A, float(num_elite), int(full_cov),
                                             float(step_size), _vp(self.mean), _vp(self.cov), _vp(ws), self.stream()))
 
+    def check_status(self):
+        """Raise if a sampler kernel has flagged an error since the last call (read after the action of a control
+        step has arrived, i.e. behind every kernel of that step): an indefinite covariance would otherwise turn into
+        NaN samples, mean and action without a word, and a short MT19937 stream would leave stale samples behind."""
+        st = self._status_np
+        if st[0] or st[1]:
+            chol, mt = int(st[0]), int(st[1])
+            st[:] = 0
+            if chol:
+                raise _lib.MjmpcError("the action covariance on the device is indefinite or not finite: its Cholesky "
+                                      "factor (sampler colouring) does not exist")
+            raise _lib.MjmpcError("device MT19937 sampler: the generated stream was too short for the requested "
+                                  "draw (status %d); samples are incomplete" % mt)
+
     def _q0_view(self, ws, P):
         addr = self.lib.mjmpc_workspace_q0(_vp(ws), P, self.H, self.A)
         off = (addr - ws.data_ptr()) // 8
@@ -321,7 +340,7 @@ class DeviceUpdater:
             self._rec["mt_first"] = first
             nbytes = self.lib.mjmpc_mt19937_workspace_bytes(first + n)
             self._rec["mt_ws"] = torch.empty((nbytes + 15) // 16 * 2, dtype=torch.float64, device=self.device)
-            self._rec["mt_status"] = torch.zeros(1, dtype=torch.int32, device=self.device)
+            self._rec["mt_status"] = self.mt_status
             # jump-ahead plan: serial head + MT_SEGMENTS workgroups (tables are host-computed once per size)
             head, seg, nseg = mt_jump.plan_segments(int(self.lib.mjmpc_mt19937_stream_words(first + n)), self.mt_segments)
             if nseg:

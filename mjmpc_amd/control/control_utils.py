@@ -21,17 +21,3 @@ def generate_noise(cov, filter_coeffs, shape, base_seed):
     for t in range(2, horizon):
         eps[:, t, :] = b0 * eps[:, t, :] + b1 * eps[:, t - 1, :] + b2 * eps[:, t - 2, :]
     return eps
-
-
-def scale_ctrl(ctrl, action_low_limit, action_up_limit, squash_fn="clip"):
-    """mjmpc/utils/control_utils.py:3-12 (unused by the open-loop controllers; kept for API parity)."""
-    ctrl = np.asarray(ctrl)
-    if ctrl.ndim == 1:
-        ctrl = ctrl[np.newaxis, :, np.newaxis]
-    half = (action_up_limit - action_low_limit) / 2.0
-    mid = (action_up_limit + action_low_limit) / 2.0
-    if squash_fn == "clip":
-        ctrl = np.clip(ctrl, -1.0, 1.0)
-    elif squash_fn == "tanh":
-        ctrl = np.tanh(ctrl)
-    return mid[np.newaxis, :] + ctrl * half[np.newaxis, :]

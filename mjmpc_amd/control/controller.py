@@ -285,8 +285,11 @@ class OLGaussianMPC(Controller):
         self._graph = None
         self._noise_valid = False
 
+    def _host_uploads_per_step(self):
+        return False            # subclasses whose _device_update uploads host tables on every call say True
+
     def _graph_capable(self):
-        return (self.noise_mode in ('device', 'device_mt19937') and getattr(self._rollout_fn, "accepts_device", False)
+        return (not self._host_uploads_per_step() and self.noise_mode in ('device', 'device_mt19937') and getattr(self._rollout_fn, "accepts_device", False)
                 and self.base_action in ('null', 'repeat') and self.sample_mode == 'mean'
                 and (self._static_cov() or (self._device_cov() and self.noise_mode == 'device'))
                 and (self.dev.comm.world_size == 1 or (self._fused_capable()
@@ -363,8 +366,8 @@ class OLGaussianMPC(Controller):
                                               dtype=self.noise_dtype, d_step=self._step_dev,
                                               particle_offset=self.dev.comm.rank * n_loc,
                                               device_cov_diagonal=self.cov_type == 'diagonal')
-            if self.use_zero_control_seq:
-                delta[-1] = (-self.dev.mean).to(delta.dtype)
+            if self.use_zero_control_seq and self.dev.comm.rank == self.dev.comm.world_size - 1:
+                delta[-1] = (-self.dev.mean).to(delta.dtype)    # the LAST particle of the whole set (olgaussian_mpc.py:110-111)
             traj = self._rollout_fn(n_loc, self.horizon, self.dev.mean, delta, mode="open_loop")
             self._device_update(traj)
         self._action_dev.copy_(self.dev.mean[0])
@@ -407,6 +410,10 @@ class OLGaussianMPC(Controller):
                     self._device_iteration()
                 self._graph = g
             except Exception as e:          # e.g. a collective that cannot be captured: run eagerly instead
+                if self.dev.comm.world_size > 1:
+                    # a rank that falls back alone would issue a different collective sequence than its peers
+                    raise RuntimeError("hipGraph capture of the sharded control iteration failed on rank %d: %s"
+                                       % (self.dev.comm.rank, e)) from e
                 import warnings
                 warnings.warn("hipGraph capture of the control iteration failed (%s); running eagerly" % (e,))
                 torch.cuda.synchronize(self.dev.device)
@@ -459,10 +466,13 @@ class OLGaussianMPC(Controller):
 
     def optimize(self, state, calc_val=False, hotstart=True):
         if getattr(self, "graph_fallback", False) and not calc_val and hotstart:
-            return self._optimize_eager_after_fallback(state)
-        if self._graph_on and not calc_val and hotstart:
-            return self._optimize_graphed(state)
-        return super().optimize(state, calc_val, hotstart)
+            out = self._optimize_eager_after_fallback(state)
+        elif self._graph_on and not calc_val and hotstart:
+            out = self._optimize_graphed(state)
+        else:
+            out = super().optimize(state, calc_val, hotstart)
+        self.dev.check_status()         # sampler error flags (host-visible memory: no copy, no synchronisation)
+        return out
 
     # -- shift / reset (olgaussian_mpc.py:116-135) -------------------------------------------------
     def _shift(self):

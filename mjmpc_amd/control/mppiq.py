@@ -28,6 +28,10 @@ class MPPIQ(OLGaussianMPC):
     def _static_cov(self):
         return self.alpha == 1
 
+    def _host_uploads_per_step(self):
+        return True             # td_lambda_returns uploads its weight table (and cov^-1) from the host on every update:
+                                # not capturable - enable_graph() refuses instead of failing inside the capture
+
     def _returns(self, trajectories):
         """mppiq.py:91-126: per-step total cost -> TD(lambda) returns, on the device."""
         qvals = trajectories.get("qvals") if hasattr(trajectories, "get") else None

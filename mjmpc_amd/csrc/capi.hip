@@ -47,7 +47,9 @@ struct mjmpc_arm_s {
     double* model_f64 = nullptr;
     double* state = nullptr;        // MJMPC_ARM_STATE_LEN
     unsigned* diag = nullptr;
-    double* pinned = nullptr;       // host staging for set_state
+    double* pinned = nullptr;       // host staging for set_state: a ring of STAGE_SLOTS vectors, one event each
+    hipEvent_t staged[4] = {nullptr, nullptr, nullptr, nullptr};
+    int stage_next = 0;
     int n_shards = 1;               // > 1: model_f32 / model_f64 hold one block per shard
     double* shard_states = nullptr; // n_state_shards state vectors (per-shard start states)
     int n_state_shards = 0;
@@ -82,7 +84,8 @@ int mjmpc_arm_create(const double* blob, int n_blob, int device, mjmpc_arm_t* ou
     HIP_TRY(hipMalloc(&h->model_f64, sizeof(double) * n_blob));
     HIP_TRY(hipMalloc(&h->state, sizeof(double) * MJMPC_ARM_STATE_LEN));
     HIP_TRY(hipMalloc(&h->diag, MJMPC_DIAG_BYTES));
-    HIP_TRY(hipHostMalloc(&h->pinned, sizeof(double) * MJMPC_ARM_STATE_LEN));
+    HIP_TRY(hipHostMalloc(&h->pinned, sizeof(double) * MJMPC_ARM_STATE_LEN * 4));
+    for (int k = 0; k < 4; ++k) HIP_TRY(hipEventCreateWithFlags(&h->staged[k], hipEventDisableTiming));
     HIP_TRY(hipMemcpy(h->model_f32, f32.data(), sizeof(float) * n_blob, hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(h->model_f64, blob, sizeof(double) * n_blob, hipMemcpyHostToDevice));
     HIP_TRY(hipMemset(h->state, 0, sizeof(double) * MJMPC_ARM_STATE_LEN));
@@ -155,6 +158,7 @@ int mjmpc_arm_destroy(mjmpc_arm_t h) {
     hipFree(h->diag);
     hipFree(h->shard_states);
     hipHostFree(h->pinned);
+    for (int k = 0; k < 4; ++k) if (h->staged[k]) hipEventDestroy(h->staged[k]);
     delete h;
     return 0;
 }
@@ -172,12 +176,18 @@ int mjmpc_arm_set_state(mjmpc_arm_t h, const double* qpos, const double* qvel, c
     if (!h || !qpos || !qvel || !target_pos) return fail(MJMPC_E_BADARG, "null argument");
     hipStream_t s = (hipStream_t)stream;
     HIP_TRY(hipSetDevice(h->device));
-    HIP_TRY(hipStreamSynchronize(s));            // the staging buffer may still be in flight
-    std::memset(h->pinned, 0, sizeof(double) * MJMPC_ARM_STATE_LEN);
-    std::memcpy(h->pinned, qpos, sizeof(double) * h->nv);
-    std::memcpy(h->pinned + mjmpc::LANES, qvel, sizeof(double) * h->nv);
-    std::memcpy(h->pinned + 2 * mjmpc::LANES, target_pos, sizeof(double) * 3);
-    HIP_TRY(hipMemcpyAsync(h->state, h->pinned, sizeof(double) * MJMPC_ARM_STATE_LEN, hipMemcpyHostToDevice, s));
+    // Staging ring: wait only for the copy that last used THIS slot (four calls ago), never for the stream - a
+    // captured control iteration still running on `s` keeps running while the next state is being staged.
+    const int slot = h->stage_next;
+    h->stage_next = (slot + 1) & 3;
+    HIP_TRY(hipEventSynchronize(h->staged[slot]));
+    double* stage = h->pinned + (size_t)slot * MJMPC_ARM_STATE_LEN;
+    std::memset(stage, 0, sizeof(double) * MJMPC_ARM_STATE_LEN);
+    std::memcpy(stage, qpos, sizeof(double) * h->nv);
+    std::memcpy(stage + mjmpc::LANES, qvel, sizeof(double) * h->nv);
+    std::memcpy(stage + 2 * mjmpc::LANES, target_pos, sizeof(double) * 3);
+    HIP_TRY(hipMemcpyAsync(h->state, stage, sizeof(double) * MJMPC_ARM_STATE_LEN, hipMemcpyHostToDevice, s));
+    HIP_TRY(hipEventRecord(h->staged[slot], s));
     return 0;
 }
 

@@ -532,20 +532,33 @@ __global__ void shift_kernel(double* __restrict__ mean, int H, int A, int mode, 
 // Device-resident covariance (CEM, DMD-MPC with update_cov): the factor the sampler colours its normals with is
 // computed where the covariance lives, so an adapting covariance never leaves the GPU.
 // chol = lower Cholesky factor of cov (numpy.linalg.cholesky in control_utils.generate_noise's place); one
-// workgroup, column by column.  *status = 1 if cov is not positive definite (the factor is then NaN).
+// workgroup, column by column.  The reference samples with np.random.multivariate_normal, whose SVD colouring
+// accepts positive SEMI-definite covariances (full-covariance CEM with fewer than A independent elite rows, a
+// variance that underflowed): a pivot that vanishes to rounding (|d| <= 1e-13 * largest diagonal entry) gets a zero
+// column - a valid factor L L' = cov of the rank-deficient matrix - instead of a NaN factor.  *status = 1 only for a
+// genuinely indefinite matrix (pivot below -tolerance) or non-finite input; the host raises on it
+// (DeviceUpdater.check_status).
 __global__ void cholesky_kernel(const double* __restrict__ cov, int A, double* __restrict__ chol, int* status) {
     __shared__ double L[64 * 64];
+    __shared__ double tol;
     const int i = threadIdx.x;
     if (i < A) for (int j = 0; j < A; ++j) L[i * A + j] = j <= i ? cov[i * A + j] : 0.0;
+    if (i == 0) {
+        double mx = 0.0;
+        for (int k = 0; k < A; ++k) mx = fmax(mx, fabs(cov[k * A + k]));
+        tol = 1e-13 * mx;
+    }
     __syncthreads();
     for (int k = 0; k < A; ++k) {
+        const double d = L[k * A + k];          // every lane reads the pivot before lane k overwrites it
+        const bool dead = !(d > tol);
+        __syncthreads();
         if (i == k) {
-            const double d = L[k * A + k];
-            if (!(d > 0.0) && status) *status = 1;
-            L[k * A + k] = sqrt(d);
+            if ((!(d >= -tol) || !(d == d)) && status) *status = 1;
+            L[k * A + k] = dead ? 0.0 : sqrt(d);
         }
         __syncthreads();
-        if (i > k && i < A) L[i * A + k] /= L[k * A + k];
+        if (i > k && i < A) L[i * A + k] = dead ? 0.0 : L[i * A + k] / L[k * A + k];
         __syncthreads();
         if (i > k && i < A) for (int j = k + 1; j <= i; ++j) L[i * A + j] -= L[i * A + k] * L[j * A + k];
         __syncthreads();

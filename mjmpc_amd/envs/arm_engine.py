@@ -108,8 +108,10 @@ class ArmRolloutEngine:
                                   for k in range(self.num_shards)]
 
     def get_env_state(self):
-        return [dict(qp=self._state["qp"].copy(), qv=self._state["qv"].copy(),
-                     qa=np.zeros(self.model.nv), target_pos=self._state["target_pos"].copy(), timestep=0)]
+        """One state dict - or, after a per-shard ``set_env_state``, one per shard (subproc_vec_env.py:253-256)."""
+        states = self._shard_state_list if getattr(self, "_per_shard_states", False) else [self._state]
+        return [dict(qp=st["qp"].copy(), qv=st["qv"].copy(), qa=np.zeros(self.model.nv),
+                     target_pos=st["target_pos"].copy(), timestep=0) for st in states]
 
     def rollout(self, num_particles, horizon, mean, noise, mode="open_loop"):
         """``SubprocVecEnv.rollout``: numpy in, numpy out, reference layouts.

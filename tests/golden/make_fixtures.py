@@ -298,6 +298,17 @@ def fx_e2e(ref):
          alpha=1, gamma=0.99, filter_coeffs=[0.25, 0.8, 0.0], **kw), 6, out)
     _e2e(ref, "pend_rs", w, s0, lambda: ref.RandomShooting(init_cov=0.8, base_action="null", step_size=1.0,
          gamma=1.0, filter_coeffs=[1.0, 0.0, 0.0], **kw), 4, out)
+    # the three olgaussian_mpc.py branches no other fixture takes:
+    #   use_zero_control_seq (:110-111: the last particle's perturbation is -mean, i.e. it rolls out zero controls),
+    #   base_action='random' (:122-123: the new last row comes from the GLOBAL numpy stream, which generate_noise
+    #   left just behind the (P, H) draw of this step), sample_mode='sample' (:72-75: action = mean[0] + one draw
+    #   seeded seed + 123 * num_steps)
+    _e2e(ref, "pend_zero", w, s0, lambda: ref.MPPI(init_cov=0.8, base_action="null", lam=0.1, step_size=0.9,
+         alpha=1, gamma=0.99, filter_coeffs=[0.25, 0.8, 0.0], use_zero_control_seq=True, **kw), 5, out)
+    _e2e(ref, "pend_random", w, s0, lambda: ref.MPPI(init_cov=0.8, base_action="random", lam=0.1, step_size=0.9,
+         alpha=1, gamma=0.99, filter_coeffs=[0.25, 0.8, 0.0], **kw), 5, out)
+    _e2e(ref, "pend_sample", w, s0, lambda: ref.MPPI(init_cov=0.8, base_action="null", lam=0.1, step_size=0.9,
+         alpha=1, gamma=0.99, filter_coeffs=[0.25, 0.8, 0.0], sample_mode="sample", **kw), 5, out)
     # ---------------- LQR  (d_state 3 (column vector), d_action 2)
     rs = np.random.RandomState(3)
     Amat = np.eye(3) + 0.05 * rs.randn(3, 3)

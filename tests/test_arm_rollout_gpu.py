@@ -291,3 +291,16 @@ def test_cubic_impedance_and_fast_joints(raw_arm):
         np.testing.assert_allclose(nobs, o_nobs, rtol=0, atol=1e-8)
     assert eng.solver_failures() == 0
     assert ref.newton_stats()["calls"] > 0                    # the limits really were active
+
+
+def test_get_env_state_after_per_shard_states(raw_arm):
+    """SubprocVecEnv.get_env_state returns one state per worker; after a per-shard set_env_state so does the engine."""
+    from mjmpc_amd.envs.arm_engine import ArmRolloutEngine
+    eng = ArmRolloutEngine(raw_arm, dtype="f64", num_shards=2)
+    s0 = dict(qp=np.zeros(7), qv=np.zeros(7), target_pos=np.array([0.1, 0.1, 0.1]))
+    s1 = dict(qp=0.1 * np.ones(7), qv=np.zeros(7), target_pos=np.array([0.2, 0.1, 0.1]))
+    eng.set_env_state([s0, s1])
+    got = eng.get_env_state()
+    assert len(got) == 2 and np.array_equal(got[1]["qp"], s1["qp"]) and np.array_equal(got[0]["target_pos"], s0["target_pos"])
+    eng.set_env_state(s0)
+    assert len(eng.get_env_state()) == 1

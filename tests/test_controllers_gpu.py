@@ -158,6 +158,22 @@ def test_e2e_pendulum_mppi(golden):
                                             gamma=0.99, filter_coeffs=[0.25, 0.8, 0.0], **kw), PendulumRef())
 
 
+@pytest.mark.parametrize("tag,extra", [("pend_zero", dict(use_zero_control_seq=True)),
+                                       ("pend_random", dict(base_action="random")),
+                                       ("pend_sample", dict(sample_mode="sample"))])
+def test_e2e_pendulum_mppi_branches(golden, tag, extra):
+    """The three olgaussian_mpc.py branches (:110-111 zero-control particle, :122-123 random last row from the
+    global numpy stream, :72-75 sampled action) against the reference's own optimize() sequences."""
+    from mjmpc_amd.control import MPPI
+    from oracle.envs_ref import PendulumRef
+    kw = dict(d_state=2, d_obs=3, d_action=1, horizon=10, num_particles=48, n_iters=1,
+              action_lows=np.array([-2.0]), action_highs=np.array([2.0]), seed=123)
+    args = dict(init_cov=0.8, base_action="null", lam=0.1, step_size=0.9, alpha=1, gamma=0.99,
+                filter_coeffs=[0.25, 0.8, 0.0])
+    args.update(extra)
+    _e2e(golden, tag, lambda: MPPI(**args, **kw), PendulumRef())
+
+
 def test_e2e_pendulum_rs(golden):
     from mjmpc_amd.control import RandomShooting
     from oracle.envs_ref import PendulumRef
@@ -412,3 +428,73 @@ def test_clgaussian_mpc_closed_loop_rollouts(golden):
     np.testing.assert_allclose(a, want, **TOL)
     with pytest.raises(ValueError):
         eng.rollout(Pn, Hn, g["pend_W"], g["pend_noise"], "closed_loop")
+
+
+def test_capture_failure_falls_back_to_eager(raw_arm, monkeypatch):
+    """controller.py, _optimize_graphed: if the runtime refuses to capture the control iteration the controller
+    warns once and runs the same iteration eagerly - the closed loop must walk through the same actions."""
+    import torch
+    from mjmpc_amd.control import MPPI
+    from mjmpc_amd.envs.arm_engine import ArmRolloutEngine, make_device_rollout_fn
+
+    def run(break_capture, steps=5):
+        eng = ArmRolloutEngine(raw_arm, dtype="f64")
+        c = MPPI(d_state=eng.d_state, d_obs=eng.d_obs, d_action=7, horizon=16, init_cov=1.0, base_action="null",
+                 lam=0.05, num_particles=256, step_size=1.0, alpha=1, gamma=1.0, n_iters=1,
+                 action_lows=eng.action_lows, action_highs=eng.action_highs, filter_coeffs=[0.25, 0.8, 0.0], seed=5,
+                 noise_mode="device")
+        c.rollout_fn = make_device_rollout_fn(eng)
+        c.set_sim_state_fn = lambda s: None
+        eng.set_env_state(dict(qp=np.array([0.1, 0.2, 0.0, -0.5, 0.0, -0.3, 0.0]), qv=np.zeros(7),
+                               target_pos=np.array([0.2, -0.1, 0.2])))
+        c.enable_graph(post_step=eng.step_state)
+        if break_capture:
+            class Refuse:
+                def __init__(self, *a, **k):
+                    raise RuntimeError("capture refused (test)")
+            monkeypatch.setattr(torch.cuda, "graph", Refuse)
+        acts = []
+        with pytest.warns(UserWarning, match="capture") if break_capture else _nullcontext():
+            for _ in range(steps):
+                a, _ = c.optimize({})
+                acts.append(a)
+        torch.cuda.synchronize()
+        assert bool(getattr(c, "graph_fallback", False)) == break_capture
+        return np.array(acts), eng.get_env_state()[0]
+
+    class _nullcontext:
+        def __enter__(self):
+            return None
+
+        def __exit__(self, *a):
+            return False
+
+    a_graph, _ = run(False)
+    a_eager, _ = run(True)
+    np.testing.assert_allclose(a_eager, a_graph, rtol=0, atol=1e-9)
+
+
+def test_semidefinite_covariance_samples_and_indefinite_raises():
+    """The device-resident covariance path factors cov on the GPU.  numpy's multivariate_normal (the reference's
+    sampler) accepts a positive SEMI-definite covariance; so does the kernel (zero column on a vanished pivot).
+    An indefinite covariance has no factor: the flag reaches the host and optimize() would raise (check_status)."""
+    import torch
+    from mjmpc_amd import _lib
+    from mjmpc_amd.control._device import DeviceUpdater
+    Pn, Hn, An = 20000, 4, 3
+    dev = DeviceUpdater(Hn, An, np.ones(Hn))
+    B = np.array([[1.0, 0.0], [0.5, 1.0], [-1.0, 2.0]])
+    cov = B @ B.T                                            # rank 2
+    dev.cov.copy_(torch.from_numpy(cov))
+    x = dev.sample_noise(Pn, None, [1.0, 0.0, 0.0], 3, 0).cpu().numpy().reshape(-1, An)
+    assert np.isfinite(x).all()
+    np.testing.assert_allclose(np.cov(x, rowvar=False), cov, rtol=0.05, atol=0.05)
+    L = dev._rec["chol"].cpu().numpy().reshape(An, An)
+    np.testing.assert_allclose(L @ L.T, cov, rtol=1e-12, atol=1e-12)
+    dev.check_status()                                       # nothing flagged
+    dev.cov.copy_(torch.from_numpy(np.diag([1.0, -0.5, 1.0])))
+    dev.sample_noise(Pn, None, [1.0, 0.0, 0.0], 3, 0)
+    torch.cuda.synchronize()
+    with pytest.raises(_lib.MjmpcError, match="indefinite"):
+        dev.check_status()
+    dev.check_status()                                       # the flag is cleared once reported

@@ -153,7 +153,8 @@ def test_lqr_mean_only(golden):
     assert np.array_equal(act, g["lqr_meanonly_act"])
 
 
-def _run_e2e(make_update, env, g, tag, P, H, A, seed, n_iters, noise_cov, coeffs, base="null"):
+def _run_e2e(make_update, env, g, tag, P, H, A, seed, n_iters, noise_cov, coeffs, base="null", zero_seq=False,
+             sample=False):
     """Controller.optimize() loop (controller.py:207-257) rebuilt from the oracle pieces."""
     mean = np.zeros((H, A))
     cov = noise_cov * np.eye(A)
@@ -163,9 +164,13 @@ def _run_e2e(make_update, env, g, tag, P, H, A, seed, n_iters, noise_cov, coeffs
         np.testing.assert_allclose(state, g[tag + "_states"][k], rtol=1e-12, atol=1e-12)
         for _ in range(n_iters):
             noise = cr.generate_noise(cov, coeffs, (P, H), seed + k)
+            if zero_seq:
+                noise[-1] = -mean                       # olgaussian_mpc.py:110-111
             obs, rew, act, done, nobs = er.rollout(env, state, P, H, mean, noise)
             mean, cov = make_update(-rew, act, mean, cov)
         a = mean[0].copy()
+        if sample:                                      # olgaussian_mpc.py:72-75
+            a = a + cr.generate_noise(cov, coeffs, (1, 1), seed + 123 * k).reshape(A)
         np.testing.assert_allclose(a, g[tag + "_actions"][k], rtol=1e-10, atol=1e-10)
         mean, cov = make_update.shift(mean, cov)
         state, _ = env.step(state, a)
@@ -181,6 +186,23 @@ def test_e2e_pendulum_mppi(golden):
         return cr.mppi_update(costs, actions, mean, cov, gs, 0.1, 1, 0.9), cov
     upd.shift = lambda mean, cov: (cr.shift_mean(mean, "null"), cov)
     _run_e2e(upd, er.PendulumRef(), g, "pend_mppi", 48, H, 1, 123, 1, 0.8, [0.25, 0.8, 0.0])
+
+
+def test_e2e_pendulum_mppi_branches(golden):
+    """use_zero_control_seq, base_action='random' (global numpy stream, left behind the step's (P, H) draw) and
+    sample_mode='sample' (olgaussian_mpc.py:110-111, 122-123, 72-75)."""
+    g = golden("e2e")
+    H = 10
+    gs = cr.gamma_seq(0.99, H)
+
+    def upd(costs, actions, mean, cov):
+        return cr.mppi_update(costs, actions, mean, cov, gs, 0.1, 1, 0.9), cov
+    upd.shift = lambda mean, cov: (cr.shift_mean(mean, "null"), cov)
+    _run_e2e(upd, er.PendulumRef(), g, "pend_zero", 48, H, 1, 123, 1, 0.8, [0.25, 0.8, 0.0], zero_seq=True)
+    _run_e2e(upd, er.PendulumRef(), g, "pend_sample", 48, H, 1, 123, 1, 0.8, [0.25, 0.8, 0.0], sample=True)
+    upd.shift = lambda mean, cov: (cr.shift_mean(mean, "random", np.array([0.8])), cov)
+    _run_e2e(upd, er.PendulumRef(), g, "pend_random", 48, H, 1, 123, 1, 0.8, [0.25, 0.8, 0.0])
+    assert np.abs(g["pend_random_final_mean"][-1]).max() > 0          # the random row really is there
 
 
 def test_e2e_lqr_cem(golden):
