@@ -190,6 +190,12 @@ int mjmpc_cem_elite_cov(int dtype, int64_t P, int H, int A, const void* d_action
                         const double* d_sum_records, int G, double* d_cov_record, void* d_ws, void* stream);
 int mjmpc_cem_final(const double* d_cov_records, int G, int64_t P, int H, int A, double n_elite, int full_cov,
                     double step_size, double* d_mean, double* d_cov, void* d_ws, void* stream);
+/* The sharded form with ONE record exchange after the q0 gather (two collectives per iteration): each GPU
+ * calls mjmpc_cem_elite_sums, then mjmpc_cem_elite_cov with ITS OWN sum record (G = 1: scatter about its own mean
+ * delta) and all-gathers  rec_g = { sum record [1 + H*A] | cov record [A*A] };  this call pools them (pairwise-
+ * variance identity; exactly the two-pass np.cov / np.var of cem.py:76-80 when G = 1) and updates mean and cov.   */
+int mjmpc_cem_combine(const double* d_records, int G, int H, int A, double n_elite, int full_cov, double step_size,
+                      double* d_mean, double* d_cov, void* stream);
 
 /* RandomShooting._update_distribution (mjmpc/control/random_shooting.py:52-62). */
 int mjmpc_rs_best(int dtype, int64_t P, int H, int A, const void* d_actions, int64_t offset, double* d_record,

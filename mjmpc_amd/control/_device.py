@@ -28,6 +28,9 @@ class SingleProcessComm:
     def all_gather_flat(self, t):
         return t
 
+    def all_agree(self, ok, device=None):
+        return bool(ok)
+
 
 class TorchDistComm:
     """One process per GPU over torch.distributed (backend "nccl" = RCCL over xGMI; "gloo" in CPU tests)."""
@@ -51,6 +54,15 @@ class TorchDistComm:
 
     def all_gather_flat(self, t):
         return self.all_gather(t).reshape(-1)
+
+    def all_agree(self, ok, device=None):
+        """True iff ``ok`` holds on EVERY rank (an all-reduce(MIN) outside any capture): ranks use it to take a
+        code path together - e.g. to drop from graph replay to eager launches as one, never alone."""
+        import torch
+        dev = device if self.backend == "nccl" else "cpu"
+        t = torch.tensor([1 if ok else 0], dtype=torch.int32, device=dev)
+        self._dist.all_reduce(t, op=self._dist.ReduceOp.MIN, group=self._group)
+        return bool(t.item())
 
 
 class DeviceUpdater:
@@ -243,16 +255,18 @@ class DeviceUpdater:
             q0 = self._q0_view(ws, P)
             q_all = self.comm.all_gather_flat(q0)
             q_all_ptr, P_all = _vp(q_all), P * G
-        srec = self.record("cem_sum", 1 + self.H * self.A)
+        # one record per GPU: { n_g | sum of elite actions | scatter of ITS elite deltas about ITS OWN mean } - the
+        # second (and last) exchange of the iteration; mjmpc_cem_combine pools the scatters
+        HA = self.H * self.A
+        rec = self.record("cem_rec", 1 + HA + self.A * self.A)
+        srec, crec = rec[:1 + HA], rec[1 + HA:]
         _lib.check(self.lib.mjmpc_cem_elite_sums(code, P, self.H, self.A, _vp(actions), q_all_ptr, P_all, rank * P,
                                                  int(num_elite), _vp(srec), _vp(ws), self.stream()))
-        srecs = self.comm.all_gather(srec)
-        crec = self.record("cem_cov", self.A * self.A)
-        _lib.check(self.lib.mjmpc_cem_elite_cov(code, P, self.H, self.A, _vp(actions), _vp(self.mean), _vp(srecs), G,
+        _lib.check(self.lib.mjmpc_cem_elite_cov(code, P, self.H, self.A, _vp(actions), _vp(self.mean), _vp(srec), 1,
                                                 _vp(crec), _vp(ws), self.stream()))
-        crecs = self.comm.all_gather(crec)
-        _lib.check(self.lib.mjmpc_cem_final(_vp(crecs), G, P, self.H, self.A, float(num_elite), int(full_cov),
-                                            float(step_size), _vp(self.mean), _vp(self.cov), _vp(ws), self.stream()))
+        recs = self.comm.all_gather(rec)
+        _lib.check(self.lib.mjmpc_cem_combine(_vp(recs), G, self.H, self.A, float(num_elite), int(full_cov),
+                                              float(step_size), _vp(self.mean), _vp(self.cov), self.stream()))
 
     def check_status(self):
         """Raise if a sampler kernel has flagged an error since the last call (read after the action of a control

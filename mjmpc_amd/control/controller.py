@@ -404,18 +404,20 @@ class OLGaussianMPC(Controller):
             self._step_dev.copy_(keep[1])
             self.dev.cov.copy_(keep[2])
             self._noise_valid = False       # the dry run left the samples of step + 1 behind
+            err = None
             try:
                 g = torch.cuda.CUDAGraph()
                 with torch.cuda.graph(g):
                     self._device_iteration()
                 self._graph = g
-            except Exception as e:          # e.g. a collective that cannot be captured: run eagerly instead
-                if self.dev.comm.world_size > 1:
-                    # a rank that falls back alone would issue a different collective sequence than its peers
-                    raise RuntimeError("hipGraph capture of the sharded control iteration failed on rank %d: %s"
-                                       % (self.dev.comm.rank, e)) from e
+            except Exception as e:          # e.g. a collective that cannot be captured
+                err = e
+            # Sharded runs decide TOGETHER (one all-reduce outside the capture): a rank that fell back alone would
+            # issue a different collective sequence than its peers.  Every rank then runs eagerly, or none does.
+            if not self.dev.comm.all_agree(err is None, self.dev.device):
                 import warnings
-                warnings.warn("hipGraph capture of the control iteration failed (%s); running eagerly" % (e,))
+                warnings.warn("hipGraph capture of the control iteration failed (%s); running eagerly"
+                              % (err if err is not None else "on another rank",))
                 torch.cuda.synchronize(self.dev.device)
                 self.dev.mean.copy_(keep[0])
                 self.dev.cov.copy_(keep[2])

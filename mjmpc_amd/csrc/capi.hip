@@ -446,6 +446,12 @@ int mjmpc_cem_final(const double* d_cov_records, int G, int64_t P, int H, int A,
                            (double*)d_ws, (hipStream_t)stream));
 }
 
+int mjmpc_cem_combine(const double* d_records, int G, int H, int A, double n_elite, int full_cov, double step_size,
+                      double* d_mean, double* d_cov, void* stream) {
+    if (!d_records || !d_mean || !d_cov) return fail(MJMPC_E_BADARG, "null argument");
+    PLAIN(mjmpc::cem_combine(d_records, G, H, A, n_elite, full_cov, step_size, d_mean, d_cov, (hipStream_t)stream));
+}
+
 int mjmpc_rs_best(int dtype, int64_t P, int H, int A, const void* d_actions, int64_t offset, double* d_record,
                   void* d_ws, void* stream) {
     if (!d_actions || !d_record || !d_ws) return fail(MJMPC_E_BADARG, "null argument");

@@ -39,6 +39,9 @@ hipError_t cem_elite_cov(const T* actions, const double* mean, const double* sum
                          double* crecord, double* ws, hipStream_t s);
 hipError_t cem_final(const double* crecords, int G, long P, int H, int A, double n_elite, int full, double step,
                      double* mean, double* cov, double* ws, hipStream_t s);
+// records[g] = {n_g | sum_elite a [H*A] | scatter of rank g's elite deltas about ITS OWN mean [A*A]} -> mean, cov
+hipError_t cem_combine(const double* records, int G, int H, int A, double n_elite, int full, double step, double* mean,
+                       double* cov, hipStream_t s);
 
 // Random shooting: {min q0, global index, action[H*A]} record and the combine.
 template <typename T>

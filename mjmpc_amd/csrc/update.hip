@@ -463,6 +463,59 @@ __global__ void cem_final_kernel(const double* __restrict__ crec, int G, int H, 
     if (j < HA) mean[j] = (1.0 - step) * mean[j] + step * elite_mean[j];
 }
 
+// Sharded CEM in ONE record exchange after the q0 gather (SURVEY 8e budgets two collectives per iteration): every
+// GPU sends  rec_g = { n_g | sum_elite a [H*A] | S_g [A*A] }  with S_g the scatter of ITS elite deltas about ITS OWN
+// mean delta mu_g; the pooled scatter about the global mean mu follows from the pairwise-variance identity
+//   S = sum_g S_g + sum_g (H n_g) (mu_g - mu)(mu_g - mu)'
+// which is as stable as the two-pass formula (no difference of large squares) and is exactly the two-pass result on
+// one GPU (mu_0 == mu, evaluated by the same expression).  One workgroup: new mean, new covariance (cem.py:76-86).
+__global__ void cem_combine_kernel(const double* __restrict__ rec, int G, int H, int A, double n_elite, int full,
+                                   double step, double* __restrict__ mean, double* __restrict__ cov) {
+    extern __shared__ double sh[];          // dsum[G][A] | mu[A]
+    const int HA = H * A, R = 1 + HA + A * A;
+    double* dsum = sh;
+    double* mu = sh + G * A;
+    double cnt = 0.0;
+    for (int g = 0; g < G; ++g) cnt += rec[(long)g * R];
+    for (int idx = threadIdx.x; idx < G * A; idx += blockDim.x) {
+        const int g = idx / A, a = idx % A;
+        const double* r = rec + (long)g * R;
+        double sacc = 0.0;
+        for (int t = 0; t < H; ++t) sacc += r[1 + t * A + a] / r[0] - mean[t * A + a];     // elite_mean_g - mean, as cem_mean_kernel
+        dsum[idx] = r[0] > 0.0 ? sacc / (double)H : 0.0;                                   // mu_g[a]
+    }
+    __syncthreads();
+    for (int a = threadIdx.x; a < A; a += blockDim.x) {
+        if (G == 1) { mu[a] = dsum[a]; continue; }
+        double sacc = 0.0;
+        for (int t = 0; t < H; ++t) {
+            double e = 0.0;
+            for (int g = 0; g < G; ++g) e += rec[(long)g * R + 1 + t * A + a];
+            sacc += e / cnt - mean[t * A + a];
+        }
+        mu[a] = sacc / (double)H;
+    }
+    __syncthreads();
+    for (int j = threadIdx.x; j < A * A; j += blockDim.x) {
+        const int i = j / A, k = j % A;
+        double C = 0.0;
+        for (int g = 0; g < G; ++g) {
+            const double* r = rec + (long)g * R;
+            C += r[1 + HA + j];
+            if (G > 1) C += (double)H * r[0] * (dsum[g * A + i] - mu[i]) * (dsum[g * A + k] - mu[k]);
+        }
+        const double N = (double)H * n_elite;
+        const double upd = full ? C / (N - 1.0) : (i == k ? C / N : 0.0);
+        cov[j] = (1.0 - step) * cov[j] + step * upd;
+    }
+    __syncthreads();                        // every read of the old mean is done
+    for (int j = threadIdx.x; j < HA; j += blockDim.x) {
+        double e = 0.0;
+        for (int g = 0; g < G; ++g) e += rec[(long)g * R + 1 + j];
+        mean[j] = (1.0 - step) * mean[j] + step * (e / cnt);
+    }
+}
+
 // ---- random shooting --------------------------------------------------------------------------------
 // first index of the minimum (np.argmin), single workgroup
 __global__ void argmin_kernel(const double* __restrict__ q, long P, double* __restrict__ out_val, long* __restrict__ out_idx) {
@@ -834,6 +887,14 @@ hipError_t cem_final(const double* crecords, int G, long P, int H, int A, double
     const int n = H * A > A * A ? H * A : A * A;
     hipLaunchKernelGGL(cem_final_kernel, dim3(nblocks(n, BLK)), dim3(BLK), 0, s, crecords, G, H, A, n_elite, full, step,
                        w.elite_mean, mean, cov);
+    return hipGetLastError();
+}
+
+hipError_t cem_combine(const double* records, int G, int H, int A, double n_elite, int full, double step, double* mean,
+                       double* cov, hipStream_t s) {
+    if (G < 1 || A < 1) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(cem_combine_kernel, dim3(1), dim3(BLK), sizeof(double) * (G + 1) * A, s, records, G, H, A, n_elite,
+                       full, step, mean, cov);
     return hipGetLastError();
 }
 

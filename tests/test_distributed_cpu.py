@@ -32,6 +32,9 @@ def _worker(rank, world, port, q):
         from mjmpc_amd.control.sharding import local_block, slice_local
         comm = TorchDistComm()
         assert (comm.rank, comm.world_size) == (rank, world)
+        # a code-path decision every rank takes together (graph replay -> eager fallback, controller.py)
+        assert comm.all_agree(True) is True
+        assert comm.all_agree(rank == 0) is False
         P, H, A, lam, step = 64, 6, 3, 0.05, 0.7
         rs = np.random.RandomState(42)                       # same data on every rank
         mean = rs.randn(H, A) * 0.2
@@ -54,20 +57,30 @@ def _worker(rank, world, port, q):
         np.testing.assert_allclose(c1, c_ref, rtol=1e-12, atol=1e-13)
         np.testing.assert_allclose(val, cr.dmd_value(costs, gs, lam), rtol=1e-12)
         np.testing.assert_allclose(m1, cr.mppi_update(costs, actions, mean, cov, gs, lam, 1, step), rtol=1e-12, atol=1e-13)
-        # ---- CEM: all-gather q0, global-rank elite flags, all-gather of elite sums
+        # ---- CEM: all-gather q0, global-rank elite flags, then ONE all-gather of {n_g | sum of elite actions |
+        # scatter of the rank's elite deltas about ITS OWN mean delta}, pooled by the pairwise-variance identity
+        # (mjmpc_cem_combine): two collectives per iteration
         k = int(P * 0.25)
         q0 = cr.cost_to_go(costs.copy(), gs)[:, 0]
         q_all = comm.all_gather_flat(torch.from_numpy(q0[off:off + n].copy())).numpy()
         assert np.array_equal(q_all, q0)                                       # worker-order concatenation
         flags = cr.elite_flags(q0[off:off + n], q_all, off, k)
-        srec = np.concatenate([[flags.sum()], actions[off:off + n][flags].sum(0).reshape(-1)])
-        srecs = comm.all_gather(torch.from_numpy(srec)).numpy()
-        assert srecs[:, 0].sum() == k
-        elite_mean = srecs[:, 1:].sum(0).reshape(H, A) / k
-        dbar = (elite_mean - mean).mean(0)
-        d = (actions[off:off + n][flags] - mean[None] - dbar).reshape(-1, A)
-        crecs = comm.all_gather(torch.from_numpy((d.T @ d).reshape(-1))).numpy()
-        cov_cem = (1 - step) * cov + step * crecs.sum(0).reshape(A, A) / (H * k - 1)
+        n_g = float(flags.sum())
+        asum = actions[off:off + n][flags].sum(0)
+        mu_g = (asum / n_g - mean).mean(0) if n_g else np.zeros(A)
+        d = (actions[off:off + n][flags] - mean[None] - mu_g).reshape(-1, A)
+        rec = np.concatenate([[n_g], asum.reshape(-1), (d.T @ d).reshape(-1)])
+        recs = comm.all_gather(torch.from_numpy(rec)).numpy()
+        assert recs[:, 0].sum() == k
+        elite_mean = recs[:, 1:1 + H * A].sum(0).reshape(H, A) / k
+        mu = (elite_mean - mean).mean(0)
+        S = np.zeros((A, A))
+        for r in recs:
+            S += r[1 + H * A:].reshape(A, A)
+            if r[0]:
+                dm = (r[1:1 + H * A].reshape(H, A) / r[0] - mean).mean(0) - mu
+                S += H * r[0] * np.outer(dm, dm)
+        cov_cem = (1 - step) * cov + step * S / (H * k - 1)
         mean_cem = (1 - step) * mean + step * elite_mean
         m_ref, c_ref = cr.cem_update(costs, actions, mean, cov, gs, 0.25, step, "full")
         np.testing.assert_allclose(mean_cem, m_ref, rtol=1e-12, atol=1e-13)

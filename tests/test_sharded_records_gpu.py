@@ -108,6 +108,24 @@ def test_cem_and_rs_records_combine(problem, G):
                                      "full" if full else "diagonal")
         np.testing.assert_allclose(d.get_mean(), m_ref, rtol=1e-12, atol=1e-12)
         np.testing.assert_allclose(d.get_cov(), c_ref, rtol=1e-11, atol=1e-12)
+    # CEM as the controllers run it: ONE record per GPU after the q0 gather (scatter about the rank's own mean
+    # delta), pooled by mjmpc_cem_combine - two collectives per iteration
+    recs = torch.empty((G, 1 + H * A + A * A), dtype=torch.float64, device="cuda")
+    for g, d in enumerate(devs):
+        d.set_mean(pr["mean"])
+        recs[g, :1 + H * A] = srecs[g]
+        _lib.check(lib.mjmpc_cem_elite_cov(_lib.F64, n, H, A, _vp(acts[g]), _vp(d.mean), _vp(srecs[g]), 1,
+                                           _vp(crecs[g]), _vp(d.workspace(n)), d.stream()))
+        recs[g, 1 + H * A:] = crecs[g]
+    for full in (1, 0):
+        d = devs[0]
+        d.set_mean(pr["mean"])
+        d.set_cov(pr["cov"])
+        _lib.check(lib.mjmpc_cem_combine(_vp(recs), G, H, A, float(k), full, step, _vp(d.mean), _vp(d.cov), d.stream()))
+        m_ref, c_ref = cr.cem_update(pr["costs"], pr["actions"], pr["mean"], pr["cov"], pr["gs"], 0.2, step,
+                                     "full" if full else "diagonal")
+        np.testing.assert_allclose(d.get_mean(), m_ref, rtol=1e-12, atol=1e-12)
+        np.testing.assert_allclose(d.get_cov(), c_ref, rtol=1e-11, atol=1e-12)
 
 
 @pytest.mark.parametrize("G", [2, 3, 4])
