@@ -113,6 +113,29 @@ int mjmpc_arm_rollout_fused(mjmpc_arm_t h, int dtype, int64_t P, int H, const do
 int mjmpc_arm_step_state(mjmpc_arm_t h, int dtype, const double* d_action, void* d_cost, void* d_next_obs,
                          void* stream);
 
+/* ---- tree engine: the same worker-pool replacement for models the serial-chain arm engine cannot hold ----------
+ * (first cut): a kinematic TREE of up to 32 hinge dofs, gravity, joint limits, up to 8 frictionless
+ * sphere/plane contacts, reacher-style reward and observation.  Constant block produced by
+ * mjmpc_amd/models/compile_tree.py::compile_tree and mirrored by mjmpc_amd/csrc/tree_model.h; per-link fields are
+ * [component][32 lanes], links numbered depth-first:
+ *   off[3][32] axis[3][32] mass[32] com[3][32] inertia[6][32] armature damping range_lo range_hi limited gear ctrl_lo
+ *   ctrl_hi dof_invweight0 parent subsize anc[5][32] ancmask[2][32] (each [32]) nv timestep frame_skip jumps site_link
+ *   site_pos[3] n_sphere plane_n[3] plane_d sol_K sol_B sol_dmin sol_dmax sol_width sol_mid sol_power gravity[3]
+ *   spheres[8][8] = {link, pos[3], r, margin, invweight, pad}
+ * Same call shapes and reference counterparts as the arm engine (subproc_vec_env.py:91-111, 128-186, 235-251).     */
+#define MJMPC_TREE_BLOB_LEN 1175
+/* Device state vector of a tree engine: qpos[32] | qvel[32] | target_pos[3]  (float64). */
+#define MJMPC_TREE_STATE_LEN 67
+typedef struct mjmpc_tree_s* mjmpc_tree_t;
+int mjmpc_tree_create(const double* model_blob, int n_blob, int device, mjmpc_tree_t* out);
+int mjmpc_tree_destroy(mjmpc_tree_t h);
+int mjmpc_tree_dims(mjmpc_tree_t h, int* nv, int* nu, int* d_obs);
+/* synchronous on `stream` (the state is staged from pageable memory) */
+int mjmpc_tree_set_state(mjmpc_tree_t h, const double* qpos, const double* qvel, const double* target_pos, void* stream);
+int mjmpc_tree_rollout(mjmpc_tree_t h, int dtype, int64_t P, int H, const double* d_mean, const void* d_noise,
+                       void* d_costs, void* d_actions, void* d_obs, void* d_next_obs, void* stream);
+int mjmpc_tree_solver_failures(mjmpc_tree_t h, uint32_t* count);
+
 /* rollout_fn over the reference's two analytic numpy envs (stateless; every pointer is a device
  * pointer): kind 0 = PendulumEnv (mjmpc/envs/basic/pendulum.py:33-50; d_params = [max_speed,
  * max_torque, dt, g, m, l], d_state = [th, thdot], observations have 3 entries), kind 1 = LQREnv

@@ -11,6 +11,8 @@
 #include "analytic_rollout.h"
 #include "arm_rollout.h"
 #include "noise_mt.h"
+#include "tree_model.h"
+#include "tree_rollout.h"
 #include "update.h"
 
 // failure counter (one unsigned) followed by the phase-clock slots of developer builds (arm_rollout.hip, Stamps)
@@ -53,6 +55,15 @@ struct mjmpc_arm_s {
     int n_shards = 1;               // > 1: model_f32 / model_f64 hold one block per shard
     double* shard_states = nullptr; // n_state_shards state vectors (per-shard start states)
     int n_state_shards = 0;
+};
+
+struct mjmpc_tree_s {
+    int device = 0;
+    int nv = 0, nu = 0, d_obs = 0;
+    float* model_f32 = nullptr;
+    double* model_f64 = nullptr;
+    double* state = nullptr;        // MJMPC_TREE_STATE_LEN
+    unsigned* diag = nullptr;
 };
 
 extern "C" {
@@ -310,6 +321,97 @@ extern "C" int mjmpc_debug_stamps(mjmpc_arm_t h, unsigned long long* out32) {
     return 0;
 }
 #endif
+
+/* ---- tree engine ------------------------------------------------------------------------------------ */
+int mjmpc_tree_create(const double* blob, int n_blob, int device, mjmpc_tree_t* out) {
+    if (!blob || !out) return fail(MJMPC_E_BADARG, "null argument");
+    if (n_blob != mjmpc::TREE_BLOB_LEN)
+        return fail(MJMPC_E_BADMODEL, "tree model blob has %d scalars, expected %d", n_blob, (int)mjmpc::TREE_BLOB_LEN);
+    const int nv = (int)blob[mjmpc::T_NV];
+    if (nv < 1 || nv > mjmpc::TL) return fail(MJMPC_E_BADMODEL, "nv = %d outside 1..%d", nv, mjmpc::TL);
+    if ((int)blob[mjmpc::T_N_SPHERE] > mjmpc::TREE_MAX_SPHERES) return fail(MJMPC_E_BADMODEL, "too many collision spheres");
+    if (mjmpc_device_count() <= device) return fail(MJMPC_E_NOGPU, "HIP device %d not present", device);
+    HIP_TRY(hipSetDevice(device));
+    mjmpc_tree_s* h = new mjmpc_tree_s();
+    h->device = device;
+    h->nv = h->nu = nv;
+    h->d_obs = 2 * nv + 6;
+    std::vector<float> f32(blob, blob + n_blob);
+    HIP_TRY(hipMalloc(&h->model_f32, sizeof(float) * n_blob));
+    HIP_TRY(hipMalloc(&h->model_f64, sizeof(double) * n_blob));
+    HIP_TRY(hipMalloc(&h->state, sizeof(double) * MJMPC_TREE_STATE_LEN));
+    HIP_TRY(hipMalloc(&h->diag, sizeof(unsigned)));
+    HIP_TRY(hipMemcpy(h->model_f32, f32.data(), sizeof(float) * n_blob, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(h->model_f64, blob, sizeof(double) * n_blob, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemset(h->state, 0, sizeof(double) * MJMPC_TREE_STATE_LEN));
+    HIP_TRY(hipMemset(h->diag, 0, sizeof(unsigned)));
+    *out = h;
+    return 0;
+}
+
+int mjmpc_tree_destroy(mjmpc_tree_t h) {
+    if (!h) return 0;
+    hipSetDevice(h->device);
+    hipFree(h->model_f32);
+    hipFree(h->model_f64);
+    hipFree(h->state);
+    hipFree(h->diag);
+    delete h;
+    return 0;
+}
+
+int mjmpc_tree_dims(mjmpc_tree_t h, int* nv, int* nu, int* d_obs) {
+    if (!h) return fail(MJMPC_E_BADARG, "null engine");
+    if (nv) *nv = h->nv;
+    if (nu) *nu = h->nu;
+    if (d_obs) *d_obs = h->d_obs;
+    return 0;
+}
+
+int mjmpc_tree_set_state(mjmpc_tree_t h, const double* qpos, const double* qvel, const double* target_pos,
+                         void* stream) {
+    if (!h || !qpos || !qvel || !target_pos) return fail(MJMPC_E_BADARG, "null argument");
+    HIP_TRY(hipSetDevice(h->device));
+    double st[MJMPC_TREE_STATE_LEN] = {0};
+    std::memcpy(st, qpos, sizeof(double) * h->nv);
+    std::memcpy(st + mjmpc::TL, qvel, sizeof(double) * h->nv);
+    std::memcpy(st + 2 * mjmpc::TL, target_pos, sizeof(double) * 3);
+    // pageable source: the runtime stages it before returning, so `st` may go out of scope
+    HIP_TRY(hipMemcpyAsync(h->state, st, sizeof(st), hipMemcpyHostToDevice, (hipStream_t)stream));
+    HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
+    return 0;
+}
+
+int mjmpc_tree_rollout(mjmpc_tree_t h, int dtype, int64_t P, int H, const double* d_mean, const void* d_noise,
+                       void* d_costs, void* d_actions, void* d_obs, void* d_next_obs, void* stream) {
+    if (!h || !d_mean || !d_costs) return fail(MJMPC_E_BADARG, "null argument");
+    if (P < 0 || H < 0) return fail(MJMPC_E_BADARG, "negative size");
+    HIP_TRY(hipSetDevice(h->device));
+    hipStream_t s = (hipStream_t)stream;
+    hipError_t e;
+    if (dtype == MJMPC_F32)
+        e = mjmpc::launch_tree_rollout<float>(h->model_f32, h->nv, h->state, (long)P, H, h->nu, d_mean,
+                                              (const float*)d_noise, (float*)d_costs, (float*)d_actions, (float*)d_obs,
+                                              (float*)d_next_obs, h->diag, s);
+    else if (dtype == MJMPC_F64)
+        e = mjmpc::launch_tree_rollout<double>(h->model_f64, h->nv, h->state, (long)P, H, h->nu, d_mean,
+                                               (const double*)d_noise, (double*)d_costs, (double*)d_actions,
+                                               (double*)d_obs, (double*)d_next_obs, h->diag, s);
+    else
+        return fail(MJMPC_E_BADARG, "unknown dtype %d", dtype);
+    if (e != hipSuccess) return hip_fail(e, "tree_rollout launch");
+    return 0;
+}
+
+int mjmpc_tree_solver_failures(mjmpc_tree_t h, uint32_t* count) {
+    if (!h || !count) return fail(MJMPC_E_BADARG, "null argument");
+    HIP_TRY(hipSetDevice(h->device));
+    HIP_TRY(hipDeviceSynchronize());
+    unsigned c = 0;
+    HIP_TRY(hipMemcpy(&c, h->diag, sizeof(unsigned), hipMemcpyDeviceToHost));
+    *count = c;
+    return 0;
+}
 
 int mjmpc_analytic_rollout(int kind, const double* d_params, int n_state, int n_action, const double* d_state, int dtype,
                            int64_t P, int H, const double* d_mean, const void* d_noise, void* d_costs, void* d_actions,

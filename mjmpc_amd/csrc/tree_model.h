@@ -1,0 +1,58 @@
+// Constant block of a compiled kinematic TREE of hinge links (mjmpc_amd/models/compile_tree.py, TREE_LAYOUT).
+// Offsets are in scalars; per-link fields are stored [component][32 lanes].  Links are numbered depth-first
+// (a link's subtree is the contiguous index range [i, i + subsize_i)), link frames are world-aligned at qpos0.
+#pragma once
+
+namespace mjmpc {
+
+constexpr int TL = 32;              // lanes per particle (one per link / dof)
+constexpr int TREE_MAX_SPHERES = 8;
+constexpr int TREE_SPH_STRIDE = 8;  // link, pos[3], r, margin, invweight, (pad)
+
+enum TreeOffset : int {
+    // the first 25 per-link fields are the arm block's, 32 lanes wide
+    T_OFF = 0,                          // 3 x 32   joint anchor minus the parent link's, world axes at qpos0
+    T_AXIS = T_OFF + 3 * TL,            // 3 x 32
+    T_MASS = T_AXIS + 3 * TL,
+    T_COM = T_MASS + TL,                // 3 x 32   relative to the joint anchor
+    T_INERTIA = T_COM + 3 * TL,         // 6 x 32   xx yy zz xy xz yz about the link's centre of mass
+    T_ARMATURE = T_INERTIA + 6 * TL,
+    T_DAMPING = T_ARMATURE + TL,
+    T_RANGE_LO = T_DAMPING + TL,
+    T_RANGE_HI = T_RANGE_LO + TL,
+    T_LIMITED = T_RANGE_HI + TL,
+    T_GEAR = T_LIMITED + TL,
+    T_CTRL_LO = T_GEAR + TL,
+    T_CTRL_HI = T_CTRL_LO + TL,
+    T_DOF_INVW = T_CTRL_HI + TL,
+    // topology
+    T_PARENT = T_DOF_INVW + TL,         // parent link, -1 for a root
+    T_SUBSIZE = T_PARENT + TL,          // links in my subtree, myself included
+    T_ANC = T_SUBSIZE + TL,             // 5 x 32: ancestor at distance 1, 2, 4, 8, 16 (-1: none)
+    T_ANCMASK = T_ANC + 5 * TL,         // 2 x 32: bits 0-15 / 16-31 of {j : link j is me or one of my ancestors}
+                                        // (two halves so that the f32 copy of the block holds them exactly)
+    // scalars
+    T_NV = T_ANCMASK + 2 * TL,
+    T_TIMESTEP,
+    T_FRAME_SKIP,
+    T_JUMPS,                            // pointer-jumping rounds = ceil(log2(tree depth))
+    T_SITE_LINK,
+    T_SITE_POS,                         // 3
+    T_N_SPHERE = T_SITE_POS + 3,
+    T_PLANE_N,                          // 3
+    T_PLANE_D = T_PLANE_N + 3,
+    T_SOL_K,
+    T_SOL_B,
+    T_SOL_DMIN,
+    T_SOL_DMAX,
+    T_SOL_WIDTH,
+    T_SOL_MID,
+    T_SOL_POWER,
+    T_GRAVITY,                          // 3
+    T_SPH = T_GRAVITY + 3,              // TREE_MAX_SPHERES x TREE_SPH_STRIDE
+    TREE_BLOB_LEN = T_SPH + TREE_MAX_SPHERES * TREE_SPH_STRIDE
+};
+
+static_assert(TREE_BLOB_LEN == 1175, "keep in sync with mjmpc_amd/models/compile_tree.py::TREE_LAYOUT");
+
+}  // namespace mjmpc

@@ -1,0 +1,576 @@
+// Fused rollout kernel for a kinematic TREE of hinge links (first cut): the same
+//   for b in particles: for t in horizon: env.step(mean[t] + noise[b,t])
+// double loop as arm_rollout.hip (reference mjmpc/envs/gym_env_wrapper.py:125-153, reacher-style reward and
+// observation, MuJoCo mj_step inlined), for models the 8-lane serial-chain kernel cannot hold: up to 32 hinge dofs on
+// a branching tree (a hand on an arm), gravity, joint limits, up to 8 frictionless sphere/plane contacts.
+//
+// Execution model: ONE PARTICLE = 32 LANES (lane = link = dof, links numbered depth-first), two particles per
+// wavefront, four wavefronts per workgroup sharing one LDS copy of the model block.  Lanes talk through a small
+// per-particle LDS area (a wavefront owns its area: in-order LDS, no s_barrier).  Everything is expressed in world
+// coordinates about the world origin, so the tree recursions become
+//   root-to-link accumulations  (forward kinematics, spatial velocity, velocity-product acceleration)
+//       = pointer jumping over the ancestor tables (ceil(log2 depth) rounds of "read my 2^k-th ancestor"),
+//   link-to-leaves accumulations (Newton-Euler forces, composite inertias)
+//       = range sums over the depth-first numbering: a doubling table T_k[i] = x_i + ... + x_{i+2^k-1} is built in
+//         log2(32) rounds and every link adds the blocks that tile [i, i + subtree size) - exact (no cancelling
+//         differences of prefix sums) and the same instruction stream for every topology.
+// The mass matrix lives one ROW PER LANE in registers (M[i][j] = S_j . F_i for j on the path to the root, the
+// other triangle by one transposition through LDS); H = M + J'DJ and M + hB are factored as dense LDL' with the
+// pivot column broadcast through LDS, solves likewise.  The soft-constraint problem is the arm kernel's primal
+// active-set Newton iteration, with several contact rows.
+#include <hip/hip_runtime.h>
+
+#include "lanegroup.h"
+#include "tree_model.h"
+#include "tree_rollout.h"
+
+namespace mjmpc {
+namespace {
+
+constexpr int TREE_MAXIT = 16;
+constexpr int WG_WAVES = 2;
+
+#define TSYNC()                                                \
+    do {                                                       \
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); \
+        asm volatile("" ::: "memory");                         \
+        __builtin_amdgcn_sched_barrier(0);                     \
+    } while (0)
+
+// per-particle LDS area, in scalars (NV = compile-time bound on the dofs)
+constexpr int A_X = 0;                      // 12 x 32 exchange (kinematics, path sums, doubling tables)
+constexpr int A_SF = A_X + 6 * TL;          // S[6][32] beside the first half of the exchange area (used apart from it)
+constexpr int A_MT = 0;                     // NV x (NV + 1) transposition tile, overlays A_X / A_SF
+constexpr int area0(int NV) { return NV * (NV + 1) > 12 * TL ? NV * (NV + 1) : 12 * TL; }
+constexpr int a_col(int NV) { return (area0(NV) + 3) / 4 * 4; }           // pivot column / broadcast vector
+constexpr int a_jc(int NV) { return a_col(NV) + TL; }                      // contact Jacobian rows [8][32]
+constexpr int a_cs(int NV) { return a_jc(NV) + TREE_MAX_SPHERES * TL; }    // per sphere: centre[3], dist, D, aref
+constexpr int a_misc(int NV) { return a_cs(NV) + TREE_MAX_SPHERES * 8; }   // site[3]
+constexpr int a_len(int NV) { return a_misc(NV) + 8; }
+
+template <typename T>
+__device__ __forceinline__ void cross3(const T* a, const T* b, T* c) {
+    c[0] = a[1] * b[2] - a[2] * b[1];
+    c[1] = a[2] * b[0] - a[0] * b[2];
+    c[2] = a[0] * b[1] - a[1] * b[0];
+}
+template <typename T>
+__device__ __forceinline__ T dot3(const T* a, const T* b) { return a[0] * b[0] + a[1] * b[1] + a[2] * b[2]; }
+template <typename T>
+__device__ __forceinline__ void mv3(const T* R, const T* x, T* y) {
+    for (int i = 0; i < 3; ++i) y[i] = R[3 * i] * x[0] + R[3 * i + 1] * x[1] + R[3 * i + 2] * x[2];
+}
+template <typename T>
+__device__ __forceinline__ void symv3(const T* S, const T* x, T* y) {      // xx yy zz xy xz yz
+    y[0] = S[0] * x[0] + S[3] * x[1] + S[4] * x[2];
+    y[1] = S[3] * x[0] + S[1] * x[1] + S[5] * x[2];
+    y[2] = S[4] * x[0] + S[5] * x[1] + S[2] * x[2];
+}
+
+// sum over the 32 lanes of a particle (contact rows only: rare path)
+template <typename T>
+__device__ __forceinline__ T sum32(T x) {
+    for (int o = 16; o > 0; o >>= 1) x += __shfl_xor(x, o);
+    return x;
+}
+
+struct Topo {       // my link's place in the tree (registers)
+    int parent, subsize, anc[5], jumps;
+    unsigned ancmask;
+};
+
+// x[c] <- sum over my path to the root (myself included) of x[c]: pointer jumping
+template <int NC, typename T>
+__device__ __forceinline__ void path_sum(T* x, const Topo& tp, T* X, int l) {
+    for (int k = 0; k < tp.jumps; ++k) {
+#pragma unroll
+        for (int c = 0; c < NC; ++c) X[c * TL + l] = x[c];
+        TSYNC();
+        const int a = tp.anc[k];
+        if (a >= 0) {
+#pragma unroll
+            for (int c = 0; c < NC; ++c) x[c] += X[c * TL + a];
+        }
+        TSYNC();
+    }
+}
+
+// x[c] <- sum over my subtree (myself included) of x[c]; subtree = links [l, l + subsize): doubling tables in two
+// LDS buffers of NC x 32, the blocks of sizes 2^k that tile the range are added as the tables appear
+template <int NC, typename T>
+__device__ __forceinline__ void subtree_sum(T* x, const Topo& tp, T* X, int l) {
+    static_assert(NC <= 6, "two buffers of NC x 32 must fit the 12 x 32 exchange area");
+    T cur[NC], acc[NC];
+#pragma unroll
+    for (int c = 0; c < NC; ++c) { cur[c] = x[c]; acc[c] = T(0); }
+    int pos = l;
+#pragma unroll
+    for (int k = 0; k < 6; ++k) {
+        T* buf = X + (k & 1) * NC * TL;
+#pragma unroll
+        for (int c = 0; c < NC; ++c) buf[c * TL + l] = cur[c];      // T_k[l]
+        TSYNC();
+        if ((tp.subsize >> k) & 1) {
+#pragma unroll
+            for (int c = 0; c < NC; ++c) acc[c] += buf[c * TL + pos];
+            pos += 1 << k;
+        }
+        if (k < 5) {
+            const int nb = l + (1 << k);
+            if (nb < TL) {
+#pragma unroll
+                for (int c = 0; c < NC; ++c) cur[c] += buf[c * TL + nb];   // T_{k+1}[l] = T_k[l] + T_k[l + 2^k]
+            }
+        }
+    }
+    TSYNC();
+#pragma unroll
+    for (int c = 0; c < NC; ++c) x[c] = acc[c];
+}
+
+// MuJoCo mj_makeImpedance + mj_referenceConstraint for one scalar row (r = pos - margin); constants from LDS
+template <typename T>
+__device__ __forceinline__ void tree_row_params(const T* m, T r, T diag_approx, T jv, T& D, T& aref) {
+    const T dmin = m[T_SOL_DMIN], dmax = m[T_SOL_DMAX], width = m[T_SOL_WIDTH], mid = m[T_SOL_MID];
+    const int n = (int)m[T_SOL_POWER];
+    T x = fabs(r) * rcp_(width), y;
+    x = x > T(1) ? T(1) : x;
+    const bool lo = x <= mid;
+    const T xa = lo ? x : T(1) - x, ma = lo ? mid : T(1) - mid;
+    T num = xa, den = T(1);
+    for (int k = 1; k < n; ++k) {           // integer power (the model compiler rejects anything else)
+        num *= xa;
+        den *= ma;
+    }
+    const T qq = num * rcp_(den);
+    y = n == 1 ? x : (lo ? qq : T(1) - qq);
+    const T imp = dmin + y * (dmax - dmin);
+    T Rr = (T(1) - imp) * rcp_(imp) * diag_approx;
+    Rr = Rr < T(1e-15) ? T(1e-15) : Rr;
+    D = rcp_(Rr);
+    aref = -m[T_SOL_B] * jv - m[T_SOL_K] * imp * r;
+}
+
+// Dense LDL' of the symmetric matrix whose row l lives in a[0..NV) of lane l (both triangles kept current, so that
+// after step k row k holds d_k l_jk for j > k: what the back substitution needs).  The pivot column travels through
+// the particle's LDS vector COL.  Rows >= nv are identity rows (spare lanes).
+template <int NV, typename T>
+__device__ __forceinline__ void ldl_factor(T* a, T* COL, int l) {
+#pragma unroll
+    for (int k = 0; k < NV; ++k) {
+        COL[l] = a[k];                      // a[l][k] of every lane = column k
+        TSYNC();
+        const T inv = rcp_(COL[k]);
+        const bool below = l > k;
+        const T lik = below ? a[k] * inv : T(0);
+#pragma unroll
+        for (int j = k + 1; j < NV; ++j) a[j] -= lik * COL[j];     // rows <= k: lik = 0, untouched
+        a[k] = below ? lik : a[k];
+        TSYNC();
+    }
+}
+
+// b <- (L D L')^-1 b, one entry per lane
+template <int NV, typename T>
+__device__ __forceinline__ T ldl_solve(const T* a, T b, T* COL, int l) {
+#pragma unroll
+    for (int k = 0; k < NV; ++k) {          // L y = b
+        COL[l] = b;
+        TSYNC();
+        const T yk = COL[k];
+        b -= (l > k ? a[k] : T(0)) * yk;
+        TSYNC();
+    }
+    T diag = l < NV ? a[0] : T(1);          // (lanes beyond NV carry no row)
+#pragma unroll
+    for (int k = 1; k < NV; ++k) diag = (l == k) ? a[k] : diag;
+    const T invd = rcp_(diag);
+#pragma unroll
+    for (int j = NV - 1; j >= 0; --j) {     // D L' x = y:  x_k = (y_k - sum_{j>k} (d_k l_jk) x_j) / d_k
+        const T xk = b * invd;              // final for lane j at this point
+        COL[l] = xk;
+        TSYNC();
+        const T xj = COL[j];
+        b -= (l < j ? a[j] : T(0)) * xj;
+        TSYNC();
+    }
+    return l < NV ? b * invd : T(0);
+}
+
+template <typename T, int NV>
+__global__ __launch_bounds__(64 * WG_WAVES) void tree_rollout_kernel(
+    const T* __restrict__ model, const double* __restrict__ state, long P, int H, int A, const double* __restrict__ mean,
+    const T* __restrict__ noise, T* __restrict__ cost, T* __restrict__ act, T* __restrict__ obs, T* __restrict__ nobs,
+    unsigned* diag) {
+    constexpr int A_COL = a_col(NV), A_JC = a_jc(NV), A_CS = a_cs(NV), A_MISC = a_misc(NV), A_LEN = a_len(NV);
+    __shared__ __attribute__((aligned(16))) T lds[TREE_BLOB_LEN + 1 + 2 * WG_WAVES * A_LEN];
+    T* M = lds;
+    for (int k = threadIdx.x; k < TREE_BLOB_LEN; k += blockDim.x) M[k] = model[k];
+    for (int k = threadIdx.x; k < 2 * WG_WAVES * A_LEN; k += blockDim.x) lds[TREE_BLOB_LEN + 1 + k] = T(0);
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int l = lane & 31, half = lane >> 5;
+    const long pid = ((long)blockIdx.x * WG_WAVES + wave) * 2 + half;
+    const bool live = pid < P;
+    T* X = lds + TREE_BLOB_LEN + 1 + (wave * 2 + half) * A_LEN;
+    T* COL = X + A_COL;
+    const int nv = (int)M[T_NV], frame_skip = (int)M[T_FRAME_SKIP], site_link = (int)M[T_SITE_LINK];
+    const int n_sphere = (int)M[T_N_SPHERE];
+    const int dobs = 2 * nv + 6;
+    Topo tp;
+    tp.parent = (int)M[T_PARENT + l];
+    tp.subsize = (int)M[T_SUBSIZE + l];
+    for (int k = 0; k < 5; ++k) tp.anc[k] = (int)M[T_ANC + k * TL + l];
+    tp.jumps = (int)M[T_JUMPS];
+    tp.ancmask = (unsigned)M[T_ANCMASK + l] | ((unsigned)M[T_ANCMASK + TL + l] << 16);
+    const bool dof = l < nv;
+
+    T q = dof ? (T)state[l] : T(0), v = dof ? (T)state[TL + l] : T(0);
+    const T tgt[3] = {(T)state[2 * TL], (T)state[2 * TL + 1], (T)state[2 * TL + 2]};
+    T sq, cq;
+    sincos_(q, sq, cq);
+    const T h = M[T_TIMESTEP];
+    const T damping = M[T_DAMPING + l], armature = M[T_ARMATURE + l];
+    const T pn[3] = {M[T_PLANE_N], M[T_PLANE_N + 1], M[T_PLANE_N + 2]};
+    const bool has_u = l < A;
+    int lim_mem = 0;                // inst | act << 1 of my limit row in the previous substep
+    unsigned con_mem = 0;           // contact rows of the previous substep: inst bits | act bits << 8
+    T hand_prev[3] = {T(0), T(0), T(0)}, q_prev = q, v_prev = v;
+
+    for (int t = 0; t < H; ++t) {
+        T u = T(0);
+        if (has_u) {
+            u = (T)mean[t * A + l];
+            if (noise && live) u += noise[(pid * H + t) * A + l];
+            if (act && live) act[(pid * H + t) * A + l] = u;        // unclipped (gym_env_wrapper.py:151)
+        }
+        const T tau_act = M[T_GEAR + l] * fmin(fmax(u, M[T_CTRL_LO + l]), M[T_CTRL_HI + l]);
+        T hand[3] = {T(0), T(0), T(0)};
+        for (int sub = 0; sub < frame_skip; ++sub) {
+            // ---- 1. forward kinematics: X_l = X_parent o (Rodrigues(axis, q), off), by pointer jumping
+            T R[9], p[3], ax[3];
+            {
+                const T s = sq, c = cq, tt = T(1) - cq;
+                for (int k = 0; k < 3; ++k) { ax[k] = M[T_AXIS + k * TL + l]; p[k] = M[T_OFF + k * TL + l]; }
+                R[0] = c + tt * ax[0] * ax[0];
+                R[1] = tt * ax[0] * ax[1] - s * ax[2];
+                R[2] = tt * ax[0] * ax[2] + s * ax[1];
+                R[3] = tt * ax[0] * ax[1] + s * ax[2];
+                R[4] = c + tt * ax[1] * ax[1];
+                R[5] = tt * ax[1] * ax[2] - s * ax[0];
+                R[6] = tt * ax[0] * ax[2] - s * ax[1];
+                R[7] = tt * ax[1] * ax[2] + s * ax[0];
+                R[8] = c + tt * ax[2] * ax[2];
+            }
+            for (int k = 0; k < tp.jumps; ++k) {
+#pragma unroll
+                for (int c = 0; c < 9; ++c) X[c * TL + l] = R[c];
+#pragma unroll
+                for (int c = 0; c < 3; ++c) X[(9 + c) * TL + l] = p[c];
+                TSYNC();
+                const int a = tp.anc[k];
+                if (a >= 0) {
+                    T Ra[9], pa[3], Rn[9], tv[3];
+#pragma unroll
+                    for (int c = 0; c < 9; ++c) Ra[c] = X[c * TL + a];
+#pragma unroll
+                    for (int c = 0; c < 3; ++c) pa[c] = X[(9 + c) * TL + a];
+                    for (int i = 0; i < 3; ++i)
+                        for (int j = 0; j < 3; ++j)
+                            Rn[3 * i + j] = Ra[3 * i] * R[j] + Ra[3 * i + 1] * R[3 + j] + Ra[3 * i + 2] * R[6 + j];
+                    mv3(Ra, p, tv);
+                    for (int c = 0; c < 3; ++c) p[c] = pa[c] + tv[c];
+                    for (int c = 0; c < 9; ++c) R[c] = Rn[c];
+                }
+                TSYNC();
+            }
+            // tracked site (its link's lane publishes it; consumed once per env step)
+            if (l == site_link) {
+                const T sp[3] = {M[T_SITE_POS], M[T_SITE_POS + 1], M[T_SITE_POS + 2]};
+                T tv[3];
+                mv3(R, sp, tv);
+                for (int k = 0; k < 3; ++k) X[A_MISC + k] = p[k] + tv[k];
+            }
+            // collision spheres: centre and signed distance, published by the sphere's link
+            for (int s = 0; s < n_sphere; ++s) {
+                const T* sp = M + T_SPH + s * TREE_SPH_STRIDE;
+                if (l == (int)sp[0]) {
+                    T tv[3], ctr[3];
+                    mv3(R, sp + 1, tv);
+                    for (int k = 0; k < 3; ++k) ctr[k] = p[k] + tv[k];
+                    for (int k = 0; k < 3; ++k) X[A_CS + s * 8 + k] = ctr[k];
+                    X[A_CS + s * 8 + 3] = dot3(ctr, pn) - M[T_PLANE_D] - sp[4];
+                }
+            }
+            TSYNC();
+            if (sub == frame_skip - 1 || (t == 0 && sub == 0))
+                for (int k = 0; k < 3; ++k) hand[k] = X[A_MISC + k];
+            if (t == 0 && sub == 0)
+                for (int k = 0; k < 3; ++k) hand_prev[k] = hand[k];     // fresh observation after set_env_state
+
+            // ---- 2. world-frame quantities of my link, about the world origin
+            const T mass = M[T_MASS + l];
+            T a[3], cw[3], tv[3], Ib[6], hm[3], sw[3], sv[3];
+            mv3(R, ax, a);
+            {
+                const T com[3] = {M[T_COM + l], M[T_COM + TL + l], M[T_COM + 2 * TL + l]};
+                mv3(R, com, tv);
+            }
+            for (int k = 0; k < 3; ++k) cw[k] = p[k] + tv[k];
+            {
+                T Il[6], RI[9];
+                for (int k = 0; k < 6; ++k) Il[k] = M[T_INERTIA + k * TL + l];
+                for (int i = 0; i < 3; ++i) {
+                    const T* r = R + 3 * i;
+                    RI[3 * i + 0] = r[0] * Il[0] + r[1] * Il[3] + r[2] * Il[4];
+                    RI[3 * i + 1] = r[0] * Il[3] + r[1] * Il[1] + r[2] * Il[5];
+                    RI[3 * i + 2] = r[0] * Il[4] + r[1] * Il[5] + r[2] * Il[2];
+                }
+                const T cc = dot3(cw, cw);
+                Ib[0] = dot3(RI + 0, R + 0) + mass * (cc - cw[0] * cw[0]);
+                Ib[1] = dot3(RI + 3, R + 3) + mass * (cc - cw[1] * cw[1]);
+                Ib[2] = dot3(RI + 6, R + 6) + mass * (cc - cw[2] * cw[2]);
+                Ib[3] = dot3(RI + 0, R + 3) - mass * cw[0] * cw[1];
+                Ib[4] = dot3(RI + 0, R + 6) - mass * cw[0] * cw[2];
+                Ib[5] = dot3(RI + 3, R + 6) - mass * cw[1] * cw[2];
+            }
+            for (int k = 0; k < 3; ++k) { hm[k] = mass * cw[k]; sw[k] = a[k]; }
+            cross3(p, a, sv);
+
+            // ---- 3. bias force: spatial velocity and velocity-product acceleration along the path to the root,
+            //         body forces summed over the subtree
+            T bias;
+            {
+                T V[6], Ac[6];
+                for (int k = 0; k < 3; ++k) { V[k] = sw[k] * v; V[3 + k] = sv[k] * v; }
+                T xw[3] = {V[0], V[1], V[2]}, xv[3] = {V[3], V[4], V[5]};
+                path_sum<6>(V, tp, X, l);
+                T dw[3], d1[3], d2[3];
+                cross3(V, xw, dw);
+                cross3(V, xv, d1);
+                cross3(V + 3, xw, d2);
+                for (int k = 0; k < 3; ++k) { Ac[k] = dw[k]; Ac[3 + k] = d1[k] + d2[k]; }
+                path_sum<6>(Ac, tp, X, l);
+                for (int k = 0; k < 3; ++k) Ac[3 + k] -= M[T_GRAVITY + k];          // base acceleration -g
+                // f = I A + V x* (I V),  I(w, v) = (Ib w + h x v, m v - h x w)
+                T nV[3], fV[3], nA[3], fA[3], t1[3], t2[3], c1[3], c2[3], c3[3], f[6];
+                symv3(Ib, V, nV);
+                cross3(hm, V + 3, t1);
+                cross3(hm, V, t2);
+                for (int k = 0; k < 3; ++k) { nV[k] += t1[k]; fV[k] = mass * V[3 + k] - t2[k]; }
+                symv3(Ib, Ac, nA);
+                cross3(hm, Ac + 3, t1);
+                cross3(hm, Ac, t2);
+                for (int k = 0; k < 3; ++k) { nA[k] += t1[k]; fA[k] = mass * Ac[3 + k] - t2[k]; }
+                cross3(V, nV, c1);
+                cross3(V + 3, fV, c2);
+                cross3(V, fV, c3);
+                for (int k = 0; k < 3; ++k) { f[k] = nA[k] + c1[k] + c2[k]; f[3 + k] = fA[k] + c3[k]; }
+                subtree_sum<6>(f, tp, X, l);
+                bias = dot3(sw, f) + dot3(sv, f + 3);
+            }
+
+            // ---- 4. composite inertia over the subtree, F = Ic S, mass matrix -> the particle's LDS tile MT (row l =
+            //         lane l's row; it stays there for the rest of the substep, the factorisations load copies)
+            T* MT = X + A_MT;
+            {
+                T c6[6] = {Ib[0], Ib[1], Ib[2], Ib[3], Ib[4], Ib[5]}, c4[4] = {mass, hm[0], hm[1], hm[2]};
+                subtree_sum<6>(c6, tp, X, l);
+                subtree_sum<4>(c4, tp, X, l);
+                T F[6], t1[3], t2[3];
+                symv3(c6, sw, F);
+                cross3(c4 + 1, sv, t1);
+                cross3(c4 + 1, sw, t2);
+                for (int k = 0; k < 3; ++k) { F[k] += t1[k]; F[3 + k] = c4[0] * sv[k] - t2[k]; }
+                T* S_ = X + A_SF;
+                for (int k = 0; k < 3; ++k) { S_[k * TL + l] = sw[k]; S_[(3 + k) * TL + l] = sv[k]; }
+                TSYNC();
+                // u[j] = S_j . F_l, meaningful where j is on my path to the root (myself included); spare lanes
+                // (l >= nv) hold identity rows, which keeps the factorisations regular
+                T urow[NV];
+#pragma unroll
+                for (int j = 0; j < NV; ++j) {
+                    T s = T(0);
+#pragma unroll
+                    for (int c = 0; c < 6; ++c) s += S_[c * TL + j] * F[c];
+                    s = (j == l) ? s + armature : s;
+                    urow[j] = dof ? (((tp.ancmask >> j) & 1u) ? s : T(0)) : ((j == l) ? T(1) : T(0));
+                }
+                TSYNC();                    // S_ lies inside the tile
+                if (l < NV) {
+#pragma unroll
+                    for (int j = 0; j < NV; ++j) MT[l * (NV + 1) + j] = urow[j];
+                }
+                TSYNC();
+                // the other triangle: M[l][j] = u_j[l] for j in my subtree (entries right of the diagonal; the lanes
+                // they are read from only write right of THEIR diagonal, i.e. elsewhere)
+                if (l < NV) {
+#pragma unroll
+                    for (int j = 0; j < NV; ++j)
+                        if (j > l && j < l + tp.subsize) MT[l * (NV + 1) + j] = MT[j * (NV + 1) + l];
+                }
+                TSYNC();
+            }
+            const T tau = dof ? -bias - damping * v + tau_act : T(0);
+
+            // ---- 5. constraint rows: joint limits (mj_instantiateLimit, strict dist < 0) ...
+            T sig = T(0), dist = T(0), D = T(0), aref = T(0);
+            bool inst = false;
+            if (dof && M[T_LIMITED + l] != T(0)) {
+                const T dlo = q - M[T_RANGE_LO + l], dhi = M[T_RANGE_HI + l] - q;
+                if (dlo < T(0)) { sig = T(1); dist = dlo; inst = true; }
+                else if (dhi < T(0)) { sig = T(-1); dist = dhi; inst = true; }
+            }
+            // ... and plane-sphere contacts (mjc_PlaneSphere, condim 1): Jacobian row in LDS, scalars per sphere
+            unsigned cinst = 0;
+            for (int s = 0; s < n_sphere; ++s) {
+                const T* sp = M + T_SPH + s * TREE_SPH_STRIDE;
+                const T cdist = X[A_CS + s * 8 + 3];
+                const bool ci = cdist < sp[5];
+                if (__any(ci)) {
+                    const int sl = (int)sp[0];
+                    T r[3], ar[3];
+                    for (int k = 0; k < 3; ++k) r[k] = X[A_CS + s * 8 + k] - pn[k] * (sp[4] + T(0.5) * cdist) - p[k];
+                    cross3(a, r, ar);
+                    const unsigned smask = (unsigned)M[T_ANCMASK + sl] | ((unsigned)M[T_ANCMASK + TL + sl] << 16);
+                    const T jc = (ci && dof && ((smask >> l) & 1u)) ? dot3(pn, ar) : T(0);
+                    X[A_JC + s * TL + l] = jc;
+                    const T jv = sum32(jc * v);
+                    T Dc, arc;
+                    tree_row_params(M, cdist - sp[5], sp[6], jv, Dc, arc);
+                    if (l == 0) { X[A_CS + s * 8 + 4] = ci ? Dc : T(0); X[A_CS + s * 8 + 5] = ci ? arc : T(0); }
+                    if (ci) cinst |= 1u << s;
+                }
+            }
+            TSYNC();
+            const bool any_rows = __any(inst || cinst != 0);
+            T qfrc_c = T(0);
+            if (any_rows) {
+                tree_row_params(M, dist, M[T_DOF_INVW + l], sig * v, D, aref);
+                D = inst ? D : T(0);
+                aref = inst ? aref : T(0);
+                // initial active set: a row that existed in the previous substep keeps its state, a new row is active
+                bool actv = inst && ((lim_mem & 1) ? (lim_mem & 2) != 0 : true);
+                unsigned cact = 0;
+                for (int s = 0; s < n_sphere; ++s)
+                    if ((cinst >> s) & 1u) cact |= ((con_mem >> s) & 1u) ? (((con_mem >> (8 + s)) & 1u) << s) : (1u << s);
+                bool changed = true;
+                T xa = T(0);
+                for (int it = 0; it < TREE_MAXIT; ++it) {
+                    T arow[NV];
+#pragma unroll
+                    for (int j = 0; j < NV; ++j) arow[j] = l < NV ? MT[l * (NV + 1) + j] : T(0);
+                    T rhs = tau + (actv ? D * sig * aref : T(0));
+                    T dg = actv ? D : T(0);
+                    for (int s = 0; s < n_sphere; ++s) {
+                        if (!__any((cact >> s) & 1u)) continue;
+                        const bool on = (cact >> s) & 1u;
+                        const T Dc = on ? X[A_CS + s * 8 + 4] : T(0), jl = X[A_JC + s * TL + l];
+                        rhs += Dc * jl * X[A_CS + s * 8 + 5];
+                        const T w = Dc * jl;
+#pragma unroll
+                        for (int j = 0; j < NV; ++j) arow[j] += w * X[A_JC + s * TL + j];
+                    }
+#pragma unroll
+                    for (int j = 0; j < NV; ++j) arow[j] = (j == l) ? arow[j] + dg : arow[j];
+                    ldl_factor<NV>(arow, COL, l);
+                    xa = ldl_solve<NV>(arow, rhs, COL, l);
+                    const bool act2 = inst && (sig * xa - aref < T(0));
+                    unsigned cact2 = 0;
+                    for (int s = 0; s < n_sphere; ++s) {
+                        if (!__any((cinst >> s) & 1u)) continue;
+                        const T res = sum32(X[A_JC + s * TL + l] * xa) - X[A_CS + s * 8 + 5];
+                        if (((cinst >> s) & 1u) && res < T(0)) cact2 |= 1u << s;
+                    }
+                    changed = (act2 != actv) || (cact2 != cact);
+                    actv = act2;
+                    cact = cact2;
+                    if (!__any(changed)) break;
+                }
+                if (changed && diag) atomicAdd(diag, 1u);
+                lim_mem = (inst ? 1 : 0) | (actv ? 2 : 0);
+                con_mem = cinst | (cact << 8);
+                qfrc_c = actv ? -D * (sig * xa - aref) * sig : T(0);
+                for (int s = 0; s < n_sphere; ++s) {
+                    if (!__any((cact >> s) & 1u)) continue;
+                    const T jl = X[A_JC + s * TL + l];
+                    const T res = sum32(jl * xa) - X[A_CS + s * 8 + 5];
+                    if ((cact >> s) & 1u) qfrc_c += jl * (-X[A_CS + s * 8 + 4] * res);
+                }
+            } else {
+                lim_mem = 0;
+                con_mem = 0;
+            }
+            // ---- 6. mj_Euler with implicit joint damping: (M + h B) qacc = qfrc_smooth + qfrc_constraint
+            T qacc;
+            {
+                T erow[NV];
+#pragma unroll
+                for (int j = 0; j < NV; ++j) {
+                    const T mij = l < NV ? MT[l * (NV + 1) + j] : T(0);
+                    erow[j] = (j == l && dof) ? mij + h * damping : mij;
+                }
+                ldl_factor<NV>(erow, COL, l);
+                qacc = ldl_solve<NV>(erow, tau + qfrc_c, COL, l);
+            }
+            if (dof) {
+                v += h * qacc;
+                const T dq = h * v;
+                q += dq;
+                T sd, cd;
+                if (__builtin_expect(__any(fabs(dq) > T(0.25)), 0)) {
+                    sincos_(q, sq, cq);
+                } else {
+                    sincos_small(dq, sd, cd);
+                    const T s1 = sq * cd + cq * sd, c1 = cq * cd - sq * sd;
+                    const T kk = T(1.5) - T(0.5) * (s1 * s1 + c1 * c1);
+                    sq = s1 * kk;
+                    cq = c1 * kk;
+                }
+            }
+        }
+        // reward = -(|h-g|_1 + 5 |h-g|_2), h = site position lagging one substep (reacher_env.py:31-35)
+        const T dx = hand[0] - tgt[0], dy = hand[1] - tgt[1], dz = hand[2] - tgt[2];
+        const T cst = fabs(dx) + fabs(dy) + fabs(dz) + T(5) * sqrt_(dx * dx + dy * dy + dz * dz);
+        if (live && l == 0) cost[pid * H + t] = cst;
+        if (live && (obs || nobs)) {
+            const long o = (pid * H + t) * dobs;
+            if (obs) {
+                if (dof) { obs[o + l] = q_prev; obs[o + nv + l] = v_prev; }
+                if (l < 3) { obs[o + 2 * nv + l] = hand_prev[l]; obs[o + 2 * nv + 3 + l] = hand_prev[l] - tgt[l]; }
+            }
+            if (nobs) {
+                if (dof) { nobs[o + l] = q; nobs[o + nv + l] = v; }
+                if (l < 3) { nobs[o + 2 * nv + l] = hand[l]; nobs[o + 2 * nv + 3 + l] = hand[l] - tgt[l]; }
+            }
+        }
+        q_prev = q;
+        v_prev = v;
+        for (int k = 0; k < 3; ++k) hand_prev[k] = hand[k];
+    }
+}
+
+}  // namespace
+
+template <typename T>
+hipError_t launch_tree_rollout(const T* model, int nv, const double* state, long P, int H, int A, const double* mean,
+                               const T* noise, T* cost, T* act, T* obs, T* nobs, unsigned* diag, hipStream_t stream) {
+    if (P <= 0 || H <= 0) return hipSuccess;
+    const unsigned grid = (unsigned)((P + 2 * WG_WAVES - 1) / (2 * WG_WAVES));
+#define MJMPC_TREE_LAUNCH(NV_)                                                                                      \
+    hipLaunchKernelGGL((tree_rollout_kernel<T, NV_>), dim3(grid), dim3(64 * WG_WAVES), 0, stream, model, state, P, H, \
+                       A, mean, noise, cost, act, obs, nobs, diag)
+    if (nv <= 8) MJMPC_TREE_LAUNCH(8);
+    else if (nv <= 16) MJMPC_TREE_LAUNCH(16);
+    else if (nv <= 24) MJMPC_TREE_LAUNCH(24);
+    else MJMPC_TREE_LAUNCH(32);
+#undef MJMPC_TREE_LAUNCH
+    return hipGetLastError();
+}
+
+template hipError_t launch_tree_rollout<float>(const float*, int, const double*, long, int, int, const double*,
+                                               const float*, float*, float*, float*, float*, unsigned*, hipStream_t);
+template hipError_t launch_tree_rollout<double>(const double*, int, const double*, long, int, int, const double*,
+                                                const double*, double*, double*, double*, double*, unsigned*, hipStream_t);
+
+}  // namespace mjmpc

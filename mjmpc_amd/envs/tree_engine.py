@@ -1,0 +1,144 @@
+"""GPU rollout engine for kinematic-tree models - ``ArmRolloutEngine``'s sibling for models the serial-chain kernel
+cannot hold (a hand on an arm, up to 32 hinge dofs, gravity, several sphere/plane contacts).
+
+Same reference-shaped surface (``SubprocVecEnv.rollout / set_env_state / reset / close``,
+mjmpc/envs/vec_env/subproc_vec_env.py:128-186, 235-251), so ``make_rollout_fn`` / ``make_device_rollout_fn`` of
+``arm_engine`` and every controller work on it unchanged:
+
+    sim_env = TreeRolloutEngine(hand24_raw())
+    controller.set_sim_state_fn = sim_env.set_env_state
+    controller.rollout_fn = make_device_rollout_fn(sim_env)
+
+One HIP launch per rollout (mjmpc_amd/csrc/tree_rollout.hip) through the C ABI (``mjmpc_tree_*``).
+"""
+import ctypes
+import time
+
+import numpy as np
+
+from .. import _lib
+from ..models.compile_tree import TreeModel, compile_tree
+from ..models.raw import RawModel
+from .arm_engine import _DT, _ptr, _torch
+
+
+class TreeRolloutEngine:
+    def __init__(self, model, device=0, dtype="f64", num_shards=1):
+        if isinstance(model, RawModel):
+            model = compile_tree(model)
+        if not isinstance(model, TreeModel):
+            raise TypeError("model must be a RawModel or a compiled TreeModel")
+        if dtype not in _DT:
+            raise ValueError("dtype must be 'f32' or 'f64'")
+        self.model, self.dtype = model, dtype
+        self._code, self._np = _DT[dtype]
+        self.num_shards = int(num_shards)
+        self._lib = _lib.require_gpu()
+        torch = _torch()
+        self.device = torch.device("cuda", device)
+        self._tdtype = torch.float32 if dtype == "f32" else torch.float64
+        h = ctypes.c_void_p()
+        blob = np.ascontiguousarray(model.blob, np.float64)
+        _lib.check(self._lib.mjmpc_tree_create(blob.ctypes.data_as(_lib._dp), blob.size, device, ctypes.byref(h)))
+        self._h = h
+        self.d_action, self.d_obs = model.nu, model.d_obs
+        self.d_state = 3 * model.nv + 3 + 1
+        self.action_lows, self.action_highs = model.ctrl_lo.copy(), model.ctrl_hi.copy()
+        self.closed = False
+        self._buf = {}
+        self.set_env_state(dict(qp=np.zeros(model.nv), qv=np.zeros(model.nv), qa=np.zeros(model.nv),
+                                target_pos=model.target_default.copy(), timestep=0))
+
+    # ------------------------------------------------------------------ reference-shaped API
+    def set_env_state(self, state_dicts):
+        state = state_dicts[0] if isinstance(state_dicts, (list, tuple)) else state_dicts
+        if isinstance(state_dicts, (list, tuple)) and len(state_dicts) not in (1, self.num_shards):
+            raise AssertionError("num states should equal 1 (same for all envs) or 1 per env")
+        qp = np.ascontiguousarray(state["qp"], np.float64).reshape(-1)
+        qv = np.ascontiguousarray(state["qv"], np.float64).reshape(-1)
+        tg = np.ascontiguousarray(state["target_pos"], np.float64).reshape(-1)
+        if qp.size != self.model.nv or qv.size != self.model.nv or tg.size != 3:
+            raise ValueError("state has the wrong dimensions for this model")
+        self._state = dict(qp=qp.copy(), qv=qv.copy(), target_pos=tg.copy())
+        _lib.check(self._lib.mjmpc_tree_set_state(self._h, qp.ctypes.data_as(_lib._dp), qv.ctypes.data_as(_lib._dp),
+                                                  tg.ctypes.data_as(_lib._dp), self._stream()))
+
+    def get_env_state(self):
+        st = self._state
+        return [dict(qp=st["qp"].copy(), qv=st["qv"].copy(), qa=np.zeros(self.model.nv),
+                     target_pos=st["target_pos"].copy(), timestep=0)]
+
+    def reset(self):
+        self.set_env_state(dict(qp=np.zeros(self.model.nv), qv=np.zeros(self.model.nv),
+                                target_pos=self.model.target_default.copy()))
+        return self.get_env_state()
+
+    def close(self):
+        if not self.closed:
+            self._lib.mjmpc_tree_destroy(self._h)
+            self.closed = True
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def rollout(self, num_particles, horizon, mean, noise, mode="open_loop"):
+        """``SubprocVecEnv.rollout``: numpy in, numpy out -> (obs, rew, act, done, info, next_obs)."""
+        t0 = time.time()
+        out = self.rollout_device(num_particles, horizon, mean, noise, mode, want_obs=True)
+        costs, act, obs, nobs = (x.to("cpu").numpy().astype(np.float64, copy=False) for x in out)
+        done = np.zeros((num_particles, horizon))
+        info = [{"total_time": time.time() - t0} for _ in range(self.num_shards)]
+        return obs, -costs, act, done, info, nobs
+
+    def rollout_device(self, num_particles, horizon, mean, noise, mode="open_loop", want_obs=False, want_actions=True):
+        if mode != "open_loop":
+            raise ValueError("unsupported rollout mode %r (the tree engine runs 'open_loop')" % (mode,))
+        if num_particles % self.num_shards != 0:
+            raise AssertionError("Number of particles must be divisible by number of shards")
+        torch = _torch()
+        P, H, A = int(num_particles), int(horizon), self.d_action
+        mean_d = self._as_device(mean, torch.float64, (H, A))
+        noise_d = None if noise is None else self._as_device(noise, self._tdtype, (P, H, A))
+        costs = self._buffer("costs", (P, H))
+        act = self._buffer("act", (P, H, A)) if want_actions else None
+        obs = self._buffer("obs", (P, H, self.d_obs)) if want_obs else None
+        nobs = self._buffer("nobs", (P, H, self.d_obs)) if want_obs else None
+        _lib.check(self._lib.mjmpc_tree_rollout(self._h, self._code, P, H, _ptr(mean_d), _ptr(noise_d), _ptr(costs),
+                                                _ptr(act), _ptr(obs), _ptr(nobs), self._stream()))
+        return costs, act, obs, nobs
+
+    def step(self, action):
+        """Advance the engine's own state by one env step (a one-particle rollout, state round trip through the host:
+        the tree engine keeps no device-resident "real env").  Returns (next_obs, reward)."""
+        _, rew, _, _, _, nobs = self.rollout(1, 1, np.asarray(action, np.float64).reshape(1, -1), None)
+        nv = self.model.nv
+        self.set_env_state(dict(qp=nobs[0, 0, :nv], qv=nobs[0, 0, nv:2 * nv], target_pos=self._state["target_pos"]))
+        return nobs[0, 0].copy(), float(rew[0, 0])
+
+    def solver_failures(self):
+        c = ctypes.c_uint32()
+        _lib.check(self._lib.mjmpc_tree_solver_failures(self._h, ctypes.byref(c)))
+        return int(c.value)
+
+    # ------------------------------------------------------------------ helpers
+    def _stream(self):
+        return ctypes.c_void_p(_torch().cuda.current_stream(self.device).cuda_stream)
+
+    def _buffer(self, name, shape):
+        torch = _torch()
+        t = self._buf.get(name)
+        if t is None or tuple(t.shape) != tuple(shape):
+            t = torch.empty(shape, dtype=self._tdtype, device=self.device)
+            self._buf[name] = t
+        return t
+
+    def _as_device(self, x, tdtype, shape):
+        torch = _torch()
+        if not isinstance(x, torch.Tensor):
+            x = torch.from_numpy(np.ascontiguousarray(x))
+        if tuple(x.shape) != tuple(shape):
+            raise ValueError("expected shape %s, got %s" % (shape, tuple(x.shape)))
+        return x.to(device=self.device, dtype=tdtype).contiguous()

@@ -35,10 +35,10 @@
 #include <omp.h>
 #endif
 
-#define MAXB 16            /* bodies incl. world */
-#define MAXV 12
-#define MAXG 32
-#define MAXS 4             /* collision spheres */
+#define MAXB 48            /* bodies incl. world */
+#define MAXV 32
+#define MAXG 96
+#define MAXS 8             /* collision spheres */
 #define MAXC (2 * MAXV + MAXS)
 #define MJ_MINVAL 1e-15    /* MuJoCo mjMINVAL */
 
