@@ -395,6 +395,8 @@ __global__ __launch_bounds__(64 * WG_WAVES) void tree_rollout_kernel(
                     for (int c = 0; c < 6; ++c) s += S_[c * TL + j] * F[c];
                     s = (j == l) ? s + armature : s;
                     urow[j] = dof ? (((tp.ancmask >> j) & 1u) ? s : T(0)) : ((j == l) ? T(1) : T(0));
+                    // keep the scheduler from hoisting all 6 NV broadcast reads to the top (it did: 512 registers)
+                    if ((j & 3) == 3) __builtin_amdgcn_sched_barrier(0);
                 }
                 TSYNC();                    // S_ lies inside the tile
                 if (l < NV) {
@@ -475,12 +477,18 @@ __global__ __launch_bounds__(64 * WG_WAVES) void tree_rollout_kernel(
                     for (int j = 0; j < NV; ++j) arow[j] = (j == l) ? arow[j] + dg : arow[j];
                     ldl_factor<NV>(arow, COL, l);
                     xa = ldl_solve<NV>(arow, rhs, COL, l);
-                    const bool act2 = inst && (sig * xa - aref < T(0));
+                    // f32: a row whose residual is within rounding of zero keeps its state (as in arm_rollout.hip)
+                    const T resl = sig * xa - aref;
+                    const T band = sizeof(T) == 4 ? T(4e-6) * (fabs(aref) + fabs(xa) + T(1)) : T(0);
+                    const bool act2 = inst && (actv ? !(resl > band) : (resl < -band));
                     unsigned cact2 = 0;
                     for (int s = 0; s < n_sphere; ++s) {
                         if (!__any((cinst >> s) & 1u)) continue;
-                        const T res = sum32(X[A_JC + s * TL + l] * xa) - X[A_CS + s * 8 + 5];
-                        if (((cinst >> s) & 1u) && res < T(0)) cact2 |= 1u << s;
+                        const T arc = X[A_CS + s * 8 + 5];
+                        const T res = sum32(X[A_JC + s * TL + l] * xa) - arc;
+                        const T bc = sizeof(T) == 4 ? T(4e-6) * (fabs(arc) + fabs(res + arc) + T(1)) : T(0);
+                        const bool was = (cact >> s) & 1u;
+                        if (((cinst >> s) & 1u) && (was ? !(res > bc) : (res < -bc))) cact2 |= 1u << s;
                     }
                     changed = (act2 != actv) || (cact2 != cact);
                     actv = act2;

@@ -276,7 +276,8 @@ def make_device_rollout_fn(sim_env):
         return dict(costs=costs, actions=act, observations=None, next_observations=None, dones=None,
                     infos={"total_time": np.array([time.time() - t0] * sim_env.num_shards)})
     rollout_fn.accepts_device = True          # controllers may hand over their device-resident mean
-    rollout_fn.fused = sim_env.rollout_fused  # filter + cost-to-go fused into the launch (graph fast path)
+    if hasattr(sim_env, "rollout_fused"):   # filter + cost-to-go fused into the launch (graph fast path)
+        rollout_fn.fused = sim_env.rollout_fused
     return rollout_fn
 
 

@@ -7,6 +7,8 @@
         here the whole population on one)
   cfg4* DMD-MPC, 65536 particles x H64 on the 7-dof arm (BASELINE names pen-v0, whose assets are not in the
         reference tree: throughput of the same controller path on the model we have, flagged)
+  cfg4t DMD-MPC, 65536 particles x H64 on the synthetic 24-dof hand-on-an-arm TREE (mjmpc_amd/models/hand24.py,
+        tree kernel): pen-v0's SHAPE of work - a branching 24-hinge tree, gravity, fingertip contacts; flagged
 One step = Controller.optimize() + stepping the real arm on the device, all data resident in HBM.  One JSON line each.
 """
 import argparse
@@ -56,11 +58,59 @@ def run(name, make, P, H, steps, warmup, dtype, note):
                       "solver_failures": eng.solver_failures(), "note": note}), flush=True)
 
 
+def run_tree(name, make, P, H, steps, warmup, dtype, note):
+    """The same loop on the tree engine (no device-resident "real env": the state makes a host round trip)."""
+    import torch
+    from mjmpc_amd.envs.arm_engine import make_device_rollout_fn
+    from mjmpc_amd.envs.tree_engine import TreeRolloutEngine
+    from mjmpc_amd.models.hand24 import hand24_raw
+    raw = hand24_raw()
+    eng = TreeRolloutEngine(raw, dtype=dtype)
+    ctrl = make(eng, P, H)
+    ctrl.rollout_fn = make_device_rollout_fn(eng)
+    ctrl.set_sim_state_fn = eng.set_env_state
+    state = eng.reset()[0]
+    ev = []
+
+    def step(st):
+        a, _ = ctrl.optimize(st)
+        eng.set_env_state(st)
+        nobs, _ = eng.step(a)
+        return eng.get_env_state()[0], nobs
+
+    for _ in range(warmup):
+        state, _ = step(state)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        state, nobs = step(state)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    # the rollout kernel alone, back to back on the run's own buffers
+    noise_t = ctrl.dev._rec[("noise", dtype)]
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(3):
+        eng.rollout_device(P, H, ctrl.dev.mean, noise_t)
+    e1.record()
+    torch.cuda.synchronize()
+    kern_ms = e0.elapsed_time(e1) / 3
+    nv = eng.model.nv
+    print(json.dumps({"config": name, "particles": P, "horizon": H, "dtype": dtype, "steps": steps,
+                      "ms_per_step": dt / steps * 1e3, "control_loop_hz": steps / dt,
+                      "particle_steps_per_s": P * H * ctrl.n_iters * steps / dt, "rollout_kernel_ms": kern_ms,
+                      "launch": "eager launches", "dofs": nv,
+                      "final_distance_to_target": float(np.linalg.norm(nobs[2 * nv + 3:2 * nv + 6])),
+                      "solver_failures": eng.solver_failures(), "note": note}), flush=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--steps", type=int, default=30)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--dtype", choices=["f64", "f32"], default="f64")
+    ap.add_argument("--tree-particles", type=int, default=65536)
+    ap.add_argument("--only-tree", action="store_true")
     args = ap.parse_args()
     from mjmpc_amd.control import CEM, DMDMPC, MPPI
 
@@ -69,19 +119,29 @@ def main():
                     action_lows=eng.action_lows, action_highs=eng.action_highs, seed=123, noise_mode="device",
                     noise_dtype=args.dtype)
 
-    run("cfg1 reacher_7dof-v0 MPPI 1024xH32",
-        lambda e, P, H: MPPI(init_cov=1.0, base_action="null", lam=0.01, step_size=1.0, alpha=1, gamma=1.0,
-                             filter_coeffs=[0.25, 0.8, 0.0], **kw(e, P, H)),
-        1024, 32, args.steps, args.warmup, args.dtype, "")
-    run("cfg3 reacher_7dof-v0 CEM full-cov 16384xH32 elite 0.1 (one GPU)",
-        lambda e, P, H: CEM(init_cov=1.0, base_action="null", elite_frac=0.1, step_size=1.0, gamma=1.0, beta=0.1,
-                            cov_type="full", filter_coeffs=[0.25, 0.8, 0.0], **kw(e, P, H)),
-        16384, 32, args.steps, args.warmup, args.dtype, "covariance changes every step: the Cholesky factor is a host "
-        "computation, so the iteration runs as eager launches")
-    run("cfg4* DMD-MPC 65536xH64 on the 7-dof arm (pen-v0 assets absent)",
-        lambda e, P, H: DMDMPC(init_cov=1.0, beta=0.1, base_action="null", lam=0.1, step_size=1.0, gamma=1.0,
-                               update_cov=False, cov_type="diagonal", filter_coeffs=[0.25, 0.8, 0.0], **kw(e, P, H)),
-        65536, 64, max(5, args.steps // 3), 2, args.dtype, "stand-in model; throughput only")
+    if not args.only_tree:
+        run("cfg1 reacher_7dof-v0 MPPI 1024xH32",
+            lambda e, P, H: MPPI(init_cov=1.0, base_action="null", lam=0.01, step_size=1.0, alpha=1, gamma=1.0,
+                                 filter_coeffs=[0.25, 0.8, 0.0], **kw(e, P, H)),
+            1024, 32, args.steps, args.warmup, args.dtype, "")
+        run("cfg3 reacher_7dof-v0 CEM full-cov 16384xH32 elite 0.1 (one GPU)",
+            lambda e, P, H: CEM(init_cov=1.0, base_action="null", elite_frac=0.1, step_size=1.0, gamma=1.0, beta=0.1,
+                                cov_type="full", filter_coeffs=[0.25, 0.8, 0.0], **kw(e, P, H)),
+            16384, 32, args.steps, args.warmup, args.dtype, "covariance changes every step: the Cholesky factor is a host "
+            "computation, so the iteration runs as eager launches")
+        run("cfg4* DMD-MPC 65536xH64 on the 7-dof arm (pen-v0 assets absent)",
+            lambda e, P, H: DMDMPC(init_cov=1.0, beta=0.1, base_action="null", lam=0.1, step_size=1.0, gamma=1.0,
+                                   update_cov=False, cov_type="diagonal", filter_coeffs=[0.25, 0.8, 0.0], **kw(e, P, H)),
+            65536, 64, max(5, args.steps // 3), 2, args.dtype, "stand-in model; throughput only")
+
+    def kw24(eng, P, H):
+        return dict(kw(eng, P, H), d_action=24)
+
+    run_tree("cfg4t DMD-MPC 65536xH64 on the synthetic 24-dof hand tree (pen-v0 assets absent)",
+             lambda e, P, H: DMDMPC(init_cov=0.3, beta=0.1, base_action="null", lam=0.1, step_size=1.0, gamma=1.0,
+                                    update_cov=False, cov_type="diagonal", filter_coeffs=[0.25, 0.8, 0.0], **kw24(e, P, H)),
+             args.tree_particles, 64, max(3, args.steps // 10), 1, args.dtype,
+             "synthetic tree with pen-v0's shape of work (24 hinges, gravity, 5 fingertip contacts); throughput only")
 
 
 if __name__ == "__main__":
