@@ -129,7 +129,8 @@ class ArmRolloutEngine:
         ``np_random(base_seed + i*12345)`` a uniform value in ``m (1 +- noise)``, ``m = (1 + bias) * default``
         for every ``{param_id: {name: [noise_scale, bias_scale]}}`` entry (gym_env_wrapper.py:367-416) and
         from then on simulates its own model.  Supported: body_mass, body_inertia, dof_damping, geom_size
-        (collision geoms), geom_friction (accepted, no effect: every contact here is frictionless condim 1).
+        (collision geoms), geom_friction (accepted, no effect: every contact here is frictionless condim 1),
+        dof_frictionloss (the default is 0 and the randomization multiplicative: stays 0, the draw is consumed).
         Returns (default_params, randomized_params), one dict per shard."""
         if self.raw is None:
             raise ValueError("randomize_dynamics needs the engine to be built from a RawModel")
@@ -146,7 +147,10 @@ class ArmRolloutEngine:
                     mean = (1.0 + bias_scale) * np.asarray(cur, float)
                     val = rng.uniform(mean - mean * noise_scale, mean + mean * noise_scale)
                     rand.setdefault(param_id, {})[name] = val
-            ov = {k: v for k, v in rand.items() if k != "geom_friction"}
+            if any(np.any(np.asarray(v) != 0) for v in rand.get("dof_frictionloss", {}).values()):
+                raise NotImplementedError("a non-zero dof_frictionloss adds friction-loss constraint rows, which the "
+                                          "arm kernel does not model")
+            ov = {k: v for k, v in rand.items() if k not in ("geom_friction", "dof_frictionloss")}
             blobs.append(compile_arm(self.raw, overrides=ov, base=base).blob)
         blobs = np.ascontiguousarray(np.stack(blobs), np.float64)
         _lib.check(self._lib.mjmpc_arm_set_shard_models(self._h, blobs.ctypes.data_as(_lib._dp), self.num_shards))
@@ -169,7 +173,11 @@ class ArmRolloutEngine:
             half = 0.5 * np.linalg.norm(np.asarray(g.b, float) - np.asarray(g.a, float)) if g.type == 2 else 0.0
             return np.array([g.radius, half, 0.0])
         if param_id == "dof_frictionloss":
-            raise NotImplementedError("dof_frictionloss adds friction-loss constraint rows, which the arm kernel does not model")
+            # RawJoint carries no frictionloss: every model this engine loads has MuJoCo's default 0 (sawyer.xml:5 sets
+            # none).  The reference's randomization is multiplicative (gym_env_wrapper.py:409-411), so the randomized
+            # value of a zero default is exactly 0: the draw is consumed, no friction-loss row ever appears.
+            next(b for b in raw.bodies if b.joint is not None and b.joint.name == name)     # unknown joint -> error
+            return 0.0
         raise ValueError("Unknown dynamics field")
 
     def reset(self):

@@ -198,8 +198,11 @@ def test_dynamics_randomization_per_shard(raw_arm):
            "body_inertia": {"r_upper_arm_link": [0.4, 1.0]},
            "dof_damping": {"r_elbow_flex_joint": [0.5, 2.0], "r_shoulder_pan_joint": [0.1, -0.5]},
            "geom_size": {"wrist_ball": [0.2, 0.0]},
-           "geom_friction": {"wrist_ball": [0.1, 0.0]}}
+           "geom_friction": {"wrist_ball": [0.1, 0.0]},
+           # sawyer.xml sets no frictionloss (MuJoCo default 0) and the randomization is multiplicative: stays 0
+           "dof_frictionloss": {"r_wrist_flex_joint": [0.3, 1.0]}}
     defaults, rand = eng.randomize_dynamics(cfg, base_seed=123)
+    assert all(r["dof_frictionloss"]["r_wrist_flex_joint"] == 0.0 for r in rand)
     assert len(rand) == S and rand[0]["body_mass"]["r_forearm_link"] != rand[1]["body_mass"]["r_forearm_link"]
     m0 = defaults[0]["body_mass"]["r_forearm_link"]
     for r in rand:                                        # uniform in m (1 +- noise), m = (1 + bias) default
