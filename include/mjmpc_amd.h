@@ -121,9 +121,10 @@ int mjmpc_arm_step_state(mjmpc_arm_t h, int dtype, const double* d_action, void*
  *   off[3][32] axis[3][32] mass[32] com[3][32] inertia[6][32] armature damping range_lo range_hi limited gear ctrl_lo
  *   ctrl_hi dof_invweight0 parent subsize anc[5][32] ancmask[2][32] (each [32]) nv timestep frame_skip jumps site_link
  *   site_pos[3] n_sphere plane_n[3] plane_d sol_K sol_B sol_dmin sol_dmax sol_width sol_mid sol_power gravity[3]
- *   spheres[8][8] = {link, pos[3], r, margin, invweight, pad}
+ *   spheres[8][8] = {link, pos[3], r, margin, invweight, pad}  depth[32] n_rounds elim[31][32] (elimination lists of the
+ *   tree-sparse L'DL: the descendants of every link sorted by height, packed k | distance << 8 | height << 16, -1 ends)
  * Same call shapes and reference counterparts as the arm engine (subproc_vec_env.py:91-111, 128-186, 235-251).     */
-#define MJMPC_TREE_BLOB_LEN 1175
+#define MJMPC_TREE_BLOB_LEN 2200
 /* Device state vector of a tree engine: qpos[32] | qvel[32] | target_pos[3]  (float64). */
 #define MJMPC_TREE_STATE_LEN 67
 typedef struct mjmpc_tree_s* mjmpc_tree_t;

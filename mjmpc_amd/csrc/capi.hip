@@ -1,6 +1,7 @@
 // extern "C" entry points declared in include/mjmpc_amd.h.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
@@ -59,7 +60,7 @@ struct mjmpc_arm_s {
 
 struct mjmpc_tree_s {
     int device = 0;
-    int nv = 0, nu = 0, d_obs = 0;
+    int nv = 0, nu = 0, d_obs = 0, max_path = 0;
     float* model_f32 = nullptr;
     double* model_f64 = nullptr;
     double* state = nullptr;        // MJMPC_TREE_STATE_LEN
@@ -336,6 +337,7 @@ int mjmpc_tree_create(const double* blob, int n_blob, int device, mjmpc_tree_t* 
     h->device = device;
     h->nv = h->nu = nv;
     h->d_obs = 2 * nv + 6;
+    for (int l = 0; l < nv; ++l) h->max_path = std::max(h->max_path, (int)blob[mjmpc::T_DEPTH + l] + 1);
     std::vector<float> f32(blob, blob + n_blob);
     HIP_TRY(hipMalloc(&h->model_f32, sizeof(float) * n_blob));
     HIP_TRY(hipMalloc(&h->model_f64, sizeof(double) * n_blob));
@@ -390,11 +392,11 @@ int mjmpc_tree_rollout(mjmpc_tree_t h, int dtype, int64_t P, int H, const double
     hipStream_t s = (hipStream_t)stream;
     hipError_t e;
     if (dtype == MJMPC_F32)
-        e = mjmpc::launch_tree_rollout<float>(h->model_f32, h->nv, h->state, (long)P, H, h->nu, d_mean,
+        e = mjmpc::launch_tree_rollout<float>(h->model_f32, h->max_path, h->state, (long)P, H, h->nu, d_mean,
                                               (const float*)d_noise, (float*)d_costs, (float*)d_actions, (float*)d_obs,
                                               (float*)d_next_obs, h->diag, s);
     else if (dtype == MJMPC_F64)
-        e = mjmpc::launch_tree_rollout<double>(h->model_f64, h->nv, h->state, (long)P, H, h->nu, d_mean,
+        e = mjmpc::launch_tree_rollout<double>(h->model_f64, h->max_path, h->state, (long)P, H, h->nu, d_mean,
                                                (const double*)d_noise, (double*)d_costs, (double*)d_actions,
                                                (double*)d_obs, (double*)d_next_obs, h->diag, s);
     else

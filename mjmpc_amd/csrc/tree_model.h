@@ -50,9 +50,14 @@ enum TreeOffset : int {
     T_SOL_POWER,
     T_GRAVITY,                          // 3
     T_SPH = T_GRAVITY + 3,              // TREE_MAX_SPHERES x TREE_SPH_STRIDE
-    TREE_BLOB_LEN = T_SPH + TREE_MAX_SPHERES * TREE_SPH_STRIDE
+    // tree-sparse L'DL: links of equal height above their deepest leaf are eliminated together (one round per height)
+    T_DEPTH = T_SPH + TREE_MAX_SPHERES * TREE_SPH_STRIDE,      // 32: strict ancestors of the link
+    T_N_ROUNDS = T_DEPTH + TL,          // max height + 1
+    T_ELIM,                             // 31 x 32, [entry][lane]: my descendants sorted by height, packed
+                                        // k | distance << 8 | height << 16; -1 terminates the list
+    TREE_BLOB_LEN = T_ELIM + (TL - 1) * TL
 };
 
-static_assert(TREE_BLOB_LEN == 1175, "keep in sync with mjmpc_amd/models/compile_tree.py::TREE_LAYOUT");
+static_assert(TREE_BLOB_LEN == 2200, "keep in sync with mjmpc_amd/models/compile_tree.py::TREE_LAYOUT");
 
 }  // namespace mjmpc

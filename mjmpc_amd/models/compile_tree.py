@@ -27,6 +27,12 @@ TREE_LAYOUT = [
     ("n_sphere", 1), ("plane_n", 3), ("plane_d", 1),
     ("sol_K", 1), ("sol_B", 1), ("sol_dmin", 1), ("sol_dmax", 1), ("sol_width", 1), ("sol_mid", 1), ("sol_power", 1),
     ("gravity", 3), ("spheres", TREE_MAX_SPHERES * SPH_STRIDE),
+    # tree-sparse L'DL (MuJoCo's factorisation order: leaves first, no fill-in): links of equal HEIGHT above their
+    # deepest leaf are mutually unrelated and are eliminated together, one round per height
+    ("depth", TL),                  # strict ancestors of the link
+    ("n_rounds", 1),                # max height + 1
+    ("elim", (TL - 1) * TL),        # [entry][lane]: my descendants sorted by height, packed k | dist << 8 | height << 16
+                                    # (-1 terminates): the rows that update mine, round by round
 ]
 TREE_BLOB_LEN = sum(n for _, n in TREE_LAYOUT)
 TREE_STATE_LEN = 2 * TL + 3           # qpos[32] | qvel[32] | target_pos[3]
@@ -55,6 +61,7 @@ class TreeModel:
     ctrl_lo: np.ndarray
     ctrl_hi: np.ndarray
     parent: np.ndarray             # parent link of every link (-1: root)
+    max_path: int                  # links on the longest root-to-leaf path
     body_mass: np.ndarray
     body_invweight0: np.ndarray
     dof_invweight0: np.ndarray
@@ -111,6 +118,10 @@ def compile_tree(raw: RawModel) -> TreeModel:
                 k = parent[k]
             if inside != desc:
                 raise ValueError("links must be numbered depth-first (as an MJCF file lists its bodies)")
+    height = np.zeros(nv, int)
+    for i in range(nv - 1, -1, -1):
+        if parent[i] >= 0:
+            height[parent[i]] = max(height[parent[i]], height[i] + 1)
     depth = np.zeros(nv, int)
     anc = -np.ones((5, nv), int)
     ancmask = np.zeros(nv, np.int64)
@@ -161,6 +172,13 @@ def compile_tree(raw: RawModel) -> TreeModel:
         f["anc"][e * TL:e * TL + nv] = anc[e]
     f["ancmask"][:nv] = ancmask & 0xFFFF
     f["ancmask"][TL:TL + nv] = ancmask >> 16
+    f["depth"][:nv] = depth - 1
+    f["n_rounds"][0] = height.max() + 1
+    f["elim"][:] = -1.0
+    for i in range(nv):
+        desc = sorted(range(i + 1, i + subsize[i]), key=lambda k: (height[k], k))
+        for e, k in enumerate(desc):
+            f["elim"][e * TL + i] = k | ((depth[k] - depth[i]) << 8) | (height[k] << 16)
 
     if len(raw.actuators) != nv:
         raise ValueError("tree kernel expects one motor per hinge")
@@ -241,4 +259,5 @@ def compile_tree(raw: RawModel) -> TreeModel:
     assert blob.size == TREE_BLOB_LEN
     return TreeModel(blob=blob, nv=nv, nu=nv, d_obs=2 * nv + 6, timestep=raw.timestep, frame_skip=raw.frame_skip,
                      target_default=np.asarray(raw.target_pos, float), ctrl_lo=ctrl_lo, ctrl_hi=ctrl_hi, parent=parent,
+                     max_path=int(depth.max()),
                      body_mass=mass, body_invweight0=body_iw, dof_invweight0=dof_iw, link_of_body=link_of_body)

@@ -21,7 +21,7 @@ def hand():
 
 def test_two_compilers_agree_on_the_hand(hand):
     raw, m, ref = hand
-    assert m.blob.shape == (TREE_BLOB_LEN,) and TREE_BLOB_LEN == 1175
+    assert m.blob.shape == (TREE_BLOB_LEN,) and TREE_BLOB_LEN == 2200
     assert (m.nv, m.nu, m.d_obs) == (24, 24, 54)
     mass, ipos, inertia = ref.inertial()
     np.testing.assert_allclose(m.body_mass, mass[1:], rtol=1e-12)
@@ -44,7 +44,13 @@ def test_topology_tables(hand):
     full = mask[0] | (mask[1] << 16)
     assert full[7] == sum(1 << k for k in (0, 1, 2, 3, 4, 5, 6, 7))
     assert full[23] == sum(1 << k for k in (0, 1, 2, 3, 20, 21, 22, 23))
-    assert m.field("jumps")[0] == 3                                         # longest path: 8 links
+    assert m.field("jumps")[0] == 3 and m.max_path == 8                     # longest path: 8 links
+    # elimination lists of the tree-sparse L'DL: descendants sorted by height, packed k | distance << 8 | height << 16
+    assert m.field("n_rounds")[0] == 8 and list(m.field("depth")[[0, 3, 4, 7]]) == [0, 3, 4, 7]
+    el = m.field("elim").reshape(TL - 1, TL).astype(int)
+    first = [(x & 255, (x >> 8) & 255, x >> 16) for x in el[:6, 3]]        # the wrist link: five fingertips first
+    assert first == [(7, 4, 0), (11, 4, 0), (15, 4, 0), (19, 4, 0), (23, 4, 0), (6, 3, 1)]
+    assert (el[:, 3] >= 0).sum() == 20 and (el[:, 7] >= 0).sum() == 0 and (el[:, 0] >= 0).sum() == 23
     assert (m.field("parent")[24:] == -1).all() and (m.field("subsize")[24:] == 0).all()
 
 
