@@ -278,6 +278,10 @@ int mjmpc_cov_add_diag(double* d_cov, int A, const double* d_diag, double scale,
 
 /* The recursive filter of generate_noise alone (control_utils.py:32-33), in place on d_noise [P][H][A]. */
 int mjmpc_filter_noise(int dtype, void* d_noise, int64_t P, int H, int A, const double* d_coeffs, void* stream);
+/* noise[row][:] <- noise[row][:] B for `rows` rows of A scalars, B float64 [A][A] row-major: the colouring step of
+ * np.random.multivariate_normal (control_utils.py:30), B = sqrt(s)[:, None] * v from the SVD of cov (host, LAPACK),
+ * applied to the standard-normal stream mjmpc_sample_noise_mt19937[_jump] regenerates with scale 1.          */
+int mjmpc_color_noise(int dtype, void* d_noise, int64_t rows, int A, const double* d_B, void* stream);
 
 /* control_utils.generate_noise (mjmpc/utils/control_utils.py:24-34), SEED-IDENTICAL mode for an isotropic
  * covariance c*I: d_noise[0..n_normals) = scale * the numpy legacy stream `np.random.seed(seed + *d_step);

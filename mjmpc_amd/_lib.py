@@ -67,6 +67,7 @@ SIGNATURES = {
     "mjmpc_shift_mean": (_int, [_vp, _int, _int, _int, _vp, _vp]),
     "mjmpc_cholesky_lower": (_int, [_vp, _int, _vp, _vp, _vp]),
     "mjmpc_cov_add_diag": (_int, [_vp, _int, _vp, _dbl, _vp]),
+    "mjmpc_color_noise": (_int, [_int, _vp, _i64, _int, _vp, _vp]),
     "mjmpc_filter_noise": (_int, [_int, _vp, _i64, _int, _int, _vp, _vp]),
     "mjmpc_mt19937_workspace_bytes": (_i64, [_i64]),
     "mjmpc_sample_noise_mt19937": (_int, [_int, _vp, _i64, _dbl, ctypes.c_uint64, _vp, _vp, _vp, _vp]),

@@ -336,14 +336,24 @@ class DeviceUpdater:
     def sample_noise_mt19937(self, P, cov, filter_coeffs, seed, offset, dtype="f64", d_step=None, filtered=True,
                              particle_offset=0):
         """The reference's own noise (legacy numpy stream of ``np.random.seed(seed + offset)``) regenerated
-        on the device; isotropic covariance only.  Returns the (P,H,A) tensor, filtered unless told not to.
+        on the device.  Isotropic covariance c*I: bit-identical up to libm's last bit.  General covariance: numpy
+        colours the standard-normal stream with ``B = sqrt(s)[:, None] * v`` from ``svd(cov)`` (LAPACK, on the host
+        here as there) - the same stream, the same B, a fixed-order product on the device instead of BLAS' ``dot``
+        (agreement ~1e-15 relative, not bit-for-bit).  Returns the (P,H,A) tensor, filtered unless told not to.
         ``particle_offset``: global index of local particle 0 - a rank of a sharded run keeps its own block of the
         one stream (and regenerates the stream up to the end of that block: rejections make positions data dependent)."""
         torch = self.torch
         cov = np.asarray(cov, np.float64)
         c = float(cov[0, 0])
-        if np.count_nonzero(cov - c * np.eye(self.A)) != 0:
-            raise ValueError("seed-identical device noise needs an isotropic covariance c*I")
+        general = np.count_nonzero(cov - c * np.eye(self.A)) != 0
+        if general:
+            cached = self._rec.get("mt_cov")
+            if cached is None or not np.array_equal(cached, cov):
+                _, sv, vt = np.linalg.svd(cov)                       # what np.random.multivariate_normal does
+                B = np.sqrt(sv)[:, None] * vt
+                self.record("mt_B", self.A * self.A).copy_(torch.from_numpy(np.ascontiguousarray(B).reshape(-1)))
+                self._rec["mt_cov"] = cov.copy()
+            c = 1.0
         tdt = torch.float32 if dtype == "f32" else torch.float64
         key = ("noise_mt", dtype)
         buf = self._rec.get(key)
@@ -374,6 +384,9 @@ class DeviceUpdater:
             _lib.F32 if dtype == "f32" else _lib.F64, _vp(buf), n, float(np.sqrt(c)),
             (int(seed) + int(offset)) & (2 ** 64 - 1), _vp(d_step), _vp(jidx), _vp(jstarts), head, seg, nseg, first,
             _vp(self._rec["mt_ws"]), _vp(self._rec["mt_status"]), self.stream()))
+        if general:
+            _lib.check(self.lib.mjmpc_color_noise(_lib.F32 if dtype == "f32" else _lib.F64, _vp(buf), P * self.H, self.A,
+                                                  _vp(self._rec["mt_B"]), self.stream()))
         if filtered and not (fc[0] == 1.0 and fc[1] == 0.0 and fc[2] == 0.0):
             _lib.check(self.lib.mjmpc_filter_noise(_lib.F32 if dtype == "f32" else _lib.F64, _vp(buf), P, self.H, self.A,
                                                    _vp(co), self.stream()))

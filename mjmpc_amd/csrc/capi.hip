@@ -643,6 +643,13 @@ int mjmpc_filter_noise(int dtype, void* d_noise, int64_t P, int H, int A, const 
              mjmpc::filter_noise<double>((double*)d_noise, (long)P, H, A, d_coeffs, s));
 }
 
+int mjmpc_color_noise(int dtype, void* d_noise, int64_t rows, int A, const double* d_B, void* stream) {
+    if (!d_noise || !d_B) return fail(MJMPC_E_BADARG, "null argument");
+    hipStream_t s = (hipStream_t)stream;
+    DISPATCH(dtype, mjmpc::color_rows<float>((float*)d_noise, (long)rows, A, d_B, s),
+             mjmpc::color_rows<double>((double*)d_noise, (long)rows, A, d_B, s));
+}
+
 int64_t mjmpc_mt19937_workspace_bytes(int64_t n_normals) { return (int64_t)mjmpc::mt_workspace_bytes((long)n_normals); }
 
 int mjmpc_sample_noise_mt19937(int dtype, void* d_noise, int64_t n_normals, double scale, uint64_t seed,

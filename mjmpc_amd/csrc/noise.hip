@@ -113,6 +113,34 @@ hipError_t filter_noise(T* noise, long P, int H, int A, const double* coeffs, hi
     hipLaunchKernelGGL(filter_kernel<T>, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, s, noise, P, H, A, coeffs);
     return hipGetLastError();
 }
+// x[row][:] <- x[row][:] B  (rows of A standard normals -> N(0, cov) samples): numpy's multivariate_normal colours
+// its standard-normal stream with B = sqrt(s)[:, None] * v from the SVD of cov (control_utils.py:30 reaches that
+// through np.random.multivariate_normal); the seed-identical MT19937 mode applies the host-computed B here.
+// One thread per row, fixed summation order.
+template <typename T>
+__global__ void color_rows_kernel(T* __restrict__ x, long rows, int A, const double* __restrict__ B) {
+    const long r = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= rows) return;
+    double in[64], out[64];
+    for (int i = 0; i < A; ++i) in[i] = (double)x[r * A + i];
+    for (int j = 0; j < A; ++j) {
+        double sacc = 0.0;
+        for (int i = 0; i < A; ++i) sacc = fma(in[i], B[i * A + j], sacc);
+        out[j] = sacc;
+    }
+    for (int j = 0; j < A; ++j) x[r * A + j] = (T)out[j];
+}
+
+template <typename T>
+hipError_t color_rows(T* x, long rows, int A, const double* B, hipStream_t s) {
+    if (A < 1 || A > 64) return hipErrorInvalidValue;
+    if (rows <= 0) return hipSuccess;
+    hipLaunchKernelGGL(color_rows_kernel<T>, dim3((unsigned)((rows + 127) / 128)), dim3(128), 0, s, x, rows, A, B);
+    return hipGetLastError();
+}
+template hipError_t color_rows<float>(float*, long, int, const double*, hipStream_t);
+template hipError_t color_rows<double>(double*, long, int, const double*, hipStream_t);
+
 template hipError_t filter_noise<float>(float*, long, int, int, const double*, hipStream_t);
 template hipError_t filter_noise<double>(double*, long, int, int, const double*, hipStream_t);
 

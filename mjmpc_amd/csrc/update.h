@@ -78,5 +78,8 @@ hipError_t sample_noise(T* noise, long P, int H, int A, const double* chol, cons
 // the in-place recursive 3-tap filter of control_utils.py:32-33 on its own
 template <typename T>
 hipError_t filter_noise(T* noise, long P, int H, int A, const double* coeffs, hipStream_t s);
+// x[row][:] <- x[row][:] B, B float64 [A][A] row-major (numpy's SVD colouring of a standard-normal stream)
+template <typename T>
+hipError_t color_rows(T* x, long rows, int A, const double* B, hipStream_t s);
 
 }  // namespace mjmpc

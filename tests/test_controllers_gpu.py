@@ -134,6 +134,8 @@ def _e2e(golden, tag, make, env, steps_check=True):
         state["cur"] = np.asarray(s["state"], float).reshape(-1).copy()
 
     def rollout_fn(num_particles, horizon, mean, noise, mode):
+        if hasattr(noise, "cpu"):               # device samplers hand over CUDA tensors
+            noise = noise.cpu().numpy().astype(np.float64)
         obs, rew, act, done, nobs = er.rollout(env, state["cur"], num_particles, horizon, mean, noise)
         return dict(observations=obs, actions=act, costs=-rew, dones=done, next_observations=nobs)
 
@@ -195,6 +197,19 @@ def test_e2e_lqr_cem_and_dmd(golden):
     _e2e(golden, "lqr_dmd", lambda: DMDMPC(init_cov=1.0, beta=0.1, base_action="null", lam=0.5, step_size=0.7,
                                             gamma=1.0, update_cov=True, cov_type="diagonal",
                                             filter_coeffs=[1.0, 0.0, 0.0], **kw), env)
+
+
+def test_e2e_lqr_cem_seed_identical_on_the_device(golden):
+    """Full-covariance CEM with the reference's own noise stream regenerated on the GPU (noise_mode
+    'device_mt19937', general covariance through numpy's SVD colouring): the reference's optimize() sequence."""
+    from mjmpc_amd.control import CEM
+    from oracle.envs_ref import LQRRef
+    g = golden("e2e")
+    env = LQRRef(g["lqr_A"], g["lqr_B"], g["lqr_Q"], g["lqr_R"])
+    kw = dict(d_state=3, d_obs=3, d_action=2, horizon=8, num_particles=40, n_iters=2,
+              action_lows=-np.ones(2) * 5, action_highs=np.ones(2) * 5, seed=77, noise_mode="device_mt19937")
+    _e2e(golden, "lqr_cem", lambda: CEM(init_cov=1.0, base_action="null", elite_frac=0.2, step_size=0.8, gamma=1.0,
+                                         beta=0.1, cov_type="full", filter_coeffs=[1.0, 0.0, 0.0], **kw), env)
 
 
 def test_device_noise_statistics():

@@ -47,8 +47,11 @@ def test_full_size_stream_alignment_and_step_counter():
         d = _ulp_diff(got, want)
         assert d.max() <= 4, d.max()                  # device log() vs glibc + the sqrt(c) scaling: last bits
         assert (d == 0).mean() > 0.95
-    with pytest.raises(ValueError):
-        dev.sample_noise_mt19937(8, np.diag([1.0, 2, 1, 1, 1, 1, 1]), [1.0, 0.0, 0.0], 1, 0)
+    # a non-isotropic (here: diagonal) covariance goes through numpy's SVD colouring (test below), no longer refused
+    from mjmpc_amd.control.control_utils import generate_noise
+    cov = np.diag([1.0, 2, 1, 1, 1, 1, 1])
+    got = dev.sample_noise_mt19937(8, cov, [1.0, 0.0, 0.0], 1, 0).cpu().numpy()
+    np.testing.assert_allclose(got, generate_noise(cov, [1.0, 0.0, 0.0], (8, H), 1), rtol=1e-12, atol=1e-13)
 
 
 def test_jump_ahead_segmentation_is_bit_identical_to_the_serial_stream():
@@ -123,3 +126,24 @@ def test_sharded_block_of_the_stream():
     from mjmpc_amd.control.control_utils import generate_noise
     want = generate_noise(0.9 * np.eye(A), [0.25, 0.8, 0.0], (P, H), seed + 2)
     np.testing.assert_allclose(full, want, rtol=4e-15, atol=4e-15)
+
+
+def test_general_covariance_matches_numpy_svd_colouring():
+    """np.random.multivariate_normal colours its standard-normal stream with sqrt(s)[:, None] * v from svd(cov)
+    (control_utils.py:30).  The device regenerates the stream and applies the same (host-computed) matrix in a fixed
+    order: agreement to rounding of the 7-term products, not bit for bit (BLAS' dot has its own order)."""
+    from mjmpc_amd.control._device import DeviceUpdater
+    from mjmpc_amd.control.control_utils import generate_noise
+    P, H, A, seed = 300, 12, 5, 77
+    rs = np.random.RandomState(1)
+    Bm = rs.randn(A, A)
+    cov = Bm @ Bm.T + 0.2 * np.eye(A)
+    dev = DeviceUpdater(H, A, np.ones(H))
+    for coeffs in ([1.0, 0.0, 0.0], [0.25, 0.8, 0.1]):
+        got = dev.sample_noise_mt19937(P, cov, coeffs, seed, 4).cpu().numpy()
+        want = generate_noise(cov, coeffs, (P, H), seed + 4)
+        np.testing.assert_allclose(got, want, rtol=1e-12, atol=1e-13)
+    assert int(dev._rec["mt_status"].item()) == 0
+    # a sharded rank keeps its block of the one stream
+    mine = dev.sample_noise_mt19937(100, cov, [1.0, 0.0, 0.0], seed, 4, particle_offset=100).cpu().numpy()
+    np.testing.assert_allclose(mine, generate_noise(cov, [1.0, 0.0, 0.0], (P, H), seed + 4)[100:200], rtol=1e-12, atol=1e-13)
