@@ -99,3 +99,54 @@ def test_tree_f32_within_stated_tolerance(hand):
     err = np.abs(rew - o[1])
     print("tree f32 cost error: max %.3e mean %.3e" % (err.max(), err.mean()))
     assert err.max() < 5e-3
+
+
+def test_tree_pen_config_size_65536x64(hand):
+    """BASELINE config 5's size on the synthetic tree (one GPU): a 65536 x 64 rollout; size-independent properties
+    on everything (determinism of duplicated particles, obs[t] = next_obs[t-1], cost = f(hand - target)) and the
+    oracle itself on every 1021st particle at 1e-9."""
+    raw, eng, ref = hand
+    import torch
+    P, H, A = 65536, 64, 24
+    st = dict(STATES[1], target_pos=np.array(raw.target_pos))
+    g = torch.Generator(device="cuda").manual_seed(5)
+    noise = 0.5 * torch.randn(P, H, A, device="cuda", dtype=torch.float64, generator=g)
+    noise[P // 2:] = noise[:P // 2]
+    mean = np.zeros((H, A))
+    eng.set_env_state(dict(st, qa=np.zeros(24), timestep=0))
+    costs, act, obs, nobs = eng.rollout_device(P, H, mean, noise, want_obs=True)
+    assert torch.equal(costs[:P // 2], costs[P // 2:])
+    assert torch.equal(obs[:, 1:], nobs[:, :-1])
+    d = nobs[..., 2 * A + 3:2 * A + 6]
+    want = d.abs().sum(-1) + 5 * (d * d).sum(-1).sqrt()
+    assert torch.isfinite(costs).all() and float((costs - want).abs().max()) < 1e-12
+    idx = np.arange(0, P // 2, 1021)
+    sub = noise[idx].cpu().numpy()
+    _, o_rew, _, _, o_nobs = ref.rollout(st["qp"], st["qv"], st["target_pos"], mean, sub)
+    np.testing.assert_allclose(costs[idx].cpu().numpy(), -o_rew, rtol=1e-9, atol=1e-9)
+    np.testing.assert_allclose(nobs[idx].cpu().numpy(), o_nobs, rtol=0, atol=1e-9)
+    assert eng.solver_failures() == 0
+
+
+def test_dmd_step_on_the_tree(hand):
+    """DMD-MPC (the controller BASELINE config 5 names) over the tree engine: optimize() = dmd_update on oracle
+    rollouts from the same host noise, 512 x 16."""
+    from mjmpc_amd.control import DMDMPC
+    from mjmpc_amd.envs.arm_engine import make_rollout_fn
+    from oracle import controllers_ref as cr
+    raw, eng, ref = hand
+    P, H, A = 512, 16, 24
+    ctrl = DMDMPC(d_state=eng.d_state, d_obs=eng.d_obs, d_action=A, horizon=H, init_cov=0.3, beta=0.1, base_action="null",
+                  lam=0.5, num_particles=P, step_size=0.9, gamma=0.99, n_iters=1, update_cov=True, cov_type="diagonal",
+                  action_lows=eng.action_lows, action_highs=eng.action_highs, filter_coeffs=[0.25, 0.8, 0.0], seed=11)
+    ctrl.set_sim_state_fn = eng.set_env_state
+    ctrl.rollout_fn = make_rollout_fn(eng)
+    st = dict(STATES[0], target_pos=np.array(raw.target_pos), qa=np.zeros(24), timestep=0)
+    action, _ = ctrl.optimize(st)
+    mean0, cov0 = np.zeros((H, A)), 0.3 * np.eye(A)
+    noise = cr.generate_noise(cov0, [0.25, 0.8, 0.0], (P, H), 11)
+    _, rew, act, _, _ = ref.rollout(st["qp"], st["qv"], st["target_pos"], mean0, noise, want_obs=False)
+    mean1, cov1 = cr.dmd_update(-rew, act, mean0, cov0, cr.gamma_seq(0.99, H), 0.5, 0.9, True, "diagonal")
+    np.testing.assert_allclose(action, mean1[0], rtol=0, atol=1e-9)
+    np.testing.assert_allclose(ctrl.mean_action, cr.shift_mean(mean1, "null"), rtol=0, atol=1e-9)
+    np.testing.assert_allclose(ctrl.cov_action, cr.dmd_shift_cov(cov1, 0.1, True), rtol=1e-9, atol=1e-12)
