@@ -3,7 +3,7 @@
 # (b) two ranks sharing cuda:0 over gloo -> rank / sharding / barrier / MAX-reduce plumbing of bench.py
 cd "$(dirname "$0")/.."
 echo "== (a) nccl world 1, graph"
-RANK=0 LOCAL_RANK=0 WORLD_SIZE=1 python - <<'PY'
+RANK=0 LOCAL_RANK=0 WORLD_SIZE=1 timeout 180 python - <<'PY'
 import os, sys, numpy as np, torch, torch.distributed as dist
 sys.path.insert(0, os.getcwd())
 os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = "29533"
@@ -60,4 +60,4 @@ assert np.abs(got - ref).max() < 1e-9
 dist.destroy_process_group()
 PY
 echo "== (b) gloo world 2 on cuda:0"
-python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29544 bench.py --gpus 2 --steps 20 --warmup 3 --backend gloo --device 0 --no-cpu-baseline 2>&1 | tail -2 | cut -c1-700
+timeout 300 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29544 bench.py --gpus 2 --steps 20 --warmup 3 --backend gloo --device 0 --no-cpu-baseline 2>&1 | tail -2 | cut -c1-700
