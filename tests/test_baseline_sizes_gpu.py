@@ -115,7 +115,10 @@ def test_f32_three_waves_per_simd_32768(raw_arm, ref_arm):
     costs, nobs = costs.cpu().numpy().astype(np.float64), nobs.cpu().numpy().astype(np.float64)
     _, o_rew, _, _, o_nobs = ref_arm.rollout(MOVING["qp"], MOVING["qv"], MOVING["target_pos"], mean, noise)
     err = np.abs(costs + o_rew)
-    print("f32 @ 32768: cost error max %.3e mean %.3e" % (err.max(), err.mean()))
+    q = np.quantile(err, [0.5, 0.999, 0.99999])
+    print("f32 @ 32768: cost error max %.3e mean %.3e, median %.1e, 99.9 %% %.1e, 99.999 %% %.1e" % ((err.max(), err.mean()) + tuple(q)))
     assert err.max() < 2e-3
+    assert q[1] < 1e-4          # SURVEY 8d's provisional f32 target holds for 99.9 % of the 10^6 costs; the tail comes from
+                                # limit rows that switch one substep apart in f32 and f64 (discontinuous activation)
     assert np.abs(nobs[:, -1, :7] - o_nobs[:, -1, :7]).max() < 2e-2
     assert eng.solver_failures() == 0
