@@ -22,7 +22,7 @@ import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
 
-def run(name, make, P, H, steps, warmup, dtype, note):
+def _run_arm(name, make, P, H, steps, warmup, dtype, note):
     import torch
     from mjmpc_amd.envs.arm_engine import ArmRolloutEngine, make_device_rollout_fn
     from mjmpc_amd.models.reacher7dof import reacher7dof_raw
@@ -111,6 +111,7 @@ def main():
     ap.add_argument("--dtype", choices=["f64", "f32"], default="f64")
     ap.add_argument("--tree-particles", type=int, default=65536)
     ap.add_argument("--only-tree", action="store_true")
+    ap.add_argument("--only", default="", help="run only the arm configurations whose name starts with this (cfg1, cfg3, cfg4)")
     args = ap.parse_args()
     from mjmpc_amd.control import CEM, DMDMPC, MPPI
 
@@ -118,6 +119,10 @@ def main():
         return dict(d_state=eng.d_state, d_obs=eng.d_obs, d_action=7, horizon=H, num_particles=P, n_iters=1,
                     action_lows=eng.action_lows, action_highs=eng.action_highs, seed=123, noise_mode="device",
                     noise_dtype=args.dtype)
+
+    def run(name, *a):
+        if name.startswith(args.only):
+            _run_arm(name, *a)
 
     if not args.only_tree:
         run("cfg1 reacher_7dof-v0 MPPI 1024xH32",
@@ -137,6 +142,8 @@ def main():
     def kw24(eng, P, H):
         return dict(kw(eng, P, H), d_action=24)
 
+    if args.only:
+        return
     run_tree("cfg4t DMD-MPC 65536xH64 on the synthetic 24-dof hand tree (pen-v0 assets absent)",
              lambda e, P, H: DMDMPC(init_cov=0.3, beta=0.1, base_action="null", lam=0.1, step_size=1.0, gamma=1.0,
                                     update_cov=False, cov_type="diagonal", filter_coeffs=[0.25, 0.8, 0.0], **kw24(e, P, H)),
