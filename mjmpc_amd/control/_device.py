@@ -243,13 +243,17 @@ class DeviceUpdater:
                                                      self.stream()))
 
     # ------------------------------------------------------------------ CEM
-    def cem_update(self, costs, actions, num_elite, step_size, full_cov):
+    def cem_update(self, costs, actions, num_elite, step_size, full_cov, q0=None):
+        """``q0``: cost_to_go(costs)[:, 0] when the rollout launch has already produced it (float64 [P], device)."""
         costs, actions, P = self._pair(costs, actions)
         ws = self.workspace(P)
         code = self.code(costs)
         G, rank = self.comm.world_size, self.comm.rank
-        _lib.check(self.lib.mjmpc_traj_cost(code, P, self.H, self.A, _vp(costs), _vp(self.gseq), self.gamma_zero,
-                                            _vp(ws), self.stream()))
+        if q0 is not None:
+            self._q0_view(ws, P).copy_(q0)
+        else:
+            _lib.check(self.lib.mjmpc_traj_cost(code, P, self.H, self.A, _vp(costs), _vp(self.gseq), self.gamma_zero,
+                                                _vp(ws), self.stream()))
         q_all_ptr, P_all = None, P
         if G > 1:
             q0 = self._q0_view(ws, P)
@@ -288,12 +292,15 @@ class DeviceUpdater:
         return ws[off:off + P]
 
     # ------------------------------------------------------------------ random shooting
-    def rs_update(self, costs, actions, step_size):
+    def rs_update(self, costs, actions, step_size, q0=None):
         costs, actions, P = self._pair(costs, actions)
         ws = self.workspace(P)
         code = self.code(costs)
-        _lib.check(self.lib.mjmpc_traj_cost(code, P, self.H, self.A, _vp(costs), _vp(self.gseq), self.gamma_zero,
-                                            _vp(ws), self.stream()))
+        if q0 is not None:
+            self._q0_view(ws, P).copy_(q0)
+        else:
+            _lib.check(self.lib.mjmpc_traj_cost(code, P, self.H, self.A, _vp(costs), _vp(self.gseq), self.gamma_zero,
+                                                _vp(ws), self.stream()))
         rec = self.record("rs", 2 + self.H * self.A)
         _lib.check(self.lib.mjmpc_rs_best(code, P, self.H, self.A, _vp(actions), self.comm.rank * P, _vp(rec), _vp(ws),
                                           self.stream()))

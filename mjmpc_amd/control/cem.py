@@ -20,9 +20,12 @@ class CEM(OLGaussianMPC):
     def _device_cov(self):
         return self.cov_type in ('diagonal', 'full')
 
+    def _wants_q0(self):
+        return True
+
     def _device_update(self, trajectories):
         self.dev.cem_update(trajectories["costs"], trajectories["actions"], self.num_elite, self.step_size,
-                            self.cov_type == 'full')
+                            self.cov_type == 'full', q0=trajectories.get("q0"))
 
     def _device_shift_cov(self):
         self.dev.add_cov_diag(self.init_cov, self.beta)

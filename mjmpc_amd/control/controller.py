@@ -310,6 +310,9 @@ class OLGaussianMPC(Controller):
     def _fused_capable(self):
         return False            # MPPI overrides: filter + cost-to-go + update/shift fusions
 
+    def _wants_q0(self):
+        return False            # CEM / random shooting: the update reads nothing of the costs but q0
+
     def _draw_raw(self, n_loc, steps_ahead):
         """Unfiltered device noise of control step (device step counter + steps_ahead)."""
         if self.noise_mode == 'device_mt19937':
@@ -356,7 +359,17 @@ class OLGaussianMPC(Controller):
             if self._graph_post is not None:
                 self._graph_post(self._action_dev)
             return
+        # Updates that only need q0 = cost_to_go(costs)[:, 0] (CEM, random shooting) take it from the rollout launch, which
+        # also applies the noise filter on the fly: one filter pass and one cost-to-go pass less per iteration
+        q0_fused = (self._wants_q0() and self.noise_mode == 'device' and hasattr(self._rollout_fn, "fused")
+                    and not self.dev.gamma_zero and not self.use_zero_control_seq)
         for _ in range(self.n_iters):
+            if q0_fused:
+                raw = self._draw_raw(n_loc, 0)
+                costs, actions, q0 = self._rollout_fn.fused(n_loc, self.horizon, self.dev.mean, raw,
+                                                            self.dev.record("coeffs", 3), self.dev.gseq)
+                self._device_update(dict(costs=costs, actions=actions, q0=q0))
+                continue
             if self.noise_mode == 'device_mt19937':
                 delta = self.dev.sample_noise_mt19937(n_loc, self._cov_host, self.filter_coeffs, self.seed_val, 0,
                                                       dtype=self.noise_dtype, d_step=self._step_dev,

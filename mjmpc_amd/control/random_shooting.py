@@ -16,8 +16,11 @@ class RandomShooting(OLGaussianMPC):
     def _static_cov(self):
         return True
 
+    def _wants_q0(self):
+        return True
+
     def _device_update(self, trajectories):
-        self.dev.rs_update(trajectories["costs"], trajectories["actions"], self.step_size)
+        self.dev.rs_update(trajectories["costs"], trajectories["actions"], self.step_size, q0=trajectories.get("q0"))
 
     def _update_distribution(self, trajectories):
         """random_shooting.py:52-62: move the mean towards the single best action sequence."""
