@@ -307,3 +307,33 @@ def test_get_env_state_after_per_shard_states(raw_arm):
     assert len(got) == 2 and np.array_equal(got[1]["qp"], s1["qp"]) and np.array_equal(got[0]["target_pos"], s0["target_pos"])
     eng.set_env_state(s0)
     assert len(eng.get_env_state()) == 1
+
+
+def test_two_wave_and_one_wave_kernels_agree(tmp_path):
+    """The same 4096 x 32 rollout through both execution shapes of the arm kernel (MJMPC_ARM_DUO=1: two wavefronts per
+    particle group, explicit inverses, Sherman-Morrison re-iteration; =0: one wavefront does everything): costs agree
+    to 1e-11 relative - two algebraically different solver organisations on identical inputs."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = tmp_path / "run.py"
+    script.write_text(
+        "import sys, numpy as np, torch\n"
+        "sys.path.insert(0, %r)\n"
+        "from mjmpc_amd.envs.arm_engine import ArmRolloutEngine\n"
+        "from mjmpc_amd.models.reacher7dof import reacher7dof_raw\n"
+        "eng = ArmRolloutEngine(reacher7dof_raw(), dtype='f64')\n"
+        "eng.set_env_state(dict(qp=np.array([0.0, 0.7, 0.0, -0.2, 0.0, -0.1, 0.0]), qv=np.array([0.0, 1.5, 0, 0, 0, 0, 0.0]),\n"
+        "                       target_pos=np.array([0.2, -0.1, -0.25])))\n"
+        "g = torch.Generator(device='cuda').manual_seed(3)\n"
+        "noise = torch.randn(4096, 32, 7, device='cuda', dtype=torch.float64, generator=g)\n"
+        "c, a, _, _ = eng.rollout_device(4096, 32, np.zeros((32, 7)), noise)\n"
+        "np.save(sys.argv[1], c.cpu().numpy()); assert eng.solver_failures() == 0\n" % root)
+    out = {}
+    for duo in ("0", "1"):
+        path = str(tmp_path / ("c%s.npy" % duo))
+        subprocess.run([sys.executable, str(script), path], check=True, timeout=300, env=dict(os.environ, MJMPC_ARM_DUO=duo))
+        out[duo] = np.load(path)
+    np.testing.assert_allclose(out["1"], out["0"], rtol=1e-11, atol=1e-12)
+    assert np.abs(out["1"] - out["0"]).max() > 0        # ... and they ARE different programs
