@@ -22,11 +22,21 @@ import yaml
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
 from mjmpc_amd.envs.arm_engine import ArmRolloutEngine, make_device_rollout_fn, make_rollout_fn   # noqa: E402
-from mjmpc_amd.envs.reacher_env import ContinualReacher7DOFEnv, Reacher7DOFEnv                   # noqa: E402
+from mjmpc_amd.envs.reacher_env import ContinualReacher7DOFEnv, HandTreeEnv, Reacher7DOFEnv      # noqa: E402
+from mjmpc_amd.envs.tree_engine import TreeRolloutEngine                                         # noqa: E402
+from mjmpc_amd.models.hand24 import hand24_raw                                                   # noqa: E402
 from mjmpc_amd.models.reacher7dof import reacher7dof_raw                                         # noqa: E402
 from mjmpc_amd.policies import MPCPolicy                                                         # noqa: E402
 
-ENVS = {"reacher_7dof-v0": Reacher7DOFEnv, "continual_reacher-v0": ContinualReacher7DOFEnv}
+ENVS = {"reacher_7dof-v0": Reacher7DOFEnv, "continual_reacher-v0": ContinualReacher7DOFEnv,
+        "hand_tree-v0": HandTreeEnv}           # the last one: the synthetic 24-dof tree on the tree engine
+
+
+def make_sim(env_name, dtype, num_shards):
+    """The rollout engine standing in for the reference's SubprocVecEnv worker pool."""
+    if env_name == "hand_tree-v0":
+        return TreeRolloutEngine(hand24_raw(), dtype=dtype, num_shards=num_shards)
+    return ArmRolloutEngine(reacher7dof_raw(), dtype=dtype, num_shards=num_shards)
 
 
 def main():
@@ -53,7 +63,7 @@ def main():
 
     env = ENVS[exp["env_name"]](dtype=args.dtype)                    # the "real" environment
     env.real_env_step(True)
-    sim = ArmRolloutEngine(reacher7dof_raw(), dtype=args.dtype, num_shards=num_cpu)   # the rollout engine
+    sim = make_sim(exp["env_name"], args.dtype, num_cpu)             # the rollout engine
     if args.dyn_randomize_config:
         with open(args.dyn_randomize_config) as f:
             default_params, randomized = sim.randomize_dynamics(yaml.safe_load(f), base_seed=exp["seed"])
@@ -98,7 +108,7 @@ def main():
         trajectories.append(dict(observations=np.array(observations), actions=np.array(actions),
                                  rewards=np.array(rewards), env_infos=dict(goal_achieved=np.array(infos))))
         print("episode %d: reward %.3f, final distance to target %.4f" % (i, ep_rewards[i],
-                                                                          np.linalg.norm(observations[-1][17:20])))
+                                                                          np.linalg.norm(observations[-1][-3:])))
     failures = sim.solver_failures()
     sim.close()
     print("Avg. reward = %.4f, Std. Reward = %.4f, Success Metric = %.1f" % (

@@ -109,3 +109,24 @@ class ContinualReacher7DOFEnv(Reacher7DOFEnv):
     def trigger_timed_events(self):
         if self.env_timestep % 50 == 0 and self.env_timestep > 0 and self.real_step is True:
             self.target_reset()
+
+
+class HandTreeEnv(Reacher7DOFEnv):
+    """``hand_tree-v0``: the synthetic 24-dof hand-on-an-arm tree (mjmpc_amd/models/hand24.py) with the reacher task -
+    bring the index fingertip to a target above the table - stepped by the TREE engine at P = 1.  Not a reference
+    environment: it gives the tree kernel (pen-v0's shape of work) a closed loop to run in."""
+    max_episode_steps = 100
+
+    def __init__(self, device=0, dtype="f64", engine=None):
+        if engine is None:
+            from .tree_engine import TreeRolloutEngine
+            from ..models.hand24 import hand24_raw
+            engine = TreeRolloutEngine(hand24_raw(), device=device, dtype=dtype)
+        super().__init__(device=device, dtype=dtype, engine=engine)
+
+    def target_reset(self):
+        t = np.zeros(3)                              # a box in front of the hand's rest pose, above the table
+        t[0] = self.np_random.uniform(low=0.45, high=0.65)
+        t[1] = self.np_random.uniform(low=-0.55, high=-0.25)
+        t[2] = self.np_random.uniform(low=-0.05, high=0.15)
+        self._target = t

@@ -41,3 +41,19 @@ def test_continual_config_parses(tmp_path):
     out = subprocess.run([sys.executable, os.path.join(ROOT, "examples", "example_mpc.py"), "--config", cfg,
                           "--controller", "mppi", "--noise_mode", "device"], capture_output=True, text=True, timeout=300)
     assert out.returncode == 0, out.stderr[-2000:]
+
+
+def test_tree_config_runs(tmp_path):
+    """examples/configs/hand_tree_gpu.yml: the same driver over the tree engine (24-dof hand), a short DMD-MPC episode."""
+    with open(os.path.join(ROOT, "examples", "configs", "hand_tree_gpu.yml")) as f:
+        exp = yaml.safe_load(f)
+    exp["n_episodes"], exp["max_ep_length"] = 1, 5
+    for block in exp.values():
+        if isinstance(block, dict) and "particles_per_cpu" in block:
+            block["particles_per_cpu"] = 128
+    p = tmp_path / "tree.yml"
+    p.write_text(yaml.safe_dump(exp))
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "examples", "example_mpc.py"), "--config", str(p),
+                          "--controller", "dmd", "--noise_mode", "device"], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr[-2000:]
+    assert "Success Metric" in out.stdout and "solver failures 0" in out.stdout
