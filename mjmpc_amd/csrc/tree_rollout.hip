@@ -519,7 +519,7 @@ __global__ __launch_bounds__(64 * wg_waves(DP)) void tree_rollout_kernel(
                     // f32: a row whose residual is within rounding of zero keeps its state (as in arm_rollout.hip)
                     const T resl = sig * xa - aref;
                     const T band = sizeof(T) == 4 ? T(2e-5) * (fabs(aref) + fabs(xa) + T(1)) : T(0);
-                    const bool act2 = inst && (actv ? !(resl > band) : (resl < -band));
+                    bool act2 = inst && (actv ? !(resl > band) : (resl < -band));
                     unsigned cact2 = 0;
                     for (int s = 0; s < n_sphere; ++s) {
                         if (!__any((cinst >> s) & 1u)) continue;
@@ -530,6 +530,47 @@ __global__ __launch_bounds__(64 * wg_waves(DP)) void tree_rollout_kernel(
                         if (((cinst >> s) & 1u) && (was ? !(res > bc) : (res < -bc))) cact2 |= 1u << s;
                     }
                     changed = (act2 != actv) || (cact2 != cact);
+                    // One limit row j of a particle changed state (the usual reason for another iteration):
+                    // H' = H + c e_j e_j', c = +-D_j, rhs' = rhs + c sig_j aref_j e_j.  With z = H^-1 e_j - one more pair of
+                    // triangular solves with the factor at hand, a third of a factor + solve - Sherman-Morrison gives
+                    // a' = y - c z y_j / (1 + c z_j),  y = a + (c sig_j aref_j) z.  Several flips in one particle or a
+                    // contact-row flip take the general path (next iteration refactors).
+                    if (__any(changed)) {
+                        const bool flip = act2 != actv;
+                        const unsigned nflip = __popc((unsigned)(__ballot(flip) >> (32 * half)));
+                        if (!__any(cact2 != cact || nflip > 1u)) {
+                            const T zl = tree_solve<DP>(hrow, flip ? T(1) : T(0), ELIM, AT, ROW, VEC, l, n_rounds, depth, max_depth);
+                            if (flip) {
+                                const T c = act2 ? D : -D;
+                                VEC[0] = c;
+                                VEC[1] = c * sig * aref;
+                                VEC[2] = zl;
+                                VEC[3] = xa;
+                            }
+                            TSYNC();
+                            if (nflip == 1u) {
+                                const T c = VEC[0], dl = VEC[1], zj = VEC[2], yj = VEC[3] + dl * zj;
+                                xa = (xa + dl * zl) - c * zl * yj * rcp_(T(1) + c * zj);
+                            }
+                            TSYNC();
+                            actv = act2;                // the sets the corrected solution belongs to
+                            const T resl2 = sig * xa - aref;
+                            const T band2 = sizeof(T) == 4 ? T(2e-5) * (fabs(aref) + fabs(xa) + T(1)) : T(0);
+                            const bool act3 = inst && (actv ? !(resl2 > band2) : (resl2 < -band2));
+                            unsigned cact3 = 0;
+                            for (int s = 0; s < n_sphere; ++s) {
+                                if (!__any((cinst >> s) & 1u)) continue;
+                                const T arc = X[A_CS + s * 8 + 5];
+                                const T res = sum32(X[A_JC + s * TL + l] * xa) - arc;
+                                const T bc = sizeof(T) == 4 ? T(2e-5) * (fabs(arc) + fabs(res + arc) + T(1)) : T(0);
+                                const bool was = (cact >> s) & 1u;
+                                if (((cinst >> s) & 1u) && (was ? !(res > bc) : (res < -bc))) cact3 |= 1u << s;
+                            }
+                            act2 = act3;
+                            cact2 = cact3;
+                            changed = (act2 != actv) || (cact2 != cact);
+                        }
+                    }
                     // f32 only: with accelerations of 1e4 rad/s^2 on gram-sized finger links a row can sit within
                     // rounding of its switching point and flip back and forth; a particle whose set returns to the one
                     // of two iterations ago has converged to working precision (either set gives the same forces)
