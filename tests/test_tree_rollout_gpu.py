@@ -150,3 +150,44 @@ def test_dmd_step_on_the_tree(hand):
     np.testing.assert_allclose(action, mean1[0], rtol=0, atol=1e-9)
     np.testing.assert_allclose(ctrl.mean_action, cr.shift_mean(mean1, "null"), rtol=0, atol=1e-9)
     np.testing.assert_allclose(ctrl.cov_action, cr.dmd_shift_cov(cov1, 0.1, True), rtol=1e-9, atol=1e-12)
+
+
+@pytest.mark.parametrize("n_links", [12, 20])
+def test_deep_chains_use_the_wider_row_instantiations(n_links):
+    """Root-to-leaf paths longer than 8 links run the DP = 16 / DP = 32 instantiations of the tree kernel (path-indexed
+    rows of 16 / 32 entries): a 12-link and a 20-link chain with a two-link side branch, gravity on, against the oracle."""
+    from mjmpc_amd.envs.tree_engine import TreeRolloutEngine
+    from mjmpc_amd.models.raw import GEOM_CAPSULE, GEOM_SPHERE, RawActuator, RawBody, RawGeom, RawJoint, RawModel, RawPlane
+    from oracle.physics_ref import RefArm
+    axes = [(0, 0, 1), (0, 1, 0), (1, 0, 0)]
+    bodies = []
+    for i in range(n_links):
+        r = 0.03 - 0.001 * i
+        bodies.append(RawBody("l%d" % i, i - 1, (0.0, 0.0, 0.3) if i == 0 else (0.08, 0.0, 0.0),
+                              joint=RawJoint(axes[i % 3], (-1.2, 1.2), True, 0.3, 0.002, "j%d" % i),
+                              geoms=[RawGeom(GEOM_CAPSULE, r, (0, 0, 0), (0.08, 0, 0), margin=0.001)]))
+    # a side branch half way up, so that the model is a tree and not a chain
+    mid = n_links // 2
+    bodies.insert(mid + 1, RawBody("b0", mid, (0.0, 0.05, 0.0), joint=RawJoint((0, 0, 1), (-1, 1), True, 0.2, 0.001, "jb0"),
+                                   geoms=[RawGeom(GEOM_CAPSULE, 0.015, (0, 0, 0), (0, 0.06, 0), margin=0.001)]))
+    bodies.insert(mid + 2, RawBody("b1", mid + 1, (0.0, 0.06, 0.0), joint=RawJoint((1, 0, 0), (-1, 1), True, 0.2, 0.001, "jb1"),
+                                   geoms=[RawGeom(GEOM_SPHERE, 0.02, (0, 0.03, 0), collide=True, margin=0.001)]))
+    for b in bodies[mid + 3:]:                      # the rest of the main chain hangs off link `mid`, after the branch
+        b.parent = b.parent + 2 if b.parent > mid else b.parent
+    bodies[mid + 3].parent = mid
+    nv = len(bodies)
+    raw = RawModel(bodies=bodies, actuators=[RawActuator(b.joint.name, 0.5, (-1, 1)) for b in bodies],
+                   site_body=nv - 1, site_pos=(0.08, 0, 0), target_pos=(0.5, 0.2, 0.4),
+                   plane=RawPlane((0, 0, -0.05), (0, 0, 1), 0.001), timestep=0.004, frame_skip=2, gravity=(0, 0, -9.81))
+    eng, ref = TreeRolloutEngine(raw, dtype="f64"), RefArm(raw.to_flat())
+    assert eng.model.max_path == n_links and nv == n_links + 2          # 12 -> DP = 16, 20 -> DP = 32
+    rs = np.random.RandomState(n_links)
+    P, H = 66, 12
+    q0, v0 = 0.3 * rs.randn(nv), 0.5 * rs.randn(nv)
+    noise, mean = 0.5 * rs.standard_normal((P, H, nv)), 0.1 * rs.standard_normal((H, nv))
+    eng.set_env_state(dict(qp=q0, qv=v0, target_pos=np.array(raw.target_pos)))
+    obs, rew, act, done, info, nobs = eng.rollout(P, H, mean, noise, "open_loop")
+    o = ref.rollout(q0, v0, np.array(raw.target_pos), mean, noise)
+    np.testing.assert_allclose(rew, o[1], rtol=1e-9, atol=1e-9)
+    np.testing.assert_allclose(nobs, o[4], rtol=0, atol=1e-9)
+    assert eng.solver_failures() == 0
