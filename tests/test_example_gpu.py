@@ -57,3 +57,26 @@ def test_tree_config_runs(tmp_path):
                           "--controller", "dmd", "--noise_mode", "device"], capture_output=True, text=True, timeout=300)
     assert out.returncode == 0, out.stderr[-2000:]
     assert "Success Metric" in out.stdout and "solver failures 0" in out.stdout
+
+
+def test_integration_md_ctypes_stub_runs(raw_arm, ref_arm):
+    """The ctypes stub INTEGRATION.md section 3 shows a maintainer (HipVecEnv) is executed as written and compared with
+    the oracle: the documented binding is a working binding."""
+    import numpy as np
+    from mjmpc_amd.models.compile import compile_arm
+    text = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    sec = text[text.index("## 3."):text.index("## 4.")]
+    code = sec[sec.index("```python") + len("```python"):]
+    code = code[:code.index("```")]
+    code = code.replace('ctypes.CDLL("libmjmpc_amd.so")', 'ctypes.CDLL(%r)' % os.path.join(ROOT, "mjmpc_amd", "libmjmpc_amd.so"))
+    ns = {}
+    exec(compile(code, "INTEGRATION.md#3", "exec"), ns)
+    env = ns["HipVecEnv"](np.ascontiguousarray(compile_arm(raw_arm).blob))
+    st = dict(qp=np.array([0.3, 0.5, -0.2, -1.0, 0.4, -0.6, 0.2]), qv=np.zeros(7), target_pos=np.array([0.1, 0.1, 0.1]))
+    env.set_env_state(st)
+    rs = np.random.RandomState(0)
+    mean, noise = 0.1 * rs.randn(8, 7), rs.randn(16, 8, 7)
+    obs, rew, act, done, info, nobs = env.rollout(16, 8, mean, noise)
+    o = ref_arm.rollout(st["qp"], st["qv"], st["target_pos"], mean, noise)
+    np.testing.assert_allclose(rew, o[1], rtol=1e-9, atol=1e-9)
+    np.testing.assert_allclose(nobs, o[4], rtol=0, atol=1e-9)
