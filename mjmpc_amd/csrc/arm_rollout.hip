@@ -656,6 +656,10 @@ __device__ __forceinline__ void arm_front(const MT& M, const ArmInts& I, T& q, T
                 for (int i = 0; i < MAX_LINKS; ++i) col[i] = (i == l8) ? T(1) : T(0);
                 F.solve(col);
                 ST.mark(it == 0 ? 6 : 9);               // factorisation + inverse / further iterations
+                // E2: the DYN wave finished (M + h B)^-1 long ago (it needs ~1000 cycles after E1, this wave ~2000 to get
+                // here): taking the rendezvous now instead of at the end of the substep leaves only E3 between the last
+                // Newton iteration and the integration
+                if (it == 0) duo_barrier();
                 T acc = T(0);
 #pragma unroll
                 for (int i = 0; i < MAX_LINKS; ++i) acc += col[i] * ldsM[V_RH + i];
@@ -715,7 +719,8 @@ __device__ __forceinline__ void arm_front(const MT& M, const ArmInts& I, T& q, T
             }
         }
         ldsM[V_RE + l8] = tau + qfrc_c;
-        duo_barrier();                                  // E2: inverse of the Euler matrix in
+        if (!any_rows) duo_barrier();                   // E2 (substeps without rows; otherwise taken inside the loop)
+        else LDS_WAVE_SYNC();
         ST.mark(7);
         T x = T(0);
 #pragma unroll
