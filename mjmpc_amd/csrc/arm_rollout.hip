@@ -584,6 +584,7 @@ __device__ __forceinline__ void arm_front(const MT& M, const ArmInts& I, T& q, T
         ST.mark(3);
         tau = ldsM[V_TAU + l8];
     }
+    T ei[MAX_LINKS];            // SOLVE: my row of (M + h B)^-1 (read once the DYN wave has published it)
 
     // 6. constraint rows.  Limits: MuJoCo mj_instantiateLimit, strict dist < margin(=0)
     T sig = T(0), dist = T(0);
@@ -644,6 +645,9 @@ __device__ __forceinline__ void arm_front(const MT& M, const ArmInts& I, T& q, T
                 LDS_WAVE_SYNC();
                 Dense<T> F;
                 F.load(ldsM, ldsM + V_DH);
+                T rh[MAX_LINKS];            // the right-hand side, fetched with the matrix: its LDS latency hides behind the
+#pragma unroll                              // factorisation instead of standing behind the barrier
+                for (int i = 0; i < MAX_LINKS; ++i) rh[i] = ldsM[V_RH + i];
                 if (any_c && __any(cact)) {
                     T jv[MAX_LINKS];
 #pragma unroll
@@ -659,10 +663,14 @@ __device__ __forceinline__ void arm_front(const MT& M, const ArmInts& I, T& q, T
                 // E2: the DYN wave finished (M + h B)^-1 long ago (it needs ~1000 cycles after E1, this wave ~2000 to get
                 // here): taking the rendezvous now instead of at the end of the substep leaves only E3 between the last
                 // Newton iteration and the integration
-                if (it == 0) duo_barrier();
+                if (it == 0) {
+                    duo_barrier();
+#pragma unroll
+                    for (int i = 0; i < MAX_LINKS; ++i) ei[i] = ldsM[V_EI + l8 * LANES + i];   // my row of (M + h B)^-1, early
+                }
                 T acc = T(0);
 #pragma unroll
-                for (int i = 0; i < MAX_LINKS; ++i) acc += col[i] * ldsM[V_RH + i];
+                for (int i = 0; i < MAX_LINKS; ++i) acc += col[i] * rh[i];
                 aw = acc;
                 bool act2, cact2;
                 active_set(aw, sig, aref, jc, arefc, inst, cinst, act, cact, act2, cact2);
@@ -719,12 +727,17 @@ __device__ __forceinline__ void arm_front(const MT& M, const ArmInts& I, T& q, T
             }
         }
         ldsM[V_RE + l8] = tau + qfrc_c;
-        if (!any_rows) duo_barrier();                   // E2 (substeps without rows; otherwise taken inside the loop)
-        else LDS_WAVE_SYNC();
+        if (!any_rows) {
+            duo_barrier();                              // E2 (substeps without rows; otherwise taken inside the loop)
+#pragma unroll
+            for (int i = 0; i < MAX_LINKS; ++i) ei[i] = ldsM[V_EI + l8 * LANES + i];
+        } else {
+            LDS_WAVE_SYNC();
+        }
         ST.mark(7);
         T x = T(0);
 #pragma unroll
-        for (int i = 0; i < MAX_LINKS; ++i) x += ldsM[V_EI + l8 * LANES + i] * ldsM[V_RE + i];
+        for (int i = 0; i < MAX_LINKS; ++i) x += ei[i] * ldsM[V_RE + i];
         ldsM[V_XE + l8] = x;
         free_step = !any_rows;
         ST.mark(10);    // constraint force, Euler product
