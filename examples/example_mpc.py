@@ -22,20 +22,26 @@ import yaml
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
 from mjmpc_amd.envs.arm_engine import ArmRolloutEngine, make_device_rollout_fn, make_rollout_fn   # noqa: E402
+from mjmpc_amd.envs.locomotion_env import HalfCheetahEnv, SwimmerEnv                             # noqa: E402
 from mjmpc_amd.envs.reacher_env import ContinualReacher7DOFEnv, HandTreeEnv, Reacher7DOFEnv      # noqa: E402
 from mjmpc_amd.envs.tree_engine import TreeRolloutEngine                                         # noqa: E402
+from mjmpc_amd.models.half_cheetah import half_cheetah_raw                                       # noqa: E402
 from mjmpc_amd.models.hand24 import hand24_raw                                                   # noqa: E402
 from mjmpc_amd.models.reacher7dof import reacher7dof_raw                                         # noqa: E402
+from mjmpc_amd.models.swimmer import swimmer_raw                                                 # noqa: E402
 from mjmpc_amd.policies import MPCPolicy                                                         # noqa: E402
 
+# the reference's registered MuJoCo envs whose models are vendored (mjmpc/envs/__init__.py:11-31), plus the synthetic
+# 24-dof tree; all but the two reachers run on the tree engine
 ENVS = {"reacher_7dof-v0": Reacher7DOFEnv, "continual_reacher-v0": ContinualReacher7DOFEnv,
-        "hand_tree-v0": HandTreeEnv}           # the last one: the synthetic 24-dof tree on the tree engine
+        "Swimmer-v0": SwimmerEnv, "HalfCheetah-v0": HalfCheetahEnv, "hand_tree-v0": HandTreeEnv}
+TREE_MODELS = {"hand_tree-v0": hand24_raw, "Swimmer-v0": swimmer_raw, "HalfCheetah-v0": half_cheetah_raw}
 
 
 def make_sim(env_name, dtype, num_shards):
     """The rollout engine standing in for the reference's SubprocVecEnv worker pool."""
-    if env_name == "hand_tree-v0":
-        return TreeRolloutEngine(hand24_raw(), dtype=dtype, num_shards=num_shards)
+    if env_name in TREE_MODELS:
+        return TreeRolloutEngine(TREE_MODELS[env_name](), dtype=dtype, num_shards=num_shards)
     return ArmRolloutEngine(reacher7dof_raw(), dtype=dtype, num_shards=num_shards)
 
 
@@ -107,8 +113,11 @@ def main():
             ep_rewards[i] += reward
         trajectories.append(dict(observations=np.array(observations), actions=np.array(actions),
                                  rewards=np.array(rewards), env_infos=dict(goal_achieved=np.array(infos))))
-        print("episode %d: reward %.3f, final distance to target %.4f" % (i, ep_rewards[i],
-                                                                          np.linalg.norm(observations[-1][-3:])))
+        if exp["env_name"] in ("Swimmer-v0", "HalfCheetah-v0"):
+            print("episode %d: reward %.3f, forward progress %.3f m" % (i, ep_rewards[i], env.get_env_state()["qpos"][0]))
+        else:
+            print("episode %d: reward %.3f, final distance to target %.4f" % (i, ep_rewards[i],
+                                                                              np.linalg.norm(observations[-1][-3:])))
     failures = sim.solver_failures()
     sim.close()
     print("Avg. reward = %.4f, Std. Reward = %.4f, Success Metric = %.1f" % (

@@ -61,6 +61,7 @@ struct mjmpc_arm_s {
 struct mjmpc_tree_s {
     int device = 0;
     int nv = 0, nu = 0, d_obs = 0, max_path = 0;
+    bool full = false;              // friction cones, more than 8 contact points or a medium: the full kernel
     float* model_f32 = nullptr;
     double* model_f64 = nullptr;
     double* state = nullptr;        // MJMPC_TREE_STATE_LEN
@@ -330,13 +331,19 @@ int mjmpc_tree_create(const double* blob, int n_blob, int device, mjmpc_tree_t* 
         return fail(MJMPC_E_BADMODEL, "tree model blob has %d scalars, expected %d", n_blob, (int)mjmpc::TREE_BLOB_LEN);
     const int nv = (int)blob[mjmpc::T_NV];
     if (nv < 1 || nv > mjmpc::TL) return fail(MJMPC_E_BADMODEL, "nv = %d outside 1..%d", nv, mjmpc::TL);
-    if ((int)blob[mjmpc::T_N_SPHERE] > mjmpc::TREE_MAX_SPHERES) return fail(MJMPC_E_BADMODEL, "too many collision spheres");
+    if ((int)blob[mjmpc::T_N_SPHERE] > mjmpc::TREE_MAX_SPHERES) return fail(MJMPC_E_BADMODEL, "too many contact points");
+    const int nu = (int)blob[mjmpc::T_NU], task = (int)blob[mjmpc::T_TASK], skip = (int)blob[mjmpc::T_OBS_SKIP];
+    if (nu < 1 || nu > nv || task < 0 || task > 1 || skip < 0 || skip >= nv)
+        return fail(MJMPC_E_BADMODEL, "nu = %d, task = %d, obs_skip = %d do not fit nv = %d", nu, task, skip, nv);
     if (mjmpc_device_count() <= device) return fail(MJMPC_E_NOGPU, "HIP device %d not present", device);
     HIP_TRY(hipSetDevice(device));
     mjmpc_tree_s* h = new mjmpc_tree_s();
     h->device = device;
-    h->nv = h->nu = nv;
-    h->d_obs = 2 * nv + 6;
+    h->nv = nv;
+    h->nu = (int)blob[mjmpc::T_NU];
+    h->d_obs = (int)blob[mjmpc::T_TASK] == 1 ? 2 * nv - (int)blob[mjmpc::T_OBS_SKIP] : 2 * nv + 6;
+    h->full = blob[mjmpc::T_ANY_FRICTION] != 0.0 || (int)blob[mjmpc::T_N_SPHERE] > 8 || blob[mjmpc::T_DENSITY] > 0.0 ||
+              blob[mjmpc::T_VISCOSITY] > 0.0;
     for (int l = 0; l < nv; ++l) h->max_path = std::max(h->max_path, (int)blob[mjmpc::T_DEPTH + l] + 1);
     std::vector<float> f32(blob, blob + n_blob);
     HIP_TRY(hipMalloc(&h->model_f32, sizeof(float) * n_blob));
@@ -392,11 +399,11 @@ int mjmpc_tree_rollout(mjmpc_tree_t h, int dtype, int64_t P, int H, const double
     hipStream_t s = (hipStream_t)stream;
     hipError_t e;
     if (dtype == MJMPC_F32)
-        e = mjmpc::launch_tree_rollout<float>(h->model_f32, h->max_path, h->state, (long)P, H, h->nu, d_mean,
+        e = mjmpc::launch_tree_rollout<float>(h->model_f32, h->max_path, h->full, h->state, (long)P, H, h->nu, d_mean,
                                               (const float*)d_noise, (float*)d_costs, (float*)d_actions, (float*)d_obs,
                                               (float*)d_next_obs, h->diag, s);
     else if (dtype == MJMPC_F64)
-        e = mjmpc::launch_tree_rollout<double>(h->model_f64, h->max_path, h->state, (long)P, H, h->nu, d_mean,
+        e = mjmpc::launch_tree_rollout<double>(h->model_f64, h->max_path, h->full, h->state, (long)P, H, h->nu, d_mean,
                                                (const double*)d_noise, (double*)d_costs, (double*)d_actions,
                                                (double*)d_obs, (double*)d_next_obs, h->diag, s);
     else

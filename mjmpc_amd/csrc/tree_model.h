@@ -1,4 +1,4 @@
-// Constant block of a compiled kinematic TREE of hinge links (mjmpc_amd/models/compile_tree.py, TREE_LAYOUT).
+// Constant block of a compiled kinematic TREE of hinge / slide links (mjmpc_amd/models/compile_tree.py, TREE_LAYOUT).
 // Offsets are in scalars; per-link fields are stored [component][32 lanes].  Links are numbered depth-first
 // (a link's subtree is the contiguous index range [i, i + subsize_i)), link frames are world-aligned at qpos0.
 #pragma once
@@ -6,8 +6,8 @@
 namespace mjmpc {
 
 constexpr int TL = 32;              // lanes per particle (one per link / dof)
-constexpr int TREE_MAX_SPHERES = 8;
-constexpr int TREE_SPH_STRIDE = 8;  // link, pos[3], r, margin, invweight, (pad)
+constexpr int TREE_MAX_SPHERES = 16; // contact points against the plane (a colliding capsule is its two end spheres)
+constexpr int TREE_SPH_STRIDE = 12; // link, pos[3], r, margin, invweight, mu (0: frictionless row), capsule axis[3], (pad)
 
 enum TreeOffset : int {
     // the first 25 per-link fields are the arm block's, 32 lanes wide
@@ -31,8 +31,15 @@ enum TreeOffset : int {
     T_ANC = T_SUBSIZE + TL,             // 5 x 32: ancestor at distance 1, 2, 4, 8, 16 (-1: none)
     T_ANCMASK = T_ANC + 5 * TL,         // 2 x 32: bits 0-15 / 16-31 of {j : link j is me or one of my ancestors}
                                         // (two halves so that the f32 copy of the block holds them exactly)
+    // joint kind, springs, motors, medium
+    T_JTYPE = T_ANCMASK + 2 * TL,       // 1 hinge, 2 slide
+    T_STIFFNESS = T_JTYPE + TL,
+    T_SPRINGREF = T_STIFFNESS + TL,
+    T_ACT = T_SPRINGREF + TL,           // index of the action that drives this dof (-1: none)
+    T_FBOX = T_ACT + TL,                // 3 x 32   box of equal inertia (fluid model), 0 for massless links
+    T_FROT = T_FBOX + 3 * TL,           // 9 x 32   principal axes of the link's inertia in the link frame (row-major)
     // scalars
-    T_NV = T_ANCMASK + 2 * TL,
+    T_NV = T_FROT + 9 * TL,
     T_TIMESTEP,
     T_FRAME_SKIP,
     T_JUMPS,                            // pointer-jumping rounds = ceil(log2(tree depth))
@@ -49,7 +56,21 @@ enum TreeOffset : int {
     T_SOL_MID,
     T_SOL_POWER,
     T_GRAVITY,                          // 3
-    T_SPH = T_GRAVITY + 3,              // TREE_MAX_SPHERES x TREE_SPH_STRIDE
+    T_NU = T_GRAVITY + 3,
+    T_TASK,                             // 0 reach a target with the site, 1 forward progress of qpos[0]
+    T_CTRL_COST,
+    T_OBS_SKIP,
+    T_DENSITY,
+    T_VISCOSITY,
+    T_LSOL_K,                           // joint-limit rows: their own solref / solimp
+    T_LSOL_B,
+    T_LSOL_DMIN,
+    T_LSOL_DMAX,
+    T_LSOL_WIDTH,
+    T_LSOL_MID,
+    T_LSOL_POWER,
+    T_ANY_FRICTION,                     // some contact point has mu > 0 (pyramidal rows)
+    T_SPH,                              // TREE_MAX_SPHERES x TREE_SPH_STRIDE
     // tree-sparse L'DL: links of equal height above their deepest leaf are eliminated together (one round per height)
     T_DEPTH = T_SPH + TREE_MAX_SPHERES * TREE_SPH_STRIDE,      // 32: strict ancestors of the link
     T_N_ROUNDS = T_DEPTH + TL,          // max height + 1
@@ -58,6 +79,6 @@ enum TreeOffset : int {
     TREE_BLOB_LEN = T_ELIM + (TL - 1) * TL
 };
 
-static_assert(TREE_BLOB_LEN == 2200, "keep in sync with mjmpc_amd/models/compile_tree.py::TREE_LAYOUT");
+static_assert(TREE_BLOB_LEN == 2854, "keep in sync with mjmpc_amd/models/compile_tree.py::TREE_LAYOUT");
 
 }  // namespace mjmpc

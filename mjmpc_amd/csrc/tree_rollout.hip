@@ -1,8 +1,11 @@
-// Fused rollout kernel for a kinematic TREE of hinge links (first cut): the same
+// Fused rollout kernel for a kinematic TREE of hinge / slide links: the same
 //   for b in particles: for t in horizon: env.step(mean[t] + noise[b,t])
-// double loop as arm_rollout.hip (reference mjmpc/envs/gym_env_wrapper.py:125-153, reacher-style reward and
-// observation, MuJoCo mj_step inlined), for models the 8-lane serial-chain kernel cannot hold: up to 32 hinge dofs on
-// a branching tree (a hand on an arm), gravity, joint limits, up to 8 frictionless sphere/plane contacts.
+// double loop as arm_rollout.hip (reference mjmpc/envs/gym_env_wrapper.py:125-153, MuJoCo mj_step inlined), for
+// models the 8-lane serial-chain kernel cannot hold: up to 32 dofs on a branching tree (a hand on an arm; the
+// reference's vendored swimmer.xml and half_cheetah.xml with their slide/slide/hinge floating roots), gravity, joint
+// limits and springs, motors on a subset of the joints, the inertia-box fluid model, up to 16 sphere/plane contact
+// points (capsule ends) with frictionless rows or pyramidal friction cones.  Cost and observation follow the model's
+// task: the reacher's (reacher_env.py:29-47) or forward progress (swimmer.py:10-24, half_cheetah.py:10-25).
 //
 // Execution model: ONE PARTICLE = 32 LANES (lane = link = dof, links numbered depth-first), two particles per
 // wavefront, four wavefronts per workgroup sharing one LDS copy of the model block and of the topology tables.  Lanes talk through a small
@@ -25,6 +28,8 @@
 // is the arm kernel's primal active-set Newton iteration, with several contact rows.
 #include <hip/hip_runtime.h>
 
+#include <type_traits>
+
 #include "lanegroup.h"
 #include "tree_model.h"
 #include "tree_rollout.h"
@@ -38,7 +43,8 @@ constexpr int TREE_MAXIT = 16;
 #ifndef TREE_SKIP
 #define TREE_SKIP 0
 #endif
-constexpr int wg_waves(int DP) { return DP <= 8 ? 4 : (DP <= 16 ? 2 : 1); }   // LDS: [32][2 DP] rows per particle
+// waves per workgroup (LDS: [32][2 DP] rows per particle, plus three Jacobian rows per contact point with friction)
+constexpr int wg_waves(int DP, bool fric) { return fric ? (DP <= 16 ? 2 : 1) : (DP <= 8 ? 4 : (DP <= 16 ? 2 : 1)); }
 
 #define TSYNC()                                                \
     do {                                                       \
@@ -56,10 +62,11 @@ constexpr int A_ROW = 0;                    // path-indexed rows [32][row_stride
 // doubles = 128 B put them on two: measured 16-way conflicts)
 constexpr int row_stride(int DP) { return 2 * DP + 1; }
 constexpr int a_vec(int DP) { return (row_stride(DP) * TL > 12 * TL ? row_stride(DP) * TL : 12 * TL) + 3 & ~3; }   // broadcast vector [32]
-constexpr int a_jc(int DP) { return a_vec(DP) + TL; }                      // contact Jacobian rows [8][32]
-constexpr int a_cs(int DP) { return a_jc(DP) + TREE_MAX_SPHERES * TL; }    // per sphere: centre[3], dist, D, aref
-constexpr int a_misc(int DP) { return a_cs(DP) + TREE_MAX_SPHERES * 8; }   // site[3]
-constexpr int a_len(int DP) { return a_misc(DP) + 8; }
+constexpr int a_jc(int DP) { return a_vec(DP) + TL; }                      // contact Jacobian rows [NS][NJ][32]
+constexpr int CS = 12;      // per contact point: centre[3], dist, D, aref (normal part), mu B Jt1.v, mu B Jt2.v, axis[3]
+constexpr int a_cs(int DP, int NS, int NJ) { return a_jc(DP) + NS * NJ * TL; }
+constexpr int a_misc(int DP, int NS, int NJ) { return a_cs(DP, NS, NJ) + NS * CS; }   // site[3]
+constexpr int a_len(int DP, int NS, int NJ) { return a_misc(DP, NS, NJ) + 8; }
 
 template <typename T>
 __device__ __forceinline__ void cross3(const T* a, const T* b, T* c) {
@@ -88,18 +95,24 @@ __device__ __forceinline__ T sum32(T x) {
 }
 
 struct Topo {       // my link's place in the tree (registers)
-    int parent, subsize, anc[5], jumps;
+    int parent, subsize, jumps;
     unsigned ancmask;
+    const int* at;  // LDS: at[c * 32 + l] = ancestor of link l at distance c < DP (-1 beyond the root)
 };
+// my ancestor at distance 2^k (pointer jumping), -1 beyond the root
+template <int DP>
+__device__ __forceinline__ int jump_anc(const Topo& tp, int k, int l) {
+    return (1 << k) < DP ? tp.at[(1 << k) * TL + l] : -1;
+}
 
 // x[c] <- sum over my path to the root (myself included) of x[c]: pointer jumping
-template <int NC, typename T>
+template <int NC, int DP, typename T>
 __device__ __forceinline__ void path_sum(T* x, const Topo& tp, T* X, int l) {
     for (int k = 0; k < tp.jumps; ++k) {
 #pragma unroll
         for (int c = 0; c < NC; ++c) X[c * TL + l] = x[c];
         TSYNC();
-        const int a = tp.anc[k];
+        const int a = jump_anc<DP>(tp, k, l);
         if (a >= 0) {
 #pragma unroll
             for (int c = 0; c < NC; ++c) x[c] += X[c * TL + a];
@@ -142,10 +155,11 @@ __device__ __forceinline__ void subtree_sum(T* x, const Topo& tp, T* X, int l) {
 }
 
 // MuJoCo mj_makeImpedance + mj_referenceConstraint for one scalar row (r = pos - margin); constants from LDS
+// sol = {K, B, dmin, dmax, width, mid, power}: the contact set (T_SOL_K) or the joint-limit set (T_LSOL_K)
 template <typename T>
-__device__ __forceinline__ void tree_row_params(const T* m, T r, T diag_approx, T jv, T& D, T& aref) {
-    const T dmin = m[T_SOL_DMIN], dmax = m[T_SOL_DMAX], width = m[T_SOL_WIDTH], mid = m[T_SOL_MID];
-    const int n = (int)m[T_SOL_POWER];
+__device__ __forceinline__ void tree_row_params(const T* sol, T r, T diag_approx, T jv, T& D, T& aref) {
+    const T dmin = sol[2], dmax = sol[3], width = sol[4], mid = sol[5];
+    const int n = (int)sol[6];
     T x = fabs(r) * rcp_(width), y;
     x = x > T(1) ? T(1) : x;
     const bool lo = x <= mid;
@@ -161,7 +175,7 @@ __device__ __forceinline__ void tree_row_params(const T* m, T r, T diag_approx, 
     T Rr = (T(1) - imp) * rcp_(imp) * diag_approx;
     Rr = Rr < T(1e-15) ? T(1e-15) : Rr;
     D = rcp_(Rr);
-    aref = -m[T_SOL_B] * jv - m[T_SOL_K] * imp * r;
+    aref = -sol[1] * jv - sol[0] * imp * r;
 }
 
 // Tree-sparse L'DL, in place: in  r[c] = A[l][ancestor at distance c]  (c < DP, zero beyond the root),
@@ -232,13 +246,17 @@ __device__ __forceinline__ T tree_solve(const T* r, T b, const int* ELIM, const 
     return b;
 }
 
-template <typename T, int DP>
-__global__ __launch_bounds__(64 * wg_waves(DP)) void tree_rollout_kernel(
+template <typename T, int DP, int NS, bool FRIC>
+__global__ __launch_bounds__(64 * wg_waves(DP, FRIC)) void tree_rollout_kernel(
     const T* __restrict__ model, const double* __restrict__ state, long P, int H, int A, const double* __restrict__ mean,
     const T* __restrict__ noise, T* __restrict__ cost, T* __restrict__ act, T* __restrict__ obs, T* __restrict__ nobs,
     unsigned* diag) {
-    constexpr int WG_WAVES = wg_waves(DP);
-    constexpr int A_VEC = a_vec(DP), A_JC = a_jc(DP), A_CS = a_cs(DP), A_MISC = a_misc(DP), A_LEN = a_len(DP);
+    constexpr int WG_WAVES = wg_waves(DP, FRIC);
+    constexpr int NJ = FRIC ? 3 : 1;        // Jacobian rows kept per contact point: normal (+ two tangents)
+    constexpr int NR = FRIC ? 4 : 1;        // constraint rows per contact point: Jn (+- mu Jt_k)
+    typedef typename std::conditional<FRIC, unsigned long long, unsigned>::type mask_t;    // NR bits per contact point
+    constexpr int A_VEC = a_vec(DP), A_JC = a_jc(DP), A_CS = a_cs(DP, NS, NJ), A_MISC = a_misc(DP, NS, NJ),
+                  A_LEN = a_len(DP, NS, NJ);
     constexpr int NBLOB = T_DEPTH;          // the scalar part of the block; the topology tables go to integer LDS
     __shared__ __attribute__((aligned(16))) T lds[NBLOB + 1 + 2 * WG_WAVES * A_LEN];
     __shared__ int ELIM[(TL - 1) * TL];     // elimination lists
@@ -262,17 +280,24 @@ __global__ __launch_bounds__(64 * wg_waves(DP)) void tree_rollout_kernel(
     T* X = lds + NBLOB + 1 + (wave * 2 + half) * A_LEN;
     T* ROW = X + A_ROW;
     T* VEC = X + A_VEC;
-    const int n_rounds = (int)model[T_N_ROUNDS], depth = (int)model[T_DEPTH + l];
+    const int n_rounds = __builtin_amdgcn_readfirstlane((int)model[T_N_ROUNDS]), depth = (int)model[T_DEPTH + l];
     int max_depth = 0;
     for (int c = 0; c < DP; ++c) max_depth += __any(AT[c * TL + l] >= 0) ? 1 : 0;     // links on the longest path
-    const int nv = (int)M[T_NV], frame_skip = (int)M[T_FRAME_SKIP], site_link = (int)M[T_SITE_LINK];
-    const int n_sphere = (int)M[T_N_SPHERE];
-    const int dobs = 2 * nv + 6;
+    // model-wide integers: the same in every lane, kept in scalar registers
+    const int nv = __builtin_amdgcn_readfirstlane((int)M[T_NV]), frame_skip = __builtin_amdgcn_readfirstlane((int)M[T_FRAME_SKIP]);
+    const int site_link = __builtin_amdgcn_readfirstlane((int)M[T_SITE_LINK]);
+    const int n_sphere = __builtin_amdgcn_readfirstlane(min((int)M[T_N_SPHERE], NS));
+    const int task = __builtin_amdgcn_readfirstlane((int)M[T_TASK]), obs_skip = __builtin_amdgcn_readfirstlane((int)M[T_OBS_SKIP]);
+    const int dobs = task == 1 ? 2 * nv - obs_skip : 2 * nv + 6;
+    const bool slide = (int)M[T_JTYPE + l] == 2;
+    const int act_id = (int)M[T_ACT + l];
+    const bool fluid = FRIC && (M[T_DENSITY] > T(0) || M[T_VISCOSITY] > T(0));   // (the full instantiation only)
+
     Topo tp;
     tp.parent = (int)M[T_PARENT + l];
     tp.subsize = (int)M[T_SUBSIZE + l];
-    for (int k = 0; k < 5; ++k) tp.anc[k] = (int)M[T_ANC + k * TL + l];
-    tp.jumps = (int)M[T_JUMPS];
+    tp.at = AT;
+    tp.jumps = __builtin_amdgcn_readfirstlane((int)M[T_JUMPS]);
     tp.ancmask = (unsigned)M[T_ANCMASK + l] | ((unsigned)M[T_ANCMASK + TL + l] << 16);
     const bool dof = l < nv;
 
@@ -285,7 +310,8 @@ __global__ __launch_bounds__(64 * wg_waves(DP)) void tree_rollout_kernel(
     const T pn[3] = {M[T_PLANE_N], M[T_PLANE_N + 1], M[T_PLANE_N + 2]};
     const bool has_u = l < A;
     int lim_mem = 0;                // inst | act << 1 of my limit row in the previous substep
-    unsigned con_mem = 0;           // contact rows of the previous substep: inst bits | act bits << 8
+    unsigned cinst_mem = 0;         // contact points of the previous substep ...
+    mask_t cact_mem = 0;            // ... and which of their rows were active
     T hand_prev[3] = {T(0), T(0), T(0)}, q_prev = q, v_prev = v;
 
     for (int t = 0; t < H; ++t) {
@@ -295,7 +321,10 @@ __global__ __launch_bounds__(64 * wg_waves(DP)) void tree_rollout_kernel(
             if (noise && live) u += noise[(pid * H + t) * A + l];
             if (act && live) act[(pid * H + t) * A + l] = u;        // unclipped (gym_env_wrapper.py:151)
         }
-        const T tau_act = M[T_GEAR + l] * fmin(fmax(u, M[T_CTRL_LO + l]), M[T_CTRL_HI + l]);
+        // lane a holds action a; the dof it drives picks it up (motors may sit on any subset of the joints)
+        const T u_dof = __shfl(u, act_id >= 0 ? act_id : 0, TL);
+        const T tau_act = act_id >= 0 ? M[T_GEAR + l] * fmin(fmax(u_dof, M[T_CTRL_LO + l]), M[T_CTRL_HI + l]) : T(0);
+        if (task == 1 && l == 0) X[A_MISC + 4] = q;        // qpos[0] when the env step starts
         T hand[3] = {T(0), T(0), T(0)};
         for (int sub = 0; sub < frame_skip; ++sub) {
             // ---- 1. forward kinematics: X_l = X_parent o (Rodrigues(axis, q), off), by pointer jumping
@@ -312,6 +341,10 @@ __global__ __launch_bounds__(64 * wg_waves(DP)) void tree_rollout_kernel(
                 R[6] = tt * ax[0] * ax[2] - s * ax[1];
                 R[7] = tt * ax[1] * ax[2] + s * ax[0];
                 R[8] = c + tt * ax[2] * ax[2];
+                if (slide) {            // a slide joint moves its frame along the axis and does not turn it
+                    for (int k = 0; k < 9; ++k) R[k] = (k & 3) == 0 ? T(1) : T(0);
+                    for (int k = 0; k < 3; ++k) p[k] += ax[k] * q;
+                }
             }
             for (int k = 0; k < tp.jumps; ++k) {
 #pragma unroll
@@ -319,7 +352,7 @@ __global__ __launch_bounds__(64 * wg_waves(DP)) void tree_rollout_kernel(
 #pragma unroll
                 for (int c = 0; c < 3; ++c) X[(9 + c) * TL + l] = p[c];
                 TSYNC();
-                const int a = tp.anc[k];
+                const int a = jump_anc<DP>(tp, k, l);
                 if (a >= 0) {
                     T Ra[9], pa[3], Rn[9], tv[3];
 #pragma unroll
@@ -349,8 +382,12 @@ __global__ __launch_bounds__(64 * wg_waves(DP)) void tree_rollout_kernel(
                     T tv[3], ctr[3];
                     mv3(R, sp + 1, tv);
                     for (int k = 0; k < 3; ++k) ctr[k] = p[k] + tv[k];
-                    for (int k = 0; k < 3; ++k) X[A_CS + s * 8 + k] = ctr[k];
-                    X[A_CS + s * 8 + 3] = dot3(ctr, pn) - M[T_PLANE_D] - sp[4];
+                    for (int k = 0; k < 3; ++k) X[A_CS + s * CS + k] = ctr[k];
+                    X[A_CS + s * CS + 3] = dot3(ctr, pn) - M[T_PLANE_D] - sp[4];
+                    if (FRIC) {         // the capsule axis the contact frame is aligned with (zero for a sphere)
+                        mv3(R, sp + 8, tv);
+                        for (int k = 0; k < 3; ++k) X[A_CS + s * CS + 8 + k] = tv[k];
+                    }
                 }
             }
             TSYNC();
@@ -385,8 +422,11 @@ __global__ __launch_bounds__(64 * wg_waves(DP)) void tree_rollout_kernel(
                 Ib[4] = dot3(RI + 0, R + 6) - mass * cw[0] * cw[2];
                 Ib[5] = dot3(RI + 3, R + 6) - mass * cw[1] * cw[2];
             }
-            for (int k = 0; k < 3; ++k) { hm[k] = mass * cw[k]; sw[k] = a[k]; }
+            // motion subspace about the world origin: hinge (a, p x a), slide (0, a)
+            for (int k = 0; k < 3; ++k) { hm[k] = mass * cw[k]; sw[k] = slide ? T(0) : a[k]; }
             cross3(p, a, sv);
+            if (slide)
+                for (int k = 0; k < 3; ++k) sv[k] = a[k];
 
             // ---- 3. bias force: spatial velocity and velocity-product acceleration along the path to the root,
             //         body forces summed over the subtree
@@ -395,13 +435,13 @@ __global__ __launch_bounds__(64 * wg_waves(DP)) void tree_rollout_kernel(
                 T V[6], Ac[6];
                 for (int k = 0; k < 3; ++k) { V[k] = sw[k] * v; V[3 + k] = sv[k] * v; }
                 T xw[3] = {V[0], V[1], V[2]}, xv[3] = {V[3], V[4], V[5]};
-                path_sum<6>(V, tp, X, l);
+                path_sum<6, DP>(V, tp, X, l);
                 T dw[3], d1[3], d2[3];
                 cross3(V, xw, dw);
                 cross3(V, xv, d1);
                 cross3(V + 3, xw, d2);
                 for (int k = 0; k < 3; ++k) { Ac[k] = dw[k]; Ac[3 + k] = d1[k] + d2[k]; }
-                path_sum<6>(Ac, tp, X, l);
+                path_sum<6, DP>(Ac, tp, X, l);
                 for (int k = 0; k < 3; ++k) Ac[3 + k] -= M[T_GRAVITY + k];          // base acceleration -g
                 // f = I A + V x* (I V),  I(w, v) = (Ib w + h x v, m v - h x w)
                 T nV[3], fV[3], nA[3], fA[3], t1[3], t2[3], c1[3], c2[3], c3[3], f[6];
@@ -417,6 +457,39 @@ __global__ __launch_bounds__(64 * wg_waves(DP)) void tree_rollout_kernel(
                 cross3(V + 3, fV, c2);
                 cross3(V, fV, c3);
                 for (int k = 0; k < 3; ++k) { f[k] = nA[k] + c1[k] + c2[k]; f[3 + k] = fA[k] + c3[k]; }
+                if (fluid) {
+                    // MuJoCo mj_passive, inertia-box fluid model: viscous and drag wrench on the box of equal inertia,
+                    // evaluated in the link's inertial frame at its centre of mass; an external wrench on my link
+                    // leaves the force balance the subtree sums collect
+                    T Xf[9], vc[3], lw[3], lv[3], lf[3], lt[3], bx[3], wf[3], wt[3], t3[3];
+                    {
+                        T Fr[9];
+                        for (int k = 0; k < 9; ++k) Fr[k] = M[T_FROT + k * TL + l];
+                        for (int i = 0; i < 3; ++i)
+                            for (int j = 0; j < 3; ++j)
+                                Xf[3 * i + j] = R[3 * i] * Fr[j] + R[3 * i + 1] * Fr[3 + j] + R[3 * i + 2] * Fr[6 + j];
+                    }
+                    cross3(V, cw, t3);
+                    for (int k = 0; k < 3; ++k) { vc[k] = V[3 + k] + t3[k]; bx[k] = M[T_FBOX + k * TL + l]; }
+                    for (int i = 0; i < 3; ++i) {
+                        lw[i] = Xf[i] * V[0] + Xf[3 + i] * V[1] + Xf[6 + i] * V[2];
+                        lv[i] = Xf[i] * vc[0] + Xf[3 + i] * vc[1] + Xf[6 + i] * vc[2];
+                    }
+                    const T visc = M[T_VISCOSITY], rho = M[T_DENSITY], PI = T(3.14159265358979323846);
+                    const T diam = (bx[0] + bx[1] + bx[2]) * T(1.0 / 3.0);
+                    for (int i = 0; i < 3; ++i) {
+                        const int j1 = (i + 1) % 3, j2 = (i + 2) % 3;
+                        const T b1 = bx[j1] * bx[j1], b2 = bx[j2] * bx[j2];
+                        lt[i] = -PI * diam * diam * diam * visc * lw[i] -
+                                rho * bx[i] * (b1 * b1 + b2 * b2) * fabs(lw[i]) * lw[i] * T(1.0 / 64.0);
+                        lf[i] = -T(3) * PI * diam * visc * lv[i] - T(0.5) * rho * bx[j1] * bx[j2] * fabs(lv[i]) * lv[i];
+                    }
+                    mv3(Xf, lf, wf);
+                    mv3(Xf, lt, wt);
+                    cross3(cw, wf, t3);
+                    if (mass > T(0))
+                        for (int k = 0; k < 3; ++k) { f[k] -= wt[k] + t3[k]; f[3 + k] -= wf[k]; }
+                }
                 subtree_sum<6>(f, tp, X, l);
                 bias = dot3(sw, f) + dot3(sv, f + 3);
             }
@@ -449,7 +522,7 @@ __global__ __launch_bounds__(64 * wg_waves(DP)) void tree_rollout_kernel(
                 mrow[0] = dof ? mrow[0] + armature : T(1);     // spare lanes: unit diagonal, no ancestors
                 TSYNC();                    // S_ lies inside the area the factorisation publishes rows to
             }
-            const T tau = dof ? -bias - damping * v + tau_act : T(0);
+            const T tau = dof ? -bias - damping * v - M[T_STIFFNESS + l] * (q - M[T_SPRINGREF + l]) + tau_act : T(0);
 
             // ---- 5. constraint rows: joint limits (mj_instantiateLimit, strict dist < 0) ...
             T sig = T(0), dist = T(0), D = T(0), aref = T(0);
@@ -459,24 +532,59 @@ __global__ __launch_bounds__(64 * wg_waves(DP)) void tree_rollout_kernel(
                 if (dlo < T(0)) { sig = T(1); dist = dlo; inst = true; }
                 else if (dhi < T(0)) { sig = T(-1); dist = dhi; inst = true; }
             }
-            // ... and plane-sphere contacts (mjc_PlaneSphere, condim 1): Jacobian row in LDS, scalars per sphere
+            // ... and plane-sphere contacts (mjc_PlaneSphere / the two ends mjc_PlaneCapsule tests): Jacobian rows in
+            // LDS, scalars per contact point.  condim 1: one row Jn.  condim 3 (FRIC): MuJoCo's pyramidal cone - the four
+            // rows Jn +- mu Jt_k in the frame mju_makeFrame builds from the normal and the capsule axis, every row with
+            // diagApprox = tran (1 + mu^2), R = 2 mu^2 R_first, and its own reference acceleration.
             unsigned cinst = 0;
             for (int s = 0; s < n_sphere; ++s) {
                 const T* sp = M + T_SPH + s * TREE_SPH_STRIDE;
-                const T cdist = X[A_CS + s * 8 + 3];
+                T* cs = X + A_CS + s * CS;
+                const T cdist = cs[3];
                 const bool ci = cdist < sp[5];
                 if (__any(ci)) {
                     const int sl = (int)sp[0];
-                    T r[3], ar[3];
-                    for (int k = 0; k < 3; ++k) r[k] = X[A_CS + s * 8 + k] - pn[k] * (sp[4] + T(0.5) * cdist) - p[k];
-                    cross3(a, r, ar);
+                    // velocity of the contact point per unit joint velocity, from the motion subspace about the world
+                    // origin: g = sw x c + sv  (hinge: a x (c - p); slide: a)
+                    T r[3], g[3];
+                    for (int k = 0; k < 3; ++k) r[k] = cs[k] - pn[k] * (sp[4] + T(0.5) * cdist);
+                    cross3(sw, r, g);
+                    for (int k = 0; k < 3; ++k) g[k] += sv[k];
                     const unsigned smask = (unsigned)M[T_ANCMASK + sl] | ((unsigned)M[T_ANCMASK + TL + sl] << 16);
-                    const T jc = (ci && dof && ((smask >> l) & 1u)) ? dot3(pn, ar) : T(0);
-                    X[A_JC + s * TL + l] = jc;
+                    const bool mine = ci && dof && ((smask >> l) & 1u);
+                    const T jc = mine ? dot3(pn, g) : T(0);
+                    X[A_JC + (s * NJ) * TL + l] = jc;
                     const T jv = sum32(jc * v);
-                    T Dc, arc;
-                    tree_row_params(M, cdist - sp[5], sp[6], jv, Dc, arc);
-                    if (l == 0) { X[A_CS + s * 8 + 4] = ci ? Dc : T(0); X[A_CS + s * 8 + 5] = ci ? arc : T(0); }
+                    const T mu = FRIC ? sp[7] : T(0);
+                    T Dc, arc, mb1 = T(0), mb2 = T(0);
+                    if (FRIC) {
+                        T ax3[3] = {cs[8], cs[9], cs[10]}, t1[3], t2[3];
+                        if (dot3(ax3, ax3) < T(0.25)) {
+                            const bool yy = pn[1] < T(0.5) && pn[1] > T(-0.5);
+                            ax3[0] = T(0);
+                            ax3[1] = yy ? T(1) : T(0);
+                            ax3[2] = yy ? T(0) : T(1);
+                        }
+                        const T pr = dot3(pn, ax3);
+                        for (int k = 0; k < 3; ++k) t1[k] = ax3[k] - pr * pn[k];
+                        const T nn = dot3(t1, t1);
+                        if (nn < T(1e-30)) { t1[0] = T(1); t1[1] = T(0); t1[2] = T(0); }
+                        else { const T inv = rcp_(sqrt_(nn)); for (int k = 0; k < 3; ++k) t1[k] *= inv; }
+                        cross3(pn, t1, t2);
+                        const bool fr = mine && mu > T(0);
+                        const T j1 = fr ? dot3(t1, g) : T(0), j2 = fr ? dot3(t2, g) : T(0);
+                        X[A_JC + (s * NJ + 1) * TL + l] = j1;
+                        X[A_JC + (s * NJ + 2) * TL + l] = j2;
+                        mb1 = mu * M[T_SOL_B] * sum32(j1 * v);
+                        mb2 = mu * M[T_SOL_B] * sum32(j2 * v);
+                    }
+                    tree_row_params(M + T_SOL_K, cdist - sp[5], sp[6] * (T(1) + mu * mu), jv, Dc, arc);
+                    if (mu > T(0)) Dc *= T(0.5) * rcp_(mu * mu);
+                    if (l == 0) {
+                        cs[4] = ci ? Dc : T(0);
+                        cs[5] = ci ? arc : T(0);
+                        if (FRIC) { cs[6] = mb1; cs[7] = mb2; }
+                    }
                     if (ci) cinst |= 1u << s;
                 }
             }
@@ -484,16 +592,56 @@ __global__ __launch_bounds__(64 * wg_waves(DP)) void tree_rollout_kernel(
             const bool any_rows = !(TREE_SKIP & 1) && __any(inst || cinst != 0);
             T qfrc_c = T(0);
             if (any_rows) {
-                tree_row_params(M, dist, M[T_DOF_INVW + l], sig * v, D, aref);
+                tree_row_params(M + T_LSOL_K, dist, M[T_DOF_INVW + l], sig * v, D, aref);
                 D = inst ? D : T(0);
                 aref = inst ? aref : T(0);
+                // rows of contact point s with friction mu (uniform per particle): all NR, else one
+                auto rows_of = [&](int s) -> unsigned { return (FRIC && M[T_SPH + s * TREE_SPH_STRIDE + 7] > T(0)) ? 15u : 1u; };
+                // residuals J_r a - aref_r of the rows of contact point s, given a (one entry per lane)
+                auto residuals = [&](int s, T xa_, T* res) {
+                    const T* cs = X + A_CS + s * CS;
+                    const T an = sum32(X[A_JC + (s * NJ) * TL + l] * xa_);
+                    res[0] = an - cs[5];
+                    if (FRIC) {
+                        const T mu = M[T_SPH + s * TREE_SPH_STRIDE + 7];
+                        const T a1 = mu * sum32(X[A_JC + (s * NJ + 1) * TL + l] * xa_);
+                        const T a2 = mu * sum32(X[A_JC + (s * NJ + 2) * TL + l] * xa_);
+                        res[0] = an + a1 - (cs[5] - cs[6]);
+                        res[1 % NR] = an - a1 - (cs[5] + cs[6]);
+                        res[2 % NR] = an + a2 - (cs[5] - cs[7]);
+                        res[3 % NR] = an - a2 - (cs[5] + cs[7]);
+                        if (!(mu > T(0))) res[0] = an - cs[5];
+                    }
+                };
+                // the active set a solution belongs to next: a row stays / becomes active while its residual is negative
+                auto next_set = [&](T xa_, mask_t cur) -> mask_t {
+                    mask_t nxt = 0;
+                    for (int s = 0; s < n_sphere; ++s) {
+                        if (!__any((cinst >> s) & 1u)) continue;
+                        T res[NR];
+                        residuals(s, xa_, res);
+                        const unsigned rows = rows_of(s);
+                        for (int r = 0; r < NR; ++r) {
+                            if (!((rows >> r) & 1u)) continue;
+                            const T arr = res[r];
+                            // f32: a row whose residual is within rounding of zero keeps its state (as in arm_rollout.hip)
+                            const T bc = sizeof(T) == 4 ? T(2e-5) * (fabs(X[A_CS + s * CS + 5]) + fabs(arr + X[A_CS + s * CS + 5]) + T(1)) : T(0);
+                            const bool was = (cur >> (s * NR + r)) & 1u;
+                            if (((cinst >> s) & 1u) && (was ? !(arr > bc) : (arr < -bc))) nxt |= mask_t(1) << (s * NR + r);
+                        }
+                    }
+                    return nxt;
+                };
                 // initial active set: a row that existed in the previous substep keeps its state, a new row is active
                 bool actv = inst && ((lim_mem & 1) ? (lim_mem & 2) != 0 : true);
-                unsigned cact = 0;
+                mask_t cact = 0;
                 for (int s = 0; s < n_sphere; ++s)
-                    if ((cinst >> s) & 1u) cact |= ((con_mem >> s) & 1u) ? (((con_mem >> (8 + s)) & 1u) << s) : (1u << s);
+                    if ((cinst >> s) & 1u) {
+                        const mask_t rows = rows_of(s);
+                        cact |= ((cinst_mem >> s) & 1u) ? (cact_mem & (rows << (s * NR))) : (rows << (s * NR));
+                    }
                 bool changed = true, act_pp = false;
-                unsigned cact_pp = 0;
+                mask_t cact_pp = 0;
                 T xa = T(0);
                 for (int it = 0; it < TREE_MAXIT; ++it) {
                     T hrow[DP];
@@ -502,15 +650,36 @@ __global__ __launch_bounds__(64 * wg_waves(DP)) void tree_rollout_kernel(
                     T rhs = tau + (actv ? D * sig * aref : T(0));
                     hrow[0] += actv ? D : T(0);
                     for (int s = 0; s < n_sphere; ++s) {
-                        if (!__any((cact >> s) & 1u)) continue;
-                        const bool on = (cact >> s) & 1u;
-                        const T Dc = on ? X[A_CS + s * 8 + 4] : T(0), jl = X[A_JC + s * TL + l];
-                        rhs += Dc * jl * X[A_CS + s * 8 + 5];
-                        const T w = Dc * jl;        // a contact row couples only dofs on one path: the pattern holds
+                        const unsigned bits = (unsigned)(cact >> (s * NR)) & ((1u << NR) - 1u);
+                        if (!__any(bits != 0)) continue;
+                        const T* cs = X + A_CS + s * CS;
+                        const T Dc = bits ? cs[4] : T(0), jl = X[A_JC + (s * NJ) * TL + l];
+                        // sum over the active rows r of D J_r J_r' and D J_r aref_r, J_r = Jn + s_r mu Jt_k(r):
+                        // grouped by the three Jacobians kept per point (counts and signed counts of the active rows)
+                        const T na = T(__popc(bits));
+                        T wn = Dc * na * jl, w1 = T(0), w2 = T(0);
+                        T rsum = na * cs[5];
+                        if (FRIC) {
+                            const T mu = M[T_SPH + s * TREE_SPH_STRIDE + 7];
+                            const T j1 = mu * X[A_JC + (s * NJ + 1) * TL + l], j2 = mu * X[A_JC + (s * NJ + 2) * TL + l];
+                            const T n1 = T(__popc(bits & 3u)), s1 = T((int)(bits & 1u) - (int)((bits >> 1) & 1u));
+                            const T n2 = T(__popc(bits & 12u)), s2 = T((int)((bits >> 2) & 1u) - (int)((bits >> 3) & 1u));
+                            wn += Dc * (s1 * j1 + s2 * j2);
+                            w1 = Dc * mu * (s1 * jl + n1 * j1);
+                            w2 = Dc * mu * (s2 * jl + n2 * j2);
+                            rsum -= s1 * cs[6] + s2 * cs[7];
+                            rhs += Dc * (j1 * (s1 * cs[5] - n1 * cs[6]) + j2 * (s2 * cs[5] - n2 * cs[7]));
+                        }
+                        rhs += Dc * jl * rsum;
+                        // a contact row couples only dofs on one path: the pattern holds
 #pragma unroll
                         for (int c = 0; c < DP; ++c) {
                             const int an = AT[c * TL + l];
-                            if (an >= 0) hrow[c] += w * X[A_JC + s * TL + an];
+                            if (an >= 0) {
+                                T acc = wn * X[A_JC + (s * NJ) * TL + an];
+                                if (FRIC) acc += w1 * X[A_JC + (s * NJ + 1) * TL + an] + w2 * X[A_JC + (s * NJ + 2) * TL + an];
+                                hrow[c] += acc;
+                            }
                         }
                     }
                     TSYNC();
@@ -520,15 +689,7 @@ __global__ __launch_bounds__(64 * wg_waves(DP)) void tree_rollout_kernel(
                     const T resl = sig * xa - aref;
                     const T band = sizeof(T) == 4 ? T(2e-5) * (fabs(aref) + fabs(xa) + T(1)) : T(0);
                     bool act2 = inst && (actv ? !(resl > band) : (resl < -band));
-                    unsigned cact2 = 0;
-                    for (int s = 0; s < n_sphere; ++s) {
-                        if (!__any((cinst >> s) & 1u)) continue;
-                        const T arc = X[A_CS + s * 8 + 5];
-                        const T res = sum32(X[A_JC + s * TL + l] * xa) - arc;
-                        const T bc = sizeof(T) == 4 ? T(2e-5) * (fabs(arc) + fabs(res + arc) + T(1)) : T(0);
-                        const bool was = (cact >> s) & 1u;
-                        if (((cinst >> s) & 1u) && (was ? !(res > bc) : (res < -bc))) cact2 |= 1u << s;
-                    }
+                    mask_t cact2 = next_set(xa, cact);
                     changed = (act2 != actv) || (cact2 != cact);
                     // One limit row j of a particle changed state (the usual reason for another iteration):
                     // H' = H + c e_j e_j', c = +-D_j, rhs' = rhs + c sig_j aref_j e_j.  With z = H^-1 e_j - one more pair of
@@ -556,18 +717,8 @@ __global__ __launch_bounds__(64 * wg_waves(DP)) void tree_rollout_kernel(
                             actv = act2;                // the sets the corrected solution belongs to
                             const T resl2 = sig * xa - aref;
                             const T band2 = sizeof(T) == 4 ? T(2e-5) * (fabs(aref) + fabs(xa) + T(1)) : T(0);
-                            const bool act3 = inst && (actv ? !(resl2 > band2) : (resl2 < -band2));
-                            unsigned cact3 = 0;
-                            for (int s = 0; s < n_sphere; ++s) {
-                                if (!__any((cinst >> s) & 1u)) continue;
-                                const T arc = X[A_CS + s * 8 + 5];
-                                const T res = sum32(X[A_JC + s * TL + l] * xa) - arc;
-                                const T bc = sizeof(T) == 4 ? T(2e-5) * (fabs(arc) + fabs(res + arc) + T(1)) : T(0);
-                                const bool was = (cact >> s) & 1u;
-                                if (((cinst >> s) & 1u) && (was ? !(res > bc) : (res < -bc))) cact3 |= 1u << s;
-                            }
-                            act2 = act3;
-                            cact2 = cact3;
+                            act2 = inst && (actv ? !(resl2 > band2) : (resl2 < -band2));
+                            cact2 = next_set(xa, cact);
                             changed = (act2 != actv) || (cact2 != cact);
                         }
                     }
@@ -583,17 +734,34 @@ __global__ __launch_bounds__(64 * wg_waves(DP)) void tree_rollout_kernel(
                 }
                 if (changed && diag) atomicAdd(diag, 1u);
                 lim_mem = (inst ? 1 : 0) | (actv ? 2 : 0);
-                con_mem = cinst | (cact << 8);
+                cinst_mem = cinst;
+                cact_mem = cact;
                 qfrc_c = actv ? -D * (sig * xa - aref) * sig : T(0);
                 for (int s = 0; s < n_sphere; ++s) {
-                    if (!__any((cact >> s) & 1u)) continue;
-                    const T jl = X[A_JC + s * TL + l];
-                    const T res = sum32(jl * xa) - X[A_CS + s * 8 + 5];
-                    if ((cact >> s) & 1u) qfrc_c += jl * (-X[A_CS + s * 8 + 4] * res);
+                    const unsigned bits = (unsigned)(cact >> (s * NR)) & ((1u << NR) - 1u);
+                    if (!__any(bits != 0)) continue;
+                    T res[NR];
+                    residuals(s, xa, res);
+                    const T Dc = X[A_CS + s * CS + 4], jl = X[A_JC + (s * NJ) * TL + l];
+                    T fn = T(0), f1 = T(0), f2 = T(0);      // sum of row forces on Jn, mu Jt1, mu Jt2
+                    for (int r = 0; r < NR; ++r) {
+                        const T fr = ((bits >> r) & 1u) ? -Dc * res[r] : T(0);
+                        fn += fr;
+                        if (FRIC) {
+                            if (r < 2) f1 += (r & 1) ? -fr : fr;
+                            else f2 += (r & 1) ? -fr : fr;
+                        }
+                    }
+                    qfrc_c += jl * fn;
+                    if (FRIC) {
+                        const T mu = M[T_SPH + s * TREE_SPH_STRIDE + 7];
+                        qfrc_c += mu * (X[A_JC + (s * NJ + 1) * TL + l] * f1 + X[A_JC + (s * NJ + 2) * TL + l] * f2);
+                    }
                 }
             } else {
                 lim_mem = 0;
-                con_mem = 0;
+                cinst_mem = 0;
+                cact_mem = 0;
             }
             // ---- 6. mj_Euler with implicit joint damping: (M + h B) qacc = qfrc_smooth + qfrc_constraint
             T qacc;
@@ -611,7 +779,7 @@ __global__ __launch_bounds__(64 * wg_waves(DP)) void tree_rollout_kernel(
                 const T dq = h * v;
                 q += dq;
                 T sd, cd;
-                if (__builtin_expect(__any(fabs(dq) > T(0.25)), 0)) {
+                if (__builtin_expect(__any(!slide && fabs(dq) > T(0.25)), 0)) {
                     sincos_(q, sq, cq);
                 } else {
                     sincos_small(dq, sd, cd);
@@ -622,11 +790,29 @@ __global__ __launch_bounds__(64 * wg_waves(DP)) void tree_rollout_kernel(
                 }
             }
         }
-        // reward = -(|h-g|_1 + 5 |h-g|_2), h = site position lagging one substep (reacher_env.py:31-35)
-        const T dx = hand[0] - tgt[0], dy = hand[1] - tgt[1], dz = hand[2] - tgt[2];
-        const T cst = fabs(dx) + fabs(dy) + fabs(dz) + T(5) * sqrt_(dx * dx + dy * dy + dz * dz);
+        T cst;
+        if (task == 1) {
+            // reward = forward progress of qpos[0] over the env step / dt - c |a|^2, the action as given
+            // (swimmer.py:10-19, half_cheetah.py:10-19)
+            const T usq = sum32(has_u ? u * u : T(0));
+            cst = M[T_CTRL_COST] * usq - (__shfl(q, 0, TL) - X[A_MISC + 4]) * rcp_(h * T(frame_skip));
+        } else {
+            // reward = -(|h-g|_1 + 5 |h-g|_2), h = site position lagging one substep (reacher_env.py:31-35)
+            const T dx = hand[0] - tgt[0], dy = hand[1] - tgt[1], dz = hand[2] - tgt[2];
+            cst = fabs(dx) + fabs(dy) + fabs(dz) + T(5) * sqrt_(dx * dx + dy * dy + dz * dz);
+        }
         if (live && l == 0) cost[pid * H + t] = cst;
-        if (live && (obs || nobs)) {
+        if (live && (obs || nobs) && task == 1) {           // obs = [qpos[skip:], qvel]
+            const long o = (pid * H + t) * dobs;
+            if (obs && dof) {
+                if (l >= obs_skip) obs[o + l - obs_skip] = q_prev;
+                obs[o + nv - obs_skip + l] = v_prev;
+            }
+            if (nobs && dof) {
+                if (l >= obs_skip) nobs[o + l - obs_skip] = q;
+                nobs[o + nv - obs_skip + l] = v;
+            }
+        } else if (live && (obs || nobs)) {
             const long o = (pid * H + t) * dobs;
             if (obs) {
                 if (dof) { obs[o + l] = q_prev; obs[o + nv + l] = v_prev; }
@@ -646,22 +832,32 @@ __global__ __launch_bounds__(64 * wg_waves(DP)) void tree_rollout_kernel(
 }  // namespace
 
 template <typename T>
-hipError_t launch_tree_rollout(const T* model, int max_path, const double* state, long P, int H, int A, const double* mean,
-                               const T* noise, T* cost, T* act, T* obs, T* nobs, unsigned* diag, hipStream_t stream) {
+hipError_t launch_tree_rollout(const T* model, int max_path, bool full, const double* state, long P, int H,
+                               int A, const double* mean, const T* noise, T* cost, T* act, T* obs, T* nobs, unsigned* diag,
+                               hipStream_t stream) {
     if (P <= 0 || H <= 0) return hipSuccess;
-#define MJMPC_TREE_LAUNCH(DP_)                                                                                       \
-    hipLaunchKernelGGL((tree_rollout_kernel<T, DP_>), dim3((unsigned)((P + 2 * wg_waves(DP_) - 1) / (2 * wg_waves(DP_)))), \
-                       dim3(64 * wg_waves(DP_)), 0, stream, model, state, P, H, A, mean, noise, cost, act, obs, nobs, diag)
-    if (max_path <= 8) MJMPC_TREE_LAUNCH(8);
-    else if (max_path <= 16) MJMPC_TREE_LAUNCH(16);
-    else MJMPC_TREE_LAUNCH(32);
+#define MJMPC_TREE_LAUNCH(DP_, NS_, FR_)                                                                              \
+    hipLaunchKernelGGL((tree_rollout_kernel<T, DP_, NS_, FR_>),                                                       \
+                       dim3((unsigned)((P + 2 * wg_waves(DP_, FR_) - 1) / (2 * wg_waves(DP_, FR_)))),                 \
+                       dim3(64 * wg_waves(DP_, FR_)), 0, stream, model, state, P, H, A, mean, noise, cost, act, obs, nobs, diag)
+    // models in air with up to 8 frictionless contact points keep the lean instantiation; friction cones, more points
+    // or a medium take the full one (three Jacobians per point, 16 points, fluid forces)
+    if (!full) {
+        if (max_path <= 8) MJMPC_TREE_LAUNCH(8, 8, false);
+        else if (max_path <= 16) MJMPC_TREE_LAUNCH(16, 8, false);
+        else MJMPC_TREE_LAUNCH(32, 8, false);
+    } else {
+        if (max_path <= 8) MJMPC_TREE_LAUNCH(8, 16, true);
+        else if (max_path <= 16) MJMPC_TREE_LAUNCH(16, 16, true);
+        else MJMPC_TREE_LAUNCH(32, 16, true);
+    }
 #undef MJMPC_TREE_LAUNCH
     return hipGetLastError();
 }
 
-template hipError_t launch_tree_rollout<float>(const float*, int, const double*, long, int, int, const double*,
+template hipError_t launch_tree_rollout<float>(const float*, int, bool, const double*, long, int, int, const double*,
                                                const float*, float*, float*, float*, float*, unsigned*, hipStream_t);
-template hipError_t launch_tree_rollout<double>(const double*, int, const double*, long, int, int, const double*,
+template hipError_t launch_tree_rollout<double>(const double*, int, bool, const double*, long, int, int, const double*,
                                                 const double*, double*, double*, double*, double*, unsigned*, hipStream_t);
 
 }  // namespace mjmpc

@@ -1,5 +1,9 @@
 """GPU rollout engine for kinematic-tree models - ``ArmRolloutEngine``'s sibling for models the serial-chain kernel
-cannot hold (a hand on an arm, up to 32 hinge dofs, gravity, several sphere/plane contacts).
+cannot hold (a hand on an arm; the reference's vendored swimmer and half-cheetah with their floating
+roots, springs, fluid forces and frictional contacts; up to 32 hinge / slide dofs).
+
+The state dictionary follows the model's task: the reacher's ``{qp, qv, target_pos}`` (reacher_env.py:81-99) or the
+locomotion envs' ``{qpos, qvel}`` (swimmer.py:33-50, half_cheetah.py:36-51).
 
 Same reference-shaped surface (``SubprocVecEnv.rollout / set_env_state / reset / close``,
 mjmpc/envs/vec_env/subproc_vec_env.py:128-186, 235-251), so ``make_rollout_fn`` / ``make_device_rollout_fn`` of
@@ -18,7 +22,7 @@ import numpy as np
 
 from .. import _lib
 from ..models.compile_tree import TreeModel, compile_tree
-from ..models.raw import RawModel
+from ..models.raw import TASK_FORWARD, RawModel
 from .arm_engine import _DT, _ptr, _torch
 
 
@@ -42,21 +46,22 @@ class TreeRolloutEngine:
         _lib.check(self._lib.mjmpc_tree_create(blob.ctypes.data_as(_lib._dp), blob.size, device, ctypes.byref(h)))
         self._h = h
         self.d_action, self.d_obs = model.nu, model.d_obs
-        self.d_state = 3 * model.nv + 3 + 1
+        self.forward_task = model.task == TASK_FORWARD
+        self.d_state = 2 * model.nv if self.forward_task else 3 * model.nv + 3 + 1
         self.action_lows, self.action_highs = model.ctrl_lo.copy(), model.ctrl_hi.copy()
         self.closed = False
         self._buf = {}
-        self.set_env_state(dict(qp=np.zeros(model.nv), qv=np.zeros(model.nv), qa=np.zeros(model.nv),
-                                target_pos=model.target_default.copy(), timestep=0))
+        self.reset()
 
     # ------------------------------------------------------------------ reference-shaped API
     def set_env_state(self, state_dicts):
         state = state_dicts[0] if isinstance(state_dicts, (list, tuple)) else state_dicts
         if isinstance(state_dicts, (list, tuple)) and len(state_dicts) not in (1, self.num_shards):
             raise AssertionError("num states should equal 1 (same for all envs) or 1 per env")
-        qp = np.ascontiguousarray(state["qp"], np.float64).reshape(-1)
-        qv = np.ascontiguousarray(state["qv"], np.float64).reshape(-1)
-        tg = np.ascontiguousarray(state["target_pos"], np.float64).reshape(-1)
+        kq, kv = ("qpos", "qvel") if "qpos" in state else ("qp", "qv")
+        qp = np.ascontiguousarray(state[kq], np.float64).reshape(-1)
+        qv = np.ascontiguousarray(state[kv], np.float64).reshape(-1)
+        tg = np.ascontiguousarray(state.get("target_pos", self.model.target_default), np.float64).reshape(-1)
         if qp.size != self.model.nv or qv.size != self.model.nv or tg.size != 3:
             raise ValueError("state has the wrong dimensions for this model")
         self._state = dict(qp=qp.copy(), qv=qv.copy(), target_pos=tg.copy())
@@ -65,6 +70,8 @@ class TreeRolloutEngine:
 
     def get_env_state(self):
         st = self._state
+        if self.forward_task:
+            return [dict(qpos=st["qp"].copy(), qvel=st["qv"].copy())]
         return [dict(qp=st["qp"].copy(), qv=st["qv"].copy(), qa=np.zeros(self.model.nv),
                      target_pos=st["target_pos"].copy(), timestep=0)]
 
@@ -113,6 +120,9 @@ class TreeRolloutEngine:
     def step(self, action):
         """Advance the engine's own state by one env step (a one-particle rollout, state round trip through the host:
         the tree engine keeps no device-resident "real env").  Returns (next_obs, reward)."""
+        if self.forward_task and self.model.obs_skip:
+            raise ValueError("the observation leaves out qpos[:%d]; step an engine compiled with obs_skip = 0"
+                             % self.model.obs_skip)
         _, rew, _, _, _, nobs = self.rollout(1, 1, np.asarray(action, np.float64).reshape(1, -1), None)
         nv = self.model.nv
         self.set_env_state(dict(qp=nobs[0, 0, :nv], qv=nobs[0, 0, nv:2 * nv], target_pos=self._state["target_pos"]))

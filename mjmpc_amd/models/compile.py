@@ -116,6 +116,17 @@ def compile_arm(raw: RawModel, overrides=None, base: "ArmModel" = None) -> ArmMo
     qpos0 constants: pass the unperturbed model as ``base`` and its dof/body invweight0 are kept."""
     overrides = overrides or {}
     nb = len(raw.bodies)
+    # what only the tree kernel executes (models/compile_tree.py)
+    joints = [b.joint for b in raw.bodies if b.joint is not None]
+    if any(j.type != 1 or j.stiffness != 0 for j in joints):
+        raise ValueError("arm kernel: hinge joints without springs only (slide joints / springs: the tree engine)")
+    if raw.density > 0 or raw.viscosity > 0 or raw.task != 0:
+        raise ValueError("arm kernel: no medium, reach task only (the tree engine runs the locomotion models)")
+    if raw.plane is not None and any(g.collide and max(g.condim, raw.plane.condim) > 1 for b in raw.bodies for g in b.geoms):
+        raise ValueError("arm kernel: frictionless (condim 1) contacts only (friction cones: the tree engine)")
+    if (raw.solref_limit is not None and tuple(raw.solref_limit) != tuple(raw.solref)) or \
+            (raw.solimp_limit is not None and tuple(raw.solimp_limit) != tuple(raw.solimp)):
+        raise ValueError("arm kernel: joint limits share the contacts' solref / solimp")
     # ---- per-body inertial + pose at qpos0 ------------------------------------------------
     R0 = [None] * nb
     p0 = [None] * nb

@@ -1,32 +1,41 @@
-"""Host-side model compiler for kinematic TREES of hinge links: RawModel -> the constant block of the tree kernel
-(``mjmpc_amd/csrc/tree_rollout.hip``, layout mirrored by ``csrc/tree_model.h``).
+"""Host-side model compiler for kinematic TREES of hinge / slide links: RawModel -> the constant block of the tree
+kernel (``mjmpc_amd/csrc/tree_rollout.hip``, layout mirrored by ``csrc/tree_model.h``).
 
-Same conventions as ``compile.compile_arm`` (one link per hinge, welded bodies merged into the link that carries
+Same conventions as ``compile.compile_arm`` (one link per joint, welded bodies merged into the link that carries
 them, link frames world-aligned at qpos0, MuJoCo's inertiafromgeom and ``mj_setConst`` constants), without the
 serial-chain restriction: a link may carry several child links.  The kernel wants the links numbered depth-first, so
 that a subtree is a contiguous index range; an MJCF file lists its bodies that way, and a model that does not is
-rejected.  Up to 32 dofs, one motor per hinge in joint order, up to 8 collision spheres against one plane.
+rejected.  Up to 32 dofs (hinge or slide; a body with several joints arrives as a chain of massless bodies), joint
+springs, motors on any subset of the joints, up to 16 contact points against one plane (a colliding capsule is its two
+end spheres; frictionless rows or pyramidal friction cones), the inertia-box fluid model, and the task (reach /
+forward progress) the kernel's cost and observation follow.
 """
 from dataclasses import dataclass
 
 import numpy as np
 
 from .compile import _geom_inertial, _quat2mat, _shift_inertia
-from .raw import GEOM_SPHERE, RawModel
+from .raw import GEOM_SPHERE, JOINT_HINGE, JOINT_SLIDE, TASK_FORWARD, TASK_REACH, RawModel
 
 TL = 32                     # lanes per particle
-TREE_MAX_SPHERES = 8
-SPH_STRIDE = 8
+TREE_MAX_SPHERES = 16
+SPH_STRIDE = 12
+MJ_MINIMP, MJ_MAXIMP = 1e-4, 0.9999     # MuJoCo's clamp on solimp (getsolparam)
 
 TREE_LAYOUT = [
     ("off", 3 * TL), ("axis", 3 * TL), ("mass", TL), ("com", 3 * TL), ("inertia", 6 * TL),
     ("armature", TL), ("damping", TL), ("range_lo", TL), ("range_hi", TL), ("limited", TL), ("gear", TL),
     ("ctrl_lo", TL), ("ctrl_hi", TL), ("dof_invweight0", TL),
     ("parent", TL), ("subsize", TL), ("anc", 5 * TL), ("ancmask", 2 * TL),
+    ("jtype", TL), ("stiffness", TL), ("springref", TL), ("act", TL), ("fbox", 3 * TL), ("frot", 9 * TL),
     ("nv", 1), ("timestep", 1), ("frame_skip", 1), ("jumps", 1), ("site_link", 1), ("site_pos", 3),
     ("n_sphere", 1), ("plane_n", 3), ("plane_d", 1),
     ("sol_K", 1), ("sol_B", 1), ("sol_dmin", 1), ("sol_dmax", 1), ("sol_width", 1), ("sol_mid", 1), ("sol_power", 1),
-    ("gravity", 3), ("spheres", TREE_MAX_SPHERES * SPH_STRIDE),
+    ("gravity", 3),
+    ("nu", 1), ("task", 1), ("ctrl_cost", 1), ("obs_skip", 1), ("density", 1), ("viscosity", 1),
+    ("lsol_K", 1), ("lsol_B", 1), ("lsol_dmin", 1), ("lsol_dmax", 1), ("lsol_width", 1), ("lsol_mid", 1), ("lsol_power", 1),
+    ("any_friction", 1),
+    ("spheres", TREE_MAX_SPHERES * SPH_STRIDE),
     # tree-sparse L'DL (MuJoCo's factorisation order: leaves first, no fill-in): links of equal HEIGHT above their
     # deepest leaf are mutually unrelated and are eliminated together, one round per height
     ("depth", TL),                  # strict ancestors of the link
@@ -60,6 +69,8 @@ class TreeModel:
     target_default: np.ndarray
     ctrl_lo: np.ndarray
     ctrl_hi: np.ndarray
+    task: int
+    obs_skip: int
     parent: np.ndarray             # parent link of every link (-1: root)
     max_path: int                  # links on the longest root-to-leaf path
     body_mass: np.ndarray
@@ -70,6 +81,20 @@ class TreeModel:
     def field(self, name):
         o, n = TREE_OFFSETS[name]
         return self.blob[o:o + n]
+
+
+def _principal_frame(I):
+    """Principal moments and axes (columns) of a body's inertia tensor in its own frame: the body axes when the
+    tensor is diagonal there, else its eigenvectors - which are only defined when the moments are distinct."""
+    I = np.asarray(I, float)
+    off = abs(I[0, 1]) + abs(I[0, 2]) + abs(I[1, 2])
+    if off <= 1e-12 * np.trace(I):
+        return np.diag(I).copy(), np.eye(3)
+    w, V = np.linalg.eigh(I)
+    if min(w[1] - w[0], w[2] - w[1]) < 1e-9 * w[2]:
+        raise NotImplementedError("fluid model: a body whose inertia has equal principal moments must be aligned with "
+                                  "its body frame (the inertial frame is otherwise ambiguous)")
+    return w, V
 
 
 def compile_tree(raw: RawModel) -> TreeModel:
@@ -88,11 +113,14 @@ def compile_tree(raw: RawModel) -> TreeModel:
             ipos[i] = sum(m * c for m, c, _ in parts) / mass[i]
             inert[i] = sum(_shift_inertia(I, m, c - ipos[i]) for m, c, I in parts)
 
-    # ---- links: one per hinge, welded bodies merged into the link that carries them ----------------------
+    # ---- links: one per joint, welded bodies merged into the link that carries them ----------------------
     jointed = [i for i, b in enumerate(raw.bodies) if b.joint is not None]
     nv = len(jointed)
     if not 1 <= nv <= TL:
-        raise ValueError("tree kernel supports 1..%d hinge dofs, got %d" % (TL, nv))
+        raise ValueError("tree kernel supports 1..%d dofs, got %d" % (TL, nv))
+    jtype = [raw.bodies[i].joint.type for i in jointed]
+    if any(t not in (JOINT_HINGE, JOINT_SLIDE) for t in jtype):
+        raise ValueError("joints must be hinges or slides")
     link_of_body, parent = [-1] * nb, []
     for i, b in enumerate(raw.bodies):
         pl = -1 if b.parent < 0 else link_of_body[b.parent]
@@ -161,9 +189,26 @@ def compile_tree(raw: RawModel) -> TreeModel:
             f["inertia"][k * TL + li] = I[r, c]
         f["armature"][li] = jt.armature
         f["damping"][li] = jt.damping
+        f["jtype"][li] = jt.type
+        f["stiffness"][li], f["springref"][li] = jt.stiffness, jt.springref
+        if raw.density > 0 or raw.viscosity > 0:
+            # MuJoCo's fluid model acts body by body on the box of equal inertia, in the body's inertial frame
+            massive = [i for i in members if mass[i] > 0]
+            if len(massive) > 1:
+                raise NotImplementedError("the fluid model needs one body per link (no welded bodies with mass)")
+            if massive:
+                i = massive[0]
+                w, V = _principal_frame(inert[i])
+                for c in range(3):
+                    x = max(w[(c + 1) % 3] + w[(c + 2) % 3] - w[c], 1e-15)
+                    f["fbox"][c * TL + li] = np.sqrt(x / mass[i] * 6.0)
+                f["frot"][li::TL] = (R0[i] @ V).reshape(-1)
+            else:
+                f["frot"][li::TL] = np.eye(3).reshape(-1)
         f["range_lo"][li], f["range_hi"][li] = jt.range
         f["limited"][li] = 1.0 if jt.limited else 0.0
     f["axis"][2 * TL + nv:3 * TL] = 1.0         # spare lanes: a unit axis keeps their (unused) rotation orthonormal
+    f["jtype"][nv:] = JOINT_HINGE
     f["parent"][:] = -1.0
     f["parent"][:nv] = parent
     f["subsize"][:nv] = subsize
@@ -180,14 +225,18 @@ def compile_tree(raw: RawModel) -> TreeModel:
         for e, k in enumerate(desc):
             f["elim"][e * TL + i] = k | ((depth[k] - depth[i]) << 8) | (height[k] << 16)
 
-    if len(raw.actuators) != nv:
-        raise ValueError("tree kernel expects one motor per hinge")
-    ctrl_lo, ctrl_hi = np.zeros(nv), np.zeros(nv)
-    for a, act in enumerate(raw.actuators):
-        if raw.dof_of_joint(act.joint) != a:
-            raise ValueError("motors must be listed in joint order")
-        f["gear"][a] = act.gear
-        f["ctrl_lo"][a], f["ctrl_hi"][a] = act.ctrlrange
+    nu = len(raw.actuators)
+    if not 1 <= nu <= nv:
+        raise ValueError("tree kernel expects between one motor and one per joint")
+    ctrl_lo, ctrl_hi = np.zeros(nu), np.zeros(nu)
+    f["act"][:] = -1.0
+    for a, act in enumerate(raw.actuators):         # action a drives the dof of its joint (any subset, any order)
+        d = raw.dof_of_joint(act.joint)
+        if f["act"][d] >= 0:
+            raise ValueError("two motors on joint %r" % act.joint)
+        f["act"][d] = a
+        f["gear"][d] = act.gear
+        f["ctrl_lo"][d], f["ctrl_hi"][d] = act.ctrlrange
         ctrl_lo[a], ctrl_hi[a] = act.ctrlrange
 
     # ---- constants at qpos0 (MuJoCo mj_setConst): M0, dof / body invweight0 ------------------------------
@@ -198,7 +247,7 @@ def compile_tree(raw: RawModel) -> TreeModel:
         J = np.zeros((3, nv))
         for k in range(nv):
             if on_path(k, link):
-                J[:, k] = np.cross(axis_w[k], pt - origin[k])
+                J[:, k] = axis_w[k] if jtype[k] == JOINT_SLIDE else np.cross(axis_w[k], pt - origin[k])
         return J
 
     M0 = np.diag(f["armature"][:nv]).astype(float)
@@ -209,7 +258,7 @@ def compile_tree(raw: RawModel) -> TreeModel:
         Jp = jac_point(p0[i] + R0[i] @ ipos[i], li)
         Jr = np.zeros((3, nv))
         for k in range(nv):
-            if on_path(k, li):
+            if on_path(k, li) and jtype[k] == JOINT_HINGE:
                 Jr[:, k] = axis_w[k]
         Iw = R0[i] @ inert[i] @ R0[i].T
         M0 += mass[i] * Jp.T @ Jp + Jr.T @ Iw @ Jr
@@ -226,38 +275,73 @@ def compile_tree(raw: RawModel) -> TreeModel:
     sb = raw.site_body
     f["site_link"][0] = link_of_body[sb]
     f["site_pos"][:] = p0[sb] + R0[sb] @ np.asarray(raw.site_pos, float) - origin[link_of_body[sb]]
-    spheres = [(i, g) for i, b in enumerate(raw.bodies) for g in b.geoms if g.collide]
-    if raw.plane is not None and spheres:
-        if len(spheres) > TREE_MAX_SPHERES:
-            raise ValueError("tree kernel supports %d collision spheres" % TREE_MAX_SPHERES)
+    # contact points: a colliding sphere, or the two end spheres of a colliding capsule - the "to" end first, as
+    # MuJoCo's mjc_PlaneCapsule tests them - which also hand their axis to the contact frame.  Friction and condim of
+    # a contact are the larger of the two geoms' (mj_contactParam with equal priorities).
+    points = []
+    for i, b in enumerate(raw.bodies):
+        for g in b.geoms:
+            if not g.collide:
+                continue
+            if g.type == GEOM_SPHERE:
+                points.append((i, g, np.asarray(g.a, float), np.zeros(3)))
+            else:
+                a, e = np.asarray(g.a, float), np.asarray(g.b, float)
+                u = (e - a) / np.linalg.norm(e - a)
+                points += [(i, g, e, u), (i, g, a, u)]
+    if raw.plane is not None and points:
+        if len(points) > TREE_MAX_SPHERES:
+            raise ValueError("tree kernel supports %d contact points (a capsule counts two)" % TREE_MAX_SPHERES)
         n = np.asarray(raw.plane.normal, float)
         n = n / np.linalg.norm(n)
         f["plane_n"][:] = n
         f["plane_d"][0] = n @ np.asarray(raw.plane.pos, float)
-        f["n_sphere"][0] = len(spheres)
-        for s, (i, g) in enumerate(spheres):
-            if g.type != GEOM_SPHERE:
-                raise ValueError("only sphere-plane contacts are supported")
+        f["n_sphere"][0] = len(points)
+        for s, (i, g, pos, u) in enumerate(points):
             li = link_of_body[i]
             rec = f["spheres"][s * SPH_STRIDE:(s + 1) * SPH_STRIDE]
             rec[0] = li
-            rec[1:4] = p0[i] + R0[i] @ np.asarray(g.a, float) - origin[li]
+            rec[1:4] = p0[i] + R0[i] @ pos - origin[li]
             rec[4] = g.radius
             rec[5] = max(raw.plane.margin, g.margin)            # MuJoCo: max of the two geom margins
             rec[6] = 0.0 + body_iw[i]                           # the world body weighs 0
-    tc, dr = raw.solref
-    tc = max(tc, 2 * raw.timestep)                              # refsafe
-    dmin, dmax, width, mid, power = raw.solimp
-    if power < 1 or power != int(power) or power > 64:
-        raise NotImplementedError("solimp power must be an integer in [1, 64] (MuJoCo's default is 2), got %r" % (power,))
-    f["sol_K"][0] = 1.0 / (dmax * dmax * tc * tc * dr * dr)
-    f["sol_B"][0] = 2.0 / (dmax * tc)
-    f["sol_dmin"][0], f["sol_dmax"][0] = dmin, dmax
-    f["sol_width"][0], f["sol_mid"][0], f["sol_power"][0] = width, mid, power
+            condim = max(int(g.condim), int(raw.plane.condim))
+            if condim not in (1, 3):
+                raise NotImplementedError("contacts are condim 1 (frictionless) or 3 (pyramidal cone), got %d" % condim)
+            rec[7] = max(g.friction, raw.plane.friction) if condim == 3 else 0.0
+            rec[8:11] = R0[i] @ u
+        f["any_friction"][0] = 1.0 if any(f["spheres"][s * SPH_STRIDE + 7] > 0 for s in range(len(points))) else 0.0
+
+    def sol_set(prefix, solref, solimp):
+        tc, dr = solref
+        if tc <= 0 or dr <= 0:
+            raise NotImplementedError("solref must be the standard (timeconst, dampratio) pair")
+        tc = max(tc, 2 * raw.timestep)                              # refsafe
+        dmin, dmax, width, mid, power = solimp
+        dmin, dmax = np.clip(dmin, MJ_MINIMP, MJ_MAXIMP), np.clip(dmax, MJ_MINIMP, MJ_MAXIMP)
+        mid, width, power = np.clip(mid, MJ_MINIMP, MJ_MAXIMP), max(width, 0.0), max(power, 1.0)
+        if power != int(power) or power > 64:
+            raise NotImplementedError("solimp power must be an integer in [1, 64] (MuJoCo's default is 2), got %r" % (power,))
+        f[prefix + "_K"][0] = 1.0 / (dmax * dmax * tc * tc * dr * dr)
+        f[prefix + "_B"][0] = 2.0 / (dmax * tc)
+        if width <= 1e-15:                                          # MuJoCo getimpedance: a flat impedance
+            dmin = dmax = 0.5 * (dmin + dmax)
+            width = 1.0
+        f[prefix + "_dmin"][0], f[prefix + "_dmax"][0] = dmin, dmax
+        f[prefix + "_width"][0], f[prefix + "_mid"][0], f[prefix + "_power"][0] = width, mid, power
+
+    sol_set("sol", raw.solref, raw.solimp)
+    sol_set("lsol", raw.solref if raw.solref_limit is None else raw.solref_limit,
+            raw.solimp if raw.solimp_limit is None else raw.solimp_limit)
     f["gravity"][:] = raw.gravity
+    f["nu"][0], f["task"][0], f["ctrl_cost"][0], f["obs_skip"][0] = nu, raw.task, raw.ctrl_cost, raw.obs_skip
+    f["density"][0], f["viscosity"][0] = raw.density, raw.viscosity
+    if raw.task not in (TASK_REACH, TASK_FORWARD) or not 0 <= raw.obs_skip < nv:
+        raise ValueError("unknown task / observation layout")
+    d_obs = 2 * nv - raw.obs_skip if raw.task == TASK_FORWARD else 2 * nv + 6
     blob = np.concatenate([f[name] for name, _ in TREE_LAYOUT]).astype(np.float64)
     assert blob.size == TREE_BLOB_LEN
-    return TreeModel(blob=blob, nv=nv, nu=nv, d_obs=2 * nv + 6, timestep=raw.timestep, frame_skip=raw.frame_skip,
+    return TreeModel(blob=blob, nv=nv, nu=nu, d_obs=d_obs, timestep=raw.timestep, frame_skip=raw.frame_skip,
                      target_default=np.asarray(raw.target_pos, float), ctrl_lo=ctrl_lo, ctrl_hi=ctrl_hi, parent=parent,
-                     max_path=int(depth.max()),
+                     task=int(raw.task), obs_skip=int(raw.obs_skip), max_path=int(depth.max()),
                      body_mass=mass, body_invweight0=body_iw, dof_invweight0=dof_iw, link_of_body=link_of_body)

@@ -1,10 +1,12 @@
-"""Raw (un-compiled) articulated-arm description.
+"""Raw (un-compiled) articulated-body description.
 
-This is the framework's own, minimal model format: exactly the subset of MJCF that
-``reacher_7dof-v0`` needs (reference asset ``mjmpc/envs/assets/xml/sawyer.xml``):
-a kinematic tree of bodies with at most one hinge joint each, sphere / capsule geoms
-(used only for ``inertiafromgeom``), one optional collision plane on the world body,
-collision spheres, joint-torque motors and one tracked site.
+This is the framework's own, minimal model format: the subset of MJCF that the reference's vendored models need
+(``mjmpc/envs/assets/xml/sawyer.xml``, ``swimmer.xml``, ``half_cheetah.xml``): a kinematic tree of bodies with at
+most one hinge or slide joint each (a body with several joints is a chain of massless bodies, which is what
+MuJoCo's kinematics does with it), joint springs, sphere / capsule geoms (``inertiafromgeom``; colliding ones
+against one world plane, frictionless or with a pyramidal friction cone), joint-torque motors on some or all
+joints, the inertia-box fluid model, and a task: reach a target with a tracked site (reacher) or move forward
+(swimmer / half-cheetah).
 
 ``RawModel.to_flat()`` serialises it to a flat float64 vector.  The SAME flat vector
 feeds two independent compilers:
@@ -22,7 +24,11 @@ import numpy as np
 GEOM_SPHERE = 1
 GEOM_CAPSULE = 2
 
-HEADER_LEN = 40
+HEADER_LEN = 56
+JOINT_HINGE = 1
+JOINT_SLIDE = 2
+TASK_REACH = 0              # reward -(|h-g|_1 + 5 |h-g|_2), obs [qpos, qvel, h, h-g]      (reacher_env.py:29-47)
+TASK_FORWARD = 1            # reward (x' - x)/dt - c |a|^2, obs [qpos[skip:], qvel]         (swimmer.py, half_cheetah.py)
 BODY_STRIDE = 20
 GEOM_STRIDE = 16
 ACT_STRIDE = 4
@@ -36,6 +42,9 @@ class RawJoint:
     damping: float = 0.0
     armature: float = 0.0
     name: str = ""
+    type: int = JOINT_HINGE
+    stiffness: float = 0.0                  # joint spring towards springref (MuJoCo qfrc_passive)
+    springref: float = 0.0
 
 
 @dataclass
@@ -48,6 +57,8 @@ class RawGeom:
     collide: bool = False                   # contype & conaffinity match the plane
     margin: float = 0.0
     name: str = ""
+    friction: float = 1.0                   # sliding friction (MuJoCo default "1 0.005 0.0001", first entry)
+    condim: int = 1
 
 
 @dataclass
@@ -72,6 +83,8 @@ class RawPlane:
     pos: Sequence[float]
     normal: Sequence[float]
     margin: float
+    friction: float = 1.0
+    condim: int = 1
 
 
 @dataclass
@@ -87,6 +100,13 @@ class RawModel:
     gravity: Sequence[float] = (0.0, 0.0, 0.0)
     solref: Sequence[float] = (0.02, 1.0)           # MuJoCo defaults
     solimp: Sequence[float] = (0.9, 0.95, 0.001, 0.5, 2.0)
+    solref_limit: Optional[Sequence[float]] = None  # joint-limit rows (MJCF solreflimit / solimplimit); None: as above
+    solimp_limit: Optional[Sequence[float]] = None
+    density: float = 0.0                            # medium (MuJoCo <option density viscosity>): inertia-box fluid model
+    viscosity: float = 0.0
+    task: int = TASK_REACH
+    ctrl_cost: float = 0.0                          # TASK_FORWARD: weight of |a|^2
+    obs_skip: int = 0                               # TASK_FORWARD: leading qpos entries left out of the observation
 
     # ------------------------------------------------------------------
     @property
@@ -120,6 +140,12 @@ class RawModel:
             h[23:26] = self.plane.pos
             h[26:29] = self.plane.normal
             h[29] = self.plane.margin
+            h[35] = self.plane.friction
+            h[36] = self.plane.condim
+        h[30], h[31] = self.density, self.viscosity
+        h[32], h[33], h[34] = self.task, self.ctrl_cost, self.obs_skip
+        h[40:42] = self.solref if self.solref_limit is None else self.solref_limit
+        h[42:47] = self.solimp if self.solimp_limit is None else self.solimp_limit
         out = [h]
         for b in self.bodies:
             r = np.zeros(BODY_STRIDE)
@@ -127,7 +153,9 @@ class RawModel:
             r[1:4] = b.pos
             r[4:8] = b.quat
             if b.joint is not None:
-                r[8] = 1.0
+                r[8] = float(b.joint.type)
+                r[17] = b.joint.stiffness
+                r[18] = b.joint.springref
                 r[9:12] = b.joint.axis
                 r[12:14] = b.joint.range
                 r[14] = 1.0 if b.joint.limited else 0.0
@@ -144,6 +172,8 @@ class RawModel:
             r[9] = g.density
             r[10] = 1.0 if g.collide else 0.0
             r[11] = g.margin
+            r[12] = g.friction
+            r[13] = g.condim
             out.append(r)
         for a in self.actuators:
             r = np.zeros(ACT_STRIDE)

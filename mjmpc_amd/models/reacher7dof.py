@@ -16,11 +16,11 @@ _MARGIN = 0.002
 
 
 def _cap(name, r, a, b):
-    return RawGeom(GEOM_CAPSULE, r, a, b, margin=_MARGIN, name=name)
+    return RawGeom(GEOM_CAPSULE, r, a, b, margin=_MARGIN, friction=0.5, name=name)
 
 
 def _sph(name, r, p, collide=False):
-    return RawGeom(GEOM_SPHERE, r, p, collide=collide, margin=_MARGIN, name=name)
+    return RawGeom(GEOM_SPHERE, r, p, collide=collide, margin=_MARGIN, friction=0.5, name=name)
 
 
 def _hinge(name, axis, lo, hi, damping=_DAMP):
@@ -80,7 +80,7 @@ def reacher7dof_raw() -> RawModel:
         actuators=actuators,
         site_body=8, site_pos=(0.0, 0.0, 0.0),              # "finger", sawyer.xml:59
         target_pos=(0.1, 0.1, 0.1),                         # "target", sawyer.xml:13
-        plane=RawPlane(pos=(0.0, 0.5, -0.425), normal=Z, margin=_MARGIN),   # sawyer.xml:11
+        plane=RawPlane(pos=(0.0, 0.5, -0.425), normal=Z, margin=_MARGIN, friction=0.5),   # sawyer.xml:11
         timestep=0.01,                                      # sawyer.xml:3
         frame_skip=2,                                       # reacher_env.py:21
         gravity=(0.0, 0.0, 0.0),                            # sawyer.xml:3

@@ -38,11 +38,11 @@
 #define MAXB 48            /* bodies incl. world */
 #define MAXV 32
 #define MAXG 96
-#define MAXS 8             /* collision spheres */
-#define MAXC (2 * MAXV + MAXS)
+#define MAXS 16            /* collision spheres (a colliding capsule is its two end spheres) */
+#define MAXC (2 * MAXV + 4 * MAXS)
 #define MJ_MINVAL 1e-15    /* MuJoCo mjMINVAL */
 
-#define HEADER_LEN 40
+#define HEADER_LEN 56
 #define BODY_STRIDE 20
 #define GEOM_STRIDE 16
 #define ACT_STRIDE 4
@@ -56,11 +56,13 @@ typedef struct {
     int parent[MAXB];
     double bpos[MAXB][3], bR0[MAXB][9];      /* fixed offset / rotation in the parent frame */
     int dofid[MAXB];                         /* -1: welded */
+    int jtype[MAXB];                         /* 1 hinge, 2 slide */
     double jaxis[MAXB][3];
     int dof_body[MAXV];
     double range[MAXV][2];
     int limited[MAXV];
-    double damping[MAXV], armature[MAXV];
+    double damping[MAXV], armature[MAXV], stiffness[MAXV], springref[MAXV];
+    int dof_type[MAXV];
     /* inertial (inertiafromgeom) */
     double mass[MAXB], ipos[MAXB][3], inertia[MAXB][9];  /* tensor about the COM, body frame */
     /* motors */
@@ -74,6 +76,15 @@ typedef struct {
     double plane_pos[3], plane_n[3], plane_margin;
     int sph_body[MAXS];
     double sph_pos[MAXS][3], sph_r[MAXS], sph_margin[MAXS];
+    double sph_mu[MAXS], sph_axis[MAXS][3];   /* friction (0: frictionless row) and capsule axis in the body frame */
+    /* joint-limit rows may carry their own solver parameters (MJCF solreflimit / solimplimit) */
+    double solref_l[2], solimp_l[5];
+    /* medium: MuJoCo's inertia-box fluid model; principal frame / equivalent box of every body */
+    double density, viscosity;
+    double iR[MAXB][9], ibox[MAXB][3];
+    /* task: 0 reach (reacher_env.py), 1 forward progress (swimmer.py / half_cheetah.py) */
+    int task, obs_skip;
+    double ctrl_cost;
     /* constants computed at qpos0 (MuJoCo mj_setConst) */
     double dof_invweight0[MAXV], body_invweight0[MAXB];
     /* statistics */
@@ -162,7 +173,12 @@ static void kinematics(const OrModel *m, const double *q, Kin *k) {
         for (int i = 0; i < 3; i++) k->xpos[b][i] = k->xpos[p][i] + t[i];
         matmul3(k->xmat[p], m->bR0[b], R);
         int j = m->dofid[b];
-        if (j >= 0) {
+        if (j >= 0 && m->jtype[b] == 2) {       /* slide: the frame moves along its axis, no rotation */
+            memcpy(k->xmat[b], R, sizeof(R));
+            matvec3(R, m->jaxis[b], k->xaxis[j]);
+            for (int i = 0; i < 3; i++) k->xpos[b][i] += k->xaxis[j][i] * q[j];
+            memcpy(k->xanchor[j], k->xpos[b], sizeof(double) * 3);
+        } else if (j >= 0) {
             double E[9];
             axisangle2mat(m->jaxis[b], q[j], E);
             matmul3(R, E, k->xmat[b]);
@@ -194,8 +210,12 @@ static void jacobian(const OrModel *m, const Kin *k, int b, const double *point,
         double col[3] = {0, 0, 0}, ax[3] = {0, 0, 0};
         if (dof_affects(m, j, b)) {
             double r[3] = {point[0] - k->xanchor[j][0], point[1] - k->xanchor[j][1], point[2] - k->xanchor[j][2]};
-            cross3(k->xaxis[j], r, col);
-            memcpy(ax, k->xaxis[j], sizeof(ax));
+            if (m->dof_type[j] == 2) {
+                memcpy(col, k->xaxis[j], sizeof(col));
+            } else {
+                cross3(k->xaxis[j], r, col);
+                memcpy(ax, k->xaxis[j], sizeof(ax));
+            }
         }
         for (int i = 0; i < 3; i++) {
             Jp[i * nv + j] = col[i];
@@ -259,7 +279,11 @@ static void rne(const OrModel *m, const Kin *k, const double *v, const double *a
             w[b][i] = w[p][i];
             al[b][i] = al[p][i];
         }
-        if (j >= 0) {
+        if (j >= 0 && m->jtype[b] == 2) {       /* slide: Coriolis 2 w x (axis v) and axis qacc on the origin */
+            double wxa[3];
+            cross3(w[p], k->xaxis[j], wxa);
+            for (int i = 0; i < 3; i++) oacc[b][i] += 2 * wxa[i] * v[j] + (a ? k->xaxis[j][i] * a[j] : 0.0);
+        } else if (j >= 0) {
             double wxa[3];
             cross3(w[p], k->xaxis[j], wxa);
             for (int i = 0; i < 3; i++) {
@@ -285,7 +309,7 @@ static void rne(const OrModel *m, const Kin *k, const double *v, const double *a
     }
     for (int b = m->nbody - 1; b >= 1; b--) {
         int p = m->parent[b], j = m->dofid[b];
-        if (j >= 0) tau[j] = dot3(k->xaxis[j], N[b]);
+        if (j >= 0) tau[j] = m->jtype[b] == 2 ? dot3(k->xaxis[j], F[b]) : dot3(k->xaxis[j], N[b]);
         if (p > 0) {
             double r[3], rxF[3];
             for (int i = 0; i < 3; i++) r[i] = k->xpos[b][i] - k->xpos[p][i];
@@ -347,6 +371,15 @@ OrModel *or_model_compile(const double *f, int n) {
     memcpy(m->plane_pos, f + 23, 24);
     memcpy(m->plane_n, f + 26, 24);
     m->plane_margin = f[29];
+    m->density = f[30];
+    m->viscosity = f[31];
+    m->task = (int)f[32];
+    m->ctrl_cost = f[33];
+    m->obs_skip = (int)f[34];
+    double plane_mu = f[35];
+    int plane_condim = (int)f[36];
+    memcpy(m->solref_l, f + 40, 16);
+    memcpy(m->solimp_l, f + 42, 40);
     m->dofid[0] = -1;
     int nv = 0;
     for (int b = 1; b <= nb; b++) {
@@ -358,6 +391,10 @@ OrModel *or_model_compile(const double *f, int n) {
         if (r[8] != 0) {
             int j = nv++;
             m->dofid[b] = j;
+            m->jtype[b] = (int)r[8];
+            m->dof_type[j] = (int)r[8];
+            m->stiffness[j] = r[17];
+            m->springref[j] = r[18];
             m->dof_body[j] = b;
             double nrm = sqrt(dot3(r + 9, r + 9));
             for (int i = 0; i < 3; i++) m->jaxis[b][i] = r[9 + i] / nrm;
@@ -377,12 +414,23 @@ OrModel *or_model_compile(const double *f, int n) {
         const double *r = g0 + g * GEOM_STRIDE;
         gb[g] = (int)r[0] + 1;
         geom_inertia((int)r[1], r[2], r + 3, r + 6, r[9], &gm[g], gp[g], gI[g]);
-        if (r[10] != 0 && (int)r[1] == 1 && m->nsphere < MAXS) {
+        /* colliding geoms: a sphere, or a capsule = its two end spheres, "to" end first (mjc_PlaneCapsule tests
+         * pos + axis * halflength, then pos - axis * halflength, and aligns the contact frame with the axis).
+         * Contact friction / condim = max over the two geoms (MuJoCo mj_contactParam, equal priorities). */
+        int ends = r[10] != 0 ? ((int)r[1] == 1 ? 1 : 2) : 0;
+        for (int e = 0; e < ends && m->nsphere < MAXS; e++) {
             int s = m->nsphere++;
             m->sph_body[s] = gb[g];
-            memcpy(m->sph_pos[s], r + 3, 24);
+            memcpy(m->sph_pos[s], (ends == 2 && e == 0) ? r + 6 : r + 3, 24);
             m->sph_r[s] = r[2];
             m->sph_margin[s] = r[11];
+            double mu = r[12] > plane_mu ? r[12] : plane_mu;
+            int condim = (int)r[13] > plane_condim ? (int)r[13] : plane_condim;
+            m->sph_mu[s] = condim >= 3 ? mu : 0.0;
+            if (ends == 2) {
+                double u[3] = {r[6] - r[3], r[7] - r[4], r[8] - r[5]}, len = sqrt(dot3(u, u));
+                for (int i = 0; i < 3; i++) m->sph_axis[s][i] = u[i] / len;
+            }
         }
     }
     for (int b = 1; b <= nb; b++) {
@@ -420,8 +468,72 @@ void or_model_free(OrModel *m) { free(m); }
 
 /* MuJoCo mj_setConst (set0): at qpos0, dof_invweight0[j] = (M^-1)_jj for hinge dofs,
  * body_invweight0[b] (translational) = trace(Jcom M^-1 Jcom^T) / 3, world = 0. */
+/* eigen-decomposition of a symmetric 3x3 (cyclic Jacobi): A = V diag(w) V^T, columns of V = axes */
+static void eig3(const double *A, double *w, double *V) {
+    double a[9];
+    memcpy(a, A, sizeof(a));
+    static const double I3[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
+    memcpy(V, I3, sizeof(I3));
+    for (int sweep = 0; sweep < 60; sweep++) {
+        double off = fabs(a[1]) + fabs(a[2]) + fabs(a[5]);
+        if (off <= 1e-300) break;
+        for (int p = 0; p < 2; p++)
+            for (int q = p + 1; q < 3; q++) {
+                double apq = a[3 * p + q];
+                if (apq == 0) continue;
+                double th = (a[3 * q + q] - a[3 * p + p]) / (2 * apq);
+                double t = (th >= 0 ? 1.0 : -1.0) / (fabs(th) + sqrt(th * th + 1));
+                double c = 1 / sqrt(t * t + 1), sn = t * c;
+                for (int k = 0; k < 3; k++) {       /* A <- A G */
+                    double akp = a[3 * k + p], akq = a[3 * k + q];
+                    a[3 * k + p] = c * akp - sn * akq;
+                    a[3 * k + q] = sn * akp + c * akq;
+                }
+                for (int k = 0; k < 3; k++) {       /* A <- G^T A */
+                    double apk = a[3 * p + k], aqk = a[3 * q + k];
+                    a[3 * p + k] = c * apk - sn * aqk;
+                    a[3 * q + k] = sn * apk + c * aqk;
+                }
+                for (int k = 0; k < 3; k++) {
+                    double vkp = V[3 * k + p], vkq = V[3 * k + q];
+                    V[3 * k + p] = c * vkp - sn * vkq;
+                    V[3 * k + q] = sn * vkp + c * vkq;
+                }
+            }
+    }
+    for (int i = 0; i < 3; i++) w[i] = a[4 * i];
+}
+
+static void clamp_solimp(double *si) {         /* MuJoCo getsolparam: mjMINIMP = 1e-4, mjMAXIMP = 0.9999 */
+    for (int i = 0; i < 2; i++) { if (si[i] < 1e-4) si[i] = 1e-4; if (si[i] > 0.9999) si[i] = 0.9999; }
+    if (si[2] < 0) si[2] = 0;
+    if (si[3] < 1e-4) si[3] = 1e-4;
+    if (si[3] > 0.9999) si[3] = 0.9999;
+    if (si[4] < 1) si[4] = 1;
+}
+
 static void set_const(OrModel *m) {
     int nv = m->nv;
+    clamp_solimp(m->solimp);
+    clamp_solimp(m->solimp_l);
+    /* inertial frames: principal axes of every body's inertia tensor (body frame when it is diagonal there) and
+     * the box of equal inertia, MuJoCo mj_passive: box_i = sqrt(6 (I_j + I_k - I_i) / m) */
+    for (int b = 1; b < m->nbody; b++) {
+        double w[3], tr = m->inertia[b][0] + m->inertia[b][4] + m->inertia[b][8];
+        double off = fabs(m->inertia[b][1]) + fabs(m->inertia[b][2]) + fabs(m->inertia[b][5]);
+        static const double I3[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
+        if (off <= 1e-12 * tr) {
+            memcpy(m->iR[b], I3, sizeof(I3));
+            for (int i = 0; i < 3; i++) w[i] = m->inertia[b][4 * i];
+        } else {
+            eig3(m->inertia[b], w, m->iR[b]);
+        }
+        for (int i = 0; i < 3; i++) {
+            double x = w[(i + 1) % 3] + w[(i + 2) % 3] - w[i];
+            if (x < MJ_MINVAL) x = MJ_MINVAL;
+            m->ibox[b][i] = m->mass[b] > MJ_MINVAL ? sqrt(x / m->mass[b] * 6.0) : 0.0;
+        }
+    }
     double q0[MAXV] = {0}, M[MAXV * MAXV];
     Kin k;
     kinematics(m, q0, &k);
@@ -450,9 +562,9 @@ static void set_const(OrModel *m) {
 /* ---------------------------------------------------------------- soft constraints */
 /* MuJoCo mj_makeImpedance / getimpedance / mj_referenceConstraint for one scalar row.
  * pos: signed distance, margin: activation margin; r = pos - margin. */
-static void row_params(const OrModel *m, double pos, double margin, double diagApprox, double jv,
-                       double *D, double *aref) {
-    double dmin = m->solimp[0], dmax = m->solimp[1], width = m->solimp[2], mid = m->solimp[3], power = m->solimp[4];
+static void row_params_set(const OrModel *m, const double *solref, const double *solimp, double pos, double margin,
+                           double diagApprox, double jv, double *D, double *aref) {
+    double dmin = solimp[0], dmax = solimp[1], width = solimp[2], mid = solimp[3], power = solimp[4];
     double r = pos - margin, imp;
     if (dmin == dmax || width <= MJ_MINVAL) {
         imp = 0.5 * (dmin + dmax);
@@ -472,10 +584,14 @@ static void row_params(const OrModel *m, double pos, double margin, double diagA
     if (R < MJ_MINVAL) R = MJ_MINVAL;
     *D = 1 / R;
     /* standard solref = (timeconst, dampratio); refsafe: timeconst >= 2*timestep */
-    double tc = m->solref[0], dr = m->solref[1];
+    double tc = solref[0], dr = solref[1];
     if (tc < 2 * m->timestep) tc = 2 * m->timestep;
     double b = 2 / (dmax * tc), kk = 1 / (dmax * dmax * tc * tc * dr * dr);
     *aref = -b * jv - kk * imp * r;
+}
+static void row_params(const OrModel *m, double pos, double margin, double diagApprox, double jv,
+                       double *D, double *aref) {
+    row_params_set(m, m->solref, m->solimp, pos, margin, diagApprox, jv, D, aref);
 }
 
 /* minimise  1/2 (a - a_s)^T M (a - a_s) + sum_i 1/2 D_i min(0, J_i a - aref_i)^2
@@ -492,7 +608,7 @@ static void solve_rows(OrModel *m, int nv, const double *M, const double *fs, in
     double scale = 1;
     for (int i = 0; i < nv; i++) if (fabs(fs[i]) > scale) scale = fabs(fs[i]);
     m->newton_calls++;
-    int it;
+    int it, polished = 0;
     for (it = 0; it < 100 && nc > 0; it++) {
         double jar[MAXC], g[MAXV], H[MAXV * MAXV], d[MAXV];
         for (int i = 0; i < nv; i++) {
@@ -514,7 +630,12 @@ static void solve_rows(OrModel *m, int nv, const double *M, const double *fs, in
         }
         double gn = 0;
         for (int i = 0; i < nv; i++) if (fabs(g[i]) > gn) gn = fabs(g[i]);
-        if (gn <= 1e-11 * scale) break;
+        /* converged: one more Newton step with the final active set lands on its exact minimiser (the problem is
+         * piecewise quadratic), so that the oracle's own stopping tolerance stays out of parity comparisons */
+        if (gn <= 1e-11 * scale) {
+            if (polished) break;
+            polished = 1;
+        }
         chol(H, nv);
         for (int i = 0; i < nv; i++) d[i] = -g[i];
         chol_solve(H, nv, d);
@@ -582,7 +703,49 @@ void or_step(OrModel *m, double *q, double *v, const double *ctrl, double *site_
     }
     mass_matrix(m, &k, M);
     rne(m, &k, v, NULL, bias);
-    for (int j = 0; j < nv; j++) fs[j] = -bias[j] - m->damping[j] * v[j];     /* passive: no springs */
+    /* passive: joint dampers and springs (MuJoCo mj_passive) */
+    for (int j = 0; j < nv; j++) {
+        fs[j] = -bias[j] - m->damping[j] * v[j];
+        if (m->stiffness[j] != 0) fs[j] -= m->stiffness[j] * (q[j] - m->springref[j]);
+    }
+    /* ... and the medium: viscous and drag forces on the box of equal inertia of every body, evaluated in the body's
+     * inertial frame at its centre of mass, applied there (mj_passive, inertia-box fluid model) */
+    if (m->density > 0 || m->viscosity > 0) {
+        const double PI = 3.14159265358979323846;
+        for (int b = 1; b < m->nbody; b++) {
+            if (m->mass[b] <= MJ_MINVAL) continue;
+            double Jp[3 * MAXV], Jr[3 * MAXV], vc[3] = {0, 0, 0}, w[3] = {0, 0, 0}, X[9], lv[3], lw[3], lf[3] = {0, 0, 0}, lt[3] = {0, 0, 0};
+            jacobian(m, &k, b, k.xipos[b], Jp, Jr);
+            for (int i = 0; i < 3; i++)
+                for (int j = 0; j < nv; j++) { vc[i] += Jp[i * nv + j] * v[j]; w[i] += Jr[i * nv + j] * v[j]; }
+            matmul3(k.xmat[b], m->iR[b], X);
+            for (int i = 0; i < 3; i++) {
+                lv[i] = X[i] * vc[0] + X[3 + i] * vc[1] + X[6 + i] * vc[2];
+                lw[i] = X[i] * w[0] + X[3 + i] * w[1] + X[6 + i] * w[2];
+            }
+            const double *bx = m->ibox[b];
+            if (m->viscosity > 0) {
+                double diam = (bx[0] + bx[1] + bx[2]) / 3.0;
+                for (int i = 0; i < 3; i++) {
+                    lt[i] += -PI * diam * diam * diam * m->viscosity * lw[i];
+                    lf[i] += -3.0 * PI * diam * m->viscosity * lv[i];
+                }
+            }
+            if (m->density > 0) {
+                for (int i = 0; i < 3; i++) {
+                    int j1 = (i + 1) % 3, j2 = (i + 2) % 3;
+                    lf[i] -= 0.5 * m->density * bx[j1] * bx[j2] * fabs(lv[i]) * lv[i];
+                    lt[i] -= m->density * bx[i] * (bx[j1] * bx[j1] * bx[j1] * bx[j1] + bx[j2] * bx[j2] * bx[j2] * bx[j2]) *
+                             fabs(lw[i]) * lw[i] / 64.0;
+                }
+            }
+            double wf[3], wt[3];
+            matvec3(X, lf, wf);
+            matvec3(X, lt, wt);
+            for (int j = 0; j < nv; j++)
+                for (int i = 0; i < 3; i++) fs[j] += Jp[i * nv + j] * wf[i] + Jr[i * nv + j] * wt[i];
+        }
+    }
     for (int a = 0; a < m->nu; a++) {                                          /* motors, ctrllimited */
         double u = ctrl[a];
         if (u < m->ctrl_lo[a]) u = m->ctrl_lo[a];
@@ -599,7 +762,7 @@ void or_step(OrModel *m, double *q, double *v, const double *ctrl, double *site_
             if (dist < 0) {
                 memset(J[nc], 0, sizeof(J[nc]));
                 J[nc][j] = -side;
-                row_params(m, dist, 0.0, m->dof_invweight0[j], -side * v[j], &D[nc], &aref[nc]);
+                row_params_set(m, m->solref_l, m->solimp_l, dist, 0.0, m->dof_invweight0[j], -side * v[j], &D[nc], &aref[nc]);
                 nc++;
             }
         }
@@ -614,16 +777,53 @@ void or_step(OrModel *m, double *q, double *v, const double *ctrl, double *site_
         double dist = dot3(c, m->plane_n) - m->sph_r[s];
         double margin = m->plane_margin > m->sph_margin[s] ? m->plane_margin : m->sph_margin[s];
         if (dist < margin) {
-            double cp[3], Jp[3 * MAXV], jv = 0;
+            double cp[3], Jp[3 * MAXV], jv = 0, tran = m->body_invweight0[0] + m->body_invweight0[b];
+            const double *n = m->plane_n;
             for (int i = 0; i < 3; i++)
-                cp[i] = k.xpos[b][i] + t[i] - m->plane_n[i] * (m->sph_r[s] + 0.5 * dist);
+                cp[i] = k.xpos[b][i] + t[i] - n[i] * (m->sph_r[s] + 0.5 * dist);
             jacobian(m, &k, b, cp, Jp, NULL);
-            for (int j = 0; j < nv; j++) {
-                J[nc][j] = m->plane_n[0] * Jp[j] + m->plane_n[1] * Jp[nv + j] + m->plane_n[2] * Jp[2 * nv + j];
-                jv += J[nc][j] * v[j];
+            if (m->sph_mu[s] <= 0) {            /* condim 1: one frictionless row */
+                for (int j = 0; j < nv; j++) {
+                    J[nc][j] = n[0] * Jp[j] + n[1] * Jp[nv + j] + n[2] * Jp[2 * nv + j];
+                    jv += J[nc][j] * v[j];
+                }
+                row_params(m, dist, margin, tran, jv, &D[nc], &aref[nc]);
+                nc++;
+            } else {
+                /* condim 3, pyramidal cone (MuJoCo's default): tangent frame = mju_makeFrame(normal, capsule axis or
+                 * nothing), rows Jn +- mu Jt_k; diagApprox = tran (1 + mu^2), all four rows share R = 2 mu^2 R_first */
+                double mu = m->sph_mu[s], t1[3], t2[3], ax[3];
+                matvec3(k.xmat[b], m->sph_axis[s], ax);
+                if (sqrt(dot3(ax, ax)) < 0.5) {
+                    ax[0] = 0; ax[1] = 0; ax[2] = 0;
+                    if (n[1] < 0.5 && n[1] > -0.5) ax[1] = 1; else ax[2] = 1;
+                }
+                double pr = dot3(n, ax), nr = 0;
+                for (int i = 0; i < 3; i++) { t1[i] = ax[i] - pr * n[i]; nr += t1[i] * t1[i]; }
+                nr = sqrt(nr);
+                if (nr < MJ_MINVAL) { t1[0] = 1; t1[1] = 0; t1[2] = 0; }
+                else for (int i = 0; i < 3; i++) t1[i] /= nr;
+                cross3(n, t1, t2);
+                double D0, a0;
+                row_params(m, dist, margin, tran * (1 + mu * mu), 0.0, &D0, &a0);
+                double Rpy = 2 * mu * mu / D0;
+                for (int kk = 0; kk < 2; kk++) {
+                    const double *tt = kk == 0 ? t1 : t2;
+                    for (int sg = 1; sg >= -1; sg -= 2) {
+                        double jvr = 0, Dd, ar;
+                        for (int j = 0; j < nv; j++) {
+                            double jn = n[0] * Jp[j] + n[1] * Jp[nv + j] + n[2] * Jp[2 * nv + j];
+                            double jt = tt[0] * Jp[j] + tt[1] * Jp[nv + j] + tt[2] * Jp[2 * nv + j];
+                            J[nc][j] = jn + sg * mu * jt;
+                            jvr += J[nc][j] * v[j];
+                        }
+                        row_params(m, dist, margin, tran * (1 + mu * mu), jvr, &Dd, &ar);
+                        D[nc] = 1 / Rpy;
+                        aref[nc] = ar;
+                        nc++;
+                    }
+                }
             }
-            row_params(m, dist, margin, m->body_invweight0[0] + m->body_invweight0[b], jv, &D[nc], &aref[nc]);
-            nc++;
         }
     }
     solve_rows(m, nv, M, fs, nc, J, aref, D, qacc, force);
@@ -667,7 +867,7 @@ int or_threads(int n) {
 /* ---------------------------------------------------------------- accessors for tests */
 int or_nv(const OrModel *m) { return m->nv; }
 int or_nbody(const OrModel *m) { return m->nbody; }
-int or_dobs(const OrModel *m) { return 2 * m->nv + 6; }
+int or_dobs(const OrModel *m) { return m->task == 1 ? 2 * m->nv - m->obs_skip : 2 * m->nv + 6; }
 void or_get_inertial(const OrModel *m, double *mass, double *ipos, double *inertia) {
     for (int b = 0; b < m->nbody; b++) {
         mass[b] = m->mass[b];
@@ -713,6 +913,19 @@ double or_kinetic(const OrModel *m, const double *q, const double *v) {
  * reward = -(|h-g|_1 + 5 |h-g|_2) with h = data.site_xpos[finger] (lagging one substep) and
  * obs = [qpos, qvel, h, h - g] (reacher_env.py:41-47). */
 static double env_step(OrModel *m, double *q, double *v, const double *u, const double *target, double *obs) {
+    if (m->task == 1) {
+        /* SwimmerEnv.step / HalfCheetahEnv.step (swimmer.py:10-19, half_cheetah.py:10-19): reward = forward progress
+         * of qpos[0] over the env step / dt - c * |a|^2 (the action as given, unclipped), obs = [qpos[skip:], qvel] */
+        int nv = m->nv, sk = m->obs_skip;
+        double x0 = q[0], c = 0;
+        for (int s = 0; s < m->frame_skip; s++) or_step(m, q, v, u, NULL, NULL);
+        for (int a = 0; a < m->nu; a++) c += u[a] * u[a];
+        if (obs) {
+            memcpy(obs, q + sk, sizeof(double) * (nv - sk));
+            memcpy(obs + nv - sk, v, sizeof(double) * nv);
+        }
+        return (q[0] - x0) / (m->timestep * m->frame_skip) - m->ctrl_cost * c;
+    }
     double h[3] = {0, 0, 0};
     for (int s = 0; s < m->frame_skip; s++) or_step(m, q, v, u, h, NULL);
     double d[3] = {h[0] - target[0], h[1] - target[1], h[2] - target[2]};
@@ -757,9 +970,9 @@ void or_rollout_cl(OrModel *m, const double *qp0, const double *qv0, const doubl
 static void rollout_impl(OrModel *m, const double *qp0, const double *qv0, const double *target, long P, int H,
                          const double *mean, const double *noise, double *obs, double *rew, double *act,
                          double *done, double *next_obs, int closed_loop) {
-    int nv = m->nv, nu = m->nu, dobs = 2 * nv + 6;
-    double h0[3];
-    or_site(m, qp0, h0);
+    int nv = m->nv, nu = m->nu, dobs = or_dobs(m);
+    double h0[3] = {0, 0, 0};
+    if (m->task == 0) or_site(m, qp0, h0);
     long calls = 0, iters = 0, fails = 0;
 #pragma omp parallel for schedule(static) reduction(+ : calls, iters, fails)
     for (long b = 0; b < P; b++) {
@@ -768,9 +981,14 @@ static void rollout_impl(OrModel *m, const double *qp0, const double *qv0, const
         double q[MAXV], v[MAXV], cur[2 * MAXV + 6], nxt[2 * MAXV + 6], u[MAXV];
         memcpy(q, qp0, sizeof(double) * nv);
         memcpy(v, qv0, sizeof(double) * nv);
-        memcpy(cur, q, sizeof(double) * nv);
-        memcpy(cur + nv, v, sizeof(double) * nv);
-        for (int i = 0; i < 3; i++) { cur[2 * nv + i] = h0[i]; cur[2 * nv + 3 + i] = h0[i] - target[i]; }
+        if (m->task == 1) {
+            memcpy(cur, q + m->obs_skip, sizeof(double) * (nv - m->obs_skip));
+            memcpy(cur + nv - m->obs_skip, v, sizeof(double) * nv);
+        } else {
+            memcpy(cur, q, sizeof(double) * nv);
+            memcpy(cur + nv, v, sizeof(double) * nv);
+            for (int i = 0; i < 3; i++) { cur[2 * nv + i] = h0[i]; cur[2 * nv + 3 + i] = h0[i] - target[i]; }
+        }
         for (int t = 0; t < H; t++) {
             for (int a = 0; a < nu; a++) {
                 double ma;

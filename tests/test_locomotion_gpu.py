@@ -1,0 +1,173 @@
+"""GPU parity of the tree kernel on the reference's vendored locomotion models (mjmpc/envs/assets/xml/swimmer.xml,
+half_cheetah.xml; restated in mjmpc_amd/models/) against the FP64 C oracle, through the C ABI: slide joints and
+floating roots, joint springs, motors on a subset of the joints, the inertia-box fluid model (swimmer), capsule/plane
+contacts with pyramidal friction cones (cheetah), the forward-progress reward and its observation layout.
+
+Tolerances.  f64: 1e-9 (SURVEY 8d's gate).  The swimmer holds it over whole rollouts.  The cheetah's contact dynamics
+amplify a rounding-level difference by about 1.4x per env step (measured: 2e-15 after one step, 4e-11 after eight,
+1e-6 after thirty-two - in f64 and f32 alike, scaled by the unit roundoff), so its 1e-9 comparisons are one-step checks
+from many states plus a horizon-8 rollout, and longer horizons are compared at the tolerance that growth implies.
+f32 is compared over one env step (abs 2e-3) and through the statistics MPC consumes."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import yaml
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _models():
+    from mjmpc_amd.models.half_cheetah import half_cheetah_raw
+    from mjmpc_amd.models.swimmer import swimmer_raw
+    return dict(swimmer=swimmer_raw, cheetah=half_cheetah_raw)
+
+
+@pytest.fixture(scope="module", params=["swimmer", "cheetah"])
+def loco(request):
+    from mjmpc_amd.envs.tree_engine import TreeRolloutEngine
+    from oracle.physics_ref import RefArm
+    raw = _models()[request.param]()
+    return request.param, raw, TreeRolloutEngine(raw, dtype="f64"), RefArm(raw.to_flat())
+
+
+def _case(name, nv, nu, seed, P, H):
+    rs = np.random.RandomState(seed)
+    q0, v0 = 0.15 * rs.standard_normal(nv), 0.5 * rs.standard_normal(nv)
+    if name == "cheetah":
+        q0[1] = rs.uniform(-0.12, 0.05)                # from resting on the ground to just above it
+    return q0, v0, 0.3 * rs.standard_normal((H, nu)), 0.7 * rs.standard_normal((P, H, nu))
+
+
+def test_f64_rollout_matches_oracle(loco):
+    name, raw, eng, ref = loco
+    H = 24 if name == "swimmer" else 8
+    q0, v0, mean, noise = _case(name, ref.nv, eng.d_action, 1, 101, H)
+    eng.set_env_state(dict(qpos=q0, qvel=v0))
+    obs, rew, act, done, info, nobs = eng.rollout(101, H, mean, noise)
+    o_obs, o_rew, o_act, _, o_nobs = ref.rollout(q0, v0, np.zeros(3), mean, noise)
+    assert obs.shape == (101, H, eng.d_obs) and eng.d_obs == 2 * ref.nv - raw.obs_skip
+    assert np.array_equal(act, o_act)                   # the action as given (unclipped), though the motors clip it
+    np.testing.assert_allclose(rew, o_rew, rtol=1e-9, atol=1e-9)
+    np.testing.assert_allclose(nobs, o_nobs, rtol=0, atol=1e-9)
+    np.testing.assert_allclose(obs, o_obs, rtol=0, atol=1e-9)
+    np.testing.assert_allclose(obs[:, 0], np.broadcast_to(np.concatenate([q0[raw.obs_skip:], v0]), obs[:, 0].shape), atol=1e-15)
+    assert eng.solver_failures() == 0
+
+
+def test_f64_single_steps_from_many_states(loco):
+    """One env step (4 / 5 substeps) from 24 random states, 32 actions each, at 1e-10."""
+    name, raw, eng, ref = loco
+    worst = 0.0
+    for seed in range(24):
+        q0, v0, mean, noise = _case(name, ref.nv, eng.d_action, 100 + seed, 32, 1)
+        eng.set_env_state(dict(qpos=q0, qvel=v0))
+        obs, rew, act, done, info, nobs = eng.rollout(32, 1, mean, 3.0 * noise)      # well past the control limits
+        o = ref.rollout(q0, v0, np.zeros(3), mean, 3.0 * noise)
+        worst = max(worst, np.abs(nobs - o[4]).max(), np.abs(rew - o[1]).max())
+    assert worst < 1e-10 and eng.solver_failures() == 0
+    if name == "cheetah":
+        assert ref.newton_stats()["iters"] > 0          # the states did touch the ground
+
+
+def test_cheetah_long_horizon_error_growth():
+    """Horizon 32: the f64 kernel stays within the rounding-amplification envelope of the oracle (median 1e-9, max 1e-4)."""
+    from mjmpc_amd.envs.tree_engine import TreeRolloutEngine
+    from oracle.physics_ref import RefArm
+    raw = _models()["cheetah"]()
+    eng, ref = TreeRolloutEngine(raw, dtype="f64"), RefArm(raw.to_flat())
+    q0, v0, mean, noise = _case("cheetah", 9, 6, 7, 256, 32)
+    eng.set_env_state(dict(qpos=q0, qvel=v0))
+    obs, rew, act, done, info, nobs = eng.rollout(256, 32, mean, noise)
+    o = ref.rollout(q0, v0, np.zeros(3), mean, noise)
+    e = np.abs(nobs - o[4]).max(axis=2)
+    assert np.median(e[:, -1]) < 1e-9 and e.max() < 1e-4 and eng.solver_failures() == 0
+
+
+@pytest.mark.parametrize("name", ["swimmer", "cheetah"])
+def test_f32_one_step_and_rollout_statistics(name):
+    from mjmpc_amd.envs.tree_engine import TreeRolloutEngine
+    from oracle.physics_ref import RefArm
+    raw = _models()[name]()
+    eng, ref = TreeRolloutEngine(raw, dtype="f32"), RefArm(raw.to_flat())
+    q0, v0, mean, noise = _case(name, ref.nv, eng.d_action, 3, 256, 1)
+    eng.set_env_state(dict(qpos=q0, qvel=v0))
+    obs, rew, act, done, info, nobs = eng.rollout(256, 1, mean, noise)
+    o = ref.rollout(q0, v0, np.zeros(3), mean, noise)
+    assert np.abs(nobs - o[4]).max() < 2e-3 and np.abs(rew - o[1]).max() < 2e-3        # measured 1e-4 / 2e-4
+    # what MPC consumes: the cost-to-go of every particle over a horizon; particles diverge one by one on the cheetah
+    # (chaotic contacts), their distribution does not
+    H = 16
+    q0, v0, mean, noise = _case(name, ref.nv, eng.d_action, 4, 1024, H)
+    eng.set_env_state(dict(qpos=q0, qvel=v0))
+    _, rew, _, _, _, _ = eng.rollout(1024, H, mean, noise)
+    o = ref.rollout(q0, v0, np.zeros(3), mean, noise)
+    ret, oret = rew.sum(axis=1), o[1].sum(axis=1)
+    assert abs(ret.mean() - oret.mean()) < 0.02 * oret.std() + 1e-3
+    assert abs(ret.std() - oret.std()) < 0.05 * oret.std()
+    assert np.corrcoef(ret, oret)[0, 1] > (0.999 if name == "swimmer" else 0.97)
+    assert eng.solver_failures() <= 2
+
+
+def test_env_classes_step_like_the_oracle():
+    """SwimmerEnv / HalfCheetahEnv (the reference's env classes on the tree engine): step, observation, state round trip."""
+    from mjmpc_amd.envs.locomotion_env import HalfCheetahEnv, SwimmerEnv
+    from oracle.physics_ref import RefArm
+    for cls, key in ((SwimmerEnv, "reward_fwd"), (HalfCheetahEnv, "reward_run")):
+        env = cls()
+        ref = RefArm(env.raw.to_flat())
+        ob = env.reset(seed=5)
+        st = env.get_env_state()
+        assert set(st) == {"qpos", "qvel"} and ob.shape == (env.d_obs,)
+        q, v = st["qpos"].copy(), st["qvel"].copy()
+        rs = np.random.RandomState(0)
+        for _ in range(5):
+            a = rs.uniform(-1.5, 1.5, env.d_action)
+            ob, r, done, info = env.step(a)
+            q, v, ro, oo = ref.env_step(q, v, a, np.zeros(3))
+            np.testing.assert_allclose(ob, oo, atol=1e-9)
+            assert abs(r - ro) < 1e-9 and done is False
+            assert abs(info[key] + info["reward_ctrl"] - r) < 1e-9
+        env.set_env_state(st)
+        np.testing.assert_array_equal(env.get_env_state()["qpos"], st["qpos"])
+
+
+def test_mppi_makes_the_cheetah_run():
+    """Closed loop through the unchanged controller classes: MPPI over the tree engine moves the cheetah forward,
+    a zero policy does not."""
+    from mjmpc_amd.control.mppi import MPPI
+    from mjmpc_amd.envs.arm_engine import make_device_rollout_fn
+    from mjmpc_amd.envs.locomotion_env import HalfCheetahEnv
+    from mjmpc_amd.envs.tree_engine import TreeRolloutEngine
+    env = HalfCheetahEnv(dtype="f32")
+    sim = TreeRolloutEngine(env.raw, dtype="f32")
+    ctrl = MPPI(d_state=env.d_state, d_obs=env.d_obs, d_action=env.d_action, action_lows=env.action_lows,
+                action_highs=env.action_highs, horizon=16, init_cov=0.3, base_action="null", lam=0.2, num_particles=1024,
+                step_size=1.0, alpha=1, gamma=1.0, n_iters=1, filter_coeffs=[0.25, 0.8, 0.0], seed=0,
+                noise_mode="device", noise_dtype="f32")
+    ctrl.set_sim_state_fn = sim.set_env_state
+    ctrl.rollout_fn = make_device_rollout_fn(sim)
+    env.reset(seed=0)
+    for _ in range(60):
+        a, _ = ctrl.optimize(env.get_env_state())
+        env.step(a)
+    assert env.get_env_state()["qpos"][0] > 1.0         # metres in 3 s of simulated time
+
+
+@pytest.mark.parametrize("cfg,controller", [("half_cheetah_gpu.yml", "mppi"), ("swimmer_gpu.yml", "cem")])
+def test_example_driver_on_locomotion_configs(tmp_path, cfg, controller):
+    with open(os.path.join(ROOT, "examples", "configs", cfg)) as f:
+        exp = yaml.safe_load(f)
+    exp["n_episodes"], exp["max_ep_length"] = 1, 5
+    for block in exp.values():
+        if isinstance(block, dict) and "particles_per_cpu" in block:
+            block["particles_per_cpu"] = 128
+    p = tmp_path / "loco.yml"
+    p.write_text(yaml.safe_dump(exp))
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "examples", "example_mpc.py"), "--config", str(p),
+                          "--controller", controller, "--noise_mode", "device"], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr[-2000:]
+    assert "forward progress" in out.stdout and "solver failures 0" in out.stdout

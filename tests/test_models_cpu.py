@@ -66,10 +66,17 @@ def test_loader_on_a_small_model_and_rejections(tmp_path):
     (tmp_path / "bad.xml").write_text(bad)
     with pytest.raises(ValueError):
         load_mjcf(str(tmp_path / "bad.xml"))
-    bad = xml.replace('<joint name="j1"', '<joint name="j1" type="slide"')
+    bad = xml.replace('<joint name="j1"', '<joint name="j1" type="ball"')
     (tmp_path / "bad2.xml").write_text(bad)
     with pytest.raises(ValueError):
         load_mjcf(str(tmp_path / "bad2.xml"))
+    # a slide joint loads (the tree engine runs it); the serial-chain arm kernel says it cannot
+    slide = xml.replace('<joint name="j1"', '<joint name="j1" type="slide"')
+    (tmp_path / "slide.xml").write_text(slide)
+    raw2 = load_mjcf(str(tmp_path / "slide.xml"))
+    assert [b.joint.type for b in raw2.bodies] == [1, 2]
+    with pytest.raises(ValueError, match="tree engine"):
+        compile_arm(raw2)
 
 
 def test_systematic_resampling_matches_the_serial_walk(golden):

@@ -21,7 +21,7 @@ def hand():
 
 def test_two_compilers_agree_on_the_hand(hand):
     raw, m, ref = hand
-    assert m.blob.shape == (TREE_BLOB_LEN,) and TREE_BLOB_LEN == 2200
+    assert m.blob.shape == (TREE_BLOB_LEN,) and TREE_BLOB_LEN == 2854
     assert (m.nv, m.nu, m.d_obs) == (24, 24, 54)
     mass, ipos, inertia = ref.inertial()
     np.testing.assert_allclose(m.body_mass, mass[1:], rtol=1e-12)
@@ -75,7 +75,7 @@ def test_mjcf_loader_on_a_branching_model(tmp_path):
     <mujoco>
       <compiler inertiafromgeom="true" angle="radian" coordinate="local"/>
       <option timestep="0.004" gravity="0 0 -9.81" integrator="Euler"/>
-      <default><joint armature="0.01" damping="0.2" limited="true"/><geom margin="0.001" contype="0" conaffinity="0"/></default>
+      <default><joint armature="0.01" damping="0.2" limited="true"/><geom margin="0.001" contype="0" conaffinity="0" condim="1"/></default>
       <worldbody>
         <geom type="plane" pos="0 0 -0.2" size="1 1 1" contype="1" conaffinity="1"/>
         <site name="target" pos="0.3 0 0.2"/>
