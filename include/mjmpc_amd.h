@@ -114,17 +114,24 @@ int mjmpc_arm_step_state(mjmpc_arm_t h, int dtype, const double* d_action, void*
                          void* stream);
 
 /* ---- tree engine: the same worker-pool replacement for models the serial-chain arm engine cannot hold ----------
- * (first cut): a kinematic TREE of up to 32 hinge dofs, gravity, joint limits, up to 8 frictionless
- * sphere/plane contacts, reacher-style reward and observation.  Constant block produced by
- * mjmpc_amd/models/compile_tree.py::compile_tree and mirrored by mjmpc_amd/csrc/tree_model.h; per-link fields are
- * [component][32 lanes], links numbered depth-first:
+ * (SURVEY 8f rank 4): a kinematic TREE of up to 32 hinge / slide dofs (the reference's vendored sawyer.xml, swimmer.xml
+ * and half_cheetah.xml; a synthetic 24-dof hand): gravity, joint limits and springs, motors on a subset of the joints,
+ * MuJoCo's inertia-box fluid model, up to 16 sphere- or capsule-end / plane contact points, frictionless or with
+ * pyramidal friction cones.  Reward and observation follow the block's task: 0 = reach (reacher_env.py:29-47, d_obs =
+ * 2 nv + 6), 1 = forward progress (swimmer.py:10-24, half_cheetah.py:10-25, d_obs = 2 nv - obs_skip).  Constant block
+ * produced by mjmpc_amd/models/compile_tree.py::compile_tree and mirrored by mjmpc_amd/csrc/tree_model.h; per-link
+ * fields are [component][32 lanes], links numbered depth-first:
  *   off[3][32] axis[3][32] mass[32] com[3][32] inertia[6][32] armature damping range_lo range_hi limited gear ctrl_lo
- *   ctrl_hi dof_invweight0 parent subsize anc[5][32] ancmask[2][32] (each [32]) nv timestep frame_skip jumps site_link
- *   site_pos[3] n_sphere plane_n[3] plane_d sol_K sol_B sol_dmin sol_dmax sol_width sol_mid sol_power gravity[3]
- *   spheres[8][8] = {link, pos[3], r, margin, invweight, pad}  depth[32] n_rounds elim[31][32] (elimination lists of the
- *   tree-sparse L'DL: the descendants of every link sorted by height, packed k | distance << 8 | height << 16, -1 ends)
- * Same call shapes and reference counterparts as the arm engine (subproc_vec_env.py:91-111, 128-186, 235-251).     */
-#define MJMPC_TREE_BLOB_LEN 2200
+ *   ctrl_hi dof_invweight0 parent subsize anc[5][32] ancmask[2][32] jtype stiffness springref act (each [32])
+ *   fbox[3][32] frot[9][32]  nv timestep frame_skip jumps site_link site_pos[3] n_sphere plane_n[3] plane_d
+ *   sol_{K,B,dmin,dmax,width,mid,power} gravity[3] nu task ctrl_cost obs_skip density viscosity
+ *   lsol_{K,B,dmin,dmax,width,mid,power} any_friction
+ *   spheres[16][12] = {link, pos[3], r, margin, invweight, mu, capsule axis[3], pad}  depth[32] n_rounds elim[31][32]
+ *   (elimination lists of the tree-sparse L'DL: the descendants of every link sorted by height, packed
+ *   k | distance << 8 | height << 16, -1 ends)
+ * Same call shapes and reference counterparts as the arm engine (subproc_vec_env.py:91-111, 128-186, 235-251);
+ * target_pos is ignored by task 1.                                                                                  */
+#define MJMPC_TREE_BLOB_LEN 2854
 /* Device state vector of a tree engine: qpos[32] | qvel[32] | target_pos[3]  (float64). */
 #define MJMPC_TREE_STATE_LEN 67
 typedef struct mjmpc_tree_s* mjmpc_tree_t;

@@ -61,7 +61,7 @@ struct mjmpc_arm_s {
 struct mjmpc_tree_s {
     int device = 0;
     int nv = 0, nu = 0, d_obs = 0, max_path = 0;
-    bool full = false;              // friction cones, more than 8 contact points or a medium: the full kernel
+    bool full = false;              // slide joints, springs, friction cones, > 8 contact points or a medium: the full kernel
     float* model_f32 = nullptr;
     double* model_f64 = nullptr;
     double* state = nullptr;        // MJMPC_TREE_STATE_LEN
@@ -344,6 +344,8 @@ int mjmpc_tree_create(const double* blob, int n_blob, int device, mjmpc_tree_t* 
     h->d_obs = (int)blob[mjmpc::T_TASK] == 1 ? 2 * nv - (int)blob[mjmpc::T_OBS_SKIP] : 2 * nv + 6;
     h->full = blob[mjmpc::T_ANY_FRICTION] != 0.0 || (int)blob[mjmpc::T_N_SPHERE] > 8 || blob[mjmpc::T_DENSITY] > 0.0 ||
               blob[mjmpc::T_VISCOSITY] > 0.0;
+    for (int l = 0; l < nv; ++l)
+        h->full = h->full || (int)blob[mjmpc::T_JTYPE + l] == 2 || blob[mjmpc::T_STIFFNESS + l] != 0.0;
     for (int l = 0; l < nv; ++l) h->max_path = std::max(h->max_path, (int)blob[mjmpc::T_DEPTH + l] + 1);
     std::vector<float> f32(blob, blob + n_blob);
     HIP_TRY(hipMalloc(&h->model_f32, sizeof(float) * n_blob));

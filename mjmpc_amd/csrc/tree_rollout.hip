@@ -96,23 +96,21 @@ __device__ __forceinline__ T sum32(T x) {
 
 struct Topo {       // my link's place in the tree (registers)
     int parent, subsize, jumps;
+    int anc[5];     // my ancestor at distance 2^k (pointer jumping), -1 beyond the root; only ever indexed by an
+                    // unrolled loop counter, so that it stays in registers
     unsigned ancmask;
-    const int* at;  // LDS: at[c * 32 + l] = ancestor of link l at distance c < DP (-1 beyond the root)
 };
-// my ancestor at distance 2^k (pointer jumping), -1 beyond the root
-template <int DP>
-__device__ __forceinline__ int jump_anc(const Topo& tp, int k, int l) {
-    return (1 << k) < DP ? tp.at[(1 << k) * TL + l] : -1;
-}
 
 // x[c] <- sum over my path to the root (myself included) of x[c]: pointer jumping
 template <int NC, int DP, typename T>
 __device__ __forceinline__ void path_sum(T* x, const Topo& tp, T* X, int l) {
-    for (int k = 0; k < tp.jumps; ++k) {
+#pragma unroll
+    for (int k = 0; k < 5; ++k) {
+        if (k >= tp.jumps) break;
 #pragma unroll
         for (int c = 0; c < NC; ++c) X[c * TL + l] = x[c];
         TSYNC();
-        const int a = jump_anc<DP>(tp, k, l);
+        const int a = tp.anc[k];
         if (a >= 0) {
 #pragma unroll
             for (int c = 0; c < NC; ++c) x[c] += X[c * TL + a];
@@ -246,8 +244,12 @@ __device__ __forceinline__ T tree_solve(const T* r, T b, const int* ELIM, const 
     return b;
 }
 
+// waves per SIMD the register allocation aims at: the lean kernels for short paths fit three (f32) / two (f64)
+// workgroups' LDS on a CU
+constexpr int min_waves(int scalar_bytes, int DP, bool fric) { return (DP <= 8 && !fric) ? (scalar_bytes == 4 ? 3 : 2) : 1; }
+
 template <typename T, int DP, int NS, bool FRIC>
-__global__ __launch_bounds__(64 * wg_waves(DP, FRIC)) void tree_rollout_kernel(
+__global__ __launch_bounds__(64 * wg_waves(DP, FRIC), min_waves(sizeof(T), DP, FRIC)) void tree_rollout_kernel(
     const T* __restrict__ model, const double* __restrict__ state, long P, int H, int A, const double* __restrict__ mean,
     const T* __restrict__ noise, T* __restrict__ cost, T* __restrict__ act, T* __restrict__ obs, T* __restrict__ nobs,
     unsigned* diag) {
@@ -289,14 +291,15 @@ __global__ __launch_bounds__(64 * wg_waves(DP, FRIC)) void tree_rollout_kernel(
     const int n_sphere = __builtin_amdgcn_readfirstlane(min((int)M[T_N_SPHERE], NS));
     const int task = __builtin_amdgcn_readfirstlane((int)M[T_TASK]), obs_skip = __builtin_amdgcn_readfirstlane((int)M[T_OBS_SKIP]);
     const int dobs = task == 1 ? 2 * nv - obs_skip : 2 * nv + 6;
-    const bool slide = (int)M[T_JTYPE + l] == 2;
+    const bool slide = FRIC && (int)M[T_JTYPE + l] == 2;      // (slide joints, springs, a medium: the full instantiation only)
     const int act_id = (int)M[T_ACT + l];
     const bool fluid = FRIC && (M[T_DENSITY] > T(0) || M[T_VISCOSITY] > T(0));   // (the full instantiation only)
 
     Topo tp;
     tp.parent = (int)M[T_PARENT + l];
     tp.subsize = (int)M[T_SUBSIZE + l];
-    tp.at = AT;
+#pragma unroll
+    for (int k = 0; k < 5; ++k) tp.anc[k] = (1 << k) < DP ? AT[(1 << k) * TL + l] : -1;
     tp.jumps = __builtin_amdgcn_readfirstlane((int)M[T_JUMPS]);
     tp.ancmask = (unsigned)M[T_ANCMASK + l] | ((unsigned)M[T_ANCMASK + TL + l] << 16);
     const bool dof = l < nv;
@@ -346,13 +349,15 @@ __global__ __launch_bounds__(64 * wg_waves(DP, FRIC)) void tree_rollout_kernel(
                     for (int k = 0; k < 3; ++k) p[k] += ax[k] * q;
                 }
             }
-            for (int k = 0; k < tp.jumps; ++k) {
+#pragma unroll
+            for (int k = 0; k < 5; ++k) {
+                if (k >= tp.jumps) break;
 #pragma unroll
                 for (int c = 0; c < 9; ++c) X[c * TL + l] = R[c];
 #pragma unroll
                 for (int c = 0; c < 3; ++c) X[(9 + c) * TL + l] = p[c];
                 TSYNC();
-                const int a = jump_anc<DP>(tp, k, l);
+                const int a = tp.anc[k];
                 if (a >= 0) {
                     T Ra[9], pa[3], Rn[9], tv[3];
 #pragma unroll
@@ -522,7 +527,7 @@ __global__ __launch_bounds__(64 * wg_waves(DP, FRIC)) void tree_rollout_kernel(
                 mrow[0] = dof ? mrow[0] + armature : T(1);     // spare lanes: unit diagonal, no ancestors
                 TSYNC();                    // S_ lies inside the area the factorisation publishes rows to
             }
-            const T tau = dof ? -bias - damping * v - M[T_STIFFNESS + l] * (q - M[T_SPRINGREF + l]) + tau_act : T(0);
+            const T tau = dof ? -bias - damping * v - (FRIC ? M[T_STIFFNESS + l] * (q - M[T_SPRINGREF + l]) : T(0)) + tau_act : T(0);
 
             // ---- 5. constraint rows: joint limits (mj_instantiateLimit, strict dist < 0) ...
             T sig = T(0), dist = T(0), D = T(0), aref = T(0);
@@ -840,8 +845,8 @@ hipError_t launch_tree_rollout(const T* model, int max_path, bool full, const do
     hipLaunchKernelGGL((tree_rollout_kernel<T, DP_, NS_, FR_>),                                                       \
                        dim3((unsigned)((P + 2 * wg_waves(DP_, FR_) - 1) / (2 * wg_waves(DP_, FR_)))),                 \
                        dim3(64 * wg_waves(DP_, FR_)), 0, stream, model, state, P, H, A, mean, noise, cost, act, obs, nobs, diag)
-    // models in air with up to 8 frictionless contact points keep the lean instantiation; friction cones, more points
-    // or a medium take the full one (three Jacobians per point, 16 points, fluid forces)
+    // hinge trees in air with up to 8 frictionless contact points keep the lean instantiation; slide joints, springs,
+    // friction cones, more points or a medium take the full one (three Jacobians per point, 16 points, fluid forces)
     if (!full) {
         if (max_path <= 8) MJMPC_TREE_LAUNCH(8, 8, false);
         else if (max_path <= 16) MJMPC_TREE_LAUNCH(16, 8, false);

@@ -58,22 +58,28 @@ def _run_arm(name, make, P, H, steps, warmup, dtype, note):
                       "solver_failures": eng.solver_failures(), "note": note}), flush=True)
 
 
-def run_tree(name, make, P, H, steps, warmup, dtype, note):
-    """The same loop on the tree engine (no device-resident "real env": the state makes a host round trip)."""
+def run_tree(name, make, P, H, steps, warmup, dtype, note, raw_fn=None, env_cls=None):
+    """The same loop on the tree engine (no device-resident "real env": the state makes a host round trip).  With
+    `env_cls` (a locomotion model) the real environment is that class, which owns its stepping engine."""
     import torch
     from mjmpc_amd.envs.arm_engine import make_device_rollout_fn
     from mjmpc_amd.envs.tree_engine import TreeRolloutEngine
     from mjmpc_amd.models.hand24 import hand24_raw
-    raw = hand24_raw()
+    raw = (raw_fn or hand24_raw)()
     eng = TreeRolloutEngine(raw, dtype=dtype)
     ctrl = make(eng, P, H)
     ctrl.rollout_fn = make_device_rollout_fn(eng)
     ctrl.set_sim_state_fn = eng.set_env_state
-    state = eng.reset()[0]
-    ev = []
+    env = env_cls(dtype=dtype) if env_cls else None
+    if env is not None:
+        env.reset(seed=123)
+    state = env.get_env_state() if env is not None else eng.reset()[0]
 
     def step(st):
         a, _ = ctrl.optimize(st)
+        if env is not None:
+            nobs, _, _, _ = env.step(a)
+            return env.get_env_state(), nobs
         eng.set_env_state(st)
         nobs, _ = eng.step(a)
         return eng.get_env_state()[0], nobs
@@ -96,12 +102,26 @@ def run_tree(name, make, P, H, steps, warmup, dtype, note):
     torch.cuda.synchronize()
     kern_ms = e0.elapsed_time(e1) / 3
     nv = eng.model.nv
-    print(json.dumps({"config": name, "particles": P, "horizon": H, "dtype": dtype, "steps": steps,
-                      "ms_per_step": dt / steps * 1e3, "control_loop_hz": steps / dt,
-                      "particle_steps_per_s": P * H * ctrl.n_iters * steps / dt, "rollout_kernel_ms": kern_ms,
-                      "launch": "eager launches", "dofs": nv,
-                      "final_distance_to_target": float(np.linalg.norm(nobs[2 * nv + 3:2 * nv + 6])),
-                      "solver_failures": eng.solver_failures(), "note": note}), flush=True)
+    out = {"config": name, "particles": P, "horizon": H, "dtype": dtype, "steps": steps,
+           "ms_per_step": dt / steps * 1e3, "control_loop_hz": steps / dt,
+           "particle_steps_per_s": P * H * ctrl.n_iters * steps / dt, "rollout_kernel_ms": kern_ms,
+           "launch": "eager launches", "dofs": nv, "frame_skip": raw.frame_skip,
+           "solver_failures": eng.solver_failures(), "note": note}
+    if env is not None:
+        out["forward_progress_m"] = float(state["qpos"][0])
+        # the oracle on this host's cores, same model, a bounded sample of the same rollout (for scale, not a target)
+        from oracle import physics_ref
+        ref = physics_ref.RefArm(raw.to_flat())
+        ps = min(P, 512)
+        rs = np.random.RandomState(0)
+        t0 = time.perf_counter()
+        ref.rollout(state["qpos"], state["qvel"], np.zeros(3), np.zeros((H, eng.d_action)), 0.5 * rs.standard_normal((ps, H, eng.d_action)),
+                    want_obs=False)
+        out["cpu_oracle_particle_steps_per_s"] = ps * H / (time.perf_counter() - t0)
+        out["cpu_oracle_threads"] = physics_ref.threads()
+    else:
+        out["final_distance_to_target"] = float(np.linalg.norm(nobs[2 * nv + 3:2 * nv + 6]))
+    print(json.dumps(out), flush=True)
 
 
 def main():
@@ -111,6 +131,7 @@ def main():
     ap.add_argument("--dtype", choices=["f64", "f32"], default="f64")
     ap.add_argument("--tree-particles", type=int, default=65536)
     ap.add_argument("--only-tree", action="store_true")
+    ap.add_argument("--only-hand", action="store_true", help="of the tree configurations, only the 24-dof hand")
     ap.add_argument("--only", default="", help="run only the arm configurations whose name starts with this (cfg1, cfg3, cfg4)")
     args = ap.parse_args()
     from mjmpc_amd.control import CEM, DMDMPC, MPPI
@@ -144,6 +165,15 @@ def main():
 
     if args.only:
         return
+    if not args.only_hand:
+        from mjmpc_amd.envs.locomotion_env import HalfCheetahEnv, SwimmerEnv
+        from mjmpc_amd.models.half_cheetah import half_cheetah_raw
+        from mjmpc_amd.models.swimmer import swimmer_raw
+        for nm, raw_fn, env_cls, A in (("HalfCheetah-v0", half_cheetah_raw, HalfCheetahEnv, 6), ("Swimmer-v0", swimmer_raw, SwimmerEnv, 4)):
+            run_tree("loco %s MPPI 4096xH32 (reference-registered env over its vendored XML; no reference experiment file)" % nm,
+                     lambda e, P, H, A=A: MPPI(init_cov=0.3, base_action="null", lam=0.2, step_size=1.0, alpha=1, gamma=1.0,
+                                               filter_coeffs=[0.25, 0.8, 0.0], **dict(kw(e, P, H), d_action=A)),
+                     4096, 32, max(10, args.steps // 2), 2, args.dtype, "tree engine, full instantiation", raw_fn, env_cls)
     run_tree("cfg4t DMD-MPC 65536xH64 on the synthetic 24-dof hand tree (pen-v0 assets absent)",
              lambda e, P, H: DMDMPC(init_cov=0.3, beta=0.1, base_action="null", lam=0.1, step_size=1.0, gamma=1.0,
                                     update_cov=False, cov_type="diagonal", filter_coeffs=[0.25, 0.8, 0.0], **kw24(e, P, H)),
