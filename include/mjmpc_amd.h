@@ -126,7 +126,7 @@ int mjmpc_arm_step_state(mjmpc_arm_t h, int dtype, const double* d_action, void*
  *   fbox[3][32] frot[9][32]  nv timestep frame_skip jumps site_link site_pos[3] n_sphere plane_n[3] plane_d
  *   sol_{K,B,dmin,dmax,width,mid,power} gravity[3] nu task ctrl_cost obs_skip density viscosity
  *   lsol_{K,B,dmin,dmax,width,mid,power} any_friction
- *   spheres[16][12] = {link, pos[3], r, margin, invweight, mu, capsule axis[3], pad}  depth[32] n_rounds elim[31][32]
+ *   spheres[16][12] = {link, pos[3], r, margin, invweight, mu, capsule axis[3], depth of the link}  depth[32] n_rounds elim[31][32]
  *   (elimination lists of the tree-sparse L'DL: the descendants of every link sorted by height, packed
  *   k | distance << 8 | height << 16, -1 ends)
  * Same call shapes and reference counterparts as the arm engine (subproc_vec_env.py:91-111, 128-186, 235-251);

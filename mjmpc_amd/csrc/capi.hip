@@ -325,6 +325,17 @@ extern "C" int mjmpc_debug_stamps(mjmpc_arm_t h, unsigned long long* out32) {
 #endif
 
 /* ---- tree engine ------------------------------------------------------------------------------------ */
+#define MJMPC_TREE_DIAG_BYTES (8 + 8 * 16)      /* failure counter, then the developer clocks of -DTREE_STATS builds */
+#ifdef TREE_STATS
+// developer builds only (not declared in include/mjmpc_amd.h): read and clear the phase clocks / iteration counts
+extern "C" int mjmpc_debug_tree_stats(mjmpc_tree_t h, unsigned long long* out16) {
+    if (!h || !out16) return fail(MJMPC_E_BADARG, "null argument");
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemcpy(out16, (char*)h->diag + 8, 8 * 16, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemset((char*)h->diag + 8, 0, 8 * 16));
+    return 0;
+}
+#endif
 int mjmpc_tree_create(const double* blob, int n_blob, int device, mjmpc_tree_t* out) {
     if (!blob || !out) return fail(MJMPC_E_BADARG, "null argument");
     if (n_blob != mjmpc::TREE_BLOB_LEN)
@@ -351,11 +362,11 @@ int mjmpc_tree_create(const double* blob, int n_blob, int device, mjmpc_tree_t* 
     HIP_TRY(hipMalloc(&h->model_f32, sizeof(float) * n_blob));
     HIP_TRY(hipMalloc(&h->model_f64, sizeof(double) * n_blob));
     HIP_TRY(hipMalloc(&h->state, sizeof(double) * MJMPC_TREE_STATE_LEN));
-    HIP_TRY(hipMalloc(&h->diag, sizeof(unsigned)));
+    HIP_TRY(hipMalloc(&h->diag, MJMPC_TREE_DIAG_BYTES));
     HIP_TRY(hipMemcpy(h->model_f32, f32.data(), sizeof(float) * n_blob, hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(h->model_f64, blob, sizeof(double) * n_blob, hipMemcpyHostToDevice));
     HIP_TRY(hipMemset(h->state, 0, sizeof(double) * MJMPC_TREE_STATE_LEN));
-    HIP_TRY(hipMemset(h->diag, 0, sizeof(unsigned)));
+    HIP_TRY(hipMemset(h->diag, 0, MJMPC_TREE_DIAG_BYTES));
     *out = h;
     return 0;
 }

@@ -7,7 +7,7 @@ namespace mjmpc {
 
 constexpr int TL = 32;              // lanes per particle (one per link / dof)
 constexpr int TREE_MAX_SPHERES = 16; // contact points against the plane (a colliding capsule is its two end spheres)
-constexpr int TREE_SPH_STRIDE = 12; // link, pos[3], r, margin, invweight, mu (0: frictionless row), capsule axis[3], (pad)
+constexpr int TREE_SPH_STRIDE = 12; // link, pos[3], r, margin, invweight, mu (0: frictionless row), capsule axis[3], depth of the link
 
 enum TreeOffset : int {
     // the first 25 per-link fields are the arm block's, 32 lanes wide

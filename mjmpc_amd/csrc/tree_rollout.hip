@@ -44,7 +44,31 @@ constexpr int TREE_MAXIT = 16;
 #define TREE_SKIP 0
 #endif
 // waves per workgroup (LDS: [32][2 DP] rows per particle, plus three Jacobian rows per contact point with friction)
-constexpr int wg_waves(int DP, bool fric) { return fric ? (DP <= 16 ? 2 : 1) : (DP <= 8 ? 4 : (DP <= 16 ? 2 : 1)); }
+// developer builds (-DTREE_STATS, tools/tree_stats.py): shader-clock per phase and Newton iteration counts of the first
+// particle of the launch, accumulated behind the failure counter (diag + 2 ... as 64-bit words)
+#ifdef TREE_STATS
+struct TreeClock {
+    unsigned long long t;
+    unsigned long long* out;
+    __device__ void start(unsigned* diag, bool on) { out = on ? (unsigned long long*)(diag + 2) : nullptr; t = __builtin_readcyclecounter(); }
+    __device__ void mark(int slot) {
+        const unsigned long long n = __builtin_readcyclecounter();
+        if (out) atomicAdd(out + slot, n - t);
+        t = n;
+    }
+    __device__ void count(int slot, unsigned v) { if (out) atomicAdd(out + slot, (unsigned long long)v); }
+};
+#else
+struct TreeClock {
+    __device__ void start(unsigned*, bool) {}
+    __device__ void mark(int) {}
+    __device__ void count(int, unsigned) {}
+};
+#endif
+
+constexpr int wg_waves(int DP, bool fric, int scalar_bytes = 8) {
+    return DP <= 8 ? 4 : (DP <= 16 ? 2 : 1);
+}
 
 #define TSYNC()                                                \
     do {                                                       \
@@ -62,9 +86,11 @@ constexpr int A_ROW = 0;                    // path-indexed rows [32][row_stride
 // doubles = 128 B put them on two: measured 16-way conflicts)
 constexpr int row_stride(int DP) { return 2 * DP + 1; }
 constexpr int a_vec(int DP) { return (row_stride(DP) * TL > 12 * TL ? row_stride(DP) * TL : 12 * TL) + 3 & ~3; }   // broadcast vector [32]
-constexpr int a_jc(int DP) { return a_vec(DP) + TL; }                      // contact Jacobian rows [NS][NJ][32]
+// contact Jacobian rows [NS][NJ][DP], PATH-INDEXED like the matrix rows: a contact point on link L moves only with the
+// dofs on L's path to the root, entry c belongs to L's ancestor at distance c (a quarter of a [32]-lane row at DP = 8)
+constexpr int a_jc(int DP) { return a_vec(DP) + TL; }
 constexpr int CS = 12;      // per contact point: centre[3], dist, D, aref (normal part), mu B Jt1.v, mu B Jt2.v, axis[3]
-constexpr int a_cs(int DP, int NS, int NJ) { return a_jc(DP) + NS * NJ * TL; }
+constexpr int a_cs(int DP, int NS, int NJ) { return a_jc(DP) + NS * NJ * DP; }
 constexpr int a_misc(int DP, int NS, int NJ) { return a_cs(DP, NS, NJ) + NS * CS; }   // site[3]
 constexpr int a_len(int DP, int NS, int NJ) { return a_misc(DP, NS, NJ) + 8; }
 
@@ -87,11 +113,28 @@ __device__ __forceinline__ void symv3(const T* S, const T* x, T* y) {      // xx
     y[2] = S[4] * x[0] + S[5] * x[1] + S[2] * x[2];
 }
 
-// sum over the 32 lanes of a particle (contact rows only: rare path)
+// the two 16-lane rows of a particle's 32 lanes added up, result in both: v_permlane16_swap (gfx950) exchanges the odd
+// rows of its first operand with the even rows of its second, so (x, x) comes back as (even-row value, odd-row value)
+__device__ __forceinline__ float add_rows(float x) {
+    const unsigned u = __float_as_uint(x);
+    const auto r = __builtin_amdgcn_permlane16_swap(u, u, false, false);
+    return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+__device__ __forceinline__ double add_rows(double x) {
+    const unsigned lo = (unsigned)__double2loint(x), hi = (unsigned)__double2hiint(x);
+    const auto a = __builtin_amdgcn_permlane16_swap(lo, lo, false, false);
+    const auto b = __builtin_amdgcn_permlane16_swap(hi, hi, false, false);
+    return __hiloint2double((int)b[0], (int)a[0]) + __hiloint2double((int)b[1], (int)a[1]);
+}
+// sum over the 32 lanes of a particle, result in every lane: four DPP steps inside the 16-lane rows and one row swap
+// (no LDS crossbar: a ds_bpermute butterfly costs five times as much)
 template <typename T>
 __device__ __forceinline__ T sum32(T x) {
-    for (int o = 16; o > 0; o >>= 1) x += __shfl_xor(x, o);
-    return x;
+    x += dpp_all<0xB1>(x);          // quad_perm [1,0,3,2]
+    x += dpp_all<0x4E>(x);          // quad_perm [2,3,0,1]
+    x += dpp_all<0x141>(x);         // row_half_mirror: i <-> 7 - i
+    x += dpp_all<0x140>(x);         // row_mirror: i <-> 15 - i
+    return add_rows(x);
 }
 
 struct Topo {       // my link's place in the tree (registers)
@@ -249,11 +292,11 @@ __device__ __forceinline__ T tree_solve(const T* r, T b, const int* ELIM, const 
 constexpr int min_waves(int scalar_bytes, int DP, bool fric) { return (DP <= 8 && !fric) ? (scalar_bytes == 4 ? 3 : 2) : 1; }
 
 template <typename T, int DP, int NS, bool FRIC>
-__global__ __launch_bounds__(64 * wg_waves(DP, FRIC), min_waves(sizeof(T), DP, FRIC)) void tree_rollout_kernel(
+__global__ __launch_bounds__(64 * wg_waves(DP, FRIC, sizeof(T)), min_waves(sizeof(T), DP, FRIC)) void tree_rollout_kernel(
     const T* __restrict__ model, const double* __restrict__ state, long P, int H, int A, const double* __restrict__ mean,
     const T* __restrict__ noise, T* __restrict__ cost, T* __restrict__ act, T* __restrict__ obs, T* __restrict__ nobs,
     unsigned* diag) {
-    constexpr int WG_WAVES = wg_waves(DP, FRIC);
+    constexpr int WG_WAVES = wg_waves(DP, FRIC, sizeof(T));
     constexpr int NJ = FRIC ? 3 : 1;        // Jacobian rows kept per contact point: normal (+ two tangents)
     constexpr int NR = FRIC ? 4 : 1;        // constraint rows per contact point: Jn (+- mu Jt_k)
     typedef typename std::conditional<FRIC, unsigned long long, unsigned>::type mask_t;    // NR bits per contact point
@@ -316,6 +359,8 @@ __global__ __launch_bounds__(64 * wg_waves(DP, FRIC), min_waves(sizeof(T), DP, F
     unsigned cinst_mem = 0;         // contact points of the previous substep ...
     mask_t cact_mem = 0;            // ... and which of their rows were active
     T hand_prev[3] = {T(0), T(0), T(0)}, q_prev = q, v_prev = v;
+    TreeClock clk;
+    clk.start(diag, blockIdx.x == 0 && threadIdx.x == 0);
 
     for (int t = 0; t < H; ++t) {
         T u = T(0);
@@ -331,6 +376,7 @@ __global__ __launch_bounds__(64 * wg_waves(DP, FRIC), min_waves(sizeof(T), DP, F
         T hand[3] = {T(0), T(0), T(0)};
         for (int sub = 0; sub < frame_skip; ++sub) {
             // ---- 1. forward kinematics: X_l = X_parent o (Rodrigues(axis, q), off), by pointer jumping
+            clk.mark(7);
             T R[9], p[3], ax[3];
             {
                 const T s = sq, c = cq, tt = T(1) - cq;
@@ -380,20 +426,37 @@ __global__ __launch_bounds__(64 * wg_waves(DP, FRIC), min_waves(sizeof(T), DP, F
                 mv3(R, sp, tv);
                 for (int k = 0; k < 3; ++k) X[A_MISC + k] = p[k] + tv[k];
             }
-            // collision spheres: centre and signed distance, published by the sphere's link
-            for (int s = 0; s < n_sphere; ++s) {
-                const T* sp = M + T_SPH + s * TREE_SPH_STRIDE;
-                if (l == (int)sp[0]) {
-                    T tv[3], ctr[3];
-                    mv3(R, sp + 1, tv);
-                    for (int k = 0; k < 3; ++k) ctr[k] = p[k] + tv[k];
-                    for (int k = 0; k < 3; ++k) X[A_CS + s * CS + k] = ctr[k];
-                    X[A_CS + s * CS + 3] = dot3(ctr, pn) - M[T_PLANE_D] - sp[4];
-                    if (FRIC) {         // the capsule axis the contact frame is aligned with (zero for a sphere)
-                        mv3(R, sp + 8, tv);
-                        for (int k = 0; k < 3; ++k) X[A_CS + s * CS + 8 + k] = tv[k];
+            // contact points: centre, signed distance (and the capsule axis the contact frame is aligned with), one
+            // point per lane - every link publishes its frame, lane s reads the frame of point s's link
+            unsigned cinst = 0, ucinst = 0;     // points in contact: of my particle / of either particle of the wavefront
+            if (n_sphere > 0) {
+                bool ci_mine = false;
+#pragma unroll
+                for (int c = 0; c < 9; ++c) X[c * TL + l] = R[c];
+#pragma unroll
+                for (int c = 0; c < 3; ++c) X[(9 + c) * TL + l] = p[c];
+                TSYNC();
+                if (l < n_sphere) {
+                    const T* sp = M + T_SPH + l * TREE_SPH_STRIDE;
+                    const int sl = (int)sp[0];
+                    T Rl[9], ctr[3], tv[3];
+#pragma unroll
+                    for (int c = 0; c < 9; ++c) Rl[c] = X[c * TL + sl];
+                    mv3(Rl, sp + 1, tv);
+                    for (int k = 0; k < 3; ++k) ctr[k] = X[(9 + k) * TL + sl] + tv[k];
+                    T* cs = X + A_CS + l * CS;
+                    for (int k = 0; k < 3; ++k) cs[k] = ctr[k];
+                    const T cdist = dot3(ctr, pn) - M[T_PLANE_D] - sp[4];
+                    cs[3] = cdist;
+                    ci_mine = cdist < sp[5];            // mj_collision: included while dist < margin
+                    if (FRIC) {
+                        mv3(Rl, sp + 8, tv);
+                        for (int k = 0; k < 3; ++k) cs[8 + k] = tv[k];
                     }
                 }
+                const unsigned long long b = __ballot(ci_mine);
+                cinst = (unsigned)(b >> (32 * half));
+                ucinst = (unsigned)b | (unsigned)(b >> 32);
             }
             TSYNC();
             if (sub == frame_skip - 1 || (t == 0 && sub == 0))
@@ -402,6 +465,7 @@ __global__ __launch_bounds__(64 * wg_waves(DP, FRIC), min_waves(sizeof(T), DP, F
                 for (int k = 0; k < 3; ++k) hand_prev[k] = hand[k];     // fresh observation after set_env_state
 
             // ---- 2. world-frame quantities of my link, about the world origin
+            clk.mark(0);
             const T mass = M[T_MASS + l];
             T a[3], cw[3], tv[3], Ib[6], hm[3], sw[3], sv[3];
             mv3(R, ax, a);
@@ -501,6 +565,7 @@ __global__ __launch_bounds__(64 * wg_waves(DP, FRIC), min_waves(sizeof(T), DP, F
 
             // ---- 4. composite inertia over the subtree, F = Ic S, my path-indexed mass-matrix row
             //         mrow[c] = M[l][ancestor at distance c] = S_anc . F_l
+            clk.mark(1);
             T mrow[DP];
             {
                 T c6[6] = {Ib[0], Ib[1], Ib[2], Ib[3], Ib[4], Ib[5]}, c4[4] = {mass, hm[0], hm[1], hm[2]};
@@ -530,6 +595,7 @@ __global__ __launch_bounds__(64 * wg_waves(DP, FRIC), min_waves(sizeof(T), DP, F
             const T tau = dof ? -bias - damping * v - (FRIC ? M[T_STIFFNESS + l] * (q - M[T_SPRINGREF + l]) : T(0)) + tau_act : T(0);
 
             // ---- 5. constraint rows: joint limits (mj_instantiateLimit, strict dist < 0) ...
+            clk.mark(2);
             T sig = T(0), dist = T(0), D = T(0), aref = T(0);
             bool inst = false;
             if (dof && M[T_LIMITED + l] != T(0)) {
@@ -541,62 +607,70 @@ __global__ __launch_bounds__(64 * wg_waves(DP, FRIC), min_waves(sizeof(T), DP, F
             // LDS, scalars per contact point.  condim 1: one row Jn.  condim 3 (FRIC): MuJoCo's pyramidal cone - the four
             // rows Jn +- mu Jt_k in the frame mju_makeFrame builds from the normal and the capsule axis, every row with
             // diagApprox = tran (1 + mu^2), R = 2 mu^2 R_first, and its own reference acceleration.
-            unsigned cinst = 0;
-            for (int s = 0; s < n_sphere; ++s) {
+            // my entry of the Jacobian rows of point s: the distance from its link up to me, -1 if I am not on that path
+            // (or the point is not in contact for my particle)
+            auto own_idx = [&](int s) -> int {
+                const T* sp = M + T_SPH + s * TREE_SPH_STRIDE;
+                const int idx = (int)sp[11] - depth;
+                return (((cinst >> s) & 1u) && dof && idx >= 0 && AT[idx * TL + (int)sp[0]] == l) ? idx : -1;
+            };
+            for (unsigned um = ucinst; um; um &= um - 1) {
+                const int s = __builtin_ctz(um);
                 const T* sp = M + T_SPH + s * TREE_SPH_STRIDE;
                 T* cs = X + A_CS + s * CS;
+                T* jrow = X + A_JC + s * NJ * DP;
                 const T cdist = cs[3];
-                const bool ci = cdist < sp[5];
-                if (__any(ci)) {
-                    const int sl = (int)sp[0];
-                    // velocity of the contact point per unit joint velocity, from the motion subspace about the world
-                    // origin: g = sw x c + sv  (hinge: a x (c - p); slide: a)
-                    T r[3], g[3];
-                    for (int k = 0; k < 3; ++k) r[k] = cs[k] - pn[k] * (sp[4] + T(0.5) * cdist);
-                    cross3(sw, r, g);
-                    for (int k = 0; k < 3; ++k) g[k] += sv[k];
-                    const unsigned smask = (unsigned)M[T_ANCMASK + sl] | ((unsigned)M[T_ANCMASK + TL + sl] << 16);
-                    const bool mine = ci && dof && ((smask >> l) & 1u);
-                    const T jc = mine ? dot3(pn, g) : T(0);
-                    X[A_JC + (s * NJ) * TL + l] = jc;
-                    const T jv = sum32(jc * v);
-                    const T mu = FRIC ? sp[7] : T(0);
-                    T Dc, arc, mb1 = T(0), mb2 = T(0);
-                    if (FRIC) {
-                        T ax3[3] = {cs[8], cs[9], cs[10]}, t1[3], t2[3];
-                        if (dot3(ax3, ax3) < T(0.25)) {
-                            const bool yy = pn[1] < T(0.5) && pn[1] > T(-0.5);
-                            ax3[0] = T(0);
-                            ax3[1] = yy ? T(1) : T(0);
-                            ax3[2] = yy ? T(0) : T(1);
-                        }
-                        const T pr = dot3(pn, ax3);
-                        for (int k = 0; k < 3; ++k) t1[k] = ax3[k] - pr * pn[k];
-                        const T nn = dot3(t1, t1);
-                        if (nn < T(1e-30)) { t1[0] = T(1); t1[1] = T(0); t1[2] = T(0); }
-                        else { const T inv = rcp_(sqrt_(nn)); for (int k = 0; k < 3; ++k) t1[k] *= inv; }
-                        cross3(pn, t1, t2);
-                        const bool fr = mine && mu > T(0);
-                        const T j1 = fr ? dot3(t1, g) : T(0), j2 = fr ? dot3(t2, g) : T(0);
-                        X[A_JC + (s * NJ + 1) * TL + l] = j1;
-                        X[A_JC + (s * NJ + 2) * TL + l] = j2;
-                        mb1 = mu * M[T_SOL_B] * sum32(j1 * v);
-                        mb2 = mu * M[T_SOL_B] * sum32(j2 * v);
+                const bool ci = (cinst >> s) & 1u;
+                const int dsl = (int)sp[11], oi = own_idx(s);
+                // velocity of the contact point per unit joint velocity, from the motion subspace about the world
+                // origin: g = sw x c + sv  (hinge: a x (c - p); slide: a)
+                T r[3], g[3];
+                for (int k = 0; k < 3; ++k) r[k] = cs[k] - pn[k] * (sp[4] + T(0.5) * cdist);
+                cross3(sw, r, g);
+                for (int k = 0; k < 3; ++k) g[k] += sv[k];
+                const T jc = oi >= 0 ? dot3(pn, g) : T(0);
+                if (oi >= 0) jrow[oi] = jc;
+                if (ci && l > dsl && l < DP) jrow[l] = T(0);        // past the root: read by shorter paths' lanes
+                const T jv = sum32(jc * v);
+                const T mu = FRIC ? sp[7] : T(0);
+                T Dc, arc, mb1 = T(0), mb2 = T(0);
+                if (FRIC) {
+                    T ax3[3] = {cs[8], cs[9], cs[10]}, t1[3], t2[3];
+                    if (dot3(ax3, ax3) < T(0.25)) {
+                        const bool yy = pn[1] < T(0.5) && pn[1] > T(-0.5);
+                        ax3[0] = T(0);
+                        ax3[1] = yy ? T(1) : T(0);
+                        ax3[2] = yy ? T(0) : T(1);
                     }
-                    tree_row_params(M + T_SOL_K, cdist - sp[5], sp[6] * (T(1) + mu * mu), jv, Dc, arc);
-                    if (mu > T(0)) Dc *= T(0.5) * rcp_(mu * mu);
-                    if (l == 0) {
-                        cs[4] = ci ? Dc : T(0);
-                        cs[5] = ci ? arc : T(0);
-                        if (FRIC) { cs[6] = mb1; cs[7] = mb2; }
-                    }
-                    if (ci) cinst |= 1u << s;
+                    const T pr = dot3(pn, ax3);
+                    for (int k = 0; k < 3; ++k) t1[k] = ax3[k] - pr * pn[k];
+                    const T nn = dot3(t1, t1);
+                    if (nn < T(1e-30)) { t1[0] = T(1); t1[1] = T(0); t1[2] = T(0); }
+                    else { const T inv = rcp_(sqrt_(nn)); for (int k = 0; k < 3; ++k) t1[k] *= inv; }
+                    cross3(pn, t1, t2);
+                    const bool fr = oi >= 0 && mu > T(0);
+                    const T j1 = fr ? dot3(t1, g) : T(0), j2 = fr ? dot3(t2, g) : T(0);
+                    if (oi >= 0) { jrow[DP + oi] = j1; jrow[2 * DP + oi] = j2; }
+                    if (ci && l > dsl && l < DP) { jrow[DP + l] = T(0); jrow[2 * DP + l] = T(0); }
+                    mb1 = mu * M[T_SOL_B] * sum32(j1 * v);
+                    mb2 = mu * M[T_SOL_B] * sum32(j2 * v);
+                }
+                tree_row_params(M + T_SOL_K, cdist - sp[5], sp[6] * (T(1) + mu * mu), jv, Dc, arc);
+                if (mu > T(0)) Dc *= T(0.5) * rcp_(mu * mu);
+                if (l == 0 && ci) {
+                    cs[4] = Dc;
+                    cs[5] = arc;
+                    if (FRIC) { cs[6] = mb1; cs[7] = mb2; }
                 }
             }
             TSYNC();
             const bool any_rows = !(TREE_SKIP & 1) && __any(inst || cinst != 0);
             T qfrc_c = T(0);
+            clk.mark(3);
+            clk.count(8, 1);
+            clk.count(9, __popc(cinst));
             if (any_rows) {
+                clk.count(10, 1);
                 tree_row_params(M + T_LSOL_K, dist, M[T_DOF_INVW + l], sig * v, D, aref);
                 D = inst ? D : T(0);
                 aref = inst ? aref : T(0);
@@ -605,12 +679,14 @@ __global__ __launch_bounds__(64 * wg_waves(DP, FRIC), min_waves(sizeof(T), DP, F
                 // residuals J_r a - aref_r of the rows of contact point s, given a (one entry per lane)
                 auto residuals = [&](int s, T xa_, T* res) {
                     const T* cs = X + A_CS + s * CS;
-                    const T an = sum32(X[A_JC + (s * NJ) * TL + l] * xa_);
+                    const T* jrow = X + A_JC + s * NJ * DP;
+                    const int oi = own_idx(s);
+                    const T an = sum32(oi >= 0 ? jrow[oi] * xa_ : T(0));
                     res[0] = an - cs[5];
                     if (FRIC) {
                         const T mu = M[T_SPH + s * TREE_SPH_STRIDE + 7];
-                        const T a1 = mu * sum32(X[A_JC + (s * NJ + 1) * TL + l] * xa_);
-                        const T a2 = mu * sum32(X[A_JC + (s * NJ + 2) * TL + l] * xa_);
+                        const T a1 = mu * sum32(oi >= 0 ? jrow[DP + oi] * xa_ : T(0));
+                        const T a2 = mu * sum32(oi >= 0 ? jrow[2 * DP + oi] * xa_ : T(0));
                         res[0] = an + a1 - (cs[5] - cs[6]);
                         res[1 % NR] = an - a1 - (cs[5] + cs[6]);
                         res[2 % NR] = an + a2 - (cs[5] - cs[7]);
@@ -621,8 +697,8 @@ __global__ __launch_bounds__(64 * wg_waves(DP, FRIC), min_waves(sizeof(T), DP, F
                 // the active set a solution belongs to next: a row stays / becomes active while its residual is negative
                 auto next_set = [&](T xa_, mask_t cur) -> mask_t {
                     mask_t nxt = 0;
-                    for (int s = 0; s < n_sphere; ++s) {
-                        if (!__any((cinst >> s) & 1u)) continue;
+                    for (unsigned um = ucinst; um; um &= um - 1) {
+                        const int s = __builtin_ctz(um);
                         T res[NR];
                         residuals(s, xa_, res);
                         const unsigned rows = rows_of(s);
@@ -640,11 +716,13 @@ __global__ __launch_bounds__(64 * wg_waves(DP, FRIC), min_waves(sizeof(T), DP, F
                 // initial active set: a row that existed in the previous substep keeps its state, a new row is active
                 bool actv = inst && ((lim_mem & 1) ? (lim_mem & 2) != 0 : true);
                 mask_t cact = 0;
-                for (int s = 0; s < n_sphere; ++s)
+                for (unsigned um = ucinst; um; um &= um - 1) {
+                    const int s = __builtin_ctz(um);
                     if ((cinst >> s) & 1u) {
                         const mask_t rows = rows_of(s);
                         cact |= ((cinst_mem >> s) & 1u) ? (cact_mem & (rows << (s * NR))) : (rows << (s * NR));
                     }
+                }
                 bool changed = true, act_pp = false;
                 mask_t cact_pp = 0;
                 T xa = T(0);
@@ -654,11 +732,14 @@ __global__ __launch_bounds__(64 * wg_waves(DP, FRIC), min_waves(sizeof(T), DP, F
                     for (int c = 0; c < DP; ++c) hrow[c] = mrow[c];
                     T rhs = tau + (actv ? D * sig * aref : T(0));
                     hrow[0] += actv ? D : T(0);
-                    for (int s = 0; s < n_sphere; ++s) {
+                    for (unsigned um = ucinst; um; um &= um - 1) {
+                        const int s = __builtin_ctz(um);
                         const unsigned bits = (unsigned)(cact >> (s * NR)) & ((1u << NR) - 1u);
                         if (!__any(bits != 0)) continue;
                         const T* cs = X + A_CS + s * CS;
-                        const T Dc = bits ? cs[4] : T(0), jl = X[A_JC + (s * NJ) * TL + l];
+                        const T* jrow = X + A_JC + s * NJ * DP;
+                        const int oi = own_idx(s);
+                        const T Dc = bits ? cs[4] : T(0), jl = oi >= 0 ? jrow[oi] : T(0);
                         // sum over the active rows r of D J_r J_r' and D J_r aref_r, J_r = Jn + s_r mu Jt_k(r):
                         // grouped by the three Jacobians kept per point (counts and signed counts of the active rows)
                         const T na = T(__popc(bits));
@@ -666,7 +747,7 @@ __global__ __launch_bounds__(64 * wg_waves(DP, FRIC), min_waves(sizeof(T), DP, F
                         T rsum = na * cs[5];
                         if (FRIC) {
                             const T mu = M[T_SPH + s * TREE_SPH_STRIDE + 7];
-                            const T j1 = mu * X[A_JC + (s * NJ + 1) * TL + l], j2 = mu * X[A_JC + (s * NJ + 2) * TL + l];
+                            const T j1 = oi >= 0 ? mu * jrow[DP + oi] : T(0), j2 = oi >= 0 ? mu * jrow[2 * DP + oi] : T(0);
                             const T n1 = T(__popc(bits & 3u)), s1 = T((int)(bits & 1u) - (int)((bits >> 1) & 1u));
                             const T n2 = T(__popc(bits & 12u)), s2 = T((int)((bits >> 2) & 1u) - (int)((bits >> 3) & 1u));
                             wn += Dc * (s1 * j1 + s2 * j2);
@@ -676,14 +757,16 @@ __global__ __launch_bounds__(64 * wg_waves(DP, FRIC), min_waves(sizeof(T), DP, F
                             rhs += Dc * (j1 * (s1 * cs[5] - n1 * cs[6]) + j2 * (s2 * cs[5] - n2 * cs[7]));
                         }
                         rhs += Dc * jl * rsum;
-                        // a contact row couples only dofs on one path: the pattern holds
+                        // a contact row couples only dofs on one path: the pattern holds, and my ancestor at distance c
+                        // sits c entries further along the point's rows (zeros past the root)
+                        if (oi >= 0) {
 #pragma unroll
-                        for (int c = 0; c < DP; ++c) {
-                            const int an = AT[c * TL + l];
-                            if (an >= 0) {
-                                T acc = wn * X[A_JC + (s * NJ) * TL + an];
-                                if (FRIC) acc += w1 * X[A_JC + (s * NJ + 1) * TL + an] + w2 * X[A_JC + (s * NJ + 2) * TL + an];
-                                hrow[c] += acc;
+                            for (int c = 0; c < DP; ++c) {
+                                if (oi + c < DP) {
+                                    T acc = wn * jrow[oi + c];
+                                    if (FRIC) acc += w1 * jrow[DP + oi + c] + w2 * jrow[2 * DP + oi + c];
+                                    hrow[c] += acc;
+                                }
                             }
                         }
                     }
@@ -735,6 +818,7 @@ __global__ __launch_bounds__(64 * wg_waves(DP, FRIC), min_waves(sizeof(T), DP, F
                     cact_pp = cact;
                     actv = act2;
                     cact = cact2;
+                    clk.count(11, 1);
                     if (!__any(changed)) break;
                 }
                 if (changed && diag) atomicAdd(diag, 1u);
@@ -742,12 +826,15 @@ __global__ __launch_bounds__(64 * wg_waves(DP, FRIC), min_waves(sizeof(T), DP, F
                 cinst_mem = cinst;
                 cact_mem = cact;
                 qfrc_c = actv ? -D * (sig * xa - aref) * sig : T(0);
-                for (int s = 0; s < n_sphere; ++s) {
+                for (unsigned um = ucinst; um; um &= um - 1) {
+                    const int s = __builtin_ctz(um);
                     const unsigned bits = (unsigned)(cact >> (s * NR)) & ((1u << NR) - 1u);
                     if (!__any(bits != 0)) continue;
                     T res[NR];
                     residuals(s, xa, res);
-                    const T Dc = X[A_CS + s * CS + 4], jl = X[A_JC + (s * NJ) * TL + l];
+                    const T* jrow = X + A_JC + s * NJ * DP;
+                    const int oi = own_idx(s);
+                    const T Dc = X[A_CS + s * CS + 4], jl = oi >= 0 ? jrow[oi] : T(0);
                     T fn = T(0), f1 = T(0), f2 = T(0);      // sum of row forces on Jn, mu Jt1, mu Jt2
                     for (int r = 0; r < NR; ++r) {
                         const T fr = ((bits >> r) & 1u) ? -Dc * res[r] : T(0);
@@ -760,7 +847,7 @@ __global__ __launch_bounds__(64 * wg_waves(DP, FRIC), min_waves(sizeof(T), DP, F
                     qfrc_c += jl * fn;
                     if (FRIC) {
                         const T mu = M[T_SPH + s * TREE_SPH_STRIDE + 7];
-                        qfrc_c += mu * (X[A_JC + (s * NJ + 1) * TL + l] * f1 + X[A_JC + (s * NJ + 2) * TL + l] * f2);
+                        if (oi >= 0) qfrc_c += mu * (jrow[DP + oi] * f1 + jrow[2 * DP + oi] * f2);
                     }
                 }
             } else {
@@ -769,6 +856,7 @@ __global__ __launch_bounds__(64 * wg_waves(DP, FRIC), min_waves(sizeof(T), DP, F
                 cact_mem = 0;
             }
             // ---- 6. mj_Euler with implicit joint damping: (M + h B) qacc = qfrc_smooth + qfrc_constraint
+            clk.mark(4);
             T qacc;
             {
                 mrow[0] += dof ? h * damping : T(0);
@@ -779,6 +867,7 @@ __global__ __launch_bounds__(64 * wg_waves(DP, FRIC), min_waves(sizeof(T), DP, F
                     qacc = tree_solve<DP>(mrow, tau + qfrc_c, ELIM, AT, ROW, VEC, l, n_rounds, depth, max_depth);
                 }
             }
+            clk.mark(5);
             if (dof) {
                 v += h * qacc;
                 const T dq = h * v;
@@ -843,8 +932,8 @@ hipError_t launch_tree_rollout(const T* model, int max_path, bool full, const do
     if (P <= 0 || H <= 0) return hipSuccess;
 #define MJMPC_TREE_LAUNCH(DP_, NS_, FR_)                                                                              \
     hipLaunchKernelGGL((tree_rollout_kernel<T, DP_, NS_, FR_>),                                                       \
-                       dim3((unsigned)((P + 2 * wg_waves(DP_, FR_) - 1) / (2 * wg_waves(DP_, FR_)))),                 \
-                       dim3(64 * wg_waves(DP_, FR_)), 0, stream, model, state, P, H, A, mean, noise, cost, act, obs, nobs, diag)
+                       dim3((unsigned)((P + 2 * wg_waves(DP_, FR_, sizeof(T)) - 1) / (2 * wg_waves(DP_, FR_, sizeof(T))))), \
+                       dim3(64 * wg_waves(DP_, FR_, sizeof(T))), 0, stream, model, state, P, H, A, mean, noise, cost, act, obs, nobs, diag)
     // hinge trees in air with up to 8 frictionless contact points keep the lean instantiation; slide joints, springs,
     // friction cones, more points or a medium take the full one (three Jacobians per point, 16 points, fluid forces)
     if (!full) {

@@ -310,6 +310,7 @@ def compile_tree(raw: RawModel) -> TreeModel:
                 raise NotImplementedError("contacts are condim 1 (frictionless) or 3 (pyramidal cone), got %d" % condim)
             rec[7] = max(g.friction, raw.plane.friction) if condim == 3 else 0.0
             rec[8:11] = R0[i] @ u
+            rec[11] = depth[li] - 1                             # strict ancestors of the point's link
         f["any_friction"][0] = 1.0 if any(f["spheres"][s * SPH_STRIDE + 7] > 0 for s in range(len(points))) else 0.0
 
     def sol_set(prefix, solref, solimp):

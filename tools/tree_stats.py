@@ -1,0 +1,58 @@
+"""Phase clocks and Newton statistics of the tree rollout kernel (developer tool).
+
+    python tools/tree_stats.py --build                      # instrumented copy of the library (-DTREE_STATS)
+    python tools/tree_stats.py [hand|swimmer|cheetah] [dtype] [P] [H]
+
+Prints, for the first particle of the launch, shader cycles per substep in each phase and the constraint statistics."""
+import ctypes, glob, os, subprocess, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+LIB = os.path.join(ROOT, "tools", "_build", "libmjmpc_amd_treestats.so")
+CSRC = os.path.join(ROOT, "mjmpc_amd", "csrc")
+NAMES = ["kinematics + contact geometry", "link quantities + bias forces (+ fluid)", "composite inertia + mass-matrix row",
+         "constraint rows", "Newton iterations", "Euler factor + solve", "-", "integrate + records"]
+
+if __name__ == "__main__":
+    if "--build" in sys.argv:
+        os.makedirs(os.path.dirname(LIB), exist_ok=True)
+        subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
+                               "-Wno-unused-value", "-DTREE_STATS", "-I", CSRC] + sorted(glob.glob(os.path.join(CSRC, "*.hip"))) + ["-o", LIB])
+        sys.exit(0)
+    os.environ["MJMPC_AMD_LIB"] = LIB
+    import numpy as np
+    import torch
+    from mjmpc_amd import _lib
+    from mjmpc_amd.envs.tree_engine import TreeRolloutEngine
+    from mjmpc_amd.models.half_cheetah import half_cheetah_raw
+    from mjmpc_amd.models.hand24 import hand24_raw
+    from mjmpc_amd.models.swimmer import swimmer_raw
+    args = sys.argv[1:]
+    name = args[0] if args else "cheetah"
+    dt = args[1] if len(args) > 1 else "f64"
+    P = int(args[2]) if len(args) > 2 else 4096
+    H = int(args[3]) if len(args) > 3 else 32
+    raw = dict(hand=hand24_raw, swimmer=swimmer_raw, cheetah=half_cheetah_raw)[name]()
+    eng = TreeRolloutEngine(raw, dtype=dt)
+    if name == "cheetah":
+        eng.set_env_state(dict(qpos=np.array([0.0, -0.1324, 0.0521, 0.0342, 0.0679, -0.0139, -0.0589, -0.14, -0.131]), qvel=np.zeros(9)))
+    lib = _lib.load()
+    lib.mjmpc_debug_tree_stats.restype = ctypes.c_int
+    lib.mjmpc_debug_tree_stats.argtypes = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_ulonglong)]
+    A = eng.d_action
+    g = torch.Generator(device="cuda").manual_seed(0)
+    noise = 0.5 * torch.randn(P, H, A, device="cuda", dtype=torch.float32 if dt == "f32" else torch.float64, generator=g)
+    mean = torch.zeros(H, A, device="cuda", dtype=torch.float64)
+    out = (ctypes.c_ulonglong * 16)()
+    eng.rollout_device(P, H, mean, noise)
+    lib.mjmpc_debug_tree_stats(eng._h, out)
+    eng.rollout_device(P, H, mean, noise)
+    lib.mjmpc_debug_tree_stats(eng._h, out)
+    v = list(out)
+    nsub = max(v[8], 1)
+    print("%s %s P=%d H=%d: %d substeps of particle 0" % (name, dt, P, H, nsub))
+    tot = sum(v[:8])
+    for i, nm in enumerate(NAMES):
+        if nm != "-":
+            print("  %-45s %8.0f cycles/substep  %5.1f %%" % (nm, v[i] / nsub, 100.0 * v[i] / tot))
+    print("  total %.0f cycles/substep; contact points per substep %.2f; substeps with rows %.0f %%; Newton iterations per such substep %.2f"
+          % (tot / nsub, v[9] / nsub, 100.0 * v[10] / nsub, v[11] / max(v[10], 1)))

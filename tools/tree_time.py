@@ -1,4 +1,4 @@
-"""Rollout-kernel time of the tree engine on the 24-dof hand: python tools/tree_time.py [P] [H] [dtype]
+"""Rollout-kernel time of the tree engine: python tools/tree_time.py [P] [H] [dtype] [hand|swimmer|cheetah]
 (MJMPC_AMD_LIB selects an alternative build of the library, e.g. one compiled with -DTREE_SKIP=...)."""
 import os, sys
 import numpy as np
@@ -9,10 +9,21 @@ from mjmpc_amd.models.hand24 import hand24_raw
 P = int(sys.argv[1]) if len(sys.argv) > 1 else 65536
 H = int(sys.argv[2]) if len(sys.argv) > 2 else 16
 dt = sys.argv[3] if len(sys.argv) > 3 else "f64"
-eng = TreeRolloutEngine(hand24_raw(), dtype=dt)
+name = sys.argv[4] if len(sys.argv) > 4 else "hand"
+if name == "hand":
+    raw = hand24_raw()
+else:
+    from mjmpc_amd.models.half_cheetah import half_cheetah_raw
+    from mjmpc_amd.models.swimmer import swimmer_raw
+    raw = dict(swimmer=swimmer_raw, cheetah=half_cheetah_raw)[name]()
+eng = TreeRolloutEngine(raw, dtype=dt)
+A = eng.d_action
+if name == "cheetah":       # resting on its feet: contacts from the first substep on
+    q0 = np.array([0.0, -0.1324, 0.0521, 0.0342, 0.0679, -0.0139, -0.0589, -0.14, -0.131])
+    eng.set_env_state(dict(qpos=q0, qvel=np.zeros(9)))
 g = torch.Generator(device="cuda").manual_seed(0)
-noise = 0.5 * torch.randn(P, H, 24, device="cuda", dtype=torch.float32 if dt == "f32" else torch.float64, generator=g)
-mean = torch.zeros(H, 24, device="cuda", dtype=torch.float64)
+noise = 0.5 * torch.randn(P, H, A, device="cuda", dtype=torch.float32 if dt == "f32" else torch.float64, generator=g)
+mean = torch.zeros(H, A, device="cuda", dtype=torch.float64)
 eng.rollout_device(P, H, mean, noise)
 torch.cuda.synchronize()
 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -22,5 +33,5 @@ for _ in range(3):
 e1.record()
 torch.cuda.synchronize()
 ms = e0.elapsed_time(e1) / 3
-print("%s P=%d H=%d: %.2f ms/rollout, %.2f us per wave-substep at 2048 resident waves, fails=%d"
-      % (dt, P, H, ms, ms * 1e3 * 2048 / (P * H * 2 / 2), eng.solver_failures()), flush=True)
+print("%s %s P=%d H=%d: %.2f ms/rollout, %.2f us per particle-pair substep per SIMD, fails=%d"
+      % (name, dt, P, H, ms, ms * 1e3 / (max(1.0, P / 2 / 1024) * H * raw.frame_skip), eng.solver_failures()), flush=True)
