@@ -325,14 +325,14 @@ extern "C" int mjmpc_debug_stamps(mjmpc_arm_t h, unsigned long long* out32) {
 #endif
 
 /* ---- tree engine ------------------------------------------------------------------------------------ */
-#define MJMPC_TREE_DIAG_BYTES (8 + 8 * 16)      /* failure counter, then the developer clocks of -DTREE_STATS builds */
+#define MJMPC_TREE_DIAG_BYTES (8 + 8 * 24)      /* failure counter, then the developer clocks of -DTREE_STATS builds */
 #ifdef TREE_STATS
 // developer builds only (not declared in include/mjmpc_amd.h): read and clear the phase clocks / iteration counts
-extern "C" int mjmpc_debug_tree_stats(mjmpc_tree_t h, unsigned long long* out16) {
-    if (!h || !out16) return fail(MJMPC_E_BADARG, "null argument");
+extern "C" int mjmpc_debug_tree_stats(mjmpc_tree_t h, unsigned long long* out24) {
+    if (!h || !out24) return fail(MJMPC_E_BADARG, "null argument");
     HIP_TRY(hipDeviceSynchronize());
-    HIP_TRY(hipMemcpy(out16, (char*)h->diag + 8, 8 * 16, hipMemcpyDeviceToHost));
-    HIP_TRY(hipMemset((char*)h->diag + 8, 0, 8 * 16));
+    HIP_TRY(hipMemcpy(out24, (char*)h->diag + 8, 8 * 24, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemset((char*)h->diag + 8, 0, 8 * 24));
     return 0;
 }
 #endif

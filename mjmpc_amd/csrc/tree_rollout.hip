@@ -57,12 +57,19 @@ struct TreeClock {
         t = n;
     }
     __device__ void count(int slot, unsigned v) { if (out) atomicAdd(out + slot, (unsigned long long)v); }
+    unsigned long long t2;      // a second clock for the parts of the Newton iteration (slots 12 ...): lap(-1) starts it
+    __device__ void lap(int slot) {
+        const unsigned long long n = __builtin_readcyclecounter();
+        if (out && slot >= 0) atomicAdd(out + slot, n - t2);
+        t2 = n;
+    }
 };
 #else
 struct TreeClock {
     __device__ void start(unsigned*, bool) {}
     __device__ void mark(int) {}
     __device__ void count(int, unsigned) {}
+    __device__ void lap(int) {}
 };
 #endif
 
@@ -726,6 +733,7 @@ __global__ __launch_bounds__(64 * wg_waves(DP, FRIC, sizeof(T)), min_waves(sizeo
                 bool changed = true, act_pp = false;
                 mask_t cact_pp = 0;
                 T xa = T(0);
+                clk.lap(-1);
                 for (int it = 0; it < TREE_MAXIT; ++it) {
                     T hrow[DP];
 #pragma unroll
@@ -771,8 +779,11 @@ __global__ __launch_bounds__(64 * wg_waves(DP, FRIC, sizeof(T)), min_waves(sizeo
                         }
                     }
                     TSYNC();
+                    clk.lap(12);
                     tree_factor<DP>(hrow, ELIM, ROW, l, n_rounds);
+                    clk.lap(13);
                     xa = tree_solve<DP>(hrow, rhs, ELIM, AT, ROW, VEC, l, n_rounds, depth, max_depth);
+                    clk.lap(14);
                     // f32: a row whose residual is within rounding of zero keeps its state (as in arm_rollout.hip)
                     const T resl = sig * xa - aref;
                     const T band = sizeof(T) == 4 ? T(2e-5) * (fabs(aref) + fabs(xa) + T(1)) : T(0);
@@ -787,6 +798,16 @@ __global__ __launch_bounds__(64 * wg_waves(DP, FRIC, sizeof(T)), min_waves(sizeo
                     if (__any(changed)) {
                         const bool flip = act2 != actv;
                         const unsigned nflip = __popc((unsigned)(__ballot(flip) >> (32 * half)));
+#ifdef TREE_STATS
+                        {   // what kind of change asks for another iteration (particle 0)
+                            const unsigned ncf = __popcll((unsigned long long)(cact2 ^ cact));
+                            clk.count(16, 1);
+                            clk.count(17, nflip == 1u && ncf == 0u);
+                            clk.count(18, nflip == 0u && ncf == 1u);
+                            clk.count(19, nflip + ncf > 1u);
+                            clk.count(20, nflip == 0u && ncf == 0u);     // only the other particle of the wave changed
+                        }
+#endif
                         if (!__any(cact2 != cact || nflip > 1u)) {
                             const T zl = tree_solve<DP>(hrow, flip ? T(1) : T(0), ELIM, AT, ROW, VEC, l, n_rounds, depth, max_depth);
                             if (flip) {
@@ -819,6 +840,7 @@ __global__ __launch_bounds__(64 * wg_waves(DP, FRIC, sizeof(T)), min_waves(sizeo
                     actv = act2;
                     cact = cact2;
                     clk.count(11, 1);
+                    clk.lap(15);
                     if (!__any(changed)) break;
                 }
                 if (changed && diag) atomicAdd(diag, 1u);

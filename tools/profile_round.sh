@@ -16,5 +16,10 @@ rocprofv3 --kernel-trace --pmc SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/${TAG}_pmcF -o f -- python3 tools/pmc_run.py 4096 f64 > $OUT/${TAG}_pmcF.log 2>&1
 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/${TAG}_pmcW -o w -- python3 tools/pmc_run.py 4096 f64 > $OUT/${TAG}_pmcW.log 2>&1
 python3 tools/pmc_summarize.py $TAG $OUT > $OUT/${TAG}_pmc_summary.txt 2>&1
+# 4. the other configurations (arm: cfg1 / cfg3 / cfg4*, tree engine: locomotion + the 24-dof hand), and the tree kernel under rocprof
+for DT in f64 f32; do
+  python3 tools/bench_configs.py --steps 60 --dtype $DT > $OUT/${TAG}_other_configs_$DT.jsonl 2> $OUT/${TAG}_other_configs_$DT.err
+done
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/${TAG}_prof_tree -o ${TAG}_tree -- python3 tools/bench_configs.py --only-tree --dtype f64 > $OUT/${TAG}_tree_under_rocprof.jsonl 2> $OUT/${TAG}_prof_tree.err
 find $OUT -name "*.csv" -size +20M -delete
 ls $OUT | grep $TAG

@@ -42,7 +42,7 @@ if __name__ == "__main__":
     g = torch.Generator(device="cuda").manual_seed(0)
     noise = 0.5 * torch.randn(P, H, A, device="cuda", dtype=torch.float32 if dt == "f32" else torch.float64, generator=g)
     mean = torch.zeros(H, A, device="cuda", dtype=torch.float64)
-    out = (ctypes.c_ulonglong * 16)()
+    out = (ctypes.c_ulonglong * 24)()
     eng.rollout_device(P, H, mean, noise)
     lib.mjmpc_debug_tree_stats(eng._h, out)
     eng.rollout_device(P, H, mean, noise)
@@ -54,5 +54,10 @@ if __name__ == "__main__":
     for i, nm in enumerate(NAMES):
         if nm != "-":
             print("  %-45s %8.0f cycles/substep  %5.1f %%" % (nm, v[i] / nsub, 100.0 * v[i] / tot))
+    ni = max(v[11], 1)
+    print("  per Newton iteration: assemble H %.0f, factor %.0f, solve %.0f, next active set (+ rank-one correction) %.0f cycles"
+          % (v[12] / ni, v[13] / ni, v[14] / ni, v[15] / ni))
+    print("  iterations that found a changed set: %d - one limit row %d, one contact row %d, several rows %d, only the wave's other particle %d"
+          % (v[16], v[17], v[18], v[19], v[20]))
     print("  total %.0f cycles/substep; contact points per substep %.2f; substeps with rows %.0f %%; Newton iterations per such substep %.2f"
           % (tot / nsub, v[9] / nsub, 100.0 * v[10] / nsub, v[11] / max(v[10], 1)))
