@@ -412,11 +412,11 @@ int mjmpc_tree_rollout(mjmpc_tree_t h, int dtype, int64_t P, int H, const double
     hipStream_t s = (hipStream_t)stream;
     hipError_t e;
     if (dtype == MJMPC_F32)
-        e = mjmpc::launch_tree_rollout<float>(h->model_f32, h->max_path, h->full, h->state, (long)P, H, h->nu, d_mean,
+        e = mjmpc::launch_tree_rollout<float>(h->model_f32, h->max_path, h->full, h->nv, h->state, (long)P, H, h->nu, d_mean,
                                               (const float*)d_noise, (float*)d_costs, (float*)d_actions, (float*)d_obs,
                                               (float*)d_next_obs, h->diag, s);
     else if (dtype == MJMPC_F64)
-        e = mjmpc::launch_tree_rollout<double>(h->model_f64, h->max_path, h->full, h->state, (long)P, H, h->nu, d_mean,
+        e = mjmpc::launch_tree_rollout<double>(h->model_f64, h->max_path, h->full, h->nv, h->state, (long)P, H, h->nu, d_mean,
                                                (const double*)d_noise, (double*)d_costs, (double*)d_actions,
                                                (double*)d_obs, (double*)d_next_obs, h->diag, s);
     else

@@ -73,8 +73,8 @@ struct TreeClock {
 };
 #endif
 
-constexpr int wg_waves(int DP, bool fric, int scalar_bytes = 8) {
-    return DP <= 8 ? 4 : (DP <= 16 ? 2 : 1);
+constexpr int wg_waves(int DP, bool fric, int scalar_bytes = 8, int PL = 32) {
+    return DP <= 8 ? 4 : (DP <= 16 ? (PL == 16 && scalar_bytes == 4 ? 4 : 2) : 1);
 }
 
 #define TSYNC()                                                \
@@ -86,20 +86,20 @@ constexpr int wg_waves(int DP, bool fric, int scalar_bytes = 8) {
 
 // per-particle LDS area, in scalars (DP = compile-time bound on the links of a root-to-leaf path)
 constexpr int A_X = 0;                      // 12 x 32 exchange (kinematics, path sums, doubling tables)
-constexpr int A_SF = A_X + 6 * TL;          // S[6][32], beside the first half of the exchange area (used apart from it)
+constexpr int a_sf(int PL) { return A_X + 6 * PL; }     // S[6][PL], beside the first half of the exchange area (used apart from it)
 constexpr int A_ROW = 0;                    // path-indexed rows [32][row_stride]; overlays A_X / A_SF
 // row stride: 2 DP entries (so that dist + c never leaves the row) + 1, an odd number of
 // doubles: 32 lanes reading 32 different rows at the same offset then hit 32 different bank pairs (a stride of 16
 // doubles = 128 B put them on two: measured 16-way conflicts)
 constexpr int row_stride(int DP) { return 2 * DP + 1; }
-constexpr int a_vec(int DP) { return (row_stride(DP) * TL > 12 * TL ? row_stride(DP) * TL : 12 * TL) + 3 & ~3; }   // broadcast vector [32]
+constexpr int a_vec(int DP, int PL) { return (row_stride(DP) * PL > 12 * PL ? row_stride(DP) * PL : 12 * PL) + 3 & ~3; }   // broadcast vector [PL]
 // contact Jacobian rows [NS][NJ][DP], PATH-INDEXED like the matrix rows: a contact point on link L moves only with the
 // dofs on L's path to the root, entry c belongs to L's ancestor at distance c (a quarter of a [32]-lane row at DP = 8)
-constexpr int a_jc(int DP) { return a_vec(DP) + TL; }
+constexpr int a_jc(int DP, int PL) { return a_vec(DP, PL) + PL; }
 constexpr int CS = 12;      // per contact point: centre[3], dist, D, aref (normal part), mu B Jt1.v, mu B Jt2.v, axis[3]
-constexpr int a_cs(int DP, int NS, int NJ) { return a_jc(DP) + NS * NJ * DP; }
-constexpr int a_misc(int DP, int NS, int NJ) { return a_cs(DP, NS, NJ) + NS * CS; }   // site[3]
-constexpr int a_len(int DP, int NS, int NJ) { return a_misc(DP, NS, NJ) + 8; }
+constexpr int a_cs(int DP, int NS, int NJ, int PL) { return a_jc(DP, PL) + NS * NJ * DP; }
+constexpr int a_misc(int DP, int NS, int NJ, int PL) { return a_cs(DP, NS, NJ, PL) + NS * CS; }   // site[3]
+constexpr int a_len(int DP, int NS, int NJ, int PL) { return a_misc(DP, NS, NJ, PL) + 8; }
 
 template <typename T>
 __device__ __forceinline__ void cross3(const T* a, const T* b, T* c) {
@@ -135,13 +135,13 @@ __device__ __forceinline__ double add_rows(double x) {
 }
 // sum over the 32 lanes of a particle, result in every lane: four DPP steps inside the 16-lane rows and one row swap
 // (no LDS crossbar: a ds_bpermute butterfly costs five times as much)
-template <typename T>
-__device__ __forceinline__ T sum32(T x) {
+template <int PL, typename T>
+__device__ __forceinline__ T sum_lanes(T x) {
     x += dpp_all<0xB1>(x);          // quad_perm [1,0,3,2]
     x += dpp_all<0x4E>(x);          // quad_perm [2,3,0,1]
     x += dpp_all<0x141>(x);         // row_half_mirror: i <-> 7 - i
     x += dpp_all<0x140>(x);         // row_mirror: i <-> 15 - i
-    return add_rows(x);
+    return PL == 32 ? add_rows(x) : x;      // (16 lanes per particle: a particle is one DPP row)
 }
 
 struct Topo {       // my link's place in the tree (registers)
@@ -152,18 +152,18 @@ struct Topo {       // my link's place in the tree (registers)
 };
 
 // x[c] <- sum over my path to the root (myself included) of x[c]: pointer jumping
-template <int NC, int DP, typename T>
+template <int NC, int DP, int PL, typename T>
 __device__ __forceinline__ void path_sum(T* x, const Topo& tp, T* X, int l) {
 #pragma unroll
     for (int k = 0; k < 5; ++k) {
         if (k >= tp.jumps) break;
 #pragma unroll
-        for (int c = 0; c < NC; ++c) X[c * TL + l] = x[c];
+        for (int c = 0; c < NC; ++c) X[c * PL + l] = x[c];
         TSYNC();
         const int a = tp.anc[k];
         if (a >= 0) {
 #pragma unroll
-            for (int c = 0; c < NC; ++c) x[c] += X[c * TL + a];
+            for (int c = 0; c < NC; ++c) x[c] += X[c * PL + a];
         }
         TSYNC();
     }
@@ -171,29 +171,30 @@ __device__ __forceinline__ void path_sum(T* x, const Topo& tp, T* X, int l) {
 
 // x[c] <- sum over my subtree (myself included) of x[c]; subtree = links [l, l + subsize): doubling tables in two
 // LDS buffers of NC x 32, the blocks of sizes 2^k that tile the range are added as the tables appear
-template <int NC, typename T>
+template <int NC, int PL, typename T>
 __device__ __forceinline__ void subtree_sum(T* x, const Topo& tp, T* X, int l) {
-    static_assert(NC <= 6, "two buffers of NC x 32 must fit the 12 x 32 exchange area");
+    static_assert(NC <= 6, "two buffers of NC x PL must fit the 12 x PL exchange area");
+    constexpr int LOG = PL == 32 ? 5 : 4;
     T cur[NC], acc[NC];
 #pragma unroll
     for (int c = 0; c < NC; ++c) { cur[c] = x[c]; acc[c] = T(0); }
     int pos = l;
 #pragma unroll
-    for (int k = 0; k < 6; ++k) {
-        T* buf = X + (k & 1) * NC * TL;
+    for (int k = 0; k <= LOG; ++k) {
+        T* buf = X + (k & 1) * NC * PL;
 #pragma unroll
-        for (int c = 0; c < NC; ++c) buf[c * TL + l] = cur[c];      // T_k[l]
+        for (int c = 0; c < NC; ++c) buf[c * PL + l] = cur[c];      // T_k[l]
         TSYNC();
         if ((tp.subsize >> k) & 1) {
 #pragma unroll
-            for (int c = 0; c < NC; ++c) acc[c] += buf[c * TL + pos];
+            for (int c = 0; c < NC; ++c) acc[c] += buf[c * PL + pos];
             pos += 1 << k;
         }
-        if (k < 5) {
+        if (k < LOG) {
             const int nb = l + (1 << k);
-            if (nb < TL) {
+            if (nb < PL) {
 #pragma unroll
-                for (int c = 0; c < NC; ++c) cur[c] += buf[c * TL + nb];   // T_{k+1}[l] = T_k[l] + T_k[l + 2^k]
+                for (int c = 0; c < NC; ++c) cur[c] += buf[c * PL + nb];   // T_{k+1}[l] = T_k[l] + T_k[l + 2^k]
             }
         }
     }
@@ -232,7 +233,7 @@ __device__ __forceinline__ void tree_row_params(const T* sol, T r, T diag_approx
 // k | dist << 8 | height << 16, -1 ends it):  r[c] -= (r_k[dist] / r_k[0]) r_k[dist + c].  Rows are 2 DP (+1) long
 // so that dist + c never leaves the row; what is read past a row's own path (dist + c > depth of k) only ever
 // lands in entries of r past MY path (c > my depth), which nothing consumes; slot 2 DP carries 1 / D_k.
-template <int DP, typename T>
+template <int DP, int PL, typename T>
 __device__ __forceinline__ void tree_factor(T* r, const int* ELIM, T* ROW, int l, int n_rounds) {
     int e = 0, ent = ELIM[l];
     for (int hgt = 0; hgt + 1 < n_rounds; ++hgt) {     // (the last round holds roots only: nobody to update)
@@ -248,7 +249,7 @@ __device__ __forceinline__ void tree_factor(T* r, const int* ELIM, T* ROW, int l
 #pragma unroll
                 for (int c = 0; c < DP; ++c) r[c] -= f * rk[a + c];
                 ++e;
-                ent = e < TL - 1 ? ELIM[e * TL + l] : -1;
+                ent = e < PL - 1 ? ELIM[e * PL + l] : -1;
             }
         }
         TSYNC();
@@ -262,7 +263,7 @@ __device__ __forceinline__ void tree_factor(T* r, const int* ELIM, T* ROW, int l
 }
 
 // x <- (L' D L)^-1 b, one entry per lane; ROW holds the factor (tree_factor), AT[c * 32 + l] = my ancestor at distance c
-template <int DP, typename T>
+template <int DP, int PL, typename T>
 __device__ __forceinline__ T tree_solve(const T* r, T b, const int* ELIM, const int* AT, const T* ROW, T* VEC, int l,
                                         int n_rounds, int depth, int max_depth) {
     // L' w = b, leaves first:  w_i = b_i - sum over descendants k of L[k][i] w_k
@@ -275,7 +276,7 @@ __device__ __forceinline__ T tree_solve(const T* r, T b, const int* ELIM, const 
                 const int k = ent & 255, a = (ent >> 8) & 255;
                 b -= ROW[k * row_stride(DP) + a] * VEC[k];
                 ++e;
-                ent = e < TL - 1 ? ELIM[e * TL + l] : -1;
+                ent = e < PL - 1 ? ELIM[e * PL + l] : -1;
             }
         }
         TSYNC();
@@ -287,7 +288,7 @@ __device__ __forceinline__ T tree_solve(const T* r, T b, const int* ELIM, const 
         TSYNC();
         if (depth > dl) {
             const int c = depth - dl;
-            b -= ROW[l * row_stride(DP) + c] * VEC[AT[c * TL + l]];
+            b -= ROW[l * row_stride(DP) + c] * VEC[AT[c * PL + l]];
         }
         TSYNC();
     }
@@ -298,43 +299,47 @@ __device__ __forceinline__ T tree_solve(const T* r, T b, const int* ELIM, const 
 // workgroups' LDS on a CU
 constexpr int min_waves(int scalar_bytes, int DP, bool fric) { return (DP <= 8 && !fric) ? (scalar_bytes == 4 ? 3 : 2) : 1; }
 
-template <typename T, int DP, int NS, bool FRIC>
-__global__ __launch_bounds__(64 * wg_waves(DP, FRIC, sizeof(T)), min_waves(sizeof(T), DP, FRIC)) void tree_rollout_kernel(
+// PL = lanes per particle: 32, or 16 for models of up to 16 dofs (four particles per wavefront, a particle = one DPP row)
+template <typename T, int DP, int NS, bool FRIC, int PL>
+__global__ __launch_bounds__(64 * wg_waves(DP, FRIC, sizeof(T), PL), min_waves(sizeof(T), DP, FRIC)) void tree_rollout_kernel(
     const T* __restrict__ model, const double* __restrict__ state, long P, int H, int A, const double* __restrict__ mean,
     const T* __restrict__ noise, T* __restrict__ cost, T* __restrict__ act, T* __restrict__ obs, T* __restrict__ nobs,
     unsigned* diag) {
-    constexpr int WG_WAVES = wg_waves(DP, FRIC, sizeof(T));
+    constexpr int WG_WAVES = wg_waves(DP, FRIC, sizeof(T), PL);
+    constexpr int PPW = 64 / PL;            // particles per wavefront
+    constexpr int A_SF = a_sf(PL);
+    static_assert(DP <= PL && NS <= PL, "a path / the contact points must fit the lanes of a particle");
     constexpr int NJ = FRIC ? 3 : 1;        // Jacobian rows kept per contact point: normal (+ two tangents)
     constexpr int NR = FRIC ? 4 : 1;        // constraint rows per contact point: Jn (+- mu Jt_k)
     typedef typename std::conditional<FRIC, unsigned long long, unsigned>::type mask_t;    // NR bits per contact point
-    constexpr int A_VEC = a_vec(DP), A_JC = a_jc(DP), A_CS = a_cs(DP, NS, NJ), A_MISC = a_misc(DP, NS, NJ),
-                  A_LEN = a_len(DP, NS, NJ);
+    constexpr int A_VEC = a_vec(DP, PL), A_JC = a_jc(DP, PL), A_CS = a_cs(DP, NS, NJ, PL), A_MISC = a_misc(DP, NS, NJ, PL),
+                  A_LEN = a_len(DP, NS, NJ, PL);
     constexpr int NBLOB = T_DEPTH;          // the scalar part of the block; the topology tables go to integer LDS
-    __shared__ __attribute__((aligned(16))) T lds[NBLOB + 1 + 2 * WG_WAVES * A_LEN];
-    __shared__ int ELIM[(TL - 1) * TL];     // elimination lists
-    __shared__ int AT[DP * TL];             // AT[c * 32 + l] = ancestor of link l at distance c (-1 beyond the root)
+    __shared__ __attribute__((aligned(16))) T lds[NBLOB + 1 + PPW * WG_WAVES * A_LEN];
+    __shared__ int ELIM[(PL - 1) * PL];     // elimination lists
+    __shared__ int AT[DP * PL];             // AT[c * PL + l] = ancestor of link l at distance c (-1 beyond the root)
     T* M = lds;
     for (int k = threadIdx.x; k < NBLOB; k += blockDim.x) M[k] = model[k];
-    for (int k = threadIdx.x; k < (TL - 1) * TL; k += blockDim.x) ELIM[k] = (int)model[T_ELIM + k];
-    for (int k = threadIdx.x; k < 2 * WG_WAVES * A_LEN; k += blockDim.x) lds[NBLOB + 1 + k] = T(0);
-    if (threadIdx.x < TL) {
+    for (int k = threadIdx.x; k < (PL - 1) * PL; k += blockDim.x) ELIM[k] = (int)model[T_ELIM + (k / PL) * TL + (k % PL)];
+    for (int k = threadIdx.x; k < PPW * WG_WAVES * A_LEN; k += blockDim.x) lds[NBLOB + 1 + k] = T(0);
+    if (threadIdx.x < PL) {
         int a = threadIdx.x;
         for (int c = 0; c < DP; ++c) {
-            AT[c * TL + threadIdx.x] = a;
+            AT[c * PL + threadIdx.x] = a;
             a = a >= 0 ? (int)model[T_PARENT + a] : -1;
         }
     }
     __syncthreads();
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int l = lane & 31, half = lane >> 5;
-    const long pid = ((long)blockIdx.x * WG_WAVES + wave) * 2 + half;
+    const int l = lane & (PL - 1), half = lane / PL;        // `half`: which particle of the wavefront (0 .. PPW - 1)
+    const long pid = ((long)blockIdx.x * WG_WAVES + wave) * PPW + half;
     const bool live = pid < P;
-    T* X = lds + NBLOB + 1 + (wave * 2 + half) * A_LEN;
+    T* X = lds + NBLOB + 1 + (wave * PPW + half) * A_LEN;
     T* ROW = X + A_ROW;
     T* VEC = X + A_VEC;
     const int n_rounds = __builtin_amdgcn_readfirstlane((int)model[T_N_ROUNDS]), depth = (int)model[T_DEPTH + l];
     int max_depth = 0;
-    for (int c = 0; c < DP; ++c) max_depth += __any(AT[c * TL + l] >= 0) ? 1 : 0;     // links on the longest path
+    for (int c = 0; c < DP; ++c) max_depth += __any(AT[c * PL + l] >= 0) ? 1 : 0;     // links on the longest path
     // model-wide integers: the same in every lane, kept in scalar registers
     const int nv = __builtin_amdgcn_readfirstlane((int)M[T_NV]), frame_skip = __builtin_amdgcn_readfirstlane((int)M[T_FRAME_SKIP]);
     const int site_link = __builtin_amdgcn_readfirstlane((int)M[T_SITE_LINK]);
@@ -349,7 +354,7 @@ __global__ __launch_bounds__(64 * wg_waves(DP, FRIC, sizeof(T)), min_waves(sizeo
     tp.parent = (int)M[T_PARENT + l];
     tp.subsize = (int)M[T_SUBSIZE + l];
 #pragma unroll
-    for (int k = 0; k < 5; ++k) tp.anc[k] = (1 << k) < DP ? AT[(1 << k) * TL + l] : -1;
+    for (int k = 0; k < 5; ++k) tp.anc[k] = (1 << k) < DP ? AT[(1 << k) * PL + l] : -1;
     tp.jumps = __builtin_amdgcn_readfirstlane((int)M[T_JUMPS]);
     tp.ancmask = (unsigned)M[T_ANCMASK + l] | ((unsigned)M[T_ANCMASK + TL + l] << 16);
     const bool dof = l < nv;
@@ -377,7 +382,7 @@ __global__ __launch_bounds__(64 * wg_waves(DP, FRIC, sizeof(T)), min_waves(sizeo
             if (act && live) act[(pid * H + t) * A + l] = u;        // unclipped (gym_env_wrapper.py:151)
         }
         // lane a holds action a; the dof it drives picks it up (motors may sit on any subset of the joints)
-        const T u_dof = __shfl(u, act_id >= 0 ? act_id : 0, TL);
+        const T u_dof = __shfl(u, act_id >= 0 ? act_id : 0, PL);
         const T tau_act = act_id >= 0 ? M[T_GEAR + l] * fmin(fmax(u_dof, M[T_CTRL_LO + l]), M[T_CTRL_HI + l]) : T(0);
         if (task == 1 && l == 0) X[A_MISC + 4] = q;        // qpos[0] when the env step starts
         T hand[3] = {T(0), T(0), T(0)};
@@ -406,17 +411,17 @@ __global__ __launch_bounds__(64 * wg_waves(DP, FRIC, sizeof(T)), min_waves(sizeo
             for (int k = 0; k < 5; ++k) {
                 if (k >= tp.jumps) break;
 #pragma unroll
-                for (int c = 0; c < 9; ++c) X[c * TL + l] = R[c];
+                for (int c = 0; c < 9; ++c) X[c * PL + l] = R[c];
 #pragma unroll
-                for (int c = 0; c < 3; ++c) X[(9 + c) * TL + l] = p[c];
+                for (int c = 0; c < 3; ++c) X[(9 + c) * PL + l] = p[c];
                 TSYNC();
                 const int a = tp.anc[k];
                 if (a >= 0) {
                     T Ra[9], pa[3], Rn[9], tv[3];
 #pragma unroll
-                    for (int c = 0; c < 9; ++c) Ra[c] = X[c * TL + a];
+                    for (int c = 0; c < 9; ++c) Ra[c] = X[c * PL + a];
 #pragma unroll
-                    for (int c = 0; c < 3; ++c) pa[c] = X[(9 + c) * TL + a];
+                    for (int c = 0; c < 3; ++c) pa[c] = X[(9 + c) * PL + a];
                     for (int i = 0; i < 3; ++i)
                         for (int j = 0; j < 3; ++j)
                             Rn[3 * i + j] = Ra[3 * i] * R[j] + Ra[3 * i + 1] * R[3 + j] + Ra[3 * i + 2] * R[6 + j];
@@ -439,18 +444,18 @@ __global__ __launch_bounds__(64 * wg_waves(DP, FRIC, sizeof(T)), min_waves(sizeo
             if (n_sphere > 0) {
                 bool ci_mine = false;
 #pragma unroll
-                for (int c = 0; c < 9; ++c) X[c * TL + l] = R[c];
+                for (int c = 0; c < 9; ++c) X[c * PL + l] = R[c];
 #pragma unroll
-                for (int c = 0; c < 3; ++c) X[(9 + c) * TL + l] = p[c];
+                for (int c = 0; c < 3; ++c) X[(9 + c) * PL + l] = p[c];
                 TSYNC();
                 if (l < n_sphere) {
                     const T* sp = M + T_SPH + l * TREE_SPH_STRIDE;
                     const int sl = (int)sp[0];
                     T Rl[9], ctr[3], tv[3];
 #pragma unroll
-                    for (int c = 0; c < 9; ++c) Rl[c] = X[c * TL + sl];
+                    for (int c = 0; c < 9; ++c) Rl[c] = X[c * PL + sl];
                     mv3(Rl, sp + 1, tv);
-                    for (int k = 0; k < 3; ++k) ctr[k] = X[(9 + k) * TL + sl] + tv[k];
+                    for (int k = 0; k < 3; ++k) ctr[k] = X[(9 + k) * PL + sl] + tv[k];
                     T* cs = X + A_CS + l * CS;
                     for (int k = 0; k < 3; ++k) cs[k] = ctr[k];
                     const T cdist = dot3(ctr, pn) - M[T_PLANE_D] - sp[4];
@@ -462,8 +467,9 @@ __global__ __launch_bounds__(64 * wg_waves(DP, FRIC, sizeof(T)), min_waves(sizeo
                     }
                 }
                 const unsigned long long b = __ballot(ci_mine);
-                cinst = (unsigned)(b >> (32 * half));
+                cinst = (unsigned)(b >> (PL * half)) & (PL == 32 ? ~0u : 0xFFFFu);
                 ucinst = (unsigned)b | (unsigned)(b >> 32);
+                if (PL == 16) ucinst = (ucinst | (ucinst >> 16)) & 0xFFFFu;
             }
             TSYNC();
             if (sub == frame_skip - 1 || (t == 0 && sub == 0))
@@ -511,13 +517,13 @@ __global__ __launch_bounds__(64 * wg_waves(DP, FRIC, sizeof(T)), min_waves(sizeo
                 T V[6], Ac[6];
                 for (int k = 0; k < 3; ++k) { V[k] = sw[k] * v; V[3 + k] = sv[k] * v; }
                 T xw[3] = {V[0], V[1], V[2]}, xv[3] = {V[3], V[4], V[5]};
-                path_sum<6, DP>(V, tp, X, l);
+                path_sum<6, DP, PL>(V, tp, X, l);
                 T dw[3], d1[3], d2[3];
                 cross3(V, xw, dw);
                 cross3(V, xv, d1);
                 cross3(V + 3, xw, d2);
                 for (int k = 0; k < 3; ++k) { Ac[k] = dw[k]; Ac[3 + k] = d1[k] + d2[k]; }
-                path_sum<6, DP>(Ac, tp, X, l);
+                path_sum<6, DP, PL>(Ac, tp, X, l);
                 for (int k = 0; k < 3; ++k) Ac[3 + k] -= M[T_GRAVITY + k];          // base acceleration -g
                 // f = I A + V x* (I V),  I(w, v) = (Ib w + h x v, m v - h x w)
                 T nV[3], fV[3], nA[3], fA[3], t1[3], t2[3], c1[3], c2[3], c3[3], f[6];
@@ -566,7 +572,7 @@ __global__ __launch_bounds__(64 * wg_waves(DP, FRIC, sizeof(T)), min_waves(sizeo
                     if (mass > T(0))
                         for (int k = 0; k < 3; ++k) { f[k] -= wt[k] + t3[k]; f[3 + k] -= wf[k]; }
                 }
-                subtree_sum<6>(f, tp, X, l);
+                subtree_sum<6, PL>(f, tp, X, l);
                 bias = dot3(sw, f) + dot3(sv, f + 3);
             }
 
@@ -576,23 +582,23 @@ __global__ __launch_bounds__(64 * wg_waves(DP, FRIC, sizeof(T)), min_waves(sizeo
             T mrow[DP];
             {
                 T c6[6] = {Ib[0], Ib[1], Ib[2], Ib[3], Ib[4], Ib[5]}, c4[4] = {mass, hm[0], hm[1], hm[2]};
-                subtree_sum<6>(c6, tp, X, l);
-                subtree_sum<4>(c4, tp, X, l);
+                subtree_sum<6, PL>(c6, tp, X, l);
+                subtree_sum<4, PL>(c4, tp, X, l);
                 T F[6], t1[3], t2[3];
                 symv3(c6, sw, F);
                 cross3(c4 + 1, sv, t1);
                 cross3(c4 + 1, sw, t2);
                 for (int k = 0; k < 3; ++k) { F[k] += t1[k]; F[3 + k] = c4[0] * sv[k] - t2[k]; }
                 T* S_ = X + A_SF;
-                for (int k = 0; k < 3; ++k) { S_[k * TL + l] = sw[k]; S_[(3 + k) * TL + l] = sv[k]; }
+                for (int k = 0; k < 3; ++k) { S_[k * PL + l] = sw[k]; S_[(3 + k) * PL + l] = sv[k]; }
                 TSYNC();
 #pragma unroll
                 for (int c = 0; c < DP; ++c) {
-                    const int an = AT[c * TL + l];
+                    const int an = AT[c * PL + l];
                     T sacc = T(0);
                     if (an >= 0) {
 #pragma unroll
-                        for (int k = 0; k < 6; ++k) sacc += S_[k * TL + an] * F[k];
+                        for (int k = 0; k < 6; ++k) sacc += S_[k * PL + an] * F[k];
                     }
                     mrow[c] = sacc;
                 }
@@ -619,7 +625,7 @@ __global__ __launch_bounds__(64 * wg_waves(DP, FRIC, sizeof(T)), min_waves(sizeo
             auto own_idx = [&](int s) -> int {
                 const T* sp = M + T_SPH + s * TREE_SPH_STRIDE;
                 const int idx = (int)sp[11] - depth;
-                return (((cinst >> s) & 1u) && dof && idx >= 0 && AT[idx * TL + (int)sp[0]] == l) ? idx : -1;
+                return (((cinst >> s) & 1u) && dof && idx >= 0 && AT[idx * PL + (int)sp[0]] == l) ? idx : -1;
             };
             for (unsigned um = ucinst; um; um &= um - 1) {
                 const int s = __builtin_ctz(um);
@@ -638,7 +644,7 @@ __global__ __launch_bounds__(64 * wg_waves(DP, FRIC, sizeof(T)), min_waves(sizeo
                 const T jc = oi >= 0 ? dot3(pn, g) : T(0);
                 if (oi >= 0) jrow[oi] = jc;
                 if (ci && l > dsl && l < DP) jrow[l] = T(0);        // past the root: read by shorter paths' lanes
-                const T jv = sum32(jc * v);
+                const T jv = sum_lanes<PL>(jc * v);
                 const T mu = FRIC ? sp[7] : T(0);
                 T Dc, arc, mb1 = T(0), mb2 = T(0);
                 if (FRIC) {
@@ -659,8 +665,8 @@ __global__ __launch_bounds__(64 * wg_waves(DP, FRIC, sizeof(T)), min_waves(sizeo
                     const T j1 = fr ? dot3(t1, g) : T(0), j2 = fr ? dot3(t2, g) : T(0);
                     if (oi >= 0) { jrow[DP + oi] = j1; jrow[2 * DP + oi] = j2; }
                     if (ci && l > dsl && l < DP) { jrow[DP + l] = T(0); jrow[2 * DP + l] = T(0); }
-                    mb1 = mu * M[T_SOL_B] * sum32(j1 * v);
-                    mb2 = mu * M[T_SOL_B] * sum32(j2 * v);
+                    mb1 = mu * M[T_SOL_B] * sum_lanes<PL>(j1 * v);
+                    mb2 = mu * M[T_SOL_B] * sum_lanes<PL>(j2 * v);
                 }
                 tree_row_params(M + T_SOL_K, cdist - sp[5], sp[6] * (T(1) + mu * mu), jv, Dc, arc);
                 if (mu > T(0)) Dc *= T(0.5) * rcp_(mu * mu);
@@ -688,12 +694,12 @@ __global__ __launch_bounds__(64 * wg_waves(DP, FRIC, sizeof(T)), min_waves(sizeo
                     const T* cs = X + A_CS + s * CS;
                     const T* jrow = X + A_JC + s * NJ * DP;
                     const int oi = own_idx(s);
-                    const T an = sum32(oi >= 0 ? jrow[oi] * xa_ : T(0));
+                    const T an = sum_lanes<PL>(oi >= 0 ? jrow[oi] * xa_ : T(0));
                     res[0] = an - cs[5];
                     if (FRIC) {
                         const T mu = M[T_SPH + s * TREE_SPH_STRIDE + 7];
-                        const T a1 = mu * sum32(oi >= 0 ? jrow[DP + oi] * xa_ : T(0));
-                        const T a2 = mu * sum32(oi >= 0 ? jrow[2 * DP + oi] * xa_ : T(0));
+                        const T a1 = mu * sum_lanes<PL>(oi >= 0 ? jrow[DP + oi] * xa_ : T(0));
+                        const T a2 = mu * sum_lanes<PL>(oi >= 0 ? jrow[2 * DP + oi] * xa_ : T(0));
                         res[0] = an + a1 - (cs[5] - cs[6]);
                         res[1 % NR] = an - a1 - (cs[5] + cs[6]);
                         res[2 % NR] = an + a2 - (cs[5] - cs[7]);
@@ -780,9 +786,9 @@ __global__ __launch_bounds__(64 * wg_waves(DP, FRIC, sizeof(T)), min_waves(sizeo
                     }
                     TSYNC();
                     clk.lap(12);
-                    tree_factor<DP>(hrow, ELIM, ROW, l, n_rounds);
+                    tree_factor<DP, PL>(hrow, ELIM, ROW, l, n_rounds);
                     clk.lap(13);
-                    xa = tree_solve<DP>(hrow, rhs, ELIM, AT, ROW, VEC, l, n_rounds, depth, max_depth);
+                    xa = tree_solve<DP, PL>(hrow, rhs, ELIM, AT, ROW, VEC, l, n_rounds, depth, max_depth);
                     clk.lap(14);
                     // f32: a row whose residual is within rounding of zero keeps its state (as in arm_rollout.hip)
                     const T resl = sig * xa - aref;
@@ -797,7 +803,7 @@ __global__ __launch_bounds__(64 * wg_waves(DP, FRIC, sizeof(T)), min_waves(sizeo
                     // contact-row flip take the general path (next iteration refactors).
                     if (__any(changed)) {
                         const bool flip = act2 != actv;
-                        const unsigned nflip = __popc((unsigned)(__ballot(flip) >> (32 * half)));
+                        const unsigned nflip = __popc((unsigned)(__ballot(flip) >> (PL * half)) & (PL == 32 ? ~0u : 0xFFFFu));
 #ifdef TREE_STATS
                         {   // what kind of change asks for another iteration (particle 0)
                             const unsigned ncf = __popcll((unsigned long long)(cact2 ^ cact));
@@ -809,7 +815,7 @@ __global__ __launch_bounds__(64 * wg_waves(DP, FRIC, sizeof(T)), min_waves(sizeo
                         }
 #endif
                         if (!__any(cact2 != cact || nflip > 1u)) {
-                            const T zl = tree_solve<DP>(hrow, flip ? T(1) : T(0), ELIM, AT, ROW, VEC, l, n_rounds, depth, max_depth);
+                            const T zl = tree_solve<DP, PL>(hrow, flip ? T(1) : T(0), ELIM, AT, ROW, VEC, l, n_rounds, depth, max_depth);
                             if (flip) {
                                 const T c = act2 ? D : -D;
                                 VEC[0] = c;
@@ -885,8 +891,8 @@ __global__ __launch_bounds__(64 * wg_waves(DP, FRIC, sizeof(T)), min_waves(sizeo
                 if (TREE_SKIP & 2) {
                     qacc = (tau + qfrc_c) * rcp_(mrow[0]);
                 } else {
-                    tree_factor<DP>(mrow, ELIM, ROW, l, n_rounds);
-                    qacc = tree_solve<DP>(mrow, tau + qfrc_c, ELIM, AT, ROW, VEC, l, n_rounds, depth, max_depth);
+                    tree_factor<DP, PL>(mrow, ELIM, ROW, l, n_rounds);
+                    qacc = tree_solve<DP, PL>(mrow, tau + qfrc_c, ELIM, AT, ROW, VEC, l, n_rounds, depth, max_depth);
                 }
             }
             clk.mark(5);
@@ -910,8 +916,8 @@ __global__ __launch_bounds__(64 * wg_waves(DP, FRIC, sizeof(T)), min_waves(sizeo
         if (task == 1) {
             // reward = forward progress of qpos[0] over the env step / dt - c |a|^2, the action as given
             // (swimmer.py:10-19, half_cheetah.py:10-19)
-            const T usq = sum32(has_u ? u * u : T(0));
-            cst = M[T_CTRL_COST] * usq - (__shfl(q, 0, TL) - X[A_MISC + 4]) * rcp_(h * T(frame_skip));
+            const T usq = sum_lanes<PL>(has_u ? u * u : T(0));
+            cst = M[T_CTRL_COST] * usq - (__shfl(q, 0, PL) - X[A_MISC + 4]) * rcp_(h * T(frame_skip));
         } else {
             // reward = -(|h-g|_1 + 5 |h-g|_2), h = site position lagging one substep (reacher_env.py:31-35)
             const T dx = hand[0] - tgt[0], dy = hand[1] - tgt[1], dz = hand[2] - tgt[2];
@@ -948,32 +954,39 @@ __global__ __launch_bounds__(64 * wg_waves(DP, FRIC, sizeof(T)), min_waves(sizeo
 }  // namespace
 
 template <typename T>
-hipError_t launch_tree_rollout(const T* model, int max_path, bool full, const double* state, long P, int H,
+hipError_t launch_tree_rollout(const T* model, int max_path, bool full, int nv, const double* state, long P, int H,
                                int A, const double* mean, const T* noise, T* cost, T* act, T* obs, T* nobs, unsigned* diag,
                                hipStream_t stream) {
     if (P <= 0 || H <= 0) return hipSuccess;
-#define MJMPC_TREE_LAUNCH(DP_, NS_, FR_)                                                                              \
-    hipLaunchKernelGGL((tree_rollout_kernel<T, DP_, NS_, FR_>),                                                       \
-                       dim3((unsigned)((P + 2 * wg_waves(DP_, FR_, sizeof(T)) - 1) / (2 * wg_waves(DP_, FR_, sizeof(T))))), \
-                       dim3(64 * wg_waves(DP_, FR_, sizeof(T))), 0, stream, model, state, P, H, A, mean, noise, cost, act, obs, nobs, diag)
+#define MJMPC_TREE_LAUNCH(DP_, NS_, FR_, PL_)                                                                         \
+    {                                                                                                                 \
+        constexpr int per_wg = wg_waves(DP_, FR_, sizeof(T), PL_) * (64 / PL_);                                       \
+        hipLaunchKernelGGL((tree_rollout_kernel<T, DP_, NS_, FR_, PL_>), dim3((unsigned)((P + per_wg - 1) / per_wg)), \
+                           dim3(64 * wg_waves(DP_, FR_, sizeof(T), PL_)), 0, stream, model, state, P, H, A, mean,     \
+                           noise, cost, act, obs, nobs, diag);                                                        \
+    }
     // hinge trees in air with up to 8 frictionless contact points keep the lean instantiation; slide joints, springs,
-    // friction cones, more points or a medium take the full one (three Jacobians per point, 16 points, fluid forces)
+    // friction cones, more points or a medium take the full one (three Jacobians per point, 16 points, fluid forces),
+    // which also comes with 16 lanes per particle for models of up to 16 dofs (the reference's swimmer and cheetah)
     if (!full) {
-        if (max_path <= 8) MJMPC_TREE_LAUNCH(8, 8, false);
-        else if (max_path <= 16) MJMPC_TREE_LAUNCH(16, 8, false);
-        else MJMPC_TREE_LAUNCH(32, 8, false);
+        if (max_path <= 8) MJMPC_TREE_LAUNCH(8, 8, false, 32)
+        else if (max_path <= 16) MJMPC_TREE_LAUNCH(16, 8, false, 32)
+        else MJMPC_TREE_LAUNCH(32, 8, false, 32)
+    } else if (nv <= 16 && !(sizeof(T) == 4 && P <= 4096)) {    // (f32 at <= 4096 particles: two half-empty waves per SIMD hide more latency)
+        if (max_path <= 8) MJMPC_TREE_LAUNCH(8, 16, true, 16)
+        else MJMPC_TREE_LAUNCH(16, 16, true, 16)
     } else {
-        if (max_path <= 8) MJMPC_TREE_LAUNCH(8, 16, true);
-        else if (max_path <= 16) MJMPC_TREE_LAUNCH(16, 16, true);
-        else MJMPC_TREE_LAUNCH(32, 16, true);
+        if (max_path <= 8) MJMPC_TREE_LAUNCH(8, 16, true, 32)
+        else if (max_path <= 16) MJMPC_TREE_LAUNCH(16, 16, true, 32)
+        else MJMPC_TREE_LAUNCH(32, 16, true, 32)
     }
 #undef MJMPC_TREE_LAUNCH
     return hipGetLastError();
 }
 
-template hipError_t launch_tree_rollout<float>(const float*, int, bool, const double*, long, int, int, const double*,
+template hipError_t launch_tree_rollout<float>(const float*, int, bool, int, const double*, long, int, int, const double*,
                                                const float*, float*, float*, float*, float*, unsigned*, hipStream_t);
-template hipError_t launch_tree_rollout<double>(const double*, int, bool, const double*, long, int, int, const double*,
+template hipError_t launch_tree_rollout<double>(const double*, int, bool, int, const double*, long, int, int, const double*,
                                                 const double*, double*, double*, double*, double*, unsigned*, hipStream_t);
 
 }  // namespace mjmpc
