@@ -112,6 +112,23 @@ def test_f32_one_step_and_rollout_statistics(name):
     assert eng.solver_failures() <= 2
 
 
+@pytest.mark.parametrize("name", ["swimmer", "cheetah"])
+def test_f32_launches_above_4096_particles_run_16_lanes_per_particle(name):
+    """f32 launches of more than 4096 particles take the 16-lanes-per-particle instantiation (smaller ones keep 32 lanes):
+    6001 particles (a ragged last wavefront), two env steps, every particle against the oracle."""
+    from mjmpc_amd.envs.tree_engine import TreeRolloutEngine
+    from oracle.physics_ref import RefArm
+    raw = _models()[name]()
+    eng, ref = TreeRolloutEngine(raw, dtype="f32"), RefArm(raw.to_flat())
+    q0, v0, mean, noise = _case(name, ref.nv, eng.d_action, 9, 6001, 2)
+    eng.set_env_state(dict(qpos=q0, qvel=v0))
+    obs, rew, act, done, info, nobs = eng.rollout(6001, 2, mean, noise)
+    o = ref.rollout(q0, v0, np.zeros(3), mean, noise)
+    e = np.abs(nobs - o[4]).max(axis=(1, 2))
+    assert np.median(e) < 2e-4 and np.quantile(e, 0.99) < 2e-3 and e.max() < 5e-2       # (contacts: a few particles switch a substep apart)
+    assert np.abs(rew - o[1]).max() < 5e-2 and eng.solver_failures() <= 2
+
+
 def test_env_classes_step_like_the_oracle():
     """SwimmerEnv / HalfCheetahEnv (the reference's env classes on the tree engine): step, observation, state round trip."""
     from mjmpc_amd.envs.locomotion_env import HalfCheetahEnv, SwimmerEnv

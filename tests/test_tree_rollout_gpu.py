@@ -152,10 +152,12 @@ def test_dmd_step_on_the_tree(hand):
     np.testing.assert_allclose(ctrl.cov_action, cr.dmd_shift_cov(cov1, 0.1, True), rtol=1e-9, atol=1e-12)
 
 
-@pytest.mark.parametrize("n_links", [12, 20])
-def test_deep_chains_use_the_wider_row_instantiations(n_links):
+@pytest.mark.parametrize("n_links,full", [(12, False), (20, False), (12, True), (20, True)])
+def test_deep_chains_use_the_wider_row_instantiations(n_links, full):
     """Root-to-leaf paths longer than 8 links run the DP = 16 / DP = 32 instantiations of the tree kernel (path-indexed
-    rows of 16 / 32 entries): a 12-link and a 20-link chain with a two-link side branch, gravity on, against the oracle."""
+    rows of 16 / 32 entries): a 12-link and a 20-link chain with a two-link side branch, gravity on, against the oracle.
+    `full`: joint springs and a friction cone on the contact sphere send the same models through the full instantiation
+    (14 dofs: 16 lanes per particle, 22 dofs: 32)."""
     from mjmpc_amd.envs.tree_engine import TreeRolloutEngine
     from mjmpc_amd.models.raw import GEOM_CAPSULE, GEOM_SPHERE, RawActuator, RawBody, RawGeom, RawJoint, RawModel, RawPlane
     from oracle.physics_ref import RefArm
@@ -164,22 +166,26 @@ def test_deep_chains_use_the_wider_row_instantiations(n_links):
     for i in range(n_links):
         r = 0.03 - 0.001 * i
         bodies.append(RawBody("l%d" % i, i - 1, (0.0, 0.0, 0.3) if i == 0 else (0.08, 0.0, 0.0),
-                              joint=RawJoint(axes[i % 3], (-1.2, 1.2), True, 0.3, 0.002, "j%d" % i),
+                              joint=RawJoint(axes[i % 3], (-1.2, 1.2), True, 0.3, 0.002, "j%d" % i,
+                                             stiffness=(2.0 if full and i % 4 == 1 else 0.0), springref=0.1),
                               geoms=[RawGeom(GEOM_CAPSULE, r, (0, 0, 0), (0.08, 0, 0), margin=0.001)]))
     # a side branch half way up, so that the model is a tree and not a chain
     mid = n_links // 2
     bodies.insert(mid + 1, RawBody("b0", mid, (0.0, 0.05, 0.0), joint=RawJoint((0, 0, 1), (-1, 1), True, 0.2, 0.001, "jb0"),
                                    geoms=[RawGeom(GEOM_CAPSULE, 0.015, (0, 0, 0), (0, 0.06, 0), margin=0.001)]))
     bodies.insert(mid + 2, RawBody("b1", mid + 1, (0.0, 0.06, 0.0), joint=RawJoint((1, 0, 0), (-1, 1), True, 0.2, 0.001, "jb1"),
-                                   geoms=[RawGeom(GEOM_SPHERE, 0.02, (0, 0.03, 0), collide=True, margin=0.001)]))
+                                   geoms=[RawGeom(GEOM_SPHERE, 0.02, (0, 0.03, 0), collide=True, margin=0.001,
+                                                  friction=0.6, condim=3 if full else 1)]))
     for b in bodies[mid + 3:]:                      # the rest of the main chain hangs off link `mid`, after the branch
         b.parent = b.parent + 2 if b.parent > mid else b.parent
     bodies[mid + 3].parent = mid
     nv = len(bodies)
     raw = RawModel(bodies=bodies, actuators=[RawActuator(b.joint.name, 0.5, (-1, 1)) for b in bodies],
                    site_body=nv - 1, site_pos=(0.08, 0, 0), target_pos=(0.5, 0.2, 0.4),
-                   plane=RawPlane((0, 0, -0.05), (0, 0, 1), 0.001), timestep=0.004, frame_skip=2, gravity=(0, 0, -9.81))
+                   plane=RawPlane((0, 0, -0.05), (0, 0, 1), 0.001, friction=0.3, condim=3 if full else 1), timestep=0.004,
+                   frame_skip=2, gravity=(0, 0, -9.81))
     eng, ref = TreeRolloutEngine(raw, dtype="f64"), RefArm(raw.to_flat())
+    assert eng.model.field("any_friction")[0] == (1.0 if full else 0.0)
     assert eng.model.max_path == n_links and nv == n_links + 2          # 12 -> DP = 16, 20 -> DP = 32
     rs = np.random.RandomState(n_links)
     P, H = 66, 12
@@ -188,6 +194,36 @@ def test_deep_chains_use_the_wider_row_instantiations(n_links):
     eng.set_env_state(dict(qp=q0, qv=v0, target_pos=np.array(raw.target_pos)))
     obs, rew, act, done, info, nobs = eng.rollout(P, H, mean, noise, "open_loop")
     o = ref.rollout(q0, v0, np.array(raw.target_pos), mean, noise)
+    np.testing.assert_allclose(rew, o[1], rtol=1e-9, atol=1e-9)
+    np.testing.assert_allclose(nobs, o[4], rtol=0, atol=1e-9)
+    assert eng.solver_failures() == 0
+
+
+def test_hand_with_friction_runs_the_full_kernel_at_32_lanes():
+    """The 24-dof hand with friction cones on its fingertips and springs in the finger joints: more than 16 dofs, so the
+    full instantiation runs 32 lanes per particle (DP = 8); start state with the fingertips pressed on the table."""
+    import dataclasses
+    from mjmpc_amd.envs.tree_engine import TreeRolloutEngine
+    from mjmpc_amd.models.hand24 import hand24_raw
+    from oracle.physics_ref import RefArm
+    raw = hand24_raw()
+    for b in raw.bodies:
+        if b.joint is not None and b.name.endswith("_mid"):
+            b.joint.stiffness, b.joint.springref = 0.05, 0.3
+        for g in b.geoms:
+            if g.collide:
+                g.friction, g.condim = 0.8, 3
+    raw.plane = dataclasses.replace(raw.plane, friction=0.5, condim=3)
+    eng, ref = TreeRolloutEngine(raw, dtype="f64"), RefArm(raw.to_flat())
+    assert eng.model.field("any_friction")[0] == 1.0 and eng.model.nv == 24
+    st = STATES[1]
+    P, H, A = 67, 16, 24
+    mean = 0.2 * np.random.RandomState(5).standard_normal((H, A))
+    noise = _noise(P, H, A, 50, 0.7)
+    eng.set_env_state(dict(st, target_pos=np.array(raw.target_pos)))
+    obs, rew, act, done, info, nobs = eng.rollout(P, H, mean, noise)
+    o = ref.rollout(st["qp"], st["qv"], np.array(raw.target_pos), mean, noise)
+    assert ref.newton_stats()["iters"] > 0
     np.testing.assert_allclose(rew, o[1], rtol=1e-9, atol=1e-9)
     np.testing.assert_allclose(nobs, o[4], rtol=0, atol=1e-9)
     assert eng.solver_failures() == 0
