@@ -51,12 +51,17 @@ def parse():
     return ap.parse_args()
 
 
-def cpu_baseline(P, H, budget_s):
+def cpu_baseline(P, H, budget_s, raw=None, qpos=None, qvel=None, noise_scale=1.0):
     """The FP64 C oracle (kind "port") on this box's host cores: same model, same start state, same
-    noise recipe; a bounded sample of the workload (batches of >= 32 particles per thread x H until the budget)."""
+    noise recipe; a bounded sample of the workload (batches of >= 32 particles per thread x H until the budget).
+    `raw` (default: the reacher) lets tools/bench_configs.py time the other models through this same leg."""
     from mjmpc_amd.models.reacher7dof import reacher7dof_raw
     from oracle.physics_ref import RefArm, threads
-    arm = RefArm(reacher7dof_raw().to_flat())
+    raw = raw or reacher7dof_raw()
+    arm = RefArm(raw.to_flat())
+    A = len(raw.actuators)
+    q0 = np.zeros(arm.nv) if qpos is None else np.asarray(qpos, float)
+    v0 = np.zeros(arm.nv) if qvel is None else np.asarray(qvel, float)
     avail = len(os.sched_getaffinity(0))
     try:                                    # a cgroup CPU quota below the visible core count: more threads only thrash
         with open("/sys/fs/cgroup/cpu.max") as f:
@@ -68,22 +73,22 @@ def cpu_baseline(P, H, budget_s):
     cores = threads(avail)
     rs = np.random.RandomState(123)
     batch = max(512, 32 * cores)            # >= 32 particles per thread, or OpenMP fork/join dominates
-    noise = rs.standard_normal((batch, H, 7))
+    noise = noise_scale * rs.standard_normal((batch, H, A))
     for t in range(2, H):
         noise[:, t] = 0.25 * noise[:, t] + 0.8 * noise[:, t - 1]
-    mean = np.zeros((H, 7))
+    mean = np.zeros((H, A))
     tgt = np.array([0.1, 0.1, 0.1])
-    arm.rollout(np.zeros(7), np.zeros(7), tgt, mean, noise[:64], want_obs=False)     # warm up
+    arm.rollout(q0, v0, tgt, mean, noise[:64], want_obs=False)     # warm up
     n, t0 = 0, time.time()
     while time.time() - t0 < 0.8 * budget_s:
-        arm.rollout(np.zeros(7), np.zeros(7), tgt, mean, noise, want_obs=False)
+        arm.rollout(q0, v0, tgt, mean, noise, want_obs=False)
         n += batch
     dt = time.time() - t0
     # the same code on ONE thread (2 s), to tell host-core scaling limits (cgroup quotas, SMT) from code speed
     threads(1)
     n1, t1 = 0, time.time()
     while time.time() - t1 < 0.2 * budget_s:
-        arm.rollout(np.zeros(7), np.zeros(7), tgt, mean, noise[:64], want_obs=False)
+        arm.rollout(q0, v0, tgt, mean, noise[:64], want_obs=False)
         n1 += 64
     dt1 = time.time() - t1
     threads(cores)

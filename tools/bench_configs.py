@@ -109,16 +109,12 @@ def run_tree(name, make, P, H, steps, warmup, dtype, note, raw_fn=None, env_cls=
            "solver_failures": eng.solver_failures(), "note": note}
     if env is not None:
         out["forward_progress_m"] = float(state["qpos"][0])
-        # the oracle on this host's cores, same model, a bounded sample of the same rollout (for scale, not a target)
-        from oracle import physics_ref
-        ref = physics_ref.RefArm(raw.to_flat())
-        ps = min(P, 4096)
-        rs = np.random.RandomState(0)
-        t0 = time.perf_counter()
-        ref.rollout(state["qpos"], state["qvel"], np.zeros(3), np.zeros((H, eng.d_action)), 0.5 * rs.standard_normal((ps, H, eng.d_action)),
-                    want_obs=False)
-        out["cpu_oracle_particle_steps_per_s"] = ps * H / (time.perf_counter() - t0)
-        out["cpu_oracle_threads"] = physics_ref.threads()
+        # the CPU restatement on this host's cores, same model and start state, through bench.py's cpu_baseline leg
+        # (a bounded sample; for scale, not a target)
+        sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+        import bench
+        cb = bench.cpu_baseline(P, H, 4.0, raw=raw, qpos=state["qpos"], qvel=state["qvel"], noise_scale=0.5)
+        out["cpu_baseline"] = {k: cb[k] for k in ("value", "unit", "cores", "kind", "single_thread_value")}
     else:
         out["final_distance_to_target"] = float(np.linalg.norm(nobs[2 * nv + 3:2 * nv + 6]))
     print(json.dumps(out), flush=True)

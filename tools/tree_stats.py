@@ -7,7 +7,7 @@ Prints, for the first particle of the launch, shader cycles per substep in each 
 import ctypes, glob, os, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-LIB = os.path.join(ROOT, "tools", "_build", "libmjmpc_amd_treestats.so")
+LIB = os.environ.get("TREE_STATS_LIB", os.path.join(ROOT, "tools", "_build", "libmjmpc_amd_treestats.so"))
 CSRC = os.path.join(ROOT, "mjmpc_amd", "csrc")
 NAMES = ["kinematics + contact geometry", "link quantities + bias forces (+ fluid)", "composite inertia + mass-matrix row",
          "constraint rows", "Newton iterations", "Euler factor + solve", "-", "integrate + records"]
