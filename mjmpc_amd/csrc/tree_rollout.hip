@@ -99,7 +99,17 @@ constexpr int a_jc(int DP, int PL) { return a_vec(DP, PL) + PL; }
 constexpr int CS = 12;      // per contact point: centre[3], dist, D, aref (normal part), mu B Jt1.v, mu B Jt2.v, axis[3]
 constexpr int a_cs(int DP, int NS, int NJ, int PL) { return a_jc(DP, PL) + NS * NJ * DP; }
 constexpr int a_misc(int DP, int NS, int NJ, int PL) { return a_cs(DP, NS, NJ, PL) + NS * CS; }   // site[3]
-constexpr int a_len(int DP, int NS, int NJ, int PL) { return a_misc(DP, NS, NJ, PL) + 8; }
+constexpr int a_row2(int DP, int NS, int NJ, int PL) { return a_misc(DP, NS, NJ, PL) + 8; }     // the Euler matrix's factor
+// the full instantiation with rows of up to 16 entries factors the Euler matrix beside the first Newton matrix (two
+// 32-entry rows do not fit the register file; the lean instantiation runs the large launches, where the second row area
+// would cost a resident workgroup per CU: 65536 x 64 on the hand 77 -> 129 ms - as it would in the f32 launches with 16
+// lanes per particle, which are the large ones: 32768 x 32 on the cheetah 18 -> 35 ms)
+constexpr bool merge_factor(int DP, bool fric, int scalar_bytes, int PL) {
+    return fric && DP <= 16 && !(scalar_bytes == 4 && PL == 16);
+}
+constexpr int a_len(int DP, int NS, int NJ, int PL, int scalar_bytes) {
+    return a_row2(DP, NS, NJ, PL) + (merge_factor(DP, NJ == 3, scalar_bytes, PL) ? row_stride(DP) * PL : 0);
+}
 
 template <typename T>
 __device__ __forceinline__ void cross3(const T* a, const T* b, T* c) {
@@ -262,6 +272,39 @@ __device__ __forceinline__ void tree_factor(T* r, const int* ELIM, T* ROW, int l
     TSYNC();
 }
 
+// The same for TWO matrices of the tree's pattern in one pass over the rounds (H = M + J'DJ of the first Newton iteration
+// and the Euler matrix M + hB): one set of LDS round trips and list walks instead of two.
+template <int DP, int PL, typename T>
+__device__ __forceinline__ void tree_factor2(T* r, T* q, const int* ELIM, T* ROW, T* ROW2, int l, int n_rounds) {
+    int e = 0, ent = ELIM[l];
+    for (int hgt = 0; hgt + 1 < n_rounds; ++hgt) {
+#pragma unroll
+        for (int c = 0; c < DP; ++c) { ROW[l * row_stride(DP) + c] = r[c]; ROW2[l * row_stride(DP) + c] = q[c]; }
+        ROW[l * row_stride(DP) + 2 * DP] = rcp_(r[0]);
+        ROW2[l * row_stride(DP) + 2 * DP] = rcp_(q[0]);
+        TSYNC();
+        while (__any(ent >= 0 && (ent >> 16) == hgt)) {
+            if (ent >= 0 && (ent >> 16) == hgt) {
+                const T* rk = ROW + (ent & 255) * row_stride(DP);
+                const T* qk = ROW2 + (ent & 255) * row_stride(DP);
+                const int a = (ent >> 8) & 255;
+                const T f = rk[a] * rk[2 * DP], g = qk[a] * qk[2 * DP];
+#pragma unroll
+                for (int c = 0; c < DP; ++c) { r[c] -= f * rk[a + c]; q[c] -= g * qk[a + c]; }
+                ++e;
+                ent = e < PL - 1 ? ELIM[e * PL + l] : -1;
+            }
+        }
+        TSYNC();
+    }
+    const T invd = rcp_(r[0]), invq = rcp_(q[0]);
+#pragma unroll
+    for (int c = 1; c < DP; ++c) { r[c] *= invd; q[c] *= invq; }
+#pragma unroll
+    for (int c = 0; c < DP; ++c) { ROW[l * row_stride(DP) + c] = r[c]; ROW2[l * row_stride(DP) + c] = q[c]; }
+    TSYNC();
+}
+
 // x <- (L' D L)^-1 b, one entry per lane; ROW holds the factor (tree_factor), AT[c * 32 + l] = my ancestor at distance c
 template <int DP, int PL, typename T>
 __device__ __forceinline__ T tree_solve(const T* r, T b, const int* ELIM, const int* AT, const T* ROW, T* VEC, int l,
@@ -313,7 +356,7 @@ __global__ __launch_bounds__(64 * wg_waves(DP, FRIC, sizeof(T), PL), min_waves(s
     constexpr int NR = FRIC ? 4 : 1;        // constraint rows per contact point: Jn (+- mu Jt_k)
     typedef typename std::conditional<FRIC, unsigned long long, unsigned>::type mask_t;    // NR bits per contact point
     constexpr int A_VEC = a_vec(DP, PL), A_JC = a_jc(DP, PL), A_CS = a_cs(DP, NS, NJ, PL), A_MISC = a_misc(DP, NS, NJ, PL),
-                  A_LEN = a_len(DP, NS, NJ, PL);
+                  A_ROW2 = a_row2(DP, NS, NJ, PL), A_LEN = a_len(DP, NS, NJ, PL, sizeof(T));
     constexpr int NBLOB = T_DEPTH;          // the scalar part of the block; the topology tables go to integer LDS
     __shared__ __attribute__((aligned(16))) T lds[NBLOB + 1 + PPW * WG_WAVES * A_LEN];
     __shared__ int ELIM[(PL - 1) * PL];     // elimination lists
@@ -336,6 +379,7 @@ __global__ __launch_bounds__(64 * wg_waves(DP, FRIC, sizeof(T), PL), min_waves(s
     const bool live = pid < P;
     T* X = lds + NBLOB + 1 + (wave * PPW + half) * A_LEN;
     T* ROW = X + A_ROW;
+    T* ROW2 = X + A_ROW2;
     T* VEC = X + A_VEC;
     const int n_rounds = __builtin_amdgcn_readfirstlane((int)model[T_N_ROUNDS]), depth = (int)model[T_DEPTH + l];
     int max_depth = 0;
@@ -679,6 +723,7 @@ __global__ __launch_bounds__(64 * wg_waves(DP, FRIC, sizeof(T), PL), min_waves(s
             TSYNC();
             const bool any_rows = !(TREE_SKIP & 1) && __any(inst || cinst != 0);
             T qfrc_c = T(0);
+            T erow[merge_factor(DP, FRIC, sizeof(T), PL) ? DP : 1];      // factor of the Euler matrix when it was computed beside the first Newton factor
             clk.mark(3);
             clk.count(8, 1);
             clk.count(9, __popc(cinst));
@@ -786,7 +831,14 @@ __global__ __launch_bounds__(64 * wg_waves(DP, FRIC, sizeof(T), PL), min_waves(s
                     }
                     TSYNC();
                     clk.lap(12);
-                    tree_factor<DP, PL>(hrow, ELIM, ROW, l, n_rounds);
+                    if (merge_factor(DP, FRIC, sizeof(T), PL) && it == 0 && !(TREE_SKIP & 2)) {      // ... and the Euler matrix M + h B rides along (consumed in step 6)
+#pragma unroll
+                        for (int c = 0; c < DP; ++c) erow[c] = mrow[c];
+                        erow[0] += dof ? h * damping : T(0);
+                        tree_factor2<DP, PL>(hrow, erow, ELIM, ROW, ROW2, l, n_rounds);
+                    } else {
+                        tree_factor<DP, PL>(hrow, ELIM, ROW, l, n_rounds);
+                    }
                     clk.lap(13);
                     xa = tree_solve<DP, PL>(hrow, rhs, ELIM, AT, ROW, VEC, l, n_rounds, depth, max_depth);
                     clk.lap(14);
@@ -887,10 +939,12 @@ __global__ __launch_bounds__(64 * wg_waves(DP, FRIC, sizeof(T), PL), min_waves(s
             clk.mark(4);
             T qacc;
             {
-                mrow[0] += dof ? h * damping : T(0);
                 if (TREE_SKIP & 2) {
-                    qacc = (tau + qfrc_c) * rcp_(mrow[0]);
+                    qacc = (tau + qfrc_c) * rcp_(mrow[0] + (dof ? h * damping : T(0)));
+                } else if (merge_factor(DP, FRIC, sizeof(T), PL) && any_rows) {
+                    qacc = tree_solve<DP, PL>(erow, tau + qfrc_c, ELIM, AT, ROW2, VEC, l, n_rounds, depth, max_depth);
                 } else {
+                    mrow[0] += dof ? h * damping : T(0);
                     tree_factor<DP, PL>(mrow, ELIM, ROW, l, n_rounds);
                     qacc = tree_solve<DP, PL>(mrow, tau + qfrc_c, ELIM, AT, ROW, VEC, l, n_rounds, depth, max_depth);
                 }
