@@ -55,8 +55,9 @@ def _quat2mat(q):
                      [2 * (x * z - w * y), 2 * (y * z + w * x), 1 - 2 * (x * x + y * y)]])
 
 
-def _geom_inertial(g):
-    """(mass, centre, inertia about centre) of one geom, MuJoCo inertiafromgeom conventions."""
+def _geom_inertial(g, cap=1.0):
+    """(mass, centre, inertia about centre) of one geom, MuJoCo inertiafromgeom conventions; ``cap``: the capsule end
+    caps' volume in units of pi r^3 (MuJoCo 2.0: 1, later versions 4/3 - raw.MJ20_CAPSULE_CAP)."""
     r = float(g.radius)
     if g.type == GEOM_SPHERE:
         m = g.density * 4.0 / 3.0 * np.pi * r ** 3
@@ -65,7 +66,7 @@ def _geom_inertial(g):
         a, b = np.asarray(g.a, float), np.asarray(g.b, float)
         h = np.linalg.norm(b - a)
         u = (b - a) / h
-        m = g.density * (np.pi * r * r * h + 4.0 / 3.0 * np.pi * r ** 3)
+        m = g.density * (np.pi * r * r * h + cap * np.pi * r ** 3)
         ms = m * 4 * r / (4 * r + 3 * h)
         mc = m - ms
         i_perp = mc * (3 * r * r + h * h) / 12 + 0.4 * ms * r * r + ms * h * (3 * r + 2 * h) / 8
@@ -139,7 +140,7 @@ def compile_arm(raw: RawModel, overrides=None, base: "ArmModel" = None) -> ArmMo
             raise ValueError("bodies must be listed parents-first")
         R0[i] = Rp @ _quat2mat(b.quat)
         p0[i] = pp + Rp @ np.asarray(b.pos, float)
-        parts = [_geom_inertial(g) for g in b.geoms]
+        parts = [_geom_inertial(g, raw.capsule_cap_factor) for g in b.geoms]
         mass[i] = sum(m for m, _, _ in parts)
         if mass[i] > 0:
             ipos[i] = sum(m * c for m, c, _ in parts) / mass[i]

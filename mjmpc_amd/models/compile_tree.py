@@ -107,7 +107,7 @@ def compile_tree(raw: RawModel) -> TreeModel:
         Rp, pp = (np.eye(3), np.zeros(3)) if b.parent < 0 else (R0[b.parent], p0[b.parent])
         R0[i] = Rp @ _quat2mat(b.quat)
         p0[i] = pp + Rp @ np.asarray(b.pos, float)
-        parts = [_geom_inertial(g) for g in b.geoms]
+        parts = [_geom_inertial(g, raw.capsule_cap_factor) for g in b.geoms]
         mass[i] = sum(m for m, _, _ in parts)
         if mass[i] > 0:
             ipos[i] = sum(m * c for m, c, _ in parts) / mass[i]

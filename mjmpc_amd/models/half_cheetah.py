@@ -10,8 +10,8 @@ observation = [qpos[1:], qvel].
 import numpy as np
 
 from .compile import _geom_inertial
-from .raw import (GEOM_CAPSULE, JOINT_HINGE, JOINT_SLIDE, TASK_FORWARD, RawActuator, RawBody, RawGeom, RawJoint, RawModel,
-                  RawPlane)
+from .raw import (GEOM_CAPSULE, JOINT_HINGE, JOINT_SLIDE, MJ20_CAPSULE_CAP, TASK_FORWARD, RawActuator, RawBody, RawGeom,
+                  RawJoint, RawModel, RawPlane)
 
 _R = 0.046
 _MU = 0.4                                           # half_cheetah.xml:38: friction=".4 .1 .1", condim 3
@@ -53,7 +53,7 @@ def half_cheetah_raw(frame_skip=5) -> RawModel:
                 geoms=[_cap("ffoot", (0.045, 0.0, -0.07), 0.07, -0.6)]),
     ]
     # settotalmass="14" (half_cheetah.xml:33): MuJoCo scales every mass and inertia by 14 / (mass from density 1000)
-    total = sum(_geom_inertial(g)[0] for b in bodies for g in b.geoms)
+    total = sum(_geom_inertial(g, MJ20_CAPSULE_CAP)[0] for b in bodies for g in b.geoms)
     for b in bodies:
         for g in b.geoms:
             g.density *= 14.0 / total

@@ -21,8 +21,8 @@ import xml.etree.ElementTree as ET
 import numpy as np
 
 from .compile import _geom_inertial
-from .raw import (GEOM_CAPSULE, GEOM_SPHERE, JOINT_HINGE, JOINT_SLIDE, TASK_FORWARD, TASK_REACH, RawActuator, RawBody,
-                  RawGeom, RawJoint, RawModel, RawPlane)
+from .raw import (GEOM_CAPSULE, GEOM_SPHERE, JOINT_HINGE, JOINT_SLIDE, MJ20_CAPSULE_CAP, TASK_FORWARD, TASK_REACH, RawActuator,
+                  RawBody, RawGeom, RawJoint, RawModel, RawPlane)
 
 _VISUAL_BODY_TAGS = ("light", "camera")
 _TOP_TAGS = ("compiler", "option", "default", "worldbody", "actuator", "asset", "size", "visual", "statistic", "custom")
@@ -248,7 +248,7 @@ def load_mjcf(path, hand_site="finger", target_site="target", frame_skip=2, task
         for g in b.geoms:
             del g._contype, g._conaffinity, g._solver
     if totalmass is not None:           # MuJoCo scales every body mass and inertia by the same factor
-        total = sum(_geom_inertial(g)[0] for b in bodies for g in b.geoms)
+        total = sum(_geom_inertial(g, MJ20_CAPSULE_CAP)[0] for b in bodies for g in b.geoms)
         for b in bodies:
             for g in b.geoms:
                 g.density *= totalmass / total

@@ -27,6 +27,14 @@ GEOM_CAPSULE = 2
 HEADER_LEN = 56
 JOINT_HINGE = 1
 JOINT_SLIDE = 2
+# MuJoCo 2.0 - the version the reference pins (mujoco-py >=2.0,<2.1) - computes a capsule's volume as pi r^2 (h + r): the
+# two end caps count pi r^3 instead of 4/3 pi r^3.  That is what the body masses gym users have printed for years say
+# to nine digits (HalfCheetah under mujoco-py 2.0: 6.36031332, 1.53524804, 1.58093995, 1.0691906, 1.42558747,
+# 1.17885117, 0.84986945 with settotalmass 14; Hopper: 3.53429174, 3.92699082, 2.71433605, 5.0893801), and
+# tests/test_locomotion_cpu.py holds the model compilers to those numbers.  MuJoCo >= 2.1.2 uses 4/3 (Hopper-v4:
+# 3.6651914 ...): set ``RawModel.capsule_cap_factor = 4/3`` for that.  The inertia of a capsule of given mass follows
+# MuJoCo's published formula in both cases ([EXT], unpinned).
+MJ20_CAPSULE_CAP = 1.0
 TASK_REACH = 0              # reward -(|h-g|_1 + 5 |h-g|_2), obs [qpos, qvel, h, h-g]      (reacher_env.py:29-47)
 TASK_FORWARD = 1            # reward (x' - x)/dt - c |a|^2, obs [qpos[skip:], qvel]         (swimmer.py, half_cheetah.py)
 BODY_STRIDE = 20
@@ -107,6 +115,7 @@ class RawModel:
     task: int = TASK_REACH
     ctrl_cost: float = 0.0                          # TASK_FORWARD: weight of |a|^2
     obs_skip: int = 0                               # TASK_FORWARD: leading qpos entries left out of the observation
+    capsule_cap_factor: float = MJ20_CAPSULE_CAP    # capsule volume = pi r^2 h + factor * pi r^3 (see MJ20_CAPSULE_CAP)
 
     # ------------------------------------------------------------------
     @property
@@ -144,6 +153,7 @@ class RawModel:
             h[36] = self.plane.condim
         h[30], h[31] = self.density, self.viscosity
         h[32], h[33], h[34] = self.task, self.ctrl_cost, self.obs_skip
+        h[37] = self.capsule_cap_factor
         h[40:42] = self.solref if self.solref_limit is None else self.solref_limit
         h[42:47] = self.solimp if self.solimp_limit is None else self.solimp_limit
         out = [h]

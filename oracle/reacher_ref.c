@@ -325,7 +325,7 @@ static void rne(const OrModel *m, const Kin *k, const double *v, const double *a
 /* ---------------------------------------------------------------- model compile */
 /* MuJoCo compiler, inertiafromgeom="true": geom mass = density * volume; sphere 2/5 m r^2;
  * capsule = cylinder + two hemispheres (MuJoCo user_objects: mjCGeom::SetInertia). */
-static void geom_inertia(int type, double r, const double *a, const double *b_, double density,
+static void geom_inertia(int type, double r, const double *a, const double *b_, double density, double cap,
                          double *mass, double *pos, double *I) {
     const double PI = 3.14159265358979323846;
     memset(I, 0, sizeof(double) * 9);
@@ -339,7 +339,9 @@ static void geom_inertia(int type, double r, const double *a, const double *b_, 
         double len = sqrt(dot3(u, u));
         for (int i = 0; i < 3; i++) { u[i] /= len; pos[i] = 0.5 * (a[i] + b_[i]); }
         double h = len;     /* cylinder height = 2 * half-length */
-        *mass = density * (PI * r * r * h + 4.0 / 3.0 * PI * r * r * r);
+        /* cap: the end caps' volume in units of pi r^3 - 1 in MuJoCo 2.0 (which the reference pins; gym's published
+         * body masses say so to nine digits), 4/3 from MuJoCo 2.1.2 on; the flat model carries it */
+        *mass = density * (PI * r * r * h + cap * PI * r * r * r);
         double ms = (*mass) * 4 * r / (4 * r + 3 * h), mc = (*mass) - ms;
         double Iperp = mc * (3 * r * r + h * h) / 12 + 0.4 * ms * r * r + ms * h * (3 * r + 2 * h) / 8;
         double Iax = mc * r * r / 2 + 0.4 * ms * r * r;
@@ -413,7 +415,7 @@ OrModel *or_model_compile(const double *f, int n) {
     for (int g = 0; g < ng; g++) {
         const double *r = g0 + g * GEOM_STRIDE;
         gb[g] = (int)r[0] + 1;
-        geom_inertia((int)r[1], r[2], r + 3, r + 6, r[9], &gm[g], gp[g], gI[g]);
+        geom_inertia((int)r[1], r[2], r + 3, r + 6, r[9], f[37], &gm[g], gp[g], gI[g]);
         /* colliding geoms: a sphere, or a capsule = its two end spheres, "to" end first (mjc_PlaneCapsule tests
          * pos + axis * halflength, then pos - axis * halflength, and aligns the contact frame with the axis).
          * Contact friction / condim = max over the two geoms (MuJoCo mj_contactParam, equal priorities). */
@@ -668,6 +670,7 @@ static void solve_rows(OrModel *m, int nv, const double *M, const double *fs, in
                 double t = bp[j]; bp[j] = bp[j - 1]; bp[j - 1] = t;
                 int ti = idx[j]; idx[j] = idx[j - 1]; idx[j - 1] = ti;
             }
+        if (!(c1 > 0)) break;               /* a zero step (the polishing iteration from an exact minimiser): done */
         double alpha = -c0 / c1;
         for (int i = 0; i < nbp; i++) {
             if (alpha <= bp[i]) break;

@@ -18,7 +18,9 @@ def test_counting_build_is_the_oracle_and_counts_30k_flop_per_particle_step():
     mean, tgt = np.zeros((H, 7)), np.array([0.1, 0.1, 0.1])
     d = count_flops(flat, np.zeros(7), np.zeros(7), tgt, mean, noise)
     _, rew, _, _, _ = RefArm(flat).rollout(np.zeros(7), np.zeros(7), tgt, mean, noise, want_obs=False)
-    assert np.array_equal(d["rew"], rew)                       # same source, same arithmetic, bit for bit
+    # same source, same arithmetic - up to the polishing Newton step the counting build leaves out (it would be counted
+    # as work of the algorithm; it moves results by less than the oracle's 1e-11 stopping tolerance)
+    np.testing.assert_allclose(d["rew"], rew, rtol=1e-10, atol=1e-10)
     assert d["flops"] == d["add"] + d["mul"] + d["div"] + d["sqrt"] + d["trig"]
     assert 2.5e4 < d["flops"] < 3.5e4                          # 30 284 on this sample (bench.py reports the exact count)
     assert d["trig"] > 14 and d["sqrt"] > 2                    # 7 joints x 2 substeps x (sin, cos); the cost's norm

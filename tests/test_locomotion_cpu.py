@@ -47,6 +47,25 @@ def test_two_compilers_agree(raw_fn, nv, nu, dobs, total):
     assert sorted(a for a in act if a >= 0) == list(range(nu)) and (act[:3] == -1).all()     # the root is not actuated
 
 
+def test_model_compilers_reproduce_mujoco_20_body_masses():
+    """The one piece of the physics half that IS pinned on MuJoCo's own output: `model.body_mass` of HalfCheetah as
+    mujoco-py 2.0 users print it (settotalmass 14 over capsules whose end caps MuJoCo 2.0 counts as pi r^3 - with
+    4/3 pi r^3 the torso would weigh 6.2502), and the same rule on Hopper's four capsules (gym's 3.53429174 ...;
+    MuJoCo >= 2.1.2 and gymnasium's -v4 give 3.6651914 ...).  Both model compilers, nine digits."""
+    from oracle.physics_ref import RefArm
+    published = [6.36031332, 1.53524804, 1.58093995, 1.0691906, 1.42558747, 1.17885117, 0.84986945]
+    raw = half_cheetah_raw()
+    np.testing.assert_allclose(compile_tree(raw).body_mass[2:], published, rtol=0, atol=5e-9)
+    np.testing.assert_allclose(RefArm(raw.to_flat()).inertial()[0][3:], published, rtol=0, atol=5e-9)
+    from mjmpc_amd.models.compile import _geom_inertial
+    from mjmpc_amd.models.raw import GEOM_CAPSULE, MJ20_CAPSULE_CAP
+    hopper = [(0.05, 0.4), (0.05, 0.45), (0.04, 0.5), (0.06, 0.39)]         # radius, length of gym's hopper.xml capsules
+    m20 = [_geom_inertial(RawGeom(GEOM_CAPSULE, r, (0, 0, 0), (0, 0, h)), MJ20_CAPSULE_CAP)[0] for r, h in hopper]
+    m21 = [_geom_inertial(RawGeom(GEOM_CAPSULE, r, (0, 0, 0), (0, 0, h)), 4.0 / 3.0)[0] for r, h in hopper]
+    np.testing.assert_allclose(m20, [3.53429174, 3.92699082, 2.71433605, 5.0893801], rtol=0, atol=5e-9)
+    np.testing.assert_allclose(m21, [3.6651914, 4.0578905, 2.7813567, 5.3155748], rtol=0, atol=5e-8)
+
+
 @pytest.mark.parametrize("raw_fn", [swimmer_raw, half_cheetah_raw])
 def test_oracle_identities_with_slide_joints(raw_fn):
     """M symmetric positive definite and RNE(q, v, a) - RNE(q, v, 0) = (M - armature) a: the Jacobian-built mass matrix

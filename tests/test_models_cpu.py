@@ -19,7 +19,12 @@ def test_blob_layout_and_kinematic_constants():
     off = m.field("off").reshape(3, 8).T
     np.testing.assert_allclose(off[:7].sum(0), [0.821, -0.6, 0.0], atol=1e-15)     # hand at qpos0
     assert m.field("armature")[7] == 1.0 and m.field("mass")[7] == 0.0             # spare lane
-    np.testing.assert_allclose(m.field("mass")[:7].sum(), 47.10975, rtol=1e-6)
+    # capsule volume as MuJoCo 2.0 computes it (end caps pi r^3, models/raw.py::MJ20_CAPSULE_CAP); with the 4/3 of later
+    # versions the arm weighs SURVEY appendix A's 47.110 kg
+    np.testing.assert_allclose(m.field("mass")[:7].sum(), 44.414266, rtol=1e-6)
+    import dataclasses
+    m43 = compile_arm(dataclasses.replace(reacher7dof_raw(), capsule_cap_factor=4.0 / 3.0))
+    np.testing.assert_allclose(m43.field("mass")[:7].sum(), 47.10975, rtol=1e-6)
     assert m.field("sph_margin")[0] == 0.002 and m.field("n_sphere")[0] == 1
 
 

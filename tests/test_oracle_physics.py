@@ -17,10 +17,17 @@ from oracle.physics_ref import RefArm
 SURVEY_MASSES = [24.3117, 10.4720, 0.28484, 5.42867, 1.35717, 0.28484, 2.80911, 0.016755, 2.14466]
 
 
-def test_masses_match_hand_derivation(ref_arm):
+def test_masses_match_hand_derivation(raw_arm, ref_arm):
+    """SURVEY appendix A derived its sanity masses with the textbook capsule volume (end caps 4/3 pi r^3); MuJoCo 2.0,
+    which the reference pins, counts the caps pi r^3 (models/raw.py::MJ20_CAPSULE_CAP, the default): both are checked."""
+    import dataclasses
+    mass43, _, _ = RefArm(dataclasses.replace(raw_arm, capsule_cap_factor=4.0 / 3.0).to_flat()).inertial()
+    np.testing.assert_allclose(mass43[1:], SURVEY_MASSES, rtol=2e-5)
+    assert abs(mass43.sum() - 47.110) < 1e-3
     mass, _, _ = ref_arm.inertial()
-    np.testing.assert_allclose(mass[1:], SURVEY_MASSES, rtol=2e-5)
-    assert abs(mass.sum() - 47.110) < 1e-3
+    r, hl = 0.1, 0.3                                    # the pan link's capsule: (0,0,-.4) -> (0,0,.2), radius .1
+    pan = 1000 * (np.pi * r * r * 2 * hl + np.pi * r ** 3) + 1000 * 4 / 3 * np.pi * (2 * 0.05 ** 3 + 2 * 0.03 ** 3)
+    assert abs(mass[1] - pan) < 1e-9 and abs(mass.sum() - 44.414266) < 1e-5
 
 
 def test_two_compilers_agree(raw_arm, ref_arm):
@@ -175,3 +182,68 @@ def test_rollout_layout(ref_arm):
         assert r == rew[3, t]
         np.testing.assert_array_equal(o, nobs[3, t])
     assert ref_arm.newton_stats()["fails"] == 0
+
+
+def _limit_rows(raw, ref, q, v):
+    """Joint-limit rows of one substep, restated in numpy (impedance, reference acceleration): (J, D, aref) each."""
+    joints = [b.joint for b in raw.bodies if b.joint is not None]
+    dofw, _ = ref.invweight0()
+    h = raw.timestep
+    dmin, dmax, width, mid, power = raw.solimp
+    tc, dr = max(raw.solref[0], 2 * h), raw.solref[1]
+    rows = []
+    for j, jt in enumerate(joints):
+        for side, bound in ((-1, jt.range[0]), (1, jt.range[1])):
+            dist = side * (bound - q[j])
+            if jt.limited and dist < 0:
+                x = abs(dist) / width
+                y = 1.0 if x >= 1 else (x ** power / mid ** (power - 1) if x <= mid else 1 - (1 - x) ** power / (1 - mid) ** (power - 1))
+                imp = dmin + y * (dmax - dmin)
+                J = np.zeros(len(joints))
+                J[j] = -side
+                rows.append((J, 1.0 / max((1 - imp) / imp * dofw[j], 1e-15),
+                             -2 / (dmax * tc) * (-side * v[j]) - imp * dist / (dmax * dmax * tc * tc * dr * dr)))
+    return rows
+
+
+def test_constraint_solver_matches_kkt_enumeration(raw_arm, ref_arm):
+    """The oracle's Newton + line search against brute force: every subset of the limit rows is tried as the active
+    set, the one consistent with its own solution is the unique minimiser.  States with two or three joints past
+    their limits, incl. the one on which a zero polishing step once produced 0/0 in the line search."""
+    import itertools
+    joints = [b.joint for b in raw_arm.bodies if b.joint is not None]
+    lo, hi = np.array([j.range[0] for j in joints]), np.array([j.range[1] for j in joints])
+    damp, gear = np.array([j.damping for j in joints]), np.array([a.gear for a in raw_arm.actuators])
+    cases = [(np.array([0.63395138, 0.94957624, 1.49866263, -2.32676372, -1.53308188, -1.11386727, -0.16821426]),
+              np.array([-0.70879538, 1.14306517, -1.62665656, -0.02570151, 0.64803507, 0.28575956, -9.98607415]),
+              np.array([-1.43339186, -1.61867497, -0.28029994, 1.9364087, -0.50533047, -1.14888822, 0.91139836]))]
+    rs = np.random.RandomState(11)
+    for _ in range(12):
+        q = lo + (hi - lo) * rs.rand(7)
+        for j in rs.choice(7, 3, replace=False):
+            q[j] = (hi[j] + 0.02 * rs.rand()) if rs.rand() < 0.5 else (lo[j] - 0.02 * rs.rand())
+        q[1] = min(q[1], 0.3)                       # hand above the table: limit rows only
+        cases.append((q, 3.0 * rs.randn(7), 2.0 * rs.randn(7)))
+    checked = 0
+    for q, v, u in cases:
+        for _ in range(2):                          # two substeps each
+            M, bias = ref_arm.mass_matrix(q), ref_arm.rne(q, v)
+            fs = -bias - damp * v + gear * np.clip(u, -1, 1)
+            rows = _limit_rows(raw_arm, ref_arm, q, v)
+            q2, v2, _, diag = ref_arm.step(q, v, u)
+            if int(diag[0]) == len(rows) and rows:  # (no contact row in this substep)
+                sols = []
+                for mask in itertools.product([0, 1], repeat=len(rows)):
+                    H, rhs = M.copy(), fs.copy()
+                    for m, (J, D, ar) in zip(mask, rows):
+                        if m:
+                            H += D * np.outer(J, J)
+                            rhs += D * ar * J
+                    a = np.linalg.solve(H, rhs)
+                    if all(((J @ a - ar) < 0) == bool(m) for m, (J, D, ar) in zip(mask, rows)):
+                        sols.append(a)
+                assert len(sols) == 1
+                np.testing.assert_allclose(diag[1:8], sols[0], rtol=1e-9, atol=1e-9)
+                checked += 1
+            q, v = q2, v2
+    assert checked >= 12 and ref_arm.newton_stats()["fails"] == 0
