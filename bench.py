@@ -43,6 +43,10 @@ def parse():
     ap.add_argument("--noise", choices=["device", "mt19937", "host"], default="device",
                     help="device: Philox on the GPU; mt19937: the reference's own numpy stream regenerated on the GPU "
                          "(seed-identical particles); host: numpy on the host, uploaded")
+    ap.add_argument("--workload", choices=["reacher", "half_cheetah", "swimmer", "hand24"], default="reacher",
+                    help="reacher: the BASELINE.json headline (default).  The others run the same MPPI loop on the tree engine "
+                         "(SURVEY 8f rank 4: the reference's vendored HalfCheetah / Swimmer models, the synthetic 24-dof hand) "
+                         "and print the same line for them; one GPU")
     ap.add_argument("--no-graph", action="store_true", help="launch every kernel eagerly instead of replaying a hipGraph")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=10.0)
@@ -104,6 +108,109 @@ def cpu_baseline(P, H, budget_s, raw=None, qpos=None, qvel=None, noise_scale=1.0
                       "one thread: %d particles in %.1f s%s" % (n, H, cores, dt, n1, dt1, quota)}
 
 
+def tree_workload(args):
+    """The same line for a tree-engine model: MPPI closed loop, the real env stepped by the engine at P = 1
+    with the state making a host round trip, eager launches."""
+    import torch
+    from mjmpc_amd.control import MPPI
+    from mjmpc_amd.envs.arm_engine import make_device_rollout_fn
+    from mjmpc_amd.envs.tree_engine import TreeRolloutEngine
+    from mjmpc_amd.models.compile_tree import compile_tree
+    if args.workload == "hand24":
+        from mjmpc_amd.models.hand24 import hand24_raw
+        raw, env, name, lam, cov = hand24_raw(), None, "hand_tree-v0 (synthetic 24-dof hand)", 0.05, 0.3
+    else:
+        from mjmpc_amd.envs import locomotion_env
+        from mjmpc_amd.models.half_cheetah import half_cheetah_raw
+        from mjmpc_amd.models.swimmer import swimmer_raw
+        raw = dict(half_cheetah=half_cheetah_raw, swimmer=swimmer_raw)[args.workload]()
+        env = dict(half_cheetah=locomotion_env.HalfCheetahEnv, swimmer=locomotion_env.SwimmerEnv)[args.workload](dtype=args.dtype)
+        name, lam, cov = dict(half_cheetah="HalfCheetah-v0", swimmer="Swimmer-v0")[args.workload], 0.2, 0.3
+    torch.cuda.set_device(0)
+    P, H = args.particles, args.horizon
+    eng = TreeRolloutEngine(raw, dtype=args.dtype)
+    A = eng.d_action
+    ctrl = MPPI(d_state=eng.d_state, d_obs=eng.d_obs, d_action=A, horizon=H, init_cov=cov, base_action="null", lam=lam,
+                num_particles=P, step_size=1.0, alpha=1, gamma=1.0, n_iters=1, action_lows=eng.action_lows,
+                action_highs=eng.action_highs, filter_coeffs=[0.25, 0.8, 0.0], seed=123, noise_mode="device",
+                noise_dtype=args.dtype)
+    ctrl.rollout_fn = make_device_rollout_fn(eng)
+    ctrl.set_sim_state_fn = eng.set_env_state
+    if env is not None:
+        env.reset(seed=123)
+        state = env.get_env_state()
+    else:
+        state = eng.reset()[0]
+
+    def control_step(st):
+        a, _ = ctrl.optimize(st)
+        if env is not None:
+            env.step(a)
+            return env.get_env_state()
+        eng.set_env_state(st)
+        eng.step(a)
+        return eng.get_env_state()[0]
+
+    for _ in range(args.warmup):
+        state = control_step(state)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        state = control_step(state)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    noise_t = ctrl.dev._rec[("noise", args.dtype)]
+    eng.set_env_state(state)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    eng.rollout_device(P, H, ctrl.dev.mean, noise_t)
+    e0.record()
+    for _ in range(5):
+        eng.rollout_device(P, H, ctrl.dev.mean, noise_t)
+    e1.record()
+    torch.cuda.synchronize()
+    kern_ms = e0.elapsed_time(e1) / 5
+    s = 8 if args.dtype == "f64" else 4
+    b_alg = (3 * A + 2) * s
+    achieved = b_alg * P * H / (kern_ms * 1e-3) / 1e9
+    qpos = state["qpos"] if "qpos" in state else state["qp"]
+    qvel = state["qvel"] if "qvel" in state else state["qv"]
+    valu = None
+    try:
+        from oracle.physics_ref import count_flops
+        rs = np.random.RandomState(123)
+        fl = count_flops(raw.to_flat(), qpos, qvel, np.zeros(3), np.zeros((H, A)), np.sqrt(cov) * rs.standard_normal((32, H, A)))
+        peak_tf = FP64_VALU_PEAK_TF if args.dtype == "f64" else FP32_VALU_PEAK_TF
+        tf = fl["flops"] * P * H / (kern_ms * 1e-3) / 1e12
+        valu = {"bound": "valu", "flops_per_particle_step": fl["flops"], "achieved": tf, "peak": peak_tf, "unit": "TFLOP/s",
+                "frac": tf / peak_tf,
+                "counted_by": "oracle/flop_count.cpp on a 32 x H sample from the run's last state: the ORACLE's formulation "
+                              "(dense Jacobian-built mass matrix and Cholesky), which on a tree does more arithmetic than the "
+                              "kernel's sparse one - an upper bound on the kernel's useful FLOP rate, not its instruction count"}
+    except Exception as e:
+        valu = {"bound": "valu", "error": "FLOP-counting oracle build unavailable: %s" % (e,)}
+    m = compile_tree(raw)
+    out = {"metric": "particle-steps/sec (%s MPPI %dp x H%d, control loop incl. noise, rollout, update, shift)" % (name, P, H),
+           "value": P * H * args.steps / dt, "unit": "particle-steps/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
+           "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+           "dtype": args.dtype, "data": "synthetic",
+           "config": {"workload": "%s MPPI lam=%g H=%d, %d particles, frame_skip %d, %d dofs, filter [0.25,0.8,0], closed loop "
+                                  "(tree engine; not a BASELINE.json configuration)" % (name, lam, H, P, raw.frame_skip, m.nv),
+                      "noise": "device", "particles_per_gpu": P, "horizon": H, "ranks_seen": 1, "backend": None, "launch": "eager"},
+           "control_loop_hz": args.steps / dt,
+           "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                        "traffic": None, "traffic_source": None, "valu": valu, "alg_bytes_per_launch": b_alg * P * H,
+                        "kernel": "tree_rollout_kernel<%s>" % ("double" if args.dtype == "f64" else "float"), "kernel_ms": kern_ms,
+                        "kernel_entry": "mjmpc_tree_rollout", "alg_bytes_per_particle_step": b_alg,
+                        "note": "latency-bound path (DESIGN 4.6): serial rounds of the tree factorisation and solves, the Newton "
+                                "loop of the wavefront's slowest particle"},
+           "solver_failures": eng.solver_failures()}
+    if env is not None:
+        out["forward_progress_m"] = float(qpos[0])
+    if not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(P, H, args.cpu_seconds, raw=raw, qpos=qpos, qvel=qvel, noise_scale=float(np.sqrt(cov)))
+    print(json.dumps(out), flush=True)
+
+
 def counted_flops(H):
     """algorithmic FLOPs per particle-step, counted (not estimated) by running the instrumented build of
     the oracle (oracle/flop_count.cpp: reacher_ref.c compiled with a counting scalar) on a sample of this workload."""
@@ -132,6 +239,10 @@ def profile_figure(name, dtype, P, H):
 
 def main():
     args = parse()
+    if args.workload != "reacher":
+        if int(os.environ.get("WORLD_SIZE", "1")) != 1 or args.gpus != 1:
+            raise SystemExit("--workload %s runs on one GPU" % args.workload)
+        return tree_workload(args)
     import torch
     import torch.distributed as dist
     world = int(os.environ.get("WORLD_SIZE", "1"))

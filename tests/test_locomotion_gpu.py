@@ -188,3 +188,18 @@ def test_example_driver_on_locomotion_configs(tmp_path, cfg, controller):
                           "--controller", controller, "--noise_mode", "device"], capture_output=True, text=True, timeout=300)
     assert out.returncode == 0, out.stderr[-2000:]
     assert "forward progress" in out.stdout and "solver failures 0" in out.stdout
+
+
+def test_bench_line_for_a_tree_workload():
+    """`bench.py --workload swimmer`: the bench's JSON contract (roofline incl. the counted-FLOP block, cpu_baseline)
+    for a tree-engine model."""
+    import json
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--workload", "swimmer", "--particles", "256",
+                          "--horizon", "8", "--steps", "3", "--warmup", "1", "--cpu-seconds", "1"],
+                         capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr[-2000:]
+    d = json.loads(out.stdout.strip().splitlines()[-1])
+    assert d["unit"] == "particle-steps/s" and d["n_gpus"] == 1 and d["vs_baseline"] is None and d["dtype"] == "f64"
+    assert d["roofline"]["kernel"].startswith("tree_rollout_kernel") and d["roofline"]["kernel_ms"] > 0
+    assert 0 < d["roofline"]["frac"] < 1 and d["roofline"]["valu"]["flops_per_particle_step"] > 1e4
+    assert d["cpu_baseline"]["kind"] == "port" and d["cpu_baseline"]["value"] > 0 and d["solver_failures"] == 0
