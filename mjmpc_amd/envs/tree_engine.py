@@ -128,6 +128,11 @@ class TreeRolloutEngine:
         self.set_env_state(dict(qp=nobs[0, 0, :nv], qv=nobs[0, 0, nv:2 * nv], target_pos=self._state["target_pos"]))
         return nobs[0, 0].copy(), float(rew[0, 0])
 
+    def randomize_dynamics(self, param_dict, base_seed=None):
+        """``SubprocVecEnv.randomize_dynamics`` (subproc_vec_env.py:304-312) is built for the arm engine (per-shard model
+        blocks, ``ArmRolloutEngine.randomize_dynamics``); the tree kernel shares one model block per workgroup."""
+        raise NotImplementedError("dynamics randomization runs on ArmRolloutEngine; the tree engine has one model per launch")
+
     def solver_failures(self):
         c = ctypes.c_uint32()
         _lib.check(self._lib.mjmpc_tree_solver_failures(self._h, ctypes.byref(c)))
