@@ -138,6 +138,10 @@ typedef struct mjmpc_tree_s* mjmpc_tree_t;
 int mjmpc_tree_create(const double* model_blob, int n_blob, int device, mjmpc_tree_t* out);
 int mjmpc_tree_destroy(mjmpc_tree_t h);
 int mjmpc_tree_dims(mjmpc_tree_t h, int* nv, int* nu, int* d_obs);
+/* SubprocVecEnv.randomize_dynamics for the tree engine (subproc_vec_env.py:304-312, gym_env_wrapper.py:367-416): n_shards
+ * model blocks [n_shards][MJMPC_TREE_BLOB_LEN] of the engine's topology; from then on shard i of a rollout (particles
+ * [i P / n_shards, (i + 1) P / n_shards), P % n_shards == 0) simulates block i. */
+int mjmpc_tree_set_shard_models(mjmpc_tree_t h, const double* model_blobs, int n_shards);
 /* synchronous on `stream` (the state is staged from pageable memory) */
 int mjmpc_tree_set_state(mjmpc_tree_t h, const double* qpos, const double* qvel, const double* target_pos, void* stream);
 int mjmpc_tree_rollout(mjmpc_tree_t h, int dtype, int64_t P, int H, const double* d_mean, const void* d_noise,

@@ -62,6 +62,7 @@ struct mjmpc_tree_s {
     int device = 0;
     int nv = 0, nu = 0, d_obs = 0, max_path = 0;
     bool full = false;              // slide joints, springs, friction cones, > 8 contact points or a medium: the full kernel
+    int n_shards = 1;               // > 1: model_f32 / model_f64 hold one block per shard
     float* model_f32 = nullptr;
     double* model_f64 = nullptr;
     double* state = nullptr;        // MJMPC_TREE_STATE_LEN
@@ -336,6 +337,13 @@ extern "C" int mjmpc_debug_tree_stats(mjmpc_tree_t h, unsigned long long* out24)
     return 0;
 }
 #endif
+static bool tree_blob_is_full(const double* blob, int nv) {
+    bool full = blob[mjmpc::T_ANY_FRICTION] != 0.0 || (int)blob[mjmpc::T_N_SPHERE] > 8 || blob[mjmpc::T_DENSITY] > 0.0 ||
+                blob[mjmpc::T_VISCOSITY] > 0.0;
+    for (int l = 0; l < nv; ++l) full = full || (int)blob[mjmpc::T_JTYPE + l] == 2 || blob[mjmpc::T_STIFFNESS + l] != 0.0;
+    return full;
+}
+
 int mjmpc_tree_create(const double* blob, int n_blob, int device, mjmpc_tree_t* out) {
     if (!blob || !out) return fail(MJMPC_E_BADARG, "null argument");
     if (n_blob != mjmpc::TREE_BLOB_LEN)
@@ -353,10 +361,7 @@ int mjmpc_tree_create(const double* blob, int n_blob, int device, mjmpc_tree_t* 
     h->nv = nv;
     h->nu = (int)blob[mjmpc::T_NU];
     h->d_obs = (int)blob[mjmpc::T_TASK] == 1 ? 2 * nv - (int)blob[mjmpc::T_OBS_SKIP] : 2 * nv + 6;
-    h->full = blob[mjmpc::T_ANY_FRICTION] != 0.0 || (int)blob[mjmpc::T_N_SPHERE] > 8 || blob[mjmpc::T_DENSITY] > 0.0 ||
-              blob[mjmpc::T_VISCOSITY] > 0.0;
-    for (int l = 0; l < nv; ++l)
-        h->full = h->full || (int)blob[mjmpc::T_JTYPE + l] == 2 || blob[mjmpc::T_STIFFNESS + l] != 0.0;
+    h->full = tree_blob_is_full(blob, nv);
     for (int l = 0; l < nv; ++l) h->max_path = std::max(h->max_path, (int)blob[mjmpc::T_DEPTH + l] + 1);
     std::vector<float> f32(blob, blob + n_blob);
     HIP_TRY(hipMalloc(&h->model_f32, sizeof(float) * n_blob));
@@ -368,6 +373,39 @@ int mjmpc_tree_create(const double* blob, int n_blob, int device, mjmpc_tree_t* 
     HIP_TRY(hipMemset(h->state, 0, sizeof(double) * MJMPC_TREE_STATE_LEN));
     HIP_TRY(hipMemset(h->diag, 0, MJMPC_TREE_DIAG_BYTES));
     *out = h;
+    return 0;
+}
+
+int mjmpc_tree_set_shard_models(mjmpc_tree_t h, const double* blobs, int n_shards) {
+    if (!h || !blobs || n_shards < 1) return fail(MJMPC_E_BADARG, "bad argument");
+    HIP_TRY(hipSetDevice(h->device));
+    const size_t L = (size_t)mjmpc::TREE_BLOB_LEN, n = (size_t)n_shards * L;
+    bool full = false;
+    for (int s = 0; s < n_shards; ++s) {
+        const double* b = blobs + (size_t)s * L;
+        // the topology (and with it the kernel instantiation and the launch shape) is the engine's: a shard may differ
+        // in masses, inertias, damping, contact radii and friction - what dynamics randomization edits
+        if ((int)b[mjmpc::T_NV] != h->nv || (int)b[mjmpc::T_NU] != h->nu || (int)b[mjmpc::T_N_SPHERE] > mjmpc::TREE_MAX_SPHERES)
+            return fail(MJMPC_E_BADMODEL, "shard %d does not have the engine's dimensions", s);
+        for (int l = 0; l < h->nv; ++l)
+            if ((int)b[mjmpc::T_DEPTH + l] + 1 > h->max_path)
+                return fail(MJMPC_E_BADMODEL, "shard %d has a different topology", s);
+        full = full || tree_blob_is_full(b, h->nv);
+    }
+    std::vector<float> f32(blobs, blobs + n);
+    HIP_TRY(hipDeviceSynchronize());
+    float* m32 = nullptr;
+    double* m64 = nullptr;
+    HIP_TRY(hipMalloc(&m32, sizeof(float) * n));
+    HIP_TRY(hipMalloc(&m64, sizeof(double) * n));
+    HIP_TRY(hipMemcpy(m32, f32.data(), sizeof(float) * n, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(m64, blobs, sizeof(double) * n, hipMemcpyHostToDevice));
+    hipFree(h->model_f32);
+    hipFree(h->model_f64);
+    h->model_f32 = m32;
+    h->model_f64 = m64;
+    h->n_shards = n_shards;
+    h->full = h->full || full;
     return 0;
 }
 
@@ -408,15 +446,16 @@ int mjmpc_tree_rollout(mjmpc_tree_t h, int dtype, int64_t P, int H, const double
                        void* d_costs, void* d_actions, void* d_obs, void* d_next_obs, void* stream) {
     if (!h || !d_mean || !d_costs) return fail(MJMPC_E_BADARG, "null argument");
     if (P < 0 || H < 0) return fail(MJMPC_E_BADARG, "negative size");
+    if (P % h->n_shards != 0) return fail(MJMPC_E_BADARG, "%lld particles do not divide into %d model shards", (long long)P, h->n_shards);
     HIP_TRY(hipSetDevice(h->device));
     hipStream_t s = (hipStream_t)stream;
     hipError_t e;
     if (dtype == MJMPC_F32)
-        e = mjmpc::launch_tree_rollout<float>(h->model_f32, h->max_path, h->full, h->nv, h->state, (long)P, H, h->nu, d_mean,
+        e = mjmpc::launch_tree_rollout<float>(h->model_f32, h->n_shards, h->max_path, h->full, h->nv, h->state, (long)P, H, h->nu, d_mean,
                                               (const float*)d_noise, (float*)d_costs, (float*)d_actions, (float*)d_obs,
                                               (float*)d_next_obs, h->diag, s);
     else if (dtype == MJMPC_F64)
-        e = mjmpc::launch_tree_rollout<double>(h->model_f64, h->max_path, h->full, h->nv, h->state, (long)P, H, h->nu, d_mean,
+        e = mjmpc::launch_tree_rollout<double>(h->model_f64, h->n_shards, h->max_path, h->full, h->nv, h->state, (long)P, H, h->nu, d_mean,
                                                (const double*)d_noise, (double*)d_costs, (double*)d_actions,
                                                (double*)d_obs, (double*)d_next_obs, h->diag, s);
     else

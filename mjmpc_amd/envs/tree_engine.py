@@ -28,6 +28,7 @@ from .arm_engine import _DT, _ptr, _torch
 
 class TreeRolloutEngine:
     def __init__(self, model, device=0, dtype="f64", num_shards=1):
+        self.raw = model if isinstance(model, RawModel) else None
         if isinstance(model, RawModel):
             model = compile_tree(model)
         if not isinstance(model, TreeModel):
@@ -51,6 +52,8 @@ class TreeRolloutEngine:
         self.action_lows, self.action_highs = model.ctrl_lo.copy(), model.ctrl_hi.copy()
         self.closed = False
         self._buf = {}
+        self.default_dyn_params = [dict() for _ in range(self.num_shards)]
+        self.randomized_dyn_params = [dict() for _ in range(self.num_shards)]
         self.reset()
 
     # ------------------------------------------------------------------ reference-shaped API
@@ -128,10 +131,57 @@ class TreeRolloutEngine:
         self.set_env_state(dict(qp=nobs[0, 0, :nv], qv=nobs[0, 0, nv:2 * nv], target_pos=self._state["target_pos"]))
         return nobs[0, 0].copy(), float(rew[0, 0])
 
-    def randomize_dynamics(self, param_dict, base_seed=None):
-        """``SubprocVecEnv.randomize_dynamics`` (subproc_vec_env.py:304-312) is built for the arm engine (per-shard model
-        blocks, ``ArmRolloutEngine.randomize_dynamics``); the tree kernel shares one model block per workgroup."""
-        raise NotImplementedError("dynamics randomization runs on ArmRolloutEngine; the tree engine has one model per launch")
+    def randomize_dynamics(self, param_dict, base_seed):
+        """``SubprocVecEnv.randomize_dynamics`` (subproc_vec_env.py:304-312), as ``ArmRolloutEngine.randomize_dynamics``:
+        shard i draws from ``np_random(base_seed + i*12345)`` a uniform value in ``m (1 +- noise)``, ``m = (1 + bias) *
+        default`` for every ``{param_id: {name: [noise_scale, bias_scale]}}`` entry (gym_env_wrapper.py:367-416) and from
+        then on simulates its own model block (``mjmpc_tree_set_shard_models``).  Supported: body_mass, body_inertia,
+        dof_damping, geom_size and geom_friction of colliding geoms; dof_frictionloss only with its zero default.
+        Returns (default_params, randomized_params), one dict per shard."""
+        if self.raw is None:
+            raise ValueError("randomize_dynamics needs the engine to be built from a RawModel")
+        from .seeding import np_random
+        blobs = []
+        for i in range(self.num_shards):
+            rng, _ = np_random(int(base_seed) + i * 12345)
+            defaults, rand = self.default_dyn_params[i], self.randomized_dyn_params[i]
+            for param_id, entries in param_dict.items():
+                for name, (noise_scale, bias_scale) in entries.items():
+                    cur = defaults.setdefault(param_id, {}).get(name)
+                    if cur is None:
+                        cur = defaults[param_id][name] = self._default_param(param_id, name)
+                    mean = (1.0 + bias_scale) * np.asarray(cur, float)
+                    rand.setdefault(param_id, {})[name] = rng.uniform(mean - mean * noise_scale, mean + mean * noise_scale)
+            if any(np.any(np.asarray(v) != 0) for v in rand.get("dof_frictionloss", {}).values()):
+                raise NotImplementedError("a non-zero dof_frictionloss adds friction-loss constraint rows, which the tree "
+                                          "kernel does not model")
+            ov = {k: v for k, v in rand.items() if k != "dof_frictionloss"}
+            blobs.append(compile_tree(self.raw, overrides=ov, base=self.model).blob)
+        blobs = np.ascontiguousarray(np.stack(blobs), np.float64)
+        _lib.check(self._lib.mjmpc_tree_set_shard_models(self._h, blobs.ctypes.data_as(_lib._dp), self.num_shards))
+        self.shard_blobs = blobs
+        return self.default_dyn_params, self.randomized_dyn_params
+
+    def _default_param(self, param_id, name):
+        from ..models.compile import principal_inertia
+        raw, m = self.raw, self.model
+        names = [b.name for b in raw.bodies]
+        if param_id == "body_mass":
+            return float(m.body_mass[names.index(name)])
+        if param_id == "body_inertia":
+            return principal_inertia(m.body_inertia[names.index(name)])[0]
+        if param_id == "dof_damping":
+            return float(next(b.joint.damping for b in raw.bodies if b.joint is not None and b.joint.name == name))
+        if param_id in ("geom_size", "geom_friction"):
+            g = next(g for b in raw.bodies for g in b.geoms if g.name == name)
+            if param_id == "geom_friction":
+                return np.array([g.friction, 0.005, 0.0001])          # (torsional / rolling: MuJoCo's defaults, unused here)
+            half = 0.5 * np.linalg.norm(np.asarray(g.b, float) - np.asarray(g.a, float)) if g.type == 2 else 0.0
+            return np.array([g.radius, half, 0.0])
+        if param_id == "dof_frictionloss":
+            next(b for b in raw.bodies if b.joint is not None and b.joint.name == name)     # unknown joint -> error
+            return 0.0
+        raise ValueError("Unknown dynamics field")
 
     def solver_failures(self):
         c = ctypes.c_uint32()

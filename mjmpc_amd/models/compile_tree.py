@@ -14,7 +14,7 @@ from dataclasses import dataclass
 
 import numpy as np
 
-from .compile import _geom_inertial, _quat2mat, _shift_inertia
+from .compile import _geom_inertial, _quat2mat, _shift_inertia, principal_inertia
 from .raw import GEOM_SPHERE, JOINT_HINGE, JOINT_SLIDE, TASK_FORWARD, TASK_REACH, RawModel
 
 TL = 32                     # lanes per particle
@@ -74,6 +74,7 @@ class TreeModel:
     parent: np.ndarray             # parent link of every link (-1: root)
     max_path: int                  # links on the longest root-to-leaf path
     body_mass: np.ndarray
+    body_inertia: np.ndarray       # per raw body, tensor about its centre of mass in the body frame
     body_invweight0: np.ndarray
     dof_invweight0: np.ndarray
     link_of_body: list
@@ -97,7 +98,13 @@ def _principal_frame(I):
     return w, V
 
 
-def compile_tree(raw: RawModel) -> TreeModel:
+def compile_tree(raw: RawModel, overrides=None, base: "TreeModel" = None) -> TreeModel:
+    """``overrides`` mimics run-time edits of the compiled MuJoCo model (dynamics randomization,
+    mjmpc/envs/gym_env_wrapper.py:367-416), as ``compile.compile_arm`` does: ``{"body_mass": {body: m}, "body_inertia":
+    {body: [I1, I2, I3]}, "dof_damping": {joint: d}, "geom_size": {geom: [r, half, ..]}, "geom_friction": {geom: [mu, ..]}}``.
+    Like MuJoCo, such edits do NOT recompute the qpos0 constants: pass the unperturbed model as ``base`` and its
+    dof / body invweight0 are kept."""
+    overrides = overrides or {}
     nb = len(raw.bodies)
     R0, p0 = [None] * nb, [None] * nb
     mass, ipos, inert = np.zeros(nb), np.zeros((nb, 3)), np.zeros((nb, 3, 3))
@@ -112,6 +119,11 @@ def compile_tree(raw: RawModel) -> TreeModel:
         if mass[i] > 0:
             ipos[i] = sum(m * c for m, c, _ in parts) / mass[i]
             inert[i] = sum(_shift_inertia(I, m, c - ipos[i]) for m, c, I in parts)
+        if b.name in overrides.get("body_mass", {}):
+            mass[i] = float(overrides["body_mass"][b.name])          # inertia / COM untouched, as in MuJoCo
+        if b.name in overrides.get("body_inertia", {}):
+            _, V = principal_inertia(inert[i])
+            inert[i] = V @ np.diag(np.asarray(overrides["body_inertia"][b.name], float)) @ V.T
 
     # ---- links: one per joint, welded bodies merged into the link that carries them ----------------------
     jointed = [i for i, b in enumerate(raw.bodies) if b.joint is not None]
@@ -188,7 +200,7 @@ def compile_tree(raw: RawModel) -> TreeModel:
         for k, (r, c) in enumerate([(0, 0), (1, 1), (2, 2), (0, 1), (0, 2), (1, 2)]):
             f["inertia"][k * TL + li] = I[r, c]
         f["armature"][li] = jt.armature
-        f["damping"][li] = jt.damping
+        f["damping"][li] = float(overrides.get("dof_damping", {}).get(jt.name, jt.damping))
         f["jtype"][li] = jt.type
         f["stiffness"][li], f["springref"][li] = jt.stiffness, jt.springref
         if raw.density > 0 or raw.viscosity > 0:
@@ -283,12 +295,17 @@ def compile_tree(raw: RawModel) -> TreeModel:
         for g in b.geoms:
             if not g.collide:
                 continue
+            size = overrides.get("geom_size", {}).get(g.name)       # run-time edit: [radius, half-length, -]
+            radius = float(np.ravel(size)[0]) if size is not None else g.radius
             if g.type == GEOM_SPHERE:
-                points.append((i, g, np.asarray(g.a, float), np.zeros(3)))
+                points.append((i, g, np.asarray(g.a, float), np.zeros(3), radius))
             else:
                 a, e = np.asarray(g.a, float), np.asarray(g.b, float)
                 u = (e - a) / np.linalg.norm(e - a)
-                points += [(i, g, e, u), (i, g, a, u)]
+                if size is not None:                                # the ends move with the half-length, the centre stays
+                    c, half = 0.5 * (a + e), float(np.ravel(size)[1])
+                    a, e = c - half * u, c + half * u
+                points += [(i, g, e, u, radius), (i, g, a, u, radius)]
     if raw.plane is not None and points:
         if len(points) > TREE_MAX_SPHERES:
             raise ValueError("tree kernel supports %d contact points (a capsule counts two)" % TREE_MAX_SPHERES)
@@ -297,18 +314,20 @@ def compile_tree(raw: RawModel) -> TreeModel:
         f["plane_n"][:] = n
         f["plane_d"][0] = n @ np.asarray(raw.plane.pos, float)
         f["n_sphere"][0] = len(points)
-        for s, (i, g, pos, u) in enumerate(points):
+        for s, (i, g, pos, u, radius) in enumerate(points):
             li = link_of_body[i]
             rec = f["spheres"][s * SPH_STRIDE:(s + 1) * SPH_STRIDE]
             rec[0] = li
             rec[1:4] = p0[i] + R0[i] @ pos - origin[li]
-            rec[4] = g.radius
+            rec[4] = radius
             rec[5] = max(raw.plane.margin, g.margin)            # MuJoCo: max of the two geom margins
-            rec[6] = 0.0 + body_iw[i]                           # the world body weighs 0
+            rec[6] = 0.0 + (base.body_invweight0[i] if base is not None else body_iw[i])     # the world body weighs 0
             condim = max(int(g.condim), int(raw.plane.condim))
             if condim not in (1, 3):
                 raise NotImplementedError("contacts are condim 1 (frictionless) or 3 (pyramidal cone), got %d" % condim)
-            rec[7] = max(g.friction, raw.plane.friction) if condim == 3 else 0.0
+            mu_g = overrides.get("geom_friction", {}).get(g.name)
+            mu_g = float(np.ravel(mu_g)[0]) if mu_g is not None else g.friction
+            rec[7] = max(mu_g, raw.plane.friction) if condim == 3 else 0.0
             rec[8:11] = R0[i] @ u
             rec[11] = depth[li] - 1                             # strict ancestors of the point's link
         f["any_friction"][0] = 1.0 if any(f["spheres"][s * SPH_STRIDE + 7] > 0 for s in range(len(points))) else 0.0
@@ -340,9 +359,12 @@ def compile_tree(raw: RawModel) -> TreeModel:
     if raw.task not in (TASK_REACH, TASK_FORWARD) or not 0 <= raw.obs_skip < nv:
         raise ValueError("unknown task / observation layout")
     d_obs = 2 * nv - raw.obs_skip if raw.task == TASK_FORWARD else 2 * nv + 6
+    if base is not None:            # run-time edit: MuJoCo keeps the constants mj_setConst computed at load time
+        f["dof_invweight0"][:] = base.field("dof_invweight0")
+        dof_iw, body_iw = base.dof_invweight0.copy(), base.body_invweight0.copy()
     blob = np.concatenate([f[name] for name, _ in TREE_LAYOUT]).astype(np.float64)
     assert blob.size == TREE_BLOB_LEN
     return TreeModel(blob=blob, nv=nv, nu=nu, d_obs=d_obs, timestep=raw.timestep, frame_skip=raw.frame_skip,
                      target_default=np.asarray(raw.target_pos, float), ctrl_lo=ctrl_lo, ctrl_hi=ctrl_hi, parent=parent,
                      task=int(raw.task), obs_skip=int(raw.obs_skip), max_path=int(depth.max()),
-                     body_mass=mass, body_invweight0=body_iw, dof_invweight0=dof_iw, link_of_body=link_of_body)
+                     body_mass=mass, body_inertia=inert, body_invweight0=body_iw, dof_invweight0=dof_iw, link_of_body=link_of_body)

@@ -124,6 +124,12 @@ class RefArm:
     def set_sphere_radius(self, idx, r):
         self._L.or_set_sphere_radius(ctypes.c_void_p(self._h), int(idx), ctypes.c_double(r))
 
+    def set_sphere_pos(self, idx, xyz):
+        self._L.or_set_sphere_pos(ctypes.c_void_p(self._h), int(idx), _p(_c(xyz)))
+
+    def set_sphere_mu(self, idx, mu):
+        self._L.or_set_sphere_mu(ctypes.c_void_p(self._h), int(idx), ctypes.c_double(mu))
+
     # -- compiled constants -------------------------------------------------
     def inertial(self):
         mass = np.zeros(self.nbody)

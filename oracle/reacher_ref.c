@@ -514,13 +514,11 @@ static void clamp_solimp(double *si) {         /* MuJoCo getsolparam: mjMINIMP =
     if (si[4] < 1) si[4] = 1;
 }
 
-static void set_const(OrModel *m) {
-    int nv = m->nv;
-    clamp_solimp(m->solimp);
-    clamp_solimp(m->solimp_l);
-    /* inertial frames: principal axes of every body's inertia tensor (body frame when it is diagonal there) and
-     * the box of equal inertia, MuJoCo mj_passive: box_i = sqrt(6 (I_j + I_k - I_i) / m) */
-    for (int b = 1; b < m->nbody; b++) {
+/* inertial frame of body b: principal axes of its inertia tensor (the body frame when it is diagonal there) and the box
+ * of equal inertia, MuJoCo mj_passive: box_i = sqrt(6 (I_j + I_k - I_i) / m); MuJoCo evaluates the box from the current
+ * body_mass / body_inertia, so run-time edits (dynamics randomization) refresh it */
+static void body_box(OrModel *m, int b) {
+    {
         double w[3], tr = m->inertia[b][0] + m->inertia[b][4] + m->inertia[b][8];
         double off = fabs(m->inertia[b][1]) + fabs(m->inertia[b][2]) + fabs(m->inertia[b][5]);
         static const double I3[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
@@ -536,6 +534,15 @@ static void set_const(OrModel *m) {
             m->ibox[b][i] = m->mass[b] > MJ_MINVAL ? sqrt(x / m->mass[b] * 6.0) : 0.0;
         }
     }
+}
+
+static void set_const(OrModel *m) {
+    int nv = m->nv;
+    clamp_solimp(m->solimp);
+    clamp_solimp(m->solimp_l);
+    /* inertial frames: principal axes of every body's inertia tensor (body frame when it is diagonal there) and
+     * the box of equal inertia, MuJoCo mj_passive: box_i = sqrt(6 (I_j + I_k - I_i) / m) */
+    for (int b = 1; b < m->nbody; b++) body_box(m, b);
     double q0[MAXV] = {0}, M[MAXV * MAXV];
     Kin k;
     kinematics(m, q0, &k);
@@ -855,8 +862,10 @@ void or_step(OrModel *m, double *q, double *v, const double *ctrl, double *site_
 /* ---------------------------------------------------------------- run-time model edits (dynamics randomization)
  * gym_env_wrapper.py:367-416 writes model.body_mass / body_inertia / dof_damping / geom_size in place;
  * MuJoCo does not re-run mj_setConst afterwards, so dof/body_invweight0 keep their load-time values. */
-void or_set_body_mass(OrModel *m, int body, double mass) { m->mass[body] = mass; }
-void or_set_body_inertia(OrModel *m, int body, const double *I9) { memcpy(m->inertia[body], I9, 72); }
+void or_set_body_mass(OrModel *m, int body, double mass) { m->mass[body] = mass; body_box(m, body); }
+void or_set_body_inertia(OrModel *m, int body, const double *I9) { memcpy(m->inertia[body], I9, 72); body_box(m, body); }
+void or_set_sphere_mu(OrModel *m, int s, double mu) { m->sph_mu[s] = mu; }
+void or_set_sphere_pos(OrModel *m, int s, const double *xyz) { memcpy(m->sph_pos[s], xyz, 24); }
 void or_set_dof_damping(OrModel *m, int dof, double d) { m->damping[dof] = d; }
 void or_set_sphere_radius(OrModel *m, int s, double r) { m->sph_r[s] = r; }
 
