@@ -1,4 +1,4 @@
-"""One-off randomized sweep at a larger scale than the test suite's (developer tool): python tools/big_sweep.py [trials]"""
+"""One-off randomized sweep at a larger scale than the test suite's (developer tool): python tests/big_sweep.py [trials]"""
 import sys, time
 import numpy as np
 sys.path.insert(0, "/root/repo")
