@@ -149,8 +149,8 @@ def main():
         run("cfg3 reacher_7dof-v0 CEM full-cov 16384xH32 elite 0.1 (one GPU)",
             lambda e, P, H: CEM(init_cov=1.0, base_action="null", elite_frac=0.1, step_size=1.0, gamma=1.0, beta=0.1,
                                 cov_type="full", filter_coeffs=[0.25, 0.8, 0.0], **kw(e, P, H)),
-            16384, 32, args.steps, args.warmup, args.dtype, "covariance changes every step: the Cholesky factor is a host "
-            "computation, so the iteration runs as eager launches")
+            16384, 32, args.steps, args.warmup, args.dtype, "covariance adapts every step on the device (moments, refit, "
+            "Cholesky): the iteration replays as one hipGraph")
         run("cfg4* DMD-MPC 65536xH64 on the 7-dof arm (pen-v0 assets absent)",
             lambda e, P, H: DMDMPC(init_cov=1.0, beta=0.1, base_action="null", lam=0.1, step_size=1.0, gamma=1.0,
                                    update_cov=False, cov_type="diagonal", filter_coeffs=[0.25, 0.8, 0.0], **kw(e, P, H)),
