@@ -109,8 +109,8 @@ def cpu_baseline(P, H, budget_s, raw=None, qpos=None, qvel=None, noise_scale=1.0
 
 
 def tree_workload(args):
-    """The same line for a tree-engine model: MPPI closed loop, the real env stepped by the engine at P = 1
-    with the state making a host round trip, eager launches."""
+    """The same line for a tree-engine model: MPPI closed loop, the real env kept on the device
+    (``TreeRolloutEngine.step_state``) and captured with the iteration in a hipGraph, as for the reacher."""
     import torch
     from mjmpc_amd.control import MPPI
     from mjmpc_amd.envs.arm_engine import make_device_rollout_fn
@@ -135,32 +135,32 @@ def tree_workload(args):
                 action_highs=eng.action_highs, filter_coeffs=[0.25, 0.8, 0.0], seed=123, noise_mode="device",
                 noise_dtype=args.dtype)
     ctrl.rollout_fn = make_device_rollout_fn(eng)
-    ctrl.set_sim_state_fn = eng.set_env_state
+    ctrl.set_sim_state_fn = lambda s: None           # the "real" env lives on the device (step_state)
     if env is not None:
-        env.reset(seed=123)
-        state = env.get_env_state()
+        env.reset(seed=123)                         # the reference's reset noise, then the engine owns the state
+        eng.set_env_state(env.get_env_state())
     else:
-        state = eng.reset()[0]
+        eng.reset()
+    graphed = not args.no_graph and ctrl._graph_capable()
+    if graphed:
+        ctrl.enable_graph(post_step=eng.step_state)
+    resident = {"resident": True}
 
-    def control_step(st):
-        a, _ = ctrl.optimize(st)
-        if env is not None:
-            env.step(a)
-            return env.get_env_state()
-        eng.set_env_state(st)
-        eng.step(a)
-        return eng.get_env_state()[0]
+    def control_step():
+        a, _ = ctrl.optimize(resident)
+        if not graphed:
+            eng.step_state(a)
 
     for _ in range(args.warmup):
-        state = control_step(state)
+        control_step()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        state = control_step(state)
+        control_step()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
+    state = eng.get_state_device()
     noise_t = ctrl.dev._rec[("noise", args.dtype)]
-    eng.set_env_state(state)
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     eng.rollout_device(P, H, ctrl.dev.mean, noise_t)
     e0.record()
@@ -195,7 +195,8 @@ def tree_workload(args):
            "dtype": args.dtype, "data": "synthetic",
            "config": {"workload": "%s MPPI lam=%g H=%d, %d particles, frame_skip %d, %d dofs, filter [0.25,0.8,0], closed loop "
                                   "(tree engine; not a BASELINE.json configuration)" % (name, lam, H, P, raw.frame_skip, m.nv),
-                      "noise": "device", "particles_per_gpu": P, "horizon": H, "ranks_seen": 1, "backend": None, "launch": "eager"},
+                      "noise": "device", "particles_per_gpu": P, "horizon": H, "ranks_seen": 1, "backend": None,
+                      "launch": "hipGraph replay" if (graphed and not getattr(ctrl, "graph_fallback", False)) else "eager"},
            "control_loop_hz": args.steps / dt,
            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                         "traffic": None, "traffic_source": None, "valu": valu, "alg_bytes_per_launch": b_alg * P * H,

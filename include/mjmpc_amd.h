@@ -146,6 +146,11 @@ int mjmpc_tree_set_shard_models(mjmpc_tree_t h, const double* model_blobs, int n
 int mjmpc_tree_set_state(mjmpc_tree_t h, const double* qpos, const double* qvel, const double* target_pos, void* stream);
 int mjmpc_tree_rollout(mjmpc_tree_t h, int dtype, int64_t P, int H, const double* d_mean, const void* d_noise,
                        void* d_costs, void* d_actions, void* d_obs, void* d_next_obs, void* stream);
+/* The "real" environment kept on the device, as mjmpc_arm_step_state (env.step of the reference's closed loop,
+ * examples/example_mpc.py:165-168): one env step from the engine's state with d_action (device float64[nu]), the state
+ * advanced in place; d_cost dtype[1], d_next_obs dtype[d_obs] or NULL.  mjmpc_tree_get_state reads qpos / qvel back. */
+int mjmpc_tree_step_state(mjmpc_tree_t h, int dtype, const double* d_action, void* d_cost, void* d_next_obs, void* stream);
+int mjmpc_tree_get_state(mjmpc_tree_t h, double* qpos, double* qvel, void* stream);
 int mjmpc_tree_solver_failures(mjmpc_tree_t h, uint32_t* count);
 
 /* rollout_fn over the reference's two analytic numpy envs (stateless; every pointer is a device

@@ -464,6 +464,35 @@ int mjmpc_tree_rollout(mjmpc_tree_t h, int dtype, int64_t P, int H, const double
     return 0;
 }
 
+int mjmpc_tree_step_state(mjmpc_tree_t h, int dtype, const double* d_action, void* d_cost, void* d_next_obs, void* stream) {
+    if (!h || !d_action || !d_cost) return fail(MJMPC_E_BADARG, "null argument");
+    HIP_TRY(hipSetDevice(h->device));
+    hipStream_t s = (hipStream_t)stream;
+    hipError_t e;
+    // one particle, one env step, no noise, shard 0's model; the state vector is advanced in place
+    if (dtype == MJMPC_F32)
+        e = mjmpc::launch_tree_rollout<float>(h->model_f32, 1, h->max_path, h->full, h->nv, h->state, 1, 1, h->nu, d_action, nullptr,
+                                              (float*)d_cost, nullptr, nullptr, (float*)d_next_obs, h->diag, s, h->state);
+    else if (dtype == MJMPC_F64)
+        e = mjmpc::launch_tree_rollout<double>(h->model_f64, 1, h->max_path, h->full, h->nv, h->state, 1, 1, h->nu, d_action, nullptr,
+                                               (double*)d_cost, nullptr, nullptr, (double*)d_next_obs, h->diag, s, h->state);
+    else
+        return fail(MJMPC_E_BADARG, "unknown dtype %d", dtype);
+    if (e != hipSuccess) return hip_fail(e, "tree_step_state launch");
+    return 0;
+}
+
+int mjmpc_tree_get_state(mjmpc_tree_t h, double* qpos, double* qvel, void* stream) {
+    if (!h || !qpos || !qvel) return fail(MJMPC_E_BADARG, "null argument");
+    HIP_TRY(hipSetDevice(h->device));
+    double st[MJMPC_TREE_STATE_LEN];
+    HIP_TRY(hipMemcpyAsync(st, h->state, sizeof(st), hipMemcpyDeviceToHost, (hipStream_t)stream));
+    HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
+    std::memcpy(qpos, st, sizeof(double) * h->nv);
+    std::memcpy(qvel, st + mjmpc::TL, sizeof(double) * h->nv);
+    return 0;
+}
+
 int mjmpc_tree_solver_failures(mjmpc_tree_t h, uint32_t* count) {
     if (!h || !count) return fail(MJMPC_E_BADARG, "null argument");
     HIP_TRY(hipSetDevice(h->device));

@@ -7,11 +7,12 @@ namespace mjmpc {
 // sphere/plane contact points, frictionless or with pyramidal friction cones); see tree_rollout.hip.  max_path = links
 // on the longest root-to-leaf path; full = the model needs the instantiation with slide joints / springs / friction
 // cones / more than 8 contact points / fluid forces (with nv <= 16 it runs 16 lanes per particle).  n_shards > 1: model holds one block per shard of P / n_shards
-// consecutive particles (dynamics randomization).  model: TREE_BLOB_LEN scalars of T; state: f64 [qpos(32) | qvel(32) | target(3)];
+// consecutive particles (dynamics randomization).  state_out (P = 1 only): the particle's final qpos / qvel are written
+// there in the layout of `state` (the device-resident real env).  model: TREE_BLOB_LEN scalars of T; state: f64 [qpos(32) | qvel(32) | target(3)];
 // mean f64 [H][A]; noise / cost / act / obs / nobs of T in the reference's C-order layouts (may be null except cost).
 template <typename T>
 hipError_t launch_tree_rollout(const T* model, int n_shards, int max_path, bool full, int nv, const double* state, long P, int H,
                                int A, const double* mean, const T* noise, T* cost, T* act, T* obs, T* nobs, unsigned* diag,
-                               hipStream_t stream);
+                               hipStream_t stream, double* state_out = nullptr);
 
 }  // namespace mjmpc

@@ -347,7 +347,7 @@ template <typename T, int DP, int NS, bool FRIC, int PL>
 __global__ __launch_bounds__(64 * wg_waves(DP, FRIC, sizeof(T), PL), min_waves(sizeof(T), DP, FRIC)) void tree_rollout_kernel(
     const T* __restrict__ model_all, const double* __restrict__ state, long P, long shard_size, int H, int A, const double* __restrict__ mean,
     const T* __restrict__ noise, T* __restrict__ cost, T* __restrict__ act, T* __restrict__ obs, T* __restrict__ nobs,
-    unsigned* diag) {
+    unsigned* diag, double* state_out) {
     constexpr int WG_WAVES = wg_waves(DP, FRIC, sizeof(T), PL);
     constexpr int PPW = 64 / PL;            // particles per wavefront
     constexpr int A_SF = a_sf(PL);
@@ -1007,6 +1007,12 @@ __global__ __launch_bounds__(64 * wg_waves(DP, FRIC, sizeof(T), PL), min_waves(s
         v_prev = v;
         for (int k = 0; k < 3; ++k) hand_prev[k] = hand[k];
     }
+    // the "real env" kept on the device (mjmpc_tree_step_state): particle 0 leaves its state where the next rollout
+    // reads it (the launch has one particle; `state` was read before the first step)
+    if (state_out && pid == 0 && dof) {
+        state_out[l] = (double)q;
+        state_out[TL + l] = (double)v;
+    }
 }
 
 }  // namespace
@@ -1014,8 +1020,9 @@ __global__ __launch_bounds__(64 * wg_waves(DP, FRIC, sizeof(T), PL), min_waves(s
 template <typename T>
 hipError_t launch_tree_rollout(const T* model, int n_shards, int max_path, bool full, int nv, const double* state, long P, int H,
                                int A, const double* mean, const T* noise, T* cost, T* act, T* obs, T* nobs, unsigned* diag,
-                               hipStream_t stream) {
+                               hipStream_t stream, double* state_out) {
     if (P <= 0 || H <= 0) return hipSuccess;
+    if (state_out && P != 1) return hipErrorInvalidValue;
     if (n_shards < 1 || P % n_shards != 0) return hipErrorInvalidValue;
     const long shard = P / n_shards;
 #define MJMPC_TREE_LAUNCH(DP_, NS_, FR_, PL_)                                                                         \
@@ -1024,7 +1031,7 @@ hipError_t launch_tree_rollout(const T* model, int n_shards, int max_path, bool 
         hipLaunchKernelGGL((tree_rollout_kernel<T, DP_, NS_, FR_, PL_>),                                              \
                            dim3((unsigned)((shard + per_wg - 1) / per_wg), (unsigned)n_shards),                       \
                            dim3(64 * wg_waves(DP_, FR_, sizeof(T), PL_)), 0, stream, model, state, P, shard, H, A,    \
-                           mean, noise, cost, act, obs, nobs, diag);                                                  \
+                           mean, noise, cost, act, obs, nobs, diag, state_out);                                       \
     }
     // hinge trees in air with up to 8 frictionless contact points keep the lean instantiation; slide joints, springs,
     // friction cones, more points or a medium take the full one (three Jacobians per point, 16 points, fluid forces),
@@ -1033,7 +1040,7 @@ hipError_t launch_tree_rollout(const T* model, int n_shards, int max_path, bool 
         if (max_path <= 8) MJMPC_TREE_LAUNCH(8, 8, false, 32)
         else if (max_path <= 16) MJMPC_TREE_LAUNCH(16, 8, false, 32)
         else MJMPC_TREE_LAUNCH(32, 8, false, 32)
-    } else if (nv <= 16 && !(sizeof(T) == 4 && P <= 4096)) {    // (f32 at <= 4096 particles: two half-empty waves per SIMD hide more latency)
+    } else if (nv <= 16 && !(sizeof(T) == 4 && P <= 4096 && P > 1)) {    // (f32 at <= 4096 particles: two half-empty waves per SIMD hide more latency)
         if (max_path <= 8) MJMPC_TREE_LAUNCH(8, 16, true, 16)
         else MJMPC_TREE_LAUNCH(16, 16, true, 16)
     } else {
@@ -1046,8 +1053,8 @@ hipError_t launch_tree_rollout(const T* model, int n_shards, int max_path, bool 
 }
 
 template hipError_t launch_tree_rollout<float>(const float*, int, int, bool, int, const double*, long, int, int, const double*,
-                                               const float*, float*, float*, float*, float*, unsigned*, hipStream_t);
+                                               const float*, float*, float*, float*, float*, unsigned*, hipStream_t, double*);
 template hipError_t launch_tree_rollout<double>(const double*, int, int, bool, int, const double*, long, int, int, const double*,
-                                                const double*, double*, double*, double*, double*, unsigned*, hipStream_t);
+                                                const double*, double*, double*, double*, double*, unsigned*, hipStream_t, double*);
 
 }  // namespace mjmpc

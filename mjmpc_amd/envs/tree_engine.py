@@ -131,6 +131,25 @@ class TreeRolloutEngine:
         self.set_env_state(dict(qp=nobs[0, 0, :nv], qv=nobs[0, 0, nv:2 * nv], target_pos=self._state["target_pos"]))
         return nobs[0, 0].copy(), float(rew[0, 0])
 
+    def step_state(self, action):
+        """Advance the engine state in place by one env step (the "real env" kept on the device, as
+        ``ArmRolloutEngine.step_state``).  ``action``: numpy (A,) or CUDA float64 tensor.  Returns (cost, next_obs)
+        device tensors; ``get_state_device()`` reads the state back."""
+        torch = _torch()
+        a = self._as_device(action, torch.float64, (self.d_action,))
+        cost = self._buffer("step_cost", (1,))
+        nobs = self._buffer("step_obs", (self.d_obs,))
+        _lib.check(self._lib.mjmpc_tree_step_state(self._h, self._code, _ptr(a), _ptr(cost), _ptr(nobs), self._stream()))
+        return cost, nobs
+
+    def get_state_device(self):
+        """The device-resident state as the task's state dictionary (one D2H copy; synchronises the stream)."""
+        qp, qv = np.zeros(self.model.nv), np.zeros(self.model.nv)
+        _lib.check(self._lib.mjmpc_tree_get_state(self._h, qp.ctypes.data_as(_lib._dp), qv.ctypes.data_as(_lib._dp), self._stream()))
+        if self.forward_task:
+            return dict(qpos=qp, qvel=qv)
+        return dict(qp=qp, qv=qv, qa=np.zeros(self.model.nv), target_pos=self._state["target_pos"].copy(), timestep=0)
+
     def randomize_dynamics(self, param_dict, base_seed):
         """``SubprocVecEnv.randomize_dynamics`` (subproc_vec_env.py:304-312), as ``ArmRolloutEngine.randomize_dynamics``:
         shard i draws from ``np_random(base_seed + i*12345)`` a uniform value in ``m (1 +- noise)``, ``m = (1 + bias) *

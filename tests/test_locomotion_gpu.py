@@ -264,3 +264,52 @@ def test_dynamics_randomization_per_shard_on_the_tree_engine():
     assert eng.solver_failures() == 0
     with pytest.raises(Exception):
         eng.rollout(62, H, mean, noise[:62])                    # particles must divide into the shards
+
+
+@pytest.mark.parametrize("name", ["swimmer", "cheetah"])
+def test_device_resident_env_step_and_graph_replay(name):
+    """``TreeRolloutEngine.step_state`` (the real env kept on the device) equals the env class's host-side step, and an
+    MPPI closed loop replayed as a hipGraph (iteration + env step captured) equals the eager one."""
+    from mjmpc_amd.control.mppi import MPPI
+    from mjmpc_amd.envs.arm_engine import make_device_rollout_fn
+    from mjmpc_amd.envs.locomotion_env import HalfCheetahEnv, SwimmerEnv
+    from mjmpc_amd.envs.tree_engine import TreeRolloutEngine
+    env = dict(swimmer=SwimmerEnv, cheetah=HalfCheetahEnv)[name]()
+    env.reset(seed=3)
+    eng = TreeRolloutEngine(env.raw, dtype="f64")
+    eng.set_env_state(env.get_env_state())
+    rs = np.random.RandomState(1)
+    for _ in range(6):
+        a = rs.uniform(-1.2, 1.2, env.d_action)
+        ob, r, _, _ = env.step(a)
+        cost, nobs = eng.step_state(a)
+        assert abs(float(cost.item()) + r) < 1e-12
+        np.testing.assert_allclose(nobs.cpu().numpy(), ob, rtol=0, atol=1e-12)
+    st = eng.get_state_device()
+    np.testing.assert_allclose(st["qpos"], env.get_env_state()["qpos"], rtol=0, atol=1e-12)
+    np.testing.assert_allclose(st["qvel"], env.get_env_state()["qvel"], rtol=0, atol=1e-12)
+
+    def closed_loop(graph):
+        e = TreeRolloutEngine(env.raw, dtype="f64")
+        c = MPPI(d_state=e.d_state, d_obs=e.d_obs, d_action=e.d_action, action_lows=e.action_lows, action_highs=e.action_highs,
+                 horizon=8, init_cov=0.3, base_action="null", lam=0.5, num_particles=256, step_size=1.0, alpha=1, gamma=1.0,
+                 n_iters=1, filter_coeffs=[0.25, 0.8, 0.0], seed=5, noise_mode="device", noise_dtype="f64")
+        c.rollout_fn = make_device_rollout_fn(e)
+        c.set_sim_state_fn = lambda s: None
+        e.set_env_state(dict(qpos=0.05 * np.arange(e.model.nv), qvel=np.zeros(e.model.nv)))
+        if graph:
+            assert c._graph_capable()
+            c.enable_graph(post_step=e.step_state)
+        acts = []
+        for _ in range(8):
+            a, _ = c.optimize({"resident": True})
+            acts.append(np.array(a))
+            if not graph:
+                e.step_state(a)
+        assert e.solver_failures() == 0
+        return np.array(acts), e.get_state_device()
+
+    a_e, s_e = closed_loop(False)
+    a_g, s_g = closed_loop(True)
+    np.testing.assert_allclose(a_g, a_e, rtol=0, atol=1e-9)
+    np.testing.assert_allclose(s_g["qpos"], s_e["qpos"], rtol=0, atol=1e-8)

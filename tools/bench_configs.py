@@ -59,8 +59,8 @@ def _run_arm(name, make, P, H, steps, warmup, dtype, note):
 
 
 def run_tree(name, make, P, H, steps, warmup, dtype, note, raw_fn=None, env_cls=None):
-    """The same loop on the tree engine (no device-resident "real env": the state makes a host round trip).  With
-    `env_cls` (a locomotion model) the real environment is that class, which owns its stepping engine."""
+    """The same loop on the tree engine (the real env kept on the device and captured with the iteration).  With `env_cls`
+    (a locomotion model) that class draws the reference's reset noise for the start state."""
     import torch
     from mjmpc_amd.envs.arm_engine import make_device_rollout_fn
     from mjmpc_amd.envs.tree_engine import TreeRolloutEngine
@@ -69,29 +69,34 @@ def run_tree(name, make, P, H, steps, warmup, dtype, note, raw_fn=None, env_cls=
     eng = TreeRolloutEngine(raw, dtype=dtype)
     ctrl = make(eng, P, H)
     ctrl.rollout_fn = make_device_rollout_fn(eng)
-    ctrl.set_sim_state_fn = eng.set_env_state
+    ctrl.set_sim_state_fn = lambda s: None               # the real env lives on the device (TreeRolloutEngine.step_state)
     env = env_cls(dtype=dtype) if env_cls else None
     if env is not None:
         env.reset(seed=123)
-    state = env.get_env_state() if env is not None else eng.reset()[0]
+        eng.set_env_state(env.get_env_state())
+    else:
+        eng.reset()
+    graphed = ctrl._graph_capable()
+    if graphed:
+        ctrl.enable_graph(post_step=eng.step_state)
+    resident = {"resident": True}
 
-    def step(st):
-        a, _ = ctrl.optimize(st)
-        if env is not None:
-            nobs, _, _, _ = env.step(a)
-            return env.get_env_state(), nobs
-        eng.set_env_state(st)
-        nobs, _ = eng.step(a)
-        return eng.get_env_state()[0], nobs
+    def step():
+        a, _ = ctrl.optimize(resident)
+        if not graphed:
+            eng.step_state(a)
 
     for _ in range(warmup):
-        state, _ = step(state)
+        step()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(steps):
-        state, nobs = step(state)
+        step()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
+    state = eng.get_state_device()
+    _, nobs_t = eng.step_state(np.zeros(eng.d_action))
+    nobs = nobs_t.cpu().numpy()
     # the rollout kernel alone, back to back on the run's own buffers
     noise_t = ctrl.dev._rec[("noise", dtype)]
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -105,7 +110,7 @@ def run_tree(name, make, P, H, steps, warmup, dtype, note, raw_fn=None, env_cls=
     out = {"config": name, "particles": P, "horizon": H, "dtype": dtype, "steps": steps,
            "ms_per_step": dt / steps * 1e3, "control_loop_hz": steps / dt,
            "particle_steps_per_s": P * H * ctrl.n_iters * steps / dt, "rollout_kernel_ms": kern_ms,
-           "launch": "eager launches", "dofs": nv, "frame_skip": raw.frame_skip,
+           "launch": "hipGraph replay" if graphed else "eager launches", "dofs": nv, "frame_skip": raw.frame_skip,
            "solver_failures": eng.solver_failures(), "note": note}
     if env is not None:
         out["forward_progress_m"] = float(state["qpos"][0])
