@@ -132,8 +132,9 @@ int mjmpc_arm_step_state(mjmpc_arm_t h, int dtype, const double* d_action, void*
  * Same call shapes and reference counterparts as the arm engine (subproc_vec_env.py:91-111, 128-186, 235-251);
  * target_pos is ignored by task 1.                                                                                  */
 #define MJMPC_TREE_BLOB_LEN 2854
-/* Device state vector of a tree engine: qpos[32] | qvel[32] | target_pos[3]  (float64). */
-#define MJMPC_TREE_STATE_LEN 67
+/* Device state vector of a tree engine: qpos[32] | qvel[32] | target_pos[3] | site of the fresh observation[3]  (float64;
+ * the last three are filled by mjmpc_tree_rollout_cl). */
+#define MJMPC_TREE_STATE_LEN 70
 typedef struct mjmpc_tree_s* mjmpc_tree_t;
 int mjmpc_tree_create(const double* model_blob, int n_blob, int device, mjmpc_tree_t* out);
 int mjmpc_tree_destroy(mjmpc_tree_t h);
@@ -151,6 +152,10 @@ int mjmpc_tree_rollout(mjmpc_tree_t h, int dtype, int64_t P, int H, const double
  * advanced in place; d_cost dtype[1], d_next_obs dtype[d_obs] or NULL.  mjmpc_tree_get_state reads qpos / qvel back. */
 int mjmpc_tree_step_state(mjmpc_tree_t h, int dtype, const double* d_action, void* d_cost, void* d_next_obs, void* stream);
 int mjmpc_tree_get_state(mjmpc_tree_t h, double* qpos, double* qvel, void* stream);
+/* rollout(mode="closed_loop_linear") (gym_env_wrapper.py:135-136) as mjmpc_arm_rollout_cl: d_weights float64 [(d_obs + 1)][nu],
+ * the nominal action of a step is weights' [observation the step starts from; 1]. */
+int mjmpc_tree_rollout_cl(mjmpc_tree_t h, int dtype, int64_t P, int H, const double* d_weights, const void* d_noise,
+                          void* d_costs, void* d_actions, void* d_obs, void* d_next_obs, void* stream);
 int mjmpc_tree_solver_failures(mjmpc_tree_t h, uint32_t* count);
 
 /* rollout_fn over the reference's two analytic numpy envs (stateless; every pointer is a device

@@ -54,6 +54,8 @@ struct mjmpc_arm_s {
     hipEvent_t staged[4] = {nullptr, nullptr, nullptr, nullptr};
     int stage_next = 0;
     int n_shards = 1;               // > 1: model_f32 / model_f64 hold one block per shard
+    double* zero_action = nullptr;  // [32] zeros (the kinematics-only launch of mjmpc_tree_rollout_cl)
+    double* scratch = nullptr;      // [8] a place for that launch's cost
     double* shard_states = nullptr; // n_state_shards state vectors (per-shard start states)
     int n_state_shards = 0;
 };
@@ -63,6 +65,8 @@ struct mjmpc_tree_s {
     int nv = 0, nu = 0, d_obs = 0, max_path = 0;
     bool full = false;              // slide joints, springs, friction cones, > 8 contact points or a medium: the full kernel
     int n_shards = 1;               // > 1: model_f32 / model_f64 hold one block per shard
+    double* zero_action = nullptr;  // [32] zeros (the kinematics-only launch of mjmpc_tree_rollout_cl)
+    double* scratch = nullptr;      // [8] a place for that launch's cost
     float* model_f32 = nullptr;
     double* model_f64 = nullptr;
     double* state = nullptr;        // MJMPC_TREE_STATE_LEN
@@ -372,6 +376,9 @@ int mjmpc_tree_create(const double* blob, int n_blob, int device, mjmpc_tree_t* 
     HIP_TRY(hipMemcpy(h->model_f64, blob, sizeof(double) * n_blob, hipMemcpyHostToDevice));
     HIP_TRY(hipMemset(h->state, 0, sizeof(double) * MJMPC_TREE_STATE_LEN));
     HIP_TRY(hipMemset(h->diag, 0, MJMPC_TREE_DIAG_BYTES));
+    HIP_TRY(hipMalloc(&h->zero_action, sizeof(double) * 40));
+    HIP_TRY(hipMemset(h->zero_action, 0, sizeof(double) * 40));
+    h->scratch = h->zero_action + 32;
     *out = h;
     return 0;
 }
@@ -416,6 +423,7 @@ int mjmpc_tree_destroy(mjmpc_tree_t h) {
     hipFree(h->model_f64);
     hipFree(h->state);
     hipFree(h->diag);
+    hipFree(h->zero_action);
     delete h;
     return 0;
 }
@@ -461,6 +469,38 @@ int mjmpc_tree_rollout(mjmpc_tree_t h, int dtype, int64_t P, int H, const double
     else
         return fail(MJMPC_E_BADARG, "unknown dtype %d", dtype);
     if (e != hipSuccess) return hip_fail(e, "tree_rollout launch");
+    return 0;
+}
+
+int mjmpc_tree_rollout_cl(mjmpc_tree_t h, int dtype, int64_t P, int H, const double* d_weights, const void* d_noise,
+                          void* d_costs, void* d_actions, void* d_obs, void* d_next_obs, void* stream) {
+    if (!h || !d_weights || !d_costs) return fail(MJMPC_E_BADARG, "null argument");
+    if (P < 0 || H < 0) return fail(MJMPC_E_BADARG, "negative size");
+    if (P % h->n_shards != 0) return fail(MJMPC_E_BADARG, "%lld particles do not divide into %d model shards", (long long)P, h->n_shards);
+    HIP_TRY(hipSetDevice(h->device));
+    hipStream_t s = (hipStream_t)stream;
+    hipError_t e;
+    // the first action depends on the fresh observation, whose tracked site comes out of a kinematics pass: a
+    // one-particle, one-step launch (its cost lands in the workspace and is discarded) leaves it in the state vector
+    double* site0 = h->state + 2 * mjmpc::TL + 3;
+    if (dtype == MJMPC_F32) {
+        e = mjmpc::launch_tree_rollout<float>(h->model_f32, 1, h->max_path, h->full, h->nv, h->state, 1, 1, h->nu, h->zero_action, nullptr,
+                                              (float*)h->scratch, nullptr, nullptr, nullptr, h->diag, s, nullptr, nullptr, site0);
+        if (e == hipSuccess)
+            e = mjmpc::launch_tree_rollout<float>(h->model_f32, h->n_shards, h->max_path, h->full, h->nv, h->state, (long)P, H, h->nu,
+                                                  d_weights, (const float*)d_noise, (float*)d_costs, (float*)d_actions, (float*)d_obs,
+                                                  (float*)d_next_obs, h->diag, s, nullptr, d_weights, nullptr);
+    } else if (dtype == MJMPC_F64) {
+        e = mjmpc::launch_tree_rollout<double>(h->model_f64, 1, h->max_path, h->full, h->nv, h->state, 1, 1, h->nu, h->zero_action, nullptr,
+                                               (double*)h->scratch, nullptr, nullptr, nullptr, h->diag, s, nullptr, nullptr, site0);
+        if (e == hipSuccess)
+            e = mjmpc::launch_tree_rollout<double>(h->model_f64, h->n_shards, h->max_path, h->full, h->nv, h->state, (long)P, H, h->nu,
+                                                   d_weights, (const double*)d_noise, (double*)d_costs, (double*)d_actions,
+                                                   (double*)d_obs, (double*)d_next_obs, h->diag, s, nullptr, d_weights, nullptr);
+    } else {
+        return fail(MJMPC_E_BADARG, "unknown dtype %d", dtype);
+    }
+    if (e != hipSuccess) return hip_fail(e, "tree_rollout_cl launch");
     return 0;
 }
 

@@ -8,11 +8,14 @@ namespace mjmpc {
 // on the longest root-to-leaf path; full = the model needs the instantiation with slide joints / springs / friction
 // cones / more than 8 contact points / fluid forces (with nv <= 16 it runs 16 lanes per particle).  n_shards > 1: model holds one block per shard of P / n_shards
 // consecutive particles (dynamics randomization).  state_out (P = 1 only): the particle's final qpos / qvel are written
-// there in the layout of `state` (the device-resident real env).  model: TREE_BLOB_LEN scalars of T; state: f64 [qpos(32) | qvel(32) | target(3)];
+// there in the layout of `state` (the device-resident real env).  clw: closed_loop_linear weights f64 [(d_obs + 1)][A]
+// instead of `mean` (the fresh observation's site is read from state[2 * 32 + 3 ...], which a P = 1 launch with site_out
+// pointing there provides).  model: TREE_BLOB_LEN scalars of T; state: f64 [qpos(32) | qvel(32) | target(3)];
 // mean f64 [H][A]; noise / cost / act / obs / nobs of T in the reference's C-order layouts (may be null except cost).
 template <typename T>
 hipError_t launch_tree_rollout(const T* model, int n_shards, int max_path, bool full, int nv, const double* state, long P, int H,
                                int A, const double* mean, const T* noise, T* cost, T* act, T* obs, T* nobs, unsigned* diag,
-                               hipStream_t stream, double* state_out = nullptr);
+                               hipStream_t stream, double* state_out = nullptr, const double* clw = nullptr,
+                               double* site_out = nullptr);
 
 }  // namespace mjmpc

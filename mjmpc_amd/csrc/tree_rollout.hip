@@ -347,7 +347,7 @@ template <typename T, int DP, int NS, bool FRIC, int PL>
 __global__ __launch_bounds__(64 * wg_waves(DP, FRIC, sizeof(T), PL), min_waves(sizeof(T), DP, FRIC)) void tree_rollout_kernel(
     const T* __restrict__ model_all, const double* __restrict__ state, long P, long shard_size, int H, int A, const double* __restrict__ mean,
     const T* __restrict__ noise, T* __restrict__ cost, T* __restrict__ act, T* __restrict__ obs, T* __restrict__ nobs,
-    unsigned* diag, double* state_out) {
+    unsigned* diag, double* state_out, const double* __restrict__ clw, double* site_out) {
     constexpr int WG_WAVES = wg_waves(DP, FRIC, sizeof(T), PL);
     constexpr int PPW = 64 / PL;            // particles per wavefront
     constexpr int A_SF = a_sf(PL);
@@ -418,14 +418,35 @@ __global__ __launch_bounds__(64 * wg_waves(DP, FRIC, sizeof(T), PL), min_waves(s
     int lim_mem = 0;                // inst | act << 1 of my limit row in the previous substep
     unsigned cinst_mem = 0;         // contact points of the previous substep ...
     mask_t cact_mem = 0;            // ... and which of their rows were active
+    // closed_loop_linear (gym_env_wrapper.py:135-136): the first action needs the site of the fresh observation, which
+    // a one-particle launch left in the state vector beforehand (site_out below, mjmpc_tree_rollout_cl)
     T hand_prev[3] = {T(0), T(0), T(0)}, q_prev = q, v_prev = v;
+    if (clw)
+        for (int k = 0; k < 3; ++k) hand_prev[k] = (T)state[2 * TL + 3 + k];
     TreeClock clk;
     clk.start(diag, blockIdx.x == 0 && threadIdx.x == 0);
 
     for (int t = 0; t < H; ++t) {
         T u = T(0);
-        if (has_u) {
+        if (clw) {
+            // mean_act = W' [obs; 1] with the observation this step starts from (gym_env_wrapper.py:135-136): every
+            // lane weighs the entries it holds, one 32-lane sum per action
+            const int iq = task == 1 ? l - obs_skip : l, iv = task == 1 ? nv - obs_skip + l : nv + l;
+            for (int a = 0; a < A; ++a) {
+                T part = T(0);
+                if (dof) {
+                    if (iq >= 0) part += (T)clw[iq * A + a] * q;
+                    part += (T)clw[iv * A + a] * v;
+                }
+                if (task == 0 && l < 3)
+                    part += (T)clw[(2 * nv + l) * A + a] * hand_prev[l] + (T)clw[(2 * nv + 3 + l) * A + a] * (hand_prev[l] - tgt[l]);
+                const T sa = sum_lanes<PL>(part) + (T)clw[dobs * A + a];
+                if (l == a) u = sa;
+            }
+        } else if (has_u) {
             u = (T)mean[t * A + l];
+        }
+        if (has_u) {
             if (noise && live) u += noise[(pid * H + t) * A + l];
             if (act && live) act[(pid * H + t) * A + l] = u;        // unclipped (gym_env_wrapper.py:151)
         }
@@ -522,8 +543,10 @@ __global__ __launch_bounds__(64 * wg_waves(DP, FRIC, sizeof(T), PL), min_waves(s
             TSYNC();
             if (sub == frame_skip - 1 || (t == 0 && sub == 0))
                 for (int k = 0; k < 3; ++k) hand[k] = X[A_MISC + k];
-            if (t == 0 && sub == 0)
+            if (t == 0 && sub == 0) {
                 for (int k = 0; k < 3; ++k) hand_prev[k] = hand[k];     // fresh observation after set_env_state
+                if (site_out && pid == 0 && l < 3) site_out[l] = (double)hand[l];
+            }
 
             // ---- 2. world-frame quantities of my link, about the world origin
             clk.mark(0);
@@ -1020,9 +1043,9 @@ __global__ __launch_bounds__(64 * wg_waves(DP, FRIC, sizeof(T), PL), min_waves(s
 template <typename T>
 hipError_t launch_tree_rollout(const T* model, int n_shards, int max_path, bool full, int nv, const double* state, long P, int H,
                                int A, const double* mean, const T* noise, T* cost, T* act, T* obs, T* nobs, unsigned* diag,
-                               hipStream_t stream, double* state_out) {
+                               hipStream_t stream, double* state_out, const double* clw, double* site_out) {
     if (P <= 0 || H <= 0) return hipSuccess;
-    if (state_out && P != 1) return hipErrorInvalidValue;
+    if ((state_out || site_out) && P != 1) return hipErrorInvalidValue;
     if (n_shards < 1 || P % n_shards != 0) return hipErrorInvalidValue;
     const long shard = P / n_shards;
 #define MJMPC_TREE_LAUNCH(DP_, NS_, FR_, PL_)                                                                         \
@@ -1031,7 +1054,7 @@ hipError_t launch_tree_rollout(const T* model, int n_shards, int max_path, bool 
         hipLaunchKernelGGL((tree_rollout_kernel<T, DP_, NS_, FR_, PL_>),                                              \
                            dim3((unsigned)((shard + per_wg - 1) / per_wg), (unsigned)n_shards),                       \
                            dim3(64 * wg_waves(DP_, FR_, sizeof(T), PL_)), 0, stream, model, state, P, shard, H, A,    \
-                           mean, noise, cost, act, obs, nobs, diag, state_out);                                       \
+                           mean, noise, cost, act, obs, nobs, diag, state_out, clw, site_out);                        \
     }
     // hinge trees in air with up to 8 frictionless contact points keep the lean instantiation; slide joints, springs,
     // friction cones, more points or a medium take the full one (three Jacobians per point, 16 points, fluid forces),
@@ -1053,8 +1076,8 @@ hipError_t launch_tree_rollout(const T* model, int n_shards, int max_path, bool 
 }
 
 template hipError_t launch_tree_rollout<float>(const float*, int, int, bool, int, const double*, long, int, int, const double*,
-                                               const float*, float*, float*, float*, float*, unsigned*, hipStream_t, double*);
+                                               const float*, float*, float*, float*, float*, unsigned*, hipStream_t, double*, const double*, double*);
 template hipError_t launch_tree_rollout<double>(const double*, int, int, bool, int, const double*, long, int, int, const double*,
-                                                const double*, double*, double*, double*, double*, unsigned*, hipStream_t, double*);
+                                                const double*, double*, double*, double*, double*, unsigned*, hipStream_t, double*, const double*, double*);
 
 }  // namespace mjmpc

@@ -104,20 +104,22 @@ class TreeRolloutEngine:
         return obs, -costs, act, done, info, nobs
 
     def rollout_device(self, num_particles, horizon, mean, noise, mode="open_loop", want_obs=False, want_actions=True):
-        if mode != "open_loop":
-            raise ValueError("unsupported rollout mode %r (the tree engine runs 'open_loop')" % (mode,))
+        if mode not in ("open_loop", "closed_loop_linear"):
+            raise ValueError("unsupported rollout mode %r ('open_loop' or 'closed_loop_linear')" % (mode,))
         if num_particles % self.num_shards != 0:
             raise AssertionError("Number of particles must be divisible by number of shards")
         torch = _torch()
         P, H, A = int(num_particles), int(horizon), self.d_action
-        mean_d = self._as_device(mean, torch.float64, (H, A))
+        closed = mode == "closed_loop_linear"
+        mean_d = self._as_device(mean, torch.float64, (self.d_obs + 1, A) if closed else (H, A))
         noise_d = None if noise is None else self._as_device(noise, self._tdtype, (P, H, A))
         costs = self._buffer("costs", (P, H))
         act = self._buffer("act", (P, H, A)) if want_actions else None
         obs = self._buffer("obs", (P, H, self.d_obs)) if want_obs else None
         nobs = self._buffer("nobs", (P, H, self.d_obs)) if want_obs else None
-        _lib.check(self._lib.mjmpc_tree_rollout(self._h, self._code, P, H, _ptr(mean_d), _ptr(noise_d), _ptr(costs),
-                                                _ptr(act), _ptr(obs), _ptr(nobs), self._stream()))
+        fn = self._lib.mjmpc_tree_rollout_cl if closed else self._lib.mjmpc_tree_rollout
+        _lib.check(fn(self._h, self._code, P, H, _ptr(mean_d), _ptr(noise_d), _ptr(costs), _ptr(act), _ptr(obs), _ptr(nobs),
+                      self._stream()))
         return costs, act, obs, nobs
 
     def step(self, action):

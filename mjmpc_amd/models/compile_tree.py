@@ -44,7 +44,7 @@ TREE_LAYOUT = [
                                     # (-1 terminates): the rows that update mine, round by round
 ]
 TREE_BLOB_LEN = sum(n for _, n in TREE_LAYOUT)
-TREE_STATE_LEN = 2 * TL + 3           # qpos[32] | qvel[32] | target_pos[3]
+TREE_STATE_LEN = 2 * TL + 6           # qpos[32] | qvel[32] | target_pos[3] | fresh site[3]
 
 
 def _offsets():

@@ -227,3 +227,44 @@ def test_hand_with_friction_runs_the_full_kernel_at_32_lanes():
     np.testing.assert_allclose(rew, o[1], rtol=1e-9, atol=1e-9)
     np.testing.assert_allclose(nobs, o[4], rtol=0, atol=1e-9)
     assert eng.solver_failures() == 0
+
+
+@pytest.mark.parametrize("model", ["hand", "cheetah", "swimmer"])
+def test_closed_loop_linear_mode_on_the_tree_engine(model):
+    """``rollout(mode="closed_loop_linear")`` (gym_env_wrapper.py:135-136) on the tree engine: the nominal action of a step
+    is weights' [observation the step starts from; 1] - reach-task observation incl. the lagging site on the hand, the
+    forward task's [qpos[skip:], qvel] on the locomotion models - against the oracle's closed-loop rollout."""
+    from mjmpc_amd.envs.tree_engine import TreeRolloutEngine
+    from mjmpc_amd.models.half_cheetah import half_cheetah_raw
+    from mjmpc_amd.models.hand24 import hand24_raw
+    from mjmpc_amd.models.swimmer import swimmer_raw
+    from oracle.physics_ref import RefArm
+    raw = dict(hand=hand24_raw, cheetah=half_cheetah_raw, swimmer=swimmer_raw)[model]()
+    eng, ref = TreeRolloutEngine(raw, dtype="f64"), RefArm(raw.to_flat())
+    nv, A, dobs = eng.model.nv, eng.d_action, eng.d_obs
+    rs = np.random.RandomState(21)
+    P, H = 37, 6
+    W = 0.15 * rs.standard_normal((dobs + 1, A))
+    noise = 0.3 * rs.standard_normal((P, H, A))
+    if model == "hand":
+        st = dict(STATES[1], target_pos=np.array(raw.target_pos))
+        q0, v0, tgt = st["qp"], st["qv"], st["target_pos"]
+    else:
+        q0, v0, tgt = 0.1 * rs.standard_normal(nv), 0.5 * rs.standard_normal(nv), np.zeros(3)
+        if model == "cheetah":
+            q0[1] = -0.1
+        st = dict(qpos=q0, qvel=v0)
+    eng.set_env_state(st)
+    obs, rew, act, done, info, nobs = eng.rollout(P, H, W, noise, "closed_loop_linear")
+    o_obs, o_rew, o_act, _, o_nobs = ref.rollout(q0, v0, tgt, W, noise, mode="closed_loop_linear")
+    np.testing.assert_allclose(act, o_act, rtol=0, atol=1e-9)
+    np.testing.assert_allclose(rew, o_rew, rtol=1e-9, atol=1e-9)
+    np.testing.assert_allclose(obs, o_obs, rtol=0, atol=1e-9)
+    np.testing.assert_allclose(nobs, o_nobs, rtol=0, atol=1e-9)
+    assert np.abs(act - noise).max() > 1e-2                 # the feedback term is really there
+    # mean-only closed-loop rollout (noise None), and the open-loop mode is untouched by the state vector's new tail
+    obs1, rew1, act1, _, _, _ = eng.rollout(1, H, W, None, "closed_loop_linear")
+    o1 = ref.rollout(q0, v0, tgt, W, None, mode="closed_loop_linear", horizon=H)
+    np.testing.assert_allclose(rew1, o1[1], rtol=1e-9, atol=1e-9)
+    with pytest.raises(ValueError):
+        eng.rollout(P, H, W, noise, "closed_loop_quadratic")
