@@ -1063,12 +1063,19 @@ hipError_t launch_arm_rollout(const T* model, const double* state, long P, int H
     // MJMPC_ARM_DUO=0/1 overrides the choice (developer switch for A/B timing).
     static const int duo_env = [] { const char* e = getenv("MJMPC_ARM_DUO"); return e ? atoi(e) : -1; }();
     const bool duo = !fuse.clw && (duo_env >= 0 ? duo_env != 0 : 2L * grid <= simds);
+    // between half a wave and one wave per SIMD (4096 < P <= 8192 on 256 CUs) the one-wave kernel is capped at ONE
+    // resident wave per SIMD as well: inside the replayed control iteration the dispatcher otherwise doubles waves up on
+    // some SIMDs while others idle (8192 particles: 361 us per launch in the loop against 280 us back to back)
+    static const int one_env = [] { const char* e = getenv("MJMPC_ARM_ONE"); return e ? atoi(e) : -1; }();
+    const bool one_per_simd = !duo && !fuse.clw && (one_env >= 0 ? one_env != 0 : (long)grid <= simds);
 #define MJMPC_LAUNCH_W(STEP_, CL_, W_, DUO_)                                                                        \
     hipLaunchKernelGGL((arm_rollout_kernel<T, STEP_, CL_, W_, DUO_>), dim3(grid), dim3(DUO_ ? 128 : 64), 0, stream,  \
                        model, state, P, H, A, mean, noise, cost, act, obs, nobs, state_out, diag, fuse)
 #define MJMPC_LAUNCH(STEP_, CL_)                                 \
     do {                                                         \
-        if constexpr (sizeof(T) == 8) {                          \
+        if (one_per_simd) {                                      \
+            MJMPC_LAUNCH_W(STEP_, CL_, 1, false);                \
+        } else if constexpr (sizeof(T) == 8) {                   \
             MJMPC_LAUNCH_W(STEP_, CL_, 2, false);                \
         } else {                                                 \
             if (cap == 2) MJMPC_LAUNCH_W(STEP_, CL_, 2, false);  \
