@@ -102,8 +102,14 @@ def cpu_baseline(P, H, budget_s, raw=None, qpos=None, qvel=None, noise_scale=1.0
             quota = "; cgroup cpu.max = %s" % f.read().strip()
     except OSError:
         pass
+    cpu_model = ""
+    try:
+        with open("/proc/cpuinfo") as f:
+            cpu_model = next((ln.split(":", 1)[1].strip() for ln in f if ln.startswith("model name")), "")
+    except OSError:
+        pass
     return {"value": n * H / dt, "unit": "particle-steps/s", "cores": cores, "kind": "port",
-            "single_thread_value": n1 * H / dt1,
+            "single_thread_value": n1 * H / dt1, "cpu_model": cpu_model, "visible_cpus": len(os.sched_getaffinity(0)),
             "sample": "%d particles x H=%d rollouts of the same workload (OpenMP over particles, %d threads), %.1f s; "
                       "one thread: %d particles in %.1f s%s" % (n, H, cores, dt, n1, dt1, quota)}
 
