@@ -143,8 +143,13 @@ int mjmpc_tree_dims(mjmpc_tree_t h, int* nv, int* nu, int* d_obs);
  * model blocks [n_shards][MJMPC_TREE_BLOB_LEN] of the engine's topology; from then on shard i of a rollout (particles
  * [i P / n_shards, (i + 1) P / n_shards), P % n_shards == 0) simulates block i. */
 int mjmpc_tree_set_shard_models(mjmpc_tree_t h, const double* model_blobs, int n_shards);
-/* synchronous on `stream` (the state is staged from pageable memory) */
+/* set_sim_state_fn (subproc_vec_env.py:235-251), asynchronous on `stream` like mjmpc_arm_set_state (pinned staging ring). */
 int mjmpc_tree_set_state(mjmpc_tree_t h, const double* qpos, const double* qvel, const double* target_pos, void* stream);
+/* One start state per shard, as mjmpc_arm_set_shard_states (SubprocVecEnv.set_env_state with one dict per worker,
+ * subproc_vec_env.py:242-251): states = float64 [n_shards][MJMPC_TREE_STATE_LEN] (HOST pointer, layout qpos[32] | qvel[32] |
+ * target[3] | 3 unused); particles of shard k then start from states[k].  With per-shard models the two shard counts
+ * must agree.  n_shards = 0 returns to the single engine state. */
+int mjmpc_tree_set_shard_states(mjmpc_tree_t h, const double* states, int n_shards, void* stream);
 int mjmpc_tree_rollout(mjmpc_tree_t h, int dtype, int64_t P, int H, const double* d_mean, const void* d_noise,
                        void* d_costs, void* d_actions, void* d_obs, void* d_next_obs, void* stream);
 /* The "real" environment kept on the device, as mjmpc_arm_step_state (env.step of the reference's closed loop,

@@ -37,6 +37,7 @@ SIGNATURES = {
     "mjmpc_tree_dims": (_int, [_vp, ctypes.POINTER(_int), ctypes.POINTER(_int), ctypes.POINTER(_int)]),
     "mjmpc_tree_set_shard_models": (_int, [_vp, _dp, _int]),
     "mjmpc_tree_set_state": (_int, [_vp, _dp, _dp, _dp, _vp]),
+    "mjmpc_tree_set_shard_states": (_int, [_vp, _dp, _int, _vp]),
     "mjmpc_tree_rollout": (_int, [_vp, _int, _i64, _int, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "mjmpc_tree_rollout_cl": (_int, [_vp, _int, _i64, _int, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "mjmpc_tree_step_state": (_int, [_vp, _int, _vp, _vp, _vp, _vp]),

@@ -1,44 +1,78 @@
-"""Build the HIP library in-tree:  python -m mjmpc_amd.build
+"""Build the HIP library in-tree:  python -m mjmpc_amd.build [--force] [-v]
 
-One plain `hipcc -shared` of mjmpc_amd/csrc/*.hip for gfx950 -> mjmpc_amd/libmjmpc_amd.so.
-hipcc cross-compiles without a GPU; the .so is git-ignored but travels with gpurun snapshots.
+Every mjmpc_amd/csrc/*.hip is compiled for gfx950 into an object under mjmpc_amd/_build/ (only when it or a header
+is newer than its object; the sources compile side by side) and the objects are linked into
+mjmpc_amd/libmjmpc_amd.so.  hipcc cross-compiles without a GPU; the .so is git-ignored but travels with gpurun
+snapshots.
 """
 import glob
 import os
 import subprocess
 import sys
+from concurrent.futures import ThreadPoolExecutor
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
+OBJ = os.path.join(HERE, "_build")
 LIB = os.path.join(HERE, "libmjmpc_amd.so")
 ARCH = "gfx950"
+FLAGS = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-Wno-unused-value", "-Wno-pass-failed", "-I", CSRC]
 
 
 def sources():
     return sorted(glob.glob(os.path.join(CSRC, "*.hip")))
 
 
-def _stale():
-    if not os.path.exists(LIB):
+def _headers():
+    return glob.glob(os.path.join(CSRC, "*.h")) + [os.path.join(HERE, "..", "include", "mjmpc_amd.h")]
+
+
+def _obj(src):
+    return os.path.join(OBJ, os.path.splitext(os.path.basename(src))[0] + ".o")
+
+
+def _stale(target, deps):
+    if not os.path.exists(target):
         return True
-    t = os.path.getmtime(LIB)
-    deps = sources() + glob.glob(os.path.join(CSRC, "*.h")) + [os.path.join(HERE, "..", "include", "mjmpc_amd.h")]
+    t = os.path.getmtime(target)
     return any(os.path.getmtime(d) > t for d in deps)
 
 
-def build(force=False, verbose=False):
-    if not force and not _stale():
-        return LIB
+def build(force=False, verbose=False, extra_flags=(), lib=None):
+    """``extra_flags`` / ``lib``: developer builds (e.g. ``-DMJMPC_STAMPS`` into tools/_build/) - they compile every
+    source afresh into their own object directory beside ``lib``."""
+    lib = lib or LIB
+    objdir = OBJ if lib == LIB else os.path.join(os.path.dirname(lib), "_obj_" + os.path.basename(lib))
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    cmd = [hipcc, "--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-shared", "-Wno-unused-value", "-Wno-pass-failed",
-           "-I", CSRC] + sources() + ["-o", LIB]
-    if verbose:
-        cmd.insert(1, "-Rpass-analysis=kernel-resource-usage")
-        print(" ".join(cmd))
-    subprocess.check_call(cmd)
-    return LIB
+    hdrs = _headers()
+    if not force and lib == LIB and not _stale(lib, sources() + hdrs):
+        return lib              # (the objects do not travel with gpurun snapshots; the library does)
+    todo = [s for s in sources()
+            if force or lib != LIB or _stale(os.path.join(objdir, os.path.basename(_obj(s))), [s] + hdrs)]
+    if not todo and not _stale(lib, [os.path.join(objdir, os.path.basename(_obj(s))) for s in sources()]):
+        return lib
+    os.makedirs(objdir, exist_ok=True)
+
+    def compile_one(src):
+        cmd = [hipcc] + FLAGS + list(extra_flags) + ["-c", src, "-o", os.path.join(objdir, os.path.basename(_obj(src)))]
+        if verbose:
+            cmd.insert(1, "-Rpass-analysis=kernel-resource-usage")
+            print(" ".join(cmd), flush=True)
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        return src, r
+
+    with ThreadPoolExecutor(max_workers=min(4, max(1, len(todo)))) as ex:
+        results = list(ex.map(compile_one, todo))
+    for src, r in results:
+        if verbose or r.returncode != 0:
+            sys.stderr.write(r.stderr)
+        if r.returncode != 0:
+            raise subprocess.CalledProcessError(r.returncode, "hipcc -c " + src)
+    objs = [os.path.join(objdir, os.path.basename(_obj(s))) for s in sources()]
+    subprocess.check_call([hipcc, "--offload-arch=" + ARCH, "-shared", "-fPIC"] + objs + ["-o", lib])
+    return lib
 
 
 if __name__ == "__main__":
-    build(force="--force" in sys.argv, verbose=True)
+    build(force="--force" in sys.argv, verbose="-v" in sys.argv or "--force" in sys.argv)
     print("built", LIB)

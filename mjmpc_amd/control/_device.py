@@ -273,18 +273,27 @@ class DeviceUpdater:
                                               float(step_size), _vp(self.mean), _vp(self.cov), self.stream()))
 
     def check_status(self):
-        """Raise if a sampler kernel has flagged an error since the last call (read after the action of a control
-        step has arrived, i.e. behind every kernel of that step): an indefinite covariance would otherwise turn into
-        NaN samples, mean and action without a word, and a short MT19937 stream would leave stale samples behind."""
+        """Raise if a sampler kernel has flagged an error: an indefinite covariance would otherwise turn into NaN
+        samples, mean and action without a word, and a short MT19937 stream would leave stale samples behind.  The kernels
+        only ever SET their flag (sticky: a later successful draw does not erase an earlier failure); the host clears
+        exactly the flags it reports, and reports both when both are up.  Eager iterations: read behind every kernel of
+        the control step that has just returned its action.  Captured iterations return the action while the graph's
+        tail (the next step's Cholesky factor and samples) is still running, so a failure of that tail raises one
+        ``optimize()`` later - on the step whose samples it spoiled."""
         st = self._status_np
-        if st[0] or st[1]:
-            chol, mt = int(st[0]), int(st[1])
-            st[:] = 0
-            if chol:
-                raise _lib.MjmpcError("the action covariance on the device is indefinite or not finite: its Cholesky "
-                                      "factor (sampler colouring) does not exist")
-            raise _lib.MjmpcError("device MT19937 sampler: the generated stream was too short for the requested "
-                                  "draw (status %d); samples are incomplete" % mt)
+        chol, mt = int(st[0]), int(st[1])
+        if not (chol or mt):
+            return
+        msgs = []
+        if chol:
+            st[0] = 0
+            msgs.append("the action covariance on the device is indefinite or not finite: its Cholesky factor (sampler "
+                        "colouring) does not exist")
+        if mt:
+            st[1] = 0
+            msgs.append("device MT19937 sampler: the generated stream was too short for the requested draw (status %d); "
+                        "samples are incomplete" % mt)
+        raise _lib.MjmpcError("; ".join(msgs))
 
     def _q0_view(self, ws, P):
         addr = self.lib.mjmpc_workspace_q0(_vp(ws), P, self.H, self.A)

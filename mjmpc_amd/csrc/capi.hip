@@ -71,6 +71,12 @@ struct mjmpc_tree_s {
     double* model_f64 = nullptr;
     double* state = nullptr;        // MJMPC_TREE_STATE_LEN
     unsigned* diag = nullptr;
+    double* shard_states = nullptr; // n_state_shards state vectors (per-shard start states)
+    int n_state_shards = 0;
+    double* pinned = nullptr;       // host staging for set_state: a ring of 4 vectors, one event each
+    hipEvent_t staged[4] = {nullptr, nullptr, nullptr, nullptr};
+    int stage_next = 0;
+    std::vector<double> topo;       // create-time topology tables (shard blocks must match them)
 };
 
 extern "C" {
@@ -348,6 +354,35 @@ static bool tree_blob_is_full(const double* blob, int nv) {
     return full;
 }
 
+// the tables a shard block must share with the engine's create-time block: they fix the kernel instantiation, the
+// launch shape and the factorisation schedule (dynamics randomization edits masses, inertias, damping, contact radii and
+// friction - never the tree)
+static bool tree_same_topology(const double* a, const double* b) {
+    auto same = [&](int off, int n) { return std::memcmp(a + off, b + off, sizeof(double) * n) == 0; };
+    return same(mjmpc::T_PARENT, mjmpc::TL) && same(mjmpc::T_SUBSIZE, mjmpc::TL) && same(mjmpc::T_ANC, 5 * mjmpc::TL) &&
+           same(mjmpc::T_JTYPE, mjmpc::TL) && same(mjmpc::T_ACT, mjmpc::TL) && same(mjmpc::T_DEPTH, mjmpc::TL) &&
+           same(mjmpc::T_N_ROUNDS, 1) && same(mjmpc::T_ELIM, (mjmpc::TL - 1) * mjmpc::TL) && same(mjmpc::T_NV, 1) &&
+           same(mjmpc::T_NU, 1) && same(mjmpc::T_TASK, 1) && same(mjmpc::T_OBS_SKIP, 1) && same(mjmpc::T_JUMPS, 1);
+}
+
+static int tree_create_impl(mjmpc_tree_s* h, const double* blob, int n_blob) {
+    std::vector<float> f32(blob, blob + n_blob);
+    HIP_TRY(hipMalloc(&h->model_f32, sizeof(float) * n_blob));
+    HIP_TRY(hipMalloc(&h->model_f64, sizeof(double) * n_blob));
+    HIP_TRY(hipMalloc(&h->state, sizeof(double) * MJMPC_TREE_STATE_LEN));
+    HIP_TRY(hipMalloc(&h->diag, MJMPC_TREE_DIAG_BYTES));
+    HIP_TRY(hipMemcpy(h->model_f32, f32.data(), sizeof(float) * n_blob, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(h->model_f64, blob, sizeof(double) * n_blob, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemset(h->state, 0, sizeof(double) * MJMPC_TREE_STATE_LEN));
+    HIP_TRY(hipMemset(h->diag, 0, MJMPC_TREE_DIAG_BYTES));
+    HIP_TRY(hipMalloc(&h->zero_action, sizeof(double) * 40));
+    HIP_TRY(hipMemset(h->zero_action, 0, sizeof(double) * 40));
+    h->scratch = h->zero_action + 32;
+    HIP_TRY(hipHostMalloc(&h->pinned, sizeof(double) * MJMPC_TREE_STATE_LEN * 4));
+    for (int k = 0; k < 4; ++k) HIP_TRY(hipEventCreateWithFlags(&h->staged[k], hipEventDisableTiming));
+    return 0;
+}
+
 int mjmpc_tree_create(const double* blob, int n_blob, int device, mjmpc_tree_t* out) {
     if (!blob || !out) return fail(MJMPC_E_BADARG, "null argument");
     if (n_blob != mjmpc::TREE_BLOB_LEN)
@@ -367,36 +402,26 @@ int mjmpc_tree_create(const double* blob, int n_blob, int device, mjmpc_tree_t* 
     h->d_obs = (int)blob[mjmpc::T_TASK] == 1 ? 2 * nv - (int)blob[mjmpc::T_OBS_SKIP] : 2 * nv + 6;
     h->full = tree_blob_is_full(blob, nv);
     for (int l = 0; l < nv; ++l) h->max_path = std::max(h->max_path, (int)blob[mjmpc::T_DEPTH + l] + 1);
-    std::vector<float> f32(blob, blob + n_blob);
-    HIP_TRY(hipMalloc(&h->model_f32, sizeof(float) * n_blob));
-    HIP_TRY(hipMalloc(&h->model_f64, sizeof(double) * n_blob));
-    HIP_TRY(hipMalloc(&h->state, sizeof(double) * MJMPC_TREE_STATE_LEN));
-    HIP_TRY(hipMalloc(&h->diag, MJMPC_TREE_DIAG_BYTES));
-    HIP_TRY(hipMemcpy(h->model_f32, f32.data(), sizeof(float) * n_blob, hipMemcpyHostToDevice));
-    HIP_TRY(hipMemcpy(h->model_f64, blob, sizeof(double) * n_blob, hipMemcpyHostToDevice));
-    HIP_TRY(hipMemset(h->state, 0, sizeof(double) * MJMPC_TREE_STATE_LEN));
-    HIP_TRY(hipMemset(h->diag, 0, MJMPC_TREE_DIAG_BYTES));
-    HIP_TRY(hipMalloc(&h->zero_action, sizeof(double) * 40));
-    HIP_TRY(hipMemset(h->zero_action, 0, sizeof(double) * 40));
-    h->scratch = h->zero_action + 32;
+    h->topo.assign(blob, blob + n_blob);
+    if (int rc = tree_create_impl(h, blob, n_blob)) {       // a failed allocation leaves nothing behind
+        mjmpc_tree_destroy(h);
+        return rc;
+    }
     *out = h;
     return 0;
 }
 
 int mjmpc_tree_set_shard_models(mjmpc_tree_t h, const double* blobs, int n_shards) {
     if (!h || !blobs || n_shards < 1) return fail(MJMPC_E_BADARG, "bad argument");
+    if (h->n_state_shards > 1 && n_shards > 1 && n_shards != h->n_state_shards)
+        return fail(MJMPC_E_BADARG, "%d model shards but %d per-shard start states", n_shards, h->n_state_shards);
     HIP_TRY(hipSetDevice(h->device));
     const size_t L = (size_t)mjmpc::TREE_BLOB_LEN, n = (size_t)n_shards * L;
     bool full = false;
     for (int s = 0; s < n_shards; ++s) {
         const double* b = blobs + (size_t)s * L;
-        // the topology (and with it the kernel instantiation and the launch shape) is the engine's: a shard may differ
-        // in masses, inertias, damping, contact radii and friction - what dynamics randomization edits
-        if ((int)b[mjmpc::T_NV] != h->nv || (int)b[mjmpc::T_NU] != h->nu || (int)b[mjmpc::T_N_SPHERE] > mjmpc::TREE_MAX_SPHERES)
-            return fail(MJMPC_E_BADMODEL, "shard %d does not have the engine's dimensions", s);
-        for (int l = 0; l < h->nv; ++l)
-            if ((int)b[mjmpc::T_DEPTH + l] + 1 > h->max_path)
-                return fail(MJMPC_E_BADMODEL, "shard %d has a different topology", s);
+        if ((int)b[mjmpc::T_N_SPHERE] > mjmpc::TREE_MAX_SPHERES || !tree_same_topology(b, h->topo.data()))
+            return fail(MJMPC_E_BADMODEL, "shard %d does not have the engine's topology / dimensions", s);
         full = full || tree_blob_is_full(b, h->nv);
     }
     std::vector<float> f32(blobs, blobs + n);
@@ -404,15 +429,44 @@ int mjmpc_tree_set_shard_models(mjmpc_tree_t h, const double* blobs, int n_shard
     float* m32 = nullptr;
     double* m64 = nullptr;
     HIP_TRY(hipMalloc(&m32, sizeof(float) * n));
-    HIP_TRY(hipMalloc(&m64, sizeof(double) * n));
-    HIP_TRY(hipMemcpy(m32, f32.data(), sizeof(float) * n, hipMemcpyHostToDevice));
-    HIP_TRY(hipMemcpy(m64, blobs, sizeof(double) * n, hipMemcpyHostToDevice));
+    if (hipError_t e = hipMalloc(&m64, sizeof(double) * n); e != hipSuccess) {
+        hipFree(m32);
+        return hip_fail(e, "hipMalloc");
+    }
+    hipError_t e = hipMemcpy(m32, f32.data(), sizeof(float) * n, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(m64, blobs, sizeof(double) * n, hipMemcpyHostToDevice);
+    if (e != hipSuccess) {
+        hipFree(m32);
+        hipFree(m64);
+        return hip_fail(e, "hipMemcpy");
+    }
     hipFree(h->model_f32);
     hipFree(h->model_f64);
     h->model_f32 = m32;
     h->model_f64 = m64;
     h->n_shards = n_shards;
-    h->full = h->full || full;
+    h->full = full;             // of the NEW set of blocks (they replace the old ones)
+    return 0;
+}
+
+int mjmpc_tree_set_shard_states(mjmpc_tree_t h, const double* states, int n_shards, void* stream) {
+    if (!h || (n_shards > 0 && !states) || n_shards < 0) return fail(MJMPC_E_BADARG, "bad argument");
+    if (h->n_shards > 1 && n_shards > 1 && n_shards != h->n_shards)
+        return fail(MJMPC_E_BADARG, "%d per-shard start states but %d model shards", n_shards, h->n_shards);
+    HIP_TRY(hipSetDevice(h->device));
+    if (n_shards != h->n_state_shards) {
+        HIP_TRY(hipDeviceSynchronize());
+        hipFree(h->shard_states);
+        h->shard_states = nullptr;
+        h->n_state_shards = 0;
+        if (n_shards > 0) HIP_TRY(hipMalloc(&h->shard_states, sizeof(double) * MJMPC_TREE_STATE_LEN * n_shards));
+        h->n_state_shards = n_shards;
+    }
+    if (n_shards > 0) {
+        HIP_TRY(hipMemcpyAsync(h->shard_states, states, sizeof(double) * MJMPC_TREE_STATE_LEN * n_shards,
+                               hipMemcpyHostToDevice, (hipStream_t)stream));
+        HIP_TRY(hipStreamSynchronize((hipStream_t)stream));      // `states` is pageable host memory
+    }
     return 0;
 }
 
@@ -424,6 +478,9 @@ int mjmpc_tree_destroy(mjmpc_tree_t h) {
     hipFree(h->state);
     hipFree(h->diag);
     hipFree(h->zero_action);
+    hipFree(h->shard_states);
+    if (h->pinned) hipHostFree(h->pinned);
+    for (int k = 0; k < 4; ++k) if (h->staged[k]) hipEventDestroy(h->staged[k]);
     delete h;
     return 0;
 }
@@ -439,14 +496,20 @@ int mjmpc_tree_dims(mjmpc_tree_t h, int* nv, int* nu, int* d_obs) {
 int mjmpc_tree_set_state(mjmpc_tree_t h, const double* qpos, const double* qvel, const double* target_pos,
                          void* stream) {
     if (!h || !qpos || !qvel || !target_pos) return fail(MJMPC_E_BADARG, "null argument");
+    hipStream_t s = (hipStream_t)stream;
     HIP_TRY(hipSetDevice(h->device));
-    double st[MJMPC_TREE_STATE_LEN] = {0};
+    // staging ring as mjmpc_arm_set_state: wait only for the copy that last used THIS slot (four calls ago), never for
+    // the stream - a captured control iteration still running on `s` keeps running while the next state is staged
+    const int slot = h->stage_next;
+    h->stage_next = (slot + 1) & 3;
+    HIP_TRY(hipEventSynchronize(h->staged[slot]));
+    double* st = h->pinned + (size_t)slot * MJMPC_TREE_STATE_LEN;
+    std::memset(st, 0, sizeof(double) * MJMPC_TREE_STATE_LEN);
     std::memcpy(st, qpos, sizeof(double) * h->nv);
     std::memcpy(st + mjmpc::TL, qvel, sizeof(double) * h->nv);
     std::memcpy(st + 2 * mjmpc::TL, target_pos, sizeof(double) * 3);
-    // pageable source: the runtime stages it before returning, so `st` may go out of scope
-    HIP_TRY(hipMemcpyAsync(h->state, st, sizeof(st), hipMemcpyHostToDevice, (hipStream_t)stream));
-    HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
+    HIP_TRY(hipMemcpyAsync(h->state, st, sizeof(double) * MJMPC_TREE_STATE_LEN, hipMemcpyHostToDevice, s));
+    HIP_TRY(hipEventRecord(h->staged[slot], s));
     return 0;
 }
 
@@ -454,18 +517,21 @@ int mjmpc_tree_rollout(mjmpc_tree_t h, int dtype, int64_t P, int H, const double
                        void* d_costs, void* d_actions, void* d_obs, void* d_next_obs, void* stream) {
     if (!h || !d_mean || !d_costs) return fail(MJMPC_E_BADARG, "null argument");
     if (P < 0 || H < 0) return fail(MJMPC_E_BADARG, "negative size");
-    if (P % h->n_shards != 0) return fail(MJMPC_E_BADARG, "%lld particles do not divide into %d model shards", (long long)P, h->n_shards);
+    const int nss = h->n_state_shards > 1 ? h->n_state_shards : 1;
+    if (P % h->n_shards != 0 || P % nss != 0)
+        return fail(MJMPC_E_BADARG, "%lld particles do not divide into %d shards", (long long)P, std::max(h->n_shards, nss));
     HIP_TRY(hipSetDevice(h->device));
     hipStream_t s = (hipStream_t)stream;
     hipError_t e;
+    const double* st = nss > 1 ? h->shard_states : h->state;
     if (dtype == MJMPC_F32)
-        e = mjmpc::launch_tree_rollout<float>(h->model_f32, h->n_shards, h->max_path, h->full, h->nv, h->state, (long)P, H, h->nu, d_mean,
+        e = mjmpc::launch_tree_rollout<float>(h->model_f32, h->n_shards, h->max_path, h->full, h->nv, st, (long)P, H, h->nu, d_mean,
                                               (const float*)d_noise, (float*)d_costs, (float*)d_actions, (float*)d_obs,
-                                              (float*)d_next_obs, h->diag, s);
+                                              (float*)d_next_obs, h->diag, s, nullptr, nullptr, nullptr, nss);
     else if (dtype == MJMPC_F64)
-        e = mjmpc::launch_tree_rollout<double>(h->model_f64, h->n_shards, h->max_path, h->full, h->nv, h->state, (long)P, H, h->nu, d_mean,
+        e = mjmpc::launch_tree_rollout<double>(h->model_f64, h->n_shards, h->max_path, h->full, h->nv, st, (long)P, H, h->nu, d_mean,
                                                (const double*)d_noise, (double*)d_costs, (double*)d_actions,
-                                               (double*)d_obs, (double*)d_next_obs, h->diag, s);
+                                               (double*)d_obs, (double*)d_next_obs, h->diag, s, nullptr, nullptr, nullptr, nss);
     else
         return fail(MJMPC_E_BADARG, "unknown dtype %d", dtype);
     if (e != hipSuccess) return hip_fail(e, "tree_rollout launch");
@@ -476,29 +542,39 @@ int mjmpc_tree_rollout_cl(mjmpc_tree_t h, int dtype, int64_t P, int H, const dou
                           void* d_costs, void* d_actions, void* d_obs, void* d_next_obs, void* stream) {
     if (!h || !d_weights || !d_costs) return fail(MJMPC_E_BADARG, "null argument");
     if (P < 0 || H < 0) return fail(MJMPC_E_BADARG, "negative size");
-    if (P % h->n_shards != 0) return fail(MJMPC_E_BADARG, "%lld particles do not divide into %d model shards", (long long)P, h->n_shards);
+    const int nss = h->n_state_shards > 1 ? h->n_state_shards : 1;
+    if (P % h->n_shards != 0 || P % nss != 0)
+        return fail(MJMPC_E_BADARG, "%lld particles do not divide into %d shards", (long long)P, std::max(h->n_shards, nss));
     HIP_TRY(hipSetDevice(h->device));
     hipStream_t s = (hipStream_t)stream;
-    hipError_t e;
+    hipError_t e = hipSuccess;
+    double* st = nss > 1 ? h->shard_states : h->state;
     // the first action depends on the fresh observation, whose tracked site comes out of a kinematics pass: a
-    // one-particle, one-step launch (its cost lands in the workspace and is discarded) leaves it in the state vector
-    double* site0 = h->state + 2 * mjmpc::TL + 3;
-    if (dtype == MJMPC_F32) {
-        e = mjmpc::launch_tree_rollout<float>(h->model_f32, 1, h->max_path, h->full, h->nv, h->state, 1, 1, h->nu, h->zero_action, nullptr,
-                                              (float*)h->scratch, nullptr, nullptr, nullptr, h->diag, s, nullptr, nullptr, site0);
-        if (e == hipSuccess)
-            e = mjmpc::launch_tree_rollout<float>(h->model_f32, h->n_shards, h->max_path, h->full, h->nv, h->state, (long)P, H, h->nu,
+    // one-particle, one-step launch per start state (its cost lands in the workspace and is discarded) leaves it in
+    // the state vector
+    for (int k = 0; k < nss && e == hipSuccess; ++k) {
+        double* sk = st + (size_t)k * MJMPC_TREE_STATE_LEN;
+        double* site0 = sk + 2 * mjmpc::TL + 3;
+        if (dtype == MJMPC_F32)
+            e = mjmpc::launch_tree_rollout<float>(h->model_f32 + (h->n_shards > 1 ? (size_t)k * mjmpc::TREE_BLOB_LEN : 0), 1, h->max_path,
+                                                  h->full, h->nv, sk, 1, 1, h->nu, h->zero_action, nullptr, (float*)h->scratch,
+                                                  nullptr, nullptr, nullptr, h->diag, s, nullptr, nullptr, site0);
+        else if (dtype == MJMPC_F64)
+            e = mjmpc::launch_tree_rollout<double>(h->model_f64 + (h->n_shards > 1 ? (size_t)k * mjmpc::TREE_BLOB_LEN : 0), 1, h->max_path,
+                                                   h->full, h->nv, sk, 1, 1, h->nu, h->zero_action, nullptr, (double*)h->scratch,
+                                                   nullptr, nullptr, nullptr, h->diag, s, nullptr, nullptr, site0);
+        else
+            return fail(MJMPC_E_BADARG, "unknown dtype %d", dtype);
+    }
+    if (e == hipSuccess) {
+        if (dtype == MJMPC_F32)
+            e = mjmpc::launch_tree_rollout<float>(h->model_f32, h->n_shards, h->max_path, h->full, h->nv, st, (long)P, H, h->nu,
                                                   d_weights, (const float*)d_noise, (float*)d_costs, (float*)d_actions, (float*)d_obs,
-                                                  (float*)d_next_obs, h->diag, s, nullptr, d_weights, nullptr);
-    } else if (dtype == MJMPC_F64) {
-        e = mjmpc::launch_tree_rollout<double>(h->model_f64, 1, h->max_path, h->full, h->nv, h->state, 1, 1, h->nu, h->zero_action, nullptr,
-                                               (double*)h->scratch, nullptr, nullptr, nullptr, h->diag, s, nullptr, nullptr, site0);
-        if (e == hipSuccess)
-            e = mjmpc::launch_tree_rollout<double>(h->model_f64, h->n_shards, h->max_path, h->full, h->nv, h->state, (long)P, H, h->nu,
+                                                  (float*)d_next_obs, h->diag, s, nullptr, d_weights, nullptr, nss);
+        else
+            e = mjmpc::launch_tree_rollout<double>(h->model_f64, h->n_shards, h->max_path, h->full, h->nv, st, (long)P, H, h->nu,
                                                    d_weights, (const double*)d_noise, (double*)d_costs, (double*)d_actions,
-                                                   (double*)d_obs, (double*)d_next_obs, h->diag, s, nullptr, d_weights, nullptr);
-    } else {
-        return fail(MJMPC_E_BADARG, "unknown dtype %d", dtype);
+                                                   (double*)d_obs, (double*)d_next_obs, h->diag, s, nullptr, d_weights, nullptr, nss);
     }
     if (e != hipSuccess) return hip_fail(e, "tree_rollout_cl launch");
     return 0;

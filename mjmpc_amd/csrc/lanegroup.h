@@ -32,16 +32,12 @@ __device__ __forceinline__ double dpp_all(double x) {
 }
 
 // ---------------------------------------------------------------------------------------------------
-// Lane layout.  A DPP row is 16 lanes = two particles.  Two ways to place them:
-//   BLOCKED      lane = 8 * particle + link      (links of a particle are adjacent lanes)
-//   INTERLEAVED  lane = 2 * link + particle      (the two particles of a row alternate)
-// With the interleaved layout a shift by S links is a row shift by 2S lanes, which never crosses from
+// Lane layout.  A DPP row is 16 lanes = two particles, INTERLEAVED: lane = 2 * link + particle (the two particles
+// of a row alternate).  A shift by S links is then a row shift by 2S lanes, which never crosses from
 // one particle into the other and falls off the END OF THE ROW exactly at the chain boundary: DPP's own
 // bound_ctrl (zero) / `old` (fill) semantics do the masking, so scans need no v_cndmask and - in f32 -
-// fold into a single v_add_f32_dpp.  The price is one more DPP per broadcast (three instead of two).
-#ifndef MJMPC_INTERLEAVED
-#define MJMPC_INTERLEAVED 1
-#endif
+// fold into a single v_add_f32_dpp.  (A blocked layout, lane = 8 * particle + link, saves one DPP per broadcast
+// but needs a select after every scan step: measured slower in round 1 and removed.)
 
 // zero-filling DPP (bound_ctrl): lanes whose source falls outside the row read 0
 template <int CTRL>
@@ -54,8 +50,6 @@ __device__ __forceinline__ double dpp_zero(double x) {
     int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(x), CTRL, 0xF, 0xF, true);
     return __hiloint2double(hi, lo);
 }
-
-#if MJMPC_INTERLEAVED
 
 __device__ __forceinline__ int lane_link(int lane) { return (lane >> 1) & 7; }
 __device__ __forceinline__ int lane_slot(int lane) { return ((lane >> 4) << 1) | (lane & 1); }
@@ -101,60 +95,6 @@ __device__ __forceinline__ T gsum(T x) {
     return x;
 }
 
-#else  // ---------------------------------------------------------------------------- BLOCKED layout
-
-__device__ __forceinline__ int lane_link(int lane) { return lane & 7; }
-__device__ __forceinline__ int lane_slot(int lane) { return lane >> 3; }
-__device__ __forceinline__ int lane_of_link(int lane, int link) { return (lane & ~7) | link; }
-
-// lane i <- x[i - S] inside the group, `fill` where i < S          (row_shr)
-template <int S, typename T>
-__device__ __forceinline__ T shr(T x, T fill, int l8) {
-    if constexpr (S == 4) {
-        return dpp<0x114, 0xA>(fill, x);            // banks 1,3 = lanes 4-7 / 12-15 of the row
-    } else {
-        T t = dpp<0x110 + S, 0xF>(fill, x);
-        return l8 >= S ? t : fill;
-    }
-}
-// lane i <- x[i + S] inside the group, `fill` where i + S > 7      (row_shl)
-template <int S, typename T>
-__device__ __forceinline__ T shl(T x, T fill, int l8) {
-    if constexpr (S == 4) {
-        return dpp<0x104, 0x5>(fill, x);            // banks 0,2 = lanes 0-3 / 8-11
-    } else {
-        T t = dpp<0x100 + S, 0xF>(fill, x);
-        return l8 + S < 8 ? t : fill;
-    }
-}
-template <int S, typename T>
-__device__ __forceinline__ T shr0(T x, int l8) { return shr<S>(x, T(0), l8); }
-template <int S, typename T>
-__device__ __forceinline__ T shl0(T x, int l8) { return shl<S>(x, T(0), l8); }
-// unmasked row_shl: lanes with i + S > 7 receive another particle's data - caller discards them
-template <int S, typename T>
-__device__ __forceinline__ T shl_raw(T x) {
-    return dpp<0x100 + S, 0xF>(x, x);
-}
-// every lane of the group <- x[K]
-template <int K, typename T>
-__device__ __forceinline__ T bcast(T x) {
-    constexpr int q = K & 3;
-    constexpr int QP = q | (q << 2) | (q << 4) | (q << 6);
-    T t = dpp_all<QP>(x);                           // broadcast inside each quad (every lane valid)
-    if constexpr (K < 4) return dpp<0x114, 0xA>(t, t);   // lanes 4-7 <- lanes 0-3
-    else return dpp<0x104, 0x5>(t, t);                   // lanes 0-3 <- lanes 4-7
-}
-// sum over the 8 lanes of the group, result in every lane
-template <typename T>
-__device__ __forceinline__ T gsum(T x) {
-    x += dpp_all<0x141>(x);                         // row_half_mirror: i <-> 7 - i
-    x += dpp_all<0xB1>(x);                          // quad_perm [1,0,3,2]
-    x += dpp_all<0x4E>(x);                          // quad_perm [2,3,0,1]
-    return x;
-}
-
-#endif
 
 // inclusive prefix / suffix sums over the links of a particle
 template <typename T>

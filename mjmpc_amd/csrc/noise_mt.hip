@@ -265,7 +265,7 @@ __global__ void polar_emit_kernel(const unsigned* __restrict__ w, long n_attempt
     }
     if (blockIdx.x == 0 && threadIdx.x == 0) {
         const long need = (last + 1) / 2;
-        if (status) *status = offsets[gridDim.x] >= need ? 0 : 1;              // 1: not enough attempts generated
+        if (status && offsets[gridDim.x] < need) *status = 1;     // sticky (the host clears what it reports): not enough attempts generated
     }
 }
 

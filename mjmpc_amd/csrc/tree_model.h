@@ -79,6 +79,7 @@ enum TreeOffset : int {
     TREE_BLOB_LEN = T_ELIM + (TL - 1) * TL
 };
 
+constexpr int TREE_STATE_LEN = 2 * TL + 6;   // qpos[32] | qvel[32] | target[3] | site of the fresh observation[3]
 static_assert(TREE_BLOB_LEN == 2854, "keep in sync with mjmpc_amd/models/compile_tree.py::TREE_LAYOUT");
 
 }  // namespace mjmpc

@@ -12,10 +12,12 @@ namespace mjmpc {
 // instead of `mean` (the fresh observation's site is read from state[2 * 32 + 3 ...], which a P = 1 launch with site_out
 // pointing there provides).  model: TREE_BLOB_LEN scalars of T; state: f64 [qpos(32) | qvel(32) | target(3)];
 // mean f64 [H][A]; noise / cost / act / obs / nobs of T in the reference's C-order layouts (may be null except cost).
+// n_state_shards > 1: `state` holds one TREE_STATE_LEN vector per shard (per-worker start states); with both kinds of
+// shards their counts must agree.
 template <typename T>
-hipError_t launch_tree_rollout(const T* model, int n_shards, int max_path, bool full, int nv, const double* state, long P, int H,
+hipError_t launch_tree_rollout(const T* model, int n_model_shards, int max_path, bool full, int nv, const double* state, long P, int H,
                                int A, const double* mean, const T* noise, T* cost, T* act, T* obs, T* nobs, unsigned* diag,
                                hipStream_t stream, double* state_out = nullptr, const double* clw = nullptr,
-                               double* site_out = nullptr);
+                               double* site_out = nullptr, int n_state_shards = 1);
 
 }  // namespace mjmpc

@@ -345,7 +345,8 @@ constexpr int min_waves(int scalar_bytes, int DP, bool fric) { return (DP <= 8 &
 // PL = lanes per particle: 32, or 16 for models of up to 16 dofs (four particles per wavefront, a particle = one DPP row)
 template <typename T, int DP, int NS, bool FRIC, int PL>
 __global__ __launch_bounds__(64 * wg_waves(DP, FRIC, sizeof(T), PL), min_waves(sizeof(T), DP, FRIC)) void tree_rollout_kernel(
-    const T* __restrict__ model_all, const double* __restrict__ state, long P, long shard_size, int H, int A, const double* __restrict__ mean,
+    const T* __restrict__ model_all, int model_stride, const double* __restrict__ state, int state_stride, long P, long shard_size, int H,
+    int A, const double* __restrict__ mean,
     const T* __restrict__ noise, T* __restrict__ cost, T* __restrict__ act, T* __restrict__ obs, T* __restrict__ nobs,
     unsigned* diag, double* state_out, const double* __restrict__ clw, double* site_out) {
     constexpr int WG_WAVES = wg_waves(DP, FRIC, sizeof(T), PL);
@@ -361,9 +362,11 @@ __global__ __launch_bounds__(64 * wg_waves(DP, FRIC, sizeof(T), PL), min_waves(s
     __shared__ __attribute__((aligned(16))) T lds[NBLOB + 1 + PPW * WG_WAVES * A_LEN];
     __shared__ int ELIM[(PL - 1) * PL];     // elimination lists
     __shared__ int AT[DP * PL];             // AT[c * PL + l] = ancestor of link l at distance c (-1 beyond the root)
-    // dynamics randomization (SubprocVecEnv.randomize_dynamics): gridDim.y shards of shard_size consecutive particles,
-    // each with its own model block; a workgroup never straddles two shards
-    const T* model = model_all + (long)blockIdx.y * TREE_BLOB_LEN;
+    // gridDim.y shards of shard_size consecutive particles (the reference's workers); a workgroup never straddles two.
+    // Dynamics randomization (SubprocVecEnv.randomize_dynamics) gives each its own model block (model_stride != 0),
+    // a per-worker set_env_state (subproc_vec_env.py:242-251) its own start state (state_stride != 0).
+    const T* model = model_all + (long)blockIdx.y * model_stride;
+    state += (long)blockIdx.y * state_stride;
     T* M = lds;
     for (int k = threadIdx.x; k < NBLOB; k += blockDim.x) M[k] = model[k];
     for (int k = threadIdx.x; k < (PL - 1) * PL; k += blockDim.x) ELIM[k] = (int)model[T_ELIM + (k / PL) * TL + (k % PL)];
@@ -1041,20 +1044,25 @@ __global__ __launch_bounds__(64 * wg_waves(DP, FRIC, sizeof(T), PL), min_waves(s
 }  // namespace
 
 template <typename T>
-hipError_t launch_tree_rollout(const T* model, int n_shards, int max_path, bool full, int nv, const double* state, long P, int H,
+hipError_t launch_tree_rollout(const T* model, int n_model_shards, int max_path, bool full, int nv, const double* state, long P, int H,
                                int A, const double* mean, const T* noise, T* cost, T* act, T* obs, T* nobs, unsigned* diag,
-                               hipStream_t stream, double* state_out, const double* clw, double* site_out) {
+                               hipStream_t stream, double* state_out, const double* clw, double* site_out, int n_state_shards) {
     if (P <= 0 || H <= 0) return hipSuccess;
     if ((state_out || site_out) && P != 1) return hipErrorInvalidValue;
-    if (n_shards < 1 || P % n_shards != 0) return hipErrorInvalidValue;
+    if (n_model_shards < 1 || n_state_shards < 1) return hipErrorInvalidValue;
+    if (n_model_shards > 1 && n_state_shards > 1 && n_model_shards != n_state_shards) return hipErrorInvalidValue;
+    const int n_shards = n_model_shards > n_state_shards ? n_model_shards : n_state_shards;
+    if (P % n_shards != 0) return hipErrorInvalidValue;
     const long shard = P / n_shards;
+    const int model_stride = n_model_shards > 1 ? TREE_BLOB_LEN : 0, state_stride = n_state_shards > 1 ? TREE_STATE_LEN : 0;
 #define MJMPC_TREE_LAUNCH(DP_, NS_, FR_, PL_)                                                                         \
     {                                                                                                                 \
         constexpr int per_wg = wg_waves(DP_, FR_, sizeof(T), PL_) * (64 / PL_);                                       \
         hipLaunchKernelGGL((tree_rollout_kernel<T, DP_, NS_, FR_, PL_>),                                              \
                            dim3((unsigned)((shard + per_wg - 1) / per_wg), (unsigned)n_shards),                       \
-                           dim3(64 * wg_waves(DP_, FR_, sizeof(T), PL_)), 0, stream, model, state, P, shard, H, A,    \
-                           mean, noise, cost, act, obs, nobs, diag, state_out, clw, site_out);                        \
+                           dim3(64 * wg_waves(DP_, FR_, sizeof(T), PL_)), 0, stream, model, model_stride, state,      \
+                           state_stride, P, shard, H, A, mean, noise, cost, act, obs, nobs, diag, state_out, clw,     \
+                           site_out);                                                                                 \
     }
     // hinge trees in air with up to 8 frictionless contact points keep the lean instantiation; slide joints, springs,
     // friction cones, more points or a medium take the full one (three Jacobians per point, 16 points, fluid forces),
@@ -1076,8 +1084,8 @@ hipError_t launch_tree_rollout(const T* model, int n_shards, int max_path, bool 
 }
 
 template hipError_t launch_tree_rollout<float>(const float*, int, int, bool, int, const double*, long, int, int, const double*,
-                                               const float*, float*, float*, float*, float*, unsigned*, hipStream_t, double*, const double*, double*);
+                                               const float*, float*, float*, float*, float*, unsigned*, hipStream_t, double*, const double*, double*, int);
 template hipError_t launch_tree_rollout<double>(const double*, int, int, bool, int, const double*, long, int, int, const double*,
-                                                const double*, double*, double*, double*, double*, unsigned*, hipStream_t, double*, const double*, double*);
+                                                const double*, double*, double*, double*, double*, unsigned*, hipStream_t, double*, const double*, double*, int);
 
 }  // namespace mjmpc

@@ -23,7 +23,7 @@ import numpy as np
 from .. import _lib
 from ..models.compile_tree import TreeModel, compile_tree
 from ..models.raw import TASK_FORWARD, RawModel
-from .arm_engine import _DT, _ptr, _torch
+from .arm_engine import _DT, _ptr, _same_state, _torch
 
 
 class TreeRolloutEngine:
@@ -57,26 +57,53 @@ class TreeRolloutEngine:
         self.reset()
 
     # ------------------------------------------------------------------ reference-shaped API
-    def set_env_state(self, state_dicts):
-        state = state_dicts[0] if isinstance(state_dicts, (list, tuple)) else state_dicts
-        if isinstance(state_dicts, (list, tuple)) and len(state_dicts) not in (1, self.num_shards):
-            raise AssertionError("num states should equal 1 (same for all envs) or 1 per env")
+    def _unpack(self, state):
         kq, kv = ("qpos", "qvel") if "qpos" in state else ("qp", "qv")
         qp = np.ascontiguousarray(state[kq], np.float64).reshape(-1)
         qv = np.ascontiguousarray(state[kv], np.float64).reshape(-1)
         tg = np.ascontiguousarray(state.get("target_pos", self.model.target_default), np.float64).reshape(-1)
         if qp.size != self.model.nv or qv.size != self.model.nv or tg.size != 3:
             raise ValueError("state has the wrong dimensions for this model")
-        self._state = dict(qp=qp.copy(), qv=qv.copy(), target_pos=tg.copy())
-        _lib.check(self._lib.mjmpc_tree_set_state(self._h, qp.ctypes.data_as(_lib._dp), qv.ctypes.data_as(_lib._dp),
-                                                  tg.ctypes.data_as(_lib._dp), self._stream()))
+        return dict(qp=qp.copy(), qv=qv.copy(), target_pos=tg.copy())
+
+    def set_env_state(self, state_dicts):
+        """``SubprocVecEnv.set_env_state`` (subproc_vec_env.py:235-251): one dict (every shard starts from it), a list
+        holding one dict, or one dict per shard (shard k's particles start from states[k])."""
+        if isinstance(state_dicts, (list, tuple)):
+            if len(state_dicts) not in (1, self.num_shards):
+                raise AssertionError("num states should equal 1 (same for all envs) or 1 per env")
+            states = [self._unpack(s) for s in state_dicts]
+            if any(not _same_state(states[0], s) for s in states[1:]):
+                return self._set_shard_states(states)
+            state = states[0]
+        else:
+            state = self._unpack(state_dicts)
+        if getattr(self, "_per_shard_states", False):
+            _lib.check(self._lib.mjmpc_tree_set_shard_states(self._h, None, 0, self._stream()))
+            self._per_shard_states = False
+        self._state = state
+        _lib.check(self._lib.mjmpc_tree_set_state(self._h, state["qp"].ctypes.data_as(_lib._dp),
+                                                  state["qv"].ctypes.data_as(_lib._dp),
+                                                  state["target_pos"].ctypes.data_as(_lib._dp), self._stream()))
+
+    def _set_shard_states(self, states):
+        nv = self.model.nv
+        arr = np.zeros((self.num_shards, 70))                   # MJMPC_TREE_STATE_LEN: qpos[32] | qvel[32] | target[3] | -
+        for k, s in enumerate(states):
+            arr[k, :nv], arr[k, 32:32 + nv], arr[k, 64:67] = s["qp"], s["qv"], s["target_pos"]
+        _lib.check(self._lib.mjmpc_tree_set_shard_states(self._h, arr.ctypes.data_as(_lib._dp), self.num_shards,
+                                                         self._stream()))
+        self._per_shard_states = True
+        self._shard_state_list = states
+        self._state = states[0]
 
     def get_env_state(self):
-        st = self._state
+        """One state dict - or, after a per-shard ``set_env_state``, one per shard (subproc_vec_env.py:253-256)."""
+        states = self._shard_state_list if getattr(self, "_per_shard_states", False) else [self._state]
         if self.forward_task:
-            return [dict(qpos=st["qp"].copy(), qvel=st["qv"].copy())]
+            return [dict(qpos=st["qp"].copy(), qvel=st["qv"].copy()) for st in states]
         return [dict(qp=st["qp"].copy(), qv=st["qv"].copy(), qa=np.zeros(self.model.nv),
-                     target_pos=st["target_pos"].copy(), timestep=0)]
+                     target_pos=st["target_pos"].copy(), timestep=0) for st in states]
 
     def reset(self):
         self.set_env_state(dict(qp=np.zeros(self.model.nv), qv=np.zeros(self.model.nv),
@@ -86,6 +113,7 @@ class TreeRolloutEngine:
     def close(self):
         if not self.closed:
             self._lib.mjmpc_tree_destroy(self._h)
+            self._h = None              # later calls fail with "null engine" instead of touching freed memory
             self.closed = True
 
     def __del__(self):

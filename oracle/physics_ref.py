@@ -31,6 +31,42 @@ def build_flops(force=False):
     return so
 
 
+NATIVE_FLAGS = "-O3 -march=native -ffp-contract=fast -fPIC -fopenmp -std=gnu11"
+
+
+def build_flags():
+    """The flags of the library bench.py's cpu_baseline leg times (see build_native)."""
+    return "gcc " + NATIVE_FLAGS
+
+
+def build_native():
+    """The same source built for THIS host (``-O3 -march=native``, FMA contraction allowed): what bench.py's
+    ``cpu_baseline`` leg times, so that the CPU figure is not handicapped by the checker's portable ``-O2`` build.  The
+    library is rebuilt whenever the host CPU differs from the one it was built on (it travels with gpurun snapshots
+    from the build container to the GPU box).  Falls back to the portable build if this host cannot compile."""
+    so = os.path.join(_HERE, "libreacher_ref_native.so")
+    stamp = os.path.join(_HERE, "libreacher_ref_native.stamp")
+    src = os.path.join(_HERE, "reacher_ref.c")
+    cpu = ""
+    try:
+        with open("/proc/cpuinfo") as f:
+            cpu = "".join(ln for ln in f if ln.startswith(("model name", "flags")))[:20000]
+    except OSError:
+        pass
+    import hashlib
+    want = hashlib.sha1((cpu + NATIVE_FLAGS).encode()).hexdigest()
+    have = open(stamp).read().strip() if os.path.exists(stamp) else ""
+    if not os.path.exists(so) or have != want or os.path.getmtime(so) < os.path.getmtime(src):
+        try:
+            subprocess.check_call(["gcc"] + NATIVE_FLAGS.split() + ["-shared", "-o", so, src, "-lm"],
+                                  stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+            with open(stamp, "w") as f:
+                f.write(want)
+        except (OSError, subprocess.CalledProcessError):
+            return build()
+    return so
+
+
 def count_flops(flat, qp0, qv0, target, mean, noise):
     """Floating-point operations the oracle executes per particle-step of ``rollout``: a dict with the
     tallies per kind and ``flops`` = add + mul + div + sqrt + trig (one each; compares are listed, not counted)."""
@@ -56,33 +92,43 @@ def count_flops(flat, qp0, qv0, target, mean, noise):
     return d
 
 
-def _lib():
-    global _LIB
+_NATIVE = None
+
+
+def _lib(native=False):
+    global _LIB, _NATIVE
+    if native:
+        if _NATIVE is None:
+            _NATIVE = _bind(ctypes.CDLL(build_native()))
+        return _NATIVE
     if _LIB is None:
-        L = ctypes.CDLL(build())
-        L.or_model_compile.restype = ctypes.c_void_p
-        L.or_model_compile.argtypes = [_dp, ctypes.c_int]
-        L.or_model_free.argtypes = [ctypes.c_void_p]
-        for name in ("or_nv", "or_nbody", "or_dobs"):
-            getattr(L, name).restype = ctypes.c_int
-            getattr(L, name).argtypes = [ctypes.c_void_p]
-        L.or_kinetic.restype = ctypes.c_double
-        L.or_kinetic.argtypes = [ctypes.c_void_p, _dp, _dp]
-        L.or_env_step.restype = ctypes.c_double
-        L.or_env_step.argtypes = [ctypes.c_void_p, _dp, _dp, _dp, _dp, _dp]
-        L.or_step.argtypes = [ctypes.c_void_p, _dp, _dp, _dp, _dp, _dp]
-        L.or_rollout.argtypes = [ctypes.c_void_p, _dp, _dp, _dp, ctypes.c_long, ctypes.c_int,
-                                 _dp, _dp, _dp, _dp, _dp, _dp, _dp]
-        L.or_rollout_cl.argtypes = L.or_rollout.argtypes
-        L.or_threads.restype = ctypes.c_int
-        L.or_threads.argtypes = [ctypes.c_int]
-        _LIB = L
+        _LIB = _bind(ctypes.CDLL(build()))
     return _LIB
 
 
-def threads(n=0):
+def _bind(L):
+    L.or_model_compile.restype = ctypes.c_void_p
+    L.or_model_compile.argtypes = [_dp, ctypes.c_int]
+    L.or_model_free.argtypes = [ctypes.c_void_p]
+    for name in ("or_nv", "or_nbody", "or_dobs"):
+        getattr(L, name).restype = ctypes.c_int
+        getattr(L, name).argtypes = [ctypes.c_void_p]
+    L.or_kinetic.restype = ctypes.c_double
+    L.or_kinetic.argtypes = [ctypes.c_void_p, _dp, _dp]
+    L.or_env_step.restype = ctypes.c_double
+    L.or_env_step.argtypes = [ctypes.c_void_p, _dp, _dp, _dp, _dp, _dp]
+    L.or_step.argtypes = [ctypes.c_void_p, _dp, _dp, _dp, _dp, _dp]
+    L.or_rollout.argtypes = [ctypes.c_void_p, _dp, _dp, _dp, ctypes.c_long, ctypes.c_int,
+                             _dp, _dp, _dp, _dp, _dp, _dp, _dp]
+    L.or_rollout_cl.argtypes = L.or_rollout.argtypes
+    L.or_threads.restype = ctypes.c_int
+    L.or_threads.argtypes = [ctypes.c_int]
+    return L
+
+
+def threads(n=0, native=False):
     """OpenMP threads used by RefArm.rollout (n > 0 sets the count first)."""
-    return _lib().or_threads(int(n))
+    return _lib(native).or_threads(int(n))
 
 
 def _p(a):
@@ -96,9 +142,10 @@ def _c(a):
 class RefArm:
     """FP64 reference arm: compiled from ``RawModel.to_flat()`` by the C oracle itself."""
 
-    def __init__(self, flat):
+    def __init__(self, flat, native=False):
+        """``native``: the -O3 -march=native build (bench.py's cpu_baseline leg); the checker uses the portable one."""
         flat = _c(flat)
-        self._L = _lib()
+        self._L = _lib(native)
         self._h = self._L.or_model_compile(_p(flat), flat.size)
         if not self._h:
             raise ValueError("oracle: bad model blob")

@@ -268,3 +268,47 @@ def test_closed_loop_linear_mode_on_the_tree_engine(model):
     np.testing.assert_allclose(rew1, o1[1], rtol=1e-9, atol=1e-9)
     with pytest.raises(ValueError):
         eng.rollout(P, H, W, noise, "closed_loop_quadratic")
+
+
+def test_per_shard_start_states_on_the_tree_engine():
+    """``SubprocVecEnv.set_env_state`` with one state dict per worker (subproc_vec_env.py:242-251) on the tree engine:
+    shard k's particles start from states[k] (open loop and closed_loop_linear), ``get_env_state`` returns one state per
+    shard, and a single dict brings every shard back to one state."""
+    from mjmpc_amd.envs.tree_engine import TreeRolloutEngine
+    from mjmpc_amd.models.hand24 import hand24_raw
+    from oracle.physics_ref import RefArm
+    raw = hand24_raw()
+    S = 2
+    eng, ref = TreeRolloutEngine(raw, dtype="f64", num_shards=S), RefArm(raw.to_flat())
+    tgt = np.array(raw.target_pos)
+    sts = [dict(STATES[k], target_pos=tgt + 0.05 * k) for k in range(S)]
+    P, H, A = 12, 6, 24
+    mean = 0.2 * np.random.RandomState(8).standard_normal((H, A))
+    noise = _noise(P, H, A, 77, 0.5)
+    eng.set_env_state([dict(s, qa=np.zeros(24), timestep=0) for s in sts])
+    got = eng.get_env_state()
+    assert len(got) == S and np.array_equal(got[1]["qp"], sts[1]["qp"]) and np.array_equal(got[1]["target_pos"], sts[1]["target_pos"])
+    obs, rew, act, done, info, nobs = eng.rollout(P, H, mean, noise, "open_loop")
+    n = P // S
+    for k, st in enumerate(sts):
+        o = ref.rollout(st["qp"], st["qv"], st["target_pos"], mean, noise[k * n:(k + 1) * n])
+        np.testing.assert_allclose(rew[k * n:(k + 1) * n], o[1], rtol=1e-9, atol=1e-9)
+        np.testing.assert_allclose(obs[k * n:(k + 1) * n], o[0], rtol=0, atol=1e-9)
+        np.testing.assert_allclose(nobs[k * n:(k + 1) * n], o[4], rtol=0, atol=1e-9)
+    assert np.abs(rew[:n] - rew[n:]).max() > 1e-3                     # the shards really differ
+    # closed_loop_linear: the fresh observation's site is taken per start state
+    W = 0.05 * np.random.RandomState(9).standard_normal((eng.d_obs + 1, A))
+    obs, rew, act, done, info, nobs = eng.rollout(P, H, W, noise, "closed_loop_linear")
+    for k, st in enumerate(sts):
+        o = ref.rollout(st["qp"], st["qv"], st["target_pos"], W, noise[k * n:(k + 1) * n], mode="closed_loop_linear")
+        np.testing.assert_allclose(rew[k * n:(k + 1) * n], o[1], rtol=1e-9, atol=1e-9)
+        np.testing.assert_allclose(act[k * n:(k + 1) * n], o[2], rtol=1e-9, atol=1e-9)
+    # back to one state for everybody
+    eng.set_env_state(dict(sts[1], qa=np.zeros(24), timestep=0))
+    assert len(eng.get_env_state()) == 1
+    _, rew1, _, _, _, _ = eng.rollout(P, H, mean, noise, "open_loop")
+    o = ref.rollout(sts[1]["qp"], sts[1]["qv"], sts[1]["target_pos"], mean, noise)
+    np.testing.assert_allclose(rew1, o[1], rtol=1e-9, atol=1e-9)
+    with pytest.raises(AssertionError):
+        eng.set_env_state([dict(sts[0]), dict(sts[1]), dict(sts[0])])
+    assert eng.solver_failures() == 0
