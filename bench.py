@@ -63,6 +63,16 @@ def parse(argv=None):
                     help="mppi (headline); cem: full covariance, elite_frac 0.1 (BASELINE config 4); dmd: DMD-MPC (config 5)")
     ap.add_argument("--scaling", choices=["weak", "strong"], default="weak")
     ap.add_argument("--no-graph", action="store_true", help="launch every kernel eagerly instead of replaying a hipGraph")
+    ap.add_argument("--no-mono", action="store_true",
+                    help="keep the control iteration in its separate launches (sampler, rollout, two update launches, env step) "
+                         "instead of the one-launch iteration (mjmpc_arm_mppi_step)")
+    ap.add_argument("--lookahead", action="store_true",
+                    help="enqueue iteration k+1 before waiting for the action of iteration k (the real env lives on the device, so "
+                         "nothing the host provides enters an iteration); off by default: every optimize() then starts after the "
+                         "previous action has reached the host")
+    ap.add_argument("--process-warmup", type=int, default=60,
+                    help="throw-away control steps before controller and env are reset and the W warm-up steps begin, so that "
+                         "the timed steps do not pay for a fresh process (idle clocks, first-touch, lazy runtime initialisation)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=10.0)
     ap.add_argument("--backend", default="nccl", help=argparse.SUPPRESS)          # test knobs: gloo on one GPU
@@ -185,7 +195,8 @@ def make_workload(args, local, comm, P_tot):
         w.update(name="reacher_7dof-v0", lam={"mppi": 0.01, "dmd": 0.1}, cov=1.0, env=None,
                  kernel="arm_rollout_kernel", target=np.array([0.1, 0.1, 0.1]), frame_skip=2, nv=7,
                  tail="closed loop from qpos0 to target [0.1,0.1,0.1]")
-        eng.set_env_state(dict(qp=np.zeros(7), qv=np.zeros(7), target_pos=w["target"]))
+        w["reset"] = lambda: eng.set_env_state(dict(qp=np.zeros(7), qv=np.zeros(7), target_pos=w["target"]))
+        w["reset"]()
     else:
         from mjmpc_amd.envs.tree_engine import TreeRolloutEngine
         from mjmpc_amd.models.compile_tree import compile_tree
@@ -207,10 +218,12 @@ def make_workload(args, local, comm, P_tot):
                       % ("" if args.workload != "hand24" else "; stand-in for pen-v0, whose assets are absent"))
         if env is not None:
             env.reset(seed=123)                         # the reference's reset noise, then the engine owns the state
-            eng.set_env_state(env.get_env_state())
-            w["x0"] = float(env.get_env_state()["qpos"][0])
+            st0 = env.get_env_state()
+            w["reset"] = lambda: eng.set_env_state(st0)
+            w["x0"] = float(st0["qpos"][0])
         else:
-            eng.reset()
+            w["reset"] = eng.reset
+        w["reset"]()
     A = eng.d_action
     kw = dict(d_state=eng.d_state, d_obs=eng.d_obs, d_action=A, horizon=H, num_particles=P_tot, n_iters=1,
               action_lows=eng.action_lows, action_highs=eng.action_highs, seed=123, base_action="null", gamma=1.0,
@@ -282,7 +295,7 @@ def main():
     ctrl.set_sim_state_fn = lambda s: None          # the "real" env lives on the device (step_state)
     state = {"resident": True}
     if graphed:
-        ctrl.enable_graph(post_step=eng.step_state)      # the env step is captured with the iteration
+        ctrl.enable_graph(post_step=eng.step_state, mono=not args.no_mono, lookahead=args.lookahead)   # the env step is captured with the iteration
 
     def control_step():
         action, _ = ctrl.optimize(state)
@@ -295,6 +308,17 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    # Process warm-up (outside the W warm-up steps and the timed region): a fresh process runs its first control steps up
+    # to 7 % slow - idle GPU clocks, first-touch of pinned and device buffers, lazily initialised runtime paths (measured:
+    # 20 timed steps after 5 warm-up steps 0.218-0.225 ms per step in a fresh process, 0.205 ms for the same 25 steps
+    # repeated in a warm one).  --process-warmup throw-away control steps run first; controller and env are then reset,
+    # so that the W warm-up steps and the K timed steps are the closed loop from the initial state, as without it.
+    if args.process_warmup > 0:
+        for _ in range(args.process_warmup):
+            control_step()
+        sync()
+        ctrl.reset()
+        w["reset"]()
     for _ in range(args.warmup):
         control_step()
     sync()
@@ -308,6 +332,18 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 
+    # where the closed loop ended up (read BEFORE the timing launches below, which - for the fused iteration - step the env)
+    extra = {}
+    if args.workload == "reacher":
+        _, nobs = eng.step_state(np.zeros(A))
+        extra["final_distance_to_target"] = float(torch.linalg.norm(nobs[17:20]).item())
+        qpos, qvel = np.zeros(7), np.zeros(7)           # the FLOP sample and the CPU baseline start where the run started
+    else:
+        st = eng.get_state_device()
+        qpos = st["qpos"] if "qpos" in st else st["qp"]
+        qvel = st["qvel"] if "qvel" in st else st["qv"]
+        if w["env"] is not None:
+            extra["forward_progress_m"] = float(qpos[0]) - w["x0"]      # since the reset (whose noise moves qpos[0] too)
     # The dominant kernel, timed with events on its launch stream: 20 back-to-back launches of the SAME entry point the
     # control iteration uses (inside a replayed graph there is nothing to bracket from the host) on the run's own buffers
     fused_entry = (args.noise == "device" and hasattr(base_fn, "fused") and not ctrl.use_zero_control_seq
@@ -317,8 +353,17 @@ def main():
         noise_t = last.get("noise")
     coeffs = ctrl.dev.record("coeffs", 3)
 
+    mono = graphed and getattr(ctrl, "_mono", False)
+    if mono:
+        chol_t, coeffs_t, _ = ctrl.dev.prepare_noise(ctrl._cov_host, ctrl.filter_coeffs)
+        t_step = torch.zeros(1, dtype=torch.int64, device="cuda")
+        t_rec = torch.zeros(2 + H * A, dtype=torch.float64, device="cuda") if world > 1 else None
+
     def launch():
-        if fused_entry:
+        if mono:        # the fused iteration's two launches from the state the run ended in (no env step: the state stays)
+            eng.mppi_step(P_loc, H, ctrl.dev.mean, ctrl.dev.mean_alt, ctrl.dev.gseq, coeffs_t, chol_t, ctrl.seed_val, 0, 0, t_step, ctrl.lam,
+                          ctrl.step_size, 0, record=t_rec, env_step=False)
+        elif fused_entry:
             eng.rollout_fused(P_loc, H, ctrl.dev.mean, noise_t, coeffs, ctrl.dev.gseq)
         else:
             eng.rollout_device(P_loc, H, ctrl.dev.mean, noise_t)
@@ -333,17 +378,6 @@ def main():
     torch.cuda.synchronize()
     kern_ms = e0.elapsed_time(e1) / n_t
 
-    extra = {}
-    if args.workload == "reacher":
-        _, nobs = eng.step_state(np.zeros(A))
-        extra["final_distance_to_target"] = float(torch.linalg.norm(nobs[17:20]).item())
-        qpos, qvel = np.zeros(7), np.zeros(7)           # the FLOP sample and the CPU baseline start where the run started
-    else:
-        st = eng.get_state_device()
-        qpos = st["qpos"] if "qpos" in st else st["qp"]
-        qvel = st["qvel"] if "qvel" in st else st["qv"]
-        if w["env"] is not None:
-            extra["forward_progress_m"] = float(qpos[0]) - w["x0"]      # since the reset (whose noise moves qpos[0] too)
     fails = eng.solver_failures()
 
     # HBM bytes of one launch of the dominant kernel from the PMC counters (separate rocprofv3 passes,
@@ -384,6 +418,8 @@ def main():
         except Exception as e:          # the counting build is measurement infrastructure: never lose the line over it
             valu = {"bound": "valu", "error": "FLOP-counting oracle build unavailable: %s" % (e,)}
     launch_kind = "hipGraph replay" if (graphed and not getattr(ctrl, "graph_fallback", False)) else "eager"
+    if graphed and getattr(ctrl, "_graph", None) == "direct":
+        launch_kind = "two kernels per iteration, launched directly"
     out = {
         "metric": "particle-steps/sec (%s %s %dp x H%d per GPU, control loop incl. noise, rollout, update, shift)"
                   % (w["name"], args.controller.upper() if args.controller != "dmd" else "DMD-MPC", P_loc, H),
@@ -396,7 +432,9 @@ def main():
                    "horizon": H, "ranks_seen": dist.get_world_size() if world > 1 else 1,
                    "backend": (dist.get_backend() if world > 1 else None),
                    "collectives_per_step": (0 if world == 1 else (2 if args.controller == "cem" else 1)),
-                   "launch": launch_kind},
+                   "launch": launch_kind + (", rollout + record launches, all-gather, combine, env step" if (mono and world > 1) else "")
+                             + (", next iteration enqueued ahead" if (mono and args.lookahead and world == 1) else ""),
+                   "process_warmup_steps": args.process_warmup},
         "control_loop_hz": args.steps / dt,
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
@@ -405,8 +443,9 @@ def main():
                      "alg_bytes_per_launch": b_alg * P_loc * H,
                      "kernel": "%s<%s>" % (w["kernel"], "double" if args.dtype == "f64" else "float"),
                      "kernel_ms": kern_ms,
-                     "kernel_entry": ("mjmpc_arm_rollout" if args.workload == "reacher" else "mjmpc_tree_rollout")
-                                     + ("_fused" if fused_entry else ""),
+                     "kernel_entry": ("mjmpc_arm_mppi_step (two launches: sampling + rollout + cost-to-go | update + action + shift; kernel_ms is their sum, without the env step the second launch also takes in the loop)"
+                                      if mono else ("mjmpc_arm_rollout" if args.workload == "reacher" else "mjmpc_tree_rollout")
+                                      + ("_fused" if fused_entry else "")),
                      "alg_bytes_per_particle_step": b_alg,
                      "note": "latency/VALU-bound path (SURVEY 8d): >100 counted FLOP per algorithmic byte, HBM fraction is small by "
                              "construction; `valu` is the roofline that binds"},

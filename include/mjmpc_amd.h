@@ -106,6 +106,30 @@ int mjmpc_arm_rollout_fused(mjmpc_arm_t h, int dtype, int64_t P, int H, const do
                             const double* d_filter_coeffs, const double* d_gseq, void* d_costs, void* d_actions,
                             double* d_q0, void* stream);
 
+/* One Controller.optimize() of MPPI / DMD-MPC without covariance adaptation (controller.py:207-257: generate_rollouts ->
+ * _update_distribution -> _get_next_action -> _shift) plus env.step of the closed loop (examples/example_mpc.py:165-168)
+ * in TWO launches, for a diagonal action covariance, per-particle softmax weights and no control cost (mppi.py:69-97 with
+ * alpha = 1, gaussian_dmd.py:65-104 with update_cov = False):
+ *   1. the rollout kernel draws the samples itself - the Philox stream of mjmpc_sample_noise (diag(d_chol) colours it,
+ *      d_filter_coeffs float64[3] or NULL filters it as control_utils.py:32-33), keyed by (seed, offset + *d_step_counter,
+ *      particle_offset + particle, channel, t) -, keeps its particles' actions in LDS and leaves one softmax record
+ *      {max, S, W[H][A]} per workgroup;
+ *   2. the finish kernel (H workgroups) merges the records: d_mean_out <- shift((1 - step_size) d_mean + step_size W / S)
+ *      (shift_mode 0 'null', 1 'repeat', < 0 none; d_mean_out must NOT alias d_mean, which the launch only reads); the
+ *      action (row 0 of the updated mean) goes to d_action_out (device float64[A], may be NULL) and to h_action_slots
+ *      (MAPPED PINNED host float64[2][A + 1], may be NULL: slot (*d_step_counter & 1) receives the action and then, as
+ *      completion flag, the new step count); *d_step_counter advances; env_step != 0: the engine state advances by one
+ *      env step with that action (d_step_cost dtype[1], d_step_next_obs dtype[d_obs], may be NULL).
+ *   Sharded runs pass d_record (float64 [2 + H*A]): step 2 then leaves this GPU's record {max, S, W} there and nothing
+ *   else (all-gather, then mjmpc_mppi_fused_combine and mjmpc_arm_step_state); d_mean_out is not used.
+ * d_gseq float64[H] (gamma_seq, no zero entry).  d_costs / d_actions (dtype [P][H] / [P][H][A]) and d_q0 (float64 [P])
+ * are optional outputs.  One model block and one start state only. */
+int mjmpc_arm_mppi_step(mjmpc_arm_t h, int dtype, int64_t P, int H, const double* d_mean, double* d_mean_out,
+                        const double* d_gseq, const double* d_filter_coeffs, const double* d_chol, uint64_t seed,
+                        uint64_t offset, int64_t particle_offset, int64_t* d_step_counter, double lam, double step_size,
+                        int shift_mode, double* d_action_out, double* h_action_slots, double* d_record, int env_step,
+                        void* d_step_cost, void* d_step_next_obs, void* d_costs, void* d_actions, double* d_q0, void* stream);
+
 /* env.step of the "real" environment kept on the device (examples/example_mpc.py:168 ->
  * Reacher7DOFEnv.step, reacher_env.py:29-39): advances the engine state IN PLACE by one env step
  * under d_action (float64 [A]), writes the step cost (= -reward, dtype[1]) and, if not NULL, the

@@ -77,6 +77,7 @@ class DeviceUpdater:
         self.gamma_zero = int(bool(np.any(g == 0)))
         self.gseq = torch.from_numpy(g.copy()).to(self.device)
         self.mean = torch.zeros((self.H, self.A), dtype=torch.float64, device=self.device)
+        self.mean_alt = torch.zeros_like(self.mean)       # the fused iteration writes the new mean here, then the two swap
         self.cov = torch.zeros((self.A, self.A), dtype=torch.float64, device=self.device)
         self.covinv = torch.zeros((self.A, self.A), dtype=torch.float64, device=self.device)
         self.value = torch.zeros(1, dtype=torch.float64, device=self.device)
@@ -241,6 +242,14 @@ class DeviceUpdater:
                                                      float(step_size), int(shift_mode), _vp(self.mean),
                                                      _vp(action_out), None, _vp(action_pinned), _vp(step_counter),
                                                      self.stream()))
+
+    def mppi_fused_combine(self, rec, P_local, lam, step_size, shift_mode, action_out, action_pinned, step_counter):
+        """Sharded one-launch iterations: all-gather this GPU's record and finish the iteration on every rank."""
+        recs = self.comm.all_gather(rec)
+        G = recs.shape[0]
+        _lib.check(self.lib.mjmpc_mppi_fused_combine(_vp(recs), G, float(P_local * G), self.H, self.A, float(lam),
+                                                     float(step_size), int(shift_mode), _vp(self.mean), _vp(action_out),
+                                                     None, _vp(action_pinned), _vp(step_counter), self.stream()))
 
     # ------------------------------------------------------------------ CEM
     def cem_update(self, costs, actions, num_elite, step_size, full_cov, q0=None):
@@ -408,6 +417,20 @@ class DeviceUpdater:
                                                    _vp(co), self.stream()))
         return buf
 
+    def prepare_noise(self, cov, filter_coeffs):
+        """Upload the sampler's parameters for a HOST covariance (Cholesky factor, filter coefficients) without drawing:
+        what ``sample_noise`` does ahead of its launch.  Returns (chol, coeffs, chol_is_diagonal)."""
+        torch = self.torch
+        fc = np.asarray(filter_coeffs, np.float64)
+        cov = np.asarray(cov, np.float64)
+        cached = self._rec.get("noise_params")
+        if cached is None or cached[0] is None or not (np.array_equal(cached[0], cov) and np.array_equal(cached[1], fc)):
+            self.record("chol", self.A * self.A).copy_(torch.from_numpy(np.linalg.cholesky(cov).reshape(-1).copy()))
+            self.record("coeffs", 3).copy_(torch.from_numpy(fc.copy()))
+            self._rec["noise_params"] = (cov.copy(), fc.copy())
+            self._rec["chol_diag"] = int(np.count_nonzero(cov - np.diag(np.diag(cov))) == 0)
+        return self._rec["chol"], self._rec["coeffs"], self._rec["chol_diag"]
+
     def sample_noise(self, P, cov, filter_coeffs, seed, offset, dtype="f64", particle_offset=0, d_step=None,
                      filtered=True, device_cov_diagonal=False):
         """Philox noise coloured by ``cov`` (host array), or - ``cov=None`` - by the device-resident ``self.cov``
@@ -431,16 +454,7 @@ class DeviceUpdater:
                 self._rec["noise_params"] = (None, fc.copy())
             self._rec["chol_diag"] = int(bool(device_cov_diagonal))
         else:
-            cov = np.asarray(cov, np.float64)
-            cached = self._rec.get("noise_params")
-            if cached is None or cached[0] is None or not (np.array_equal(cached[0], cov)
-                                                           and np.array_equal(cached[1], fc)):
-                chol = self.record("chol", self.A * self.A)
-                chol.copy_(torch.from_numpy(np.linalg.cholesky(cov).reshape(-1).copy()))
-                co = self.record("coeffs", 3)
-                co.copy_(torch.from_numpy(fc.copy()))
-                self._rec["noise_params"] = (cov.copy(), fc.copy())
-                self._rec["chol_diag"] = int(np.count_nonzero(cov - np.diag(np.diag(cov))) == 0)
+            self.prepare_noise(cov, fc)
         chol, co = self._rec["chol"], self._rec["coeffs"]
         _lib.check(self.lib.mjmpc_sample_noise(_lib.F32 if dtype == "f32" else _lib.F64, _vp(buf), P, self.H, self.A,
                                                _vp(chol), _vp(co) if filtered else None, int(seed) & (2 ** 64 - 1),

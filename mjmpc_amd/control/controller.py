@@ -168,6 +168,10 @@ class OLGaussianMPC(Controller):
         self._graph = None
         self._graph_post = None
         self._graph_on = False
+        self._want_mono = True
+        self._mono = False
+        self._lookahead = False
+        self._ahead = 0
         self._push()
 
     # -- host <-> device mirrors ---------------------------------------------------------------
@@ -270,12 +274,22 @@ class OLGaussianMPC(Controller):
         return self._rollout_fn(self.local_particles, self.horizon, mean, delta, mode="open_loop")
 
     # -- hipGraph fast path ---------------------------------------------------------------------
-    def enable_graph(self, post_step=None):
+    def enable_graph(self, post_step=None, lookahead=False, mono=True):
         """Capture one whole control iteration (noise -> rollout -> update -> action -> shift) as a
         hipGraph and replay it from ``optimize()``: one launch and one stream sync per step instead of
         ~12 launches.  Needs a device-resident pipeline: ``noise_mode='device'``, a rollout_fn made by
         ``make_device_rollout_fn``, a static covariance, and a shift that needs no host RNG.
-        ``post_step(action_tensor)`` is captured too (e.g. stepping the real env on the device)."""
+        ``post_step(action_tensor)`` is captured too (e.g. stepping the real env on the device).
+
+        ``mono``: where the engine offers it (``rollout_fn.mono``: MPPI / DMD-MPC with a static diagonal covariance on
+        the arm engine) the iteration is ONE kernel - sampling, rollout, update, action, shift and, if ``post_step`` is
+        that engine's own ``step_state``, the env step (``mjmpc_arm_mppi_step``).
+
+        ``lookahead``: the caller promises that the states it passes to ``optimize()`` carry no information - the real
+        env lives on the device and ``post_step`` advances it - so iteration k + 1 depends on nothing the host provides.
+        ``optimize()`` then enqueues iteration k + 1 BEFORE it waits for the action of iteration k: the GPU goes from
+        one iteration to the next without waiting for the host's round trip.  The device then runs one iteration
+        ahead of the actions the host has seen; host mirrors (``mean_action``) read the device's latest."""
         if not self._graph_capable():
             raise ValueError("this controller configuration cannot run as a captured graph "
                              "(needs noise_mode='device', a device rollout_fn, static covariance, "
@@ -284,6 +298,10 @@ class OLGaussianMPC(Controller):
         self._graph_post = post_step
         self._graph = None
         self._noise_valid = False
+        self._want_mono = bool(mono)
+        self._mono = False
+        self._lookahead = bool(lookahead)
+        self._ahead = 0                 # iterations enqueued beyond the ones whose action the host has taken
 
     def _host_uploads_per_step(self):
         return False            # subclasses whose _device_update uploads host tables on every call say True
@@ -328,13 +346,58 @@ class OLGaussianMPC(Controller):
         """Host covariance for the sampler, or None when the covariance adapts on the device."""
         return self._cov_host if self._static_cov() else None
 
+    def _bind_mono(self, env_step):
+        """Bind the fused iteration's arguments once (``rollout_fn.mono_launcher``): per step it is one C call."""
+        n_loc = self.local_particles
+        chol, coeffs, _ = self.dev.prepare_noise(self._cov_host, self.filter_coeffs)
+        fc = np.asarray(self.filter_coeffs, np.float64)
+        coeffs = None if (fc[0] == 1.0 and fc[1] == 0.0 and fc[2] == 0.0) else coeffs
+        eng = getattr(self._rollout_fn, "engine", None)
+        post = self._graph_post
+        own_step = post is not None and getattr(post, "__self__", None) is eng and getattr(post, "__name__", "") == "step_state"
+        sharded = self.dev.comm.world_size > 1
+        self._mono_rec = self.dev.record("fused_rec", 2 + self.horizon * self.d_action) if sharded else None
+        self._mono_steps_env = bool(env_step and own_step and not sharded)
+        # one bound launcher per direction of the mean's double buffer (the iteration reads one tensor and writes the
+        # other; _device_iteration swaps them afterwards and picks the launcher by the tensor that is the mean then)
+        self._mono_launch = {}
+        for src, dst in ((self.dev.mean, self.dev.mean_alt), (self.dev.mean_alt, self.dev.mean)):
+            self._mono_launch[id(src)], _ = self._rollout_fn.mono_launcher(
+                n_loc, self.horizon, src, dst, self.dev.gseq, coeffs, chol, self.seed_val, 0, self.dev.comm.rank * n_loc,
+                self._step_dev, self.lam, self.step_size, _SHIFT_MODES[self.base_action], action_out=self._action_dev,
+                action_slots=None if sharded else self._action_pin, record=self._mono_rec, env_step=self._mono_steps_env)
+
     def _noise_ahead(self):
         """Captured fused iterations with the Philox sampler draw the next step's samples inside the update."""
-        return self._graph_on and self.noise_mode == 'device' and self._fused_capable()
+        return self._graph_on and self.noise_mode == 'device' and self._fused_capable() and not self._mono
+
+    def _mono_capable(self):
+        """The whole iteration in one launch (``rollout_fn.mono``): the fused MPPI / DMD-MPC update, the Philox sampler,
+        a static DIAGONAL covariance, one iteration per step."""
+        if not (getattr(self, "_want_mono", True) and self._graph_on and self.noise_mode == 'device' and self.n_iters == 1
+                and self._fused_capable() and self._static_cov() and hasattr(self._rollout_fn, "mono")):
+            return False
+        cov = np.asarray(self._cov_host, np.float64)
+        eng = getattr(self._rollout_fn, "engine", None)
+        if hasattr(eng, "mppi_step_supported") and not eng.mppi_step_supported(self.local_particles, self.horizon):
+            return False
+        return (np.count_nonzero(cov - np.diag(np.diag(cov))) == 0 and getattr(eng, "num_shards", 1) == 1
+                and not getattr(eng, "_per_shard_states", False) and not hasattr(eng, "shard_blobs")
+                and getattr(eng, "dtype", self.noise_dtype) == self.noise_dtype)
 
     def _device_iteration(self):
         """The control iteration without any host synchronisation (capturable)."""
         n_loc = self.local_particles
+        if self._mono:
+            self._mono_launch[id(self.dev.mean)]()
+            if self.dev.comm.world_size == 1:       # the new mean was written to the other buffer: it is the mean now
+                self.dev.mean, self.dev.mean_alt = self.dev.mean_alt, self.dev.mean
+            else:
+                self.dev.mppi_fused_combine(self._mono_rec, n_loc, self.lam, self.step_size, _SHIFT_MODES[self.base_action],
+                                            self._action_dev, self._action_pin, self._step_dev)
+            if self._graph_post is not None and not self._mono_steps_env:
+                self._graph_post(self._action_dev)
+            return
         if self._fused_capable():
             # noise (raw) -> rollout (filters the noise, emits the cost-to-go) -> update + action + shift
             coeffs = self.dev.record("coeffs", 3)
@@ -396,63 +459,91 @@ class OLGaussianMPC(Controller):
         self._sync_in()
         self._set_sim_state_fn(copy.deepcopy(state))
         if self._graph is None:
+            self._mono = self._mono_capable()           # (decided once per capture: the test reads host arrays)
             self._step_dev = torch.full((1,), self.num_steps, dtype=torch.int64, device=self.dev.device)
             self._step_host = self.num_steps
             self._action_dev = torch.zeros(self.d_action, dtype=torch.float64, device=self.dev.device)
-            self._action_pin = torch.zeros(self.d_action + 1, dtype=torch.float64).pin_memory()    # action | step flag
+            # action | step flag, two slots: one-launch iterations publish into slot (step & 1), the others into slot 0
+            self._action_pin = torch.zeros(2 * (self.d_action + 1), dtype=torch.float64).pin_memory()
             self._action_np = self._action_pin.numpy()
-            # eager dry run on a side stream (allocates every buffer), with the state it must not consume
-            keep = (self.dev.mean.clone(), self._step_dev.clone(), self.dev.cov.clone())
-            side = torch.cuda.Stream(self.dev.device)
-            side.wait_stream(torch.cuda.current_stream(self.dev.device))
-            post, self._graph_post = self._graph_post, None
-            with torch.cuda.stream(side):
-                if self._noise_ahead():
-                    self._draw_raw(self.local_particles, 0)     # buffer + sampler parameters for the dry run
-                self._device_iteration()
-            torch.cuda.current_stream(self.dev.device).wait_stream(side)
-            torch.cuda.synchronize(self.dev.device)
-            self._graph_post = post
-            self.dev.mean.copy_(keep[0])
-            self._step_dev.copy_(keep[1])
-            self.dev.cov.copy_(keep[2])
-            self._noise_valid = False       # the dry run left the samples of step + 1 behind
-            err = None
-            try:
-                g = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(g):
-                    self._device_iteration()
-                self._graph = g
-            except Exception as e:          # e.g. a collective that cannot be captured
-                err = e
-            # Sharded runs decide TOGETHER (one all-reduce outside the capture): a rank that fell back alone would
-            # issue a different collective sequence than its peers.  Every rank then runs eagerly, or none does.
-            if not self.dev.comm.all_agree(err is None, self.dev.device):
-                import warnings
-                warnings.warn("hipGraph capture of the control iteration failed (%s); running eagerly"
-                              % (err if err is not None else "on another rank",))
-                torch.cuda.synchronize(self.dev.device)
-                self.dev.mean.copy_(keep[0])
-                self.dev.cov.copy_(keep[2])
-                self._graph_on = False
-                self._graph = None
-                self.graph_fallback = True
-                return self._optimize_eager_after_fallback(state)
+            if self._mono and self.dev.comm.world_size == 1:
+                # one kernel per iteration: nothing to capture - the launch is enqueued directly (a hipGraph replay of a
+                # one-kernel graph costs ~13 us between replays on the device side, a plain launch next to nothing)
+                self._bind_mono(env_step=True)
+                self._graph = "direct"
+            else:
+                self._capture_iteration()
+        if self._graph is None:                 # capture failed: every rank has dropped to eager launches
+            return self._optimize_eager_after_fallback(state)
         if self._step_host != self.num_steps:
+            if self._ahead:
+                raise RuntimeError("num_steps was changed while an iteration enqueued ahead was in flight")
             self._step_dev.fill_(self.num_steps)
             self._noise_valid = False
         if self._noise_ahead() and not self._noise_valid:
             self._draw_raw(self.local_particles, 0)             # the current step's samples (first step / after a jump)
             self._noise_valid = True
-        self._action_np[self.d_action] = -1.0               # completion flag (see _wait_action)
-        self._graph.replay()
+        replay = self._device_iteration if self._graph == "direct" else self._graph.replay
+        if self._ahead == 0:
+            self._action_np[self._slot(self.num_steps) + self.d_action] = -1.0      # completion flag (see _wait_action)
+            replay()
+            self._ahead = 1
+        if self._lookahead and self._mono and self.dev.comm.world_size == 1:
+            # iteration k + 1 goes into the queue before the host waits for the action of iteration k
+            self._action_np[self._slot(self.num_steps + 1) + self.d_action] = -1.0
+            replay()
+            self._ahead += 1
         action = self._wait_action()
+        self._ahead -= 1
         self.num_steps += 1
         self._step_host = self.num_steps
         self._mean_stale = True
         if not self._static_cov():
             self._cov_stale = True
         return action, 0.0
+
+    def _capture_iteration(self):
+        """Capture the control iteration as a hipGraph (``self._graph``; None if the runtime refused and every rank
+        agreed to run eagerly)."""
+        torch = self.dev.torch
+        if self._mono:
+            self._bind_mono(env_step=False)         # (sharded: the env step follows the combine as a launch of its own)
+        # eager dry run on a side stream (allocates every buffer), with the state it must not consume
+        keep = (self.dev.mean.clone(), self._step_dev.clone(), self.dev.cov.clone())
+        side = torch.cuda.Stream(self.dev.device)
+        side.wait_stream(torch.cuda.current_stream(self.dev.device))
+        post, self._graph_post = self._graph_post, None
+        with torch.cuda.stream(side):
+            if self._noise_ahead():
+                self._draw_raw(self.local_particles, 0)     # buffer + sampler parameters for the dry run
+            self._device_iteration()
+        torch.cuda.current_stream(self.dev.device).wait_stream(side)
+        torch.cuda.synchronize(self.dev.device)
+        self._graph_post = post
+        self.dev.mean.copy_(keep[0])
+        self._step_dev.copy_(keep[1])
+        self.dev.cov.copy_(keep[2])
+        self._noise_valid = False       # the dry run left the samples of step + 1 behind
+        err = None
+        try:
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                self._device_iteration()
+            self._graph = g
+        except Exception as e:          # e.g. a collective that cannot be captured
+            err = e
+        # Sharded runs decide TOGETHER (one all-reduce outside the capture): a rank that fell back alone would
+        # issue a different collective sequence than its peers.  Every rank then runs eagerly, or none does.
+        if not self.dev.comm.all_agree(err is None, self.dev.device):
+            import warnings
+            warnings.warn("hipGraph capture of the control iteration failed (%s); running eagerly"
+                          % (err if err is not None else "on another rank",))
+            torch.cuda.synchronize(self.dev.device)
+            self.dev.mean.copy_(keep[0])
+            self.dev.cov.copy_(keep[2])
+            self._graph_on = False
+            self._graph = None
+            self.graph_fallback = True
 
     def _wait_action(self):
         """The action of the replayed iteration.  The fused update writes it into mapped pinned memory followed by
@@ -464,14 +555,20 @@ class OLGaussianMPC(Controller):
         if not self._fused_capable():
             self.dev.torch.cuda.current_stream(self.dev.device).synchronize()
             return self._action_np[:A].copy()
+        o = self._slot(self.num_steps)
         flag, want, spins = self._action_np, float(self.num_steps + 1), 0
-        while flag[A] != want:
+        while flag[o + A] != want:
             spins += 1
             if spins > 2000000:                         # ~1 s without an answer: let the runtime report what happened
                 self.dev.torch.cuda.current_stream(self.dev.device).synchronize()
-                if flag[A] != want:
+                if flag[o + A] != want:
                     raise RuntimeError("captured control iteration finished without publishing its action")
-        return flag[:A].copy()
+        return flag[o:o + A].copy()
+
+    def _slot(self, step):
+        """Offset of the pinned slot the iteration of ``step`` publishes into (see _optimize_graphed)."""
+        two = self._mono and self.dev.comm.world_size == 1
+        return (step & 1) * (self.d_action + 1) if two else 0
 
     def _optimize_eager_after_fallback(self, state):
         action, value = Controller.optimize(self, state, False, True)
@@ -501,6 +598,9 @@ class OLGaussianMPC(Controller):
         self._pull()
 
     def reset(self):
+        if self._ahead:                 # an iteration enqueued ahead is still running: let it finish before the state goes
+            self.dev.torch.cuda.synchronize(self.dev.device)
+            self._ahead = 0
         self.num_steps = 0
         self.mean_action = np.zeros(shape=(self.horizon, self.d_action))
         self.cov_action = np.diag(self.init_cov)

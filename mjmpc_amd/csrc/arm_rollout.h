@@ -21,10 +21,48 @@ struct RolloutFusion {
     double* q0_out = nullptr;
 };
 
+// TWO launches per control iteration (mjmpc_arm_mppi_step).  The rollout kernel draws its own samples, keeps the actions
+// of its particles in LDS and leaves one softmax record {max, S, W[H][A]} per workgroup; the finish kernel (H workgroups,
+// one per horizon row) merges the records, updates the mean (mppi.py:69-82), publishes the action, shifts the horizon
+// (olgaussian_mpc.py:116-129) and steps the device-resident real env - sampling, GymEnvWrapper.rollout, cost_to_go,
+// _update_distribution, _get_next_action, _shift and env.step of one Controller.optimize().
+struct MonoStep {
+    // sampler: eps_raw[p][t][a] = chol[a][a] z(seed, offset + *d_step, p + particle_offset, a, t) - the Philox draws of
+    // noise.hip's noise_kernel for a DIAGONAL covariance, made by the lane that consumes them
+    const double* chol = nullptr;           // device [A][A]
+    unsigned long long seed = 0, offset = 0;
+    long particle_offset = 0;
+    const long long* d_step = nullptr;
+    // update
+    double lam = 1.0, step_size = 1.0;
+    int shift_mode = 0;                     // 0 'null', 1 'repeat', < 0 no shift
+    double* tree = nullptr;                 // one record [2 + H A] per rollout workgroup (mono_record_doubles)
+    double* action_out = nullptr;           // device [A]
+    double* action_host = nullptr;          // mapped pinned [2][A + 1]: slot (step & 1) = action | completion flag (step + 1)
+    long long* step_counter = nullptr;      // advanced by one
+    double* record = nullptr;               // sharded runs: this GPU's record [max | S | W[H*A]] INSTEAD of update/shift/env step
+    // real env: advanced in place by one env step with the new action
+    double* state_io = nullptr;
+    void* step_cost = nullptr;              // T[1]
+    void* step_nobs = nullptr;              // T[2 nv + 6]
+};
+long mono_record_doubles(long groups, int H, int A);
+
 // Fused (particles x horizon x frame_skip) rollout of a compiled arm; see arm_rollout.hip.
 template <typename T>
 hipError_t launch_arm_rollout(const T* model, const double* state, long P, int H, int A, const double* mean,
                               const T* noise, T* cost, T* act, T* obs, T* nobs, double* state_out,
-                              unsigned* diag, hipStream_t stream, RolloutFusion fuse = RolloutFusion());
+                              unsigned* diag, hipStream_t stream, RolloutFusion fuse = RolloutFusion(),
+                              const MonoStep* mono = nullptr, const MonoStep* mono_dev = nullptr);
+// (mono: host copy, checked by the launcher; mono_dev: the same structure in device memory, read by the kernels - written
+// there by upload_mono_params, a one-thread kernel, so that it is stream-ordered and capturable)
+hipError_t upload_mono_params(const MonoStep& mo, MonoStep* dst, hipStream_t stream);
+// the finish launch: records [n_rec][2 + H A] -> mean_out (mean_in is only read; the two must not alias), action, step
+// counter, env step (env_step != 0); or, with mono->record, this GPU's record
+template <typename T>
+hipError_t launch_arm_mppi_finish(const T* model, const double* records, long n_rec, int H, int A, const double* mean_in,
+                                  double* mean_out, const MonoStep* mono_dev, int env_step, unsigned* diag, hipStream_t stream);
+// workgroups the launch of P particles uses (the reduction tree is sized by it)
+long arm_rollout_groups(long P);
 
 }  // namespace mjmpc

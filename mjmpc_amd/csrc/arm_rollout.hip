@@ -26,6 +26,7 @@
 #include "arm_model.h"
 #include "arm_rollout.h"
 #include "lanegroup.h"
+#include "noise_device.h"
 
 namespace mjmpc {
 namespace {
@@ -250,7 +251,10 @@ struct Dense {
 // and back.  The stride keeps 16-byte alignment and shifts consecutive particles by 4 (f32) / 8 (f64) banks.
 constexpr int V_DH = LANES * LANES, V_RH = V_DH + LANES, V_DE = V_RH + LANES, V_RE = V_DE + LANES, V_XH = V_RE + LANES,
               V_XE = V_XH + LANES, V_JC = V_XE + LANES, V_TAU = V_JC + LANES, V_EI = V_TAU + LANES,
-              PSTRIDE = V_EI + LANES * LANES + 4;      // V_EI: (M + h B)^-1, DUO only
+              PSTRIDE = V_EI + LANES * LANES + 4,      // V_EI: (M + h B)^-1, DUO only
+              // the limit rows the DYN wave hands to the SOLVE wave at E1 travel in vectors the SOLVE wave only
+              // (re)writes after it has taken them, and nobody touches between E3 and E1
+              V_LS = V_XH, V_LD = V_DH, V_LA = V_RH;
 
 // u_i += sum_k W[k][i] q_k + W[nv+k][i] v_k   (the joint part of clw^T obs), link values by DPP broadcast
 template <int K, typename T>
@@ -502,6 +506,36 @@ __device__ __forceinline__ void active_set(T aw, T sig, T aref, T jc, T arefc, b
     }
 }
 
+// DUO launches: which wave evaluates the joint-limit rows (see arm_front)
+template <typename T>
+__device__ __forceinline__ constexpr bool rows_by_dyn() {
+#ifdef ARM_ROWS_IN_SOLVE
+    return false;
+#else
+    return sizeof(T) == 8;
+#endif
+}
+
+// joint-limit row of my dof (MuJoCo mj_instantiateLimit, strict dist < margin(=0)): sig = +-1 (0: no row), and - when
+// some lane of the wavefront has a row - its regulariser D = 1 / R and reference acceleration
+template <typename T, typename MT>
+__device__ __forceinline__ void limit_row(const MT& M, T q, T v, T& sig, T& D, T& aref) {
+    T dist = T(0);
+    sig = T(0);
+    if (M.link(O_LIMITED) != T(0)) {
+        const T dlo = q - M.link(O_RANGE_LO), dhi = M.link(O_RANGE_HI) - q;
+        if (dlo < T(0)) { sig = T(1); dist = dlo; }
+        else if (dhi < T(0)) { sig = T(-1); dist = dhi; }
+    }
+    D = T(0);
+    aref = T(0);
+    if (__any(sig != T(0))) {
+        row_params(M, dist, M.link(O_DOF_INVW), sig * v, D, aref);
+        D = sig != T(0) ? D : T(0);
+        aref = sig != T(0) ? aref : T(0);
+    }
+}
+
 template <int ROLE, typename T, typename MT>
 __device__ __forceinline__ void arm_front(const MT& M, const ArmInts& I, T& q, T& v, T& aw, T& sq, T& cq,
                                           int& rows, T tau_act, T* ldsM, int lane, int l8, T* site,
@@ -547,7 +581,18 @@ __device__ __forceinline__ void arm_front(const MT& M, const ArmInts& I, T& q, T
         // 5. smooth force: -bias + passive damping + motor, handed to the SOLVE wave
         const T bias = bias_force(M, L, v, l8);
         ldsM[V_TAU + l8] = -bias - M.link(O_DAMPING) * v + tau_act;
-        ST.mark(2);     // velocities, bias forces
+        // the joint-limit rows too (a function of q and v alone): this wave reaches E1 ~700 cycles before the SOLVE
+        // wave, which used to spend ~800 on them right after it
+        // (f64 only: 181 -> 176.5 us per 4096 x 32 launch; in f32, whose scans are single instructions, the DYN wave has
+        // no such slack and the move costs 3 %.  ARM_ROWS_IN_SOLVE: developer A/B switch back to the round-2 split)
+        if constexpr (rows_by_dyn<T>()) {
+            T sg, Dl, al;
+            limit_row(M, q, v, sg, Dl, al);
+            ldsM[V_LS + l8] = sg;
+            ldsM[V_LD + l8] = Dl;
+            ldsM[V_LA + l8] = al;
+        }
+        ST.mark(2);     // velocities, bias forces, limit rows
         duo_barrier();                                  // E1: tau out; mass-matrix tile and Euler diagonal in
         ST.mark(3);
         // 8'. explicit inverse of the Euler matrix M + h B while the SOLVE wave works on the constraints: every lane
@@ -586,15 +631,20 @@ __device__ __forceinline__ void arm_front(const MT& M, const ArmInts& I, T& q, T
     }
     T ei[MAX_LINKS];            // SOLVE: my row of (M + h B)^-1 (read once the DYN wave has published it)
 
-    // 6. constraint rows.  Limits: MuJoCo mj_instantiateLimit, strict dist < margin(=0)
-    T sig = T(0), dist = T(0);
+    // 6. constraint rows.  Limits (SOLVE: evaluated by the DYN wave before E1)
+    T sig = T(0), dist = T(0), D = T(0), aref = T(0);
     bool inst = false;
-    if (M.link(O_LIMITED) != T(0)) {
+    constexpr bool rows_from_dyn = ROLE == SOLVE && rows_by_dyn<T>();
+    if constexpr (rows_from_dyn) {
+        sig = ldsM[V_LS + l8];
+        D = ldsM[V_LD + l8];
+        aref = ldsM[V_LA + l8];
+        inst = sig != T(0);
+    } else if (M.link(O_LIMITED) != T(0)) {
         T dlo = q - M.link(O_RANGE_LO), dhi = M.link(O_RANGE_HI) - q;
         if (dlo < T(0)) { sig = T(1); dist = dlo; inst = true; }
         else if (dhi < T(0)) { sig = T(-1); dist = dhi; inst = true; }
     }
-    T D = T(0), aref = T(0);
     // plane-sphere contact (condim 1): mjc_PlaneSphere + mj_instantiateContact
     bool cinst = false;
     T jc = T(0), Dc = T(0), arefc = T(0);
@@ -613,10 +663,12 @@ __device__ __forceinline__ void arm_front(const MT& M, const ArmInts& I, T& q, T
     }
     const bool any_rows = __any(inst || cinst);
     if (!any_rows) rows = 0;
-    if (any_rows) {
-        row_params(M, dist, M.link(O_DOF_INVW), sig * v, D, aref);
-        D = inst ? D : T(0);
-        aref = inst ? aref : T(0);
+    if constexpr (!rows_from_dyn) {
+        if (any_rows) {
+            row_params(M, dist, M.link(O_DOF_INVW), sig * v, D, aref);
+            D = inst ? D : T(0);
+            aref = inst ? aref : T(0);
+        }
     }
     ST.mark(5);         // constraint rows
     // initial active set: a row that existed in the previous substep keeps its state, a new row is assumed
@@ -660,13 +712,10 @@ __device__ __forceinline__ void arm_front(const MT& M, const ArmInts& I, T& q, T
                 for (int i = 0; i < MAX_LINKS; ++i) col[i] = (i == l8) ? T(1) : T(0);
                 F.solve(col);
                 ST.mark(it == 0 ? 6 : 9);               // factorisation + inverse / further iterations
-                // E2: the DYN wave finished (M + h B)^-1 long ago (it needs ~1000 cycles after E1, this wave ~2000 to get
-                // here): taking the rendezvous now instead of at the end of the substep leaves only E3 between the last
-                // Newton iteration and the integration
-                if (it == 0) {
+                if (it == 0 && !rows_by_dyn<T>()) {     // (E2 where round 2 had it: this wave arrives ~2000 cycles after E1)
                     duo_barrier();
 #pragma unroll
-                    for (int i = 0; i < MAX_LINKS; ++i) ei[i] = ldsM[V_EI + l8 * LANES + i];   // my row of (M + h B)^-1, early
+                    for (int i = 0; i < MAX_LINKS; ++i) ei[i] = ldsM[V_EI + l8 * LANES + i];
                 }
                 T acc = T(0);
 #pragma unroll
@@ -678,6 +727,15 @@ __device__ __forceinline__ void arm_front(const MT& M, const ArmInts& I, T& q, T
                 changed = flip || cflip;
                 act = act2;
                 cact = cact2;
+                // E2: the DYN wave needs ~1000 cycles after E1 for (M + h B)^-1; with the limit rows arriving from it
+                // this wave gets HERE in about as many (after the first factorisation it would still wait ~400).  Taking
+                // the rendezvous inside the first iteration rather than at the end of the substep leaves only E3
+                // between the last Newton iteration and the integration.
+                if (it == 0 && rows_by_dyn<T>()) {
+                    duo_barrier();
+#pragma unroll
+                    for (int i = 0; i < MAX_LINKS; ++i) ei[i] = ldsM[V_EI + l8 * LANES + i];   // my row of (M + h B)^-1, early
+                }
                 ST.mark(it == 0 ? 8 : 9);               // acceleration + active-set check / further iterations
                 if (!__any(changed)) break;
                 // One limit row j of a particle changed state (the usual case): H' = H + c e_j e_j', c = +-D_j, and the
@@ -853,6 +911,244 @@ __device__ __forceinline__ void arm_back(const MT& M, T& q, T& v, T& aw, T& sq, 
     ST.mark(13);        // integration
 }
 
+// ---- the rest of the control iteration (MONO launches) -----------------------------------------------
+// Dynamic LDS of a MONO rollout workgroup, in doubles: MONO_RED scratch (cost-to-go of its 8 particles, their weights) |
+// the action tile T[8][H A].
+constexpr int MONO_RED = 32;
+
+// One env step of the real arm (Reacher7DOFEnv.step, reacher_env.py:29-39) by this workgroup, from (q, v, tgt) - my
+// lane's entries of the f64 state vector `st` (qpos[8] | qvel[8] | target[3]), read by the caller - with the action in
+// `action` (LDS): the same substeps as a particle of the rollout - all eight particle slots carry the one state, slot 0
+// writes it back.  DUO: wave 0 = DYN, wave 1 = SOLVE as in the rollout.  The particle blocks of `lds` must be zero.
+template <typename T, bool DUO, typename MT>
+__device__ __forceinline__ void real_env_step(const MT& M, const ArmInts& I, const MonoStep& mo, double* st, T q, T v,
+                                              const T* tgt, const double* action, int A, T* lds, int lane, int wave, int l8,
+                                              int g, unsigned* diag) {
+    const int nv = I.nv;
+    T* ldsM = lds + g * PSTRIDE;
+    T aw = T(0);
+    if (l8 >= nv) { q = T(0); v = T(0); }
+    T sinq, cosq;
+    sincos_(q, sinq, cosq);
+    int rows = 0;
+    Stamps ST;
+    ST.begin();
+    bool fs = false;
+    if (DUO && wave == 1) {
+        if constexpr (DUO) {
+            T nosite[3];
+            for (int sub = 0; sub < I.frame_skip; ++sub) {
+                arm_front<SOLVE>(M, I, q, v, aw, sinq, cosq, rows, T(0), ldsM, lane, l8, nosite, diag, fs, ST);
+                arm_back<SOLVE>(M, q, v, aw, sinq, cosq, ldsM, l8, fs, ST);
+            }
+        }
+        return;
+    }
+    constexpr int R = DUO ? DYN : SOLO;
+    const T u = l8 < A ? (T)action[l8] : T(0);
+    const T tau_act = M.link(O_GEAR) * fmin(fmax(u, M.link(O_CTRL_LO)), M.link(O_CTRL_HI));
+    T site[3];
+    for (int sub = 0; sub < I.frame_skip; ++sub) {
+        if (R == DYN && sub > 0) arm_back<R>(M, q, v, aw, sinq, cosq, ldsM, l8, fs, ST);
+        arm_front<R>(M, I, q, v, aw, sinq, cosq, rows, tau_act, ldsM, lane, l8, site, diag, fs, ST);
+        if constexpr (R == SOLO) arm_back<R>(M, q, v, aw, sinq, cosq, ldsM, l8, fs, ST);
+    }
+    const int site_lane = lane_of_link(lane, I.site_link);
+    for (int k = 0; k < 3; ++k) site[k] = __shfl(site[k], site_lane);
+    if constexpr (R == DYN) arm_back<R>(M, q, v, aw, sinq, cosq, ldsM, l8, fs, ST);
+    if (g == 0) {
+        const T dx = site[0] - tgt[0], dy = site[1] - tgt[1], dz = site[2] - tgt[2];
+        if (mo.step_cost && l8 == 0)
+            ((T*)mo.step_cost)[0] = fabs(dx) + fabs(dy) + fabs(dz) + T(5) * sqrt_(dx * dx + dy * dy + dz * dz);
+        if (mo.step_nobs) {
+            T* o = (T*)mo.step_nobs;
+            if (l8 < nv) { o[l8] = q; o[nv + l8] = v; }
+            if (l8 < 3) {
+                const T hh = l8 == 0 ? site[0] : (l8 == 1 ? site[1] : site[2]);
+                const T gg = l8 == 0 ? tgt[0] : (l8 == 1 ? tgt[1] : tgt[2]);
+                o[2 * nv + l8] = hh;
+                o[2 * nv + 3 + l8] = hh - gg;
+            }
+        }
+        if (l8 < nv) {
+            st[l8] = (double)q;
+            st[LANES + l8] = (double)v;
+        }
+    }
+}
+
+// Softmax statistics of this workgroup's particles -> record {max, S, W[H A]} with weights exp(x_p - max),
+// x_p = -q0_p / lam (mppi.py:84-97), left in global memory for the finish kernel.
+template <typename T, bool DUO>
+__device__ __forceinline__ void mono_record(double lam, double* __restrict__ rec_out, int HA, double* red, const T* actT) {
+    constexpr int NT = DUO ? 128 : 64;
+    const int tid = threadIdx.x;
+    __syncthreads();                // q0 of the particles and the action tile are complete
+    if (tid < LANES) {              // eight lanes: max, weights, their sum (8-lane butterfly inside one DPP row)
+        const double q = red[tid], x = q == INFINITY ? -INFINITY : (-1.0 / lam) * q;
+        double m = x;
+        for (int o = 1; o < LANES; o <<= 1) m = fmax(m, __shfl_xor(m, o));
+        const double e = x == -INFINITY ? 0.0 : exp(x - m);
+        double S = e;
+        for (int o = 1; o < LANES; o <<= 1) S += __shfl_xor(S, o);
+        red[LANES + tid] = e;
+        if (tid == 0) { rec_out[0] = m; rec_out[1] = S; }
+    }
+    __syncthreads();
+    double e[LANES];
+#pragma unroll
+    for (int k = 0; k < LANES; ++k) e[k] = red[LANES + k];
+    for (int j = tid; j < HA; j += NT) {
+        double acc = 0.0;
+#pragma unroll
+        for (int k = 0; k < LANES; ++k) acc += e[k] * (double)actT[k * HA + j];
+        rec_out[2 + j] = acc;
+    }
+}
+
+// The second (and last) launch of a fused control iteration: H workgroups, one per horizon row.  Workgroup t merges the
+// records of all rollout workgroups for ITS row of the weighted action sum (thread tid walks the records tid, tid + 128, ...
+// with a running maximum; the threads' partials are then rescaled to the workgroup's maximum and added in a fixed order:
+// the same result whoever runs where), forms the new mean row (mppi.py:69-82) and writes it where the shift puts it
+// (olgaussian_mpc.py:116-129) - into mean_out, a buffer of its own, because other workgroups still read mean_in.
+// Workgroup 0's row is the action: it publishes it (device copy, mapped pinned host slot + completion flag), advances
+// the step counter and then steps the device-resident real env with its two wavefronts in the DYN / SOLVE roles of the
+// rollout; what that step needs from global memory (model block, state) is fetched at the top of the kernel, under the
+// latency of the record loads.  Sharded runs (mop->record): the rows of this GPU's record {max, S, W} instead.
+constexpr int MAX_A = 8;
+constexpr int FIN_CHUNK = 4;        // records per thread in flight
+template <typename T>
+__global__ __launch_bounds__(128) void arm_mppi_finish_kernel(const T* __restrict__ model, const double* __restrict__ recs, long n_rec,
+                                                              int H, int A, const double* __restrict__ mean_in,
+                                                              double* __restrict__ mean_out, const MonoStep* __restrict__ mop,
+                                                              int env_step, unsigned* diag) {
+    __shared__ __attribute__((aligned(16))) T lds[LANES * PSTRIDE + ARM_BLOB_LEN + 3];
+    __shared__ double sh[2 * (2 + MAX_A)];
+    const int tid = threadIdx.x, t = blockIdx.x, HA = H * A, rec = 2 + HA;
+    const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const MonoStep mo = *mop;
+    const bool stepper = t == 0 && env_step && mo.state_io && !mo.record;
+    // ---- loads first: the records of my first chunk, my mean row, and - the workgroup that steps the env - model and state
+    double rm[FIN_CHUNK], rs[FIN_CHUNK], rw[FIN_CHUNK][MAX_A];
+    auto fetch = [&](long base) {
+#pragma unroll
+        for (int k = 0; k < FIN_CHUNK; ++k) {
+            const long b = base + tid + 128L * k;
+            const double* r = recs + (b < n_rec ? b : 0) * rec;
+            rm[k] = b < n_rec ? r[0] : -INFINITY;
+            rs[k] = r[1];
+#pragma unroll
+            for (int a = 0; a < MAX_A; ++a) rw[k][a] = a < A ? r[2 + t * A + a] : 0.0;
+        }
+    };
+    fetch(0);
+    const double mean_old = (tid < A && !mo.record) ? mean_in[t * A + tid] : 0.0;
+    const long long count = (t == 0 && mo.step_counter) ? *mo.step_counter : 0;
+    const int l8 = lane_link(lane), g = lane_slot(lane);
+    T q0 = T(0), v0 = T(0), tgt[3] = {T(0), T(0), T(0)};
+    if (stepper) {
+        for (int k = tid; k < ARM_BLOB_LEN; k += 128) lds[LANES * PSTRIDE + k] = model[k];
+        for (int k = tid; k < LANES * PSTRIDE; k += 128) lds[k] = T(0);
+        q0 = (T)mo.state_io[l8];
+        v0 = (T)mo.state_io[LANES + l8];
+        for (int k = 0; k < 3; ++k) tgt[k] = (T)mo.state_io[2 * LANES + k];
+    }
+    // ---- my share of the records, with a running maximum
+    double m = -INFINITY, S = 0.0, W[MAX_A];
+#pragma unroll
+    for (int a = 0; a < MAX_A; ++a) W[a] = 0.0;
+    for (long base = 0; base < n_rec; base += 128L * FIN_CHUNK) {
+        if (base > 0) fetch(base);
+        double mn = m;
+#pragma unroll
+        for (int k = 0; k < FIN_CHUNK; ++k) mn = fmax(mn, rm[k]);
+        const double sc = m == -INFINITY ? 0.0 : exp(m - mn);
+        S *= sc;
+#pragma unroll
+        for (int a = 0; a < MAX_A; ++a) W[a] *= sc;
+#pragma unroll
+        for (int k = 0; k < FIN_CHUNK; ++k) {
+            const double c = rm[k] == -INFINITY ? 0.0 : exp(rm[k] - mn);
+            S += c * rs[k];
+#pragma unroll
+            for (int a = 0; a < MAX_A; ++a) W[a] += c * rw[k][a];
+        }
+        m = mn;
+    }
+    // ---- the workgroup's maximum, then the rescaled partials added up (wave butterflies, one LDS hop)
+    double M = m;
+    for (int o = 32; o > 0; o >>= 1) M = fmax(M, __shfl_xor(M, o));
+    if (lane == 0) sh[wave] = M;
+    __syncthreads();
+    M = fmax(sh[0], sh[1]);
+    const double f = m == -INFINITY ? 0.0 : exp(m - M);
+    S *= f;
+    for (int o = 32; o > 0; o >>= 1) S += __shfl_xor(S, o);
+#pragma unroll
+    for (int a = 0; a < MAX_A; ++a) {
+        W[a] *= f;
+        for (int o = 32; o > 0; o >>= 1) W[a] += __shfl_xor(W[a], o);
+    }
+    __syncthreads();
+    if (lane == 0) {
+        sh[wave * (2 + MAX_A) + 1] = S;
+#pragma unroll
+        for (int a = 0; a < MAX_A; ++a) sh[wave * (2 + MAX_A) + 2 + a] = W[a];
+    }
+    __syncthreads();
+    S = sh[1] + sh[(2 + MAX_A) + 1];
+    const double wsum = tid < A ? sh[2 + tid] + sh[(2 + MAX_A) + 2 + tid] : 0.0;
+    if (mo.record) {
+        if (tid < A) mo.record[2 + t * A + tid] = wsum;
+        if (t == 0 && tid == 0) { mo.record[0] = M; mo.record[1] = S; }
+        return;
+    }
+    double nm = 0.0;
+    if (tid < A) {
+        nm = (1.0 - mo.step_size) * mean_old + mo.step_size * (wsum / S);
+        if (mo.shift_mode < 0) {
+            mean_out[t * A + tid] = nm;
+        } else {
+            if (t > 0) mean_out[(t - 1) * A + tid] = nm;
+            if (t == H - 1) mean_out[t * A + tid] = mo.shift_mode == 0 ? 0.0 : nm;       // 'null' / 'repeat'
+        }
+    }
+    if (t != 0) return;
+    // ---- the action: publish, count the step, step the real env
+    __syncthreads();
+    if (tid < A) sh[tid] = nm;
+    double* slot = mo.action_host ? mo.action_host + (count & 1) * (A + 1) : nullptr;
+    if (tid < A) {
+        if (mo.action_out) mo.action_out[tid] = nm;
+        // mapped pinned host memory, system-scope stores: the action, then - once they are acknowledged - the new step
+        // count as the completion flag (two slots: a launch enqueued ahead cannot overwrite an action not yet read)
+        if (slot) __hip_atomic_store(slot + tid, nm, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+    if (wave == 0) {                // (the wave that wrote the action waits for the acknowledgement; the other goes on)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (tid == 0) {
+            if (mo.step_counter) *mo.step_counter = count + 1;              // noise stream of the next step
+            if (slot) __hip_atomic_store(slot + A, (double)(count + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+    }
+    if (!stepper) return;
+    __syncthreads();                // action in LDS, model block staged, particle blocks zeroed
+    Model<T, true> Mv{lds + LANES * PSTRIDE, l8};
+    Mv.cache();
+    ArmInts I;
+    I.site_link = (int)lds[LANES * PSTRIDE + O_SITE_LINK];
+    I.n_sphere = (int)lds[LANES * PSTRIDE + O_N_SPHERE];
+    I.sph_link = (int)lds[LANES * PSTRIDE + O_SPH_LINK];
+    I.frame_skip = (int)lds[LANES * PSTRIDE + O_FRAME_SKIP];
+    I.nv = (int)lds[LANES * PSTRIDE + O_NV];
+    I.site_link = __builtin_amdgcn_readfirstlane(I.site_link);
+    I.n_sphere = __builtin_amdgcn_readfirstlane(I.n_sphere);
+    I.sph_link = __builtin_amdgcn_readfirstlane(I.sph_link);
+    I.frame_skip = __builtin_amdgcn_readfirstlane(I.frame_skip);
+    I.nv = __builtin_amdgcn_readfirstlane(I.nv);
+    real_env_step<T, true>(Mv, I, mo, mo.state_io, q0, v0, tgt, sh, A, lds, lane, wave, l8, g, diag);
+}
+
 // ---- the rollout kernel -------------------------------------------------------------------------
 // state: f64 [qpos(8) | qvel(8) | target(3)]; mean: f64 [H][A]; noise/cost/act/obs/next_obs: T, in the
 // reference's C-order layouts (P,H,A) / (P,H) / (P,H,2nv+6).  noise, act, obs, next_obs may be null.
@@ -867,15 +1163,20 @@ __device__ __forceinline__ void arm_back(const MT& M, T& q, T& v, T& aw, T& sq, 
 // long as the crowded ones (measured inside the control loop at 16 384 particles: 0.42 ms against 0.31 ms) - so
 // such launches use the instantiation capped at two.
 // DUO = two wavefronts per particle group (roles DYN / SOLVE above), for launches of at most half a wave per SIMD.
-template <typename T, bool STEP, bool CL, int WAVES, bool DUO>
+// MONO = the whole control iteration in this launch (struct MonoStep, arm_rollout.h): samples drawn in the kernel, actions
+// kept in LDS, softmax partials reduced up a tree of arrival counters, mean update / action / shift / real-env step by the
+// workgroup that arrives last.
+template <typename T, bool STEP, bool CL, int WAVES, bool DUO, bool MONO>
 __global__ __launch_bounds__(DUO ? 128 : 64) __attribute__((amdgpu_waves_per_eu(WAVES, WAVES))) void arm_rollout_kernel(const T* __restrict__ model, const double* state,
-                                                         long P, int H, int A, const double* __restrict__ mean,
+                                                         long P, int H, int A, const double* mean,
                                                          const T* __restrict__ noise, T* __restrict__ cost,
                                                          T* __restrict__ act, T* __restrict__ obs,
                                                          T* __restrict__ nobs, double* state_out, unsigned* diag,
-                                                         RolloutFusion fuse) {
+                                                         RolloutFusion fuse, const MonoStep* __restrict__ mop) {
     __shared__ __attribute__((aligned(16))) T lds[LANES * PSTRIDE + ARM_BLOB_LEN + 3];
+    extern __shared__ __attribute__((aligned(16))) double dyn_lds[];     // MONO: scratch [MONO_RED] | action tile T[8][H A]
     static_assert(!(DUO && CL), "the closed-loop-linear variant runs one wave per particle group");
+    static_assert(!(MONO && (CL || STEP)), "the one-launch iteration is open-loop MPPI");
     constexpr int NT = DUO ? 128 : 64;
     const int lane = threadIdx.x & 63;
     const int wave = DUO ? __builtin_amdgcn_readfirstlane(threadIdx.x >> 6) : 0;
@@ -927,8 +1228,10 @@ __global__ __launch_bounds__(DUO ? 128 : 64) __attribute__((amdgpu_waves_per_eu(
     }
 
     constexpr int R = DUO ? DYN : SOLO;
-    if constexpr (DUO) {
-        if (wave == 1) {            // the SOLVE wave: no inputs, no records - mass matrix, constraints, solves
+    const int HA = H * A;
+    T* actT = (T*)(dyn_lds + MONO_RED);          // MONO: the actions of my workgroup's particles, [8][H A]
+    if (DUO && wave == 1) {         // the SOLVE wave: no inputs, no records - mass matrix, constraints, solves
+        if constexpr (DUO) {
             bool fs;
             T nosite[3];
             for (int t = 0; t < H; ++t)
@@ -937,28 +1240,54 @@ __global__ __launch_bounds__(DUO ? 128 : 64) __attribute__((amdgpu_waves_per_eu(
                     arm_back<SOLVE>(M, q, v, aw, sinq, cosq, ldsM, l8, fs, ST);
                 }
             ST.flush(diag, 1, lane);
-            return;
         }
-    }
+        if constexpr (!MONO) return;
+    } else {
 
     // inputs of step t+1 are fetched while step t computes (a lone wave would otherwise sit out the full
     // HBM latency of its noise load at the top of every env step)
     T eps_next = T(0);
-    double mean_next = 0.0, gs_next = (fuse.q0_out && H > 0) ? fuse.gseq[0] : 0.0;   // (a load consumed in the iteration
+    double mean_next = 0.0, gs_next = (fuse.gseq && H > 0) ? fuse.gseq[0] : 0.0;   // (a load consumed in the iteration
     // that issues it would make its s_waitcnt also wait for the prefetches issued before it)
+    // MONO: the raw sample of (particle, channel l8, step t) is drawn here instead of loaded - the same Philox block the
+    // sampler kernel (noise.hip) would have used for it: one block yields the normals of steps 4k ... 4k + 3
+    const bool sampled = MONO && has_u && live;
+    float z_keep[3] = {0.0f, 0.0f, 0.0f};
+    // (only three normals live across env steps; the sampler's parameters are re-read - scalar loads, cache hits - by the
+    // draw of every fourth step instead of occupying registers throughout the rollout)
+    auto draw = [&](int t) -> T {
+#ifdef MONO_NO_DRAW                 // developer A/B builds (tools/mono_time.py)
+        return T(0.25);
+#endif
+        const double chol_aa = mop->chol[l8 * A + l8];
+        float z;
+        if (!(t & 3)) {
+            const unsigned long long off = mop->offset + (mop->d_step ? (unsigned long long)*mop->d_step : 0ull);
+            float q4[4];
+            normal_quad(mop->seed, off, (unsigned long long)((pid + mop->particle_offset) * A + l8), (unsigned)(t >> 2), q4);
+            z = q4[0];
+            z_keep[0] = q4[1];
+            z_keep[1] = q4[2];
+            z_keep[2] = q4[3];
+        } else {
+            z = (t & 3) == 1 ? z_keep[0] : ((t & 3) == 2 ? z_keep[1] : z_keep[2]);
+        }
+        return (T)(chol_aa * (double)z);
+    };
     if (has_u && H > 0) {
         if constexpr (!CL) mean_next = mean[l8];
-        if (noise && live) eps_next = noise[(pid * H) * A + l8];
+        if constexpr (MONO) { if (sampled) eps_next = draw(0); }
+        else if (noise && live) eps_next = noise[(pid * H) * A + l8];
     }
 
     for (int t = 0; t < H; ++t) {
         T u = T(0);
         const T eps_cur = eps_next;
         const double mean_cur = mean_next, gs_cur = gs_next;
-        if (fuse.q0_out && t + 1 < H) gs_next = fuse.gseq[t + 1];
+        if (fuse.gseq && t + 1 < H) gs_next = fuse.gseq[t + 1];
         if (has_u && t + 1 < H) {
             if constexpr (!CL) mean_next = mean[(t + 1) * A + l8];
-            if (noise && live) eps_next = noise[(pid * H + t + 1) * A + l8];
+            if constexpr (!MONO) { if (noise && live) eps_next = noise[(pid * H + t + 1) * A + l8]; }
         }
         if constexpr (CL) {         // u = clw^T [q, v, hand, hand - target, 1]
             const int wl = has_u ? l8 : 0;
@@ -971,7 +1300,7 @@ __global__ __launch_bounds__(DUO ? 128 : 64) __attribute__((amdgpu_waves_per_eu(
         }
         if (has_u) {
             if constexpr (!CL) u = (T)mean_cur;
-            if (noise && live) {
+            if (MONO ? sampled : (noise && live)) {
                 T eps = eps_cur;
                 if (fuse.filt) {            // eps[t] = b0 eps[t] + b1 eps[t-1] + b2 eps[t-2], t >= 2
                     const double f = t >= 2 ? fb0 * (double)eps + fb1 * e1 + fb2 * e2 : (double)eps;
@@ -982,6 +1311,7 @@ __global__ __launch_bounds__(DUO ? 128 : 64) __attribute__((amdgpu_waves_per_eu(
                 u += eps;
             }
             if (act && live) act[(pid * H + t) * A + l8] = u;        // unclipped (gym_env_wrapper.py:151)
+            if constexpr (MONO) actT[g * HA + t * A + l8] = u;
         }
         // MuJoCo clamps ctrl, not the record
         const T tau_act = M.link(O_GEAR) * fmin(fmax(u, M.link(O_CTRL_LO)), M.link(O_CTRL_HI));
@@ -1004,8 +1334,10 @@ __global__ __launch_bounds__(DUO ? 128 : 64) __attribute__((amdgpu_waves_per_eu(
         // reward = -(|h-g|_1 + 5 |h-g|_2), h = site_xpos lagging one substep (reacher_env.py:31-35)
         T dx = site[0] - tgt[0], dy = site[1] - tgt[1], dz = site[2] - tgt[2];
         T cst = fabs(dx) + fabs(dy) + fabs(dz) + T(5) * sqrt_(dx * dx + dy * dy + dz * dz);
-        if (live && l8 == 0) cost[pid * H + t] = cst;
-        if (fuse.q0_out) q0acc += gs_cur * (double)cst;
+        if (live && l8 == 0 && (!MONO || cost)) cost[pid * H + t] = cst;
+        if (fuse.gseq) q0acc += gs_cur * (double)cst;
+        // MONO: the next step's sample, drawn while the SOLVE wave is still iterating (DUO) / once per env step (SOLO)
+        if constexpr (MONO) { if (sampled && t + 1 < H) eps_next = draw(t + 1); }
         if constexpr (R == DYN) arm_back<R>(M, q, v, aw, sinq, cosq, ldsM, l8, fs, ST);
         if (live && (obs || nobs)) {
             const long o = (pid * H + t) * dobs;
@@ -1040,14 +1372,43 @@ __global__ __launch_bounds__(DUO ? 128 : 64) __attribute__((amdgpu_waves_per_eu(
         state_out[l8] = (double)q;
         state_out[LANES + l8] = (double)v;
     }
+    if constexpr (MONO) { if (l8 == 0) dyn_lds[g] = live ? q0acc : INFINITY; }     // cost-to-go of my particle
+    }   // (wave 0 / the one wave)
+    if constexpr (MONO)
+        mono_record<T, DUO>(mop->lam, mop->tree + (long)blockIdx.x * (2 + HA), HA, dyn_lds, actT);
 }
 
 }  // namespace
 
+namespace {
+__global__ void mono_params_kernel(MonoStep mo, MonoStep* dst) { *dst = mo; }
+}  // namespace
+hipError_t upload_mono_params(const MonoStep& mo, MonoStep* dst, hipStream_t stream) {
+    hipLaunchKernelGGL(mono_params_kernel, dim3(1), dim3(1), 0, stream, mo, dst);
+    return hipGetLastError();
+}
+
+long arm_rollout_groups(long P) { return (P + LANES - 1) / LANES; }
+long mono_record_doubles(long groups, int H, int A) { return groups * (2 + (long)H * A); }
+
+template <typename T>
+hipError_t launch_arm_mppi_finish(const T* model, const double* records, long n_rec, int H, int A, const double* mean_in,
+                                  double* mean_out, const MonoStep* mono_dev, int env_step, unsigned* diag, hipStream_t stream) {
+    if (A > MAX_A || H < 1 || n_rec < 1) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(arm_mppi_finish_kernel<T>, dim3((unsigned)H), dim3(128), 0, stream, model, records, n_rec, H, A, mean_in,
+                       mean_out, mono_dev, env_step, diag);
+    return hipGetLastError();
+}
+template hipError_t launch_arm_mppi_finish<float>(const float*, const double*, long, int, int, const double*, double*,
+                                                  const MonoStep*, int, unsigned*, hipStream_t);
+template hipError_t launch_arm_mppi_finish<double>(const double*, const double*, long, int, int, const double*, double*,
+                                                   const MonoStep*, int, unsigned*, hipStream_t);
+
 template <typename T>
 hipError_t launch_arm_rollout(const T* model, const double* state, long P, int H, int A, const double* mean,
                               const T* noise, T* cost, T* act, T* obs, T* nobs, double* state_out,
-                              unsigned* diag, hipStream_t stream, RolloutFusion fuse) {
+                              unsigned* diag, hipStream_t stream, RolloutFusion fuse, const MonoStep* mono,
+                              const MonoStep* mono_dev) {
     if (P <= 0 || H <= 0) return hipSuccess;
     const unsigned grid = (unsigned)((P + LANES - 1) / LANES);
     // Cap the resident waves per SIMD at what this launch needs (2, or - f32 only, f64 does not fit - 3): the
@@ -1068,25 +1429,33 @@ hipError_t launch_arm_rollout(const T* model, const double* state, long P, int H
     // some SIMDs while others idle (8192 particles: 361 us per launch in the loop against 280 us back to back)
     static const int one_env = [] { const char* e = getenv("MJMPC_ARM_ONE"); return e ? atoi(e) : -1; }();
     const bool one_per_simd = !duo && !fuse.clw && (one_env >= 0 ? one_env != 0 : (long)grid <= simds);
-#define MJMPC_LAUNCH_W(STEP_, CL_, W_, DUO_)                                                                        \
-    hipLaunchKernelGGL((arm_rollout_kernel<T, STEP_, CL_, W_, DUO_>), dim3(grid), dim3(DUO_ ? 128 : 64), 0, stream,  \
-                       model, state, P, H, A, mean, noise, cost, act, obs, nobs, state_out, diag, fuse)
-#define MJMPC_LAUNCH(STEP_, CL_)                                 \
-    do {                                                         \
-        if (one_per_simd) {                                      \
-            MJMPC_LAUNCH_W(STEP_, CL_, 1, false);                \
-        } else if constexpr (sizeof(T) == 8) {                   \
-            MJMPC_LAUNCH_W(STEP_, CL_, 2, false);                \
-        } else {                                                 \
-            if (cap == 2) MJMPC_LAUNCH_W(STEP_, CL_, 2, false);  \
-            else MJMPC_LAUNCH_W(STEP_, CL_, 3, false);           \
-        }                                                        \
+    const size_t dyn = mono ? sizeof(double) * MONO_RED + sizeof(T) * LANES * (size_t)H * A : 0;
+#define MJMPC_LAUNCH_W(STEP_, CL_, W_, DUO_, MONO_)                                                                   \
+    hipLaunchKernelGGL((arm_rollout_kernel<T, STEP_, CL_, W_, DUO_, MONO_>), dim3(grid), dim3(DUO_ ? 128 : 64), dyn,  \
+                       stream, model, state, P, H, A, mean, noise, cost, act, obs, nobs, state_out, diag, fuse, mono_dev)
+#define MJMPC_LAUNCH(STEP_, CL_, MONO_)                                 \
+    do {                                                                \
+        if (one_per_simd) {                                             \
+            MJMPC_LAUNCH_W(STEP_, CL_, 1, false, MONO_);                \
+        } else if constexpr (sizeof(T) == 8) {                          \
+            MJMPC_LAUNCH_W(STEP_, CL_, 2, false, MONO_);                \
+        } else {                                                        \
+            if (cap == 2) MJMPC_LAUNCH_W(STEP_, CL_, 2, false, MONO_);  \
+            else MJMPC_LAUNCH_W(STEP_, CL_, 3, false, MONO_);           \
+        }                                                               \
     } while (0)
-    if (fuse.clw) MJMPC_LAUNCH(false, true);
-    else if (duo && state_out) MJMPC_LAUNCH_W(true, false, 1, true);
-    else if (duo) MJMPC_LAUNCH_W(false, false, 1, true);
-    else if (state_out) MJMPC_LAUNCH(true, false);
-    else MJMPC_LAUNCH(false, false);
+    if (mono) {
+        if (fuse.clw || state_out || obs || nobs || !fuse.gseq || !mono->chol || !mono->tree || !mono_dev)
+            return hipErrorInvalidValue;
+        if (dyn + sizeof(T) * (LANES * PSTRIDE + ARM_BLOB_LEN + 3) > 64 * 1024) return hipErrorInvalidValue;     // H A too large for the LDS tile
+        if (duo) MJMPC_LAUNCH_W(false, false, 1, true, true);
+        else MJMPC_LAUNCH(false, false, true);
+    }
+    else if (fuse.clw) MJMPC_LAUNCH(false, true, false);
+    else if (duo && state_out) MJMPC_LAUNCH_W(true, false, 1, true, false);
+    else if (duo) MJMPC_LAUNCH_W(false, false, 1, true, false);
+    else if (state_out) MJMPC_LAUNCH(true, false, false);
+    else MJMPC_LAUNCH(false, false, false);
 #undef MJMPC_LAUNCH
 #undef MJMPC_LAUNCH_W
     return hipGetLastError();
@@ -1094,9 +1463,9 @@ hipError_t launch_arm_rollout(const T* model, const double* state, long P, int H
 
 template hipError_t launch_arm_rollout<float>(const float*, const double*, long, int, int, const double*,
                                               const float*, float*, float*, float*, float*, double*, unsigned*,
-                                              hipStream_t, RolloutFusion);
+                                              hipStream_t, RolloutFusion, const MonoStep*, const MonoStep*);
 template hipError_t launch_arm_rollout<double>(const double*, const double*, long, int, int, const double*,
                                                const double*, double*, double*, double*, double*, double*, unsigned*,
-                                               hipStream_t, RolloutFusion);
+                                               hipStream_t, RolloutFusion, const MonoStep*, const MonoStep*);
 
 }  // namespace mjmpc

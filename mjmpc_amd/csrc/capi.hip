@@ -58,6 +58,14 @@ struct mjmpc_arm_s {
     double* scratch = nullptr;      // [8] a place for that launch's cost
     double* shard_states = nullptr; // n_state_shards state vectors (per-shard start states)
     int n_state_shards = 0;
+    // mjmpc_arm_mppi_step: the rollout workgroups' records (sized for mono_groups workgroups, horizon mono_H), and
+    // the launches' parameter block in device memory (rewritten only when a parameter changes)
+    double* mono_tree = nullptr;
+    long mono_groups = 0;
+    int mono_H = 0;
+    mjmpc::MonoStep* mono_dev = nullptr;
+    mjmpc::MonoStep mono_cached;
+    bool mono_valid = false;
 };
 
 struct mjmpc_tree_s {
@@ -181,6 +189,8 @@ int mjmpc_arm_destroy(mjmpc_arm_t h) {
     hipFree(h->state);
     hipFree(h->diag);
     hipFree(h->shard_states);
+    hipFree(h->mono_tree);
+    hipFree(h->mono_dev);
     hipHostFree(h->pinned);
     for (int k = 0; k < 4; ++k) if (h->staged[k]) hipEventDestroy(h->staged[k]);
     delete h;
@@ -293,6 +303,80 @@ int mjmpc_arm_rollout_fused(mjmpc_arm_t h, int dtype, int64_t P, int H, const do
     else
         return fail(MJMPC_E_BADARG, "unknown dtype %d", dtype);
     if (e != hipSuccess) return hip_fail(e, "arm_rollout_fused launch");
+    return 0;
+}
+
+int mjmpc_arm_mppi_step(mjmpc_arm_t h, int dtype, int64_t P, int H, const double* d_mean, double* d_mean_out,
+                        const double* d_gseq, const double* d_filter_coeffs, const double* d_chol, uint64_t seed,
+                        uint64_t offset, int64_t particle_offset, int64_t* d_step_counter, double lam, double step_size,
+                        int shift_mode, double* d_action_out, double* h_action_slots, double* d_record, int env_step,
+                        void* d_step_cost, void* d_step_next_obs, void* d_costs, void* d_actions, double* d_q0, void* stream) {
+    if (!h || !d_mean || !d_gseq || !d_chol) return fail(MJMPC_E_BADARG, "null argument");
+    if (!d_record && (!d_mean_out || d_mean_out == d_mean))
+        return fail(MJMPC_E_BADARG, "d_mean_out must be a buffer of its own (the finish launch reads d_mean while it writes)");
+    if (P < 1 || H < 1) return fail(MJMPC_E_BADARG, "P and H must be positive");
+    if (!(lam > 0) || shift_mode > 1) return fail(MJMPC_E_BADARG, "bad lam / shift_mode");
+    if (h->n_shards > 1 || h->n_state_shards > 1)
+        return fail(MJMPC_E_BADARG, "the fused iteration runs one model and one start state (no per-shard blocks)");
+    HIP_TRY(hipSetDevice(h->device));
+    hipStream_t s = (hipStream_t)stream;
+    const long groups = mjmpc::arm_rollout_groups((long)P);
+    if (groups != h->mono_groups || H != h->mono_H) {
+        HIP_TRY(hipDeviceSynchronize());
+        hipFree(h->mono_tree);
+        h->mono_tree = nullptr;
+        h->mono_groups = 0;
+        HIP_TRY(hipMalloc(&h->mono_tree, sizeof(double) * mjmpc::mono_record_doubles(groups, H, h->nu)));
+        h->mono_groups = groups;
+        h->mono_H = H;
+        h->mono_valid = false;
+    }
+    if (!h->mono_dev) HIP_TRY(hipMalloc(&h->mono_dev, sizeof(mjmpc::MonoStep)));
+    mjmpc::MonoStep mo;
+    std::memset(&mo, 0, sizeof(mo));            // (padding too: the block is compared bytewise below)
+    mo.chol = d_chol;
+    mo.seed = seed;
+    mo.offset = offset;
+    mo.particle_offset = (long)particle_offset;
+    mo.d_step = (const long long*)d_step_counter;
+    mo.lam = lam;
+    mo.step_size = step_size;
+    mo.shift_mode = shift_mode;
+    mo.tree = h->mono_tree;
+    mo.action_out = d_action_out;
+    mo.action_host = h_action_slots;
+    mo.step_counter = (long long*)d_step_counter;
+    mo.record = d_record;
+    mo.state_io = h->state;
+    mo.step_cost = d_step_cost;
+    mo.step_nobs = d_step_next_obs;
+    if (!h->mono_valid || std::memcmp(&mo, &h->mono_cached, sizeof(mo)) != 0) {
+        HIP_TRY(mjmpc::upload_mono_params(mo, h->mono_dev, s));         // stream-ordered, before the launches that read it
+        h->mono_cached = mo;
+        h->mono_valid = true;
+    }
+    const int do_env = (env_step && !d_record) ? 1 : 0;
+    mjmpc::RolloutFusion fuse;
+    fuse.filt = d_filter_coeffs;
+    fuse.gseq = d_gseq;
+    fuse.q0_out = d_q0;
+    hipError_t e;
+    if (dtype == MJMPC_F32) {
+        e = mjmpc::launch_arm_rollout<float>(h->model_f32, h->state, (long)P, H, h->nu, d_mean, nullptr, (float*)d_costs,
+                                             (float*)d_actions, nullptr, nullptr, nullptr, h->diag, s, fuse, &mo, h->mono_dev);
+        if (e == hipSuccess)
+            e = mjmpc::launch_arm_mppi_finish<float>(h->model_f32, h->mono_tree, groups, H, h->nu, d_mean, d_mean_out, h->mono_dev,
+                                                     do_env, h->diag, s);
+    } else if (dtype == MJMPC_F64) {
+        e = mjmpc::launch_arm_rollout<double>(h->model_f64, h->state, (long)P, H, h->nu, d_mean, nullptr, (double*)d_costs,
+                                              (double*)d_actions, nullptr, nullptr, nullptr, h->diag, s, fuse, &mo, h->mono_dev);
+        if (e == hipSuccess)
+            e = mjmpc::launch_arm_mppi_finish<double>(h->model_f64, h->mono_tree, groups, H, h->nu, d_mean, d_mean_out, h->mono_dev,
+                                                      do_env, h->diag, s);
+    } else {
+        return fail(MJMPC_E_BADARG, "unknown dtype %d", dtype);
+    }
+    if (e != hipSuccess) return hip_fail(e, "arm_mppi_step launch");
     return 0;
 }
 

@@ -5,7 +5,7 @@
 // (mjmpc_amd.control.control_utils.generate_noise + upload).
 //
 // Every normal is a pure function of
-// (seed, step offset, particle, channel, t/2), so a channel of a correlated sample,
+// (seed, step offset, particle, channel, t/4), so a channel of a correlated sample,
 // eps[a] = sum_{b<=a} L[a][b] z[b], is recomputed locally instead of exchanged between threads.
 #include <hip/hip_runtime.h>
 
@@ -15,7 +15,7 @@
 namespace mjmpc {
 namespace {
 
-// pass 1: coloured normals, one thread per (particle, channel, t-pair)
+// pass 1: coloured normals, one thread per (particle, channel, t-quad)
 template <typename T>
 __global__ void noise_kernel(T* __restrict__ noise, long P, int H, int A, const double* __restrict__ chol,
                              unsigned long long seed, unsigned long long offset, long particle_offset,
@@ -25,7 +25,7 @@ __global__ void noise_kernel(T* __restrict__ noise, long P, int H, int A, const 
                      diag_only);
 }
 
-// Full (lower-triangular) colouring: one thread per (particle, t-pair) draws the A independent normal pairs ONCE and
+// Full (lower-triangular) colouring: one thread per (particle, t-quad) draws the A independent normal quadruples ONCE and
 // forms all A channels from them - the per-element kernel above would draw z_b again for every channel a >= b
 // (A (A+1) / 2 Philox blocks instead of A; 56 -> 16 us at 16384 x 32 x 7).  Same draws, same order of summation.
 constexpr int NOISE_MAXA = 8;      // loops are unrolled to this bound so that the draws stay in registers
@@ -34,33 +34,34 @@ __global__ void noise_full_kernel(T* __restrict__ noise, long P, int H, int A, c
                                   unsigned long long seed, unsigned long long offset, long particle_offset,
                                   const long long* __restrict__ d_step) {
     if (d_step) offset += (unsigned long long)*d_step;
-    const int H2 = (H + 1) / 2;
+    const int H4 = (H + 3) / 4;
     const long gid = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (gid >= P * H2) return;
-    const int t2 = (int)(gid % H2);
-    const long p = gid / H2;
-    double z0[NOISE_MAXA], z1[NOISE_MAXA];
+    if (gid >= P * H4) return;
+    const int t4 = (int)(gid % H4);
+    const long p = gid / H4;
+    float z[NOISE_MAXA][4];
 #pragma unroll
     for (int b = 0; b < NOISE_MAXA; ++b) {
-        z0[b] = 0.0;
-        z1[b] = 0.0;
-        if (b < A) normal_pair(seed, offset, (unsigned long long)((p + particle_offset) * A + b), (unsigned)t2, z0[b], z1[b]);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) z[b][k] = 0.0f;
+        if (b < A) normal_quad(seed, offset, (unsigned long long)((p + particle_offset) * A + b), (unsigned)t4, z[b]);
     }
-    const int t = 2 * t2;
+    const int t = 4 * t4;
 #pragma unroll
     for (int a = 0; a < NOISE_MAXA; ++a) {
         if (a < A) {
-            double x0 = 0.0, x1 = 0.0;
+            double x[4] = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
             for (int b = 0; b <= a; ++b) {
                 const double l = chol[a * A + b];
                 if (l != 0.0) {
-                    x0 += l * z0[b];
-                    x1 += l * z1[b];
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) x[k] += l * (double)z[b][k];
                 }
             }
-            noise[(p * H + t) * A + a] = (T)x0;
-            if (t + 1 < H) noise[(p * H + t + 1) * A + a] = (T)x1;
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+                if (t + k < H) noise[(p * H + t + k) * A + a] = (T)x[k];
         }
     }
 }
@@ -92,9 +93,9 @@ hipError_t sample_noise(T* noise, long P, int H, int A, const double* chol, cons
                         unsigned long long seed, unsigned long long offset, long particle_offset, const long long* d_step,
                         hipStream_t s, int diag_only) {
     if (P <= 0 || H <= 0) return hipSuccess;
-    const long n = P * A * ((H + 1) / 2), m = P * A;
+    const long n = P * A * ((H + 3) / 4), m = P * A;
     if (!diag_only && A <= NOISE_MAXA) {
-        const long nf = P * ((H + 1) / 2);
+        const long nf = P * ((H + 3) / 4);
         hipLaunchKernelGGL(noise_full_kernel<T>, dim3((unsigned)((nf + 63) / 64)), dim3(64), 0, s, noise, P, H, A, chol, seed,
                            offset, particle_offset, d_step);
     } else {

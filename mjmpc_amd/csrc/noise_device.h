@@ -12,10 +12,15 @@ __device__ __forceinline__ void philox_round(unsigned& c0, unsigned& c1, unsigne
     c0 = n0; c1 = lo1; c2 = n2; c3 = lo0;
 }
 
-// two independent standard normals from one Philox4x32-10 block (53-bit uniforms, Box-Muller)
-__device__ __forceinline__ void normal_pair(unsigned long long seed, unsigned long long offset, unsigned long long chan,
-                                            unsigned pair, double& z0, double& z1) {
-    unsigned c0 = (unsigned)chan, c1 = (unsigned)(chan >> 32), c2 = pair, c3 = (unsigned)offset;
+// FOUR independent standard normals from one Philox4x32-10 block: every 32-bit word is one uniform, two Box-Muller
+// pairs.  The transcendental part runs on the hardware's single-precision units - v_log_f32, v_sqrt_f32 and
+// v_sin_f32 / v_cos_f32, whose argument is in REVOLUTIONS, i.e. the uniform itself, no range reduction - (relative error
+// ~1e-6 on a random variate: statistically invisible; a draw costs ~1/3 of round 2's 53-bit / libm version, which matters
+// where the rollout kernel draws its own samples).  Radius from (w + 0.5) 2^-32 in (0, 1]: |z| <= 6.8.  The normals ARE
+// single-precision numbers; callers widen them.
+__device__ __forceinline__ void normal_quad(unsigned long long seed, unsigned long long offset, unsigned long long chan,
+                                            unsigned quad, float* z) {
+    unsigned c0 = (unsigned)chan, c1 = (unsigned)(chan >> 32), c2 = quad, c3 = (unsigned)offset;
     unsigned k0 = (unsigned)seed, k1 = (unsigned)(seed >> 32) ^ (unsigned)(offset >> 32);
 #pragma unroll
     for (int r = 0; r < 10; ++r) {
@@ -23,40 +28,40 @@ __device__ __forceinline__ void normal_pair(unsigned long long seed, unsigned lo
         k0 += 0x9E3779B9u;
         k1 += 0xBB67AE85u;
     }
-    // 53-bit uniforms; the transcendental part of Box-Muller runs in single precision (relative error
-    // ~1e-7 on a random variate: statistically invisible, 4x cheaper than the f64 library calls)
-    const double two53 = 1.0 / 9007199254740992.0;
-    const unsigned long long a = (((unsigned long long)c0 << 32) | c1) >> 11, b = (((unsigned long long)c2 << 32) | c3) >> 11;
-    const float u1 = (float)(((double)a + 0.5) * two53), u2 = (float)((double)b * two53);
-    const float r = sqrtf(-2.0f * logf(u1));
-    float s, c;
-    sincospif(2.0f * u2, &s, &c);
-    z0 = (double)(r * c);
-    z1 = (double)(r * s);
+    const float two32 = 2.3283064365386963e-10f;                        // 2^-32
+    const float ln2x2 = 1.3862943611198906f;                            // 2 ln 2
+    const float u0 = ((float)c0 + 0.5f) * two32, u1 = ((float)c2 + 0.5f) * two32;     // (small words, the tail, are exact)
+    const float r0 = __builtin_amdgcn_sqrtf(-ln2x2 * __builtin_amdgcn_logf(u0));      // sqrt(-2 ln u), v_log_f32 = log2
+    const float r1 = __builtin_amdgcn_sqrtf(-ln2x2 * __builtin_amdgcn_logf(u1));
+    const float a0 = (float)c1 * two32, a1 = (float)c3 * two32;                         // angle in revolutions, [0, 1]
+    z[0] = r0 * __builtin_amdgcn_cosf(a0);
+    z[1] = r0 * __builtin_amdgcn_sinf(a0);
+    z[2] = r1 * __builtin_amdgcn_cosf(a1);
+    z[3] = r1 * __builtin_amdgcn_sinf(a1);
 }
 
-// coloured normals of one (particle, channel, t-pair): gid enumerates P x ceil(H/2) x A
+// coloured normals of one (particle, channel, t-quad): gid enumerates P x ceil(H/4) x A
 template <typename T>
 __device__ __forceinline__ void noise_element(T* __restrict__ noise, long gid, long P, int H, int A,
                                               const double* __restrict__ chol, unsigned long long seed,
                                               unsigned long long offset, long particle_offset, int diag_only) {
-    const int H2 = (H + 1) / 2;
-    if (gid >= P * H2 * A) return;
+    const int H4 = (H + 3) / 4;
+    if (gid >= P * H4 * A) return;
     const int a = (int)(gid % A);
-    const int t2 = (int)((gid / A) % H2);
-    const long p = gid / ((long)A * H2);
-    double x0 = 0.0, x1 = 0.0;
+    const int t4 = (int)((gid / A) % H4);
+    const long p = gid / ((long)A * H4);
+    double x[4] = {0.0, 0.0, 0.0, 0.0};
     for (int b = diag_only ? a : 0; b <= a; ++b) {
         const double l = chol[a * A + b];
         if (l == 0.0) continue;
-        double z0, z1;
-        normal_pair(seed, offset, (unsigned long long)((p + particle_offset) * A + b), (unsigned)t2, z0, z1);
-        x0 += l * z0;
-        x1 += l * z1;
+        float z[4];
+        normal_quad(seed, offset, (unsigned long long)((p + particle_offset) * A + b), (unsigned)t4, z);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) x[k] += l * (double)z[k];
     }
-    const int t = 2 * t2;
-    noise[(p * H + t) * A + a] = (T)x0;
-    if (t + 1 < H) noise[(p * H + t + 1) * A + a] = (T)x1;
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+        if (4 * t4 + k < H) noise[(p * H + 4 * t4 + k) * A + a] = (T)x[k];
 }
 
 // what the fused update needs to draw the next step's raw samples (noise == nullptr: nothing to draw)

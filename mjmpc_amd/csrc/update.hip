@@ -937,7 +937,7 @@ hipError_t mppi_fused_update(const double* q0, const T* actions, double lam, dou
     long long* snap = nullptr;
     if (next && next->noise) {
         nn = *next;
-        extra = nblocks(P * ((H + 1) / 2) * A, BLK);
+        extra = nblocks(P * ((H + 3) / 4) * A, BLK);
         snap = (long long*)(w.scratch + 8);
     }
     hipLaunchKernelGGL(fused_partial_kernel<T>, dim3(nb), dim3(BLK), 0, s, q0, actions, lam, P, HA, w.partial, nn.d_step,

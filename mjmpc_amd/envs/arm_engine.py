@@ -237,6 +237,62 @@ class ArmRolloutEngine:
                                                      _ptr(q0), self._stream()))
         return costs, act, q0
 
+    def mppi_step_supported(self, num_particles, horizon):
+        """The fused iteration is built for launches of at most one wavefront per SIMD pair (two wavefronts per particle
+        group, 4096 particles on 256 CUs) - the latency-bound regime, where the launches it saves matter; larger
+        populations keep the separate sampler / rollout / update launches (their rollout kernel needs the registers and
+        the LDS the fused one spends on sampling and on the action tile)."""
+        torch = _torch()
+        simds = 4 * torch.cuda.get_device_properties(self.device).multi_processor_count
+        groups = (int(num_particles) + 7) // 8
+        lds = 8 * (32 + 8 * int(horizon) * self.d_action * (8 if self.dtype == "f64" else 4) // 8)
+        return 2 * groups <= simds and lds <= 40 * 1024
+
+    def mppi_step(self, num_particles, horizon, mean, mean_out, gamma_seq, filter_coeffs, chol, seed, offset,
+                  particle_offset, step_counter, lam, step_size, shift_mode, action_out=None, action_slots=None, record=None,
+                  env_step=False, want_trajectories=False):
+        """One whole control iteration in two launches (``mjmpc_arm_mppi_step``): sampling (the Philox stream of
+        ``DeviceUpdater.sample_noise`` for a diagonal covariance), rollout, cost-to-go | softmax update of ``mean`` into
+        ``mean_out`` (a tensor of its own), action read-out, shift, and - ``env_step`` - one step of the device-resident
+        real env with that action.  All tensors are CUDA tensors (``mean`` / ``mean_out`` float64 (H,A), ``gamma_seq``
+        float64 (H,), ``filter_coeffs`` float64 (3,) or None, ``chol`` float64 (A,A), ``step_counter`` int64 (1,));
+        ``action_slots`` is a pinned host tensor (2, A+1).  ``record`` (float64 (2 + H*A,)): sharded runs - this GPU's
+        softmax record instead of the update.  Returns (costs, actions, q0) device tensors when ``want_trajectories``."""
+        launch, out = self.mppi_step_launcher(num_particles, horizon, mean, mean_out, gamma_seq, filter_coeffs, chol, seed,
+                                              offset, particle_offset, step_counter, lam, step_size, shift_mode, action_out,
+                                              action_slots, record, env_step, want_trajectories)
+        launch()
+        return out
+
+    def mppi_step_launcher(self, num_particles, horizon, mean, mean_out, gamma_seq, filter_coeffs, chol, seed, offset,
+                           particle_offset, step_counter, lam, step_size, shift_mode, action_out=None, action_slots=None,
+                           record=None, env_step=False, want_trajectories=False):
+        """``mppi_step`` with its arguments bound once: returns (launch, outputs) where ``launch()`` enqueues the
+        iteration on the stream that is current NOW (one C call, nothing converted per step) - what a control loop
+        calls every step.  The tensors must stay alive (and in place) while the launcher is in use."""
+        torch = _torch()
+        P, H, A = int(num_particles), int(horizon), self.d_action
+        costs = act = q0 = None
+        if want_trajectories:
+            costs, act = self._buffer("costs", (P, H)), self._buffer("act", (P, H, A))
+            q0 = self._buf.get("q0")
+            if q0 is None or q0.shape[0] != P:
+                q0 = self._buf["q0"] = torch.empty(P, dtype=torch.float64, device=self.device)
+        scost = self._buffer("step_cost", (1,)) if env_step else None
+        snobs = self._buffer("step_obs", (self.d_obs,)) if env_step else None
+        keep = (mean, mean_out, gamma_seq, filter_coeffs, chol, step_counter, action_out, action_slots, record, scost, snobs,
+                costs, act, q0)
+        args = (self._h, self._code, P, H, _ptr(mean), _ptr(mean_out), _ptr(gamma_seq), _ptr(filter_coeffs), _ptr(chol),
+                int(seed) & (2 ** 64 - 1), int(offset), int(particle_offset), _ptr(step_counter), float(lam), float(step_size),
+                int(shift_mode), _ptr(action_out), _ptr(action_slots), _ptr(record), int(bool(env_step)), _ptr(scost),
+                _ptr(snobs), _ptr(costs), _ptr(act), _ptr(q0), self._stream())
+        fn, check = self._lib.mjmpc_arm_mppi_step, _lib.check
+
+        def launch(_keep=keep):
+            check(fn(*args))
+
+        return launch, ((costs, act, q0) if want_trajectories else None)
+
     def step_state(self, action):
         """Advance the engine state in place by one env step (the "real env" kept on the device).
         ``action``: numpy (A,) or CUDA float64 tensor.  Returns (cost, next_obs) device tensors."""
@@ -284,8 +340,12 @@ def make_device_rollout_fn(sim_env):
         return dict(costs=costs, actions=act, observations=None, next_observations=None, dones=None,
                     infos={"total_time": np.array([time.time() - t0] * sim_env.num_shards)})
     rollout_fn.accepts_device = True          # controllers may hand over their device-resident mean
+    rollout_fn.engine = sim_env
     if hasattr(sim_env, "rollout_fused"):   # filter + cost-to-go fused into the launch (graph fast path)
         rollout_fn.fused = sim_env.rollout_fused
+    if hasattr(sim_env, "mppi_step"):       # the whole iteration in one launch (captured iterations of MPPI / DMD-MPC)
+        rollout_fn.mono = sim_env.mppi_step
+        rollout_fn.mono_launcher = sim_env.mppi_step_launcher
     return rollout_fn
 
 

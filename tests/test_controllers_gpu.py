@@ -222,7 +222,7 @@ def test_device_noise_statistics():
     cov = B @ B.T + 0.3 * np.eye(An)
     raw = dev.sample_noise(Pn, cov, [1.0, 0.0, 0.0], 7, 3).cpu().numpy()
     flat = raw.reshape(-1, An)
-    np.testing.assert_allclose(flat.mean(0), 0, atol=0.02)
+    np.testing.assert_allclose(flat.mean(0), 0, atol=5 * np.sqrt(np.diag(cov).max() / flat.shape[0]))      # five sigma of a sample mean
     np.testing.assert_allclose(np.cov(flat, rowvar=False), cov, rtol=0.05, atol=0.03)
     assert abs(np.corrcoef(raw[:, 0, 0], raw[:, 1, 0])[0, 1]) < 0.03          # white along the horizon
     co = [0.25, 0.8, 0.1]
@@ -462,7 +462,7 @@ def test_capture_failure_falls_back_to_eager(raw_arm, monkeypatch):
         c.set_sim_state_fn = lambda s: None
         eng.set_env_state(dict(qp=np.array([0.1, 0.2, 0.0, -0.5, 0.0, -0.3, 0.0]), qv=np.zeros(7),
                                target_pos=np.array([0.2, -0.1, 0.2])))
-        c.enable_graph(post_step=eng.step_state)
+        c.enable_graph(post_step=eng.step_state, mono=False)     # (the fused iteration is launched directly: nothing to capture)
         if break_capture:
             class Refuse:
                 def __init__(self, *a, **k):
