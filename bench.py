@@ -56,9 +56,11 @@ def parse(argv=None):
     ap.add_argument("--noise", choices=["device", "mt19937", "host"], default="device",
                     help="device: Philox on the GPU; mt19937: the reference's own numpy stream regenerated on the GPU "
                          "(seed-identical particles); host: numpy on the host, uploaded")
-    ap.add_argument("--workload", choices=["reacher", "half_cheetah", "swimmer", "hand24"], default="reacher",
+    ap.add_argument("--workload", choices=["reacher", "half_cheetah", "swimmer", "hand24", "pen_hand"], default="reacher",
                     help="reacher: the BASELINE.json headline (default).  The others run the same loop on the tree engine "
-                         "(SURVEY 8f rank 4: the reference's vendored HalfCheetah / Swimmer models, the synthetic 24-dof hand)")
+                         "(SURVEY 8f rank 4: the reference's vendored HalfCheetah / Swimmer models, the synthetic 24-dof hand, "
+                         "and pen_hand: a 6-dof pen on that hand - position servos, capsule-capsule contacts with friction "
+                         "cones, pen-v0's shape of reward)")
     ap.add_argument("--controller", choices=["mppi", "cem", "dmd"], default="mppi",
                     help="mppi (headline); cem: full covariance, elite_frac 0.1 (BASELINE config 4); dmd: DMD-MPC (config 5)")
     ap.add_argument("--scaling", choices=["weak", "strong"], default="weak")
@@ -200,9 +202,14 @@ def make_workload(args, local, comm, P_tot):
     else:
         from mjmpc_amd.envs.tree_engine import TreeRolloutEngine
         from mjmpc_amd.models.compile_tree import compile_tree
+        start = None
         if args.workload == "hand24":
             from mjmpc_amd.models.hand24 import hand24_raw
             raw, env, name, lam = hand24_raw(), None, "hand_tree-v0 (synthetic 24-dof hand)", {"mppi": 0.05, "dmd": 0.1}
+        elif args.workload == "pen_hand":
+            from mjmpc_amd.models.pen_hand import holding_state, pen_hand_raw
+            raw, env, name, lam = pen_hand_raw(), None, "pen_hand-v0 (synthetic 6-dof pen in a 24-dof hand)", {"mppi": 0.05, "dmd": 0.1}
+            start = holding_state()
         else:
             from mjmpc_amd.envs import locomotion_env
             from mjmpc_amd.models.half_cheetah import half_cheetah_raw
@@ -212,15 +219,20 @@ def make_workload(args, local, comm, P_tot):
                 dtype=args.dtype, device=local)
             name, lam = dict(half_cheetah="HalfCheetah-v0", swimmer="Swimmer-v0")[args.workload], {"mppi": 0.2, "dmd": 0.2}
         eng = TreeRolloutEngine(raw, device=local, dtype=args.dtype)
-        w.update(name=name, lam=lam, cov=0.3, env=env, kernel="tree_rollout_kernel", target=np.zeros(3),
+        w.update(name=name, lam=lam, cov=0.3, env=env, kernel="tree_rollout_kernel", target=np.asarray(raw.target_pos, float),
                  frame_skip=raw.frame_skip, nv=compile_tree(raw).nv,
                  tail="closed loop (tree engine; not a BASELINE.json configuration%s)"
-                      % ("" if args.workload != "hand24" else "; stand-in for pen-v0, whose assets are absent"))
+                      % ("" if args.workload not in ("hand24", "pen_hand") else "; stand-in for pen-v0, whose assets are absent"))
         if env is not None:
             env.reset(seed=123)                         # the reference's reset noise, then the engine owns the state
             st0 = env.get_env_state()
             w["reset"] = lambda: eng.set_env_state(st0)
             w["x0"] = float(st0["qpos"][0])
+        elif start is not None:
+            st0 = dict(start, target_pos=np.asarray(raw.target_pos, float))
+            w["reset"] = lambda: eng.set_env_state(st0)
+            w["hold"] = start["qp"][6:].copy()          # servo targets of the start pose: the controller's initial mean
+            w["cov"] = 0.01
         else:
             w["reset"] = eng.reset
         w["reset"]()
@@ -239,6 +251,13 @@ def make_workload(args, local, comm, P_tot):
     else:
         ctrl = DMDMPC(lam=w["lam"]["dmd"], beta=0.1, update_cov=False, cov_type="diagonal", **kw)
         desc = "DMD-MPC lam=%g" % w["lam"]["dmd"]
+    if "hold" in w:                 # position servos: the nominal control is the pose, not zero
+        def hold(ctrl=ctrl, pose=w["hold"], reset=w["reset"]):
+            reset()
+            ctrl.mean_action = np.tile(pose, (H, 1))
+        w["reset"] = hold
+        ctrl.base_action = "repeat"
+        hold()
     w.update(raw=raw, eng=eng, ctrl=ctrl, A=A, desc=desc)
     return w
 

@@ -155,7 +155,7 @@ int mjmpc_arm_step_state(mjmpc_arm_t h, int dtype, const double* d_action, void*
  *   k | distance << 8 | height << 16, -1 ends)
  * Same call shapes and reference counterparts as the arm engine (subproc_vec_env.py:91-111, 128-186, 235-251);
  * target_pos is ignored by task 1.                                                                                  */
-#define MJMPC_TREE_BLOB_LEN 2854
+#define MJMPC_TREE_BLOB_LEN 3116
 /* Device state vector of a tree engine: qpos[32] | qvel[32] | target_pos[3] | site of the fresh observation[3]  (float64;
  * the last three are filled by mjmpc_tree_rollout_cl). */
 #define MJMPC_TREE_STATE_LEN 70

@@ -443,7 +443,7 @@ static bool tree_blob_is_full(const double* blob, int nv) {
 // friction - never the tree)
 static bool tree_same_topology(const double* a, const double* b) {
     auto same = [&](int off, int n) { return std::memcmp(a + off, b + off, sizeof(double) * n) == 0; };
-    return same(mjmpc::T_PARENT, mjmpc::TL) && same(mjmpc::T_SUBSIZE, mjmpc::TL) && same(mjmpc::T_ANC, 5 * mjmpc::TL) &&
+    return same(mjmpc::T_PARENT, mjmpc::TL) && same(mjmpc::T_EPARENT, mjmpc::TL) && same(mjmpc::T_SUBSIZE, mjmpc::TL) && same(mjmpc::T_ANC, 5 * mjmpc::TL) &&
            same(mjmpc::T_JTYPE, mjmpc::TL) && same(mjmpc::T_ACT, mjmpc::TL) && same(mjmpc::T_DEPTH, mjmpc::TL) &&
            same(mjmpc::T_N_ROUNDS, 1) && same(mjmpc::T_ELIM, (mjmpc::TL - 1) * mjmpc::TL) && same(mjmpc::T_NV, 1) &&
            same(mjmpc::T_NU, 1) && same(mjmpc::T_TASK, 1) && same(mjmpc::T_OBS_SKIP, 1) && same(mjmpc::T_JUMPS, 1);
@@ -475,7 +475,7 @@ int mjmpc_tree_create(const double* blob, int n_blob, int device, mjmpc_tree_t* 
     if (nv < 1 || nv > mjmpc::TL) return fail(MJMPC_E_BADMODEL, "nv = %d outside 1..%d", nv, mjmpc::TL);
     if ((int)blob[mjmpc::T_N_SPHERE] > mjmpc::TREE_MAX_SPHERES) return fail(MJMPC_E_BADMODEL, "too many contact points");
     const int nu = (int)blob[mjmpc::T_NU], task = (int)blob[mjmpc::T_TASK], skip = (int)blob[mjmpc::T_OBS_SKIP];
-    if (nu < 1 || nu > nv || task < 0 || task > 1 || skip < 0 || skip >= nv)
+    if (nu < 1 || nu > nv || task < 0 || task > 2 || skip < 0 || skip >= nv)
         return fail(MJMPC_E_BADMODEL, "nu = %d, task = %d, obs_skip = %d do not fit nv = %d", nu, task, skip, nv);
     if (mjmpc_device_count() <= device) return fail(MJMPC_E_NOGPU, "HIP device %d not present", device);
     HIP_TRY(hipSetDevice(device));

@@ -6,11 +6,16 @@
 namespace mjmpc {
 
 constexpr int TL = 32;              // lanes per particle (one per link / dof)
-constexpr int TREE_MAX_SPHERES = 16; // contact points against the plane (a colliding capsule is its two end spheres)
-constexpr int TREE_SPH_STRIDE = 12; // link, pos[3], r, margin, invweight, mu (0: frictionless row), capsule axis[3], depth of the link
+constexpr int TREE_MAX_SPHERES = 16; // contact points: spheres against the plane (a colliding capsule is its two end
+                                     // spheres) and geom-geom pairs (one point each)
+// contact record: [0] link A, [1:4] centre / segment start on A, [4] radius, [5] margin, [6] invweight (both bodies),
+// [7] mu (0: frictionless row), [8:11] capsule axis (plane contacts: frame hint) / segment vector on A (geom-geom),
+// [11] depth of link A in the elimination tree, [12] kind (0 sphere-plane, 1 geom-geom), [13] link B, [14:17] segment
+// start on B, [17] radius B, [18:21] segment vector on B
+constexpr int TREE_SPH_STRIDE = 24;
 
 enum TreeOffset : int {
-    // the first 25 per-link fields are the arm block's, 32 lanes wide
+    // ---- staged in LDS by the kernel.  The first 14 per-link fields are the arm block's, 32 lanes wide
     T_OFF = 0,                          // 3 x 32   joint anchor minus the parent link's, world axes at qpos0
     T_AXIS = T_OFF + 3 * TL,            // 3 x 32
     T_MASS = T_AXIS + 3 * TL,
@@ -25,21 +30,14 @@ enum TreeOffset : int {
     T_CTRL_LO = T_GEAR + TL,
     T_CTRL_HI = T_CTRL_LO + TL,
     T_DOF_INVW = T_CTRL_HI + TL,
-    // topology
-    T_PARENT = T_DOF_INVW + TL,         // parent link, -1 for a root
-    T_SUBSIZE = T_PARENT + TL,          // links in my subtree, myself included
-    T_ANC = T_SUBSIZE + TL,             // 5 x 32: ancestor at distance 1, 2, 4, 8, 16 (-1: none)
-    T_ANCMASK = T_ANC + 5 * TL,         // 2 x 32: bits 0-15 / 16-31 of {j : link j is me or one of my ancestors}
-                                        // (two halves so that the f32 copy of the block holds them exactly)
-    // joint kind, springs, motors, medium
-    T_JTYPE = T_ANCMASK + 2 * TL,       // 1 hinge, 2 slide
-    T_STIFFNESS = T_JTYPE + TL,
+    // springs, medium, servos
+    T_STIFFNESS = T_DOF_INVW + TL,
     T_SPRINGREF = T_STIFFNESS + TL,
-    T_ACT = T_SPRINGREF + TL,           // index of the action that drives this dof (-1: none)
-    T_FBOX = T_ACT + TL,                // 3 x 32   box of equal inertia (fluid model), 0 for massless links
+    T_FBOX = T_SPRINGREF + TL,          // 3 x 32   box of equal inertia (fluid model), 0 for massless links
     T_FROT = T_FBOX + 3 * TL,           // 9 x 32   principal axes of the link's inertia in the link frame (row-major)
+    T_KPG = T_FROT + 9 * TL,            // position servos: gear^2 kp (the stiffness of their bias at the joint)
     // scalars
-    T_NV = T_FROT + 9 * TL,
+    T_NV = T_KPG + TL,
     T_TIMESTEP,
     T_FRAME_SKIP,
     T_JUMPS,                            // pointer-jumping rounds = ceil(log2(tree depth))
@@ -57,7 +55,7 @@ enum TreeOffset : int {
     T_SOL_POWER,
     T_GRAVITY,                          // 3
     T_NU = T_GRAVITY + 3,
-    T_TASK,                             // 0 reach a target with the site, 1 forward progress of qpos[0]
+    T_TASK,                             // 0 reach a target with the site, 1 forward progress of qpos[0], 2 reorient an object
     T_CTRL_COST,
     T_OBS_SKIP,
     T_DENSITY,
@@ -69,10 +67,24 @@ enum TreeOffset : int {
     T_LSOL_WIDTH,
     T_LSOL_MID,
     T_LSOL_POWER,
-    T_ANY_FRICTION,                     // some contact point has mu > 0 (pyramidal rows)
-    T_SPH,                              // TREE_MAX_SPHERES x TREE_SPH_STRIDE
+    T_ANY_FRICTION,                     // the model needs the full instantiation (friction cones, geom-geom pairs, servos)
+    T_SITE_AXIS,                        // 3: task 2, the object's axis in the site link's frame
+    T_TARGET_DIR = T_SITE_AXIS + 3,     // 3: ... and the direction it should point in
+    T_SPH = T_TARGET_DIR + 3,           // TREE_MAX_SPHERES x TREE_SPH_STRIDE
+    // ---- read once per launch, from global memory: topology, joint kinds, action map
+    T_TOPO = T_SPH + TREE_MAX_SPHERES * TREE_SPH_STRIDE,
+    T_PARENT = T_TOPO,                  // parent link, -1 for a root
+    T_SUBSIZE = T_PARENT + TL,          // links in my subtree, myself included
+    T_ANC = T_SUBSIZE + TL,             // 5 x 32: ancestor at distance 1, 2, 4, 8, 16 (-1: none)
+    T_ANCMASK = T_ANC + 5 * TL,         // 2 x 32: bits 0-15 / 16-31 of {j : link j is me or one of my ancestors}
+                                        // (two halves so that the f32 copy of the block holds them exactly)
+    T_JTYPE = T_ANCMASK + 2 * TL,       // 1 hinge, 2 slide
+    T_ACT = T_JTYPE + TL,               // index of the action that drives this dof (-1: none)
+    T_EPARENT = T_ACT + TL,             // parent in the ELIMINATION tree of the sparse factorisation: the kinematic parent,
+                                        // except that a manipulator's root hangs under the last link of the object it
+                                        // touches (geom-geom contacts couple the two trees; see compile_tree.py)
     // tree-sparse L'DL: links of equal height above their deepest leaf are eliminated together (one round per height)
-    T_DEPTH = T_SPH + TREE_MAX_SPHERES * TREE_SPH_STRIDE,      // 32: strict ancestors of the link
+    T_DEPTH = T_EPARENT + TL,           // 32: strict ancestors of the link in the elimination tree
     T_N_ROUNDS = T_DEPTH + TL,          // max height + 1
     T_ELIM,                             // 31 x 32, [entry][lane]: my descendants sorted by height, packed
                                         // k | distance << 8 | height << 16; -1 terminates the list
@@ -80,6 +92,6 @@ enum TreeOffset : int {
 };
 
 constexpr int TREE_STATE_LEN = 2 * TL + 6;   // qpos[32] | qvel[32] | target[3] | site of the fresh observation[3]
-static_assert(TREE_BLOB_LEN == 2854, "keep in sync with mjmpc_amd/models/compile_tree.py::TREE_LAYOUT");
+static_assert(TREE_BLOB_LEN == 3116, "keep in sync with mjmpc_amd/models/compile_tree.py::TREE_LAYOUT");
 
 }  // namespace mjmpc

@@ -96,7 +96,9 @@ constexpr int a_vec(int DP, int PL) { return (row_stride(DP) * PL > 12 * PL ? ro
 // contact Jacobian rows [NS][NJ][DP], PATH-INDEXED like the matrix rows: a contact point on link L moves only with the
 // dofs on L's path to the root, entry c belongs to L's ancestor at distance c (a quarter of a [32]-lane row at DP = 8)
 constexpr int a_jc(int DP, int PL) { return a_vec(DP, PL) + PL; }
-constexpr int CS = 12;      // per contact point: centre[3], dist, D, aref (normal part), mu B Jt1.v, mu B Jt2.v, axis[3]
+constexpr int CS = 12;      // per contact point: sphere centre (lean instantiation) / contact point (full)[3], dist, D, aref
+                            // (normal part), mu B Jt1.v, mu B Jt2.v, [3] capsule axis = hint for the contact frame
+                            // (sphere-plane) / contact normal (geom-geom), -
 constexpr int a_cs(int DP, int NS, int NJ, int PL) { return a_jc(DP, PL) + NS * NJ * DP; }
 constexpr int a_misc(int DP, int NS, int NJ, int PL) { return a_cs(DP, NS, NJ, PL) + NS * CS; }   // site[3]
 constexpr int a_row2(int DP, int NS, int NJ, int PL) { return a_misc(DP, NS, NJ, PL) + 8; }     // the Euler matrix's factor
@@ -358,10 +360,10 @@ __global__ __launch_bounds__(64 * wg_waves(DP, FRIC, sizeof(T), PL), min_waves(s
     typedef typename std::conditional<FRIC, unsigned long long, unsigned>::type mask_t;    // NR bits per contact point
     constexpr int A_VEC = a_vec(DP, PL), A_JC = a_jc(DP, PL), A_CS = a_cs(DP, NS, NJ, PL), A_MISC = a_misc(DP, NS, NJ, PL),
                   A_ROW2 = a_row2(DP, NS, NJ, PL), A_LEN = a_len(DP, NS, NJ, PL, sizeof(T));
-    constexpr int NBLOB = T_DEPTH;          // the scalar part of the block; the topology tables go to integer LDS
+    constexpr int NBLOB = T_TOPO;           // the constants the loop reads; topology tables are read once, from global memory
     __shared__ __attribute__((aligned(16))) T lds[NBLOB + 1 + PPW * WG_WAVES * A_LEN];
     __shared__ int ELIM[(PL - 1) * PL];     // elimination lists
-    __shared__ int AT[DP * PL];             // AT[c * PL + l] = ancestor of link l at distance c (-1 beyond the root)
+    __shared__ int AT[DP * PL];             // AT[c * PL + l] = ancestor of link l at distance c IN THE ELIMINATION TREE (-1 beyond the root)
     // gridDim.y shards of shard_size consecutive particles (the reference's workers); a workgroup never straddles two.
     // Dynamics randomization (SubprocVecEnv.randomize_dynamics) gives each its own model block (model_stride != 0),
     // a per-worker set_env_state (subproc_vec_env.py:242-251) its own start state (state_stride != 0).
@@ -375,7 +377,7 @@ __global__ __launch_bounds__(64 * wg_waves(DP, FRIC, sizeof(T), PL), min_waves(s
         int a = threadIdx.x;
         for (int c = 0; c < DP; ++c) {
             AT[c * PL + threadIdx.x] = a;
-            a = a >= 0 ? (int)model[T_PARENT + a] : -1;
+            a = a >= 0 ? (int)model[T_EPARENT + a] : -1;       // (the ELIMINATION tree: tree_model.h)
         }
     }
     __syncthreads();
@@ -397,17 +399,17 @@ __global__ __launch_bounds__(64 * wg_waves(DP, FRIC, sizeof(T), PL), min_waves(s
     const int n_sphere = __builtin_amdgcn_readfirstlane(min((int)M[T_N_SPHERE], NS));
     const int task = __builtin_amdgcn_readfirstlane((int)M[T_TASK]), obs_skip = __builtin_amdgcn_readfirstlane((int)M[T_OBS_SKIP]);
     const int dobs = task == 1 ? 2 * nv - obs_skip : 2 * nv + 6;
-    const bool slide = FRIC && (int)M[T_JTYPE + l] == 2;      // (slide joints, springs, a medium: the full instantiation only)
-    const int act_id = (int)M[T_ACT + l];
+    const bool slide = FRIC && (int)model[T_JTYPE + l] == 2;      // (slide joints, springs, a medium: the full instantiation only)
+    const int act_id = (int)model[T_ACT + l];
     const bool fluid = FRIC && (M[T_DENSITY] > T(0) || M[T_VISCOSITY] > T(0));   // (the full instantiation only)
 
     Topo tp;
-    tp.parent = (int)M[T_PARENT + l];
-    tp.subsize = (int)M[T_SUBSIZE + l];
+    tp.parent = (int)model[T_PARENT + l];
+    tp.subsize = (int)model[T_SUBSIZE + l];
 #pragma unroll
-    for (int k = 0; k < 5; ++k) tp.anc[k] = (1 << k) < DP ? AT[(1 << k) * PL + l] : -1;
+    for (int k = 0; k < 5; ++k) tp.anc[k] = (int)model[T_ANC + k * TL + l];      // (kinematic ancestors: pointer jumping)
     tp.jumps = __builtin_amdgcn_readfirstlane((int)M[T_JUMPS]);
-    tp.ancmask = (unsigned)M[T_ANCMASK + l] | ((unsigned)M[T_ANCMASK + TL + l] << 16);
+    tp.ancmask = (unsigned)model[T_ANCMASK + l] | ((unsigned)model[T_ANCMASK + TL + l] << 16);
     const bool dof = l < nv;
 
     T q = dof ? (T)state[l] : T(0), v = dof ? (T)state[TL + l] : T(0);
@@ -457,7 +459,7 @@ __global__ __launch_bounds__(64 * wg_waves(DP, FRIC, sizeof(T), PL), min_waves(s
         const T u_dof = __shfl(u, act_id >= 0 ? act_id : 0, PL);
         const T tau_act = act_id >= 0 ? M[T_GEAR + l] * fmin(fmax(u_dof, M[T_CTRL_LO + l]), M[T_CTRL_HI + l]) : T(0);
         if (task == 1 && l == 0) X[A_MISC + 4] = q;        // qpos[0] when the env step starts
-        T hand[3] = {T(0), T(0), T(0)};
+        T hand[3] = {T(0), T(0), T(0)}, haxis[3] = {T(0), T(0), T(0)};
         for (int sub = 0; sub < frame_skip; ++sub) {
             // ---- 1. forward kinematics: X_l = X_parent o (Rodrigues(axis, q), off), by pointer jumping
             clk.mark(7);
@@ -509,6 +511,11 @@ __global__ __launch_bounds__(64 * wg_waves(DP, FRIC, sizeof(T), PL), min_waves(s
                 T tv[3];
                 mv3(R, sp, tv);
                 for (int k = 0; k < 3; ++k) X[A_MISC + k] = p[k] + tv[k];
+                if (FRIC && task == 2) {        // the object's axis in the world
+                    const T sa[3] = {M[T_SITE_AXIS], M[T_SITE_AXIS + 1], M[T_SITE_AXIS + 2]};
+                    mv3(R, sa, tv);
+                    for (int k = 0; k < 3; ++k) X[A_MISC + 5 + k] = tv[k];
+                }
             }
             // contact points: centre, signed distance (and the capsule axis the contact frame is aligned with), one
             // point per lane - every link publishes its frame, lane s reads the frame of point s's link
@@ -523,19 +530,84 @@ __global__ __launch_bounds__(64 * wg_waves(DP, FRIC, sizeof(T), PL), min_waves(s
                 if (l < n_sphere) {
                     const T* sp = M + T_SPH + l * TREE_SPH_STRIDE;
                     const int sl = (int)sp[0];
-                    T Rl[9], ctr[3], tv[3];
+                    T Rl[9], pl[3], tv[3];
 #pragma unroll
                     for (int c = 0; c < 9; ++c) Rl[c] = X[c * PL + sl];
-                    mv3(Rl, sp + 1, tv);
-                    for (int k = 0; k < 3; ++k) ctr[k] = X[(9 + k) * PL + sl] + tv[k];
                     T* cs = X + A_CS + l * CS;
-                    for (int k = 0; k < 3; ++k) cs[k] = ctr[k];
-                    const T cdist = dot3(ctr, pn) - M[T_PLANE_D] - sp[4];
-                    cs[3] = cdist;
-                    ci_mine = cdist < sp[5];            // mj_collision: included while dist < margin
-                    if (FRIC) {
-                        mv3(Rl, sp + 8, tv);
-                        for (int k = 0; k < 3; ++k) cs[8 + k] = tv[k];
+                    if constexpr (!FRIC) {          // (the lean instantiation: spheres against the plane, frictionless)
+                        T ctr[3];
+                        mv3(Rl, sp + 1, tv);
+                        for (int k = 0; k < 3; ++k) ctr[k] = X[(9 + k) * PL + sl] + tv[k];
+                        for (int k = 0; k < 3; ++k) cs[k] = ctr[k];
+                        const T cdist = dot3(ctr, pn) - M[T_PLANE_D] - sp[4];
+                        cs[3] = cdist;
+                        ci_mine = cdist < sp[5];
+                    }
+#pragma unroll
+                    for (int c = 0; c < 3; ++c) pl[c] = FRIC ? X[(9 + c) * PL + sl] : T(0);
+                    if (!FRIC) {
+                    } else if (sp[12] == T(0)) {
+                        // sphere / capsule end against the plane (mjc_PlaneSphere, mjc_PlaneCapsule)
+                        T ctr[3];
+                        mv3(Rl, sp + 1, tv);
+                        for (int k = 0; k < 3; ++k) ctr[k] = pl[k] + tv[k];
+                        const T cdist = dot3(ctr, pn) - M[T_PLANE_D] - sp[4];
+                        cs[3] = cdist;
+                        ci_mine = cdist < sp[5];            // mj_collision: included while dist < margin
+                        if (FRIC) {                         // the contact point, and the capsule axis the frame is aligned with
+                            for (int k = 0; k < 3; ++k) cs[k] = ctr[k] - pn[k] * (sp[4] + T(0.5) * cdist);
+                            mv3(Rl, sp + 8, tv);
+                            for (int k = 0; k < 3; ++k) cs[8 + k] = tv[k];
+                        } else {
+                            for (int k = 0; k < 3; ++k) cs[k] = ctr[k];
+                        }
+                    } else {
+                        // geom-geom (mjc_SphereSphere / SphereCapsule / CapsuleCapsule): closest points of the two
+                        // segments; normal from the object's geom (B) to the manipulator's (A), point midway
+                        const int sb = (int)sp[13];
+                        T Rb[9], o1[3], d1[3], o2[3], d2[3];
+#pragma unroll
+                        for (int c = 0; c < 9; ++c) Rb[c] = X[c * PL + sb];
+                        mv3(Rl, sp + 1, tv);
+                        for (int k = 0; k < 3; ++k) o1[k] = pl[k] + tv[k];
+                        mv3(Rl, sp + 8, d1);
+                        mv3(Rb, sp + 14, tv);
+                        for (int k = 0; k < 3; ++k) o2[k] = X[(9 + k) * PL + sb] + tv[k];
+                        mv3(Rb, sp + 18, d2);
+                        T ss, tt;
+                        {
+                            const T r3[3] = {o1[0] - o2[0], o1[1] - o2[1], o1[2] - o2[2]};
+                            const T a = dot3(d1, d1), e = dot3(d2, d2), f = dot3(d2, r3), EPS = T(1e-18);
+                            auto clamp01 = [](T x) { return x < T(0) ? T(0) : (x > T(1) ? T(1) : x); };
+                            if (a <= EPS && e <= EPS) { ss = T(0); tt = T(0); }
+                            else if (a <= EPS) { ss = T(0); tt = clamp01(f / e); }
+                            else {
+                                const T c = dot3(d1, r3);
+                                if (e <= EPS) { tt = T(0); ss = clamp01(-c / a); }
+                                else {
+                                    const T b = dot3(d1, d2), denom = a * e - b * b;
+                                    ss = denom > T(1e-12) * a * e ? clamp01((b * f - c * e) / denom) : T(0);
+                                    tt = (b * ss + f) / e;
+                                    if (tt < T(0)) { tt = T(0); ss = clamp01(-c / a); }
+                                    else if (tt > T(1)) { tt = T(1); ss = clamp01((b - c) / a); }
+                                }
+                            }
+                        }
+                        T c2[3], diff[3];
+                        for (int k = 0; k < 3; ++k) {
+                            c2[k] = o2[k] + tt * d2[k];
+                            diff[k] = o1[k] + ss * d1[k] - c2[k];
+                        }
+                        const T len = sqrt_(dot3(diff, diff));
+                        const T inv = len > T(1e-14) ? T(1) / len : T(0);
+                        const T cdist = len - sp[4] - sp[17];
+                        for (int k = 0; k < 3; ++k) {
+                            const T nk = diff[k] * inv;
+                            cs[8 + k] = nk;
+                            cs[k] = c2[k] + nk * (sp[17] + T(0.5) * cdist);
+                        }
+                        cs[3] = cdist;
+                        ci_mine = len > T(1e-14) && cdist < sp[5];
                     }
                 }
                 const unsigned long long b = __ballot(ci_mine);
@@ -545,7 +617,10 @@ __global__ __launch_bounds__(64 * wg_waves(DP, FRIC, sizeof(T), PL), min_waves(s
             }
             TSYNC();
             if (sub == frame_skip - 1 || (t == 0 && sub == 0))
-                for (int k = 0; k < 3; ++k) hand[k] = X[A_MISC + k];
+                for (int k = 0; k < 3; ++k) {
+                    hand[k] = X[A_MISC + k];
+                    if constexpr (FRIC) haxis[k] = X[A_MISC + 5 + k];      // (task 2 runs the full instantiation)
+                }
             if (t == 0 && sub == 0) {
                 for (int k = 0; k < 3; ++k) hand_prev[k] = hand[k];     // fresh observation after set_env_state
                 if (site_out && pid == 0 && l < 3) site_out[l] = (double)hand[l];
@@ -670,7 +745,9 @@ __global__ __launch_bounds__(64 * wg_waves(DP, FRIC, sizeof(T), PL), min_waves(s
                 for (int c = 0; c < DP; ++c) {
                     const int an = AT[c * PL + l];
                     T sacc = T(0);
-                    if (an >= 0) {
+                    // (full instantiation: elimination-tree ancestors that are not kinematic ones - the object's links
+                    // above a manipulator - have no entry; the lean one has no geom-geom pairs, the two trees coincide)
+                    if (an >= 0 && (!FRIC || ((tp.ancmask >> an) & 1u))) {
 #pragma unroll
                         for (int k = 0; k < 6; ++k) sacc += S_[k * PL + an] * F[k];
                     }
@@ -679,7 +756,8 @@ __global__ __launch_bounds__(64 * wg_waves(DP, FRIC, sizeof(T), PL), min_waves(s
                 mrow[0] = dof ? mrow[0] + armature : T(1);     // spare lanes: unit diagonal, no ancestors
                 TSYNC();                    // S_ lies inside the area the factorisation publishes rows to
             }
-            const T tau = dof ? -bias - damping * v - (FRIC ? M[T_STIFFNESS + l] * (q - M[T_SPRINGREF + l]) : T(0)) + tau_act : T(0);
+            // (position servos: the bias -kp * (gear q) of MJCF <position>, a stiffness gear^2 kp about 0 at the joint)
+            const T tau = dof ? -bias - damping * v - (FRIC ? M[T_STIFFNESS + l] * (q - M[T_SPRINGREF + l]) + M[T_KPG + l] * q : T(0)) + tau_act : T(0);
 
             // ---- 5. constraint rows: joint limits (mj_instantiateLimit, strict dist < 0) ...
             clk.mark(2);
@@ -711,11 +789,23 @@ __global__ __launch_bounds__(64 * wg_waves(DP, FRIC, sizeof(T), PL), min_waves(s
                 const int dsl = (int)sp[11], oi = own_idx(s);
                 // velocity of the contact point per unit joint velocity, from the motion subspace about the world
                 // origin: g = sw x c + sv  (hinge: a x (c - p); slide: a)
-                T r[3], g[3];
-                for (int k = 0; k < 3; ++k) r[k] = cs[k] - pn[k] * (sp[4] + T(0.5) * cdist);
+                // ... of the material point of every link that carries one of the two geoms: + on the side of geom A,
+                // - on the side of geom B (the world's plane has no side), 0 for elimination-path links that carry neither
+                T r[3], g[3], nbuf[3];
+                const T* nrm = pn;
+                T side = T(1);
+                if constexpr (FRIC) {
+                    const bool geomgeom = sp[12] != T(0);
+                    for (int k = 0; k < 3; ++k) { r[k] = cs[k]; nbuf[k] = geomgeom ? cs[8 + k] : pn[k]; }
+                    nrm = nbuf;
+                    const int lA = (int)sp[0], lB = (int)sp[13];
+                    side = T((lA >= l && lA < l + tp.subsize) ? 1 : 0) - T((lB >= l && lB < l + tp.subsize) ? 1 : 0);
+                } else {
+                    for (int k = 0; k < 3; ++k) r[k] = cs[k] - pn[k] * (sp[4] + T(0.5) * cdist);
+                }
                 cross3(sw, r, g);
                 for (int k = 0; k < 3; ++k) g[k] += sv[k];
-                const T jc = oi >= 0 ? dot3(pn, g) : T(0);
+                const T jc = oi >= 0 ? (FRIC ? side * dot3(nrm, g) : dot3(pn, g)) : T(0);
                 if (oi >= 0) jrow[oi] = jc;
                 if (ci && l > dsl && l < DP) jrow[l] = T(0);        // past the root: read by shorter paths' lanes
                 const T jv = sum_lanes<PL>(jc * v);
@@ -723,20 +813,21 @@ __global__ __launch_bounds__(64 * wg_waves(DP, FRIC, sizeof(T), PL), min_waves(s
                 T Dc, arc, mb1 = T(0), mb2 = T(0);
                 if (FRIC) {
                     T ax3[3] = {cs[8], cs[9], cs[10]}, t1[3], t2[3];
+                    if (sp[12] != T(0)) { ax3[0] = T(0); ax3[1] = T(0); ax3[2] = T(0); }     // (geom-geom: that slot holds the normal)
                     if (dot3(ax3, ax3) < T(0.25)) {
-                        const bool yy = pn[1] < T(0.5) && pn[1] > T(-0.5);
+                        const bool yy = nrm[1] < T(0.5) && nrm[1] > T(-0.5);
                         ax3[0] = T(0);
                         ax3[1] = yy ? T(1) : T(0);
                         ax3[2] = yy ? T(0) : T(1);
                     }
-                    const T pr = dot3(pn, ax3);
-                    for (int k = 0; k < 3; ++k) t1[k] = ax3[k] - pr * pn[k];
+                    const T pr = dot3(nrm, ax3);
+                    for (int k = 0; k < 3; ++k) t1[k] = ax3[k] - pr * nrm[k];
                     const T nn = dot3(t1, t1);
                     if (nn < T(1e-30)) { t1[0] = T(1); t1[1] = T(0); t1[2] = T(0); }
                     else { const T inv = rcp_(sqrt_(nn)); for (int k = 0; k < 3; ++k) t1[k] *= inv; }
-                    cross3(pn, t1, t2);
+                    cross3(nrm, t1, t2);
                     const bool fr = oi >= 0 && mu > T(0);
-                    const T j1 = fr ? dot3(t1, g) : T(0), j2 = fr ? dot3(t2, g) : T(0);
+                    const T j1 = fr ? side * dot3(t1, g) : T(0), j2 = fr ? side * dot3(t2, g) : T(0);
                     if (oi >= 0) { jrow[DP + oi] = j1; jrow[2 * DP + oi] = j2; }
                     if (ci && l > dsl && l < DP) { jrow[DP + l] = T(0); jrow[2 * DP + l] = T(0); }
                     mb1 = mu * M[T_SOL_B] * sum_lanes<PL>(j1 * v);
@@ -1006,6 +1097,11 @@ __global__ __launch_bounds__(64 * wg_waves(DP, FRIC, sizeof(T), PL), min_waves(s
             // reward = -(|h-g|_1 + 5 |h-g|_2), h = site position lagging one substep (reacher_env.py:31-35)
             const T dx = hand[0] - tgt[0], dy = hand[1] - tgt[1], dz = hand[2] - tgt[2];
             cst = fabs(dx) + fabs(dy) + fabs(dz) + T(5) * sqrt_(dx * dx + dy * dy + dz * dz);
+            // task 2, the shape of pen-v0's reward (examples/configs/hand/pen-v0.yml:8): the object to its target
+            // position, its axis to its target direction
+            if (FRIC && task == 2)
+                cst = sqrt_(dx * dx + dy * dy + dz * dz) -
+                      (haxis[0] * M[T_TARGET_DIR] + haxis[1] * M[T_TARGET_DIR + 1] + haxis[2] * M[T_TARGET_DIR + 2]);
         }
         if (live && l == 0) cost[pid * H + t] = cst;
         if (live && (obs || nobs) && task == 1) {           // obs = [qpos[skip:], qvel]

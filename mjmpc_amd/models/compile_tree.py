@@ -15,19 +15,24 @@ from dataclasses import dataclass
 import numpy as np
 
 from .compile import _geom_inertial, _quat2mat, _shift_inertia, principal_inertia
-from .raw import GEOM_SPHERE, JOINT_HINGE, JOINT_SLIDE, TASK_FORWARD, TASK_REACH, RawModel
+from .raw import GEOM_SPHERE, JOINT_HINGE, JOINT_SLIDE, TASK_FORWARD, TASK_ORIENT, TASK_REACH, RawModel
 
 TL = 32                     # lanes per particle
 TREE_MAX_SPHERES = 16
-SPH_STRIDE = 12
+SPH_STRIDE = 24             # contact record: [0] link A, [1:4] centre / segment start on A, [4] radius, [5] margin,
+                            # [6] invweight (both bodies), [7] mu, [8:11] capsule axis (plane contacts: frame hint) /
+                            # segment vector on A (geom-geom), [11] depth of link A in the elimination tree, [12] kind
+                            # (0 sphere-plane, 1 geom-geom), [13] link B, [14:17] segment start on B, [17] radius B,
+                            # [18:21] segment vector on B
 MJ_MINIMP, MJ_MAXIMP = 1e-4, 0.9999     # MuJoCo's clamp on solimp (getsolparam)
 
 TREE_LAYOUT = [
+    # ---- staged in LDS by the kernel: per-link constants, scalars, contact records
     ("off", 3 * TL), ("axis", 3 * TL), ("mass", TL), ("com", 3 * TL), ("inertia", 6 * TL),
     ("armature", TL), ("damping", TL), ("range_lo", TL), ("range_hi", TL), ("limited", TL), ("gear", TL),
     ("ctrl_lo", TL), ("ctrl_hi", TL), ("dof_invweight0", TL),
-    ("parent", TL), ("subsize", TL), ("anc", 5 * TL), ("ancmask", 2 * TL),
-    ("jtype", TL), ("stiffness", TL), ("springref", TL), ("act", TL), ("fbox", 3 * TL), ("frot", 9 * TL),
+    ("stiffness", TL), ("springref", TL), ("fbox", 3 * TL), ("frot", 9 * TL),
+    ("kpg", TL),                    # position servos: gear^2 kp, the stiffness of their bias -kp * (gear q) at the joint
     ("nv", 1), ("timestep", 1), ("frame_skip", 1), ("jumps", 1), ("site_link", 1), ("site_pos", 3),
     ("n_sphere", 1), ("plane_n", 3), ("plane_d", 1),
     ("sol_K", 1), ("sol_B", 1), ("sol_dmin", 1), ("sol_dmax", 1), ("sol_width", 1), ("sol_mid", 1), ("sol_power", 1),
@@ -35,10 +40,15 @@ TREE_LAYOUT = [
     ("nu", 1), ("task", 1), ("ctrl_cost", 1), ("obs_skip", 1), ("density", 1), ("viscosity", 1),
     ("lsol_K", 1), ("lsol_B", 1), ("lsol_dmin", 1), ("lsol_dmax", 1), ("lsol_width", 1), ("lsol_mid", 1), ("lsol_power", 1),
     ("any_friction", 1),
+    ("site_axis", 3), ("target_dir", 3),    # TASK_ORIENT: object axis in the site link's frame, its target direction
     ("spheres", TREE_MAX_SPHERES * SPH_STRIDE),
+    # ---- read once per launch from global memory: topology, joint kinds, action map
+    ("parent", TL), ("subsize", TL), ("anc", 5 * TL), ("ancmask", 2 * TL), ("jtype", TL), ("act", TL),
+    ("eparent", TL),                # parent in the ELIMINATION tree (= parent, but the manipulator's root hangs under the
+                                    # object's last link when geom-geom contacts couple the two trees)
     # tree-sparse L'DL (MuJoCo's factorisation order: leaves first, no fill-in): links of equal HEIGHT above their
     # deepest leaf are mutually unrelated and are eliminated together, one round per height
-    ("depth", TL),                  # strict ancestors of the link
+    ("depth", TL),                  # strict ancestors of the link IN THE ELIMINATION TREE
     ("n_rounds", 1),                # max height + 1
     ("elim", (TL - 1) * TL),        # [entry][lane]: my descendants sorted by height, packed k | dist << 8 | height << 16
                                     # (-1 terminates): the rows that update mine, round by round
@@ -176,6 +186,61 @@ def compile_tree(raw: RawModel, overrides=None, base: "TreeModel" = None) -> Tre
         depth[i] = d                            # links on my path to the root, myself included
     jumps = int(np.ceil(np.log2(depth.max()))) if depth.max() > 1 else 0
 
+    # ---- elimination tree of the sparse factorisation -------------------------------------------------------
+    # H = M + J' D J has M's pattern (entries only between a link and its ancestors) as long as every constraint row
+    # touches the dofs of ONE root path.  A contact between a manipulator link and an object link touches two trees.
+    # Hanging the manipulator's root under the object's last link - in the tree the FACTORISATION walks, not in the
+    # kinematic one - puts both on one path again: the object's dofs are eliminated last, fill-in stays inside the
+    # path-indexed rows.  (The object must be a serial chain listed before the manipulator.)
+    geom_names = {g.name: (i, g) for i, b in enumerate(raw.bodies) for g in b.geoms if g.name}
+    pair_geoms = []
+    for ga, gb in raw.pairs:
+        if ga not in geom_names or gb not in geom_names:
+            raise ValueError("collision pair names an unknown geom: %r / %r" % (ga, gb))
+        pair_geoms.append((geom_names[ga], geom_names[gb]))
+
+    def root_of(k):
+        while parent[k] >= 0:
+            k = parent[k]
+        return k
+
+    eparent = parent.copy()
+    if pair_geoms:
+        obj_roots = {root_of(link_of_body[ib]) for (_, _), (ib, _) in pair_geoms}
+        man_roots = {root_of(link_of_body[ia]) for (ia, _), (_, _) in pair_geoms}
+        if len(obj_roots) != 1 or obj_roots & man_roots:
+            raise NotImplementedError("geom-geom pairs must pair geoms of the manipulator(s) with geoms of ONE object tree")
+        ro = obj_roots.pop()
+        chain = list(range(ro, ro + subsize[ro]))
+        if any(parent[k] != k - 1 for k in chain[1:]):
+            raise NotImplementedError("the object of geom-geom pairs must be a serial chain of joints")
+        for rm in sorted(man_roots):
+            if rm < ro:
+                raise NotImplementedError("list the object before the manipulator (its dofs are eliminated last)")
+            eparent[rm] = chain[-1]
+    edepth = np.zeros(nv, int)
+    for i in range(nv):
+        k, d = i, 0
+        while k >= 0:
+            k, d = eparent[k], d + 1
+        edepth[i] = d
+    if edepth.max() > TL:
+        raise ValueError("elimination path too long")
+    eheight = np.zeros(nv, int)
+    for i in range(nv - 1, -1, -1):            # (links are numbered parents-first in both trees)
+        if eparent[i] >= 0:
+            eheight[eparent[i]] = max(eheight[eparent[i]], eheight[i] + 1)
+
+    def e_descendants(i):
+        out = []
+        for k in range(nv):
+            j = eparent[k]
+            while j >= 0 and j != i:
+                j = eparent[j]
+            if j == i:
+                out.append(k)
+        return out
+
     f = {name: np.zeros(n) for name, n in TREE_LAYOUT}
     origin = [p0[j] for j in jointed]
     axis_w = []
@@ -229,13 +294,15 @@ def compile_tree(raw: RawModel, overrides=None, base: "TreeModel" = None) -> Tre
         f["anc"][e * TL:e * TL + nv] = anc[e]
     f["ancmask"][:nv] = ancmask & 0xFFFF
     f["ancmask"][TL:TL + nv] = ancmask >> 16
-    f["depth"][:nv] = depth - 1
-    f["n_rounds"][0] = height.max() + 1
+    f["eparent"][:] = -1.0
+    f["eparent"][:nv] = eparent
+    f["depth"][:nv] = edepth - 1
+    f["n_rounds"][0] = eheight.max() + 1
     f["elim"][:] = -1.0
     for i in range(nv):
-        desc = sorted(range(i + 1, i + subsize[i]), key=lambda k: (height[k], k))
+        desc = sorted(e_descendants(i), key=lambda k: (eheight[k], k))
         for e, k in enumerate(desc):
-            f["elim"][e * TL + i] = k | ((depth[k] - depth[i]) << 8) | (height[k] << 16)
+            f["elim"][e * TL + i] = k | ((edepth[k] - edepth[i]) << 8) | (eheight[k] << 16)
 
     nu = len(raw.actuators)
     if not 1 <= nu <= nv:
@@ -247,7 +314,10 @@ def compile_tree(raw: RawModel, overrides=None, base: "TreeModel" = None) -> Tre
         if f["act"][d] >= 0:
             raise ValueError("two motors on joint %r" % act.joint)
         f["act"][d] = a
-        f["gear"][d] = act.gear
+        # motor: gear * clip(ctrl).  Position servo (MJCF <position kp>): gear * kp * (clip(ctrl) - gear * q) - the ctrl
+        # part through an effective gear, the bias as a joint stiffness gear^2 kp about 0
+        f["gear"][d] = act.gear * (act.kp if act.kp > 0 else 1.0)
+        f["kpg"][d] = act.gear * act.gear * act.kp
         f["ctrl_lo"][d], f["ctrl_hi"][d] = act.ctrlrange
         ctrl_lo[a], ctrl_hi[a] = act.ctrlrange
 
@@ -306,31 +376,74 @@ def compile_tree(raw: RawModel, overrides=None, base: "TreeModel" = None) -> Tre
                     c, half = 0.5 * (a + e), float(np.ravel(size)[1])
                     a, e = c - half * u, c + half * u
                 points += [(i, g, e, u, radius), (i, g, a, u, radius)]
-    if raw.plane is not None and points:
-        if len(points) > TREE_MAX_SPHERES:
-            raise ValueError("tree kernel supports %d contact points (a capsule counts two)" % TREE_MAX_SPHERES)
+    if raw.plane is None:
+        points = []
+    if len(points) + len(pair_geoms) > TREE_MAX_SPHERES:
+        raise ValueError("tree kernel supports %d contact points (a capsule on the plane counts two, a geom-geom pair one)"
+                         % TREE_MAX_SPHERES)
+    if raw.plane is not None:
         n = np.asarray(raw.plane.normal, float)
         n = n / np.linalg.norm(n)
         f["plane_n"][:] = n
         f["plane_d"][0] = n @ np.asarray(raw.plane.pos, float)
-        f["n_sphere"][0] = len(points)
-        for s, (i, g, pos, u, radius) in enumerate(points):
-            li = link_of_body[i]
-            rec = f["spheres"][s * SPH_STRIDE:(s + 1) * SPH_STRIDE]
-            rec[0] = li
-            rec[1:4] = p0[i] + R0[i] @ pos - origin[li]
-            rec[4] = radius
-            rec[5] = max(raw.plane.margin, g.margin)            # MuJoCo: max of the two geom margins
-            rec[6] = 0.0 + (base.body_invweight0[i] if base is not None else body_iw[i])     # the world body weighs 0
-            condim = max(int(g.condim), int(raw.plane.condim))
-            if condim not in (1, 3):
-                raise NotImplementedError("contacts are condim 1 (frictionless) or 3 (pyramidal cone), got %d" % condim)
-            mu_g = overrides.get("geom_friction", {}).get(g.name)
-            mu_g = float(np.ravel(mu_g)[0]) if mu_g is not None else g.friction
-            rec[7] = max(mu_g, raw.plane.friction) if condim == 3 else 0.0
-            rec[8:11] = R0[i] @ u
-            rec[11] = depth[li] - 1                             # strict ancestors of the point's link
-        f["any_friction"][0] = 1.0 if any(f["spheres"][s * SPH_STRIDE + 7] > 0 for s in range(len(points))) else 0.0
+    f["n_sphere"][0] = len(points) + len(pair_geoms)
+
+    def geom_mu(g):
+        mu_g = overrides.get("geom_friction", {}).get(g.name)
+        return float(np.ravel(mu_g)[0]) if mu_g is not None else g.friction
+
+    def body_w(i):
+        return base.body_invweight0[i] if base is not None else body_iw[i]
+
+    for s, (i, g, pos, u, radius) in enumerate(points):
+        li = link_of_body[i]
+        rec = f["spheres"][s * SPH_STRIDE:(s + 1) * SPH_STRIDE]
+        rec[0] = li
+        rec[1:4] = p0[i] + R0[i] @ pos - origin[li]
+        rec[4] = radius
+        rec[5] = max(raw.plane.margin, g.margin)            # MuJoCo: max of the two geom margins
+        rec[6] = 0.0 + body_w(i)                            # the world body weighs 0
+        condim = max(int(g.condim), int(raw.plane.condim))
+        if condim not in (1, 3):
+            raise NotImplementedError("contacts are condim 1 (frictionless) or 3 (pyramidal cone), got %d" % condim)
+        rec[7] = max(geom_mu(g), raw.plane.friction) if condim == 3 else 0.0
+        rec[8:11] = R0[i] @ u
+        rec[11] = edepth[li] - 1                            # strict ancestors of the point's link (elimination tree)
+        rec[13] = -1.0
+    # geom-geom pairs: both geoms as segments (start, vector; a sphere has a zero vector) in their links' frames; the
+    # record is anchored at the manipulator's link, whose elimination path contains the object's links
+    for s, ((ia, ga), (ib, gb)) in enumerate(pair_geoms, start=len(points)):
+        rec = f["spheres"][s * SPH_STRIDE:(s + 1) * SPH_STRIDE]
+        la, lb = link_of_body[ia], link_of_body[ib]
+
+        def seg(i, g, li):
+            size = overrides.get("geom_size", {}).get(g.name)
+            r = float(np.ravel(size)[0]) if size is not None else g.radius
+            a = np.asarray(g.a, float)
+            if g.type == GEOM_SPHERE:
+                return p0[i] + R0[i] @ a - origin[li], np.zeros(3), r
+            e = np.asarray(g.b, float)
+            if size is not None:
+                u, c, half = (e - a) / np.linalg.norm(e - a), 0.5 * (a + e), float(np.ravel(size)[1])
+                a, e = c - half * u, c + half * u
+            return p0[i] + R0[i] @ a - origin[li], R0[i] @ (e - a), r
+
+        a0, da, ra = seg(ia, ga, la)
+        b0, db, rb = seg(ib, gb, lb)
+        condim = max(int(ga.condim), int(gb.condim))
+        if condim not in (1, 3):
+            raise NotImplementedError("contacts are condim 1 (frictionless) or 3 (pyramidal cone), got %d" % condim)
+        rec[0], rec[1:4], rec[4] = la, a0, ra
+        rec[5] = max(ga.margin, gb.margin)
+        rec[6] = body_w(ia) + body_w(ib)
+        rec[7] = max(geom_mu(ga), geom_mu(gb)) if condim == 3 else 0.0
+        rec[8:11] = da
+        rec[11] = edepth[la] - 1
+        rec[12] = 1.0
+        rec[13], rec[14:17], rec[17], rec[18:21] = lb, b0, rb, db
+    nsp = len(points) + len(pair_geoms)
+    f["any_friction"][0] = 1.0 if (any(f["spheres"][s * SPH_STRIDE + 7] > 0 for s in range(nsp)) or pair_geoms
+                                   or any(f["kpg"] != 0) or raw.task == TASK_ORIENT) else 0.0
 
     def sol_set(prefix, solref, solimp):
         tc, dr = solref
@@ -356,8 +469,10 @@ def compile_tree(raw: RawModel, overrides=None, base: "TreeModel" = None) -> Tre
     f["gravity"][:] = raw.gravity
     f["nu"][0], f["task"][0], f["ctrl_cost"][0], f["obs_skip"][0] = nu, raw.task, raw.ctrl_cost, raw.obs_skip
     f["density"][0], f["viscosity"][0] = raw.density, raw.viscosity
-    if raw.task not in (TASK_REACH, TASK_FORWARD) or not 0 <= raw.obs_skip < nv:
+    if raw.task not in (TASK_REACH, TASK_FORWARD, TASK_ORIENT) or not 0 <= raw.obs_skip < nv:
         raise ValueError("unknown task / observation layout")
+    f["site_axis"][:] = R0[sb] @ np.asarray(raw.site_axis, float)
+    f["target_dir"][:] = raw.target_dir
     d_obs = 2 * nv - raw.obs_skip if raw.task == TASK_FORWARD else 2 * nv + 6
     if base is not None:            # run-time edit: MuJoCo keeps the constants mj_setConst computed at load time
         f["dof_invweight0"][:] = base.field("dof_invweight0")
@@ -366,5 +481,5 @@ def compile_tree(raw: RawModel, overrides=None, base: "TreeModel" = None) -> Tre
     assert blob.size == TREE_BLOB_LEN
     return TreeModel(blob=blob, nv=nv, nu=nu, d_obs=d_obs, timestep=raw.timestep, frame_skip=raw.frame_skip,
                      target_default=np.asarray(raw.target_pos, float), ctrl_lo=ctrl_lo, ctrl_hi=ctrl_hi, parent=parent,
-                     task=int(raw.task), obs_skip=int(raw.obs_skip), max_path=int(depth.max()),
+                     task=int(raw.task), obs_skip=int(raw.obs_skip), max_path=int(edepth.max()),
                      body_mass=mass, body_inertia=inert, body_invweight0=body_iw, dof_invweight0=dof_iw, link_of_body=link_of_body)

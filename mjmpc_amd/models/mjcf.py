@@ -11,7 +11,9 @@ Enough for the three models the reference vendors (mjmpc/envs/assets/xml/sawyer.
 * sphere and capsule geoms (``fromto``, or ``size pos`` with ``quat`` / ``axisangle``), ``density``, ``margin``,
   ``friction``, ``condim``, ``contype`` / ``conaffinity`` (what collides is decided against the one world plane,
   with MuJoCo's rule), ``solref`` / ``solimp`` (one set per model);
-* one world ``<geom type="plane">``, world and body ``<site>``s, ``<motor joint gear ctrlrange ctrllimited>``.
+* one world ``<geom type="plane">``, world and body ``<site>``s, ``<motor joint gear ctrlrange ctrllimited>`` and
+  ``<position joint kp ctrlrange ctrllimited>`` actuators, ``<contact><pair geom1 geom2>`` (sphere / capsule geoms of a
+  manipulator against those of one free object).
 
 Anything that would change the simulation and is not modelled raises ValueError, so that a model is never silently
 simulated wrongly; purely visual elements (asset, light, camera, material, rgba ...) are skipped.
@@ -85,8 +87,8 @@ def load_mjcf(path, hand_site="finger", target_site="target", frame_skip=2, task
     """``task=TASK_FORWARD`` (with ``ctrl_cost`` / ``obs_skip``) loads a locomotion model: no tracked site is needed."""
     root = ET.parse(path).getroot()
     for e in root:
-        if e.tag == "contact" and len(e) == 0:
-            continue                    # an empty <contact> section (sawyer.xml:94-99 holds comments only)
+        if e.tag == "contact" and all(c.tag == "pair" for c in e):
+            continue                    # empty (sawyer.xml:94-99 holds comments only) or <pair geom1 geom2> entries, read below
         if e.tag not in _TOP_TAGS:
             raise ValueError("unsupported element <%s>" % e.tag)
     comp = root.find("compiler")
@@ -257,10 +259,16 @@ def load_mjcf(path, hand_site="finger", target_site="target", frame_skip=2, task
     act = root.find("actuator")
     for m in (list(act) if act is not None else []):
         ma = lambda k, d=None: dfl.attr("motor", m, None, k, d)         # noqa: E731
-        if m.tag != "motor" or ma("ctrllimited", "false") != "true":
-            raise ValueError("only ctrllimited <motor> actuators are supported")
+        if m.tag not in ("motor", "position") or ma("ctrllimited", "false") != "true":
+            raise ValueError("only ctrllimited <motor> / <position> actuators are supported")
         gear = _floats(ma("gear"), None, [1.0])[0]
-        acts.append(RawActuator(m.get("joint"), gear, _floats(ma("ctrlrange"), 2)))
+        kp = float(m.get("kp", "1")) if m.tag == "position" else 0.0       # MJCF <position>: kp defaults to 1
+        acts.append(RawActuator(m.get("joint"), gear, _floats(ma("ctrlrange"), 2), kp=kp))
+    # explicit geom-geom collision candidates (<contact><pair geom1=... geom2=...>): manipulator geom first, object second
+    pairs = []
+    con = root.find("contact")
+    for pr in (list(con) if con is not None else []):
+        pairs.append((pr.get("geom1"), pr.get("geom2")))
     if task == TASK_REACH:
         if hand_site not in sites or sites[hand_site][0] < 0:
             raise ValueError("tracked site %r must be attached to a body" % hand_site)
@@ -271,4 +279,4 @@ def load_mjcf(path, hand_site="finger", target_site="target", frame_skip=2, task
     return RawModel(bodies=bodies, actuators=acts, site_body=site_body, site_pos=site_pos, target_pos=target, plane=plane,
                     timestep=timestep, frame_skip=frame_skip, gravity=gravity, solref=solref, solimp=full_solimp(solimp),
                     solref_limit=lsolref, solimp_limit=full_solimp(lsolimp), density=density, viscosity=viscosity,
-                    task=task, ctrl_cost=ctrl_cost, obs_skip=obs_skip)
+                    task=task, ctrl_cost=ctrl_cost, obs_skip=obs_skip, pairs=pairs)

@@ -37,9 +37,13 @@ JOINT_SLIDE = 2
 MJ20_CAPSULE_CAP = 1.0
 TASK_REACH = 0              # reward -(|h-g|_1 + 5 |h-g|_2), obs [qpos, qvel, h, h-g]      (reacher_env.py:29-47)
 TASK_FORWARD = 1            # reward (x' - x)/dt - c |a|^2, obs [qpos[skip:], qvel]         (swimmer.py, half_cheetah.py)
+TASK_ORIENT = 2             # in-hand reorientation, the shape of pen-v0's reward (examples/configs/hand/pen-v0.yml:8): the
+                            # tracked site rides on the object; reward -|h-g|_2 + d.d*, d = the object's axis (site_axis
+                            # carried by the site's body), d* = target_dir; obs as TASK_REACH
 BODY_STRIDE = 20
 GEOM_STRIDE = 16
-ACT_STRIDE = 4
+ACT_STRIDE = 5
+PAIR_STRIDE = 2
 
 
 @dataclass
@@ -84,6 +88,8 @@ class RawActuator:
     joint: str
     gear: float
     ctrlrange: Sequence[float]
+    kp: float = 0.0                         # 0: motor, force = gear * clip(ctrl).  > 0: MJCF <position kp=...>, a servo -
+                                            # force = kp * (clip(ctrl) - gear * q), applied through the gear
 
 
 @dataclass
@@ -116,6 +122,11 @@ class RawModel:
     ctrl_cost: float = 0.0                          # TASK_FORWARD: weight of |a|^2
     obs_skip: int = 0                               # TASK_FORWARD: leading qpos entries left out of the observation
     capsule_cap_factor: float = MJ20_CAPSULE_CAP    # capsule volume = pi r^2 h + factor * pi r^3 (see MJ20_CAPSULE_CAP)
+    # geom-geom collision candidates, as names (geom on the manipulator, geom on the object): sphere / capsule pairs, one
+    # contact point each (closest points of the two segments); friction / condim / margin = the larger of the two geoms'
+    pairs: List[Sequence[str]] = field(default_factory=list)
+    site_axis: Sequence[float] = (0.0, 0.0, 0.0)    # TASK_ORIENT: the object's axis in the frame of the site's body
+    target_dir: Sequence[float] = (0.0, 0.0, 1.0)   # TASK_ORIENT: the direction that axis should point in (world)
 
     # ------------------------------------------------------------------
     @property
@@ -154,6 +165,9 @@ class RawModel:
         h[30], h[31] = self.density, self.viscosity
         h[32], h[33], h[34] = self.task, self.ctrl_cost, self.obs_skip
         h[37] = self.capsule_cap_factor
+        h[38] = len(self.pairs)
+        h[47:50] = self.site_axis
+        h[50:53] = self.target_dir
         h[40:42] = self.solref if self.solref_limit is None else self.solref_limit
         h[42:47] = self.solimp if self.solimp_limit is None else self.solimp_limit
         out = [h]
@@ -190,5 +204,11 @@ class RawModel:
             r[0] = self.dof_of_joint(a.joint)
             r[1] = a.gear
             r[2:4] = a.ctrlrange
+            r[4] = a.kp
             out.append(r)
+        names = [g.name for _, g in geoms]
+        for ga, gb in self.pairs:
+            if names.count(ga) != 1 or names.count(gb) != 1:
+                raise ValueError("collision pair (%r, %r) must name one geom each" % (ga, gb))
+            out.append(np.array([names.index(ga), names.index(gb)], float))
         return np.concatenate(out).astype(np.float64)

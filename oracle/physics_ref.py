@@ -219,10 +219,11 @@ class RefArm:
     def step(self, q, v, ctrl):
         """One mj_step.  Returns (q', v', site position seen by that step, diag)."""
         q, v = _c(q).copy(), _c(v).copy()
-        site = np.zeros(3)
+        site = np.zeros(6)              # the site, then the object's axis (task 2) in the world
         diag = np.zeros(1 + self.nv)
         self._L.or_step(self._h, _p(q), _p(v), _p(_c(ctrl)), _p(site), _p(diag))
-        return q, v, site, diag
+        self.last_axis = site[3:].copy()
+        return q, v, site[:3].copy(), diag
 
     def env_step(self, q, v, u, target):
         q, v = _c(q).copy(), _c(v).copy()

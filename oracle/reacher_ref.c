@@ -39,13 +39,15 @@
 #define MAXV 32
 #define MAXG 96
 #define MAXS 16            /* collision spheres (a colliding capsule is its two end spheres) */
-#define MAXC (2 * MAXV + 4 * MAXS)
+#define MAXC (2 * MAXV + 4 * MAXS + 4 * 16)
 #define MJ_MINVAL 1e-15    /* MuJoCo mjMINVAL */
 
 #define HEADER_LEN 56
 #define BODY_STRIDE 20
 #define GEOM_STRIDE 16
-#define ACT_STRIDE 4
+#define ACT_STRIDE 5
+#define PAIR_STRIDE 2
+#define MAXP 16            /* geom-geom collision pairs */
 
 typedef struct {
     int nbody, nv, nu;
@@ -67,7 +69,7 @@ typedef struct {
     double mass[MAXB], ipos[MAXB][3], inertia[MAXB][9];  /* tensor about the COM, body frame */
     /* motors */
     int act_dof[MAXV];
-    double gear[MAXV], ctrl_lo[MAXV], ctrl_hi[MAXV];
+    double gear[MAXV], ctrl_lo[MAXV], ctrl_hi[MAXV], kp[MAXV];   /* kp > 0: position servo (MJCF <position>) */
     /* site + target */
     int site_body;
     double site_pos[3], target_default[3];
@@ -77,6 +79,11 @@ typedef struct {
     int sph_body[MAXS];
     double sph_pos[MAXS][3], sph_r[MAXS], sph_margin[MAXS];
     double sph_mu[MAXS], sph_axis[MAXS][3];   /* friction (0: frictionless row) and capsule axis in the body frame */
+    /* geom-geom pairs: two segments (a sphere is a segment of length 0) with radii, on two bodies */
+    int npair, pair_body[MAXP][2];
+    double pair_a[MAXP][2][3], pair_d[MAXP][2][3], pair_r[MAXP][2], pair_margin[MAXP], pair_mu[MAXP];
+    /* TASK 2 (in-hand reorientation): object axis in the site body's frame, direction it should point in */
+    double site_axis[3], target_dir[3];
     /* joint-limit rows may carry their own solver parameters (MJCF solreflimit / solimplimit) */
     double solref_l[2], solimp_l[5];
     /* medium: MuJoCo's inertia-box fluid model; principal frame / equivalent box of every body */
@@ -354,8 +361,9 @@ static void set_const(OrModel *m);
 
 OrModel *or_model_compile(const double *f, int n) {
     OrModel *m = (OrModel *)calloc(1, sizeof(OrModel));
-    int nb = (int)f[0], ng = (int)f[1], nu = (int)f[2];
-    if (n != HEADER_LEN + nb * BODY_STRIDE + ng * GEOM_STRIDE + nu * ACT_STRIDE || nb + 1 > MAXB || ng > MAXG) {
+    int nb = (int)f[0], ng = (int)f[1], nu = (int)f[2], np_ = (int)f[38];
+    if (n != HEADER_LEN + nb * BODY_STRIDE + ng * GEOM_STRIDE + nu * ACT_STRIDE + np_ * PAIR_STRIDE || nb + 1 > MAXB ||
+        ng > MAXG || np_ > MAXP) {
         free(m);
         return NULL;
     }
@@ -382,6 +390,8 @@ OrModel *or_model_compile(const double *f, int n) {
     int plane_condim = (int)f[36];
     memcpy(m->solref_l, f + 40, 16);
     memcpy(m->solimp_l, f + 42, 40);
+    memcpy(m->site_axis, f + 47, 24);
+    memcpy(m->target_dir, f + 50, 24);
     m->dofid[0] = -1;
     int nv = 0;
     for (int b = 1; b <= nb; b++) {
@@ -461,6 +471,27 @@ OrModel *or_model_compile(const double *f, int n) {
         m->gear[a] = a0[a * ACT_STRIDE + 1];
         m->ctrl_lo[a] = a0[a * ACT_STRIDE + 2];
         m->ctrl_hi[a] = a0[a * ACT_STRIDE + 3];
+        m->kp[a] = a0[a * ACT_STRIDE + 4];
+    }
+    /* geom-geom pairs: every geom is a segment (from, to - from) with a radius; friction / condim / margin of a
+     * contact = the larger of the two geoms' (MuJoCo mj_contactParam with equal priorities) */
+    const double *p0 = a0 + nu * ACT_STRIDE;
+    m->npair = np_;
+    for (int k = 0; k < np_; k++) {
+        double mu = 0, margin = 0;
+        int condim = 1;
+        for (int e = 0; e < 2; e++) {
+            const double *r = g0 + (int)p0[k * PAIR_STRIDE + e] * GEOM_STRIDE;
+            m->pair_body[k][e] = (int)r[0] + 1;
+            memcpy(m->pair_a[k][e], r + 3, 24);
+            for (int i = 0; i < 3; i++) m->pair_d[k][e][i] = (int)r[1] == 1 ? 0.0 : r[6 + i] - r[3 + i];
+            m->pair_r[k][e] = r[2];
+            if (r[12] > mu) mu = r[12];
+            if (r[11] > margin) margin = r[11];
+            if ((int)r[13] > condim) condim = (int)r[13];
+        }
+        m->pair_margin[k] = margin;
+        m->pair_mu[k] = condim >= 3 ? mu : 0.0;
     }
     set_const(m);
     return m;
@@ -701,6 +732,83 @@ static void solve_rows(OrModel *m, int nv, const double *M, const double *fs, in
     }
 }
 
+/* closest points of two segments p1 + s d1, p2 + t d2, s, t in [0, 1] (a sphere is a segment of length 0); parallel
+ * segments take s = 0 */
+static double clamp01(double x) { return x < 0 ? 0 : (x > 1 ? 1 : x); }
+static void seg_seg(const double *p1, const double *d1, const double *p2, const double *d2, double *s, double *t) {
+    double r[3] = {p1[0] - p2[0], p1[1] - p2[1], p1[2] - p2[2]};
+    double a = dot3(d1, d1), e = dot3(d2, d2), f = dot3(d2, r);
+    const double EPS = 1e-18;
+    if (a <= EPS && e <= EPS) { *s = *t = 0; return; }
+    if (a <= EPS) { *s = 0; *t = clamp01(f / e); return; }
+    double c = dot3(d1, r);
+    if (e <= EPS) { *t = 0; *s = clamp01(-c / a); return; }
+    double b = dot3(d1, d2), denom = a * e - b * b;
+    *s = denom > 1e-12 * a * e ? clamp01((b * f - c * e) / denom) : 0.0;
+    *t = (b * (*s) + f) / e;
+    if (*t < 0) { *t = 0; *s = clamp01(-c / a); }
+    else if (*t > 1) { *t = 1; *s = clamp01((b - c) / a); }
+}
+
+/* constraint rows of ONE contact (MuJoCo mj_instantiateContact + mj_makeConstraint for a contact): normal n (from body B
+ * to body A; B = 0 is the world), contact point cp, signed distance dist, friction mu (0: condim 1, one frictionless
+ * row; else condim 3, MuJoCo's default pyramidal cone: rows Jn +- mu Jt_k in the frame mju_makeFrame builds from the
+ * normal and - if it is not zero - the axis hint; diagApprox = tran (1 + mu^2), all four rows R = 2 mu^2 R_first).
+ * J = the relative velocity of the two bodies' material points at cp. */
+static void contact_rows(const OrModel *m, const Kin *k, const double *v, const double *n, const double *cp, int bA, int bB,
+                         double dist, double margin, double mu, const double *axis_hint, double (*J)[MAXV], double *aref,
+                         double *D, int *pnc) {
+    int nv = m->nv, nc = *pnc;
+    double Jp[3 * MAXV], Jq[3 * MAXV];
+    jacobian(m, k, bA, cp, Jp, NULL);
+    if (bB > 0) {
+        jacobian(m, k, bB, cp, Jq, NULL);
+        for (int i = 0; i < 3 * nv; i++) Jp[i] -= Jq[i];
+    }
+    double tran = m->body_invweight0[bA] + m->body_invweight0[bB];
+    if (mu <= 0) {
+        double jv = 0;
+        for (int j = 0; j < nv; j++) {
+            J[nc][j] = n[0] * Jp[j] + n[1] * Jp[nv + j] + n[2] * Jp[2 * nv + j];
+            jv += J[nc][j] * v[j];
+        }
+        row_params(m, dist, margin, tran, jv, &D[nc], &aref[nc]);
+        nc++;
+    } else {
+        double t1[3], t2[3], ax[3] = {axis_hint[0], axis_hint[1], axis_hint[2]};
+        if (sqrt(dot3(ax, ax)) < 0.5) {
+            ax[0] = 0; ax[1] = 0; ax[2] = 0;
+            if (n[1] < 0.5 && n[1] > -0.5) ax[1] = 1; else ax[2] = 1;
+        }
+        double pr = dot3(n, ax), nr = 0;
+        for (int i = 0; i < 3; i++) { t1[i] = ax[i] - pr * n[i]; nr += t1[i] * t1[i]; }
+        nr = sqrt(nr);
+        if (nr < MJ_MINVAL) { t1[0] = 1; t1[1] = 0; t1[2] = 0; }
+        else for (int i = 0; i < 3; i++) t1[i] /= nr;
+        cross3(n, t1, t2);
+        double D0, a0;
+        row_params(m, dist, margin, tran * (1 + mu * mu), 0.0, &D0, &a0);
+        double Rpy = 2 * mu * mu / D0;
+        for (int kk = 0; kk < 2; kk++) {
+            const double *tt = kk == 0 ? t1 : t2;
+            for (int sg = 1; sg >= -1; sg -= 2) {
+                double jvr = 0, Dd, ar;
+                for (int j = 0; j < nv; j++) {
+                    double jn = n[0] * Jp[j] + n[1] * Jp[nv + j] + n[2] * Jp[2 * nv + j];
+                    double jt = tt[0] * Jp[j] + tt[1] * Jp[nv + j] + tt[2] * Jp[2 * nv + j];
+                    J[nc][j] = jn + sg * mu * jt;
+                    jvr += J[nc][j] * v[j];
+                }
+                row_params(m, dist, margin, tran * (1 + mu * mu), jvr, &Dd, &ar);
+                D[nc] = 1 / Rpy;
+                aref[nc] = ar;
+                nc++;
+            }
+        }
+    }
+    *pnc = nc;
+}
+
 /* ---------------------------------------------------------------- one mj_step */
 /* q, v updated in place; site_out (optional) = finger site position computed from the q the step
  * STARTED with (MuJoCo runs kinematics before integrating and MjSim.step() does not call
@@ -710,10 +818,11 @@ void or_step(OrModel *m, double *q, double *v, const double *ctrl, double *site_
     Kin k;
     double M[MAXV * MAXV], bias[MAXV], fs[MAXV];
     kinematics(m, q, &k);
-    if (site_out) {
+    if (site_out) {                 /* [0:3] the site, [3:6] the object's axis (task 2) in the world */
         double t[3];
         matvec3(k.xmat[m->site_body], m->site_pos, t);
         for (int i = 0; i < 3; i++) site_out[i] = k.xpos[m->site_body][i] + t[i];
+        matvec3(k.xmat[m->site_body], m->site_axis, site_out + 3);
     }
     mass_matrix(m, &k, M);
     rne(m, &k, v, NULL, bias);
@@ -764,7 +873,8 @@ void or_step(OrModel *m, double *q, double *v, const double *ctrl, double *site_
         double u = ctrl[a];
         if (u < m->ctrl_lo[a]) u = m->ctrl_lo[a];
         if (u > m->ctrl_hi[a]) u = m->ctrl_hi[a];
-        fs[m->act_dof[a]] += m->gear[a] * u;
+        /* motor: gear * ctrl; position servo (MJCF <position kp>): gain kp, bias -kp * length, length = gear * q */
+        fs[m->act_dof[a]] += m->kp[a] > 0 ? m->gear[a] * m->kp[a] * (u - m->gear[a] * q[m->act_dof[a]]) : m->gear[a] * u;
     }
     /* constraint rows: MuJoCo mj_instantiateLimit (dist < margin, jnt margin = 0) */
     double J[MAXC][MAXV], aref[MAXC], D[MAXC], force[MAXC], qacc[MAXV];
@@ -781,7 +891,7 @@ void or_step(OrModel *m, double *q, double *v, const double *ctrl, double *site_
             }
         }
     }
-    /* plane-sphere contact, condim 1 (mjc_PlaneSphere + mj_instantiateContact):
+    /* plane-sphere contacts (mjc_PlaneSphere / the two ends mjc_PlaneCapsule tests + mj_instantiateContact):
      * margin = max of the two geom margins, gap = 0, included when dist < margin */
     for (int s = 0; m->has_plane && s < m->nsphere; s++) {
         int b = m->sph_body[s];
@@ -791,53 +901,42 @@ void or_step(OrModel *m, double *q, double *v, const double *ctrl, double *site_
         double dist = dot3(c, m->plane_n) - m->sph_r[s];
         double margin = m->plane_margin > m->sph_margin[s] ? m->plane_margin : m->sph_margin[s];
         if (dist < margin) {
-            double cp[3], Jp[3 * MAXV], jv = 0, tran = m->body_invweight0[0] + m->body_invweight0[b];
-            const double *n = m->plane_n;
-            for (int i = 0; i < 3; i++)
-                cp[i] = k.xpos[b][i] + t[i] - n[i] * (m->sph_r[s] + 0.5 * dist);
-            jacobian(m, &k, b, cp, Jp, NULL);
-            if (m->sph_mu[s] <= 0) {            /* condim 1: one frictionless row */
-                for (int j = 0; j < nv; j++) {
-                    J[nc][j] = n[0] * Jp[j] + n[1] * Jp[nv + j] + n[2] * Jp[2 * nv + j];
-                    jv += J[nc][j] * v[j];
-                }
-                row_params(m, dist, margin, tran, jv, &D[nc], &aref[nc]);
-                nc++;
-            } else {
-                /* condim 3, pyramidal cone (MuJoCo's default): tangent frame = mju_makeFrame(normal, capsule axis or
-                 * nothing), rows Jn +- mu Jt_k; diagApprox = tran (1 + mu^2), all four rows share R = 2 mu^2 R_first */
-                double mu = m->sph_mu[s], t1[3], t2[3], ax[3];
-                matvec3(k.xmat[b], m->sph_axis[s], ax);
-                if (sqrt(dot3(ax, ax)) < 0.5) {
-                    ax[0] = 0; ax[1] = 0; ax[2] = 0;
-                    if (n[1] < 0.5 && n[1] > -0.5) ax[1] = 1; else ax[2] = 1;
-                }
-                double pr = dot3(n, ax), nr = 0;
-                for (int i = 0; i < 3; i++) { t1[i] = ax[i] - pr * n[i]; nr += t1[i] * t1[i]; }
-                nr = sqrt(nr);
-                if (nr < MJ_MINVAL) { t1[0] = 1; t1[1] = 0; t1[2] = 0; }
-                else for (int i = 0; i < 3; i++) t1[i] /= nr;
-                cross3(n, t1, t2);
-                double D0, a0;
-                row_params(m, dist, margin, tran * (1 + mu * mu), 0.0, &D0, &a0);
-                double Rpy = 2 * mu * mu / D0;
-                for (int kk = 0; kk < 2; kk++) {
-                    const double *tt = kk == 0 ? t1 : t2;
-                    for (int sg = 1; sg >= -1; sg -= 2) {
-                        double jvr = 0, Dd, ar;
-                        for (int j = 0; j < nv; j++) {
-                            double jn = n[0] * Jp[j] + n[1] * Jp[nv + j] + n[2] * Jp[2 * nv + j];
-                            double jt = tt[0] * Jp[j] + tt[1] * Jp[nv + j] + tt[2] * Jp[2 * nv + j];
-                            J[nc][j] = jn + sg * mu * jt;
-                            jvr += J[nc][j] * v[j];
-                        }
-                        row_params(m, dist, margin, tran * (1 + mu * mu), jvr, &Dd, &ar);
-                        D[nc] = 1 / Rpy;
-                        aref[nc] = ar;
-                        nc++;
-                    }
-                }
+            double cp[3], ax[3];
+            for (int i = 0; i < 3; i++) cp[i] = k.xpos[b][i] + t[i] - m->plane_n[i] * (m->sph_r[s] + 0.5 * dist);
+            matvec3(k.xmat[b], m->sph_axis[s], ax);
+            contact_rows(m, &k, v, m->plane_n, cp, b, 0, dist, margin, m->sph_mu[s], ax, J, aref, D, &nc);
+        }
+    }
+    /* geom-geom contacts (mjc_SphereSphere / SphereCapsule / CapsuleCapsule): the closest points of the two segments,
+     * one contact; normal from the second geom to the first, contact point midway between the surfaces; the contact
+     * frame comes from the normal alone (mju_makeFrame) */
+    for (int p = 0; p < m->npair; p++) {
+        double o[2][3], d[2][3];
+        for (int e = 0; e < 2; e++) {
+            int b = m->pair_body[p][e];
+            double t[3];
+            matvec3(k.xmat[b], m->pair_a[p][e], t);
+            for (int i = 0; i < 3; i++) o[e][i] = k.xpos[b][i] + t[i];
+            matvec3(k.xmat[b], m->pair_d[p][e], d[e]);
+        }
+        double sA, sB, c1[3], c2[3], diff[3];
+        seg_seg(o[0], d[0], o[1], d[1], &sA, &sB);
+        for (int i = 0; i < 3; i++) {
+            c1[i] = o[0][i] + sA * d[0][i];
+            c2[i] = o[1][i] + sB * d[1][i];
+            diff[i] = c1[i] - c2[i];
+        }
+        double len = sqrt(dot3(diff, diff));
+        if (len < 1e-14) continue;                  /* coincident axes: no normal */
+        double dist = len - m->pair_r[p][0] - m->pair_r[p][1];
+        if (dist < m->pair_margin[p]) {
+            double n[3], cp[3], none[3] = {0, 0, 0};
+            for (int i = 0; i < 3; i++) {
+                n[i] = diff[i] / len;
+                cp[i] = c2[i] + n[i] * (m->pair_r[p][1] + 0.5 * dist);
             }
+            contact_rows(m, &k, v, n, cp, m->pair_body[p][0], m->pair_body[p][1], dist, m->pair_margin[p], m->pair_mu[p],
+                         none, J, aref, D, &nc);
         }
     }
     solve_rows(m, nv, M, fs, nc, J, aref, D, qacc, force);
@@ -884,6 +983,7 @@ int or_threads(int n) {
 int or_nv(const OrModel *m) { return m->nv; }
 int or_nbody(const OrModel *m) { return m->nbody; }
 int or_dobs(const OrModel *m) { return m->task == 1 ? 2 * m->nv - m->obs_skip : 2 * m->nv + 6; }
+int or_npair(const OrModel *m) { return m->npair; }
 void or_get_inertial(const OrModel *m, double *mass, double *ipos, double *inertia) {
     for (int b = 0; b < m->nbody; b++) {
         mass[b] = m->mass[b];
@@ -942,8 +1042,8 @@ static double env_step(OrModel *m, double *q, double *v, const double *u, const 
         }
         return (q[0] - x0) / (m->timestep * m->frame_skip) - m->ctrl_cost * c;
     }
-    double h[3] = {0, 0, 0};
-    for (int s = 0; s < m->frame_skip; s++) or_step(m, q, v, u, h, NULL);
+    double h[3] = {0, 0, 0}, h6[6];
+    for (int s = 0; s < m->frame_skip; s++) { or_step(m, q, v, u, h6, NULL); memcpy(h, h6, 24); }
     double d[3] = {h[0] - target[0], h[1] - target[1], h[2] - target[2]};
     double l1 = fabs(d[0]) + fabs(d[1]) + fabs(d[2]), l2 = sqrt(dot3(d, d));
     if (obs) {
@@ -953,6 +1053,9 @@ static double env_step(OrModel *m, double *q, double *v, const double *u, const 
         memcpy(obs + 2 * nv, h, 24);
         memcpy(obs + 2 * nv + 3, d, 24);
     }
+    /* task 2: the shape of pen-v0's reward (object to its target position, object axis to its target direction; both
+     * from the kinematics the last substep started with, like the site) */
+    if (m->task == 2) return -l2 + dot3(h6 + 3, m->target_dir);
     return -l1 - 5.0 * l2;
 }
 
@@ -988,7 +1091,7 @@ static void rollout_impl(OrModel *m, const double *qp0, const double *qv0, const
                          double *done, double *next_obs, int closed_loop) {
     int nv = m->nv, nu = m->nu, dobs = or_dobs(m);
     double h0[3] = {0, 0, 0};
-    if (m->task == 0) or_site(m, qp0, h0);
+    if (m->task != 1) or_site(m, qp0, h0);
     long calls = 0, iters = 0, fails = 0;
 #pragma omp parallel for schedule(static) reduction(+ : calls, iters, fails)
     for (long b = 0; b < P; b++) {

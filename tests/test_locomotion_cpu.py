@@ -174,7 +174,7 @@ def test_cheetah_settles_on_its_feet_and_the_tree_compiler_reads_its_contacts():
     raw = half_cheetah_raw()
     m = compile_tree(raw)
     assert m.field("n_sphere")[0] == 16 and m.field("any_friction")[0] == 1 and m.max_path == 6
-    sph = m.field("spheres").reshape(16, 12)
+    sph = m.field("spheres").reshape(16, 24)
     assert np.allclose(sph[:, 7], 0.4) and np.allclose(sph[:, 4], 0.046) and np.allclose(np.linalg.norm(sph[:, 8:11], axis=1), 1)
     assert list(m.parent) == [-1, 0, 1, 2, 3, 4, 2, 6, 7]
     ref = RefArm(raw.to_flat())

@@ -1,0 +1,97 @@
+"""GPU parity of the tree kernel's geom-geom contacts, position servos, elimination tree and reorientation task against
+the FP64 C oracle, on the synthetic pen-in-hand model (mjmpc_amd/models/pen_hand.py: the work of pen-v0, reference
+examples/configs/hand/pen-v0.yml:8 - a 6-dof object on a 24-dof hand, capsule-capsule contacts with friction cones).
+Tolerance: f64 costs and observations at 1e-9 (SURVEY 8d's gate) over short rollouts; over long ones the contact
+dynamics amplify rounding like the cheetah's (stated per test)."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def pen():
+    from mjmpc_amd.envs.tree_engine import TreeRolloutEngine
+    from mjmpc_amd.models.pen_hand import holding_state, pen_hand_raw
+    from oracle.physics_ref import RefArm
+    raw = pen_hand_raw()
+    return raw, TreeRolloutEngine(raw, dtype="f64"), RefArm(raw.to_flat()), holding_state()
+
+
+def _noise(P, H, A, seed, scale):
+    rs = np.random.RandomState(seed)
+    eps = scale * rs.standard_normal((P, H, A))
+    for t in range(2, H):
+        eps[:, t] = 0.25 * eps[:, t] + 0.8 * eps[:, t - 1]
+    return eps
+
+
+def _settled(ref, st, steps=400):
+    """Let the pen come to rest on the hand (servo targets = the start pose): a state with live geom-geom contacts."""
+    q, v = st["qp"].copy(), st["qv"].copy()
+    u = q[6:].copy()
+    for _ in range(steps):
+        q, v, _, diag = ref.step(q, v, u)
+    assert diag[0] >= 8, "the pen should be resting on the hand (contact rows: %d)" % diag[0]
+    return q, v, u
+
+
+def test_pen_hand_uses_the_elimination_tree(pen):
+    raw, eng, ref, st = pen
+    m = eng.model
+    assert m.nv == 30 and eng.d_action == 24 and m.max_path == 14          # 6 object links above the hand's 8-link paths
+    ep = m.field("eparent")[:30].astype(int)
+    assert ep[6] == 5 and list(ep[:6]) == [-1, 0, 1, 2, 3, 4]               # the hand's root hangs under the pen's last link
+    assert int(m.field("n_sphere")[0]) == 15
+
+
+@pytest.mark.parametrize("start", ["falling", "resting"])
+def test_pen_hand_f64_matches_oracle(pen, start):
+    raw, eng, ref, st = pen
+    tgt = np.array(raw.target_pos)
+    if start == "resting":
+        q0, v0, u0 = _settled(ref, st)
+    else:
+        q0, v0, u0 = st["qp"].copy(), st["qv"].copy(), st["qp"][6:].copy()
+    P, H, A = 37, 6, 24
+    mean = np.tile(u0, (H, 1))
+    noise = _noise(P, H, A, 5, 0.15)
+    eng.set_env_state(dict(qp=q0, qv=v0, target_pos=tgt))
+    obs, rew, act, done, info, nobs = eng.rollout(P, H, mean, noise, "open_loop")
+    o_obs, o_rew, o_act, _, o_nobs = ref.rollout(q0, v0, tgt, mean, noise)
+    assert np.array_equal(act, o_act)
+    np.testing.assert_allclose(rew, o_rew, rtol=1e-9, atol=1e-9)
+    np.testing.assert_allclose(nobs, o_nobs, rtol=0, atol=1e-9)
+    np.testing.assert_allclose(obs, o_obs, rtol=0, atol=1e-9)
+    assert eng.solver_failures() == 0
+
+
+def test_pen_hand_contacts_hold_the_pen(pen):
+    """The kernel's own rollout keeps the pen on the hand: mean-only rollout of 0.5 s from the resting state."""
+    raw, eng, ref, st = pen
+    q0, v0, u0 = _settled(ref, st)
+    H = 50
+    eng.set_env_state(dict(qp=q0, qv=v0, target_pos=np.array(raw.target_pos)))
+    obs, rew, act, done, info, nobs = eng.rollout(1, H, np.tile(u0, (H, 1)), None, "open_loop")
+    z = nobs[0, :, 2]                       # OBJTz: the pen's height relative to its qpos0
+    assert np.all(z > q0[2] - 0.004), "the pen sank through the fingers: %s" % z[-5:]
+    assert eng.solver_failures() == 0
+
+
+def test_pen_hand_one_step_from_random_states(pen):
+    """One env step from 64 random states around the resting pose (different contact sets): 1e-9."""
+    raw, eng, ref, st = pen
+    q0, v0, u0 = _settled(ref, st)
+    rs = np.random.RandomState(11)
+    tgt = np.array(raw.target_pos)
+    worst = 0.0
+    for k in range(64):
+        q = q0 + np.concatenate([0.004 * rs.standard_normal(3), 0.15 * rs.standard_normal(3), 0.1 * rs.standard_normal(24)])
+        v = np.concatenate([0.1 * rs.standard_normal(3), 1.0 * rs.standard_normal(3), 0.5 * rs.standard_normal(24)])
+        u = u0 + 0.2 * rs.standard_normal(24)
+        eng.set_env_state(dict(qp=q, qv=v, target_pos=tgt))
+        _, rew, _, _, _, nobs = eng.rollout(1, 1, u[None], None, "open_loop")
+        q1, v1, r1, o1 = ref.env_step(q, v, u, tgt)
+        worst = max(worst, np.abs(nobs[0, 0] - o1).max() / max(1.0, np.abs(o1).max()), abs(rew[0, 0] - r1))
+    assert worst < 1e-9, worst
+    assert eng.solver_failures() == 0
