@@ -106,12 +106,15 @@ constexpr int a_row2(int DP, int NS, int NJ, int PL) { return a_misc(DP, NS, NJ,
 // 32-entry rows do not fit the register file; the lean instantiation runs the large launches, where the second row area
 // would cost a resident workgroup per CU: 65536 x 64 on the hand 77 -> 129 ms - as it would in the f32 launches with 16
 // lanes per particle, which are the large ones: 32768 x 32 on the cheetah 18 -> 35 ms)
-constexpr bool merge_factor(int DP, bool fric, int scalar_bytes, int PL) {
-    return fric && DP <= 16 && !(scalar_bytes == 4 && PL == 16);
+// (DN > 0: 16-lane particles factor densely in registers - see dense_factor - and have nothing to merge)
+constexpr bool merge_factor(int DP, bool fric, int scalar_bytes, int PL, int DN = 0) {
+    return DN == 0 && fric && DP <= 16 && !(scalar_bytes == 4 && PL == 16);
 }
-constexpr int a_len(int DP, int NS, int NJ, int PL, int scalar_bytes) {
-    return a_row2(DP, NS, NJ, PL) + (merge_factor(DP, NJ == 3, scalar_bytes, PL) ? row_stride(DP) * PL : 0);
+constexpr int TILE_STRIDE = 17;     // the dense 16 x 16 tile of a 16-lane particle (odd stride: conflict-free columns)
+constexpr int a_len(int DP, int NS, int NJ, int PL, int scalar_bytes, int DN = 0) {
+    return a_row2(DP, NS, NJ, PL) + (merge_factor(DP, NJ == 3, scalar_bytes, PL, DN) ? row_stride(DP) * PL : 0);
 }
+static_assert(TILE_STRIDE * 16 <= row_stride(8) * 16, "the dense tile lives in the (otherwise unused) row area");
 
 template <typename T>
 __device__ __forceinline__ void cross3(const T* a, const T* b, T* c) {
@@ -340,12 +343,111 @@ __device__ __forceinline__ T tree_solve(const T* r, T b, const int* ELIM, const 
     return b;
 }
 
+// ---- dense linear algebra of a 16-lane particle, in registers (DN > 0) -------------------------------------------
+// A particle of <= 16 dofs is ONE DPP row, and DPP's row_newbcast:K hands lane K's value to every lane of its row
+// in one move: a right-looking dense L D L' with one matrix ROW per lane needs no LDS round at all - per pivot one
+// broadcast of the pivot, one of each entry of the pivot row - where the tree-sparse factorisation through LDS pays
+// a publish / pull round trip per tree level (HalfCheetah: 7.0 k cycles per factorisation, 4.7 k per solve; dense:
+// < 1 k each).  Fill-in is free in a dense row, so the natural order (root first) does.
+template <int K>
+__device__ __forceinline__ float bcast_row(float x) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0x150 + K, 0xF, 0xF, false));
+}
+template <int K>
+__device__ __forceinline__ double bcast_row(double x) {
+    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(x), 0x150 + K, 0xF, 0xF, false);
+    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(x), 0x150 + K, 0xF, 0xF, false);
+    return __hiloint2double(hi, lo);
+}
+
+// acc += (lane K's x) * m  in ONE instruction: v_fmac with a DPP row_newbcast source (f64 DPP knows no other control).
+// The two wait states a DPP read wants after a VALU write of the same register (GFX9 hazard; the compiler cannot see
+// into the asm) are spelled out.
+template <int K>
+__device__ __forceinline__ void fma_bcast(double& acc, double x, double m) {
+    asm volatile("s_nop 1\n\tv_fmac_f64_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(x), "v"(m), "n"(K));
+}
+template <int K>
+__device__ __forceinline__ void fma_bcast(float& acc, float x, float m) {
+    asm volatile("s_nop 1\n\tv_fmac_f32_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(x), "v"(m), "n"(K));
+}
+
+// my (symmetric) row of H from its path-indexed form, through the particle's tile: tile[l][anc] = tile[anc][l] = h[c],
+// zero elsewhere.  (The tile shares the exchange area of the kinematics: cleared on every use.)
+template <int DP, int DN, int PL, typename T>
+__device__ __forceinline__ void dense_row(const T* h, const int* AT, T* TILE, int l, T* r) {
+#pragma unroll
+    for (int j = 0; j < DN; ++j) TILE[l * TILE_STRIDE + j] = T(0);
+    TSYNC();
+#pragma unroll
+    for (int c = 0; c < DP; ++c) {
+        const int an = AT[c * PL + l];
+        if (an >= 0) {
+            TILE[l * TILE_STRIDE + an] = h[c];
+            if (c > 0) TILE[an * TILE_STRIDE + l] = h[c];
+        }
+    }
+    TSYNC();
+#pragma unroll
+    for (int j = 0; j < DN; ++j) r[j] = TILE[l * TILE_STRIDE + j];
+    TSYNC();
+}
+
+// in: r[j] = H[l][j].  out: r[k] = L[l][k] for k < l, r[j] = D_l L[j][l] for j > l (what the backward solve wants),
+// dinv = 1 / D_l.  Lanes past the matrix (l >= DN, or unit rows of spare lanes) ride along untouched.
+template <int K, int DN, typename T>
+struct DenseStep {
+    static __device__ __forceinline__ void run(T* r, T& dinv, int l) {
+        const T inv = rcp_(bcast_row<K>(r[K]));
+        dinv = l == K ? inv : dinv;
+        const T lik = l > K ? r[K] * inv : T(0), nlik = -lik;
+#pragma unroll
+        for (int j = K + 1; j < DN; ++j) fma_bcast<K>(r[j], r[j], nlik);       // r[j] -= lik * (lane K's r[j])
+        r[K] = l > K ? lik : r[K];
+        if constexpr (K + 1 < DN) DenseStep<K + 1, DN, T>::run(r, dinv, l);
+    }
+};
+template <int DN, typename T>
+__device__ __forceinline__ void dense_factor(T* r, T& dinv, int l) {
+    asm volatile("" : "+v"(l));     // (the lane masks below are recomputed here, not kept - and spilled - across the substep)
+    dinv = T(1);
+    DenseStep<0, DN, T>::run(r, dinv, l);
+}
+
+// x <- (L D L')^-1 b, one entry per lane
+template <int K, int DN, typename T>
+struct DenseFwd {
+    static __device__ __forceinline__ void run(const T* r, T& x, int l) {
+        fma_bcast<K>(x, x, l > K ? -r[K] : T(0));       // x -= L[l][K] * (lane K's x, final by now)
+        if constexpr (K + 2 < DN) DenseFwd<K + 1, DN, T>::run(r, x, l);
+    }
+};
+template <int J, int DN, typename T>
+struct DenseBwd {
+    static __device__ __forceinline__ void run(const T* r, T dinv, T z, T& acc, int l) {
+        const T xj = z - dinv * acc;                    // final in lane J (its acc is complete)
+        fma_bcast<J>(acc, xj, l < J ? r[J] : T(0));
+        if constexpr (J > 1) DenseBwd<J - 1, DN, T>::run(r, dinv, z, acc, l);
+    }
+};
+template <int DN, typename T>
+__device__ __forceinline__ T dense_solve(const T* r, T dinv, T b, int l) {
+    asm volatile("" : "+v"(l));
+    T x = b;
+    DenseFwd<0, DN, T>::run(r, x, l);
+    const T z = x * dinv;                               // (backward: x_i = z_i - dinv_i sum_{j > i} r_i[j] x_j)
+    T acc = T(0);
+    DenseBwd<DN - 1, DN, T>::run(r, dinv, z, acc, l);
+    return z - dinv * acc;
+}
+
 // waves per SIMD the register allocation aims at: the lean kernels for short paths fit three (f32) / two (f64)
 // workgroups' LDS on a CU
 constexpr int min_waves(int scalar_bytes, int DP, bool fric) { return (DP <= 8 && !fric) ? (scalar_bytes == 4 ? 3 : 2) : 1; }
 
 // PL = lanes per particle: 32, or 16 for models of up to 16 dofs (four particles per wavefront, a particle = one DPP row)
-template <typename T, int DP, int NS, bool FRIC, int PL>
+// DN > 0 (with PL = 16): the dense in-register factorisation of a matrix of up to DN dofs instead of the tree-sparse one
+template <typename T, int DP, int NS, bool FRIC, int PL, int DN>
 __global__ __launch_bounds__(64 * wg_waves(DP, FRIC, sizeof(T), PL), min_waves(sizeof(T), DP, FRIC)) void tree_rollout_kernel(
     const T* __restrict__ model_all, int model_stride, const double* __restrict__ state, int state_stride, long P, long shard_size, int H,
     int A, const double* __restrict__ mean,
@@ -359,7 +461,9 @@ __global__ __launch_bounds__(64 * wg_waves(DP, FRIC, sizeof(T), PL), min_waves(s
     constexpr int NR = FRIC ? 4 : 1;        // constraint rows per contact point: Jn (+- mu Jt_k)
     typedef typename std::conditional<FRIC, unsigned long long, unsigned>::type mask_t;    // NR bits per contact point
     constexpr int A_VEC = a_vec(DP, PL), A_JC = a_jc(DP, PL), A_CS = a_cs(DP, NS, NJ, PL), A_MISC = a_misc(DP, NS, NJ, PL),
-                  A_ROW2 = a_row2(DP, NS, NJ, PL), A_LEN = a_len(DP, NS, NJ, PL, sizeof(T));
+                  A_ROW2 = a_row2(DP, NS, NJ, PL), A_LEN = a_len(DP, NS, NJ, PL, sizeof(T), DN);
+    static_assert(DN == 0 || (PL == 16 && DN <= 16 && DP <= DN), "dense rows: one particle = one DPP row");
+    constexpr bool MERGE = merge_factor(DP, FRIC, sizeof(T), PL, DN);
     constexpr int NBLOB = T_TOPO;           // the constants the loop reads; topology tables are read once, from global memory
     __shared__ __attribute__((aligned(16))) T lds[NBLOB + 1 + PPW * WG_WAVES * A_LEN];
     __shared__ int ELIM[(PL - 1) * PL];     // elimination lists
@@ -844,7 +948,7 @@ __global__ __launch_bounds__(64 * wg_waves(DP, FRIC, sizeof(T), PL), min_waves(s
             TSYNC();
             const bool any_rows = !(TREE_SKIP & 1) && __any(inst || cinst != 0);
             T qfrc_c = T(0);
-            T erow[merge_factor(DP, FRIC, sizeof(T), PL) ? DP : 1];      // factor of the Euler matrix when it was computed beside the first Newton factor
+            T erow[MERGE ? DP : 1];      // factor of the Euler matrix when it was computed beside the first Newton factor
             clk.mark(3);
             clk.count(8, 1);
             clk.count(9, __popc(cinst));
@@ -952,7 +1056,11 @@ __global__ __launch_bounds__(64 * wg_waves(DP, FRIC, sizeof(T), PL), min_waves(s
                     }
                     TSYNC();
                     clk.lap(12);
-                    if (merge_factor(DP, FRIC, sizeof(T), PL) && it == 0 && !(TREE_SKIP & 2)) {      // ... and the Euler matrix M + h B rides along (consumed in step 6)
+                    T hd[DN > 0 ? DN : 1], hdinv = T(1);        // DN > 0: my dense row of H, then of its factor
+                    if constexpr (DN > 0) {
+                        dense_row<DP, DN, PL>(hrow, AT, ROW, l, hd);
+                        dense_factor<DN>(hd, hdinv, l);
+                    } else if (MERGE && it == 0 && !(TREE_SKIP & 2)) {      // ... and the Euler matrix M + h B rides along (consumed in step 6)
 #pragma unroll
                         for (int c = 0; c < DP; ++c) erow[c] = mrow[c];
                         erow[0] += dof ? h * damping : T(0);
@@ -961,7 +1069,8 @@ __global__ __launch_bounds__(64 * wg_waves(DP, FRIC, sizeof(T), PL), min_waves(s
                         tree_factor<DP, PL>(hrow, ELIM, ROW, l, n_rounds);
                     }
                     clk.lap(13);
-                    xa = tree_solve<DP, PL>(hrow, rhs, ELIM, AT, ROW, VEC, l, n_rounds, depth, max_depth);
+                    if constexpr (DN > 0) xa = dense_solve<DN>(hd, hdinv, rhs, l);
+                    else xa = tree_solve<DP, PL>(hrow, rhs, ELIM, AT, ROW, VEC, l, n_rounds, depth, max_depth);
                     clk.lap(14);
                     // f32: a row whose residual is within rounding of zero keeps its state (as in arm_rollout.hip)
                     const T resl = sig * xa - aref;
@@ -988,7 +1097,9 @@ __global__ __launch_bounds__(64 * wg_waves(DP, FRIC, sizeof(T), PL), min_waves(s
                         }
 #endif
                         if (!__any(cact2 != cact || nflip > 1u)) {
-                            const T zl = tree_solve<DP, PL>(hrow, flip ? T(1) : T(0), ELIM, AT, ROW, VEC, l, n_rounds, depth, max_depth);
+                            T zl;
+                            if constexpr (DN > 0) zl = dense_solve<DN>(hd, hdinv, flip ? T(1) : T(0), l);
+                            else zl = tree_solve<DP, PL>(hrow, flip ? T(1) : T(0), ELIM, AT, ROW, VEC, l, n_rounds, depth, max_depth);
                             if (flip) {
                                 const T c = act2 ? D : -D;
                                 VEC[0] = c;
@@ -1062,8 +1173,14 @@ __global__ __launch_bounds__(64 * wg_waves(DP, FRIC, sizeof(T), PL), min_waves(s
             {
                 if (TREE_SKIP & 2) {
                     qacc = (tau + qfrc_c) * rcp_(mrow[0] + (dof ? h * damping : T(0)));
-                } else if (merge_factor(DP, FRIC, sizeof(T), PL) && any_rows) {
+                } else if (MERGE && any_rows) {
                     qacc = tree_solve<DP, PL>(erow, tau + qfrc_c, ELIM, AT, ROW2, VEC, l, n_rounds, depth, max_depth);
+                } else if constexpr (DN > 0) {
+                    mrow[0] += dof ? h * damping : T(0);
+                    T ed[DN > 0 ? DN : 1], edinv;
+                    dense_row<DP, DN, PL>(mrow, AT, ROW, l, ed);
+                    dense_factor<DN>(ed, edinv, l);
+                    qacc = dense_solve<DN>(ed, edinv, tau + qfrc_c, l);
                 } else {
                     mrow[0] += dof ? h * damping : T(0);
                     tree_factor<DP, PL>(mrow, ELIM, ROW, l, n_rounds);
@@ -1151,10 +1268,11 @@ hipError_t launch_tree_rollout(const T* model, int n_model_shards, int max_path,
     if (P % n_shards != 0) return hipErrorInvalidValue;
     const long shard = P / n_shards;
     const int model_stride = n_model_shards > 1 ? TREE_BLOB_LEN : 0, state_stride = n_state_shards > 1 ? TREE_STATE_LEN : 0;
-#define MJMPC_TREE_LAUNCH(DP_, NS_, FR_, PL_)                                                                         \
+#define MJMPC_TREE_LAUNCH(DP_, NS_, FR_, PL_) MJMPC_TREE_LAUNCH_D(DP_, NS_, FR_, PL_, 0)
+#define MJMPC_TREE_LAUNCH_D(DP_, NS_, FR_, PL_, DN_)                                                                  \
     {                                                                                                                 \
         constexpr int per_wg = wg_waves(DP_, FR_, sizeof(T), PL_) * (64 / PL_);                                       \
-        hipLaunchKernelGGL((tree_rollout_kernel<T, DP_, NS_, FR_, PL_>),                                              \
+        hipLaunchKernelGGL((tree_rollout_kernel<T, DP_, NS_, FR_, PL_, DN_>),                                         \
                            dim3((unsigned)((shard + per_wg - 1) / per_wg), (unsigned)n_shards),                       \
                            dim3(64 * wg_waves(DP_, FR_, sizeof(T), PL_)), 0, stream, model, model_stride, state,      \
                            state_stride, P, shard, H, A, mean, noise, cost, act, obs, nobs, diag, state_out, clw,     \
@@ -1168,14 +1286,18 @@ hipError_t launch_tree_rollout(const T* model, int n_model_shards, int max_path,
         else if (max_path <= 16) MJMPC_TREE_LAUNCH(16, 8, false, 32)
         else MJMPC_TREE_LAUNCH(32, 8, false, 32)
     } else if (nv <= 16 && !(sizeof(T) == 4 && P <= 4096 && P > 1)) {    // (f32 at <= 4096 particles: two half-empty waves per SIMD hide more latency)
-        if (max_path <= 8) MJMPC_TREE_LAUNCH(8, 16, true, 16)
-        else MJMPC_TREE_LAUNCH(16, 16, true, 16)
+        // (16 lanes per particle: the dense in-register factorisation, sized for the model)
+        if (max_path <= 8 && nv <= 8) MJMPC_TREE_LAUNCH_D(8, 16, true, 16, 8)
+        else if (max_path <= 8 && nv <= 12) MJMPC_TREE_LAUNCH_D(8, 16, true, 16, 12)
+        else if (max_path <= 8) MJMPC_TREE_LAUNCH_D(8, 16, true, 16, 16)
+        else MJMPC_TREE_LAUNCH_D(16, 16, true, 16, 16)
     } else {
         if (max_path <= 8) MJMPC_TREE_LAUNCH(8, 16, true, 32)
         else if (max_path <= 16) MJMPC_TREE_LAUNCH(16, 16, true, 32)
         else MJMPC_TREE_LAUNCH(32, 16, true, 32)
     }
 #undef MJMPC_TREE_LAUNCH
+#undef MJMPC_TREE_LAUNCH_D
     return hipGetLastError();
 }
 
