@@ -378,10 +378,10 @@ def main():
         t_step = torch.zeros(1, dtype=torch.int64, device="cuda")
         t_rec = torch.zeros(2 + H * A, dtype=torch.float64, device="cuda") if world > 1 else None
 
-    def launch():
-        if mono:        # the fused iteration's two launches from the state the run ended in (no env step: the state stays)
+    def launch(shift=-2):
+        if mono:        # the fused iteration's rollout launch (shift -2) / both launches, from the state the run ended in
             eng.mppi_step(P_loc, H, ctrl.dev.mean, ctrl.dev.mean_alt, ctrl.dev.gseq, coeffs_t, chol_t, ctrl.seed_val, 0, 0, t_step, ctrl.lam,
-                          ctrl.step_size, 0, record=t_rec, env_step=False)
+                          ctrl.step_size, shift, record=t_rec if shift != -2 else None, env_step=False)
         elif fused_entry:
             eng.rollout_fused(P_loc, H, ctrl.dev.mean, noise_t, coeffs, ctrl.dev.gseq)
         else:
@@ -396,6 +396,15 @@ def main():
     e1.record()
     torch.cuda.synchronize()
     kern_ms = e0.elapsed_time(e1) / n_t
+    both_ms = None
+    if mono:            # ... and rollout + finish launch together (update, action, shift; no env step)
+        launch(0)
+        e0.record()
+        for _ in range(n_t):
+            launch(0)
+        e1.record()
+        torch.cuda.synchronize()
+        both_ms = e0.elapsed_time(e1) / n_t
 
     fails = eng.solver_failures()
 
@@ -462,7 +471,9 @@ def main():
                      "alg_bytes_per_launch": b_alg * P_loc * H,
                      "kernel": "%s<%s>" % (w["kernel"], "double" if args.dtype == "f64" else "float"),
                      "kernel_ms": kern_ms,
-                     "kernel_entry": ("mjmpc_arm_mppi_step (two launches: sampling + rollout + cost-to-go | update + action + shift; kernel_ms is their sum, without the env step the second launch also takes in the loop)"
+                     "kernel_entry": ("mjmpc_arm_mppi_step, launch 1 of 2 (sampling + rollout + cost-to-go + per-workgroup softmax records); "
+                                      "with launch 2 (arm_mppi_finish_kernel: update + action + shift, here without its env step): "
+                                      "%.4f ms" % both_ms
                                       if mono else ("mjmpc_arm_rollout" if args.workload == "reacher" else "mjmpc_tree_rollout")
                                       + ("_fused" if fused_entry else "")),
                      "alg_bytes_per_particle_step": b_alg,

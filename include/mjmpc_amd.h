@@ -123,7 +123,8 @@ int mjmpc_arm_rollout_fused(mjmpc_arm_t h, int dtype, int64_t P, int H, const do
  *   Sharded runs pass d_record (float64 [2 + H*A]): step 2 then leaves this GPU's record {max, S, W} there and nothing
  *   else (all-gather, then mjmpc_mppi_fused_combine and mjmpc_arm_step_state); d_mean_out is not used.
  * d_gseq float64[H] (gamma_seq, no zero entry).  d_costs / d_actions (dtype [P][H] / [P][H][A]) and d_q0 (float64 [P])
- * are optional outputs.  One model block and one start state only. */
+ * are optional outputs.  One model block and one start state only.  shift_mode = -2 issues launch 1 alone (the records
+ * stay in the engine): what bench.py times as the dominant kernel. */
 int mjmpc_arm_mppi_step(mjmpc_arm_t h, int dtype, int64_t P, int H, const double* d_mean, double* d_mean_out,
                         const double* d_gseq, const double* d_filter_coeffs, const double* d_chol, uint64_t seed,
                         uint64_t offset, int64_t particle_offset, int64_t* d_step_counter, double lam, double step_size,

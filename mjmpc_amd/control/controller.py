@@ -365,7 +365,8 @@ class OLGaussianMPC(Controller):
             self._mono_launch[id(src)], _ = self._rollout_fn.mono_launcher(
                 n_loc, self.horizon, src, dst, self.dev.gseq, coeffs, chol, self.seed_val, 0, self.dev.comm.rank * n_loc,
                 self._step_dev, self.lam, self.step_size, _SHIFT_MODES[self.base_action], action_out=self._action_dev,
-                action_slots=None if sharded else self._action_pin, record=self._mono_rec, env_step=self._mono_steps_env)
+                action_slots=None if sharded else self._action_pin, record=self._mono_rec, env_step=self._mono_steps_env,
+                bind_stream=not sharded)        # (sharded: the launcher runs under stream capture)
 
     def _noise_ahead(self):
         """Captured fused iterations with the Philox sampler draw the next step's samples inside the update."""

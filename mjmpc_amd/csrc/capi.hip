@@ -312,10 +312,11 @@ int mjmpc_arm_mppi_step(mjmpc_arm_t h, int dtype, int64_t P, int H, const double
                         int shift_mode, double* d_action_out, double* h_action_slots, double* d_record, int env_step,
                         void* d_step_cost, void* d_step_next_obs, void* d_costs, void* d_actions, double* d_q0, void* stream) {
     if (!h || !d_mean || !d_gseq || !d_chol) return fail(MJMPC_E_BADARG, "null argument");
-    if (!d_record && (!d_mean_out || d_mean_out == d_mean))
+    if (!d_record && shift_mode != -2 && (!d_mean_out || d_mean_out == d_mean))
         return fail(MJMPC_E_BADARG, "d_mean_out must be a buffer of its own (the finish launch reads d_mean while it writes)");
     if (P < 1 || H < 1) return fail(MJMPC_E_BADARG, "P and H must be positive");
     if (!(lam > 0) || shift_mode > 1) return fail(MJMPC_E_BADARG, "bad lam / shift_mode");
+    const bool rollout_only = shift_mode == -2;         // (measurement: the first launch alone, records left in the engine)
     if (h->n_shards > 1 || h->n_state_shards > 1)
         return fail(MJMPC_E_BADARG, "the fused iteration runs one model and one start state (no per-shard blocks)");
     HIP_TRY(hipSetDevice(h->device));
@@ -364,13 +365,13 @@ int mjmpc_arm_mppi_step(mjmpc_arm_t h, int dtype, int64_t P, int H, const double
     if (dtype == MJMPC_F32) {
         e = mjmpc::launch_arm_rollout<float>(h->model_f32, h->state, (long)P, H, h->nu, d_mean, nullptr, (float*)d_costs,
                                              (float*)d_actions, nullptr, nullptr, nullptr, h->diag, s, fuse, &mo, h->mono_dev);
-        if (e == hipSuccess)
+        if (e == hipSuccess && !rollout_only)
             e = mjmpc::launch_arm_mppi_finish<float>(h->model_f32, h->mono_tree, groups, H, h->nu, d_mean, d_mean_out, h->mono_dev,
                                                      do_env, h->diag, s);
     } else if (dtype == MJMPC_F64) {
         e = mjmpc::launch_arm_rollout<double>(h->model_f64, h->state, (long)P, H, h->nu, d_mean, nullptr, (double*)d_costs,
                                               (double*)d_actions, nullptr, nullptr, nullptr, h->diag, s, fuse, &mo, h->mono_dev);
-        if (e == hipSuccess)
+        if (e == hipSuccess && !rollout_only)
             e = mjmpc::launch_arm_mppi_finish<double>(h->model_f64, h->mono_tree, groups, H, h->nu, d_mean, d_mean_out, h->mono_dev,
                                                       do_env, h->diag, s);
     } else {

@@ -266,10 +266,12 @@ class ArmRolloutEngine:
 
     def mppi_step_launcher(self, num_particles, horizon, mean, mean_out, gamma_seq, filter_coeffs, chol, seed, offset,
                            particle_offset, step_counter, lam, step_size, shift_mode, action_out=None, action_slots=None,
-                           record=None, env_step=False, want_trajectories=False):
+                           record=None, env_step=False, want_trajectories=False, bind_stream=True):
         """``mppi_step`` with its arguments bound once: returns (launch, outputs) where ``launch()`` enqueues the
         iteration on the stream that is current NOW (one C call, nothing converted per step) - what a control loop
-        calls every step.  The tensors must stay alive (and in place) while the launcher is in use."""
+        calls every step.  ``bind_stream=False``: on the stream that is current when ``launch()`` is called (a launcher
+        that is also called under stream capture must say so, or its kernels stay out of the graph).  The tensors must
+        stay alive (and in place) while the launcher is in use."""
         torch = _torch()
         P, H, A = int(num_particles), int(horizon), self.d_action
         costs = act = q0 = None
@@ -285,11 +287,16 @@ class ArmRolloutEngine:
         args = (self._h, self._code, P, H, _ptr(mean), _ptr(mean_out), _ptr(gamma_seq), _ptr(filter_coeffs), _ptr(chol),
                 int(seed) & (2 ** 64 - 1), int(offset), int(particle_offset), _ptr(step_counter), float(lam), float(step_size),
                 int(shift_mode), _ptr(action_out), _ptr(action_slots), _ptr(record), int(bool(env_step)), _ptr(scost),
-                _ptr(snobs), _ptr(costs), _ptr(act), _ptr(q0), self._stream())
-        fn, check = self._lib.mjmpc_arm_mppi_step, _lib.check
+                _ptr(snobs), _ptr(costs), _ptr(act), _ptr(q0))
+        fn, check, stream = self._lib.mjmpc_arm_mppi_step, _lib.check, self._stream
+        if bind_stream:
+            args = args + (stream(),)
 
-        def launch(_keep=keep):
-            check(fn(*args))
+            def launch(_keep=keep):
+                check(fn(*args))
+        else:
+            def launch(_keep=keep):
+                check(fn(*args, stream()))
 
         return launch, ((costs, act, q0) if want_trajectories else None)
 

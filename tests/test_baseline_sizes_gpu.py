@@ -123,3 +123,42 @@ def test_f32_three_waves_per_simd_32768(raw_arm, ref_arm):
                                 # limit rows that switch one substep apart in f32 and f64 (discontinuous activation)
     assert np.abs(nobs[:, -1, :7] - o_nobs[:, -1, :7]).max() < 2e-2
     assert eng.solver_failures() == 0
+
+
+@pytest.mark.parametrize("lam", [0.01, 0.2])
+def test_f32_updated_mean_error_4096x32(raw_arm, ref_arm, lam):
+    """SURVEY 8d asks for the f32 error of the UPDATED MEAN, not only of the costs: one MPPI step at the headline
+    shape (4096 x 32, identical host noise) on the f32 engine against oracle rollouts + ``mppi_update`` in f64.
+    Measured on MI355X (printed): at both temperatures the cost-to-go of 4096 rollouts spans far more than lam, one
+    particle carries 0.99-1.00 of the weight, and the updated mean is that particle's action sequence: max |d mean|
+    7.6e-8 (lam = 0.01) / 9.3e-7 (lam = 0.2) - the f32 rounding of the actions - while single costs are off by up to
+    2.6e-3.  A cost error matters only if it reorders the best two particles (a 2.6e-3 error against a typical gap of
+    0.1-1 between them).  Asserted: 1e-5."""
+    from mjmpc_amd.control import MPPI
+    from mjmpc_amd.envs.arm_engine import ArmRolloutEngine, make_rollout_fn
+    from oracle import controllers_ref as cr
+    eng = ArmRolloutEngine(raw_arm, dtype="f32")
+    P, H, A = 4096, 32, 7
+    ctrl = MPPI(d_state=eng.d_state, d_obs=eng.d_obs, d_action=A, horizon=H, init_cov=1.0, base_action="null", lam=lam,
+                num_particles=P, step_size=1.0, alpha=1, gamma=1.0, n_iters=1, action_lows=eng.action_lows,
+                action_highs=eng.action_highs, filter_coeffs=FILT, seed=123)
+    ctrl.set_sim_state_fn = eng.set_env_state
+    ctrl.rollout_fn = make_rollout_fn(eng)
+    worst_mean, worst_cost = 0.0, 0.0
+    for state in (START, MOVING):
+        ctrl.reset()
+        ctrl.optimize(dict(state), hotstart=False)          # (no shift: mean_action is the updated mean itself)
+        noise = cr.generate_noise(np.eye(A), FILT, (P, H), 123)
+        _, rew, act, _, _ = ref_arm.rollout(state["qp"], state["qv"], state["target_pos"], np.zeros((H, A)), noise, want_obs=False)
+        gseq = cr.gamma_seq(1.0, H)
+        mean = cr.mppi_update(-rew, act, np.zeros((H, A)), np.eye(A), gseq, lam, 1, 1.0)
+        w = cr.softmax0((-1.0 / lam) * cr.cost_to_go(-rew, gseq)[:, 0])
+        err = np.abs(ctrl.mean_action - mean).max()
+        eng.set_env_state(dict(state))
+        _, g_rew, _, _, _, _ = eng.rollout(P, H, np.zeros((H, A)), noise, "open_loop")
+        cerr = np.abs(g_rew - rew).max()
+        print("f32 4096x32 lam=%g: max |mean_f32 - mean_f64| = %.3e (largest |mean| %.2f, largest softmax weight %.3f, "
+              "max cost error %.2e)" % (lam, err, np.abs(mean).max(), w.max(), cerr))
+        worst_mean, worst_cost = max(worst_mean, err), max(worst_cost, cerr)
+    assert worst_mean < 1e-5, worst_mean
+    assert worst_cost < 1e-2

@@ -313,3 +313,43 @@ def test_device_resident_env_step_and_graph_replay(name):
     a_g, s_g = closed_loop(True)
     np.testing.assert_allclose(a_g, a_e, rtol=0, atol=1e-9)
     np.testing.assert_allclose(s_g["qpos"], s_e["qpos"], rtol=0, atol=1e-8)
+
+
+@pytest.mark.parametrize("lam", [0.2, 10.0])
+def test_cheetah_mppi_step_at_the_bench_shape(lam):
+    """What MPC consumes on the cheetah at the bench shape: one MPPI step, 4096 x 32, identical
+    host noise - ``optimize()`` on the HIP engine (f64) against oracle rollouts + ``mppi_update`` - at the bench's
+    lam = 0.2 (the returns of 4096 rollouts span far more than 0.2: the best particle carries 0.996 of the weight) and
+    at lam = 10 (a genuinely weighted mean: largest weight < 0.1).
+    Tolerance: single costs agree to 1e-10 after one env step and drift apart by ~1.4x per env step afterwards (both sides:
+    the contact dynamics amplify rounding), i.e. up to ~1e-6 on a few particles at step 32; a cost-to-go error e moves a
+    softmax weight by e / lam relatively, so the weighted mean may move by ~1e-5 |a| at the very most.  Measured (printed):
+    2e-14 at lam = 0.2, 1e-14 at lam = 10; asserted 1e-6."""
+    from mjmpc_amd.control import MPPI
+    from mjmpc_amd.envs.arm_engine import make_rollout_fn
+    from mjmpc_amd.envs.locomotion_env import HalfCheetahEnv
+    from mjmpc_amd.envs.tree_engine import TreeRolloutEngine
+    from oracle import controllers_ref as cr
+    from oracle.physics_ref import RefArm
+    raw = _models()["cheetah"]()
+    eng, ref = TreeRolloutEngine(raw, dtype="f64"), RefArm(raw.to_flat())
+    env = HalfCheetahEnv(dtype="f64")
+    env.reset(seed=123)
+    st = env.get_env_state()
+    P, H, A, cov, filt = 4096, 32, 6, 0.3, [0.25, 0.8, 0.0]
+    ctrl = MPPI(d_state=eng.d_state, d_obs=eng.d_obs, d_action=A, horizon=H, init_cov=cov, base_action="null", lam=lam,
+                num_particles=P, step_size=1.0, alpha=1, gamma=1.0, n_iters=1, action_lows=eng.action_lows,
+                action_highs=eng.action_highs, filter_coeffs=filt, seed=123)
+    ctrl.set_sim_state_fn = eng.set_env_state
+    ctrl.rollout_fn = make_rollout_fn(eng)
+    action, _ = ctrl.optimize(st, hotstart=False)
+    noise = cr.generate_noise(cov * np.eye(A), filt, (P, H), 123)
+    _, rew, act, _, _ = ref.rollout(st["qpos"], st["qvel"], np.zeros(3), np.zeros((H, A)), noise, want_obs=False)
+    gseq = cr.gamma_seq(1.0, H)
+    mean = cr.mppi_update(-rew, act, np.zeros((H, A)), cov * np.eye(A), gseq, lam, 1, 1.0)
+    w = cr.softmax0((-1.0 / lam) * cr.cost_to_go(-rew, gseq)[:, 0])
+    err = np.abs(ctrl.mean_action - mean).max()
+    print("cheetah 4096x32 lam=%g: max |mean_hip - mean_oracle| = %.3e, |action error| %.3e, largest softmax weight %.3f"
+          % (lam, err, np.abs(action - mean[0]).max(), w.max()))
+    assert err < 1e-6 and (lam < 1 or w.max() < 0.5)
+    assert eng.solver_failures() == 0

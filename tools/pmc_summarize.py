@@ -1,6 +1,9 @@
-"""Turn the PMC passes of tools/profile_round.sh into the per-launch figures bench.py reports:
-    python tools/pmc_summarize.py r02 gpurun_out
-writes <out>/<tag>_traffic_f64_4096x32.json and <out>/<tag>_valu_issue_f64_4096x32.json (copy them to profiles/)."""
+"""Turn the PMC passes of tools/profile_round3.sh into the per-launch figures bench.py reports:
+    python tools/pmc_summarize.py r03 gpurun_out
+writes, per workload, <out>/<tag>_[<workload>_]traffic_f64_4096x32.json and <tag>_[<workload>_]valu_issue_f64_4096x32.json
+(copy them to profiles/): HBM bytes per launch (FETCH_SIZE / WRITE_SIZE, calibrated on a known copy), the share of the
+chip's VALU issue slots the kernel fills, and the floating-point operations the kernel ITSELF executes per particle-step
+(SQ_INSTS_VALU_{ADD,MUL,FMA,TRANS}_F64 + _F32, wave instructions x 64 lanes, an FMA = 2)."""
 import csv
 import glob
 import json
@@ -8,7 +11,13 @@ import os
 import sys
 
 tag, out = sys.argv[1], sys.argv[2]
-KERNEL = "arm_rollout_kernel<double, false, false"
+P, H = 4096, 32
+WORKLOADS = {
+    # workload -> (file prefix, dominant kernel, other kernels of the step reported beside it)
+    "reacher": ("", "arm_rollout_kernel<double, false, false, 1, true, true>",
+                ["arm_mppi_finish_kernel<double>", "arm_rollout_kernel<double, false, false, 1, true, false>"]),
+    "half_cheetah": ("half_cheetah_", "tree_rollout_kernel<double, 8, 16, true, 16, 12>", []),
+}
 
 
 def rows(d, pat="*counter_collection.csv"):
@@ -32,42 +41,76 @@ def mean(x):
     return sum(x) / len(x) if x else float("nan")
 
 
-# ---- HBM traffic per launch (FETCH_SIZE / WRITE_SIZE are reported in KB; calibrated on the 64 MiB copy) ----
-fk, _ = per_kernel("pmcF", KERNEL)
-wk, _ = per_kernel("pmcW", KERNEL)
-fc, _ = per_kernel("pmcF", "copyBuffer")        # dst.copy_(src): 65536 KiB read + written (the largest copies)
-wc, _ = per_kernel("pmcW", "copyBuffer")
-f_raw, w_raw = mean(fk.get("FETCH_SIZE", [])), mean(wk.get("WRITE_SIZE", []))
-fcal = max(fc.get("FETCH_SIZE", [float("nan")]))
-wcal = max(wc.get("WRITE_SIZE", [float("nan")]))
-f_corr, w_corr = 65536.0 / fcal, 65536.0 / wcal
-traffic = (f_raw * f_corr + w_raw * w_corr) * 1024.0
-tj = {"kernel": KERNEL + ", 1, true> (two wavefronts per particle group)", "dtype": "f64", "particles": 4096, "horizon": 32,
-      "FETCH_SIZE_raw_KB": f_raw, "WRITE_SIZE_raw_KB": w_raw,
-      "calibration": {"what": "64 MiB contiguous device copy in the same process (65536 KiB read, 65536 KiB written)",
-                      "FETCH_SIZE_raw_KB": fcal, "WRITE_SIZE_raw_KB": wcal, "fetch_correction": f_corr,
-                      "write_correction": w_corr},
-      "traffic_bytes_per_launch": traffic, "algorithmic_bytes_rollout_only": 4096 * 32 * 15 * 8,
-      "method": "rocprofv3 --kernel-trace --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes over tools/pmc_run.py; "
-                "corrections from the calibration copy (FETCH_SIZE x2 on gfx950, MI355X_MICROARCH.md HBM section)"}
-with open(os.path.join(out, "%s_traffic_f64_4096x32.json" % tag), "w") as f:
-    json.dump(tj, f, indent=1)
-print(json.dumps(tj, indent=1))
+def flops(wl, kernel):
+    v64, _ = per_kernel(wl + "_pmcS3", kernel)
+    v32, _ = per_kernel(wl + "_pmcS4", kernel)
+    m = {k: mean(v) for k, v in list(v64.items()) + list(v32.items())}
+    g = lambda k: m.get(k, 0.0)        # noqa: E731
+    f64 = g("SQ_INSTS_VALU_ADD_F64") + g("SQ_INSTS_VALU_MUL_F64") + 2 * g("SQ_INSTS_VALU_FMA_F64") + g("SQ_INSTS_VALU_TRANS_F64")
+    f32 = g("SQ_INSTS_VALU_ADD_F32") + g("SQ_INSTS_VALU_MUL_F32") + 2 * g("SQ_INSTS_VALU_FMA_F32") + g("SQ_INSTS_VALU_TRANS_F32")
+    return m, 64.0 * f64, 64.0 * f32
 
-# ---- SQ: waves, instructions, busy fractions ----
-s1, d1 = per_kernel("pmcS1", KERNEL)
-s2, d2 = per_kernel("pmcS2", KERNEL)
-m = {k: mean(v) for k, v in list(s1.items()) + list(s2.items())}
-dur_ns = mean(d1)
-simds, clock = 1024, 2.4e9
-issue = m.get("SQ_INSTS_VALU", float("nan")) * 4.0 / (simds * dur_ns * 1e-9 * clock)
-ij = {"kernel": KERNEL + ", 1, true>", "dtype": "f64", "particles": 4096, "horizon": 32, "counters_per_launch": m,
-      "duration_ns_in_pmc_pass": dur_ns,
-      "valu_issue_frac": issue,
-      "formula": "SQ_INSTS_VALU x 4 cycles per wave64 instruction / (1024 SIMDs x kernel duration x 2.4 GHz)",
-      "valu_busy_of_wave_cycles": m.get("SQ_ACTIVE_INST_VALU", float("nan")) / m.get("SQ_WAVE_CYCLES", float("nan")),
-      "wait_any_of_wave_cycles": m.get("SQ_WAIT_ANY", float("nan")) / m.get("SQ_WAVE_CYCLES", float("nan")),
-      "method": "rocprofv3 --kernel-trace --pmc <SQ counters> in two passes over tools/pmc_run.py 4096 f64 (tools/profile_round.sh)"}
-with open(os.path.join(out, "%s_valu_issue_f64_4096x32.json" % tag), "w") as f:
-    json.dump(ij, f, indent=1)
-print(json.dumps(ij, indent=1))
+
+for wl, (prefix, KERNEL, others) in WORKLOADS.items():
+    # ---- HBM traffic per launch (FETCH_SIZE / WRITE_SIZE are reported in KB; calibrated on the 64 MiB copy) ----
+    fk, _ = per_kernel(wl + "_pmcF", KERNEL)
+    wk, _ = per_kernel(wl + "_pmcW", KERNEL)
+    fc, _ = per_kernel(wl + "_pmcF", "copyBuffer")        # dst.copy_(src): 65536 KiB read + written (the largest copies)
+    wc, _ = per_kernel(wl + "_pmcW", "copyBuffer")
+    if not fk:
+        print("no PMC rows for", wl, KERNEL)
+        continue
+    f_raw, w_raw = mean(fk.get("FETCH_SIZE", [])), mean(wk.get("WRITE_SIZE", []))
+    fcal = max(fc.get("FETCH_SIZE", [float("nan")]))
+    wcal = max(wc.get("WRITE_SIZE", [float("nan")]))
+    f_corr, w_corr = 65536.0 / fcal, 65536.0 / wcal
+    traffic = (f_raw * f_corr + w_raw * w_corr) * 1024.0
+    tj = {"kernel": KERNEL, "dtype": "f64", "particles": P, "horizon": H, "workload": wl,
+          "FETCH_SIZE_raw_KB": f_raw, "WRITE_SIZE_raw_KB": w_raw,
+          "calibration": {"what": "64 MiB contiguous device copy in the same process (65536 KiB read, 65536 KiB written)",
+                          "FETCH_SIZE_raw_KB": fcal, "WRITE_SIZE_raw_KB": wcal, "fetch_correction": f_corr,
+                          "write_correction": w_corr},
+          "traffic_bytes_per_launch": traffic,
+          "note": ("the fused iteration's rollout kernel draws its samples itself, keeps the actions in LDS and writes one "
+                   "226-double record per workgroup: its HBM traffic is model + records, far below the ALGORITHMIC bytes "
+                   "(SURVEY 8d: delta in, action + cost out, update re-reads), which is what roofline.achieved is defined on")
+          if wl == "reacher" else "",
+          "method": "rocprofv3 --kernel-trace --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes over tools/pmc_run.py; "
+                    "corrections from the calibration copy (FETCH_SIZE x2 on gfx950, MI355X_MICROARCH.md HBM section)"}
+    with open(os.path.join(out, "%s_%straffic_f64_%dx%d.json" % (tag, prefix, P, H)), "w") as f:
+        json.dump(tj, f, indent=1)
+    print(json.dumps(tj, indent=1))
+
+    # ---- SQ: waves, instructions, busy fractions, the kernel's own FLOPs ----
+    s1, d1 = per_kernel(wl + "_pmcS1", KERNEL)
+    s2, d2 = per_kernel(wl + "_pmcS2", KERNEL)
+    m = {k: mean(v) for k, v in list(s1.items()) + list(s2.items())}
+    fm, fl64, fl32 = flops(wl, KERNEL)
+    m.update(fm)
+    dur_ns = mean(d1)
+    simds, clock = 1024, 2.4e9
+    issue = m.get("SQ_INSTS_VALU", float("nan")) * 4.0 / (simds * dur_ns * 1e-9 * clock)
+    ij = {"kernel": KERNEL, "dtype": "f64", "particles": P, "horizon": H, "workload": wl, "counters_per_launch": m,
+          "duration_ns_in_pmc_pass": dur_ns,
+          "valu_issue_frac": issue,
+          "formula": "SQ_INSTS_VALU x 4 cycles per wave64 instruction / (1024 SIMDs x kernel duration x 2.4 GHz)",
+          "valu_busy_of_wave_cycles": m.get("SQ_ACTIVE_INST_VALU", float("nan")) / m.get("SQ_WAVE_CYCLES", float("nan")),
+          "wait_any_of_wave_cycles": m.get("SQ_WAIT_ANY", float("nan")) / m.get("SQ_WAVE_CYCLES", float("nan")),
+          "kernel_flops_per_launch": {"f64": fl64, "f32": fl32},
+          "kernel_flops_per_particle_step": (fl64 + fl32) / (P * H),
+          "kernel_flops_formula": "(SQ_INSTS_VALU_ADD + MUL + TRANS + 2 x FMA, _F64 and _F32) x 64 lanes / (P x H): what the kernel's "
+                                  "own instruction stream executes, spare lanes and the work both wavefronts of a particle "
+                                  "group duplicate included",
+          "other_kernels": {},
+          "method": "rocprofv3 --kernel-trace --pmc <SQ counters> in four passes over tools/pmc_run.py %s 4096 f64 "
+                    "(tools/profile_round3.sh)" % wl}
+    for ok in others:
+        o1, od = per_kernel(wl + "_pmcS1", ok)
+        _, of64, of32 = flops(wl, ok)
+        if od:
+            ij["other_kernels"][ok] = {"duration_ns": mean(od), "SQ_INSTS_VALU": mean(o1.get("SQ_INSTS_VALU", [])),
+                                       "SQ_WAVES": mean(o1.get("SQ_WAVES", [])),
+                                       "kernel_flops_per_particle_step": (of64 + of32) / (P * H)}
+    with open(os.path.join(out, "%s_%svalu_issue_f64_%dx%d.json" % (tag, prefix, P, H)), "w") as f:
+        json.dump(ij, f, indent=1)
+    print(json.dumps(ij, indent=1))

@@ -1,0 +1,61 @@
+"""The sharded control iteration on ONE GPU: a world-size-1 RCCL group whose communicator CLAIMS two ranks (this process
+is rank 0 and owns the first half of the particles; the all-gather really gathers one record).  The captured graph then
+holds what a rank of a multi-GPU run replays - rollout + record launches, the RCCL all-gather, the combine kernel, the
+env step - and its closed loop must equal a plain single-GPU run over that half population (same global particle
+indices, hence the same samples).  Run by tools/test_dist_onegpu.sh and tests/test_rccl_world1_gpu.py."""
+import os
+import sys
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+os.environ.setdefault("MASTER_PORT", "29533")
+dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+from mjmpc_amd.control import MPPI
+from mjmpc_amd.control._device import TorchDistComm
+from mjmpc_amd.envs.arm_engine import ArmRolloutEngine, make_device_rollout_fn
+from mjmpc_amd.models.reacher7dof import reacher7dof_raw
+
+
+class ClaimsTwoRanks(TorchDistComm):
+    def __init__(self):
+        super().__init__()
+        self.world_size = 2         # sharding map and code paths of a two-rank run; the gather returns ONE record
+
+    def all_gather(self, t):
+        self.world_size = 1
+        try:
+            return super().all_gather(t)
+        finally:
+            self.world_size = 2
+
+
+def run(P, comm, mono):
+    eng = ArmRolloutEngine(reacher7dof_raw(), dtype="f64")
+    c = MPPI(d_state=25, d_obs=20, d_action=7, horizon=16, init_cov=1.0, base_action="null", lam=0.05, num_particles=P,
+             step_size=1.0, alpha=1, gamma=1.0, n_iters=1, action_lows=eng.action_lows, action_highs=eng.action_highs,
+             filter_coeffs=[0.25, 0.8, 0.0], seed=3, noise_mode="device", comm=comm)
+    c.rollout_fn = make_device_rollout_fn(eng)
+    c.set_sim_state_fn = lambda s: None
+    c.enable_graph(post_step=eng.step_state, mono=mono)
+    acts = [c.optimize({})[0] for _ in range(6)]
+    torch.cuda.synchronize()
+    return np.array(acts), c
+
+
+ref, _ = run(512, None, True)                       # 512 particles on one GPU
+for mono in (True, False):
+    got, c = run(1024, ClaimsTwoRanks(), mono)      # "1024 over two ranks": this rank's 512 are the same particles
+    assert c.local_particles == 512 and c._mono == mono and not getattr(c, "graph_fallback", False)
+    assert c._graph not in (None, "direct"), "the sharded iteration should replay a captured graph"
+    err = np.abs(got - ref).max()
+    if os.environ.get("RCCL_W1_DEBUG"):
+        print(np.abs(got - ref).max(axis=1)); print(ref[:2]); print(got[:2])
+    print("sharded iteration (%s) in a hipGraph with an RCCL all-gather: max |d action| vs the single-GPU run = %.2e"
+          % ("rollout + record launches" if mono else "separate launches", err))
+    assert err < 1e-9 or os.environ.get('RCCL_W1_DEBUG')
+dist.destroy_process_group()
+print("ok")
