@@ -140,18 +140,23 @@ int mjmpc_arm_step_state(mjmpc_arm_t h, int dtype, const double* d_action, void*
 
 /* ---- tree engine: the same worker-pool replacement for models the serial-chain arm engine cannot hold ----------
  * (SURVEY 8f rank 4): a kinematic TREE of up to 32 hinge / slide dofs (the reference's vendored sawyer.xml, swimmer.xml
- * and half_cheetah.xml; a synthetic 24-dof hand): gravity, joint limits and springs, motors on a subset of the joints,
- * MuJoCo's inertia-box fluid model, up to 16 sphere- or capsule-end / plane contact points, frictionless or with
- * pyramidal friction cones.  Reward and observation follow the block's task: 0 = reach (reacher_env.py:29-47, d_obs =
- * 2 nv + 6), 1 = forward progress (swimmer.py:10-24, half_cheetah.py:10-25, d_obs = 2 nv - obs_skip).  Constant block
+ * and half_cheetah.xml; a synthetic 24-dof hand, and that hand holding a 6-dof pen): gravity, joint limits and springs,
+ * motors or position servos on a subset of the joints, MuJoCo's inertia-box fluid model, up to 16 contact points -
+ * sphere- or capsule-end / plane, or sphere / capsule geom-geom pairs - frictionless or with pyramidal friction cones.
+ * Reward and observation follow the block's task: 0 = reach (reacher_env.py:29-47, d_obs = 2 nv + 6), 1 = forward
+ * progress (swimmer.py:10-24, half_cheetah.py:10-25, d_obs = 2 nv - obs_skip), 2 = reorient an object (the shape of
+ * pen-v0's reward, examples/configs/hand/pen-v0.yml:8; d_obs = 2 nv + 6).  Constant block (MJMPC_TREE_BLOB_LEN float64)
  * produced by mjmpc_amd/models/compile_tree.py::compile_tree and mirrored by mjmpc_amd/csrc/tree_model.h; per-link
  * fields are [component][32 lanes], links numbered depth-first:
  *   off[3][32] axis[3][32] mass[32] com[3][32] inertia[6][32] armature damping range_lo range_hi limited gear ctrl_lo
- *   ctrl_hi dof_invweight0 parent subsize anc[5][32] ancmask[2][32] jtype stiffness springref act (each [32])
- *   fbox[3][32] frot[9][32]  nv timestep frame_skip jumps site_link site_pos[3] n_sphere plane_n[3] plane_d
+ *   ctrl_hi dof_invweight0 stiffness springref (each [32]) fbox[3][32] frot[9][32] kpg[32] (servos: gear^2 kp)
+ *   nv timestep frame_skip jumps site_link site_pos[3] n_sphere plane_n[3] plane_d
  *   sol_{K,B,dmin,dmax,width,mid,power} gravity[3] nu task ctrl_cost obs_skip density viscosity
- *   lsol_{K,B,dmin,dmax,width,mid,power} any_friction
- *   spheres[16][12] = {link, pos[3], r, margin, invweight, mu, capsule axis[3], depth of the link}  depth[32] n_rounds elim[31][32]
+ *   lsol_{K,B,dmin,dmax,width,mid,power} any_friction site_axis[3] target_dir[3]
+ *   spheres[16][24] = {link A, start[3], rA, margin, invweight, mu, capsule axis / segment vector on A [3], depth of
+ *   link A in the elimination tree, kind (0 sphere-plane, 1 geom-geom), link B, start on B [3], rB, segment vector on B [3]}
+ *   parent subsize anc[5][32] ancmask[2][32] jtype act eparent (parent in the elimination tree of the factorisation)
+ *   depth[32] n_rounds elim[31][32]
  *   (elimination lists of the tree-sparse L'DL: the descendants of every link sorted by height, packed
  *   k | distance << 8 | height << 16, -1 ends)
  * Same call shapes and reference counterparts as the arm engine (subproc_vec_env.py:91-111, 128-186, 235-251);

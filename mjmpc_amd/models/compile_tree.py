@@ -204,10 +204,30 @@ def compile_tree(raw: RawModel, overrides=None, base: "TreeModel" = None) -> Tre
             k = parent[k]
         return k
 
+    def is_ancestor(a, k):          # link a is k or one of k's (kinematic) ancestors
+        while k >= 0:
+            if k == a:
+                return True
+            k = parent[k]
+        return False
+
     eparent = parent.copy()
-    if pair_geoms:
-        obj_roots = {root_of(link_of_body[ib]) for (_, _), (ib, _) in pair_geoms}
-        man_roots = {root_of(link_of_body[ia]) for (ia, _), (_, _) in pair_geoms}
+    # pairs inside ONE kinematic tree (self-collision: swimmer.xml's segments) need no help as long as one link is an
+    # ancestor of the other - the row then lives on the deeper link's path; listed deeper geom first
+    cross = []
+    for (ia, ga), (ib, gb) in pair_geoms:
+        la, lb = link_of_body[ia], link_of_body[ib]
+        if la < 0 or lb < 0:
+            raise NotImplementedError("geom-geom pairs must name geoms on moving bodies")
+        if root_of(la) != root_of(lb):
+            cross.append(((ia, ga), (ib, gb)))
+        elif not is_ancestor(lb, la):
+            raise NotImplementedError("a self-collision pair must list the deeper geom first, and its links must lie on one "
+                                      "root path (a pair across two branches would fill the sparse factorisation in): "
+                                      "%r / %r" % (ga.name, gb.name))
+    if cross:
+        obj_roots = {root_of(link_of_body[ib]) for (_, _), (ib, _) in cross}
+        man_roots = {root_of(link_of_body[ia]) for (ia, _), (_, _) in cross}
         if len(obj_roots) != 1 or obj_roots & man_roots:
             raise NotImplementedError("geom-geom pairs must pair geoms of the manipulator(s) with geoms of ONE object tree")
         ro = obj_roots.pop()

@@ -83,8 +83,10 @@ class _Defaults:
         return self.cls[c][tag].get(key, fallback)
 
 
-def load_mjcf(path, hand_site="finger", target_site="target", frame_skip=2, task=TASK_REACH, ctrl_cost=0.0, obs_skip=0):
-    """``task=TASK_FORWARD`` (with ``ctrl_cost`` / ``obs_skip``) loads a locomotion model: no tracked site is needed."""
+def load_mjcf(path, hand_site="finger", target_site="target", frame_skip=2, task=TASK_REACH, ctrl_cost=0.0, obs_skip=0,
+              self_collision=True):
+    """``task=TASK_FORWARD`` (with ``ctrl_cost`` / ``obs_skip``) loads a locomotion model: no tracked site is needed.
+    ``self_collision=False`` leaves out the geom-geom pairs MuJoCo would derive from contype / conaffinity."""
     root = ET.parse(path).getroot()
     for e in root:
         if e.tag == "contact" and all(c.tag == "pair" for c in e):
@@ -183,8 +185,12 @@ def load_mjcf(path, hand_site="finger", target_site="target", frame_skip=2, task
                         name=j.get("name", ""), type=JOINT_SLIDE if t == "slide" else JOINT_HINGE,
                         stiffness=float(ja("stiffness", "0")), springref=float(ja("springref", "0")))
 
-    def walk(e, parent, active):
+    xml_body, xml_parent = [], []       # per RawBody: the XML body it belongs to; per XML body: its parent XML body
+
+    def walk(e, parent, active, xparent=-1):
         active = e.get("childclass", active)
+        xid = len(xml_parent)
+        xml_parent.append(xparent)
         joints = [parse_joint(j, active) for j in e.findall("joint")]
         name = e.get("name", "body%d" % len(bodies))
         pos, quat = _floats(e.get("pos"), 3, [0.0, 0.0, 0.0]), _floats(e.get("quat"), 4, [1.0, 0.0, 0.0, 0.0])
@@ -197,6 +203,7 @@ def load_mjcf(path, hand_site="finger", target_site="target", frame_skip=2, task
                 jt.name = "%s_joint%d" % (name, k)
             bodies.append(RawBody("%s~%d" % (name, k), parent, pos if k == 0 else [0.0, 0.0, 0.0],
                                   quat if k == 0 else [1.0, 0.0, 0.0, 0.0], jt, []))
+            xml_body.append(xid)
             parent = len(bodies) - 1
         idx = len(bodies)
         first = len(joints) <= 1
@@ -205,6 +212,7 @@ def load_mjcf(path, hand_site="finger", target_site="target", frame_skip=2, task
             jt.name = "%s_joint%d" % (name, len(joints) - 1)
         bodies.append(RawBody(name, parent, pos if first else [0.0, 0.0, 0.0], quat if first else [1.0, 0.0, 0.0, 0.0], jt,
                               [parse_geom(g, active) for g in e.findall("geom")]))
+        xml_body.append(xid)
         for s in e.findall("site"):
             sites[s.get("name")] = (idx, _floats(s.get("pos"), 3, [0.0, 0.0, 0.0]))
         for c in e:
@@ -213,7 +221,7 @@ def load_mjcf(path, hand_site="finger", target_site="target", frame_skip=2, task
             if c.tag == "inertial":
                 raise ValueError("explicit <inertial> is not supported (inertiafromgeom only)")
         for c in e.findall("body"):
-            walk(c, idx, active)
+            walk(c, idx, active, xid)
 
     for e in world.findall("body"):
         walk(e, -1, world.get("childclass"))
@@ -238,6 +246,25 @@ def load_mjcf(path, hand_site="finger", target_site="target", frame_skip=2, task
             plane = RawPlane(pos=_floats(plane_elem.get("pos"), 3, [0.0, 0.0, 0.0]), normal=(0.0, 0.0, 1.0),
                              margin=float(pa("margin", "0")), friction=_floats(pa("friction", "1 0.005 0.0001"))[0],
                              condim=int(pa("condim", "3")))
+    # ... and body geoms against each other (self_collision): MuJoCo's rule - the contype / conaffinity masks match, the
+    # two bodies differ and are not parent and child.  Later geom first (on a chain: the deeper one, which is the order
+    # compile_tree asks for).  swimmer.xml's segments are the vendored case (default contype = conaffinity = 1).
+    auto_pairs = []
+    if self_collision:
+        flat = [(bi, g) for bi, b in enumerate(bodies) for g in b.geoms]
+        for ib in range(len(flat)):
+            for ia in range(ib):
+                (ba, ga_), (bb, gb_) = flat[ia], flat[ib]
+                xa, xb = xml_body[ba], xml_body[bb]
+                if xa == xb or xml_parent[xa] == xb or xml_parent[xb] == xa:
+                    continue
+                if not ((ga_._contype & gb_._conaffinity) or (gb_._contype & ga_._conaffinity)):
+                    continue
+                for k, (bi, g) in ((ia, flat[ia]), (ib, flat[ib])):
+                    if not g.name:
+                        g.name = "%s_geom%d" % (bodies[bi].name, k)
+                    geom_solver.add(g._solver)
+                auto_pairs.append((gb_.name, ga_.name))
     if len(geom_solver) > 1 or len(limit_solver) > 1:
         raise ValueError("one solref / solimp set for contacts and one for joint limits")
 
@@ -265,7 +292,7 @@ def load_mjcf(path, hand_site="finger", target_site="target", frame_skip=2, task
         kp = float(m.get("kp", "1")) if m.tag == "position" else 0.0       # MJCF <position>: kp defaults to 1
         acts.append(RawActuator(m.get("joint"), gear, _floats(ma("ctrlrange"), 2), kp=kp))
     # explicit geom-geom collision candidates (<contact><pair geom1=... geom2=...>): manipulator geom first, object second
-    pairs = []
+    pairs = list(auto_pairs)
     con = root.find("contact")
     for pr in (list(con) if con is not None else []):
         pairs.append((pr.get("geom1"), pr.get("geom2")))

@@ -183,3 +183,67 @@ def test_cheetah_settles_on_its_feet_and_the_tree_compiler_reads_its_contacts():
         q, v, r, obs = ref.env_step(q, v, np.zeros(6), np.zeros(3))
     assert np.abs(v).max() < 1e-6 and -0.2 < q[1] < -0.05 and abs(q[2]) < 0.2 and ref.newton_stats()["fails"] == 0
     assert obs.shape == (17,) and np.allclose(obs[:8], q[1:]) and abs(r) < 1e-6
+
+
+def _swimmer_segments(theta):
+    """End points of the five 0.3-long segments for joint angles theta[4] (root at the origin, heading +x)."""
+    pts, ang, segs = [np.zeros(2)], 0.0, []
+    for k in range(5):
+        ang += theta[k - 1] if k else 0.0
+        e = pts[-1] + 0.3 * np.array([np.cos(ang), np.sin(ang)])
+        segs.append((pts[-1], e))
+        pts.append(e)
+    return segs
+
+
+def _gap(sa, sb, ra, rb):
+    t = np.linspace(0.0, 1.0, 31)
+    A = sa[0][None] + t[:, None] * (sa[1] - sa[0])[None]
+    B = sb[0][None] + t[:, None] * (sb[1] - sb[0])[None]
+    return np.sqrt(((A[:, None] - B[None]) ** 2).sum(-1)).min() - ra - rb
+
+
+def test_swimmer_self_contact_reachability():
+    """swimmer.xml's segments collide with each other (default contype / conaffinity; parent and child excluded).  Within
+    the joint ranges of +-1.5 rad: segments TWO apart never touch; segments three or four apart do once the chain curls
+    into a loop - every joint between them bent the same way beyond ~1.15 rad."""
+    import itertools
+    radii = (0.07, 0.065, 0.06, 0.055, 0.05)
+    best = {}
+    for lim in (1.1, 1.5):
+        grid = np.linspace(-lim, lim, 7)
+        for th in itertools.product(grid, repeat=4):
+            segs = _swimmer_segments(th)
+            for i in range(5):
+                for j in range(i + 2, 5):
+                    g = _gap(segs[i], segs[j], radii[i], radii[j])
+                    best[(lim, j - i)] = min(best.get((lim, j - i), 9.0), g)
+    assert best[(1.5, 2)] > 0.15                            # unreachable at any admissible posture
+    assert best[(1.1, 3)] > 0.05 and best[(1.1, 4)] > 0.05  # ... and so is everything below ~1.1 rad of bend
+    assert best[(1.5, 3)] < -0.04 and best[(1.5, 4)] < -0.04    # a curled chain does touch itself
+    raw = swimmer_raw()
+    assert sorted(raw.pairs) == sorted(("seg%d" % b, "seg%d" % a) for b in range(5) for a in range(b - 1))
+
+
+def test_curled_swimmer_pushes_itself_apart():
+    """Oracle: the chain curled onto itself (tail inside the torso's capsule).  With the pairs the contact force opens the
+    loop; without them nothing does."""
+    from oracle.physics_ref import RefArm
+    q = np.zeros(7)
+    q[3:] = -1.45
+    radii = (0.07, 0.065, 0.06, 0.055, 0.05)
+
+    def run(raw, steps):
+        ref, qq, vv = RefArm(_in_vacuum(raw).to_flat()), q.copy(), np.zeros(7)
+        for _ in range(steps):
+            qq, vv = ref.step(qq, vv, np.zeros(4))[:2]
+        return qq, vv
+
+    g0 = _gap(*[_swimmer_segments(q[3:])[k] for k in (0, 3)], radii[0], radii[3])
+    assert g0 < -0.01
+    q1, v1 = run(swimmer_raw(), 40)
+    q2, v2 = run(swimmer_raw(self_collision=False), 40)
+    g1 = _gap(*[_swimmer_segments(q1[3:])[k] for k in (0, 3)], radii[0], radii[3])
+    g2 = _gap(*[_swimmer_segments(q2[3:])[k] for k in (0, 3)], radii[0], radii[3])
+    assert np.all(np.isfinite(q1)) and g1 > g0 + 0.01 and g1 > -0.005, (g0, g1)
+    assert abs(g2 - g0) < 1e-9 and np.allclose(v2, 0.0, atol=1e-12)       # at rest in vacuum nothing moves it

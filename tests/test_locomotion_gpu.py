@@ -353,3 +353,44 @@ def test_cheetah_mppi_step_at_the_bench_shape(lam):
           % (lam, err, np.abs(action - mean[0]).max(), w.max()))
     assert err < 1e-6 and (lam < 1 or w.max() < 0.5)
     assert eng.solver_failures() == 0
+
+
+def test_swimmer_self_contact_matches_oracle():
+    """swimmer.xml's segments collide with each other (capsule-capsule, pyramidal friction): the chain curled into a loop -
+    up to three pairs in contact, rows between links of ONE kinematic path - rollouts at 1e-9, f64, and one env step from
+    32 curled states; and the launches that never curl are unchanged by the pairs (bit-identical costs)."""
+    from mjmpc_amd.envs.tree_engine import TreeRolloutEngine
+    from mjmpc_amd.models.swimmer import swimmer_raw
+    from oracle.physics_ref import RefArm
+    raw = swimmer_raw()
+    eng, ref = TreeRolloutEngine(raw, dtype="f64"), RefArm(raw.to_flat())
+    rs = np.random.RandomState(5)
+    worst, touched = 0.0, 0
+    for k in range(32):
+        q0 = np.zeros(7)
+        q0[:3] = rs.uniform(-1, 1, 3)
+        q0[3:] = rs.choice([-1.0, 1.0]) * rs.uniform(1.25, 1.5, 4)
+        v0 = 0.5 * rs.standard_normal(7)
+        mean, noise = np.zeros((1, 4)), rs.standard_normal((16, 1, 4))
+        eng.set_env_state(dict(qpos=q0, qvel=v0))
+        obs, rew, act, done, info, nobs = eng.rollout(16, 1, mean, noise)
+        before = ref.newton_stats()["iters"]
+        o = ref.rollout(q0, v0, np.zeros(3), mean, noise)
+        touched += ref.newton_stats()["iters"] > before
+        worst = max(worst, np.abs(nobs - o[4]).max(), np.abs(rew - o[1]).max())
+    assert touched >= 24 and worst < 1e-9 and eng.solver_failures() == 0, (touched, worst)
+    # a rollout that starts curled and is driven further in
+    q0 = np.array([0.0, 0.0, 0.3, -1.4, -1.45, -1.4, -1.35])
+    mean, noise = -0.5 * np.ones((12, 4)), 0.5 * rs.standard_normal((64, 12, 4))
+    eng.set_env_state(dict(qpos=q0, qvel=np.zeros(7)))
+    obs, rew, act, done, info, nobs = eng.rollout(64, 12, mean, noise)
+    o_obs, o_rew, o_act, _, o_nobs = ref.rollout(q0, np.zeros(7), np.zeros(3), mean, noise)
+    np.testing.assert_allclose(rew, o_rew, rtol=1e-9, atol=1e-9)
+    np.testing.assert_allclose(nobs, o_nobs, rtol=0, atol=1e-9)
+    # straight-ish postures: the pairs are never in contact and change nothing
+    plain = TreeRolloutEngine(swimmer_raw(self_collision=False), dtype="f64")
+    q0, v0, mean, noise = _case("swimmer", 7, 4, 3, 64, 16)
+    for e in (eng, plain):
+        e.set_env_state(dict(qpos=q0, qvel=v0))
+    a, b = eng.rollout(64, 16, mean, noise)[1], plain.rollout(64, 16, mean, noise)[1]
+    assert np.array_equal(a, b)

@@ -9,6 +9,8 @@
         reference tree: throughput of the same controller path on the model we have, flagged)
   cfg4t DMD-MPC, 65536 particles x H64 on the synthetic 24-dof hand-on-an-arm TREE (mjmpc_amd/models/hand24.py,
         tree kernel): pen-v0's SHAPE of work - a branching 24-hinge tree, gravity, fingertip contacts; flagged
+  cfg4p DMD-MPC, 65536 particles x H64 on the synthetic pen-in-hand model (mjmpc_amd/models/pen_hand.py): the hand with
+        position servos, a 6-dof pen, capsule-capsule contacts with friction, pen-v0's orientation reward; flagged
 One step = Controller.optimize() + stepping the real arm on the device, all data resident in HBM.  One JSON line each.
 """
 import argparse
@@ -53,12 +55,18 @@ def _run_arm(name, make, P, H, steps, warmup, dtype, note):
     print(json.dumps({"config": name, "particles": P, "horizon": H, "dtype": dtype, "steps": steps,
                       "ms_per_step": dt / steps * 1e3, "control_loop_hz": steps / dt,
                       "particle_steps_per_s": P * H * ctrl.n_iters * steps / dt,
-                      "launch": "hipGraph replay" if graphed else "eager launches",
+                      "launch": _launch_kind(ctrl, graphed),
                       "final_distance_to_target": float(torch.linalg.norm(nobs[17:20]).item()),
                       "solver_failures": eng.solver_failures(), "note": note}), flush=True)
 
 
-def run_tree(name, make, P, H, steps, warmup, dtype, note, raw_fn=None, env_cls=None):
+def _launch_kind(ctrl, graphed):
+    if not graphed:
+        return "eager launches"
+    return "two kernels per iteration, launched directly" if getattr(ctrl, "_graph", None) == "direct" else "hipGraph replay"
+
+
+def run_tree(name, make, P, H, steps, warmup, dtype, note, raw_fn=None, env_cls=None, noise_scale=0.5):
     """The same loop on the tree engine (the real env kept on the device and captured with the iteration).  With `env_cls`
     (a locomotion model) that class draws the reference's reset noise for the start state."""
     import torch
@@ -74,6 +82,7 @@ def run_tree(name, make, P, H, steps, warmup, dtype, note, raw_fn=None, env_cls=
     if env is not None:
         env.reset(seed=123)
         eng.set_env_state(env.get_env_state())
+        x0 = float(env.get_env_state()["qpos"][0])
     else:
         eng.reset()
     graphed = ctrl._graph_capable()
@@ -110,15 +119,15 @@ def run_tree(name, make, P, H, steps, warmup, dtype, note, raw_fn=None, env_cls=
     out = {"config": name, "particles": P, "horizon": H, "dtype": dtype, "steps": steps,
            "ms_per_step": dt / steps * 1e3, "control_loop_hz": steps / dt,
            "particle_steps_per_s": P * H * ctrl.n_iters * steps / dt, "rollout_kernel_ms": kern_ms,
-           "launch": "hipGraph replay" if graphed else "eager launches", "dofs": nv, "frame_skip": raw.frame_skip,
+           "launch": _launch_kind(ctrl, graphed), "dofs": nv, "frame_skip": raw.frame_skip,
            "solver_failures": eng.solver_failures(), "note": note}
     if env is not None:
-        out["forward_progress_m"] = float(state["qpos"][0])
+        out["forward_progress_m"] = float(state["qpos"][0]) - x0       # since the reset (whose noise moves qpos[0] too)
         # the CPU restatement on this host's cores, same model and start state, through bench.py's cpu_baseline leg
         # (a bounded sample; for scale, not a target)
         sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
         import bench
-        cb = bench.cpu_baseline(P, H, 4.0, raw=raw, qpos=state["qpos"], qvel=state["qvel"], noise_scale=0.5)
+        cb = bench.cpu_baseline(P, H, 4.0, raw=raw, qpos=state["qpos"], qvel=state["qvel"], noise_scale=noise_scale)
         out["cpu_baseline"] = {k: cb[k] for k in ("value", "unit", "cores", "kind", "single_thread_value")}
     else:
         out["final_distance_to_target"] = float(np.linalg.norm(nobs[2 * nv + 3:2 * nv + 6]))
@@ -133,6 +142,7 @@ def main():
     ap.add_argument("--tree-particles", type=int, default=65536)
     ap.add_argument("--only-tree", action="store_true")
     ap.add_argument("--only-hand", action="store_true", help="of the tree configurations, only the 24-dof hand")
+    ap.add_argument("--pen", action="store_true", help="also cfg4p: the pen-in-hand model at the same size (about 1 s per step)")
     ap.add_argument("--only", default="", help="run only the arm configurations whose name starts with this (cfg1, cfg3, cfg4)")
     args = ap.parse_args()
     from mjmpc_amd.control import CEM, DMDMPC, MPPI
@@ -174,12 +184,19 @@ def main():
             run_tree("loco %s MPPI 4096xH32 (reference-registered env over its vendored XML; no reference experiment file)" % nm,
                      lambda e, P, H, A=A: MPPI(init_cov=0.3, base_action="null", lam=0.2, step_size=1.0, alpha=1, gamma=1.0,
                                                filter_coeffs=[0.25, 0.8, 0.0], **dict(kw(e, P, H), d_action=A)),
-                     4096, 32, max(10, args.steps // 2), 2, args.dtype, "tree engine, full instantiation", raw_fn, env_cls)
+                     4096, 32, max(10, args.steps // 2), 2, args.dtype, "tree engine, full instantiation", raw_fn, env_cls,
+                     noise_scale=float(np.sqrt(0.3)))
     run_tree("cfg4t DMD-MPC 65536xH64 on the synthetic 24-dof hand tree (pen-v0 assets absent)",
              lambda e, P, H: DMDMPC(init_cov=0.3, beta=0.1, base_action="null", lam=0.1, step_size=1.0, gamma=1.0,
                                     update_cov=False, cov_type="diagonal", filter_coeffs=[0.25, 0.8, 0.0], **kw24(e, P, H)),
              args.tree_particles, 64, max(3, args.steps // 10), 1, args.dtype,
              "synthetic tree with pen-v0's shape of work (24 hinges, gravity, 5 fingertip contacts); throughput only")
+    if args.pen:        # bench.py has this workload (servo set points as the nominal control, 'repeat' shift): its line
+        import subprocess
+        root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+        subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--workload", "pen_hand", "--controller", "dmd",
+                        "--particles", str(args.tree_particles), "--horizon", "64", "--steps", str(max(3, args.steps // 10)),
+                        "--warmup", "1", "--process-warmup", "0", "--no-cpu-baseline", "--dtype", args.dtype], check=True)
 
 
 if __name__ == "__main__":
