@@ -96,9 +96,10 @@ constexpr int a_vec(int DP, int PL) { return (row_stride(DP) * PL > 12 * PL ? ro
 // contact Jacobian rows [NS][NJ][DP], PATH-INDEXED like the matrix rows: a contact point on link L moves only with the
 // dofs on L's path to the root, entry c belongs to L's ancestor at distance c (a quarter of a [32]-lane row at DP = 8)
 constexpr int a_jc(int DP, int PL) { return a_vec(DP, PL) + PL; }
-constexpr int CS = 12;      // per contact point: sphere centre (lean instantiation) / contact point (full)[3], dist, D, aref
-                            // (normal part), mu B Jt1.v, mu B Jt2.v, [3] capsule axis = hint for the contact frame
-                            // (sphere-plane) / contact normal (geom-geom), -
+constexpr int CS = 15;      // per contact point: sphere centre (lean instantiation) / contact point (full)[3], dist, D, aref
+                            // (normal part), mu B Jt1.v, mu B Jt2.v, [8:11] contact normal (geom-geom; after the Newton
+                            // iteration: the point's force sums on Jn, mu Jt1, mu Jt2), [11:14] first tangent of the
+                            // contact frame (mju_makeFrame from the normal and the capsule axis), -
 constexpr int a_cs(int DP, int NS, int NJ, int PL) { return a_jc(DP, PL) + NS * NJ * DP; }
 constexpr int a_misc(int DP, int NS, int NJ, int PL) { return a_cs(DP, NS, NJ, PL) + NS * CS; }   // site[3]
 constexpr int a_row2(int DP, int NS, int NJ, int PL) { return a_misc(DP, NS, NJ, PL) + 8; }     // the Euler matrix's factor
@@ -159,6 +160,20 @@ __device__ __forceinline__ T sum_lanes(T x) {
     return PL == 32 ? add_rows(x) : x;      // (16 lanes per particle: a particle is one DPP row)
 }
 
+// bitwise OR over the lanes of a particle, result in every lane (same butterfly as sum_lanes)
+template <int PL>
+__device__ __forceinline__ unsigned or_lanes(unsigned x) {
+    x |= (unsigned)__builtin_amdgcn_update_dpp(0, (int)x, 0xB1, 0xF, 0xF, false);
+    x |= (unsigned)__builtin_amdgcn_update_dpp(0, (int)x, 0x4E, 0xF, 0xF, false);
+    x |= (unsigned)__builtin_amdgcn_update_dpp(0, (int)x, 0x141, 0xF, 0xF, false);
+    x |= (unsigned)__builtin_amdgcn_update_dpp(0, (int)x, 0x140, 0xF, 0xF, false);
+    if (PL == 32) {
+        const auto r = __builtin_amdgcn_permlane16_swap(x, x, false, false);
+        x = r[0] | r[1];
+    }
+    return x;
+}
+
 struct Topo {       // my link's place in the tree (registers)
     int parent, subsize, jumps;
     int anc[5];     // my ancestor at distance 2^k (pointer jumping), -1 beyond the root; only ever indexed by an
@@ -216,6 +231,24 @@ __device__ __forceinline__ void subtree_sum(T* x, const Topo& tp, T* X, int l) {
     TSYNC();
 #pragma unroll
     for (int c = 0; c < NC; ++c) x[c] = acc[c];
+}
+
+// first tangent of the contact frame: mju_makeFrame's rule - the hint (capsule axis) made orthogonal to the normal, or,
+// without a usable hint, the y (else z) axis
+template <typename T>
+__device__ __forceinline__ void frame_tangent(const T* nrm, const T* hint, T* t1) {
+    T ax3[3] = {hint[0], hint[1], hint[2]};
+    if (dot3(ax3, ax3) < T(0.25)) {
+        const bool yy = nrm[1] < T(0.5) && nrm[1] > T(-0.5);
+        ax3[0] = T(0);
+        ax3[1] = yy ? T(1) : T(0);
+        ax3[2] = yy ? T(0) : T(1);
+    }
+    const T pr = dot3(nrm, ax3);
+    for (int k = 0; k < 3; ++k) t1[k] = ax3[k] - pr * nrm[k];
+    const T nn = dot3(t1, t1);
+    if (nn < T(1e-30)) { t1[0] = T(1); t1[1] = T(0); t1[2] = T(0); }
+    else { const T inv = rcp_(sqrt_(nn)); for (int k = 0; k < 3; ++k) t1[k] *= inv; }
 }
 
 // MuJoCo mj_makeImpedance + mj_referenceConstraint for one scalar row (r = pos - margin); constants from LDS
@@ -393,6 +426,17 @@ __device__ __forceinline__ void dense_row(const T* h, const int* AT, T* TILE, in
     TSYNC();
 }
 
+// r[j] += wn (lane j's jn) + w1 (lane j's j1) + w2 (lane j's j2): the contribution of one contact point to my dense row
+template <int J, int DN, bool FRIC, typename T>
+__device__ __forceinline__ void dense_contact(T* r, T jn, T j1, T j2, T wn, T w1, T w2) {
+    fma_bcast<J>(r[J], jn, wn);
+    if constexpr (FRIC) {
+        fma_bcast<J>(r[J], j1, w1);
+        fma_bcast<J>(r[J], j2, w2);
+    }
+    if constexpr (J + 1 < DN) dense_contact<J + 1, DN, FRIC>(r, jn, j1, j2, wn, w1, w2);
+}
+
 // in: r[j] = H[l][j].  out: r[k] = L[l][k] for k < l, r[j] = D_l L[j][l] for j > l (what the backward solve wants),
 // dinv = 1 / D_l.  Lanes past the matrix (l >= DN, or unit rows of spare lanes) ride along untouched.
 template <int K, int DN, typename T>
@@ -443,7 +487,9 @@ __device__ __forceinline__ T dense_solve(const T* r, T dinv, T b, int l) {
 
 // waves per SIMD the register allocation aims at: the lean kernels for short paths fit three (f32) / two (f64)
 // workgroups' LDS on a CU
-constexpr int min_waves(int scalar_bytes, int DP, bool fric) { return (DP <= 8 && !fric) ? (scalar_bytes == 4 ? 3 : 2) : 1; }
+constexpr int min_waves(int scalar_bytes, int DP, bool fric) {
+    return (DP <= 8 && !fric) ? (scalar_bytes == 4 ? 3 : 2) : ((DP <= 8 && scalar_bytes == 4) ? 2 : 1);
+}
 
 // PL = lanes per particle: 32, or 16 for models of up to 16 dofs (four particles per wavefront, a particle = one DPP row)
 // DN > 0 (with PL = 16): the dense in-register factorisation of a matrix of up to DN dofs instead of the tree-sparse one
@@ -658,10 +704,10 @@ __global__ __launch_bounds__(64 * wg_waves(DP, FRIC, sizeof(T), PL), min_waves(s
                         const T cdist = dot3(ctr, pn) - M[T_PLANE_D] - sp[4];
                         cs[3] = cdist;
                         ci_mine = cdist < sp[5];            // mj_collision: included while dist < margin
-                        if (FRIC) {                         // the contact point, and the capsule axis the frame is aligned with
+                        if (FRIC) {                         // the contact point, and the frame aligned with the capsule axis
                             for (int k = 0; k < 3; ++k) cs[k] = ctr[k] - pn[k] * (sp[4] + T(0.5) * cdist);
                             mv3(Rl, sp + 8, tv);
-                            for (int k = 0; k < 3; ++k) cs[8 + k] = tv[k];
+                            frame_tangent(pn, tv, cs + 11);
                         } else {
                             for (int k = 0; k < 3; ++k) cs[k] = ctr[k];
                         }
@@ -705,11 +751,15 @@ __global__ __launch_bounds__(64 * wg_waves(DP, FRIC, sizeof(T), PL), min_waves(s
                         const T len = sqrt_(dot3(diff, diff));
                         const T inv = len > T(1e-14) ? T(1) / len : T(0);
                         const T cdist = len - sp[4] - sp[17];
+                        T nv3[3];
                         for (int k = 0; k < 3; ++k) {
                             const T nk = diff[k] * inv;
+                            nv3[k] = nk;
                             cs[8 + k] = nk;
                             cs[k] = c2[k] + nk * (sp[17] + T(0.5) * cdist);
                         }
+                        const T zero3[3] = {T(0), T(0), T(0)};
+                        frame_tangent(nv3, zero3, cs + 11);
                         cs[3] = cdist;
                         ci_mine = len > T(1e-14) && cdist < sp[5];
                     }
@@ -886,9 +936,8 @@ __global__ __launch_bounds__(64 * wg_waves(DP, FRIC, sizeof(T), PL), min_waves(s
             for (unsigned um = ucinst; um; um &= um - 1) {
                 const int s = __builtin_ctz(um);
                 const T* sp = M + T_SPH + s * TREE_SPH_STRIDE;
-                T* cs = X + A_CS + s * CS;
+                const T* cs = X + A_CS + s * CS;
                 T* jrow = X + A_JC + s * NJ * DP;
-                const T cdist = cs[3];
                 const bool ci = (cinst >> s) & 1u;
                 const int dsl = (int)sp[11], oi = own_idx(s);
                 // velocity of the contact point per unit joint velocity, from the motion subspace about the world
@@ -905,50 +954,69 @@ __global__ __launch_bounds__(64 * wg_waves(DP, FRIC, sizeof(T), PL), min_waves(s
                     const int lA = (int)sp[0], lB = (int)sp[13];
                     side = T((lA >= l && lA < l + tp.subsize) ? 1 : 0) - T((lB >= l && lB < l + tp.subsize) ? 1 : 0);
                 } else {
-                    for (int k = 0; k < 3; ++k) r[k] = cs[k] - pn[k] * (sp[4] + T(0.5) * cdist);
+                    for (int k = 0; k < 3; ++k) r[k] = cs[k] - pn[k] * (sp[4] + T(0.5) * cs[3]);
                 }
                 cross3(sw, r, g);
                 for (int k = 0; k < 3; ++k) g[k] += sv[k];
                 const T jc = oi >= 0 ? (FRIC ? side * dot3(nrm, g) : dot3(pn, g)) : T(0);
                 if (oi >= 0) jrow[oi] = jc;
                 if (ci && l > dsl && l < DP) jrow[l] = T(0);        // past the root: read by shorter paths' lanes
-                const T jv = sum_lanes<PL>(jc * v);
-                const T mu = FRIC ? sp[7] : T(0);
-                T Dc, arc, mb1 = T(0), mb2 = T(0);
-                if (FRIC) {
-                    T ax3[3] = {cs[8], cs[9], cs[10]}, t1[3], t2[3];
-                    if (sp[12] != T(0)) { ax3[0] = T(0); ax3[1] = T(0); ax3[2] = T(0); }     // (geom-geom: that slot holds the normal)
-                    if (dot3(ax3, ax3) < T(0.25)) {
-                        const bool yy = nrm[1] < T(0.5) && nrm[1] > T(-0.5);
-                        ax3[0] = T(0);
-                        ax3[1] = yy ? T(1) : T(0);
-                        ax3[2] = yy ? T(0) : T(1);
+                if constexpr (!FRIC) {      // (one frictionless row per point: a lane sum is cheaper than the walk below)
+                    const T jv = sum_lanes<PL>(jc * v);
+                    T Dc, arc;
+                    tree_row_params(M + T_SOL_K, cs[3] - sp[5], sp[6], jv, Dc, arc);
+                    if (l == 0 && ci) {
+                        X[A_CS + s * CS + 4] = Dc;
+                        X[A_CS + s * CS + 5] = arc;
                     }
-                    const T pr = dot3(nrm, ax3);
-                    for (int k = 0; k < 3; ++k) t1[k] = ax3[k] - pr * nrm[k];
-                    const T nn = dot3(t1, t1);
-                    if (nn < T(1e-30)) { t1[0] = T(1); t1[1] = T(0); t1[2] = T(0); }
-                    else { const T inv = rcp_(sqrt_(nn)); for (int k = 0; k < 3; ++k) t1[k] *= inv; }
+                }
+                if (FRIC) {
+                    // the contact frame's tangents: the first from the geometry stage (frame_tangent), t2 = n x t1
+                    const T t1[3] = {cs[11], cs[12], cs[13]};
+                    T t2[3];
                     cross3(nrm, t1, t2);
-                    const bool fr = oi >= 0 && mu > T(0);
+                    const bool fr = oi >= 0 && sp[7] > T(0);
                     const T j1 = fr ? side * dot3(t1, g) : T(0), j2 = fr ? side * dot3(t2, g) : T(0);
                     if (oi >= 0) { jrow[DP + oi] = j1; jrow[2 * DP + oi] = j2; }
                     if (ci && l > dsl && l < DP) { jrow[DP + l] = T(0); jrow[2 * DP + l] = T(0); }
-                    mb1 = mu * M[T_SOL_B] * sum_lanes<PL>(j1 * v);
-                    mb2 = mu * M[T_SOL_B] * sum_lanes<PL>(j2 * v);
                 }
-                tree_row_params(M + T_SOL_K, cdist - sp[5], sp[6] * (T(1) + mu * mu), jv, Dc, arc);
-                if (mu > T(0)) Dc *= T(0.5) * rcp_(mu * mu);
-                if (l == 0 && ci) {
+            }
+            // ... then, one point per lane: the point's velocity along its three Jacobians (a walk along its path, the joint
+            // velocities through the broadcast vector) and the row parameters D, aref (cs[4:8])
+            if (FRIC && ucinst != 0) {
+                VEC[l] = v;
+                TSYNC();
+                if (l < NS && ((cinst >> l) & 1u)) {
+                    const T* sp = M + T_SPH + l * TREE_SPH_STRIDE;
+                    const T* jrow = X + A_JC + l * NJ * DP;
+                    T* cs = X + A_CS + l * CS;
+                    const int link = (int)sp[0], dsl = (int)sp[11];
+                    T jv = T(0), j1v = T(0), j2v = T(0);
+#pragma unroll
+                    for (int c = 0; c < DP; ++c) {
+                        if (c <= dsl) {
+                            const T xv = VEC[AT[c * PL + link]];
+                            jv += jrow[c] * xv;
+                            if (FRIC) { j1v += jrow[DP + c] * xv; j2v += jrow[2 * DP + c] * xv; }
+                        }
+                    }
+                    const T mu = FRIC ? sp[7] : T(0);
+                    T Dc, arc;
+                    tree_row_params(M + T_SOL_K, cs[3] - sp[5], sp[6] * (T(1) + mu * mu), jv, Dc, arc);
+                    if (mu > T(0)) Dc *= T(0.5) * rcp_(mu * mu);
                     cs[4] = Dc;
                     cs[5] = arc;
-                    if (FRIC) { cs[6] = mb1; cs[7] = mb2; }
+                    if (FRIC) { cs[6] = mu * M[T_SOL_B] * j1v; cs[7] = mu * M[T_SOL_B] * j2v; }
                 }
             }
             TSYNC();
             const bool any_rows = !(TREE_SKIP & 1) && __any(inst || cinst != 0);
             T qfrc_c = T(0);
             T erow[MERGE ? DP : 1];      // factor of the Euler matrix when it was computed beside the first Newton factor
+            // dense path: my row of M as a DENSE row, once per substep - the Newton matrices and the Euler matrix are this
+            // row plus diagonal terms plus broadcast products of the contact Jacobians (no tile round trip per matrix)
+            T md[DN > 0 ? DN : 1];
+            if constexpr (DN > 0) dense_row<DP, DN, PL>(mrow, AT, ROW, l, md);
             clk.mark(3);
             clk.count(8, 1);
             clk.count(9, __popc(cinst));
@@ -959,42 +1027,79 @@ __global__ __launch_bounds__(64 * wg_waves(DP, FRIC, sizeof(T), PL), min_waves(s
                 aref = inst ? aref : T(0);
                 // rows of contact point s with friction mu (uniform per particle): all NR, else one
                 auto rows_of = [&](int s) -> unsigned { return (FRIC && M[T_SPH + s * TREE_SPH_STRIDE + 7] > T(0)) ? 15u : 1u; };
-                // residuals J_r a - aref_r of the rows of contact point s, given a (one entry per lane)
-                auto residuals = [&](int s, T xa_, T* res) {
-                    const T* cs = X + A_CS + s * CS;
-                    const T* jrow = X + A_JC + s * NJ * DP;
-                    const int oi = own_idx(s);
-                    const T an = sum_lanes<PL>(oi >= 0 ? jrow[oi] * xa_ : T(0));
+                // POINT-PARALLEL residuals: lane s owns contact point s.  The solution goes through the broadcast vector; the
+                // owner walks the point's path-indexed Jacobians (entry c belongs to the ancestor at distance c of the
+                // point's link in the elimination tree) - one pass for all points instead of three lane sums per point.
+                const bool my_pt = l < NS && ((cinst >> l) & 1u);
+                auto point_residuals = [&](T xa_, T* res) {
+                    VEC[l] = xa_;
+                    TSYNC();
+                    T an = T(0), a1 = T(0), a2 = T(0);
+                    if (my_pt) {
+                        const T* sp = M + T_SPH + l * TREE_SPH_STRIDE;
+                        const T* jrow = X + A_JC + l * NJ * DP;
+                        const int link = (int)sp[0], dsl = (int)sp[11];
+#pragma unroll
+                        for (int c = 0; c < DP; ++c) {
+                            if (c <= dsl) {
+                                const T xv = VEC[AT[c * PL + link]];
+                                an += jrow[c] * xv;
+                                if (FRIC) { a1 += jrow[DP + c] * xv; a2 += jrow[2 * DP + c] * xv; }
+                            }
+                        }
+                    }
+                    const T* cs = X + A_CS + (l < NS ? l : 0) * CS;
                     res[0] = an - cs[5];
                     if (FRIC) {
-                        const T mu = M[T_SPH + s * TREE_SPH_STRIDE + 7];
-                        const T a1 = mu * sum_lanes<PL>(oi >= 0 ? jrow[DP + oi] * xa_ : T(0));
-                        const T a2 = mu * sum_lanes<PL>(oi >= 0 ? jrow[2 * DP + oi] * xa_ : T(0));
+                        const T mu = M[T_SPH + (l < NS ? l : 0) * TREE_SPH_STRIDE + 7];
+                        a1 *= mu;
+                        a2 *= mu;
                         res[0] = an + a1 - (cs[5] - cs[6]);
                         res[1 % NR] = an - a1 - (cs[5] + cs[6]);
                         res[2 % NR] = an + a2 - (cs[5] - cs[7]);
                         res[3 % NR] = an - a2 - (cs[5] + cs[7]);
                         if (!(mu > T(0))) res[0] = an - cs[5];
                     }
+                    TSYNC();
                 };
                 // the active set a solution belongs to next: a row stays / becomes active while its residual is negative
                 auto next_set = [&](T xa_, mask_t cur) -> mask_t {
-                    mask_t nxt = 0;
-                    for (unsigned um = ucinst; um; um &= um - 1) {
-                        const int s = __builtin_ctz(um);
-                        T res[NR];
-                        residuals(s, xa_, res);
-                        const unsigned rows = rows_of(s);
+                    if constexpr (!FRIC) {
+                        mask_t nxt = 0;
+                        for (unsigned um = ucinst; um; um &= um - 1) {
+                            const int s = __builtin_ctz(um);
+                            const int oi = own_idx(s);
+                            const T ar5 = X[A_CS + s * CS + 5];
+                            const T arr = sum_lanes<PL>(oi >= 0 ? X[A_JC + s * NJ * DP + oi] * xa_ : T(0)) - ar5;
+                            const T bc = sizeof(T) == 4 ? T(2e-5) * (fabs(ar5) + fabs(arr + ar5) + T(1)) : T(0);
+                            const bool was = (cur >> s) & 1u;
+                            if (((cinst >> s) & 1u) && (was ? !(arr > bc) : (arr < -bc))) nxt |= mask_t(1) << s;
+                        }
+                        return nxt;
+                    }
+                    T res[NR];
+                    point_residuals(xa_, res);
+                    unsigned nb = 0;
+                    if (my_pt) {
+                        const unsigned rows = rows_of(l);
+                        const T ar5 = X[A_CS + l * CS + 5];
+#pragma unroll
                         for (int r = 0; r < NR; ++r) {
-                            if (!((rows >> r) & 1u)) continue;
                             const T arr = res[r];
                             // f32: a row whose residual is within rounding of zero keeps its state (as in arm_rollout.hip)
-                            const T bc = sizeof(T) == 4 ? T(2e-5) * (fabs(X[A_CS + s * CS + 5]) + fabs(arr + X[A_CS + s * CS + 5]) + T(1)) : T(0);
-                            const bool was = (cur >> (s * NR + r)) & 1u;
-                            if (((cinst >> s) & 1u) && (was ? !(arr > bc) : (arr < -bc))) nxt |= mask_t(1) << (s * NR + r);
+                            const T bc = sizeof(T) == 4 ? T(2e-5) * (fabs(ar5) + fabs(arr + ar5) + T(1)) : T(0);
+                            const bool was = (cur >> (l * NR + r)) & 1u;
+                            if (((rows >> r) & 1u) && (was ? !(arr > bc) : (arr < -bc))) nb |= 1u << r;
                         }
                     }
-                    return nxt;
+                    // every lane gets the particle's mask: bit s * NR + r, an OR over the owners' nibbles
+                    if constexpr (NR == 1) {
+                        return (mask_t)or_lanes<PL>(nb << (l & 31));
+                    } else {
+                        const unsigned lo = or_lanes<PL>(l < 8 ? nb << (4 * l) : 0u);
+                        const unsigned hi = or_lanes<PL>((l >= 8 && l < 16) ? nb << (4 * (l - 8)) : 0u);
+                        return (mask_t)(((unsigned long long)hi << 32) | lo);
+                    }
                 };
                 // initial active set: a row that existed in the previous substep keeps its state, a new row is active
                 bool actv = inst && ((lim_mem & 1) ? (lim_mem & 2) != 0 : true);
@@ -1012,10 +1117,16 @@ __global__ __launch_bounds__(64 * wg_waves(DP, FRIC, sizeof(T), PL), min_waves(s
                 clk.lap(-1);
                 for (int it = 0; it < TREE_MAXIT; ++it) {
                     T hrow[DP];
+                    T hd[DN > 0 ? DN : 1], hdinv = T(1);        // DN > 0: my dense row of H, then of its factor
+                    if constexpr (DN > 0) {
 #pragma unroll
-                    for (int c = 0; c < DP; ++c) hrow[c] = mrow[c];
+                        for (int j = 0; j < DN; ++j) hd[j] = md[j] + ((j == l && actv) ? D : T(0));
+                    } else {
+#pragma unroll
+                        for (int c = 0; c < DP; ++c) hrow[c] = mrow[c];
+                        hrow[0] += actv ? D : T(0);
+                    }
                     T rhs = tau + (actv ? D * sig * aref : T(0));
-                    hrow[0] += actv ? D : T(0);
                     for (unsigned um = ucinst; um; um &= um - 1) {
                         const int s = __builtin_ctz(um);
                         const unsigned bits = (unsigned)(cact >> (s * NR)) & ((1u << NR) - 1u);
@@ -1029,9 +1140,12 @@ __global__ __launch_bounds__(64 * wg_waves(DP, FRIC, sizeof(T), PL), min_waves(s
                         const T na = T(__popc(bits));
                         T wn = Dc * na * jl, w1 = T(0), w2 = T(0);
                         T rsum = na * cs[5];
+                        T t1l = T(0), t2l = T(0);           // my entries of the two tangent Jacobians
                         if (FRIC) {
                             const T mu = M[T_SPH + s * TREE_SPH_STRIDE + 7];
-                            const T j1 = oi >= 0 ? mu * jrow[DP + oi] : T(0), j2 = oi >= 0 ? mu * jrow[2 * DP + oi] : T(0);
+                            t1l = oi >= 0 ? jrow[DP + oi] : T(0);
+                            t2l = oi >= 0 ? jrow[2 * DP + oi] : T(0);
+                            const T j1 = mu * t1l, j2 = mu * t2l;
                             const T n1 = T(__popc(bits & 3u)), s1 = T((int)(bits & 1u) - (int)((bits >> 1) & 1u));
                             const T n2 = T(__popc(bits & 12u)), s2 = T((int)((bits >> 2) & 1u) - (int)((bits >> 3) & 1u));
                             wn += Dc * (s1 * j1 + s2 * j2);
@@ -1041,9 +1155,12 @@ __global__ __launch_bounds__(64 * wg_waves(DP, FRIC, sizeof(T), PL), min_waves(s
                             rhs += Dc * (j1 * (s1 * cs[5] - n1 * cs[6]) + j2 * (s2 * cs[5] - n2 * cs[7]));
                         }
                         rhs += Dc * jl * rsum;
-                        // a contact row couples only dofs on one path: the pattern holds, and my ancestor at distance c
-                        // sits c entries further along the point's rows (zeros past the root)
-                        if (oi >= 0) {
+                        if constexpr (DN > 0) {
+                            // dense row: H[l][j] += wn Jn[j] + w1 Jt1[j] + w2 Jt2[j], lane j's entries by DPP broadcast
+                            dense_contact<0, DN, FRIC>(hd, jl, t1l, t2l, wn, w1, w2);
+                        } else if (oi >= 0) {
+                            // a contact row couples only dofs on one path: the pattern holds, and my ancestor at distance c
+                            // sits c entries further along the point's rows (zeros past the root)
 #pragma unroll
                             for (int c = 0; c < DP; ++c) {
                                 if (oi + c < DP) {
@@ -1056,9 +1173,7 @@ __global__ __launch_bounds__(64 * wg_waves(DP, FRIC, sizeof(T), PL), min_waves(s
                     }
                     TSYNC();
                     clk.lap(12);
-                    T hd[DN > 0 ? DN : 1], hdinv = T(1);        // DN > 0: my dense row of H, then of its factor
                     if constexpr (DN > 0) {
-                        dense_row<DP, DN, PL>(hrow, AT, ROW, l, hd);
                         dense_factor<DN>(hd, hdinv, l);
                     } else if (MERGE && it == 0 && !(TREE_SKIP & 2)) {      // ... and the Euler matrix M + h B rides along (consumed in step 6)
 #pragma unroll
@@ -1138,29 +1253,51 @@ __global__ __launch_bounds__(64 * wg_waves(DP, FRIC, sizeof(T), PL), min_waves(s
                 cinst_mem = cinst;
                 cact_mem = cact;
                 qfrc_c = actv ? -D * (sig * xa - aref) * sig : T(0);
-                for (unsigned um = ucinst; um; um &= um - 1) {
-                    const int s = __builtin_ctz(um);
-                    const unsigned bits = (unsigned)(cact >> (s * NR)) & ((1u << NR) - 1u);
-                    if (!__any(bits != 0)) continue;
+                if constexpr (!FRIC) {
+                    for (unsigned um = ucinst; um; um &= um - 1) {
+                        const int s = __builtin_ctz(um);
+                        if (!__any((cact >> s) & 1u)) continue;
+                        const int oi = own_idx(s);
+                        const T jl = oi >= 0 ? X[A_JC + s * NJ * DP + oi] : T(0);
+                        const T arr = sum_lanes<PL>(jl * xa) - X[A_CS + s * CS + 5];
+                        qfrc_c += ((cact >> s) & 1u) ? -X[A_CS + s * CS + 4] * arr * jl : T(0);
+                    }
+                } else if (ucinst != 0) {
                     T res[NR];
-                    residuals(s, xa, res);
-                    const T* jrow = X + A_JC + s * NJ * DP;
-                    const int oi = own_idx(s);
-                    const T Dc = X[A_CS + s * CS + 4], jl = oi >= 0 ? jrow[oi] : T(0);
-                    T fn = T(0), f1 = T(0), f2 = T(0);      // sum of row forces on Jn, mu Jt1, mu Jt2
-                    for (int r = 0; r < NR; ++r) {
-                        const T fr = ((bits >> r) & 1u) ? -Dc * res[r] : T(0);
-                        fn += fr;
-                        if (FRIC) {
-                            if (r < 2) f1 += (r & 1) ? -fr : fr;
-                            else f2 += (r & 1) ? -fr : fr;
+                    point_residuals(xa, res);
+                    if (my_pt) {        // my point's row forces, summed per Jacobian: on Jn, mu Jt1, mu Jt2
+                        const unsigned bits = (unsigned)(cact >> (l * NR)) & ((1u << NR) - 1u);
+                        T* cs = X + A_CS + l * CS;
+                        const T Dc = cs[4];
+                        T fn = T(0), f1 = T(0), f2 = T(0);
+#pragma unroll
+                        for (int r = 0; r < NR; ++r) {
+                            const T fr = ((bits >> r) & 1u) ? -Dc * res[r] : T(0);
+                            fn += fr;
+                            if (FRIC) {
+                                if (r < 2) f1 += (r & 1) ? -fr : fr;
+                                else f2 += (r & 1) ? -fr : fr;
+                            }
+                        }
+                        const T mu = FRIC ? M[T_SPH + l * TREE_SPH_STRIDE + 7] : T(0);
+                        cs[8] = fn;
+                        cs[9] = mu * f1;
+                        cs[10] = mu * f2;
+                    }
+                    TSYNC();
+                    for (unsigned um = ucinst; um; um &= um - 1) {
+                        const int s = __builtin_ctz(um);
+                        const unsigned bits = (unsigned)(cact >> (s * NR)) & ((1u << NR) - 1u);
+                        if (!__any(bits != 0)) continue;
+                        const int oi = own_idx(s);
+                        if (oi >= 0 && bits) {
+                            const T* jrow = X + A_JC + s * NJ * DP;
+                            const T* cs = X + A_CS + s * CS;
+                            qfrc_c += jrow[oi] * cs[8];
+                            if (FRIC) qfrc_c += jrow[DP + oi] * cs[9] + jrow[2 * DP + oi] * cs[10];
                         }
                     }
-                    qfrc_c += jl * fn;
-                    if (FRIC) {
-                        const T mu = M[T_SPH + s * TREE_SPH_STRIDE + 7];
-                        if (oi >= 0) qfrc_c += mu * (jrow[DP + oi] * f1 + jrow[2 * DP + oi] * f2);
-                    }
+                    TSYNC();
                 }
             } else {
                 lim_mem = 0;
@@ -1176,9 +1313,9 @@ __global__ __launch_bounds__(64 * wg_waves(DP, FRIC, sizeof(T), PL), min_waves(s
                 } else if (MERGE && any_rows) {
                     qacc = tree_solve<DP, PL>(erow, tau + qfrc_c, ELIM, AT, ROW2, VEC, l, n_rounds, depth, max_depth);
                 } else if constexpr (DN > 0) {
-                    mrow[0] += dof ? h * damping : T(0);
                     T ed[DN > 0 ? DN : 1], edinv;
-                    dense_row<DP, DN, PL>(mrow, AT, ROW, l, ed);
+#pragma unroll
+                    for (int j = 0; j < DN; ++j) ed[j] = md[j] + ((j == l && dof) ? h * damping : T(0));
                     dense_factor<DN>(ed, edinv, l);
                     qacc = dense_solve<DN>(ed, edinv, tau + qfrc_c, l);
                 } else {
@@ -1285,7 +1422,7 @@ hipError_t launch_tree_rollout(const T* model, int n_model_shards, int max_path,
         if (max_path <= 8) MJMPC_TREE_LAUNCH(8, 8, false, 32)
         else if (max_path <= 16) MJMPC_TREE_LAUNCH(16, 8, false, 32)
         else MJMPC_TREE_LAUNCH(32, 8, false, 32)
-    } else if (nv <= 16 && !(sizeof(T) == 4 && P <= 4096 && P > 1)) {    // (f32 at <= 4096 particles: two half-empty waves per SIMD hide more latency)
+    } else if (nv <= 16) {
         // (16 lanes per particle: the dense in-register factorisation, sized for the model)
         if (max_path <= 8 && nv <= 8) MJMPC_TREE_LAUNCH_D(8, 16, true, 16, 8)
         else if (max_path <= 8 && nv <= 12) MJMPC_TREE_LAUNCH_D(8, 16, true, 16, 12)

@@ -43,6 +43,13 @@ def run(P, comm, mono):
     c.enable_graph(post_step=eng.step_state, mono=mono)
     acts = [c.optimize({})[0] for _ in range(6)]
     torch.cuda.synchronize()
+    # ... and once more after a reset (bench.py resets controller and env behind its process warm-up: the iteration is
+    # captured a second time, collective included)
+    c.reset()
+    eng.set_env_state(dict(qp=np.zeros(7), qv=np.zeros(7), target_pos=eng.model.target_default.copy()))
+    again = [c.optimize({})[0] for _ in range(6)]
+    torch.cuda.synchronize()
+    assert np.abs(np.array(again) - np.array(acts)).max() < 1e-12, "the closed loop after reset() differs"
     return np.array(acts), c
 
 
