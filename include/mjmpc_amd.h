@@ -131,6 +131,18 @@ int mjmpc_arm_mppi_step(mjmpc_arm_t h, int dtype, int64_t P, int H, const double
                         int shift_mode, double* d_action_out, double* h_action_slots, double* d_record, int env_step,
                         void* d_step_cost, void* d_step_next_obs, void* d_costs, void* d_actions, double* d_q0, void* stream);
 
+/* Sharded runs (one rank per GPU): what follows the all-gather of the per-GPU records that mjmpc_arm_mppi_step left
+ * (d_record != NULL) - ONE launch that merges the n_records gathered records [max | S | W[H*A]] in rank order (bit-identical
+ * on every rank), updates the mean (mppi.py:69-82) into d_mean_out (a buffer of its own) already shifted
+ * (olgaussian_mpc.py:116-129), publishes the action into slot (step & 1) of h_action_slots (mapped pinned [2][A+1], value
+ * then step count), advances the step counter and, with env_step != 0, steps the device-resident real env.  The parameter
+ * block of this call lives in device memory and is rewritten (stream-ordered) only when the arguments change: a captured
+ * graph that holds this launch stays valid as long as no later call passes different arguments. */
+int mjmpc_arm_mppi_combine(mjmpc_arm_t h, int dtype, const double* d_records, int n_records, int H, const double* d_mean,
+                           double* d_mean_out, int64_t* d_step_counter, double step_size, int shift_mode,
+                           double* d_action_out, double* h_action_slots, int env_step, void* d_step_cost,
+                           void* d_step_next_obs, void* stream);
+
 /* env.step of the "real" environment kept on the device (examples/example_mpc.py:168 ->
  * Reacher7DOFEnv.step, reacher_env.py:29-39): advances the engine state IN PLACE by one env step
  * under d_action (float64 [A]), writes the step cost (= -reward, dtype[1]) and, if not NULL, the

@@ -140,6 +140,18 @@ class Controller(ABC):
 _SHIFT_MODES = {'null': 0, 'repeat': 1, 'random': 2}
 
 
+class _AlternatingGraphs:
+    """Two captured iterations, one per direction of the mean's double buffer: ``replay()`` runs the one that reads the
+    buffer that is the mean now, then makes the buffer it wrote the mean."""
+
+    def __init__(self, dev, graphs):
+        self.dev, self.graphs = dev, graphs
+
+    def replay(self):
+        self.graphs[id(self.dev.mean)].replay()
+        self.dev.mean, self.dev.mean_alt = self.dev.mean_alt, self.dev.mean
+
+
 class OLGaussianMPC(Controller):
     """Open-loop Gaussian MPC: N(mean_action[t], cov_action) per horizon step."""
 
@@ -357,16 +369,23 @@ class OLGaussianMPC(Controller):
         own_step = post is not None and getattr(post, "__self__", None) is eng and getattr(post, "__name__", "") == "step_state"
         sharded = self.dev.comm.world_size > 1
         self._mono_rec = self.dev.record("fused_rec", 2 + self.horizon * self.d_action) if sharded else None
-        self._mono_steps_env = bool(env_step and own_step and not sharded)
+        # the launch that finishes the iteration also steps the real env when that env is this engine's resident state
+        self._mono_steps_env = bool(env_step and own_step)
         # one bound launcher per direction of the mean's double buffer (the iteration reads one tensor and writes the
         # other; _device_iteration swaps them afterwards and picks the launcher by the tensor that is the mean then)
-        self._mono_launch = {}
+        self._mono_launch, self._mono_combine = {}, {}
+        recs = self.dev.comm.all_gather(self._mono_rec) if sharded else None   # (the persistent receive buffer, [G][2 + H A])
         for src, dst in ((self.dev.mean, self.dev.mean_alt), (self.dev.mean_alt, self.dev.mean)):
             self._mono_launch[id(src)], _ = self._rollout_fn.mono_launcher(
                 n_loc, self.horizon, src, dst, self.dev.gseq, coeffs, chol, self.seed_val, 0, self.dev.comm.rank * n_loc,
                 self._step_dev, self.lam, self.step_size, _SHIFT_MODES[self.base_action], action_out=self._action_dev,
-                action_slots=None if sharded else self._action_pin, record=self._mono_rec, env_step=self._mono_steps_env,
+                action_slots=None if sharded else self._action_pin, record=self._mono_rec,
+                env_step=self._mono_steps_env and not sharded,
                 bind_stream=not sharded)        # (sharded: the launcher runs under stream capture)
+            if sharded:         # behind the all-gather: merge the G records, update + shift, action, env step - one launch
+                self._mono_combine[id(src)] = self._rollout_fn.combine_launcher(
+                    recs, recs.shape[0], self.horizon, src, dst, self._step_dev, self.step_size,
+                    _SHIFT_MODES[self.base_action], self._action_dev, self._action_pin, self._mono_steps_env)
 
     def _noise_ahead(self):
         """Captured fused iterations with the Philox sampler draw the next step's samples inside the update."""
@@ -390,12 +409,13 @@ class OLGaussianMPC(Controller):
         """The control iteration without any host synchronisation (capturable)."""
         n_loc = self.local_particles
         if self._mono:
-            self._mono_launch[id(self.dev.mean)]()
-            if self.dev.comm.world_size == 1:       # the new mean was written to the other buffer: it is the mean now
-                self.dev.mean, self.dev.mean_alt = self.dev.mean_alt, self.dev.mean
-            else:
-                self.dev.mppi_fused_combine(self._mono_rec, n_loc, self.lam, self.step_size, _SHIFT_MODES[self.base_action],
-                                            self._action_dev, self._action_pin, self._step_dev)
+            key = id(self.dev.mean)
+            self._mono_launch[key]()
+            if self.dev.comm.world_size > 1:
+                self.dev.comm.all_gather(self._mono_rec)        # (into the buffer the combine launch is bound to)
+                self._mono_combine[key]()
+            # the new mean was written to the other buffer: it is the mean now
+            self.dev.mean, self.dev.mean_alt = self.dev.mean_alt, self.dev.mean
             if self._graph_post is not None and not self._mono_steps_env:
                 self._graph_post(self._action_dev)
             return
@@ -507,8 +527,9 @@ class OLGaussianMPC(Controller):
         """Capture the control iteration as a hipGraph (``self._graph``; None if the runtime refused and every rank
         agreed to run eagerly)."""
         torch = self.dev.torch
+        sharded_mono = self._mono and self.dev.comm.world_size > 1
         if self._mono:
-            self._bind_mono(env_step=False)         # (sharded: the env step follows the combine as a launch of its own)
+            self._bind_mono(env_step=False)         # (the dry run below must not step the real env)
         # eager dry run on a side stream (allocates every buffer), with the state it must not consume
         keep = (self.dev.mean.clone(), self._step_dev.clone(), self.dev.cov.clone())
         side = torch.cuda.Stream(self.dev.device)
@@ -527,10 +548,23 @@ class OLGaussianMPC(Controller):
         self._noise_valid = False       # the dry run left the samples of step + 1 behind
         err = None
         try:
-            g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g):
-                self._device_iteration()
-            self._graph = g
+            if sharded_mono:
+                # the iteration reads one buffer of the mean and writes the other: one graph per direction, replayed in
+                # turn; its last launch (the combine behind the all-gather) steps the real env when that is the engine's
+                self._bind_mono(env_step=True)
+                graphs = {}
+                for _ in range(2):
+                    g = torch.cuda.CUDAGraph()
+                    key = id(self.dev.mean)
+                    with torch.cuda.graph(g):
+                        self._device_iteration()        # (swaps dev.mean / dev.mean_alt: the second pass is the way back)
+                    graphs[key] = g
+                self._graph = _AlternatingGraphs(self.dev, graphs)
+            else:
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g):
+                    self._device_iteration()
+                self._graph = g
         except Exception as e:          # e.g. a collective that cannot be captured
             err = e
         # Sharded runs decide TOGETHER (one all-reduce outside the capture): a rank that fell back alone would
@@ -568,8 +602,7 @@ class OLGaussianMPC(Controller):
 
     def _slot(self, step):
         """Offset of the pinned slot the iteration of ``step`` publishes into (see _optimize_graphed)."""
-        two = self._mono and self.dev.comm.world_size == 1
-        return (step & 1) * (self.d_action + 1) if two else 0
+        return (step & 1) * (self.d_action + 1) if self._mono else 0
 
     def _optimize_eager_after_fallback(self, state):
         action, value = Controller.optimize(self, state, False, True)

@@ -66,6 +66,9 @@ struct mjmpc_arm_s {
     mjmpc::MonoStep* mono_dev = nullptr;
     mjmpc::MonoStep mono_cached;
     bool mono_valid = false;
+    mjmpc::MonoStep* comb_dev = nullptr;        // parameter block of mjmpc_arm_mppi_combine (sharded runs)
+    mjmpc::MonoStep comb_cached;
+    bool comb_valid = false;
 };
 
 struct mjmpc_tree_s {
@@ -191,6 +194,7 @@ int mjmpc_arm_destroy(mjmpc_arm_t h) {
     hipFree(h->shard_states);
     hipFree(h->mono_tree);
     hipFree(h->mono_dev);
+    hipFree(h->comb_dev);
     hipHostFree(h->pinned);
     for (int k = 0; k < 4; ++k) if (h->staged[k]) hipEventDestroy(h->staged[k]);
     delete h;
@@ -378,6 +382,45 @@ int mjmpc_arm_mppi_step(mjmpc_arm_t h, int dtype, int64_t P, int H, const double
         return fail(MJMPC_E_BADARG, "unknown dtype %d", dtype);
     }
     if (e != hipSuccess) return hip_fail(e, "arm_mppi_step launch");
+    return 0;
+}
+
+int mjmpc_arm_mppi_combine(mjmpc_arm_t h, int dtype, const double* d_records, int n_records, int H, const double* d_mean,
+                           double* d_mean_out, int64_t* d_step_counter, double step_size, int shift_mode,
+                           double* d_action_out, double* h_action_slots, int env_step, void* d_step_cost,
+                           void* d_step_next_obs, void* stream) {
+    if (!h || !d_records || !d_mean || !d_mean_out || d_mean_out == d_mean) return fail(MJMPC_E_BADARG, "null / aliased argument");
+    if (n_records < 1 || H < 1 || shift_mode > 1 || shift_mode < -1) return fail(MJMPC_E_BADARG, "bad n_records / H / shift_mode");
+    if (env_step && (h->n_shards > 1 || h->n_state_shards > 1))
+        return fail(MJMPC_E_BADARG, "the fused env step runs one model and one state (no per-shard blocks)");
+    HIP_TRY(hipSetDevice(h->device));
+    hipStream_t s = (hipStream_t)stream;
+    if (!h->comb_dev) HIP_TRY(hipMalloc(&h->comb_dev, sizeof(mjmpc::MonoStep)));
+    mjmpc::MonoStep mo;
+    std::memset(&mo, 0, sizeof(mo));
+    mo.step_size = step_size;
+    mo.shift_mode = shift_mode;
+    mo.action_out = d_action_out;
+    mo.action_host = h_action_slots;
+    mo.step_counter = (long long*)d_step_counter;
+    mo.state_io = h->state;
+    mo.step_cost = d_step_cost;
+    mo.step_nobs = d_step_next_obs;
+    if (!h->comb_valid || std::memcmp(&mo, &h->comb_cached, sizeof(mo)) != 0) {
+        HIP_TRY(mjmpc::upload_mono_params(mo, h->comb_dev, s));
+        h->comb_cached = mo;
+        h->comb_valid = true;
+    }
+    hipError_t e;
+    if (dtype == MJMPC_F32)
+        e = mjmpc::launch_arm_mppi_finish<float>(h->model_f32, d_records, n_records, H, h->nu, d_mean, d_mean_out, h->comb_dev,
+                                                 env_step ? 1 : 0, h->diag, s);
+    else if (dtype == MJMPC_F64)
+        e = mjmpc::launch_arm_mppi_finish<double>(h->model_f64, d_records, n_records, H, h->nu, d_mean, d_mean_out, h->comb_dev,
+                                                  env_step ? 1 : 0, h->diag, s);
+    else
+        return fail(MJMPC_E_BADARG, "unknown dtype %d", dtype);
+    if (e != hipSuccess) return hip_fail(e, "arm_mppi_combine launch");
     return 0;
 }
 

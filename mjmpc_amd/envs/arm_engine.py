@@ -300,6 +300,23 @@ class ArmRolloutEngine:
 
         return launch, ((costs, act, q0) if want_trajectories else None)
 
+    def mppi_combine_launcher(self, records, n_records, horizon, mean, mean_out, step_counter, step_size, shift_mode,
+                              action_out, action_slots, env_step):
+        """Sharded runs: the launch behind the record all-gather (``mjmpc_arm_mppi_combine``) with its arguments bound;
+        ``launch()`` enqueues it on the stream that is current WHEN IT IS CALLED (it is called under stream capture)."""
+        scost = self._buffer("step_cost", (1,))         # (bound whether or not this launcher steps the env: the parameter
+        snobs = self._buffer("step_obs", (self.d_obs,))  #  block of the call then never changes between launchers)
+        keep = (records, mean, mean_out, step_counter, action_out, action_slots, scost, snobs)
+        args = (self._h, self._code, _ptr(records), int(n_records), int(horizon), _ptr(mean), _ptr(mean_out),
+                _ptr(step_counter), float(step_size), int(shift_mode), _ptr(action_out), _ptr(action_slots),
+                int(bool(env_step)), _ptr(scost), _ptr(snobs))
+        fn, check, stream = self._lib.mjmpc_arm_mppi_combine, _lib.check, self._stream
+
+        def launch(_keep=keep):
+            check(fn(*args, stream()))
+
+        return launch
+
     def step_state(self, action):
         """Advance the engine state in place by one env step (the "real env" kept on the device).
         ``action``: numpy (A,) or CUDA float64 tensor.  Returns (cost, next_obs) device tensors."""
@@ -353,6 +370,7 @@ def make_device_rollout_fn(sim_env):
     if hasattr(sim_env, "mppi_step"):       # the whole iteration in one launch (captured iterations of MPPI / DMD-MPC)
         rollout_fn.mono = sim_env.mppi_step
         rollout_fn.mono_launcher = sim_env.mppi_step_launcher
+        rollout_fn.combine_launcher = sim_env.mppi_combine_launcher
     return rollout_fn
 
 

@@ -64,5 +64,31 @@ for mono in (True, False):
     print("sharded iteration (%s) in a hipGraph with an RCCL all-gather: max |d action| vs the single-GPU run = %.2e"
           % ("rollout + record launches" if mono else "separate launches", err))
     assert err < 1e-9 or os.environ.get('RCCL_W1_DEBUG')
-dist.destroy_process_group()
 print("ok")
+if "--time" not in sys.argv:
+    dist.destroy_process_group()
+
+if "--time" in sys.argv:        # per-step time of the sharded iteration (4096 particles on this rank) beside the single-GPU one
+    import time
+
+    def timed(P, comm, mono, H=32):
+        eng = ArmRolloutEngine(reacher7dof_raw(), dtype="f64")
+        c = MPPI(d_state=25, d_obs=20, d_action=7, horizon=H, init_cov=1.0, base_action="null", lam=0.01, num_particles=P,
+                 step_size=1.0, alpha=1, gamma=1.0, n_iters=1, action_lows=eng.action_lows, action_highs=eng.action_highs,
+                 filter_coeffs=[0.25, 0.8, 0.0], seed=3, noise_mode="device", comm=comm)
+        c.rollout_fn = make_device_rollout_fn(eng)
+        c.set_sim_state_fn = lambda s: None
+        c.enable_graph(post_step=eng.step_state, mono=mono)
+        for _ in range(60):
+            c.optimize({})
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(200):
+            c.optimize({})
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) / 200 * 1e3
+
+    print("single GPU, 4096 particles:                      %.4f ms per step" % timed(4096, None, True))
+    print("rank of a sharded run (RCCL all-gather, 3 launches): %.4f ms per step" % timed(8192, ClaimsTwoRanks(), True))
+    print("rank of a sharded run, separate launches:          %.4f ms per step" % timed(8192, ClaimsTwoRanks(), False))
+    dist.destroy_process_group()

@@ -31,8 +31,12 @@ if __name__ == "__main__":
     dt = args[1] if len(args) > 1 else "f64"
     P = int(args[2]) if len(args) > 2 else 4096
     H = int(args[3]) if len(args) > 3 else 32
-    raw = dict(hand=hand24_raw, swimmer=swimmer_raw, cheetah=half_cheetah_raw)[name]()
+    from mjmpc_amd.models.pen_hand import holding_state, pen_hand_raw
+    raw = dict(hand=hand24_raw, swimmer=swimmer_raw, cheetah=half_cheetah_raw, pen=pen_hand_raw)[name]()
     eng = TreeRolloutEngine(raw, dtype=dt)
+    if name == "pen":
+        st = holding_state()
+        eng.set_env_state(dict(qpos=st["qp"], qvel=st["qv"], target_pos=np.asarray(raw.target_pos, float)))
     if name == "cheetah":
         eng.set_env_state(dict(qpos=np.array([0.0, -0.1324, 0.0521, 0.0342, 0.0679, -0.0139, -0.0589, -0.14, -0.131]), qvel=np.zeros(9)))
     lib = _lib.load()
@@ -40,8 +44,10 @@ if __name__ == "__main__":
     lib.mjmpc_debug_tree_stats.argtypes = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_ulonglong)]
     A = eng.d_action
     g = torch.Generator(device="cuda").manual_seed(0)
-    noise = 0.5 * torch.randn(P, H, A, device="cuda", dtype=torch.float32 if dt == "f32" else torch.float64, generator=g)
+    noise = (0.1 if name == "pen" else 0.5) * torch.randn(P, H, A, device="cuda", dtype=torch.float32 if dt == "f32" else torch.float64, generator=g)
     mean = torch.zeros(H, A, device="cuda", dtype=torch.float64)
+    if name == "pen":
+        mean += torch.from_numpy(st["qp"][6:]).to(mean)
     out = (ctypes.c_ulonglong * 24)()
     eng.rollout_device(P, H, mean, noise)
     lib.mjmpc_debug_tree_stats(eng._h, out)
