@@ -1,5 +1,9 @@
-import re,sys,subprocess
-out=subprocess.run(["/opt/rocm/bin/hipcc","--offload-arch=gfx950","-O3","-std=c++17","-fPIC","-Wno-unused-value","-Wno-pass-failed","-I","mjmpc_amd/csrc","-Rpass-analysis=kernel-resource-usage","-c",sys.argv[1],"-o","/tmp/x.o"]+sys.argv[3:],capture_output=True,text=True).stderr
+"""Registers, scratch, occupancy and LDS of every kernel in one source, with the product build's flags:
+    python tools/kres.py mjmpc_amd/csrc/tree_rollout.hip [name filter] [extra flags]"""
+import os,re,sys,subprocess
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from mjmpc_amd.build import flags_for
+out=subprocess.run(["/opt/rocm/bin/hipcc"]+flags_for(sys.argv[1])+["-Rpass-analysis=kernel-resource-usage","-c",sys.argv[1],"-o","/tmp/x.o"]+sys.argv[3:],capture_output=True,text=True).stderr
 cur=None; rows={}
 for ln in out.splitlines():
     m=re.search(r"Function Name: (\S+)",ln)

@@ -15,8 +15,8 @@ NAMES = ["kinematics + contact geometry", "link quantities + bias forces (+ flui
 if __name__ == "__main__":
     if "--build" in sys.argv:
         os.makedirs(os.path.dirname(LIB), exist_ok=True)
-        subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
-                               "-Wno-unused-value", "-DTREE_STATS", "-I", CSRC] + sorted(glob.glob(os.path.join(CSRC, "*.hip"))) + ["-o", LIB])
+        from mjmpc_amd.build import build
+        build(extra_flags=["-DTREE_STATS"], lib=LIB)         # (the product build's per-source flags + the clocks)
         sys.exit(0)
     os.environ["MJMPC_AMD_LIB"] = LIB
     import numpy as np
