@@ -24,13 +24,23 @@ print("deepcopy state %.2f us" % t(lambda: copy.deepcopy(state)))
 print("noise_ahead    %.2f us" % t(c._noise_ahead))
 print("fused_capable  %.2f us" % t(c._fused_capable))
 print("flag copy      %.2f us" % t(lambda: c._action_np[:7].copy()))
+launch = c._device_iteration if c._graph == "direct" else c._graph.replay
 N = 300
 t0 = time.perf_counter()
-for _ in range(N): c._graph.replay()
+for _ in range(N): launch()
 t1 = time.perf_counter(); torch.cuda.synchronize()
-print("replay() call  %.2f us (enqueue only)" % ((t1 - t0) / N * 1e6))
+print("iteration enqueue %.2f us (%s)" % ((t1 - t0) / N * 1e6, "two direct launches" if c._graph == "direct" else "graph replay"))
 c._step_dev.fill_(c.num_steps); torch.cuda.synchronize()
 c._noise_valid = False
+# host time of one optimize() with the GPU work taken out: the launch and the wait replaced by no-ops
+real_iter, real_wait = c._device_iteration, c._wait_action
+c._device_iteration = lambda: None
+c._wait_action = lambda: c._action_np[:7].copy()
+print("optimize() host path without launch and wait %.2f us" % t(lambda: c.optimize(state), 5000))
+c._device_iteration, c._wait_action = real_iter, real_wait
+c.reset(); eng.set_env_state(dict(qp=np.zeros(7), qv=np.zeros(7), target_pos=np.array([0.1, 0.1, 0.1])))
+for _ in range(100): c.optimize(state)
+torch.cuda.synchronize()
 t0 = time.perf_counter()
 for _ in range(2000): c.optimize(state)
 torch.cuda.synchronize()
