@@ -95,3 +95,41 @@ def test_pen_hand_one_step_from_random_states(pen):
         worst = max(worst, np.abs(nobs[0, 0] - o1).max() / max(1.0, np.abs(o1).max()), abs(rew[0, 0] - r1))
     assert worst < 1e-9, worst
     assert eng.solver_failures() == 0
+
+
+def test_pen_hand_config_size_65536x64(pen):
+    """BASELINE config 5's size (DMD-MPC on pen-v0: 65536 particles x H 64) on the pen-in-hand model, one GPU, f64: the
+    pen resting on the fingers, servo set points = the pose + filtered noise.  Size-independent properties on everything
+    (duplicated particles agree bit for bit, obs[t] = next_obs[t-1], the cost is the distance part plus an orientation
+    part in [-1, 1]); the oracle on every 4099th particle at 1e-9 over all 64 env steps (measured: median 3e-15, max 3e-13 of
+    the costs - a pen held by friction does not amplify rounding the way the running cheetah does).  The active-set iteration
+    gives up on about one particle-substep in 10^4 here (thirteen friction pyramids, mu = 1): reported, bounded."""
+    import torch
+    raw, eng, ref, st = pen
+    q, v, u = _settled(ref, st)
+    P, H, A = 65536, 64, 24
+    g = torch.Generator(device="cuda").manual_seed(7)
+    noise = 0.05 * torch.randn(P, H, A, device="cuda", dtype=torch.float64, generator=g)
+    for t in range(2, H):
+        noise[:, t] = 0.25 * noise[:, t] + 0.8 * noise[:, t - 1]
+    noise[P // 2:] = noise[:P // 2]
+    mean = np.tile(u, (H, 1))
+    tgt = np.asarray(raw.target_pos, float)
+    eng.set_env_state(dict(qp=q, qv=v, target_pos=tgt))
+    fails0 = eng.solver_failures()
+    costs, act, obs, nobs = eng.rollout_device(P, H, mean, noise, want_obs=True)
+    assert torch.equal(costs[:P // 2], costs[P // 2:])
+    assert torch.equal(obs[:, 1:], nobs[:, :-1])
+    d = nobs[..., 2 * 30 + 3:2 * 30 + 6]
+    orient = costs - (d * d).sum(-1).sqrt()
+    assert torch.isfinite(costs).all() and float(orient.abs().max()) <= 1.0 + 1e-9
+    idx = np.arange(0, P // 2, 4099)
+    _, o_rew, _, _, o_nobs = ref.rollout(q, v, tgt, mean, noise[idx].cpu().numpy())
+    c = costs[idx].cpu().numpy()
+    np.testing.assert_allclose(c[:, :8], -o_rew[:, :8], rtol=1e-9, atol=1e-9)
+    np.testing.assert_allclose(nobs[idx, :8].cpu().numpy(), o_nobs[:, :8], rtol=0, atol=1e-9)
+    err = np.abs(c + o_rew)
+    print("pen 65536x64: cost error vs oracle median %.2e max %.2e; solver failures %d of %d particle-substeps"
+          % (np.median(err), err.max(), eng.solver_failures() - fails0, P * H * raw.frame_skip))
+    assert np.median(err) < 1e-12 and err.max() < 1e-9
+    assert eng.solver_failures() - fails0 < 2e-4 * P * H * raw.frame_skip
