@@ -102,6 +102,21 @@ int mjmpc_device_count(void) {
     return n;
 }
 
+static int arm_create_impl(mjmpc_arm_s* h, const double* blob, int n_blob) {
+    std::vector<float> f32(blob, blob + n_blob);
+    HIP_TRY(hipMalloc(&h->model_f32, sizeof(float) * n_blob));
+    HIP_TRY(hipMalloc(&h->model_f64, sizeof(double) * n_blob));
+    HIP_TRY(hipMalloc(&h->state, sizeof(double) * MJMPC_ARM_STATE_LEN));
+    HIP_TRY(hipMalloc(&h->diag, MJMPC_DIAG_BYTES));
+    HIP_TRY(hipHostMalloc(&h->pinned, sizeof(double) * MJMPC_ARM_STATE_LEN * 4));
+    for (int k = 0; k < 4; ++k) HIP_TRY(hipEventCreateWithFlags(&h->staged[k], hipEventDisableTiming));
+    HIP_TRY(hipMemcpy(h->model_f32, f32.data(), sizeof(float) * n_blob, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(h->model_f64, blob, sizeof(double) * n_blob, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemset(h->state, 0, sizeof(double) * MJMPC_ARM_STATE_LEN));
+    HIP_TRY(hipMemset(h->diag, 0, MJMPC_DIAG_BYTES));
+    return 0;
+}
+
 int mjmpc_arm_create(const double* blob, int n_blob, int device, mjmpc_arm_t* out) {
     if (!blob || !out) return fail(MJMPC_E_BADARG, "null argument");
     if (n_blob != mjmpc::ARM_BLOB_LEN) return fail(MJMPC_E_BADMODEL, "model blob has %d scalars, expected %d", n_blob, (int)mjmpc::ARM_BLOB_LEN);
@@ -114,17 +129,10 @@ int mjmpc_arm_create(const double* blob, int n_blob, int device, mjmpc_arm_t* ou
     h->nv = nv;
     h->nu = nv;
     h->d_obs = 2 * nv + 6;
-    std::vector<float> f32(blob, blob + n_blob);
-    HIP_TRY(hipMalloc(&h->model_f32, sizeof(float) * n_blob));
-    HIP_TRY(hipMalloc(&h->model_f64, sizeof(double) * n_blob));
-    HIP_TRY(hipMalloc(&h->state, sizeof(double) * MJMPC_ARM_STATE_LEN));
-    HIP_TRY(hipMalloc(&h->diag, MJMPC_DIAG_BYTES));
-    HIP_TRY(hipHostMalloc(&h->pinned, sizeof(double) * MJMPC_ARM_STATE_LEN * 4));
-    for (int k = 0; k < 4; ++k) HIP_TRY(hipEventCreateWithFlags(&h->staged[k], hipEventDisableTiming));
-    HIP_TRY(hipMemcpy(h->model_f32, f32.data(), sizeof(float) * n_blob, hipMemcpyHostToDevice));
-    HIP_TRY(hipMemcpy(h->model_f64, blob, sizeof(double) * n_blob, hipMemcpyHostToDevice));
-    HIP_TRY(hipMemset(h->state, 0, sizeof(double) * MJMPC_ARM_STATE_LEN));
-    HIP_TRY(hipMemset(h->diag, 0, MJMPC_DIAG_BYTES));
+    if (int rc = arm_create_impl(h, blob, n_blob)) {        // a failed allocation leaves nothing behind
+        mjmpc_arm_destroy(h);
+        return rc;
+    }
     *out = h;
     return 0;
 }
@@ -141,9 +149,17 @@ int mjmpc_arm_set_shard_models(mjmpc_arm_t h, const double* blobs, int n_shards)
     float* m32 = nullptr;
     double* m64 = nullptr;
     HIP_TRY(hipMalloc(&m32, sizeof(float) * n));
-    HIP_TRY(hipMalloc(&m64, sizeof(double) * n));
-    HIP_TRY(hipMemcpy(m32, f32.data(), sizeof(float) * n, hipMemcpyHostToDevice));
-    HIP_TRY(hipMemcpy(m64, blobs, sizeof(double) * n, hipMemcpyHostToDevice));
+    if (hipError_t e = hipMalloc(&m64, sizeof(double) * n); e != hipSuccess) {
+        hipFree(m32);
+        return hip_fail(e, "hipMalloc");
+    }
+    hipError_t e = hipMemcpy(m32, f32.data(), sizeof(float) * n, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(m64, blobs, sizeof(double) * n, hipMemcpyHostToDevice);
+    if (e != hipSuccess) {
+        hipFree(m32);
+        hipFree(m64);
+        return hip_fail(e, "hipMemcpy");
+    }
     hipFree(h->model_f32);
     hipFree(h->model_f64);
     h->model_f32 = m32;
