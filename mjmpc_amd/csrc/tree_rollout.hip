@@ -91,8 +91,14 @@ constexpr int A_ROW = 0;                    // path-indexed rows [32][row_stride
 // row stride: 2 DP entries (so that dist + c never leaves the row) + 1, an odd number of
 // doubles: 32 lanes reading 32 different rows at the same offset then hit 32 different bank pairs (a stride of 16
 // doubles = 128 B put them on two: measured 16-way conflicts)
-constexpr int row_stride(int DP) { return 2 * DP + 1; }
-constexpr int a_vec(int DP, int PL) { return (row_stride(DP) * PL > 12 * PL ? row_stride(DP) * PL : 12 * PL) + 3 & ~3; }   // broadcast vector [PL]
+constexpr int row_stride(int DP) { return DP + 1; }
+constexpr int TILE_STRIDE = 17;     // the dense 16 x 16 tile of a 16-lane particle (odd stride: conflict-free columns)
+constexpr int a_max(int a, int b) { return a > b ? a : b; }
+// the row area also holds the exchange buffers (12 x PL) and, for 16-lane particles, the dense tile; a row read may
+// run up to DP - 1 entries past the last row (see tree_factor): the broadcast vector behind it is finite data too
+constexpr int a_vec(int DP, int PL) {
+    return (a_max(a_max(row_stride(DP) * PL, 12 * PL), PL == 16 ? TILE_STRIDE * 16 : 0) + 3) & ~3;     // broadcast vector [PL]
+}
 // contact Jacobian rows [NS][NJ][DP], PATH-INDEXED like the matrix rows: a contact point on link L moves only with the
 // dofs on L's path to the root, entry c belongs to L's ancestor at distance c (a quarter of a [32]-lane row at DP = 8)
 constexpr int a_jc(int DP, int PL) { return a_vec(DP, PL) + PL; }
@@ -109,13 +115,12 @@ constexpr int a_row2(int DP, int NS, int NJ, int PL) { return a_misc(DP, NS, NJ,
 // lanes per particle, which are the large ones: 32768 x 32 on the cheetah 18 -> 35 ms)
 // (DN > 0: 16-lane particles factor densely in registers - see dense_factor - and have nothing to merge)
 constexpr bool merge_factor(int DP, bool fric, int scalar_bytes, int PL, int DN = 0) {
-    return DN == 0 && fric && DP <= 16 && !(scalar_bytes == 4 && PL == 16);
+    return DN == 0 && fric && DP <= 16 && !(scalar_bytes == 4 && PL == 16) && !(scalar_bytes == 8 && DP > 8);
 }
-constexpr int TILE_STRIDE = 17;     // the dense 16 x 16 tile of a 16-lane particle (odd stride: conflict-free columns)
 constexpr int a_len(int DP, int NS, int NJ, int PL, int scalar_bytes, int DN = 0) {
     return a_row2(DP, NS, NJ, PL) + (merge_factor(DP, NJ == 3, scalar_bytes, PL, DN) ? row_stride(DP) * PL : 0);
 }
-static_assert(TILE_STRIDE * 16 <= row_stride(8) * 16, "the dense tile lives in the (otherwise unused) row area");
+static_assert(TILE_STRIDE * 16 <= a_vec(8, 16), "the dense tile lives in the (otherwise unused) row area");
 
 template <typename T>
 __device__ __forceinline__ void cross3(const T* a, const T* b, T* c) {
@@ -278,22 +283,23 @@ __device__ __forceinline__ void tree_row_params(const T* sol, T r, T diag_approx
 // Tree-sparse L'DL, in place: in  r[c] = A[l][ancestor at distance c]  (c < DP, zero beyond the root),
 // out r[0] = D_l, r[c] = L[l][ancestor at distance c] (c >= 1).  One round per height: every lane publishes its row,
 // then pulls the rows of its descendants of that height (elimination list ELIM[e * 32 + l], sorted by height:
-// k | dist << 8 | height << 16, -1 ends it):  r[c] -= (r_k[dist] / r_k[0]) r_k[dist + c].  Rows are 2 DP (+1) long
-// so that dist + c never leaves the row; what is read past a row's own path (dist + c > depth of k) only ever
-// lands in entries of r past MY path (c > my depth), which nothing consumes; slot 2 DP carries 1 / D_k.
+// k | dist << 8 | height << 16, -1 ends it):  r[c] -= (r_k[dist] / r_k[0]) r_k[dist + c].  Rows are DP + 1 long (slot DP
+// carries 1 / D_k); dist + c may run past a row's own path (dist + c > depth of k) and even past the row, into the next
+// lane's - published, finite - data: what is read there only ever lands in entries of r past MY path (c > my depth),
+// which nothing consumes (they are published with the row and read again only into such entries).
 template <int DP, int PL, typename T>
 __device__ __forceinline__ void tree_factor(T* r, const int* ELIM, T* ROW, int l, int n_rounds) {
     int e = 0, ent = ELIM[l];
     for (int hgt = 0; hgt + 1 < n_rounds; ++hgt) {     // (the last round holds roots only: nobody to update)
 #pragma unroll
         for (int c = 0; c < DP; ++c) ROW[l * row_stride(DP) + c] = r[c];
-        ROW[l * row_stride(DP) + 2 * DP] = rcp_(r[0]);             // 1 / D of a row that is final; read by its ancestors
+        ROW[l * row_stride(DP) + DP] = rcp_(r[0]);                 // 1 / D of a row that is final; read by its ancestors
         TSYNC();
         while (__any(ent >= 0 && (ent >> 16) == hgt)) {
             if (ent >= 0 && (ent >> 16) == hgt) {
                 const T* rk = ROW + (ent & 255) * row_stride(DP);
                 const int a = (ent >> 8) & 255;
-                const T f = rk[a] * rk[2 * DP];
+                const T f = rk[a] * rk[DP];
 #pragma unroll
                 for (int c = 0; c < DP; ++c) r[c] -= f * rk[a + c];
                 ++e;
@@ -318,15 +324,15 @@ __device__ __forceinline__ void tree_factor2(T* r, T* q, const int* ELIM, T* ROW
     for (int hgt = 0; hgt + 1 < n_rounds; ++hgt) {
 #pragma unroll
         for (int c = 0; c < DP; ++c) { ROW[l * row_stride(DP) + c] = r[c]; ROW2[l * row_stride(DP) + c] = q[c]; }
-        ROW[l * row_stride(DP) + 2 * DP] = rcp_(r[0]);
-        ROW2[l * row_stride(DP) + 2 * DP] = rcp_(q[0]);
+        ROW[l * row_stride(DP) + DP] = rcp_(r[0]);
+        ROW2[l * row_stride(DP) + DP] = rcp_(q[0]);
         TSYNC();
         while (__any(ent >= 0 && (ent >> 16) == hgt)) {
             if (ent >= 0 && (ent >> 16) == hgt) {
                 const T* rk = ROW + (ent & 255) * row_stride(DP);
                 const T* qk = ROW2 + (ent & 255) * row_stride(DP);
                 const int a = (ent >> 8) & 255;
-                const T f = rk[a] * rk[2 * DP], g = qk[a] * qk[2 * DP];
+                const T f = rk[a] * rk[DP], g = qk[a] * qk[DP];
 #pragma unroll
                 for (int c = 0; c < DP; ++c) { r[c] -= f * rk[a + c]; q[c] -= g * qk[a + c]; }
                 ++e;
@@ -1393,6 +1399,48 @@ __global__ __launch_bounds__(64 * wg_waves(DP, FRIC, sizeof(T), PL), min_waves(s
 
 }  // namespace
 
+// The 16-lane dense instantiations live in a translation unit of their own (tree_rollout_dense.hip, which includes this
+// file with TREE_DENSE_TU defined): it is compiled with the iterative-ILP scheduling strategy, which pays for those
+// one-wave-per-SIMD kernels and not for the others (mjmpc_amd/build.py).
+struct TreeLaunchArgs {
+    int model_stride, state_stride, n_shards, H, A;
+    long P, shard;
+    const double *state, *mean, *clw;
+    unsigned* diag;
+    double *state_out, *site_out;
+    hipStream_t stream;
+};
+template <typename T>
+hipError_t launch_tree_rollout_dense(int max_path, int nv, const T* model, const T* noise, T* cost, T* act, T* obs, T* nobs,
+                                     const TreeLaunchArgs& a);
+
+#define MJMPC_TREE_LAUNCH(DP_, NS_, FR_, PL_) MJMPC_TREE_LAUNCH_D(DP_, NS_, FR_, PL_, 0)
+#define MJMPC_TREE_LAUNCH_D(DP_, NS_, FR_, PL_, DN_)                                                                  \
+    {                                                                                                                 \
+        constexpr int per_wg = wg_waves(DP_, FR_, sizeof(T), PL_) * (64 / PL_);                                       \
+        hipLaunchKernelGGL((tree_rollout_kernel<T, DP_, NS_, FR_, PL_, DN_>),                                         \
+                           dim3((unsigned)((a.shard + per_wg - 1) / per_wg), (unsigned)a.n_shards),                   \
+                           dim3(64 * wg_waves(DP_, FR_, sizeof(T), PL_)), 0, a.stream, model, a.model_stride, a.state, \
+                           a.state_stride, a.P, a.shard, a.H, a.A, a.mean, noise, cost, act, obs, nobs, a.diag,       \
+                           a.state_out, a.clw, a.site_out);                                                           \
+    }
+
+#ifdef TREE_DENSE_TU
+template <typename T>
+hipError_t launch_tree_rollout_dense(int max_path, int nv, const T* model, const T* noise, T* cost, T* act, T* obs, T* nobs,
+                                     const TreeLaunchArgs& a) {
+    // (16 lanes per particle: the dense in-register factorisation, sized for the model)
+    if (max_path <= 8 && nv <= 8) MJMPC_TREE_LAUNCH_D(8, 16, true, 16, 8)
+    else if (max_path <= 8 && nv <= 12) MJMPC_TREE_LAUNCH_D(8, 16, true, 16, 12)
+    else if (max_path <= 8) MJMPC_TREE_LAUNCH_D(8, 16, true, 16, 16)
+    else MJMPC_TREE_LAUNCH_D(16, 16, true, 16, 16)
+    return hipGetLastError();
+}
+template hipError_t launch_tree_rollout_dense<float>(int, int, const float*, const float*, float*, float*, float*, float*,
+                                                     const TreeLaunchArgs&);
+template hipError_t launch_tree_rollout_dense<double>(int, int, const double*, const double*, double*, double*, double*, double*,
+                                                      const TreeLaunchArgs&);
+#else
 template <typename T>
 hipError_t launch_tree_rollout(const T* model, int n_model_shards, int max_path, bool full, int nv, const double* state, long P, int H,
                                int A, const double* mean, const T* noise, T* cost, T* act, T* obs, T* nobs, unsigned* diag,
@@ -1401,20 +1449,22 @@ hipError_t launch_tree_rollout(const T* model, int n_model_shards, int max_path,
     if ((state_out || site_out) && P != 1) return hipErrorInvalidValue;
     if (n_model_shards < 1 || n_state_shards < 1) return hipErrorInvalidValue;
     if (n_model_shards > 1 && n_state_shards > 1 && n_model_shards != n_state_shards) return hipErrorInvalidValue;
-    const int n_shards = n_model_shards > n_state_shards ? n_model_shards : n_state_shards;
-    if (P % n_shards != 0) return hipErrorInvalidValue;
-    const long shard = P / n_shards;
-    const int model_stride = n_model_shards > 1 ? TREE_BLOB_LEN : 0, state_stride = n_state_shards > 1 ? TREE_STATE_LEN : 0;
-#define MJMPC_TREE_LAUNCH(DP_, NS_, FR_, PL_) MJMPC_TREE_LAUNCH_D(DP_, NS_, FR_, PL_, 0)
-#define MJMPC_TREE_LAUNCH_D(DP_, NS_, FR_, PL_, DN_)                                                                  \
-    {                                                                                                                 \
-        constexpr int per_wg = wg_waves(DP_, FR_, sizeof(T), PL_) * (64 / PL_);                                       \
-        hipLaunchKernelGGL((tree_rollout_kernel<T, DP_, NS_, FR_, PL_, DN_>),                                         \
-                           dim3((unsigned)((shard + per_wg - 1) / per_wg), (unsigned)n_shards),                       \
-                           dim3(64 * wg_waves(DP_, FR_, sizeof(T), PL_)), 0, stream, model, model_stride, state,      \
-                           state_stride, P, shard, H, A, mean, noise, cost, act, obs, nobs, diag, state_out, clw,     \
-                           site_out);                                                                                 \
-    }
+    TreeLaunchArgs a;
+    a.n_shards = n_model_shards > n_state_shards ? n_model_shards : n_state_shards;
+    if (P % a.n_shards != 0) return hipErrorInvalidValue;
+    a.P = P;
+    a.shard = P / a.n_shards;
+    a.H = H;
+    a.A = A;
+    a.model_stride = n_model_shards > 1 ? TREE_BLOB_LEN : 0;
+    a.state_stride = n_state_shards > 1 ? TREE_STATE_LEN : 0;
+    a.state = state;
+    a.mean = mean;
+    a.clw = clw;
+    a.diag = diag;
+    a.state_out = state_out;
+    a.site_out = site_out;
+    a.stream = stream;
     // hinge trees in air with up to 8 frictionless contact points keep the lean instantiation; slide joints, springs,
     // friction cones, more points or a medium take the full one (three Jacobians per point, 16 points, fluid forces),
     // which also comes with 16 lanes per particle for models of up to 16 dofs (the reference's swimmer and cheetah)
@@ -1423,18 +1473,12 @@ hipError_t launch_tree_rollout(const T* model, int n_model_shards, int max_path,
         else if (max_path <= 16) MJMPC_TREE_LAUNCH(16, 8, false, 32)
         else MJMPC_TREE_LAUNCH(32, 8, false, 32)
     } else if (nv <= 16) {
-        // (16 lanes per particle: the dense in-register factorisation, sized for the model)
-        if (max_path <= 8 && nv <= 8) MJMPC_TREE_LAUNCH_D(8, 16, true, 16, 8)
-        else if (max_path <= 8 && nv <= 12) MJMPC_TREE_LAUNCH_D(8, 16, true, 16, 12)
-        else if (max_path <= 8) MJMPC_TREE_LAUNCH_D(8, 16, true, 16, 16)
-        else MJMPC_TREE_LAUNCH_D(16, 16, true, 16, 16)
+        return launch_tree_rollout_dense<T>(max_path, nv, model, noise, cost, act, obs, nobs, a);
     } else {
         if (max_path <= 8) MJMPC_TREE_LAUNCH(8, 16, true, 32)
         else if (max_path <= 16) MJMPC_TREE_LAUNCH(16, 16, true, 32)
         else MJMPC_TREE_LAUNCH(32, 16, true, 32)
     }
-#undef MJMPC_TREE_LAUNCH
-#undef MJMPC_TREE_LAUNCH_D
     return hipGetLastError();
 }
 
@@ -1442,5 +1486,8 @@ template hipError_t launch_tree_rollout<float>(const float*, int, int, bool, int
                                                const float*, float*, float*, float*, float*, unsigned*, hipStream_t, double*, const double*, double*, int);
 template hipError_t launch_tree_rollout<double>(const double*, int, int, bool, int, const double*, long, int, int, const double*,
                                                 const double*, double*, double*, double*, double*, unsigned*, hipStream_t, double*, const double*, double*, int);
+#endif
+#undef MJMPC_TREE_LAUNCH
+#undef MJMPC_TREE_LAUNCH_D
 
 }  // namespace mjmpc
