@@ -66,11 +66,20 @@ def build(force=False, verbose=False, extra_flags=(), lib=None):
     os.makedirs(objdir, exist_ok=True)
 
     def compile_one(src):
-        cmd = [hipcc] + flags_for(src) + list(extra_flags) + ["-c", src, "-o", os.path.join(objdir, os.path.basename(_obj(src)))]
-        if verbose:
-            cmd.insert(1, "-Rpass-analysis=kernel-resource-usage")
-            print(" ".join(cmd), flush=True)
-        r = subprocess.run(cmd, capture_output=True, text=True)
+        out = os.path.join(objdir, os.path.basename(_obj(src)))
+        extra = PER_SOURCE_FLAGS.get(os.path.basename(src), [])
+        for special in ([extra] if extra else []) + [[]]:
+            cmd = [hipcc] + FLAGS + special + list(extra_flags) + ["-c", src, "-o", out]
+            if verbose:
+                cmd.insert(1, "-Rpass-analysis=kernel-resource-usage")
+                print(" ".join(cmd), flush=True)
+            r = subprocess.run(cmd, capture_output=True, text=True)
+            if r.returncode == 0 or not special:
+                break
+            # a scheduling strategy is a tuning flag: if this compiler cannot take it for this source (the iterative
+            # scheduler has crashed on some variants of the tree kernel), build the source without it and say so
+            sys.stderr.write("mjmpc_amd.build: %s did not compile with %s (%s); compiling it with the default flags\n"
+                             % (os.path.basename(src), " ".join(special), (r.stderr.strip().splitlines() or ["?"])[-1][:160]))
         return src, r
 
     with ThreadPoolExecutor(max_workers=min(4, max(1, len(todo)))) as ex:

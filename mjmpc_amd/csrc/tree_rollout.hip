@@ -115,7 +115,7 @@ constexpr int a_row2(int DP, int NS, int NJ, int PL) { return a_misc(DP, NS, NJ,
 // lanes per particle, which are the large ones: 32768 x 32 on the cheetah 18 -> 35 ms)
 // (DN > 0: 16-lane particles factor densely in registers - see dense_factor - and have nothing to merge)
 constexpr bool merge_factor(int DP, bool fric, int scalar_bytes, int PL, int DN = 0) {
-    return DN == 0 && fric && DP <= 16 && !(scalar_bytes == 4 && PL == 16) && !(scalar_bytes == 8 && DP > 8);
+    return DN == 0 && (fric || DP <= 8) && DP <= 16 && !(scalar_bytes == 4 && PL == 16) && !(scalar_bytes == 8 && DP > 8);
 }
 constexpr int a_len(int DP, int NS, int NJ, int PL, int scalar_bytes, int DN = 0) {
     return a_row2(DP, NS, NJ, PL) + (merge_factor(DP, NJ == 3, scalar_bytes, PL, DN) ? row_stride(DP) * PL : 0);
