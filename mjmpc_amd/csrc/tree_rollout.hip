@@ -280,114 +280,7 @@ __device__ __forceinline__ void tree_row_params(const T* sol, T r, T diag_approx
     aref = -sol[1] * jv - sol[0] * imp * r;
 }
 
-// Tree-sparse L'DL, in place: in  r[c] = A[l][ancestor at distance c]  (c < DP, zero beyond the root),
-// out r[0] = D_l, r[c] = L[l][ancestor at distance c] (c >= 1).  One round per height: every lane publishes its row,
-// then pulls the rows of its descendants of that height (elimination list ELIM[e * 32 + l], sorted by height:
-// k | dist << 8 | height << 16, -1 ends it):  r[c] -= (r_k[dist] / r_k[0]) r_k[dist + c].  Rows are DP + 1 long (slot DP
-// carries 1 / D_k); dist + c may run past a row's own path (dist + c > depth of k) and even past the row, into the next
-// lane's - published, finite - data: what is read there only ever lands in entries of r past MY path (c > my depth),
-// which nothing consumes (they are published with the row and read again only into such entries).
-template <int DP, int PL, typename T>
-__device__ __forceinline__ void tree_factor(T* r, const int* ELIM, T* ROW, int l, int n_rounds) {
-    int e = 0, ent = ELIM[l];
-    for (int hgt = 0; hgt + 1 < n_rounds; ++hgt) {     // (the last round holds roots only: nobody to update)
-#pragma unroll
-        for (int c = 0; c < DP; ++c) ROW[l * row_stride(DP) + c] = r[c];
-        ROW[l * row_stride(DP) + DP] = rcp_(r[0]);                 // 1 / D of a row that is final; read by its ancestors
-        TSYNC();
-        while (__any(ent >= 0 && (ent >> 16) == hgt)) {
-            if (ent >= 0 && (ent >> 16) == hgt) {
-                const T* rk = ROW + (ent & 255) * row_stride(DP);
-                const int a = (ent >> 8) & 255;
-                const T f = rk[a] * rk[DP];
-#pragma unroll
-                for (int c = 0; c < DP; ++c) r[c] -= f * rk[a + c];
-                ++e;
-                ent = e < PL - 1 ? ELIM[e * PL + l] : -1;
-            }
-        }
-        TSYNC();
-    }
-    const T invd = rcp_(r[0]);
-#pragma unroll
-    for (int c = 1; c < DP; ++c) r[c] *= invd;
-#pragma unroll
-    for (int c = 0; c < DP; ++c) ROW[l * row_stride(DP) + c] = r[c];       // the solves read L from here
-    TSYNC();
-}
-
-// The same for TWO matrices of the tree's pattern in one pass over the rounds (H = M + J'DJ of the first Newton iteration
-// and the Euler matrix M + hB): one set of LDS round trips and list walks instead of two.
-template <int DP, int PL, typename T>
-__device__ __forceinline__ void tree_factor2(T* r, T* q, const int* ELIM, T* ROW, T* ROW2, int l, int n_rounds) {
-    int e = 0, ent = ELIM[l];
-    for (int hgt = 0; hgt + 1 < n_rounds; ++hgt) {
-#pragma unroll
-        for (int c = 0; c < DP; ++c) { ROW[l * row_stride(DP) + c] = r[c]; ROW2[l * row_stride(DP) + c] = q[c]; }
-        ROW[l * row_stride(DP) + DP] = rcp_(r[0]);
-        ROW2[l * row_stride(DP) + DP] = rcp_(q[0]);
-        TSYNC();
-        while (__any(ent >= 0 && (ent >> 16) == hgt)) {
-            if (ent >= 0 && (ent >> 16) == hgt) {
-                const T* rk = ROW + (ent & 255) * row_stride(DP);
-                const T* qk = ROW2 + (ent & 255) * row_stride(DP);
-                const int a = (ent >> 8) & 255;
-                const T f = rk[a] * rk[DP], g = qk[a] * qk[DP];
-#pragma unroll
-                for (int c = 0; c < DP; ++c) { r[c] -= f * rk[a + c]; q[c] -= g * qk[a + c]; }
-                ++e;
-                ent = e < PL - 1 ? ELIM[e * PL + l] : -1;
-            }
-        }
-        TSYNC();
-    }
-    const T invd = rcp_(r[0]), invq = rcp_(q[0]);
-#pragma unroll
-    for (int c = 1; c < DP; ++c) { r[c] *= invd; q[c] *= invq; }
-#pragma unroll
-    for (int c = 0; c < DP; ++c) { ROW[l * row_stride(DP) + c] = r[c]; ROW2[l * row_stride(DP) + c] = q[c]; }
-    TSYNC();
-}
-
-// x <- (L' D L)^-1 b, one entry per lane; ROW holds the factor (tree_factor), AT[c * 32 + l] = my ancestor at distance c
-template <int DP, int PL, typename T>
-__device__ __forceinline__ T tree_solve(const T* r, T b, const int* ELIM, const int* AT, const T* ROW, T* VEC, int l,
-                                        int n_rounds, int depth, int max_depth) {
-    // L' w = b, leaves first:  w_i = b_i - sum over descendants k of L[k][i] w_k
-    int e = 0, ent = ELIM[l];
-    for (int hgt = 0; hgt + 1 < n_rounds; ++hgt) {
-        VEC[l] = b;
-        TSYNC();
-        while (__any(ent >= 0 && (ent >> 16) == hgt)) {
-            if (ent >= 0 && (ent >> 16) == hgt) {
-                const int k = ent & 255, a = (ent >> 8) & 255;
-                b -= ROW[k * row_stride(DP) + a] * VEC[k];
-                ++e;
-                ent = e < PL - 1 ? ELIM[e * PL + l] : -1;
-            }
-        }
-        TSYNC();
-    }
-    b *= rcp_(r[0]);
-    // L x = u, root first:  x_i = u_i - sum over ancestors L[i][anc] x_anc; level dl finalises the links of depth dl
-    for (int dl = 0; dl + 1 < max_depth; ++dl) {
-        VEC[l] = b;
-        TSYNC();
-        if (depth > dl) {
-            const int c = depth - dl;
-            b -= ROW[l * row_stride(DP) + c] * VEC[AT[c * PL + l]];
-        }
-        TSYNC();
-    }
-    return b;
-}
-
-// ---- dense linear algebra of a 16-lane particle, in registers (DN > 0) -------------------------------------------
-// A particle of <= 16 dofs is ONE DPP row, and DPP's row_newbcast:K hands lane K's value to every lane of its row
-// in one move: a right-looking dense L D L' with one matrix ROW per lane needs no LDS round at all - per pivot one
-// broadcast of the pivot, one of each entry of the pivot row - where the tree-sparse factorisation through LDS pays
-// a publish / pull round trip per tree level (HalfCheetah: 7.0 k cycles per factorisation, 4.7 k per solve; dense:
-// < 1 k each).  Fill-in is free in a dense row, so the natural order (root first) does.
+// ---- DPP row broadcasts (a 16-lane row: a whole 16-lane particle, or the first half of a 32-lane one) -----------
 template <int K>
 __device__ __forceinline__ float bcast_row(float x) {
     return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0x150 + K, 0xF, 0xF, false));
@@ -430,6 +323,238 @@ __device__ __forceinline__ void dense_row(const T* h, const int* AT, T* TILE, in
 #pragma unroll
     for (int j = 0; j < DN; ++j) r[j] = TILE[l * TILE_STRIDE + j];
     TSYNC();
+}
+
+// ---- the TRUNK of the elimination tree --------------------------------------------------------------------------
+// Links 0 .. kt-1 that form a chain from the root, every one with a single child (the arm under a hand; the object's
+// chain above a manipulator): they are eliminated LAST, one per round, and in the rounds scheme each of those rounds is
+// an LDS round trip with one busy lane.  Their lanes sit in one DPP row, so the trunk is done in registers instead: the
+// rows go to ABSOLUTE column order (through LDS, once), a dense leaves-first L'DL with DPP broadcasts follows, and the
+// triangular solves take the trunk's levels as broadcast FMAs.  kt is the same for every particle of a launch.
+template <int DP>
+struct Trunk { static constexpr int KT = DP < 16 ? DP : 16; };
+
+// ra[col] = A[l][col] (col <= l < kt, absolute columns) in, the factor out: ra[l] = D_l, ra[col] = L[l][col]
+template <int K, int KT, typename T>
+struct TrunkStep {
+    static __device__ __forceinline__ void run(T* ra, int l, int kt) {
+        if (K < kt) {
+            asm volatile("" : "+v"(l));     // (lane masks recomputed here, not kept - and spilled - across the substep)
+            const T invd = rcp_(bcast_row<K>(ra[K]));
+            T fj = T(0);                        // A[K][l] / D_K for lanes l < K: lane K's entry of MY column
+#pragma unroll
+            for (int col = 0; col < K; ++col) {
+                const T v = bcast_row<K>(ra[col]);
+                fj = (l == col) ? v : fj;
+            }
+            fj *= invd;
+            const T nf = -fj;
+#pragma unroll
+            for (int col = 0; col < K; ++col) {
+                fma_bcast<K>(ra[col], ra[col], nf);                 // A[l][col] -= f_l A[K][col]   (lanes >= K: f = 0)
+                ra[col] = (l == K) ? ra[col] * invd : ra[col];      // row K itself becomes L[K][.]
+            }
+        }
+        if constexpr (K > 1) TrunkStep<K - 1, KT, T>::run(ra, l, kt);
+    }
+};
+
+// trunk lanes: path-indexed registers -> absolute columns, through the published rows
+template <int DP, int PL, typename T>
+__device__ __forceinline__ void trunk_load(T* ra, const T* ROW, int l, int kt) {
+    constexpr int KT = Trunk<DP>::KT;
+    asm volatile("" : "+v"(l));
+#pragma unroll
+    for (int col = 0; col < KT; ++col) ra[col] = (l < kt && col <= l) ? ROW[l * row_stride(DP) + (l - col)] : T(0);
+}
+template <int DP, int PL, typename T>
+__device__ __forceinline__ void trunk_store(const T* ra, T* ROW, int l, int kt) {
+    constexpr int KT = Trunk<DP>::KT;
+    asm volatile("" : "+v"(l));
+#pragma unroll
+    for (int col = 0; col < KT; ++col)
+        if (l < kt && col <= l) ROW[l * row_stride(DP) + (l - col)] = ra[col];
+}
+
+template <int K, int KT, typename T>
+struct TrunkFwd {       // L' w = b on the trunk, leaves first: b_l -= L[K][l] b_K, K descending
+    static __device__ __forceinline__ void run(const T* cK, T& b, int kt) {
+        if (K < kt) fma_bcast<K>(b, b, -cK[K]);
+        if constexpr (K > 1) TrunkFwd<K - 1, KT, T>::run(cK, b, kt);
+    }
+};
+template <int A, int KT, typename T>
+struct TrunkBwd {       // L x = u on the trunk, root first: x_l -= L[l][a] x_a, a ascending
+    static __device__ __forceinline__ void run(const T* La, T& b, int kt) {
+        if (A + 1 < kt) fma_bcast<A>(b, b, -La[A]);
+        if constexpr (A + 2 < KT) TrunkBwd<A + 1, KT, T>::run(La, b, kt);
+    }
+};
+
+// Tree-sparse L'DL, in place: in  r[c] = A[l][ancestor at distance c]  (c < DP, zero beyond the root),
+// out r[0] = D_l, r[c] = L[l][ancestor at distance c] (c >= 1).  One round per height: every lane publishes its row,
+// then pulls the rows of its descendants of that height (elimination list ELIM[e * 32 + l], sorted by height:
+// k | dist << 8 | height << 16, -1 ends it):  r[c] -= (r_k[dist] / r_k[0]) r_k[dist + c].  Rows are DP + 1 long (slot DP
+// carries 1 / D_k); dist + c may run past a row's own path (dist + c > depth of k) and even past the row, into the next
+// lane's - published, finite - data: what is read there only ever lands in entries of r past MY path (c > my depth),
+// which nothing consumes (they are published with the row and read again only into such entries).
+template <int DP, int PL, typename T>
+__device__ __forceinline__ void tree_factor(T* r, const int* ELIM, T* ROW, int l, int n_rounds, int kt) {
+    constexpr int KT = Trunk<DP>::KT;
+    int e = 0, ent = ELIM[l];
+    const int lds_rounds = n_rounds - kt;                   // heights below the trunk's lowest link (kt = 1: all but the root's)
+    const bool trunk = kt >= 2 && l < kt;                   // trunk lanes take their updates after the rounds, all at once
+    for (int hgt = 0; hgt < lds_rounds; ++hgt) {
+#pragma unroll
+        for (int c = 0; c < DP; ++c) ROW[l * row_stride(DP) + c] = r[c];
+        ROW[l * row_stride(DP) + DP] = rcp_(r[0]);                 // 1 / D of a row that is final; read by its ancestors
+        TSYNC();
+        while (__any(ent >= 0 && (ent >> 16) == hgt)) {
+            if (ent >= 0 && (ent >> 16) == hgt) {
+                const T* rk = ROW + (ent & 255) * row_stride(DP);
+                const int a = (ent >> 8) & 255;
+                const T f = rk[a] * rk[DP];
+#pragma unroll
+                for (int c = 0; c < DP; ++c) r[c] -= f * rk[a + c];
+                ++e;
+                ent = e < PL - 1 ? ELIM[e * PL + l] : -1;
+            }
+        }
+        TSYNC();
+    }
+    const T invd = rcp_(r[0]);
+    const bool below = !trunk;                              // my row is final: scale it (trunk rows: by the trunk steps)
+#pragma unroll
+    for (int c = 1; c < DP; ++c) r[c] = below ? r[c] * invd : r[c];
+#pragma unroll
+    for (int c = 0; c < DP; ++c) ROW[l * row_stride(DP) + c] = r[c];       // the solves read L from here
+    TSYNC();
+    if (kt >= 2) {
+        T ra[KT];
+        trunk_load<DP, PL>(ra, ROW, l, kt);
+        TrunkStep<KT - 1, KT, T>::run(ra, l, kt);
+        TSYNC();
+        trunk_store<DP, PL>(ra, ROW, l, kt);
+        TSYNC();
+        if (trunk) {
+#pragma unroll
+            for (int c = 0; c < DP; ++c) r[c] = ROW[l * row_stride(DP) + c];
+        }
+    }
+}
+
+// The same for TWO matrices of the tree's pattern in one pass over the rounds (H = M + J'DJ of the first Newton iteration
+// and the Euler matrix M + hB): one set of LDS round trips and list walks instead of two.
+template <int DP, int PL, typename T>
+__device__ __forceinline__ void tree_factor2(T* r, T* q, const int* ELIM, T* ROW, T* ROW2, int l, int n_rounds, int kt) {
+    constexpr int KT = Trunk<DP>::KT;
+    int e = 0, ent = ELIM[l];
+    const int lds_rounds = n_rounds - kt;
+    const bool trunk = kt >= 2 && l < kt;
+    for (int hgt = 0; hgt < lds_rounds; ++hgt) {
+#pragma unroll
+        for (int c = 0; c < DP; ++c) { ROW[l * row_stride(DP) + c] = r[c]; ROW2[l * row_stride(DP) + c] = q[c]; }
+        ROW[l * row_stride(DP) + DP] = rcp_(r[0]);
+        ROW2[l * row_stride(DP) + DP] = rcp_(q[0]);
+        TSYNC();
+        while (__any(ent >= 0 && (ent >> 16) == hgt)) {
+            if (ent >= 0 && (ent >> 16) == hgt) {
+                const T* rk = ROW + (ent & 255) * row_stride(DP);
+                const T* qk = ROW2 + (ent & 255) * row_stride(DP);
+                const int a = (ent >> 8) & 255;
+                const T f = rk[a] * rk[DP], g = qk[a] * qk[DP];
+#pragma unroll
+                for (int c = 0; c < DP; ++c) { r[c] -= f * rk[a + c]; q[c] -= g * qk[a + c]; }
+                ++e;
+                ent = e < PL - 1 ? ELIM[e * PL + l] : -1;
+            }
+        }
+        TSYNC();
+    }
+    const T invd = rcp_(r[0]), invq = rcp_(q[0]);
+    const bool below = !trunk;
+#pragma unroll
+    for (int c = 1; c < DP; ++c) { r[c] = below ? r[c] * invd : r[c]; q[c] = below ? q[c] * invq : q[c]; }
+#pragma unroll
+    for (int c = 0; c < DP; ++c) { ROW[l * row_stride(DP) + c] = r[c]; ROW2[l * row_stride(DP) + c] = q[c]; }
+    TSYNC();
+    if (kt >= 2) {
+        T ra[KT];
+        trunk_load<DP, PL>(ra, ROW, l, kt);
+        TrunkStep<KT - 1, KT, T>::run(ra, l, kt);
+        TSYNC();
+        trunk_store<DP, PL>(ra, ROW, l, kt);
+        trunk_load<DP, PL>(ra, ROW2, l, kt);
+        TrunkStep<KT - 1, KT, T>::run(ra, l, kt);
+        TSYNC();
+        trunk_store<DP, PL>(ra, ROW2, l, kt);
+        TSYNC();
+        if (trunk) {
+#pragma unroll
+            for (int c = 0; c < DP; ++c) { r[c] = ROW[l * row_stride(DP) + c]; q[c] = ROW2[l * row_stride(DP) + c]; }
+        }
+    }
+}
+
+// x <- (L' D L)^-1 b, one entry per lane; ROW holds the factor (tree_factor), AT[c * 32 + l] = my ancestor at distance c
+template <int DP, int PL, typename T>
+__device__ __forceinline__ T tree_solve(const T* r, T b, const int* ELIM, const int* AT, const T* ROW, T* VEC, int l,
+                                        int n_rounds, int depth, int max_depth, int kt) {
+    constexpr int KT = Trunk<DP>::KT;
+    // L' w = b, leaves first:  w_i = b_i - sum over descendants k of L[k][i] w_k
+    int e = 0, ent = ELIM[l];
+    const int lds_rounds = n_rounds - kt;
+    const bool trunk = kt >= 2 && l < kt;
+    for (int hgt = 0; hgt < lds_rounds; ++hgt) {
+        VEC[l] = b;
+        TSYNC();
+        while (__any(ent >= 0 && (ent >> 16) == hgt)) {
+            if (ent >= 0 && (ent >> 16) == hgt) {
+                const int k = ent & 255, a = (ent >> 8) & 255;
+                b -= ROW[k * row_stride(DP) + a] * VEC[k];
+                ++e;
+                ent = e < PL - 1 ? ELIM[e * PL + l] : -1;
+            }
+        }
+        TSYNC();
+    }
+    if (kt >= 2) {          // the trunk's rounds: my column of its factor from the published rows, then broadcast FMAs
+        asm volatile("" : "+v"(l));
+        T cK[KT];
+#pragma unroll
+        for (int K = 1; K < KT; ++K) cK[K] = (K < kt && l < K) ? ROW[K * row_stride(DP) + (K - l)] : T(0);
+        cK[0] = T(0);
+        TrunkFwd<KT - 1, KT, T>::run(cK, b, kt);
+    }
+    b *= rcp_(r[0]);
+    // L x = u, root first:  x_i = u_i - sum over ancestors L[i][anc] x_anc; level dl finalises the links of depth dl
+    int dl0 = 0;
+    if (kt >= 2) {
+        T La[KT];
+#pragma unroll
+        for (int a = 0; a < KT; ++a) La[a] = (l < kt && a < l) ? ROW[l * row_stride(DP) + (l - a)] : T(0);
+        TrunkBwd<0, KT, T>::run(La, b, kt);
+        // everybody below the trunk takes all its trunk ancestors (depth 0 .. kt-1: lanes 0 .. kt-1) in one round
+        VEC[l] = b;
+        TSYNC();
+        if (l >= kt) {
+            for (int dl = 0; dl < kt; ++dl) {
+                if (depth > dl) b -= ROW[l * row_stride(DP) + (depth - dl)] * VEC[dl];
+            }
+        }
+        TSYNC();
+        dl0 = kt;
+    }
+    for (int dl = dl0; dl + 1 < max_depth; ++dl) {
+        VEC[l] = b;
+        TSYNC();
+        if (depth > dl) {
+            const int c = depth - dl;
+            b -= ROW[l * row_stride(DP) + c] * VEC[AT[c * PL + l]];
+        }
+        TSYNC();
+    }
+    return b;
 }
 
 // r[j] += wn (lane j's jn) + w1 (lane j's j1) + w2 (lane j's j2): the contribution of one contact point to my dense row
@@ -549,6 +674,15 @@ __global__ __launch_bounds__(64 * wg_waves(DP, FRIC, sizeof(T), PL), min_waves(s
     const int n_rounds = __builtin_amdgcn_readfirstlane((int)model[T_N_ROUNDS]), depth = (int)model[T_DEPTH + l];
     int max_depth = 0;
     for (int c = 0; c < DP; ++c) max_depth += __any(AT[c * PL + l] >= 0) ? 1 : 0;     // links on the longest path
+    // the trunk of the elimination tree (see TrunkStep): links 0 .. kt-1 chained from the single root, one child each
+    int kt = 1;
+    if constexpr (DN == 0) {
+        const int nv_ = __builtin_amdgcn_readfirstlane((int)model[T_NV]);
+        const int ep = (half == 0 && l < nv_) ? (int)model[T_EPARENT + l] : -2;
+        if (__ballot(ep == -1) == 1ull) {
+            while (kt < Trunk<DP>::KT && kt < nv_ && __ballot(ep == kt - 1) == (1ull << kt)) ++kt;
+        }
+    }
     // model-wide integers: the same in every lane, kept in scalar registers
     const int nv = __builtin_amdgcn_readfirstlane((int)M[T_NV]), frame_skip = __builtin_amdgcn_readfirstlane((int)M[T_FRAME_SKIP]);
     const int site_link = __builtin_amdgcn_readfirstlane((int)M[T_SITE_LINK]);
@@ -1185,13 +1319,13 @@ __global__ __launch_bounds__(64 * wg_waves(DP, FRIC, sizeof(T), PL), min_waves(s
 #pragma unroll
                         for (int c = 0; c < DP; ++c) erow[c] = mrow[c];
                         erow[0] += dof ? h * damping : T(0);
-                        tree_factor2<DP, PL>(hrow, erow, ELIM, ROW, ROW2, l, n_rounds);
+                        tree_factor2<DP, PL>(hrow, erow, ELIM, ROW, ROW2, l, n_rounds, kt);
                     } else {
-                        tree_factor<DP, PL>(hrow, ELIM, ROW, l, n_rounds);
+                        tree_factor<DP, PL>(hrow, ELIM, ROW, l, n_rounds, kt);
                     }
                     clk.lap(13);
                     if constexpr (DN > 0) xa = dense_solve<DN>(hd, hdinv, rhs, l);
-                    else xa = tree_solve<DP, PL>(hrow, rhs, ELIM, AT, ROW, VEC, l, n_rounds, depth, max_depth);
+                    else xa = tree_solve<DP, PL>(hrow, rhs, ELIM, AT, ROW, VEC, l, n_rounds, depth, max_depth, kt);
                     clk.lap(14);
                     // f32: a row whose residual is within rounding of zero keeps its state (as in arm_rollout.hip)
                     const T resl = sig * xa - aref;
@@ -1220,7 +1354,7 @@ __global__ __launch_bounds__(64 * wg_waves(DP, FRIC, sizeof(T), PL), min_waves(s
                         if (!__any(cact2 != cact || nflip > 1u)) {
                             T zl;
                             if constexpr (DN > 0) zl = dense_solve<DN>(hd, hdinv, flip ? T(1) : T(0), l);
-                            else zl = tree_solve<DP, PL>(hrow, flip ? T(1) : T(0), ELIM, AT, ROW, VEC, l, n_rounds, depth, max_depth);
+                            else zl = tree_solve<DP, PL>(hrow, flip ? T(1) : T(0), ELIM, AT, ROW, VEC, l, n_rounds, depth, max_depth, kt);
                             if (flip) {
                                 const T c = act2 ? D : -D;
                                 VEC[0] = c;
@@ -1317,7 +1451,7 @@ __global__ __launch_bounds__(64 * wg_waves(DP, FRIC, sizeof(T), PL), min_waves(s
                 if (TREE_SKIP & 2) {
                     qacc = (tau + qfrc_c) * rcp_(mrow[0] + (dof ? h * damping : T(0)));
                 } else if (MERGE && any_rows) {
-                    qacc = tree_solve<DP, PL>(erow, tau + qfrc_c, ELIM, AT, ROW2, VEC, l, n_rounds, depth, max_depth);
+                    qacc = tree_solve<DP, PL>(erow, tau + qfrc_c, ELIM, AT, ROW2, VEC, l, n_rounds, depth, max_depth, kt);
                 } else if constexpr (DN > 0) {
                     T ed[DN > 0 ? DN : 1], edinv;
 #pragma unroll
@@ -1326,8 +1460,8 @@ __global__ __launch_bounds__(64 * wg_waves(DP, FRIC, sizeof(T), PL), min_waves(s
                     qacc = dense_solve<DN>(ed, edinv, tau + qfrc_c, l);
                 } else {
                     mrow[0] += dof ? h * damping : T(0);
-                    tree_factor<DP, PL>(mrow, ELIM, ROW, l, n_rounds);
-                    qacc = tree_solve<DP, PL>(mrow, tau + qfrc_c, ELIM, AT, ROW, VEC, l, n_rounds, depth, max_depth);
+                    tree_factor<DP, PL>(mrow, ELIM, ROW, l, n_rounds, kt);
+                    qacc = tree_solve<DP, PL>(mrow, tau + qfrc_c, ELIM, AT, ROW, VEC, l, n_rounds, depth, max_depth, kt);
                 }
             }
             clk.mark(5);
