@@ -103,7 +103,8 @@ def test_pen_hand_config_size_65536x64(pen):
     (duplicated particles agree bit for bit, obs[t] = next_obs[t-1], the cost is the distance part plus an orientation
     part in [-1, 1]); the oracle on every 4099th particle at 1e-9 over all 64 env steps (measured: median 3e-15, max 3e-13 of
     the costs - a pen held by friction does not amplify rounding the way the running cheetah does).  The active-set iteration
-    gives up on about one particle-substep in 10^4 here (thirteen friction pyramids, mu = 1): reported, bounded."""
+    gives up on a few particle-substeps in 10^6 here (thirteen friction pyramids, mu = 1; the counter adds one per lane; DESIGN
+    4.6.2): reported, bounded."""
     import torch
     raw, eng, ref, st = pen
     q, v, u = _settled(ref, st)
