@@ -1388,7 +1388,11 @@ __global__ __launch_bounds__(64 * wg_waves(DP, FRIC, sizeof(T), PL), min_waves(s
                     clk.lap(15);
                     if (!__any(changed)) break;
                 }
-                if (changed && diag) atomicAdd(diag, 1u);
+                if (diag) {        // one count per particle-substep whose rows were still changing when the iterations ran out
+                    const unsigned long long cb = __ballot(changed);
+                    const unsigned mine = (unsigned)(cb >> (PL * half)) & (PL == 32 ? ~0u : 0xFFFFu);
+                    if (l == 0 && mine != 0u) atomicAdd(diag, 1u);
+                }
                 lim_mem = (inst ? 1 : 0) | (actv ? 2 : 0);
                 cinst_mem = cinst;
                 cact_mem = cact;

@@ -103,8 +103,7 @@ def test_pen_hand_config_size_65536x64(pen):
     (duplicated particles agree bit for bit, obs[t] = next_obs[t-1], the cost is the distance part plus an orientation
     part in [-1, 1]); the oracle on every 4099th particle at 1e-9 over all 64 env steps (measured: median 3e-15, max 3e-13 of
     the costs - a pen held by friction does not amplify rounding the way the running cheetah does).  The active-set iteration
-    gives up on a few particle-substeps in 10^6 here (thirteen friction pyramids, mu = 1; the counter adds one per lane; DESIGN
-    4.6.2): reported, bounded."""
+    gives up on a few particle-substeps in 10^6 here (thirteen friction pyramids, mu = 1): reported, bounded."""
     import torch
     raw, eng, ref, st = pen
     q, v, u = _settled(ref, st)
@@ -133,4 +132,4 @@ def test_pen_hand_config_size_65536x64(pen):
     print("pen 65536x64: cost error vs oracle median %.2e max %.2e; solver failures %d of %d particle-substeps"
           % (np.median(err), err.max(), eng.solver_failures() - fails0, P * H * raw.frame_skip))
     assert np.median(err) < 1e-12 and err.max() < 1e-9
-    assert eng.solver_failures() - fails0 < 2e-4 * P * H * raw.frame_skip
+    assert eng.solver_failures() - fails0 < 2e-5 * P * H * raw.frame_skip
