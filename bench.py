@@ -512,6 +512,13 @@ def main():
                                                noise_scale=noise_scale)
         print(json.dumps(out), flush=True)
     if world > 1:
+        # captured graphs that hold RCCL kernels go before the group does (its watchdog thread otherwise races the
+        # interpreter's shutdown: an abort at exit, one run in a few, after the line has been printed)
+        import gc
+        ctrl._graph = None
+        gc.collect()
+        torch.cuda.synchronize()
+        dist.barrier()
         dist.destroy_process_group()
 
 

@@ -264,7 +264,7 @@ class DeviceUpdater:
             _lib.check(self.lib.mjmpc_traj_cost(code, P, self.H, self.A, _vp(costs), _vp(self.gseq), self.gamma_zero,
                                                 _vp(ws), self.stream()))
         q_all_ptr, P_all = None, P
-        if G > 1:
+        if G > 1 or getattr(self.comm, "always_collective", False):    # (the flag: one-GPU tests of the sharded path)
             q0 = self._q0_view(ws, P)
             q_all = self.comm.all_gather_flat(q0)
             q_all_ptr, P_all = _vp(q_all), P * G

@@ -322,8 +322,9 @@ class OLGaussianMPC(Controller):
         return (not self._host_uploads_per_step() and self.noise_mode in ('device', 'device_mt19937') and getattr(self._rollout_fn, "accepts_device", False)
                 and self.base_action in ('null', 'repeat') and self.sample_mode == 'mean'
                 and (self._static_cov() or (self._device_cov() and self.noise_mode == 'device'))
-                and (self.dev.comm.world_size == 1 or (self._fused_capable()
-                                                       and getattr(self.dev.comm, "backend", "") == "nccl")))
+                and (self.dev.comm.world_size == 1 or getattr(self.dev.comm, "backend", "") == "nccl"))
+        # (sharded runs: RCCL collectives are captured with the iteration - MPPI / DMD-MPC one record all-gather, CEM its
+        # two exchanges, random shooting one; if the runtime refuses, every rank drops to eager launches together)
 
     def _static_cov(self):
         return False            # subclasses whose update leaves cov_action alone say True

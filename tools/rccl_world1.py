@@ -50,23 +50,71 @@ def run(P, comm, mono):
     again = [c.optimize({})[0] for _ in range(6)]
     torch.cuda.synchronize()
     assert np.abs(np.array(again) - np.array(acts)).max() < 1e-12, "the closed loop after reset() differs"
-    return np.array(acts), c
+    info = (c.local_particles, c._mono, getattr(c, "graph_fallback", False), c._graph not in (None, "direct"))
+    c._graph = None             # (captured graphs hold the communicator's resources: gone before the group is)
+    return np.array(acts), info
 
 
 ref, _ = run(512, None, True)                       # 512 particles on one GPU
 for mono in (True, False):
-    got, c = run(1024, ClaimsTwoRanks(), mono)      # "1024 over two ranks": this rank's 512 are the same particles
-    assert c.local_particles == 512 and c._mono == mono and not getattr(c, "graph_fallback", False)
-    assert c._graph not in (None, "direct"), "the sharded iteration should replay a captured graph"
+    got, info = run(1024, ClaimsTwoRanks(), mono)   # "1024 over two ranks": this rank's 512 are the same particles
+    assert info[0] == 512 and info[1] == mono and not info[2]
+    assert info[3], "the sharded iteration should replay a captured graph"
     err = np.abs(got - ref).max()
     if os.environ.get("RCCL_W1_DEBUG"):
         print(np.abs(got - ref).max(axis=1)); print(ref[:2]); print(got[:2])
     print("sharded iteration (%s) in a hipGraph with an RCCL all-gather: max |d action| vs the single-GPU run = %.2e"
           % ("rollout + record launches" if mono else "separate launches", err))
     assert err < 1e-9 or os.environ.get('RCCL_W1_DEBUG')
-print("ok")
-if "--time" not in sys.argv:
+
+# The other controllers' exchanges inside a captured graph: CEM (the q0 all-gather + the elite-record all-gather), DMD-MPC
+# with an adapting covariance and random shooting (one record all-gather each) over a REAL world-size-1 RCCL communicator
+# (its collectives are forced even where one rank could skip them) = the same controller without a communicator.
+from mjmpc_amd.control import CEM, DMDMPC, RandomShooting
+
+
+class AlwaysCollective(TorchDistComm):
+    always_collective = True
+
+
+def run_other(make, comm):
+    eng = ArmRolloutEngine(reacher7dof_raw(), dtype="f64")
+    kw = dict(d_state=25, d_obs=20, d_action=7, horizon=16, num_particles=512, n_iters=1, gamma=1.0, step_size=0.8,
+              action_lows=eng.action_lows, action_highs=eng.action_highs, filter_coeffs=[0.25, 0.8, 0.0], seed=5,
+              base_action="null", noise_mode="device", comm=comm)
+    c = make(kw)
+    c.rollout_fn = make_device_rollout_fn(eng)
+    c.set_sim_state_fn = lambda s: None
+    assert c._graph_capable()
+    c.enable_graph(post_step=eng.step_state)
+    acts = np.array([c.optimize({})[0] for _ in range(5)])
+    torch.cuda.synchronize()
+    assert c._graph is not None and not getattr(c, "graph_fallback", False)
+    c._graph = None             # (captured graphs hold the communicator's resources: gone before the group is)
+    return acts
+
+
+for name, make in (("CEM full covariance", lambda kw: CEM(init_cov=1.0, elite_frac=0.1, beta=0.1, cov_type="full", **kw)),
+                   ("DMD-MPC update_cov", lambda kw: DMDMPC(init_cov=1.0, lam=0.1, beta=0.1, update_cov=True, cov_type="diagonal", **kw)),
+                   ("random shooting", lambda kw: RandomShooting(init_cov=1.0, **kw))):
+    a0, a1 = run_other(make, None), run_other(make, AlwaysCollective())
+    err = np.abs(a0 - a1).max()
+    print("%s: captured iteration with its RCCL exchanges vs without a communicator: max |d action| = %.2e" % (name, err))
+    assert err < 1e-10
+print("ok", flush=True)
+
+
+def shutdown():
+    """Captured graphs that hold RCCL kernels must be gone before the process group is: the watchdog thread of the group
+    otherwise races interpreter shutdown (seen as an abort at exit, one run in a few)."""
+    import gc
+    gc.collect()
+    torch.cuda.synchronize()
     dist.destroy_process_group()
+
+
+if "--time" not in sys.argv:
+    shutdown()
 
 if "--time" in sys.argv:        # per-step time of the sharded iteration (4096 particles on this rank) beside the single-GPU one
     import time
@@ -86,9 +134,10 @@ if "--time" in sys.argv:        # per-step time of the sharded iteration (4096 p
         for _ in range(200):
             c.optimize({})
         torch.cuda.synchronize()
+        c._graph = None
         return (time.perf_counter() - t0) / 200 * 1e3
 
     print("single GPU, 4096 particles:                      %.4f ms per step" % timed(4096, None, True))
     print("rank of a sharded run (RCCL all-gather, 3 launches): %.4f ms per step" % timed(8192, ClaimsTwoRanks(), True))
     print("rank of a sharded run, separate launches:          %.4f ms per step" % timed(8192, ClaimsTwoRanks(), False))
-    dist.destroy_process_group()
+    shutdown()
