@@ -18,15 +18,19 @@ LIB = os.path.join(HERE, "libmjmpc_amd.so")
 ARCH = "gfx950"
 FLAGS = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-Wno-unused-value", "-Wno-pass-failed", "-I", CSRC]
 # The tree kernel's 16-lane dense instantiations (tree_rollout_dense.hip) run ONE wave per SIMD through long straight-line
-# phases: the iterative ILP scheduler interleaves their independent dependency chains better than the default
-# (occupancy-first) strategy - measured on MI355X: HalfCheetah 4096 x 32 f64 3.48 -> 3.13 ms, Swimmer 1.48 -> 1.29 ms,
-# f32 3.11 -> 2.85 ms.  The 32-lane instantiations and the arm kernel (hand-placed scheduling barriers) do not gain, and
-# one of the former crashes that scheduler in this compiler: they keep the default.
-PER_SOURCE_FLAGS = {"tree_rollout_dense.hip": ["-mllvm", "-amdgpu-sched-strategy=iterative-ilp"]}
+# phases: LLVM's iterative schedulers interleave their independent dependency chains better than the default strategy -
+# measured on MI355X: HalfCheetah 4096 x 32 f64 3.55 -> 3.12 ms, Swimmer 1.50 -> 1.33 ms, f32 32768 x 32 13.2 -> 12.4 ms
+# (iterative-ilp and iterative-maxocc alike).  The 32-lane instantiations and the arm kernel (hand-placed scheduling
+# barriers) do not gain and keep the default.  These schedulers crash this compiler on SOME variants of the kernel
+# (which ones changes with unrelated edits), so a source lists alternatives: the first that compiles is used, the plain
+# flags last.
+PER_SOURCE_FLAGS = {"tree_rollout_dense.hip": [["-mllvm", "-amdgpu-sched-strategy=iterative-ilp"],
+                                               ["-mllvm", "-amdgpu-sched-strategy=iterative-maxocc"]]}
 
 
-def flags_for(src):
-    return FLAGS + PER_SOURCE_FLAGS.get(os.path.basename(src), [])
+def flags_for(src, alternative=0):
+    alts = PER_SOURCE_FLAGS.get(os.path.basename(src), [])
+    return FLAGS + (alts[alternative] if alternative < len(alts) else [])
 
 
 def sources():
@@ -67,8 +71,8 @@ def build(force=False, verbose=False, extra_flags=(), lib=None):
 
     def compile_one(src):
         out = os.path.join(objdir, os.path.basename(_obj(src)))
-        extra = PER_SOURCE_FLAGS.get(os.path.basename(src), [])
-        for special in ([extra] if extra else []) + [[]]:
+        alts = PER_SOURCE_FLAGS.get(os.path.basename(src), [])
+        for special in list(alts) + [[]]:
             cmd = [hipcc] + FLAGS + special + list(extra_flags) + ["-c", src, "-o", out]
             if verbose:
                 cmd.insert(1, "-Rpass-analysis=kernel-resource-usage")
@@ -76,10 +80,9 @@ def build(force=False, verbose=False, extra_flags=(), lib=None):
             r = subprocess.run(cmd, capture_output=True, text=True)
             if r.returncode == 0 or not special:
                 break
-            # a scheduling strategy is a tuning flag: if this compiler cannot take it for this source (the iterative
-            # scheduler has crashed on some variants of the tree kernel), build the source without it and say so
-            sys.stderr.write("mjmpc_amd.build: %s did not compile with %s (%s); compiling it with the default flags\n"
-                             % (os.path.basename(src), " ".join(special), (r.stderr.strip().splitlines() or ["?"])[-1][:160]))
+            # a scheduling strategy is a tuning flag: if this compiler cannot take it for this source, try the next
+            sys.stderr.write("mjmpc_amd.build: %s did not compile with %s; trying the next alternative\n"
+                             % (os.path.basename(src), " ".join(special)))
         return src, r
 
     with ThreadPoolExecutor(max_workers=min(4, max(1, len(todo)))) as ex:

@@ -616,6 +616,35 @@ __device__ __forceinline__ T dense_solve(const T* r, T dinv, T b, int l) {
     return z - dinv * acc;
 }
 
+// Exact line search of the constraint solver's safeguard (see the Newton loop): the root in [0, 1] of the increasing,
+// piecewise linear  phi'(al) = g0 + al dg + sum over the particle's rows of D_r min(0, r_r + al dr_r) dr_r  - every lane
+// brings its limit row (Dl, rl, drl) and, as the owner of a contact point, that point's rows (Dc, rb[], drb[]).  Bisection
+// to 2^-24, then the secant between the last bracket (exact when no row switches inside it).  A function of its own,
+// not inlined: it runs in a few particle-substeps per million and must not cost the kernel's hot path registers.
+template <int PL, int NR, typename T>
+__device__ __noinline__ T exact_line_search(T g0, T dg, T Dl, T rl, T drl, T Dc, const T* rb, const T* drb) {
+    auto phi = [&](T al) -> T {
+        const T r = rl + al * drl;
+        T tsum = Dl * (r < T(0) ? r : T(0)) * drl;
+#pragma unroll
+        for (int k = 0; k < NR; ++k) {
+            const T rr = rb[k] + al * drb[k];
+            tsum += Dc * (rr < T(0) ? rr : T(0)) * drb[k];
+        }
+        return g0 + al * dg + sum_lanes<PL>(tsum);
+    };
+    T fhi = phi(T(1));
+    if (!(fhi > T(0))) return T(1);
+    T lo = T(0), hi = T(1), flo = phi(T(0));
+    if (!(flo < T(0))) return T(1);             // (numerically not a descent direction: take the Newton point)
+    for (int b = 0; b < 24; ++b) {
+        const T mid = T(0.5) * (lo + hi), fm = phi(mid);
+        if (fm > T(0)) { hi = mid; fhi = fm; } else { lo = mid; flo = fm; }
+    }
+    const T den = fhi - flo;
+    return den > T(0) ? lo - flo * (hi - lo) * rcp_(den) : lo;
+}
+
 // waves per SIMD the register allocation aims at: the lean kernels for short paths fit three (f32) / two (f64)
 // workgroups' LDS on a CU
 constexpr int min_waves(int scalar_bytes, int DP, bool fric) {
@@ -1202,7 +1231,72 @@ __global__ __launch_bounds__(64 * wg_waves(DP, FRIC, sizeof(T), PL), min_waves(s
                     }
                     TSYNC();
                 };
-                // the active set a solution belongs to next: a row stays / becomes active while its residual is negative
+                // the rows the owners' residuals ask for, as the particle's mask in every lane (bit s * NR + r: an OR over the
+                // owners' nibbles): a row stays / becomes active while its residual is negative
+                auto rows_from_res = [&](const T* res, mask_t cur) -> mask_t {
+                    unsigned nb = 0;
+                    if (my_pt) {
+                        const unsigned rows = rows_of(l);
+                        const T ar5 = X[A_CS + l * CS + 5];
+#pragma unroll
+                        for (int r = 0; r < NR; ++r) {
+                            const T arr = res[r];
+                            // f32: a row whose residual is within rounding of zero keeps its state (as in arm_rollout.hip)
+                            const T bc = sizeof(T) == 4 ? T(2e-5) * (fabs(ar5) + fabs(arr + ar5) + T(1)) : T(0);
+                            const bool was = (cur >> (l * NR + r)) & 1u;
+                            if (((rows >> r) & 1u) && (was ? !(arr > bc) : (arr < -bc))) nb |= 1u << r;
+                        }
+                    }
+                    if constexpr (NR == 1) {
+                        return (mask_t)or_lanes<PL>(nb << (l & 31));
+                    } else {
+                        const unsigned lo = or_lanes<PL>(l < 8 ? nb << (4 * l) : 0u);
+                        const unsigned hi = or_lanes<PL>((l >= 8 && l < 16) ? nb << (4 * (l - 8)) : 0u);
+                        return (mask_t)(((unsigned long long)hi << 32) | lo);
+                    }
+                };
+                // J' f of the rows of the set (act_, cact_) at the acceleration whose owner residuals are res (friction
+                // instantiation): the owners sum their rows' forces per Jacobian into cs[8:11], every dof collects its entries
+                auto force_of = [&](T xa_, const T* res, bool act_, mask_t cact_) -> T {
+                    T qf = act_ ? -D * (sig * xa_ - aref) * sig : T(0);
+                    if (ucinst != 0) {
+                        if (my_pt) {
+                            const unsigned bits = (unsigned)(cact_ >> (l * NR)) & ((1u << NR) - 1u);
+                            T* cs = X + A_CS + l * CS;
+                            const T Dc = cs[4];
+                            T fn = T(0), f1 = T(0), f2 = T(0);
+#pragma unroll
+                            for (int r = 0; r < NR; ++r) {
+                                const T fr = ((bits >> r) & 1u) ? -Dc * res[r] : T(0);
+                                fn += fr;
+                                if (FRIC) {
+                                    if (r < 2) f1 += (r & 1) ? -fr : fr;
+                                    else f2 += (r & 1) ? -fr : fr;
+                                }
+                            }
+                            const T mu = FRIC ? M[T_SPH + l * TREE_SPH_STRIDE + 7] : T(0);
+                            cs[8] = fn;
+                            cs[9] = mu * f1;
+                            cs[10] = mu * f2;
+                        }
+                        TSYNC();
+                        for (unsigned um = ucinst; um; um &= um - 1) {
+                            const int s = __builtin_ctz(um);
+                            const unsigned bits = (unsigned)(cact_ >> (s * NR)) & ((1u << NR) - 1u);
+                            if (!__any(bits != 0)) continue;
+                            const int oi = own_idx(s);
+                            if (oi >= 0 && bits) {
+                                const T* jrow = X + A_JC + s * NJ * DP;
+                                const T* cs = X + A_CS + s * CS;
+                                qf += jrow[oi] * cs[8];
+                                if (FRIC) qf += jrow[DP + oi] * cs[9] + jrow[2 * DP + oi] * cs[10];
+                            }
+                        }
+                        TSYNC();
+                    }
+                    return qf;
+                };
+                // the active set a solution belongs to next
                 auto next_set = [&](T xa_, mask_t cur) -> mask_t {
                     if constexpr (!FRIC) {
                         mask_t nxt = 0;
@@ -1219,27 +1313,7 @@ __global__ __launch_bounds__(64 * wg_waves(DP, FRIC, sizeof(T), PL), min_waves(s
                     }
                     T res[NR];
                     point_residuals(xa_, res);
-                    unsigned nb = 0;
-                    if (my_pt) {
-                        const unsigned rows = rows_of(l);
-                        const T ar5 = X[A_CS + l * CS + 5];
-#pragma unroll
-                        for (int r = 0; r < NR; ++r) {
-                            const T arr = res[r];
-                            // f32: a row whose residual is within rounding of zero keeps its state (as in arm_rollout.hip)
-                            const T bc = sizeof(T) == 4 ? T(2e-5) * (fabs(ar5) + fabs(arr + ar5) + T(1)) : T(0);
-                            const bool was = (cur >> (l * NR + r)) & 1u;
-                            if (((rows >> r) & 1u) && (was ? !(arr > bc) : (arr < -bc))) nb |= 1u << r;
-                        }
-                    }
-                    // every lane gets the particle's mask: bit s * NR + r, an OR over the owners' nibbles
-                    if constexpr (NR == 1) {
-                        return (mask_t)or_lanes<PL>(nb << (l & 31));
-                    } else {
-                        const unsigned lo = or_lanes<PL>(l < 8 ? nb << (4 * l) : 0u);
-                        const unsigned hi = or_lanes<PL>((l >= 8 && l < 16) ? nb << (4 * (l - 8)) : 0u);
-                        return (mask_t)(((unsigned long long)hi << 32) | lo);
-                    }
+                    return rows_from_res(res, cur);
                 };
                 // initial active set: a row that existed in the previous substep keeps its state, a new row is active
                 bool actv = inst && ((lim_mem & 1) ? (lim_mem & 2) != 0 : true);
@@ -1253,6 +1327,11 @@ __global__ __launch_bounds__(64 * wg_waves(DP, FRIC, sizeof(T), PL), min_waves(s
                 }
                 bool changed = true, act_pp = false;
                 mask_t cact_pp = 0;
+                constexpr int LS_START = 5;         // iterations before the safeguard takes over (friction instantiation)
+                bool ls_on = false;
+                T a_b = T(0), g_b = T(0), rb[NR];
+#pragma unroll
+                for (int r = 0; r < NR; ++r) rb[r] = T(0);
                 T xa = T(0);
                 clk.lap(-1);
                 for (int it = 0; it < TREE_MAXIT; ++it) {
@@ -1331,8 +1410,64 @@ __global__ __launch_bounds__(64 * wg_waves(DP, FRIC, sizeof(T), PL), min_waves(s
                     const T resl = sig * xa - aref;
                     const T band = sizeof(T) == 4 ? T(2e-5) * (fabs(aref) + fabs(xa) + T(1)) : T(0);
                     bool act2 = inst && (actv ? !(resl > band) : (resl < -band));
-                    mask_t cact2 = next_set(xa, cact);
+                    T rN[NR];                                   // friction instantiation: my point's residuals at xa
+                    mask_t cact2;
+                    if constexpr (FRIC) {
+                        point_residuals(xa, rN);
+                        cact2 = rows_from_res(rN, cact);
+                    } else {
+                        cact2 = next_set(xa, cact);
+                    }
                     changed = (act2 != actv) || (cact2 != cact);
+                    // SAFEGUARD (friction instantiation).  The plain iteration - solve with the set, adopt the set the solution
+                    // asks for - has no line search and can cycle when several friction pyramids switch rows together
+                    // (periods 3 and 4 seen on the pen-in-hand model; the iterate kept then was arbitrary).  From iteration
+                    // LS_START on it becomes MuJoCo's Newton method: a base point a_b with its set, the Newton point xa of
+                    // that set, and an EXACT line search on the true (piecewise quadratic, convex) objective between them:
+                    //   phi'(al) = p.(M a - tau) + sum_rows D_r min(0, r_r(a)) (J_r p),  a = a_b + al p,  p = xa - a_b,
+                    // where M a - tau is linear in al and known at both ends without a product with M: at a Newton point
+                    // it equals the constraint force J' f of the rows of its set (the solve's own equation), and the base
+                    // point inherits it by the same interpolation; the residuals are affine in al.
+                    if constexpr (FRIC) {
+                        if (it >= LS_START && __any(changed)) {
+                            const T gN = force_of(xa, rN, actv, cact);      // M xa - tau = J' f of the set's rows (the solve's equation)
+                            if (!ls_on) {
+                                a_b = xa;
+                                g_b = gN;
+#pragma unroll
+                                for (int r = 0; r < NR; ++r) rb[r] = rN[r];
+                                ls_on = true;
+                            } else {
+                                const unsigned long long fb = __ballot(changed);
+                                const bool pch = ((unsigned)(fb >> (PL * half)) & (PL == 32 ? ~0u : 0xFFFFu)) != 0u;
+                                if (pch) {      // (a particle whose Newton point reproduces its set has converged: full step)
+                                    const T pv = xa - a_b;
+                                    const T gbp = sum_lanes<PL>(g_b * pv), gNp = sum_lanes<PL>(gN * pv);
+                                    const T rl0 = sig * a_b - aref, rl1 = sig * xa - aref;
+                                    const T Dc = my_pt ? X[A_CS + l * CS + 4] : T(0);
+                                    const unsigned rows = my_pt ? rows_of(l) : 0u;
+                                    T drb[NR];
+#pragma unroll
+                                    for (int r = 0; r < NR; ++r) drb[r] = ((rows >> r) & 1u) ? rN[r] - rb[r] : T(0);
+                                    const T al = exact_line_search<PL, NR>(gbp, gNp - gbp, D, rl0, rl1 - rl0, Dc, rb, drb);
+                                    a_b += al * pv;
+                                    g_b += al * (gN - g_b);
+#pragma unroll
+                                    for (int r = 0; r < NR; ++r) rb[r] += al * (rN[r] - rb[r]);
+                                    xa = a_b;                   // the iterate: what is kept if the iterations run out
+                                    const T rlb = sig * a_b - aref;
+                                    act2 = inst && (rlb < T(0));
+                                    cact2 = rows_from_res(rb, cact);
+                                    changed = true;
+                                } else {
+                                    a_b = xa;
+                                    g_b = gN;
+#pragma unroll
+                                    for (int r = 0; r < NR; ++r) rb[r] = rN[r];
+                                }
+                            }
+                        }
+                    }
                     // One limit row j of a particle changed state (the usual reason for another iteration):
                     // H' = H + c e_j e_j', c = +-D_j, rhs' = rhs + c sig_j aref_j e_j.  With z = H^-1 e_j - one more pair of
                     // triangular solves with the factor at hand, a third of a factor + solve - Sherman-Morrison gives
@@ -1351,7 +1486,7 @@ __global__ __launch_bounds__(64 * wg_waves(DP, FRIC, sizeof(T), PL), min_waves(s
                             clk.count(20, nflip == 0u && ncf == 0u);     // only the other particle of the wave changed
                         }
 #endif
-                        if (!__any(cact2 != cact || nflip > 1u)) {
+                        if (!(FRIC && it >= LS_START) && !__any(cact2 != cact || nflip > 1u)) {
                             T zl;
                             if constexpr (DN > 0) zl = dense_solve<DN>(hd, hdinv, flip ? T(1) : T(0), l);
                             else zl = tree_solve<DP, PL>(hrow, flip ? T(1) : T(0), ELIM, AT, ROW, VEC, l, n_rounds, depth, max_depth, kt);
@@ -1406,42 +1541,10 @@ __global__ __launch_bounds__(64 * wg_waves(DP, FRIC, sizeof(T), PL), min_waves(s
                         const T arr = sum_lanes<PL>(jl * xa) - X[A_CS + s * CS + 5];
                         qfrc_c += ((cact >> s) & 1u) ? -X[A_CS + s * CS + 4] * arr * jl : T(0);
                     }
-                } else if (ucinst != 0) {
+                } else {
                     T res[NR];
-                    point_residuals(xa, res);
-                    if (my_pt) {        // my point's row forces, summed per Jacobian: on Jn, mu Jt1, mu Jt2
-                        const unsigned bits = (unsigned)(cact >> (l * NR)) & ((1u << NR) - 1u);
-                        T* cs = X + A_CS + l * CS;
-                        const T Dc = cs[4];
-                        T fn = T(0), f1 = T(0), f2 = T(0);
-#pragma unroll
-                        for (int r = 0; r < NR; ++r) {
-                            const T fr = ((bits >> r) & 1u) ? -Dc * res[r] : T(0);
-                            fn += fr;
-                            if (FRIC) {
-                                if (r < 2) f1 += (r & 1) ? -fr : fr;
-                                else f2 += (r & 1) ? -fr : fr;
-                            }
-                        }
-                        const T mu = FRIC ? M[T_SPH + l * TREE_SPH_STRIDE + 7] : T(0);
-                        cs[8] = fn;
-                        cs[9] = mu * f1;
-                        cs[10] = mu * f2;
-                    }
-                    TSYNC();
-                    for (unsigned um = ucinst; um; um &= um - 1) {
-                        const int s = __builtin_ctz(um);
-                        const unsigned bits = (unsigned)(cact >> (s * NR)) & ((1u << NR) - 1u);
-                        if (!__any(bits != 0)) continue;
-                        const int oi = own_idx(s);
-                        if (oi >= 0 && bits) {
-                            const T* jrow = X + A_JC + s * NJ * DP;
-                            const T* cs = X + A_CS + s * CS;
-                            qfrc_c += jrow[oi] * cs[8];
-                            if (FRIC) qfrc_c += jrow[DP + oi] * cs[9] + jrow[2 * DP + oi] * cs[10];
-                        }
-                    }
-                    TSYNC();
+                    if (ucinst != 0) point_residuals(xa, res);
+                    qfrc_c = force_of(xa, res, actv, cact);
                 }
             } else {
                 lim_mem = 0;

@@ -3,7 +3,10 @@
 import os,re,sys,subprocess
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from mjmpc_amd.build import flags_for
-out=subprocess.run(["/opt/rocm/bin/hipcc"]+flags_for(sys.argv[1])+["-Rpass-analysis=kernel-resource-usage","-c",sys.argv[1],"-o","/tmp/x.o"]+sys.argv[3:],capture_output=True,text=True).stderr
+for alt in range(3):        # (the product build's alternatives: the first flag set this compiler takes)
+    res=subprocess.run(["/opt/rocm/bin/hipcc"]+flags_for(sys.argv[1],alt)+["-Rpass-analysis=kernel-resource-usage","-c",sys.argv[1],"-o","/tmp/x.o"]+sys.argv[3:],capture_output=True,text=True)
+    if res.returncode==0: break
+out=res.stderr
 cur=None; rows={}
 for ln in out.splitlines():
     m=re.search(r"Function Name: (\S+)",ln)
