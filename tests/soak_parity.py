@@ -1,7 +1,7 @@
-"""Long randomized parity sweep, HIP kernels against the FP64 oracle (developer tool; the bounded versions live in
+"""Long randomized parity sweep, HIP kernels against the FP64 oracle (a checker, not collected by pytest; the bounded versions live in
 tests/test_stress_parity_gpu.py and tests/test_stress_locomotion_gpu.py).
 
-    python tools/soak_parity.py [trials] [seed]
+    python tests/soak_parity.py [trials] [seed]
 
 Per trial: a random model-appropriate start state, mean and filtered noise; arm 4096 x 32 (every cost), 24-dof hand
 512 x 16, pen-in-hand 256 x 8 from the settled pose, one env step of the cheetah / swimmer from 64 random states.  Prints the

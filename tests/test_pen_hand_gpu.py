@@ -140,7 +140,7 @@ def test_constraint_solver_converges_on_hard_contact_states(pen):
     0.3 rad on the servo set points), 256 x 8 rollouts each.  Before the solver's line-search safeguard the
     plain active-set iteration cycled with periods 3 and 4 on a handful of these particle-substeps, kept an arbitrary
     iterate and the rollout blew up (cost 1e45 in trial 59); now: no solver failure, and every cost within 1e-4 relative of
-    the oracle (measured 3e-8; 7e-6 in a longer sweep of tools/soak_parity.py: eight env steps of contact dynamics under large perturbations amplify rounding; the gentle
+    the oracle (measured 3e-8; 7e-6 in a longer sweep of tests/soak_parity.py: eight env steps of contact dynamics under large perturbations amplify rounding; the gentle
     cases above hold 1e-9)."""
     raw, eng, ref, st = pen
     q, v, u = _settled(ref, st)
