@@ -3,13 +3,17 @@
 // double loop as arm_rollout.hip (reference mjmpc/envs/gym_env_wrapper.py:125-153, MuJoCo mj_step inlined), for
 // models the 8-lane serial-chain kernel cannot hold: up to 32 dofs on a branching tree (a hand on an arm; the
 // reference's vendored swimmer.xml and half_cheetah.xml with their slide/slide/hinge floating roots), gravity, joint
-// limits and springs, motors on a subset of the joints, the inertia-box fluid model, up to 16 sphere/plane contact
-// points (capsule ends) with frictionless rows or pyramidal friction cones.  Cost and observation follow the model's
-// task: the reacher's (reacher_env.py:29-47) or forward progress (swimmer.py:10-24, half_cheetah.py:10-25).
+// limits and springs, motors or position servos on a subset of the joints, the inertia-box fluid model, up to 16 contact
+// points - sphere / capsule end against the plane, or sphere / capsule geom-geom pairs (an object in a hand; the swimmer's
+// self-collision) - with frictionless rows or pyramidal friction cones.  Cost and observation follow the model's task: the
+// reacher's (reacher_env.py:29-47), forward progress (swimmer.py:10-24, half_cheetah.py:10-25) or the shape of pen-v0's
+// reorientation reward (examples/configs/hand/pen-v0.yml:8).
 //
 // Execution model: ONE PARTICLE = 32 LANES (lane = link = dof, links numbered depth-first), two particles per
-// wavefront, four wavefronts per workgroup sharing one LDS copy of the model block and of the topology tables.  Lanes talk through a small
-// per-particle LDS area (a wavefront owns its area: in-order LDS, no s_barrier).  Everything is expressed in world
+// wavefront - or 16 lanes (one DPP row) and four particles per wavefront for models of up to 16 dofs, which also factor
+// densely in registers (tree_rollout_dense.hip) - and up to four wavefronts per workgroup sharing one LDS copy of the
+// model's constants.  Lanes talk through a small per-particle LDS area (a wavefront owns its area: in-order LDS, no
+// s_barrier).  Everything is expressed in world
 // coordinates about the world origin, so the tree recursions become
 //   root-to-link accumulations  (forward kinematics, spatial velocity, velocity-product acceleration)
 //       = pointer jumping over the ancestor tables (ceil(log2 depth) rounds of "read my 2^k-th ancestor"),
@@ -24,8 +28,11 @@
 // eliminated TOGETHER: one round per height (8 rounds, not 24 pivots), every lane pulling the rows of its descendants
 // of that height from LDS (a host-built list per lane).  H = M + J'DJ keeps the pattern (a contact row couples only
 // dofs on one path), so the constraint solver and the Euler solve use the same factorisation; the two triangular
-// solves run leaves-first (L') and root-first (L), one LDS round per height / depth.  The soft-constraint problem
-// is the arm kernel's primal active-set Newton iteration, with several contact rows.
+// solves run leaves-first (L') and root-first (L), one LDS round per height / depth - except for the TRUNK (the chain of
+// single-child links from the root), which is factored and solved in registers with DPP broadcasts.  A geom-geom contact
+// between two trees is kept inside that pattern by an ELIMINATION tree that hangs the manipulator under the object
+// (compile_tree.py).  The soft-constraint problem is the arm kernel's primal active-set Newton iteration with several
+// contact rows; in the friction instantiation an exact line search takes over when it does not settle (MuJoCo's Newton).
 #include <hip/hip_runtime.h>
 
 #include <type_traits>
@@ -43,7 +50,6 @@ constexpr int TREE_MAXIT = 16;
 #ifndef TREE_SKIP
 #define TREE_SKIP 0
 #endif
-// waves per workgroup (LDS: [32][2 DP] rows per particle, plus three Jacobian rows per contact point with friction)
 // developer builds (-DTREE_STATS, tools/tree_stats.py): shader-clock per phase and Newton iteration counts of the first
 // particle of the launch, accumulated behind the failure counter (diag + 2 ... as 64-bit words)
 #ifdef TREE_STATS
