@@ -24,8 +24,8 @@ FLAGS = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-Wno-unused-va
 # barriers) do not gain and keep the default.  These schedulers crash this compiler on SOME variants of the kernel
 # (which ones changes with unrelated edits), so a source lists alternatives: the first that compiles is used, the plain
 # flags last.
-PER_SOURCE_FLAGS = {"tree_rollout_dense.hip": [["-mllvm", "-amdgpu-sched-strategy=iterative-ilp"],
-                                               ["-mllvm", "-amdgpu-sched-strategy=iterative-maxocc"]]}
+PER_SOURCE_FLAGS = {"tree_rollout_dense.hip": [["-mllvm", "-amdgpu-sched-strategy=iterative-maxocc"],
+                                               ["-mllvm", "-amdgpu-sched-strategy=iterative-ilp"]]}
 
 
 def flags_for(src, alternative=0):
