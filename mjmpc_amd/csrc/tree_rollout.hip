@@ -45,6 +45,9 @@ namespace mjmpc {
 namespace {
 
 constexpr int TREE_MAXIT = 16;
+#ifndef TREE_DPP_SUBTREE
+#define TREE_DPP_SUBTREE 1
+#endif
 // developer switch for phase timing (tools/tree_time.py with a build -DTREE_SKIP=bits): 1 = no Newton iteration,
 // 2 = no Euler factor/solve, 4 = no mass-matrix assembly, 8 = no bias forces.  Product builds: 0.
 #ifndef TREE_SKIP
@@ -215,6 +218,24 @@ __device__ __forceinline__ void path_sum(T* x, const Topo& tp, T* X, int l) {
 template <int NC, int PL, typename T>
 __device__ __forceinline__ void subtree_sum(T* x, const Topo& tp, T* X, int l) {
     static_assert(NC <= 6, "two buffers of NC x PL must fit the 12 x PL exchange area");
+    if constexpr (PL == 16 && TREE_DPP_SUBTREE) {
+        // 16-lane particles: a particle is one DPP row, so the suffix sums S_l = x_l + ... + x_15 are four zero-filling
+        // row shifts, and the subtree [l, l + n) is S_l - S_{l+n} (one ds_bpermute per dword; no LDS round trip).  The
+        // difference cancels: relative error eps * (sum over the links behind me in the row / my subtree's) - a factor
+        // of a few on the models this runs (<= 16 links), against the exact doubling tables of the 32-lane particles.
+#pragma unroll
+        for (int c = 0; c < NC; ++c) {
+            T s = x[c];
+            s += dpp_zero<0x101>(s);        // row_shl:1
+            s += dpp_zero<0x102>(s);
+            s += dpp_zero<0x104>(s);
+            s += dpp_zero<0x108>(s);
+            const int end = l + tp.subsize;
+            const T tail = __shfl(s, end & 15, 16);
+            x[c] = s - (end < 16 ? tail : T(0));
+        }
+        return;
+    }
     constexpr int LOG = PL == 32 ? 5 : 4;
     T cur[NC], acc[NC];
 #pragma unroll
