@@ -1188,13 +1188,14 @@ __global__ __launch_bounds__(64 * wg_waves(DP, FRIC, sizeof(T), PL), min_waves(s
                     T* cs = X + A_CS + l * CS;
                     const int link = (int)sp[0], dsl = (int)sp[11];
                     T jv = T(0), j1v = T(0), j2v = T(0);
+                    int pa[DP];
 #pragma unroll
-                    for (int c = 0; c < DP; ++c) {
-                        if (c <= dsl) {
-                            const T xv = VEC[AT[c * PL + link]];
-                            jv += jrow[c] * xv;
-                            if (FRIC) { j1v += jrow[DP + c] * xv; j2v += jrow[2 * DP + c] * xv; }
-                        }
+                    for (int c = 0; c < DP; ++c) pa[c] = AT[(c <= dsl ? c : 0) * PL + link];
+#pragma unroll
+                    for (int c = 0; c < DP; ++c) {       // (branch-free, as in point_residuals: zeros past the root)
+                        const T xv = VEC[pa[c]];
+                        jv += jrow[c] * xv;
+                        if (FRIC) { j1v += jrow[DP + c] * xv; j2v += jrow[2 * DP + c] * xv; }
                     }
                     const T mu = FRIC ? sp[7] : T(0);
                     T Dc, arc;
@@ -1235,13 +1236,16 @@ __global__ __launch_bounds__(64 * wg_waves(DP, FRIC, sizeof(T), PL), min_waves(s
                         const T* sp = M + T_SPH + l * TREE_SPH_STRIDE;
                         const T* jrow = X + A_JC + l * NJ * DP;
                         const int link = (int)sp[0], dsl = (int)sp[11];
+                        // (branch-free: entries past the root are zero in the three rows - written so by the rows phase -
+                        // and the index is clamped, so that all the loads of the walk are in flight together)
+                        int pa[DP];
+#pragma unroll
+                        for (int c = 0; c < DP; ++c) pa[c] = AT[(c <= dsl ? c : 0) * PL + link];
 #pragma unroll
                         for (int c = 0; c < DP; ++c) {
-                            if (c <= dsl) {
-                                const T xv = VEC[AT[c * PL + link]];
-                                an += jrow[c] * xv;
-                                if (FRIC) { a1 += jrow[DP + c] * xv; a2 += jrow[2 * DP + c] * xv; }
-                            }
+                            const T xv = VEC[pa[c]];
+                            an += jrow[c] * xv;
+                            if (FRIC) { a1 += jrow[DP + c] * xv; a2 += jrow[2 * DP + c] * xv; }
                         }
                     }
                     const T* cs = X + A_CS + (l < NS ? l : 0) * CS;
