@@ -749,6 +749,21 @@ __global__ __launch_bounds__(64 * wg_waves(DP, FRIC, sizeof(T), PL), min_waves(s
     const int act_id = (int)model[T_ACT + l];
     const bool fluid = FRIC && (M[T_DENSITY] > T(0) || M[T_VISCOSITY] > T(0));   // (the full instantiation only)
 
+    // my place on the path of every contact point (5 bits each: 1 + the distance from the point's link up to me, 0 if I
+    // am not on that path) - a constant of the model; the contact code reads it instead of two LDS tables
+    unsigned long long own_path0 = 0;
+    unsigned own_path1 = 0;
+    {
+        const int ns_ = min((int)M[T_N_SPHERE], NS);
+        const bool dof_ = l < (int)M[T_NV];
+        for (int s = 0; s < ns_; ++s) {
+            const T* sp = M + T_SPH + s * TREE_SPH_STRIDE;
+            const int idx = (int)sp[11] - depth;
+            const int code = (dof_ && idx >= 0 && idx < DP && AT[idx * PL + (int)sp[0]] == l) ? idx + 1 : 0;
+            if (s < 12) own_path0 |= (unsigned long long)code << (5 * s);
+            else own_path1 |= (unsigned)code << (5 * (s - 12));
+        }
+    }
     Topo tp;
     tp.parent = (int)model[T_PARENT + l];
     tp.subsize = (int)model[T_SUBSIZE + l];
@@ -1124,10 +1139,10 @@ __global__ __launch_bounds__(64 * wg_waves(DP, FRIC, sizeof(T), PL), min_waves(s
             // diagApprox = tran (1 + mu^2), R = 2 mu^2 R_first, and its own reference acceleration.
             // my entry of the Jacobian rows of point s: the distance from its link up to me, -1 if I am not on that path
             // (or the point is not in contact for my particle)
+            // (where I sit on the point's path is a constant of the model, packed once per launch: own_path)
             auto own_idx = [&](int s) -> int {
-                const T* sp = M + T_SPH + s * TREE_SPH_STRIDE;
-                const int idx = (int)sp[11] - depth;
-                return (((cinst >> s) & 1u) && dof && idx >= 0 && AT[idx * PL + (int)sp[0]] == l) ? idx : -1;
+                const int code = s < 12 ? (int)((own_path0 >> (5 * s)) & 31ull) : (int)((own_path1 >> (5 * (s - 12))) & 31u);
+                return ((cinst >> s) & 1u) ? code - 1 : -1;
             };
             for (unsigned um = ucinst; um; um &= um - 1) {
                 const int s = __builtin_ctz(um);
