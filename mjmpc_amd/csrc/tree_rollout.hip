@@ -330,6 +330,17 @@ template <int K>
 __device__ __forceinline__ void fma_bcast(float& acc, float x, float m) {
     asm volatile("s_nop 1\n\tv_fmac_f32_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(x), "v"(m), "n"(K));
 }
+// ... the same WITHOUT the wait states: for a broadcast source that no VALU instruction has written within the last two
+// issue slots (a register that is only read in the surrounding sequence; callers say why)
+template <int K>
+__device__ __forceinline__ void fma_bcast_settled(double& acc, double x, double m) {
+    asm volatile("v_fmac_f64_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(x), "v"(m), "n"(K));
+}
+template <int K>
+__device__ __forceinline__ void fma_bcast_settled(float& acc, float x, float m) {
+    asm volatile("v_fmac_f32_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(x), "v"(m), "n"(K));
+}
+__device__ __forceinline__ void dpp_settle() { asm volatile("s_nop 1"); }
 
 // my (symmetric) row of H from its path-indexed form, through the particle's tile: tile[l][anc] = tile[anc][l] = h[c],
 // zero elsewhere.  (The tile shares the exchange area of the kinematics: cleared on every use.)
@@ -376,11 +387,11 @@ struct TrunkStep {
             }
             fj *= invd;
             const T nf = -fj;
+            dpp_settle();
 #pragma unroll
-            for (int col = 0; col < K; ++col) {
-                fma_bcast<K>(ra[col], ra[col], nf);                 // A[l][col] -= f_l A[K][col]   (lanes >= K: f = 0)
-                ra[col] = (l == K) ? ra[col] * invd : ra[col];      // row K itself becomes L[K][.]
-            }
+            for (int col = 0; col < K; ++col) fma_bcast_settled<K>(ra[col], ra[col], nf);   // A[l][col] -= f_l A[K][col]  (lanes >= K: f = 0)
+#pragma unroll
+            for (int col = 0; col < K; ++col) ra[col] = (l == K) ? ra[col] * invd : ra[col];  // row K itself becomes L[K][.]
         }
         if constexpr (K > 1) TrunkStep<K - 1, KT, T>::run(ra, l, kt);
     }
@@ -587,10 +598,11 @@ __device__ __forceinline__ T tree_solve(const T* r, T b, const int* ELIM, const 
 // r[j] += wn (lane j's jn) + w1 (lane j's j1) + w2 (lane j's j2): the contribution of one contact point to my dense row
 template <int J, int DN, bool FRIC, typename T>
 __device__ __forceinline__ void dense_contact(T* r, T jn, T j1, T j2, T wn, T w1, T w2) {
-    fma_bcast<J>(r[J], jn, wn);
+    if constexpr (J == 0) dpp_settle();         // (jn, j1, j2 are only read from here on: one pair of wait states for all)
+    fma_bcast_settled<J>(r[J], jn, wn);
     if constexpr (FRIC) {
-        fma_bcast<J>(r[J], j1, w1);
-        fma_bcast<J>(r[J], j2, w2);
+        fma_bcast_settled<J>(r[J], j1, w1);
+        fma_bcast_settled<J>(r[J], j2, w2);
     }
     if constexpr (J + 1 < DN) dense_contact<J + 1, DN, FRIC>(r, jn, j1, j2, wn, w1, w2);
 }
@@ -603,8 +615,9 @@ struct DenseStep {
         const T inv = rcp_(bcast_row<K>(r[K]));
         dinv = l == K ? inv : dinv;
         const T lik = l > K ? r[K] * inv : T(0), nlik = -lik;
+        dpp_settle();       // (the r[j] below were last written a pivot ago; one pair of wait states covers the select above)
 #pragma unroll
-        for (int j = K + 1; j < DN; ++j) fma_bcast<K>(r[j], r[j], nlik);       // r[j] -= lik * (lane K's r[j])
+        for (int j = K + 1; j < DN; ++j) fma_bcast_settled<K>(r[j], r[j], nlik);       // r[j] -= lik * (lane K's r[j])
         r[K] = l > K ? lik : r[K];
         if constexpr (K + 1 < DN) DenseStep<K + 1, DN, T>::run(r, dinv, l);
     }
