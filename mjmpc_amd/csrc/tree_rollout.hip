@@ -595,6 +595,21 @@ __device__ __forceinline__ T tree_solve(const T* r, T b, const int* ELIM, const 
     return b;
 }
 
+// my dense row of the mass matrix: md[j] = S_j . F_l (j an ancestor of l, or l), S_l . F_j (j in l's subtree), else 0
+template <int J, int DN, typename T>
+__device__ __forceinline__ void dense_mass_row(T* md, const T* S, const T* F, int l, unsigned ancmask, int subsize, bool dof) {
+    if constexpr (J == 0) dpp_settle();         // (S and F are only read below)
+    T up = T(0), dn = T(0);
+#pragma unroll
+    for (int k = 0; k < 6; ++k) {
+        fma_bcast_settled<J>(up, S[k], F[k]);   // (lane J's S) . (my F)
+        fma_bcast_settled<J>(dn, F[k], S[k]);   // (lane J's F) . (my S)
+    }
+    const bool anc = (ancmask >> J) & 1u, sub = J > l && J < l + subsize;
+    md[J] = dof ? (anc ? up : (sub ? dn : T(0))) : T(0);
+    if constexpr (J + 1 < DN) dense_mass_row<J + 1, DN>(md, S, F, l, ancmask, subsize, dof);
+}
+
 // r[j] += wn (lane j's jn) + w1 (lane j's j1) + w2 (lane j's j2): the contribution of one contact point to my dense row
 template <int J, int DN, bool FRIC, typename T>
 __device__ __forceinline__ void dense_contact(T* r, T jn, T j1, T j2, T wn, T w1, T w2) {
@@ -1107,6 +1122,9 @@ __global__ __launch_bounds__(64 * wg_waves(DP, FRIC, sizeof(T), PL), min_waves(s
             //         mrow[c] = M[l][ancestor at distance c] = S_anc . F_l
             clk.mark(1);
             T mrow[DP];
+            // dense path: my row of M as a DENSE row, once per substep - the Newton matrices and the Euler matrix are this
+            // row plus diagonal terms plus broadcast products of the contact Jacobians (no tile round trip per matrix)
+            T md[DN > 0 ? DN : 1];
             {
                 T c6[6] = {Ib[0], Ib[1], Ib[2], Ib[3], Ib[4], Ib[5]}, c4[4] = {mass, hm[0], hm[1], hm[2]};
                 subtree_sum<6, PL>(c6, tp, X, l);
@@ -1116,6 +1134,17 @@ __global__ __launch_bounds__(64 * wg_waves(DP, FRIC, sizeof(T), PL), min_waves(s
                 cross3(c4 + 1, sv, t1);
                 cross3(c4 + 1, sw, t2);
                 for (int k = 0; k < 3; ++k) { F[k] += t1[k]; F[3 + k] = c4[0] * sv[k] - t2[k]; }
+                if constexpr (DN > 0) {
+                    // 16-lane particles: my DENSE row straight from DPP broadcasts - column j is S_j . F_l where j is one of
+                    // my ancestors (or me), S_l . F_j where j lies in my subtree, zero otherwise; no LDS, no path-indexed row
+                    const T Sl[6] = {sw[0], sw[1], sw[2], sv[0], sv[1], sv[2]};
+                    dense_mass_row<0, DN>(md, Sl, F, l, tp.ancmask, tp.subsize, dof);
+#pragma unroll
+                    for (int j = 0; j < DN; ++j) md[j] = (j == l) ? (dof ? md[j] + armature : T(1)) : md[j];
+#pragma unroll
+                    for (int c = 0; c < DP; ++c) mrow[c] = T(0);
+                    mrow[0] = T(1);
+                } else {
                 T* S_ = X + A_SF;
                 for (int k = 0; k < 3; ++k) { S_[k * PL + l] = sw[k]; S_[(3 + k) * PL + l] = sv[k]; }
                 TSYNC();
@@ -1133,6 +1162,7 @@ __global__ __launch_bounds__(64 * wg_waves(DP, FRIC, sizeof(T), PL), min_waves(s
                 }
                 mrow[0] = dof ? mrow[0] + armature : T(1);     // spare lanes: unit diagonal, no ancestors
                 TSYNC();                    // S_ lies inside the area the factorisation publishes rows to
+                }
             }
             // (position servos: the bias -kp * (gear q) of MJCF <position>, a stiffness gear^2 kp about 0 at the joint)
             const T tau = dof ? -bias - damping * v - (FRIC ? M[T_STIFFNESS + l] * (q - M[T_SPRINGREF + l]) + M[T_KPG + l] * q : T(0)) + tau_act : T(0);
@@ -1238,10 +1268,6 @@ __global__ __launch_bounds__(64 * wg_waves(DP, FRIC, sizeof(T), PL), min_waves(s
             const bool any_rows = !(TREE_SKIP & 1) && __any(inst || cinst != 0);
             T qfrc_c = T(0);
             T erow[MERGE ? DP : 1];      // factor of the Euler matrix when it was computed beside the first Newton factor
-            // dense path: my row of M as a DENSE row, once per substep - the Newton matrices and the Euler matrix are this
-            // row plus diagonal terms plus broadcast products of the contact Jacobians (no tile round trip per matrix)
-            T md[DN > 0 ? DN : 1];
-            if constexpr (DN > 0) dense_row<DP, DN, PL>(mrow, AT, ROW, l, md);
             clk.mark(3);
             clk.count(8, 1);
             clk.count(9, __popc(cinst));
