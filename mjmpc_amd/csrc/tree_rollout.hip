@@ -188,6 +188,106 @@ __device__ __forceinline__ unsigned or_lanes(unsigned x) {
     return x;
 }
 
+// ---- DPP row broadcasts (a 16-lane row: a whole 16-lane particle, or the first half of a 32-lane one) -----------
+template <int K>
+__device__ __forceinline__ float bcast_row(float x) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0x150 + K, 0xF, 0xF, false));
+}
+template <int K>
+__device__ __forceinline__ double bcast_row(double x) {
+    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(x), 0x150 + K, 0xF, 0xF, false);
+    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(x), 0x150 + K, 0xF, 0xF, false);
+    return __hiloint2double(hi, lo);
+}
+
+// acc += (lane K's x) * m  in ONE instruction: v_fmac with a DPP row_newbcast source (f64 DPP knows no other control).
+// The two wait states a DPP read wants after a VALU write of the same register (GFX9 hazard; the compiler cannot see
+// into the asm) are spelled out.
+template <int K>
+__device__ __forceinline__ void fma_bcast(double& acc, double x, double m) {
+    asm volatile("s_nop 1\n\tv_fmac_f64_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(x), "v"(m), "n"(K));
+}
+template <int K>
+__device__ __forceinline__ void fma_bcast(float& acc, float x, float m) {
+    asm volatile("s_nop 1\n\tv_fmac_f32_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(x), "v"(m), "n"(K));
+}
+// GROUPS of such broadcast FMAs as ONE asm statement each: the wait states once, in front, and nothing the compiler could
+// put between the instructions.  (Dropping the wait states from single-instruction statements whose sources "are only
+// read in the surrounding sequence" measured 10 % faster on the cheetah and was withdrawn: the compiler may reload such
+// a register from an AGPR, or finish computing it, right before the statement - f32 HalfCheetah failed its parity test
+// that way.  Inside one statement that cannot happen; a source written by an EARLIER instruction of the group is a
+// plain VALU dependency, which the hardware interlocks - only the DPP read of a freshly written register is not.)
+#define MJMPC_BC " row_newbcast:%"
+#define MJMPC_BCT " row_mask:0xf bank_mask:0xf\n\t"
+#define MJMPC_DPP_GROUPS(T_, SFX_)                                                                                          \
+    /* acc += (lane K's x0) * m0 + (lane K's x1) * m1 + (lane K's x2) * m2 */                                               \
+    template <int K>                                                                                                        \
+    __device__ __forceinline__ void fma_bcast_3(T_& acc, T_ x0, T_ x1, T_ x2, T_ m0, T_ m1, T_ m2) {                       \
+        asm volatile("s_nop 1\n\t"                                                                                        \
+                     "v_fmac_" SFX_ "_dpp %0, %1, %4" MJMPC_BC "7" MJMPC_BCT                                                \
+                     "v_fmac_" SFX_ "_dpp %0, %2, %5" MJMPC_BC "7" MJMPC_BCT                                                \
+                     "v_fmac_" SFX_ "_dpp %0, %3, %6" MJMPC_BC "7 row_mask:0xf bank_mask:0xf"                               \
+                     : "+v"(acc) : "v"(x0), "v"(x1), "v"(x2), "v"(m0), "v"(m1), "v"(m2), "n"(K));                          \
+    }                                                                                                                       \
+    /* a_i += (lane K's a_i) * m, four accumulators */                                                                      \
+    template <int K>                                                                                                        \
+    __device__ __forceinline__ void fma_bcast_self4(T_& a0, T_& a1, T_& a2, T_& a3, T_ m) {                                \
+        asm volatile("s_nop 1\n\t"                                                                                        \
+                     "v_fmac_" SFX_ "_dpp %0, %0, %4" MJMPC_BC "5" MJMPC_BCT                                                \
+                     "v_fmac_" SFX_ "_dpp %1, %1, %4" MJMPC_BC "5" MJMPC_BCT                                                \
+                     "v_fmac_" SFX_ "_dpp %2, %2, %4" MJMPC_BC "5" MJMPC_BCT                                                \
+                     "v_fmac_" SFX_ "_dpp %3, %3, %4" MJMPC_BC "5 row_mask:0xf bank_mask:0xf"                               \
+                     : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3) : "v"(m), "n"(K));                                           \
+    }                                                                                                                       \
+    /* acc[c] += (lane K's x[c]) * m, six components */                                                                     \
+    template <int K>                                                                                                        \
+    __device__ __forceinline__ void fma_bcast_vec6(T_* acc, const T_* x, T_ m) {                                           \
+        asm volatile("s_nop 1\n\t"                                                                                        \
+                     "v_fmac_" SFX_ "_dpp %0, %6, %12" MJMPC_BC "13" MJMPC_BCT                                              \
+                     "v_fmac_" SFX_ "_dpp %1, %7, %12" MJMPC_BC "13" MJMPC_BCT                                              \
+                     "v_fmac_" SFX_ "_dpp %2, %8, %12" MJMPC_BC "13" MJMPC_BCT                                              \
+                     "v_fmac_" SFX_ "_dpp %3, %9, %12" MJMPC_BC "13" MJMPC_BCT                                              \
+                     "v_fmac_" SFX_ "_dpp %4, %10, %12" MJMPC_BC "13" MJMPC_BCT                                             \
+                     "v_fmac_" SFX_ "_dpp %5, %11, %12" MJMPC_BC "13 row_mask:0xf bank_mask:0xf"                            \
+                     : "+v"(acc[0]), "+v"(acc[1]), "+v"(acc[2]), "+v"(acc[3]), "+v"(acc[4]), "+v"(acc[5])                  \
+                     : "v"(x[0]), "v"(x[1]), "v"(x[2]), "v"(x[3]), "v"(x[4]), "v"(x[5]), "v"(m), "n"(K));                 \
+    }                                                                                                                       \
+    /* up += (lane K's s) . f,  dn += (lane K's f) . s   over six components */                                             \
+    template <int K>                                                                                                        \
+    __device__ __forceinline__ void fma_bcast_dots6(T_& up, T_& dn, const T_* s, const T_* f) {                            \
+        asm volatile("s_nop 1\n\t"                                                                                        \
+                     "v_fmac_" SFX_ "_dpp %0, %2, %8" MJMPC_BC "14" MJMPC_BCT                                               \
+                     "v_fmac_" SFX_ "_dpp %1, %8, %2" MJMPC_BC "14" MJMPC_BCT                                               \
+                     "v_fmac_" SFX_ "_dpp %0, %3, %9" MJMPC_BC "14" MJMPC_BCT                                               \
+                     "v_fmac_" SFX_ "_dpp %1, %9, %3" MJMPC_BC "14" MJMPC_BCT                                               \
+                     "v_fmac_" SFX_ "_dpp %0, %4, %10" MJMPC_BC "14" MJMPC_BCT                                              \
+                     "v_fmac_" SFX_ "_dpp %1, %10, %4" MJMPC_BC "14" MJMPC_BCT                                              \
+                     "v_fmac_" SFX_ "_dpp %0, %5, %11" MJMPC_BC "14" MJMPC_BCT                                              \
+                     "v_fmac_" SFX_ "_dpp %1, %11, %5" MJMPC_BC "14" MJMPC_BCT                                              \
+                     "v_fmac_" SFX_ "_dpp %0, %6, %12" MJMPC_BC "14" MJMPC_BCT                                              \
+                     "v_fmac_" SFX_ "_dpp %1, %12, %6" MJMPC_BC "14" MJMPC_BCT                                              \
+                     "v_fmac_" SFX_ "_dpp %0, %7, %13" MJMPC_BC "14" MJMPC_BCT                                              \
+                     "v_fmac_" SFX_ "_dpp %1, %13, %7" MJMPC_BC "14 row_mask:0xf bank_mask:0xf"                             \
+                     : "+v"(up), "+v"(dn)                                                                                   \
+                     : "v"(s[0]), "v"(s[1]), "v"(s[2]), "v"(s[3]), "v"(s[4]), "v"(s[5]), "v"(f[0]), "v"(f[1]), "v"(f[2]),  \
+                       "v"(f[3]), "v"(f[4]), "v"(f[5]), "n"(K));                                                           \
+    }
+MJMPC_DPP_GROUPS(double, "f64")
+MJMPC_DPP_GROUPS(float, "f32")
+#undef MJMPC_DPP_GROUPS
+
+// a_j += (lane K's a_j) * m for j in [J0, J1): groups of four, then singles
+template <int K, int J0, int J1, typename T>
+__device__ __forceinline__ void fma_bcast_self_range(T* a, T m) {
+    if constexpr (J1 - J0 >= 4) {
+        fma_bcast_self4<K>(a[J0], a[J0 + 1], a[J0 + 2], a[J0 + 3], m);
+        fma_bcast_self_range<K, J0 + 4, J1>(a, m);
+    } else if constexpr (J1 - J0 >= 1) {
+        fma_bcast<K>(a[J0], a[J0], m);
+        fma_bcast_self_range<K, J0 + 1, J1>(a, m);
+    }
+}
+
 struct Topo {       // my link's place in the tree (registers)
     int parent, subsize, jumps;
     int anc[5];     // my ancestor at distance 2^k (pointer jumping), -1 beyond the root; only ever indexed by an
@@ -196,8 +296,24 @@ struct Topo {       // my link's place in the tree (registers)
 };
 
 // x[c] <- sum over my path to the root (myself included) of x[c]: pointer jumping
-template <int NC, int DP, int PL, typename T>
+template <int J, int NC, int NCOL, typename T>
+__device__ __forceinline__ void path_sum_bcast(T* acc, const T* x, unsigned ancmask) {
+    const T take = ((ancmask >> J) & 1u) ? T(1) : T(0);         // lane J is me or one of my ancestors
+    static_assert(NC == 6, "six components per path sum (a spatial vector)");
+    fma_bcast_vec6<J>(acc, x, take);
+    if constexpr (J + 1 < NCOL) path_sum_bcast<J + 1, NC, NCOL>(acc, x, ancmask);
+}
+template <int NC, int DP, int PL, int NCOL = 16, typename T>
 __device__ __forceinline__ void path_sum(T* x, const Topo& tp, T* X, int l) {
+    if constexpr (PL == 16) {       // one DPP row: every ancestor's value by broadcast, no LDS round per jump
+        T acc[NC];
+#pragma unroll
+        for (int c = 0; c < NC; ++c) acc[c] = T(0);
+        path_sum_bcast<0, NC, NCOL>(acc, x, tp.ancmask);
+#pragma unroll
+        for (int c = 0; c < NC; ++c) x[c] = acc[c];
+        return;
+    }
 #pragma unroll
     for (int k = 0; k < 5; ++k) {
         if (k >= tp.jumps) break;
@@ -307,62 +423,6 @@ __device__ __forceinline__ void tree_row_params(const T* sol, T r, T diag_approx
     aref = -sol[1] * jv - sol[0] * imp * r;
 }
 
-// ---- DPP row broadcasts (a 16-lane row: a whole 16-lane particle, or the first half of a 32-lane one) -----------
-template <int K>
-__device__ __forceinline__ float bcast_row(float x) {
-    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0x150 + K, 0xF, 0xF, false));
-}
-template <int K>
-__device__ __forceinline__ double bcast_row(double x) {
-    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(x), 0x150 + K, 0xF, 0xF, false);
-    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(x), 0x150 + K, 0xF, 0xF, false);
-    return __hiloint2double(hi, lo);
-}
-
-// acc += (lane K's x) * m  in ONE instruction: v_fmac with a DPP row_newbcast source (f64 DPP knows no other control).
-// The two wait states a DPP read wants after a VALU write of the same register (GFX9 hazard; the compiler cannot see
-// into the asm) are spelled out.
-template <int K>
-__device__ __forceinline__ void fma_bcast(double& acc, double x, double m) {
-    asm volatile("s_nop 1\n\tv_fmac_f64_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(x), "v"(m), "n"(K));
-}
-template <int K>
-__device__ __forceinline__ void fma_bcast(float& acc, float x, float m) {
-    asm volatile("s_nop 1\n\tv_fmac_f32_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(x), "v"(m), "n"(K));
-}
-// ... the same WITHOUT the wait states: for a broadcast source that no VALU instruction has written within the last two
-// issue slots (a register that is only read in the surrounding sequence; callers say why)
-template <int K>
-__device__ __forceinline__ void fma_bcast_settled(double& acc, double x, double m) {
-    asm volatile("v_fmac_f64_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(x), "v"(m), "n"(K));
-}
-template <int K>
-__device__ __forceinline__ void fma_bcast_settled(float& acc, float x, float m) {
-    asm volatile("v_fmac_f32_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(x), "v"(m), "n"(K));
-}
-__device__ __forceinline__ void dpp_settle() { asm volatile("s_nop 1"); }
-
-// my (symmetric) row of H from its path-indexed form, through the particle's tile: tile[l][anc] = tile[anc][l] = h[c],
-// zero elsewhere.  (The tile shares the exchange area of the kinematics: cleared on every use.)
-template <int DP, int DN, int PL, typename T>
-__device__ __forceinline__ void dense_row(const T* h, const int* AT, T* TILE, int l, T* r) {
-#pragma unroll
-    for (int j = 0; j < DN; ++j) TILE[l * TILE_STRIDE + j] = T(0);
-    TSYNC();
-#pragma unroll
-    for (int c = 0; c < DP; ++c) {
-        const int an = AT[c * PL + l];
-        if (an >= 0) {
-            TILE[l * TILE_STRIDE + an] = h[c];
-            if (c > 0) TILE[an * TILE_STRIDE + l] = h[c];
-        }
-    }
-    TSYNC();
-#pragma unroll
-    for (int j = 0; j < DN; ++j) r[j] = TILE[l * TILE_STRIDE + j];
-    TSYNC();
-}
-
 // ---- the TRUNK of the elimination tree --------------------------------------------------------------------------
 // Links 0 .. kt-1 that form a chain from the root, every one with a single child (the arm under a hand; the object's
 // chain above a manipulator): they are eliminated LAST, one per round, and in the rounds scheme each of those rounds is
@@ -387,9 +447,7 @@ struct TrunkStep {
             }
             fj *= invd;
             const T nf = -fj;
-            dpp_settle();
-#pragma unroll
-            for (int col = 0; col < K; ++col) fma_bcast_settled<K>(ra[col], ra[col], nf);   // A[l][col] -= f_l A[K][col]  (lanes >= K: f = 0)
+            fma_bcast_self_range<K, 0, K>(ra, nf);             // A[l][col] -= f_l A[K][col]  (lanes >= K: f = 0)
 #pragma unroll
             for (int col = 0; col < K; ++col) ra[col] = (l == K) ? ra[col] * invd : ra[col];  // row K itself becomes L[K][.]
         }
@@ -598,13 +656,8 @@ __device__ __forceinline__ T tree_solve(const T* r, T b, const int* ELIM, const 
 // my dense row of the mass matrix: md[j] = S_j . F_l (j an ancestor of l, or l), S_l . F_j (j in l's subtree), else 0
 template <int J, int DN, typename T>
 __device__ __forceinline__ void dense_mass_row(T* md, const T* S, const T* F, int l, unsigned ancmask, int subsize, bool dof) {
-    if constexpr (J == 0) dpp_settle();         // (S and F are only read below)
     T up = T(0), dn = T(0);
-#pragma unroll
-    for (int k = 0; k < 6; ++k) {
-        fma_bcast_settled<J>(up, S[k], F[k]);   // (lane J's S) . (my F)
-        fma_bcast_settled<J>(dn, F[k], S[k]);   // (lane J's F) . (my S)
-    }
+    fma_bcast_dots6<J>(up, dn, S, F);           // (lane J's S) . (my F),  (lane J's F) . (my S)
     const bool anc = (ancmask >> J) & 1u, sub = J > l && J < l + subsize;
     md[J] = dof ? (anc ? up : (sub ? dn : T(0))) : T(0);
     if constexpr (J + 1 < DN) dense_mass_row<J + 1, DN>(md, S, F, l, ancmask, subsize, dof);
@@ -613,12 +666,8 @@ __device__ __forceinline__ void dense_mass_row(T* md, const T* S, const T* F, in
 // r[j] += wn (lane j's jn) + w1 (lane j's j1) + w2 (lane j's j2): the contribution of one contact point to my dense row
 template <int J, int DN, bool FRIC, typename T>
 __device__ __forceinline__ void dense_contact(T* r, T jn, T j1, T j2, T wn, T w1, T w2) {
-    if constexpr (J == 0) dpp_settle();         // (jn, j1, j2 are only read from here on: one pair of wait states for all)
-    fma_bcast_settled<J>(r[J], jn, wn);
-    if constexpr (FRIC) {
-        fma_bcast_settled<J>(r[J], j1, w1);
-        fma_bcast_settled<J>(r[J], j2, w2);
-    }
+    if constexpr (FRIC) fma_bcast_3<J>(r[J], jn, j1, j2, wn, w1, w2);
+    else fma_bcast<J>(r[J], jn, wn);
     if constexpr (J + 1 < DN) dense_contact<J + 1, DN, FRIC>(r, jn, j1, j2, wn, w1, w2);
 }
 
@@ -630,9 +679,7 @@ struct DenseStep {
         const T inv = rcp_(bcast_row<K>(r[K]));
         dinv = l == K ? inv : dinv;
         const T lik = l > K ? r[K] * inv : T(0), nlik = -lik;
-        dpp_settle();       // (the r[j] below were last written a pivot ago; one pair of wait states covers the select above)
-#pragma unroll
-        for (int j = K + 1; j < DN; ++j) fma_bcast_settled<K>(r[j], r[j], nlik);       // r[j] -= lik * (lane K's r[j])
+        fma_bcast_self_range<K, K + 1, DN>(r, nlik);        // r[j] -= lik * (lane K's r[j]), j > K
         r[K] = l > K ? lik : r[K];
         if constexpr (K + 1 < DN) DenseStep<K + 1, DN, T>::run(r, dinv, l);
     }
@@ -1059,13 +1106,13 @@ __global__ __launch_bounds__(64 * wg_waves(DP, FRIC, sizeof(T), PL), min_waves(s
                 T V[6], Ac[6];
                 for (int k = 0; k < 3; ++k) { V[k] = sw[k] * v; V[3 + k] = sv[k] * v; }
                 T xw[3] = {V[0], V[1], V[2]}, xv[3] = {V[3], V[4], V[5]};
-                path_sum<6, DP, PL>(V, tp, X, l);
+                path_sum<6, DP, PL, (DN > 0 ? DN : 16)>(V, tp, X, l);
                 T dw[3], d1[3], d2[3];
                 cross3(V, xw, dw);
                 cross3(V, xv, d1);
                 cross3(V + 3, xw, d2);
                 for (int k = 0; k < 3; ++k) { Ac[k] = dw[k]; Ac[3 + k] = d1[k] + d2[k]; }
-                path_sum<6, DP, PL>(Ac, tp, X, l);
+                path_sum<6, DP, PL, (DN > 0 ? DN : 16)>(Ac, tp, X, l);
                 for (int k = 0; k < 3; ++k) Ac[3 + k] -= M[T_GRAVITY + k];          // base acceleration -g
                 // f = I A + V x* (I V),  I(w, v) = (Ib w + h x v, m v - h x w)
                 T nV[3], fV[3], nA[3], fA[3], t1[3], t2[3], c1[3], c2[3], c3[3], f[6];
