@@ -839,6 +839,17 @@ __global__ __launch_bounds__(64 * wg_waves(DP, FRIC, sizeof(T), PL), min_waves(s
             else own_path1 |= (unsigned)code << (5 * (s - 12));
         }
     }
+    // owner lanes (lane s < n_sphere owns contact point s): the lanes on my point's path, nearest first, five bits each
+    // (paths of up to 12 links; longer ones read the ancestor table) - what the point-parallel walks index the broadcast
+    // vector with
+    unsigned long long pt_path = 0;
+    if constexpr (DP <= 12) {
+        if (l < min((int)M[T_N_SPHERE], NS)) {
+            const T* sp = M + T_SPH + l * TREE_SPH_STRIDE;
+            const int link = (int)sp[0], dsl = (int)sp[11];
+            for (int c = 0; c < DP; ++c) pt_path |= (unsigned long long)(AT[(c <= dsl ? c : 0) * PL + link] & 31) << (5 * c);
+        }
+    }
     Topo tp;
     tp.parent = (int)model[T_PARENT + l];
     tp.subsize = (int)model[T_SUBSIZE + l];
@@ -1295,7 +1306,8 @@ __global__ __launch_bounds__(64 * wg_waves(DP, FRIC, sizeof(T), PL), min_waves(s
                     T jv = T(0), j1v = T(0), j2v = T(0);
                     int pa[DP];
 #pragma unroll
-                    for (int c = 0; c < DP; ++c) pa[c] = AT[(c <= dsl ? c : 0) * PL + link];
+                    for (int c = 0; c < DP; ++c)
+                        pa[c] = DP <= 12 ? (int)((pt_path >> (5 * c)) & 31ull) : AT[(c <= dsl ? c : 0) * PL + link];
 #pragma unroll
                     for (int c = 0; c < DP; ++c) {       // (branch-free, as in point_residuals: zeros past the root)
                         const T xv = VEC[pa[c]];
@@ -1341,7 +1353,8 @@ __global__ __launch_bounds__(64 * wg_waves(DP, FRIC, sizeof(T), PL), min_waves(s
                         // and the index is clamped, so that all the loads of the walk are in flight together)
                         int pa[DP];
 #pragma unroll
-                        for (int c = 0; c < DP; ++c) pa[c] = AT[(c <= dsl ? c : 0) * PL + link];
+                        for (int c = 0; c < DP; ++c)
+                            pa[c] = DP <= 12 ? (int)((pt_path >> (5 * c)) & 31ull) : AT[(c <= dsl ? c : 0) * PL + link];
 #pragma unroll
                         for (int c = 0; c < DP; ++c) {
                             const T xv = VEC[pa[c]];
