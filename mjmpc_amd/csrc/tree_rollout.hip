@@ -1332,9 +1332,11 @@ __global__ __launch_bounds__(64 * wg_waves(DP, FRIC, sizeof(T), PL), min_waves(s
             clk.count(9, __popc(cinst));
             if (any_rows) {
                 clk.count(10, 1);
-                tree_row_params(M + T_LSOL_K, dist, M[T_DOF_INVW + l], sig * v, D, aref);
-                D = inst ? D : T(0);
-                aref = inst ? aref : T(0);
+                if (__any(inst)) {      // (the impedance arithmetic only when some lane of the wavefront has a limit row)
+                    tree_row_params(M + T_LSOL_K, dist, M[T_DOF_INVW + l], sig * v, D, aref);
+                    D = inst ? D : T(0);
+                    aref = inst ? aref : T(0);
+                }
                 // rows of contact point s with friction mu (uniform per particle): all NR, else one
                 auto rows_of = [&](int s) -> unsigned { return (FRIC && M[T_SPH + s * TREE_SPH_STRIDE + 7] > T(0)) ? 15u : 1u; };
                 // POINT-PARALLEL residuals: lane s owns contact point s.  The solution goes through the broadcast vector; the
