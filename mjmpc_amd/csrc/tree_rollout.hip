@@ -163,6 +163,19 @@ __device__ __forceinline__ double add_rows(double x) {
     const auto b = __builtin_amdgcn_permlane16_swap(hi, hi, false, false);
     return __hiloint2double((int)b[0], (int)a[0]) + __hiloint2double((int)b[1], (int)a[1]);
 }
+// the value the same lane of the particle's other 16-lane row holds
+__device__ __forceinline__ float swap_rows(float x) {
+    const unsigned u = __float_as_uint(x);
+    const auto r = __builtin_amdgcn_permlane16_swap(u, u, false, false);
+    return __uint_as_float((threadIdx.x & 16) ? r[0] : r[1]);       // (r = {even-row value, odd-row value} at my position)
+}
+__device__ __forceinline__ double swap_rows(double x) {
+    const unsigned lo = (unsigned)__double2loint(x), hi = (unsigned)__double2hiint(x);
+    const auto a = __builtin_amdgcn_permlane16_swap(lo, lo, false, false);
+    const auto b = __builtin_amdgcn_permlane16_swap(hi, hi, false, false);
+    const bool odd = threadIdx.x & 16;
+    return __hiloint2double((int)(odd ? b[0] : b[1]), (int)(odd ? a[0] : a[1]));
+}
 // sum over the 32 lanes of a particle, result in every lane: four DPP steps inside the 16-lane rows and one row swap
 // (no LDS crossbar: a ds_bpermute butterfly costs five times as much)
 template <int PL, typename T>
@@ -290,6 +303,7 @@ __device__ __forceinline__ void fma_bcast_self_range(T* a, T m) {
 
 struct Topo {       // my link's place in the tree (registers)
     int parent, subsize, jumps;
+    int seg_end;    // one past the last link of my kinematic tree (links are numbered tree by tree, depth-first)
     int anc[5];     // my ancestor at distance 2^k (pointer jumping), -1 beyond the root; only ever indexed by an
                     // unrolled loop counter, so that it stays in registers
     unsigned ancmask;
@@ -334,21 +348,31 @@ __device__ __forceinline__ void path_sum(T* x, const Topo& tp, T* X, int l) {
 template <int NC, int PL, typename T>
 __device__ __forceinline__ void subtree_sum(T* x, const Topo& tp, T* X, int l) {
     static_assert(NC <= 6, "two buffers of NC x PL must fit the 12 x PL exchange area");
-    if constexpr (PL == 16 && TREE_DPP_SUBTREE) {
-        // 16-lane particles: a particle is one DPP row, so the suffix sums S_l = x_l + ... + x_15 are four zero-filling
-        // row shifts, and the subtree [l, l + n) is S_l - S_{l+n} (one ds_bpermute per dword; no LDS round trip).  The
-        // difference cancels: relative error eps * (sum over the links behind me in the row / my subtree's) - a factor
-        // of a few on the models this runs (<= 16 links), against the exact doubling tables of the 32-lane particles.
+    if constexpr (TREE_DPP_SUBTREE) {
+        // The suffix sums S_l = x_l + ... + x_(end of my TREE) are zero-filling DPP row shifts (a 16-lane particle is one
+        // row; a 32-lane one adds the second row's total to the first: its lane 0, by a row swap and a broadcast), and
+        // the subtree [l, l + n) is S_l - S_{l+n}, one ds_bpermute per dword - no LDS round trip.  The scan is SEGMENTED at
+        // the roots (tp.seg_end): a light object listed before a heavy manipulator would otherwise lose its inertia in
+        // the difference.  Inside one tree the difference still cancels: relative error eps * (what follows me in my tree
+        // / my subtree), a few tens on the models here - against the exact doubling tables below (TREE_DPP_SUBTREE = 0).
+        const int end = l + tp.subsize;
 #pragma unroll
         for (int c = 0; c < NC; ++c) {
             T s = x[c];
-            s += dpp_zero<0x101>(s);        // row_shl:1
-            s += dpp_zero<0x102>(s);
-            s += dpp_zero<0x104>(s);
-            s += dpp_zero<0x108>(s);
-            const int end = l + tp.subsize;
-            const T tail = __shfl(s, end & 15, 16);
-            x[c] = s - (end < 16 ? tail : T(0));
+            T t = dpp_zero<0x101>(s);
+            s += l + 1 < tp.seg_end ? t : T(0);
+            t = dpp_zero<0x102>(s);
+            s += l + 2 < tp.seg_end ? t : T(0);
+            t = dpp_zero<0x104>(s);
+            s += l + 4 < tp.seg_end ? t : T(0);
+            t = dpp_zero<0x108>(s);
+            s += l + 8 < tp.seg_end ? t : T(0);
+            if constexpr (PL == 32) {
+                const T other = bcast_row<0>(swap_rows(s));     // lane 0 of the particle's OTHER row, in every lane of mine
+                s += (l < 16 && tp.seg_end > 16) ? other : T(0);
+            }
+            const T tail = __shfl(s, end & (PL - 1), PL);
+            x[c] = s - (end < tp.seg_end ? tail : T(0));
         }
         return;
     }
@@ -853,6 +877,12 @@ __global__ __launch_bounds__(64 * wg_waves(DP, FRIC, sizeof(T), PL), min_waves(s
     Topo tp;
     tp.parent = (int)model[T_PARENT + l];
     tp.subsize = (int)model[T_SUBSIZE + l];
+    {
+        const int nv_ = (int)model[T_NV];
+        const unsigned long long rb = __ballot(half == 0 && l < nv_ && tp.parent < 0);      // the roots (same model for every particle)
+        const unsigned later = l + 1 < 32 ? (unsigned)(rb >> (l + 1)) : 0u;
+        tp.seg_end = l >= nv_ ? l + 1 : (later ? min(nv_, l + 1 + __builtin_ctz(later)) : nv_);
+    }
 #pragma unroll
     for (int k = 0; k < 5; ++k) tp.anc[k] = (int)model[T_ANC + k * TL + l];      // (kinematic ancestors: pointer jumping)
     tp.jumps = __builtin_amdgcn_readfirstlane((int)M[T_JUMPS]);
