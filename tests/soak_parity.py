@@ -103,7 +103,7 @@ for k in range(trials):
     ok = np.cumsum(fast, axis=1) == 0
     unstable += int((~ok[:, -1]).sum())
     err = np.abs(c + rew) / np.maximum(1.0, np.abs(rew))
-    worst["pen 256x8"] = max(worst.get("pen 256x8", 0.0), float((err * ok).max()))
+    worst["pen 256x8"] = max(worst.get("pen 256x8", 0.0), float(np.where(ok, err, 0.0).max()))
 print("pen: worst %.2e (%d of %d rollouts go unstable on both sides and are compared up to there), failures kernel %d oracle %d  (%.0f s)"
       % (worst["pen 256x8"], unstable, trials * 256, eng.solver_failures(), ref.newton_stats()["fails"], time.time() - t0), flush=True)
 # ---- locomotion: one env step from many states
