@@ -624,12 +624,12 @@ __device__ __forceinline__ T tree_solve(const T* r, T b, const int* ELIM, const 
     // L' w = b, leaves first:  w_i = b_i - sum over descendants k of L[k][i] w_k
     int e = 0, ent = ELIM[l];
     const int lds_rounds = n_rounds - kt;
-    const bool trunk = kt >= 2 && l < kt;
+    const bool trunk = kt >= 2 && l < kt;       // trunk lanes take everything below the trunk AFTER the rounds, in one go
     for (int hgt = 0; hgt < lds_rounds; ++hgt) {
         VEC[l] = b;
         TSYNC();
-        while (__any(ent >= 0 && (ent >> 16) == hgt)) {
-            if (ent >= 0 && (ent >> 16) == hgt) {
+        while (__any(!trunk && ent >= 0 && (ent >> 16) == hgt)) {
+            if (!trunk && ent >= 0 && (ent >> 16) == hgt) {
                 const int k = ent & 255, a = (ent >> 8) & 255;
                 b -= ROW[k * row_stride(DP) + a] * VEC[k];
                 ++e;
@@ -638,7 +638,33 @@ __device__ __forceinline__ T tree_solve(const T* r, T b, const int* ELIM, const 
         }
         TSYNC();
     }
-    if (kt >= 2) {          // the trunk's rounds: my column of its factor from the published rows, then broadcast FMAs
+    if (kt >= 2) {
+        // w_k of every link below the trunk is final: the trunk lanes' pulls (an arm under a hand: one per finger link)
+        // are independent of each other now - four list entries per trip, eight loads in flight - where in the rounds
+        // each of them stood behind the previous one and every round waited for them
+        VEC[l] = b;
+        TSYNC();
+        for (int e0 = 0; e0 < PL - 1; e0 += 4) {
+            int en[4];
+            bool ok[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                en[u] = (trunk && e0 + u < PL - 1) ? ELIM[(e0 + u) * PL + l] : -1;
+                ok[u] = en[u] >= 0 && (en[u] >> 16) < lds_rounds;
+            }
+            if (!__any(ok[0])) break;           // (the lists are sorted by height: nothing below the trunk is left)
+            T lv[4], wv[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int k = ok[u] ? en[u] & 255 : 0, a = ok[u] ? (en[u] >> 8) & 255 : 0;
+                lv[u] = ROW[k * row_stride(DP) + a];
+                wv[u] = VEC[k];
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) b -= ok[u] ? lv[u] * wv[u] : T(0);
+        }
+        TSYNC();
+        // the trunk's rounds: my column of its factor from the published rows, then broadcast FMAs
         asm volatile("" : "+v"(l));
         T cK[KT];
 #pragma unroll
