@@ -1,6 +1,9 @@
-python -m pytest tests/test_locomotion_gpu.py tests/test_stress_locomotion_gpu.py tests/test_tree_rollout_gpu.py tests/test_pen_hand_gpu.py -x -q 2>&1 | tail -3
-python tools/tree_time.py 4096 32 f64 cheetah 2>&1 | grep -v amdgpu | tail -1
-python tools/tree_time.py 4096 32 f64 swimmer 2>&1 | grep -v amdgpu | tail -1
-python tools/tree_time.py 4096 32 f32 cheetah 2>&1 | grep -v amdgpu | tail -1
-python tools/tree_time.py 32768 32 f32 cheetah 2>&1 | grep -v amdgpu | tail -1
-python bench.py --workload pen_hand --steps 5 --warmup 2 --no-cpu-baseline --process-warmup 0 2>/dev/null | python -c "import sys,json; j=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('pen mppi 4096x32', j['ms_per_step'], j['roofline']['kernel_ms'], j['solver_failures'])"
+bash tools/profile_round3.sh r03 > gpurun_out/r03_profile.log 2>&1
+python tools/bench_configs.py --steps 60 --pen > gpurun_out/r03_other_configs_f64.jsonl 2> gpurun_out/r03_cfg.err
+python tools/bench_configs.py --steps 60 --dtype f32 > gpurun_out/r03_other_configs_f32.jsonl 2>> gpurun_out/r03_cfg.err
+for wl in half_cheetah swimmer hand24 pen_hand; do python bench.py --workload $wl --steps 10 --warmup 3 2>/dev/null | tail -1; done > gpurun_out/r03_tree_bench_lines.jsonl
+for a in "4096 32 f64 cheetah" "4096 32 f32 cheetah" "32768 32 f64 cheetah" "32768 32 f32 cheetah" "4096 32 f64 swimmer" "65536 64 f64 hand" "65536 64 f32 hand"; do python tools/tree_time.py $a 2>&1 | grep -v amdgpu | tail -1; done > gpurun_out/r03_tree_time.txt
+python tools/tree_stats.py cheetah f64 4096 32 2>&1 | grep -v amdgpu.ids > gpurun_out/r03_tree_stats.txt
+python tools/tree_stats.py hand f64 65536 64 2>&1 | grep -v amdgpu.ids >> gpurun_out/r03_tree_stats.txt
+python tools/tree_stats.py pen f64 4096 32 2>&1 | grep -v amdgpu.ids >> gpurun_out/r03_tree_stats.txt
+cat gpurun_out/r03_tree_time.txt
