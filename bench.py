@@ -15,7 +15,7 @@ subproc_vec_env.py:161-168); the per-GPU record of the update is all-gathered (R
 
     --scaling weak    (default) --particles is the block of ONE GPU, the population grows with N
     --scaling strong  --particles is the whole population, divided over the N GPUs
-    --controller {mppi,cem,dmd}; --workload {reacher,half_cheetah,swimmer,hand24}
+    --controller {mppi,cem,dmd}; --workload {reacher,half_cheetah,swimmer,hand24,pen_hand}
 
 BASELINE.json configurations: 2 = ``--particles 1024``; 3 = default (sawyer.xml is the vendored 7-dof arm);
 4 = ``--controller cem --particles 16384 --scaling strong --gpus 4``;
@@ -23,8 +23,10 @@ BASELINE.json configurations: 2 = ``--particles 1024``; 3 = default (sawyer.xml 
 
 Prints ONE JSON line (rank 0) with `roofline` (dominant kernel = the rollout kernel, timed live with
 events on the launch stream; the HBM block SURVEY 8d defines plus `valu`, the roofline that actually binds:
-FLOPs per particle-step COUNTED by the instrumented oracle build, oracle/flop_count.cpp) and `cpu_baseline`
-(oracle/ on the host cores, N = 1 only).
+FLOPs per particle-step COUNTED by the instrumented oracle build, oracle/flop_count.cpp, beside the kernel's own count
+and issue fraction from the SQ counter passes kept under profiles/), `cpu_baseline` (oracle/ on the host cores, N = 1
+only) and, for the fused two-launch iteration on one GPU, `pipelined`: the same closed loop with the next iteration
+enqueued before the host waits for the current action (reported beside the headline, never as it).
 """
 import argparse
 import json
