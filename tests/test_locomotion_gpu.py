@@ -394,3 +394,23 @@ def test_swimmer_self_contact_matches_oracle():
         e.set_env_state(dict(qpos=q0, qvel=v0))
     a, b = eng.rollout(64, 16, mean, noise)[1], plain.rollout(64, 16, mean, noise)[1]
     assert np.array_equal(a, b)
+
+
+@pytest.mark.parametrize("name", ["swimmer", "cheetah"])
+def test_f32_results_do_not_depend_on_the_batch_size(name):
+    """The instantiation is chosen from model and dtype alone (round 2 picked 32 lanes per particle for f32 launches of
+    <= 4096 particles and 16 above): a particle's f32 trajectory is the same bits whether it is rolled out alone (the
+    device-resident real env: P = 1), with 4095 others or with 8191 others."""
+    from mjmpc_amd.envs.tree_engine import TreeRolloutEngine
+    raw = _models()[name]()
+    eng = TreeRolloutEngine(raw, dtype="f32")
+    nv = eng.model.nv
+    q0, v0, mean, noise = _case(name, nv, eng.d_action, 9, 8192, 6)
+    eng.set_env_state(dict(qpos=q0, qvel=v0))
+    ref = None
+    for P in (1, 4096, 8192):
+        out = eng.rollout_device(P, 6, mean, noise[:P].astype(np.float32), want_obs=True)
+        got = (out[0][0].cpu().numpy().copy(), out[3][0].cpu().numpy().copy())
+        if ref is None:
+            ref = got
+        assert np.array_equal(got[0], ref[0]) and np.array_equal(got[1], ref[1]), P
