@@ -1366,6 +1366,10 @@ __global__ __launch_bounds__(DUO ? 128 : 64) __attribute__((amdgpu_waves_per_eu(
         ST.mark(14);    // observation records, loop
     }
     ST.flush(diag, 0, lane);
+    // A rollout that diverged numerically (MuJoCo would have reset that simulation) carries a non-finite return: it
+    // leaves the update as +inf - zero weight in the softmax updates, last in the elite ranking - instead of poisoning
+    // the mean with a NaN
+    if (!(fabs(q0acc) < INFINITY)) q0acc = INFINITY;
     if (fuse.q0_out && live && l8 == 0) fuse.q0_out[pid] = q0acc;
     // "real env" stepping on the device: particle 0 writes its final (qpos, qvel) back into a state vector
     if (state_out && pid == 0 && l8 < nv) {

@@ -60,6 +60,9 @@ __global__ void traj_cost_kernel(const T* __restrict__ costs, const T* __restric
                 cq = accc / gseq[t];
             }
         }
+        // (a rollout that diverged numerically - MuJoCo would have reset that simulation - carries a non-finite return:
+        // +inf, i.e. zero weight / last in the ranking, instead of a NaN that poisons the mean)
+        if (!(fabs(qt) < INFINITY)) qt = INFINITY;
         if (Hw > 1) x[p * Hw + t] = neg_inv_lam * (qt + lam * cq);
         else if (t == 0) x[p] = neg_inv_lam * (qt + lam * cq);
         if (t == 0 && q0) q0[p] = qt;

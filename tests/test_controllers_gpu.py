@@ -513,3 +513,43 @@ def test_semidefinite_covariance_samples_and_indefinite_raises():
     with pytest.raises(_lib.MjmpcError, match="indefinite"):
         dev.check_status()
     dev.check_status()                                       # the flag is cleared once reported
+
+
+def test_diverged_rollouts_do_not_poison_the_update():
+    """A rollout whose simulation diverged numerically carries NaN / inf costs (MuJoCo would have reset it): the
+    MPPI and CEM updates treat its return as +inf - zero weight, never elite - i.e. they equal the update over the
+    finite particles alone, instead of a NaN mean."""
+    from mjmpc_amd.control._device import DeviceUpdater
+    from oracle import controllers_ref as cr
+    P, H, A = 256, 8, 3
+    rs = np.random.RandomState(4)
+    costs, actions = rs.rand(P, H) * 3.0, rs.randn(P, H, A)
+    mean0, cov0, gseq = 0.1 * rs.randn(H, A), np.eye(A), cr.gamma_seq(0.97, H)
+    bad = np.array([3, 77, 200, 255])
+    dirty = costs.copy()
+    dirty[3, 2] = np.nan
+    dirty[77, 5] = np.inf
+    dirty[200, :] = np.nan
+    dirty[255, 0] = 1e308
+    dirty[255, 1] = 1e308          # overflows in the cost-to-go
+    keep = np.setdiff1d(np.arange(P), bad)
+    dev = DeviceUpdater(H, A, gseq)
+    dev.set_mean(mean0)
+    dev.softmax_update(dirty, actions, 0.7, 0.9)
+    got = dev.mean.cpu().numpy()
+    want = cr.mppi_update(costs[keep], actions[keep], mean0, cov0, gseq, 0.7, 1, 0.9)
+    assert np.isfinite(got).all()
+    np.testing.assert_allclose(got, want, rtol=0, atol=1e-12)
+    # CEM: the elite are the best of the finite ones
+    dev2 = DeviceUpdater(H, A, gseq)
+    dev2.set_mean(mean0)
+    dev2.set_cov(cov0)
+    k = 25
+    dev2.cem_update(dirty, actions, k, 0.8, False)
+    q0 = cr.cost_to_go(costs.copy(), gseq)[:, 0]
+    q0[bad] = np.inf
+    ids = np.argsort(q0, kind="stable")[:k]
+    assert not set(ids) & set(bad)
+    want_mean = 0.2 * mean0 + 0.8 * actions[ids].mean(0)
+    assert np.isfinite(dev2.mean.cpu().numpy()).all()
+    np.testing.assert_allclose(dev2.mean.cpu().numpy(), want_mean, rtol=0, atol=1e-12)
