@@ -172,3 +172,28 @@ def test_sharded_record_of_the_launch():
     W = np.exp(r0[0] - m) * r0[2:] + np.exp(r1[0] - m) * r1[2:]
     np.testing.assert_allclose(s, w[1], rtol=1e-12)
     np.testing.assert_allclose(W, w[2:], rtol=1e-10, atol=1e-13)
+
+
+def test_combine_rejects_bad_arguments():
+    """``mjmpc_arm_mppi_combine`` (the launch behind the record all-gather of a sharded run): argument checks."""
+    import ctypes
+    import torch
+    from mjmpc_amd import _lib
+    eng = _engine()
+    lib = _lib.require_gpu()
+    H, A = 8, 7
+    recs = torch.zeros(2, 2 + H * A, dtype=torch.float64, device="cuda")
+    mean = torch.zeros(H, A, dtype=torch.float64, device="cuda")
+    alt = torch.zeros_like(mean)
+    step = torch.zeros(1, dtype=torch.int64, device="cuda")
+    vp = lambda t: ctypes.c_void_p(t.data_ptr())
+
+    def call(mean_out, n_rec=2, shift=0):
+        return lib.mjmpc_arm_mppi_combine(eng._h, eng._code, vp(recs), n_rec, H, vp(mean), vp(mean_out), vp(step), 1.0, shift,
+                                          None, None, 0, None, None, None)
+
+    assert call(alt) == 0
+    torch.cuda.synchronize()
+    for bad in (call(mean), call(alt, n_rec=0), call(alt, shift=2)):       # aliased mean, no records, unknown shift mode
+        assert bad != 0
+        assert lib.mjmpc_last_error()
