@@ -511,6 +511,39 @@ struct TrunkBwd {       // L x = u on the trunk, root first: x_l -= L[l][a] x_a,
     }
 };
 
+// The updates of the trunk rows by ALL the links below the trunk (their Schur complement), taken at once when those rows
+// are final: S[j][c] = sum over links k below the trunk of L[k][j] D_k L[k][c] (j, c trunk links, c <= j).  Link k reads
+// its own entries for the trunk links back from its published row (trunk link c is depth_k - c links above it), forms
+// the products in registers, and ONE lane sum per (j, c) gives every lane the total; trunk lane j subtracts S[j][.] from
+// its row (absolute column order, see trunk_load).  In the rounds these were pulls by the trunk lanes - the arm under a
+// hand pulled one row per finger per round, and every round waited for it.
+constexpr int TRUNK_SCHUR_MAX = 6;
+template <int J, int C, int KT, int PL, typename T>
+struct TrunkSchur {
+    static __device__ __forceinline__ void run(T* ra, const T* tk, T dk, int l, int kt) {
+        if (J < kt) {
+            const T s = sum_lanes<PL>(tk[J] * dk * tk[C]);
+            ra[C] = (l == J) ? ra[C] - s : ra[C];
+        }
+        if constexpr (C < J) TrunkSchur<J, C + 1, KT, PL, T>::run(ra, tk, dk, l, kt);
+        else if constexpr (J + 1 < KT && J + 1 < TRUNK_SCHUR_MAX) TrunkSchur<J + 1, 0, KT, PL, T>::run(ra, tk, dk, l, kt);
+    }
+};
+template <int DP, int PL, typename T>
+__device__ __forceinline__ void trunk_schur(T* ra, const T* ROW, int l, int depth, int kt) {
+    constexpr int KT = Trunk<DP>::KT;
+    asm volatile("" : "+v"(l));
+    T tk[KT];
+    const bool below = l >= kt;
+#pragma unroll
+    for (int c = 0; c < KT; ++c) {
+        const int d = depth - c;                                    // trunk link c is d links above me
+        tk[c] = (below && c < kt && d >= 1 && d < DP) ? ROW[l * row_stride(DP) + d] : T(0);
+    }
+    const T dk = below ? ROW[l * row_stride(DP)] : T(0);
+    TrunkSchur<0, 0, KT, PL, T>::run(ra, tk, dk, l, kt);
+}
+
 // Tree-sparse L'DL, in place: in  r[c] = A[l][ancestor at distance c]  (c < DP, zero beyond the root),
 // out r[0] = D_l, r[c] = L[l][ancestor at distance c] (c >= 1).  One round per height: every lane publishes its row,
 // then pulls the rows of its descendants of that height (elimination list ELIM[e * 32 + l], sorted by height:
@@ -519,18 +552,22 @@ struct TrunkBwd {       // L x = u on the trunk, root first: x_l -= L[l][a] x_a,
 // lane's - published, finite - data: what is read there only ever lands in entries of r past MY path (c > my depth),
 // which nothing consumes (they are published with the row and read again only into such entries).
 template <int DP, int PL, typename T>
-__device__ __forceinline__ void tree_factor(T* r, const int* ELIM, T* ROW, int l, int n_rounds, int kt) {
+__device__ __forceinline__ void tree_factor(T* r, const int* ELIM, T* ROW, int l, int n_rounds, int kt, int depth) {
     constexpr int KT = Trunk<DP>::KT;
     int e = 0, ent = ELIM[l];
     const int lds_rounds = n_rounds - kt;                   // heights below the trunk's lowest link (kt = 1: all but the root's)
-    const bool trunk = kt >= 2 && l < kt;                   // trunk lanes take their updates after the rounds, all at once
+    // short trunks (an arm: k (k + 1) / 2 lane sums) take the updates from below as ONE Schur complement after the rounds
+    // (trunk_schur); long ones (an object's six joints above an arm: 55 sums) keep pulling rows in the rounds
+    const bool schur = DP <= 8 && kt >= 2 && kt <= TRUNK_SCHUR_MAX;     // (compiled for the short-path instantiations only)
+    const bool trunk = kt >= 2 && l < kt;
+    const bool defer = schur && trunk;
     for (int hgt = 0; hgt < lds_rounds; ++hgt) {
 #pragma unroll
         for (int c = 0; c < DP; ++c) ROW[l * row_stride(DP) + c] = r[c];
         ROW[l * row_stride(DP) + DP] = rcp_(r[0]);                 // 1 / D of a row that is final; read by its ancestors
         TSYNC();
-        while (__any(ent >= 0 && (ent >> 16) == hgt)) {
-            if (ent >= 0 && (ent >> 16) == hgt) {
+        while (__any(!defer && ent >= 0 && (ent >> 16) == hgt)) {
+            if (!defer && ent >= 0 && (ent >> 16) == hgt) {
                 const T* rk = ROW + (ent & 255) * row_stride(DP);
                 const int a = (ent >> 8) & 255;
                 const T f = rk[a] * rk[DP];
@@ -552,6 +589,7 @@ __device__ __forceinline__ void tree_factor(T* r, const int* ELIM, T* ROW, int l
     if (kt >= 2) {
         T ra[KT];
         trunk_load<DP, PL>(ra, ROW, l, kt);
+        if constexpr (DP <= 8) { if (schur) trunk_schur<DP, PL>(ra, ROW, l, depth, kt); }
         TrunkStep<KT - 1, KT, T>::run(ra, l, kt);
         TSYNC();
         trunk_store<DP, PL>(ra, ROW, l, kt);
@@ -566,19 +604,21 @@ __device__ __forceinline__ void tree_factor(T* r, const int* ELIM, T* ROW, int l
 // The same for TWO matrices of the tree's pattern in one pass over the rounds (H = M + J'DJ of the first Newton iteration
 // and the Euler matrix M + hB): one set of LDS round trips and list walks instead of two.
 template <int DP, int PL, typename T>
-__device__ __forceinline__ void tree_factor2(T* r, T* q, const int* ELIM, T* ROW, T* ROW2, int l, int n_rounds, int kt) {
+__device__ __forceinline__ void tree_factor2(T* r, T* q, const int* ELIM, T* ROW, T* ROW2, int l, int n_rounds, int kt, int depth) {
     constexpr int KT = Trunk<DP>::KT;
     int e = 0, ent = ELIM[l];
     const int lds_rounds = n_rounds - kt;
+    const bool schur = DP <= 8 && kt >= 2 && kt <= TRUNK_SCHUR_MAX;     // (compiled for the short-path instantiations only)
     const bool trunk = kt >= 2 && l < kt;
+    const bool defer = schur && trunk;
     for (int hgt = 0; hgt < lds_rounds; ++hgt) {
 #pragma unroll
         for (int c = 0; c < DP; ++c) { ROW[l * row_stride(DP) + c] = r[c]; ROW2[l * row_stride(DP) + c] = q[c]; }
         ROW[l * row_stride(DP) + DP] = rcp_(r[0]);
         ROW2[l * row_stride(DP) + DP] = rcp_(q[0]);
         TSYNC();
-        while (__any(ent >= 0 && (ent >> 16) == hgt)) {
-            if (ent >= 0 && (ent >> 16) == hgt) {
+        while (__any(!defer && ent >= 0 && (ent >> 16) == hgt)) {
+            if (!defer && ent >= 0 && (ent >> 16) == hgt) {
                 const T* rk = ROW + (ent & 255) * row_stride(DP);
                 const T* qk = ROW2 + (ent & 255) * row_stride(DP);
                 const int a = (ent >> 8) & 255;
@@ -601,10 +641,12 @@ __device__ __forceinline__ void tree_factor2(T* r, T* q, const int* ELIM, T* ROW
     if (kt >= 2) {
         T ra[KT];
         trunk_load<DP, PL>(ra, ROW, l, kt);
+        if constexpr (DP <= 8) { if (schur) trunk_schur<DP, PL>(ra, ROW, l, depth, kt); }
         TrunkStep<KT - 1, KT, T>::run(ra, l, kt);
         TSYNC();
         trunk_store<DP, PL>(ra, ROW, l, kt);
         trunk_load<DP, PL>(ra, ROW2, l, kt);
+        if constexpr (DP <= 8) { if (schur) trunk_schur<DP, PL>(ra, ROW2, l, depth, kt); }
         TrunkStep<KT - 1, KT, T>::run(ra, l, kt);
         TSYNC();
         trunk_store<DP, PL>(ra, ROW2, l, kt);
@@ -1601,9 +1643,9 @@ __global__ __launch_bounds__(64 * wg_waves(DP, FRIC, sizeof(T), PL), min_waves(s
 #pragma unroll
                         for (int c = 0; c < DP; ++c) erow[c] = mrow[c];
                         erow[0] += dof ? h * damping : T(0);
-                        tree_factor2<DP, PL>(hrow, erow, ELIM, ROW, ROW2, l, n_rounds, kt);
+                        tree_factor2<DP, PL>(hrow, erow, ELIM, ROW, ROW2, l, n_rounds, kt, depth);
                     } else {
-                        tree_factor<DP, PL>(hrow, ELIM, ROW, l, n_rounds, kt);
+                        tree_factor<DP, PL>(hrow, ELIM, ROW, l, n_rounds, kt, depth);
                     }
                     clk.lap(13);
                     if constexpr (DN > 0) xa = dense_solve<DN>(hd, hdinv, rhs, l);
@@ -1770,7 +1812,7 @@ __global__ __launch_bounds__(64 * wg_waves(DP, FRIC, sizeof(T), PL), min_waves(s
                     qacc = dense_solve<DN>(ed, edinv, tau + qfrc_c, l);
                 } else {
                     mrow[0] += dof ? h * damping : T(0);
-                    tree_factor<DP, PL>(mrow, ELIM, ROW, l, n_rounds, kt);
+                    tree_factor<DP, PL>(mrow, ELIM, ROW, l, n_rounds, kt, depth);
                     qacc = tree_solve<DP, PL>(mrow, tau + qfrc_c, ELIM, AT, ROW, VEC, l, n_rounds, depth, max_depth, kt);
                 }
             }
