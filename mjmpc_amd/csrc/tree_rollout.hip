@@ -681,9 +681,29 @@ __device__ __forceinline__ T tree_solve(const T* r, T b, const int* ELIM, const 
         TSYNC();
     }
     if (kt >= 2) {
-        // w_k of every link below the trunk is final: the trunk lanes' pulls (an arm under a hand: one per finger link)
-        // are independent of each other now - four list entries per trip, eight loads in flight - where in the rounds
-        // each of them stood behind the previous one and every round waited for them
+        // w_k of every link below the trunk is final.  Short trunks on short paths: trunk lane j needs sum_k L[k][j] w_k over
+        // all the links below - every such link reads its entries for the trunk links back from its own row and ONE lane
+        // sum per trunk link hands the total over (as trunk_schur does for the factorisation).  Otherwise the trunk lanes
+        // pull, but independently of each other now: four list entries per trip, eight loads in flight.
+        if (DP <= 8 && kt <= TRUNK_SCHUR_MAX) {
+            if constexpr (DP <= 8) {
+                const bool below = l >= kt;
+                T tk[TRUNK_SCHUR_MAX];
+#pragma unroll
+                for (int c = 0; c < TRUNK_SCHUR_MAX; ++c) {
+                    const int d = depth - c;
+                    tk[c] = (below && c < kt && d >= 1 && d < DP) ? ROW[l * row_stride(DP) + d] : T(0);
+                }
+                const T wk = below ? b : T(0);
+#pragma unroll
+                for (int j = 0; j < TRUNK_SCHUR_MAX; ++j) {
+                    if (j < kt) {
+                        const T sj = sum_lanes<PL>(tk[j] * wk);
+                        b = (l == j) ? b - sj : b;
+                    }
+                }
+            }
+        } else {
         VEC[l] = b;
         TSYNC();
         for (int e0 = 0; e0 < PL - 1; e0 += 4) {
@@ -706,6 +726,7 @@ __device__ __forceinline__ T tree_solve(const T* r, T b, const int* ELIM, const 
             for (int u = 0; u < 4; ++u) b -= ok[u] ? lv[u] * wv[u] : T(0);
         }
         TSYNC();
+        }
         // the trunk's rounds: my column of its factor from the published rows, then broadcast FMAs
         asm volatile("" : "+v"(l));
         T cK[KT];
