@@ -685,18 +685,19 @@ __device__ __forceinline__ T tree_solve(const T* r, T b, const int* ELIM, const 
         // all the links below - every such link reads its entries for the trunk links back from its own row and ONE lane
         // sum per trunk link hands the total over (as trunk_schur does for the factorisation).  Otherwise the trunk lanes
         // pull, but independently of each other now: four list entries per trip, eight loads in flight.
-        if (DP <= 8 && kt <= TRUNK_SCHUR_MAX) {
-            if constexpr (DP <= 8) {
+        constexpr int KS = DP <= 8 ? TRUNK_SCHUR_MAX : 12;     // trunk links the lane-sum path of the SOLVE takes (one sum each)
+        if (DP <= 16 && kt <= KS) {
+            if constexpr (DP <= 16) {
                 const bool below = l >= kt;
-                T tk[TRUNK_SCHUR_MAX];
+                T tk[KS];
 #pragma unroll
-                for (int c = 0; c < TRUNK_SCHUR_MAX; ++c) {
+                for (int c = 0; c < KS; ++c) {
                     const int d = depth - c;
                     tk[c] = (below && c < kt && d >= 1 && d < DP) ? ROW[l * row_stride(DP) + d] : T(0);
                 }
                 const T wk = below ? b : T(0);
 #pragma unroll
-                for (int j = 0; j < TRUNK_SCHUR_MAX; ++j) {
+                for (int j = 0; j < KS; ++j) {
                     if (j < kt) {
                         const T sj = sum_lanes<PL>(tk[j] * wk);
                         b = (l == j) ? b - sj : b;
