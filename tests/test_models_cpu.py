@@ -118,3 +118,69 @@ def test_impedance_power_must_be_a_small_integer():
     for bad in (2.5, 0.5, 100.0):
         with pytest.raises(NotImplementedError):
             compile_arm(dataclasses.replace(raw, solimp=(0.9, 0.95, 0.001, 0.5, bad)))
+
+
+def test_loader_position_servos_pairs_and_self_collision(tmp_path):
+    """Round 3's MJCF additions on a small model: an object on a slide + hinge, a two-link manipulator with <position> servos,
+    an explicit <contact><pair>, and MuJoCo's contype / conaffinity rule for body geoms against each other."""
+    from mjmpc_amd.models.compile_tree import compile_tree
+    from mjmpc_amd.models.raw import TASK_REACH
+    xml = textwrap.dedent("""
+    <mujoco>
+      <compiler inertiafromgeom="true" angle="radian" coordinate="local"/>
+      <option timestep="0.002" gravity="0 0 -9.81" integrator="Euler"/>
+      <default><joint limited="true" damping="0.1"/><geom contype="0" conaffinity="0" condim="3" friction="0.8 0.005 0.0001"/></default>
+      <worldbody>
+        <site name="target" pos="0 0 0.3"/>
+        <body name="obj" pos="0.1 0 0.2">
+          <joint name="oz" type="slide" axis="0 0 1" range="-1 1"/>
+          <joint name="ory" type="hinge" axis="0 1 0" range="-3 3"/>
+          <geom name="pen" type="capsule" fromto="-0.05 0 0 0.05 0 0" size="0.01"/>
+          <site name="finger" pos="0 0 0"/>
+        </body>
+        <body name="a" pos="0 0 0.1">
+          <joint name="j0" axis="0 1 0" range="-1 1"/>
+          <geom name="ga" type="capsule" fromto="0 0 0 0.2 0 0" size="0.02"/>
+          <body name="b" pos="0.2 0 0">
+            <joint name="j1" axis="0 1 0" range="-2 2"/>
+            <geom name="gb" type="sphere" pos="0.05 0 0" size="0.03"/>
+          </body>
+        </body>
+      </worldbody>
+      <contact><pair geom1="ga" geom2="pen"/><pair geom1="gb" geom2="pen"/></contact>
+      <actuator>
+        <position joint="j0" kp="40" ctrlrange="-1 1" ctrllimited="true"/>
+        <position joint="j1" kp="10" gear="2" ctrlrange="-2 2" ctrllimited="true"/>
+      </actuator>
+    </mujoco>""")
+    p = tmp_path / "obj_arm.xml"
+    p.write_text(xml)
+    raw = load_mjcf(str(p), task=TASK_REACH)
+    assert [(a.joint, a.gear, a.kp) for a in raw.actuators] == [("j0", 1.0, 40.0), ("j1", 2.0, 10.0)]
+    assert raw.pairs == [("ga", "pen"), ("gb", "pen")]          # explicit pairs only: the masks are 0
+    m = compile_tree(raw)
+    assert m.nv == 4 and int(m.field("n_sphere")[0]) == 2 and int(m.field("any_friction")[0]) == 1
+    # servo: effective gear gear * kp, stiffness gear^2 kp at the joint
+    np.testing.assert_allclose(m.field("gear")[2:4], [40.0, 20.0])
+    np.testing.assert_allclose(m.field("kpg")[2:4], [40.0, 40.0])
+    # the manipulator's root hangs under the object's last link in the elimination tree
+    assert list(m.field("eparent")[:4].astype(int)) == [-1, 0, 1, 2] and m.max_path == 4
+    np.testing.assert_allclose(m.field("spheres").reshape(16, 24)[:2, 7], [0.8, 0.8])      # mu of both pairs
+    # masks that match: MuJoCo's rule adds the body-geom pairs that are not parent and child (here: both manipulator geoms
+    # against the object's; ga - gb are parent and child); later geom first
+    auto = load_mjcf(_write(tmp_path, "auto.xml", xml.replace('contype="0" conaffinity="0"', 'contype="1" conaffinity="1"')
+                                                      .replace('<contact><pair geom1="ga" geom2="pen"/><pair geom1="gb" geom2="pen"/></contact>', "")),
+                     task=TASK_REACH)
+    assert sorted(auto.pairs) == [("ga", "pen"), ("gb", "pen")]
+    assert load_mjcf(str(tmp_path / "auto.xml"), task=TASK_REACH, self_collision=False).pairs == []
+    # a pair across two branches of one tree would fill the sparse factorisation in: refused
+    bad = xml.replace('<body name="b" pos="0.2 0 0">', '<body name="c" pos="0 0.1 0"><joint name="j2" axis="0 1 0" range="-1 1"/>'
+                      '<geom name="gc" type="sphere" pos="0.05 0 0" size="0.03"/></body><body name="b" pos="0.2 0 0">')
+    bad = bad.replace('<pair geom1="gb" geom2="pen"/>', '<pair geom1="gb" geom2="gc"/>')
+    with pytest.raises(NotImplementedError):
+        compile_tree(load_mjcf(_write(tmp_path, "bad_pair.xml", bad), task=TASK_REACH))
+
+
+def _write(tmp_path, name, text):
+    (tmp_path / name).write_text(text)
+    return str(tmp_path / name)
