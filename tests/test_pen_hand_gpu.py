@@ -162,3 +162,60 @@ def test_constraint_solver_converges_on_hard_contact_states(pen):
     print("hard contact states: worst relative cost error %.2e, solver failures %d" % (worst, eng.solver_failures() - f0))
     assert eng.solver_failures() == f0 and ref.newton_stats()["fails"] == 0
     assert worst < 1e-4
+
+
+def test_object_on_a_small_manipulator_runs_the_dense_path(tmp_path):
+    """An object (slide + hinge) falling onto a two-link manipulator with position servos, 4 dofs in all: models of up to
+    16 dofs take the 16-lane DENSE instantiation, here with an elimination tree that differs from the kinematic one
+    (the manipulator hangs under the object) and geom-geom contacts - a combination the pen-in-hand model (32 lanes, sparse)
+    and the swimmer's self-collision (one tree) do not cover.  f64, costs and observations against the oracle at 1e-9."""
+    import textwrap
+    from mjmpc_amd.envs.tree_engine import TreeRolloutEngine
+    from mjmpc_amd.models.mjcf import load_mjcf
+    from mjmpc_amd.models.raw import TASK_REACH
+    from oracle.physics_ref import RefArm
+    xml = textwrap.dedent("""
+    <mujoco>
+      <compiler inertiafromgeom="true" angle="radian" coordinate="local"/>
+      <option timestep="0.002" gravity="0 0 -9.81" integrator="Euler"/>
+      <default><joint limited="true" damping="0.1"/><geom contype="0" conaffinity="0" condim="3" friction="0.8 0.005 0.0001"/></default>
+      <worldbody>
+        <site name="target" pos="0 0 0.3"/>
+        <body name="obj" pos="0.1 0 0.2">
+          <joint name="oz" type="slide" axis="0 0 1" range="-1 1"/>
+          <joint name="ory" type="hinge" axis="0 1 0" range="-3 3"/>
+          <geom name="pen" type="capsule" fromto="-0.05 0 0 0.05 0 0" size="0.01"/>
+          <site name="finger" pos="0 0 0"/>
+        </body>
+        <body name="a" pos="0 0 0.1">
+          <joint name="j0" axis="0 1 0" range="-1 1"/>
+          <geom name="ga" type="capsule" fromto="0 0 0 0.2 0 0" size="0.02"/>
+          <body name="b" pos="0.2 0 0">
+            <joint name="j1" axis="0 1 0" range="-2 2"/>
+            <geom name="gb" type="sphere" pos="0.05 0 0" size="0.03"/>
+          </body>
+        </body>
+      </worldbody>
+      <contact><pair geom1="ga" geom2="pen"/><pair geom1="gb" geom2="pen"/></contact>
+      <actuator>
+        <position joint="j0" kp="40" ctrlrange="-1 1" ctrllimited="true"/>
+        <position joint="j1" kp="10" gear="2" ctrlrange="-2 2" ctrllimited="true"/>
+      </actuator>
+    </mujoco>""")
+    (tmp_path / "obj_arm.xml").write_text(xml)
+    raw = load_mjcf(str(tmp_path / "obj_arm.xml"), task=TASK_REACH, frame_skip=5)
+    eng, ref = TreeRolloutEngine(raw, dtype="f64"), RefArm(raw.to_flat())
+    assert eng.model.nv == 4
+    rs = np.random.RandomState(2)
+    P, H = 64, 30
+    q0, v0 = np.array([-0.05, 0.1, 0.0, 0.0]), np.zeros(4)      # the object 2 cm above the link, slightly tilted
+    mean, noise = np.zeros((H, 2)), _noise(P, H, 2, 3, 0.2)
+    tgt = np.asarray(raw.target_pos, float)
+    eng.set_env_state(dict(qp=q0, qv=v0, target_pos=tgt))
+    obs, rew, act, done, info, nobs = eng.rollout(P, H, mean, noise)
+    before = ref.newton_stats()["iters"]
+    o_obs, o_rew, o_act, _, o_nobs = ref.rollout(q0, v0, tgt, mean, noise)
+    assert ref.newton_stats()["iters"] > before + P * H          # the object did land on the manipulator
+    np.testing.assert_allclose(rew, o_rew, rtol=1e-9, atol=1e-9)
+    np.testing.assert_allclose(nobs, o_nobs, rtol=0, atol=1e-9)
+    assert eng.solver_failures() == 0
