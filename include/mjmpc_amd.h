@@ -335,6 +335,14 @@ int mjmpc_q0_sum(int64_t P, int H, int A, double* d_out, void* d_ws, void* strea
 /* OLGaussianMPC._shift (mjmpc/control/olgaussian_mpc.py:116-129).  mode 0 'null', 1 'repeat',
  * 2 the appended row is read from d_row ('random': drawn by the host from np.random).            */
 int mjmpc_shift_mean(double* d_mean, int H, int A, int mode, const double* d_row, void* stream);
+/* The tail of Controller.optimize (controller.py:240-257: `_get_next_action`, `num_steps += 1`, `_shift`) in ONE launch
+ * for device-resident controllers: d_action_out / h_action_mapped (float64 [A], either may be NULL; the latter is
+ * mapped pinned host memory) <- mean[0]; the shift of mjmpc_shift_mean; *d_step_counter += 1 (may be NULL); and, when
+ * d_cov is not NULL, cov += cov_scale * diag(d_cov_diag) as in mjmpc_cov_add_diag (cem.py:89-95,
+ * gaussian_dmd.py:107-113).  A <= 64.                                                                          */
+int mjmpc_step_tail(double* d_mean, int H, int A, int shift_mode, const double* d_row, double* d_action_out,
+                    double* h_action_mapped, int64_t* d_step_counter, double* d_cov, const double* d_cov_diag,
+                    double cov_scale, void* stream);
 
 /* Covariance kept on the device (CEM cem.py:75-95, DMDMPC with update_cov gaussian_dmd.py:77-113): the lower
  * Cholesky factor d_chol (float64 [A][A]) that mjmpc_sample_noise colours its normals with, computed from the

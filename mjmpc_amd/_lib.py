@@ -73,6 +73,7 @@ SIGNATURES = {
                                                    _int, _vp]),
     "mjmpc_q0_sum": (_int, [_i64, _int, _int, _vp, _vp, _vp]),
     "mjmpc_shift_mean": (_int, [_vp, _int, _int, _int, _vp, _vp]),
+    "mjmpc_step_tail": (_int, [_vp, _int, _int, _int, _vp, _vp, _vp, _vp, _vp, _vp, _dbl, _vp]),
     "mjmpc_cholesky_lower": (_int, [_vp, _int, _vp, _vp, _vp]),
     "mjmpc_cov_add_diag": (_int, [_vp, _int, _vp, _dbl, _vp]),
     "mjmpc_color_noise": (_int, [_int, _vp, _i64, _int, _vp, _vp]),

@@ -259,7 +259,7 @@ class DeviceUpdater:
         code = self.code(costs)
         G, rank = self.comm.world_size, self.comm.rank
         if q0 is not None:
-            self._q0_view(ws, P).copy_(q0)
+            self._take_q0(ws, P, q0)
         else:
             _lib.check(self.lib.mjmpc_traj_cost(code, P, self.H, self.A, _vp(costs), _vp(self.gseq), self.gamma_zero,
                                                 _vp(ws), self.stream()))
@@ -304,6 +304,16 @@ class DeviceUpdater:
                         "samples are incomplete" % mt)
         raise _lib.MjmpcError("; ".join(msgs))
 
+    def q0_destination(self, P):
+        """Where the updates expect cost_to_go(costs)[:, 0] (float64 [P], a view of the workspace): a rollout launch that
+        writes its q0 there saves the copy."""
+        return self._q0_view(self.workspace(P), P)
+
+    def _take_q0(self, ws, P, q0):
+        view = self._q0_view(ws, P)
+        if q0.data_ptr() != view.data_ptr():
+            view.copy_(q0)
+
     def _q0_view(self, ws, P):
         addr = self.lib.mjmpc_workspace_q0(_vp(ws), P, self.H, self.A)
         off = (addr - ws.data_ptr()) // 8
@@ -315,7 +325,7 @@ class DeviceUpdater:
         ws = self.workspace(P)
         code = self.code(costs)
         if q0 is not None:
-            self._q0_view(ws, P).copy_(q0)
+            self._take_q0(ws, P, q0)
         else:
             _lib.check(self.lib.mjmpc_traj_cost(code, P, self.H, self.A, _vp(costs), _vp(self.gseq), self.gamma_zero,
                                                 _vp(ws), self.stream()))
@@ -346,17 +356,31 @@ class DeviceUpdater:
             row_d.copy_(self.torch.from_numpy(np.ascontiguousarray(row, np.float64)))
         _lib.check(self.lib.mjmpc_shift_mean(_vp(self.mean), self.H, self.A, int(mode), _vp(row_d), self.stream()))
 
+    def _cov_diag(self, diag):
+        """The device copy of a covariance-growth diagonal (None = identity), uploaded when it changes."""
+        if diag is None:
+            return None
+        d = self.record("cov_diag", self.A)
+        cached = self._rec.get("cov_diag_host")
+        diag = np.ascontiguousarray(diag, np.float64)
+        if cached is None or not np.array_equal(cached, diag):
+            d.copy_(self.torch.from_numpy(diag.copy()))
+            self._rec["cov_diag_host"] = diag.copy()
+        return d
+
     def add_cov_diag(self, diag, scale):
         """cov += scale * diag(diag) on the device (diag None: identity)."""
-        d = None
-        if diag is not None:
-            d = self.record("cov_diag", self.A)
-            cached = self._rec.get("cov_diag_host")
-            diag = np.ascontiguousarray(diag, np.float64)
-            if cached is None or not np.array_equal(cached, diag):
-                d.copy_(self.torch.from_numpy(diag.copy()))
-                self._rec["cov_diag_host"] = diag.copy()
-        _lib.check(self.lib.mjmpc_cov_add_diag(_vp(self.cov), self.A, _vp(d), float(scale), self.stream()))
+        _lib.check(self.lib.mjmpc_cov_add_diag(_vp(self.cov), self.A, _vp(self._cov_diag(diag)), float(scale),
+                                               self.stream()))
+
+    def step_tail(self, mode, action_out, action_pinned, step_counter, grow_cov=None):
+        """The end of a device-resident control step in one launch (``mjmpc_step_tail``): action = mean[0] to the device
+        and the pinned host buffer, shift (mode 0 'null' / 1 'repeat'), step counter + 1, and - ``grow_cov`` = (diag or
+        None, scale) - the covariance growth of the shift."""
+        d, scale = (self._cov_diag(grow_cov[0]), float(grow_cov[1])) if grow_cov is not None else (None, 0.0)
+        _lib.check(self.lib.mjmpc_step_tail(_vp(self.mean), self.H, self.A, int(mode), None, _vp(action_out),
+                                            _vp(action_pinned), _vp(step_counter),
+                                            _vp(self.cov) if grow_cov is not None else None, _vp(d), scale, self.stream()))
 
     def sample_noise_mt19937(self, P, cov, filter_coeffs, seed, offset, dtype="f64", d_step=None, filtered=True,
                              particle_offset=0):

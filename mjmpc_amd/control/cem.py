@@ -27,8 +27,8 @@ class CEM(OLGaussianMPC):
         self.dev.cem_update(trajectories["costs"], trajectories["actions"], self.num_elite, self.step_size,
                             self.cov_type == 'full', q0=trajectories.get("q0"))
 
-    def _device_shift_cov(self):
-        self.dev.add_cov_diag(self.init_cov, self.beta)
+    def _shift_cov_args(self):
+        return self.init_cov, self.beta
 
     def _update_distribution(self, trajectories):
         """cem.py:65-86: the num_elite particles of least cost-to-go (ties by particle index) refit

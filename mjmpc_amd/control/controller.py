@@ -22,6 +22,7 @@ Extra constructor keywords (all optional, defaults reproduce the reference bit f
   device      CUDA device ordinal;  comm  particle-sharding communicator (see _device.py)
 """
 import copy
+import inspect
 from abc import ABC, abstractmethod
 
 import numpy as np
@@ -332,8 +333,22 @@ class OLGaussianMPC(Controller):
     def _device_cov(self):
         return False            # subclasses that adapt the covariance entirely on the device say True
 
+    def _q0_kw(self, n_loc):
+        """``q0_out=`` for fused rollouts that take it: the launch writes the cost-to-go where the update reads it."""
+        fused = self._rollout_fn.fused
+        if "q0_out" not in inspect.signature(fused).parameters:
+            return {}
+        return dict(q0_out=self.dev.q0_destination(n_loc))
+
+    def _shift_cov_args(self):
+        """(diag or None = identity, scale) of the covariance growth after the shift (cem.py:94, gaussian_dmd.py:111);
+        None: the covariance does not grow."""
+        return None
+
     def _device_shift_cov(self):
-        pass                    # ... and grow it here after the shift (cem.py:94, gaussian_dmd.py:111)
+        grow = self._shift_cov_args()
+        if grow is not None:
+            self.dev.add_cov_diag(*grow)
 
     def _device_update(self, trajectories):
         raise NotImplementedError
@@ -452,7 +467,7 @@ class OLGaussianMPC(Controller):
             if q0_fused:
                 raw = self._draw_raw(n_loc, 0)
                 costs, actions, q0 = self._rollout_fn.fused(n_loc, self.horizon, self.dev.mean, raw,
-                                                            self.dev.record("coeffs", 3), self.dev.gseq)
+                                                            self.dev.record("coeffs", 3), self.dev.gseq, **self._q0_kw(n_loc))
                 self._device_update(dict(costs=costs, actions=actions, q0=q0))
                 continue
             if self.noise_mode == 'device_mt19937':
@@ -468,11 +483,9 @@ class OLGaussianMPC(Controller):
                 delta[-1] = (-self.dev.mean).to(delta.dtype)    # the LAST particle of the whole set (olgaussian_mpc.py:110-111)
             traj = self._rollout_fn(n_loc, self.horizon, self.dev.mean, delta, mode="open_loop")
             self._device_update(traj)
-        self._action_dev.copy_(self.dev.mean[0])
-        self._action_pin[:self.d_action].copy_(self._action_dev, non_blocking=True)
-        self.dev.shift(_SHIFT_MODES[self.base_action], None)
-        self._device_shift_cov()
-        self._step_dev.add_(1)
+        # action read-out (device copy + pinned host copy), shift, covariance growth, step counter: one launch
+        self.dev.step_tail(_SHIFT_MODES[self.base_action], self._action_dev, self._action_pin, self._step_dev,
+                           self._shift_cov_args())
         if self._graph_post is not None:
             self._graph_post(self._action_dev)
 

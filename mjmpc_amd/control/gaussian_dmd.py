@@ -42,9 +42,8 @@ class DMDMPC(OLGaussianMPC):
         self.dev.softmax_update(trajectories["costs"], trajectories["actions"], self.lam, self.step_size,
                                 cov_mode=self._cov_mode())
 
-    def _device_shift_cov(self):
-        if self.update_cov:
-            self.dev.add_cov_diag(None, self.beta)
+    def _shift_cov_args(self):
+        return (None, self.beta) if self.update_cov else None
 
     def _update_distribution(self, trajectories):
         """gaussian_dmd.py:65-104: softmax weights; weighted mean; if update_cov the weighted scatter,

@@ -974,6 +974,15 @@ int mjmpc_shift_mean(double* d_mean, int H, int A, int mode, const double* d_row
     PLAIN(mjmpc::shift_mean(d_mean, H, A, mode, d_row, (hipStream_t)stream));
 }
 
+int mjmpc_step_tail(double* d_mean, int H, int A, int shift_mode, const double* d_row, double* d_action_out,
+                    double* h_action_mapped, int64_t* d_step_counter, double* d_cov, const double* d_cov_diag,
+                    double cov_scale, void* stream) {
+    if (!d_mean || (shift_mode == 2 && !d_row) || shift_mode < 0 || shift_mode > 2 || A < 1 || A > 64 || H < 1)
+        return fail(MJMPC_E_BADARG, "bad argument");
+    PLAIN(mjmpc::step_tail(d_mean, H, A, shift_mode, d_row, d_action_out, h_action_mapped, (long long*)d_step_counter,
+                           d_cov, d_cov_diag, cov_scale, (hipStream_t)stream));
+}
+
 int mjmpc_cholesky_lower(const double* d_cov, int A, double* d_chol, int* d_status, void* stream) {
     if (!d_cov || !d_chol || A < 1 || A > 64) return fail(MJMPC_E_BADARG, "bad argument (A <= 64)");
     PLAIN(mjmpc::cholesky_lower(d_cov, A, d_chol, d_status, (hipStream_t)stream));

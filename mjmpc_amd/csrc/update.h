@@ -64,6 +64,9 @@ hipError_t mppi_fused_combine(const double* records, int G, double P_total, doub
 
 hipError_t q0_sum(long P, int H, int A, double* out, double* ws, hipStream_t s);
 hipError_t shift_mean(double* mean, int H, int A, int mode, const double* row, hipStream_t s);
+// action read-out (device + mapped host copy), shift, step counter + 1, cov += scale * diag(d): one launch
+hipError_t step_tail(double* mean, int H, int A, int mode, const double* row, double* action_out, double* action_host,
+                     long long* step_counter, double* cov, const double* d, double scale, hipStream_t s);
 // lower Cholesky factor of a device-resident covariance (A <= 64); cov += scale * diag(d) (d null: identity)
 hipError_t cholesky_lower(const double* cov, int A, double* chol, int* status, hipStream_t s);
 hipError_t cov_add_diag(double* cov, int A, const double* d, double scale, hipStream_t s);

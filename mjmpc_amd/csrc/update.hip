@@ -269,6 +269,7 @@ __global__ __launch_bounds__(1024) void kth_key_kernel(const double* __restrict_
     __shared__ unsigned long long prefix_s, less_s;
     __shared__ long need_s, cut_s, sel_need, wtot[16], scan_v[256];
     __shared__ int sel_bin, sel_unique;
+    bool single = false;                    // the selection ended on the one particle that holds the k-th key
     const int tid = threadIdx.x;
     if (k <= 0) {                                           // empty elite set
         if (tid == 0) { thr[0] = 0ull; thr[1] = 0ull; thr[2] = ~0ull; }
@@ -351,9 +352,13 @@ __global__ __launch_bounds__(1024) void kth_key_kernel(const double* __restrict_
 #pragma unroll
             for (long r = 0; r < rounds; ++r) {
                 const unsigned long long key = key_at(r);
-                if ((r * 1024 + tid < P_all) && (key & mask) == want) prefix_s = key;
+                if ((r * 1024 + tid < P_all) && (key & mask) == want) {
+                    prefix_s = key;
+                    cut_s = r * 1024 + tid;         // no other particle has this key: it is the last elite one
+                }
             }
             __syncthreads();
+            single = true;
             break;
         }
     }
@@ -363,10 +368,13 @@ __global__ __launch_bounds__(1024) void kth_key_kernel(const double* __restrict_
     long seen = 0;
     unsigned long long c = 0;
 #pragma unroll
-    for (long r = 0; r < rounds; ++r) {
+    for (long r = 0; r < rounds; ++r) c += (r * 1024 + tid < P_all) && key_at(r) < T;
+    // ties: the index of the room-th particle (in index order) whose key equals T - two barriers per round, skipped
+    // when the selection has already named the one holder of T
+#pragma unroll
+    for (long r = 0; r < (single ? 0 : rounds); ++r) {
         const long j = r * 1024 + tid;
         const unsigned long long key = key_at(r);
-        c += (j < P_all) && key < T;
         const bool eq = (j < P_all) && key == T;
         // rank of this particle among the ties, in index order: ballot inside the wavefront + wavefront totals
         const unsigned long long m = __ballot(eq);
@@ -388,57 +396,140 @@ __global__ __launch_bounds__(1024) void kth_key_kernel(const double* __restrict_
     if (tid == 0) { thr[0] = T; thr[1] = less_s; thr[2] = (unsigned long long)(cut_s < 0 ? P_all : cut_s); }
 }
 
-// elite[i] = 1 iff local particle i is among the k smallest in (q0, global index) order
-__global__ void elite_flag_kernel(const double* __restrict__ q_local, long P_local, long offset,
-                                  const unsigned long long* __restrict__ thr, int* __restrict__ elite) {
-    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= P_local) return;
-    const unsigned long long T = thr[0], key = order_key(q_local[i]);
-    elite[i] = key < T || (key == T && offset + i <= (long)thr[2]);
+// list[0..n) = the local indices of the elite particles in index order, *count = n: the moment kernels below then read
+// elite rows only (a tenth of the population at elite_frac 0.1) with independent loads, where a walk over the flags of
+// all particles paid one dependent trip to memory per elite.  One workgroup; coalesced rounds of 1024 particles, the
+// wavefront ballots' popcounts scanned once (dynamic LDS: 16 counts per round), then every elite lane knows its slot.
+__global__ __launch_bounds__(1024) void elite_list_kernel(const double* __restrict__ q_local, long P_local, long offset,
+                                                          const unsigned long long* __restrict__ thr,
+                                                          int* __restrict__ list, int* __restrict__ count) {
+    extern __shared__ int cnt[];            // [rounds][16] ballot popcounts -> exclusive prefixes
+    __shared__ int wtot[16];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int rounds = (int)((P_local + 1023) / 1024), n = rounds * 16;
+    const unsigned long long T = thr[0];
+    const long cut = (long)thr[2];
+    auto is_elite = [&](long i) {
+        if (i >= P_local) return false;
+        const unsigned long long key = order_key(q_local[i]);
+        return key < T || (key == T && offset + i <= cut);
+    };
+    for (int r = 0; r < rounds; ++r) {
+        const unsigned long long m = __ballot(is_elite((long)r * 1024 + tid));
+        if (lane == 0) cnt[r * 16 + wave] = __popcll(m);
+    }
+    __syncthreads();
+    // exclusive scan of the n counts in (round, wavefront) order: a run of `per` entries per thread
+    const int per = (n + 1023) / 1024, c0 = tid * per;
+    int own = 0;
+    for (int k = 0; k < per; ++k) own += c0 + k < n ? cnt[c0 + k] : 0;
+    int incl = own;
+    for (int o = 1; o < 64; o <<= 1) {
+        const int u = __shfl_up(incl, o);
+        if (lane >= o) incl += u;
+    }
+    if (lane == 63) wtot[wave] = incl;
+    __syncthreads();
+    int at = incl - own, total = 0;
+    for (int w = 0; w < 16; ++w) {
+        if (w < wave) at += wtot[w];
+        total += wtot[w];
+    }
+    for (int k = 0; k < per; ++k)
+        if (c0 + k < n) {
+            const int v = cnt[c0 + k];
+            cnt[c0 + k] = at;
+            at += v;
+        }
+    __syncthreads();
+    for (int r = 0; r < rounds; ++r) {
+        const long i = (long)r * 1024 + tid;
+        const bool e = is_elite(i);
+        const unsigned long long m = __ballot(e);
+        if (e) list[cnt[r * 16 + wave] + __popcll(m & ((1ull << lane) - 1ull))] = (int)i;
+    }
+    if (tid == 0) *count = total;
 }
 
-// pass 0: partial[b] = { count, sum_elite a[H*A] }        pass 1: partial[b] = { sum_elite,t (d-dm)(d-dm)' [A*A] }
+// partial[b] = { number of elite rows in block b, sum of their action rows [H*A] }   (E list entries per workgroup)
 template <typename T>
-__global__ void elite_partial_kernel(const int* __restrict__ elite, const T* __restrict__ actions,
-                                     const double* __restrict__ mean, const double* __restrict__ dmean, long P, int H,
-                                     int A, int chunk, int pass, double* __restrict__ partial) {
-    const int HA = H * A;
-    const long p0 = (long)blockIdx.x * chunk;
-    const int n = (int)((P - p0) < chunk ? (P - p0) : chunk);
-    if (pass == 0) {
-        double* out = partial + (long)blockIdx.x * (1 + HA);
-        if (threadIdx.x == 0) {
-            double c = 0.0;
-            for (int p = 0; p < n; ++p) c += elite[p0 + p];
-            out[0] = c;
-        }
-        for (int j = threadIdx.x; j < HA; j += blockDim.x) {
-            double s = 0.0;
-            for (int p = 0; p < n; ++p)
-                if (elite[p0 + p]) s += (double)actions[(p0 + p) * HA + j];
-            out[1 + j] = s;
-        }
-    } else {
-        double* out = partial + (long)blockIdx.x * (A * A);
-        for (int idx = threadIdx.x; idx < A * A; idx += blockDim.x) {
-            const int i = idx / A, k = idx % A;
-            double s = 0.0;
-            for (int p = 0; p < n; ++p) {
-                if (!elite[p0 + p]) continue;
-                const T* ap = actions + (p0 + p) * HA;
-                for (int t = 0; t < H; ++t)
-                    s += ((double)ap[t * A + i] - mean[t * A + i] - dmean[i]) *
-                         ((double)ap[t * A + k] - mean[t * A + k] - dmean[k]);
-            }
-            out[idx] = s;
-        }
+__global__ void elite_rows_sum_kernel(const int* __restrict__ list, const int* __restrict__ count,
+                                      const T* __restrict__ actions, int HA, int E, double* __restrict__ partial) {
+    const int n = *count, e0 = blockIdx.x * E;
+    if (e0 >= n && blockIdx.x > 0) return;      // (its partial is not read: ordered_sum_counted_kernel)
+    const int ne = n - e0 < 0 ? 0 : (n - e0 < E ? n - e0 : E);
+    double* out = partial + (long)blockIdx.x * (1 + HA);
+    if (threadIdx.x == 0) out[0] = (double)ne;
+    for (int j = threadIdx.x; j < HA; j += blockDim.x) {
+        double s = 0.0;
+        for (int e = 0; e < ne; ++e) s += (double)actions[(long)list[e0 + e] * HA + j];
+        out[1 + j] = s;
     }
 }
 
-__global__ void ordered_sum_kernel(const double* __restrict__ partial, int nb, int rec, double* __restrict__ out) {
+// partial[b] = sum over block b's elite rows and all steps of (d - dm)(d - dm)' [A*A], for tiles that fit LDS: the E x H
+// deltas are staged once, every thread owns one (i, k) entry and one slice of the E * H rows, and the slices are added
+// in a fixed order
+template <typename T>
+__global__ __launch_bounds__(1024) void elite_rows_scatter_lds_kernel(const int* __restrict__ list, const int* __restrict__ count,
+                                                                      const T* __restrict__ actions,
+                                                                      const double* __restrict__ mean,
+                                                                      const double* __restrict__ dmean, int H, int A, int E,
+                                                                      double* __restrict__ partial) {
+    extern __shared__ double tile[];        // d[E * H][A] | red[S][A * A]
+    const int n = *count, e0 = blockIdx.x * E, HA = H * A, AA = A * A;
+    if (e0 >= n && blockIdx.x > 0) return;
+    const int ne = n - e0 < 0 ? 0 : (n - e0 < E ? n - e0 : E);
+    for (int w = threadIdx.x; w < ne * HA; w += blockDim.x) {
+        const int e = w / HA, j = w - e * HA;
+        tile[w] = (double)actions[(long)list[e0 + e] * HA + j] - mean[j] - dmean[j % A];
+    }
+    __syncthreads();
+    const int S = (int)blockDim.x / AA, rows = ne * H;
+    double* red = tile + E * HA;
+    if ((int)threadIdx.x < S * AA) {
+        const int sl = threadIdx.x / AA, idx = threadIdx.x - sl * AA, i = idx / A, k = idx - i * A;
+        double s = 0.0;
+        for (int r = sl; r < rows; r += S) s += tile[r * A + i] * tile[r * A + k];
+        red[threadIdx.x] = s;
+    }
+    __syncthreads();
+    if ((int)threadIdx.x < AA) {
+        double s = 0.0;
+        for (int sl = 0; sl < S; ++sl) s += red[sl * AA + threadIdx.x];
+        partial[(long)blockIdx.x * AA + threadIdx.x] = s;
+    }
+}
+
+// partial[b * TQ + tq] = sum over block b's elite rows and the steps t = tq, tq + TQ, ... of (d - dm)(d - dm)' [A*A]
+template <typename T>
+__global__ void elite_rows_scatter_kernel(const int* __restrict__ list, const int* __restrict__ count,
+                                          const T* __restrict__ actions, const double* __restrict__ mean,
+                                          const double* __restrict__ dmean, int H, int A, int E, int TQ,
+                                          double* __restrict__ partial) {
+    const int n = *count, e0 = blockIdx.x * E, HA = H * A, AA = A * A;
+    if (e0 >= n && blockIdx.x > 0) return;
+    const int ne = n - e0 < 0 ? 0 : (n - e0 < E ? n - e0 : E);
+    for (int w = threadIdx.x; w < AA * TQ; w += blockDim.x) {
+        const int tq = w / AA, idx = w - tq * AA, i = idx / A, k = idx - i * A;
+        const double di = dmean[i], dk = dmean[k];
+        double s = 0.0;
+        for (int e = 0; e < ne; ++e) {
+            const T* ap = actions + (long)list[e0 + e] * HA;
+            for (int t = tq; t < H; t += TQ)
+                s += ((double)ap[t * A + i] - mean[t * A + i] - di) * ((double)ap[t * A + k] - mean[t * A + k] - dk);
+        }
+        partial[((long)blockIdx.x * TQ + tq) * AA + idx] = s;
+    }
+}
+
+// sum over the partials of the workgroups that held elite rows: ceil(*count / E) * mult of them (at least mult)
+__global__ void ordered_sum_counted_kernel(const double* __restrict__ partial, const int* __restrict__ count, int E,
+                                           int mult, int rec, double* __restrict__ out) {
     const int j = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     if (j >= rec) return;
-    const double s = wave_entry_sum(partial, nb, rec, j);
+    const int n = *count, nbe = n > 0 ? (n + E - 1) / E : 1;
+    const double s = wave_entry_sum(partial, nbe * mult, rec, j);
     if ((threadIdx.x & 63) == 0) out[j] = s;
 }
 
@@ -596,6 +687,24 @@ __global__ void shift_kernel(double* __restrict__ mean, int H, int A, int mode, 
     for (int t = 0; t + 1 < H; ++t) mean[t * A + a] = mean[(t + 1) * A + a];   // column-wise: no cross-thread hazard
     last[a] = mode == 0 ? 0.0 : (mode == 1 ? (H >= 2 ? mean[(H - 2) * A + a] : mean[a]) : row[a]);
     mean[(H - 1) * A + a] = last[a];
+}
+
+// The tail of a control step in one launch: read the action out (mean[0] -> device copy and mapped host copy), shift the
+// horizon, advance the device step counter, and grow the covariance by scale * diag(d) (the shift of CEM / DMD-MPC with
+// update_cov) - five stream operations of ~5 us each when issued one by one.  Any of the outputs may be null.
+__global__ void step_tail_kernel(double* __restrict__ mean, int H, int A, int mode, const double* __restrict__ row,
+                                 double* __restrict__ action_out, double* __restrict__ action_host,
+                                 long long* __restrict__ step_counter, double* __restrict__ cov,
+                                 const double* __restrict__ d, double scale) {
+    const int a = threadIdx.x;
+    if (a == 0 && step_counter) *step_counter += 1;
+    if (a >= A) return;
+    const double act = mean[a];
+    if (action_out) action_out[a] = act;
+    if (action_host) action_host[a] = act;
+    for (int t = 0; t + 1 < H; ++t) mean[t * A + a] = mean[(t + 1) * A + a];
+    mean[(H - 1) * A + a] = mode == 0 ? 0.0 : (mode == 1 ? (H >= 2 ? mean[(H - 2) * A + a] : act) : row[a]);
+    if (cov) cov[a * A + a] += scale * (d ? d[a] : 1.0);
 }
 
 // Device-resident covariance (CEM, DMD-MPC with update_cov): the factor the sampler colours its normals with is
@@ -802,6 +911,9 @@ struct Ws {
     }
 };
 
+// number of entries of the elite list (elite_list_kernel), behind the selection thresholds in the scratch block
+static inline int* elite_count(const Ws& w) { return (int*)(w.scratch + 8); }
+
 template <typename T>
 hipError_t traj_cost(const T* costs, const T* actions, const double* mean, const double* covinv, const double* gseq,
                      int gamma_zero, double lam, int alpha, int tbw, long P, int H, int A, double* ws,
@@ -871,17 +983,23 @@ template <typename T>
 hipError_t cem_elite_sums(const T* actions, const double* q_all, long P_all, long offset, long k, long P, int H, int A,
                           double* record, double* ws, hipStream_t s) {
     Ws w(ws, P, H, A);
-    const int HA = H * A, nb = nblocks(P, CHUNK);
+    const int HA = H * A;
     const double* qa = q_all ? q_all : w.q0;
     unsigned long long* thr = (unsigned long long*)w.scratch;
     const long Pa = q_all ? P_all : P;
     if (Pa <= 16 * 1024) hipLaunchKernelGGL(kth_key_kernel<16>, dim3(1), dim3(1024), 0, s, qa, Pa, k, thr);
     else if (Pa <= 32 * 1024) hipLaunchKernelGGL(kth_key_kernel<32>, dim3(1), dim3(1024), 0, s, qa, Pa, k, thr);
     else hipLaunchKernelGGL(kth_key_kernel<0>, dim3(1), dim3(1024), 0, s, qa, Pa, k, thr);
-    hipLaunchKernelGGL(elite_flag_kernel, dim3(nblocks(P, BLK)), dim3(BLK), 0, s, w.q0, P, offset, thr, w.elite);
-    hipLaunchKernelGGL(elite_partial_kernel<T>, dim3(nb), dim3(BLK), 0, s, w.elite, actions, (const double*)nullptr,
-                       (const double*)nullptr, P, H, A, CHUNK, 0, w.partial);
-    hipLaunchKernelGGL(ordered_sum_kernel, dim3(nblocks(1 + HA, BLK / 64)), dim3(BLK), 0, s, w.partial, nb, 1 + HA, record);
+    // the local elite rows as a list (index order), then moments over those rows only
+    const long kmax = k < P ? (k > 0 ? k : 0) : P;
+    const int nbe = kmax > 0 ? nblocks(kmax, CHUNK) : 1;
+    const size_t list_lds = sizeof(int) * 16 * (size_t)((P + 1023) / 1024);
+    if (list_lds > 48 * 1024) return hipErrorInvalidValue;          // (> 786 432 particles on one GPU)
+    hipLaunchKernelGGL(elite_list_kernel, dim3(1), dim3(1024), list_lds, s, w.q0, P, offset, thr, w.elite, elite_count(w));
+    hipLaunchKernelGGL(elite_rows_sum_kernel<T>, dim3(nbe), dim3(BLK), 0, s, w.elite, elite_count(w), actions, HA, CHUNK,
+                       w.partial);
+    hipLaunchKernelGGL(ordered_sum_counted_kernel, dim3(nblocks(1 + HA, BLK / 64)), dim3(BLK), 0, s, w.partial,
+                       elite_count(w), CHUNK, 1, 1 + HA, record);
     return hipGetLastError();
 }
 
@@ -889,11 +1007,24 @@ template <typename T>
 hipError_t cem_elite_cov(const T* actions, const double* mean, const double* sum_records, int G, long P, int H, int A,
                          double* crecord, double* ws, hipStream_t s) {
     Ws w(ws, P, H, A);
-    const int nb = nblocks(P, CHUNK);
+    // (every local row may be elite: the list is at most P long; the partials were sized for P / CHUNK workgroups of
+    // H + H A + A A entries, which bounds the number of step-slices a workgroup may keep apart)
+    const int nbe = nblocks(P, CHUNK) < (1 << 20) ? nblocks(P, CHUNK) : (1 << 20);
+    int tq = (H + H * A + A * A) / (A * A);
+    tq = tq < 1 ? 1 : (tq > 4 ? 4 : tq);
+    tq = tq > H ? H : tq;
     hipLaunchKernelGGL(cem_mean_kernel, dim3(1), dim3(BLK), 0, s, sum_records, G, H, A, mean, w.elite_mean, w.dmean);
-    hipLaunchKernelGGL(elite_partial_kernel<T>, dim3(nb), dim3(BLK), 0, s, w.elite, actions, mean, w.dmean, P, H, A,
-                       CHUNK, 1, w.partial);
-    hipLaunchKernelGGL(ordered_sum_kernel, dim3(nblocks(A * A, BLK / 64)), dim3(BLK), 0, s, w.partial, nb, A * A, crecord);
+    const size_t lds = sizeof(double) * ((size_t)CHUNK * H * A + (size_t)(1024 / (A * A > 1024 ? 1024 : A * A)) * A * A);
+    if (A * A <= 1024 && lds <= 48 * 1024) {
+        hipLaunchKernelGGL(elite_rows_scatter_lds_kernel<T>, dim3(nbe), dim3(1024), lds, s, w.elite, elite_count(w), actions,
+                           mean, w.dmean, H, A, CHUNK, w.partial);
+        tq = 1;
+    } else {
+        hipLaunchKernelGGL(elite_rows_scatter_kernel<T>, dim3(nbe), dim3(BLK), 0, s, w.elite, elite_count(w), actions, mean,
+                           w.dmean, H, A, CHUNK, tq, w.partial);
+    }
+    hipLaunchKernelGGL(ordered_sum_counted_kernel, dim3(nblocks(A * A, BLK / 64)), dim3(BLK), 0, s, w.partial,
+                       elite_count(w), CHUNK, tq, A * A, crecord);
     return hipGetLastError();
 }
 
@@ -985,6 +1116,14 @@ hipError_t cov_add_diag(double* cov, int A, const double* d, double scale, hipSt
 hipError_t shift_mean(double* mean, int H, int A, int mode, const double* row, hipStream_t s) {
     if (A > 64) return hipErrorInvalidValue;
     hipLaunchKernelGGL(shift_kernel, dim3(1), dim3(64), 0, s, mean, H, A, mode, row);
+    return hipGetLastError();
+}
+
+hipError_t step_tail(double* mean, int H, int A, int mode, const double* row, double* action_out, double* action_host,
+                     long long* step_counter, double* cov, const double* d, double scale, hipStream_t s) {
+    if (A > 64) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(step_tail_kernel, dim3(1), dim3(64), 0, s, mean, H, A, mode, row, action_out, action_host,
+                       step_counter, cov, d, scale);
     return hipGetLastError();
 }
 

@@ -219,17 +219,18 @@ class ArmRolloutEngine:
                       _ptr(nobs), self._stream()))
         return costs, act, obs, nobs
 
-    def rollout_fused(self, num_particles, horizon, mean, raw_noise, filter_coeffs, gamma_seq):
+    def rollout_fused(self, num_particles, horizon, mean, raw_noise, filter_coeffs, gamma_seq, q0_out=None):
         """Device-resident rollout with the noise filter and the discounted cost-to-go fused into the
         launch (``mjmpc_arm_rollout_fused``).  All arguments are CUDA tensors (``filter_coeffs`` may be
-        None).  Returns (costs, actions, q0)."""
+        None; ``q0_out``: a float64 [P] tensor the cost-to-go is written to instead of the engine's own
+        buffer).  Returns (costs, actions, q0)."""
         torch = _torch()
         P, H, A = int(num_particles), int(horizon), self.d_action
         mean_d = self._as_device(mean, torch.float64, (H, A))
         noise_d = self._as_device(raw_noise, self._tdtype, (P, H, A))
         costs = self._buffer("costs", (P, H))
         act = self._buffer("act", (P, H, A))
-        q0 = self._buf.get("q0")
+        q0 = q0_out if q0_out is not None else self._buf.get("q0")
         if q0 is None or q0.shape[0] != P:
             q0 = self._buf["q0"] = torch.empty(P, dtype=torch.float64, device=self.device)
         _lib.check(self._lib.mjmpc_arm_rollout_fused(self._h, self._code, P, H, _ptr(mean_d), _ptr(noise_d),
