@@ -252,27 +252,35 @@ __global__ void softmax_weights_kernel(const double* __restrict__ x, const doubl
 // Elite selection = the k smallest particles in (q0, global index) order.  A most-significant-byte radix select
 // over the order-preserving integer image of the doubles finds the k-th smallest key in 8 passes of one
 // workgroup (the first version ranked every particle against every other: 1.2 ms at 16 384 particles);
-// thr = { k-th smallest key, number of particles with a smaller key }.
 __device__ __forceinline__ unsigned long long order_key(double q) {
     const unsigned long long b = (unsigned long long)__double_as_longlong(q);
     return (b >> 63) ? ~b : (b | 0x8000000000000000ull);
 }
 
-// thr = { k-th smallest key T, number of particles with a smaller key, cut }: among the particles whose key
-// EQUALS T, those with global index <= cut complete the elite set (ties go to the smaller index).
+// thr = { k-th smallest key T, (unused), cut }: among the particles whose key EQUALS T, those with global index <= cut
+// complete the elite set (ties go to the smaller index).
 // NPER > 0: every thread keeps its NPER keys (particles tid, tid + 1024, ...) in registers for all passes - the
 // passes are then pure register / LDS work instead of 8 x P/1024 dependent trips to L2 (138 -> ~15 us at 16 384).
+// Round 3: the leading bits all keys share are found by one AND / OR reduction instead of a pass each (the costs of one
+// population share sign, exponent and often more) and the 8-bit digit windows count down from the first differing bit; once the bucket that holds the rank has at most KTH_CAND keys
+// they are ranked against each other directly in (key, index) order - which also settles ties exactly, so the
+// barrier-per-round tie walk only runs when more than KTH_CAND particles hold the k-th key itself.
+constexpr int KTH_CAND = 32;        // (the ranking is a loop of dependent LDS reads: 256 candidates cost more than a pass)
 template <int NPER>
 __global__ __launch_bounds__(1024) void kth_key_kernel(const double* __restrict__ q_all, long P_all, long k,
-                                                       unsigned long long* __restrict__ thr) {
+                                                       unsigned long long* __restrict__ thr, long offset, long P_local,
+                                                       int* __restrict__ list, int* __restrict__ count) {
     __shared__ unsigned hist[256];
-    __shared__ unsigned long long prefix_s, less_s;
-    __shared__ long need_s, cut_s, sel_need, wtot[16], scan_v[256];
-    __shared__ int sel_bin, sel_unique;
-    bool single = false;                    // the selection ended on the one particle that holds the k-th key
+    __shared__ unsigned long long prefix_s, red_and[16], red_or[16], cand_key[KTH_CAND];
+    __shared__ long need_s, cut_s, sel_need, wtot[16], scan_v[256], cand_idx[KTH_CAND];
+    __shared__ int sel_bin, sel_cnt, ncand;
+    bool single = false;                    // the selection has named the last elite particle itself (T and cut)
     const int tid = threadIdx.x;
     if (k <= 0) {                                           // empty elite set
-        if (tid == 0) { thr[0] = 0ull; thr[1] = 0ull; thr[2] = ~0ull; }
+        if (tid == 0) {
+            thr[0] = 0ull; thr[1] = 0ull; thr[2] = ~0ull;
+            if (list) *count = 0;
+        }
         return;
     }
     constexpr int NK = NPER > 0 ? NPER : 1;
@@ -290,18 +298,42 @@ __global__ __launch_bounds__(1024) void kth_key_kernel(const double* __restrict_
         const long j = r * 1024 + tid;
         return j < P_all ? order_key(q_all[j]) : ~0ull;
     };
-    if (tid == 0) { prefix_s = 0ull; need_s = k; less_s = 0ull; cut_s = -1; }     // need = rank still to be located
+    // bits every key shares: the passes start at the first bit in which two keys differ
+    unsigned long long kand = ~0ull, kor = 0ull;
+#pragma unroll
+    for (long r = 0; r < rounds; ++r)
+        if (r * 1024 + tid < P_all) {
+            const unsigned long long key = key_at(r);
+            kand &= key;
+            kor |= key;
+        }
+    for (int o = 32; o > 0; o >>= 1) {
+        kand &= __shfl_xor(kand, o);
+        kor |= __shfl_xor(kor, o);
+    }
+    if ((tid & 63) == 0) { red_and[tid >> 6] = kand; red_or[tid >> 6] = kor; }
+    if (tid == 0) { need_s = k; cut_s = -1; }       // need = rank still to be located
     __syncthreads();
-    for (int byte = 7; byte >= 0; --byte) {
+    for (int w = 0; w < 16; ++w) { kand &= red_and[w]; kor |= red_or[w]; }
+    // digits are 8-bit windows counted down from the most significant bit in which two keys differ (not byte-aligned:
+    // the first window then spreads the population over up to 256 buckets instead of the handful a byte that is mostly
+    // exponent offers - few buckets mean 64 lanes serialising on a few LDS words - and the second usually ends it)
+    const unsigned long long differ = kand ^ kor;
+    const int top = differ ? 64 - __clzll((long long)differ) : 0;       // 0: all keys are equal
+    if (tid == 0) prefix_s = top == 64 ? 0ull : (kand & (~0ull << top));
+    __syncthreads();
+    for (int hi = top; hi > 0;) {
+        const int width = hi >= 8 ? 8 : hi, shift = hi - width;
+        hi = shift;
         if (tid < 256) hist[tid] = 0u;
         __syncthreads();
         const unsigned long long prefix = prefix_s;
-        const unsigned long long himask = byte == 7 ? 0ull : (~0ull << (8 * (byte + 1)));
+        const unsigned long long himask = shift + width == 64 ? 0ull : (~0ull << (shift + width));
 #pragma unroll
         for (long r = 0; r < rounds; ++r) {
             const unsigned long long key = key_at(r);
             const bool in = (r * 1024 + tid < P_all) && (key & himask) == prefix;
-            const unsigned bin = (unsigned)(key >> (8 * byte)) & 0xFFu;
+            const unsigned bin = (unsigned)(key >> shift) & ((1u << width) - 1u);
             // costs of one population share their leading bytes: when every candidate of the wavefront falls
             // into the same bin, one lane adds the count instead of 64 lanes serialising on one LDS word
             const unsigned long long m = __ballot(in);
@@ -333,44 +365,54 @@ __global__ __launch_bounds__(1024) void kth_key_kernel(const double* __restrict_
             for (int w = 0; w < (tid >> 6); ++w) off += wtot[w];
             const long incl = scan_v[tid] + off, excl = incl - (long)hist[tid], need = need_s;
             const long total = wtot[0] + wtot[1] + wtot[2] + wtot[3];
-            if ((excl < need && need <= incl) || (tid == 255 && total < need)) {      // (k > P_all: everything is elite)
+            if ((excl < need && need <= incl) || (tid == (1 << width) - 1 && total < need)) {   // (k > P_all: everything is elite)
                 sel_bin = tid;
                 sel_need = need - excl;
-                sel_unique = (hist[tid] == 1u && total >= need) ? 1 : 0;
+                sel_cnt = (int)(hist[tid] < 0x7fffffffu ? hist[tid] : 0x7fffffffu);
             }
         }
         __syncthreads();
         if (tid == 0) {
             need_s = sel_need;
-            prefix_s = prefix | ((unsigned long long)sel_bin << (8 * byte));
+            prefix_s = prefix | ((unsigned long long)sel_bin << shift);
+            ncand = 0;
         }
         __syncthreads();
-        // One candidate left in the selected bucket: it IS the k-th key - its holder publishes the remaining bytes and
-        // the other passes are skipped (costs of one population separate after ~4 of the 8 bytes: 42 -> ~22 us at 16 384)
-        if (sel_unique && byte > 0) {
-            const unsigned long long want = prefix_s, mask = ~0ull << (8 * byte);
+        // Few keys left in the selected bucket (and the rank lies inside it): rank them against each other in
+        // (key, index) order - the need-th one IS the k-th key, and its index the tie cut; the remaining passes are
+        // skipped (costs of one population separate after two 8-bit windows)
+        if (sel_cnt <= KTH_CAND && sel_need <= (long)sel_cnt) {
+            const unsigned long long want = prefix_s, mask = ~0ull << shift;
+            const int n = sel_cnt;
 #pragma unroll
             for (long r = 0; r < rounds; ++r) {
                 const unsigned long long key = key_at(r);
                 if ((r * 1024 + tid < P_all) && (key & mask) == want) {
-                    prefix_s = key;
-                    cut_s = r * 1024 + tid;         // no other particle has this key: it is the last elite one
+                    const int slot = atomicAdd(&ncand, 1);
+                    cand_key[slot] = key;
+                    cand_idx[slot] = r * 1024 + tid;
                 }
+            }
+            __syncthreads();
+            if (tid < n) {
+                const unsigned long long mk = cand_key[tid];
+                const long mi = cand_idx[tid];
+                long rank = 0;
+                for (int u = 0; u < n; ++u) {
+                    const unsigned long long uk = cand_key[u];
+                    rank += (uk < mk) || (uk == mk && cand_idx[u] < mi);
+                }
+                if (rank + 1 == need_s) { prefix_s = mk; cut_s = mi; }
             }
             __syncthreads();
             single = true;
             break;
         }
     }
-    // particles strictly below T, and the index of the need_s-th particle (in index order) equal to T
+    // unless the ranking above has named it: the index of the need_s-th particle (in index order) equal to T
     const unsigned long long T = prefix_s;
     const long room = need_s;
     long seen = 0;
-    unsigned long long c = 0;
-#pragma unroll
-    for (long r = 0; r < rounds; ++r) c += (r * 1024 + tid < P_all) && key_at(r) < T;
-    // ties: the index of the room-th particle (in index order) whose key equals T - two barriers per round, skipped
-    // when the selection has already named the one holder of T
 #pragma unroll
     for (long r = 0; r < (single ? 0 : rounds); ++r) {
         const long j = r * 1024 + tid;
@@ -391,9 +433,49 @@ __global__ __launch_bounds__(1024) void kth_key_kernel(const double* __restrict_
         seen += n;
         __syncthreads();
     }
-    atomicAdd(&less_s, c);
-    __syncthreads();
-    if (tid == 0) { thr[0] = T; thr[1] = less_s; thr[2] = (unsigned long long)(cut_s < 0 ? P_all : cut_s); }
+    if (tid == 0) { thr[0] = T; thr[1] = 0ull; thr[2] = (unsigned long long)(cut_s < 0 ? P_all : cut_s); }
+    // With the keys in registers the elite LIST of the local block [offset, offset + P_local) follows at once (what
+    // elite_list_kernel does from memory for the streamed instantiation): ballots per round, one scan of their counts.
+    if constexpr (NPER > 0) {
+        if (!list) return;
+        __shared__ int lcnt[NPER * 16];
+        const long cut = cut_s < 0 ? P_all : cut_s;
+        const int lane = tid & 63, wave = tid >> 6;
+        unsigned flags = 0u;
+#pragma unroll
+        for (int r = 0; r < NPER; ++r) {
+            const long j = (long)r * 1024 + tid;
+            const bool e = j < P_all && j >= offset && j < offset + P_local && (keys[r] < T || (keys[r] == T && j <= cut));
+            const unsigned long long m = __ballot(e);
+            if (lane == 0) lcnt[r * 16 + wave] = __popcll(m);
+            flags |= e ? (1u << r) : 0u;
+        }
+        __syncthreads();
+        constexpr int n = NPER * 16;            // <= 1024: one entry per thread
+        const int own = tid < n ? lcnt[tid] : 0;
+        int incl = own;
+        for (int o = 1; o < 64; o <<= 1) {
+            const int u = __shfl_up(incl, o);
+            if (lane >= o) incl += u;
+        }
+        __syncthreads();                        // (wtot is reused: the tie walk's last reads are behind this barrier)
+        if (lane == 63) wtot[wave] = incl;
+        __syncthreads();
+        int at = incl - own, total = 0;
+        for (int w = 0; w < 16; ++w) {
+            if (w < wave) at += (int)wtot[w];
+            total += (int)wtot[w];
+        }
+        if (tid < n) lcnt[tid] = at;
+        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < NPER; ++r) {
+            const bool e = (flags >> r) & 1u;
+            const unsigned long long m = __ballot(e);
+            if (e) list[lcnt[r * 16 + wave] + __popcll(m & ((1ull << lane) - 1ull))] = (int)((long)r * 1024 + tid - offset);
+        }
+        if (tid == 0) *count = total;
+    }
 }
 
 // list[0..n) = the local indices of the elite particles in index order, *count = n: the moment kernels below then read
@@ -987,15 +1069,20 @@ hipError_t cem_elite_sums(const T* actions, const double* q_all, long P_all, lon
     const double* qa = q_all ? q_all : w.q0;
     unsigned long long* thr = (unsigned long long*)w.scratch;
     const long Pa = q_all ? P_all : P;
-    if (Pa <= 16 * 1024) hipLaunchKernelGGL(kth_key_kernel<16>, dim3(1), dim3(1024), 0, s, qa, Pa, k, thr);
-    else if (Pa <= 32 * 1024) hipLaunchKernelGGL(kth_key_kernel<32>, dim3(1), dim3(1024), 0, s, qa, Pa, k, thr);
-    else hipLaunchKernelGGL(kth_key_kernel<0>, dim3(1), dim3(1024), 0, s, qa, Pa, k, thr);
     // the local elite rows as a list (index order), then moments over those rows only
     const long kmax = k < P ? (k > 0 ? k : 0) : P;
     const int nbe = kmax > 0 ? nblocks(kmax, CHUNK) : 1;
-    const size_t list_lds = sizeof(int) * 16 * (size_t)((P + 1023) / 1024);
-    if (list_lds > 48 * 1024) return hipErrorInvalidValue;          // (> 786 432 particles on one GPU)
-    hipLaunchKernelGGL(elite_list_kernel, dim3(1), dim3(1024), list_lds, s, w.q0, P, offset, thr, w.elite, elite_count(w));
+    const long off = q_all ? offset : 0;
+    if (Pa <= 16 * 1024) {
+        hipLaunchKernelGGL(kth_key_kernel<16>, dim3(1), dim3(1024), 0, s, qa, Pa, k, thr, off, P, w.elite, elite_count(w));
+    } else if (Pa <= 32 * 1024) {
+        hipLaunchKernelGGL(kth_key_kernel<32>, dim3(1), dim3(1024), 0, s, qa, Pa, k, thr, off, P, w.elite, elite_count(w));
+    } else {
+        const size_t list_lds = sizeof(int) * 16 * (size_t)((P + 1023) / 1024);
+        if (list_lds > 48 * 1024) return hipErrorInvalidValue;          // (> 786 432 particles on one GPU)
+        hipLaunchKernelGGL(kth_key_kernel<0>, dim3(1), dim3(1024), 0, s, qa, Pa, k, thr, 0L, 0L, (int*)nullptr, (int*)nullptr);
+        hipLaunchKernelGGL(elite_list_kernel, dim3(1), dim3(1024), list_lds, s, w.q0, P, off, thr, w.elite, elite_count(w));
+    }
     hipLaunchKernelGGL(elite_rows_sum_kernel<T>, dim3(nbe), dim3(BLK), 0, s, w.elite, elite_count(w), actions, HA, CHUNK,
                        w.partial);
     hipLaunchKernelGGL(ordered_sum_counted_kernel, dim3(nblocks(1 + HA, BLK / 64)), dim3(BLK), 0, s, w.partial,

@@ -368,6 +368,40 @@ def test_cem_elite_selection_with_ties_negative_costs_and_large_populations(P_, 
     np.testing.assert_allclose(c.cov_action, want_cov, rtol=1e-11, atol=1e-12)
 
 
+@pytest.mark.parametrize("case", ["all_equal", "threshold_in_a_large_tie", "everything_elite", "two_values"])
+def test_cem_elite_selection_degenerate_populations(case):
+    """The select kernel's corner paths: every key equal (no byte differs: the passes are skipped and the tie walk names
+    the cut), more ties at the threshold than the direct ranking takes (> 256), k = P, and keys that differ in one
+    low byte only."""
+    from mjmpc_amd.control import CEM
+    rs = np.random.RandomState(11)
+    P_, Hh, Aa = 5000, 4, 3
+    costs = np.zeros((P_, Hh))
+    frac = 0.3
+    if case == "all_equal":
+        costs[:] = 1.25
+    elif case == "threshold_in_a_large_tie":
+        costs[:, 0] = np.where(rs.rand(P_) < 0.6, 0.0, rs.randn(P_) ** 2 + 0.5)       # 60 % exact zeros, k = 30 %
+    elif case == "everything_elite":
+        costs = rs.randn(P_, Hh)
+        frac = 1.0
+    else:
+        costs[:, 0] = np.where(rs.rand(P_) < 0.5, 1.0, np.nextafter(1.0, 2.0))
+    mean0 = 0.2 * rs.randn(Hh, Aa)
+    actions = mean0[None] + rs.randn(P_, Hh, Aa)
+    c = CEM(init_cov=1.0, base_action="null", elite_frac=frac, step_size=1.0, gamma=1.0, beta=0.0, cov_type="full",
+            d_state=5, d_obs=6, d_action=Aa, horizon=Hh, num_particles=P_, n_iters=1, action_lows=-np.ones(Aa),
+            action_highs=np.ones(Aa), seed=1)
+    c.mean_action = mean0.copy()
+    c._update_distribution(dict(costs=costs, actions=actions))
+    k = int(P_ * frac)
+    q0 = costs[:, ::-1].cumsum(axis=1)[:, -1]
+    ids = np.argsort(q0, kind="stable")[:k]
+    d = (actions - mean0[None])[ids].reshape(Hh * k, Aa)
+    np.testing.assert_allclose(c.mean_action, actions[ids].mean(axis=0), rtol=1e-11, atol=1e-12)
+    np.testing.assert_allclose(c.cov_action, np.cov(d, rowvar=False), rtol=1e-11, atol=1e-12)
+
+
 def test_mppiq_returns_update_and_value(golden):
     """MPPIQ (mppiq.py:73-165) against the reference's outputs: TD(lambda) returns kernel, update, value."""
     from mjmpc_amd.control import MPPIQ
