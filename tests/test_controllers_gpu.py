@@ -587,3 +587,40 @@ def test_diverged_rollouts_do_not_poison_the_update():
     want_mean = 0.2 * mean0 + 0.8 * actions[ids].mean(0)
     assert np.isfinite(dev2.mean.cpu().numpy()).all()
     np.testing.assert_allclose(dev2.mean.cpu().numpy(), want_mean, rtol=0, atol=1e-12)
+
+
+@pytest.mark.parametrize("mode,grow", [(0, None), (1, "diag"), (1, "identity"), (0, "diag")])
+def test_step_tail_is_action_shift_counter_and_covariance_growth(mode, grow):
+    """``mjmpc_step_tail`` = the end of a device-resident control step in one launch: action <- mean[0] (device copy
+    and pinned host copy), the shift of olgaussian_mpc.py:116-129, num_steps + 1, and the covariance growth of
+    cem.py:94 / gaussian_dmd.py:111 - against the separate entries and numpy."""
+    import torch
+    from mjmpc_amd.control._device import DeviceUpdater
+    rs = np.random.RandomState(5)
+    Hn, An = 9, 5
+    mean, cov, diag = rs.randn(Hn, An), np.cov(rs.randn(40, An), rowvar=False), rs.rand(An) + 0.1
+    dev = DeviceUpdater(Hn, An, np.ones(Hn))
+    dev.set_mean(mean)
+    dev.set_cov(cov)
+    act = torch.zeros(An, dtype=torch.float64, device="cuda")
+    pin = torch.zeros(2 * (An + 1), dtype=torch.float64).pin_memory()
+    step = torch.full((1,), 41, dtype=torch.int64, device="cuda")
+    args = None if grow is None else ((diag if grow == "diag" else None), 0.3)
+    dev.step_tail(mode, act, pin, step, args)
+    torch.cuda.synchronize()
+    want = np.vstack([mean[1:], np.zeros(An) if mode == 0 else mean[-1]])
+    want_cov = cov if grow is None else cov + 0.3 * np.diag(diag if grow == "diag" else np.ones(An))
+    np.testing.assert_array_equal(act.cpu().numpy(), mean[0])
+    np.testing.assert_array_equal(pin[:An].numpy(), mean[0])
+    np.testing.assert_array_equal(dev.get_mean(), want)
+    np.testing.assert_allclose(dev.get_cov(), want_cov, rtol=0, atol=1e-15)
+    assert int(step.item()) == 42
+    # the separate entries leave the same mean and covariance behind
+    dev2 = DeviceUpdater(Hn, An, np.ones(Hn))
+    dev2.set_mean(mean)
+    dev2.set_cov(cov)
+    dev2.shift(mode)
+    if args is not None:
+        dev2.add_cov_diag(*args)
+    np.testing.assert_array_equal(dev2.get_mean(), dev.get_mean())
+    np.testing.assert_array_equal(dev2.get_cov(), dev.get_cov())
