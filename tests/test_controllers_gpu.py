@@ -624,3 +624,28 @@ def test_step_tail_is_action_shift_counter_and_covariance_growth(mode, grow):
         dev2.add_cov_diag(*args)
     np.testing.assert_array_equal(dev2.get_mean(), dev.get_mean())
     np.testing.assert_array_equal(dev2.get_cov(), dev.get_cov())
+
+
+@pytest.mark.parametrize("P_,Hh,Aa,frac,cov_type", [(1000, 64, 24, 0.1, "full"), (300, 3, 40, 0.5, "full"),
+                                                     (5000, 50, 7, 0.1, "full"), (777, 5, 2, 0.3, "diagonal"),
+                                                     (4096, 32, 7, 0.02, "full"), (130, 7, 1, 0.9, "full")])
+def test_cem_moments_over_the_elite_list_at_other_shapes(P_, Hh, Aa, frac, cov_type):
+    """The elite-row moment kernels choose their layout by shape: the LDS-staged scatter when 16 x H x A deltas fit, the
+    sliced one otherwise (wide actions, long horizons, A x A larger than a workgroup) - every branch against numpy."""
+    from mjmpc_amd.control import CEM
+    rs = np.random.RandomState(P_ + Aa)
+    costs = rs.rand(P_, Hh)
+    mean0 = 0.2 * rs.randn(Hh, Aa)
+    actions = mean0[None] + rs.randn(P_, Hh, Aa)
+    c = CEM(init_cov=1.0, base_action="null", elite_frac=frac, step_size=0.7, gamma=1.0, beta=0.0, cov_type=cov_type,
+            d_state=5, d_obs=6, d_action=Aa, horizon=Hh, num_particles=P_, n_iters=1, action_lows=-np.ones(Aa),
+            action_highs=np.ones(Aa), seed=1)
+    c.mean_action = mean0.copy()
+    c._update_distribution(dict(costs=costs, actions=actions))
+    k = int(P_ * frac)
+    q0 = costs[:, ::-1].cumsum(axis=1)[:, -1]
+    ids = np.argsort(q0, kind="stable")[:k]
+    d = (actions - mean0[None])[ids].reshape(Hh * k, Aa)
+    upd = np.atleast_2d(np.cov(d, rowvar=False)) if cov_type == "full" else np.diag(np.var(d, axis=0))
+    np.testing.assert_allclose(c.mean_action, 0.3 * mean0 + 0.7 * actions[ids].mean(axis=0), rtol=1e-11, atol=1e-12)
+    np.testing.assert_allclose(c.cov_action, 0.3 * np.eye(Aa) + 0.7 * upd, rtol=1e-10, atol=1e-12)
