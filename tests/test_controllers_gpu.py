@@ -649,3 +649,26 @@ def test_cem_moments_over_the_elite_list_at_other_shapes(P_, Hh, Aa, frac, cov_t
     upd = np.atleast_2d(np.cov(d, rowvar=False)) if cov_type == "full" else np.diag(np.var(d, axis=0))
     np.testing.assert_allclose(c.mean_action, 0.3 * mean0 + 0.7 * actions[ids].mean(axis=0), rtol=1e-11, atol=1e-12)
     np.testing.assert_allclose(c.cov_action, 0.3 * np.eye(Aa) + 0.7 * upd, rtol=1e-10, atol=1e-12)
+
+
+@pytest.mark.parametrize("dtype", ["f64", "f32"])
+def test_full_covariance_sampler_staged_and_direct_stores_agree(dtype):
+    """``noise_full_kernel`` writes through an LDS tile when H is a multiple of 4 and directly otherwise: the draws are
+    keyed by (particle, channel, t // 4), so the first steps of an H = 8 and an H = 7 draw are the same numbers; a
+    population that leaves the last workgroup partly idle; and the diagonal-covariance kernel draws them too."""
+    from mjmpc_amd.control._device import DeviceUpdater
+    An, Pn = 5, 37
+    rs = np.random.RandomState(2)
+    B = rs.randn(An, An)
+    cov = B @ B.T + 0.5 * np.eye(An)
+    x8 = DeviceUpdater(8, An, np.ones(8)).sample_noise(Pn, cov, [1.0, 0.0, 0.0], 9, 3, dtype=dtype).cpu().numpy()
+    x7 = DeviceUpdater(7, An, np.ones(7)).sample_noise(Pn, cov, [1.0, 0.0, 0.0], 9, 3, dtype=dtype).cpu().numpy()
+    assert np.isfinite(x8).all() and np.abs(x8).max() > 1.0
+    np.testing.assert_array_equal(x8[:, :7], x7)
+    # an isotropic covariance through the full-covariance kernel = the diagonal kernel's draws (same Philox keys)
+    iso = 0.49 * np.eye(An)
+    near = iso.copy()
+    near[0, 1] = near[1, 0] = 1e-300                        # off-diagonal entry: takes the full-covariance kernel
+    d8 = DeviceUpdater(8, An, np.ones(8)).sample_noise(Pn, iso, [1.0, 0.0, 0.0], 9, 3, dtype=dtype).cpu().numpy()
+    f8 = DeviceUpdater(8, An, np.ones(8)).sample_noise(Pn, near, [1.0, 0.0, 0.0], 9, 3, dtype=dtype).cpu().numpy()
+    np.testing.assert_allclose(f8, d8, rtol=1e-6 if dtype == "f32" else 1e-14, atol=0)
