@@ -1253,18 +1253,26 @@ __global__ __launch_bounds__(DUO ? 128 : 64) __attribute__((amdgpu_waves_per_eu(
     // sampler kernel (noise.hip) would have used for it: one block yields the normals of steps 4k ... 4k + 3
     const bool sampled = MONO && has_u && live;
     float z_keep[3] = {0.0f, 0.0f, 0.0f};
-    // (only three normals live across env steps; the sampler's parameters are re-read - scalar loads, cache hits - by the
-    // draw of every fourth step instead of occupying registers throughout the rollout)
+    // (three normals live across env steps.  The sampler's parameters are read ONCE: a draw sits between E2 and E3 of a
+    // substep, in the DYN wave's slack, and a global load per env step - even a cache hit - outlasted that slack:
+    // hoisting them costs 16 AGPRs and 1.5 us less per launch)
+    double chol_h = 0.0;
+    unsigned long long seed_h = 0ull, off_h = 0ull, key_h = 0ull;
+    if constexpr (MONO) {
+        if (sampled) chol_h = mop->chol[l8 * A + l8];
+        seed_h = mop->seed;
+        off_h = mop->offset + (mop->d_step ? (unsigned long long)*mop->d_step : 0ull);
+        key_h = (unsigned long long)((pid + mop->particle_offset) * A + l8);
+    }
     auto draw = [&](int t) -> T {
-#ifdef MONO_NO_DRAW                 // developer A/B builds (tools/mono_time.py)
+#ifdef MONO_NO_DRAW                 // developer A/B builds (tools/mono_time.py; NB: constant actions change the physics too)
         return T(0.25);
 #endif
-        const double chol_aa = mop->chol[l8 * A + l8];
+        const double chol_aa = chol_h;
         float z;
         if (!(t & 3)) {
-            const unsigned long long off = mop->offset + (mop->d_step ? (unsigned long long)*mop->d_step : 0ull);
             float q4[4];
-            normal_quad(mop->seed, off, (unsigned long long)((pid + mop->particle_offset) * A + l8), (unsigned)(t >> 2), q4);
+            normal_quad(seed_h, off_h, key_h, (unsigned)(t >> 2), q4);
             z = q4[0];
             z_keep[0] = q4[1];
             z_keep[1] = q4[2];
