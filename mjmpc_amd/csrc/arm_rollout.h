@@ -53,15 +53,14 @@ template <typename T>
 hipError_t launch_arm_rollout(const T* model, const double* state, long P, int H, int A, const double* mean,
                               const T* noise, T* cost, T* act, T* obs, T* nobs, double* state_out,
                               unsigned* diag, hipStream_t stream, RolloutFusion fuse = RolloutFusion(),
-                              const MonoStep* mono = nullptr, const MonoStep* mono_dev = nullptr);
-// (mono: host copy, checked by the launcher; mono_dev: the same structure in device memory, read by the kernels - written
-// there by upload_mono_params, a one-thread kernel, so that it is stream-ordered and capturable)
-hipError_t upload_mono_params(const MonoStep& mo, MonoStep* dst, hipStream_t stream);
+                              const MonoStep* mono = nullptr);
+// (mono: the fused iteration's parameters; the kernels take the structure BY VALUE - a kernel argument arrives with the
+// launch, where a block in device memory cost every workgroup a dependent round trip before its first useful load)
 // the finish launch: records [n_rec][2 + H A] -> mean_out (mean_in is only read; the two must not alias), action, step
 // counter, env step (env_step != 0); or, with mono->record, this GPU's record
 template <typename T>
 hipError_t launch_arm_mppi_finish(const T* model, const double* records, long n_rec, int H, int A, const double* mean_in,
-                                  double* mean_out, const MonoStep* mono_dev, int env_step, unsigned* diag, hipStream_t stream);
+                                  double* mean_out, const MonoStep& mono, int env_step, unsigned* diag, hipStream_t stream);
 // workgroups the launch of P particles uses (the reduction tree is sized by it)
 long arm_rollout_groups(long P);
 

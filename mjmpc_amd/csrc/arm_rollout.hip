@@ -1014,19 +1014,18 @@ __device__ __forceinline__ void mono_record(double lam, double* __restrict__ rec
 // Workgroup 0's row is the action: it publishes it (device copy, mapped pinned host slot + completion flag), advances
 // the step counter and then steps the device-resident real env with its two wavefronts in the DYN / SOLVE roles of the
 // rollout; what that step needs from global memory (model block, state) is fetched at the top of the kernel, under the
-// latency of the record loads.  Sharded runs (mop->record): the rows of this GPU's record {max, S, W} instead.
+// latency of the record loads.  Sharded runs (mo.record): the rows of this GPU's record {max, S, W} instead.
 constexpr int MAX_A = 8;
 constexpr int FIN_CHUNK = 4;        // records per thread in flight
 template <typename T>
 __global__ __launch_bounds__(128) void arm_mppi_finish_kernel(const T* __restrict__ model, const double* __restrict__ recs, long n_rec,
                                                               int H, int A, const double* __restrict__ mean_in,
-                                                              double* __restrict__ mean_out, const MonoStep* __restrict__ mop,
+                                                              double* __restrict__ mean_out, const MonoStep mo,
                                                               int env_step, unsigned* diag) {
     __shared__ __attribute__((aligned(16))) T lds[LANES * PSTRIDE + ARM_BLOB_LEN + 3];
     __shared__ double sh[2 * (2 + MAX_A)];
     const int tid = threadIdx.x, t = blockIdx.x, HA = H * A, rec = 2 + HA;
     const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const MonoStep mo = *mop;
     const bool stepper = t == 0 && env_step && mo.state_io && !mo.record;
     // ---- loads first: the records of my first chunk, my mean row, and - the workgroup that steps the env - model and state
     double rm[FIN_CHUNK], rs[FIN_CHUNK], rw[FIN_CHUNK][MAX_A];
@@ -1172,7 +1171,8 @@ __global__ __launch_bounds__(DUO ? 128 : 64) __attribute__((amdgpu_waves_per_eu(
                                                          const T* __restrict__ noise, T* __restrict__ cost,
                                                          T* __restrict__ act, T* __restrict__ obs,
                                                          T* __restrict__ nobs, double* state_out, unsigned* diag,
-                                                         RolloutFusion fuse, const MonoStep* __restrict__ mop) {
+                                                         RolloutFusion fuse, const MonoStep mono_arg) {
+    const MonoStep* mop = &mono_arg;      // (a kernel argument: its fields arrive with the other arguments, no pointer chase)
     __shared__ __attribute__((aligned(16))) T lds[LANES * PSTRIDE + ARM_BLOB_LEN + 3];
     extern __shared__ __attribute__((aligned(16))) double dyn_lds[];     // MONO: scratch [MONO_RED] | action tile T[8][H A]
     static_assert(!(DUO && CL), "the closed-loop-linear variant runs one wave per particle group");
@@ -1392,35 +1392,27 @@ __global__ __launch_bounds__(DUO ? 128 : 64) __attribute__((amdgpu_waves_per_eu(
 
 }  // namespace
 
-namespace {
-__global__ void mono_params_kernel(MonoStep mo, MonoStep* dst) { *dst = mo; }
-}  // namespace
-hipError_t upload_mono_params(const MonoStep& mo, MonoStep* dst, hipStream_t stream) {
-    hipLaunchKernelGGL(mono_params_kernel, dim3(1), dim3(1), 0, stream, mo, dst);
-    return hipGetLastError();
-}
-
 long arm_rollout_groups(long P) { return (P + LANES - 1) / LANES; }
 long mono_record_doubles(long groups, int H, int A) { return groups * (2 + (long)H * A); }
 
 template <typename T>
 hipError_t launch_arm_mppi_finish(const T* model, const double* records, long n_rec, int H, int A, const double* mean_in,
-                                  double* mean_out, const MonoStep* mono_dev, int env_step, unsigned* diag, hipStream_t stream) {
+                                  double* mean_out, const MonoStep& mono, int env_step, unsigned* diag, hipStream_t stream) {
     if (A > MAX_A || H < 1 || n_rec < 1) return hipErrorInvalidValue;
     hipLaunchKernelGGL(arm_mppi_finish_kernel<T>, dim3((unsigned)H), dim3(128), 0, stream, model, records, n_rec, H, A, mean_in,
-                       mean_out, mono_dev, env_step, diag);
+                       mean_out, mono, env_step, diag);
     return hipGetLastError();
 }
 template hipError_t launch_arm_mppi_finish<float>(const float*, const double*, long, int, int, const double*, double*,
-                                                  const MonoStep*, int, unsigned*, hipStream_t);
+                                                  const MonoStep&, int, unsigned*, hipStream_t);
 template hipError_t launch_arm_mppi_finish<double>(const double*, const double*, long, int, int, const double*, double*,
-                                                   const MonoStep*, int, unsigned*, hipStream_t);
+                                                   const MonoStep&, int, unsigned*, hipStream_t);
 
 template <typename T>
 hipError_t launch_arm_rollout(const T* model, const double* state, long P, int H, int A, const double* mean,
                               const T* noise, T* cost, T* act, T* obs, T* nobs, double* state_out,
-                              unsigned* diag, hipStream_t stream, RolloutFusion fuse, const MonoStep* mono,
-                              const MonoStep* mono_dev) {
+                              unsigned* diag, hipStream_t stream, RolloutFusion fuse,
+                              const MonoStep* mono) {
     if (P <= 0 || H <= 0) return hipSuccess;
     const unsigned grid = (unsigned)((P + LANES - 1) / LANES);
     // Cap the resident waves per SIMD at what this launch needs (2, or - f32 only, f64 does not fit - 3): the
@@ -1441,10 +1433,11 @@ hipError_t launch_arm_rollout(const T* model, const double* state, long P, int H
     // some SIMDs while others idle (8192 particles: 361 us per launch in the loop against 280 us back to back)
     static const int one_env = [] { const char* e = getenv("MJMPC_ARM_ONE"); return e ? atoi(e) : -1; }();
     const bool one_per_simd = !duo && !fuse.clw && (one_env >= 0 ? one_env != 0 : (long)grid <= simds);
+    const MonoStep mono_arg = mono ? *mono : MonoStep();
     const size_t dyn = mono ? sizeof(double) * MONO_RED + sizeof(T) * LANES * (size_t)H * A : 0;
 #define MJMPC_LAUNCH_W(STEP_, CL_, W_, DUO_, MONO_)                                                                   \
     hipLaunchKernelGGL((arm_rollout_kernel<T, STEP_, CL_, W_, DUO_, MONO_>), dim3(grid), dim3(DUO_ ? 128 : 64), dyn,  \
-                       stream, model, state, P, H, A, mean, noise, cost, act, obs, nobs, state_out, diag, fuse, mono_dev)
+                       stream, model, state, P, H, A, mean, noise, cost, act, obs, nobs, state_out, diag, fuse, mono_arg)
 #define MJMPC_LAUNCH(STEP_, CL_, MONO_)                                 \
     do {                                                                \
         if (one_per_simd) {                                             \
@@ -1457,7 +1450,7 @@ hipError_t launch_arm_rollout(const T* model, const double* state, long P, int H
         }                                                               \
     } while (0)
     if (mono) {
-        if (fuse.clw || state_out || obs || nobs || !fuse.gseq || !mono->chol || !mono->tree || !mono_dev)
+        if (fuse.clw || state_out || obs || nobs || !fuse.gseq || !mono->chol || !mono->tree)
             return hipErrorInvalidValue;
         if (dyn + sizeof(T) * (LANES * PSTRIDE + ARM_BLOB_LEN + 3) > 64 * 1024) return hipErrorInvalidValue;     // H A too large for the LDS tile
         if (duo) MJMPC_LAUNCH_W(false, false, 1, true, true);
@@ -1475,9 +1468,9 @@ hipError_t launch_arm_rollout(const T* model, const double* state, long P, int H
 
 template hipError_t launch_arm_rollout<float>(const float*, const double*, long, int, int, const double*,
                                               const float*, float*, float*, float*, float*, double*, unsigned*,
-                                              hipStream_t, RolloutFusion, const MonoStep*, const MonoStep*);
+                                              hipStream_t, RolloutFusion, const MonoStep*);
 template hipError_t launch_arm_rollout<double>(const double*, const double*, long, int, int, const double*,
                                                const double*, double*, double*, double*, double*, double*, unsigned*,
-                                               hipStream_t, RolloutFusion, const MonoStep*, const MonoStep*);
+                                               hipStream_t, RolloutFusion, const MonoStep*);
 
 }  // namespace mjmpc

@@ -63,12 +63,6 @@ struct mjmpc_arm_s {
     double* mono_tree = nullptr;
     long mono_groups = 0;
     int mono_H = 0;
-    mjmpc::MonoStep* mono_dev = nullptr;
-    mjmpc::MonoStep mono_cached;
-    bool mono_valid = false;
-    mjmpc::MonoStep* comb_dev = nullptr;        // parameter block of mjmpc_arm_mppi_combine (sharded runs)
-    mjmpc::MonoStep comb_cached;
-    bool comb_valid = false;
 };
 
 struct mjmpc_tree_s {
@@ -209,8 +203,6 @@ int mjmpc_arm_destroy(mjmpc_arm_t h) {
     hipFree(h->diag);
     hipFree(h->shard_states);
     hipFree(h->mono_tree);
-    hipFree(h->mono_dev);
-    hipFree(h->comb_dev);
     hipHostFree(h->pinned);
     for (int k = 0; k < 4; ++k) if (h->staged[k]) hipEventDestroy(h->staged[k]);
     delete h;
@@ -350,11 +342,8 @@ int mjmpc_arm_mppi_step(mjmpc_arm_t h, int dtype, int64_t P, int H, const double
         HIP_TRY(hipMalloc(&h->mono_tree, sizeof(double) * mjmpc::mono_record_doubles(groups, H, h->nu)));
         h->mono_groups = groups;
         h->mono_H = H;
-        h->mono_valid = false;
     }
-    if (!h->mono_dev) HIP_TRY(hipMalloc(&h->mono_dev, sizeof(mjmpc::MonoStep)));
-    mjmpc::MonoStep mo;
-    std::memset(&mo, 0, sizeof(mo));            // (padding too: the block is compared bytewise below)
+    mjmpc::MonoStep mo;             // (travels to both kernels by value, as a kernel argument)
     mo.chol = d_chol;
     mo.seed = seed;
     mo.offset = offset;
@@ -371,11 +360,6 @@ int mjmpc_arm_mppi_step(mjmpc_arm_t h, int dtype, int64_t P, int H, const double
     mo.state_io = h->state;
     mo.step_cost = d_step_cost;
     mo.step_nobs = d_step_next_obs;
-    if (!h->mono_valid || std::memcmp(&mo, &h->mono_cached, sizeof(mo)) != 0) {
-        HIP_TRY(mjmpc::upload_mono_params(mo, h->mono_dev, s));         // stream-ordered, before the launches that read it
-        h->mono_cached = mo;
-        h->mono_valid = true;
-    }
     const int do_env = (env_step && !d_record) ? 1 : 0;
     mjmpc::RolloutFusion fuse;
     fuse.filt = d_filter_coeffs;
@@ -384,15 +368,15 @@ int mjmpc_arm_mppi_step(mjmpc_arm_t h, int dtype, int64_t P, int H, const double
     hipError_t e;
     if (dtype == MJMPC_F32) {
         e = mjmpc::launch_arm_rollout<float>(h->model_f32, h->state, (long)P, H, h->nu, d_mean, nullptr, (float*)d_costs,
-                                             (float*)d_actions, nullptr, nullptr, nullptr, h->diag, s, fuse, &mo, h->mono_dev);
+                                             (float*)d_actions, nullptr, nullptr, nullptr, h->diag, s, fuse, &mo);
         if (e == hipSuccess && !rollout_only)
-            e = mjmpc::launch_arm_mppi_finish<float>(h->model_f32, h->mono_tree, groups, H, h->nu, d_mean, d_mean_out, h->mono_dev,
+            e = mjmpc::launch_arm_mppi_finish<float>(h->model_f32, h->mono_tree, groups, H, h->nu, d_mean, d_mean_out, mo,
                                                      do_env, h->diag, s);
     } else if (dtype == MJMPC_F64) {
         e = mjmpc::launch_arm_rollout<double>(h->model_f64, h->state, (long)P, H, h->nu, d_mean, nullptr, (double*)d_costs,
-                                              (double*)d_actions, nullptr, nullptr, nullptr, h->diag, s, fuse, &mo, h->mono_dev);
+                                              (double*)d_actions, nullptr, nullptr, nullptr, h->diag, s, fuse, &mo);
         if (e == hipSuccess && !rollout_only)
-            e = mjmpc::launch_arm_mppi_finish<double>(h->model_f64, h->mono_tree, groups, H, h->nu, d_mean, d_mean_out, h->mono_dev,
+            e = mjmpc::launch_arm_mppi_finish<double>(h->model_f64, h->mono_tree, groups, H, h->nu, d_mean, d_mean_out, mo,
                                                       do_env, h->diag, s);
     } else {
         return fail(MJMPC_E_BADARG, "unknown dtype %d", dtype);
@@ -411,9 +395,7 @@ int mjmpc_arm_mppi_combine(mjmpc_arm_t h, int dtype, const double* d_records, in
         return fail(MJMPC_E_BADARG, "the fused env step runs one model and one state (no per-shard blocks)");
     HIP_TRY(hipSetDevice(h->device));
     hipStream_t s = (hipStream_t)stream;
-    if (!h->comb_dev) HIP_TRY(hipMalloc(&h->comb_dev, sizeof(mjmpc::MonoStep)));
     mjmpc::MonoStep mo;
-    std::memset(&mo, 0, sizeof(mo));
     mo.step_size = step_size;
     mo.shift_mode = shift_mode;
     mo.action_out = d_action_out;
@@ -422,17 +404,12 @@ int mjmpc_arm_mppi_combine(mjmpc_arm_t h, int dtype, const double* d_records, in
     mo.state_io = h->state;
     mo.step_cost = d_step_cost;
     mo.step_nobs = d_step_next_obs;
-    if (!h->comb_valid || std::memcmp(&mo, &h->comb_cached, sizeof(mo)) != 0) {
-        HIP_TRY(mjmpc::upload_mono_params(mo, h->comb_dev, s));
-        h->comb_cached = mo;
-        h->comb_valid = true;
-    }
     hipError_t e;
     if (dtype == MJMPC_F32)
-        e = mjmpc::launch_arm_mppi_finish<float>(h->model_f32, d_records, n_records, H, h->nu, d_mean, d_mean_out, h->comb_dev,
+        e = mjmpc::launch_arm_mppi_finish<float>(h->model_f32, d_records, n_records, H, h->nu, d_mean, d_mean_out, mo,
                                                  env_step ? 1 : 0, h->diag, s);
     else if (dtype == MJMPC_F64)
-        e = mjmpc::launch_arm_mppi_finish<double>(h->model_f64, d_records, n_records, H, h->nu, d_mean, d_mean_out, h->comb_dev,
+        e = mjmpc::launch_arm_mppi_finish<double>(h->model_f64, d_records, n_records, H, h->nu, d_mean, d_mean_out, mo,
                                                   env_step ? 1 : 0, h->diag, s);
     else
         return fail(MJMPC_E_BADARG, "unknown dtype %d", dtype);
