@@ -998,8 +998,22 @@ __global__ __launch_bounds__(64 * wg_waves(DP, FRIC, sizeof(T), PL), min_waves(s
     TreeClock clk;
     clk.start(diag, blockIdx.x == 0 && threadIdx.x == 0);
 
+    // the inputs of step t + 1 are fetched while step t computes: consumed where they are loaded, every env step would
+    // begin with a trip to HBM for the particle's sample that a wave alone on its SIMD cannot hide
+    T eps_next = T(0);
+    double mean_next = 0.0;
+    if (has_u && H > 0) {
+        if (!clw) mean_next = mean[l];
+        if (noise && live) eps_next = noise[(pid * H) * A + l];
+    }
     for (int t = 0; t < H; ++t) {
         T u = T(0);
+        const T eps_cur = eps_next;
+        const double mean_cur = mean_next;
+        if (has_u && t + 1 < H) {
+            if (!clw) mean_next = mean[(t + 1) * A + l];
+            if (noise && live) eps_next = noise[(pid * H + t + 1) * A + l];
+        }
         if (clw) {
             // mean_act = W' [obs; 1] with the observation this step starts from (gym_env_wrapper.py:135-136): every
             // lane weighs the entries it holds, one 32-lane sum per action
@@ -1016,10 +1030,10 @@ __global__ __launch_bounds__(64 * wg_waves(DP, FRIC, sizeof(T), PL), min_waves(s
                 if (l == a) u = sa;
             }
         } else if (has_u) {
-            u = (T)mean[t * A + l];
+            u = (T)mean_cur;
         }
         if (has_u) {
-            if (noise && live) u += noise[(pid * H + t) * A + l];
+            if (noise && live) u += eps_cur;
             if (act && live) act[(pid * H + t) * A + l] = u;        // unclipped (gym_env_wrapper.py:151)
         }
         // lane a holds action a; the dof it drives picks it up (motors may sit on any subset of the joints)
