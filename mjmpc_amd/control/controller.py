@@ -336,9 +336,10 @@ class OLGaussianMPC(Controller):
     def _q0_kw(self, n_loc):
         """``q0_out=`` for fused rollouts that take it: the launch writes the cost-to-go where the update reads it."""
         fused = self._rollout_fn.fused
-        if "q0_out" not in inspect.signature(fused).parameters:
-            return {}
-        return dict(q0_out=self.dev.q0_destination(n_loc))
+        cached = getattr(self, "_q0_kw_for", None)
+        if cached is None or cached[0] is not fused:            # (inspect.signature costs tens of microseconds)
+            cached = self._q0_kw_for = (fused, "q0_out" in inspect.signature(fused).parameters)
+        return dict(q0_out=self.dev.q0_destination(n_loc)) if cached[1] else {}
 
     def _shift_cov_args(self):
         """(diag or None = identity, scale) of the covariance growth after the shift (cem.py:94, gaussian_dmd.py:111);
@@ -405,7 +406,7 @@ class OLGaussianMPC(Controller):
 
     def _noise_ahead(self):
         """Captured fused iterations with the Philox sampler draw the next step's samples inside the update."""
-        return self._graph_on and self.noise_mode == 'device' and self._fused_capable() and not self._mono
+        return (not self._mono) and self._graph_on and self.noise_mode == 'device' and self._fused_capable()
 
     def _mono_capable(self):
         """The whole iteration in one launch (``rollout_fn.mono``): the fused MPPI / DMD-MPC update, the Philox sampler,
@@ -423,8 +424,7 @@ class OLGaussianMPC(Controller):
 
     def _device_iteration(self):
         """The control iteration without any host synchronisation (capturable)."""
-        n_loc = self.local_particles
-        if self._mono:
+        if self._mono:              # (first: this branch is the host leg of the headline's control step)
             key = id(self.dev.mean)
             self._mono_launch[key]()
             if self.dev.comm.world_size > 1:
@@ -435,6 +435,7 @@ class OLGaussianMPC(Controller):
             if self._graph_post is not None and not self._mono_steps_env:
                 self._graph_post(self._action_dev)
             return
+        n_loc = self.local_particles
         if self._fused_capable():
             # noise (raw) -> rollout (filters the noise, emits the cost-to-go) -> update + action + shift
             coeffs = self.dev.record("coeffs", 3)
@@ -492,7 +493,7 @@ class OLGaussianMPC(Controller):
     def _optimize_graphed(self, state):
         torch = self.dev.torch
         self._sync_in()
-        self._set_sim_state_fn(copy.deepcopy(state))
+        self._set_sim_state_fn(copy.deepcopy(state) if state is not None else None)
         if self._graph is None:
             self._mono = self._mono_capable()           # (decided once per capture: the test reads host arrays)
             self._step_dev = torch.full((1,), self.num_steps, dtype=torch.int64, device=self.dev.device)
