@@ -469,7 +469,16 @@ struct Stamps {
 #ifdef MJMPC_STAMPS
     long long last, acc[16];
     __device__ __forceinline__ void begin() { for (int k = 0; k < 16; ++k) acc[k] = 0; last = clock64(); }
+    // -DMJMPC_STAMPS_MASK=0x..: only the marks whose bit is set read the clock (e.g. 0x1c = the two sides of E1 alone: the
+    // full set of marks costs ~500 cycles per substep, more than the waits it is meant to measure)
+#ifdef MJMPC_STAMPS_MASK
+    __device__ __forceinline__ void mark(int k) {
+        if (!((MJMPC_STAMPS_MASK >> k) & 1)) return;
+        const long long t = clock64(); acc[k] += t - last; last = t;
+    }
+#else
     __device__ __forceinline__ void mark(int k) { const long long t = clock64(); acc[k] += t - last; last = t; }
+#endif
     __device__ __forceinline__ void flush(unsigned* diag, int wave, int lane) {
         if (diag && blockIdx.x == 0 && lane == 0)
             for (int k = 0; k < 16; ++k) ((unsigned long long*)diag)[2 + 16 * wave + k] = (unsigned long long)acc[k];

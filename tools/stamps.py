@@ -14,7 +14,7 @@ CSRC = os.path.join(ROOT, "mjmpc_amd", "csrc")
 def build():
     os.makedirs(os.path.dirname(LIB), exist_ok=True)
     cmd = ["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wno-unused-value",
-           "-DMJMPC_STAMPS", "-I", CSRC] + sorted(glob.glob(os.path.join(CSRC, "*.hip"))) + ["-o", LIB]
+           "-DMJMPC_STAMPS", "-I", CSRC] + [a for a in sys.argv[1:] if a.startswith("-D")] + sorted(glob.glob(os.path.join(CSRC, "*.hip"))) + ["-o", LIB]
     subprocess.check_call(cmd)
 
 
