@@ -26,8 +26,12 @@ FLAGS = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-Wno-unused-va
 # flags last.
 PER_SOURCE_FLAGS = {"tree_rollout_dense.hip": [["-mllvm", "-amdgpu-sched-strategy=iterative-maxocc"],
                                                ["-mllvm", "-amdgpu-sched-strategy=iterative-ilp"]],
-                    # the arm kernel: 1 % (f64 control step 0.2000 -> 0.1980 ms, three A/B pairs on one box; f32 2 %)
-                    "arm_rollout.hip": [["-mllvm", "-amdgpu-sched-strategy=iterative-maxocc"]]}
+                    # the arm kernel: 1 % (f64 control step 0.2000 -> 0.1980 ms, three A/B pairs on one box; f32 2 %) with
+                    # iterative-maxocc; iterative-ilp another 1 % on the fused iteration's kernel and 3 % in f32 (two A/B
+                    # pairs: f64 control step 0.1957 -> 0.1935 ms, pipelined 0.1910 -> 0.1883; the plain two-wave launch
+                    # +0.5 %, one-wave launches unchanged; max-ilp as maxocc, iterative-minreg / max-memory-clause slower)
+                    "arm_rollout.hip": [["-mllvm", "-amdgpu-sched-strategy=iterative-ilp"],
+                                        ["-mllvm", "-amdgpu-sched-strategy=iterative-maxocc"]]}
 
 
 def flags_for(src, alternative=0):
