@@ -20,12 +20,16 @@ FLAGS = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-Wno-unused-va
 # The tree kernel's 16-lane dense instantiations (tree_rollout_dense.hip) run ONE wave per SIMD through long straight-line
 # phases: LLVM's iterative schedulers interleave their independent dependency chains better than the default strategy -
 # measured on MI355X: HalfCheetah 4096 x 32 f64 3.55 -> 3.12 ms, Swimmer 1.50 -> 1.33 ms, f32 32768 x 32 13.2 -> 12.4 ms
-# (iterative-ilp and iterative-maxocc alike).  The 32-lane instantiations do not gain and keep the default; the arm kernel
+# (iterative-ilp and iterative-maxocc alike).  The 32-lane instantiations gain a per cent or two (below); the arm kernel
 # (hand-placed scheduling barriers between its phases) gains a per cent.  These schedulers crash this compiler on SOME variants of the kernel
 # (which ones changes with unrelated edits), so a source lists alternatives: the first that compiles is used, the plain
 # flags last.
 PER_SOURCE_FLAGS = {"tree_rollout_dense.hip": [["-mllvm", "-amdgpu-sched-strategy=iterative-maxocc"],
                                                ["-mllvm", "-amdgpu-sched-strategy=iterative-ilp"]],
+                    # the 32-lane instantiations: iterative-maxocc takes 1.6 % (f64) / 2.5 % (f32) off the hand at
+                    # 65 536 x 64 (52.7 -> 51.9 ms, 31.8 -> 31.0 ms from tools/tree_time.py's start state; two A/B pairs);
+                    # max-ilp is 1-6 % slower everywhere, iterative-ilp has crashed the compiler on this source
+                    "tree_rollout.hip": [["-mllvm", "-amdgpu-sched-strategy=iterative-maxocc"]],
                     # the arm kernel: 1 % (f64 control step 0.2000 -> 0.1980 ms, three A/B pairs on one box; f32 2 %) with
                     # iterative-maxocc; iterative-ilp another 1 % on the fused iteration's kernel and 3 % in f32 (two A/B
                     # pairs: f64 control step 0.1957 -> 0.1935 ms, pipelined 0.1910 -> 0.1883; the plain two-wave launch
