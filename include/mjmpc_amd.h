@@ -275,7 +275,9 @@ int mjmpc_softmax_weights(int64_t P, int H, int A, const double* d_wnorm, void* 
 
 /* CEM._update_distribution (mjmpc/control/cem.py:63-86) in three steps.  Elite = the k particles
  * with the smallest (q0, global index); d_q_all is the all-gathered q0 of every GPU (NULL = this
- * GPU holds all particles) and `offset` the global index of local particle 0.                     */
+ * GPU holds all particles; `offset` is then ignored) and `offset` the global index of local particle 0.
+ * The local elite rows are kept as a list in d_ws, which mjmpc_cem_elite_cov reads: call them in this order
+ * on the same workspace.                                                                             */
 int mjmpc_cem_elite_sums(int dtype, int64_t P, int H, int A, const void* d_actions, const double* d_q_all,
                          int64_t P_all, int64_t offset, int64_t k, double* d_sum_record, void* d_ws, void* stream);
 int mjmpc_cem_elite_cov(int dtype, int64_t P, int H, int A, const void* d_actions, const double* d_mean,
