@@ -239,27 +239,36 @@ def make_workload(args, local, comm, P_tot):
             w["reset"] = eng.reset
         w["reset"]()
     A = eng.d_action
-    kw = dict(d_state=eng.d_state, d_obs=eng.d_obs, d_action=A, horizon=H, num_particles=P_tot, n_iters=1,
-              action_lows=eng.action_lows, action_highs=eng.action_highs, seed=123, base_action="null", gamma=1.0,
-              step_size=1.0, filter_coeffs=[0.25, 0.8, 0.0], init_cov=w["cov"],
-              noise_mode={"mt19937": "device_mt19937"}.get(args.noise, args.noise), noise_dtype=args.dtype,
-              device=local, comm=comm)
-    if args.controller == "mppi":
-        ctrl = MPPI(lam=w["lam"]["mppi"], alpha=1, **kw)
-        desc = "MPPI lam=%g" % w["lam"]["mppi"]
-    elif args.controller == "cem":
-        ctrl = CEM(elite_frac=0.1, beta=0.1, cov_type="full", **kw)
-        desc = "CEM full-cov elite_frac=0.1 beta=0.1"
-    else:
-        ctrl = DMDMPC(lam=w["lam"]["dmd"], beta=0.1, update_cov=False, cov_type="diagonal", **kw)
-        desc = "DMD-MPC lam=%g" % w["lam"]["dmd"]
-    if "hold" in w:                 # position servos: the nominal control is the pose, not zero
-        def hold(ctrl=ctrl, pose=w["hold"], reset=w["reset"]):
+    base_reset = w["reset"]
+
+    def make_ctrl(P_total):
+        """A controller over P_total particles (this rank's block of them) on this workload's engine, and the reset
+        that goes with it."""
+        kw = dict(d_state=eng.d_state, d_obs=eng.d_obs, d_action=A, horizon=H, num_particles=P_total, n_iters=1,
+                  action_lows=eng.action_lows, action_highs=eng.action_highs, seed=123, base_action="null", gamma=1.0,
+                  step_size=1.0, filter_coeffs=[0.25, 0.8, 0.0], init_cov=w["cov"],
+                  noise_mode={"mt19937": "device_mt19937"}.get(args.noise, args.noise), noise_dtype=args.dtype,
+                  device=local, comm=comm)
+        if args.controller == "mppi":
+            ctrl = MPPI(lam=w["lam"]["mppi"], alpha=1, **kw)
+            desc = "MPPI lam=%g" % w["lam"]["mppi"]
+        elif args.controller == "cem":
+            ctrl = CEM(elite_frac=0.1, beta=0.1, cov_type="full", **kw)
+            desc = "CEM full-cov elite_frac=0.1 beta=0.1"
+        else:
+            ctrl = DMDMPC(lam=w["lam"]["dmd"], beta=0.1, update_cov=False, cov_type="diagonal", **kw)
+            desc = "DMD-MPC lam=%g" % w["lam"]["dmd"]
+        reset = base_reset
+        if "hold" in w:                 # position servos: the nominal control is the pose, not zero
+            def reset(ctrl=ctrl, pose=w["hold"]):
+                base_reset()
+                ctrl.mean_action = np.tile(pose, (H, 1))
+            ctrl.base_action = "repeat"
             reset()
-            ctrl.mean_action = np.tile(pose, (H, 1))
-        w["reset"] = hold
-        ctrl.base_action = "repeat"
-        hold()
+        return ctrl, desc, reset
+
+    ctrl, desc, w["reset"] = make_ctrl(P_tot)
+    w["make_ctrl"] = make_ctrl
     w.update(raw=raw, eng=eng, ctrl=ctrl, A=A, desc=desc)
     return w
 
@@ -288,6 +297,7 @@ def main():
         from mjmpc_amd.control._device import TorchDistComm
         comm = TorchDistComm()
 
+    from mjmpc_amd.build import build_info
     from mjmpc_amd.envs.arm_engine import make_device_rollout_fn
 
     H = args.horizon
@@ -307,21 +317,7 @@ def main():
         return base_fn(num_particles, horizon, mean, noise, mode)
 
     rollout_fn.accepts_device = True
-    ctrl.rollout_fn = base_fn
-    graphed = not args.no_graph and args.noise != "host" and ctrl._graph_capable()
-    if not graphed:
-        ctrl.rollout_fn = rollout_fn
-        if hasattr(base_fn, "fused"):
-            rollout_fn.fused = base_fn.fused
-    ctrl.set_sim_state_fn = lambda s: None          # the "real" env lives on the device (step_state)
     state = {"resident": True}
-    if graphed:
-        ctrl.enable_graph(post_step=eng.step_state, mono=not args.no_mono, lookahead=args.lookahead)   # the env step is captured with the iteration
-
-    def control_step():
-        action, _ = ctrl.optimize(state)
-        if not graphed:
-            eng.step_state(action)          # (in graph mode the env step is part of the captured iteration)
 
     def sync():
         torch.cuda.synchronize()
@@ -329,29 +325,54 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    # Process warm-up (outside the W warm-up steps and the timed region): a fresh process runs its first control steps up
-    # to 7 % slow - idle GPU clocks, first-touch of pinned and device buffers, lazily initialised runtime paths (measured:
-    # 20 timed steps after 5 warm-up steps 0.218-0.225 ms per step in a fresh process, 0.205 ms for the same 25 steps
-    # repeated in a warm one).  --process-warmup throw-away control steps run first; controller and env are then reset,
-    # so that the W warm-up steps and the K timed steps are the closed loop from the initial state, as without it.
-    if args.process_warmup > 0:
-        for _ in range(args.process_warmup):
+    def wire(ctrl):
+        """Rollout callbacks + captured iteration of a controller on this workload's engine; returns (graphed, step)."""
+        ctrl.rollout_fn = base_fn
+        graphed = not args.no_graph and args.noise != "host" and ctrl._graph_capable()
+        if not graphed:
+            ctrl.rollout_fn = rollout_fn
+            if hasattr(base_fn, "fused"):
+                rollout_fn.fused = base_fn.fused
+        ctrl.set_sim_state_fn = lambda s: None          # the "real" env lives on the device (step_state)
+        if graphed:
+            ctrl.enable_graph(post_step=eng.step_state, mono=not args.no_mono, lookahead=args.lookahead)   # the env step is captured with the iteration
+
+        def control_step():
+            action, _ = ctrl.optimize(state)
+            if not graphed:
+                eng.step_state(action)          # (in graph mode the env step is part of the captured iteration)
+
+        return graphed, control_step
+
+    def timed_loop(ctrl, control_step, reset, process_warmup):
+        """process warm-up, reset, W warm-up steps, K timed steps between barriers; MAX over ranks."""
+        # Process warm-up (outside the W warm-up steps and the timed region): a fresh process runs its first control steps
+        # up to 7 % slow - idle GPU clocks, first-touch of pinned and device buffers, lazily initialised runtime paths
+        # (measured: 20 timed steps after 5 warm-up steps 0.218-0.225 ms per step in a fresh process, 0.205 ms for the same
+        # 25 steps repeated in a warm one).  --process-warmup throw-away control steps run first; controller and env are
+        # then reset, so that the W warm-up steps and the K timed steps are the closed loop from the initial state.
+        if process_warmup > 0:
+            for _ in range(process_warmup):
+                control_step()
+            sync()
+            ctrl.reset()
+            reset()
+        for _ in range(args.warmup):
             control_step()
         sync()
-        ctrl.reset()
-        w["reset"]()
-    for _ in range(args.warmup):
-        control_step()
-    sync()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        control_step()
-    sync()
-    dt = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            control_step()
+        sync()
+        dt = time.perf_counter() - t0
+        if world > 1:
+            t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt = float(t.item())
+        return dt
+
+    graphed, control_step = wire(ctrl)
+    dt = timed_loop(ctrl, control_step, w["reset"], args.process_warmup)
 
     # where the closed loop ended up (read BEFORE the launches below)
     extra = {}
@@ -430,6 +451,32 @@ def main():
         torch.cuda.synchronize()
         both_ms = e0.elapsed_time(e1) / n_t
 
+    # N > 1, weak scaling (the default the driver runs): the SAME invocation also answers the other reading of the metric
+    # ("4096 particles x H=32 reported at 1, 2, 4 and 8": the reference's num_particles is a total,
+    # examples/example_mpc.py:78-79) - a second controller over --particles IN TOTAL, this rank's block = particles / N,
+    # on the same engine, timed the same way.  Reported beside the headline as `strong`, never as `value`.
+    strong = None
+    if world > 1 and args.scaling == "weak":
+        if args.particles % world or (args.particles // world) % 8:
+            strong = {"skipped": "%d particles do not split into blocks of a multiple of 8 over %d GPUs" % (args.particles, world)}
+        else:
+            import gc
+            ctrl._graph = None              # graphs holding RCCL kernels of the weak loop go first
+            gc.collect()
+            torch.cuda.synchronize()
+            ctrl_s, _, reset_s = w["make_ctrl"](args.particles)
+            graphed_s, step_s = wire(ctrl_s)
+            reset_s()
+            dts = timed_loop(ctrl_s, step_s, reset_s, min(args.process_warmup, 20))
+            strong = {"ms_per_step": dts / args.steps * 1e3, "value": args.particles * H * ctrl_s.n_iters * args.steps / dts,
+                      "unit": "particle-steps/s", "control_loop_hz": args.steps / dts, "particles_total": args.particles,
+                      "particles_per_gpu": args.particles // world, "scaling": "strong",
+                      "launch": ("hipGraph replay" if (graphed_s and not getattr(ctrl_s, "graph_fallback", False)) else "eager"),
+                      "what": "the same closed loop with --particles as the TOTAL population, split over the ranks "
+                              "(subproc_vec_env.py:161-168); same steps / warmup, MAX over ranks"}
+            ctrl_s._graph = None
+            gc.collect()
+            torch.cuda.synchronize()
     fails = eng.solver_failures()
 
     # HBM bytes of one launch of the dominant kernel from the PMC counters (separate rocprofv3 passes,
@@ -486,7 +533,11 @@ def main():
                    "collectives_per_step": (0 if world == 1 else (2 if args.controller == "cem" else 1)),
                    "launch": launch_kind + (", rollout + record launches, all-gather, combine, env step" if (mono and world > 1) else "")
                              + (", next iteration enqueued ahead" if (mono and args.lookahead and world == 1) else ""),
-                   "process_warmup_steps": args.process_warmup},
+                   "process_warmup_steps": args.process_warmup,
+                   # which tuning alternative each HIP source was compiled with (mjmpc_amd/build.py: the first that this
+                   # compiler accepts; profiles/ were measured with alternative 0 of every source)
+                   "build": {k: (v["flags"] or "default") + ("" if v.get("alternative", 0) == 0 else " [FALLBACK alternative %d of %d]" % (v["alternative"], v["of"]))
+                             for k, v in build_info().get("sources", {}).items() if v.get("of", 0) > 0 or v.get("alternative", 0) != 0}},
         "control_loop_hz": args.steps / dt,
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
@@ -507,6 +558,8 @@ def main():
     }
     if pipelined:
         out["pipelined"] = pipelined
+    if strong:
+        out["strong"] = strong
     out.update(extra)
     if rank == 0:
         if world == 1 and not args.no_cpu_baseline:

@@ -121,10 +121,14 @@ int mjmpc_arm_rollout_fused(mjmpc_arm_t h, int dtype, int64_t P, int H, const do
  *      completion flag, the new step count); *d_step_counter advances; env_step != 0: the engine state advances by one
  *      env step with that action (d_step_cost dtype[1], d_step_next_obs dtype[d_obs], may be NULL).
  *   Sharded runs pass d_record (float64 [2 + H*A]): step 2 then leaves this GPU's record {max, S, W} there and nothing
- *   else (all-gather, then mjmpc_mppi_fused_combine and mjmpc_arm_step_state); d_mean_out is not used.
+ *   else (all-gather, then mjmpc_arm_mppi_combine, which also steps the env); d_mean_out is not used.
  * d_gseq float64[H] (gamma_seq, no zero entry).  d_costs / d_actions (dtype [P][H] / [P][H][A]) and d_q0 (float64 [P])
  * are optional outputs.  One model block and one start state only.  shift_mode = -2 issues launch 1 alone (the records
- * stay in the engine): what bench.py times as the dominant kernel. */
+ * stay in the engine): what bench.py times as the dominant kernel.
+ * Lifetime / hipGraph rule: every parameter - including the pointer to the engine's per-workgroup record buffer - travels
+ * to the two kernels BY VALUE, so a captured graph holds them.  The record buffer only grows and an outgrown buffer stays
+ * allocated until mjmpc_arm_destroy, so a graph captured at one (P, H) stays valid after calls at another; a call that
+ * would have to GROW the buffer while its stream is capturing returns MJMPC_E_BADARG (call once outside the capture first). */
 int mjmpc_arm_mppi_step(mjmpc_arm_t h, int dtype, int64_t P, int H, const double* d_mean, double* d_mean_out,
                         const double* d_gseq, const double* d_filter_coeffs, const double* d_chol, uint64_t seed,
                         uint64_t offset, int64_t particle_offset, int64_t* d_step_counter, double lam, double step_size,
@@ -135,9 +139,9 @@ int mjmpc_arm_mppi_step(mjmpc_arm_t h, int dtype, int64_t P, int H, const double
  * (d_record != NULL) - ONE launch that merges the n_records gathered records [max | S | W[H*A]] in rank order (bit-identical
  * on every rank), updates the mean (mppi.py:69-82) into d_mean_out (a buffer of its own) already shifted
  * (olgaussian_mpc.py:116-129), publishes the action into slot (step & 1) of h_action_slots (mapped pinned [2][A+1], value
- * then step count), advances the step counter and, with env_step != 0, steps the device-resident real env.  The parameter
- * block of this call lives in device memory and is rewritten (stream-ordered) only when the arguments change: a captured
- * graph that holds this launch stays valid as long as no later call passes different arguments. */
+ * then step count), advances the step counter and, with env_step != 0, steps the device-resident real env.  The
+ * parameters travel by value as kernel arguments: a captured graph that holds this launch is valid for as long as the
+ * buffers it was given (d_records, d_mean, d_mean_out, the counters, the pinned slots) live. */
 int mjmpc_arm_mppi_combine(mjmpc_arm_t h, int dtype, const double* d_records, int n_records, int H, const double* d_mean,
                            double* d_mean_out, int64_t* d_step_counter, double step_size, int shift_mode,
                            double* d_action_out, double* h_action_slots, int env_step, void* d_step_cost,

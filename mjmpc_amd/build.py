@@ -6,6 +6,7 @@ mjmpc_amd/libmjmpc_amd.so.  hipcc cross-compiles without a GPU; the .so is git-i
 snapshots.
 """
 import glob
+import json
 import os
 import subprocess
 import sys
@@ -15,6 +16,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(HERE, "_build")
 LIB = os.path.join(HERE, "libmjmpc_amd.so")
+INFO = os.path.join(HERE, "build_info.json")     # which tuning alternative every source was compiled with (travels with the .so)
 ARCH = "gfx950"
 FLAGS = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-Wno-unused-value", "-Wno-pass-failed", "-I", CSRC]
 # The tree kernel's 16-lane dense instantiations (tree_rollout_dense.hip) run ONE wave per SIMD through long straight-line
@@ -79,20 +81,26 @@ def build(force=False, verbose=False, extra_flags=(), lib=None):
         return lib
     os.makedirs(objdir, exist_ok=True)
 
+    chosen = {}
+
     def compile_one(src):
         out = os.path.join(objdir, os.path.basename(_obj(src)))
         alts = PER_SOURCE_FLAGS.get(os.path.basename(src), [])
-        for special in list(alts) + [[]]:
+        for k, special in enumerate(list(alts) + [[]]):
             cmd = [hipcc] + FLAGS + special + list(extra_flags) + ["-c", src, "-o", out]
             if verbose:
                 cmd.insert(1, "-Rpass-analysis=kernel-resource-usage")
                 print(" ".join(cmd), flush=True)
             r = subprocess.run(cmd, capture_output=True, text=True)
             if r.returncode == 0 or not special:
+                chosen[os.path.basename(src)] = {"flags": " ".join(special), "alternative": k, "of": len(alts)}
                 break
-            # a scheduling strategy is a tuning flag: if this compiler cannot take it for this source, try the next
-            sys.stderr.write("mjmpc_amd.build: %s did not compile with %s; trying the next alternative\n"
-                             % (os.path.basename(src), " ".join(special)))
+            # a scheduling strategy is a tuning flag: if this compiler cannot take it for this source, try the next -
+            # loudly (stdout too): the committed profiles were measured with the FIRST alternative of every source
+            msg = ("mjmpc_amd.build: WARNING %s did not compile with %s; trying the next alternative (performance figures "
+                   "under profiles/ were measured with the first)\n" % (os.path.basename(src), " ".join(special)))
+            sys.stderr.write(msg)
+            sys.stdout.write(msg)
         return src, r
 
     with ThreadPoolExecutor(max_workers=min(4, max(1, len(todo)))) as ex:
@@ -104,7 +112,35 @@ def build(force=False, verbose=False, extra_flags=(), lib=None):
             raise subprocess.CalledProcessError(r.returncode, "hipcc -c " + src)
     objs = [os.path.join(objdir, os.path.basename(_obj(s))) for s in sources()]
     subprocess.check_call([hipcc, "--offload-arch=" + ARCH, "-shared", "-fPIC"] + objs + ["-o", lib])
+    # which alternative each source took: kept beside the library (sources not recompiled keep their earlier entry)
+    info_path = INFO if lib == LIB else lib + ".build_info.json"
+    info = {}
+    if os.path.exists(info_path):
+        try:
+            with open(info_path) as f:
+                info = json.load(f).get("sources", {})
+        except (OSError, ValueError):
+            info = {}
+    info = {k: v for k, v in info.items() if k in {os.path.basename(s) for s in sources()}}
+    info.update(chosen)
+    for s_ in sources():
+        info.setdefault(os.path.basename(s_), {"flags": "unknown (object older than build_info.json)", "alternative": -1,
+                                               "of": len(PER_SOURCE_FLAGS.get(os.path.basename(s_), []))})
+    with open(info_path, "w") as f:
+        json.dump({"arch": ARCH, "common_flags": " ".join(FLAGS[:-2]), "extra_flags": " ".join(extra_flags),
+                   "sources": info}, f, indent=1, sort_keys=True)
     return lib
+
+
+def build_info(lib=None):
+    """{source: {"flags", "alternative", "of"}} of the library in the tree (bench.py echoes it in `config`); a source
+    compiled with anything but its first alternative is a build whose performance differs from profiles/."""
+    path = INFO if lib in (None, LIB) else lib + ".build_info.json"
+    try:
+        with open(path) as f:
+            return json.load(f)
+    except (OSError, ValueError):
+        return {"sources": {}, "note": "build_info.json missing: library built by an older build.py"}
 
 
 if __name__ == "__main__":

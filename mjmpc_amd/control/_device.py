@@ -243,14 +243,6 @@ class DeviceUpdater:
                                                      _vp(action_out), None, _vp(action_pinned), _vp(step_counter),
                                                      self.stream()))
 
-    def mppi_fused_combine(self, rec, P_local, lam, step_size, shift_mode, action_out, action_pinned, step_counter):
-        """Sharded one-launch iterations: all-gather this GPU's record and finish the iteration on every rank."""
-        recs = self.comm.all_gather(rec)
-        G = recs.shape[0]
-        _lib.check(self.lib.mjmpc_mppi_fused_combine(_vp(recs), G, float(P_local * G), self.H, self.A, float(lam),
-                                                     float(step_size), int(shift_mode), _vp(self.mean), _vp(action_out),
-                                                     None, _vp(action_pinned), _vp(step_counter), self.stream()))
-
     # ------------------------------------------------------------------ CEM
     def cem_update(self, costs, actions, num_elite, step_size, full_cov, q0=None):
         """``q0``: cost_to_go(costs)[:, 0] when the rollout launch has already produced it (float64 [P], device)."""

@@ -302,7 +302,11 @@ class OLGaussianMPC(Controller):
         env lives on the device and ``post_step`` advances it - so iteration k + 1 depends on nothing the host provides.
         ``optimize()`` then enqueues iteration k + 1 BEFORE it waits for the action of iteration k: the GPU goes from
         one iteration to the next without waiting for the host's round trip.  The device then runs one iteration
-        ahead of the actions the host has seen; host mirrors (``mean_action``) read the device's latest."""
+        ahead of the actions the host has seen; host mirrors (``mean_action``) read the device's latest.  Whatever the
+        host assigns between two ``optimize()`` calls (``mean_action``, ``cov_action``, ``num_steps``; an engine
+        ``set_env_state``) cannot reach the iteration that is already in flight: ``optimize()`` raises when it finds
+        such an assignment; call ``reset()`` (which drains the queue) before editing the distribution or the engine
+        state from the host."""
         if not self._graph_capable():
             raise ValueError("this controller configuration cannot run as a captured graph "
                              "(needs noise_mode='device', a device rollout_fn, static covariance, "
@@ -490,8 +494,18 @@ class OLGaussianMPC(Controller):
         if self._graph_post is not None:
             self._graph_post(self._action_dev)
 
+    def _host_dirty(self):
+        """A host-assigned mean / covariance the device has not seen (what ``_sync_in`` would upload)."""
+        return ((not self._mean_stale and (self._mean_seen is None or not np.array_equal(self._mean_host, self._mean_seen)))
+                or (not self._cov_stale and (self._cov_seen is None or not np.array_equal(self._cov_host, self._cov_seen))))
+
     def _optimize_graphed(self, state):
         torch = self.dev.torch
+        if self._ahead > 0 and self._host_dirty():
+            # lookahead: iteration k + 1 is already in the queue, computed from the device's mean; an upload now would land
+            # behind it and silently take effect one step late (like num_steps below)
+            raise RuntimeError("mean_action / cov_action were assigned while an iteration enqueued ahead "
+                               "(enable_graph(lookahead=True)) was in flight; call reset() first, or run without lookahead")
         self._sync_in()
         self._set_sim_state_fn(copy.deepcopy(state) if state is not None else None)
         if self._graph is None:
@@ -594,6 +608,10 @@ class OLGaussianMPC(Controller):
             self._graph_on = False
             self._graph = None
             self.graph_fallback = True
+            # a later enable_graph() / reset() starts clean: no half-bound launchers keyed by the (possibly swapped)
+            # mean buffers, no one-launch mode
+            self._mono = False
+            self._mono_launch, self._mono_combine = {}, {}
 
     def _wait_action(self):
         """The action of the replayed iteration.  The fused update writes it into mapped pinned memory followed by

@@ -1171,9 +1171,10 @@ __global__ __launch_bounds__(128) void arm_mppi_finish_kernel(const T* __restric
 // long as the crowded ones (measured inside the control loop at 16 384 particles: 0.42 ms against 0.31 ms) - so
 // such launches use the instantiation capped at two.
 // DUO = two wavefronts per particle group (roles DYN / SOLVE above), for launches of at most half a wave per SIMD.
-// MONO = the whole control iteration in this launch (struct MonoStep, arm_rollout.h): samples drawn in the kernel, actions
-// kept in LDS, softmax partials reduced up a tree of arrival counters, mean update / action / shift / real-env step by the
-// workgroup that arrives last.
+// MONO = launch 1 of the two-launch control iteration (struct MonoStep, arm_rollout.h, by value): samples drawn in the
+// kernel, actions kept in LDS, ONE softmax record {max, S, W[H A]} per workgroup left in the engine's record buffer; the
+// merge, mean update, action, shift and real-env step are launch 2 (arm_mppi_finish_kernel).  (An in-kernel merge behind
+// arrival counters was measured and dropped: agent-scope fences / dependent L2 round trips cost more than a launch.)
 template <typename T, bool STEP, bool CL, int WAVES, bool DUO, bool MONO>
 __global__ __launch_bounds__(DUO ? 128 : 64) __attribute__((amdgpu_waves_per_eu(WAVES, WAVES))) void arm_rollout_kernel(const T* __restrict__ model, const double* state,
                                                          long P, int H, int A, const double* mean,

@@ -58,11 +58,12 @@ struct mjmpc_arm_s {
     double* scratch = nullptr;      // [8] a place for that launch's cost
     double* shard_states = nullptr; // n_state_shards state vectors (per-shard start states)
     int n_state_shards = 0;
-    // mjmpc_arm_mppi_step: the rollout workgroups' records (sized for mono_groups workgroups, horizon mono_H), and
-    // the launches' parameter block in device memory (rewritten only when a parameter changes)
+    // mjmpc_arm_mppi_step: the rollout workgroups' records.  The pointer travels to the kernels BY VALUE (MonoStep), so a
+    // captured graph holds it: the buffer only ever GROWS, and a buffer it outgrew stays allocated until the handle is
+    // destroyed (mono_retired) - a graph captured at one (P, H) survives later calls at another
     double* mono_tree = nullptr;
-    long mono_groups = 0;
-    int mono_H = 0;
+    size_t mono_cap = 0;            // doubles
+    std::vector<double*> mono_retired;
 };
 
 struct mjmpc_tree_s {
@@ -203,6 +204,7 @@ int mjmpc_arm_destroy(mjmpc_arm_t h) {
     hipFree(h->diag);
     hipFree(h->shard_states);
     hipFree(h->mono_tree);
+    for (double* p : h->mono_retired) hipFree(p);
     hipHostFree(h->pinned);
     for (int k = 0; k < 4; ++k) if (h->staged[k]) hipEventDestroy(h->staged[k]);
     delete h;
@@ -334,14 +336,18 @@ int mjmpc_arm_mppi_step(mjmpc_arm_t h, int dtype, int64_t P, int H, const double
     HIP_TRY(hipSetDevice(h->device));
     hipStream_t s = (hipStream_t)stream;
     const long groups = mjmpc::arm_rollout_groups((long)P);
-    if (groups != h->mono_groups || H != h->mono_H) {
-        HIP_TRY(hipDeviceSynchronize());
-        hipFree(h->mono_tree);
-        h->mono_tree = nullptr;
-        h->mono_groups = 0;
-        HIP_TRY(hipMalloc(&h->mono_tree, sizeof(double) * mjmpc::mono_record_doubles(groups, H, h->nu)));
-        h->mono_groups = groups;
-        h->mono_H = H;
+    const size_t need = (size_t)mjmpc::mono_record_doubles(groups, H, h->nu);
+    if (need > h->mono_cap) {
+        // grow only, never under a capture (an allocation would invalidate it), and never free what an earlier graph
+        // may still point at
+        hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+        if (hipStreamIsCapturing(s, &cs) == hipSuccess && cs != hipStreamCaptureStatusNone)
+            return fail(MJMPC_E_BADARG, "the record buffer must grow for this (P, H): call once outside stream capture first");
+        double* bigger = nullptr;
+        HIP_TRY(hipMalloc(&bigger, sizeof(double) * need));
+        if (h->mono_tree) h->mono_retired.push_back(h->mono_tree);
+        h->mono_tree = bigger;
+        h->mono_cap = need;
     }
     mjmpc::MonoStep mo;             // (travels to both kernels by value, as a kernel argument)
     mo.chol = d_chol;

@@ -55,6 +55,7 @@ static inline bool isfinite_cd(cd a) { return ::isfinite(a.v); }
 #undef _OPENMP
 #define double cd
 #define OR_NO_POLISH 1
+#define OR_DENSE_JACOBIANS 1
 extern "C" {
 #include "reacher_ref.c"
 }

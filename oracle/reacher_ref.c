@@ -240,23 +240,35 @@ static void world_inertia(const OrModel *m, const Kin *k, int b, double *Iw) {
     matmul3(T, Rt, Iw);
 }
 
-/* M(q) = sum_b m_b Jp^T Jp + Jr^T Iw Jr  + diag(armature)   (nv x nv, row-major) */
+/* M(q) = sum_b m_b Jp^T Jp + Jr^T Iw Jr  + diag(armature)   (nv x nv, row-major).  A body's Jacobians have non-zero
+ * columns only for the dofs on its path to the root: the products run over that list (the FLOP-counting build,
+ * OR_DENSE_JACOBIANS, keeps the full nv x nv loops - same values, the skipped terms are exact zeros - so that the counted
+ * figure stays the dense formulation's of the earlier rounds) */
 static void mass_matrix(const OrModel *m, const Kin *k, double *M) {
     int nv = m->nv;
     memset(M, 0, sizeof(double) * nv * nv);
     for (int b = 1; b < m->nbody; b++) {
         if (m->mass[b] <= 0) continue;
         double Jp[3 * MAXV], Jr[3 * MAXV], Iw[9], IJ[3 * MAXV];
+        int idx[MAXV], n = 0;
         jacobian(m, k, b, k->xipos[b], Jp, Jr);
         world_inertia(m, k, b, Iw);
+        for (int j = 0; j < nv; j++) {
+#ifndef OR_DENSE_JACOBIANS
+            if (!dof_affects(m, j, b)) continue;
+#endif
+            idx[n++] = j;
+        }
         for (int i = 0; i < 3; i++)
-            for (int j = 0; j < nv; j++) {
+            for (int jj = 0; jj < n; jj++) {
+                int j = idx[jj];
                 double s = 0;
                 for (int c = 0; c < 3; c++) s += Iw[3 * i + c] * Jr[c * nv + j];
                 IJ[i * nv + j] = s;
             }
-        for (int i = 0; i < nv; i++)
-            for (int j = 0; j < nv; j++) {
+        for (int ii = 0; ii < n; ii++)
+            for (int jj = 0; jj < n; jj++) {
+                int i = idx[ii], j = idx[jj];
                 double s = 0;
                 for (int c = 0; c < 3; c++) s += m->mass[b] * Jp[c * nv + i] * Jp[c * nv + j] + Jr[c * nv + i] * IJ[c * nv + j];
                 M[i * nv + j] += s;

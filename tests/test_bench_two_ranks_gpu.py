@@ -33,6 +33,17 @@ def test_two_ranks_on_one_gpu():
     assert j["n_gpus"] == 2 and j["scaling"] == "weak" and j["solver_failures"] == 0
     assert j["config"]["particles_per_gpu"] == 512
     assert abs(j["value"] - 2 * 512 * 32 * 6 / (j["ms_per_step"] * 6e-3)) / j["value"] < 1e-6     # whole-job aggregate
+    _check_strong_block(j)
+
+
+def _check_strong_block(j, H=32):
+    """One --gpus N invocation answers both readings of the metric: `value` is weak scaling (--particles per GPU), and
+    the `strong` block is the same loop over --particles IN TOTAL (examples/example_mpc.py:78-79: num_particles is a total)."""
+    st = j["strong"]
+    assert st["scaling"] == "strong" and st["particles_total"] == 512 and st["particles_per_gpu"] == 256
+    assert abs(st["value"] - 512 * H * 6 / (st["ms_per_step"] * 6e-3)) / st["value"] < 1e-6
+    assert abs(st["control_loop_hz"] - 1e3 / st["ms_per_step"]) / st["control_loop_hz"] < 1e-6
+    assert j["scaling"] == "weak"                       # the headline keeps its label
 
 
 def _self_launched(*flags):
@@ -49,6 +60,8 @@ def test_self_launch_mppi():
     assert j["scaling"] == "weak" and j["config"]["particles_total"] == 1024 and j["config"]["collectives_per_step"] == 1
     assert abs(j["value"] - 2 * 512 * 32 * 6 / (j["ms_per_step"] * 6e-3)) / j["value"] < 1e-6
     assert j["solver_failures"] == 0
+    _check_strong_block(j)
+    assert "arm_rollout.hip" in j["config"]["build"]       # which scheduler alternative the kernels were compiled with
 
 
 def test_self_launch_cem_strong_scaling():
@@ -58,6 +71,7 @@ def test_self_launch_cem_strong_scaling():
     assert j["config"]["particles_per_gpu"] == 256 and j["config"]["particles_total"] == 512
     assert abs(j["value"] - 512 * 32 * 6 / (j["ms_per_step"] * 6e-3)) / j["value"] < 1e-6
     assert j["solver_failures"] == 0 and j["final_distance_to_target"] < 1.0
+    assert "strong" not in j                            # (the headline already is the strong reading)
 
 
 def test_self_launch_dmd_on_the_hand_tree():
@@ -66,6 +80,7 @@ def test_self_launch_dmd_on_the_hand_tree():
     assert j["config"]["ranks_seen"] == 2 and j["roofline"]["kernel"].startswith("tree_rollout_kernel")
     assert abs(j["value"] - 2 * 512 * 8 * 6 / (j["ms_per_step"] * 6e-3)) / j["value"] < 1e-6
     assert j["solver_failures"] == 0
+    _check_strong_block(j, H=8)
 
 
 def test_sharded_equals_unsharded_action_sequence():
