@@ -177,14 +177,28 @@ int mjmpc_arm_step_state(mjmpc_arm_t h, int dtype, const double* d_action, void*
  *   k | distance << 8 | height << 16, -1 ends)
  * Same call shapes and reference counterparts as the arm engine (subproc_vec_env.py:91-111, 128-186, 235-251);
  * target_pos is ignored by task 1.                                                                                  */
-#define MJMPC_TREE_BLOB_LEN 3116
-/* Device state vector of a tree engine: qpos[32] | qvel[32] | target_pos[3] | site of the fresh observation[3]  (float64;
- * the last three are filled by mjmpc_tree_rollout_cl). */
-#define MJMPC_TREE_STATE_LEN 70
+#define MJMPC_TREE_BLOB_LEN 3606
+/* Round 4, the GENERAL instantiation (block field `gen`; models without these features run the earlier kernels unchanged):
+ * ball and free joints (quaternion links: qpos has nq >= nv entries in MuJoCo's layout, d_obs = nq + nv + 6 or nq + nv -
+ * obs_skip), joint anchors off the body origin, explicit inertials, box geoms (eight corner points against the plane, one
+ * point against a sphere), static geoms of the world body (link -1), friction-loss rows (dof_frictionloss), connect and
+ * joint equalities, limits of fixed tendons over one or two joints.  The block then continues
+ *   gen nq has_ball fsol_{K,B,dmin,dmax,width,mid,power} frictionloss[32] qadr[32] qoff[32] pext[16][24]
+ * (pext: what the new record kinds need beyond spheres[.][24]; layout in csrc/tree_model.h). */
+/* A state vector as the C ABI takes it (mjmpc_tree_set_shard_states): MuJoCo's layout, qpos[40] (nq entries used) |
+ * qvel[32] | target_pos[3] | 3 reserved (float64). */
+#define MJMPC_TREE_STATE_LEN 78
+/* The device-resident state vector: one coordinate per link - qpos[32] | qvel[32] | target_pos[3] | site of the fresh
+ * observation[3] (filled by mjmpc_tree_rollout_cl) | quaternion w[32] (a ball joint keeps x, y, z in its three links'
+ * qpos entries and w here). */
+#define MJMPC_TREE_DEVICE_STATE_LEN 102
 typedef struct mjmpc_tree_s* mjmpc_tree_t;
 int mjmpc_tree_create(const double* model_blob, int n_blob, int device, mjmpc_tree_t* out);
 int mjmpc_tree_destroy(mjmpc_tree_t h);
 int mjmpc_tree_dims(mjmpc_tree_t h, int* nv, int* nu, int* d_obs);
+/* entries of qpos in MuJoCo's layout (nv + one per ball / free joint); mjmpc_tree_set_state / _get_state take and return
+ * qpos[nq], qvel[nv] in that layout */
+int mjmpc_tree_nq(mjmpc_tree_t h);
 /* SubprocVecEnv.randomize_dynamics for the tree engine (subproc_vec_env.py:304-312, gym_env_wrapper.py:367-416): n_shards
  * model blocks [n_shards][MJMPC_TREE_BLOB_LEN] of the engine's topology; from then on shard i of a rollout (particles
  * [i P / n_shards, (i + 1) P / n_shards), P % n_shards == 0) simulates block i. */
@@ -192,8 +206,8 @@ int mjmpc_tree_set_shard_models(mjmpc_tree_t h, const double* model_blobs, int n
 /* set_sim_state_fn (subproc_vec_env.py:235-251), asynchronous on `stream` like mjmpc_arm_set_state (pinned staging ring). */
 int mjmpc_tree_set_state(mjmpc_tree_t h, const double* qpos, const double* qvel, const double* target_pos, void* stream);
 /* One start state per shard, as mjmpc_arm_set_shard_states (SubprocVecEnv.set_env_state with one dict per worker,
- * subproc_vec_env.py:242-251): states = float64 [n_shards][MJMPC_TREE_STATE_LEN] (HOST pointer, layout qpos[32] | qvel[32] |
- * target[3] | 3 unused); particles of shard k then start from states[k].  With per-shard models the two shard counts
+ * subproc_vec_env.py:242-251): states = float64 [n_shards][MJMPC_TREE_STATE_LEN] (HOST pointer, layout qpos[40] | qvel[32] |
+ * target[3] | 3 unused, MuJoCo's qpos layout); particles of shard k then start from states[k].  With per-shard models the two shard counts
  * must agree.  n_shards = 0 returns to the single engine state. */
 int mjmpc_tree_set_shard_states(mjmpc_tree_t h, const double* states, int n_shards, void* stream);
 int mjmpc_tree_rollout(mjmpc_tree_t h, int dtype, int64_t P, int H, const double* d_mean, const void* d_noise,

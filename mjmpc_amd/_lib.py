@@ -38,6 +38,7 @@ SIGNATURES = {
     "mjmpc_tree_create": (_int, [_dp, _int, _int, ctypes.POINTER(_vp)]),
     "mjmpc_tree_destroy": (_int, [_vp]),
     "mjmpc_tree_dims": (_int, [_vp, ctypes.POINTER(_int), ctypes.POINTER(_int), ctypes.POINTER(_int)]),
+    "mjmpc_tree_nq": (_int, [_vp]),
     "mjmpc_tree_set_shard_models": (_int, [_vp, _dp, _int]),
     "mjmpc_tree_set_state": (_int, [_vp, _dp, _dp, _dp, _vp]),
     "mjmpc_tree_set_shard_states": (_int, [_vp, _dp, _int, _vp]),

@@ -68,14 +68,15 @@ struct mjmpc_arm_s {
 
 struct mjmpc_tree_s {
     int device = 0;
-    int nv = 0, nu = 0, d_obs = 0, max_path = 0;
+    int nv = 0, nu = 0, d_obs = 0, max_path = 0, nq = 0;
     bool full = false;              // slide joints, springs, friction cones, > 8 contact points or a medium: the full kernel
+    bool gen = false;               // ball / free joints, friction loss, boxes, equalities, tendon limits: the general instantiation
     int n_shards = 1;               // > 1: model_f32 / model_f64 hold one block per shard
     double* zero_action = nullptr;  // [32] zeros (the kinematics-only launch of mjmpc_tree_rollout_cl)
     double* scratch = nullptr;      // [8] a place for that launch's cost
     float* model_f32 = nullptr;
     double* model_f64 = nullptr;
-    double* state = nullptr;        // MJMPC_TREE_STATE_LEN
+    double* state = nullptr;        // MJMPC_TREE_DEVICE_STATE_LEN
     unsigned* diag = nullptr;
     double* shard_states = nullptr; // n_state_shards state vectors (per-shard start states)
     int n_state_shards = 0;
@@ -463,6 +464,8 @@ extern "C" int mjmpc_debug_stamps(mjmpc_arm_t h, unsigned long long* out32) {
 #endif
 
 /* ---- tree engine ------------------------------------------------------------------------------------ */
+static_assert(MJMPC_TREE_BLOB_LEN == mjmpc::TREE_BLOB_LEN && MJMPC_TREE_DEVICE_STATE_LEN == mjmpc::TREE_STATE_LEN &&
+              MJMPC_TREE_STATE_LEN == mjmpc::TREE_PUBLIC_STATE_LEN, "include/mjmpc_amd.h and csrc/tree_model.h disagree");
 #define MJMPC_TREE_DIAG_BYTES (8 + 8 * 24)      /* failure counter, then the developer clocks of -DTREE_STATS builds */
 #ifdef TREE_STATS
 // developer builds only (not declared in include/mjmpc_amd.h): read and clear the phase clocks / iteration counts
@@ -474,9 +477,46 @@ extern "C" int mjmpc_debug_tree_stats(mjmpc_tree_t h, unsigned long long* out24)
     return 0;
 }
 #endif
+// MuJoCo's layout (qpos[nq], qvel[nv], target[3]) -> the device state vector: one coordinate per LINK, a ball joint's
+// quaternion as x, y, z in its three links' entries and w in its first link's w entry, a free joint's translations relative
+// to the body position (the links are slides from there)
+static void tree_pack_state(const mjmpc_tree_s* h, const double* qpos, const double* qvel, const double* target, double* st) {
+    std::memset(st, 0, sizeof(double) * MJMPC_TREE_DEVICE_STATE_LEN);
+    const double* b = h->topo.data();
+    for (int l = 0; l < h->nv; ++l) {
+        const int kind = (int)b[mjmpc::T_JTYPE + l], adr = (int)b[mjmpc::T_QADR + l];
+        st[mjmpc::TREE_QW + l] = 1.0;
+        if (kind == mjmpc::LINK_BALL_X) {
+            st[mjmpc::TREE_QW + l] = qpos[adr];
+            st[l] = qpos[adr + 1];
+            st[l + 1] = qpos[adr + 2];
+            st[l + 2] = qpos[adr + 3];
+        } else if (kind <= mjmpc::LINK_SLIDE) {
+            st[l] = qpos[adr] - b[mjmpc::T_QOFF + l];
+        }
+        st[mjmpc::TL + l] = qvel[l];
+    }
+    std::memcpy(st + 2 * mjmpc::TL, target, sizeof(double) * 3);
+}
+static void tree_unpack_state(const mjmpc_tree_s* h, const double* st, double* qpos, double* qvel) {
+    const double* b = h->topo.data();
+    for (int l = 0; l < h->nv; ++l) {
+        const int kind = (int)b[mjmpc::T_JTYPE + l], adr = (int)b[mjmpc::T_QADR + l];
+        if (kind == mjmpc::LINK_BALL_X) {
+            qpos[adr] = st[mjmpc::TREE_QW + l];
+            qpos[adr + 1] = st[l];
+            qpos[adr + 2] = st[l + 1];
+            qpos[adr + 3] = st[l + 2];
+        } else if (kind <= mjmpc::LINK_SLIDE) {
+            qpos[adr] = st[l] + b[mjmpc::T_QOFF + l];
+        }
+        qvel[l] = st[mjmpc::TL + l];
+    }
+}
+
 static bool tree_blob_is_full(const double* blob, int nv) {
     bool full = blob[mjmpc::T_ANY_FRICTION] != 0.0 || (int)blob[mjmpc::T_N_SPHERE] > 8 || blob[mjmpc::T_DENSITY] > 0.0 ||
-                blob[mjmpc::T_VISCOSITY] > 0.0;
+                blob[mjmpc::T_VISCOSITY] > 0.0 || blob[mjmpc::T_GEN] != 0.0;
     for (int l = 0; l < nv; ++l) full = full || (int)blob[mjmpc::T_JTYPE + l] == 2 || blob[mjmpc::T_STIFFNESS + l] != 0.0;
     return full;
 }
@@ -489,23 +529,24 @@ static bool tree_same_topology(const double* a, const double* b) {
     return same(mjmpc::T_PARENT, mjmpc::TL) && same(mjmpc::T_EPARENT, mjmpc::TL) && same(mjmpc::T_SUBSIZE, mjmpc::TL) && same(mjmpc::T_ANC, 5 * mjmpc::TL) &&
            same(mjmpc::T_JTYPE, mjmpc::TL) && same(mjmpc::T_ACT, mjmpc::TL) && same(mjmpc::T_DEPTH, mjmpc::TL) &&
            same(mjmpc::T_N_ROUNDS, 1) && same(mjmpc::T_ELIM, (mjmpc::TL - 1) * mjmpc::TL) && same(mjmpc::T_NV, 1) &&
-           same(mjmpc::T_NU, 1) && same(mjmpc::T_TASK, 1) && same(mjmpc::T_OBS_SKIP, 1) && same(mjmpc::T_JUMPS, 1);
+           same(mjmpc::T_NU, 1) && same(mjmpc::T_TASK, 1) && same(mjmpc::T_OBS_SKIP, 1) && same(mjmpc::T_JUMPS, 1) &&
+           same(mjmpc::T_NQ, 1) && same(mjmpc::T_QADR, mjmpc::TL) && same(mjmpc::T_HAS_BALL, 1);
 }
 
 static int tree_create_impl(mjmpc_tree_s* h, const double* blob, int n_blob) {
     std::vector<float> f32(blob, blob + n_blob);
     HIP_TRY(hipMalloc(&h->model_f32, sizeof(float) * n_blob));
     HIP_TRY(hipMalloc(&h->model_f64, sizeof(double) * n_blob));
-    HIP_TRY(hipMalloc(&h->state, sizeof(double) * MJMPC_TREE_STATE_LEN));
+    HIP_TRY(hipMalloc(&h->state, sizeof(double) * MJMPC_TREE_DEVICE_STATE_LEN));
     HIP_TRY(hipMalloc(&h->diag, MJMPC_TREE_DIAG_BYTES));
     HIP_TRY(hipMemcpy(h->model_f32, f32.data(), sizeof(float) * n_blob, hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(h->model_f64, blob, sizeof(double) * n_blob, hipMemcpyHostToDevice));
-    HIP_TRY(hipMemset(h->state, 0, sizeof(double) * MJMPC_TREE_STATE_LEN));
+    HIP_TRY(hipMemset(h->state, 0, sizeof(double) * MJMPC_TREE_DEVICE_STATE_LEN));
     HIP_TRY(hipMemset(h->diag, 0, MJMPC_TREE_DIAG_BYTES));
     HIP_TRY(hipMalloc(&h->zero_action, sizeof(double) * 40));
     HIP_TRY(hipMemset(h->zero_action, 0, sizeof(double) * 40));
     h->scratch = h->zero_action + 32;
-    HIP_TRY(hipHostMalloc(&h->pinned, sizeof(double) * MJMPC_TREE_STATE_LEN * 4));
+    HIP_TRY(hipHostMalloc(&h->pinned, sizeof(double) * MJMPC_TREE_DEVICE_STATE_LEN * 4));
     for (int k = 0; k < 4; ++k) HIP_TRY(hipEventCreateWithFlags(&h->staged[k], hipEventDisableTiming));
     return 0;
 }
@@ -526,8 +567,14 @@ int mjmpc_tree_create(const double* blob, int n_blob, int device, mjmpc_tree_t* 
     h->device = device;
     h->nv = nv;
     h->nu = (int)blob[mjmpc::T_NU];
-    h->d_obs = (int)blob[mjmpc::T_TASK] == 1 ? 2 * nv - (int)blob[mjmpc::T_OBS_SKIP] : 2 * nv + 6;
+    h->nq = (int)blob[mjmpc::T_NQ];
+    if (h->nq < nv || h->nq > mjmpc::TREE_NQ_MAX) {
+        delete h;
+        return fail(MJMPC_E_BADMODEL, "nq = %d does not fit nv = %d", (int)blob[mjmpc::T_NQ], nv);
+    }
+    h->d_obs = (int)blob[mjmpc::T_TASK] == 1 ? h->nq + nv - (int)blob[mjmpc::T_OBS_SKIP] : h->nq + nv + 6;
     h->full = tree_blob_is_full(blob, nv);
+    h->gen = blob[mjmpc::T_GEN] != 0.0;
     for (int l = 0; l < nv; ++l) h->max_path = std::max(h->max_path, (int)blob[mjmpc::T_DEPTH + l] + 1);
     h->topo.assign(blob, blob + n_blob);
     if (int rc = tree_create_impl(h, blob, n_blob)) {       // a failed allocation leaves nothing behind
@@ -550,6 +597,8 @@ int mjmpc_tree_set_shard_models(mjmpc_tree_t h, const double* blobs, int n_shard
         if ((int)b[mjmpc::T_N_SPHERE] > mjmpc::TREE_MAX_SPHERES || !tree_same_topology(b, h->topo.data()))
             return fail(MJMPC_E_BADMODEL, "shard %d does not have the engine's topology / dimensions", s);
         full = full || tree_blob_is_full(b, h->nv);
+        if ((b[mjmpc::T_GEN] != 0.0) != h->gen)
+            return fail(MJMPC_E_BADMODEL, "shard %d needs a different kernel instantiation than the engine's model", s);
     }
     std::vector<float> f32(blobs, blobs + n);
     HIP_TRY(hipDeviceSynchronize());
@@ -586,13 +635,19 @@ int mjmpc_tree_set_shard_states(mjmpc_tree_t h, const double* states, int n_shar
         hipFree(h->shard_states);
         h->shard_states = nullptr;
         h->n_state_shards = 0;
-        if (n_shards > 0) HIP_TRY(hipMalloc(&h->shard_states, sizeof(double) * MJMPC_TREE_STATE_LEN * n_shards));
+        if (n_shards > 0) HIP_TRY(hipMalloc(&h->shard_states, sizeof(double) * MJMPC_TREE_DEVICE_STATE_LEN * n_shards));
         h->n_state_shards = n_shards;
     }
     if (n_shards > 0) {
-        HIP_TRY(hipMemcpyAsync(h->shard_states, states, sizeof(double) * MJMPC_TREE_STATE_LEN * n_shards,
-                               hipMemcpyHostToDevice, (hipStream_t)stream));
-        HIP_TRY(hipStreamSynchronize((hipStream_t)stream));      // `states` is pageable host memory
+        std::vector<double> packed((size_t)n_shards * MJMPC_TREE_DEVICE_STATE_LEN);
+        for (int k = 0; k < n_shards; ++k) {
+            const double* pub = states + (size_t)k * MJMPC_TREE_STATE_LEN;     // qpos[40] | qvel[32] | target[3] | -
+            tree_pack_state(h, pub, pub + mjmpc::TREE_NQ_MAX, pub + mjmpc::TREE_NQ_MAX + mjmpc::TL,
+                            packed.data() + (size_t)k * MJMPC_TREE_DEVICE_STATE_LEN);
+        }
+        HIP_TRY(hipMemcpyAsync(h->shard_states, packed.data(), sizeof(double) * packed.size(), hipMemcpyHostToDevice,
+                               (hipStream_t)stream));
+        HIP_TRY(hipStreamSynchronize((hipStream_t)stream));      // `packed` is pageable host memory
     }
     return 0;
 }
@@ -620,6 +675,8 @@ int mjmpc_tree_dims(mjmpc_tree_t h, int* nv, int* nu, int* d_obs) {
     return 0;
 }
 
+int mjmpc_tree_nq(mjmpc_tree_t h) { return h ? h->nq : -1; }
+
 int mjmpc_tree_set_state(mjmpc_tree_t h, const double* qpos, const double* qvel, const double* target_pos,
                          void* stream) {
     if (!h || !qpos || !qvel || !target_pos) return fail(MJMPC_E_BADARG, "null argument");
@@ -630,12 +687,9 @@ int mjmpc_tree_set_state(mjmpc_tree_t h, const double* qpos, const double* qvel,
     const int slot = h->stage_next;
     h->stage_next = (slot + 1) & 3;
     HIP_TRY(hipEventSynchronize(h->staged[slot]));
-    double* st = h->pinned + (size_t)slot * MJMPC_TREE_STATE_LEN;
-    std::memset(st, 0, sizeof(double) * MJMPC_TREE_STATE_LEN);
-    std::memcpy(st, qpos, sizeof(double) * h->nv);
-    std::memcpy(st + mjmpc::TL, qvel, sizeof(double) * h->nv);
-    std::memcpy(st + 2 * mjmpc::TL, target_pos, sizeof(double) * 3);
-    HIP_TRY(hipMemcpyAsync(h->state, st, sizeof(double) * MJMPC_TREE_STATE_LEN, hipMemcpyHostToDevice, s));
+    double* st = h->pinned + (size_t)slot * MJMPC_TREE_DEVICE_STATE_LEN;
+    tree_pack_state(h, qpos, qvel, target_pos, st);
+    HIP_TRY(hipMemcpyAsync(h->state, st, sizeof(double) * MJMPC_TREE_DEVICE_STATE_LEN, hipMemcpyHostToDevice, s));
     HIP_TRY(hipEventRecord(h->staged[slot], s));
     return 0;
 }
@@ -654,11 +708,11 @@ int mjmpc_tree_rollout(mjmpc_tree_t h, int dtype, int64_t P, int H, const double
     if (dtype == MJMPC_F32)
         e = mjmpc::launch_tree_rollout<float>(h->model_f32, h->n_shards, h->max_path, h->full, h->nv, st, (long)P, H, h->nu, d_mean,
                                               (const float*)d_noise, (float*)d_costs, (float*)d_actions, (float*)d_obs,
-                                              (float*)d_next_obs, h->diag, s, nullptr, nullptr, nullptr, nss);
+                                              (float*)d_next_obs, h->diag, s, nullptr, nullptr, nullptr, nss, h->gen);
     else if (dtype == MJMPC_F64)
         e = mjmpc::launch_tree_rollout<double>(h->model_f64, h->n_shards, h->max_path, h->full, h->nv, st, (long)P, H, h->nu, d_mean,
                                                (const double*)d_noise, (double*)d_costs, (double*)d_actions,
-                                               (double*)d_obs, (double*)d_next_obs, h->diag, s, nullptr, nullptr, nullptr, nss);
+                                               (double*)d_obs, (double*)d_next_obs, h->diag, s, nullptr, nullptr, nullptr, nss, h->gen);
     else
         return fail(MJMPC_E_BADARG, "unknown dtype %d", dtype);
     if (e != hipSuccess) return hip_fail(e, "tree_rollout launch");
@@ -669,6 +723,7 @@ int mjmpc_tree_rollout_cl(mjmpc_tree_t h, int dtype, int64_t P, int H, const dou
                           void* d_costs, void* d_actions, void* d_obs, void* d_next_obs, void* stream) {
     if (!h || !d_weights || !d_costs) return fail(MJMPC_E_BADARG, "null argument");
     if (P < 0 || H < 0) return fail(MJMPC_E_BADARG, "negative size");
+    if (h->gen) return fail(MJMPC_E_BADARG, "closed_loop_linear rollouts are not built for models of the general instantiation");
     const int nss = h->n_state_shards > 1 ? h->n_state_shards : 1;
     if (P % h->n_shards != 0 || P % nss != 0)
         return fail(MJMPC_E_BADARG, "%lld particles do not divide into %d shards", (long long)P, std::max(h->n_shards, nss));
@@ -680,16 +735,16 @@ int mjmpc_tree_rollout_cl(mjmpc_tree_t h, int dtype, int64_t P, int H, const dou
     // one-particle, one-step launch per start state (its cost lands in the workspace and is discarded) leaves it in
     // the state vector
     for (int k = 0; k < nss && e == hipSuccess; ++k) {
-        double* sk = st + (size_t)k * MJMPC_TREE_STATE_LEN;
+        double* sk = st + (size_t)k * MJMPC_TREE_DEVICE_STATE_LEN;
         double* site0 = sk + 2 * mjmpc::TL + 3;
         if (dtype == MJMPC_F32)
             e = mjmpc::launch_tree_rollout<float>(h->model_f32 + (h->n_shards > 1 ? (size_t)k * mjmpc::TREE_BLOB_LEN : 0), 1, h->max_path,
                                                   h->full, h->nv, sk, 1, 1, h->nu, h->zero_action, nullptr, (float*)h->scratch,
-                                                  nullptr, nullptr, nullptr, h->diag, s, nullptr, nullptr, site0);
+                                                  nullptr, nullptr, nullptr, h->diag, s, nullptr, nullptr, site0, 1, h->gen);
         else if (dtype == MJMPC_F64)
             e = mjmpc::launch_tree_rollout<double>(h->model_f64 + (h->n_shards > 1 ? (size_t)k * mjmpc::TREE_BLOB_LEN : 0), 1, h->max_path,
                                                    h->full, h->nv, sk, 1, 1, h->nu, h->zero_action, nullptr, (double*)h->scratch,
-                                                   nullptr, nullptr, nullptr, h->diag, s, nullptr, nullptr, site0);
+                                                   nullptr, nullptr, nullptr, h->diag, s, nullptr, nullptr, site0, 1, h->gen);
         else
             return fail(MJMPC_E_BADARG, "unknown dtype %d", dtype);
     }
@@ -697,11 +752,11 @@ int mjmpc_tree_rollout_cl(mjmpc_tree_t h, int dtype, int64_t P, int H, const dou
         if (dtype == MJMPC_F32)
             e = mjmpc::launch_tree_rollout<float>(h->model_f32, h->n_shards, h->max_path, h->full, h->nv, st, (long)P, H, h->nu,
                                                   d_weights, (const float*)d_noise, (float*)d_costs, (float*)d_actions, (float*)d_obs,
-                                                  (float*)d_next_obs, h->diag, s, nullptr, d_weights, nullptr, nss);
+                                                  (float*)d_next_obs, h->diag, s, nullptr, d_weights, nullptr, nss, h->gen);
         else
             e = mjmpc::launch_tree_rollout<double>(h->model_f64, h->n_shards, h->max_path, h->full, h->nv, st, (long)P, H, h->nu,
                                                    d_weights, (const double*)d_noise, (double*)d_costs, (double*)d_actions,
-                                                   (double*)d_obs, (double*)d_next_obs, h->diag, s, nullptr, d_weights, nullptr, nss);
+                                                   (double*)d_obs, (double*)d_next_obs, h->diag, s, nullptr, d_weights, nullptr, nss, h->gen);
     }
     if (e != hipSuccess) return hip_fail(e, "tree_rollout_cl launch");
     return 0;
@@ -715,10 +770,10 @@ int mjmpc_tree_step_state(mjmpc_tree_t h, int dtype, const double* d_action, voi
     // one particle, one env step, no noise, shard 0's model; the state vector is advanced in place
     if (dtype == MJMPC_F32)
         e = mjmpc::launch_tree_rollout<float>(h->model_f32, 1, h->max_path, h->full, h->nv, h->state, 1, 1, h->nu, d_action, nullptr,
-                                              (float*)d_cost, nullptr, nullptr, (float*)d_next_obs, h->diag, s, h->state);
+                                              (float*)d_cost, nullptr, nullptr, (float*)d_next_obs, h->diag, s, h->state, nullptr, nullptr, 1, h->gen);
     else if (dtype == MJMPC_F64)
         e = mjmpc::launch_tree_rollout<double>(h->model_f64, 1, h->max_path, h->full, h->nv, h->state, 1, 1, h->nu, d_action, nullptr,
-                                               (double*)d_cost, nullptr, nullptr, (double*)d_next_obs, h->diag, s, h->state);
+                                               (double*)d_cost, nullptr, nullptr, (double*)d_next_obs, h->diag, s, h->state, nullptr, nullptr, 1, h->gen);
     else
         return fail(MJMPC_E_BADARG, "unknown dtype %d", dtype);
     if (e != hipSuccess) return hip_fail(e, "tree_step_state launch");
@@ -728,11 +783,10 @@ int mjmpc_tree_step_state(mjmpc_tree_t h, int dtype, const double* d_action, voi
 int mjmpc_tree_get_state(mjmpc_tree_t h, double* qpos, double* qvel, void* stream) {
     if (!h || !qpos || !qvel) return fail(MJMPC_E_BADARG, "null argument");
     HIP_TRY(hipSetDevice(h->device));
-    double st[MJMPC_TREE_STATE_LEN];
+    double st[MJMPC_TREE_DEVICE_STATE_LEN];
     HIP_TRY(hipMemcpyAsync(st, h->state, sizeof(st), hipMemcpyDeviceToHost, (hipStream_t)stream));
     HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
-    std::memcpy(qpos, st, sizeof(double) * h->nv);
-    std::memcpy(qvel, st + mjmpc::TL, sizeof(double) * h->nv);
+    tree_unpack_state(h, st, qpos, qvel);
     return 0;
 }
 

@@ -88,10 +88,35 @@ enum TreeOffset : int {
     T_N_ROUNDS = T_DEPTH + TL,          // max height + 1
     T_ELIM,                             // 31 x 32, [entry][lane]: my descendants sorted by height, packed
                                         // k | distance << 8 | height << 16; -1 terminates the list
-    TREE_BLOB_LEN = T_ELIM + (TL - 1) * TL
+    // ---- constants of the GENERAL instantiation (round 4): ball / free joints, friction loss, boxes, equalities, tendon
+    // limits.  Models that need none of it (T_GEN = 0) run the instantiations of the earlier rounds, which never read this.
+    T_GEN = T_ELIM + (TL - 1) * TL,     // 1: the model needs the general instantiation
+    T_NQ,                               // entries of MuJoCo's qpos (a ball joint: 4 for 3 dofs, a free joint 7 for 6)
+    T_HAS_BALL,
+    T_FSOL_K,                           // friction-loss rows: solreffriction / solimpfriction as {K, B, dmin, dmax, width, mid, power}
+    T_FRICTIONLOSS = T_FSOL_K + 7,      // 32: dry friction per dof (0: no row)
+    T_QADR = T_FRICTIONLOSS + TL,       // 32: the link's entry in qpos (BALL_X link: the quaternion's w); -1: none
+    T_QOFF = T_QADR + TL,               // 32: added to the link's coordinate in qpos (free joint translations: the body position)
+    T_PEXT = T_QOFF + TL,               // TREE_MAX_SPHERES x TREE_PEXT_STRIDE: what the new record kinds need beyond [24]
+    TREE_BLOB_LEN = T_PEXT + TREE_MAX_SPHERES * 24
 };
+constexpr int TREE_PEXT_STRIDE = 24;    // [0:3] box half sizes, [3:12] box orientation in its link's frame | dof row: [0] 0 joint
+                                        // equality / 1 tendon limit, [1] coef A (joint equality: 1 = anchor dof is joint 2),
+                                        // [2] coef B, [3:5] range, [5] margin, [6:11] polycoef | [12:19] the row's own solver
+                                        // set (equalities), [19] bilateral, [20] connect: sign of (body 1 - body 2)
+// link kinds (T_JTYPE): a ball joint is three links - the first holds the quaternion and turns the frame, the others ride
+// along with the body's own y / z axes; a free joint is three slides along the world axes and a ball
+enum TreeLinkKind : int { LINK_HINGE = 1, LINK_SLIDE = 2, LINK_BALL_X = 3, LINK_BALL_Y = 4, LINK_BALL_Z = 5 };
+// contact-record kinds ([12])
+enum TreePointKind : int { PT_PLANE = 0, PT_SEGSEG = 1, PT_SPHERE_BOX = 2, PT_BOX_SPHERE = 3, PT_CONNECT = 4, PT_DOFROW = 5 };
 
-constexpr int TREE_STATE_LEN = 2 * TL + 6;   // qpos[32] | qvel[32] | target[3] | site of the fresh observation[3]
-static_assert(TREE_BLOB_LEN == 3116, "keep in sync with mjmpc_amd/models/compile_tree.py::TREE_LAYOUT");
+// device state: qpos[32] | qvel[32] | target[3] | site of the fresh observation[3] | quaternion w[32], one entry per LINK
+// (a BALL_X link keeps x, y, z in the qpos entries of its three links and w in its own w entry)
+constexpr int TREE_STATE_LEN = 3 * TL + 6;
+constexpr int TREE_QW = 2 * TL + 6;
+constexpr int TREE_NQ_MAX = 40;
+// the C ABI's state vectors (mjmpc_tree_set_shard_states): MuJoCo's layout - qpos[40] | qvel[32] | target[3] | reserved[3]
+constexpr int TREE_PUBLIC_STATE_LEN = TREE_NQ_MAX + TL + 6;
+static_assert(TREE_BLOB_LEN == 3606, "keep in sync with mjmpc_amd/models/compile_tree.py::TREE_LAYOUT");
 
 }  // namespace mjmpc

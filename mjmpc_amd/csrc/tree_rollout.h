@@ -10,7 +10,8 @@ namespace mjmpc {
 // consecutive particles (dynamics randomization).  state_out (P = 1 only): the particle's final qpos / qvel are written
 // there in the layout of `state` (the device-resident real env).  clw: closed_loop_linear weights f64 [(d_obs + 1)][A]
 // instead of `mean` (the fresh observation's site is read from state[2 * 32 + 3 ...], which a P = 1 launch with site_out
-// pointing there provides).  model: TREE_BLOB_LEN scalars of T; state: f64 [qpos(32) | qvel(32) | target(3)];
+// pointing there provides).  model: TREE_BLOB_LEN scalars of T; state: f64 TREE_STATE_LEN (tree_model.h);
+// gen: the model block asks for the general instantiation (T_GEN: ball / free joints, friction loss, boxes, equalities);
 // mean f64 [H][A]; noise / cost / act / obs / nobs of T in the reference's C-order layouts (may be null except cost).
 // n_state_shards > 1: `state` holds one TREE_STATE_LEN vector per shard (per-worker start states); with both kinds of
 // shards their counts must agree.
@@ -18,6 +19,6 @@ template <typename T>
 hipError_t launch_tree_rollout(const T* model, int n_model_shards, int max_path, bool full, int nv, const double* state, long P, int H,
                                int A, const double* mean, const T* noise, T* cost, T* act, T* obs, T* nobs, unsigned* diag,
                                hipStream_t stream, double* state_out = nullptr, const double* clw = nullptr,
-                               double* site_out = nullptr, int n_state_shards = 1);
+                               double* site_out = nullptr, int n_state_shards = 1, bool gen = false);
 
 }  // namespace mjmpc

@@ -111,13 +111,16 @@ constexpr int a_vec(int DP, int PL) {
 // contact Jacobian rows [NS][NJ][DP], PATH-INDEXED like the matrix rows: a contact point on link L moves only with the
 // dofs on L's path to the root, entry c belongs to L's ancestor at distance c (a quarter of a [32]-lane row at DP = 8)
 constexpr int a_jc(int DP, int PL) { return a_vec(DP, PL) + PL; }
-constexpr int CS = 15;      // per contact point: sphere centre (lean instantiation) / contact point (full)[3], dist, D, aref
+constexpr int CS_BASE = 15; // per contact point: sphere centre (lean instantiation) / contact point (full)[3], dist, D, aref
                             // (normal part), mu B Jt1.v, mu B Jt2.v, [8:11] contact normal (geom-geom; after the Newton
                             // iteration: the point's force sums on Jn, mu Jt1, mu Jt2), [11:14] first tangent of the
                             // contact frame (mju_makeFrame from the normal and the capsule axis), -
+// general instantiation: five more scalars per record - [15:18] the three rows' D of a connect equality (their reference
+// accelerations in [5:8]; the two anchors in [0:3] and [11:14]), [18:20] spare
+constexpr int CS_GEN = 20;
 constexpr int a_cs(int DP, int NS, int NJ, int PL) { return a_jc(DP, PL) + NS * NJ * DP; }
-constexpr int a_misc(int DP, int NS, int NJ, int PL) { return a_cs(DP, NS, NJ, PL) + NS * CS; }   // site[3]
-constexpr int a_row2(int DP, int NS, int NJ, int PL) { return a_misc(DP, NS, NJ, PL) + 8; }     // the Euler matrix's factor
+constexpr int a_misc(int DP, int NS, int NJ, int PL, int CSZ = CS_BASE) { return a_cs(DP, NS, NJ, PL) + NS * CSZ; }   // site[3]
+constexpr int a_row2(int DP, int NS, int NJ, int PL, int CSZ = CS_BASE) { return a_misc(DP, NS, NJ, PL, CSZ) + 8; }     // the Euler matrix's factor
 // the full instantiation with rows of up to 16 entries factors the Euler matrix beside the first Newton matrix (two
 // 32-entry rows do not fit the register file; the lean instantiation runs the large launches, where the second row area
 // would cost a resident workgroup per CU: 65536 x 64 on the hand 77 -> 129 ms - as it would in the f32 launches with 16
@@ -126,8 +129,8 @@ constexpr int a_row2(int DP, int NS, int NJ, int PL) { return a_misc(DP, NS, NJ,
 constexpr bool merge_factor(int DP, bool fric, int scalar_bytes, int PL, int DN = 0) {
     return DN == 0 && (fric || DP <= 8) && DP <= 16 && !(scalar_bytes == 4 && PL == 16) && !(scalar_bytes == 8 && DP > 8);
 }
-constexpr int a_len(int DP, int NS, int NJ, int PL, int scalar_bytes, int DN = 0) {
-    return a_row2(DP, NS, NJ, PL) + (merge_factor(DP, NJ == 3, scalar_bytes, PL, DN) ? row_stride(DP) * PL : 0);
+constexpr int a_len(int DP, int NS, int NJ, int PL, int scalar_bytes, int DN = 0, int CSZ = CS_BASE) {
+    return a_row2(DP, NS, NJ, PL, CSZ) + (merge_factor(DP, NJ == 3, scalar_bytes, PL, DN) ? row_stride(DP) * PL : 0);
 }
 static_assert(TILE_STRIDE * 16 <= a_vec(8, 16), "the dense tile lives in the (otherwise unused) row area");
 
@@ -837,15 +840,24 @@ __device__ __forceinline__ T dense_solve(const T* r, T dinv, T b, int l) {
 // brings its limit row (Dl, rl, drl) and, as the owner of a contact point, that point's rows (Dc, rb[], drb[]).  Bisection
 // to 2^-24, then the secant between the last bracket (exact when no row switches inside it).  A function of its own,
 // not inlined: it runs in a few particle-substeps per million and must not cost the kernel's hot path registers.
-template <int PL, int NR, typename T>
-__device__ __noinline__ T exact_line_search(T g0, T dg, T Dl, T rl, T drl, T Dc, const T* rb, const T* drb) {
+// General instantiation (GEN): a point's rows may carry their own D (Dk: a connect equality) and be BILATERAL (bil: cost
+// 1/2 D r^2 on both sides), and every lane brings its friction-loss row (Df, bound ff, residual rf + al drf: the slope of
+// the Huber cost is D r clamped to +-ff).
+template <int PL, int NR, bool GEN, typename T>
+__device__ __noinline__ T exact_line_search(T g0, T dg, T Dl, T rl, T drl, T Dc, const T* rb, const T* drb, const T* Dk, bool bil,
+                                            T Df, T ff, T rf, T drf) {
     auto phi = [&](T al) -> T {
         const T r = rl + al * drl;
         T tsum = Dl * (r < T(0) ? r : T(0)) * drl;
 #pragma unroll
         for (int k = 0; k < NR; ++k) {
             const T rr = rb[k] + al * drb[k];
-            tsum += Dc * (rr < T(0) ? rr : T(0)) * drb[k];
+            if constexpr (GEN) tsum += (Dk ? Dk[k] : Dc) * ((bil || rr < T(0)) ? rr : T(0)) * drb[k];
+            else tsum += Dc * (rr < T(0) ? rr : T(0)) * drb[k];
+        }
+        if constexpr (GEN) {
+            const T sl = Df * (rf + al * drf);
+            tsum += fmin(fmax(sl, -ff), ff) * drf;
         }
         return g0 + al * dg + sum_lanes<PL>(tsum);
     };
@@ -869,7 +881,10 @@ constexpr int min_waves(int scalar_bytes, int DP, bool fric) {
 
 // PL = lanes per particle: 32, or 16 for models of up to 16 dofs (four particles per wavefront, a particle = one DPP row)
 // DN > 0 (with PL = 16): the dense in-register factorisation of a matrix of up to DN dofs instead of the tree-sparse one
-template <typename T, int DP, int NS, bool FRIC, int PL, int DN>
+// GEN: the general instantiation (round 4) - ball / free joints (quaternion links), friction-loss rows, sphere / box pairs,
+// static geoms, connect / joint equalities, fixed-tendon limits.  Models that need none of it run GEN = false, whose code
+// is the earlier rounds' to the instruction.
+template <typename T, int DP, int NS, bool FRIC, int PL, int DN, bool GEN = false>
 __global__ __launch_bounds__(64 * wg_waves(DP, FRIC, sizeof(T), PL), min_waves(sizeof(T), DP, FRIC)) void tree_rollout_kernel(
     const T* __restrict__ model_all, int model_stride, const double* __restrict__ state, int state_stride, long P, long shard_size, int H,
     int A, const double* __restrict__ mean,
@@ -882,14 +897,17 @@ __global__ __launch_bounds__(64 * wg_waves(DP, FRIC, sizeof(T), PL), min_waves(s
     constexpr int NJ = FRIC ? 3 : 1;        // Jacobian rows kept per contact point: normal (+ two tangents)
     constexpr int NR = FRIC ? 4 : 1;        // constraint rows per contact point: Jn (+- mu Jt_k)
     typedef typename std::conditional<FRIC, unsigned long long, unsigned>::type mask_t;    // NR bits per contact point
-    constexpr int A_VEC = a_vec(DP, PL), A_JC = a_jc(DP, PL), A_CS = a_cs(DP, NS, NJ, PL), A_MISC = a_misc(DP, NS, NJ, PL),
-                  A_ROW2 = a_row2(DP, NS, NJ, PL), A_LEN = a_len(DP, NS, NJ, PL, sizeof(T), DN);
+    static_assert(!GEN || FRIC, "the general instantiation extends the full one");
+    constexpr int CS = GEN ? CS_GEN : CS_BASE;
+    constexpr int A_VEC = a_vec(DP, PL), A_JC = a_jc(DP, PL), A_CS = a_cs(DP, NS, NJ, PL), A_MISC = a_misc(DP, NS, NJ, PL, CS),
+                  A_ROW2 = a_row2(DP, NS, NJ, PL, CS), A_LEN = a_len(DP, NS, NJ, PL, sizeof(T), DN, CS);
     static_assert(DN == 0 || (PL == 16 && DN <= 16 && DP <= DN), "dense rows: one particle = one DPP row");
     constexpr bool MERGE = merge_factor(DP, FRIC, sizeof(T), PL, DN);
     constexpr int NBLOB = T_TOPO;           // the constants the loop reads; topology tables are read once, from global memory
     __shared__ __attribute__((aligned(16))) T lds[NBLOB + 1 + PPW * WG_WAVES * A_LEN];
     __shared__ int ELIM[(PL - 1) * PL];     // elimination lists
     __shared__ int AT[DP * PL];             // AT[c * PL + l] = ancestor of link l at distance c IN THE ELIMINATION TREE (-1 beyond the root)
+    __shared__ T PEXT[GEN ? TREE_MAX_SPHERES * TREE_PEXT_STRIDE : 1];      // (GEN) what the new record kinds need beyond [24]
     // gridDim.y shards of shard_size consecutive particles (the reference's workers); a workgroup never straddles two.
     // Dynamics randomization (SubprocVecEnv.randomize_dynamics) gives each its own model block (model_stride != 0),
     // a per-worker set_env_state (subproc_vec_env.py:242-251) its own start state (state_stride != 0).
@@ -899,6 +917,8 @@ __global__ __launch_bounds__(64 * wg_waves(DP, FRIC, sizeof(T), PL), min_waves(s
     for (int k = threadIdx.x; k < NBLOB; k += blockDim.x) M[k] = model[k];
     for (int k = threadIdx.x; k < (PL - 1) * PL; k += blockDim.x) ELIM[k] = (int)model[T_ELIM + (k / PL) * TL + (k % PL)];
     for (int k = threadIdx.x; k < PPW * WG_WAVES * A_LEN; k += blockDim.x) lds[NBLOB + 1 + k] = T(0);
+    if constexpr (GEN)
+        for (int k = threadIdx.x; k < TREE_MAX_SPHERES * TREE_PEXT_STRIDE; k += blockDim.x) PEXT[k] = model[T_PEXT + k];
     if (threadIdx.x < PL) {
         int a = threadIdx.x;
         for (int c = 0; c < DP; ++c) {
@@ -933,7 +953,8 @@ __global__ __launch_bounds__(64 * wg_waves(DP, FRIC, sizeof(T), PL), min_waves(s
     const int site_link = __builtin_amdgcn_readfirstlane((int)M[T_SITE_LINK]);
     const int n_sphere = __builtin_amdgcn_readfirstlane(min((int)M[T_N_SPHERE], NS));
     const int task = __builtin_amdgcn_readfirstlane((int)M[T_TASK]), obs_skip = __builtin_amdgcn_readfirstlane((int)M[T_OBS_SKIP]);
-    const int dobs = task == 1 ? 2 * nv - obs_skip : 2 * nv + 6;
+    const int nq = GEN ? __builtin_amdgcn_readfirstlane((int)model[T_NQ]) : nv;     // entries of MuJoCo's qpos
+    const int dobs = task == 1 ? nq + nv - obs_skip : nq + nv + 6;
     const bool slide = FRIC && (int)model[T_JTYPE + l] == 2;      // (slide joints, springs, a medium: the full instantiation only)
     const int act_id = (int)model[T_ACT + l];
     const bool fluid = FRIC && (M[T_DENSITY] > T(0) || M[T_VISCOSITY] > T(0));   // (the full instantiation only)
@@ -978,8 +999,26 @@ __global__ __launch_bounds__(64 * wg_waves(DP, FRIC, sizeof(T), PL), min_waves(s
     tp.jumps = __builtin_amdgcn_readfirstlane((int)M[T_JUMPS]);
     tp.ancmask = (unsigned)model[T_ANCMASK + l] | ((unsigned)model[T_ANCMASK + TL + l] << 16);
     const bool dof = l < nv;
+    // (GEN) my link's kind: a ball joint is three links - the first (BALL_X) holds the quaternion (q = x, qy, qz, qw) and
+    // turns the frame, the other two ride along (identity transform; their axes are the body's own y and z) - a free
+    // joint three slides along the world axes and a ball.  qadr / qoff: my coordinate's place in MuJoCo's qpos.
+    const int lkind = GEN ? (int)model[T_JTYPE + l] : 1;
+    const int ball_g = (GEN && dof && lkind >= LINK_BALL_X) ? lkind - LINK_BALL_X : -1;
+    const bool has_ball = GEN && __builtin_amdgcn_readfirstlane((int)model[T_HAS_BALL]) != 0;
+    const int qadr = GEN ? (int)model[T_QADR + l] : l;
+    const T qoff = GEN ? model[T_QOFF + l] : T(0);
+    const T floss = (GEN && dof) ? model[T_FRICTIONLOSS + l] : T(0);            // dry friction of my dof (0: no row)
+    const bool any_floss = GEN && __any(floss > T(0));
+    T fsol[7];                                                                  // friction-loss rows' solver set
+#pragma unroll
+    for (int k = 0; k < 7; ++k) fsol[k] = GEN ? model[T_FSOL_K + k] : T(0);
 
     T q = dof ? (T)state[l] : T(0), v = dof ? (T)state[TL + l] : T(0);
+    T qy = T(0), qz = T(0), qw = T(1);
+    if constexpr (GEN) {
+        if (ball_g == 0) { qy = (T)state[l + 1]; qz = (T)state[l + 2]; qw = (T)state[TREE_QW + l]; }
+        if (ball_g > 0) q = T(0);
+    }
     const T tgt[3] = {(T)state[2 * TL], (T)state[2 * TL + 1], (T)state[2 * TL + 2]};
     T sq, cq;
     sincos_(q, sq, cq);
@@ -988,11 +1027,13 @@ __global__ __launch_bounds__(64 * wg_waves(DP, FRIC, sizeof(T), PL), min_waves(s
     const T pn[3] = {M[T_PLANE_N], M[T_PLANE_N + 1], M[T_PLANE_N + 2]};
     const bool has_u = l < A;
     int lim_mem = 0;                // inst | act << 1 of my limit row in the previous substep
+    int fl_mem = 0;                 // (GEN) 1 | (state + 1) << 1 of my friction-loss row in the previous substep
     unsigned cinst_mem = 0;         // contact points of the previous substep ...
     mask_t cact_mem = 0;            // ... and which of their rows were active
     // closed_loop_linear (gym_env_wrapper.py:135-136): the first action needs the site of the fresh observation, which
     // a one-particle launch left in the state vector beforehand (site_out below, mjmpc_tree_rollout_cl)
     T hand_prev[3] = {T(0), T(0), T(0)}, q_prev = q, v_prev = v;
+    T qy_prev = qy, qz_prev = qz, qw_prev = qw;
     if (clw)
         for (int k = 0; k < 3; ++k) hand_prev[k] = (T)state[2 * TL + 3 + k];
     TreeClock clk;
@@ -1061,6 +1102,21 @@ __global__ __launch_bounds__(64 * wg_waves(DP, FRIC, sizeof(T), PL), min_waves(s
                     for (int k = 0; k < 9; ++k) R[k] = (k & 3) == 0 ? T(1) : T(0);
                     for (int k = 0; k < 3; ++k) p[k] += ax[k] * q;
                 }
+                if constexpr (GEN) {
+                    if (ball_g > 0) {                   // the ball's second and third link: no transform of their own
+                        for (int k = 0; k < 9; ++k) R[k] = (k & 3) == 0 ? T(1) : T(0);
+                    } else if (ball_g == 0) {
+                        // MuJoCo's quaternion has its vector part in the BODY frame; link frames are world-aligned at qpos0, where
+                        // the body's axes are the three links' axes: v_w = x ax_x + y ax_y + z ax_z, R = quat2mat(w, v_w)
+                        T vw[3];
+                        for (int k = 0; k < 3; ++k)
+                            vw[k] = q * ax[k] + qy * M[T_AXIS + k * TL + l + 1] + qz * M[T_AXIS + k * TL + l + 2];
+                        const T w_ = qw, x_ = vw[0], y_ = vw[1], z_ = vw[2];
+                        R[0] = T(1) - T(2) * (y_ * y_ + z_ * z_); R[1] = T(2) * (x_ * y_ - w_ * z_); R[2] = T(2) * (x_ * z_ + w_ * y_);
+                        R[3] = T(2) * (x_ * y_ + w_ * z_); R[4] = T(1) - T(2) * (x_ * x_ + z_ * z_); R[5] = T(2) * (y_ * z_ - w_ * x_);
+                        R[6] = T(2) * (x_ * z_ - w_ * y_); R[7] = T(2) * (y_ * z_ + w_ * x_); R[8] = T(1) - T(2) * (x_ * x_ + y_ * y_);
+                    }
+                }
             }
 #pragma unroll
             for (int k = 0; k < 5; ++k) {
@@ -1107,6 +1163,7 @@ __global__ __launch_bounds__(64 * wg_waves(DP, FRIC, sizeof(T), PL), min_waves(s
                 for (int c = 0; c < 9; ++c) X[c * PL + l] = R[c];
 #pragma unroll
                 for (int c = 0; c < 3; ++c) X[(9 + c) * PL + l] = p[c];
+                if constexpr (GEN) VEC[l] = q;          // (dof rows read their joints' coordinates)
                 TSYNC();
                 if (l < n_sphere) {
                     const T* sp = M + T_SPH + l * TREE_SPH_STRIDE;
@@ -1142,18 +1199,129 @@ __global__ __launch_bounds__(64 * wg_waves(DP, FRIC, sizeof(T), PL), min_waves(s
                         } else {
                             for (int k = 0; k < 3; ++k) cs[k] = ctr[k];
                         }
+                    } else if (GEN && sp[12] == T(PT_DOFROW)) {
+                        // a row over one or two joint coordinates (anchor dof A = sp[0], the other, B, above it): a joint
+                        // equality q1 = poly(q2) (always there, bilateral) or a fixed-tendon limit on cA qA + cB qB
+                        const T* ex = PEXT + l * TREE_PEXT_STRIDE;
+                        const int dB = (int)sp[13];
+                        const T qA = VEC[sl], qB = dB >= 0 ? VEC[dB] : T(0);
+                        if (ex[0] == T(0)) {
+                            const bool swapped = ex[1] != T(0);         // the anchor dof is joint 2, joint 1 rides above it
+                            const T x = swapped ? qA : qB, q1 = swapped ? qB : qA;
+                            const T poly = ex[6] + x * (ex[7] + x * (ex[8] + x * (ex[9] + x * ex[10])));
+                            const T dpoly = ex[7] + x * (T(2) * ex[8] + x * (T(3) * ex[9] + x * T(4) * ex[10]));
+                            cs[3] = q1 - poly;
+                            cs[0] = swapped ? -dpoly : T(1);            // entry of dof A, of dof B
+                            cs[1] = swapped ? T(1) : (dB >= 0 ? -dpoly : T(0));
+                            ci_mine = true;
+                        } else {
+                            const T len = ex[1] * qA + ex[2] * qB, dlo = len - ex[3], dhi = ex[4] - len;
+                            const bool lo = dlo < ex[5], hi = !lo && dhi < ex[5];
+                            const T sg = lo ? T(1) : T(-1);
+                            cs[3] = lo ? dlo : dhi;
+                            cs[0] = sg * ex[1];
+                            cs[1] = sg * ex[2];
+                            ci_mine = lo || hi;
+                        }
+                        for (int k = 0; k < 3; ++k) { cs[8 + k] = T(0); cs[11 + k] = T(0); }
+                    } else if (GEN && sp[12] == T(PT_CONNECT)) {
+                        // connect equality: the anchor as a point of body A and as a point of body B (-1: the world)
+                        const int sb = (int)sp[13];
+                        mv3(Rl, sp + 1, tv);
+                        for (int k = 0; k < 3; ++k) cs[k] = pl[k] + tv[k];
+                        if (sb >= 0) {
+                            T Rb[9];
+#pragma unroll
+                            for (int c = 0; c < 9; ++c) Rb[c] = X[c * PL + sb];
+                            mv3(Rb, sp + 14, tv);
+                            for (int k = 0; k < 3; ++k) cs[11 + k] = X[(9 + k) * PL + sb] + tv[k];
+                        } else {
+                            for (int k = 0; k < 3; ++k) cs[11 + k] = sp[14 + k];
+                        }
+                        cs[3] = T(0);
+                        ci_mine = true;
+                    } else if (GEN && (sp[12] == T(PT_SPHERE_BOX) || sp[12] == T(PT_BOX_SPHERE))) {
+                        // a sphere against a box (mjc_SphereBox): the box's closest point to the sphere's centre, or - centre
+                        // inside - the nearest face; normal from geom B to geom A, contact point midway between the surfaces
+                        const bool boxA = sp[12] == T(PT_BOX_SPHERE);
+                        const int sb = (int)sp[13];
+                        const T* ex = PEXT + l * TREE_PEXT_STRIDE;
+                        T Rb[9], oA[3], oB[3];
+#pragma unroll
+                        for (int c = 0; c < 9; ++c) Rb[c] = sb >= 0 ? X[c * PL + sb] : ((c & 3) == 0 ? T(1) : T(0));
+                        mv3(Rl, sp + 1, tv);
+                        for (int k = 0; k < 3; ++k) oA[k] = pl[k] + tv[k];
+                        mv3(Rb, sp + 14, tv);
+                        for (int k = 0; k < 3; ++k) oB[k] = (sb >= 0 ? X[(9 + k) * PL + sb] : T(0)) + tv[k];
+                        const T* Rx = boxA ? Rl : Rb;                       // the box's link
+                        const T* ob = boxA ? oA : oB;
+                        const T* os = boxA ? oB : oA;
+                        const T rs = boxA ? sp[17] : sp[4];
+                        T Rw[9];
+                        for (int i = 0; i < 3; ++i)
+                            for (int j = 0; j < 3; ++j)
+                                Rw[3 * i + j] = Rx[3 * i] * ex[3 + j] + Rx[3 * i + 1] * ex[6 + j] + Rx[3 * i + 2] * ex[9 + j];
+                        const T rel[3] = {os[0] - ob[0], os[1] - ob[1], os[2] - ob[2]};
+                        T loc[3], cl[3];
+                        bool inside = true;
+                        for (int i = 0; i < 3; ++i) {
+                            loc[i] = Rw[i] * rel[0] + Rw[3 + i] * rel[1] + Rw[6 + i] * rel[2];
+                            cl[i] = fmin(fmax(loc[i], -ex[i]), ex[i]);
+                            inside = inside && cl[i] == loc[i];
+                        }
+                        T nb[3] = {T(0), T(0), T(0)}, len;
+                        if (inside) {
+                            int kk = 0;
+                            T best = ex[0] - fabs(loc[0]);
+                            for (int i = 1; i < 3; ++i) {
+                                const T gap = ex[i] - fabs(loc[i]);
+                                if (gap < best) { best = gap; kk = i; }
+                            }
+                            const T sg = loc[kk] >= T(0) ? T(1) : T(-1);
+                            for (int i = 0; i < 3; ++i) {
+                                if (i == kk) cl[i] = sg * ex[i];
+                                nb[i] = sg * Rw[3 * i + kk];
+                            }
+                            len = -best;
+                        }
+                        T cb[3];
+                        mv3(Rw, cl, cb);
+                        for (int k = 0; k < 3; ++k) cb[k] += ob[k];
+                        bool ok = true;
+                        if (!inside) {
+                            for (int k = 0; k < 3; ++k) nb[k] = os[k] - cb[k];
+                            len = sqrt_(dot3(nb, nb));
+                            ok = len > T(1e-14);
+                            const T inv = ok ? T(1) / len : T(0);
+                            for (int k = 0; k < 3; ++k) nb[k] *= inv;
+                        }
+                        // nb points from the box to the sphere; the contact's normal from geom B to geom A
+                        const T sgn = boxA ? T(-1) : T(1);
+                        const T cdist = len - rs;
+                        T nv3[3];
+                        for (int k = 0; k < 3; ++k) {
+                            nv3[k] = sgn * nb[k];
+                            cs[8 + k] = nv3[k];
+                            // midway between the surfaces: from geom B's surface point along the normal
+                            const T onB = boxA ? os[k] + nv3[k] * rs : cb[k];
+                            cs[k] = onB + nv3[k] * (T(0.5) * cdist);
+                        }
+                        const T zero3[3] = {T(0), T(0), T(0)};
+                        frame_tangent(nv3, zero3, cs + 11);
+                        cs[3] = cdist;
+                        ci_mine = ok && cdist < sp[5];
                     } else {
                         // geom-geom (mjc_SphereSphere / SphereCapsule / CapsuleCapsule): closest points of the two
                         // segments; normal from the object's geom (B) to the manipulator's (A), point midway
                         const int sb = (int)sp[13];
                         T Rb[9], o1[3], d1[3], o2[3], d2[3];
 #pragma unroll
-                        for (int c = 0; c < 9; ++c) Rb[c] = X[c * PL + sb];
+                        for (int c = 0; c < 9; ++c) Rb[c] = (!GEN || sb >= 0) ? X[c * PL + sb] : ((c & 3) == 0 ? T(1) : T(0));
                         mv3(Rl, sp + 1, tv);
                         for (int k = 0; k < 3; ++k) o1[k] = pl[k] + tv[k];
                         mv3(Rl, sp + 8, d1);
                         mv3(Rb, sp + 14, tv);
-                        for (int k = 0; k < 3; ++k) o2[k] = X[(9 + k) * PL + sb] + tv[k];
+                        for (int k = 0; k < 3; ++k) o2[k] = ((!GEN || sb >= 0) ? X[(9 + k) * PL + sb] : T(0)) + tv[k];
                         mv3(Rb, sp + 18, d2);
                         T ss, tt;
                         {
@@ -1253,9 +1421,25 @@ __global__ __launch_bounds__(64 * wg_waves(DP, FRIC, sizeof(T), PL), min_waves(s
                 T xw[3] = {V[0], V[1], V[2]}, xv[3] = {V[3], V[4], V[5]};
                 path_sum<6, DP, PL, (DN > 0 ? DN : 16)>(V, tp, X, l);
                 T dw[3], d1[3], d2[3];
+                if (GEN && has_ball) {
+                    // a ball joint's three axes move with the BODY: sum_k d/dt(S_k) v_k = V_before x sum_k S_k v_k, V_before the
+                    // velocity in front of the joint (MuJoCo's mj_comVel takes all three cdof_dot with it) - my cumulative
+                    // velocity less my own and my group predecessors' contributions
+                    T Vb[6];
+#pragma unroll
+                    for (int c = 0; c < 6; ++c) {
+                        const T own = c < 3 ? xw[c] : xv[c - 3];
+                        const T s1 = __shfl_up(own, 1, PL), s2 = __shfl_up(own, 2, PL);
+                        Vb[c] = V[c] - own - (ball_g >= 1 ? s1 : T(0)) - (ball_g == 2 ? s2 : T(0));
+                    }
+                    cross3(Vb, xw, dw);
+                    cross3(Vb, xv, d1);
+                    cross3(Vb + 3, xw, d2);
+                } else {
                 cross3(V, xw, dw);
                 cross3(V, xv, d1);
                 cross3(V + 3, xw, d2);
+                }
                 for (int k = 0; k < 3; ++k) { Ac[k] = dw[k]; Ac[3 + k] = d1[k] + d2[k]; }
                 path_sum<6, DP, PL, (DN > 0 ? DN : 16)>(Ac, tp, X, l);
                 for (int k = 0; k < 3; ++k) Ac[3 + k] -= M[T_GRAVITY + k];          // base acceleration -g
@@ -1404,7 +1588,30 @@ __global__ __launch_bounds__(64 * wg_waves(DP, FRIC, sizeof(T), PL), min_waves(s
                 }
                 cross3(sw, r, g);
                 for (int k = 0; k < 3; ++k) g[k] += sv[k];
-                const T jc = oi >= 0 ? (FRIC ? side * dot3(nrm, g) : dot3(pn, g)) : T(0);
+                T jc = oi >= 0 ? (FRIC ? side * dot3(nrm, g) : dot3(pn, g)) : T(0);
+                T jgen1 = T(0), jgen2 = T(0);
+                bool genrow = false;
+                if constexpr (GEN) {
+                    const int kind = (int)sp[12];
+                    if (kind == PT_DOFROW) {            // my joint coordinate's coefficient
+                        genrow = true;
+                        jc = oi >= 0 ? (l == (int)sp[0] ? cs[0] : (l == (int)sp[13] ? cs[1] : T(0))) : T(0);
+                    } else if (kind == PT_CONNECT) {
+                        // rows along the world axes: what my dof moves body A's anchor, less what it moves body B's
+                        genrow = true;
+                        const int lA = (int)sp[0], lB = (int)sp[13];
+                        const T inA = (lA >= l && lA < l + tp.subsize) ? T(1) : T(0);
+                        const T inB = (lB >= l && lB < l + tp.subsize) ? T(1) : T(0);
+                        const T pB[3] = {cs[11], cs[12], cs[13]};
+                        T gB[3];
+                        cross3(sw, pB, gB);             // (r = cs[0:3] is A's anchor: g above)
+                        const T e0 = inA * g[0] - inB * (gB[0] + sv[0]), e1 = inA * g[1] - inB * (gB[1] + sv[1]),
+                                e2 = inA * g[2] - inB * (gB[2] + sv[2]);
+                        jc = oi >= 0 ? e0 : T(0);
+                        jgen1 = oi >= 0 ? e1 : T(0);
+                        jgen2 = oi >= 0 ? e2 : T(0);
+                    }
+                }
                 if (oi >= 0) jrow[oi] = jc;
                 if (ci && l > dsl && l < DP) jrow[l] = T(0);        // past the root: read by shorter paths' lanes
                 if constexpr (!FRIC) {      // (one frictionless row per point: a lane sum is cheaper than the walk below)
@@ -1422,7 +1629,8 @@ __global__ __launch_bounds__(64 * wg_waves(DP, FRIC, sizeof(T), PL), min_waves(s
                     T t2[3];
                     cross3(nrm, t1, t2);
                     const bool fr = oi >= 0 && sp[7] > T(0);
-                    const T j1 = fr ? side * dot3(t1, g) : T(0), j2 = fr ? side * dot3(t2, g) : T(0);
+                    T j1 = fr ? side * dot3(t1, g) : T(0), j2 = fr ? side * dot3(t2, g) : T(0);
+                    if (GEN && genrow) { j1 = jgen1; j2 = jgen2; }
                     if (oi >= 0) { jrow[DP + oi] = j1; jrow[2 * DP + oi] = j2; }
                     if (ci && l > dsl && l < DP) { jrow[DP + l] = T(0); jrow[2 * DP + l] = T(0); }
                 }
@@ -1450,15 +1658,37 @@ __global__ __launch_bounds__(64 * wg_waves(DP, FRIC, sizeof(T), PL), min_waves(s
                     }
                     const T mu = FRIC ? sp[7] : T(0);
                     T Dc, arc;
+                    const int kind = GEN ? (int)sp[12] : 0;
+                    if (GEN && kind == PT_CONNECT) {
+                        // three bilateral rows along the world axes, each with its own violation, D and reference acceleration
+                        const T* ex = PEXT + l * TREE_PEXT_STRIDE;
+                        const T jk[3] = {jv, j1v, j2v};
+#pragma unroll
+                        for (int k = 0; k < 3; ++k) {
+                            tree_row_params(ex + 12, cs[k] - cs[11 + k], sp[6], jk[k], Dc, arc);
+                            cs[15 + k] = Dc;
+                            cs[5 + k] = arc;
+                        }
+                        cs[4] = cs[15];
+                    } else if (GEN && kind == PT_DOFROW) {
+                        const T* ex = PEXT + l * TREE_PEXT_STRIDE;
+                        if (ex[0] == T(0)) tree_row_params(ex + 12, cs[3], sp[6], jv, Dc, arc);              // joint equality
+                        else tree_row_params(M + T_LSOL_K, cs[3] - sp[5], sp[6], jv, Dc, arc);               // tendon limit
+                        cs[4] = Dc;
+                        cs[5] = arc;
+                        cs[6] = T(0);
+                        cs[7] = T(0);
+                    } else {
                     tree_row_params(M + T_SOL_K, cs[3] - sp[5], sp[6] * (T(1) + mu * mu), jv, Dc, arc);
                     if (mu > T(0)) Dc *= T(0.5) * rcp_(mu * mu);
                     cs[4] = Dc;
                     cs[5] = arc;
                     if (FRIC) { cs[6] = mu * M[T_SOL_B] * j1v; cs[7] = mu * M[T_SOL_B] * j2v; }
+                    }
                 }
             }
             TSYNC();
-            const bool any_rows = !(TREE_SKIP & 1) && __any(inst || cinst != 0);
+            const bool any_rows = !(TREE_SKIP & 1) && (__any(inst || cinst != 0) || any_floss);
             T qfrc_c = T(0);
             T erow[MERGE ? DP : 1];      // factor of the Euler matrix when it was computed beside the first Newton factor
             clk.mark(3);
@@ -1472,7 +1702,35 @@ __global__ __launch_bounds__(64 * wg_waves(DP, FRIC, sizeof(T), PL), min_waves(s
                     aref = inst ? aref : T(0);
                 }
                 // rows of contact point s with friction mu (uniform per particle): all NR, else one
-                auto rows_of = [&](int s) -> unsigned { return (FRIC && M[T_SPH + s * TREE_SPH_STRIDE + 7] > T(0)) ? 15u : 1u; };
+                auto rows_of = [&](int s) -> unsigned {
+                    if (GEN && (int)M[T_SPH + s * TREE_SPH_STRIDE + 12] == PT_CONNECT) return 7u;
+                    return (FRIC && M[T_SPH + s * TREE_SPH_STRIDE + 7] > T(0)) ? 15u : 1u;
+                };
+                // (GEN) my record's kind; bilateral records (equalities) keep all their rows active on both sides
+                const int my_kind = (GEN && l < NS) ? (int)M[T_SPH + l * TREE_SPH_STRIDE + 12] : 0;
+                const bool my_bil = GEN && l < NS && PEXT[(l < NS ? l : 0) * TREE_PEXT_STRIDE + 19] != T(0);
+                // (GEN) my dof's friction-loss row: J = e_l, pos = 0 -> D from the impedance at 0, aref = -B v
+                T Df = T(0), areff = T(0);
+                int fstate = 0;                     // -1: r <= -R f (force +f), 0: quadratic zone, +1: r >= R f (force -f)
+                if (GEN && any_floss) {
+                    tree_row_params(fsol, T(0), M[T_DOF_INVW + l], v, Df, areff);
+                    Df = floss > T(0) ? Df : T(0);
+                    fstate = (fl_mem & 1) ? (fl_mem >> 1) - 1 : 0;
+                    fstate = floss > T(0) ? fstate : 0;
+                }
+                auto fl_state_of = [&](T xa_, int cur) -> int {
+                    if (!(floss > T(0))) return 0;
+                    const T sl = Df * (xa_ - areff);
+                    // f32: a slope within rounding of the bound keeps its zone
+                    const T bc = sizeof(T) == 4 ? T(2e-5) * (fabs(sl) + floss) : T(0);
+                    if (cur < 0) return sl > -floss + bc ? (sl >= floss ? 1 : 0) : -1;
+                    if (cur > 0) return sl < floss - bc ? (sl <= -floss ? -1 : 0) : 1;
+                    return sl <= -floss - bc ? -1 : (sl >= floss + bc ? 1 : 0);
+                };
+                auto fl_force = [&](T xa_, int st) -> T {        // -s'(r) of the Huber cost
+                    if (!(floss > T(0))) return T(0);
+                    return st == 0 ? -Df * (xa_ - areff) : (st < 0 ? floss : -floss);
+                };
                 // POINT-PARALLEL residuals: lane s owns contact point s.  The solution goes through the broadcast vector; the
                 // owner walks the point's path-indexed Jacobians (entry c belongs to the ancestor at distance c of the
                 // point's link in the elimination tree) - one pass for all points instead of three lane sums per point.
@@ -1502,6 +1760,7 @@ __global__ __launch_bounds__(64 * wg_waves(DP, FRIC, sizeof(T), PL), min_waves(s
                     res[0] = an - cs[5];
                     if (FRIC) {
                         const T mu = M[T_SPH + (l < NS ? l : 0) * TREE_SPH_STRIDE + 7];
+                        const T c1 = a1, c2 = a2;
                         a1 *= mu;
                         a2 *= mu;
                         res[0] = an + a1 - (cs[5] - cs[6]);
@@ -1509,6 +1768,12 @@ __global__ __launch_bounds__(64 * wg_waves(DP, FRIC, sizeof(T), PL), min_waves(s
                         res[2 % NR] = an + a2 - (cs[5] - cs[7]);
                         res[3 % NR] = an - a2 - (cs[5] + cs[7]);
                         if (!(mu > T(0))) res[0] = an - cs[5];
+                        if (GEN && my_kind == PT_CONNECT) {         // three independent rows, one per Jacobian
+                            res[0] = an - cs[5];
+                            res[1 % NR] = c1 - cs[6];
+                            res[2 % NR] = c2 - cs[7];
+                            res[3 % NR] = T(0);
+                        }
                     }
                     TSYNC();
                 };
@@ -1525,7 +1790,7 @@ __global__ __launch_bounds__(64 * wg_waves(DP, FRIC, sizeof(T), PL), min_waves(s
                             // f32: a row whose residual is within rounding of zero keeps its state (as in arm_rollout.hip)
                             const T bc = sizeof(T) == 4 ? T(2e-5) * (fabs(ar5) + fabs(arr + ar5) + T(1)) : T(0);
                             const bool was = (cur >> (l * NR + r)) & 1u;
-                            if (((rows >> r) & 1u) && (was ? !(arr > bc) : (arr < -bc))) nb |= 1u << r;
+                            if (((rows >> r) & 1u) && (my_bil || (was ? !(arr > bc) : (arr < -bc)))) nb |= 1u << r;
                         }
                     }
                     if constexpr (NR == 1) {
@@ -1538,8 +1803,9 @@ __global__ __launch_bounds__(64 * wg_waves(DP, FRIC, sizeof(T), PL), min_waves(s
                 };
                 // J' f of the rows of the set (act_, cact_) at the acceleration whose owner residuals are res (friction
                 // instantiation): the owners sum their rows' forces per Jacobian into cs[8:11], every dof collects its entries
-                auto force_of = [&](T xa_, const T* res, bool act_, mask_t cact_) -> T {
+                auto force_of = [&](T xa_, const T* res, bool act_, mask_t cact_, int fst_) -> T {
                     T qf = act_ ? -D * (sig * xa_ - aref) * sig : T(0);
+                    if constexpr (GEN) qf += fl_force(xa_, fst_);
                     if (ucinst != 0) {
                         if (my_pt) {
                             const unsigned bits = (unsigned)(cact_ >> (l * NR)) & ((1u << NR) - 1u);
@@ -1559,6 +1825,11 @@ __global__ __launch_bounds__(64 * wg_waves(DP, FRIC, sizeof(T), PL), min_waves(s
                             cs[8] = fn;
                             cs[9] = mu * f1;
                             cs[10] = mu * f2;
+                            if (GEN && my_kind == PT_CONNECT) {     // f_k = -D_k r_k on the three Jacobians
+                                cs[8] = -cs[15] * res[0];
+                                cs[9] = -cs[16] * res[1 % NR];
+                                cs[10] = -cs[17] * res[2 % NR];
+                            }
                         }
                         TSYNC();
                         for (unsigned um = ucinst; um; um &= um - 1) {
@@ -1608,6 +1879,7 @@ __global__ __launch_bounds__(64 * wg_waves(DP, FRIC, sizeof(T), PL), min_waves(s
                 }
                 bool changed = true, act_pp = false;
                 mask_t cact_pp = 0;
+                int fst_pp = 0;
                 constexpr int LS_START = 5;         // iterations before the safeguard takes over (friction instantiation)
                 bool ls_on = false;
                 T a_b = T(0), g_b = T(0), rb[NR];
@@ -1618,15 +1890,17 @@ __global__ __launch_bounds__(64 * wg_waves(DP, FRIC, sizeof(T), PL), min_waves(s
                 for (int it = 0; it < TREE_MAXIT; ++it) {
                     T hrow[DP];
                     T hd[DN > 0 ? DN : 1], hdinv = T(1);        // DN > 0: my dense row of H, then of its factor
+                    const T Dfq = (GEN && fstate == 0) ? Df : T(0);     // the friction-loss row in its quadratic zone
                     if constexpr (DN > 0) {
 #pragma unroll
-                        for (int j = 0; j < DN; ++j) hd[j] = md[j] + ((j == l && actv) ? D : T(0));
+                        for (int j = 0; j < DN; ++j) hd[j] = md[j] + ((j == l && actv) ? D : T(0)) + (j == l ? Dfq : T(0));
                     } else {
 #pragma unroll
                         for (int c = 0; c < DP; ++c) hrow[c] = mrow[c];
-                        hrow[0] += actv ? D : T(0);
+                        hrow[0] += (actv ? D : T(0)) + Dfq;
                     }
                     T rhs = tau + (actv ? D * sig * aref : T(0));
+                    if constexpr (GEN) rhs += fstate == 0 ? Dfq * areff : (fstate < 0 ? floss : -floss);
                     for (unsigned um = ucinst; um; um &= um - 1) {
                         const int s = __builtin_ctz(um);
                         const unsigned bits = (unsigned)(cact >> (s * NR)) & ((1u << NR) - 1u);
@@ -1654,6 +1928,15 @@ __global__ __launch_bounds__(64 * wg_waves(DP, FRIC, sizeof(T), PL), min_waves(s
                             rsum -= s1 * cs[6] + s2 * cs[7];
                             rhs += Dc * (j1 * (s1 * cs[5] - n1 * cs[6]) + j2 * (s2 * cs[5] - n2 * cs[7]));
                         }
+                        if (GEN && (int)M[T_SPH + s * TREE_SPH_STRIDE + 12] == PT_CONNECT) {
+                            // three independent bilateral rows: H += sum_k D_k J_k J_k', rhs += sum_k D_k aref_k J_k
+                            wn = cs[15] * jl;
+                            w1 = cs[16] * t1l;
+                            w2 = cs[17] * t2l;
+                            rhs += w1 * cs[6] + w2 * cs[7];
+                            rsum = cs[5];
+                            rhs += wn * rsum;
+                        } else
                         rhs += Dc * jl * rsum;
                         if constexpr (DN > 0) {
                             // dense row: H[l][j] += wn Jn[j] + w1 Jt1[j] + w2 Jt2[j], lane j's entries by DPP broadcast
@@ -1699,7 +1982,9 @@ __global__ __launch_bounds__(64 * wg_waves(DP, FRIC, sizeof(T), PL), min_waves(s
                     } else {
                         cact2 = next_set(xa, cact);
                     }
-                    changed = (act2 != actv) || (cact2 != cact);
+                    int fst2 = 0;
+                    if constexpr (GEN) fst2 = fl_state_of(xa, fstate);
+                    changed = (act2 != actv) || (cact2 != cact) || (GEN && fst2 != fstate);
                     // SAFEGUARD (friction instantiation).  The plain iteration - solve with the set, adopt the set the solution
                     // asks for - has no line search and can cycle when several friction pyramids switch rows together
                     // (periods 3 and 4 seen on the pen-in-hand model; the iterate kept then was arbitrary).  From iteration
@@ -1711,7 +1996,7 @@ __global__ __launch_bounds__(64 * wg_waves(DP, FRIC, sizeof(T), PL), min_waves(s
                     // point inherits it by the same interpolation; the residuals are affine in al.
                     if constexpr (FRIC) {
                         if (it >= LS_START && __any(changed)) {
-                            const T gN = force_of(xa, rN, actv, cact);      // M xa - tau = J' f of the set's rows (the solve's equation)
+                            const T gN = force_of(xa, rN, actv, cact, fstate);      // M xa - tau = J' f of the set's rows (the solve's equation)
                             if (!ls_on) {
                                 a_b = xa;
                                 g_b = gN;
@@ -1730,7 +2015,18 @@ __global__ __launch_bounds__(64 * wg_waves(DP, FRIC, sizeof(T), PL), min_waves(s
                                     T drb[NR];
 #pragma unroll
                                     for (int r = 0; r < NR; ++r) drb[r] = ((rows >> r) & 1u) ? rN[r] - rb[r] : T(0);
-                                    const T al = exact_line_search<PL, NR>(gbp, gNp - gbp, D, rl0, rl1 - rl0, Dc, rb, drb);
+                                    T al;
+                                    if constexpr (GEN) {
+                                        const T* Dk = (my_pt && my_kind == PT_CONNECT) ? X + A_CS + l * CS + 15 : nullptr;
+                                        T Dk3[NR];
+#pragma unroll
+                                        for (int r = 0; r < NR; ++r) Dk3[r] = (Dk && r < 3) ? Dk[r] : Dc;
+                                        al = exact_line_search<PL, NR, true>(gbp, gNp - gbp, D, rl0, rl1 - rl0, Dc, rb, drb, (const T*)Dk3, my_bil,
+                                                                             Df, floss, a_b - areff, pv);
+                                    } else {
+                                        al = exact_line_search<PL, NR, false>(gbp, gNp - gbp, D, rl0, rl1 - rl0, Dc, rb, drb, (const T*)nullptr, false,
+                                                                              T(0), T(0), T(0), T(0));
+                                    }
                                     a_b += al * pv;
                                     g_b += al * (gN - g_b);
 #pragma unroll
@@ -1739,6 +2035,7 @@ __global__ __launch_bounds__(64 * wg_waves(DP, FRIC, sizeof(T), PL), min_waves(s
                                     const T rlb = sig * a_b - aref;
                                     act2 = inst && (rlb < T(0));
                                     cact2 = rows_from_res(rb, cact);
+                                    if constexpr (GEN) fst2 = fl_state_of(xa, 0);
                                     changed = true;
                                 } else {
                                     a_b = xa;
@@ -1767,7 +2064,7 @@ __global__ __launch_bounds__(64 * wg_waves(DP, FRIC, sizeof(T), PL), min_waves(s
                             clk.count(20, nflip == 0u && ncf == 0u);     // only the other particle of the wave changed
                         }
 #endif
-                        if (!(FRIC && it >= LS_START) && !__any(cact2 != cact || nflip > 1u)) {
+                        if (!(FRIC && it >= LS_START) && !__any(cact2 != cact || nflip > 1u || (GEN && fst2 != fstate))) {
                             T zl;
                             if constexpr (DN > 0) zl = dense_solve<DN>(hd, hdinv, flip ? T(1) : T(0), l);
                             else zl = tree_solve<DP, PL>(hrow, flip ? T(1) : T(0), ELIM, AT, ROW, VEC, l, n_rounds, depth, max_depth, kt);
@@ -1789,17 +2086,20 @@ __global__ __launch_bounds__(64 * wg_waves(DP, FRIC, sizeof(T), PL), min_waves(s
                             const T band2 = sizeof(T) == 4 ? T(2e-5) * (fabs(aref) + fabs(xa) + T(1)) : T(0);
                             act2 = inst && (actv ? !(resl2 > band2) : (resl2 < -band2));
                             cact2 = next_set(xa, cact);
-                            changed = (act2 != actv) || (cact2 != cact);
+                            if constexpr (GEN) fst2 = fl_state_of(xa, fstate);
+                            changed = (act2 != actv) || (cact2 != cact) || (GEN && fst2 != fstate);
                         }
                     }
                     // f32 only: with accelerations of 1e4 rad/s^2 on gram-sized finger links a row can sit within
                     // rounding of its switching point and flip back and forth; a particle whose set returns to the one
                     // of two iterations ago has converged to working precision (either set gives the same forces)
-                    if (sizeof(T) == 4 && it >= 2 && act2 == act_pp && cact2 == cact_pp) changed = false;
+                    if (sizeof(T) == 4 && it >= 2 && act2 == act_pp && cact2 == cact_pp && (!GEN || fst2 == fst_pp)) changed = false;
                     act_pp = actv;
                     cact_pp = cact;
+                    fst_pp = fstate;
                     actv = act2;
                     cact = cact2;
+                    fstate = fst2;
                     clk.count(11, 1);
                     clk.lap(15);
                     if (!__any(changed)) break;
@@ -1810,6 +2110,7 @@ __global__ __launch_bounds__(64 * wg_waves(DP, FRIC, sizeof(T), PL), min_waves(s
                     if (l == 0 && mine != 0u) atomicAdd(diag, 1u);
                 }
                 lim_mem = (inst ? 1 : 0) | (actv ? 2 : 0);
+                if constexpr (GEN) fl_mem = floss > T(0) ? (1 | ((fstate + 1) << 1)) : 0;
                 cinst_mem = cinst;
                 cact_mem = cact;
                 qfrc_c = actv ? -D * (sig * xa - aref) * sig : T(0);
@@ -1825,10 +2126,11 @@ __global__ __launch_bounds__(64 * wg_waves(DP, FRIC, sizeof(T), PL), min_waves(s
                 } else {
                     T res[NR];
                     if (ucinst != 0) point_residuals(xa, res);
-                    qfrc_c = force_of(xa, res, actv, cact);
+                    qfrc_c = force_of(xa, res, actv, cact, fstate);
                 }
             } else {
                 lim_mem = 0;
+                fl_mem = 0;
                 cinst_mem = 0;
                 cact_mem = 0;
             }
@@ -1853,7 +2155,27 @@ __global__ __launch_bounds__(64 * wg_waves(DP, FRIC, sizeof(T), PL), min_waves(s
                 }
             }
             clk.mark(5);
-            if (dof) {
+            if (GEN && has_ball) {
+                // mj_integratePos of a ball joint: q <- q * exp(h w / 2), w = the joint's three velocities (body frame) - the
+                // first link gathers its followers' and owns the quaternion
+                const T vn = v + h * qacc;
+                const T wy = __shfl_down(vn, 1, PL), wz = __shfl_down(vn, 2, PL);
+                if (ball_g == 0) {
+                    const T nn = sqrt_(vn * vn + wy * wy + wz * wz);
+                    if (nn > T(1e-15)) {
+                        T sh, ch;
+                        sincos_(T(0.5) * h * nn, sh, ch);
+                        const T k = sh / nn, rx = vn * k, ry = wy * k, rz = wz * k;
+                        const T w2 = qw * ch - q * rx - qy * ry - qz * rz, x2 = qw * rx + q * ch + qy * rz - qz * ry,
+                                y2 = qw * ry - q * rz + qy * ch + qz * rx, z2 = qw * rz + q * ry - qy * rx + qz * ch;
+                        const T inv = T(1) / sqrt_(w2 * w2 + x2 * x2 + y2 * y2 + z2 * z2);
+                        qw = w2 * inv; q = x2 * inv; qy = y2 * inv; qz = z2 * inv;
+                    }
+                }
+            }
+            if (GEN && ball_g >= 0) {
+                v += h * qacc;
+            } else if (dof) {
                 v += h * qacc;
                 const T dq = h * v;
                 q += dq;
@@ -1886,35 +2208,54 @@ __global__ __launch_bounds__(64 * wg_waves(DP, FRIC, sizeof(T), PL), min_waves(s
                       (haxis[0] * M[T_TARGET_DIR] + haxis[1] * M[T_TARGET_DIR + 1] + haxis[2] * M[T_TARGET_DIR + 2]);
         }
         if (live && l == 0) cost[pid * H + t] = cst;
+        // my link's coordinate(s) in MuJoCo's qpos layout (GEN: a ball's first link writes the quaternion, w first; a free
+        // joint's translations are absolute positions; without GEN qadr = l, nq = nv)
+        auto put_q = [&](T* dst, long o, int skip, T x_, T y_, T z_, T w_) {
+            if (!dof || qadr < skip) return;
+            if (GEN && ball_g == 0) {
+                dst[o + qadr - skip] = w_;
+                dst[o + qadr - skip + 1] = x_;
+                dst[o + qadr - skip + 2] = y_;
+                dst[o + qadr - skip + 3] = z_;
+            } else if (!GEN || ball_g < 0) {
+                dst[o + qadr - skip] = x_ + qoff;
+            }
+        };
         if (live && (obs || nobs) && task == 1) {           // obs = [qpos[skip:], qvel]
             const long o = (pid * H + t) * dobs;
             if (obs && dof) {
-                if (l >= obs_skip) obs[o + l - obs_skip] = q_prev;
-                obs[o + nv - obs_skip + l] = v_prev;
+                put_q(obs, o, obs_skip, q_prev, qy_prev, qz_prev, qw_prev);
+                obs[o + nq - obs_skip + l] = v_prev;
             }
             if (nobs && dof) {
-                if (l >= obs_skip) nobs[o + l - obs_skip] = q;
-                nobs[o + nv - obs_skip + l] = v;
+                put_q(nobs, o, obs_skip, q, qy, qz, qw);
+                nobs[o + nq - obs_skip + l] = v;
             }
         } else if (live && (obs || nobs)) {
             const long o = (pid * H + t) * dobs;
             if (obs) {
-                if (dof) { obs[o + l] = q_prev; obs[o + nv + l] = v_prev; }
-                if (l < 3) { obs[o + 2 * nv + l] = hand_prev[l]; obs[o + 2 * nv + 3 + l] = hand_prev[l] - tgt[l]; }
+                if (dof) { put_q(obs, o, 0, q_prev, qy_prev, qz_prev, qw_prev); obs[o + nq + l] = v_prev; }
+                if (l < 3) { obs[o + nq + nv + l] = hand_prev[l]; obs[o + nq + nv + 3 + l] = hand_prev[l] - tgt[l]; }
             }
             if (nobs) {
-                if (dof) { nobs[o + l] = q; nobs[o + nv + l] = v; }
-                if (l < 3) { nobs[o + 2 * nv + l] = hand[l]; nobs[o + 2 * nv + 3 + l] = hand[l] - tgt[l]; }
+                if (dof) { put_q(nobs, o, 0, q, qy, qz, qw); nobs[o + nq + l] = v; }
+                if (l < 3) { nobs[o + nq + nv + l] = hand[l]; nobs[o + nq + nv + 3 + l] = hand[l] - tgt[l]; }
             }
         }
         q_prev = q;
         v_prev = v;
+        if constexpr (GEN) { qy_prev = qy; qz_prev = qz; qw_prev = qw; }
         for (int k = 0; k < 3; ++k) hand_prev[k] = hand[k];
     }
     // the "real env" kept on the device (mjmpc_tree_step_state): particle 0 leaves its state where the next rollout
     // reads it (the launch has one particle; `state` was read before the first step)
     if (state_out && pid == 0 && dof) {
-        state_out[l] = (double)q;
+        if (!GEN || ball_g <= 0) state_out[l] = (double)q;         // (a ball's first link owns its followers' qpos entries)
+        if (GEN && ball_g == 0) {
+            state_out[l + 1] = (double)qy;
+            state_out[l + 2] = (double)qz;
+            state_out[TREE_QW + l] = (double)qw;
+        }
         state_out[TL + l] = (double)v;
     }
 }
@@ -1933,14 +2274,15 @@ struct TreeLaunchArgs {
     hipStream_t stream;
 };
 template <typename T>
-hipError_t launch_tree_rollout_dense(int max_path, int nv, const T* model, const T* noise, T* cost, T* act, T* obs, T* nobs,
+hipError_t launch_tree_rollout_dense(int max_path, int nv, bool gen, const T* model, const T* noise, T* cost, T* act, T* obs, T* nobs,
                                      const TreeLaunchArgs& a);
 
-#define MJMPC_TREE_LAUNCH(DP_, NS_, FR_, PL_) MJMPC_TREE_LAUNCH_D(DP_, NS_, FR_, PL_, 0)
-#define MJMPC_TREE_LAUNCH_D(DP_, NS_, FR_, PL_, DN_)                                                                  \
+#define MJMPC_TREE_LAUNCH(DP_, NS_, FR_, PL_) MJMPC_TREE_LAUNCH_D(DP_, NS_, FR_, PL_, 0, false)
+#define MJMPC_TREE_LAUNCH_G(DP_, NS_, FR_, PL_) MJMPC_TREE_LAUNCH_D(DP_, NS_, FR_, PL_, 0, true)
+#define MJMPC_TREE_LAUNCH_D(DP_, NS_, FR_, PL_, DN_, GEN_)                                                            \
     {                                                                                                                 \
         constexpr int per_wg = wg_waves(DP_, FR_, sizeof(T), PL_) * (64 / PL_);                                       \
-        hipLaunchKernelGGL((tree_rollout_kernel<T, DP_, NS_, FR_, PL_, DN_>),                                         \
+        hipLaunchKernelGGL((tree_rollout_kernel<T, DP_, NS_, FR_, PL_, DN_, GEN_>),                                   \
                            dim3((unsigned)((a.shard + per_wg - 1) / per_wg), (unsigned)a.n_shards),                   \
                            dim3(64 * wg_waves(DP_, FR_, sizeof(T), PL_)), 0, a.stream, model, a.model_stride, a.state, \
                            a.state_stride, a.P, a.shard, a.H, a.A, a.mean, noise, cost, act, obs, nobs, a.diag,       \
@@ -1949,25 +2291,31 @@ hipError_t launch_tree_rollout_dense(int max_path, int nv, const T* model, const
 
 #ifdef TREE_DENSE_TU
 template <typename T>
-hipError_t launch_tree_rollout_dense(int max_path, int nv, const T* model, const T* noise, T* cost, T* act, T* obs, T* nobs,
+hipError_t launch_tree_rollout_dense(int max_path, int nv, bool gen, const T* model, const T* noise, T* cost, T* act, T* obs, T* nobs,
                                      const TreeLaunchArgs& a) {
     // (16 lanes per particle: the dense in-register factorisation, sized for the model)
-    if (max_path <= 8 && nv <= 8) MJMPC_TREE_LAUNCH_D(8, 16, true, 16, 8)
-    else if (max_path <= 8 && nv <= 12) MJMPC_TREE_LAUNCH_D(8, 16, true, 16, 12)
-    else if (max_path <= 8) MJMPC_TREE_LAUNCH_D(8, 16, true, 16, 16)
-    else MJMPC_TREE_LAUNCH_D(16, 16, true, 16, 16)
+    if (gen) {          // the general instantiation comes in two sizes
+        if (max_path <= 8) MJMPC_TREE_LAUNCH_D(8, 16, true, 16, 16, true)
+        else MJMPC_TREE_LAUNCH_D(16, 16, true, 16, 16, true)
+    }
+    else if (max_path <= 8 && nv <= 8) MJMPC_TREE_LAUNCH_D(8, 16, true, 16, 8, false)
+    else if (max_path <= 8 && nv <= 12) MJMPC_TREE_LAUNCH_D(8, 16, true, 16, 12, false)
+    else if (max_path <= 8) MJMPC_TREE_LAUNCH_D(8, 16, true, 16, 16, false)
+    else MJMPC_TREE_LAUNCH_D(16, 16, true, 16, 16, false)
     return hipGetLastError();
 }
-template hipError_t launch_tree_rollout_dense<float>(int, int, const float*, const float*, float*, float*, float*, float*,
+template hipError_t launch_tree_rollout_dense<float>(int, int, bool, const float*, const float*, float*, float*, float*, float*,
                                                      const TreeLaunchArgs&);
-template hipError_t launch_tree_rollout_dense<double>(int, int, const double*, const double*, double*, double*, double*, double*,
+template hipError_t launch_tree_rollout_dense<double>(int, int, bool, const double*, const double*, double*, double*, double*, double*,
                                                       const TreeLaunchArgs&);
 #else
 template <typename T>
 hipError_t launch_tree_rollout(const T* model, int n_model_shards, int max_path, bool full, int nv, const double* state, long P, int H,
                                int A, const double* mean, const T* noise, T* cost, T* act, T* obs, T* nobs, unsigned* diag,
-                               hipStream_t stream, double* state_out, const double* clw, double* site_out, int n_state_shards) {
+                               hipStream_t stream, double* state_out, const double* clw, double* site_out, int n_state_shards,
+                               bool gen) {
     if (P <= 0 || H <= 0) return hipSuccess;
+    if (gen && (!full || clw)) return hipErrorInvalidValue;     // (closed_loop_linear is not built for the general instantiation)
     if ((state_out || site_out) && P != 1) return hipErrorInvalidValue;
     if (n_model_shards < 1 || n_state_shards < 1) return hipErrorInvalidValue;
     if (n_model_shards > 1 && n_state_shards > 1 && n_model_shards != n_state_shards) return hipErrorInvalidValue;
@@ -1995,7 +2343,10 @@ hipError_t launch_tree_rollout(const T* model, int n_model_shards, int max_path,
         else if (max_path <= 16) MJMPC_TREE_LAUNCH(16, 8, false, 32)
         else MJMPC_TREE_LAUNCH(32, 8, false, 32)
     } else if (nv <= 16) {
-        return launch_tree_rollout_dense<T>(max_path, nv, model, noise, cost, act, obs, nobs, a);
+        return launch_tree_rollout_dense<T>(max_path, nv, gen, model, noise, cost, act, obs, nobs, a);
+    } else if (gen) {
+        if (max_path <= 16) MJMPC_TREE_LAUNCH_G(16, 16, true, 32)
+        else MJMPC_TREE_LAUNCH_G(32, 16, true, 32)
     } else {
         if (max_path <= 8) MJMPC_TREE_LAUNCH(8, 16, true, 32)
         else if (max_path <= 16) MJMPC_TREE_LAUNCH(16, 16, true, 32)
@@ -2005,11 +2356,12 @@ hipError_t launch_tree_rollout(const T* model, int n_model_shards, int max_path,
 }
 
 template hipError_t launch_tree_rollout<float>(const float*, int, int, bool, int, const double*, long, int, int, const double*,
-                                               const float*, float*, float*, float*, float*, unsigned*, hipStream_t, double*, const double*, double*, int);
+                                               const float*, float*, float*, float*, float*, unsigned*, hipStream_t, double*, const double*, double*, int, bool);
 template hipError_t launch_tree_rollout<double>(const double*, int, int, bool, int, const double*, long, int, int, const double*,
-                                                const double*, double*, double*, double*, double*, unsigned*, hipStream_t, double*, const double*, double*, int);
+                                                const double*, double*, double*, double*, double*, unsigned*, hipStream_t, double*, const double*, double*, int, bool);
 #endif
 #undef MJMPC_TREE_LAUNCH
+#undef MJMPC_TREE_LAUNCH_G
 #undef MJMPC_TREE_LAUNCH_D
 
 }  // namespace mjmpc

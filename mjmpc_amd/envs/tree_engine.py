@@ -48,7 +48,7 @@ class TreeRolloutEngine:
         self._h = h
         self.d_action, self.d_obs = model.nu, model.d_obs
         self.forward_task = model.task == TASK_FORWARD
-        self.d_state = 2 * model.nv if self.forward_task else 3 * model.nv + 3 + 1
+        self.d_state = model.nq + model.nv if self.forward_task else model.nq + 2 * model.nv + 3 + 1
         self.action_lows, self.action_highs = model.ctrl_lo.copy(), model.ctrl_hi.copy()
         self.closed = False
         self._buf = {}
@@ -62,7 +62,7 @@ class TreeRolloutEngine:
         qp = np.ascontiguousarray(state[kq], np.float64).reshape(-1)
         qv = np.ascontiguousarray(state[kv], np.float64).reshape(-1)
         tg = np.ascontiguousarray(state.get("target_pos", self.model.target_default), np.float64).reshape(-1)
-        if qp.size != self.model.nv or qv.size != self.model.nv or tg.size != 3:
+        if qp.size != self.model.nq or qv.size != self.model.nv or tg.size != 3:     # (qpos in MuJoCo's layout: nq entries)
             raise ValueError("state has the wrong dimensions for this model")
         return dict(qp=qp.copy(), qv=qv.copy(), target_pos=tg.copy())
 
@@ -87,10 +87,10 @@ class TreeRolloutEngine:
                                                   state["target_pos"].ctypes.data_as(_lib._dp), self._stream()))
 
     def _set_shard_states(self, states):
-        nv = self.model.nv
-        arr = np.zeros((self.num_shards, 70))                   # MJMPC_TREE_STATE_LEN: qpos[32] | qvel[32] | target[3] | -
+        nv, nq = self.model.nv, self.model.nq
+        arr = np.zeros((self.num_shards, 78))                   # MJMPC_TREE_STATE_LEN: qpos[40] | qvel[32] | target[3] | -
         for k, s in enumerate(states):
-            arr[k, :nv], arr[k, 32:32 + nv], arr[k, 64:67] = s["qp"], s["qv"], s["target_pos"]
+            arr[k, :nq], arr[k, 40:40 + nv], arr[k, 72:75] = s["qp"], s["qv"], s["target_pos"]
         _lib.check(self._lib.mjmpc_tree_set_shard_states(self._h, arr.ctypes.data_as(_lib._dp), self.num_shards,
                                                          self._stream()))
         self._per_shard_states = True
@@ -106,7 +106,7 @@ class TreeRolloutEngine:
                      target_pos=st["target_pos"].copy(), timestep=0) for st in states]
 
     def reset(self):
-        self.set_env_state(dict(qp=np.zeros(self.model.nv), qv=np.zeros(self.model.nv),
+        self.set_env_state(dict(qp=self.model.qpos0.copy(), qv=np.zeros(self.model.nv),
                                 target_pos=self.model.target_default.copy()))
         return self.get_env_state()
 
@@ -134,6 +134,9 @@ class TreeRolloutEngine:
     def rollout_device(self, num_particles, horizon, mean, noise, mode="open_loop", want_obs=False, want_actions=True):
         if mode not in ("open_loop", "closed_loop_linear"):
             raise ValueError("unsupported rollout mode %r ('open_loop' or 'closed_loop_linear')" % (mode,))
+        if mode == "closed_loop_linear" and getattr(self.model, "general", False):
+            raise NotImplementedError("closed_loop_linear rollouts are not built for models with ball / free joints, friction "
+                                      "loss, boxes, equalities or tendons (the general kernel instantiation)")
         if num_particles % self.num_shards != 0:
             raise AssertionError("Number of particles must be divisible by number of shards")
         torch = _torch()
@@ -157,8 +160,8 @@ class TreeRolloutEngine:
             raise ValueError("the observation leaves out qpos[:%d]; step an engine compiled with obs_skip = 0"
                              % self.model.obs_skip)
         _, rew, _, _, _, nobs = self.rollout(1, 1, np.asarray(action, np.float64).reshape(1, -1), None)
-        nv = self.model.nv
-        self.set_env_state(dict(qp=nobs[0, 0, :nv], qv=nobs[0, 0, nv:2 * nv], target_pos=self._state["target_pos"]))
+        nv, nq = self.model.nv, self.model.nq
+        self.set_env_state(dict(qp=nobs[0, 0, :nq], qv=nobs[0, 0, nq:nq + nv], target_pos=self._state["target_pos"]))
         return nobs[0, 0].copy(), float(rew[0, 0])
 
     def step_state(self, action):
@@ -174,7 +177,7 @@ class TreeRolloutEngine:
 
     def get_state_device(self):
         """The device-resident state as the task's state dictionary (one D2H copy; synchronises the stream)."""
-        qp, qv = np.zeros(self.model.nv), np.zeros(self.model.nv)
+        qp, qv = np.zeros(self.model.nq), np.zeros(self.model.nv)
         _lib.check(self._lib.mjmpc_tree_get_state(self._h, qp.ctypes.data_as(_lib._dp), qv.ctypes.data_as(_lib._dp), self._stream()))
         if self.forward_task:
             return dict(qpos=qp, qvel=qv)
@@ -185,7 +188,7 @@ class TreeRolloutEngine:
         shard i draws from ``np_random(base_seed + i*12345)`` a uniform value in ``m (1 +- noise)``, ``m = (1 + bias) *
         default`` for every ``{param_id: {name: [noise_scale, bias_scale]}}`` entry (gym_env_wrapper.py:367-416) and from
         then on simulates its own model block (``mjmpc_tree_set_shard_models``).  Supported: body_mass, body_inertia,
-        dof_damping, geom_size and geom_friction of colliding geoms; dof_frictionloss only with its zero default.
+        dof_damping, dof_frictionloss (friction-loss constraint rows), geom_size and geom_friction of colliding geoms.
         Returns (default_params, randomized_params), one dict per shard."""
         if self.raw is None:
             raise ValueError("randomize_dynamics needs the engine to be built from a RawModel")
@@ -201,11 +204,9 @@ class TreeRolloutEngine:
                         cur = defaults[param_id][name] = self._default_param(param_id, name)
                     mean = (1.0 + bias_scale) * np.asarray(cur, float)
                     rand.setdefault(param_id, {})[name] = rng.uniform(mean - mean * noise_scale, mean + mean * noise_scale)
-            if any(np.any(np.asarray(v) != 0) for v in rand.get("dof_frictionloss", {}).values()):
-                raise NotImplementedError("a non-zero dof_frictionloss adds friction-loss constraint rows, which the tree "
-                                          "kernel does not model")
-            ov = {k: v for k, v in rand.items() if k != "dof_frictionloss"}
-            blobs.append(compile_tree(self.raw, overrides=ov, base=self.model).blob)
+            # (dof_frictionloss: friction-loss constraint rows - the general kernel instantiation, which the engine's own model
+            # must already run: a model whose defaults are all zero keeps them zero under a multiplicative draw)
+            blobs.append(compile_tree(self.raw, overrides=rand, base=self.model).blob)
         blobs = np.ascontiguousarray(np.stack(blobs), np.float64)
         _lib.check(self._lib.mjmpc_tree_set_shard_models(self._h, blobs.ctypes.data_as(_lib._dp), self.num_shards))
         self.shard_blobs = blobs
@@ -228,8 +229,7 @@ class TreeRolloutEngine:
             half = 0.5 * np.linalg.norm(np.asarray(g.b, float) - np.asarray(g.a, float)) if g.type == 2 else 0.0
             return np.array([g.radius, half, 0.0])
         if param_id == "dof_frictionloss":
-            next(b for b in raw.bodies if b.joint is not None and b.joint.name == name)     # unknown joint -> error
-            return 0.0
+            return float(next(b.joint.frictionloss for b in raw.bodies if b.joint is not None and b.joint.name == name))
         raise ValueError("Unknown dynamics field")
 
     def solver_failures(self):

@@ -14,7 +14,7 @@ from dataclasses import dataclass
 
 import numpy as np
 
-from .raw import GEOM_CAPSULE, GEOM_SPHERE, RawModel
+from .raw import GEOM_BOX, GEOM_CAPSULE, GEOM_SPHERE, RawModel
 
 LANES = 8          # lanes per particle in the HIP kernel
 MAX_LINKS = 7
@@ -72,6 +72,12 @@ def _geom_inertial(g, cap=1.0):
         i_perp = mc * (3 * r * r + h * h) / 12 + 0.4 * ms * r * r + ms * h * (3 * r + 2 * h) / 8
         i_ax = mc * r * r / 2 + 0.4 * ms * r * r
         return m, 0.5 * (a + b), i_perp * np.eye(3) + (i_ax - i_perp) * np.outer(u, u)
+    if g.type == GEOM_BOX:                  # a = centre, b = half sizes, quat = orientation in the body frame
+        hx, hy, hz = (float(x) for x in g.b)
+        m = g.density * 8.0 * hx * hy * hz
+        R = _quat2mat(g.quat)
+        Ib = np.diag([m / 3.0 * (hy * hy + hz * hz), m / 3.0 * (hx * hx + hz * hz), m / 3.0 * (hx * hx + hy * hy)])
+        return m, np.asarray(g.a, float), R @ Ib @ R.T
     raise ValueError("unsupported geom type %r" % (g.type,))
 
 
@@ -119,8 +125,11 @@ def compile_arm(raw: RawModel, overrides=None, base: "ArmModel" = None) -> ArmMo
     nb = len(raw.bodies)
     # what only the tree kernel executes (models/compile_tree.py)
     joints = [b.joint for b in raw.bodies if b.joint is not None]
-    if any(j.type != 1 or j.stiffness != 0 for j in joints):
-        raise ValueError("arm kernel: hinge joints without springs only (slide joints / springs: the tree engine)")
+    if any(j.type != 1 or j.stiffness != 0 or j.frictionloss != 0 or any(np.asarray(j.pos, float) != 0) for j in joints):
+        raise ValueError("arm kernel: hinge joints at the body origin without springs or friction loss only "
+                         "(slide / ball / free joints, springs, friction loss, joint anchors: the tree engine)")
+    if raw.equalities or raw.tendons or raw.world_geoms or any(b.inertial is not None for b in raw.bodies):
+        raise ValueError("arm kernel: no equalities, tendons, static geoms or explicit inertials (the tree engine has them)")
     if raw.density > 0 or raw.viscosity > 0 or raw.task != 0:
         raise ValueError("arm kernel: no medium, reach task only (the tree engine runs the locomotion models)")
     if raw.plane is not None and any(g.collide and max(g.condim, raw.plane.condim) > 1 for b in raw.bodies for g in b.geoms):

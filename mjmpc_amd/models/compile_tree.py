@@ -15,7 +15,8 @@ from dataclasses import dataclass
 import numpy as np
 
 from .compile import _geom_inertial, _quat2mat, _shift_inertia, principal_inertia
-from .raw import GEOM_SPHERE, JOINT_HINGE, JOINT_SLIDE, TASK_FORWARD, TASK_ORIENT, TASK_REACH, RawModel
+from .raw import (EQ_CONNECT, EQ_JOINT, GEOM_BOX, GEOM_CAPSULE, GEOM_SPHERE, JOINT_BALL, JOINT_FREE, JOINT_HINGE, JOINT_SLIDE,
+                  TASK_FORWARD, TASK_ORIENT, TASK_REACH, RawModel)
 
 TL = 32                     # lanes per particle
 TREE_MAX_SPHERES = 16
@@ -25,6 +26,18 @@ SPH_STRIDE = 24             # contact record: [0] link A, [1:4] centre / segment
                             # (0 sphere-plane, 1 geom-geom), [13] link B, [14:17] segment start on B, [17] radius B,
                             # [18:21] segment vector on B
 MJ_MINIMP, MJ_MAXIMP = 1e-4, 0.9999     # MuJoCo's clamp on solimp (getsolparam)
+# link kinds (T_JTYPE): one link = one dof.  A ball joint is three links (the first holds the quaternion and turns the
+# frame, the other two ride along: their axes are the body's own y and z), a free joint three slides along the WORLD axes
+# followed by a ball
+LINK_HINGE, LINK_SLIDE, LINK_BALL_X, LINK_BALL_Y, LINK_BALL_Z = 1, 2, 3, 4, 5
+# contact-record kinds ([12]): sphere/plane, segment/segment, sphere(A)/box(B), box(A)/sphere(B), connect equality,
+# dof row (joint equality or fixed-tendon limit)
+PT_PLANE, PT_SEGSEG, PT_SPHERE_BOX, PT_BOX_SPHERE, PT_CONNECT, PT_DOFROW = 0, 1, 2, 3, 4, 5
+PEXT_STRIDE = 24            # per contact record, general instantiation: [0:3] box half sizes, [3:12] box orientation in its
+                            # link's frame (row-major) | dof row: [0] 0 joint equality / 1 tendon limit, [1] coef A, [2] coef
+                            # B, [3:5] range, [5] margin, [6:11] polycoef; [12:19] the row's solver set {K, B, dmin, dmax,
+                            # width, mid, power} (equalities), [19] bilateral flag
+TREE_NQ_MAX = 40
 
 TREE_LAYOUT = [
     # ---- staged in LDS by the kernel: per-link constants, scalars, contact records
@@ -52,9 +65,18 @@ TREE_LAYOUT = [
     ("n_rounds", 1),                # max height + 1
     ("elim", (TL - 1) * TL),        # [entry][lane]: my descendants sorted by height, packed k | dist << 8 | height << 16
                                     # (-1 terminates): the rows that update mine, round by round
+    # ---- the GENERAL instantiation's constants (round 4): ball / free joints, friction loss, boxes, equalities, tendons
+    ("gen", 1),                     # the model needs the general instantiation
+    ("nq", 1), ("has_ball", 1),
+    ("fsol_K", 1), ("fsol_B", 1), ("fsol_dmin", 1), ("fsol_dmax", 1), ("fsol_width", 1), ("fsol_mid", 1), ("fsol_power", 1),
+    ("frictionloss", TL),           # per dof: dry friction (one friction-loss row each)
+    ("qadr", TL),                   # the link's entry in MuJoCo's qpos (ball: the quaternion's w, on the BALL_X link; -1: none)
+    ("qoff", TL),                   # added to the link's coordinate in qpos (a free joint's translations: the body position)
+    ("pext", TREE_MAX_SPHERES * PEXT_STRIDE),
 ]
 TREE_BLOB_LEN = sum(n for _, n in TREE_LAYOUT)
-TREE_STATE_LEN = 2 * TL + 6           # qpos[32] | qvel[32] | target_pos[3] | fresh site[3]
+TREE_STATE_LEN = 3 * TL + 6           # device: qpos[32] | qvel[32] | target_pos[3] | fresh site[3] | quaternion w[32], per LINK
+TREE_PUBLIC_STATE_LEN = TREE_NQ_MAX + TL + 6     # C ABI (per-shard states): qpos[40] (MuJoCo layout) | qvel[32] | target[3] | -
 
 
 def _offsets():
@@ -88,6 +110,8 @@ class TreeModel:
     body_invweight0: np.ndarray
     dof_invweight0: np.ndarray
     link_of_body: list
+    nq: int = 0
+    qpos0: np.ndarray = None
 
     def field(self, name):
         o, n = TREE_OFFSETS[name]
@@ -108,12 +132,9 @@ def _principal_frame(I):
     return w, V
 
 
-def compile_tree(raw: RawModel, overrides=None, base: "TreeModel" = None) -> TreeModel:
-    """``overrides`` mimics run-time edits of the compiled MuJoCo model (dynamics randomization,
-    mjmpc/envs/gym_env_wrapper.py:367-416), as ``compile.compile_arm`` does: ``{"body_mass": {body: m}, "body_inertia":
-    {body: [I1, I2, I3]}, "dof_damping": {joint: d}, "geom_size": {geom: [r, half, ..]}, "geom_friction": {geom: [mu, ..]}}``.
-    Like MuJoCo, such edits do NOT recompute the qpos0 constants: pass the unperturbed model as ``base`` and its
-    dof / body invweight0 are kept."""
+def body_inertials(raw: RawModel, overrides=None):
+    """Per raw body: pose at qpos0 (R0, p0), mass, centre of mass and inertia tensor about it in the body frame
+    (inertiafromgeom, or the body's explicit <inertial>), with the run-time edits of ``overrides`` applied."""
     overrides = overrides or {}
     nb = len(raw.bodies)
     R0, p0 = [None] * nb, [None] * nb
@@ -124,36 +145,77 @@ def compile_tree(raw: RawModel, overrides=None, base: "TreeModel" = None) -> Tre
         Rp, pp = (np.eye(3), np.zeros(3)) if b.parent < 0 else (R0[b.parent], p0[b.parent])
         R0[i] = Rp @ _quat2mat(b.quat)
         p0[i] = pp + Rp @ np.asarray(b.pos, float)
-        parts = [_geom_inertial(g, raw.capsule_cap_factor) for g in b.geoms]
-        mass[i] = sum(m for m, _, _ in parts)
-        if mass[i] > 0:
-            ipos[i] = sum(m * c for m, c, _ in parts) / mass[i]
-            inert[i] = sum(_shift_inertia(I, m, c - ipos[i]) for m, c, I in parts)
+        if b.inertial is not None:
+            mass[i] = float(b.inertial.mass)
+            ipos[i] = np.asarray(b.inertial.pos, float)
+            inert[i] = np.asarray(b.inertial.inertia, float).reshape(3, 3)
+        else:
+            parts = [_geom_inertial(g, raw.capsule_cap_factor) for g in b.geoms]
+            mass[i] = sum(m for m, _, _ in parts)
+            if mass[i] > 0:
+                ipos[i] = sum(m * c for m, c, _ in parts) / mass[i]
+                inert[i] = sum(_shift_inertia(I, m, c - ipos[i]) for m, c, I in parts)
         if b.name in overrides.get("body_mass", {}):
             mass[i] = float(overrides["body_mass"][b.name])          # inertia / COM untouched, as in MuJoCo
         if b.name in overrides.get("body_inertia", {}):
             _, V = principal_inertia(inert[i])
             inert[i] = V @ np.diag(np.asarray(overrides["body_inertia"][b.name], float)) @ V.T
+    return R0, p0, mass, ipos, inert
 
-    # ---- links: one per joint, welded bodies merged into the link that carries them ----------------------
-    jointed = [i for i, b in enumerate(raw.bodies) if b.joint is not None]
-    nv = len(jointed)
-    if not 1 <= nv <= TL:
-        raise ValueError("tree kernel supports 1..%d dofs, got %d" % (TL, nv))
-    jtype = [raw.bodies[i].joint.type for i in jointed]
-    if any(t not in (JOINT_HINGE, JOINT_SLIDE) for t in jtype):
-        raise ValueError("joints must be hinges or slides")
-    link_of_body, parent = [-1] * nb, []
+
+def compile_tree(raw: RawModel, overrides=None, base: "TreeModel" = None) -> TreeModel:
+    """``overrides`` mimics run-time edits of the compiled MuJoCo model (dynamics randomization,
+    mjmpc/envs/gym_env_wrapper.py:367-416), as ``compile.compile_arm`` does: ``{"body_mass": {body: m}, "body_inertia":
+    {body: [I1, I2, I3]}, "dof_damping": {joint: d}, "dof_frictionloss": {joint: f}, "geom_size": {geom: [r, half, ..]},
+    "geom_friction": {geom: [mu, ..]}}``.
+    Like MuJoCo, such edits do NOT recompute the qpos0 constants: pass the unperturbed model as ``base`` and its
+    dof / body invweight0 are kept."""
+    overrides = overrides or {}
+    nb = len(raw.bodies)
+    R0, p0, mass, ipos, inert = body_inertials(raw, overrides)
+
+    # ---- links: one per DOF.  Welded bodies merge into the link that carries them; a ball joint is three links, a free
+    # joint three world-axis slides and a ball; the body itself (mass, geoms, children) rides on the LAST link of its joint
+    link_body, link_kind, link_axis, link_first = [], [], [], []
+    first_link, link_of_body, parent = [-1] * nb, [-1] * nb, []
+    gen = False
     for i, b in enumerate(raw.bodies):
         pl = -1 if b.parent < 0 else link_of_body[b.parent]
-        if b.joint is not None:
-            link_of_body[i] = jointed.index(i)
-            parent.append(pl)
-        else:
-            if pl < 0:
-                raise ValueError("static body %s before the first joint is not supported" % b.name)
+        if b.joint is None:
+            # a static body (welded to the world before any joint) carries geoms that never move: nothing to simulate
             link_of_body[i] = pl
+            continue
+        jt = b.joint
+        if jt.type in (JOINT_HINGE, JOINT_SLIDE):
+            ax = np.asarray(jt.axis, float)
+            kinds = [(LINK_HINGE if jt.type == JOINT_HINGE else LINK_SLIDE, R0[i] @ (ax / np.linalg.norm(ax)))]
+        elif jt.type == JOINT_BALL:
+            kinds = [(LINK_BALL_X + c, R0[i][:, c].copy()) for c in range(3)]
+        elif jt.type == JOINT_FREE:
+            if b.parent >= 0:
+                raise ValueError("a free joint belongs to a child of the world body")
+            kinds = [(LINK_SLIDE, np.eye(3)[c]) for c in range(3)] + [(LINK_BALL_X + c, R0[i][:, c].copy()) for c in range(3)]
+        else:
+            raise ValueError("unknown joint type %r" % (jt.type,))
+        gen = gen or jt.type in (JOINT_BALL, JOINT_FREE)
+        first_link[i] = len(parent)
+        for c, (kd, ax) in enumerate(kinds):
+            parent.append(pl if c == 0 else len(parent) - 1)
+            link_body.append(i)
+            link_kind.append(kd)
+            link_axis.append(ax)
+            link_first.append(c == 0)
+        link_of_body[i] = len(parent) - 1
+    nv = len(parent)
+    if nv != raw.nv:
+        raise AssertionError("dof count mismatch")
+    if not 1 <= nv <= TL:
+        raise ValueError("tree kernel supports 1..%d dofs, got %d" % (TL, nv))
+    for li in range(nv):        # a ball's three links must share a 16-lane row (their velocities meet through row shifts)
+        if link_kind[li] == LINK_BALL_X and li // 16 != (li + 2) // 16:
+            raise NotImplementedError("a ball joint's three dofs must not straddle lanes 15 / 16: reorder the bodies")
     parent = np.array(parent, int)
+    jtype = list(link_kind)
     subsize = np.ones(nv, int)
     for i in range(nv - 1, -1, -1):
         if parent[i] >= 0:
@@ -187,57 +249,57 @@ def compile_tree(raw: RawModel, overrides=None, base: "TreeModel" = None) -> Tre
     jumps = int(np.ceil(np.log2(depth.max()))) if depth.max() > 1 else 0
 
     # ---- elimination tree of the sparse factorisation -------------------------------------------------------
-    # H = M + J' D J has M's pattern (entries only between a link and its ancestors) as long as every constraint row
-    # touches the dofs of ONE root path.  A contact between a manipulator link and an object link touches two trees.
-    # Hanging the manipulator's root under the object's last link - in the tree the FACTORISATION walks, not in the
-    # kinematic one - puts both on one path again: the object's dofs are eliminated last, fill-in stays inside the
-    # path-indexed rows.  (The object must be a serial chain listed before the manipulator.)
+    # H = M + J' D J.  M couples a link with its kinematic ancestors; a constraint row couples every dof it touches with
+    # every other: the links on the paths of BOTH bodies of a geom-geom pair or a connect equality, the two joints of a
+    # joint equality or a tendon.  The factorisation eliminates links from the highest index down (leaves first), and the
+    # tree it walks is the ELIMINATION TREE of that pattern (symbolic Cholesky: the parent of a link is the highest link
+    # below it that its elimination touches): every row's dofs then lie on one path of it, no fill-in leaves the
+    # path-indexed rows, and for a plain kinematic tree it IS the kinematic tree.  An object listed BEFORE the manipulator
+    # that touches it ends up above the manipulator's root (its dofs are eliminated last: short paths); couplings between
+    # siblings or across branches chain the branches up instead of being refused.
     geom_names = {g.name: (i, g) for i, b in enumerate(raw.bodies) for g in b.geoms if g.name}
+    geom_names.update({g.name: (-1, g) for g in raw.world_geoms if g.name})
+    bnames = [b.name for b in raw.bodies]
+
+    def blink(i):
+        return -1 if i < 0 else link_of_body[i]
+
+    def kpath(link):
+        out = []
+        while link >= 0:
+            out.append(link)
+            link = parent[link]
+        return out
+
     pair_geoms = []
     for ga, gb in raw.pairs:
         if ga not in geom_names or gb not in geom_names:
             raise ValueError("collision pair names an unknown geom: %r / %r" % (ga, gb))
-        pair_geoms.append((geom_names[ga], geom_names[gb]))
-
-    def root_of(k):
-        while parent[k] >= 0:
-            k = parent[k]
-        return k
-
-    def is_ancestor(a, k):          # link a is k or one of k's (kinematic) ancestors
-        while k >= 0:
-            if k == a:
-                return True
-            k = parent[k]
-        return False
-
-    eparent = parent.copy()
-    # pairs inside ONE kinematic tree (self-collision: swimmer.xml's segments) need no help as long as one link is an
-    # ancestor of the other - the row then lives on the deeper link's path; listed deeper geom first
-    cross = []
-    for (ia, ga), (ib, gb) in pair_geoms:
-        la, lb = link_of_body[ia], link_of_body[ib]
-        if la < 0 or lb < 0:
-            raise NotImplementedError("geom-geom pairs must name geoms on moving bodies")
-        if root_of(la) != root_of(lb):
-            cross.append(((ia, ga), (ib, gb)))
-        elif not is_ancestor(lb, la):
-            raise NotImplementedError("a self-collision pair must list the deeper geom first, and its links must lie on one "
-                                      "root path (a pair across two branches would fill the sparse factorisation in): "
-                                      "%r / %r" % (ga.name, gb.name))
-    if cross:
-        obj_roots = {root_of(link_of_body[ib]) for (_, _), (ib, _) in cross}
-        man_roots = {root_of(link_of_body[ia]) for (ia, _), (_, _) in cross}
-        if len(obj_roots) != 1 or obj_roots & man_roots:
-            raise NotImplementedError("geom-geom pairs must pair geoms of the manipulator(s) with geoms of ONE object tree")
-        ro = obj_roots.pop()
-        chain = list(range(ro, ro + subsize[ro]))
-        if any(parent[k] != k - 1 for k in chain[1:]):
-            raise NotImplementedError("the object of geom-geom pairs must be a serial chain of joints")
-        for rm in sorted(man_roots):
-            if rm < ro:
-                raise NotImplementedError("list the object before the manipulator (its dofs are eliminated last)")
-            eparent[rm] = chain[-1]
+        A, B = geom_names[ga], geom_names[gb]
+        if blink(A[0]) < 0 and blink(B[0]) < 0:
+            raise NotImplementedError("pair %r / %r: both geoms are static" % (ga, gb))
+        if blink(B[0]) > blink(A[0]):               # the record is anchored at the higher link, whose elimination path
+            A, B = B, A                             # holds the other's
+        pair_geoms.append((A, B))
+    coupled = [set(kpath(blink(A[0])) + kpath(blink(B[0]))) for A, B in pair_geoms]
+    for e in raw.equalities:
+        if e.type == EQ_CONNECT:
+            coupled.append(set(kpath(blink(bnames.index(e.obj1))) + kpath(blink(bnames.index(e.obj2)) if e.obj2 else -1)))
+        elif e.type == EQ_JOINT:
+            coupled.append({raw.dof_of_joint(e.obj1)} | ({raw.dof_of_joint(e.obj2)} if e.obj2 else set()))
+    for t in raw.tendons:
+        if t.limited:
+            coupled.append({raw.dof_of_joint(jn) for jn, _ in t.joints})
+    struct = [set(kpath(i)[1:]) for i in range(nv)]             # lower-index links my row touches: M's pattern ...
+    for S in coupled:                                           # ... and every constraint row's clique
+        for i in S:
+            struct[i] |= {j for j in S if j < i}
+    eparent = -np.ones(nv, int)
+    for j in range(nv - 1, -1, -1):
+        if struct[j]:
+            pj = max(struct[j])
+            eparent[j] = pj
+            struct[pj] |= struct[j] - {pj}
     edepth = np.zeros(nv, int)
     for i in range(nv):
         k, d = i, 0
@@ -251,6 +313,13 @@ def compile_tree(raw: RawModel, overrides=None, base: "TreeModel" = None) -> Tre
         if eparent[i] >= 0:
             eheight[eparent[i]] = max(eheight[eparent[i]], eheight[i] + 1)
 
+    def e_is_ancestor(a, k):
+        while k >= 0:
+            if k == a:
+                return True
+            k = eparent[k]
+        return False
+
     def e_descendants(i):
         out = []
         for k in range(nv):
@@ -262,15 +331,23 @@ def compile_tree(raw: RawModel, overrides=None, base: "TreeModel" = None) -> Tre
         return out
 
     f = {name: np.zeros(n) for name, n in TREE_LAYOUT}
-    origin = [p0[j] for j in jointed]
-    axis_w = []
-    for li, bj in enumerate(jointed):
+    origin = []
+    for li in range(nv):
+        bj = link_body[li]
         jt = raw.bodies[bj].joint
+        anchor = p0[bj] + (R0[bj] @ np.asarray(jt.pos, float) if jt.type in (JOINT_HINGE, JOINT_BALL) else 0.0)
+        origin.append(np.asarray(anchor, float))
+    axis_w = list(link_axis)
+    slide_like = [k == LINK_SLIDE for k in link_kind]
+    qadr, nq_run = np.full(nv, -1.0), 0
+    for li in range(nv):
+        bj = link_body[li]
+        jt = raw.bodies[bj].joint
+        last = link_of_body[bj] == li
         prev = origin[parent[li]] if parent[li] >= 0 else np.zeros(3)
-        axis = R0[bj] @ (np.asarray(jt.axis, float) / np.linalg.norm(jt.axis))
-        axis_w.append(axis)
-        members = [i for i in range(nb) if link_of_body[i] == li]
-        m = mass[members].sum()
+        axis = axis_w[li]
+        members = [i for i in range(nb) if link_of_body[i] == li] if last else []
+        m = mass[members].sum() if members else 0.0
         if m > 0:
             com_w = sum(mass[i] * (p0[i] + R0[i] @ ipos[i]) for i in members) / m
             I = sum(_shift_inertia(R0[i] @ inert[i] @ R0[i].T, mass[i], p0[i] + R0[i] @ ipos[i] - com_w)
@@ -286,8 +363,26 @@ def compile_tree(raw: RawModel, overrides=None, base: "TreeModel" = None) -> Tre
             f["inertia"][k * TL + li] = I[r, c]
         f["armature"][li] = jt.armature
         f["damping"][li] = float(overrides.get("dof_damping", {}).get(jt.name, jt.damping))
-        f["jtype"][li] = jt.type
-        f["stiffness"][li], f["springref"][li] = jt.stiffness, jt.springref
+        f["frictionloss"][li] = float(overrides.get("dof_frictionloss", {}).get(jt.name, jt.frictionloss))
+        f["jtype"][li] = link_kind[li]
+        single = jt.type in (JOINT_HINGE, JOINT_SLIDE)
+        if single:
+            f["stiffness"][li], f["springref"][li] = jt.stiffness, jt.springref
+        elif jt.stiffness != 0 or jt.limited:
+            raise NotImplementedError("ball / free joints: no springs, no limits")
+        # MuJoCo's qpos: one entry per hinge / slide, (w, x, y, z) per ball, position + quaternion per free joint
+        if link_first[li]:
+            nq_here = nq_run
+            nq_run += jt.nq
+        k_in = li - first_link[bj]
+        if single:
+            qadr[li] = nq_here
+        elif jt.type == JOINT_BALL:
+            qadr[li] = nq_here if k_in == 0 else -1
+        else:
+            qadr[li] = nq_here + k_in if k_in < 3 else (nq_here + 3 if k_in == 3 else -1)
+            if k_in < 3:
+                f["qoff"][li] = p0[bj][k_in]
         if raw.density > 0 or raw.viscosity > 0:
             # MuJoCo's fluid model acts body by body on the box of equal inertia, in the body's inertial frame
             massive = [i for i in members if mass[i] > 0]
@@ -302,8 +397,14 @@ def compile_tree(raw: RawModel, overrides=None, base: "TreeModel" = None) -> Tre
                 f["frot"][li::TL] = (R0[i] @ V).reshape(-1)
             else:
                 f["frot"][li::TL] = np.eye(3).reshape(-1)
-        f["range_lo"][li], f["range_hi"][li] = jt.range
-        f["limited"][li] = 1.0 if jt.limited else 0.0
+        if single:
+            f["range_lo"][li], f["range_hi"][li] = jt.range
+            f["limited"][li] = 1.0 if jt.limited else 0.0
+    nq = nq_run
+    if nq > TREE_NQ_MAX:
+        raise ValueError("too many qpos entries")
+    f["qadr"][:] = -1.0
+    f["qadr"][:nv] = qadr
     f["axis"][2 * TL + nv:3 * TL] = 1.0         # spare lanes: a unit axis keeps their (unused) rotation orthonormal
     f["jtype"][nv:] = JOINT_HINGE
     f["parent"][:] = -1.0
@@ -330,7 +431,11 @@ def compile_tree(raw: RawModel, overrides=None, base: "TreeModel" = None) -> Tre
     ctrl_lo, ctrl_hi = np.zeros(nu), np.zeros(nu)
     f["act"][:] = -1.0
     for a, act in enumerate(raw.actuators):         # action a drives the dof of its joint (any subset, any order)
+        if act.tendon:
+            raise NotImplementedError("actuators on tendons are not compiled for the kernel")
         d = raw.dof_of_joint(act.joint)
+        if link_kind[d] not in (LINK_HINGE, LINK_SLIDE) or raw.bodies[link_body[d]].joint.type not in (JOINT_HINGE, JOINT_SLIDE):
+            raise NotImplementedError("actuators drive hinge / slide joints")
         if f["act"][d] >= 0:
             raise ValueError("two motors on joint %r" % act.joint)
         f["act"][d] = a
@@ -343,29 +448,38 @@ def compile_tree(raw: RawModel, overrides=None, base: "TreeModel" = None) -> Tre
 
     # ---- constants at qpos0 (MuJoCo mj_setConst): M0, dof / body invweight0 ------------------------------
     def on_path(k, link):
-        return bool((ancmask[link] >> k) & 1)
+        return link >= 0 and bool((ancmask[link] >> k) & 1)
 
     def jac_point(pt, link):
         J = np.zeros((3, nv))
         for k in range(nv):
             if on_path(k, link):
-                J[:, k] = axis_w[k] if jtype[k] == JOINT_SLIDE else np.cross(axis_w[k], pt - origin[k])
+                J[:, k] = axis_w[k] if slide_like[k] else np.cross(axis_w[k], pt - origin[k])
+        return J
+
+    def jac_rot(link):
+        J = np.zeros((3, nv))
+        for k in range(nv):
+            if on_path(k, link) and not slide_like[k]:
+                J[:, k] = axis_w[k]
         return J
 
     M0 = np.diag(f["armature"][:nv]).astype(float)
     for i in range(nb):
-        if mass[i] <= 0:
+        if mass[i] <= 0 or link_of_body[i] < 0:
             continue
         li = link_of_body[i]
         Jp = jac_point(p0[i] + R0[i] @ ipos[i], li)
-        Jr = np.zeros((3, nv))
-        for k in range(nv):
-            if on_path(k, li) and jtype[k] == JOINT_HINGE:
-                Jr[:, k] = axis_w[k]
+        Jr = jac_rot(li)
         Iw = R0[i] @ inert[i] @ R0[i].T
         M0 += mass[i] * Jp.T @ Jp + Jr.T @ Iw @ Jr
     M0inv = np.linalg.inv(M0)
     dof_iw = np.diag(M0inv).copy()
+    for i, b in enumerate(raw.bodies):      # MuJoCo averages a ball's three entries, a free joint's translations and rotations
+        if b.joint is not None and b.joint.type in (JOINT_BALL, JOINT_FREE):
+            j = first_link[i]
+            for g in range(2 if b.joint.type == JOINT_FREE else 1):
+                dof_iw[j + 3 * g:j + 3 * g + 3] = dof_iw[j + 3 * g:j + 3 * g + 3].mean()
     f["dof_invweight0"][:nv] = dof_iw
     body_iw = np.zeros(nb)
     for i in range(nb):
@@ -375,13 +489,18 @@ def compile_tree(raw: RawModel, overrides=None, base: "TreeModel" = None) -> Tre
     # ---- scalars, site, contacts --------------------------------------------------------------------------
     f["nv"][0], f["timestep"][0], f["frame_skip"][0], f["jumps"][0] = nv, raw.timestep, raw.frame_skip, jumps
     sb = raw.site_body
+    if link_of_body[sb] < 0:
+        raise ValueError("the tracked site must ride on a moving body")
     f["site_link"][0] = link_of_body[sb]
     f["site_pos"][:] = p0[sb] + R0[sb] @ np.asarray(raw.site_pos, float) - origin[link_of_body[sb]]
-    # contact points: a colliding sphere, or the two end spheres of a colliding capsule - the "to" end first, as
-    # MuJoCo's mjc_PlaneCapsule tests them - which also hand their axis to the contact frame.  Friction and condim of
-    # a contact are the larger of the two geoms' (mj_contactParam with equal priorities).
+    # contact points: a colliding sphere, the two end spheres of a colliding capsule - the "to" end first, as
+    # MuJoCo's mjc_PlaneCapsule tests them - which also hand their axis to the contact frame, or the eight corners of a
+    # colliding box (mjc_PlaneBox; radius 0).  Friction and condim of a contact are the larger of the two geoms'
+    # (mj_contactParam with equal priorities).
     points = []
     for i, b in enumerate(raw.bodies):
+        if link_of_body[i] < 0:
+            continue
         for g in b.geoms:
             if not g.collide:
                 continue
@@ -389,6 +508,12 @@ def compile_tree(raw: RawModel, overrides=None, base: "TreeModel" = None) -> Tre
             radius = float(np.ravel(size)[0]) if size is not None else g.radius
             if g.type == GEOM_SPHERE:
                 points.append((i, g, np.asarray(g.a, float), np.zeros(3), radius))
+            elif g.type == GEOM_BOX:
+                half = np.asarray(np.ravel(size)[:3] if size is not None else g.b, float)
+                Rg = _quat2mat(g.quat)
+                for e in range(8):
+                    c = np.array([half[0] if e & 1 else -half[0], half[1] if e & 2 else -half[1], half[2] if e & 4 else -half[2]])
+                    points.append((i, g, np.asarray(g.a, float) + Rg @ c, np.zeros(3), 0.0))
             else:
                 a, e = np.asarray(g.a, float), np.asarray(g.b, float)
                 u = (e - a) / np.linalg.norm(e - a)
@@ -398,22 +523,34 @@ def compile_tree(raw: RawModel, overrides=None, base: "TreeModel" = None) -> Tre
                 points += [(i, g, e, u, radius), (i, g, a, u, radius)]
     if raw.plane is None:
         points = []
-    if len(points) + len(pair_geoms) > TREE_MAX_SPHERES:
-        raise ValueError("tree kernel supports %d contact points (a capsule on the plane counts two, a geom-geom pair one)"
-                         % TREE_MAX_SPHERES)
+    n_eq_pts = len(raw.equalities)
+    n_tn_pts = sum(1 for t in raw.tendons if t.limited)
+    if len(points) + len(pair_geoms) + n_eq_pts + n_tn_pts > TREE_MAX_SPHERES:
+        raise ValueError("tree kernel supports %d contact records (a capsule on the plane counts two, a box eight, a geom-geom "
+                         "pair, an equality and a tendon limit one each)" % TREE_MAX_SPHERES)
     if raw.plane is not None:
         n = np.asarray(raw.plane.normal, float)
         n = n / np.linalg.norm(n)
         f["plane_n"][:] = n
         f["plane_d"][0] = n @ np.asarray(raw.plane.pos, float)
-    f["n_sphere"][0] = len(points) + len(pair_geoms)
 
     def geom_mu(g):
         mu_g = overrides.get("geom_friction", {}).get(g.name)
         return float(np.ravel(mu_g)[0]) if mu_g is not None else g.friction
 
     def body_w(i):
+        if i < 0:
+            return 0.0                                              # the world body weighs 0
         return base.body_invweight0[i] if base is not None else body_iw[i]
+
+    def in_link(i, v):
+        """A point / vector given in body i's frame, in the world-aligned frame of the body's link (world: as it is)."""
+        return np.asarray(v, float) if i < 0 else R0[i] @ np.asarray(v, float)
+
+    def link_point(i, pos):
+        if i < 0 or link_of_body[i] < 0:        # static: world coordinates (a static body's pose is baked in)
+            return (p0[i] + R0[i] @ np.asarray(pos, float)) if i >= 0 else np.asarray(pos, float)
+        return p0[i] + R0[i] @ np.asarray(pos, float) - origin[link_of_body[i]]
 
     for s, (i, g, pos, u, radius) in enumerate(points):
         li = link_of_body[i]
@@ -430,26 +567,32 @@ def compile_tree(raw: RawModel, overrides=None, base: "TreeModel" = None) -> Tre
         rec[8:11] = R0[i] @ u
         rec[11] = edepth[li] - 1                            # strict ancestors of the point's link (elimination tree)
         rec[13] = -1.0
-    # geom-geom pairs: both geoms as segments (start, vector; a sphere has a zero vector) in their links' frames; the
-    # record is anchored at the manipulator's link, whose elimination path contains the object's links
-    for s, ((ia, ga), (ib, gb)) in enumerate(pair_geoms, start=len(points)):
+    # geom-geom pairs: spheres / capsules as segments (start, vector; a sphere has a zero vector) in their links' frames;
+    # ONE geom of a pair may be a box (against a sphere).  The record is anchored at link A, whose elimination path
+    # contains link B (an object's links above a manipulator, an ancestor in the same tree, or the world: -1)
+    s = len(points)
+    for (ia, ga), (ib, gb) in pair_geoms:
         rec = f["spheres"][s * SPH_STRIDE:(s + 1) * SPH_STRIDE]
-        la, lb = link_of_body[ia], link_of_body[ib]
+        ext = f["pext"][s * PEXT_STRIDE:(s + 1) * PEXT_STRIDE]
+        la, lb = blink(ia), blink(ib)
+        assert lb < 0 or e_is_ancestor(lb, la)
 
-        def seg(i, g, li):
+        def seg(i, g):
             size = overrides.get("geom_size", {}).get(g.name)
             r = float(np.ravel(size)[0]) if size is not None else g.radius
             a = np.asarray(g.a, float)
             if g.type == GEOM_SPHERE:
-                return p0[i] + R0[i] @ a - origin[li], np.zeros(3), r
+                return link_point(i, a), np.zeros(3), r
+            if g.type == GEOM_BOX:
+                return link_point(i, a), np.zeros(3), 0.0
             e = np.asarray(g.b, float)
             if size is not None:
                 u, c, half = (e - a) / np.linalg.norm(e - a), 0.5 * (a + e), float(np.ravel(size)[1])
                 a, e = c - half * u, c + half * u
-            return p0[i] + R0[i] @ a - origin[li], R0[i] @ (e - a), r
+            return link_point(i, a), in_link(i, e - a), r
 
-        a0, da, ra = seg(ia, ga, la)
-        b0, db, rb = seg(ib, gb, lb)
+        a0, da, ra = seg(ia, ga)
+        b0, db, rb = seg(ib, gb)
         condim = max(int(ga.condim), int(gb.condim))
         if condim not in (1, 3):
             raise NotImplementedError("contacts are condim 1 (frictionless) or 3 (pyramidal cone), got %d" % condim)
@@ -459,13 +602,24 @@ def compile_tree(raw: RawModel, overrides=None, base: "TreeModel" = None) -> Tre
         rec[7] = max(geom_mu(ga), geom_mu(gb)) if condim == 3 else 0.0
         rec[8:11] = da
         rec[11] = edepth[la] - 1
-        rec[12] = 1.0
+        rec[12] = PT_SEGSEG
         rec[13], rec[14:17], rec[17], rec[18:21] = lb, b0, rb, db
-    nsp = len(points) + len(pair_geoms)
-    f["any_friction"][0] = 1.0 if (any(f["spheres"][s * SPH_STRIDE + 7] > 0 for s in range(nsp)) or pair_geoms
-                                   or any(f["kpg"] != 0) or raw.task == TASK_ORIENT) else 0.0
+        boxes = [k for k, g in enumerate((ga, gb)) if g.type == GEOM_BOX]
+        if boxes:
+            if len(boxes) == 2 or (gb if boxes[0] == 0 else ga).type != GEOM_SPHERE:
+                raise NotImplementedError("a box collides with the plane and with spheres (box-box / box-capsule are not built)")
+            ibx, gbx = (ia, ga) if boxes[0] == 0 else (ib, gb)
+            size = overrides.get("geom_size", {}).get(gbx.name)
+            ext[0:3] = np.ravel(size)[:3] if size is not None else gbx.b
+            Rl = _quat2mat(gbx.quat) if ibx < 0 else R0[ibx] @ _quat2mat(gbx.quat)
+            ext[3:12] = Rl.reshape(-1)
+            rec[12] = PT_BOX_SPHERE if boxes[0] == 0 else PT_SPHERE_BOX
+            gen = True
+        if lb < 0:
+            gen = True              # (a static second geom: the general instantiation knows the world as "link -1")
+        s += 1
 
-    def sol_set(prefix, solref, solimp):
+    def sol_values(solref, solimp):
         tc, dr = solref
         if tc <= 0 or dr <= 0:
             raise NotImplementedError("solref must be the standard (timeconst, dampratio) pair")
@@ -475,17 +629,100 @@ def compile_tree(raw: RawModel, overrides=None, base: "TreeModel" = None) -> Tre
         mid, width, power = np.clip(mid, MJ_MINIMP, MJ_MAXIMP), max(width, 0.0), max(power, 1.0)
         if power != int(power) or power > 64:
             raise NotImplementedError("solimp power must be an integer in [1, 64] (MuJoCo's default is 2), got %r" % (power,))
-        f[prefix + "_K"][0] = 1.0 / (dmax * dmax * tc * tc * dr * dr)
-        f[prefix + "_B"][0] = 2.0 / (dmax * tc)
+        K, B = 1.0 / (dmax * dmax * tc * tc * dr * dr), 2.0 / (dmax * tc)
         if width <= 1e-15:                                          # MuJoCo getimpedance: a flat impedance
             dmin = dmax = 0.5 * (dmin + dmax)
             width = 1.0
-        f[prefix + "_dmin"][0], f[prefix + "_dmax"][0] = dmin, dmax
-        f[prefix + "_width"][0], f[prefix + "_mid"][0], f[prefix + "_power"][0] = width, mid, power
+        return [K, B, dmin, dmax, width, mid, power]
+
+    # equality constraints and tendon limits ride in the contact records too (general instantiation)
+    def full_solimp(si):
+        return tuple(si) + (0.9, 0.95, 0.001, 0.5, 2.0)[len(si):]
+
+    for e in raw.equalities:
+        rec = f["spheres"][s * SPH_STRIDE:(s + 1) * SPH_STRIDE]
+        ext = f["pext"][s * PEXT_STRIDE:(s + 1) * PEXT_STRIDE]
+        ext[12:19] = sol_values(e.solref, full_solimp(e.solimp))
+        ext[19] = 1.0
+        gen = True
+        if e.type == EQ_CONNECT:
+            i1, i2 = bnames.index(e.obj1), (bnames.index(e.obj2) if e.obj2 else -1)
+            anchor_w = p0[i1] + R0[i1] @ np.asarray(e.anchor, float)        # the shared point at qpos0, world
+            l1, l2 = blink(i1), blink(i2)
+            if l1 < 0 and l2 < 0:
+                raise NotImplementedError("connect %r / %r: both bodies are static" % (e.obj1, e.obj2))
+            if l2 > l1:
+                i1, i2, l1, l2 = i2, i1, l2, l1         # anchored at the higher link (a bilateral row's sign is immaterial)
+            assert l2 < 0 or e_is_ancestor(l2, l1) or all(e_is_ancestor(k, l1) for k in kpath(l2))
+            rec[0], rec[1:4] = l1, anchor_w - origin[l1]
+            rec[13], rec[14:17] = l2, (anchor_w - origin[l2]) if l2 >= 0 else anchor_w
+            rec[6] = body_w(i1) + body_w(i2)
+            rec[11] = edepth[l1] - 1
+            rec[12] = PT_CONNECT
+        elif e.type == EQ_JOINT:
+            d1, d2 = raw.dof_of_joint(e.obj1), (raw.dof_of_joint(e.obj2) if e.obj2 else -1)
+            for d in (d1, d2):
+                if d >= 0 and link_kind[d] not in (LINK_HINGE, LINK_SLIDE):
+                    raise NotImplementedError("joint equalities couple hinge / slide joints")
+            w = (base.dof_invweight0 if base is not None else dof_iw)
+            rec[6] = w[d1] + (w[d2] if d2 >= 0 else 0.0)
+            # anchored at the higher dof; [1] which of the two carries q1 (coefficient +1)
+            if d2 > d1:
+                rec[0], rec[13], ext[1] = d2, d1, 1.0       # anchor = joint 2, the other (joint 1) above it
+            else:
+                rec[0], rec[13], ext[1] = d1, d2, 0.0
+            assert rec[13] < 0 or e_is_ancestor(int(rec[13]), int(rec[0]))
+            ext[0] = 0.0
+            ext[6:11] = e.polycoef
+            rec[11] = edepth[int(rec[0])] - 1
+            rec[12] = PT_DOFROW
+        else:
+            raise NotImplementedError("weld equalities are not built (connect and joint are)")
+        s += 1
+    for t in raw.tendons:
+        if not t.limited:
+            continue
+        if len(t.joints) > 2:
+            raise NotImplementedError("tendon limits over more than two joints are not compiled for the kernel")
+        rec = f["spheres"][s * SPH_STRIDE:(s + 1) * SPH_STRIDE]
+        ext = f["pext"][s * PEXT_STRIDE:(s + 1) * PEXT_STRIDE]
+        dofs = [(raw.dof_of_joint(jn), float(c)) for jn, c in t.joints]
+        if any(link_kind[d] not in (LINK_HINGE, LINK_SLIDE) for d, _ in dofs):
+            raise NotImplementedError("fixed tendons run over hinge / slide joints")
+        dofs.sort(key=lambda dc: -dc[0])                    # the higher dof first: the other lies on its elimination path
+        assert len(dofs) == 1 or e_is_ancestor(dofs[1][0], dofs[0][0])
+        Jt = np.zeros(nv)
+        for d, c in dofs:
+            Jt[d] += c
+        rec[0], rec[13] = dofs[0][0], (dofs[1][0] if len(dofs) == 2 else -1)
+        rec[5] = t.margin
+        rec[6] = float(Jt @ M0inv @ Jt) if base is None else base.tendon_invweight0[t.name]
+        rec[11] = edepth[dofs[0][0]] - 1
+        rec[12] = PT_DOFROW
+        ext[0] = 1.0
+        ext[1], ext[2] = dofs[0][1], (dofs[1][1] if len(dofs) == 2 else 0.0)
+        ext[3:5] = t.range
+        ext[5] = t.margin
+        gen = True
+        s += 1
+    nsp = s
+    f["n_sphere"][0] = nsp
+    gen = gen or bool(np.any(f["frictionloss"] > 0))
+    f["gen"][0] = 1.0 if gen else 0.0
+    f["nq"][0] = nq
+    f["has_ball"][0] = 1.0 if any(k == LINK_BALL_X for k in link_kind) else 0.0
+    f["any_friction"][0] = 1.0 if (any(f["spheres"][k * SPH_STRIDE + 7] > 0 for k in range(nsp)) or pair_geoms
+                                   or any(f["kpg"] != 0) or raw.task == TASK_ORIENT or gen) else 0.0
+
+    def sol_set(prefix, solref, solimp):
+        vals = sol_values(solref, solimp)
+        for name, v in zip(("_K", "_B", "_dmin", "_dmax", "_width", "_mid", "_power"), vals):
+            f[prefix + name][0] = v
 
     sol_set("sol", raw.solref, raw.solimp)
     sol_set("lsol", raw.solref if raw.solref_limit is None else raw.solref_limit,
             raw.solimp if raw.solimp_limit is None else raw.solimp_limit)
+    sol_set("fsol", raw.solref_friction, full_solimp(raw.solimp_friction))
     f["gravity"][:] = raw.gravity
     f["nu"][0], f["task"][0], f["ctrl_cost"][0], f["obs_skip"][0] = nu, raw.task, raw.ctrl_cost, raw.obs_skip
     f["density"][0], f["viscosity"][0] = raw.density, raw.viscosity
@@ -493,13 +730,24 @@ def compile_tree(raw: RawModel, overrides=None, base: "TreeModel" = None) -> Tre
         raise ValueError("unknown task / observation layout")
     f["site_axis"][:] = R0[sb] @ np.asarray(raw.site_axis, float)
     f["target_dir"][:] = raw.target_dir
-    d_obs = 2 * nv - raw.obs_skip if raw.task == TASK_FORWARD else 2 * nv + 6
+    d_obs = nq + nv - raw.obs_skip if raw.task == TASK_FORWARD else nq + nv + 6
+    tendon_iw = {}
+    for t in raw.tendons:
+        Jt = np.zeros(nv)
+        for jn, c in t.joints:
+            Jt[raw.dof_of_joint(jn)] += float(c)
+        tendon_iw[t.name] = float(Jt @ M0inv @ Jt)
     if base is not None:            # run-time edit: MuJoCo keeps the constants mj_setConst computed at load time
         f["dof_invweight0"][:] = base.field("dof_invweight0")
         dof_iw, body_iw = base.dof_invweight0.copy(), base.body_invweight0.copy()
+        tendon_iw = dict(base.tendon_invweight0)
     blob = np.concatenate([f[name] for name, _ in TREE_LAYOUT]).astype(np.float64)
     assert blob.size == TREE_BLOB_LEN
-    return TreeModel(blob=blob, nv=nv, nu=nu, d_obs=d_obs, timestep=raw.timestep, frame_skip=raw.frame_skip,
-                     target_default=np.asarray(raw.target_pos, float), ctrl_lo=ctrl_lo, ctrl_hi=ctrl_hi, parent=parent,
-                     task=int(raw.task), obs_skip=int(raw.obs_skip), max_path=int(edepth.max()),
-                     body_mass=mass, body_inertia=inert, body_invweight0=body_iw, dof_invweight0=dof_iw, link_of_body=link_of_body)
+    tm = TreeModel(blob=blob, nv=nv, nu=nu, d_obs=d_obs, timestep=raw.timestep, frame_skip=raw.frame_skip,
+                   target_default=np.asarray(raw.target_pos, float), ctrl_lo=ctrl_lo, ctrl_hi=ctrl_hi, parent=parent,
+                   task=int(raw.task), obs_skip=int(raw.obs_skip), max_path=int(edepth.max()),
+                   body_mass=mass, body_inertia=inert, body_invweight0=body_iw, dof_invweight0=dof_iw, link_of_body=link_of_body,
+                   nq=nq, qpos0=raw.qpos0)
+    tm.tendon_invweight0 = tendon_iw
+    tm.general = bool(gen)
+    return tm

@@ -1,19 +1,27 @@
 """MJCF-subset loader: the part of MuJoCo's XML the rollout kernels can execute.
 
-Enough for the three models the reference vendors (mjmpc/envs/assets/xml/sawyer.xml, swimmer.xml, half_cheetah.xml):
+The three models the reference vendors (mjmpc/envs/assets/xml/sawyer.xml, swimmer.xml, half_cheetah.xml) and, since
+round 4, the kinds of model its other experiment files name (examples/configs/classic_control/cartpole*.yml,
+panda/tray_glass-v0.yml, sawyer/door-v0.yml, hand/*-v0.yml):
 
-* ``<compiler angle="radian" coordinate="local" inertiafromgeom="true" settotalmass>``,
+* ``<compiler angle="radian|degree" coordinate="local" inertiafromgeom="true|auto" settotalmass>``,
   ``<option timestep gravity density viscosity integrator="Euler">``;
 * ``<default>`` with nested classes, ``class=`` / ``childclass=`` (joint, geom and motor attributes);
-* nested ``<body pos quat>`` with any number of hinge / slide ``<joint>``s anchored at the body origin - a body with
-  several joints becomes a chain of massless bodies, one joint each, which is what MuJoCo's kinematics does with it;
-  joint ``axis range limited damping armature stiffness springref``, ``solreflimit`` / ``solimplimit`` (one set per model);
-* sphere and capsule geoms (``fromto``, or ``size pos`` with ``quat`` / ``axisangle``), ``density``, ``margin``,
-  ``friction``, ``condim``, ``contype`` / ``conaffinity`` (what collides is decided against the one world plane,
-  with MuJoCo's rule), ``solref`` / ``solimp`` (one set per model);
-* one world ``<geom type="plane">``, world and body ``<site>``s, ``<motor joint gear ctrlrange ctrllimited>`` and
-  ``<position joint kp ctrlrange ctrllimited>`` actuators, ``<contact><pair geom1 geom2>`` (sphere / capsule geoms of a
-  manipulator against those of one free object).
+* nested ``<body pos quat|axisangle|euler>`` with any number of hinge / slide ``<joint>``s (anchor ``pos`` anywhere in
+  the body) - a body with several joints becomes a chain of massless bodies, one joint each, which is what MuJoCo's
+  kinematics does with it - or ONE ball joint, or a ``<freejoint/>`` / free joint (children of the world body);
+  joint ``axis range limited damping armature stiffness springref frictionloss``, ``solreflimit`` / ``solimplimit``,
+  ``solreffriction`` / ``solimpfriction`` (one set each per model); explicit ``<inertial pos quat mass
+  diaginertia|fullinertia>``;
+* sphere, capsule and box geoms (``fromto``, or ``size pos`` with ``quat`` / ``axisangle`` / ``euler``), ``density``,
+  ``mass``, ``margin``, ``friction``, ``condim``, ``contype`` / ``conaffinity`` (what collides with the world plane and -
+  ``self_collision`` - with other bodies is decided by MuJoCo's rule), ``solref`` / ``solimp`` (one set per model);
+* one world ``<geom type="plane">`` in any orientation, static sphere / capsule / box geoms on the world body (they
+  collide with moving geoms through MuJoCo's contype / conaffinity rule or an explicit ``<pair>``), world and body
+  ``<site>``s, ``<motor joint gear ctrlrange ctrllimited>`` and ``<position joint kp ctrlrange ctrllimited>`` actuators,
+  ``<contact><pair geom1 geom2>``; geom pairs: sphere / capsule against sphere / capsule, sphere against box;
+* ``<equality><connect body1 body2 anchor>`` and ``<joint joint1 joint2 polycoef>`` (``solref`` / ``solimp`` each),
+  ``<tendon><fixed limited range><joint joint coef/>`` over one or two joints.
 
 Anything that would change the simulation and is not modelled raises ValueError, so that a model is never silently
 simulated wrongly; purely visual elements (asset, light, camera, material, rgba ...) are skipped.
@@ -22,12 +30,56 @@ import xml.etree.ElementTree as ET
 
 import numpy as np
 
-from .compile import _geom_inertial
-from .raw import (GEOM_CAPSULE, GEOM_SPHERE, JOINT_HINGE, JOINT_SLIDE, MJ20_CAPSULE_CAP, TASK_FORWARD, TASK_REACH, RawActuator,
-                  RawBody, RawGeom, RawJoint, RawModel, RawPlane)
+from .compile import _geom_inertial, _quat2mat
+from .raw import (EQ_CONNECT, EQ_JOINT, GEOM_BOX, GEOM_CAPSULE, GEOM_SPHERE, JOINT_BALL, JOINT_FREE, JOINT_HINGE, JOINT_SLIDE,
+                  MJ20_CAPSULE_CAP, TASK_FORWARD, TASK_REACH, RawActuator, RawBody, RawEquality, RawGeom, RawInertial,
+                  RawJoint, RawModel, RawPlane, RawTendon)
 
 _VISUAL_BODY_TAGS = ("light", "camera")
-_TOP_TAGS = ("compiler", "option", "default", "worldbody", "actuator", "asset", "size", "visual", "statistic", "custom")
+_TOP_TAGS = ("compiler", "option", "default", "worldbody", "actuator", "asset", "size", "visual", "statistic", "custom",
+             "equality", "tendon")
+
+
+def _mat2quat(R):
+    """Unit quaternion (w, x, y, z) of a rotation matrix."""
+    R = np.asarray(R, float)
+    tr = np.trace(R)
+    if tr > 0:
+        sq = np.sqrt(tr + 1.0) * 2
+        q = [0.25 * sq, (R[2, 1] - R[1, 2]) / sq, (R[0, 2] - R[2, 0]) / sq, (R[1, 0] - R[0, 1]) / sq]
+    elif R[0, 0] > R[1, 1] and R[0, 0] > R[2, 2]:
+        sq = np.sqrt(1.0 + R[0, 0] - R[1, 1] - R[2, 2]) * 2
+        q = [(R[2, 1] - R[1, 2]) / sq, 0.25 * sq, (R[0, 1] + R[1, 0]) / sq, (R[0, 2] + R[2, 0]) / sq]
+    elif R[1, 1] > R[2, 2]:
+        sq = np.sqrt(1.0 + R[1, 1] - R[0, 0] - R[2, 2]) * 2
+        q = [(R[0, 2] - R[2, 0]) / sq, (R[0, 1] + R[1, 0]) / sq, 0.25 * sq, (R[1, 2] + R[2, 1]) / sq]
+    else:
+        sq = np.sqrt(1.0 + R[2, 2] - R[0, 0] - R[1, 1]) * 2
+        q = [(R[1, 0] - R[0, 1]) / sq, (R[0, 2] + R[2, 0]) / sq, (R[1, 2] + R[2, 1]) / sq, 0.25 * sq]
+    return np.asarray(q, float)
+
+
+def _rodrigues(ax, ang):
+    ax = np.asarray(ax, float) / np.linalg.norm(ax)
+    K = np.array([[0, -ax[2], ax[1]], [ax[2], 0, -ax[0]], [-ax[1], ax[0], 0]])
+    return np.eye(3) + np.sin(ang) * K + (1 - np.cos(ang)) * K @ K
+
+
+def _orientation(e, deg):
+    """Rotation matrix of an element's ``quat`` / ``axisangle`` / ``euler`` (MuJoCo's default intrinsic x-y-z sequence)
+    attribute, or None when it carries none; angles in degrees unless the model says radian."""
+    if e.get("quat") is not None:
+        return _quat2mat(_floats(e.get("quat"), 4))
+    if e.get("axisangle") is not None:
+        v = _floats(e.get("axisangle"), 4)
+        return _rodrigues(v[:3], v[3] * deg)
+    if e.get("euler") is not None:
+        a = [x * deg for x in _floats(e.get("euler"), 3)]
+        return _rodrigues([1, 0, 0], a[0]) @ _rodrigues([0, 1, 0], a[1]) @ _rodrigues([0, 0, 1], a[2])
+    for k in ("xyaxes", "zaxis"):
+        if e.get(k) is not None:
+            raise ValueError("orientation must be given as quat, axisangle or euler")
+    return None
 
 
 def _floats(s, n=None, default=None):
@@ -95,15 +147,18 @@ def load_mjcf(path, hand_site="finger", target_site="target", frame_skip=2, task
             raise ValueError("unsupported element <%s>" % e.tag)
     comp = root.find("compiler")
     totalmass = None
+    deg = np.pi / 180.0                 # MuJoCo's default angle unit is the degree
     if comp is not None:
-        if comp.get("angle", "degree") != "radian" or comp.get("coordinate", "local") != "local":
-            raise ValueError("only angle='radian', coordinate='local' are supported")
+        if comp.get("angle", "degree") not in ("radian", "degree") or comp.get("coordinate", "local") != "local":
+            raise ValueError("angle must be 'radian' or 'degree', coordinate 'local'")
+        if comp.get("angle", "degree") == "radian":
+            deg = 1.0
         if comp.get("inertiafromgeom", "auto") not in ("true", "auto"):
-            raise ValueError("inertiafromgeom must be true")
+            raise ValueError("inertiafromgeom must be true or auto")
+        if comp.get("eulerseq", "xyz") != "xyz":
+            raise ValueError("eulerseq must be xyz")
         if comp.get("settotalmass") is not None:
             totalmass = float(comp.get("settotalmass"))
-    else:
-        raise ValueError("angle='radian' must be set (MuJoCo's default is degrees)")
     opt = root.find("option")
     oget = (lambda k, d: opt.get(k, d)) if opt is not None else (lambda k, d: d)
     timestep = float(oget("timestep", "0.002"))
@@ -120,7 +175,8 @@ def load_mjcf(path, hand_site="finger", target_site="target", frame_skip=2, task
     bodies, sites = [], {}
     plane_elem = None
     world = root.find("worldbody")
-    geom_solver, limit_solver = set(), set()
+    geom_solver, limit_solver, friction_solver = set(), set(), set()
+    DEF_SOL = ((0.02, 1.0), (0.9, 0.95, 0.001, 0.5, 2.0))
 
     def parse_geom(e, active):
         ga = lambda k, d=None: dfl.attr("geom", e, active, k, d)        # noqa: E731
@@ -132,6 +188,7 @@ def load_mjcf(path, hand_site="finger", target_site="target", frame_skip=2, task
         if float(ga("gap", "0")) != 0.0:
             raise ValueError("geom gap is not supported")
         pos = np.asarray(_floats(e.get("pos"), 3, [0.0, 0.0, 0.0]))
+        Rg = _orientation(e, deg)
         if t == "sphere":
             g = RawGeom(GEOM_SPHERE, size[0], tuple(pos), **common)
         elif t == "capsule":
@@ -139,29 +196,38 @@ def load_mjcf(path, hand_site="finger", target_site="target", frame_skip=2, task
             if ft is not None:
                 a, b = ft[:3], ft[3:]
             else:
-                if e.get("quat") is not None:
-                    z = _quat_z(_floats(e.get("quat"), 4))
-                elif e.get("axisangle") is not None:
-                    z = _axisangle_z(_floats(e.get("axisangle"), 4))
-                elif e.get("euler") is not None or e.get("zaxis") is not None or e.get("xyaxes") is not None:
-                    raise ValueError("geom orientation must be fromto, quat or axisangle")
-                else:
-                    z = np.array([0.0, 0.0, 1.0])
+                z = np.array([0.0, 0.0, 1.0]) if Rg is None else Rg[:, 2]
                 a, b = tuple(pos - size[1] * z), tuple(pos + size[1] * z)
             g = RawGeom(GEOM_CAPSULE, size[0], tuple(a), tuple(b), **common)
+        elif t == "box":
+            if e.get("fromto") is not None:
+                raise ValueError("box geoms take size / pos / orientation, not fromto")
+            if size is None or len(size) != 3:
+                raise ValueError("a box needs three half sizes")
+            g = RawGeom(GEOM_BOX, 0.0, tuple(pos), tuple(size), quat=tuple(_mat2quat(Rg) if Rg is not None else (1.0, 0.0, 0.0, 0.0)),
+                        **common)
         else:
             raise ValueError("unsupported geom type %r" % t)
+        if ga("mass") is not None:          # MJCF: mass overrides density
+            g.density = 1.0
+            vol = _geom_inertial(g, MJ20_CAPSULE_CAP)[0]
+            g.density = float(ga("mass")) / vol
         g._contype, g._conaffinity = int(ga("contype", "1")), int(ga("conaffinity", "1"))
         g._solver = (tuple(_floats(ga("solref", "0.02 1"))), tuple(_floats(ga("solimp", "0.9 0.95 0.001 0.5 2"))))
         return g
 
+    world_geoms = []
     for e in world:
         if e.tag == "geom":
-            if dfl.attr("geom", e, None, "type", "sphere") != "plane":
-                raise ValueError("only a plane may be attached to the world body")
-            if plane_elem is not None:
-                raise ValueError("one world plane at most")
-            plane_elem = e
+            if dfl.attr("geom", e, world.get("childclass"), "type", "sphere") == "plane":
+                if plane_elem is not None:
+                    raise ValueError("one world plane at most")
+                plane_elem = e
+            else:
+                g = parse_geom(e, world.get("childclass"))
+                if not g.name:
+                    g.name = "world_geom%d" % len(world_geoms)
+                world_geoms.append(g)
         elif e.tag == "site":
             sites[e.get("name")] = (-1, _floats(e.get("pos"), 3, [0.0, 0.0, 0.0]))
         elif e.tag != "body" and e.tag not in _VISUAL_BODY_TAGS:
@@ -169,21 +235,32 @@ def load_mjcf(path, hand_site="finger", target_site="target", frame_skip=2, task
 
     def parse_joint(j, active):
         ja = lambda k, d=None: dfl.attr("joint", j, active, k, d)       # noqa: E731
-        t = ja("type", "hinge")
-        if t not in ("hinge", "slide"):
-            raise ValueError("only hinge and slide joints are supported, got %r" % t)
-        if _floats(j.get("pos"), 3, [0.0, 0.0, 0.0]) != [0.0, 0.0, 0.0]:
-            raise ValueError("joint anchors must be at the body origin")
-        if float(ja("frictionloss", "0")) != 0.0 or float(ja("margin", "0")) != 0.0:
-            raise ValueError("joint frictionloss / margin are not supported")
-        limited = ja("limited", "false") == "true"
+        t = "free" if j.tag == "freejoint" else ja("type", "hinge")
+        if t not in ("hinge", "slide", "ball", "free"):
+            raise ValueError("unknown joint type %r" % t)
+        if float(ja("margin", "0")) != 0.0 or float(ja("ref", "0")) != 0.0:
+            raise ValueError("joint margin / ref are not supported")
+        if j.tag == "freejoint":            # MJCF: <freejoint/> takes no defaults: no damping, armature or friction loss
+            return RawJoint(axis=[0.0, 0.0, 1.0], range=[0.0, 0.0], limited=False, name=j.get("name", ""), type=JOINT_FREE)
+        limited = ja("limited", "false") == "true" and t != "free"      # (MuJoCo ignores limits on free joints)
+        if limited and t == "ball":
+            raise ValueError("limits of ball joints are not supported")
         if limited:
             limit_solver.add((tuple(_floats(ja("solreflimit", "0.02 1"))),
                               tuple(_floats(ja("solimplimit", "0.9 0.95 0.001 0.5 2")))))
-        return RawJoint(axis=_floats(ja("axis"), 3, [0.0, 0.0, 1.0]), range=_floats(ja("range"), 2, [0.0, 0.0]),
+        floss = float(ja("frictionloss", "0"))
+        if floss != 0.0:
+            friction_solver.add((tuple(_floats(ja("solreffriction", "0.02 1"))),
+                                 tuple(_floats(ja("solimpfriction", "0.9 0.95 0.001 0.5 2")))))
+        ang = deg if t == "hinge" else 1.0      # (a hinge's range and spring reference are angles)
+        rng = [x * ang for x in _floats(ja("range"), 2, [0.0, 0.0])]
+        jtype = {"hinge": JOINT_HINGE, "slide": JOINT_SLIDE, "ball": JOINT_BALL, "free": JOINT_FREE}[t]
+        return RawJoint(axis=_floats(ja("axis"), 3, [0.0, 0.0, 1.0]), range=rng,
                         limited=limited, damping=float(ja("damping", "0")), armature=float(ja("armature", "0")),
-                        name=j.get("name", ""), type=JOINT_SLIDE if t == "slide" else JOINT_HINGE,
-                        stiffness=float(ja("stiffness", "0")), springref=float(ja("springref", "0")))
+                        name=j.get("name", ""), type=jtype,
+                        stiffness=float(ja("stiffness", "0")), springref=float(ja("springref", "0")) * ang,
+                        pos=_floats(j.get("pos"), 3, [0.0, 0.0, 0.0]) if t in ("hinge", "ball") else [0.0, 0.0, 0.0],
+                        frictionloss=floss)
 
     xml_body, xml_parent = [], []       # per RawBody: the XML body it belongs to; per XML body: its parent XML body
 
@@ -191,12 +268,15 @@ def load_mjcf(path, hand_site="finger", target_site="target", frame_skip=2, task
         active = e.get("childclass", active)
         xid = len(xml_parent)
         xml_parent.append(xparent)
-        joints = [parse_joint(j, active) for j in e.findall("joint")]
+        joints = [parse_joint(j, active) for j in e if j.tag in ("joint", "freejoint")]
         name = e.get("name", "body%d" % len(bodies))
-        pos, quat = _floats(e.get("pos"), 3, [0.0, 0.0, 0.0]), _floats(e.get("quat"), 4, [1.0, 0.0, 0.0, 0.0])
-        for k in ("axisangle", "euler", "xyaxes", "zaxis"):
-            if e.get(k) is not None:
-                raise ValueError("body orientation must be given as quat")
+        pos = _floats(e.get("pos"), 3, [0.0, 0.0, 0.0])
+        Rb = _orientation(e, deg)
+        quat = [1.0, 0.0, 0.0, 0.0] if Rb is None else list(_mat2quat(Rb))
+        if any(j.type in (JOINT_BALL, JOINT_FREE) for j in joints) and len(joints) > 1:
+            raise ValueError("a ball or free joint must be its body's only joint")
+        if any(j.type == JOINT_FREE for j in joints) and parent >= 0:
+            raise ValueError("a free joint belongs to a child of the world body")
         # joints 0 .. n-2 ride on massless bodies; the last one (or none) on the body itself
         for k, jt in enumerate(joints[:-1]):
             if not jt.name:
@@ -210,16 +290,25 @@ def load_mjcf(path, hand_site="finger", target_site="target", frame_skip=2, task
         jt = joints[-1] if joints else None
         if jt is not None and not jt.name:
             jt.name = "%s_joint%d" % (name, len(joints) - 1)
-        bodies.append(RawBody(name, parent, pos if first else [0.0, 0.0, 0.0], quat if first else [1.0, 0.0, 0.0, 0.0], jt,
-                              [parse_geom(g, active) for g in e.findall("geom")]))
-        xml_body.append(xid)
-        for s in e.findall("site"):
-            sites[s.get("name")] = (idx, _floats(s.get("pos"), 3, [0.0, 0.0, 0.0]))
+        inertial = None
         for c in e:
-            if c.tag not in ("joint", "geom", "site", "body", "inertial") + _VISUAL_BODY_TAGS:
+            if c.tag not in ("joint", "freejoint", "geom", "site", "body", "inertial") + _VISUAL_BODY_TAGS:
                 raise ValueError("unsupported body element <%s>" % c.tag)
             if c.tag == "inertial":
-                raise ValueError("explicit <inertial> is not supported (inertiafromgeom only)")
+                ipos = _floats(c.get("pos"), 3, [0.0, 0.0, 0.0])
+                Ri = _orientation(c, deg)
+                Ri = np.eye(3) if Ri is None else Ri
+                if c.get("fullinertia") is not None:
+                    xx, yy, zz, xy, xz, yz = _floats(c.get("fullinertia"), 6)
+                    I = np.array([[xx, xy, xz], [xy, yy, yz], [xz, yz, zz]])
+                else:
+                    I = Ri @ np.diag(_floats(c.get("diaginertia"), 3)) @ Ri.T
+                inertial = RawInertial(float(c.get("mass")), ipos, I)
+        bodies.append(RawBody(name, parent, pos if first else [0.0, 0.0, 0.0], quat if first else [1.0, 0.0, 0.0, 0.0], jt,
+                              [parse_geom(g, active) for g in e.findall("geom")], inertial))
+        xml_body.append(xid)
+        for s_ in e.findall("site"):
+            sites[s_.get("name")] = (idx, _floats(s_.get("pos"), 3, [0.0, 0.0, 0.0]))
         for c in e.findall("body"):
             walk(c, idx, active, xid)
 
@@ -229,7 +318,7 @@ def load_mjcf(path, hand_site="finger", target_site="target", frame_skip=2, task
     # what collides: every body geom against the one world plane, MuJoCo's contype / conaffinity rule
     plane = None
     if plane_elem is not None:
-        pa = lambda k, d=None: dfl.attr("geom", plane_elem, None, k, d)     # noqa: E731
+        pa = lambda k, d=None: dfl.attr("geom", plane_elem, world.get("childclass"), k, d)     # noqa: E731
         pct, pca = int(pa("contype", "1")), int(pa("conaffinity", "1"))
         hit = False
         for b in bodies:
@@ -239,48 +328,91 @@ def load_mjcf(path, hand_site="finger", target_site="target", frame_skip=2, task
                 if g.collide:
                     geom_solver.add(g._solver)
         if hit:
-            q = _floats(plane_elem.get("quat"), 4, [1.0, 0.0, 0.0, 0.0])
-            if q != [1.0, 0.0, 0.0, 0.0]:
-                raise ValueError("rotated planes are not supported")
+            Rp = _orientation(plane_elem, deg)
+            normal = (0.0, 0.0, 1.0) if Rp is None else tuple(Rp[:, 2])
             geom_solver.add((tuple(_floats(pa("solref", "0.02 1"))), tuple(_floats(pa("solimp", "0.9 0.95 0.001 0.5 2")))))
-            plane = RawPlane(pos=_floats(plane_elem.get("pos"), 3, [0.0, 0.0, 0.0]), normal=(0.0, 0.0, 1.0),
+            plane = RawPlane(pos=_floats(plane_elem.get("pos"), 3, [0.0, 0.0, 0.0]), normal=normal,
                              margin=float(pa("margin", "0")), friction=_floats(pa("friction", "1 0.005 0.0001"))[0],
                              condim=int(pa("condim", "3")))
-    # ... and body geoms against each other (self_collision): MuJoCo's rule - the contype / conaffinity masks match, the
-    # two bodies differ and are not parent and child.  Later geom first (on a chain: the deeper one, which is the order
-    # compile_tree asks for).  swimmer.xml's segments are the vendored case (default contype = conaffinity = 1).
+    # ... and geoms against each other (self_collision): MuJoCo's rule - the contype / conaffinity masks match, the two
+    # bodies differ and are not parent and child (the world body is nobody's parent in that rule), and at least one of
+    # them moves.  Later geom first (on a chain: the deeper one, which is the order compile_tree asks for).
+    # swimmer.xml's segments are the vendored case (default contype = conaffinity = 1).
     auto_pairs = []
     if self_collision:
-        flat = [(bi, g) for bi, b in enumerate(bodies) for g in b.geoms]
+        moving = [False] * len(bodies)
+        for bi, b in enumerate(bodies):
+            moving[bi] = b.joint is not None or (b.parent >= 0 and moving[b.parent])
+        flat = [(-1, g) for g in world_geoms] + [(bi, g) for bi, b in enumerate(bodies) for g in b.geoms]
         for ib in range(len(flat)):
             for ia in range(ib):
                 (ba, ga_), (bb, gb_) = flat[ia], flat[ib]
-                xa, xb = xml_body[ba], xml_body[bb]
-                if xa == xb or xml_parent[xa] == xb or xml_parent[xb] == xa:
+                if not ((ba >= 0 and moving[ba]) or (bb >= 0 and moving[bb])):
                     continue
+                if ba >= 0 and bb >= 0:
+                    xa, xb = xml_body[ba], xml_body[bb]
+                    if xa == xb or xml_parent[xa] == xb or xml_parent[xb] == xa:
+                        continue
                 if not ((ga_._contype & gb_._conaffinity) or (gb_._contype & ga_._conaffinity)):
                     continue
+                kinds = sorted((ga_.type, gb_.type))
+                if GEOM_BOX in kinds and kinds != [GEOM_SPHERE, GEOM_BOX]:
+                    raise ValueError("geoms %r / %r would collide (contype / conaffinity) but a box only collides with the plane "
+                                     "and with spheres here: mask the pair out or replace the geom"
+                                     % (ga_.name or "?", gb_.name or "?"))
                 for k, (bi, g) in ((ia, flat[ia]), (ib, flat[ib])):
                     if not g.name:
-                        g.name = "%s_geom%d" % (bodies[bi].name, k)
+                        g.name = "%s_geom%d" % (bodies[bi].name if bi >= 0 else "world", k)
                     geom_solver.add(g._solver)
                 auto_pairs.append((gb_.name, ga_.name))
-    if len(geom_solver) > 1 or len(limit_solver) > 1:
-        raise ValueError("one solref / solimp set for contacts and one for joint limits")
+    # explicit geom-geom collision candidates (<contact><pair geom1=... geom2=...>)
+    pairs = list(auto_pairs)
+    con = root.find("contact")
+    every = {g.name: g for b in bodies for g in b.geoms if g.name}
+    every.update({g.name: g for g in world_geoms})
+    for pr in (list(con) if con is not None else []):
+        pairs.append((pr.get("geom1"), pr.get("geom2")))
+        for nm in (pr.get("geom1"), pr.get("geom2")):
+            if nm in every:
+                geom_solver.add(every[nm]._solver)
+    if len(geom_solver) > 1 or len(limit_solver) > 1 or len(friction_solver) > 1:
+        raise ValueError("one solref / solimp set for contacts, one for joint limits and one for friction loss")
 
     def full_solimp(si):
         return tuple(si) + (0.9, 0.95, 0.001, 0.5, 2.0)[len(si):]
 
-    solref, solimp = geom_solver.pop() if geom_solver else ((0.02, 1.0), (0.9, 0.95, 0.001, 0.5, 2.0))
-    lsolref, lsolimp = limit_solver.pop() if limit_solver else ((0.02, 1.0), (0.9, 0.95, 0.001, 0.5, 2.0))
-    for b in bodies:
-        for g in b.geoms:
-            del g._contype, g._conaffinity, g._solver
+    solref, solimp = geom_solver.pop() if geom_solver else DEF_SOL
+    lsolref, lsolimp = limit_solver.pop() if limit_solver else DEF_SOL
+    fsolref, fsolimp = friction_solver.pop() if friction_solver else DEF_SOL
+    for g in [g for b in bodies for g in b.geoms] + world_geoms:
+        del g._contype, g._conaffinity, g._solver
     if totalmass is not None:           # MuJoCo scales every body mass and inertia by the same factor
-        total = sum(_geom_inertial(g, MJ20_CAPSULE_CAP)[0] for b in bodies for g in b.geoms)
+        total = sum(_geom_inertial(g, MJ20_CAPSULE_CAP)[0] for b in bodies for g in b.geoms if b.inertial is None)
+        total += sum(b.inertial.mass for b in bodies if b.inertial is not None)
         for b in bodies:
             for g in b.geoms:
                 g.density *= totalmass / total
+            if b.inertial is not None:
+                b.inertial.mass *= totalmass / total
+                b.inertial.inertia = np.asarray(b.inertial.inertia, float) * (totalmass / total)
+
+    # fixed tendons
+    tendons = []
+    tn = root.find("tendon")
+    for t in (list(tn) if tn is not None else []):
+        if t.tag != "fixed":
+            raise ValueError("only fixed tendons are supported, got <%s>" % t.tag)
+        if float(t.get("stiffness", "0")) != 0 or float(t.get("damping", "0")) != 0 or float(t.get("frictionloss", "0")) != 0:
+            raise ValueError("tendon stiffness / damping / frictionloss are not supported")
+        lim = t.get("limited", "false") == "true"
+        if lim:
+            limit_solver.add((tuple(_floats(t.get("solreflimit", "0.02 1"))), tuple(_floats(t.get("solimplimit", "0.9 0.95 0.001 0.5 2")))))
+            if limit_solver != {(tuple(lsolref), tuple(lsolimp))} and (lsolref, lsolimp) != DEF_SOL:
+                raise ValueError("tendon limits share the joint limits' solref / solimp")
+            lsolref, lsolimp = list(limit_solver)[0]
+        tendons.append(RawTendon(t.get("name", "tendon%d" % len(tendons)),
+                                 [(j.get("joint"), float(j.get("coef", "1"))) for j in t.findall("joint")],
+                                 limited=lim, range=_floats(t.get("range"), 2, [0.0, 0.0]), margin=float(t.get("margin", "0"))))
 
     acts = []
     act = root.find("actuator")
@@ -290,12 +422,25 @@ def load_mjcf(path, hand_site="finger", target_site="target", frame_skip=2, task
             raise ValueError("only ctrllimited <motor> / <position> actuators are supported")
         gear = _floats(ma("gear"), None, [1.0])[0]
         kp = float(m.get("kp", "1")) if m.tag == "position" else 0.0       # MJCF <position>: kp defaults to 1
-        acts.append(RawActuator(m.get("joint"), gear, _floats(ma("ctrlrange"), 2), kp=kp))
-    # explicit geom-geom collision candidates (<contact><pair geom1=... geom2=...>): manipulator geom first, object second
-    pairs = list(auto_pairs)
-    con = root.find("contact")
-    for pr in (list(con) if con is not None else []):
-        pairs.append((pr.get("geom1"), pr.get("geom2")))
+        if m.get("joint") is None and m.get("tendon") is None:
+            raise ValueError("an actuator acts on a joint or on a fixed tendon")
+        acts.append(RawActuator(m.get("joint") or "", gear, _floats(ma("ctrlrange"), 2), kp=kp, tendon=m.get("tendon") or ""))
+
+    # equality constraints
+    equalities = []
+    eqs = root.find("equality")
+    for q in (list(eqs) if eqs is not None else []):
+        if q.get("active", "true") != "true":
+            continue
+        kw = dict(solref=tuple(_floats(q.get("solref", "0.02 1"))), solimp=full_solimp(_floats(q.get("solimp", "0.9 0.95 0.001 0.5 2"))))
+        if q.tag == "connect":
+            equalities.append(RawEquality(EQ_CONNECT, q.get("body1"), q.get("body2") or "", anchor=_floats(q.get("anchor"), 3), **kw))
+        elif q.tag == "joint":
+            equalities.append(RawEquality(EQ_JOINT, q.get("joint1"), q.get("joint2") or "",
+                                          polycoef=_floats(q.get("polycoef", "0 1 0 0 0"), 5), **kw))
+        else:
+            raise ValueError("equality <%s> is not supported (connect and joint are)" % q.tag)
+
     if task == TASK_REACH:
         if hand_site not in sites or sites[hand_site][0] < 0:
             raise ValueError("tracked site %r must be attached to a body" % hand_site)
@@ -306,4 +451,5 @@ def load_mjcf(path, hand_site="finger", target_site="target", frame_skip=2, task
     return RawModel(bodies=bodies, actuators=acts, site_body=site_body, site_pos=site_pos, target_pos=target, plane=plane,
                     timestep=timestep, frame_skip=frame_skip, gravity=gravity, solref=solref, solimp=full_solimp(solimp),
                     solref_limit=lsolref, solimp_limit=full_solimp(lsolimp), density=density, viscosity=viscosity,
-                    task=task, ctrl_cost=ctrl_cost, obs_skip=obs_skip, pairs=pairs)
+                    task=task, ctrl_cost=ctrl_cost, obs_skip=obs_skip, pairs=pairs, world_geoms=world_geoms,
+                    equalities=equalities, tendons=tendons, solref_friction=fsolref, solimp_friction=full_solimp(fsolimp))

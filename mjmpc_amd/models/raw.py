@@ -23,10 +23,16 @@ import numpy as np
 
 GEOM_SPHERE = 1
 GEOM_CAPSULE = 2
+GEOM_BOX = 3                # a = centre, b = half sizes, quat = orientation, all in the body frame
 
-HEADER_LEN = 56
+HEADER_LEN = 80
 JOINT_HINGE = 1
 JOINT_SLIDE = 2
+JOINT_BALL = 3              # 3 dofs (angular velocity in the body frame), qpos = unit quaternion (w, x, y, z)
+JOINT_FREE = 4              # 6 dofs (world-frame linear velocity, body-frame angular velocity), qpos = position + quaternion
+EQ_CONNECT = 1              # MJCF <equality><connect body1 body2 anchor>: a point shared by two bodies (3 rows)
+EQ_WELD = 2                 # <weld body1 body2>: relative pose of two bodies fixed at its qpos0 value (6 rows)
+EQ_JOINT = 3                # <joint joint1 joint2 polycoef>: q1 = poly(q2) (1 row)
 # MuJoCo 2.0 - the version the reference pins (mujoco-py >=2.0,<2.1) - computes a capsule's volume as pi r^2 (h + r): the
 # two end caps count pi r^3 instead of 4/3 pi r^3.  That is what the body masses gym users have printed for years say
 # to nine digits (HalfCheetah under mujoco-py 2.0: 6.36031332, 1.53524804, 1.58093995, 1.0691906, 1.42558747,
@@ -40,10 +46,15 @@ TASK_FORWARD = 1            # reward (x' - x)/dt - c |a|^2, obs [qpos[skip:], qv
 TASK_ORIENT = 2             # in-hand reorientation, the shape of pen-v0's reward (examples/configs/hand/pen-v0.yml:8): the
                             # tracked site rides on the object; reward -|h-g|_2 + d.d*, d = the object's axis (site_axis
                             # carried by the site's body), d* = target_dir; obs as TASK_REACH
-BODY_STRIDE = 20
-GEOM_STRIDE = 16
-ACT_STRIDE = 5
+BODY_STRIDE = 40
+GEOM_STRIDE = 24
+ACT_STRIDE = 6
 PAIR_STRIDE = 2
+EQ_STRIDE = 28
+TENDON_MAX_JOINTS = 4
+TENDON_STRIDE = 8 + 2 * TENDON_MAX_JOINTS
+JOINT_NDOF = {JOINT_HINGE: 1, JOINT_SLIDE: 1, JOINT_BALL: 3, JOINT_FREE: 6}
+JOINT_NQ = {JOINT_HINGE: 1, JOINT_SLIDE: 1, JOINT_BALL: 4, JOINT_FREE: 7}
 
 
 @dataclass
@@ -57,6 +68,16 @@ class RawJoint:
     type: int = JOINT_HINGE
     stiffness: float = 0.0                  # joint spring towards springref (MuJoCo qfrc_passive)
     springref: float = 0.0
+    pos: Sequence[float] = (0.0, 0.0, 0.0)  # anchor in the body frame (hinge / ball; MJCF joint pos)
+    frictionloss: float = 0.0               # dry friction: one friction-loss constraint row per dof (MuJoCo dof_frictionloss)
+
+    @property
+    def ndof(self):
+        return JOINT_NDOF[self.type]
+
+    @property
+    def nq(self):
+        return JOINT_NQ[self.type]
 
 
 @dataclass
@@ -71,6 +92,15 @@ class RawGeom:
     name: str = ""
     friction: float = 1.0                   # sliding friction (MuJoCo default "1 0.005 0.0001", first entry)
     condim: int = 1
+    quat: Sequence[float] = (1.0, 0.0, 0.0, 0.0)    # box: orientation in the body frame
+
+
+@dataclass
+class RawInertial:
+    """MJCF <inertial>: replaces inertiafromgeom for its body (tensor about ``pos`` in the BODY frame's axes)."""
+    mass: float
+    pos: Sequence[float]
+    inertia: Sequence[Sequence[float]]      # 3 x 3, body-frame axes
 
 
 @dataclass
@@ -81,6 +111,28 @@ class RawBody:
     quat: Sequence[float] = (1.0, 0.0, 0.0, 0.0)
     joint: Optional[RawJoint] = None
     geoms: List[RawGeom] = field(default_factory=list)
+    inertial: Optional[RawInertial] = None
+
+
+@dataclass
+class RawEquality:
+    type: int                               # EQ_CONNECT / EQ_WELD / EQ_JOINT
+    obj1: str                               # body (connect, weld) or joint (joint) name
+    obj2: str = ""                          # "" = the world body / no second joint
+    anchor: Sequence[float] = (0.0, 0.0, 0.0)       # connect: the shared point in body1's frame
+    polycoef: Sequence[float] = (0.0, 1.0, 0.0, 0.0, 0.0)
+    solref: Sequence[float] = (0.02, 1.0)
+    solimp: Sequence[float] = (0.9, 0.95, 0.001, 0.5, 2.0)
+
+
+@dataclass
+class RawTendon:
+    """MJCF <tendon><fixed>: length = sum coef_i q_i over hinge / slide joints; ``limited`` adds limit rows."""
+    name: str
+    joints: Sequence[Sequence]              # [(joint name, coef), ...], at most TENDON_MAX_JOINTS
+    limited: bool = False
+    range: Sequence[float] = (0.0, 0.0)
+    margin: float = 0.0
 
 
 @dataclass
@@ -90,6 +142,7 @@ class RawActuator:
     ctrlrange: Sequence[float]
     kp: float = 0.0                         # 0: motor, force = gear * clip(ctrl).  > 0: MJCF <position kp=...>, a servo -
                                             # force = kp * (clip(ctrl) - gear * q), applied through the gear
+    tendon: str = ""                        # not "": the actuator pulls on this fixed tendon instead of a joint
 
 
 @dataclass
@@ -127,6 +180,12 @@ class RawModel:
     pairs: List[Sequence[str]] = field(default_factory=list)
     site_axis: Sequence[float] = (0.0, 0.0, 0.0)    # TASK_ORIENT: the object's axis in the frame of the site's body
     target_dir: Sequence[float] = (0.0, 0.0, 1.0)   # TASK_ORIENT: the direction that axis should point in (world)
+    world_geoms: List[RawGeom] = field(default_factory=list)   # static sphere / capsule / box geoms of the world body
+                                                                # (collide only through ``pairs``)
+    equalities: List[RawEquality] = field(default_factory=list)
+    tendons: List[RawTendon] = field(default_factory=list)
+    solref_friction: Sequence[float] = (0.02, 1.0)  # friction-loss rows (MJCF solreffriction / solimpfriction)
+    solimp_friction: Sequence[float] = (0.9, 0.95, 0.001, 0.5, 2.0)
 
     # ------------------------------------------------------------------
     @property
@@ -134,15 +193,53 @@ class RawModel:
         return [b.joint.name for b in self.bodies if b.joint is not None]
 
     @property
+    def joints(self):
+        return [b.joint for b in self.bodies if b.joint is not None]
+
+    @property
     def nv(self):
-        return len(self.joint_names)
+        return sum(j.ndof for j in self.joints)
+
+    @property
+    def nq(self):
+        return sum(j.nq for j in self.joints)
 
     def dof_of_joint(self, name):
-        return self.joint_names.index(name)
+        """Address of the joint's first dof (MuJoCo jnt_dofadr)."""
+        adr = 0
+        for j in self.joints:
+            if j.name == name:
+                return adr
+            adr += j.ndof
+        raise ValueError("unknown joint %r" % (name,))
+
+    def qpos_of_joint(self, name):
+        adr = 0
+        for j in self.joints:
+            if j.name == name:
+                return adr
+            adr += j.nq
+        raise ValueError("unknown joint %r" % (name,))
+
+    @property
+    def qpos0(self):
+        """MuJoCo's qpos0: zeros for hinge / slide joints, the identity quaternion for a ball joint, the body's own
+        position and orientation for a free joint."""
+        out = []
+        for b in self.bodies:
+            if b.joint is None:
+                continue
+            if b.joint.type == JOINT_BALL:
+                out += [1.0, 0.0, 0.0, 0.0]
+            elif b.joint.type == JOINT_FREE:
+                out += list(b.pos) + list(np.asarray(b.quat, float) / np.linalg.norm(b.quat))
+            else:
+                out += [0.0]
+        return np.array(out, float)
 
     def to_flat(self) -> np.ndarray:
         """Flat float64 serialisation (layout documented in include/mjmpc_amd.h)."""
-        geoms = [(bi, g) for bi, b in enumerate(self.bodies) for g in b.geoms]
+        geoms = [(bi, g) for bi, b in enumerate(self.bodies) for g in b.geoms] + [(-1, g) for g in self.world_geoms]
         h = np.zeros(HEADER_LEN)
         h[0] = len(self.bodies)
         h[1] = len(geoms)
@@ -170,6 +267,9 @@ class RawModel:
         h[50:53] = self.target_dir
         h[40:42] = self.solref if self.solref_limit is None else self.solref_limit
         h[42:47] = self.solimp if self.solimp_limit is None else self.solimp_limit
+        h[53], h[54] = len(self.equalities), len(self.tendons)
+        h[56:58] = self.solref_friction
+        h[58:63] = self.solimp_friction
         out = [h]
         for b in self.bodies:
             r = np.zeros(BODY_STRIDE)
@@ -185,6 +285,13 @@ class RawModel:
                 r[14] = 1.0 if b.joint.limited else 0.0
                 r[15] = b.joint.damping
                 r[16] = b.joint.armature
+                r[19:22] = b.joint.pos
+                r[22] = b.joint.frictionloss
+            if b.inertial is not None:
+                r[23] = 1.0
+                r[24] = b.inertial.mass
+                r[25:28] = b.inertial.pos
+                r[28:37] = np.asarray(b.inertial.inertia, float).reshape(9)
             out.append(r)
         for bi, g in geoms:
             r = np.zeros(GEOM_STRIDE)
@@ -198,10 +305,16 @@ class RawModel:
             r[11] = g.margin
             r[12] = g.friction
             r[13] = g.condim
+            r[14:18] = g.quat
             out.append(r)
+        tnames = [t.name for t in self.tendons]
         for a in self.actuators:
             r = np.zeros(ACT_STRIDE)
-            r[0] = self.dof_of_joint(a.joint)
+            if a.tendon:
+                r[0] = tnames.index(a.tendon)
+                r[5] = 1.0
+            else:
+                r[0] = self.dof_of_joint(a.joint)
             r[1] = a.gear
             r[2:4] = a.ctrlrange
             r[4] = a.kp
@@ -211,4 +324,31 @@ class RawModel:
             if names.count(ga) != 1 or names.count(gb) != 1:
                 raise ValueError("collision pair (%r, %r) must name one geom each" % (ga, gb))
             out.append(np.array([names.index(ga), names.index(gb)], float))
+        bnames = [b.name for b in self.bodies]
+        for e in self.equalities:
+            r = np.zeros(EQ_STRIDE)
+            r[0] = e.type
+            if e.type == EQ_JOINT:
+                r[1] = self.dof_of_joint(e.obj1)
+                r[2] = self.dof_of_joint(e.obj2) if e.obj2 else -1
+            else:
+                r[1] = bnames.index(e.obj1)
+                r[2] = bnames.index(e.obj2) if e.obj2 else -1
+            r[3:6] = e.anchor
+            r[6:11] = e.polycoef
+            r[11:13] = e.solref
+            r[13:18] = e.solimp
+            out.append(r)
+        for t in self.tendons:
+            if not 1 <= len(t.joints) <= TENDON_MAX_JOINTS:
+                raise ValueError("a fixed tendon takes 1..%d joints" % TENDON_MAX_JOINTS)
+            r = np.zeros(TENDON_STRIDE)
+            r[0] = len(t.joints)
+            r[1] = 1.0 if t.limited else 0.0
+            r[2:4] = t.range
+            r[4] = t.margin
+            for k, (jn, coef) in enumerate(t.joints):
+                r[8 + 2 * k] = self.dof_of_joint(jn)
+                r[9 + 2 * k] = coef
+            out.append(r)
         return np.concatenate(out).astype(np.float64)

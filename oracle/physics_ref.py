@@ -110,7 +110,7 @@ def _bind(L):
     L.or_model_compile.restype = ctypes.c_void_p
     L.or_model_compile.argtypes = [_dp, ctypes.c_int]
     L.or_model_free.argtypes = [ctypes.c_void_p]
-    for name in ("or_nv", "or_nbody", "or_dobs"):
+    for name in ("or_nv", "or_nq", "or_nbody", "or_dobs"):
         getattr(L, name).restype = ctypes.c_int
         getattr(L, name).argtypes = [ctypes.c_void_p]
     L.or_kinetic.restype = ctypes.c_double
@@ -150,7 +150,10 @@ class RefArm:
         if not self._h:
             raise ValueError("oracle: bad model blob")
         self.nv = self._L.or_nv(self._h)
+        self.nq = self._L.or_nq(self._h)
         self.nbody = self._L.or_nbody(self._h)
+        self.qpos0 = np.zeros(self.nq)
+        self._L.or_qpos0(ctypes.c_void_p(self._h), _p(self.qpos0))
         self.d_obs = self._L.or_dobs(self._h)
 
     def __del__(self):
@@ -167,6 +170,9 @@ class RefArm:
 
     def set_dof_damping(self, dof, d):
         self._L.or_set_dof_damping(ctypes.c_void_p(self._h), int(dof), ctypes.c_double(d))
+
+    def set_dof_frictionloss(self, dof, f):
+        self._L.or_set_dof_frictionloss(ctypes.c_void_p(self._h), int(dof), ctypes.c_double(f))
 
     def set_sphere_radius(self, idx, r):
         self._L.or_set_sphere_radius(ctypes.c_void_p(self._h), int(idx), ctypes.c_double(r))

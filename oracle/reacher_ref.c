@@ -37,38 +37,56 @@
 
 #define MAXB 48            /* bodies incl. world */
 #define MAXV 32
+#define MAXQ (MAXV + 8)    /* qpos: a ball joint takes 4 entries for 3 dofs, a free joint 7 for 6 */
 #define MAXG 96
-#define MAXS 16            /* collision spheres (a colliding capsule is its two end spheres) */
-#define MAXC (2 * MAXV + 4 * MAXS + 4 * 16)
+#define MAXS 32            /* collision spheres (a colliding capsule is its two end spheres, a box its eight corners) */
+#define MAXE 8             /* equality constraints */
+#define MAXT 8             /* fixed tendons */
+#define MAXTJ 4            /* joints per tendon */
+#define MAXC (3 * MAXV + 4 * MAXS + 4 * 16 + 6 * MAXE + 2 * MAXT)
 #define MJ_MINVAL 1e-15    /* MuJoCo mjMINVAL */
 
-#define HEADER_LEN 56
-#define BODY_STRIDE 20
-#define GEOM_STRIDE 16
-#define ACT_STRIDE 5
+#define HEADER_LEN 80
+#define BODY_STRIDE 40
+#define GEOM_STRIDE 24
+#define ACT_STRIDE 6
 #define PAIR_STRIDE 2
+#define EQ_STRIDE 28
+#define TENDON_STRIDE (8 + 2 * MAXTJ)
 #define MAXP 16            /* geom-geom collision pairs */
+/* joint kinds (mjmpc_amd/models/raw.py) */
+#define JHINGE 1
+#define JSLIDE 2
+#define JBALL 3
+#define JFREE 4
+/* constraint row kinds of the primal problem (MuJoCo mj_constraintUpdate) */
+#define ROW_UNI 0          /* limits, contacts: cost 1/2 D min(0, r)^2 */
+#define ROW_EQ 1           /* equality: 1/2 D r^2 */
+#define ROW_FRIC 2         /* friction loss f: Huber - 1/2 D r^2 inside |r| < R f, linear f |r| - 1/2 R f^2 outside */
 
 typedef struct {
-    int nbody, nv, nu;
+    int nbody, nv, nq, nu;
     double timestep, gravity[3];
     int frame_skip;
     double solref[2], solimp[5];
     /* tree */
     int parent[MAXB];
-    double bpos[MAXB][3], bR0[MAXB][9];      /* fixed offset / rotation in the parent frame */
-    int dofid[MAXB];                         /* -1: welded */
-    int jtype[MAXB];                         /* 1 hinge, 2 slide */
-    double jaxis[MAXB][3];
+    double bpos[MAXB][3], bR0[MAXB][9], bquat0[MAXB][4];      /* fixed offset / rotation in the parent frame */
+    int dofid[MAXB];                         /* address of the body's first dof, -1: welded */
+    int qadr[MAXB];                          /* address of the joint's first qpos entry */
+    int jtype[MAXB];                         /* 1 hinge, 2 slide, 3 ball, 4 free */
+    double jaxis[MAXB][3], jpos[MAXB][3];    /* axis and anchor in the body frame */
     int dof_body[MAXV];
     double range[MAXV][2];
     int limited[MAXV];
-    double damping[MAXV], armature[MAXV], stiffness[MAXV], springref[MAXV];
-    int dof_type[MAXV];
+    double damping[MAXV], armature[MAXV], stiffness[MAXV], springref[MAXV], frictionloss[MAXV];
+    int dof_type[MAXV];                      /* 1 rotation about xaxis through xanchor, 2 translation along xaxis */
+    int dof_qadr[MAXV];                      /* hinge / slide dofs: their qpos entry (-1 for ball / free dofs) */
+    double solref_f[2], solimp_f[5];         /* friction-loss rows */
     /* inertial (inertiafromgeom) */
     double mass[MAXB], ipos[MAXB][3], inertia[MAXB][9];  /* tensor about the COM, body frame */
     /* motors */
-    int act_dof[MAXV];
+    int act_dof[MAXV], act_tendon[MAXV];     /* act_tendon: the actuator pulls on fixed tendon act_dof[a] */
     double gear[MAXV], ctrl_lo[MAXV], ctrl_hi[MAXV], kp[MAXV];   /* kp > 0: position servo (MJCF <position>) */
     /* site + target */
     int site_body;
@@ -82,6 +100,14 @@ typedef struct {
     /* geom-geom pairs: two segments (a sphere is a segment of length 0) with radii, on two bodies */
     int npair, pair_body[MAXP][2];
     double pair_a[MAXP][2][3], pair_d[MAXP][2][3], pair_r[MAXP][2], pair_margin[MAXP], pair_mu[MAXP];
+    int pair_box[MAXP];                      /* -1: two segments; e: geom e of the pair is a BOX (the other a sphere) */
+    double pair_R[MAXP][9], pair_half[MAXP][3];   /* that box: orientation in its body's frame, half sizes (pair_a = centre) */
+    /* equality constraints (MJCF <equality>): connect / weld (two bodies, 0 = world) and joint (two dofs, -1 = none) */
+    int neq, eq_type[MAXE], eq_o1[MAXE], eq_o2[MAXE];
+    double eq_anchor[MAXE][2][3], eq_relquat[MAXE][4], eq_poly[MAXE][5], eq_solref[MAXE][2], eq_solimp[MAXE][5];
+    /* fixed tendons: length = sum coef q over hinge / slide dofs; limit rows */
+    int ntendon, tn_n[MAXT], tn_dof[MAXT][MAXTJ], tn_limited[MAXT];
+    double tn_coef[MAXT][MAXTJ], tn_range[MAXT][2], tn_margin[MAXT], tn_invweight0[MAXT];
     /* TASK 2 (in-hand reorientation): object axis in the site body's frame, direction it should point in */
     double site_axis[3], target_dir[3];
     /* joint-limit rows may carry their own solver parameters (MJCF solreflimit / solimplimit) */
@@ -93,7 +119,8 @@ typedef struct {
     int task, obs_skip;
     double ctrl_cost;
     /* constants computed at qpos0 (MuJoCo mj_setConst) */
-    double dof_invweight0[MAXV], body_invweight0[MAXB];
+    double dof_invweight0[MAXV], body_invweight0[MAXB], body_invweight0r[MAXB];     /* (translational, rotational) */
+    double qpos0[MAXQ];
     /* statistics */
     long newton_iters, newton_calls, newton_fail;
 } OrModel;
@@ -129,6 +156,21 @@ static void axisangle2mat(const double *u, double ang, double *R) {
     R[0] = c + t * u[0] * u[0];        R[1] = t * u[0] * u[1] - s * u[2]; R[2] = t * u[0] * u[2] + s * u[1];
     R[3] = t * u[0] * u[1] + s * u[2]; R[4] = c + t * u[1] * u[1];        R[5] = t * u[1] * u[2] - s * u[0];
     R[6] = t * u[0] * u[2] - s * u[1]; R[7] = t * u[1] * u[2] + s * u[0]; R[8] = c + t * u[2] * u[2];
+}
+/* quaternion product (w, x, y, z) and MuJoCo mju_quatIntegrate: q <- q * exp(1/2 w h), w in the local frame */
+static void quatmul(const double *a, const double *b, double *c) {
+    c[0] = a[0] * b[0] - a[1] * b[1] - a[2] * b[2] - a[3] * b[3];
+    c[1] = a[0] * b[1] + a[1] * b[0] + a[2] * b[3] - a[3] * b[2];
+    c[2] = a[0] * b[2] - a[1] * b[3] + a[2] * b[0] + a[3] * b[1];
+    c[3] = a[0] * b[3] + a[1] * b[2] - a[2] * b[1] + a[3] * b[0];
+}
+static void quat_integrate(double *q, const double *w, double h) {
+    double n = sqrt(w[0] * w[0] + w[1] * w[1] + w[2] * w[2]), ang = n * h;
+    if (n < MJ_MINVAL) return;
+    double sn = sin(0.5 * ang) / n, r[4] = {cos(0.5 * ang), w[0] * sn, w[1] * sn, w[2] * sn}, t[4];
+    quatmul(q, r, t);
+    double nn = sqrt(t[0] * t[0] + t[1] * t[1] + t[2] * t[2] + t[3] * t[3]);
+    for (int i = 0; i < 4; i++) q[i] = t[i] / nn;
 }
 /* dense Cholesky A = L L^T (lower, in place); returns 0 on success */
 static int chol(double *A, int n) {
@@ -166,8 +208,9 @@ typedef struct {
     double xaxis[MAXV][3], xanchor[MAXV][3];
 } Kin;
 
-/* MuJoCo mj_kinematics restricted to hinge joints anchored at the body origin (jnt pos = 0,
- * qpos0 = 0): xquat = parent * body_quat * rot(axis, q). */
+/* MuJoCo mj_kinematics: xpos / xquat = parent o (body pos, quat), then the body's joint: a hinge or ball turns the frame
+ * about its anchor (jnt pos, fixed in both frames), a slide moves it along its axis, a free joint replaces it by
+ * qpos[0:3], qpos[3:7].  Per dof: world axis and anchor (ball / free rotations: the body's own x, y, z axes). */
 static void kinematics(const OrModel *m, const double *q, Kin *k) {
     memset(k->xpos[0], 0, sizeof(k->xpos[0]));
     static const double I3[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
@@ -179,18 +222,42 @@ static void kinematics(const OrModel *m, const double *q, Kin *k) {
         matvec3(k->xmat[p], m->bpos[b], t);
         for (int i = 0; i < 3; i++) k->xpos[b][i] = k->xpos[p][i] + t[i];
         matmul3(k->xmat[p], m->bR0[b], R);
-        int j = m->dofid[b];
-        if (j >= 0 && m->jtype[b] == 2) {       /* slide: the frame moves along its axis, no rotation */
+        int j = m->dofid[b], jt = j >= 0 ? m->jtype[b] : 0;
+        if (jt == JSLIDE) {                     /* slide: the frame moves along its axis, no rotation */
             memcpy(k->xmat[b], R, sizeof(R));
             matvec3(R, m->jaxis[b], k->xaxis[j]);
-            for (int i = 0; i < 3; i++) k->xpos[b][i] += k->xaxis[j][i] * q[j];
+            for (int i = 0; i < 3; i++) k->xpos[b][i] += k->xaxis[j][i] * q[m->qadr[b]];
             memcpy(k->xanchor[j], k->xpos[b], sizeof(double) * 3);
-        } else if (j >= 0) {
-            double E[9];
-            axisangle2mat(m->jaxis[b], q[j], E);
+        } else if (jt == JHINGE || jt == JBALL) {
+            double E[9], anchor[3];
+            matvec3(R, m->jpos[b], t);
+            for (int i = 0; i < 3; i++) anchor[i] = k->xpos[b][i] + t[i];
+            if (jt == JHINGE) axisangle2mat(m->jaxis[b], q[m->qadr[b]], E);
+            else quat2mat(q + m->qadr[b], E);
             matmul3(R, E, k->xmat[b]);
-            matvec3(k->xmat[b], m->jaxis[b], k->xaxis[j]);
-            memcpy(k->xanchor[j], k->xpos[b], sizeof(double) * 3);
+            matvec3(k->xmat[b], m->jpos[b], t);
+            for (int i = 0; i < 3; i++) k->xpos[b][i] = anchor[i] - t[i];
+            if (jt == JHINGE) {
+                matvec3(k->xmat[b], m->jaxis[b], k->xaxis[j]);
+                memcpy(k->xanchor[j], anchor, sizeof(anchor));
+            } else {
+                for (int c = 0; c < 3; c++) {
+                    for (int i = 0; i < 3; i++) k->xaxis[j + c][i] = k->xmat[b][3 * i + c];
+                    memcpy(k->xanchor[j + c], anchor, sizeof(anchor));
+                }
+            }
+        } else if (jt == JFREE) {
+            const double *qq = q + m->qadr[b];
+            memcpy(k->xpos[b], qq, sizeof(double) * 3);
+            quat2mat(qq + 3, k->xmat[b]);
+            for (int c = 0; c < 3; c++) {
+                for (int i = 0; i < 3; i++) {
+                    k->xaxis[j + c][i] = i == c ? 1.0 : 0.0;                    /* translations: world axes */
+                    k->xaxis[j + 3 + c][i] = k->xmat[b][3 * i + c];             /* rotations: body axes */
+                }
+                memcpy(k->xanchor[j + c], k->xpos[b], sizeof(double) * 3);
+                memcpy(k->xanchor[j + 3 + c], k->xpos[b], sizeof(double) * 3);
+            }
         } else {
             memcpy(k->xmat[b], R, sizeof(R));
         }
@@ -278,7 +345,11 @@ static void mass_matrix(const OrModel *m, const Kin *k, double *M) {
 }
 
 /* Recursive Newton-Euler in the inertial frame: tau = M(q) qacc + c(q, qvel) (+ gravity).
- * MuJoCo mj_rne; with qacc = NULL it returns the bias force qfrc_bias. */
+ * MuJoCo mj_rne; with qacc = NULL it returns the bias force qfrc_bias.
+ * A body's joint turns it about an ANCHOR that is fixed in the parent too: the anchor's acceleration follows from the
+ * parent's motion, the body origin's from the body's own.  The axes of a ball joint (and of the rotations of a free
+ * joint) move with the body: sum_k d/dt(axis_k) v_k = w_body x (w_body - w_parent) = w_parent x sum_k axis_k v_k, which
+ * is what MuJoCo's mj_comVel does by taking all three cdof_dot with the velocity BEFORE the joint. */
 static void rne(const OrModel *m, const Kin *k, const double *v, const double *a, double *tau) {
     double w[MAXB][3], al[MAXB][3], oacc[MAXB][3];    /* ang. vel, ang. acc, origin acceleration */
     double F[MAXB][3], N[MAXB][3];                    /* net force at COM, net moment about body origin */
@@ -286,30 +357,41 @@ static void rne(const OrModel *m, const Kin *k, const double *v, const double *a
     memset(al[0], 0, 24);
     for (int i = 0; i < 3; i++) oacc[0][i] = -m->gravity[i];
     for (int b = 1; b < m->nbody; b++) {
-        int p = m->parent[b], j = m->dofid[b];
-        double r[3], t1[3], t2[3];
-        for (int i = 0; i < 3; i++) r[i] = k->xpos[b][i] - k->xpos[p][i];
+        int p = m->parent[b], j = m->dofid[b], jt = j >= 0 ? m->jtype[b] : 0;
+        double r[3], t1[3], t2[3], t3[3], anc[3];
+        /* the point the body hangs on: its joint's anchor (hinge, ball), else its origin */
+        if (jt == JHINGE || jt == JBALL) memcpy(anc, k->xanchor[j], sizeof(anc));
+        else memcpy(anc, k->xpos[b], sizeof(anc));
+        for (int i = 0; i < 3; i++) r[i] = anc[i] - k->xpos[p][i];
         cross3(al[p], r, t1);
         cross3(w[p], r, t2);
-        double t3[3];
         cross3(w[p], t2, t3);
+        double aacc[3];
         for (int i = 0; i < 3; i++) {
-            oacc[b][i] = oacc[p][i] + t1[i] + t3[i];
+            aacc[i] = oacc[p][i] + t1[i] + t3[i];
             w[b][i] = w[p][i];
             al[b][i] = al[p][i];
         }
-        if (j >= 0 && m->jtype[b] == 2) {       /* slide: Coriolis 2 w x (axis v) and axis qacc on the origin */
+        int nd = jt == JFREE ? 6 : (jt == JBALL ? 3 : (jt ? 1 : 0));
+        for (int d = 0; d < nd; d++) {
+            int jd = j + d;
             double wxa[3];
-            cross3(w[p], k->xaxis[j], wxa);
-            for (int i = 0; i < 3; i++) oacc[b][i] += 2 * wxa[i] * v[j] + (a ? k->xaxis[j][i] * a[j] : 0.0);
-        } else if (j >= 0) {
-            double wxa[3];
-            cross3(w[p], k->xaxis[j], wxa);
-            for (int i = 0; i < 3; i++) {
-                w[b][i] += k->xaxis[j][i] * v[j];
-                al[b][i] += wxa[i] * v[j] + (a ? k->xaxis[j][i] * a[j] : 0.0);
+            cross3(w[p], k->xaxis[jd], wxa);
+            if (m->dof_type[jd] == 2) {     /* translation: Coriolis 2 w x (axis v) and axis qacc on the anchor */
+                for (int i = 0; i < 3; i++) aacc[i] += 2 * wxa[i] * v[jd] + (a ? k->xaxis[jd][i] * a[jd] : 0.0);
+            } else {
+                for (int i = 0; i < 3; i++) {
+                    w[b][i] += k->xaxis[jd][i] * v[jd];
+                    al[b][i] += wxa[i] * v[jd] + (a ? k->xaxis[jd][i] * a[jd] : 0.0);
+                }
             }
         }
+        /* body origin from the anchor, with the body's own rotation */
+        for (int i = 0; i < 3; i++) r[i] = k->xpos[b][i] - anc[i];
+        cross3(al[b], r, t1);
+        cross3(w[b], r, t2);
+        cross3(w[b], t2, t3);
+        for (int i = 0; i < 3; i++) oacc[b][i] = aacc[i] + t1[i] + t3[i];
         /* COM acceleration */
         double d[3], cacc[3], Iw[9], Iwv[3], Ial[3], wIw[3];
         for (int i = 0; i < 3; i++) d[i] = k->xipos[b][i] - k->xpos[b][i];
@@ -327,8 +409,19 @@ static void rne(const OrModel *m, const Kin *k, const double *v, const double *a
         for (int i = 0; i < 3; i++) N[b][i] = Ial[i] + wIw[i] + dxF[i];
     }
     for (int b = m->nbody - 1; b >= 1; b--) {
-        int p = m->parent[b], j = m->dofid[b];
-        if (j >= 0) tau[j] = m->jtype[b] == 2 ? dot3(k->xaxis[j], F[b]) : dot3(k->xaxis[j], N[b]);
+        int p = m->parent[b], j = m->dofid[b], jt = j >= 0 ? m->jtype[b] : 0;
+        int nd = jt == JFREE ? 6 : (jt == JBALL ? 3 : (jt ? 1 : 0));
+        for (int d = 0; d < nd; d++) {
+            int jd = j + d;
+            if (m->dof_type[jd] == 2) {
+                tau[jd] = dot3(k->xaxis[jd], F[b]);
+            } else {                        /* moment about the anchor = moment about the origin + (origin - anchor) x F */
+                double r[3], rxF[3];
+                for (int i = 0; i < 3; i++) r[i] = k->xpos[b][i] - k->xanchor[jd][i];
+                cross3(r, F[b], rxF);
+                tau[jd] = dot3(k->xaxis[jd], N[b]) + dot3(k->xaxis[jd], rxF);
+            }
+        }
         if (p > 0) {
             double r[3], rxF[3];
             for (int i = 0; i < 3; i++) r[i] = k->xpos[b][i] - k->xpos[p][i];
@@ -344,11 +437,28 @@ static void rne(const OrModel *m, const Kin *k, const double *v, const double *a
 /* ---------------------------------------------------------------- model compile */
 /* MuJoCo compiler, inertiafromgeom="true": geom mass = density * volume; sphere 2/5 m r^2;
  * capsule = cylinder + two hemispheres (MuJoCo user_objects: mjCGeom::SetInertia). */
-static void geom_inertia(int type, double r, const double *a, const double *b_, double density, double cap,
-                         double *mass, double *pos, double *I) {
+static void geom_inertia(int type, double r, const double *a, const double *b_, const double *quat, double density,
+                         double cap, double *mass, double *pos, double *I) {
     const double PI = 3.14159265358979323846;
     memset(I, 0, sizeof(double) * 9);
-    if (type == 1) {
+    if (type == 3) {            /* box: centre a, half sizes b_, orientation quat (body frame) */
+        double R[9], Ib[3], T[9] = {0};
+        *mass = density * 8.0 * b_[0] * b_[1] * b_[2];
+        memcpy(pos, a, 24);
+        for (int i = 0; i < 3; i++) {
+            int j1 = (i + 1) % 3, j2 = (i + 2) % 3;
+            Ib[i] = (*mass) / 3.0 * (b_[j1] * b_[j1] + b_[j2] * b_[j2]);
+        }
+        quat2mat(quat, R);
+        for (int i = 0; i < 3; i++)
+            for (int j = 0; j < 3; j++) T[3 * i + j] = R[3 * i + j] * Ib[j];
+        for (int i = 0; i < 3; i++)
+            for (int j = 0; j < 3; j++) {
+                double sacc = 0;
+                for (int c = 0; c < 3; c++) sacc += T[3 * i + c] * R[3 * j + c];
+                I[3 * i + j] = sacc;
+            }
+    } else if (type == 1) {
         *mass = density * 4.0 / 3.0 * PI * r * r * r;
         memcpy(pos, a, 24);
         double i = 0.4 * (*mass) * r * r;
@@ -373,9 +483,10 @@ static void set_const(OrModel *m);
 
 OrModel *or_model_compile(const double *f, int n) {
     OrModel *m = (OrModel *)calloc(1, sizeof(OrModel));
-    int nb = (int)f[0], ng = (int)f[1], nu = (int)f[2], np_ = (int)f[38];
-    if (n != HEADER_LEN + nb * BODY_STRIDE + ng * GEOM_STRIDE + nu * ACT_STRIDE + np_ * PAIR_STRIDE || nb + 1 > MAXB ||
-        ng > MAXG || np_ > MAXP) {
+    int nb = (int)f[0], ng = (int)f[1], nu = (int)f[2], np_ = (int)f[38], ne = (int)f[53], nt = (int)f[54];
+    if (n != HEADER_LEN + nb * BODY_STRIDE + ng * GEOM_STRIDE + nu * ACT_STRIDE + np_ * PAIR_STRIDE + ne * EQ_STRIDE +
+                 nt * TENDON_STRIDE ||
+        nb + 1 > MAXB || ng > MAXG || np_ > MAXP || ne > MAXE || nt > MAXT) {
         free(m);
         return NULL;
     }
@@ -404,49 +515,93 @@ OrModel *or_model_compile(const double *f, int n) {
     memcpy(m->solimp_l, f + 42, 40);
     memcpy(m->site_axis, f + 47, 24);
     memcpy(m->target_dir, f + 50, 24);
+    memcpy(m->solref_f, f + 56, 16);
+    memcpy(m->solimp_f, f + 58, 40);
     m->dofid[0] = -1;
-    int nv = 0;
+    int nv = 0, nq = 0;
+    int has_inertial[MAXB] = {0};
     for (int b = 1; b <= nb; b++) {
         const double *r = f + HEADER_LEN + (b - 1) * BODY_STRIDE;
         m->parent[b] = (int)r[0] + 1;
         memcpy(m->bpos[b], r + 1, 24);
         quat2mat(r + 4, m->bR0[b]);
+        {
+            double qn = sqrt(r[4] * r[4] + r[5] * r[5] + r[6] * r[6] + r[7] * r[7]);
+            for (int i = 0; i < 4; i++) m->bquat0[b][i] = r[4 + i] / qn;
+        }
         m->dofid[b] = -1;
         if (r[8] != 0) {
-            int j = nv++;
-            m->dofid[b] = j;
-            m->jtype[b] = (int)r[8];
-            m->dof_type[j] = (int)r[8];
-            m->stiffness[j] = r[17];
-            m->springref[j] = r[18];
-            m->dof_body[j] = b;
+            int jt = (int)r[8], nd = jt == JFREE ? 6 : (jt == JBALL ? 3 : 1);
+            if (nv + nd > MAXV || (jt == JFREE && m->parent[b] != 0)) { free(m); return NULL; }
+            m->dofid[b] = nv;
+            m->qadr[b] = nq;
+            m->jtype[b] = jt;
             double nrm = sqrt(dot3(r + 9, r + 9));
-            for (int i = 0; i < 3; i++) m->jaxis[b][i] = r[9 + i] / nrm;
-            m->range[j][0] = r[12];
-            m->range[j][1] = r[13];
-            m->limited[j] = (int)r[14];
-            m->damping[j] = r[15];
-            m->armature[j] = r[16];
+            for (int i = 0; i < 3; i++) m->jaxis[b][i] = nrm > 0 ? r[9 + i] / nrm : 0.0;
+            memcpy(m->jpos[b], r + 19, 24);
+            for (int d = 0; d < nd; d++) {
+                int j = nv + d;
+                m->dof_type[j] = (jt == JSLIDE || (jt == JFREE && d < 3)) ? 2 : 1;
+                m->dof_body[j] = b;
+                m->dof_qadr[j] = nd == 1 ? nq : -1;
+                m->damping[j] = r[15];
+                m->armature[j] = r[16];
+                m->frictionloss[j] = r[22];
+            }
+            if (nd == 1) {
+                m->stiffness[nv] = r[17];
+                m->springref[nv] = r[18];
+                m->range[nv][0] = r[12];
+                m->range[nv][1] = r[13];
+                m->limited[nv] = (int)r[14];
+            }
+            /* qpos0: zero (hinge, slide), the identity (ball), the body's own pose (free) */
+            if (jt == JBALL) m->qpos0[nq] = 1.0;
+            if (jt == JFREE) {
+                memcpy(m->qpos0 + nq, m->bpos[b], 24);
+                memcpy(m->qpos0 + nq + 3, m->bquat0[b], 32);
+            }
+            nv += nd;
+            nq += jt == JFREE ? 7 : (jt == JBALL ? 4 : 1);
+        }
+        if (r[23] != 0) {               /* explicit <inertial>: mass, centre, full tensor in the body frame's axes */
+            has_inertial[b] = 1;
+            m->mass[b] = r[24];
+            memcpy(m->ipos[b], r + 25, 24);
+            memcpy(m->inertia[b], r + 28, 72);
         }
     }
     m->nv = nv;
+    m->nq = nq;
     /* inertiafromgeom */
     double gm[MAXG], gp[MAXG][3], gI[MAXG][9];
     int gb[MAXG];
     const double *g0 = f + HEADER_LEN + nb * BODY_STRIDE;
     for (int g = 0; g < ng; g++) {
         const double *r = g0 + g * GEOM_STRIDE;
-        gb[g] = (int)r[0] + 1;
-        geom_inertia((int)r[1], r[2], r + 3, r + 6, r[9], f[37], &gm[g], gp[g], gI[g]);
-        /* colliding geoms: a sphere, or a capsule = its two end spheres, "to" end first (mjc_PlaneCapsule tests
-         * pos + axis * halflength, then pos - axis * halflength, and aligns the contact frame with the axis).
+        gb[g] = (int)r[0] + 1;              /* 0: a static geom of the world body */
+        geom_inertia((int)r[1], r[2], r + 3, r + 6, r + 14, r[9], f[37], &gm[g], gp[g], gI[g]);
+        /* colliding geoms: a sphere, a capsule = its two end spheres, "to" end first (mjc_PlaneCapsule tests
+         * pos + axis * halflength, then pos - axis * halflength, and aligns the contact frame with the axis), a box = its
+         * eight corners (mjc_PlaneBox; MuJoCo keeps at most four of them, this restatement all that are within the margin).
          * Contact friction / condim = max over the two geoms (MuJoCo mj_contactParam, equal priorities). */
-        int ends = r[10] != 0 ? ((int)r[1] == 1 ? 1 : 2) : 0;
-        for (int e = 0; e < ends && m->nsphere < MAXS; e++) {
+        int gt = (int)r[1];
+        int ends = (r[10] != 0 && gb[g] > 0) ? (gt == 1 ? 1 : (gt == 2 ? 2 : 8)) : 0;
+        double Rb[9];
+        if (gt == 3) quat2mat(r + 14, Rb);
+        for (int e = 0; e < ends; e++) {
+            if (m->nsphere >= MAXS) { free(m); return NULL; }
             int s = m->nsphere++;
             m->sph_body[s] = gb[g];
-            memcpy(m->sph_pos[s], (ends == 2 && e == 0) ? r + 6 : r + 3, 24);
-            m->sph_r[s] = r[2];
+            if (gt == 3) {
+                double c[3] = {(e & 1 ? 1 : -1) * r[6], (e & 2 ? 1 : -1) * r[7], (e & 4 ? 1 : -1) * r[8]}, t[3];
+                matvec3(Rb, c, t);
+                for (int i = 0; i < 3; i++) m->sph_pos[s][i] = r[3 + i] + t[i];
+                m->sph_r[s] = 0.0;
+            } else {
+                memcpy(m->sph_pos[s], (ends == 2 && e == 0) ? r + 6 : r + 3, 24);
+                m->sph_r[s] = r[2];
+            }
             m->sph_margin[s] = r[11];
             double mu = r[12] > plane_mu ? r[12] : plane_mu;
             int condim = (int)r[13] > plane_condim ? (int)r[13] : plane_condim;
@@ -458,6 +613,7 @@ OrModel *or_model_compile(const double *f, int n) {
         }
     }
     for (int b = 1; b <= nb; b++) {
+        if (has_inertial[b]) continue;
         double mass = 0, com[3] = {0, 0, 0};
         for (int g = 0; g < ng; g++)
             if (gb[g] == b) {
@@ -484,26 +640,66 @@ OrModel *or_model_compile(const double *f, int n) {
         m->ctrl_lo[a] = a0[a * ACT_STRIDE + 2];
         m->ctrl_hi[a] = a0[a * ACT_STRIDE + 3];
         m->kp[a] = a0[a * ACT_STRIDE + 4];
+        m->act_tendon[a] = (int)a0[a * ACT_STRIDE + 5];
     }
-    /* geom-geom pairs: every geom is a segment (from, to - from) with a radius; friction / condim / margin of a
-     * contact = the larger of the two geoms' (MuJoCo mj_contactParam with equal priorities) */
+    /* geom-geom pairs: spheres and capsules are segments (from, to - from) with a radius; ONE geom of a pair may be a box
+     * (against a sphere); friction / condim / margin of a contact = the larger of the two geoms' (MuJoCo mj_contactParam
+     * with equal priorities) */
     const double *p0 = a0 + nu * ACT_STRIDE;
     m->npair = np_;
     for (int k = 0; k < np_; k++) {
         double mu = 0, margin = 0;
         int condim = 1;
+        m->pair_box[k] = -1;
         for (int e = 0; e < 2; e++) {
             const double *r = g0 + (int)p0[k * PAIR_STRIDE + e] * GEOM_STRIDE;
             m->pair_body[k][e] = (int)r[0] + 1;
             memcpy(m->pair_a[k][e], r + 3, 24);
-            for (int i = 0; i < 3; i++) m->pair_d[k][e][i] = (int)r[1] == 1 ? 0.0 : r[6 + i] - r[3 + i];
-            m->pair_r[k][e] = r[2];
+            for (int i = 0; i < 3; i++) m->pair_d[k][e][i] = (int)r[1] == 2 ? r[6 + i] - r[3 + i] : 0.0;
+            m->pair_r[k][e] = (int)r[1] == 3 ? 0.0 : r[2];
+            if ((int)r[1] == 3) {
+                if (m->pair_box[k] >= 0) { free(m); return NULL; }      /* box-box is not restated */
+                m->pair_box[k] = e;
+                quat2mat(r + 14, m->pair_R[k]);
+                memcpy(m->pair_half[k], r + 6, 24);
+            }
             if (r[12] > mu) mu = r[12];
             if (r[11] > margin) margin = r[11];
             if ((int)r[13] > condim) condim = (int)r[13];
         }
+        if (m->pair_box[k] >= 0 && dot3(m->pair_d[k][1 - m->pair_box[k]], m->pair_d[k][1 - m->pair_box[k]]) > 0) {
+            free(m);                    /* box-capsule is not restated */
+            return NULL;
+        }
         m->pair_margin[k] = margin;
         m->pair_mu[k] = condim >= 3 ? mu : 0.0;
+    }
+    const double *e0 = p0 + np_ * PAIR_STRIDE;
+    m->neq = ne;
+    for (int k = 0; k < ne; k++) {
+        const double *r = e0 + k * EQ_STRIDE;
+        m->eq_type[k] = (int)r[0];
+        if (m->eq_type[k] != 1 && m->eq_type[k] != 3) { free(m); return NULL; }     /* connect and joint only */
+        m->eq_o1[k] = (int)r[1] + (m->eq_type[k] == 3 ? 0 : 1);        /* bodies: 0 = world; dofs: -1 = none */
+        m->eq_o2[k] = (int)r[2] + (m->eq_type[k] == 3 ? 0 : 1);
+        memcpy(m->eq_anchor[k][0], r + 3, 24);
+        memcpy(m->eq_poly[k], r + 6, 40);
+        memcpy(m->eq_solref[k], r + 11, 16);
+        memcpy(m->eq_solimp[k], r + 13, 40);
+    }
+    const double *t0 = e0 + ne * EQ_STRIDE;
+    m->ntendon = nt;
+    for (int k = 0; k < nt; k++) {
+        const double *r = t0 + k * TENDON_STRIDE;
+        m->tn_n[k] = (int)r[0];
+        m->tn_limited[k] = (int)r[1];
+        m->tn_range[k][0] = r[2];
+        m->tn_range[k][1] = r[3];
+        m->tn_margin[k] = r[4];
+        for (int i = 0; i < m->tn_n[k]; i++) {
+            m->tn_dof[k][i] = (int)r[8 + 2 * i];
+            m->tn_coef[k][i] = r[9 + 2 * i];
+        }
     }
     set_const(m);
     return m;
@@ -583,12 +779,14 @@ static void set_const(OrModel *m) {
     int nv = m->nv;
     clamp_solimp(m->solimp);
     clamp_solimp(m->solimp_l);
+    clamp_solimp(m->solimp_f);
+    for (int e = 0; e < m->neq; e++) clamp_solimp(m->eq_solimp[e]);
     /* inertial frames: principal axes of every body's inertia tensor (body frame when it is diagonal there) and
      * the box of equal inertia, MuJoCo mj_passive: box_i = sqrt(6 (I_j + I_k - I_i) / m) */
     for (int b = 1; b < m->nbody; b++) body_box(m, b);
-    double q0[MAXV] = {0}, M[MAXV * MAXV];
+    double M[MAXV * MAXV];
     Kin k;
-    kinematics(m, q0, &k);
+    kinematics(m, m->qpos0, &k);
     mass_matrix(m, &k, M);
     chol(M, nv);
     for (int j = 0; j < nv; j++) {
@@ -597,17 +795,48 @@ static void set_const(OrModel *m) {
         chol_solve(M, nv, e);
         m->dof_invweight0[j] = e[j];
     }
-    m->body_invweight0[0] = 0;
+    /* MuJoCo averages the entries of a ball joint, and of the translations and of the rotations of a free joint */
     for (int b = 1; b < m->nbody; b++) {
-        double Jp[3 * MAXV], tr = 0;
-        jacobian(m, &k, b, k.xipos[b], Jp, NULL);
+        int j = m->dofid[b];
+        if (j < 0 || (m->jtype[b] != JBALL && m->jtype[b] != JFREE)) continue;
+        for (int g = 0; g < (m->jtype[b] == JFREE ? 2 : 1); g++) {
+            double avg = (m->dof_invweight0[j + 3 * g] + m->dof_invweight0[j + 3 * g + 1] + m->dof_invweight0[j + 3 * g + 2]) / 3;
+            for (int c = 0; c < 3; c++) m->dof_invweight0[j + 3 * g + c] = avg;
+        }
+    }
+    m->body_invweight0[0] = m->body_invweight0r[0] = 0;
+    for (int b = 1; b < m->nbody; b++) {
+        double Jp[3 * MAXV], Jr[3 * MAXV], tr = 0, trr = 0;
+        jacobian(m, &k, b, k.xipos[b], Jp, Jr);
         for (int i = 0; i < 3; i++) {
             double x[MAXV];
             memcpy(x, Jp + i * nv, sizeof(double) * nv);
             chol_solve(M, nv, x);
             for (int j = 0; j < nv; j++) tr += Jp[i * nv + j] * x[j];
+            memcpy(x, Jr + i * nv, sizeof(double) * nv);
+            chol_solve(M, nv, x);
+            for (int j = 0; j < nv; j++) trr += Jr[i * nv + j] * x[j];
         }
         m->body_invweight0[b] = tr / 3;
+        m->body_invweight0r[b] = trr / 3;
+    }
+    for (int t = 0; t < m->ntendon; t++) {       /* tendon_invweight0 = J M0^-1 J' */
+        double x[MAXV] = {0}, y[MAXV], acc = 0;
+        for (int i = 0; i < m->tn_n[t]; i++) x[m->tn_dof[t][i]] += m->tn_coef[t][i];
+        memcpy(y, x, sizeof(x));
+        chol_solve(M, nv, y);
+        for (int j = 0; j < nv; j++) acc += x[j] * y[j];
+        m->tn_invweight0[t] = acc;
+    }
+    /* equality constraints at qpos0 (MuJoCo's compiler): a connect's anchor as seen from body 2 */
+    for (int e = 0; e < m->neq; e++) {
+        if (m->eq_type[e] != 1) continue;
+        int b1 = m->eq_o1[e], b2 = m->eq_o2[e];
+        double w1[3], d[3];
+        matvec3(k.xmat[b1], m->eq_anchor[e][0], w1);
+        for (int i = 0; i < 3; i++) d[i] = k.xpos[b1][i] + w1[i] - k.xpos[b2][i];
+        for (int i = 0; i < 3; i++)
+            m->eq_anchor[e][1][i] = k.xmat[b2][i] * d[0] + k.xmat[b2][3 + i] * d[1] + k.xmat[b2][6 + i] * d[2];
     }
 }
 
@@ -646,12 +875,29 @@ static void row_params(const OrModel *m, double pos, double margin, double diagA
     row_params_set(m, m->solref, m->solimp, pos, margin, diagApprox, jv, D, aref);
 }
 
-/* minimise  1/2 (a - a_s)^T M (a - a_s) + sum_i 1/2 D_i min(0, J_i a - aref_i)^2
- * (MuJoCo primal problem for frictionless unilateral rows; the Newton solver of mj_fwdConstraint
- * converges to this unique minimiser up to its 1e-8 tolerance). Here: Newton + exact line search,
- * run to machine precision.  fs = M a_s.  Returns qacc in a and row forces in force. */
+/* minimise  1/2 (a - a_s)^T M (a - a_s) + sum_i s_i(J_i a - aref_i)
+ * (MuJoCo's primal problem, mj_constraintUpdate): per row kind the cost s(r) is
+ *   ROW_UNI   limits, frictionless and pyramidal contacts   1/2 D min(0, r)^2
+ *   ROW_EQ    equality                                      1/2 D r^2
+ *   ROW_FRIC  friction loss f                                1/2 D r^2 for |r| < R f, else f |r| - 1/2 R f^2   (R = 1 / D)
+ * - convex and piecewise quadratic; the Newton solver of mj_fwdConstraint converges to this unique minimiser up to its
+ * 1e-8 tolerance.  Here: Newton + exact line search, run to machine precision.  fs = M a_s.  Returns qacc in a and row
+ * forces -s'(r) in force. */
+static double row_slope(int kind, double D, double fl, double r, double *curv) {     /* s'(r), and s''(r) in curv */
+    if (kind == ROW_EQ) { *curv = D; return D * r; }
+    if (kind == ROW_FRIC) {
+        if (D * r <= -fl) { *curv = 0; return -fl; }
+        if (D * r >= fl) { *curv = 0; return fl; }
+        *curv = D;
+        return D * r;
+    }
+    if (r < 0) { *curv = D; return D * r; }
+    *curv = 0;
+    return 0;
+}
 static void solve_rows(OrModel *m, int nv, const double *M, const double *fs, int nc,
-                       double (*J)[MAXV], const double *aref, const double *D, double *a, double *force) {
+                       double (*J)[MAXV], const double *aref, const double *D, const int *kind, const double *floss,
+                       double *a, double *force) {
     double L[MAXV * MAXV];
     memcpy(L, M, sizeof(double) * nv * nv);
     chol(L, nv);
@@ -677,10 +923,20 @@ static void solve_rows(OrModel *m, int nv, const double *M, const double *fs, in
             double s = -aref[c];
             for (int j = 0; j < nv; j++) s += J[c][j] * a[j];
             jar[c] = s;
-            if (s < 0) {
+            if (kind[c] == ROW_UNI) {           /* (the arithmetic of the earlier rounds, kept as it was) */
+                if (s < 0) {
+                    for (int i = 0; i < nv; i++) {
+                        g[i] += D[c] * s * J[c][i];
+                        for (int j = 0; j < nv; j++) H[i * nv + j] += D[c] * J[c][i] * J[c][j];
+                    }
+                }
+            } else {
+                double curv, sl = row_slope(kind[c], D[c], floss[c], s, &curv);
                 for (int i = 0; i < nv; i++) {
-                    g[i] += D[c] * s * J[c][i];
-                    for (int j = 0; j < nv; j++) H[i * nv + j] += D[c] * J[c][i] * J[c][j];
+                    if (J[c][i] == 0) continue;
+                    g[i] += sl * J[c][i];
+                    if (curv != 0)
+                        for (int j = 0; j < nv; j++) H[i * nv + j] += curv * J[c][i] * J[c][j];
                 }
             }
         }
@@ -695,9 +951,10 @@ static void solve_rows(OrModel *m, int nv, const double *M, const double *fs, in
         chol(H, nv);
         for (int i = 0; i < nv; i++) d[i] = -g[i];
         chol_solve(H, nv, d);
-        /* exact line search: phi'(alpha) = p0 + alpha p1 + sum_c D jd min(0, jar + alpha jd) */
-        double p0 = 0, p1 = 0, jd[MAXC], bp[MAXC];
-        int idx[MAXC], nbp = 0;
+        /* exact line search: phi'(alpha) = p0 + alpha p1 + sum_c s_c'(jar_c + alpha jd_c) jd_c, piecewise linear and
+         * increasing: c0 + alpha c1 on the current piece; every break point carries the change of (c0, c1) across it */
+        double p0 = 0, p1 = 0, bp[2 * MAXC], dc0[2 * MAXC], dc1[2 * MAXC];
+        int nbp = 0;
         for (int i = 0; i < nv; i++) {
             double Md = 0, Ma = -fs[i];
             for (int j = 0; j < nv; j++) { Md += M[i * nv + j] * d[j]; Ma += M[i * nv + j] * a[j]; }
@@ -708,28 +965,53 @@ static void solve_rows(OrModel *m, int nv, const double *M, const double *fs, in
         for (int c = 0; c < nc; c++) {
             double s = 0;
             for (int j = 0; j < nv; j++) s += J[c][j] * d[j];
-            jd[c] = s;
-            if (jar[c] < 0 || (jar[c] == 0 && s < 0)) { c0 += D[c] * s * jar[c]; c1 += D[c] * s * s; }
-            if (s != 0) {
-                double al = -jar[c] / s;
-                if (al > 0) { bp[nbp] = al; idx[nbp++] = c; }
+            if (kind[c] == ROW_UNI) {
+                if (jar[c] < 0 || (jar[c] == 0 && s < 0)) { c0 += D[c] * s * jar[c]; c1 += D[c] * s * s; }
+                if (s != 0) {
+                    double al = -jar[c] / s;
+                    if (al > 0) {
+                        /* row c toggles at al: it was active iff jar < 0 (or jar == 0 moving down) */
+                        double sgn = jar[c] < 0 ? -1.0 : 1.0;
+                        bp[nbp] = al; dc0[nbp] = sgn * D[c] * s * jar[c]; dc1[nbp] = sgn * D[c] * s * s; nbp++;
+                    }
+                }
+            } else if (kind[c] == ROW_EQ) {
+                c0 += D[c] * s * jar[c];
+                c1 += D[c] * s * s;
+            } else {
+                /* friction loss: zones r <= -R f (slope -f), |r| < R f (D r), r >= R f (+f); in zone z the row adds
+                 * (z0[z], z1[z]) to (c0, c1) */
+                double Rf = floss[c] / D[c];
+                double z0[3] = {-floss[c] * s, D[c] * s * jar[c], floss[c] * s}, z1[3] = {0, D[c] * s * s, 0};
+                int z = jar[c] <= -Rf ? 0 : (jar[c] >= Rf ? 2 : 1);
+                if (s > 0 && jar[c] == -Rf) z = 1;          /* on a border, moving inwards */
+                if (s < 0 && jar[c] == Rf) z = 1;
+                c0 += z0[z];
+                c1 += z1[z];
+                if (s != 0) {
+                    int dir = s > 0 ? 1 : -1;
+                    for (int zz = z; zz + dir >= 0 && zz + dir <= 2; zz += dir) {
+                        double border = (dir > 0 ? (zz == 0 ? -Rf : Rf) : (zz == 2 ? Rf : -Rf));
+                        double al = (border - jar[c]) / s;
+                        if (al > 0) {
+                            bp[nbp] = al; dc0[nbp] = z0[zz + dir] - z0[zz]; dc1[nbp] = z1[zz + dir] - z1[zz]; nbp++;
+                        }
+                    }
+                }
             }
         }
         for (int i = 1; i < nbp; i++)       /* insertion sort of break points */
             for (int j = i; j > 0 && bp[j] < bp[j - 1]; j--) {
                 double t = bp[j]; bp[j] = bp[j - 1]; bp[j - 1] = t;
-                int ti = idx[j]; idx[j] = idx[j - 1]; idx[j - 1] = ti;
+                t = dc0[j]; dc0[j] = dc0[j - 1]; dc0[j - 1] = t;
+                t = dc1[j]; dc1[j] = dc1[j - 1]; dc1[j - 1] = t;
             }
         if (!(c1 > 0)) break;               /* a zero step (the polishing iteration from an exact minimiser): done */
         double alpha = -c0 / c1;
         for (int i = 0; i < nbp; i++) {
             if (alpha <= bp[i]) break;
-            int c = idx[i];
-            /* row c toggles at bp[i]: it was active iff jar < 0 (or jar == 0 moving down) */
-            int was_active = jar[c] < 0;
-            double sgn = was_active ? -1.0 : 1.0;
-            c0 += sgn * D[c] * jd[c] * jar[c];
-            c1 += sgn * D[c] * jd[c] * jd[c];
+            c0 += dc0[i];
+            c1 += dc1[i];
             alpha = -c0 / c1;
             if (alpha < bp[i]) alpha = bp[i];
         }
@@ -738,9 +1020,10 @@ static void solve_rows(OrModel *m, int nv, const double *M, const double *fs, in
     m->newton_iters += it;
     if (it >= 100) m->newton_fail++;
     for (int c = 0; c < nc; c++) {
-        double s = -aref[c];
+        double s = -aref[c], curv;
         for (int j = 0; j < nv; j++) s += J[c][j] * a[j];
-        force[c] = s < 0 ? -D[c] * s : 0.0;
+        if (kind[c] == ROW_UNI) force[c] = s < 0 ? -D[c] * s : 0.0;
+        else force[c] = -row_slope(kind[c], D[c], floss[c], s, &curv);
     }
 }
 
@@ -841,7 +1124,7 @@ void or_step(OrModel *m, double *q, double *v, const double *ctrl, double *site_
     /* passive: joint dampers and springs (MuJoCo mj_passive) */
     for (int j = 0; j < nv; j++) {
         fs[j] = -bias[j] - m->damping[j] * v[j];
-        if (m->stiffness[j] != 0) fs[j] -= m->stiffness[j] * (q[j] - m->springref[j]);
+        if (m->stiffness[j] != 0) fs[j] -= m->stiffness[j] * (q[m->dof_qadr[j]] - m->springref[j]);
     }
     /* ... and the medium: viscous and drag forces on the box of equal inertia of every body, evaluated in the body's
      * inertial frame at its centre of mass, applied there (mj_passive, inertia-box fluid model) */
@@ -885,16 +1168,83 @@ void or_step(OrModel *m, double *q, double *v, const double *ctrl, double *site_
         double u = ctrl[a];
         if (u < m->ctrl_lo[a]) u = m->ctrl_lo[a];
         if (u > m->ctrl_hi[a]) u = m->ctrl_hi[a];
+        if (m->act_tendon[a]) {
+            /* an actuator on a fixed tendon: length = sum coef q, moment arm of dof i = gear * coef_i */
+            int t = m->act_dof[a];
+            double len = 0;
+            for (int i = 0; i < m->tn_n[t]; i++) len += m->tn_coef[t][i] * q[m->dof_qadr[m->tn_dof[t][i]]];
+            double frc = m->kp[a] > 0 ? m->kp[a] * (u - m->gear[a] * len) : u;
+            for (int i = 0; i < m->tn_n[t]; i++) fs[m->tn_dof[t][i]] += m->gear[a] * m->tn_coef[t][i] * frc;
+            continue;
+        }
         /* motor: gear * ctrl; position servo (MJCF <position kp>): gain kp, bias -kp * length, length = gear * q */
-        fs[m->act_dof[a]] += m->kp[a] > 0 ? m->gear[a] * m->kp[a] * (u - m->gear[a] * q[m->act_dof[a]]) : m->gear[a] * u;
+        double qa = m->kp[a] > 0 ? q[m->dof_qadr[m->act_dof[a]]] : 0.0;
+        fs[m->act_dof[a]] += m->kp[a] > 0 ? m->gear[a] * m->kp[a] * (u - m->gear[a] * qa) : m->gear[a] * u;
     }
-    /* constraint rows: MuJoCo mj_instantiateLimit (dist < margin, jnt margin = 0) */
-    double J[MAXC][MAXV], aref[MAXC], D[MAXC], force[MAXC], qacc[MAXV];
+    /* constraint rows, in MuJoCo's order: equality, friction loss, limits, contacts */
+    static const double ZERO3[3] = {0, 0, 0};
+    double J[MAXC][MAXV], aref[MAXC], D[MAXC], floss[MAXC], force[MAXC], qacc[MAXV];
+    int kind[MAXC];
     int nc = 0;
+    for (int e = 0; e < m->neq; e++) {
+        if (m->eq_type[e] == 1) {
+            /* connect: the anchor as a point of body 1 and as a point of body 2 coincide; rows along the world axes,
+             * J = jacp(body 1, p1) - jacp(body 2, p2), diagApprox = the two bodies' translational invweight0 */
+            int b1 = m->eq_o1[e], b2 = m->eq_o2[e];
+            double p1[3], p2[3], t[3], J1[3 * MAXV], J2[3 * MAXV];
+            matvec3(k.xmat[b1], m->eq_anchor[e][0], t);
+            for (int i = 0; i < 3; i++) p1[i] = k.xpos[b1][i] + t[i];
+            matvec3(k.xmat[b2], m->eq_anchor[e][1], t);
+            for (int i = 0; i < 3; i++) p2[i] = k.xpos[b2][i] + t[i];
+            jacobian(m, &k, b1, p1, J1, NULL);
+            jacobian(m, &k, b2, p2, J2, NULL);
+            for (int i = 0; i < 3; i++) {
+                double jv = 0;
+                for (int j = 0; j < nv; j++) {
+                    J[nc][j] = J1[i * nv + j] - (b2 > 0 ? J2[i * nv + j] : 0.0);
+                    jv += J[nc][j] * v[j];
+                }
+                row_params_set(m, m->eq_solref[e], m->eq_solimp[e], p1[i] - p2[i], 0.0,
+                               m->body_invweight0[b1] + m->body_invweight0[b2], jv, &D[nc], &aref[nc]);
+                kind[nc] = ROW_EQ;
+                floss[nc] = 0;
+                nc++;
+            }
+        } else {
+            /* joint: q1 - q1_0 = poly(q2 - q2_0) (qpos0 = 0 for hinge / slide joints) */
+            int d1 = m->eq_o1[e], d2 = m->eq_o2[e];
+            const double *pc = m->eq_poly[e];
+            double x = d2 >= 0 ? q[m->dof_qadr[d2]] : 0.0;
+            double poly = pc[0] + x * (pc[1] + x * (pc[2] + x * (pc[3] + x * pc[4])));
+            double dpoly = pc[1] + x * (2 * pc[2] + x * (3 * pc[3] + x * 4 * pc[4]));
+            memset(J[nc], 0, sizeof(J[nc]));
+            J[nc][d1] = 1.0;
+            if (d2 >= 0) J[nc][d2] = -dpoly;
+            double jv = v[d1] - (d2 >= 0 ? dpoly * v[d2] : 0.0);
+            row_params_set(m, m->eq_solref[e], m->eq_solimp[e], q[m->dof_qadr[d1]] - poly, 0.0,
+                           m->dof_invweight0[d1] + (d2 >= 0 ? m->dof_invweight0[d2] : 0.0), jv, &D[nc], &aref[nc]);
+            kind[nc] = ROW_EQ;
+            floss[nc] = 0;
+            nc++;
+        }
+    }
+    /* friction loss (mj_instantiateFriction): one row per dof with frictionloss > 0, J = e_j, pos = 0 */
     for (int j = 0; j < nv; j++) {
-        if (!m->limited[j]) continue;
+        if (!(m->frictionloss[j] > 0)) continue;
+        memset(J[nc], 0, sizeof(J[nc]));
+        J[nc][j] = 1.0;
+        row_params_set(m, m->solref_f, m->solimp_f, 0.0, 0.0, m->dof_invweight0[j], v[j], &D[nc], &aref[nc]);
+        kind[nc] = ROW_FRIC;
+        floss[nc] = m->frictionloss[j];
+        nc++;
+    }
+    int nc_uni0 = nc;
+    /* joint limits: MuJoCo mj_instantiateLimit (dist < margin, jnt margin = 0); hinge and slide joints */
+    for (int j = 0; j < nv; j++) {
+        if (!m->limited[j] || m->dof_qadr[j] < 0) continue;
+        double qj = q[m->dof_qadr[j]];
         for (int side = -1; side <= 1; side += 2) {
-            double dist = side * (m->range[j][(side + 1) / 2] - q[j]);
+            double dist = side * (m->range[j][(side + 1) / 2] - qj);
             if (dist < 0) {
                 memset(J[nc], 0, sizeof(J[nc]));
                 J[nc][j] = -side;
@@ -903,8 +1253,26 @@ void or_step(OrModel *m, double *q, double *v, const double *ctrl, double *site_
             }
         }
     }
-    /* plane-sphere contacts (mjc_PlaneSphere / the two ends mjc_PlaneCapsule tests + mj_instantiateContact):
-     * margin = max of the two geom margins, gap = 0, included when dist < margin */
+    /* tendon limits: length = sum coef q; rows like the joint limits' with J = +-coef, diagApprox = tendon_invweight0 */
+    for (int t = 0; t < m->ntendon; t++) {
+        if (!m->tn_limited[t]) continue;
+        double len = 0, lv = 0;
+        for (int i = 0; i < m->tn_n[t]; i++) {
+            len += m->tn_coef[t][i] * q[m->dof_qadr[m->tn_dof[t][i]]];
+            lv += m->tn_coef[t][i] * v[m->tn_dof[t][i]];
+        }
+        for (int side = -1; side <= 1; side += 2) {
+            double dist = side * (m->tn_range[t][(side + 1) / 2] - len);
+            if (dist < m->tn_margin[t]) {
+                memset(J[nc], 0, sizeof(J[nc]));
+                for (int i = 0; i < m->tn_n[t]; i++) J[nc][m->tn_dof[t][i]] += -side * m->tn_coef[t][i];
+                row_params_set(m, m->solref_l, m->solimp_l, dist, m->tn_margin[t], m->tn_invweight0[t], -side * lv, &D[nc], &aref[nc]);
+                nc++;
+            }
+        }
+    }
+    /* plane-sphere contacts (mjc_PlaneSphere / the two ends mjc_PlaneCapsule tests / the corners mjc_PlaneBox tests +
+     * mj_instantiateContact): margin = max of the two geom margins, gap = 0, included when dist < margin */
     for (int s = 0; m->has_plane && s < m->nsphere; s++) {
         int b = m->sph_body[s];
         double c[3], t[3];
@@ -921,7 +1289,8 @@ void or_step(OrModel *m, double *q, double *v, const double *ctrl, double *site_
     }
     /* geom-geom contacts (mjc_SphereSphere / SphereCapsule / CapsuleCapsule): the closest points of the two segments,
      * one contact; normal from the second geom to the first, contact point midway between the surfaces; the contact
-     * frame comes from the normal alone (mju_makeFrame) */
+     * frame comes from the normal alone (mju_makeFrame).  A sphere against a box (mjc_SphereBox): the closest point of
+     * the box to the sphere's centre (centre outside the box), or the nearest face (centre inside). */
     for (int p = 0; p < m->npair; p++) {
         double o[2][3], d[2][3];
         for (int e = 0; e < 2; e++) {
@@ -931,27 +1300,81 @@ void or_step(OrModel *m, double *q, double *v, const double *ctrl, double *site_
             for (int i = 0; i < 3; i++) o[e][i] = k.xpos[b][i] + t[i];
             matvec3(k.xmat[b], m->pair_d[p][e], d[e]);
         }
-        double sA, sB, c1[3], c2[3], diff[3];
+        double c1[3], c2[3], diff[3], len;
+        if (m->pair_box[p] >= 0) {
+            int eb = m->pair_box[p], es = 1 - eb, bb = m->pair_body[p][eb];
+            double Rw[9], loc[3], cl[3], rel[3], nb[3], cb[3];
+            matmul3(k.xmat[bb], m->pair_R[p], Rw);
+            for (int i = 0; i < 3; i++) rel[i] = o[es][i] - o[eb][i];
+            int inside = 1;
+            for (int i = 0; i < 3; i++) {
+                loc[i] = Rw[i] * rel[0] + Rw[3 + i] * rel[1] + Rw[6 + i] * rel[2];
+                cl[i] = loc[i] < -m->pair_half[p][i] ? -m->pair_half[p][i] : (loc[i] > m->pair_half[p][i] ? m->pair_half[p][i] : loc[i]);
+                if (cl[i] != loc[i]) inside = 0;
+            }
+            double depth_in = 0;
+            if (inside) {       /* the face the centre is nearest to: surface point on it, outward normal */
+                int kk = 0;
+                double best = 1e300;
+                for (int i = 0; i < 3; i++) {
+                    double gap = m->pair_half[p][i] - fabs(loc[i]);
+                    if (gap < best) { best = gap; kk = i; }
+                }
+                depth_in = best;
+                double sg = loc[kk] >= 0 ? 1.0 : -1.0;
+                cl[kk] = sg * m->pair_half[p][kk];
+                double nl[3] = {0, 0, 0};
+                nl[kk] = sg;
+                matvec3(Rw, nl, nb);
+            }
+            matvec3(Rw, cl, cb);
+            for (int i = 0; i < 3; i++) cb[i] += o[eb][i];          /* the box's closest surface point, world */
+            if (!inside) {
+                for (int i = 0; i < 3; i++) nb[i] = o[es][i] - cb[i];
+                len = sqrt(dot3(nb, nb));
+                if (len < 1e-14) continue;
+                for (int i = 0; i < 3; i++) nb[i] /= len;
+            } else {
+                len = -depth_in;                                    /* centre below the surface: negative distance */
+            }
+            /* as two "closest points" c1 (geom 0's side) - c2 (geom 1's side) along the normal from geom 1 to geom 0 */
+            for (int i = 0; i < 3; i++) {
+                double sgn = es == 0 ? 1.0 : -1.0;                  /* nb points from the box to the sphere */
+                diff[i] = sgn * nb[i];
+                c1[i] = es == 0 ? o[es][i] : cb[i];
+                c2[i] = es == 0 ? cb[i] : o[es][i];
+            }
+            double dist = len - m->pair_r[p][0] - m->pair_r[p][1];
+            if (dist < m->pair_margin[p]) {
+                double cp[3];
+                for (int i = 0; i < 3; i++) cp[i] = c2[i] + diff[i] * (m->pair_r[p][1] + 0.5 * dist);
+                contact_rows(m, &k, v, diff, cp, m->pair_body[p][0], m->pair_body[p][1], dist, m->pair_margin[p], m->pair_mu[p],
+                             ZERO3, J, aref, D, &nc);
+            }
+            continue;
+        }
+        double sA, sB;
         seg_seg(o[0], d[0], o[1], d[1], &sA, &sB);
         for (int i = 0; i < 3; i++) {
             c1[i] = o[0][i] + sA * d[0][i];
             c2[i] = o[1][i] + sB * d[1][i];
             diff[i] = c1[i] - c2[i];
         }
-        double len = sqrt(dot3(diff, diff));
+        len = sqrt(dot3(diff, diff));
         if (len < 1e-14) continue;                  /* coincident axes: no normal */
         double dist = len - m->pair_r[p][0] - m->pair_r[p][1];
         if (dist < m->pair_margin[p]) {
-            double n[3], cp[3], none[3] = {0, 0, 0};
+            double n[3], cp[3];
             for (int i = 0; i < 3; i++) {
                 n[i] = diff[i] / len;
                 cp[i] = c2[i] + n[i] * (m->pair_r[p][1] + 0.5 * dist);
             }
             contact_rows(m, &k, v, n, cp, m->pair_body[p][0], m->pair_body[p][1], dist, m->pair_margin[p], m->pair_mu[p],
-                         none, J, aref, D, &nc);
+                         ZERO3, J, aref, D, &nc);
         }
     }
-    solve_rows(m, nv, M, fs, nc, J, aref, D, qacc, force);
+    for (int c = nc_uni0; c < nc; c++) { kind[c] = ROW_UNI; floss[c] = 0; }
+    solve_rows(m, nv, M, fs, nc, J, aref, D, kind, floss, qacc, force);
     /* mj_Euler with implicit joint damping: (M + h diag(damping)) qacc' = qfrc_smooth + qfrc_constraint */
     double rhs[MAXV];
     memcpy(rhs, fs, sizeof(double) * nv);
@@ -960,9 +1383,20 @@ void or_step(OrModel *m, double *q, double *v, const double *ctrl, double *site_
     for (int j = 0; j < nv; j++) M[j * nv + j] += m->timestep * m->damping[j];
     chol(M, nv);
     chol_solve(M, nv, rhs);
-    for (int j = 0; j < nv; j++) {
-        v[j] += m->timestep * rhs[j];
-        q[j] += m->timestep * v[j];
+    for (int j = 0; j < nv; j++) v[j] += m->timestep * rhs[j];
+    /* mj_integratePos: hinge / slide q += h v; ball / free orientation: q <- q * exp(h w / 2), w in the body frame */
+    for (int b = 1; b < m->nbody; b++) {
+        int j = m->dofid[b];
+        if (j < 0) continue;
+        double *qq = q + m->qadr[b];
+        if (m->jtype[b] == JBALL) {
+            quat_integrate(qq, v + j, m->timestep);
+        } else if (m->jtype[b] == JFREE) {
+            for (int i = 0; i < 3; i++) qq[i] += m->timestep * v[j + i];
+            quat_integrate(qq + 3, v + j + 3, m->timestep);
+        } else {
+            qq[0] += m->timestep * v[j];
+        }
     }
     if (diag) {
         diag[0] = nc;
@@ -978,6 +1412,7 @@ void or_set_body_inertia(OrModel *m, int body, const double *I9) { memcpy(m->ine
 void or_set_sphere_mu(OrModel *m, int s, double mu) { m->sph_mu[s] = mu; }
 void or_set_sphere_pos(OrModel *m, int s, const double *xyz) { memcpy(m->sph_pos[s], xyz, 24); }
 void or_set_dof_damping(OrModel *m, int dof, double d) { m->damping[dof] = d; }
+void or_set_dof_frictionloss(OrModel *m, int dof, double f) { m->frictionloss[dof] = f; }
 void or_set_sphere_radius(OrModel *m, int s, double r) { m->sph_r[s] = r; }
 
 /* number of OpenMP threads or_rollout uses (n > 0 sets it first); 1 without OpenMP */
@@ -993,8 +1428,10 @@ int or_threads(int n) {
 
 /* ---------------------------------------------------------------- accessors for tests */
 int or_nv(const OrModel *m) { return m->nv; }
+int or_nq(const OrModel *m) { return m->nq; }
 int or_nbody(const OrModel *m) { return m->nbody; }
-int or_dobs(const OrModel *m) { return m->task == 1 ? 2 * m->nv - m->obs_skip : 2 * m->nv + 6; }
+int or_dobs(const OrModel *m) { return m->task == 1 ? m->nq + m->nv - m->obs_skip : m->nq + m->nv + 6; }
+void or_qpos0(const OrModel *m, double *q) { memcpy(q, m->qpos0, sizeof(double) * m->nq); }
 int or_npair(const OrModel *m) { return m->npair; }
 void or_get_inertial(const OrModel *m, double *mass, double *ipos, double *inertia) {
     for (int b = 0; b < m->nbody; b++) {
@@ -1044,13 +1481,13 @@ static double env_step(OrModel *m, double *q, double *v, const double *u, const 
     if (m->task == 1) {
         /* SwimmerEnv.step / HalfCheetahEnv.step (swimmer.py:10-19, half_cheetah.py:10-19): reward = forward progress
          * of qpos[0] over the env step / dt - c * |a|^2 (the action as given, unclipped), obs = [qpos[skip:], qvel] */
-        int nv = m->nv, sk = m->obs_skip;
+        int nv = m->nv, nq = m->nq, sk = m->obs_skip;
         double x0 = q[0], c = 0;
         for (int s = 0; s < m->frame_skip; s++) or_step(m, q, v, u, NULL, NULL);
         for (int a = 0; a < m->nu; a++) c += u[a] * u[a];
         if (obs) {
-            memcpy(obs, q + sk, sizeof(double) * (nv - sk));
-            memcpy(obs + nv - sk, v, sizeof(double) * nv);
+            memcpy(obs, q + sk, sizeof(double) * (nq - sk));
+            memcpy(obs + nq - sk, v, sizeof(double) * nv);
         }
         return (q[0] - x0) / (m->timestep * m->frame_skip) - m->ctrl_cost * c;
     }
@@ -1059,11 +1496,11 @@ static double env_step(OrModel *m, double *q, double *v, const double *u, const 
     double d[3] = {h[0] - target[0], h[1] - target[1], h[2] - target[2]};
     double l1 = fabs(d[0]) + fabs(d[1]) + fabs(d[2]), l2 = sqrt(dot3(d, d));
     if (obs) {
-        int nv = m->nv;
-        memcpy(obs, q, sizeof(double) * nv);
-        memcpy(obs + nv, v, sizeof(double) * nv);
-        memcpy(obs + 2 * nv, h, 24);
-        memcpy(obs + 2 * nv + 3, d, 24);
+        int nv = m->nv, nq = m->nq;
+        memcpy(obs, q, sizeof(double) * nq);
+        memcpy(obs + nq, v, sizeof(double) * nv);
+        memcpy(obs + nq + nv, h, 24);
+        memcpy(obs + nq + nv + 3, d, 24);
     }
     /* task 2: the shape of pen-v0's reward (object to its target position, object axis to its target direction; both
      * from the kinematics the last substep started with, like the site) */
@@ -1101,7 +1538,7 @@ void or_rollout_cl(OrModel *m, const double *qp0, const double *qv0, const doubl
 static void rollout_impl(OrModel *m, const double *qp0, const double *qv0, const double *target, long P, int H,
                          const double *mean, const double *noise, double *obs, double *rew, double *act,
                          double *done, double *next_obs, int closed_loop) {
-    int nv = m->nv, nu = m->nu, dobs = or_dobs(m);
+    int nv = m->nv, nq = m->nq, nu = m->nu, dobs = or_dobs(m);
     double h0[3] = {0, 0, 0};
     if (m->task != 1) or_site(m, qp0, h0);
     long calls = 0, iters = 0, fails = 0;
@@ -1109,16 +1546,16 @@ static void rollout_impl(OrModel *m, const double *qp0, const double *qv0, const
     for (long b = 0; b < P; b++) {
         OrModel loc = *m;       /* private statistics */
         loc.newton_calls = loc.newton_iters = loc.newton_fail = 0;
-        double q[MAXV], v[MAXV], cur[2 * MAXV + 6], nxt[2 * MAXV + 6], u[MAXV];
-        memcpy(q, qp0, sizeof(double) * nv);
+        double q[MAXQ], v[MAXV], cur[MAXQ + MAXV + 6], nxt[MAXQ + MAXV + 6], u[MAXV];
+        memcpy(q, qp0, sizeof(double) * nq);
         memcpy(v, qv0, sizeof(double) * nv);
         if (m->task == 1) {
-            memcpy(cur, q + m->obs_skip, sizeof(double) * (nv - m->obs_skip));
-            memcpy(cur + nv - m->obs_skip, v, sizeof(double) * nv);
+            memcpy(cur, q + m->obs_skip, sizeof(double) * (nq - m->obs_skip));
+            memcpy(cur + nq - m->obs_skip, v, sizeof(double) * nv);
         } else {
-            memcpy(cur, q, sizeof(double) * nv);
-            memcpy(cur + nv, v, sizeof(double) * nv);
-            for (int i = 0; i < 3; i++) { cur[2 * nv + i] = h0[i]; cur[2 * nv + 3 + i] = h0[i] - target[i]; }
+            memcpy(cur, q, sizeof(double) * nq);
+            memcpy(cur + nq, v, sizeof(double) * nv);
+            for (int i = 0; i < 3; i++) { cur[nq + nv + i] = h0[i]; cur[nq + nv + 3 + i] = h0[i] - target[i]; }
         }
         for (int t = 0; t < H; t++) {
             for (int a = 0; a < nu; a++) {

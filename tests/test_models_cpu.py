@@ -173,12 +173,17 @@ def test_loader_position_servos_pairs_and_self_collision(tmp_path):
                      task=TASK_REACH)
     assert sorted(auto.pairs) == [("ga", "pen"), ("gb", "pen")]
     assert load_mjcf(str(tmp_path / "auto.xml"), task=TASK_REACH, self_collision=False).pairs == []
-    # a pair across two branches of one tree would fill the sparse factorisation in: refused
+    # a pair across two branches of one tree (round 4): the elimination tree - the symbolic Cholesky of M's pattern plus
+    # every row's clique - chains the two branches, so that the row's dofs lie on one path of it (rounds 1-3 refused it)
     bad = xml.replace('<body name="b" pos="0.2 0 0">', '<body name="c" pos="0 0.1 0"><joint name="j2" axis="0 1 0" range="-1 1"/>'
                       '<geom name="gc" type="sphere" pos="0.05 0 0" size="0.03"/></body><body name="b" pos="0.2 0 0">')
     bad = bad.replace('<pair geom1="gb" geom2="pen"/>', '<pair geom1="gb" geom2="gc"/>')
-    with pytest.raises(NotImplementedError):
-        compile_tree(load_mjcf(_write(tmp_path, "bad_pair.xml", bad), task=TASK_REACH))
+    mb = compile_tree(load_mjcf(_write(tmp_path, "branch_pair.xml", bad), task=TASK_REACH))
+    ep = list(mb.field("eparent")[:mb.nv].astype(int))
+    # links: 0, 1 the object (untouched by the remaining pairs ga-pen ... gb-gc), 2 = j0, 3 = j2 (body c), 4 = j1 (body b);
+    # gb (link 4) against gc (link 3): link 4's row now reaches link 3, which becomes its parent in the elimination tree
+    assert mb.nv == 5 and ep[4] == 3 and ep[3] == 2 and mb.max_path == 5
+    assert list(mb.parent) == [-1, 0, -1, 2, 2]                     # (the kinematic tree is what it was)
 
 
 def _write(tmp_path, name, text):
