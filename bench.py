@@ -58,11 +58,13 @@ def parse(argv=None):
     ap.add_argument("--noise", choices=["device", "mt19937", "host"], default="device",
                     help="device: Philox on the GPU; mt19937: the reference's own numpy stream regenerated on the GPU "
                          "(seed-identical particles); host: numpy on the host, uploaded")
-    ap.add_argument("--workload", choices=["reacher", "half_cheetah", "swimmer", "hand24", "pen_hand"], default="reacher",
+    ap.add_argument("--workload", choices=["reacher", "half_cheetah", "swimmer", "hand24", "pen_hand", "cartpole", "tray", "door"],
+                    default="reacher",
                     help="reacher: the BASELINE.json headline (default).  The others run the same loop on the tree engine "
                          "(SURVEY 8f rank 4: the reference's vendored HalfCheetah / Swimmer models, the synthetic 24-dof hand, "
                          "and pen_hand: a 6-dof pen on that hand - position servos, capsule-capsule contacts with friction "
-                         "cones, pen-v0's shape of reward)")
+                         "cones, pen-v0's shape of reward); cartpole / tray / door: the round-4 synthetic MJCF models of the "
+                         "general kernel instantiation (friction loss; free joint + boxes; equality + static geoms)")
     ap.add_argument("--controller", choices=["mppi", "cem", "dmd"], default="mppi",
                     help="mppi (headline); cem: full covariance, elite_frac 0.1 (BASELINE config 4); dmd: DMD-MPC (config 5)")
     ap.add_argument("--scaling", choices=["weak", "strong"], default="weak")
@@ -212,6 +214,12 @@ def make_workload(args, local, comm, P_tot):
             from mjmpc_amd.models.pen_hand import holding_state, pen_hand_raw
             raw, env, name, lam = pen_hand_raw(), None, "pen_hand-v0 (synthetic 6-dof pen in a 24-dof hand)", {"mppi": 0.05, "dmd": 0.1}
             start = holding_state()
+        elif args.workload in ("cartpole", "tray", "door"):
+            from mjmpc_amd.models.synthetic import start_state, synthetic_raw
+            raw, env = synthetic_raw(args.workload), None
+            name = "%s_synthetic-v0 (mjmpc_amd/models/assets/%s.xml)" % (args.workload, args.workload)
+            lam = {"mppi": 0.05, "dmd": 0.1}
+            gen_start = start_state(args.workload, raw)
         else:
             from mjmpc_amd.envs import locomotion_env
             from mjmpc_amd.models.half_cheetah import half_cheetah_raw
@@ -230,6 +238,9 @@ def make_workload(args, local, comm, P_tot):
             st0 = env.get_env_state()
             w["reset"] = lambda: eng.set_env_state(st0)
             w["x0"] = float(st0["qpos"][0])
+        elif args.workload in ("cartpole", "tray", "door"):
+            w["reset"] = lambda: eng.set_env_state(gen_start)
+            w["cov"] = 0.01 if args.workload == "tray" else 0.3
         elif start is not None:
             st0 = dict(start, target_pos=np.asarray(raw.target_pos, float))
             w["reset"] = lambda: eng.set_env_state(st0)

@@ -24,18 +24,24 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from mjmpc_amd.envs.arm_engine import ArmRolloutEngine, make_device_rollout_fn, make_rollout_fn   # noqa: E402
 from mjmpc_amd.envs.locomotion_env import HalfCheetahEnv, SwimmerEnv                             # noqa: E402
 from mjmpc_amd.envs.reacher_env import ContinualReacher7DOFEnv, HandTreeEnv, Reacher7DOFEnv      # noqa: E402
+from mjmpc_amd.envs.synthetic_env import CartPoleEnv, DoorEnv, TrayEnv                           # noqa: E402
 from mjmpc_amd.envs.tree_engine import TreeRolloutEngine                                         # noqa: E402
 from mjmpc_amd.models.half_cheetah import half_cheetah_raw                                       # noqa: E402
 from mjmpc_amd.models.hand24 import hand24_raw                                                   # noqa: E402
 from mjmpc_amd.models.reacher7dof import reacher7dof_raw                                         # noqa: E402
 from mjmpc_amd.models.swimmer import swimmer_raw                                                 # noqa: E402
+from mjmpc_amd.models.synthetic import synthetic_raw                                             # noqa: E402
 from mjmpc_amd.policies import MPCPolicy                                                         # noqa: E402
 
 # the reference's registered MuJoCo envs whose models are vendored (mjmpc/envs/__init__.py:11-31), plus the synthetic
 # 24-dof tree; all but the two reachers run on the tree engine
 ENVS = {"reacher_7dof-v0": Reacher7DOFEnv, "continual_reacher-v0": ContinualReacher7DOFEnv,
-        "Swimmer-v0": SwimmerEnv, "HalfCheetah-v0": HalfCheetahEnv, "hand_tree-v0": HandTreeEnv}
-TREE_MODELS = {"hand_tree-v0": hand24_raw, "Swimmer-v0": swimmer_raw, "HalfCheetah-v0": half_cheetah_raw}
+        "Swimmer-v0": SwimmerEnv, "HalfCheetah-v0": HalfCheetahEnv, "hand_tree-v0": HandTreeEnv,
+        # round 4: synthetic MJCF models of the kinds the reference's other experiment files name (general kernel instantiation)
+        "cartpole_friction-v0": CartPoleEnv, "tray_glass_synthetic-v0": TrayEnv, "door_latch_synthetic-v0": DoorEnv}
+TREE_MODELS = {"hand_tree-v0": hand24_raw, "Swimmer-v0": swimmer_raw, "HalfCheetah-v0": half_cheetah_raw,
+               "cartpole_friction-v0": lambda: synthetic_raw("cartpole"), "tray_glass_synthetic-v0": lambda: synthetic_raw("tray"),
+               "door_latch_synthetic-v0": lambda: synthetic_raw("door")}
 
 
 def make_sim(env_name, dtype, num_shards):
@@ -116,8 +122,8 @@ def main():
         if exp["env_name"] in ("Swimmer-v0", "HalfCheetah-v0"):
             print("episode %d: reward %.3f, forward progress %.3f m" % (i, ep_rewards[i], env.get_env_state()["qpos"][0]))
         else:
-            print("episode %d: reward %.3f, final distance to target %.4f" % (i, ep_rewards[i],
-                                                                              np.linalg.norm(observations[-1][-3:])))
+            print("episode %d: reward %.3f, final distance to target %.4f (closest %.4f)"
+                  % (i, ep_rewards[i], np.linalg.norm(observations[-1][-3:]), min(np.linalg.norm(o[-3:]) for o in observations)))
     failures = sim.solver_failures()
     sim.close()
     print("Avg. reward = %.4f, Std. Reward = %.4f, Success Metric = %.1f" % (

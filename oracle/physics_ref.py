@@ -202,6 +202,17 @@ class RefArm:
         self._L.or_get_newton_stats(ctypes.c_void_p(self._h), out)
         return dict(calls=out[0], iters=out[1], fails=out[2])
 
+    def solve_rows(self, M, fs, J, aref, D, kind, floss):
+        """The constraint solver alone (test hook): minimise 1/2 (a - M^-1 fs)' M (a - M^-1 fs) + sum_i s_i(J_i a - aref_i)
+        with row kinds 0 unilateral, 1 equality, 2 friction loss; returns (a, row forces)."""
+        M, fs, J = _c(M), _c(fs), _c(J)
+        nv, nc = fs.size, J.shape[0]
+        kind = np.ascontiguousarray(kind, dtype=np.int32)
+        a, force = np.zeros(nv), np.zeros(max(nc, 1))
+        self._L.or_solve_rows(ctypes.c_void_p(self._h), nv, _p(M), _p(fs), nc, _p(J), _p(_c(aref)), _p(_c(D)),
+                              kind.ctypes.data_as(ctypes.POINTER(ctypes.c_int)), _p(_c(floss)), _p(a), _p(force))
+        return a, force[:nc]
+
     # -- building blocks ----------------------------------------------------
     def mass_matrix(self, q):
         M = np.zeros((self.nv, self.nv))

@@ -1027,6 +1027,15 @@ static void solve_rows(OrModel *m, int nv, const double *M, const double *fs, in
     }
 }
 
+/* test hook (tests/test_general_models_cpu.py): the solver alone, J row-major [nc][nv] */
+void or_solve_rows(OrModel *m, int nv, const double *M, const double *fs, int nc, const double *Jflat, const double *aref,
+                   const double *D, const int *kind, const double *floss, double *a, double *force) {
+    static double J[MAXC][MAXV];
+    for (int c = 0; c < nc; c++)
+        for (int j = 0; j < MAXV; j++) J[c][j] = j < nv ? Jflat[c * nv + j] : 0.0;
+    solve_rows(m, nv, M, fs, nc, J, aref, D, kind, floss, a, force);
+}
+
 /* closest points of two segments p1 + s d1, p2 + t d2, s, t in [0, 1] (a sphere is a segment of length 0); parallel
  * segments take s = 0 */
 static double clamp01(double x) { return x < 0 ? 0 : (x > 1 ? 1 : x); }

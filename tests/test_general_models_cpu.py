@@ -1,0 +1,381 @@
+"""CPU: the oracle's round-4 physics - friction-loss rows, ball and free joints, joint anchors, boxes, equalities, tendon
+limits - held to mechanics and to itself (MuJoCo is absent: PARITY UNPINNED, see oracle/reacher_ref.c), the constraint
+solver with its three row kinds against an independent minimiser, the MJCF loader's new features, and the two model
+compilers (oracle C / mjmpc_amd.models.compile_tree) against each other on the synthetic models."""
+import textwrap
+
+import numpy as np
+import pytest
+
+from mjmpc_amd.models.compile_tree import compile_tree
+from mjmpc_amd.models.mjcf import load_mjcf
+from mjmpc_amd.models.raw import TASK_REACH
+from mjmpc_amd.models.synthetic import FRAME_SKIP, start_state, synthetic_raw
+from oracle.physics_ref import RefArm
+
+HEAD = '<mujoco><compiler angle="radian" coordinate="local" inertiafromgeom="auto"/>'
+
+
+def _model(tmp_path, body, name="m.xml", gravity="0 0 -9.81", extra="", timestep="0.002", head=HEAD, **kw):
+    xml = head + '<option timestep="%s" gravity="%s" integrator="Euler"/>' % (timestep, gravity) + \
+        '<default><geom contype="0" conaffinity="0"/></default><worldbody><site name="target" pos="0 0 0"/>' + \
+        textwrap.dedent(body) + "</worldbody>" + extra + "</mujoco>"
+    (tmp_path / name).write_text(xml)
+    raw = load_mjcf(str(tmp_path / name), task=TASK_REACH, **kw)
+    return raw, RefArm(raw.to_flat())
+
+
+def _run(ref, q, v, u, n):
+    for _ in range(n):
+        q, v, site, diag = ref.step(q, v, u)
+    return q, v, diag
+
+
+# ------------------------------------------------------------------------------------------ friction loss
+BLOCK = """
+<body name="block"><joint name="x" type="slide" axis="1 0 0" frictionloss="%g"/>
+  <geom type="sphere" size="0.1" mass="%g"/><site name="finger"/></body>"""
+ACT = '<actuator><motor joint="x" gear="1" ctrlrange="-100 100" ctrllimited="true"/></actuator>'
+
+
+def test_friction_loss_holds_below_its_bound_and_slides_above(tmp_path):
+    """A 2 kg block on a slide joint with frictionloss 3 N: a 2 N push only makes it creep (the soft constraint's
+    steady state: D B v = F), a 5 N push accelerates it at (5 - 3) / m, and it coasts to a stop at 3 / m."""
+    raw, ref = _model(tmp_path, BLOCK % (3.0, 2.0), extra=ACT)
+    m = ref.inertial()[0][1]
+    assert abs(m - 2.0) < 1e-12
+    q, v, diag = _run(ref, np.zeros(1), np.zeros(1), np.array([2.0]), 500)
+    D = 1.0 / ((1 - 0.9) / 0.9 * (1.0 / m))             # R = (1 - imp) / imp * dof_invweight0 at imp(0) = dmin
+    B = 2.0 / (0.95 * 0.02)
+    assert 0 < v[0] < 1.05 * 2.0 / (D * B) and abs(v[0] - 2.0 / (D * B)) < 1e-6      # creeping, at the soft constraint's rate
+    assert diag[0] == 1
+    q, v, _ = _run(ref, np.zeros(1), np.zeros(1), np.array([5.0]), 500)
+    assert abs(v[0] - (5.0 - 3.0) / m * 1.0) < 1e-9                                   # 500 steps of 2 ms
+    q, v, _ = _run(ref, np.zeros(1), np.array([1.0]), np.zeros(1), 200)               # coasting: -f / m for 0.4 s
+    assert abs(v[0] - (1.0 - 3.0 / m * 0.4)) < 1e-9
+    q, v, _ = _run(ref, q, v, np.zeros(1), 400)                                       # ... and it stops, and stays
+    assert abs(v[0]) < 1e-6
+
+
+def test_constraint_solver_row_kinds_against_an_independent_minimiser(tmp_path):
+    """solve_rows (Newton + exact line search over unilateral, equality and Huber rows) against scipy's minimiser of the
+    same convex cost, random problems; and its KKT conditions exactly: M a - fs = J' f with f the rows' slopes."""
+    from scipy.optimize import minimize
+    raw, ref = _model(tmp_path, BLOCK % (0.0, 1.0), extra=ACT)
+    rs = np.random.RandomState(0)
+    for trial in range(30):
+        nv, nc = rs.randint(2, 7), rs.randint(1, 9)
+        A = rs.standard_normal((nv, nv))
+        M = A @ A.T + nv * np.eye(nv)
+        fs = 5 * rs.standard_normal(nv)
+        J = rs.standard_normal((nc, nv)) * (rs.uniform(size=(nc, nv)) < 0.7)
+        aref, D = 3 * rs.standard_normal(nc), rs.uniform(0.5, 20, nc)
+        kind = rs.randint(0, 3, nc)
+        fl = np.where(kind == 2, rs.uniform(0.1, 3.0, nc), 0.0)
+
+        def cost(a):
+            r = J @ a - aref
+            c = 0.5 * a @ M @ a - fs @ a
+            for i in range(nc):
+                if kind[i] == 0:
+                    c += 0.5 * D[i] * min(0.0, r[i]) ** 2
+                elif kind[i] == 1:
+                    c += 0.5 * D[i] * r[i] ** 2
+                else:
+                    Rf = fl[i] / D[i]
+                    c += 0.5 * D[i] * r[i] ** 2 if abs(r[i]) < Rf else fl[i] * abs(r[i]) - 0.5 * Rf * fl[i]
+            return c
+
+        a, f = ref.solve_rows(M, fs, J, aref, D, kind, fl)
+        r = J @ a - aref
+        slope = np.where(kind == 0, D * np.minimum(0, r), np.where(kind == 1, D * r, np.clip(D * r, -fl, fl)))
+        np.testing.assert_allclose(f, -slope, rtol=0, atol=1e-12)
+        np.testing.assert_allclose(M @ a - fs, J.T @ f, rtol=0, atol=1e-9)            # stationarity of the convex cost
+        best = minimize(cost, np.linalg.solve(M, fs), method="BFGS", options=dict(gtol=1e-10)).x
+        assert cost(a) <= cost(best) + 1e-9
+        np.testing.assert_allclose(a, best, rtol=0, atol=2e-5)
+    assert ref.newton_stats()["fails"] == 0
+
+
+# ------------------------------------------------------------------------------------------ free and ball joints
+FREE_BODY = """
+<body name="brick" pos="0.3 -0.2 1.0" quat="0.9 0.1 -0.3 0.2">
+  <freejoint name="f"/>
+  <geom name="g" type="box" size="0.1 0.05 0.02" pos="0.01 0 0.02" quat="0.95 0.2 0 0.1" density="700"/>
+  <geom type="sphere" pos="0.1 0 0" size="0.03" density="2000"/><site name="finger"/></body>"""
+
+
+def _world_inertial(ref, q):
+    """(mass, com, world-frame inertia about com) of body 1 of a free-jointed model at qpos q."""
+    mass, ipos, inertia = ref.inertial()
+    w, x, y, z = q[3:7] / np.linalg.norm(q[3:7])
+    R = np.array([[1 - 2 * (y * y + z * z), 2 * (x * y - w * z), 2 * (x * z + w * y)],
+                  [2 * (x * y + w * z), 1 - 2 * (x * x + z * z), 2 * (y * z - w * x)],
+                  [2 * (x * z - w * y), 2 * (y * z + w * x), 1 - 2 * (x * x + y * y)]])
+    return mass[1], q[:3] + R @ ipos[1], R @ inertia[1] @ R.T, R
+
+
+def test_free_body_momentum_and_free_fall(tmp_path):
+    """A free-jointed body (qpos = position + quaternion, qvel = world linear + body-frame angular velocity) with an
+    off-centre mass: without gravity its linear momentum, its angular momentum about the centre of mass and its kinetic
+    energy are conserved to the integrator's order - the errors HALVE with the time step (the body origin is not the
+    centre of mass, so M depends on q and semi-implicit Euler is first order); with gravity the centre of mass falls at g."""
+    raw, ref = _model(tmp_path, FREE_BODY, gravity="0 0 0", timestep="0.0005")
+    assert (ref.nv, ref.nq) == (6, 7)
+    np.testing.assert_allclose(ref.qpos0, [0.3, -0.2, 1.0] + list(np.array([0.9, 0.1, -0.3, 0.2]) / np.linalg.norm([0.9, 0.1, -0.3, 0.2])))
+    q, v = ref.qpos0.copy(), np.array([0.3, -0.1, 0.2, 2.0, -3.0, 1.5])
+
+    def momenta(q, v):
+        m, com, Iw, R = _world_inertial(ref, q)
+        w = R @ v[3:]
+        vc = v[:3] + np.cross(w, com - q[:3])
+        return m * vc, Iw @ w, 0.5 * m * vc @ vc + 0.5 * w @ Iw @ w
+
+    p0, L0, E0 = momenta(q, v)
+    assert abs(ref.kinetic(q, v) - E0) < 1e-12          # the Jacobian-built mass matrix agrees with rigid-body mechanics
+    q0, v0 = q.copy(), v.copy()
+    for _ in range(2000):
+        q, v, _, _ = ref.step(q, v, np.zeros(0))
+    p1, L1, E1 = momenta(q, v)
+    ep, eL, eE = np.linalg.norm(p1 - p0) / np.linalg.norm(p0), np.linalg.norm(L1 - L0) / np.linalg.norm(L0), abs(E1 - E0) / E0
+    assert ep < 3e-3 and eL < 3e-3 and eE < 3e-3
+    assert abs(np.linalg.norm(q[3:7]) - 1) < 1e-12
+    raw, ref = _model(tmp_path, FREE_BODY, gravity="0 0 0", timestep="0.00025", name="half.xml")
+    q, v = q0, v0
+    for _ in range(4000):
+        q, v, _, _ = ref.step(q, v, np.zeros(0))
+    p2, L2, E2 = momenta(q, v)
+    assert np.linalg.norm(p2 - p0) / np.linalg.norm(p0) < 0.6 * ep and np.linalg.norm(L2 - L0) / np.linalg.norm(L0) < 0.6 * eL
+    assert abs(E2 - E0) / E0 < 0.6 * eE
+    raw, ref = _model(tmp_path, FREE_BODY, name="g.xml")
+    q, v = ref.qpos0.copy(), np.array([0.0, 0.0, 0.0, 1.0, 2.0, -1.0])
+    _, com0, _, R = _world_inertial(ref, q)
+    vc0 = v[:3] + np.cross(R @ v[3:], com0 - q[:3])             # the centre of mass moves with the spin about the origin
+    for _ in range(100):
+        q, v, _, _ = ref.step(q, v, np.zeros(0))
+    _, com1, _, _ = _world_inertial(ref, q)
+    t = 0.2
+    np.testing.assert_allclose(com1 - com0, vc0 * t + np.array([0, 0, -0.5 * 9.81 * t * (t + 0.002)]), rtol=0, atol=3e-4)
+
+
+BALL = """
+<body name="bob" pos="0.1 0.2 1.0" quat="0.8 0.2 0.1 -0.3">
+  <joint name="b" type="ball" pos="%s"/>
+  <geom type="capsule" fromto="%s" size="0.02" density="900"/><site name="finger" pos="%s"/></body>"""
+
+
+def test_ball_joint_pendulum_and_anchor_offset(tmp_path):
+    """A ball-jointed pendulum: energy and the angular momentum about the vertical through the anchor are conserved to
+    the integrator's order; and the SAME pendulum written with its body frame at the anchor (joint pos 0) instead of
+    0.3 m away from it (joint pos = the anchor in the body frame) moves identically."""
+    raw_a, ref_a = _model(tmp_path, BALL % ("0 0 0.3", "0 0 0.3 0.05 0 -0.1", "0.05 0 -0.1"), name="a.xml", timestep="0.0005")
+    # the same body, frame moved to the anchor: body pos += R0 (0, 0, 0.3); geometry shifted by -(0, 0, 0.3)
+    R0 = np.array(ref_a.mass_matrix(ref_a.qpos0)) * 0           # (placeholder to keep numpy import used)
+    from mjmpc_amd.models.compile import _quat2mat
+    R0 = _quat2mat([0.8, 0.2, 0.1, -0.3])
+    p = np.array([0.1, 0.2, 1.0]) + R0 @ np.array([0, 0, 0.3])
+    body_b = BALL.replace('pos="0.1 0.2 1.0"', 'pos="%.17g %.17g %.17g"' % tuple(p)) % ("0 0 0", "0 0 0 0.05 0 -0.4", "0.05 0 -0.4")
+    raw_b, ref_b = _model(tmp_path, body_b, name="b.xml", timestep="0.0005")
+    qa, va = ref_a.qpos0.copy(), np.array([1.0, -2.0, 0.5])
+    qb, vb = qa.copy(), va.copy()
+    anchor = p
+
+    def energy_Lz(ref, q, v):
+        m, ipos, inertia = ref.inertial()
+        from mjmpc_amd.models.compile import _quat2mat as qm
+        R = R0 @ qm(q)                                          # body orientation: parent o body quat o joint quat
+        w = R @ v
+        # body origin from the anchor (joint pos fixed in the body frame)
+        jpos = np.array([0, 0, 0.3]) if ref is ref_a else np.zeros(3)
+        origin = anchor - R @ jpos
+        com = origin + R @ ipos[1]
+        vc = np.cross(w, com - anchor)
+        Iw = R @ inertia[1] @ R.T
+        return (0.5 * m[1] * vc @ vc + 0.5 * w @ Iw @ w + m[1] * 9.81 * com[2],
+                (m[1] * np.cross(com - anchor, vc) + Iw @ w)[2], com)
+
+    E0, L0, c0 = energy_Lz(ref_a, qa, va)
+    Eb, Lb, cb = energy_Lz(ref_b, qb, vb)
+    assert abs(E0 - Eb) < 1e-12 and abs(L0 - Lb) < 1e-12
+    swing = 0.0
+    for _ in range(2000):
+        qa, va, sa, _ = ref_a.step(qa, va, np.zeros(0))
+        qb, vb, sb, _ = ref_b.step(qb, vb, np.zeros(0))
+        swing = max(swing, np.linalg.norm(energy_Lz(ref_a, qa, va)[2] - c0))
+    np.testing.assert_allclose(qa, qb, rtol=0, atol=1e-10)
+    np.testing.assert_allclose(va, vb, rtol=0, atol=1e-9)
+    np.testing.assert_allclose(sa, sb, rtol=0, atol=1e-10)      # the tracked site, through two different frames
+    E1, L1, c1 = energy_Lz(ref_a, qa, va)
+    assert swing > 0.1                                          # it did swing (about one period in this second)
+    assert abs(E1 - E0) < 5e-3 * abs(E0) and abs(L1 - L0) < 5e-3 * max(abs(L0), 0.01)
+
+
+def test_hinge_anchor_offset_and_explicit_inertial(tmp_path):
+    """A door leaf hinged at its edge: joint pos off the body origin = the same leaf with its frame on the hinge line; and
+    an explicit <inertial> = the geom it was computed from."""
+    leaf_a = """<body name="leaf" pos="0.45 0 1"><joint name="h" type="hinge" axis="0 0.1 1" pos="-0.45 0 0" damping="0.1"/>
+      <geom type="box" size="0.45 0.02 1.0" density="300"/><site name="finger" pos="0.4 0 0"/></body>"""
+    leaf_b = """<body name="leaf" pos="0 0 1"><joint name="h" type="hinge" axis="0 0.1 1" damping="0.1"/>
+      <geom type="box" size="0.45 0.02 1.0" pos="0.45 0 0" density="300"/><site name="finger" pos="0.85 0 0"/></body>"""
+    m = 300 * 8 * 0.45 * 0.02 * 1.0
+    leaf_c = leaf_a.replace('<geom type="box" size="0.45 0.02 1.0" density="300"/>',
+                            '<inertial pos="0 0 0" mass="%.17g" diaginertia="%.17g %.17g %.17g"/><geom type="sphere" size="0.01" density="0"/>'
+                            % (m, m / 3 * (0.02 ** 2 + 1.0), m / 3 * (0.45 ** 2 + 1.0), m / 3 * (0.45 ** 2 + 0.02 ** 2)))
+    runs = []
+    for k, body in enumerate((leaf_a, leaf_b, leaf_c)):
+        raw, ref = _model(tmp_path, body, name="leaf%d.xml" % k, gravity="0 -3 -9.81")
+        q, v = np.array([0.3]), np.array([1.0])
+        sites = []
+        for _ in range(300):
+            q, v, s, _ = ref.step(q, v, np.zeros(0))
+            sites.append(s)
+        runs.append((q, v, np.array(sites)))
+    for q, v, s in runs[1:]:
+        np.testing.assert_allclose(q, runs[0][0], rtol=0, atol=1e-11)
+        np.testing.assert_allclose(v, runs[0][1], rtol=0, atol=1e-10)
+        np.testing.assert_allclose(s, runs[0][2], rtol=0, atol=1e-11)
+
+
+# ------------------------------------------------------------------------------------------ boxes
+def test_box_rests_and_slides_on_the_plane(tmp_path):
+    """A free box on the world plane: four corner contacts carry it at rest (penetration of the soft contacts: a fraction
+    of a millimetre), and sliding it decelerates at mu g on average (pyramidal cone along an axis)."""
+    body = """<geom name="floor" type="plane" pos="0 0 0" size="5 5 0.1" contype="1" conaffinity="1" friction="0.5 0.005 0.0001" condim="3"/>
+    <body name="box" pos="0 0 0.0501"><freejoint/>
+      <geom name="b" type="box" size="0.1 0.08 0.05" density="800" contype="1" conaffinity="1" friction="0.5 0.005 0.0001" condim="3"/>
+      <site name="finger"/></body>"""
+    raw, ref = _model(tmp_path, body)
+    q, v = ref.qpos0.copy(), np.zeros(6)
+    for _ in range(500):
+        q, v, _, diag = ref.step(q, v, np.zeros(0))
+    assert diag[0] == 16                                        # 4 corners x 4 pyramid rows
+    assert 0.0495 < q[2] < 0.0501 and np.abs(v).max() < 1e-6
+    np.testing.assert_allclose(q[3:7], [1, 0, 0, 0], atol=1e-9)
+    v = np.array([1.5, 0, 0, 0, 0, 0])
+    v0 = []
+    for _ in range(100):
+        q, v, _, _ = ref.step(q, v, np.zeros(0))
+        v0.append(v[0])
+    dec = (v0[0] - v0[-1]) / (99 * 0.002)
+    assert abs(dec - 0.5 * 9.81) < 0.08 * 0.5 * 9.81, dec       # (soft pyramid rows: a few per cent under mu g; the box pitches)
+
+
+def test_sphere_rests_on_a_static_box(tmp_path):
+    """Sphere / box contact against a STATIC geom of the world body: a ball dropped on a block (turned about the vertical)
+    settles on its top face; dropped just past an edge it touches the edge's nearest point - the normal is diagonal - and
+    is pushed off sideways."""
+    body = """<geom name="block" type="box" pos="0 0 0.2" size="0.2 0.2 0.05" euler="0 0 0.5" friction="1.5 0.005 0.0001" condim="3"/>
+    <body name="ball" pos="%s 0 0.32"><freejoint/>
+      <geom name="s" type="sphere" size="0.05" density="1000" friction="1.5 0.005 0.0001" condim="3"/><site name="finger"/></body>"""
+    extra = '<contact><pair geom1="s" geom2="block"/></contact>'
+    raw, ref = _model(tmp_path, body % "0.05", extra=extra)
+    q, v = ref.qpos0.copy(), np.zeros(6)
+    for _ in range(800):
+        q, v, _, diag = ref.step(q, v, np.zeros(0))
+    assert diag[0] == 4 and -1e-3 < q[2] - 0.30 < 1e-5 and np.abs(v).max() < 1e-5 and abs(q[0] - 0.05) < 1e-6
+    # past the edge: in the block's frame the ball sits 0.02 m beyond the +x face, centre above the top face
+    c, s_ = np.cos(0.5), np.sin(0.5)
+    raw, ref = _model(tmp_path, (body % ("%.17g" % (0.22 * c))).replace('pos="%.17g 0 0.32"' % (0.22 * c), 'pos="%.17g %.17g 0.32"' % (0.22 * c, 0.22 * s_)),
+                      extra=extra, name="edge.xml")
+    q, v = ref.qpos0.copy(), np.zeros(6)
+    hit = False
+    for _ in range(300):
+        q, v, _, diag = ref.step(q, v, np.zeros(0))
+        hit = hit or diag[0] > 0
+    out = np.array([c, s_, 0.0])                                # the face's outward direction
+    assert hit and v[:3] @ out > 0.05 and q[2] < 0.28           # pushed off along the face normal, and falling
+    assert abs(v[:3] @ np.array([-s_, c, 0.0])) < 0.02 * (v[:3] @ out)     # (next to) nothing along the edge: the friction
+                                                                           # pyramid's axes are not the edge's
+
+
+# ------------------------------------------------------------------------------------------ equalities, tendon
+def test_fourbar_loop_stays_closed_and_the_tendon_limit_holds():
+    raw = synthetic_raw("fourbar")
+    ref = RefArm(raw.to_flat())
+    q, v = ref.qpos0.copy(), np.zeros(6)
+    tip0 = np.array([0.4, 0, 0.4])                              # the rocker's tip at qpos0: pinned there
+    worst, tmax = 0.0, 0.0
+
+    def tip(q):
+        a0, a1, a2 = q[0], q[0] + q[1], q[0] + q[1] + q[2]
+        # planar chain about y: crank 0.2 up, coupler 0.4 along x, rocker 0.3 down
+        rot = lambda a, vec: np.array([np.cos(a) * vec[0] + np.sin(a) * vec[2], 0, -np.sin(a) * vec[0] + np.cos(a) * vec[2]])
+        return np.array([0, 0, 0.5]) + rot(a0, [0, 0, 0.2]) + rot(a1, [0.4, 0, 0]) + rot(a2, [0, 0, -0.3])
+
+    np.testing.assert_allclose(tip(q), tip0, atol=1e-12)
+    for k in range(1500):
+        u = np.array([0.1 if k < 700 else -0.1])
+        q, v, _, diag = ref.step(q, v, u)
+        worst = max(worst, np.linalg.norm(tip(q) - tip0))
+        tmax = max(tmax, abs(q[0] + 0.5 * q[1]))
+    assert worst < 3e-3, worst                                  # the soft constraint's violation (the crank reaches 10 rad/s)
+    assert abs(q[0]) > 0.2                                      # the linkage did move
+    assert 0.6 < tmax < 0.6 + 0.015, tmax                       # tendon length j0 + 0.5 j1 limited to +-0.6: reached, held
+    assert ref.newton_stats()["fails"] == 0
+
+
+def test_door_latch_follows_the_handle_and_holds_the_door():
+    raw = synthetic_raw("door")
+    ref = RefArm(raw.to_flat())
+    q, v = ref.qpos0.copy(), np.zeros(3)
+    # handle at rest, bolt out: pushing the door (1 N m against 0.3 N m of hinge friction) leaves it latched against the strike
+    for _ in range(400):
+        q, v, _, diag = ref.step(q, v, np.array([0.0, 0.25]))
+    assert q[0] < 0.01 and diag[0] >= 6, (q, diag[0])          # equality + hinge friction + the bolt on the strike (4 rows)
+    # turn the handle (servo to 1.05 rad): the joint equality retracts the bolt; the same push now opens the door
+    worst = 0.0
+    for _ in range(900):
+        q, v, _, diag = ref.step(q, v, np.array([1.05, 0.25]))
+        worst = max(worst, abs(q[2] + 0.02865 * q[1]))
+    assert worst < 4e-3, worst                                  # (the bolt is dragged along the strike while it retracts)
+    assert abs(q[2] + 0.02865 * q[1]) < 5e-4
+    assert q[1] > 0.7 and q[2] < -0.02 and q[0] > 0.3, q
+    assert ref.newton_stats()["fails"] == 0
+
+
+# ------------------------------------------------------------------------------------------ loader and compilers
+def test_degrees_and_radians_load_the_same_model(tmp_path):
+    body_deg = """<body name="a" pos="0 0 1" euler="0 30 0"><joint name="j" type="hinge" axis="0 1 0" limited="true" range="-45 90" springref="10" stiffness="1"/>
+      <geom type="capsule" size="0.02 0.1" axisangle="1 0 0 90" density="500"/><site name="finger"/></body>"""
+    body_rad = body_deg.replace('euler="0 30 0"', 'euler="0 %.17g 0"' % np.deg2rad(30)).replace('range="-45 90"', 'range="%.17g %.17g"' % (np.deg2rad(-45), np.deg2rad(90))) \
+        .replace('springref="10"', 'springref="%.17g"' % np.deg2rad(10)).replace('axisangle="1 0 0 90"', 'axisangle="1 0 0 %.17g"' % np.deg2rad(90))
+    rd, _ = _model(tmp_path, body_deg, name="deg.xml", head=HEAD.replace("radian", "degree"))
+    rr, _ = _model(tmp_path, body_rad, name="rad.xml")
+    np.testing.assert_allclose(rd.to_flat(), rr.to_flat(), rtol=0, atol=1e-15)
+    assert abs(rd.bodies[0].joint.range[1] - np.pi / 2) < 1e-15
+
+
+def test_loader_refuses_what_is_not_modelled(tmp_path):
+    for body, extra, msg in [
+        ('<body name="a"><joint type="ball" limited="true" range="0 1"/><geom type="sphere" size="0.1"/><site name="finger"/></body>', "", "ball"),
+        ('<body name="a"><joint/><geom type="cylinder" size="0.1 0.1"/><site name="finger"/></body>', "", "geom type"),
+        ('<body name="a"><joint name="j"/><geom type="sphere" size="0.1"/><site name="finger"/></body>',
+         '<equality><weld body1="a"/></equality>', "weld"),
+        ('<body name="a"><joint name="j"/><geom type="sphere" size="0.1"/><site name="finger"/></body>',
+         '<tendon><spatial/></tendon>', "fixed tendons"),
+    ]:
+        with pytest.raises(ValueError, match=msg):
+            _model(tmp_path, body, extra=extra, name="bad.xml")
+    # box against box / capsule: derived from the masks -> refused with advice; a box against the plane and spheres is fine
+    body = """<body name="a"><freejoint/><geom name="x" type="box" size="0.1 0.1 0.1" contype="1" conaffinity="1"/><site name="finger"/></body>
+    <body name="b" pos="1 0 0"><freejoint/><geom name="y" type="capsule" size="0.1 0.1" contype="1" conaffinity="1"/></body>"""
+    with pytest.raises(ValueError, match="box only collides"):
+        _model(tmp_path, body, name="bb.xml")
+
+
+@pytest.mark.parametrize("name", sorted(FRAME_SKIP))
+def test_two_compilers_agree_on_the_synthetic_models(name):
+    """The oracle's C model compile and the host compiler for the kernel: masses, inertias, dof / body invweight0 (with
+    MuJoCo's averaging over ball and free joints), qpos0, dimensions."""
+    raw = synthetic_raw(name)
+    m, ref = compile_tree(raw), RefArm(raw.to_flat())
+    assert m.general and (ref.nv, ref.nq, ref.d_obs) == (m.nv, m.nq, m.d_obs)
+    mass, ipos, inertia = ref.inertial()
+    np.testing.assert_allclose(mass[1:], m.body_mass, rtol=1e-13)
+    np.testing.assert_allclose(inertia[1:], m.body_inertia, rtol=0, atol=1e-13)
+    d, b = ref.invweight0()
+    np.testing.assert_allclose(d, m.dof_invweight0, rtol=1e-10)
+    np.testing.assert_allclose(b[1:], m.body_invweight0, rtol=1e-10, atol=1e-14)
+    np.testing.assert_allclose(ref.qpos0, m.qpos0, rtol=0, atol=1e-15)
+    st = start_state(name, raw)
+    assert st["qp"].shape == (m.nq,) and st["qv"].shape == (m.nv,)
