@@ -309,6 +309,35 @@ int mjmpc_cem_final(const double* d_cov_records, int G, int64_t P, int H, int A,
 int mjmpc_cem_combine(const double* d_records, int G, int H, int A, double n_elite, int full_cov, double step_size,
                       double* d_mean, double* d_cov, void* stream);
 
+/* The fused CEM step (round 4; cem.py:65-95 in two launches beside the rollout instead of nine):
+ *   mjmpc_cem_select_moments  the elite threshold (k-th smallest q0, ties by particle index, exactly as
+ *       mjmpc_cem_elite_sums), the elite list, and per workgroup {rows, sum of elite action rows, scatter of their deltas
+ *       about a provisional centre} - every workgroup repeats the selection and takes a slice of the elite rows; it also
+ *       snapshots mean, cov and *d_step_counter for the finish launch.  q0 is read from d_ws (mjmpc_workspace_q0) or,
+ *       sharded, from the gathered d_q_all [P_all] with this GPU's block at `offset`;
+ *   mjmpc_cem_record          (sharded runs) the partials -> this GPU's record {n | sum a [H*A] | scatter about its own
+ *       mean [A*A]}, the layout mjmpc_cem_combine pools; all-gather it;
+ *   mjmpc_cem_finish          d_records == NULL: one GPU, the partials in d_ws; else the G gathered records.  New mean and
+ *       covariance (np.var ddof 0 / np.cov ddof 1 over the H k elite deltas, step-size blend), cov += grow_scale *
+ *       diag(d_grow_diag) (CEM._shift, cem.py:94; NULL: identity), its lower Cholesky factor -> d_chol (may be NULL;
+ *       positive semi-definite input as mjmpc_cholesky_lower, *d_status = 1 if indefinite), the action (row 0 of the new
+ *       mean) -> d_action_out / h_action_pinned (mapped pinned, may be NULL), the horizon shift (0 'null', 1 'repeat',
+ *       < 0 none), *d_step_counter = snapshot + 1, and - d_next_noise != NULL - the RAW Philox samples of the next
+ *       control step, [P][H][A] of dtype, coloured by the new factor: the stream of mjmpc_sample_noise(..., filter NULL,
+ *       seed, offset, particle_offset, d_step_counter), sample for sample.
+ * mjmpc_cem_fused_supported: A <= 8, A <= H + 1, P_all <= 32768, the moment tiles fit the workspace (else use the
+ * separate entries above).  Same workspace for the three calls; d_mean / d_cov as given to the first. */
+int mjmpc_cem_fused_supported(int64_t P_all, int64_t P, int64_t k, int H, int A);
+int mjmpc_cem_select_moments(int dtype, int64_t P, int H, int A, const void* d_actions, const double* d_q_all, int64_t P_all,
+                             int64_t offset, int64_t k, const double* d_mean, const double* d_cov,
+                             const int64_t* d_step_counter, void* d_ws, void* stream);
+int mjmpc_cem_record(int64_t P, int H, int A, int64_t k, const double* d_mean, double* d_record, void* d_ws, void* stream);
+int mjmpc_cem_finish(int dtype, int64_t P, int H, int A, int64_t k, const double* d_records, int G, double n_elite,
+                     int full_cov, double step_size, int shift_mode, double* d_mean, double* d_cov, double* d_chol,
+                     int* d_status, const double* d_grow_diag, double grow_scale, double* d_action_out,
+                     double* h_action_pinned, int64_t* d_step_counter, void* d_next_noise, uint64_t seed, uint64_t offset,
+                     int64_t particle_offset, void* d_ws, void* stream);
+
 /* RandomShooting._update_distribution (mjmpc/control/random_shooting.py:52-62). */
 int mjmpc_rs_best(int dtype, int64_t P, int H, int A, const void* d_actions, int64_t offset, double* d_record,
                   void* d_ws, void* stream);

@@ -64,6 +64,11 @@ SIGNATURES = {
     "mjmpc_cem_elite_cov": (_int, [_int, _i64, _int, _int, _vp, _vp, _vp, _int, _vp, _vp, _vp]),
     "mjmpc_cem_final": (_int, [_vp, _int, _i64, _int, _int, _dbl, _int, _dbl, _vp, _vp, _vp, _vp]),
     "mjmpc_cem_combine": (_int, [_vp, _int, _int, _int, _dbl, _int, _dbl, _vp, _vp, _vp]),
+    "mjmpc_cem_fused_supported": (_int, [_i64, _i64, _i64, _int, _int]),
+    "mjmpc_cem_select_moments": (_int, [_int, _i64, _int, _int, _vp, _vp, _i64, _i64, _i64, _vp, _vp, _vp, _vp, _vp]),
+    "mjmpc_cem_record": (_int, [_i64, _int, _int, _i64, _vp, _vp, _vp, _vp]),
+    "mjmpc_cem_finish": (_int, [_int, _i64, _int, _int, _i64, _vp, _int, _dbl, _int, _dbl, _int, _vp, _vp, _vp, _vp, _vp, _dbl,
+                                _vp, _vp, _vp, _vp, ctypes.c_uint64, ctypes.c_uint64, _i64, _vp, _vp]),
     "mjmpc_rs_best": (_int, [_int, _i64, _int, _int, _vp, _i64, _vp, _vp, _vp]),
     "mjmpc_rs_combine": (_int, [_vp, _int, _int, _int, _dbl, _vp, _vp]),
     "mjmpc_mppi_fused_update": (_int, [_int, _i64, _int, _int, _vp, _vp, _dbl, _dbl, _int, _vp, _vp, _vp, _vp, _vp, _vp,

@@ -273,6 +273,41 @@ class DeviceUpdater:
         _lib.check(self.lib.mjmpc_cem_combine(_vp(recs), G, self.H, self.A, float(num_elite), int(full_cov),
                                               float(step_size), _vp(self.mean), _vp(self.cov), self.stream()))
 
+    def cem_fused_supported(self, P, num_elite):
+        """The two-launch CEM step (``cem_fused_step``) covers this shape (A <= 8, P x world <= 32768, ...)."""
+        return bool(self.lib.mjmpc_cem_fused_supported(P * self.comm.world_size, P, int(num_elite), self.H, self.A))
+
+    def cem_fused_step(self, actions, num_elite, step_size, full_cov, shift_mode, action_out, action_pinned, step_counter,
+                       grow, next_noise, seed, particle_offset):
+        """One CEM update + the tail of the control step in two launches (three and two exchanges when sharded):
+        selection + elite list + moments (``mjmpc_cem_select_moments``; q0 is where the rollout launch left it), then refit +
+        covariance growth + Cholesky factor + action + shift + step counter + the NEXT step's raw samples into
+        ``next_noise`` (``mjmpc_cem_finish``).  ``grow`` = (diag tensor or None, scale) or None (cem.py:94)."""
+        P = actions.shape[0]
+        ws = self.workspace(P)
+        code = self.code(actions)
+        G, rank = self.comm.world_size, self.comm.rank
+        q_all_ptr, P_all = None, P
+        if G > 1 or getattr(self.comm, "always_collective", False):
+            q_all = self.comm.all_gather_flat(self._q0_view(ws, P))
+            q_all_ptr, P_all = _vp(q_all), P * G
+        _lib.check(self.lib.mjmpc_cem_select_moments(code, P, self.H, self.A, _vp(actions), q_all_ptr, P_all, rank * P,
+                                                     int(num_elite), _vp(self.mean), _vp(self.cov), _vp(step_counter),
+                                                     _vp(ws), self.stream()))
+        recs_ptr, n_rec = None, 1
+        if q_all_ptr is not None:
+            rec = self.record("cem_rec", 1 + self.H * self.A + self.A * self.A)
+            _lib.check(self.lib.mjmpc_cem_record(P, self.H, self.A, int(num_elite), _vp(self.mean), _vp(rec), _vp(ws), self.stream()))
+            recs = self.comm.all_gather(rec)
+            recs_ptr, n_rec = _vp(recs), recs.shape[0]
+        gd, gs = (None, 0.0) if grow is None else (self._cov_diag(grow[0]), grow[1])
+        chol = self.record("chol", self.A * self.A)
+        _lib.check(self.lib.mjmpc_cem_finish(code, P, self.H, self.A, int(num_elite), recs_ptr, n_rec, float(num_elite),
+                                             int(full_cov), float(step_size), int(shift_mode), _vp(self.mean), _vp(self.cov),
+                                             _vp(chol), _vp(self.chol_status), _vp(gd), float(gs), _vp(action_out),
+                                             _vp(action_pinned), _vp(step_counter), _vp(next_noise),
+                                             int(seed) & (2 ** 64 - 1), 0, int(particle_offset), _vp(ws), self.stream()))
+
     def check_status(self):
         """Raise if a sampler kernel has flagged an error: an indefinite covariance would otherwise turn into NaN
         samples, mean and action without a word, and a short MT19937 stream would leave stale samples behind.  The kernels

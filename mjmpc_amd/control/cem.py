@@ -23,6 +23,14 @@ class CEM(OLGaussianMPC):
     def _wants_q0(self):
         return True
 
+    def _cem_fused(self):
+        """The two-launch CEM step (``DeviceUpdater.cem_fused_step``): a captured / device-resident iteration with the
+        Philox sampler, one iteration per step, a rollout launch that emits q0 and filters raw samples."""
+        return (self._graph_on and getattr(self, "_want_cem_fused", True) and self.noise_mode == 'device' and self.n_iters == 1
+                and hasattr(self._rollout_fn, "fused") and not self.dev.gamma_zero and not self.use_zero_control_seq
+                and self.cov_type in ('diagonal', 'full') and self.num_elite >= 1
+                and self.dev.cem_fused_supported(self.local_particles, self.num_elite))
+
     def _device_update(self, trajectories):
         self.dev.cem_update(trajectories["costs"], trajectories["actions"], self.num_elite, self.step_size,
                             self.cov_type == 'full', q0=trajectories.get("q0"))

@@ -410,7 +410,11 @@ class OLGaussianMPC(Controller):
 
     def _noise_ahead(self):
         """Captured fused iterations with the Philox sampler draw the next step's samples inside the update."""
-        return (not self._mono) and self._graph_on and self.noise_mode == 'device' and self._fused_capable()
+        return ((not self._mono) and self._graph_on and self.noise_mode == 'device'
+                and (self._fused_capable() or self._cem_fused()))
+
+    def _cem_fused(self):
+        return False            # CEM overrides: selection + moments and refit + tail + next samples, two launches
 
     def _mono_capable(self):
         """The whole iteration in one launch (``rollout_fn.mono``): the fused MPPI / DMD-MPC update, the Philox sampler,
@@ -461,6 +465,21 @@ class OLGaussianMPC(Controller):
                                            self._action_dev if last else None,
                                            self._action_pin if last else None, self._step_dev if last else None,
                                            draw_next=nxt)
+            if self._graph_post is not None:
+                self._graph_post(self._action_dev)
+            return
+        if self._cem_fused():
+            # CEM (cem.py:65-95) beside the rollout in TWO launches: selection + elite list + moments, then refit + covariance
+            # growth + Cholesky factor + action + shift + step counter + the raw samples of the NEXT step, drawn with the new
+            # factor into the buffer this step's rollout has finished reading
+            raw = self.dev._rec[("noise", self.noise_dtype)]
+            costs, actions, q0 = self._rollout_fn.fused(n_loc, self.horizon, self.dev.mean, raw, self.dev.record("coeffs", 3),
+                                                        self.dev.gseq, **self._q0_kw(n_loc))
+            if self._q0_kw(n_loc) == {}:
+                self.dev._take_q0(self.dev.workspace(n_loc), n_loc, q0)
+            self.dev.cem_fused_step(actions, self.num_elite, self.step_size, self.cov_type == 'full',
+                                    _SHIFT_MODES[self.base_action], self._action_dev, self._action_pin, self._step_dev,
+                                    self._shift_cov_args(), raw, self.seed_val, self.dev.comm.rank * n_loc)
             if self._graph_post is not None:
                 self._graph_post(self._action_dev)
             return

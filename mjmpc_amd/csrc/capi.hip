@@ -941,6 +941,50 @@ int mjmpc_cem_combine(const double* d_records, int G, int H, int A, double n_eli
     PLAIN(mjmpc::cem_combine(d_records, G, H, A, n_elite, full_cov, step_size, d_mean, d_cov, (hipStream_t)stream));
 }
 
+int mjmpc_cem_fused_supported(int64_t P_all, int64_t P, int64_t k, int H, int A) {
+    return mjmpc::cem_fused_supported((long)P_all, (long)P, (long)k, H, A) ? 1 : 0;
+}
+
+int mjmpc_cem_select_moments(int dtype, int64_t P, int H, int A, const void* d_actions, const double* d_q_all, int64_t P_all,
+                             int64_t offset, int64_t k, const double* d_mean, const double* d_cov,
+                             const int64_t* d_step_counter, void* d_ws, void* stream) {
+    if (!d_actions || !d_mean || !d_cov || !d_ws) return fail(MJMPC_E_BADARG, "null argument");
+    if (!mjmpc::cem_fused_supported(d_q_all ? (long)P_all : (long)P, (long)P, (long)k, H, A))
+        return fail(MJMPC_E_BADARG, "shape outside the fused CEM step (mjmpc_cem_fused_supported)");
+    hipStream_t s = (hipStream_t)stream;
+    DISPATCH(dtype,
+             mjmpc::cem_select_moments<float>((const float*)d_actions, d_q_all, (long)P_all, (long)offset, (long)k, (long)P, H, A,
+                                              d_mean, d_cov, (const long long*)d_step_counter, (double*)d_ws, s),
+             mjmpc::cem_select_moments<double>((const double*)d_actions, d_q_all, (long)P_all, (long)offset, (long)k, (long)P, H,
+                                               A, d_mean, d_cov, (const long long*)d_step_counter, (double*)d_ws, s));
+}
+
+int mjmpc_cem_record(int64_t P, int H, int A, int64_t k, const double* d_mean, double* d_record, void* d_ws, void* stream) {
+    if (!d_mean || !d_record || !d_ws) return fail(MJMPC_E_BADARG, "null argument");
+    PLAIN(mjmpc::cem_record((long)k, (long)P, H, A, d_mean, d_record, (double*)d_ws, (hipStream_t)stream));
+}
+
+int mjmpc_cem_finish(int dtype, int64_t P, int H, int A, int64_t k, const double* d_records, int G, double n_elite,
+                     int full_cov, double step_size, int shift_mode, double* d_mean, double* d_cov, double* d_chol,
+                     int* d_status, const double* d_grow_diag, double grow_scale, double* d_action_out,
+                     double* h_action_pinned, int64_t* d_step_counter, void* d_next_noise, uint64_t seed, uint64_t offset,
+                     int64_t particle_offset, void* d_ws, void* stream) {
+    if (!d_mean || !d_cov || !d_ws) return fail(MJMPC_E_BADARG, "null argument");
+    if (shift_mode > 1) return fail(MJMPC_E_BADARG, "shift_mode must be < 0 (none), 0 (null) or 1 (repeat)");
+    if (!mjmpc::cem_fused_supported((long)P, (long)P, (long)k, H, A))
+        return fail(MJMPC_E_BADARG, "shape outside the fused CEM step (mjmpc_cem_fused_supported)");
+    hipStream_t s = (hipStream_t)stream;
+    DISPATCH(dtype,
+             mjmpc::cem_finish<float>(d_records, G, (long)k, (long)P, H, A, n_elite, full_cov, step_size, shift_mode, d_mean, d_cov,
+                                      d_chol, d_status, d_grow_diag, grow_scale, d_action_out, h_action_pinned,
+                                      (long long*)d_step_counter, (float*)d_next_noise, seed, offset, (long)particle_offset,
+                                      (double*)d_ws, s),
+             mjmpc::cem_finish<double>(d_records, G, (long)k, (long)P, H, A, n_elite, full_cov, step_size, shift_mode, d_mean, d_cov,
+                                       d_chol, d_status, d_grow_diag, grow_scale, d_action_out, h_action_pinned,
+                                       (long long*)d_step_counter, (double*)d_next_noise, seed, offset, (long)particle_offset,
+                                       (double*)d_ws, s));
+}
+
 int mjmpc_rs_best(int dtype, int64_t P, int H, int A, const void* d_actions, int64_t offset, double* d_record,
                   void* d_ws, void* stream) {
     if (!d_actions || !d_record || !d_ws) return fail(MJMPC_E_BADARG, "null argument");

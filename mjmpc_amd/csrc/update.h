@@ -43,6 +43,21 @@ hipError_t cem_final(const double* crecords, int G, long P, int H, int A, double
 hipError_t cem_combine(const double* records, int G, int H, int A, double n_elite, int full, double step, double* mean,
                        double* cov, hipStream_t s);
 
+// The fused CEM step (round 4): selection + elite list + moments in ONE launch (every workgroup repeats the selection and
+// takes a slice of the elite rows), then - sharded runs only - this GPU's record for the gather, then ONE finish launch
+// (refit, covariance growth, Cholesky factor, action, shift, step counter, the next step's raw samples).
+bool cem_fused_supported(long P_all, long P, long k, int H, int A);
+template <typename T>
+hipError_t cem_select_moments(const T* actions, const double* q_all, long P_all, long offset, long k, long P, int H, int A,
+                              const double* mean, const double* cov, const long long* d_step, double* ws, hipStream_t s);
+hipError_t cem_record(long k, long P, int H, int A, const double* mean, double* record, double* ws, hipStream_t s);
+// records == nullptr: one GPU, the partials in the workspace; else G gathered records.  noise == nullptr: no draw.
+template <typename T>
+hipError_t cem_finish(const double* records, int G, long k, long P, int H, int A, double n_elite, int full, double step,
+                      int shift_mode, double* mean, double* cov, double* chol, int* status, const double* grow_diag,
+                      double grow_scale, double* action_out, double* action_host, long long* step_counter, T* noise,
+                      unsigned long long seed, unsigned long long offset, long particle_offset, double* ws, hipStream_t s);
+
 // Random shooting: {min q0, global index, action[H*A]} record and the combine.
 template <typename T>
 hipError_t rs_best(const T* actions, long offset, long P, int H, int A, double* record, double* ws, hipStream_t s);

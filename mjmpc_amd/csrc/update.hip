@@ -265,11 +265,31 @@ __device__ __forceinline__ unsigned long long order_key(double q) {
 // population share sign, exponent and often more) and the 8-bit digit windows count down from the first differing bit; once the bucket that holds the rank has at most KTH_CAND keys
 // they are ranked against each other directly in (key, index) order - which also settles ties exactly, so the
 // barrier-per-round tie walk only runs when more than KTH_CAND particles hold the k-th key itself.
+constexpr int NOISE_MAXA_U = 8;     // as noise.hip's NOISE_MAXA: action channels the in-register sampler unrolls to
 constexpr int KTH_CAND = 32;        // (the ranking is a loop of dependent LDS reads: 256 candidates cost more than a pass)
-template <int NPER>
+// Round 4, MOM = true (cem_select_moments): the SAME selection run redundantly by every workgroup of a grid - the keys are
+// 128 KB that every CU reads from L2, the selection is a few dozen barriers of one workgroup either way - so that each
+// workgroup knows the elite list and goes straight on to the moments of ITS slice of it (E elite rows): the sum of the
+// rows and their scatter about a PROVISIONAL centre (the mean of the first CEM_HEAD elite rows, which every workgroup
+// forms alike) - the shifted-data form of the two-pass np.cov: cem_finish subtracts N (mu - c)(mu - c)' with mu - c a
+// fraction of a standard deviation, so nothing cancels.  One launch replaces selection, list, row sums, their reduction,
+// the mean, and the scatter pass.  Workgroup 0 also snapshots what the finish launch must read unmodified while it
+// rewrites it (mean, covariance, step counter).
+constexpr int CEM_HEAD = 64, CEM_E_MAX = 64;
+template <typename TA>
+struct CemMoments {
+    const TA* actions;
+    const double *mean, *cov;
+    const long long* d_step;
+    double *partial, *cprime, *mean_prev, *cov_prev;
+    long long* step_prev;
+    int H, A, E;
+};
+template <int NPER, typename TA = double, bool MOM = false>
 __global__ __launch_bounds__(1024) void kth_key_kernel(const double* __restrict__ q_all, long P_all, long k,
                                                        unsigned long long* __restrict__ thr, long offset, long P_local,
-                                                       int* __restrict__ list, int* __restrict__ count) {
+                                                       int* __restrict__ list, int* __restrict__ count,
+                                                       CemMoments<TA> mo = CemMoments<TA>()) {
     __shared__ unsigned hist[256];
     __shared__ unsigned long long prefix_s, red_and[16], red_or[16], cand_key[KTH_CAND];
     __shared__ long need_s, cut_s, sel_need, wtot[16], scan_v[256], cand_idx[KTH_CAND];
@@ -433,7 +453,7 @@ __global__ __launch_bounds__(1024) void kth_key_kernel(const double* __restrict_
         seen += n;
         __syncthreads();
     }
-    if (tid == 0) { thr[0] = T; thr[1] = 0ull; thr[2] = (unsigned long long)(cut_s < 0 ? P_all : cut_s); }
+    if (tid == 0 && (!MOM || blockIdx.x == 0)) { thr[0] = T; thr[1] = 0ull; thr[2] = (unsigned long long)(cut_s < 0 ? P_all : cut_s); }
     // With the keys in registers the elite LIST of the local block [offset, offset + P_local) follows at once (what
     // elite_list_kernel does from memory for the streamed instantiation): ballots per round, one scan of their counts.
     if constexpr (NPER > 0) {
@@ -468,13 +488,80 @@ __global__ __launch_bounds__(1024) void kth_key_kernel(const double* __restrict_
         }
         if (tid < n) lcnt[tid] = at;
         __syncthreads();
+        __shared__ int head[CEM_HEAD], mine[CEM_E_MAX];
 #pragma unroll
         for (int r = 0; r < NPER; ++r) {
             const bool e = (flags >> r) & 1u;
             const unsigned long long m = __ballot(e);
-            if (e) list[lcnt[r * 16 + wave] + __popcll(m & ((1ull << lane) - 1ull))] = (int)((long)r * 1024 + tid - offset);
+            if (e) {
+                const int pos = lcnt[r * 16 + wave] + __popcll(m & ((1ull << lane) - 1ull));
+                const int idx = (int)((long)r * 1024 + tid - offset);
+                if (!MOM || blockIdx.x == 0) list[pos] = idx;
+                if constexpr (MOM) {
+                    if (pos < CEM_HEAD) head[pos] = idx;
+                    const int rel = pos - (int)blockIdx.x * mo.E;
+                    if (rel >= 0 && rel < mo.E) mine[rel] = idx;
+                }
+            }
         }
-        if (tid == 0) *count = total;
+        if (tid == 0 && (!MOM || blockIdx.x == 0)) *count = total;
+        if constexpr (MOM) {
+            extern __shared__ double dyn[];         // tile[E * HA] | red[S * AA] | cdiff[HA] | cprime[A]
+            const int H = mo.H, A = mo.A, HA = H * A, AA = A * A, E = mo.E;
+            double* tile = dyn;
+            double* red = tile + E * HA;
+            double* cdiff = red + (1024 / AA) * AA;
+            double* cpr = cdiff + HA;
+            __syncthreads();
+            const int n = total, e0 = (int)blockIdx.x * E;
+            const int ne = n - e0 < 0 ? 0 : (n - e0 < E ? n - e0 : E);
+            const int nh = n < CEM_HEAD ? n : CEM_HEAD;
+            // the provisional centre: mean of the first elite rows (every workgroup alike), as a mean DELTA per channel
+            for (int j = tid; j < HA; j += 1024) {
+                double c = 0.0;
+                for (int e = 0; e < nh; ++e) c += (double)mo.actions[(long)head[e] * HA + j];
+                cdiff[j] = (nh > 0 ? c / (double)nh : 0.0) - mo.mean[j];
+            }
+            __syncthreads();
+            if (tid < A) {
+                double c = 0.0;
+                for (int t = 0; t < H; ++t) c += cdiff[t * A + tid];
+                cpr[tid] = c / (double)H;
+                if (blockIdx.x == 0) mo.cprime[tid] = cpr[tid];
+            }
+            if (blockIdx.x == 0) {      // what cem_finish reads while it rewrites mean / cov / the step counter
+                for (int j = tid; j < HA; j += 1024) mo.mean_prev[j] = mo.mean[j];
+                for (int j = tid; j < AA; j += 1024) mo.cov_prev[j] = mo.cov[j];
+                if (tid == 0) *mo.step_prev = mo.d_step ? *mo.d_step : 0ll;
+            }
+            __syncthreads();
+            double* out = mo.partial + (long)blockIdx.x * (1 + HA + AA);
+            if (tid == 0) out[0] = (double)ne;
+            // my rows: staged once (deltas about the mean and the provisional centre), summed per entry, scattered
+            for (int w = tid; w < ne * HA; w += 1024) {
+                const int e = w / HA, j = w - e * HA;
+                tile[w] = (double)mo.actions[(long)mine[e] * HA + j] - mo.mean[j] - cpr[j % A];
+            }
+            __syncthreads();
+            for (int j = tid; j < HA; j += 1024) {          // sum of the action rows = sum of deltas + ne (mean + c)
+                double sacc = 0.0;
+                for (int e = 0; e < ne; ++e) sacc += tile[e * HA + j];
+                out[1 + j] = sacc + (double)ne * (mo.mean[j] + cpr[j % A]);
+            }
+            const int S = 1024 / AA, rows = ne * H;
+            if (tid < S * AA) {
+                const int sl = tid / AA, idx = tid - sl * AA, i = idx / A, kk = idx - i * A;
+                double sacc = 0.0;
+                for (int r = sl; r < rows; r += S) sacc += tile[r * A + i] * tile[r * A + kk];
+                red[tid] = sacc;
+            }
+            __syncthreads();
+            if (tid < AA) {
+                double sacc = 0.0;
+                for (int sl = 0; sl < S; ++sl) sacc += red[sl * AA + tid];
+                out[1 + HA + tid] = sacc;
+            }
+        }
     }
 }
 
@@ -702,6 +789,210 @@ __global__ void cem_combine_kernel(const double* __restrict__ rec, int G, int H,
         double e = 0.0;
         for (int g = 0; g < G; ++g) e += rec[(long)g * R + 1 + j];
         mean[j] = (1.0 - step) * mean[j] + step * (e / cnt);
+    }
+}
+
+// ---- the fused CEM step (round 4): cem_select_moments (above) -> [cem_record -> all-gather] -> cem_finish -----------------
+// cem_record (sharded runs): the workgroups' partials {n_b, sum a, scatter about the provisional centre c} -> THIS GPU's
+// record {n_g | sum a [H*A] | S_g [A*A]}, S_g the scatter about its OWN mean delta mu_g = what cem_combine_kernel pools:
+// S_g = S_c - (H n_g) (mu_g - c)(mu_g - c)'.  One workgroup.
+__global__ void cem_record_kernel(const double* __restrict__ partial, int NB, int H, int A, const double* __restrict__ mean,
+                                  const double* __restrict__ cprime, double* __restrict__ rec) {
+    extern __shared__ double sh[];          // sum[HA] | d[A]
+    const int HA = H * A, AA = A * A, R = 1 + HA + AA;
+    double cnt = 0.0;
+    for (int b = 0; b < NB; ++b) cnt += partial[(long)b * R];
+    for (int j = threadIdx.x; j < HA; j += blockDim.x) {
+        double sacc = 0.0;
+        for (int b = 0; b < NB; ++b) sacc += partial[(long)b * R + 1 + j];
+        sh[j] = sacc;
+        rec[1 + j] = sacc;
+    }
+    __syncthreads();
+    for (int a = threadIdx.x; a < A; a += blockDim.x) {
+        double sacc = 0.0;
+        for (int t = 0; t < H; ++t) sacc += sh[t * A + a] / cnt - mean[t * A + a];
+        sh[HA + a] = cnt > 0.0 ? sacc / (double)H - cprime[a] : 0.0;       // mu_g - c
+    }
+    __syncthreads();
+    for (int j = threadIdx.x; j < AA; j += blockDim.x) {
+        double C = 0.0;
+        for (int b = 0; b < NB; ++b) C += partial[(long)b * R + 1 + HA + j];
+        rec[1 + HA + j] = C - (double)H * cnt * sh[HA + j / A] * sh[HA + j % A];
+    }
+    if (threadIdx.x == 0) rec[0] = cnt;
+}
+
+// cem_finish: everything behind the moments in ONE launch - refit of mean and covariance (cem.py:76-86: np.var ddof 0 on
+// the diagonal / np.cov ddof 1), the covariance's growth of the shift (cem.py:94), its Cholesky factor, the action
+// (device copy + mapped host copy), the horizon shift, the step counter, and the raw Philox samples of the NEXT control
+// step drawn with the new factor (the sampler kernel's stream, sample for sample).  Every workgroup forms the new
+// covariance and its factor itself (a few KB of partials / records, A <= 8); workgroup 0 writes the state; all of them
+// then draw.  They read mean / cov / step counter from the snapshots the selection launch left, never from the
+// buffers workgroup 0 rewrites.  mode 0: `in` = NB partials about the provisional centre (one GPU); mode 1: `in` = G
+// gathered records about their own means (cem_combine_kernel's pooling).
+struct CemFinish {
+    const double *in, *cprime, *mean_prev, *cov_prev, *grow_diag;
+    const long long* step_prev;
+    double *mean, *cov, *chol, *action_out, *action_host;
+    long long* step_counter;
+    int* status;
+    void* noise;
+    int n_in, mode, H, A, full, shift_mode;
+    double n_elite, step, grow_scale;
+    unsigned long long seed, offset;
+    long particle_offset, P;
+};
+constexpr int CEM_FIN_THREADS = 256;
+template <typename T>
+__global__ __launch_bounds__(CEM_FIN_THREADS) void cem_finish_kernel(CemFinish f) {
+    extern __shared__ double sh[];          // sumA[HA] | mu[(G + 1) * A] | C[AA] | L[AA] | per-wave store tiles
+    const int H = f.H, A = f.A, HA = H * A, AA = A * A, R = 1 + HA + AA, G = f.n_in;
+    const int tid = threadIdx.x;
+    double* sumA = sh;
+    double* mu = sumA + HA;                 // mode 0: mu - c [A]; mode 1: mu_g [G][A], then mu [A]
+    double* Cn = mu + (G + 1) * A;
+    double* L = Cn + AA;
+    T* tiles = (T*)(L + AA);
+    double cnt = 0.0;
+    for (int g = 0; g < G; ++g) cnt += f.in[(long)g * R];
+    for (int j = tid; j < HA; j += CEM_FIN_THREADS) {
+        double sacc = 0.0;
+        for (int g = 0; g < G; ++g) sacc += f.in[(long)g * R + 1 + j];
+        sumA[j] = sacc;
+    }
+    __syncthreads();
+    if (f.mode == 0) {
+        for (int a = tid; a < A; a += CEM_FIN_THREADS) {
+            double sacc = 0.0;
+            for (int t = 0; t < H; ++t) sacc += sumA[t * A + a] / cnt - f.mean_prev[t * A + a];
+            mu[a] = cnt > 0.0 ? sacc / (double)H - f.cprime[a] : 0.0;
+        }
+    } else {
+        for (int idx = tid; idx < G * A; idx += CEM_FIN_THREADS) {
+            const int g = idx / A, a = idx % A;
+            const double* r = f.in + (long)g * R;
+            double sacc = 0.0;
+            for (int t = 0; t < H; ++t) sacc += r[1 + t * A + a] / r[0] - f.mean_prev[t * A + a];
+            mu[idx] = r[0] > 0.0 ? sacc / (double)H : 0.0;
+        }
+        for (int a = tid; a < A; a += CEM_FIN_THREADS) {
+            double sacc = 0.0;
+            for (int t = 0; t < H; ++t) sacc += sumA[t * A + a] / cnt - f.mean_prev[t * A + a];
+            mu[G * A + a] = sacc / (double)H;
+        }
+    }
+    __syncthreads();
+    for (int j = tid; j < AA; j += CEM_FIN_THREADS) {
+        const int i = j / A, k = j % A;
+        double C = 0.0;
+        for (int g = 0; g < G; ++g) {
+            const double* r = f.in + (long)g * R;
+            C += r[1 + HA + j];
+            if (f.mode == 1 && G > 1) C += (double)H * r[0] * (mu[g * A + i] - mu[G * A + i]) * (mu[g * A + k] - mu[G * A + k]);
+        }
+        if (f.mode == 0) C -= (double)H * cnt * mu[i] * mu[k];
+        const double N = (double)H * f.n_elite;
+        const double upd = f.full ? C / (N - 1.0) : (i == k ? C / N : 0.0);
+        double c = (1.0 - f.step) * f.cov_prev[j] + f.step * upd;
+        if (i == k) c += f.grow_scale * (f.grow_diag ? f.grow_diag[i] : 1.0);          // cem.py:94
+        Cn[j] = c;
+        L[j] = k <= i ? c : 0.0;
+    }
+    __syncthreads();
+    // Cholesky factor of the new covariance, as cholesky_kernel: positive SEMI-definite input gets a zero column
+    if (tid < 64) {
+        double tol = 0.0;
+        for (int k = 0; k < A; ++k) tol = fmax(tol, fabs(Cn[k * A + k]));
+        tol *= 1e-13;
+        const int i = tid;
+        for (int k = 0; k < A; ++k) {
+            const double d = L[k * A + k];
+            const bool dead = !(d > tol);
+            __builtin_amdgcn_wave_barrier();
+            if (i == k) {
+                if ((!(d >= -tol) || !(d == d)) && f.status && blockIdx.x == 0) *f.status = 1;
+                L[k * A + k] = dead ? 0.0 : sqrt(d);
+            }
+            __builtin_amdgcn_wave_barrier();
+            if (i > k && i < A) L[i * A + k] = dead ? 0.0 : L[i * A + k] / L[k * A + k];
+            __builtin_amdgcn_wave_barrier();
+            if (i > k && i < A) for (int j = k + 1; j <= i; ++j) L[i * A + j] -= L[i * A + k] * L[j * A + k];
+            __builtin_amdgcn_wave_barrier();
+        }
+    }
+    __syncthreads();
+    if (blockIdx.x == 0) {
+        for (int j = tid; j < AA; j += CEM_FIN_THREADS) { f.cov[j] = Cn[j]; if (f.chol) f.chol[j] = L[j]; }
+        // new mean, action, shift (olgaussian_mpc.py:69-78, 116-129)
+        for (int j = tid; j < HA; j += CEM_FIN_THREADS) sumA[j] = (1.0 - f.step) * f.mean_prev[j] + f.step * (sumA[j] / cnt);
+        __syncthreads();
+        if (tid < A) {
+            if (f.action_out) f.action_out[tid] = sumA[tid];
+            if (f.action_host) f.action_host[tid] = sumA[tid];
+        }
+        if (tid == 0 && f.step_counter) *f.step_counter = *f.step_prev + 1;
+        for (int j = tid; j < HA; j += CEM_FIN_THREADS) {
+            double v = sumA[j];
+            if (f.shift_mode >= 0) {
+                const int t = j / A, a = j % A;
+                if (t + 1 < H) v = sumA[j + A];
+                else v = f.shift_mode == 0 ? 0.0 : sumA[(H - 1) * A + a];
+            }
+            f.mean[j] = v;
+        }
+    }
+    if (!f.noise) return;
+    // the next step's raw samples: noise_full_kernel's work items (particle, t-quad), 64 per wavefront per trip, through a
+    // per-wavefront LDS tile so that full rows go out (H a multiple of 4)
+    const int H4 = (H + 3) / 4, lane = tid & 63, wave = tid >> 6;
+    const long items = f.P * H4, nwaves = (long)gridDim.x * (CEM_FIN_THREADS / 64);
+    const unsigned long long offset = f.offset + (unsigned long long)(*f.step_prev + 1);
+    const bool staged = (H & 3) == 0;
+    const int run = 4 * A, pad = run + 1;
+    T* tile = tiles + wave * 64 * (4 * NOISE_MAXA_U + 1);
+    T* noise = (T*)f.noise;
+    for (long base = ((long)blockIdx.x * (CEM_FIN_THREADS / 64) + wave) * 64; base < items; base += nwaves * 64) {
+        const long gid = base + lane;
+        const bool live = gid < items;
+        const int t4 = (int)(gid % H4);
+        const long p = gid / H4;
+        float z[NOISE_MAXA_U][4];
+#pragma unroll
+        for (int b = 0; b < NOISE_MAXA_U; ++b) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) z[b][k] = 0.0f;
+            if (b < A && live) normal_quad(f.seed, offset, (unsigned long long)((p + f.particle_offset) * A + b), (unsigned)t4, z[b]);
+        }
+        const int t = 4 * t4;
+#pragma unroll
+        for (int a = 0; a < NOISE_MAXA_U; ++a) {
+            if (a < A) {
+                double x[4] = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+                for (int b = 0; b <= a; ++b) {
+                    const double l = L[a * A + b];
+                    if (l != 0.0) {
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) x[k] += l * (double)z[b][k];
+                    }
+                }
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    if (staged) tile[lane * pad + k * A + a] = (T)x[k];
+                    else if (live && t + k < H) noise[(p * H + t + k) * A + a] = (T)x[k];
+                }
+            }
+        }
+        if (staged) {
+            __builtin_amdgcn_wave_barrier();
+            const long first = base * run, total = f.P * (long)H * A;
+            for (int i = lane; i < 64 * run; i += 64) {
+                const int th = i / run, off = i - th * run;
+                if (first + i < total) noise[first + i] = tile[th * pad + off];
+            }
+            __builtin_amdgcn_wave_barrier();
+        }
     }
 }
 
@@ -1090,6 +1381,83 @@ hipError_t cem_elite_sums(const T* actions, const double* q_all, long P_all, lon
     return hipGetLastError();
 }
 
+// ---- the fused CEM step (round 4) -----------------------------------------------------------------------------------------
+// elite rows per workgroup of cem_select_moments: as many as a 60 KB tile holds (no opt-in to large dynamic LDS), at most 64
+static int cem_fused_rows(int H, int A) {
+    const int HA = H * A, AA = A * A;
+    const long room = 60 * 1024 / 8 - (1024 / AA) * AA - HA - A;
+    const long e = room / HA;
+    return (int)(e > CEM_E_MAX ? CEM_E_MAX : e);
+}
+bool cem_fused_supported(long P_all, long P, long k, int H, int A) {
+    if (A < 1 || A > NOISE_MAXA_U || H < 1 || k < 1 || P_all > 32768 || P < 1 || A * A > 1024 || A * A > H * A + A) return false;
+    const int E = cem_fused_rows(H, A);
+    return E >= 4 && (k + E - 1) / E <= (P + CHUNK - 1) / CHUNK;        // (the partials fit the workspace's partial area)
+}
+static inline double* cem_cprime(const Ws& w) { return w.scratch + 16; }
+static inline long long* cem_step_prev(const Ws& w) { return (long long*)(w.scratch + 32); }
+static inline double* cem_cov_prev(const Ws& w, int A) { return w.dmean + A; }
+
+template <typename T>
+hipError_t cem_select_moments(const T* actions, const double* q_all, long P_all, long offset, long k, long P, int H, int A,
+                              const double* mean, const double* cov, const long long* d_step, double* ws, hipStream_t s) {
+    Ws w(ws, P, H, A);
+    const double* qa = q_all ? q_all : w.q0;
+    const long Pa = q_all ? P_all : P, off = q_all ? offset : 0;
+    if (!cem_fused_supported(Pa, P, k, H, A)) return hipErrorInvalidValue;
+    const int E = cem_fused_rows(H, A), HA = H * A, AA = A * A;
+    const int NB = (int)((k + E - 1) / E);
+    CemMoments<T> mo;
+    mo.actions = actions; mo.mean = mean; mo.cov = cov; mo.d_step = d_step;
+    mo.partial = w.partial; mo.cprime = cem_cprime(w); mo.mean_prev = w.elite_mean; mo.cov_prev = cem_cov_prev(w, A);
+    mo.step_prev = cem_step_prev(w);
+    mo.H = H; mo.A = A; mo.E = E;
+    const size_t lds = sizeof(double) * ((size_t)E * HA + (1024 / AA) * AA + HA + A);
+    unsigned long long* thr = (unsigned long long*)w.scratch;
+    if (Pa <= 16384)
+        hipLaunchKernelGGL((kth_key_kernel<16, T, true>), dim3(NB), dim3(1024), lds, s, qa, Pa, k, thr, off, P, w.elite, elite_count(w), mo);
+    else
+        hipLaunchKernelGGL((kth_key_kernel<32, T, true>), dim3(NB), dim3(1024), lds, s, qa, Pa, k, thr, off, P, w.elite, elite_count(w), mo);
+    return hipGetLastError();
+}
+
+hipError_t cem_record(long k, long P, int H, int A, const double* mean, double* record, double* ws, hipStream_t s) {
+    Ws w(ws, P, H, A);
+    const int E = cem_fused_rows(H, A), NB = (int)((k + E - 1) / E);
+    hipLaunchKernelGGL(cem_record_kernel, dim3(1), dim3(BLK), sizeof(double) * (H * A + A), s, w.partial, NB, H, A, mean,
+                       cem_cprime(w), record);
+    return hipGetLastError();
+}
+
+template <typename T>
+hipError_t cem_finish(const double* records, int G, long k, long P, int H, int A, double n_elite, int full, double step,
+                      int shift_mode, double* mean, double* cov, double* chol, int* status, const double* grow_diag,
+                      double grow_scale, double* action_out, double* action_host, long long* step_counter, T* noise,
+                      unsigned long long seed, unsigned long long offset, long particle_offset, double* ws, hipStream_t s) {
+    Ws w(ws, P, H, A);
+    const int E = cem_fused_rows(H, A), HA = H * A, AA = A * A;
+    CemFinish f;
+    f.mode = records ? 1 : 0;
+    f.in = records ? records : w.partial;
+    f.n_in = records ? G : (int)((k + E - 1) / E);
+    f.cprime = cem_cprime(w); f.mean_prev = w.elite_mean; f.cov_prev = cem_cov_prev(w, A); f.grow_diag = grow_diag;
+    f.step_prev = cem_step_prev(w);
+    f.mean = mean; f.cov = cov; f.chol = chol; f.action_out = action_out; f.action_host = action_host;
+    f.step_counter = step_counter; f.status = status; f.noise = (void*)noise;
+    f.H = H; f.A = A; f.full = full; f.shift_mode = shift_mode;
+    f.n_elite = n_elite; f.step = step; f.grow_scale = grow_scale;
+    f.seed = seed; f.offset = offset; f.particle_offset = particle_offset; f.P = P;
+    const long items = P * ((H + 3) / 4);
+    long nwg = noise ? (items + 4 * CEM_FIN_THREADS - 1) / (4 * CEM_FIN_THREADS) : 1;     // four trips per wavefront
+    if (nwg < 1) nwg = 1;
+    if (nwg > 512) nwg = 512;
+    const size_t lds = sizeof(double) * ((size_t)HA + (f.n_in + 1) * A + 2 * AA) +
+                       sizeof(T) * (CEM_FIN_THREADS / 64) * 64 * (4 * NOISE_MAXA_U + 1);
+    if (lds > 64 * 1024) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(cem_finish_kernel<T>, dim3((unsigned)nwg), dim3(CEM_FIN_THREADS), lds, s, f);
+    return hipGetLastError();
+}
+
 template <typename T>
 hipError_t cem_elite_cov(const T* actions, const double* mean, const double* sum_records, int G, long P, int H, int A,
                          double* crecord, double* ws, hipStream_t s) {
@@ -1226,6 +1594,11 @@ hipError_t step_tail(double* mean, int H, int A, int mode, const double* row, do
                                           double*, hipStream_t);                                                     \
     template hipError_t cem_elite_cov<T>(const T*, const double*, const double*, int, long, int, int, double*,       \
                                          double*, hipStream_t);                                                      \
+    template hipError_t cem_select_moments<T>(const T*, const double*, long, long, long, long, int, int, const double*, \
+                                              const double*, const long long*, double*, hipStream_t);                \
+    template hipError_t cem_finish<T>(const double*, int, long, long, int, int, double, int, double, int, double*,   \
+                                      double*, double*, int*, const double*, double, double*, double*, long long*, T*, \
+                                      unsigned long long, unsigned long long, long, double*, hipStream_t);           \
     template hipError_t rs_best<T>(const T*, long, long, int, int, double*, double*, hipStream_t);                   \
     template hipError_t mppi_fused_update<T>(const double*, const T*, double, double, int, long, int, int, double*,  \
                                              double*, double*, double*, double*, hipStream_t, double*, long long*,   \
