@@ -843,7 +843,7 @@ struct CemFinish {
     unsigned long long seed, offset;
     long particle_offset, P;
 };
-constexpr int CEM_FIN_THREADS = 256;
+constexpr int CEM_FIN_THREADS = 128;
 template <typename T>
 __global__ __launch_bounds__(CEM_FIN_THREADS) void cem_finish_kernel(CemFinish f) {
     extern __shared__ double sh[];          // sumA[HA] | mu[(G + 1) * A] | C[AA] | L[AA] | per-wave store tiles
