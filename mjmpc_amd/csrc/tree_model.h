@@ -103,12 +103,13 @@ enum TreeOffset : int {
 constexpr int TREE_PEXT_STRIDE = 24;    // [0:3] box half sizes, [3:12] box orientation in its link's frame | dof row: [0] 0 joint
                                         // equality / 1 tendon limit, [1] coef A (joint equality: 1 = anchor dof is joint 2),
                                         // [2] coef B, [3:5] range, [5] margin, [6:11] polycoef | [12:19] the row's own solver
-                                        // set (equalities), [19] bilateral, [20] connect: sign of (body 1 - body 2)
+                                        // set (equalities), [19] bilateral, [20] weld: +1 link A carries body 1, -1 body 2; weld: [0:9] body 2's orientation at qpos0
 // link kinds (T_JTYPE): a ball joint is three links - the first holds the quaternion and turns the frame, the others ride
 // along with the body's own y / z axes; a free joint is three slides along the world axes and a ball
 enum TreeLinkKind : int { LINK_HINGE = 1, LINK_SLIDE = 2, LINK_BALL_X = 3, LINK_BALL_Y = 4, LINK_BALL_Z = 5 };
 // contact-record kinds ([12])
-enum TreePointKind : int { PT_PLANE = 0, PT_SEGSEG = 1, PT_SPHERE_BOX = 2, PT_BOX_SPHERE = 3, PT_CONNECT = 4, PT_DOFROW = 5 };
+enum TreePointKind : int { PT_PLANE = 0, PT_SEGSEG = 1, PT_SPHERE_BOX = 2, PT_BOX_SPHERE = 3, PT_CONNECT = 4, PT_DOFROW = 5,
+                           PT_WELD = 6 };      // (a weld equality is a PT_CONNECT record at body 2's origin plus a PT_WELD record: its rotation rows)
 
 // device state: qpos[32] | qvel[32] | target[3] | site of the fresh observation[3] | quaternion w[32], one entry per LINK
 // (a BALL_X link keeps x, y, z in the qpos entries of its three links and w in its own w entry)

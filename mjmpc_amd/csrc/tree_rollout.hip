@@ -1240,6 +1240,52 @@ __global__ __launch_bounds__(64 * wg_waves(DP, FRIC, sizeof(T), PL), min_waves(s
                         }
                         cs[3] = T(0);
                         ci_mine = true;
+                    } else if (GEN && sp[12] == T(PT_WELD)) {
+                        // weld equality, rotation rows (mj_instantiateEquality, mjEQ_WELD): the error quaternion inv(q2) q1 qrel -
+                        // with link frames world-aligned at qpos0 it is R0_2' (R_link2' R_link1) R0_2 - has the residual as
+                        // its vector part and 1/2 (w u + u x v), u = R2' (w1 - w2), as its velocity: G = 1/2 R0_2' (w I - [v]x)
+                        // R_link2' maps a dof's angular motion (w1 - w2) to its three Jacobian entries
+                        const int sb = (int)sp[13];
+                        const T* ex = PEXT + l * TREE_PEXT_STRIDE;
+                        T Rb[9];
+#pragma unroll
+                        for (int c = 0; c < 9; ++c) Rb[c] = sb >= 0 ? X[c * PL + sb] : ((c & 3) == 0 ? T(1) : T(0));
+                        const bool a_is_1 = ex[20] > T(0);
+                        const T* R1 = a_is_1 ? Rl : Rb;
+                        const T* R2 = a_is_1 ? Rb : Rl;
+                        T E[9];
+                        for (int i = 0; i < 3; ++i)
+                            for (int j = 0; j < 3; ++j) E[3 * i + j] = R2[i] * R1[j] + R2[3 + i] * R1[3 + j] + R2[6 + i] * R1[6 + j];
+                        T qe[4];
+                        {
+                            const T tr = E[0] + E[4] + E[8];
+                            if (tr > T(0)) {
+                                const T sq = sqrt_(tr + T(1)) * T(2), iv = T(1) / sq;
+                                qe[0] = T(0.25) * sq; qe[1] = (E[7] - E[5]) * iv; qe[2] = (E[2] - E[6]) * iv; qe[3] = (E[3] - E[1]) * iv;
+                            } else if (E[0] > E[4] && E[0] > E[8]) {
+                                const T sq = sqrt_(T(1) + E[0] - E[4] - E[8]) * T(2), iv = T(1) / sq;
+                                qe[0] = (E[7] - E[5]) * iv; qe[1] = T(0.25) * sq; qe[2] = (E[1] + E[3]) * iv; qe[3] = (E[2] + E[6]) * iv;
+                            } else if (E[4] > E[8]) {
+                                const T sq = sqrt_(T(1) + E[4] - E[0] - E[8]) * T(2), iv = T(1) / sq;
+                                qe[0] = (E[2] - E[6]) * iv; qe[1] = (E[1] + E[3]) * iv; qe[2] = T(0.25) * sq; qe[3] = (E[5] + E[7]) * iv;
+                            } else {
+                                const T sq = sqrt_(T(1) + E[8] - E[0] - E[4]) * T(2), iv = T(1) / sq;
+                                qe[0] = (E[3] - E[1]) * iv; qe[1] = (E[2] + E[6]) * iv; qe[2] = (E[5] + E[7]) * iv; qe[3] = T(0.25) * sq;
+                            }
+                            if (qe[0] < T(0)) for (int k = 0; k < 4; ++k) qe[k] = -qe[k];
+                        }
+                        // K = (w I - [v]x) R_link2'  (row i, column j), then G = 1/2 R0_2' K
+                        const T w_ = qe[0], vx = qe[1], vy = qe[2], vz = qe[3];
+                        const T Wm[9] = {w_, vz, -vy, -vz, w_, vx, vy, -vx, w_};
+                        T K[9];
+                        for (int i = 0; i < 3; ++i)
+                            for (int j = 0; j < 3; ++j) K[3 * i + j] = Wm[3 * i] * R2[3 * j] + Wm[3 * i + 1] * R2[3 * j + 1] + Wm[3 * i + 2] * R2[3 * j + 2];
+                        for (int i = 0; i < 3; ++i) {
+                            for (int j = 0; j < 3; ++j)
+                                cs[3 * i + j] = T(0.5) * (ex[i] * K[j] + ex[3 + i] * K[3 + j] + ex[6 + i] * K[6 + j]);
+                            cs[11 + i] = ex[i] * vx + ex[3 + i] * vy + ex[6 + i] * vz;        // residual = R0_2' v
+                        }
+                        ci_mine = true;
                     } else if (GEN && (sp[12] == T(PT_SPHERE_BOX) || sp[12] == T(PT_BOX_SPHERE))) {
                         // a sphere against a box (mjc_SphereBox): the box's closest point to the sphere's centre, or - centre
                         // inside - the nearest face; normal from geom B to geom A, contact point midway between the surfaces
@@ -1610,6 +1656,17 @@ __global__ __launch_bounds__(64 * wg_waves(DP, FRIC, sizeof(T), PL), min_waves(s
                         jc = oi >= 0 ? e0 : T(0);
                         jgen1 = oi >= 0 ? e1 : T(0);
                         jgen2 = oi >= 0 ? e2 : T(0);
+                    } else if (kind == PT_WELD) {
+                        // my dof's angular motion of body 1 less that of body 2, through the record's G
+                        genrow = true;
+                        const int lA = (int)sp[0], lB = (int)sp[13];
+                        const T inA = (lA >= l && lA < l + tp.subsize) ? T(1) : T(0);
+                        const T inB = (lB >= l && lB < l + tp.subsize) ? T(1) : T(0);
+                        const T sd = PEXT[s * TREE_PEXT_STRIDE + 20] > T(0) ? inA - inB : inB - inA;
+                        const T dwv[3] = {sd * sw[0], sd * sw[1], sd * sw[2]};
+                        jc = oi >= 0 ? cs[0] * dwv[0] + cs[1] * dwv[1] + cs[2] * dwv[2] : T(0);
+                        jgen1 = oi >= 0 ? cs[3] * dwv[0] + cs[4] * dwv[1] + cs[5] * dwv[2] : T(0);
+                        jgen2 = oi >= 0 ? cs[6] * dwv[0] + cs[7] * dwv[1] + cs[8] * dwv[2] : T(0);
                     }
                 }
                 if (oi >= 0) jrow[oi] = jc;
@@ -1659,13 +1716,16 @@ __global__ __launch_bounds__(64 * wg_waves(DP, FRIC, sizeof(T), PL), min_waves(s
                     const T mu = FRIC ? sp[7] : T(0);
                     T Dc, arc;
                     const int kind = GEN ? (int)sp[12] : 0;
-                    if (GEN && kind == PT_CONNECT) {
-                        // three bilateral rows along the world axes, each with its own violation, D and reference acceleration
+                    if (GEN && (kind == PT_CONNECT || kind == PT_WELD)) {
+                        // three bilateral rows (connect: along the world axes; weld: the rotation error's components), each
+                        // with its own violation, D and reference acceleration
                         const T* ex = PEXT + l * TREE_PEXT_STRIDE;
                         const T jk[3] = {jv, j1v, j2v};
+                        const T pos3[3] = {kind == PT_WELD ? cs[11] : cs[0] - cs[11], kind == PT_WELD ? cs[12] : cs[1] - cs[12],
+                                           kind == PT_WELD ? cs[13] : cs[2] - cs[13]};
 #pragma unroll
                         for (int k = 0; k < 3; ++k) {
-                            tree_row_params(ex + 12, cs[k] - cs[11 + k], sp[6], jk[k], Dc, arc);
+                            tree_row_params(ex + 12, pos3[k], sp[6], jk[k], Dc, arc);
                             cs[15 + k] = Dc;
                             cs[5 + k] = arc;
                         }
@@ -1703,7 +1763,7 @@ __global__ __launch_bounds__(64 * wg_waves(DP, FRIC, sizeof(T), PL), min_waves(s
                 }
                 // rows of contact point s with friction mu (uniform per particle): all NR, else one
                 auto rows_of = [&](int s) -> unsigned {
-                    if (GEN && (int)M[T_SPH + s * TREE_SPH_STRIDE + 12] == PT_CONNECT) return 7u;
+                    if (GEN && ((int)M[T_SPH + s * TREE_SPH_STRIDE + 12] == PT_CONNECT || (int)M[T_SPH + s * TREE_SPH_STRIDE + 12] == PT_WELD)) return 7u;
                     return (FRIC && M[T_SPH + s * TREE_SPH_STRIDE + 7] > T(0)) ? 15u : 1u;
                 };
                 // (GEN) my record's kind; bilateral records (equalities) keep all their rows active on both sides
@@ -1768,7 +1828,7 @@ __global__ __launch_bounds__(64 * wg_waves(DP, FRIC, sizeof(T), PL), min_waves(s
                         res[2 % NR] = an + a2 - (cs[5] - cs[7]);
                         res[3 % NR] = an - a2 - (cs[5] + cs[7]);
                         if (!(mu > T(0))) res[0] = an - cs[5];
-                        if (GEN && my_kind == PT_CONNECT) {         // three independent rows, one per Jacobian
+                        if (GEN && (my_kind == PT_CONNECT || my_kind == PT_WELD)) {         // three independent rows, one per Jacobian
                             res[0] = an - cs[5];
                             res[1 % NR] = c1 - cs[6];
                             res[2 % NR] = c2 - cs[7];
@@ -1825,7 +1885,7 @@ __global__ __launch_bounds__(64 * wg_waves(DP, FRIC, sizeof(T), PL), min_waves(s
                             cs[8] = fn;
                             cs[9] = mu * f1;
                             cs[10] = mu * f2;
-                            if (GEN && my_kind == PT_CONNECT) {     // f_k = -D_k r_k on the three Jacobians
+                            if (GEN && (my_kind == PT_CONNECT || my_kind == PT_WELD)) {     // f_k = -D_k r_k on the three Jacobians
                                 cs[8] = -cs[15] * res[0];
                                 cs[9] = -cs[16] * res[1 % NR];
                                 cs[10] = -cs[17] * res[2 % NR];
@@ -1928,7 +1988,7 @@ __global__ __launch_bounds__(64 * wg_waves(DP, FRIC, sizeof(T), PL), min_waves(s
                             rsum -= s1 * cs[6] + s2 * cs[7];
                             rhs += Dc * (j1 * (s1 * cs[5] - n1 * cs[6]) + j2 * (s2 * cs[5] - n2 * cs[7]));
                         }
-                        if (GEN && (int)M[T_SPH + s * TREE_SPH_STRIDE + 12] == PT_CONNECT) {
+                        if (GEN && ((int)M[T_SPH + s * TREE_SPH_STRIDE + 12] == PT_CONNECT || (int)M[T_SPH + s * TREE_SPH_STRIDE + 12] == PT_WELD)) {
                             // three independent bilateral rows: H += sum_k D_k J_k J_k', rhs += sum_k D_k aref_k J_k
                             wn = cs[15] * jl;
                             w1 = cs[16] * t1l;
@@ -2017,7 +2077,7 @@ __global__ __launch_bounds__(64 * wg_waves(DP, FRIC, sizeof(T), PL), min_waves(s
                                     for (int r = 0; r < NR; ++r) drb[r] = ((rows >> r) & 1u) ? rN[r] - rb[r] : T(0);
                                     T al;
                                     if constexpr (GEN) {
-                                        const T* Dk = (my_pt && my_kind == PT_CONNECT) ? X + A_CS + l * CS + 15 : nullptr;
+                                        const T* Dk = (my_pt && (my_kind == PT_CONNECT || my_kind == PT_WELD)) ? X + A_CS + l * CS + 15 : nullptr;
                                         T Dk3[NR];
 #pragma unroll
                                         for (int r = 0; r < NR; ++r) Dk3[r] = (Dk && r < 3) ? Dk[r] : Dc;

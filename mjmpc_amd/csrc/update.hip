@@ -265,6 +265,21 @@ __device__ __forceinline__ unsigned long long order_key(double q) {
 // population share sign, exponent and often more) and the 8-bit digit windows count down from the first differing bit; once the bucket that holds the rank has at most KTH_CAND keys
 // they are ranked against each other directly in (key, index) order - which also settles ties exactly, so the
 // barrier-per-round tie walk only runs when more than KTH_CAND particles hold the k-th key itself.
+// sum_{g < n} p[g * stride] in a FIXED order with eight loads in flight: a plain `for (g) acc += p[g * stride]` waits for
+// every load before it issues the next - half a microsecond per term when the terms are in L2 (measured: 59 partials of
+// the fused CEM step summed that way cost 31 us)
+__device__ __forceinline__ double sum_strided(const double* __restrict__ p, int n, long stride) {
+    double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0, a4 = 0.0, a5 = 0.0, a6 = 0.0, a7 = 0.0;
+    int g = 0;
+    for (; g + 8 <= n; g += 8) {
+        const double v0 = p[(long)g * stride], v1 = p[(long)(g + 1) * stride], v2 = p[(long)(g + 2) * stride],
+                     v3 = p[(long)(g + 3) * stride], v4 = p[(long)(g + 4) * stride], v5 = p[(long)(g + 5) * stride],
+                     v6 = p[(long)(g + 6) * stride], v7 = p[(long)(g + 7) * stride];
+        a0 += v0; a1 += v1; a2 += v2; a3 += v3; a4 += v4; a5 += v5; a6 += v6; a7 += v7;
+    }
+    for (; g < n; ++g) a0 += p[(long)g * stride];
+    return ((a0 + a1) + (a2 + a3)) + ((a4 + a5) + (a6 + a7));
+}
 constexpr int NOISE_MAXA_U = 8;     // as noise.hip's NOISE_MAXA: action channels the in-register sampler unrolls to
 constexpr int KTH_CAND = 32;        // (the ranking is a loop of dependent LDS reads: 256 candidates cost more than a pass)
 // Round 4, MOM = true (cem_select_moments): the SAME selection run redundantly by every workgroup of a grid - the keys are
@@ -276,6 +291,9 @@ constexpr int KTH_CAND = 32;        // (the ranking is a loop of dependent LDS r
 // the mean, and the scatter pass.  Workgroup 0 also snapshots what the finish launch must read unmodified while it
 // rewrites it (mean, covariance, step counter).
 constexpr int CEM_HEAD = 64, CEM_E_MAX = 64;
+#ifndef CEM_E_ROWS
+#define CEM_E_ROWS 32
+#endif
 template <typename TA>
 struct CemMoments {
     const TA* actions;
@@ -517,10 +535,21 @@ __global__ __launch_bounds__(1024) void kth_key_kernel(const double* __restrict_
             const int ne = n - e0 < 0 ? 0 : (n - e0 < E ? n - e0 : E);
             const int nh = n < CEM_HEAD ? n : CEM_HEAD;
             // the provisional centre: mean of the first elite rows (every workgroup alike), as a mean DELTA per channel
-            for (int j = tid; j < HA; j += 1024) {
-                double c = 0.0;
-                for (int e = 0; e < nh; ++e) c += (double)mo.actions[(long)head[e] * HA + j];
-                cdiff[j] = (nh > 0 ? c / (double)nh : 0.0) - mo.mean[j];
+            // (HA entries x nh rows over 1024 threads: a thread takes one entry and a quarter of the rows - independent loads -
+            // and the quarters are added in a fixed order)
+            {
+                double* part = tile;                    // [4][HA] (the tile is free until the rows are staged)
+                const int q4 = tid / 256, j0 = tid - q4 * 256;
+                for (int j = j0; j < HA; j += 256) {
+                    double c = 0.0;
+                    for (int e = q4; e < nh; e += 4) c += (double)mo.actions[(long)head[e] * HA + j];
+                    part[q4 * HA + j] = c;
+                }
+                __syncthreads();
+                for (int j = tid; j < HA; j += 1024) {
+                    const double c = (part[j] + part[HA + j]) + (part[2 * HA + j] + part[3 * HA + j]);
+                    cdiff[j] = (nh > 0 ? c / (double)nh : 0.0) - mo.mean[j];
+                }
             }
             __syncthreads();
             if (tid < A) {
@@ -800,11 +829,9 @@ __global__ void cem_record_kernel(const double* __restrict__ partial, int NB, in
                                   const double* __restrict__ cprime, double* __restrict__ rec) {
     extern __shared__ double sh[];          // sum[HA] | d[A]
     const int HA = H * A, AA = A * A, R = 1 + HA + AA;
-    double cnt = 0.0;
-    for (int b = 0; b < NB; ++b) cnt += partial[(long)b * R];
+    const double cnt = sum_strided(partial, NB, R);
     for (int j = threadIdx.x; j < HA; j += blockDim.x) {
-        double sacc = 0.0;
-        for (int b = 0; b < NB; ++b) sacc += partial[(long)b * R + 1 + j];
+        const double sacc = sum_strided(partial + 1 + j, NB, R);
         sh[j] = sacc;
         rec[1 + j] = sacc;
     }
@@ -816,8 +843,7 @@ __global__ void cem_record_kernel(const double* __restrict__ partial, int NB, in
     }
     __syncthreads();
     for (int j = threadIdx.x; j < AA; j += blockDim.x) {
-        double C = 0.0;
-        for (int b = 0; b < NB; ++b) C += partial[(long)b * R + 1 + HA + j];
+        const double C = sum_strided(partial + 1 + HA + j, NB, R);
         rec[1 + HA + j] = C - (double)H * cnt * sh[HA + j / A] * sh[HA + j % A];
     }
     if (threadIdx.x == 0) rec[0] = cnt;
@@ -843,7 +869,7 @@ struct CemFinish {
     unsigned long long seed, offset;
     long particle_offset, P;
 };
-constexpr int CEM_FIN_THREADS = 128;
+constexpr int CEM_FIN_THREADS = 256;
 template <typename T>
 __global__ __launch_bounds__(CEM_FIN_THREADS) void cem_finish_kernel(CemFinish f) {
     extern __shared__ double sh[];          // sumA[HA] | mu[(G + 1) * A] | C[AA] | L[AA] | per-wave store tiles
@@ -854,13 +880,8 @@ __global__ __launch_bounds__(CEM_FIN_THREADS) void cem_finish_kernel(CemFinish f
     double* Cn = mu + (G + 1) * A;
     double* L = Cn + AA;
     T* tiles = (T*)(L + AA);
-    double cnt = 0.0;
-    for (int g = 0; g < G; ++g) cnt += f.in[(long)g * R];
-    for (int j = tid; j < HA; j += CEM_FIN_THREADS) {
-        double sacc = 0.0;
-        for (int g = 0; g < G; ++g) sacc += f.in[(long)g * R + 1 + j];
-        sumA[j] = sacc;
-    }
+    const double cnt = sum_strided(f.in, G, R);
+    for (int j = tid; j < HA; j += CEM_FIN_THREADS) sumA[j] = sum_strided(f.in + 1 + j, G, R);
     __syncthreads();
     if (f.mode == 0) {
         for (int a = tid; a < A; a += CEM_FIN_THREADS) {
@@ -885,12 +906,10 @@ __global__ __launch_bounds__(CEM_FIN_THREADS) void cem_finish_kernel(CemFinish f
     __syncthreads();
     for (int j = tid; j < AA; j += CEM_FIN_THREADS) {
         const int i = j / A, k = j % A;
-        double C = 0.0;
-        for (int g = 0; g < G; ++g) {
-            const double* r = f.in + (long)g * R;
-            C += r[1 + HA + j];
-            if (f.mode == 1 && G > 1) C += (double)H * r[0] * (mu[g * A + i] - mu[G * A + i]) * (mu[g * A + k] - mu[G * A + k]);
-        }
+        double C = sum_strided(f.in + 1 + HA + j, G, R);
+        if (f.mode == 1 && G > 1)
+            for (int g = 0; g < G; ++g)
+                C += (double)H * f.in[(long)g * R] * (mu[g * A + i] - mu[G * A + i]) * (mu[g * A + k] - mu[G * A + k]);
         if (f.mode == 0) C -= (double)H * cnt * mu[i] * mu[k];
         const double N = (double)H * f.n_elite;
         const double upd = f.full ? C / (N - 1.0) : (i == k ? C / N : 0.0);
@@ -950,7 +969,7 @@ __global__ __launch_bounds__(CEM_FIN_THREADS) void cem_finish_kernel(CemFinish f
     const unsigned long long offset = f.offset + (unsigned long long)(*f.step_prev + 1);
     const bool staged = (H & 3) == 0;
     const int run = 4 * A, pad = run + 1;
-    T* tile = tiles + wave * 64 * (4 * NOISE_MAXA_U + 1);
+    T* tile = tiles + wave * 64 * (4 * A + 1);
     T* noise = (T*)f.noise;
     for (long base = ((long)blockIdx.x * (CEM_FIN_THREADS / 64) + wave) * 64; base < items; base += nwaves * 64) {
         const long gid = base + lane;
@@ -1385,9 +1404,12 @@ hipError_t cem_elite_sums(const T* actions, const double* q_all, long P_all, lon
 // elite rows per workgroup of cem_select_moments: as many as a 60 KB tile holds (no opt-in to large dynamic LDS), at most 64
 static int cem_fused_rows(int H, int A) {
     const int HA = H * A, AA = A * A;
-    const long room = 60 * 1024 / 8 - (1024 / AA) * AA - HA - A;
+    const long room = 150 * 1024 / 8 - (1024 / AA) * AA - HA - A;      // (160 KB of LDS per CU; large dynamic LDS is opted in)
     const long e = room / HA;
-    return (int)(e > CEM_E_MAX ? CEM_E_MAX : e);
+    // (32 rows per workgroup measured best at 16384 x 32 x 7: more rows lengthen the moments phase of every workgroup - 64:
+    // 39.5 us for the launch -, fewer multiply the partials the finish launch sums - 28: 34.7 us but 59 partials)
+    const long cap = CEM_E_ROWS < CEM_E_MAX ? CEM_E_ROWS : CEM_E_MAX;
+    return (int)(e > cap ? cap : e);
 }
 bool cem_fused_supported(long P_all, long P, long k, int H, int A) {
     if (A < 1 || A > NOISE_MAXA_U || H < 1 || k < 1 || P_all > 32768 || P < 1 || A * A > 1024 || A * A > H * A + A) return false;
@@ -1412,12 +1434,17 @@ hipError_t cem_select_moments(const T* actions, const double* q_all, long P_all,
     mo.partial = w.partial; mo.cprime = cem_cprime(w); mo.mean_prev = w.elite_mean; mo.cov_prev = cem_cov_prev(w, A);
     mo.step_prev = cem_step_prev(w);
     mo.H = H; mo.A = A; mo.E = E;
-    const size_t lds = sizeof(double) * ((size_t)E * HA + (1024 / AA) * AA + HA + A);
+    const size_t lds = sizeof(double) * ((size_t)(E > 4 ? E : 4) * HA + (1024 / AA) * AA + HA + A);
     unsigned long long* thr = (unsigned long long*)w.scratch;
-    if (Pa <= 16384)
+    if (Pa <= 16384) {
+        if (lds > 64 * 1024)
+            (void)hipFuncSetAttribute((const void*)kth_key_kernel<16, T, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         hipLaunchKernelGGL((kth_key_kernel<16, T, true>), dim3(NB), dim3(1024), lds, s, qa, Pa, k, thr, off, P, w.elite, elite_count(w), mo);
-    else
+    } else {
+        if (lds > 64 * 1024)
+            (void)hipFuncSetAttribute((const void*)kth_key_kernel<32, T, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         hipLaunchKernelGGL((kth_key_kernel<32, T, true>), dim3(NB), dim3(1024), lds, s, qa, Pa, k, thr, off, P, w.elite, elite_count(w), mo);
+    }
     return hipGetLastError();
 }
 
@@ -1448,12 +1475,14 @@ hipError_t cem_finish(const double* records, int G, long k, long P, int H, int A
     f.n_elite = n_elite; f.step = step; f.grow_scale = grow_scale;
     f.seed = seed; f.offset = offset; f.particle_offset = particle_offset; f.P = P;
     const long items = P * ((H + 3) / 4);
-    long nwg = noise ? (items + 4 * CEM_FIN_THREADS - 1) / (4 * CEM_FIN_THREADS) : 1;     // four trips per wavefront
+    long nwg = noise ? (items + CEM_FIN_THREADS - 1) / CEM_FIN_THREADS : 1;       // one trip per wavefront up to 1024 workgroups
     if (nwg < 1) nwg = 1;
-    if (nwg > 512) nwg = 512;
+    if (nwg > 1024) nwg = 1024;
     const size_t lds = sizeof(double) * ((size_t)HA + (f.n_in + 1) * A + 2 * AA) +
-                       sizeof(T) * (CEM_FIN_THREADS / 64) * 64 * (4 * NOISE_MAXA_U + 1);
-    if (lds > 64 * 1024) return hipErrorInvalidValue;
+                       sizeof(T) * (CEM_FIN_THREADS / 64) * 64 * (4 * A + 1);
+    if (lds > 150 * 1024) return hipErrorInvalidValue;
+    if (lds > 64 * 1024)
+        (void)hipFuncSetAttribute((const void*)cem_finish_kernel<T>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipLaunchKernelGGL(cem_finish_kernel<T>, dim3((unsigned)nwg), dim3(CEM_FIN_THREADS), lds, s, f);
     return hipGetLastError();
 }

@@ -15,7 +15,7 @@ from dataclasses import dataclass
 import numpy as np
 
 from .compile import _geom_inertial, _quat2mat, _shift_inertia, principal_inertia
-from .raw import (EQ_CONNECT, EQ_JOINT, GEOM_BOX, GEOM_CAPSULE, GEOM_SPHERE, JOINT_BALL, JOINT_FREE, JOINT_HINGE, JOINT_SLIDE,
+from .raw import (EQ_CONNECT, EQ_JOINT, EQ_WELD, GEOM_BOX, GEOM_CAPSULE, GEOM_SPHERE, JOINT_BALL, JOINT_FREE, JOINT_HINGE, JOINT_SLIDE,
                   TASK_FORWARD, TASK_ORIENT, TASK_REACH, RawModel)
 
 TL = 32                     # lanes per particle
@@ -32,7 +32,7 @@ MJ_MINIMP, MJ_MAXIMP = 1e-4, 0.9999     # MuJoCo's clamp on solimp (getsolparam)
 LINK_HINGE, LINK_SLIDE, LINK_BALL_X, LINK_BALL_Y, LINK_BALL_Z = 1, 2, 3, 4, 5
 # contact-record kinds ([12]): sphere/plane, segment/segment, sphere(A)/box(B), box(A)/sphere(B), connect equality,
 # dof row (joint equality or fixed-tendon limit)
-PT_PLANE, PT_SEGSEG, PT_SPHERE_BOX, PT_BOX_SPHERE, PT_CONNECT, PT_DOFROW = 0, 1, 2, 3, 4, 5
+PT_PLANE, PT_SEGSEG, PT_SPHERE_BOX, PT_BOX_SPHERE, PT_CONNECT, PT_DOFROW, PT_WELD = 0, 1, 2, 3, 4, 5, 6
 PEXT_STRIDE = 24            # per contact record, general instantiation: [0:3] box half sizes, [3:12] box orientation in its
                             # link's frame (row-major) | dof row: [0] 0 joint equality / 1 tendon limit, [1] coef A, [2] coef
                             # B, [3:5] range, [5] margin, [6:11] polycoef; [12:19] the row's solver set {K, B, dmin, dmax,
@@ -283,7 +283,7 @@ def compile_tree(raw: RawModel, overrides=None, base: "TreeModel" = None) -> Tre
         pair_geoms.append((A, B))
     coupled = [set(kpath(blink(A[0])) + kpath(blink(B[0]))) for A, B in pair_geoms]
     for e in raw.equalities:
-        if e.type == EQ_CONNECT:
+        if e.type in (EQ_CONNECT, EQ_WELD):
             coupled.append(set(kpath(blink(bnames.index(e.obj1))) + kpath(blink(bnames.index(e.obj2)) if e.obj2 else -1)))
         elif e.type == EQ_JOINT:
             coupled.append({raw.dof_of_joint(e.obj1)} | ({raw.dof_of_joint(e.obj2)} if e.obj2 else set()))
@@ -481,10 +481,12 @@ def compile_tree(raw: RawModel, overrides=None, base: "TreeModel" = None) -> Tre
             for g in range(2 if b.joint.type == JOINT_FREE else 1):
                 dof_iw[j + 3 * g:j + 3 * g + 3] = dof_iw[j + 3 * g:j + 3 * g + 3].mean()
     f["dof_invweight0"][:nv] = dof_iw
-    body_iw = np.zeros(nb)
+    body_iw, body_iw_rot = np.zeros(nb), np.zeros(nb)
     for i in range(nb):
         Jp = jac_point(p0[i] + R0[i] @ ipos[i], link_of_body[i])
         body_iw[i] = np.trace(Jp @ M0inv @ Jp.T) / 3.0
+        Jr = jac_rot(link_of_body[i])
+        body_iw_rot[i] = np.trace(Jr @ M0inv @ Jr.T) / 3.0
 
     # ---- scalars, site, contacts --------------------------------------------------------------------------
     f["nv"][0], f["timestep"][0], f["frame_skip"][0], f["jumps"][0] = nv, raw.timestep, raw.frame_skip, jumps
@@ -523,7 +525,7 @@ def compile_tree(raw: RawModel, overrides=None, base: "TreeModel" = None) -> Tre
                 points += [(i, g, e, u, radius), (i, g, a, u, radius)]
     if raw.plane is None:
         points = []
-    n_eq_pts = len(raw.equalities)
+    n_eq_pts = len(raw.equalities) + sum(1 for e in raw.equalities if e.type == EQ_WELD)     # (a weld takes two records)
     n_tn_pts = sum(1 for t in raw.tendons if t.limited)
     if len(points) + len(pair_geoms) + n_eq_pts + n_tn_pts > TREE_MAX_SPHERES:
         raise ValueError("tree kernel supports %d contact records (a capsule on the plane counts two, a box eight, a geom-geom "
@@ -645,9 +647,11 @@ def compile_tree(raw: RawModel, overrides=None, base: "TreeModel" = None) -> Tre
         ext[12:19] = sol_values(e.solref, full_solimp(e.solimp))
         ext[19] = 1.0
         gen = True
-        if e.type == EQ_CONNECT:
+        if e.type in (EQ_CONNECT, EQ_WELD):
             i1, i2 = bnames.index(e.obj1), (bnames.index(e.obj2) if e.obj2 else -1)
-            anchor_w = p0[i1] + R0[i1] @ np.asarray(e.anchor, float)        # the shared point at qpos0, world
+            # the shared point at qpos0, world: a connect's anchor (given in body 1); a weld's is body 2's origin
+            anchor_w = (p0[i1] + R0[i1] @ np.asarray(e.anchor, float)) if e.type == EQ_CONNECT else (p0[i2] if i2 >= 0 else np.zeros(3))
+            j1, j2 = i1, i2
             l1, l2 = blink(i1), blink(i2)
             if l1 < 0 and l2 < 0:
                 raise NotImplementedError("connect %r / %r: both bodies are static" % (e.obj1, e.obj2))
@@ -659,6 +663,19 @@ def compile_tree(raw: RawModel, overrides=None, base: "TreeModel" = None) -> Tre
             rec[6] = body_w(i1) + body_w(i2)
             rec[11] = edepth[l1] - 1
             rec[12] = PT_CONNECT
+            if e.type == EQ_WELD:
+                # second record: the rotation rows.  ext[0:9] = body 2's orientation at qpos0 (world: identity), [20] which
+                # of the record's links carries body 1
+                s += 1
+                rec2 = f["spheres"][s * SPH_STRIDE:(s + 1) * SPH_STRIDE]
+                ext2 = f["pext"][s * PEXT_STRIDE:(s + 1) * PEXT_STRIDE]
+                rec2[0], rec2[13], rec2[11], rec2[12] = l1, l2, edepth[l1] - 1, PT_WELD
+                rw = (lambda i: 0.0 if i < 0 else (base.body_invweight0_rot[i] if base is not None else body_iw_rot[i]))
+                rec2[6] = rw(j1) + rw(j2)
+                ext2[0:9] = (R0[j2] if j2 >= 0 else np.eye(3)).reshape(-1)
+                ext2[12:19] = ext[12:19]
+                ext2[19] = 1.0
+                ext2[20] = 1.0 if i1 == j1 else -1.0
         elif e.type == EQ_JOINT:
             d1, d2 = raw.dof_of_joint(e.obj1), (raw.dof_of_joint(e.obj2) if e.obj2 else -1)
             for d in (d1, d2):
@@ -677,7 +694,7 @@ def compile_tree(raw: RawModel, overrides=None, base: "TreeModel" = None) -> Tre
             rec[11] = edepth[int(rec[0])] - 1
             rec[12] = PT_DOFROW
         else:
-            raise NotImplementedError("weld equalities are not built (connect and joint are)")
+            raise NotImplementedError("unknown equality type %r" % (e.type,))
         s += 1
     for t in raw.tendons:
         if not t.limited:
@@ -749,5 +766,6 @@ def compile_tree(raw: RawModel, overrides=None, base: "TreeModel" = None) -> Tre
                    body_mass=mass, body_inertia=inert, body_invweight0=body_iw, dof_invweight0=dof_iw, link_of_body=link_of_body,
                    nq=nq, qpos0=raw.qpos0)
     tm.tendon_invweight0 = tendon_iw
+    tm.body_invweight0_rot = base.body_invweight0_rot.copy() if base is not None else body_iw_rot
     tm.general = bool(gen)
     return tm

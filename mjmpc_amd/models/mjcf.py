@@ -20,7 +20,8 @@ panda/tray_glass-v0.yml, sawyer/door-v0.yml, hand/*-v0.yml):
   collide with moving geoms through MuJoCo's contype / conaffinity rule or an explicit ``<pair>``), world and body
   ``<site>``s, ``<motor joint gear ctrlrange ctrllimited>`` and ``<position joint kp ctrlrange ctrllimited>`` actuators,
   ``<contact><pair geom1 geom2>``; geom pairs: sphere / capsule against sphere / capsule, sphere against box;
-* ``<equality><connect body1 body2 anchor>`` and ``<joint joint1 joint2 polycoef>`` (``solref`` / ``solimp`` each),
+* ``<equality><connect body1 body2 anchor>``, ``<weld body1 body2>`` and ``<joint joint1 joint2 polycoef>`` (``solref`` /
+  ``solimp`` each),
   ``<tendon><fixed limited range><joint joint coef/>`` over one or two joints.
 
 Anything that would change the simulation and is not modelled raises ValueError, so that a model is never silently
@@ -31,7 +32,7 @@ import xml.etree.ElementTree as ET
 import numpy as np
 
 from .compile import _geom_inertial, _quat2mat
-from .raw import (EQ_CONNECT, EQ_JOINT, GEOM_BOX, GEOM_CAPSULE, GEOM_SPHERE, JOINT_BALL, JOINT_FREE, JOINT_HINGE, JOINT_SLIDE,
+from .raw import (EQ_CONNECT, EQ_JOINT, EQ_WELD, GEOM_BOX, GEOM_CAPSULE, GEOM_SPHERE, JOINT_BALL, JOINT_FREE, JOINT_HINGE, JOINT_SLIDE,
                   MJ20_CAPSULE_CAP, TASK_FORWARD, TASK_REACH, RawActuator, RawBody, RawEquality, RawGeom, RawInertial,
                   RawJoint, RawModel, RawPlane, RawTendon)
 
@@ -438,8 +439,12 @@ def load_mjcf(path, hand_site="finger", target_site="target", frame_skip=2, task
         elif q.tag == "joint":
             equalities.append(RawEquality(EQ_JOINT, q.get("joint1"), q.get("joint2") or "",
                                           polycoef=_floats(q.get("polycoef", "0 1 0 0 0"), 5), **kw))
+        elif q.tag == "weld":
+            if q.get("relpose") is not None:
+                raise ValueError("weld relpose is not supported (the relative pose at qpos0 is what a weld keeps)")
+            equalities.append(RawEquality(EQ_WELD, q.get("body1"), q.get("body2") or "", **kw))
         else:
-            raise ValueError("equality <%s> is not supported (connect and joint are)" % q.tag)
+            raise ValueError("equality <%s> is not supported (connect, weld and joint are)" % q.tag)
 
     if task == TASK_REACH:
         if hand_site not in sites or sites[hand_site][0] < 0:

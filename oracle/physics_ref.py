@@ -197,6 +197,11 @@ class RefArm:
         self._L.or_get_invweight0(ctypes.c_void_p(self._h), _p(dof), _p(body))
         return dof, body
 
+    def invweight0_rot(self):
+        body = np.zeros(self.nbody)
+        self._L.or_get_invweight0_rot(ctypes.c_void_p(self._h), _p(body))
+        return body
+
     def newton_stats(self):
         out = (ctypes.c_long * 3)()
         self._L.or_get_newton_stats(ctypes.c_void_p(self._h), out)

@@ -104,7 +104,7 @@ typedef struct {
     double pair_R[MAXP][9], pair_half[MAXP][3];   /* that box: orientation in its body's frame, half sizes (pair_a = centre) */
     /* equality constraints (MJCF <equality>): connect / weld (two bodies, 0 = world) and joint (two dofs, -1 = none) */
     int neq, eq_type[MAXE], eq_o1[MAXE], eq_o2[MAXE];
-    double eq_anchor[MAXE][2][3], eq_relquat[MAXE][4], eq_poly[MAXE][5], eq_solref[MAXE][2], eq_solimp[MAXE][5];
+    double eq_anchor[MAXE][2][3], eq_relR[MAXE][9], eq_poly[MAXE][5], eq_solref[MAXE][2], eq_solimp[MAXE][5];
     /* fixed tendons: length = sum coef q over hinge / slide dofs; limit rows */
     int ntendon, tn_n[MAXT], tn_dof[MAXT][MAXTJ], tn_limited[MAXT];
     double tn_coef[MAXT][MAXTJ], tn_range[MAXT][2], tn_margin[MAXT], tn_invweight0[MAXT];
@@ -171,6 +171,24 @@ static void quat_integrate(double *q, const double *w, double h) {
     quatmul(q, r, t);
     double nn = sqrt(t[0] * t[0] + t[1] * t[1] + t[2] * t[2] + t[3] * t[3]);
     for (int i = 0; i < 4; i++) q[i] = t[i] / nn;
+}
+/* unit quaternion (w, x, y, z) of a rotation matrix, w >= 0 */
+static void mat2quat(const double *R, double *q) {
+    double tr = R[0] + R[4] + R[8];
+    if (tr > 0) {
+        double sq = sqrt(tr + 1.0) * 2;
+        q[0] = 0.25 * sq; q[1] = (R[7] - R[5]) / sq; q[2] = (R[2] - R[6]) / sq; q[3] = (R[3] - R[1]) / sq;
+    } else if (R[0] > R[4] && R[0] > R[8]) {
+        double sq = sqrt(1.0 + R[0] - R[4] - R[8]) * 2;
+        q[0] = (R[7] - R[5]) / sq; q[1] = 0.25 * sq; q[2] = (R[1] + R[3]) / sq; q[3] = (R[2] + R[6]) / sq;
+    } else if (R[4] > R[8]) {
+        double sq = sqrt(1.0 + R[4] - R[0] - R[8]) * 2;
+        q[0] = (R[2] - R[6]) / sq; q[1] = (R[1] + R[3]) / sq; q[2] = 0.25 * sq; q[3] = (R[5] + R[7]) / sq;
+    } else {
+        double sq = sqrt(1.0 + R[8] - R[0] - R[4]) * 2;
+        q[0] = (R[3] - R[1]) / sq; q[1] = (R[2] + R[6]) / sq; q[2] = (R[5] + R[7]) / sq; q[3] = 0.25 * sq;
+    }
+    if (q[0] < 0) for (int i = 0; i < 4; i++) q[i] = -q[i];
 }
 /* dense Cholesky A = L L^T (lower, in place); returns 0 on success */
 static int chol(double *A, int n) {
@@ -679,7 +697,7 @@ OrModel *or_model_compile(const double *f, int n) {
     for (int k = 0; k < ne; k++) {
         const double *r = e0 + k * EQ_STRIDE;
         m->eq_type[k] = (int)r[0];
-        if (m->eq_type[k] != 1 && m->eq_type[k] != 3) { free(m); return NULL; }     /* connect and joint only */
+        if (m->eq_type[k] < 1 || m->eq_type[k] > 3) { free(m); return NULL; }
         m->eq_o1[k] = (int)r[1] + (m->eq_type[k] == 3 ? 0 : 1);        /* bodies: 0 = world; dofs: -1 = none */
         m->eq_o2[k] = (int)r[2] + (m->eq_type[k] == 3 ? 0 : 1);
         memcpy(m->eq_anchor[k][0], r + 3, 24);
@@ -828,11 +846,23 @@ static void set_const(OrModel *m) {
         for (int j = 0; j < nv; j++) acc += x[j] * y[j];
         m->tn_invweight0[t] = acc;
     }
-    /* equality constraints at qpos0 (MuJoCo's compiler): a connect's anchor as seen from body 2 */
+    /* equality constraints at qpos0 (MuJoCo's compiler): a connect's anchor as seen from body 2; a weld's shared point is
+     * body 2's origin (seen from body 1) and its relative orientation R1' R2 */
     for (int e = 0; e < m->neq; e++) {
-        if (m->eq_type[e] != 1) continue;
+        if (m->eq_type[e] == 3) continue;
         int b1 = m->eq_o1[e], b2 = m->eq_o2[e];
         double w1[3], d[3];
+        if (m->eq_type[e] == 2) {
+            for (int i = 0; i < 3; i++) d[i] = k.xpos[b2][i] - k.xpos[b1][i];
+            for (int i = 0; i < 3; i++)
+                m->eq_anchor[e][0][i] = k.xmat[b1][i] * d[0] + k.xmat[b1][3 + i] * d[1] + k.xmat[b1][6 + i] * d[2];
+            for (int i = 0; i < 3; i++)
+                for (int j = 0; j < 3; j++) {
+                    double sacc = 0;
+                    for (int c = 0; c < 3; c++) sacc += k.xmat[b1][3 * c + i] * k.xmat[b2][3 * c + j];
+                    m->eq_relR[e][3 * i + j] = sacc;
+                }
+        }
         matvec3(k.xmat[b1], m->eq_anchor[e][0], w1);
         for (int i = 0; i < 3; i++) d[i] = k.xpos[b1][i] + w1[i] - k.xpos[b2][i];
         for (int i = 0; i < 3; i++)
@@ -1196,7 +1226,7 @@ void or_step(OrModel *m, double *q, double *v, const double *ctrl, double *site_
     int kind[MAXC];
     int nc = 0;
     for (int e = 0; e < m->neq; e++) {
-        if (m->eq_type[e] == 1) {
+        if (m->eq_type[e] == 1 || m->eq_type[e] == 2) {
             /* connect: the anchor as a point of body 1 and as a point of body 2 coincide; rows along the world axes,
              * J = jacp(body 1, p1) - jacp(body 2, p2), diagApprox = the two bodies' translational invweight0 */
             int b1 = m->eq_o1[e], b2 = m->eq_o2[e];
@@ -1218,6 +1248,36 @@ void or_step(OrModel *m, double *q, double *v, const double *ctrl, double *site_
                 kind[nc] = ROW_EQ;
                 floss[nc] = 0;
                 nc++;
+            }
+            if (m->eq_type[e] == 2) {
+                /* weld, rotation (MuJoCo mj_instantiateEquality, mjEQ_WELD): the error quaternion inv(q2) q1 qrel is the
+                 * identity at qpos0; its vector part is the residual (three rows, in body 2's frame), its derivative
+                 * 1/2 inv(q2) (0, w1 - w2) q1 qrel the Jacobian: with (w, v) the error quaternion and u = R2' (jacr1 -
+                 * jacr2)_j, column j is 1/2 (w u + u x v).  diagApprox = the two bodies' ROTATIONAL invweight0. */
+                double E[9], T[9], R2t[9], qe[4], Jr1[3 * MAXV], Jr2[3 * MAXV], Jd[3 * MAXV];
+                for (int i = 0; i < 3; i++)
+                    for (int j = 0; j < 3; j++) R2t[3 * i + j] = k.xmat[b2][3 * j + i];
+                matmul3(R2t, k.xmat[b1], T);
+                matmul3(T, m->eq_relR[e], E);
+                mat2quat(E, qe);
+                jacobian(m, &k, b1, k.xpos[b1], Jd, Jr1);
+                jacobian(m, &k, b2, k.xpos[b2], Jd, Jr2);
+                for (int j = 0; j < nv; j++) {
+                    double dw[3] = {Jr1[j] - (b2 > 0 ? Jr2[j] : 0.0), Jr1[nv + j] - (b2 > 0 ? Jr2[nv + j] : 0.0),
+                                    Jr1[2 * nv + j] - (b2 > 0 ? Jr2[2 * nv + j] : 0.0)}, u[3], uxv[3];
+                    matvec3(R2t, dw, u);
+                    cross3(u, qe + 1, uxv);
+                    for (int i = 0; i < 3; i++) J[nc + i][j] = 0.5 * (qe[0] * u[i] + uxv[i]);
+                }
+                for (int i = 0; i < 3; i++) {
+                    double jv = 0;
+                    for (int j = 0; j < nv; j++) jv += J[nc][j] * v[j];
+                    row_params_set(m, m->eq_solref[e], m->eq_solimp[e], qe[1 + i], 0.0,
+                                   m->body_invweight0r[b1] + m->body_invweight0r[b2], jv, &D[nc], &aref[nc]);
+                    kind[nc] = ROW_EQ;
+                    floss[nc] = 0;
+                    nc++;
+                }
             }
         } else {
             /* joint: q1 - q1_0 = poly(q2 - q2_0) (qpos0 = 0 for hinge / slide joints) */
@@ -1453,6 +1513,7 @@ void or_get_invweight0(const OrModel *m, double *dof, double *body) {
     memcpy(dof, m->dof_invweight0, sizeof(double) * m->nv);
     memcpy(body, m->body_invweight0, sizeof(double) * m->nbody);
 }
+void or_get_invweight0_rot(const OrModel *m, double *body) { memcpy(body, m->body_invweight0r, sizeof(double) * m->nbody); }
 void or_get_newton_stats(const OrModel *m, long *out) {
     out[0] = m->newton_calls; out[1] = m->newton_iters; out[2] = m->newton_fail;
 }

@@ -78,7 +78,7 @@ def test_fused_step_against_the_oracle_16384x32(ref_arm):
     cov2 = cr.cem_shift_cov(cov1, 0.02, 0.5 * np.ones(A))
     np.testing.assert_allclose(c.cov_action, cov2, rtol=1e-9, atol=1e-12)
     # the finish launch drew step 2's raw samples with the new covariance's factor: the sampler kernel's stream
-    want = c.dev.sample_noise(P, c.cov_action, FILT, 7, 1, filtered=False)
+    want = c.dev.sample_noise(P, None, FILT, 7, 1, filtered=False)          # (factor of the device-resident covariance)
     torch.cuda.synchronize()
     assert torch.equal(next_raw, want)
     assert eng.solver_failures() == 0

@@ -350,7 +350,7 @@ def test_loader_refuses_what_is_not_modelled(tmp_path):
         ('<body name="a"><joint type="ball" limited="true" range="0 1"/><geom type="sphere" size="0.1"/><site name="finger"/></body>', "", "ball"),
         ('<body name="a"><joint/><geom type="cylinder" size="0.1 0.1"/><site name="finger"/></body>', "", "geom type"),
         ('<body name="a"><joint name="j"/><geom type="sphere" size="0.1"/><site name="finger"/></body>',
-         '<equality><weld body1="a"/></equality>', "weld"),
+         '<equality><distance geom1="a" geom2="b"/></equality>', "equality"),
         ('<body name="a"><joint name="j"/><geom type="sphere" size="0.1"/><site name="finger"/></body>',
          '<tendon><spatial/></tendon>', "fixed tendons"),
     ]:
@@ -379,3 +379,45 @@ def test_two_compilers_agree_on_the_synthetic_models(name):
     np.testing.assert_allclose(ref.qpos0, m.qpos0, rtol=0, atol=1e-15)
     st = start_state(name, raw)
     assert st["qp"].shape == (m.nq,) and st["qv"].shape == (m.nv,)
+
+
+WELDED = """
+<body name="a" pos="0 0 1" quat="0.9 0.1 0.2 -0.1"><freejoint/>
+  <geom type="box" size="0.1 0.06 0.03" density="600"/><site name="finger"/></body>
+<body name="b" pos="0.25 0.05 1.1" quat="0.7 -0.3 0.1 0.4"><freejoint/>
+  <geom type="capsule" fromto="0 0 0 0.1 0 0.05" size="0.03" density="900"/></body>
+<body name="arm" pos="-0.5 0 1"><joint name="h" type="hinge" axis="0 1 0" damping="0.01"/>
+  <geom type="capsule" fromto="0 0 0 0.3 0 0" size="0.02" density="500"/></body>"""
+WELDS = ('<equality><weld body1="a" body2="b" solref="0.005 1"/><weld body1="arm" solref="0.005 1"/></equality>'
+         '<actuator><motor joint="h" gear="1" ctrlrange="-1 1" ctrllimited="true"/></actuator>')
+
+
+def test_weld_keeps_the_relative_pose(tmp_path):
+    """Two free bodies welded to each other tumble as ONE rigid body (their relative pose at qpos0 is kept to a fraction
+    of a millimetre / milliradian while the pair falls and spins), and a pendulum welded to the world stays put."""
+    from mjmpc_amd.models.compile import _quat2mat
+    raw, ref = _model(tmp_path, WELDED, extra=WELDS, timestep="0.001")
+    m = compile_tree(raw)
+    assert m.general and (m.nv, m.nq) == (13, 15) and int(m.field("n_sphere")[0]) == 4      # two records per weld
+    np.testing.assert_allclose(ref.invweight0_rot()[1:], m.body_invweight0_rot, rtol=1e-10)
+    q, v = ref.qpos0.copy(), np.zeros(13)
+    v[0:6] = [0.3, 0.0, 0.5, 2.0, -1.0, 1.5]
+    v[6:12] = [0.3, 0.0, 0.5, 0.0, 0.0, 0.0]                    # (not consistent with a's spin: the weld pulls it along)
+
+    def rel(q):
+        Ra, Rb = _quat2mat(q[3:7]), _quat2mat(q[10:14])
+        return Ra.T @ (q[7:10] - q[0:3]), Ra.T @ Rb
+
+    p0, R0 = rel(q)
+    worst_p, worst_R = 0.0, 0.0
+    for k in range(600):
+        q, v, _, diag = ref.step(q, v, np.zeros(1))
+        if k > 100:                                             # (after the inconsistent start has been absorbed)
+            p, R = rel(q)
+            worst_p = max(worst_p, np.linalg.norm(p - p0))
+            worst_R = max(worst_R, np.linalg.norm(R - R0))
+    assert diag[0] == 12                                        # 2 welds x (3 + 3) rows
+    assert worst_p < 1e-3 and worst_R < 5e-3, (worst_p, worst_R)
+    assert abs(q[14]) < 2e-3                                    # the welded pendulum did not fall
+    assert q[2] < 1.0 - 0.5 * 9.81 * 0.6 ** 2 * 0.8            # ... while the pair did
+    assert ref.newton_stats()["fails"] == 0

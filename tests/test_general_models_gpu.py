@@ -213,3 +213,48 @@ def test_f32_general_instantiation_statistics(rig):
     err = np.abs(rew - o_rew) / np.maximum(1.0, np.abs(o_rew))
     print("%s f32: cost error median %.2e max %.2e, failures %d" % (name, np.median(err), err.max(), e32.solver_failures()))
     assert np.isfinite(rew).all() and np.median(err) < 1e-4 and err.max() < 5e-2
+
+
+def test_weld_equality_matches_oracle(tmp_path):
+    """<equality><weld>: two free bodies welded to each other and a pendulum welded to the world (tests/
+    test_general_models_cpu.py::WELDED): 12-link elimination paths on the dense 16-lane general instantiation, six
+    bilateral rows per weld - three at body 2's origin, three on the error quaternion's vector part.  One env step from 32
+    random states (relative pose perturbed: the rows pull) at 1e-9, a 64 x 10 rollout at 1e-8."""
+    from mjmpc_amd.envs.tree_engine import TreeRolloutEngine
+    from oracle.physics_ref import RefArm
+    import importlib.util, os
+    spec = importlib.util.spec_from_file_location("general_models_cpu", os.path.join(os.path.dirname(os.path.abspath(__file__)), "test_general_models_cpu.py"))
+    cpu = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(cpu)
+    WELDED, WELDS, _model = cpu.WELDED, cpu.WELDS, cpu._model
+    raw, ref = _model(tmp_path, WELDED, extra=WELDS, timestep="0.002", frame_skip=2)
+    eng = TreeRolloutEngine(raw, dtype="f64")
+    assert eng.model.general and eng.model.nv == 13 and eng.model.max_path == 12
+    rs = np.random.RandomState(4)
+    tgt = np.asarray(raw.target_pos, float)
+    worst = 0.0
+    for k in range(32):
+        q, v = raw.qpos0.copy(), np.zeros(13)
+        q[0:3] += 0.05 * rs.standard_normal(3)
+        q[3:7] = _quat_mul(q[3:7], _quat(rs, 0.5))
+        q[7:10] += 0.05 * rs.standard_normal(3) + 0.004 * rs.standard_normal(3)
+        q[10:14] = _quat_mul(q[10:14], _quat(rs, 0.02 if k % 2 else 0.5))
+        q[14] = 0.02 * rs.standard_normal()
+        v[:] = rs.standard_normal(13) * np.r_[0.3 * np.ones(3), 2 * np.ones(3), 0.3 * np.ones(3), 2 * np.ones(3), 1.0]
+        u = rs.uniform(-1, 1, 1)
+        eng.set_env_state(dict(qp=q, qv=v, target_pos=tgt))
+        _, rew, _, _, _, nobs = eng.rollout(1, 1, u[None], None, "open_loop")
+        q1, v1, r1, o1 = ref.env_step(q, v, u, tgt)
+        worst = max(worst, np.abs(nobs[0, 0] - o1).max() / max(1.0, np.abs(o1).max()), abs(rew[0, 0] - r1) / max(1.0, abs(r1)))
+    print("weld: one env step from 32 random states, worst relative error %.2e" % worst)
+    assert worst < 1e-9, worst
+    P, H = 64, 10
+    q, v = raw.qpos0.copy(), np.zeros(13)
+    v[0:6] = [0.3, 0.0, 0.5, 2.0, -1.0, 1.5]
+    eps = 0.5 * rs.standard_normal((P, H, 1))
+    eng.set_env_state(dict(qp=q, qv=v, target_pos=tgt))
+    obs, rew, act, done, info, nobs = eng.rollout(P, H, np.zeros((H, 1)), eps, "open_loop")
+    o_obs, o_rew, _, _, o_nobs = ref.rollout(q, v, tgt, np.zeros((H, 1)), eps)
+    np.testing.assert_allclose(rew, o_rew, rtol=1e-8, atol=1e-8)
+    np.testing.assert_allclose(nobs, o_nobs, rtol=0, atol=1e-7)
+    assert eng.solver_failures() == 0 and ref.newton_stats()["fails"] == 0
