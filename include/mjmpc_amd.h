@@ -177,13 +177,13 @@ int mjmpc_arm_step_state(mjmpc_arm_t h, int dtype, const double* d_action, void*
  *   k | distance << 8 | height << 16, -1 ends)
  * Same call shapes and reference counterparts as the arm engine (subproc_vec_env.py:91-111, 128-186, 235-251);
  * target_pos is ignored by task 1.                                                                                  */
-#define MJMPC_TREE_BLOB_LEN 3606
+#define MJMPC_TREE_BLOB_LEN 3638
 /* Round 4, the GENERAL instantiation (block field `gen`; models without these features run the earlier kernels unchanged):
  * ball and free joints (quaternion links: qpos has nq >= nv entries in MuJoCo's layout, d_obs = nq + nv + 6 or nq + nv -
  * obs_skip), joint anchors off the body origin, explicit inertials, box geoms (eight corner points against the plane, one
  * point against a sphere), static geoms of the world body (link -1), friction-loss rows (dof_frictionloss), connect and
  * joint equalities, limits of fixed tendons over one or two joints.  The block then continues
- *   gen nq has_ball fsol_{K,B,dmin,dmax,width,mid,power} frictionloss[32] qadr[32] qoff[32] pext[16][24]
+ *   gen nq has_ball fsol_{K,B,dmin,dmax,width,mid,power} frictionloss[32] qadr[32] qoff[32] pext[16][24] qw0[32]
  * (pext: what the new record kinds need beyond spheres[.][24]; layout in csrc/tree_model.h). */
 /* A state vector as the C ABI takes it (mjmpc_tree_set_shard_states): MuJoCo's layout, qpos[40] (nq entries used) |
  * qvel[32] | target_pos[3] | 3 reserved (float64). */

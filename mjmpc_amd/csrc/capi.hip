@@ -487,10 +487,13 @@ static void tree_pack_state(const mjmpc_tree_s* h, const double* qpos, const dou
         const int kind = (int)b[mjmpc::T_JTYPE + l], adr = (int)b[mjmpc::T_QADR + l];
         st[mjmpc::TREE_QW + l] = 1.0;
         if (kind == mjmpc::LINK_BALL_X) {
-            st[mjmpc::TREE_QW + l] = qpos[adr];
-            st[l] = qpos[adr + 1];
-            st[l + 1] = qpos[adr + 2];
-            st[l + 2] = qpos[adr + 3];
+            // the device quaternion is relative to the qpos0 pose: q_link = conj(q0) * qpos (a free joint's qpos is absolute)
+            const double w0 = b[mjmpc::T_QW0 + l], x0 = -b[mjmpc::T_QOFF + l], y0 = -b[mjmpc::T_QOFF + l + 1], z0 = -b[mjmpc::T_QOFF + l + 2];
+            const double w = qpos[adr], x = qpos[adr + 1], y = qpos[adr + 2], z = qpos[adr + 3];
+            st[mjmpc::TREE_QW + l] = w0 * w - x0 * x - y0 * y - z0 * z;
+            st[l] = w0 * x + x0 * w + y0 * z - z0 * y;
+            st[l + 1] = w0 * y - x0 * z + y0 * w + z0 * x;
+            st[l + 2] = w0 * z + x0 * y - y0 * x + z0 * w;
         } else if (kind <= mjmpc::LINK_SLIDE) {
             st[l] = qpos[adr] - b[mjmpc::T_QOFF + l];
         }
@@ -502,11 +505,13 @@ static void tree_unpack_state(const mjmpc_tree_s* h, const double* st, double* q
     const double* b = h->topo.data();
     for (int l = 0; l < h->nv; ++l) {
         const int kind = (int)b[mjmpc::T_JTYPE + l], adr = (int)b[mjmpc::T_QADR + l];
-        if (kind == mjmpc::LINK_BALL_X) {
-            qpos[adr] = st[mjmpc::TREE_QW + l];
-            qpos[adr + 1] = st[l];
-            qpos[adr + 2] = st[l + 1];
-            qpos[adr + 3] = st[l + 2];
+        if (kind == mjmpc::LINK_BALL_X) {          // qpos = q0 * q_link
+            const double w0 = b[mjmpc::T_QW0 + l], x0 = b[mjmpc::T_QOFF + l], y0 = b[mjmpc::T_QOFF + l + 1], z0 = b[mjmpc::T_QOFF + l + 2];
+            const double w = st[mjmpc::TREE_QW + l], x = st[l], y = st[l + 1], z = st[l + 2];
+            qpos[adr] = w0 * w - x0 * x - y0 * y - z0 * z;
+            qpos[adr + 1] = w0 * x + x0 * w + y0 * z - z0 * y;
+            qpos[adr + 2] = w0 * y - x0 * z + y0 * w + z0 * x;
+            qpos[adr + 3] = w0 * z + x0 * y - y0 * x + z0 * w;
         } else if (kind <= mjmpc::LINK_SLIDE) {
             qpos[adr] = st[l] + b[mjmpc::T_QOFF + l];
         }
@@ -530,7 +535,7 @@ static bool tree_same_topology(const double* a, const double* b) {
            same(mjmpc::T_JTYPE, mjmpc::TL) && same(mjmpc::T_ACT, mjmpc::TL) && same(mjmpc::T_DEPTH, mjmpc::TL) &&
            same(mjmpc::T_N_ROUNDS, 1) && same(mjmpc::T_ELIM, (mjmpc::TL - 1) * mjmpc::TL) && same(mjmpc::T_NV, 1) &&
            same(mjmpc::T_NU, 1) && same(mjmpc::T_TASK, 1) && same(mjmpc::T_OBS_SKIP, 1) && same(mjmpc::T_JUMPS, 1) &&
-           same(mjmpc::T_NQ, 1) && same(mjmpc::T_QADR, mjmpc::TL) && same(mjmpc::T_HAS_BALL, 1);
+           same(mjmpc::T_NQ, 1) && same(mjmpc::T_QADR, mjmpc::TL) && same(mjmpc::T_HAS_BALL, 1) && same(mjmpc::T_QW0, mjmpc::TL);
 }
 
 static int tree_create_impl(mjmpc_tree_s* h, const double* blob, int n_blob) {

@@ -98,7 +98,10 @@ enum TreeOffset : int {
     T_QADR = T_FRICTIONLOSS + TL,       // 32: the link's entry in qpos (BALL_X link: the quaternion's w); -1: none
     T_QOFF = T_QADR + TL,               // 32: added to the link's coordinate in qpos (free joint translations: the body position)
     T_PEXT = T_QOFF + TL,               // TREE_MAX_SPHERES x TREE_PEXT_STRIDE: what the new record kinds need beyond [24]
-    TREE_BLOB_LEN = T_PEXT + TREE_MAX_SPHERES * 24
+    T_QW0 = T_PEXT + TREE_MAX_SPHERES * 24,     // 32: BALL_X links: w of the joint's qpos0 quaternion q0 (x, y, z in the three
+                                        // links' T_QOFF): identity for a ball joint, the body's orientation for a free
+                                        // joint, whose qpos quaternion is ABSOLUTE - the kernel's is relative, qpos = q0 * q_link
+    TREE_BLOB_LEN = T_QW0 + TL
 };
 constexpr int TREE_PEXT_STRIDE = 24;    // [0:3] box half sizes, [3:12] box orientation in its link's frame | dof row: [0] 0 joint
                                         // equality / 1 tendon limit, [1] coef A (joint equality: 1 = anchor dof is joint 2),
@@ -118,6 +121,6 @@ constexpr int TREE_QW = 2 * TL + 6;
 constexpr int TREE_NQ_MAX = 40;
 // the C ABI's state vectors (mjmpc_tree_set_shard_states): MuJoCo's layout - qpos[40] | qvel[32] | target[3] | reserved[3]
 constexpr int TREE_PUBLIC_STATE_LEN = TREE_NQ_MAX + TL + 6;
-static_assert(TREE_BLOB_LEN == 3606, "keep in sync with mjmpc_amd/models/compile_tree.py::TREE_LAYOUT");
+static_assert(TREE_BLOB_LEN == 3638, "keep in sync with mjmpc_amd/models/compile_tree.py::TREE_LAYOUT");
 
 }  // namespace mjmpc

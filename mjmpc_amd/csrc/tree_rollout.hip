@@ -1007,6 +1007,9 @@ __global__ __launch_bounds__(64 * wg_waves(DP, FRIC, sizeof(T), PL), min_waves(s
     const bool has_ball = GEN && __builtin_amdgcn_readfirstlane((int)model[T_HAS_BALL]) != 0;
     const int qadr = GEN ? (int)model[T_QADR + l] : l;
     const T qoff = GEN ? model[T_QOFF + l] : T(0);
+    // (BALL_X links) the joint's qpos0 quaternion q0: MuJoCo's qpos = q0 * (the link's quaternion, relative to the qpos0 pose)
+    const T q0w = (GEN && ball_g == 0) ? model[T_QW0 + l] : T(1);
+    const T q0y = (GEN && ball_g == 0) ? model[T_QOFF + l + 1] : T(0), q0z = (GEN && ball_g == 0) ? model[T_QOFF + l + 2] : T(0);
     const T floss = (GEN && dof) ? model[T_FRICTIONLOSS + l] : T(0);            // dry friction of my dof (0: no row)
     const bool any_floss = GEN && __any(floss > T(0));
     T fsol[7];                                                                  // friction-loss rows' solver set
@@ -2273,10 +2276,11 @@ __global__ __launch_bounds__(64 * wg_waves(DP, FRIC, sizeof(T), PL), min_waves(s
         auto put_q = [&](T* dst, long o, int skip, T x_, T y_, T z_, T w_) {
             if (!dof || qadr < skip) return;
             if (GEN && ball_g == 0) {
-                dst[o + qadr - skip] = w_;
-                dst[o + qadr - skip + 1] = x_;
-                dst[o + qadr - skip + 2] = y_;
-                dst[o + qadr - skip + 3] = z_;
+                const T x0 = qoff;
+                dst[o + qadr - skip] = q0w * w_ - x0 * x_ - q0y * y_ - q0z * z_;
+                dst[o + qadr - skip + 1] = q0w * x_ + x0 * w_ + q0y * z_ - q0z * y_;
+                dst[o + qadr - skip + 2] = q0w * y_ - x0 * z_ + q0y * w_ + q0z * x_;
+                dst[o + qadr - skip + 3] = q0w * z_ + x0 * y_ - q0y * x_ + q0z * w_;
             } else if (!GEN || ball_g < 0) {
                 dst[o + qadr - skip] = x_ + qoff;
             }

@@ -71,8 +71,11 @@ TREE_LAYOUT = [
     ("fsol_K", 1), ("fsol_B", 1), ("fsol_dmin", 1), ("fsol_dmax", 1), ("fsol_width", 1), ("fsol_mid", 1), ("fsol_power", 1),
     ("frictionloss", TL),           # per dof: dry friction (one friction-loss row each)
     ("qadr", TL),                   # the link's entry in MuJoCo's qpos (ball: the quaternion's w, on the BALL_X link; -1: none)
-    ("qoff", TL),                   # added to the link's coordinate in qpos (a free joint's translations: the body position)
+    ("qoff", TL),                   # added to the link's coordinate in qpos (a free joint's translations: the body position);
+                                    # on a quaternion's three links: x, y, z of the joint's qpos0 quaternion (see qw0)
     ("pext", TREE_MAX_SPHERES * PEXT_STRIDE),
+    ("qw0", TL),                    # BALL_X links: w of qpos0's quaternion q0 (ball joint: 1, 0, 0, 0; free joint: the body's
+                                    # orientation).  The kernel's quaternion is RELATIVE to the qpos0 pose: qpos = q0 * q_link
 ]
 TREE_BLOB_LEN = sum(n for _, n in TREE_LAYOUT)
 TREE_STATE_LEN = 3 * TL + 6           # device: qpos[32] | qvel[32] | target_pos[3] | fresh site[3] | quaternion w[32], per LINK
@@ -383,6 +386,13 @@ def compile_tree(raw: RawModel, overrides=None, base: "TreeModel" = None) -> Tre
             qadr[li] = nq_here + k_in if k_in < 3 else (nq_here + 3 if k_in == 3 else -1)
             if k_in < 3:
                 f["qoff"][li] = p0[bj][k_in]
+            else:                                   # a free joint's quaternion is the body's ABSOLUTE orientation
+                bq = np.asarray(raw.bodies[bj].quat, float) / np.linalg.norm(raw.bodies[bj].quat)
+                f["qoff"][li] = bq[1 + k_in - 3]
+                if k_in == 3:
+                    f["qw0"][li] = bq[0]
+        if jt.type == JOINT_BALL and k_in == 0:
+            f["qw0"][li] = 1.0
         if raw.density > 0 or raw.viscosity > 0:
             # MuJoCo's fluid model acts body by body on the box of equal inertia, in the body's inertial frame
             massive = [i for i in members if mass[i] > 0]
