@@ -135,6 +135,16 @@ int mjmpc_arm_mppi_step(mjmpc_arm_t h, int dtype, int64_t P, int H, const double
                         int shift_mode, double* d_action_out, double* h_action_slots, double* d_record, int env_step,
                         void* d_step_cost, void* d_step_next_obs, void* d_costs, void* d_actions, double* d_q0, void* stream);
 
+/* The rollout of mjmpc_arm_mppi_step on its own, for updates other than MPPI's (CEM: cem.py:65-95): the kernel draws its
+ * samples itself - the Philox stream of mjmpc_sample_noise keyed by (seed, offset + *d_step_counter, particle_offset +
+ * particle, channel, t), coloured by d_chol (chol_full != 0: the whole lower triangle, an adapting full covariance; 0: its
+ * diagonal) and filtered by d_filter_coeffs (NULL: none) - and writes costs [P][H] (optional), actions [P][H][A] (optional)
+ * and d_q0 float64 [P] = sum_t gseq[t] cost[p][t] (optional).  Graph-capture rule as mjmpc_arm_mppi_step. */
+int mjmpc_arm_rollout_sampled(mjmpc_arm_t h, int dtype, int64_t P, int H, const double* d_mean, const double* d_gseq,
+                              const double* d_filter_coeffs, const double* d_chol, int chol_full, uint64_t seed, uint64_t offset,
+                              int64_t particle_offset, const int64_t* d_step_counter, void* d_costs, void* d_actions,
+                              double* d_q0, void* stream);
+
 /* Sharded runs (one rank per GPU): what follows the all-gather of the per-GPU records that mjmpc_arm_mppi_step left
  * (d_record != NULL) - ONE launch that merges the n_records gathered records [max | S | W[H*A]] in rank order (bit-identical
  * on every rank), updates the mean (mppi.py:69-82) into d_mean_out (a buffer of its own) already shifted

@@ -273,6 +273,19 @@ class DeviceUpdater:
         _lib.check(self.lib.mjmpc_cem_combine(_vp(recs), G, self.H, self.A, float(num_elite), int(full_cov),
                                               float(step_size), _vp(self.mean), _vp(self.cov), self.stream()))
 
+    def factor_cov(self, filter_coeffs):
+        """Lower Cholesky factor of the device-resident covariance into the ``chol`` record, and the filter coefficients
+        into theirs (what ``sample_noise(cov=None)`` sets up before it draws)."""
+        torch = self.torch
+        chol = self.record("chol", self.A * self.A)
+        _lib.check(self.lib.mjmpc_cholesky_lower(_vp(self.cov), self.A, _vp(chol), _vp(self.chol_status), self.stream()))
+        fc = np.asarray(filter_coeffs, np.float64)
+        cached = self._rec.get("noise_params")
+        if cached is None or cached[0] is not None or not np.array_equal(cached[1], fc):
+            self.record("coeffs", 3).copy_(torch.from_numpy(fc.copy()))
+            self._rec["noise_params"] = (None, fc.copy())
+        return chol
+
     def cem_fused_supported(self, P, num_elite):
         """The two-launch CEM step (``cem_fused_step``) covers this shape (A <= 8, P x world <= 32768, ...)."""
         return bool(self.lib.mjmpc_cem_fused_supported(P * self.comm.world_size, P, int(num_elite), self.H, self.A))

@@ -411,7 +411,17 @@ class OLGaussianMPC(Controller):
     def _noise_ahead(self):
         """Captured fused iterations with the Philox sampler draw the next step's samples inside the update."""
         return ((not self._mono) and self._graph_on and self.noise_mode == 'device'
-                and (self._fused_capable() or self._cem_fused()))
+                and (self._fused_capable() or (self._cem_fused() and not self._cem_in_kernel())))
+
+    def _cem_in_kernel(self):
+        """The fused CEM step on launches the engine can sample for itself (``rollout_fn.sampled``: at most one wavefront
+        per SIMD pair, as the one-launch MPPI iteration): no sample buffer at all - the rollout kernel colours its own
+        Philox draws with the factor the finish launch of the previous step left on the device."""
+        eng = getattr(self._rollout_fn, "engine", None)
+        return (self._cem_fused() and getattr(self, "_want_cem_in_kernel", True) and hasattr(self._rollout_fn, "sampled")
+                and hasattr(eng, "mppi_step_supported") and eng.mppi_step_supported(self.local_particles, self.horizon)
+                and getattr(eng, "num_shards", 1) == 1 and not getattr(eng, "_per_shard_states", False)
+                and not hasattr(eng, "shard_blobs") and getattr(eng, "dtype", self.noise_dtype) == self.noise_dtype)
 
     def _cem_fused(self):
         return False            # CEM overrides: selection + moments and refit + tail + next samples, two launches
@@ -472,11 +482,21 @@ class OLGaussianMPC(Controller):
             # CEM (cem.py:65-95) beside the rollout in TWO launches: selection + elite list + moments, then refit + covariance
             # growth + Cholesky factor + action + shift + step counter + the raw samples of the NEXT step, drawn with the new
             # factor into the buffer this step's rollout has finished reading
-            raw = self.dev._rec[("noise", self.noise_dtype)]
-            costs, actions, q0 = self._rollout_fn.fused(n_loc, self.horizon, self.dev.mean, raw, self.dev.record("coeffs", 3),
-                                                        self.dev.gseq, **self._q0_kw(n_loc))
-            if self._q0_kw(n_loc) == {}:
-                self.dev._take_q0(self.dev.workspace(n_loc), n_loc, q0)
+            in_kernel = self._cem_in_kernel()
+            if in_kernel:
+                fc = np.asarray(self.filter_coeffs, np.float64)
+                coeffs = None if (fc[0] == 1.0 and fc[1] == 0.0 and fc[2] == 0.0) else self.dev.record("coeffs", 3)
+                costs, actions, q0 = self._rollout_fn.sampled(n_loc, self.horizon, self.dev.mean, self.dev.gseq, coeffs,
+                                                              self.dev.record("chol", self.d_action * self.d_action), True,
+                                                              self.seed_val, 0, self.dev.comm.rank * n_loc, self._step_dev,
+                                                              q0_out=self.dev.q0_destination(n_loc))
+                raw = None
+            else:
+                raw = self.dev._rec[("noise", self.noise_dtype)]
+                costs, actions, q0 = self._rollout_fn.fused(n_loc, self.horizon, self.dev.mean, raw, self.dev.record("coeffs", 3),
+                                                            self.dev.gseq, **self._q0_kw(n_loc))
+                if self._q0_kw(n_loc) == {}:
+                    self.dev._take_q0(self.dev.workspace(n_loc), n_loc, q0)
             self.dev.cem_fused_step(actions, self.num_elite, self.step_size, self.cov_type == 'full',
                                     _SHIFT_MODES[self.base_action], self._action_dev, self._action_pin, self._step_dev,
                                     self._shift_cov_args(), raw, self.seed_val, self.dev.comm.rank * n_loc)
@@ -552,6 +572,9 @@ class OLGaussianMPC(Controller):
         if self._noise_ahead() and not self._noise_valid:
             self._draw_raw(self.local_particles, 0)             # the current step's samples (first step / after a jump)
             self._noise_valid = True
+        if self._cem_in_kernel() and not self._noise_valid:
+            self.dev.factor_cov(self.filter_coeffs)             # the factor the first rollout colours its draws with
+            self._noise_valid = True
         replay = self._device_iteration if self._graph == "direct" else self._graph.replay
         if self._ahead == 0:
             self._action_np[self._slot(self.num_steps) + self.d_action] = -1.0      # completion flag (see _wait_action)
@@ -586,6 +609,8 @@ class OLGaussianMPC(Controller):
         with torch.cuda.stream(side):
             if self._noise_ahead():
                 self._draw_raw(self.local_particles, 0)     # buffer + sampler parameters for the dry run
+            if self._cem_in_kernel():
+                self.dev.factor_cov(self.filter_coeffs)
             self._device_iteration()
         torch.cuda.current_stream(self.dev.device).wait_stream(side)
         torch.cuda.synchronize(self.dev.device)

@@ -30,6 +30,8 @@ struct MonoStep {
     // sampler: eps_raw[p][t][a] = chol[a][a] z(seed, offset + *d_step, p + particle_offset, a, t) - the Philox draws of
     // noise.hip's noise_kernel for a DIAGONAL covariance, made by the lane that consumes them
     const double* chol = nullptr;           // device [A][A]
+    int chol_full = 0;                      // 1: the whole lower triangle colours the draws (eps[a] = sum_{b <= a} chol[a][b] z_b,
+                                            // noise_full_kernel's stream: CEM's adapting covariance), 0: its diagonal
     unsigned long long seed = 0, offset = 0;
     long particle_offset = 0;
     const long long* d_step = nullptr;

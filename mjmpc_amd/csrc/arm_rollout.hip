@@ -1267,9 +1267,14 @@ __global__ __launch_bounds__(DUO ? 128 : 64) __attribute__((amdgpu_waves_per_eu(
     // substep, in the DYN wave's slack, and a global load per env step - even a cache hit - outlasted that slack:
     // hoisting them costs 16 AGPRs and 1.5 us less per launch)
     double chol_h = 0.0;
+    double chol_row[LANES - 1];             // full covariance: my row of the factor (entries b <= l8)
+    bool chol_full = false;
     unsigned long long seed_h = 0ull, off_h = 0ull, key_h = 0ull;
     if constexpr (MONO) {
+        chol_full = mop->chol_full != 0;
         if (sampled) chol_h = mop->chol[l8 * A + l8];
+#pragma unroll
+        for (int b = 0; b < LANES - 1; ++b) chol_row[b] = (chol_full && sampled && b <= l8 && b < A) ? mop->chol[l8 * A + b] : 0.0;
         seed_h = mop->seed;
         off_h = mop->offset + (mop->d_step ? (unsigned long long)*mop->d_step : 0ull);
         key_h = (unsigned long long)((pid + mop->particle_offset) * A + l8);
@@ -1279,24 +1284,40 @@ __global__ __launch_bounds__(DUO ? 128 : 64) __attribute__((amdgpu_waves_per_eu(
         return T(0.25);
 #endif
         const double chol_aa = chol_h;
-        float z;
-        if (!(t & 3)) {
-            float q4[4];
-            normal_quad(seed_h, off_h, key_h, (unsigned)(t >> 2), q4);
-            z = q4[0];
-            z_keep[0] = q4[1];
-            z_keep[1] = q4[2];
-            z_keep[2] = q4[3];
-        } else {
-            z = (t & 3) == 1 ? z_keep[0] : ((t & 3) == 2 ? z_keep[1] : z_keep[2]);
+        float z = 0.0f;
+        if (sampled) {
+            if (!(t & 3)) {
+                float q4[4];
+                normal_quad(seed_h, off_h, key_h, (unsigned)(t >> 2), q4);
+                z = q4[0];
+                z_keep[0] = q4[1];
+                z_keep[1] = q4[2];
+                z_keep[2] = q4[3];
+            } else {
+                z = (t & 3) == 1 ? z_keep[0] : ((t & 3) == 2 ? z_keep[1] : z_keep[2]);
+            }
+        }
+        if (chol_full) {
+            // eps[a] = sum_{b <= a} L[a][b] z_b in noise_full_kernel's order: the channels' normals by DPP broadcast inside
+            // the particle's 8 lanes (every lane takes part: the broadcasts run outside the `sampled` branch)
+            double x = 0.0;
+            float zb;
+            zb = bcast<0>(z); if (chol_row[0] != 0.0) x += chol_row[0] * (double)zb;
+            zb = bcast<1>(z); if (chol_row[1] != 0.0) x += chol_row[1] * (double)zb;
+            zb = bcast<2>(z); if (chol_row[2] != 0.0) x += chol_row[2] * (double)zb;
+            zb = bcast<3>(z); if (chol_row[3] != 0.0) x += chol_row[3] * (double)zb;
+            zb = bcast<4>(z); if (chol_row[4] != 0.0) x += chol_row[4] * (double)zb;
+            zb = bcast<5>(z); if (chol_row[5] != 0.0) x += chol_row[5] * (double)zb;
+            zb = bcast<6>(z); if (chol_row[6] != 0.0) x += chol_row[6] * (double)zb;
+            return (T)x;
         }
         return (T)(chol_aa * (double)z);
     };
     if (has_u && H > 0) {
         if constexpr (!CL) mean_next = mean[l8];
-        if constexpr (MONO) { if (sampled) eps_next = draw(0); }
-        else if (noise && live) eps_next = noise[(pid * H) * A + l8];
+        if constexpr (!MONO) { if (noise && live) eps_next = noise[(pid * H) * A + l8]; }
     }
+    if constexpr (MONO) { if (H > 0) { const T e0 = draw(0); if (sampled) eps_next = e0; } }    // (every lane: DPP broadcasts)
 
     for (int t = 0; t < H; ++t) {
         T u = T(0);
@@ -1355,7 +1376,7 @@ __global__ __launch_bounds__(DUO ? 128 : 64) __attribute__((amdgpu_waves_per_eu(
         if (live && l8 == 0 && (!MONO || cost)) cost[pid * H + t] = cst;
         if (fuse.gseq) q0acc += gs_cur * (double)cst;
         // MONO: the next step's sample, drawn while the SOLVE wave is still iterating (DUO) / once per env step (SOLO)
-        if constexpr (MONO) { if (sampled && t + 1 < H) eps_next = draw(t + 1); }
+        if constexpr (MONO) { if (t + 1 < H) { const T en = draw(t + 1); if (sampled) eps_next = en; } }
         if constexpr (R == DYN) arm_back<R>(M, q, v, aw, sinq, cosq, ldsM, l8, fs, ST);
         if (live && (obs || nobs)) {
             const long o = (pid * H + t) * dobs;

@@ -392,6 +392,55 @@ int mjmpc_arm_mppi_step(mjmpc_arm_t h, int dtype, int64_t P, int H, const double
     return 0;
 }
 
+int mjmpc_arm_rollout_sampled(mjmpc_arm_t h, int dtype, int64_t P, int H, const double* d_mean, const double* d_gseq,
+                              const double* d_filter_coeffs, const double* d_chol, int chol_full, uint64_t seed, uint64_t offset,
+                              int64_t particle_offset, const int64_t* d_step_counter, void* d_costs, void* d_actions,
+                              double* d_q0, void* stream) {
+    if (!h || !d_mean || !d_gseq || !d_chol) return fail(MJMPC_E_BADARG, "null argument");
+    if (P < 1 || H < 1) return fail(MJMPC_E_BADARG, "P and H must be positive");
+    if (h->n_shards > 1 || h->n_state_shards > 1)
+        return fail(MJMPC_E_BADARG, "sampled rollouts run one model and one start state (no per-shard blocks)");
+    HIP_TRY(hipSetDevice(h->device));
+    hipStream_t s = (hipStream_t)stream;
+    const long groups = mjmpc::arm_rollout_groups((long)P);
+    const size_t need = (size_t)mjmpc::mono_record_doubles(groups, H, h->nu);      // (the launch also leaves its softmax partials)
+    if (need > h->mono_cap) {
+        hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+        if (hipStreamIsCapturing(s, &cs) == hipSuccess && cs != hipStreamCaptureStatusNone)
+            return fail(MJMPC_E_BADARG, "the record buffer must grow for this (P, H): call once outside stream capture first");
+        double* bigger = nullptr;
+        HIP_TRY(hipMalloc(&bigger, sizeof(double) * need));
+        if (h->mono_tree) h->mono_retired.push_back(h->mono_tree);
+        h->mono_tree = bigger;
+        h->mono_cap = need;
+    }
+    mjmpc::MonoStep mo;
+    mo.chol = d_chol;
+    mo.chol_full = chol_full ? 1 : 0;
+    mo.seed = seed;
+    mo.offset = offset;
+    mo.particle_offset = (long)particle_offset;
+    mo.d_step = (const long long*)d_step_counter;
+    mo.lam = 1.0;
+    mo.shift_mode = -2;
+    mo.tree = h->mono_tree;
+    mjmpc::RolloutFusion fuse;
+    fuse.filt = d_filter_coeffs;
+    fuse.gseq = d_gseq;
+    fuse.q0_out = d_q0;
+    hipError_t e;
+    if (dtype == MJMPC_F32)
+        e = mjmpc::launch_arm_rollout<float>(h->model_f32, h->state, (long)P, H, h->nu, d_mean, nullptr, (float*)d_costs,
+                                             (float*)d_actions, nullptr, nullptr, nullptr, h->diag, s, fuse, &mo);
+    else if (dtype == MJMPC_F64)
+        e = mjmpc::launch_arm_rollout<double>(h->model_f64, h->state, (long)P, H, h->nu, d_mean, nullptr, (double*)d_costs,
+                                              (double*)d_actions, nullptr, nullptr, nullptr, h->diag, s, fuse, &mo);
+    else
+        return fail(MJMPC_E_BADARG, "unknown dtype %d", dtype);
+    if (e != hipSuccess) return hip_fail(e, "arm_rollout_sampled launch");
+    return 0;
+}
+
 int mjmpc_arm_mppi_combine(mjmpc_arm_t h, int dtype, const double* d_records, int n_records, int H, const double* d_mean,
                            double* d_mean_out, int64_t* d_step_counter, double step_size, int shift_mode,
                            double* d_action_out, double* h_action_slots, int env_step, void* d_step_cost,

@@ -45,6 +45,10 @@ namespace mjmpc {
 namespace {
 
 constexpr int TREE_MAXIT = 16;
+// the friction instantiations' safeguarded iteration (exact line search from iteration LS_START on: MuJoCo's Newton method
+// proper, which terminates - a finite number of active sets, a strictly decreasing convex cost) may run on to MuJoCo's own
+// cap: round 3 stopped it at 16 and counted a handful of particle-substeps per 10^8 on the pen-in-hand model as failures
+constexpr int TREE_MAXIT_LS = 100;
 #ifndef TREE_DPP_SUBTREE
 #define TREE_DPP_SUBTREE 1
 #endif
@@ -1950,7 +1954,7 @@ __global__ __launch_bounds__(64 * wg_waves(DP, FRIC, sizeof(T), PL), min_waves(s
                 for (int r = 0; r < NR; ++r) rb[r] = T(0);
                 T xa = T(0);
                 clk.lap(-1);
-                for (int it = 0; it < TREE_MAXIT; ++it) {
+                for (int it = 0; it < (FRIC ? TREE_MAXIT_LS : TREE_MAXIT); ++it) {
                     T hrow[DP];
                     T hd[DN > 0 ? DN : 1], hdinv = T(1);        // DN > 0: my dense row of H, then of its factor
                     const T Dfq = (GEN && fstate == 0) ? Df : T(0);     // the friction-loss row in its quadratic zone

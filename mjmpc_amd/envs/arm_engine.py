@@ -249,6 +249,26 @@ class ArmRolloutEngine:
         lds = 8 * (32 + 8 * int(horizon) * self.d_action * (8 if self.dtype == "f64" else 4) // 8)
         return 2 * groups <= simds and lds <= 40 * 1024
 
+    def rollout_sampled(self, num_particles, horizon, mean, gamma_seq, filter_coeffs, chol, chol_full, seed, offset,
+                        particle_offset, step_counter, q0_out=None):
+        """A rollout whose samples are drawn in the kernel (``mjmpc_arm_rollout_sampled``): the Philox stream of
+        ``DeviceUpdater.sample_noise``, coloured by the device-resident factor ``chol`` (``chol_full``: its whole lower
+        triangle - CEM's adapting covariance), filtered on the fly.  Returns (costs, actions, q0) device tensors; nothing
+        but the model, the state, the mean and the factor is read from memory."""
+        torch = _torch()
+        P, H, A = int(num_particles), int(horizon), self.d_action
+        costs, act = self._buffer("costs", (P, H)), self._buffer("act", (P, H, A))
+        q0 = q0_out
+        if q0 is None:
+            q0 = self._buf.get("q0")
+            if q0 is None or q0.shape[0] != P:
+                q0 = self._buf["q0"] = torch.empty(P, dtype=torch.float64, device=self.device)
+        _lib.check(self._lib.mjmpc_arm_rollout_sampled(self._h, self._code, P, H, _ptr(mean), _ptr(gamma_seq), _ptr(filter_coeffs),
+                                                       _ptr(chol), int(bool(chol_full)), int(seed) & (2 ** 64 - 1), int(offset),
+                                                       int(particle_offset), _ptr(step_counter), _ptr(costs), _ptr(act), _ptr(q0),
+                                                       self._stream()))
+        return costs, act, q0
+
     def mppi_step(self, num_particles, horizon, mean, mean_out, gamma_seq, filter_coeffs, chol, seed, offset,
                   particle_offset, step_counter, lam, step_size, shift_mode, action_out=None, action_slots=None, record=None,
                   env_step=False, want_trajectories=False):
@@ -370,6 +390,7 @@ def make_device_rollout_fn(sim_env):
         rollout_fn.fused = sim_env.rollout_fused
     if hasattr(sim_env, "mppi_step"):       # the whole iteration in one launch (captured iterations of MPPI / DMD-MPC)
         rollout_fn.mono = sim_env.mppi_step
+        rollout_fn.sampled = sim_env.rollout_sampled     # rollouts that draw their own samples (any update that reads q0 / actions)
         rollout_fn.mono_launcher = sim_env.mppi_step_launcher
         rollout_fn.combine_launcher = sim_env.mppi_combine_launcher
     return rollout_fn

@@ -15,7 +15,7 @@ MOVING = dict(qp=np.array([0.3, 0.5, -0.2, -1.0, 0.4, -0.6, 0.2]), qv=np.array([
               qa=np.zeros(7), target_pos=np.array([-0.25, 0.15, 0.2]), timestep=0)
 
 
-def _cem(eng, P, H, cov_type, fused, elite_frac=0.1, seed=7, step_size=0.8, beta=0.02, base="null"):
+def _cem(eng, P, H, cov_type, fused, elite_frac=0.1, seed=7, step_size=0.8, beta=0.02, base="null", in_kernel=True):
     from mjmpc_amd.control import CEM
     from mjmpc_amd.envs.arm_engine import make_device_rollout_fn
     c = CEM(d_state=eng.d_state, d_obs=eng.d_obs, d_action=7, horizon=H, init_cov=0.5, base_action=base,
@@ -25,6 +25,7 @@ def _cem(eng, P, H, cov_type, fused, elite_frac=0.1, seed=7, step_size=0.8, beta
     c.rollout_fn = make_device_rollout_fn(eng)
     c.set_sim_state_fn = lambda s: None
     c._want_cem_fused = fused
+    c._want_cem_in_kernel = in_kernel
     c.enable_graph(post_step=eng.step_state)
     return c
 
@@ -115,3 +116,19 @@ def test_fused_step_degenerate_populations():
         assert int(step.item()) == 5
         L = dev._rec["chol"].cpu().numpy().reshape(A, A)
         np.testing.assert_allclose(L @ L.T, cov1, rtol=1e-10, atol=1e-13)
+
+
+@pytest.mark.parametrize("P,H,cov_type,dtype", [(4096, 32, "full", "f64"), (1024, 12, "diagonal", "f64"), (2000, 16, "full", "f32")])
+def test_rollout_that_draws_its_own_full_covariance_samples(P, H, cov_type, dtype):
+    """At most one wavefront per SIMD pair (P <= 4096 on 256 CUs) the CEM step needs no sample buffer: the rollout launch
+    colours its own Philox draws with the whole lower triangle of the factor the finish launch left (``mjmpc_arm_rollout_sampled``,
+    chol_full) - the same closed loop as with the samples drawn into a buffer by the finish launch."""
+    a1, m1, c1, e1, ctl1 = _loop(P, H, cov_type, True, 6, dtype=dtype, in_kernel=True)
+    assert ctl1._cem_in_kernel()
+    a0, m0, c0, e0, ctl0 = _loop(P, H, cov_type, True, 6, dtype=dtype, in_kernel=False)
+    assert not ctl0._cem_in_kernel()
+    tol = 1e-9 if dtype == "f64" else 2e-3
+    np.testing.assert_allclose(a1[0], a0[0], rtol=0, atol=1e-12 if dtype == "f64" else 2e-5)
+    np.testing.assert_allclose(a1, a0, rtol=0, atol=tol)
+    np.testing.assert_allclose(c1, c0, rtol=1e-7 if dtype == "f64" else 1e-2, atol=1e-12)
+    assert e1.solver_failures() == 0
