@@ -429,6 +429,7 @@ def main():
     coeffs = ctrl.dev.record("coeffs", 3)
 
     mono = graphed and getattr(ctrl, "_mono", False)
+    sampled_entry = graphed and hasattr(ctrl, "_cem_in_kernel") and ctrl._cem_in_kernel()
     if mono:
         chol_t, coeffs_t, _ = ctrl.dev.prepare_noise(ctrl._cov_host, ctrl.filter_coeffs)
         t_step = torch.zeros(1, dtype=torch.int64, device="cuda")
@@ -438,6 +439,9 @@ def main():
         if mono:        # the fused iteration's rollout launch (shift -2) / both launches, from the state the run ended in
             eng.mppi_step(P_loc, H, ctrl.dev.mean, ctrl.dev.mean_alt, ctrl.dev.gseq, coeffs_t, chol_t, ctrl.seed_val, 0, 0, t_step, ctrl.lam,
                           ctrl.step_size, shift, record=t_rec if shift != -2 else None, env_step=False)
+        elif sampled_entry:     # CEM on a small launch: the rollout kernel draws its own full-covariance samples
+            eng.rollout_sampled(P_loc, H, ctrl.dev.mean, ctrl.dev.gseq, coeffs, ctrl.dev.record("chol", A * A), True,
+                                ctrl.seed_val, 0, 0, ctrl._step_dev)
         elif fused_entry:
             eng.rollout_fused(P_loc, H, ctrl.dev.mean, noise_t, coeffs, ctrl.dev.gseq)
         else:
@@ -560,8 +564,9 @@ def main():
                      "kernel_entry": ("mjmpc_arm_mppi_step, launch 1 of 2 (sampling + rollout + cost-to-go + per-workgroup softmax records); "
                                       "with launch 2 (arm_mppi_finish_kernel: update + action + shift, here without its env step): "
                                       "%.4f ms" % both_ms
-                                      if mono else ("mjmpc_arm_rollout" if args.workload == "reacher" else "mjmpc_tree_rollout")
-                                      + ("_fused" if fused_entry else "")),
+                                      if mono else ("mjmpc_arm_rollout_sampled (Philox draws + full-covariance colouring in the kernel)" if sampled_entry
+                                                    else ("mjmpc_arm_rollout" if args.workload == "reacher" else "mjmpc_tree_rollout")
+                                                    + ("_fused" if fused_entry else ""))),
                      "alg_bytes_per_particle_step": b_alg,
                      "note": "latency/VALU-bound path (SURVEY 8d): >100 counted FLOP per algorithmic byte, HBM fraction is small by "
                              "construction; `valu` is the roofline that binds"},
