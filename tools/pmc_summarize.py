@@ -16,7 +16,7 @@ WORKLOADS = {
     # workload -> (file prefix, dominant kernel, other kernels of the step reported beside it)
     "reacher": ("", "arm_rollout_kernel<double, false, false, 1, true, true>",
                 ["arm_mppi_finish_kernel<double>", "arm_rollout_kernel<double, false, false, 1, true, false>"]),
-    "half_cheetah": ("half_cheetah_", "tree_rollout_kernel<double, 8, 16, true, 16, 12>", []),
+    "half_cheetah": ("half_cheetah_", "tree_rollout_kernel<double, 8, 16, true, 16, 12", []),
 }
 
 
