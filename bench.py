@@ -309,6 +309,7 @@ def main():
         comm = TorchDistComm()
 
     from mjmpc_amd.build import build_info
+    from mjmpc_amd.control.controller import resident_state
     from mjmpc_amd.envs.arm_engine import make_device_rollout_fn
 
     H = args.horizon
@@ -344,7 +345,7 @@ def main():
             ctrl.rollout_fn = rollout_fn
             if hasattr(base_fn, "fused"):
                 rollout_fn.fused = base_fn.fused
-        ctrl.set_sim_state_fn = lambda s: None          # the "real" env lives on the device (step_state)
+        ctrl.set_sim_state_fn = resident_state          # the "real" env lives on the device (step_state)
         if graphed:
             ctrl.enable_graph(post_step=eng.step_state, mono=not args.no_mono, lookahead=args.lookahead)   # the env step is captured with the iteration
 

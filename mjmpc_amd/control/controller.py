@@ -141,6 +141,16 @@ class Controller(ABC):
 _SHIFT_MODES = {'null': 0, 'repeat': 1, 'random': 2}
 
 
+def resident_state(state):
+    """``set_sim_state_fn`` of a closed loop whose real env lives on the device (``engine.step_state`` advances it inside
+    the captured iteration): there is nothing to copy or upload, and ``optimize()`` skips the deep copy of the state
+    dictionary the reference makes for the callback (controller.py:217: 2 us of the host's turn-around per control step)."""
+    return None
+
+
+resident_state.ignores_state = True
+
+
 class _AlternatingGraphs:
     """Two captured iterations, one per direction of the mean's double buffer: ``replay()`` runs the one that reads the
     buffer that is the mean now, then makes the buffer it wrote the mean."""
@@ -546,7 +556,8 @@ class OLGaussianMPC(Controller):
             raise RuntimeError("mean_action / cov_action were assigned while an iteration enqueued ahead "
                                "(enable_graph(lookahead=True)) was in flight; call reset() first, or run without lookahead")
         self._sync_in()
-        self._set_sim_state_fn(copy.deepcopy(state) if state is not None else None)
+        if not getattr(self._set_sim_state_fn, "ignores_state", False):
+            self._set_sim_state_fn(copy.deepcopy(state) if state is not None else None)
         if self._graph is None:
             self._mono = self._mono_capable()           # (decided once per capture: the test reads host arrays)
             self._step_dev = torch.full((1,), self.num_steps, dtype=torch.int64, device=self.dev.device)
