@@ -573,6 +573,10 @@ def main():
                              "construction; `valu` is the roofline that binds"},
         "solver_failures": fails,
     }
+    if hasattr(eng, "diverged_substeps"):
+        # (tree engine) particle-substeps whose constraint solution was not finite - diverged rollouts, cost +inf, no weight
+        # in the update; apart from solver_failures (= a finite problem the iteration cap ended)
+        out["diverged_particle_substeps"] = eng.diverged_substeps()
     if pipelined:
         out["pipelined"] = pipelined
     if strong:

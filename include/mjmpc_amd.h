@@ -232,6 +232,10 @@ int mjmpc_tree_get_state(mjmpc_tree_t h, double* qpos, double* qvel, void* strea
 int mjmpc_tree_rollout_cl(mjmpc_tree_t h, int dtype, int64_t P, int H, const double* d_weights, const void* d_noise,
                           void* d_costs, void* d_actions, void* d_obs, void* d_next_obs, void* stream);
 int mjmpc_tree_solver_failures(mjmpc_tree_t h, uint32_t* count);
+/* Particle-substeps since create whose constraint solution was not finite: rollouts that diverged (MuJoCo would reset
+ * such a simulation, mj_checkAcc [EXT]; here their costs become +inf and the updates give them no weight).  They are not
+ * counted by mjmpc_tree_solver_failures. */
+int mjmpc_tree_diverged(mjmpc_tree_t h, uint32_t* count);
 
 /* rollout_fn over the reference's two analytic numpy envs (stateless; every pointer is a device
  * pointer): kind 0 = PendulumEnv (mjmpc/envs/basic/pendulum.py:33-50; d_params = [max_speed,

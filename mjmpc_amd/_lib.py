@@ -49,6 +49,7 @@ SIGNATURES = {
     "mjmpc_tree_step_state": (_int, [_vp, _int, _vp, _vp, _vp, _vp]),
     "mjmpc_tree_get_state": (_int, [_vp, _dp, _dp, _vp]),
     "mjmpc_tree_solver_failures": (_int, [_vp, ctypes.POINTER(ctypes.c_uint32)]),
+    "mjmpc_tree_diverged": (_int, [_vp, ctypes.POINTER(ctypes.c_uint32)]),
     "mjmpc_analytic_rollout": (_int, [_int, _vp, _int, _int, _vp, _int, _i64, _int, _vp, _vp, _vp, _vp, _vp, _vp, _int,
                                       _vp]),
     "mjmpc_arm_solver_failures": (_int, [_vp, ctypes.POINTER(ctypes.c_uint32)]),

@@ -854,6 +854,16 @@ int mjmpc_tree_solver_failures(mjmpc_tree_t h, uint32_t* count) {
     return 0;
 }
 
+int mjmpc_tree_diverged(mjmpc_tree_t h, uint32_t* count) {
+    if (!h || !count) return fail(MJMPC_E_BADARG, "null argument");
+    HIP_TRY(hipSetDevice(h->device));
+    HIP_TRY(hipDeviceSynchronize());
+    unsigned c = 0;
+    HIP_TRY(hipMemcpy(&c, h->diag + 1, sizeof(unsigned), hipMemcpyDeviceToHost));
+    *count = c;
+    return 0;
+}
+
 int mjmpc_analytic_rollout(int kind, const double* d_params, int n_state, int n_action, const double* d_state, int dtype,
                            int64_t P, int H, const double* d_mean, const void* d_noise, void* d_costs, void* d_actions,
                            void* d_obs, void* d_next_obs, int closed_loop_linear, void* stream) {

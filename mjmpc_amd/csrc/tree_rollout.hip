@@ -128,7 +128,8 @@ constexpr int a_row2(int DP, int NS, int NJ, int PL, int CSZ = CS_BASE) { return
 // the full instantiation with rows of up to 16 entries factors the Euler matrix beside the first Newton matrix (two
 // 32-entry rows do not fit the register file; the lean instantiation runs the large launches, where the second row area
 // would cost a resident workgroup per CU: 65536 x 64 on the hand 77 -> 129 ms - as it would in the f32 launches with 16
-// lanes per particle, which are the large ones: 32768 x 32 on the cheetah 18 -> 35 ms)
+// lanes per particle, which are the large ones: 32768 x 32 on the cheetah 18 -> 35 ms; f64 rows of 16: three such rows
+// at once spill - 256 VGPRs + 153 AGPRs + 80 bytes of scratch - and the pen-in-hand launch goes from 17.0 to 31.7 ms)
 // (DN > 0: 16-lane particles factor densely in registers - see dense_factor - and have nothing to merge)
 constexpr bool merge_factor(int DP, bool fric, int scalar_bytes, int PL, int DN = 0) {
     return DN == 0 && (fric || DP <= 8) && DP <= 16 && !(scalar_bytes == 4 && PL == 16) && !(scalar_bytes == 8 && DP > 8);
@@ -868,7 +869,7 @@ __device__ __noinline__ T exact_line_search(T g0, T dg, T Dl, T rl, T drl, T Dc,
     T fhi = phi(T(1));
     if (!(fhi > T(0))) return T(1);
     T lo = T(0), hi = T(1), flo = phi(T(0));
-    if (!(flo < T(0))) return T(1);             // (numerically not a descent direction: take the Newton point)
+    if (!(flo < T(0))) return T(0);             // (numerically not a descent direction: the gradient at the base point is zero to rounding - stay)
     for (int b = 0; b < 24; ++b) {
         const T mid = T(0.5) * (lo + hi), fm = phi(mid);
         if (fm > T(0)) { hi = mid; fhi = fm; } else { lo = mid; flo = fm; }
@@ -2094,6 +2095,12 @@ __global__ __launch_bounds__(64 * wg_waves(DP, FRIC, sizeof(T), PL), min_waves(s
                                         al = exact_line_search<PL, NR, false>(gbp, gNp - gbp, D, rl0, rl1 - rl0, Dc, rb, drb, (const T*)nullptr, false,
                                                                               T(0), T(0), T(0), T(0));
                                     }
+                                    // a step below the working precision of the iterate (a base point on a kink of the
+                                    // objective, where a row at zero residual may be counted either way): the safeguarded
+                                    // iteration has reached its fixed point - mj_solNewton stops likewise once the
+                                    // improvement falls under its tolerance
+                                    const bool moved = fabs(al * pv) > (sizeof(T) == 4 ? T(1e-6) : T(1e-14)) * (fabs(a_b) + T(1));
+                                    const bool pmoved = ((unsigned)(__ballot(moved) >> (PL * half)) & (PL == 32 ? ~0u : 0xFFFFu)) != 0u;
                                     a_b += al * pv;
                                     g_b += al * (gN - g_b);
 #pragma unroll
@@ -2103,7 +2110,17 @@ __global__ __launch_bounds__(64 * wg_waves(DP, FRIC, sizeof(T), PL), min_waves(s
                                     act2 = inst && (rlb < T(0));
                                     cact2 = rows_from_res(rb, cact);
                                     if constexpr (GEN) fst2 = fl_state_of(xa, 0);
-                                    changed = true;
+                                    changed = pmoved;
+#ifdef TREE_DEBUG_CAP
+                                    if (it >= TREE_MAXIT_LS - 6) {
+                                        const unsigned am = (unsigned)(__ballot(actv) >> (PL * half)) & (PL == 32 ? ~0u : 0xFFFFu);
+                                        const unsigned am2 = (unsigned)(__ballot(act2) >> (PL * half)) & (PL == 32 ? ~0u : 0xFFFFu);
+                                        const T pn = sum_lanes<PL>(pv * pv), an = sum_lanes<PL>(a_b * a_b);
+                                        if (l == 0) printf("cap pid=%ld t=%d sub=%d it=%d al=%.17g |p|=%.3g |a|=%.3g gbp=%.3g gNp=%.3g act=%x->%x cact=%llx->%llx\n",
+                                                           (long)pid, t, sub, it, (double)al, (double)sqrt_(pn), (double)sqrt_(an), (double)gbp, (double)gNp,
+                                                           am, am2, (unsigned long long)cact, (unsigned long long)cact2);
+                                    }
+#endif
                                 } else {
                                     a_b = xa;
                                     g_b = gN;
@@ -2116,8 +2133,11 @@ __global__ __launch_bounds__(64 * wg_waves(DP, FRIC, sizeof(T), PL), min_waves(s
                     // One limit row j of a particle changed state (the usual reason for another iteration):
                     // H' = H + c e_j e_j', c = +-D_j, rhs' = rhs + c sig_j aref_j e_j.  With z = H^-1 e_j - one more pair of
                     // triangular solves with the factor at hand, a third of a factor + solve - Sherman-Morrison gives
-                    // a' = y - c z y_j / (1 + c z_j),  y = a + (c sig_j aref_j) z.  Several flips in one particle or a
-                    // contact-row flip take the general path (next iteration refactors).
+                    // a' = y - c z y_j / (1 + c z_j),  y = a + (c sig_j aref_j) z.  Several flips in one particle take the
+                    // general path (next iteration refactors) - and with them the wave: which of the two paths a particle's
+                    // change takes depends on its wave-mates, so results are reproducible for a given launch shape
+                    // and equal to rounding across shapes (measured, 4096 x 32: cheetah 2.28 -> 2.21 ms, tray 3.52 -> 3.35,
+                    // pen-in-hand f64 17.0 -> 15.9, f32 16.2 -> 13.7 ms and no iteration-cap hits where there were 16).
                     if (__any(changed)) {
                         const bool flip = act2 != actv;
                         const unsigned nflip = __popc((unsigned)(__ballot(flip) >> (PL * half)) & (PL == 32 ? ~0u : 0xFFFFu));
@@ -2131,23 +2151,50 @@ __global__ __launch_bounds__(64 * wg_waves(DP, FRIC, sizeof(T), PL), min_waves(s
                             clk.count(20, nflip == 0u && ncf == 0u);     // only the other particle of the wave changed
                         }
 #endif
-                        if (!(FRIC && it >= LS_START) && !__any(cact2 != cact || nflip > 1u || (GEN && fst2 != fstate))) {
+                        // ... or ONE contact row r of a point s (J = Jn +- mu Jt_k, c = +-D_s, its own aref): the same
+                        // correction with z = H^-1 J' and lane sums for J z and J a
+                        const mask_t cdiff = FRIC ? (cact2 ^ cact) : mask_t(0);
+                        const unsigned ncf = FRIC ? (unsigned)__popcll((unsigned long long)cdiff) : (cact2 != cact ? 2u : 0u);
+                        if (!(FRIC && it >= LS_START) && !__any(nflip + ncf > 1u || (GEN && fst2 != fstate))) {
+                            T jz_ = flip ? T(1) : T(0);         // my entry of the changed row
+                            T cc = T(0), ar = T(0);
+                            const bool cflip = __any(ncf == 1u);
+                            if (FRIC && cflip && ncf == 1u) {
+                                const int bit = __builtin_ctzll((unsigned long long)cdiff), s = bit / NR, r = bit - s * NR;
+                                const T* cs = X + A_CS + s * CS;
+                                const T* jrow = X + A_JC + s * NJ * DP;
+                                const int oi = own_idx(s), k = 1 + (r >> 1);
+                                const T mu = M[T_SPH + s * TREE_SPH_STRIDE + 7];
+                                const T sgn = (r & 1) ? T(-1) : T(1);
+                                jz_ = oi >= 0 ? jrow[oi] + (mu > T(0) ? sgn * mu * jrow[k * DP + oi] : T(0)) : T(0);
+                                cc = ((cact2 >> bit) & 1u) ? cs[4] : -cs[4];
+                                ar = mu > T(0) ? cs[5] - sgn * cs[5 + k] : cs[5];
+                            }
                             T zl;
-                            if constexpr (DN > 0) zl = dense_solve<DN>(hd, hdinv, flip ? T(1) : T(0), l);
-                            else zl = tree_solve<DP, PL>(hrow, flip ? T(1) : T(0), ELIM, AT, ROW, VEC, l, n_rounds, depth, max_depth, kt);
-                            if (flip) {
-                                const T c = act2 ? D : -D;
-                                VEC[0] = c;
-                                VEC[1] = c * sig * aref;
-                                VEC[2] = zl;
-                                VEC[3] = xa;
+                            if constexpr (DN > 0) zl = dense_solve<DN>(hd, hdinv, jz_, l);
+                            else zl = tree_solve<DP, PL>(hrow, jz_, ELIM, AT, ROW, VEC, l, n_rounds, depth, max_depth, kt);
+                            if (!cflip) {
+                                if (flip) {
+                                    const T c = act2 ? D : -D;
+                                    VEC[0] = c;
+                                    VEC[1] = c * sig * aref;
+                                    VEC[2] = zl;
+                                    VEC[3] = xa;
+                                }
+                                TSYNC();
+                                if (nflip == 1u) {
+                                    const T c = VEC[0], dl = VEC[1], zj = VEC[2], yj = VEC[3] + dl * zj;
+                                    xa = (xa + dl * zl) - c * zl * yj * rcp_(T(1) + c * zj);
+                                }
+                                TSYNC();
+                            } else {
+                                const T cp = sum_lanes<PL>(flip ? (act2 ? D : -D) : T(0)) + cc;
+                                const T arp = sum_lanes<PL>(flip ? sig * aref : T(0)) + ar;
+                                const T jz = sum_lanes<PL>(jz_ * zl), ja = sum_lanes<PL>(jz_ * xa);
+                                const T dl = cp * arp, yj = ja + dl * jz;
+                                xa = (xa + dl * zl) - cp * zl * yj * rcp_(T(1) + cp * jz);
+                                cact = cact2;
                             }
-                            TSYNC();
-                            if (nflip == 1u) {
-                                const T c = VEC[0], dl = VEC[1], zj = VEC[2], yj = VEC[3] + dl * zj;
-                                xa = (xa + dl * zl) - c * zl * yj * rcp_(T(1) + c * zj);
-                            }
-                            TSYNC();
                             actv = act2;                // the sets the corrected solution belongs to
                             const T resl2 = sig * xa - aref;
                             const T band2 = sizeof(T) == 4 ? T(2e-5) * (fabs(aref) + fabs(xa) + T(1)) : T(0);
@@ -2161,6 +2208,13 @@ __global__ __launch_bounds__(64 * wg_waves(DP, FRIC, sizeof(T), PL), min_waves(s
                     // rounding of its switching point and flip back and forth; a particle whose set returns to the one
                     // of two iterations ago has converged to working precision (either set gives the same forces)
                     if (sizeof(T) == 4 && it >= 2 && act2 == act_pp && cact2 == cact_pp && (!GEN || fst2 == fst_pp)) changed = false;
+                    // a particle whose accelerations have left the range of the arithmetic (not finite, or beyond 1e100 / 1e30
+                    // rad/s^2, whose squares overflow) has diverged - its cost becomes +inf and the update gives it no weight:
+                    // nothing to iterate on - counted apart from the solver's own failures below
+                    if (FRIC && it >= LS_START) {
+                        const unsigned long long nf = __ballot(!(fabs(xa) < T(sizeof(T) == 4 ? 1e30 : 1e100)));
+                        if (((unsigned)(nf >> (PL * half)) & (PL == 32 ? ~0u : 0xFFFFu)) != 0u) changed = false;
+                    }
                     act_pp = actv;
                     cact_pp = cact;
                     fst_pp = fstate;
@@ -2222,6 +2276,10 @@ __global__ __launch_bounds__(64 * wg_waves(DP, FRIC, sizeof(T), PL), min_waves(s
                 }
             }
             clk.mark(5);
+            if (diag) {         // one count per particle-substep whose acceleration has left the range of the arithmetic (a diverged rollout)
+                const unsigned long long nf = __ballot(!(fabs(qacc) < T(sizeof(T) == 4 ? 1e30 : 1e100)));
+                if (l == 0 && ((unsigned)(nf >> (PL * half)) & (PL == 32 ? ~0u : 0xFFFFu)) != 0u) atomicAdd(diag + 1, 1u);
+            }
             if (GEN && has_ball) {
                 // mj_integratePos of a ball joint: q <- q * exp(h w / 2), w = the joint's three velocities (body frame) - the
                 // first link gathers its followers' and owns the quaternion

@@ -237,6 +237,13 @@ class TreeRolloutEngine:
         _lib.check(self._lib.mjmpc_tree_solver_failures(self._h, ctypes.byref(c)))
         return int(c.value)
 
+    def diverged_substeps(self):
+        """Particle-substeps whose constraint solution was not finite (diverged rollouts: cost +inf, no weight in the
+        updates) - counted apart from solver_failures()."""
+        c = ctypes.c_uint32()
+        _lib.check(self._lib.mjmpc_tree_diverged(self._h, ctypes.byref(c)))
+        return int(c.value)
+
     # ------------------------------------------------------------------ helpers
     def _stream(self):
         return ctypes.c_void_p(_torch().cuda.current_stream(self.device).cuda_stream)

@@ -399,18 +399,37 @@ def test_swimmer_self_contact_matches_oracle():
 @pytest.mark.parametrize("name", ["swimmer", "cheetah"])
 def test_f32_results_do_not_depend_on_the_batch_size(name):
     """The instantiation is chosen from model and dtype alone (round 2 picked 32 lanes per particle for f32 launches of
-    <= 4096 particles and 16 above): a particle's f32 trajectory is the same bits whether it is rolled out alone (the
-    device-resident real env: P = 1), with 4095 others or with 8191 others."""
+    <= 4096 particles and 16 above): a particle's f32 trajectory is the same bits with 4095 others or with 8191 others
+    (the same wave-mates), and equal to rounding when it is rolled out alone (the device-resident real env, P = 1:
+    whether a re-iteration is a rank-one correction or a refactorisation is decided per wavefront, tree_rollout.hip)."""
     from mjmpc_amd.envs.tree_engine import TreeRolloutEngine
     raw = _models()[name]()
     eng = TreeRolloutEngine(raw, dtype="f32")
     nv = eng.model.nv
     q0, v0, mean, noise = _case(name, nv, eng.d_action, 9, 8192, 6)
     eng.set_env_state(dict(qpos=q0, qvel=v0))
-    ref = None
+    got = {}
     for P in (1, 4096, 8192):
         out = eng.rollout_device(P, 6, mean, noise[:P].astype(np.float32), want_obs=True)
-        got = (out[0][0].cpu().numpy().copy(), out[3][0].cpu().numpy().copy())
-        if ref is None:
-            ref = got
-        assert np.array_equal(got[0], ref[0]) and np.array_equal(got[1], ref[1]), P
+        got[P] = (out[0][0].cpu().numpy().copy(), out[3][0].cpu().numpy().copy())
+    assert np.array_equal(got[4096][0], got[8192][0]) and np.array_equal(got[4096][1], got[8192][1])
+    np.testing.assert_allclose(got[1][0], got[4096][0], rtol=2e-4, atol=2e-4)
+    np.testing.assert_allclose(got[1][1], got[4096][1], rtol=2e-4, atol=2e-4)
+
+
+def test_diverged_rollouts_are_counted_apart_from_solver_failures():
+    """A particle whose accelerations are no longer finite stops iterating (there is nothing to converge to), is counted
+    by diverged_substeps() - mjmpc_tree_diverged - and not by solver_failures(); its costs are not finite, which the
+    updates read as +inf (test_controllers_gpu.py::test_diverged_rollouts_do_not_poison_the_update).  MuJoCo would reset
+    such a simulation (mj_checkAcc [EXT])."""
+    from mjmpc_amd.envs.tree_engine import TreeRolloutEngine
+    raw = _models()["cheetah"]()
+    eng = TreeRolloutEngine(raw, dtype="f64")
+    q0, v0, mean, noise = _case("cheetah", eng.model.nv, eng.d_action, 3, 64, 4)
+    eng.set_env_state(dict(qpos=q0, qvel=v0))
+    eng.rollout(64, 4, mean, noise)
+    assert eng.diverged_substeps() == 0 and eng.solver_failures() == 0
+    eng.set_env_state(dict(qpos=q0, qvel=np.full(eng.model.nv, 1e200)))
+    rew = eng.rollout(64, 4, mean, noise)[1]
+    assert not np.isfinite(rew).all()
+    assert eng.diverged_substeps() > 0 and eng.solver_failures() == 0

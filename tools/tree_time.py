@@ -1,4 +1,4 @@
-"""Rollout-kernel time of the tree engine: python tools/tree_time.py [P] [H] [dtype] [hand|swimmer|cheetah]
+"""Rollout-kernel time of the tree engine: python tools/tree_time.py [P] [H] [dtype] [hand|swimmer|cheetah|pen|cartpole|tray|door]
 (MJMPC_AMD_LIB selects an alternative build of the library, e.g. one compiled with -DTREE_SKIP=...)."""
 import os, sys
 import numpy as np
@@ -10,20 +10,34 @@ P = int(sys.argv[1]) if len(sys.argv) > 1 else 65536
 H = int(sys.argv[2]) if len(sys.argv) > 2 else 16
 dt = sys.argv[3] if len(sys.argv) > 3 else "f64"
 name = sys.argv[4] if len(sys.argv) > 4 else "hand"
+start = None
 if name == "hand":
     raw = hand24_raw()
+elif name == "pen":
+    from mjmpc_amd.models.pen_hand import holding_state, pen_hand_raw
+    raw = pen_hand_raw()
+    st = holding_state()
+    start = dict(qpos=st["qp"], qvel=st["qv"], target_pos=np.asarray(raw.target_pos, float))
+elif name in ("cartpole", "tray", "door"):
+    from mjmpc_amd.models.synthetic import start_state, synthetic_raw
+    raw = synthetic_raw(name)
+    start = start_state(name, raw)
 else:
     from mjmpc_amd.models.half_cheetah import half_cheetah_raw
     from mjmpc_amd.models.swimmer import swimmer_raw
     raw = dict(swimmer=swimmer_raw, cheetah=half_cheetah_raw)[name]()
 eng = TreeRolloutEngine(raw, dtype=dt)
 A = eng.d_action
+if start is not None:
+    eng.set_env_state(start)
 if name == "cheetah":       # resting on its feet: contacts from the first substep on
     q0 = np.array([0.0, -0.1324, 0.0521, 0.0342, 0.0679, -0.0139, -0.0589, -0.14, -0.131])
     eng.set_env_state(dict(qpos=q0, qvel=np.zeros(9)))
 g = torch.Generator(device="cuda").manual_seed(0)
-noise = 0.5 * torch.randn(P, H, A, device="cuda", dtype=torch.float32 if dt == "f32" else torch.float64, generator=g)
+noise = (0.1 if name in ("pen", "tray") else 0.5) * torch.randn(P, H, A, device="cuda", dtype=torch.float32 if dt == "f32" else torch.float64, generator=g)
 mean = torch.zeros(H, A, device="cuda", dtype=torch.float64)
+if name == "pen":           # position servos: hold the start pose
+    mean += torch.from_numpy(st["qp"][6:]).to(mean)
 eng.rollout_device(P, H, mean, noise)
 torch.cuda.synchronize()
 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
