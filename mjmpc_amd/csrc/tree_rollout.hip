@@ -34,6 +34,7 @@
 // (compile_tree.py).  The soft-constraint problem is the arm kernel's primal active-set Newton iteration with several
 // contact rows; in the friction instantiation an exact line search takes over when it does not settle (MuJoCo's Newton).
 #include <hip/hip_runtime.h>
+#include <cstdlib>
 
 #include <type_traits>
 
@@ -292,6 +293,27 @@ __device__ __forceinline__ void fma_bcast(float& acc, float x, float m) {
                      : "+v"(up), "+v"(dn)                                                                                   \
                      : "v"(s[0]), "v"(s[1]), "v"(s[2]), "v"(s[3]), "v"(s[4]), "v"(s[5]), "v"(f[0]), "v"(f[1]), "v"(f[2]),  \
                        "v"(f[3]), "v"(f[4]), "v"(f[5]), "n"(K));                                                           \
+    }                                                                                                                       \
+    /* up += (lane K's sb) . f,  dn += (lane K's fb) . s   - the broadcast sources apart from the multipliers */            \
+    template <int K>                                                                                                        \
+    __device__ __forceinline__ void fma_bcast_dots6x(T_& up, T_& dn, const T_* sb, const T_* fb, const T_* s, const T_* f) { \
+        asm volatile("s_nop 1\n\t"                                                                                        \
+                     "v_fmac_" SFX_ "_dpp %0, %2, %20" MJMPC_BC "26" MJMPC_BCT                                              \
+                     "v_fmac_" SFX_ "_dpp %1, %8, %14" MJMPC_BC "26" MJMPC_BCT                                              \
+                     "v_fmac_" SFX_ "_dpp %0, %3, %21" MJMPC_BC "26" MJMPC_BCT                                              \
+                     "v_fmac_" SFX_ "_dpp %1, %9, %15" MJMPC_BC "26" MJMPC_BCT                                              \
+                     "v_fmac_" SFX_ "_dpp %0, %4, %22" MJMPC_BC "26" MJMPC_BCT                                              \
+                     "v_fmac_" SFX_ "_dpp %1, %10, %16" MJMPC_BC "26" MJMPC_BCT                                             \
+                     "v_fmac_" SFX_ "_dpp %0, %5, %23" MJMPC_BC "26" MJMPC_BCT                                              \
+                     "v_fmac_" SFX_ "_dpp %1, %11, %17" MJMPC_BC "26" MJMPC_BCT                                             \
+                     "v_fmac_" SFX_ "_dpp %0, %6, %24" MJMPC_BC "26" MJMPC_BCT                                              \
+                     "v_fmac_" SFX_ "_dpp %1, %12, %18" MJMPC_BC "26" MJMPC_BCT                                             \
+                     "v_fmac_" SFX_ "_dpp %0, %7, %25" MJMPC_BC "26" MJMPC_BCT                                              \
+                     "v_fmac_" SFX_ "_dpp %1, %13, %19" MJMPC_BC "26 row_mask:0xf bank_mask:0xf"                            \
+                     : "+v"(up), "+v"(dn)                                                                                   \
+                     : "v"(sb[0]), "v"(sb[1]), "v"(sb[2]), "v"(sb[3]), "v"(sb[4]), "v"(sb[5]), "v"(fb[0]), "v"(fb[1]),     \
+                       "v"(fb[2]), "v"(fb[3]), "v"(fb[4]), "v"(fb[5]), "v"(s[0]), "v"(s[1]), "v"(s[2]), "v"(s[3]),        \
+                       "v"(s[4]), "v"(s[5]), "v"(f[0]), "v"(f[1]), "v"(f[2]), "v"(f[3]), "v"(f[4]), "v"(f[5]), "n"(K));   \
     }
 MJMPC_DPP_GROUPS(double, "f64")
 MJMPC_DPP_GROUPS(float, "f32")
@@ -840,6 +862,191 @@ __device__ __forceinline__ T dense_solve(const T* r, T dinv, T b, int l) {
     return z - dinv * acc;
 }
 
+// ---- dense factorisation for 32-lane particles (DN = 32): the particle's two 16-lane DPP rows hold dofs 0..15 (the EVEN
+// row) and 16..31 (the ODD row).  v_permlane16_swap hands every lane the value its partner lane of the other row holds,
+// so a broadcast from any of the 32 lanes is that exchange plus a row broadcast.  Lane l keeps row l of the matrix:
+// even-row lanes need columns 0..15 only (A11); odd-row lanes all 32 (A21 | A22).  Right-looking L D L':
+//   pivot K < 16 (an even-row lane): columns K+1..15 of the pivot row cross the rows (swap + broadcast FMA); columns
+//     16..31 are A[K][j] = A[j][K], the not yet scaled entry K of odd-row lane j - a broadcast inside the odd row;
+//   pivot K >= 16: the 16-lane scheme inside the odd row (even-row lanes ride along with a zero multiplier).
+// At the end the odd row's L[j][0..15] are transposed through LDS into the even-row lanes' entries 16..31 (as D_i L[j][i],
+// what the backward solve reads).  ~900 instructions against the tree-sparse factorisation's rounds of LDS traffic:
+// measured on the pen-in-hand model (30 dofs, elimination paths of 16) 20 k -> see DESIGN 4.6.5 cycles per factorisation.
+__device__ __forceinline__ void row_pair(float x, float& even, float& odd) {
+    const unsigned u = __float_as_uint(x);
+    const auto r = __builtin_amdgcn_permlane16_swap(u, u, false, false);
+    even = __uint_as_float(r[0]);
+    odd = __uint_as_float(r[1]);
+}
+__device__ __forceinline__ void row_pair(double x, double& even, double& odd) {
+    const unsigned lo = (unsigned)__double2loint(x), hi = (unsigned)__double2hiint(x);
+    const auto a = __builtin_amdgcn_permlane16_swap(lo, lo, false, false);
+    const auto b = __builtin_amdgcn_permlane16_swap(hi, hi, false, false);
+    even = __hiloint2double((int)b[0], (int)a[0]);
+    odd = __hiloint2double((int)b[1], (int)a[1]);
+}
+template <typename T>
+__device__ __forceinline__ T row_even(T x) { T e, o; row_pair(x, e, o); return e; }
+template <typename T>
+__device__ __forceinline__ T row_odd(T x) { T e, o; row_pair(x, e, o); return o; }
+
+// r[J0 + c] += (lane (J0 + c) % 16's x) * m for c < N: up to four broadcast FMAs per asm statement (one set of wait states)
+#define MJMPC_COLS(T_, SFX_)                                                                                                 \
+    template <int L0, int L1, int L2, int L3>                                                                               \
+    __device__ __forceinline__ void fma_bcast_cols4(T_& a0, T_& a1, T_& a2, T_& a3, T_ x, T_ m) {                          \
+        asm volatile("s_nop 1\n\t"                                                                                        \
+                     "v_fmac_" SFX_ "_dpp %0, %4, %5 row_newbcast:%6 row_mask:0xf bank_mask:0xf\n\t"                      \
+                     "v_fmac_" SFX_ "_dpp %1, %4, %5 row_newbcast:%7 row_mask:0xf bank_mask:0xf\n\t"                      \
+                     "v_fmac_" SFX_ "_dpp %2, %4, %5 row_newbcast:%8 row_mask:0xf bank_mask:0xf\n\t"                      \
+                     "v_fmac_" SFX_ "_dpp %3, %4, %5 row_newbcast:%9 row_mask:0xf bank_mask:0xf"                            \
+                     : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3) : "v"(x), "v"(m), "n"(L0), "n"(L1), "n"(L2), "n"(L3));     \
+    }
+MJMPC_COLS(double, "f64")
+MJMPC_COLS(float, "f32")
+#undef MJMPC_COLS
+// columns [J0, J1) of a step: r[j] += (lane j % 16 of my row's x) * m
+template <int J0, int J1, typename T>
+__device__ __forceinline__ void dense32_cols(T* r, T x, T m) {
+    if constexpr (J1 - J0 >= 4) {
+        fma_bcast_cols4<J0 % 16, (J0 + 1) % 16, (J0 + 2) % 16, (J0 + 3) % 16>(r[J0], r[J0 + 1], r[J0 + 2], r[J0 + 3], x, m);
+        dense32_cols<J0 + 4, J1>(r, x, m);
+    } else if constexpr (J1 - J0 >= 1) {
+        fma_bcast<J0 % 16>(r[J0], x, m);
+        dense32_cols<J0 + 1, J1>(r, x, m);
+    }
+}
+// the reciprocal of pivot K (the diagonal entry of lane K), in every lane that will use it
+template <int K, typename T>
+__device__ __forceinline__ T dense32_pivot_inv(const T* r) {
+    if constexpr (K < 16) return rcp_(bcast_row<K>(row_even(r[K])));
+    else return rcp_(bcast_row<K - 16>(r[K]));          // (only the odd-row lanes use it: theirs is the right one)
+}
+// Step K.  A[K][j] = A[j][K] (the matrix is symmetric and lane j > K has not scaled its entry K yet), so the pivot row is
+// never sent anywhere: every lane broadcasts-reads "entry K of lane j" - from its own row for columns of its own half,
+// through ONE row exchange of entry K per step for the even-row columns the odd-row lanes need.
+template <int K, typename T>
+struct Dense32Step {
+    static __device__ __forceinline__ void run(T* r, T& dinv, int l, T inv) {
+        dinv = l == K ? inv : dinv;
+        const T rk = r[K];
+        const T lik = l > K ? rk * inv : T(0), nlik = -lik;
+        T inv_next = T(0);
+        if constexpr (K < 16) {
+            const T rke = row_even(rk);                     // entry K of the even-row partner (even-row lanes: my own)
+            const T nlik_odd = l >= 16 ? nlik : T(0);      // (even-row lanes keep no columns 16 .. 31)
+            if constexpr (K + 1 < 16) {
+                dense32_cols<K + 1, K + 2>(r, rke, nlik);
+                inv_next = dense32_pivot_inv<K + 1>(r);     // (the next pivot is final: its reciprocal overlaps the rest of the step)
+                dense32_cols<K + 2, 16>(r, rke, nlik);
+                dense32_cols<16, 32>(r, rk, nlik_odd);
+            } else {
+                dense32_cols<16, 17>(r, rk, nlik_odd);
+                inv_next = dense32_pivot_inv<16>(r);
+                dense32_cols<17, 32>(r, rk, nlik_odd);
+            }
+        } else if constexpr (K + 1 < 32) {
+            const T nlik_odd = l >= 16 ? nlik : T(0);
+            dense32_cols<K + 1, K + 2>(r, rk, nlik_odd);
+            inv_next = dense32_pivot_inv<K + 1>(r);
+            dense32_cols<K + 2, 32>(r, rk, nlik_odd);
+        }
+        r[K] = l > K ? lik : rk;
+        if constexpr (K + 1 < 32) Dense32Step<K + 1, T>::run(r, dinv, l, inv_next);
+    }
+};
+// TR: 16 x 17 scalars of LDS (the row area, idle in this instantiation)
+template <typename T>
+__device__ __forceinline__ void dense32_factor(T* r, T& dinv, int l, T* TR) {
+    asm volatile("" : "+v"(l));
+    dinv = T(1);
+    Dense32Step<0, T>::run(r, dinv, l, dense32_pivot_inv<0>(r));
+    if (l >= 16) {
+#pragma unroll
+        for (int k = 0; k < 16; ++k) TR[(l - 16) * 17 + k] = r[k];
+    }
+    TSYNC();
+    if (l < 16) {
+        const T d = rcp_(dinv);
+#pragma unroll
+        for (int j = 0; j < 16; ++j) r[16 + j] = TR[j * 17 + l] * d;
+    }
+    TSYNC();
+}
+// L y = b in three legs: the even row's triangle (odd-row lanes ride along with zero multipliers), the odd-row lanes'
+// 16 products with the even row's y (one row exchange), the odd row's triangle; L' x = z the other way round.
+template <int K, int K1, typename T>
+__device__ __forceinline__ void dense32_fwd_tri(const T* r, T& x, int l, bool mine) {
+    if constexpr (K + 1 < K1) {
+        fma_bcast<K % 16>(x, x, (mine && l > K) ? -r[K] : T(0));
+        dense32_fwd_tri<K + 1, K1>(r, x, l, mine);
+    }
+}
+template <int J, int J0, typename T>
+__device__ __forceinline__ void dense32_bwd_tri(const T* r, T dinv, T z, T& acc, int l, bool mine) {
+    if constexpr (J > J0) {
+        const T xj = z - dinv * acc;                    // final in lane J
+        fma_bcast<J % 16>(acc, xj, (mine && l < J) ? r[J] : T(0));
+        dense32_bwd_tri<J - 1, J0>(r, dinv, z, acc, l, mine);
+    }
+}
+template <int C, typename T>
+__device__ __forceinline__ void dense32_cross(const T* r, T& acc, T xo, T sgn, bool mine) {       // acc += sgn sum_c r[C0 + c] (lane c's xo)
+    if constexpr (C < 16) {
+        fma_bcast<C>(acc, xo, mine ? sgn * r[C] : T(0));
+        dense32_cross<C + 1>(r, acc, xo, sgn, mine);
+    }
+}
+template <typename T>
+__device__ __forceinline__ T dense32_solve(const T* r, T dinv, T b, int l) {
+    asm volatile("" : "+v"(l));
+    const bool even = l < 16;
+    T x = b;
+    dense32_fwd_tri<0, 16>(r, x, l, even);                      // y_0 .. y_15
+    dense32_cross<0>(r, x, row_even(x), T(-1), !even);          // odd-row lanes: x -= sum_{K < 16} L[l][K] y_K
+    dense32_fwd_tri<16, 32>(r, x, l, !even);
+    const T z = x * dinv;
+    T acc = T(0);
+    dense32_bwd_tri<31, 16>(r, dinv, z, acc, l, !even);         // x_31 .. x_17 (x_16: its sum is complete)
+    dense32_cross<0>(r + 16, acc, row_odd(z - dinv * acc), T(1), even);     // even-row lanes: acc += sum_{J >= 16} (D_l L[J][l]) x_J
+    dense32_bwd_tri<15, 0>(r, dinv, z, acc, l, even);
+    return z - dinv * acc;
+}
+// my dense row of the mass matrix (see dense_mass_row): Se / Fe = the even-row partner's S and F, So / Fo the odd-row one's
+template <int J, typename T>
+__device__ __forceinline__ void dense32_mass_row(T* md, const T* Se, const T* Fe, const T* So, const T* Fo, const T* S, const T* F,
+                                                 int l, unsigned ancmask, int subsize, bool dof) {
+    T up = T(0), dn = T(0);
+    if constexpr (J < 16) fma_bcast_dots6x<J>(up, dn, Se, Fe, S, F);
+    else fma_bcast_dots6x<J - 16>(up, dn, So, Fo, S, F);
+    const bool anc = (ancmask >> J) & 1u, sub = J > l && J < l + subsize;
+    md[J] = dof ? (anc ? up : (sub ? dn : T(0))) : T(0);
+    if constexpr (J + 1 < 32) dense32_mass_row<J + 1>(md, Se, Fe, So, Fo, S, F, l, ancmask, subsize, dof);
+}
+// r[j] += wn (lane j's jn) + w1 (lane j's j1) + w2 (lane j's j2) over the 32 lanes; je / jo = the Jacobians' entries as
+// the even-row / odd-row partner holds them
+template <int J, bool FRIC, typename T>
+__device__ __forceinline__ void dense32_contact(T* r, const T* je, const T* jo, T wn, T w1, T w2) {
+    if constexpr (J < 16) {
+        if constexpr (FRIC) fma_bcast_3<J>(r[J], je[0], je[1], je[2], wn, w1, w2);
+        else fma_bcast<J>(r[J], je[0], wn);
+    } else {
+        if constexpr (FRIC) fma_bcast_3<J - 16>(r[J], jo[0], jo[1], jo[2], wn, w1, w2);
+        else fma_bcast<J - 16>(r[J], jo[0], wn);
+    }
+    if constexpr (J + 1 < 32) dense32_contact<J + 1, FRIC>(r, je, jo, wn, w1, w2);
+}
+// one name for both dense schemes
+template <int DN, typename T>
+__device__ __forceinline__ void dense_factor_any(T* r, T& dinv, int l, T* TR) {
+    if constexpr (DN == 32) dense32_factor(r, dinv, l, TR);
+    else dense_factor<DN>(r, dinv, l);
+}
+template <int DN, typename T>
+__device__ __forceinline__ T dense_solve_any(const T* r, T dinv, T b, int l) {
+    if constexpr (DN == 32) return dense32_solve(r, dinv, b, l);
+    else return dense_solve<DN>(r, dinv, b, l);
+}
+
 // Exact line search of the constraint solver's safeguard (see the Newton loop): the root in [0, 1] of the increasing,
 // piecewise linear  phi'(al) = g0 + al dg + sum over the particle's rows of D_r min(0, r_r + al dr_r) dr_r  - every lane
 // brings its limit row (Dl, rl, drl) and, as the owner of a contact point, that point's rows (Dc, rb[], drb[]).  Bisection
@@ -906,7 +1113,7 @@ __global__ __launch_bounds__(64 * wg_waves(DP, FRIC, sizeof(T), PL), min_waves(s
     constexpr int CS = GEN ? CS_GEN : CS_BASE;
     constexpr int A_VEC = a_vec(DP, PL), A_JC = a_jc(DP, PL), A_CS = a_cs(DP, NS, NJ, PL), A_MISC = a_misc(DP, NS, NJ, PL, CS),
                   A_ROW2 = a_row2(DP, NS, NJ, PL, CS), A_LEN = a_len(DP, NS, NJ, PL, sizeof(T), DN, CS);
-    static_assert(DN == 0 || (PL == 16 && DN <= 16 && DP <= DN), "dense rows: one particle = one DPP row");
+    static_assert(DN == 0 || (PL == 16 && DN <= 16 && DP <= DN) || (PL == 32 && DN == 32), "dense rows: one particle = one DPP row, or two (DN = 32)");
     constexpr bool MERGE = merge_factor(DP, FRIC, sizeof(T), PL, DN);
     constexpr int NBLOB = T_TOPO;           // the constants the loop reads; topology tables are read once, from global memory
     __shared__ __attribute__((aligned(16))) T lds[NBLOB + 1 + PPW * WG_WAVES * A_LEN];
@@ -1568,6 +1775,12 @@ __global__ __launch_bounds__(64 * wg_waves(DP, FRIC, sizeof(T), PL), min_waves(s
                     // 16-lane particles: my DENSE row straight from DPP broadcasts - column j is S_j . F_l where j is one of
                     // my ancestors (or me), S_l . F_j where j lies in my subtree, zero otherwise; no LDS, no path-indexed row
                     const T Sl[6] = {sw[0], sw[1], sw[2], sv[0], sv[1], sv[2]};
+                    if constexpr (DN == 32) {
+                        T Se[6], So[6], Fe[6], Fo[6];
+#pragma unroll
+                        for (int k = 0; k < 6; ++k) { row_pair(Sl[k], Se[k], So[k]); row_pair(F[k], Fe[k], Fo[k]); }
+                        dense32_mass_row<0>(md, Se, Fe, So, Fo, Sl, F, l, tp.ancmask, tp.subsize, dof);
+                    } else
                     dense_mass_row<0, DN>(md, Sl, F, l, tp.ancmask, tp.subsize, dof);
 #pragma unroll
                     for (int j = 0; j < DN; ++j) md[j] = (j == l) ? (dof ? md[j] + armature : T(1)) : md[j];
@@ -2008,6 +2221,12 @@ __global__ __launch_bounds__(64 * wg_waves(DP, FRIC, sizeof(T), PL), min_waves(s
                         rhs += Dc * jl * rsum;
                         if constexpr (DN > 0) {
                             // dense row: H[l][j] += wn Jn[j] + w1 Jt1[j] + w2 Jt2[j], lane j's entries by DPP broadcast
+                            if constexpr (DN == 32) {
+                                T je[3], jo[3];
+                                row_pair(jl, je[0], jo[0]);
+                                if (FRIC) { row_pair(t1l, je[1], jo[1]); row_pair(t2l, je[2], jo[2]); }
+                                dense32_contact<0, FRIC>(hd, je, jo, wn, w1, w2);
+                            } else
                             dense_contact<0, DN, FRIC>(hd, jl, t1l, t2l, wn, w1, w2);
                         } else if (oi >= 0) {
                             // a contact row couples only dofs on one path: the pattern holds, and my ancestor at distance c
@@ -2025,7 +2244,7 @@ __global__ __launch_bounds__(64 * wg_waves(DP, FRIC, sizeof(T), PL), min_waves(s
                     TSYNC();
                     clk.lap(12);
                     if constexpr (DN > 0) {
-                        dense_factor<DN>(hd, hdinv, l);
+                        dense_factor_any<DN>(hd, hdinv, l, X + A_ROW);
                     } else if (MERGE && it == 0 && !(TREE_SKIP & 2)) {      // ... and the Euler matrix M + h B rides along (consumed in step 6)
 #pragma unroll
                         for (int c = 0; c < DP; ++c) erow[c] = mrow[c];
@@ -2035,7 +2254,7 @@ __global__ __launch_bounds__(64 * wg_waves(DP, FRIC, sizeof(T), PL), min_waves(s
                         tree_factor<DP, PL>(hrow, ELIM, ROW, l, n_rounds, kt, depth);
                     }
                     clk.lap(13);
-                    if constexpr (DN > 0) xa = dense_solve<DN>(hd, hdinv, rhs, l);
+                    if constexpr (DN > 0) xa = dense_solve_any<DN>(hd, hdinv, rhs, l);
                     else xa = tree_solve<DP, PL>(hrow, rhs, ELIM, AT, ROW, VEC, l, n_rounds, depth, max_depth, kt);
                     clk.lap(14);
                     // f32: a row whose residual is within rounding of zero keeps its state (as in arm_rollout.hip)
@@ -2171,7 +2390,7 @@ __global__ __launch_bounds__(64 * wg_waves(DP, FRIC, sizeof(T), PL), min_waves(s
                                 ar = mu > T(0) ? cs[5] - sgn * cs[5 + k] : cs[5];
                             }
                             T zl;
-                            if constexpr (DN > 0) zl = dense_solve<DN>(hd, hdinv, jz_, l);
+                            if constexpr (DN > 0) zl = dense_solve_any<DN>(hd, hdinv, jz_, l);
                             else zl = tree_solve<DP, PL>(hrow, jz_, ELIM, AT, ROW, VEC, l, n_rounds, depth, max_depth, kt);
                             if (!cflip) {
                                 if (flip) {
@@ -2267,8 +2486,8 @@ __global__ __launch_bounds__(64 * wg_waves(DP, FRIC, sizeof(T), PL), min_waves(s
                     T ed[DN > 0 ? DN : 1], edinv;
 #pragma unroll
                     for (int j = 0; j < DN; ++j) ed[j] = md[j] + ((j == l && dof) ? h * damping : T(0));
-                    dense_factor<DN>(ed, edinv, l);
-                    qacc = dense_solve<DN>(ed, edinv, tau + qfrc_c, l);
+                    dense_factor_any<DN>(ed, edinv, l, X + A_ROW);
+                    qacc = dense_solve_any<DN>(ed, edinv, tau + qfrc_c, l);
                 } else {
                     mrow[0] += dof ? h * damping : T(0);
                     tree_factor<DP, PL>(mrow, ELIM, ROW, l, n_rounds, kt, depth);
@@ -2420,7 +2639,11 @@ template <typename T>
 hipError_t launch_tree_rollout_dense(int max_path, int nv, bool gen, const T* model, const T* noise, T* cost, T* act, T* obs, T* nobs,
                                      const TreeLaunchArgs& a) {
     // (16 lanes per particle: the dense in-register factorisation, sized for the model)
-    if (gen) {          // the general instantiation comes in two sizes
+    if (nv > 16) {      // 32 lanes per particle, the dense factorisation over the particle's two DPP rows (dense32_factor)
+        if (max_path <= 16) MJMPC_TREE_LAUNCH_D(16, 16, true, 32, 32, false)
+        else MJMPC_TREE_LAUNCH_D(32, 16, true, 32, 32, false)
+    }
+    else if (gen) {          // the general instantiation comes in two sizes
         if (max_path <= 8) MJMPC_TREE_LAUNCH_D(8, 16, true, 16, 16, true)
         else MJMPC_TREE_LAUNCH_D(16, 16, true, 16, 16, true)
     }
@@ -2469,6 +2692,12 @@ hipError_t launch_tree_rollout(const T* model, int n_model_shards, int max_path,
         else if (max_path <= 16) MJMPC_TREE_LAUNCH(16, 8, false, 32)
         else MJMPC_TREE_LAUNCH(32, 8, false, 32)
     } else if (nv <= 16) {
+        return launch_tree_rollout_dense<T>(max_path, nv, gen, model, noise, cost, act, obs, nobs, a);
+    } else if (!gen && max_path > 8 && !getenv("MJMPC_TREE_SPARSE")) {
+        // 17 .. 32 dofs on elimination paths of more than 8 links: dense over the particle's 32 lanes - measured at 4096 x 32:
+        // pen-in-hand (paths of 16) f64 16.2 -> 9.8 ms, f32 13.8 -> 8.0; with paths of up to 8 links (a hand with friction
+        // cones) the tree-sparse factorisation with its merged Euler matrix stays ahead, 4.15 against 4.27 ms
+        // (MJMPC_TREE_SPARSE in the environment keeps the tree-sparse one everywhere: the A/B switch of tools/tree_time.py)
         return launch_tree_rollout_dense<T>(max_path, nv, gen, model, noise, cost, act, obs, nobs, a);
     } else if (gen) {
         if (max_path <= 16) MJMPC_TREE_LAUNCH_G(16, 16, true, 32)

@@ -1,4 +1,4 @@
-"""Rollout-kernel time of the tree engine: python tools/tree_time.py [P] [H] [dtype] [hand|swimmer|cheetah|pen|cartpole|tray|door]
+"""Rollout-kernel time of the tree engine: python tools/tree_time.py [P] [H] [dtype] [hand|handf|swimmer|cheetah|pen|cartpole|tray|door]
 (MJMPC_AMD_LIB selects an alternative build of the library, e.g. one compiled with -DTREE_SKIP=...)."""
 import os, sys
 import numpy as np
@@ -11,8 +11,15 @@ H = int(sys.argv[2]) if len(sys.argv) > 2 else 16
 dt = sys.argv[3] if len(sys.argv) > 3 else "f64"
 name = sys.argv[4] if len(sys.argv) > 4 else "hand"
 start = None
-if name == "hand":
+if name in ("hand", "handf"):
     raw = hand24_raw()
+    if name == "handf":         # friction cones on the fingertips and the table: the full instantiation (more than 16 dofs)
+        import dataclasses
+        for b in raw.bodies:
+            for g_ in b.geoms:
+                if g_.collide:
+                    g_.friction, g_.condim = 0.8, 3
+        raw.plane = dataclasses.replace(raw.plane, friction=0.5, condim=3)
 elif name == "pen":
     from mjmpc_amd.models.pen_hand import holding_state, pen_hand_raw
     raw = pen_hand_raw()
