@@ -863,15 +863,12 @@ __device__ __forceinline__ T dense_solve(const T* r, T dinv, T b, int l) {
 }
 
 // ---- dense factorisation for 32-lane particles (DN = 32): the particle's two 16-lane DPP rows hold dofs 0..15 (the EVEN
-// row) and 16..31 (the ODD row).  v_permlane16_swap hands every lane the value its partner lane of the other row holds,
-// so a broadcast from any of the 32 lanes is that exchange plus a row broadcast.  Lane l keeps row l of the matrix:
-// even-row lanes need columns 0..15 only (A11); odd-row lanes all 32 (A21 | A22).  Right-looking L D L':
-//   pivot K < 16 (an even-row lane): columns K+1..15 of the pivot row cross the rows (swap + broadcast FMA); columns
-//     16..31 are A[K][j] = A[j][K], the not yet scaled entry K of odd-row lane j - a broadcast inside the odd row;
-//   pivot K >= 16: the 16-lane scheme inside the odd row (even-row lanes ride along with a zero multiplier).
-// At the end the odd row's L[j][0..15] are transposed through LDS into the even-row lanes' entries 16..31 (as D_i L[j][i],
-// what the backward solve reads).  ~900 instructions against the tree-sparse factorisation's rounds of LDS traffic:
-// measured on the pen-in-hand model (30 dofs, elimination paths of 16) 20 k -> see DESIGN 4.6.5 cycles per factorisation.
+// row) and 16..31 (the ODD row); v_permlane16_swap hands every lane the value its partner lane of the other row holds.
+// Lane l keeps row l of the matrix: even-row lanes columns 0..15 only (A11), odd-row lanes all 32 (A21 | A22).
+// Right-looking L D L' - see Dense32Step for how a step gets by with one row exchange.  At the end the odd row's
+// L[j][0..15] are transposed through LDS into the even-row lanes' entries 16..31 (as D_i L[j][i], what the backward solve
+// reads).  Measured on the pen-in-hand model (30 dofs, elimination paths of 16 links), cycles per factorisation / solve:
+// tree-sparse 20.4 k / 10.6 k, this 8.6 k / 3.2 k.
 __device__ __forceinline__ void row_pair(float x, float& even, float& odd) {
     const unsigned u = __float_as_uint(x);
     const auto r = __builtin_amdgcn_permlane16_swap(u, u, false, false);

@@ -23,9 +23,29 @@ for WL in half_cheetah swimmer hand24 pen_hand cartpole tray door; do
 done
 : > $OUT/${TAG}_controllers.jsonl
 python3 bench.py --controller cem --particles 16384 --steps 100 --warmup 10 --no-cpu-baseline >> $OUT/${TAG}_controllers.jsonl 2>> $OUT/${TAG}_bench_f64.err
+python3 bench.py --controller cem --particles 1024 --steps 100 --warmup 10 --no-cpu-baseline >> $OUT/${TAG}_controllers.jsonl 2>> $OUT/${TAG}_bench_f64.err
 python3 bench.py --controller cem --particles 4096 --steps 100 --warmup 10 --no-cpu-baseline >> $OUT/${TAG}_controllers.jsonl 2>> $OUT/${TAG}_bench_f64.err
 python3 bench.py --controller dmd --particles 4096 --steps 100 --warmup 10 --no-cpu-baseline >> $OUT/${TAG}_controllers.jsonl 2>> $OUT/${TAG}_bench_f64.err
 python3 tools/bench_configs.py --steps 40 --pen > $OUT/${TAG}_other_configs_f64.jsonl 2>> $OUT/${TAG}_bench_f64.err
+python3 tools/bench_configs.py --steps 40 --pen --dtype f32 > $OUT/${TAG}_other_configs_f32.jsonl 2>> $OUT/${TAG}_bench_f64.err
+# tree kernel: launch times from a fixed start state (tools/tree_time.py; MJMPC_TREE_SPARSE=1: the tree-sparse factorisation
+# where the dense 32-lane one is the default) and, when the instrumented library is there, its phase clocks
+: > $OUT/${TAG}_tree_time.txt
+for c in "4096 32 f64 cheetah" "4096 32 f64 swimmer" "4096 32 f64 hand" "4096 32 f64 handf" "4096 32 f64 pen" "4096 32 f32 pen" "4096 32 f64 tray" "4096 32 f64 door" "4096 32 f64 cartpole" "65536 16 f64 hand"; do
+  python3 tools/tree_time.py $c 2>/dev/null | tail -1 >> $OUT/${TAG}_tree_time.txt
+done
+for c in "4096 32 f64 pen" "4096 32 f32 pen" "4096 32 f64 handf"; do
+  echo -n "MJMPC_TREE_SPARSE=1: " >> $OUT/${TAG}_tree_time.txt
+  MJMPC_TREE_SPARSE=1 python3 tools/tree_time.py $c 2>/dev/null | tail -1 >> $OUT/${TAG}_tree_time.txt
+done
+if [ -f tools/_build/libmjmpc_amd_treestats.so ]; then
+  : > $OUT/${TAG}_tree_stats.txt
+  for m in cheetah swimmer hand pen; do python3 tools/tree_stats.py $m f64 4096 32 2>/dev/null | tail -11 >> $OUT/${TAG}_tree_stats.txt; done
+  python3 tools/tree_stats.py pen f32 4096 32 2>/dev/null | tail -11 >> $OUT/${TAG}_tree_stats.txt
+fi
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/${TAG}_prof_pen -o ${TAG}_pen -- python3 bench.py --workload pen_hand --controller dmd --particles 65536 --horizon 64 --steps 4 --warmup 1 --process-warmup 0 --no-cpu-baseline > $OUT/${TAG}_pen_65536x64_line_under_rocprof.json 2> $OUT/${TAG}_prof_pen.err
+f=$(find $OUT/${TAG}_prof_pen -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp $f $OUT/${TAG}_pen_65536x64_kernel_stats.csv
+rm -rf $OUT/${TAG}_prof_pen
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/${TAG}_prof_f64 -o ${TAG}_f64 -- python3 bench.py --steps 100 --warmup 10 --no-cpu-baseline > $OUT/${TAG}_bench_f64_line_under_rocprof.json 2> $OUT/${TAG}_prof_f64.err
 f=$(find $OUT/${TAG}_prof_f64 -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp $f $OUT/${TAG}_bench_f64_kernel_stats.csv
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/${TAG}_prof_cem -o ${TAG}_cem -- python3 bench.py --controller cem --particles 16384 --steps 100 --warmup 10 --no-cpu-baseline > $OUT/${TAG}_cem_line_under_rocprof.json 2> $OUT/${TAG}_prof_cem.err
