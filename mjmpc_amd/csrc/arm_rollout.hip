@@ -515,6 +515,14 @@ __device__ __forceinline__ void active_set(T aw, T sig, T aref, T jc, T arefc, b
     }
 }
 
+// developer A/B switch: the SOLVE wave takes E2 (the Euler inverse's hand-over) after its Newton iterations instead of
+// inside the first one - measured (round 4, 4096 x 32 f64): rollout kernel 0.1775 -> 0.186 ms, the inverse's row then
+// arrives with its LDS latency in front of the Euler product; off
+#ifdef ARM_E2_LATE
+constexpr bool E2_LATE = true;
+#else
+constexpr bool E2_LATE = false;
+#endif
 // DUO launches: which wave evaluates the joint-limit rows (see arm_front)
 template <typename T>
 __device__ __forceinline__ constexpr bool rows_by_dyn() {
@@ -721,7 +729,7 @@ __device__ __forceinline__ void arm_front(const MT& M, const ArmInts& I, T& q, T
                 for (int i = 0; i < MAX_LINKS; ++i) col[i] = (i == l8) ? T(1) : T(0);
                 F.solve(col);
                 ST.mark(it == 0 ? 6 : 9);               // factorisation + inverse / further iterations
-                if (it == 0 && !rows_by_dyn<T>()) {     // (E2 where round 2 had it: this wave arrives ~2000 cycles after E1)
+                if (it == 0 && !rows_by_dyn<T>() && !E2_LATE) {     // (E2 where round 2 had it: this wave arrives ~2000 cycles after E1)
                     duo_barrier();
 #pragma unroll
                     for (int i = 0; i < MAX_LINKS; ++i) ei[i] = ldsM[V_EI + l8 * LANES + i];
@@ -740,7 +748,7 @@ __device__ __forceinline__ void arm_front(const MT& M, const ArmInts& I, T& q, T
                 // this wave gets HERE in about as many (after the first factorisation it would still wait ~400).  Taking
                 // the rendezvous inside the first iteration rather than at the end of the substep leaves only E3
                 // between the last Newton iteration and the integration.
-                if (it == 0 && rows_by_dyn<T>()) {
+                if (it == 0 && rows_by_dyn<T>() && !E2_LATE) {
                     duo_barrier();
 #pragma unroll
                     for (int i = 0; i < MAX_LINKS; ++i) ei[i] = ldsM[V_EI + l8 * LANES + i];   // my row of (M + h B)^-1, early
@@ -794,7 +802,7 @@ __device__ __forceinline__ void arm_front(const MT& M, const ArmInts& I, T& q, T
             }
         }
         ldsM[V_RE + l8] = tau + qfrc_c;
-        if (!any_rows) {
+        if (!any_rows || E2_LATE) {
             duo_barrier();                              // E2 (substeps without rows; otherwise taken inside the loop)
 #pragma unroll
             for (int i = 0; i < MAX_LINKS; ++i) ei[i] = ldsM[V_EI + l8 * LANES + i];
