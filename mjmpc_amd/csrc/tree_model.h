@@ -35,9 +35,11 @@ enum TreeOffset : int {
     T_SPRINGREF = T_STIFFNESS + TL,
     T_FBOX = T_SPRINGREF + TL,          // 3 x 32   box of equal inertia (fluid model), 0 for massless links
     T_FROT = T_FBOX + 3 * TL,           // 9 x 32   principal axes of the link's inertia in the link frame (row-major)
-    T_KPG = T_FROT + 9 * TL,            // position servos: gear^2 kp (the stiffness of their bias at the joint)
+    T_KPG = T_FROT + 9 * TL,            // actuator bias on the length, at the joint: -gear^2 biasprm[1] (position servo: gear^2 kp)
+    T_KVG = T_KPG + TL,                 // ... on the velocity: -gear^2 biasprm[2] (<velocity kv>: gear^2 kv); explicit, not part of M + hB
+    T_TAU0 = T_KVG + TL,                // ... constant: gear biasprm[0]
     // scalars
-    T_NV = T_KPG + TL,
+    T_NV = T_TAU0 + TL,
     T_TIMESTEP,
     T_FRAME_SKIP,
     T_JUMPS,                            // pointer-jumping rounds = ceil(log2(tree depth))
@@ -121,6 +123,6 @@ constexpr int TREE_QW = 2 * TL + 6;
 constexpr int TREE_NQ_MAX = 40;
 // the C ABI's state vectors (mjmpc_tree_set_shard_states): MuJoCo's layout - qpos[40] | qvel[32] | target[3] | reserved[3]
 constexpr int TREE_PUBLIC_STATE_LEN = TREE_NQ_MAX + TL + 6;
-static_assert(TREE_BLOB_LEN == 3638, "keep in sync with mjmpc_amd/models/compile_tree.py::TREE_LAYOUT");
+static_assert(TREE_BLOB_LEN == 3702, "keep in sync with mjmpc_amd/models/compile_tree.py::TREE_LAYOUT");
 
 }  // namespace mjmpc

@@ -45,7 +45,9 @@ TREE_LAYOUT = [
     ("armature", TL), ("damping", TL), ("range_lo", TL), ("range_hi", TL), ("limited", TL), ("gear", TL),
     ("ctrl_lo", TL), ("ctrl_hi", TL), ("dof_invweight0", TL),
     ("stiffness", TL), ("springref", TL), ("fbox", 3 * TL), ("frot", 9 * TL),
-    ("kpg", TL),                    # position servos: gear^2 kp, the stiffness of their bias -kp * (gear q) at the joint
+    ("kpg", TL),                    # actuator bias on the length, as a joint stiffness about 0: -gear^2 biasprm[1] (servo: gear^2 kp)
+    ("kvg", TL),                    # ... on the velocity: -gear^2 biasprm[2]  (explicit: MuJoCo's Euler is implicit in joint damping only)
+    ("tau0", TL),                   # ... constant: gear biasprm[0]
     ("nv", 1), ("timestep", 1), ("frame_skip", 1), ("jumps", 1), ("site_link", 1), ("site_pos", 3),
     ("n_sphere", 1), ("plane_n", 3), ("plane_d", 1),
     ("sol_K", 1), ("sol_B", 1), ("sol_dmin", 1), ("sol_dmax", 1), ("sol_width", 1), ("sol_mid", 1), ("sol_power", 1),
@@ -449,11 +451,15 @@ def compile_tree(raw: RawModel, overrides=None, base: "TreeModel" = None) -> Tre
         if f["act"][d] >= 0:
             raise ValueError("two motors on joint %r" % act.joint)
         f["act"][d] = a
-        # motor: gear * clip(ctrl).  Position servo (MJCF <position kp>): gear * kp * (clip(ctrl) - gear * q) - the ctrl
-        # part through an effective gear, the bias as a joint stiffness gear^2 kp about 0
-        f["gear"][d] = act.gear * (act.kp if act.kp > 0 else 1.0)
-        f["kpg"][d] = act.gear * act.gear * act.kp
-        f["ctrl_lo"][d], f["ctrl_hi"][d] = act.ctrlrange
+        # joint torque = gear * (gain * clip(ctrl) + b0 + b1 * gear q + b2 * gear v)  (mj_fwdActuation, gaintype fixed,
+        # biastype affine; motor: gain 1; <position kp>: gain kp, b1 = -kp; <velocity kv>: gain kv, b2 = -kv): the ctrl part
+        # through an effective gear, the rest as a stiffness about 0, a damping-like term and a constant at the joint
+        b0, b1, b2 = act.bias
+        f["gear"][d] = act.gear * act.gain
+        f["kpg"][d] = -act.gear * act.gear * b1
+        f["kvg"][d] = -act.gear * act.gear * b2
+        f["tau0"][d] = act.gear * b0
+        f["ctrl_lo"][d], f["ctrl_hi"][d] = act.ctrlrange if act.ctrllimited else (-np.inf, np.inf)
         ctrl_lo[a], ctrl_hi[a] = act.ctrlrange
 
     # ---- constants at qpos0 (MuJoCo mj_setConst): M0, dof / body invweight0 ------------------------------
@@ -739,7 +745,7 @@ def compile_tree(raw: RawModel, overrides=None, base: "TreeModel" = None) -> Tre
     f["nq"][0] = nq
     f["has_ball"][0] = 1.0 if any(k == LINK_BALL_X for k in link_kind) else 0.0
     f["any_friction"][0] = 1.0 if (any(f["spheres"][k * SPH_STRIDE + 7] > 0 for k in range(nsp)) or pair_geoms
-                                   or any(f["kpg"] != 0) or raw.task == TASK_ORIENT or gen) else 0.0
+                                   or any(f["kpg"] != 0) or any(f["kvg"] != 0) or any(f["tau0"] != 0) or raw.task == TASK_ORIENT or gen) else 0.0
 
     def sol_set(prefix, solref, solimp):
         vals = sol_values(solref, solimp)

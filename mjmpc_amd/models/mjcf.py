@@ -18,7 +18,8 @@ panda/tray_glass-v0.yml, sawyer/door-v0.yml, hand/*-v0.yml):
   ``self_collision`` - with other bodies is decided by MuJoCo's rule), ``solref`` / ``solimp`` (one set per model);
 * one world ``<geom type="plane">`` in any orientation, static sphere / capsule / box geoms on the world body (they
   collide with moving geoms through MuJoCo's contype / conaffinity rule or an explicit ``<pair>``), world and body
-  ``<site>``s, ``<motor joint gear ctrlrange ctrllimited>`` and ``<position joint kp ctrlrange ctrllimited>`` actuators,
+  ``<site>``s, ``<motor>`` / ``<position kp>`` / ``<velocity kv>`` / ``<general gainprm biasprm biastype=affine>`` actuators
+  (``joint gear ctrlrange ctrllimited``; no activation dynamics, no force limits),
   ``<contact><pair geom1 geom2>``; geom pairs: sphere / capsule against sphere / capsule, sphere against box;
 * ``<equality><connect body1 body2 anchor>``, ``<weld body1 body2>`` and ``<joint joint1 joint2 polycoef>`` (``solref`` /
   ``solimp`` each),
@@ -109,7 +110,7 @@ class _Defaults:
     """``<default>`` classes: attributes of joint / geom / motor, inherited from the enclosing class."""
 
     def __init__(self, root):
-        self.cls = {"main": {"joint": {}, "geom": {}, "motor": {}}}
+        self.cls = {"main": {"joint": {}, "geom": {}, "motor": {}}}     # ("motor" holds the actuator defaults of every shortcut)
         top = root.find("default")
         if top is not None:
             self._read(top, "main", None)
@@ -120,6 +121,10 @@ class _Defaults:
             e = node.find(tag)
             if e is not None:
                 base[tag].update(e.attrib)
+        for tag in ("general", "position", "velocity"):     # MuJoCo keeps ONE actuator default per class: the shortcuts all set it
+            e = node.find(tag)
+            if e is not None:
+                base["motor"].update(e.attrib)
         self.cls[name] = base
         for child in node.findall("default"):
             cname = child.get("class")
@@ -419,13 +424,32 @@ def load_mjcf(path, hand_site="finger", target_site="target", frame_skip=2, task
     act = root.find("actuator")
     for m in (list(act) if act is not None else []):
         ma = lambda k, d=None: dfl.attr("motor", m, None, k, d)         # noqa: E731
-        if m.tag not in ("motor", "position") or ma("ctrllimited", "false") != "true":
-            raise ValueError("only ctrllimited <motor> / <position> actuators are supported")
+        if m.tag not in ("motor", "position", "velocity", "general"):
+            raise ValueError("unsupported actuator <%s> (motor, position, velocity and general are)" % m.tag)
+        for k in ("dyntype", "gaintype", "biastype"):
+            if m.tag == "general" and ma(k, "none" if k != "gaintype" else "fixed") not in (
+                    ("none",) if k == "dyntype" else (("fixed",) if k == "gaintype" else ("none", "affine"))):
+                raise ValueError("general actuators: dyntype none, gaintype fixed, biastype none / affine")
+        if ma("forcelimited", "false") == "true":
+            raise ValueError("actuator forcerange is not supported")
+        limited = ma("ctrllimited", "false") == "true"
+        if ma("ctrlrange") is None:
+            raise ValueError("an actuator needs a ctrlrange (it bounds the action space; ctrllimited says whether the physics clamp)")
         gear = _floats(ma("gear"), None, [1.0])[0]
-        kp = float(m.get("kp", "1")) if m.tag == "position" else 0.0       # MJCF <position>: kp defaults to 1
+        gainprm, biasprm, kp = None, None, 0.0
+        if m.tag == "position":
+            kp = float(ma("kp", "1"))                      # MJCF <position>: kp defaults to 1
+        elif m.tag == "velocity":
+            kv = float(ma("kv", "1"))
+            gainprm, biasprm = kv, (0.0, 0.0, -kv)
+        elif m.tag == "general":
+            gainprm = _floats(ma("gainprm"), None, [1.0])[0]
+            bp = list(_floats(ma("biasprm"), None, [0.0])) + [0.0, 0.0, 0.0]
+            biasprm = tuple(bp[:3]) if ma("biastype", "none") == "affine" else (0.0, 0.0, 0.0)
         if m.get("joint") is None and m.get("tendon") is None:
             raise ValueError("an actuator acts on a joint or on a fixed tendon")
-        acts.append(RawActuator(m.get("joint") or "", gear, _floats(ma("ctrlrange"), 2), kp=kp, tendon=m.get("tendon") or ""))
+        acts.append(RawActuator(m.get("joint") or "", gear, _floats(ma("ctrlrange"), 2), kp=kp, tendon=m.get("tendon") or "",
+                                gainprm=gainprm, biasprm=biasprm, ctrllimited=limited))
 
     # equality constraints
     equalities = []

@@ -48,7 +48,7 @@ TASK_ORIENT = 2             # in-hand reorientation, the shape of pen-v0's rewar
                             # carried by the site's body), d* = target_dir; obs as TASK_REACH
 BODY_STRIDE = 40
 GEOM_STRIDE = 24
-ACT_STRIDE = 6
+ACT_STRIDE = 11
 PAIR_STRIDE = 2
 EQ_STRIDE = 28
 TENDON_MAX_JOINTS = 4
@@ -143,6 +143,21 @@ class RawActuator:
     kp: float = 0.0                         # 0: motor, force = gear * clip(ctrl).  > 0: MJCF <position kp=...>, a servo -
                                             # force = kp * (clip(ctrl) - gear * q), applied through the gear
     tendon: str = ""                        # not "": the actuator pulls on this fixed tendon instead of a joint
+    # MJCF <general> with gaintype fixed / biastype affine (and <velocity kv>): scalar force = gainprm * clip(ctrl) +
+    # biasprm[0] + biasprm[1] * length + biasprm[2] * velocity, length = gear * q; None = what `kp` says
+    gainprm: Optional[float] = None
+    biasprm: Optional[Sequence[float]] = None
+    ctrllimited: bool = True                # False: the control is not clamped (ctrlrange still bounds the action space)
+
+    @property
+    def gain(self):
+        return float(self.gainprm) if self.gainprm is not None else (self.kp if self.kp > 0 else 1.0)
+
+    @property
+    def bias(self):
+        if self.biasprm is not None:
+            return tuple(float(x) for x in self.biasprm)
+        return (0.0, -self.kp, 0.0) if self.kp > 0 else (0.0, 0.0, 0.0)
 
 
 @dataclass
@@ -318,6 +333,9 @@ class RawModel:
             r[1] = a.gear
             r[2:4] = a.ctrlrange
             r[4] = a.kp
+            r[6] = a.gain
+            r[7:10] = a.bias
+            r[10] = 1.0 if a.ctrllimited else 0.0
             out.append(r)
         names = [g.name for _, g in geoms]
         for ga, gb in self.pairs:

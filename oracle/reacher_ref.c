@@ -49,7 +49,7 @@
 #define HEADER_LEN 80
 #define BODY_STRIDE 40
 #define GEOM_STRIDE 24
-#define ACT_STRIDE 6
+#define ACT_STRIDE 11
 #define PAIR_STRIDE 2
 #define EQ_STRIDE 28
 #define TENDON_STRIDE (8 + 2 * MAXTJ)
@@ -87,7 +87,12 @@ typedef struct {
     double mass[MAXB], ipos[MAXB][3], inertia[MAXB][9];  /* tensor about the COM, body frame */
     /* motors */
     int act_dof[MAXV], act_tendon[MAXV];     /* act_tendon: the actuator pulls on fixed tendon act_dof[a] */
-    double gear[MAXV], ctrl_lo[MAXV], ctrl_hi[MAXV], kp[MAXV];   /* kp > 0: position servo (MJCF <position>) */
+    double gear[MAXV], ctrl_lo[MAXV], ctrl_hi[MAXV];
+    /* MuJoCo actuator with gaintype fixed / biastype affine (mj_fwdActuation [EXT]): scalar force = gain ctrl + bias[0] +
+     * bias[1] length + bias[2] velocity, length = gear q; a motor is gain 1, <position kp> gain kp / bias (0, -kp, 0),
+     * <velocity kv> gain kv / bias (0, 0, -kv) */
+    double act_gain[MAXV], act_bias[MAXV][3];
+    int ctrllimited[MAXV];
     /* site + target */
     int site_body;
     double site_pos[3], target_default[3];
@@ -657,8 +662,10 @@ OrModel *or_model_compile(const double *f, int n) {
         m->gear[a] = a0[a * ACT_STRIDE + 1];
         m->ctrl_lo[a] = a0[a * ACT_STRIDE + 2];
         m->ctrl_hi[a] = a0[a * ACT_STRIDE + 3];
-        m->kp[a] = a0[a * ACT_STRIDE + 4];
         m->act_tendon[a] = (int)a0[a * ACT_STRIDE + 5];
+        m->act_gain[a] = a0[a * ACT_STRIDE + 6];
+        for (int i = 0; i < 3; i++) m->act_bias[a][i] = a0[a * ACT_STRIDE + 7 + i];
+        m->ctrllimited[a] = a0[a * ACT_STRIDE + 10] != 0.0;
     }
     /* geom-geom pairs: spheres and capsules are segments (from, to - from) with a radius; ONE geom of a pair may be a box
      * (against a sphere); friction / condim / margin of a contact = the larger of the two geoms' (MuJoCo mj_contactParam
@@ -1203,22 +1210,30 @@ void or_step(OrModel *m, double *q, double *v, const double *ctrl, double *site_
                 for (int i = 0; i < 3; i++) fs[j] += Jp[i * nv + j] * wf[i] + Jr[i * nv + j] * wt[i];
         }
     }
-    for (int a = 0; a < m->nu; a++) {                                          /* motors, ctrllimited */
+    for (int a = 0; a < m->nu; a++) {                                          /* actuators */
         double u = ctrl[a];
-        if (u < m->ctrl_lo[a]) u = m->ctrl_lo[a];
-        if (u > m->ctrl_hi[a]) u = m->ctrl_hi[a];
+        if (m->ctrllimited[a]) {
+            if (u < m->ctrl_lo[a]) u = m->ctrl_lo[a];
+            if (u > m->ctrl_hi[a]) u = m->ctrl_hi[a];
+        }
+        const double *b = m->act_bias[a];
         if (m->act_tendon[a]) {
-            /* an actuator on a fixed tendon: length = sum coef q, moment arm of dof i = gear * coef_i */
+            /* an actuator on a fixed tendon: length = gear sum coef q, moment arm of dof i = gear * coef_i */
             int t = m->act_dof[a];
-            double len = 0;
-            for (int i = 0; i < m->tn_n[t]; i++) len += m->tn_coef[t][i] * q[m->dof_qadr[m->tn_dof[t][i]]];
-            double frc = m->kp[a] > 0 ? m->kp[a] * (u - m->gear[a] * len) : u;
+            double len = 0, vel = 0;
+            for (int i = 0; i < m->tn_n[t]; i++) {
+                len += m->tn_coef[t][i] * q[m->dof_qadr[m->tn_dof[t][i]]];
+                vel += m->tn_coef[t][i] * v[m->tn_dof[t][i]];
+            }
+            double frc = m->act_gain[a] * u + b[0] + b[1] * m->gear[a] * len + b[2] * m->gear[a] * vel;
             for (int i = 0; i < m->tn_n[t]; i++) fs[m->tn_dof[t][i]] += m->gear[a] * m->tn_coef[t][i] * frc;
             continue;
         }
-        /* motor: gear * ctrl; position servo (MJCF <position kp>): gain kp, bias -kp * length, length = gear * q */
-        double qa = m->kp[a] > 0 ? q[m->dof_qadr[m->act_dof[a]]] : 0.0;
-        fs[m->act_dof[a]] += m->kp[a] > 0 ? m->gear[a] * m->kp[a] * (u - m->gear[a] * qa) : m->gear[a] * u;
+        /* on a joint: length = gear q, velocity = gear v, the force acts through the gear */
+        int d = m->act_dof[a];
+        double len = (b[1] != 0.0) ? m->gear[a] * q[m->dof_qadr[d]] : 0.0;
+        double frc = m->act_gain[a] * u + b[0] + b[1] * len + b[2] * m->gear[a] * v[d];
+        fs[d] += m->gear[a] * frc;
     }
     /* constraint rows, in MuJoCo's order: equality, friction loss, limits, contacts */
     static const double ZERO3[3] = {0, 0, 0};

@@ -421,3 +421,58 @@ def test_weld_keeps_the_relative_pose(tmp_path):
     assert abs(q[14]) < 2e-3                                    # the welded pendulum did not fall
     assert q[2] < 1.0 - 0.5 * 9.81 * 0.6 ** 2 * 0.8            # ... while the pair did
     assert ref.newton_stats()["fails"] == 0
+
+
+# ------------------------------------------------------------------------------------------ actuators
+ARM2 = """
+<body name="a" pos="0 0 1"><joint name="j1" type="hinge" axis="0 1 0" damping="0.1" armature="0.01"/>
+  <geom type="capsule" fromto="0 0 0 0.3 0 0" size="0.03"/>
+  <body name="b" pos="0.3 0 0"><joint name="j2" type="hinge" axis="0 1 0" damping="0.1" armature="0.01"/>
+    <geom type="capsule" fromto="0 0 0 0.2 0 0" size="0.02"/><site name="finger" pos="0.2 0 0"/></body></body>"""
+
+
+def test_velocity_and_general_actuators(tmp_path):
+    """mj_fwdActuation with gaintype fixed / biastype affine [EXT]: scalar force = gain ctrl + b0 + b1 (gear q) + b2 (gear v),
+    joint torque = gear force.  A <velocity kv> servo settles at the commanded joint speed; a <general> with the
+    parameters of a <position kp> IS that servo (same trajectory to rounding); the constant bias b0 acts like a motor at
+    ctrl = b0 / gain; ctrllimited="false" leaves the control unclamped; defaults reach every shortcut."""
+    acts = ('<actuator><velocity joint="j1" kv="5" gear="2" ctrlrange="-3 3" ctrllimited="true"/>'
+            '<motor joint="j2" gear="1" ctrlrange="-1 1" ctrllimited="true"/></actuator>')
+    raw, ref = _model(tmp_path, ARM2, gravity="0 0 0", extra=acts, name="vel.xml")
+    a = raw.actuators[0]
+    assert a.gain == 5.0 and a.bias == (0.0, 0.0, -5.0) and raw.actuators[1].gain == 1.0 and raw.actuators[1].bias == (0, 0, 0)
+    q, v, _ = _run(ref, raw.qpos0.copy(), np.zeros(2), np.array([1.5, 0.0]), 3000)
+    # steady state: gear kv (u - gear w) = damping w  ->  w = gear kv u / (damping + gear^2 kv)
+    assert abs(v[0] - 2 * 5 * 1.5 / (0.1 + 4 * 5)) < 1e-6
+    # general == position
+    pos = '<actuator><position joint="j1" kp="30" gear="1.5" ctrlrange="-1 1" ctrllimited="true"/><motor joint="j2" ctrlrange="-1 1" ctrllimited="true"/></actuator>'
+    gen = ('<actuator><general joint="j1" gainprm="30" biastype="affine" biasprm="0 -30 0" gear="1.5" ctrlrange="-1 1" ctrllimited="true"/>'
+           '<motor joint="j2" ctrlrange="-1 1" ctrllimited="true"/></actuator>')
+    _, rp = _model(tmp_path, ARM2, extra=pos, name="pos.xml")
+    rg_raw, rg = _model(tmp_path, ARM2, extra=gen, name="gen.xml")
+    assert rg_raw.actuators[0].gain == 30.0 and rg_raw.actuators[0].bias == (0.0, -30.0, 0.0)
+    u = np.array([0.4, -0.3])
+    qa, va, _ = _run(rp, rg_raw.qpos0.copy(), np.zeros(2), u, 400)
+    qb, vb, _ = _run(rg, rg_raw.qpos0.copy(), np.zeros(2), u, 400)
+    np.testing.assert_allclose(np.r_[qa, va], np.r_[qb, vb], rtol=0, atol=1e-10)
+    # constant bias = a motor held at b0 / gain; unclamped control
+    b0 = ('<actuator><general joint="j1" gainprm="2" biastype="affine" biasprm="0.6 0 0" gear="3" ctrlrange="-1 1" ctrllimited="false"/>'
+          '<motor joint="j2" ctrlrange="-1 1" ctrllimited="true"/></actuator>')
+    mot = '<actuator><motor joint="j1" gear="3" ctrlrange="-100 100" ctrllimited="true"/><motor joint="j2" ctrlrange="-1 1" ctrllimited="true"/></actuator>'
+    rb_raw, rb = _model(tmp_path, ARM2, extra=b0, name="b0.xml")
+    _, rm = _model(tmp_path, ARM2, extra=mot, name="mot.xml")
+    assert not rb_raw.actuators[0].ctrllimited
+    qa, va, _ = _run(rb, rb_raw.qpos0.copy(), np.zeros(2), np.array([2.5, 0.0]), 200)         # 2 * 2.5 + 0.6 = 5.6 (beyond the range)
+    qb, vb, _ = _run(rm, rb_raw.qpos0.copy(), np.zeros(2), np.array([5.6, 0.0]), 200)
+    np.testing.assert_allclose(np.r_[qa, va], np.r_[qb, vb], rtol=0, atol=1e-10)
+    # one actuator default per class, whichever shortcut sets it
+    dflt = HEAD.replace("<mujoco>", '<mujoco><default><general ctrllimited="true" ctrlrange="-2 2" gear="4"/></default>')
+    rd, _ = _model(tmp_path, ARM2, extra='<actuator><velocity joint="j1" kv="3"/><motor joint="j2"/></actuator>', name="d.xml", head=dflt)
+    assert rd.actuators[0].gear == 4.0 and list(rd.actuators[1].ctrlrange) == [-2.0, 2.0] and rd.actuators[0].ctrllimited
+    # the compiled blocks: ctrl part through an effective gear, biases at the joint; unclamped -> infinite bounds in the kernel's block
+    tm = compile_tree(rb_raw)
+    assert tm.field("gear")[0] == 6.0 and tm.field("tau0")[0] == 3 * 0.6 and np.isinf(tm.field("ctrl_lo")[0]) and tm.ctrl_lo[0] == -1.0
+    tv = compile_tree(raw)
+    assert tv.field("kvg")[0] == 4 * 5.0 and tv.field("kpg")[0] == 0.0 and tv.field("gear")[0] == 10.0
+    with pytest.raises(ValueError, match="dyntype"):
+        _model(tmp_path, ARM2, extra='<actuator><general joint="j1" dyntype="integrator" ctrlrange="-1 1"/><motor joint="j2" ctrlrange="-1 1"/></actuator>', name="dyn.xml")

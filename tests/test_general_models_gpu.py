@@ -258,3 +258,40 @@ def test_weld_equality_matches_oracle(tmp_path):
     np.testing.assert_allclose(rew, o_rew, rtol=1e-8, atol=1e-8)
     np.testing.assert_allclose(nobs, o_nobs, rtol=0, atol=1e-7)
     assert eng.solver_failures() == 0 and ref.newton_stats()["fails"] == 0
+
+
+def test_velocity_and_general_actuators_match_oracle(tmp_path):
+    """<velocity kv>, <general gainprm biasprm biastype="affine"> with all three bias terms, and an unclamped control
+    (ctrllimited="false") on a two-link arm under gravity: the kernel carries the bias as a stiffness, a velocity term
+    and a constant torque at the joint (T_KPG / T_KVG / T_TAU0).  One env step from 32 random states at 1e-9, a 64 x 12
+    rollout at 1e-9."""
+    from mjmpc_amd.envs.tree_engine import TreeRolloutEngine
+    import importlib.util, os
+    spec = importlib.util.spec_from_file_location("general_models_cpu", os.path.join(os.path.dirname(os.path.abspath(__file__)), "test_general_models_cpu.py"))
+    cpu = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(cpu)
+    acts = ('<actuator><velocity joint="j1" kv="4" gear="2" ctrlrange="-3 3" ctrllimited="true"/>'
+            '<general joint="j2" gainprm="6" biastype="affine" biasprm="0.3 -5 -0.2" gear="1.5" ctrlrange="-1 1" ctrllimited="false"/></actuator>')
+    raw, ref = cpu._model(tmp_path, cpu.ARM2, extra=acts, timestep="0.004", frame_skip=2)
+    eng = TreeRolloutEngine(raw, dtype="f64")
+    assert eng.model.field("kvg")[0] == 16.0 and eng.model.field("tau0")[1] == 1.5 * 0.3 and not eng.model.general
+    rs = np.random.RandomState(11)
+    tgt = np.asarray(raw.target_pos, float)
+    worst = 0.0
+    for _ in range(32):
+        q, v, u = rs.uniform(-2, 2, 2), 3 * rs.standard_normal(2), rs.uniform(-4, 4, 2)      # (controls beyond both ranges)
+        eng.set_env_state(dict(qp=q, qv=v, target_pos=tgt))
+        _, rew, _, _, _, nobs = eng.rollout(1, 1, u[None], None, "open_loop")
+        q1, v1, r1, o1 = ref.env_step(q, v, u, tgt)
+        worst = max(worst, np.abs(nobs[0, 0] - o1).max() / max(1.0, np.abs(o1).max()), abs(rew[0, 0] - r1) / max(1.0, abs(r1)))
+    print("actuators: one env step from 32 random states, worst relative error %.2e" % worst)
+    assert worst < 1e-9, worst
+    P, H = 64, 12
+    q, v = np.array([0.3, -0.5]), np.zeros(2)
+    eps = 1.5 * rs.standard_normal((P, H, 2))
+    eng.set_env_state(dict(qp=q, qv=v, target_pos=tgt))
+    obs, rew, act, done, info, nobs = eng.rollout(P, H, np.zeros((H, 2)), eps, "open_loop")
+    o_obs, o_rew, _, _, o_nobs = ref.rollout(q, v, tgt, np.zeros((H, 2)), eps)
+    np.testing.assert_allclose(rew, o_rew, rtol=1e-9, atol=1e-9)
+    np.testing.assert_allclose(nobs, o_nobs, rtol=0, atol=1e-9)
+    assert np.array_equal(eng.action_lows, [-3.0, -1.0]) and np.array_equal(eng.action_highs, [3.0, 1.0])
