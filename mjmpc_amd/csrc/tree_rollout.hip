@@ -2639,7 +2639,8 @@ hipError_t launch_tree_rollout_dense(int max_path, int nv, bool gen, const T* mo
                                      const TreeLaunchArgs& a) {
     // (16 lanes per particle: the dense in-register factorisation, sized for the model)
     if (nv > 16) {      // 32 lanes per particle, the dense factorisation over the particle's two DPP rows (dense32_factor)
-        if (max_path <= 16) MJMPC_TREE_LAUNCH_D(16, 16, true, 32, 32, false)
+        if (gen) MJMPC_TREE_LAUNCH_D(16, 16, true, 32, 32, true)       // (general models: paths of up to 16 links)
+        else if (max_path <= 16) MJMPC_TREE_LAUNCH_D(16, 16, true, 32, 32, false)
         else MJMPC_TREE_LAUNCH_D(32, 16, true, 32, 32, false)
     }
     else if (gen) {          // the general instantiation comes in two sizes
@@ -2692,7 +2693,7 @@ hipError_t launch_tree_rollout(const T* model, int n_model_shards, int max_path,
         else MJMPC_TREE_LAUNCH(32, 8, false, 32)
     } else if (nv <= 16) {
         return launch_tree_rollout_dense<T>(max_path, nv, gen, model, noise, cost, act, obs, nobs, a);
-    } else if (!gen && max_path > 8 && !getenv("MJMPC_TREE_SPARSE")) {
+    } else if (max_path > 8 && !(gen && max_path > 16) && !getenv("MJMPC_TREE_SPARSE")) {
         // 17 .. 32 dofs on elimination paths of more than 8 links: dense over the particle's 32 lanes - measured at 4096 x 32:
         // pen-in-hand (paths of 16) f64 16.2 -> 9.8 ms, f32 13.8 -> 8.0; with paths of up to 8 links (a hand with friction
         // cones) the tree-sparse factorisation with its merged Euler matrix stays ahead, 4.15 against 4.27 ms

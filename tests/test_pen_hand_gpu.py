@@ -274,3 +274,42 @@ def test_pen_hand_dmd_closed_loop_4096x64(pen):
     assert diverged <= 12                   # (a handful; a model problem, not a solver one)
     if diverged == 0:
         assert eng.solver_failures() == f0 and ref.newton_stats()["fails"] == nf0
+
+
+def test_pen_hand_with_friction_loss_on_the_general_32_lane_instantiation():
+    """The pen-in-hand model with dry friction in the finger joints (dof_frictionloss, the field the reference randomizes:
+    gym_env_wrapper.py:387-389): friction-loss rows send its 30 dofs through the GENERAL instantiation at 32 lanes per
+    particle (the synthetic general models have at most 13 dofs and run 16 lanes).  One env step from 48 random states at
+    1e-9, a 37 x 6 rollout at 1e-9."""
+    from mjmpc_amd.envs.tree_engine import TreeRolloutEngine
+    from mjmpc_amd.models.pen_hand import holding_state, pen_hand_raw
+    from oracle.physics_ref import RefArm
+    raw = pen_hand_raw()
+    for b in raw.bodies:
+        if b.joint is not None and (b.name.endswith("_mid") or b.name.endswith("_prox") or b.name == "arm_wrist"):
+            b.joint.frictionloss = 0.02
+    assert sum(b.joint.frictionloss > 0 for b in raw.bodies if b.joint is not None) == 11
+    eng, ref, st = TreeRolloutEngine(raw, dtype="f64"), RefArm(raw.to_flat()), holding_state()
+    assert eng.model.general and eng.model.nv == 30
+    q0, v0, u0 = _settled(ref, st)
+    rs = np.random.RandomState(12)
+    tgt = np.array(raw.target_pos)
+    worst = 0.0
+    for k in range(48):
+        q = q0 + np.concatenate([0.004 * rs.standard_normal(3), 0.15 * rs.standard_normal(3), 0.1 * rs.standard_normal(24)])
+        v = np.concatenate([0.1 * rs.standard_normal(3), 1.0 * rs.standard_normal(3), 0.5 * rs.standard_normal(24)]) * (k % 3 > 0)
+        u = u0 + 0.2 * rs.standard_normal(24)
+        eng.set_env_state(dict(qp=q, qv=v, target_pos=tgt))
+        _, rew, _, _, _, nobs = eng.rollout(1, 1, u[None], None, "open_loop")
+        q1, v1, r1, o1 = ref.env_step(q, v, u, tgt)
+        worst = max(worst, np.abs(nobs[0, 0] - o1).max() / max(1.0, np.abs(o1).max()), abs(rew[0, 0] - r1))
+    print("pen-in-hand with friction loss: one env step from 48 random states, worst error %.2e" % worst)
+    assert worst < 1e-9, worst
+    P, H, A = 37, 6, 24
+    mean, noise = np.tile(u0, (H, 1)), _noise(P, H, A, 6, 0.15)
+    eng.set_env_state(dict(qp=q0, qv=v0, target_pos=tgt))
+    obs, rew, act, done, info, nobs = eng.rollout(P, H, mean, noise, "open_loop")
+    o_obs, o_rew, o_act, _, o_nobs = ref.rollout(q0, v0, tgt, mean, noise)
+    np.testing.assert_allclose(rew, o_rew, rtol=1e-9, atol=1e-9)
+    np.testing.assert_allclose(nobs, o_nobs, rtol=0, atol=1e-9)
+    assert eng.solver_failures() == 0

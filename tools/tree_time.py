@@ -1,4 +1,4 @@
-"""Rollout-kernel time of the tree engine: python tools/tree_time.py [P] [H] [dtype] [hand|handf|swimmer|cheetah|pen|cartpole|tray|door]
+"""Rollout-kernel time of the tree engine: python tools/tree_time.py [P] [H] [dtype] [hand|handf|swimmer|cheetah|pen|penf|cartpole|tray|door]
 (MJMPC_AMD_LIB selects an alternative build of the library, e.g. one compiled with -DTREE_SKIP=...)."""
 import os, sys
 import numpy as np
@@ -20,9 +20,13 @@ if name in ("hand", "handf"):
                 if g_.collide:
                     g_.friction, g_.condim = 0.8, 3
         raw.plane = dataclasses.replace(raw.plane, friction=0.5, condim=3)
-elif name == "pen":
+elif name in ("pen", "penf"):
     from mjmpc_amd.models.pen_hand import holding_state, pen_hand_raw
     raw = pen_hand_raw()
+    if name == "penf":          # dry friction in the finger joints: friction-loss rows -> the GENERAL instantiation at 32 lanes
+        for b in raw.bodies:
+            if b.joint is not None and (b.name.endswith("_mid") or b.name.endswith("_prox") or b.name == "arm_wrist"):
+                b.joint.frictionloss = 0.02
     st = holding_state()
     start = dict(qpos=st["qp"], qvel=st["qv"], target_pos=np.asarray(raw.target_pos, float))
 elif name in ("cartpole", "tray", "door"):
@@ -41,9 +45,9 @@ if name == "cheetah":       # resting on its feet: contacts from the first subst
     q0 = np.array([0.0, -0.1324, 0.0521, 0.0342, 0.0679, -0.0139, -0.0589, -0.14, -0.131])
     eng.set_env_state(dict(qpos=q0, qvel=np.zeros(9)))
 g = torch.Generator(device="cuda").manual_seed(0)
-noise = (0.1 if name in ("pen", "tray") else 0.5) * torch.randn(P, H, A, device="cuda", dtype=torch.float32 if dt == "f32" else torch.float64, generator=g)
+noise = (0.1 if name in ("pen", "penf", "tray") else 0.5) * torch.randn(P, H, A, device="cuda", dtype=torch.float32 if dt == "f32" else torch.float64, generator=g)
 mean = torch.zeros(H, A, device="cuda", dtype=torch.float64)
-if name == "pen":           # position servos: hold the start pose
+if name in ("pen", "penf"):           # position servos: hold the start pose
     mean += torch.from_numpy(st["qp"][6:]).to(mean)
 eng.rollout_device(P, H, mean, noise)
 torch.cuda.synchronize()
