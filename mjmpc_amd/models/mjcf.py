@@ -25,9 +25,15 @@ panda/tray_glass-v0.yml, sawyer/door-v0.yml, hand/*-v0.yml):
   ``solimp`` each),
   ``<tendon><fixed limited range><joint joint coef/>`` over one or two joints.
 
+* the layout of robot model files: ``<include file>`` (anywhere, nested; sections that then occur several times are
+  merged), ``<contact><exclude body1 body2>``, mesh / cylinder / ellipsoid geoms as VISUALS (masked out of every
+  collision, on a body with an explicit ``<inertial>``), ``<sensor>`` and ``<keyframe>`` sections (read by nobody here).
+
 Anything that would change the simulation and is not modelled raises ValueError, so that a model is never silently
-simulated wrongly; purely visual elements (asset, light, camera, material, rgba ...) are skipped.
+simulated wrongly (colliding meshes, mocap bodies, noslip iterations, disabled option flags, other solvers, activation
+dynamics ...); purely visual elements (asset, light, camera, material, rgba ...) are skipped.
 """
+import os
 import xml.etree.ElementTree as ET
 
 import numpy as np
@@ -39,7 +45,28 @@ from .raw import (EQ_CONNECT, EQ_JOINT, EQ_WELD, GEOM_BOX, GEOM_CAPSULE, GEOM_SP
 
 _VISUAL_BODY_TAGS = ("light", "camera")
 _TOP_TAGS = ("compiler", "option", "default", "worldbody", "actuator", "asset", "size", "visual", "statistic", "custom",
-             "equality", "tendon")
+             "equality", "tendon", "sensor", "keyframe")     # (sensors and keyframes do not enter the simulation)
+_SHAPE_ONLY_TYPES = ("mesh", "cylinder", "ellipsoid")       # geom types that are accepted only where they cannot matter
+
+
+def _expand_includes(node, basedir, depth=0):
+    """MJCF ``<include file="...">``: the children of the included file's root take the element's place (paths relative
+    to the main model's directory, as MuJoCo resolves them)."""
+    if depth > 16:
+        raise ValueError("<include> nested too deeply (a cycle?)")
+    k = 0
+    while k < len(node):
+        c = node[k]
+        if c.tag == "include":
+            sub = ET.parse(os.path.join(basedir, c.get("file"))).getroot()
+            _expand_includes(sub, basedir, depth + 1)
+            node.remove(c)
+            for j, x in enumerate(list(sub)):
+                node.insert(k + j, x)
+            k += len(sub)
+        else:
+            _expand_includes(c, basedir, depth)
+            k += 1
 
 
 def _mat2quat(R):
@@ -146,9 +173,20 @@ def load_mjcf(path, hand_site="finger", target_site="target", frame_skip=2, task
     """``task=TASK_FORWARD`` (with ``ctrl_cost`` / ``obs_skip``) loads a locomotion model: no tracked site is needed.
     ``self_collision=False`` leaves out the geom-geom pairs MuJoCo would derive from contype / conaffinity."""
     root = ET.parse(path).getroot()
+    _expand_includes(root, os.path.dirname(os.path.abspath(path)))
+    # (several <default> / <worldbody> / <actuator> / <contact> ... sections, as included files bring them: merged in order)
+    for tag in ("worldbody", "actuator", "contact", "equality", "tendon", "asset", "sensor"):
+        same = root.findall(tag)
+        for extra in same[1:]:
+            same[0].extend(list(extra))
+            root.remove(extra)
+    tops = root.findall("default")
+    for extra in tops[1:]:
+        tops[0].extend(list(extra))
+        root.remove(extra)
     for e in root:
-        if e.tag == "contact" and all(c.tag == "pair" for c in e):
-            continue                    # empty (sawyer.xml:94-99 holds comments only) or <pair geom1 geom2> entries, read below
+        if e.tag == "contact" and all(c.tag in ("pair", "exclude") for c in e):
+            continue                    # empty (sawyer.xml:94-99 holds comments only), <pair geom1 geom2> or <exclude body1 body2>, read below
         if e.tag not in _TOP_TAGS:
             raise ValueError("unsupported element <%s>" % e.tag)
     comp = root.find("compiler")
@@ -175,6 +213,10 @@ def load_mjcf(path, hand_site="finger", target_site="target", frame_skip=2, task
         raise ValueError("only pyramidal friction cones with impratio 1 are supported")
     if _floats(oget("wind", None), 3, [0.0, 0.0, 0.0]) != [0.0, 0.0, 0.0]:
         raise ValueError("wind is not supported")
+    if oget("solver", "Newton") != "Newton" or int(oget("noslip_iterations", "0")) != 0:
+        raise ValueError("the Newton solver without noslip iterations is what is modelled")
+    if opt is not None and opt.find("flag") is not None and any(v != "enable" for v in opt.find("flag").attrib.values()):
+        raise ValueError("<option><flag>: only MuJoCo's default (all features enabled) is modelled")
     density, viscosity = float(oget("density", "0")), float(oget("viscosity", "0"))
     dfl = _Defaults(root)
 
@@ -184,9 +226,21 @@ def load_mjcf(path, hand_site="finger", target_site="target", frame_skip=2, task
     geom_solver, limit_solver, friction_solver = set(), set(), set()
     DEF_SOL = ((0.02, 1.0), (0.9, 0.95, 0.001, 0.5, 2.0))
 
-    def parse_geom(e, active):
+    inertia_from_geom_always = comp is not None and comp.get("inertiafromgeom", "auto") == "true"
+
+    def parse_geom(e, active, has_inertial=False):
         ga = lambda k, d=None: dfl.attr("geom", e, active, k, d)        # noqa: E731
         t = ga("type", "sphere")
+        if ga("mesh") is not None and e.get("type") is None:
+            t = "mesh"                  # (a geom that names a mesh is a mesh geom)
+        if t in _SHAPE_ONLY_TYPES:
+            # meshes, cylinders and ellipsoids are neither collided nor integrated here: such a geom is accepted where it
+            # can do neither - masked out of every collision and on a body whose mass comes from an explicit <inertial>
+            # (the usual layout of robot models: visual meshes, primitive collision geoms, inertials from CAD)
+            if int(ga("contype", "1")) == 0 and int(ga("conaffinity", "1")) == 0 and has_inertial and not inertia_from_geom_always:
+                return None
+            raise ValueError("unsupported geom type %r (accepted only as a visual: contype = conaffinity = 0 on a body with an "
+                             "explicit <inertial>)" % t)
         size = _floats(ga("size"))
         common = dict(density=float(ga("density", "1000")), margin=float(ga("margin", "0")),
                       friction=_floats(ga("friction", "1 0.005 0.0001"))[0], condim=int(ga("condim", "3")),
@@ -230,7 +284,9 @@ def load_mjcf(path, hand_site="finger", target_site="target", frame_skip=2, task
                     raise ValueError("one world plane at most")
                 plane_elem = e
             else:
-                g = parse_geom(e, world.get("childclass"))
+                g = parse_geom(e, world.get("childclass"), has_inertial=True)      # (the world body has no mass to get wrong)
+                if g is None:
+                    continue
                 if not g.name:
                     g.name = "world_geom%d" % len(world_geoms)
                 world_geoms.append(g)
@@ -268,7 +324,7 @@ def load_mjcf(path, hand_site="finger", target_site="target", frame_skip=2, task
                         pos=_floats(j.get("pos"), 3, [0.0, 0.0, 0.0]) if t in ("hinge", "ball") else [0.0, 0.0, 0.0],
                         frictionloss=floss)
 
-    xml_body, xml_parent = [], []       # per RawBody: the XML body it belongs to; per XML body: its parent XML body
+    xml_body, xml_parent, xml_name = [], [], []     # per RawBody: the XML body it belongs to; per XML body: its parent XML body, its name
 
     def walk(e, parent, active, xparent=-1):
         active = e.get("childclass", active)
@@ -276,6 +332,7 @@ def load_mjcf(path, hand_site="finger", target_site="target", frame_skip=2, task
         xml_parent.append(xparent)
         joints = [parse_joint(j, active) for j in e if j.tag in ("joint", "freejoint")]
         name = e.get("name", "body%d" % len(bodies))
+        xml_name.append(name)
         pos = _floats(e.get("pos"), 3, [0.0, 0.0, 0.0])
         Rb = _orientation(e, deg)
         quat = [1.0, 0.0, 0.0, 0.0] if Rb is None else list(_mat2quat(Rb))
@@ -310,8 +367,11 @@ def load_mjcf(path, hand_site="finger", target_site="target", frame_skip=2, task
                 else:
                     I = Ri @ np.diag(_floats(c.get("diaginertia"), 3)) @ Ri.T
                 inertial = RawInertial(float(c.get("mass")), ipos, I)
+        if e.get("mocap", "false") == "true":
+            raise ValueError("mocap bodies are not supported")
+        geoms_ = [parse_geom(g, active, has_inertial=inertial is not None) for g in e.findall("geom")]
         bodies.append(RawBody(name, parent, pos if first else [0.0, 0.0, 0.0], quat if first else [1.0, 0.0, 0.0, 0.0], jt,
-                              [parse_geom(g, active) for g in e.findall("geom")], inertial))
+                              [g for g in geoms_ if g is not None], inertial))
         xml_body.append(xid)
         for s_ in e.findall("site"):
             sites[s_.get("name")] = (idx, _floats(s_.get("pos"), 3, [0.0, 0.0, 0.0]))
@@ -345,6 +405,10 @@ def load_mjcf(path, hand_site="finger", target_site="target", frame_skip=2, task
     # them moves.  Later geom first (on a chain: the deeper one, which is the order compile_tree asks for).
     # swimmer.xml's segments are the vendored case (default contype = conaffinity = 1).
     auto_pairs = []
+    con = root.find("contact")
+    excluded = set()                    # <contact><exclude body1 body2>: no derived pair between geoms of these two bodies
+    for ex in (con.findall("exclude") if con is not None else []):
+        excluded.add(frozenset((ex.get("body1"), ex.get("body2"))))
     if self_collision:
         moving = [False] * len(bodies)
         for bi, b in enumerate(bodies):
@@ -358,6 +422,8 @@ def load_mjcf(path, hand_site="finger", target_site="target", frame_skip=2, task
                 if ba >= 0 and bb >= 0:
                     xa, xb = xml_body[ba], xml_body[bb]
                     if xa == xb or xml_parent[xa] == xb or xml_parent[xb] == xa:
+                        continue
+                    if frozenset((xml_name[xa], xml_name[xb])) in excluded:
                         continue
                 if not ((ga_._contype & gb_._conaffinity) or (gb_._contype & ga_._conaffinity)):
                     continue
@@ -373,10 +439,9 @@ def load_mjcf(path, hand_site="finger", target_site="target", frame_skip=2, task
                 auto_pairs.append((gb_.name, ga_.name))
     # explicit geom-geom collision candidates (<contact><pair geom1=... geom2=...>)
     pairs = list(auto_pairs)
-    con = root.find("contact")
     every = {g.name: g for b in bodies for g in b.geoms if g.name}
     every.update({g.name: g for g in world_geoms})
-    for pr in (list(con) if con is not None else []):
+    for pr in (con.findall("pair") if con is not None else []):
         pairs.append((pr.get("geom1"), pr.get("geom2")))
         for nm in (pr.get("geom1"), pr.get("geom2")):
             if nm in every:

@@ -476,3 +476,41 @@ def test_velocity_and_general_actuators(tmp_path):
     assert tv.field("kvg")[0] == 4 * 5.0 and tv.field("kpg")[0] == 0.0 and tv.field("gear")[0] == 10.0
     with pytest.raises(ValueError, match="dyntype"):
         _model(tmp_path, ARM2, extra='<actuator><general joint="j1" dyntype="integrator" ctrlrange="-1 1"/><motor joint="j2" ctrlrange="-1 1"/></actuator>', name="dyn.xml")
+
+
+# ------------------------------------------------------------------------------------------ the layout of robot models
+def test_includes_visual_meshes_excludes_and_sensors(tmp_path):
+    """What real robot MJCF files are made of and the simulation does not depend on: <include>d parts, <asset> meshes on
+    visual geoms (masked out of collisions, on bodies with explicit inertials), <sensor> / <keyframe> sections; and
+    <contact><exclude>, which does change the collision candidates.  The model with all of that equals the plain one."""
+    body = """
+    <body name="a" pos="0 0 0.5"><joint name="j1" type="hinge" axis="0 1 0" damping="0.2"/>
+      <inertial pos="0.1 0 0" mass="1.2" diaginertia="0.01 0.02 0.02"/>
+      <geom name="ca" type="capsule" fromto="0 0 0 0.3 0 0" size="0.03" contype="1" conaffinity="1"/>%s
+      <body name="b" pos="0.3 0 0"><joint name="j2" type="hinge" axis="0 1 0" damping="0.2"/>
+        <inertial pos="0.1 0 0" mass="0.5" diaginertia="0.004 0.006 0.006"/>
+        <geom name="cb" type="capsule" fromto="0 0 0 0.2 0 0" size="0.02" contype="1" conaffinity="1"/>
+        <body name="c" pos="0.2 0 0"><joint name="j3" type="hinge" axis="0 1 0" damping="0.2"/>
+          <inertial pos="0.05 0 0" mass="0.2" diaginertia="0.001 0.002 0.002"/>
+          <geom name="cc" type="capsule" fromto="0 0 0 0.15 0 0" size="0.02" contype="1" conaffinity="1"/><site name="finger" pos="0.15 0 0"/>
+        </body></body></body>"""
+    acts = '<actuator>' + "".join('<motor joint="j%d" ctrlrange="-1 1" ctrllimited="true"/>' % k for k in (1, 2, 3)) + '</actuator>'
+    plain, ref0 = _model(tmp_path, body % "", extra=acts, name="plain.xml")
+    assert [tuple(p) for p in plain.pairs] == [("cc", "ca")]            # a and c are not parent and child: MuJoCo would collide them
+    (tmp_path / "acts.xml").write_text("<mujocoinclude>" + acts + "</mujocoinclude>")
+    (tmp_path / "vis.xml").write_text('<mujocoinclude><asset><mesh name="shell" file="shell.stl"/></asset>'
+                                      '<sensor><jointpos joint="j1"/></sensor></mujocoinclude>')
+    vis = '<geom type="mesh" mesh="shell" contype="0" conaffinity="0"/><geom type="cylinder" size="0.05 0.1" contype="0" conaffinity="0"/>'
+    extra = ('<include file="acts.xml"/><include file="vis.xml"/><keyframe><key qpos="0 0 0"/></keyframe>')
+    rich, ref1 = _model(tmp_path, body % vis, extra=extra, name="rich.xml")
+    assert np.array_equal(plain.to_flat(), rich.to_flat())
+    ex, _ = _model(tmp_path, body % "", extra=acts + '<contact><exclude body1="a" body2="c"/></contact>', name="ex.xml")
+    assert ex.pairs == []
+    # a mesh that would collide, or whose body takes its mass from its geoms, is refused
+    with pytest.raises(ValueError, match="visual"):
+        _model(tmp_path, body % '<geom type="mesh" mesh="shell" contype="1" conaffinity="0"/>', extra=acts, name="bad1.xml")
+    no_inertial = (body % vis).replace('<inertial pos="0.1 0 0" mass="1.2" diaginertia="0.01 0.02 0.02"/>', "")
+    with pytest.raises(ValueError, match="visual"):
+        _model(tmp_path, no_inertial, extra=acts, name="bad2.xml")
+    with pytest.raises(ValueError, match="noslip"):
+        _model(tmp_path, body % "", extra=acts, name="ns.xml", head=HEAD + '<option noslip_iterations="5"/>')
