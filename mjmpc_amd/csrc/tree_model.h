@@ -13,6 +13,7 @@ constexpr int TREE_MAX_SPHERES = 16; // contact points: spheres against the plan
 // [11] depth of link A in the elimination tree, [12] kind (0 sphere-plane, 1 geom-geom), [13] link B, [14:17] segment
 // start on B, [17] radius B, [18:21] segment vector on B
 constexpr int TREE_SPH_STRIDE = 24;
+constexpr int TREE_SOL_CLASSES = 8;
 
 enum TreeOffset : int {
     // ---- staged in LDS by the kernel.  The first 14 per-link fields are the arm block's, 32 lanes wide
@@ -72,7 +73,11 @@ enum TreeOffset : int {
     T_ANY_FRICTION,                     // the model needs the full instantiation (friction cones, geom-geom pairs, servos)
     T_SITE_AXIS,                        // 3: task 2, the object's axis in the site link's frame
     T_TARGET_DIR = T_SITE_AXIS + 3,     // 3: ... and the direction it should point in
-    T_SPH = T_TARGET_DIR + 3,           // TREE_MAX_SPHERES x TREE_SPH_STRIDE
+    // the solver-parameter sets of the model ({K, B, dmin, dmax, width, mid, power} each): a contact record names its set in
+    // [21] (the two geoms' solref / solimp mixed by mj_contactParam; tendon limits: the tendon's), a dof in T_DOFCLS
+    T_SOLTAB = T_TARGET_DIR + 3,        // TREE_SOL_CLASSES x 7
+    T_DOFCLS = T_SOLTAB + 8 * 7,        // 32: limit-row set + 8 * friction-loss-row set of the dof
+    T_SPH = T_DOFCLS + TL,              // TREE_MAX_SPHERES x TREE_SPH_STRIDE
     // ---- read once per launch, from global memory: topology, joint kinds, action map
     T_TOPO = T_SPH + TREE_MAX_SPHERES * TREE_SPH_STRIDE,
     T_PARENT = T_TOPO,                  // parent link, -1 for a root
@@ -123,6 +128,6 @@ constexpr int TREE_QW = 2 * TL + 6;
 constexpr int TREE_NQ_MAX = 40;
 // the C ABI's state vectors (mjmpc_tree_set_shard_states): MuJoCo's layout - qpos[40] | qvel[32] | target[3] | reserved[3]
 constexpr int TREE_PUBLIC_STATE_LEN = TREE_NQ_MAX + TL + 6;
-static_assert(TREE_BLOB_LEN == 3702, "keep in sync with mjmpc_amd/models/compile_tree.py::TREE_LAYOUT");
+static_assert(TREE_BLOB_LEN == 3790, "keep in sync with mjmpc_amd/models/compile_tree.py::TREE_LAYOUT");
 
 }  // namespace mjmpc

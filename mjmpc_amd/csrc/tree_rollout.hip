@@ -454,7 +454,7 @@ __device__ __forceinline__ void frame_tangent(const T* nrm, const T* hint, T* t1
 }
 
 // MuJoCo mj_makeImpedance + mj_referenceConstraint for one scalar row (r = pos - margin); constants from LDS
-// sol = {K, B, dmin, dmax, width, mid, power}: the contact set (T_SOL_K) or the joint-limit set (T_LSOL_K)
+// sol = {K, B, dmin, dmax, width, mid, power}: one of the model's sets (T_SOLTAB)
 template <typename T>
 __device__ __forceinline__ void tree_row_params(const T* sol, T r, T diag_approx, T jv, T& D, T& aref) {
     const T dmin = sol[2], dmax = sol[3], width = sol[4], mid = sol[5];
@@ -1221,9 +1221,10 @@ __global__ __launch_bounds__(64 * wg_waves(DP, FRIC, sizeof(T), PL), min_waves(s
     const T q0y = (GEN && ball_g == 0) ? model[T_QOFF + l + 1] : T(0), q0z = (GEN && ball_g == 0) ? model[T_QOFF + l + 2] : T(0);
     const T floss = (GEN && dof) ? model[T_FRICTIONLOSS + l] : T(0);            // dry friction of my dof (0: no row)
     const bool any_floss = GEN && __any(floss > T(0));
+    const int dofcls = (int)model[T_DOFCLS + l];                                // my dof's solver sets: limit row | friction-loss row << 3
     T fsol[7];                                                                  // friction-loss rows' solver set
 #pragma unroll
-    for (int k = 0; k < 7; ++k) fsol[k] = GEN ? model[T_FSOL_K + k] : T(0);
+    for (int k = 0; k < 7; ++k) fsol[k] = GEN ? model[T_SOLTAB + 7 * (dofcls >> 3) + k] : T(0);
 
     T q = dof ? (T)state[l] : T(0), v = dof ? (T)state[TL + l] : T(0);
     T qy = T(0), qz = T(0), qw = T(1);
@@ -1894,7 +1895,7 @@ __global__ __launch_bounds__(64 * wg_waves(DP, FRIC, sizeof(T), PL), min_waves(s
                 if constexpr (!FRIC) {      // (one frictionless row per point: a lane sum is cheaper than the walk below)
                     const T jv = sum_lanes<PL>(jc * v);
                     T Dc, arc;
-                    tree_row_params(M + T_SOL_K, cs[3] - sp[5], sp[6], jv, Dc, arc);
+                    tree_row_params(M + T_SOLTAB + 7 * (int)sp[21], cs[3] - sp[5], sp[6], jv, Dc, arc);
                     if (l == 0 && ci) {
                         X[A_CS + s * CS + 4] = Dc;
                         X[A_CS + s * CS + 5] = arc;
@@ -1953,17 +1954,18 @@ __global__ __launch_bounds__(64 * wg_waves(DP, FRIC, sizeof(T), PL), min_waves(s
                     } else if (GEN && kind == PT_DOFROW) {
                         const T* ex = PEXT + l * TREE_PEXT_STRIDE;
                         if (ex[0] == T(0)) tree_row_params(ex + 12, cs[3], sp[6], jv, Dc, arc);              // joint equality
-                        else tree_row_params(M + T_LSOL_K, cs[3] - sp[5], sp[6], jv, Dc, arc);               // tendon limit
+                        else tree_row_params(M + T_SOLTAB + 7 * (int)sp[21], cs[3] - sp[5], sp[6], jv, Dc, arc);     // tendon limit
                         cs[4] = Dc;
                         cs[5] = arc;
                         cs[6] = T(0);
                         cs[7] = T(0);
                     } else {
-                    tree_row_params(M + T_SOL_K, cs[3] - sp[5], sp[6] * (T(1) + mu * mu), jv, Dc, arc);
+                    const T* csol = M + T_SOLTAB + 7 * (int)sp[21];         // the contact's own solver set
+                    tree_row_params(csol, cs[3] - sp[5], sp[6] * (T(1) + mu * mu), jv, Dc, arc);
                     if (mu > T(0)) Dc *= T(0.5) * rcp_(mu * mu);
                     cs[4] = Dc;
                     cs[5] = arc;
-                    if (FRIC) { cs[6] = mu * M[T_SOL_B] * j1v; cs[7] = mu * M[T_SOL_B] * j2v; }
+                    if (FRIC) { cs[6] = mu * csol[1] * j1v; cs[7] = mu * csol[1] * j2v; }
                     }
                 }
             }
@@ -1977,7 +1979,7 @@ __global__ __launch_bounds__(64 * wg_waves(DP, FRIC, sizeof(T), PL), min_waves(s
             if (any_rows) {
                 clk.count(10, 1);
                 if (__any(inst)) {      // (the impedance arithmetic only when some lane of the wavefront has a limit row)
-                    tree_row_params(M + T_LSOL_K, dist, M[T_DOF_INVW + l], sig * v, D, aref);
+                    tree_row_params(M + T_SOLTAB + 7 * (dofcls & 7), dist, M[T_DOF_INVW + l], sig * v, D, aref);
                     D = inst ? D : T(0);
                     aref = inst ? aref : T(0);
                 }

@@ -16,7 +16,7 @@ import numpy as np
 
 from .compile import _geom_inertial, _quat2mat, _shift_inertia, principal_inertia
 from .raw import (EQ_CONNECT, EQ_JOINT, EQ_WELD, GEOM_BOX, GEOM_CAPSULE, GEOM_SPHERE, JOINT_BALL, JOINT_FREE, JOINT_HINGE, JOINT_SLIDE,
-                  TASK_FORWARD, TASK_ORIENT, TASK_REACH, RawModel)
+                  TASK_FORWARD, TASK_ORIENT, TASK_REACH, RawModel, mix_contact_solver)
 
 TL = 32                     # lanes per particle
 TREE_MAX_SPHERES = 16
@@ -39,6 +39,7 @@ PEXT_STRIDE = 24            # per contact record, general instantiation: [0:3] b
                             # width, mid, power} (equalities), [19] bilateral flag
 TREE_NQ_MAX = 40
 
+SOL_CLASSES = 8                 # distinct solver-parameter sets a model may use (contacts, joint limits, friction loss, tendon limits)
 TREE_LAYOUT = [
     # ---- staged in LDS by the kernel: per-link constants, scalars, contact records
     ("off", 3 * TL), ("axis", 3 * TL), ("mass", TL), ("com", 3 * TL), ("inertia", 6 * TL),
@@ -56,6 +57,8 @@ TREE_LAYOUT = [
     ("lsol_K", 1), ("lsol_B", 1), ("lsol_dmin", 1), ("lsol_dmax", 1), ("lsol_width", 1), ("lsol_mid", 1), ("lsol_power", 1),
     ("any_friction", 1),
     ("site_axis", 3), ("target_dir", 3),    # TASK_ORIENT: object axis in the site link's frame, its target direction
+    # the model's solver-parameter sets {K, B, dmin, dmax, width, mid, power}: contact records name theirs in [21], dofs in dofcls
+    ("soltab", SOL_CLASSES * 7), ("dofcls", TL),
     ("spheres", TREE_MAX_SPHERES * SPH_STRIDE),
     # ---- read once per launch from global memory: topology, joint kinds, action map
     ("parent", TL), ("subsize", TL), ("anc", 5 * TL), ("ancmask", 2 * TL), ("jtype", TL), ("act", TL),
@@ -570,6 +573,55 @@ def compile_tree(raw: RawModel, overrides=None, base: "TreeModel" = None) -> Tre
             return (p0[i] + R0[i] @ np.asarray(pos, float)) if i >= 0 else np.asarray(pos, float)
         return p0[i] + R0[i] @ np.asarray(pos, float) - origin[link_of_body[i]]
 
+    def sol_values(solref, solimp):
+        tc, dr = solref
+        if tc <= 0 or dr <= 0:
+            raise NotImplementedError("solref must be the standard (timeconst, dampratio) pair")
+        tc = max(tc, 2 * raw.timestep)                              # refsafe
+        dmin, dmax, width, mid, power = full_solimp(solimp)
+        dmin, dmax = np.clip(dmin, MJ_MINIMP, MJ_MAXIMP), np.clip(dmax, MJ_MINIMP, MJ_MAXIMP)
+        mid, width, power = np.clip(mid, MJ_MINIMP, MJ_MAXIMP), max(width, 0.0), max(power, 1.0)
+        if power != int(power) or power > 64:
+            raise NotImplementedError("solimp power must be an integer in [1, 64] (MuJoCo's default is 2), got %r" % (power,))
+        K, B = 1.0 / (dmax * dmax * tc * tc * dr * dr), 2.0 / (dmax * tc)
+        if width <= 1e-15:                                          # MuJoCo getimpedance: a flat impedance
+            dmin = dmax = 0.5 * (dmin + dmax)
+            width = 1.0
+        return [K, B, dmin, dmax, width, mid, power]
+
+    def full_solimp(si):
+        return tuple(si) + (0.9, 0.95, 0.001, 0.5, 2.0)[len(si):]
+
+    # the model's distinct solver-parameter sets (contacts after mj_contactParam's mixing, joint limits, friction loss,
+    # tendon limits): a table in the block, an index per record / dof
+    sol_classes = []
+
+    def sol_class(solref, solimp):
+        vals = tuple(float(x) for x in sol_values(solref, solimp))
+        if vals not in sol_classes:
+            if len(sol_classes) == SOL_CLASSES:
+                raise NotImplementedError("more than %d distinct solref / solimp sets in one model" % SOL_CLASSES)
+            sol_classes.append(vals)
+            f["soltab"][7 * (len(sol_classes) - 1):7 * len(sol_classes)] = vals
+        return float(sol_classes.index(vals))
+
+    def contact_set(g):
+        """(solref, solimp, solmix, priority) of a geom or of the plane, the model's set where it has none of its own."""
+        return (raw.solref if g.solref is None else g.solref, raw.solimp if g.solimp is None else g.solimp, g.solmix, g.priority)
+
+    lim_default = (raw.solref if raw.solref_limit is None else raw.solref_limit, raw.solimp if raw.solimp_limit is None else raw.solimp_limit)
+    sol_class(raw.solref, raw.solimp)           # (class 0: the model's contact set - what records of models built by hand get)
+    for b in raw.bodies:
+        if b.joint is None:
+            continue
+        jt = b.joint
+        lc = sol_class(lim_default[0] if jt.solref_limit is None else jt.solref_limit,
+                       lim_default[1] if jt.solimp_limit is None else jt.solimp_limit) if jt.limited else 0.0
+        fc = sol_class(raw.solref_friction if jt.solref_friction is None else jt.solref_friction,
+                       raw.solimp_friction if jt.solimp_friction is None else jt.solimp_friction) if jt.frictionloss > 0 else 0.0
+        d0 = raw.dof_of_joint(jt.name)
+        f["dofcls"][d0:d0 + jt.ndof] = lc + 8.0 * fc
+
     for s, (i, g, pos, u, radius) in enumerate(points):
         li = link_of_body[i]
         rec = f["spheres"][s * SPH_STRIDE:(s + 1) * SPH_STRIDE]
@@ -585,6 +637,7 @@ def compile_tree(raw: RawModel, overrides=None, base: "TreeModel" = None) -> Tre
         rec[8:11] = R0[i] @ u
         rec[11] = edepth[li] - 1                            # strict ancestors of the point's link (elimination tree)
         rec[13] = -1.0
+        rec[21] = sol_class(*mix_contact_solver(contact_set(g), contact_set(raw.plane)))
     # geom-geom pairs: spheres / capsules as segments (start, vector; a sphere has a zero vector) in their links' frames;
     # ONE geom of a pair may be a box (against a sphere).  The record is anchored at link A, whose elimination path
     # contains link B (an object's links above a manipulator, an ancestor in the same tree, or the world: -1)
@@ -622,6 +675,7 @@ def compile_tree(raw: RawModel, overrides=None, base: "TreeModel" = None) -> Tre
         rec[11] = edepth[la] - 1
         rec[12] = PT_SEGSEG
         rec[13], rec[14:17], rec[17], rec[18:21] = lb, b0, rb, db
+        rec[21] = sol_class(*mix_contact_solver(contact_set(ga), contact_set(gb)))
         boxes = [k for k, g in enumerate((ga, gb)) if g.type == GEOM_BOX]
         if boxes:
             if len(boxes) == 2 or (gb if boxes[0] == 0 else ga).type != GEOM_SPHERE:
@@ -637,26 +691,7 @@ def compile_tree(raw: RawModel, overrides=None, base: "TreeModel" = None) -> Tre
             gen = True              # (a static second geom: the general instantiation knows the world as "link -1")
         s += 1
 
-    def sol_values(solref, solimp):
-        tc, dr = solref
-        if tc <= 0 or dr <= 0:
-            raise NotImplementedError("solref must be the standard (timeconst, dampratio) pair")
-        tc = max(tc, 2 * raw.timestep)                              # refsafe
-        dmin, dmax, width, mid, power = solimp
-        dmin, dmax = np.clip(dmin, MJ_MINIMP, MJ_MAXIMP), np.clip(dmax, MJ_MINIMP, MJ_MAXIMP)
-        mid, width, power = np.clip(mid, MJ_MINIMP, MJ_MAXIMP), max(width, 0.0), max(power, 1.0)
-        if power != int(power) or power > 64:
-            raise NotImplementedError("solimp power must be an integer in [1, 64] (MuJoCo's default is 2), got %r" % (power,))
-        K, B = 1.0 / (dmax * dmax * tc * tc * dr * dr), 2.0 / (dmax * tc)
-        if width <= 1e-15:                                          # MuJoCo getimpedance: a flat impedance
-            dmin = dmax = 0.5 * (dmin + dmax)
-            width = 1.0
-        return [K, B, dmin, dmax, width, mid, power]
-
     # equality constraints and tendon limits ride in the contact records too (general instantiation)
-    def full_solimp(si):
-        return tuple(si) + (0.9, 0.95, 0.001, 0.5, 2.0)[len(si):]
-
     for e in raw.equalities:
         rec = f["spheres"][s * SPH_STRIDE:(s + 1) * SPH_STRIDE]
         ext = f["pext"][s * PEXT_STRIDE:(s + 1) * PEXT_STRIDE]
@@ -736,6 +771,8 @@ def compile_tree(raw: RawModel, overrides=None, base: "TreeModel" = None) -> Tre
         ext[1], ext[2] = dofs[0][1], (dofs[1][1] if len(dofs) == 2 else 0.0)
         ext[3:5] = t.range
         ext[5] = t.margin
+        rec[21] = sol_class(lim_default[0] if t.solref_limit is None else t.solref_limit,
+                            lim_default[1] if t.solimp_limit is None else t.solimp_limit)
         gen = True
         s += 1
     nsp = s

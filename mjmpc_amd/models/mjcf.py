@@ -11,11 +11,12 @@ panda/tray_glass-v0.yml, sawyer/door-v0.yml, hand/*-v0.yml):
   the body) - a body with several joints becomes a chain of massless bodies, one joint each, which is what MuJoCo's
   kinematics does with it - or ONE ball joint, or a ``<freejoint/>`` / free joint (children of the world body);
   joint ``axis range limited damping armature stiffness springref frictionloss``, ``solreflimit`` / ``solimplimit``,
-  ``solreffriction`` / ``solimpfriction`` (one set each per model); explicit ``<inertial pos quat mass
+  ``solreffriction`` / ``solimpfriction`` (per joint); explicit ``<inertial pos quat mass
   diaginertia|fullinertia>``;
 * sphere, capsule and box geoms (``fromto``, or ``size pos`` with ``quat`` / ``axisangle`` / ``euler``), ``density``,
   ``mass``, ``margin``, ``friction``, ``condim``, ``contype`` / ``conaffinity`` (what collides with the world plane and -
-  ``self_collision`` - with other bodies is decided by MuJoCo's rule), ``solref`` / ``solimp`` (one set per model);
+  ``self_collision`` - with other bodies is decided by MuJoCo's rule), ``solref`` / ``solimp`` / ``solmix`` / ``priority`` per geom (a contact's
+  set is mixed from its two geoms', mj_contactParam; up to eight distinct sets per model);
 * one world ``<geom type="plane">`` in any orientation, static sphere / capsule / box geoms on the world body (they
   collide with moving geoms through MuJoCo's contype / conaffinity rule or an explicit ``<pair>``), world and body
   ``<site>``s, ``<motor>`` / ``<position kp>`` / ``<velocity kv>`` / ``<general gainprm biasprm biastype=affine>`` actuators
@@ -223,7 +224,7 @@ def load_mjcf(path, hand_site="finger", target_site="target", frame_skip=2, task
     bodies, sites = [], {}
     plane_elem = None
     world = root.find("worldbody")
-    geom_solver, limit_solver, friction_solver = set(), set(), set()
+    geom_solver, limit_solver, friction_solver = [], [], []     # the sets in use: the most frequent becomes the model's own
     DEF_SOL = ((0.02, 1.0), (0.9, 0.95, 0.001, 0.5, 2.0))
 
     inertia_from_geom_always = comp is not None and comp.get("inertiafromgeom", "auto") == "true"
@@ -274,6 +275,7 @@ def load_mjcf(path, hand_site="finger", target_site="target", frame_skip=2, task
             g.density = float(ga("mass")) / vol
         g._contype, g._conaffinity = int(ga("contype", "1")), int(ga("conaffinity", "1"))
         g._solver = (tuple(_floats(ga("solref", "0.02 1"))), tuple(_floats(ga("solimp", "0.9 0.95 0.001 0.5 2"))))
+        g.solmix, g.priority = float(ga("solmix", "1")), int(ga("priority", "0"))
         return g
 
     world_geoms = []
@@ -307,13 +309,14 @@ def load_mjcf(path, hand_site="finger", target_site="target", frame_skip=2, task
         limited = ja("limited", "false") == "true" and t != "free"      # (MuJoCo ignores limits on free joints)
         if limited and t == "ball":
             raise ValueError("limits of ball joints are not supported")
+        lim_set = fric_set = None
         if limited:
-            limit_solver.add((tuple(_floats(ja("solreflimit", "0.02 1"))),
-                              tuple(_floats(ja("solimplimit", "0.9 0.95 0.001 0.5 2")))))
+            lim_set = (tuple(_floats(ja("solreflimit", "0.02 1"))), tuple(_floats(ja("solimplimit", "0.9 0.95 0.001 0.5 2"))))
+            limit_solver.append(lim_set)
         floss = float(ja("frictionloss", "0"))
         if floss != 0.0:
-            friction_solver.add((tuple(_floats(ja("solreffriction", "0.02 1"))),
-                                 tuple(_floats(ja("solimpfriction", "0.9 0.95 0.001 0.5 2")))))
+            fric_set = (tuple(_floats(ja("solreffriction", "0.02 1"))), tuple(_floats(ja("solimpfriction", "0.9 0.95 0.001 0.5 2"))))
+            friction_solver.append(fric_set)
         ang = deg if t == "hinge" else 1.0      # (a hinge's range and spring reference are angles)
         rng = [x * ang for x in _floats(ja("range"), 2, [0.0, 0.0])]
         jtype = {"hinge": JOINT_HINGE, "slide": JOINT_SLIDE, "ball": JOINT_BALL, "free": JOINT_FREE}[t]
@@ -322,7 +325,8 @@ def load_mjcf(path, hand_site="finger", target_site="target", frame_skip=2, task
                         name=j.get("name", ""), type=jtype,
                         stiffness=float(ja("stiffness", "0")), springref=float(ja("springref", "0")) * ang,
                         pos=_floats(j.get("pos"), 3, [0.0, 0.0, 0.0]) if t in ("hinge", "ball") else [0.0, 0.0, 0.0],
-                        frictionloss=floss)
+                        frictionloss=floss, solref_limit=lim_set and lim_set[0], solimp_limit=lim_set and lim_set[1],
+                        solref_friction=fric_set and fric_set[0], solimp_friction=fric_set and fric_set[1])
 
     xml_body, xml_parent, xml_name = [], [], []     # per RawBody: the XML body it belongs to; per XML body: its parent XML body, its name
 
@@ -392,14 +396,16 @@ def load_mjcf(path, hand_site="finger", target_site="target", frame_skip=2, task
                 g.collide = bool((g._contype & pca) or (pct & g._conaffinity))
                 hit = hit or g.collide
                 if g.collide:
-                    geom_solver.add(g._solver)
+                    geom_solver.append(g._solver)
         if hit:
             Rp = _orientation(plane_elem, deg)
             normal = (0.0, 0.0, 1.0) if Rp is None else tuple(Rp[:, 2])
-            geom_solver.add((tuple(_floats(pa("solref", "0.02 1"))), tuple(_floats(pa("solimp", "0.9 0.95 0.001 0.5 2")))))
+            plane_set = (tuple(_floats(pa("solref", "0.02 1"))), tuple(_floats(pa("solimp", "0.9 0.95 0.001 0.5 2"))))
+            geom_solver.append(plane_set)
             plane = RawPlane(pos=_floats(plane_elem.get("pos"), 3, [0.0, 0.0, 0.0]), normal=normal,
                              margin=float(pa("margin", "0")), friction=_floats(pa("friction", "1 0.005 0.0001"))[0],
-                             condim=int(pa("condim", "3")))
+                             condim=int(pa("condim", "3")), solmix=float(pa("solmix", "1")), priority=int(pa("priority", "0")))
+            plane._solver = plane_set
     # ... and geoms against each other (self_collision): MuJoCo's rule - the contype / conaffinity masks match, the two
     # bodies differ and are not parent and child (the world body is nobody's parent in that rule), and at least one of
     # them moves.  Later geom first (on a chain: the deeper one, which is the order compile_tree asks for).
@@ -435,28 +441,50 @@ def load_mjcf(path, hand_site="finger", target_site="target", frame_skip=2, task
                 for k, (bi, g) in ((ia, flat[ia]), (ib, flat[ib])):
                     if not g.name:
                         g.name = "%s_geom%d" % (bodies[bi].name if bi >= 0 else "world", k)
-                    geom_solver.add(g._solver)
+                    geom_solver.append(g._solver)
                 auto_pairs.append((gb_.name, ga_.name))
     # explicit geom-geom collision candidates (<contact><pair geom1=... geom2=...>)
     pairs = list(auto_pairs)
     every = {g.name: g for b in bodies for g in b.geoms if g.name}
     every.update({g.name: g for g in world_geoms})
     for pr in (con.findall("pair") if con is not None else []):
+        if any(k in pr.attrib for k in ("condim", "friction", "solref", "solimp", "margin", "gap")):
+            raise ValueError("<pair> with its own contact parameters is not supported (the geoms' are mixed, mj_contactParam)")
         pairs.append((pr.get("geom1"), pr.get("geom2")))
         for nm in (pr.get("geom1"), pr.get("geom2")):
             if nm in every:
-                geom_solver.add(every[nm]._solver)
-    if len(geom_solver) > 1 or len(limit_solver) > 1 or len(friction_solver) > 1:
-        raise ValueError("one solref / solimp set for contacts, one for joint limits and one for friction loss")
+                geom_solver.append(every[nm]._solver)
+    for sets in (geom_solver, limit_solver, friction_solver):
+        if any(r[0] <= 0 or r[1] <= 0 for r, _ in sets):
+            raise ValueError("solref must be the standard (timeconst, dampratio) pair: negative (direct) values are not supported")
 
     def full_solimp(si):
         return tuple(si) + (0.9, 0.95, 0.001, 0.5, 2.0)[len(si):]
 
-    solref, solimp = geom_solver.pop() if geom_solver else DEF_SOL
-    lsolref, lsolimp = limit_solver.pop() if limit_solver else DEF_SOL
-    fsolref, fsolimp = friction_solver.pop() if friction_solver else DEF_SOL
+    def common(sets):                   # the most frequent set becomes the model's own; elements keep theirs only where it differs
+        return max(sets, key=sets.count) if sets else DEF_SOL
+
+    solref, solimp = common(geom_solver)
+    lsolref, lsolimp = common(limit_solver)
+    fsolref, fsolimp = common(friction_solver)
     for g in [g for b in bodies for g in b.geoms] + world_geoms:
+        if g._solver != (solref, solimp):
+            g.solref, g.solimp = g._solver[0], full_solimp(g._solver[1])
         del g._contype, g._conaffinity, g._solver
+    if plane is not None:
+        if plane._solver != (solref, solimp):
+            plane.solref, plane.solimp = plane._solver[0], full_solimp(plane._solver[1])
+        del plane._solver
+    for b in bodies:
+        jt = b.joint
+        if jt is None:
+            continue
+        if jt.solref_limit is not None:
+            same = (tuple(jt.solref_limit), tuple(jt.solimp_limit)) == (lsolref, lsolimp)
+            jt.solref_limit, jt.solimp_limit = (None, None) if same else (jt.solref_limit, full_solimp(jt.solimp_limit))
+        if jt.solref_friction is not None:
+            same = (tuple(jt.solref_friction), tuple(jt.solimp_friction)) == (fsolref, fsolimp)
+            jt.solref_friction, jt.solimp_friction = (None, None) if same else (jt.solref_friction, full_solimp(jt.solimp_friction))
     if totalmass is not None:           # MuJoCo scales every body mass and inertia by the same factor
         total = sum(_geom_inertial(g, MJ20_CAPSULE_CAP)[0] for b in bodies for g in b.geoms if b.inertial is None)
         total += sum(b.inertial.mass for b in bodies if b.inertial is not None)
@@ -476,14 +504,20 @@ def load_mjcf(path, hand_site="finger", target_site="target", frame_skip=2, task
         if float(t.get("stiffness", "0")) != 0 or float(t.get("damping", "0")) != 0 or float(t.get("frictionloss", "0")) != 0:
             raise ValueError("tendon stiffness / damping / frictionloss are not supported")
         lim = t.get("limited", "false") == "true"
+        tset = None
         if lim:
-            limit_solver.add((tuple(_floats(t.get("solreflimit", "0.02 1"))), tuple(_floats(t.get("solimplimit", "0.9 0.95 0.001 0.5 2")))))
-            if limit_solver != {(tuple(lsolref), tuple(lsolimp))} and (lsolref, lsolimp) != DEF_SOL:
-                raise ValueError("tendon limits share the joint limits' solref / solimp")
-            lsolref, lsolimp = list(limit_solver)[0]
+            tset = (tuple(_floats(t.get("solreflimit", "0.02 1"))), tuple(_floats(t.get("solimplimit", "0.9 0.95 0.001 0.5 2"))))
+            if tset[0][0] <= 0 or tset[0][1] <= 0:
+                raise ValueError("solref must be the standard (timeconst, dampratio) pair")
+            if not limit_solver:
+                lsolref, lsolimp = tset             # (no limited joint: the tendons' set is the model's limit set)
+                limit_solver.append(tset)
+            if tset == (tuple(lsolref), tuple(lsolimp)):
+                tset = None
         tendons.append(RawTendon(t.get("name", "tendon%d" % len(tendons)),
                                  [(j.get("joint"), float(j.get("coef", "1"))) for j in t.findall("joint")],
-                                 limited=lim, range=_floats(t.get("range"), 2, [0.0, 0.0]), margin=float(t.get("margin", "0"))))
+                                 limited=lim, range=_floats(t.get("range"), 2, [0.0, 0.0]), margin=float(t.get("margin", "0")),
+                                 solref_limit=tset and tset[0], solimp_limit=tset and full_solimp(tset[1])))
 
     acts = []
     act = root.find("actuator")

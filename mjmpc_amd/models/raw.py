@@ -46,13 +46,40 @@ TASK_FORWARD = 1            # reward (x' - x)/dt - c |a|^2, obs [qpos[skip:], qv
 TASK_ORIENT = 2             # in-hand reorientation, the shape of pen-v0's reward (examples/configs/hand/pen-v0.yml:8): the
                             # tracked site rides on the object; reward -|h-g|_2 + d.d*, d = the object's axis (site_axis
                             # carried by the site's body), d* = target_dir; obs as TASK_REACH
-BODY_STRIDE = 40
-GEOM_STRIDE = 24
+BODY_STRIDE = 56
+GEOM_STRIDE = 33
 ACT_STRIDE = 11
 PAIR_STRIDE = 2
 EQ_STRIDE = 28
 TENDON_MAX_JOINTS = 4
-TENDON_STRIDE = 8 + 2 * TENDON_MAX_JOINTS
+TENDON_STRIDE = 8 + 2 * TENDON_MAX_JOINTS + 7
+
+
+def _solimp5(si):
+    """MJCF solimp with fewer than five entries: the rest from MuJoCo's default (0.9 0.95 0.001 0.5 2)."""
+    si = tuple(float(x) for x in si)
+    return si + (0.9, 0.95, 0.001, 0.5, 2.0)[len(si):]
+
+
+def mix_contact_solver(a, b):
+    """(solref, solimp) of a contact between two geoms / a geom and the plane, each given as (solref, solimp, solmix,
+    priority): MuJoCo mj_contactParam [EXT] - the higher priority wins; equal priorities: weights solmix_a : solmix_b
+    (both below mjMINVAL: 1 : 1; one below: the other wins)."""
+    (ra, ia, ma, pa), (rb, ib, mb, pb) = a, b
+    if pa != pb:
+        r, i = (ra, ia) if pa > pb else (rb, ib)
+        return tuple(float(x) for x in r), _solimp5(i)
+    MINVAL = 1e-15
+    if ma >= MINVAL and mb >= MINVAL:
+        w = ma / (ma + mb)
+    elif ma < MINVAL and mb < MINVAL:
+        w = 0.5
+    else:
+        w = 0.0 if ma < MINVAL else 1.0
+    ia, ib = _solimp5(ia), _solimp5(ib)
+    return (tuple(w * x + (1 - w) * y for x, y in zip(ra, rb)), tuple(w * x + (1 - w) * y for x, y in zip(ia, ib)))
+
+
 JOINT_NDOF = {JOINT_HINGE: 1, JOINT_SLIDE: 1, JOINT_BALL: 3, JOINT_FREE: 6}
 JOINT_NQ = {JOINT_HINGE: 1, JOINT_SLIDE: 1, JOINT_BALL: 4, JOINT_FREE: 7}
 
@@ -70,6 +97,11 @@ class RawJoint:
     springref: float = 0.0
     pos: Sequence[float] = (0.0, 0.0, 0.0)  # anchor in the body frame (hinge / ball; MJCF joint pos)
     frictionloss: float = 0.0               # dry friction: one friction-loss constraint row per dof (MuJoCo dof_frictionloss)
+    # this joint's own solver parameters (MJCF solreflimit / solimplimit, solreffriction / solimpfriction); None: the model's
+    solref_limit: Optional[Sequence[float]] = None
+    solimp_limit: Optional[Sequence[float]] = None
+    solref_friction: Optional[Sequence[float]] = None
+    solimp_friction: Optional[Sequence[float]] = None
 
     @property
     def ndof(self):
@@ -93,6 +125,13 @@ class RawGeom:
     friction: float = 1.0                   # sliding friction (MuJoCo default "1 0.005 0.0001", first entry)
     condim: int = 1
     quat: Sequence[float] = (1.0, 0.0, 0.0, 0.0)    # box: orientation in the body frame
+    # contact solver parameters of this geom (None: the model's solref / solimp) and how two geoms' are combined
+    # (MuJoCo mj_contactParam [EXT]: the higher priority wins; equal priorities: solref / solimp averaged with weights
+    # solmix_1 : solmix_2, friction / condim / margin the larger of the two)
+    solref: Optional[Sequence[float]] = None
+    solimp: Optional[Sequence[float]] = None
+    solmix: float = 1.0
+    priority: int = 0
 
 
 @dataclass
@@ -133,6 +172,8 @@ class RawTendon:
     limited: bool = False
     range: Sequence[float] = (0.0, 0.0)
     margin: float = 0.0
+    solref_limit: Optional[Sequence[float]] = None     # None: the model's joint-limit set
+    solimp_limit: Optional[Sequence[float]] = None
 
 
 @dataclass
@@ -167,6 +208,10 @@ class RawPlane:
     margin: float
     friction: float = 1.0
     condim: int = 1
+    solref: Optional[Sequence[float]] = None        # as RawGeom
+    solimp: Optional[Sequence[float]] = None
+    solmix: float = 1.0
+    priority: int = 0
 
 
 @dataclass
@@ -274,6 +319,9 @@ class RawModel:
             h[29] = self.plane.margin
             h[35] = self.plane.friction
             h[36] = self.plane.condim
+            h[63:65] = self.solref if self.plane.solref is None else self.plane.solref
+            h[65:70] = _solimp5(self.solimp if self.plane.solimp is None else self.plane.solimp)
+            h[70], h[71] = self.plane.solmix, self.plane.priority
         h[30], h[31] = self.density, self.viscosity
         h[32], h[33], h[34] = self.task, self.ctrl_cost, self.obs_skip
         h[37] = self.capsule_cap_factor
@@ -302,6 +350,12 @@ class RawModel:
                 r[16] = b.joint.armature
                 r[19:22] = b.joint.pos
                 r[22] = b.joint.frictionloss
+                lim_ref = self.solref if self.solref_limit is None else self.solref_limit
+                lim_imp = self.solimp if self.solimp_limit is None else self.solimp_limit
+                r[40:42] = lim_ref if b.joint.solref_limit is None else b.joint.solref_limit
+                r[42:47] = _solimp5(lim_imp if b.joint.solimp_limit is None else b.joint.solimp_limit)
+                r[47:49] = self.solref_friction if b.joint.solref_friction is None else b.joint.solref_friction
+                r[49:54] = _solimp5(self.solimp_friction if b.joint.solimp_friction is None else b.joint.solimp_friction)
             if b.inertial is not None:
                 r[23] = 1.0
                 r[24] = b.inertial.mass
@@ -321,6 +375,9 @@ class RawModel:
             r[12] = g.friction
             r[13] = g.condim
             r[14:18] = g.quat
+            r[24:26] = self.solref if g.solref is None else g.solref
+            r[26:31] = _solimp5(self.solimp if g.solimp is None else g.solimp)
+            r[31], r[32] = g.solmix, g.priority
             out.append(r)
         tnames = [t.name for t in self.tendons]
         for a in self.actuators:
@@ -368,5 +425,9 @@ class RawModel:
             for k, (jn, coef) in enumerate(t.joints):
                 r[8 + 2 * k] = self.dof_of_joint(jn)
                 r[9 + 2 * k] = coef
+            lim_ref = self.solref if self.solref_limit is None else self.solref_limit
+            lim_imp = self.solimp if self.solimp_limit is None else self.solimp_limit
+            r[8 + 2 * TENDON_MAX_JOINTS:10 + 2 * TENDON_MAX_JOINTS] = lim_ref if t.solref_limit is None else t.solref_limit
+            r[10 + 2 * TENDON_MAX_JOINTS:15 + 2 * TENDON_MAX_JOINTS] = _solimp5(lim_imp if t.solimp_limit is None else t.solimp_limit)
             out.append(r)
         return np.concatenate(out).astype(np.float64)

@@ -47,12 +47,12 @@
 #define MJ_MINVAL 1e-15    /* MuJoCo mjMINVAL */
 
 #define HEADER_LEN 80
-#define BODY_STRIDE 40
-#define GEOM_STRIDE 24
+#define BODY_STRIDE 56
+#define GEOM_STRIDE 33
 #define ACT_STRIDE 11
 #define PAIR_STRIDE 2
 #define EQ_STRIDE 28
-#define TENDON_STRIDE (8 + 2 * MAXTJ)
+#define TENDON_STRIDE (8 + 2 * MAXTJ + 7)
 #define MAXP 16            /* geom-geom collision pairs */
 /* joint kinds (mjmpc_amd/models/raw.py) */
 #define JHINGE 1
@@ -82,7 +82,8 @@ typedef struct {
     double damping[MAXV], armature[MAXV], stiffness[MAXV], springref[MAXV], frictionloss[MAXV];
     int dof_type[MAXV];                      /* 1 rotation about xaxis through xanchor, 2 translation along xaxis */
     int dof_qadr[MAXV];                      /* hinge / slide dofs: their qpos entry (-1 for ball / free dofs) */
-    double solref_f[2], solimp_f[5];         /* friction-loss rows */
+    double solref_f[2], solimp_f[5];         /* friction-loss rows (the model's set; every dof may carry its own) */
+    double dof_solref_l[MAXV][2], dof_solimp_l[MAXV][5], dof_solref_f[MAXV][2], dof_solimp_f[MAXV][5];
     /* inertial (inertiafromgeom) */
     double mass[MAXB], ipos[MAXB][3], inertia[MAXB][9];  /* tensor about the COM, body frame */
     /* motors */
@@ -102,9 +103,11 @@ typedef struct {
     int sph_body[MAXS];
     double sph_pos[MAXS][3], sph_r[MAXS], sph_margin[MAXS];
     double sph_mu[MAXS], sph_axis[MAXS][3];   /* friction (0: frictionless row) and capsule axis in the body frame */
+    double sph_solref[MAXS][2], sph_solimp[MAXS][5];   /* the contact's solver parameters (mj_contactParam: geom x plane) */
     /* geom-geom pairs: two segments (a sphere is a segment of length 0) with radii, on two bodies */
     int npair, pair_body[MAXP][2];
     double pair_a[MAXP][2][3], pair_d[MAXP][2][3], pair_r[MAXP][2], pair_margin[MAXP], pair_mu[MAXP];
+    double pair_solref[MAXP][2], pair_solimp[MAXP][5];
     int pair_box[MAXP];                      /* -1: two segments; e: geom e of the pair is a BOX (the other a sphere) */
     double pair_R[MAXP][9], pair_half[MAXP][3];   /* that box: orientation in its body's frame, half sizes (pair_a = centre) */
     /* equality constraints (MJCF <equality>): connect / weld (two bodies, 0 = world) and joint (two dofs, -1 = none) */
@@ -113,6 +116,7 @@ typedef struct {
     /* fixed tendons: length = sum coef q over hinge / slide dofs; limit rows */
     int ntendon, tn_n[MAXT], tn_dof[MAXT][MAXTJ], tn_limited[MAXT];
     double tn_coef[MAXT][MAXTJ], tn_range[MAXT][2], tn_margin[MAXT], tn_invweight0[MAXT];
+    double tn_solref[MAXT][2], tn_solimp[MAXT][5];
     /* TASK 2 (in-hand reorientation): object axis in the site body's frame, direction it should point in */
     double site_axis[3], target_dir[3];
     /* joint-limit rows may carry their own solver parameters (MJCF solreflimit / solimplimit) */
@@ -503,6 +507,18 @@ static void geom_inertia(int type, double r, const double *a, const double *b_, 
 }
 
 static void set_const(OrModel *m);
+/* MuJoCo mj_contactParam [EXT]: solver parameters of a contact between two geoms, each {solref[2], solimp[5], solmix,
+ * priority} (entries 24..32 of a geom record; the plane's in the header): the higher priority wins; equal priorities:
+ * solref / solimp averaged with weights solmix_a : solmix_b */
+static void mix_solver(const double *a, const double *b, double *solref, double *solimp) {
+    double w;
+    if (a[8] != b[8]) w = a[8] > b[8] ? 1.0 : 0.0;
+    else if (a[7] >= MJ_MINVAL && b[7] >= MJ_MINVAL) w = a[7] / (a[7] + b[7]);
+    else if (a[7] < MJ_MINVAL && b[7] < MJ_MINVAL) w = 0.5;
+    else w = a[7] < MJ_MINVAL ? 0.0 : 1.0;
+    for (int i = 0; i < 2; i++) solref[i] = w * a[i] + (1 - w) * b[i];
+    for (int i = 0; i < 5; i++) solimp[i] = w * a[2 + i] + (1 - w) * b[2 + i];
+}
 
 OrModel *or_model_compile(const double *f, int n) {
     OrModel *m = (OrModel *)calloc(1, sizeof(OrModel));
@@ -570,6 +586,10 @@ OrModel *or_model_compile(const double *f, int n) {
                 m->damping[j] = r[15];
                 m->armature[j] = r[16];
                 m->frictionloss[j] = r[22];
+                memcpy(m->dof_solref_l[j], r + 40, 16);
+                memcpy(m->dof_solimp_l[j], r + 42, 40);
+                memcpy(m->dof_solref_f[j], r + 47, 16);
+                memcpy(m->dof_solimp_f[j], r + 49, 40);
             }
             if (nd == 1) {
                 m->stiffness[nv] = r[17];
@@ -629,6 +649,7 @@ OrModel *or_model_compile(const double *f, int n) {
             double mu = r[12] > plane_mu ? r[12] : plane_mu;
             int condim = (int)r[13] > plane_condim ? (int)r[13] : plane_condim;
             m->sph_mu[s] = condim >= 3 ? mu : 0.0;
+            mix_solver(r + 24, f + 63, m->sph_solref[s], m->sph_solimp[s]);
             if (ends == 2) {
                 double u[3] = {r[6] - r[3], r[7] - r[4], r[8] - r[5]}, len = sqrt(dot3(u, u));
                 for (int i = 0; i < 3; i++) m->sph_axis[s][i] = u[i] / len;
@@ -698,6 +719,8 @@ OrModel *or_model_compile(const double *f, int n) {
         }
         m->pair_margin[k] = margin;
         m->pair_mu[k] = condim >= 3 ? mu : 0.0;
+        mix_solver(g0 + (int)p0[k * PAIR_STRIDE] * GEOM_STRIDE + 24, g0 + (int)p0[k * PAIR_STRIDE + 1] * GEOM_STRIDE + 24,
+                   m->pair_solref[k], m->pair_solimp[k]);
     }
     const double *e0 = p0 + np_ * PAIR_STRIDE;
     m->neq = ne;
@@ -721,6 +744,8 @@ OrModel *or_model_compile(const double *f, int n) {
         m->tn_range[k][0] = r[2];
         m->tn_range[k][1] = r[3];
         m->tn_margin[k] = r[4];
+        memcpy(m->tn_solref[k], r + 8 + 2 * MAXTJ, 16);
+        memcpy(m->tn_solimp[k], r + 10 + 2 * MAXTJ, 40);
         for (int i = 0; i < m->tn_n[k]; i++) {
             m->tn_dof[k][i] = (int)r[8 + 2 * i];
             m->tn_coef[k][i] = r[9 + 2 * i];
@@ -806,6 +831,10 @@ static void set_const(OrModel *m) {
     clamp_solimp(m->solimp_l);
     clamp_solimp(m->solimp_f);
     for (int e = 0; e < m->neq; e++) clamp_solimp(m->eq_solimp[e]);
+    for (int j = 0; j < m->nv; j++) { clamp_solimp(m->dof_solimp_l[j]); clamp_solimp(m->dof_solimp_f[j]); }
+    for (int s = 0; s < m->nsphere; s++) clamp_solimp(m->sph_solimp[s]);
+    for (int k = 0; k < m->npair; k++) clamp_solimp(m->pair_solimp[k]);
+    for (int t = 0; t < m->ntendon; t++) clamp_solimp(m->tn_solimp[t]);
     /* inertial frames: principal axes of every body's inertia tensor (body frame when it is diagonal there) and
      * the box of equal inertia, MuJoCo mj_passive: box_i = sqrt(6 (I_j + I_k - I_i) / m) */
     for (int b = 1; b < m->nbody; b++) body_box(m, b);
@@ -907,11 +936,6 @@ static void row_params_set(const OrModel *m, const double *solref, const double 
     double b = 2 / (dmax * tc), kk = 1 / (dmax * dmax * tc * tc * dr * dr);
     *aref = -b * jv - kk * imp * r;
 }
-static void row_params(const OrModel *m, double pos, double margin, double diagApprox, double jv,
-                       double *D, double *aref) {
-    row_params_set(m, m->solref, m->solimp, pos, margin, diagApprox, jv, D, aref);
-}
-
 /* minimise  1/2 (a - a_s)^T M (a - a_s) + sum_i s_i(J_i a - aref_i)
  * (MuJoCo's primal problem, mj_constraintUpdate): per row kind the cost s(r) is
  *   ROW_UNI   limits, frictionless and pyramidal contacts   1/2 D min(0, r)^2
@@ -1097,7 +1121,8 @@ static void seg_seg(const double *p1, const double *d1, const double *p2, const 
  * normal and - if it is not zero - the axis hint; diagApprox = tran (1 + mu^2), all four rows R = 2 mu^2 R_first).
  * J = the relative velocity of the two bodies' material points at cp. */
 static void contact_rows(const OrModel *m, const Kin *k, const double *v, const double *n, const double *cp, int bA, int bB,
-                         double dist, double margin, double mu, const double *axis_hint, double (*J)[MAXV], double *aref,
+                         double dist, double margin, double mu, const double *solref, const double *solimp,
+                         const double *axis_hint, double (*J)[MAXV], double *aref,
                          double *D, int *pnc) {
     int nv = m->nv, nc = *pnc;
     double Jp[3 * MAXV], Jq[3 * MAXV];
@@ -1113,7 +1138,7 @@ static void contact_rows(const OrModel *m, const Kin *k, const double *v, const 
             J[nc][j] = n[0] * Jp[j] + n[1] * Jp[nv + j] + n[2] * Jp[2 * nv + j];
             jv += J[nc][j] * v[j];
         }
-        row_params(m, dist, margin, tran, jv, &D[nc], &aref[nc]);
+        row_params_set(m, solref, solimp, dist, margin, tran, jv, &D[nc], &aref[nc]);
         nc++;
     } else {
         double t1[3], t2[3], ax[3] = {axis_hint[0], axis_hint[1], axis_hint[2]};
@@ -1128,7 +1153,7 @@ static void contact_rows(const OrModel *m, const Kin *k, const double *v, const 
         else for (int i = 0; i < 3; i++) t1[i] /= nr;
         cross3(n, t1, t2);
         double D0, a0;
-        row_params(m, dist, margin, tran * (1 + mu * mu), 0.0, &D0, &a0);
+        row_params_set(m, solref, solimp, dist, margin, tran * (1 + mu * mu), 0.0, &D0, &a0);
         double Rpy = 2 * mu * mu / D0;
         for (int kk = 0; kk < 2; kk++) {
             const double *tt = kk == 0 ? t1 : t2;
@@ -1140,7 +1165,7 @@ static void contact_rows(const OrModel *m, const Kin *k, const double *v, const 
                     J[nc][j] = jn + sg * mu * jt;
                     jvr += J[nc][j] * v[j];
                 }
-                row_params(m, dist, margin, tran * (1 + mu * mu), jvr, &Dd, &ar);
+                row_params_set(m, solref, solimp, dist, margin, tran * (1 + mu * mu), jvr, &Dd, &ar);
                 D[nc] = 1 / Rpy;
                 aref[nc] = ar;
                 nc++;
@@ -1317,7 +1342,7 @@ void or_step(OrModel *m, double *q, double *v, const double *ctrl, double *site_
         if (!(m->frictionloss[j] > 0)) continue;
         memset(J[nc], 0, sizeof(J[nc]));
         J[nc][j] = 1.0;
-        row_params_set(m, m->solref_f, m->solimp_f, 0.0, 0.0, m->dof_invweight0[j], v[j], &D[nc], &aref[nc]);
+        row_params_set(m, m->dof_solref_f[j], m->dof_solimp_f[j], 0.0, 0.0, m->dof_invweight0[j], v[j], &D[nc], &aref[nc]);
         kind[nc] = ROW_FRIC;
         floss[nc] = m->frictionloss[j];
         nc++;
@@ -1332,7 +1357,7 @@ void or_step(OrModel *m, double *q, double *v, const double *ctrl, double *site_
             if (dist < 0) {
                 memset(J[nc], 0, sizeof(J[nc]));
                 J[nc][j] = -side;
-                row_params_set(m, m->solref_l, m->solimp_l, dist, 0.0, m->dof_invweight0[j], -side * v[j], &D[nc], &aref[nc]);
+                row_params_set(m, m->dof_solref_l[j], m->dof_solimp_l[j], dist, 0.0, m->dof_invweight0[j], -side * v[j], &D[nc], &aref[nc]);
                 nc++;
             }
         }
@@ -1350,7 +1375,7 @@ void or_step(OrModel *m, double *q, double *v, const double *ctrl, double *site_
             if (dist < m->tn_margin[t]) {
                 memset(J[nc], 0, sizeof(J[nc]));
                 for (int i = 0; i < m->tn_n[t]; i++) J[nc][m->tn_dof[t][i]] += -side * m->tn_coef[t][i];
-                row_params_set(m, m->solref_l, m->solimp_l, dist, m->tn_margin[t], m->tn_invweight0[t], -side * lv, &D[nc], &aref[nc]);
+                row_params_set(m, m->tn_solref[t], m->tn_solimp[t], dist, m->tn_margin[t], m->tn_invweight0[t], -side * lv, &D[nc], &aref[nc]);
                 nc++;
             }
         }
@@ -1368,7 +1393,7 @@ void or_step(OrModel *m, double *q, double *v, const double *ctrl, double *site_
             double cp[3], ax[3];
             for (int i = 0; i < 3; i++) cp[i] = k.xpos[b][i] + t[i] - m->plane_n[i] * (m->sph_r[s] + 0.5 * dist);
             matvec3(k.xmat[b], m->sph_axis[s], ax);
-            contact_rows(m, &k, v, m->plane_n, cp, b, 0, dist, margin, m->sph_mu[s], ax, J, aref, D, &nc);
+            contact_rows(m, &k, v, m->plane_n, cp, b, 0, dist, margin, m->sph_mu[s], m->sph_solref[s], m->sph_solimp[s], ax, J, aref, D, &nc);
         }
     }
     /* geom-geom contacts (mjc_SphereSphere / SphereCapsule / CapsuleCapsule): the closest points of the two segments,
@@ -1432,7 +1457,7 @@ void or_step(OrModel *m, double *q, double *v, const double *ctrl, double *site_
             if (dist < m->pair_margin[p]) {
                 double cp[3];
                 for (int i = 0; i < 3; i++) cp[i] = c2[i] + diff[i] * (m->pair_r[p][1] + 0.5 * dist);
-                contact_rows(m, &k, v, diff, cp, m->pair_body[p][0], m->pair_body[p][1], dist, m->pair_margin[p], m->pair_mu[p],
+                contact_rows(m, &k, v, diff, cp, m->pair_body[p][0], m->pair_body[p][1], dist, m->pair_margin[p], m->pair_mu[p], m->pair_solref[p], m->pair_solimp[p],
                              ZERO3, J, aref, D, &nc);
             }
             continue;
@@ -1453,7 +1478,7 @@ void or_step(OrModel *m, double *q, double *v, const double *ctrl, double *site_
                 n[i] = diff[i] / len;
                 cp[i] = c2[i] + n[i] * (m->pair_r[p][1] + 0.5 * dist);
             }
-            contact_rows(m, &k, v, n, cp, m->pair_body[p][0], m->pair_body[p][1], dist, m->pair_margin[p], m->pair_mu[p],
+            contact_rows(m, &k, v, n, cp, m->pair_body[p][0], m->pair_body[p][1], dist, m->pair_margin[p], m->pair_mu[p], m->pair_solref[p], m->pair_solimp[p],
                          ZERO3, J, aref, D, &nc);
         }
     }

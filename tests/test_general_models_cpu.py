@@ -514,3 +514,58 @@ def test_includes_visual_meshes_excludes_and_sensors(tmp_path):
         _model(tmp_path, no_inertial, extra=acts, name="bad2.xml")
     with pytest.raises(ValueError, match="noslip"):
         _model(tmp_path, body % "", extra=acts, name="ns.xml", head=HEAD + '<option noslip_iterations="5"/>')
+
+
+# ------------------------------------------------------------------------------------------ solver parameters per element
+MIXED = """
+<geom name="floor" type="plane" pos="0 0 0" size="5 5 0.1" contype="1" conaffinity="1" condim="3" friction="0.7"
+      solref="0.03 1" solimp="0.8 0.9 0.002" solmix="3"/>
+<body name="ball" pos="0 0 0.1"><freejoint name="ball_free"/>
+  <geom name="ball" type="sphere" size="0.1" mass="0.5" contype="1" conaffinity="1" condim="3" solref="0.01 1" solimp="0.9 0.95 0.001"/>
+  <site name="finger"/></body>
+<body name="pa" pos="1 0 1"><joint name="ja" type="hinge" axis="0 1 0" limited="true" range="-0.3 0.3" frictionloss="0.05"
+    solreflimit="%s" solimplimit="0.9 0.95 0.001" solreffriction="%s"/>
+  <geom type="capsule" fromto="0 0 0 0.3 0 0" size="0.03" mass="0.4"/></body>
+<body name="pb" pos="2 0 1"><joint name="jb" type="hinge" axis="0 1 0" limited="true" range="-0.3 0.3" frictionloss="0.05"
+    solreflimit="%s" solimplimit="0.9 0.95 0.001" solreffriction="%s"/>
+  <geom type="capsule" fromto="0 0 0 0.3 0 0" size="0.03" mass="0.4"/></body>"""
+MIXED_ACT = ('<actuator><motor joint="ja" ctrlrange="-1 1" ctrllimited="true"/><motor joint="jb" ctrlrange="-1 1" ctrllimited="true"/></actuator>')
+
+
+def test_solver_parameters_per_geom_and_per_joint(tmp_path):
+    """MuJoCo mj_contactParam [EXT]: a contact's solref / solimp are its two geoms' averaged with weights solmix_1 : solmix_2
+    (a higher priority wins outright); joint-limit and friction-loss rows carry their joint's own sets.  The mixed model
+    equals, trajectory for trajectory, models that give every element the resulting numbers directly."""
+    from mjmpc_amd.models.raw import mix_contact_solver
+    r, i = mix_contact_solver(((0.01, 1.0), (0.9, 0.95, 0.001), 1.0, 0), ((0.03, 1.0), (0.8, 0.9, 0.002), 3.0, 0))
+    np.testing.assert_allclose(r, (0.025, 1.0))
+    np.testing.assert_allclose(i, (0.825, 0.9125, 0.00175, 0.5, 2.0))
+    assert mix_contact_solver(((0.01, 1.0), (0.9, 0.95, 0.001), 1.0, 2), ((0.03, 1.0), (0.8, 0.9, 0.002), 3.0, 0))[0] == (0.01, 1.0)
+    assert mix_contact_solver(((0.01, 1.0), (0.9,), 0.0, 0), ((0.03, 1.0), (0.8,), 0.0, 0))[0] == (0.02, 1.0)
+    raw, ref = _model(tmp_path, MIXED % ("0.01 1", "0.02 1", "0.05 1", "0.08 1"), extra=MIXED_ACT, name="mixed.xml")
+    assert raw.plane.solmix == 3.0 and {tuple(b.joint.solref_limit or ()) for b in raw.bodies[1:]} == {(), (0.05, 1.0)}
+    tm = compile_tree(raw)
+    tab = tm.field("soltab").reshape(8, 7)
+    assert np.count_nonzero(tab[:, 0]) == 5         # the ball's own set (= pendulum a's limit set), the mixed one, b's limit set, two friction sets
+    # the same numbers given directly
+    direct = 'solref="0.025 1" solimp="0.825 0.9125 0.00175"'
+    same = MIXED.replace('solref="0.03 1" solimp="0.8 0.9 0.002" solmix="3"', direct).replace('solref="0.01 1" solimp="0.9 0.95 0.001"', direct)
+    _, ref_a = _model(tmp_path, same % ("0.01 1", "0.02 1", "0.01 1", "0.02 1"), extra=MIXED_ACT, name="a.xml")
+    _, ref_b = _model(tmp_path, same % ("0.05 1", "0.08 1", "0.05 1", "0.08 1"), extra=MIXED_ACT, name="b.xml")
+    q0 = raw.qpos0.copy()
+    q0[2] = 0.12                                    # the ball drops 2 cm onto the floor, with some spin and drift
+    v0 = np.zeros(raw.nv)
+    v0[0], v0[4], v0[6], v0[7] = 0.3, 2.0, 3.0, -3.0    # both pendulums swing into their limits
+    u = np.array([0.3, -0.3])
+    qm, vm, _ = _run(ref, q0, v0, u, 400)
+    qa, va, _ = _run(ref_a, q0, v0, u, 400)
+    qb, vb, _ = _run(ref_b, q0, v0, u, 400)
+    np.testing.assert_allclose(np.r_[qm[:7], vm[:6]], np.r_[qa[:7], va[:6]], rtol=0, atol=1e-11)      # the ball: same in all three
+    np.testing.assert_allclose(np.r_[qm[7], vm[6]], np.r_[qa[7], va[6]], rtol=0, atol=1e-11)          # pendulum a: the stiff sets
+    np.testing.assert_allclose(np.r_[qm[8], vm[7]], np.r_[qb[8], vb[7]], rtol=0, atol=1e-11)          # pendulum b: the soft sets
+    assert abs(qa[8] - qb[8]) > 1e-4                # (and the sets do matter)
+    nine = "".join('<body name="s%d" pos="%d 1 0.2"><joint type="slide" axis="0 0 1"/><geom type="sphere" size="0.1" contype="1" conaffinity="1" solref="%g 1"/></body>'
+                   % (k, k, 0.01 + 0.002 * k) for k in range(9))
+    rr, _ = _model(tmp_path, MIXED % ("0.01 1", "0.02 1", "0.05 1", "0.08 1") + nine, extra=MIXED_ACT, name="nine.xml", self_collision=False)
+    with pytest.raises(NotImplementedError, match="distinct solref"):
+        compile_tree(rr)
