@@ -777,7 +777,6 @@ int mjmpc_tree_rollout_cl(mjmpc_tree_t h, int dtype, int64_t P, int H, const dou
                           void* d_costs, void* d_actions, void* d_obs, void* d_next_obs, void* stream) {
     if (!h || !d_weights || !d_costs) return fail(MJMPC_E_BADARG, "null argument");
     if (P < 0 || H < 0) return fail(MJMPC_E_BADARG, "negative size");
-    if (h->gen) return fail(MJMPC_E_BADARG, "closed_loop_linear rollouts are not built for models of the general instantiation");
     const int nss = h->n_state_shards > 1 ? h->n_state_shards : 1;
     if (P % h->n_shards != 0 || P % nss != 0)
         return fail(MJMPC_E_BADARG, "%lld particles do not divide into %d shards", (long long)P, std::max(h->n_shards, nss));

@@ -1271,15 +1271,29 @@ __global__ __launch_bounds__(64 * wg_waves(DP, FRIC, sizeof(T), PL), min_waves(s
         if (clw) {
             // mean_act = W' [obs; 1] with the observation this step starts from (gym_env_wrapper.py:135-136): every
             // lane weighs the entries it holds, one 32-lane sum per action
-            const int iq = task == 1 ? l - obs_skip : l, iv = task == 1 ? nv - obs_skip + l : nv + l;
+            // (general models: qpos in MuJoCo's layout - my coordinate sits at qadr, offset by qoff; a ball joint's first
+            // link holds the quaternion, which the observation shows as q0 * q_link; velocities follow the nq coordinates)
+            const int skip = task == 1 ? obs_skip : 0;
+            const int iq = (GEN ? qadr : l) - skip, iv = nq - skip + l;
+            T oq[4] = {q + (GEN ? qoff : T(0)), T(0), T(0), T(0)};
+            if (GEN && ball_g == 0) {
+                const T x0 = qoff;
+                oq[0] = q0w * qw - x0 * q - q0y * qy - q0z * qz;
+                oq[1] = q0w * q + x0 * qw + q0y * qz - q0z * qy;
+                oq[2] = q0w * qy - x0 * qz + q0y * qw + q0z * q;
+                oq[3] = q0w * qz + x0 * qy - q0y * q + q0z * qw;
+            }
+            const bool has_q = dof && iq >= 0 && (!GEN || ball_g <= 0);
             for (int a = 0; a < A; ++a) {
                 T part = T(0);
                 if (dof) {
-                    if (iq >= 0) part += (T)clw[iq * A + a] * q;
+                    if (has_q) part += (T)clw[iq * A + a] * oq[0];
+                    if (GEN && ball_g == 0 && iq >= 0)
+                        for (int k = 1; k < 4; ++k) part += (T)clw[(iq + k) * A + a] * oq[k];
                     part += (T)clw[iv * A + a] * v;
                 }
                 if (task == 0 && l < 3)
-                    part += (T)clw[(2 * nv + l) * A + a] * hand_prev[l] + (T)clw[(2 * nv + 3 + l) * A + a] * (hand_prev[l] - tgt[l]);
+                    part += (T)clw[(nq + nv + l) * A + a] * hand_prev[l] + (T)clw[(nq + nv + 3 + l) * A + a] * (hand_prev[l] - tgt[l]);
                 const T sa = sum_lanes<PL>(part) + (T)clw[dobs * A + a];
                 if (l == a) u = sa;
             }
@@ -2666,7 +2680,7 @@ hipError_t launch_tree_rollout(const T* model, int n_model_shards, int max_path,
                                hipStream_t stream, double* state_out, const double* clw, double* site_out, int n_state_shards,
                                bool gen) {
     if (P <= 0 || H <= 0) return hipSuccess;
-    if (gen && (!full || clw)) return hipErrorInvalidValue;     // (closed_loop_linear is not built for the general instantiation)
+    if (gen && !full) return hipErrorInvalidValue;
     if ((state_out || site_out) && P != 1) return hipErrorInvalidValue;
     if (n_model_shards < 1 || n_state_shards < 1) return hipErrorInvalidValue;
     if (n_model_shards > 1 && n_state_shards > 1 && n_model_shards != n_state_shards) return hipErrorInvalidValue;

@@ -134,9 +134,6 @@ class TreeRolloutEngine:
     def rollout_device(self, num_particles, horizon, mean, noise, mode="open_loop", want_obs=False, want_actions=True):
         if mode not in ("open_loop", "closed_loop_linear"):
             raise ValueError("unsupported rollout mode %r ('open_loop' or 'closed_loop_linear')" % (mode,))
-        if mode == "closed_loop_linear" and getattr(self.model, "general", False):
-            raise NotImplementedError("closed_loop_linear rollouts are not built for models with ball / free joints, friction "
-                                      "loss, boxes, equalities or tendons (the general kernel instantiation)")
         if num_particles % self.num_shards != 0:
             raise AssertionError("Number of particles must be divisible by number of shards")
         torch = _torch()

@@ -337,3 +337,24 @@ def test_per_element_solver_parameters_match_oracle(tmp_path):
     np.testing.assert_allclose(rew, o_rew, rtol=1e-9, atol=1e-9)
     np.testing.assert_allclose(nobs, o_nobs, rtol=0, atol=1e-9)
     assert eng.solver_failures() == 0
+
+
+def test_closed_loop_linear_mode_on_general_models(rig):
+    """``rollout(mode="closed_loop_linear")`` (gym_env_wrapper.py:135-136) on models with quaternion coordinates: the
+    observation the weights multiply is [qpos (MuJoCo's layout, nq entries), qvel, site, site - target]."""
+    name, raw, eng, ref = rig
+    rs = np.random.RandomState(31)
+    A, dobs = eng.d_action, eng.d_obs
+    assert dobs == raw.nq + raw.nv + 6
+    P, H = 33, 5
+    W = 0.1 * rs.standard_normal((dobs + 1, A))
+    noise = 0.2 * rs.standard_normal((P, H, A))
+    q, v = random_state(name, raw, rs, big=0.3)
+    tgt = np.asarray(raw.target_pos, float)
+    eng.set_env_state(dict(qp=q, qv=v, target_pos=tgt))
+    obs, rew, act, done, info, nobs = eng.rollout(P, H, W, noise, "closed_loop_linear")
+    o_obs, o_rew, o_act, _, o_nobs = ref.rollout(q, v, tgt, W, noise, mode="closed_loop_linear")
+    np.testing.assert_allclose(act, o_act, rtol=0, atol=1e-9)
+    np.testing.assert_allclose(rew, o_rew, rtol=1e-8, atol=1e-8)
+    np.testing.assert_allclose(nobs, o_nobs, rtol=0, atol=1e-7)
+    assert np.abs(act - noise).max() > 1e-2
