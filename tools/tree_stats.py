@@ -1,7 +1,7 @@
 """Phase clocks and Newton statistics of the tree rollout kernel (developer tool).
 
     python tools/tree_stats.py --build                      # instrumented copy of the library (-DTREE_STATS)
-    python tools/tree_stats.py [hand|swimmer|cheetah] [dtype] [P] [H]
+    python tools/tree_stats.py [hand|swimmer|cheetah|pen|cartpole|tray|door] [dtype] [P] [H]
 
 Prints, for the first particle of the launch, shader cycles per substep in each phase and the constraint statistics."""
 import ctypes, glob, os, subprocess, sys
@@ -32,8 +32,14 @@ if __name__ == "__main__":
     P = int(args[2]) if len(args) > 2 else 4096
     H = int(args[3]) if len(args) > 3 else 32
     from mjmpc_amd.models.pen_hand import holding_state, pen_hand_raw
-    raw = dict(hand=hand24_raw, swimmer=swimmer_raw, cheetah=half_cheetah_raw, pen=pen_hand_raw)[name]()
+    if name in ("cartpole", "tray", "door"):
+        from mjmpc_amd.models.synthetic import start_state, synthetic_raw
+        raw = synthetic_raw(name)
+    else:
+        raw = dict(hand=hand24_raw, swimmer=swimmer_raw, cheetah=half_cheetah_raw, pen=pen_hand_raw)[name]()
     eng = TreeRolloutEngine(raw, dtype=dt)
+    if name in ("cartpole", "tray", "door"):
+        eng.set_env_state(start_state(name, raw))
     if name == "pen":
         st = holding_state()
         eng.set_env_state(dict(qpos=st["qp"], qvel=st["qv"], target_pos=np.asarray(raw.target_pos, float)))
@@ -44,7 +50,7 @@ if __name__ == "__main__":
     lib.mjmpc_debug_tree_stats.argtypes = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_ulonglong)]
     A = eng.d_action
     g = torch.Generator(device="cuda").manual_seed(0)
-    noise = (0.1 if name == "pen" else 0.5) * torch.randn(P, H, A, device="cuda", dtype=torch.float32 if dt == "f32" else torch.float64, generator=g)
+    noise = (0.1 if name in ("pen", "tray") else 0.5) * torch.randn(P, H, A, device="cuda", dtype=torch.float32 if dt == "f32" else torch.float64, generator=g)
     mean = torch.zeros(H, A, device="cuda", dtype=torch.float64)
     if name == "pen":
         mean += torch.from_numpy(st["qp"][6:]).to(mean)
@@ -63,7 +69,7 @@ if __name__ == "__main__":
     ni = max(v[11], 1)
     print("  per Newton iteration: assemble H %.0f, factor %.0f, solve %.0f, next active set (+ rank-one correction) %.0f cycles"
           % (v[12] / ni, v[13] / ni, v[14] / ni, v[15] / ni))
-    print("  iterations that found a changed set: %d - one limit row %d, one contact row %d, several rows %d, only the wave's other particle %d"
-          % (v[16], v[17], v[18], v[19], v[20]))
+    print("  iterations that found a changed set: %d - one limit row %d, one contact row %d, several rows %d, only the wave's other particle %d; friction-loss zone changes %d"
+          % (v[16], v[17], v[18], v[19], v[20], v[21]))
     print("  total %.0f cycles/substep; contact points per substep %.2f; substeps with rows %.0f %%; Newton iterations per such substep %.2f"
           % (tot / nsub, v[9] / nsub, 100.0 * v[10] / nsub, v[11] / max(v[10], 1)))
