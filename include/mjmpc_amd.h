@@ -177,10 +177,10 @@ int mjmpc_arm_step_state(mjmpc_arm_t h, int dtype, const double* d_action, void*
  *   off[3][32] axis[3][32] mass[32] com[3][32] inertia[6][32] armature damping range_lo range_hi limited gear ctrl_lo
  *   ctrl_hi dof_invweight0 stiffness springref (each [32]) fbox[3][32] frot[9][32] kpg[32] kvg[32] tau0[32] (affine actuator bias at the joint: -gear^2 b1, -gear^2 b2, gear b0; servos: kpg = gear^2 kp)
  *   nv timestep frame_skip jumps site_link site_pos[3] n_sphere plane_n[3] plane_d
- *   sol_{K,B,dmin,dmax,width,mid,power} gravity[3] nu task ctrl_cost obs_skip density viscosity
- *   lsol_{K,B,dmin,dmax,width,mid,power} any_friction site_axis[3] target_dir[3]
- *   soltab[8][7] (the model's distinct solver-parameter sets, as sol_*: a contact record names its own in slot [21]) dofcls[32]
- *   (the dof's limit-row set + 8 * its friction-loss-row set)
+ *   gravity[3] nu task ctrl_cost obs_skip density viscosity any_friction site_axis[3] target_dir[3]
+ *   soltab[8][7] (the model's distinct solver-parameter sets {K, B, dmin, dmax, width, mid, power} - MuJoCo's solref /
+ *   solimp after refsafe and clamping; a contact record names its own in slot [21]) dofcls[32] (the dof's limit-row set +
+ *   8 * its friction-loss-row set)
  *   spheres[16][24] = {link A, start[3], rA, margin, invweight, mu, capsule axis / segment vector on A [3], depth of
  *   link A in the elimination tree, kind (0 sphere-plane, 1 geom-geom), link B, start on B [3], rB, segment vector on B [3]}
  *   parent subsize anc[5][32] ancmask[2][32] jtype act eparent (parent in the elimination tree of the factorisation)
@@ -189,13 +189,13 @@ int mjmpc_arm_step_state(mjmpc_arm_t h, int dtype, const double* d_action, void*
  *   k | distance << 8 | height << 16, -1 ends)
  * Same call shapes and reference counterparts as the arm engine (subproc_vec_env.py:91-111, 128-186, 235-251);
  * target_pos is ignored by task 1.                                                                                  */
-#define MJMPC_TREE_BLOB_LEN 3790
+#define MJMPC_TREE_BLOB_LEN 3769
 /* Round 4, the GENERAL instantiation (block field `gen`; models without these features run the earlier kernels unchanged):
  * ball and free joints (quaternion links: qpos has nq >= nv entries in MuJoCo's layout, d_obs = nq + nv + 6 or nq + nv -
  * obs_skip), joint anchors off the body origin, explicit inertials, box geoms (eight corner points against the plane, one
  * point against a sphere), static geoms of the world body (link -1), friction-loss rows (dof_frictionloss), connect and
  * joint equalities, limits of fixed tendons over one or two joints.  The block then continues
- *   gen nq has_ball fsol_{K,B,dmin,dmax,width,mid,power} frictionloss[32] qadr[32] qoff[32] pext[16][24] qw0[32]
+ *   gen nq has_ball frictionloss[32] qadr[32] qoff[32] pext[16][24] qw0[32]
  * (pext: what the new record kinds need beyond spheres[.][24]; layout in csrc/tree_model.h). */
 /* A state vector as the C ABI takes it (mjmpc_tree_set_shard_states): MuJoCo's layout, qpos[40] (nq entries used) |
  * qvel[32] | target_pos[3] | 3 reserved (float64). */

@@ -49,13 +49,6 @@ enum TreeOffset : int {
     T_N_SPHERE = T_SITE_POS + 3,
     T_PLANE_N,                          // 3
     T_PLANE_D = T_PLANE_N + 3,
-    T_SOL_K,
-    T_SOL_B,
-    T_SOL_DMIN,
-    T_SOL_DMAX,
-    T_SOL_WIDTH,
-    T_SOL_MID,
-    T_SOL_POWER,
     T_GRAVITY,                          // 3
     T_NU = T_GRAVITY + 3,
     T_TASK,                             // 0 reach a target with the site, 1 forward progress of qpos[0], 2 reorient an object
@@ -63,13 +56,6 @@ enum TreeOffset : int {
     T_OBS_SKIP,
     T_DENSITY,
     T_VISCOSITY,
-    T_LSOL_K,                           // joint-limit rows: their own solref / solimp
-    T_LSOL_B,
-    T_LSOL_DMIN,
-    T_LSOL_DMAX,
-    T_LSOL_WIDTH,
-    T_LSOL_MID,
-    T_LSOL_POWER,
     T_ANY_FRICTION,                     // the model needs the full instantiation (friction cones, geom-geom pairs, servos)
     T_SITE_AXIS,                        // 3: task 2, the object's axis in the site link's frame
     T_TARGET_DIR = T_SITE_AXIS + 3,     // 3: ... and the direction it should point in
@@ -100,8 +86,7 @@ enum TreeOffset : int {
     T_GEN = T_ELIM + (TL - 1) * TL,     // 1: the model needs the general instantiation
     T_NQ,                               // entries of MuJoCo's qpos (a ball joint: 4 for 3 dofs, a free joint 7 for 6)
     T_HAS_BALL,
-    T_FSOL_K,                           // friction-loss rows: solreffriction / solimpfriction as {K, B, dmin, dmax, width, mid, power}
-    T_FRICTIONLOSS = T_FSOL_K + 7,      // 32: dry friction per dof (0: no row)
+    T_FRICTIONLOSS,                     // 32: dry friction per dof (0: no row)
     T_QADR = T_FRICTIONLOSS + TL,       // 32: the link's entry in qpos (BALL_X link: the quaternion's w); -1: none
     T_QOFF = T_QADR + TL,               // 32: added to the link's coordinate in qpos (free joint translations: the body position)
     T_PEXT = T_QOFF + TL,               // TREE_MAX_SPHERES x TREE_PEXT_STRIDE: what the new record kinds need beyond [24]
@@ -128,6 +113,6 @@ constexpr int TREE_QW = 2 * TL + 6;
 constexpr int TREE_NQ_MAX = 40;
 // the C ABI's state vectors (mjmpc_tree_set_shard_states): MuJoCo's layout - qpos[40] | qvel[32] | target[3] | reserved[3]
 constexpr int TREE_PUBLIC_STATE_LEN = TREE_NQ_MAX + TL + 6;
-static_assert(TREE_BLOB_LEN == 3790, "keep in sync with mjmpc_amd/models/compile_tree.py::TREE_LAYOUT");
+static_assert(TREE_BLOB_LEN == 3769, "keep in sync with mjmpc_amd/models/compile_tree.py::TREE_LAYOUT");
 
 }  // namespace mjmpc

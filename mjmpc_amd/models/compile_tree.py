@@ -51,10 +51,8 @@ TREE_LAYOUT = [
     ("tau0", TL),                   # ... constant: gear biasprm[0]
     ("nv", 1), ("timestep", 1), ("frame_skip", 1), ("jumps", 1), ("site_link", 1), ("site_pos", 3),
     ("n_sphere", 1), ("plane_n", 3), ("plane_d", 1),
-    ("sol_K", 1), ("sol_B", 1), ("sol_dmin", 1), ("sol_dmax", 1), ("sol_width", 1), ("sol_mid", 1), ("sol_power", 1),
     ("gravity", 3),
     ("nu", 1), ("task", 1), ("ctrl_cost", 1), ("obs_skip", 1), ("density", 1), ("viscosity", 1),
-    ("lsol_K", 1), ("lsol_B", 1), ("lsol_dmin", 1), ("lsol_dmax", 1), ("lsol_width", 1), ("lsol_mid", 1), ("lsol_power", 1),
     ("any_friction", 1),
     ("site_axis", 3), ("target_dir", 3),    # TASK_ORIENT: object axis in the site link's frame, its target direction
     # the model's solver-parameter sets {K, B, dmin, dmax, width, mid, power}: contact records name theirs in [21], dofs in dofcls
@@ -73,7 +71,6 @@ TREE_LAYOUT = [
     # ---- the GENERAL instantiation's constants (round 4): ball / free joints, friction loss, boxes, equalities, tendons
     ("gen", 1),                     # the model needs the general instantiation
     ("nq", 1), ("has_ball", 1),
-    ("fsol_K", 1), ("fsol_B", 1), ("fsol_dmin", 1), ("fsol_dmax", 1), ("fsol_width", 1), ("fsol_mid", 1), ("fsol_power", 1),
     ("frictionloss", TL),           # per dof: dry friction (one friction-loss row each)
     ("qadr", TL),                   # the link's entry in MuJoCo's qpos (ball: the quaternion's w, on the BALL_X link; -1: none)
     ("qoff", TL),                   # added to the link's coordinate in qpos (a free joint's translations: the body position);
@@ -784,15 +781,6 @@ def compile_tree(raw: RawModel, overrides=None, base: "TreeModel" = None) -> Tre
     f["any_friction"][0] = 1.0 if (any(f["spheres"][k * SPH_STRIDE + 7] > 0 for k in range(nsp)) or pair_geoms
                                    or any(f["kpg"] != 0) or any(f["kvg"] != 0) or any(f["tau0"] != 0) or raw.task == TASK_ORIENT or gen) else 0.0
 
-    def sol_set(prefix, solref, solimp):
-        vals = sol_values(solref, solimp)
-        for name, v in zip(("_K", "_B", "_dmin", "_dmax", "_width", "_mid", "_power"), vals):
-            f[prefix + name][0] = v
-
-    sol_set("sol", raw.solref, raw.solimp)
-    sol_set("lsol", raw.solref if raw.solref_limit is None else raw.solref_limit,
-            raw.solimp if raw.solimp_limit is None else raw.solimp_limit)
-    sol_set("fsol", raw.solref_friction, full_solimp(raw.solimp_friction))
     f["gravity"][:] = raw.gravity
     f["nu"][0], f["task"][0], f["ctrl_cost"][0], f["obs_skip"][0] = nu, raw.task, raw.ctrl_cost, raw.obs_skip
     f["density"][0], f["viscosity"][0] = raw.density, raw.viscosity
