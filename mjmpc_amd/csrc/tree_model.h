@@ -39,8 +39,10 @@ enum TreeOffset : int {
     T_KPG = T_FROT + 9 * TL,            // actuator bias on the length, at the joint: -gear^2 biasprm[1] (position servo: gear^2 kp)
     T_KVG = T_KPG + TL,                 // ... on the velocity: -gear^2 biasprm[2] (<velocity kv>: gear^2 kv); explicit, not part of M + hB
     T_TAU0 = T_KVG + TL,                // ... constant: gear biasprm[0]
+    T_TAU_LO = T_TAU0 + TL,             // forcerange of the dof's actuator at the joint: gear * forcerange, lower / upper (+-inf: none)
+    T_TAU_HI = T_TAU_LO + TL,
     // scalars
-    T_NV = T_TAU0 + TL,
+    T_NV = T_TAU_HI + TL,
     T_TIMESTEP,
     T_FRAME_SKIP,
     T_JUMPS,                            // pointer-jumping rounds = ceil(log2(tree depth))
@@ -113,6 +115,6 @@ constexpr int TREE_QW = 2 * TL + 6;
 constexpr int TREE_NQ_MAX = 40;
 // the C ABI's state vectors (mjmpc_tree_set_shard_states): MuJoCo's layout - qpos[40] | qvel[32] | target[3] | reserved[3]
 constexpr int TREE_PUBLIC_STATE_LEN = TREE_NQ_MAX + TL + 6;
-static_assert(TREE_BLOB_LEN == 3769, "keep in sync with mjmpc_amd/models/compile_tree.py::TREE_LAYOUT");
+static_assert(TREE_BLOB_LEN == 3833, "keep in sync with mjmpc_amd/models/compile_tree.py::TREE_LAYOUT");
 
 }  // namespace mjmpc

@@ -1821,8 +1821,9 @@ __global__ __launch_bounds__(64 * wg_waves(DP, FRIC, sizeof(T), PL), min_waves(s
             }
             // (position servos: the bias -kp * (gear q) of MJCF <position>, a stiffness gear^2 kp about 0 at the joint)
             // (... and the rest of an affine actuator bias: -gear^2 b2 v, gear b0 - explicit terms, mj_fwdActuation)
-            const T tau = dof ? -bias - damping * v - (FRIC ? M[T_STIFFNESS + l] * (q - M[T_SPRINGREF + l]) + M[T_KPG + l] * q +
-                                                               M[T_KVG + l] * v - M[T_TAU0 + l] : T(0)) + tau_act : T(0);
+            // ... the actuator's joint torque clamped to its forcerange (+-inf without one) before it joins the passive forces)
+            const T tau_a = FRIC ? fmin(fmax(tau_act - M[T_KPG + l] * q - M[T_KVG + l] * v + M[T_TAU0 + l], M[T_TAU_LO + l]), M[T_TAU_HI + l]) : tau_act;
+            const T tau = dof ? -bias - damping * v - (FRIC ? M[T_STIFFNESS + l] * (q - M[T_SPRINGREF + l]) : T(0)) + tau_a : T(0);
 
             // ---- 5. constraint rows: joint limits (mj_instantiateLimit, strict dist < 0) ...
             clk.mark(2);

@@ -208,7 +208,7 @@ def compile_arm(raw: RawModel, overrides=None, base: "ArmModel" = None) -> ArmMo
         raise ValueError("arm kernel expects one motor per hinge")
     ctrl_lo, ctrl_hi = np.zeros(nv), np.zeros(nv)
     for a, act in enumerate(raw.actuators):
-        if act.tendon or act.gain != 1.0 or any(x != 0.0 for x in act.bias) or not act.ctrllimited:
+        if act.tendon or act.gain != 1.0 or any(x != 0.0 for x in act.bias) or not act.ctrllimited or act.forcerange is not None:
             raise ValueError("arm kernel: ctrllimited motors only (servos and general actuators run on the tree engine)")
         if raw.dof_of_joint(act.joint) != a:
             raise ValueError("motors must be listed in joint order")

@@ -49,6 +49,7 @@ TREE_LAYOUT = [
     ("kpg", TL),                    # actuator bias on the length, as a joint stiffness about 0: -gear^2 biasprm[1] (servo: gear^2 kp)
     ("kvg", TL),                    # ... on the velocity: -gear^2 biasprm[2]  (explicit: MuJoCo's Euler is implicit in joint damping only)
     ("tau0", TL),                   # ... constant: gear biasprm[0]
+    ("tau_lo", TL), ("tau_hi", TL), # the actuator's forcerange at the joint (gear * forcerange, ordered); +-inf: none
     ("nv", 1), ("timestep", 1), ("frame_skip", 1), ("jumps", 1), ("site_link", 1), ("site_pos", 3),
     ("n_sphere", 1), ("plane_n", 3), ("plane_d", 1),
     ("gravity", 3),
@@ -442,6 +443,7 @@ def compile_tree(raw: RawModel, overrides=None, base: "TreeModel" = None) -> Tre
         raise ValueError("tree kernel expects between one motor and one per joint")
     ctrl_lo, ctrl_hi = np.zeros(nu), np.zeros(nu)
     f["act"][:] = -1.0
+    f["tau_lo"][:], f["tau_hi"][:] = -np.inf, np.inf
     for a, act in enumerate(raw.actuators):         # action a drives the dof of its joint (any subset, any order)
         if act.tendon:
             raise NotImplementedError("actuators on tendons are not compiled for the kernel")
@@ -460,6 +462,9 @@ def compile_tree(raw: RawModel, overrides=None, base: "TreeModel" = None) -> Tre
         f["kvg"][d] = -act.gear * act.gear * b2
         f["tau0"][d] = act.gear * b0
         f["ctrl_lo"][d], f["ctrl_hi"][d] = act.ctrlrange if act.ctrllimited else (-np.inf, np.inf)
+        if act.forcerange is not None:
+            ends = sorted((act.gear * act.forcerange[0], act.gear * act.forcerange[1]))
+            f["tau_lo"][d], f["tau_hi"][d] = ends
         ctrl_lo[a], ctrl_hi[a] = act.ctrlrange
 
     # ---- constants at qpos0 (MuJoCo mj_setConst): M0, dof / body invweight0 ------------------------------
@@ -779,7 +784,7 @@ def compile_tree(raw: RawModel, overrides=None, base: "TreeModel" = None) -> Tre
     f["nq"][0] = nq
     f["has_ball"][0] = 1.0 if any(k == LINK_BALL_X for k in link_kind) else 0.0
     f["any_friction"][0] = 1.0 if (any(f["spheres"][k * SPH_STRIDE + 7] > 0 for k in range(nsp)) or pair_geoms
-                                   or any(f["kpg"] != 0) or any(f["kvg"] != 0) or any(f["tau0"] != 0) or raw.task == TASK_ORIENT or gen) else 0.0
+                                   or any(f["kpg"] != 0) or any(f["kvg"] != 0) or any(f["tau0"] != 0) or bool(np.any(np.isfinite(f["tau_lo"]))) or bool(np.any(np.isfinite(f["tau_hi"]))) or raw.task == TASK_ORIENT or gen) else 0.0
 
     f["gravity"][:] = raw.gravity
     f["nu"][0], f["task"][0], f["ctrl_cost"][0], f["obs_skip"][0] = nu, raw.task, raw.ctrl_cost, raw.obs_skip

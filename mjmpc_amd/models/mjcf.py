@@ -20,7 +20,7 @@ panda/tray_glass-v0.yml, sawyer/door-v0.yml, hand/*-v0.yml):
 * one world ``<geom type="plane">`` in any orientation, static sphere / capsule / box geoms on the world body (they
   collide with moving geoms through MuJoCo's contype / conaffinity rule or an explicit ``<pair>``), world and body
   ``<site>``s, ``<motor>`` / ``<position kp>`` / ``<velocity kv>`` / ``<general gainprm biasprm biastype=affine>`` actuators
-  (``joint gear ctrlrange ctrllimited``; no activation dynamics, no force limits),
+  (``joint gear ctrlrange ctrllimited forcerange forcelimited``; no activation dynamics),
   ``<contact><pair geom1 geom2>``; geom pairs: sphere / capsule against sphere / capsule, sphere against box;
 * ``<equality><connect body1 body2 anchor>``, ``<weld body1 body2>`` and ``<joint joint1 joint2 polycoef>`` (``solref`` /
   ``solimp`` each),
@@ -529,8 +529,7 @@ def load_mjcf(path, hand_site="finger", target_site="target", frame_skip=2, task
             if m.tag == "general" and ma(k, "none" if k != "gaintype" else "fixed") not in (
                     ("none",) if k == "dyntype" else (("fixed",) if k == "gaintype" else ("none", "affine"))):
                 raise ValueError("general actuators: dyntype none, gaintype fixed, biastype none / affine")
-        if ma("forcelimited", "false") == "true":
-            raise ValueError("actuator forcerange is not supported")
+        forcerange = tuple(_floats(ma("forcerange"), 2)) if ma("forcelimited", "false") == "true" else None
         limited = ma("ctrllimited", "false") == "true"
         if ma("ctrlrange") is None:
             raise ValueError("an actuator needs a ctrlrange (it bounds the action space; ctrllimited says whether the physics clamp)")
@@ -548,7 +547,7 @@ def load_mjcf(path, hand_site="finger", target_site="target", frame_skip=2, task
         if m.get("joint") is None and m.get("tendon") is None:
             raise ValueError("an actuator acts on a joint or on a fixed tendon")
         acts.append(RawActuator(m.get("joint") or "", gear, _floats(ma("ctrlrange"), 2), kp=kp, tendon=m.get("tendon") or "",
-                                gainprm=gainprm, biasprm=biasprm, ctrllimited=limited))
+                                gainprm=gainprm, biasprm=biasprm, ctrllimited=limited, forcerange=forcerange))
 
     # equality constraints
     equalities = []

@@ -48,7 +48,7 @@ TASK_ORIENT = 2             # in-hand reorientation, the shape of pen-v0's rewar
                             # carried by the site's body), d* = target_dir; obs as TASK_REACH
 BODY_STRIDE = 56
 GEOM_STRIDE = 33
-ACT_STRIDE = 11
+ACT_STRIDE = 14
 PAIR_STRIDE = 2
 EQ_STRIDE = 28
 TENDON_MAX_JOINTS = 4
@@ -189,6 +189,7 @@ class RawActuator:
     gainprm: Optional[float] = None
     biasprm: Optional[Sequence[float]] = None
     ctrllimited: bool = True                # False: the control is not clamped (ctrlrange still bounds the action space)
+    forcerange: Optional[Sequence[float]] = None    # MJCF forcelimited / forcerange: the scalar force is clamped to it
 
     @property
     def gain(self):
@@ -393,6 +394,8 @@ class RawModel:
             r[6] = a.gain
             r[7:10] = a.bias
             r[10] = 1.0 if a.ctrllimited else 0.0
+            if a.forcerange is not None:
+                r[11], r[12:14] = 1.0, a.forcerange
             out.append(r)
         names = [g.name for _, g in geoms]
         for ga, gb in self.pairs:

@@ -49,7 +49,7 @@
 #define HEADER_LEN 80
 #define BODY_STRIDE 56
 #define GEOM_STRIDE 33
-#define ACT_STRIDE 11
+#define ACT_STRIDE 14
 #define PAIR_STRIDE 2
 #define EQ_STRIDE 28
 #define TENDON_STRIDE (8 + 2 * MAXTJ + 7)
@@ -93,7 +93,8 @@ typedef struct {
      * bias[1] length + bias[2] velocity, length = gear q; a motor is gain 1, <position kp> gain kp / bias (0, -kp, 0),
      * <velocity kv> gain kv / bias (0, 0, -kv) */
     double act_gain[MAXV], act_bias[MAXV][3];
-    int ctrllimited[MAXV];
+    int ctrllimited[MAXV], forcelimited[MAXV];
+    double forcerange[MAXV][2];              /* mj_fwdActuation clamps the scalar force when forcelimited */
     /* site + target */
     int site_body;
     double site_pos[3], target_default[3];
@@ -687,6 +688,9 @@ OrModel *or_model_compile(const double *f, int n) {
         m->act_gain[a] = a0[a * ACT_STRIDE + 6];
         for (int i = 0; i < 3; i++) m->act_bias[a][i] = a0[a * ACT_STRIDE + 7 + i];
         m->ctrllimited[a] = a0[a * ACT_STRIDE + 10] != 0.0;
+        m->forcelimited[a] = a0[a * ACT_STRIDE + 11] != 0.0;
+        m->forcerange[a][0] = a0[a * ACT_STRIDE + 12];
+        m->forcerange[a][1] = a0[a * ACT_STRIDE + 13];
     }
     /* geom-geom pairs: spheres and capsules are segments (from, to - from) with a radius; ONE geom of a pair may be a box
      * (against a sphere); friction / condim / margin of a contact = the larger of the two geoms' (MuJoCo mj_contactParam
@@ -1251,6 +1255,7 @@ void or_step(OrModel *m, double *q, double *v, const double *ctrl, double *site_
                 vel += m->tn_coef[t][i] * v[m->tn_dof[t][i]];
             }
             double frc = m->act_gain[a] * u + b[0] + b[1] * m->gear[a] * len + b[2] * m->gear[a] * vel;
+            if (m->forcelimited[a]) frc = frc < m->forcerange[a][0] ? m->forcerange[a][0] : (frc > m->forcerange[a][1] ? m->forcerange[a][1] : frc);
             for (int i = 0; i < m->tn_n[t]; i++) fs[m->tn_dof[t][i]] += m->gear[a] * m->tn_coef[t][i] * frc;
             continue;
         }
@@ -1258,6 +1263,7 @@ void or_step(OrModel *m, double *q, double *v, const double *ctrl, double *site_
         int d = m->act_dof[a];
         double len = (b[1] != 0.0) ? m->gear[a] * q[m->dof_qadr[d]] : 0.0;
         double frc = m->act_gain[a] * u + b[0] + b[1] * len + b[2] * m->gear[a] * v[d];
+        if (m->forcelimited[a]) frc = frc < m->forcerange[a][0] ? m->forcerange[a][0] : (frc > m->forcerange[a][1] ? m->forcerange[a][1] : frc);
         fs[d] += m->gear[a] * frc;
     }
     /* constraint rows, in MuJoCo's order: equality, friction loss, limits, contacts */

@@ -474,6 +474,18 @@ def test_velocity_and_general_actuators(tmp_path):
     assert tm.field("gear")[0] == 6.0 and tm.field("tau0")[0] == 3 * 0.6 and np.isinf(tm.field("ctrl_lo")[0]) and tm.ctrl_lo[0] == -1.0
     tv = compile_tree(raw)
     assert tv.field("kvg")[0] == 4 * 5.0 and tv.field("kpg")[0] == 0.0 and tv.field("gear")[0] == 10.0
+    # forcerange: a position servo far from its target pushes with the bound - a motor held at that force
+    sat = ('<actuator><position joint="j1" kp="200" gear="2" ctrlrange="-3 3" ctrllimited="true" forcelimited="true" forcerange="-1.5 0.7"/>'
+           '<motor joint="j2" ctrlrange="-1 1" ctrllimited="true"/></actuator>')
+    mot2 = '<actuator><motor joint="j1" gear="2" ctrlrange="-3 3" ctrllimited="true"/><motor joint="j2" ctrlrange="-1 1" ctrllimited="true"/></actuator>'
+    rs_raw, rsat = _model(tmp_path, ARM2, extra=sat, name="sat.xml")
+    _, rmo = _model(tmp_path, ARM2, extra=mot2, name="mot2.xml")
+    assert tuple(rs_raw.actuators[0].forcerange) == (-1.5, 0.7)
+    qa, va, _ = _run(rsat, rs_raw.qpos0.copy(), np.zeros(2), np.array([3.0, 0.0]), 30)         # 200 * (3 - 2 q) >> 0.7: saturated
+    qb, vb, _ = _run(rmo, rs_raw.qpos0.copy(), np.zeros(2), np.array([0.7, 0.0]), 30)
+    np.testing.assert_allclose(np.r_[qa, va], np.r_[qb, vb], rtol=0, atol=1e-12)
+    ts = compile_tree(rs_raw)
+    assert ts.field("tau_lo")[0] == -3.0 and ts.field("tau_hi")[0] == 1.4 and np.isinf(ts.field("tau_hi")[1])
     with pytest.raises(ValueError, match="dyntype"):
         _model(tmp_path, ARM2, extra='<actuator><general joint="j1" dyntype="integrator" ctrlrange="-1 1"/><motor joint="j2" ctrlrange="-1 1"/></actuator>', name="dyn.xml")
 

@@ -261,8 +261,8 @@ def test_weld_equality_matches_oracle(tmp_path):
 
 
 def test_velocity_and_general_actuators_match_oracle(tmp_path):
-    """<velocity kv>, <general gainprm biasprm biastype="affine"> with all three bias terms, and an unclamped control
-    (ctrllimited="false") on a two-link arm under gravity: the kernel carries the bias as a stiffness, a velocity term
+    """<velocity kv>, <general gainprm biasprm biastype="affine"> with all three bias terms, an unclamped control
+    (ctrllimited="false") and a force limit (forcerange, reached by a third of the random states) on a two-link arm under gravity: the kernel carries the bias as a stiffness, a velocity term
     and a constant torque at the joint (T_KPG / T_KVG / T_TAU0).  One env step from 32 random states at 1e-9, a 64 x 12
     rollout at 1e-9."""
     from mjmpc_amd.envs.tree_engine import TreeRolloutEngine
@@ -271,7 +271,8 @@ def test_velocity_and_general_actuators_match_oracle(tmp_path):
     cpu = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(cpu)
     acts = ('<actuator><velocity joint="j1" kv="4" gear="2" ctrlrange="-3 3" ctrllimited="true"/>'
-            '<general joint="j2" gainprm="6" biastype="affine" biasprm="0.3 -5 -0.2" gear="1.5" ctrlrange="-1 1" ctrllimited="false"/></actuator>')
+            '<general joint="j2" gainprm="6" biastype="affine" biasprm="0.3 -5 -0.2" gear="1.5" ctrlrange="-1 1" ctrllimited="false" '
+            'forcelimited="true" forcerange="-4 6"/></actuator>')
     raw, ref = cpu._model(tmp_path, cpu.ARM2, extra=acts, timestep="0.004", frame_skip=2)
     eng = TreeRolloutEngine(raw, dtype="f64")
     assert eng.model.field("kvg")[0] == 16.0 and eng.model.field("tau0")[1] == 1.5 * 0.3 and not eng.model.general
