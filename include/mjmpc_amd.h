@@ -176,7 +176,8 @@ int mjmpc_arm_step_state(mjmpc_arm_t h, int dtype, const double* d_action, void*
  * fields are [component][32 lanes], links numbered depth-first:
  *   off[3][32] axis[3][32] mass[32] com[3][32] inertia[6][32] armature damping range_lo range_hi limited gear ctrl_lo
  *   ctrl_hi dof_invweight0 stiffness springref (each [32]) fbox[3][32] frot[9][32] kpg[32] kvg[32] tau0[32] (affine actuator bias at the joint: -gear^2 b1, -gear^2 b2, gear b0; servos: kpg = gear^2 kp)
- *   tau_lo[32] tau_hi[32] (the actuator's forcerange at the joint, +-inf without one)
+ *   tau_lo[32] tau_hi[32] (the actuator's forcerange at the joint, +-inf without one) tcoef[32] tpartner[32] tpcoef[32]
+ *   (actuators on fixed tendons: the dof's coefficient, the tendon's other dof and its coefficient)
  *   nv timestep frame_skip jumps site_link site_pos[3] n_sphere plane_n[3] plane_d
  *   gravity[3] nu task ctrl_cost obs_skip density viscosity any_friction site_axis[3] target_dir[3]
  *   soltab[8][7] (the model's distinct solver-parameter sets {K, B, dmin, dmax, width, mid, power} - MuJoCo's solref /
@@ -190,7 +191,7 @@ int mjmpc_arm_step_state(mjmpc_arm_t h, int dtype, const double* d_action, void*
  *   k | distance << 8 | height << 16, -1 ends)
  * Same call shapes and reference counterparts as the arm engine (subproc_vec_env.py:91-111, 128-186, 235-251);
  * target_pos is ignored by task 1.                                                                                  */
-#define MJMPC_TREE_BLOB_LEN 3833
+#define MJMPC_TREE_BLOB_LEN 3929
 /* Round 4, the GENERAL instantiation (block field `gen`; models without these features run the earlier kernels unchanged):
  * ball and free joints (quaternion links: qpos has nq >= nv entries in MuJoCo's layout, d_obs = nq + nv + 6 or nq + nv -
  * obs_skip), joint anchors off the body origin, explicit inertials, box geoms (eight corner points against the plane, one

@@ -41,8 +41,14 @@ enum TreeOffset : int {
     T_TAU0 = T_KVG + TL,                // ... constant: gear biasprm[0]
     T_TAU_LO = T_TAU0 + TL,             // forcerange of the dof's actuator at the joint: gear * forcerange, lower / upper (+-inf: none)
     T_TAU_HI = T_TAU_LO + TL,
+    // actuators on fixed tendons (over one or two joints): the dof's coefficient in the tendon (1: a joint actuator), the
+    // other dof of the tendon (-1: none) and its coefficient; length = tcoef q + tpcoef q_partner, torque = tcoef * (the
+    // tendon's clamped force through the gear); T_GEAR / T_KPG / T_KVG / T_TAU0 / T_TAU_LO / _HI then act on the tendon
+    T_TCOEF = T_TAU_HI + TL,
+    T_TPARTNER = T_TCOEF + TL,
+    T_TPCOEF = T_TPARTNER + TL,
     // scalars
-    T_NV = T_TAU_HI + TL,
+    T_NV = T_TPCOEF + TL,
     T_TIMESTEP,
     T_FRAME_SKIP,
     T_JUMPS,                            // pointer-jumping rounds = ceil(log2(tree depth))
@@ -115,6 +121,6 @@ constexpr int TREE_QW = 2 * TL + 6;
 constexpr int TREE_NQ_MAX = 40;
 // the C ABI's state vectors (mjmpc_tree_set_shard_states): MuJoCo's layout - qpos[40] | qvel[32] | target[3] | reserved[3]
 constexpr int TREE_PUBLIC_STATE_LEN = TREE_NQ_MAX + TL + 6;
-static_assert(TREE_BLOB_LEN == 3833, "keep in sync with mjmpc_amd/models/compile_tree.py::TREE_LAYOUT");
+static_assert(TREE_BLOB_LEN == 3929, "keep in sync with mjmpc_amd/models/compile_tree.py::TREE_LAYOUT");
 
 }  // namespace mjmpc

@@ -1166,6 +1166,7 @@ __global__ __launch_bounds__(64 * wg_waves(DP, FRIC, sizeof(T), PL), min_waves(s
     const int dobs = task == 1 ? nq + nv - obs_skip : nq + nv + 6;
     const bool slide = FRIC && (int)model[T_JTYPE + l] == 2;      // (slide joints, springs, a medium: the full instantiation only)
     const int act_id = (int)model[T_ACT + l];
+    const bool any_tendon_act = FRIC && __any((int)model[T_TPARTNER + l] >= 0 || model[T_TCOEF + l] != T(1));
     const bool fluid = FRIC && (M[T_DENSITY] > T(0) || M[T_VISCOSITY] > T(0));   // (the full instantiation only)
 
     // my place on the path of every contact point (5 bits each: 1 + the distance from the point's link up to me, 0 if I
@@ -1822,7 +1823,17 @@ __global__ __launch_bounds__(64 * wg_waves(DP, FRIC, sizeof(T), PL), min_waves(s
             // (position servos: the bias -kp * (gear q) of MJCF <position>, a stiffness gear^2 kp about 0 at the joint)
             // (... and the rest of an affine actuator bias: -gear^2 b2 v, gear b0 - explicit terms, mj_fwdActuation)
             // ... the actuator's joint torque clamped to its forcerange (+-inf without one) before it joins the passive forces)
-            const T tau_a = FRIC ? fmin(fmax(tau_act - M[T_KPG + l] * q - M[T_KVG + l] * v + M[T_TAU0 + l], M[T_TAU_LO + l]), M[T_TAU_HI + l]) : tau_act;
+            // (an actuator on a fixed tendon: length and velocity are the tendon's, over my dof and the tendon's other one, and my
+            // share of its force is my coefficient's)
+            T alen = q, avel = v, acoef = T(1);
+            if (FRIC && any_tendon_act) {
+                const int tp = (int)M[T_TPARTNER + l];
+                const T pq = __shfl(q, tp >= 0 ? tp : 0, PL), pv = __shfl(v, tp >= 0 ? tp : 0, PL);
+                acoef = M[T_TCOEF + l];
+                alen = acoef * q + (tp >= 0 ? M[T_TPCOEF + l] * pq : T(0));
+                avel = acoef * v + (tp >= 0 ? M[T_TPCOEF + l] * pv : T(0));
+            }
+            const T tau_a = FRIC ? acoef * fmin(fmax(tau_act - M[T_KPG + l] * alen - M[T_KVG + l] * avel + M[T_TAU0 + l], M[T_TAU_LO + l]), M[T_TAU_HI + l]) : tau_act;
             const T tau = dof ? -bias - damping * v - (FRIC ? M[T_STIFFNESS + l] * (q - M[T_SPRINGREF + l]) : T(0)) + tau_a : T(0);
 
             // ---- 5. constraint rows: joint limits (mj_instantiateLimit, strict dist < 0) ...

@@ -50,6 +50,7 @@ TREE_LAYOUT = [
     ("kvg", TL),                    # ... on the velocity: -gear^2 biasprm[2]  (explicit: MuJoCo's Euler is implicit in joint damping only)
     ("tau0", TL),                   # ... constant: gear biasprm[0]
     ("tau_lo", TL), ("tau_hi", TL), # the actuator's forcerange at the joint (gear * forcerange, ordered); +-inf: none
+    ("tcoef", TL), ("tpartner", TL), ("tpcoef", TL),   # actuators on fixed tendons over one or two joints (tcoef 1, tpartner -1: a joint actuator)
     ("nv", 1), ("timestep", 1), ("frame_skip", 1), ("jumps", 1), ("site_link", 1), ("site_pos", 3),
     ("n_sphere", 1), ("plane_n", 3), ("plane_d", 1),
     ("gravity", 3),
@@ -444,15 +445,26 @@ def compile_tree(raw: RawModel, overrides=None, base: "TreeModel" = None) -> Tre
     ctrl_lo, ctrl_hi = np.zeros(nu), np.zeros(nu)
     f["act"][:] = -1.0
     f["tau_lo"][:], f["tau_hi"][:] = -np.inf, np.inf
+    f["tcoef"][:], f["tpartner"][:] = 1.0, -1.0
     for a, act in enumerate(raw.actuators):         # action a drives the dof of its joint (any subset, any order)
         if act.tendon:
-            raise NotImplementedError("actuators on tendons are not compiled for the kernel")
-        d = raw.dof_of_joint(act.joint)
-        if link_kind[d] not in (LINK_HINGE, LINK_SLIDE) or raw.bodies[link_body[d]].joint.type not in (JOINT_HINGE, JOINT_SLIDE):
-            raise NotImplementedError("actuators drive hinge / slide joints")
-        if f["act"][d] >= 0:
-            raise ValueError("two motors on joint %r" % act.joint)
-        f["act"][d] = a
+            # the tendon's one or two dofs share the action; each carries its coefficient and the other's
+            tn = [t for t in raw.tendons if t.name == act.tendon]
+            if len(tn) != 1 or not 1 <= len(tn[0].joints) <= 2:
+                raise NotImplementedError("actuators on fixed tendons over one or two joints are compiled for the kernel")
+            tdofs = [(raw.dof_of_joint(jn), float(c)) for jn, c in tn[0].joints]
+        else:
+            tdofs = [(raw.dof_of_joint(act.joint), 1.0)]
+        for k, (d, c) in enumerate(tdofs):
+            if link_kind[d] not in (LINK_HINGE, LINK_SLIDE) or raw.bodies[link_body[d]].joint.type not in (JOINT_HINGE, JOINT_SLIDE):
+                raise NotImplementedError("actuators drive hinge / slide joints")
+            if f["act"][d] >= 0:
+                raise ValueError("two actuators on the joint of dof %d" % d)
+            f["act"][d] = a
+            f["tcoef"][d] = c
+            if len(tdofs) == 2:
+                f["tpartner"][d], f["tpcoef"][d] = tdofs[1 - k]
+        d = tdofs[0][0]
         # joint torque = gear * (gain * clip(ctrl) + b0 + b1 * gear q + b2 * gear v)  (mj_fwdActuation, gaintype fixed,
         # biastype affine; motor: gain 1; <position kp>: gain kp, b1 = -kp; <velocity kv>: gain kv, b2 = -kv): the ctrl part
         # through an effective gear, the rest as a stiffness about 0, a damping-like term and a constant at the joint
@@ -465,6 +477,9 @@ def compile_tree(raw: RawModel, overrides=None, base: "TreeModel" = None) -> Tre
         if act.forcerange is not None:
             ends = sorted((act.gear * act.forcerange[0], act.gear * act.forcerange[1]))
             f["tau_lo"][d], f["tau_hi"][d] = ends
+        for d2, _ in tdofs[1:]:
+            for name in ("gear", "kpg", "kvg", "tau0", "ctrl_lo", "ctrl_hi", "tau_lo", "tau_hi"):
+                f[name][d2] = f[name][d]
         ctrl_lo[a], ctrl_hi[a] = act.ctrlrange
 
     # ---- constants at qpos0 (MuJoCo mj_setConst): M0, dof / body invweight0 ------------------------------
@@ -784,7 +799,7 @@ def compile_tree(raw: RawModel, overrides=None, base: "TreeModel" = None) -> Tre
     f["nq"][0] = nq
     f["has_ball"][0] = 1.0 if any(k == LINK_BALL_X for k in link_kind) else 0.0
     f["any_friction"][0] = 1.0 if (any(f["spheres"][k * SPH_STRIDE + 7] > 0 for k in range(nsp)) or pair_geoms
-                                   or any(f["kpg"] != 0) or any(f["kvg"] != 0) or any(f["tau0"] != 0) or bool(np.any(np.isfinite(f["tau_lo"]))) or bool(np.any(np.isfinite(f["tau_hi"]))) or raw.task == TASK_ORIENT or gen) else 0.0
+                                   or any(f["kpg"] != 0) or any(f["kvg"] != 0) or any(f["tau0"] != 0) or bool(np.any(np.isfinite(f["tau_lo"]))) or bool(np.any(f["tpartner"] >= 0)) or bool(np.any(f["tcoef"] != 1.0)) or bool(np.any(np.isfinite(f["tau_hi"]))) or raw.task == TASK_ORIENT or gen) else 0.0
 
     f["gravity"][:] = raw.gravity
     f["nu"][0], f["task"][0], f["ctrl_cost"][0], f["obs_skip"][0] = nu, raw.task, raw.ctrl_cost, raw.obs_skip

@@ -359,3 +359,46 @@ def test_closed_loop_linear_mode_on_general_models(rig):
     np.testing.assert_allclose(rew, o_rew, rtol=1e-8, atol=1e-8)
     np.testing.assert_allclose(nobs, o_nobs, rtol=0, atol=1e-7)
     assert np.abs(act - noise).max() > 1e-2
+
+
+def test_actuators_on_fixed_tendons_match_oracle(tmp_path):
+    """A position servo and a force-limited general actuator, each pulling on a fixed tendon (over two joints / over one):
+    tendon length and velocity across the two lanes, each dof takes its coefficient's share of the tendon force.  One env step
+    from 32 random states at 1e-9, a 64 x 12 rollout at 1e-9."""
+    from mjmpc_amd.envs.tree_engine import TreeRolloutEngine
+    import importlib.util, os
+    spec = importlib.util.spec_from_file_location("general_models_cpu", os.path.join(os.path.dirname(os.path.abspath(__file__)), "test_general_models_cpu.py"))
+    cpu = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(cpu)
+    body = cpu.ARM2.replace('<site name="finger" pos="0.2 0 0"/></body></body>',
+                            '<site name="finger" pos="0.2 0 0"/><body name="c" pos="0.2 0 0"><joint name="j3" type="hinge" axis="0 0 1" damping="0.05"/>'
+                            '<geom type="capsule" fromto="0 0 0 0.1 0 0" size="0.015"/></body></body></body>')
+    extra = ('<tendon><fixed name="t12"><joint joint="j1" coef="1.0"/><joint joint="j2" coef="-0.5"/></fixed>'
+             '<fixed name="t3" limited="true" range="-0.8 0.8"><joint joint="j3" coef="2.0"/></fixed></tendon>'
+             '<actuator><position tendon="t12" kp="15" gear="1.5" ctrlrange="-1 1" ctrllimited="true"/>'
+             '<general tendon="t3" gainprm="3" biastype="affine" biasprm="0.1 -2 -0.1" gear="0.5" ctrlrange="-2 2" ctrllimited="true" '
+             'forcelimited="true" forcerange="-1.5 1.5"/></actuator>')
+    raw, ref = cpu._model(tmp_path, body, extra=extra, timestep="0.004", frame_skip=2)
+    eng = TreeRolloutEngine(raw, dtype="f64")
+    m = eng.model
+    assert list(m.field("act")[:3]) == [0, 0, 1] and list(m.field("tpartner")[:3]) == [1, 0, -1] and m.field("tcoef")[2] == 2.0
+    rs = np.random.RandomState(13)
+    tgt = np.asarray(raw.target_pos, float)
+    worst = 0.0
+    for _ in range(32):
+        q, v, u = rs.uniform(-1.5, 1.5, 3), 3 * rs.standard_normal(3), rs.uniform(-2.5, 2.5, 2)
+        q[2] = rs.uniform(-0.5, 0.5)                    # (the limited tendon: 2 q3 in [-0.8, 0.8], crossed now and then)
+        eng.set_env_state(dict(qp=q, qv=v, target_pos=tgt))
+        _, rew, _, _, _, nobs = eng.rollout(1, 1, u[None], None, "open_loop")
+        q1, v1, r1, o1 = ref.env_step(q, v, u, tgt)
+        worst = max(worst, np.abs(nobs[0, 0] - o1).max() / max(1.0, np.abs(o1).max()), abs(rew[0, 0] - r1) / max(1.0, abs(r1)))
+    print("tendon actuators: one env step from 32 random states, worst relative error %.2e" % worst)
+    assert worst < 1e-9, worst
+    P, H = 64, 12
+    q, v = np.array([0.3, -0.5, 0.1]), np.zeros(3)
+    eps = 1.0 * rs.standard_normal((P, H, 2))
+    eng.set_env_state(dict(qp=q, qv=v, target_pos=tgt))
+    obs, rew, act, done, info, nobs = eng.rollout(P, H, np.zeros((H, 2)), eps, "open_loop")
+    o_obs, o_rew, _, _, o_nobs = ref.rollout(q, v, tgt, np.zeros((H, 2)), eps)
+    np.testing.assert_allclose(rew, o_rew, rtol=1e-9, atol=1e-9)
+    np.testing.assert_allclose(nobs, o_nobs, rtol=0, atol=1e-9)
