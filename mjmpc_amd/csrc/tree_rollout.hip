@@ -33,6 +33,9 @@
 // between two trees is kept inside that pattern by an ELIMINATION tree that hangs the manipulator under the object
 // (compile_tree.py).  The soft-constraint problem is the arm kernel's primal active-set Newton iteration with several
 // contact rows; in the friction instantiation an exact line search takes over when it does not settle (MuJoCo's Newton).
+// Round 4: the GENERAL instantiation (GEN: ball / free joints as quaternion links, friction-loss rows, boxes, static geoms,
+// equalities, tendon limits, solver parameters per row, affine actuators) and a DENSE factorisation over the 32 lanes of
+// a particle (DN = 32: models of 17 .. 32 dofs whose elimination paths are longer than 8 links) - see dense32_factor.
 #include <hip/hip_runtime.h>
 #include <cstdlib>
 
