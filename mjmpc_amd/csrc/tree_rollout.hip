@@ -1396,6 +1396,15 @@ __global__ __launch_bounds__(64 * wg_waves(DP, FRIC, sizeof(T), PL), min_waves(s
                 for (int c = 0; c < 3; ++c) X[(9 + c) * PL + l] = p[c];
                 if constexpr (GEN) VEC[l] = q;          // (dof rows read their joints' coordinates)
                 TSYNC();
+                // (a ball-joint limit's record reads its joint's quaternion from the link that holds it)
+                T bq[3] = {T(0), T(0), T(0)};
+                if (GEN && has_ball) {
+                    const bool blim = l < n_sphere && M[T_SPH + l * TREE_SPH_STRIDE + 12] == T(PT_DOFROW) && PEXT[l * TREE_PEXT_STRIDE] == T(2);
+                    const int src = blim ? (int)PEXT[l * TREE_PEXT_STRIDE + 1] : l;
+                    bq[0] = __shfl(qy, src, PL);
+                    bq[1] = __shfl(qz, src, PL);
+                    bq[2] = __shfl(qw, src, PL);
+                }
                 if (l < n_sphere) {
                     const T* sp = M + T_SPH + l * TREE_SPH_STRIDE;
                     const int sl = (int)sp[0];
@@ -1436,7 +1445,22 @@ __global__ __launch_bounds__(64 * wg_waves(DP, FRIC, sizeof(T), PL), min_waves(s
                         const T* ex = PEXT + l * TREE_PEXT_STRIDE;
                         const int dB = (int)sp[13];
                         const T qA = VEC[sl], qB = dB >= 0 ? VEC[dB] : T(0);
-                        if (ex[0] == T(0)) {
+                        if (ex[0] == T(2)) {
+                            // ball-joint limit (mj_instantiateLimit, mjJNT_BALL): the joint quaternion as axis * angle
+                            // (mju_quat2Vel: angle = 2 atan2(|xyz|, w), wrapped to (-pi, pi]); dist = max(range) - |angle|,
+                            // J = -axis over the joint's three dofs: mine (the last link) in cs[0], the middle one's in
+                            // cs[1], the first's in cs[2]
+                            const T x = VEC[(int)ex[1]], y = bq[0], z = bq[1], w = bq[2];
+                            const T sn = sqrt_(x * x + y * y + z * z);
+                            T ang = T(2) * (T)atan2((double)sn, (double)w);
+                            if (ang > T(3.14159265358979323846)) ang -= T(2 * 3.14159265358979323846);
+                            const T k = (sn > T(1e-15)) ? (ang < T(0) ? T(1) : T(-1)) * rcp_(sn) : T(0);
+                            cs[3] = ex[4] - fabs(ang);
+                            cs[0] = k * z;
+                            cs[1] = k * y;
+                            cs[2] = k * x;
+                            ci_mine = sn > T(1e-15) && cs[3] < T(0);
+                        } else if (ex[0] == T(0)) {
                             const bool swapped = ex[1] != T(0);         // the anchor dof is joint 2, joint 1 rides above it
                             const T x = swapped ? qA : qB, q1 = swapped ? qB : qA;
                             const T poly = ex[6] + x * (ex[7] + x * (ex[8] + x * (ex[9] + x * ex[10])));
@@ -1891,7 +1915,8 @@ __global__ __launch_bounds__(64 * wg_waves(DP, FRIC, sizeof(T), PL), min_waves(s
                     const int kind = (int)sp[12];
                     if (kind == PT_DOFROW) {            // my joint coordinate's coefficient
                         genrow = true;
-                        jc = oi >= 0 ? (l == (int)sp[0] ? cs[0] : (l == (int)sp[13] ? cs[1] : T(0))) : T(0);
+                        const int lC = PEXT[s * TREE_PEXT_STRIDE] == T(2) ? (int)PEXT[s * TREE_PEXT_STRIDE + 1] : -1;      // (a ball limit's third dof)
+                        jc = oi >= 0 ? (l == (int)sp[0] ? cs[0] : (l == (int)sp[13] ? cs[1] : (l == lC ? cs[2] : T(0)))) : T(0);
                     } else if (kind == PT_CONNECT) {
                         // rows along the world axes: what my dof moves body A's anchor, less what it moves body B's
                         genrow = true;
@@ -1983,7 +2008,7 @@ __global__ __launch_bounds__(64 * wg_waves(DP, FRIC, sizeof(T), PL), min_waves(s
                     } else if (GEN && kind == PT_DOFROW) {
                         const T* ex = PEXT + l * TREE_PEXT_STRIDE;
                         if (ex[0] == T(0)) tree_row_params(ex + 12, cs[3], sp[6], jv, Dc, arc);              // joint equality
-                        else tree_row_params(M + T_SOLTAB + 7 * (int)sp[21], cs[3] - sp[5], sp[6], jv, Dc, arc);     // tendon limit
+                        else tree_row_params(M + T_SOLTAB + 7 * (int)sp[21], cs[3] - sp[5], sp[6], jv, Dc, arc);     // tendon / ball-joint limit
                         cs[4] = Dc;
                         cs[5] = arc;
                         cs[6] = T(0);

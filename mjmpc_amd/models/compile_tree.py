@@ -375,8 +375,8 @@ def compile_tree(raw: RawModel, overrides=None, base: "TreeModel" = None) -> Tre
         single = jt.type in (JOINT_HINGE, JOINT_SLIDE)
         if single:
             f["stiffness"][li], f["springref"][li] = jt.stiffness, jt.springref
-        elif jt.stiffness != 0 or jt.limited:
-            raise NotImplementedError("ball / free joints: no springs, no limits")
+        elif jt.stiffness != 0 or (jt.limited and jt.type != JOINT_BALL):
+            raise NotImplementedError("ball / free joints: no springs; limits on ball joints only")
         # MuJoCo's qpos: one entry per hinge / slide, (w, x, y, z) per ball, position + quaternion per free joint
         if link_first[li]:
             nq_here = nq_run
@@ -562,7 +562,7 @@ def compile_tree(raw: RawModel, overrides=None, base: "TreeModel" = None) -> Tre
     if raw.plane is None:
         points = []
     n_eq_pts = len(raw.equalities) + sum(1 for e in raw.equalities if e.type == EQ_WELD)     # (a weld takes two records)
-    n_tn_pts = sum(1 for t in raw.tendons if t.limited)
+    n_tn_pts = sum(1 for t in raw.tendons if t.limited) + sum(1 for b in raw.bodies if b.joint is not None and b.joint.type == JOINT_BALL and b.joint.limited)
     if len(points) + len(pair_geoms) + n_eq_pts + n_tn_pts > TREE_MAX_SPHERES:
         raise ValueError("tree kernel supports %d contact records (a capsule on the plane counts two, a box eight, a geom-geom "
                          "pair, an equality and a tendon limit one each)" % TREE_MAX_SPHERES)
@@ -790,6 +790,27 @@ def compile_tree(raw: RawModel, overrides=None, base: "TreeModel" = None) -> Tre
         ext[5] = t.margin
         rec[21] = sol_class(lim_default[0] if t.solref_limit is None else t.solref_limit,
                             lim_default[1] if t.solimp_limit is None else t.solimp_limit)
+        gen = True
+        s += 1
+    # ball-joint limits (mj_instantiateLimit, mjJNT_BALL): one row over the joint's three dofs, J = -axis of the joint
+    # quaternion's rotation; a dof-row record anchored at the joint's LAST link (its first two lie on its elimination path)
+    for b in raw.bodies:
+        jt = b.joint
+        if jt is None or jt.type != JOINT_BALL or not jt.limited:
+            continue
+        d0 = raw.dof_of_joint(jt.name)
+        rec = f["spheres"][s * SPH_STRIDE:(s + 1) * SPH_STRIDE]
+        ext = f["pext"][s * PEXT_STRIDE:(s + 1) * PEXT_STRIDE]
+        assert link_kind[d0] == LINK_BALL_X and e_is_ancestor(d0 + 1, d0 + 2) and e_is_ancestor(d0, d0 + 2)
+        rec[0], rec[13] = d0 + 2, d0 + 1
+        rec[6] = dof_iw[d0] if base is None else base.dof_invweight0[d0]
+        rec[11] = edepth[d0 + 2] - 1
+        rec[12] = PT_DOFROW
+        ext[0] = 2.0
+        ext[1] = d0                                         # the link that holds the quaternion
+        ext[3:5] = 0.0, max(jt.range)
+        rec[21] = sol_class(lim_default[0] if jt.solref_limit is None else jt.solref_limit,
+                            lim_default[1] if jt.solimp_limit is None else jt.solimp_limit)
         gen = True
         s += 1
     nsp = s

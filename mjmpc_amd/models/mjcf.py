@@ -9,7 +9,8 @@ panda/tray_glass-v0.yml, sawyer/door-v0.yml, hand/*-v0.yml):
 * ``<default>`` with nested classes, ``class=`` / ``childclass=`` (joint, geom and motor attributes);
 * nested ``<body pos quat|axisangle|euler>`` with any number of hinge / slide ``<joint>``s (anchor ``pos`` anywhere in
   the body) - a body with several joints becomes a chain of massless bodies, one joint each, which is what MuJoCo's
-  kinematics does with it - or ONE ball joint, or a ``<freejoint/>`` / free joint (children of the world body);
+  kinematics does with it - or ONE ball joint (``limited range="0 max"``: a cone on its rotation angle), or a ``<freejoint/>`` /
+  free joint (children of the world body);
   joint ``axis range limited damping armature stiffness springref frictionloss``, ``solreflimit`` / ``solimplimit``,
   ``solreffriction`` / ``solimpfriction`` (per joint); explicit ``<inertial pos quat mass
   diaginertia|fullinertia>``;
@@ -307,8 +308,6 @@ def load_mjcf(path, hand_site="finger", target_site="target", frame_skip=2, task
         if j.tag == "freejoint":            # MJCF: <freejoint/> takes no defaults: no damping, armature or friction loss
             return RawJoint(axis=[0.0, 0.0, 1.0], range=[0.0, 0.0], limited=False, name=j.get("name", ""), type=JOINT_FREE)
         limited = ja("limited", "false") == "true" and t != "free"      # (MuJoCo ignores limits on free joints)
-        if limited and t == "ball":
-            raise ValueError("limits of ball joints are not supported")
         lim_set = fric_set = None
         if limited:
             lim_set = (tuple(_floats(ja("solreflimit", "0.02 1"))), tuple(_floats(ja("solimplimit", "0.9 0.95 0.001 0.5 2"))))

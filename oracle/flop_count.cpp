@@ -48,6 +48,7 @@ static inline cd fabs(cd a) { return cd(::fabs(a.v)); }
 static inline cd sin(cd a) { g_tally.trig++; return cd(::sin(a.v)); }
 static inline cd cos(cd a) { g_tally.trig++; return cd(::cos(a.v)); }
 static inline cd pow(cd a, cd b) { g_tally.trig++; return cd(::pow(a.v, b.v)); }
+static inline cd atan2(cd a, cd b) { g_tally.trig++; return cd(::atan2(a.v, b.v)); }
 static inline cd fmin(cd a, cd b) { g_tally.cmp++; return cd(::fmin(a.v, b.v)); }
 static inline cd fmax(cd a, cd b) { g_tally.cmp++; return cd(::fmax(a.v, b.v)); }
 static inline bool isfinite_cd(cd a) { return ::isfinite(a.v); }

@@ -58,6 +58,7 @@
 #define JHINGE 1
 #define JSLIDE 2
 #define JBALL 3
+#define OR_PI 3.14159265358979323846
 #define JFREE 4
 /* constraint row kinds of the primal problem (MuJoCo mj_constraintUpdate) */
 #define ROW_UNI 0          /* limits, contacts: cost 1/2 D min(0, r)^2 */
@@ -79,6 +80,8 @@ typedef struct {
     int dof_body[MAXV];
     double range[MAXV][2];
     int limited[MAXV];
+    int ball_limited[MAXB];                  /* a ball joint's limit: the rotation angle stays below ball_range (MJCF range="0 max") */
+    double ball_range[MAXB];
     double damping[MAXV], armature[MAXV], stiffness[MAXV], springref[MAXV], frictionloss[MAXV];
     int dof_type[MAXV];                      /* 1 rotation about xaxis through xanchor, 2 translation along xaxis */
     int dof_qadr[MAXV];                      /* hinge / slide dofs: their qpos entry (-1 for ball / free dofs) */
@@ -591,6 +594,10 @@ OrModel *or_model_compile(const double *f, int n) {
                 memcpy(m->dof_solimp_l[j], r + 42, 40);
                 memcpy(m->dof_solref_f[j], r + 47, 16);
                 memcpy(m->dof_solimp_f[j], r + 49, 40);
+            }
+            if (jt == JBALL) {
+                m->ball_limited[b] = (int)r[14];
+                m->ball_range[b] = r[12] > r[13] ? r[12] : r[13];
             }
             if (nd == 1) {
                 m->stiffness[nv] = r[17];
@@ -1366,6 +1373,30 @@ void or_step(OrModel *m, double *q, double *v, const double *ctrl, double *site_
                 row_params_set(m, m->dof_solref_l[j], m->dof_solimp_l[j], dist, 0.0, m->dof_invweight0[j], -side * v[j], &D[nc], &aref[nc]);
                 nc++;
             }
+        }
+    }
+    /* ball-joint limits (mj_instantiateLimit, mjJNT_BALL [EXT]): the joint quaternion as axis * angle (mju_quat2Vel with
+     * dt = 1: angle = 2 atan2(|xyz|, w), wrapped to (-pi, pi]), dist = max(range) - |angle|; one row, J = -axis over the
+     * joint's three dofs (angular velocity in the child body's frame), diagApprox = the dofs' invweight0 */
+    for (int b = 1; b <= m->nbody; b++) {
+        if (m->jtype[b] != JBALL || !m->ball_limited[b]) continue;
+        const double *qq = q + m->qadr[b];
+        double ax[3] = {qq[1], qq[2], qq[3]}, sn = sqrt(dot3(ax, ax));
+        if (sn < MJ_MINVAL) continue;
+        double ang = 2 * atan2(sn, qq[0]);
+        if (ang > OR_PI) ang -= 2 * OR_PI;
+        double sgn = ang < 0 ? -1.0 : 1.0, value = fabs(ang);
+        double dist = m->ball_range[b] - value;
+        if (dist < 0) {
+            int d0 = m->dofid[b];
+            double jv = 0;
+            memset(J[nc], 0, sizeof(J[nc]));
+            for (int i = 0; i < 3; i++) {
+                J[nc][d0 + i] = -sgn * ax[i] / sn;
+                jv += J[nc][d0 + i] * v[d0 + i];
+            }
+            row_params_set(m, m->dof_solref_l[d0], m->dof_solimp_l[d0], dist, 0.0, m->dof_invweight0[d0], jv, &D[nc], &aref[nc]);
+            nc++;
         }
     }
     /* tendon limits: length = sum coef q; rows like the joint limits' with J = +-coef, diagApprox = tendon_invweight0 */

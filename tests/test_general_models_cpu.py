@@ -347,7 +347,6 @@ def test_degrees_and_radians_load_the_same_model(tmp_path):
 
 def test_loader_refuses_what_is_not_modelled(tmp_path):
     for body, extra, msg in [
-        ('<body name="a"><joint type="ball" limited="true" range="0 1"/><geom type="sphere" size="0.1"/><site name="finger"/></body>', "", "ball"),
         ('<body name="a"><joint/><geom type="cylinder" size="0.1 0.1"/><site name="finger"/></body>', "", "geom type"),
         ('<body name="a"><joint name="j"/><geom type="sphere" size="0.1"/><site name="finger"/></body>',
          '<equality><distance geom1="a" geom2="b"/></equality>', "equality"),
@@ -581,3 +580,37 @@ def test_solver_parameters_per_geom_and_per_joint(tmp_path):
     rr, _ = _model(tmp_path, MIXED % ("0.01 1", "0.02 1", "0.05 1", "0.08 1") + nine, extra=MIXED_ACT, name="nine.xml", self_collision=False)
     with pytest.raises(NotImplementedError, match="distinct solref"):
         compile_tree(rr)
+
+
+def test_ball_joint_limit_keeps_the_rotation_angle_below_its_range(tmp_path):
+    """mj_instantiateLimit for a ball joint [EXT]: the angle of the joint quaternion's rotation stays below max(range) - a
+    soft row over the joint's three dofs, J = -axis.  A spinning, swinging body: unlimited it turns through more than 2 rad,
+    limited to 0.6 rad it is turned back there (soft row: 0.1 rad of overshoot at this speed), and inside the cone the two models agree."""
+    body = """
+    <body name="bob" pos="0 0 1"><joint name="bj" type="ball" damping="0.02"%s/>
+      <geom type="capsule" fromto="0 0 0 0.3 0 -0.1" size="0.03" mass="0.5"/><site name="finger" pos="0.3 0 -0.1"/>
+      <body name="tip" pos="0.3 0 -0.1"><joint name="h" type="hinge" axis="0 1 0" damping="0.05"/>
+        <geom type="capsule" fromto="0 0 0 0.1 0 0" size="0.02" mass="0.1"/></body></body>"""
+    BALL_LIMIT_ACT = '<actuator><motor joint="h" gear="0.2" ctrlrange="-1 1" ctrllimited="true"/></actuator>'
+    raw_f, ref_f = _model(tmp_path, body % "", name="free.xml", timestep="0.001", extra=BALL_LIMIT_ACT)
+    raw_l, ref_l = _model(tmp_path, body % ' limited="true" range="0 0.6"', name="lim.xml", timestep="0.001", extra=BALL_LIMIT_ACT)
+    assert raw_l.bodies[0].joint.limited and max(raw_l.bodies[0].joint.range) == 0.6
+    tm = compile_tree(raw_l)
+    assert tm.general and int(tm.field("n_sphere")[0]) == 1 and tm.field("pext")[0] == 2.0
+
+    def angle(q):
+        return 2 * np.arctan2(np.linalg.norm(q[1:4]), q[0])
+
+    qf, vf = raw_f.qpos0.copy(), np.array([1.0, 3.0, -2.0, 0.0])
+    ql, vl = qf.copy(), vf.copy()
+    worst_f = worst_l = 0.0
+    agree_until = None
+    for k in range(1500):
+        qf, vf, _, _ = ref_f.step(qf, vf, np.zeros(1))
+        ql, vl, _, dg = ref_l.step(ql, vl, np.zeros(1))
+        worst_f, worst_l = max(worst_f, angle(qf)), max(worst_l, angle(ql))
+        if agree_until is None and angle(qf) > 0.6:
+            agree_until = k
+            np.testing.assert_allclose(ql, qf, rtol=0, atol=1e-6)     # (identical until the cone is reached)
+    assert agree_until is not None and worst_f > 2.0
+    assert 0.6 < worst_l < 0.75, worst_l                # (a soft row with a 20 ms time constant, met at 3.7 rad/s)

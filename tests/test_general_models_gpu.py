@@ -402,3 +402,48 @@ def test_actuators_on_fixed_tendons_match_oracle(tmp_path):
     o_obs, o_rew, _, _, o_nobs = ref.rollout(q, v, tgt, np.zeros((H, 2)), eps)
     np.testing.assert_allclose(rew, o_rew, rtol=1e-9, atol=1e-9)
     np.testing.assert_allclose(nobs, o_nobs, rtol=0, atol=1e-9)
+
+
+def test_ball_joint_limit_matches_oracle(tmp_path):
+    """A limited ball joint (mj_instantiateLimit, mjJNT_BALL): one soft row over the joint's three dofs, J = -axis of the
+    joint quaternion's rotation, evaluated by the record's lane from the quaternion its joint's first link holds.  One env
+    step from 48 random orientations (inside and beyond the cone) at 1e-9, a 64 x 12 rollout at 1e-9."""
+    from mjmpc_amd.envs.tree_engine import TreeRolloutEngine
+    import importlib.util, os
+    spec = importlib.util.spec_from_file_location("general_models_cpu", os.path.join(os.path.dirname(os.path.abspath(__file__)), "test_general_models_cpu.py"))
+    cpu = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(cpu)
+    body = """
+    <body name="bob" pos="0 0 1" quat="0.9 0.1 -0.3 0.2"><joint name="bj" type="ball" damping="0.02" limited="true" range="0 0.6" solreflimit="0.015 1"/>
+      <geom type="capsule" fromto="0 0 0 0.3 0 -0.1" size="0.03" mass="0.5"/><site name="finger" pos="0.3 0 -0.1"/>
+      <body name="tip" pos="0.3 0 -0.1"><joint name="h" type="hinge" axis="0 1 0" damping="0.05" limited="true" range="-1 1"/>
+        <geom type="capsule" fromto="0 0 0 0.1 0 0" size="0.02" mass="0.1"/></body></body>"""
+    act = '<actuator><motor joint="h" gear="0.2" ctrlrange="-1 1" ctrllimited="true"/></actuator>'
+    raw, ref = cpu._model(tmp_path, body, extra=act, timestep="0.002", frame_skip=2)
+    eng = TreeRolloutEngine(raw, dtype="f64")
+    assert eng.model.general and eng.model.nv == 4 and raw.nq == 5
+    rs = np.random.RandomState(17)
+    tgt = np.asarray(raw.target_pos, float)
+    worst, beyond = 0.0, 0
+    for k in range(48):
+        q, v = raw.qpos0.copy(), np.zeros(4)
+        q[0:4] = _quat(rs, 0.5 if k % 2 else 1.2)
+        q[4] = rs.uniform(-1.2, 1.2)
+        v[:] = rs.standard_normal(4) * [2, 2, 2, 3]
+        beyond += 2 * np.arctan2(np.linalg.norm(q[1:4]), q[0]) > 0.6
+        u = rs.uniform(-1, 1, 1)
+        eng.set_env_state(dict(qp=q, qv=v, target_pos=tgt))
+        _, rew, _, _, _, nobs = eng.rollout(1, 1, u[None], None, "open_loop")
+        q1, v1, r1, o1 = ref.env_step(q, v, u, tgt)
+        worst = max(worst, np.abs(nobs[0, 0] - o1).max() / max(1.0, np.abs(o1).max()), abs(rew[0, 0] - r1) / max(1.0, abs(r1)))
+    print("ball-joint limit: one env step from 48 random states (%d beyond the cone), worst relative error %.2e" % (beyond, worst))
+    assert worst < 1e-9 and beyond >= 10, (worst, beyond)
+    P, H = 64, 12
+    q, v = raw.qpos0.copy(), np.array([1.0, 3.0, -2.0, 0.5])
+    eps = 0.5 * rs.standard_normal((P, H, 1))
+    eng.set_env_state(dict(qp=q, qv=v, target_pos=tgt))
+    obs, rew, act_, done, info, nobs = eng.rollout(P, H, np.zeros((H, 1)), eps, "open_loop")
+    o_obs, o_rew, _, _, o_nobs = ref.rollout(q, v, tgt, np.zeros((H, 1)), eps)
+    np.testing.assert_allclose(rew, o_rew, rtol=1e-9, atol=1e-9)
+    np.testing.assert_allclose(nobs, o_nobs, rtol=0, atol=1e-9)
+    assert eng.solver_failures() == 0
