@@ -681,18 +681,22 @@ def compile_tree(raw: RawModel, overrides=None, base: "TreeModel" = None) -> Tre
 
         a0, da, ra = seg(ia, ga)
         b0, db, rb = seg(ib, gb)
-        condim = max(int(ga.condim), int(gb.condim))
+        # the pair's contact parameters: mj_contactParam's mixing of the two geoms', or the model's <pair> element
+        condim, mu_p, margin_p, psolref, psolimp = raw.pair_contact(ga, gb, (ga.name, gb.name))
+        over = raw.pair_params.get((ga.name, gb.name), raw.pair_params.get((gb.name, ga.name), {}))
+        if "friction" not in over:                          # (run-time geom_friction edits act on the geoms' values)
+            mu_p = max(geom_mu(ga), geom_mu(gb)) if ga.priority == gb.priority else geom_mu(ga if ga.priority > gb.priority else gb)
         if condim not in (1, 3):
             raise NotImplementedError("contacts are condim 1 (frictionless) or 3 (pyramidal cone), got %d" % condim)
         rec[0], rec[1:4], rec[4] = la, a0, ra
-        rec[5] = max(ga.margin, gb.margin)
+        rec[5] = margin_p
         rec[6] = body_w(ia) + body_w(ib)
-        rec[7] = max(geom_mu(ga), geom_mu(gb)) if condim == 3 else 0.0
+        rec[7] = mu_p if condim == 3 else 0.0
         rec[8:11] = da
         rec[11] = edepth[la] - 1
         rec[12] = PT_SEGSEG
         rec[13], rec[14:17], rec[17], rec[18:21] = lb, b0, rb, db
-        rec[21] = sol_class(*mix_contact_solver(contact_set(ga), contact_set(gb)))
+        rec[21] = sol_class(psolref, psolimp)
         boxes = [k for k, g in enumerate((ga, gb)) if g.type == GEOM_BOX]
         if boxes:
             if len(boxes) == 2 or (gb if boxes[0] == 0 else ga).type != GEOM_SPHERE:

@@ -22,7 +22,8 @@ panda/tray_glass-v0.yml, sawyer/door-v0.yml, hand/*-v0.yml):
   collide with moving geoms through MuJoCo's contype / conaffinity rule or an explicit ``<pair>``), world and body
   ``<site>``s, ``<motor>`` / ``<position kp>`` / ``<velocity kv>`` / ``<general gainprm biasprm biastype=affine>`` actuators
   (``joint gear ctrlrange ctrllimited forcerange forcelimited``; no activation dynamics),
-  ``<contact><pair geom1 geom2>``; geom pairs: sphere / capsule against sphere / capsule, sphere against box;
+  ``<contact><pair geom1 geom2 [condim friction margin solref solimp]>``; geom pairs: sphere / capsule against sphere /
+  capsule, sphere against box;
 * ``<equality><connect body1 body2 anchor>``, ``<weld body1 body2>`` and ``<joint joint1 joint2 polycoef>`` (``solref`` /
   ``solimp`` each),
   ``<tendon><fixed limited range><joint joint coef/>`` over one or two joints.
@@ -446,9 +447,28 @@ def load_mjcf(path, hand_site="finger", target_site="target", frame_skip=2, task
     pairs = list(auto_pairs)
     every = {g.name: g for b in bodies for g in b.geoms if g.name}
     every.update({g.name: g for g in world_geoms})
+    pair_params = {}
     for pr in (con.findall("pair") if con is not None else []):
-        if any(k in pr.attrib for k in ("condim", "friction", "solref", "solimp", "margin", "gap")):
-            raise ValueError("<pair> with its own contact parameters is not supported (the geoms' are mixed, mj_contactParam)")
+        if float(pr.get("gap", "0")) != 0.0:
+            raise ValueError("<pair gap> is not supported")
+        over = {}
+        if pr.get("condim") is not None:
+            over["condim"] = int(pr.get("condim"))
+        if pr.get("friction") is not None:
+            fr = _floats(pr.get("friction"))
+            if len(fr) > 1 and fr[1] != fr[0]:
+                raise ValueError("<pair friction>: the two tangential coefficients must be equal (isotropic pyramids)")
+            over["friction"] = fr[0]
+        if pr.get("margin") is not None:
+            over["margin"] = float(pr.get("margin"))
+        if pr.get("solref") is not None:
+            over["solref"] = tuple(_floats(pr.get("solref"), 2))
+            if over["solref"][0] <= 0 or over["solref"][1] <= 0:
+                raise ValueError("solref must be the standard (timeconst, dampratio) pair")
+        if pr.get("solimp") is not None:
+            over["solimp"] = tuple(_floats(pr.get("solimp")))
+        if over:
+            pair_params[(pr.get("geom1"), pr.get("geom2"))] = over
         pairs.append((pr.get("geom1"), pr.get("geom2")))
         for nm in (pr.get("geom1"), pr.get("geom2")):
             if nm in every:
@@ -577,5 +597,5 @@ def load_mjcf(path, hand_site="finger", target_site="target", frame_skip=2, task
     return RawModel(bodies=bodies, actuators=acts, site_body=site_body, site_pos=site_pos, target_pos=target, plane=plane,
                     timestep=timestep, frame_skip=frame_skip, gravity=gravity, solref=solref, solimp=full_solimp(solimp),
                     solref_limit=lsolref, solimp_limit=full_solimp(lsolimp), density=density, viscosity=viscosity,
-                    task=task, ctrl_cost=ctrl_cost, obs_skip=obs_skip, pairs=pairs, world_geoms=world_geoms,
+                    task=task, ctrl_cost=ctrl_cost, obs_skip=obs_skip, pairs=pairs, pair_params=pair_params, world_geoms=world_geoms,
                     equalities=equalities, tendons=tendons, solref_friction=fsolref, solimp_friction=full_solimp(fsolimp))

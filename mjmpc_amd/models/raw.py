@@ -49,7 +49,7 @@ TASK_ORIENT = 2             # in-hand reorientation, the shape of pen-v0's rewar
 BODY_STRIDE = 56
 GEOM_STRIDE = 33
 ACT_STRIDE = 14
-PAIR_STRIDE = 2
+PAIR_STRIDE = 12
 EQ_STRIDE = 28
 TENDON_MAX_JOINTS = 4
 TENDON_STRIDE = 8 + 2 * TENDON_MAX_JOINTS + 7
@@ -239,6 +239,9 @@ class RawModel:
     # geom-geom collision candidates, as names (geom on the manipulator, geom on the object): sphere / capsule pairs, one
     # contact point each (closest points of the two segments); friction / condim / margin = the larger of the two geoms'
     pairs: List[Sequence[str]] = field(default_factory=list)
+    # MJCF <pair> attributes that replace what the two geoms would give: {(geom1, geom2): {"condim", "friction", "margin",
+    # "solref", "solimp"}} (any subset)
+    pair_params: dict = field(default_factory=dict)
     site_axis: Sequence[float] = (0.0, 0.0, 0.0)    # TASK_ORIENT: the object's axis in the frame of the site's body
     target_dir: Sequence[float] = (0.0, 0.0, 1.0)   # TASK_ORIENT: the direction that axis should point in (world)
     world_geoms: List[RawGeom] = field(default_factory=list)   # static sphere / capsule / box geoms of the world body
@@ -297,6 +300,25 @@ class RawModel:
             else:
                 out += [0.0]
         return np.array(out, float)
+
+    def pair_contact(self, ga, gb, key=None):
+        """(condim, friction, margin, solref, solimp) of the contacts of a geom pair: MuJoCo mj_contactParam [EXT] - the
+        larger condim / friction / margin, solref / solimp mixed (mix_contact_solver) - unless the model's <pair> says
+        otherwise (``pair_params``)."""
+        def cset(g):
+            return (self.solref if g.solref is None else g.solref, self.solimp if g.solimp is None else g.solimp, g.solmix, g.priority)
+        solref, solimp = mix_contact_solver(cset(ga), cset(gb))
+        if ga.priority != gb.priority:
+            top = ga if ga.priority > gb.priority else gb
+            condim, mu = int(top.condim), float(top.friction)
+        else:
+            condim, mu = max(int(ga.condim), int(gb.condim)), max(float(ga.friction), float(gb.friction))
+        margin = max(float(ga.margin), float(gb.margin))
+        over = self.pair_params.get(tuple(key), self.pair_params.get(tuple(key)[::-1], {})) if key is not None else {}
+        condim, mu, margin = int(over.get("condim", condim)), float(over.get("friction", mu)), float(over.get("margin", margin))
+        solref = tuple(float(x) for x in over.get("solref", solref))
+        solimp = _solimp5(over.get("solimp", solimp))
+        return condim, mu, margin, solref, solimp
 
     def to_flat(self) -> np.ndarray:
         """Flat float64 serialisation (layout documented in include/mjmpc_amd.h)."""
@@ -401,7 +423,9 @@ class RawModel:
         for ga, gb in self.pairs:
             if names.count(ga) != 1 or names.count(gb) != 1:
                 raise ValueError("collision pair (%r, %r) must name one geom each" % (ga, gb))
-            out.append(np.array([names.index(ga), names.index(gb)], float))
+            gd = {g.name: g for _, g in geoms}
+            condim, mu, margin, solref, solimp = self.pair_contact(gd[ga], gd[gb], (ga, gb))
+            out.append(np.array([names.index(ga), names.index(gb), condim, mu, margin, *solref, *solimp], float))
         bnames = [b.name for b in self.bodies]
         for e in self.equalities:
             r = np.zeros(EQ_STRIDE)

@@ -50,7 +50,7 @@
 #define BODY_STRIDE 56
 #define GEOM_STRIDE 33
 #define ACT_STRIDE 14
-#define PAIR_STRIDE 2
+#define PAIR_STRIDE 12
 #define EQ_STRIDE 28
 #define TENDON_STRIDE (8 + 2 * MAXTJ + 7)
 #define MAXP 16            /* geom-geom collision pairs */
@@ -705,11 +705,12 @@ OrModel *or_model_compile(const double *f, int n) {
     const double *p0 = a0 + nu * ACT_STRIDE;
     m->npair = np_;
     for (int k = 0; k < np_; k++) {
-        double mu = 0, margin = 0;
-        int condim = 1;
+        /* (condim, friction, margin, solref, solimp of the pair's contacts arrive resolved: mj_contactParam's mixing of the
+         * two geoms' values, or what the model's <pair> element says - RawModel.pair_contact) */
+        const double *pr = p0 + k * PAIR_STRIDE;
         m->pair_box[k] = -1;
         for (int e = 0; e < 2; e++) {
-            const double *r = g0 + (int)p0[k * PAIR_STRIDE + e] * GEOM_STRIDE;
+            const double *r = g0 + (int)pr[e] * GEOM_STRIDE;
             m->pair_body[k][e] = (int)r[0] + 1;
             memcpy(m->pair_a[k][e], r + 3, 24);
             for (int i = 0; i < 3; i++) m->pair_d[k][e][i] = (int)r[1] == 2 ? r[6 + i] - r[3 + i] : 0.0;
@@ -720,18 +721,15 @@ OrModel *or_model_compile(const double *f, int n) {
                 quat2mat(r + 14, m->pair_R[k]);
                 memcpy(m->pair_half[k], r + 6, 24);
             }
-            if (r[12] > mu) mu = r[12];
-            if (r[11] > margin) margin = r[11];
-            if ((int)r[13] > condim) condim = (int)r[13];
         }
         if (m->pair_box[k] >= 0 && dot3(m->pair_d[k][1 - m->pair_box[k]], m->pair_d[k][1 - m->pair_box[k]]) > 0) {
             free(m);                    /* box-capsule is not restated */
             return NULL;
         }
-        m->pair_margin[k] = margin;
-        m->pair_mu[k] = condim >= 3 ? mu : 0.0;
-        mix_solver(g0 + (int)p0[k * PAIR_STRIDE] * GEOM_STRIDE + 24, g0 + (int)p0[k * PAIR_STRIDE + 1] * GEOM_STRIDE + 24,
-                   m->pair_solref[k], m->pair_solimp[k]);
+        m->pair_margin[k] = pr[4];
+        m->pair_mu[k] = (int)pr[2] >= 3 ? pr[3] : 0.0;
+        memcpy(m->pair_solref[k], pr + 5, 16);
+        memcpy(m->pair_solimp[k], pr + 7, 40);
     }
     const double *e0 = p0 + np_ * PAIR_STRIDE;
     m->neq = ne;

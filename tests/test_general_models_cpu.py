@@ -614,3 +614,34 @@ def test_ball_joint_limit_keeps_the_rotation_angle_below_its_range(tmp_path):
             np.testing.assert_allclose(ql, qf, rtol=0, atol=1e-6)     # (identical until the cone is reached)
     assert agree_until is not None and worst_f > 2.0
     assert 0.6 < worst_l < 0.75, worst_l                # (a soft row with a 20 ms time constant, met at 3.7 rad/s)
+
+
+def test_pair_elements_override_the_geoms_contact_parameters(tmp_path):
+    """<contact><pair geom1 geom2 condim friction margin solref solimp>: what the element gives replaces mj_contactParam's
+    mix of the two geoms' values, the rest stays mixed; the model with the override equals the one whose geoms carry the
+    numbers themselves."""
+    body = """
+    <geom name="post" type="sphere" pos="0 0 0.2" size="0.2" friction="0.9"%s/>
+    <body name="ball" pos="0.05 0 0.52"><freejoint/>
+      <geom name="ball" type="sphere" size="0.1" mass="0.4" friction="0.3"%s/><site name="finger"/></body>
+    <body name="arm" pos="1 0 1"><joint name="h" type="hinge" axis="0 1 0"/><geom type="capsule" fromto="0 0 0 0.2 0 0" size="0.02"/></body>"""
+    act = '<actuator><motor joint="h" ctrlrange="-1 1" ctrllimited="true"/></actuator>'
+    over = '<contact><pair geom1="ball" geom2="post" condim="1" margin="0.004" solref="0.012 1"/></contact>'
+    plain = '<contact><pair geom1="ball" geom2="post"/></contact>'
+    c3 = ' condim="3"'
+    ra, refa = _model(tmp_path, body % (c3, c3), extra=act + over, name="over.xml")
+    assert ra.pair_params == {("ball", "post"): {"condim": 1, "margin": 0.004, "solref": (0.012, 1.0)}}
+    assert ra.pair_contact(ra.bodies[0].geoms[0], ra.world_geoms[0], ("ball", "post"))[:3] == (1, 0.9, 0.004)
+    direct = ' condim="1" margin="0.004" solref="0.012 1"'
+    rb, refb = _model(tmp_path, body % (direct, direct), extra=act + plain, name="direct.xml")
+    q, v = ra.qpos0.copy(), np.zeros(ra.nv)
+    qa, va, _ = _run(refa, q, v, np.zeros(1), 300)
+    qb, vb, _ = _run(refb, q, v, np.zeros(1), 300)
+    np.testing.assert_allclose(np.r_[qa, va], np.r_[qb, vb], rtol=0, atol=1e-12)
+    rc, refc = _model(tmp_path, body % (c3, c3), extra=act + plain, name="plain.xml")      # (friction cone: it does not slide off as fast)
+    qc, vc, _ = _run(refc, q, v, np.zeros(1), 300)
+    assert np.abs(qc[:3] - qa[:3]).max() > 1e-3
+    ta, tb = compile_tree(ra), compile_tree(rb)
+    np.testing.assert_array_equal(ta.field("spheres")[:21], tb.field("spheres")[:21])        # ([21]: the record's solver set, numbered per model)
+    sa, sb = int(ta.field("spheres")[21]), int(tb.field("spheres")[21])
+    np.testing.assert_array_equal(ta.field("soltab").reshape(8, 7)[sa], tb.field("soltab").reshape(8, 7)[sb])
