@@ -1,0 +1,194 @@
+"""GPU parity on RANDOM models: kinematic trees drawn from a seed - topology, joint kinds (hinge / slide, a ball or a free
+root now and then), limits, springs, friction loss, armature, capsule and sphere geoms against a plane with friction,
+geom-geom pairs, affine actuators with force limits, a joint equality or a limited tendon, solver parameters per element -
+compiled for the kernel and for the C oracle from the same RawModel and compared over one env step from random states
+and over a short rollout.  Whatever instantiation the model asks for (lean / full, 16 or 32 lanes, sparse or dense,
+general or not) is what runs.  Tolerances: 1e-9 per env step (SURVEY 8d's gate), 1e-7 over a 6-step rollout (contacts
+amplify rounding).  Models the compiler refuses (more than 16 contact records ...) are redrawn."""
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _quat(rs, scale):
+    w = scale * rs.standard_normal(3)
+    a = np.linalg.norm(w)
+    return np.concatenate([[np.cos(a / 2)], np.sin(a / 2) * w / max(a, 1e-12)])
+
+
+def random_model(seed):
+    from mjmpc_amd.models.raw import (EQ_JOINT, GEOM_CAPSULE, GEOM_SPHERE, JOINT_BALL, JOINT_FREE, JOINT_HINGE, JOINT_SLIDE,
+                                      RawActuator, RawBody, RawEquality, RawGeom, RawJoint, RawModel, RawPlane, RawTendon)
+    rs = np.random.RandomState(seed)
+    deep = seed % 6 == 5                    # every sixth model: long chains (elimination paths beyond 16 links)
+    n_bodies = int(rs.randint(18, 27)) if deep else int(rs.randint(3, 24))
+    general = rs.rand() < 0.6
+    bodies, budget = [], 30
+    for i in range(n_bodies):
+        # (bodies in depth-first order, as an MJCF file lists them: the parent is the previous body or one of its ancestors -
+        # or the world, which starts another tree)
+        if i == 0:
+            parent = -1
+        else:
+            chain, k = [], i - 1
+            while k >= 0:
+                chain.append(k)
+                k = bodies[k].parent
+            parent = -1 if rs.rand() < (0.03 if deep else 0.12) else int(chain[min(len(chain) - 1, int(rs.exponential(0.15 if deep else 1.0)))])
+        kind = JOINT_HINGE
+        r = rs.rand()
+        if parent < 0 and general and r < 0.3:
+            kind = JOINT_FREE
+        elif general and r < 0.15 and parent >= 0:
+            kind = JOINT_BALL
+        elif r < 0.35:
+            kind = JOINT_SLIDE
+        ndof = {JOINT_HINGE: 1, JOINT_SLIDE: 1, JOINT_BALL: 3, JOINT_FREE: 6}[kind]
+        if budget - ndof < 0:
+            break
+        budget -= ndof
+        axis = rs.standard_normal(3)
+        axis /= np.linalg.norm(axis)
+        limited = kind in (JOINT_HINGE, JOINT_SLIDE) and rs.rand() < 0.6
+        lo = -rs.uniform(0.2, 1.0) * (0.2 if kind == JOINT_SLIDE else 1.0)
+        hi = rs.uniform(0.2, 1.0) * (0.2 if kind == JOINT_SLIDE else 1.0)
+        jt = RawJoint(axis=tuple(axis), range=(lo, hi), limited=limited, damping=float(rs.uniform(0.02, 0.3)),
+                      armature=float(rs.uniform(0.0, 0.01)), name="j%d" % i, type=kind,
+                      stiffness=float(rs.uniform(0, 2.0)) if (kind in (JOINT_HINGE, JOINT_SLIDE) and rs.rand() < 0.3) else 0.0,
+                      springref=float(rs.uniform(-0.2, 0.2)),
+                      pos=tuple(0.03 * rs.standard_normal(3)) if (general and kind in (JOINT_HINGE, JOINT_BALL) and rs.rand() < 0.4) else (0.0, 0.0, 0.0),
+                      frictionloss=float(rs.uniform(0.01, 0.1)) if (general and kind in (JOINT_HINGE, JOINT_SLIDE) and rs.rand() < 0.25) else 0.0)
+        if kind == JOINT_BALL and rs.rand() < 0.5:
+            jt.limited, jt.range = True, (0.0, float(rs.uniform(0.4, 1.0)))
+        if jt.limited and rs.rand() < 0.3:
+            jt.solref_limit, jt.solimp_limit = (float(rs.uniform(0.01, 0.04)), 1.0), (0.9, 0.95, 0.001, 0.5, 2.0)
+        length = rs.uniform(0.08, 0.25)
+        d = rs.standard_normal(3)
+        d *= length / np.linalg.norm(d)
+        rad = float(rs.uniform(0.015, 0.04))
+        geoms = [RawGeom(GEOM_CAPSULE, rad, (0.0, 0.0, 0.0), tuple(d), density=float(rs.uniform(500, 1500)), margin=0.002,
+                         name="c%d" % i, friction=float(rs.uniform(0.3, 1.0)), condim=3 if rs.rand() < 0.7 else 1)]
+        if rs.rand() < 0.3:
+            geoms.append(RawGeom(GEOM_SPHERE, 1.2 * rad, tuple(d), density=800.0, margin=0.002, name="s%d" % i,
+                                 friction=float(rs.uniform(0.3, 1.0)), condim=3))
+        if rs.rand() < 0.25:
+            geoms[0].solref, geoms[0].solimp, geoms[0].solmix = (float(rs.uniform(0.01, 0.03)), 1.0), (0.9, 0.95, 0.001, 0.5, 2.0), float(rs.uniform(0.5, 2))
+        pos = (float(0.4 * rs.standard_normal()), float(0.4 * rs.standard_normal()), float(rs.uniform(0.3, 0.7))) if parent < 0 \
+            else tuple(np.asarray(bodies[parent].geoms[0].b) * rs.uniform(0.5, 1.0))
+        quat = tuple(_quat(rs, 0.5)) if rs.rand() < 0.5 else (1.0, 0.0, 0.0, 0.0)
+        bodies.append(RawBody("b%d" % i, parent, pos, quat=quat, joint=jt, geoms=geoms))
+    # what collides with the plane: a few geoms (each capsule is two records)
+    records = 0
+    order = list(rs.permutation(len(bodies)))
+    for i in order:
+        for g in bodies[i].geoms:
+            cost = 2 if g.type == GEOM_CAPSULE else 1
+            if records + cost <= 8 and rs.rand() < 0.5:
+                g.collide = True
+                records += cost
+    # geom-geom pairs between bodies that are not parent and child
+    pairs = []
+    for _ in range(int(rs.randint(0, 4))):
+        a, b = rs.choice(len(bodies), 2, replace=False) if len(bodies) > 2 else (0, 1)
+        if bodies[a].parent == b or bodies[b].parent == a or a == b:
+            continue
+        if records + 1 <= 12:
+            pairs.append((bodies[max(a, b)].geoms[0].name, bodies[min(a, b)].geoms[0].name))
+            records += 1
+    single = [b.joint.name for b in bodies if b.joint.type in (JOINT_HINGE, JOINT_SLIDE)]
+    if not single:
+        bodies[-1].joint = RawJoint(axis=(0.0, 1.0, 0.0), range=(-1.0, 1.0), limited=False, damping=0.1, name=bodies[-1].joint.name)
+        single = [bodies[-1].joint.name]
+    # actuators on a random subset of the hinge / slide joints
+    acts = []
+    for n in single:
+        if rs.rand() < 0.7 or not acts:
+            r = rs.rand()
+            kw = {}
+            if r < 0.3:
+                kw = dict(kp=float(rs.uniform(2, 20)))
+            elif r < 0.45:
+                kw = dict(gainprm=float(rs.uniform(0.5, 3)), biasprm=(float(rs.uniform(-0.1, 0.1)), -float(rs.uniform(0, 5)), -float(rs.uniform(0, 0.3))))
+            if rs.rand() < 0.2:
+                kw["forcerange"] = (-float(rs.uniform(0.3, 1)), float(rs.uniform(0.3, 1)))
+            acts.append(RawActuator(n, float(rs.uniform(0.3, 2.0)), (-1.0, 1.0), ctrllimited=bool(rs.rand() < 0.85), **kw))
+    equalities, tendons = [], []
+    if general and len(single) >= 2 and rs.rand() < 0.4:
+        a, b = rs.choice(len(single), 2, replace=False)
+        equalities.append(RawEquality(EQ_JOINT, single[a], single[b], polycoef=(0.0, float(rs.uniform(-1, 1)), 0.0, 0.0, 0.0)))
+        records += 1
+    if general and len(single) >= 2 and rs.rand() < 0.4 and records < 14:
+        a, b = rs.choice(len(single), 2, replace=False)
+        tendons.append(RawTendon("t0", [(single[a], 1.0), (single[b], float(rs.uniform(-1, 1)))], limited=True, range=(-0.3, 0.3)))
+    plane = RawPlane(pos=(0.0, 0.0, 0.0), normal=(0.0, 0.0, 1.0), margin=0.002, friction=float(rs.uniform(0.3, 1.0)),
+                     condim=3 if rs.rand() < 0.7 else 1)
+    return RawModel(bodies=bodies, actuators=acts, site_body=len(bodies) - 1, site_pos=(0.05, 0.0, 0.0), target_pos=(0.3, 0.1, 0.4),
+                    plane=plane, timestep=0.002, frame_skip=2, gravity=(0.0, 0.0, -9.81), pairs=pairs, equalities=equalities,
+                    tendons=tendons)
+
+
+def random_state(raw, rs):
+    from mjmpc_amd.models.raw import JOINT_BALL, JOINT_FREE
+    q, v = raw.qpos0.copy(), rs.standard_normal(raw.nv)
+    adr = 0
+    for b in raw.bodies:
+        jt = b.joint
+        if jt.type == JOINT_FREE:
+            q[adr:adr + 3] += 0.05 * rs.standard_normal(3)
+            q[adr + 2] = rs.uniform(0.05, 0.6)
+            q[adr + 3:adr + 7] = _quat(rs, 1.0)
+        elif jt.type == JOINT_BALL:
+            q[adr:adr + 4] = _quat(rs, 0.8)
+        else:
+            q[adr] = rs.uniform(-1.2, 1.2) * (0.25 if jt.type == 2 else 1.0)
+        adr += jt.nq
+    return q, v
+
+
+# (MJMPC_FUZZ_SEEDS=a:b in the environment runs another range of seeds - a soak run, not part of the suite)
+_SEEDS = range(*[int(x) for x in os.environ["MJMPC_FUZZ_SEEDS"].split(":")]) if os.environ.get("MJMPC_FUZZ_SEEDS") else range(48)
+
+
+@pytest.mark.parametrize("seed", _SEEDS)
+def test_random_model_matches_oracle(seed):
+    from mjmpc_amd.envs.tree_engine import TreeRolloutEngine
+    from oracle.physics_ref import RefArm
+    raw, eng, tries = None, None, 0
+    while eng is None:
+        raw = random_model(1000 * tries + seed)
+        try:
+            eng = TreeRolloutEngine(raw, dtype="f64")
+            ref = RefArm(raw.to_flat())
+        except (ValueError, NotImplementedError, AssertionError):
+            eng, tries = None, tries + 1
+            assert tries < 20
+    m = eng.model
+    rs = np.random.RandomState(seed + 77)
+    tgt = np.asarray(raw.target_pos, float)
+    A = eng.d_action
+    worst = 0.0
+    for k in range(12):
+        q, v = random_state(raw, rs)
+        v *= (0.0 if k % 4 == 0 else 1.0)
+        u = rs.uniform(-1.5, 1.5, A)
+        eng.set_env_state(dict(qp=q, qv=v, target_pos=tgt))
+        _, rew, _, _, _, nobs = eng.rollout(1, 1, u[None], None, "open_loop")
+        q1, v1, r1, o1 = ref.env_step(q, v, u, tgt)
+        if not np.isfinite(o1).all():
+            continue
+        worst = max(worst, np.abs(nobs[0, 0] - o1).max() / max(1.0, np.abs(o1).max()), abs(rew[0, 0] - r1) / max(1.0, abs(r1)))
+    print("seed %d: nv %d nq %d, %d bodies, %d records, general %s, max path %d: worst relative error %.2e"
+          % (seed, m.nv, raw.nq, len(raw.bodies), int(m.field("n_sphere")[0]), m.general, m.max_path, worst))
+    assert worst < 1e-9, worst
+    P, H = 32, 6
+    q, v = random_state(raw, rs)
+    eps = 0.5 * rs.standard_normal((P, H, A))
+    eng.set_env_state(dict(qp=q, qv=0.3 * v, target_pos=tgt))
+    obs, rew, act, done, info, nobs = eng.rollout(P, H, np.zeros((H, A)), eps, "open_loop")
+    o_obs, o_rew, _, _, o_nobs = ref.rollout(q, 0.3 * v, tgt, np.zeros((H, A)), eps)
+    ok = np.isfinite(o_nobs).all(axis=(1, 2))
+    np.testing.assert_allclose(nobs[ok], o_nobs[ok], rtol=0, atol=1e-7)
+    np.testing.assert_allclose(rew[ok], o_rew[ok], rtol=1e-7, atol=1e-7)
