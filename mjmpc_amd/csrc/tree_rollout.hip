@@ -1087,7 +1087,10 @@ __device__ __noinline__ T exact_line_search(T g0, T dg, T Dl, T rl, T drl, T Dc,
 
 // waves per SIMD the register allocation aims at: the lean kernels for short paths fit three (f32) / two (f64)
 // workgroups' LDS on a CU
-constexpr int min_waves(int scalar_bytes, int DP, bool fric) {
+constexpr int min_waves(int scalar_bytes, int DP, bool fric, bool gen = false) {
+#ifdef TREE_GEN_F32_ONE_WAVE            // developer A/B (round 4): the general f32 kernels spill 512 B per lane at two waves per SIMD; at one
+    if (gen) return 1;                  // they gain 3-5 % on 4096-particle launches and lose a third at 32768 (cart-pole 2.11 -> 3.13 ms): off
+#endif
     return (DP <= 8 && !fric) ? (scalar_bytes == 4 ? 3 : 2) : ((DP <= 8 && scalar_bytes == 4) ? 2 : 1);
 }
 
@@ -1097,7 +1100,7 @@ constexpr int min_waves(int scalar_bytes, int DP, bool fric) {
 // static geoms, connect / joint equalities, fixed-tendon limits.  Models that need none of it run GEN = false, whose code
 // is the earlier rounds' to the instruction.
 template <typename T, int DP, int NS, bool FRIC, int PL, int DN, bool GEN = false>
-__global__ __launch_bounds__(64 * wg_waves(DP, FRIC, sizeof(T), PL), min_waves(sizeof(T), DP, FRIC)) void tree_rollout_kernel(
+__global__ __launch_bounds__(64 * wg_waves(DP, FRIC, sizeof(T), PL), min_waves(sizeof(T), DP, FRIC, GEN)) void tree_rollout_kernel(
     const T* __restrict__ model_all, int model_stride, const double* __restrict__ state, int state_stride, long P, long shard_size, int H,
     int A, const double* __restrict__ mean,
     const T* __restrict__ noise, T* __restrict__ cost, T* __restrict__ act, T* __restrict__ obs, T* __restrict__ nobs,
