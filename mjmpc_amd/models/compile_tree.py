@@ -15,7 +15,7 @@ from dataclasses import dataclass
 import numpy as np
 
 from .compile import _geom_inertial, _quat2mat, _shift_inertia, principal_inertia
-from .raw import (EQ_CONNECT, EQ_JOINT, EQ_WELD, GEOM_BOX, GEOM_CAPSULE, GEOM_SPHERE, JOINT_BALL, JOINT_FREE, JOINT_HINGE, JOINT_SLIDE,
+from .raw import (EQ_CONNECT, EQ_JOINT, EQ_WELD, GEOM_BOX, GEOM_SPHERE, JOINT_BALL, JOINT_FREE, JOINT_HINGE, JOINT_SLIDE,
                   TASK_FORWARD, TASK_ORIENT, TASK_REACH, RawModel, mix_contact_solver)
 
 TL = 32                     # lanes per particle

@@ -43,7 +43,7 @@ import numpy as np
 
 from .compile import _geom_inertial, _quat2mat
 from .raw import (EQ_CONNECT, EQ_JOINT, EQ_WELD, GEOM_BOX, GEOM_CAPSULE, GEOM_SPHERE, JOINT_BALL, JOINT_FREE, JOINT_HINGE, JOINT_SLIDE,
-                  MJ20_CAPSULE_CAP, TASK_FORWARD, TASK_REACH, RawActuator, RawBody, RawEquality, RawGeom, RawInertial,
+                  MJ20_CAPSULE_CAP, TASK_REACH, RawActuator, RawBody, RawEquality, RawGeom, RawInertial,
                   RawJoint, RawModel, RawPlane, RawTendon)
 
 _VISUAL_BODY_TAGS = ("light", "camera")

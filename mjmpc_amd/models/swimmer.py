@@ -12,7 +12,6 @@ three or four apart touch when the joints between them are all bent the same way
 into a loop (tests/test_locomotion_cpu.py).  ``self_collision=False`` leaves the pairs out.  Task (mjmpc/envs/basic/swimmer.py:7-24): frame_skip 4, reward = forward progress of qpos[0] / dt - 1e-4 |a|^2,
 observation = [qpos[2:], qvel].
 """
-import numpy as np
 
 from .raw import (GEOM_CAPSULE, JOINT_HINGE, JOINT_SLIDE, TASK_FORWARD, RawActuator, RawBody, RawGeom, RawJoint, RawModel)
 

@@ -4,7 +4,7 @@
     python tools/tree_stats.py [hand|swimmer|cheetah|pen|cartpole|tray|door] [dtype] [P] [H]
 
 Prints, for the first particle of the launch, shader cycles per substep in each phase and the constraint statistics."""
-import ctypes, glob, os, subprocess, sys
+import ctypes, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 LIB = os.environ.get("TREE_STATS_LIB", os.path.join(ROOT, "tools", "_build", "libmjmpc_amd_treestats.so"))
