@@ -515,10 +515,16 @@ __device__ __forceinline__ void active_set(T aw, T sig, T aref, T jc, T arefc, b
     }
 }
 
+// developer A/B switch (round 4): the two waves of a DUO group trade their chains - see arm_front
+#ifdef ARM_SWAP_ROLES
+constexpr bool ARM_SWAP = true;
+#else
+constexpr bool ARM_SWAP = false;
+#endif
 // developer A/B switch: the SOLVE wave takes E2 (the Euler inverse's hand-over) after its Newton iterations instead of
 // inside the first one - measured (round 4, 4096 x 32 f64): rollout kernel 0.1775 -> 0.186 ms, the inverse's row then
 // arrives with its LDS latency in front of the Euler product; off
-#ifdef ARM_E2_LATE
+#if defined(ARM_E2_LATE) || defined(ARM_SWAP_ROLES)
 constexpr bool E2_LATE = true;
 #else
 constexpr bool E2_LATE = false;
@@ -594,6 +600,30 @@ __device__ __forceinline__ void arm_front(const MT& M, const ArmInts& I, T& q, T
     link_frames(M, L);
     ST.mark(1);         // world-frame link quantities
 
+    if constexpr (ROLE == DYN && ARM_SWAP) {
+        // (ARM_SWAP) this wave - the one that also reads the inputs, draws the samples and writes the records - takes the
+        // LIGHT chain: mass matrix, limit rows, then the Euler inverse; the other wave the heavy one: bias forces, constraint
+        // solve, Euler product.  The motor torque travels to it through LDS (read after E1).
+        ldsM[V_TAU + l8] = tau_act;
+        T dg = mass_matrix_tile(L, l8, ldsM);
+        dg += M.link(O_ARMATURE);
+        ldsM[V_JC + l8] = dg;                           // (the Newton matrix's diagonal starts from it; the slot is the other wave's own after E1)
+        ldsM[V_DE + l8] = dg + M.glob(O_TIMESTEP) * M.link(O_DAMPING);
+        ST.mark(4);
+        duo_barrier();                                  // E1: tile, Euler diagonal, limit rows, motor torque out
+        ST.mark(3);
+        Dense<T> F;
+        F.load(ldsM, ldsM + V_DE);
+        F.factor();
+        T col[MAX_LINKS];
+#pragma unroll
+        for (int i = 0; i < MAX_LINKS; ++i) col[i] = (i == l8) ? T(1) : T(0);
+        F.solve(col);
+#pragma unroll
+        for (int i = 0; i < MAX_LINKS; ++i) ldsM[V_EI + l8 * LANES + i] = col[i];
+        ST.mark(6);
+        return;                                         // (E2 is taken in arm_back, behind this wave's records and sampler)
+    }
     if constexpr (ROLE == DYN) {
         // 5. smooth force: -bias + passive damping + motor, handed to the SOLVE wave
         const T bias = bias_force(M, L, v, l8);
@@ -631,28 +661,43 @@ __device__ __forceinline__ void arm_front(const MT& M, const ArmInts& I, T& q, T
     }
 
     T bias = T(0);
-    if constexpr (ROLE == SOLO) bias = bias_force(M, L, v, l8);
-    T dgM = mass_matrix_tile(L, l8, ldsM);
+    if constexpr (ROLE == SOLO || (ROLE == SOLVE && ARM_SWAP)) bias = bias_force(M, L, v, l8);
+    T dgM = T(0);
     const T damping = M.link(O_DAMPING), h = M.glob(O_TIMESTEP);
-    dgM += M.link(O_ARMATURE);
-    ldsM[V_DE + l8] = dgM + h * damping;
+    if constexpr (!(ROLE == SOLVE && ARM_SWAP)) {
+        dgM = mass_matrix_tile(L, l8, ldsM);
+        dgM += M.link(O_ARMATURE);
+        ldsM[V_DE + l8] = dgM + h * damping;
+    }
     if constexpr (ROLE == SOLO) LDS_WAVE_SYNC();
     ST.mark(4);         // (bias forces,) composite inertia, mass matrix, tile
 
     // 5. smooth force: -bias + passive damping + motor (SOLVE: arrives from the DYN wave at E1)
     T tau = -bias - damping * v + tau_act;
+    T sw_sg = T(0), sw_D = T(0), sw_a = T(0);           // (ARM_SWAP: my limit row, evaluated in front of E1 - this wave gets there first)
+    if constexpr (ROLE == SOLVE && ARM_SWAP) limit_row(M, q, v, sw_sg, sw_D, sw_a);
     if constexpr (ROLE == SOLVE) {
         duo_barrier();                                  // E1: tau in; tile and Euler diagonal out
         ST.mark(3);
-        tau = ldsM[V_TAU + l8];
+        if constexpr (ARM_SWAP) {
+            tau += ldsM[V_TAU + l8];                    // (the motor torque; bias and damping are this wave's own)
+            dgM = ldsM[V_JC + l8];
+        } else {
+            tau = ldsM[V_TAU + l8];
+        }
     }
     T ei[MAX_LINKS];            // SOLVE: my row of (M + h B)^-1 (read once the DYN wave has published it)
 
     // 6. constraint rows.  Limits (SOLVE: evaluated by the DYN wave before E1)
     T sig = T(0), dist = T(0), D = T(0), aref = T(0);
     bool inst = false;
-    constexpr bool rows_from_dyn = ROLE == SOLVE && rows_by_dyn<T>();
-    if constexpr (rows_from_dyn) {
+    constexpr bool rows_from_dyn = ROLE == SOLVE && (rows_by_dyn<T>() || ARM_SWAP);
+    if constexpr (ROLE == SOLVE && ARM_SWAP) {
+        sig = sw_sg;
+        D = sw_D;
+        aref = sw_a;
+        inst = sig != T(0);
+    } else if constexpr (rows_from_dyn) {
         sig = ldsM[V_LS + l8];
         D = ldsM[V_LD + l8];
         aref = ldsM[V_LA + l8];
@@ -729,7 +774,7 @@ __device__ __forceinline__ void arm_front(const MT& M, const ArmInts& I, T& q, T
                 for (int i = 0; i < MAX_LINKS; ++i) col[i] = (i == l8) ? T(1) : T(0);
                 F.solve(col);
                 ST.mark(it == 0 ? 6 : 9);               // factorisation + inverse / further iterations
-                if (it == 0 && !rows_by_dyn<T>() && !E2_LATE) {     // (E2 where round 2 had it: this wave arrives ~2000 cycles after E1)
+                if (it == 0 && !(rows_by_dyn<T>() || ARM_SWAP) && !E2_LATE) {     // (E2 where round 2 had it: this wave arrives ~2000 cycles after E1)
                     duo_barrier();
 #pragma unroll
                     for (int i = 0; i < MAX_LINKS; ++i) ei[i] = ldsM[V_EI + l8 * LANES + i];
@@ -748,7 +793,7 @@ __device__ __forceinline__ void arm_front(const MT& M, const ArmInts& I, T& q, T
                 // this wave gets HERE in about as many (after the first factorisation it would still wait ~400).  Taking
                 // the rendezvous inside the first iteration rather than at the end of the substep leaves only E3
                 // between the last Newton iteration and the integration.
-                if (it == 0 && rows_by_dyn<T>() && !E2_LATE) {
+                if (it == 0 && (rows_by_dyn<T>() || ARM_SWAP) && !E2_LATE) {
                     duo_barrier();
 #pragma unroll
                     for (int i = 0; i < MAX_LINKS; ++i) ei[i] = ldsM[V_EI + l8 * LANES + i];   // my row of (M + h B)^-1, early
@@ -894,6 +939,7 @@ template <int ROLE, typename T, typename MT>
 __device__ __forceinline__ void arm_back(const MT& M, T& q, T& v, T& aw, T& sq, T& cq, T* ldsM, int l8,
                                          bool free_step, Stamps& ST) {
     ST.mark(11);        // DYN: env-step records
+    if constexpr (ROLE == DYN && ARM_SWAP) { duo_barrier(); ST.mark(7); }      // E2: inverse out (the other wave takes it after its Newton iterations)
     if constexpr (ROLE == SOLO) LDS_WAVE_SYNC();
     else duo_barrier();                                 // E3
     ST.mark(12);        // wait at B
