@@ -1,6 +1,8 @@
 """GPU parity on RANDOM models: kinematic trees drawn from a seed - topology, joint kinds (hinge / slide, a ball or a free
 root now and then), limits, springs, friction loss, armature, capsule and sphere geoms against a plane with friction,
-geom-geom pairs, affine actuators with force limits, a joint equality or a limited tendon, solver parameters per element -
+geom-geom pairs (some with <pair> overrides), boxes (a static slab under the spheres, a box's corners on the plane), affine
+actuators with force limits, on joints or on a tendon, joint / connect / weld equalities, a limited tendon, solver parameters
+per element -
 compiled for the kernel and for the C oracle from the same RawModel and compared over one env step from random states
 and over a short rollout.  Whatever instantiation the model asks for (lean / full, 16 or 32 lanes, sparse or dense,
 general or not) is what runs.  Tolerances: 1e-9 per env step (SURVEY 8d's gate), 1e-7 over a 6-step rollout (contacts
@@ -20,8 +22,9 @@ def _quat(rs, scale):
 
 
 def random_model(seed):
-    from mjmpc_amd.models.raw import (EQ_JOINT, GEOM_CAPSULE, GEOM_SPHERE, JOINT_BALL, JOINT_FREE, JOINT_HINGE, JOINT_SLIDE,
-                                      RawActuator, RawBody, RawEquality, RawGeom, RawJoint, RawModel, RawPlane, RawTendon)
+    from mjmpc_amd.models.raw import (EQ_CONNECT, EQ_JOINT, EQ_WELD, GEOM_BOX, GEOM_CAPSULE, GEOM_SPHERE, JOINT_BALL, JOINT_FREE,
+                                      JOINT_HINGE, JOINT_SLIDE, RawActuator, RawBody, RawEquality, RawGeom, RawJoint, RawModel,
+                                      RawPlane, RawTendon)
     rs = np.random.RandomState(seed)
     deep = seed % 6 == 5                    # every sixth model: long chains (elimination paths beyond 16 links)
     n_bodies = int(rs.randint(18, 27)) if deep else int(rs.randint(3, 24))
@@ -81,12 +84,13 @@ def random_model(seed):
         quat = tuple(_quat(rs, 0.5)) if rs.rand() < 0.5 else (1.0, 0.0, 0.0, 0.0)
         bodies.append(RawBody("b%d" % i, parent, pos, quat=quat, joint=jt, geoms=geoms))
     # what collides with the plane: a few geoms (each capsule is two records)
-    records = 0
+    want_box = general and rs.rand() < 0.25             # (a box on the plane: eight records)
+    records = 8 if want_box else 0
     order = list(rs.permutation(len(bodies)))
     for i in order:
         for g in bodies[i].geoms:
             cost = 2 if g.type == GEOM_CAPSULE else 1
-            if records + cost <= 8 and rs.rand() < 0.5:
+            if records + cost <= (11 if want_box else 8) and rs.rand() < 0.5:
                 g.collide = True
                 records += cost
     # geom-geom pairs between bodies that are not parent and child
@@ -98,6 +102,24 @@ def random_model(seed):
         if records + 1 <= 12:
             pairs.append((bodies[max(a, b)].geoms[0].name, bodies[min(a, b)].geoms[0].name))
             records += 1
+    # general models: a static box of the world body that the spheres may hit, a box riding on a body (corners against
+    # the plane), a connect or a weld between two bodies, a <pair> with its own parameters
+    world_geoms, pair_params = [], {}
+    spheres = [(i, g) for i, b in enumerate(bodies) for g in b.geoms if g.type == GEOM_SPHERE]
+    if general and spheres and rs.rand() < 0.35 and records < 12:
+        world_geoms.append(RawGeom(GEOM_BOX, 0.0, (0.3, 0.0, 0.1), (0.3, 0.3, 0.1), name="slab", friction=0.6, condim=3, margin=0.002,
+                                   quat=tuple(_quat(rs, 0.2))))
+        for i, g in spheres[:2]:
+            if records < 13:
+                pairs.append((g.name, "slab"))
+                records += 1
+    if want_box:
+        k = int(rs.randint(len(bodies)))
+        bodies[k].geoms.append(RawGeom(GEOM_BOX, 0.0, (0.0, 0.0, 0.0), (0.04, 0.03, 0.02), density=700.0, margin=0.002, name="box%d" % k,
+                                       friction=0.5, condim=3, collide=True, quat=tuple(_quat(rs, 0.5))))
+    if pairs and rs.rand() < 0.4:
+        pair_params[tuple(pairs[0])] = dict(condim=int(rs.choice([1, 3])), friction=float(rs.uniform(0.2, 1.2)), margin=0.003,
+                                            solref=(float(rs.uniform(0.008, 0.03)), 1.0))
     single = [b.joint.name for b in bodies if b.joint.type in (JOINT_HINGE, JOINT_SLIDE)]
     if not single:
         bodies[-1].joint = RawJoint(axis=(0.0, 1.0, 0.0), range=(-1.0, 1.0), limited=False, damping=0.1, name=bodies[-1].joint.name)
@@ -123,11 +145,24 @@ def random_model(seed):
     if general and len(single) >= 2 and rs.rand() < 0.4 and records < 14:
         a, b = rs.choice(len(single), 2, replace=False)
         tendons.append(RawTendon("t0", [(single[a], 1.0), (single[b], float(rs.uniform(-1, 1)))], limited=True, range=(-0.3, 0.3)))
+        records += 1
+        if rs.rand() < 0.6:                             # ... with an actuator pulling on it instead of its joints' own
+            acts = [a_ for a_ in acts if a_.joint not in (single[a], single[b])]
+            acts.append(RawActuator("", float(rs.uniform(0.5, 1.5)), (-1.0, 1.0), kp=float(rs.uniform(2, 10)), tendon="t0"))
+    if general and len(bodies) >= 3 and rs.rand() < 0.3 and records + 2 <= 15:
+        a, b = rs.choice(len(bodies), 2, replace=False)
+        if rs.rand() < 0.6:
+            equalities.append(RawEquality(EQ_CONNECT, bodies[max(a, b)].name, bodies[min(a, b)].name if rs.rand() < 0.7 else "",
+                                          anchor=tuple(0.05 * rs.standard_normal(3))))
+            records += 1
+        else:
+            equalities.append(RawEquality(EQ_WELD, bodies[max(a, b)].name, bodies[min(a, b)].name if rs.rand() < 0.7 else ""))
+            records += 2
     plane = RawPlane(pos=(0.0, 0.0, 0.0), normal=(0.0, 0.0, 1.0), margin=0.002, friction=float(rs.uniform(0.3, 1.0)),
                      condim=3 if rs.rand() < 0.7 else 1)
     return RawModel(bodies=bodies, actuators=acts, site_body=len(bodies) - 1, site_pos=(0.05, 0.0, 0.0), target_pos=(0.3, 0.1, 0.4),
                     plane=plane, timestep=0.002, frame_skip=2, gravity=(0.0, 0.0, -9.81), pairs=pairs, equalities=equalities,
-                    tendons=tendons)
+                    tendons=tendons, world_geoms=world_geoms, pair_params=pair_params)
 
 
 def random_state(raw, rs):
