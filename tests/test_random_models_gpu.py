@@ -227,6 +227,13 @@ def test_random_model_matches_oracle(seed):
     ok = np.isfinite(o_nobs).all(axis=(1, 2))
     np.testing.assert_allclose(nobs[ok], o_nobs[ok], rtol=0, atol=1e-7)
     np.testing.assert_allclose(rew[ok], o_rew[ok], rtol=1e-7, atol=1e-7)
+    # the same start in mode="closed_loop_linear" (gym_env_wrapper.py:135-136): actions from the observation each step starts from
+    W = 0.05 * rs.standard_normal((eng.d_obs + 1, A))
+    obs, rew, act, done, info, nobs = eng.rollout(8, 4, W, eps[:8, :4], "closed_loop_linear")
+    o_obs, o_rew, o_act, _, o_nobs = ref.rollout(q, 0.3 * v, tgt, W, eps[:8, :4], mode="closed_loop_linear")
+    ok = np.isfinite(o_nobs).all(axis=(1, 2))
+    np.testing.assert_allclose(act[ok], o_act[ok], rtol=0, atol=1e-7)
+    np.testing.assert_allclose(nobs[ok], o_nobs[ok], rtol=0, atol=1e-7)
 
 
 @pytest.mark.parametrize("seed", range(0, 48, 4))
