@@ -43,7 +43,7 @@ import numpy as np
 
 from .compile import _geom_inertial, _quat2mat
 from .raw import (EQ_CONNECT, EQ_JOINT, EQ_WELD, GEOM_BOX, GEOM_CAPSULE, GEOM_SPHERE, JOINT_BALL, JOINT_FREE, JOINT_HINGE, JOINT_SLIDE,
-                  MJ20_CAPSULE_CAP, TASK_REACH, RawActuator, RawBody, RawEquality, RawGeom, RawInertial,
+                  MJ20_CAPSULE_CAP, TASK_FORWARD, TASK_REACH, RawActuator, RawBody, RawEquality, RawGeom, RawInertial,
                   RawJoint, RawModel, RawPlane, RawTendon)
 
 _VISUAL_BODY_TAGS = ("light", "camera")
@@ -480,12 +480,17 @@ def load_mjcf(path, hand_site="finger", target_site="target", frame_skip=2, task
     def full_solimp(si):
         return tuple(si) + (0.9, 0.95, 0.001, 0.5, 2.0)[len(si):]
 
-    def common(sets):                   # the most frequent set becomes the model's own; elements keep theirs only where it differs
+    def common(sets, tag, kref, kimp):
+        # the model's own set: what the top-level <default> says, else the most frequent one in use; elements keep theirs
+        # only where it differs
+        d = dfl.cls["main"][tag]
+        if kref in d or kimp in d:
+            return (tuple(_floats(d.get(kref, "0.02 1"))), tuple(_floats(d.get(kimp, "0.9 0.95 0.001 0.5 2"))))
         return max(sets, key=sets.count) if sets else DEF_SOL
 
-    solref, solimp = common(geom_solver)
-    lsolref, lsolimp = common(limit_solver)
-    fsolref, fsolimp = common(friction_solver)
+    solref, solimp = common(geom_solver, "geom", "solref", "solimp")
+    lsolref, lsolimp = common(limit_solver, "joint", "solreflimit", "solimplimit")
+    fsolref, fsolimp = common(friction_solver, "joint", "solreffriction", "solimpfriction")
     for g in [g for b in bodies for g in b.geoms] + world_geoms:
         if g._solver != (solref, solimp):
             g.solref, g.solimp = g._solver[0], full_solimp(g._solver[1])
@@ -587,7 +592,7 @@ def load_mjcf(path, hand_site="finger", target_site="target", frame_skip=2, task
         else:
             raise ValueError("equality <%s> is not supported (connect, weld and joint are)" % q.tag)
 
-    if task == TASK_REACH:
+    if task != TASK_FORWARD:                # (reach and reorientation tasks track a site; forward progress reads qpos[0])
         if hand_site not in sites or sites[hand_site][0] < 0:
             raise ValueError("tracked site %r must be attached to a body" % hand_site)
         site_body, site_pos = sites[hand_site]

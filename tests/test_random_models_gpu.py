@@ -64,6 +64,12 @@ def random_model(seed):
                       springref=float(rs.uniform(-0.2, 0.2)),
                       pos=tuple(0.03 * rs.standard_normal(3)) if (general and kind in (JOINT_HINGE, JOINT_BALL) and rs.rand() < 0.4) else (0.0, 0.0, 0.0),
                       frictionloss=float(rs.uniform(0.01, 0.1)) if (general and kind in (JOINT_HINGE, JOINT_SLIDE) and rs.rand() < 0.25) else 0.0)
+        if kind in (JOINT_BALL, JOINT_FREE):            # (axis and spring reference mean nothing there)
+            jt.axis, jt.springref = (0.0, 0.0, 1.0), 0.0
+        if kind == JOINT_FREE:                          # (<freejoint/>: no damping, no armature, no range)
+            jt.range, jt.damping, jt.armature = (0.0, 0.0), 0.0, 0.0
+        if kind == JOINT_BALL and not jt.limited:
+            jt.range = (0.0, 0.0)
         if kind == JOINT_BALL and rs.rand() < 0.5:
             jt.limited, jt.range = True, (0.0, float(rs.uniform(0.4, 1.0)))
         if jt.limited and rs.rand() < 0.3:
