@@ -360,6 +360,9 @@ __global__ __launch_bounds__(1024) void kth_key_kernel(const double* __restrict_
     const int top = differ ? 64 - __clzll((long long)differ) : 0;       // 0: all keys are equal
     if (tid == 0) prefix_s = top == 64 ? 0ull : (kand & (~0ull << top));
     __syncthreads();
+#if defined(KTH_STOP) && KTH_STOP == 1       // developer builds: phase timing by early exits (tools/cem_phases.sh)
+    return;
+#endif
     for (int hi = top; hi > 0;) {
         const int width = hi >= 8 ? 8 : hi, shift = hi - width;
         hi = shift;
@@ -447,6 +450,9 @@ __global__ __launch_bounds__(1024) void kth_key_kernel(const double* __restrict_
             break;
         }
     }
+#if defined(KTH_STOP) && KTH_STOP == 2
+    return;
+#endif
     // unless the ranking above has named it: the index of the need_s-th particle (in index order) equal to T
     const unsigned long long T = prefix_s;
     const long room = need_s;
@@ -523,6 +529,9 @@ __global__ __launch_bounds__(1024) void kth_key_kernel(const double* __restrict_
             }
         }
         if (tid == 0 && (!MOM || blockIdx.x == 0)) *count = total;
+#if defined(KTH_STOP) && KTH_STOP == 3
+        return;
+#endif
         if constexpr (MOM) {
             extern __shared__ double dyn[];         // tile[E * HA] | red[S * AA] | cdiff[HA] | cprime[A]
             const int H = mo.H, A = mo.A, HA = H * A, AA = A * A, E = mo.E;
@@ -552,6 +561,9 @@ __global__ __launch_bounds__(1024) void kth_key_kernel(const double* __restrict_
                 }
             }
             __syncthreads();
+#if defined(KTH_STOP) && KTH_STOP == 4
+            return;
+#endif
             if (tid < A) {
                 double c = 0.0;
                 for (int t = 0; t < H; ++t) c += cdiff[t * A + tid];
