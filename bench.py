@@ -562,6 +562,8 @@ def main():
                      "alg_bytes_per_launch": b_alg * P_loc * H,
                      "kernel": "%s<%s>" % (w["kernel"], "double" if args.dtype == "f64" else "float"),
                      "kernel_ms": kern_ms,
+                     "kernel_ms_how": "HIP events around %d back-to-back launches of the iteration's entry point on the run's own buffers, "
+                                      "FROM THE STATE THE RUN ENDED IN (a contact-rich final state can cost more than the loop's average step)" % n_t,
                      "kernel_entry": ("mjmpc_arm_mppi_step, launch 1 of 2 (sampling + rollout + cost-to-go + per-workgroup softmax records); "
                                       "with launch 2 (arm_mppi_finish_kernel: update + action + shift, here without its env step): "
                                       "%.4f ms" % both_ms
