@@ -339,8 +339,9 @@ int mjmpc_cem_combine(const double* d_records, int G, int H, int A, double n_eli
  *       covariance (np.var ddof 0 / np.cov ddof 1 over the H k elite deltas, step-size blend), cov += grow_scale *
  *       diag(d_grow_diag) (CEM._shift, cem.py:94; NULL: identity), its lower Cholesky factor -> d_chol (may be NULL;
  *       positive semi-definite input as mjmpc_cholesky_lower, *d_status = 1 if indefinite), the action (row 0 of the new
- *       mean) -> d_action_out / h_action_pinned (mapped pinned, may be NULL), the horizon shift (0 'null', 1 'repeat',
- *       < 0 none), *d_step_counter = snapshot + 1, and - d_next_noise != NULL - the RAW Philox samples of the next
+ *       mean) -> d_action_out / h_action_pinned (mapped pinned, A + 1 doubles, may be NULL: the action, then - behind a
+ *       system-scope fence - the new step count as a completion flag the host can poll while the launch is still
+ *       drawing), the horizon shift (0 'null', 1 'repeat', < 0 none), *d_step_counter = snapshot + 1, and - d_next_noise != NULL - the RAW Philox samples of the next
  *       control step, [P][H][A] of dtype, coloured by the new factor: the stream of mjmpc_sample_noise(..., filter NULL,
  *       seed, offset, particle_offset, d_step_counter), sample for sample.
  * mjmpc_cem_fused_supported: A <= 8, A <= H + 1, P_all <= 32768, the moment tiles fit the workspace (else use the

@@ -675,7 +675,7 @@ class OLGaussianMPC(Controller):
         never waits for the host round trip.  (Sharded runs publish from the combine kernel after the all-gather.)
         Other update paths: one stream synchronisation."""
         A = self.d_action
-        if not self._fused_capable():
+        if not (self._fused_capable() or self._cem_fused()):        # (the fused CEM step's finish launch publishes the flag too)
             self.dev.torch.cuda.current_stream(self.dev.device).synchronize()
             return self._action_np[:A].copy()
         o = self._slot(self.num_steps)

@@ -379,7 +379,7 @@ __global__ __launch_bounds__(1024) void kth_key_kernel(const double* __restrict_
             // into the same bin, one lane adds the count instead of 64 lanes serialising on one LDS word
             const unsigned long long m = __ballot(in);
             if (m) {
-                const unsigned lead = __shfl(bin, __ffsll((long long)m) - 1);
+                const unsigned lead = (unsigned)__builtin_amdgcn_readlane((int)bin, __ffsll((long long)m) - 1);  // (v_readlane: no LDS trip)
                 if (__all(!in || bin == lead)) {
                     if ((tid & 63) == 0) atomicAdd(&hist[lead], (unsigned)__popcll(m));
                 } else if (in) {
@@ -483,13 +483,14 @@ __global__ __launch_bounds__(1024) void kth_key_kernel(const double* __restrict_
     if constexpr (NPER > 0) {
         if (!list) return;
         __shared__ int lcnt[NPER * 16];
-        const long cut = cut_s < 0 ? P_all : cut_s;
-        const int lane = tid & 63, wave = tid >> 6;
+        const int cut = (int)(cut_s < 0 ? P_all : cut_s), pall = (int)P_all;        // (NPER > 0: at most 32 768 keys)
+        const unsigned ploc = (unsigned)P_local;
+        const int lane = tid & 63, wave = tid >> 6, jrel = tid - (int)offset;
         unsigned flags = 0u;
 #pragma unroll
         for (int r = 0; r < NPER; ++r) {
-            const long j = (long)r * 1024 + tid;
-            const bool e = j < P_all && j >= offset && j < offset + P_local && (keys[r] < T || (keys[r] == T && j <= cut));
+            const int j = r * 1024 + tid;
+            const bool e = j < pall && (unsigned)(r * 1024 + jrel) < ploc && (keys[r] < T || (keys[r] == T && j <= cut));
             const unsigned long long m = __ballot(e);
             if (lane == 0) lcnt[r * 16 + wave] = __popcll(m);
             flags |= e ? (1u << r) : 0u;
@@ -519,7 +520,7 @@ __global__ __launch_bounds__(1024) void kth_key_kernel(const double* __restrict_
             const unsigned long long m = __ballot(e);
             if (e) {
                 const int pos = lcnt[r * 16 + wave] + __popcll(m & ((1ull << lane) - 1ull));
-                const int idx = (int)((long)r * 1024 + tid - offset);
+                const int idx = r * 1024 + jrel;
                 if (!MOM || blockIdx.x == 0) list[pos] = idx;
                 if constexpr (MOM) {
                     if (pos < CEM_HEAD) head[pos] = idx;
@@ -958,11 +959,18 @@ __global__ __launch_bounds__(CEM_FIN_THREADS) void cem_finish_kernel(CemFinish f
         // new mean, action, shift (olgaussian_mpc.py:69-78, 116-129)
         for (int j = tid; j < HA; j += CEM_FIN_THREADS) sumA[j] = (1.0 - f.step) * f.mean_prev[j] + f.step * (sumA[j] / cnt);
         __syncthreads();
+        // mapped pinned host memory: the action, then - once those writes are visible system-wide - the new step count as
+        // a completion flag: the host picks the action up while this launch is still drawing and the env step has not run
         if (tid < A) {
             if (f.action_out) f.action_out[tid] = sumA[tid];
-            if (f.action_host) f.action_host[tid] = sumA[tid];
+            if (f.action_host) { f.action_host[tid] = sumA[tid]; __threadfence_system(); }
         }
-        if (tid == 0 && f.step_counter) *f.step_counter = *f.step_prev + 1;
+        __syncthreads();
+        if (tid == 0) {
+            const long long count = *f.step_prev + 1;
+            if (f.step_counter) *f.step_counter = count;
+            if (f.action_host) { f.action_host[A] = (double)count; __threadfence_system(); }
+        }
         for (int j = tid; j < HA; j += CEM_FIN_THREADS) {
             double v = sumA[j];
             if (f.shift_mode >= 0) {
@@ -1395,7 +1403,11 @@ hipError_t cem_elite_sums(const T* actions, const double* q_all, long P_all, lon
     const long kmax = k < P ? (k > 0 ? k : 0) : P;
     const int nbe = kmax > 0 ? nblocks(kmax, CHUNK) : 1;
     const long off = q_all ? offset : 0;
-    if (Pa <= 16 * 1024) {
+    if (Pa <= 4 * 1024) {          // (keys per thread by the population: padding rounds cost as much as full ones)
+        hipLaunchKernelGGL(kth_key_kernel<4>, dim3(1), dim3(1024), 0, s, qa, Pa, k, thr, off, P, w.elite, elite_count(w));
+    } else if (Pa <= 8 * 1024) {
+        hipLaunchKernelGGL(kth_key_kernel<8>, dim3(1), dim3(1024), 0, s, qa, Pa, k, thr, off, P, w.elite, elite_count(w));
+    } else if (Pa <= 16 * 1024) {
         hipLaunchKernelGGL(kth_key_kernel<16>, dim3(1), dim3(1024), 0, s, qa, Pa, k, thr, off, P, w.elite, elite_count(w));
     } else if (Pa <= 32 * 1024) {
         hipLaunchKernelGGL(kth_key_kernel<32>, dim3(1), dim3(1024), 0, s, qa, Pa, k, thr, off, P, w.elite, elite_count(w));
@@ -1448,15 +1460,21 @@ hipError_t cem_select_moments(const T* actions, const double* q_all, long P_all,
     mo.H = H; mo.A = A; mo.E = E;
     const size_t lds = sizeof(double) * ((size_t)(E > 4 ? E : 4) * HA + (1024 / AA) * AA + HA + A);
     unsigned long long* thr = (unsigned long long*)w.scratch;
-    if (Pa <= 16384) {
-        if (lds > 64 * 1024)
-            (void)hipFuncSetAttribute((const void*)kth_key_kernel<16, T, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        hipLaunchKernelGGL((kth_key_kernel<16, T, true>), dim3(NB), dim3(1024), lds, s, qa, Pa, k, thr, off, P, w.elite, elite_count(w), mo);
-    } else {
-        if (lds > 64 * 1024)
-            (void)hipFuncSetAttribute((const void*)kth_key_kernel<32, T, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        hipLaunchKernelGGL((kth_key_kernel<32, T, true>), dim3(NB), dim3(1024), lds, s, qa, Pa, k, thr, off, P, w.elite, elite_count(w), mo);
-    }
+    // keys per thread by the population: the launch is bound by its per-key instructions, padding rounds cost
+    // as much as full ones
+#define MJMPC_SELECT_MOMENTS(NPER_)                                                                                          \
+    do {                                                                                                                     \
+        if (lds > 64 * 1024)                                                                                                 \
+            (void)hipFuncSetAttribute((const void*)kth_key_kernel<NPER_, T, true>, hipFuncAttributeMaxDynamicSharedMemorySize, \
+                                      (int)lds);                                                                             \
+        hipLaunchKernelGGL((kth_key_kernel<NPER_, T, true>), dim3(NB), dim3(1024), lds, s, qa, Pa, k, thr, off, P, w.elite,  \
+                           elite_count(w), mo);                                                                              \
+    } while (0)
+    if (Pa <= 4096) MJMPC_SELECT_MOMENTS(4);
+    else if (Pa <= 8192) MJMPC_SELECT_MOMENTS(8);
+    else if (Pa <= 16384) MJMPC_SELECT_MOMENTS(16);
+    else MJMPC_SELECT_MOMENTS(32);
+#undef MJMPC_SELECT_MOMENTS
     return hipGetLastError();
 }
 

@@ -2,6 +2,7 @@
 all-gather INSIDE the captured hipGraph, the combine kernel, the env step - on one GPU (world-size-1 RCCL group, a
 communicator that claims two ranks): tools/rccl_world1.py, run in a process of its own."""
 import os
+import socket
 import subprocess
 import sys
 
@@ -13,7 +14,11 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 def test_sharded_iteration_with_rccl_in_the_graph():
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
-    env.update(RANK="0", LOCAL_RANK="0", WORLD_SIZE="1", MASTER_ADDR="127.0.0.1", MASTER_PORT="29541",
+    s = socket.socket()                 # a free port (a fixed one can still be held by an earlier test's rendezvous)
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env.update(RANK="0", LOCAL_RANK="0", WORLD_SIZE="1", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
                HSA_ENABLE_IPC_MODE_LEGACY="0")
     out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "rccl_world1.py")], capture_output=True, text=True,
                          timeout=300, env=env)
