@@ -404,8 +404,9 @@ int mjmpc_q0_sum(int64_t P, int H, int A, double* d_out, void* d_ws, void* strea
  * 2 the appended row is read from d_row ('random': drawn by the host from np.random).            */
 int mjmpc_shift_mean(double* d_mean, int H, int A, int mode, const double* d_row, void* stream);
 /* The tail of Controller.optimize (controller.py:240-257: `_get_next_action`, `num_steps += 1`, `_shift`) in ONE launch
- * for device-resident controllers: d_action_out / h_action_mapped (float64 [A], either may be NULL; the latter is
- * mapped pinned host memory) <- mean[0]; the shift of mjmpc_shift_mean; *d_step_counter += 1 (may be NULL); and, when
+ * for device-resident controllers: d_action_out (float64 [A]) / h_action_mapped (float64 [A + 1], mapped pinned host
+ * memory: the action, then - behind a system-scope fence - the new step count as a completion flag; 0 without a
+ * counter) <- mean[0], either may be NULL; the shift of mjmpc_shift_mean; *d_step_counter += 1 (may be NULL); and, when
  * d_cov is not NULL, cov += cov_scale * diag(d_cov_diag) as in mjmpc_cov_add_diag (cem.py:89-95,
  * gaussian_dmd.py:107-113).  A <= 64.                                                                          */
 int mjmpc_step_tail(double* d_mean, int H, int A, int shift_mode, const double* d_row, double* d_action_out,

@@ -673,11 +673,9 @@ class OLGaussianMPC(Controller):
         the new step count; polling that flag returns the action as soon as it exists, while the rest of the
         graph (e.g. the captured env step) is still running - the next replay is enqueued behind it, so the GPU
         never waits for the host round trip.  (Sharded runs publish from the combine kernel after the all-gather.)
-        Other update paths: one stream synchronisation."""
+        Every tail of a captured iteration publishes this way: the fused MPPI / DMD-MPC update, the fused CEM step's
+        finish launch, and ``mjmpc_step_tail`` for everything else."""
         A = self.d_action
-        if not (self._fused_capable() or self._cem_fused()):        # (the fused CEM step's finish launch publishes the flag too)
-            self.dev.torch.cuda.current_stream(self.dev.device).synchronize()
-            return self._action_np[:A].copy()
         o = self._slot(self.num_steps)
         flag, want, spins = self._action_np, float(self.num_steps + 1), 0
         while flag[o + A] != want:

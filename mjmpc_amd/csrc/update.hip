@@ -1109,11 +1109,19 @@ __global__ void step_tail_kernel(double* __restrict__ mean, int H, int A, int mo
                                  long long* __restrict__ step_counter, double* __restrict__ cov,
                                  const double* __restrict__ d, double scale) {
     const int a = threadIdx.x;
-    if (a == 0 && step_counter) *step_counter += 1;
+    long long count = 0;
+    if (a == 0 && step_counter) count = (*step_counter += 1);
     if (a >= A) return;
     const double act = mean[a];
     if (action_out) action_out[a] = act;
-    if (action_host) action_host[a] = act;
+    // mapped pinned host memory: the action, then - behind a system-scope fence - the new step count as a completion flag
+    // (one wavefront: lane 0's flag write follows every lane's action write in program order), so that the host can pick
+    // the action up while the rest of the captured iteration (the real env's step) is still running
+    if (action_host) {
+        action_host[a] = act;
+        __threadfence_system();
+        if (a == 0) { action_host[A] = (double)count; __threadfence_system(); }
+    }
     for (int t = 0; t + 1 < H; ++t) mean[t * A + a] = mean[(t + 1) * A + a];
     mean[(H - 1) * A + a] = mode == 0 ? 0.0 : (mode == 1 ? (H >= 2 ? mean[(H - 2) * A + a] : act) : row[a]);
     if (cov) cov[a * A + a] += scale * (d ? d[a] : 1.0);
