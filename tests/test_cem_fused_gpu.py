@@ -102,8 +102,12 @@ def test_fused_step_degenerate_populations():
         dev._q0_view(ws, P).copy_(torch.from_numpy(q0).cuda())
         step = torch.full((1,), 4, dtype=torch.int64, device="cuda")
         act = torch.zeros(A, dtype=torch.float64, device="cuda")
-        dev.cem_fused_step(actions, k, 0.7, True, 1, act, None, step, (None, 0.25), None, 3, 0)
+        pin = torch.full((A + 1,), -1.0, dtype=torch.float64).pin_memory()
+        dev.cem_fused_step(actions, k, 0.7, True, 1, act, pin, step, (None, 0.25), None, 3, 0)
         torch.cuda.synchronize()
+        # mapped host copy: the action, then the new step count as the completion flag a captured loop polls
+        np.testing.assert_array_equal(pin[:A].numpy(), act.cpu().numpy())
+        assert pin[A].item() == 5.0
         ids = np.lexsort((np.arange(P), q0))[:k]                      # (q0, index) order: ties go to the smaller index
         el = actions.cpu().numpy()[ids]
         d = (el - mean0[None]).reshape(k * H, A)

@@ -612,6 +612,7 @@ def test_step_tail_is_action_shift_counter_and_covariance_growth(mode, grow):
     want_cov = cov if grow is None else cov + 0.3 * np.diag(diag if grow == "diag" else np.ones(An))
     np.testing.assert_array_equal(act.cpu().numpy(), mean[0])
     np.testing.assert_array_equal(pin[:An].numpy(), mean[0])
+    assert pin[An].item() == 42.0               # the completion flag behind the action: the new step count
     np.testing.assert_array_equal(dev.get_mean(), want)
     np.testing.assert_allclose(dev.get_cov(), want_cov, rtol=0, atol=1e-15)
     assert int(step.item()) == 42
