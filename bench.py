@@ -72,6 +72,9 @@ def parse(argv=None):
     ap.add_argument("--no-mono", action="store_true",
                     help="keep the control iteration in its separate launches (sampler, rollout, two update launches, env step) "
                          "instead of the one-launch iteration (mjmpc_arm_mppi_step)")
+    ap.add_argument("--no-tape", action="store_true",
+                    help="replay the captured iteration as a hipGraph instead of as the list of its library calls "
+                         "(Controller.enable_graph(tape=False); one GPU)")
     ap.add_argument("--lookahead", action="store_true",
                     help="enqueue iteration k+1 before waiting for the action of iteration k (the real env lives on the device, so "
                          "nothing the host provides enters an iteration); off by default: every optimize() then starts after the "
@@ -347,7 +350,7 @@ def main():
                 rollout_fn.fused = base_fn.fused
         ctrl.set_sim_state_fn = resident_state          # the "real" env lives on the device (step_state)
         if graphed:
-            ctrl.enable_graph(post_step=eng.step_state, mono=not args.no_mono, lookahead=args.lookahead)   # the env step is captured with the iteration
+            ctrl.enable_graph(post_step=eng.step_state, mono=not args.no_mono, lookahead=args.lookahead, tape=not args.no_tape)   # the env step is captured with the iteration
 
         def control_step():
             action, _ = ctrl.optimize(state)
@@ -535,6 +538,8 @@ def main():
     launch_kind = "hipGraph replay" if (graphed and not getattr(ctrl, "graph_fallback", False)) else "eager"
     if graphed and getattr(ctrl, "_graph", None) == "direct":
         launch_kind = "two kernels per iteration, launched directly"
+    elif graphed and launch_kind != "eager" and getattr(ctrl, "launch_mode", None):
+        launch_kind = ctrl.launch_mode          # "hipGraph replay" or "launch tape (n calls, k kernels)"
     out = {
         "metric": "particle-steps/sec (%s %s %dp x H%d per GPU, control loop incl. noise, rollout, update, shift)"
                   % (w["name"], args.controller.upper() if args.controller != "dmd" else "DMD-MPC", P_loc, H),

@@ -49,6 +49,10 @@ int mjmpc_abi_version(void);
 const char* mjmpc_last_error(void);
 /* Number of visible HIP devices (0 when there is no GPU / no driver). */
 int mjmpc_device_count(void);
+/* n_out[0] = kernel nodes, n_out[1] = nodes of any kind of a captured hipGraph_t (a host-side check: the controller
+ * compares the captured control iteration with a capture of its own launch tape before it trusts the tape; no reference
+ * counterpart). */
+int mjmpc_graph_kernel_nodes(void* hip_graph, int64_t* n_out);
 
 /* ---- arm engine: replaces the SubprocVecEnv worker pool for reacher_7dof-v0 ------------------
  * reference: mjmpc/envs/vec_env/subproc_vec_env.py:91-111 (worker start-up),

@@ -92,6 +92,7 @@ SIGNATURES = {
     "mjmpc_mt19937_stream_words": (_i64, [_i64]),
     "mjmpc_sample_noise_mt19937_jump": (_int, [_int, _vp, _i64, _dbl, ctypes.c_uint64, _vp, _vp, _vp, _i64, _i64, _int,
                                                  _i64, _vp, _vp, _vp]),
+    "mjmpc_graph_kernel_nodes": (_int, [_vp, ctypes.POINTER(ctypes.c_int64)]),
     "mjmpc_sample_noise": (_int, [_int, _vp, _i64, _int, _int, _vp, _vp, ctypes.c_uint64, ctypes.c_uint64, _i64, _vp, _int, _vp]),
 }
 
@@ -119,6 +120,33 @@ def load():
             fn.restype, fn.argtypes = res, args
         _LIB = lib
     return _LIB
+
+
+class recording:
+    """``with recording(tape):`` every call into the library made inside the block is also appended to ``tape`` as
+    (function, args) - the launch sequence of one control iteration, which ``Controller`` replays call by call where
+    that is cheaper than a hipGraph replay (control/controller.py ``_LaunchTape``)."""
+
+    def __init__(self, tape):
+        self.tape, self.saved = tape, {}
+
+    def __enter__(self):
+        lib = load()
+        for name in SIGNATURES:
+            fn = getattr(lib, name)
+            self.saved[name] = fn
+
+            def wrapper(*args, _fn=fn, _tape=self.tape):
+                _tape.append((_fn, args))
+                return _fn(*args)
+            setattr(lib, name, wrapper)
+        return self
+
+    def __exit__(self, *exc):
+        lib = load()
+        for name, fn in self.saved.items():
+            setattr(lib, name, fn)
+        return False
 
 
 def check(rc):

@@ -22,11 +22,13 @@ Extra constructor keywords (all optional, defaults reproduce the reference bit f
   device      CUDA device ordinal;  comm  particle-sharding communicator (see _device.py)
 """
 import copy
+import ctypes
 import inspect
 from abc import ABC, abstractmethod
 
 import numpy as np
 
+from .. import _lib
 from ._device import DeviceUpdater
 from .sharding import local_block
 from .control_utils import generate_noise
@@ -163,6 +165,31 @@ class _AlternatingGraphs:
         self.dev.mean, self.dev.mean_alt = self.dev.mean_alt, self.dev.mean
 
 
+class _LaunchTape:
+    """The captured control iteration as the list of library calls that make it up, replayed call by call on the current
+    stream.  On this runtime consecutive hipGraph replays are 9-13 us apart on the device whatever the host does
+    (tools/kernel_gaps.py), plain launches follow each other at once - so an iteration whose launches are ALL calls into
+    the library (checked by the owner: a capture of the tape's replay has as many kernel nodes as the captured iteration
+    itself) runs from its tape.  Arguments are the ones recorded under capture; the stream argument (last by this
+    library's convention) is replaced by the stream that is current at replay."""
+
+    def __init__(self, calls, recorded_stream, dev):
+        self.dev = dev
+        self.calls = []
+        for fn, args in calls:          # (calls that take no stream are host-side queries - sizes, addresses - not launches)
+            tail = args[-1] if args else None
+            tail = getattr(tail, "value", tail)
+            if tail is not None and tail == recorded_stream:
+                self.calls.append((fn, args[:-1]))
+
+    def replay(self):
+        s = self.dev.torch.cuda.current_stream(self.dev.device).cuda_stream
+        for fn, args in self.calls:
+            rc = fn(*args, s)
+            if rc:
+                _lib.check(rc)
+
+
 class OLGaussianMPC(Controller):
     """Open-loop Gaussian MPC: N(mean_action[t], cov_action) per horizon step."""
 
@@ -297,7 +324,7 @@ class OLGaussianMPC(Controller):
         return self._rollout_fn(self.local_particles, self.horizon, mean, delta, mode="open_loop")
 
     # -- hipGraph fast path ---------------------------------------------------------------------
-    def enable_graph(self, post_step=None, lookahead=False, mono=True):
+    def enable_graph(self, post_step=None, lookahead=False, mono=True, tape=True):
         """Capture one whole control iteration (noise -> rollout -> update -> action -> shift) as a
         hipGraph and replay it from ``optimize()``: one launch and one stream sync per step instead of
         ~12 launches.  Needs a device-resident pipeline: ``noise_mode='device'``, a rollout_fn made by
@@ -307,6 +334,10 @@ class OLGaussianMPC(Controller):
         ``mono``: where the engine offers it (``rollout_fn.mono``: MPPI / DMD-MPC with a static diagonal covariance on
         the arm engine) the iteration is ONE kernel - sampling, rollout, update, action, shift and, if ``post_step`` is
         that engine's own ``step_state``, the env step (``mjmpc_arm_mppi_step``).
+
+        ``tape`` (one GPU): an iteration of several launches runs from the recorded list of its library calls instead
+        of a hipGraph replay when that list is the whole iteration (``_LaunchTape``: consecutive graph replays are
+        ~10 us apart on the device, plain launches are not); ``launch_mode`` says which one is in use.
 
         ``lookahead``: the caller promises that the states it passes to ``optimize()`` carry no information - the real
         env lives on the device and ``post_step`` advances it - so iteration k + 1 depends on nothing the host provides.
@@ -326,6 +357,8 @@ class OLGaussianMPC(Controller):
         self._graph = None
         self._noise_valid = False
         self._want_mono = bool(mono)
+        self._want_tape = bool(tape)
+        self.launch_mode = "hipGraph replay"
         self._mono = False
         self._lookahead = bool(lookahead)
         self._ahead = 0                 # iterations enqueued beyond the ones whose action the host has taken
@@ -571,6 +604,7 @@ class OLGaussianMPC(Controller):
                 # one-kernel graph costs ~13 us between replays on the device side, a plain launch next to nothing)
                 self._bind_mono(env_step=True)
                 self._graph = "direct"
+                self.launch_mode = "launched directly"
             else:
                 self._capture_iteration()
         if self._graph is None:                 # capture failed: every rank has dropped to eager launches
@@ -580,11 +614,11 @@ class OLGaussianMPC(Controller):
                 raise RuntimeError("num_steps was changed while an iteration enqueued ahead was in flight")
             self._step_dev.fill_(self.num_steps)
             self._noise_valid = False
-        if self._noise_ahead() and not self._noise_valid:
-            self._draw_raw(self.local_particles, 0)             # the current step's samples (first step / after a jump)
-            self._noise_valid = True
-        if self._cem_in_kernel() and not self._noise_valid:
-            self.dev.factor_cov(self.filter_coeffs)             # the factor the first rollout colours its draws with
+        if not self._noise_valid:               # (first step / after a jump of the step counter; the tests below cost ~20 us)
+            if self._noise_ahead():
+                self._draw_raw(self.local_particles, 0)         # the current step's samples
+            elif self._cem_in_kernel():
+                self.dev.factor_cov(self.filter_coeffs)         # the factor the first rollout colours its draws with
             self._noise_valid = True
         replay = self._device_iteration if self._graph == "direct" else self._graph.replay
         if self._ahead == 0:
@@ -644,6 +678,16 @@ class OLGaussianMPC(Controller):
                         self._device_iteration()        # (swaps dev.mean / dev.mean_alt: the second pass is the way back)
                     graphs[key] = g
                 self._graph = _AlternatingGraphs(self.dev, graphs)
+            elif (getattr(self, "_want_tape", True) and self.dev.comm.world_size == 1
+                  and not getattr(self.dev.comm, "always_collective", False)):
+                # the iteration's library calls are recorded while it is captured; it then runs from that tape if the
+                # tape is the whole iteration (as many kernel nodes in a capture of its replay as in the capture itself)
+                tape = []
+                g = torch.cuda.CUDAGraph(keep_graph=True)
+                with torch.cuda.graph(g), _lib.recording(tape):
+                    cap_stream = torch.cuda.current_stream(self.dev.device).cuda_stream
+                    self._device_iteration()
+                self._graph = self._tape_or_graph(g, tape, cap_stream)
             else:
                 g = torch.cuda.CUDAGraph()
                 with torch.cuda.graph(g):
@@ -667,6 +711,29 @@ class OLGaussianMPC(Controller):
             # mean buffers, no one-launch mode
             self._mono = False
             self._mono_launch, self._mono_combine = {}, {}
+
+    def _tape_or_graph(self, g, tape, cap_stream):
+        """The launch tape of the iteration just captured in ``g`` if it reproduces the capture, else ``g``."""
+        torch = self.dev.torch
+        self.launch_mode = "hipGraph replay"
+        try:
+            t = _LaunchTape(tape, cap_stream, self.dev)
+            g2 = torch.cuda.CUDAGraph(keep_graph=True)
+            with torch.cuda.graph(g2):
+                t.replay()
+            n1, n2 = (ctypes.c_int64 * 2)(), (ctypes.c_int64 * 2)()
+            _lib.check(self.dev.lib.mjmpc_graph_kernel_nodes(ctypes.c_void_p(int(g.raw_cuda_graph())), n1))
+            _lib.check(self.dev.lib.mjmpc_graph_kernel_nodes(ctypes.c_void_p(int(g2.raw_cuda_graph())), n2))
+            del g2
+            # (kernel nodes AND nodes of any kind: a collective or a tensor copy inside the iteration is not a library call)
+            if n1[0] > 0 and n1[0] == n2[0] and n1[1] == n2[1]:
+                self.launch_mode = "launch tape (%d calls, %d kernels)" % (len(t.calls), n1[0])
+                return t
+        except Exception as e:         # (an older runtime without raw graph access, a call that cannot be re-captured ...)
+            import warnings
+            warnings.warn("launch tape not available (%s); replaying the hipGraph" % (e,))
+        g.instantiate()
+        return g
 
     def _wait_action(self):
         """The action of the replayed iteration.  The fused update writes it into mapped pinned memory followed by

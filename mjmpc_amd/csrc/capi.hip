@@ -98,6 +98,23 @@ int mjmpc_device_count(void) {
     return n;
 }
 
+int mjmpc_graph_kernel_nodes(void* hip_graph, int64_t* n_out) {
+    if (!hip_graph || !n_out) return fail(MJMPC_E_BADARG, "null argument");
+    size_t n = 0;
+    HIP_TRY(hipGraphGetNodes((hipGraph_t)hip_graph, nullptr, &n));
+    std::vector<hipGraphNode_t> nodes(n);
+    if (n) HIP_TRY(hipGraphGetNodes((hipGraph_t)hip_graph, nodes.data(), &n));
+    int64_t k = 0;
+    for (size_t i = 0; i < n; ++i) {
+        hipGraphNodeType t;
+        HIP_TRY(hipGraphNodeGetType(nodes[i], &t));
+        k += t == hipGraphNodeTypeKernel;
+    }
+    n_out[0] = k;
+    n_out[1] = (int64_t)n;
+    return 0;
+}
+
 static int arm_create_impl(mjmpc_arm_s* h, const double* blob, int n_blob) {
     std::vector<float> f32(blob, blob + n_blob);
     HIP_TRY(hipMalloc(&h->model_f32, sizeof(float) * n_blob));
