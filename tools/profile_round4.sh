@@ -65,4 +65,5 @@ for WL in reacher half_cheetah; do for p in S1 S2 S3 S4 F W; do
   f=$(find $OUT/${TAG}_${WL}_pmc$p -name "*counter_collection.csv" | head -1); [ -n "$f" ] && cp $f $OUT/${TAG}_${WL}_pmc_${p}_counter_collection.csv
 done; done
 rm -rf $OUT/${TAG}_*_pmcS1 $OUT/${TAG}_*_pmcS2 $OUT/${TAG}_*_pmcS3 $OUT/${TAG}_*_pmcS4 $OUT/${TAG}_*_pmcF $OUT/${TAG}_*_pmcW $OUT/${TAG}_prof_f64 $OUT/${TAG}_prof_cem $OUT/${TAG}_prof_tree
+[ "$TAG" = r04 ] && bash tools/profile_cem.sh > /dev/null 2>&1      # the CEM lines, kernel stats at 16384 and 4096, selection phases
 ls $OUT | grep $TAG
