@@ -896,6 +896,19 @@ __global__ __launch_bounds__(CEM_FIN_THREADS) void cem_finish_kernel(CemFinish f
     const double cnt = sum_strided(f.in, G, R);
     for (int j = tid; j < HA; j += CEM_FIN_THREADS) sumA[j] = sum_strided(f.in + 1 + j, G, R);
     __syncthreads();
+    // The action (row 0 of the new mean) is known here, before covariance and factor: it goes to mapped pinned host memory
+    // at once, followed - once those writes are visible system-wide - by the new step count as a completion flag (one
+    // wavefront: lane 0's flag write follows every lane's action write in program order).  The host picks the action up
+    // and enqueues the next iteration while this launch is still refitting, drawing, and the env step has not run.
+    if (blockIdx.x == 0 && tid < A) {
+        const double act = (1.0 - f.step) * f.mean_prev[tid] + f.step * (sumA[tid] / cnt);
+        if (f.action_out) f.action_out[tid] = act;
+        if (f.action_host) {
+            f.action_host[tid] = act;
+            __threadfence_system();
+            if (tid == 0) { f.action_host[A] = (double)(*f.step_prev + 1); __threadfence_system(); }
+        }
+    }
     if (f.mode == 0) {
         for (int a = tid; a < A; a += CEM_FIN_THREADS) {
             double sacc = 0.0;
@@ -959,18 +972,7 @@ __global__ __launch_bounds__(CEM_FIN_THREADS) void cem_finish_kernel(CemFinish f
         // new mean, action, shift (olgaussian_mpc.py:69-78, 116-129)
         for (int j = tid; j < HA; j += CEM_FIN_THREADS) sumA[j] = (1.0 - f.step) * f.mean_prev[j] + f.step * (sumA[j] / cnt);
         __syncthreads();
-        // mapped pinned host memory: the action, then - once those writes are visible system-wide - the new step count as
-        // a completion flag: the host picks the action up while this launch is still drawing and the env step has not run
-        if (tid < A) {
-            if (f.action_out) f.action_out[tid] = sumA[tid];
-            if (f.action_host) { f.action_host[tid] = sumA[tid]; __threadfence_system(); }
-        }
-        __syncthreads();
-        if (tid == 0) {
-            const long long count = *f.step_prev + 1;
-            if (f.step_counter) *f.step_counter = count;
-            if (f.action_host) { f.action_host[A] = (double)count; __threadfence_system(); }
-        }
+        if (tid == 0 && f.step_counter) *f.step_counter = *f.step_prev + 1;
         for (int j = tid; j < HA; j += CEM_FIN_THREADS) {
             double v = sumA[j];
             if (f.shift_mode >= 0) {
