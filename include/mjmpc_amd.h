@@ -230,6 +230,13 @@ int mjmpc_tree_set_state(mjmpc_tree_t h, const double* qpos, const double* qvel,
 int mjmpc_tree_set_shard_states(mjmpc_tree_t h, const double* states, int n_shards, void* stream);
 int mjmpc_tree_rollout(mjmpc_tree_t h, int dtype, int64_t P, int H, const double* d_mean, const void* d_noise,
                        void* d_costs, void* d_actions, void* d_obs, void* d_next_obs, void* stream);
+/* mjmpc_tree_rollout with the two fusions of mjmpc_arm_rollout_fused (round 4): d_filter_coeffs float64[3] or NULL - d_noise
+ * holds RAW samples, filtered inside the kernel (control_utils.py:32-33); d_gseq float64[H] + d_q0 float64[P] (both or
+ * neither) - d_q0[p] = sum_t gseq[t] * cost[p][t] = cost_to_go(costs, gamma_seq)[:, 0] (control_utils.py:37-46; +inf for a
+ * diverged rollout).  No observations. */
+int mjmpc_tree_rollout_fused(mjmpc_tree_t h, int dtype, int64_t P, int H, const double* d_mean, const void* d_noise,
+                             const double* d_filter_coeffs, const double* d_gseq, void* d_costs, void* d_actions,
+                             double* d_q0, void* stream);
 /* The "real" environment kept on the device, as mjmpc_arm_step_state (env.step of the reference's closed loop,
  * examples/example_mpc.py:165-168): one env step from the engine's state with d_action (device float64[nu]), the state
  * advanced in place; d_cost dtype[1], d_next_obs dtype[d_obs] or NULL.  mjmpc_tree_get_state reads qpos / qvel back. */

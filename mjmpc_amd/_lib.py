@@ -31,6 +31,7 @@ SIGNATURES = {
     "mjmpc_arm_rollout": (_int, [_vp, _int, _i64, _int, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "mjmpc_arm_rollout_cl": (_int, [_vp, _int, _i64, _int, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "mjmpc_arm_rollout_fused": (_int, [_vp, _int, _i64, _int, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "mjmpc_tree_rollout_fused": (_int, [_vp, _int, _i64, _int, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "mjmpc_arm_step_state": (_int, [_vp, _int, _vp, _vp, _vp, _vp]),
     "mjmpc_arm_mppi_combine": (_int, [_vp, _int, _vp, _int, _int, _vp, _vp, _vp, ctypes.c_double, _int, _vp, _vp, _int, _vp, _vp, _vp]),
     "mjmpc_arm_rollout_sampled": (_int, [_vp, _int, _i64, _int, _vp, _vp, _vp, _vp, _int, ctypes.c_uint64, ctypes.c_uint64, _i64, _vp,

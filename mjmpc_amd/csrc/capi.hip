@@ -790,6 +790,37 @@ int mjmpc_tree_rollout(mjmpc_tree_t h, int dtype, int64_t P, int H, const double
     return 0;
 }
 
+int mjmpc_tree_rollout_fused(mjmpc_tree_t h, int dtype, int64_t P, int H, const double* d_mean, const void* d_noise,
+                             const double* d_filter_coeffs, const double* d_gseq, void* d_costs, void* d_actions, double* d_q0,
+                             void* stream) {
+    if (!h || !d_mean || !d_costs) return fail(MJMPC_E_BADARG, "null argument");
+    if ((d_q0 != nullptr) != (d_gseq != nullptr)) return fail(MJMPC_E_BADARG, "d_q0 and d_gseq go together");
+    if (P < 0 || H < 0) return fail(MJMPC_E_BADARG, "negative size");
+    const int nss = h->n_state_shards > 1 ? h->n_state_shards : 1;
+    if (P % h->n_shards != 0 || P % nss != 0)
+        return fail(MJMPC_E_BADARG, "%lld particles do not divide into %d shards", (long long)P, std::max(h->n_shards, nss));
+    HIP_TRY(hipSetDevice(h->device));
+    hipStream_t s = (hipStream_t)stream;
+    mjmpc::TreeFusion fuse;
+    fuse.filt = d_filter_coeffs;
+    fuse.gseq = d_gseq;
+    fuse.q0_out = d_q0;
+    hipError_t e;
+    const double* st = nss > 1 ? h->shard_states : h->state;
+    if (dtype == MJMPC_F32)
+        e = mjmpc::launch_tree_rollout<float>(h->model_f32, h->n_shards, h->max_path, h->full, h->nv, st, (long)P, H, h->nu, d_mean,
+                                              (const float*)d_noise, (float*)d_costs, (float*)d_actions, nullptr, nullptr, h->diag,
+                                              s, nullptr, nullptr, nullptr, nss, h->gen, fuse);
+    else if (dtype == MJMPC_F64)
+        e = mjmpc::launch_tree_rollout<double>(h->model_f64, h->n_shards, h->max_path, h->full, h->nv, st, (long)P, H, h->nu, d_mean,
+                                               (const double*)d_noise, (double*)d_costs, (double*)d_actions, nullptr, nullptr,
+                                               h->diag, s, nullptr, nullptr, nullptr, nss, h->gen, fuse);
+    else
+        return fail(MJMPC_E_BADARG, "unknown dtype %d", dtype);
+    if (e != hipSuccess) return hip_fail(e, "tree_rollout_fused launch");
+    return 0;
+}
+
 int mjmpc_tree_rollout_cl(mjmpc_tree_t h, int dtype, int64_t P, int H, const double* d_weights, const void* d_noise,
                           void* d_costs, void* d_actions, void* d_obs, void* d_next_obs, void* stream) {
     if (!h || !d_weights || !d_costs) return fail(MJMPC_E_BADARG, "null argument");

@@ -15,10 +15,20 @@ namespace mjmpc {
 // mean f64 [H][A]; noise / cost / act / obs / nobs of T in the reference's C-order layouts (may be null except cost).
 // n_state_shards > 1: `state` holds one TREE_STATE_LEN vector per shard (per-worker start states); with both kinds of
 // shards their counts must agree.
+// Fusions riding in the rollout launch (as RolloutFusion of the arm kernel): the reference's recursive noise filter applied
+// to the raw samples on the fly (control_utils.py:32-33; filt = three float64 coefficients), and the discounted cost-to-go
+// of every particle, q0_out[p] = sum_t gseq[t] * cost[p][t] (control_utils.py:37-46 at t = 0; +inf for a diverged rollout).
+struct TreeFusion {
+    const double* filt = nullptr;
+    const double* gseq = nullptr;
+    double* q0_out = nullptr;
+};
+
 template <typename T>
 hipError_t launch_tree_rollout(const T* model, int n_model_shards, int max_path, bool full, int nv, const double* state, long P, int H,
                                int A, const double* mean, const T* noise, T* cost, T* act, T* obs, T* nobs, unsigned* diag,
                                hipStream_t stream, double* state_out = nullptr, const double* clw = nullptr,
-                               double* site_out = nullptr, int n_state_shards = 1, bool gen = false);
+                               double* site_out = nullptr, int n_state_shards = 1, bool gen = false,
+                               TreeFusion fuse = TreeFusion());
 
 }  // namespace mjmpc

@@ -1104,7 +1104,7 @@ __global__ __launch_bounds__(64 * wg_waves(DP, FRIC, sizeof(T), PL), min_waves(s
     const T* __restrict__ model_all, int model_stride, const double* __restrict__ state, int state_stride, long P, long shard_size, int H,
     int A, const double* __restrict__ mean,
     const T* __restrict__ noise, T* __restrict__ cost, T* __restrict__ act, T* __restrict__ obs, T* __restrict__ nobs,
-    unsigned* diag, double* state_out, const double* __restrict__ clw, double* site_out) {
+    unsigned* diag, double* state_out, const double* __restrict__ clw, double* site_out, TreeFusion fuse) {
     constexpr int WG_WAVES = wg_waves(DP, FRIC, sizeof(T), PL);
     constexpr int PPW = 64 / PL;            // particles per wavefront
     constexpr int A_SF = a_sf(PL);
@@ -1267,14 +1267,19 @@ __global__ __launch_bounds__(64 * wg_waves(DP, FRIC, sizeof(T), PL), min_waves(s
         if (!clw) mean_next = mean[l];
         if (noise && live) eps_next = noise[(pid * H) * A + l];
     }
+    // fused into the launch (TreeFusion): the recursive noise filter and the discounted cost-to-go
+    double fb0 = 1.0, fb1 = 0.0, fb2 = 0.0, fe1 = 0.0, fe2 = 0.0, q0acc = 0.0;
+    if (fuse.filt) { fb0 = fuse.filt[0]; fb1 = fuse.filt[1]; fb2 = fuse.filt[2]; }
+    double gs_next = (fuse.gseq && H > 0) ? fuse.gseq[0] : 0.0;
     for (int t = 0; t < H; ++t) {
         T u = T(0);
         const T eps_cur = eps_next;
-        const double mean_cur = mean_next;
+        const double mean_cur = mean_next, gs_cur = gs_next;
         if (has_u && t + 1 < H) {
             if (!clw) mean_next = mean[(t + 1) * A + l];
             if (noise && live) eps_next = noise[(pid * H + t + 1) * A + l];
         }
+        if (fuse.gseq && t + 1 < H) gs_next = fuse.gseq[t + 1];
         if (clw) {
             // mean_act = W' [obs; 1] with the observation this step starts from (gym_env_wrapper.py:135-136): every
             // lane weighs the entries it holds, one 32-lane sum per action
@@ -1308,7 +1313,16 @@ __global__ __launch_bounds__(64 * wg_waves(DP, FRIC, sizeof(T), PL), min_waves(s
             u = (T)mean_cur;
         }
         if (has_u) {
-            if (noise && live) u += eps_cur;
+            if (noise && live) {
+                T eps = eps_cur;
+                if (fuse.filt) {            // eps[t] = b0 eps[t] + b1 eps[t-1] + b2 eps[t-2], t >= 2 (control_utils.py:32-33)
+                    const double f = t >= 2 ? fb0 * (double)eps + fb1 * fe1 + fb2 * fe2 : (double)eps;
+                    fe2 = fe1;
+                    fe1 = f;
+                    eps = (T)f;
+                }
+                u += eps;
+            }
             if (act && live) act[(pid * H + t) * A + l] = u;        // unclipped (gym_env_wrapper.py:151)
         }
         // lane a holds action a; the dof it drives picks it up (motors may sit on any subset of the joints)
@@ -2615,6 +2629,7 @@ __global__ __launch_bounds__(64 * wg_waves(DP, FRIC, sizeof(T), PL), min_waves(s
                       (haxis[0] * M[T_TARGET_DIR] + haxis[1] * M[T_TARGET_DIR + 1] + haxis[2] * M[T_TARGET_DIR + 2]);
         }
         if (live && l == 0) cost[pid * H + t] = cst;
+        if (fuse.gseq) q0acc += gs_cur * (double)cst;
         // my link's coordinate(s) in MuJoCo's qpos layout (GEN: a ball's first link writes the quaternion, w first; a free
         // joint's translations are absolute positions; without GEN qadr = l, nq = nv)
         auto put_q = [&](T* dst, long o, int skip, T x_, T y_, T z_, T w_) {
@@ -2655,6 +2670,9 @@ __global__ __launch_bounds__(64 * wg_waves(DP, FRIC, sizeof(T), PL), min_waves(s
         if constexpr (GEN) { qy_prev = qy; qz_prev = qz; qw_prev = qw; }
         for (int k = 0; k < 3; ++k) hand_prev[k] = hand[k];
     }
+    // a rollout that diverged numerically carries a non-finite return: +inf - zero weight in the softmax updates, last in
+    // the elite ranking - instead of a NaN in the mean (as the arm kernel)
+    if (fuse.q0_out && live && l == 0) fuse.q0_out[pid] = fabs(q0acc) < (double)INFINITY ? q0acc : (double)INFINITY;
     // the "real env" kept on the device (mjmpc_tree_step_state): particle 0 leaves its state where the next rollout
     // reads it (the launch has one particle; `state` was read before the first step)
     if (state_out && pid == 0 && dof) {
@@ -2680,6 +2698,7 @@ struct TreeLaunchArgs {
     unsigned* diag;
     double *state_out, *site_out;
     hipStream_t stream;
+    TreeFusion fuse;
 };
 template <typename T>
 hipError_t launch_tree_rollout_dense(int max_path, int nv, bool gen, const T* model, const T* noise, T* cost, T* act, T* obs, T* nobs,
@@ -2694,7 +2713,7 @@ hipError_t launch_tree_rollout_dense(int max_path, int nv, bool gen, const T* mo
                            dim3((unsigned)((a.shard + per_wg - 1) / per_wg), (unsigned)a.n_shards),                   \
                            dim3(64 * wg_waves(DP_, FR_, sizeof(T), PL_)), 0, a.stream, model, a.model_stride, a.state, \
                            a.state_stride, a.P, a.shard, a.H, a.A, a.mean, noise, cost, act, obs, nobs, a.diag,       \
-                           a.state_out, a.clw, a.site_out);                                                           \
+                           a.state_out, a.clw, a.site_out, a.fuse);                                                   \
     }
 
 #ifdef TREE_DENSE_TU
@@ -2728,7 +2747,7 @@ template <typename T>
 hipError_t launch_tree_rollout(const T* model, int n_model_shards, int max_path, bool full, int nv, const double* state, long P, int H,
                                int A, const double* mean, const T* noise, T* cost, T* act, T* obs, T* nobs, unsigned* diag,
                                hipStream_t stream, double* state_out, const double* clw, double* site_out, int n_state_shards,
-                               bool gen) {
+                               bool gen, TreeFusion fuse) {
     if (P <= 0 || H <= 0) return hipSuccess;
     if (gen && !full) return hipErrorInvalidValue;
     if ((state_out || site_out) && P != 1) return hipErrorInvalidValue;
@@ -2750,6 +2769,7 @@ hipError_t launch_tree_rollout(const T* model, int n_model_shards, int max_path,
     a.state_out = state_out;
     a.site_out = site_out;
     a.stream = stream;
+    a.fuse = fuse;
     // hinge trees in air with up to 8 frictionless contact points keep the lean instantiation; slide joints, springs,
     // friction cones, more points or a medium take the full one (three Jacobians per point, 16 points, fluid forces),
     // which also comes with 16 lanes per particle for models of up to 16 dofs (the reference's swimmer and cheetah)
@@ -2777,9 +2797,9 @@ hipError_t launch_tree_rollout(const T* model, int n_model_shards, int max_path,
 }
 
 template hipError_t launch_tree_rollout<float>(const float*, int, int, bool, int, const double*, long, int, int, const double*,
-                                               const float*, float*, float*, float*, float*, unsigned*, hipStream_t, double*, const double*, double*, int, bool);
+                                               const float*, float*, float*, float*, float*, unsigned*, hipStream_t, double*, const double*, double*, int, bool, TreeFusion);
 template hipError_t launch_tree_rollout<double>(const double*, int, int, bool, int, const double*, long, int, int, const double*,
-                                                const double*, double*, double*, double*, double*, unsigned*, hipStream_t, double*, const double*, double*, int, bool);
+                                                const double*, double*, double*, double*, double*, unsigned*, hipStream_t, double*, const double*, double*, int, bool, TreeFusion);
 #endif
 #undef MJMPC_TREE_LAUNCH
 #undef MJMPC_TREE_LAUNCH_G

@@ -150,6 +150,26 @@ class TreeRolloutEngine:
                       self._stream()))
         return costs, act, obs, nobs
 
+    def rollout_fused(self, num_particles, horizon, mean, raw_noise, filter_coeffs, gamma_seq, q0_out=None):
+        """Device-resident rollout with the noise filter and the discounted cost-to-go fused into the launch
+        (``mjmpc_tree_rollout_fused``, as ``ArmRolloutEngine.rollout_fused``).  All arguments are CUDA tensors
+        (``filter_coeffs`` may be None; ``q0_out``: a float64 [P] tensor the cost-to-go is written to instead of the engine's
+        own buffer).  Returns (costs, actions, q0)."""
+        if num_particles % self.num_shards != 0:
+            raise AssertionError("Number of particles must be divisible by number of shards")
+        torch = _torch()
+        P, H, A = int(num_particles), int(horizon), self.d_action
+        mean_d = self._as_device(mean, torch.float64, (H, A))
+        noise_d = self._as_device(raw_noise, self._tdtype, (P, H, A))
+        costs = self._buffer("costs", (P, H))
+        act = self._buffer("act", (P, H, A))
+        q0 = q0_out if q0_out is not None else self._buf.get("q0")
+        if q0 is None or q0.shape[0] != P:
+            q0 = self._buf["q0"] = torch.empty(P, dtype=torch.float64, device=self.device)
+        _lib.check(self._lib.mjmpc_tree_rollout_fused(self._h, self._code, P, H, _ptr(mean_d), _ptr(noise_d), _ptr(filter_coeffs),
+                                                      _ptr(gamma_seq), _ptr(costs), _ptr(act), _ptr(q0), self._stream()))
+        return costs, act, q0
+
     def step(self, action):
         """Advance the engine's own state by one env step (a one-particle rollout, state round trip through the host:
         the tree engine keeps no device-resident "real env").  Returns (next_obs, reward)."""

@@ -433,3 +433,41 @@ def test_diverged_rollouts_are_counted_apart_from_solver_failures():
     rew = eng.rollout(64, 4, mean, noise)[1]
     assert not np.isfinite(rew).all()
     assert eng.diverged_substeps() > 0 and eng.solver_failures() == 0
+
+
+@pytest.mark.parametrize("model,dtype", [("cheetah", "f64"), ("cheetah", "f32"), ("cartpole", "f64")])
+def test_tree_rollout_fused_equals_filter_rollout_and_cost_to_go(model, dtype):
+    """``mjmpc_tree_rollout_fused`` (round 4): the recursive noise filter (control_utils.py:32-33) and the discounted
+    cost-to-go at t = 0 (control_utils.py:37-46) inside the rollout launch = filter pass + plain rollout + numpy."""
+    import torch
+    from mjmpc_amd.control._device import DeviceUpdater
+    from mjmpc_amd.envs.tree_engine import TreeRolloutEngine
+    if model == "cheetah":
+        from mjmpc_amd.models.half_cheetah import half_cheetah_raw
+        raw, start = half_cheetah_raw(), None
+    else:
+        from mjmpc_amd.models.synthetic import start_state, synthetic_raw
+        raw = synthetic_raw(model)
+        start = start_state(model, raw)
+    eng = TreeRolloutEngine(raw, dtype=dtype)
+    if start is not None:
+        eng.set_env_state(start)
+    P, H, A = 512, 12, eng.d_action
+    assert hasattr(eng, "rollout_fused")
+    filt, gamma = [0.25, 0.8, 0.1], 0.97
+    dev = DeviceUpdater(H, A, gamma ** np.arange(H))
+    rs = np.random.RandomState(3)
+    mean = torch.from_numpy(0.2 * rs.standard_normal((H, A))).cuda()
+    raw_noise = dev.sample_noise(P, 0.3 * np.eye(A), filt, 11, 0, dtype=dtype, filtered=False).clone()
+    filtered = dev.sample_noise(P, 0.3 * np.eye(A), filt, 11, 0, dtype=dtype, filtered=True).clone()
+    coeffs = torch.tensor(filt, dtype=torch.float64, device="cuda")
+    c1, a1, q1 = (x.clone() for x in eng.rollout_fused(P, H, mean, raw_noise, coeffs, dev.gseq))
+    c0, a0, _, _ = eng.rollout_device(P, H, mean, filtered)
+    torch.cuda.synchronize()
+    tol = 1e-12 if dtype == "f64" else 2e-5
+    np.testing.assert_allclose(a1.cpu().numpy(), a0.cpu().numpy(), rtol=0, atol=tol)
+    ctol = 1e-9 if dtype == "f64" else 5e-3
+    np.testing.assert_allclose(c1.cpu().numpy(), c0.cpu().numpy(), rtol=ctol, atol=ctol)
+    want = (c1.cpu().numpy().astype(np.float64) * (gamma ** np.arange(H))[None]).sum(1)
+    np.testing.assert_allclose(q1.cpu().numpy(), want, rtol=1e-12 if dtype == "f64" else 1e-6, atol=1e-12)
+    assert eng.solver_failures() == 0
