@@ -471,3 +471,41 @@ def test_tree_rollout_fused_equals_filter_rollout_and_cost_to_go(model, dtype):
     want = (c1.cpu().numpy().astype(np.float64) * (gamma ** np.arange(H))[None]).sum(1)
     np.testing.assert_allclose(q1.cpu().numpy(), want, rtol=1e-12 if dtype == "f64" else 1e-6, atol=1e-12)
     assert eng.solver_failures() == 0
+
+
+def test_cem_on_a_tree_model_takes_the_fused_step_and_matches_the_eager_loop():
+    """With ``rollout_fused`` the tree engine gives CEM its q0 path: a captured iteration is the fused CEM step (A <= 8) and
+    walks through the same closed loop as the eager, launch-by-launch controller."""
+    import torch
+    from mjmpc_amd.control import CEM
+    from mjmpc_amd.envs.arm_engine import make_device_rollout_fn
+    from mjmpc_amd.envs.tree_engine import TreeRolloutEngine
+    from mjmpc_amd.models.half_cheetah import half_cheetah_raw
+
+    def loop(graph):
+        e = TreeRolloutEngine(half_cheetah_raw(), dtype="f64")
+        c = CEM(d_state=e.d_state, d_obs=e.d_obs, d_action=e.d_action, action_lows=e.action_lows, action_highs=e.action_highs,
+                horizon=8, init_cov=0.3, base_action="null", elite_frac=0.1, beta=0.05, cov_type="full", num_particles=512,
+                step_size=0.8, gamma=1.0, n_iters=1, filter_coeffs=[0.25, 0.8, 0.0], seed=5, noise_mode="device",
+                noise_dtype="f64")
+        c.rollout_fn = make_device_rollout_fn(e)
+        c.set_sim_state_fn = lambda s: None
+        e.set_env_state(dict(qpos=0.05 * np.arange(e.model.nv), qvel=np.zeros(e.model.nv)))
+        if graph:
+            c.enable_graph(post_step=e.step_state)
+        acts = []
+        for _ in range(6):
+            a, _ = c.optimize({"resident": True})
+            acts.append(np.array(a))
+            if not graph:
+                e.step_state(a)
+        torch.cuda.synchronize()
+        assert e.solver_failures() == 0
+        if graph:
+            assert c._cem_fused() and c.launch_mode.startswith("launch tape")
+        return np.array(acts), c.cov_action.copy()
+
+    a_e, c_e = loop(False)
+    a_g, c_g = loop(True)
+    np.testing.assert_allclose(a_g, a_e, rtol=0, atol=1e-8)
+    np.testing.assert_allclose(c_g, c_e, rtol=1e-7, atol=1e-10)
