@@ -112,3 +112,27 @@ def test_a_tape_that_misses_a_launch_is_refused():
     torch.cuda.synchronize()
     assert c.launch_mode == "hipGraph replay"
     assert np.all(np.isfinite(a0))
+
+
+def test_tape_is_recorded_again_after_a_reset():
+    """``reset()`` drops the captured iteration; the next ``optimize()`` captures and records afresh - the episode after the
+    reset equals the first one (same seed, same start state), under the tape as under the hipGraph."""
+    import torch
+    from mjmpc_amd.control import CEM
+    from mjmpc_amd.envs.arm_engine import ArmRolloutEngine, make_device_rollout_fn
+    from mjmpc_amd.models.reacher7dof import reacher7dof_raw
+    eng = ArmRolloutEngine(reacher7dof_raw(), dtype="f64")
+    c = CEM(d_state=eng.d_state, d_obs=eng.d_obs, d_action=7, horizon=12, num_particles=1024, n_iters=1, init_cov=0.6,
+            elite_frac=0.1, step_size=0.7, beta=0.05, cov_type="full", action_lows=eng.action_lows, action_highs=eng.action_highs,
+            filter_coeffs=[0.25, 0.8, 0.0], seed=9, noise_mode="device", gamma=0.99, base_action="null")
+    c.rollout_fn = make_device_rollout_fn(eng)
+    c.set_sim_state_fn = lambda s: None
+    c.enable_graph(post_step=eng.step_state)
+    episodes = []
+    for _ in range(2):
+        c.reset()
+        eng.set_env_state(START)
+        episodes.append(np.array([c.optimize({})[0] for _ in range(4)]))
+        torch.cuda.synchronize()
+        assert c.launch_mode.startswith("launch tape")
+    np.testing.assert_array_equal(episodes[0], episodes[1])
