@@ -1238,38 +1238,68 @@ __global__ void fused_final_kernel(const double* __restrict__ partial, int nb, i
                          nn.offset + (unsigned long long)*step_snapshot, nn.particle_offset, nn.diag_only);
         return;
     }
-    extern __shared__ double sh[];          // sc[nb] | ss[nb] | nm[H*A] | red[4]
-    const int HA = H * A, rec = 2 + HA;
+    // sc[nb] | ss[nb] | nm[H*A] | red[32] | part[nsl * H*A].  A workgroup of 1024 threads (launches with many partials:
+    // the merge is a chain of nb / 8 trips to L2 per entry, 16 us of the critical path at 256 partials) splits the partials
+    // into nsl = 4 slices, one per 256 threads, and adds the slices in order; 256 threads keep one slice and the order of
+    // the earlier rounds.  Either way the order is fixed: bit-reproducible.
+    extern __shared__ double sh[];
+    const int HA = H * A, rec = 2 + HA, tid = threadIdx.x, nth = blockDim.x, nw = nth >> 6;
+    const int nsl = nth >= 512 ? nth / 256 : 1, sl = nsl > 1 ? tid / 256 : 0, jt = nsl > 1 ? tid % 256 : tid, jstep = nsl > 1 ? 256 : nth;
     double* sc = sh;
     double* ss = sh + nb;
     double* nm = ss + nb;
     double* red = nm + HA;
+    double* part = red + 32;
     double m = -INFINITY;
-    for (int b = threadIdx.x; b < nb; b += blockDim.x) m = fmax(m, partial[(long)b * rec]);
+    for (int b = tid; b < nb; b += nth) m = fmax(m, partial[(long)b * rec]);
     m = wave_max(m);
-    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
+    if ((tid & 63) == 0) red[tid >> 6] = m;
     __syncthreads();
-    const double M = fmax(fmax(red[0], red[1]), fmax(red[2], red[3]));
-    for (int b = threadIdx.x; b < nb; b += blockDim.x) {
+    double M = red[0];
+    for (int w = 1; w < nw; ++w) M = fmax(M, red[w]);
+    for (int b = tid; b < nb; b += nth) {
         sc[b] = exp(partial[(long)b * rec] - M);
         ss[b] = partial[(long)b * rec + 1];
     }
     __syncthreads();
     double S = 0.0;
-    for (int b = 0; b < nb; ++b) S += sc[b] * ss[b];                            // every thread, same order
-    for (int j = threadIdx.x; j < HA; j += blockDim.x) {
+    if (nsl == 1) {
+        for (int b = 0; b < nb; ++b) S += sc[b] * ss[b];                        // every thread, same order
+    } else {                    // (1024 partials: the serial walk is 8 us of LDS round trips) strided sums, then a fixed tree
+        double sloc = 0.0;
+        for (int b = tid; b < nb; b += nth) sloc += sc[b] * ss[b];
+        sloc = wave_sum(sloc);
+        if ((tid & 63) == 0) red[16 + (tid >> 6)] = sloc;
+        __syncthreads();
+        for (int w = 0; w < nw; ++w) S += red[16 + w];
+    }
+    const int per = (nb + nsl - 1) / nsl, b0 = sl * per, b1 = b0 + per < nb ? b0 + per : nb;
+    for (int j = jt; j < HA; j += jstep) {
         double W = 0.0;
-        int b = 0;
-        for (; b + 8 <= nb; b += 8) {                   // eight loads in flight; same order of summation
+        int b = b0;
+        for (; b + 8 <= b1; b += 8) {                   // eight loads in flight; same order of summation
             double v[8];
 #pragma unroll
             for (int u = 0; u < 8; ++u) v[u] = partial[(long)(b + u) * rec + 2 + j];
 #pragma unroll
             for (int u = 0; u < 8; ++u) W += sc[b + u] * v[u];
         }
-        for (; b < nb; ++b) W += sc[b] * partial[(long)b * rec + 2 + j];
-        if (record) record[2 + j] = W;
-        nm[j] = (1.0 - step) * mean[j] + step * (W / S);
+        for (; b < b1; ++b) W += sc[b] * partial[(long)b * rec + 2 + j];
+        if (nsl > 1) {
+            part[sl * HA + j] = W;
+        } else {
+            if (record) record[2 + j] = W;
+            nm[j] = (1.0 - step) * mean[j] + step * (W / S);
+        }
+    }
+    if (nsl > 1) {
+        __syncthreads();
+        for (int j = tid; j < HA; j += nth) {
+            double W = part[j];
+            for (int q = 1; q < nsl; ++q) W += part[q * HA + j];
+            if (record) record[2 + j] = W;
+            nm[j] = (1.0 - step) * mean[j] + step * (W / S);
+        }
     }
     if (threadIdx.x == 0) {
         if (record) { record[0] = M; record[1] = S; }
@@ -1593,14 +1623,20 @@ hipError_t mppi_fused_update(const double* q0, const T* actions, double lam, dou
     NextNoise nn{};
     int extra = 0;
     long long* snap = nullptr;
+    // many partials (P > 4096): the merging workgroup takes 1024 threads and four slices of the partials
+    const int fth = nb > 64 ? 1024 : BLK, nsl = fth >= 512 ? fth / 256 : 1;
     if (next && next->noise) {
         nn = *next;
-        extra = nblocks(P * ((H + 3) / 4) * A, BLK);
+        extra = nblocks(P * ((H + 3) / 4) * A, fth);
         snap = (long long*)(w.scratch + 8);
     }
     hipLaunchKernelGGL(fused_partial_kernel<T>, dim3(nb), dim3(BLK), 0, s, q0, actions, lam, P, HA, w.partial, nn.d_step,
                        snap);
-    hipLaunchKernelGGL(fused_final_kernel<T>, dim3(1 + extra), dim3(BLK), sizeof(double) * (2 * nb + HA + 4), s, w.partial, nb,
+    const size_t lds = sizeof(double) * (2 * (size_t)nb + HA + 32 + (nsl > 1 ? (size_t)nsl * HA : 0));
+    if (lds > 150 * 1024) return hipErrorInvalidValue;
+    if (lds > 64 * 1024)
+        (void)hipFuncSetAttribute((const void*)fused_final_kernel<T>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(fused_final_kernel<T>, dim3(1 + extra), dim3(fth), lds, s, w.partial, nb,
                        H, A, lam, step, shift_mode, (double)P, mean, action_out, record, value, action_host, step_counter,
                        nn, P, (const long long*)snap);
     return hipGetLastError();
@@ -1613,7 +1649,7 @@ hipError_t mppi_fused_combine(const double* records, int G, double P_total, doub
                               int H, int A, double* mean, double* action_out, double* value, double* action_host,
                               long long* step_counter, hipStream_t s) {
     const int HA = H * A;
-    hipLaunchKernelGGL(fused_final_kernel<double>, dim3(1), dim3(BLK), sizeof(double) * (2 * G + HA + 4), s, records, G, H,
+    hipLaunchKernelGGL(fused_final_kernel<double>, dim3(1), dim3(BLK), sizeof(double) * (2 * G + HA + 32), s, records, G, H,
                        A, lam, step, shift_mode, P_total, mean, action_out, (double*)nullptr, value, action_host,
                        step_counter, NextNoise{}, 0L, (const long long*)nullptr);
     return hipGetLastError();
