@@ -23,7 +23,13 @@
 extern "C" {
 #endif
 
-#define MJMPC_ABI_VERSION 1
+/* Bumped whenever a blob / state layout, a buffer size or a signature changes incompatibly; mjmpc_amd/_lib.py refuses a
+ * library whose mjmpc_abi_version() differs from the one it was written for.
+ *   1: rounds 1-3.
+ *   2: round 4 - MJMPC_TREE_BLOB_LEN 3116 -> 3929 (solref / solimp scalars replaced by the table of solver sets, new
+ *      field order), MJMPC_TREE_STATE_LEN 70 -> 78 (qpos[40] | qvel[32] | target[3] | 3 reserved), tree set / get state
+ *      take qpos[nq], and mjmpc_step_tail writes A + 1 doubles into h_action_mapped (action + completion flag). */
+#define MJMPC_ABI_VERSION 2
 
 #define MJMPC_F32 0
 #define MJMPC_F64 1

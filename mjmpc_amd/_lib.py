@@ -4,11 +4,13 @@ There is NO CPU fallback: if the library is missing or no GPU is visible, the pr
 """
 import ctypes
 import os
+import threading
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("MJMPC_AMD_LIB", os.path.join(_HERE, "libmjmpc_amd.so"))
 
 F32, F64 = 0, 1
+ABI_VERSION = 2      # include/mjmpc_amd.h MJMPC_ABI_VERSION this binding was written for
 
 _vp = ctypes.c_void_p
 _i64 = ctypes.c_int64
@@ -119,6 +121,10 @@ def load():
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(lib, name)
             fn.restype, fn.argtypes = res, args
+        got = lib.mjmpc_abi_version()
+        if got != ABI_VERSION:
+            raise MjmpcError("%s speaks ABI version %d, this binding expects %d (blob / state layouts differ): rebuild "
+                             "it with `python -m mjmpc_amd.build --force`" % (LIB_PATH, got, ABI_VERSION))
         _LIB = lib
     return _LIB
 
@@ -128,17 +134,24 @@ class recording:
     (function, args) - the launch sequence of one control iteration, which ``Controller`` replays call by call where
     that is cheaper than a hipGraph replay (control/controller.py ``_LaunchTape``)."""
 
+    _lock = threading.Lock()        # the wrappers sit on the process-wide CDLL: one recording at a time
+
     def __init__(self, tape):
         self.tape, self.saved = tape, {}
+        self.owner = None
 
     def __enter__(self):
         lib = load()
+        if not recording._lock.acquire(timeout=60.0):
+            raise MjmpcError("another thread has been recording a launch tape for a minute")
+        self.owner = threading.get_ident()
         for name in SIGNATURES:
             fn = getattr(lib, name)
             self.saved[name] = fn
 
-            def wrapper(*args, _fn=fn, _tape=self.tape):
-                _tape.append((_fn, args))
+            def wrapper(*args, _fn=fn, _tape=self.tape, _me=self.owner):
+                if threading.get_ident() == _me:        # (another thread's calls - a second controller - are not this tape's)
+                    _tape.append((_fn, args))
                 return _fn(*args)
             setattr(lib, name, wrapper)
         return self
@@ -147,6 +160,7 @@ class recording:
         lib = load()
         for name, fn in self.saved.items():
             setattr(lib, name, fn)
+        recording._lock.release()
         return False
 
 

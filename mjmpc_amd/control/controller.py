@@ -153,6 +153,12 @@ def resident_state(state):
 resident_state.ignores_state = True
 
 
+def _keep_graph_supported(torch):
+    """``torch.cuda.CUDAGraph(keep_graph=True)`` + ``raw_cuda_graph()`` arrived together (what the launch tape's acceptance
+    test reads); a torch without them replays the plain hipGraph instead of losing the captured path altogether."""
+    return hasattr(torch.cuda.CUDAGraph, "raw_cuda_graph")
+
+
 class _AlternatingGraphs:
     """Two captured iterations, one per direction of the mean's double buffer: ``replay()`` runs the one that reads the
     buffer that is the mean now, then makes the buffer it wrote the mean."""
@@ -277,6 +283,8 @@ class OLGaussianMPC(Controller):
         if not self._cov_stale and (self._cov_seen is None or not np.array_equal(self._cov_host, self._cov_seen)):
             self.dev.set_cov(self._cov_host)
             self._cov_seen = np.array(self._cov_host, copy=True)
+            return True         # a covariance went up: samples drawn ahead / a factor left on the device are stale
+        return False
 
     @property
     def local_particles(self):
@@ -588,7 +596,14 @@ class OLGaussianMPC(Controller):
             # behind it and silently take effect one step late (like num_steps below)
             raise RuntimeError("mean_action / cov_action were assigned while an iteration enqueued ahead "
                                "(enable_graph(lookahead=True)) was in flight; call reset() first, or run without lookahead")
-        self._sync_in()
+        if self._sync_in() and self._graph is not None:
+            # A covariance assigned on the host between two captured steps: this step's samples were already drawn (by
+            # the previous update / finish launch) or would be coloured with the factor that launch left behind - draw
+            # them again from the covariance just uploaded.  A static covariance is also baked into the capture (bound
+            # sampler parameters, the one-launch iteration's diagonal test): capture again.
+            self._noise_valid = False
+            if self._static_cov():
+                self._graph = None
         if not getattr(self._set_sim_state_fn, "ignores_state", False):
             self._set_sim_state_fn(copy.deepcopy(state) if state is not None else None)
         if self._graph is None:
@@ -679,7 +694,7 @@ class OLGaussianMPC(Controller):
                     graphs[key] = g
                 self._graph = _AlternatingGraphs(self.dev, graphs)
             elif (getattr(self, "_want_tape", True) and self.dev.comm.world_size == 1
-                  and not getattr(self.dev.comm, "always_collective", False)):
+                  and not getattr(self.dev.comm, "always_collective", False) and _keep_graph_supported(torch)):
                 # the iteration's library calls are recorded while it is captured; it then runs from that tape if the
                 # tape is the whole iteration (as many kernel nodes in a capture of its replay as in the capture itself)
                 tape = []

@@ -230,6 +230,7 @@ def load_mjcf(path, hand_site="finger", target_site="target", frame_skip=2, task
     DEF_SOL = ((0.02, 1.0), (0.9, 0.95, 0.001, 0.5, 2.0))
 
     inertia_from_geom_always = comp is not None and comp.get("inertiafromgeom", "auto") == "true"
+    autolimits = comp is not None and comp.get("autolimits", "false") == "true"
 
     def parse_geom(e, active, has_inertial=False):
         ga = lambda k, d=None: dfl.attr("geom", e, active, k, d)        # noqa: E731
@@ -308,7 +309,18 @@ def load_mjcf(path, hand_site="finger", target_site="target", frame_skip=2, task
             raise ValueError("joint margin / ref are not supported")
         if j.tag == "freejoint":            # MJCF: <freejoint/> takes no defaults: no damping, armature or friction loss
             return RawJoint(axis=[0.0, 0.0, 1.0], range=[0.0, 0.0], limited=False, name=j.get("name", ""), type=JOINT_FREE)
-        limited = ja("limited", "false") == "true" and t != "free"      # (MuJoCo ignores limits on free joints)
+        lim_attr = ja("limited", "false")
+        if lim_attr == "auto":          # MuJoCo >= 2.2.2: with <compiler autolimits="true"> a range implies the limit
+            if autolimits:
+                lim_attr = "true" if ja("range") is not None else "false"
+            elif ja("range") is not None:
+                raise ValueError("joint %r: limited=\"auto\" with a range needs <compiler autolimits=\"true\"> (MuJoCo "
+                                 "refuses the model too)" % j.get("name", "?"))
+            else:
+                lim_attr = "false"
+        if lim_attr not in ("true", "false"):
+            raise ValueError("joint limited must be true, false or auto")
+        limited = lim_attr == "true" and t != "free"      # (MuJoCo ignores limits on free joints)
         lim_set = fric_set = None
         if limited:
             lim_set = (tuple(_floats(ja("solreflimit", "0.02 1"))), tuple(_floats(ja("solimplimit", "0.9 0.95 0.001 0.5 2"))))
@@ -317,8 +329,9 @@ def load_mjcf(path, hand_site="finger", target_site="target", frame_skip=2, task
         if floss != 0.0:
             fric_set = (tuple(_floats(ja("solreffriction", "0.02 1"))), tuple(_floats(ja("solimpfriction", "0.9 0.95 0.001 0.5 2"))))
             friction_solver.append(fric_set)
-        ang = deg if t == "hinge" else 1.0      # (a hinge's range and spring reference are angles)
-        rng = [x * ang for x in _floats(ja("range"), 2, [0.0, 0.0])]
+        ang = deg if t == "hinge" else 1.0      # (a hinge's range and spring reference are angles ...
+        rng_ang = deg if t in ("hinge", "ball") else 1.0        # ... and so is a ball joint's range: the cone's half angle)
+        rng = [x * rng_ang for x in _floats(ja("range"), 2, [0.0, 0.0])]
         jtype = {"hinge": JOINT_HINGE, "slide": JOINT_SLIDE, "ball": JOINT_BALL, "free": JOINT_FREE}[t]
         return RawJoint(axis=_floats(ja("axis"), 3, [0.0, 0.0, 1.0]), range=rng,
                         limited=limited, damping=float(ja("damping", "0")), armature=float(ja("armature", "0")),
@@ -371,6 +384,8 @@ def load_mjcf(path, hand_site="finger", target_site="target", frame_skip=2, task
                 else:
                     I = Ri @ np.diag(_floats(c.get("diaginertia"), 3)) @ Ri.T
                 inertial = RawInertial(float(c.get("mass")), ipos, I)
+        if inertia_from_geom_always and inertial is not None and e.findall("geom"):
+            inertial = None             # inertiafromgeom="true": MuJoCo computes the body's inertia from its geoms and ignores <inertial>
         if e.get("mocap", "false") == "true":
             raise ValueError("mocap bodies are not supported")
         geoms_ = [parse_geom(g, active, has_inertial=inertial is not None) for g in e.findall("geom")]

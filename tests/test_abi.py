@@ -25,7 +25,7 @@ def test_library_exports_every_declared_symbol():
     for n in names:
         assert hasattr(lib, n), n
     assert sorted(_lib.SIGNATURES) == names          # the ctypes table covers the header exactly
-    assert lib.mjmpc_abi_version() == 1
+    assert lib.mjmpc_abi_version() == _lib.ABI_VERSION == int(re.search(r"#define MJMPC_ABI_VERSION (\d+)", open(os.path.join(ROOT, "include", "mjmpc_amd.h")).read()).group(1))
 
 
 def test_no_cpu_fallback():

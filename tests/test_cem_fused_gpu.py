@@ -136,3 +136,57 @@ def test_rollout_that_draws_its_own_full_covariance_samples(P, H, cov_type, dtyp
     np.testing.assert_allclose(a1, a0, rtol=0, atol=tol)
     np.testing.assert_allclose(c1, c0, rtol=1e-7 if dtype == "f64" else 1e-2, atol=1e-12)
     assert e1.solver_failures() == 0
+
+
+@pytest.mark.parametrize("kind,P", [("cem_in_kernel", 2048), ("cem_buffer", 2048), ("cem_unfused", 2048), ("dmd_cov", 1024),
+                                     ("mppi_static", 1024)])
+def test_covariance_assigned_on_the_host_between_captured_steps(kind, P):
+    """``cov_action`` assigned between two captured ``optimize()`` calls (the reference lets users edit it at any time) takes
+    effect in the NEXT step's samples, as in the eager loop: the samples the previous finish launch drew ahead - or the
+    factor it left for the rollout launch that colours its own draws - are made again from the uploaded covariance
+    (they were not, so the rollout sampled the old covariance while the refit blended with the new one)."""
+    import torch
+    from mjmpc_amd.control import CEM, DMDMPC, MPPI
+    from mjmpc_amd.envs.arm_engine import ArmRolloutEngine, make_device_rollout_fn
+    from mjmpc_amd.models.reacher7dof import reacher7dof_raw
+    rs = np.random.RandomState(3)
+    B = rs.standard_normal((7, 7))
+    new_cov = 0.05 * B @ B.T + 0.2 * np.eye(7)
+    if kind == "mppi_static":
+        new_cov = np.diag(np.diag(new_cov))
+
+    def run(graph):
+        eng = ArmRolloutEngine(reacher7dof_raw(), dtype="f64")
+        eng.set_env_state(MOVING)
+        kw = dict(d_state=eng.d_state, d_obs=eng.d_obs, d_action=7, horizon=12, num_particles=P, n_iters=1, gamma=1.0,
+                  action_lows=eng.action_lows, action_highs=eng.action_highs, filter_coeffs=FILT, seed=11,
+                  noise_mode="device", base_action="null")
+        if kind.startswith("cem"):
+            c = CEM(init_cov=0.5, elite_frac=0.1, step_size=0.8, beta=0.02, cov_type="full", **kw)
+            c._want_cem_fused = kind != "cem_unfused"
+            c._want_cem_in_kernel = kind == "cem_in_kernel"
+        elif kind == "dmd_cov":
+            c = DMDMPC(init_cov=0.5, beta=0.02, lam=0.2, step_size=0.8, update_cov=True, cov_type="full", **kw)
+        else:
+            c = MPPI(init_cov=0.5, lam=0.2, step_size=0.8, alpha=1, **kw)
+        c.rollout_fn = make_device_rollout_fn(eng)
+        c.set_sim_state_fn = lambda s: None
+        if graph:
+            c.enable_graph(post_step=eng.step_state)
+        acts = []
+        for k in range(6):
+            if k == 3:
+                c.cov_action = new_cov.copy()
+            a, _ = c.optimize({})
+            if not graph:
+                eng.step_state(a)
+            acts.append(a)
+        torch.cuda.synchronize()
+        assert not getattr(c, "graph_fallback", False)
+        return np.array(acts), c.mean_action.copy(), c.cov_action.copy()
+
+    a_g, m_g, c_g = run(True)
+    a_e, m_e, c_e = run(False)
+    np.testing.assert_allclose(a_g, a_e, rtol=0, atol=1e-9)
+    np.testing.assert_allclose(m_g, m_e, rtol=0, atol=1e-9)
+    np.testing.assert_allclose(c_g, c_e, rtol=1e-8, atol=1e-12)

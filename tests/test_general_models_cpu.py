@@ -345,6 +345,35 @@ def test_degrees_and_radians_load_the_same_model(tmp_path):
     assert abs(rd.bodies[0].joint.range[1] - np.pi / 2) < 1e-15
 
 
+def test_ball_range_in_degrees_inertial_under_inertiafromgeom_and_autolimits(tmp_path):
+    """ADVICE r4 (MuJoCo's compiler semantics): a BALL joint's range is an angle too; inertiafromgeom="true" ignores an
+    explicit <inertial>; limited="auto" follows <compiler autolimits>."""
+    ball = """<body name="a" pos="0 0 1"><joint name="j" type="ball" limited="true" range="0 60"/>
+      <geom type="capsule" size="0.02 0.1" density="500"/><site name="finger"/></body>"""
+    rd, _ = _model(tmp_path, ball, name="bd.xml", head=HEAD.replace("radian", "degree"))
+    assert abs(rd.bodies[0].joint.range[1] - np.pi / 3) < 1e-15
+    rr, _ = _model(tmp_path, ball.replace("0 60", "0 %.17g" % (np.pi / 3)), name="br.xml")
+    np.testing.assert_allclose(rd.to_flat(), rr.to_flat(), rtol=0, atol=1e-15)
+    # an explicit inertial beside a geom: used under "auto", ignored under "true"
+    body = """<body name="a" pos="0 0 1"><joint name="j" type="hinge" axis="0 1 0"/><inertial pos="0 0 0" mass="7" diaginertia="1 1 1"/>
+      <geom type="sphere" size="0.1" density="1000"/><site name="finger"/></body>"""
+    ra, _ = _model(tmp_path, body, name="ia.xml")
+    rt, _ = _model(tmp_path, body, name="it.xml", head=HEAD.replace('inertiafromgeom="auto"', 'inertiafromgeom="true"'))
+    assert ra.bodies[0].inertial is not None and ra.bodies[0].inertial.mass == 7.0
+    assert rt.bodies[0].inertial is None
+    m_geom = 1000 * 4 / 3 * np.pi * 0.1 ** 3
+    from mjmpc_amd.models.compile_tree import body_inertials
+    np.testing.assert_allclose(body_inertials(rt, {})[2][0], m_geom, rtol=1e-12)
+    np.testing.assert_allclose(body_inertials(ra, {})[2][0], 7.0, rtol=1e-12)
+    # limited="auto": a range implies the limit only with autolimits
+    auto = """<body name="a" pos="0 0 1"><joint name="j" type="hinge" axis="0 1 0" limited="auto" range="-1 1"/>
+      <joint name="k" type="hinge" axis="1 0 0" limited="auto"/><geom type="sphere" size="0.1"/><site name="finger"/></body>"""
+    r1, _ = _model(tmp_path, auto, name="al.xml", head=HEAD.replace("<compiler ", '<compiler autolimits="true" '))
+    assert [b.joint.limited for b in r1.bodies] == [True, False]
+    with pytest.raises(ValueError, match="autolimits"):
+        _model(tmp_path, auto, name="al2.xml")
+
+
 def test_loader_refuses_what_is_not_modelled(tmp_path):
     for body, extra, msg in [
         ('<body name="a"><joint/><geom type="cylinder" size="0.1 0.1"/><site name="finger"/></body>', "", "geom type"),
