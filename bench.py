@@ -602,6 +602,8 @@ def main():
         gc.collect()
         torch.cuda.synchronize()
         dist.barrier()
+        if comm is not None:
+            comm.close()            # (the library's own RCCL communicator, TorchDistComm.lib_collectives)
         dist.destroy_process_group()
 
 

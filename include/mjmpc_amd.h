@@ -29,7 +29,9 @@ extern "C" {
  *   2: round 4 - MJMPC_TREE_BLOB_LEN 3116 -> 3929 (solref / solimp scalars replaced by the table of solver sets, new
  *      field order), MJMPC_TREE_STATE_LEN 70 -> 78 (qpos[40] | qvel[32] | target[3] | 3 reserved), tree set / get state
  *      take qpos[nq], and mjmpc_step_tail writes A + 1 doubles into h_action_mapped (action + completion flag). */
-#define MJMPC_ABI_VERSION 2
+/*   3: round 5 - rollouts emulate MuJoCo's reset on instability (finite costs where version 2 returned +inf;
+ *      mjmpc_arm_diverged). */
+#define MJMPC_ABI_VERSION 3
 
 #define MJMPC_F32 0
 #define MJMPC_F64 1
@@ -253,10 +255,14 @@ int mjmpc_tree_get_state(mjmpc_tree_t h, double* qpos, double* qvel, void* strea
 int mjmpc_tree_rollout_cl(mjmpc_tree_t h, int dtype, int64_t P, int H, const double* d_weights, const void* d_noise,
                           void* d_costs, void* d_actions, void* d_obs, void* d_next_obs, void* stream);
 int mjmpc_tree_solver_failures(mjmpc_tree_t h, uint32_t* count);
-/* Particle-substeps since create whose constraint solution was not finite: rollouts that diverged (MuJoCo would reset
- * such a simulation, mj_checkAcc [EXT]; here their costs become +inf and the updates give them no weight).  They are not
- * counted by mjmpc_tree_solver_failures. */
+/* Resets since create: particle-substeps in which MuJoCo's mj_checkPos / mj_checkVel / mj_checkAcc [EXT] would have found a NaN
+ * or an entry beyond mjMAXVAL = 1e10 in qpos / qvel / qacc and called mj_resetData (the rollouts of
+ * mjmpc/envs/gym_env_wrapper.py:125-153 run through mj_step).  The kernels do what MuJoCo does: the particle goes on from
+ * qpos0 with zero velocity, and with zero controls until its env step ends (mj_resetData zeroes data.ctrl, which
+ * do_simulation wrote once before its frame_skip substeps), so its costs stay finite.  Not counted by
+ * mjmpc_*_solver_failures.  (Since ABI version 3; before, such particles carried a +inf return.) */
 int mjmpc_tree_diverged(mjmpc_tree_t h, uint32_t* count);
+int mjmpc_arm_diverged(mjmpc_arm_t h, uint32_t* count);
 
 /* rollout_fn over the reference's two analytic numpy envs (stateless; every pointer is a device
  * pointer): kind 0 = PendulumEnv (mjmpc/envs/basic/pendulum.py:33-50; d_params = [max_speed,
@@ -274,6 +280,23 @@ int mjmpc_analytic_rollout(int kind, const double* d_params, int n_state, int n_
 /* Number of (particle, substep) constraint solves whose active set had not settled after the
  * iteration cap since engine creation (synchronises the device).  0 in every test.               */
 int mjmpc_arm_solver_failures(mjmpc_arm_t h, uint32_t* count);
+
+/* ---- the exchange of a sharded run, issued from the library ---------------------------------------
+ * reference: SubprocVecEnv gathers its workers' results through pipes (mjmpc/envs/vec_env/subproc_vec_env.py:161-186); here
+ * each rank (one process per GPU) contributes one small float64 record per control iteration and every rank combines the
+ * gathered records identically.  The all-gather is RCCL's, on the iteration's stream; issuing it through this
+ * ABI instead of torch.distributed makes the sharded iteration a sequence of LIBRARY calls, which runs from the launch tape
+ * / as direct launches like the one-GPU loop (no hipGraph replay gap).  RCCL is bound at run time (dlopen of the copy the
+ * process already holds); without it these entries fail with MJMPC_E_NOGPU and callers keep torch.distributed.
+ *   mjmpc_comm_unique_id   rank 0: 128 opaque bytes (ncclGetUniqueId) to hand to every rank by any means
+ *   mjmpc_comm_create      every rank, collectively (ncclCommInitRank) on HIP device `device`
+ *   mjmpc_comm_all_gather_f64   d_recv[world][count] <- every rank's d_send[count] (device pointers; may be captured)  */
+#define MJMPC_COMM_ID_BYTES 128
+typedef struct mjmpc_comm_s* mjmpc_comm_t;
+int mjmpc_comm_unique_id(void* id_out);
+int mjmpc_comm_create(const void* id_bytes, int world_size, int rank, int device, mjmpc_comm_t* out);
+int mjmpc_comm_all_gather_f64(mjmpc_comm_t c, const double* d_send, double* d_recv, int64_t count, void* stream);
+int mjmpc_comm_destroy(mjmpc_comm_t c);
 
 /* ---- sampling-distribution updates: the device side of Controller._update_distribution --------
  * All functions below are stateless; `d_ws` is a caller-owned device workspace of at least

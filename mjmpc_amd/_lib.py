@@ -10,7 +10,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("MJMPC_AMD_LIB", os.path.join(_HERE, "libmjmpc_amd.so"))
 
 F32, F64 = 0, 1
-ABI_VERSION = 2      # include/mjmpc_amd.h MJMPC_ABI_VERSION this binding was written for
+ABI_VERSION = 3      # include/mjmpc_amd.h MJMPC_ABI_VERSION this binding was written for
 
 _vp = ctypes.c_void_p
 _i64 = ctypes.c_int64
@@ -56,6 +56,7 @@ SIGNATURES = {
     "mjmpc_analytic_rollout": (_int, [_int, _vp, _int, _int, _vp, _int, _i64, _int, _vp, _vp, _vp, _vp, _vp, _vp, _int,
                                       _vp]),
     "mjmpc_arm_solver_failures": (_int, [_vp, ctypes.POINTER(ctypes.c_uint32)]),
+    "mjmpc_arm_diverged": (_int, [_vp, ctypes.POINTER(ctypes.c_uint32)]),
     "mjmpc_update_workspace_bytes": (_i64, [_i64, _int, _int]),
     "mjmpc_softmax_record_len": (_int, [_int, _int, _int]),
     "mjmpc_traj_cost": (_int, [_int, _i64, _int, _int, _vp, _vp, _int, _vp, _vp]),
@@ -96,6 +97,10 @@ SIGNATURES = {
     "mjmpc_sample_noise_mt19937_jump": (_int, [_int, _vp, _i64, _dbl, ctypes.c_uint64, _vp, _vp, _vp, _i64, _i64, _int,
                                                  _i64, _vp, _vp, _vp]),
     "mjmpc_graph_kernel_nodes": (_int, [_vp, ctypes.POINTER(ctypes.c_int64)]),
+    "mjmpc_comm_unique_id": (_int, [_vp]),
+    "mjmpc_comm_create": (_int, [_vp, _int, _int, _int, ctypes.POINTER(_vp)]),
+    "mjmpc_comm_all_gather_f64": (_int, [_vp, _vp, _vp, _i64, _vp]),
+    "mjmpc_comm_destroy": (_int, [_vp]),
     "mjmpc_sample_noise": (_int, [_int, _vp, _i64, _int, _int, _vp, _vp, ctypes.c_uint64, ctypes.c_uint64, _i64, _vp, _int, _vp]),
 }
 

@@ -33,15 +33,58 @@ class SingleProcessComm:
 
 
 class TorchDistComm:
-    """One process per GPU over torch.distributed (backend "nccl" = RCCL over xGMI; "gloo" in CPU tests)."""
+    """One process per GPU over torch.distributed (backend "nccl" = RCCL over xGMI; "gloo" in CPU tests).
 
-    def __init__(self, group=None):
+    ``library_collectives`` (default: on where the backend is RCCL; ``MJMPC_TORCH_COLLECTIVES=1`` in the environment turns it
+    off): the float64 all-gathers of the control iteration are issued by libmjmpc_amd.so itself on a communicator of its
+    own (``mjmpc_comm_*``: the ranks of this group, the id handed out through one torch broadcast) - the same RCCL
+    collective, but a LIBRARY call, so that a sharded iteration runs from the launch tape / as direct launches like the
+    one-GPU loop instead of a hipGraph replay (controller.py).  Call ``close()`` before the process group
+    is destroyed."""
+
+    def __init__(self, group=None, library_collectives=None):
+        import os
         import torch.distributed as dist
         self._dist, self._group = dist, group
         self.rank = dist.get_rank(group)
         self.world_size = dist.get_world_size(group)
         self.backend = dist.get_backend(group)
         self._out = {}
+        self._lib_comm = None               # the library's communicator, made on first use
+        self._gather_ranks = self.world_size
+        if library_collectives is None:
+            library_collectives = self.backend == "nccl" and not os.environ.get("MJMPC_TORCH_COLLECTIVES")
+        self.lib_collectives = bool(library_collectives) and self.backend == "nccl"
+
+    def _library_comm(self, device):
+        """ncclCommInitRank of the library's own communicator over the ranks of this group (collective; outside any
+        stream capture: the controllers' dry run / first eager iteration gets here first)."""
+        import torch
+        lib = _lib.load()
+        ident = torch.zeros(128, dtype=torch.uint8, device=device)
+        if self.rank == 0:
+            buf = (ctypes.c_ubyte * 128)()
+            _lib.check(lib.mjmpc_comm_unique_id(buf))
+            ident.copy_(torch.frombuffer(bytearray(buf), dtype=torch.uint8))
+        src = self._dist.get_global_rank(self._group, 0) if self._group is not None else 0
+        self._dist.broadcast(ident, src=src, group=self._group)
+        raw = bytes(ident.cpu().numpy().tobytes())
+        h = ctypes.c_void_p()
+        _lib.check(lib.mjmpc_comm_create(ctypes.c_char_p(raw), self._dist.get_world_size(self._group), self._dist.get_rank(self._group),
+                                         device.index if device.index is not None else torch.cuda.current_device(), ctypes.byref(h)))
+        self._lib_comm = (lib, h)
+
+    def close(self):
+        if self._lib_comm is not None:
+            lib, h = self._lib_comm
+            self._lib_comm = None
+            lib.mjmpc_comm_destroy(h)
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
     def all_gather(self, t):
         import torch
@@ -49,8 +92,34 @@ class TorchDistComm:
         out = self._out.get(key)            # persistent receive buffer: a captured graph replays into it
         if out is None:
             out = self._out[key] = torch.empty(self.world_size * t.numel(), dtype=t.dtype, device=t.device)
+        if self.lib_collectives and t.is_cuda and t.dtype == torch.float64:
+            if self._lib_comm is None:
+                self._library_comm(t.device)
+            lib, h = self._lib_comm
+            src = t.reshape(-1).contiguous()
+            if src.data_ptr() != t.data_ptr():
+                self._keep = src            # (a copy made for contiguity must outlive the asynchronous collective)
+            _lib.check(lib.mjmpc_comm_all_gather_f64(h, ctypes.c_void_p(src.data_ptr()), ctypes.c_void_p(out.data_ptr()), src.numel(),
+                                                     ctypes.c_void_p(torch.cuda.current_stream(t.device).cuda_stream)))
+            return out.reshape(self.world_size, t.numel())
         self._dist.all_gather_into_tensor(out, t.reshape(-1).contiguous(), group=self._group)   # flat: gloo insists
         return out.reshape(self.world_size, t.numel())
+
+    def all_gather_launcher(self, t):
+        """``launch()`` = ``all_gather(t)`` into its persistent buffer with the arguments bound once (the host leg of a
+        sharded control step: one C call on the stream that is current when it runs)."""
+        out = self.all_gather(t)            # (makes the buffer and, the first time, the library's communicator)
+        if not (self.lib_collectives and self._lib_comm is not None and t.is_contiguous()):
+            return lambda: self.all_gather(t)
+        import torch
+        lib, h = self._lib_comm
+        fn, check, dev = lib.mjmpc_comm_all_gather_f64, _lib.check, t.device
+        args = (h, ctypes.c_void_p(t.data_ptr()), ctypes.c_void_p(out.data_ptr()), t.numel())
+        stream = torch.cuda.current_stream
+
+        def launch(_keep=(t, out)):
+            check(fn(*args, ctypes.c_void_p(stream(dev).cuda_stream)))
+        return launch
 
     def all_gather_flat(self, t):
         return self.all_gather(t).reshape(-1)

@@ -430,8 +430,9 @@ class OLGaussianMPC(Controller):
         """Host covariance for the sampler, or None when the covariance adapts on the device."""
         return self._cov_host if self._static_cov() else None
 
-    def _bind_mono(self, env_step):
-        """Bind the fused iteration's arguments once (``rollout_fn.mono_launcher``): per step it is one C call."""
+    def _bind_mono(self, env_step, direct=False):
+        """Bind the fused iteration's arguments once (``rollout_fn.mono_launcher``): per step it is one C call.
+        ``direct``: the launchers are never called under stream capture (the stream is bound too)."""
         n_loc = self.local_particles
         chol, coeffs, _ = self.dev.prepare_noise(self._cov_host, self.filter_coeffs)
         fc = np.asarray(self.filter_coeffs, np.float64)
@@ -447,13 +448,17 @@ class OLGaussianMPC(Controller):
         # other; _device_iteration swaps them afterwards and picks the launcher by the tensor that is the mean then)
         self._mono_launch, self._mono_combine = {}, {}
         recs = self.dev.comm.all_gather(self._mono_rec) if sharded else None   # (the persistent receive buffer, [G][2 + H A])
+        self._mono_gather = None
+        if sharded:
+            mk = getattr(self.dev.comm, "all_gather_launcher", None)
+            self._mono_gather = mk(self._mono_rec) if (mk and direct) else (lambda: self.dev.comm.all_gather(self._mono_rec))
         for src, dst in ((self.dev.mean, self.dev.mean_alt), (self.dev.mean_alt, self.dev.mean)):
             self._mono_launch[id(src)], _ = self._rollout_fn.mono_launcher(
                 n_loc, self.horizon, src, dst, self.dev.gseq, coeffs, chol, self.seed_val, 0, self.dev.comm.rank * n_loc,
                 self._step_dev, self.lam, self.step_size, _SHIFT_MODES[self.base_action], action_out=self._action_dev,
                 action_slots=None if sharded else self._action_pin, record=self._mono_rec,
                 env_step=self._mono_steps_env and not sharded,
-                bind_stream=not sharded)        # (sharded: the launcher runs under stream capture)
+                bind_stream=direct or not sharded)     # (sharded, captured: the launcher runs under stream capture)
             if sharded:         # behind the all-gather: merge the G records, update + shift, action, env step - one launch
                 self._mono_combine[id(src)] = self._rollout_fn.combine_launcher(
                     recs, recs.shape[0], self.horizon, src, dst, self._step_dev, self.step_size,
@@ -497,7 +502,7 @@ class OLGaussianMPC(Controller):
             key = id(self.dev.mean)
             self._mono_launch[key]()
             if self.dev.comm.world_size > 1:
-                self.dev.comm.all_gather(self._mono_rec)        # (into the buffer the combine launch is bound to)
+                self._mono_gather()                             # (into the buffer the combine launch is bound to)
                 self._mono_combine[key]()
             # the new mean was written to the other buffer: it is the mean now
             self.dev.mean, self.dev.mean_alt = self.dev.mean_alt, self.dev.mean
@@ -614,10 +619,11 @@ class OLGaussianMPC(Controller):
             # action | step flag, two slots: one-launch iterations publish into slot (step & 1), the others into slot 0
             self._action_pin = torch.zeros(2 * (self.d_action + 1), dtype=torch.float64).pin_memory()
             self._action_np = self._action_pin.numpy()
-            if self._mono and self.dev.comm.world_size == 1:
-                # one kernel per iteration: nothing to capture - the launch is enqueued directly (a hipGraph replay of a
-                # one-kernel graph costs ~13 us between replays on the device side, a plain launch next to nothing)
-                self._bind_mono(env_step=True)
+            if self._mono and (self.dev.comm.world_size == 1 or getattr(self.dev.comm, "lib_collectives", False)):
+                # two launches per iteration - sharded: rollout + record, the library's all-gather, the combine launch -
+                # and nothing to capture: they are enqueued directly (a hipGraph replay costs 9-13 us between replays on
+                # the device side, plain launches next to nothing)
+                self._bind_mono(env_step=True, direct=True)
                 self._graph = "direct"
                 self.launch_mode = "launched directly"
             else:
@@ -693,8 +699,11 @@ class OLGaussianMPC(Controller):
                         self._device_iteration()        # (swaps dev.mean / dev.mean_alt: the second pass is the way back)
                     graphs[key] = g
                 self._graph = _AlternatingGraphs(self.dev, graphs)
-            elif (getattr(self, "_want_tape", True) and self.dev.comm.world_size == 1
-                  and not getattr(self.dev.comm, "always_collective", False) and _keep_graph_supported(torch)):
+            elif (getattr(self, "_want_tape", True) and _keep_graph_supported(torch)
+                  and (getattr(self.dev.comm, "lib_collectives", False)
+                       or (self.dev.comm.world_size == 1 and not getattr(self.dev.comm, "always_collective", False)))):
+                # (sharded runs: the exchange is a library call too when the communicator issues it through the C ABI -
+                # TorchDistComm.lib_collectives; a torch.distributed collective is not, and such an iteration stays a graph)
                 # the iteration's library calls are recorded while it is captured; it then runs from that tape if the
                 # tape is the whole iteration (as many kernel nodes in a capture of its replay as in the capture itself)
                 tape = []

@@ -12,6 +12,14 @@ namespace mjmpc {
 //   shard_size          > 0: particles [k*shard_size, (k+1)*shard_size) use model block k (dynamics randomization:
 //                       every shard of the reference's worker pool simulates its own perturbed model)
 //   state_shard_size    > 0: likewise for the start state: shard k starts from state vector k
+//   reset_rec           MuJoCo's reset on instability (mj_checkPos / mj_checkVel / mj_checkAcc -> mj_resetData, [EXT]; the
+//                       rollouts of gym_env_wrapper.py:125-153 run through it): one record of ARM_RESET_LEN float64 per model
+//                       block - qpos[8] | qvel[8] ONE SUBSTEP AFTER the reset state (qpos0 = 0, zero velocity, zero
+//                       controls) | the tracked site[3] AT the reset state | sin[8] | cos[8] of that qpos.  A particle whose qpos / qvel hold a NaN or an
+//                       entry beyond 1e10 when a substep begins restarts that substep from the reset state, one whose
+//                       acceleration does continues from the record; its controls are zero until the env step ends.
+//                       nullptr: no resets (e.g. the launch that makes the record: one particle, frame_skip 1).
+constexpr int ARM_RESET_LEN = 35;
 struct RolloutFusion {
     long shard_size = 0;
     long state_shard_size = 0;
@@ -19,6 +27,7 @@ struct RolloutFusion {
     const double* filt = nullptr;
     const double* gseq = nullptr;
     double* q0_out = nullptr;
+    const double* reset_rec = nullptr;
 };
 
 // TWO launches per control iteration (mjmpc_arm_mppi_step).  The rollout kernel draws its own samples, keeps the actions
@@ -47,6 +56,7 @@ struct MonoStep {
     double* state_io = nullptr;
     void* step_cost = nullptr;              // T[1]
     void* step_nobs = nullptr;              // T[2 nv + 6]
+    const double* reset_rec = nullptr;      // the real env's reset record (RolloutFusion::reset_rec of its model block)
 };
 long mono_record_doubles(long groups, int H, int A);
 

@@ -559,11 +559,65 @@ __device__ __forceinline__ void limit_row(const MT& M, T q, T v, T& sig, T& D, T
     }
 }
 
+// MuJoCo's reset on instability (mj_checkPos / mj_checkVel / mj_checkAcc -> mj_resetData [EXT]).
+// ResetCtl::rst = the reset record of my model block (RolloutFusion::reset_rec), nullptr: no resets.  ONE test per substep,
+// where it ends (arm_back: the acceleration, the integrated qpos and qvel): a NaN or an entry beyond mjMAXVAL = 1e10 in
+//   the acceleration -> mj_checkAcc: the particle goes on from the record (the state one substep after the reset state), bit 0;
+//   qpos / qvel      -> the NEXT mj_step's mj_checkPos / mj_checkVel: noted (bit 1) and applied where that substep begins
+//                       (arm_front) - until then the state, e.g. in the next observation, is what MuJoCo shows too.
+// Either way the particle's controls are zero until its env step ends (bit 0; mj_resetData zeroes data.ctrl, which
+// do_simulation wrote once before its frame_skip calls of sim.step()).  `any` is wave-uniform (a scalar register): a wave
+// none of whose particles ever reset pays the test in arm_back and two scalar branches per substep, nothing else.  Every
+// role of a particle group takes the same decisions from the same (q, v, qacc), so the two waves of a group stay in step.
+struct ResetCtl {
+    bool any = false;           // some particle of this wavefront has reset, or has a reset pending
+    bool count = false;         // per lane: a live particle (its resets are counted)
+};
+// per particle and wavefront (the two waves of a DUO group keep their own copy: they pass the same points at their own pace):
+// 1 zero controls | 2 reset pending | 4 the latest arm_back reset on the acceleration - in a spare slot of the particle's LDS
+// block, read and written on the rare path only (a register of its own cost the fused iteration's kernel, the one with the
+// least room, copies in its hot loops)
+template <int ROLE, typename T>
+__device__ __forceinline__ int rflags(const T* ldsM) { return (int)ldsM[PSTRIDE - 4 + (ROLE == SOLVE ? 1 : 0)]; }
+template <int ROLE, typename T>
+__device__ __forceinline__ void rflags_set(T* ldsM, int f) { ldsM[PSTRIDE - 4 + (ROLE == SOLVE ? 1 : 0)] = (T)f; }
+// where the record lives is asked for only on the rare path (a callable): held in registers through the substep it cost
+// the fused iteration's kernel - the one with the least room - scalar spills in its hot loops (measured: +4 % per launch)
+struct NoResetRecord {
+    __device__ __forceinline__ const double* operator()() const { return nullptr; }
+};
+__device__ __forceinline__ unsigned long long particle_lanes(int lane) { return 0x5555ull << ((lane & 0x30) | (lane & 1)); }
+template <typename T>
+__device__ __forceinline__ bool mj_is_bad(T x) { return !(fabs(x) <= T(1e10)); }       // mju_isBad
+// the start state of a rollout (the first mj_step's mj_checkPos / mj_checkVel)
+template <int ROLE, typename T>
+__device__ __forceinline__ void reset_check_start(ResetCtl& rc, T q, T v, int lane, T* ldsM) {
+    const unsigned long long bal = __ballot(mj_is_bad(q) || mj_is_bad(v));
+    if (bal != 0ull) {
+        rc.any = true;
+        if (bal & particle_lanes(lane)) rflags_set<ROLE>(ldsM, 2);
+    }
+}
+
 template <int ROLE, typename T, typename MT>
 __device__ __forceinline__ void arm_front(const MT& M, const ArmInts& I, T& q, T& v, T& aw, T& sq, T& cq,
                                           int& rows, T tau_act, T* ldsM, int lane, int l8, T* site,
-                                          unsigned* diag, bool& free_step, Stamps& ST) {
+                                          unsigned* diag, bool& free_step, Stamps& ST, ResetCtl* rc = nullptr) {
     free_step = false;
+#ifdef MJMPC_NO_RESET         // developer A/B: the reset emulation compiled out (tools/ab_build.py)
+    rc = nullptr;
+#endif
+    if (rc && __builtin_expect(rc->any, 0)) {
+        int f = rflags<ROLE>(ldsM) & ~4;
+        if (f & 2) {                        // mj_checkPos / mj_checkVel of this mj_step: mj_resetData, and on from there
+            q = T(0); v = T(0); sq = T(0); cq = T(1); aw = T(0);
+            rows = 0;
+            f = 1;
+            if (ROLE != SOLVE && diag && l8 == 0 && rc->count) atomicAdd(diag + 1, 1u);
+        }
+        rflags_set<ROLE>(ldsM, f);
+        if (f & 1) tau_act = M.link(O_GEAR) * fmin(fmax(T(0), M.link(O_CTRL_LO)), M.link(O_CTRL_HI));
+    }
     PHASE();
     LinkFrame<T> L;
     kinematics(M, sq, cq, l8, L);
@@ -935,9 +989,10 @@ __device__ __forceinline__ void arm_front(const MT& M, const ArmInts& I, T& q, T
 }
 
 // second half of a substep: take delivery of qacc and integrate (every role runs the same instructions)
-template <int ROLE, typename T, typename MT>
+template <int ROLE, typename T, typename MT, typename RST = NoResetRecord>
 __device__ __forceinline__ void arm_back(const MT& M, T& q, T& v, T& aw, T& sq, T& cq, T* ldsM, int l8,
-                                         bool free_step, Stamps& ST) {
+                                         bool free_step, Stamps& ST, int lane = 0, ResetCtl* rc = nullptr,
+                                         unsigned* diag = nullptr, RST record = RST()) {
     ST.mark(11);        // DYN: env-step records
     if constexpr (ROLE == DYN && ARM_SWAP) { duo_barrier(); ST.mark(7); }      // E2: inverse out (the other wave takes it after its Newton iterations)
     if constexpr (ROLE == SOLO) LDS_WAVE_SYNC();
@@ -954,8 +1009,11 @@ __device__ __forceinline__ void arm_back(const MT& M, T& q, T& v, T& aw, T& sq, 
         q = add_rn(q, dq);
         // advance (sin q, cos q) by dq: angle addition with a short series, one Newton step of renormalisation.
         // Large steps (|dq| > 0.25 rad per substep, never seen with h = 0.01): series at dq / 256, doubled back up.
+        // (ONE wave-level test guards everything rare about the integration - this, and MuJoCo's reset on instability below: a
+        // NaN or an entry beyond mjMAXVAL = 1e10 in the acceleration or the integrated state makes |dq| = h |v| huge or NaN)
         T sd, cd;
-        if (__builtin_expect(__any(fabs(dq) > T(0.25)), 0)) {
+        const bool big = __any(!(fabs(dq) <= T(0.25)));
+        if (__builtin_expect(big, 0)) {
             sincos_small(dq * T(1.0 / 256.0), sd, cd);
             for (int k = 0; k < 8; ++k) {
                 const T s2 = T(2) * sd * cd;
@@ -969,6 +1027,33 @@ __device__ __forceinline__ void arm_back(const MT& M, T& q, T& v, T& aw, T& sq, 
         const T k = T(1.5) - T(0.5) * (s1 * s1 + c1 * c1);
         sq = s1 * k;
         cq = c1 * k;
+#ifdef MJMPC_NO_RESET
+        rc = nullptr;
+#endif
+        if (rc && __builtin_expect(big, 0)) {
+            // the substep's test (ResetCtl).  The acceleration every role holds is the Euler solve's (M + h B)^-1
+            // (qfrc_smooth + qfrc_constraint), which stands in for mj_forward's qacc
+            const unsigned long long bal = __ballot(mj_is_bad(x) || mj_is_bad(q) || mj_is_bad(v));
+            if (bal != 0ull) {
+                rc->any = true;
+                const unsigned long long mine = particle_lanes(lane);
+                const double* rst = record();
+                if (rst == nullptr) {
+                    // (no record: the launch that makes it)
+                } else if (__ballot(mj_is_bad(x)) & mine) {
+                    // mj_checkAcc: mj_resetData, mj_forward again, mj_Euler from the reset state = the record
+                    q = (T)rst[l8];
+                    v = (T)rst[LANES + l8];
+                    sq = (T)rst[2 * LANES + 3 + l8];
+                    cq = (T)rst[3 * LANES + 3 + l8];
+                    aw = T(0);
+                    rflags_set<ROLE>(ldsM, rflags<ROLE>(ldsM) | 1 | 4);
+                    if (ROLE != SOLVE && diag && l8 == 0 && rc->count) atomicAdd(diag + 1, 1u);
+                } else if (bal & mine) {
+                    rflags_set<ROLE>(ldsM, rflags<ROLE>(ldsM) | 2);
+                }
+            }
+        }
     }
     LDS_WAVE_SYNC();            // the tile is rewritten by the next substep
     ST.mark(13);        // integration
@@ -997,12 +1082,19 @@ __device__ __forceinline__ void real_env_step(const MT& M, const ArmInts& I, con
     Stamps ST;
     ST.begin();
     bool fs = false;
+    ResetCtl rc;
+    rc.count = g == 0;              // (all eight particle slots carry the one state: they reset together; slot 0 counts)
+    auto record = [&mo]() -> const double* { return mo.reset_rec; };
+    if (mo.reset_rec) {
+        if (DUO && wave == 1) reset_check_start<SOLVE>(rc, q, v, lane, ldsM);
+        else reset_check_start<SOLO>(rc, q, v, lane, ldsM);
+    }
     if (DUO && wave == 1) {
         if constexpr (DUO) {
             T nosite[3];
             for (int sub = 0; sub < I.frame_skip; ++sub) {
-                arm_front<SOLVE>(M, I, q, v, aw, sinq, cosq, rows, T(0), ldsM, lane, l8, nosite, diag, fs, ST);
-                arm_back<SOLVE>(M, q, v, aw, sinq, cosq, ldsM, l8, fs, ST);
+                arm_front<SOLVE>(M, I, q, v, aw, sinq, cosq, rows, T(0), ldsM, lane, l8, nosite, diag, fs, ST, &rc);
+                arm_back<SOLVE>(M, q, v, aw, sinq, cosq, ldsM, l8, fs, ST, lane, &rc, nullptr, record);
             }
         }
         return;
@@ -1011,14 +1103,17 @@ __device__ __forceinline__ void real_env_step(const MT& M, const ArmInts& I, con
     const T u = l8 < A ? (T)action[l8] : T(0);
     const T tau_act = M.link(O_GEAR) * fmin(fmax(u, M.link(O_CTRL_LO)), M.link(O_CTRL_HI));
     T site[3];
+    unsigned* dcount = diag;
     for (int sub = 0; sub < I.frame_skip; ++sub) {
-        if (R == DYN && sub > 0) arm_back<R>(M, q, v, aw, sinq, cosq, ldsM, l8, fs, ST);
-        arm_front<R>(M, I, q, v, aw, sinq, cosq, rows, tau_act, ldsM, lane, l8, site, diag, fs, ST);
-        if constexpr (R == SOLO) arm_back<R>(M, q, v, aw, sinq, cosq, ldsM, l8, fs, ST);
+        if (R == DYN && sub > 0) arm_back<R>(M, q, v, aw, sinq, cosq, ldsM, l8, fs, ST, lane, &rc, dcount, record);
+        arm_front<R>(M, I, q, v, aw, sinq, cosq, rows, tau_act, ldsM, lane, l8, site, dcount, fs, ST, &rc);
+        if constexpr (R == SOLO) arm_back<R>(M, q, v, aw, sinq, cosq, ldsM, l8, fs, ST, lane, &rc, dcount, record);
     }
     const int site_lane = lane_of_link(lane, I.site_link);
     for (int k = 0; k < 3; ++k) site[k] = __shfl(site[k], site_lane);
-    if constexpr (R == DYN) arm_back<R>(M, q, v, aw, sinq, cosq, ldsM, l8, fs, ST);
+    if constexpr (R == DYN) arm_back<R>(M, q, v, aw, sinq, cosq, ldsM, l8, fs, ST, lane, &rc, dcount, record);
+    if (rc.any && (rflags<R>(ldsM) & 4))    // the last substep ended in mj_checkAcc's reset: site_xpos is the reset state's
+        for (int k = 0; k < 3; ++k) site[k] = (T)mo.reset_rec[2 * LANES + k];
     if (g == 0) {
         const T dx = site[0] - tgt[0], dy = site[1] - tgt[1], dz = site[2] - tgt[2];
         if (mo.step_cost && l8 == 0)
@@ -1249,6 +1344,18 @@ __global__ __launch_bounds__(DUO ? 128 : 64) __attribute__((amdgpu_waves_per_eu(
     const bool live = pid < P;
     for (int k = threadIdx.x; k < LANES * PSTRIDE; k += NT) lds[k] = T(0);
     T* ldsModel = lds + LANES * PSTRIDE;
+    ResetCtl rc;
+    rc.count = live;
+    // my model block's reset record: its address waits in LDS for the rare path (held in scalar registers through the
+    // rollout it cost this kernel spills in its hot loops)
+    __shared__ const double* s_reset_rec;
+    if (threadIdx.x == 0) {
+        const double* r = fuse.reset_rec;
+        if (r && fuse.shard_size > 0) r += ((long)blockIdx.x * LANES / fuse.shard_size) * ARM_RESET_LEN;
+        s_reset_rec = r;
+    }
+    auto record = []() -> const double* { return *(const double* volatile*)&s_reset_rec; };
+    const bool resets = fuse.reset_rec != nullptr;
     if (fuse.shard_size > 0) model += ((long)blockIdx.x * LANES / fuse.shard_size) * ARM_BLOB_LEN;
     if (fuse.state_shard_size > 0) state += ((long)blockIdx.x * LANES / fuse.state_shard_size) * (2 * LANES + 3);
     for (int k = threadIdx.x; k < ARM_BLOB_LEN; k += NT) ldsModel[k] = model[k];
@@ -1270,6 +1377,10 @@ __global__ __launch_bounds__(DUO ? 128 : 64) __attribute__((amdgpu_waves_per_eu(
     if (l8 >= nv) { q = T(0); v = T(0); }
     T sinq, cosq;
     sincos_(q, sinq, cosq);
+    if (resets) {
+        if (DUO && wave == 1) reset_check_start<SOLVE>(rc, q, v, lane, ldsM);
+        else reset_check_start<SOLO>(rc, q, v, lane, ldsM);
+    }
     const int site_lane = lane_of_link(lane, I.site_link);
     int rows = 0;
     T cq = q, cv = v, chand[3] = {T(0), T(0), T(0)};
@@ -1300,8 +1411,8 @@ __global__ __launch_bounds__(DUO ? 128 : 64) __attribute__((amdgpu_waves_per_eu(
             T nosite[3];
             for (int t = 0; t < H; ++t)
                 for (int sub = 0; sub < I.frame_skip; ++sub) {
-                    arm_front<SOLVE>(M, I, q, v, aw, sinq, cosq, rows, T(0), ldsM, lane, l8, nosite, diag, fs, ST);
-                    arm_back<SOLVE>(M, q, v, aw, sinq, cosq, ldsM, l8, fs, ST);
+                    arm_front<SOLVE>(M, I, q, v, aw, sinq, cosq, rows, T(0), ldsM, lane, l8, nosite, diag, fs, ST, &rc);
+                    arm_back<SOLVE>(M, q, v, aw, sinq, cosq, ldsM, l8, fs, ST, lane, &rc, nullptr, record);
                 }
             ST.flush(diag, 1, lane);
         }
@@ -1410,16 +1521,22 @@ __global__ __launch_bounds__(DUO ? 128 : 64) __attribute__((amdgpu_waves_per_eu(
         const T tau_act = M.link(O_GEAR) * fmin(fmax(u, M.link(O_CTRL_LO)), M.link(O_CTRL_HI));
         T site[3];
         bool fs = false;
+        if (__builtin_expect(rc.any, 0)) rflags_set<R>(ldsM, rflags<R>(ldsM) & 2);     // a new env step: do_simulation writes data.ctrl again (a pending reset stays)
         for (int sub = 0; sub < I.frame_skip; ++sub) {
-            if (R == DYN && sub > 0) arm_back<R>(M, q, v, aw, sinq, cosq, ldsM, l8, fs, ST);
-            arm_front<R>(M, I, q, v, aw, sinq, cosq, rows, tau_act, ldsM, lane, l8, site, diag, fs, ST);
-            if constexpr (R == SOLO) arm_back<R>(M, q, v, aw, sinq, cosq, ldsM, l8, fs, ST);
+            if (R == DYN && sub > 0) arm_back<R>(M, q, v, aw, sinq, cosq, ldsM, l8, fs, ST, lane, &rc, diag, record);
+            arm_front<R>(M, I, q, v, aw, sinq, cosq, rows, tau_act, ldsM, lane, l8, site, diag, fs, ST, &rc);
+            if constexpr (R == SOLO) arm_back<R>(M, q, v, aw, sinq, cosq, ldsM, l8, fs, ST, lane, &rc, diag, record);
             if (t == 0 && sub == 0 && obs)                  // fresh observation after set_env_state
                 for (int k = 0; k < 3; ++k) chand[k] = __shfl(site[k], site_lane);
         }
         // DYN: the last substep is integrated further down - the cost record needs only its kinematics and is
         // written while the SOLVE wave is still solving
         for (int k = 0; k < 3; ++k) site[k] = __shfl(site[k], site_lane);
+        // (the last substep ended in mj_checkAcc's reset: mj_forward ran again from the reset state, site_xpos is that state's)
+        if (R == SOLO && __builtin_expect(rc.any, 0)) {
+            if (rflags<R>(ldsM) & 4)
+                for (int k = 0; k < 3; ++k) site[k] = (T)record()[2 * LANES + k];
+        }
         // Take delivery of the prefetched inputs HERE, before this step's stores are issued: loads and stores share
         // one in-order counter (vmcnt), and the register hand-over the compiler otherwise places on the loop's
         // back-edge waits with vmcnt(0) - i.e. for the cost / observation stores just issued (~2000 cycles per step).
@@ -1431,7 +1548,30 @@ __global__ __launch_bounds__(DUO ? 128 : 64) __attribute__((amdgpu_waves_per_eu(
         if (fuse.gseq) q0acc += gs_cur * (double)cst;
         // MONO: the next step's sample, drawn while the SOLVE wave is still iterating (DUO) / once per env step (SOLO)
         if constexpr (MONO) { if (t + 1 < H) { const T en = draw(t + 1); if (sampled) eps_next = en; } }
-        if constexpr (R == DYN) arm_back<R>(M, q, v, aw, sinq, cosq, ldsM, l8, fs, ST);
+        if constexpr (R == DYN) {
+            arm_back<R>(M, q, v, aw, sinq, cosq, ldsM, l8, fs, ST, lane, &rc, diag, record);
+#ifndef ARM_NO_FIXUP            // (developer A/B)
+            if (__builtin_expect(rc.any, 0)) {
+                // the last substep ended in mj_checkAcc's reset: site_xpos is the reset state's (mj_forward ran again) - the
+                // cost written ahead of the integration above is written again
+                // (the substep began from a state mj_checkPos / mj_checkVel passed: its site and the cost from it are finite)
+                if (rflags<R>(ldsM) & 4) {
+#ifdef ARM_FIXUP_LIVE           // (developer A/B: the cost written above kept live instead of made again)
+                    T ex, ey, ez;
+                    const T c_old = cst;
+#else
+                    T ex = site[0] - tgt[0], ey = site[1] - tgt[1], ez = site[2] - tgt[2];
+                    const T c_old = fabs(ex) + fabs(ey) + fabs(ez) + T(5) * sqrt_(ex * ex + ey * ey + ez * ez);
+#endif
+                    for (int k = 0; k < 3; ++k) site[k] = (T)record()[2 * LANES + k];
+                    ex = site[0] - tgt[0]; ey = site[1] - tgt[1]; ez = site[2] - tgt[2];
+                    const T c_new = fabs(ex) + fabs(ey) + fabs(ez) + T(5) * sqrt_(ex * ex + ey * ey + ez * ez);
+                    if (live && l8 == 0 && (!MONO || cost)) cost[pid * H + t] = c_new;
+                    if (fuse.gseq) q0acc += fuse.gseq[t] * ((double)c_new - (double)c_old);
+                }
+            }
+#endif
+        }
         if (live && (obs || nobs)) {
             const long o = (pid * H + t) * dobs;
             if (obs) {

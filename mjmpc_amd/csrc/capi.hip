@@ -2,6 +2,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <cmath>
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
@@ -30,6 +31,13 @@ int fail(int code, const char* fmt, ...) {
     va_end(ap);
     return code;
 }
+
+}  // namespace
+namespace mjmpc {
+// (comm.hip reports through the same thread-local message as the entry points of this file)
+int set_error(int code, const char* what, const char* detail) { return fail(code, "%s: %s", what, detail); }
+}  // namespace mjmpc
+namespace {
 
 int hip_fail(hipError_t e, const char* what) {
     return fail((int)e, "%s: %s", what, hipGetErrorString(e));
@@ -61,6 +69,7 @@ struct mjmpc_arm_s {
     // mjmpc_arm_mppi_step: the rollout workgroups' records.  The pointer travels to the kernels BY VALUE (MonoStep), so a
     // captured graph holds it: the buffer only ever GROWS, and a buffer it outgrew stays allocated until the handle is
     // destroyed (mono_retired) - a graph captured at one (P, H) survives later calls at another
+    double* reset_rec = nullptr;    // n_shards records of ARM_RESET_LEN: MuJoCo's reset on instability (RolloutFusion::reset_rec)
     double* mono_tree = nullptr;
     size_t mono_cap = 0;            // doubles
     std::vector<double*> mono_retired;
@@ -84,6 +93,7 @@ struct mjmpc_tree_s {
     hipEvent_t staged[4] = {nullptr, nullptr, nullptr, nullptr};
     int stage_next = 0;
     std::vector<double> topo;       // create-time topology tables (shard blocks must match them)
+    double* reset_rec = nullptr;    // n_shards records of TREE_RESET_LEN: MuJoCo's reset on instability (TreeFusion::reset_rec)
 };
 
 extern "C" {
@@ -115,6 +125,56 @@ int mjmpc_graph_kernel_nodes(void* hip_graph, int64_t* n_out) {
     return 0;
 }
 
+static mjmpc::RolloutFusion arm_fuse(const mjmpc_arm_s* h) {
+    mjmpc::RolloutFusion f;
+    f.reset_rec = h->reset_rec;
+    return f;
+}
+
+// The reset records of `n_shards` model blocks (host, ARM_BLOB_LEN each): per block ONE substep of the f64 kernel itself
+// from the reset state (qpos0 = 0, zero velocity, zero controls) on a copy of the block with frame_skip 1 - state_out
+// receives the state after it, the next observation's site entries are the site at the reset state.  Synchronous; called
+// when the engine is created and when its model blocks are replaced.
+static int arm_make_reset_records(mjmpc_arm_s* h, const double* blobs, int n_shards) {
+    const size_t L = (size_t)mjmpc::ARM_BLOB_LEN, R = (size_t)mjmpc::ARM_RESET_LEN;
+    const int dobs = 2 * h->nv + 6;
+    double *rec = nullptr, *tmp = nullptr;
+    HIP_TRY(hipMalloc(&rec, sizeof(double) * R * n_shards));
+    // scratch: model block | state (19) | mean (8) | cost (1) | next observation (dobs)
+    const size_t nscr = L + MJMPC_ARM_STATE_LEN + 8 + 1 + dobs;
+    hipError_t e = hipMalloc(&tmp, sizeof(double) * nscr);
+    if (e == hipSuccess) e = hipMemset(tmp, 0, sizeof(double) * nscr);
+    if (e == hipSuccess) e = hipMemset(rec, 0, sizeof(double) * R * n_shards);
+    std::vector<double> b(L);
+    double *st = tmp + L, *mean = st + MJMPC_ARM_STATE_LEN, *cost = mean + 8, *nobs = cost + 1;
+    for (int k = 0; k < n_shards && e == hipSuccess; ++k) {
+        std::memcpy(b.data(), blobs + (size_t)k * L, sizeof(double) * L);
+        b[mjmpc::O_FRAME_SKIP] = 1.0;
+        e = hipMemcpy(tmp, b.data(), sizeof(double) * L, hipMemcpyHostToDevice);
+        if (e != hipSuccess) break;
+        double* rk = rec + (size_t)k * R;
+        e = mjmpc::launch_arm_rollout<double>(tmp, st, 1, 1, h->nu, mean, nullptr, cost, nullptr, nullptr, nobs, rk, h->diag, nullptr);
+        if (e == hipSuccess) e = hipMemcpy(rk + 2 * mjmpc::LANES, nobs + 2 * h->nv, sizeof(double) * 3, hipMemcpyDeviceToDevice);
+        if (e == hipSuccess) e = hipDeviceSynchronize();
+        if (e != hipSuccess) break;
+        double host[mjmpc::ARM_RESET_LEN];          // sin / cos of the record's qpos (the kernels carry them beside q)
+        e = hipMemcpy(host, rk, sizeof(double) * 19, hipMemcpyDeviceToHost);
+        for (int l = 0; l < mjmpc::LANES; ++l) {
+            host[19 + l] = std::sin(host[l]);
+            host[19 + mjmpc::LANES + l] = std::cos(host[l]);
+        }
+        if (e == hipSuccess) e = hipMemcpy(rk + 19, host + 19, sizeof(double) * 16, hipMemcpyHostToDevice);
+    }
+    hipFree(tmp);
+    if (e != hipSuccess) {
+        hipFree(rec);
+        return hip_fail(e, "reset record");
+    }
+    hipFree(h->reset_rec);
+    h->reset_rec = rec;
+    return 0;
+}
+
 static int arm_create_impl(mjmpc_arm_s* h, const double* blob, int n_blob) {
     std::vector<float> f32(blob, blob + n_blob);
     HIP_TRY(hipMalloc(&h->model_f32, sizeof(float) * n_blob));
@@ -127,7 +187,7 @@ static int arm_create_impl(mjmpc_arm_s* h, const double* blob, int n_blob) {
     HIP_TRY(hipMemcpy(h->model_f64, blob, sizeof(double) * n_blob, hipMemcpyHostToDevice));
     HIP_TRY(hipMemset(h->state, 0, sizeof(double) * MJMPC_ARM_STATE_LEN));
     HIP_TRY(hipMemset(h->diag, 0, MJMPC_DIAG_BYTES));
-    return 0;
+    return arm_make_reset_records(h, blob, 1);
 }
 
 int mjmpc_arm_create(const double* blob, int n_blob, int device, mjmpc_arm_t* out) {
@@ -178,7 +238,7 @@ int mjmpc_arm_set_shard_models(mjmpc_arm_t h, const double* blobs, int n_shards)
     h->model_f32 = m32;
     h->model_f64 = m64;
     h->n_shards = n_shards;
-    return 0;
+    return arm_make_reset_records(h, blobs, n_shards);
 }
 
 int mjmpc_arm_set_shard_states(mjmpc_arm_t h, const double* states, int n_shards, void* stream) {
@@ -221,6 +281,7 @@ int mjmpc_arm_destroy(mjmpc_arm_t h) {
     hipFree(h->state);
     hipFree(h->diag);
     hipFree(h->shard_states);
+    hipFree(h->reset_rec);
     hipFree(h->mono_tree);
     for (double* p : h->mono_retired) hipFree(p);
     hipHostFree(h->pinned);
@@ -266,7 +327,7 @@ int mjmpc_arm_rollout(mjmpc_arm_t h, int dtype, int64_t P, int H, const double* 
     HIP_TRY(hipSetDevice(h->device));
     hipStream_t s = (hipStream_t)stream;
     hipError_t e;
-    mjmpc::RolloutFusion fuse;
+    mjmpc::RolloutFusion fuse = arm_fuse(h);
     if (int rc = shard_fusion(h, P, fuse)) return rc;
     const double* st = fuse.state_shard_size > 0 ? h->shard_states : h->state;
     if (dtype == MJMPC_F32) {
@@ -290,7 +351,7 @@ int mjmpc_arm_rollout_cl(mjmpc_arm_t h, int dtype, int64_t P, int H, const doubl
     if (P < 0 || H < 0) return fail(MJMPC_E_BADARG, "negative size");
     HIP_TRY(hipSetDevice(h->device));
     hipStream_t s = (hipStream_t)stream;
-    mjmpc::RolloutFusion fuse;
+    mjmpc::RolloutFusion fuse = arm_fuse(h);
     if (int rc = shard_fusion(h, P, fuse)) return rc;
     const double* st = fuse.state_shard_size > 0 ? h->shard_states : h->state;
     fuse.clw = d_weights;
@@ -317,7 +378,7 @@ int mjmpc_arm_rollout_fused(mjmpc_arm_t h, int dtype, int64_t P, int H, const do
     if (P < 0 || H < 0) return fail(MJMPC_E_BADARG, "negative size");
     HIP_TRY(hipSetDevice(h->device));
     hipStream_t s = (hipStream_t)stream;
-    mjmpc::RolloutFusion fuse;
+    mjmpc::RolloutFusion fuse = arm_fuse(h);
     if (int rc = shard_fusion(h, P, fuse)) return rc;
     const double* st = fuse.state_shard_size > 0 ? h->shard_states : h->state;
     fuse.filt = d_filter_coeffs;
@@ -384,8 +445,9 @@ int mjmpc_arm_mppi_step(mjmpc_arm_t h, int dtype, int64_t P, int H, const double
     mo.state_io = h->state;
     mo.step_cost = d_step_cost;
     mo.step_nobs = d_step_next_obs;
+    mo.reset_rec = h->reset_rec;
     const int do_env = (env_step && !d_record) ? 1 : 0;
-    mjmpc::RolloutFusion fuse;
+    mjmpc::RolloutFusion fuse = arm_fuse(h);
     fuse.filt = d_filter_coeffs;
     fuse.gseq = d_gseq;
     fuse.q0_out = d_q0;
@@ -441,7 +503,7 @@ int mjmpc_arm_rollout_sampled(mjmpc_arm_t h, int dtype, int64_t P, int H, const 
     mo.lam = 1.0;
     mo.shift_mode = -2;
     mo.tree = h->mono_tree;
-    mjmpc::RolloutFusion fuse;
+    mjmpc::RolloutFusion fuse = arm_fuse(h);
     fuse.filt = d_filter_coeffs;
     fuse.gseq = d_gseq;
     fuse.q0_out = d_q0;
@@ -477,6 +539,7 @@ int mjmpc_arm_mppi_combine(mjmpc_arm_t h, int dtype, const double* d_records, in
     mo.state_io = h->state;
     mo.step_cost = d_step_cost;
     mo.step_nobs = d_step_next_obs;
+    mo.reset_rec = h->reset_rec;
     hipError_t e;
     if (dtype == MJMPC_F32)
         e = mjmpc::launch_arm_mppi_finish<float>(h->model_f32, d_records, n_records, H, h->nu, d_mean, d_mean_out, mo,
@@ -498,10 +561,10 @@ int mjmpc_arm_step_state(mjmpc_arm_t h, int dtype, const double* d_action, void*
     hipError_t e;
     if (dtype == MJMPC_F32)
         e = mjmpc::launch_arm_rollout<float>(h->model_f32, h->state, 1, 1, h->nu, d_action, nullptr, (float*)d_cost,
-                                             nullptr, nullptr, (float*)d_next_obs, h->state, h->diag, s);
+                                             nullptr, nullptr, (float*)d_next_obs, h->state, h->diag, s, arm_fuse(h));
     else if (dtype == MJMPC_F64)
         e = mjmpc::launch_arm_rollout<double>(h->model_f64, h->state, 1, 1, h->nu, d_action, nullptr, (double*)d_cost,
-                                              nullptr, nullptr, (double*)d_next_obs, h->state, h->diag, s);
+                                              nullptr, nullptr, (double*)d_next_obs, h->state, h->diag, s, arm_fuse(h));
     else
         return fail(MJMPC_E_BADARG, "unknown dtype %d", dtype);
     if (e != hipSuccess) return hip_fail(e, "arm_step_state launch");
@@ -514,6 +577,16 @@ int mjmpc_arm_solver_failures(mjmpc_arm_t h, uint32_t* count) {
     HIP_TRY(hipDeviceSynchronize());
     unsigned c = 0;
     HIP_TRY(hipMemcpy(&c, h->diag, sizeof(unsigned), hipMemcpyDeviceToHost));
+    *count = c;
+    return 0;
+}
+
+int mjmpc_arm_diverged(mjmpc_arm_t h, uint32_t* count) {
+    if (!h || !count) return fail(MJMPC_E_BADARG, "null argument");
+    HIP_TRY(hipSetDevice(h->device));
+    HIP_TRY(hipDeviceSynchronize());
+    unsigned c = 0;
+    HIP_TRY(hipMemcpy(&c, h->diag + 1, sizeof(unsigned), hipMemcpyDeviceToHost));
     *count = c;
     return 0;
 }
@@ -604,6 +677,55 @@ static bool tree_same_topology(const double* a, const double* b) {
            same(mjmpc::T_NQ, 1) && same(mjmpc::T_QADR, mjmpc::TL) && same(mjmpc::T_HAS_BALL, 1) && same(mjmpc::T_QW0, mjmpc::TL);
 }
 
+// what every rollout launch of the engine carries besides its own fusions: the reset records (one per model shard; shard >= 0:
+// a launch that runs that one shard's model block)
+static mjmpc::TreeFusion tree_fuse(const mjmpc_tree_s* h, int shard = -1) {
+    mjmpc::TreeFusion f;
+    if (h->reset_rec) {
+        f.reset_rec = h->reset_rec + (shard > 0 && h->n_shards > 1 ? (size_t)shard * mjmpc::TREE_RESET_LEN : 0);
+        f.reset_stride = (shard < 0 && h->n_shards > 1) ? mjmpc::TREE_RESET_LEN : 0;
+    }
+    return f;
+}
+
+// The reset records of `n_shards` model blocks (host, TREE_BLOB_LEN each): per block ONE substep of the f64 kernel itself
+// from the reset state (qpos0 = the device's zero coordinates and identity quaternions, zero velocity, zero controls) on a
+// copy of the block with frame_skip 1 - state_out receives the state after it, site_out / axis_out the site and the object
+// axis at the reset state.  Synchronous; called when the engine is created and when its model blocks are replaced.
+static int tree_make_reset_records(mjmpc_tree_s* h, const double* blobs, int n_shards) {
+    const size_t L = (size_t)mjmpc::TREE_BLOB_LEN, R = (size_t)mjmpc::TREE_RESET_LEN;
+    double *rec = nullptr, *tmp = nullptr, *st = nullptr;
+    HIP_TRY(hipMalloc(&rec, sizeof(double) * R * n_shards));
+    hipError_t e = hipMalloc(&tmp, sizeof(double) * L);
+    if (e == hipSuccess) e = hipMalloc(&st, sizeof(double) * mjmpc::TREE_STATE_LEN);
+    if (e == hipSuccess) e = hipMemset(rec, 0, sizeof(double) * R * n_shards);
+    std::vector<double> b(L), s0(mjmpc::TREE_STATE_LEN, 0.0);
+    for (int l = 0; l < mjmpc::TL; ++l) s0[mjmpc::TREE_QW + l] = 1.0;
+    if (e == hipSuccess) e = hipMemcpy(st, s0.data(), sizeof(double) * s0.size(), hipMemcpyHostToDevice);
+    for (int k = 0; k < n_shards && e == hipSuccess; ++k) {
+        std::memcpy(b.data(), blobs + (size_t)k * L, sizeof(double) * L);
+        b[mjmpc::T_FRAME_SKIP] = 1.0;
+        e = hipMemcpy(tmp, b.data(), sizeof(double) * L, hipMemcpyHostToDevice);
+        if (e != hipSuccess) break;
+        double* rk = rec + (size_t)k * R;
+        mjmpc::TreeFusion f;
+        f.axis_out = rk + mjmpc::TREE_STATE_LEN + 3;
+        e = mjmpc::launch_tree_rollout<double>(tmp, 1, h->max_path, h->full, h->nv, st, 1, 1, h->nu, h->zero_action, nullptr,
+                                               (double*)h->scratch, nullptr, nullptr, nullptr, h->diag, nullptr, rk, nullptr,
+                                               rk + mjmpc::TREE_STATE_LEN, 1, h->gen, f);
+        if (e == hipSuccess) e = hipDeviceSynchronize();
+    }
+    hipFree(tmp);
+    hipFree(st);
+    if (e != hipSuccess) {
+        hipFree(rec);
+        return hip_fail(e, "reset record");
+    }
+    hipFree(h->reset_rec);
+    h->reset_rec = rec;
+    return 0;
+}
+
 static int tree_create_impl(mjmpc_tree_s* h, const double* blob, int n_blob) {
     std::vector<float> f32(blob, blob + n_blob);
     HIP_TRY(hipMalloc(&h->model_f32, sizeof(float) * n_blob));
@@ -619,7 +741,7 @@ static int tree_create_impl(mjmpc_tree_s* h, const double* blob, int n_blob) {
     h->scratch = h->zero_action + 32;
     HIP_TRY(hipHostMalloc(&h->pinned, sizeof(double) * MJMPC_TREE_DEVICE_STATE_LEN * 4));
     for (int k = 0; k < 4; ++k) HIP_TRY(hipEventCreateWithFlags(&h->staged[k], hipEventDisableTiming));
-    return 0;
+    return tree_make_reset_records(h, blob, 1);
 }
 
 int mjmpc_tree_create(const double* blob, int n_blob, int device, mjmpc_tree_t* out) {
@@ -693,7 +815,7 @@ int mjmpc_tree_set_shard_models(mjmpc_tree_t h, const double* blobs, int n_shard
     h->model_f64 = m64;
     h->n_shards = n_shards;
     h->full = full;             // of the NEW set of blocks (they replace the old ones)
-    return 0;
+    return tree_make_reset_records(h, blobs, n_shards);
 }
 
 int mjmpc_tree_set_shard_states(mjmpc_tree_t h, const double* states, int n_shards, void* stream) {
@@ -732,6 +854,7 @@ int mjmpc_tree_destroy(mjmpc_tree_t h) {
     hipFree(h->diag);
     hipFree(h->zero_action);
     hipFree(h->shard_states);
+    hipFree(h->reset_rec);
     if (h->pinned) hipHostFree(h->pinned);
     for (int k = 0; k < 4; ++k) if (h->staged[k]) hipEventDestroy(h->staged[k]);
     delete h;
@@ -779,11 +902,11 @@ int mjmpc_tree_rollout(mjmpc_tree_t h, int dtype, int64_t P, int H, const double
     if (dtype == MJMPC_F32)
         e = mjmpc::launch_tree_rollout<float>(h->model_f32, h->n_shards, h->max_path, h->full, h->nv, st, (long)P, H, h->nu, d_mean,
                                               (const float*)d_noise, (float*)d_costs, (float*)d_actions, (float*)d_obs,
-                                              (float*)d_next_obs, h->diag, s, nullptr, nullptr, nullptr, nss, h->gen);
+                                              (float*)d_next_obs, h->diag, s, nullptr, nullptr, nullptr, nss, h->gen, tree_fuse(h));
     else if (dtype == MJMPC_F64)
         e = mjmpc::launch_tree_rollout<double>(h->model_f64, h->n_shards, h->max_path, h->full, h->nv, st, (long)P, H, h->nu, d_mean,
                                                (const double*)d_noise, (double*)d_costs, (double*)d_actions,
-                                               (double*)d_obs, (double*)d_next_obs, h->diag, s, nullptr, nullptr, nullptr, nss, h->gen);
+                                               (double*)d_obs, (double*)d_next_obs, h->diag, s, nullptr, nullptr, nullptr, nss, h->gen, tree_fuse(h));
     else
         return fail(MJMPC_E_BADARG, "unknown dtype %d", dtype);
     if (e != hipSuccess) return hip_fail(e, "tree_rollout launch");
@@ -801,7 +924,7 @@ int mjmpc_tree_rollout_fused(mjmpc_tree_t h, int dtype, int64_t P, int H, const 
         return fail(MJMPC_E_BADARG, "%lld particles do not divide into %d shards", (long long)P, std::max(h->n_shards, nss));
     HIP_TRY(hipSetDevice(h->device));
     hipStream_t s = (hipStream_t)stream;
-    mjmpc::TreeFusion fuse;
+    mjmpc::TreeFusion fuse = tree_fuse(h);
     fuse.filt = d_filter_coeffs;
     fuse.gseq = d_gseq;
     fuse.q0_out = d_q0;
@@ -841,11 +964,11 @@ int mjmpc_tree_rollout_cl(mjmpc_tree_t h, int dtype, int64_t P, int H, const dou
         if (dtype == MJMPC_F32)
             e = mjmpc::launch_tree_rollout<float>(h->model_f32 + (h->n_shards > 1 ? (size_t)k * mjmpc::TREE_BLOB_LEN : 0), 1, h->max_path,
                                                   h->full, h->nv, sk, 1, 1, h->nu, h->zero_action, nullptr, (float*)h->scratch,
-                                                  nullptr, nullptr, nullptr, h->diag, s, nullptr, nullptr, site0, 1, h->gen);
+                                                  nullptr, nullptr, nullptr, h->diag, s, nullptr, nullptr, site0, 1, h->gen, tree_fuse(h, k));
         else if (dtype == MJMPC_F64)
             e = mjmpc::launch_tree_rollout<double>(h->model_f64 + (h->n_shards > 1 ? (size_t)k * mjmpc::TREE_BLOB_LEN : 0), 1, h->max_path,
                                                    h->full, h->nv, sk, 1, 1, h->nu, h->zero_action, nullptr, (double*)h->scratch,
-                                                   nullptr, nullptr, nullptr, h->diag, s, nullptr, nullptr, site0, 1, h->gen);
+                                                   nullptr, nullptr, nullptr, h->diag, s, nullptr, nullptr, site0, 1, h->gen, tree_fuse(h, k));
         else
             return fail(MJMPC_E_BADARG, "unknown dtype %d", dtype);
     }
@@ -853,11 +976,11 @@ int mjmpc_tree_rollout_cl(mjmpc_tree_t h, int dtype, int64_t P, int H, const dou
         if (dtype == MJMPC_F32)
             e = mjmpc::launch_tree_rollout<float>(h->model_f32, h->n_shards, h->max_path, h->full, h->nv, st, (long)P, H, h->nu,
                                                   d_weights, (const float*)d_noise, (float*)d_costs, (float*)d_actions, (float*)d_obs,
-                                                  (float*)d_next_obs, h->diag, s, nullptr, d_weights, nullptr, nss, h->gen);
+                                                  (float*)d_next_obs, h->diag, s, nullptr, d_weights, nullptr, nss, h->gen, tree_fuse(h));
         else
             e = mjmpc::launch_tree_rollout<double>(h->model_f64, h->n_shards, h->max_path, h->full, h->nv, st, (long)P, H, h->nu,
                                                    d_weights, (const double*)d_noise, (double*)d_costs, (double*)d_actions,
-                                                   (double*)d_obs, (double*)d_next_obs, h->diag, s, nullptr, d_weights, nullptr, nss, h->gen);
+                                                   (double*)d_obs, (double*)d_next_obs, h->diag, s, nullptr, d_weights, nullptr, nss, h->gen, tree_fuse(h));
     }
     if (e != hipSuccess) return hip_fail(e, "tree_rollout_cl launch");
     return 0;
@@ -871,10 +994,10 @@ int mjmpc_tree_step_state(mjmpc_tree_t h, int dtype, const double* d_action, voi
     // one particle, one env step, no noise, shard 0's model; the state vector is advanced in place
     if (dtype == MJMPC_F32)
         e = mjmpc::launch_tree_rollout<float>(h->model_f32, 1, h->max_path, h->full, h->nv, h->state, 1, 1, h->nu, d_action, nullptr,
-                                              (float*)d_cost, nullptr, nullptr, (float*)d_next_obs, h->diag, s, h->state, nullptr, nullptr, 1, h->gen);
+                                              (float*)d_cost, nullptr, nullptr, (float*)d_next_obs, h->diag, s, h->state, nullptr, nullptr, 1, h->gen, tree_fuse(h, 0));
     else if (dtype == MJMPC_F64)
         e = mjmpc::launch_tree_rollout<double>(h->model_f64, 1, h->max_path, h->full, h->nv, h->state, 1, 1, h->nu, d_action, nullptr,
-                                               (double*)d_cost, nullptr, nullptr, (double*)d_next_obs, h->diag, s, h->state, nullptr, nullptr, 1, h->gen);
+                                               (double*)d_cost, nullptr, nullptr, (double*)d_next_obs, h->diag, s, h->state, nullptr, nullptr, 1, h->gen, tree_fuse(h, 0));
     else
         return fail(MJMPC_E_BADARG, "unknown dtype %d", dtype);
     if (e != hipSuccess) return hip_fail(e, "tree_step_state launch");

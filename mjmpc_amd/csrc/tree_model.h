@@ -118,6 +118,8 @@ enum TreePointKind : int { PT_PLANE = 0, PT_SEGSEG = 1, PT_SPHERE_BOX = 2, PT_BO
 // (a BALL_X link keeps x, y, z in the qpos entries of its three links and w in its own w entry)
 constexpr int TREE_STATE_LEN = 3 * TL + 6;
 constexpr int TREE_QW = 2 * TL + 6;
+// reset record (TreeFusion::reset_rec): a device state vector, then the site and the object axis at the reset state
+constexpr int TREE_RESET_LEN = TREE_STATE_LEN + 6;
 constexpr int TREE_NQ_MAX = 40;
 // the C ABI's state vectors (mjmpc_tree_set_shard_states): MuJoCo's layout - qpos[40] | qvel[32] | target[3] | reserved[3]
 constexpr int TREE_PUBLIC_STATE_LEN = TREE_NQ_MAX + TL + 6;

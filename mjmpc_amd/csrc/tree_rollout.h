@@ -18,10 +18,21 @@ namespace mjmpc {
 // Fusions riding in the rollout launch (as RolloutFusion of the arm kernel): the reference's recursive noise filter applied
 // to the raw samples on the fly (control_utils.py:32-33; filt = three float64 coefficients), and the discounted cost-to-go
 // of every particle, q0_out[p] = sum_t gseq[t] * cost[p][t] (control_utils.py:37-46 at t = 0; +inf for a diverged rollout).
+// MuJoCo's reset on instability (mj_checkPos / mj_checkVel / mj_checkAcc -> mj_resetData, [EXT]; the rollouts of
+// gym_env_wrapper.py:125-153 run through it): reset_rec = one record per model shard (reset_stride apart; 0: one record) -
+// the device state vector one substep after the reset state (qpos0, zero velocity, zero controls), then site[3] and object
+// axis[3] AT the reset state (TREE_RESET_LEN scalars, tree_model.h).  A particle whose qpos / qvel hold a NaN or an entry
+// beyond 1e10 when a substep begins restarts that substep from the reset state; one whose acceleration does continues from
+// the record; either way its controls are zero for the rest of the env step (mj_resetData zeroes data.ctrl, which
+// do_simulation wrote once before its frame_skip calls of sim.step()).  nullptr: no resets (the launch that MAKES the
+// record: one particle, one step of a model block with frame_skip 1, axis_out receiving the axis).
 struct TreeFusion {
     const double* filt = nullptr;
     const double* gseq = nullptr;
     double* q0_out = nullptr;
+    const double* reset_rec = nullptr;
+    int reset_stride = 0;
+    double* axis_out = nullptr;
 };
 
 template <typename T>

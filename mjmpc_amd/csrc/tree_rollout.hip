@@ -1256,6 +1256,31 @@ __global__ __launch_bounds__(64 * wg_waves(DP, FRIC, sizeof(T), PL), min_waves(s
     T qy_prev = qy, qz_prev = qz, qw_prev = qw;
     if (clw)
         for (int k = 0; k < 3; ++k) hand_prev[k] = (T)state[2 * TL + 3 + k];
+    // MuJoCo's reset on instability (TreeFusion::reset_rec): my particle's lanes as a ballot mask, the bound of mju_isBad
+#ifdef MJMPC_NO_RESET         // developer A/B: the reset emulation compiled out (tools/ab_build.py)
+    const double* rst = nullptr;
+#else
+    const double* rst = fuse.reset_rec ? fuse.reset_rec + (long)blockIdx.y * fuse.reset_stride : nullptr;
+#endif
+    const unsigned long long my_lanes = (PL == 32 ? 0xFFFFFFFFull : 0xFFFFull) << (PL * half);
+    const T MJ_MAXVAL = T(1e10);
+    // ONE test per substep, where it ends (the acceleration, the integrated qpos and qvel); `rst_any` is wave-uniform (a
+    // scalar register): a wave none of whose particles ever reset pays that test and one scalar branch per substep.
+    // rst_pend (per lane, uniform over a particle): qpos / qvel left MuJoCo's bounds - the NEXT mj_step's mj_checkPos /
+    // mj_checkVel resets, where that substep begins (until then the state, e.g. in the next observation, is what MuJoCo shows)
+    bool rst_any = false, rst_pend = false;
+    auto state_is_bad = [&]() -> bool {
+        bool bad = dof && (!(fabs(q) <= MJ_MAXVAL) || !(fabs(v) <= MJ_MAXVAL));
+        if constexpr (GEN) bad = bad || (ball_g == 0 && (!(fabs(qy) <= MJ_MAXVAL) || !(fabs(qz) <= MJ_MAXVAL) || !(fabs(qw) <= MJ_MAXVAL)));
+        return bad;
+    };
+    if (rst) {                  // the start state (the first mj_step's mj_checkPos / mj_checkVel)
+        const unsigned long long bb = __ballot(state_is_bad());
+        if (bb != 0ull) {
+            rst_any = true;
+            rst_pend = (bb & my_lanes) != 0ull;
+        }
+    }
     TreeClock clk;
     clk.start(diag, blockIdx.x == 0 && threadIdx.x == 0);
 
@@ -1327,10 +1352,23 @@ __global__ __launch_bounds__(64 * wg_waves(DP, FRIC, sizeof(T), PL), min_waves(s
         }
         // lane a holds action a; the dof it drives picks it up (motors may sit on any subset of the joints)
         const T u_dof = __shfl(u, act_id >= 0 ? act_id : 0, PL);
-        const T tau_act = act_id >= 0 ? M[T_GEAR + l] * fmin(fmax(u_dof, M[T_CTRL_LO + l]), M[T_CTRL_HI + l]) : T(0);
+        T tau_act = act_id >= 0 ? M[T_GEAR + l] * fmin(fmax(u_dof, M[T_CTRL_LO + l]), M[T_CTRL_HI + l]) : T(0);
         if (task == 1 && l == 0) X[A_MISC + 4] = q;        // qpos[0] when the env step starts
         T hand[3] = {T(0), T(0), T(0)}, haxis[3] = {T(0), T(0), T(0)};
         for (int sub = 0; sub < frame_skip; ++sub) {
+            // ---- 0. mj_checkPos / mj_checkVel found a NaN or an entry beyond mjMAXVAL in my particle's state (noted where the
+            //         previous substep ended): mj_resetData - qpos0, zero velocity, zero controls until the env step ends -
+            //         and the substep runs from there
+            if (__builtin_expect(rst_any, 0)) {
+                if (rst_pend) {
+                    rst_pend = false;
+                    q = T(0); v = T(0); sq = T(0); cq = T(1);
+                    qy = T(0); qz = T(0); qw = T(1);
+                    tau_act = act_id >= 0 ? M[T_GEAR + l] * fmin(fmax(T(0), M[T_CTRL_LO + l]), M[T_CTRL_HI + l]) : T(0);
+                    lim_mem = 0; fl_mem = 0; cinst_mem = 0; cact_mem = 0;
+                    if (diag && l == 0 && live) atomicAdd(diag + 1, 1u);
+                }
+            }
             // ---- 1. forward kinematics: X_l = X_parent o (Rodrigues(axis, q), off), by pointer jumping
             clk.mark(7);
             T R[9], p[3], ax[3];
@@ -1695,6 +1733,7 @@ __global__ __launch_bounds__(64 * wg_waves(DP, FRIC, sizeof(T), PL), min_waves(s
             if (t == 0 && sub == 0) {
                 for (int k = 0; k < 3; ++k) hand_prev[k] = hand[k];     // fresh observation after set_env_state
                 if (site_out && pid == 0 && l < 3) site_out[l] = (double)hand[l];
+                if (fuse.axis_out && pid == 0 && l < 3) fuse.axis_out[l] = (double)haxis[l];
             }
 
             // ---- 2. world-frame quantities of my link, about the world origin
@@ -2043,6 +2082,7 @@ __global__ __launch_bounds__(64 * wg_waves(DP, FRIC, sizeof(T), PL), min_waves(s
             TSYNC();
             const bool any_rows = !(TREE_SKIP & 1) && (__any(inst || cinst != 0) || any_floss);
             T qfrc_c = T(0);
+            T acc_fwd = T(0);            // mj_forward's acceleration (the constraint solver's) where the wavefront has rows
             T erow[MERGE ? DP : 1];      // factor of the Euler matrix when it was computed beside the first Newton factor
             clk.mark(3);
             clk.count(8, 1);
@@ -2216,6 +2256,7 @@ __global__ __launch_bounds__(64 * wg_waves(DP, FRIC, sizeof(T), PL), min_waves(s
                         }
                         return nxt;
                     }
+                    if (ucinst == 0) return mask_t(0);
                     T res[NR];
                     point_residuals(xa_, res);
                     return rows_from_res(res, cur);
@@ -2336,8 +2377,14 @@ __global__ __launch_bounds__(64 * wg_waves(DP, FRIC, sizeof(T), PL), min_waves(s
                     T rN[NR];                                   // friction instantiation: my point's residuals at xa
                     mask_t cact2;
                     if constexpr (FRIC) {
-                        point_residuals(xa, rN);
-                        cact2 = rows_from_res(rN, cact);
+                        if (ucinst != 0) {              // (wave-uniform: no point or record this substep - limit / friction-loss rows only)
+                            point_residuals(xa, rN);
+                            cact2 = rows_from_res(rN, cact);
+                        } else {
+#pragma unroll
+                            for (int r = 0; r < NR; ++r) rN[r] = T(0);
+                            cact2 = 0;
+                        }
                     } else {
                         cact2 = next_set(xa, cact);
                     }
@@ -2530,6 +2577,7 @@ __global__ __launch_bounds__(64 * wg_waves(DP, FRIC, sizeof(T), PL), min_waves(s
                 if constexpr (GEN) fl_mem = floss > T(0) ? (1 | ((fstate + 1) << 1)) : 0;
                 cinst_mem = cinst;
                 cact_mem = cact;
+                acc_fwd = xa;
                 qfrc_c = actv ? -D * (sig * xa - aref) * sig : T(0);
                 if constexpr (!FRIC) {
                     for (unsigned um = ucinst; um; um &= um - 1) {
@@ -2572,7 +2620,11 @@ __global__ __launch_bounds__(64 * wg_waves(DP, FRIC, sizeof(T), PL), min_waves(s
                 }
             }
             clk.mark(5);
-            if (diag) {         // one count per particle-substep whose acceleration has left the range of the arithmetic (a diverged rollout)
+            // mj_checkAcc: a NaN or an entry beyond mjMAXVAL in the acceleration mj_forward arrived at - the constraint solver's
+            // where the wavefront had rows (for a particle without rows of its own that is M^-1 qfrc_smooth, as in MuJoCo),
+            // else the Euler solve's (M + h B)^-1 qfrc_smooth, which stands in for M^-1 qfrc_smooth
+            const bool acc_bad = rst && dof && !(fabs(any_rows ? acc_fwd : qacc) <= MJ_MAXVAL);
+            if (!rst && diag) {  // (no reset record: one count per particle-substep whose acceleration has left the arithmetic)
                 const unsigned long long nf = __ballot(!(fabs(qacc) < T(sizeof(T) == 4 ? 1e30 : 1e100)));
                 if (l == 0 && ((unsigned)(nf >> (PL * half)) & (PL == 32 ? ~0u : 0xFFFFu)) != 0u) atomicAdd(diag + 1, 1u);
             }
@@ -2594,21 +2646,55 @@ __global__ __launch_bounds__(64 * wg_waves(DP, FRIC, sizeof(T), PL), min_waves(s
                     }
                 }
             }
-            if (GEN && ball_g >= 0) {
-                v += h * qacc;
-            } else if (dof) {
-                v += h * qacc;
-                const T dq = h * v;
+            // ONE wave-level test guards everything rare about the integration: a hinge step beyond the reach of the angle-
+            // addition series (|dq| > 0.25 rad), and MuJoCo's reset on instability - a NaN or an entry beyond mjMAXVAL = 1e10 in
+            // the acceleration or the integrated state can only come about through a velocity jump h |qacc| beyond 1e3 (1e10 h
+            // is 1e6 or more for any time step of 1e-4 s or more; a NaN fails every <=), so the exact tests run behind it
+            bool odd = dof && !(fabs(h * qacc) <= T(1e3));
+            if (any_rows) odd = odd || (dof && !(fabs(h * acc_fwd) <= T(1e3)));
+            const bool angle = dof && !(GEN && ball_g >= 0);        // my coordinate integrates as q += h v
+            T dq = T(0);
+            if (dof) v += h * qacc;
+            if (angle) {
+                dq = h * v;
                 q += dq;
+                odd = odd || (!slide && !(fabs(dq) <= T(0.25)));
+            }
+            const bool big = __any(odd);
+            if (__builtin_expect(big, 0)) {
+                if (angle) sincos_(q, sq, cq);
+            } else if (angle) {
                 T sd, cd;
-                if (__builtin_expect(__any(!slide && fabs(dq) > T(0.25)), 0)) {
-                    sincos_(q, sq, cq);
-                } else {
-                    sincos_small(dq, sd, cd);
-                    const T s1 = sq * cd + cq * sd, c1 = cq * cd - sq * sd;
-                    const T kk = T(1.5) - T(0.5) * (s1 * s1 + c1 * c1);
-                    sq = s1 * kk;
-                    cq = c1 * kk;
+                sincos_small(dq, sd, cd);
+                const T s1 = sq * cd + cq * sd, c1 = cq * cd - sq * sd;
+                const T kk = T(1.5) - T(0.5) * (s1 * s1 + c1 * c1);
+                sq = s1 * kk;
+                cq = c1 * kk;
+            }
+            if (rst && __builtin_expect(big, 0)) {
+                const unsigned long long bb = __ballot(acc_bad || state_is_bad());
+                if (bb != 0ull) {
+                    rst_any = true;
+                    const bool acc_reset = (__ballot(acc_bad) & my_lanes) != 0ull;
+                    rst_pend = !acc_reset && (bb & my_lanes) != 0ull;
+                    if (acc_reset) {
+                        // ... -> mj_resetData, mj_forward AGAIN and mj_Euler from there: the state one substep after the reset state -
+                        // a constant of the model, made once per engine (TreeFusion::reset_rec); controls stay zero until the env
+                        // step ends, and site_xpos is the reset state's (the second mj_forward's)
+                        q = dof ? (T)rst[l] : T(0);
+                        v = dof ? (T)rst[TL + l] : T(0);
+                        if constexpr (GEN) {
+                            qy = T(0); qz = T(0); qw = T(1);
+                            if (ball_g == 0) { qy = (T)rst[l + 1]; qz = (T)rst[l + 2]; qw = (T)rst[TREE_QW + l]; }
+                            if (ball_g > 0) q = T(0);
+                        }
+                        sincos_(q, sq, cq);
+                        tau_act = act_id >= 0 ? M[T_GEAR + l] * fmin(fmax(T(0), M[T_CTRL_LO + l]), M[T_CTRL_HI + l]) : T(0);
+                        lim_mem = 0; fl_mem = 0; cinst_mem = 0; cact_mem = 0;
+                        if (sub == frame_skip - 1)
+                            for (int k = 0; k < 3; ++k) { hand[k] = (T)rst[TREE_STATE_LEN + k]; haxis[k] = (T)rst[TREE_STATE_LEN + 3 + k]; }
+                        if (diag && l == 0 && live) atomicAdd(diag + 1, 1u);
+                    }
                 }
             }
         }
@@ -2628,6 +2714,10 @@ __global__ __launch_bounds__(64 * wg_waves(DP, FRIC, sizeof(T), PL), min_waves(s
                 cst = sqrt_(dx * dx + dy * dy + dz * dz) -
                       (haxis[0] * M[T_TARGET_DIR] + haxis[1] * M[T_TARGET_DIR + 1] + haxis[2] * M[T_TARGET_DIR + 2]);
         }
+        // Take delivery of the prefetched inputs HERE, before this step's stores are issued (as arm_rollout.hip does): loads and
+        // stores share one in-order counter (vmcnt), and the register hand-over the compiler otherwise places on the loop's
+        // back-edge waits with vmcnt(0) - i.e. for the cost / observation stores just issued
+        asm volatile("" : "+v"(eps_next), "+v"(mean_next));
         if (live && l == 0) cost[pid * H + t] = cst;
         if (fuse.gseq) q0acc += gs_cur * (double)cst;
         // my link's coordinate(s) in MuJoCo's qpos layout (GEN: a ball's first link writes the quaternion, w first; a free

@@ -354,6 +354,13 @@ class ArmRolloutEngine:
         _lib.check(self._lib.mjmpc_arm_solver_failures(self._h, ctypes.byref(c)))
         return int(c.value)
 
+    def diverged_substeps(self):
+        """Resets: particle-substeps in which MuJoCo's mj_checkPos / mj_checkVel / mj_checkAcc would have called mj_resetData
+        (a NaN or an entry beyond 1e10 in qpos / qvel / qacc); the kernel does the same (see TreeRolloutEngine)."""
+        c = ctypes.c_uint32()
+        _lib.check(self._lib.mjmpc_arm_diverged(self._h, ctypes.byref(c)))
+        return int(c.value)
+
     # ------------------------------------------------------------------ helpers
     def _stream(self):
         return ctypes.c_void_p(_torch().cuda.current_stream(self.device).cuda_stream)

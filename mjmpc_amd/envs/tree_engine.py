@@ -255,8 +255,9 @@ class TreeRolloutEngine:
         return int(c.value)
 
     def diverged_substeps(self):
-        """Particle-substeps whose constraint solution was not finite (diverged rollouts: cost +inf, no weight in the
-        updates) - counted apart from solver_failures()."""
+        """Resets: particle-substeps in which MuJoCo's mj_checkPos / mj_checkVel / mj_checkAcc would have called mj_resetData
+        (a NaN or an entry beyond 1e10 in qpos / qvel / qacc); the kernel does the same and the particle rolls on from
+        qpos0 with finite costs - counted apart from solver_failures()."""
         c = ctypes.c_uint32()
         _lib.check(self._lib.mjmpc_tree_diverged(self._h, ctypes.byref(c)))
         return int(c.value)

@@ -118,6 +118,10 @@ def _bind(L):
     L.or_env_step.restype = ctypes.c_double
     L.or_env_step.argtypes = [ctypes.c_void_p, _dp, _dp, _dp, _dp, _dp]
     L.or_step.argtypes = [ctypes.c_void_p, _dp, _dp, _dp, _dp, _dp]
+    L.or_step_mj.restype = ctypes.c_int
+    L.or_step_mj.argtypes = [ctypes.c_void_p, _dp, _dp, _dp, _dp, _dp]
+    L.or_get_resets.restype = ctypes.c_long
+    L.or_get_resets.argtypes = [ctypes.c_void_p]
     L.or_rollout.argtypes = [ctypes.c_void_p, _dp, _dp, _dp, ctypes.c_long, ctypes.c_int,
                              _dp, _dp, _dp, _dp, _dp, _dp, _dp]
     L.or_rollout_cl.argtypes = L.or_rollout.argtypes
@@ -206,6 +210,17 @@ class RefArm:
         out = (ctypes.c_long * 3)()
         self._L.or_get_newton_stats(ctypes.c_void_p(self._h), out)
         return dict(calls=out[0], iters=out[1], fails=out[2])
+
+    def resets(self):
+        """mj_resetData calls so far (mj_checkPos / mj_checkVel / mj_checkAcc found a NaN or an entry beyond 1e10)."""
+        return int(self._L.or_get_resets(ctypes.c_void_p(self._h)))
+
+    def step_mj(self, q, v, ctrl):
+        """One mj_step with data.ctrl in-out: returns (q', v', site, ctrl after the step - zeroed by a reset -, resets)."""
+        q, v, u = _c(q).copy(), _c(v).copy(), _c(ctrl).copy()
+        site = np.zeros(6)
+        n = self._L.or_step_mj(self._h, _p(q), _p(v), _p(u), _p(site), None)
+        return q, v, site[:3].copy(), u, n
 
     def solve_rows(self, M, fs, J, aref, D, kind, floss):
         """The constraint solver alone (test hook): minimise 1/2 (a - M^-1 fs)' M (a - M^-1 fs) + sum_i s_i(J_i a - aref_i)

@@ -136,6 +136,7 @@ typedef struct {
     double qpos0[MAXQ];
     /* statistics */
     long newton_iters, newton_calls, newton_fail;
+    long resets;                             /* mj_resetData calls of mj_checkPos / mj_checkVel / mj_checkAcc (or_step) */
 } OrModel;
 
 /* ---------------------------------------------------------------- small linear algebra */
@@ -1185,10 +1186,20 @@ static void contact_rows(const OrModel *m, const Kin *k, const double *v, const 
 }
 
 /* ---------------------------------------------------------------- one mj_step */
+static int or_is_bad(double x) { return !(x <= 1e10 && x >= -1e10); }      /* mju_isBad: NaN, or beyond mjMAXVAL */
+static void or_reset_data(const OrModel *m, double *q, double *v, double *ctrl) {     /* mj_resetData, the part the path reads */
+    memcpy(q, m->qpos0, sizeof(double) * m->nq);
+    memset(v, 0, sizeof(double) * m->nv);
+    memset(ctrl, 0, sizeof(double) * m->nu);
+}
+
 /* q, v updated in place; site_out (optional) = finger site position computed from the q the step
  * STARTED with (MuJoCo runs kinematics before integrating and MjSim.step() does not call
  * mj_forward afterwards, so data.site_xpos lags qpos by one substep). */
-void or_step(OrModel *m, double *q, double *v, const double *ctrl, double *site_out, double *diag) {
+/* mj_forward + mj_Euler.  check_acc: MuJoCo's mj_checkAcc - when the acceleration mj_forward arrives at (d->qacc: the
+ * constraint solver's, M^-1 qfrc_smooth without rows) holds a NaN or an entry beyond mjMAXVAL = 1e10, return 1 BEFORE
+ * integrating (the caller resets and runs the substep again, as mj_step does). */
+static int step_impl(OrModel *m, double *q, double *v, const double *ctrl, double *site_out, double *diag, int check_acc) {
     int nv = m->nv;
     Kin k;
     double M[MAXV * MAXV], bias[MAXV], fs[MAXV];
@@ -1519,6 +1530,9 @@ void or_step(OrModel *m, double *q, double *v, const double *ctrl, double *site_
     }
     for (int c = nc_uni0; c < nc; c++) { kind[c] = ROW_UNI; floss[c] = 0; }
     solve_rows(m, nv, M, fs, nc, J, aref, D, kind, floss, qacc, force);
+    if (check_acc)
+        for (int j = 0; j < nv; j++)
+            if (or_is_bad(qacc[j])) return 1;
     /* mj_Euler with implicit joint damping: (M + h diag(damping)) qacc' = qfrc_smooth + qfrc_constraint */
     double rhs[MAXV];
     memcpy(rhs, fs, sizeof(double) * nv);
@@ -1546,6 +1560,40 @@ void or_step(OrModel *m, double *q, double *v, const double *ctrl, double *site_
         diag[0] = nc;
         for (int j = 0; j < nv; j++) diag[1 + j] = qacc[j];
     }
+    return 0;
+}
+
+/* mj_step [EXT] = mj_checkPos, mj_checkVel, mj_forward, mj_checkAcc, mj_Euler.  The checks (engine_forward.c) look for a
+ * NaN or an entry beyond mjMAXVAL = 1e10 (mju_isBad) in qpos / qvel / qacc; on one they issue the "simulation is unstable"
+ * warning and call mj_resetData - qpos = qpos0, qvel = 0, ctrl = 0 (act, time, warm start too) - after which mj_checkAcc
+ * runs mj_forward again and the step goes on from the reset state.  ctrl is IN-OUT: mjrl's do_simulation writes
+ * data.ctrl once per env step and then calls sim.step() frame_skip times (mjrl mujoco_env.py [EXT]; the call site is
+ * reacher_env.py:30), so a reset leaves the remaining substeps of that env step with zero controls.  Returns the number
+ * of resets (0 .. 2).  (Under mujoco-py's DEFAULT warning callback the same warning raises MujocoException out of
+ * sim.step() and the reference's worker dies, gym_env_wrapper.py:125-153 catches nothing; what is restated here is
+ * MuJoCo's own behaviour, which is what runs with mujoco_py.ignore_mujoco_warnings.) */
+int or_step_mj(OrModel *m, double *q, double *v, double *ctrl, double *site_out, double *diag) {
+    int resets = 0, bad = 0;
+    for (int i = 0; i < m->nq; i++) bad |= or_is_bad(q[i]);
+    for (int i = 0; i < m->nv; i++) bad |= or_is_bad(v[i]);
+    if (bad) {
+        or_reset_data(m, q, v, ctrl);
+        resets++;
+    }
+    if (step_impl(m, q, v, ctrl, site_out, diag, 1)) {
+        or_reset_data(m, q, v, ctrl);
+        resets++;
+        step_impl(m, q, v, ctrl, site_out, diag, 0);
+    }
+    m->resets += resets;
+    return resets;
+}
+
+/* one mj_step with controls that are not written back (a reset zeroes a private copy) */
+void or_step(OrModel *m, double *q, double *v, const double *ctrl, double *site_out, double *diag) {
+    double u[MAXV];
+    memcpy(u, ctrl, sizeof(double) * m->nu);
+    or_step_mj(m, q, v, u, site_out, diag);
 }
 
 /* ---------------------------------------------------------------- run-time model edits (dynamics randomization)
@@ -1592,6 +1640,7 @@ void or_get_invweight0_rot(const OrModel *m, double *body) { memcpy(body, m->bod
 void or_get_newton_stats(const OrModel *m, long *out) {
     out[0] = m->newton_calls; out[1] = m->newton_iters; out[2] = m->newton_fail;
 }
+long or_get_resets(const OrModel *m) { return m->resets; }
 void or_mass_matrix(const OrModel *m, const double *q, double *M) {
     Kin k;
     kinematics(m, q, &k);
@@ -1627,8 +1676,9 @@ static double env_step(OrModel *m, double *q, double *v, const double *u, const 
         /* SwimmerEnv.step / HalfCheetahEnv.step (swimmer.py:10-19, half_cheetah.py:10-19): reward = forward progress
          * of qpos[0] over the env step / dt - c * |a|^2 (the action as given, unclipped), obs = [qpos[skip:], qvel] */
         int nv = m->nv, nq = m->nq, sk = m->obs_skip;
-        double x0 = q[0], c = 0;
-        for (int s = 0; s < m->frame_skip; s++) or_step(m, q, v, u, NULL, NULL);
+        double x0 = q[0], c = 0, uu[MAXV];
+        memcpy(uu, u, sizeof(double) * m->nu);              /* data.ctrl: written once per env step, zeroed by a reset */
+        for (int s = 0; s < m->frame_skip; s++) or_step_mj(m, q, v, uu, NULL, NULL);
         for (int a = 0; a < m->nu; a++) c += u[a] * u[a];
         if (obs) {
             memcpy(obs, q + sk, sizeof(double) * (nq - sk));
@@ -1636,8 +1686,9 @@ static double env_step(OrModel *m, double *q, double *v, const double *u, const 
         }
         return (q[0] - x0) / (m->timestep * m->frame_skip) - m->ctrl_cost * c;
     }
-    double h[3] = {0, 0, 0}, h6[6];
-    for (int s = 0; s < m->frame_skip; s++) { or_step(m, q, v, u, h6, NULL); memcpy(h, h6, 24); }
+    double h[3] = {0, 0, 0}, h6[6], uu[MAXV];
+    memcpy(uu, u, sizeof(double) * m->nu);
+    for (int s = 0; s < m->frame_skip; s++) { or_step_mj(m, q, v, uu, h6, NULL); memcpy(h, h6, 24); }
     double d[3] = {h[0] - target[0], h[1] - target[1], h[2] - target[2]};
     double l1 = fabs(d[0]) + fabs(d[1]) + fabs(d[2]), l2 = sqrt(dot3(d, d));
     if (obs) {
@@ -1686,11 +1737,11 @@ static void rollout_impl(OrModel *m, const double *qp0, const double *qv0, const
     int nv = m->nv, nq = m->nq, nu = m->nu, dobs = or_dobs(m);
     double h0[3] = {0, 0, 0};
     if (m->task != 1) or_site(m, qp0, h0);
-    long calls = 0, iters = 0, fails = 0;
-#pragma omp parallel for schedule(static) reduction(+ : calls, iters, fails)
+    long calls = 0, iters = 0, fails = 0, resets = 0;
+#pragma omp parallel for schedule(static) reduction(+ : calls, iters, fails, resets)
     for (long b = 0; b < P; b++) {
         OrModel loc = *m;       /* private statistics */
-        loc.newton_calls = loc.newton_iters = loc.newton_fail = 0;
+        loc.newton_calls = loc.newton_iters = loc.newton_fail = loc.resets = 0;
         double q[MAXQ], v[MAXV], cur[MAXQ + MAXV + 6], nxt[MAXQ + MAXV + 6], u[MAXV];
         memcpy(q, qp0, sizeof(double) * nq);
         memcpy(v, qv0, sizeof(double) * nv);
@@ -1722,7 +1773,7 @@ static void rollout_impl(OrModel *m, const double *qp0, const double *qv0, const
             if (done) done[o] = 0.0;
             memcpy(cur, nxt, sizeof(double) * dobs);
         }
-        calls += loc.newton_calls; iters += loc.newton_iters; fails += loc.newton_fail;
+        calls += loc.newton_calls; iters += loc.newton_iters; fails += loc.newton_fail; resets += loc.resets;
     }
-    m->newton_calls += calls; m->newton_iters += iters; m->newton_fail += fails;
+    m->newton_calls += calls; m->newton_iters += iters; m->newton_fail += fails; m->resets += resets;
 }

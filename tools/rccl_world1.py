@@ -20,9 +20,13 @@ from mjmpc_amd.envs.arm_engine import ArmRolloutEngine, make_device_rollout_fn
 from mjmpc_amd.models.reacher7dof import reacher7dof_raw
 
 
+COMMS = []
+
+
 class ClaimsTwoRanks(TorchDistComm):
     def __init__(self):
         super().__init__()
+        COMMS.append(self)
         self.world_size = 2         # sharding map and code paths of a two-rank run; the gather returns ONE record
 
     def all_gather(self, t):
@@ -50,7 +54,7 @@ def run(P, comm, mono):
     again = [c.optimize({})[0] for _ in range(6)]
     torch.cuda.synchronize()
     assert np.abs(np.array(again) - np.array(acts)).max() < 1e-12, "the closed loop after reset() differs"
-    info = (c.local_particles, c._mono, getattr(c, "graph_fallback", False), c._graph not in (None, "direct"))
+    info = (c.local_particles, c._mono, getattr(c, "graph_fallback", False), c._graph is not None, c.launch_mode)
     c._graph = None             # (captured graphs hold the communicator's resources: gone before the group is)
     return np.array(acts), info
 
@@ -59,12 +63,19 @@ ref, _ = run(512, None, True)                       # 512 particles on one GPU
 for mono in (True, False):
     got, info = run(1024, ClaimsTwoRanks(), mono)   # "1024 over two ranks": this rank's 512 are the same particles
     assert info[0] == 512 and info[1] == mono and not info[2]
-    assert info[3], "the sharded iteration should replay a captured graph"
+    assert info[3], "the sharded iteration should run as a captured graph, from its launch tape or as direct launches"
+    # the all-gather is issued by the library (TorchDistComm.lib_collectives): the fused iteration is three direct launches,
+    # the separate launches run from the launch tape; with MJMPC_TORCH_COLLECTIVES=1 (torch.distributed's collective) both
+    # replay a hipGraph
+    if os.environ.get("MJMPC_TORCH_COLLECTIVES"):
+        assert info[4] == "hipGraph replay", info[4]
+    else:
+        assert info[4].startswith("launched directly" if mono else "launch tape"), info[4]
     err = np.abs(got - ref).max()
     if os.environ.get("RCCL_W1_DEBUG"):
         print(np.abs(got - ref).max(axis=1)); print(ref[:2]); print(got[:2])
-    print("sharded iteration (%s) in a hipGraph with an RCCL all-gather: max |d action| vs the single-GPU run = %.2e"
-          % ("rollout + record launches" if mono else "separate launches", err))
+    print("sharded iteration (%s; %s) with an RCCL all-gather: max |d action| vs the single-GPU run = %.2e"
+          % ("rollout + record launches" if mono else "separate launches", info[4], err))
     assert err < 1e-9 or os.environ.get('RCCL_W1_DEBUG')
 
 # The other controllers' exchanges inside a captured graph: CEM (the q0 all-gather + the elite-record all-gather), DMD-MPC
@@ -75,6 +86,10 @@ from mjmpc_amd.control import CEM, DMDMPC, RandomShooting
 
 class AlwaysCollective(TorchDistComm):
     always_collective = True
+
+    def __init__(self):
+        super().__init__()
+        COMMS.append(self)
 
 
 def run_other(make, comm):
@@ -90,6 +105,8 @@ def run_other(make, comm):
     acts = np.array([c.optimize({})[0] for _ in range(5)])
     torch.cuda.synchronize()
     assert c._graph is not None and not getattr(c, "graph_fallback", False)
+    if comm is not None and not os.environ.get("MJMPC_TORCH_COLLECTIVES"):
+        assert c.launch_mode.startswith("launch tape"), c.launch_mode      # (its exchanges are library calls)
     c._graph = None             # (captured graphs hold the communicator's resources: gone before the group is)
     return acts
 
@@ -110,6 +127,8 @@ def shutdown():
     import gc
     gc.collect()
     torch.cuda.synchronize()
+    for c in COMMS:
+        c.close()               # (the library's own communicators)
     dist.destroy_process_group()
 
 
