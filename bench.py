@@ -58,7 +58,7 @@ def parse(argv=None):
     ap.add_argument("--noise", choices=["device", "mt19937", "host"], default="device",
                     help="device: Philox on the GPU; mt19937: the reference's own numpy stream regenerated on the GPU "
                          "(seed-identical particles); host: numpy on the host, uploaded")
-    ap.add_argument("--workload", choices=["reacher", "half_cheetah", "swimmer", "hand24", "pen_hand", "cartpole", "tray", "door"],
+    ap.add_argument("--workload", choices=["reacher", "half_cheetah", "swimmer", "hand24", "pen_hand", "cartpole", "tray", "door", "gripper"],
                     default="reacher",
                     help="reacher: the BASELINE.json headline (default).  The others run the same loop on the tree engine "
                          "(SURVEY 8f rank 4: the reference's vendored HalfCheetah / Swimmer models, the synthetic 24-dof hand, "
@@ -217,7 +217,7 @@ def make_workload(args, local, comm, P_tot):
             from mjmpc_amd.models.pen_hand import holding_state, pen_hand_raw
             raw, env, name, lam = pen_hand_raw(), None, "pen_hand-v0 (synthetic 6-dof pen in a 24-dof hand)", {"mppi": 0.05, "dmd": 0.1}
             start = holding_state()
-        elif args.workload in ("cartpole", "tray", "door"):
+        elif args.workload in ("cartpole", "tray", "door", "gripper"):
             from mjmpc_amd.models.synthetic import start_state, synthetic_raw
             raw, env = synthetic_raw(args.workload), None
             name = "%s_synthetic-v0 (mjmpc_amd/models/assets/%s.xml)" % (args.workload, args.workload)
@@ -241,9 +241,9 @@ def make_workload(args, local, comm, P_tot):
             st0 = env.get_env_state()
             w["reset"] = lambda: eng.set_env_state(st0)
             w["x0"] = float(st0["qpos"][0])
-        elif args.workload in ("cartpole", "tray", "door"):
+        elif args.workload in ("cartpole", "tray", "door", "gripper"):
             w["reset"] = lambda: eng.set_env_state(gen_start)
-            w["cov"] = 0.01 if args.workload == "tray" else 0.3
+            w["cov"] = 0.01 if args.workload in ("tray", "gripper") else 0.3
         elif start is not None:
             st0 = dict(start, target_pos=np.asarray(raw.target_pos, float))
             w["reset"] = lambda: eng.set_env_state(st0)

@@ -24,7 +24,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from mjmpc_amd.envs.arm_engine import ArmRolloutEngine, make_device_rollout_fn, make_rollout_fn   # noqa: E402
 from mjmpc_amd.envs.locomotion_env import HalfCheetahEnv, SwimmerEnv                             # noqa: E402
 from mjmpc_amd.envs.reacher_env import ContinualReacher7DOFEnv, HandTreeEnv, Reacher7DOFEnv      # noqa: E402
-from mjmpc_amd.envs.synthetic_env import CartPoleEnv, DoorEnv, TrayEnv                           # noqa: E402
+from mjmpc_amd.envs.synthetic_env import CartPoleEnv, DoorEnv, GripperEnv, TrayEnv                           # noqa: E402
 from mjmpc_amd.envs.tree_engine import TreeRolloutEngine                                         # noqa: E402
 from mjmpc_amd.models.half_cheetah import half_cheetah_raw                                       # noqa: E402
 from mjmpc_amd.models.hand24 import hand24_raw                                                   # noqa: E402
@@ -38,10 +38,11 @@ from mjmpc_amd.policies import MPCPolicy                                        
 ENVS = {"reacher_7dof-v0": Reacher7DOFEnv, "continual_reacher-v0": ContinualReacher7DOFEnv,
         "Swimmer-v0": SwimmerEnv, "HalfCheetah-v0": HalfCheetahEnv, "hand_tree-v0": HandTreeEnv,
         # round 4: synthetic MJCF models of the kinds the reference's other experiment files name (general kernel instantiation)
-        "cartpole_friction-v0": CartPoleEnv, "tray_glass_synthetic-v0": TrayEnv, "door_latch_synthetic-v0": DoorEnv}
+        "cartpole_friction-v0": CartPoleEnv, "tray_glass_synthetic-v0": TrayEnv, "door_latch_synthetic-v0": DoorEnv,
+        "pen_gripper_synthetic-v0": GripperEnv}      # (round 5: capsule / box and cylinder / plane contacts, joint ref / margin)
 TREE_MODELS = {"hand_tree-v0": hand24_raw, "Swimmer-v0": swimmer_raw, "HalfCheetah-v0": half_cheetah_raw,
                "cartpole_friction-v0": lambda: synthetic_raw("cartpole"), "tray_glass_synthetic-v0": lambda: synthetic_raw("tray"),
-               "door_latch_synthetic-v0": lambda: synthetic_raw("door")}
+               "door_latch_synthetic-v0": lambda: synthetic_raw("door"), "pen_gripper_synthetic-v0": lambda: synthetic_raw("gripper")}
 
 
 def make_sim(env_name, dtype, num_shards):

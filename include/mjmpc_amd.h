@@ -203,7 +203,7 @@ int mjmpc_arm_step_state(mjmpc_arm_t h, int dtype, const double* d_action, void*
  *   k | distance << 8 | height << 16, -1 ends)
  * Same call shapes and reference counterparts as the arm engine (subproc_vec_env.py:91-111, 128-186, 235-251);
  * target_pos is ignored by task 1.                                                                                  */
-#define MJMPC_TREE_BLOB_LEN 3929
+#define MJMPC_TREE_BLOB_LEN 3961
 /* Round 4, the GENERAL instantiation (block field `gen`; models without these features run the earlier kernels unchanged):
  * ball and free joints (quaternion links: qpos has nq >= nv entries in MuJoCo's layout, d_obs = nq + nv + 6 or nq + nv -
  * obs_skip), joint anchors off the body origin, explicit inertials, box geoms (eight corner points against the plane, one

@@ -101,7 +101,8 @@ enum TreeOffset : int {
     T_QW0 = T_PEXT + TREE_MAX_SPHERES * 24,     // 32: BALL_X links: w of the joint's qpos0 quaternion q0 (x, y, z in the three
                                         // links' T_QOFF): identity for a ball joint, the body's orientation for a free
                                         // joint, whose qpos quaternion is ABSOLUTE - the kernel's is relative, qpos = q0 * q_link
-    TREE_BLOB_LEN = T_QW0 + TL
+    T_JMARGIN = T_QW0 + TL,             // 32 (round 5): MJCF joint margin - a hinge / slide dof's limit row exists while dist < margin
+    TREE_BLOB_LEN = T_JMARGIN + TL
 };
 constexpr int TREE_PEXT_STRIDE = 24;    // [0:3] box half sizes, [3:12] box orientation in its link's frame | dof row: [0] 0 joint
                                         // equality / 1 tendon limit, [1] coef A (joint equality: 1 = anchor dof is joint 2),
@@ -112,7 +113,14 @@ constexpr int TREE_PEXT_STRIDE = 24;    // [0:3] box half sizes, [3:12] box orie
 enum TreeLinkKind : int { LINK_HINGE = 1, LINK_SLIDE = 2, LINK_BALL_X = 3, LINK_BALL_Y = 4, LINK_BALL_Z = 5 };
 // contact-record kinds ([12])
 enum TreePointKind : int { PT_PLANE = 0, PT_SEGSEG = 1, PT_SPHERE_BOX = 2, PT_BOX_SPHERE = 3, PT_CONNECT = 4, PT_DOFROW = 5,
-                           PT_WELD = 6 };      // (a weld equality is a PT_CONNECT record at body 2's origin plus a PT_WELD record: its rotation rows)
+                           PT_WELD = 6,        // (a weld equality is a PT_CONNECT record at body 2's origin plus a PT_WELD record: its rotation rows)
+                           // round 5 - records that come in GROUPS of [23] consecutive ones, [22] = the record's index in its group:
+                           PT_PLANE_CYL = 7,   // a cylinder on the plane (mjc_PlaneCylinder): candidate point k of four; [1:4] centre, [4] radius,
+                                               // [8:11] axis, [14] half height
+                           PT_CAPSULE_BOX = 8, PT_BOX_CAPSULE = 9 };   // a capsule against a box: candidate k of three (the axis' nearest point,
+                                               // the two ends); segment as PT_SEGSEG, box as PT_SPHERE_BOX.  (A box's corners on the plane
+                                               // are PT_PLANE records with [23] = 8, [22] = corner, [14:17] = the box centre: mjc_PlaneBox
+                                               // skips corners above the centre and keeps four contacts)
 
 // device state: qpos[32] | qvel[32] | target[3] | site of the fresh observation[3] | quaternion w[32], one entry per LINK
 // (a BALL_X link keeps x, y, z in the qpos entries of its three links and w in its own w entry)
@@ -123,6 +131,6 @@ constexpr int TREE_RESET_LEN = TREE_STATE_LEN + 6;
 constexpr int TREE_NQ_MAX = 40;
 // the C ABI's state vectors (mjmpc_tree_set_shard_states): MuJoCo's layout - qpos[40] | qvel[32] | target[3] | reserved[3]
 constexpr int TREE_PUBLIC_STATE_LEN = TREE_NQ_MAX + TL + 6;
-static_assert(TREE_BLOB_LEN == 3929, "keep in sync with mjmpc_amd/models/compile_tree.py::TREE_LAYOUT");
+static_assert(TREE_BLOB_LEN == 3961, "keep in sync with mjmpc_amd/models/compile_tree.py::TREE_LAYOUT");
 
 }  // namespace mjmpc

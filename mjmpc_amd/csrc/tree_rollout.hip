@@ -1047,6 +1047,77 @@ __device__ __forceinline__ T dense_solve_any(const T* r, T dinv, T b, int l) {
     else return dense_solve<DN>(r, dinv, b, l);
 }
 
+// The surface point of a solid box (half sizes h, its own frame) nearest to `loc` (that frame): outside - the clamped point,
+// normal towards `loc`; inside - the nearest face and its outward normal; len = signed distance (mjc_SphereBox's geometry;
+// the oracle's box_point).  false: `loc` lies on the surface to rounding (no normal).
+template <typename T>
+__device__ __forceinline__ bool box_point(const T* h, const T* loc, T* cl, T* nb, T& len) {
+    bool inside = true;
+    for (int i = 0; i < 3; ++i) {
+        cl[i] = fmin(fmax(loc[i], -h[i]), h[i]);
+        inside = inside && cl[i] == loc[i];
+    }
+    nb[0] = T(0); nb[1] = T(0); nb[2] = T(0);
+    if (inside) {
+        int kk = 0;
+        T best = h[0] - fabs(loc[0]);
+        for (int i = 1; i < 3; ++i) {
+            const T gap = h[i] - fabs(loc[i]);
+            if (gap < best) { best = gap; kk = i; }
+        }
+        const T sg = loc[kk] >= T(0) ? T(1) : T(-1);
+        for (int i = 0; i < 3; ++i) {
+            if (i == kk) { cl[i] = sg * h[i]; nb[i] = sg; }
+        }
+        len = -best;
+        return true;
+    }
+    for (int i = 0; i < 3; ++i) nb[i] = loc[i] - cl[i];
+    len = sqrt_(dot3(nb, nb));
+    if (!(len > T(1e-14))) return false;
+    const T inv = T(1) / len;
+    for (int i = 0; i < 3; ++i) nb[i] *= inv;
+    return true;
+}
+
+// The parameter t in [0, 1] at which the segment a + t b (box frame) comes nearest to the solid box: the squared distance is
+// convex and piecewise quadratic, its pieces end where a coordinate crosses a face plane (at most six break points); every
+// piece is minimised in closed form and the least minimum taken, the first where pieces tie (the oracle's seg_box_param)
+template <typename T>
+__device__ __noinline__ T seg_box_param(const T* h, const T* a, const T* b) {
+    T bp[8];
+    bp[0] = T(0);
+    bp[7] = T(1);
+    for (int i = 0; i < 3; ++i)
+        for (int sg = 0; sg < 2; ++sg) {
+            T t = T(1);             // (a coordinate that does not move has no crossing: a duplicate of the end point)
+            if (b[i] != T(0)) t = ((sg ? h[i] : -h[i]) - a[i]) / b[i];
+            bp[1 + 2 * i + sg] = fmin(fmax(t, T(0)), T(1));
+        }
+    for (int i = 1; i < 8; ++i)
+        for (int j = i; j > 0 && bp[j] < bp[j - 1]; --j) { const T t = bp[j]; bp[j] = bp[j - 1]; bp[j - 1] = t; }
+    T best_f = T(1e300), best_t = T(0);
+    if (sizeof(T) == 4) best_f = T(3e38);
+    for (int k = 0; k < 7; ++k) {
+        const T u = bp[k], w = bp[k + 1], mid = T(0.5) * (u + w);
+        T B = T(0), C = T(0), off[3];
+        int act[3];
+        for (int i = 0; i < 3; ++i) {
+            const T si = a[i] + mid * b[i];
+            act[i] = si > h[i] ? 1 : (si < -h[i] ? -1 : 0);
+            off[i] = a[i] - T(act[i]) * h[i];
+            if (act[i]) { B += b[i] * b[i]; C += b[i] * off[i]; }
+        }
+        T tc = u;
+        if (B > T(0)) tc = fmin(fmax(-C / B, u), w);
+        T f = T(0);
+        for (int i = 0; i < 3; ++i)
+            if (act[i]) { const T e = off[i] + tc * b[i]; f += e * e; }
+        if (f < best_f) { best_f = f; best_t = tc; }
+    }
+    return best_t;
+}
+
 // Exact line search of the constraint solver's safeguard (see the Newton loop): the root in [0, 1] of the increasing,
 // piecewise linear  phi'(al) = g0 + al dg + sum over the particle's rows of D_r min(0, r_r + al dr_r) dr_r  - every lane
 // brings its limit row (Dl, rl, drl) and, as the owner of a contact point, that point's rows (Dc, rb[], drb[]).  Bisection
@@ -1227,6 +1298,7 @@ __global__ __launch_bounds__(64 * wg_waves(DP, FRIC, sizeof(T), PL), min_waves(s
     const T q0w = (GEN && ball_g == 0) ? model[T_QW0 + l] : T(1);
     const T q0y = (GEN && ball_g == 0) ? model[T_QOFF + l + 1] : T(0), q0z = (GEN && ball_g == 0) ? model[T_QOFF + l + 2] : T(0);
     const T floss = (GEN && dof) ? model[T_FRICTIONLOSS + l] : T(0);            // dry friction of my dof (0: no row)
+    const T jmargin = (GEN && dof) ? model[T_JMARGIN + l] : T(0);               // MJCF joint margin: my limit row exists while dist < margin
     const bool any_floss = GEN && __any(floss > T(0));
     const int dofcls = (int)model[T_DOFCLS + l];                                // my dof's solver sets: limit row | friction-loss row << 3
     T fsol[7];                                                                  // friction-loss rows' solver set
@@ -1487,6 +1559,12 @@ __global__ __launch_bounds__(64 * wg_waves(DP, FRIC, sizeof(T), PL), min_waves(s
                         const T cdist = dot3(ctr, pn) - M[T_PLANE_D] - sp[4];
                         cs[3] = cdist;
                         ci_mine = cdist < sp[5];            // mj_collision: included while dist < margin
+                        if (GEN && sp[23] == T(8)) {        // a box's corner (mjc_PlaneBox): not one above the box centre ...
+                            T tc[3];
+                            mv3(Rl, sp + 14, tc);
+                            const T up = (tv[0] - tc[0]) * pn[0] + (tv[1] - tc[1]) * pn[1] + (tv[2] - tc[2]) * pn[2];
+                            ci_mine = ci_mine && !(up > T(0));      // (... and at most four per box: below, behind the ballot)
+                        }
                         if (FRIC) {                         // the contact point, and the frame aligned with the capsule axis
                             for (int k = 0; k < 3; ++k) cs[k] = ctr[k] - pn[k] * (sp[4] + T(0.5) * cdist);
                             mv3(Rl, sp + 8, tv);
@@ -1596,10 +1674,55 @@ __global__ __launch_bounds__(64 * wg_waves(DP, FRIC, sizeof(T), PL), min_waves(s
                             cs[11 + i] = ex[i] * vx + ex[3 + i] * vy + ex[6 + i] * vz;        // residual = R0_2' v
                         }
                         ci_mine = true;
-                    } else if (GEN && (sp[12] == T(PT_SPHERE_BOX) || sp[12] == T(PT_BOX_SPHERE))) {
+                    } else if (GEN && sp[12] == T(PT_PLANE_CYL)) {
+                        // a cylinder on the plane (mjc_PlaneCylinder, as the oracle restates it): the lowest point of the lower
+                        // cap's rim, the point below it on the other cap's rim, two more points of the lower rim 120 degrees to
+                        // either side - candidate sp[22] of the four; the later ones count only if the first does
+                        T ctr[3], a3[3], vec[3];
+                        mv3(Rl, sp + 1, tv);
+                        for (int k = 0; k < 3; ++k) ctr[k] = pl[k] + tv[k];
+                        mv3(Rl, sp + 8, a3);
+                        T pa = dot3(pn, a3);
+                        if (pa > T(0)) { for (int k = 0; k < 3; ++k) a3[k] = -a3[k]; pa = -pa; }
+                        for (int k = 0; k < 3; ++k) vec[k] = pn[k] - pa * a3[k];
+                        T len = sqrt_(dot3(vec, vec));
+                        if (len < T(1e-12)) {
+                            const bool yy = a3[1] < T(0.5) && a3[1] > T(-0.5);
+                            const T ax3[3] = {T(0), yy ? T(1) : T(0), yy ? T(0) : T(1)};
+                            const T pr = dot3(a3, ax3);
+                            for (int k = 0; k < 3; ++k) vec[k] = ax3[k] - pr * a3[k];
+                            len = sqrt_(dot3(vec, vec));
+                        }
+                        const T rr = sp[4], hh = sp[14], sc0 = rr / len;
+                        for (int k = 0; k < 3; ++k) vec[k] *= sc0;
+                        const T d0 = dot3(pn, ctr) - M[T_PLANE_D], pv = dot3(pn, vec), d1 = d0 + pa * hh - pv;
+                        const int kk = (int)sp[22];
+                        T pt3[3], cdist;
+                        if (kk == 0) {
+                            for (int k = 0; k < 3; ++k) pt3[k] = ctr[k] + a3[k] * hh - vec[k];
+                            cdist = d1;
+                        } else if (kk == 1) {
+                            for (int k = 0; k < 3; ++k) pt3[k] = ctr[k] - a3[k] * hh - vec[k];
+                            cdist = d0 - pa * hh - pv;
+                        } else {
+                            T v1[3];
+                            cross3(vec, a3, v1);
+                            const T sc = (kk == 2 ? T(1) : T(-1)) * T(0.86602540378443864676);
+                            for (int k = 0; k < 3; ++k) pt3[k] = ctr[k] + a3[k] * hh + T(0.5) * vec[k] + sc * v1[k];
+                            cdist = d0 + pa * hh + T(0.5) * pv;
+                        }
+                        for (int k = 0; k < 3; ++k) { cs[k] = pt3[k] - pn[k] * (T(0.5) * cdist); cs[8 + k] = pn[k]; }
+                        const T zero3[3] = {T(0), T(0), T(0)};
+                        frame_tangent(pn, zero3, cs + 11);
+                        cs[3] = cdist;
+                        ci_mine = d1 < sp[5] && cdist < sp[5];
+                    } else if (GEN && (sp[12] == T(PT_SPHERE_BOX) || sp[12] == T(PT_BOX_SPHERE) || sp[12] == T(PT_CAPSULE_BOX) || sp[12] == T(PT_BOX_CAPSULE))) {
                         // a sphere against a box (mjc_SphereBox): the box's closest point to the sphere's centre, or - centre
-                        // inside - the nearest face; normal from geom B to geom A, contact point midway between the surfaces
-                        const bool boxA = sp[12] == T(PT_BOX_SPHERE);
+                        // inside - the nearest face; normal from geom B to geom A, contact point midway between the surfaces.
+                        // A capsule against a box (round 5; a scheme of its own, see the oracle): candidate sp[22] of three -
+                        // where the capsule's axis comes nearest to the box, its two ends where they are not that point
+                        const bool boxA = sp[12] == T(PT_BOX_SPHERE) || sp[12] == T(PT_BOX_CAPSULE);
+                        const bool capsule = sp[12] == T(PT_CAPSULE_BOX) || sp[12] == T(PT_BOX_CAPSULE);
                         const int sb = (int)sp[13];
                         const T* ex = PEXT + l * TREE_PEXT_STRIDE;
                         T Rb[9], oA[3], oB[3];
@@ -1611,46 +1734,32 @@ __global__ __launch_bounds__(64 * wg_waves(DP, FRIC, sizeof(T), PL), min_waves(s
                         for (int k = 0; k < 3; ++k) oB[k] = (sb >= 0 ? X[(9 + k) * PL + sb] : T(0)) + tv[k];
                         const T* Rx = boxA ? Rl : Rb;                       // the box's link
                         const T* ob = boxA ? oA : oB;
-                        const T* os = boxA ? oB : oA;
+                        const T* os0 = boxA ? oB : oA;
                         const T rs = boxA ? sp[17] : sp[4];
                         T Rw[9];
                         for (int i = 0; i < 3; ++i)
                             for (int j = 0; j < 3; ++j)
                                 Rw[3 * i + j] = Rx[3 * i] * ex[3 + j] + Rx[3 * i + 1] * ex[6 + j] + Rx[3 * i + 2] * ex[9 + j];
-                        const T rel[3] = {os[0] - ob[0], os[1] - ob[1], os[2] - ob[2]};
-                        T loc[3], cl[3];
-                        bool inside = true;
-                        for (int i = 0; i < 3; ++i) {
-                            loc[i] = Rw[i] * rel[0] + Rw[3 + i] * rel[1] + Rw[6 + i] * rel[2];
-                            cl[i] = fmin(fmax(loc[i], -ex[i]), ex[i]);
-                            inside = inside && cl[i] == loc[i];
+                        const T rel[3] = {os0[0] - ob[0], os0[1] - ob[1], os0[2] - ob[2]};
+                        T loc[3], cl[3], os[3] = {os0[0], os0[1], os0[2]};
+                        for (int i = 0; i < 3; ++i) loc[i] = Rw[i] * rel[0] + Rw[3 + i] * rel[1] + Rw[6 + i] * rel[2];
+                        bool ok = true;
+                        if (capsule) {
+                            T dv[3], bl[3];
+                            if (boxA) mv3(Rb, sp + 18, dv); else mv3(Rl, sp + 8, dv);
+                            for (int i = 0; i < 3; ++i) bl[i] = Rw[i] * dv[0] + Rw[3 + i] * dv[1] + Rw[6 + i] * dv[2];
+                            const T tstar = seg_box_param(ex, loc, bl);
+                            const int cand = (int)sp[22];
+                            const T tt = cand == 0 ? tstar : (cand == 1 ? T(0) : T(1));
+                            ok = cand == 0 || tt != tstar;
+                            for (int i = 0; i < 3; ++i) { loc[i] += tt * bl[i]; os[i] += tt * dv[i]; }
                         }
-                        T nb[3] = {T(0), T(0), T(0)}, len;
-                        if (inside) {
-                            int kk = 0;
-                            T best = ex[0] - fabs(loc[0]);
-                            for (int i = 1; i < 3; ++i) {
-                                const T gap = ex[i] - fabs(loc[i]);
-                                if (gap < best) { best = gap; kk = i; }
-                            }
-                            const T sg = loc[kk] >= T(0) ? T(1) : T(-1);
-                            for (int i = 0; i < 3; ++i) {
-                                if (i == kk) cl[i] = sg * ex[i];
-                                nb[i] = sg * Rw[3 * i + kk];
-                            }
-                            len = -best;
-                        }
+                        T nl[3], nb[3], len = T(0);
+                        ok = box_point(ex, loc, cl, nl, len) && ok;
+                        mv3(Rw, nl, nb);
                         T cb[3];
                         mv3(Rw, cl, cb);
                         for (int k = 0; k < 3; ++k) cb[k] += ob[k];
-                        bool ok = true;
-                        if (!inside) {
-                            for (int k = 0; k < 3; ++k) nb[k] = os[k] - cb[k];
-                            len = sqrt_(dot3(nb, nb));
-                            ok = len > T(1e-14);
-                            const T inv = ok ? T(1) / len : T(0);
-                            for (int k = 0; k < 3; ++k) nb[k] *= inv;
-                        }
                         // nb points from the box to the sphere; the contact's normal from geom B to geom A
                         const T sgn = boxA ? T(-1) : T(1);
                         const T cdist = len - rs;
@@ -1719,7 +1828,19 @@ __global__ __launch_bounds__(64 * wg_waves(DP, FRIC, sizeof(T), PL), min_waves(s
                         ci_mine = len > T(1e-14) && cdist < sp[5];
                     }
                 }
-                const unsigned long long b = __ballot(ci_mine);
+                unsigned long long b = __ballot(ci_mine);
+                if constexpr (GEN) {
+                    // mjc_PlaneBox keeps a box's first four contacts, in corner order: a corner with four counted corners of its
+                    // box (records l - k .. l - 1 of its group) ahead of it is dropped
+                    bool capped = false;
+                    if (l < n_sphere && M[T_SPH + l * TREE_SPH_STRIDE + 23] == T(8)) {
+                        const int k = (int)M[T_SPH + l * TREE_SPH_STRIDE + 22];
+                        const unsigned mine = (unsigned)(b >> (PL * half));
+                        const unsigned ahead = mine & ((1u << l) - 1u) & ~((1u << (l - k)) - 1u);
+                        capped = __popc(ahead) >= 4;
+                    }
+                    if (__any(capped)) b = __ballot(ci_mine && !capped);
+                }
                 cinst = (unsigned)(b >> (PL * half)) & (PL == 32 ? ~0u : 0xFFFFu);
                 ucinst = (unsigned)b | (unsigned)(b >> 32);
                 if (PL == 16) ucinst = (ucinst | (ucinst >> 16)) & 0xFFFFu;
@@ -1925,8 +2046,8 @@ __global__ __launch_bounds__(64 * wg_waves(DP, FRIC, sizeof(T), PL), min_waves(s
             bool inst = false;
             if (dof && M[T_LIMITED + l] != T(0)) {
                 const T dlo = q - M[T_RANGE_LO + l], dhi = M[T_RANGE_HI + l] - q;
-                if (dlo < T(0)) { sig = T(1); dist = dlo; inst = true; }
-                else if (dhi < T(0)) { sig = T(-1); dist = dhi; inst = true; }
+                if (dlo < jmargin) { sig = T(1); dist = dlo; inst = true; }
+                else if (dhi < jmargin) { sig = T(-1); dist = dhi; inst = true; }
             }
             // ... and plane-sphere contacts (mjc_PlaneSphere / the two ends mjc_PlaneCapsule tests): Jacobian rows in
             // LDS, scalars per contact point.  condim 1: one row Jn.  condim 3 (FRIC): MuJoCo's pyramidal cone - the four
@@ -2090,7 +2211,7 @@ __global__ __launch_bounds__(64 * wg_waves(DP, FRIC, sizeof(T), PL), min_waves(s
             if (any_rows) {
                 clk.count(10, 1);
                 if (__any(inst)) {      // (the impedance arithmetic only when some lane of the wavefront has a limit row)
-                    tree_row_params(M + T_SOLTAB + 7 * (dofcls & 7), dist, M[T_DOF_INVW + l], sig * v, D, aref);
+                    tree_row_params(M + T_SOLTAB + 7 * (dofcls & 7), dist - jmargin, M[T_DOF_INVW + l], sig * v, D, aref);
                     D = inst ? D : T(0);
                     aref = inst ? aref : T(0);
                 }

@@ -88,3 +88,10 @@ class DoorEnv(SyntheticEnv):
     model_name = "door"
     max_episode_steps = 150
     goal_radius = 0.1
+
+
+class GripperEnv(SyntheticEnv):
+    """Lift the pen (a free capsule lying across the gripper's two box fingers) to the target above it without dropping it."""
+    model_name = "gripper"
+    max_episode_steps = 100
+    goal_radius = 0.03

@@ -14,7 +14,7 @@ from dataclasses import dataclass
 
 import numpy as np
 
-from .raw import GEOM_BOX, GEOM_CAPSULE, GEOM_SPHERE, RawModel
+from .raw import GEOM_BOX, GEOM_CAPSULE, GEOM_CYLINDER, GEOM_SPHERE, RawModel
 
 LANES = 8          # lanes per particle in the HIP kernel
 MAX_LINKS = 7
@@ -72,6 +72,13 @@ def _geom_inertial(g, cap=1.0):
         i_perp = mc * (3 * r * r + h * h) / 12 + 0.4 * ms * r * r + ms * h * (3 * r + 2 * h) / 8
         i_ax = mc * r * r / 2 + 0.4 * ms * r * r
         return m, 0.5 * (a + b), i_perp * np.eye(3) + (i_ax - i_perp) * np.outer(u, u)
+    if g.type == GEOM_CYLINDER:             # between a and b (flat ends)
+        a, b = np.asarray(g.a, float), np.asarray(g.b, float)
+        h = np.linalg.norm(b - a)
+        u = (b - a) / h
+        m = g.density * np.pi * r * r * h
+        i_ax, i_perp = 0.5 * m * r * r, m * (3 * r * r + h * h) / 12
+        return m, 0.5 * (a + b), i_perp * np.eye(3) + (i_ax - i_perp) * np.outer(u, u)
     if g.type == GEOM_BOX:                  # a = centre, b = half sizes, quat = orientation in the body frame
         hx, hy, hz = (float(x) for x in g.b)
         m = g.density * 8.0 * hx * hy * hz
@@ -125,9 +132,10 @@ def compile_arm(raw: RawModel, overrides=None, base: "ArmModel" = None) -> ArmMo
     nb = len(raw.bodies)
     # what only the tree kernel executes (models/compile_tree.py)
     joints = [b.joint for b in raw.bodies if b.joint is not None]
-    if any(j.type != 1 or j.stiffness != 0 or j.frictionloss != 0 or any(np.asarray(j.pos, float) != 0) for j in joints):
+    if any(j.type != 1 or j.stiffness != 0 or j.frictionloss != 0 or any(np.asarray(j.pos, float) != 0) or j.margin != 0 or j.ref != 0
+           for j in joints):
         raise ValueError("arm kernel: hinge joints at the body origin without springs or friction loss only "
-                         "(slide / ball / free joints, springs, friction loss, joint anchors: the tree engine)")
+                         "(slide / ball / free joints, springs, friction loss, joint anchors, margin / ref: the tree engine)")
     if raw.equalities or raw.tendons or raw.world_geoms or any(b.inertial is not None for b in raw.bodies):
         raise ValueError("arm kernel: no equalities, tendons, static geoms or explicit inertials (the tree engine has them)")
     if raw.density > 0 or raw.viscosity > 0 or raw.task != 0:
@@ -264,7 +272,7 @@ def compile_arm(raw: RawModel, overrides=None, base: "ArmModel" = None) -> ArmMo
         f["sph_link"][0] = li
         f["sph_pos"][:] = p0[i] + R0[i] @ np.asarray(g.a, float) - origin[li]
         f["sph_r"][0] = float(np.ravel(overrides.get("geom_size", {}).get(g.name, [g.radius]))[0])
-        f["sph_margin"][0] = max(raw.plane.margin, g.margin)     # MuJoCo: max of geom margins
+        f["sph_margin"][0] = max(raw.plane.margin, g.margin) - max(raw.plane.gap, g.gap)     # MuJoCo: max of geom margins, less the larger gap
         f["sph_invweight"][0] = 0.0 + body_iw[i]                 # world body weighs 0
         f["plane_n"][:] = n
         f["plane_d"][0] = n @ np.asarray(raw.plane.pos, float)

@@ -15,7 +15,7 @@ from dataclasses import dataclass
 import numpy as np
 
 from .compile import _geom_inertial, _quat2mat, _shift_inertia, principal_inertia
-from .raw import (EQ_CONNECT, EQ_JOINT, EQ_WELD, GEOM_BOX, GEOM_SPHERE, JOINT_BALL, JOINT_FREE, JOINT_HINGE, JOINT_SLIDE,
+from .raw import (EQ_CONNECT, EQ_JOINT, EQ_WELD, GEOM_BOX, GEOM_CAPSULE, GEOM_CYLINDER, GEOM_SPHERE, JOINT_BALL, JOINT_FREE, JOINT_HINGE, JOINT_SLIDE,
                   TASK_FORWARD, TASK_ORIENT, TASK_REACH, RawModel, mix_contact_solver)
 
 TL = 32                     # lanes per particle
@@ -33,6 +33,10 @@ LINK_HINGE, LINK_SLIDE, LINK_BALL_X, LINK_BALL_Y, LINK_BALL_Z = 1, 2, 3, 4, 5
 # contact-record kinds ([12]): sphere/plane, segment/segment, sphere(A)/box(B), box(A)/sphere(B), connect equality,
 # dof row (joint equality or fixed-tendon limit)
 PT_PLANE, PT_SEGSEG, PT_SPHERE_BOX, PT_BOX_SPHERE, PT_CONNECT, PT_DOFROW, PT_WELD = 0, 1, 2, 3, 4, 5, 6
+# round 5: a cylinder's candidate point k (record [22]) on the plane; a capsule (A) against a box (B) and the other way
+# round - candidate k of three: where the capsule's axis comes nearest to the box, its two ends.  A box's corners on the
+# plane stay PT_PLANE records with [23] = 8 (the group's size), [22] = the corner's index and [14:17] = the box centre
+PT_PLANE_CYL, PT_CAPSULE_BOX, PT_BOX_CAPSULE = 7, 8, 9
 PEXT_STRIDE = 24            # per contact record, general instantiation: [0:3] box half sizes, [3:12] box orientation in its
                             # link's frame (row-major) | dof row: [0] 0 joint equality / 1 tendon limit, [1] coef A, [2] coef
                             # B, [3:5] range, [5] margin, [6:11] polycoef; [12:19] the row's solver set {K, B, dmin, dmax,
@@ -80,6 +84,7 @@ TREE_LAYOUT = [
     ("pext", TREE_MAX_SPHERES * PEXT_STRIDE),
     ("qw0", TL),                    # BALL_X links: w of qpos0's quaternion q0 (ball joint: 1, 0, 0, 0; free joint: the body's
                                     # orientation).  The kernel's quaternion is RELATIVE to the qpos0 pose: qpos = q0 * q_link
+    ("jmargin", TL),                # round 5: MJCF joint margin - the limit row of a hinge / slide dof exists while dist < margin
 ]
 TREE_BLOB_LEN = sum(n for _, n in TREE_LAYOUT)
 TREE_STATE_LEN = 3 * TL + 6           # device: qpos[32] | qvel[32] | target_pos[3] | fresh site[3] | quaternion w[32], per LINK
@@ -374,7 +379,12 @@ def compile_tree(raw: RawModel, overrides=None, base: "TreeModel" = None) -> Tre
         f["jtype"][li] = link_kind[li]
         single = jt.type in (JOINT_HINGE, JOINT_SLIDE)
         if single:
-            f["stiffness"][li], f["springref"][li] = jt.stiffness, jt.springref
+            # (MJCF joint ref = qpos0: the kernel's coordinate is qpos - ref, so everything stated on qpos - range, spring
+            # reference, actuator and tendon lengths - moves by it; qoff brings qpos back at the boundary)
+            f["stiffness"][li], f["springref"][li] = jt.stiffness, jt.springref - jt.ref
+            f["qoff"][li] = jt.ref
+            f["jmargin"][li] = jt.margin
+            gen = gen or jt.margin != 0.0
         elif jt.stiffness != 0 or (jt.limited and jt.type != JOINT_BALL):
             raise NotImplementedError("ball / free joints: no springs; limits on ball joints only")
         # MuJoCo's qpos: one entry per hinge / slide, (w, x, y, z) per ball, position + quaternion per free joint
@@ -412,7 +422,7 @@ def compile_tree(raw: RawModel, overrides=None, base: "TreeModel" = None) -> Tre
             else:
                 f["frot"][li::TL] = np.eye(3).reshape(-1)
         if single:
-            f["range_lo"][li], f["range_hi"][li] = jt.range
+            f["range_lo"][li], f["range_hi"][li] = jt.range[0] - jt.ref, jt.range[1] - jt.ref
             f["limited"][li] = 1.0 if jt.limited else 0.0
     nq = nq_run
     if nq > TREE_NQ_MAX:
@@ -472,7 +482,8 @@ def compile_tree(raw: RawModel, overrides=None, base: "TreeModel" = None) -> Tre
         f["gear"][d] = act.gear * act.gain
         f["kpg"][d] = -act.gear * act.gear * b1
         f["kvg"][d] = -act.gear * act.gear * b2
-        f["tau0"][d] = act.gear * b0
+        # (length = gear * sum coef qpos, qpos = the kernel's coordinate + ref)
+        f["tau0"][d] = act.gear * b0 + act.gear * act.gear * b1 * sum(c * raw.bodies[link_body[dd]].joint.ref for dd, c in tdofs)
         f["ctrl_lo"][d], f["ctrl_hi"][d] = act.ctrlrange if act.ctrllimited else (-np.inf, np.inf)
         if act.forcerange is not None:
             ends = sorted((act.gear * act.forcerange[0], act.gear * act.forcerange[1]))
@@ -551,7 +562,14 @@ def compile_tree(raw: RawModel, overrides=None, base: "TreeModel" = None) -> Tre
                 Rg = _quat2mat(g.quat)
                 for e in range(8):
                     c = np.array([half[0] if e & 1 else -half[0], half[1] if e & 2 else -half[1], half[2] if e & 4 else -half[2]])
-                    points.append((i, g, np.asarray(g.a, float) + Rg @ c, np.zeros(3), 0.0))
+                    points.append((i, g, np.asarray(g.a, float) + Rg @ c, np.zeros(3), 0.0, ("box", e, np.asarray(g.a, float))))
+            elif g.type == GEOM_CYLINDER:
+                a, e = np.asarray(g.a, float), np.asarray(g.b, float)
+                u, c, hh = (e - a) / np.linalg.norm(e - a), 0.5 * (a + e), 0.5 * np.linalg.norm(e - a)
+                if size is not None:
+                    hh = float(np.ravel(size)[1])
+                for k in range(4):
+                    points.append((i, g, c, u, radius, ("cyl", k, hh)))
             else:
                 a, e = np.asarray(g.a, float), np.asarray(g.b, float)
                 u = (e - a) / np.linalg.norm(e - a)
@@ -563,9 +581,10 @@ def compile_tree(raw: RawModel, overrides=None, base: "TreeModel" = None) -> Tre
         points = []
     n_eq_pts = len(raw.equalities) + sum(1 for e in raw.equalities if e.type == EQ_WELD)     # (a weld takes two records)
     n_tn_pts = sum(1 for t in raw.tendons if t.limited) + sum(1 for b in raw.bodies if b.joint is not None and b.joint.type == JOINT_BALL and b.joint.limited)
-    if len(points) + len(pair_geoms) + n_eq_pts + n_tn_pts > TREE_MAX_SPHERES:
-        raise ValueError("tree kernel supports %d contact records (a capsule on the plane counts two, a box eight, a geom-geom "
-                         "pair, an equality and a tendon limit one each)" % TREE_MAX_SPHERES)
+    n_pair_pts = sum(3 if sorted((ga.type, gb.type)) == [GEOM_CAPSULE, GEOM_BOX] else 1 for (_, ga), (_, gb) in pair_geoms)
+    if len(points) + n_pair_pts + n_eq_pts + n_tn_pts > TREE_MAX_SPHERES:
+        raise ValueError("tree kernel supports %d contact records (a capsule on the plane counts two, a box eight, a cylinder four, "
+                         "a capsule-box pair three, any other geom-geom pair, an equality and a tendon limit one each)" % TREE_MAX_SPHERES)
     if raw.plane is not None:
         n = np.asarray(raw.plane.normal, float)
         n = n / np.linalg.norm(n)
@@ -639,13 +658,14 @@ def compile_tree(raw: RawModel, overrides=None, base: "TreeModel" = None) -> Tre
         d0 = raw.dof_of_joint(jt.name)
         f["dofcls"][d0:d0 + jt.ndof] = lc + 8.0 * fc
 
-    for s, (i, g, pos, u, radius) in enumerate(points):
+    for s, pt in enumerate(points):
+        i, g, pos, u, radius = pt[:5]
         li = link_of_body[i]
         rec = f["spheres"][s * SPH_STRIDE:(s + 1) * SPH_STRIDE]
         rec[0] = li
         rec[1:4] = p0[i] + R0[i] @ pos - origin[li]
         rec[4] = radius
-        rec[5] = max(raw.plane.margin, g.margin)            # MuJoCo: max of the two geom margins
+        rec[5] = max(raw.plane.margin, g.margin) - max(raw.plane.gap, g.gap)    # MuJoCo: max of the two geom margins, less the larger gap (includemargin)
         rec[6] = 0.0 + body_w(i)                            # the world body weighs 0
         condim = max(int(g.condim), int(raw.plane.condim))
         if condim not in (1, 3):
@@ -655,6 +675,14 @@ def compile_tree(raw: RawModel, overrides=None, base: "TreeModel" = None) -> Tre
         rec[11] = edepth[li] - 1                            # strict ancestors of the point's link (elimination tree)
         rec[13] = -1.0
         rec[21] = sol_class(*mix_contact_solver(contact_set(g), contact_set(raw.plane)))
+        if len(pt) > 5 and pt[5][0] == "box":       # mjc_PlaneBox: corners above the centre are skipped, four contacts at most
+            rec[22], rec[23] = pt[5][1], 8.0
+            rec[14:17] = p0[i] + R0[i] @ pt[5][2] - origin[li]
+            gen = True
+        elif len(pt) > 5:                           # mjc_PlaneCylinder: candidate point k of four
+            rec[12], rec[22], rec[23] = PT_PLANE_CYL, pt[5][1], 4.0
+            rec[14] = pt[5][2]
+            gen = True
     # geom-geom pairs: spheres / capsules as segments (start, vector; a sphere has a zero vector) in their links' frames;
     # ONE geom of a pair may be a box (against a sphere).  The record is anchored at link A, whose elimination path
     # contains link B (an object's links above a manipulator, an ancestor in the same tree, or the world: -1)
@@ -698,19 +726,32 @@ def compile_tree(raw: RawModel, overrides=None, base: "TreeModel" = None) -> Tre
         rec[13], rec[14:17], rec[17], rec[18:21] = lb, b0, rb, db
         rec[21] = sol_class(psolref, psolimp)
         boxes = [k for k, g in enumerate((ga, gb)) if g.type == GEOM_BOX]
+        if GEOM_CYLINDER in (ga.type, gb.type):
+            raise NotImplementedError("a cylinder collides with the plane only")
+        copies = 1
         if boxes:
-            if len(boxes) == 2 or (gb if boxes[0] == 0 else ga).type != GEOM_SPHERE:
-                raise NotImplementedError("a box collides with the plane and with spheres (box-box / box-capsule are not built)")
+            other = gb if boxes[0] == 0 else ga
+            if len(boxes) == 2:
+                raise NotImplementedError("a box collides with the plane, with spheres and with capsules (box-box is not built)")
             ibx, gbx = (ia, ga) if boxes[0] == 0 else (ib, gb)
             size = overrides.get("geom_size", {}).get(gbx.name)
             ext[0:3] = np.ravel(size)[:3] if size is not None else gbx.b
             Rl = _quat2mat(gbx.quat) if ibx < 0 else R0[ibx] @ _quat2mat(gbx.quat)
             ext[3:12] = Rl.reshape(-1)
-            rec[12] = PT_BOX_SPHERE if boxes[0] == 0 else PT_SPHERE_BOX
+            if other.type == GEOM_CAPSULE:          # three candidate contacts: the axis' nearest point, the two ends
+                rec[12] = PT_BOX_CAPSULE if boxes[0] == 0 else PT_CAPSULE_BOX
+                rec[23] = 3.0
+                copies = 3
+            else:
+                rec[12] = PT_BOX_SPHERE if boxes[0] == 0 else PT_SPHERE_BOX
             gen = True
         if lb < 0:
             gen = True              # (a static second geom: the general instantiation knows the world as "link -1")
-        s += 1
+        for k in range(1, copies):
+            f["spheres"][(s + k) * SPH_STRIDE:(s + k + 1) * SPH_STRIDE] = rec
+            f["spheres"][(s + k) * SPH_STRIDE + 22] = k
+            f["pext"][(s + k) * PEXT_STRIDE:(s + k + 1) * PEXT_STRIDE] = ext
+        s += copies
 
     # equality constraints and tendon limits ride in the contact records too (general instantiation)
     for e in raw.equalities:
@@ -790,7 +831,8 @@ def compile_tree(raw: RawModel, overrides=None, base: "TreeModel" = None) -> Tre
         rec[12] = PT_DOFROW
         ext[0] = 1.0
         ext[1], ext[2] = dofs[0][1], (dofs[1][1] if len(dofs) == 2 else 0.0)
-        ext[3:5] = t.range
+        shift = sum(c * raw.bodies[link_body[d]].joint.ref for d, c in dofs)      # (length on qpos = on the kernel's coordinates + this)
+        ext[3:5] = t.range[0] - shift, t.range[1] - shift
         ext[5] = t.margin
         rec[21] = sol_class(lim_default[0] if t.solref_limit is None else t.solref_limit,
                             lim_default[1] if t.solimp_limit is None else t.solimp_limit)

@@ -9,7 +9,7 @@ massless single-joint bodies (what the loader makes of a body with several joint
 several joints."""
 import numpy as np
 
-from .raw import (EQ_CONNECT, EQ_JOINT, EQ_WELD, GEOM_BOX, GEOM_CAPSULE, GEOM_SPHERE, JOINT_BALL, JOINT_FREE, JOINT_HINGE, JOINT_SLIDE,
+from .raw import (EQ_CONNECT, EQ_JOINT, EQ_WELD, GEOM_BOX, GEOM_CAPSULE, GEOM_CYLINDER, GEOM_SPHERE, JOINT_BALL, JOINT_FREE, JOINT_HINGE, JOINT_SLIDE,
                   RawModel)
 
 
@@ -31,15 +31,17 @@ def _sol(prefix, solref, solimp):
 
 
 def _geom_xml(g, plane_collide):
-    t = {GEOM_SPHERE: "sphere", GEOM_CAPSULE: "capsule", GEOM_BOX: "box"}[g.type]
+    t = {GEOM_SPHERE: "sphere", GEOM_CAPSULE: "capsule", GEOM_BOX: "box", GEOM_CYLINDER: "cylinder"}[g.type]
     a = ' name="%s" type="%s"' % (g.name, t) if g.name else ' type="%s"' % t
     if g.type == GEOM_SPHERE:
         a += ' size="%s" pos="%s"' % (_f(g.radius), _v(g.a))
-    elif g.type == GEOM_CAPSULE:
+    elif g.type in (GEOM_CAPSULE, GEOM_CYLINDER):
         a += ' size="%s" fromto="%s %s"' % (_f(g.radius), _v(g.a), _v(g.b))
     else:
         a += ' size="%s" pos="%s" quat="%s"' % (_v(g.b), _v(g.a), _v(g.quat))
     a += ' density="%s" margin="%s" friction="%s 0.005 0.0001" condim="%d"' % (_f(g.density), _f(g.margin), _f(g.friction), int(g.condim))
+    if g.gap:
+        a += ' gap="%s"' % _f(g.gap)
     a += ' contype="%d" conaffinity="0"' % (1 if (plane_collide and g.collide) else 0)
     a += _sol(("solref", "solimp"), g.solref, g.solimp)
     if g.solmix != 1.0:
@@ -61,6 +63,8 @@ def _joint_xml(j):
     a += ' limited="%s" range="%s" damping="%s" armature="%s"' % ("true" if j.limited else "false", _v(j.range), _f(j.damping), _f(j.armature))
     if j.type in (JOINT_HINGE, JOINT_SLIDE):
         a += ' stiffness="%s" springref="%s"' % (_f(j.stiffness), _f(j.springref))
+        if j.margin or j.ref:
+            a += ' margin="%s" ref="%s"' % (_f(j.margin), _f(j.ref))
     if j.frictionloss:
         a += ' frictionloss="%s"' % _f(j.frictionloss)
     a += _sol(("solreflimit", "solimplimit"), j.solref_limit, j.solimp_limit)
@@ -87,9 +91,9 @@ def to_mjcf(raw: RawModel, hand_site="finger", target_site="target") -> str:
         s, c = np.linalg.norm(ax), float(z @ n)
         quat = (1.0, 0.0, 0.0, 0.0) if s < 1e-15 and c > 0 else ((0.0, 1.0, 0.0, 0.0) if s < 1e-15 else
                                                                   tuple(np.r_[np.cos(np.arctan2(s, c) / 2), np.sin(np.arctan2(s, c) / 2) * ax / s]))
-        lines.append('    <geom name="floor" type="plane" size="5 5 0.1" pos="%s" quat="%s" margin="%s" friction="%s 0.005 0.0001" condim="%d" '
+        lines.append('    <geom name="floor" type="plane" size="5 5 0.1" pos="%s" quat="%s" margin="%s" gap="%s" friction="%s 0.005 0.0001" condim="%d" '
                      'contype="0" conaffinity="1"%s%s%s/>'
-                     % (_v(p.pos), _v(quat), _f(p.margin), _f(p.friction), int(p.condim), _sol(("solref", "solimp"), p.solref, p.solimp),
+                     % (_v(p.pos), _v(quat), _f(p.margin), _f(p.gap), _f(p.friction), int(p.condim), _sol(("solref", "solimp"), p.solref, p.solimp),
                         ' solmix="%s"' % _f(p.solmix) if p.solmix != 1.0 else "", ' priority="%d"' % p.priority if p.priority else ""))
     lines.append('    <site name="%s" pos="%s"/>' % (target_site, _v(raw.target_pos)))
     for g in raw.world_geoms:

@@ -42,14 +42,14 @@ import xml.etree.ElementTree as ET
 import numpy as np
 
 from .compile import _geom_inertial, _quat2mat
-from .raw import (EQ_CONNECT, EQ_JOINT, EQ_WELD, GEOM_BOX, GEOM_CAPSULE, GEOM_SPHERE, JOINT_BALL, JOINT_FREE, JOINT_HINGE, JOINT_SLIDE,
+from .raw import (EQ_CONNECT, EQ_JOINT, EQ_WELD, GEOM_BOX, GEOM_CAPSULE, GEOM_CYLINDER, GEOM_SPHERE, JOINT_BALL, JOINT_FREE, JOINT_HINGE, JOINT_SLIDE,
                   MJ20_CAPSULE_CAP, TASK_FORWARD, TASK_REACH, RawActuator, RawBody, RawEquality, RawGeom, RawInertial,
                   RawJoint, RawModel, RawPlane, RawTendon)
 
 _VISUAL_BODY_TAGS = ("light", "camera")
 _TOP_TAGS = ("compiler", "option", "default", "worldbody", "actuator", "asset", "size", "visual", "statistic", "custom",
              "equality", "tendon", "sensor", "keyframe")     # (sensors and keyframes do not enter the simulation)
-_SHAPE_ONLY_TYPES = ("mesh", "cylinder", "ellipsoid")       # geom types that are accepted only where they cannot matter
+_SHAPE_ONLY_TYPES = ("mesh", "ellipsoid")       # geom types that are accepted only where they cannot matter
 
 
 def _expand_includes(node, basedir, depth=0):
@@ -237,6 +237,8 @@ def load_mjcf(path, hand_site="finger", target_site="target", frame_skip=2, task
         t = ga("type", "sphere")
         if ga("mesh") is not None and e.get("type") is None:
             t = "mesh"                  # (a geom that names a mesh is a mesh geom)
+        if t == "cylinder" and int(ga("contype", "1")) == 0 and int(ga("conaffinity", "1")) == 0 and has_inertial and not inertia_from_geom_always:
+            return None                 # (a purely visual cylinder: neither collided nor integrated)
         if t in _SHAPE_ONLY_TYPES:
             # meshes, cylinders and ellipsoids are neither collided nor integrated here: such a geom is accepted where it
             # can do neither - masked out of every collision and on a body whose mass comes from an explicit <inertial>
@@ -246,23 +248,21 @@ def load_mjcf(path, hand_site="finger", target_site="target", frame_skip=2, task
             raise ValueError("unsupported geom type %r (accepted only as a visual: contype = conaffinity = 0 on a body with an "
                              "explicit <inertial>)" % t)
         size = _floats(ga("size"))
-        common = dict(density=float(ga("density", "1000")), margin=float(ga("margin", "0")),
+        common = dict(density=float(ga("density", "1000")), margin=float(ga("margin", "0")), gap=float(ga("gap", "0")),
                       friction=_floats(ga("friction", "1 0.005 0.0001"))[0], condim=int(ga("condim", "3")),
                       name=e.get("name", ""))
-        if float(ga("gap", "0")) != 0.0:
-            raise ValueError("geom gap is not supported")
         pos = np.asarray(_floats(e.get("pos"), 3, [0.0, 0.0, 0.0]))
         Rg = _orientation(e, deg)
         if t == "sphere":
             g = RawGeom(GEOM_SPHERE, size[0], tuple(pos), **common)
-        elif t == "capsule":
+        elif t in ("capsule", "cylinder"):
             ft = _floats(e.get("fromto"), 6)
             if ft is not None:
                 a, b = ft[:3], ft[3:]
             else:
                 z = np.array([0.0, 0.0, 1.0]) if Rg is None else Rg[:, 2]
                 a, b = tuple(pos - size[1] * z), tuple(pos + size[1] * z)
-            g = RawGeom(GEOM_CAPSULE, size[0], tuple(a), tuple(b), **common)
+            g = RawGeom(GEOM_CAPSULE if t == "capsule" else GEOM_CYLINDER, size[0], tuple(a), tuple(b), **common)
         elif t == "box":
             if e.get("fromto") is not None:
                 raise ValueError("box geoms take size / pos / orientation, not fromto")
@@ -305,8 +305,9 @@ def load_mjcf(path, hand_site="finger", target_site="target", frame_skip=2, task
         t = "free" if j.tag == "freejoint" else ja("type", "hinge")
         if t not in ("hinge", "slide", "ball", "free"):
             raise ValueError("unknown joint type %r" % t)
-        if float(ja("margin", "0")) != 0.0 or float(ja("ref", "0")) != 0.0:
-            raise ValueError("joint margin / ref are not supported")
+        jmargin, jref = float(ja("margin", "0")), float(ja("ref", "0"))
+        if t in ("ball", "free") and (jmargin != 0.0 or jref != 0.0):
+            raise ValueError("joint margin / ref are modelled for hinge and slide joints")
         if j.tag == "freejoint":            # MJCF: <freejoint/> takes no defaults: no damping, armature or friction loss
             return RawJoint(axis=[0.0, 0.0, 1.0], range=[0.0, 0.0], limited=False, name=j.get("name", ""), type=JOINT_FREE)
         lim_attr = ja("limited", "false")
@@ -333,7 +334,9 @@ def load_mjcf(path, hand_site="finger", target_site="target", frame_skip=2, task
         rng_ang = deg if t in ("hinge", "ball") else 1.0        # ... and so is a ball joint's range: the cone's half angle)
         rng = [x * rng_ang for x in _floats(ja("range"), 2, [0.0, 0.0])]
         jtype = {"hinge": JOINT_HINGE, "slide": JOINT_SLIDE, "ball": JOINT_BALL, "free": JOINT_FREE}[t]
-        return RawJoint(axis=_floats(ja("axis"), 3, [0.0, 0.0, 1.0]), range=rng,
+        if t == "hinge":
+            jmargin, jref = jmargin * deg, jref * deg       # (angles)
+        return RawJoint(axis=_floats(ja("axis"), 3, [0.0, 0.0, 1.0]), range=rng, margin=jmargin, ref=jref,
                         limited=limited, damping=float(ja("damping", "0")), armature=float(ja("armature", "0")),
                         name=j.get("name", ""), type=jtype,
                         stiffness=float(ja("stiffness", "0")), springref=float(ja("springref", "0")) * ang,
@@ -418,7 +421,7 @@ def load_mjcf(path, hand_site="finger", target_site="target", frame_skip=2, task
             plane_set = (tuple(_floats(pa("solref", "0.02 1"))), tuple(_floats(pa("solimp", "0.9 0.95 0.001 0.5 2"))))
             geom_solver.append(plane_set)
             plane = RawPlane(pos=_floats(plane_elem.get("pos"), 3, [0.0, 0.0, 0.0]), normal=normal,
-                             margin=float(pa("margin", "0")), friction=_floats(pa("friction", "1 0.005 0.0001"))[0],
+                             margin=float(pa("margin", "0")), gap=float(pa("gap", "0")), friction=_floats(pa("friction", "1 0.005 0.0001"))[0],
                              condim=int(pa("condim", "3")), solmix=float(pa("solmix", "1")), priority=int(pa("priority", "0")))
             plane._solver = plane_set
     # ... and geoms against each other (self_collision): MuJoCo's rule - the contype / conaffinity masks match, the two
@@ -449,9 +452,13 @@ def load_mjcf(path, hand_site="finger", target_site="target", frame_skip=2, task
                 if not ((ga_._contype & gb_._conaffinity) or (gb_._contype & ga_._conaffinity)):
                     continue
                 kinds = sorted((ga_.type, gb_.type))
-                if GEOM_BOX in kinds and kinds != [GEOM_SPHERE, GEOM_BOX]:
-                    raise ValueError("geoms %r / %r would collide (contype / conaffinity) but a box only collides with the plane "
-                                     "and with spheres here: mask the pair out or replace the geom"
+                if GEOM_CYLINDER in kinds:
+                    raise ValueError("geoms %r / %r would collide (contype / conaffinity) but a cylinder only collides with the "
+                                     "plane here (MuJoCo sends cylinder pairs to its general convex collider): mask the pair out "
+                                     "or use a capsule" % (ga_.name or "?", gb_.name or "?"))
+                if kinds == [GEOM_BOX, GEOM_BOX]:
+                    raise ValueError("geoms %r / %r would collide (contype / conaffinity) but a box only collides with the plane, "
+                                     "with spheres and with capsules here: mask the pair out or replace the geom"
                                      % (ga_.name or "?", gb_.name or "?"))
                 for k, (bi, g) in ((ia, flat[ia]), (ib, flat[ib])):
                     if not g.name:
@@ -464,8 +471,6 @@ def load_mjcf(path, hand_site="finger", target_site="target", frame_skip=2, task
     every.update({g.name: g for g in world_geoms})
     pair_params = {}
     for pr in (con.findall("pair") if con is not None else []):
-        if float(pr.get("gap", "0")) != 0.0:
-            raise ValueError("<pair gap> is not supported")
         over = {}
         if pr.get("condim") is not None:
             over["condim"] = int(pr.get("condim"))
@@ -474,8 +479,9 @@ def load_mjcf(path, hand_site="finger", target_site="target", frame_skip=2, task
             if len(fr) > 1 and fr[1] != fr[0]:
                 raise ValueError("<pair friction>: the two tangential coefficients must be equal (isotropic pyramids)")
             over["friction"] = fr[0]
-        if pr.get("margin") is not None:
-            over["margin"] = float(pr.get("margin"))
+        if pr.get("margin") is not None or pr.get("gap") is not None:
+            # (a <pair>'s own margin and gap, MuJoCo defaults 0: the contacts enter the solver while dist < margin - gap)
+            over["margin"] = float(pr.get("margin", "0")) - float(pr.get("gap", "0"))
         if pr.get("solref") is not None:
             over["solref"] = tuple(_floats(pr.get("solref"), 2))
             if over["solref"][0] <= 0 or over["solref"][1] <= 0:

@@ -24,6 +24,7 @@ import numpy as np
 GEOM_SPHERE = 1
 GEOM_CAPSULE = 2
 GEOM_BOX = 3                # a = centre, b = half sizes, quat = orientation, all in the body frame
+GEOM_CYLINDER = 4           # a = "from", b = "to" (the centres of the two flat ends), radius; collides with the plane only
 
 HEADER_LEN = 80
 JOINT_HINGE = 1
@@ -102,6 +103,8 @@ class RawJoint:
     solimp_limit: Optional[Sequence[float]] = None
     solref_friction: Optional[Sequence[float]] = None
     solimp_friction: Optional[Sequence[float]] = None
+    margin: float = 0.0                     # MJCF joint margin: the limit row exists while dist < margin (hinge / slide)
+    ref: float = 0.0                        # MJCF joint ref: qpos0 of a hinge / slide joint (the pose the model is drawn in)
 
     @property
     def ndof(self):
@@ -132,6 +135,8 @@ class RawGeom:
     solimp: Optional[Sequence[float]] = None
     solmix: float = 1.0
     priority: int = 0
+    gap: float = 0.0                        # MJCF geom gap: a contact enters the solver while dist < margin - gap (MuJoCo's
+                                            # includemargin; margin and gap of a pair: the larger of the two geoms' each)
 
 
 @dataclass
@@ -213,6 +218,7 @@ class RawPlane:
     solimp: Optional[Sequence[float]] = None
     solmix: float = 1.0
     priority: int = 0
+    gap: float = 0.0
 
 
 @dataclass
@@ -287,8 +293,8 @@ class RawModel:
 
     @property
     def qpos0(self):
-        """MuJoCo's qpos0: zeros for hinge / slide joints, the identity quaternion for a ball joint, the body's own
-        position and orientation for a free joint."""
+        """MuJoCo's qpos0: ``ref`` (default zero) for hinge / slide joints, the identity quaternion for a ball joint, the
+        body's own position and orientation for a free joint."""
         out = []
         for b in self.bodies:
             if b.joint is None:
@@ -298,7 +304,7 @@ class RawModel:
             elif b.joint.type == JOINT_FREE:
                 out += list(b.pos) + list(np.asarray(b.quat, float) / np.linalg.norm(b.quat))
             else:
-                out += [0.0]
+                out += [float(b.joint.ref)]
         return np.array(out, float)
 
     def pair_contact(self, ga, gb, key=None):
@@ -313,7 +319,7 @@ class RawModel:
             condim, mu = int(top.condim), float(top.friction)
         else:
             condim, mu = max(int(ga.condim), int(gb.condim)), max(float(ga.friction), float(gb.friction))
-        margin = max(float(ga.margin), float(gb.margin))
+        margin = max(float(ga.margin), float(gb.margin)) - max(float(ga.gap), float(gb.gap))       # (includemargin)
         over = self.pair_params.get(tuple(key), self.pair_params.get(tuple(key)[::-1], {})) if key is not None else {}
         condim, mu, margin = int(over.get("condim", condim)), float(over.get("friction", mu)), float(over.get("margin", margin))
         solref = tuple(float(x) for x in over.get("solref", solref))
@@ -345,6 +351,7 @@ class RawModel:
             h[63:65] = self.solref if self.plane.solref is None else self.plane.solref
             h[65:70] = _solimp5(self.solimp if self.plane.solimp is None else self.plane.solimp)
             h[70], h[71] = self.plane.solmix, self.plane.priority
+            h[72] = self.plane.gap
         h[30], h[31] = self.density, self.viscosity
         h[32], h[33], h[34] = self.task, self.ctrl_cost, self.obs_skip
         h[37] = self.capsule_cap_factor
@@ -379,6 +386,7 @@ class RawModel:
                 r[42:47] = _solimp5(lim_imp if b.joint.solimp_limit is None else b.joint.solimp_limit)
                 r[47:49] = self.solref_friction if b.joint.solref_friction is None else b.joint.solref_friction
                 r[49:54] = _solimp5(self.solimp_friction if b.joint.solimp_friction is None else b.joint.solimp_friction)
+                r[54], r[55] = b.joint.margin, b.joint.ref
             if b.inertial is not None:
                 r[23] = 1.0
                 r[24] = b.inertial.mass
@@ -398,6 +406,7 @@ class RawModel:
             r[12] = g.friction
             r[13] = g.condim
             r[14:18] = g.quat
+            r[18] = g.gap
             r[24:26] = self.solref if g.solref is None else g.solref
             r[26:31] = _solimp5(self.solimp if g.solimp is None else g.solimp)
             r[31], r[32] = g.solmix, g.priority

@@ -78,7 +78,7 @@ typedef struct {
     int jtype[MAXB];                         /* 1 hinge, 2 slide, 3 ball, 4 free */
     double jaxis[MAXB][3], jpos[MAXB][3];    /* axis and anchor in the body frame */
     int dof_body[MAXV];
-    double range[MAXV][2];
+    double range[MAXV][2], jmargin[MAXV];    /* limits of hinge / slide joints: the row exists while dist < jmargin (MJCF joint margin) */
     int limited[MAXV];
     int ball_limited[MAXB];                  /* a ball joint's limit: the rotation angle stays below ball_range (MJCF range="0 max") */
     double ball_range[MAXB];
@@ -103,10 +103,15 @@ typedef struct {
     double site_pos[3], target_default[3];
     /* contact: one plane (world) versus collision spheres */
     int has_plane, nsphere;
-    double plane_pos[3], plane_n[3], plane_margin;
+    double plane_pos[3], plane_n[3], plane_margin, plane_gap;
     int sph_body[MAXS];
-    double sph_pos[MAXS][3], sph_r[MAXS], sph_margin[MAXS];
+    double sph_pos[MAXS][3], sph_r[MAXS], sph_margin[MAXS], sph_gap[MAXS];    /* (geom gap: MuJoCo's includemargin = margin - gap) */
     double sph_mu[MAXS], sph_axis[MAXS][3];   /* friction (0: frictionless row) and capsule axis in the body frame */
+    /* round 5: 1 = a box's corner (mjc_PlaneBox: corners above the box centre are skipped, at most four contacts per box),
+     * 2 = one of a cylinder's four candidate points on the plane (mjc_PlaneCylinder); sph_k = its index in its geom's group,
+     * sph_ctr = the geom's centre in the body frame; cylinders: sph_axis = the axis, sph_r = radius, sph_hh = half height */
+    int sph_kind[MAXS], sph_k[MAXS];
+    double sph_ctr[MAXS][3], sph_hh[MAXS];
     double sph_solref[MAXS][2], sph_solimp[MAXS][5];   /* the contact's solver parameters (mj_contactParam: geom x plane) */
     /* geom-geom pairs: two segments (a sphere is a segment of length 0) with radii, on two bodies */
     int npair, pair_body[MAXP][2];
@@ -258,13 +263,13 @@ static void kinematics(const OrModel *m, const double *q, Kin *k) {
         if (jt == JSLIDE) {                     /* slide: the frame moves along its axis, no rotation */
             memcpy(k->xmat[b], R, sizeof(R));
             matvec3(R, m->jaxis[b], k->xaxis[j]);
-            for (int i = 0; i < 3; i++) k->xpos[b][i] += k->xaxis[j][i] * q[m->qadr[b]];
+            for (int i = 0; i < 3; i++) k->xpos[b][i] += k->xaxis[j][i] * (q[m->qadr[b]] - m->qpos0[m->qadr[b]]);
             memcpy(k->xanchor[j], k->xpos[b], sizeof(double) * 3);
         } else if (jt == JHINGE || jt == JBALL) {
             double E[9], anchor[3];
             matvec3(R, m->jpos[b], t);
             for (int i = 0; i < 3; i++) anchor[i] = k->xpos[b][i] + t[i];
-            if (jt == JHINGE) axisangle2mat(m->jaxis[b], q[m->qadr[b]], E);
+            if (jt == JHINGE) axisangle2mat(m->jaxis[b], q[m->qadr[b]] - m->qpos0[m->qadr[b]], E);
             else quat2mat(q + m->qadr[b], E);
             matmul3(R, E, k->xmat[b]);
             matvec3(k->xmat[b], m->jpos[b], t);
@@ -490,6 +495,14 @@ static void geom_inertia(int type, double r, const double *a, const double *b_, 
                 for (int c = 0; c < 3; c++) sacc += T[3 * i + c] * R[3 * j + c];
                 I[3 * i + j] = sacc;
             }
+    } else if (type == 4) {     /* cylinder between a and b_ (flat ends): m r^2 / 2 about the axis, m (3 r^2 + h^2) / 12 across */
+        double u[3] = {b_[0] - a[0], b_[1] - a[1], b_[2] - a[2]};
+        double h = sqrt(dot3(u, u));
+        for (int i = 0; i < 3; i++) { u[i] /= h; pos[i] = 0.5 * (a[i] + b_[i]); }
+        *mass = density * PI * r * r * h;
+        double Iax = 0.5 * (*mass) * r * r, Iperp = (*mass) * (3 * r * r + h * h) / 12;
+        for (int i = 0; i < 3; i++)
+            for (int j = 0; j < 3; j++) I[3 * i + j] = (i == j ? Iperp : 0.0) + (Iax - Iperp) * u[i] * u[j];
     } else if (type == 1) {
         *mass = density * 4.0 / 3.0 * PI * r * r * r;
         memcpy(pos, a, 24);
@@ -548,6 +561,7 @@ OrModel *or_model_compile(const double *f, int n) {
     memcpy(m->plane_pos, f + 23, 24);
     memcpy(m->plane_n, f + 26, 24);
     m->plane_margin = f[29];
+    m->plane_gap = f[72];
     m->density = f[30];
     m->viscosity = f[31];
     m->task = (int)f[32];
@@ -606,6 +620,8 @@ OrModel *or_model_compile(const double *f, int n) {
                 m->range[nv][0] = r[12];
                 m->range[nv][1] = r[13];
                 m->limited[nv] = (int)r[14];
+                m->jmargin[nv] = r[54];
+                m->qpos0[nq] = r[55];           /* MJCF joint ref: the kinematics turn / move by qpos - qpos0 */
             }
             /* qpos0: zero (hinge, slide), the identity (ball), the body's own pose (free) */
             if (jt == JBALL) m->qpos0[nq] = 1.0;
@@ -638,28 +654,42 @@ OrModel *or_model_compile(const double *f, int n) {
          * eight corners (mjc_PlaneBox; MuJoCo keeps at most four of them, this restatement all that are within the margin).
          * Contact friction / condim = max over the two geoms (MuJoCo mj_contactParam, equal priorities). */
         int gt = (int)r[1];
-        int ends = (r[10] != 0 && gb[g] > 0) ? (gt == 1 ? 1 : (gt == 2 ? 2 : 8)) : 0;
+        int ends = (r[10] != 0 && gb[g] > 0) ? (gt == 1 ? 1 : (gt == 2 ? 2 : (gt == 3 ? 8 : 4))) : 0;
         double Rb[9];
         if (gt == 3) quat2mat(r + 14, Rb);
         for (int e = 0; e < ends; e++) {
             if (m->nsphere >= MAXS) { free(m); return NULL; }
             int s = m->nsphere++;
             m->sph_body[s] = gb[g];
+            m->sph_k[s] = e;
             if (gt == 3) {
                 double c[3] = {(e & 1 ? 1 : -1) * r[6], (e & 2 ? 1 : -1) * r[7], (e & 4 ? 1 : -1) * r[8]}, t[3];
                 matvec3(Rb, c, t);
                 for (int i = 0; i < 3; i++) m->sph_pos[s][i] = r[3 + i] + t[i];
                 m->sph_r[s] = 0.0;
+                m->sph_kind[s] = 1;
+                memcpy(m->sph_ctr[s], r + 3, 24);
+            } else if (gt == 4) {
+                double u[3] = {r[6] - r[3], r[7] - r[4], r[8] - r[5]}, len = sqrt(dot3(u, u));
+                for (int i = 0; i < 3; i++) {
+                    m->sph_axis[s][i] = u[i] / len;
+                    m->sph_ctr[s][i] = 0.5 * (r[3 + i] + r[6 + i]);
+                    m->sph_pos[s][i] = m->sph_ctr[s][i];
+                }
+                m->sph_r[s] = r[2];
+                m->sph_hh[s] = 0.5 * len;
+                m->sph_kind[s] = 2;
             } else {
-                memcpy(m->sph_pos[s], (ends == 2 && e == 0) ? r + 6 : r + 3, 24);
+                memcpy(m->sph_pos[s], (gt == 2 && e == 0) ? r + 6 : r + 3, 24);
                 m->sph_r[s] = r[2];
             }
             m->sph_margin[s] = r[11];
+            m->sph_gap[s] = r[18];
             double mu = r[12] > plane_mu ? r[12] : plane_mu;
             int condim = (int)r[13] > plane_condim ? (int)r[13] : plane_condim;
             m->sph_mu[s] = condim >= 3 ? mu : 0.0;
             mix_solver(r + 24, f + 63, m->sph_solref[s], m->sph_solimp[s]);
-            if (ends == 2) {
+            if (gt == 2) {
                 double u[3] = {r[6] - r[3], r[7] - r[4], r[8] - r[5]}, len = sqrt(dot3(u, u));
                 for (int i = 0; i < 3; i++) m->sph_axis[s][i] = u[i] / len;
             }
@@ -716,16 +746,13 @@ OrModel *or_model_compile(const double *f, int n) {
             memcpy(m->pair_a[k][e], r + 3, 24);
             for (int i = 0; i < 3; i++) m->pair_d[k][e][i] = (int)r[1] == 2 ? r[6 + i] - r[3 + i] : 0.0;
             m->pair_r[k][e] = (int)r[1] == 3 ? 0.0 : r[2];
+            if ((int)r[1] == 4) { free(m); return NULL; }               /* a cylinder collides with the plane only */
             if ((int)r[1] == 3) {
                 if (m->pair_box[k] >= 0) { free(m); return NULL; }      /* box-box is not restated */
                 m->pair_box[k] = e;
                 quat2mat(r + 14, m->pair_R[k]);
                 memcpy(m->pair_half[k], r + 6, 24);
             }
-        }
-        if (m->pair_box[k] >= 0 && dot3(m->pair_d[k][1 - m->pair_box[k]], m->pair_d[k][1 - m->pair_box[k]]) > 0) {
-            free(m);                    /* box-capsule is not restated */
-            return NULL;
         }
         m->pair_margin[k] = pr[4];
         m->pair_mu[k] = (int)pr[2] >= 3 ? pr[3] : 0.0;
@@ -1185,6 +1212,77 @@ static void contact_rows(const OrModel *m, const Kin *k, const double *v, const 
     *pnc = nc;
 }
 
+/* The surface point of a solid box (half sizes h, in its own frame) nearest to a point `loc` given in that frame
+ * (mjc_SphereBox's geometry): outside - the clamped point, normal from it to `loc`; inside - the nearest face, its outward
+ * normal.  len = signed distance of `loc` from the surface (negative inside).  Returns 0 when `loc` lies ON the surface to
+ * rounding (no normal). */
+static int box_point(const double *h, const double *loc, double *cl, double *nb, double *len) {
+    int inside = 1;
+    for (int i = 0; i < 3; i++) {
+        cl[i] = loc[i] < -h[i] ? -h[i] : (loc[i] > h[i] ? h[i] : loc[i]);
+        if (cl[i] != loc[i]) inside = 0;
+    }
+    if (inside) {       /* the face the point is nearest to: surface point on it, outward normal */
+        int kk = 0;
+        double best = 1e300;
+        for (int i = 0; i < 3; i++) {
+            double gap = h[i] - fabs(loc[i]);
+            if (gap < best) { best = gap; kk = i; }
+        }
+        double sg = loc[kk] >= 0 ? 1.0 : -1.0;
+        cl[kk] = sg * h[kk];
+        nb[0] = nb[1] = nb[2] = 0;
+        nb[kk] = sg;
+        *len = -best;
+        return 1;
+    }
+    for (int i = 0; i < 3; i++) nb[i] = loc[i] - cl[i];
+    *len = sqrt(dot3(nb, nb));
+    if (*len < 1e-14) return 0;
+    for (int i = 0; i < 3; i++) nb[i] /= *len;
+    return 1;
+}
+
+/* The parameter t in [0, 1] at which the segment a + t b (box frame) comes nearest to the solid box of half sizes h: the
+ * squared distance f(t) = sum_i max(0, |a_i + t b_i| - h_i)^2 is convex and piecewise quadratic - its pieces end where a
+ * coordinate crosses a face plane (at most six break points) - so every piece is minimised in closed form and the least
+ * minimum taken (the first one where several pieces tie: the lowest t). */
+static double seg_box_param(const double *h, const double *a, const double *b) {
+    double bp[8];
+    int n = 8;
+    bp[0] = 0.0;
+    bp[7] = 1.0;
+    for (int i = 0; i < 3; i++)
+        for (int sg = 0; sg < 2; sg++) {
+            double t = 1.0;         /* (a coordinate that does not move has no crossing: a duplicate of the end point) */
+            if (b[i] != 0.0) t = ((sg ? h[i] : -h[i]) - a[i]) / b[i];
+            bp[1 + 2 * i + sg] = t < 0 ? 0.0 : (t > 1 ? 1.0 : t);
+        }
+    for (int i = 1; i < n; i++)
+        for (int j = i; j > 0 && bp[j] < bp[j - 1]; j--) { double t = bp[j]; bp[j] = bp[j - 1]; bp[j - 1] = t; }
+    double best_f = 1e300, best_t = 0.0;
+    for (int k = 0; k + 1 < n; k++) {
+        double u = bp[k], w = bp[k + 1], mid = 0.5 * (u + w), B = 0, C = 0;
+        double off[3];
+        int act[3];
+        for (int i = 0; i < 3; i++) {
+            double si = a[i] + mid * b[i];
+            act[i] = si > h[i] ? 1 : (si < -h[i] ? -1 : 0);
+            off[i] = a[i] - act[i] * h[i];
+            if (act[i]) { B += b[i] * b[i]; C += b[i] * off[i]; }
+        }
+        double tc = u;
+        if (B > 0) { tc = -C / B; tc = tc < u ? u : (tc > w ? w : tc); }
+        double f = 0;
+        for (int i = 0; i < 3; i++)
+            if (act[i]) { double e = off[i] + tc * b[i]; f += e * e; }
+        if (f < best_f) { best_f = f; best_t = tc; }
+    }
+    return best_t;
+}
+
+double or_seg_box_param(const double *h, const double *a, const double *b) { return seg_box_param(h, a, b); }      /* (test hook) */
+
 /* ---------------------------------------------------------------- one mj_step */
 static int or_is_bad(double x) { return !(x <= 1e10 && x >= -1e10); }      /* mju_isBad: NaN, or beyond mjMAXVAL */
 static void or_reset_data(const OrModel *m, double *q, double *v, double *ctrl) {     /* mj_resetData, the part the path reads */
@@ -1342,17 +1440,17 @@ static int step_impl(OrModel *m, double *q, double *v, const double *ctrl, doubl
                 }
             }
         } else {
-            /* joint: q1 - q1_0 = poly(q2 - q2_0) (qpos0 = 0 for hinge / slide joints) */
+            /* joint: q1 - q1_0 = poly(q2 - q2_0) (qpos0 = the joints' ref) */
             int d1 = m->eq_o1[e], d2 = m->eq_o2[e];
             const double *pc = m->eq_poly[e];
-            double x = d2 >= 0 ? q[m->dof_qadr[d2]] : 0.0;
+            double x = d2 >= 0 ? q[m->dof_qadr[d2]] - m->qpos0[m->dof_qadr[d2]] : 0.0;
             double poly = pc[0] + x * (pc[1] + x * (pc[2] + x * (pc[3] + x * pc[4])));
             double dpoly = pc[1] + x * (2 * pc[2] + x * (3 * pc[3] + x * 4 * pc[4]));
             memset(J[nc], 0, sizeof(J[nc]));
             J[nc][d1] = 1.0;
             if (d2 >= 0) J[nc][d2] = -dpoly;
             double jv = v[d1] - (d2 >= 0 ? dpoly * v[d2] : 0.0);
-            row_params_set(m, m->eq_solref[e], m->eq_solimp[e], q[m->dof_qadr[d1]] - poly, 0.0,
+            row_params_set(m, m->eq_solref[e], m->eq_solimp[e], q[m->dof_qadr[d1]] - m->qpos0[m->dof_qadr[d1]] - poly, 0.0,
                            m->dof_invweight0[d1] + (d2 >= 0 ? m->dof_invweight0[d2] : 0.0), jv, &D[nc], &aref[nc]);
             kind[nc] = ROW_EQ;
             floss[nc] = 0;
@@ -1370,16 +1468,16 @@ static int step_impl(OrModel *m, double *q, double *v, const double *ctrl, doubl
         nc++;
     }
     int nc_uni0 = nc;
-    /* joint limits: MuJoCo mj_instantiateLimit (dist < margin, jnt margin = 0); hinge and slide joints */
+    /* joint limits: MuJoCo mj_instantiateLimit (dist < margin, the joint's own); hinge and slide joints */
     for (int j = 0; j < nv; j++) {
         if (!m->limited[j] || m->dof_qadr[j] < 0) continue;
         double qj = q[m->dof_qadr[j]];
         for (int side = -1; side <= 1; side += 2) {
             double dist = side * (m->range[j][(side + 1) / 2] - qj);
-            if (dist < 0) {
+            if (dist < m->jmargin[j]) {
                 memset(J[nc], 0, sizeof(J[nc]));
                 J[nc][j] = -side;
-                row_params_set(m, m->dof_solref_l[j], m->dof_solimp_l[j], dist, 0.0, m->dof_invweight0[j], -side * v[j], &D[nc], &aref[nc]);
+                row_params_set(m, m->dof_solref_l[j], m->dof_solimp_l[j], dist, m->jmargin[j], m->dof_invweight0[j], -side * v[j], &D[nc], &aref[nc]);
                 nc++;
             }
         }
@@ -1428,13 +1526,72 @@ static int step_impl(OrModel *m, double *q, double *v, const double *ctrl, doubl
     }
     /* plane-sphere contacts (mjc_PlaneSphere / the two ends mjc_PlaneCapsule tests / the corners mjc_PlaneBox tests +
      * mj_instantiateContact): margin = max of the two geom margins, gap = 0, included when dist < margin */
+    int box_count = 0;          /* contacts of the box whose corners are being walked (mjc_PlaneBox keeps at most four) */
     for (int s = 0; m->has_plane && s < m->nsphere; s++) {
         int b = m->sph_body[s];
         double c[3], t[3];
+        double margin = (m->plane_margin > m->sph_margin[s] ? m->plane_margin : m->sph_margin[s]) -
+                        (m->plane_gap > m->sph_gap[s] ? m->plane_gap : m->sph_gap[s]);       /* includemargin = margin - gap */
+        if (m->sph_kind[s] == 2) {
+            /* a cylinder on the plane (mjc_PlaneCylinder [EXT], restated from its published description: the lowest point of
+             * the lower cap's rim, the point below it on the other cap's rim, and two more points of the lower cap's rim 120
+             * degrees to either side - a triangle under a cylinder that stands, a line under one that lies): point sph_k of
+             * the four; a point counts while its distance is below the margin, the later ones only if the first does */
+            double ctr[3], a[3], vec[3], n[3] = {m->plane_n[0], m->plane_n[1], m->plane_n[2]};
+            matvec3(k.xmat[b], m->sph_ctr[s], t);
+            for (int i = 0; i < 3; i++) ctr[i] = k.xpos[b][i] + t[i];
+            matvec3(k.xmat[b], m->sph_axis[s], a);
+            double pa = dot3(n, a);
+            if (pa > 0) { for (int i = 0; i < 3; i++) a[i] = -a[i]; pa = -pa; }      /* the axis points down the normal */
+            for (int i = 0; i < 3; i++) vec[i] = n[i] - pa * a[i];                   /* the normal within the cap's plane */
+            double len = sqrt(dot3(vec, vec)), r = m->sph_r[s], hh = m->sph_hh[s];
+            if (len < 1e-12) {          /* upright: any direction of the cap's plane - the frame tangent of the axis */
+                double ax[3] = {0, 0, 0};
+                if (a[1] < 0.5 && a[1] > -0.5) ax[1] = 1; else ax[2] = 1;
+                double pr = dot3(a, ax);
+                for (int i = 0; i < 3; i++) vec[i] = ax[i] - pr * a[i];
+                len = sqrt(dot3(vec, vec));
+            }
+            for (int i = 0; i < 3; i++) vec[i] *= r / len;
+            double d0 = 0;
+            for (int i = 0; i < 3; i++) d0 += n[i] * (ctr[i] - m->plane_pos[i]);
+            double pv = dot3(n, vec), d1 = d0 + pa * hh - pv;
+            if (!(d1 < margin)) continue;
+            double pt[3], dist;
+            int kk = m->sph_k[s];
+            if (kk == 0) {
+                for (int i = 0; i < 3; i++) pt[i] = ctr[i] + a[i] * hh - vec[i];
+                dist = d1;
+            } else if (kk == 1) {
+                for (int i = 0; i < 3; i++) pt[i] = ctr[i] - a[i] * hh - vec[i];
+                dist = d0 - pa * hh - pv;
+            } else {
+                double v1[3];
+                cross3(vec, a, v1);
+                double sc = (kk == 2 ? 1.0 : -1.0) * sqrt(3.0) / 2;
+                for (int i = 0; i < 3; i++) pt[i] = ctr[i] + a[i] * hh + 0.5 * vec[i] + sc * v1[i];
+                dist = d0 + pa * hh + 0.5 * pv;
+            }
+            if (dist < margin) {
+                double cp[3];
+                for (int i = 0; i < 3; i++) cp[i] = pt[i] - n[i] * 0.5 * dist;
+                contact_rows(m, &k, v, m->plane_n, cp, b, 0, dist, margin, m->sph_mu[s], m->sph_solref[s], m->sph_solimp[s], ZERO3, J, aref, D, &nc);
+            }
+            continue;
+        }
         matvec3(k.xmat[b], m->sph_pos[s], t);
         for (int i = 0; i < 3; i++) c[i] = k.xpos[b][i] + t[i] - m->plane_pos[i];
         double dist = dot3(c, m->plane_n) - m->sph_r[s];
-        double margin = m->plane_margin > m->sph_margin[s] ? m->plane_margin : m->sph_margin[s];
+        if (m->sph_kind[s] == 1) {
+            /* a box's corner (mjc_PlaneBox [EXT]): corners on the upper side of the box centre are skipped, and the box
+             * contributes its first four contacts in corner order */
+            if (m->sph_k[s] == 0) box_count = 0;
+            double tc[3], rel[3];
+            matvec3(k.xmat[b], m->sph_ctr[s], tc);
+            for (int i = 0; i < 3; i++) rel[i] = t[i] - tc[i];
+            if (dot3(rel, m->plane_n) > 0 || box_count >= 4) continue;
+            if (dist < margin) box_count++;
+        }
         if (dist < margin) {
             double cp[3], ax[3];
             for (int i = 0; i < 3; i++) cp[i] = k.xpos[b][i] + t[i] - m->plane_n[i] * (m->sph_r[s] + 0.5 * dist);
@@ -1457,54 +1614,43 @@ static int step_impl(OrModel *m, double *q, double *v, const double *ctrl, doubl
         }
         double c1[3], c2[3], diff[3], len;
         if (m->pair_box[p] >= 0) {
+            /* a sphere or a capsule against a box.  Sphere (mjc_SphereBox): the box's surface point nearest to the centre.
+             * Capsule (mjc_CapsuleBox [EXT]; restated as a scheme of its own, not MuJoCo's routine): up to three contacts - where
+             * the capsule's axis comes nearest to the box, and its two ends (each an end sphere against the box) where they
+             * are not that point themselves */
             int eb = m->pair_box[p], es = 1 - eb, bb = m->pair_body[p][eb];
-            double Rw[9], loc[3], cl[3], rel[3], nb[3], cb[3];
+            double Rw[9], a_loc[3], b_loc[3], rel[3];
             matmul3(k.xmat[bb], m->pair_R[p], Rw);
             for (int i = 0; i < 3; i++) rel[i] = o[es][i] - o[eb][i];
-            int inside = 1;
             for (int i = 0; i < 3; i++) {
-                loc[i] = Rw[i] * rel[0] + Rw[3 + i] * rel[1] + Rw[6 + i] * rel[2];
-                cl[i] = loc[i] < -m->pair_half[p][i] ? -m->pair_half[p][i] : (loc[i] > m->pair_half[p][i] ? m->pair_half[p][i] : loc[i]);
-                if (cl[i] != loc[i]) inside = 0;
+                a_loc[i] = Rw[i] * rel[0] + Rw[3 + i] * rel[1] + Rw[6 + i] * rel[2];
+                b_loc[i] = Rw[i] * d[es][0] + Rw[3 + i] * d[es][1] + Rw[6 + i] * d[es][2];
             }
-            double depth_in = 0;
-            if (inside) {       /* the face the centre is nearest to: surface point on it, outward normal */
-                int kk = 0;
-                double best = 1e300;
+            int capsule = dot3(m->pair_d[p][es], m->pair_d[p][es]) > 0;
+            double tstar = capsule ? seg_box_param(m->pair_half[p], a_loc, b_loc) : 0.0;
+            for (int cand = 0; cand < (capsule ? 3 : 1); cand++) {
+                double tt = cand == 0 ? tstar : (cand == 1 ? 0.0 : 1.0);
+                if (cand > 0 && tt == tstar) continue;
+                double loc[3], cl[3], nb[3], cb[3], nw[3], ps[3];
+                for (int i = 0; i < 3; i++) { loc[i] = a_loc[i] + tt * b_loc[i]; ps[i] = o[es][i] + tt * d[es][i]; }
+                if (!box_point(m->pair_half[p], loc, cl, nb, &len)) continue;
+                matvec3(Rw, cl, cb);
+                matvec3(Rw, nb, nw);
+                for (int i = 0; i < 3; i++) cb[i] += o[eb][i];          /* the box's nearest surface point, world */
+                /* as two "closest points" c1 (geom 0's side) - c2 (geom 1's side) along the normal from geom 1 to geom 0 */
                 for (int i = 0; i < 3; i++) {
-                    double gap = m->pair_half[p][i] - fabs(loc[i]);
-                    if (gap < best) { best = gap; kk = i; }
+                    double sgn = es == 0 ? 1.0 : -1.0;                  /* nw points from the box to the sphere */
+                    diff[i] = sgn * nw[i];
+                    c1[i] = es == 0 ? ps[i] : cb[i];
+                    c2[i] = es == 0 ? cb[i] : ps[i];
                 }
-                depth_in = best;
-                double sg = loc[kk] >= 0 ? 1.0 : -1.0;
-                cl[kk] = sg * m->pair_half[p][kk];
-                double nl[3] = {0, 0, 0};
-                nl[kk] = sg;
-                matvec3(Rw, nl, nb);
-            }
-            matvec3(Rw, cl, cb);
-            for (int i = 0; i < 3; i++) cb[i] += o[eb][i];          /* the box's closest surface point, world */
-            if (!inside) {
-                for (int i = 0; i < 3; i++) nb[i] = o[es][i] - cb[i];
-                len = sqrt(dot3(nb, nb));
-                if (len < 1e-14) continue;
-                for (int i = 0; i < 3; i++) nb[i] /= len;
-            } else {
-                len = -depth_in;                                    /* centre below the surface: negative distance */
-            }
-            /* as two "closest points" c1 (geom 0's side) - c2 (geom 1's side) along the normal from geom 1 to geom 0 */
-            for (int i = 0; i < 3; i++) {
-                double sgn = es == 0 ? 1.0 : -1.0;                  /* nb points from the box to the sphere */
-                diff[i] = sgn * nb[i];
-                c1[i] = es == 0 ? o[es][i] : cb[i];
-                c2[i] = es == 0 ? cb[i] : o[es][i];
-            }
-            double dist = len - m->pair_r[p][0] - m->pair_r[p][1];
-            if (dist < m->pair_margin[p]) {
-                double cp[3];
-                for (int i = 0; i < 3; i++) cp[i] = c2[i] + diff[i] * (m->pair_r[p][1] + 0.5 * dist);
-                contact_rows(m, &k, v, diff, cp, m->pair_body[p][0], m->pair_body[p][1], dist, m->pair_margin[p], m->pair_mu[p], m->pair_solref[p], m->pair_solimp[p],
-                             ZERO3, J, aref, D, &nc);
+                double dist = len - m->pair_r[p][0] - m->pair_r[p][1];
+                if (dist < m->pair_margin[p]) {
+                    double cp[3];
+                    for (int i = 0; i < 3; i++) cp[i] = c2[i] + diff[i] * (m->pair_r[p][1] + 0.5 * dist);
+                    contact_rows(m, &k, v, diff, cp, m->pair_body[p][0], m->pair_body[p][1], dist, m->pair_margin[p], m->pair_mu[p], m->pair_solref[p], m->pair_solimp[p],
+                                 ZERO3, J, aref, D, &nc);
+                }
             }
             continue;
         }

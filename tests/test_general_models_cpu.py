@@ -376,7 +376,7 @@ def test_ball_range_in_degrees_inertial_under_inertiafromgeom_and_autolimits(tmp
 
 def test_loader_refuses_what_is_not_modelled(tmp_path):
     for body, extra, msg in [
-        ('<body name="a"><joint/><geom type="cylinder" size="0.1 0.1"/><site name="finger"/></body>', "", "geom type"),
+        ('<body name="a"><joint/><geom type="ellipsoid" size="0.1 0.1 0.2"/><site name="finger"/></body>', "", "geom type"),
         ('<body name="a"><joint name="j"/><geom type="sphere" size="0.1"/><site name="finger"/></body>',
          '<equality><distance geom1="a" geom2="b"/></equality>', "equality"),
         ('<body name="a"><joint name="j"/><geom type="sphere" size="0.1"/><site name="finger"/></body>',
@@ -384,11 +384,16 @@ def test_loader_refuses_what_is_not_modelled(tmp_path):
     ]:
         with pytest.raises(ValueError, match=msg):
             _model(tmp_path, body, extra=extra, name="bad.xml")
-    # box against box / capsule: derived from the masks -> refused with advice; a box against the plane and spheres is fine
+    # box against box, a cylinder against anything but the plane: derived from the masks -> refused with advice; a box against
+    # the plane, spheres and (round 5) capsules is fine
     body = """<body name="a"><freejoint/><geom name="x" type="box" size="0.1 0.1 0.1" contype="1" conaffinity="1"/><site name="finger"/></body>
-    <body name="b" pos="1 0 0"><freejoint/><geom name="y" type="capsule" size="0.1 0.1" contype="1" conaffinity="1"/></body>"""
+    <body name="b" pos="1 0 0"><freejoint/><geom name="y" type="%s" size="0.1 0.1 0.1" contype="1" conaffinity="1"/></body>"""
     with pytest.raises(ValueError, match="box only collides"):
-        _model(tmp_path, body, name="bb.xml")
+        _model(tmp_path, body % "box", name="bb.xml")
+    with pytest.raises(ValueError, match="cylinder only collides"):
+        _model(tmp_path, (body % "cylinder").replace('size="0.1 0.1 0.1" contype="1" conaffinity="1"/></body>', 'size="0.1 0.1" contype="1" conaffinity="1"/></body>'), name="bc.xml")
+    raw, _ = _model(tmp_path, (body % "capsule").replace('size="0.1 0.1 0.1" contype="1" conaffinity="1"/></body>', 'size="0.1 0.1" contype="1" conaffinity="1"/></body>'), name="bk.xml")
+    assert raw.pairs == [("y", "x")]
 
 
 @pytest.mark.parametrize("name", sorted(FRAME_SKIP))
@@ -674,3 +679,159 @@ def test_pair_elements_override_the_geoms_contact_parameters(tmp_path):
     np.testing.assert_array_equal(ta.field("spheres")[:21], tb.field("spheres")[:21])        # ([21]: the record's solver set, numbered per model)
     sa, sb = int(ta.field("spheres")[21]), int(tb.field("spheres")[21])
     np.testing.assert_array_equal(ta.field("soltab").reshape(8, 7)[sa], tb.field("soltab").reshape(8, 7)[sb])
+
+
+# ------------------------------------------------------------------------------------------ round 5: joint margin / ref, geom gap
+def test_joint_margin_ref_and_geom_gap_on_the_oracle(tmp_path):
+    """MJCF joint ``margin`` (the limit row exists while dist < margin and acts on dist - margin), joint ``ref`` (qpos0: the
+    kinematics turn by qpos - ref while range, springs and actuator lengths are stated on qpos) and geom ``gap`` (a contact
+    enters the solver while dist < margin - gap): [EXT] semantics, held to what they must mean mechanically."""
+    pend = """<body name="a" pos="0 0 1"><joint name="j" type="hinge" axis="0 1 0" limited="true" range="-0.5 0.5"%s/>
+      <geom type="capsule" size="0.02 0.1" pos="0 0 -0.1" density="500"/><site name="finger" pos="0 0 -0.2"/></body>"""
+    act = '<actuator><motor joint="j" gear="1" ctrlrange="-10 10" ctrllimited="true"/></actuator>'
+    # 1. margin: at q = 0.45 (0.05 inside the limit) a margin of 0.1 already pushes back, no margin does not
+    _, r0 = _model(tmp_path, pend % "", gravity="0 0 0", extra=act, name="m0.xml")
+    _, r1 = _model(tmp_path, pend % ' margin="0.1"', gravity="0 0 0", extra=act, name="m1.xml")
+    q0, v0, _, d0 = r0.step([0.45], [0.0], [0.0])
+    q1, v1, _, d1 = r1.step([0.45], [0.0], [0.0])
+    assert d0[0] == 0 and v0[0] == 0.0
+    assert d1[0] == 1 and v1[0] < 0.0
+    # ... and a row at the same VIOLATION pos - margin gives the same push: q = 0.55 without margin = q = 0.45 with margin 0.1
+    q2, v2, _, d2 = r0.step([0.55], [0.0], [0.0])
+    np.testing.assert_allclose(v1, v2, rtol=1e-12)
+    # 2. ref: the model with ref = 0.3 in coordinates qpos - 0.3 IS the model without ref whose range / springref moved by -0.3
+    spring = ' stiffness="2" springref="0.1" ref="0.3"'
+    _, ra = _model(tmp_path, pend % spring, extra=act, name="r1.xml")
+    _, rb = _model(tmp_path, (pend % ' stiffness="2" springref="-0.2"').replace('range="-0.5 0.5"', 'range="-0.8 0.2"'), extra=act, name="r0.xml")
+    assert ra.qpos0[0] == 0.3
+    qa, va, qb, vb = np.array([0.3 + 0.15]), np.array([0.4]), np.array([0.15]), np.array([0.4])
+    for k in range(400):
+        qa, va, sa, _ = ra.step(qa, va, [6.0])
+        qb, vb, sb, _ = rb.step(qb, vb, [6.0])
+    np.testing.assert_allclose(qa - 0.3, qb, rtol=0, atol=1e-12)
+    np.testing.assert_allclose(sa, sb, rtol=0, atol=1e-12)
+    assert qb[0] > 0.19                                     # (it did run into the upper limit)
+    # ... position servos read qpos itself
+    servo = '<actuator><position joint="j" kp="30" ctrlrange="-1 1" ctrllimited="true"/></actuator>'
+    _, rc = _model(tmp_path, pend % ' ref="0.3" damping="1"', gravity="0 0 0", extra=servo, name="r2.xml")
+    qc, vc = np.array([0.3]), np.array([0.0])
+    for k in range(3000):
+        qc, vc, _, _ = rc.step(qc, vc, [0.4])
+    assert abs(qc[0] - 0.4) < 1e-6                          # the set point is a qpos
+    # 3. gap: a sphere resting 1.5 mm above the plane - inside the margin of 4 mm, outside margin - gap = 1 mm: no force
+    ball = """<body name="s" pos="0 0 0.1015"><joint type="slide" axis="0 0 1"/><geom type="sphere" size="0.1" contype="1" conaffinity="1"
+      margin="0.004"%s/><site name="finger"/></body><geom type="plane" size="1 1 0.1" contype="1" conaffinity="1"/>"""
+    a1 = '<actuator><motor joint="s_joint0" gear="1" ctrlrange="-1 1" ctrllimited="true"/></actuator>'
+    _, g0 = _model(tmp_path, ball % "", gravity="0 0 0", extra=a1, name="g0.xml")
+    _, g1 = _model(tmp_path, ball % ' gap="0.003"', gravity="0 0 0", extra=a1, name="g1.xml")
+    assert g0.step([0.0], [0.0], [0.0])[3][0] >= 1 and g1.step([0.0], [0.0], [0.0])[3][0] == 0
+    assert g0.step([0.0], [0.0], [0.0])[1][0] > 0.0 and g1.step([0.0], [0.0], [0.0])[1][0] == 0.0
+    # ... and once inside margin - gap the row acts on dist - (margin - gap): the same push as margin 1 mm without a gap
+    _, g2 = _model(tmp_path, (ball % "").replace('margin="0.004"', 'margin="0.001"'), gravity="0 0 0", extra=a1, name="g2.xml")
+    np.testing.assert_allclose(g1.step([-0.001], [0.0], [0.0])[1], g2.step([-0.001], [0.0], [0.0])[1], rtol=1e-12)
+
+
+def test_two_compilers_agree_on_joint_ref(tmp_path):
+    """``compile_tree`` moves range / spring reference / actuator constants by the joint's ref (the kernel's coordinate is qpos -
+    ref); the oracle keeps qpos and subtracts qpos0 in its kinematics: the same constants at qpos0."""
+    body = """<body name="a" pos="0 0 1"><joint name="j" type="hinge" axis="0 1 0" limited="true" range="-0.5 0.9" ref="0.2" margin="0.05" stiffness="1" springref="0.4"/>
+      <geom type="capsule" size="0.02 0.1" pos="0 0 -0.1" density="500"/>
+      <body name="b" pos="0 0 -0.2"><joint name="k" type="slide" axis="0 0 1" limited="true" range="-0.1 0.1" ref="-0.03"/>
+      <geom type="sphere" size="0.03"/><site name="finger"/></body></body>"""
+    act = '<actuator><position joint="j" kp="5" ctrlrange="-1 1" ctrllimited="true"/><motor joint="k" gear="1" ctrlrange="-1 1" ctrllimited="true"/></actuator>'
+    raw, ref = _model(tmp_path, body, extra=act, name="cr.xml")
+    m = compile_tree(raw)
+    assert m.general
+    f = m.field
+    np.testing.assert_allclose(f("range_lo")[:2], [-0.7, -0.07], atol=1e-15)
+    np.testing.assert_allclose(f("range_hi")[:2], [0.7, 0.13], atol=1e-15)
+    np.testing.assert_allclose(f("springref")[0], 0.2, atol=1e-15)
+    np.testing.assert_allclose(f("qoff")[:2], [0.2, -0.03], atol=1e-15)
+    np.testing.assert_allclose(f("jmargin")[:2], [0.05, 0.0], atol=1e-15)
+    np.testing.assert_allclose(f("tau0")[0], -5.0 * 0.2, atol=1e-15)           # gear^2 b1 ref, b1 = -kp
+    dof, _ = ref.invweight0()
+    np.testing.assert_allclose(f("dof_invweight0")[:2], dof, rtol=1e-12)
+
+
+# ------------------------------------------------------------------------------------------ round 5: colliders
+def test_cylinder_rests_on_the_plane_lying_and_standing(tmp_path):
+    """A cylinder on the plane (mjc_PlaneCylinder as restated: the lowest rim point, the point under it on the other cap, two
+    more rim points 120 degrees apart): standing it rests on a triangle of three points, lying on the two rim points of its
+    line of contact - at its radius / half height above the plane, without tipping; its mass and inertia are a cylinder's."""
+    for name, euler, z_rest, rows in (("stand", "0 0 0", 0.15, 3), ("lie", "0 1.5707963267948966 0", 0.05, 2)):
+        body = """<body name="c" pos="0 0 %g" euler="%s"><freejoint/><geom type="cylinder" size="0.05 0.15" density="800" contype="1" conaffinity="1"
+          margin="0.002" friction="0.7 0.005 0.0001"/><site name="finger"/></body><geom type="plane" size="1 1 0.1" contype="1" conaffinity="1" margin="0.002"/>"""
+        raw, ref = _model(tmp_path, body % (z_rest + 0.01, euler), name="cyl_%s.xml" % name)
+        mass, _, inertia = ref.inertial()
+        m = 800 * np.pi * 0.05 ** 2 * 0.3
+        np.testing.assert_allclose(mass[1], m, rtol=1e-12)
+        np.testing.assert_allclose(np.sort(np.diag(inertia[1])), np.sort([0.5 * m * 0.05 ** 2] + 2 * [m * (3 * 0.05 ** 2 + 0.3 ** 2) / 12]), rtol=1e-12)
+        q, v = raw.qpos0.copy(), np.zeros(6)
+        for k in range(1500):
+            q, v, _, d = ref.step(q, v, [])
+        assert abs(q[2] - z_rest) < 2e-3 and np.abs(v).max() < 1e-3, (name, q, v)
+        assert d[0] == 4 * rows                                 # (pyramidal cones: four rows per contact point)
+        up = np.array([2 * (q[4] * q[6] + q[3] * q[5]), 2 * (q[5] * q[6] - q[3] * q[4]), 1 - 2 * (q[4] ** 2 + q[5] ** 2)])     # the body's z axis
+        want = np.array([0, 0, 1.0]) if name == "stand" else None
+        if want is not None:
+            assert up @ want > 1 - 1e-6
+        else:
+            assert abs(up[2]) < 1e-3                            # still lying
+    assert ref.newton_stats()["fails"] == 0
+
+
+def test_a_box_on_the_plane_keeps_four_corners_below_its_centre(tmp_path):
+    """mjc_PlaneBox: corners on the upper side of the box centre are skipped and four contacts are kept - a thin slab pushed
+    INTO the plane (all eight corners within the margin) gets four contacts, not eight."""
+    body = """<body name="b" pos="0 0 0.004"><freejoint/><geom type="box" size="0.1 0.08 0.005" contype="1" conaffinity="1" condim="1" margin="0.02"/>
+      <site name="finger"/></body><geom type="plane" size="1 1 0.1" contype="1" conaffinity="1" condim="1" margin="0.02"/>"""
+    raw, ref = _model(tmp_path, body, name="slab.xml")
+    q, v, _, d = ref.step(raw.qpos0.copy(), np.zeros(6), [])
+    assert d[0] == 4
+
+
+def test_capsule_on_a_box_rests_and_a_tilted_one_touches_once(tmp_path):
+    """A capsule against a box (round 5; three candidate contacts: where its axis comes nearest to the box, its two ends): lying
+    along the top of a static box it rests at its radius above the face on more than one contact and stays level; tilted,
+    only its lower end touches; hanging over the edge across the box it is held by the contact at the edge region."""
+    world = '<geom name="slab" type="box" pos="0 0 0.1" size="0.3 0.2 0.1" contype="1" conaffinity="1" friction="0.8 0.005 0.0001"/>'
+    body = """<body name="c" pos="0 0 %g" euler="0 %g 0"><freejoint/><geom name="cap" type="capsule" size="0.03 0.12" density="600" contype="1" conaffinity="1"
+      margin="0.002" friction="0.8 0.005 0.0001"/><site name="finger"/></body>"""
+    # lying flat on the top face (z = 0.2): rest height 0.23
+    raw, ref = _model(tmp_path, world + body % (0.235, np.pi / 2), name="cb0.xml")
+    q, v = raw.qpos0.copy(), np.zeros(6)
+    for k in range(2000):
+        q, v, _, d = ref.step(q, v, [])
+    assert abs(q[2] - 0.23) < 2e-3 and np.abs(v).max() < 1e-3 and d[0] >= 8          # two or three contact points
+    axis_z = 1 - 2 * (q[4] ** 2 + q[5] ** 2)
+    assert abs(axis_z) < 2e-3                                   # level
+    # tilted by 0.4 rad: one contact, at the lower end
+    raw, ref = _model(tmp_path, world + body % (0.30, np.pi / 2 - 0.4), name="cb1.xml")
+    q, v, _, d = ref.step(raw.qpos0.copy(), np.zeros(6), [])
+    assert d[0] == 0
+    q0 = raw.qpos0.copy()
+    q0[2] = 0.2 + 0.03 + 0.12 * np.sin(0.4) - 0.001             # the lower end 1 mm into the face
+    q, v, _, d = ref.step(q0, np.zeros(6), [])
+    assert d[0] == 4 and v[2] > -9.81 * 0.002                   # (pushed up against gravity)
+    assert ref.newton_stats()["fails"] == 0
+
+
+def test_segment_box_closest_parameter_against_brute_force():
+    """The closed-form piecewise minimisation behind the capsule-box contact against a dense scan."""
+    import ctypes
+    from oracle.physics_ref import _lib, _p, _c
+    L = _lib()
+    L.or_seg_box_param.restype = ctypes.c_double
+    L.or_seg_box_param.argtypes = [ctypes.POINTER(ctypes.c_double)] * 3
+    rs = np.random.RandomState(0)
+    ts = np.linspace(0, 1, 20001)
+    for k in range(300):
+        h = rs.uniform(0.05, 0.5, 3)
+        a, b = rs.uniform(-1, 1, 3), rs.uniform(-1.5, 1.5, 3)
+        if k % 5 == 0:
+            b[rs.randint(3)] = 0.0                              # parallel to a pair of faces
+        t = L.or_seg_box_param(_p(_c(h)), _p(_c(a)), _p(_c(b)))
+        pts = a[None] + ts[:, None] * b[None]
+        f = (np.maximum(np.abs(pts) - h[None], 0.0) ** 2).sum(1)
+        ft = (np.maximum(np.abs(a + t * b) - h, 0.0) ** 2).sum()
+        assert 0.0 <= t <= 1.0 and ft <= f.min() + 1e-12, (k, t, ft, f.min())

@@ -77,8 +77,10 @@ def test_loader_on_a_small_model_and_rejections(tmp_path):
         compile_arm(load_mjcf(str(tmp_path / "ball.xml")))
     bad = xml.replace('<joint name="j1"', '<joint name="j1" ref="0.1"')
     (tmp_path / "bad2.xml").write_text(bad)
-    with pytest.raises(ValueError):
-        load_mjcf(str(tmp_path / "bad2.xml"))
+    raw_ref = load_mjcf(str(tmp_path / "bad2.xml"))        # (joint ref loads since round 5: the tree engine runs it, the arm kernel says so)
+    assert raw_ref.bodies[1].joint.ref == 0.1 and raw_ref.qpos0[1] == 0.1
+    with pytest.raises(ValueError, match="tree engine"):
+        compile_arm(raw_ref)
     # a slide joint loads (the tree engine runs it); the serial-chain arm kernel says it cannot
     slide = xml.replace('<joint name="j1"', '<joint name="j1" type="slide"')
     (tmp_path / "slide.xml").write_text(slide)

@@ -22,10 +22,12 @@ def _quat(rs, scale):
 
 
 def random_model(seed):
-    from mjmpc_amd.models.raw import (EQ_CONNECT, EQ_JOINT, EQ_WELD, GEOM_BOX, GEOM_CAPSULE, GEOM_SPHERE, JOINT_BALL, JOINT_FREE,
+    from mjmpc_amd.models.raw import (EQ_CONNECT, EQ_JOINT, EQ_WELD, GEOM_BOX, GEOM_CAPSULE, GEOM_CYLINDER, GEOM_SPHERE, JOINT_BALL, JOINT_FREE,
                                       JOINT_HINGE, JOINT_SLIDE, RawActuator, RawBody, RawEquality, RawGeom, RawJoint, RawModel,
                                       RawPlane, RawTendon)
     rs = np.random.RandomState(seed)
+    rs5 = np.random.RandomState(seed + 1000003)     # round 5's attributes (joint margin / ref, geom gap) from a stream of their own:
+                                                    # the models of the earlier rounds' seeds keep everything else they had
     deep = seed % 6 == 5                    # every sixth model: long chains (elimination paths beyond 16 links)
     n_bodies = int(rs.randint(18, 27)) if deep else int(rs.randint(3, 24))
     general = rs.rand() < 0.6
@@ -74,6 +76,11 @@ def random_model(seed):
             jt.limited, jt.range = True, (0.0, float(rs.uniform(0.4, 1.0)))
         if jt.limited and rs.rand() < 0.3:
             jt.solref_limit, jt.solimp_limit = (float(rs.uniform(0.01, 0.04)), 1.0), (0.9, 0.95, 0.001, 0.5, 2.0)
+        if general and kind in (JOINT_HINGE, JOINT_SLIDE):
+            if jt.limited and rs5.rand() < 0.3:
+                jt.margin = float(rs5.uniform(0.01, 0.1)) * (0.2 if kind == JOINT_SLIDE else 1.0)
+            if rs5.rand() < 0.2:
+                jt.ref = float(rs5.uniform(-0.3, 0.3)) * (0.2 if kind == JOINT_SLIDE else 1.0)
         length = rs.uniform(0.08, 0.25)
         d = rs.standard_normal(3)
         d *= length / np.linalg.norm(d)
@@ -83,6 +90,8 @@ def random_model(seed):
         if rs.rand() < 0.3:
             geoms.append(RawGeom(GEOM_SPHERE, 1.2 * rad, tuple(d), density=800.0, margin=0.002, name="s%d" % i,
                                  friction=float(rs.uniform(0.3, 1.0)), condim=3))
+        if general and rs5.rand() < 0.2:
+            geoms[0].margin, geoms[0].gap = 0.004, float(rs5.uniform(0.0005, 0.003))
         if rs.rand() < 0.25:
             geoms[0].solref, geoms[0].solimp, geoms[0].solmix = (float(rs.uniform(0.01, 0.03)), 1.0), (0.9, 0.95, 0.001, 0.5, 2.0), float(rs.uniform(0.5, 2))
         pos = (float(0.4 * rs.standard_normal()), float(0.4 * rs.standard_normal()), float(rs.uniform(0.3, 0.7))) if parent < 0 \
@@ -119,6 +128,18 @@ def random_model(seed):
             if records < 13:
                 pairs.append((g.name, "slab"))
                 records += 1
+    # round 5: capsules against the static slab (three records each), a cylinder riding on a body (four records on the plane)
+    if general and world_geoms and records + 3 <= 13 and rs5.rand() < 0.6:
+        k = int(rs5.randint(len(bodies)))
+        pairs.append((bodies[k].geoms[0].name, "slab"))
+        records += 3
+    if general and records + 4 <= 13 and rs5.rand() < 0.3:
+        k = int(rs5.randint(len(bodies)))
+        ax = rs5.standard_normal(3)
+        ax *= float(rs5.uniform(0.02, 0.06)) / np.linalg.norm(ax)
+        bodies[k].geoms.append(RawGeom(GEOM_CYLINDER, float(rs5.uniform(0.02, 0.05)), tuple(-ax), tuple(ax), density=600.0, margin=0.002,
+                                       name="cyl%d" % k, friction=0.6, condim=3, collide=True))
+        records += 4
     if want_box:
         k = int(rs.randint(len(bodies)))
         bodies[k].geoms.append(RawGeom(GEOM_BOX, 0.0, (0.0, 0.0, 0.0), (0.04, 0.03, 0.02), density=700.0, margin=0.002, name="box%d" % k,
@@ -184,7 +205,7 @@ def random_state(raw, rs):
         elif jt.type == JOINT_BALL:
             q[adr:adr + 4] = _quat(rs, 0.8)
         else:
-            q[adr] = rs.uniform(-1.2, 1.2) * (0.25 if jt.type == 2 else 1.0)
+            q[adr] = jt.ref + rs.uniform(-1.2, 1.2) * (0.25 if jt.type == 2 else 1.0)
         adr += jt.nq
     return q, v
 

@@ -21,7 +21,7 @@ def hand():
 
 def test_two_compilers_agree_on_the_hand(hand):
     raw, m, ref = hand
-    assert m.blob.shape == (TREE_BLOB_LEN,) and TREE_BLOB_LEN == 3929
+    assert m.blob.shape == (TREE_BLOB_LEN,) and TREE_BLOB_LEN == 3961
     assert (m.nv, m.nu, m.d_obs) == (24, 24, 54)
     mass, ipos, inertia = ref.inertial()
     np.testing.assert_allclose(m.body_mass, mass[1:], rtol=1e-12)

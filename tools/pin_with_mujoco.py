@@ -64,7 +64,7 @@ def _model(name):
         rm = importlib.util.module_from_spec(spec)
         spec.loader.exec_module(rm)
         return rm.random_model(int(name.split(":")[1]))
-    if name in ("cartpole", "tray", "door", "fourbar"):
+    if name in ("cartpole", "tray", "door", "fourbar", "gripper"):
         from mjmpc_amd.models.synthetic import synthetic_raw
         return synthetic_raw(name)
     from mjmpc_amd.models import half_cheetah, hand24, pen_hand, reacher7dof, swimmer

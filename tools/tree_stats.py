@@ -32,13 +32,13 @@ if __name__ == "__main__":
     P = int(args[2]) if len(args) > 2 else 4096
     H = int(args[3]) if len(args) > 3 else 32
     from mjmpc_amd.models.pen_hand import holding_state, pen_hand_raw
-    if name in ("cartpole", "tray", "door"):
+    if name in ("cartpole", "tray", "door", "gripper"):
         from mjmpc_amd.models.synthetic import start_state, synthetic_raw
         raw = synthetic_raw(name)
     else:
         raw = dict(hand=hand24_raw, swimmer=swimmer_raw, cheetah=half_cheetah_raw, pen=pen_hand_raw)[name]()
     eng = TreeRolloutEngine(raw, dtype=dt)
-    if name in ("cartpole", "tray", "door"):
+    if name in ("cartpole", "tray", "door", "gripper"):
         eng.set_env_state(start_state(name, raw))
     if name == "pen":
         st = holding_state()
@@ -50,8 +50,10 @@ if __name__ == "__main__":
     lib.mjmpc_debug_tree_stats.argtypes = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_ulonglong)]
     A = eng.d_action
     g = torch.Generator(device="cuda").manual_seed(0)
-    noise = (0.1 if name in ("pen", "tray") else 0.5) * torch.randn(P, H, A, device="cuda", dtype=torch.float32 if dt == "f32" else torch.float64, generator=g)
+    noise = (0.1 if name in ("pen", "tray") else (0.05 if name == "gripper" else 0.5)) * torch.randn(P, H, A, device="cuda", dtype=torch.float32 if dt == "f32" else torch.float64, generator=g)
     mean = torch.zeros(H, A, device="cuda", dtype=torch.float64)
+    if name == "gripper":
+        mean[:, 1:] = 0.2           # (finger servos: the pose the model is drawn in)
     if name == "pen":
         mean += torch.from_numpy(st["qp"][6:]).to(mean)
     out = (ctypes.c_ulonglong * 24)()

@@ -29,7 +29,7 @@ elif name in ("pen", "penf"):
                 b.joint.frictionloss = 0.02
     st = holding_state()
     start = dict(qpos=st["qp"], qvel=st["qv"], target_pos=np.asarray(raw.target_pos, float))
-elif name in ("cartpole", "tray", "door"):
+elif name in ("cartpole", "tray", "door", "gripper"):
     from mjmpc_amd.models.synthetic import start_state, synthetic_raw
     raw = synthetic_raw(name)
     start = start_state(name, raw)
@@ -45,8 +45,10 @@ if name == "cheetah":       # resting on its feet: contacts from the first subst
     q0 = np.array([0.0, -0.1324, 0.0521, 0.0342, 0.0679, -0.0139, -0.0589, -0.14, -0.131])
     eng.set_env_state(dict(qpos=q0, qvel=np.zeros(9)))
 g = torch.Generator(device="cuda").manual_seed(0)
-noise = (0.1 if name in ("pen", "penf", "tray") else 0.5) * torch.randn(P, H, A, device="cuda", dtype=torch.float32 if dt == "f32" else torch.float64, generator=g)
+noise = (0.1 if name in ("pen", "penf", "tray") else (0.05 if name == "gripper" else 0.5)) * torch.randn(P, H, A, device="cuda", dtype=torch.float32 if dt == "f32" else torch.float64, generator=g)
 mean = torch.zeros(H, A, device="cuda", dtype=torch.float64)
+if name == "gripper":
+    mean[:, 1:] = 0.2           # (finger servos: the pose the model is drawn in)
 if name in ("pen", "penf"):           # position servos: hold the start pose
     mean += torch.from_numpy(st["qp"][6:]).to(mean)
 eng.rollout_device(P, H, mean, noise)
