@@ -79,7 +79,8 @@ struct mjmpc_tree_s {
     int device = 0;
     int nv = 0, nu = 0, d_obs = 0, max_path = 0, nq = 0;
     bool full = false;              // slide joints, springs, friction cones, > 8 contact points or a medium: the full kernel
-    bool gen = false;               // ball / free joints, friction loss, boxes, equalities, tendon limits: the general instantiation
+    int gen = 0;                    // T_GEN: 1 ball / free joints, friction loss, boxes, equalities, tendon limits (the general
+                                    // instantiation), 2 round 5's record kinds on top (instantiations of their own)
     int n_shards = 1;               // > 1: model_f32 / model_f64 hold one block per shard
     double* zero_action = nullptr;  // [32] zeros (the kinematics-only launch of mjmpc_tree_rollout_cl)
     double* scratch = nullptr;      // [8] a place for that launch's cost
@@ -767,7 +768,7 @@ int mjmpc_tree_create(const double* blob, int n_blob, int device, mjmpc_tree_t* 
     }
     h->d_obs = (int)blob[mjmpc::T_TASK] == 1 ? h->nq + nv - (int)blob[mjmpc::T_OBS_SKIP] : h->nq + nv + 6;
     h->full = tree_blob_is_full(blob, nv);
-    h->gen = blob[mjmpc::T_GEN] != 0.0;
+    h->gen = (int)blob[mjmpc::T_GEN];
     for (int l = 0; l < nv; ++l) h->max_path = std::max(h->max_path, (int)blob[mjmpc::T_DEPTH + l] + 1);
     h->topo.assign(blob, blob + n_blob);
     if (int rc = tree_create_impl(h, blob, n_blob)) {       // a failed allocation leaves nothing behind
@@ -790,7 +791,7 @@ int mjmpc_tree_set_shard_models(mjmpc_tree_t h, const double* blobs, int n_shard
         if ((int)b[mjmpc::T_N_SPHERE] > mjmpc::TREE_MAX_SPHERES || !tree_same_topology(b, h->topo.data()))
             return fail(MJMPC_E_BADMODEL, "shard %d does not have the engine's topology / dimensions", s);
         full = full || tree_blob_is_full(b, h->nv);
-        if ((b[mjmpc::T_GEN] != 0.0) != h->gen)
+        if ((int)b[mjmpc::T_GEN] != h->gen)
             return fail(MJMPC_E_BADMODEL, "shard %d needs a different kernel instantiation than the engine's model", s);
     }
     std::vector<float> f32(blobs, blobs + n);

@@ -117,6 +117,9 @@ enum TreePointKind : int { PT_PLANE = 0, PT_SEGSEG = 1, PT_SPHERE_BOX = 2, PT_BO
                            // round 5 - records that come in GROUPS of [23] consecutive ones, [22] = the record's index in its group:
                            PT_PLANE_CYL = 7,   // a cylinder on the plane (mjc_PlaneCylinder): candidate point k of four; [1:4] centre, [4] radius,
                                                // [8:11] axis, [14] half height
+                           PT_BOX_BOX = 10,    // two boxes: contact k of four (SAT, then face clipping or the edge pair; see the oracle's box_box);
+                                               // box A in PEXT [0:12] as PT_SPHERE_BOX's, box B's orientation in ITS link's frame as a
+                                               // quaternion in PEXT [12:16], its half sizes in [16:19]
                            PT_CAPSULE_BOX = 8, PT_BOX_CAPSULE = 9 };   // a capsule against a box: candidate k of three (the axis' nearest point,
                                                // the two ends); segment as PT_SEGSEG, box as PT_SPHERE_BOX.  (A box's corners on the plane
                                                // are PT_PLANE records with [23] = 8, [22] = corner, [14:17] = the box centre: mjc_PlaneBox

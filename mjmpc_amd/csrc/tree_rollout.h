@@ -11,7 +11,8 @@ namespace mjmpc {
 // there in the layout of `state` (the device-resident real env).  clw: closed_loop_linear weights f64 [(d_obs + 1)][A]
 // instead of `mean` (the fresh observation's site is read from state[2 * 32 + 3 ...], which a P = 1 launch with site_out
 // pointing there provides).  model: TREE_BLOB_LEN scalars of T; state: f64 TREE_STATE_LEN (tree_model.h);
-// gen: the model block asks for the general instantiation (T_GEN: ball / free joints, friction loss, boxes, equalities);
+// gen: the model block's T_GEN - 1: the general instantiation (ball / free joints, friction loss, boxes, equalities), 2: with round
+// 5's record kinds on top (a cylinder on the plane, capsule / box and box / box pairs, mjc_PlaneBox's corner rule);
 // mean f64 [H][A]; noise / cost / act / obs / nobs of T in the reference's C-order layouts (may be null except cost).
 // n_state_shards > 1: `state` holds one TREE_STATE_LEN vector per shard (per-worker start states); with both kinds of
 // shards their counts must agree.
@@ -39,7 +40,7 @@ template <typename T>
 hipError_t launch_tree_rollout(const T* model, int n_model_shards, int max_path, bool full, int nv, const double* state, long P, int H,
                                int A, const double* mean, const T* noise, T* cost, T* act, T* obs, T* nobs, unsigned* diag,
                                hipStream_t stream, double* state_out = nullptr, const double* clw = nullptr,
-                               double* site_out = nullptr, int n_state_shards = 1, bool gen = false,
+                               double* site_out = nullptr, int n_state_shards = 1, int gen = 0,
                                TreeFusion fuse = TreeFusion());
 
 }  // namespace mjmpc

@@ -1096,7 +1096,7 @@ __device__ __noinline__ T seg_box_param(const T* h, const T* a, const T* b) {
         }
     for (int i = 1; i < 8; ++i)
         for (int j = i; j > 0 && bp[j] < bp[j - 1]; --j) { const T t = bp[j]; bp[j] = bp[j - 1]; bp[j - 1] = t; }
-    T best_f = T(1e300), best_t = T(0);
+    T best_f = T(1e300), best_t = T(0), zlo = T(2), zhi = T(-1);
     if (sizeof(T) == 4) best_f = T(3e38);
     for (int k = 0; k < 7; ++k) {
         const T u = bp[k], w = bp[k + 1], mid = T(0.5) * (u + w);
@@ -1114,8 +1114,278 @@ __device__ __noinline__ T seg_box_param(const T* h, const T* a, const T* b) {
         for (int i = 0; i < 3; ++i)
             if (act[i]) { const T e = off[i] + tc * b[i]; f += e * e; }
         if (f < best_f) { best_f = f; best_t = tc; }
+        if (!act[0] && !act[1] && !act[2]) {        // (no coordinate outside its faces on this piece: the axis runs INSIDE the box here)
+            zlo = fmin(zlo, u);
+            zhi = fmax(zhi, w);
+        }
     }
+    // an axis that enters the box has distance 0 on a whole stretch: a point well inside it, three eighths of the way (see the oracle)
+    if (zhi >= zlo) return zlo + T(0.375) * (zhi - zlo);
     return best_t;
+}
+
+// closest points of two segments p1 + s d1, p2 + t d2 (the clamped closed form of the geom-geom records; the oracle's seg_seg)
+template <typename T>
+__device__ __forceinline__ void seg_seg_params(const T* o1, const T* d1, const T* o2, const T* d2, T& ss, T& tt) {
+    const T r3[3] = {o1[0] - o2[0], o1[1] - o2[1], o1[2] - o2[2]};
+    const T a = dot3(d1, d1), e = dot3(d2, d2), f = dot3(d2, r3), EPS = T(1e-18);
+    auto clamp01 = [](T x) { return x < T(0) ? T(0) : (x > T(1) ? T(1) : x); };
+    if (a <= EPS && e <= EPS) { ss = T(0); tt = T(0); }
+    else if (a <= EPS) { ss = T(0); tt = clamp01(f / e); }
+    else {
+        const T c = dot3(d1, r3);
+        if (e <= EPS) { tt = T(0); ss = clamp01(-c / a); }
+        else {
+            const T b = dot3(d1, d2), denom = a * e - b * b;
+            ss = denom > T(1e-12) * a * e ? clamp01((b * f - c * e) / denom) : T(0);
+            tt = (b * ss + f) / e;
+            if (tt < T(0)) { tt = T(0); ss = clamp01(-c / a); }
+            else if (tt > T(1)) { tt = T(1); ss = clamp01((b - c) / a); }
+        }
+    }
+}
+
+// Two boxes (round 5): contact `want` of the up to four the oracle's box_box makes - the same separating-axis test (edge axes
+// must beat the best face axis by 5 %), the same Sutherland-Hodgman clipping of the incident face against the reference
+// face's side planes, the same edge-pair closest points, in the same order of operations.  R0 / R1: row-major, their COLUMNS
+// are the boxes' axes in the world.  n: unit normal from box 1 to box 0.  false: no such contact.
+template <typename T>
+__device__ __noinline__ bool box_box_contact(const T* c0, const T* R0, const T* h0, const T* c1, const T* R1, const T* h1, T margin,
+                                             int want, T* n, T* pos, T& dist) {
+    T A[3][3], B[3][3], d[3];
+    for (int i = 0; i < 3; ++i)
+        for (int k = 0; k < 3; ++k) { A[i][k] = R0[3 * k + i]; B[i][k] = R1[3 * k + i]; }
+    for (int k = 0; k < 3; ++k) d[k] = c1[k] - c0[k];
+    T best = T(sizeof(T) == 4 ? -3e38 : -1e300), bestL[3] = {T(0), T(0), T(1)};
+    int code = -1;
+    for (int t = 0; t < 6; ++t) {
+        const T* L = t < 3 ? A[t] : B[t - 3];
+        T ra = T(0), rb = T(0);
+        for (int i = 0; i < 3; ++i) { ra += h0[i] * fabs(dot3(L, A[i])); rb += h1[i] * fabs(dot3(L, B[i])); }
+        const T sep = fabs(dot3(L, d)) - ra - rb;
+        if (sep > best) { best = sep; code = t; bestL[0] = L[0]; bestL[1] = L[1]; bestL[2] = L[2]; }
+    }
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j) {
+            T L[3];
+            cross3(A[i], B[j], L);
+            const T ln = sqrt_(dot3(L, L));
+            if (ln < T(1e-9)) continue;
+            for (int k = 0; k < 3; ++k) L[k] /= ln;
+            T ra = T(0), rb = T(0);
+            for (int k = 0; k < 3; ++k) { ra += h0[k] * fabs(dot3(L, A[k])); rb += h1[k] * fabs(dot3(L, B[k])); }
+            const T sep = fabs(dot3(L, d)) - ra - rb;
+            if (sep > best + T(0.05) * fabs(best) + T(1e-12)) { best = sep; code = 6 + 3 * i + j; bestL[0] = L[0]; bestL[1] = L[1]; bestL[2] = L[2]; }
+        }
+    if (!(best < margin)) return false;
+    const T sgn = dot3(bestL, d) < T(0) ? T(-1) : T(1);
+    T L[3];
+    for (int k = 0; k < 3; ++k) { L[k] = sgn * bestL[k]; n[k] = -L[k]; }
+    if (code >= 6) {
+        if (want != 0) return false;
+        const int i = (code - 6) / 3, j = (code - 6) % 3;
+        T pa[3], pb[3];
+        for (int k = 0; k < 3; ++k) { pa[k] = c0[k]; pb[k] = c1[k]; }
+        for (int a = 0; a < 3; ++a) {
+            if (a != i) { const T sg = dot3(L, A[a]) > T(0) ? T(1) : T(-1); for (int k = 0; k < 3; ++k) pa[k] += sg * h0[a] * A[a][k]; }
+            if (a != j) { const T sg = dot3(L, B[a]) > T(0) ? T(-1) : T(1); for (int k = 0; k < 3; ++k) pb[k] += sg * h1[a] * B[a][k]; }
+        }
+        T sa[3], da[3], sb[3], db[3], ta, tb;
+        for (int k = 0; k < 3; ++k) {
+            sa[k] = pa[k] - h0[i] * A[i][k]; da[k] = T(2) * h0[i] * A[i][k];
+            sb[k] = pb[k] - h1[j] * B[j][k]; db[k] = T(2) * h1[j] * B[j][k];
+        }
+        seg_seg_params(sa, da, sb, db, ta, tb);
+        T dd = T(0);
+        for (int k = 0; k < 3; ++k) {
+            const T qa = sa[k] + ta * da[k], qb = sb[k] + tb * db[k];
+            dd += (qb - qa) * L[k];
+            pos[k] = T(0.5) * (qa + qb);
+        }
+        dist = dd;
+        return dd < margin;
+    }
+    const bool ref1 = code >= 3;
+    const int fi = code % 3;
+    const T (*RA)[3] = ref1 ? B : A;
+    const T (*IA)[3] = ref1 ? A : B;
+    const T *hr = ref1 ? h1 : h0, *hi = ref1 ? h0 : h1, *cr = ref1 ? c1 : c0, *ci = ref1 ? c0 : c1;
+    T nr[3];
+    for (int k = 0; k < 3; ++k) nr[k] = ref1 ? -L[k] : L[k];
+    int ii = 0;
+    T most = T(-1);
+    for (int a = 0; a < 3; ++a) { const T c = fabs(dot3(nr, IA[a])); if (c > most) { most = c; ii = a; } }
+    const T si = dot3(nr, IA[ii]) > T(0) ? T(-1) : T(1);
+    const int i1 = (ii + 1) % 3, i2 = (ii + 2) % 3;
+    T poly[8][3], tmp[8][3];
+    int np_ = 4;
+    for (int c = 0; c < 4; ++c) {
+        const T s1 = (c == 0 || c == 3) ? T(1) : T(-1), s2 = c < 2 ? T(1) : T(-1);
+        for (int k = 0; k < 3; ++k) poly[c][k] = ci[k] + si * hi[ii] * IA[ii][k] + s1 * hi[i1] * IA[i1][k] + s2 * hi[i2] * IA[i2][k];
+    }
+    const int r1 = (fi + 1) % 3, r2 = (fi + 2) % 3;
+    for (int side = 0; side < 4 && np_ > 0; ++side) {
+        const T* u = RA[side < 2 ? r1 : r2];
+        const T sg = (side & 1) ? T(-1) : T(1), hu = hr[side < 2 ? r1 : r2];
+        int nt = 0;
+        for (int c = 0; c < np_; ++c) {
+            const T* P = poly[c];
+            const T* Q = poly[(c + 1) % np_];
+            T dp = T(0), dq = T(0);
+            for (int k = 0; k < 3; ++k) { dp += sg * u[k] * (P[k] - cr[k]); dq += sg * u[k] * (Q[k] - cr[k]); }
+            dp -= hu; dq -= hu;
+            if (dp <= T(0) && nt < 8) { for (int k = 0; k < 3; ++k) tmp[nt][k] = P[k]; ++nt; }
+            if (((dp < T(0) && dq > T(0)) || (dp > T(0) && dq < T(0))) && nt < 8) {
+                const T t = dp / (dp - dq);
+                for (int k = 0; k < 3; ++k) tmp[nt][k] = P[k] + t * (Q[k] - P[k]);
+                ++nt;
+            }
+        }
+        np_ = nt;
+        for (int c = 0; c < nt; ++c)
+            for (int k = 0; k < 3; ++k) poly[c][k] = tmp[c][k];
+    }
+    // the clipped corners within the margin of the reference face, then corner want * nk / 4 of them (the first four as they are)
+    int nk = 0;
+    T kd[8];
+    for (int c = 0; c < np_; ++c) {
+        T dd = -hr[fi];
+        for (int k = 0; k < 3; ++k) dd += nr[k] * (poly[c][k] - cr[k]);
+        if (dd < margin) {
+            for (int k = 0; k < 3; ++k) tmp[nk][k] = poly[c][k];
+            kd[nk++] = dd;
+        }
+    }
+    const int nout = nk < 4 ? nk : 4;
+    if (want >= nout) return false;
+    const int src = nk <= 4 ? want : (want * nk) / 4;
+    dist = kd[src];
+    for (int k = 0; k < 3; ++k) pos[k] = tmp[src][k] - T(0.5) * kd[src] * nr[k];
+    return true;
+}
+
+// Round 5's contact-record kinds, evaluated by the record's lane (GEN = 2 instantiations only): link poses by value (A: the
+// record's link, B: link [13] or the world), the record and its extension.
+template <typename T>
+struct LinkPose { T R[9], p[3]; };
+template <typename T>
+struct ExtraContact { T cp[3], n[3], t1[3], dist; bool hit; };
+template <typename T>
+__device__ __forceinline__ ExtraContact<T> extra_geometry(int kind, LinkPose<T> fa, LinkPose<T> fb, const T* sp, const T* ex, T pnx, T pny, T pnz, T plane_d) {
+    ExtraContact<T> out;
+    const T pn[3] = {pnx, pny, pnz}, zero3[3] = {T(0), T(0), T(0)};
+    const T* Rl = fa.R;
+    const T* Rb = fb.R;
+    T tv[3], oA[3], oB[3];
+    mv3(Rl, sp + 1, tv);
+    for (int k = 0; k < 3; ++k) oA[k] = fa.p[k] + tv[k];
+    out.hit = false;
+    out.dist = T(0);
+    for (int k = 0; k < 3; ++k) { out.cp[k] = T(0); out.n[k] = pn[k]; out.t1[k] = T(0); }
+    if (kind == PT_PLANE_CYL) {
+        // a cylinder on the plane (mjc_PlaneCylinder, as the oracle restates it): the lowest point of the lower cap's rim, the
+        // point below it on the other cap's rim, two more points of the lower rim 120 degrees to either side - candidate
+        // sp[22] of the four; the later ones count only if the first does
+        T a3[3], vec[3];
+        mv3(Rl, sp + 8, a3);
+        T pa = dot3(pn, a3);
+        if (pa > T(0)) { for (int k = 0; k < 3; ++k) a3[k] = -a3[k]; pa = -pa; }
+        for (int k = 0; k < 3; ++k) vec[k] = pn[k] - pa * a3[k];
+        T len = sqrt_(dot3(vec, vec));
+        if (len < T(1e-12)) {
+            const bool yy = a3[1] < T(0.5) && a3[1] > T(-0.5);
+            const T ax3[3] = {T(0), yy ? T(1) : T(0), yy ? T(0) : T(1)};
+            const T pr = dot3(a3, ax3);
+            for (int k = 0; k < 3; ++k) vec[k] = ax3[k] - pr * a3[k];
+            len = sqrt_(dot3(vec, vec));
+        }
+        const T rr = sp[4], hh = sp[14], sc0 = rr / len;
+        for (int k = 0; k < 3; ++k) vec[k] *= sc0;
+        const T d0 = dot3(pn, oA) - plane_d, pv = dot3(pn, vec), d1 = d0 + pa * hh - pv;
+        const int kk = (int)sp[22];
+        T pt3[3], cdist;
+        if (kk == 0) {
+            for (int k = 0; k < 3; ++k) pt3[k] = oA[k] + a3[k] * hh - vec[k];
+            cdist = d1;
+        } else if (kk == 1) {
+            for (int k = 0; k < 3; ++k) pt3[k] = oA[k] - a3[k] * hh - vec[k];
+            cdist = d0 - pa * hh - pv;
+        } else {
+            T v1[3];
+            cross3(vec, a3, v1);
+            const T sc = (kk == 2 ? T(1) : T(-1)) * T(0.86602540378443864676);
+            for (int k = 0; k < 3; ++k) pt3[k] = oA[k] + a3[k] * hh + T(0.5) * vec[k] + sc * v1[k];
+            cdist = d0 + pa * hh + T(0.5) * pv;
+        }
+        for (int k = 0; k < 3; ++k) out.cp[k] = pt3[k] - pn[k] * (T(0.5) * cdist);
+        frame_tangent(pn, zero3, out.t1);
+        out.dist = cdist;
+        out.hit = d1 < sp[5] && cdist < sp[5];
+        return out;
+    }
+    mv3(Rb, sp + 14, tv);
+    for (int k = 0; k < 3; ++k) oB[k] = fb.p[k] + tv[k];
+    if (kind == PT_BOX_BOX) {
+        // two boxes: contact sp[22] of up to four (box_box_contact)
+        T RwA[9], RwB[9], Q[9];
+        {
+            const T w_ = ex[12], x_ = ex[13], y_ = ex[14], z_ = ex[15];
+            Q[0] = T(1) - T(2) * (y_ * y_ + z_ * z_); Q[1] = T(2) * (x_ * y_ - w_ * z_); Q[2] = T(2) * (x_ * z_ + w_ * y_);
+            Q[3] = T(2) * (x_ * y_ + w_ * z_); Q[4] = T(1) - T(2) * (x_ * x_ + z_ * z_); Q[5] = T(2) * (y_ * z_ - w_ * x_);
+            Q[6] = T(2) * (x_ * z_ - w_ * y_); Q[7] = T(2) * (y_ * z_ + w_ * x_); Q[8] = T(1) - T(2) * (x_ * x_ + y_ * y_);
+        }
+        for (int i = 0; i < 3; ++i)
+            for (int j = 0; j < 3; ++j) {
+                RwA[3 * i + j] = Rl[3 * i] * ex[3 + j] + Rl[3 * i + 1] * ex[6 + j] + Rl[3 * i + 2] * ex[9 + j];
+                RwB[3 * i + j] = Rb[3 * i] * Q[j] + Rb[3 * i + 1] * Q[3 + j] + Rb[3 * i + 2] * Q[6 + j];
+            }
+        T nv3[3] = {T(0), T(0), T(1)}, cp3[3] = {T(0), T(0), T(0)}, cdist = T(0);
+        const bool ok = box_box_contact(oA, RwA, ex, oB, RwB, ex + 16, sp[5], (int)sp[22], nv3, cp3, cdist);
+        for (int k = 0; k < 3; ++k) { out.n[k] = nv3[k]; out.cp[k] = cp3[k]; }
+        frame_tangent(nv3, zero3, out.t1);
+        out.dist = cdist;
+        out.hit = ok && cdist < sp[5];
+        return out;
+    }
+    // a capsule against a box (a scheme of its own, see the oracle): candidate sp[22] of three - where the capsule's axis comes
+    // nearest to the box (a point of its stretch inside, should it pass through), its two ends where they are not that point
+    const bool boxA = kind == PT_BOX_CAPSULE;
+    const T* Rx = boxA ? Rl : Rb;                       // the box's link
+    const T* ob = boxA ? oA : oB;
+    const T* os0 = boxA ? oB : oA;
+    const T rs = boxA ? sp[17] : sp[4];
+    T Rw[9];
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j)
+            Rw[3 * i + j] = Rx[3 * i] * ex[3 + j] + Rx[3 * i + 1] * ex[6 + j] + Rx[3 * i + 2] * ex[9 + j];
+    const T rel[3] = {os0[0] - ob[0], os0[1] - ob[1], os0[2] - ob[2]};
+    T loc[3], cl[3], os[3] = {os0[0], os0[1], os0[2]}, dv[3], bl[3];
+    for (int i = 0; i < 3; ++i) loc[i] = Rw[i] * rel[0] + Rw[3 + i] * rel[1] + Rw[6 + i] * rel[2];
+    if (boxA) mv3(Rb, sp + 18, dv); else mv3(Rl, sp + 8, dv);
+    for (int i = 0; i < 3; ++i) bl[i] = Rw[i] * dv[0] + Rw[3 + i] * dv[1] + Rw[6 + i] * dv[2];
+    const T tstar = seg_box_param(ex, loc, bl);
+    const int cand = (int)sp[22];
+    const T tt = cand == 0 ? tstar : (cand == 1 ? T(0) : T(1));
+    bool ok = cand == 0 || tt != tstar;
+    for (int i = 0; i < 3; ++i) { loc[i] += tt * bl[i]; os[i] += tt * dv[i]; }
+    T nl[3], nb[3], len = T(0);
+    ok = box_point(ex, loc, cl, nl, len) && ok;
+    mv3(Rw, nl, nb);
+    T cb[3];
+    mv3(Rw, cl, cb);
+    for (int k = 0; k < 3; ++k) cb[k] += ob[k];
+    // nb points from the box to the capsule; the contact's normal from geom B to geom A
+    const T sgn = boxA ? T(-1) : T(1);
+    const T cdist = len - rs;
+    for (int k = 0; k < 3; ++k) {
+        out.n[k] = sgn * nb[k];
+        const T onB = boxA ? os[k] + out.n[k] * rs : cb[k];      // geom B's surface point; the contact midway along the normal
+        out.cp[k] = onB + out.n[k] * (T(0.5) * cdist);
+    }
+    frame_tangent(out.n, zero3, out.t1);
+    out.dist = cdist;
+    out.hit = ok && cdist < sp[5];
+    return out;
 }
 
 // Exact line search of the constraint solver's safeguard (see the Newton loop): the root in [0, 1] of the increasing,
@@ -1126,7 +1396,7 @@ __device__ __noinline__ T seg_box_param(const T* h, const T* a, const T* b) {
 // General instantiation (GEN): a point's rows may carry their own D (Dk: a connect equality) and be BILATERAL (bil: cost
 // 1/2 D r^2 on both sides), and every lane brings its friction-loss row (Df, bound ff, residual rf + al drf: the slope of
 // the Huber cost is D r clamped to +-ff).
-template <int PL, int NR, bool GEN, typename T>
+template <int PL, int NR, int GEN, typename T>
 __device__ __noinline__ T exact_line_search(T g0, T dg, T Dl, T rl, T drl, T Dc, const T* rb, const T* drb, const T* Dk, bool bil,
                                             T Df, T ff, T rf, T drf) {
     auto phi = [&](T al) -> T {
@@ -1158,7 +1428,7 @@ __device__ __noinline__ T exact_line_search(T g0, T dg, T Dl, T rl, T drl, T Dc,
 
 // waves per SIMD the register allocation aims at: the lean kernels for short paths fit three (f32) / two (f64)
 // workgroups' LDS on a CU
-constexpr int min_waves(int scalar_bytes, int DP, bool fric, bool gen = false) {
+constexpr int min_waves(int scalar_bytes, int DP, bool fric, int gen = 0) {
 #ifdef TREE_GEN_F32_ONE_WAVE            // developer A/B (round 4): the general f32 kernels spill 512 B per lane at two waves per SIMD; at one
     if (gen) return 1;                  // they gain 3-5 % on 4096-particle launches and lose a third at 32768 (cart-pole 2.11 -> 3.13 ms): off
 #endif
@@ -1168,9 +1438,12 @@ constexpr int min_waves(int scalar_bytes, int DP, bool fric, bool gen = false) {
 // PL = lanes per particle: 32, or 16 for models of up to 16 dofs (four particles per wavefront, a particle = one DPP row)
 // DN > 0 (with PL = 16): the dense in-register factorisation of a matrix of up to DN dofs instead of the tree-sparse one
 // GEN: the general instantiation (round 4) - ball / free joints (quaternion links), friction-loss rows, sphere / box pairs,
-// static geoms, connect / joint equalities, fixed-tendon limits.  Models that need none of it run GEN = false, whose code
+// static geoms, connect / joint equalities, fixed-tendon limits.  GEN = 2 (round 5): also a cylinder on the plane, capsule / box
+// and box / box contacts, mjc_PlaneBox's corner rule - instantiations of their own, so that the models of round 4 keep the
+// kernels they had (inlined into the one general kernel the new geometry cost the door model 6 %, behind a call 10 %).
+// Models that need none of it run GEN = 0, whose code
 // is the earlier rounds' to the instruction.
-template <typename T, int DP, int NS, bool FRIC, int PL, int DN, bool GEN = false>
+template <typename T, int DP, int NS, bool FRIC, int PL, int DN, int GEN = 0>
 __global__ __launch_bounds__(64 * wg_waves(DP, FRIC, sizeof(T), PL), min_waves(sizeof(T), DP, FRIC, GEN)) void tree_rollout_kernel(
     const T* __restrict__ model_all, int model_stride, const double* __restrict__ state, int state_stride, long P, long shard_size, int H,
     int A, const double* __restrict__ mean,
@@ -1550,7 +1823,24 @@ __global__ __launch_bounds__(64 * wg_waves(DP, FRIC, sizeof(T), PL), min_waves(s
                     }
 #pragma unroll
                     for (int c = 0; c < 3; ++c) pl[c] = FRIC ? X[(9 + c) * PL + sl] : T(0);
-                    if (!FRIC) {
+                    bool extra = false;
+                    if constexpr (GEN >= 2) {
+                        if (sp[12] >= T(PT_PLANE_CYL)) {
+                            // round 5's record kinds - a cylinder on the plane, a capsule against a box, two boxes (extra_geometry)
+                            extra = true;
+                            const int sb = (int)sp[13];
+                            LinkPose<T> fa, fb;
+#pragma unroll
+                            for (int c = 0; c < 9; ++c) { fa.R[c] = Rl[c]; fb.R[c] = sb >= 0 ? X[c * PL + sb] : ((c & 3) == 0 ? T(1) : T(0)); }
+#pragma unroll
+                            for (int c = 0; c < 3; ++c) { fa.p[c] = pl[c]; fb.p[c] = sb >= 0 ? X[(9 + c) * PL + sb] : T(0); }
+                            const ExtraContact<T> g = extra_geometry<T>((int)sp[12], fa, fb, sp, PEXT + l * TREE_PEXT_STRIDE, pn[0], pn[1], pn[2], M[T_PLANE_D]);
+                            for (int k = 0; k < 3; ++k) { cs[k] = g.cp[k]; cs[8 + k] = g.n[k]; cs[11 + k] = g.t1[k]; }
+                            cs[3] = g.dist;
+                            ci_mine = g.hit;
+                        }
+                    }
+                    if (!FRIC || extra) {
                     } else if (sp[12] == T(0)) {
                         // sphere / capsule end against the plane (mjc_PlaneSphere, mjc_PlaneCapsule)
                         T ctr[3];
@@ -1559,7 +1849,7 @@ __global__ __launch_bounds__(64 * wg_waves(DP, FRIC, sizeof(T), PL), min_waves(s
                         const T cdist = dot3(ctr, pn) - M[T_PLANE_D] - sp[4];
                         cs[3] = cdist;
                         ci_mine = cdist < sp[5];            // mj_collision: included while dist < margin
-                        if (GEN && sp[23] == T(8)) {        // a box's corner (mjc_PlaneBox): not one above the box centre ...
+                        if (GEN >= 2 && sp[23] == T(8)) {   // a box's corner (mjc_PlaneBox): not one above the box centre ...
                             T tc[3];
                             mv3(Rl, sp + 14, tc);
                             const T up = (tv[0] - tc[0]) * pn[0] + (tv[1] - tc[1]) * pn[1] + (tv[2] - tc[2]) * pn[2];
@@ -1674,55 +1964,10 @@ __global__ __launch_bounds__(64 * wg_waves(DP, FRIC, sizeof(T), PL), min_waves(s
                             cs[11 + i] = ex[i] * vx + ex[3 + i] * vy + ex[6 + i] * vz;        // residual = R0_2' v
                         }
                         ci_mine = true;
-                    } else if (GEN && sp[12] == T(PT_PLANE_CYL)) {
-                        // a cylinder on the plane (mjc_PlaneCylinder, as the oracle restates it): the lowest point of the lower
-                        // cap's rim, the point below it on the other cap's rim, two more points of the lower rim 120 degrees to
-                        // either side - candidate sp[22] of the four; the later ones count only if the first does
-                        T ctr[3], a3[3], vec[3];
-                        mv3(Rl, sp + 1, tv);
-                        for (int k = 0; k < 3; ++k) ctr[k] = pl[k] + tv[k];
-                        mv3(Rl, sp + 8, a3);
-                        T pa = dot3(pn, a3);
-                        if (pa > T(0)) { for (int k = 0; k < 3; ++k) a3[k] = -a3[k]; pa = -pa; }
-                        for (int k = 0; k < 3; ++k) vec[k] = pn[k] - pa * a3[k];
-                        T len = sqrt_(dot3(vec, vec));
-                        if (len < T(1e-12)) {
-                            const bool yy = a3[1] < T(0.5) && a3[1] > T(-0.5);
-                            const T ax3[3] = {T(0), yy ? T(1) : T(0), yy ? T(0) : T(1)};
-                            const T pr = dot3(a3, ax3);
-                            for (int k = 0; k < 3; ++k) vec[k] = ax3[k] - pr * a3[k];
-                            len = sqrt_(dot3(vec, vec));
-                        }
-                        const T rr = sp[4], hh = sp[14], sc0 = rr / len;
-                        for (int k = 0; k < 3; ++k) vec[k] *= sc0;
-                        const T d0 = dot3(pn, ctr) - M[T_PLANE_D], pv = dot3(pn, vec), d1 = d0 + pa * hh - pv;
-                        const int kk = (int)sp[22];
-                        T pt3[3], cdist;
-                        if (kk == 0) {
-                            for (int k = 0; k < 3; ++k) pt3[k] = ctr[k] + a3[k] * hh - vec[k];
-                            cdist = d1;
-                        } else if (kk == 1) {
-                            for (int k = 0; k < 3; ++k) pt3[k] = ctr[k] - a3[k] * hh - vec[k];
-                            cdist = d0 - pa * hh - pv;
-                        } else {
-                            T v1[3];
-                            cross3(vec, a3, v1);
-                            const T sc = (kk == 2 ? T(1) : T(-1)) * T(0.86602540378443864676);
-                            for (int k = 0; k < 3; ++k) pt3[k] = ctr[k] + a3[k] * hh + T(0.5) * vec[k] + sc * v1[k];
-                            cdist = d0 + pa * hh + T(0.5) * pv;
-                        }
-                        for (int k = 0; k < 3; ++k) { cs[k] = pt3[k] - pn[k] * (T(0.5) * cdist); cs[8 + k] = pn[k]; }
-                        const T zero3[3] = {T(0), T(0), T(0)};
-                        frame_tangent(pn, zero3, cs + 11);
-                        cs[3] = cdist;
-                        ci_mine = d1 < sp[5] && cdist < sp[5];
-                    } else if (GEN && (sp[12] == T(PT_SPHERE_BOX) || sp[12] == T(PT_BOX_SPHERE) || sp[12] == T(PT_CAPSULE_BOX) || sp[12] == T(PT_BOX_CAPSULE))) {
+                    } else if (GEN && (sp[12] == T(PT_SPHERE_BOX) || sp[12] == T(PT_BOX_SPHERE))) {
                         // a sphere against a box (mjc_SphereBox): the box's closest point to the sphere's centre, or - centre
-                        // inside - the nearest face; normal from geom B to geom A, contact point midway between the surfaces.
-                        // A capsule against a box (round 5; a scheme of its own, see the oracle): candidate sp[22] of three -
-                        // where the capsule's axis comes nearest to the box, its two ends where they are not that point
-                        const bool boxA = sp[12] == T(PT_BOX_SPHERE) || sp[12] == T(PT_BOX_CAPSULE);
-                        const bool capsule = sp[12] == T(PT_CAPSULE_BOX) || sp[12] == T(PT_BOX_CAPSULE);
+                        // inside - the nearest face; normal from geom B to geom A, contact point midway between the surfaces
+                        const bool boxA = sp[12] == T(PT_BOX_SPHERE);
                         const int sb = (int)sp[13];
                         const T* ex = PEXT + l * TREE_PEXT_STRIDE;
                         T Rb[9], oA[3], oB[3];
@@ -1734,32 +1979,46 @@ __global__ __launch_bounds__(64 * wg_waves(DP, FRIC, sizeof(T), PL), min_waves(s
                         for (int k = 0; k < 3; ++k) oB[k] = (sb >= 0 ? X[(9 + k) * PL + sb] : T(0)) + tv[k];
                         const T* Rx = boxA ? Rl : Rb;                       // the box's link
                         const T* ob = boxA ? oA : oB;
-                        const T* os0 = boxA ? oB : oA;
+                        const T* os = boxA ? oB : oA;
                         const T rs = boxA ? sp[17] : sp[4];
                         T Rw[9];
                         for (int i = 0; i < 3; ++i)
                             for (int j = 0; j < 3; ++j)
                                 Rw[3 * i + j] = Rx[3 * i] * ex[3 + j] + Rx[3 * i + 1] * ex[6 + j] + Rx[3 * i + 2] * ex[9 + j];
-                        const T rel[3] = {os0[0] - ob[0], os0[1] - ob[1], os0[2] - ob[2]};
-                        T loc[3], cl[3], os[3] = {os0[0], os0[1], os0[2]};
-                        for (int i = 0; i < 3; ++i) loc[i] = Rw[i] * rel[0] + Rw[3 + i] * rel[1] + Rw[6 + i] * rel[2];
-                        bool ok = true;
-                        if (capsule) {
-                            T dv[3], bl[3];
-                            if (boxA) mv3(Rb, sp + 18, dv); else mv3(Rl, sp + 8, dv);
-                            for (int i = 0; i < 3; ++i) bl[i] = Rw[i] * dv[0] + Rw[3 + i] * dv[1] + Rw[6 + i] * dv[2];
-                            const T tstar = seg_box_param(ex, loc, bl);
-                            const int cand = (int)sp[22];
-                            const T tt = cand == 0 ? tstar : (cand == 1 ? T(0) : T(1));
-                            ok = cand == 0 || tt != tstar;
-                            for (int i = 0; i < 3; ++i) { loc[i] += tt * bl[i]; os[i] += tt * dv[i]; }
+                        const T rel[3] = {os[0] - ob[0], os[1] - ob[1], os[2] - ob[2]};
+                        T loc[3], cl[3];
+                        bool inside = true;
+                        for (int i = 0; i < 3; ++i) {
+                            loc[i] = Rw[i] * rel[0] + Rw[3 + i] * rel[1] + Rw[6 + i] * rel[2];
+                            cl[i] = fmin(fmax(loc[i], -ex[i]), ex[i]);
+                            inside = inside && cl[i] == loc[i];
                         }
-                        T nl[3], nb[3], len = T(0);
-                        ok = box_point(ex, loc, cl, nl, len) && ok;
-                        mv3(Rw, nl, nb);
+                        T nb[3] = {T(0), T(0), T(0)}, len;
+                        if (inside) {
+                            int kk = 0;
+                            T best = ex[0] - fabs(loc[0]);
+                            for (int i = 1; i < 3; ++i) {
+                                const T gap = ex[i] - fabs(loc[i]);
+                                if (gap < best) { best = gap; kk = i; }
+                            }
+                            const T sg = loc[kk] >= T(0) ? T(1) : T(-1);
+                            for (int i = 0; i < 3; ++i) {
+                                if (i == kk) cl[i] = sg * ex[i];
+                                nb[i] = sg * Rw[3 * i + kk];
+                            }
+                            len = -best;
+                        }
                         T cb[3];
                         mv3(Rw, cl, cb);
                         for (int k = 0; k < 3; ++k) cb[k] += ob[k];
+                        bool ok = true;
+                        if (!inside) {
+                            for (int k = 0; k < 3; ++k) nb[k] = os[k] - cb[k];
+                            len = sqrt_(dot3(nb, nb));
+                            ok = len > T(1e-14);
+                            const T inv = ok ? T(1) / len : T(0);
+                            for (int k = 0; k < 3; ++k) nb[k] *= inv;
+                        }
                         // nb points from the box to the sphere; the contact's normal from geom B to geom A
                         const T sgn = boxA ? T(-1) : T(1);
                         const T cdist = len - rs;
@@ -1829,7 +2088,7 @@ __global__ __launch_bounds__(64 * wg_waves(DP, FRIC, sizeof(T), PL), min_waves(s
                     }
                 }
                 unsigned long long b = __ballot(ci_mine);
-                if constexpr (GEN) {
+                if constexpr (GEN >= 2) {
                     // mjc_PlaneBox keeps a box's first four contacts, in corner order: a corner with four counted corners of its
                     // box (records l - k .. l - 1 of its group) ahead of it is dropped
                     bool capped = false;
@@ -2912,11 +3171,11 @@ struct TreeLaunchArgs {
     TreeFusion fuse;
 };
 template <typename T>
-hipError_t launch_tree_rollout_dense(int max_path, int nv, bool gen, const T* model, const T* noise, T* cost, T* act, T* obs, T* nobs,
+hipError_t launch_tree_rollout_dense(int max_path, int nv, int gen, const T* model, const T* noise, T* cost, T* act, T* obs, T* nobs,
                                      const TreeLaunchArgs& a);
 
-#define MJMPC_TREE_LAUNCH(DP_, NS_, FR_, PL_) MJMPC_TREE_LAUNCH_D(DP_, NS_, FR_, PL_, 0, false)
-#define MJMPC_TREE_LAUNCH_G(DP_, NS_, FR_, PL_) MJMPC_TREE_LAUNCH_D(DP_, NS_, FR_, PL_, 0, true)
+#define MJMPC_TREE_LAUNCH(DP_, NS_, FR_, PL_) MJMPC_TREE_LAUNCH_D(DP_, NS_, FR_, PL_, 0, 0)
+#define MJMPC_TREE_LAUNCH_G(DP_, NS_, FR_, PL_, G_) MJMPC_TREE_LAUNCH_D(DP_, NS_, FR_, PL_, 0, G_)
 #define MJMPC_TREE_LAUNCH_D(DP_, NS_, FR_, PL_, DN_, GEN_)                                                            \
     {                                                                                                                 \
         constexpr int per_wg = wg_waves(DP_, FR_, sizeof(T), PL_) * (64 / PL_);                                       \
@@ -2929,36 +3188,43 @@ hipError_t launch_tree_rollout_dense(int max_path, int nv, bool gen, const T* mo
 
 #ifdef TREE_DENSE_TU
 template <typename T>
-hipError_t launch_tree_rollout_dense(int max_path, int nv, bool gen, const T* model, const T* noise, T* cost, T* act, T* obs, T* nobs,
+hipError_t launch_tree_rollout_dense(int max_path, int nv, int gen, const T* model, const T* noise, T* cost, T* act, T* obs, T* nobs,
                                      const TreeLaunchArgs& a) {
     // (16 lanes per particle: the dense in-register factorisation, sized for the model)
     if (nv > 16) {      // 32 lanes per particle, the dense factorisation over the particle's two DPP rows (dense32_factor)
-        if (gen) MJMPC_TREE_LAUNCH_D(16, 16, true, 32, 32, true)       // (general models: paths of up to 16 links)
-        else if (max_path <= 16) MJMPC_TREE_LAUNCH_D(16, 16, true, 32, 32, false)
-        else MJMPC_TREE_LAUNCH_D(32, 16, true, 32, 32, false)
+        if (gen >= 2) MJMPC_TREE_LAUNCH_D(16, 16, true, 32, 32, 2)     // (round 5's record kinds: instantiations of their own)
+        else if (gen) MJMPC_TREE_LAUNCH_D(16, 16, true, 32, 32, 1)     // (general models: paths of up to 16 links)
+        else if (max_path <= 16) MJMPC_TREE_LAUNCH_D(16, 16, true, 32, 32, 0)
+        else MJMPC_TREE_LAUNCH_D(32, 16, true, 32, 32, 0)
+    }
+    else if (gen >= 2) {
+        if (max_path <= 8 && nv <= 8) MJMPC_TREE_LAUNCH_D(8, 16, true, 16, 8, 2)
+        else if (max_path <= 8 && nv <= 12) MJMPC_TREE_LAUNCH_D(8, 16, true, 16, 12, 2)
+        else if (max_path <= 8) MJMPC_TREE_LAUNCH_D(8, 16, true, 16, 16, 2)
+        else MJMPC_TREE_LAUNCH_D(16, 16, true, 16, 16, 2)
     }
     else if (gen) {          // the general instantiation comes in four sizes (measured, 4096 x 32 f64: cart-pole 0.95 -> 0.68 ms and door 1.55 -> 1.22 ms with rows of 8 instead of 16)
-        if (max_path <= 8 && nv <= 8) MJMPC_TREE_LAUNCH_D(8, 16, true, 16, 8, true)
-        else if (max_path <= 8 && nv <= 12) MJMPC_TREE_LAUNCH_D(8, 16, true, 16, 12, true)
-        else if (max_path <= 8) MJMPC_TREE_LAUNCH_D(8, 16, true, 16, 16, true)
-        else MJMPC_TREE_LAUNCH_D(16, 16, true, 16, 16, true)
+        if (max_path <= 8 && nv <= 8) MJMPC_TREE_LAUNCH_D(8, 16, true, 16, 8, 1)
+        else if (max_path <= 8 && nv <= 12) MJMPC_TREE_LAUNCH_D(8, 16, true, 16, 12, 1)
+        else if (max_path <= 8) MJMPC_TREE_LAUNCH_D(8, 16, true, 16, 16, 1)
+        else MJMPC_TREE_LAUNCH_D(16, 16, true, 16, 16, 1)
     }
-    else if (max_path <= 8 && nv <= 8) MJMPC_TREE_LAUNCH_D(8, 16, true, 16, 8, false)
-    else if (max_path <= 8 && nv <= 12) MJMPC_TREE_LAUNCH_D(8, 16, true, 16, 12, false)
-    else if (max_path <= 8) MJMPC_TREE_LAUNCH_D(8, 16, true, 16, 16, false)
-    else MJMPC_TREE_LAUNCH_D(16, 16, true, 16, 16, false)
+    else if (max_path <= 8 && nv <= 8) MJMPC_TREE_LAUNCH_D(8, 16, true, 16, 8, 0)
+    else if (max_path <= 8 && nv <= 12) MJMPC_TREE_LAUNCH_D(8, 16, true, 16, 12, 0)
+    else if (max_path <= 8) MJMPC_TREE_LAUNCH_D(8, 16, true, 16, 16, 0)
+    else MJMPC_TREE_LAUNCH_D(16, 16, true, 16, 16, 0)
     return hipGetLastError();
 }
-template hipError_t launch_tree_rollout_dense<float>(int, int, bool, const float*, const float*, float*, float*, float*, float*,
+template hipError_t launch_tree_rollout_dense<float>(int, int, int, const float*, const float*, float*, float*, float*, float*,
                                                      const TreeLaunchArgs&);
-template hipError_t launch_tree_rollout_dense<double>(int, int, bool, const double*, const double*, double*, double*, double*, double*,
+template hipError_t launch_tree_rollout_dense<double>(int, int, int, const double*, const double*, double*, double*, double*, double*,
                                                       const TreeLaunchArgs&);
 #else
 template <typename T>
 hipError_t launch_tree_rollout(const T* model, int n_model_shards, int max_path, bool full, int nv, const double* state, long P, int H,
                                int A, const double* mean, const T* noise, T* cost, T* act, T* obs, T* nobs, unsigned* diag,
                                hipStream_t stream, double* state_out, const double* clw, double* site_out, int n_state_shards,
-                               bool gen, TreeFusion fuse) {
+                               int gen, TreeFusion fuse) {
     if (P <= 0 || H <= 0) return hipSuccess;
     if (gen && !full) return hipErrorInvalidValue;
     if ((state_out || site_out) && P != 1) return hipErrorInvalidValue;
@@ -2990,15 +3256,19 @@ hipError_t launch_tree_rollout(const T* model, int n_model_shards, int max_path,
         else MJMPC_TREE_LAUNCH(32, 8, false, 32)
     } else if (nv <= 16) {
         return launch_tree_rollout_dense<T>(max_path, nv, gen, model, noise, cost, act, obs, nobs, a);
-    } else if (max_path > 8 && !(gen && max_path > 16) && !getenv("MJMPC_TREE_SPARSE")) {
+    } else if (gen >= 2 ? max_path <= 16 : (max_path > 8 && !(gen && max_path > 16) && !getenv("MJMPC_TREE_SPARSE"))) {
         // 17 .. 32 dofs on elimination paths of more than 8 links: dense over the particle's 32 lanes - measured at 4096 x 32:
         // pen-in-hand (paths of 16) f64 16.2 -> 9.8 ms, f32 13.8 -> 8.0; with paths of up to 8 links (a hand with friction
         // cones) the tree-sparse factorisation with its merged Euler matrix stays ahead, 4.15 against 4.27 ms
         // (MJMPC_TREE_SPARSE in the environment keeps the tree-sparse one everywhere: the A/B switch of tools/tree_time.py)
         return launch_tree_rollout_dense<T>(max_path, nv, gen, model, noise, cost, act, obs, nobs, a);
+    } else if (gen >= 2) {
+        // (round 5's record kinds: dense over 32 lanes whatever the path length up to 16 links - the one instantiation; the
+        // tree-sparse kernel only for elimination paths beyond that)
+        MJMPC_TREE_LAUNCH_G(32, 16, true, 32, 2)
     } else if (gen) {
-        if (max_path <= 16) MJMPC_TREE_LAUNCH_G(16, 16, true, 32)
-        else MJMPC_TREE_LAUNCH_G(32, 16, true, 32)
+        if (max_path <= 16) MJMPC_TREE_LAUNCH_G(16, 16, true, 32, 1)
+        else MJMPC_TREE_LAUNCH_G(32, 16, true, 32, 1)
     } else {
         if (max_path <= 8) MJMPC_TREE_LAUNCH(8, 16, true, 32)
         else if (max_path <= 16) MJMPC_TREE_LAUNCH(16, 16, true, 32)
@@ -3008,9 +3278,9 @@ hipError_t launch_tree_rollout(const T* model, int n_model_shards, int max_path,
 }
 
 template hipError_t launch_tree_rollout<float>(const float*, int, int, bool, int, const double*, long, int, int, const double*,
-                                               const float*, float*, float*, float*, float*, unsigned*, hipStream_t, double*, const double*, double*, int, bool, TreeFusion);
+                                               const float*, float*, float*, float*, float*, unsigned*, hipStream_t, double*, const double*, double*, int, int, TreeFusion);
 template hipError_t launch_tree_rollout<double>(const double*, int, int, bool, int, const double*, long, int, int, const double*,
-                                                const double*, double*, double*, double*, double*, unsigned*, hipStream_t, double*, const double*, double*, int, bool, TreeFusion);
+                                                const double*, double*, double*, double*, double*, unsigned*, hipStream_t, double*, const double*, double*, int, int, TreeFusion);
 #endif
 #undef MJMPC_TREE_LAUNCH
 #undef MJMPC_TREE_LAUNCH_G

@@ -26,6 +26,25 @@ SPH_STRIDE = 24             # contact record: [0] link A, [1:4] centre / segment
                             # (0 sphere-plane, 1 geom-geom), [13] link B, [14:17] segment start on B, [17] radius B,
                             # [18:21] segment vector on B
 MJ_MINIMP, MJ_MAXIMP = 1e-4, 0.9999     # MuJoCo's clamp on solimp (getsolparam)
+
+
+def _mat2quat(R):
+    """Unit quaternion (w, x, y, z) of a rotation matrix."""
+    R = np.asarray(R, float)
+    tr = np.trace(R)
+    if tr > 0:
+        sq = np.sqrt(tr + 1.0) * 2
+        q = [0.25 * sq, (R[2, 1] - R[1, 2]) / sq, (R[0, 2] - R[2, 0]) / sq, (R[1, 0] - R[0, 1]) / sq]
+    elif R[0, 0] > R[1, 1] and R[0, 0] > R[2, 2]:
+        sq = np.sqrt(1.0 + R[0, 0] - R[1, 1] - R[2, 2]) * 2
+        q = [(R[2, 1] - R[1, 2]) / sq, 0.25 * sq, (R[0, 1] + R[1, 0]) / sq, (R[0, 2] + R[2, 0]) / sq]
+    elif R[1, 1] > R[2, 2]:
+        sq = np.sqrt(1.0 + R[1, 1] - R[0, 0] - R[2, 2]) * 2
+        q = [(R[0, 2] - R[2, 0]) / sq, (R[0, 1] + R[1, 0]) / sq, 0.25 * sq, (R[1, 2] + R[2, 1]) / sq]
+    else:
+        sq = np.sqrt(1.0 + R[2, 2] - R[0, 0] - R[1, 1]) * 2
+        q = [(R[1, 0] - R[0, 1]) / sq, (R[0, 2] + R[2, 0]) / sq, (R[1, 2] + R[2, 1]) / sq, 0.25 * sq]
+    return np.asarray(q, float)
 # link kinds (T_JTYPE): one link = one dof.  A ball joint is three links (the first holds the quaternion and turns the
 # frame, the other two ride along: their axes are the body's own y and z), a free joint three slides along the WORLD axes
 # followed by a ball
@@ -36,7 +55,7 @@ PT_PLANE, PT_SEGSEG, PT_SPHERE_BOX, PT_BOX_SPHERE, PT_CONNECT, PT_DOFROW, PT_WEL
 # round 5: a cylinder's candidate point k (record [22]) on the plane; a capsule (A) against a box (B) and the other way
 # round - candidate k of three: where the capsule's axis comes nearest to the box, its two ends.  A box's corners on the
 # plane stay PT_PLANE records with [23] = 8 (the group's size), [22] = the corner's index and [14:17] = the box centre
-PT_PLANE_CYL, PT_CAPSULE_BOX, PT_BOX_CAPSULE = 7, 8, 9
+PT_PLANE_CYL, PT_CAPSULE_BOX, PT_BOX_CAPSULE, PT_BOX_BOX = 7, 8, 9, 10     # (box-box: contact k of four; see tree_model.h)
 PEXT_STRIDE = 24            # per contact record, general instantiation: [0:3] box half sizes, [3:12] box orientation in its
                             # link's frame (row-major) | dof row: [0] 0 joint equality / 1 tendon limit, [1] coef A, [2] coef
                             # B, [3:5] range, [5] margin, [6:11] polycoef; [12:19] the row's solver set {K, B, dmin, dmax,
@@ -75,7 +94,7 @@ TREE_LAYOUT = [
     ("elim", (TL - 1) * TL),        # [entry][lane]: my descendants sorted by height, packed k | dist << 8 | height << 16
                                     # (-1 terminates): the rows that update mine, round by round
     # ---- the GENERAL instantiation's constants (round 4): ball / free joints, friction loss, boxes, equalities, tendons
-    ("gen", 1),                     # the model needs the general instantiation
+    ("gen", 1),                     # 1: the model needs the general instantiation; 2: with round 5's record kinds (their own instantiations)
     ("nq", 1), ("has_ball", 1),
     ("frictionloss", TL),           # per dof: dry friction (one friction-loss row each)
     ("qadr", TL),                   # the link's entry in MuJoCo's qpos (ball: the quaternion's w, on the BALL_X link; -1: none)
@@ -581,10 +600,11 @@ def compile_tree(raw: RawModel, overrides=None, base: "TreeModel" = None) -> Tre
         points = []
     n_eq_pts = len(raw.equalities) + sum(1 for e in raw.equalities if e.type == EQ_WELD)     # (a weld takes two records)
     n_tn_pts = sum(1 for t in raw.tendons if t.limited) + sum(1 for b in raw.bodies if b.joint is not None and b.joint.type == JOINT_BALL and b.joint.limited)
-    n_pair_pts = sum(3 if sorted((ga.type, gb.type)) == [GEOM_CAPSULE, GEOM_BOX] else 1 for (_, ga), (_, gb) in pair_geoms)
+    n_pair_pts = sum(3 if sorted((ga.type, gb.type)) == [GEOM_CAPSULE, GEOM_BOX] else (4 if (ga.type, gb.type) == (GEOM_BOX, GEOM_BOX) else 1)
+                     for (_, ga), (_, gb) in pair_geoms)
     if len(points) + n_pair_pts + n_eq_pts + n_tn_pts > TREE_MAX_SPHERES:
         raise ValueError("tree kernel supports %d contact records (a capsule on the plane counts two, a box eight, a cylinder four, "
-                         "a capsule-box pair three, any other geom-geom pair, an equality and a tendon limit one each)" % TREE_MAX_SPHERES)
+                         "a capsule-box pair three, a box-box pair four, any other geom-geom pair, an equality and a tendon limit one each)" % TREE_MAX_SPHERES)
     if raw.plane is not None:
         n = np.asarray(raw.plane.normal, float)
         n = n / np.linalg.norm(n)
@@ -729,10 +749,20 @@ def compile_tree(raw: RawModel, overrides=None, base: "TreeModel" = None) -> Tre
         if GEOM_CYLINDER in (ga.type, gb.type):
             raise NotImplementedError("a cylinder collides with the plane only")
         copies = 1
-        if boxes:
+        if len(boxes) == 2:
+            # two boxes: box A as a sphere-box record's box, box B's orientation in ITS link's frame as a quaternion + half sizes
+            for (ibx, gbx), at in (((ia, ga), 0), ((ib, gb), 12)):
+                size = overrides.get("geom_size", {}).get(gbx.name)
+                half = np.ravel(size)[:3] if size is not None else gbx.b
+                Rl = _quat2mat(gbx.quat) if ibx < 0 else R0[ibx] @ _quat2mat(gbx.quat)
+                if at == 0:
+                    ext[0:3], ext[3:12] = half, Rl.reshape(-1)
+                else:
+                    ext[12:16], ext[16:19] = _mat2quat(Rl), half
+            rec[12], rec[23], copies = PT_BOX_BOX, 4.0, 4
+            gen = True
+        elif boxes:
             other = gb if boxes[0] == 0 else ga
-            if len(boxes) == 2:
-                raise NotImplementedError("a box collides with the plane, with spheres and with capsules (box-box is not built)")
             ibx, gbx = (ia, ga) if boxes[0] == 0 else (ib, gb)
             size = overrides.get("geom_size", {}).get(gbx.name)
             ext[0:3] = np.ravel(size)[:3] if size is not None else gbx.b
@@ -862,7 +892,9 @@ def compile_tree(raw: RawModel, overrides=None, base: "TreeModel" = None) -> Tre
     nsp = s
     f["n_sphere"][0] = nsp
     gen = gen or bool(np.any(f["frictionloss"] > 0))
-    f["gen"][0] = 1.0 if gen else 0.0
+    kinds_used = f["spheres"].reshape(TREE_MAX_SPHERES, SPH_STRIDE)[:nsp]
+    gen2 = bool(np.any(kinds_used[:, 12] >= PT_PLANE_CYL) or np.any(kinds_used[:, 23] == 8.0))
+    f["gen"][0] = 2.0 if gen2 else (1.0 if gen else 0.0)
     f["nq"][0] = nq
     f["has_ball"][0] = 1.0 if any(k == LINK_BALL_X for k in link_kind) else 0.0
     f["any_friction"][0] = 1.0 if (any(f["spheres"][k * SPH_STRIDE + 7] > 0 for k in range(nsp)) or pair_geoms

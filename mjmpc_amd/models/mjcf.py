@@ -11,25 +11,25 @@ panda/tray_glass-v0.yml, sawyer/door-v0.yml, hand/*-v0.yml):
   the body) - a body with several joints becomes a chain of massless bodies, one joint each, which is what MuJoCo's
   kinematics does with it - or ONE ball joint (``limited range="0 max"``: a cone on its rotation angle), or a ``<freejoint/>`` /
   free joint (children of the world body);
-  joint ``axis range limited damping armature stiffness springref frictionloss``, ``solreflimit`` / ``solimplimit``,
+  joint ``axis range limited|auto damping armature stiffness springref frictionloss margin ref``, ``solreflimit`` / ``solimplimit``,
   ``solreffriction`` / ``solimpfriction`` (per joint); explicit ``<inertial pos quat mass
   diaginertia|fullinertia>``;
-* sphere, capsule and box geoms (``fromto``, or ``size pos`` with ``quat`` / ``axisangle`` / ``euler``), ``density``,
-  ``mass``, ``margin``, ``friction``, ``condim``, ``contype`` / ``conaffinity`` (what collides with the world plane and -
+* sphere, capsule, box and cylinder geoms (``fromto``, or ``size pos`` with ``quat`` / ``axisangle`` / ``euler``), ``density``,
+  ``mass``, ``margin``, ``gap``, ``friction``, ``condim``, ``contype`` / ``conaffinity`` (what collides with the world plane and -
   ``self_collision`` - with other bodies is decided by MuJoCo's rule), ``solref`` / ``solimp`` / ``solmix`` / ``priority`` per geom (a contact's
   set is mixed from its two geoms', mj_contactParam; up to eight distinct sets per model);
 * one world ``<geom type="plane">`` in any orientation, static sphere / capsule / box geoms on the world body (they
   collide with moving geoms through MuJoCo's contype / conaffinity rule or an explicit ``<pair>``), world and body
   ``<site>``s, ``<motor>`` / ``<position kp>`` / ``<velocity kv>`` / ``<general gainprm biasprm biastype=affine>`` actuators
   (``joint gear ctrlrange ctrllimited forcerange forcelimited``; no activation dynamics),
-  ``<contact><pair geom1 geom2 [condim friction margin solref solimp]>``; geom pairs: sphere / capsule against sphere /
-  capsule, sphere against box;
+  ``<contact><pair geom1 geom2 [condim friction margin gap solref solimp]>``; geom pairs: sphere / capsule against sphere /
+  capsule, sphere / capsule / box against box (round 5; cylinders collide with the plane only);
 * ``<equality><connect body1 body2 anchor>``, ``<weld body1 body2>`` and ``<joint joint1 joint2 polycoef>`` (``solref`` /
   ``solimp`` each),
   ``<tendon><fixed limited range><joint joint coef/>`` over one or two joints.
 
 * the layout of robot model files: ``<include file>`` (anywhere, nested; sections that then occur several times are
-  merged), ``<contact><exclude body1 body2>``, mesh / cylinder / ellipsoid geoms as VISUALS (masked out of every
+  merged), ``<contact><exclude body1 body2>``, mesh / ellipsoid geoms (and cylinders there) as VISUALS (masked out of every
   collision, on a body with an explicit ``<inertial>``), ``<sensor>`` and ``<keyframe>`` sections (read by nobody here).
 
 Anything that would change the simulation and is not modelled raises ValueError, so that a model is never silently
@@ -456,10 +456,6 @@ def load_mjcf(path, hand_site="finger", target_site="target", frame_skip=2, task
                     raise ValueError("geoms %r / %r would collide (contype / conaffinity) but a cylinder only collides with the "
                                      "plane here (MuJoCo sends cylinder pairs to its general convex collider): mask the pair out "
                                      "or use a capsule" % (ga_.name or "?", gb_.name or "?"))
-                if kinds == [GEOM_BOX, GEOM_BOX]:
-                    raise ValueError("geoms %r / %r would collide (contype / conaffinity) but a box only collides with the plane, "
-                                     "with spheres and with capsules here: mask the pair out or replace the geom"
-                                     % (ga_.name or "?", gb_.name or "?"))
                 for k, (bi, g) in ((ia, flat[ia]), (ib, flat[ib])):
                     if not g.name:
                         g.name = "%s_geom%d" % (bodies[bi].name if bi >= 0 else "world", k)

@@ -43,7 +43,7 @@
 #define MAXE 8             /* equality constraints */
 #define MAXT 8             /* fixed tendons */
 #define MAXTJ 4            /* joints per tendon */
-#define MAXC (3 * MAXV + 4 * MAXS + 4 * 16 + 6 * MAXE + 2 * MAXT)
+#define MAXC (3 * MAXV + 4 * MAXS + 4 * 4 * 16 + 6 * MAXE + 2 * MAXT)    /* (a geom pair: up to four contacts of four rows) */
 #define MJ_MINVAL 1e-15    /* MuJoCo mjMINVAL */
 
 #define HEADER_LEN 80
@@ -119,6 +119,7 @@ typedef struct {
     double pair_solref[MAXP][2], pair_solimp[MAXP][5];
     int pair_box[MAXP];                      /* -1: two segments; e: geom e of the pair is a BOX (the other a sphere) */
     double pair_R[MAXP][9], pair_half[MAXP][3];   /* that box: orientation in its body's frame, half sizes (pair_a = centre) */
+    double pair_R2[MAXP][9], pair_half2[MAXP][3]; /* pair_box = 2 (round 5): BOTH geoms are boxes - geom 0's in pair_R / pair_half, geom 1's here */
     /* equality constraints (MJCF <equality>): connect / weld (two bodies, 0 = world) and joint (two dofs, -1 = none) */
     int neq, eq_type[MAXE], eq_o1[MAXE], eq_o2[MAXE];
     double eq_anchor[MAXE][2][3], eq_relR[MAXE][9], eq_poly[MAXE][5], eq_solref[MAXE][2], eq_solimp[MAXE][5];
@@ -748,10 +749,15 @@ OrModel *or_model_compile(const double *f, int n) {
             m->pair_r[k][e] = (int)r[1] == 3 ? 0.0 : r[2];
             if ((int)r[1] == 4) { free(m); return NULL; }               /* a cylinder collides with the plane only */
             if ((int)r[1] == 3) {
-                if (m->pair_box[k] >= 0) { free(m); return NULL; }      /* box-box is not restated */
-                m->pair_box[k] = e;
-                quat2mat(r + 14, m->pair_R[k]);
-                memcpy(m->pair_half[k], r + 6, 24);
+                if (m->pair_box[k] >= 0) {          /* the second box of a box-box pair */
+                    m->pair_box[k] = 2;
+                    quat2mat(r + 14, m->pair_R2[k]);
+                    memcpy(m->pair_half2[k], r + 6, 24);
+                } else {
+                    m->pair_box[k] = e;
+                    quat2mat(r + 14, m->pair_R[k]);
+                    memcpy(m->pair_half[k], r + 6, 24);
+                }
             }
         }
         m->pair_margin[k] = pr[4];
@@ -1246,7 +1252,8 @@ static int box_point(const double *h, const double *loc, double *cl, double *nb,
 /* The parameter t in [0, 1] at which the segment a + t b (box frame) comes nearest to the solid box of half sizes h: the
  * squared distance f(t) = sum_i max(0, |a_i + t b_i| - h_i)^2 is convex and piecewise quadratic - its pieces end where a
  * coordinate crosses a face plane (at most six break points) - so every piece is minimised in closed form and the least
- * minimum taken (the first one where several pieces tie: the lowest t). */
+ * minimum taken (the first one where several pieces tie: the lowest t) - or, when the segment passes through the box, a
+ * point of its stretch inside. */
 static double seg_box_param(const double *h, const double *a, const double *b) {
     double bp[8];
     int n = 8;
@@ -1260,7 +1267,7 @@ static double seg_box_param(const double *h, const double *a, const double *b) {
         }
     for (int i = 1; i < n; i++)
         for (int j = i; j > 0 && bp[j] < bp[j - 1]; j--) { double t = bp[j]; bp[j] = bp[j - 1]; bp[j - 1] = t; }
-    double best_f = 1e300, best_t = 0.0;
+    double best_f = 1e300, best_t = 0.0, zlo = 2.0, zhi = -1.0;
     for (int k = 0; k + 1 < n; k++) {
         double u = bp[k], w = bp[k + 1], mid = 0.5 * (u + w), B = 0, C = 0;
         double off[3];
@@ -1277,8 +1284,147 @@ static double seg_box_param(const double *h, const double *a, const double *b) {
         for (int i = 0; i < 3; i++)
             if (act[i]) { double e = off[i] + tc * b[i]; f += e * e; }
         if (f < best_f) { best_f = f; best_t = tc; }
+        if (!act[0] && !act[1] && !act[2]) {        /* (no coordinate outside its faces on this piece: the axis runs INSIDE the box here) */
+            if (u < zlo) zlo = u;
+            if (w > zhi) zhi = w;
+        }
     }
+    /* an axis that enters the box has distance 0 on a whole stretch [zlo, zhi]: a point well inside it, whose nearest face is
+     * defined whatever the rounding (an end point of the stretch lies ON the surface: inside or outside by one ulp) - three
+     * eighths of the way rather than the middle, which lies exactly between two faces whenever the axis runs straight through
+     * the box's centre plane (the sign of a zero would pick the face) */
+    if (zhi >= zlo) return zlo + 0.375 * (zhi - zlo);
     return best_t;
+}
+
+/* Two boxes (round 5; mjc_BoxBox [EXT] is restated as a scheme of its own, not MuJoCo's routine): box 0 (centre c0, axes = the
+ * COLUMNS of R0, half sizes h0) against box 1.  Separating-axis test over the 15 candidate axes (3 + 3 face normals, 9 edge
+ * cross products; an edge axis must beat the best face axis by 5 % of its magnitude, as in most SAT colliders, so that faces
+ * resting on each other take the face path); then
+ *   a FACE axis: the other box's face most opposed to it is clipped against the four side planes of the reference face
+ *                (Sutherland-Hodgman); the clipped polygon's corners within the margin are contacts, four of them at most
+ *                (corners k n / 4 of an n-gon), each midway between the corner and the reference face;
+ *   an EDGE axis: the closest points of the two edges, one contact midway.
+ * n (out): unit normal from box 1 towards box 0.  Returns the number of contacts (pos[k], dist[k]). */
+static int box_box(const double *c0, const double *R0, const double *h0, const double *c1, const double *R1, const double *h1,
+                   double margin, double *n, double (*pos)[3], double *dist) {
+    double A[3][3], B[3][3], d[3], hA[3] = {h0[0], h0[1], h0[2]}, hB[3] = {h1[0], h1[1], h1[2]};
+    for (int i = 0; i < 3; i++)
+        for (int k = 0; k < 3; k++) { A[i][k] = R0[3 * k + i]; B[i][k] = R1[3 * k + i]; }     /* A[i] = axis i of box 0, world */
+    for (int k = 0; k < 3; k++) d[k] = c1[k] - c0[k];
+    /* ---- the axis of least penetration (largest separation) */
+    double best = -1e300, bestL[3] = {0, 0, 1};
+    int code = -1;                          /* 0..2 face of box 0, 3..5 face of box 1, 6 + 3 i + j edge i of box 0 x edge j of box 1 */
+    for (int t = 0; t < 6; t++) {
+        const double *L = t < 3 ? A[t] : B[t - 3];
+        double ra = 0, rb = 0;
+        for (int i = 0; i < 3; i++) { ra += hA[i] * fabs(dot3(L, A[i])); rb += hB[i] * fabs(dot3(L, B[i])); }
+        double sep = fabs(dot3(L, d)) - ra - rb;
+        if (sep > best) { best = sep; code = t; memcpy(bestL, L, 24); }
+    }
+    for (int i = 0; i < 3; i++)
+        for (int j = 0; j < 3; j++) {
+            double L[3];
+            cross3(A[i], B[j], L);
+            double ln = sqrt(dot3(L, L));
+            if (ln < 1e-9) continue;                                /* parallel edges: a face axis covers them */
+            for (int k = 0; k < 3; k++) L[k] /= ln;
+            double ra = 0, rb = 0;
+            for (int k = 0; k < 3; k++) { ra += hA[k] * fabs(dot3(L, A[k])); rb += hB[k] * fabs(dot3(L, B[k])); }
+            double sep = fabs(dot3(L, d)) - ra - rb;
+            if (sep > best + 0.05 * fabs(best) + 1e-12) { best = sep; code = 6 + 3 * i + j; memcpy(bestL, L, 24); }
+        }
+    if (!(best < margin)) return 0;
+    /* L points from box 0 to box 1; the contact normal from box 1 to box 0 */
+    double sgn = dot3(bestL, d) < 0 ? -1.0 : 1.0, L[3];
+    for (int k = 0; k < 3; k++) { L[k] = sgn * bestL[k]; n[k] = -L[k]; }
+    if (code >= 6) {
+        int i = (code - 6) / 3, j = (code - 6) % 3;
+        double pa[3], pb[3];
+        for (int k = 0; k < 3; k++) { pa[k] = c0[k]; pb[k] = c1[k]; }
+        for (int a = 0; a < 3; a++) {
+            if (a != i) { double sg = dot3(L, A[a]) > 0 ? 1.0 : -1.0; for (int k = 0; k < 3; k++) pa[k] += sg * hA[a] * A[a][k]; }
+            if (a != j) { double sg = dot3(L, B[a]) > 0 ? -1.0 : 1.0; for (int k = 0; k < 3; k++) pb[k] += sg * hB[a] * B[a][k]; }
+        }
+        /* the two edges as segments: start at the edge centre minus the half length */
+        double sa[3], da[3], sb[3], db[3], ta, tb;
+        for (int k = 0; k < 3; k++) {
+            sa[k] = pa[k] - hA[i] * A[i][k]; da[k] = 2 * hA[i] * A[i][k];
+            sb[k] = pb[k] - hB[j] * B[j][k]; db[k] = 2 * hB[j] * B[j][k];
+        }
+        seg_seg(sa, da, sb, db, &ta, &tb);
+        double qa[3], qb[3];
+        for (int k = 0; k < 3; k++) { qa[k] = sa[k] + ta * da[k]; qb[k] = sb[k] + tb * db[k]; }
+        double dd = 0;
+        for (int k = 0; k < 3; k++) dd += (qb[k] - qa[k]) * L[k];
+        dist[0] = dd;
+        for (int k = 0; k < 3; k++) pos[0][k] = 0.5 * (qa[k] + qb[k]);
+        return dd < margin ? 1 : 0;
+    }
+    /* ---- face contact: the reference box owns the axis */
+    int ref1 = code >= 3, fi = code % 3;
+    const double (*RA)[3] = ref1 ? B : A;       /* reference box axes / incident box axes */
+    const double (*IA)[3] = ref1 ? A : B;
+    const double *hr = ref1 ? hB : hA, *hi = ref1 ? hA : hB, *cr = ref1 ? c1 : c0, *ci = ref1 ? c0 : c1;
+    double nr[3];                               /* outward normal of the reference face: towards the incident box */
+    for (int k = 0; k < 3; k++) nr[k] = ref1 ? -L[k] : L[k];
+    /* incident face: the incident box's face whose outward normal is most opposed to nr */
+    int ii = 0;
+    double most = -1;
+    for (int a = 0; a < 3; a++) { double c = fabs(dot3(nr, IA[a])); if (c > most) { most = c; ii = a; } }
+    double si = dot3(nr, IA[ii]) > 0 ? -1.0 : 1.0;
+    int i1 = (ii + 1) % 3, i2 = (ii + 2) % 3;
+    double poly[16][3], tmp[16][3];
+    int np_ = 4;
+    for (int c = 0; c < 4; c++) {
+        double s1 = (c == 0 || c == 3) ? 1.0 : -1.0, s2 = c < 2 ? 1.0 : -1.0;
+        for (int k = 0; k < 3; k++) poly[c][k] = ci[k] + si * hi[ii] * IA[ii][k] + s1 * hi[i1] * IA[i1][k] + s2 * hi[i2] * IA[i2][k];
+    }
+    int r1 = (fi + 1) % 3, r2 = (fi + 2) % 3;
+    for (int side = 0; side < 4 && np_ > 0; side++) {
+        /* side plane: u . (p - cr) <= hu */
+        const double *u = RA[side < 2 ? r1 : r2];
+        double sg = (side & 1) ? -1.0 : 1.0, hu = hr[side < 2 ? r1 : r2];
+        int nt = 0;
+        for (int c = 0; c < np_; c++) {
+            const double *P = poly[c], *Q = poly[(c + 1) % np_];
+            double dp = 0, dq = 0;
+            for (int k = 0; k < 3; k++) { dp += sg * u[k] * (P[k] - cr[k]); dq += sg * u[k] * (Q[k] - cr[k]); }
+            dp -= hu; dq -= hu;
+            if (dp <= 0) { memcpy(tmp[nt++], P, 24); }
+            if ((dp < 0 && dq > 0) || (dp > 0 && dq < 0)) {
+                double t = dp / (dp - dq);
+                for (int k = 0; k < 3; k++) tmp[nt][k] = P[k] + t * (Q[k] - P[k]);
+                nt++;
+            }
+        }
+        np_ = nt;
+        memcpy(poly, tmp, sizeof(double) * 3 * nt);
+    }
+    /* the clipped corners within the margin of the reference face */
+    double keep[16][3], kd[16];
+    int nk = 0;
+    for (int c = 0; c < np_; c++) {
+        double dd = -hr[fi];
+        for (int k = 0; k < 3; k++) dd += nr[k] * (poly[c][k] - cr[k]);
+        if (dd < margin) { memcpy(keep[nk], poly[c], 24); kd[nk++] = dd; }
+    }
+    int nout = nk < 4 ? nk : 4;
+    for (int c = 0; c < nout; c++) {
+        int src = nk <= 4 ? c : (c * nk) / 4;
+        dist[c] = kd[src];
+        for (int k = 0; k < 3; k++) pos[c][k] = keep[src][k] - 0.5 * kd[src] * nr[k];
+    }
+    return nout;
+}
+
+/* (test hook) box_box on flat arrays: R row-major; returns the count, n[3], pos[4][3], dist[4] */
+int or_box_box(const double *c0, const double *R0, const double *h0, const double *c1, const double *R1, const double *h1, double margin,
+               double *n, double *pos, double *dist) {
+    double P[4][3];
+    int k = box_box(c0, R0, h0, c1, R1, h1, margin, n, P, dist);
+    memcpy(pos, P, sizeof(P));
+    return k;
 }
 
 double or_seg_box_param(const double *h, const double *a, const double *b) { return seg_box_param(h, a, b); }      /* (test hook) */
@@ -1613,6 +1759,16 @@ static int step_impl(OrModel *m, double *q, double *v, const double *ctrl, doubl
             matvec3(k.xmat[b], m->pair_d[p][e], d[e]);
         }
         double c1[3], c2[3], diff[3], len;
+        if (m->pair_box[p] == 2) {
+            double Rw0[9], Rw1[9], n[3], P4[4][3], d4[4];
+            matmul3(k.xmat[m->pair_body[p][0]], m->pair_R[p], Rw0);
+            matmul3(k.xmat[m->pair_body[p][1]], m->pair_R2[p], Rw1);
+            int nct = box_box(o[0], Rw0, m->pair_half[p], o[1], Rw1, m->pair_half2[p], m->pair_margin[p], n, P4, d4);
+            for (int c = 0; c < nct; c++)
+                contact_rows(m, &k, v, n, P4[c], m->pair_body[p][0], m->pair_body[p][1], d4[c], m->pair_margin[p], m->pair_mu[p], m->pair_solref[p],
+                             m->pair_solimp[p], ZERO3, J, aref, D, &nc);
+            continue;
+        }
         if (m->pair_box[p] >= 0) {
             /* a sphere or a capsule against a box.  Sphere (mjc_SphereBox): the box's surface point nearest to the centre.
              * Capsule (mjc_CapsuleBox [EXT]; restated as a scheme of its own, not MuJoCo's routine): up to three contacts - where

@@ -384,12 +384,12 @@ def test_loader_refuses_what_is_not_modelled(tmp_path):
     ]:
         with pytest.raises(ValueError, match=msg):
             _model(tmp_path, body, extra=extra, name="bad.xml")
-    # box against box, a cylinder against anything but the plane: derived from the masks -> refused with advice; a box against
-    # the plane, spheres and (round 5) capsules is fine
+    # a cylinder against anything but the plane: derived from the masks -> refused with advice; a box against the plane,
+    # spheres and (round 5) capsules and boxes is fine
     body = """<body name="a"><freejoint/><geom name="x" type="box" size="0.1 0.1 0.1" contype="1" conaffinity="1"/><site name="finger"/></body>
     <body name="b" pos="1 0 0"><freejoint/><geom name="y" type="%s" size="0.1 0.1 0.1" contype="1" conaffinity="1"/></body>"""
-    with pytest.raises(ValueError, match="box only collides"):
-        _model(tmp_path, body % "box", name="bb.xml")
+    rawbb, _ = _model(tmp_path, body % "box", name="bb.xml")            # (box-box: four contact records, round 5)
+    assert rawbb.pairs == [("y", "x")]
     with pytest.raises(ValueError, match="cylinder only collides"):
         _model(tmp_path, (body % "cylinder").replace('size="0.1 0.1 0.1" contype="1" conaffinity="1"/></body>', 'size="0.1 0.1" contype="1" conaffinity="1"/></body>'), name="bc.xml")
     raw, _ = _model(tmp_path, (body % "capsule").replace('size="0.1 0.1 0.1" contype="1" conaffinity="1"/></body>', 'size="0.1 0.1" contype="1" conaffinity="1"/></body>'), name="bk.xml")
@@ -835,3 +835,87 @@ def test_segment_box_closest_parameter_against_brute_force():
         f = (np.maximum(np.abs(pts) - h[None], 0.0) ** 2).sum(1)
         ft = (np.maximum(np.abs(a + t * b) - h, 0.0) ** 2).sum()
         assert 0.0 <= t <= 1.0 and ft <= f.min() + 1e-12, (k, t, ft, f.min())
+
+
+def test_a_box_rests_on_a_static_box_and_slides_off_a_tilted_one(tmp_path):
+    """Two boxes (round 5: separating axes, then the incident face clipped against the reference face - up to four contacts - or
+    the closest points of an edge pair): a box dropped on a static slab comes to rest on it, level, at its half height above
+    the slab's top; rotated about the vertical (an octagonal overlap) it still rests on four contacts; on a slab tilted beyond
+    the friction angle it slides."""
+    slab = '<geom name="slab" type="box" pos="0 0 0.1" size="0.3 0.3 0.1" contype="1" conaffinity="1" friction="0.6 0.005 0.0001"%s/>'
+    box = """<body name="b" pos="0 0 0.255" euler="0 0 %g"><freejoint/><geom name="cube" type="box" size="0.05 0.04 0.05" density="600" contype="1" conaffinity="1"
+      margin="0.002" friction="0.6 0.005 0.0001"/><site name="finger"/></body>"""
+    for yaw in (0.0, 0.6):
+        raw, ref = _model(tmp_path, slab % "" + box % yaw, name="bb%d.xml" % int(10 * yaw))
+        q, v = raw.qpos0.copy(), np.zeros(6)
+        for k in range(1500):
+            q, v, _, d = ref.step(q, v, [])
+        assert abs(q[2] - 0.25) < 2e-3 and np.abs(v).max() < 1e-3 and d[0] == 16, (yaw, q, d[0])
+        assert abs(1 - 2 * (q[4] ** 2 + q[5] ** 2) - 1) < 1e-5      # level
+    raw, ref = _model(tmp_path, slab % ' euler="0.8 0 0"' + box % 0.0, name="bbt.xml")       # 0.8 rad > atan(0.6)
+    q, v = raw.qpos0.copy(), np.zeros(6)
+    q[1], q[2] = -0.1, 0.33
+    q[3:7] = [np.cos(0.4), np.sin(0.4), 0, 0]
+    y0 = q[1]
+    for k in range(600):
+        q, v, _, d = ref.step(q, v, [])
+    assert q[1] < y0 - 0.1 and ref.newton_stats()["fails"] == 0       # it slid down the slope
+
+
+def test_box_box_contacts_lie_between_the_boxes():
+    """Random pairs of boxes: no contact when a separating axis leaves more than the margin; otherwise every contact point lies
+    within its own distance (+ margin) of BOTH boxes, the normal is a unit vector from box 1 towards box 0, and pushing box 0
+    along it increases every contact's distance."""
+    import ctypes
+    from oracle.physics_ref import _lib, _p, _c
+    L = _lib()
+    dp = ctypes.POINTER(ctypes.c_double)
+    L.or_box_box.restype = ctypes.c_int
+    L.or_box_box.argtypes = [dp] * 6 + [ctypes.c_double] + [dp] * 3
+
+    def quat2mat(q):
+        w, x, y, z = q / np.linalg.norm(q)
+        return np.array([[1 - 2 * (y * y + z * z), 2 * (x * y - w * z), 2 * (x * z + w * y)], [2 * (x * y + w * z), 1 - 2 * (x * x + z * z), 2 * (y * z - w * x)],
+                         [2 * (x * z - w * y), 2 * (y * z + w * x), 1 - 2 * (x * x + y * y)]])
+
+    def call(c0, R0, h0, c1, R1, h1, margin):
+        n, pos, d = np.zeros(3), np.zeros((4, 3)), np.zeros(4)
+        k = L.or_box_box(_p(_c(c0)), _p(_c(R0)), _p(_c(h0)), _p(_c(c1)), _p(_c(R1)), _p(_c(h1)), margin, _p(n), _p(pos), _p(d))
+        return k, n, pos[:k], d[:k]
+
+    def outside(p, c, R, h):            # distance of a point from a solid box (0 inside)
+        loc = R.T @ (p - c)
+        return np.linalg.norm(np.maximum(np.abs(loc) - h, 0.0))
+
+    rs = np.random.RandomState(1)
+    hit = edge = 0
+    for trial in range(400):
+        h0, h1 = rs.uniform(0.03, 0.2, 3), rs.uniform(0.03, 0.2, 3)
+        R0, R1 = quat2mat(rs.standard_normal(4)), quat2mat(rs.standard_normal(4))
+        if trial % 4 == 0:
+            R1 = R0 @ quat2mat(np.r_[np.cos(0.3), 0, 0, np.sin(0.3)])       # a shared axis: face contacts with edge-parallel cases
+        c0, c1 = np.zeros(3), rs.standard_normal(3) * 0.18
+        margin = 0.004
+        k, n, pos, d = call(c0, R0, h0, c1, R1, h1, margin)
+        # brute-force separation over the 15 axes
+        axes = [R0[:, i] for i in range(3)] + [R1[:, i] for i in range(3)] + [np.cross(R0[:, i], R1[:, j]) for i in range(3) for j in range(3)]
+        sep = -np.inf
+        for a in axes:
+            if np.linalg.norm(a) < 1e-9:
+                continue
+            a = a / np.linalg.norm(a)
+            sep = max(sep, abs(a @ (c1 - c0)) - sum(h0[i] * abs(a @ R0[:, i]) for i in range(3)) - sum(h1[i] * abs(a @ R1[:, i]) for i in range(3)))
+        if sep >= margin:
+            assert k == 0
+            continue
+        if k == 0:
+            continue                    # (an edge pair whose closest points are further apart than the axis' separation says)
+        hit += 1
+        assert abs(np.linalg.norm(n) - 1) < 1e-12 and n @ (c0 - c1) > 0
+        for p, dd in zip(pos, d):
+            assert dd < margin and dd >= sep - 0.06 * abs(sep) - 1e-9      # (an edge axis wins only by 5 %)
+            assert outside(p, c0, R0, h0) <= abs(dd) / 2 + margin + 1e-9 and outside(p, c1, R1, h1) <= abs(dd) / 2 + margin + 1e-9
+        k2, n2, pos2, d2 = call(c0 + 1e-4 * n, R0, h0, c1, R1, h1, margin + 1e-3)
+        if k2 == k and np.allclose(n2, n):
+            assert np.all(d2 > d - 1e-9)
+    assert hit > 80

@@ -249,7 +249,7 @@ def test_pen_hand_dmd_closed_loop_4096x64(pen):
     c.mean_action = np.tile(u0, (H, 1))
     mean, cov, gseq = np.tile(u0, (H, 1)), cov0 * np.eye(A), cr.gamma_seq(1.0, H)
     f0, worst_a, worst_m, diverged = eng.solver_failures(), 0.0, 0.0, 0
-    nf0 = ref.newton_stats()["fails"]
+    nf0, r0 = ref.newton_stats()["fails"], ref.resets()
     for step in range(6):
         action, _ = c.optimize(dict(qp=q, qv=v, target_pos=tgt))
         noise = c.dev.sample_noise(P, cov, [0.25, 0.8, 0.0], 123, step, filtered=True).cpu().numpy()
@@ -272,7 +272,9 @@ def test_pen_hand_dmd_closed_loop_4096x64(pen):
           "(oracle %d), rollouts that diverged in the oracle %d of %d"
           % (worst_a, worst_m, eng.solver_failures() - f0, ref.newton_stats()["fails"] - nf0, diverged, 6 * P))
     assert diverged <= 12                   # (a handful; a model problem, not a solver one)
-    if diverged == 0:
+    # (since round 5 a rollout that goes numerically unstable is RESET as MuJoCo resets it - mj_checkAcc - in the kernel and the
+    # oracle alike, tests/test_reset_gpu.py: its costs stay finite; on the way there the solver may give up on either side)
+    if diverged == 0 and ref.resets() == r0:
         assert eng.solver_failures() == f0 and ref.newton_stats()["fails"] == nf0
 
 

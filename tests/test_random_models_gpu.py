@@ -144,6 +144,18 @@ def random_model(seed):
         k = int(rs.randint(len(bodies)))
         bodies[k].geoms.append(RawGeom(GEOM_BOX, 0.0, (0.0, 0.0, 0.0), (0.04, 0.03, 0.02), density=700.0, margin=0.002, name="box%d" % k,
                                        friction=0.5, condim=3, collide=True, quat=tuple(_quat(rs, 0.5))))
+        if world_geoms and records + 4 <= 16 and rs5.rand() < 0.7:      # round 5: ... and against the static slab (box-box: four records)
+            pairs.append(("box%d" % k, "slab"))
+            records += 4
+    elif general and records + 4 <= 14 and (seed % 5 == 2 or (world_geoms and rs5.rand() < 0.4)):
+        if not world_geoms:
+            world_geoms.append(RawGeom(GEOM_BOX, 0.0, (0.3, 0.0, 0.1), (0.3, 0.3, 0.1), name="slab", friction=0.6, condim=3, margin=0.002,
+                                       quat=tuple(_quat(rs5, 0.2))))
+        k = int(rs5.randint(len(bodies)))
+        bodies[k].geoms.append(RawGeom(GEOM_BOX, 0.0, (0.0, 0.0, 0.0), (0.05, 0.03, 0.04), density=700.0, margin=0.002, name="bx%d" % k,
+                                       friction=0.5, condim=3, collide=False, quat=tuple(_quat(rs5, 0.5))))
+        pairs.append(("bx%d" % k, "slab"))
+        records += 4
     if pairs and rs.rand() < 0.4:
         pair_params[tuple(pairs[0])] = dict(condim=int(rs.choice([1, 3])), friction=float(rs.uniform(0.2, 1.2)), margin=0.003,
                                             solref=(float(rs.uniform(0.008, 0.03)), 1.0))
