@@ -32,6 +32,7 @@ PER_SOURCE_FLAGS = {"tree_rollout_dense.hip": [["-mllvm", "-amdgpu-sched-strateg
                     # 65 536 x 64 (52.7 -> 51.9 ms, 31.8 -> 31.0 ms from tools/tree_time.py's start state; two A/B pairs);
                     # max-ilp is 1-6 % slower everywhere, iterative-ilp has crashed the compiler on this source
                     "tree_rollout.hip": [["-mllvm", "-amdgpu-sched-strategy=iterative-maxocc"]],
+                    "tree_rollout_cone.hip": [["-mllvm", "-amdgpu-sched-strategy=iterative-maxocc"]],
                     # the arm kernel: 1 % (f64 control step 0.2000 -> 0.1980 ms, three A/B pairs on one box; f32 2 %) with
                     # iterative-maxocc; iterative-ilp another 1 % on the fused iteration's kernel and 3 % in f32 (two A/B
                     # pairs: f64 control step 0.1957 -> 0.1935 ms, pipelined 0.1910 -> 0.1883; the plain two-wave launch
@@ -51,7 +52,7 @@ def sources():
 
 def _headers():
     return (glob.glob(os.path.join(CSRC, "*.h")) + [os.path.join(HERE, "..", "include", "mjmpc_amd.h")]
-            + [os.path.join(CSRC, "tree_rollout.hip")])        # (tree_rollout_dense.hip includes it)
+            + [os.path.join(CSRC, "tree_rollout.hip")])        # (tree_rollout_dense.hip and tree_rollout_cone.hip include it)
 
 
 def _obj(src):

@@ -126,6 +126,11 @@ constexpr int CS_BASE = 15; // per contact point: sphere centre (lean instantiat
 // general instantiation: five more scalars per record - [15:18] the three rows' D of a connect equality (their reference
 // accelerations in [5:8]; the two anchors in [0:3] and [11:14]), [18:20] spare
 constexpr int CS_GEN = 20;
+// elliptic friction cones (GEN = 3, round 5): once the rows are built, a contact record's [11:20] hold the cone's quadratic
+// model at the solver's base point - [14:20] the symmetric 3 x 3 weight W over (normal, tangent 1, tangent 2) as 00 01 02 11
+// 12 22, [11:14] the vector b of  H = M + sum J' W J,  rhs = tau + sum J' b  (see cone_model; the tangent in [11:14] has
+// served by then, the geometry stage writes it afresh every substep)
+constexpr int CS_W = 14, CS_B = 11;
 constexpr int a_cs(int DP, int NS, int NJ, int PL) { return a_jc(DP, PL) + NS * NJ * DP; }
 constexpr int a_misc(int DP, int NS, int NJ, int PL, int CSZ = CS_BASE) { return a_cs(DP, NS, NJ, PL) + NS * CSZ; }   // site[3]
 constexpr int a_row2(int DP, int NS, int NJ, int PL, int CSZ = CS_BASE) { return a_misc(DP, NS, NJ, PL, CSZ) + 8; }     // the Euler matrix's factor
@@ -1426,6 +1431,85 @@ __device__ __noinline__ T exact_line_search(T g0, T dg, T Dl, T rl, T drl, T Dc,
     return den > T(0) ? lo - flo * (hi - lo) * rcp_(den) : lo;
 }
 
+// The same root with ELLIPTIC cones among the particle's records (GEN = 3): phi' is increasing and continuous but no longer
+// piecewise linear - the lane that owns an elliptic record (ell) adds grad s(r + al dr) . dr of the cone's cost s (zones and
+// formulas: MuJoCo PrimalUpdateConstraint [EXT]; DESIGN 2 derives them).  Newton's iteration on phi' with
+// phi'' alongside, kept inside the bracket (a bisection step when it leaves it); on a piecewise linear phi' it lands on the
+// root once it is on the root's piece.  D0 = the normal row's D, ir = impratio (tangent rows: D0 ir), fr the friction
+// coefficient, mu = fr / sqrt(ir).
+template <int PL, int NR, typename T>
+__device__ __noinline__ T cone_line_search(T g0, T dg, T Dl, T rl, T drl, T Dc, const T* rb, const T* drb, const T* Dk, bool bil,
+                                           T Df, T ff, T rf, T drf, bool ell, T fr, T ir, T mu, bool& at_floor) {
+    // (no lane-dependent branch in here: the lane sums below are DPP exchanges, every lane of the particle must arrive at
+    // them together - the cone's and the plain rows' parts are both computed and one selected)
+    auto phi = [&](T al, T& curv) -> T {
+        const T r = rl + al * drl;
+        T tsum = Dl * (r < T(0) ? r : T(0)) * drl, csum = r < T(0) ? Dl * drl * drl : T(0);
+        T te, ce;
+        {
+            const T r0 = rb[0] + al * drb[0], r1 = rb[1] + al * drb[1], r2 = rb[2] + al * drb[2];
+            const T N = mu * r0, U1 = fr * r1, U2 = fr * r2, Tt = sqrt_(U1 * U1 + U2 * U2);
+            const T Dt = Dc * ir;
+            const bool top = N >= mu * Tt || (Tt <= T(0) && N >= T(0));
+            const bool bottom = !top && (mu * N + Tt <= T(0) || (Tt <= T(0) && N < T(0)));
+            const T tb = Dc * r0 * drb[0] + Dt * (r1 * drb[1] + r2 * drb[2]);
+            const T cb = Dc * drb[0] * drb[0] + Dt * (drb[1] * drb[1] + drb[2] * drb[2]);
+            const T iT = rcp_(Tt > T(0) ? Tt : T(1)), u1 = U1 * iT, u2 = U2 * iT;
+            const T Dm = Dc * rcp_(mu * mu * (T(1) + mu * mu)), NmT = N - mu * Tt;
+            // d/dal of (N - mu T): mu dr0 - mu fr (u . dr_t);  d2/dal2 of T: fr^2 (|dr_t|^2 - (u . dr_t)^2) / T
+            const T ud = u1 * drb[1] + u2 * drb[2];
+            const T dNmT = mu * drb[0] - mu * fr * ud;
+            const T tm = Dm * NmT * dNmT;
+            const T cm = Dm * dNmT * dNmT - Dm * NmT * mu * fr * fr * (drb[1] * drb[1] + drb[2] * drb[2] - ud * ud) * iT;
+            te = top ? T(0) : (bottom ? tb : tm);
+            ce = top ? T(0) : (bottom ? cb : cm);
+        }
+        T tr = T(0), cr = T(0);
+#pragma unroll
+        for (int k = 0; k < NR; ++k) {
+            const T rr = rb[k] + al * drb[k];
+            const T Dr = Dk ? Dk[k] : Dc;
+            const bool on = bil || rr < T(0);
+            tr += Dr * (on ? rr : T(0)) * drb[k];
+            cr += on ? Dr * drb[k] * drb[k] : T(0);
+        }
+        tsum += ell ? te : tr;
+        csum += ell ? ce : cr;
+        const T sl = Df * (rf + al * drf);
+        tsum += fmin(fmax(sl, -ff), ff) * drf;
+        csum += (sl > -ff && sl < ff) ? Df * drf * drf : T(0);
+        // (the root finder's decisions must be the same in every lane of the particle: each lane evaluates its rows at ITS
+        // alpha, and the sums mix them.  Lane sums were seen to differ between lanes here - two groups of lanes settling on
+        // two different "roots" - so the first lane's values are the particle's)
+        curv = __shfl(dg + sum_lanes<PL>(csum), 0, PL);
+        return __shfl(g0 + al * dg + sum_lanes<PL>(tsum), 0, PL);
+    };
+    T c1, c0;
+    T fhi = phi(T(1), c1);
+    const T flo = phi(T(0), c0);
+    // (full step: phi'(1) <= 0 - or phi'(0) >= 0: in exact arithmetic a Newton direction descends, phi'(0) = -p'Hp; M a - tau
+    // at the base point is known through the solves' own equation, i.e. to eps |H| |a|, and once the gradient along p is
+    // below that the sign of phi'(0) is noise: the iteration is at the floor of its arithmetic, where the Newton step itself
+    // is the best correction there is - staying would stop a few digits short of it)
+    bool done = !(fhi > T(0)) || !(flo < T(0));
+    at_floor = !(flo < T(0));       // (... and the particle has converged: the caller stops iterating on it)
+    T al = T(1);
+    T lo = T(0), hi = T(1), f = fhi, fp = c1;
+    const T tol = T(sizeof(T) == 4 ? 1e-6 : 1e-14) * (fabs(flo) + fabs(fhi));
+    for (int k = 0; k < 40 && __any(!done); ++k) {
+        T an = al - f * rcp_(fp);
+        if (!(fp > T(0)) || !(an > lo) || !(an < hi)) an = T(0.5) * (lo + hi);
+        T fn, cn;
+        fn = phi(an, cn);
+        if (!done) {
+            al = an; f = fn; fp = cn;
+            if (fn > T(0)) hi = an; else lo = an;
+            done = fabs(fn) <= tol || !(hi - lo > T(sizeof(T) == 4 ? 1e-7 : 1e-16));
+        }
+    }
+    return al;
+}
+
 // waves per SIMD the register allocation aims at: the lean kernels for short paths fit three (f32) / two (f64)
 // workgroups' LDS on a CU
 constexpr int min_waves(int scalar_bytes, int DP, bool fric, int gen = 0) {
@@ -1543,6 +1627,22 @@ __global__ __launch_bounds__(64 * wg_waves(DP, FRIC, sizeof(T), PL), min_waves(s
             const T* sp = M + T_SPH + l * TREE_SPH_STRIDE;
             const int link = (int)sp[0], dsl = (int)sp[11];
             for (int c = 0; c < DP; ++c) pt_path |= (unsigned long long)(AT[(c <= dsl ? c : 0) * PL + link] & 31) << (5 * c);
+        }
+    }
+    // (GEN = 3) the records that are contacts under an ELLIPTIC cone (PEXT[21] = impratio > 0): bit s, and bit 4 s + 1 of the
+    // row mask - an elliptic record's nibble there is its ZONE (0 top: no force, 1 bottom: three quadratic rows, 2 middle: on
+    // the cone), not four row bits
+    unsigned ell16 = 0;
+    unsigned long long ell_mid = 0;
+    if constexpr (GEN >= 3) {
+        const int ns_ = min((int)M[T_N_SPHERE], NS);
+        for (int s = 0; s < ns_; ++s) {
+            const int kind = (int)M[T_SPH + s * TREE_SPH_STRIDE + 12];
+            if (kind != PT_CONNECT && kind != PT_WELD && kind != PT_DOFROW && M[T_SPH + s * TREE_SPH_STRIDE + 7] > T(0) &&
+                PEXT[s * TREE_PEXT_STRIDE + 21] > T(0)) {
+                ell16 |= 1u << s;
+                ell_mid |= 2ull << (4 * s);
+            }
         }
     }
     Topo tp;
@@ -2451,11 +2551,21 @@ __global__ __launch_bounds__(64 * wg_waves(DP, FRIC, sizeof(T), PL), min_waves(s
                         cs[7] = T(0);
                     } else {
                     const T* csol = M + T_SOLTAB + 7 * (int)sp[21];         // the contact's own solver set
+                    if (GEN >= 3 && ((ell16 >> l) & 1u)) {
+                        // elliptic cone (mj_instantiateContact / mj_makeImpedance): the normal row's diagApprox is tran itself,
+                        // the tangent rows are pure damping - reference accelerations -B Jt.v (their R = R_normal / impratio)
+                        tree_row_params(csol, cs[3] - sp[5], sp[6], jv, Dc, arc);
+                        cs[4] = Dc;
+                        cs[5] = arc;
+                        cs[6] = -csol[1] * j1v;
+                        cs[7] = -csol[1] * j2v;
+                    } else {
                     tree_row_params(csol, cs[3] - sp[5], sp[6] * (T(1) + mu * mu), jv, Dc, arc);
                     if (mu > T(0)) Dc *= T(0.5) * rcp_(mu * mu);
                     cs[4] = Dc;
                     cs[5] = arc;
                     if (FRIC) { cs[6] = mu * csol[1] * j1v; cs[7] = mu * csol[1] * j2v; }
+                    }
                     }
                 }
             }
@@ -2477,11 +2587,68 @@ __global__ __launch_bounds__(64 * wg_waves(DP, FRIC, sizeof(T), PL), min_waves(s
                 // rows of contact point s with friction mu (uniform per particle): all NR, else one
                 auto rows_of = [&](int s) -> unsigned {
                     if (GEN && ((int)M[T_SPH + s * TREE_SPH_STRIDE + 12] == PT_CONNECT || (int)M[T_SPH + s * TREE_SPH_STRIDE + 12] == PT_WELD)) return 7u;
+                    if (GEN >= 3 && ((ell16 >> s) & 1u)) return 7u;         // (three residuals: normal, two tangents)
                     return (FRIC && M[T_SPH + s * TREE_SPH_STRIDE + 7] > T(0)) ? 15u : 1u;
                 };
                 // (GEN) my record's kind; bilateral records (equalities) keep all their rows active on both sides
                 const int my_kind = (GEN && l < NS) ? (int)M[T_SPH + l * TREE_SPH_STRIDE + 12] : 0;
                 const bool my_bil = GEN && l < NS && PEXT[(l < NS ? l : 0) * TREE_PEXT_STRIDE + 19] != T(0);
+                const bool my_ell = GEN >= 3 && l < NS && ((ell16 >> l) & 1u);
+                // my elliptic record: friction coefficient, impratio = D_tangent / D_normal, regularised friction mu = fr / sqrt(impratio)
+                const T ell_fr = my_ell ? M[T_SPH + l * TREE_SPH_STRIDE + 7] : T(1);
+                const T ell_ir = my_ell ? PEXT[l * TREE_PEXT_STRIDE + 21] : T(1);
+                const T ell_mu = ell_fr * rcp_(sqrt_(ell_ir));
+                // zone of the cone at residuals r (MuJoCo PrimalUpdateConstraint): U = (mu r0, fr r1, fr r2), N = U0, T = |(U1, U2)|
+                auto cone_zone = [&](const T* r) -> unsigned {
+                    const T N = ell_mu * r[0], Tt = ell_fr * sqrt_(r[1] * r[1] + r[2] * r[2]);
+                    if (N >= ell_mu * Tt || (Tt <= T(0) && N >= T(0))) return 0u;
+                    if (ell_mu * N + Tt <= T(0) || (Tt <= T(0) && N < T(0))) return 1u;
+                    return 2u;
+                };
+                // gradient of the cone's cost at r (its zone given), and - H != nullptr - the Hessian as 00 01 02 11 12 22
+                auto cone_grad = [&](unsigned zone, const T* r, T D0, T* g, T* H) {
+                    const T Dt = D0 * ell_ir;
+                    if (zone == 1u) {
+                        g[0] = D0 * r[0]; g[1] = Dt * r[1]; g[2] = Dt * r[2];
+                        if (H) { H[0] = D0; H[1] = T(0); H[2] = T(0); H[3] = Dt; H[4] = T(0); H[5] = Dt; }
+                        return;
+                    }
+                    if (zone == 0u) {
+                        g[0] = g[1] = g[2] = T(0);
+                        if (H) { H[0] = H[1] = H[2] = H[3] = H[4] = H[5] = T(0); }
+                        return;
+                    }
+                    const T mu = ell_mu, fr = ell_fr;
+                    const T N = mu * r[0], U1 = fr * r[1], U2 = fr * r[2], Tt = sqrt_(U1 * U1 + U2 * U2), iT = rcp_(Tt);
+                    const T Dm = D0 * rcp_(mu * mu * (T(1) + mu * mu)), NmT = N - mu * Tt;
+                    const T u1 = U1 * iT, u2 = U2 * iT;
+                    g[0] = Dm * NmT * mu;
+                    g[1] = -Dm * NmT * mu * fr * u1;
+                    g[2] = -Dm * NmT * mu * fr * u2;
+                    if (H) {
+                        const T a = Dm * mu * mu, bq = -Dm * NmT * mu * fr * fr * iT;
+                        H[0] = a;
+                        H[1] = -a * fr * u1;
+                        H[2] = -a * fr * u2;
+                        H[3] = a * fr * fr * u1 * u1 + bq * (T(1) - u1 * u1);
+                        H[4] = a * fr * fr * u1 * u2 - bq * u1 * u2;
+                        H[5] = a * fr * fr * u2 * u2 + bq * (T(1) - u2 * u2);
+                    }
+                };
+                // the quadratic model of my elliptic record at the base point's residuals r (zone z): H += J' W J, rhs += J' b with
+                // b = W (r + aref) - grad, so that the solve's equation reads M xa - tau = -J' (grad + W (r(xa) - r))
+                auto cone_model = [&](unsigned zone, const T* r) {
+                    if (!my_ell || !((cinst >> l) & 1u)) return;
+                    T* cs = X + A_CS + l * CS;
+                    T g[3], W[6];
+                    cone_grad(zone, r, cs[4], g, W);
+                    const T x0 = r[0] + cs[5], x1 = r[1] + cs[6], x2 = r[2] + cs[7];
+#pragma unroll
+                    for (int k = 0; k < 6; ++k) cs[CS_W + k] = W[k];
+                    cs[CS_B] = W[0] * x0 + W[1] * x1 + W[2] * x2 - g[0];
+                    cs[CS_B + 1] = W[1] * x0 + W[3] * x1 + W[4] * x2 - g[1];
+                    cs[CS_B + 2] = W[2] * x0 + W[4] * x1 + W[5] * x2 - g[2];
+                };
                 // (GEN) my dof's friction-loss row: J = e_l, pos = 0 -> D from the impedance at 0, aref = -B v
                 T Df = T(0), areff = T(0);
                 int fstate = 0;                     // -1: r <= -R f (force +f), 0: quadratic zone, +1: r >= R f (force -f)
@@ -2541,7 +2708,7 @@ __global__ __launch_bounds__(64 * wg_waves(DP, FRIC, sizeof(T), PL), min_waves(s
                         res[2 % NR] = an + a2 - (cs[5] - cs[7]);
                         res[3 % NR] = an - a2 - (cs[5] + cs[7]);
                         if (!(mu > T(0))) res[0] = an - cs[5];
-                        if (GEN && (my_kind == PT_CONNECT || my_kind == PT_WELD)) {         // three independent rows, one per Jacobian
+                        if (GEN && (my_kind == PT_CONNECT || my_kind == PT_WELD || my_ell)) {         // three independent rows, one per Jacobian
                             res[0] = an - cs[5];
                             res[1 % NR] = c1 - cs[6];
                             res[2 % NR] = c2 - cs[7];
@@ -2554,7 +2721,9 @@ __global__ __launch_bounds__(64 * wg_waves(DP, FRIC, sizeof(T), PL), min_waves(s
                 // owners' nibbles): a row stays / becomes active while its residual is negative
                 auto rows_from_res = [&](const T* res, mask_t cur) -> mask_t {
                     unsigned nb = 0;
-                    if (my_pt) {
+                    if (GEN >= 3 && my_pt && my_ell) {
+                        nb = cone_zone(res);            // (an elliptic record's nibble: its zone)
+                    } else if (my_pt) {
                         const unsigned rows = rows_of(l);
                         const T ar5 = X[A_CS + l * CS + 5];
 #pragma unroll
@@ -2576,7 +2745,9 @@ __global__ __launch_bounds__(64 * wg_waves(DP, FRIC, sizeof(T), PL), min_waves(s
                 };
                 // J' f of the rows of the set (act_, cact_) at the acceleration whose owner residuals are res (friction
                 // instantiation): the owners sum their rows' forces per Jacobian into cs[8:11], every dof collects its entries
-                auto force_of = [&](T xa_, const T* res, bool act_, mask_t cact_, int fst_) -> T {
+                // (elliptic records, GEN = 3: `lin` - the force of the record's quadratic model, b - W (r + aref), which is what the
+                // solve's equation holds at its Newton point; else the cone's own force -grad at r)
+                auto force_of = [&](T xa_, const T* res, bool act_, mask_t cact_, int fst_, bool lin = false) -> T {
                     T qf = act_ ? -D * (sig * xa_ - aref) * sig : T(0);
                     if constexpr (GEN) qf += fl_force(xa_, fst_);
                     if (ucinst != 0) {
@@ -2602,6 +2773,22 @@ __global__ __launch_bounds__(64 * wg_waves(DP, FRIC, sizeof(T), PL), min_waves(s
                                 cs[8] = -cs[15] * res[0];
                                 cs[9] = -cs[16] * res[1 % NR];
                                 cs[10] = -cs[17] * res[2 % NR];
+                            }
+                            if (GEN >= 3 && my_ell) {
+                                if (lin) {
+                                    const T x0 = res[0] + cs[5], x1 = res[1 % NR] + cs[6], x2 = res[2 % NR] + cs[7];
+                                    const bool on = bits != 0u;
+                                    const T* W = cs + CS_W;
+                                    cs[8] = on ? cs[CS_B] - (W[0] * x0 + W[1] * x1 + W[2] * x2) : T(0);
+                                    cs[9] = on ? cs[CS_B + 1] - (W[1] * x0 + W[3] * x1 + W[4] * x2) : T(0);
+                                    cs[10] = on ? cs[CS_B + 2] - (W[2] * x0 + W[4] * x1 + W[5] * x2) : T(0);
+                                } else {
+                                    T g[3];
+                                    cone_grad(cone_zone(res), res, Dc, g, (T*)nullptr);
+                                    cs[8] = -g[0];
+                                    cs[9] = -g[1];
+                                    cs[10] = -g[2];
+                                }
                             }
                         }
                         TSYNC();
@@ -2648,13 +2835,26 @@ __global__ __launch_bounds__(64 * wg_waves(DP, FRIC, sizeof(T), PL), min_waves(s
                     const int s = __builtin_ctz(um);
                     if ((cinst >> s) & 1u) {
                         const mask_t rows = rows_of(s);
+                        if (GEN >= 3 && ((ell16 >> s) & 1u)) {
+                            // an elliptic record starts in the bottom zone (three quadratic rows: no base point needed) unless
+                            // it was in the top zone (no force) a substep ago
+                            const bool was_top = ((cinst_mem >> s) & 1u) && ((cact_mem >> (s * NR)) & mask_t(15)) == 0;
+                            cact |= was_top ? mask_t(0) : (mask_t(1) << (s * NR));
+                        } else
                         cact |= ((cinst_mem >> s) & 1u) ? (cact_mem & (rows << (s * NR))) : (rows << (s * NR));
                     }
+                }
+                if constexpr (GEN >= 3) {
+                    if (my_ell && my_pt) {
+                        const T r0[3] = {T(0), T(0), T(0)};
+                        cone_model(1u, r0);         // (bottom zone: W = diag(D), b = W aref - whatever the point)
+                    }
+                    TSYNC();
                 }
                 bool changed = true, act_pp = false;
                 mask_t cact_pp = 0;
                 int fst_pp = 0;
-                constexpr int LS_START = 5;         // iterations before the safeguard takes over (friction instantiation)
+                constexpr int LS_START = GEN >= 3 ? 0 : 5;      // iterations before the safeguard takes over (friction instantiation; elliptic cones: MuJoCo's Newton method from the start)
                 bool ls_on = false;
                 T a_b = T(0), g_b = T(0), rb[NR];
 #pragma unroll
@@ -2689,10 +2889,21 @@ __global__ __launch_bounds__(64 * wg_waves(DP, FRIC, sizeof(T), PL), min_waves(s
                         T wn = Dc * na * jl, w1 = T(0), w2 = T(0);
                         T rsum = na * cs[5];
                         T t1l = T(0), t2l = T(0);           // my entries of the two tangent Jacobians
+                        const bool ells = GEN >= 3 && ((ell16 >> s) & 1u);
                         if (FRIC) {
-                            const T mu = M[T_SPH + s * TREE_SPH_STRIDE + 7];
                             t1l = oi >= 0 ? jrow[DP + oi] : T(0);
                             t2l = oi >= 0 ? jrow[2 * DP + oi] : T(0);
+                        }
+                        if (ells) {
+                            // the cone's quadratic model at the base point (cone_model): H += J' W J, rhs += J' b
+                            const T on = bits ? T(1) : T(0);
+                            const T* W = cs + CS_W;
+                            wn = on * (W[0] * jl + W[1] * t1l + W[2] * t2l);
+                            w1 = on * (W[1] * jl + W[3] * t1l + W[4] * t2l);
+                            w2 = on * (W[2] * jl + W[4] * t1l + W[5] * t2l);
+                            rhs += on * (jl * cs[CS_B] + t1l * cs[CS_B + 1] + t2l * cs[CS_B + 2]);
+                        } else if (FRIC) {
+                            const T mu = M[T_SPH + s * TREE_SPH_STRIDE + 7];
                             const T j1 = mu * t1l, j2 = mu * t2l;
                             const T n1 = T(__popc(bits & 3u)), s1 = T((int)(bits & 1u) - (int)((bits >> 1) & 1u));
                             const T n2 = T(__popc(bits & 12u)), s2 = T((int)((bits >> 2) & 1u) - (int)((bits >> 3) & 1u));
@@ -2702,7 +2913,8 @@ __global__ __launch_bounds__(64 * wg_waves(DP, FRIC, sizeof(T), PL), min_waves(s
                             rsum -= s1 * cs[6] + s2 * cs[7];
                             rhs += Dc * (j1 * (s1 * cs[5] - n1 * cs[6]) + j2 * (s2 * cs[5] - n2 * cs[7]));
                         }
-                        if (GEN && ((int)M[T_SPH + s * TREE_SPH_STRIDE + 12] == PT_CONNECT || (int)M[T_SPH + s * TREE_SPH_STRIDE + 12] == PT_WELD)) {
+                        if (ells) {
+                        } else if (GEN && ((int)M[T_SPH + s * TREE_SPH_STRIDE + 12] == PT_CONNECT || (int)M[T_SPH + s * TREE_SPH_STRIDE + 12] == PT_WELD)) {
                             // three independent bilateral rows: H += sum_k D_k J_k J_k', rhs += sum_k D_k aref_k J_k
                             wn = cs[15] * jl;
                             w1 = cs[16] * t1l;
@@ -2771,6 +2983,9 @@ __global__ __launch_bounds__(64 * wg_waves(DP, FRIC, sizeof(T), PL), min_waves(s
                     int fst2 = 0;
                     if constexpr (GEN) fst2 = fl_state_of(xa, fstate);
                     changed = (act2 != actv) || (cact2 != cact) || (GEN && fst2 != fstate);
+                    // (GEN = 3: an elliptic record of the model's set in its middle zone - the cost is not quadratic there, the
+                    // Newton point of the model is not the minimiser: on, until the line search below stops moving)
+                    if constexpr (GEN >= 3) changed = changed || (cact & (mask_t)ell_mid) != 0;
                     // SAFEGUARD (friction instantiation).  The plain iteration - solve with the set, adopt the set the solution
                     // asks for - has no line search and can cycle when several friction pyramids switch rows together
                     // (periods 3 and 4 seen on the pen-in-hand model; the iterate kept then was arbitrary).  From iteration
@@ -2782,7 +2997,7 @@ __global__ __launch_bounds__(64 * wg_waves(DP, FRIC, sizeof(T), PL), min_waves(s
                     // point inherits it by the same interpolation; the residuals are affine in al.
                     if constexpr (FRIC) {
                         if (it >= LS_START && __any(changed)) {
-                            const T gN = force_of(xa, rN, actv, cact, fstate);      // M xa - tau = J' f of the set's rows (the solve's equation)
+                            const T gN = force_of(xa, rN, actv, cact, fstate, true);      // M xa - tau = J' f of the set's rows (the solve's equation)
                             if (!ls_on) {
                                 a_b = xa;
                                 g_b = gN;
@@ -2802,7 +3017,15 @@ __global__ __launch_bounds__(64 * wg_waves(DP, FRIC, sizeof(T), PL), min_waves(s
 #pragma unroll
                                     for (int r = 0; r < NR; ++r) drb[r] = ((rows >> r) & 1u) ? rN[r] - rb[r] : T(0);
                                     T al;
-                                    if constexpr (GEN) {
+                                    bool at_floor = false;
+                                    if constexpr (GEN >= 3) {
+                                        const T* Dk = (my_pt && (my_kind == PT_CONNECT || my_kind == PT_WELD)) ? X + A_CS + l * CS + 15 : nullptr;
+                                        T Dk3[NR];
+#pragma unroll
+                                        for (int r = 0; r < NR; ++r) Dk3[r] = (Dk && r < 3) ? Dk[r] : Dc;
+                                        al = cone_line_search<PL, NR>(gbp, gNp - gbp, D, rl0, rl1 - rl0, Dc, rb, drb, (const T*)Dk3, my_bil,
+                                                                      Df, floss, a_b - areff, pv, my_ell && my_pt, ell_fr, ell_ir, ell_mu, at_floor);
+                                    } else if constexpr (GEN) {
                                         const T* Dk = (my_pt && (my_kind == PT_CONNECT || my_kind == PT_WELD)) ? X + A_CS + l * CS + 15 : nullptr;
                                         T Dk3[NR];
 #pragma unroll
@@ -2817,7 +3040,12 @@ __global__ __launch_bounds__(64 * wg_waves(DP, FRIC, sizeof(T), PL), min_waves(s
                                     // objective, where a row at zero residual may be counted either way): the safeguarded
                                     // iteration has reached its fixed point - mj_solNewton stops likewise once the
                                     // improvement falls under its tolerance
-                                    const bool moved = fabs(al * pv) > (sizeof(T) == 4 ? T(1e-6) : T(1e-14)) * (fabs(a_b) + T(1));
+                                    // (GEN = 3: against the particle's largest acceleration - with cones in their middle zone the iteration
+                                    // goes on until it stops moving, and a dof that hardly accelerates keeps receiving the
+                                    // rounding of the others' solve: steps of 1e-13 on accelerations of 300 went on to the cap)
+                                    T a_scale = fabs(a_b);
+                                    if constexpr (GEN >= 3) a_scale = sqrt_(sum_lanes<PL>(a_b * a_b));
+                                    const bool moved = !at_floor && fabs(al * pv) > (sizeof(T) == 4 ? T(1e-6) : (GEN >= 3 ? T(1e-13) : T(1e-14))) * (a_scale + T(1));
                                     const bool pmoved = ((unsigned)(__ballot(moved) >> (PL * half)) & (PL == 32 ? ~0u : 0xFFFFu)) != 0u;
                                     a_b += al * pv;
                                     g_b += al * (gN - g_b);
@@ -2845,6 +3073,11 @@ __global__ __launch_bounds__(64 * wg_waves(DP, FRIC, sizeof(T), PL), min_waves(s
 #pragma unroll
                                     for (int r = 0; r < NR; ++r) rb[r] = rN[r];
                                 }
+                            }
+                            if constexpr (GEN >= 3) {
+                                // the next model of my elliptic record: its zone and quadratic expansion at the base point
+                                if (my_ell && my_pt) cone_model((unsigned)(cact2 >> (l * NR)) & 15u, rb);
+                                TSYNC();
                             }
                         }
                     }
@@ -3173,6 +3406,10 @@ struct TreeLaunchArgs {
 template <typename T>
 hipError_t launch_tree_rollout_dense(int max_path, int nv, int gen, const T* model, const T* noise, T* cost, T* act, T* obs, T* nobs,
                                      const TreeLaunchArgs& a);
+// ... and so do the instantiations for models with ELLIPTIC friction cones (GEN = 3; tree_rollout_cone.hip, TREE_CONE_TU)
+template <typename T>
+hipError_t launch_tree_rollout_cone(int max_path, int nv, const T* model, const T* noise, T* cost, T* act, T* obs, T* nobs,
+                                    const TreeLaunchArgs& a);
 
 #define MJMPC_TREE_LAUNCH(DP_, NS_, FR_, PL_) MJMPC_TREE_LAUNCH_D(DP_, NS_, FR_, PL_, 0, 0)
 #define MJMPC_TREE_LAUNCH_G(DP_, NS_, FR_, PL_, G_) MJMPC_TREE_LAUNCH_D(DP_, NS_, FR_, PL_, 0, G_)
@@ -3219,6 +3456,23 @@ template hipError_t launch_tree_rollout_dense<float>(int, int, int, const float*
                                                      const TreeLaunchArgs&);
 template hipError_t launch_tree_rollout_dense<double>(int, int, int, const double*, const double*, double*, double*, double*, double*,
                                                       const TreeLaunchArgs&);
+#elif defined(TREE_CONE_TU)
+template <typename T>
+hipError_t launch_tree_rollout_cone(int max_path, int nv, const T* model, const T* noise, T* cost, T* act, T* obs, T* nobs,
+                                    const TreeLaunchArgs& a) {
+    if (nv > 16) {
+        if (max_path <= 16) MJMPC_TREE_LAUNCH_D(16, 16, true, 32, 32, 3)       // dense over the particle's 32 lanes
+        else MJMPC_TREE_LAUNCH_G(32, 16, true, 32, 3)                          // tree-sparse (elimination paths beyond 16 links)
+    }
+    else if (max_path <= 8 && nv <= 8) MJMPC_TREE_LAUNCH_D(8, 16, true, 16, 8, 3)
+    else if (max_path <= 8 && nv <= 12) MJMPC_TREE_LAUNCH_D(8, 16, true, 16, 12, 3)
+    else if (max_path <= 8) MJMPC_TREE_LAUNCH_D(8, 16, true, 16, 16, 3)
+    else MJMPC_TREE_LAUNCH_D(16, 16, true, 16, 16, 3)
+    return hipGetLastError();
+}
+template hipError_t launch_tree_rollout_cone<float>(int, int, const float*, const float*, float*, float*, float*, float*, const TreeLaunchArgs&);
+template hipError_t launch_tree_rollout_cone<double>(int, int, const double*, const double*, double*, double*, double*, double*,
+                                                     const TreeLaunchArgs&);
 #else
 template <typename T>
 hipError_t launch_tree_rollout(const T* model, int n_model_shards, int max_path, bool full, int nv, const double* state, long P, int H,
@@ -3250,6 +3504,7 @@ hipError_t launch_tree_rollout(const T* model, int n_model_shards, int max_path,
     // hinge trees in air with up to 8 frictionless contact points keep the lean instantiation; slide joints, springs,
     // friction cones, more points or a medium take the full one (three Jacobians per point, 16 points, fluid forces),
     // which also comes with 16 lanes per particle for models of up to 16 dofs (the reference's swimmer and cheetah)
+    if (gen >= 3) return launch_tree_rollout_cone<T>(max_path, nv, model, noise, cost, act, obs, nobs, a);
     if (!full) {
         if (max_path <= 8) MJMPC_TREE_LAUNCH(8, 8, false, 32)
         else if (max_path <= 16) MJMPC_TREE_LAUNCH(16, 8, false, 32)

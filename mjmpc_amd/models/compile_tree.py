@@ -894,7 +894,15 @@ def compile_tree(raw: RawModel, overrides=None, base: "TreeModel" = None) -> Tre
     gen = gen or bool(np.any(f["frictionloss"] > 0))
     kinds_used = f["spheres"].reshape(TREE_MAX_SPHERES, SPH_STRIDE)[:nsp]
     gen2 = bool(np.any(kinds_used[:, 12] >= PT_PLANE_CYL) or np.any(kinds_used[:, 23] == 8.0))
-    f["gen"][0] = 2.0 if gen2 else (1.0 if gen else 0.0)
+    # elliptic friction cones (round 5, MJCF <option cone="elliptic" impratio>): the contact records with friction carry
+    # impratio in their extension [21] and the model takes the GEN = 3 instantiations
+    gen3 = False
+    if getattr(raw, "cone", "pyramidal") == "elliptic":
+        for k in range(nsp):
+            if int(kinds_used[k, 12]) not in (PT_CONNECT, PT_DOFROW, PT_WELD) and kinds_used[k, 7] > 0:
+                f["pext"][k * PEXT_STRIDE + 21] = max(float(raw.impratio), 1e-15)
+                gen3 = True
+    f["gen"][0] = 3.0 if gen3 else (2.0 if gen2 else (1.0 if gen else 0.0))
     f["nq"][0] = nq
     f["has_ball"][0] = 1.0 if any(k == LINK_BALL_X for k in link_kind) else 0.0
     f["any_friction"][0] = 1.0 if (any(f["spheres"][k * SPH_STRIDE + 7] > 0 for k in range(nsp)) or pair_geoms

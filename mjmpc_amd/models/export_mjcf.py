@@ -75,8 +75,8 @@ def _joint_xml(j):
 def to_mjcf(raw: RawModel, hand_site="finger", target_site="target") -> str:
     lines = ['<mujoco model="mjmpc_amd_export">',
              '  <compiler angle="radian" coordinate="local" inertiafromgeom="auto"/>',
-             '  <option timestep="%s" gravity="%s" density="%s" viscosity="%s" integrator="Euler"/>'
-             % (_f(raw.timestep), _v(raw.gravity), _f(raw.density), _f(raw.viscosity)),
+             '  <option timestep="%s" gravity="%s" density="%s" viscosity="%s" integrator="Euler" cone="%s" impratio="%s"/>'
+             % (_f(raw.timestep), _v(raw.gravity), _f(raw.density), _f(raw.viscosity), raw.cone, _f(raw.impratio)),
              # the model's own sets as the defaults every element without its own falls back to
              '  <default><geom solref="%s" solimp="%s"/><joint solreflimit="%s" solimplimit="%s" solreffriction="%s" solimpfriction="%s"/></default>'
              % (_v(raw.solref), _v(raw.solimp), _v(raw.solref if raw.solref_limit is None else raw.solref_limit),

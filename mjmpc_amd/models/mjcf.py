@@ -212,8 +212,9 @@ def load_mjcf(path, hand_site="finger", target_site="target", frame_skip=2, task
     gravity = _floats(oget("gravity", None), 3, [0.0, 0.0, -9.81])
     if oget("integrator", "Euler") != "Euler":
         raise ValueError("only the Euler integrator is supported")
-    if oget("cone", "pyramidal") != "pyramidal" or float(oget("impratio", "1")) != 1.0:
-        raise ValueError("only pyramidal friction cones with impratio 1 are supported")
+    cone, impratio = oget("cone", "pyramidal"), float(oget("impratio", "1"))
+    if cone not in ("pyramidal", "elliptic"):
+        raise ValueError("cone must be pyramidal or elliptic")
     if _floats(oget("wind", None), 3, [0.0, 0.0, 0.0]) != [0.0, 0.0, 0.0]:
         raise ValueError("wind is not supported")
     if oget("solver", "Newton") != "Newton" or int(oget("noslip_iterations", "0")) != 0:
@@ -618,6 +619,6 @@ def load_mjcf(path, hand_site="finger", target_site="target", frame_skip=2, task
     target = sites.get(target_site, (-1, [0.0, 0.0, 0.0]))[1]
     return RawModel(bodies=bodies, actuators=acts, site_body=site_body, site_pos=site_pos, target_pos=target, plane=plane,
                     timestep=timestep, frame_skip=frame_skip, gravity=gravity, solref=solref, solimp=full_solimp(solimp),
-                    solref_limit=lsolref, solimp_limit=full_solimp(lsolimp), density=density, viscosity=viscosity,
+                    solref_limit=lsolref, solimp_limit=full_solimp(lsolimp), density=density, viscosity=viscosity, cone=cone, impratio=impratio,
                     task=task, ctrl_cost=ctrl_cost, obs_skip=obs_skip, pairs=pairs, pair_params=pair_params, world_geoms=world_geoms,
                     equalities=equalities, tendons=tendons, solref_friction=fsolref, solimp_friction=full_solimp(fsolimp))

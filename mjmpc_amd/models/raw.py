@@ -242,6 +242,11 @@ class RawModel:
     ctrl_cost: float = 0.0                          # TASK_FORWARD: weight of |a|^2
     obs_skip: int = 0                               # TASK_FORWARD: leading qpos entries left out of the observation
     capsule_cap_factor: float = MJ20_CAPSULE_CAP    # capsule volume = pi r^2 h + factor * pi r^3 (see MJ20_CAPSULE_CAP)
+    # friction cones of condim-3 contacts (MJCF <option cone impratio>): "pyramidal" - MuJoCo's default, four rows
+    # Jn +- mu Jt per contact - or "elliptic" - three rows (normal, two tangents) under the cone's own cost, the friction
+    # rows' regulariser R = R_normal / impratio (round 5; impratio has no effect on pyramidal cones)
+    cone: str = "pyramidal"
+    impratio: float = 1.0
     # geom-geom collision candidates, as names (geom on the manipulator, geom on the object): sphere / capsule pairs, one
     # contact point each (closest points of the two segments); friction / condim / margin = the larger of the two geoms'
     pairs: List[Sequence[str]] = field(default_factory=list)
@@ -355,6 +360,9 @@ class RawModel:
         h[30], h[31] = self.density, self.viscosity
         h[32], h[33], h[34] = self.task, self.ctrl_cost, self.obs_skip
         h[37] = self.capsule_cap_factor
+        if self.cone not in ("pyramidal", "elliptic"):
+            raise ValueError("cone must be pyramidal or elliptic")
+        h[73], h[74] = (1.0 if self.cone == "elliptic" else 0.0), float(self.impratio)
         h[38] = len(self.pairs)
         h[47:50] = self.site_axis
         h[50:53] = self.target_dir

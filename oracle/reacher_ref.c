@@ -64,12 +64,16 @@
 #define ROW_UNI 0          /* limits, contacts: cost 1/2 D min(0, r)^2 */
 #define ROW_EQ 1           /* equality: 1/2 D r^2 */
 #define ROW_FRIC 2         /* friction loss f: Huber - 1/2 D r^2 inside |r| < R f, linear f |r| - 1/2 R f^2 outside */
+#define ROW_ELL 3          /* the normal row of an ELLIPTIC-cone contact (round 5); the two rows behind it are its tangents: */
+#define ROW_ELLT 4         /* ... which the normal row's entry handles (cone_eval) */
 
 typedef struct {
     int nbody, nv, nq, nu;
     double timestep, gravity[3];
     int frame_skip;
     double solref[2], solimp[5];
+    int cone;                                /* 0: pyramidal friction cones (MuJoCo's default), 1: elliptic (MJCF option cone) */
+    double impratio;                         /* elliptic cones: R of the friction rows = R of the normal row / impratio */
     /* tree */
     int parent[MAXB];
     double bpos[MAXB][3], bR0[MAXB][9], bquat0[MAXB][4];      /* fixed offset / rotation in the parent frame */
@@ -563,6 +567,8 @@ OrModel *or_model_compile(const double *f, int n) {
     memcpy(m->plane_n, f + 26, 24);
     m->plane_margin = f[29];
     m->plane_gap = f[72];
+    m->cone = (int)f[73];
+    m->impratio = f[74] > 0 ? f[74] : 1.0;
     m->density = f[30];
     m->viscosity = f[31];
     m->task = (int)f[32];
@@ -999,6 +1005,69 @@ static double row_slope(int kind, double D, double fl, double r, double *curv) {
     *curv = 0;
     return 0;
 }
+/* One ELLIPTIC-cone contact of condim 3 (MuJoCo mj_constraintUpdate / PrimalUpdateConstraint, mjCNSTR_CONTACT_ELLIPTIC
+ * [EXT]): residuals r = (normal, tangent 1, tangent 2), D0 = 1 / R of the normal row, Dt of the friction rows, friction
+ * coefficient fr.  With mu = fr sqrt(D0 / Dt) (MuJoCo's contact.mu, the regularised friction) and U = (mu r0, fr r1, fr r2),
+ * N = U0, T = |(U1, U2)|, the weighted norm D0 r0^2 + Dt (r1^2 + r2^2) = D0 / mu^2 (N^2 + T^2) is isotropic in U and the
+ * cost is D0 / (2 mu^2) times the squared distance of U from the cone N >= mu T:
+ *   top zone     N >= mu T                 0                                   (the dual cone: no force)
+ *   bottom zone  mu N + T <= 0             1/2 (D0 r0^2 + Dt (r1^2 + r2^2))    (the polar cone: all three rows quadratic)
+ *   middle zone  else                      1/2 Dm (N - mu T)^2,  Dm = D0 / (mu^2 (1 + mu^2))
+ * Returns the zone (0 / 1 / 2), the gradient in grad[3] and - when H is given - the Hessian in H[9] (both w.r.t. r). */
+static int cone_eval(double D0, double Dt, double fr, const double *r, double *grad, double *H, double *cost) {
+    double mu = fr * sqrt(D0 / Dt);
+    double N = mu * r[0], U1 = fr * r[1], U2 = fr * r[2], T = sqrt(U1 * U1 + U2 * U2);
+    if (H) memset(H, 0, 72);
+    if (N >= mu * T || (T <= 0 && N >= 0)) {
+        grad[0] = grad[1] = grad[2] = 0;
+        if (cost) *cost = 0;
+        return 0;
+    }
+    if (mu * N + T <= 0 || (T <= 0 && N < 0)) {
+        grad[0] = D0 * r[0]; grad[1] = Dt * r[1]; grad[2] = Dt * r[2];
+        if (H) { H[0] = D0; H[4] = Dt; H[8] = Dt; }
+        if (cost) *cost = 0.5 * (D0 * r[0] * r[0] + Dt * (r[1] * r[1] + r[2] * r[2]));
+        return 1;
+    }
+    double Dm = D0 / (mu * mu * (1 + mu * mu)), NmT = N - mu * T;
+    double u[2] = {U1 / T, U2 / T};
+    grad[0] = Dm * NmT * mu;
+    grad[1] = -Dm * NmT * mu * fr * u[0];
+    grad[2] = -Dm * NmT * mu * fr * u[1];
+    if (cost) *cost = 0.5 * Dm * NmT * NmT;
+    if (H) {
+        H[0] = Dm * mu * mu;
+        for (int k = 0; k < 2; k++) {
+            H[1 + k] = H[3 * (1 + k)] = -Dm * mu * mu * fr * u[k];
+            for (int l = 0; l < 2; l++)
+                H[3 * (1 + k) + 1 + l] = Dm * mu * mu * fr * fr * u[k] * u[l] - Dm * NmT * mu * fr * fr * ((k == l ? 1.0 : 0.0) - u[k] * u[l]) / T;
+        }
+    }
+    return 2;
+}
+/* phi'(alpha) and phi''(alpha) of the rows' cost along jar + alpha jd (all kinds, evaluated directly) */
+static void rows_dphi(int nc, const double *D, const int *kind, const double *floss, const double *jar, const double *jd, double alpha,
+                      double *d1, double *d2) {
+    double s1 = 0, s2 = 0;
+    for (int c = 0; c < nc; c++) {
+        if (kind[c] == ROW_ELLT) continue;
+        if (kind[c] == ROW_ELL) {
+            double r[3], g[3], H[9];
+            for (int k = 0; k < 3; k++) r[k] = jar[c + k] + alpha * jd[c + k];
+            cone_eval(D[c], D[c + 1], floss[c], r, g, H, NULL);
+            for (int k = 0; k < 3; k++) {
+                s1 += g[k] * jd[c + k];
+                for (int l = 0; l < 3; l++) s2 += H[3 * k + l] * jd[c + k] * jd[c + l];
+            }
+            continue;
+        }
+        double curv, sl = row_slope(kind[c], D[c], floss[c], jar[c] + alpha * jd[c], &curv);
+        s1 += sl * jd[c];
+        s2 += curv * jd[c] * jd[c];
+    }
+    *d1 = s1;
+    *d2 = s2;
+}
 static void solve_rows(OrModel *m, int nv, const double *M, const double *fs, int nc,
                        double (*J)[MAXV], const double *aref, const double *D, const int *kind, const double *floss,
                        double *a, double *force) {
@@ -1015,6 +1084,7 @@ static void solve_rows(OrModel *m, int nv, const double *M, const double *fs, in
 #else
     int it, polished = 0;
 #endif
+    int any_cone = 0;
     for (it = 0; it < 100 && nc > 0; it++) {
         double jar[MAXC], g[MAXV], H[MAXV * MAXV], d[MAXV];
         for (int i = 0; i < nv; i++) {
@@ -1027,7 +1097,9 @@ static void solve_rows(OrModel *m, int nv, const double *M, const double *fs, in
             double s = -aref[c];
             for (int j = 0; j < nv; j++) s += J[c][j] * a[j];
             jar[c] = s;
-            if (kind[c] == ROW_UNI) {           /* (the arithmetic of the earlier rounds, kept as it was) */
+            if (kind[c] == ROW_ELL || kind[c] == ROW_ELLT) {
+                any_cone = 1;               /* (handled below, once the three residuals of the contact are known) */
+            } else if (kind[c] == ROW_UNI) {           /* (the arithmetic of the earlier rounds, kept as it was) */
                 if (s < 0) {
                     for (int i = 0; i < nv; i++) {
                         g[i] += D[c] * s * J[c][i];
@@ -1043,6 +1115,20 @@ static void solve_rows(OrModel *m, int nv, const double *M, const double *fs, in
                         for (int j = 0; j < nv; j++) H[i * nv + j] += curv * J[c][i] * J[c][j];
                 }
             }
+        }
+        for (int c0 = 0; c0 < nc && any_cone; c0++) {
+            if (kind[c0] != ROW_ELL) continue;
+            double gr[3], Hc[9];
+            cone_eval(D[c0], D[c0 + 1], floss[c0], jar + c0, gr, Hc, NULL);
+            for (int kk = 0; kk < 3; kk++)
+                for (int i = 0; i < nv; i++) {
+                    if (J[c0 + kk][i] == 0) continue;
+                    g[i] += gr[kk] * J[c0 + kk][i];
+                    for (int ll = 0; ll < 3; ll++) {
+                        if (Hc[3 * kk + ll] == 0) continue;
+                        for (int j = 0; j < nv; j++) H[i * nv + j] += Hc[3 * kk + ll] * J[c0 + kk][i] * J[c0 + ll][j];
+                    }
+                }
         }
         double gn = 0;
         for (int i = 0; i < nv; i++) if (fabs(g[i]) > gn) gn = fabs(g[i]);
@@ -1064,6 +1150,32 @@ static void solve_rows(OrModel *m, int nv, const double *M, const double *fs, in
             for (int j = 0; j < nv; j++) { Md += M[i * nv + j] * d[j]; Ma += M[i * nv + j] * a[j]; }
             p0 += d[i] * Ma;
             p1 += d[i] * Md;
+        }
+        if (any_cone) {
+            /* elliptic cones: phi' is increasing and continuous but not piecewise linear - its root by Newton's iteration
+             * kept inside a bracket (bisection when a step leaves it), to the resolution of the arithmetic */
+            double jd[MAXC], d1, d2;
+            for (int c = 0; c < nc; c++) {
+                double s = 0;
+                for (int j = 0; j < nv; j++) s += J[c][j] * d[j];
+                jd[c] = s;
+            }
+            rows_dphi(nc, D, kind, floss, jar, jd, 0.0, &d1, &d2);
+            double f0 = p0 + d1;
+            if (!(f0 < 0)) break;                   /* (no descent left: at the minimiser to rounding) */
+            double lo = 0, hi = -1, alpha = 1;
+            for (int ls = 0; ls < 60; ls++) {
+                rows_dphi(nc, D, kind, floss, jar, jd, alpha, &d1, &d2);
+                double f = p0 + alpha * p1 + d1, fp = p1 + d2;
+                if (fabs(f) <= 1e-15 * fabs(f0)) break;
+                if (f < 0) lo = alpha; else hi = alpha;
+                double an = alpha - f / fp;
+                if (!(fp > 0) || !(an > lo) || (hi > 0 && !(an < hi))) an = hi > 0 ? 0.5 * (lo + hi) : 2 * alpha;
+                if (hi > 0 && hi - lo <= 1e-16 * hi) break;
+                alpha = an;
+            }
+            for (int i = 0; i < nv; i++) a[i] += alpha * d[i];
+            continue;
         }
         double c0 = p0, c1 = p1;
         for (int c = 0; c < nc; c++) {
@@ -1127,8 +1239,15 @@ static void solve_rows(OrModel *m, int nv, const double *M, const double *fs, in
         double s = -aref[c], curv;
         for (int j = 0; j < nv; j++) s += J[c][j] * a[j];
         if (kind[c] == ROW_UNI) force[c] = s < 0 ? -D[c] * s : 0.0;
+        else if (kind[c] == ROW_ELL || kind[c] == ROW_ELLT) force[c] = s;       /* (the residual for now: see below) */
         else force[c] = -row_slope(kind[c], D[c], floss[c], s, &curv);
     }
+    for (int c = 0; c < nc; c++)
+        if (kind[c] == ROW_ELL) {
+            double r[3] = {force[c], force[c + 1], force[c + 2]}, gr[3];
+            cone_eval(D[c], D[c + 1], floss[c], r, gr, NULL, NULL);
+            for (int k = 0; k < 3; k++) force[c + k] = -gr[k];
+        }
 }
 
 /* test hook (tests/test_general_models_cpu.py): the solver alone, J row-major [nc][nv] */
@@ -1166,7 +1285,7 @@ static void seg_seg(const double *p1, const double *d1, const double *p2, const 
 static void contact_rows(const OrModel *m, const Kin *k, const double *v, const double *n, const double *cp, int bA, int bB,
                          double dist, double margin, double mu, const double *solref, const double *solimp,
                          const double *axis_hint, double (*J)[MAXV], double *aref,
-                         double *D, int *pnc) {
+                         double *D, int *kind, double *floss, int *pnc) {
     int nv = m->nv, nc = *pnc;
     double Jp[3 * MAXV], Jq[3 * MAXV];
     jacobian(m, k, bA, cp, Jp, NULL);
@@ -1182,6 +1301,8 @@ static void contact_rows(const OrModel *m, const Kin *k, const double *v, const 
             jv += J[nc][j] * v[j];
         }
         row_params_set(m, solref, solimp, dist, margin, tran, jv, &D[nc], &aref[nc]);
+        kind[nc] = ROW_UNI;
+        floss[nc] = 0;
         nc++;
     } else {
         double t1[3], t2[3], ax[3] = {axis_hint[0], axis_hint[1], axis_hint[2]};
@@ -1195,6 +1316,33 @@ static void contact_rows(const OrModel *m, const Kin *k, const double *v, const 
         if (nr < MJ_MINVAL) { t1[0] = 1; t1[1] = 0; t1[2] = 0; }
         else for (int i = 0; i < 3; i++) t1[i] /= nr;
         cross3(n, t1, t2);
+        if (m->cone == 1) {
+            /* ELLIPTIC cone, condim 3 (mj_instantiateContact / mj_makeImpedance [EXT]): three rows - the normal, whose
+             * position is the distance, and the two tangents, whose position is 0 - on the Jacobians themselves (friction
+             * does not scale them); diagApprox of the normal row = tran; the friction rows take R = R_normal / impratio
+             * (R_j = R_1 f_0^2 / f_{j-1}^2 further on: one friction coefficient here), their reference acceleration is
+             * pure damping, -B J_t v.  The friction coefficient travels in floss[] of the normal row. */
+            double jvk[3] = {0, 0, 0}, D0, Dk, ak;
+            for (int j = 0; j < nv; j++) {
+                J[nc][j] = n[0] * Jp[j] + n[1] * Jp[nv + j] + n[2] * Jp[2 * nv + j];
+                J[nc + 1][j] = t1[0] * Jp[j] + t1[1] * Jp[nv + j] + t1[2] * Jp[2 * nv + j];
+                J[nc + 2][j] = t2[0] * Jp[j] + t2[1] * Jp[nv + j] + t2[2] * Jp[2 * nv + j];
+                for (int r = 0; r < 3; r++) jvk[r] += J[nc + r][j] * v[j];
+            }
+            row_params_set(m, solref, solimp, dist, margin, tran, jvk[0], &D0, &aref[nc]);
+            D[nc] = D0;
+            kind[nc] = ROW_ELL;
+            floss[nc] = mu;
+            for (int r = 1; r < 3; r++) {
+                row_params_set(m, solref, solimp, 0.0, 0.0, tran, jvk[r], &Dk, &ak);
+                aref[nc + r] = ak;                          /* (r = 0: the spring term vanishes) */
+                D[nc + r] = D0 * (m->impratio > MJ_MINVAL ? m->impratio : MJ_MINVAL);
+                kind[nc + r] = ROW_ELLT;
+                floss[nc + r] = 0;
+            }
+            *pnc = nc + 3;
+            return;
+        }
         double D0, a0;
         row_params_set(m, solref, solimp, dist, margin, tran * (1 + mu * mu), 0.0, &D0, &a0);
         double Rpy = 2 * mu * mu / D0;
@@ -1211,6 +1359,8 @@ static void contact_rows(const OrModel *m, const Kin *k, const double *v, const 
                 row_params_set(m, solref, solimp, dist, margin, tran * (1 + mu * mu), jvr, &Dd, &ar);
                 D[nc] = 1 / Rpy;
                 aref[nc] = ar;
+                kind[nc] = ROW_UNI;
+                floss[nc] = 0;
                 nc++;
             }
         }
@@ -1530,6 +1680,8 @@ static int step_impl(OrModel *m, double *q, double *v, const double *ctrl, doubl
     static const double ZERO3[3] = {0, 0, 0};
     double J[MAXC][MAXV], aref[MAXC], D[MAXC], floss[MAXC], force[MAXC], qacc[MAXV];
     int kind[MAXC];
+    memset(kind, 0, sizeof(kind));          /* (ROW_UNI unless a row says otherwise) */
+    memset(floss, 0, sizeof(floss));
     int nc = 0;
     for (int e = 0; e < m->neq; e++) {
         if (m->eq_type[e] == 1 || m->eq_type[e] == 2) {
@@ -1613,7 +1765,6 @@ static int step_impl(OrModel *m, double *q, double *v, const double *ctrl, doubl
         floss[nc] = m->frictionloss[j];
         nc++;
     }
-    int nc_uni0 = nc;
     /* joint limits: MuJoCo mj_instantiateLimit (dist < margin, the joint's own); hinge and slide joints */
     for (int j = 0; j < nv; j++) {
         if (!m->limited[j] || m->dof_qadr[j] < 0) continue;
@@ -1721,7 +1872,7 @@ static int step_impl(OrModel *m, double *q, double *v, const double *ctrl, doubl
             if (dist < margin) {
                 double cp[3];
                 for (int i = 0; i < 3; i++) cp[i] = pt[i] - n[i] * 0.5 * dist;
-                contact_rows(m, &k, v, m->plane_n, cp, b, 0, dist, margin, m->sph_mu[s], m->sph_solref[s], m->sph_solimp[s], ZERO3, J, aref, D, &nc);
+                contact_rows(m, &k, v, m->plane_n, cp, b, 0, dist, margin, m->sph_mu[s], m->sph_solref[s], m->sph_solimp[s], ZERO3, J, aref, D, kind, floss, &nc);
             }
             continue;
         }
@@ -1742,7 +1893,7 @@ static int step_impl(OrModel *m, double *q, double *v, const double *ctrl, doubl
             double cp[3], ax[3];
             for (int i = 0; i < 3; i++) cp[i] = k.xpos[b][i] + t[i] - m->plane_n[i] * (m->sph_r[s] + 0.5 * dist);
             matvec3(k.xmat[b], m->sph_axis[s], ax);
-            contact_rows(m, &k, v, m->plane_n, cp, b, 0, dist, margin, m->sph_mu[s], m->sph_solref[s], m->sph_solimp[s], ax, J, aref, D, &nc);
+            contact_rows(m, &k, v, m->plane_n, cp, b, 0, dist, margin, m->sph_mu[s], m->sph_solref[s], m->sph_solimp[s], ax, J, aref, D, kind, floss, &nc);
         }
     }
     /* geom-geom contacts (mjc_SphereSphere / SphereCapsule / CapsuleCapsule): the closest points of the two segments,
@@ -1766,7 +1917,7 @@ static int step_impl(OrModel *m, double *q, double *v, const double *ctrl, doubl
             int nct = box_box(o[0], Rw0, m->pair_half[p], o[1], Rw1, m->pair_half2[p], m->pair_margin[p], n, P4, d4);
             for (int c = 0; c < nct; c++)
                 contact_rows(m, &k, v, n, P4[c], m->pair_body[p][0], m->pair_body[p][1], d4[c], m->pair_margin[p], m->pair_mu[p], m->pair_solref[p],
-                             m->pair_solimp[p], ZERO3, J, aref, D, &nc);
+                             m->pair_solimp[p], ZERO3, J, aref, D, kind, floss, &nc);
             continue;
         }
         if (m->pair_box[p] >= 0) {
@@ -1805,7 +1956,7 @@ static int step_impl(OrModel *m, double *q, double *v, const double *ctrl, doubl
                     double cp[3];
                     for (int i = 0; i < 3; i++) cp[i] = c2[i] + diff[i] * (m->pair_r[p][1] + 0.5 * dist);
                     contact_rows(m, &k, v, diff, cp, m->pair_body[p][0], m->pair_body[p][1], dist, m->pair_margin[p], m->pair_mu[p], m->pair_solref[p], m->pair_solimp[p],
-                                 ZERO3, J, aref, D, &nc);
+                                 ZERO3, J, aref, D, kind, floss, &nc);
                 }
             }
             continue;
@@ -1827,10 +1978,9 @@ static int step_impl(OrModel *m, double *q, double *v, const double *ctrl, doubl
                 cp[i] = c2[i] + n[i] * (m->pair_r[p][1] + 0.5 * dist);
             }
             contact_rows(m, &k, v, n, cp, m->pair_body[p][0], m->pair_body[p][1], dist, m->pair_margin[p], m->pair_mu[p], m->pair_solref[p], m->pair_solimp[p],
-                         ZERO3, J, aref, D, &nc);
+                         ZERO3, J, aref, D, kind, floss, &nc);
         }
     }
-    for (int c = nc_uni0; c < nc; c++) { kind[c] = ROW_UNI; floss[c] = 0; }
     solve_rows(m, nv, M, fs, nc, J, aref, D, kind, floss, qacc, force);
     if (check_acc)
         for (int j = 0; j < nv; j++)

@@ -919,3 +919,151 @@ def test_box_box_contacts_lie_between_the_boxes():
         if k2 == k and np.allclose(n2, n):
             assert np.all(d2 > d - 1e-9)
     assert hit > 80
+
+
+# ------------------------------------------------------------------------------------------ elliptic friction cones (round 5)
+def _cone_cost(D0, Dt, fr, r):
+    """The elliptic cone's cost from its definition: D0 / (2 mu^2) times the squared distance of U = (mu r0, fr r1, fr r2)
+    from the cone N >= mu T - the distance computed here by projecting U onto the cone numerically (no zone formulas)."""
+    mu = fr * np.sqrt(D0 / Dt)
+    N, T = mu * r[0], fr * np.hypot(r[1], r[2])
+    # nearest point of the 2-D cone {(n, t): n >= mu t, t >= 0} to (N, T): the point itself, the apex, or the foot on the edge
+    if N >= mu * T:
+        d2 = 0.0
+    else:
+        e = np.array([mu, 1.0]) / np.hypot(mu, 1.0)             # the edge's direction (n = mu t)
+        s = max(0.0, e @ np.array([N, T]))
+        d2 = (N - s * e[0]) ** 2 + (T - s * e[1]) ** 2
+    return 0.5 * D0 / mu ** 2 * d2
+
+
+def test_elliptic_cone_rows_against_an_independent_minimiser(tmp_path):
+    """solve_rows with ELLIPTIC contacts (groups of three rows: kind 3 then 4, 4) beside the other row kinds, random
+    problems: stationarity M a - fs = J' f, forces inside the friction cone |f_t| <= fr f_n, and the cost - computed here
+    from the cone's definition as a distance, not from the oracle's zone formulas - not above scipy's minimiser's."""
+    from scipy.optimize import minimize
+    raw, ref = _model(tmp_path, BLOCK % (0.0, 1.0), extra=ACT)
+    rs = np.random.RandomState(5)
+    zones = set()
+    for trial in range(60):
+        nv, ng, nx = rs.randint(3, 8), rs.randint(1, 4), rs.randint(0, 4)
+        nc = 3 * ng + nx
+        A = rs.standard_normal((nv, nv))
+        M = A @ A.T + nv * np.eye(nv)
+        fs = 8 * rs.standard_normal(nv)
+        J = rs.standard_normal((nc, nv)) * (rs.uniform(size=(nc, nv)) < 0.8)
+        aref, D = 3 * rs.standard_normal(nc), rs.uniform(0.5, 20, nc)
+        kind = np.r_[np.tile([3, 4, 4], ng), rs.randint(0, 3, nx)].astype(int)
+        fl = np.where(kind == 2, rs.uniform(0.1, 3.0, nc), 0.0)
+        for g in range(ng):
+            D[3 * g + 1] = D[3 * g + 2] = D[3 * g] * rs.choice([1.0, 4.0, 0.3])       # impratio
+            fl[3 * g] = rs.uniform(0.2, 1.5)                                          # friction coefficient
+            aref[3 * g] = abs(aref[3 * g]) * rs.choice([1.0, 1.0, -1.0])              # (mostly: pushed into the surface)
+
+        def cost(a):
+            r = J @ a - aref
+            c = 0.5 * a @ M @ a - fs @ a
+            for g in range(ng):
+                c += _cone_cost(D[3 * g], D[3 * g + 1], fl[3 * g], r[3 * g:3 * g + 3])
+            for i in range(3 * ng, nc):
+                if kind[i] == 0:
+                    c += 0.5 * D[i] * min(0.0, r[i]) ** 2
+                elif kind[i] == 1:
+                    c += 0.5 * D[i] * r[i] ** 2
+                else:
+                    Rf = fl[i] / D[i]
+                    c += 0.5 * D[i] * r[i] ** 2 if abs(r[i]) < Rf else fl[i] * abs(r[i]) - 0.5 * Rf * fl[i]
+            return c
+
+        a, f = ref.solve_rows(M, fs, J, aref, D, kind, fl)
+        np.testing.assert_allclose(M @ a - fs, J.T @ f, rtol=0, atol=1e-9)
+        r = J @ a - aref
+        for g in range(ng):
+            fn, ft = f[3 * g], np.hypot(f[3 * g + 1], f[3 * g + 2])
+            assert fn >= -1e-12 and ft <= fl[3 * g] * fn + 1e-9
+            zones.add(0 if fn == 0 else (2 if ft > fl[3 * g] * fn - 1e-9 else 1))
+            # the force is the cost's negative gradient (central differences of the cost defined by distance)
+            for k in range(3):
+                e = np.zeros(3); e[k] = 1e-6
+                rr = r[3 * g:3 * g + 3]
+                num = (_cone_cost(D[3 * g], D[3 * g + 1], fl[3 * g], rr + e) - _cone_cost(D[3 * g], D[3 * g + 1], fl[3 * g], rr - e)) / 2e-6
+                assert abs(num + f[3 * g + k]) < 1e-5 * (1 + abs(num))
+        best = minimize(cost, a + 0.01 * rs.standard_normal(nv), method="BFGS", options=dict(gtol=1e-9)).x
+        assert cost(a) <= cost(best) + 1e-9
+        np.testing.assert_allclose(a, best, rtol=0, atol=5e-5)
+    assert zones == {0, 1, 2}                   # no force, sticking (inside the cone) and sliding (on the cone) all occurred
+    assert ref.newton_stats()["fails"] == 0
+
+
+ELL_SPHERE = """<geom name="floor" type="plane" pos="0 0 0" size="5 5 0.1" contype="1" conaffinity="1" friction="%g 0.005 0.0001" condim="3"/>
+    <body name="ball" pos="0 0 0.0999"><freejoint/>
+      <geom name="b" type="sphere" size="0.1" density="800" contype="1" conaffinity="1" friction="%g 0.005 0.0001" condim="3"/>
+      <site name="finger"/></body>"""
+
+
+def _opt_model(tmp_path, body, option, name="m.xml", **kw):
+    xml = HEAD + '<option timestep="0.002" integrator="Euler" %s/>' % option + \
+        '<default><geom contype="0" conaffinity="0"/></default><worldbody><site name="target" pos="0 0 0"/>' + \
+        textwrap.dedent(body) + "</worldbody></mujoco>"
+    (tmp_path / name).write_text(xml)
+    raw = load_mjcf(str(tmp_path / name), task=TASK_REACH, **kw)
+    return raw, RefArm(raw.to_flat())
+
+
+def test_elliptic_cone_friction_is_isotropic_and_bounded_by_mu(tmp_path):
+    """A sphere thrown into sliding on the plane (it skips: a sliding contact under MuJoCo's cone cost pushes out, and the
+    contact exists only while the sphere touches) loses speed at mu g on average - under an ELLIPTIC cone the same along an
+    axis of the contact frame and across it (three rows per contact), under the pyramidal one 1 / sqrt(2) of it across
+    (four rows: |f_1| + |f_2| <= mu f_n)."""
+    mu = 0.4
+
+    def deceleration(cone, name, rows):
+        raw, ref = _opt_model(tmp_path, ELL_SPHERE % (mu, mu), 'cone="%s"' % cone, name=name)
+        assert raw.cone == cone
+        out = []
+        for d in (np.array([1.0, 0.0]), np.array([1.0, 1.0]) / np.sqrt(2)):
+            q, v = ref.qpos0.copy(), np.zeros(6)
+            for _ in range(300):
+                q, v, _, diag = ref.step(q, v, np.zeros(0))
+            assert diag[0] == rows
+            v[:2] = 4.0 * d                                     # (sliding turns into rolling after 2 v / (7 mu g) = 0.29 s)
+            for _ in range(100):
+                q, v, _, _ = ref.step(q, v, np.zeros(0))
+            out.append((4.0 - v[:2] @ d) / (100 * 0.002))
+        return out
+
+    axis, diagonal = deceleration("elliptic", "e.xml", 3)       # normal + two tangents
+    assert abs(axis - diagonal) < 1e-9 * axis                   # isotropic
+    assert 0.85 * mu * 9.81 < axis < 1.02 * mu * 9.81, axis     # (in the air part of the time)
+    axis, diagonal = deceleration("pyramidal", "p.xml", 4)
+    assert 0.85 * mu * 9.81 < axis < 1.02 * mu * 9.81 and abs(diagonal / axis - np.sqrt(0.5)) < 0.06, (axis, diagonal)
+
+
+def test_elliptic_cone_box_sticks_below_the_friction_angle_and_impratio_hardens_it(tmp_path):
+    """A box on the plane with gravity tilted by an angle: below atan(mu) it creeps at the soft friction rows' rate -
+    which impratio 10 divides by about ten - and above it slides at g (sin - mu cos)."""
+    mu = 0.5
+    body = """<geom name="floor" type="plane" pos="0 0 0" size="5 5 0.1" contype="1" conaffinity="1" friction="%g 0.005 0.0001" condim="3"/>
+    <body name="box" pos="0 0 0.0499"><freejoint/>
+      <geom name="b" type="box" size="0.1 0.08 0.05" density="800" contype="1" conaffinity="1" friction="%g 0.005 0.0001" condim="3"/>
+      <site name="finger"/></body>""" % (mu, mu)
+
+    def slide(angle, option, name):
+        g = 9.81 * np.array([np.sin(angle), 0.0, -np.cos(angle)])
+        raw, ref = _opt_model(tmp_path, body, 'gravity="%.17g %.17g %.17g" %s' % (g[0], g[1], g[2], option), name=name)
+        q, v = ref.qpos0.copy(), np.zeros(6)
+        vs = []
+        for _ in range(400):
+            q, v, _, diag = ref.step(q, v, np.zeros(0))
+            vs.append(v[0])
+        return np.array(vs), diag
+
+    lo, diag = slide(np.arctan(mu) * 0.8, 'cone="elliptic"', "a.xml")
+    assert diag[0] == 12                                        # 4 corners x 3 rows
+    assert 0 < lo[-1] < 0.02 and abs(lo[-1] - lo[-50]) < 1e-5   # creeping at a constant, small rate
+    lo10, _ = slide(np.arctan(mu) * 0.8, 'cone="elliptic" impratio="10"', "b.xml")
+    assert 0 < lo10[-1] < 0.2 * lo[-1]
+    ang = np.arctan(mu) * 1.3
+    hi, _ = slide(ang, 'cone="elliptic"', "c.xml")
+    acc = (hi[-1] - hi[-101]) / (100 * 0.002)
+    assert abs(acc - 9.81 * (np.sin(ang) - mu * np.cos(ang))) < 0.03 * 9.81 * np.sin(ang), acc
