@@ -459,7 +459,7 @@ def main():
         launch()
     e1.record()
     torch.cuda.synchronize()
-    kern_ms = e0.elapsed_time(e1) / n_t
+    kern_final_ms = e0.elapsed_time(e1) / n_t
     both_ms = None
     if mono:            # ... and rollout + finish launch together (update, action, shift; no env step)
         launch(0)
@@ -469,6 +469,31 @@ def main():
         e1.record()
         torch.cuda.synchronize()
         both_ms = e0.elapsed_time(e1) / n_t
+
+    # ... and over the states the timed loop VISITED: the same closed loop once more from the reset (it is deterministic), the
+    # entry point launched and timed from up to 25 of the timed steps' states - `kernel_ms` is their mean, what the roofline
+    # figures below are quoted on; the end state's figure above stays beside it (a contact-rich end state costs more than
+    # the loop's average step: with it alone a line could show a kernel slower than the step that contains it)
+    ctrl.reset()
+    w["reset"]()
+    for _ in range(args.warmup):
+        control_step()
+    n_v = 4 if w["kernel"] == "arm_rollout_kernel" else 2
+    stride = max(1, args.steps // 25)
+    pairs = []
+    for k in range(args.steps):
+        if k % stride == 0:
+            torch.cuda.synchronize()
+            launch()
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record()
+            for _ in range(n_v):
+                launch()
+            b.record()
+            pairs.append((a, b))
+        control_step()
+    sync()
+    kern_ms = float(np.mean([a.elapsed_time(b) / n_v for a, b in pairs]))
 
     # N > 1, weak scaling (the default the driver runs): the SAME invocation also answers the other reading of the metric
     # ("4096 particles x H=32 reported at 1, 2, 4 and 8": the reference's num_particles is a total,
@@ -567,8 +592,11 @@ def main():
                      "alg_bytes_per_launch": b_alg * P_loc * H,
                      "kernel": "%s<%s>" % (w["kernel"], "double" if args.dtype == "f64" else "float"),
                      "kernel_ms": kern_ms,
-                     "kernel_ms_how": "HIP events around %d back-to-back launches of the iteration's entry point on the run's own buffers, "
-                                      "FROM THE STATE THE RUN ENDED IN (a contact-rich final state can cost more than the loop's average step)" % n_t,
+                     "kernel_ms_how": "mean over %d states the timed loop visited (the closed loop run once more from the reset): HIP events "
+                                      "around %d back-to-back launches of the iteration's entry point on the run's own buffers from each" % (len(pairs), n_v),
+                     "kernel_ms_final_state": kern_final_ms,
+                     "kernel_ms_final_state_how": "%d back-to-back launches from the state the run ended in (a contact-rich end state can "
+                                                  "cost more than the loop's average step)" % n_t,
                      "kernel_entry": ("mjmpc_arm_mppi_step, launch 1 of 2 (sampling + rollout + cost-to-go + per-workgroup softmax records); "
                                       "with launch 2 (arm_mppi_finish_kernel: update + action + shift, here without its env step): "
                                       "%.4f ms" % both_ms

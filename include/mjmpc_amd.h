@@ -61,6 +61,10 @@ int mjmpc_device_count(void);
  * compares the captured control iteration with a capture of its own launch tape before it trusts the tape; no reference
  * counterpart). */
 int mjmpc_graph_kernel_nodes(void* hip_graph, int64_t* n_out);
+/* n_out[0] = an order-independent hash over the graph's kernel nodes of (function, grid, block, dynamic LDS), n_out[1] =
+ * the same over all nodes' types: the second half of that check - the tape must launch the same kernels in the same shapes,
+ * not merely as many (argument values cannot be read back from a kernel node; they are the recorded ones). */
+int mjmpc_graph_signature(void* hip_graph, uint64_t* n_out);
 
 /* ---- arm engine: replaces the SubprocVecEnv worker pool for reacher_7dof-v0 ------------------
  * reference: mjmpc/envs/vec_env/subproc_vec_env.py:91-111 (worker start-up),

@@ -97,6 +97,7 @@ SIGNATURES = {
     "mjmpc_sample_noise_mt19937_jump": (_int, [_int, _vp, _i64, _dbl, ctypes.c_uint64, _vp, _vp, _vp, _i64, _i64, _int,
                                                  _i64, _vp, _vp, _vp]),
     "mjmpc_graph_kernel_nodes": (_int, [_vp, ctypes.POINTER(ctypes.c_int64)]),
+    "mjmpc_graph_signature": (_int, [_vp, ctypes.POINTER(ctypes.c_uint64)]),
     "mjmpc_comm_unique_id": (_int, [_vp]),
     "mjmpc_comm_create": (_int, [_vp, _int, _int, _int, ctypes.POINTER(_vp)]),
     "mjmpc_comm_all_gather_f64": (_int, [_vp, _vp, _vp, _i64, _vp]),

@@ -176,7 +176,7 @@ class _LaunchTape:
     stream.  On this runtime consecutive hipGraph replays are 9-13 us apart on the device whatever the host does
     (tools/kernel_gaps.py), plain launches follow each other at once - so an iteration whose launches are ALL calls into
     the library (checked by the owner: a capture of the tape's replay has as many kernel nodes as the captured iteration
-    itself) runs from its tape.  Arguments are the ones recorded under capture; the stream argument (last by this
+    itself, and they are the same kernels in the same launch shapes) runs from its tape.  Arguments are the ones recorded under capture; the stream argument (last by this
     library's convention) is replaced by the stream that is current at replay."""
 
     def __init__(self, calls, recorded_stream, dev):
@@ -748,9 +748,13 @@ class OLGaussianMPC(Controller):
             n1, n2 = (ctypes.c_int64 * 2)(), (ctypes.c_int64 * 2)()
             _lib.check(self.dev.lib.mjmpc_graph_kernel_nodes(ctypes.c_void_p(int(g.raw_cuda_graph())), n1))
             _lib.check(self.dev.lib.mjmpc_graph_kernel_nodes(ctypes.c_void_p(int(g2.raw_cuda_graph())), n2))
+            # ... and the same kernels in the same launch shapes, not merely as many (mjmpc_graph_signature)
+            s1, s2 = (ctypes.c_uint64 * 2)(), (ctypes.c_uint64 * 2)()
+            _lib.check(self.dev.lib.mjmpc_graph_signature(ctypes.c_void_p(int(g.raw_cuda_graph())), s1))
+            _lib.check(self.dev.lib.mjmpc_graph_signature(ctypes.c_void_p(int(g2.raw_cuda_graph())), s2))
             del g2
             # (kernel nodes AND nodes of any kind: a collective or a tensor copy inside the iteration is not a library call)
-            if n1[0] > 0 and n1[0] == n2[0] and n1[1] == n2[1]:
+            if n1[0] > 0 and n1[0] == n2[0] and n1[1] == n2[1] and s1[0] == s2[0] and s1[1] == s2[1]:
                 self.launch_mode = "launch tape (%d calls, %d kernels)" % (len(t.calls), n1[0])
                 return t
         except Exception as e:         # (an older runtime without raw graph access, a call that cannot be re-captured ...)

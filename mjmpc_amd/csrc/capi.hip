@@ -126,6 +126,38 @@ int mjmpc_graph_kernel_nodes(void* hip_graph, int64_t* n_out) {
     return 0;
 }
 
+// An order-independent signature of a captured graph: n_out[0] = sum over its KERNEL nodes of a hash of (function, grid,
+// block, dynamic LDS), n_out[1] = the same over every node's type.  (Argument VALUES are out of the runtime's reach - a
+// kernel node's parameter array comes without sizes - but they are the recorded ones by construction; what can differ
+// between an iteration and its tape is which kernels run and in what shape.)
+int mjmpc_graph_signature(void* hip_graph, uint64_t* n_out) {
+    if (!hip_graph || !n_out) return fail(MJMPC_E_BADARG, "null argument");
+    size_t n = 0;
+    HIP_TRY(hipGraphGetNodes((hipGraph_t)hip_graph, nullptr, &n));
+    std::vector<hipGraphNode_t> nodes(n);
+    if (n) HIP_TRY(hipGraphGetNodes((hipGraph_t)hip_graph, nodes.data(), &n));
+    auto mix = [](uint64_t h, uint64_t v) { return (h ^ v) * 1099511628211ull; };
+    uint64_t ksum = 0, tsum = 0;
+    for (size_t i = 0; i < n; ++i) {
+        hipGraphNodeType t;
+        HIP_TRY(hipGraphNodeGetType(nodes[i], &t));
+        tsum += mix(1469598103934665603ull, (uint64_t)t);
+        if (t != hipGraphNodeTypeKernel) continue;
+        hipKernelNodeParams kp;
+        HIP_TRY(hipGraphKernelNodeGetParams(nodes[i], &kp));
+        uint64_t h = 1469598103934665603ull;
+        h = mix(h, (uint64_t)(uintptr_t)kp.func);
+        h = mix(h, ((uint64_t)kp.gridDim.x << 32) | kp.gridDim.y);
+        h = mix(h, ((uint64_t)kp.gridDim.z << 32) | kp.blockDim.x);
+        h = mix(h, ((uint64_t)kp.blockDim.y << 32) | kp.blockDim.z);
+        h = mix(h, (uint64_t)kp.sharedMemBytes);
+        ksum += h;
+    }
+    n_out[0] = ksum;
+    n_out[1] = tsum;
+    return 0;
+}
+
 static mjmpc::RolloutFusion arm_fuse(const mjmpc_arm_s* h) {
     mjmpc::RolloutFusion f;
     f.reset_rec = h->reset_rec;

@@ -130,7 +130,8 @@ class ArmRolloutEngine:
         for every ``{param_id: {name: [noise_scale, bias_scale]}}`` entry (gym_env_wrapper.py:367-416) and
         from then on simulates its own model.  Supported: body_mass, body_inertia, dof_damping, geom_size
         (collision geoms), geom_friction (accepted, no effect: every contact here is frictionless condim 1),
-        dof_frictionloss (the default is 0 and the randomization multiplicative: stays 0, the draw is consumed).
+        dof_frictionloss (the default is 0 and the randomization multiplicative: stays 0, the draw is consumed),
+        sensor_noise (a known sensor's draw is consumed; no observation reads a sensor).
         Returns (default_params, randomized_params), one dict per shard."""
         if self.raw is None:
             raise ValueError("randomize_dynamics needs the engine to be built from a RawModel")
@@ -150,7 +151,7 @@ class ArmRolloutEngine:
             if any(np.any(np.asarray(v) != 0) for v in rand.get("dof_frictionloss", {}).values()):
                 raise NotImplementedError("a non-zero dof_frictionloss adds friction-loss constraint rows, which the "
                                           "arm kernel does not model")
-            ov = {k: v for k, v in rand.items() if k not in ("geom_friction", "dof_frictionloss")}
+            ov = {k: v for k, v in rand.items() if k not in ("geom_friction", "dof_frictionloss", "sensor_noise")}
             blobs.append(compile_arm(self.raw, overrides=ov, base=base).blob)
         blobs = np.ascontiguousarray(np.stack(blobs), np.float64)
         _lib.check(self._lib.mjmpc_arm_set_shard_models(self._h, blobs.ctypes.data_as(_lib._dp), self.num_shards))
@@ -178,6 +179,12 @@ class ArmRolloutEngine:
             # value of a zero default is exactly 0: the draw is consumed, no friction-loss row ever appears.
             next(b for b in raw.bodies if b.joint is not None and b.joint.name == name)     # unknown joint -> error
             return 0.0
+        if param_id == "sensor_noise":
+            # (gym_env_wrapper.py:396-398 - model.sensor_noise: MuJoCo keeps the value for the user and adds no noise itself, and no
+            # observation on the path reads a sensor: the draw is consumed, as in the reference, and changes nothing)
+            if name not in raw.sensors:
+                raise ValueError("no sensor named %r" % name)
+            return float(raw.sensors[name])
         raise ValueError("Unknown dynamics field")
 
     def reset(self):

@@ -205,7 +205,8 @@ class TreeRolloutEngine:
         shard i draws from ``np_random(base_seed + i*12345)`` a uniform value in ``m (1 +- noise)``, ``m = (1 + bias) *
         default`` for every ``{param_id: {name: [noise_scale, bias_scale]}}`` entry (gym_env_wrapper.py:367-416) and from
         then on simulates its own model block (``mjmpc_tree_set_shard_models``).  Supported: body_mass, body_inertia,
-        dof_damping, dof_frictionloss (friction-loss constraint rows), geom_size and geom_friction of colliding geoms.
+        dof_damping, dof_frictionloss (friction-loss constraint rows), geom_size and geom_friction of colliding geoms,
+        sensor_noise (a known sensor's draw is consumed; no observation reads a sensor).
         Returns (default_params, randomized_params), one dict per shard."""
         if self.raw is None:
             raise ValueError("randomize_dynamics needs the engine to be built from a RawModel")
@@ -247,6 +248,12 @@ class TreeRolloutEngine:
             return np.array([g.radius, half, 0.0])
         if param_id == "dof_frictionloss":
             return float(next(b.joint.frictionloss for b in raw.bodies if b.joint is not None and b.joint.name == name))
+        if param_id == "sensor_noise":
+            # (gym_env_wrapper.py:396-398 - model.sensor_noise: MuJoCo keeps the value for the user and adds no noise itself, and no
+            # observation on the path reads a sensor: the draw is consumed, as in the reference, and changes nothing)
+            if name not in raw.sensors:
+                raise ValueError("no sensor named %r" % name)
+            return float(raw.sensors[name])
         raise ValueError("Unknown dynamics field")
 
     def solver_failures(self):

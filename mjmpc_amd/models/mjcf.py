@@ -617,7 +617,12 @@ def load_mjcf(path, hand_site="finger", target_site="target", frame_skip=2, task
     else:
         site_body, site_pos = len(bodies) - 1, [0.0, 0.0, 0.0]
     target = sites.get(target_site, (-1, [0.0, 0.0, 0.0]))[1]
-    return RawModel(bodies=bodies, actuators=acts, site_body=site_body, site_pos=site_pos, target_pos=target, plane=plane,
+    sensors = {}
+    for sec in root.findall("sensor"):
+        for e in sec:
+            if e.get("name"):
+                sensors[e.get("name")] = float(e.get("noise", "0"))
+    return RawModel(sensors=sensors, bodies=bodies, actuators=acts, site_body=site_body, site_pos=site_pos, target_pos=target, plane=plane,
                     timestep=timestep, frame_skip=frame_skip, gravity=gravity, solref=solref, solimp=full_solimp(solimp),
                     solref_limit=lsolref, solimp_limit=full_solimp(lsolimp), density=density, viscosity=viscosity, cone=cone, impratio=impratio,
                     task=task, ctrl_cost=ctrl_cost, obs_skip=obs_skip, pairs=pairs, pair_params=pair_params, world_geoms=world_geoms,

@@ -247,6 +247,10 @@ class RawModel:
     # rows' regulariser R = R_normal / impratio (round 5; impratio has no effect on pyramidal cones)
     cone: str = "pyramidal"
     impratio: float = 1.0
+    # MJCF <sensor> elements by name -> their ``noise`` attribute: nothing on the path reads a sensor (the envs' observations
+    # are qpos / qvel / site positions) and MuJoCo itself does not apply the value; kept so that ``randomize_dynamics``'
+    # ``sensor_noise`` entries (gym_env_wrapper.py:396-398) find their sensor and consume their draw
+    sensors: dict = field(default_factory=dict)
     # geom-geom collision candidates, as names (geom on the manipulator, geom on the object): sphere / capsule pairs, one
     # contact point each (closest points of the two segments); friction / condim / margin = the larger of the two geoms'
     pairs: List[Sequence[str]] = field(default_factory=list)

@@ -544,11 +544,12 @@ def test_includes_visual_meshes_excludes_and_sensors(tmp_path):
     assert [tuple(p) for p in plain.pairs] == [("cc", "ca")]            # a and c are not parent and child: MuJoCo would collide them
     (tmp_path / "acts.xml").write_text("<mujocoinclude>" + acts + "</mujocoinclude>")
     (tmp_path / "vis.xml").write_text('<mujocoinclude><asset><mesh name="shell" file="shell.stl"/></asset>'
-                                      '<sensor><jointpos joint="j1"/></sensor></mujocoinclude>')
+                                      '<sensor><jointpos name="j1_pos" joint="j1" noise="0.01"/></sensor></mujocoinclude>')
     vis = '<geom type="mesh" mesh="shell" contype="0" conaffinity="0"/><geom type="cylinder" size="0.05 0.1" contype="0" conaffinity="0"/>'
     extra = ('<include file="acts.xml"/><include file="vis.xml"/><keyframe><key qpos="0 0 0"/></keyframe>')
     rich, ref1 = _model(tmp_path, body % vis, extra=extra, name="rich.xml")
     assert np.array_equal(plain.to_flat(), rich.to_flat())
+    assert rich.sensors == {"j1_pos": 0.01} and plain.sensors == {}     # (kept by name for randomize_dynamics' sensor_noise)
     ex, _ = _model(tmp_path, body % "", extra=acts + '<contact><exclude body1="a" body2="c"/></contact>', name="ex.xml")
     assert ex.pairs == []
     # a mesh that would collide, or whose body takes its mass from its geoms, is refused

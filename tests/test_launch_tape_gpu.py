@@ -136,3 +136,37 @@ def test_tape_is_recorded_again_after_a_reset():
         torch.cuda.synchronize()
         assert c.launch_mode.startswith("launch tape")
     np.testing.assert_array_equal(episodes[0], episodes[1])
+
+
+def test_graph_signature_tells_launch_shapes_apart():
+    """``mjmpc_graph_signature``: two captures of the same rollout have the same signature, a capture with another particle
+    count (as many kernel nodes, another grid) a different one - what the tape's acceptance compares besides node counts."""
+    import ctypes
+    import torch
+    from mjmpc_amd import _lib
+    from mjmpc_amd.envs.arm_engine import ArmRolloutEngine
+    from mjmpc_amd.models.reacher7dof import reacher7dof_raw
+    if not hasattr(torch.cuda.CUDAGraph, "raw_cuda_graph"):
+        pytest.skip("this torch has no raw graph access")
+    eng = ArmRolloutEngine(reacher7dof_raw(), dtype="f64")
+    eng.set_env_state(START)
+    lib = _lib.load()
+
+    def signature(P):
+        mean = torch.zeros(8, 7, dtype=torch.float64, device="cuda")
+        noise = torch.zeros(P, 8, 7, dtype=torch.float64, device="cuda")
+        eng.rollout_device(P, 8, mean, noise)               # (buffers exist before the capture)
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph(keep_graph=True)
+        with torch.cuda.graph(g):
+            eng.rollout_device(P, 8, mean, noise)
+        n, s = (ctypes.c_int64 * 2)(), (ctypes.c_uint64 * 2)()
+        _lib.check(lib.mjmpc_graph_kernel_nodes(ctypes.c_void_p(int(g.raw_cuda_graph())), n))
+        _lib.check(lib.mjmpc_graph_signature(ctypes.c_void_p(int(g.raw_cuda_graph())), s))
+        return (n[0], n[1]), (s[0], s[1])
+
+    n_a, s_a = signature(1024)
+    n_b, s_b = signature(1024)
+    n_c, s_c = signature(4096)
+    assert n_a == n_b == n_c and n_a[0] >= 1
+    assert s_a == s_b and s_c[0] != s_a[0] and s_c[1] == s_a[1]

@@ -222,8 +222,14 @@ def test_dynamics_randomization_per_shard_on_the_tree_engine():
     eng = TreeRolloutEngine(raw, dtype="f64", num_shards=4)
     cfg = {"body_mass": {"torso": [0.3, 0.1], "ffoot": [0.5, 0.0]}, "body_inertia": {"bthigh": [0.3, 0.0]},
            "dof_damping": {"bshin": [0.4, 0.2]}, "geom_size": {"ffoot": [0.2, 0.0], "bfoot": [0.1, 0.0]},
-           "geom_friction": {"bfoot": [0.5, 0.5]}, "dof_frictionloss": {"fshin": [0.5, 0.0]}}
+           "geom_friction": {"bfoot": [0.5, 0.5]}, "dof_frictionloss": {"fshin": [0.5, 0.0]},
+           "sensor_noise": {"torso_gyro": [0.5, 0.0]}}      # (gym_env_wrapper.py:396-398: a draw, and no effect on the dynamics)
+    with pytest.raises(ValueError):
+        eng.randomize_dynamics({"sensor_noise": {"torso_gyro": [0.5, 0.0]}}, base_seed=321)       # (no such sensor yet)
+    eng = TreeRolloutEngine(raw, dtype="f64", num_shards=4)
+    raw.sensors["torso_gyro"] = 0.02
     defaults, rand = eng.randomize_dynamics(cfg, base_seed=321)
+    assert 0.01 <= rand[0]["sensor_noise"]["torso_gyro"] <= 0.03 and defaults[0]["sensor_noise"]["torso_gyro"] == 0.02
     assert len(rand) == 4 and rand[0]["body_mass"]["torso"] != rand[1]["body_mass"]["torso"]
     names = [b.name for b in raw.bodies]
     joints = [b.joint.name for b in raw.bodies if b.joint is not None]

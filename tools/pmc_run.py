@@ -1,5 +1,5 @@
 """Launches for PMC collection (rocprofv3 --pmc passes, tools/profile_round3.sh):
-    python tools/pmc_run.py [reacher|half_cheetah|swimmer|hand24|pen_hand] [P] [dtype] [H]
+    python tools/pmc_run.py [reacher|half_cheetah|swimmer|hand24|pen_hand|cartpole|door|tray|gripper] [P] [dtype] [H]
 reacher: three fused control iterations (mjmpc_arm_mppi_step: rollout kernel + finish kernel, the default loop) and three
 plain rollouts; the tree models: three rollouts from their bench start state.  Then a calibration copy (64 MiB)."""
 import os
@@ -40,6 +40,10 @@ else:
     elif wl == "pen_hand":
         from mjmpc_amd.models.pen_hand import holding_state, pen_hand_raw
         raw, st, scale = pen_hand_raw(), holding_state(), 0.1
+    elif wl in ("cartpole", "door", "tray", "gripper"):     # the synthetic MJCF models, from their bench start state
+        from mjmpc_amd.models.synthetic import start_state, synthetic_raw
+        raw = synthetic_raw(wl)
+        st, scale = start_state(wl, raw), 0.3
     else:
         from mjmpc_amd.envs import locomotion_env
         from mjmpc_amd.models.half_cheetah import half_cheetah_raw
@@ -50,10 +54,12 @@ else:
         st, scale = env.get_env_state(), 0.55
     eng = TreeRolloutEngine(raw, dtype=dt)
     if st is not None:
-        eng.set_env_state(dict(st, target_pos=np.asarray(raw.target_pos, float)) if "qp" in st else st)
+        eng.set_env_state(dict(st, target_pos=np.asarray(raw.target_pos, float)) if ("qp" in st and "target_pos" not in st) else st)
     A = eng.d_action
     g = torch.Generator(device="cuda").manual_seed(0)
     noise = scale * torch.randn(P, H, A, device="cuda", dtype=tdt, generator=g)
+    if wl in ("cartpole", "door", "tray", "gripper"):
+        noise = noise * torch.from_numpy((eng.action_highs - eng.action_lows) / 2).to(noise)
     mean = torch.zeros(H, A, dtype=torch.float64, device="cuda")
     if wl == "pen_hand":
         mean += torch.from_numpy(st["qp"][6:]).cuda()

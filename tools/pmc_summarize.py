@@ -18,6 +18,12 @@ WORKLOADS = {
                 ["arm_mppi_finish_kernel<double>", "arm_rollout_kernel<double, false, false, 1, true, false>"]),
     "half_cheetah": ("half_cheetah_", "tree_rollout_kernel<double, 8, 16, true, 16, 12", []),
 }
+# round 5: further entries on the command line, "workload[:P]" - the directory of their passes is <tag>_<workload>[<P>]_pmc*,
+# the dominant kernel the instantiation of the workload's rollout kernel that ran longest in the S1 pass
+EXTRA = []
+for a in sys.argv[3:]:
+    wl_, _, p_ = a.partition(":")
+    EXTRA.append((wl_, int(p_) if p_ else 4096))
 
 
 def rows(d, pat="*counter_collection.csv"):
@@ -51,7 +57,22 @@ def flops(wl, kernel):
     return m, 64.0 * f64, 64.0 * f32
 
 
-for wl, (prefix, KERNEL, others) in WORKLOADS.items():
+def longest_kernel(d, base):
+    tot = {}
+    for r in rows(d):
+        if base in r["Kernel_Name"]:
+            tot.setdefault(r["Kernel_Name"], {})[r["Dispatch_Id"]] = float(r["End_Timestamp"]) - float(r["Start_Timestamp"])
+    return max(tot, key=lambda k: sum(tot[k].values())) if tot else base
+
+
+JOBS = [(wl, prefix, KERNEL, others, 4096) for wl, (prefix, KERNEL, others) in WORKLOADS.items()] if not EXTRA else []
+for wl_, p_ in EXTRA:
+    d_ = wl_ + (str(p_) if p_ != 4096 else "")
+    base = "arm_rollout_kernel<double" if wl_ == "reacher" else "tree_rollout_kernel<double"
+    # (reacher: the fused iteration's rollout kernel - the instantiations whose last argument, MONO, is true)
+    k_ = longest_kernel(d_ + "_pmcS1", base)
+    JOBS.append((d_, ("" if wl_ == "reacher" else wl_ + "_"), k_, ["arm_mppi_finish_kernel<double>"] if wl_ == "reacher" else [], p_))
+for wl, prefix, KERNEL, others, P in JOBS:
     # ---- HBM traffic per launch (FETCH_SIZE / WRITE_SIZE are reported in KB; calibrated on the 64 MiB copy) ----
     fk, _ = per_kernel(wl + "_pmcF", KERNEL)
     wk, _ = per_kernel(wl + "_pmcW", KERNEL)
