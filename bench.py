@@ -181,8 +181,9 @@ def counted_flops(raw, H, A, qpos, qvel, target, noise_scale, filtered):
 
 def profile_figure(name, dtype, P, H, prefix=""):
     """A per-launch figure that needs PMC counters (separate rocprofv3 passes, MI355X_MICROARCH.md): measured
-    offline for the headline shape and kept under profiles/; other shapes report null."""
-    for rnd in ("r04", "r03", "r02", "r01"):
+    offline and kept under profiles/ (the headline shape; since round 5 the reacher at 16384 / 65536 particles and the cart-pole,
+    door, tray and gripper workloads too); other shapes report null."""
+    for rnd in ("r05", "r04", "r03", "r02", "r01"):
         path = os.path.join(ROOT, "profiles", "%s_%s%s_%s_%dx%d.json" % (rnd, prefix, name, dtype, P, H))
         if os.path.exists(path):
             with open(path) as f:

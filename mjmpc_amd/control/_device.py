@@ -55,6 +55,36 @@ class TorchDistComm:
         if library_collectives is None:
             library_collectives = self.backend == "nccl" and not os.environ.get("MJMPC_TORCH_COLLECTIVES")
         self.lib_collectives = bool(library_collectives) and self.backend == "nccl"
+        if self.lib_collectives:
+            self._open_library_comm()
+
+    def _open_library_comm(self):
+        """The library's communicator, made when this object is (the controllers read ``lib_collectives`` when they choose how
+        to launch).  Every rank first checks that the library can reach RCCL at all; the ranks then go on TOGETHER or fall
+        back to torch.distributed's collectives together (a rank that could not bind RCCL would otherwise leave the others
+        waiting in ncclCommInitRank)."""
+        import warnings
+        import torch
+        dev = torch.device("cuda", torch.cuda.current_device())
+        ok, why = True, ""
+        try:
+            probe = (ctypes.c_ubyte * 128)()
+            _lib.check(_lib.load().mjmpc_comm_unique_id(probe))
+        except Exception as e:      # (no librccl the library can bind, an older library ...)
+            ok, why = False, str(e)
+        if self.all_agree(ok, dev):
+            try:
+                self._library_comm(dev)
+            except Exception as e:
+                ok, why = False, str(e)
+            ok = self.all_agree(ok, dev)
+        else:
+            ok = False
+        if not ok:
+            self.close()
+            self.lib_collectives = False
+            warnings.warn("mjmpc_amd: the library's own RCCL communicator is not available (%s); the control iterations' exchanges go "
+                          "through torch.distributed (hipGraph replay instead of direct launches)" % (why or "another rank failed"))
 
     def _library_comm(self, device):
         """ncclCommInitRank of the library's own communicator over the ranks of this group (collective; outside any

@@ -1,7 +1,7 @@
 """Launches for PMC collection (rocprofv3 --pmc passes, tools/profile_round3.sh):
     python tools/pmc_run.py [reacher|half_cheetah|swimmer|hand24|pen_hand|cartpole|door|tray|gripper] [P] [dtype] [H]
 reacher: three fused control iterations (mjmpc_arm_mppi_step: rollout kernel + finish kernel, the default loop) and three
-plain rollouts; the tree models: three rollouts from their bench start state.  Then a calibration copy (64 MiB)."""
+plain rollouts - above 4096 particles four launches of mjmpc_arm_rollout_fused, the captured iteration's rollout; the tree models: three rollouts from their bench start state.  Then a calibration copy (64 MiB)."""
 import os
 import sys
 
@@ -26,12 +26,17 @@ if wl == "reacher":
              action_highs=eng.action_highs, filter_coeffs=[0.25, 0.8, 0.0], seed=123, noise_mode="device", noise_dtype=dt)
     chol, coeffs, _ = c.dev.prepare_noise(c.cov_action, c.filter_coeffs)
     step = torch.zeros(1, dtype=torch.int64, device="cuda")
-    for _ in range(3):
-        eng.mppi_step(P, H, c.dev.mean, c.dev.mean_alt, c.dev.gseq, coeffs, chol, 123, 0, 0, step, 0.01, 1.0, 0, env_step=False)
     noise = torch.from_numpy(generate_noise(np.eye(7), [0.25, 0.8, 0.0], (P, H), 123)).cuda().to(tdt)
     mean = torch.zeros(H, 7, dtype=torch.float64, device="cuda")
-    for _ in range(3):
-        eng.rollout_device(P, H, mean, noise)
+    if P <= 4096:           # the fused two-launch iteration (what the control loop runs up to 4096 particles)
+        for _ in range(3):
+            eng.mppi_step(P, H, c.dev.mean, c.dev.mean_alt, c.dev.gseq, coeffs, chol, 123, 0, 0, step, 0.01, 1.0, 0, env_step=False)
+        for _ in range(3):
+            eng.rollout_device(P, H, mean, noise)
+    else:                   # above: the captured iteration's rollout launch (filter + rollout + cost-to-go on raw samples)
+        raw = torch.randn(P, H, 7, device="cuda", dtype=tdt)
+        for _ in range(4):
+            eng.rollout_fused(P, H, mean, raw, coeffs, c.dev.gseq)
 else:
     from mjmpc_amd.envs.tree_engine import TreeRolloutEngine
     if wl == "hand24":

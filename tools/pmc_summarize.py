@@ -36,8 +36,12 @@ def rows(d, pat="*counter_collection.csv"):
 def per_kernel(d, name_part):
     """counter -> list of per-dispatch values, and the dispatch durations (ns) of the matching kernel"""
     vals, dur = {}, {}
-    for r in rows(d):
-        if name_part in r["Kernel_Name"]:
+    match = [r for r in rows(d) if name_part in r["Kernel_Name"]]
+    # (the full-size launches only: since round 5 an engine makes its reset record with a one-particle launch of the same
+    # instantiation, which must not enter the per-launch means)
+    big = max((int(r.get("Grid_Size", 0) or 0) for r in match), default=0)
+    for r in match:
+        if int(r.get("Grid_Size", 0) or 0) == big:
             vals.setdefault(r["Counter_Name"], []).append(float(r["Counter_Value"]))
             dur[r["Dispatch_Id"]] = float(r["End_Timestamp"]) - float(r["Start_Timestamp"])
     return vals, list(dur.values())
@@ -71,7 +75,9 @@ for wl_, p_ in EXTRA:
     base = "arm_rollout_kernel<double" if wl_ == "reacher" else "tree_rollout_kernel<double"
     # (reacher: the fused iteration's rollout kernel - the instantiations whose last argument, MONO, is true)
     k_ = longest_kernel(d_ + "_pmcS1", base)
-    JOBS.append((d_, ("" if wl_ == "reacher" else wl_ + "_"), k_, ["arm_mppi_finish_kernel<double>"] if wl_ == "reacher" else [], p_))
+    if wl_ == "reacher" and p_ <= 4096:         # the headline's kernel by name: the fused iteration's rollout launch (DUO, MONO)
+        k_ = WORKLOADS["reacher"][1]
+    JOBS.append((d_, ("" if wl_ == "reacher" else wl_ + "_"), k_, WORKLOADS["reacher"][2] if wl_ == "reacher" else [], p_))
 for wl, prefix, KERNEL, others, P in JOBS:
     # ---- HBM traffic per launch (FETCH_SIZE / WRITE_SIZE are reported in KB; calibrated on the 64 MiB copy) ----
     fk, _ = per_kernel(wl + "_pmcF", KERNEL)
