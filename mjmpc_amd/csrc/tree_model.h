@@ -120,6 +120,8 @@ enum TreePointKind : int { PT_PLANE = 0, PT_SEGSEG = 1, PT_SPHERE_BOX = 2, PT_BO
                            PT_BOX_BOX = 10,    // two boxes: contact k of four (SAT, then face clipping or the edge pair; see the oracle's box_box);
                                                // box A in PEXT [0:12] as PT_SPHERE_BOX's, box B's orientation in ITS link's frame as a
                                                // quaternion in PEXT [12:16], its half sizes in [16:19]
+                           PT_SEG_CYL = 11,    // a sphere / capsule (geom A) against a cylinder (geom B: its axis end to end in [14:17] + [18:21],
+                           PT_CYL_SEG = 12,    // radius [17]) and the other way round: candidate [22] of [23] = 1 (sphere) or 3 (capsule)
                            PT_CAPSULE_BOX = 8, PT_BOX_CAPSULE = 9 };   // a capsule against a box: candidate k of three (the axis' nearest point,
                                                // the two ends); segment as PT_SEGSEG, box as PT_SPHERE_BOX.  (A box's corners on the plane
                                                // are PT_PLANE records with [23] = 8, [22] = corner, [14:17] = the box centre: mjc_PlaneBox

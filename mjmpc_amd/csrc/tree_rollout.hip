@@ -1088,6 +1088,50 @@ __device__ __forceinline__ bool box_point(const T* h, const T* loc, T* cl, T* nb
 // The parameter t in [0, 1] at which the segment a + t b (box frame) comes nearest to the solid box: the squared distance is
 // convex and piecewise quadratic, its pieces end where a coordinate crosses a face plane (at most six break points); every
 // piece is minimised in closed form and the least minimum taken, the first where pieces tie (the oracle's seg_box_param)
+// The surface point of a solid cylinder (axis from p0 along d, end to end; radius r) nearest to a point c: outside - the point of
+// the solid nearest to c, normal from it to c; inside - the nearest of the side and the two caps.  len = signed distance of c
+// from the surface; false when c lies on it to rounding.  (The oracle's cyl_point, operation for operation.)
+template <typename T>
+__device__ __noinline__ bool cyl_point(const T* p0, const T* d, T r, const T* c, T* q, T* n, T& len) {
+    const T L = sqrt_(dot3(d, d));
+    T u[3], w[3], rv[3], rh[3];
+    for (int i = 0; i < 3; ++i) { u[i] = d[i] / L; w[i] = c[i] - p0[i]; }
+    const T z = dot3(w, u);
+    for (int i = 0; i < 3; ++i) rv[i] = w[i] - z * u[i];
+    const T rho = sqrt_(dot3(rv, rv));
+    if (rho > T(1e-14)) {
+        for (int i = 0; i < 3; ++i) rh[i] = rv[i] / rho;
+    } else {                                // on the axis: a fixed direction across it
+        const bool xx = u[0] < T(0.9) && u[0] > T(-0.9);
+        const T e[3] = {xx ? T(1) : T(0), xx ? T(0) : T(1), T(0)};
+        T pr = dot3(e, u);
+        for (int i = 0; i < 3; ++i) rh[i] = e[i] - pr * u[i];
+        pr = sqrt_(dot3(rh, rh));
+        for (int i = 0; i < 3; ++i) rh[i] /= pr;
+    }
+    if (!(z > T(0) && z < L && rho < r)) {
+        const T zc = z < T(0) ? T(0) : (z > L ? L : z), rc = rho < r ? rho : r;
+        T diff[3];
+        for (int i = 0; i < 3; ++i) { q[i] = p0[i] + zc * u[i] + rc * rh[i]; diff[i] = c[i] - q[i]; }
+        len = sqrt_(dot3(diff, diff));
+        if (len < T(1e-14)) return false;
+        for (int i = 0; i < 3; ++i) n[i] = diff[i] / len;
+        return true;
+    }
+    const T ds = r - rho, db = z, dt = L - z;
+    if (ds <= db && ds <= dt) {
+        for (int i = 0; i < 3; ++i) { n[i] = rh[i]; q[i] = p0[i] + z * u[i] + r * rh[i]; }
+        len = -ds;
+    } else if (db <= dt) {
+        for (int i = 0; i < 3; ++i) { n[i] = -u[i]; q[i] = p0[i] + rho * rh[i]; }
+        len = -db;
+    } else {
+        for (int i = 0; i < 3; ++i) { n[i] = u[i]; q[i] = p0[i] + L * u[i] + rho * rh[i]; }
+        len = -dt;
+    }
+    return true;
+}
+
 template <typename T>
 __device__ __noinline__ T seg_box_param(const T* h, const T* a, const T* b) {
     T bp[8];
@@ -1348,6 +1392,39 @@ __device__ __forceinline__ ExtraContact<T> extra_geometry(int kind, LinkPose<T> 
         const bool ok = box_box_contact(oA, RwA, ex, oB, RwB, ex + 16, sp[5], (int)sp[22], nv3, cp3, cdist);
         for (int k = 0; k < 3; ++k) { out.n[k] = nv3[k]; out.cp[k] = cp3[k]; }
         frame_tangent(nv3, zero3, out.t1);
+        out.dist = cdist;
+        out.hit = ok && cdist < sp[5];
+        return out;
+    }
+    if (kind == PT_SEG_CYL || kind == PT_CYL_SEG) {
+        // a sphere or a capsule against a cylinder (a scheme of its own, see the oracle): candidate sp[22] of three - the point
+        // of the capsule's axis nearest to the cylinder's axis, its two ends where they are not that point - against the
+        // cylinder's nearest surface point (cyl_point)
+        const bool cylA = kind == PT_CYL_SEG;
+        T dA[3], dB[3];
+        mv3(Rl, sp + 8, dA);
+        mv3(Rb, sp + 18, dB);
+        const T* os0 = cylA ? oB : oA;
+        const T* dv = cylA ? dB : dA;
+        const T* oc = cylA ? oA : oB;
+        const T* dc = cylA ? dA : dB;
+        const T rs = cylA ? sp[17] : sp[4], rc = cylA ? sp[4] : sp[17];
+        T ts = T(0), tc = T(0);
+        if (dot3(dv, dv) > T(0)) seg_seg_params(os0, dv, oc, dc, ts, tc);
+        const int cand = (int)sp[22];
+        const T tt = cand == 0 ? ts : (cand == 1 ? T(0) : T(1));
+        bool ok = cand == 0 || tt != ts;
+        T ps[3], q[3], nn[3], len = T(0);
+        for (int k = 0; k < 3; ++k) ps[k] = os0[k] + tt * dv[k];
+        ok = cyl_point(oc, dc, rc, ps, q, nn, len) && ok;
+        const T sgn = cylA ? T(-1) : T(1);          // nn points from the cylinder to the sphere; the contact's normal from geom B to geom A
+        const T cdist = len - rs;
+        for (int k = 0; k < 3; ++k) {
+            out.n[k] = sgn * nn[k];
+            const T onB = cylA ? ps[k] + out.n[k] * rs : q[k];
+            out.cp[k] = onB + out.n[k] * (T(0.5) * cdist);
+        }
+        frame_tangent(out.n, zero3, out.t1);
         out.dist = cdist;
         out.hit = ok && cdist < sp[5];
         return out;

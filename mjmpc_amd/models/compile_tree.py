@@ -56,6 +56,7 @@ PT_PLANE, PT_SEGSEG, PT_SPHERE_BOX, PT_BOX_SPHERE, PT_CONNECT, PT_DOFROW, PT_WEL
 # round - candidate k of three: where the capsule's axis comes nearest to the box, its two ends.  A box's corners on the
 # plane stay PT_PLANE records with [23] = 8 (the group's size), [22] = the corner's index and [14:17] = the box centre
 PT_PLANE_CYL, PT_CAPSULE_BOX, PT_BOX_CAPSULE, PT_BOX_BOX = 7, 8, 9, 10     # (box-box: contact k of four; see tree_model.h)
+PT_SEG_CYL, PT_CYL_SEG = 11, 12     # a sphere / capsule (geom A) against a cylinder (geom B), and the other way round
 PEXT_STRIDE = 24            # per contact record, general instantiation: [0:3] box half sizes, [3:12] box orientation in its
                             # link's frame (row-major) | dof row: [0] 0 joint equality / 1 tendon limit, [1] coef A, [2] coef
                             # B, [3:5] range, [5] margin, [6:11] polycoef; [12:19] the row's solver set {K, B, dmin, dmax,
@@ -600,11 +601,11 @@ def compile_tree(raw: RawModel, overrides=None, base: "TreeModel" = None) -> Tre
         points = []
     n_eq_pts = len(raw.equalities) + sum(1 for e in raw.equalities if e.type == EQ_WELD)     # (a weld takes two records)
     n_tn_pts = sum(1 for t in raw.tendons if t.limited) + sum(1 for b in raw.bodies if b.joint is not None and b.joint.type == JOINT_BALL and b.joint.limited)
-    n_pair_pts = sum(3 if sorted((ga.type, gb.type)) == [GEOM_CAPSULE, GEOM_BOX] else (4 if (ga.type, gb.type) == (GEOM_BOX, GEOM_BOX) else 1)
-                     for (_, ga), (_, gb) in pair_geoms)
+    n_pair_pts = sum(3 if sorted((ga.type, gb.type)) in ([GEOM_CAPSULE, GEOM_BOX], [GEOM_CAPSULE, GEOM_CYLINDER])
+                     else (4 if (ga.type, gb.type) == (GEOM_BOX, GEOM_BOX) else 1) for (_, ga), (_, gb) in pair_geoms)
     if len(points) + n_pair_pts + n_eq_pts + n_tn_pts > TREE_MAX_SPHERES:
         raise ValueError("tree kernel supports %d contact records (a capsule on the plane counts two, a box eight, a cylinder four, "
-                         "a capsule-box pair three, a box-box pair four, any other geom-geom pair, an equality and a tendon limit one each)" % TREE_MAX_SPHERES)
+                         "a capsule-box / capsule-cylinder pair three, a box-box pair four, any other geom-geom pair, an equality and a tendon limit one each)" % TREE_MAX_SPHERES)
     if raw.plane is not None:
         n = np.asarray(raw.plane.normal, float)
         n = n / np.linalg.norm(n)
@@ -746,9 +747,17 @@ def compile_tree(raw: RawModel, overrides=None, base: "TreeModel" = None) -> Tre
         rec[13], rec[14:17], rec[17], rec[18:21] = lb, b0, rb, db
         rec[21] = sol_class(psolref, psolimp)
         boxes = [k for k, g in enumerate((ga, gb)) if g.type == GEOM_BOX]
-        if GEOM_CYLINDER in (ga.type, gb.type):
-            raise NotImplementedError("a cylinder collides with the plane only")
         copies = 1
+        if GEOM_CYLINDER in (ga.type, gb.type):
+            # a sphere / capsule against a cylinder (round 5): the cylinder is its axis segment + radius, as a capsule's record
+            # - only the kind tells the kernel to close it with flat caps; a capsule brings three candidate contacts
+            other = gb if ga.type == GEOM_CYLINDER else ga
+            if other.type not in (GEOM_SPHERE, GEOM_CAPSULE):
+                raise NotImplementedError("a cylinder collides with the plane, spheres and capsules")
+            rec[12] = PT_CYL_SEG if ga.type == GEOM_CYLINDER else PT_SEG_CYL
+            if other.type == GEOM_CAPSULE:
+                rec[23], copies = 3.0, 3
+            gen = True
         if len(boxes) == 2:
             # two boxes: box A as a sphere-box record's box, box B's orientation in ITS link's frame as a quaternion + half sizes
             for (ibx, gbx), at in (((ia, ga), 0), ((ib, gb), 12)):

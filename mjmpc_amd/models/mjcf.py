@@ -23,7 +23,7 @@ panda/tray_glass-v0.yml, sawyer/door-v0.yml, hand/*-v0.yml):
   ``<site>``s, ``<motor>`` / ``<position kp>`` / ``<velocity kv>`` / ``<general gainprm biasprm biastype=affine>`` actuators
   (``joint gear ctrlrange ctrllimited forcerange forcelimited``; no activation dynamics),
   ``<contact><pair geom1 geom2 [condim friction margin gap solref solimp]>``; geom pairs: sphere / capsule against sphere /
-  capsule, sphere / capsule / box against box (round 5; cylinders collide with the plane only);
+  capsule, sphere / capsule / box against box, sphere / capsule against cylinder (round 5);
 * ``<equality><connect body1 body2 anchor>``, ``<weld body1 body2>`` and ``<joint joint1 joint2 polycoef>`` (``solref`` /
   ``solimp`` each),
   ``<tendon><fixed limited range><joint joint coef/>`` over one or two joints.
@@ -233,12 +233,16 @@ def load_mjcf(path, hand_site="finger", target_site="target", frame_skip=2, task
     inertia_from_geom_always = comp is not None and comp.get("inertiafromgeom", "auto") == "true"
     autolimits = comp is not None and comp.get("autolimits", "false") == "true"
 
+    # (geoms an explicit <pair> names collide whatever their masks say)
+    paired_names = {pr.get(k) for c_ in root.findall("contact") for pr in c_.findall("pair") for k in ("geom1", "geom2")}
+
     def parse_geom(e, active, has_inertial=False):
         ga = lambda k, d=None: dfl.attr("geom", e, active, k, d)        # noqa: E731
         t = ga("type", "sphere")
         if ga("mesh") is not None and e.get("type") is None:
             t = "mesh"                  # (a geom that names a mesh is a mesh geom)
-        if t == "cylinder" and int(ga("contype", "1")) == 0 and int(ga("conaffinity", "1")) == 0 and has_inertial and not inertia_from_geom_always:
+        if (t == "cylinder" and int(ga("contype", "1")) == 0 and int(ga("conaffinity", "1")) == 0 and has_inertial
+                and not inertia_from_geom_always and e.get("name") not in paired_names):
             return None                 # (a purely visual cylinder: neither collided nor integrated)
         if t in _SHAPE_ONLY_TYPES:
             # meshes, cylinders and ellipsoids are neither collided nor integrated here: such a geom is accepted where it
@@ -453,10 +457,11 @@ def load_mjcf(path, hand_site="finger", target_site="target", frame_skip=2, task
                 if not ((ga_._contype & gb_._conaffinity) or (gb_._contype & ga_._conaffinity)):
                     continue
                 kinds = sorted((ga_.type, gb_.type))
-                if GEOM_CYLINDER in kinds:
-                    raise ValueError("geoms %r / %r would collide (contype / conaffinity) but a cylinder only collides with the "
-                                     "plane here (MuJoCo sends cylinder pairs to its general convex collider): mask the pair out "
-                                     "or use a capsule" % (ga_.name or "?", gb_.name or "?"))
+                if GEOM_CYLINDER in kinds and kinds not in ([GEOM_SPHERE, GEOM_CYLINDER], [GEOM_CAPSULE, GEOM_CYLINDER]):
+                    raise ValueError("geoms %r / %r would collide (contype / conaffinity) but a cylinder collides with the plane, "
+                                     "spheres and capsules only (MuJoCo sends cylinder pairs to its general convex collider; "
+                                     "cylinder-box and cylinder-cylinder have no closed form here): mask the pair out or use a "
+                                     "capsule" % (ga_.name or "?", gb_.name or "?"))
                 for k, (bi, g) in ((ia, flat[ia]), (ib, flat[ib])):
                     if not g.name:
                         g.name = "%s_geom%d" % (bodies[bi].name if bi >= 0 else "world", k)

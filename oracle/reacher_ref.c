@@ -124,6 +124,8 @@ typedef struct {
     int pair_box[MAXP];                      /* -1: two segments; e: geom e of the pair is a BOX (the other a sphere) */
     double pair_R[MAXP][9], pair_half[MAXP][3];   /* that box: orientation in its body's frame, half sizes (pair_a = centre) */
     double pair_R2[MAXP][9], pair_half2[MAXP][3]; /* pair_box = 2 (round 5): BOTH geoms are boxes - geom 0's in pair_R / pair_half, geom 1's here */
+    int pair_cyl[MAXP];                      /* -1, or e (round 5): geom e of the pair is a CYLINDER (pair_a / pair_d: its axis, end to end; */
+    double pair_cyl_r[MAXP];                 /* ... its radius here, pair_r = 0), the other geom a sphere or a capsule */
     /* equality constraints (MJCF <equality>): connect / weld (two bodies, 0 = world) and joint (two dofs, -1 = none) */
     int neq, eq_type[MAXE], eq_o1[MAXE], eq_o2[MAXE];
     double eq_anchor[MAXE][2][3], eq_relR[MAXE][9], eq_poly[MAXE][5], eq_solref[MAXE][2], eq_solimp[MAXE][5];
@@ -747,13 +749,20 @@ OrModel *or_model_compile(const double *f, int n) {
          * two geoms' values, or what the model's <pair> element says - RawModel.pair_contact) */
         const double *pr = p0 + k * PAIR_STRIDE;
         m->pair_box[k] = -1;
+        m->pair_cyl[k] = -1;
         for (int e = 0; e < 2; e++) {
             const double *r = g0 + (int)pr[e] * GEOM_STRIDE;
             m->pair_body[k][e] = (int)r[0] + 1;
             memcpy(m->pair_a[k][e], r + 3, 24);
             for (int i = 0; i < 3; i++) m->pair_d[k][e][i] = (int)r[1] == 2 ? r[6 + i] - r[3 + i] : 0.0;
             m->pair_r[k][e] = (int)r[1] == 3 ? 0.0 : r[2];
-            if ((int)r[1] == 4) { free(m); return NULL; }               /* a cylinder collides with the plane only */
+            if ((int)r[1] == 4) {               /* a cylinder: against a sphere or a capsule (round 5; a scheme of its own, cyl_point) */
+                if (m->pair_cyl[k] >= 0) { free(m); return NULL; }      /* (not against another cylinder) */
+                m->pair_cyl[k] = e;
+                m->pair_cyl_r[k] = r[2];
+                m->pair_r[k][e] = 0.0;
+                for (int i = 0; i < 3; i++) m->pair_d[k][e][i] = r[6 + i] - r[3 + i];
+            }
             if ((int)r[1] == 3) {
                 if (m->pair_box[k] >= 0) {          /* the second box of a box-box pair */
                     m->pair_box[k] = 2;
@@ -770,6 +779,7 @@ OrModel *or_model_compile(const double *f, int n) {
         m->pair_mu[k] = (int)pr[2] >= 3 ? pr[3] : 0.0;
         memcpy(m->pair_solref[k], pr + 5, 16);
         memcpy(m->pair_solimp[k], pr + 7, 40);
+        if (m->pair_cyl[k] >= 0 && m->pair_box[k] >= 0) { free(m); return NULL; }       /* (nor against a box) */
     }
     const double *e0 = p0 + np_ * PAIR_STRIDE;
     m->neq = ne;
@@ -1257,6 +1267,52 @@ void or_solve_rows(OrModel *m, int nv, const double *M, const double *fs, int nc
     for (int c = 0; c < nc; c++)
         for (int j = 0; j < MAXV; j++) J[c][j] = j < nv ? Jflat[c * nv + j] : 0.0;
     solve_rows(m, nv, M, fs, nc, J, aref, D, kind, floss, a, force);
+}
+
+/* The surface point of a solid cylinder - axis from p0 along d (end to end), radius r - nearest to a point c (world
+ * coordinates): outside, the point of the solid nearest to c (axial coordinate clamped to the caps, radial one to the
+ * radius) and the normal from it to c; inside, the nearest of the side and the two caps, its outward normal.  len = signed
+ * distance of c from the surface.  Returns 0 when c lies on the surface to rounding.  (MuJoCo 2.0 hands sphere / capsule
+ * against cylinder to its convex collider; this is the closed form a later MuJoCo's mjc_SphereCylinder computes, restated
+ * as a scheme of its own.) */
+static int cyl_point(const double *p0, const double *d, double r, const double *c, double *q, double *n, double *len) {
+    double L = sqrt(dot3(d, d)), u[3], w[3], rv[3], rh[3];
+    for (int i = 0; i < 3; i++) { u[i] = d[i] / L; w[i] = c[i] - p0[i]; }
+    double z = dot3(w, u);
+    for (int i = 0; i < 3; i++) rv[i] = w[i] - z * u[i];
+    double rho = sqrt(dot3(rv, rv));
+    if (rho > 1e-14) { for (int i = 0; i < 3; i++) rh[i] = rv[i] / rho; }
+    else {                                  /* on the axis: a fixed direction across it */
+        double e[3] = {0, 0, 0}, pr;
+        if (u[0] < 0.9 && u[0] > -0.9) e[0] = 1; else e[1] = 1;
+        pr = dot3(e, u);
+        for (int i = 0; i < 3; i++) rh[i] = e[i] - pr * u[i];
+        pr = sqrt(dot3(rh, rh));
+        for (int i = 0; i < 3; i++) rh[i] /= pr;
+    }
+    if (!(z > 0 && z < L && rho < r)) {
+        double zc = z < 0 ? 0 : (z > L ? L : z), rc = rho < r ? rho : r, diff[3];
+        for (int i = 0; i < 3; i++) { q[i] = p0[i] + zc * u[i] + rc * rh[i]; diff[i] = c[i] - q[i]; }
+        *len = sqrt(dot3(diff, diff));
+        if (*len < 1e-14) return 0;
+        for (int i = 0; i < 3; i++) n[i] = diff[i] / *len;
+        return 1;
+    }
+    double ds = r - rho, db = z, dt = L - z;
+    if (ds <= db && ds <= dt) {
+        for (int i = 0; i < 3; i++) { n[i] = rh[i]; q[i] = p0[i] + z * u[i] + r * rh[i]; }
+        *len = -ds;
+    } else if (db <= dt) {
+        for (int i = 0; i < 3; i++) { n[i] = -u[i]; q[i] = p0[i] + rho * rh[i]; }
+        *len = -db;
+    } else {
+        for (int i = 0; i < 3; i++) { n[i] = u[i]; q[i] = p0[i] + L * u[i] + rho * rh[i]; }
+        *len = -dt;
+    }
+    return 1;
+}
+int or_cyl_point(const double *p0, const double *d, double r, const double *c, double *q, double *n, double *len) {      /* (test hook) */
+    return cyl_point(p0, d, r, c, q, n, len);
 }
 
 /* closest points of two segments p1 + s d1, p2 + t d2, s, t in [0, 1] (a sphere is a segment of length 0); parallel
@@ -1910,6 +1966,35 @@ static int step_impl(OrModel *m, double *q, double *v, const double *ctrl, doubl
             matvec3(k.xmat[b], m->pair_d[p][e], d[e]);
         }
         double c1[3], c2[3], diff[3], len;
+        if (m->pair_cyl[p] >= 0) {
+            /* a sphere or a capsule against a cylinder (a scheme of its own: MuJoCo 2.0 uses its convex collider here): the
+             * cylinder's surface point nearest to the sphere's centre (cyl_point); a capsule brings up to three such contacts -
+             * the point of its axis nearest to the cylinder's AXIS, and its two ends where they are not that point */
+            int ec = m->pair_cyl[p], es = 1 - ec;
+            int capsule = dot3(m->pair_d[p][es], m->pair_d[p][es]) > 0;
+            double ts = 0, tc = 0;
+            if (capsule) seg_seg(o[es], d[es], o[ec], d[ec], &ts, &tc);
+            for (int cand = 0; cand < (capsule ? 3 : 1); cand++) {
+                double tt = cand == 0 ? ts : (cand == 1 ? 0.0 : 1.0);
+                if (cand > 0 && tt == ts) continue;
+                double ps[3], q[3], nn[3];
+                for (int i = 0; i < 3; i++) ps[i] = o[es][i] + tt * d[es][i];
+                if (!cyl_point(o[ec], d[ec], m->pair_cyl_r[p], ps, q, nn, &len)) continue;
+                for (int i = 0; i < 3; i++) {
+                    diff[i] = es == 0 ? nn[i] : -nn[i];                 /* nn points from the cylinder to the sphere */
+                    c1[i] = es == 0 ? ps[i] : q[i];
+                    c2[i] = es == 0 ? q[i] : ps[i];
+                }
+                double dist = len - m->pair_r[p][0] - m->pair_r[p][1];
+                if (dist < m->pair_margin[p]) {
+                    double cp[3];
+                    for (int i = 0; i < 3; i++) cp[i] = c2[i] + diff[i] * (m->pair_r[p][1] + 0.5 * dist);
+                    contact_rows(m, &k, v, diff, cp, m->pair_body[p][0], m->pair_body[p][1], dist, m->pair_margin[p], m->pair_mu[p], m->pair_solref[p], m->pair_solimp[p],
+                                 ZERO3, J, aref, D, kind, floss, &nc);
+                }
+            }
+            continue;
+        }
         if (m->pair_box[p] == 2) {
             double Rw0[9], Rw1[9], n[3], P4[4][3], d4[4];
             matmul3(k.xmat[m->pair_body[p][0]], m->pair_R[p], Rw0);

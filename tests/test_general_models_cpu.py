@@ -384,13 +384,13 @@ def test_loader_refuses_what_is_not_modelled(tmp_path):
     ]:
         with pytest.raises(ValueError, match=msg):
             _model(tmp_path, body, extra=extra, name="bad.xml")
-    # a cylinder against anything but the plane: derived from the masks -> refused with advice; a box against the plane,
-    # spheres and (round 5) capsules and boxes is fine
+    # a cylinder against a box (or another cylinder): derived from the masks -> refused with advice; a box against the plane,
+    # spheres and (round 5) capsules and boxes is fine, and so is a cylinder against spheres and capsules
     body = """<body name="a"><freejoint/><geom name="x" type="box" size="0.1 0.1 0.1" contype="1" conaffinity="1"/><site name="finger"/></body>
     <body name="b" pos="1 0 0"><freejoint/><geom name="y" type="%s" size="0.1 0.1 0.1" contype="1" conaffinity="1"/></body>"""
     rawbb, _ = _model(tmp_path, body % "box", name="bb.xml")            # (box-box: four contact records, round 5)
     assert rawbb.pairs == [("y", "x")]
-    with pytest.raises(ValueError, match="cylinder only collides"):
+    with pytest.raises(ValueError, match="cylinder collides with the plane, spheres and capsules only"):
         _model(tmp_path, (body % "cylinder").replace('size="0.1 0.1 0.1" contype="1" conaffinity="1"/></body>', 'size="0.1 0.1" contype="1" conaffinity="1"/></body>'), name="bc.xml")
     raw, _ = _model(tmp_path, (body % "capsule").replace('size="0.1 0.1 0.1" contype="1" conaffinity="1"/></body>', 'size="0.1 0.1" contype="1" conaffinity="1"/></body>'), name="bk.xml")
     assert raw.pairs == [("y", "x")]
@@ -1068,3 +1068,67 @@ def test_elliptic_cone_box_sticks_below_the_friction_angle_and_impratio_hardens_
     hi, _ = slide(ang, 'cone="elliptic"', "c.xml")
     acc = (hi[-1] - hi[-101]) / (100 * 0.002)
     assert abs(acc - 9.81 * (np.sin(ang) - mu * np.cos(ang))) < 0.03 * 9.81 * np.sin(ang), acc
+
+
+# ------------------------------------------------------------------------------------------ spheres / capsules on cylinders (round 5)
+def test_cylinder_nearest_surface_point_against_brute_force():
+    """cyl_point (the closed form behind sphere / capsule against cylinder) against a dense sampling of the cylinder's surface:
+    distance and nearest point for points outside (side, caps, rims) and inside."""
+    import ctypes
+    from oracle.physics_ref import build
+    L = ctypes.CDLL(build())
+    dp = ctypes.POINTER(ctypes.c_double)
+    L.or_cyl_point.restype = ctypes.c_int
+    L.or_cyl_point.argtypes = [dp, dp, ctypes.c_double, dp, dp, dp, dp]
+    _c = lambda a: np.ascontiguousarray(a, float)
+    _p = lambda a: a.ctypes.data_as(dp)
+    rs = np.random.RandomState(2)
+    for trial in range(40):
+        p0, d = rs.standard_normal(3), rs.standard_normal(3) * rs.uniform(0.2, 1.5)
+        r = rs.uniform(0.1, 0.8)
+        Lc = np.linalg.norm(d); u = d / Lc
+        e1 = np.cross(u, [1.0, 0, 0]); e1 /= np.linalg.norm(e1); e2 = np.cross(u, e1)
+        # surface samples: side, two caps
+        th = np.linspace(0, 2 * np.pi, 400, endpoint=False)
+        zz = np.linspace(0, Lc, 200)
+        side = (p0 + zz[:, None, None] * u + r * (np.cos(th)[None, :, None] * e1 + np.sin(th)[None, :, None] * e2)).reshape(-1, 3)
+        rr = np.linspace(0, r, 60)
+        disk = (rr[:, None, None] * (np.cos(th)[None, :, None] * e1 + np.sin(th)[None, :, None] * e2)).reshape(-1, 3)
+        surf = np.concatenate([side, p0 + disk, p0 + d + disk])
+        for _ in range(6):
+            c = p0 + 0.5 * d + rs.standard_normal(3) * rs.choice([0.2, 1.0, 2.0])
+            q, n, ln = np.zeros(3), np.zeros(3), np.zeros(1)
+            assert L.or_cyl_point(_p(_c(p0)), _p(_c(d)), r, _p(_c(c)), _p(q), _p(n), _p(ln)) == 1
+            z, rho = (c - p0) @ u, np.linalg.norm((c - p0) - ((c - p0) @ u) * u)
+            inside = 0 < z < Lc and rho < r
+            brute = np.linalg.norm(surf - c, axis=1).min()
+            assert abs(abs(ln[0]) - brute) < 0.01 + 0.02 * brute and (ln[0] < 0) == inside
+            assert abs(np.linalg.norm(n) - 1) < 1e-12 and abs(np.linalg.norm(q - c) - abs(ln[0])) < 1e-12
+            np.testing.assert_allclose(c - q, n * ln[0], atol=1e-12)            # outside: n points at c; inside: away from it
+
+
+def test_sphere_and_capsule_rest_on_a_static_cylinder(tmp_path):
+    """A ball dropped on the flat top of a standing cylinder rests on it; a capsule laid across a lying cylinder balances on
+    its ridge for a while with one contact at the crossing, and a capsule lying ALONG the top cap rests on it with contacts
+    at its ends."""
+    cyl = '<geom name="post" type="cylinder" fromto="0 0 0 0 0 0.3" size="0.2" contype="1" conaffinity="1" condim="3" friction="0.8 0.005 0.0001"/>'
+    ball = """<body name="ball" pos="0.05 0.02 0.381"><freejoint/>
+      <geom name="b" type="sphere" size="0.08" density="900" contype="1" conaffinity="1" condim="3"/><site name="finger"/></body>"""
+    raw, ref = _model(tmp_path, cyl + ball)
+    assert [tuple(p) for p in raw.pairs] == [("b", "post")]
+    q, v = ref.qpos0.copy(), np.zeros(6)
+    for _ in range(600):
+        q, v, _, diag = ref.step(q, v, np.zeros(0))
+    assert diag[0] == 4 and 0.3795 < q[2] < 0.3801 and np.abs(v).max() < 1e-5          # on the cap: centre one radius above it
+    # beside the post: the ball touches the curved side and is pushed away horizontally (no gravity)
+    raw, ref = _model(tmp_path, cyl + ball.replace('pos="0.05 0.02 0.381"', 'pos="0.275 0 0.15"'), gravity="0 0 0", name="side.xml")
+    q, v = ref.qpos0.copy(), np.zeros(6)
+    q, v, _, diag = ref.step(q, v, np.zeros(0))
+    assert diag[0] == 4 and v[0] > 0 and abs(v[1]) < 1e-12 and abs(v[2]) < 1e-12
+    cap = """<body name="rod" pos="0 0 0.341"><freejoint/>
+      <geom name="r" type="capsule" fromto="-0.12 0 0 0.12 0 0" size="0.04" density="900" contype="1" conaffinity="1" condim="3"/><site name="finger"/></body>"""
+    raw, ref = _model(tmp_path, cyl + cap, name="rod.xml")
+    q, v = ref.qpos0.copy(), np.zeros(6)
+    for _ in range(600):
+        q, v, _, diag = ref.step(q, v, np.zeros(0))
+    assert diag[0] >= 8 and 0.3395 < q[2] < 0.3401 and np.abs(v).max() < 1e-5          # two or three contacts along the rod

@@ -527,3 +527,70 @@ def test_joint_margin_ref_and_geom_gap_match_the_oracle(tmp_path):
     q1, v1, _, _ = ref.env_step(q, v, np.array([0.1, 0.5, -0.5]), tgt)
     np.testing.assert_allclose(got["qp"], q1, rtol=0, atol=1e-11)
     assert eng.solver_failures() == 0 and ref.newton_stats()["fails"] == 0
+
+
+CYL_PAIRS = """<mujoco><compiler angle="radian" coordinate="local" inertiafromgeom="auto"/>
+<option timestep="0.002" gravity="0 0 -9.81" integrator="Euler" %s/>
+<default><geom contype="0" conaffinity="0" condim="3" friction="0.7 0.005 0.0001" margin="0.003"/></default>
+<worldbody><site name="target" pos="0 0 0"/>
+  <geom name="floor" type="plane" pos="0 0 0" size="5 5 0.1" conaffinity="1"/>
+  <geom name="post" type="cylinder" fromto="0 0 0 0 0 0.25" size="0.12"/>
+  <body name="pusher" pos="-0.4 0 0.1"><joint name="push" type="slide" axis="1 0 0" range="-0.1 0.5" limited="true" damping="2"/>
+    <geom name="tip" type="capsule" fromto="0 0 0 0.15 0 0" size="0.025" density="800"/></body>
+  <body name="puck" pos="0.4 0 0.2"><freejoint name="puck_free"/>
+    <geom name="puck" type="cylinder" fromto="0 -0.05 0 0 0.05 0" size="0.07" density="700" contype="1"/></body>
+  <body name="ball" pos="0.02 0.01 0.34"><freejoint name="ball_free"/>
+    <geom name="ball" type="sphere" size="0.06" density="900" contype="1"/></body>
+  <body name="rod" pos="0.4 0.02 0.33"><freejoint name="rod_free"/>
+    <geom name="rod" type="capsule" fromto="-0.1 0 0 0.1 0 0" size="0.03" density="900" contype="1"/><site name="finger"/></body>
+</worldbody>
+<contact><pair geom1="ball" geom2="post"/><pair geom1="puck" geom2="rod"/><pair geom1="tip" geom2="post"/><pair geom1="puck" geom2="ball"/></contact>
+<actuator><motor joint="push" gear="20" ctrlrange="-1 1" ctrllimited="true"/></actuator></mujoco>"""
+
+
+@pytest.mark.parametrize("option", ["", 'cone="elliptic" impratio="3"'])
+def test_spheres_and_capsules_against_cylinders_match_the_oracle(tmp_path, option):
+    """Round 5: sphere / capsule against cylinder, in both geom orders, against a static and a moving cylinder (a ball on a
+    post's cap and beside it, a rod lying on / across / inside a puck, a capsule pushed into a post): one env step from 64
+    random states at 1e-9 under pyramidal and elliptic cones, and a 32 x 8 rollout."""
+    from mjmpc_amd.envs.tree_engine import TreeRolloutEngine
+    from mjmpc_amd.models.mjcf import load_mjcf
+    from oracle.physics_ref import RefArm
+    (tmp_path / "cyl.xml").write_text(CYL_PAIRS % option)
+    raw = load_mjcf(str(tmp_path / "cyl.xml"), self_collision=False)
+    assert sorted(tuple(p) for p in raw.pairs) == [("ball", "post"), ("puck", "ball"), ("puck", "rod"), ("tip", "post")]
+    eng = TreeRolloutEngine(raw, dtype="f64")
+    ref = RefArm(raw.to_flat())
+    rs = np.random.RandomState(4)
+    tgt = np.asarray(raw.target_pos, float)
+    worst, rows = 0.0, 0
+    for k in range(64):
+        q, v = raw.qpos0.copy(), np.zeros(raw.nv)
+        # puck: on the floor or in the air near the rod / ball, any attitude; ball: on / beside / inside the post or at the puck;
+        # rod: around the puck; the pusher anywhere in its range (its tip reaches the post beyond 0.13)
+        q[0] = rs.uniform(-0.12, 0.52)
+        q[1:4] = [0.4, 0.0, 0.2] + rs.standard_normal(3) * [0.04, 0.04, 0.06]
+        q[4:8] = _quat(rs, rs.choice([0.0, 0.3, 2.0]))
+        where = rs.randint(3)
+        q[8:11] = ([0.0, 0.0, 0.31] if where == 0 else ([0.17, 0.0, 0.12] if where == 1 else q[1:4] + [0.0, 0.0, 0.12])) + rs.standard_normal(3) * 0.03
+        q[11:15] = _quat(rs, 1.0)
+        q[15:18] = q[1:4] + rs.standard_normal(3) * [0.06, 0.06, 0.08] + [0.0, 0.0, 0.06]
+        q[18:22] = _quat(rs, rs.choice([0.1, 2.0]))
+        v[:] = rs.standard_normal(raw.nv) * 0.5 * rs.choice([0.0, 1.0])
+        u = rs.uniform(-1.2, 1.2, 1)
+        eng.set_env_state(dict(qp=q, qv=v, target_pos=tgt))
+        _, rew, _, _, _, nobs = eng.rollout(1, 1, u[None], None, "open_loop")
+        q1, v1, r1, o1 = ref.env_step(q, v, u, tgt)
+        rows += ref.step(q, v, np.clip(u, -1, 1))[3][0]
+        worst = max(worst, np.abs(nobs[0, 0] - o1).max() / max(1.0, np.abs(o1).max()), abs(rew[0, 0] - r1) / max(1.0, abs(r1)))
+    print("cylinder pairs (%s): one env step from 64 random states (%d rows in all), worst relative error %.2e" % (option or "pyramidal", rows, worst))
+    assert worst < 1e-9 and rows > 300
+    P, H = 32, 8
+    eps = 0.8 * rs.standard_normal((P, H, 1))
+    q, v = raw.qpos0.copy(), np.zeros(raw.nv)
+    eng.set_env_state(dict(qp=q, qv=v, target_pos=tgt))
+    _, rew, _, _, _, nobs = eng.rollout(P, H, np.zeros((H, 1)), eps, "open_loop")
+    _, o_rew, _, _, o_nobs = ref.rollout(q, v, tgt, np.zeros((H, 1)), eps)
+    np.testing.assert_allclose(nobs, o_nobs, rtol=0, atol=1e-7)
+    np.testing.assert_allclose(rew, o_rew, rtol=1e-7, atol=1e-7)
+    assert eng.solver_failures() == 0 and ref.newton_stats()["fails"] == 0

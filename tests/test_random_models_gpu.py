@@ -133,22 +133,35 @@ def random_model(seed):
         k = int(rs5.randint(len(bodies)))
         pairs.append((bodies[k].geoms[0].name, "slab"))
         records += 3
-    if general and records + 4 <= 13 and rs5.rand() < 0.3:
+    if general and records + 4 <= 13 and rs5.rand() < 0.4:
         k = int(rs5.randint(len(bodies)))
         ax = rs5.standard_normal(3)
         ax *= float(rs5.uniform(0.02, 0.06)) / np.linalg.norm(ax)
         bodies[k].geoms.append(RawGeom(GEOM_CYLINDER, float(rs5.uniform(0.02, 0.05)), tuple(-ax), tuple(ax), density=600.0, margin=0.002,
                                        name="cyl%d" % k, friction=0.6, condim=3, collide=True))
         records += 4
+        if records + 3 <= 12 and rs5.rand() < 0.8:      # ... and against a static capsule (three records) or sphere (one) beside the tree
+            kind = GEOM_CAPSULE if rs5.rand() < 0.6 else GEOM_SPHERE
+            world_geoms.append(RawGeom(kind, 0.05, (0.25, -0.2, 0.12), (0.25, 0.2, 0.2), name="bar", friction=0.5, condim=3, margin=0.002))
+            pairs.append(("cyl%d" % k, "bar"))
+            records += 3 if kind == GEOM_CAPSULE else 1
+    elif general and records + 3 <= 12 and rs5.rand() < 0.5:
+        # a static cylinder (a post) that the first capsule or sphere of a body may meet
+        k = int(rs5.randint(len(bodies)))
+        g0 = bodies[k].geoms[0]
+        if g0.type in (GEOM_CAPSULE, GEOM_SPHERE) and g0.name:
+            world_geoms.append(RawGeom(GEOM_CYLINDER, 0.08, (0.2, 0.1, 0.0), (0.2, 0.1, 0.5), name="post", friction=0.7, condim=3, margin=0.002))
+            pairs.append((g0.name, "post"))
+            records += 3 if g0.type == GEOM_CAPSULE else 1
     if want_box:
         k = int(rs.randint(len(bodies)))
         bodies[k].geoms.append(RawGeom(GEOM_BOX, 0.0, (0.0, 0.0, 0.0), (0.04, 0.03, 0.02), density=700.0, margin=0.002, name="box%d" % k,
                                        friction=0.5, condim=3, collide=True, quat=tuple(_quat(rs, 0.5))))
-        if world_geoms and records + 4 <= 16 and rs5.rand() < 0.7:      # round 5: ... and against the static slab (box-box: four records)
+        if any(g.name == "slab" for g in world_geoms) and records + 4 <= 16 and rs5.rand() < 0.7:      # round 5: ... and against the static slab (box-box: four records)
             pairs.append(("box%d" % k, "slab"))
             records += 4
     elif general and records + 4 <= 14 and (seed % 5 == 2 or (world_geoms and rs5.rand() < 0.4)):
-        if not world_geoms:
+        if not any(g.name == "slab" for g in world_geoms):
             world_geoms.append(RawGeom(GEOM_BOX, 0.0, (0.3, 0.0, 0.1), (0.3, 0.3, 0.1), name="slab", friction=0.6, condim=3, margin=0.002,
                                        quat=tuple(_quat(rs5, 0.2))))
         k = int(rs5.randint(len(bodies)))
