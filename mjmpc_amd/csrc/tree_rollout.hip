@@ -2649,7 +2649,9 @@ __global__ __launch_bounds__(64 * wg_waves(DP, FRIC, sizeof(T), PL), min_waves(s
             TSYNC();
             const bool any_rows = !(TREE_SKIP & 1) && (__any(inst || cinst != 0) || any_floss);
             T qfrc_c = T(0);
-            T acc_fwd = T(0);            // mj_forward's acceleration (the constraint solver's) where the wavefront has rows
+            // mj_forward's acceleration (the constraint solver's) where the wavefront has rows: what mj_checkAcc looks at - kept as
+            // the two tests' outcomes, not as a value that would stay live through the Euler solve
+            bool fwd_bad = false, fwd_odd = false;
             T erow[MERGE ? DP : 1];      // factor of the Euler matrix when it was computed beside the first Newton factor
             clk.mark(3);
             clk.count(8, 1);
@@ -3267,7 +3269,8 @@ __global__ __launch_bounds__(64 * wg_waves(DP, FRIC, sizeof(T), PL), min_waves(s
                 if constexpr (GEN) fl_mem = floss > T(0) ? (1 | ((fstate + 1) << 1)) : 0;
                 cinst_mem = cinst;
                 cact_mem = cact;
-                acc_fwd = xa;
+                fwd_bad = !(fabs(xa) <= MJ_MAXVAL);
+                fwd_odd = !(fabs(h * xa) <= T(1e5));
                 qfrc_c = actv ? -D * (sig * xa - aref) * sig : T(0);
                 if constexpr (!FRIC) {
                     for (unsigned um = ucinst; um; um &= um - 1) {
@@ -3313,7 +3316,7 @@ __global__ __launch_bounds__(64 * wg_waves(DP, FRIC, sizeof(T), PL), min_waves(s
             // mj_checkAcc: a NaN or an entry beyond mjMAXVAL in the acceleration mj_forward arrived at - the constraint solver's
             // where the wavefront had rows (for a particle without rows of its own that is M^-1 qfrc_smooth, as in MuJoCo),
             // else the Euler solve's (M + h B)^-1 qfrc_smooth, which stands in for M^-1 qfrc_smooth
-            const bool acc_bad = rst && dof && !(fabs(any_rows ? acc_fwd : qacc) <= MJ_MAXVAL);
+            const bool acc_bad = rst && dof && (any_rows ? fwd_bad : !(fabs(qacc) <= MJ_MAXVAL));
             if (!rst && diag) {  // (no reset record: one count per particle-substep whose acceleration has left the arithmetic)
                 const unsigned long long nf = __ballot(!(fabs(qacc) < T(sizeof(T) == 4 ? 1e30 : 1e100)));
                 if (l == 0 && ((unsigned)(nf >> (PL * half)) & (PL == 32 ? ~0u : 0xFFFFu)) != 0u) atomicAdd(diag + 1, 1u);
@@ -3336,21 +3339,27 @@ __global__ __launch_bounds__(64 * wg_waves(DP, FRIC, sizeof(T), PL), min_waves(s
                     }
                 }
             }
-            // ONE wave-level test guards everything rare about the integration: a hinge step beyond the reach of the angle-
-            // addition series (|dq| > 0.25 rad), and MuJoCo's reset on instability - a NaN or an entry beyond mjMAXVAL = 1e10 in
-            // the acceleration or the integrated state can only come about through a velocity jump h |qacc| beyond 1e3 (1e10 h
-            // is 1e6 or more for any time step of 1e-4 s or more; a NaN fails every <=), so the exact tests run behind it
-            bool odd = dof && !(fabs(h * qacc) <= T(1e3));
-            if (any_rows) odd = odd || (dof && !(fabs(h * acc_fwd) <= T(1e3)));
+            // Two wave-level tests guard what is rare about the integration.  `big`: a hinge step beyond the reach of the angle-
+            // addition series (|dq| > 0.25 rad).  `chk`: MuJoCo's reset on instability - a NaN or an entry beyond mjMAXVAL = 1e10
+            // in the acceleration or the integrated state can only come about through a velocity jump h |qacc| beyond 1e5 (1e10 h
+            // is 1e6 or more for any time step of 1e-4 s or more; a NaN fails every <=) or a coordinate step beyond 0.25, so the
+            // exact tests run behind it.  (Round 5's first version had ONE test, with the jump at 1e3, which also sent wavefronts
+            // down the full sin / cos path when only an acceleration was large: pen-in-hand 9.90 ms per 4096 x 32 launch, 9.82
+            // with the two tests apart, 9.67 with the emulation compiled out.)
+            bool odd_r = rst && dof && !(fabs(h * qacc) <= T(1e5));
+            if (any_rows) odd_r = odd_r || (rst && dof && fwd_odd);
+            bool odd = false;
             const bool angle = dof && !(GEN && ball_g >= 0);        // my coordinate integrates as q += h v
             T dq = T(0);
             if (dof) v += h * qacc;
             if (angle) {
                 dq = h * v;
                 q += dq;
-                odd = odd || (!slide && !(fabs(dq) <= T(0.25)));
+                odd = !slide && !(fabs(dq) <= T(0.25));
+                odd_r = odd_r || (rst && !(fabs(dq) <= T(0.25)));
             }
             const bool big = __any(odd);
+            const bool chk = rst && __any(odd_r);
             if (__builtin_expect(big, 0)) {
                 if (angle) sincos_(q, sq, cq);
             } else if (angle) {
@@ -3361,7 +3370,7 @@ __global__ __launch_bounds__(64 * wg_waves(DP, FRIC, sizeof(T), PL), min_waves(s
                 sq = s1 * kk;
                 cq = c1 * kk;
             }
-            if (rst && __builtin_expect(big, 0)) {
+            if (__builtin_expect(chk, 0)) {
                 const unsigned long long bb = __ballot(acc_bad || state_is_bad());
                 if (bb != 0ull) {
                     rst_any = true;
