@@ -3521,18 +3521,28 @@ hipError_t launch_tree_rollout_dense(int max_path, int nv, int gen, const T* mod
         else MJMPC_TREE_LAUNCH_D(32, 16, true, 32, 32, 0)
     }
     else if (gen >= 2) {
-        if (max_path <= 8 && nv <= 8) MJMPC_TREE_LAUNCH_D(8, 16, true, 16, 8, 2)
+        if (max_path <= 4 && nv <= 4) MJMPC_TREE_LAUNCH_D(4, 16, true, 16, 4, 2)
+        else if (max_path <= 8 && nv <= 8) MJMPC_TREE_LAUNCH_D(8, 16, true, 16, 8, 2)
         else if (max_path <= 8 && nv <= 12) MJMPC_TREE_LAUNCH_D(8, 16, true, 16, 12, 2)
         else if (max_path <= 8) MJMPC_TREE_LAUNCH_D(8, 16, true, 16, 16, 2)
         else MJMPC_TREE_LAUNCH_D(16, 16, true, 16, 16, 2)
     }
     else if (gen) {          // the general instantiation comes in four sizes (measured, 4096 x 32 f64: cart-pole 0.95 -> 0.68 ms and door 1.55 -> 1.22 ms with rows of 8 instead of 16)
+        // (round 5: rows and paths of 4 for models of up to four dofs - cart-pole 0.65 -> 0.54 ms, door 1.25 -> 1.09, f32 cart-pole
+        // 0.44 -> 0.36; eight record slots instead of sixteen on top of that: no change, not kept)
+        if (max_path <= 2 && nv <= 2) MJMPC_TREE_LAUNCH_D(2, 16, true, 16, 2, 1)         // (... and of 2: cart-pole 0.54 -> 0.475 ms, f32 0.365 -> 0.32)
+        else if (max_path <= 4 && nv <= 4) MJMPC_TREE_LAUNCH_D(4, 16, true, 16, 4, 1)
+        else
         if (max_path <= 8 && nv <= 8) MJMPC_TREE_LAUNCH_D(8, 16, true, 16, 8, 1)
         else if (max_path <= 8 && nv <= 12) MJMPC_TREE_LAUNCH_D(8, 16, true, 16, 12, 1)
         else if (max_path <= 8) MJMPC_TREE_LAUNCH_D(8, 16, true, 16, 16, 1)
+        else if (max_path <= 10 && nv <= 10) MJMPC_TREE_LAUNCH_D(10, 16, true, 16, 10, 1)      // (... tray, 10 dofs on paths of 10: 2.97 -> 2.74 ms, f32 1.37 -> 1.29)
+        else if (max_path <= 12 && nv <= 12) MJMPC_TREE_LAUNCH_D(12, 16, true, 16, 12, 1)      // (round 5: tray 3.52 -> 2.99 ms, f32 1.59 -> 1.37)
         else MJMPC_TREE_LAUNCH_D(16, 16, true, 16, 16, 1)
     }
     else if (max_path <= 8 && nv <= 8) MJMPC_TREE_LAUNCH_D(8, 16, true, 16, 8, 0)
+    // (paths of 6 instead of 8 for the cheetah: 1 %, not kept)
+    else if (max_path <= 8 && nv <= 10) MJMPC_TREE_LAUNCH_D(8, 16, true, 16, 10, 0)    // (round 5: HalfCheetah, 9 dofs: 2.29 -> 2.16 ms, f32 2.06 -> 1.92, with rows of 10 instead of 12)
     else if (max_path <= 8 && nv <= 12) MJMPC_TREE_LAUNCH_D(8, 16, true, 16, 12, 0)
     else if (max_path <= 8) MJMPC_TREE_LAUNCH_D(8, 16, true, 16, 16, 0)
     else MJMPC_TREE_LAUNCH_D(16, 16, true, 16, 16, 0)
@@ -3550,6 +3560,7 @@ hipError_t launch_tree_rollout_cone(int max_path, int nv, const T* model, const 
         if (max_path <= 16) MJMPC_TREE_LAUNCH_D(16, 16, true, 32, 32, 3)       // dense over the particle's 32 lanes
         else MJMPC_TREE_LAUNCH_G(32, 16, true, 32, 3)                          // tree-sparse (elimination paths beyond 16 links)
     }
+    else if (max_path <= 4 && nv <= 4) MJMPC_TREE_LAUNCH_D(4, 16, true, 16, 4, 3)
     else if (max_path <= 8 && nv <= 8) MJMPC_TREE_LAUNCH_D(8, 16, true, 16, 8, 3)
     else if (max_path <= 8 && nv <= 12) MJMPC_TREE_LAUNCH_D(8, 16, true, 16, 12, 3)
     else if (max_path <= 8) MJMPC_TREE_LAUNCH_D(8, 16, true, 16, 16, 3)
