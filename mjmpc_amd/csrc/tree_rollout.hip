@@ -383,7 +383,7 @@ __device__ __forceinline__ void path_sum(T* x, const Topo& tp, T* X, int l) {
 
 // x[c] <- sum over my subtree (myself included) of x[c]; subtree = links [l, l + subsize): doubling tables in two
 // LDS buffers of NC x 32, the blocks of sizes 2^k that tile the range are added as the tables appear
-template <int NC, int PL, typename T>
+template <int NC, int PL, int NL = 32, typename T>
 __device__ __forceinline__ void subtree_sum(T* x, const Topo& tp, T* X, int l) {
     static_assert(NC <= 6, "two buffers of NC x PL must fit the 12 x PL exchange area");
     if constexpr (TREE_DPP_SUBTREE) {
@@ -396,15 +396,23 @@ __device__ __forceinline__ void subtree_sum(T* x, const Topo& tp, T* X, int l) {
         const int end = l + tp.subsize;
 #pragma unroll
         for (int c = 0; c < NC; ++c) {
+            // (round 5: shifts beyond the instantiation's link count NL move nothing - compiled out: a chain of two links takes
+            // one of the four steps.  As wave-uniform run-time branches on the model's link count they cost the cheetah 1.5 %)
             T s = x[c];
             T t = dpp_zero<0x101>(s);
             s += l + 1 < tp.seg_end ? t : T(0);
-            t = dpp_zero<0x102>(s);
-            s += l + 2 < tp.seg_end ? t : T(0);
-            t = dpp_zero<0x104>(s);
-            s += l + 4 < tp.seg_end ? t : T(0);
-            t = dpp_zero<0x108>(s);
-            s += l + 8 < tp.seg_end ? t : T(0);
+            if constexpr (NL > 2) {
+                t = dpp_zero<0x102>(s);
+                s += l + 2 < tp.seg_end ? t : T(0);
+            }
+            if constexpr (NL > 4) {
+                t = dpp_zero<0x104>(s);
+                s += l + 4 < tp.seg_end ? t : T(0);
+            }
+            if constexpr (NL > 8) {
+                t = dpp_zero<0x108>(s);
+                s += l + 8 < tp.seg_end ? t : T(0);
+            }
             if constexpr (PL == 32) {
                 const T other = bcast_row<0>(swap_rows(s));     // lane 0 of the particle's OTHER row, in every lane of mine
                 s += (l < 16 && tp.seg_end > 16) ? other : T(0);
@@ -1623,6 +1631,7 @@ __global__ __launch_bounds__(64 * wg_waves(DP, FRIC, sizeof(T), PL), min_waves(s
                   A_ROW2 = a_row2(DP, NS, NJ, PL, CS), A_LEN = a_len(DP, NS, NJ, PL, sizeof(T), DN, CS);
     static_assert(DN == 0 || (PL == 16 && DN <= 16 && DP <= DN) || (PL == 32 && DN == 32), "dense rows: one particle = one DPP row, or two (DN = 32)");
     constexpr bool MERGE = merge_factor(DP, FRIC, sizeof(T), PL, DN);
+    constexpr int NLINKS = (DN > 0 && DN < PL) ? DN : PL;       // a dense instantiation's models have at most DN links
     constexpr int NBLOB = T_TOPO;           // the constants the loop reads; topology tables are read once, from global memory
     __shared__ __attribute__((aligned(16))) T lds[NBLOB + 1 + PPW * WG_WAVES * A_LEN];
     __shared__ int ELIM[(PL - 1) * PL];     // elimination lists
@@ -2404,7 +2413,7 @@ __global__ __launch_bounds__(64 * wg_waves(DP, FRIC, sizeof(T), PL), min_waves(s
                     if (mass > T(0))
                         for (int k = 0; k < 3; ++k) { f[k] -= wt[k] + t3[k]; f[3 + k] -= wf[k]; }
                 }
-                subtree_sum<6, PL>(f, tp, X, l);
+                subtree_sum<6, PL, NLINKS>(f, tp, X, l);
                 bias = dot3(sw, f) + dot3(sv, f + 3);
             }
 
@@ -2417,8 +2426,8 @@ __global__ __launch_bounds__(64 * wg_waves(DP, FRIC, sizeof(T), PL), min_waves(s
             T md[DN > 0 ? DN : 1];
             {
                 T c6[6] = {Ib[0], Ib[1], Ib[2], Ib[3], Ib[4], Ib[5]}, c4[4] = {mass, hm[0], hm[1], hm[2]};
-                subtree_sum<6, PL>(c6, tp, X, l);
-                subtree_sum<4, PL>(c4, tp, X, l);
+                subtree_sum<6, PL, NLINKS>(c6, tp, X, l);
+                subtree_sum<4, PL, NLINKS>(c4, tp, X, l);
                 T F[6], t1[3], t2[3];
                 symv3(c6, sw, F);
                 cross3(c4 + 1, sv, t1);
