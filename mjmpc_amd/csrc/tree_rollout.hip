@@ -3549,7 +3549,11 @@ hipError_t launch_tree_rollout_dense(int max_path, int nv, int gen, const T* mod
         else if (max_path <= 12 && nv <= 12) MJMPC_TREE_LAUNCH_D(12, 16, true, 16, 12, 1)      // (round 5: tray 3.52 -> 2.99 ms, f32 1.59 -> 1.37)
         else MJMPC_TREE_LAUNCH_D(16, 16, true, 16, 16, 1)
     }
+    // (... and the reference's two vendored locomotion models at their own sizes: Swimmer-v0, 7 dofs on a path of 7: 1.00 -> 0.97 ms;
+    // HalfCheetah-v0, 9 dofs: 2.14 -> 2.07, f32 1.92 -> 1.87)
+    else if (max_path <= 7 && nv <= 7) MJMPC_TREE_LAUNCH_D(7, 16, true, 16, 7, 0)
     else if (max_path <= 8 && nv <= 8) MJMPC_TREE_LAUNCH_D(8, 16, true, 16, 8, 0)
+    else if (max_path <= 8 && nv <= 9) MJMPC_TREE_LAUNCH_D(8, 16, true, 16, 9, 0)
     // (paths of 6 instead of 8 for the cheetah: 1 %, not kept)
     else if (max_path <= 8 && nv <= 10) MJMPC_TREE_LAUNCH_D(8, 16, true, 16, 10, 0)    // (round 5: HalfCheetah, 9 dofs: 2.29 -> 2.16 ms, f32 2.06 -> 1.92, with rows of 10 instead of 12)
     else if (max_path <= 8 && nv <= 12) MJMPC_TREE_LAUNCH_D(8, 16, true, 16, 12, 0)
