@@ -57,7 +57,8 @@ constexpr int TREE_MAXIT_LS = 100;
 #define TREE_DPP_SUBTREE 1
 #endif
 // developer switch for phase timing (tools/tree_time.py with a build -DTREE_SKIP=bits): 1 = no Newton iteration,
-// 2 = no Euler factor/solve, 4 = no mass-matrix assembly, 8 = no bias forces.  Product builds: 0.
+// 2 = no Euler factor/solve, 4 = no mass-matrix assembly, 8 = no bias forces, 16 = the constraint stage without its iterations,
+// 32 = with exactly one.  Product builds: 0.
 #ifndef TREE_SKIP
 #define TREE_SKIP 0
 #endif
@@ -1760,9 +1761,18 @@ __global__ __launch_bounds__(64 * wg_waves(DP, FRIC, sizeof(T), PL), min_waves(s
     const T jmargin = (GEN && dof) ? model[T_JMARGIN + l] : T(0);               // MJCF joint margin: my limit row exists while dist < margin
     const bool any_floss = GEN && __any(floss > T(0));
     const int dofcls = (int)model[T_DOFCLS + l];                                // my dof's solver sets: limit row | friction-loss row << 3
-    T fsol[7];                                                                  // friction-loss rows' solver set
+    // my dof's friction-loss row (J = e_l, position 0): its D is the impedance at 0 - a constant of the model, worked out here once
+    // (round 5; it was recomputed every substep from seven registers of solver parameters) - and its reference acceleration -B v
+    T Df0 = T(0), fB = T(0);
+    if constexpr (GEN) {
+        T fsol[7];
 #pragma unroll
-    for (int k = 0; k < 7; ++k) fsol[k] = GEN ? model[T_SOLTAB + 7 * (dofcls >> 3) + k] : T(0);
+        for (int k = 0; k < 7; ++k) fsol[k] = model[T_SOLTAB + 7 * (dofcls >> 3) + k];
+        T unused;
+        tree_row_params(fsol, T(0), model[T_DOF_INVW + l], T(0), Df0, unused);
+        Df0 = floss > T(0) ? Df0 : T(0);
+        fB = fsol[1];
+    }
 
     T q = dof ? (T)state[l] : T(0), v = dof ? (T)state[TL + l] : T(0);
     T qy = T(0), qz = T(0), qw = T(1);
@@ -2741,8 +2751,8 @@ __global__ __launch_bounds__(64 * wg_waves(DP, FRIC, sizeof(T), PL), min_waves(s
                 T Df = T(0), areff = T(0);
                 int fstate = 0;                     // -1: r <= -R f (force +f), 0: quadratic zone, +1: r >= R f (force -f)
                 if (GEN && any_floss) {
-                    tree_row_params(fsol, T(0), M[T_DOF_INVW + l], v, Df, areff);
-                    Df = floss > T(0) ? Df : T(0);
+                    Df = Df0;
+                    areff = -fB * v;
                     fstate = (fl_mem & 1) ? (fl_mem >> 1) - 1 : 0;
                     fstate = floss > T(0) ? fstate : 0;
                 }
@@ -2950,6 +2960,7 @@ __global__ __launch_bounds__(64 * wg_waves(DP, FRIC, sizeof(T), PL), min_waves(s
                 T xa = T(0);
                 clk.lap(-1);
                 for (int it = 0; it < (FRIC ? TREE_MAXIT_LS : TREE_MAXIT); ++it) {
+                    if ((TREE_SKIP & 16) || ((TREE_SKIP & 32) && it == 1)) { changed = false; break; }      // (developer timing: no iteration / one)
                     T hrow[DP];
                     T hd[DN > 0 ? DN : 1], hdinv = T(1);        // DN > 0: my dense row of H, then of its factor
                     const T Dfq = (GEN && fstate == 0) ? Df : T(0);     // the friction-loss row in its quadratic zone
