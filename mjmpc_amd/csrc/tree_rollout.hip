@@ -1524,8 +1524,12 @@ __device__ __noinline__ T exact_line_search(T g0, T dg, T Dl, T rl, T drl, T Dc,
 // root once it is on the root's piece.  D0 = the normal row's D, ir = impratio (tangent rows: D0 ir), fr the friction
 // coefficient, mu = fr / sqrt(ir).
 template <int PL, int NR, typename T>
-__device__ __noinline__ T cone_line_search(T g0, T dg, T Dl, T rl, T drl, T Dc, const T* rb, const T* drb, const T* Dk, bool bil,
-                                           T Df, T ff, T rf, T drf, bool ell, T fr, T ir, T mu, bool& at_floor) {
+__device__ __noinline__ T cone_line_search(T g0, T dg, T Dl, T rl, T drl, T Dc, T rb0, T rb1, T rb2, T rb3, T drb0, T drb1, T drb2, T drb3,
+                                           T Dk0, T Dk1, T Dk2, T Dk3, bool bil, T Df, T ff, T rf, T drf, bool ell, T fr, T ir, T mu) {
+    // (the rows arrive BY VALUE and the floor flag leaves as a negative return: arrays behind pointers and a flag behind a
+    // reference would live in scratch memory on both sides of this call)
+    const T rb[4] = {rb0, rb1, rb2, rb3}, drb[4] = {drb0, drb1, drb2, drb3}, Dk[4] = {Dk0, Dk1, Dk2, Dk3};
+    bool at_floor;
     // (no lane-dependent branch in here: the lane sums below are DPP exchanges, every lane of the particle must arrive at
     // them together - the cone's and the plain rows' parts are both computed and one selected)
     auto phi = [&](T al, T& curv) -> T {
@@ -1554,7 +1558,7 @@ __device__ __noinline__ T cone_line_search(T g0, T dg, T Dl, T rl, T drl, T Dc, 
 #pragma unroll
         for (int k = 0; k < NR; ++k) {
             const T rr = rb[k] + al * drb[k];
-            const T Dr = Dk ? Dk[k] : Dc;
+            const T Dr = Dk[k];
             const bool on = bil || rr < T(0);
             tr += Dr * (on ? rr : T(0)) * drb[k];
             cr += on ? Dr * drb[k] * drb[k] : T(0);
@@ -1593,7 +1597,7 @@ __device__ __noinline__ T cone_line_search(T g0, T dg, T Dl, T rl, T drl, T Dc, 
             done = fabs(fn) <= tol || !(hi - lo > T(sizeof(T) == 4 ? 1e-7 : 1e-16));
         }
     }
-    return al;
+    return at_floor ? T(-1) : al;           // (at the floor: the full step, flagged)
 }
 
 // waves per SIMD the register allocation aims at: the lean kernels for short paths fit three (f32) / two (f64)
@@ -3122,8 +3126,10 @@ __global__ __launch_bounds__(64 * wg_waves(DP, FRIC, sizeof(T), PL), min_waves(s
                                         T Dk3[NR];
 #pragma unroll
                                         for (int r = 0; r < NR; ++r) Dk3[r] = (Dk && r < 3) ? Dk[r] : Dc;
-                                        al = cone_line_search<PL, NR>(gbp, gNp - gbp, D, rl0, rl1 - rl0, Dc, rb, drb, (const T*)Dk3, my_bil,
-                                                                      Df, floss, a_b - areff, pv, my_ell && my_pt, ell_fr, ell_ir, ell_mu, at_floor);
+                                        al = cone_line_search<PL, NR>(gbp, gNp - gbp, D, rl0, rl1 - rl0, Dc, rb[0], rb[1 % NR], rb[2 % NR], rb[3 % NR],
+                                                                      drb[0], drb[1 % NR], drb[2 % NR], drb[3 % NR], Dk3[0], Dk3[1 % NR], Dk3[2 % NR], Dk3[3 % NR],
+                                                                      my_bil, Df, floss, a_b - areff, pv, my_ell && my_pt, ell_fr, ell_ir, ell_mu);
+                                        if (al < T(0)) { at_floor = true; al = T(1); }
                                     } else if constexpr (GEN) {
                                         const T* Dk = (my_pt && (my_kind == PT_CONNECT || my_kind == PT_WELD)) ? X + A_CS + l * CS + 15 : nullptr;
                                         T Dk3[NR];
