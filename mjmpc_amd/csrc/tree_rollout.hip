@@ -1488,15 +1488,17 @@ __device__ __forceinline__ ExtraContact<T> extra_geometry(int kind, LinkPose<T> 
 // 1/2 D r^2 on both sides), and every lane brings its friction-loss row (Df, bound ff, residual rf + al drf: the slope of
 // the Huber cost is D r clamped to +-ff).
 template <int PL, int NR, int GEN, typename T>
-__device__ __noinline__ T exact_line_search(T g0, T dg, T Dl, T rl, T drl, T Dc, const T* rb, const T* drb, const T* Dk, bool bil,
-                                            T Df, T ff, T rf, T drf) {
+__device__ __noinline__ T exact_line_search(T g0, T dg, T Dl, T rl, T drl, T Dc, T rb0, T rb1, T rb2, T rb3, T drb0, T drb1, T drb2, T drb3,
+                                            T Dk0, T Dk1, T Dk2, T Dk3, bool bil, T Df, T ff, T rf, T drf) {
+    // (the rows arrive by value, as in cone_line_search below: arrays behind pointers would keep the caller's copies in scratch)
+    const T rb[4] = {rb0, rb1, rb2, rb3}, drb[4] = {drb0, drb1, drb2, drb3}, Dk[4] = {Dk0, Dk1, Dk2, Dk3};
     auto phi = [&](T al) -> T {
         const T r = rl + al * drl;
         T tsum = Dl * (r < T(0) ? r : T(0)) * drl;
 #pragma unroll
         for (int k = 0; k < NR; ++k) {
             const T rr = rb[k] + al * drb[k];
-            if constexpr (GEN) tsum += (Dk ? Dk[k] : Dc) * ((bil || rr < T(0)) ? rr : T(0)) * drb[k];
+            if constexpr (GEN) tsum += Dk[k] * ((bil || rr < T(0)) ? rr : T(0)) * drb[k];
             else tsum += Dc * (rr < T(0) ? rr : T(0)) * drb[k];
         }
         if constexpr (GEN) {
@@ -3135,10 +3137,12 @@ __global__ __launch_bounds__(64 * wg_waves(DP, FRIC, sizeof(T), PL), min_waves(s
                                         T Dk3[NR];
 #pragma unroll
                                         for (int r = 0; r < NR; ++r) Dk3[r] = (Dk && r < 3) ? Dk[r] : Dc;
-                                        al = exact_line_search<PL, NR, true>(gbp, gNp - gbp, D, rl0, rl1 - rl0, Dc, rb, drb, (const T*)Dk3, my_bil,
-                                                                             Df, floss, a_b - areff, pv);
+                                        al = exact_line_search<PL, NR, true>(gbp, gNp - gbp, D, rl0, rl1 - rl0, Dc, rb[0], rb[1 % NR], rb[2 % NR], rb[3 % NR],
+                                                                             drb[0], drb[1 % NR], drb[2 % NR], drb[3 % NR], Dk3[0], Dk3[1 % NR], Dk3[2 % NR],
+                                                                             Dk3[3 % NR], my_bil, Df, floss, a_b - areff, pv);
                                     } else {
-                                        al = exact_line_search<PL, NR, false>(gbp, gNp - gbp, D, rl0, rl1 - rl0, Dc, rb, drb, (const T*)nullptr, false,
+                                        al = exact_line_search<PL, NR, false>(gbp, gNp - gbp, D, rl0, rl1 - rl0, Dc, rb[0], rb[1 % NR], rb[2 % NR], rb[3 % NR],
+                                                                              drb[0], drb[1 % NR], drb[2 % NR], drb[3 % NR], Dc, Dc, Dc, Dc, false,
                                                                               T(0), T(0), T(0), T(0));
                                     }
                                     // a step below the working precision of the iterate (a base point on a kink of the
