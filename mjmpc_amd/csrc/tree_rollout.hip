@@ -1505,7 +1505,9 @@ __device__ __noinline__ T exact_line_search(T g0, T dg, T Dl, T rl, T drl, T Dc,
             const T sl = Df * (rf + al * drf);
             tsum += fmin(fmax(sl, -ff), ff) * drf;
         }
-        return g0 + al * dg + sum_lanes<PL>(tsum);
+        // (the first lane's value for every lane of the particle: the bisection's decisions must not differ between lanes -
+        // see cone_line_search, where they were seen to)
+        return __shfl(g0 + al * dg + sum_lanes<PL>(tsum), 0, PL);
     };
     T fhi = phi(T(1));
     if (!(fhi > T(0))) return T(1);
