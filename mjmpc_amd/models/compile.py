@@ -277,6 +277,8 @@ def compile_arm(raw: RawModel, overrides=None, base: "ArmModel" = None) -> ArmMo
         f["plane_n"][:] = n
         f["plane_d"][0] = n @ np.asarray(raw.plane.pos, float)
     tc, dr = raw.solref
+    if tc <= 0 or dr <= 0:
+        raise NotImplementedError("arm kernel: solref must be the standard (timeconst, dampratio) pair (direct stiffness / damping: the tree engine)")
     tc = max(tc, 2 * raw.timestep)                               # refsafe
     dmin, dmax, width, mid, power = raw.solimp
     if power < 1 or power != int(power) or power > 64:

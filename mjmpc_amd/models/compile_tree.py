@@ -632,15 +632,17 @@ def compile_tree(raw: RawModel, overrides=None, base: "TreeModel" = None) -> Tre
 
     def sol_values(solref, solimp):
         tc, dr = solref
-        if tc <= 0 or dr <= 0:
-            raise NotImplementedError("solref must be the standard (timeconst, dampratio) pair")
-        tc = max(tc, 2 * raw.timestep)                              # refsafe
+        if (tc > 0) != (dr > 0):
+            raise NotImplementedError("solref must be (timeconst, dampratio), both positive, or (-stiffness, -damping), both negative")
+        direct = tc <= 0                                            # MuJoCo's direct format (round 5): no refsafe clamp
+        if not direct:
+            tc = max(tc, 2 * raw.timestep)                          # refsafe
         dmin, dmax, width, mid, power = full_solimp(solimp)
         dmin, dmax = np.clip(dmin, MJ_MINIMP, MJ_MAXIMP), np.clip(dmax, MJ_MINIMP, MJ_MAXIMP)
         mid, width, power = np.clip(mid, MJ_MINIMP, MJ_MAXIMP), max(width, 0.0), max(power, 1.0)
         if power != int(power) or power > 64:
             raise NotImplementedError("solimp power must be an integer in [1, 64] (MuJoCo's default is 2), got %r" % (power,))
-        K, B = 1.0 / (dmax * dmax * tc * tc * dr * dr), 2.0 / (dmax * tc)
+        K, B = (-tc / (dmax * dmax), -dr / dmax) if direct else (1.0 / (dmax * dmax * tc * tc * dr * dr), 2.0 / (dmax * tc))
         if width <= 1e-15:                                          # MuJoCo getimpedance: a flat impedance
             dmin = dmax = 0.5 * (dmin + dmax)
             width = 1.0

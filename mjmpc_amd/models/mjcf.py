@@ -17,7 +17,8 @@ panda/tray_glass-v0.yml, sawyer/door-v0.yml, hand/*-v0.yml):
 * sphere, capsule, box and cylinder geoms (``fromto``, or ``size pos`` with ``quat`` / ``axisangle`` / ``euler``), ``density``,
   ``mass``, ``margin``, ``gap``, ``friction``, ``condim``, ``contype`` / ``conaffinity`` (what collides with the world plane and -
   ``self_collision`` - with other bodies is decided by MuJoCo's rule), ``solref`` / ``solimp`` / ``solmix`` / ``priority`` per geom (a contact's
-  set is mixed from its two geoms', mj_contactParam; up to eight distinct sets per model);
+  set is mixed from its two geoms', mj_contactParam; up to eight distinct sets per model; ``solref`` in the standard
+  format ``(timeconst, dampratio)`` or the direct one ``(-stiffness, -damping)``, round 5);
 * one world ``<geom type="plane">`` in any orientation, static sphere / capsule / box geoms on the world body (they
   collide with moving geoms through MuJoCo's contype / conaffinity rule or an explicit ``<pair>``), world and body
   ``<site>``s, ``<motor>`` / ``<position kp>`` / ``<velocity kv>`` / ``<general gainprm biasprm biastype=affine>`` actuators
@@ -486,8 +487,8 @@ def load_mjcf(path, hand_site="finger", target_site="target", frame_skip=2, task
             over["margin"] = float(pr.get("margin", "0")) - float(pr.get("gap", "0"))
         if pr.get("solref") is not None:
             over["solref"] = tuple(_floats(pr.get("solref"), 2))
-            if over["solref"][0] <= 0 or over["solref"][1] <= 0:
-                raise ValueError("solref must be the standard (timeconst, dampratio) pair")
+            if (over["solref"][0] > 0) != (over["solref"][1] > 0):
+                raise ValueError("solref must be (timeconst, dampratio), both positive, or (-stiffness, -damping), both negative")
         if pr.get("solimp") is not None:
             over["solimp"] = tuple(_floats(pr.get("solimp")))
         if over:
@@ -497,8 +498,9 @@ def load_mjcf(path, hand_site="finger", target_site="target", frame_skip=2, task
             if nm in every:
                 geom_solver.append(every[nm]._solver)
     for sets in (geom_solver, limit_solver, friction_solver):
-        if any(r[0] <= 0 or r[1] <= 0 for r, _ in sets):
-            raise ValueError("solref must be the standard (timeconst, dampratio) pair: negative (direct) values are not supported")
+        if any((r[0] > 0) != (r[1] > 0) for r, _ in sets):
+            # (MuJoCo replaces such a pair by the default with a warning; here it is an error)
+            raise ValueError("solref must be (timeconst, dampratio), both positive, or (-stiffness, -damping), both negative")
 
     def full_solimp(si):
         return tuple(si) + (0.9, 0.95, 0.001, 0.5, 2.0)[len(si):]
@@ -554,8 +556,8 @@ def load_mjcf(path, hand_site="finger", target_site="target", frame_skip=2, task
         tset = None
         if lim:
             tset = (tuple(_floats(t.get("solreflimit", "0.02 1"))), tuple(_floats(t.get("solimplimit", "0.9 0.95 0.001 0.5 2"))))
-            if tset[0][0] <= 0 or tset[0][1] <= 0:
-                raise ValueError("solref must be the standard (timeconst, dampratio) pair")
+            if (tset[0][0] > 0) != (tset[0][1] > 0):
+                raise ValueError("solref must be (timeconst, dampratio), both positive, or (-stiffness, -damping), both negative")
             if not limit_solver:
                 lsolref, lsolimp = tset             # (no limited joint: the tendons' set is the model's limit set)
                 limit_solver.append(tset)

@@ -78,7 +78,13 @@ def mix_contact_solver(a, b):
     else:
         w = 0.0 if ma < MINVAL else 1.0
     ia, ib = _solimp5(ia), _solimp5(ib)
-    return (tuple(w * x + (1 - w) * y for x, y in zip(ra, rb)), tuple(w * x + (1 - w) * y for x, y in zip(ia, ib)))
+    # solref: blended when both are in the standard format (timeconst, dampratio > 0), else - one of them gives stiffness and
+    # damping directly, as negative numbers - the element-wise minimum: the stiffer of the two
+    if ra[0] > 0 and rb[0] > 0:
+        ref = tuple(w * x + (1 - w) * y for x, y in zip(ra, rb))
+    else:
+        ref = tuple(float(min(x, y)) for x, y in zip(ra, rb))
+    return (ref, tuple(w * x + (1 - w) * y for x, y in zip(ia, ib)))
 
 
 JOINT_NDOF = {JOINT_HINGE: 1, JOINT_SLIDE: 1, JOINT_BALL: 3, JOINT_FREE: 6}

@@ -541,7 +541,10 @@ static void mix_solver(const double *a, const double *b, double *solref, double 
     else if (a[7] >= MJ_MINVAL && b[7] >= MJ_MINVAL) w = a[7] / (a[7] + b[7]);
     else if (a[7] < MJ_MINVAL && b[7] < MJ_MINVAL) w = 0.5;
     else w = a[7] < MJ_MINVAL ? 0.0 : 1.0;
-    for (int i = 0; i < 2; i++) solref[i] = w * a[i] + (1 - w) * b[i];
+    /* (priorities differ: the winner's set as it is, w is 0 or 1.)  Equal priorities: solref blended when both are in the
+     * standard format, else - direct stiffness / damping, negative - the element-wise minimum (mj_contactParam [EXT]) */
+    if (a[8] != b[8] || (a[0] > 0 && b[0] > 0)) { for (int i = 0; i < 2; i++) solref[i] = w * a[i] + (1 - w) * b[i]; }
+    else for (int i = 0; i < 2; i++) solref[i] = a[i] < b[i] ? a[i] : b[i];
     for (int i = 0; i < 5; i++) solimp[i] = w * a[2 + i] + (1 - w) * b[2 + i];
 }
 
@@ -989,10 +992,17 @@ static void row_params_set(const OrModel *m, const double *solref, const double 
     double R = (1 - imp) / imp * diagApprox;
     if (R < MJ_MINVAL) R = MJ_MINVAL;
     *D = 1 / R;
-    /* standard solref = (timeconst, dampratio); refsafe: timeconst >= 2*timestep */
-    double tc = solref[0], dr = solref[1];
-    if (tc < 2 * m->timestep) tc = 2 * m->timestep;
-    double b = 2 / (dmax * tc), kk = 1 / (dmax * dmax * tc * tc * dr * dr);
+    /* standard solref = (timeconst, dampratio); refsafe: timeconst >= 2*timestep.  Both entries negative (round 5): the DIRECT
+     * format (-stiffness, -damping) of mj_makeImpedance [EXT] - k = -solref[0] / dmax^2, b = -solref[1] / dmax, no refsafe */
+    double tc = solref[0], dr = solref[1], b, kk;
+    if (tc > 0) {
+        if (tc < 2 * m->timestep) tc = 2 * m->timestep;
+        b = 2 / (dmax * tc);
+        kk = 1 / (dmax * dmax * tc * tc * dr * dr);
+    } else {
+        kk = -solref[0] / (dmax * dmax);
+        b = -solref[1] / dmax;
+    }
     *aref = -b * jv - kk * imp * r;
 }
 /* minimise  1/2 (a - a_s)^T M (a - a_s) + sum_i s_i(J_i a - aref_i)

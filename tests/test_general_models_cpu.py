@@ -1132,3 +1132,40 @@ def test_sphere_and_capsule_rest_on_a_static_cylinder(tmp_path):
     for _ in range(600):
         q, v, _, diag = ref.step(q, v, np.zeros(0))
     assert diag[0] >= 8 and 0.3395 < q[2] < 0.3401 and np.abs(v).max() < 1e-5          # two or three contacts along the rod
+
+
+# ------------------------------------------------------------------------------------------ direct solref (round 5)
+def test_direct_solref_gives_stiffness_and_damping(tmp_path):
+    """solref = (-stiffness, -damping), MuJoCo's direct format [EXT: k = -solref[0] / dmax^2, b = -solref[1] / dmax, no refsafe
+    clamp]: a 2 kg mass on a vertical slide joint resting in its lower limit sinks in by m g (1 - d) dmax^2 / (d^2 k m) ... -
+    with a flat impedance d = dmax = 0.9 that is g (1 - d) / k - and twice the stiffness halves it; the standard format's
+    answer is different; a pair of mixed signs is refused."""
+    def sink(solref):
+        body = """<body name="m" pos="0 0 1"><joint name="z" type="slide" axis="0 0 1" limited="true" range="-0.1 0.5"
+            solreflimit="%s" solimplimit="0.9 0.9 0.001"/><geom type="sphere" size="0.05" mass="2"/><site name="finger"/></body>""" % solref
+        raw, ref = _model(tmp_path, body, extra='<actuator><motor joint="z" ctrlrange="-1 1" ctrllimited="true"/></actuator>', name="d%d.xml" % abs(hash(solref)))
+        q, v = np.array([-0.1]), np.zeros(1)
+        for _ in range(3000):
+            q, v, _, diag = ref.step(q, v, np.zeros(1))
+        assert abs(v[0]) < 1e-9 and diag[0] == 1
+        return -0.1 - q[0]
+    s1, s2 = sink("-2000 -200"), sink("-4000 -300")
+    assert abs(s1 - 9.81 * 0.1 / 2000) < 1e-9 and abs(s2 - 9.81 * 0.1 / 4000) < 1e-9
+    assert abs(sink("0.02 1") - s1) > 1e-5
+    with pytest.raises(ValueError, match="both negative"):
+        sink("-2000 1")
+
+
+def test_two_compilers_agree_on_direct_solref(tmp_path):
+    """compile_tree's K, B for direct-format sets = what the oracle works with (one substep from a state inside the limit and
+    in contact agrees - through the CPU-side consistency check: the blob's solver table)."""
+    body = """<geom name="floor" type="plane" size="2 2 0.1" contype="1" conaffinity="1" solref="-8000 -120"/>
+    <body name="m" pos="0 0 0.2"><joint name="z" type="slide" axis="0 0 1" limited="true" range="-0.1 0.5" solreflimit="-2000 -200"/>
+      <geom name="b" type="sphere" size="0.05" mass="2" contype="1" conaffinity="1" solref="-3000 -50"/><site name="finger"/></body>"""
+    raw, ref = _model(tmp_path, body, extra='<actuator><motor joint="z" ctrlrange="-1 1" ctrllimited="true"/></actuator>')
+    m = compile_tree(raw)
+    tab = m.field("soltab").reshape(-1, 7)
+    got = sorted((round(r[0], 6), round(r[1], 6)) for r in tab if r[0] != 0)
+    # limit row: k = 2000 / 0.95^2, b = 200 / 0.95 (default solimp dmax 0.95); contact: the element-wise minimum of the two geoms' sets
+    want = sorted([(round(2000 / 0.95 ** 2, 6), round(200 / 0.95, 6)), (round(8000 / 0.95 ** 2, 6), round(120 / 0.95, 6))])
+    assert all(any(abs(g[0] - w[0]) < 1e-6 * w[0] and abs(g[1] - w[1]) < 1e-6 * w[1] for g in got) for w in want), (got, want)

@@ -594,3 +594,37 @@ def test_spheres_and_capsules_against_cylinders_match_the_oracle(tmp_path, optio
     np.testing.assert_allclose(nobs, o_nobs, rtol=0, atol=1e-7)
     np.testing.assert_allclose(rew, o_rew, rtol=1e-7, atol=1e-7)
     assert eng.solver_failures() == 0 and ref.newton_stats()["fails"] == 0
+
+
+def test_direct_solref_matches_the_oracle(tmp_path):
+    """MuJoCo's direct solref format (-stiffness, -damping) on joint limits, on the floor and on a geom (round 5; the kernel sees
+    only the K and B the model compiler works out): one env step from 64 random states of the margin / ref / gap model at 1e-9."""
+    from mjmpc_amd.envs.tree_engine import TreeRolloutEngine
+    from mjmpc_amd.models.mjcf import load_mjcf
+    from oracle.physics_ref import RefArm
+    xml = MARGIN_REF_GAP.replace('<default><geom contype="1" conaffinity="1" condim="3" friction="0.8 0.005 0.0001"/></default>',
+                                 '<default><geom contype="1" conaffinity="1" condim="3" friction="0.8 0.005 0.0001"/>'
+                                 '<joint solreflimit="-900 -40"/></default>')
+    xml = xml.replace('<geom name="floor" type="plane" size="2 2 0.1" margin="0.002" gap="0.0005"/>',
+                      '<geom name="floor" type="plane" size="2 2 0.1" margin="0.002" gap="0.0005" solref="-20000 -250"/>')
+    xml = xml.replace('<geom name="tip" type="sphere" pos="0.16 0 0" size="0.025" margin="0.006" gap="0.004"/>',
+                      '<geom name="tip" type="sphere" pos="0.16 0 0" size="0.025" margin="0.006" gap="0.004" solref="-6000 -400"/>')
+    assert xml.count("solref") == 3
+    (tmp_path / "ds.xml").write_text(xml)
+    raw = load_mjcf(str(tmp_path / "ds.xml"), self_collision=False)
+    eng = TreeRolloutEngine(raw, dtype="f64")
+    ref = RefArm(raw.to_flat())
+    rs = np.random.RandomState(6)
+    tgt = np.asarray(raw.target_pos, float)
+    worst, rows = 0.0, 0
+    for k in range(64):
+        q = raw.qpos0 + rs.uniform(-1, 1, 3) * [0.22, 1.1, 1.3]
+        v = rs.standard_normal(3) * [0.5, 3.0, 3.0] * rs.choice([0.0, 1.0])
+        u = rs.uniform(-1.2, 1.2, 3) * [0.3, 1.0, 1.0]
+        eng.set_env_state(dict(qp=q, qv=v, target_pos=tgt))
+        _, rew, _, _, _, nobs = eng.rollout(1, 1, u[None], None, "open_loop")
+        q1, v1, r1, o1 = ref.env_step(q, v, u, tgt)
+        rows += ref.step(q, v, u)[3][0] > 0
+        worst = max(worst, np.abs(nobs[0, 0] - o1).max() / max(1.0, np.abs(o1).max()), abs(rew[0, 0] - r1) / max(1.0, abs(r1)))
+    print("direct solref: one env step from 64 random states (%d with rows), worst relative error %.2e" % (rows, worst))
+    assert worst < 1e-9 and rows > 20 and eng.solver_failures() == 0

@@ -212,10 +212,17 @@ def random_model(seed):
             records += 2
     plane = RawPlane(pos=(0.0, 0.0, 0.0), normal=(0.0, 0.0, 1.0), margin=0.002, friction=float(rs.uniform(0.3, 1.0)),
                      condim=3 if rs.rand() < 0.7 else 1)
+    # round 5: now and then the floor gives stiffness and damping directly (solref < 0); mixed with a geom's standard set the
+    # contact takes the element-wise minimum
+    plane_solref = None
+    if general and rs5.rand() < 0.2:
+        plane_solref = (-float(rs5.uniform(5e3, 5e4)), -float(rs5.uniform(50, 400)))
     # round 5: a third of the general models put their condim-3 contacts under ELLIPTIC cones, impratio 1 or not
     cone, impratio = "pyramidal", 1.0
     if general and rs5.rand() < 0.35:
         cone, impratio = "elliptic", float(rs5.choice([1.0, 1.0, 0.5, 3.0, 10.0]))
+    if plane_solref is not None:
+        plane.solref = plane_solref
     return RawModel(bodies=bodies, actuators=acts, site_body=len(bodies) - 1, site_pos=(0.05, 0.0, 0.0), target_pos=(0.3, 0.1, 0.4),
                     plane=plane, timestep=0.002, frame_skip=2, gravity=(0.0, 0.0, -9.81), pairs=pairs, equalities=equalities,
                     tendons=tendons, world_geoms=world_geoms, pair_params=pair_params, cone=cone, impratio=impratio)
