@@ -34,7 +34,7 @@ panda/tray_glass-v0.yml, sawyer/door-v0.yml, hand/*-v0.yml):
   collision, on a body with an explicit ``<inertial>``), ``<sensor>`` and ``<keyframe>`` sections (read by nobody here).
 
 Anything that would change the simulation and is not modelled raises ValueError, so that a model is never silently
-simulated wrongly (colliding meshes, mocap bodies, noslip iterations, disabled option flags, other solvers, activation
+simulated wrongly (colliding meshes, mocap bodies, noslip iterations, option flags that are not modelled, other solvers, activation
 dynamics ...); purely visual elements (asset, light, camera, material, rgba ...) are skipped.
 """
 import os
@@ -220,8 +220,10 @@ def load_mjcf(path, hand_site="finger", target_site="target", frame_skip=2, task
         raise ValueError("wind is not supported")
     if oget("solver", "Newton") != "Newton" or int(oget("noslip_iterations", "0")) != 0:
         raise ValueError("the Newton solver without noslip iterations is what is modelled")
-    if opt is not None and opt.find("flag") is not None and any(v != "enable" for v in opt.find("flag").attrib.values()):
-        raise ValueError("<option><flag>: only MuJoCo's default (all features enabled) is modelled")
+    # <option><flag>: what a flag switches off is taken out of the model below (_apply_flags); flags that would change the
+    # arithmetic in ways that are not modelled raise
+    flags = dict(opt.find("flag").attrib) if opt is not None and opt.find("flag") is not None else {}
+    _check_flags(flags)
     density, viscosity = float(oget("density", "0")), float(oget("viscosity", "0"))
     dfl = _Defaults(root)
 
@@ -629,8 +631,57 @@ def load_mjcf(path, hand_site="finger", target_site="target", frame_skip=2, task
         for e in sec:
             if e.get("name"):
                 sensors[e.get("name")] = float(e.get("noise", "0"))
-    return RawModel(sensors=sensors, bodies=bodies, actuators=acts, site_body=site_body, site_pos=site_pos, target_pos=target, plane=plane,
-                    timestep=timestep, frame_skip=frame_skip, gravity=gravity, solref=solref, solimp=full_solimp(solimp),
-                    solref_limit=lsolref, solimp_limit=full_solimp(lsolimp), density=density, viscosity=viscosity, cone=cone, impratio=impratio,
-                    task=task, ctrl_cost=ctrl_cost, obs_skip=obs_skip, pairs=pairs, pair_params=pair_params, world_geoms=world_geoms,
-                    equalities=equalities, tendons=tendons, solref_friction=fsolref, solimp_friction=full_solimp(fsolimp))
+    raw = RawModel(sensors=sensors, bodies=bodies, actuators=acts, site_body=site_body, site_pos=site_pos, target_pos=target, plane=plane,
+                   timestep=timestep, frame_skip=frame_skip, gravity=gravity, solref=solref, solimp=full_solimp(solimp),
+                   solref_limit=lsolref, solimp_limit=full_solimp(lsolimp), density=density, viscosity=viscosity, cone=cone, impratio=impratio,
+                   task=task, ctrl_cost=ctrl_cost, obs_skip=obs_skip, pairs=pairs, pair_params=pair_params, world_geoms=world_geoms,
+                   equalities=equalities, tendons=tendons, solref_friction=fsolref, solimp_friction=full_solimp(fsolimp))
+    return _apply_flags(raw, flags)
+
+
+# MJCF <option><flag> (mjtDisableBit / mjtEnableBit [EXT]).  "enable" by default: constraint, equality, frictionloss, limit,
+# contact, passive, gravity, clampctrl, warmstart, filterparent, actuation, refsafe, sensor, midphase; "disable" by default:
+# override, energy, fwdinv, sensornoise.
+_FLAGS_WITHOUT_EFFECT = ("warmstart", "energy", "fwdinv", "sensornoise", "sensor", "midphase")     # (the solver here runs to
+#   convergence from any start; energies, inverse dynamics and sensors are read by nobody; midphase only prunes)
+_FLAGS_MODELLED = ("constraint", "equality", "frictionloss", "limit", "contact", "gravity", "clampctrl", "actuation")
+
+
+def _check_flags(flags):
+    for k, v in flags.items():
+        if v not in ("enable", "disable"):
+            raise ValueError("<option><flag %s=%r>: enable or disable" % (k, v))
+        if k in _FLAGS_WITHOUT_EFFECT or k in _FLAGS_MODELLED:
+            continue
+        if k == "override" and v == "disable" or k in ("passive", "filterparent", "refsafe") and v == "enable":
+            continue
+        # override (contact parameters replaced by o_margin / o_solref / o_solimp), passive off (MuJoCo 2.0's Euler step keeps the
+        # implicit damping term while the damping force is gone), filterparent off (another collision set), refsafe off
+        raise ValueError("<option><flag %s=%r> is not modelled" % (k, v))
+
+
+def _apply_flags(raw, flags):
+    off = lambda k: flags.get(k, "enable") == "disable"        # noqa: E731
+    every = off("constraint")
+    if off("gravity"):
+        raw.gravity = (0.0, 0.0, 0.0)
+    if every or off("contact"):
+        raw.plane, raw.pairs, raw.pair_params = None, [], {}
+    if every or off("equality"):
+        raw.equalities = []
+    for b in raw.bodies:
+        if b.joint is None:
+            continue
+        if every or off("limit"):
+            b.joint.limited = False
+        if every or off("frictionloss"):
+            b.joint.frictionloss = 0.0
+    if every or off("limit"):
+        for t in raw.tendons:
+            t.limited = False
+    for a in raw.actuators:
+        if off("clampctrl"):
+            a.ctrllimited = False
+        if off("actuation"):
+            a.gear = 0.0                    # (mj_fwdActuation returns with no actuator force at all)
+    return raw

@@ -1169,3 +1169,41 @@ def test_two_compilers_agree_on_direct_solref(tmp_path):
     # limit row: k = 2000 / 0.95^2, b = 200 / 0.95 (default solimp dmax 0.95); contact: the element-wise minimum of the two geoms' sets
     want = sorted([(round(2000 / 0.95 ** 2, 6), round(200 / 0.95, 6)), (round(8000 / 0.95 ** 2, 6), round(120 / 0.95, 6))])
     assert all(any(abs(g[0] - w[0]) < 1e-6 * w[0] and abs(g[1] - w[1]) < 1e-6 * w[1] for g in got) for w in want), (got, want)
+
+
+# ------------------------------------------------------------------------------------------ <option><flag> (round 5)
+def test_option_flags_switch_parts_of_the_model_off(tmp_path):
+    """<option><flag>: gravity / contact / limit / frictionloss / equality / clampctrl / actuation / constraint "disable" take the
+    corresponding parts out of the model; flags nothing here depends on (warmstart, energy, fwdinv, sensornoise, midphase) are
+    accepted either way; override on, passive / filterparent / refsafe off and unknown flags are refused."""
+    body = """<geom name="floor" type="plane" size="2 2 0.1" contype="1" conaffinity="1"/>
+    <body name="a" pos="0 0 0.3"><joint name="j" type="hinge" axis="0 1 0" limited="true" range="-0.5 0.5" frictionloss="0.2"/>
+      <geom name="g" type="capsule" fromto="0 0 0 0.3 0 0" size="0.03" contype="1" conaffinity="1"/><site name="finger" pos="0.3 0 0"/></body>"""
+    acts = '<actuator><motor joint="j" gear="3" ctrlrange="-1 1" ctrllimited="true"/></actuator>'
+
+    def load(flag, name):
+        head = HEAD + ("<option><flag %s/></option>" % flag if flag else "")
+        xml = head + '<default><geom contype="0" conaffinity="0"/></default><worldbody><site name="target" pos="0 0 0"/>' + \
+            textwrap.dedent(body) + "</worldbody>" + acts + "</mujoco>"
+        (tmp_path / name).write_text(xml)
+        return load_mjcf(str(tmp_path / name), task=TASK_REACH)
+
+    plain = load("", "p.xml")
+    assert plain.plane is not None and plain.bodies[0].joint.limited and plain.actuators[0].ctrllimited
+    same = load('warmstart="disable" energy="enable" fwdinv="enable" sensornoise="enable" midphase="disable" override="disable" passive="enable"', "s.xml")
+    assert np.array_equal(plain.to_flat(), same.to_flat())
+    off = load('gravity="disable" contact="disable" limit="disable" frictionloss="disable" clampctrl="disable"', "o.xml")
+    assert tuple(off.gravity) == (0.0, 0.0, 0.0) and off.plane is None and not off.bodies[0].joint.limited
+    assert off.bodies[0].joint.frictionloss == 0.0 and not off.actuators[0].ctrllimited
+    cons = load('constraint="disable"', "c.xml")
+    assert cons.plane is None and not cons.bodies[0].joint.limited and cons.bodies[0].joint.frictionloss == 0.0 and tuple(cons.gravity) != (0.0, 0.0, 0.0)
+    assert load('actuation="disable"', "a.xml").actuators[0].gear == 0.0
+    # ... and the oracle runs them: without gravity, limits and contacts the arm coasts at its initial speed
+    ref = RefArm(off.to_flat())
+    q, v = np.array([0.2]), np.array([1.5])
+    for _ in range(100):
+        q, v, _, diag = ref.step(q, v, np.zeros(1))
+    assert diag[0] == 0 and abs(v[0] - 1.5) < 1e-12 and abs(q[0] - 0.2 - 1.5 * 0.2) < 1e-12
+    for bad in ('override="enable"', 'passive="disable"', 'filterparent="disable"', 'refsafe="disable"', 'island="enable"', 'gravity="off"'):
+        with pytest.raises(ValueError, match="flag"):
+            load(bad, "bad.xml")
