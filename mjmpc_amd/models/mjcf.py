@@ -207,6 +207,14 @@ def load_mjcf(path, hand_site="finger", target_site="target", frame_skip=2, task
             raise ValueError("eulerseq must be xyz")
         if comp.get("settotalmass") is not None:
             totalmass = float(comp.get("settotalmass"))
+        # compiler attributes that would change masses and inertias and are not modelled (the rest - mesh / texture directories,
+        # strippath, fusestatic, discardvisual, convexhull ... - leave the simulation alone)
+        if float(comp.get("boundmass", "0")) != 0 or float(comp.get("boundinertia", "0")) != 0:
+            raise ValueError("compiler boundmass / boundinertia are not supported")
+        if comp.get("balanceinertia", "false") != "false":
+            raise ValueError("compiler balanceinertia is not supported")
+        if [int(x) for x in comp.get("inertiagrouprange", "0 5").split()] != [0, 5]:
+            raise ValueError("compiler inertiagrouprange is not supported (every geom of a body counts towards its inertia)")
     opt = root.find("option")
     oget = (lambda k, d: opt.get(k, d)) if opt is not None else (lambda k, d: d)
     timestep = float(oget("timestep", "0.002"))
