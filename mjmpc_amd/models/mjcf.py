@@ -5,7 +5,8 @@ round 4, the kinds of model its other experiment files name (examples/configs/cl
 panda/tray_glass-v0.yml, sawyer/door-v0.yml, hand/*-v0.yml):
 
 * ``<compiler angle="radian|degree" coordinate="local" inertiafromgeom="true|auto" settotalmass>``,
-  ``<option timestep gravity density viscosity integrator="Euler">``;
+  ``<option timestep gravity density viscosity integrator="Euler" cone impratio collision>`` with ``<flag>`` (the parts a flag
+  switches off are taken out of the model);
 * ``<default>`` with nested classes, ``class=`` / ``childclass=`` (joint, geom and motor attributes);
 * nested ``<body pos quat|axisangle|euler>`` with any number of hinge / slide ``<joint>``s (anchor ``pos`` anywhere in
   the body) - a body with several joints becomes a chain of massless bodies, one joint each, which is what MuJoCo's
@@ -233,6 +234,11 @@ def load_mjcf(path, hand_site="finger", target_site="target", frame_skip=2, task
     flags = dict(opt.find("flag").attrib) if opt is not None and opt.find("flag") is not None else {}
     _check_flags(flags)
     density, viscosity = float(oget("density", "0")), float(oget("viscosity", "0"))
+    # <option collision>: "all" (MuJoCo's default) - pairs derived from contype / conaffinity AND the explicit <pair>s;
+    # "predefined" - the explicit <pair>s only (no geom meets the plane through its masks); "dynamic" - the derived ones only
+    collision = oget("collision", "all")
+    if collision not in ("all", "predefined", "dynamic"):
+        raise ValueError("<option collision> must be all, predefined or dynamic")
     dfl = _Defaults(root)
 
     bodies, sites = [], {}
@@ -427,7 +433,7 @@ def load_mjcf(path, hand_site="finger", target_site="target", frame_skip=2, task
         hit = False
         for b in bodies:
             for g in b.geoms:
-                g.collide = bool((g._contype & pca) or (pct & g._conaffinity))
+                g.collide = collision != "predefined" and bool((g._contype & pca) or (pct & g._conaffinity))
                 hit = hit or g.collide
                 if g.collide:
                     geom_solver.append(g._solver)
@@ -449,7 +455,7 @@ def load_mjcf(path, hand_site="finger", target_site="target", frame_skip=2, task
     excluded = set()                    # <contact><exclude body1 body2>: no derived pair between geoms of these two bodies
     for ex in (con.findall("exclude") if con is not None else []):
         excluded.add(frozenset((ex.get("body1"), ex.get("body2"))))
-    if self_collision:
+    if self_collision and collision != "predefined":
         moving = [False] * len(bodies)
         for bi, b in enumerate(bodies):
             moving[bi] = b.joint is not None or (b.parent >= 0 and moving[b.parent])
@@ -483,7 +489,7 @@ def load_mjcf(path, hand_site="finger", target_site="target", frame_skip=2, task
     every = {g.name: g for b in bodies for g in b.geoms if g.name}
     every.update({g.name: g for g in world_geoms})
     pair_params = {}
-    for pr in (con.findall("pair") if con is not None else []):
+    for pr in (con.findall("pair") if con is not None and collision != "dynamic" else []):
         over = {}
         if pr.get("condim") is not None:
             over["condim"] = int(pr.get("condim"))

@@ -1207,3 +1207,30 @@ def test_option_flags_switch_parts_of_the_model_off(tmp_path):
     for bad in ('override="enable"', 'passive="disable"', 'filterparent="disable"', 'refsafe="disable"', 'island="enable"', 'gravity="off"'):
         with pytest.raises(ValueError, match="flag"):
             load(bad, "bad.xml")
+
+
+def test_option_collision_selects_derived_or_predefined_pairs(tmp_path):
+    """<option collision>: all (default) = derived + explicit pairs, predefined = the <pair>s only (nothing meets the plane
+    through its masks), dynamic = the derived ones only."""
+    body = """<geom name="floor" type="plane" size="2 2 0.1" contype="1" conaffinity="1"/>
+    <body name="a" pos="0 0 0.3"><freejoint/><geom name="ga" type="sphere" size="0.05" contype="1" conaffinity="1"/><site name="finger"/></body>
+    <body name="b" pos="0.5 0 0.3"><freejoint/><geom name="gb" type="sphere" size="0.05" contype="1" conaffinity="1"/></body>
+    <body name="c" pos="1 0 0.3"><freejoint/><geom name="gc" type="sphere" size="0.05" contype="2" conaffinity="2"/></body>"""
+    pair = '<contact><pair geom1="gc" geom2="ga"/></contact>'
+
+    def load(mode, name):
+        xml = HEAD + ('<option collision="%s"/>' % mode if mode else "") + \
+            '<default><geom contype="0" conaffinity="0"/></default><worldbody><site name="target" pos="0 0 0"/>' + \
+            textwrap.dedent(body) + "</worldbody>" + pair + "</mujoco>"
+        (tmp_path / name).write_text(xml)
+        return load_mjcf(str(tmp_path / name), task=TASK_REACH)
+
+    every = load("", "all.xml")
+    assert sorted(tuple(p) for p in every.pairs) == [("gb", "ga"), ("gc", "ga")] and every.plane is not None
+    assert [g.collide for b in every.bodies for g in b.geoms] == [True, True, False]
+    pre = load("predefined", "pre.xml")
+    assert [tuple(p) for p in pre.pairs] == [("gc", "ga")] and not any(g.collide for b in pre.bodies for g in b.geoms)
+    dyn = load("dynamic", "dyn.xml")
+    assert [tuple(p) for p in dyn.pairs] == [("gb", "ga")] and dyn.plane is not None
+    with pytest.raises(ValueError, match="collision"):
+        load("some", "bad.xml")
