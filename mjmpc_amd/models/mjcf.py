@@ -8,7 +8,7 @@ panda/tray_glass-v0.yml, sawyer/door-v0.yml, hand/*-v0.yml):
   ``<option timestep gravity density viscosity integrator="Euler" cone impratio collision>`` with ``<flag>`` (the parts a flag
   switches off are taken out of the model);
 * ``<default>`` with nested classes, ``class=`` / ``childclass=`` (joint, geom and motor attributes);
-* nested ``<body pos quat|axisangle|euler>`` with any number of hinge / slide ``<joint>``s (anchor ``pos`` anywhere in
+* nested ``<body pos quat|axisangle|euler|xyaxes|zaxis>`` with any number of hinge / slide ``<joint>``s (anchor ``pos`` anywhere in
   the body) - a body with several joints becomes a chain of massless bodies, one joint each, which is what MuJoCo's
   kinematics does with it - or ONE ball joint (``limited range="0 max"``: a cone on its rotation angle), or a ``<freejoint/>`` /
   free joint (children of the world body);
@@ -100,8 +100,8 @@ def _rodrigues(ax, ang):
 
 
 def _orientation(e, deg):
-    """Rotation matrix of an element's ``quat`` / ``axisangle`` / ``euler`` (MuJoCo's default intrinsic x-y-z sequence)
-    attribute, or None when it carries none; angles in degrees unless the model says radian."""
+    """Rotation matrix of an element's ``quat`` / ``axisangle`` / ``euler`` (MuJoCo's default intrinsic x-y-z sequence) /
+    ``xyaxes`` / ``zaxis`` attribute, or None when it carries none; angles in degrees unless the model says radian."""
     if e.get("quat") is not None:
         return _quat2mat(_floats(e.get("quat"), 4))
     if e.get("axisangle") is not None:
@@ -110,9 +110,22 @@ def _orientation(e, deg):
     if e.get("euler") is not None:
         a = [x * deg for x in _floats(e.get("euler"), 3)]
         return _rodrigues([1, 0, 0], a[0]) @ _rodrigues([0, 1, 0], a[1]) @ _rodrigues([0, 0, 1], a[2])
-    for k in ("xyaxes", "zaxis"):
-        if e.get(k) is not None:
-            raise ValueError("orientation must be given as quat, axisangle or euler")
+    if e.get("xyaxes") is not None:        # the frame's x axis and a vector in its xy plane (MuJoCo orthogonalises the second)
+        v = np.asarray(_floats(e.get("xyaxes"), 6), float)
+        x = v[:3] / np.linalg.norm(v[:3])
+        y = v[3:] - (x @ v[3:]) * x
+        if np.linalg.norm(y) < 1e-12:
+            raise ValueError("xyaxes: the two vectors are parallel")
+        y = y / np.linalg.norm(y)
+        return np.stack([x, y, np.cross(x, y)], axis=1)
+    if e.get("zaxis") is not None:         # the minimal rotation that takes (0, 0, 1) to the given direction
+        z = np.asarray(_floats(e.get("zaxis"), 3), float)
+        z = z / np.linalg.norm(z)
+        ax = np.cross([0.0, 0.0, 1.0], z)
+        sn, cs = np.linalg.norm(ax), z[2]
+        if sn < 1e-12:
+            return np.eye(3) if cs > 0 else _rodrigues([1.0, 0.0, 0.0], np.pi)
+        return _rodrigues(ax / sn, np.arctan2(sn, cs))
     return None
 
 

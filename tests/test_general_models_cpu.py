@@ -1234,3 +1234,20 @@ def test_option_collision_selects_derived_or_predefined_pairs(tmp_path):
     assert [tuple(p) for p in dyn.pairs] == [("gb", "ga")] and dyn.plane is not None
     with pytest.raises(ValueError, match="collision"):
         load("some", "bad.xml")
+
+
+def test_xyaxes_and_zaxis_orientations(tmp_path):
+    """Body / geom orientation as ``xyaxes`` (x axis + a vector in the xy plane, orthogonalised) and ``zaxis`` (the minimal rotation
+    of (0, 0, 1) onto the direction): the same model as with the equivalent quaternions."""
+    body = """<body name="a" pos="0 0 1" %s><joint name="j" type="hinge" axis="0 1 0"/>
+      <geom name="g" type="box" size="0.1 0.05 0.02" %s density="700"/><site name="finger" pos="0.1 0 0"/></body>"""
+    acts = '<actuator><motor joint="j" ctrlrange="-1 1" ctrllimited="true"/></actuator>'
+    # xyaxes = a rotation by 90 degrees about z (x -> y, y -> -x) given with a non-orthogonal second vector; zaxis = z -> x,
+    # i.e. 90 degrees about y
+    a, _ = _model(tmp_path, body % ('xyaxes="0 2 0 -1 0.7 0"', 'zaxis="3 0 0"'), extra=acts, name="a.xml")
+    q1 = "%.17g 0 0 %.17g" % (np.cos(np.pi / 4), np.sin(np.pi / 4))
+    q2 = "%.17g 0 %.17g 0" % (np.cos(np.pi / 4), np.sin(np.pi / 4))
+    b, _ = _model(tmp_path, body % ('quat="%s"' % q1, 'quat="%s"' % q2), extra=acts, name="b.xml")
+    np.testing.assert_allclose(a.to_flat(), b.to_flat(), rtol=0, atol=1e-15)
+    c, _ = _model(tmp_path, body % ('zaxis="0 0 -2"', ''), extra=acts, name="c.xml")         # the antipode: half a turn about x
+    np.testing.assert_allclose(np.abs(c.bodies[0].quat), [0, 1, 0, 0], atol=1e-15)
