@@ -170,6 +170,11 @@ class _Defaults:
             e = node.find(tag)
             if e is not None:
                 base["motor"].update(e.attrib)
+        # defaults of elements whose attributes are read from the elements themselves only: they would change the simulation
+        # unseen (site / mesh / material / camera / light defaults change nothing that is simulated)
+        for tag in ("pair", "equality", "tendon", "cylinder", "muscle"):
+            if node.find(tag) is not None and node.find(tag).attrib:
+                raise ValueError("<default><%s>: defaults of this element are not supported (state the attributes on the elements)" % tag)
         self.cls[name] = base
         for child in node.findall("default"):
             cname = child.get("class")
@@ -624,6 +629,14 @@ def load_mjcf(path, hand_site="finger", target_site="target", frame_skip=2, task
             biasprm = tuple(bp[:3]) if ma("biastype", "none") == "affine" else (0.0, 0.0, 0.0)
         if m.get("joint") is None and m.get("tendon") is None:
             raise ValueError("an actuator acts on a joint or on a fixed tendon")
+        if m.get("joint") is not None:
+            jt = next((b.joint for b in bodies if b.joint is not None and b.joint.name == m.get("joint")), None)
+            if jt is None:
+                raise ValueError("actuator on an unknown joint %r" % m.get("joint"))
+            if jt.type not in (JOINT_HINGE, JOINT_SLIDE):
+                raise ValueError("actuators act on hinge and slide joints (a ball / free joint takes a gear vector, which is not modelled)")
+        if len(_floats(ma("gear"), None, [1.0])) > 1 and any(x != 0 for x in _floats(ma("gear"))[1:]):
+            raise ValueError("actuator gear: only the first (scalar) entry is modelled")
         acts.append(RawActuator(m.get("joint") or "", gear, _floats(ma("ctrlrange"), 2), kp=kp, tendon=m.get("tendon") or "",
                                 gainprm=gainprm, biasprm=biasprm, ctrllimited=limited, forcerange=forcerange))
 
