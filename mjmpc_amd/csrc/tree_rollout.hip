@@ -58,7 +58,7 @@ constexpr int TREE_MAXIT_LS = 100;
 #endif
 // developer switch for phase timing (tools/tree_time.py with a build -DTREE_SKIP=bits): 1 = no Newton iteration,
 // 2 = no Euler factor/solve, 4 = no mass-matrix assembly, 8 = no bias forces, 16 = the constraint stage without its iterations,
-// 32 = with exactly one.  Product builds: 0.
+// 32 = with exactly one, 64 = no cone line search.  Product builds: 0.
 #ifndef TREE_SKIP
 #define TREE_SKIP 0
 #endif
@@ -1533,6 +1533,7 @@ __device__ __noinline__ T cone_line_search(T g0, T dg, T Dl, T rl, T drl, T Dc, 
     // (the rows arrive BY VALUE and the floor flag leaves as a negative return: arrays behind pointers and a flag behind a
     // reference would live in scratch memory on both sides of this call)
     const T rb[4] = {rb0, rb1, rb2, rb3}, drb[4] = {drb0, drb1, drb2, drb3}, Dk[4] = {Dk0, Dk1, Dk2, Dk3};
+    if (TREE_SKIP & 64) return T(1);        // (developer timing: the full step, no search)
     bool at_floor;
     // (no lane-dependent branch in here: the lane sums below are DPP exchanges, every lane of the particle must arrive at
     // them together - the cone's and the plain rows' parts are both computed and one selected)
