@@ -903,6 +903,9 @@ def compile_tree(raw: RawModel, overrides=None, base: "TreeModel" = None) -> Tre
     nsp = s
     f["n_sphere"][0] = nsp
     gen = gen or bool(np.any(f["frictionloss"] > 0))
+    # (joint ref and joint margin are read by the general instantiations only: a model that has nothing else of theirs still needs
+    # them - found by the round-5 soak, seed 8666: a three-hinge chain with two refs, simulated in the other kernels with ref = 0)
+    gen = gen or bool(np.any(f["qoff"] != 0)) or bool(np.any(f["jmargin"] != 0))
     kinds_used = f["spheres"].reshape(TREE_MAX_SPHERES, SPH_STRIDE)[:nsp]
     gen2 = bool(np.any(kinds_used[:, 12] >= PT_PLANE_CYL) or np.any(kinds_used[:, 23] == 8.0))
     # elliptic friction cones (round 5, MJCF <option cone="elliptic" impratio>): the contact records with friction carry

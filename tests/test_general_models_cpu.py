@@ -1251,3 +1251,16 @@ def test_xyaxes_and_zaxis_orientations(tmp_path):
     np.testing.assert_allclose(a.to_flat(), b.to_flat(), rtol=0, atol=1e-15)
     c, _ = _model(tmp_path, body % ('zaxis="0 0 -2"', ''), extra=acts, name="c.xml")         # the antipode: half a turn about x
     np.testing.assert_allclose(np.abs(c.bodies[0].quat), [0, 1, 0, 0], atol=1e-15)
+
+
+def test_joint_ref_or_margin_alone_asks_for_the_general_instantiation(tmp_path):
+    """A chain of plain hinges whose only general feature is a joint ``ref`` (or ``margin``) must be compiled for the general
+    kernels - the others read neither (round-5 soak, seed 8666: such a model ran with ref = 0)."""
+    body = """<body name="a" pos="0 0 1"><joint name="j" type="hinge" axis="0 1 0" limited="true" range="-1 1" %s/>
+      <geom type="capsule" fromto="0 0 0 0.3 0 0" size="0.03"/><site name="finger" pos="0.3 0 0"/></body>"""
+    acts = '<actuator><motor joint="j" ctrlrange="-1 1" ctrllimited="true"/></actuator>'
+    plain, _ = _model(tmp_path, body % "", extra=acts, name="p.xml")
+    assert not compile_tree(plain).general
+    for attr in ('ref="0.3"', 'margin="0.05"'):
+        raw, _ = _model(tmp_path, body % attr, extra=acts, name="r.xml")
+        assert compile_tree(raw).general, attr
