@@ -9,7 +9,7 @@ import json,sys
 j=json.loads(sys.stdin.read()); print('$w $dt', round(j['ms_per_step'], 4), 'ms/step  cap hits', j.get('solver_failures'), ' resets', j.get('diverged_particle_substeps'), ' dist', j.get('final_distance_to_target'))" >> $O 2>&1
   done
 done
-for r in 5000:5300 5300:5600; do
+for r in ${SOAK_SEEDS:-5000:5300 5300:5600}; do
   echo "MJMPC_FUZZ_SEEDS=$r tests/test_random_models_gpu.py:" >> $O
   MJMPC_FUZZ_SEEDS=$r timeout 2400 python -m pytest tests/test_random_models_gpu.py -q 2>&1 | tail -6 >> $O
 done
