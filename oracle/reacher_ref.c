@@ -27,6 +27,12 @@
  *   1. kinematics (body frames, site)            4. passive (-damping*v) + motor (gear*clip(ctrl))
  *   2. M(q) + armature                           5. limit / sphere-plane rows, soft-constraint solve
  *   3. bias c(q,v)                               6. semi-implicit Euler with implicit joint damping
+ *
+ * Rounds 2-5 widened the same file to every model the tree engine runs (trees, slide / ball / free joints, springs, the fluid model,
+ * friction cones - pyramidal and, round 5, ELLIPTIC with impratio -, friction loss, equalities, tendons, boxes, cylinders, static
+ * geoms, joint margin / ref, geom gap, direct solref, mj_checkPos / Vel / Acc -> mj_resetData).  All of it is [EXT] restatement and
+ * UNPINNED in the same way; where MuJoCo's own routine could not be restated to the rounding (capsule-box, box-box, sphere /
+ * capsule against cylinder) the function's comment says "a scheme of its own" and DESIGN.md 2 says what that means.
  */
 #include <math.h>
 #include <stdlib.h>
