@@ -21,9 +21,9 @@ WORKLOADS = {
 # round 5: further entries on the command line, "workload[:P]" - the directory of their passes is <tag>_<workload>[<P>]_pmc*,
 # the dominant kernel the instantiation of the workload's rollout kernel that ran longest in the S1 pass
 EXTRA = []
-for a in sys.argv[3:]:
-    wl_, _, p_ = a.partition(":")
-    EXTRA.append((wl_, int(p_) if p_ else 4096))
+for a in sys.argv[3:]:           # workload[:P[:H]]
+    parts = a.split(":")
+    EXTRA.append((parts[0], int(parts[1]) if len(parts) > 1 and parts[1] else 4096, int(parts[2]) if len(parts) > 2 else 32))
 
 
 def rows(d, pat="*counter_collection.csv"):
@@ -69,16 +69,16 @@ def longest_kernel(d, base):
     return max(tot, key=lambda k: sum(tot[k].values())) if tot else base
 
 
-JOBS = [(wl, prefix, KERNEL, others, 4096) for wl, (prefix, KERNEL, others) in WORKLOADS.items()] if not EXTRA else []
-for wl_, p_ in EXTRA:
-    d_ = wl_ + (str(p_) if p_ != 4096 else "")
+JOBS = [(wl, prefix, KERNEL, others, 4096, 32) for wl, (prefix, KERNEL, others) in WORKLOADS.items()] if not EXTRA else []
+for wl_, p_, h_ in EXTRA:
+    d_ = wl_ + (str(p_) if p_ != 4096 else "") + ("x%d" % h_ if h_ != 32 else "")
     base = "arm_rollout_kernel<double" if wl_ == "reacher" else "tree_rollout_kernel<double"
     # (reacher: the fused iteration's rollout kernel - the instantiations whose last argument, MONO, is true)
     k_ = longest_kernel(d_ + "_pmcS1", base)
     if wl_ == "reacher" and p_ <= 4096:         # the headline's kernel by name: the fused iteration's rollout launch (DUO, MONO)
         k_ = WORKLOADS["reacher"][1]
-    JOBS.append((d_, ("" if wl_ == "reacher" else wl_ + "_"), k_, WORKLOADS["reacher"][2] if wl_ == "reacher" else [], p_))
-for wl, prefix, KERNEL, others, P in JOBS:
+    JOBS.append((d_, ("" if wl_ == "reacher" else wl_ + "_"), k_, WORKLOADS["reacher"][2] if wl_ == "reacher" else [], p_, h_))
+for wl, prefix, KERNEL, others, P, H in JOBS:
     # ---- HBM traffic per launch (FETCH_SIZE / WRITE_SIZE are reported in KB; calibrated on the 64 MiB copy) ----
     fk, _ = per_kernel(wl + "_pmcF", KERNEL)
     wk, _ = per_kernel(wl + "_pmcW", KERNEL)
