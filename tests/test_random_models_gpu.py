@@ -246,6 +246,17 @@ def random_state(raw, rs):
     return q, v
 
 
+def _assert_rollouts_close(got, want, scale_from=None):
+    """Several env steps in a row: 1e-7 of the particle's largest observation (at least 1e-7 absolute).  The one-step checks
+    above hold 1e-9; over a rollout a random model with stiff rows can amplify rounding by many orders - soak seeds 15007 and
+    27612 (of 24 000) reach velocities of 1e6 and 6e2 rad/s, the oracle's OWN next observation moves by 1e-2 and 6e-6 there when
+    its state is perturbed by 1e-12, and kernel and oracle differ by 2e-10 and 6e-9 of the values (5e-4 and 4e-6 absolute)."""
+    ref = want if scale_from is None else scale_from
+    scale = np.maximum(1.0, np.abs(ref).reshape(len(ref), -1).max(axis=1))
+    err = np.abs(got - want).reshape(len(want), -1).max(axis=1)
+    assert (err <= 1e-7 * scale).all(), (err / scale).max()
+
+
 # (MJMPC_FUZZ_SEEDS=a:b in the environment runs another range of seeds - a soak run, not part of the suite)
 _SEEDS = range(*[int(x) for x in os.environ["MJMPC_FUZZ_SEEDS"].split(":")]) if os.environ.get("MJMPC_FUZZ_SEEDS") else range(48)
 
@@ -288,15 +299,15 @@ def test_random_model_matches_oracle(seed):
     obs, rew, act, done, info, nobs = eng.rollout(P, H, np.zeros((H, A)), eps, "open_loop")
     o_obs, o_rew, _, _, o_nobs = ref.rollout(q, 0.3 * v, tgt, np.zeros((H, A)), eps)
     ok = np.isfinite(o_nobs).all(axis=(1, 2))
-    np.testing.assert_allclose(nobs[ok], o_nobs[ok], rtol=0, atol=1e-7)
+    _assert_rollouts_close(nobs[ok], o_nobs[ok])
     np.testing.assert_allclose(rew[ok], o_rew[ok], rtol=1e-7, atol=1e-7)
     # the same start in mode="closed_loop_linear" (gym_env_wrapper.py:135-136): actions from the observation each step starts from
     W = 0.05 * rs.standard_normal((eng.d_obs + 1, A))
     obs, rew, act, done, info, nobs = eng.rollout(8, 4, W, eps[:8, :4], "closed_loop_linear")
     o_obs, o_rew, o_act, _, o_nobs = ref.rollout(q, 0.3 * v, tgt, W, eps[:8, :4], mode="closed_loop_linear")
     ok = np.isfinite(o_nobs).all(axis=(1, 2))
-    np.testing.assert_allclose(act[ok], o_act[ok], rtol=0, atol=1e-7)
-    np.testing.assert_allclose(nobs[ok], o_nobs[ok], rtol=0, atol=1e-7)
+    _assert_rollouts_close(act[ok], o_act[ok], o_nobs[ok])
+    _assert_rollouts_close(nobs[ok], o_nobs[ok])
 
 
 @pytest.mark.parametrize("seed", range(0, 48, 4))
