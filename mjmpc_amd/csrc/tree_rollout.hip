@@ -502,6 +502,12 @@ __device__ __forceinline__ void tree_row_params(const T* sol, T r, T diag_approx
 // triangular solves take the trunk's levels as broadcast FMAs.  kt is the same for every particle of a launch.
 template <int DP>
 struct Trunk { static constexpr int KT = DP < 16 ? DP : 16; };
+// pivot reciprocals of the in-register factorisations (-DTREE_PIVOT_RCP_FAST: developer A/B switch, one Newton step on v_rcp_f64)
+#ifdef TREE_PIVOT_RCP_FAST
+#define PIVOT_RCP rcp_fast
+#else
+#define PIVOT_RCP rcp_
+#endif
 
 // ra[col] = A[l][col] (col <= l < kt, absolute columns) in, the factor out: ra[l] = D_l, ra[col] = L[l][col]
 template <int K, int KT, typename T>
@@ -509,7 +515,7 @@ struct TrunkStep {
     static __device__ __forceinline__ void run(T* ra, int l, int kt) {
         if (K < kt) {
             asm volatile("" : "+v"(l));     // (lane masks recomputed here, not kept - and spilled - across the substep)
-            const T invd = rcp_(bcast_row<K>(ra[K]));
+            const T invd = PIVOT_RCP(bcast_row<K>(ra[K]));
             T fj = T(0);                        // A[K][l] / D_K for lanes l < K: lane K's entry of MY column
 #pragma unroll
             for (int col = 0; col < K; ++col) {
@@ -837,7 +843,7 @@ __device__ __forceinline__ void dense_contact(T* r, T jn, T j1, T j2, T wn, T w1
 template <int K, int DN, typename T>
 struct DenseStep {
     static __device__ __forceinline__ void run(T* r, T& dinv, int l) {
-        const T inv = rcp_(bcast_row<K>(r[K]));
+        const T inv = PIVOT_RCP(bcast_row<K>(r[K]));
         dinv = l == K ? inv : dinv;
         const T lik = l > K ? r[K] * inv : T(0), nlik = -lik;
         fma_bcast_self_range<K, K + 1, DN>(r, nlik);        // r[j] -= lik * (lane K's r[j]), j > K
@@ -932,8 +938,8 @@ __device__ __forceinline__ void dense32_cols(T* r, T x, T m) {
 // the reciprocal of pivot K (the diagonal entry of lane K), in every lane that will use it
 template <int K, typename T>
 __device__ __forceinline__ T dense32_pivot_inv(const T* r) {
-    if constexpr (K < 16) return rcp_(bcast_row<K>(row_even(r[K])));
-    else return rcp_(bcast_row<K - 16>(r[K]));          // (only the odd-row lanes use it: theirs is the right one)
+    if constexpr (K < 16) return PIVOT_RCP(bcast_row<K>(row_even(r[K])));
+    else return PIVOT_RCP(bcast_row<K - 16>(r[K]));          // (only the odd-row lanes use it: theirs is the right one)
 }
 // Step K.  A[K][j] = A[j][K] (the matrix is symmetric and lane j > K has not scaled its entry K yet), so the pivot row is
 // never sent anywhere: every lane broadcasts-reads "entry K of lane j" - from its own row for columns of its own half,
