@@ -46,6 +46,9 @@ if name == "cheetah":       # resting on its feet: contacts from the first subst
     eng.set_env_state(dict(qpos=q0, qvel=np.zeros(9)))
 g = torch.Generator(device="cuda").manual_seed(0)
 noise = (0.1 if name in ("pen", "penf", "tray") else (0.05 if name == "gripper" else 0.5)) * torch.randn(P, H, A, device="cuda", dtype=torch.float32 if dt == "f32" else torch.float64, generator=g)
+if os.environ.get("TREE_TIME_SAME_MATES"):      # every wavefront holds copies of ONE particle (TREE_TIME_SAME_MATES = particles
+    k = int(os.environ["TREE_TIME_SAME_MATES"])  # per wave: 4 at 16 lanes, 2 at 32): no Newton iteration is forced by a wave-mate -
+    noise = noise[::k].repeat_interleave(k, dim=0)[:P].contiguous()     # what letting particles iterate alone could gain at most
 mean = torch.zeros(H, A, device="cuda", dtype=torch.float64)
 if name == "gripper":
     mean[:, 1:] = 0.2           # (finger servos: the pose the model is drawn in)
