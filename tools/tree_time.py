@@ -49,6 +49,16 @@ noise = (0.1 if name in ("pen", "penf", "tray") else (0.05 if name == "gripper" 
 if os.environ.get("TREE_TIME_SAME_MATES"):      # every wavefront holds copies of ONE particle (TREE_TIME_SAME_MATES = particles
     k = int(os.environ["TREE_TIME_SAME_MATES"])  # per wave: 4 at 16 lanes, 2 at 32): no Newton iteration is forced by a wave-mate -
     noise = noise[::k].repeat_interleave(k, dim=0)[:P].contiguous()     # what letting particles iterate alone could gain at most
+if os.environ.get("TREE_TIME_SORT"):            # particles ordered by a similarity key before they are dealt to wavefronts (the
+    mode = os.environ["TREE_TIME_SORT"]         # updates are invariant under the order): does grouping look-alikes pay?
+    if mode == "first":                         # the first step's first action
+        key = noise[:, 0, 0]
+    elif mode == "signs":                       # the sign pattern of the first step's actions, then the first action
+        bits = (noise[:, 0, :] > 0).to(torch.float64) @ (2.0 ** torch.arange(A, device="cuda", dtype=torch.float64))
+        key = bits * 100.0 + noise[:, 0, 0].to(torch.float64)
+    else:                                       # the mean of every action over the first four steps, projected on a fixed direction
+        key = noise[:, :4, :].mean(dim=1).to(torch.float64) @ torch.linspace(1.0, 2.0, A, device="cuda", dtype=torch.float64)
+    noise = noise[torch.argsort(key)].contiguous()
 mean = torch.zeros(H, A, device="cuda", dtype=torch.float64)
 if name == "gripper":
     mean[:, 1:] = 0.2           # (finger servos: the pose the model is drawn in)
