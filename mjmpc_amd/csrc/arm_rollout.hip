@@ -22,6 +22,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdlib>
+#include <type_traits>
 
 #include "arm_model.h"
 #include "arm_rollout.h"
@@ -428,6 +429,47 @@ __device__ __forceinline__ T mass_matrix_tile(const LinkFrame<T>& L, int l8, T* 
     return d[0];
 }
 
+// The same with the diagonals S0 <= s < S1 only (the four-wave shape splits them between two wavefronts: the suffix sums and
+// the composite-inertia products are repeated by both, the shifted dot products and the tile stores are shared out).
+template <int S0, int S1, typename T>
+__device__ __forceinline__ T mass_matrix_tile_part(const LinkFrame<T>& L, int l8, T* ldsM) {
+    const T *sw = L.sw, *sv = L.sv;
+    T d[MAX_LINKS];
+#pragma unroll
+    for (int k = 0; k < MAX_LINKS; ++k) d[k] = T(0);
+    T mc = ssum(L.mass, l8), hc[3], Ic[6];
+    for (int k = 0; k < 3; ++k) hc[k] = ssum(L.hm[k], l8);
+    for (int k = 0; k < 6; ++k) Ic[k] = ssum(L.Ib[k], l8);
+    T Fn[3], Ff[3], t1[3], t2[3];
+    symvec(Ic, sw, Fn);
+    cross(hc, sv, t1);
+    cross(hc, sw, t2);
+    for (int k = 0; k < 3; ++k) { Fn[k] += t1[k]; Ff[k] = mc * sv[k] - t2[k]; }
+    auto diag_s = [&](auto SC) {
+        constexpr int S = decltype(SC)::value;
+        if constexpr (S >= S0 && S < S1) {
+            if constexpr (S == 0) {
+                d[0] = dot(sw, Fn) + dot(sv, Ff);
+            } else {
+                T fn[3], ff[3];
+                for (int c = 0; c < 3; ++c) { fn[c] = shl_raw<S>(Fn[c]); ff[c] = shl_raw<S>(Ff[c]); }
+                d[S] = dot(sw, fn) + dot(sv, ff);
+            }
+        }
+    };
+    diag_s(std::integral_constant<int, 0>()); diag_s(std::integral_constant<int, 1>()); diag_s(std::integral_constant<int, 2>());
+    diag_s(std::integral_constant<int, 3>()); diag_s(std::integral_constant<int, 4>()); diag_s(std::integral_constant<int, 5>());
+    diag_s(std::integral_constant<int, 6>());
+#pragma unroll
+    for (int sft = S0; sft < S1; ++sft) {
+        if (l8 + sft < MAX_LINKS) {
+            ldsM[l8 * LANES + l8 + sft] = d[sft];
+            ldsM[(l8 + sft) * LANES + l8] = d[sft];
+        }
+    }
+    return d[0];
+}
+
 // plane-sphere contact geometry (mjc_PlaneSphere): signed distance, and - if some particle of the wave is within
 // the margin - my dof's entry of the contact Jacobian row and the row velocity J v
 template <typename T, typename MT>
@@ -464,13 +506,37 @@ __device__ __forceinline__ void contact_geometry(const MT& M, const ArmInts& I, 
 //         H^-1 per lane, Newton iteration on the active set   [E2]   qacc = (M + h B)^-1 (tau + J'f)   [E3] integrate
 // Both waves integrate the same qacc with the same instructions, so their copies of (q, v, sin q, cos q) stay
 // bit-identical.  SOLO = one wave does everything (launches that fill the chip anyway).
-enum Role : int { SOLO = 0, DYN = 1, SOLVE = 2 };
+enum Role : int { SOLO = 0, DYN = 1, SOLVE = 2,
+                  // round 6: the roles of the FLAG-synchronised shapes (two or four wavefronts per particle group) - see flag_front
+                  QDYN = 3, QSOLVE = 4, QMASS = 5, QAUX = 6 };
+// which of the particle block's four spare slots holds this role's reset flags (every wave of a group keeps its own copy)
+template <int ROLE>
+__device__ __forceinline__ constexpr int role_slot() {
+    return (ROLE == SOLVE || ROLE == QSOLVE) ? 1 : (ROLE == QMASS ? 2 : (ROLE == QAUX ? 3 : 0));
+}
+// the role that counts a particle's resets (one wave of the group)
+template <int ROLE>
+__device__ __forceinline__ constexpr bool role_counts() { return ROLE == SOLO || ROLE == DYN || ROLE == QDYN; }
 
 // Phase timing of one wavefront (developer builds: -DMJMPC_STAMPS, read back with tools/stamps.py).  Shader-clock
 // deltas between consecutive marks are summed per phase; workgroup 0 adds its sums to diag[2 + 16 * wave + phase]
 // (64-bit slots) when the rollout ends.  In product builds every member is empty.
 struct Stamps {
-#ifdef MJMPC_STAMPS
+#if defined(MJMPC_STAMPS) && defined(MJMPC_STAMPS_ABS)
+    // -DMJMPC_STAMPS_ABS=n: a TIMELINE instead of sums - the shader clock at every mark of substep n alone (one wave's marks
+    // against another's: who posted what when; tools/stamps.py --timeline)
+    long long acc[16];
+    int nsub;
+    __device__ __forceinline__ void begin() { for (int k = 0; k < 16; ++k) acc[k] = 0; nsub = 0; }
+    __device__ __forceinline__ void mark(int k) {
+        if (nsub == MJMPC_STAMPS_ABS) acc[k] = clock64();
+        if (k == 13 || k == 15) ++nsub;          // (13: integration done)
+    }
+    __device__ __forceinline__ void flush(unsigned* diag, int wave, int lane) {
+        if (diag && blockIdx.x == 0 && lane == 0)
+            for (int k = 0; k < 16; ++k) ((unsigned long long*)diag)[2 + 16 * wave + k] = (unsigned long long)acc[k];
+    }
+#elif defined(MJMPC_STAMPS)
     long long last, acc[16];
     __device__ __forceinline__ void begin() { for (int k = 0; k < 16; ++k) acc[k] = 0; last = clock64(); }
     // -DMJMPC_STAMPS_MASK=0x..: only the marks whose bit is set read the clock (e.g. 0x1c = the two sides of E1 alone: the
@@ -481,7 +547,16 @@ struct Stamps {
         const long long t = clock64(); acc[k] += t - last; last = t;
     }
 #else
+    // (MJMPC_STAMPS_FENCE: a scheduling barrier at every mark - exact attribution at the price of a slightly different schedule)
+#ifdef MJMPC_STAMPS_FENCE
+    __device__ __forceinline__ void mark(int k) {
+        __builtin_amdgcn_sched_barrier(0);
+        const long long t = clock64(); acc[k] += t - last; last = t;
+        __builtin_amdgcn_sched_barrier(0);
+    }
+#else
     __device__ __forceinline__ void mark(int k) { const long long t = clock64(); acc[k] += t - last; last = t; }
+#endif
 #endif
     __device__ __forceinline__ void flush(unsigned* diag, int wave, int lane) {
         if (diag && blockIdx.x == 0 && lane == 0)
@@ -582,9 +657,9 @@ struct ResetCtl {
 // block, read and written on the rare path only (a register of its own cost the fused iteration's kernel, the one with the
 // least room, copies in its hot loops)
 template <int ROLE, typename T>
-__device__ __forceinline__ int rflags(const T* ldsM) { return (int)ldsM[PSTRIDE - 4 + (ROLE == SOLVE ? 1 : 0)]; }
+__device__ __forceinline__ int rflags(const T* ldsM) { return (int)ldsM[PSTRIDE - 4 + role_slot<ROLE>()]; }
 template <int ROLE, typename T>
-__device__ __forceinline__ void rflags_set(T* ldsM, int f) { ldsM[PSTRIDE - 4 + (ROLE == SOLVE ? 1 : 0)] = (T)f; }
+__device__ __forceinline__ void rflags_set(T* ldsM, int f) { ldsM[PSTRIDE - 4 + role_slot<ROLE>()] = (T)f; }
 // where the record lives is asked for only on the rare path (a callable): held in registers through the substep it cost
 // the fused iteration's kernel - the one with the least room - scalar spills in its hot loops (measured: +4 % per launch)
 struct NoResetRecord {
@@ -617,7 +692,7 @@ __device__ __forceinline__ void arm_front(const MT& M, const ArmInts& I, T& q, T
             q = T(0); v = T(0); sq = T(0); cq = T(1); aw = T(0);
             rows = 0;
             f = 1;
-            if (ROLE != SOLVE && diag && l8 == 0 && rc->count) atomicAdd(diag + 1, 1u);
+            if (role_counts<ROLE>() && diag && l8 == 0 && rc->count) atomicAdd(diag + 1, 1u);
         }
         rflags_set<ROLE>(ldsM, f);
         if (f & 1) tau_act = M.link(O_GEAR) * fmin(fmax(T(0), M.link(O_CTRL_LO)), M.link(O_CTRL_HI));
@@ -992,19 +1067,366 @@ __device__ __forceinline__ void arm_front(const MT& M, const ArmInts& I, T& q, T
     ST.mark(10);        // constraint force, Euler solve
 }
 
+// ---- FLAG-synchronised shapes (round 6): two or four wavefronts per particle group, no s_barrier ---------------------------
+// What round 5's phase clocks said about DUO (profiles/r04_arm_phase_clocks.txt): 13 % of the critical wave's cycles are waits
+// at the three barriers - a barrier makes a wave wait for the slowest wave even when what it needs next is long there.  And
+// what round 6's first attempts said (profiles/r06_arm_shapes.txt): cutting the critical chain
+//   integrate -> frames -> mass matrix -> factor H -> Newton -> Euler product
+// itself across wavefronts buys nothing - every cut costs a hand-over (~150 cycles) and repeats the frames.
+// So: the chain stays on ONE wavefront (QSOLVE), which never waits at a barrier; everything else moves to the other waves,
+// which hand their results over through LDS behind FLAGS - a flag carries the substep's sequence number, the DS unit executes a
+// wave's LDS instructions in order, so whoever sees the flag sees the data written before it:
+//   NW = 2   QSOLVE  integrate; frames, mass matrix -> tile, Euler diagonal [TILE]; contact row; takes [ROWS]; factors H, one
+//                    column of H^-1 per lane; takes [TAU] only now; Newton iteration on the active set; takes [EI];
+//                    qacc = (M + h B)^-1 (tau + J'f)  [X]
+//            QDYN    takes [X], integrates; limit rows (a function of q, v alone) [ROWS]; frames, bias forces -> tau [TAU];
+//                    takes [TILE], factors M + h B, one column of its inverse per lane [EI]; env-step records, sampler
+//   NW = 4   (launches of at most a quarter wave per SIMD, P <= 2048 on 256 CUs: the helpers have SIMDs of their own)
+//            QDYN    as above without the limit rows and the inverse
+//            QAUX    takes [X], integrates (q, v only: it needs no frames); limit rows [ROWS]; takes [TILE] [TILE2], the
+//                    inverse of M + h B [EI]
+//            QMASS   takes [X], integrates; frames, composite inertia, the FAR diagonals of the mass matrix [TILE2]
+//                    (QSOLVE computes the near ones)
+// Every wave integrates the same qacc with the same explicitly rounded operations (bit-identical copies of the state, as in
+// DUO).  Nothing is reused before its readers are done: every buffer of substep n is read before X_n is posted, and written
+// again only by waves that have taken X_n.
+// (an explicit LDS pointer: a generic `volatile int*` compiles to flat loads / stores with a vmcnt(0) drain each; and relaxed
+// workgroup-scope atomics instead of `volatile`: a volatile load is followed by an s_waitcnt of its own, which would put the
+// flag's round trip IN FRONT of the data reads instead of beside them)
+typedef __attribute__((address_space(3))) int* qflag_ptr;
+__device__ __forceinline__ int q_read(qflag_ptr qf, int which) {
+    return __hip_atomic_load(qf + which, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+__device__ __forceinline__ void q_write(qflag_ptr qf, int which, int x) {
+    __hip_atomic_store(qf + which, x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+enum QFlag : int { QF_TAU = 0, QF_TILE = 1, QF_TILE2 = 2, QF_EI = 3, QF_X = 4, QF_ROWS = 5, QF_STUCK = 7, QF_COUNT = 8 };
+__device__ __forceinline__ void q_post(qflag_ptr qf, int which, int seq, int lane) {
+    asm volatile("" ::: "memory");
+    if (lane == 0) q_write(qf, which, seq);
+    asm volatile("" ::: "memory");
+}
+// (the wait is bounded: a producer that never posts - a bug, or a wave of the group that could not be scheduled - ends
+// the wait after 2^21 polls (~0.1 s) with the sticky flag QF_STUCK, which the launch reports through the solver-failure counter
+// instead of hanging the GPU)
+__device__ __forceinline__ void q_wait(qflag_ptr qf, int which, int seq) {
+#ifdef ARM_QWAIT_NOP            // developer timing experiment: no waiting at all (the results are void)
+    return;
+#endif
+    int spins = 0;
+    while (__builtin_amdgcn_readfirstlane(q_read(qf, which)) < seq) {
+#ifdef ARM_QUAD_SLEEP           // developer A/B: sleep between polls (s_sleep n = 64 n + 1..64 clocks)
+        __builtin_amdgcn_s_sleep(ARM_QUAD_SLEEP);
+#endif
+        if (++spins > (1 << 21)) { q_write(qf, QF_STUCK, 1); break; }
+    }
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+}
+
+// Take a hand-over: the flag(s) and, IN THE SAME BATCH of LDS instructions, the data behind them (`loads`, a callable) - the
+// flag reads are issued first, the DS unit executes in order, so a flag that reads as posted vouches for the data read after
+// it; a flag that does not sends the batch round again.  One LDS round trip (~110 cycles for a lone wave) where a poll
+// followed by the reads costs two - and a substep has half a dozen hand-overs on its critical chain.
+template <typename F>
+__device__ __forceinline__ void q_take(qflag_ptr qf, int which, int seq, F&& loads, int which2 = -1) {
+    // (the first attempt is straight-line code of its own: inside a loop the compiler puts an s_waitcnt lgkmcnt(0) between the
+    // flag read and the data reads - the write-after-write hazard against the previous iteration's loads into the same
+    // registers - which is exactly the second round trip this is here to avoid)
+    int tag = q_read(qf, which);
+    int tag2 = which2 >= 0 ? q_read(qf, which2) : seq;
+    asm volatile("" ::: "memory");          // (the data loads stay behind the flag loads)
+    loads();
+    asm volatile("" ::: "memory");
+#ifndef ARM_QWAIT_NOP
+    if (__builtin_expect(!(__builtin_amdgcn_readfirstlane(tag) >= seq && __builtin_amdgcn_readfirstlane(tag2) >= seq), 0)) {
+        int spins = 0;
+        for (;;) {
+            tag = q_read(qf, which);
+            tag2 = which2 >= 0 ? q_read(qf, which2) : seq;
+            asm volatile("" ::: "memory");
+            loads();
+            asm volatile("" ::: "memory");
+            if (__builtin_amdgcn_readfirstlane(tag) >= seq && __builtin_amdgcn_readfirstlane(tag2) >= seq) break;
+            if (++spins > (1 << 21)) { q_write(qf, QF_STUCK, 1); break; }
+        }
+    }
+#endif
+    __builtin_amdgcn_sched_barrier(0);
+}
+
+template <int ROLE, int NW, typename T, typename MT>
+__device__ __forceinline__ void flag_front(const MT& M, const ArmInts& I, T& q, T& v, T& aw, T& sq, T& cq, int& rows,
+                                           T tau_act, T* ldsM, qflag_ptr qf, int seq, int lane, int l8, T* site,
+                                           unsigned* diag, bool& free_step, Stamps& ST, ResetCtl* rc = nullptr) {
+    constexpr bool ROWS_MINE = ROLE == QAUX || (ROLE == QDYN && NW == 2);       // who evaluates the limit rows and inverts M + h B
+    constexpr bool SPLIT = NW == 4;                                             // the mass matrix's diagonals on two waves
+    free_step = false;
+#ifdef MJMPC_NO_RESET
+    rc = nullptr;
+#endif
+    if (rc && __builtin_expect(rc->any, 0)) {
+        int f = rflags<ROLE>(ldsM) & ~4;
+        if (f & 2) {                        // mj_checkPos / mj_checkVel of this mj_step: mj_resetData, and on from there
+            q = T(0); v = T(0); sq = T(0); cq = T(1); aw = T(0);
+            rows = 0;
+            f = 1;
+            if (role_counts<ROLE>() && diag && l8 == 0 && rc->count) atomicAdd(diag + 1, 1u);
+        }
+        rflags_set<ROLE>(ldsM, f);
+        if (f & 1) tau_act = M.link(O_GEAR) * fmin(fmax(T(0), M.link(O_CTRL_LO)), M.link(O_CTRL_HI));
+    }
+    PHASE();
+    const T damping = M.link(O_DAMPING), h = M.glob(O_TIMESTEP);
+    auto limit_rows = [&]() {
+        // the joint-limit rows: a function of (q, v) alone
+        T sg, Dl, al;
+        limit_row(M, q, v, sg, Dl, al);
+        ldsM[V_LS + l8] = sg;
+        ldsM[V_LD + l8] = Dl;
+        ldsM[V_LA + l8] = al;
+        q_post(qf, QF_ROWS, seq, lane);
+        ST.mark(5);
+    };
+    if constexpr (ROLE == QAUX) limit_rows();
+    LinkFrame<T> L;
+    T ctr[3] = {T(0), T(0), T(0)};
+    bool near_plane = false;
+    if constexpr (ROLE != QAUX) {
+        kinematics(M, sq, cq, l8, L);
+        if constexpr (ROLE == QDYN) {
+            const T sp[3] = {M.glob(O_SITE_POS, 0), M.glob(O_SITE_POS, 1), M.glob(O_SITE_POS, 2)};
+            T t[3];
+            matvec(L.R, sp, t);
+            for (int k = 0; k < 3; ++k) site[k] = L.p[k] + t[k];
+        }
+        if (ROLE == QSOLVE && I.n_sphere > 0) {
+            const T sp[3] = {M.glob(O_SPH_POS, 0), M.glob(O_SPH_POS, 1), M.glob(O_SPH_POS, 2)};
+            T t[3];
+            matvec(L.R, sp, t);
+            for (int k = 0; k < 3; ++k) t[k] += L.p[k];
+            const T pn[3] = {M.glob(O_PLANE_N, 0), M.glob(O_PLANE_N, 1), M.glob(O_PLANE_N, 2)};
+            const bool mine = dot(t, pn) - M.glob(O_PLANE_D) - M.glob(O_SPH_R) < M.glob(O_SPH_MARGIN);
+            const unsigned long long bal = __ballot(mine);
+            near_plane = (bal >> lane_of_link(lane, I.sph_link)) & 1ull;
+            if (__any(near_plane))
+                for (int k = 0; k < 3; ++k) ctr[k] = __shfl(t[k], lane_of_link(lane, I.sph_link));
+        }
+        ST.mark(0);         // kinematics
+        PHASE();
+        link_frames(M, L);  // (inlined: what a role does not use is dropped)
+        ST.mark(1);
+    }
+    if constexpr (ROLE == QDYN) {
+        // (NW = 2: the solving wave asks for the rows when its mass matrix is done and for tau a factorisation later - the rows
+        // go out first, but behind the frames: the start of the substep belongs to what the bias forces need)
+        if constexpr (ROWS_MINE) limit_rows();
+        const T bias = bias_force(M, L, v, l8);
+        ldsM[V_TAU + l8] = -bias - damping * v + tau_act;
+        q_post(qf, QF_TAU, seq, lane);
+        ST.mark(2);
+    }
+    if constexpr (ROLE == QMASS) {
+        mass_matrix_tile_part<4, MAX_LINKS>(L, l8, ldsM);
+        q_post(qf, QF_TILE2, seq, lane);
+        ST.mark(4);
+        return;
+    }
+    if constexpr (ROWS_MINE) {
+        Dense<T> F;
+        q_take(qf, QF_TILE, seq, [&]() { F.load(ldsM, ldsM + V_DE); }, SPLIT ? QF_TILE2 : -1);
+        ST.mark(3);
+        F.factor();
+        T col[MAX_LINKS];
+#pragma unroll
+        for (int i = 0; i < MAX_LINKS; ++i) col[i] = (i == l8) ? T(1) : T(0);
+        F.solve(col);
+#pragma unroll
+        for (int i = 0; i < MAX_LINKS; ++i) ldsM[V_EI + l8 * LANES + i] = col[i];
+        q_post(qf, QF_EI, seq, lane);
+        ST.mark(6);
+    }
+    if constexpr (ROLE == QSOLVE) {
+        T dgM = SPLIT ? mass_matrix_tile_part<0, 4>(L, l8, ldsM) : mass_matrix_tile(L, l8, ldsM);
+        dgM += M.link(O_ARMATURE);
+        ldsM[V_DE + l8] = dgM + h * damping;
+        q_post(qf, QF_TILE, seq, lane);
+        ST.mark(4);         // composite inertia, mass matrix, tile
+        // the contact row
+        bool cinst = false;
+        T jc = T(0), Dc = T(0), arefc = T(0);
+        if (I.n_sphere > 0 && __any(near_plane)) {
+            T cdist, jv;
+            contact_geometry(M, I, L, ctr, v, l8, cdist, cinst, jc, jv);
+            cinst = cinst && near_plane;
+            jc = near_plane ? jc : T(0);
+            if (__any(cinst)) {
+                row_params(M, cdist - M.glob(O_SPH_MARGIN), M.glob(O_SPH_INVW), jv, Dc, arefc);
+                Dc = cinst ? Dc : T(0);
+                arefc = cinst ? arefc : T(0);
+            }
+        }
+        T sig, D, aref;
+        q_take(qf, QF_ROWS, seq, [&]() { sig = ldsM[V_LS + l8]; D = ldsM[V_LD + l8]; aref = ldsM[V_LA + l8]; },
+               SPLIT ? QF_TILE2 : -1);
+        const bool inst = sig != T(0);
+        const bool any_rows = __any(inst || cinst);
+        if (!any_rows) rows = 0;
+        bool act = inst && ((rows & 1) ? (rows & 2) != 0 : true);
+        bool cact = cinst && ((rows & 4) ? (rows & 8) != 0 : true);
+        bool changed = false;
+        const bool any_c = __any(cinst);
+        T qfrc_c = T(0);
+        ST.mark(5);         // constraint rows
+        T tau = T(0);
+        T ei[MAX_LINKS];
+        if (any_rows) {
+            if (any_c) ldsM[V_JC + l8] = jc;
+            changed = true;
+            for (int it = 0; it < newton_maxit<T>(); ++it) {
+                // the rows' parts of the right-hand side; tau joins them when it has arrived:  rhs = (tau + limit) + contact
+                ldsM[V_DH + l8] = dgM + (act ? D : T(0));
+                ldsM[V_RH + l8] = act ? D * sig * aref : T(0);
+                ldsM[V_XH + l8] = (any_c && cact) ? Dc * jc * arefc : T(0);
+                LDS_WAVE_SYNC();
+                Dense<T> F;
+                F.load(ldsM, ldsM + V_DH);
+                // (every LDS read of a phase in ONE batch, no branch between them: a lone wave pays the full ~110 cycles for
+                // each dependent round trip - seven conditional reads in a row were 700 cycles of this chain)
+                T rh[MAX_LINKS], tv[MAX_LINKS], rr[MAX_LINKS], xh[MAX_LINKS];
+#pragma unroll
+                for (int i = 0; i < MAX_LINKS; ++i) { rr[i] = ldsM[V_RH + i]; xh[i] = ldsM[V_XH + i]; }
+                if (it > 0) {
+#pragma unroll
+                    for (int i = 0; i < MAX_LINKS; ++i) tv[i] = ldsM[V_TAU + i];
+                }
+                if (any_c && __any(cact)) {
+                    T jv[MAX_LINKS];
+#pragma unroll
+                    for (int i = 0; i < MAX_LINKS; ++i) jv[i] = ldsM[V_JC + i];
+                    F.add_rank1(cact ? Dc : T(0), jv);
+                }
+                F.factor();
+                T col[MAX_LINKS];
+#pragma unroll
+                for (int i = 0; i < MAX_LINKS; ++i) col[i] = (i == l8) ? T(1) : T(0);
+                F.solve(col);
+                ST.mark(it == 0 ? 6 : 9);
+                if (it == 0) {
+                    q_take(qf, QF_TAU, seq, [&]() {         // the smooth force: needed only now
+                        tau = ldsM[V_TAU + l8];
+#pragma unroll
+                        for (int i = 0; i < MAX_LINKS; ++i) tv[i] = ldsM[V_TAU + i];
+                    });
+                    ST.mark(7);
+                }
+#pragma unroll
+                for (int i = 0; i < MAX_LINKS; ++i) rh[i] = (tv[i] + rr[i]) + xh[i];       // rhs = (tau + limit row) + contact row
+                T acc = T(0);
+#pragma unroll
+                for (int i = 0; i < MAX_LINKS; ++i) acc += col[i] * rh[i];
+                aw = acc;
+                bool act2, cact2;
+                active_set(aw, sig, aref, jc, arefc, inst, cinst, act, cact, act2, cact2);
+                const bool flip = act2 != act, cflip = cact2 != cact;
+                changed = flip || cflip;
+                act = act2;
+                cact = cact2;
+                if (it == 0) {
+                    ST.mark(8);
+                    q_take(qf, QF_EI, seq, [&]() {          // my row of (M + h B)^-1
+#pragma unroll
+                        for (int i = 0; i < MAX_LINKS; ++i) ei[i] = ldsM[V_EI + l8 * LANES + i];
+                    });
+                    ST.mark(14);    // substeps with rows: the wait for (M + h B)^-1
+                }
+                ST.mark(it == 0 ? 8 : 9);
+                if (!__any(changed)) break;
+                // one limit row of a particle changed state: Sherman-Morrison instead of a second factorisation (arm_front)
+                const float nflip = gsum(flip ? 1.0f : 0.0f);
+                if (!__any(cflip || nflip > 1.5f)) {
+                    LDS_WAVE_SYNC();                    // (V_XH: the contact parts have been read)
+                    if (flip) {
+                        T zjj = col[0];
+#pragma unroll
+                        for (int i = 1; i < MAX_LINKS; ++i) zjj = (l8 == i) ? col[i] : zjj;
+                        const T c = act ? D : -D;
+                        ldsM[V_XH + 0] = (T)l8;
+                        ldsM[V_XH + 1] = c;
+                        ldsM[V_XH + 2] = c * sig * aref;
+                        ldsM[V_XH + 3] = zjj;
+                        ldsM[V_XH + 4] = aw;
+                    }
+                    LDS_WAVE_SYNC();
+                    if (nflip > 0.5f) {
+                        const int j = (int)ldsM[V_XH + 0];
+                        const T c = ldsM[V_XH + 1], dl = ldsM[V_XH + 2], zjj = ldsM[V_XH + 3], aj = ldsM[V_XH + 4];
+                        T z = col[0];
+#pragma unroll
+                        for (int i = 1; i < MAX_LINKS; ++i) z = (j == i) ? col[i] : z;
+                        const T yj = aj + dl * zjj;
+                        aw = (aw + dl * z) - c * z * yj * rcp_(T(1) + c * zjj);
+                    }
+                    active_set(aw, sig, aref, jc, arefc, inst, cinst, act, cact, act2, cact2);
+                    changed = (act2 != act) || (cact2 != cact);
+                    act = act2;
+                    cact = cact2;
+                    ST.mark(9);
+                    if (!__any(changed)) break;
+                }
+                LDS_WAVE_SYNC();                        // V_RH / V_XH are rewritten
+            }
+            if (changed && diag) atomicAdd(diag, 1u);
+            rows = (inst ? 1 : 0) | (act ? 2 : 0) | (cinst ? 4 : 0) | (cact ? 8 : 0);
+            qfrc_c = act ? -D * (sig * aw - aref) * sig : T(0);
+            if (__any(cact)) {
+                T fcn = cact ? -Dc * (gsum(jc * aw) - arefc) : T(0);
+                qfrc_c += jc * fcn;
+            }
+            ldsM[V_RE + l8] = tau + qfrc_c;
+            LDS_WAVE_SYNC();
+        }
+        T re[MAX_LINKS];
+        if (any_rows) {
+#pragma unroll
+            for (int i = 0; i < MAX_LINKS; ++i) re[i] = ldsM[V_RE + i];
+        } else {
+            // no rows: qacc = (M + h B)^-1 tau straight from the two hand-overs, one batch
+            q_take(qf, QF_TAU, seq, [&]() {
+#pragma unroll
+                for (int i = 0; i < MAX_LINKS; ++i) { re[i] = ldsM[V_TAU + i]; ei[i] = ldsM[V_EI + l8 * LANES + i]; }
+            }, QF_EI);
+            ST.mark(15);    // substeps without rows: the wait for tau and (M + h B)^-1
+        }
+        T x = T(0);
+#pragma unroll
+        for (int i = 0; i < MAX_LINKS; ++i) x += ei[i] * re[i];
+        ldsM[V_XE + l8] = x;
+        q_post(qf, QF_X, seq, lane);
+        free_step = !any_rows;
+        ST.mark(10);
+    }
+}
+
 // second half of a substep: take delivery of qacc and integrate (every role runs the same instructions)
 template <int ROLE, typename T, typename MT, typename RST = NoResetRecord>
 __device__ __forceinline__ void arm_back(const MT& M, T& q, T& v, T& aw, T& sq, T& cq, T* ldsM, int l8,
                                          bool free_step, Stamps& ST, int lane = 0, ResetCtl* rc = nullptr,
-                                         unsigned* diag = nullptr, RST record = RST()) {
+                                         unsigned* diag = nullptr, RST record = RST(), qflag_ptr qf = nullptr,
+                                         int seq = 0) {
     ST.mark(11);        // DYN: env-step records
     if constexpr (ROLE == DYN && ARM_SWAP) { duo_barrier(); ST.mark(7); }      // E2: inverse out (the other wave takes it after its Newton iterations)
-    if constexpr (ROLE == SOLO) LDS_WAVE_SYNC();
-    else duo_barrier();                                 // E3
+    T x;
+    if constexpr (ROLE == QDYN || ROLE == QMASS || ROLE == QAUX) {
+        q_take(qf, QF_X, seq, [&]() { x = ldsM[V_XE + l8]; });          // flag shapes: qacc is out
+    } else {
+        if constexpr (ROLE == SOLO || ROLE == QSOLVE) LDS_WAVE_SYNC();
+        else duo_barrier();                             // E3
+        x = ldsM[V_XE + l8];
+    }
     ST.mark(12);        // wait at B
     const T h = M.glob(O_TIMESTEP);
     {
-        T x = ldsM[V_XE + l8];
         if (free_step) aw = x;
         // explicitly rounded products and sums: the two waves of a DUO group must compute bit-identical (q, v), so the
         // compiler may not contract these differently in the two instantiations
@@ -1052,7 +1474,7 @@ __device__ __forceinline__ void arm_back(const MT& M, T& q, T& v, T& aw, T& sq, 
                     cq = (T)rst[3 * LANES + 3 + l8];
                     aw = T(0);
                     rflags_set<ROLE>(ldsM, rflags<ROLE>(ldsM) | 1 | 4);
-                    if (ROLE != SOLVE && diag && l8 == 0 && rc->count) atomicAdd(diag + 1, 1u);
+                    if (role_counts<ROLE>() && diag && l8 == 0 && rc->count) atomicAdd(diag + 1, 1u);
                 } else if (bal & mine) {
                     rflags_set<ROLE>(ldsM, rflags<ROLE>(ldsM) | 2);
                 }
@@ -1141,9 +1563,8 @@ __device__ __forceinline__ void real_env_step(const MT& M, const ArmInts& I, con
 
 // Softmax statistics of this workgroup's particles -> record {max, S, W[H A]} with weights exp(x_p - max),
 // x_p = -q0_p / lam (mppi.py:84-97), left in global memory for the finish kernel.
-template <typename T, bool DUO>
+template <typename T, int NT>
 __device__ __forceinline__ void mono_record(double lam, double* __restrict__ rec_out, int HA, double* red, const T* actT) {
-    constexpr int NT = DUO ? 128 : 64;
     const int tid = threadIdx.x;
     __syncthreads();                // q0 of the particles and the action tile are complete
     if (tid < LANES) {              // eight lanes: max, weights, their sum (8-lane butterfly inside one DPP row)
@@ -1328,26 +1749,34 @@ __global__ __launch_bounds__(128) void arm_mppi_finish_kernel(const T* __restric
 // kernel, actions kept in LDS, ONE softmax record {max, S, W[H A]} per workgroup left in the engine's record buffer; the
 // merge, mean update, action, shift and real-env step are launch 2 (arm_mppi_finish_kernel).  (An in-kernel merge behind
 // arrival counters was measured and dropped: agent-scope fences / dependent L2 round trips cost more than a launch.)
-template <typename T, bool STEP, bool CL, int WAVES, bool DUO, bool MONO>
-__global__ __launch_bounds__(DUO ? 128 : 64) __attribute__((amdgpu_waves_per_eu(WAVES, WAVES))) void arm_rollout_kernel(const T* __restrict__ model, const double* state,
-                                                         long P, int H, int A, const double* mean,
-                                                         const T* __restrict__ noise, T* __restrict__ cost,
-                                                         T* __restrict__ act, T* __restrict__ obs,
-                                                         T* __restrict__ nobs, double* state_out, unsigned* diag,
-                                                         RolloutFusion fuse, const MonoStep mono_arg) {
-    const MonoStep* mop = &mono_arg;      // (a kernel argument: its fields arrive with the other arguments, no pointer chase)
-    __shared__ __attribute__((aligned(16))) T lds[LANES * PSTRIDE + ARM_BLOB_LEN + 3];
+// SHAPE: 1 (SOLO), 2 (DUO: two wavefronts per particle group meeting at barriers), 12 / 14 (round 6: two / four wavefronts
+// handing over behind flags, flag_front; their own __global__ below, arm_rollout_flags_kernel)
+template <typename T, bool STEP, bool CL, int SHAPE, bool MONO>
+__device__ __forceinline__ void arm_rollout_body(const T* __restrict__ model, const double* state,
+                                                 long P, int H, int A, const double* mean,
+                                                 const T* __restrict__ noise, T* __restrict__ cost,
+                                                 T* __restrict__ act, T* __restrict__ obs,
+                                                 T* __restrict__ nobs, double* state_out, unsigned* diag,
+                                                 const RolloutFusion& fuse, const MonoStep* mop) {
+    constexpr bool DUO = SHAPE == 2, QUAD = SHAPE > 10;     // QUAD: the flag-synchronised shapes
+    constexpr int NW = SHAPE > 10 ? SHAPE - 10 : SHAPE;     // wavefronts per particle group
+    constexpr int STRIDE = PSTRIDE;
+    __shared__ __attribute__((aligned(16))) T lds[LANES * STRIDE + ARM_BLOB_LEN + 3];
+    __shared__ int qflags[QF_COUNT];        // flag shapes: hand-over flags of the workgroup's waves (flag_front)
+    qflag_ptr qf = (qflag_ptr)qflags;
+    int seq = 0;                            // flag shapes: substep sequence number
     extern __shared__ __attribute__((aligned(16))) double dyn_lds[];     // MONO: scratch [MONO_RED] | action tile T[8][H A]
-    static_assert(!(DUO && CL), "the closed-loop-linear variant runs one wave per particle group");
+    static_assert(!((DUO || QUAD) && CL), "the closed-loop-linear variant runs one wave per particle group");
     static_assert(!(MONO && (CL || STEP)), "the one-launch iteration is open-loop MPPI");
-    constexpr int NT = DUO ? 128 : 64;
+    constexpr int NT = 64 * NW;
     const int lane = threadIdx.x & 63;
-    const int wave = DUO ? __builtin_amdgcn_readfirstlane(threadIdx.x >> 6) : 0;
+    const int wave = NW > 1 ? __builtin_amdgcn_readfirstlane(threadIdx.x >> 6) : 0;
     const int l8 = lane_link(lane), g = lane_slot(lane);
     const long pid = (long)blockIdx.x * LANES + g;
     const bool live = pid < P;
-    for (int k = threadIdx.x; k < LANES * PSTRIDE; k += NT) lds[k] = T(0);
-    T* ldsModel = lds + LANES * PSTRIDE;
+    for (int k = threadIdx.x; k < LANES * STRIDE; k += NT) lds[k] = T(0);
+    if (QUAD && threadIdx.x < QF_COUNT) qflags[threadIdx.x] = 0;
+    T* ldsModel = lds + LANES * STRIDE;
     ResetCtl rc;
     rc.count = live;
     // my model block's reset record: its address waits in LDS for the rare path (held in scalar registers through the
@@ -1364,8 +1793,8 @@ __global__ __launch_bounds__(DUO ? 128 : 64) __attribute__((amdgpu_waves_per_eu(
     if (fuse.state_shard_size > 0) state += ((long)blockIdx.x * LANES / fuse.state_shard_size) * (2 * LANES + 3);
     for (int k = threadIdx.x; k < ARM_BLOB_LEN; k += NT) ldsModel[k] = model[k];
     __syncthreads();
-    T* ldsM = lds + g * PSTRIDE;
-    Model<T, DUO> M{ldsModel, l8};
+    T* ldsM = lds + g * STRIDE;
+    Model<T, (DUO || QUAD)> M{ldsModel, l8};
     M.cache();
     ArmInts I;
     I.site_link = (int)model[O_SITE_LINK];
@@ -1383,6 +1812,9 @@ __global__ __launch_bounds__(DUO ? 128 : 64) __attribute__((amdgpu_waves_per_eu(
     sincos_(q, sinq, cosq);
     if (resets) {
         if (DUO && wave == 1) reset_check_start<SOLVE>(rc, q, v, lane, ldsM);
+        else if (QUAD && wave == 1) reset_check_start<QSOLVE>(rc, q, v, lane, ldsM);
+        else if (QUAD && wave == 2) reset_check_start<QAUX>(rc, q, v, lane, ldsM);
+        else if (QUAD && wave == 3) reset_check_start<QMASS>(rc, q, v, lane, ldsM);
         else reset_check_start<SOLO>(rc, q, v, lane, ldsM);
     }
     const int site_lane = lane_of_link(lane, I.site_link);
@@ -1406,7 +1838,7 @@ __global__ __launch_bounds__(DUO ? 128 : 64) __attribute__((amdgpu_waves_per_eu(
         for (int k = 0; k < 3; ++k) chand[k] = __shfl(s0[k], site_lane);
     }
 
-    constexpr int R = DUO ? DYN : SOLO;
+    constexpr int R = QUAD ? QDYN : (DUO ? DYN : SOLO);
     const int HA = H * A;
     T* actT = (T*)(dyn_lds + MONO_RED);          // MONO: the actions of my workgroup's particles, [8][H A]
     if (DUO && wave == 1) {         // the SOLVE wave: no inputs, no records - mass matrix, constraints, solves
@@ -1419,6 +1851,24 @@ __global__ __launch_bounds__(DUO ? 128 : 64) __attribute__((amdgpu_waves_per_eu(
                     arm_back<SOLVE>(M, q, v, aw, sinq, cosq, ldsM, l8, fs, ST, lane, &rc, nullptr, record);
                 }
             ST.flush(diag, 1, lane);
+        }
+        if constexpr (!MONO) return;
+    } else if (QUAD && wave >= 1) { // flag shapes: the waves beside the one that owns inputs and records (flag_front)
+        if constexpr (QUAD) {
+            bool fs;
+            T nosite[3];
+#define MJMPC_FLAG_LOOP(ROLE_)                                                                                              \
+            for (int t = 0; t < H; ++t)                                                                                     \
+                for (int sub = 0; sub < I.frame_skip; ++sub) {                                                              \
+                    ++seq;                                                                                                  \
+                    flag_front<ROLE_, NW>(M, I, q, v, aw, sinq, cosq, rows, T(0), ldsM, qf, seq, lane, l8, nosite, diag, fs, ST, &rc); \
+                    arm_back<ROLE_>(M, q, v, aw, sinq, cosq, ldsM, l8, fs, ST, lane, &rc, nullptr, record, qf, seq);       \
+                }
+            if (wave == 1) { MJMPC_FLAG_LOOP(QSOLVE) }
+            else if (wave == 2) { MJMPC_FLAG_LOOP(QAUX) }
+            else { MJMPC_FLAG_LOOP(QMASS) }
+#undef MJMPC_FLAG_LOOP
+            ST.flush(diag, wave, lane);
         }
         if constexpr (!MONO) return;
     } else {
@@ -1527,8 +1977,13 @@ __global__ __launch_bounds__(DUO ? 128 : 64) __attribute__((amdgpu_waves_per_eu(
         bool fs = false;
         if (__builtin_expect(rc.any, 0)) rflags_set<R>(ldsM, rflags<R>(ldsM) & 2);     // a new env step: do_simulation writes data.ctrl again (a pending reset stays)
         for (int sub = 0; sub < I.frame_skip; ++sub) {
-            if (R == DYN && sub > 0) arm_back<R>(M, q, v, aw, sinq, cosq, ldsM, l8, fs, ST, lane, &rc, diag, record);
-            arm_front<R>(M, I, q, v, aw, sinq, cosq, rows, tau_act, ldsM, lane, l8, site, diag, fs, ST, &rc);
+            if ((R == DYN || R == QDYN) && sub > 0) arm_back<R>(M, q, v, aw, sinq, cosq, ldsM, l8, fs, ST, lane, &rc, diag, record, qf, seq);
+            if constexpr (QUAD) {
+                ++seq;
+                flag_front<R, NW>(M, I, q, v, aw, sinq, cosq, rows, tau_act, ldsM, qf, seq, lane, l8, site, diag, fs, ST, &rc);
+            } else {
+                arm_front<R>(M, I, q, v, aw, sinq, cosq, rows, tau_act, ldsM, lane, l8, site, diag, fs, ST, &rc);
+            }
             if constexpr (R == SOLO) arm_back<R>(M, q, v, aw, sinq, cosq, ldsM, l8, fs, ST, lane, &rc, diag, record);
             if (t == 0 && sub == 0 && obs)                  // fresh observation after set_env_state
                 for (int k = 0; k < 3; ++k) chand[k] = __shfl(site[k], site_lane);
@@ -1552,8 +2007,8 @@ __global__ __launch_bounds__(DUO ? 128 : 64) __attribute__((amdgpu_waves_per_eu(
         if (fuse.gseq) q0acc += gs_cur * (double)cst;
         // MONO: the next step's sample, drawn while the SOLVE wave is still iterating (DUO) / once per env step (SOLO)
         if constexpr (MONO) { if (t + 1 < H) { const T en = draw(t + 1); if (sampled) eps_next = en; } }
-        if constexpr (R == DYN) {
-            arm_back<R>(M, q, v, aw, sinq, cosq, ldsM, l8, fs, ST, lane, &rc, diag, record);
+        if constexpr (R == DYN || R == QDYN) {
+            arm_back<R>(M, q, v, aw, sinq, cosq, ldsM, l8, fs, ST, lane, &rc, diag, record, qf, seq);
 #ifndef ARM_NO_FIXUP            // (developer A/B)
             if (__builtin_expect(rc.any, 0)) {
                 // the last substep ended in mj_checkAcc's reset: site_xpos is the reset state's (mj_forward ran again) - the
@@ -1603,6 +2058,7 @@ __global__ __launch_bounds__(DUO ? 128 : 64) __attribute__((amdgpu_waves_per_eu(
         ST.mark(14);    // observation records, loop
     }
     ST.flush(diag, 0, lane);
+    if (QUAD && diag && lane == 0 && q_read(qf, QF_STUCK)) atomicAdd(diag, 0x10000u);     // a hand-over timed out: the results are void
     // A rollout that diverged numerically (MuJoCo would have reset that simulation) carries a non-finite return: it
     // leaves the update as +inf - zero weight in the softmax updates, last in the elite ranking - instead of poisoning
     // the mean with a NaN
@@ -1616,7 +2072,31 @@ __global__ __launch_bounds__(DUO ? 128 : 64) __attribute__((amdgpu_waves_per_eu(
     if constexpr (MONO) { if (l8 == 0) dyn_lds[g] = live ? q0acc : INFINITY; }     // cost-to-go of my particle
     }   // (wave 0 / the one wave)
     if constexpr (MONO)
-        mono_record<T, DUO>(mop->lam, mop->tree + (long)blockIdx.x * (2 + HA), HA, dyn_lds, actT);
+        mono_record<T, NT>(mop->lam, mop->tree + (long)blockIdx.x * (2 + HA), HA, dyn_lds, actT);
+}
+
+template <typename T, bool STEP, bool CL, int WAVES, bool DUO, bool MONO>
+__global__ __launch_bounds__(DUO ? 128 : 64) __attribute__((amdgpu_waves_per_eu(WAVES, WAVES))) void arm_rollout_kernel(const T* __restrict__ model, const double* state,
+                                                         long P, int H, int A, const double* mean,
+                                                         const T* __restrict__ noise, T* __restrict__ cost,
+                                                         T* __restrict__ act, T* __restrict__ obs,
+                                                         T* __restrict__ nobs, double* state_out, unsigned* diag,
+                                                         RolloutFusion fuse, const MonoStep mono_arg) {
+    // (mono_arg is a kernel argument: its fields arrive with the other arguments, no pointer chase)
+    arm_rollout_body<T, STEP, CL, DUO ? 2 : 1, MONO>(model, state, P, H, A, mean, noise, cost, act, obs, nobs, state_out, diag,
+                                                     fuse, &mono_arg);
+}
+// The flag-synchronised shapes: NW = 2 (a 128-thread workgroup, as DUO) and NW = 4 (P <= 2048 on 256 CUs: a 256-thread
+// workgroup = the four waves of a particle group, one per SIMD of a CU)
+template <typename T, int NW, bool MONO>
+__global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(1, 1))) void arm_rollout_flags_kernel(const T* __restrict__ model, const double* state,
+                                                         long P, int H, int A, const double* mean,
+                                                         const T* __restrict__ noise, T* __restrict__ cost,
+                                                         T* __restrict__ act, T* __restrict__ obs,
+                                                         T* __restrict__ nobs, unsigned* diag,
+                                                         RolloutFusion fuse, const MonoStep mono_arg) {
+    arm_rollout_body<T, false, false, 10 + NW, MONO>(model, state, P, H, A, mean, noise, cost, act, obs, nobs, nullptr, diag, fuse,
+                                                     &mono_arg);
 }
 
 }  // namespace
@@ -1664,6 +2144,26 @@ hipError_t launch_arm_rollout(const T* model, const double* state, long P, int H
     const bool one_per_simd = !duo && !fuse.clw && (one_env >= 0 ? one_env != 0 : (long)grid <= simds);
     const MonoStep mono_arg = mono ? *mono : MonoStep();
     const size_t dyn = mono ? sizeof(double) * MONO_RED + sizeof(T) * LANES * (size_t)H * A : 0;
+    // Round 6: the flag-synchronised shapes take the launches DUO took (no barrier waits on the critical wave), with four
+    // wavefronts per particle group while every one of them still has a SIMD of its own (P <= 2048 on 256 CUs) - the launches
+    // that are BASELINE config 2 and the shards of a strong-scaling run.  The real-env step (state_out) keeps DUO.
+    // MJMPC_ARM_FLAGS=0 (back to DUO) / 2 / 4 overrides the choice (developer switch for A/B timing).
+    static const int flags_env = [] { const char* e = getenv("MJMPC_ARM_FLAGS"); return e ? atoi(e) : -1; }();
+    int nw = 0;
+    if (duo && !state_out && duo_env < 0) nw = flags_env >= 0 ? flags_env : (4L * grid <= simds ? 4 : 2);
+    if (nw == 2 || nw == 4) {
+        if (mono) {
+            if (obs || nobs || !fuse.gseq || !mono->chol || !mono->tree) return hipErrorInvalidValue;
+            if (dyn + sizeof(T) * (LANES * PSTRIDE + ARM_BLOB_LEN + 3) > 64 * 1024) return hipErrorInvalidValue;
+        }
+#define MJMPC_LAUNCH_F(NW_, MONO_)                                                                                        \
+        hipLaunchKernelGGL((arm_rollout_flags_kernel<T, NW_, MONO_>), dim3(grid), dim3(64 * NW_), dyn, stream, model, state, P, H, A, \
+                           mean, noise, cost, act, obs, nobs, diag, fuse, mono_arg)
+        if (nw == 4) { if (mono) MJMPC_LAUNCH_F(4, true); else MJMPC_LAUNCH_F(4, false); }
+        else { if (mono) MJMPC_LAUNCH_F(2, true); else MJMPC_LAUNCH_F(2, false); }
+#undef MJMPC_LAUNCH_F
+        return hipGetLastError();
+    }
 #define MJMPC_LAUNCH_W(STEP_, CL_, W_, DUO_, MONO_)                                                                   \
     hipLaunchKernelGGL((arm_rollout_kernel<T, STEP_, CL_, W_, DUO_, MONO_>), dim3(grid), dim3(DUO_ ? 128 : 64), dyn,  \
                        stream, model, state, P, H, A, mean, noise, cost, act, obs, nobs, state_out, diag, fuse, mono_arg)

@@ -18,7 +18,7 @@
 #include "update.h"
 
 // failure counter (one unsigned) followed by the phase-clock slots of developer builds (arm_rollout.hip, Stamps)
-constexpr size_t MJMPC_DIAG_BYTES = 8 * (2 + 32);
+constexpr size_t MJMPC_DIAG_BYTES = 8 * (2 + 64);      // counters, then the developer clocks of -DMJMPC_STAMPS builds (4 waves x 16)
 
 namespace {
 
@@ -629,8 +629,8 @@ int mjmpc_arm_diverged(mjmpc_arm_t h, uint32_t* count) {
 extern "C" int mjmpc_debug_stamps(mjmpc_arm_t h, unsigned long long* out32) {
     if (!h || !out32) return fail(MJMPC_E_BADARG, "null argument");
     HIP_TRY(hipDeviceSynchronize());
-    HIP_TRY(hipMemcpy(out32, (char*)h->diag + 16, 8 * 32, hipMemcpyDeviceToHost));
-    HIP_TRY(hipMemset((char*)h->diag + 16, 0, 8 * 32));
+    HIP_TRY(hipMemcpy(out32, (char*)h->diag + 16, 8 * 64, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemset((char*)h->diag + 16, 0, 8 * 64));
     return 0;
 }
 #endif

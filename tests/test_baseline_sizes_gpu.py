@@ -1,8 +1,8 @@
 """GPU parity at the sizes BASELINE.json quotes: the HIP path against the FP64 C oracle +
 the numpy controller restatement on the same seeded inputs, at full size.
 
-  * rollout, 1024 x 32 and 4096 x 32 (the launches that run two wavefronts per particle group): every cost vs
-    ``RefArm.rollout``, rel <= 1e-9;
+  * rollout, 512 / 1024 / 2048 x 32 (the launches that run FOUR wavefronts per particle group) and 4096 x 32 (two):
+    every cost vs ``RefArm.rollout``, rel <= 1e-9;
   * the SURVEY 7 "minimum slice": ``MPPI.optimize()`` driven by the HIP ``rollout_fn`` vs ``mppi_update`` on oracle
     rollouts, identical host noise, 1024 x 32, lam = 0.01 (BASELINE) and lam = 5.0 (a softmax that is NOT an argmin);
   * BASELINE config 3, CEM full covariance 16384 x 32, elite_frac 0.1: one whole step (HIP rollout + HIP update)
@@ -35,9 +35,10 @@ def _filtered(P, H, A, seed, scale=1.0):
     return eps
 
 
-@pytest.mark.parametrize("P", [1024, 4096])
+@pytest.mark.parametrize("P", [512, 1024, 2048, 4096])
 @pytest.mark.parametrize("state", [START, MOVING], ids=["qpos0", "moving"])
 def test_rollout_matches_oracle_at_baseline_size(eng64, ref_arm, P, state):
+    """P <= 2048: the launches of FOUR wavefronts per particle group (arm_rollout_quad_kernel, round 6); 4096: two."""
     H = 32
     noise = _filtered(P, H, 7, 1000 + P)
     mean = 0.2 * np.random.RandomState(P).standard_normal((H, 7))

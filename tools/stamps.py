@@ -18,15 +18,15 @@ def build():
     subprocess.check_call(cmd)
 
 
-NAMES = ["kinematics", "link frames", "velocities+bias (DYN)", "wait A (DYN)", "CRBA+tile", "rows", "factor #1",
-         "wait A (SOLVE)", "solve #1 + check", "more Newton iterations", "force + Euler solve", "records (DYN)", "wait B",
-         "integrate", "obs records / loop", "-"]
+NAMES = ["kinematics", "link frames", "velocities+bias (DYN)", "wait A (DYN) / tiles (QUAD)", "CRBA+tile", "rows", "factor #1",
+         "wait A (SOLVE) / tau (QUAD)", "solve #1 + check", "more Newton iterations", "force + Euler solve", "records (DYN)", "wait B / X",
+         "integrate", "obs records / loop | EI wait, rows (flags)", "EI wait, no rows (flags)"]
 
 if __name__ == "__main__":
     if "--build" in sys.argv:
         build()
         sys.exit(0)
-    os.environ["MJMPC_AMD_LIB"] = LIB
+    os.environ["MJMPC_AMD_LIB"] = os.environ.get("STAMPS_LIB", LIB)      # (STAMPS_LIB: a tools/dev_build.sh library)
     import torch
     from mjmpc_amd import _lib
     from mjmpc_amd.envs.arm_engine import ArmRolloutEngine
@@ -42,14 +42,20 @@ if __name__ == "__main__":
     g = torch.Generator(device="cuda").manual_seed(0)
     noise = torch.randn(P, H, 7, device="cuda", dtype=torch.float32 if dt == "f32" else torch.float64, generator=g)
     mean = torch.zeros(H, 7, device="cuda", dtype=torch.float64)
-    out = (ctypes.c_uint64 * 32)()
+    out = (ctypes.c_uint64 * 64)()
     for _ in range(3):
         eng.rollout_device(P, H, mean, noise)
     lib.mjmpc_debug_stamps(eng._h, out)
     eng.rollout_device(P, H, mean, noise)
     lib.mjmpc_debug_stamps(eng._h, out)
     nsub = H * 2
-    for w in range(2):
+    if "--timeline" in sys.argv:        # a library built with -DMJMPC_STAMPS_ABS=n: absolute clocks of substep n
+        ev = [(out[16 * w + k], w, k) for w in range(4) for k in range(16) if out[16 * w + k]]
+        t0 = min(e[0] for e in ev)
+        for t, w, k in sorted(ev):
+            print("%8d  %s wave %d  %s" % (t - t0, "      " * w, w, NAMES[k]))
+        sys.exit(0)
+    for w in range(4):
         tot = sum(out[16 * w + k] for k in range(16))
         if tot == 0:
             continue
