@@ -1155,6 +1155,11 @@ __device__ __forceinline__ void q_take(qflag_ptr qf, int which, int seq, F&& loa
     __builtin_amdgcn_sched_barrier(0);
 }
 
+// NW = 4: the diagonals 0 ... ARM_NEAR_DIAGS - 1 of the mass matrix stay with the solving wave, the others go to QMASS (which
+// starts a hand-over later but has nothing else to do).  Measured at 1024 x 32 f64: 1: 176.0, 2: 174.4, 3: 171.1, 4: 172.7 us
+#ifndef ARM_NEAR_DIAGS
+#define ARM_NEAR_DIAGS 3
+#endif
 template <int ROLE, int NW, typename T, typename MT>
 __device__ __forceinline__ void flag_front(const MT& M, const ArmInts& I, T& q, T& v, T& aw, T& sq, T& cq, int& rows,
                                            T tau_act, T* ldsM, qflag_ptr qf, int seq, int lane, int l8, T* site,
@@ -1227,7 +1232,7 @@ __device__ __forceinline__ void flag_front(const MT& M, const ArmInts& I, T& q, 
         ST.mark(2);
     }
     if constexpr (ROLE == QMASS) {
-        mass_matrix_tile_part<4, MAX_LINKS>(L, l8, ldsM);
+        mass_matrix_tile_part<ARM_NEAR_DIAGS, MAX_LINKS>(L, l8, ldsM);
         q_post(qf, QF_TILE2, seq, lane);
         ST.mark(4);
         return;
@@ -1247,7 +1252,7 @@ __device__ __forceinline__ void flag_front(const MT& M, const ArmInts& I, T& q, 
         ST.mark(6);
     }
     if constexpr (ROLE == QSOLVE) {
-        T dgM = SPLIT ? mass_matrix_tile_part<0, 4>(L, l8, ldsM) : mass_matrix_tile(L, l8, ldsM);
+        T dgM = SPLIT ? mass_matrix_tile_part<0, ARM_NEAR_DIAGS>(L, l8, ldsM) : mass_matrix_tile(L, l8, ldsM);
         dgM += M.link(O_ARMATURE);
         ldsM[V_DE + l8] = dgM + h * damping;
         q_post(qf, QF_TILE, seq, lane);
@@ -2144,13 +2149,13 @@ hipError_t launch_arm_rollout(const T* model, const double* state, long P, int H
     const bool one_per_simd = !duo && !fuse.clw && (one_env >= 0 ? one_env != 0 : (long)grid <= simds);
     const MonoStep mono_arg = mono ? *mono : MonoStep();
     const size_t dyn = mono ? sizeof(double) * MONO_RED + sizeof(T) * LANES * (size_t)H * A : 0;
-    // Round 6: the flag-synchronised shapes take the launches DUO took (no barrier waits on the critical wave), with four
-    // wavefronts per particle group while every one of them still has a SIMD of its own (P <= 2048 on 256 CUs) - the launches
-    // that are BASELINE config 2 and the shards of a strong-scaling run.  The real-env step (state_out) keeps DUO.
-    // MJMPC_ARM_FLAGS=0 (back to DUO) / 2 / 4 overrides the choice (developer switch for A/B timing).
+    // Round 6: the flag-synchronised shape with four wavefronts per particle group while every one of them still has a SIMD
+    // of its own (P <= 2048 on 256 CUs) - the launches that are BASELINE config 2 and the shards of a strong-scaling run.
+    // Above that DUO stays (the two-wave flag shape measures 4 % slower than DUO at 4096 particles: profiles/r06_arm_shapes.txt).
+    // The real-env step (state_out) keeps DUO.  MJMPC_ARM_FLAGS=0 (DUO) / 2 / 4 overrides the choice (developer A/B switch).
     static const int flags_env = [] { const char* e = getenv("MJMPC_ARM_FLAGS"); return e ? atoi(e) : -1; }();
     int nw = 0;
-    if (duo && !state_out && duo_env < 0) nw = flags_env >= 0 ? flags_env : (4L * grid <= simds ? 4 : 2);
+    if (duo && !state_out && duo_env < 0) nw = flags_env >= 0 ? flags_env : (4L * grid <= simds ? 4 : 0);
     if (nw == 2 || nw == 4) {
         if (mono) {
             if (obs || nobs || !fuse.gseq || !mono->chol || !mono->tree) return hipErrorInvalidValue;
