@@ -85,6 +85,11 @@ def parse(argv=None):
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=10.0)
     ap.add_argument("--backend", default="nccl", help=argparse.SUPPRESS)          # test knobs: gloo on one GPU
+    ap.add_argument("--collectives", choices=["auto", "library", "torch", "both"], default="both",
+                    help="N > 1: which path carries the control iteration's exchanges - libmjmpc_amd.so's own RCCL communicator "
+                         "(direct launches / launch tape) or torch.distributed (hipGraph replay).  'both' (default) times the "
+                         "headline on the library's path and the same loops again on torch's, reported beside it as "
+                         "`collectives_ab` (DESIGN 6); 'auto' = the library's where it is available")
     ap.add_argument("--device", type=int, default=None, help=argparse.SUPPRESS)
     return ap.parse_args(argv)
 
@@ -192,6 +197,16 @@ def profile_figure(name, dtype, P, H, prefix=""):
 
 
 # ---------------------------------------------------------------------------------------------------------- workloads
+def launch_kind_of(ctrl, graphed):
+    """How a wired controller issues its control iteration (the `launch` entries of the JSON line)."""
+    kind = "hipGraph replay" if (graphed and not getattr(ctrl, "graph_fallback", False)) else "eager"
+    if graphed and getattr(ctrl, "_graph", None) == "direct":
+        kind = "two kernels per iteration, launched directly"
+    elif graphed and kind != "eager" and getattr(ctrl, "launch_mode", None):
+        kind = ctrl.launch_mode             # "hipGraph replay" or "launch tape (n calls, k kernels)"
+    return kind
+
+
 def make_workload(args, local, comm, P_tot):
     """Engine + controller + bookkeeping of one (workload, controller) pair."""
     from mjmpc_amd.control import CEM, DMDMPC, MPPI
@@ -256,9 +271,9 @@ def make_workload(args, local, comm, P_tot):
     A = eng.d_action
     base_reset = w["reset"]
 
-    def make_ctrl(P_total):
+    def make_ctrl(P_total, comm=comm):
         """A controller over P_total particles (this rank's block of them) on this workload's engine, and the reset
-        that goes with it."""
+        that goes with it (``comm``: another communicator than the run's - the A/B of the exchange paths)."""
         kw = dict(d_state=eng.d_state, d_obs=eng.d_obs, d_action=A, horizon=H, num_particles=P_total, n_iters=1,
                   action_lows=eng.action_lows, action_highs=eng.action_highs, seed=123, base_action="null", gamma=1.0,
                   step_size=1.0, filter_coeffs=[0.25, 0.8, 0.0], init_cov=w["cov"],
@@ -310,7 +325,8 @@ def main():
         else:
             dist.init_process_group(args.backend)
         from mjmpc_amd.control._device import TorchDistComm
-        comm = TorchDistComm()
+        comm = TorchDistComm(device=torch.device("cuda", local) if args.backend == "nccl" else None,
+                             library_collectives={"torch": False, "library": True}.get(args.collectives))
 
     from mjmpc_amd.build import build_info
     from mjmpc_amd.control.controller import resident_state
@@ -500,28 +516,56 @@ def main():
     # ("4096 particles x H=32 reported at 1, 2, 4 and 8": the reference's num_particles is a total,
     # examples/example_mpc.py:78-79) - a second controller over --particles IN TOTAL, this rank's block = particles / N,
     # on the same engine, timed the same way.  Reported beside the headline as `strong`, never as `value`.
+    import gc
+
+    def side_loop(P_total, comm_):
+        """The same closed loop once more with a controller of its own (P_total particles in all, exchanges through comm_):
+        (seconds for the K timed steps, launch kind)."""
+        ctrl._graph = None                  # graphs holding RCCL kernels of the loop before go first
+        gc.collect()
+        torch.cuda.synchronize()
+        ctrl_s, _, reset_s = w["make_ctrl"](P_total, comm_)
+        graphed_s, step_s = wire(ctrl_s)
+        reset_s()
+        dts = timed_loop(ctrl_s, step_s, reset_s, min(args.process_warmup, 20))
+        kind = launch_kind_of(ctrl_s, graphed_s)
+        ctrl_s._graph = None
+        del ctrl_s
+        gc.collect()
+        torch.cuda.synchronize()
+        return dts, kind
+
     strong = None
+    strong_ok = world > 1 and args.scaling == "weak" and not (args.particles % world or (args.particles // world) % 8)
     if world > 1 and args.scaling == "weak":
-        if args.particles % world or (args.particles // world) % 8:
+        if not strong_ok:
             strong = {"skipped": "%d particles do not split into blocks of a multiple of 8 over %d GPUs" % (args.particles, world)}
         else:
-            import gc
-            ctrl._graph = None              # graphs holding RCCL kernels of the weak loop go first
-            gc.collect()
-            torch.cuda.synchronize()
-            ctrl_s, _, reset_s = w["make_ctrl"](args.particles)
-            graphed_s, step_s = wire(ctrl_s)
-            reset_s()
-            dts = timed_loop(ctrl_s, step_s, reset_s, min(args.process_warmup, 20))
-            strong = {"ms_per_step": dts / args.steps * 1e3, "value": args.particles * H * ctrl_s.n_iters * args.steps / dts,
+            dts, kind_s = side_loop(args.particles, comm)
+            strong = {"ms_per_step": dts / args.steps * 1e3, "value": args.particles * H * ctrl.n_iters * args.steps / dts,
                       "unit": "particle-steps/s", "control_loop_hz": args.steps / dts, "particles_total": args.particles,
                       "particles_per_gpu": args.particles // world, "scaling": "strong",
-                      "launch": ("hipGraph replay" if (graphed_s and not getattr(ctrl_s, "graph_fallback", False)) else "eager"),
+                      "launch": kind_s, "collectives": comm.collectives,
                       "what": "the same closed loop with --particles as the TOTAL population, split over the ranks "
                               "(subproc_vec_env.py:161-168); same steps / warmup, MAX over ranks"}
-            ctrl_s._graph = None
-            gc.collect()
-            torch.cuda.synchronize()
+    # N > 1, --collectives both: the same loops again with the exchanges on the OTHER path - torch.distributed's collectives in
+    # a replayed hipGraph where the headline ran the library's own RCCL communicator between direct launches (DESIGN 6) - so
+    # that ONE invocation of the driver's scaling run says which is faster on real links.  Never `value`.
+    collectives_ab = None
+    if world > 1 and args.collectives == "both" and args.backend == "nccl" and getattr(comm, "lib_collectives", False):
+        from mjmpc_amd.control._device import TorchDistComm as _Comm
+        comm_t = _Comm(device=torch.device("cuda", local), library_collectives=False)
+        dtw, kind_w = side_loop(P_tot, comm_t)
+        collectives_ab = {
+            "library RCCL": {"weak_ms_per_step": dt / args.steps * 1e3,
+                             "strong_ms_per_step": strong["ms_per_step"] if strong and "ms_per_step" in strong else None},
+            "torch.distributed": {"weak_ms_per_step": dtw / args.steps * 1e3, "strong_ms_per_step": None, "launch": kind_w},
+            "what": "the headline's loop (and `strong`) with the control iteration's exchanges on each path; "
+                    "the headline `value` is the library's"}
+        if strong_ok:
+            dts_t, _ = side_loop(args.particles, comm_t)
+            collectives_ab["torch.distributed"]["strong_ms_per_step"] = dts_t / args.steps * 1e3
+        comm_t.close()
     fails = eng.solver_failures()
 
     # HBM bytes of one launch of the dominant kernel from the PMC counters (separate rocprofv3 passes,
@@ -561,11 +605,7 @@ def main():
                     "issue_frac_source": issue_src}
         except Exception as e:          # the counting build is measurement infrastructure: never lose the line over it
             valu = {"bound": "valu", "error": "FLOP-counting oracle build unavailable: %s" % (e,)}
-    launch_kind = "hipGraph replay" if (graphed and not getattr(ctrl, "graph_fallback", False)) else "eager"
-    if graphed and getattr(ctrl, "_graph", None) == "direct":
-        launch_kind = "two kernels per iteration, launched directly"
-    elif graphed and launch_kind != "eager" and getattr(ctrl, "launch_mode", None):
-        launch_kind = ctrl.launch_mode          # "hipGraph replay" or "launch tape (n calls, k kernels)"
+    launch_kind = launch_kind_of(ctrl, graphed)
     out = {
         "metric": "particle-steps/sec (%s %s %dp x H%d per GPU, control loop incl. noise, rollout, update, shift)"
                   % (w["name"], args.controller.upper() if args.controller != "dmd" else "DMD-MPC", P_loc, H),
@@ -577,6 +617,11 @@ def main():
                    "controller": args.controller, "noise": args.noise, "particles_per_gpu": P_loc, "particles_total": P_tot,
                    "horizon": H, "ranks_seen": dist.get_world_size() if world > 1 else 1,
                    "backend": (dist.get_backend() if world > 1 else None),
+                   # which path carried the exchanges of the timed loop, what making the library's communicator took, and
+                   # whether any rank fell back from it (then EVERY rank did: TorchDistComm decides by all-reduce)
+                   "collectives": (comm.collectives if world > 1 else None),
+                   "comm_init_s": (round(comm.init_seconds, 4) if world > 1 else None),
+                   "collectives_fallback": ((comm.why_fell_back or True) if (world > 1 and comm.fell_back) else False),
                    "collectives_per_step": (0 if world == 1 else (2 if args.controller == "cem" else 1)),
                    "launch": launch_kind + (", rollout + record launches, all-gather, combine, env step" if (mono and world > 1) else "")
                              + (", next iteration enqueued ahead" if (mono and args.lookahead and world == 1) else ""),
@@ -617,6 +662,8 @@ def main():
         out["pipelined"] = pipelined
     if strong:
         out["strong"] = strong
+    if collectives_ab:
+        out["collectives_ab"] = collectives_ab
     out.update(extra)
     if rank == 0:
         if world == 1 and not args.no_cpu_baseline:

@@ -22,6 +22,162 @@ class SingleProcessComm:
     """World of one: the all-gather is the identity."""
     rank, world_size = 0, 1
 
+    collectives, fell_back, why_fell_back, init_seconds, lib_collectives = "none", False, "", 0.0, False
+
+    def all_gather(self, t):
+        return t.reshape(1, -1)
+
+    def all_gather_flat(self, t):
+        return t
+
+    def all_agree(self, ok, device=None):
+        return bool(ok)
+
+
+class TorchDistComm:
+    """One process per GPU over torch.distributed (backend "nccl" = RCCL over xGMI; "gloo" in CPU tests).
+
+    ``library_collectives`` (default: on where the backend is RCCL; ``MJMPC_TORCH_COLLECTIVES=1`` in the environment turns it
+    off): the float64 all-gathers of the control iteration are issued by libmjmpc_amd.so itself on a communicator of its
+    own (``mjmpc_comm_*``: the ranks of this group, the id handed out through one torch broadcast) - the same RCCL
+    collective, but a LIBRARY call, so that a sharded iteration runs from the launch tape / as direct launches like the
+    one-GPU loop instead of a hipGraph replay (controller.py).  Call ``close()`` before the process group
+    is destroyed."""
+
+    def __init__(self, group=None, library_collectives=None, device=None, init_timeout_s=None):
+        """``device``: the GPU this rank's communicator lives on (default: the current CUDA device WHEN THIS IS CALLED - call
+        ``torch.cuda.set_device`` first); ``init_timeout_s``: bound on the wait in ncclCommInitRank (default 60 s,
+        ``MJMPC_COMM_INIT_TIMEOUT``): a rank stuck longer prints why and EXITS the process with code 3 - its peers are waiting
+        for it inside a collective, there is nothing to fall back to from there."""
+        import os
+        import torch.distributed as dist
+        self._dist, self._group = dist, group
+        self.rank = dist.get_rank(group)
+        self.world_size = dist.get_world_size(group)
+        self.backend = dist.get_backend(group)
+        self._out = {}
+        self._lib_comm = None
+        self._gather_ranks = self.world_size
+        self.device = None
+        self.init_seconds = 0.0             # what making the library's communicator took (0: none was made)
+        self.fell_back = False              # the library's communicator was asked for and is not in use
+        self.why_fell_back = ""
+        self.init_timeout_s = float(init_timeout_s if init_timeout_s is not None
+                                    else os.environ.get("MJMPC_COMM_INIT_TIMEOUT", "60"))
+        if library_collectives is None:
+            library_collectives = self.backend == "nccl" and not os.environ.get("MJMPC_TORCH_COLLECTIVES")
+        want = bool(library_collectives) and self.backend == "nccl"
+        if self.backend == "nccl":
+            import torch
+            self.device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+            # ONE all-reduce decides for the whole group: ranks that disagree about the switch (an environment variable set
+            # on some of them) would otherwise enter different collectives and hang
+            agreed = self.all_agree(want, self.device)
+            if want and not agreed:
+                self.fell_back, self.why_fell_back = True, "the ranks disagree about library_collectives / MJMPC_TORCH_COLLECTIVES"
+            want = agreed
+        self.lib_collectives = want
+        if self.lib_collectives:
+            self._open_library_comm()
+
+    @property
+    def collectives(self):
+        """Which exchange path the control iterations of this communicator take (bench.py reports it)."""
+        return "library RCCL" if self.lib_collectives else "torch.distributed"
+
+    def _open_library_comm(self):
+        """The library's communicator, made when this object is (the controllers read ``lib_collectives`` when they choose how
+        to launch).  Every rank first checks that the library can reach RCCL at all; the ranks then go on TOGETHER or fall
+        back to torch.distributed's collectives together (a rank that could not bind RCCL would otherwise leave the others
+        waiting in ncclCommInitRank)."""
+        import time
+        import warnings
+        dev = self.device
+        ok, why = True, ""
+        try:
+            probe = (ctypes.c_ubyte * 128)()
+            _lib.check(_lib.load().mjmpc_comm_unique_id(probe))
+        except Exception as e:      # (no librccl the library can bind, an older library ...)
+            ok, why = False, str(e)
+        if self.all_agree(ok, dev):
+            t0 = time.perf_counter()
+            try:
+                self._library_comm(dev)
+            except Exception as e:
+                ok, why = False, str(e)
+            self.init_seconds = time.perf_counter() - t0
+            ok = self.all_agree(ok, dev)
+        else:
+            ok = False
+        if not ok:
+            self.close()
+            self.lib_collectives = False
+            self.fell_back, self.why_fell_back = True, why or "another rank failed"
+            warnings.warn("mjmpc_amd: the library's own RCCL communicator is not available (%s); the control iterations' exchanges go "
+                          "through torch.distributed (hipGraph replay instead of direct launches)" % self.why_fell_back)
+
+    def _library_comm(self, device):
+        """ncclCommInitRank of the library's own communicator over the ranks of this group (collective; outside any
+        stream capture: the controllers' dry run / first eager iteration gets here first).  The call runs on a helper thread
+        so that the wait can be bounded (``init_timeout_s``)."""
+        import os
+        import sys
+        import threading
+        import torch
+        lib = _lib.load()
+        ident = torch.zeros(128, dtype=torch.uint8, device=device)
+        if self.rank == 0:
+            buf = (ctypes.c_ubyte * 128)()
+            _lib.check(lib.mjmpc_comm_unique_id(buf))
+            ident.copy_(torch.frombuffer(bytearray(buf), dtype=torch.uint8))
+        src = self._dist.get_global_rank(self._group, 0) if self._group is not None else 0
+        self._dist.broadcast(ident, src=src, group=self._group)
+        raw = bytes(ident.cpu().numpy().tobytes())
+        h = ctypes.c_void_p()
+        box = {}
+
+        def init():
+            try:
+                box["rc"] = lib.mjmpc_comm_create(ctypes.c_char_p(raw), self._dist.get_world_size(self._group),
+                                                  self._dist.get_rank(self._group),
+                                                  device.index if device.index is not None else torch.cuda.current_device(),
+                                                  ctypes.byref(h))
+            except BaseException as e:      # noqa: B036 - handed to the caller's thread
+                box["exc"] = e
+
+        th = threading.Thread(target=init, name="mjmpc-comm-init", daemon=True)
+        th.start()
+        th.join(self.init_timeout_s)
+        if th.is_alive():
+            # ncclCommInitRank has not returned: some rank never arrived (or the fabric is down).  Nothing can be unwound from
+            # here - the peers sit in the same call - so say so and end THIS process (an exit, never a re-exec: this process
+            # has initialised the GPU)
+            sys.stderr.write("mjmpc_amd: rank %d waited %.0f s in ncclCommInitRank for the library's communicator (world size %d); "
+                             "giving up. Set MJMPC_TORCH_COLLECTIVES=1 to run the exchanges through torch.distributed.\n"
+                             % (self.rank, self.init_timeout_s, self.world_size))
+            sys.stderr.flush()
+            os._exit(3)
+        if "exc" in box:
+            raise box["exc"]
+        _lib.check(box["rc"])
+        self._lib_comm = (lib, h)
+
+    def close(self):
+        if self._lib_comm is not None:
+            lib, h = self._lib_comm
+            self._lib_comm = None
+            lib.mjmpc_comm_destroy(h)
+
+    def __del__(self):
+        # (not at interpreter teardown, and not once the process group is gone: ncclCommDestroy after HIP / RCCL shut down
+        # is undefined - call close() before destroy_process_group())
+        try:
+            import sys
+            if self._lib_comm is not None and not sys.is_finalizing() and self._dist.is_initialized():
+                self.close()
+        except Exception:
+            pass
+
     def all_gather(self, t):
         return t.reshape(1, -1)
 
@@ -123,8 +279,8 @@ class TorchDistComm:
         if out is None:
             out = self._out[key] = torch.empty(self.world_size * t.numel(), dtype=t.dtype, device=t.device)
         if self.lib_collectives and t.is_cuda and t.dtype == torch.float64:
-            if self._lib_comm is None:
-                self._library_comm(t.device)
+            if t.device != self.device:
+                raise ValueError("all_gather of a tensor on %s through a communicator made on %s" % (t.device, self.device))
             lib, h = self._lib_comm
             src = t.reshape(-1).contiguous()
             if src.data_ptr() != t.data_ptr():

@@ -34,6 +34,7 @@ def test_two_ranks_on_one_gpu():
     assert j["config"]["particles_per_gpu"] == 512
     assert abs(j["value"] - 2 * 512 * 32 * 6 / (j["ms_per_step"] * 6e-3)) / j["value"] < 1e-6     # whole-job aggregate
     _check_strong_block(j)
+    _check_collectives_fields(j)
 
 
 def _check_strong_block(j, H=32):
@@ -44,6 +45,16 @@ def _check_strong_block(j, H=32):
     assert abs(st["value"] - 512 * H * 6 / (st["ms_per_step"] * 6e-3)) / st["value"] < 1e-6
     assert abs(st["control_loop_hz"] - 1e3 / st["ms_per_step"]) / st["control_loop_hz"] < 1e-6
     assert j["scaling"] == "weak"                       # the headline keeps its label
+
+
+def _check_collectives_fields(j):
+    """the line says which exchange path ran, what the library's communicator cost to make and whether any
+    rank fell back - on gloo that is torch.distributed, no communicator, no fallback, and no A/B block (there is no second path)."""
+    c = j["config"]
+    assert c["collectives"] == "torch.distributed" and c["comm_init_s"] == 0 and c["collectives_fallback"] is False
+    assert "collectives_ab" not in j
+    if "strong" in j:
+        assert j["strong"]["collectives"] == "torch.distributed"
 
 
 def _self_launched(*flags):
@@ -61,6 +72,7 @@ def test_self_launch_mppi():
     assert abs(j["value"] - 2 * 512 * 32 * 6 / (j["ms_per_step"] * 6e-3)) / j["value"] < 1e-6
     assert j["solver_failures"] == 0
     _check_strong_block(j)
+    _check_collectives_fields(j)
     assert "arm_rollout.hip" in j["config"]["build"]       # which scheduler alternative the kernels were compiled with
 
 

@@ -24,4 +24,5 @@ def test_sharded_iteration_with_rccl_in_the_graph():
                          timeout=300, env=env)
     assert out.returncode == 0, (out.stdout[-1500:], out.stderr[-3000:])
     assert out.stdout.count("with an RCCL all-gather") == 2 and "\nok\n" in out.stdout
+    assert out.stdout.count("collectives: library RCCL") == 2          # (the path bench.py would report; no fallback)
     assert out.stdout.count("captured iteration with its RCCL exchanges") == 3        # CEM, DMD-MPC (update_cov), random shooting

@@ -61,7 +61,12 @@ def run(P, comm, mono):
 
 ref, _ = run(512, None, True)                       # 512 particles on one GPU
 for mono in (True, False):
-    got, info = run(1024, ClaimsTwoRanks(), mono)   # "1024 over two ranks": this rank's 512 are the same particles
+    comm2 = ClaimsTwoRanks()
+    # which exchange path this communicator gives the controllers (bench.py's config.collectives), and what it cost to make
+    want = "torch.distributed" if os.environ.get("MJMPC_TORCH_COLLECTIVES") else "library RCCL"
+    assert comm2.collectives == want and not comm2.fell_back, (comm2.collectives, comm2.why_fell_back)
+    print("collectives: %s (communicator made in %.3f s)" % (comm2.collectives, comm2.init_seconds))
+    got, info = run(1024, comm2, mono)              # "1024 over two ranks": this rank's 512 are the same particles
     assert info[0] == 512 and info[1] == mono and not info[2]
     assert info[3], "the sharded iteration should run as a captured graph, from its launch tape or as direct launches"
     # the all-gather is issued by the library (TorchDistComm.lib_collectives): the fused iteration is three direct launches,
