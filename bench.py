@@ -269,6 +269,7 @@ def make_workload(args, local, comm, P_tot):
             w["reset"] = eng.reset
         w["reset"]()
     A = eng.d_action
+    eng.on_env_reset = "warn"         # (a benchmark reports the real env's resets - `env_resets` - instead of raising)
     base_reset = w["reset"]
 
     def make_ctrl(P_total, comm=comm):
@@ -654,8 +655,12 @@ def main():
                              "construction; `valu` is the roofline that binds"},
         "solver_failures": fails,
     }
+    if hasattr(eng, "env_resets"):
+        # resets of the device-resident REAL env (the reference raises MujocoException there; bench.py reports instead)
+        out["env_resets"] = eng.env_resets()
     if hasattr(eng, "diverged_substeps"):
-        # (tree engine) particle-substeps whose constraint solution was not finite - diverged rollouts, cost +inf, no weight
+        # particle-substeps in which MuJoCo would have reset the simulation (NaN / > 1e10 in qpos, qvel, qacc) and the kernel did:
+        # such particles go on from qpos0 with finite costs (engine.set_reset_returns('inf') gives them +inf instead)
         # in the update; apart from solver_failures (= a finite problem the iteration cap ended)
         out["diverged_particle_substeps"] = eng.diverged_substeps()
     if pipelined:

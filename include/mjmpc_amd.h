@@ -31,7 +31,9 @@ extern "C" {
  *      take qpos[nq], and mjmpc_step_tail writes A + 1 doubles into h_action_mapped (action + completion flag). */
 /*   3: round 5 - rollouts emulate MuJoCo's reset on instability (finite costs where version 2 returned +inf;
  *      mjmpc_arm_diverged). */
-#define MJMPC_ABI_VERSION 3
+/*   4: round 6 - mjmpc_{arm,tree}_env_resets (resets of the device-resident REAL env, counted apart from the rollouts'),
+ *      mjmpc_{arm,tree}_set_reset_returns (+inf returns for particles that reset, as an engine option). */
+#define MJMPC_ABI_VERSION 4
 
 #define MJMPC_F32 0
 #define MJMPC_F64 1
@@ -267,6 +269,20 @@ int mjmpc_tree_solver_failures(mjmpc_tree_t h, uint32_t* count);
  * mjmpc_*_solver_failures.  (Since ABI version 3; before, such particles carried a +inf return.) */
 int mjmpc_tree_diverged(mjmpc_tree_t h, uint32_t* count);
 int mjmpc_arm_diverged(mjmpc_arm_t h, uint32_t* count);
+/* The resets among them that happened to the REAL env kept on the device (mjmpc_*_step_state, the env step inside
+ * mjmpc_arm_mppi_step / mjmpc_arm_mppi_combine): there the reference does not go on silently - mujoco-py's default warning
+ * callback raises MujocoException out of sim.step() in the worker that steps the env (mjmpc/envs/gym_env_wrapper.py:
+ * 64-66 -> reacher_env.py:29-39).  The host side (mjmpc_amd/envs/*_engine.py: check_env_resets) reads this counter where it
+ * synchronises anyway and raises / warns.  Since ABI version 4. */
+int mjmpc_tree_env_resets(mjmpc_tree_t h, uint32_t* count);
+int mjmpc_arm_env_resets(mjmpc_arm_t h, uint32_t* count);
+/* inf_returns != 0: a rollout particle that resets costs +inf from that env step on (its return +inf: no weight in the
+ * softmax updates, last in the elite ranking) instead of the finite costs of MuJoCo's reset state - a blown-up particle whose
+ * reset pose happens to be cheap cannot pull the mean towards the action sequence that blew it up.  Default 0 (what the
+ * reference's workers return).  Applies to launches issued afterwards; captured launchers keep what they were made with.
+ * Since ABI version 4. */
+int mjmpc_tree_set_reset_returns(mjmpc_tree_t h, int inf_returns);
+int mjmpc_arm_set_reset_returns(mjmpc_arm_t h, int inf_returns);
 
 /* rollout_fn over the reference's two analytic numpy envs (stateless; every pointer is a device
  * pointer): kind 0 = PendulumEnv (mjmpc/envs/basic/pendulum.py:33-50; d_params = [max_speed,

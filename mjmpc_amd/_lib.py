@@ -10,7 +10,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("MJMPC_AMD_LIB", os.path.join(_HERE, "libmjmpc_amd.so"))
 
 F32, F64 = 0, 1
-ABI_VERSION = 3      # include/mjmpc_amd.h MJMPC_ABI_VERSION this binding was written for
+ABI_VERSION = 4      # include/mjmpc_amd.h MJMPC_ABI_VERSION this binding was written for
 
 _vp = ctypes.c_void_p
 _i64 = ctypes.c_int64
@@ -57,6 +57,10 @@ SIGNATURES = {
                                       _vp]),
     "mjmpc_arm_solver_failures": (_int, [_vp, ctypes.POINTER(ctypes.c_uint32)]),
     "mjmpc_arm_diverged": (_int, [_vp, ctypes.POINTER(ctypes.c_uint32)]),
+    "mjmpc_tree_env_resets": (_int, [_vp, ctypes.POINTER(ctypes.c_uint32)]),
+    "mjmpc_arm_env_resets": (_int, [_vp, ctypes.POINTER(ctypes.c_uint32)]),
+    "mjmpc_tree_set_reset_returns": (_int, [_vp, _int]),
+    "mjmpc_arm_set_reset_returns": (_int, [_vp, _int]),
     "mjmpc_update_workspace_bytes": (_i64, [_i64, _int, _int]),
     "mjmpc_softmax_record_len": (_int, [_int, _int, _int]),
     "mjmpc_traj_cost": (_int, [_int, _i64, _int, _int, _vp, _vp, _int, _vp, _vp]),
@@ -124,13 +128,16 @@ def load():
         # (the other order leaves torch with "No HIP GPUs are available").
         import torch  # noqa: F401
         lib = ctypes.CDLL(LIB_PATH)
+        # the version FIRST: a stale library lacks the newer entry points, and binding them would end in a bare
+        # AttributeError instead of the instruction to rebuild
+        lib.mjmpc_abi_version.restype, lib.mjmpc_abi_version.argtypes = SIGNATURES["mjmpc_abi_version"]
+        got = lib.mjmpc_abi_version()
+        if got != ABI_VERSION:
+            raise MjmpcError("%s speaks ABI version %d, this binding expects %d (blob / state layouts or entry points differ): "
+                             "rebuild it with `python -m mjmpc_amd.build --force`" % (LIB_PATH, got, ABI_VERSION))
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(lib, name)
             fn.restype, fn.argtypes = res, args
-        got = lib.mjmpc_abi_version()
-        if got != ABI_VERSION:
-            raise MjmpcError("%s speaks ABI version %d, this binding expects %d (blob / state layouts differ): rebuild "
-                             "it with `python -m mjmpc_amd.build --force`" % (LIB_PATH, got, ABI_VERSION))
         _LIB = lib
     return _LIB
 
@@ -151,15 +158,21 @@ class recording:
         if not recording._lock.acquire(timeout=60.0):
             raise MjmpcError("another thread has been recording a launch tape for a minute")
         self.owner = threading.get_ident()
-        for name in SIGNATURES:
-            fn = getattr(lib, name)
-            self.saved[name] = fn
+        try:
+            for name in SIGNATURES:
+                fn = getattr(lib, name)
+                self.saved[name] = fn
 
-            def wrapper(*args, _fn=fn, _tape=self.tape, _me=self.owner):
-                if threading.get_ident() == _me:        # (another thread's calls - a second controller - are not this tape's)
-                    _tape.append((_fn, args))
-                return _fn(*args)
-            setattr(lib, name, wrapper)
+                def wrapper(*args, _fn=fn, _tape=self.tape, _me=self.owner):
+                    if threading.get_ident() == _me:    # (another thread's calls - a second controller - are not this tape's)
+                        _tape.append((_fn, args))
+                    return _fn(*args)
+                setattr(lib, name, wrapper)
+        except BaseException:           # (whatever was patched goes back, and the lock with it)
+            for name, fn in self.saved.items():
+                setattr(lib, name, fn)
+            recording._lock.release()
+            raise
         return self
 
     def __exit__(self, *exc):

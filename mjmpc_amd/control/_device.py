@@ -179,100 +179,6 @@ class TorchDistComm:
             pass
 
     def all_gather(self, t):
-        return t.reshape(1, -1)
-
-    def all_gather_flat(self, t):
-        return t
-
-    def all_agree(self, ok, device=None):
-        return bool(ok)
-
-
-class TorchDistComm:
-    """One process per GPU over torch.distributed (backend "nccl" = RCCL over xGMI; "gloo" in CPU tests).
-
-    ``library_collectives`` (default: on where the backend is RCCL; ``MJMPC_TORCH_COLLECTIVES=1`` in the environment turns it
-    off): the float64 all-gathers of the control iteration are issued by libmjmpc_amd.so itself on a communicator of its
-    own (``mjmpc_comm_*``: the ranks of this group, the id handed out through one torch broadcast) - the same RCCL
-    collective, but a LIBRARY call, so that a sharded iteration runs from the launch tape / as direct launches like the
-    one-GPU loop instead of a hipGraph replay (controller.py).  Call ``close()`` before the process group
-    is destroyed."""
-
-    def __init__(self, group=None, library_collectives=None):
-        import os
-        import torch.distributed as dist
-        self._dist, self._group = dist, group
-        self.rank = dist.get_rank(group)
-        self.world_size = dist.get_world_size(group)
-        self.backend = dist.get_backend(group)
-        self._out = {}
-        self._lib_comm = None               # the library's communicator, made on first use
-        self._gather_ranks = self.world_size
-        if library_collectives is None:
-            library_collectives = self.backend == "nccl" and not os.environ.get("MJMPC_TORCH_COLLECTIVES")
-        self.lib_collectives = bool(library_collectives) and self.backend == "nccl"
-        if self.lib_collectives:
-            self._open_library_comm()
-
-    def _open_library_comm(self):
-        """The library's communicator, made when this object is (the controllers read ``lib_collectives`` when they choose how
-        to launch).  Every rank first checks that the library can reach RCCL at all; the ranks then go on TOGETHER or fall
-        back to torch.distributed's collectives together (a rank that could not bind RCCL would otherwise leave the others
-        waiting in ncclCommInitRank)."""
-        import warnings
-        import torch
-        dev = torch.device("cuda", torch.cuda.current_device())
-        ok, why = True, ""
-        try:
-            probe = (ctypes.c_ubyte * 128)()
-            _lib.check(_lib.load().mjmpc_comm_unique_id(probe))
-        except Exception as e:      # (no librccl the library can bind, an older library ...)
-            ok, why = False, str(e)
-        if self.all_agree(ok, dev):
-            try:
-                self._library_comm(dev)
-            except Exception as e:
-                ok, why = False, str(e)
-            ok = self.all_agree(ok, dev)
-        else:
-            ok = False
-        if not ok:
-            self.close()
-            self.lib_collectives = False
-            warnings.warn("mjmpc_amd: the library's own RCCL communicator is not available (%s); the control iterations' exchanges go "
-                          "through torch.distributed (hipGraph replay instead of direct launches)" % (why or "another rank failed"))
-
-    def _library_comm(self, device):
-        """ncclCommInitRank of the library's own communicator over the ranks of this group (collective; outside any
-        stream capture: the controllers' dry run / first eager iteration gets here first)."""
-        import torch
-        lib = _lib.load()
-        ident = torch.zeros(128, dtype=torch.uint8, device=device)
-        if self.rank == 0:
-            buf = (ctypes.c_ubyte * 128)()
-            _lib.check(lib.mjmpc_comm_unique_id(buf))
-            ident.copy_(torch.frombuffer(bytearray(buf), dtype=torch.uint8))
-        src = self._dist.get_global_rank(self._group, 0) if self._group is not None else 0
-        self._dist.broadcast(ident, src=src, group=self._group)
-        raw = bytes(ident.cpu().numpy().tobytes())
-        h = ctypes.c_void_p()
-        _lib.check(lib.mjmpc_comm_create(ctypes.c_char_p(raw), self._dist.get_world_size(self._group), self._dist.get_rank(self._group),
-                                         device.index if device.index is not None else torch.cuda.current_device(), ctypes.byref(h)))
-        self._lib_comm = (lib, h)
-
-    def close(self):
-        if self._lib_comm is not None:
-            lib, h = self._lib_comm
-            self._lib_comm = None
-            lib.mjmpc_comm_destroy(h)
-
-    def __del__(self):
-        try:
-            self.close()
-        except Exception:
-            pass
-
-    def all_gather(self, t):
         import torch
         key = (t.numel(), t.dtype, t.device)
         out = self._out.get(key)            # persistent receive buffer: a captured graph replays into it

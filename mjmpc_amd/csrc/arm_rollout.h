@@ -28,6 +28,10 @@ struct RolloutFusion {
     const double* gseq = nullptr;
     double* q0_out = nullptr;
     const double* reset_rec = nullptr;
+    int inf_on_reset = 0;           // 1: a particle that has reset costs +inf from that env step on (q0_out +inf): it then has
+                                    // no weight in the softmax updates and ranks last for CEM - ABI 2's behaviour for diverged
+                                    // rollouts, as an engine option (mjmpc_arm_set_reset_returns); 0: the costs MuJoCo's reset
+                                    // state produces (what the reference's worker would return)
 };
 
 // TWO launches per control iteration (mjmpc_arm_mppi_step).  The rollout kernel draws its own samples, keeps the actions

@@ -651,7 +651,11 @@ __device__ __forceinline__ void limit_row(const MT& M, T q, T v, T& sig, T& D, T
 struct ResetCtl {
     bool any = false;           // some particle of this wavefront has reset, or has a reset pending
     bool count = false;         // per lane: a live particle (its resets are counted)
+    bool real = false;          // this launch steps the REAL env (state_out / the fused iteration's env step): its resets are
+                                // counted a second time, in diag[2] - the reference's worker raises MujocoException there
 };
+// (flags of rflags(): 1 zero controls | 2 reset pending | 4 the latest arm_back reset on the acceleration | 8 this particle has
+// reset at some point of the rollout - RolloutFusion::inf_on_reset)
 // per particle and wavefront (the two waves of a DUO group keep their own copy: they pass the same points at their own pace):
 // 1 zero controls | 2 reset pending | 4 the latest arm_back reset on the acceleration - in a spare slot of the particle's LDS
 // block, read and written on the rare path only (a register of its own cost the fused iteration's kernel, the one with the
@@ -691,8 +695,8 @@ __device__ __forceinline__ void arm_front(const MT& M, const ArmInts& I, T& q, T
         if (f & 2) {                        // mj_checkPos / mj_checkVel of this mj_step: mj_resetData, and on from there
             q = T(0); v = T(0); sq = T(0); cq = T(1); aw = T(0);
             rows = 0;
-            f = 1;
-            if (role_counts<ROLE>() && diag && l8 == 0 && rc->count) atomicAdd(diag + 1, 1u);
+            f = 1 | 8;
+            if (role_counts<ROLE>() && diag && l8 == 0 && rc->count) { atomicAdd(diag + 1, 1u); if (rc->real) atomicAdd(diag + 2, 1u); }
         }
         rflags_set<ROLE>(ldsM, f);
         if (f & 1) tau_act = M.link(O_GEAR) * fmin(fmax(T(0), M.link(O_CTRL_LO)), M.link(O_CTRL_HI));
@@ -1175,8 +1179,8 @@ __device__ __forceinline__ void flag_front(const MT& M, const ArmInts& I, T& q, 
         if (f & 2) {                        // mj_checkPos / mj_checkVel of this mj_step: mj_resetData, and on from there
             q = T(0); v = T(0); sq = T(0); cq = T(1); aw = T(0);
             rows = 0;
-            f = 1;
-            if (role_counts<ROLE>() && diag && l8 == 0 && rc->count) atomicAdd(diag + 1, 1u);
+            f = 1 | 8;
+            if (role_counts<ROLE>() && diag && l8 == 0 && rc->count) { atomicAdd(diag + 1, 1u); if (rc->real) atomicAdd(diag + 2, 1u); }
         }
         rflags_set<ROLE>(ldsM, f);
         if (f & 1) tau_act = M.link(O_GEAR) * fmin(fmax(T(0), M.link(O_CTRL_LO)), M.link(O_CTRL_HI));
@@ -1478,8 +1482,8 @@ __device__ __forceinline__ void arm_back(const MT& M, T& q, T& v, T& aw, T& sq, 
                     sq = (T)rst[2 * LANES + 3 + l8];
                     cq = (T)rst[3 * LANES + 3 + l8];
                     aw = T(0);
-                    rflags_set<ROLE>(ldsM, rflags<ROLE>(ldsM) | 1 | 4);
-                    if (role_counts<ROLE>() && diag && l8 == 0 && rc->count) atomicAdd(diag + 1, 1u);
+                    rflags_set<ROLE>(ldsM, rflags<ROLE>(ldsM) | 1 | 4 | 8);
+                    if (role_counts<ROLE>() && diag && l8 == 0 && rc->count) { atomicAdd(diag + 1, 1u); if (rc->real) atomicAdd(diag + 2, 1u); }
                 } else if (bal & mine) {
                     rflags_set<ROLE>(ldsM, rflags<ROLE>(ldsM) | 2);
                 }
@@ -1515,6 +1519,7 @@ __device__ __forceinline__ void real_env_step(const MT& M, const ArmInts& I, con
     bool fs = false;
     ResetCtl rc;
     rc.count = g == 0;              // (all eight particle slots carry the one state: they reset together; slot 0 counts)
+    rc.real = true;
     auto record = [&mo]() -> const double* { return mo.reset_rec; };
     if (mo.reset_rec) {
         if (DUO && wave == 1) reset_check_start<SOLVE>(rc, q, v, lane, ldsM);
@@ -1784,6 +1789,7 @@ __device__ __forceinline__ void arm_rollout_body(const T* __restrict__ model, co
     T* ldsModel = lds + LANES * STRIDE;
     ResetCtl rc;
     rc.count = live;
+    rc.real = STEP;
     // my model block's reset record: its address waits in LDS for the rare path (held in scalar registers through the
     // rollout it cost this kernel spills in its hot loops)
     __shared__ const double* s_reset_rec;
@@ -1980,7 +1986,7 @@ __device__ __forceinline__ void arm_rollout_body(const T* __restrict__ model, co
         const T tau_act = M.link(O_GEAR) * fmin(fmax(u, M.link(O_CTRL_LO)), M.link(O_CTRL_HI));
         T site[3];
         bool fs = false;
-        if (__builtin_expect(rc.any, 0)) rflags_set<R>(ldsM, rflags<R>(ldsM) & 2);     // a new env step: do_simulation writes data.ctrl again (a pending reset stays)
+        if (__builtin_expect(rc.any, 0)) rflags_set<R>(ldsM, rflags<R>(ldsM) & (2 | 8));     // a new env step: do_simulation writes data.ctrl again (a pending reset stays)
         for (int sub = 0; sub < I.frame_skip; ++sub) {
             if ((R == DYN || R == QDYN) && sub > 0) arm_back<R>(M, q, v, aw, sinq, cosq, ldsM, l8, fs, ST, lane, &rc, diag, record, qf, seq);
             if constexpr (QUAD) {
@@ -2008,14 +2014,23 @@ __device__ __forceinline__ void arm_rollout_body(const T* __restrict__ model, co
         // reward = -(|h-g|_1 + 5 |h-g|_2), h = site_xpos lagging one substep (reacher_env.py:31-35)
         T dx = site[0] - tgt[0], dy = site[1] - tgt[1], dz = site[2] - tgt[2];
         T cst = fabs(dx) + fabs(dy) + fabs(dz) + T(5) * sqrt_(dx * dx + dy * dy + dz * dz);
+        // RolloutFusion::inf_on_reset: a particle that has reset costs +inf from that env step on (no weight in the updates)
+        if (__builtin_expect(rc.any, 0)) { if (fuse.inf_on_reset && (rflags<R>(ldsM) & 8)) cst = T(INFINITY); }
         if (live && l8 == 0 && (!MONO || cost)) cost[pid * H + t] = cst;
         if (fuse.gseq) q0acc += gs_cur * (double)cst;
         // MONO: the next step's sample, drawn while the SOLVE wave is still iterating (DUO) / once per env step (SOLO)
         if constexpr (MONO) { if (t + 1 < H) { const T en = draw(t + 1); if (sampled) eps_next = en; } }
         if constexpr (R == DYN || R == QDYN) {
             arm_back<R>(M, q, v, aw, sinq, cosq, ldsM, l8, fs, ST, lane, &rc, diag, record, qf, seq);
-#ifndef ARM_NO_FIXUP            // (developer A/B)
             if (__builtin_expect(rc.any, 0)) {
+                // (inf_on_reset: the env step's last substep reset the particle after its cost had been written)
+                if (fuse.inf_on_reset && (rflags<R>(ldsM) & 8) && !(cst == T(INFINITY))) {    // (finite or NaN so far)
+                    if (live && l8 == 0 && (!MONO || cost)) cost[pid * H + t] = T(INFINITY);
+                    if (fuse.gseq) q0acc = INFINITY;
+                }
+            }
+#ifndef ARM_NO_FIXUP            // (developer A/B)
+            if (__builtin_expect(rc.any, 0) && !fuse.inf_on_reset) {
                 // the last substep ended in mj_checkAcc's reset: site_xpos is the reset state's (mj_forward ran again) - the
                 // cost written ahead of the integration above is written again
                 // (the substep began from a state mj_checkPos / mj_checkVel passed: its site and the cost from it are finite)

@@ -70,6 +70,7 @@ struct mjmpc_arm_s {
     // captured graph holds it: the buffer only ever GROWS, and a buffer it outgrew stays allocated until the handle is
     // destroyed (mono_retired) - a graph captured at one (P, H) survives later calls at another
     double* reset_rec = nullptr;    // n_shards records of ARM_RESET_LEN: MuJoCo's reset on instability (RolloutFusion::reset_rec)
+    int inf_on_reset = 0;           // mjmpc_arm_set_reset_returns
     double* mono_tree = nullptr;
     size_t mono_cap = 0;            // doubles
     std::vector<double*> mono_retired;
@@ -95,6 +96,7 @@ struct mjmpc_tree_s {
     int stage_next = 0;
     std::vector<double> topo;       // create-time topology tables (shard blocks must match them)
     double* reset_rec = nullptr;    // n_shards records of TREE_RESET_LEN: MuJoCo's reset on instability (TreeFusion::reset_rec)
+    int inf_on_reset = 0;           // mjmpc_tree_set_reset_returns
 };
 
 extern "C" {
@@ -161,6 +163,7 @@ int mjmpc_graph_signature(void* hip_graph, uint64_t* n_out) {
 static mjmpc::RolloutFusion arm_fuse(const mjmpc_arm_s* h) {
     mjmpc::RolloutFusion f;
     f.reset_rec = h->reset_rec;
+    f.inf_on_reset = h->inf_on_reset;
     return f;
 }
 
@@ -638,7 +641,7 @@ extern "C" int mjmpc_debug_stamps(mjmpc_arm_t h, unsigned long long* out32) {
 /* ---- tree engine ------------------------------------------------------------------------------------ */
 static_assert(MJMPC_TREE_BLOB_LEN == mjmpc::TREE_BLOB_LEN && MJMPC_TREE_DEVICE_STATE_LEN == mjmpc::TREE_STATE_LEN &&
               MJMPC_TREE_STATE_LEN == mjmpc::TREE_PUBLIC_STATE_LEN, "include/mjmpc_amd.h and csrc/tree_model.h disagree");
-#define MJMPC_TREE_DIAG_BYTES (8 + 8 * 24)      /* failure counter, then the developer clocks of -DTREE_STATS builds */
+#define MJMPC_TREE_DIAG_BYTES (8 + 8 * 24 + 8)  /* counters, the developer clocks of -DTREE_STATS builds, the real env's resets (TREE_DIAG_ENV_RESETS) */
 #ifdef TREE_STATS
 // developer builds only (not declared in include/mjmpc_amd.h): read and clear the phase clocks / iteration counts
 extern "C" int mjmpc_debug_tree_stats(mjmpc_tree_t h, unsigned long long* out24) {
@@ -718,6 +721,7 @@ static mjmpc::TreeFusion tree_fuse(const mjmpc_tree_s* h, int shard = -1) {
         f.reset_rec = h->reset_rec + (shard > 0 && h->n_shards > 1 ? (size_t)shard * mjmpc::TREE_RESET_LEN : 0);
         f.reset_stride = (shard < 0 && h->n_shards > 1) ? mjmpc::TREE_RESET_LEN : 0;
     }
+    f.inf_on_reset = h->inf_on_reset;
     return f;
 }
 
@@ -1064,6 +1068,38 @@ int mjmpc_tree_diverged(mjmpc_tree_t h, uint32_t* count) {
     unsigned c = 0;
     HIP_TRY(hipMemcpy(&c, h->diag + 1, sizeof(unsigned), hipMemcpyDeviceToHost));
     *count = c;
+    return 0;
+}
+
+int mjmpc_tree_env_resets(mjmpc_tree_t h, uint32_t* count) {
+    if (!h || !count) return fail(MJMPC_E_BADARG, "null argument");
+    HIP_TRY(hipSetDevice(h->device));
+    HIP_TRY(hipDeviceSynchronize());
+    unsigned c = 0;
+    HIP_TRY(hipMemcpy(&c, h->diag + mjmpc::TREE_DIAG_ENV_RESETS, sizeof(unsigned), hipMemcpyDeviceToHost));
+    *count = c;
+    return 0;
+}
+
+int mjmpc_arm_env_resets(mjmpc_arm_t h, uint32_t* count) {
+    if (!h || !count) return fail(MJMPC_E_BADARG, "null argument");
+    HIP_TRY(hipSetDevice(h->device));
+    HIP_TRY(hipDeviceSynchronize());
+    unsigned c = 0;
+    HIP_TRY(hipMemcpy(&c, h->diag + 2, sizeof(unsigned), hipMemcpyDeviceToHost));
+    *count = c;
+    return 0;
+}
+
+int mjmpc_tree_set_reset_returns(mjmpc_tree_t h, int inf_returns) {
+    if (!h) return fail(MJMPC_E_BADARG, "null argument");
+    h->inf_on_reset = inf_returns ? 1 : 0;
+    return 0;
+}
+
+int mjmpc_arm_set_reset_returns(mjmpc_arm_t h, int inf_returns) {
+    if (!h) return fail(MJMPC_E_BADARG, "null argument");
+    h->inf_on_reset = inf_returns ? 1 : 0;
     return 0;
 }
 

@@ -34,7 +34,11 @@ struct TreeFusion {
     const double* reset_rec = nullptr;
     int reset_stride = 0;
     double* axis_out = nullptr;
+    int inf_on_reset = 0;           // 1: a particle that has reset costs +inf from that env step on (RolloutFusion::inf_on_reset)
 };
+// diag (unsigned[]): [0] iteration-cap hits, [1] resets (live particles), developer clocks from byte 8 (TREE_STATS builds),
+// [TREE_DIAG_ENV_RESETS] resets of the REAL env (launches with state_out: mjmpc_tree_step_state, the control iteration's env step)
+constexpr int TREE_DIAG_ENV_RESETS = 2 + 2 * 24;
 
 template <typename T>
 hipError_t launch_tree_rollout(const T* model, int n_model_shards, int max_path, bool full, int nv, const double* state, long P, int H,

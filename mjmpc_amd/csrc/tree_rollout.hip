@@ -1824,7 +1824,7 @@ __global__ __launch_bounds__(64 * wg_waves(DP, FRIC, sizeof(T), PL), min_waves(s
     // scalar register): a wave none of whose particles ever reset pays that test and one scalar branch per substep.
     // rst_pend (per lane, uniform over a particle): qpos / qvel left MuJoCo's bounds - the NEXT mj_step's mj_checkPos /
     // mj_checkVel resets, where that substep begins (until then the state, e.g. in the next observation, is what MuJoCo shows)
-    bool rst_any = false, rst_pend = false;
+    bool rst_any = false, rst_pend = false, rst_ever = false;       // (rst_ever: this particle has reset - TreeFusion::inf_on_reset)
     auto state_is_bad = [&]() -> bool {
         bool bad = dof && (!(fabs(q) <= MJ_MAXVAL) || !(fabs(v) <= MJ_MAXVAL));
         if constexpr (GEN) bad = bad || (ball_g == 0 && (!(fabs(qy) <= MJ_MAXVAL) || !(fabs(qz) <= MJ_MAXVAL) || !(fabs(qw) <= MJ_MAXVAL)));
@@ -1922,7 +1922,8 @@ __global__ __launch_bounds__(64 * wg_waves(DP, FRIC, sizeof(T), PL), min_waves(s
                     qy = T(0); qz = T(0); qw = T(1);
                     tau_act = act_id >= 0 ? M[T_GEAR + l] * fmin(fmax(T(0), M[T_CTRL_LO + l]), M[T_CTRL_HI + l]) : T(0);
                     lim_mem = 0; fl_mem = 0; cinst_mem = 0; cact_mem = 0;
-                    if (diag && l == 0 && live) atomicAdd(diag + 1, 1u);
+                    rst_ever = true;
+                    if (diag && l == 0 && live) { atomicAdd(diag + 1, 1u); if (state_out) atomicAdd(diag + TREE_DIAG_ENV_RESETS, 1u); }
                 }
             }
             // ---- 1. forward kinematics: X_l = X_parent o (Rodrigues(axis, q), off), by pointer jumping
@@ -3431,7 +3432,8 @@ __global__ __launch_bounds__(64 * wg_waves(DP, FRIC, sizeof(T), PL), min_waves(s
                         lim_mem = 0; fl_mem = 0; cinst_mem = 0; cact_mem = 0;
                         if (sub == frame_skip - 1)
                             for (int k = 0; k < 3; ++k) { hand[k] = (T)rst[TREE_STATE_LEN + k]; haxis[k] = (T)rst[TREE_STATE_LEN + 3 + k]; }
-                        if (diag && l == 0 && live) atomicAdd(diag + 1, 1u);
+                        rst_ever = true;
+                        if (diag && l == 0 && live) { atomicAdd(diag + 1, 1u); if (state_out) atomicAdd(diag + TREE_DIAG_ENV_RESETS, 1u); }
                     }
                 }
             }
@@ -3456,6 +3458,7 @@ __global__ __launch_bounds__(64 * wg_waves(DP, FRIC, sizeof(T), PL), min_waves(s
         // stores share one in-order counter (vmcnt), and the register hand-over the compiler otherwise places on the loop's
         // back-edge waits with vmcnt(0) - i.e. for the cost / observation stores just issued
         asm volatile("" : "+v"(eps_next), "+v"(mean_next));
+        if (__builtin_expect(rst_any, 0)) { if (fuse.inf_on_reset && rst_ever) cst = T(INFINITY); }
         if (live && l == 0) cost[pid * H + t] = cst;
         if (fuse.gseq) q0acc += gs_cur * (double)cst;
         // my link's coordinate(s) in MuJoCo's qpos layout (GEN: a ball's first link writes the quaternion, w first; a free

@@ -24,6 +24,7 @@ from ..models.raw import RawModel
 
 _DT = {"f32": (_lib.F32, np.float32), "f64": (_lib.F64, np.float64)}
 
+from ._resets import EnvResetWatch, SimulationUnstableError  # noqa: F401
 
 def _torch():
     import torch
@@ -34,8 +35,9 @@ def _ptr(t):
     return None if t is None else ctypes.c_void_p(t.data_ptr())
 
 
-class ArmRolloutEngine:
+class ArmRolloutEngine(EnvResetWatch):
     """One GPU's worth of particles for a compiled arm model (``reacher_7dof-v0``)."""
+    _abi = "arm"
 
     def __init__(self, model, device=0, dtype="f64", num_shards=1):
         self.raw = model if isinstance(model, RawModel) else None

@@ -54,7 +54,8 @@ class _ForwardEnv:
         a = np.asarray(a, float).reshape(-1)
         xposbefore = self._qpos[0]
         self.engine.set_env_state(dict(qpos=self._qpos, qvel=self._qvel))
-        _, rew, _, _, _, nobs = self.engine.rollout(1, 1, a.reshape(1, -1), None)
+        with self.engine.real_step_guard("%s.step" % type(self).__name__):
+            _, rew, _, _, _, nobs = self.engine.rollout(1, 1, a.reshape(1, -1), None)
         self._qpos, self._qvel = nobs[0, 0, :self.nv].copy(), nobs[0, 0, self.nv:].copy()
         reward_fwd = (self._qpos[0] - xposbefore) / self.dt
         reward_ctrl = -self.ctrl_cost * np.square(a).sum()

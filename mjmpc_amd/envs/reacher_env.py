@@ -54,7 +54,8 @@ class Reacher7DOFEnv:
 
     def step(self, a):
         self._push()
-        obs, rew, act, done, info, nobs = self.engine.rollout(1, 1, np.asarray(a, float).reshape(1, -1), None)
+        with self.engine.real_step_guard("%s.step" % type(self).__name__):
+            obs, rew, act, done, info, nobs = self.engine.rollout(1, 1, np.asarray(a, float).reshape(1, -1), None)
         o = nobs[0, 0]
         self._qp, self._qv = o[:self.nv].copy(), o[self.nv:2 * self.nv].copy()
         self._hand = o[2 * self.nv:2 * self.nv + 3].copy()

@@ -51,7 +51,8 @@ class SyntheticEnv(Reacher7DOFEnv):
 
     def step(self, a):
         self._push()
-        obs, rew, act, done, info, nobs = self.engine.rollout(1, 1, np.asarray(a, float).reshape(1, -1), None)
+        with self.engine.real_step_guard("%s.step" % type(self).__name__):
+            obs, rew, act, done, info, nobs = self.engine.rollout(1, 1, np.asarray(a, float).reshape(1, -1), None)
         o = nobs[0, 0]
         self._qp, self._qv = o[:self.nq].copy(), o[self.nq:self.nq + self.nv].copy()
         self._hand = o[self.nq + self.nv:self.nq + self.nv + 3].copy()

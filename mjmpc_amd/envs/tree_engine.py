@@ -23,10 +23,13 @@ import numpy as np
 from .. import _lib
 from ..models.compile_tree import TreeModel, compile_tree
 from ..models.raw import TASK_FORWARD, RawModel
+from ._resets import EnvResetWatch, SimulationUnstableError  # noqa: F401
 from .arm_engine import _DT, _ptr, _same_state, _torch
 
 
-class TreeRolloutEngine:
+class TreeRolloutEngine(EnvResetWatch):
+    _abi = "tree"
+
     def __init__(self, model, device=0, dtype="f64", num_shards=1):
         self.raw = model if isinstance(model, RawModel) else None
         if isinstance(model, RawModel):
@@ -176,7 +179,8 @@ class TreeRolloutEngine:
         if self.forward_task and self.model.obs_skip:
             raise ValueError("the observation leaves out qpos[:%d]; step an engine compiled with obs_skip = 0"
                              % self.model.obs_skip)
-        _, rew, _, _, _, nobs = self.rollout(1, 1, np.asarray(action, np.float64).reshape(1, -1), None)
+        with self.real_step_guard("TreeRolloutEngine.step"):
+            _, rew, _, _, _, nobs = self.rollout(1, 1, np.asarray(action, np.float64).reshape(1, -1), None)
         nv, nq = self.model.nv, self.model.nq
         self.set_env_state(dict(qp=nobs[0, 0, :nq], qv=nobs[0, 0, nq:nq + nv], target_pos=self._state["target_pos"]))
         return nobs[0, 0].copy(), float(rew[0, 0])
@@ -196,6 +200,8 @@ class TreeRolloutEngine:
         """The device-resident state as the task's state dictionary (one D2H copy; synchronises the stream)."""
         qp, qv = np.zeros(self.model.nq), np.zeros(self.model.nv)
         _lib.check(self._lib.mjmpc_tree_get_state(self._h, qp.ctypes.data_as(_lib._dp), qv.ctypes.data_as(_lib._dp), self._stream()))
+        if self.on_env_reset != "ignore":
+            self.check_env_resets("the device-resident env (step_state)")     # (the host has synchronised anyway)
         if self.forward_task:
             return dict(qpos=qp, qvel=qv)
         return dict(qp=qp, qv=qv, qa=np.zeros(self.model.nv), target_pos=self._state["target_pos"].copy(), timestep=0)

@@ -177,7 +177,113 @@ def test_tree_device_env_step_through_a_reset():
     u = rs.uniform(-0.2, 0.2, eng.d_action)
     q1, v1, _, _ = ref.env_step(qp, qv, u, tgt)
     eng.step_state(u)
+    # (the controlled env itself blows up here: by default the engine raises where the host reads the state back - the
+    # reference's MujocoException; this test is about the emulated state behind it)
+    from mjmpc_amd.envs.tree_engine import SimulationUnstableError
+    with pytest.raises(SimulationUnstableError):
+        eng.get_state_device()
+    eng.on_env_reset = "ignore"
     got = eng.get_state_device()
     np.testing.assert_allclose(got["qp" if "qp" in got else "qpos"], q1, rtol=1e-9, atol=1e-11)
     np.testing.assert_allclose(got["qv" if "qv" in got else "qvel"], v1, rtol=1e-9, atol=1e-11)
     assert eng.diverged_substeps() >= 1
+
+
+# ---- round 6: the real env's resets are surfaced, rollouts may keep +inf returns -----------------------------
+def test_real_env_reset_is_counted_apart_and_raised(raw_arm):
+    """The reference raises MujocoException out of sim.step() when the CONTROLLED env blows up; here the device-resident env
+    counts its resets apart from the rollouts' (mjmpc_arm_env_resets) and the engine raises where the host synchronises."""
+    import torch
+    from mjmpc_amd.envs.arm_engine import ArmRolloutEngine, SimulationUnstableError
+    rs = np.random.RandomState(4)
+    qp, qv = rs.uniform(-0.5, 0.5, 7), rs.uniform(-1, 1, 7) * 1e11
+    eng = ArmRolloutEngine(raw_arm, dtype="f64")
+    assert eng.on_env_reset == "raise" and eng.env_resets() == 0
+    # rollouts from a state MuJoCo resets: counted as rollout resets only
+    eng.set_env_state(dict(qp=qp, qv=qv, target_pos=TGT))
+    eng.rollout(16, 3, np.zeros((3, 7)), 0.1 * rs.standard_normal((16, 3, 7)))
+    assert eng.diverged_substeps() > 0 and eng.env_resets() == 0
+    assert eng.check_env_resets() == 0
+    # the device-resident env stepped from it: counted as the real env's, raised at the check
+    eng.step_state(np.zeros(7))
+    torch.cuda.synchronize()
+    assert eng.env_resets() >= 1
+    with pytest.raises(SimulationUnstableError, match="MujocoException"):
+        eng.check_env_resets()
+    assert eng.check_env_resets() == 0                      # (reported once)
+    eng.on_env_reset = "warn"
+    eng.set_env_state(dict(qp=qp, qv=qv, target_pos=TGT))
+    eng.step_state(np.zeros(7))
+    with pytest.warns(UserWarning, match="was reset"):
+        assert eng.check_env_resets() >= 1
+
+
+def test_host_env_step_raises_on_a_reset(raw_arm):
+    """Reacher7DOFEnv.step (a host-synchronous one-particle rollout) from a state MuJoCo resets."""
+    from mjmpc_amd.envs.arm_engine import SimulationUnstableError
+    from mjmpc_amd.envs.reacher_env import Reacher7DOFEnv
+    env = Reacher7DOFEnv()
+    env.reset(seed=0)
+    env.step(np.zeros(7))                                   # a sane step passes
+    st = env.get_env_state()
+    st["qv"] = np.full(7, 1e11)
+    env.set_env_state(st)
+    with pytest.raises(SimulationUnstableError):
+        env.step(np.zeros(7))
+    env.engine.on_env_reset = "ignore"
+    env.set_env_state(st)
+    ob, rew, done, info = env.step(np.zeros(7))
+    assert np.isfinite(ob).all() and np.isfinite(rew)
+
+
+@pytest.mark.parametrize("P", [64, 4096, 8192])               # four waves + flags / DUO / SOLO launches
+def test_reset_returns_inf_option_arm(raw_arm, P):
+    """engine.set_reset_returns("inf"): particles that reset cost +inf from the env step of the reset on, the others are
+    untouched; with per-shard start states only the shards that blow up are affected."""
+    from mjmpc_amd.envs.arm_engine import ArmRolloutEngine
+    H, S = 6, 8
+    Pq = (P // S) * S
+    eng = ArmRolloutEngine(raw_arm, dtype="f64", num_shards=S)
+    rs = np.random.RandomState(9)
+    mean, noise = 0.3 * rs.standard_normal((H, 7)), 0.5 * rs.standard_normal((Pq, H, 7))
+    vels = [1.0, 3.0, 1.0, 1e9, 1.0, 2e10, 1.0, 1e300]
+    states = [dict(qp=rs.uniform(-0.5, 0.5, 7), qv=rs.uniform(-1, 1, 7) * vl, target_pos=TGT) for vl in vels]
+    eng.set_env_state(states)
+    _, rew_f, _, _, _, _ = eng.rollout(Pq, H, mean, noise)
+    assert np.isfinite(rew_f).all()
+    eng.set_reset_returns("inf")
+    _, rew_i, _, _, _, _ = eng.rollout(Pq, H, mean, noise)
+    per = Pq // S
+    for k, vl in enumerate(vels):
+        blk_f, blk_i = rew_f[k * per:(k + 1) * per], rew_i[k * per:(k + 1) * per]
+        if vl <= 3.0:
+            assert np.array_equal(blk_f, blk_i), vl                     # no reset: bit-identical
+        else:
+            assert np.isinf(blk_i[:, -1]).all() and (blk_i[:, -1] < 0).all(), vl   # reward = -cost = -inf at the end ...
+            first = np.argmax(np.isinf(blk_i), axis=1)
+            for p in range(min(per, 8)):                                # ... from the reset's env step on, finite before
+                assert np.isinf(blk_i[p, first[p]:]).all() and np.array_equal(blk_i[p, :first[p]], blk_f[p, :first[p]])
+    eng.set_reset_returns("finite")
+    _, rew_b, _, _, _, _ = eng.rollout(Pq, H, mean, noise)
+    assert np.array_equal(rew_b, rew_f)
+
+
+def test_reset_returns_inf_option_tree():
+    from mjmpc_amd.envs.tree_engine import TreeRolloutEngine
+    from mjmpc_amd.models.hand24 import hand24_raw
+    raw = hand24_raw()
+    eng = TreeRolloutEngine(raw, dtype="f64")
+    rs = np.random.RandomState(3)
+    P, H, A = 16, 4, eng.d_action
+    qp = np.asarray(raw.qpos0, float).copy()
+    eng.set_env_state(dict(qp=qp, qv=1e11 * rs.uniform(-1, 1, eng.model.nv), target_pos=np.asarray(raw.target_pos, float)))
+    noise = 0.1 * rs.standard_normal((P, H, A))
+    _, rew_f, _, _, _, _ = eng.rollout(P, H, np.zeros((H, A)), noise)
+    assert np.isfinite(rew_f).all() and eng.diverged_substeps() > 0
+    eng.set_reset_returns("inf")
+    _, rew_i, _, _, _, _ = eng.rollout(P, H, np.zeros((H, A)), noise)
+    assert np.isinf(rew_i).all()                            # (the start state itself resets: every env step costs +inf)
+    # and the device-resident env
+    assert eng.env_resets() == 0
+    eng.step_state(np.zeros(A))
+    assert eng.env_resets() >= 1
