@@ -71,6 +71,8 @@ struct mjmpc_arm_s {
     // destroyed (mono_retired) - a graph captured at one (P, H) survives later calls at another
     double* reset_rec = nullptr;    // n_shards records of ARM_RESET_LEN: MuJoCo's reset on instability (RolloutFusion::reset_rec)
     int inf_on_reset = 0;           // mjmpc_arm_set_reset_returns
+    std::vector<double*> reset_retired;     // reset records that were replaced: bound launchers / captured graphs carry the
+                                            // pointer by value (RolloutFusion, MonoStep), so they stay allocated until destroy
     double* mono_tree = nullptr;
     size_t mono_cap = 0;            // doubles
     std::vector<double*> mono_retired;
@@ -97,6 +99,7 @@ struct mjmpc_tree_s {
     std::vector<double> topo;       // create-time topology tables (shard blocks must match them)
     double* reset_rec = nullptr;    // n_shards records of TREE_RESET_LEN: MuJoCo's reset on instability (TreeFusion::reset_rec)
     int inf_on_reset = 0;           // mjmpc_tree_set_reset_returns
+    std::vector<double*> reset_retired;     // (as mjmpc_arm_s::reset_retired)
 };
 
 extern "C" {
@@ -171,25 +174,29 @@ static mjmpc::RolloutFusion arm_fuse(const mjmpc_arm_s* h) {
 // from the reset state (qpos0 = 0, zero velocity, zero controls) on a copy of the block with frame_skip 1 - state_out
 // receives the state after it, the next observation's site entries are the site at the reset state.  Synchronous; called
 // when the engine is created and when its model blocks are replaced.
-static int arm_make_reset_records(mjmpc_arm_s* h, const double* blobs, int n_shards) {
+// The records are returned in *out and the handle is NOT touched: the caller commits them together with the model blocks
+// (mjmpc_arm_set_shard_models), so that a failure here leaves the engine as it was; the launches count into a scratch
+// counter block of their own, not into the engine's live diagnostics.
+static int arm_make_reset_records(mjmpc_arm_s* h, const double* blobs, int n_shards, double** out) {
     const size_t L = (size_t)mjmpc::ARM_BLOB_LEN, R = (size_t)mjmpc::ARM_RESET_LEN;
     const int dobs = 2 * h->nv + 6;
     double *rec = nullptr, *tmp = nullptr;
     HIP_TRY(hipMalloc(&rec, sizeof(double) * R * n_shards));
-    // scratch: model block | state (19) | mean (8) | cost (1) | next observation (dobs)
-    const size_t nscr = L + MJMPC_ARM_STATE_LEN + 8 + 1 + dobs;
+    // scratch: model block | state (19) | mean (8) | cost (1) | next observation (dobs) | counters (MJMPC_DIAG_BYTES)
+    const size_t nscr = L + MJMPC_ARM_STATE_LEN + 8 + 1 + dobs + MJMPC_DIAG_BYTES / sizeof(double) + 1;
     hipError_t e = hipMalloc(&tmp, sizeof(double) * nscr);
     if (e == hipSuccess) e = hipMemset(tmp, 0, sizeof(double) * nscr);
     if (e == hipSuccess) e = hipMemset(rec, 0, sizeof(double) * R * n_shards);
     std::vector<double> b(L);
     double *st = tmp + L, *mean = st + MJMPC_ARM_STATE_LEN, *cost = mean + 8, *nobs = cost + 1;
+    unsigned* sdiag = (unsigned*)(nobs + dobs);
     for (int k = 0; k < n_shards && e == hipSuccess; ++k) {
         std::memcpy(b.data(), blobs + (size_t)k * L, sizeof(double) * L);
         b[mjmpc::O_FRAME_SKIP] = 1.0;
         e = hipMemcpy(tmp, b.data(), sizeof(double) * L, hipMemcpyHostToDevice);
         if (e != hipSuccess) break;
         double* rk = rec + (size_t)k * R;
-        e = mjmpc::launch_arm_rollout<double>(tmp, st, 1, 1, h->nu, mean, nullptr, cost, nullptr, nullptr, nobs, rk, h->diag, nullptr);
+        e = mjmpc::launch_arm_rollout<double>(tmp, st, 1, 1, h->nu, mean, nullptr, cost, nullptr, nullptr, nobs, rk, sdiag, nullptr);
         if (e == hipSuccess) e = hipMemcpy(rk + 2 * mjmpc::LANES, nobs + 2 * h->nv, sizeof(double) * 3, hipMemcpyDeviceToDevice);
         if (e == hipSuccess) e = hipDeviceSynchronize();
         if (e != hipSuccess) break;
@@ -206,8 +213,7 @@ static int arm_make_reset_records(mjmpc_arm_s* h, const double* blobs, int n_sha
         hipFree(rec);
         return hip_fail(e, "reset record");
     }
-    hipFree(h->reset_rec);
-    h->reset_rec = rec;
+    *out = rec;
     return 0;
 }
 
@@ -223,7 +229,7 @@ static int arm_create_impl(mjmpc_arm_s* h, const double* blob, int n_blob) {
     HIP_TRY(hipMemcpy(h->model_f64, blob, sizeof(double) * n_blob, hipMemcpyHostToDevice));
     HIP_TRY(hipMemset(h->state, 0, sizeof(double) * MJMPC_ARM_STATE_LEN));
     HIP_TRY(hipMemset(h->diag, 0, MJMPC_DIAG_BYTES));
-    return arm_make_reset_records(h, blob, 1);
+    return arm_make_reset_records(h, blob, 1, &h->reset_rec);
 }
 
 int mjmpc_arm_create(const double* blob, int n_blob, int device, mjmpc_arm_t* out) {
@@ -269,12 +275,21 @@ int mjmpc_arm_set_shard_models(mjmpc_arm_t h, const double* blobs, int n_shards)
         hipFree(m64);
         return hip_fail(e, "hipMemcpy");
     }
+    // the reset records of the NEW blocks first: if that fails the engine keeps its old models, shard count and records
+    double* rec = nullptr;
+    if (int rc = arm_make_reset_records(h, blobs, n_shards, &rec); rc != 0) {
+        hipFree(m32);
+        hipFree(m64);
+        return rc;
+    }
     hipFree(h->model_f32);
     hipFree(h->model_f64);
     h->model_f32 = m32;
     h->model_f64 = m64;
     h->n_shards = n_shards;
-    return arm_make_reset_records(h, blobs, n_shards);
+    if (h->reset_rec) h->reset_retired.push_back(h->reset_rec);     // (launchers bound earlier still point at it)
+    h->reset_rec = rec;
+    return 0;
 }
 
 int mjmpc_arm_set_shard_states(mjmpc_arm_t h, const double* states, int n_shards, void* stream) {
@@ -318,6 +333,7 @@ int mjmpc_arm_destroy(mjmpc_arm_t h) {
     hipFree(h->diag);
     hipFree(h->shard_states);
     hipFree(h->reset_rec);
+    for (double* p : h->reset_retired) hipFree(p);
     hipFree(h->mono_tree);
     for (double* p : h->mono_retired) hipFree(p);
     hipHostFree(h->pinned);
@@ -729,11 +745,16 @@ static mjmpc::TreeFusion tree_fuse(const mjmpc_tree_s* h, int shard = -1) {
 // from the reset state (qpos0 = the device's zero coordinates and identity quaternions, zero velocity, zero controls) on a
 // copy of the block with frame_skip 1 - state_out receives the state after it, site_out / axis_out the site and the object
 // axis at the reset state.  Synchronous; called when the engine is created and when its model blocks are replaced.
-static int tree_make_reset_records(mjmpc_tree_s* h, const double* blobs, int n_shards) {
+// (as arm_make_reset_records: the records come back in *out, `full` is the kernel choice of the NEW blocks, the launches count
+// into a scratch counter block)
+static int tree_make_reset_records(mjmpc_tree_s* h, const double* blobs, int n_shards, bool full, double** out) {
     const size_t L = (size_t)mjmpc::TREE_BLOB_LEN, R = (size_t)mjmpc::TREE_RESET_LEN;
     double *rec = nullptr, *tmp = nullptr, *st = nullptr;
+    unsigned* sdiag = nullptr;
     HIP_TRY(hipMalloc(&rec, sizeof(double) * R * n_shards));
     hipError_t e = hipMalloc(&tmp, sizeof(double) * L);
+    if (e == hipSuccess) e = hipMalloc(&sdiag, MJMPC_TREE_DIAG_BYTES);
+    if (e == hipSuccess) e = hipMemset(sdiag, 0, MJMPC_TREE_DIAG_BYTES);
     if (e == hipSuccess) e = hipMalloc(&st, sizeof(double) * mjmpc::TREE_STATE_LEN);
     if (e == hipSuccess) e = hipMemset(rec, 0, sizeof(double) * R * n_shards);
     std::vector<double> b(L), s0(mjmpc::TREE_STATE_LEN, 0.0);
@@ -747,19 +768,19 @@ static int tree_make_reset_records(mjmpc_tree_s* h, const double* blobs, int n_s
         double* rk = rec + (size_t)k * R;
         mjmpc::TreeFusion f;
         f.axis_out = rk + mjmpc::TREE_STATE_LEN + 3;
-        e = mjmpc::launch_tree_rollout<double>(tmp, 1, h->max_path, h->full, h->nv, st, 1, 1, h->nu, h->zero_action, nullptr,
-                                               (double*)h->scratch, nullptr, nullptr, nullptr, h->diag, nullptr, rk, nullptr,
+        e = mjmpc::launch_tree_rollout<double>(tmp, 1, h->max_path, full, h->nv, st, 1, 1, h->nu, h->zero_action, nullptr,
+                                               (double*)h->scratch, nullptr, nullptr, nullptr, sdiag, nullptr, rk, nullptr,
                                                rk + mjmpc::TREE_STATE_LEN, 1, h->gen, f);
         if (e == hipSuccess) e = hipDeviceSynchronize();
     }
     hipFree(tmp);
     hipFree(st);
+    hipFree(sdiag);
     if (e != hipSuccess) {
         hipFree(rec);
         return hip_fail(e, "reset record");
     }
-    hipFree(h->reset_rec);
-    h->reset_rec = rec;
+    *out = rec;
     return 0;
 }
 
@@ -778,7 +799,7 @@ static int tree_create_impl(mjmpc_tree_s* h, const double* blob, int n_blob) {
     h->scratch = h->zero_action + 32;
     HIP_TRY(hipHostMalloc(&h->pinned, sizeof(double) * MJMPC_TREE_DEVICE_STATE_LEN * 4));
     for (int k = 0; k < 4; ++k) HIP_TRY(hipEventCreateWithFlags(&h->staged[k], hipEventDisableTiming));
-    return tree_make_reset_records(h, blob, 1);
+    return tree_make_reset_records(h, blob, 1, h->full, &h->reset_rec);
 }
 
 int mjmpc_tree_create(const double* blob, int n_blob, int device, mjmpc_tree_t* out) {
@@ -846,13 +867,21 @@ int mjmpc_tree_set_shard_models(mjmpc_tree_t h, const double* blobs, int n_shard
         hipFree(m64);
         return hip_fail(e, "hipMemcpy");
     }
+    double* rec = nullptr;      // the reset records of the NEW blocks first: a failure leaves the engine as it was
+    if (int rc = tree_make_reset_records(h, blobs, n_shards, full, &rec); rc != 0) {
+        hipFree(m32);
+        hipFree(m64);
+        return rc;
+    }
     hipFree(h->model_f32);
     hipFree(h->model_f64);
     h->model_f32 = m32;
     h->model_f64 = m64;
     h->n_shards = n_shards;
     h->full = full;             // of the NEW set of blocks (they replace the old ones)
-    return tree_make_reset_records(h, blobs, n_shards);
+    if (h->reset_rec) h->reset_retired.push_back(h->reset_rec);
+    h->reset_rec = rec;
+    return 0;
 }
 
 int mjmpc_tree_set_shard_states(mjmpc_tree_t h, const double* states, int n_shards, void* stream) {
@@ -892,6 +921,7 @@ int mjmpc_tree_destroy(mjmpc_tree_t h) {
     hipFree(h->zero_action);
     hipFree(h->shard_states);
     hipFree(h->reset_rec);
+    for (double* p : h->reset_retired) hipFree(p);
     if (h->pinned) hipHostFree(h->pinned);
     for (int k = 0; k < 4; ++k) if (h->staged[k]) hipEventDestroy(h->staged[k]);
     delete h;

@@ -6,9 +6,20 @@
 //
 // RCCL is bound at RUN TIME (dlopen / dlsym): the library stays loadable on a box without RCCL or without a GPU, and the
 // process uses the copy of librccl that is already mapped (PyTorch ships its own) rather than a second one.
+// For the same reason the handful of RCCL declarations this file needs are written out here instead of taken from
+// <rccl/rccl.h>: the build does not depend on RCCL's development headers being installed, and cannot pick up a header that
+// disagrees with the librccl the process has mapped.  They are the stable NCCL 2 C API (ncclUniqueId = 128 opaque bytes, the
+// ncclDataType_t numbering); ncclGetVersion is checked at bind time (major version 2).
 #include <dlfcn.h>
 #include <hip/hip_runtime.h>
-#include <rccl/rccl.h>
+
+extern "C" {
+typedef struct ncclComm* ncclComm_t;
+typedef struct { char internal[128]; } ncclUniqueId;
+typedef enum { ncclSuccess = 0 } ncclResult_t;                       // (0 = success; every other value is an error code)
+typedef enum { ncclInt8 = 0, ncclUint8 = 1, ncclInt32 = 2, ncclUint32 = 3, ncclInt64 = 4, ncclUint64 = 5, ncclFloat16 = 6,
+               ncclFloat32 = 7, ncclFloat64 = 8 } ncclDataType_t;
+}
 
 #include <cstdio>
 #include <cstring>
@@ -25,6 +36,7 @@ struct Rccl {
     ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
     ncclResult_t (*AllGather)(const void*, void*, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
     const char* (*GetErrorString)(ncclResult_t) = nullptr;
+    ncclResult_t (*GetVersion)(int*) = nullptr;
     char why[256] = "";
 };
 
@@ -47,8 +59,16 @@ Rccl& rccl() {
         r.CommDestroy = (decltype(r.CommDestroy))dlsym(r.handle, "ncclCommDestroy");
         r.AllGather = (decltype(r.AllGather))dlsym(r.handle, "ncclAllGather");
         r.GetErrorString = (decltype(r.GetErrorString))dlsym(r.handle, "ncclGetErrorString");
-        if (!r.GetUniqueId || !r.CommInitRank || !r.CommDestroy || !r.AllGather || !r.GetErrorString)
-            snprintf(r.why, sizeof(r.why), "librccl.so lacks one of the five entry points");
+        r.GetVersion = (decltype(r.GetVersion))dlsym(r.handle, "ncclGetVersion");
+        if (!r.GetUniqueId || !r.CommInitRank || !r.CommDestroy || !r.AllGather || !r.GetErrorString || !r.GetVersion) {
+            snprintf(r.why, sizeof(r.why), "librccl.so lacks one of the six entry points");
+            return;
+        }
+        int v = 0;          // NCCL_VERSION_CODE: major * 10000 + minor * 100 + patch since 2.9 (major * 1000 + ... before)
+        if (r.GetVersion(&v) != ncclSuccess || !((v >= 20000 && v < 30000) || (v >= 2000 && v < 3000))) {
+            snprintf(r.why, sizeof(r.why), "librccl.so reports version code %d: the declarations in comm.hip are NCCL 2's", v);
+            r.GetUniqueId = nullptr;
+        }
     });
     return r;
 }
