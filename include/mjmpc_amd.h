@@ -272,7 +272,7 @@ int mjmpc_arm_diverged(mjmpc_arm_t h, uint32_t* count);
 /* The resets among them that happened to the REAL env kept on the device (mjmpc_*_step_state, the env step inside
  * mjmpc_arm_mppi_step / mjmpc_arm_mppi_combine): there the reference does not go on silently - mujoco-py's default warning
  * callback raises MujocoException out of sim.step() in the worker that steps the env (mjmpc/envs/gym_env_wrapper.py:
- * 64-66 -> reacher_env.py:29-39).  The host side (mjmpc_amd/envs/*_engine.py: check_env_resets) reads this counter where it
+ * 64-66 -> reacher_env.py:29-39).  The host side (the engines' check_env_resets, mjmpc_amd/envs/_resets.py) reads this counter where it
  * synchronises anyway and raises / warns.  Since ABI version 4. */
 int mjmpc_tree_env_resets(mjmpc_tree_t h, uint32_t* count);
 int mjmpc_arm_env_resets(mjmpc_arm_t h, uint32_t* count);

@@ -51,7 +51,7 @@ def sources():
 
 
 def _headers():
-    return (glob.glob(os.path.join(CSRC, "*.h")) + [os.path.join(HERE, "..", "include", "mjmpc_amd.h")]
+    return (glob.glob(os.path.join(CSRC, "*.h")) + glob.glob(os.path.join(CSRC, "*.inc")) + [os.path.join(HERE, "..", "include", "mjmpc_amd.h")]
             + [os.path.join(CSRC, "tree_rollout.hip")])        # (tree_rollout_dense.hip and tree_rollout_cone.hip include it)
 
 

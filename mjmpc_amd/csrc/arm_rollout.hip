@@ -429,6 +429,7 @@ __device__ __forceinline__ T mass_matrix_tile(const LinkFrame<T>& L, int l8, T* 
     return d[0];
 }
 
+#ifndef ARM_NO_FLAGS_CODE
 // The same with the diagonals S0 <= s < S1 only (the four-wave shape splits them between two wavefronts: the suffix sums and
 // the composite-inertia products are repeated by both, the shifted dot products and the tile stores are shared out).
 template <int S0, int S1, typename T>
@@ -470,6 +471,7 @@ __device__ __forceinline__ T mass_matrix_tile_part(const LinkFrame<T>& L, int l8
     return d[0];
 }
 
+#endif
 // plane-sphere contact geometry (mjc_PlaneSphere): signed distance, and - if some particle of the wave is within
 // the margin - my dof's entry of the contact Jacobian row and the row velocity J v
 template <typename T, typename MT>
@@ -648,14 +650,17 @@ __device__ __forceinline__ void limit_row(const MT& M, T q, T v, T& sig, T& D, T
 // do_simulation wrote once before its frame_skip calls of sim.step()).  `any` is wave-uniform (a scalar register): a wave
 // none of whose particles ever reset pays the test in arm_back and two scalar branches per substep, nothing else.  Every
 // role of a particle group takes the same decisions from the same (q, v, qacc), so the two waves of a group stay in step.
+// Flags of rflags(): 1 zero controls | 2 reset pending | 4 the latest arm_back reset on the acceleration | RST_EVER this particle
+// has reset at some point of the rollout | and two OPTIONS of the launch, parked in the same LDS word because a register of their
+// own costs the fused iteration's kernel its schedule (round 6: 182.2 against 177.8 us at 4096 x 32 f64 with two runtime
+// flags held beside the hot loops): RST_REAL this launch steps the REAL env (state_out / the fused iteration's env step) - its
+// resets are counted a second time, in diag[2], where the reference's worker raises MujocoException; RST_INF
+// RolloutFusion::inf_on_reset.  They are written once, when a launch that has them begins, and read on the rare path only.
+constexpr int RST_EVER = 8, RST_REAL = 16, RST_INF = 32, RST_OPTS = RST_REAL | RST_INF;
 struct ResetCtl {
     bool any = false;           // some particle of this wavefront has reset, or has a reset pending
     bool count = false;         // per lane: a live particle (its resets are counted)
-    bool real = false;          // this launch steps the REAL env (state_out / the fused iteration's env step): its resets are
-                                // counted a second time, in diag[2] - the reference's worker raises MujocoException there
 };
-// (flags of rflags(): 1 zero controls | 2 reset pending | 4 the latest arm_back reset on the acceleration | 8 this particle has
-// reset at some point of the rollout - RolloutFusion::inf_on_reset)
 // per particle and wavefront (the two waves of a DUO group keep their own copy: they pass the same points at their own pace):
 // 1 zero controls | 2 reset pending | 4 the latest arm_back reset on the acceleration - in a spare slot of the particle's LDS
 // block, read and written on the rare path only (a register of its own cost the fused iteration's kernel, the one with the
@@ -678,7 +683,7 @@ __device__ __forceinline__ void reset_check_start(ResetCtl& rc, T q, T v, int la
     const unsigned long long bal = __ballot(mj_is_bad(q) || mj_is_bad(v));
     if (bal != 0ull) {
         rc.any = true;
-        if (bal & particle_lanes(lane)) rflags_set<ROLE>(ldsM, 2);
+        if (bal & particle_lanes(lane)) rflags_set<ROLE>(ldsM, rflags<ROLE>(ldsM) | 2);
     }
 }
 
@@ -695,8 +700,8 @@ __device__ __forceinline__ void arm_front(const MT& M, const ArmInts& I, T& q, T
         if (f & 2) {                        // mj_checkPos / mj_checkVel of this mj_step: mj_resetData, and on from there
             q = T(0); v = T(0); sq = T(0); cq = T(1); aw = T(0);
             rows = 0;
-            f = 1 | 8;
-            if (role_counts<ROLE>() && diag && l8 == 0 && rc->count) { atomicAdd(diag + 1, 1u); if (rc->real) atomicAdd(diag + 2, 1u); }
+            f = (f & RST_OPTS) | 1 | RST_EVER;
+            if (role_counts<ROLE>() && diag && l8 == 0 && rc->count) { atomicAdd(diag + 1, 1u); if (f & RST_REAL) atomicAdd(diag + 2, 1u); }
         }
         rflags_set<ROLE>(ldsM, f);
         if (f & 1) tau_act = M.link(O_GEAR) * fmin(fmax(T(0), M.link(O_CTRL_LO)), M.link(O_CTRL_HI));
@@ -1159,6 +1164,7 @@ __device__ __forceinline__ void q_take(qflag_ptr qf, int which, int seq, F&& loa
     __builtin_amdgcn_sched_barrier(0);
 }
 
+#ifndef ARM_NO_FLAGS_CODE
 // NW = 4: the diagonals 0 ... ARM_NEAR_DIAGS - 1 of the mass matrix stay with the solving wave, the others go to QMASS (which
 // starts a hand-over later but has nothing else to do).  Measured at 1024 x 32 f64: 1: 176.0, 2: 174.4, 3: 171.1, 4: 172.7 us
 #ifndef ARM_NEAR_DIAGS
@@ -1179,8 +1185,8 @@ __device__ __forceinline__ void flag_front(const MT& M, const ArmInts& I, T& q, 
         if (f & 2) {                        // mj_checkPos / mj_checkVel of this mj_step: mj_resetData, and on from there
             q = T(0); v = T(0); sq = T(0); cq = T(1); aw = T(0);
             rows = 0;
-            f = 1 | 8;
-            if (role_counts<ROLE>() && diag && l8 == 0 && rc->count) { atomicAdd(diag + 1, 1u); if (rc->real) atomicAdd(diag + 2, 1u); }
+            f = (f & RST_OPTS) | 1 | RST_EVER;
+            if (role_counts<ROLE>() && diag && l8 == 0 && rc->count) { atomicAdd(diag + 1, 1u); if (f & RST_REAL) atomicAdd(diag + 2, 1u); }
         }
         rflags_set<ROLE>(ldsM, f);
         if (f & 1) tau_act = M.link(O_GEAR) * fmin(fmax(T(0), M.link(O_CTRL_LO)), M.link(O_CTRL_HI));
@@ -1417,6 +1423,7 @@ __device__ __forceinline__ void flag_front(const MT& M, const ArmInts& I, T& q, 
     }
 }
 
+#endif
 // second half of a substep: take delivery of qacc and integrate (every role runs the same instructions)
 template <int ROLE, typename T, typename MT, typename RST = NoResetRecord>
 __device__ __forceinline__ void arm_back(const MT& M, T& q, T& v, T& aw, T& sq, T& cq, T* ldsM, int l8,
@@ -1425,6 +1432,14 @@ __device__ __forceinline__ void arm_back(const MT& M, T& q, T& v, T& aw, T& sq, 
                                          int seq = 0) {
     ST.mark(11);        // DYN: env-step records
     if constexpr (ROLE == DYN && ARM_SWAP) { duo_barrier(); ST.mark(7); }      // E2: inverse out (the other wave takes it after its Newton iterations)
+#ifdef ARM_AB_BACK
+    if constexpr (ROLE == SOLO) LDS_WAVE_SYNC();
+    else duo_barrier();
+    ST.mark(12);
+    const T h = M.glob(O_TIMESTEP);
+    {
+        T x = ldsM[V_XE + l8];
+#else
     T x;
     if constexpr (ROLE == QDYN || ROLE == QMASS || ROLE == QAUX) {
         q_take(qf, QF_X, seq, [&]() { x = ldsM[V_XE + l8]; });          // flag shapes: qacc is out
@@ -1436,6 +1451,7 @@ __device__ __forceinline__ void arm_back(const MT& M, T& q, T& v, T& aw, T& sq, 
     ST.mark(12);        // wait at B
     const T h = M.glob(O_TIMESTEP);
     {
+#endif
         if (free_step) aw = x;
         // explicitly rounded products and sums: the two waves of a DUO group must compute bit-identical (q, v), so the
         // compiler may not contract these differently in the two instantiations
@@ -1482,8 +1498,9 @@ __device__ __forceinline__ void arm_back(const MT& M, T& q, T& v, T& aw, T& sq, 
                     sq = (T)rst[2 * LANES + 3 + l8];
                     cq = (T)rst[3 * LANES + 3 + l8];
                     aw = T(0);
-                    rflags_set<ROLE>(ldsM, rflags<ROLE>(ldsM) | 1 | 4 | 8);
-                    if (role_counts<ROLE>() && diag && l8 == 0 && rc->count) { atomicAdd(diag + 1, 1u); if (rc->real) atomicAdd(diag + 2, 1u); }
+                    const int f0 = rflags<ROLE>(ldsM);
+                    rflags_set<ROLE>(ldsM, f0 | 1 | 4 | RST_EVER);
+                    if (role_counts<ROLE>() && diag && l8 == 0 && rc->count) { atomicAdd(diag + 1, 1u); if (f0 & RST_REAL) atomicAdd(diag + 2, 1u); }
                 } else if (bal & mine) {
                     rflags_set<ROLE>(ldsM, rflags<ROLE>(ldsM) | 2);
                 }
@@ -1519,7 +1536,9 @@ __device__ __forceinline__ void real_env_step(const MT& M, const ArmInts& I, con
     bool fs = false;
     ResetCtl rc;
     rc.count = g == 0;              // (all eight particle slots carry the one state: they reset together; slot 0 counts)
-    rc.real = true;
+    // (the real env: its resets are counted apart - the option bit goes into this wave's flags word, blocks zeroed by the caller)
+    if (DUO && wave == 1) rflags_set<SOLVE>(ldsM, RST_REAL);
+    else rflags_set<SOLO>(ldsM, RST_REAL);
     auto record = [&mo]() -> const double* { return mo.reset_rec; };
     if (mo.reset_rec) {
         if (DUO && wave == 1) reset_check_start<SOLVE>(rc, q, v, lane, ldsM);
@@ -1759,341 +1778,7 @@ __global__ __launch_bounds__(128) void arm_mppi_finish_kernel(const T* __restric
 // kernel, actions kept in LDS, ONE softmax record {max, S, W[H A]} per workgroup left in the engine's record buffer; the
 // merge, mean update, action, shift and real-env step are launch 2 (arm_mppi_finish_kernel).  (An in-kernel merge behind
 // arrival counters was measured and dropped: agent-scope fences / dependent L2 round trips cost more than a launch.)
-// SHAPE: 1 (SOLO), 2 (DUO: two wavefronts per particle group meeting at barriers), 12 / 14 (round 6: two / four wavefronts
-// handing over behind flags, flag_front; their own __global__ below, arm_rollout_flags_kernel)
-template <typename T, bool STEP, bool CL, int SHAPE, bool MONO>
-__device__ __forceinline__ void arm_rollout_body(const T* __restrict__ model, const double* state,
-                                                 long P, int H, int A, const double* mean,
-                                                 const T* __restrict__ noise, T* __restrict__ cost,
-                                                 T* __restrict__ act, T* __restrict__ obs,
-                                                 T* __restrict__ nobs, double* state_out, unsigned* diag,
-                                                 const RolloutFusion& fuse, const MonoStep* mop) {
-    constexpr bool DUO = SHAPE == 2, QUAD = SHAPE > 10;     // QUAD: the flag-synchronised shapes
-    constexpr int NW = SHAPE > 10 ? SHAPE - 10 : SHAPE;     // wavefronts per particle group
-    constexpr int STRIDE = PSTRIDE;
-    __shared__ __attribute__((aligned(16))) T lds[LANES * STRIDE + ARM_BLOB_LEN + 3];
-    __shared__ int qflags[QF_COUNT];        // flag shapes: hand-over flags of the workgroup's waves (flag_front)
-    qflag_ptr qf = (qflag_ptr)qflags;
-    int seq = 0;                            // flag shapes: substep sequence number
-    extern __shared__ __attribute__((aligned(16))) double dyn_lds[];     // MONO: scratch [MONO_RED] | action tile T[8][H A]
-    static_assert(!((DUO || QUAD) && CL), "the closed-loop-linear variant runs one wave per particle group");
-    static_assert(!(MONO && (CL || STEP)), "the one-launch iteration is open-loop MPPI");
-    constexpr int NT = 64 * NW;
-    const int lane = threadIdx.x & 63;
-    const int wave = NW > 1 ? __builtin_amdgcn_readfirstlane(threadIdx.x >> 6) : 0;
-    const int l8 = lane_link(lane), g = lane_slot(lane);
-    const long pid = (long)blockIdx.x * LANES + g;
-    const bool live = pid < P;
-    for (int k = threadIdx.x; k < LANES * STRIDE; k += NT) lds[k] = T(0);
-    if (QUAD && threadIdx.x < QF_COUNT) qflags[threadIdx.x] = 0;
-    T* ldsModel = lds + LANES * STRIDE;
-    ResetCtl rc;
-    rc.count = live;
-    rc.real = STEP;
-    // my model block's reset record: its address waits in LDS for the rare path (held in scalar registers through the
-    // rollout it cost this kernel spills in its hot loops)
-    __shared__ const double* s_reset_rec;
-    if (threadIdx.x == 0) {
-        const double* r = fuse.reset_rec;
-        if (r && fuse.shard_size > 0) r += ((long)blockIdx.x * LANES / fuse.shard_size) * ARM_RESET_LEN;
-        s_reset_rec = r;
-    }
-    auto record = []() -> const double* { return *(const double* volatile*)&s_reset_rec; };
-    const bool resets = fuse.reset_rec != nullptr;
-    if (fuse.shard_size > 0) model += ((long)blockIdx.x * LANES / fuse.shard_size) * ARM_BLOB_LEN;
-    if (fuse.state_shard_size > 0) state += ((long)blockIdx.x * LANES / fuse.state_shard_size) * (2 * LANES + 3);
-    for (int k = threadIdx.x; k < ARM_BLOB_LEN; k += NT) ldsModel[k] = model[k];
-    __syncthreads();
-    T* ldsM = lds + g * STRIDE;
-    Model<T, (DUO || QUAD)> M{ldsModel, l8};
-    M.cache();
-    ArmInts I;
-    I.site_link = (int)model[O_SITE_LINK];
-    I.n_sphere = (int)model[O_N_SPHERE];
-    I.sph_link = (int)model[O_SPH_LINK];
-    I.frame_skip = (int)model[O_FRAME_SKIP];
-    I.nv = (int)model[O_NV];
-    const int nv = I.nv;
-    const int dobs = 2 * nv + 6;
-
-    T q = (T)state[l8], v = (T)state[LANES + l8], aw = T(0);
-    const T tgt[3] = {(T)state[2 * LANES], (T)state[2 * LANES + 1], (T)state[2 * LANES + 2]};
-    if (l8 >= nv) { q = T(0); v = T(0); }
-    T sinq, cosq;
-    sincos_(q, sinq, cosq);
-    if (resets) {
-        if (DUO && wave == 1) reset_check_start<SOLVE>(rc, q, v, lane, ldsM);
-        else if (QUAD && wave == 1) reset_check_start<QSOLVE>(rc, q, v, lane, ldsM);
-        else if (QUAD && wave == 2) reset_check_start<QAUX>(rc, q, v, lane, ldsM);
-        else if (QUAD && wave == 3) reset_check_start<QMASS>(rc, q, v, lane, ldsM);
-        else reset_check_start<SOLO>(rc, q, v, lane, ldsM);
-    }
-    const int site_lane = lane_of_link(lane, I.site_link);
-    int rows = 0;
-    T cq = q, cv = v, chand[3] = {T(0), T(0), T(0)};
-    const bool has_u = l8 < A;
-    Stamps ST;
-    ST.begin();
-    double fb0 = 1.0, fb1 = 0.0, fb2 = 0.0, e1 = 0.0, e2 = 0.0, q0acc = 0.0;
-    if (fuse.filt) { fb0 = fuse.filt[0]; fb1 = fuse.filt[1]; fb2 = fuse.filt[2]; }
-
-    // fresh observation after set_env_state (sim.forward()): the site position at the start state is
-    // needed BEFORE the first step when the policy is closed-loop; one extra kinematics pass provides it
-    if constexpr (CL) {
-        T qq = q, vv = v, aa = aw, ss = sinq, cc = cosq;
-        int rr = 0;
-        T s0[3];
-        bool fs0;
-        arm_front<SOLO>(M, I, qq, vv, aa, ss, cc, rr, T(0), ldsM, lane, l8, s0, (unsigned*)nullptr, fs0, ST);
-        arm_back<SOLO>(M, qq, vv, aa, ss, cc, ldsM, l8, fs0, ST);
-        for (int k = 0; k < 3; ++k) chand[k] = __shfl(s0[k], site_lane);
-    }
-
-    constexpr int R = QUAD ? QDYN : (DUO ? DYN : SOLO);
-    const int HA = H * A;
-    T* actT = (T*)(dyn_lds + MONO_RED);          // MONO: the actions of my workgroup's particles, [8][H A]
-    if (DUO && wave == 1) {         // the SOLVE wave: no inputs, no records - mass matrix, constraints, solves
-        if constexpr (DUO) {
-            bool fs;
-            T nosite[3];
-            for (int t = 0; t < H; ++t)
-                for (int sub = 0; sub < I.frame_skip; ++sub) {
-                    arm_front<SOLVE>(M, I, q, v, aw, sinq, cosq, rows, T(0), ldsM, lane, l8, nosite, diag, fs, ST, &rc);
-                    arm_back<SOLVE>(M, q, v, aw, sinq, cosq, ldsM, l8, fs, ST, lane, &rc, nullptr, record);
-                }
-            ST.flush(diag, 1, lane);
-        }
-        if constexpr (!MONO) return;
-    } else if (QUAD && wave >= 1) { // flag shapes: the waves beside the one that owns inputs and records (flag_front)
-        if constexpr (QUAD) {
-            bool fs;
-            T nosite[3];
-#define MJMPC_FLAG_LOOP(ROLE_)                                                                                              \
-            for (int t = 0; t < H; ++t)                                                                                     \
-                for (int sub = 0; sub < I.frame_skip; ++sub) {                                                              \
-                    ++seq;                                                                                                  \
-                    flag_front<ROLE_, NW>(M, I, q, v, aw, sinq, cosq, rows, T(0), ldsM, qf, seq, lane, l8, nosite, diag, fs, ST, &rc); \
-                    arm_back<ROLE_>(M, q, v, aw, sinq, cosq, ldsM, l8, fs, ST, lane, &rc, nullptr, record, qf, seq);       \
-                }
-            if (wave == 1) { MJMPC_FLAG_LOOP(QSOLVE) }
-            else if (wave == 2) { MJMPC_FLAG_LOOP(QAUX) }
-            else { MJMPC_FLAG_LOOP(QMASS) }
-#undef MJMPC_FLAG_LOOP
-            ST.flush(diag, wave, lane);
-        }
-        if constexpr (!MONO) return;
-    } else {
-
-    // inputs of step t+1 are fetched while step t computes (a lone wave would otherwise sit out the full
-    // HBM latency of its noise load at the top of every env step)
-    T eps_next = T(0);
-    double mean_next = 0.0, gs_next = (fuse.gseq && H > 0) ? fuse.gseq[0] : 0.0;   // (a load consumed in the iteration
-    // that issues it would make its s_waitcnt also wait for the prefetches issued before it)
-    // MONO: the raw sample of (particle, channel l8, step t) is drawn here instead of loaded - the same Philox block the
-    // sampler kernel (noise.hip) would have used for it: one block yields the normals of steps 4k ... 4k + 3
-    const bool sampled = MONO && has_u && live;
-    float z_keep[3] = {0.0f, 0.0f, 0.0f};
-    // (three normals live across env steps.  The sampler's parameters are read ONCE: a draw sits between E2 and E3 of a
-    // substep, in the DYN wave's slack, and a global load per env step - even a cache hit - outlasted that slack:
-    // hoisting them costs 16 AGPRs and 1.5 us less per launch)
-    double chol_h = 0.0;
-    double chol_row[LANES - 1];             // full covariance: my row of the factor (entries b <= l8)
-    bool chol_full = false;
-    unsigned long long seed_h = 0ull, off_h = 0ull, key_h = 0ull;
-    if constexpr (MONO) {
-        chol_full = mop->chol_full != 0;
-        if (sampled) chol_h = mop->chol[l8 * A + l8];
-#pragma unroll
-        for (int b = 0; b < LANES - 1; ++b) chol_row[b] = (chol_full && sampled && b <= l8 && b < A) ? mop->chol[l8 * A + b] : 0.0;
-        seed_h = mop->seed;
-        off_h = mop->offset + (mop->d_step ? (unsigned long long)*mop->d_step : 0ull);
-        key_h = (unsigned long long)((pid + mop->particle_offset) * A + l8);
-    }
-    auto draw = [&](int t) -> T {
-#ifdef MONO_NO_DRAW                 // developer A/B builds (tools/mono_time.py; NB: constant actions change the physics too)
-        return T(0.25);
-#endif
-        const double chol_aa = chol_h;
-        float z = 0.0f;
-        if (sampled) {
-            if (!(t & 3)) {
-                float q4[4];
-                normal_quad(seed_h, off_h, key_h, (unsigned)(t >> 2), q4);
-                z = q4[0];
-                z_keep[0] = q4[1];
-                z_keep[1] = q4[2];
-                z_keep[2] = q4[3];
-            } else {
-                z = (t & 3) == 1 ? z_keep[0] : ((t & 3) == 2 ? z_keep[1] : z_keep[2]);
-            }
-        }
-        if (chol_full) {
-            // eps[a] = sum_{b <= a} L[a][b] z_b in noise_full_kernel's order: the channels' normals by DPP broadcast inside
-            // the particle's 8 lanes (every lane takes part: the broadcasts run outside the `sampled` branch)
-            double x = 0.0;
-            float zb;
-            zb = bcast<0>(z); if (chol_row[0] != 0.0) x += chol_row[0] * (double)zb;
-            zb = bcast<1>(z); if (chol_row[1] != 0.0) x += chol_row[1] * (double)zb;
-            zb = bcast<2>(z); if (chol_row[2] != 0.0) x += chol_row[2] * (double)zb;
-            zb = bcast<3>(z); if (chol_row[3] != 0.0) x += chol_row[3] * (double)zb;
-            zb = bcast<4>(z); if (chol_row[4] != 0.0) x += chol_row[4] * (double)zb;
-            zb = bcast<5>(z); if (chol_row[5] != 0.0) x += chol_row[5] * (double)zb;
-            zb = bcast<6>(z); if (chol_row[6] != 0.0) x += chol_row[6] * (double)zb;
-            return (T)x;
-        }
-        return (T)(chol_aa * (double)z);
-    };
-    if (has_u && H > 0) {
-        if constexpr (!CL) mean_next = mean[l8];
-        if constexpr (!MONO) { if (noise && live) eps_next = noise[(pid * H) * A + l8]; }
-    }
-    if constexpr (MONO) { if (H > 0) { const T e0 = draw(0); if (sampled) eps_next = e0; } }    // (every lane: DPP broadcasts)
-
-    for (int t = 0; t < H; ++t) {
-        T u = T(0);
-        const T eps_cur = eps_next;
-        const double mean_cur = mean_next, gs_cur = gs_next;
-        if (fuse.gseq && t + 1 < H) gs_next = fuse.gseq[t + 1];
-        if (has_u && t + 1 < H) {
-            if constexpr (!CL) mean_next = mean[(t + 1) * A + l8];
-            if constexpr (!MONO) { if (noise && live) eps_next = noise[(pid * H + t + 1) * A + l8]; }
-        }
-        if constexpr (CL) {         // u = clw^T [q, v, hand, hand - target, 1]
-            const int wl = has_u ? l8 : 0;
-            double uu = fuse.clw[(2 * nv + 6) * A + wl];
-            cl_accumulate<0, T>(fuse.clw, A, nv, wl, cq, cv, uu);
-            for (int k = 0; k < 3; ++k)
-                uu += fuse.clw[(2 * nv + k) * A + wl] * (double)chand[k] +
-                      fuse.clw[(2 * nv + 3 + k) * A + wl] * (double)(chand[k] - tgt[k]);
-            u = has_u ? (T)uu : T(0);
-        }
-        if (has_u) {
-            if constexpr (!CL) u = (T)mean_cur;
-            if (MONO ? sampled : (noise && live)) {
-                T eps = eps_cur;
-                if (fuse.filt) {            // eps[t] = b0 eps[t] + b1 eps[t-1] + b2 eps[t-2], t >= 2
-                    const double f = t >= 2 ? fb0 * (double)eps + fb1 * e1 + fb2 * e2 : (double)eps;
-                    e2 = e1;
-                    e1 = f;
-                    eps = (T)f;
-                }
-                u += eps;
-            }
-            if (act && live) act[(pid * H + t) * A + l8] = u;        // unclipped (gym_env_wrapper.py:151)
-            if constexpr (MONO) actT[g * HA + t * A + l8] = u;
-        }
-        // MuJoCo clamps ctrl, not the record
-        const T tau_act = M.link(O_GEAR) * fmin(fmax(u, M.link(O_CTRL_LO)), M.link(O_CTRL_HI));
-        T site[3];
-        bool fs = false;
-        if (__builtin_expect(rc.any, 0)) rflags_set<R>(ldsM, rflags<R>(ldsM) & (2 | 8));     // a new env step: do_simulation writes data.ctrl again (a pending reset stays)
-        for (int sub = 0; sub < I.frame_skip; ++sub) {
-            if ((R == DYN || R == QDYN) && sub > 0) arm_back<R>(M, q, v, aw, sinq, cosq, ldsM, l8, fs, ST, lane, &rc, diag, record, qf, seq);
-            if constexpr (QUAD) {
-                ++seq;
-                flag_front<R, NW>(M, I, q, v, aw, sinq, cosq, rows, tau_act, ldsM, qf, seq, lane, l8, site, diag, fs, ST, &rc);
-            } else {
-                arm_front<R>(M, I, q, v, aw, sinq, cosq, rows, tau_act, ldsM, lane, l8, site, diag, fs, ST, &rc);
-            }
-            if constexpr (R == SOLO) arm_back<R>(M, q, v, aw, sinq, cosq, ldsM, l8, fs, ST, lane, &rc, diag, record);
-            if (t == 0 && sub == 0 && obs)                  // fresh observation after set_env_state
-                for (int k = 0; k < 3; ++k) chand[k] = __shfl(site[k], site_lane);
-        }
-        // DYN: the last substep is integrated further down - the cost record needs only its kinematics and is
-        // written while the SOLVE wave is still solving
-        for (int k = 0; k < 3; ++k) site[k] = __shfl(site[k], site_lane);
-        // (the last substep ended in mj_checkAcc's reset: mj_forward ran again from the reset state, site_xpos is that state's)
-        if (R == SOLO && __builtin_expect(rc.any, 0)) {
-            if (rflags<R>(ldsM) & 4)
-                for (int k = 0; k < 3; ++k) site[k] = (T)record()[2 * LANES + k];
-        }
-        // Take delivery of the prefetched inputs HERE, before this step's stores are issued: loads and stores share
-        // one in-order counter (vmcnt), and the register hand-over the compiler otherwise places on the loop's
-        // back-edge waits with vmcnt(0) - i.e. for the cost / observation stores just issued (~2000 cycles per step).
-        asm volatile("" : "+v"(eps_next), "+v"(mean_next), "+v"(gs_next));
-        // reward = -(|h-g|_1 + 5 |h-g|_2), h = site_xpos lagging one substep (reacher_env.py:31-35)
-        T dx = site[0] - tgt[0], dy = site[1] - tgt[1], dz = site[2] - tgt[2];
-        T cst = fabs(dx) + fabs(dy) + fabs(dz) + T(5) * sqrt_(dx * dx + dy * dy + dz * dz);
-        // RolloutFusion::inf_on_reset: a particle that has reset costs +inf from that env step on (no weight in the updates)
-        if (__builtin_expect(rc.any, 0)) { if (fuse.inf_on_reset && (rflags<R>(ldsM) & 8)) cst = T(INFINITY); }
-        if (live && l8 == 0 && (!MONO || cost)) cost[pid * H + t] = cst;
-        if (fuse.gseq) q0acc += gs_cur * (double)cst;
-        // MONO: the next step's sample, drawn while the SOLVE wave is still iterating (DUO) / once per env step (SOLO)
-        if constexpr (MONO) { if (t + 1 < H) { const T en = draw(t + 1); if (sampled) eps_next = en; } }
-        if constexpr (R == DYN || R == QDYN) {
-            arm_back<R>(M, q, v, aw, sinq, cosq, ldsM, l8, fs, ST, lane, &rc, diag, record, qf, seq);
-            if (__builtin_expect(rc.any, 0)) {
-                // (inf_on_reset: the env step's last substep reset the particle after its cost had been written)
-                if (fuse.inf_on_reset && (rflags<R>(ldsM) & 8) && !(cst == T(INFINITY))) {    // (finite or NaN so far)
-                    if (live && l8 == 0 && (!MONO || cost)) cost[pid * H + t] = T(INFINITY);
-                    if (fuse.gseq) q0acc = INFINITY;
-                }
-            }
-#ifndef ARM_NO_FIXUP            // (developer A/B)
-            if (__builtin_expect(rc.any, 0) && !fuse.inf_on_reset) {
-                // the last substep ended in mj_checkAcc's reset: site_xpos is the reset state's (mj_forward ran again) - the
-                // cost written ahead of the integration above is written again
-                // (the substep began from a state mj_checkPos / mj_checkVel passed: its site and the cost from it are finite)
-                if (rflags<R>(ldsM) & 4) {
-#ifdef ARM_FIXUP_LIVE           // (developer A/B: the cost written above kept live instead of made again)
-                    T ex, ey, ez;
-                    const T c_old = cst;
-#else
-                    T ex = site[0] - tgt[0], ey = site[1] - tgt[1], ez = site[2] - tgt[2];
-                    const T c_old = fabs(ex) + fabs(ey) + fabs(ez) + T(5) * sqrt_(ex * ex + ey * ey + ez * ez);
-#endif
-                    for (int k = 0; k < 3; ++k) site[k] = (T)record()[2 * LANES + k];
-                    ex = site[0] - tgt[0]; ey = site[1] - tgt[1]; ez = site[2] - tgt[2];
-                    const T c_new = fabs(ex) + fabs(ey) + fabs(ez) + T(5) * sqrt_(ex * ex + ey * ey + ez * ez);
-                    if (live && l8 == 0 && (!MONO || cost)) cost[pid * H + t] = c_new;
-                    if (fuse.gseq) q0acc += fuse.gseq[t] * ((double)c_new - (double)c_old);
-                }
-            }
-#endif
-        }
-        if (live && (obs || nobs)) {
-            const long o = (pid * H + t) * dobs;
-            if (obs) {
-                if (l8 < nv) { obs[o + l8] = cq; obs[o + nv + l8] = cv; }
-                if (l8 < 3) {
-                    T hh = l8 == 0 ? chand[0] : (l8 == 1 ? chand[1] : chand[2]);
-                    T gg = l8 == 0 ? tgt[0] : (l8 == 1 ? tgt[1] : tgt[2]);
-                    obs[o + 2 * nv + l8] = hh;
-                    obs[o + 2 * nv + 3 + l8] = hh - gg;
-                }
-            }
-            if (nobs) {
-                if (l8 < nv) { nobs[o + l8] = q; nobs[o + nv + l8] = v; }
-                if (l8 < 3) {
-                    T hh = l8 == 0 ? site[0] : (l8 == 1 ? site[1] : site[2]);
-                    T gg = l8 == 0 ? tgt[0] : (l8 == 1 ? tgt[1] : tgt[2]);
-                    nobs[o + 2 * nv + l8] = hh;
-                    nobs[o + 2 * nv + 3 + l8] = hh - gg;
-                }
-            }
-        }
-        cq = q;
-        cv = v;
-        for (int k = 0; k < 3; ++k) chand[k] = site[k];
-        ST.mark(14);    // observation records, loop
-    }
-    ST.flush(diag, 0, lane);
-    if (QUAD && diag && lane == 0 && q_read(qf, QF_STUCK)) atomicAdd(diag, 0x10000u);     // a hand-over timed out: the results are void
-    // A rollout that diverged numerically (MuJoCo would have reset that simulation) carries a non-finite return: it
-    // leaves the update as +inf - zero weight in the softmax updates, last in the elite ranking - instead of poisoning
-    // the mean with a NaN
-    if (!(fabs(q0acc) < INFINITY)) q0acc = INFINITY;
-    if (fuse.q0_out && live && l8 == 0) fuse.q0_out[pid] = q0acc;
-    // "real env" stepping on the device: particle 0 writes its final (qpos, qvel) back into a state vector
-    if (state_out && pid == 0 && l8 < nv) {
-        state_out[l8] = (double)q;
-        state_out[LANES + l8] = (double)v;
-    }
-    if constexpr (MONO) { if (l8 == 0) dyn_lds[g] = live ? q0acc : INFINITY; }     // cost-to-go of my particle
-    }   // (wave 0 / the one wave)
-    if constexpr (MONO)
-        mono_record<T, NT>(mop->lam, mop->tree + (long)blockIdx.x * (2 + HA), HA, dyn_lds, actT);
-}
+// (the kernels' body: arm_rollout_body.inc, #included into the two __global__ functions below)
 
 template <typename T, bool STEP, bool CL, int WAVES, bool DUO, bool MONO>
 __global__ __launch_bounds__(DUO ? 128 : 64) __attribute__((amdgpu_waves_per_eu(WAVES, WAVES))) void arm_rollout_kernel(const T* __restrict__ model, const double* state,
@@ -2102,10 +1787,14 @@ __global__ __launch_bounds__(DUO ? 128 : 64) __attribute__((amdgpu_waves_per_eu(
                                                          T* __restrict__ act, T* __restrict__ obs,
                                                          T* __restrict__ nobs, double* state_out, unsigned* diag,
                                                          RolloutFusion fuse, const MonoStep mono_arg) {
-    // (mono_arg is a kernel argument: its fields arrive with the other arguments, no pointer chase)
-    arm_rollout_body<T, STEP, CL, DUO ? 2 : 1, MONO>(model, state, P, H, A, mean, noise, cost, act, obs, nobs, state_out, diag,
-                                                     fuse, &mono_arg);
+    const MonoStep* mop = &mono_arg;      // (a kernel argument: its fields arrive with the other arguments, no pointer chase)
+    constexpr int SHAPE = DUO ? 2 : 1, NW = SHAPE;
+    constexpr bool QUAD = false;
+    const qflag_ptr qf = nullptr;
+    int seq = 0;
+#include "arm_rollout_body.inc"
 }
+#ifndef ARM_NO_FLAGS_CODE
 // The flag-synchronised shapes: NW = 2 (a 128-thread workgroup, as DUO) and NW = 4 (P <= 2048 on 256 CUs: a 256-thread
 // workgroup = the four waves of a particle group, one per SIMD of a CU)
 template <typename T, int NW, bool MONO>
@@ -2115,10 +1804,17 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(1, 1)))
                                                          T* __restrict__ act, T* __restrict__ obs,
                                                          T* __restrict__ nobs, unsigned* diag,
                                                          RolloutFusion fuse, const MonoStep mono_arg) {
-    arm_rollout_body<T, false, false, 10 + NW, MONO>(model, state, P, H, A, mean, noise, cost, act, obs, nobs, nullptr, diag, fuse,
-                                                     &mono_arg);
+    const MonoStep* mop = &mono_arg;
+    constexpr int SHAPE = 10 + NW;
+    constexpr bool STEP = false, CL = false, DUO = false, QUAD = true;
+    double* const state_out = nullptr;
+    __shared__ int qflags[QF_COUNT];        // hand-over flags of the workgroup's waves (flag_front)
+    qflag_ptr qf = (qflag_ptr)qflags;
+    int seq = 0;                            // substep sequence number
+#include "arm_rollout_body.inc"
 }
 
+#endif
 }  // namespace
 
 long arm_rollout_groups(long P) { return (P + LANES - 1) / LANES; }
@@ -2164,6 +1860,7 @@ hipError_t launch_arm_rollout(const T* model, const double* state, long P, int H
     const bool one_per_simd = !duo && !fuse.clw && (one_env >= 0 ? one_env != 0 : (long)grid <= simds);
     const MonoStep mono_arg = mono ? *mono : MonoStep();
     const size_t dyn = mono ? sizeof(double) * MONO_RED + sizeof(T) * LANES * (size_t)H * A : 0;
+#ifndef ARM_NO_FLAGS_CODE
     // Round 6: the flag-synchronised shape with four wavefronts per particle group while every one of them still has a SIMD
     // of its own (P <= 2048 on 256 CUs) - the launches that are BASELINE config 2 and the shards of a strong-scaling run.
     // Above that DUO stays (the two-wave flag shape measures 4 % slower than DUO at 4096 particles: profiles/r06_arm_shapes.txt).
@@ -2184,6 +1881,7 @@ hipError_t launch_arm_rollout(const T* model, const double* state, long P, int H
 #undef MJMPC_LAUNCH_F
         return hipGetLastError();
     }
+#endif
 #define MJMPC_LAUNCH_W(STEP_, CL_, W_, DUO_, MONO_)                                                                   \
     hipLaunchKernelGGL((arm_rollout_kernel<T, STEP_, CL_, W_, DUO_, MONO_>), dim3(grid), dim3(DUO_ ? 128 : 64), dyn,  \
                        stream, model, state, P, H, A, mean, noise, cost, act, obs, nobs, state_out, diag, fuse, mono_arg)

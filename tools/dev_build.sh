@@ -6,7 +6,7 @@ cd "$(dirname "$0")/.."
 name=$1; shift
 mkdir -p tools/_build/_dev_$name
 F="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wno-unused-value -Wno-pass-failed -I mjmpc_amd/csrc"
-/opt/rocm/bin/hipcc $F -mllvm -amdgpu-sched-strategy=iterative-ilp "$@" -c mjmpc_amd/csrc/arm_rollout.hip -o tools/_build/_dev_$name/arm_rollout.o &
+/opt/rocm/bin/hipcc $F ${ARM_SCHED--mllvm -amdgpu-sched-strategy=iterative-ilp} "$@" -c mjmpc_amd/csrc/arm_rollout.hip -o tools/_build/_dev_$name/arm_rollout.o &
 /opt/rocm/bin/hipcc $F "$@" -c mjmpc_amd/csrc/capi.hip -o tools/_build/_dev_$name/capi.o &
 wait
 objs=$(ls mjmpc_amd/_build/*.o | grep -v -e arm_rollout.o -e capi.o)
