@@ -84,6 +84,8 @@ def parse(argv=None):
                          "the timed steps do not pay for a fresh process (idle clocks, first-touch, lazy runtime initialisation)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=10.0)
+    ap.add_argument("--engine", choices=["auto", "tree"], default="auto",
+                    help="synthetic workloads: 'auto' = the arm kernels where the model fits them (cart-pole), 'tree' = always the tree engine")
     ap.add_argument("--backend", default="nccl", help=argparse.SUPPRESS)          # test knobs: gloo on one GPU
     ap.add_argument("--collectives", choices=["auto", "library", "torch", "both"], default="both",
                     help="N > 1: which path carries the control iteration's exchanges - libmjmpc_amd.so's own RCCL communicator "
@@ -188,7 +190,7 @@ def profile_figure(name, dtype, P, H, prefix=""):
     """A per-launch figure that needs PMC counters (separate rocprofv3 passes, MI355X_MICROARCH.md): measured
     offline and kept under profiles/ (the headline shape; since round 5 the reacher at 16384 / 65536 particles and the cart-pole,
     door, tray and gripper workloads too); other shapes report null."""
-    for rnd in ("r05", "r04", "r03", "r02", "r01"):
+    for rnd in ("r06", "r05", "r04", "r03", "r02", "r01"):
         path = os.path.join(ROOT, "profiles", "%s_%s%s_%s_%dx%d.json" % (rnd, prefix, name, dtype, P, H))
         if os.path.exists(path):
             with open(path) as f:
@@ -247,8 +249,16 @@ def make_workload(args, local, comm, P_tot):
             env = dict(half_cheetah=locomotion_env.HalfCheetahEnv, swimmer=locomotion_env.SwimmerEnv)[args.workload](
                 dtype=args.dtype, device=local)
             name, lam = dict(half_cheetah="HalfCheetah-v0", swimmer="Swimmer-v0")[args.workload], {"mppi": 0.2, "dmd": 0.2}
-        eng = TreeRolloutEngine(raw, device=local, dtype=args.dtype)
-        w.update(name=name, lam=lam, cov=0.3, env=env, kernel="tree_rollout_kernel", target=np.asarray(raw.target_pos, float),
+        # (round 6: models the serial-chain arm kernels take - the cart-pole: slide joints + dry friction, their extended-joint
+        # build - run there; --engine tree keeps the general tree engine for A/B)
+        from mjmpc_amd.envs import make_engine
+        eng = (TreeRolloutEngine(raw, device=local, dtype=args.dtype) if (args.engine == "tree" or env is not None)
+               else make_engine(raw, device=local, dtype=args.dtype))
+        on_arm = not isinstance(eng, TreeRolloutEngine)
+        if on_arm:
+            name += " on the arm engine (extended-joint build)"
+        w.update(name=name, lam=lam, cov=0.3, env=env, kernel="arm_rollout_kernel" if on_arm else "tree_rollout_kernel",
+                 target=np.asarray(raw.target_pos, float),
                  frame_skip=raw.frame_skip, nv=compile_tree(raw).nv,
                  tail="closed loop (tree engine; not a BASELINE.json configuration%s)"
                       % ("" if args.workload not in ("hand24", "pen_hand") else "; stand-in for pen-v0, whose assets are absent"))
@@ -259,6 +269,7 @@ def make_workload(args, local, comm, P_tot):
             w["x0"] = float(st0["qpos"][0])
         elif args.workload in ("cartpole", "tray", "door", "gripper"):
             w["reset"] = lambda: eng.set_env_state(gen_start)
+            w["start"] = gen_start
             w["cov"] = 0.01 if args.workload in ("tray", "gripper") else 0.3
         elif start is not None:
             st0 = dict(start, target_pos=np.asarray(raw.target_pos, float))
@@ -409,10 +420,13 @@ def main():
 
     # where the closed loop ended up (read BEFORE the launches below)
     extra = {}
-    if args.workload == "reacher":
+    on_arm = w["kernel"] == "arm_rollout_kernel"
+    if on_arm:
+        nv_ = w["nv"]
         _, nobs = eng.step_state(np.zeros(A))
-        extra["final_distance_to_target"] = float(torch.linalg.norm(nobs[17:20]).item())
-        qpos, qvel = np.zeros(7), np.zeros(7)           # the FLOP sample and the CPU baseline start where the run started
+        extra["final_distance_to_target"] = float(torch.linalg.norm(nobs[2 * nv_ + 3:2 * nv_ + 6]).item())
+        st0 = eng.get_env_state()[0]                    # (the host mirror of the state the run STARTED from)
+        qpos, qvel = (np.zeros(7), np.zeros(7)) if args.workload == "reacher" else (np.asarray(w["start"]["qp"], float), np.asarray(w["start"]["qv"], float))
     else:
         st = eng.get_state_device()
         qpos = st["qpos"] if "qpos" in st else st["qp"]
@@ -648,7 +662,7 @@ def main():
                                       "with launch 2 (arm_mppi_finish_kernel: update + action + shift, here without its env step): "
                                       "%.4f ms" % both_ms
                                       if mono else ("mjmpc_arm_rollout_sampled (Philox draws + full-covariance colouring in the kernel)" if sampled_entry
-                                                    else ("mjmpc_arm_rollout" if args.workload == "reacher" else "mjmpc_tree_rollout")
+                                                    else ("mjmpc_arm_rollout" if on_arm else "mjmpc_tree_rollout")
                                                     + ("_fused" if fused_entry else ""))),
                      "alg_bytes_per_particle_step": b_alg,
                      "note": "latency/VALU-bound path (SURVEY 8d): >100 counted FLOP per algorithmic byte, HBM fraction is small by "

@@ -32,7 +32,9 @@ extern "C" {
 /*   3: round 5 - rollouts emulate MuJoCo's reset on instability (finite costs where version 2 returned +inf;
  *      mjmpc_arm_diverged). */
 /*   4: round 6 - mjmpc_{arm,tree}_env_resets (resets of the device-resident REAL env, counted apart from the rollouts'),
- *      mjmpc_{arm,tree}_set_reset_returns (+inf returns for particles that reset, as an engine option). */
+ *      mjmpc_{arm,tree}_set_reset_returns (+inf returns for particles that reset, as an engine option);
+ *      MJMPC_ARM_BLOB_LEN 229 -> 255 (joint type, friction loss, nu: the arm engine takes slide joints, dry friction and
+ *      fewer motors than dofs). */
 #define MJMPC_ABI_VERSION 4
 
 #define MJMPC_F32 0
@@ -48,8 +50,9 @@ extern "C" {
  *   off[3][8] axis[3][8] mass[8] com[3][8] inertia[6][8] armature[8] damping[8] range_lo[8]
  *   range_hi[8] limited[8] gear[8] ctrl_lo[8] ctrl_hi[8] dof_invweight0[8] nv timestep frame_skip
  *   site_link site_pos[3] n_sphere sph_link sph_pos[3] sph_r sph_margin sph_invweight plane_n[3]
- *   plane_d sol_K sol_B sol_dmin sol_dmax sol_width sol_mid sol_power gravity[3]               */
-#define MJMPC_ARM_BLOB_LEN 229
+ *   plane_d sol_K sol_B sol_dmin sol_dmax sol_width sol_mid sol_power gravity[3]
+ *   jtype[8] (0 hinge, 1 slide) frictionloss[8] floss_D[8] floss_B nu                           */
+#define MJMPC_ARM_BLOB_LEN 255
 /* Device state vector of an arm engine: qpos[8] | qvel[8] | target_pos[3]  (float64). */
 #define MJMPC_ARM_STATE_LEN 19
 

@@ -38,7 +38,10 @@ PER_SOURCE_FLAGS = {"tree_rollout_dense.hip": [["-mllvm", "-amdgpu-sched-strateg
                     # pairs: f64 control step 0.1957 -> 0.1935 ms, pipelined 0.1910 -> 0.1883; the plain two-wave launch
                     # +0.5 %, one-wave launches unchanged; max-ilp as maxocc, iterative-minreg / max-memory-clause slower)
                     "arm_rollout.hip": [["-mllvm", "-amdgpu-sched-strategy=iterative-ilp"],
-                                        ["-mllvm", "-amdgpu-sched-strategy=iterative-maxocc"]]}
+                                        ["-mllvm", "-amdgpu-sched-strategy=iterative-maxocc"]],
+                    # (the extended-joint build of the same kernels: arm_rollout_xj.hip includes arm_rollout.hip)
+                    "arm_rollout_xj.hip": [["-mllvm", "-amdgpu-sched-strategy=iterative-ilp"],
+                                           ["-mllvm", "-amdgpu-sched-strategy=iterative-maxocc"]]}
 
 
 def flags_for(src, alternative=0):
@@ -52,7 +55,8 @@ def sources():
 
 def _headers():
     return (glob.glob(os.path.join(CSRC, "*.h")) + glob.glob(os.path.join(CSRC, "*.inc")) + [os.path.join(HERE, "..", "include", "mjmpc_amd.h")]
-            + [os.path.join(CSRC, "tree_rollout.hip")])        # (tree_rollout_dense.hip and tree_rollout_cone.hip include it)
+            + [os.path.join(CSRC, "tree_rollout.hip"),         # (tree_rollout_dense.hip and tree_rollout_cone.hip include it)
+               os.path.join(CSRC, "arm_rollout.hip")])         # (arm_rollout_xj.hip includes it)
 
 
 def _obj(src):

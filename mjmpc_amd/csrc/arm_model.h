@@ -43,9 +43,15 @@ enum ArmOffset : int {
     O_SOL_MID,
     O_SOL_POWER,
     O_GRAVITY,                       // 3
-    ARM_BLOB_LEN = O_GRAVITY + 3
+    // round 6: what the EXTENDED-JOINT build of the arm kernels (arm_rollout_xj.hip) reads on top - slide joints, dry friction
+    O_JTYPE = O_GRAVITY + 3,         // 8: 0 hinge, 1 slide
+    O_FLOSS = O_JTYPE + 8,           // 8: dof_frictionloss
+    O_FLOSS_D = O_FLOSS + 8,         // 8: D = 1 / R of the dof's friction-loss row
+    O_FLOSS_B = O_FLOSS_D + 8,       // b of the rows' reference acceleration -b v
+    O_NU,                            // motors (they drive dofs 0 .. nu - 1); host side only
+    ARM_BLOB_LEN
 };
 
-static_assert(ARM_BLOB_LEN == 229, "keep in sync with mjmpc_amd/models/compile.py::ARM_LAYOUT");
+static_assert(ARM_BLOB_LEN == 255, "keep in sync with mjmpc_amd/models/compile.py::ARM_LAYOUT");
 
 }  // namespace mjmpc

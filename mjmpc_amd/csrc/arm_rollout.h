@@ -79,5 +79,14 @@ hipError_t launch_arm_mppi_finish(const T* model, const double* records, long n_
                                   double* mean_out, const MonoStep& mono, int env_step, unsigned* diag, hipStream_t stream);
 // workgroups the launch of P particles uses (the reduction tree is sized by it)
 long arm_rollout_groups(long P);
+// the extended-joint build (arm_rollout_xj.hip): the same two launches for models with slide joints / friction loss
+template <typename T>
+hipError_t launch_arm_rollout_xj(const T* model, const double* state, long P, int H, int A, const double* mean,
+                                 const T* noise, T* cost, T* act, T* obs, T* nobs, double* state_out,
+                                 unsigned* diag, hipStream_t stream, RolloutFusion fuse = RolloutFusion(),
+                                 const MonoStep* mono = nullptr);
+template <typename T>
+hipError_t launch_arm_mppi_finish_xj(const T* model, const double* records, long n_rec, int H, int A, const double* mean_in,
+                                     double* mean_out, const MonoStep& mono, int env_step, unsigned* diag, hipStream_t stream);
 
 }  // namespace mjmpc

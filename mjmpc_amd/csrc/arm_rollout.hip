@@ -66,6 +66,16 @@ __device__ __forceinline__ float uniform_(float x) { return __int_as_float(__bui
 __device__ __forceinline__ double uniform_(double x) {
     return __hiloint2double(__builtin_amdgcn_readfirstlane(__double2hiint(x)), __builtin_amdgcn_readfirstlane(__double2loint(x)));
 }
+// The EXTENDED-JOINT build (round 6): csrc/arm_rollout_xj.hip compiles this file a second time with MJMPC_ARM_XJ defined - the
+// same kernels under their own exported names, with slide joints (joint type per link) and dry friction (one friction-loss
+// row per dof, MuJoCo's mj_instantiateFriction) compiled in.  Models that need neither keep running the build without them:
+// its code does not change by a single instruction.  (A translation-unit constant, not a template parameter: every helper
+// sees it without its signature growing.)
+#ifdef MJMPC_ARM_XJ
+constexpr bool XJ = true;
+#else
+constexpr bool XJ = false;
+#endif
 template <typename T, bool REG>
 struct Model {                 // view of the LDS copy of the model block
     static constexpr bool cached = REG;
@@ -94,6 +104,9 @@ struct Model {                 // view of the LDS copy of the model block
         else return m[off + c * LANES + l8];
     }
     __device__ __forceinline__ T glob(int off, int c = 0) const { return m[off + c]; }
+    // XJ: my link's entries of the extended fields (read from LDS where they are used: they are not in the cached set)
+    __device__ __forceinline__ bool xj_slide() const { return XJ && m[O_JTYPE + l8] != T(0); }
+    __device__ __forceinline__ T xj(int off) const { return m[off + l8]; }
 };
 
 __device__ __forceinline__ float mul_rn(float a, float b) { return __fmul_rn(a, b); }
@@ -300,12 +313,16 @@ struct LinkFrame {
 
 // 1. forward kinematics: local transform (Rodrigues, frames are world-aligned at qpos0) + scan
 template <typename T, typename MT>
-__device__ __forceinline__ void kinematics(const MT& M, T sq, T cq, int l8, LinkFrame<T>& L) {
+__device__ __forceinline__ void kinematics(const MT& M, T sq, T cq, int l8, LinkFrame<T>& L, T q = T(0)) {
     T* R = L.R;
     T* p = L.p;
     T* ax = L.ax;
     const T s = sq, c = cq, tt = T(1) - cq;
     for (int k = 0; k < 3; ++k) { ax[k] = M.link(O_AXIS, k); p[k] = M.link(O_OFF, k); }
+    if constexpr (XJ) {             // a slide joint: (sin, cos) stay (0, 1) - the rotation below is the identity - and q moves the origin
+        const T qs = M.xj_slide() ? q : T(0);
+        for (int k = 0; k < 3; ++k) p[k] += qs * ax[k];
+    }
     R[0] = c + tt * ax[0] * ax[0];
     R[1] = tt * ax[0] * ax[1] - s * ax[2];
     R[2] = tt * ax[0] * ax[2] + s * ax[1];
@@ -354,6 +371,10 @@ __device__ __forceinline__ void link_frames(const MT& M, LinkFrame<T>& L) {
     }
     for (int k = 0; k < 3; ++k) { L.hm[k] = mass * cw[k]; L.sw[k] = L.a[k]; }
     cross(p, L.a, L.sv);
+    if constexpr (XJ) {             // a slide joint's motion axis: S = (0, a)
+        if (M.xj_slide())
+            for (int k = 0; k < 3; ++k) { L.sw[k] = T(0); L.sv[k] = L.a[k]; }
+    }
 }
 
 // 3. joint-space bias force c(q, v) (Newton-Euler with zero joint acceleration, base acceleration -g)
@@ -487,7 +508,9 @@ __device__ __forceinline__ void contact_geometry(const MT& M, const ArmInts& I, 
         T r[3], ar[3];
         for (int k = 0; k < 3; ++k) r[k] = ctr[k] - pn[k] * (sph_r + T(0.5) * cdist) - L.p[k];
         cross(L.a, r, ar);
-        jc = (cinst && l8 <= I.sph_link) ? dot(pn, ar) : T(0);
+        T jl = dot(pn, ar);
+        if constexpr (XJ) jl = M.xj_slide() ? dot(pn, L.a) : jl;
+        jc = (cinst && l8 <= I.sph_link) ? jl : T(0);
         jv = gsum(jc * v);
     }
 }
@@ -576,6 +599,97 @@ struct Stamps {
 __device__ __forceinline__ void duo_barrier() {
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
     __builtin_amdgcn_sched_barrier(0);
+}
+
+// XJ: my dof's friction-loss row (MuJoCo mj_instantiateFriction: J = e_l at position 0, Huber cost): D = 1 / R from the
+// impedance at 0 (a constant of the model, O_FLOSS_D), reference acceleration -b v.  Zone of the row at acceleration xa:
+// -1: slope <= -f (force +f), 0: quadratic, +1: slope >= f (force -f); f32: a slope within rounding of a bound keeps its zone
+template <typename T>
+struct FlossRow {
+    T f = T(0), D = T(0), aref = T(0);
+    int z = 0;
+    __device__ __forceinline__ int zone_at(T xa) const {
+        if (!(f > T(0))) return 0;
+        const T sl = D * (xa - aref);
+        const T bc = sizeof(T) == 4 ? T(2e-5) * (fabs(sl) + f) : T(0);
+        if (z < 0) return sl > -f + bc ? (sl >= f ? 1 : 0) : -1;
+        if (z > 0) return sl < f - bc ? (sl <= -f ? -1 : 0) : 1;
+        return sl <= -f - bc ? -1 : (sl >= f + bc ? 1 : 0);
+    }
+    __device__ __forceinline__ T diag() const { return (f > T(0) && z == 0) ? D : T(0); }                   // its part of H
+    __device__ __forceinline__ T rhs() const { return f > T(0) ? (z == 0 ? D * aref : (z < 0 ? f : -f)) : T(0); }
+    __device__ __forceinline__ T force(T xa) const { return f > T(0) ? (z == 0 ? -D * (xa - aref) : (z < 0 ? f : -f)) : T(0); }
+    __device__ __forceinline__ int memory() const { return f > T(0) ? (16 | ((z + 1) << 5)) : 0; }          // bits of `rows`
+};
+template <typename T, typename MT>
+__device__ __forceinline__ FlossRow<T> floss_row(const MT& M, T v, int rows) {
+    FlossRow<T> r;
+    if constexpr (XJ) {
+        r.f = M.xj(O_FLOSS);
+        if (r.f > T(0)) {
+            r.D = M.xj(O_FLOSS_D);
+            r.aref = -M.glob(O_FLOSS_B) * v;
+            r.z = (rows & 16) ? ((rows >> 5) & 3) - 1 : 0;      // the zone the previous substep ended in
+        }
+    }
+    return r;
+}
+
+// XJ: EXACT LINE SEARCH of the constraint problem's cost along d = a_new - a_prev (MuJoCo's Newton solver does the same).
+// Without friction-loss rows the active-set iteration may take full steps - with the active set fixed the cost is quadratic and
+// the iteration settles in 1 - 3 solves - but a Huber row has no curvature in its linear zones, and full steps between zone
+// assignments can cycle (seen: 140 cap hits in 2e5 cart-pole substeps).  With the step length that minimises the TRUE cost
+// phi(alpha) = 1/2 (a - a0)' M (a - a0) + sum_rows s_i(J_i a - aref_i),  a = a_prev + alpha d,  the iteration descends and ends.
+// phi' is piecewise linear and increasing: safeguarded Newton on alpha (each evaluation: the lanes' row terms, two sums over
+// the particle's lanes).  Every lane of the particle returns ITS entry of a_prev + alpha* d.  V_XH / V_XE carry a_prev and d.
+template <typename T, typename MT>
+__device__ __forceinline__ T xj_line_search(const MT& M, T* ldsM, int l8, T a_prev, T a_new, T tau, T sig, T D, T aref,
+                                            bool inst, T jc, T Dc, T arefc, bool cinst, const FlossRow<T>& fl) {
+    const T d = a_new - a_prev;
+    ldsM[V_XH + l8] = a_prev;
+    ldsM[V_XE + l8] = d;
+    LDS_WAVE_SYNC();
+    T Ma = M.link(O_ARMATURE) * a_prev, Md = M.link(O_ARMATURE) * d;       // rows of M x (the tile holds M without the armature)
+#pragma unroll
+    for (int j = 0; j < MAX_LINKS; ++j) {
+        const T m = ldsM[l8 * LANES + j];
+        Ma += m * ldsM[V_XH + j];
+        Md += m * ldsM[V_XE + j];
+    }
+    const T g0 = gsum(d * (Ma - tau)), h0 = gsum(d * Md);                   // the smooth part: phi' = g0 + alpha h0 + rows
+    // my rows along the line: residual r(alpha) = r0 + alpha rd
+    const T rl0 = sig * a_prev - aref, rld = sig * d;                       // limit row (cost 1/2 D min(r, 0)^2)
+    const T rf0 = a_prev - fl.aref, rfd = d;                                // friction-loss row (Huber: slope clamp(D r, -f, f))
+    T rc0 = T(0), rcd = T(0);
+    const bool any_c = __any(cinst);
+    if (any_c) { rc0 = gsum(jc * a_prev) - arefc; rcd = gsum(jc * d); }     // the contact row (one per particle: counted by lane 0's share)
+    T alpha = T(1);
+    T lo = T(0), hi = T(0);                                                 // bracket once phi' has been seen positive
+    bool have_hi = false;
+#pragma unroll 1
+    for (int k = 0; k < 12; ++k) {
+        T g = T(0), hh = T(0);
+        if (inst) { const T r = rl0 + alpha * rld; if (r < T(0)) { g += D * r * rld; hh += D * rld * rld; } }
+        if (fl.f > T(0)) {
+            const T sl = fl.D * (rf0 + alpha * rfd);
+            if (sl <= -fl.f) g -= fl.f * rfd;
+            else if (sl >= fl.f) g += fl.f * rfd;
+            else { g += sl * rfd; hh += fl.D * rfd * rfd; }
+        }
+        T gp = gsum(g), hp = gsum(hh);
+        if (cinst) { const T r = rc0 + alpha * rcd; if (r < T(0)) { gp += Dc * r * rcd; hp += Dc * rcd * rcd; } }
+        const T dphi = g0 + alpha * h0 + gp, ddphi = h0 + hp;               // (uniform over the particle's lanes)
+        const bool pos = dphi > T(0);
+        if (pos) { hi = alpha; have_hi = true; } else lo = alpha;
+        const T tol = T(sizeof(T) == 4 ? 1e-6 : 1e-14) * (fabs(g0) + fabs(h0) + T(1e-30));
+        const bool done = fabs(dphi) <= tol || !(ddphi > T(0));
+        T next = alpha - dphi * rcp_(ddphi > T(0) ? ddphi : T(1));
+        if (have_hi && !(next > lo && next < hi)) next = T(0.5) * (lo + hi); // (safeguard: stay inside the bracket)
+        if (!have_hi && !(next > lo)) next = T(2) * alpha + T(1);
+        if (!done) alpha = next;
+        if (!__any(!done)) break;
+    }
+    return a_prev + alpha * d;
 }
 
 // active-set test of the constraint rows at acceleration aw (f32: a row whose residual is within rounding of zero
@@ -708,7 +822,7 @@ __device__ __forceinline__ void arm_front(const MT& M, const ArmInts& I, T& q, T
     }
     PHASE();
     LinkFrame<T> L;
-    kinematics(M, sq, cq, l8, L);
+    kinematics(M, sq, cq, l8, L, q);
     if constexpr (ROLE != SOLVE) {
         const T sp[3] = {M.glob(O_SITE_POS, 0), M.glob(O_SITE_POS, 1), M.glob(O_SITE_POS, 2)};
         T t[3];
@@ -865,7 +979,8 @@ __device__ __forceinline__ void arm_front(const MT& M, const ArmInts& I, T& q, T
             arefc = cinst ? arefc : T(0);
         }
     }
-    const bool any_rows = __any(inst || cinst);
+    FlossRow<T> fl = floss_row(M, v, rows);             // (XJ: my dof's friction-loss row; otherwise empty)
+    const bool any_rows = __any(inst || cinst || (XJ && fl.f > T(0)));
     if (!any_rows) rows = 0;
     if constexpr (!rows_from_dyn) {
         if (any_rows) {
@@ -896,7 +1011,9 @@ __device__ __forceinline__ void arm_front(const MT& M, const ArmInts& I, T& q, T
             for (int it = 0; it < newton_maxit<T>(); ++it) {
                 T rhs = tau + (act ? D * sig * aref : T(0));
                 if (any_c) rhs += cact ? Dc * jc * arefc : T(0);
-                ldsM[V_DH + l8] = dgM + (act ? D : T(0));
+                T dh = dgM + (act ? D : T(0));
+                if constexpr (XJ) { rhs += fl.rhs(); dh += fl.diag(); }
+                ldsM[V_DH + l8] = dh;
                 ldsM[V_RH + l8] = rhs;
                 LDS_WAVE_SYNC();
                 Dense<T> F;
@@ -924,6 +1041,9 @@ __device__ __forceinline__ void arm_front(const MT& M, const ArmInts& I, T& q, T
                 T acc = T(0);
 #pragma unroll
                 for (int i = 0; i < MAX_LINKS; ++i) acc += col[i] * rh[i];
+                if constexpr (XJ) {         // from the second solve on: an exact line search from the previous iterate
+                    if (it > 0) acc = xj_line_search(M, ldsM, l8, aw, acc, tau, sig, D, aref, inst, jc, Dc, arefc, cinst, fl);
+                }
                 aw = acc;
                 bool act2, cact2;
                 active_set(aw, sig, aref, jc, arefc, inst, cinst, act, cact, act2, cact2);
@@ -931,6 +1051,13 @@ __device__ __forceinline__ void arm_front(const MT& M, const ArmInts& I, T& q, T
                 changed = flip || cflip;
                 act = act2;
                 cact = cact2;
+                bool fflip = false;         // XJ: my friction-loss row changed zone (the next iteration refactors)
+                if constexpr (XJ) {
+                    const int z2 = fl.zone_at(aw);
+                    fflip = z2 != fl.z;
+                    fl.z = z2;
+                    changed = changed || fflip;
+                }
                 // E2: the DYN wave needs ~1000 cycles after E1 for (M + h B)^-1; with the limit rows arriving from it
                 // this wave gets HERE in about as many (after the first factorisation it would still wait ~400).  Taking
                 // the rendezvous inside the first iteration rather than at the end of the substep leaves only E3
@@ -948,7 +1075,7 @@ __device__ __forceinline__ void arm_front(const MT& M, const ArmInts& I, T& q, T
                 // dozen instructions instead of a second factorisation.  Several flips in one particle, or a flip of
                 // the contact row, take the general path (next iteration refactors).
                 const float nflip = gsum(flip ? 1.0f : 0.0f);
-                if (!__any(cflip || nflip > 1.5f)) {
+                if (!XJ && !__any(cflip || nflip > 1.5f || fflip)) {   // (XJ: every change refactors and goes through the line search)
                     if (flip) {
                         T zjj = col[0];
 #pragma unroll
@@ -974,15 +1101,21 @@ __device__ __forceinline__ void arm_front(const MT& M, const ArmInts& I, T& q, T
                     changed = (act2 != act) || (cact2 != cact);
                     act = act2;
                     cact = cact2;
+                    if constexpr (XJ) {
+                        const int z2 = fl.zone_at(aw);
+                        changed = changed || z2 != fl.z;
+                        fl.z = z2;
+                    }
                     ST.mark(9);
                     if (!__any(changed)) break;
                 }
                 LDS_WAVE_SYNC();                        // V_RH is rewritten
             }
             if (changed && diag) atomicAdd(diag, 1u);
-            rows = (inst ? 1 : 0) | (act ? 2 : 0) | (cinst ? 4 : 0) | (cact ? 8 : 0);
+            rows = (inst ? 1 : 0) | (act ? 2 : 0) | (cinst ? 4 : 0) | (cact ? 8 : 0) | fl.memory();
             // qfrc_constraint = J^T f,  f = -D (J a - aref) on active rows
             qfrc_c = act ? -D * (sig * aw - aref) * sig : T(0);
+            if constexpr (XJ) qfrc_c += fl.force(aw);
             if (__any(cact)) {
                 T fcn = cact ? -Dc * (gsum(jc * aw) - arefc) : T(0);
                 qfrc_c += jc * fcn;
@@ -1016,7 +1149,9 @@ __device__ __forceinline__ void arm_front(const MT& M, const ArmInts& I, T& q, T
         for (int it = 0; it < newton_maxit<T>(); ++it) {
             T rhs = tau + (act ? D * sig * aref : T(0));
             if (any_c) rhs += cact ? Dc * jc * arefc : T(0);
-            ldsM[V_DH + l8] = dgM + (act ? D : T(0));
+            T dh = dgM + (act ? D : T(0));
+            if constexpr (XJ) { rhs += fl.rhs(); dh += fl.diag(); }
+            ldsM[V_DH + l8] = dh;
             ldsM[V_RH + l8] = rhs;
             LDS_WAVE_SYNC();
             if (it == 0 || roleH) {
@@ -1039,19 +1174,31 @@ __device__ __forceinline__ void arm_front(const MT& M, const ArmInts& I, T& q, T
                 for (int i = 0; i < MAX_LINKS; ++i) ldsM[V_XH + i] = b[i];
             }
             LDS_WAVE_SYNC();
-            aw = ldsM[V_XH + l8];
+            if constexpr (XJ) {
+                const T a_new = ldsM[V_XH + l8];
+                LDS_WAVE_SYNC();            // (the line search reuses V_XH)
+                aw = it > 0 ? xj_line_search(M, ldsM, l8, aw, a_new, tau, sig, D, aref, inst, jc, Dc, arefc, cinst, fl) : a_new;
+            } else {
+                aw = ldsM[V_XH + l8];
+            }
             bool act2, cact2;
             active_set(aw, sig, aref, jc, arefc, inst, cinst, act, cact, act2, cact2);
             changed = (act2 != act) || (cact2 != cact);
             act = act2;
             cact = cact2;
+            if constexpr (XJ) {
+                const int z2 = fl.zone_at(aw);
+                changed = changed || z2 != fl.z;
+                fl.z = z2;
+            }
             ST.mark(it == 0 ? 8 : 9);                   // first solve + active-set check / further iterations
             if (!__any(changed)) break;
         }
         if (changed && diag) atomicAdd(diag, 1u);
-        rows = (inst ? 1 : 0) | (act ? 2 : 0) | (cinst ? 4 : 0) | (cact ? 8 : 0);
+        rows = (inst ? 1 : 0) | (act ? 2 : 0) | (cinst ? 4 : 0) | (cact ? 8 : 0) | fl.memory();
         // qfrc_constraint = J^T f,  f = -D (J a - aref) on active rows
         qfrc_c = act ? -D * (sig * aw - aref) * sig : T(0);
+        if constexpr (XJ) qfrc_c += fl.force(aw);
         if (__any(cact)) {
             T fcn = cact ? -Dc * (gsum(jc * aw) - arefc) : T(0);
             qfrc_c += jc * fcn;
@@ -1208,7 +1355,7 @@ __device__ __forceinline__ void flag_front(const MT& M, const ArmInts& I, T& q, 
     T ctr[3] = {T(0), T(0), T(0)};
     bool near_plane = false;
     if constexpr (ROLE != QAUX) {
-        kinematics(M, sq, cq, l8, L);
+        kinematics(M, sq, cq, l8, L, q);
         if constexpr (ROLE == QDYN) {
             const T sp[3] = {M.glob(O_SITE_POS, 0), M.glob(O_SITE_POS, 1), M.glob(O_SITE_POS, 2)};
             T t[3];
@@ -1458,21 +1605,23 @@ __device__ __forceinline__ void arm_back(const MT& M, T& q, T& v, T& aw, T& sq, 
         v = add_rn(v, mul_rn(h, x));
         const T dq = mul_rn(h, v);
         q = add_rn(q, dq);
+        const bool slide = M.xj_slide();                // (XJ: a slide joint advances q alone - its (sin, cos) stay (0, 1))
+        const T dqa = slide ? T(0) : dq;
         // advance (sin q, cos q) by dq: angle addition with a short series, one Newton step of renormalisation.
         // Large steps (|dq| > 0.25 rad per substep, never seen with h = 0.01): series at dq / 256, doubled back up.
         // (ONE wave-level test guards everything rare about the integration - this, and MuJoCo's reset on instability below: a
         // NaN or an entry beyond mjMAXVAL = 1e10 in the acceleration or the integrated state makes |dq| = h |v| huge or NaN)
         T sd, cd;
-        const bool big = __any(!(fabs(dq) <= T(0.25)));
+        const bool big = __any(!(fabs(dq) <= (slide ? T(1e5) : T(0.25))));
         if (__builtin_expect(big, 0)) {
-            sincos_small(dq * T(1.0 / 256.0), sd, cd);
+            sincos_small(dqa * T(1.0 / 256.0), sd, cd);
             for (int k = 0; k < 8; ++k) {
                 const T s2 = T(2) * sd * cd;
                 cd = T(1) - T(2) * sd * sd;
                 sd = s2;
             }
         } else {
-            sincos_small(dq, sd, cd);
+            sincos_small(dqa, sd, cd);
         }
         const T s1 = sq * cd + cq * sd, c1 = cq * cd - sq * sd;
         const T k = T(1.5) - T(0.5) * (s1 * s1 + c1 * c1);
@@ -1530,6 +1679,7 @@ __device__ __forceinline__ void real_env_step(const MT& M, const ArmInts& I, con
     if (l8 >= nv) { q = T(0); v = T(0); }
     T sinq, cosq;
     sincos_(q, sinq, cosq);
+    if constexpr (XJ) { if (M.xj_slide()) { sinq = T(0); cosq = T(1); } }
     int rows = 0;
     Stamps ST;
     ST.begin();
@@ -1817,8 +1967,14 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(1, 1)))
 #endif
 }  // namespace
 
+// (the extended-joint build exports the same two entry points under its own names: arm_rollout.h)
+#ifdef MJMPC_ARM_XJ
+#define launch_arm_mppi_finish launch_arm_mppi_finish_xj
+#define launch_arm_rollout launch_arm_rollout_xj
+#else
 long arm_rollout_groups(long P) { return (P + LANES - 1) / LANES; }
 long mono_record_doubles(long groups, int H, int A) { return groups * (2 + (long)H * A); }
+#endif
 
 template <typename T>
 hipError_t launch_arm_mppi_finish(const T* model, const double* records, long n_rec, int H, int A, const double* mean_in,

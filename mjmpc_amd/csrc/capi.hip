@@ -71,12 +71,32 @@ struct mjmpc_arm_s {
     // destroyed (mono_retired) - a graph captured at one (P, H) survives later calls at another
     double* reset_rec = nullptr;    // n_shards records of ARM_RESET_LEN: MuJoCo's reset on instability (RolloutFusion::reset_rec)
     int inf_on_reset = 0;           // mjmpc_arm_set_reset_returns
+    bool xj = false;                // slide joints / friction loss: launches go to the extended-joint build (arm_blob_is_xj)
     std::vector<double*> reset_retired;     // reset records that were replaced: bound launchers / captured graphs carry the
                                             // pointer by value (RolloutFusion, MonoStep), so they stay allocated until destroy
     double* mono_tree = nullptr;
     size_t mono_cap = 0;            // doubles
     std::vector<double*> mono_retired;
 };
+
+// which build of the arm kernels an engine's launches go to: the extended-joint one (arm_rollout_xj.hip) when some block of its
+// model has a slide joint or a dof with friction loss
+static bool arm_blob_is_xj(const double* blobs, int n_shards) {
+    for (int s = 0; s < n_shards; ++s)
+        for (int l = 0; l < mjmpc::LANES; ++l) {
+            const double* b = blobs + (size_t)s * mjmpc::ARM_BLOB_LEN;
+            if (b[mjmpc::O_JTYPE + l] != 0.0 || b[mjmpc::O_FLOSS + l] > 0.0) return true;
+        }
+    return false;
+}
+template <typename T, typename... A>
+static hipError_t arm_rollout_launch(const mjmpc_arm_s* h, A&&... a) {
+    return h->xj ? mjmpc::launch_arm_rollout_xj<T>(a...) : mjmpc::launch_arm_rollout<T>(a...);
+}
+template <typename T, typename... A>
+static hipError_t arm_finish_launch(const mjmpc_arm_s* h, A&&... a) {
+    return h->xj ? mjmpc::launch_arm_mppi_finish_xj<T>(a...) : mjmpc::launch_arm_mppi_finish<T>(a...);
+}
 
 struct mjmpc_tree_s {
     int device = 0;
@@ -196,15 +216,16 @@ static int arm_make_reset_records(mjmpc_arm_s* h, const double* blobs, int n_sha
         e = hipMemcpy(tmp, b.data(), sizeof(double) * L, hipMemcpyHostToDevice);
         if (e != hipSuccess) break;
         double* rk = rec + (size_t)k * R;
-        e = mjmpc::launch_arm_rollout<double>(tmp, st, 1, 1, h->nu, mean, nullptr, cost, nullptr, nullptr, nobs, rk, sdiag, nullptr);
+        e = arm_rollout_launch<double>(h, tmp, st, 1, 1, h->nu, mean, nullptr, cost, nullptr, nullptr, nobs, rk, sdiag, nullptr);
         if (e == hipSuccess) e = hipMemcpy(rk + 2 * mjmpc::LANES, nobs + 2 * h->nv, sizeof(double) * 3, hipMemcpyDeviceToDevice);
         if (e == hipSuccess) e = hipDeviceSynchronize();
         if (e != hipSuccess) break;
         double host[mjmpc::ARM_RESET_LEN];          // sin / cos of the record's qpos (the kernels carry them beside q)
         e = hipMemcpy(host, rk, sizeof(double) * 19, hipMemcpyDeviceToHost);
         for (int l = 0; l < mjmpc::LANES; ++l) {
-            host[19 + l] = std::sin(host[l]);
-            host[19 + mjmpc::LANES + l] = std::cos(host[l]);
+            const bool slide = b[mjmpc::O_JTYPE + l] != 0.0;     // (a slide joint's coordinate is a length: the kernels keep (0, 1))
+            host[19 + l] = slide ? 0.0 : std::sin(host[l]);
+            host[19 + mjmpc::LANES + l] = slide ? 1.0 : std::cos(host[l]);
         }
         if (e == hipSuccess) e = hipMemcpy(rk + 19, host + 19, sizeof(double) * 16, hipMemcpyHostToDevice);
     }
@@ -219,6 +240,7 @@ static int arm_make_reset_records(mjmpc_arm_s* h, const double* blobs, int n_sha
 
 static int arm_create_impl(mjmpc_arm_s* h, const double* blob, int n_blob) {
     std::vector<float> f32(blob, blob + n_blob);
+    h->xj = arm_blob_is_xj(blob, 1);
     HIP_TRY(hipMalloc(&h->model_f32, sizeof(float) * n_blob));
     HIP_TRY(hipMalloc(&h->model_f64, sizeof(double) * n_blob));
     HIP_TRY(hipMalloc(&h->state, sizeof(double) * MJMPC_ARM_STATE_LEN));
@@ -242,7 +264,7 @@ int mjmpc_arm_create(const double* blob, int n_blob, int device, mjmpc_arm_t* ou
     mjmpc_arm_s* h = new mjmpc_arm_s();
     h->device = device;
     h->nv = nv;
-    h->nu = nv;
+    h->nu = (int)blob[mjmpc::O_NU] >= 1 && (int)blob[mjmpc::O_NU] <= nv ? (int)blob[mjmpc::O_NU] : nv;
     h->d_obs = 2 * nv + 6;
     if (int rc = arm_create_impl(h, blob, n_blob)) {        // a failed allocation leaves nothing behind
         mjmpc_arm_destroy(h);
@@ -277,7 +299,10 @@ int mjmpc_arm_set_shard_models(mjmpc_arm_t h, const double* blobs, int n_shards)
     }
     // the reset records of the NEW blocks first: if that fails the engine keeps its old models, shard count and records
     double* rec = nullptr;
+    const bool xj_old = h->xj;
+    h->xj = arm_blob_is_xj(blobs, n_shards);        // (the record launches run the build the NEW blocks need)
     if (int rc = arm_make_reset_records(h, blobs, n_shards, &rec); rc != 0) {
+        h->xj = xj_old;
         hipFree(m32);
         hipFree(m64);
         return rc;
@@ -383,11 +408,11 @@ int mjmpc_arm_rollout(mjmpc_arm_t h, int dtype, int64_t P, int H, const double* 
     if (int rc = shard_fusion(h, P, fuse)) return rc;
     const double* st = fuse.state_shard_size > 0 ? h->shard_states : h->state;
     if (dtype == MJMPC_F32) {
-        e = mjmpc::launch_arm_rollout<float>(h->model_f32, st, (long)P, H, h->nu, d_mean, (const float*)d_noise,
+        e = arm_rollout_launch<float>(h, h->model_f32, st, (long)P, H, h->nu, d_mean, (const float*)d_noise,
                                              (float*)d_costs, (float*)d_actions, (float*)d_obs, (float*)d_next_obs,
                                              nullptr, h->diag, s, fuse);
     } else if (dtype == MJMPC_F64) {
-        e = mjmpc::launch_arm_rollout<double>(h->model_f64, st, (long)P, H, h->nu, d_mean,
+        e = arm_rollout_launch<double>(h, h->model_f64, st, (long)P, H, h->nu, d_mean,
                                               (const double*)d_noise, (double*)d_costs, (double*)d_actions,
                                               (double*)d_obs, (double*)d_next_obs, nullptr, h->diag, s, fuse);
     } else {
@@ -409,11 +434,11 @@ int mjmpc_arm_rollout_cl(mjmpc_arm_t h, int dtype, int64_t P, int H, const doubl
     fuse.clw = d_weights;
     hipError_t e;
     if (dtype == MJMPC_F32)
-        e = mjmpc::launch_arm_rollout<float>(h->model_f32, st, (long)P, H, h->nu, d_weights, (const float*)d_noise,
+        e = arm_rollout_launch<float>(h, h->model_f32, st, (long)P, H, h->nu, d_weights, (const float*)d_noise,
                                              (float*)d_costs, (float*)d_actions, (float*)d_obs, (float*)d_next_obs,
                                              nullptr, h->diag, s, fuse);
     else if (dtype == MJMPC_F64)
-        e = mjmpc::launch_arm_rollout<double>(h->model_f64, st, (long)P, H, h->nu, d_weights,
+        e = arm_rollout_launch<double>(h, h->model_f64, st, (long)P, H, h->nu, d_weights,
                                               (const double*)d_noise, (double*)d_costs, (double*)d_actions,
                                               (double*)d_obs, (double*)d_next_obs, nullptr, h->diag, s, fuse);
     else
@@ -438,11 +463,11 @@ int mjmpc_arm_rollout_fused(mjmpc_arm_t h, int dtype, int64_t P, int H, const do
     fuse.q0_out = d_q0;
     hipError_t e;
     if (dtype == MJMPC_F32)
-        e = mjmpc::launch_arm_rollout<float>(h->model_f32, st, (long)P, H, h->nu, d_mean, (const float*)d_noise,
+        e = arm_rollout_launch<float>(h, h->model_f32, st, (long)P, H, h->nu, d_mean, (const float*)d_noise,
                                              (float*)d_costs, (float*)d_actions, nullptr, nullptr, nullptr, h->diag, s,
                                              fuse);
     else if (dtype == MJMPC_F64)
-        e = mjmpc::launch_arm_rollout<double>(h->model_f64, st, (long)P, H, h->nu, d_mean,
+        e = arm_rollout_launch<double>(h, h->model_f64, st, (long)P, H, h->nu, d_mean,
                                               (const double*)d_noise, (double*)d_costs, (double*)d_actions, nullptr,
                                               nullptr, nullptr, h->diag, s, fuse);
     else
@@ -505,16 +530,16 @@ int mjmpc_arm_mppi_step(mjmpc_arm_t h, int dtype, int64_t P, int H, const double
     fuse.q0_out = d_q0;
     hipError_t e;
     if (dtype == MJMPC_F32) {
-        e = mjmpc::launch_arm_rollout<float>(h->model_f32, h->state, (long)P, H, h->nu, d_mean, nullptr, (float*)d_costs,
+        e = arm_rollout_launch<float>(h, h->model_f32, h->state, (long)P, H, h->nu, d_mean, nullptr, (float*)d_costs,
                                              (float*)d_actions, nullptr, nullptr, nullptr, h->diag, s, fuse, &mo);
         if (e == hipSuccess && !rollout_only)
-            e = mjmpc::launch_arm_mppi_finish<float>(h->model_f32, h->mono_tree, groups, H, h->nu, d_mean, d_mean_out, mo,
+            e = arm_finish_launch<float>(h, h->model_f32, h->mono_tree, groups, H, h->nu, d_mean, d_mean_out, mo,
                                                      do_env, h->diag, s);
     } else if (dtype == MJMPC_F64) {
-        e = mjmpc::launch_arm_rollout<double>(h->model_f64, h->state, (long)P, H, h->nu, d_mean, nullptr, (double*)d_costs,
+        e = arm_rollout_launch<double>(h, h->model_f64, h->state, (long)P, H, h->nu, d_mean, nullptr, (double*)d_costs,
                                               (double*)d_actions, nullptr, nullptr, nullptr, h->diag, s, fuse, &mo);
         if (e == hipSuccess && !rollout_only)
-            e = mjmpc::launch_arm_mppi_finish<double>(h->model_f64, h->mono_tree, groups, H, h->nu, d_mean, d_mean_out, mo,
+            e = arm_finish_launch<double>(h, h->model_f64, h->mono_tree, groups, H, h->nu, d_mean, d_mean_out, mo,
                                                       do_env, h->diag, s);
     } else {
         return fail(MJMPC_E_BADARG, "unknown dtype %d", dtype);
@@ -561,10 +586,10 @@ int mjmpc_arm_rollout_sampled(mjmpc_arm_t h, int dtype, int64_t P, int H, const 
     fuse.q0_out = d_q0;
     hipError_t e;
     if (dtype == MJMPC_F32)
-        e = mjmpc::launch_arm_rollout<float>(h->model_f32, h->state, (long)P, H, h->nu, d_mean, nullptr, (float*)d_costs,
+        e = arm_rollout_launch<float>(h, h->model_f32, h->state, (long)P, H, h->nu, d_mean, nullptr, (float*)d_costs,
                                              (float*)d_actions, nullptr, nullptr, nullptr, h->diag, s, fuse, &mo);
     else if (dtype == MJMPC_F64)
-        e = mjmpc::launch_arm_rollout<double>(h->model_f64, h->state, (long)P, H, h->nu, d_mean, nullptr, (double*)d_costs,
+        e = arm_rollout_launch<double>(h, h->model_f64, h->state, (long)P, H, h->nu, d_mean, nullptr, (double*)d_costs,
                                               (double*)d_actions, nullptr, nullptr, nullptr, h->diag, s, fuse, &mo);
     else
         return fail(MJMPC_E_BADARG, "unknown dtype %d", dtype);
@@ -594,10 +619,10 @@ int mjmpc_arm_mppi_combine(mjmpc_arm_t h, int dtype, const double* d_records, in
     mo.reset_rec = h->reset_rec;
     hipError_t e;
     if (dtype == MJMPC_F32)
-        e = mjmpc::launch_arm_mppi_finish<float>(h->model_f32, d_records, n_records, H, h->nu, d_mean, d_mean_out, mo,
+        e = arm_finish_launch<float>(h, h->model_f32, d_records, n_records, H, h->nu, d_mean, d_mean_out, mo,
                                                  env_step ? 1 : 0, h->diag, s);
     else if (dtype == MJMPC_F64)
-        e = mjmpc::launch_arm_mppi_finish<double>(h->model_f64, d_records, n_records, H, h->nu, d_mean, d_mean_out, mo,
+        e = arm_finish_launch<double>(h, h->model_f64, d_records, n_records, H, h->nu, d_mean, d_mean_out, mo,
                                                   env_step ? 1 : 0, h->diag, s);
     else
         return fail(MJMPC_E_BADARG, "unknown dtype %d", dtype);
@@ -612,10 +637,10 @@ int mjmpc_arm_step_state(mjmpc_arm_t h, int dtype, const double* d_action, void*
     hipStream_t s = (hipStream_t)stream;
     hipError_t e;
     if (dtype == MJMPC_F32)
-        e = mjmpc::launch_arm_rollout<float>(h->model_f32, h->state, 1, 1, h->nu, d_action, nullptr, (float*)d_cost,
+        e = arm_rollout_launch<float>(h, h->model_f32, h->state, 1, 1, h->nu, d_action, nullptr, (float*)d_cost,
                                              nullptr, nullptr, (float*)d_next_obs, h->state, h->diag, s, arm_fuse(h));
     else if (dtype == MJMPC_F64)
-        e = mjmpc::launch_arm_rollout<double>(h->model_f64, h->state, 1, 1, h->nu, d_action, nullptr, (double*)d_cost,
+        e = arm_rollout_launch<double>(h, h->model_f64, h->state, 1, 1, h->nu, d_action, nullptr, (double*)d_cost,
                                               nullptr, nullptr, (double*)d_next_obs, h->state, h->diag, s, arm_fuse(h));
     else
         return fail(MJMPC_E_BADARG, "unknown dtype %d", dtype);

@@ -32,6 +32,12 @@ ARM_LAYOUT = [
     ("sph_invweight", 1), ("plane_n", 3), ("plane_d", 1),
     ("sol_K", 1), ("sol_B", 1), ("sol_dmin", 1), ("sol_dmax", 1), ("sol_width", 1),
     ("sol_mid", 1), ("sol_power", 1), ("gravity", 3),
+    # round 6 (the EXTENDED-JOINT instantiation of the arm kernels, csrc/arm_rollout_xj.hip): slide joints and dry friction -
+    # the reference's classic-control models (examples/configs/classic_control/cartpole*.yml) on the serial-chain kernel
+    ("jtype", LANES),                           # 0 hinge, 1 slide
+    ("frictionloss", LANES), ("floss_D", LANES),    # dof_frictionloss and its row's D = 1 / R (impedance at position 0)
+    ("floss_B", 1),                             # b of the friction rows' reference acceleration -b v (solref_friction)
+    ("nu", 1),                                  # motors: they drive dofs 0 .. nu - 1 (until round 6 nu = nv by construction)
 ]
 ARM_BLOB_LEN = sum(n for _, n in ARM_LAYOUT)
 MJ_MINVAL = 1e-15
@@ -132,10 +138,10 @@ def compile_arm(raw: RawModel, overrides=None, base: "ArmModel" = None) -> ArmMo
     nb = len(raw.bodies)
     # what only the tree kernel executes (models/compile_tree.py)
     joints = [b.joint for b in raw.bodies if b.joint is not None]
-    if any(j.type != 1 or j.stiffness != 0 or j.frictionloss != 0 or any(np.asarray(j.pos, float) != 0) or j.margin != 0 or j.ref != 0
+    if any(j.type not in (1, 2) or j.stiffness != 0 or any(np.asarray(j.pos, float) != 0) or j.margin != 0 or j.ref != 0
            for j in joints):
-        raise ValueError("arm kernel: hinge joints at the body origin without springs or friction loss only "
-                         "(slide / ball / free joints, springs, friction loss, joint anchors, margin / ref: the tree engine)")
+        raise ValueError("arm kernel: hinge / slide joints at the body origin without springs only "
+                         "(ball / free joints, springs, joint anchors, margin / ref: the tree engine)")
     if raw.equalities or raw.tendons or raw.world_geoms or any(b.inertial is not None for b in raw.bodies):
         raise ValueError("arm kernel: no equalities, tendons, static geoms or explicit inertials (the tree engine has them)")
     if raw.density > 0 or raw.viscosity > 0 or raw.task != 0:
@@ -209,12 +215,14 @@ def compile_arm(raw: RawModel, overrides=None, base: "ArmModel" = None) -> ArmMo
         f["damping"][li] = float(overrides.get("dof_damping", {}).get(jt.name, jt.damping))
         f["range_lo"][li], f["range_hi"][li] = jt.range
         f["limited"][li] = 1.0 if jt.limited else 0.0
+        f["jtype"][li] = 1.0 if jt.type == 2 else 0.0
+        f["frictionloss"][li] = float(overrides.get("dof_frictionloss", {}).get(jt.name, jt.frictionloss))
 
     f["armature"][nv:] = 1.0        # spare lanes: unit diagonal keeps the in-register LDL^T regular
 
-    if len(raw.actuators) != nv:
-        raise ValueError("arm kernel expects one motor per hinge")
-    ctrl_lo, ctrl_hi = np.zeros(nv), np.zeros(nv)
+    if not 1 <= len(raw.actuators) <= nv:
+        raise ValueError("arm kernel expects motors on the first dofs, in joint order (at most one per dof)")
+    ctrl_lo, ctrl_hi = np.zeros(len(raw.actuators)), np.zeros(len(raw.actuators))
     for a, act in enumerate(raw.actuators):
         if act.tendon or act.gain != 1.0 or any(x != 0.0 for x in act.bias) or not act.ctrllimited or act.forcerange is not None:
             raise ValueError("arm kernel: ctrllimited motors only (servos and general actuators run on the tree engine)")
@@ -229,7 +237,7 @@ def compile_arm(raw: RawModel, overrides=None, base: "ArmModel" = None) -> ArmMo
         J = np.zeros((3, nv))
         for k in range(link + 1):
             ax = np.array([f["axis"][c * L + k] for c in range(3)])
-            J[:, k] = np.cross(ax, pt - origin[k])
+            J[:, k] = ax if f["jtype"][k] else np.cross(ax, pt - origin[k])
         return J
 
     M0 = np.diag([f["armature"][k] for k in range(nv)]).astype(float)
@@ -240,7 +248,8 @@ def compile_arm(raw: RawModel, overrides=None, base: "ArmModel" = None) -> ArmMo
         Jp = jac_point(p0[i] + R0[i] @ ipos[i], li)
         Jr = np.zeros((3, nv))
         for k in range(li + 1):
-            Jr[:, k] = [f["axis"][c * L + k] for c in range(3)]
+            if not f["jtype"][k]:
+                Jr[:, k] = [f["axis"][c * L + k] for c in range(3)]
         Iw = R0[i] @ inert[i] @ R0[i].T
         M0 += mass[i] * Jp.T @ Jp + Jr.T @ Iw @ Jr
     M0inv = np.linalg.inv(M0)
@@ -289,8 +298,28 @@ def compile_arm(raw: RawModel, overrides=None, base: "ArmModel" = None) -> ArmMo
     f["sol_dmin"][0], f["sol_dmax"][0] = dmin, dmax
     f["sol_width"][0], f["sol_mid"][0], f["sol_power"][0] = width, mid, power
     f["gravity"][:] = raw.gravity
+    f["nu"][0] = len(raw.actuators)
+    # friction-loss rows (mj_instantiateFriction): J = e_j at position 0 -> D = 1 / R from the impedance at 0, aref = -b v
+    lossy = [j for j in joints if f["frictionloss"][raw.dof_of_joint(j.name)] > 0]
+    if lossy:
+        sets = {(tuple(raw.solref_friction if j.solref_friction is None else j.solref_friction),
+                 tuple(raw.solimp_friction if j.solimp_friction is None else j.solimp_friction)) for j in lossy}
+        if len(sets) != 1:
+            raise ValueError("arm kernel: the friction-loss rows share one solref / solimp (per-joint sets: the tree engine)")
+        (ftc, fdr), fimp = sets.pop()
+        if ftc <= 0 or fdr <= 0:
+            raise NotImplementedError("arm kernel: solreffriction must be the standard (timeconst, dampratio) pair")
+        ftc = max(ftc, 2 * raw.timestep)
+        f["floss_B"][0] = 2.0 / (fimp[1] * ftc)
+        imp0 = fimp[0]                                          # the impedance at position 0 (x = 0 -> y = 0 for every power)
+        for j in lossy:
+            d = raw.dof_of_joint(j.name)
+            f["floss_D"][d] = 1.0 / max(MJ_MINVAL, (1.0 - imp0) / imp0 * dof_iw[d])
 
     if base is not None:            # run-time edit: MuJoCo keeps the constants mj_setConst computed at load time
+        for j in lossy:             # (the rows' D follows the base model's dof_invweight0)
+            d = raw.dof_of_joint(j.name)
+            f["floss_D"][d] = 1.0 / max(MJ_MINVAL, (1.0 - imp0) / imp0 * base.dof_invweight0[d])
         f["dof_invweight0"][:] = base.field("dof_invweight0")
         f["sph_invweight"][:] = base.field("sph_invweight")
         dof_iw, body_iw = base.dof_invweight0.copy(), base.body_invweight0.copy()

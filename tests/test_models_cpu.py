@@ -14,7 +14,7 @@ SAWYER = "/root/reference/mjmpc/envs/assets/xml/sawyer.xml"
 
 def test_blob_layout_and_kinematic_constants():
     m = compile_arm(reacher7dof_raw())
-    assert m.blob.shape == (ARM_BLOB_LEN,) and ARM_BLOB_LEN == 229
+    assert m.blob.shape == (ARM_BLOB_LEN,) and ARM_BLOB_LEN == 255
     assert (m.nv, m.nu, m.d_obs, m.frame_skip) == (7, 7, 20, 2)
     off = m.field("off").reshape(3, 8).T
     np.testing.assert_allclose(off[:7].sum(0), [0.821, -0.6, 0.0], atol=1e-15)     # hand at qpos0
@@ -81,13 +81,12 @@ def test_loader_on_a_small_model_and_rejections(tmp_path):
     assert raw_ref.bodies[1].joint.ref == 0.1 and raw_ref.qpos0[1] == 0.1
     with pytest.raises(ValueError, match="tree engine"):
         compile_arm(raw_ref)
-    # a slide joint loads (the tree engine runs it); the serial-chain arm kernel says it cannot
+    # a slide joint loads; since round 6 the arm kernels' extended-joint build takes it too (jtype in the blob)
     slide = xml.replace('<joint name="j1"', '<joint name="j1" type="slide"')
     (tmp_path / "slide.xml").write_text(slide)
     raw2 = load_mjcf(str(tmp_path / "slide.xml"))
     assert [b.joint.type for b in raw2.bodies] == [1, 2]
-    with pytest.raises(ValueError, match="tree engine"):
-        compile_arm(raw2)
+    assert list(compile_arm(raw2).field("jtype")[:2]) == [0.0, 1.0]
 
 
 def test_systematic_resampling_matches_the_serial_walk(golden):
