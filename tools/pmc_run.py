@@ -57,7 +57,11 @@ else:
         env = dict(half_cheetah=locomotion_env.HalfCheetahEnv, swimmer=locomotion_env.SwimmerEnv)[wl](dtype=dt)
         env.reset(seed=123)
         st, scale = env.get_env_state(), 0.55
-    eng = TreeRolloutEngine(raw, dtype=dt)
+    if wl in ("cartpole", "door", "tray", "gripper"):      # (round 6: the arm kernels where the model fits them - the cart-pole)
+        from mjmpc_amd.envs import make_engine
+        eng = make_engine(raw, dtype=dt)
+    else:
+        eng = TreeRolloutEngine(raw, dtype=dt)
     if st is not None:
         eng.set_env_state(dict(st, target_pos=np.asarray(raw.target_pos, float)) if ("qp" in st and "target_pos" not in st) else st)
     A = eng.d_action

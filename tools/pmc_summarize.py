@@ -72,10 +72,12 @@ def longest_kernel(d, base):
 JOBS = [(wl, prefix, KERNEL, others, 4096, 32) for wl, (prefix, KERNEL, others) in WORKLOADS.items()] if not EXTRA else []
 for wl_, p_, h_ in EXTRA:
     d_ = wl_ + (str(p_) if p_ != 4096 else "") + ("x%d" % h_ if h_ != 32 else "")
-    base = "arm_rollout_kernel<double" if wl_ == "reacher" else "tree_rollout_kernel<double"
+    base = "arm_rollout_kernel<double" if wl_ in ("reacher", "cartpole") else "tree_rollout_kernel<double"
+    if wl_ == "reacher" and p_ <= 2048:         # (round 6: the four-wave flag shape takes these launches)
+        base = "arm_rollout_flags_kernel<double"
     # (reacher: the fused iteration's rollout kernel - the instantiations whose last argument, MONO, is true)
     k_ = longest_kernel(d_ + "_pmcS1", base)
-    if wl_ == "reacher" and p_ <= 4096:         # the headline's kernel by name: the fused iteration's rollout launch (DUO, MONO)
+    if wl_ == "reacher" and 2048 < p_ <= 4096:  # the headline's kernel by name: the fused iteration's rollout launch (DUO, MONO)
         k_ = WORKLOADS["reacher"][1]
     JOBS.append((d_, ("" if wl_ == "reacher" else wl_ + "_"), k_, WORKLOADS["reacher"][2] if wl_ == "reacher" else [], p_, h_))
 for wl, prefix, KERNEL, others, P, H in JOBS:

@@ -57,11 +57,12 @@ pmc() {     # directory name, workload, particles
   rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/${TAG}_${d}_pmcW -o w -- python3 tools/pmc_run.py $wl $p f64 >> $OUT/${TAG}_${d}_pmc.log 2>&1
 }
 pmc reacher reacher 4096
+pmc reacher1024 reacher 1024
 pmc reacher16384 reacher 16384
 pmc reacher65536 reacher 65536
 for WL in half_cheetah cartpole door tray gripper; do pmc $WL $WL 4096; done
-python3 tools/pmc_summarize.py $TAG $OUT reacher reacher:16384 reacher:65536 half_cheetah cartpole door tray gripper > $OUT/${TAG}_pmc_summary.txt 2>&1
-for d in reacher reacher16384 reacher65536 half_cheetah cartpole door tray gripper; do for p in S1 S2 S3 S4 F W; do
+python3 tools/pmc_summarize.py $TAG $OUT reacher reacher:1024 reacher:16384 reacher:65536 half_cheetah cartpole door tray gripper > $OUT/${TAG}_pmc_summary.txt 2>&1
+for d in reacher reacher1024 reacher16384 reacher65536 half_cheetah cartpole door tray gripper; do for p in S1 S2 S3 S4 F W; do
   f=$(find $OUT/${TAG}_${d}_pmc$p -name "*counter_collection.csv" | head -1); [ -n "$f" ] && cp $f $OUT/${TAG}_${d}_pmc_${p}_counter_collection.csv
 done; done
 rm -rf $OUT/${TAG}_*_pmcS1 $OUT/${TAG}_*_pmcS2 $OUT/${TAG}_*_pmcS3 $OUT/${TAG}_*_pmcS4 $OUT/${TAG}_*_pmcF $OUT/${TAG}_*_pmcW
@@ -69,6 +70,9 @@ rm -rf $OUT/${TAG}_*_pmcS1 $OUT/${TAG}_*_pmcS2 $OUT/${TAG}_*_pmcS3 $OUT/${TAG}_*
 for c in "4096 32 f64 cheetah" "4096 32 f64 swimmer" "4096 32 f64 hand" "4096 32 f64 handf" "4096 32 f64 pen" "4096 32 f32 pen" "4096 32 f64 tray" "4096 32 f64 door" "4096 32 f64 cartpole" "4096 32 f64 gripper" "65536 16 f64 hand"; do
   python3 tools/tree_time.py $c 2>/dev/null | tail -1 >> $OUT/${TAG}_tree_time.txt
 done
+if [ -f tools/_build/libmjmpc_stampsf.so ]; then
+  for P in 1024 4096; do STAMPS_LIB=tools/_build/libmjmpc_stampsf.so python3 tools/stamps.py $P f64 2>/dev/null | grep -v amdgpu.ids > $OUT/${TAG}_arm_phase_clocks_$P.txt; done
+fi
 if [ -f tools/_build/libmjmpc_amd_treestats.so ]; then
   : > $OUT/${TAG}_tree_stats.txt
   for m in cheetah swimmer hand pen cartpole door tray gripper; do python3 tools/tree_stats.py $m f64 4096 32 2>/dev/null | tail -14 >> $OUT/${TAG}_tree_stats.txt; done
