@@ -86,6 +86,8 @@ def parse(argv=None):
     ap.add_argument("--cpu-seconds", type=float, default=10.0)
     ap.add_argument("--engine", choices=["auto", "tree"], default="auto",
                     help="synthetic workloads: 'auto' = the arm kernels where the model fits them (cart-pole), 'tree' = always the tree engine")
+    ap.add_argument("--ab-timeout", type=int, default=180, help="--collectives both: seconds the A/B of the exchange paths may take "
+                                                                "before the line is printed without it")
     ap.add_argument("--backend", default="nccl", help=argparse.SUPPRESS)          # test knobs: gloo on one GPU
     ap.add_argument("--collectives", choices=["auto", "library", "torch", "both"], default="both",
                     help="N > 1: which path carries the control iteration's exchanges - libmjmpc_amd.so's own RCCL communicator "
@@ -563,24 +565,6 @@ def main():
                       "launch": kind_s, "collectives": comm.collectives,
                       "what": "the same closed loop with --particles as the TOTAL population, split over the ranks "
                               "(subproc_vec_env.py:161-168); same steps / warmup, MAX over ranks"}
-    # N > 1, --collectives both: the same loops again with the exchanges on the OTHER path - torch.distributed's collectives in
-    # a replayed hipGraph where the headline ran the library's own RCCL communicator between direct launches (DESIGN 6) - so
-    # that ONE invocation of the driver's scaling run says which is faster on real links.  Never `value`.
-    collectives_ab = None
-    if world > 1 and args.collectives == "both" and args.backend == "nccl" and getattr(comm, "lib_collectives", False):
-        from mjmpc_amd.control._device import TorchDistComm as _Comm
-        comm_t = _Comm(device=torch.device("cuda", local), library_collectives=False)
-        dtw, kind_w = side_loop(P_tot, comm_t)
-        collectives_ab = {
-            "library RCCL": {"weak_ms_per_step": dt / args.steps * 1e3,
-                             "strong_ms_per_step": strong["ms_per_step"] if strong and "ms_per_step" in strong else None},
-            "torch.distributed": {"weak_ms_per_step": dtw / args.steps * 1e3, "strong_ms_per_step": None, "launch": kind_w},
-            "what": "the headline's loop (and `strong`) with the control iteration's exchanges on each path; "
-                    "the headline `value` is the library's"}
-        if strong_ok:
-            dts_t, _ = side_loop(args.particles, comm_t)
-            collectives_ab["torch.distributed"]["strong_ms_per_step"] = dts_t / args.steps * 1e3
-        comm_t.close()
     fails = eng.solver_failures()
 
     # HBM bytes of one launch of the dominant kernel from the PMC counters (separate rocprofv3 passes,
@@ -681,9 +665,50 @@ def main():
         out["pipelined"] = pipelined
     if strong:
         out["strong"] = strong
+    out.update(extra)
+    # N > 1, --collectives both: the same loops again with the exchanges on the OTHER path - torch.distributed's collectives in
+    # a replayed hipGraph where the headline ran the library's own RCCL communicator between direct launches (DESIGN 6) - so
+    # that ONE invocation of the driver's scaling run says which is faster on real links.  Never `value`.
+    # The headline, `strong` and everything else of the line are COMPLETE at this point; the A/B runs behind a watchdog: if it
+    # has not finished after --ab-timeout seconds (a path that has never run at N > 1 on hardware may hang in a collective),
+    # rank 0 prints the line without it and every rank ends its own process with code 0 - an exit, never a re-exec.
+    collectives_ab = None
+    if world > 1 and args.collectives == "both" and args.backend == "nccl" and getattr(comm, "lib_collectives", False):
+        import threading
+        printed = threading.Lock()
+
+        def give_up():
+            if rank == 0 and printed.acquire(blocking=False):
+                out["collectives_ab"] = {"skipped": "the A/B of the exchange paths did not finish within %d s" % args.ab_timeout}
+                print(json.dumps(out), flush=True)
+            sys.stderr.write("bench.py: rank %d: the collectives A/B exceeded %d s; ending this rank\n" % (rank, args.ab_timeout))
+            sys.stderr.flush()
+            os._exit(0)
+
+        watchdog = threading.Timer(args.ab_timeout, give_up)
+        watchdog.daemon = True
+        watchdog.start()
+        try:
+                from mjmpc_amd.control._device import TorchDistComm as _Comm
+                comm_t = _Comm(device=torch.device("cuda", local), library_collectives=False)
+                dtw, kind_w = side_loop(P_tot, comm_t)
+                collectives_ab = {
+                    "library RCCL": {"weak_ms_per_step": dt / args.steps * 1e3,
+                                     "strong_ms_per_step": strong["ms_per_step"] if strong and "ms_per_step" in strong else None},
+                    "torch.distributed": {"weak_ms_per_step": dtw / args.steps * 1e3, "strong_ms_per_step": None, "launch": kind_w},
+                    "what": "the headline's loop (and `strong`) with the control iteration's exchanges on each path; "
+                            "the headline `value` is the library's"}
+                if strong_ok:
+                    dts_t, _ = side_loop(args.particles, comm_t)
+                    collectives_ab["torch.distributed"]["strong_ms_per_step"] = dts_t / args.steps * 1e3
+                comm_t.close()
+        except Exception as e:      # (this rank alone: the others are in collectives this one will not join - the watchdog ends them)
+            collectives_ab = {"error": "%s: %s" % (type(e).__name__, e)}
+        watchdog.cancel()
+        if not printed.acquire(blocking=False):
+            return                  # (the watchdog is printing / has printed)
     if collectives_ab:
         out["collectives_ab"] = collectives_ab
-    out.update(extra)
     if rank == 0:
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(P_loc, H, args.cpu_seconds, raw=raw, qpos=qpos, qvel=qvel,
