@@ -98,15 +98,29 @@ struct Model {                 // view of the LDS copy of the model block
             solK = uniform_(m[O_SOL_K]);
             ipower = __builtin_amdgcn_readfirstlane((int)m[O_SOL_POWER]);
         }
+        cache_xj();
     }
     __device__ __forceinline__ T link(int off, int c = 0) const {
         if constexpr (REG) return reg[off / LANES + c];
         else return m[off + c * LANES + l8];
     }
     __device__ __forceinline__ T glob(int off, int c = 0) const { return m[off + c]; }
-    // XJ: my link's entries of the extended fields (read from LDS where they are used: they are not in the cached set)
-    __device__ __forceinline__ bool xj_slide() const { return XJ && m[O_JTYPE + l8] != T(0); }
-    __device__ __forceinline__ T xj(int off) const { return m[off + l8]; }
+    // XJ: my link's entries of the extended fields - cached like the others in the two-wave kernels (a lone wave pays ~110
+    // cycles per LDS round trip, and a substep asks for them in four places), read from LDS otherwise
+    bool xs = false;
+    T xf = T(0), xD = T(0), xB = T(0);
+    __device__ __forceinline__ void cache_xj() {
+        if constexpr (XJ && REG) {
+            xs = m[O_JTYPE + l8] != T(0);
+            xf = m[O_FLOSS + l8];
+            xD = m[O_FLOSS_D + l8];
+            xB = uniform_(m[O_FLOSS_B]);
+        }
+    }
+    __device__ __forceinline__ bool xj_slide() const { if constexpr (XJ && REG) return xs; else return XJ && m[O_JTYPE + l8] != T(0); }
+    __device__ __forceinline__ T xj_floss() const { if constexpr (XJ && REG) return xf; else return m[O_FLOSS + l8]; }
+    __device__ __forceinline__ T xj_floss_D() const { if constexpr (XJ && REG) return xD; else return m[O_FLOSS_D + l8]; }
+    __device__ __forceinline__ T xj_floss_B() const { if constexpr (XJ && REG) return xB; else return m[O_FLOSS_B]; }
 };
 
 __device__ __forceinline__ float mul_rn(float a, float b) { return __fmul_rn(a, b); }
@@ -625,10 +639,10 @@ template <typename T, typename MT>
 __device__ __forceinline__ FlossRow<T> floss_row(const MT& M, T v, int rows) {
     FlossRow<T> r;
     if constexpr (XJ) {
-        r.f = M.xj(O_FLOSS);
+        r.f = M.xj_floss();
         if (r.f > T(0)) {
-            r.D = M.xj(O_FLOSS_D);
-            r.aref = -M.glob(O_FLOSS_B) * v;
+            r.D = M.xj_floss_D();
+            r.aref = -M.xj_floss_B() * v;
             r.z = (rows & 16) ? ((rows >> 5) & 3) - 1 : 0;      // the zone the previous substep ended in
         }
     }
@@ -1256,7 +1270,7 @@ __device__ __forceinline__ int q_read(qflag_ptr qf, int which) {
 __device__ __forceinline__ void q_write(qflag_ptr qf, int which, int x) {
     __hip_atomic_store(qf + which, x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
-enum QFlag : int { QF_TAU = 0, QF_TILE = 1, QF_TILE2 = 2, QF_EI = 3, QF_X = 4, QF_ROWS = 5, QF_STUCK = 7, QF_COUNT = 8 };
+enum QFlag : int { QF_TAU = 0, QF_TILE = 1, QF_TILE2 = 2, QF_EI = 3, QF_X = 4, QF_ROWS = 5, QF_CROW = 6, QF_STUCK = 7, QF_COUNT = 8 };
 __device__ __forceinline__ void q_post(qflag_ptr qf, int which, int seq, int lane) {
     asm volatile("" ::: "memory");
     if (lane == 0) q_write(qf, which, seq);
@@ -1323,6 +1337,11 @@ __device__ __forceinline__ void flag_front(const MT& M, const ArmInts& I, T& q, 
                                            unsigned* diag, bool& free_step, Stamps& ST, ResetCtl* rc = nullptr) {
     constexpr bool ROWS_MINE = ROLE == QAUX || (ROLE == QDYN && NW == 2);       // who evaluates the limit rows and inverts M + h B
     constexpr bool SPLIT = NW == 4;                                             // the mass matrix's diagonals on two waves
+#ifdef ARM_CONTACT_IN_SOLVE     // developer A/B
+    constexpr bool CONTACT_BY_AUX = false;
+#else
+    constexpr bool CONTACT_BY_AUX = NW == 4;        // the contact row comes from QAUX (which waits ~2900 cycles per substep for the tile)
+#endif
     free_step = false;
 #ifdef MJMPC_NO_RESET
     rc = nullptr;
@@ -1354,7 +1373,7 @@ __device__ __forceinline__ void flag_front(const MT& M, const ArmInts& I, T& q, 
     LinkFrame<T> L;
     T ctr[3] = {T(0), T(0), T(0)};
     bool near_plane = false;
-    if constexpr (ROLE != QAUX) {
+    if constexpr (ROLE != QAUX || CONTACT_BY_AUX) {
         kinematics(M, sq, cq, l8, L, q);
         if constexpr (ROLE == QDYN) {
             const T sp[3] = {M.glob(O_SITE_POS, 0), M.glob(O_SITE_POS, 1), M.glob(O_SITE_POS, 2)};
@@ -1362,7 +1381,13 @@ __device__ __forceinline__ void flag_front(const MT& M, const ArmInts& I, T& q, 
             matvec(L.R, sp, t);
             for (int k = 0; k < 3; ++k) site[k] = L.p[k] + t[k];
         }
-        if (ROLE == QSOLVE && I.n_sphere > 0) {
+        if (ROLE == QAUX && CONTACT_BY_AUX && I.n_sphere > 0) {
+            const T sp[3] = {M.glob(O_SPH_POS, 0), M.glob(O_SPH_POS, 1), M.glob(O_SPH_POS, 2)};
+            T t[3];
+            matvec(L.R, sp, t);
+            for (int k = 0; k < 3; ++k) ctr[k] = __shfl(t[k] + L.p[k], lane_of_link(lane, I.sph_link));
+        }
+        if (ROLE == QSOLVE && !CONTACT_BY_AUX && I.n_sphere > 0) {
             const T sp[3] = {M.glob(O_SPH_POS, 0), M.glob(O_SPH_POS, 1), M.glob(O_SPH_POS, 2)};
             T t[3];
             matvec(L.R, sp, t);
@@ -1387,6 +1412,26 @@ __device__ __forceinline__ void flag_front(const MT& M, const ArmInts& I, T& q, 
         ldsM[V_TAU + l8] = -bias - damping * v + tau_act;
         q_post(qf, QF_TAU, seq, lane);
         ST.mark(2);
+    }
+    if constexpr (ROLE == QAUX && CONTACT_BY_AUX) {
+        // the contact row for the solving wave (plane / sphere: distance, my dof's Jacobian entry, impedance, reference): jc ->
+        // V_JC, {instantiated, D, aref} -> the head of V_RE (the solving wave writes V_RE only at the end of its substep, after
+        // it has taken this)
+        bool cinst = false;
+        T jc = T(0), Dc = T(0), arefc = T(0);
+        if (I.n_sphere > 0) {
+            T cdist, jv;
+            contact_geometry(M, I, L, ctr, v, l8, cdist, cinst, jc, jv);
+            if (__any(cinst)) {
+                row_params(M, cdist - M.glob(O_SPH_MARGIN), M.glob(O_SPH_INVW), jv, Dc, arefc);
+                Dc = cinst ? Dc : T(0);
+                arefc = cinst ? arefc : T(0);
+            }
+        }
+        ldsM[V_JC + l8] = jc;
+        if (l8 == 0) { ldsM[V_RE + 0] = cinst ? T(1) : T(0); ldsM[V_RE + 1] = Dc; ldsM[V_RE + 2] = arefc; }
+        q_post(qf, QF_CROW, seq, lane);
+        ST.mark(1);
     }
     if constexpr (ROLE == QMASS) {
         mass_matrix_tile_part<ARM_NEAR_DIAGS, MAX_LINKS>(L, l8, ldsM);
@@ -1417,7 +1462,7 @@ __device__ __forceinline__ void flag_front(const MT& M, const ArmInts& I, T& q, 
         // the contact row
         bool cinst = false;
         T jc = T(0), Dc = T(0), arefc = T(0);
-        if (I.n_sphere > 0 && __any(near_plane)) {
+        if (!CONTACT_BY_AUX && I.n_sphere > 0 && __any(near_plane)) {
             T cdist, jv;
             contact_geometry(M, I, L, ctr, v, l8, cdist, cinst, jc, jv);
             cinst = cinst && near_plane;
@@ -1429,8 +1474,17 @@ __device__ __forceinline__ void flag_front(const MT& M, const ArmInts& I, T& q, 
             }
         }
         T sig, D, aref;
-        q_take(qf, QF_ROWS, seq, [&]() { sig = ldsM[V_LS + l8]; D = ldsM[V_LD + l8]; aref = ldsM[V_LA + l8]; },
-               SPLIT ? QF_TILE2 : -1);
+        if constexpr (CONTACT_BY_AUX) {
+            T cin;
+            q_take(qf, QF_CROW, seq, [&]() {        // (the limit rows were posted before the contact row: one flag vouches for both)
+                sig = ldsM[V_LS + l8]; D = ldsM[V_LD + l8]; aref = ldsM[V_LA + l8];
+                jc = ldsM[V_JC + l8]; cin = ldsM[V_RE + 0]; Dc = ldsM[V_RE + 1]; arefc = ldsM[V_RE + 2];
+            }, QF_TILE2);
+            cinst = cin != T(0);
+        } else {
+            q_take(qf, QF_ROWS, seq, [&]() { sig = ldsM[V_LS + l8]; D = ldsM[V_LD + l8]; aref = ldsM[V_LA + l8]; },
+                   SPLIT ? QF_TILE2 : -1);
+        }
         const bool inst = sig != T(0);
         const bool any_rows = __any(inst || cinst);
         if (!any_rows) rows = 0;
@@ -1443,7 +1497,7 @@ __device__ __forceinline__ void flag_front(const MT& M, const ArmInts& I, T& q, 
         T tau = T(0);
         T ei[MAX_LINKS];
         if (any_rows) {
-            if (any_c) ldsM[V_JC + l8] = jc;
+            if (!CONTACT_BY_AUX && any_c) ldsM[V_JC + l8] = jc;
             changed = true;
             for (int it = 0; it < newton_maxit<T>(); ++it) {
                 // the rows' parts of the right-hand side; tau joins them when it has arrived:  rhs = (tau + limit) + contact

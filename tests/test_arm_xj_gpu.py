@@ -165,3 +165,33 @@ def test_fused_mppi_iteration_and_device_env_on_the_cartpole():
         q, v, _, _ = ref.env_step(q, v, a, tgt)
         mean = cr.shift_mean(mean, "null")
     assert eng.solver_failures() == 0
+
+
+def test_f32_stays_close(rig):
+    """The extended-joint build in single precision: one env step from random states within f32's reach of the f64 oracle (median
+    error at single-precision level, nothing non-finite, the zone tests' rounding band keeps the iteration from cycling)."""
+    from mjmpc_amd.envs.arm_engine import ArmRolloutEngine
+    name, raw, _, ref = rig
+    eng = ArmRolloutEngine(raw, dtype="f32")
+    rs = np.random.RandomState(11)
+    tgt = np.asarray(raw.target_pos, float)
+    nu = len(raw.actuators)
+    errs = []
+    for k in range(40):
+        q, v = _state(name, raw, rs, k)
+        u = rs.uniform(-1.0, 1.0, nu)
+        eng.set_env_state(dict(qp=q, qv=v, target_pos=tgt))
+        _, rew, _, _, _, nobs = eng.rollout(1, 1, u[None], None, "open_loop")
+        _, _, r1, o1 = ref.env_step(q, v, u, tgt)
+        assert np.isfinite(nobs).all()
+        errs.append(np.abs(nobs[0, 0] - o1).max() / max(1.0, np.abs(o1).max()))
+    errs = np.sort(errs)
+    print("%s f32: median %.1e, 95th percentile %.1e, worst %.1e" % (name, errs[len(errs) // 2], errs[int(0.95 * len(errs))], errs[-1]))
+    assert errs[len(errs) // 2] < 1e-4 and errs[int(0.95 * len(errs))] < 1e-2
+    P, H = 4096, 16
+    eps = 0.3 * rs.standard_normal((P, H, nu)).astype(np.float32)
+    q, v = _state(name, raw, rs, 2)
+    eng.set_env_state(dict(qp=q, qv=0.3 * v, target_pos=tgt))
+    _, rew, _, _, _, _ = eng.rollout(P, H, np.zeros((H, nu)), eps, "open_loop")
+    assert np.isfinite(rew).all()
+    assert eng.solver_failures() <= 2            # (f32: a handful of iteration-cap hits in 1.3e5 particle-substeps at most)
