@@ -91,6 +91,17 @@ struct TreeClock {
 };
 #endif
 
+// laps inside a Newton iteration (tools/tree_stats.py): slots 15 / 22 / 23 = next active set, line search, rank-one correction;
+// with -DTREE_STATS_FINE the walk of the owners' residuals, the sets made from them, and everything after
+#ifdef TREE_STATS_FINE
+#define TREE_LAP_A clk.lap(15)
+#define TREE_LAP_B clk.lap(22)
+#define TREE_LAP_C
+#else
+#define TREE_LAP_A
+#define TREE_LAP_B clk.lap(15)
+#define TREE_LAP_C clk.lap(22)
+#endif
 constexpr int wg_waves(int DP, bool fric, int scalar_bytes = 8, int PL = 32) {
     return DP <= 8 ? 4 : (DP <= 16 ? (PL == 16 && scalar_bytes == 4 ? 4 : 2) : 1);
 }
@@ -1067,6 +1078,12 @@ __device__ __forceinline__ T dense_solve_any(const T* r, T dinv, T b, int l) {
     else return dense_solve<DN>(r, dinv, b, l);
 }
 
+// round 5's colliders (GEN >= 2): functions of their own or inlined into the record walk (developer A/B: -DTREE_GEOM_INLINE)
+#ifdef TREE_GEOM_INLINE
+#define TREE_GEOM_FN __forceinline__
+#else
+#define TREE_GEOM_FN __noinline__
+#endif
 // The surface point of a solid box (half sizes h, its own frame) nearest to `loc` (that frame): outside - the clamped point,
 // normal towards `loc`; inside - the nearest face and its outward normal; len = signed distance (mjc_SphereBox's geometry;
 // the oracle's box_point).  false: `loc` lies on the surface to rounding (no normal).
@@ -1107,7 +1124,7 @@ __device__ __forceinline__ bool box_point(const T* h, const T* loc, T* cl, T* nb
 // the solid nearest to c, normal from it to c; inside - the nearest of the side and the two caps.  len = signed distance of c
 // from the surface; false when c lies on it to rounding.  (The oracle's cyl_point, operation for operation.)
 template <typename T>
-__device__ __noinline__ bool cyl_point(const T* p0, const T* d, T r, const T* c, T* q, T* n, T& len) {
+__device__ TREE_GEOM_FN bool cyl_point(const T* p0, const T* d, T r, const T* c, T* q, T* n, T& len) {
     const T L = sqrt_(dot3(d, d));
     T u[3], w[3], rv[3], rh[3];
     for (int i = 0; i < 3; ++i) { u[i] = d[i] / L; w[i] = c[i] - p0[i]; }
@@ -1148,7 +1165,7 @@ __device__ __noinline__ bool cyl_point(const T* p0, const T* d, T r, const T* c,
 }
 
 template <typename T>
-__device__ __noinline__ T seg_box_param(const T* h, const T* a, const T* b) {
+__device__ TREE_GEOM_FN T seg_box_param(const T* h, const T* a, const T* b) {
     T bp[8];
     bp[0] = T(0);
     bp[7] = T(1);
@@ -1214,7 +1231,7 @@ __device__ __forceinline__ void seg_seg_params(const T* o1, const T* d1, const T
 // face's side planes, the same edge-pair closest points, in the same order of operations.  R0 / R1: row-major, their COLUMNS
 // are the boxes' axes in the world.  n: unit normal from box 1 to box 0.  false: no such contact.
 template <typename T>
-__device__ __noinline__ bool box_box_contact(const T* c0, const T* R0, const T* h0, const T* c1, const T* R1, const T* h1, T margin,
+__device__ TREE_GEOM_FN bool box_box_contact(const T* c0, const T* R0, const T* h0, const T* c1, const T* R1, const T* h1, T margin,
                                              int want, T* n, T* pos, T& dist) {
     T A[3][3], B[3][3], d[3];
     for (int i = 0; i < 3; ++i)
@@ -2974,6 +2991,17 @@ __global__ __launch_bounds__(64 * wg_waves(DP, FRIC, sizeof(T), PL), min_waves(s
 #pragma unroll
                 for (int r = 0; r < NR; ++r) rb[r] = T(0);
                 T xa = T(0);
+                // Round 6: every decision of the iteration is taken PER PARTICLE.  A particle whose sets reproduce themselves is
+                // DONE: its solution and sets are frozen (restored where an iteration ends) while the wavefront iterates on for
+                // its mates, and whether a re-iteration is a rank-one correction is a matter of the particle's own changes - so a
+                // particle's trajectory is the same bits whoever shares its wavefront (P = 1, the device-resident real env, and
+                // the planner's copy of that particle; tests/test_locomotion_gpu.py).
+                bool pdone = false;
+                T xa_k = T(0);
+                bool actv_k = false;
+                mask_t cact_k = 0;
+                int fst_k = 0;
+                auto mine_any = [&](bool x) -> bool { return (__ballot(x) & my_lanes) != 0ull; };
                 clk.lap(-1);
                 for (int it = 0; it < (FRIC ? TREE_MAXIT_LS : TREE_MAXIT); ++it) {
                     if ((TREE_SKIP & 16) || ((TREE_SKIP & 32) && it == 1)) { changed = false; break; }      // (developer timing: no iteration / one)
@@ -3086,6 +3114,7 @@ __global__ __launch_bounds__(64 * wg_waves(DP, FRIC, sizeof(T), PL), min_waves(s
                     if constexpr (FRIC) {
                         if (ucinst != 0) {              // (wave-uniform: no point or record this substep - limit / friction-loss rows only)
                             point_residuals(xa, rN);
+                            TREE_LAP_A;
                             cact2 = rows_from_res(rN, cact);
                         } else {
 #pragma unroll
@@ -3110,6 +3139,7 @@ __global__ __launch_bounds__(64 * wg_waves(DP, FRIC, sizeof(T), PL), min_waves(s
                     // where M a - tau is linear in al and known at both ends without a product with M: at a Newton point
                     // it equals the constraint force J' f of the rows of its set (the solve's own equation), and the base
                     // point inherits it by the same interpolation; the residuals are affine in al.
+                    TREE_LAP_B;
                     if constexpr (FRIC) {
                         if (it >= LS_START && __any(changed)) {
                             const T gN = force_of(xa, rN, actv, cact, fstate, true);      // M xa - tau = J' f of the set's rows (the solve's equation)
@@ -3200,17 +3230,19 @@ __global__ __launch_bounds__(64 * wg_waves(DP, FRIC, sizeof(T), PL), min_waves(s
                             }
                         }
                     }
+                    TREE_LAP_C;
                     // One limit row j of a particle changed state (the usual reason for another iteration):
                     // H' = H + c e_j e_j', c = +-D_j, rhs' = rhs + c sig_j aref_j e_j.  With z = H^-1 e_j - one more pair of
                     // triangular solves with the factor at hand, a third of a factor + solve - Sherman-Morrison gives
                     // a' = y - c z y_j / (1 + c z_j),  y = a + (c sig_j aref_j) z.  Several flips in one particle take the
-                    // general path (next iteration refactors) - and with them the wave: which of the two paths a particle's
-                    // change takes depends on its wave-mates, so results are reproducible for a given launch shape
-                    // and equal to rounding across shapes (measured, 4096 x 32: cheetah 2.28 -> 2.21 ms, tray 3.52 -> 3.35,
+                    // general path (next iteration refactors).  Which of the two a particle's change takes is ITS OWN matter
+                    // (round 6; until then the wave's: one particle with several flips sent its mates down the general path,
+                    // and a particle's rounding depended on them): a wavefront with both kinds pays the extra solve AND the
+                    // next factorisation (measured, 4096 x 32, round 4: cheetah 2.28 -> 2.21 ms, tray 3.52 -> 3.35,
                     // pen-in-hand f64 17.0 -> 15.9, f32 16.2 -> 13.7 ms and no iteration-cap hits where there were 16).
                     if (__any(changed)) {
                         const bool flip = act2 != actv;
-                        const unsigned nflip = __popc((unsigned)(__ballot(flip) >> (PL * half)) & (PL == 32 ? ~0u : 0xFFFFu));
+                        const unsigned nflip = __popcll(__ballot(flip) & my_lanes);
 #ifdef TREE_STATS
                         {   // what kind of change asks for another iteration (particle 0)
                             const unsigned ncf = __popcll((unsigned long long)(cact2 ^ cact));
@@ -3230,11 +3262,13 @@ __global__ __launch_bounds__(64 * wg_waves(DP, FRIC, sizeof(T), PL), min_waves(s
                         // door model's iterations per substep 2.48 -> 2.09, the cart-pole's 1.77 -> 1.45, and both launches 4-6 %
                         // SLOWER: three corrections in four are followed by a refactorisation anyway, a zone change drags other
                         // rows along)
-                        if (!(FRIC && it >= LS_START) && !__any(nflip + ncf > 1u || (GEN && fst2 != fstate))) {
-                            T jz_ = flip ? T(1) : T(0);         // my entry of the changed row
+                        bool fchg = false;
+                        if constexpr (GEN) fchg = mine_any(fst2 != fstate);
+                        const bool single = !pdone && nflip + ncf == 1u && !fchg;        // (uniform over my particle)
+                        if (!(FRIC && it >= LS_START) && __any(single)) {
+                            T jz_ = (single && flip) ? T(1) : T(0);         // my entry of the changed row
                             T cc = T(0), ar = T(0);
-                            const bool cflip = __any(ncf == 1u);
-                            if (FRIC && cflip && ncf == 1u) {
+                            if (FRIC && single && ncf == 1u) {
                                 const int bit = __builtin_ctzll((unsigned long long)cdiff), s = bit / NR, r = bit - s * NR;
                                 const T* cs = X + A_CS + s * CS;
                                 const T* jrow = X + A_JC + s * NJ * DP;
@@ -3248,37 +3282,34 @@ __global__ __launch_bounds__(64 * wg_waves(DP, FRIC, sizeof(T), PL), min_waves(s
                             T zl;
                             if constexpr (DN > 0) zl = dense_solve_any<DN>(hd, hdinv, jz_, l);
                             else zl = tree_solve<DP, PL>(hrow, jz_, ELIM, AT, ROW, VEC, l, n_rounds, depth, max_depth, kt);
-                            if (!cflip) {
-                                if (flip) {
-                                    const T c = act2 ? D : -D;
-                                    VEC[0] = c;
-                                    VEC[1] = c * sig * aref;
-                                    VEC[2] = zl;
-                                    VEC[3] = xa;
-                                }
-                                TSYNC();
-                                if (nflip == 1u) {
-                                    const T c = VEC[0], dl = VEC[1], zj = VEC[2], yj = VEC[3] + dl * zj;
-                                    xa = (xa + dl * zl) - c * zl * yj * rcp_(T(1) + c * zj);
-                                }
-                                TSYNC();
-                            } else {
-                                const T cp = sum_lanes<PL>(flip ? (act2 ? D : -D) : T(0)) + cc;
-                                const T arp = sum_lanes<PL>(flip ? sig * aref : T(0)) + ar;
-                                const T jz = sum_lanes<PL>(jz_ * zl), ja = sum_lanes<PL>(jz_ * xa);
-                                const T dl = cp * arp, yj = ja + dl * jz;
-                                xa = (xa + dl * zl) - cp * zl * yj * rcp_(T(1) + cp * jz);
-                                cact = cact2;
+                            // (one formula for either kind of row: the lane sums have ONE non-zero term, they are exact)
+                            const bool fl1 = single && flip;
+                            const T cp = sum_lanes<PL>(fl1 ? (act2 ? D : -D) : T(0)) + cc;
+                            const T arp = sum_lanes<PL>(fl1 ? sig * aref : T(0)) + ar;
+                            const T jz = sum_lanes<PL>(jz_ * zl), ja = sum_lanes<PL>(jz_ * xa);
+                            const T dl = cp * arp, yj = ja + dl * jz;
+                            const T xa_c = (xa + dl * zl) - cp * zl * yj * rcp_(T(1) + cp * jz);
+                            if (single) {               // the corrected solution and the sets it belongs to
+                                xa = xa_c;
+                                if (FRIC && ncf == 1u) cact = cact2;
+                                actv = act2;
                             }
-                            actv = act2;                // the sets the corrected solution belongs to
+                            // (every lane walks the exchange; a particle that took no correction arrives at the sets it had)
                             const T resl2 = sig * xa - aref;
                             const T band2 = sizeof(T) == 4 ? T(2e-5) * (fabs(aref) + fabs(xa) + T(1)) : T(0);
-                            act2 = inst && (actv ? !(resl2 > band2) : (resl2 < -band2));
-                            cact2 = next_set(xa, cact);
-                            if constexpr (GEN) fst2 = fl_state_of(xa, fstate);
-                            changed = (act2 != actv) || (cact2 != cact) || (GEN && fst2 != fstate);
+                            const bool act2c = inst && (actv ? !(resl2 > band2) : (resl2 < -band2));
+                            const mask_t cact2c = next_set(xa, cact);
+                            int fst2c = 0;
+                            if constexpr (GEN) fst2c = fl_state_of(xa, fstate);
+                            if (single) {
+                                act2 = act2c;
+                                cact2 = cact2c;
+                                fst2 = fst2c;
+                                changed = (act2 != actv) || (cact2 != cact) || (GEN && fst2 != fstate);
+                            }
                         }
                     }
+                    clk.lap(23);
                     // f32 only: with accelerations of 1e4 rad/s^2 on gram-sized finger links a row can sit within
                     // rounding of its switching point and flip back and forth; a particle whose set returns to the one
                     // of two iterations ago has converged to working precision (either set gives the same forces)
@@ -3296,6 +3327,18 @@ __global__ __launch_bounds__(64 * wg_waves(DP, FRIC, sizeof(T), PL), min_waves(s
                     actv = act2;
                     cact = cact2;
                     fstate = fst2;
+                    // a particle none of whose lanes asks for another iteration is done: what it holds now is what it keeps,
+                    // whatever its lanes compute while the wavefront iterates on for its mates
+                    {
+                        const bool pchg = mine_any(changed);
+                        if (pdone) {
+                            xa = xa_k; actv = actv_k; cact = cact_k; fstate = fst_k;
+                            changed = false;
+                        } else if (!pchg) {
+                            pdone = true;
+                            xa_k = xa; actv_k = actv; cact_k = cact; fst_k = fstate;
+                        }
+                    }
                     clk.count(11, 1);
                     clk.lap(15);
                     if (!__any(changed)) break;
@@ -3400,15 +3443,18 @@ __global__ __launch_bounds__(64 * wg_waves(DP, FRIC, sizeof(T), PL), min_waves(s
             }
             const bool big = __any(odd);
             const bool chk = rst && __any(odd_r);
-            if (__builtin_expect(big, 0)) {
-                if (angle) sincos_(q, sq, cq);
-            } else if (angle) {
+            if (angle) {
                 T sd, cd;
                 sincos_small(dq, sd, cd);
                 const T s1 = sq * cd + cq * sd, c1 = cq * cd - sq * sd;
                 const T kk = T(1.5) - T(0.5) * (s1 * s1 + c1 * c1);
                 sq = s1 * kk;
                 cq = c1 * kk;
+            }
+            // (the full evaluation for the LANES whose step is beyond the series, behind a wave-level test: a lane's sine and
+            // cosine do not depend on its wave-mates' steps - round 6)
+            if (__builtin_expect(big, 0)) {
+                if (odd) sincos_(q, sq, cq);
             }
             if (__builtin_expect(chk, 0)) {
                 const unsigned long long bb = __ballot(acc_bad || state_is_bad());

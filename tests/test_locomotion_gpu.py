@@ -402,25 +402,32 @@ def test_swimmer_self_contact_matches_oracle():
     assert np.array_equal(a, b)
 
 
+@pytest.mark.parametrize("dtype", ["f32", "f64"])
 @pytest.mark.parametrize("name", ["swimmer", "cheetah"])
-def test_f32_results_do_not_depend_on_the_batch_size(name):
-    """The instantiation is chosen from model and dtype alone (round 2 picked 32 lanes per particle for f32 launches of
-    <= 4096 particles and 16 above): a particle's f32 trajectory is the same bits with 4095 others or with 8191 others
-    (the same wave-mates), and equal to rounding when it is rolled out alone (the device-resident real env, P = 1:
-    whether a re-iteration is a rank-one correction or a refactorisation is decided per wavefront, tree_rollout.hip)."""
+def test_results_do_not_depend_on_the_batch_size(name, dtype):
+    """The instantiation is chosen from model and dtype alone, and (round 6) every decision inside the solver is taken per
+    PARTICLE - a converged particle is frozen while the wavefront iterates on for its mates, a re-iteration is a rank-one
+    correction or a refactorisation by the particle's own changes, the sine / cosine update is chosen per lane: a particle's
+    trajectory is the same BITS with 4095 others, with 8191 others, or rolled out alone (P = 1: the device-resident real
+    env).  Until round 5 the last was 2e-4 in f32."""
     from mjmpc_amd.envs.tree_engine import TreeRolloutEngine
     raw = _models()[name]()
-    eng = TreeRolloutEngine(raw, dtype="f32")
+    eng = TreeRolloutEngine(raw, dtype=dtype)
     nv = eng.model.nv
     q0, v0, mean, noise = _case(name, nv, eng.d_action, 9, 8192, 6)
     eng.set_env_state(dict(qpos=q0, qvel=v0))
+    npdt = np.float32 if dtype == "f32" else np.float64
     got = {}
-    for P in (1, 4096, 8192):
-        out = eng.rollout_device(P, 6, mean, noise[:P].astype(np.float32), want_obs=True)
-        got[P] = (out[0][0].cpu().numpy().copy(), out[3][0].cpu().numpy().copy())
-    assert np.array_equal(got[4096][0], got[8192][0]) and np.array_equal(got[4096][1], got[8192][1])
-    np.testing.assert_allclose(got[1][0], got[4096][0], rtol=2e-4, atol=2e-4)
-    np.testing.assert_allclose(got[1][1], got[4096][1], rtol=2e-4, atol=2e-4)
+    for P in (1, 3, 4096, 8192):
+        out = eng.rollout_device(P, 6, mean, noise[:P].astype(npdt), want_obs=True)
+        got[P] = (out[0].cpu().numpy().copy(), out[3].cpu().numpy().copy())
+    for P in (1, 3, 4096):
+        assert np.array_equal(got[P][0], got[8192][0][:P]) and np.array_equal(got[P][1], got[8192][1][:P]), P
+    # ... and whoever a particle's wave-mates are: the same 64 particles in another order
+    perm = np.random.RandomState(5).permutation(64)
+    out = eng.rollout_device(64, 6, mean, noise[:64][perm].astype(npdt), want_obs=True)
+    assert np.array_equal(out[0].cpu().numpy(), got[8192][0][:64][perm])
+    assert np.array_equal(out[3].cpu().numpy(), got[8192][1][:64][perm])
 
 
 def test_diverged_rollouts_are_counted_apart_from_solver_failures():

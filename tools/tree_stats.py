@@ -69,8 +69,8 @@ if __name__ == "__main__":
         if nm != "-":
             print("  %-45s %8.0f cycles/substep  %5.1f %%" % (nm, v[i] / nsub, 100.0 * v[i] / tot))
     ni = max(v[11], 1)
-    print("  per Newton iteration: assemble H %.0f, factor %.0f, solve %.0f, next active set (+ rank-one correction) %.0f cycles"
-          % (v[12] / ni, v[13] / ni, v[14] / ni, v[15] / ni))
+    print("  per Newton iteration: assemble H %.0f, factor %.0f, solve %.0f, next active set %.0f, line search %.0f, rank-one correction %.0f cycles"
+          % (v[12] / ni, v[13] / ni, v[14] / ni, v[15] / ni, v[22] / ni, v[23] / ni))
     print("  iterations that found a changed set: %d - one limit row %d, one contact row %d, several rows %d, only the wave's other particle %d; friction-loss zone changes %d"
           % (v[16], v[17], v[18], v[19], v[20], v[21]))
     print("  total %.0f cycles/substep; contact points per substep %.2f; substeps with rows %.0f %%; Newton iterations per such substep %.2f"
