@@ -1826,6 +1826,7 @@ __global__ __launch_bounds__(64 * wg_waves(DP, FRIC, sizeof(T), PL), min_waves(s
     // closed_loop_linear (gym_env_wrapper.py:135-136): the first action needs the site of the fresh observation, which
     // a one-particle launch left in the state vector beforehand (site_out below, mjmpc_tree_rollout_cl)
     T hand_prev[3] = {T(0), T(0), T(0)}, q_prev = q, v_prev = v;
+    T xa_prev = T(0);               // the constraint solver's acceleration of the previous substep (its warm start)
     T qy_prev = qy, qz_prev = qz, qw_prev = qw;
     if (clw)
         for (int k = 0; k < 3; ++k) hand_prev[k] = (T)state[2 * TL + 3 + k];
@@ -1939,6 +1940,7 @@ __global__ __launch_bounds__(64 * wg_waves(DP, FRIC, sizeof(T), PL), min_waves(s
                     qy = T(0); qz = T(0); qw = T(1);
                     tau_act = act_id >= 0 ? M[T_GEAR + l] * fmin(fmax(T(0), M[T_CTRL_LO + l]), M[T_CTRL_HI + l]) : T(0);
                     lim_mem = 0; fl_mem = 0; cinst_mem = 0; cact_mem = 0;
+                    xa_prev = T(0);
                     rst_ever = true;
                     if (diag && l == 0 && live) { atomicAdd(diag + 1, 1u); if (state_out) atomicAdd(diag + TREE_DIAG_ENV_RESETS, 1u); }
                 }
@@ -2857,13 +2859,17 @@ __global__ __launch_bounds__(64 * wg_waves(DP, FRIC, sizeof(T), PL), min_waves(s
                     } else if (my_pt) {
                         const unsigned rows = rows_of(l);
                         const T ar5 = X[A_CS + l * CS + 5];
+                        const unsigned mynib = (unsigned)(cur >> (l * NR)) & ((1u << NR) - 1u);
 #pragma unroll
                         for (int r = 0; r < NR; ++r) {
                             const T arr = res[r];
                             // f32: a row whose residual is within rounding of zero keeps its state (as in arm_rollout.hip)
                             const T bc = sizeof(T) == 4 ? T(2e-5) * (fabs(ar5) + fabs(arr + ar5) + T(1)) : T(0);
-                            const bool was = (cur >> (l * NR + r)) & 1u;
-                            if (((rows >> r) & 1u) && (my_bil || (was ? !(arr > bc) : (arr < -bc)))) nb |= 1u << r;
+                            // (selects, not branches: four rows x three short-circuit tests compiled to a dozen exec-mask branches)
+                            const bool was = ((mynib >> r) & 1u) != 0u;
+                            const bool stay = !(arr > bc), come = arr < -bc;
+                            const bool on = (((rows >> r) & 1u) != 0u) & (my_bil | (was ? stay : come));
+                            nb |= on ? (1u << r) : 0u;
                         }
                     }
                     if constexpr (NR == 1) {
@@ -2975,6 +2981,31 @@ __global__ __launch_bounds__(64 * wg_waves(DP, FRIC, sizeof(T), PL), min_waves(s
                         cact |= ((cinst_mem >> s) & 1u) ? (cact_mem & (rows << (s * NR))) : (rows << (s * NR));
                     }
                 }
+#ifdef TREE_WARM_START
+                // developer A/B (round 6, measured and NOT kept: profiles/r06_warm_start_ab.txt - HalfCheetah 2.02 -> 2.045 ms per
+                // 4096 x 32 launch, tray 2.755 -> 2.79, f32 32768 x 32 8.40 -> 8.565: the walk costs what the saved re-iterations
+                // were worth).  MuJoCo's warm start for the rows that are NEW this substep: instead of "a new row is active", a new
+                // row is active if its residual at the PREVIOUS substep's acceleration is not positive (mj_fwdConstraint starts
+                // from qacc_warmstart and takes the rows that are violated there) - one walk of the owners' paths in the
+                // substeps where a point comes into contact, against a re-iteration when a new pyramid's four rows do not
+                // all end up active (the usual case: a sliding contact holds two or three)
+                if constexpr (FRIC && GEN < 3) {
+                    const unsigned newpts = cinst & ~cinst_mem;
+                    if (__any(newpts != 0u)) {
+                        T r0[NR];
+                        point_residuals(xa_prev, r0);
+                        const mask_t pred = rows_from_res(r0, cact);
+                        unsigned long long x = newpts;          // bit s -> bit 4 s
+                        x = (x | (x << 24)) & 0x000000ff000000ffull;
+                        x = (x | (x << 12)) & 0x000f000f000f000full;
+                        x = (x | (x << 6)) & 0x0303030303030303ull;
+                        x = (x | (x << 3)) & 0x1111111111111111ull;
+                        const mask_t nm = (mask_t)(x * 15ull);
+                        cact = (cact & ~nm) | (pred & nm);
+                    }
+                    if (inst && !(lim_mem & 1)) actv = !(sig * xa_prev - aref > T(0));
+                }
+#endif
                 if constexpr (GEN >= 3) {
                     if (my_ell && my_pt) {
                         const T r0[3] = {T(0), T(0), T(0)};
@@ -2997,6 +3028,13 @@ __global__ __launch_bounds__(64 * wg_waves(DP, FRIC, sizeof(T), PL), min_waves(s
                 // particle's trajectory is the same bits whoever shares its wavefront (P = 1, the device-resident real env, and
                 // the planner's copy of that particle; tests/test_locomotion_gpu.py).
                 bool pdone = false;
+                // (... and so are the owner residuals at that solution: the constraint force after the loop is made from them
+                // without another walk of the points' paths - unless a line-search step, whose residuals are interpolated, or the
+                // iteration cap ended a particle of the wavefront: rk_ok)
+                T rN_k[NR];
+#pragma unroll
+                for (int r = 0; r < NR; ++r) rN_k[r] = T(0);
+                bool rN_ok = false, rk_ok = false;
                 T xa_k = T(0);
                 bool actv_k = false;
                 mask_t cact_k = 0;
@@ -3111,6 +3149,7 @@ __global__ __launch_bounds__(64 * wg_waves(DP, FRIC, sizeof(T), PL), min_waves(s
                     bool act2 = inst && (actv ? !(resl > band) : (resl < -band));
                     T rN[NR];                                   // friction instantiation: my point's residuals at xa
                     mask_t cact2;
+                    rN_ok = true;                   // (rN: the owner residuals at xa)
                     if constexpr (FRIC) {
                         if (ucinst != 0) {              // (wave-uniform: no point or record this substep - limit / friction-loss rows only)
                             point_residuals(xa, rN);
@@ -3201,6 +3240,7 @@ __global__ __launch_bounds__(64 * wg_waves(DP, FRIC, sizeof(T), PL), min_waves(s
 #pragma unroll
                                     for (int r = 0; r < NR; ++r) rb[r] += al * (rN[r] - rb[r]);
                                     xa = a_b;                   // the iterate: what is kept if the iterations run out
+                                    rN_ok = false;              // (rN belongs to the Newton point, rb is interpolated)
                                     const T rlb = sig * a_b - aref;
                                     act2 = inst && (rlb < T(0));
                                     cact2 = rows_from_res(rb, cact);
@@ -3264,7 +3304,9 @@ __global__ __launch_bounds__(64 * wg_waves(DP, FRIC, sizeof(T), PL), min_waves(s
                         // rows along)
                         bool fchg = false;
                         if constexpr (GEN) fchg = mine_any(fst2 != fstate);
-                        const bool single = !pdone && nflip + ncf == 1u && !fchg;        // (uniform over my particle)
+                        // (dense rows of up to four dofs: a factorisation costs less than the correction's solve and second walk)
+                        constexpr bool RANK1 = !(DN > 0 && DN <= 4);
+                        const bool single = RANK1 && !pdone && nflip + ncf == 1u && !fchg;        // (uniform over my particle)
                         if (!(FRIC && it >= LS_START) && __any(single)) {
                             T jz_ = (single && flip) ? T(1) : T(0);         // my entry of the changed row
                             T cc = T(0), ar = T(0);
@@ -3298,7 +3340,22 @@ __global__ __launch_bounds__(64 * wg_waves(DP, FRIC, sizeof(T), PL), min_waves(s
                             const T resl2 = sig * xa - aref;
                             const T band2 = sizeof(T) == 4 ? T(2e-5) * (fabs(aref) + fabs(xa) + T(1)) : T(0);
                             const bool act2c = inst && (actv ? !(resl2 > band2) : (resl2 < -band2));
-                            const mask_t cact2c = next_set(xa, cact);
+                            mask_t cact2c = 0;
+                            if constexpr (FRIC) {
+                                T rC[NR];
+#pragma unroll
+                                for (int r = 0; r < NR; ++r) rC[r] = T(0);
+                                if (ucinst != 0) {
+                                    point_residuals(xa, rC);
+                                    cact2c = rows_from_res(rC, cact);
+                                }
+                                if (single) {
+#pragma unroll
+                                    for (int r = 0; r < NR; ++r) rN[r] = rC[r];
+                                }
+                            } else {
+                                cact2c = next_set(xa, cact);
+                            }
                             int fst2c = 0;
                             if constexpr (GEN) fst2c = fl_state_of(xa, fstate);
                             if (single) {
@@ -3337,6 +3394,9 @@ __global__ __launch_bounds__(64 * wg_waves(DP, FRIC, sizeof(T), PL), min_waves(s
                         } else if (!pchg) {
                             pdone = true;
                             xa_k = xa; actv_k = actv; cact_k = cact; fst_k = fstate;
+                            rk_ok = rN_ok;
+#pragma unroll
+                            for (int r = 0; r < NR; ++r) rN_k[r] = rN[r];
                         }
                     }
                     clk.count(11, 1);
@@ -3348,6 +3408,7 @@ __global__ __launch_bounds__(64 * wg_waves(DP, FRIC, sizeof(T), PL), min_waves(s
                     const unsigned mine = (unsigned)(cb >> (PL * half)) & (PL == 32 ? ~0u : 0xFFFFu);
                     if (l == 0 && mine != 0u) atomicAdd(diag, 1u);
                 }
+                xa_prev = xa;
                 lim_mem = (inst ? 1 : 0) | (actv ? 2 : 0);
                 if constexpr (GEN) fl_mem = floss > T(0) ? (1 | ((fstate + 1) << 1)) : 0;
                 cinst_mem = cinst;
@@ -3366,7 +3427,10 @@ __global__ __launch_bounds__(64 * wg_waves(DP, FRIC, sizeof(T), PL), min_waves(s
                     }
                 } else {
                     T res[NR];
-                    if (ucinst != 0) point_residuals(xa, res);
+#pragma unroll
+                    for (int r = 0; r < NR; ++r) res[r] = rN_k[r];
+                    // (a particle the cap stopped, or whose last step was a line search: the wavefront walks the paths once more)
+                    if (ucinst != 0 && __any(!(pdone && rk_ok))) point_residuals(xa, res);
                     qfrc_c = force_of(xa, res, actv, cact, fstate);
                 }
             } else {
@@ -3476,6 +3540,7 @@ __global__ __launch_bounds__(64 * wg_waves(DP, FRIC, sizeof(T), PL), min_waves(s
                         sincos_(q, sq, cq);
                         tau_act = act_id >= 0 ? M[T_GEAR + l] * fmin(fmax(T(0), M[T_CTRL_LO + l]), M[T_CTRL_HI + l]) : T(0);
                         lim_mem = 0; fl_mem = 0; cinst_mem = 0; cact_mem = 0;
+                        xa_prev = T(0);
                         if (sub == frame_skip - 1)
                             for (int k = 0; k < 3; ++k) { hand[k] = (T)rst[TREE_STATE_LEN + k]; haxis[k] = (T)rst[TREE_STATE_LEN + 3 + k]; }
                         rst_ever = true;
