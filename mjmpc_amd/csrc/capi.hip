@@ -682,14 +682,14 @@ extern "C" int mjmpc_debug_stamps(mjmpc_arm_t h, unsigned long long* out32) {
 /* ---- tree engine ------------------------------------------------------------------------------------ */
 static_assert(MJMPC_TREE_BLOB_LEN == mjmpc::TREE_BLOB_LEN && MJMPC_TREE_DEVICE_STATE_LEN == mjmpc::TREE_STATE_LEN &&
               MJMPC_TREE_STATE_LEN == mjmpc::TREE_PUBLIC_STATE_LEN, "include/mjmpc_amd.h and csrc/tree_model.h disagree");
-#define MJMPC_TREE_DIAG_BYTES (8 + 8 * 24 + 8)  /* counters, the developer clocks of -DTREE_STATS builds, the real env's resets (TREE_DIAG_ENV_RESETS) */
+#define MJMPC_TREE_DIAG_BYTES (8 + 8 * mjmpc::TREE_STAT_SLOTS + 8)  /* counters, the developer clocks of -DTREE_STATS builds, the real env's resets (TREE_DIAG_ENV_RESETS) */
 #ifdef TREE_STATS
 // developer builds only (not declared in include/mjmpc_amd.h): read and clear the phase clocks / iteration counts
-extern "C" int mjmpc_debug_tree_stats(mjmpc_tree_t h, unsigned long long* out24) {
-    if (!h || !out24) return fail(MJMPC_E_BADARG, "null argument");
+extern "C" int mjmpc_debug_tree_stats(mjmpc_tree_t h, unsigned long long* out48) {
+    if (!h || !out48) return fail(MJMPC_E_BADARG, "null argument");
     HIP_TRY(hipDeviceSynchronize());
-    HIP_TRY(hipMemcpy(out24, (char*)h->diag + 8, 8 * 24, hipMemcpyDeviceToHost));
-    HIP_TRY(hipMemset((char*)h->diag + 8, 0, 8 * 24));
+    HIP_TRY(hipMemcpy(out48, (char*)h->diag + 8, 8 * mjmpc::TREE_STAT_SLOTS, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemset((char*)h->diag + 8, 0, 8 * mjmpc::TREE_STAT_SLOTS));
     return 0;
 }
 #endif

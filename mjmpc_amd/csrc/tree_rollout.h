@@ -38,7 +38,8 @@ struct TreeFusion {
 };
 // diag (unsigned[]): [0] iteration-cap hits, [1] resets (live particles), developer clocks from byte 8 (TREE_STATS builds),
 // [TREE_DIAG_ENV_RESETS] resets of the REAL env (launches with state_out: mjmpc_tree_step_state, the control iteration's env step)
-constexpr int TREE_DIAG_ENV_RESETS = 2 + 2 * 24;
+constexpr int TREE_STAT_SLOTS = 48;         // 64-bit developer clocks / counts of -DTREE_STATS builds (tools/tree_stats.py)
+constexpr int TREE_DIAG_ENV_RESETS = 2 + 2 * TREE_STAT_SLOTS;
 
 template <typename T>
 hipError_t launch_tree_rollout(const T* model, int n_model_shards, int max_path, bool full, int nv, const double* state, long P, int H,

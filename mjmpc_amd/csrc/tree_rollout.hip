@@ -96,11 +96,13 @@ struct TreeClock {
 #ifdef TREE_STATS_FINE
 #define TREE_LAP_A clk.lap(15)
 #define TREE_LAP_B clk.lap(22)
-#define TREE_LAP_C
+#define TREE_LAP_C clk.lap(26)
+#define TREE_FLAP(slot_) clk.lap(slot_)         /* slots 24 ...: see tools/tree_stats.py --fine */
 #else
 #define TREE_LAP_A
 #define TREE_LAP_B clk.lap(15)
 #define TREE_LAP_C clk.lap(22)
+#define TREE_FLAP(slot_)
 #endif
 constexpr int wg_waves(int DP, bool fric, int scalar_bytes = 8, int PL = 32) {
     return DP <= 8 ? 4 : (DP <= 16 ? (PL == 16 && scalar_bytes == 4 ? 4 : 2) : 1);
@@ -2712,6 +2714,7 @@ __global__ __launch_bounds__(64 * wg_waves(DP, FRIC, sizeof(T), PL), min_waves(s
             clk.count(9, __popc(cinst));
             if (any_rows) {
                 clk.count(10, 1);
+                clk.lap(-1);
                 if (__any(inst)) {      // (the impedance arithmetic only when some lane of the wavefront has a limit row)
                     tree_row_params(M + T_SOLTAB + 7 * (dofcls & 7), dist - jmargin, M[T_DOF_INVW + l], sig * v, D, aref);
                     D = inst ? D : T(0);
@@ -3040,6 +3043,7 @@ __global__ __launch_bounds__(64 * wg_waves(DP, FRIC, sizeof(T), PL), min_waves(s
                 mask_t cact_k = 0;
                 int fst_k = 0;
                 auto mine_any = [&](bool x) -> bool { return (__ballot(x) & my_lanes) != 0ull; };
+                TREE_FLAP(31);
                 clk.lap(-1);
                 for (int it = 0; it < (FRIC ? TREE_MAXIT_LS : TREE_MAXIT); ++it) {
                     if ((TREE_SKIP & 16) || ((TREE_SKIP & 32) && it == 1)) { changed = false; break; }      // (developer timing: no iteration / one)
@@ -3056,6 +3060,7 @@ __global__ __launch_bounds__(64 * wg_waves(DP, FRIC, sizeof(T), PL), min_waves(s
                     }
                     T rhs = tau + (actv ? D * sig * aref : T(0));
                     if constexpr (GEN) rhs += fstate == 0 ? Dfq * areff : (fstate < 0 ? floss : -floss);
+                    TREE_FLAP(24);
                     for (unsigned um = ucinst; um; um &= um - 1) {
                         const int s = __builtin_ctz(um);
                         const unsigned bits = (unsigned)(cact >> (s * NR)) & ((1u << NR) - 1u);
@@ -3324,6 +3329,7 @@ __global__ __launch_bounds__(64 * wg_waves(DP, FRIC, sizeof(T), PL), min_waves(s
                             T zl;
                             if constexpr (DN > 0) zl = dense_solve_any<DN>(hd, hdinv, jz_, l);
                             else zl = tree_solve<DP, PL>(hrow, jz_, ELIM, AT, ROW, VEC, l, n_rounds, depth, max_depth, kt);
+                            TREE_FLAP(27);
                             // (one formula for either kind of row: the lane sums have ONE non-zero term, they are exact)
                             const bool fl1 = single && flip;
                             const T cp = sum_lanes<PL>(fl1 ? (act2 ? D : -D) : T(0)) + cc;
@@ -3336,6 +3342,7 @@ __global__ __launch_bounds__(64 * wg_waves(DP, FRIC, sizeof(T), PL), min_waves(s
                                 if (FRIC && ncf == 1u) cact = cact2;
                                 actv = act2;
                             }
+                            TREE_FLAP(28);
                             // (every lane walks the exchange; a particle that took no correction arrives at the sets it had)
                             const T resl2 = sig * xa - aref;
                             const T band2 = sizeof(T) == 4 ? T(2e-5) * (fabs(aref) + fabs(xa) + T(1)) : T(0);
@@ -3364,6 +3371,7 @@ __global__ __launch_bounds__(64 * wg_waves(DP, FRIC, sizeof(T), PL), min_waves(s
                                 fst2 = fst2c;
                                 changed = (act2 != actv) || (cact2 != cact) || (GEN && fst2 != fstate);
                             }
+                            TREE_FLAP(29);
                         }
                     }
                     clk.lap(23);
@@ -3403,6 +3411,7 @@ __global__ __launch_bounds__(64 * wg_waves(DP, FRIC, sizeof(T), PL), min_waves(s
                     clk.lap(15);
                     if (!__any(changed)) break;
                 }
+                clk.lap(-1);
                 if (diag) {        // one count per particle-substep whose rows were still changing when the iterations ran out
                     const unsigned long long cb = __ballot(changed);
                     const unsigned mine = (unsigned)(cb >> (PL * half)) & (PL == 32 ? ~0u : 0xFFFFu);
@@ -3433,6 +3442,7 @@ __global__ __launch_bounds__(64 * wg_waves(DP, FRIC, sizeof(T), PL), min_waves(s
                     if (ucinst != 0 && __any(!(pdone && rk_ok))) point_residuals(xa, res);
                     qfrc_c = force_of(xa, res, actv, cact, fstate);
                 }
+                TREE_FLAP(30);
             } else {
                 lim_mem = 0;
                 fl_mem = 0;

@@ -56,7 +56,7 @@ if __name__ == "__main__":
         mean[:, 1:] = 0.2           # (finger servos: the pose the model is drawn in)
     if name == "pen":
         mean += torch.from_numpy(st["qp"][6:]).to(mean)
-    out = (ctypes.c_ulonglong * 24)()
+    out = (ctypes.c_ulonglong * 48)()
     eng.rollout_device(P, H, mean, noise)
     lib.mjmpc_debug_tree_stats(eng._h, out)
     eng.rollout_device(P, H, mean, noise)
@@ -71,6 +71,10 @@ if __name__ == "__main__":
     ni = max(v[11], 1)
     print("  per Newton iteration: assemble H %.0f, factor %.0f, solve %.0f, next active set %.0f, line search %.0f, rank-one correction %.0f cycles"
           % (v[12] / ni, v[13] / ni, v[14] / ni, v[15] / ni, v[22] / ni, v[23] / ni))
+    if "fine" in LIB:       # a -DTREE_STATS_FINE build (TREE_STATS_LIB=tools/_build/libmjmpc_amd_treestatsfine.so)
+        print("  fine, per iteration: H/rhs start %.0f, per-point assembly %.0f, factor %.0f, solve %.0f, owners' walk %.0f, sets %.0f, line search %.0f; "
+              "rank-one: solve %.0f, sums %.0f, re-check %.0f; tail %.0f cycles" % tuple(v[k] / ni for k in (24, 12, 13, 14, 15, 22, 26, 27, 28, 29, 23)))
+        print("  fine, per substep with rows: before the loop %.0f, after it (constraint force) %.0f cycles" % (v[31] / max(v[10], 1), v[30] / max(v[10], 1)))
     print("  iterations that found a changed set: %d - one limit row %d, one contact row %d, several rows %d, only the wave's other particle %d; friction-loss zone changes %d"
           % (v[16], v[17], v[18], v[19], v[20], v[21]))
     print("  total %.0f cycles/substep; contact points per substep %.2f; substeps with rows %.0f %%; Newton iterations per such substep %.2f"
