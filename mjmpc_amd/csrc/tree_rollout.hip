@@ -3019,7 +3019,14 @@ __global__ __launch_bounds__(64 * wg_waves(DP, FRIC, sizeof(T), PL), min_waves(s
                 bool changed = true, act_pp = false;
                 mask_t cact_pp = 0;
                 int fst_pp = 0;
-                constexpr int LS_START = GEN >= 3 ? 0 : 5;      // iterations before the safeguard takes over (friction instantiation; elliptic cones: MuJoCo's Newton method from the start)
+                // (round 6: models with FRICTION-LOSS rows from the third iteration on - a Huber row's zone changes drag each other
+                // along and the plain iteration wandered to iteration 5 before the search took over; measured per 4096 x 32 launch:
+                // door 1.02 -> 0.935 ms, pen-in-hand with dry finger joints 22.1 -> 18.35, cart-pole 0.415 -> 0.40; a model with
+                // pyramids only LOSES by an earlier search - tray 2.755 -> 2.975 - and keeps 5; profiles/r06_ls_start_ab.txt)
+#ifndef TREE_LS_START_FLOSS
+#define TREE_LS_START_FLOSS 2
+#endif
+                const int LS_START = GEN >= 3 ? 0 : ((GEN && any_floss) ? TREE_LS_START_FLOSS : 5);      // iterations before the safeguard takes over (friction instantiation; elliptic cones: MuJoCo's Newton method from the start)
                 bool ls_on = false;
                 T a_b = T(0), g_b = T(0), rb[NR];
 #pragma unroll
