@@ -3045,10 +3045,15 @@ __global__ __launch_bounds__(64 * wg_waves(DP, FRIC, sizeof(T), PL), min_waves(s
                 // along and the plain iteration wandered to iteration 5 before the search took over; measured per 4096 x 32 launch:
                 // door 1.02 -> 0.935 ms, pen-in-hand with dry finger joints 22.1 -> 18.35, cart-pole 0.415 -> 0.40; a model with
                 // pyramids only LOSES by an earlier search - tray 2.755 -> 2.975 - and keeps 5; profiles/r06_ls_start_ab.txt)
+                // (... and, once the search found its root by false position: from the SECOND iteration on in f64 - door 0.885 -> 0.86,
+                // dry-jointed pen-in-hand 17.6 -> 16.5; f32 keeps the third: door 0.715 -> 0.775 with the second; r06_ls_start2_ab.txt)
 #ifndef TREE_LS_START_FLOSS
-#define TREE_LS_START_FLOSS 2
+#define TREE_LS_START_FLOSS (sizeof(T) == 8 ? 1 : 2)
 #endif
-                const int LS_START = GEN >= 3 ? 0 : ((GEN && any_floss) ? TREE_LS_START_FLOSS : 5);      // iterations before the safeguard takes over (friction instantiation; elliptic cones: MuJoCo's Newton method from the start)
+#ifndef TREE_LS_START_PYR
+#define TREE_LS_START_PYR 5
+#endif
+                const int LS_START = GEN >= 3 ? 0 : ((GEN && any_floss) ? TREE_LS_START_FLOSS : TREE_LS_START_PYR);      // iterations before the safeguard takes over (friction instantiation; elliptic cones: MuJoCo's Newton method from the start)
                 bool ls_on = false;
                 T a_b = T(0), g_b = T(0), rb[NR];
 #pragma unroll
