@@ -3208,6 +3208,7 @@ __global__ __launch_bounds__(64 * wg_waves(DP, FRIC, sizeof(T), PL), min_waves(s
                     // (GEN = 3: an elliptic record of the model's set in its middle zone - the cost is not quadratic there, the
                     // Newton point of the model is not the minimiser: on, until the line search below stops moving)
                     if constexpr (GEN >= 3) changed = changed || (cact & (mask_t)ell_mid) != 0;
+                    changed = changed && !pdone;        // (a frozen particle asks for nothing: no search, no correction on its account)
                     // SAFEGUARD (friction instantiation).  The plain iteration - solve with the set, adopt the set the solution
                     // asks for - has no line search and can cycle when several friction pyramids switch rows together
                     // (periods 3 and 4 seen on the pen-in-hand model; the iterate kept then was arbitrary).  From iteration
@@ -3343,8 +3344,15 @@ __global__ __launch_bounds__(64 * wg_waves(DP, FRIC, sizeof(T), PL), min_waves(s
                         // rows along)
                         bool fchg = false;
                         if constexpr (GEN) fchg = mine_any(fst2 != fstate);
-                        // (dense rows of up to four dofs: a factorisation costs less than the correction's solve and second walk)
-                        constexpr bool RANK1 = !(DN > 0 && DN <= 4);
+                        // (the 16-lane dense instantiations refactor instead: their factorisation + solve is ~1.8 k ticks, the
+                        // correction's solve + second walk ~1.7 k, and with per-particle decisions a wavefront that holds a
+                        // one-change AND a several-changes particle pays both - closed-loop HalfCheetah 1.957 -> 1.871 ms per
+                        // step without it, the others within 0.4 %: profiles/r06_rank_one_ab.txt; the 32-lane dense and the
+                        // tree-sparse instantiations, whose factorisations cost 9 - 12 k, keep the correction)
+#ifndef TREE_RANK1_OFF_DN
+#define TREE_RANK1_OFF_DN 16
+#endif
+                        constexpr bool RANK1 = !(DN > 0 && DN <= TREE_RANK1_OFF_DN);
                         const bool single = RANK1 && !pdone && nflip + ncf == 1u && !fchg;        // (uniform over my particle)
                         if (!(FRIC && it >= LS_START) && __any(single)) {
                             T jz_ = (single && flip) ? T(1) : T(0);         // my entry of the changed row
