@@ -61,3 +61,46 @@ def test_a_particle_does_not_see_its_wave_mates(name, dtype):
     for k in (0, 1, 7, 130):            # alone: its wave-mates are the launch's idle lanes
         c_1, o_1 = run(noise[k:k + 1])
         assert np.array_equal(c_1[0], c_all[k]) and np.array_equal(o_1[0], o_all[k]), k
+
+
+_WM_SEEDS = (range(*[int(x) for x in __import__("os").environ["MJMPC_WM_SEEDS"].split(":")])
+             if __import__("os").environ.get("MJMPC_WM_SEEDS") else range(0, 48, 2))
+
+
+@pytest.mark.parametrize("dtype", ["f64", "f32"])
+@pytest.mark.parametrize("seed", _WM_SEEDS)
+def test_random_models_particles_do_not_see_their_wave_mates(seed, dtype):
+    """The same property over the random-model generator of tests/test_random_models_gpu.py - every instantiation the
+    generator reaches (lean / full / general levels 1 - 3, 16 or 32 lanes, tree-sparse or dense, ball and free joints,
+    equalities, tendons, friction loss, pyramidal and elliptic cones): 32 particles from a random state, the same particles
+    in another order, four of them alone.  (MJMPC_WM_SEEDS=a:b runs another range of seeds.)"""
+    from test_random_models_gpu import MAX_REDRAWS, random_model, random_state
+    from mjmpc_amd.envs.tree_engine import TreeRolloutEngine
+    raw, eng, tries = None, None, 0
+    while eng is None:
+        raw = random_model(1000 * tries + seed)
+        try:
+            eng = TreeRolloutEngine(raw, dtype=dtype)
+        except (ValueError, NotImplementedError, AssertionError):
+            eng, tries = None, tries + 1
+            assert tries <= MAX_REDRAWS
+    rs = np.random.RandomState(seed + 1234)
+    q, v = random_state(raw, rs)
+    eng.set_env_state(dict(qp=q, qv=v, target_pos=np.asarray(raw.target_pos, float)))
+    A, H, P = eng.d_action, 6, 32
+    npdt = np.float32 if dtype == "f32" else np.float64
+    noise = rs.uniform(-1.5, 1.5, (P, H, A)).astype(npdt)
+    mean = np.zeros((H, A))
+
+    def run(nz):
+        out = eng.rollout_device(nz.shape[0], H, mean, nz, want_obs=True)
+        return out[0].cpu().numpy().copy(), out[3].cpu().numpy().copy()
+
+    c_all, o_all = run(noise)
+    perm = rs.permutation(P)
+    c_p, o_p = run(noise[perm])
+    # (NaN-safe: a particle that blows up does so identically)
+    assert np.array_equal(c_p, c_all[perm], equal_nan=True) and np.array_equal(o_p, o_all[perm], equal_nan=True)
+    for k in (0, 3, 17, 31):
+        c_1, o_1 = run(noise[k:k + 1])
+        assert np.array_equal(c_1[0], c_all[k], equal_nan=True) and np.array_equal(o_1[0], o_all[k], equal_nan=True), k
