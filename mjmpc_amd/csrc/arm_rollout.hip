@@ -706,6 +706,18 @@ __device__ __forceinline__ T xj_line_search(const MT& M, T* ldsM, int l8, T a_pr
     return a_prev + alpha * d;
 }
 
+// Developer build -DARM_PER_PARTICLE (round 6, measured: profiles/r06_arm_per_particle_ab.txt): the solver's decisions per
+// PARTICLE (8-lane group) instead of per wavefront, as the tree kernels take them since this round - a particle none of whose
+// rows changes is frozen while its seven wave-mates iterate on, the rank-one correction is taken by the particles with exactly
+// one flipped limit row, the long sine / cosine series by the lanes whose step needs it.
+template <typename T>
+struct ParticleFreeze {
+    bool done = false, act = false, cact = false;
+    T aw = T(0);
+    int z = 0;
+};
+__device__ __forceinline__ bool gany(bool x) { return gsum(x ? 1.0f : 0.0f) > 0.5f; }
+
 // active-set test of the constraint rows at acceleration aw (f32: a row whose residual is within rounding of zero
 // keeps its state - such rows otherwise flip back and forth until the iteration cap, seen a few times per 5e8
 // solves; f64 has never failed to settle and keeps the plain sign test)
@@ -1022,6 +1034,9 @@ __device__ __forceinline__ void arm_front(const MT& M, const ArmInts& I, T& q, T
         if (any_rows) {
             if (any_c) ldsM[V_JC + l8] = jc;
             changed = true;
+#ifdef ARM_PER_PARTICLE
+            ParticleFreeze<T> fz;
+#endif
             for (int it = 0; it < newton_maxit<T>(); ++it) {
                 T rhs = tau + (act ? D * sig * aref : T(0));
                 if (any_c) rhs += cact ? Dc * jc * arefc : T(0);
@@ -1061,7 +1076,7 @@ __device__ __forceinline__ void arm_front(const MT& M, const ArmInts& I, T& q, T
                 aw = acc;
                 bool act2, cact2;
                 active_set(aw, sig, aref, jc, arefc, inst, cinst, act, cact, act2, cact2);
-                const bool flip = act2 != act, cflip = cact2 != cact;
+                bool flip = act2 != act, cflip = cact2 != cact;
                 changed = flip || cflip;
                 act = act2;
                 cact = cact2;
@@ -1072,6 +1087,9 @@ __device__ __forceinline__ void arm_front(const MT& M, const ArmInts& I, T& q, T
                     fl.z = z2;
                     changed = changed || fflip;
                 }
+#ifdef ARM_PER_PARTICLE
+                if (fz.done) { aw = fz.aw; act = fz.act; cact = fz.cact; if constexpr (XJ) fl.z = fz.z; changed = flip = cflip = fflip = false; }
+#endif
                 // E2: the DYN wave needs ~1000 cycles after E1 for (M + h B)^-1; with the limit rows arriving from it
                 // this wave gets HERE in about as many (after the first factorisation it would still wait ~400).  Taking
                 // the rendezvous inside the first iteration rather than at the end of the substep leaves only E3
@@ -1089,6 +1107,42 @@ __device__ __forceinline__ void arm_front(const MT& M, const ArmInts& I, T& q, T
                 // dozen instructions instead of a second factorisation.  Several flips in one particle, or a flip of
                 // the contact row, take the general path (next iteration refactors).
                 const float nflip = gsum(flip ? 1.0f : 0.0f);
+#ifdef ARM_PER_PARTICLE
+                if (!fz.done && !gany(changed)) { fz.done = true; fz.aw = aw; fz.act = act; fz.cact = cact; fz.z = fl.z; }
+                const bool single = !XJ && !fz.done && nflip > 0.5f && nflip < 1.5f && !gany(cflip);
+                if (__any(single)) {
+                    if (single && flip) {
+                        T zjj = col[0];
+#pragma unroll
+                        for (int i = 1; i < MAX_LINKS; ++i) zjj = (l8 == i) ? col[i] : zjj;
+                        const T c = act ? D : -D;
+                        ldsM[V_XH + 0] = (T)l8;
+                        ldsM[V_XH + 1] = c;
+                        ldsM[V_XH + 2] = c * sig * aref;
+                        ldsM[V_XH + 3] = zjj;
+                        ldsM[V_XH + 4] = aw;
+                    }
+                    LDS_WAVE_SYNC();
+                    if (single) {
+                        const int j = (int)ldsM[V_XH + 0];
+                        const T c = ldsM[V_XH + 1], dl = ldsM[V_XH + 2], zjj = ldsM[V_XH + 3], aj = ldsM[V_XH + 4];
+                        T z = col[0];
+#pragma unroll
+                        for (int i = 1; i < MAX_LINKS; ++i) z = (j == i) ? col[i] : z;
+                        const T yj = aj + dl * zjj;
+                        aw = (aw + dl * z) - c * z * yj * rcp_(T(1) + c * zjj);
+                    }
+                    active_set(aw, sig, aref, jc, arefc, inst, cinst, act, cact, act2, cact2);
+                    if (single) {
+                        changed = (act2 != act) || (cact2 != cact);
+                        act = act2;
+                        cact = cact2;
+                    }
+                    if (!fz.done && !gany(changed)) { fz.done = true; fz.aw = aw; fz.act = act; fz.cact = cact; fz.z = fl.z; }
+                    ST.mark(9);
+                    if (!__any(changed)) break;
+                }
+#else
                 if (!XJ && !__any(cflip || nflip > 1.5f || fflip)) {   // (XJ: every change refactors and goes through the line search)
                     if (flip) {
                         T zjj = col[0];
@@ -1123,6 +1177,7 @@ __device__ __forceinline__ void arm_front(const MT& M, const ArmInts& I, T& q, T
                     ST.mark(9);
                     if (!__any(changed)) break;
                 }
+#endif
                 LDS_WAVE_SYNC();                        // V_RH is rewritten
             }
             if (changed && diag) atomicAdd(diag, 1u);
@@ -1160,6 +1215,9 @@ __device__ __forceinline__ void arm_front(const MT& M, const ArmInts& I, T& q, T
     if (any_rows) {
         changed = true;
         if (any_c) ldsM[V_JC + l8] = jc;
+#ifdef ARM_PER_PARTICLE
+        ParticleFreeze<T> fz;
+#endif
         for (int it = 0; it < newton_maxit<T>(); ++it) {
             T rhs = tau + (act ? D * sig * aref : T(0));
             if (any_c) rhs += cact ? Dc * jc * arefc : T(0);
@@ -1205,6 +1263,10 @@ __device__ __forceinline__ void arm_front(const MT& M, const ArmInts& I, T& q, T
                 changed = changed || z2 != fl.z;
                 fl.z = z2;
             }
+#ifdef ARM_PER_PARTICLE
+            if (fz.done) { aw = fz.aw; act = fz.act; cact = fz.cact; if constexpr (XJ) fl.z = fz.z; changed = false; }
+            else if (!gany(changed)) { fz.done = true; fz.aw = aw; fz.act = act; fz.cact = cact; fz.z = fl.z; }
+#endif
             ST.mark(it == 0 ? 8 : 9);                   // first solve + active-set check / further iterations
             if (!__any(changed)) break;
         }
@@ -1499,6 +1561,9 @@ __device__ __forceinline__ void flag_front(const MT& M, const ArmInts& I, T& q, 
         if (any_rows) {
             if (!CONTACT_BY_AUX && any_c) ldsM[V_JC + l8] = jc;
             changed = true;
+#ifdef ARM_PER_PARTICLE
+            ParticleFreeze<T> fz;
+#endif
             for (int it = 0; it < newton_maxit<T>(); ++it) {
                 // the rows' parts of the right-hand side; tau joins them when it has arrived:  rhs = (tau + limit) + contact
                 ldsM[V_DH + l8] = dgM + (act ? D : T(0));
@@ -1544,10 +1609,13 @@ __device__ __forceinline__ void flag_front(const MT& M, const ArmInts& I, T& q, 
                 aw = acc;
                 bool act2, cact2;
                 active_set(aw, sig, aref, jc, arefc, inst, cinst, act, cact, act2, cact2);
-                const bool flip = act2 != act, cflip = cact2 != cact;
+                bool flip = act2 != act, cflip = cact2 != cact;
                 changed = flip || cflip;
                 act = act2;
                 cact = cact2;
+#ifdef ARM_PER_PARTICLE
+                if (fz.done) { aw = fz.aw; act = fz.act; cact = fz.cact; changed = flip = cflip = false; }
+#endif
                 if (it == 0) {
                     ST.mark(8);
                     q_take(qf, QF_EI, seq, [&]() {          // my row of (M + h B)^-1
@@ -1560,6 +1628,43 @@ __device__ __forceinline__ void flag_front(const MT& M, const ArmInts& I, T& q, 
                 if (!__any(changed)) break;
                 // one limit row of a particle changed state: Sherman-Morrison instead of a second factorisation (arm_front)
                 const float nflip = gsum(flip ? 1.0f : 0.0f);
+#ifdef ARM_PER_PARTICLE
+                if (!fz.done && !gany(changed)) { fz.done = true; fz.aw = aw; fz.act = act; fz.cact = cact; }
+                const bool single = !fz.done && nflip > 0.5f && nflip < 1.5f && !gany(cflip);
+                if (__any(single)) {
+                    LDS_WAVE_SYNC();                    // (V_XH: the contact parts have been read)
+                    if (single && flip) {
+                        T zjj = col[0];
+#pragma unroll
+                        for (int i = 1; i < MAX_LINKS; ++i) zjj = (l8 == i) ? col[i] : zjj;
+                        const T c = act ? D : -D;
+                        ldsM[V_XH + 0] = (T)l8;
+                        ldsM[V_XH + 1] = c;
+                        ldsM[V_XH + 2] = c * sig * aref;
+                        ldsM[V_XH + 3] = zjj;
+                        ldsM[V_XH + 4] = aw;
+                    }
+                    LDS_WAVE_SYNC();
+                    if (single) {
+                        const int j = (int)ldsM[V_XH + 0];
+                        const T c = ldsM[V_XH + 1], dl = ldsM[V_XH + 2], zjj = ldsM[V_XH + 3], aj = ldsM[V_XH + 4];
+                        T z = col[0];
+#pragma unroll
+                        for (int i = 1; i < MAX_LINKS; ++i) z = (j == i) ? col[i] : z;
+                        const T yj = aj + dl * zjj;
+                        aw = (aw + dl * z) - c * z * yj * rcp_(T(1) + c * zjj);
+                    }
+                    active_set(aw, sig, aref, jc, arefc, inst, cinst, act, cact, act2, cact2);
+                    if (single) {
+                        changed = (act2 != act) || (cact2 != cact);
+                        act = act2;
+                        cact = cact2;
+                    }
+                    if (!fz.done && !gany(changed)) { fz.done = true; fz.aw = aw; fz.act = act; fz.cact = cact; }
+                    ST.mark(9);
+                    if (!__any(changed)) break;
+                }
+#else
                 if (!__any(cflip || nflip > 1.5f)) {
                     LDS_WAVE_SYNC();                    // (V_XH: the contact parts have been read)
                     if (flip) {
@@ -1590,6 +1695,7 @@ __device__ __forceinline__ void flag_front(const MT& M, const ArmInts& I, T& q, 
                     ST.mark(9);
                     if (!__any(changed)) break;
                 }
+#endif
                 LDS_WAVE_SYNC();                        // V_RH / V_XH are rewritten
             }
             if (changed && diag) atomicAdd(diag, 1u);
@@ -1674,6 +1780,9 @@ __device__ __forceinline__ void arm_back(const MT& M, T& q, T& v, T& aw, T& sq, 
                 cd = T(1) - T(2) * sd * sd;
                 sd = s2;
             }
+#ifdef ARM_PER_PARTICLE
+            if (fabs(dq) <= (slide ? T(1e5) : T(0.25))) sincos_small(dqa, sd, cd);     // (the long series in the lanes that need it)
+#endif
         } else {
             sincos_small(dqa, sd, cd);
         }
