@@ -36,6 +36,10 @@
 // Round 4: the GENERAL instantiation (GEN: ball / free joints as quaternion links, friction-loss rows, boxes, static geoms,
 // equalities, tendon limits, solver parameters per row, affine actuators) and a DENSE factorisation over the 32 lanes of
 // a particle (DN = 32: models of 17 .. 32 dofs whose elimination paths are longer than 8 links) - see dense32_factor.
+// Round 6: every decision of the solver is taken PER PARTICLE (a converged particle is frozen while its wave-mates iterate on;
+// rank-one correction or refactorisation by the particle's own changes; the long sine / cosine path per lane), so a particle's
+// trajectory does not depend on who shares its wavefront (tests/test_wave_mates_gpu.py); the exact line search finds its root
+// by false position and takes over earlier in models with friction-loss rows.
 #include <hip/hip_runtime.h>
 #include <cstdlib>
 
