@@ -3,6 +3,8 @@ decision inside the tree kernel's solver is taken per particle - a converged par
 iterate on, rank-one correction or refactorisation follows the particle's own changes, the sine / cosine update is chosen
 per lane.  Checked bitwise on every tree workload, f64 and f32: the same particles alone (P = 1, the device-resident
 real env's launch shape), in another order, and among many."""
+import os
+
 import numpy as np
 import pytest
 
@@ -63,8 +65,8 @@ def test_a_particle_does_not_see_its_wave_mates(name, dtype):
         assert np.array_equal(c_1[0], c_all[k]) and np.array_equal(o_1[0], o_all[k]), k
 
 
-_WM_SEEDS = (range(*[int(x) for x in __import__("os").environ["MJMPC_WM_SEEDS"].split(":")])
-             if __import__("os").environ.get("MJMPC_WM_SEEDS") else range(0, 48, 2))
+_WM_SEEDS = (range(*[int(x) for x in os.environ["MJMPC_WM_SEEDS"].split(":")])
+             if os.environ.get("MJMPC_WM_SEEDS") else range(0, 48, 2))
 
 
 @pytest.mark.parametrize("dtype", ["f64", "f32"])
