@@ -2275,7 +2275,7 @@ __global__ __launch_bounds__(64 * wg_waves(DP, FRIC, sizeof(T), PL), min_waves(s
                             for (int k = 0; k < 3; ++k) nb[k] = os[k] - cb[k];
                             len = sqrt_(dot3(nb, nb));
                             ok = len > T(1e-14);
-                            const T inv = ok ? T(1) / len : T(0);
+                            const T inv = ok ? rcp_(len) : T(0);
                             for (int k = 0; k < 3; ++k) nb[k] *= inv;
                         }
                         // nb points from the box to the sphere; the contact's normal from geom B to geom A
@@ -2311,19 +2311,19 @@ __global__ __launch_bounds__(64 * wg_waves(DP, FRIC, sizeof(T), PL), min_waves(s
                             const T r3[3] = {o1[0] - o2[0], o1[1] - o2[1], o1[2] - o2[2]};
                             const T a = dot3(d1, d1), e = dot3(d2, d2), f = dot3(d2, r3), EPS = T(1e-18);
                             auto clamp01 = [](T x) { return x < T(0) ? T(0) : (x > T(1) ? T(1) : x); };
-                            if (a <= EPS && e <= EPS) { ss = T(0); tt = T(0); }
-                            else if (a <= EPS) { ss = T(0); tt = clamp01(f / e); }
-                            else {
-                                const T c = dot3(d1, r3);
-                                if (e <= EPS) { tt = T(0); ss = clamp01(-c / a); }
-                                else {
-                                    const T b = dot3(d1, d2), denom = a * e - b * b;
-                                    ss = denom > T(1e-12) * a * e ? clamp01((b * f - c * e) / denom) : T(0);
-                                    tt = (b * ss + f) / e;
-                                    if (tt < T(0)) { tt = T(0); ss = clamp01(-c / a); }
-                                    else if (tt > T(1)) { tt = T(1); ss = clamp01((b - c) / a); }
-                                }
-                            }
+                            // (round 6: the clamped closed form by selects and three reciprocals made side by side - the nested
+                            // cases with their IEEE divisions ran one after the other for the record kinds of a wavefront: sphere /
+                            // sphere, sphere / capsule and capsule / capsule pairs take different ones)
+                            const T c = dot3(d1, r3), b = dot3(d1, d2), denom = a * e - b * b;
+                            const bool za = a <= EPS, ze = e <= EPS, par = !(denom > T(1e-12) * a * e);
+                            const T ia = rcp_(za ? T(1) : a), ie = rcp_(ze ? T(1) : e), idn = rcp_(par ? T(1) : denom);
+                            const T ss_lo = clamp01(-c * ia), ss_hi = clamp01((b - c) * ia);
+                            T ssg = par ? T(0) : clamp01((b * f - c * e) * idn);
+                            T ttg = (b * ssg + f) * ie;
+                            ssg = ttg < T(0) ? ss_lo : (ttg > T(1) ? ss_hi : ssg);
+                            ttg = clamp01(ttg);
+                            ss = za ? T(0) : (ze ? ss_lo : ssg);
+                            tt = za ? (ze ? T(0) : clamp01(f * ie)) : (ze ? T(0) : ttg);
                         }
                         T c2[3], diff[3];
                         for (int k = 0; k < 3; ++k) {
@@ -2331,7 +2331,7 @@ __global__ __launch_bounds__(64 * wg_waves(DP, FRIC, sizeof(T), PL), min_waves(s
                             diff[k] = o1[k] + ss * d1[k] - c2[k];
                         }
                         const T len = sqrt_(dot3(diff, diff));
-                        const T inv = len > T(1e-14) ? T(1) / len : T(0);
+                        const T inv = len > T(1e-14) ? rcp_(len) : T(0);
                         const T cdist = len - sp[4] - sp[17];
                         T nv3[3];
                         for (int k = 0; k < 3; ++k) {
