@@ -3022,7 +3022,20 @@ __global__ __launch_bounds__(64 * wg_waves(DP, FRIC, sizeof(T), PL), min_waves(s
                     const unsigned newpts = cinst & ~cinst_mem;
                     if (__any(newpts != 0u)) {
                         T r0[NR];
+#if TREE_WARM_START == 2        // ... at ZERO acceleration: the rows whose reference acceleration is positive - no walk (the owner's record)
+                        {
+                            const T* cs0 = X + A_CS + (l < NS ? l : 0) * CS;
+                            const T mu0 = M[T_SPH + (l < NS ? l : 0) * TREE_SPH_STRIDE + 7];
+                            r0[0] = -(cs0[5] - cs0[6]);
+                            r0[1 % NR] = -(cs0[5] + cs0[6]);
+                            r0[2 % NR] = -(cs0[5] - cs0[7]);
+                            r0[3 % NR] = -(cs0[5] + cs0[7]);
+                            if (!(mu0 > T(0))) r0[0] = -cs0[5];
+                            if (GEN && (my_kind == PT_CONNECT || my_kind == PT_WELD)) { r0[0] = -cs0[5]; r0[1 % NR] = -cs0[6]; r0[2 % NR] = -cs0[7]; r0[3 % NR] = T(0); }
+                        }
+#else
                         point_residuals(xa_prev, r0);
+#endif
                         const mask_t pred = rows_from_res(r0, cact);
                         unsigned long long x = newpts;          // bit s -> bit 4 s
                         x = (x | (x << 24)) & 0x000000ff000000ffull;
@@ -3032,7 +3045,9 @@ __global__ __launch_bounds__(64 * wg_waves(DP, FRIC, sizeof(T), PL), min_waves(s
                         const mask_t nm = (mask_t)(x * 15ull);
                         cact = (cact & ~nm) | (pred & nm);
                     }
+#if TREE_WARM_START != 2
                     if (inst && !(lim_mem & 1)) actv = !(sig * xa_prev - aref > T(0));
+#endif
                 }
 #endif
                 if constexpr (GEN >= 3) {
