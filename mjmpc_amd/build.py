@@ -26,13 +26,20 @@ FLAGS = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-Wno-unused-va
 # (hand-placed scheduling barriers between its phases) gains a per cent.  These schedulers crash this compiler on SOME variants of the kernel
 # (which ones changes with unrelated edits), so a source lists alternatives: the first that compiles is used, the plain
 # flags last.
-PER_SOURCE_FLAGS = {"tree_rollout_dense.hip": [["-mllvm", "-amdgpu-sched-strategy=iterative-maxocc"],
-                                               ["-mllvm", "-amdgpu-sched-strategy=iterative-ilp"]],
+# Round 6 (after the solver's control flow changed: per-particle decisions, no rank-one correction in the 16-lane kernels):
+# iterative-ilp now beats iterative-maxocc on the dense instantiations by 2 - 4 % (A/B on one box, 4096 x 32 f64 launches:
+# HalfCheetah 2.005 -> 1.96 ms, Swimmer 0.965 -> 0.93, tray 2.795 -> 2.685, door 0.87 -> 0.85, pen-in-hand 9.62 -> 9.295, f32
+# pen 7.95 -> 7.74; the default strategy: 2.09 / 0.99 / 2.865 / 0.885 / 10.03) and on the elliptic-cone instantiations in f64
+# (gripper 3.06 -> 2.97; f32 2.68 -> 2.715); the 32-lane tree-sparse source keeps maxocc (hand 2.11 -> 2.155 with ilp):
+# profiles/r06_sched_ab.txt.
+PER_SOURCE_FLAGS = {"tree_rollout_dense.hip": [["-mllvm", "-amdgpu-sched-strategy=iterative-ilp"],
+                                               ["-mllvm", "-amdgpu-sched-strategy=iterative-maxocc"]],
                     # the 32-lane instantiations: iterative-maxocc takes 1.6 % (f64) / 2.5 % (f32) off the hand at
                     # 65 536 x 64 (52.7 -> 51.9 ms, 31.8 -> 31.0 ms from tools/tree_time.py's start state; two A/B pairs);
                     # max-ilp is 1-6 % slower everywhere, iterative-ilp has crashed the compiler on this source
                     "tree_rollout.hip": [["-mllvm", "-amdgpu-sched-strategy=iterative-maxocc"]],
-                    "tree_rollout_cone.hip": [["-mllvm", "-amdgpu-sched-strategy=iterative-maxocc"]],
+                    "tree_rollout_cone.hip": [["-mllvm", "-amdgpu-sched-strategy=iterative-ilp"],
+                                              ["-mllvm", "-amdgpu-sched-strategy=iterative-maxocc"]],
                     # the arm kernel: 1 % (f64 control step 0.2000 -> 0.1980 ms, three A/B pairs on one box; f32 2 %) with
                     # iterative-maxocc; iterative-ilp another 1 % on the fused iteration's kernel and 3 % in f32 (two A/B
                     # pairs: f64 control step 0.1957 -> 0.1935 ms, pipelined 0.1910 -> 0.1883; the plain two-wave launch
