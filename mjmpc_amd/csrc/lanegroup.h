@@ -156,6 +156,17 @@ __device__ __forceinline__ void sincos_small(double x, double& s, double& c) {
     pc = fma(z, pc, -0.5);
     c = fma(z, pc, 1.0);
 }
+// 1 / sqrt(x), x > 0: hardware seed + Newton steps (as rcp_) - the contact normals need the length AND its reciprocal, which
+// is one of these and a product instead of an IEEE square root and a reciprocal
+__device__ __forceinline__ float rsqrt_(float x) {
+    float r = __builtin_amdgcn_rsqf(x);
+    return r * fmaf(-0.5f * x * r, r, 1.5f);
+}
+__device__ __forceinline__ double rsqrt_(double x) {
+    double r = __builtin_amdgcn_rsq(x);
+    r = r * fma(-0.5 * x * r, r, 1.5);
+    return r * fma(-0.5 * x * r, r, 1.5);
+}
 __device__ __forceinline__ float sqrt_(float x) { return sqrtf(x); }
 __device__ __forceinline__ double sqrt_(double x) { return sqrt(x); }
 

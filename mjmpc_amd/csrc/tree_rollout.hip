@@ -484,7 +484,7 @@ __device__ __forceinline__ void frame_tangent(const T* nrm, const T* hint, T* t1
     for (int k = 0; k < 3; ++k) t1[k] = ax3[k] - pr * nrm[k];
     const T nn = dot3(t1, t1);
     if (nn < T(1e-30)) { t1[0] = T(1); t1[1] = T(0); t1[2] = T(0); }
-    else { const T inv = rcp_(sqrt_(nn)); for (int k = 0; k < 3; ++k) t1[k] *= inv; }
+    else { const T inv = rsqrt_(nn); for (int k = 0; k < 3; ++k) t1[k] *= inv; }
 }
 
 // MuJoCo mj_makeImpedance + mj_referenceConstraint for one scalar row (r = pos - margin); constants from LDS
@@ -2330,8 +2330,9 @@ __global__ __launch_bounds__(64 * wg_waves(DP, FRIC, sizeof(T), PL), min_waves(s
                             c2[k] = o2[k] + tt * d2[k];
                             diff[k] = o1[k] + ss * d1[k] - c2[k];
                         }
-                        const T len = sqrt_(dot3(diff, diff));
-                        const T inv = len > T(1e-14) ? rcp_(len) : T(0);
+                        const T dd = dot3(diff, diff), rdd = rsqrt_(dd > T(0) ? dd : T(1));
+                        const T len = dd * rdd;
+                        const T inv = len > T(1e-14) ? rdd : T(0);
                         const T cdist = len - sp[4] - sp[17];
                         T nv3[3];
                         for (int k = 0; k < 3; ++k) {
