@@ -2334,17 +2334,22 @@ __global__ __launch_bounds__(64 * wg_waves(DP, FRIC, sizeof(T), PL), min_waves(s
                         const T len = dd * rdd;
                         const T inv = len > T(1e-14) ? rdd : T(0);
                         const T cdist = len - sp[4] - sp[17];
-                        T nv3[3];
-                        for (int k = 0; k < 3; ++k) {
-                            const T nk = diff[k] * inv;
-                            nv3[k] = nk;
-                            cs[8 + k] = nk;
-                            cs[k] = c2[k] + nk * (sp[17] + T(0.5) * cdist);
-                        }
-                        const T zero3[3] = {T(0), T(0), T(0)};
-                        frame_tangent(nv3, zero3, cs + 11);
                         cs[3] = cdist;
                         ci_mine = len > T(1e-14) && cdist < sp[5];
+                        // (the contact's point, normal and frame only where there is a contact: a record out of its margin is
+                        // never read - the swimmer's six pairs, never in touch on the bench's trajectories, skip a fifth of
+                        // this branch)
+                        if (ci_mine) {
+                            T nv3[3];
+                            for (int k = 0; k < 3; ++k) {
+                                const T nk = diff[k] * inv;
+                                nv3[k] = nk;
+                                cs[8 + k] = nk;
+                                cs[k] = c2[k] + nk * (sp[17] + T(0.5) * cdist);
+                            }
+                            const T zero3[3] = {T(0), T(0), T(0)};
+                            frame_tangent(nv3, zero3, cs + 11);
+                        }
                     }
                 }
                 unsigned long long b = __ballot(ci_mine);
